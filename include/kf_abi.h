@@ -1,0 +1,161 @@
+/*
+ * kf_abi.h -- C ABI of libkf_hip.so: the MI355X (gfx950) implementation of Koifish's quantized
+ * transformer forward path.  Plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ * its name starts with h_.  All functions return 0 (KF_OK) or a negative KOIFISH_* code
+ * (src/g_def_x.hpp:21-83) and never exit(); kf_last_error() returns the text.
+ *
+ * Each entry point replaces one seam of the reference; the seam is cited as
+ * file:line into gruai/koifish.  A kf_ctx is single-threaded by contract (the reference drives one
+ * stream from one host thread, NeuronFuse.cu:29); kernels never allocate (GTensor owns memory).
+ * bf16 is carried as uint16_t bit patterns (floatX = floatGama = __nv_bfloat16, g_float.hpp:246-262).
+ */
+#ifndef KF_ABI_H
+#define KF_ABI_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t kf_bf16;
+typedef struct kf_ctx kf_ctx;
+typedef struct kf_graph kf_graph;
+
+/* error codes: values of src/g_def_x.hpp:21-83 that this path can raise */
+#define KF_OK 0
+#define KF_INTERNAL_ERR (-11)          /* KOIFISH_INTERNAL_ERR */
+#define KF_INVALID_ARGS (-20)          /* KOIFISH_INVALID_ARGS */
+#define KF_OUTOF_GPUMEMORY (-100)      /* KOIFISH_OUTOF_GPUMEMORY */
+#define KF_QUANT_ERR (-701)            /* KOIFISH_QUANT_ERR */
+#define KF_UNSUPPORTED_DATATYPE (-1000) /* KOIFISH_UNSUPPORTED_DATATYPE */
+#define KF_HIP_CHECK (-1400)           /* KOIFISH_CUDA_CHECK */
+#define KF_BLAS_UNALIGN (-2000)        /* KOIFISH_BLAS_UNALIGN: a pointer is not 16-byte aligned (gemm.cu:119-122) */
+#define KF_RMS_PARAMS (-2100)          /* KOIFISH_RMS_PARAMS */
+
+/* typNUMBER (src/g_float.hpp:84-117), same numeric values */
+enum kf_dtype {
+    KF_F32 = 0, KF_F64, KF_F16, KF_BF16, KF_F8E5M2, KF_F8E4M3, KF_U8, KF_I8, KF_U16, KF_I16, KF_U32, KF_I32, KF_U64, KF_I64,
+    KF_Q4, KF_Q3, KF_Q2, KF_T_SIGN, KF_T_SEQ, KF_BOOL1, KF_T_BINARY, KF_T_BINARY_3, KF_T_BINARY_TILE
+};
+
+/*
+ * A weight as GTensor + its quant card hand it to a kernel (GTensor.hpp:168-490, TASKA_quant
+ * GeQuant.cpp:1297-1350).  `data` is the start of the `data||gama` allocation: packed Packed128 stream
+ * (PackedQ.hpp:28-60; W[ne0,ne1] row-major flattened, groups of lGroup consecutive elements) or plain
+ * bf16 / f8e5m2 elements.  `gama` = gama_T(GAMA) = data + szData: bf16 [R_SCALE ne0][C_SCALE ne1]
+ * [ZERO nGroup][STEP nGroup] (GTensor.cpp:456-510); NULL for unquantised types.
+ */
+typedef struct kf_weight {
+    const void* data;
+    const kf_bf16* gama;
+    int32_t type;   /* kf_dtype: KF_BF16, KF_F8E5M2, KF_Q4, KF_T_SIGN, KF_BOOL1, KF_T_BINARY */
+    int32_t ne0;    /* rows  = out features (OC) */
+    int32_t ne1;    /* cols  = in features  (IC) */
+    int32_t nGroup; /* ne0*ne1/lGroup */
+    int32_t lGroup; /* T_group, 128 */
+    int32_t qMin, qMax, qBias;
+} kf_weight;
+
+/* kf_linear epilogue flags */
+#define KF_EPI_NONE 0u
+#define KF_EPI_RESIDUAL 1u /* y = bf16(residual + bf16(W.x))   (CU_add3 after proj_cat/down: QKV.cu:687, NeuronFuse.cu:642) */
+
+/* ---- lifetime: InitCUDA / CUDA_cleanup / SYNC_STREAM (QKV.cu:501-571,600-615; E_GPU.cpp:152-175) ---- */
+int kf_init(int device, void* hip_stream_or_null, kf_ctx** out);
+int kf_destroy(kf_ctx* ctx);
+int kf_sync(kf_ctx* ctx);
+const char* kf_last_error(void);
+const char* kf_version(void);
+/* device memory (huTensor::Alloc / SerialGamaData: huTensor.cu:385-458) -- thin wrappers so that host code
+ * above this ABI needs no HIP headers */
+int kf_malloc(kf_ctx* ctx, size_t bytes, void** out);
+int kf_free(kf_ctx* ctx, void* p);
+int kf_memset(kf_ctx* ctx, void* p, int value, size_t bytes);
+int kf_h2d(kf_ctx* ctx, void* dst, const void* h_src, size_t bytes);
+int kf_d2h(kf_ctx* ctx, void* h_dst, const void* src, size_t bytes);
+int kf_d2d(kf_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* hipGraph capture of whatever is launched between begin/end on the ctx stream; replay with kf_graph_launch */
+int kf_graph_begin(kf_ctx* ctx);
+int kf_graph_end(kf_ctx* ctx, kf_graph** out);
+int kf_graph_launch(kf_ctx* ctx, kf_graph* g);
+int kf_graph_destroy(kf_graph* g);
+/* HIP events on the ctx stream (bench.py times kernels with these) */
+int kf_event_create(void** ev);
+int kf_event_record(kf_ctx* ctx, void* ev);
+int kf_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms); /* synchronises on ev_stop */
+int kf_event_destroy(void* ev);
+
+/* ---- position / token source.  Every decode kernel takes `pos` by value AND an optional device
+ * pointer d_pos: when d_pos != NULL the kernel reads *d_pos instead (so one captured graph serves many
+ * positions) and `pos` only bounds the launch geometry (it must be >= *d_pos). ---- */
+
+/* GTensor::GetDataX (GTensor.hpp:399, quantizer.cu:249-392): bf16 view of any weight into `out` [ne0*ne1] */
+int kf_dequant(kf_ctx* ctx, const kf_weight* w, kf_bf16* out);
+
+/* device quantiser, GeQuant::RTN_x / YinYang (GeQuant.cpp:428-628; device twin CU_XtoQ128_ T.cu:105-175):
+ * src bf16 [ne0*ne1] -> w->data (packed) and w->gama zero/step.  `w` must be fully described. symmetric: RTN only */
+int kf_quantize(kf_ctx* ctx, const kf_weight* w, const kf_bf16* src, int symmetric);
+
+/* SLP::Forw -> TASKA_AxB::blasLt -> CU_mm_blasLt (Neuron.hpp:418, NeuronFuse.cu:305-381, GTensor.hpp:703-741,
+ * gemm.cu:93-214): y[nTok, ne0] = alpha * x[nTok, ne1] . W^T (+ beta*y) (+ bias), fp32 accumulate, bf16 out,
+ * computed straight from the packed stream (no GetDataX round trip).  nTok == 1 in round 1.
+ * epilogue KF_EPI_RESIDUAL adds `residual` [ne0]. */
+int kf_linear(kf_ctx* ctx, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const kf_bf16* bias, int nTok, float alpha, float beta,
+              uint32_t epilogue, const kf_bf16* residual);
+
+/* LayerNormal::cuFlow -> CU_rms_infer (Neuron.hpp:453, T.cu:561-573, layernorm.cuh:800-859) */
+int kf_rmsnorm(kf_ctx* ctx, const kf_bf16* x, const kf_bf16* w, kf_bf16* y, int rows, int dim, float eps, float* rstd_or_null);
+
+/* ROPE::cuInfer (Neuron.hpp:364, rope.cu:645-672): per-head RMSNorm (CU_rms_forward_v2) then rotate-half RoPE
+ * (CU_rope2_v0) on q [n_head*hd] and on the new key row k [n_kv*hd], in place.  wq_norm/wk_norm may be NULL.
+ * rope_table: fp32 [max_pos][hd/2][2] = (cos, sin) built by kf_rope_table_host. */
+int kf_qknorm_rope(kf_ctx* ctx, kf_bf16* q, kf_bf16* k, const kf_bf16* wq_norm, const kf_bf16* wk_norm, const float* rope_table, int pos,
+                   const int32_t* d_pos, int n_head, int n_kv, int hd, float eps);
+/* host: fills h_table [n_pos][hd/2][2] with cosf/sinf(pos / powf(theta, 2j/hd)) (operator.cuh:734-772) */
+int kf_rope_table_host(float* h_table, int n_pos, int hd, float theta);
+
+/* attention triple of SelfAttention::cuInfer (QKV.cu:669-673; operator.cuh:572-632,251-277,649-668), fused,
+ * full causal length.  q bf16 [n_head*hd] (already normed+roped), kcache/vcache: layer base, row t at
+ * t*kv_stride elements; out bf16 [n_head*hd]; scratch: kf_attn_scratch_bytes(). */
+int kf_attn_decode(kf_ctx* ctx, const kf_bf16* q, const kf_bf16* kcache, const kf_bf16* vcache, kf_bf16* out, int pos, const int32_t* d_pos,
+                   int n_head, int n_kv, int hd, int kv_stride, void* scratch);
+size_t kf_attn_scratch_bytes(int n_head, int hd);
+
+/* Relu::Forw -> CU_swiglu_v0 (Neuron.hpp:384, Activation.cu:85-93) */
+int kf_swiglu(kf_ctx* ctx, const kf_bf16* gate, const kf_bf16* up, kf_bf16* out, int n);
+/* T1p1(CU_add3) (QKV.cu:687, packedN.cuh:866-875) */
+int kf_add(kf_ctx* ctx, const kf_bf16* a, const kf_bf16* b, kf_bf16* out, int n);
+/* TokenEmbed::cuInfer/OnEmbed (NeuronFuse.cu:176-218, embed.cuh:54-132).  token by value, or *d_token */
+int kf_embed(kf_ctx* ctx, const kf_weight* w, int token, const int32_t* d_token, kf_bf16* out);
+/* Head4Token::cuInfer_1 + sample_argmax (NeuronFuse.cu:842-862, GoPT.cpp:602-612): logits bf16 [ne0] (required) and
+ * the greedy id (first maximum) to d_argmax_out (device int32).  scratch: kf_head_scratch_bytes(). */
+int kf_lm_head(kf_ctx* ctx, const kf_weight* w, const kf_bf16* x, kf_bf16* logits, int32_t* d_argmax_out, void* scratch_or_null);
+size_t kf_head_scratch_bytes(void);
+
+/* ---- fused forms used by the decode step (same arithmetic as the calls above, fewer launches) ---- */
+/* [RMSNorm(x, norm_w)] -> up to 3 projections sharing the normed input.  y[i] rows go to y[i], or, when
+ * y_pos_stride[i] != 0, to y[i] + pos*y_pos_stride[i] (K.out/V.out alias the KV-cache row: TGraph.cpp:198-207) */
+int kf_norm_linear(kf_ctx* ctx, const kf_bf16* x, const kf_bf16* norm_w_or_null, float eps, int n_w, const kf_weight* const* w,
+                   kf_bf16* const* y, const int64_t* y_pos_stride, int pos, const int32_t* d_pos);
+/* [RMSNorm] -> gate & up -> SwiGLU -> act [ffn]   (FFN::cuInfer NeuronFuse.cu:615-637) */
+int kf_norm_gateup_swiglu(kf_ctx* ctx, const kf_bf16* x, const kf_bf16* norm_w_or_null, float eps, const kf_weight* gate, const kf_weight* up,
+                          kf_bf16* act);
+/* q/k-norm + RoPE + attention in one pass: q raw [n_head*hd], k_raw [n_kv*hd] (the new key before norm/rope,
+ * written normed+roped into kcache row pos), v row must already sit in vcache row pos. */
+int kf_attn_block(kf_ctx* ctx, const kf_bf16* q_raw, const kf_bf16* k_raw, kf_bf16* kcache, const kf_bf16* vcache, kf_bf16* out,
+                  const kf_bf16* wq_norm, const kf_bf16* wk_norm, const float* rope_table, int pos, const int32_t* d_pos, int n_head, int n_kv,
+                  int hd, int kv_stride, float eps, void* scratch);
+/* [final RMSNorm] + LM head + greedy pick; then state update for graph replay: d_state[0] = next token,
+ * d_state[1] += 1 (position), d_tokens_out[old pos] = next token (when non-NULL). */
+int kf_norm_lm_head(kf_ctx* ctx, const kf_bf16* x, const kf_bf16* norm_w_or_null, float eps, const kf_weight* w, kf_bf16* logits,
+                    int32_t* d_state, int32_t* d_tokens_out, void* scratch);
+/* writes the decode state {token, pos} (a one-thread kernel: capturable, no host staging buffer) */
+int kf_set_state(kf_ctx* ctx, int32_t* d_state, int token, int pos);
+/* embed lookup driven by device state: token = (d_forced && d_forced[pos] >= 0) ? d_forced[pos] : d_state[0] */
+int kf_embed_state(kf_ctx* ctx, const kf_weight* w, const int32_t* d_state, const int32_t* d_forced, kf_bf16* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,68 @@
+"""Builds the two in-tree shared libraries of koifish_amd:
+
+  libkf_hip.so   hipcc --offload-arch=gfx950: the kernels + the C ABI of include/kf_abi.h
+  libkf_host.so  g++: the C++ host mirror of the reference's neuron interface, above the ABI
+
+Both are written next to this file so they travel with the source tree.  No JIT cache.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+HOST = os.path.join(HERE, "host")
+HIP_SOURCES = ["kf_gemv.hip", "kf_attn.hip", "kf_ops.hip", "kf_abi.hip"]
+HIP_DEPS = ["kf_device.h", "kf_kernels.h"]
+LIB_HIP = os.path.join(HERE, "libkf_hip.so")
+LIB_HOST = os.path.join(HERE, "libkf_host.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -ffp-contract=off: the kernels spell every fma they want; an implicit contraction would change the rounding
+# points that the oracle pins (RoPE, kf_expf, RMSNorm).
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_hip(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    deps = srcs + [os.path.join(CSRC, d) for d in HIP_DEPS] + [os.path.join(HERE, "..", "include", "kf_abi.h")]
+    objs = []
+    for s in srcs:
+        o = s[:-4] + ".o"
+        objs.append(o)
+        if force or _stale(o, [s] + deps[len(srcs):]):
+            cmd = [HIPCC] + HIP_FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+    if force or _stale(LIB_HIP, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_HIP] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB_HIP
+
+
+def build_host(force=False, verbose=False):
+    src = os.path.join(HOST, "kf_host.cpp")
+    deps = [src, os.path.join(HOST, "kf_host.hpp"), os.path.join(HERE, "..", "include", "kf_abi.h"), LIB_HIP]
+    if force or _stale(LIB_HOST, deps):
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", LIB_HOST, src, "-L" + HERE, "-lkf_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB_HOST
+
+
+def build_all(force=False, verbose=False):
+    return build_hip(force, verbose), build_host(force, verbose)
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv, verbose=True))

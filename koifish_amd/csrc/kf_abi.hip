@@ -1,0 +1,385 @@
+// kf_abi.hip -- extern "C" boundary of libkf_hip.so (include/kf_abi.h).  Argument checks, stream plumbing and
+// hipGraph capture live here; the kernels are in kf_gemv.hip / kf_attn.hip / kf_ops.hip.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <math.h>
+
+#include "kf_kernels.h"
+
+struct kf_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    bool capturing;
+    float* amax_val; /* per-workgroup partial maxima for kf_lm_head when the caller passes no scratch */
+    int* amax_idx;
+};
+struct kf_graph {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(KF_HIP_CHECK, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define CHKCTX(c) \
+    if (!(c)) return fail(KF_INVALID_ARGS, "%s: null kf_ctx", __func__)
+#define RET(code) \
+    do {          \
+        int c_ = (code); \
+        if (c_ != KF_OK) return fail(c_, "%s failed with %d", __func__, c_); \
+        return KF_OK;    \
+    } while (0)
+
+static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+extern "C" {
+
+const char* kf_last_error(void) { return g_err; }
+const char* kf_version(void) { return "koifish_amd 0.1 (gfx950)"; }
+
+int kf_init(int device, void* stream, kf_ctx** out) {
+    if (!out) return fail(KF_INVALID_ARGS, "kf_init: out is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(KF_HIP_CHECK, "kf_init: no HIP device (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(KF_INVALID_ARGS, "kf_init: device %d of %d", device, n);
+    HIPCHK(hipSetDevice(device));
+    kf_ctx* c = new kf_ctx();
+    c->device = device;
+    c->capturing = false;
+    if (stream) {
+        c->stream = (hipStream_t)stream, c->own_stream = false;
+    } else {
+        HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    HIPCHK(hipMalloc(&c->amax_val, sizeof(float) * kf::KF_MAX_ARGMAX_PARTIALS));
+    HIPCHK(hipMalloc(&c->amax_idx, sizeof(int) * kf::KF_MAX_ARGMAX_PARTIALS));
+    *out = c;
+    return KF_OK;
+}
+int kf_destroy(kf_ctx* c) {
+    if (!c) return KF_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->amax_val), (void)hipFree(c->amax_idx);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return KF_OK;
+}
+int kf_sync(kf_ctx* c) {
+    CHKCTX(c);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return KF_OK;
+}
+int kf_malloc(kf_ctx* c, size_t bytes, void** out) {
+    CHKCTX(c);
+    if (!out) return fail(KF_INVALID_ARGS, "kf_malloc: out is null");
+    hipError_t e = hipMalloc(out, bytes ? bytes : 16);
+    if (e != hipSuccess) return fail(KF_OUTOF_GPUMEMORY, "kf_malloc(%zu): %s", bytes, hipGetErrorString(e));
+    return KF_OK;
+}
+int kf_free(kf_ctx* c, void* p) {
+    CHKCTX(c);
+    if (p) HIPCHK(hipFree(p));
+    return KF_OK;
+}
+int kf_memset(kf_ctx* c, void* p, int v, size_t bytes) {
+    CHKCTX(c);
+    HIPCHK(hipMemsetAsync(p, v, bytes, c->stream));
+    return KF_OK;
+}
+int kf_h2d(kf_ctx* c, void* dst, const void* src, size_t bytes) {
+    CHKCTX(c);
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return KF_OK;
+}
+int kf_d2h(kf_ctx* c, void* dst, const void* src, size_t bytes) {
+    CHKCTX(c);
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return KF_OK;
+}
+int kf_d2d(kf_ctx* c, void* dst, const void* src, size_t bytes) {
+    CHKCTX(c);
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return KF_OK;
+}
+
+int kf_graph_begin(kf_ctx* c) {
+    CHKCTX(c);
+    if (c->capturing) return fail(KF_INVALID_ARGS, "kf_graph_begin: already capturing");
+    HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    c->capturing = true;
+    return KF_OK;
+}
+int kf_graph_end(kf_ctx* c, kf_graph** out) {
+    CHKCTX(c);
+    if (!c->capturing || !out) return fail(KF_INVALID_ARGS, "kf_graph_end: not capturing");
+    c->capturing = false;
+    kf_graph* g = new kf_graph();
+    hipError_t e = hipStreamEndCapture(c->stream, &g->graph);
+    if (e != hipSuccess) {
+        delete g;
+        return fail(KF_HIP_CHECK, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    }
+    e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(g->graph);
+        delete g;
+        return fail(KF_HIP_CHECK, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    }
+    *out = g;
+    return KF_OK;
+}
+int kf_graph_launch(kf_ctx* c, kf_graph* g) {
+    CHKCTX(c);
+    if (!g) return fail(KF_INVALID_ARGS, "kf_graph_launch: null graph");
+    HIPCHK(hipGraphLaunch(g->exec, c->stream));
+    return KF_OK;
+}
+int kf_graph_destroy(kf_graph* g) {
+    if (!g) return KF_OK;
+    (void)hipGraphExecDestroy(g->exec);
+    (void)hipGraphDestroy(g->graph);
+    delete g;
+    return KF_OK;
+}
+
+int kf_event_create(void** ev) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    *ev = (void*)e;
+    return KF_OK;
+}
+int kf_event_record(kf_ctx* c, void* ev) {
+    CHKCTX(c);
+    HIPCHK(hipEventRecord((hipEvent_t)ev, c->stream));
+    return KF_OK;
+}
+int kf_event_elapsed_ms(void* a, void* b, float* ms) {
+    HIPCHK(hipEventSynchronize((hipEvent_t)b));
+    HIPCHK(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+    return KF_OK;
+}
+int kf_event_destroy(void* ev) {
+    if (ev) HIPCHK(hipEventDestroy((hipEvent_t)ev));
+    return KF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ operators
+static int check_weight(const kf_weight* w, const char* who) {
+    if (!w || !w->data) return fail(KF_INVALID_ARGS, "%s: null weight", who);
+    if (w->ne0 <= 0 || w->ne1 <= 0) return fail(KF_INVALID_ARGS, "%s: bad shape %d x %d", who, w->ne0, w->ne1);
+    if (!al16(w->data)) return fail(KF_BLAS_UNALIGN, "%s: weight data not 16-byte aligned", who);
+    switch (w->type) {
+        case KF_BF16: case KF_F8E5M2: break;
+        case KF_Q4: case KF_T_SIGN: case KF_BOOL1: case KF_T_BINARY:
+            if (!w->gama) return fail(KF_QUANT_ERR, "%s: quantised weight without gama", who);
+            if (w->lGroup <= 0 || ((long long)w->ne0 * w->ne1) % w->lGroup) return fail(KF_QUANT_ERR, "%s: bad group size %d", who, w->lGroup);
+            break;
+        default: return fail(KF_UNSUPPORTED_DATATYPE, "%s: unsupported weight type %d", who, w->type);
+    }
+    return KF_OK;
+}
+
+int kf_dequant(kf_ctx* c, const kf_weight* w, kf_bf16* out) {
+    CHKCTX(c);
+    int r = check_weight(w, "kf_dequant");
+    if (r) return r;
+    if (!out || !al16(out)) return fail(KF_BLAS_UNALIGN, "kf_dequant: out null/unaligned");
+    RET(kf::dequant_launch(c->stream, w, out));
+}
+int kf_quantize(kf_ctx* c, const kf_weight* w, const kf_bf16* src, int symmetric) {
+    CHKCTX(c);
+    int r = check_weight(w, "kf_quantize");
+    if (r) return r;
+    if (!src) return fail(KF_INVALID_ARGS, "kf_quantize: null src");
+    RET(kf::quantize_launch(c->stream, w, src, symmetric));
+}
+
+static void init_args(kf::GemvLaunch& L) { memset(&L, 0, sizeof(L)); L.args.alpha = 1.0f; }
+
+int kf_linear(kf_ctx* c, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const kf_bf16* bias, int nTok, float alpha, float beta, uint32_t epilogue,
+              const kf_bf16* residual) {
+    CHKCTX(c);
+    int r = check_weight(w, "kf_linear");
+    if (r) return r;
+    if (nTok != 1) return fail(KF_INVALID_ARGS, "kf_linear: nTok=%d (the decode path is nTok=1; batched prefill is a later round)", nTok);
+    if (!x || !y || !al16(x)) return fail(KF_BLAS_UNALIGN, "kf_linear: x/y null or x unaligned");
+    if ((epilogue & KF_EPI_RESIDUAL) && !residual) return fail(KF_INVALID_ARGS, "kf_linear: residual epilogue without residual");
+    kf::GemvLaunch L;
+    init_args(L);
+    L.n = 1, L.w[0] = w, L.mode = kf::GEMV_PLAIN;
+    L.args.x = x, L.args.job[0].y = y;
+    L.args.bias = bias, L.args.alpha = alpha, L.args.beta = beta;
+    L.args.residual = (epilogue & KF_EPI_RESIDUAL) ? residual : nullptr;
+    RET(kf::gemv_launch(c->stream, L));
+}
+
+int kf_norm_linear(kf_ctx* c, const kf_bf16* x, const kf_bf16* norm_w, float eps, int n_w, const kf_weight* const* w, kf_bf16* const* y,
+                   const int64_t* y_pos_stride, int pos, const int32_t* d_pos) {
+    CHKCTX(c);
+    if (n_w < 1 || n_w > 3 || !w || !y) return fail(KF_INVALID_ARGS, "kf_norm_linear: n_w=%d", n_w);
+    if (!x || !al16(x) || (norm_w && !al16(norm_w))) return fail(KF_BLAS_UNALIGN, "kf_norm_linear: x/norm_w null or unaligned");
+    kf::GemvLaunch L;
+    init_args(L);
+    L.n = n_w, L.mode = kf::GEMV_PLAIN;
+    for (int i = 0; i < n_w; i++) {
+        int r = check_weight(w[i], "kf_norm_linear");
+        if (r) return r;
+        if (!y[i]) return fail(KF_INVALID_ARGS, "kf_norm_linear: y[%d] null", i);
+        L.w[i] = w[i];
+        L.args.job[i].y = y[i];
+        L.args.job[i].y_pos_stride = y_pos_stride ? y_pos_stride[i] : 0;
+    }
+    L.args.x = x, L.args.norm_w = norm_w, L.args.eps = eps, L.args.pos = pos, L.args.d_pos = d_pos;
+    RET(kf::gemv_launch(c->stream, L));
+}
+
+int kf_norm_gateup_swiglu(kf_ctx* c, const kf_bf16* x, const kf_bf16* norm_w, float eps, const kf_weight* gate, const kf_weight* up, kf_bf16* act) {
+    CHKCTX(c);
+    int r = check_weight(gate, "kf_norm_gateup_swiglu");
+    if (r) return r;
+    r = check_weight(up, "kf_norm_gateup_swiglu");
+    if (r) return r;
+    if (!x || !act || !al16(x)) return fail(KF_BLAS_UNALIGN, "kf_norm_gateup_swiglu: x/act");
+    kf::GemvLaunch L;
+    init_args(L);
+    L.n = 2, L.w[0] = gate, L.w[1] = up, L.mode = kf::GEMV_PAIRED;
+    L.args.x = x, L.args.norm_w = norm_w, L.args.eps = eps, L.args.job[0].y = act;
+    RET(kf::gemv_launch(c->stream, L));
+}
+
+int kf_rmsnorm(kf_ctx* c, const kf_bf16* x, const kf_bf16* w, kf_bf16* y, int rows, int dim, float eps, float* rstd) {
+    CHKCTX(c);
+    if (!x || !w || !y) return fail(KF_INVALID_ARGS, "kf_rmsnorm: null pointer");
+    if (dim % 2 != 0) return fail(KF_RMS_PARAMS, "rmsnorm dim %d is not divisible by 2", dim);
+    RET(kf::rmsnorm_launch(c->stream, x, w, y, rows, dim, eps, rstd));
+}
+
+int kf_rope_table_host(float* t, int n_pos, int hd, float theta) {
+    if (!t || n_pos <= 0 || hd <= 0 || (hd & 1)) return fail(KF_INVALID_ARGS, "kf_rope_table_host: bad args");
+    for (int p = 0; p < n_pos; p++)
+        for (int j = 0; j < hd / 2; j++) {
+            const float inv_freq = 1.0f / powf(theta, (float)(j * 2) / (float)hd);
+            const float angle = (float)p * inv_freq;
+            t[((size_t)p * (hd / 2) + j) * 2] = cosf(angle);
+            t[((size_t)p * (hd / 2) + j) * 2 + 1] = sinf(angle);
+        }
+    return KF_OK;
+}
+
+int kf_qknorm_rope(kf_ctx* c, kf_bf16* q, kf_bf16* k, const kf_bf16* wq, const kf_bf16* wk, const float* table, int pos, const int32_t* d_pos, int n_head,
+                   int n_kv, int hd, float eps) {
+    CHKCTX(c);
+    if (!q) return fail(KF_INVALID_ARGS, "kf_qknorm_rope: null q");
+    RET(kf::qknorm_rope_launch(c->stream, q, k, wq, wk, table, pos, d_pos, n_head, n_kv, hd, eps));
+}
+
+size_t kf_attn_scratch_bytes(int n_head, int hd) { return sizeof(float) * (size_t)n_head * kf::KF_ATTN_MAX_SPLITS * (hd + 2); }
+
+int kf_attn_decode(kf_ctx* c, const kf_bf16* q, const kf_bf16* kc, const kf_bf16* vc, kf_bf16* out, int pos, const int32_t* d_pos, int n_head, int n_kv, int hd,
+                   int kv_stride, void* scratch) {
+    CHKCTX(c);
+    if (!q || !kc || !vc || !out || !scratch) return fail(KF_INVALID_ARGS, "kf_attn_decode: null pointer");
+    if (!al16(kc) || !al16(vc) || (kv_stride % 8)) return fail(KF_BLAS_UNALIGN, "kf_attn_decode: cache not 16-byte aligned");
+    kf::AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = q, a.kcache = const_cast<kf_bf16*>(kc), a.vcache = vc, a.out = out, a.part = (float*)scratch;
+    a.pos = pos, a.d_pos = d_pos, a.n_head = n_head, a.n_kv = n_kv, a.hd = hd, a.kv_stride = kv_stride;
+    RET(kf::attn_launch(c->stream, a));
+}
+
+int kf_attn_block(kf_ctx* c, const kf_bf16* q_raw, const kf_bf16* k_raw, kf_bf16* kc, const kf_bf16* vc, kf_bf16* out, const kf_bf16* wq, const kf_bf16* wk,
+                  const float* table, int pos, const int32_t* d_pos, int n_head, int n_kv, int hd, int kv_stride, float eps, void* scratch) {
+    CHKCTX(c);
+    if (!q_raw || !k_raw || !kc || !vc || !out || !scratch || !table) return fail(KF_INVALID_ARGS, "kf_attn_block: null pointer");
+    if (!al16(kc) || !al16(vc) || (kv_stride % 8)) return fail(KF_BLAS_UNALIGN, "kf_attn_block: cache not 16-byte aligned");
+    kf::AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = q_raw, a.k_raw = k_raw, a.kcache = kc, a.vcache = vc, a.out = out, a.part = (float*)scratch;
+    a.wq_norm = wq, a.wk_norm = wk, a.rope_table = table, a.eps = eps;
+    a.pos = pos, a.d_pos = d_pos, a.n_head = n_head, a.n_kv = n_kv, a.hd = hd, a.kv_stride = kv_stride;
+    RET(kf::attn_launch(c->stream, a));
+}
+
+int kf_swiglu(kf_ctx* c, const kf_bf16* gate, const kf_bf16* up, kf_bf16* out, int n) {
+    CHKCTX(c);
+    if (!gate || !up || !out || n <= 0) return fail(KF_INVALID_ARGS, "kf_swiglu: bad args");
+    RET(kf::swiglu_launch(c->stream, gate, up, out, n));
+}
+int kf_add(kf_ctx* c, const kf_bf16* a, const kf_bf16* b, kf_bf16* out, int n) {
+    CHKCTX(c);
+    if (!a || !b || !out || n <= 0) return fail(KF_INVALID_ARGS, "kf_add: bad args");
+    RET(kf::add_launch(c->stream, a, b, out, n));
+}
+int kf_embed(kf_ctx* c, const kf_weight* w, int token, const int32_t* d_token, kf_bf16* out) {
+    CHKCTX(c);
+    int r = check_weight(w, "kf_embed");
+    if (r) return r;
+    if (!out || !al16(out)) return fail(KF_BLAS_UNALIGN, "kf_embed: out null/unaligned");
+    if (!d_token && (token < 0 || token >= w->ne0)) return fail(KF_INVALID_ARGS, "kf_embed: token %d outside [0,%d)", token, w->ne0);
+    RET(kf::embed_launch(c->stream, w, token, d_token, nullptr, nullptr, out));
+}
+int kf_embed_state(kf_ctx* c, const kf_weight* w, const int32_t* d_state, const int32_t* d_forced, kf_bf16* out) {
+    CHKCTX(c);
+    int r = check_weight(w, "kf_embed_state");
+    if (r) return r;
+    if (!out || !al16(out) || !d_state) return fail(KF_INVALID_ARGS, "kf_embed_state: bad args");
+    RET(kf::embed_launch(c->stream, w, 0, nullptr, d_state, d_forced, out));
+}
+
+int kf_set_state(kf_ctx* c, int32_t* d_state, int token, int pos) {
+    CHKCTX(c);
+    if (!d_state) return fail(KF_INVALID_ARGS, "kf_set_state: null state");
+    RET(kf::set_state_launch(c->stream, d_state, token, pos));
+}
+
+size_t kf_head_scratch_bytes(void) { return (sizeof(float) + sizeof(int)) * (size_t)kf::KF_MAX_ARGMAX_PARTIALS; }
+
+static int head_impl(kf_ctx* c, const kf_bf16* x, const kf_bf16* norm_w, float eps, const kf_weight* w, kf_bf16* logits, int32_t* d_argmax, int32_t* d_state,
+                     int32_t* d_tokens_out, void* scratch, const char* who) {
+    int r = check_weight(w, who);
+    if (r) return r;
+    if (!x || !al16(x)) return fail(KF_BLAS_UNALIGN, "%s: x null/unaligned", who);
+    float* av = scratch ? (float*)scratch : c->amax_val;
+    int* ai = scratch ? (int*)((float*)scratch + kf::KF_MAX_ARGMAX_PARTIALS) : c->amax_idx;
+    kf_bf16* lg = logits;
+    if (!lg) return fail(KF_INVALID_ARGS, "%s: logits buffer required (vocab*2 bytes)", who);
+    kf::GemvLaunch L;
+    init_args(L);
+    L.n = 1, L.w[0] = w, L.mode = kf::GEMV_ARGMAX;
+    L.args.x = x, L.args.norm_w = norm_w, L.args.eps = eps, L.args.job[0].y = lg;
+    L.args.amax_val = av, L.args.amax_idx = ai;
+    r = kf::gemv_launch(c->stream, L);
+    if (r) return fail(r, "%s: gemv failed with %d", who, r);
+    kf::argmax_finish_launch(c->stream, av, ai, L.blocks, d_argmax, d_state, d_tokens_out);
+    return hipGetLastError() == hipSuccess ? KF_OK : fail(KF_HIP_CHECK, "%s: launch failed", who);
+}
+int kf_lm_head(kf_ctx* c, const kf_weight* w, const kf_bf16* x, kf_bf16* logits, int32_t* d_argmax_out, void* scratch) {
+    CHKCTX(c);
+    return head_impl(c, x, nullptr, 0.f, w, logits, d_argmax_out, nullptr, nullptr, scratch, "kf_lm_head");
+}
+int kf_norm_lm_head(kf_ctx* c, const kf_bf16* x, const kf_bf16* norm_w, float eps, const kf_weight* w, kf_bf16* logits, int32_t* d_state, int32_t* d_tokens_out,
+                    void* scratch) {
+    CHKCTX(c);
+    if (!d_state) return fail(KF_INVALID_ARGS, "kf_norm_lm_head: d_state is null");
+    return head_impl(c, x, norm_w, eps, w, logits, nullptr, d_state, d_tokens_out, scratch, "kf_norm_lm_head");
+}
+
+}  // extern "C"

@@ -1,0 +1,98 @@
+// kf_device.h -- device-side helpers shared by the gfx950 kernels (wave64, no portability layer).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kf {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// round-to-nearest-even, NaN stays NaN: hipcc lowers the cast to v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+__device__ __forceinline__ float round_bf16(float f) { return bf2f(f2bf(f)); }
+// two floats -> packed bf16 pair (lo = a, hi = b), one v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ float bf_lo(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
+// acc + a.lo*b.lo + a.hi*b.hi on packed bf16 pairs (v_dot2c_f32_bf16)
+__device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), acc, false);
+}
+
+// IEEE half bit pattern -> f32 (v_cvt_f32_f16)
+__device__ __forceinline__ float half_bits_to_f32(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)h); }
+
+// streamed-once data (weights, KV): non-temporal 16-byte load
+__device__ __forceinline__ u32x4 ld_nt(const u32x4* p) { return __builtin_nontemporal_load(p); }
+
+// Fixed fp32 exp: the same operation sequence as oracle/kfo_math.h kfo_expf (independent statement of one
+// recipe: Cody-Waite reduction, degree-7 Taylor/Horner in fma form, two-step power-of-two scaling), so the
+// softmax numerators and SwiGLU agree bit for bit with the CPU oracle.  Needs -ffp-contract=off.
+__device__ __forceinline__ float kf_expf(float x) {
+    if (x > 88.72283f) return __builtin_inff();
+    if (x < -87.33654f) return 0.0f;
+    if (x != x) return x;
+    float t = x * 1.44269502162933349609375f;
+    float n = (t + 12582912.0f) - 12582912.0f;
+    float r = fmaf(n, -0.693145751953125f, x);
+    r = fmaf(n, -1.428606765330187045e-06f, r);
+    float p = 1.98412701138295233249664306640625e-4f;
+    p = fmaf(p, r, 1.38888892251998186111450195312500e-3f);
+    p = fmaf(p, r, 8.33333376795053482055664062500000e-3f);
+    p = fmaf(p, r, 4.16666679084300994873046875000000e-2f);
+    p = fmaf(p, r, 1.66666671633720397949218750000000e-1f);
+    p = fmaf(p, r, 0.5f);
+    p = fmaf(p, r, 1.0f);
+    p = fmaf(p, r, 1.0f);
+    int e = (int)n;
+    int e1 = e / 2, e2 = e - e1;
+    float s1 = __uint_as_float((uint32_t)(e1 + 127) << 23), s2 = __uint_as_float((uint32_t)(e2 + 127) << 23);
+    return (p * s1) * s2;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+// Sum of squares of a bf16 vector in fp64 over a whole workgroup (nthreads a multiple of 64, <= 1024).
+// fp64 keeps the result independent of the reduction tree (products of bf16 values are exact, the fp64 sum of
+// <= 2^16 of them is exact or correctly rounded to far below an fp32 ulp), which is what lets the oracle and the
+// kernels agree bit for bit on RMSNorm.  `red` is >= 16 doubles of LDS.
+__device__ __forceinline__ double block_sumsq_bf16(const uint16_t* __restrict__ x, int n, double* red) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        double a = (double)bf2f(x[i]);
+        acc = fma(a, a, acc);
+    }
+    acc = wave_sum_f64(acc);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    double tot = 0.0;
+    for (int w = 0; w < nw; w++) tot += red[w];
+    __syncthreads();
+    return tot;
+}
+
+}  // namespace kf

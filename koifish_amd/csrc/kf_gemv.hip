@@ -1,0 +1,473 @@
+// kf_gemv.hip -- fused PackedQ unpack + mat-vec for decode (nTok = 1), gfx950 / wave64.
+//
+// Replaces GTensor::GetDataX (dequantise the whole weight to bf16 in gBUFF->tmpTernary, quantizer.cu:249-392)
+// followed by cuBLASLt (gemm.cu:93-214): the packed stream is read ONCE, 16 bytes per lane, fully coalesced,
+// dequantised in registers with the reference's bf16-stepwise arithmetic (T.cu:274) and contracted against the
+// activation held in LDS.  HBM-bound: algorithmic bytes = packed data + zero/step (+ x, y).
+//
+// Data mapping.  W[M,K] row-major flattened is a stream of 16-byte blocks (one Packed128 for 4/2/1-bit; 8 bf16;
+// 16 f8).  EPB = elements per block; a row has nBlk = K/EPB blocks.  LPR lanes (a power of two <= 64) walk one
+// row, RPS = 64/LPR rows are processed side by side by one wave ("slot"), ITERS = ceil(nBlk/LPR) loads per row.
+// Each wave owns SPW consecutive slots and keeps G of them in flight.  x sits in LDS as 16-byte chunks laid
+// out [chunk j of block][block column] so that consecutive lanes read consecutive 16-byte words (no bank
+// conflicts for ds_read_b128).
+#include "kf_kernels.h"
+
+namespace kf {
+
+// ------------------------------------------------------------------------------------------------ block dots
+// Q4: Packed128 memory image (PackedQ.hpp:99-183): dword3 (bytes 12..15) holds elements 0..7 with element 0 in
+// bits 28..31; dword2 -> 8..15; dword1 -> 16..23; dword0 -> 24..31.
+// dequant (T.cu:274, all bf16 operators):  w = bf16( bf16(step * (q - qBias)) - zero ).
+//   step*(q-qBias) is formed exactly in fp32 by one fma (q <= 15, step has 8 significant bits), rounded to
+//   bf16 by v_cvt_pk_bf16_f32 (two at a time), widened, zero subtracted in fp32 (exact operands), rounded again.
+__device__ __forceinline__ float dot_q4_dword(uint32_t D, u32x4 X, float step, float step16, float nb, float zero, float acc) {
+    const uint32_t H = D & 0xF0F0F0F0u, L = D & 0x0F0F0F0Fu;
+    uint32_t r, w;
+    r = pack_bf16x2(fmaf((float)(H >> 24), step16, nb), fmaf((float)(L >> 24), step, nb));
+    w = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
+    acc = dot2_bf16(w, X.x, acc);
+    r = pack_bf16x2(fmaf((float)((H >> 16) & 0xffu), step16, nb), fmaf((float)((L >> 16) & 0xffu), step, nb));
+    w = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
+    acc = dot2_bf16(w, X.y, acc);
+    r = pack_bf16x2(fmaf((float)((H >> 8) & 0xffu), step16, nb), fmaf((float)((L >> 8) & 0xffu), step, nb));
+    w = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
+    acc = dot2_bf16(w, X.z, acc);
+    r = pack_bf16x2(fmaf((float)(H & 0xffu), step16, nb), fmaf((float)(L & 0xffu), step, nb));
+    w = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
+    acc = dot2_bf16(w, X.w, acc);
+    return acc;
+}
+
+template <int FMT>
+struct BlockDot;
+
+template <>
+struct BlockDot<FMT_BF16> {
+    static constexpr int EPB = 8, XCH = 1;
+    static constexpr bool HAS_GAMA = false;
+    __device__ static __forceinline__ float run(u32x4 w, const u32x4* xs, int col, int nBlk, float, float, float, float acc) {
+        u32x4 X = xs[col];
+        acc = dot2_bf16(w.x, X.x, acc);
+        acc = dot2_bf16(w.y, X.y, acc);
+        acc = dot2_bf16(w.z, X.z, acc);
+        acc = dot2_bf16(w.w, X.w, acc);
+        return acc;
+    }
+};
+
+// F8E5M2: byte i of the block = element i; value = half(byte << 8) (g_float.hpp:355-383), exact in bf16.
+__device__ __forceinline__ float f8_to_f32(uint32_t hbits) { return half_bits_to_f32(hbits); }
+__device__ __forceinline__ float dot_f8_dword(uint32_t D, uint32_t X0, uint32_t X1, float acc) {
+    uint32_t w0 = pack_bf16x2(f8_to_f32((D << 8) & 0xff00u), f8_to_f32(D & 0xff00u));
+    uint32_t w1 = pack_bf16x2(f8_to_f32((D >> 8) & 0xff00u), f8_to_f32((D >> 16) & 0xff00u));
+    acc = dot2_bf16(w0, X0, acc);
+    acc = dot2_bf16(w1, X1, acc);
+    return acc;
+}
+template <>
+struct BlockDot<FMT_F8> {
+    static constexpr int EPB = 16, XCH = 2;
+    static constexpr bool HAS_GAMA = false;
+    __device__ static __forceinline__ float run(u32x4 w, const u32x4* xs, int col, int nBlk, float, float, float, float acc) {
+        u32x4 X0 = xs[col], X1 = xs[nBlk + col];
+        acc = dot_f8_dword(w.x, X0.x, X0.y, acc);
+        acc = dot_f8_dword(w.y, X0.z, X0.w, acc);
+        acc = dot_f8_dword(w.z, X1.x, X1.y, acc);
+        acc = dot_f8_dword(w.w, X1.z, X1.w, acc);
+        return acc;
+    }
+};
+
+template <>
+struct BlockDot<FMT_Q4> {
+    static constexpr int EPB = 32, XCH = 4;
+    static constexpr bool HAS_GAMA = true;
+    // nb = -qBias*step (exact)
+    __device__ static __forceinline__ float run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, float acc) {
+        const float step16 = step * 0.0625f;
+        acc = dot_q4_dword(w.w, xs[col], step, step16, nb, zero, acc);
+        acc = dot_q4_dword(w.z, xs[nBlk + col], step, step16, nb, zero, acc);
+        acc = dot_q4_dword(w.y, xs[2 * nBlk + col], step, step16, nb, zero, acc);
+        acc = dot_q4_dword(w.x, xs[3 * nBlk + col], step, step16, nb, zero, acc);
+        return acc;
+    }
+};
+
+// 2-bit (T_SIGN ternary / generic CU_Q128toX_<T,64>): element i < 32 at high >> (62-2i) (PackedQ.hpp:185-226):
+// dword3 -> elements 0..15 (element 0 in bits 30..31), dword2 -> 16..31, dword1 -> 32..47, dword0 -> 48..63.
+__device__ __forceinline__ float dot_q2_dword(uint32_t D, u32x4 Xa, u32x4 Xb, float step, float nb, float zero, float acc) {
+    const uint32_t xw[8] = {Xa.x, Xa.y, Xa.z, Xa.w, Xb.x, Xb.y, Xb.z, Xb.w};
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+        float q0 = (float)((D >> (30 - 4 * p)) & 3u), q1 = (float)((D >> (28 - 4 * p)) & 3u);
+        uint32_t r = pack_bf16x2(fmaf(q0, step, nb), fmaf(q1, step, nb));
+        uint32_t w = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
+        acc = dot2_bf16(w, xw[p], acc);
+    }
+    return acc;
+}
+template <>
+struct BlockDot<FMT_Q2> {
+    static constexpr int EPB = 64, XCH = 8;
+    static constexpr bool HAS_GAMA = true;
+    __device__ static __forceinline__ float run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, float acc) {
+        acc = dot_q2_dword(w.w, xs[col], xs[nBlk + col], step, nb, zero, acc);
+        acc = dot_q2_dword(w.z, xs[2 * nBlk + col], xs[3 * nBlk + col], step, nb, zero, acc);
+        acc = dot_q2_dword(w.y, xs[4 * nBlk + col], xs[5 * nBlk + col], step, nb, zero, acc);
+        acc = dot_q2_dword(w.x, xs[6 * nBlk + col], xs[7 * nBlk + col], step, nb, zero, acc);
+        return acc;
+    }
+};
+
+// 1-bit (BOOL1 / T_BINARY, CU_Q128toX_<T,128>): element i < 64 at high >> (63-i) (PackedQ.hpp:200-239):
+// dword3 -> elements 0..31 (element 0 = bit 31), dword2 -> 32..63, dword1 -> 64..95, dword0 -> 96..127.
+// w in {w0, w1} = {dequant(0), dequant(1)}: both are formed once per block, then selected per bit.
+__device__ __forceinline__ float dot_q1_dword(uint32_t D, const u32x4* xs, int base, int nBlk, int col, uint32_t w0, uint32_t w1, float acc) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        u32x4 X = xs[(base + c) * nBlk + col];
+        const uint32_t xw[4] = {X.x, X.y, X.z, X.w};
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int k = c * 8 + p * 2; /* elements k, k+1 of this dword */
+            uint32_t lo = ((D >> (31 - k)) & 1u) ? w1 : w0, hi = ((D >> (30 - k)) & 1u) ? w1 : w0;
+            acc = dot2_bf16((lo & 0xffffu) | (hi << 16), xw[p], acc);
+        }
+    }
+    return acc;
+}
+template <>
+struct BlockDot<FMT_Q1> {
+    static constexpr int EPB = 128, XCH = 16;
+    static constexpr bool HAS_GAMA = true;
+    __device__ static __forceinline__ float run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, float acc) {
+        // dequant(q) for q = 0, 1 (q - qBias folded into nb)
+        uint32_t r = pack_bf16x2(fmaf(0.0f, step, nb), fmaf(1.0f, step, nb));
+        uint32_t ww = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
+        const uint32_t w0 = ww & 0xffffu, w1 = ww >> 16;
+        acc = dot_q1_dword(w.w, xs, 0, nBlk, col, w0, w1, acc);
+        acc = dot_q1_dword(w.z, xs, 4, nBlk, col, w0, w1, acc);
+        acc = dot_q1_dword(w.y, xs, 8, nBlk, col, w0, w1, acc);
+        acc = dot_q1_dword(w.x, xs, 12, nBlk, col, w0, w1, acc);
+        return acc;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ kernel
+// LDS: x as u32x4 chunks [XCH][nBlk]  (K*2 bytes) + reduction scratch.
+template <int FMT, int G, int MODE>
+__global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
+    using BD = BlockDot<FMT>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);
+    double* red = reinterpret_cast<double*>(smem_raw + (size_t)a.K * 2);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave_in_blk = tid >> 6;
+    const int nBlk = a.nBlk;
+    const int pos = a.d_pos ? *a.d_pos : a.pos;
+
+    // ---- prologue: stage x (optionally RMS-normalised: rms_norm_kernel, layernorm.cuh:800-847) into LDS
+    {
+        float mul = 1.0f;
+        if (a.norm_w) {
+            double ss = block_sumsq_bf16(a.x, a.K, red);
+            float val = fmaf((float)ss, a.inv_dim, a.eps);
+            mul = 1.0f / sqrtf(val);
+        }
+        uint16_t* xs16 = reinterpret_cast<uint16_t*>(xs);
+        constexpr int XCH = BD::XCH;
+        // element e of block column c, chunk j (e = c*EPB + j*8 + i)  ->  LDS halfword ((j*nBlk + c)*8 + i)
+        for (int e8 = tid; e8 < a.K / 8; e8 += blockDim.x) {
+            const int c = e8 / XCH, j = e8 - c * XCH;
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(a.x + (size_t)e8 * 8);
+            u32x4 o = raw;
+            if (a.norm_w) {
+                const u32x4 nw = *reinterpret_cast<const u32x4*>(a.norm_w + (size_t)e8 * 8);
+                const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w}, ww[4] = {nw.x, nw.y, nw.z, nw.w};
+                uint32_t ow[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    float v0 = (bf_lo(rw[k]) * mul) * bf_lo(ww[k]), v1 = (bf_hi(rw[k]) * mul) * bf_hi(ww[k]);
+                    ow[k] = pack_bf16x2(v0, v1);
+                }
+                o.x = ow[0], o.y = ow[1], o.z = ow[2], o.w = ow[3];
+            }
+            xs[j * nBlk + c] = o;
+            (void)xs16;
+        }
+        __syncthreads();
+    }
+
+    // ---- main: this wave's slots
+    const int LPR = 1 << a.lpr_log2, RPS = 64 >> a.lpr_log2;
+    const int sub = lane >> a.lpr_log2, ll = lane & (LPR - 1);
+    const long gwave = (long)blockIdx.x * (blockDim.x >> 6) + wave_in_blk;
+    const long s_begin = gwave * a.spw;
+    long s_end = s_begin + a.spw;
+    if (s_end > a.total_slots) s_end = a.total_slots;
+
+    float best_v = -__builtin_inff();
+    int best_i = 0x7fffffff;
+
+    for (long s0 = s_begin; s0 < s_end; s0 += G) {
+        float acc[G], acc2[G];
+        int row[G], jb[G];
+        bool ok[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            acc[g] = 0.f, acc2[g] = 0.f;
+            long s = s0 + g;
+            int j = 0;
+            if (a.njobs > 1 && s >= a.job[1].slot0) j = 1;
+            if (a.njobs > 2 && s >= a.job[2].slot0) j = 2;
+            jb[g] = j;
+            row[g] = (int)(s - a.job[j].slot0) * RPS + sub;
+            ok[g] = (s < s_end) && (row[g] < a.job[j].M);
+        }
+        for (int it = 0; it < a.iters; it++) {
+            const int col = it * LPR + ll;
+            const bool cok = col < nBlk;
+            u32x4 w[G], w2[G];
+            float st[G], ze[G], st2[G], ze2[G];
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                w[g] = u32x4{0, 0, 0, 0}, w2[g] = u32x4{0, 0, 0, 0};
+                st[g] = ze[g] = st2[g] = ze2[g] = 0.f;
+                if (ok[g] && cok) {
+                    const GemvJob& jj = a.job[jb[g]];
+                    const size_t bidx = (size_t)row[g] * nBlk + col;
+                    w[g] = ld_nt(reinterpret_cast<const u32x4*>(jj.w) + bidx);
+                    if (BD::HAS_GAMA) {
+                        const size_t gi = bidx * BD::EPB / a.lGroup;
+                        st[g] = bf2f(jj.step[gi]), ze[g] = bf2f(jj.zero[gi]);
+                    }
+                    if (MODE == GEMV_PAIRED) {
+                        const GemvJob& j2 = a.job[1];
+                        w2[g] = ld_nt(reinterpret_cast<const u32x4*>(j2.w) + bidx);
+                        if (BD::HAS_GAMA) {
+                            const size_t gi = bidx * BD::EPB / a.lGroup;
+                            st2[g] = bf2f(j2.step[gi]), ze2[g] = bf2f(j2.zero[gi]);
+                        }
+                    }
+                }
+            }
+            if (cok) {
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    const float qb = (float)a.job[jb[g]].qBias;
+                    acc[g] = BD::run(w[g], xs, col, nBlk, st[g], ze[g], -(qb * st[g]), acc[g]);
+                    if (MODE == GEMV_PAIRED) {
+                        const float qb2 = (float)a.job[1].qBias;
+                        acc2[g] = BD::run(w2[g], xs, col, nBlk, st2[g], ze2[g], -(qb2 * st2[g]), acc2[g]);
+                    }
+                }
+            }
+        }
+        // reduce over the LPR lanes of each row
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            for (int m = LPR >> 1; m > 0; m >>= 1) {
+                acc[g] += __shfl_xor(acc[g], m, 64);
+                if (MODE == GEMV_PAIRED) acc2[g] += __shfl_xor(acc2[g], m, 64);
+            }
+        }
+        if (ll == 0) {
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                if (!ok[g]) continue;
+                const GemvJob& jj = a.job[jb[g]];
+                const int r = row[g];
+                uint16_t* y = jj.y + (size_t)pos * jj.y_pos_stride;
+                float v = acc[g];
+                if (MODE == GEMV_PAIRED) {
+                    // SwiGLU of the two bf16-rounded projections (CU_swiglu_v0, Activation.cu:85-93)
+                    const float gt = round_bf16(v), up = round_bf16(acc2[g]);
+                    y[r] = f2bf((gt * up) / (1.0f + kf_expf(-gt)));
+                    continue;
+                }
+                if (a.alpha != 1.0f) v = a.alpha * v;
+                if (a.beta != 0.0f) v = v + a.beta * bf2f(y[r]);
+                if (a.bias) v = v + bf2f(a.bias[r]);
+                uint16_t o = f2bf(v);
+                if (a.residual) o = f2bf(bf2f(a.residual[r]) + bf2f(o)); /* CU_add3: bf16(x + bf16(W.x)) */
+                y[r] = o;
+                if (MODE == GEMV_ARGMAX) {
+                    const float fv = bf2f(o);
+                    if (fv > best_v || (fv == best_v && r < best_i)) best_v = fv, best_i = r;
+                }
+            }
+        }
+    }
+
+    if (MODE == GEMV_ARGMAX) {
+        // first-maximum over this workgroup's rows (sample_argmax, GoPT.cpp:602-612)
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) {
+            float ov = __shfl_xor(best_v, m, 64);
+            int oi = __shfl_xor(best_i, m, 64);
+            if (ov > best_v || (ov == best_v && oi < best_i)) best_v = ov, best_i = oi;
+        }
+        float* rv = reinterpret_cast<float*>(red);
+        int* ri = reinterpret_cast<int*>(rv + 16);
+        __syncthreads();
+        if (lane == 0) rv[wave_in_blk] = best_v, ri[wave_in_blk] = best_i;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < (int)(blockDim.x >> 6); w++)
+                if (rv[w] > best_v || (rv[w] == best_v && ri[w] < best_i)) best_v = rv[w], best_i = ri[w];
+            a.amax_val[blockIdx.x] = best_v;
+            a.amax_idx[blockIdx.x] = best_i;
+        }
+    }
+}
+
+// Final pick over the per-workgroup partial maxima, then the decode-state update for graph replay.
+__global__ void __launch_bounds__(256) argmax_finish_kernel(const float* val, const int* idx, int n, int32_t* d_argmax, int32_t* d_state,
+                                                            int32_t* d_tokens_out) {
+    float bv = -__builtin_inff();
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float v = val[i];
+        int ix = idx[i];
+        if (v > bv || (v == bv && ix < bi)) bv = v, bi = ix;
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        float ov = __shfl_xor(bv, m, 64);
+        int oi = __shfl_xor(bi, m, 64);
+        if (ov > bv || (ov == bv && oi < bi)) bv = ov, bi = oi;
+    }
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    if ((threadIdx.x & 63) == 0) sv[threadIdx.x >> 6] = bv, si[threadIdx.x >> 6] = bi;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++)
+            if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) bv = sv[w], bi = si[w];
+        if (d_argmax) *d_argmax = bi;
+        if (d_state) {
+            const int p = d_state[1];
+            if (d_tokens_out) d_tokens_out[p] = bi;
+            d_state[0] = bi;
+            d_state[1] = p + 1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launcher
+static int fmt_of(int type) {
+    switch (type) {
+        case KF_BF16: return FMT_BF16;
+        case KF_F8E5M2: return FMT_F8;
+        case KF_Q4: return FMT_Q4;
+        case KF_T_SIGN: return FMT_Q2;
+        case KF_BOOL1: case KF_T_BINARY: return FMT_Q1;
+        default: return -1;
+    }
+}
+static int epb_of(int fmt) {
+    switch (fmt) {
+        case FMT_BF16: return 8;
+        case FMT_F8: return 16;
+        case FMT_Q4: return 32;
+        case FMT_Q2: return 64;
+        default: return 128;
+    }
+}
+
+template <int FMT, int MODE>
+static void launch_g(const GemvArgs& a, int G, dim3 grid, size_t smem, hipStream_t st) {
+    if (G >= 4)
+        hipLaunchKernelGGL((gemv_kernel<FMT, 4, MODE>), grid, dim3(256), smem, st, a);
+    else if (G == 2)
+        hipLaunchKernelGGL((gemv_kernel<FMT, 2, MODE>), grid, dim3(256), smem, st, a);
+    else
+        hipLaunchKernelGGL((gemv_kernel<FMT, 1, MODE>), grid, dim3(256), smem, st, a);
+}
+template <int FMT>
+static void launch_m(const GemvArgs& a, int mode, int G, dim3 grid, size_t smem, hipStream_t st) {
+    if (mode == GEMV_PAIRED)
+        launch_g<FMT, GEMV_PAIRED>(a, G, grid, smem, st);
+    else if (mode == GEMV_ARGMAX)
+        launch_g<FMT, GEMV_ARGMAX>(a, G, grid, smem, st);
+    else
+        launch_g<FMT, GEMV_PLAIN>(a, G, grid, smem, st);
+}
+
+int gemv_launch(hipStream_t st, GemvLaunch& L) {
+    GemvArgs& a = L.args;
+    const kf_weight* w0 = L.w[0];
+    const int fmt = fmt_of(w0->type);
+    if (fmt < 0) return KF_UNSUPPORTED_DATATYPE;
+    const int K = w0->ne1, epb = epb_of(fmt);
+    if (K % epb != 0 || K % 8 != 0) return KF_INVALID_ARGS;
+    const int nBlk = K / epb;
+    // LPR: the largest power of two <= 64 dividing nBlk when that is >= 16 (no idle lanes), else the largest
+    // power of two <= min(64, nBlk) with the row tail masked.
+    int lpr_log2 = 6;
+    while (lpr_log2 > 0 && (nBlk % (1 << lpr_log2)) != 0) lpr_log2--;
+    if ((1 << lpr_log2) < 16) {
+        lpr_log2 = 6;
+        while ((1 << lpr_log2) > nBlk) lpr_log2--;
+    }
+    const int LPR = 1 << lpr_log2, RPS = 64 / LPR;
+    a.K = K, a.nBlk = nBlk, a.lpr_log2 = lpr_log2, a.iters = (nBlk + LPR - 1) / LPR;
+    a.inv_dim = 1.0f / (float)K;
+    a.njobs = L.n;
+    long slots = 0;
+    for (int j = 0; j < L.n; j++) {
+        const kf_weight* w = L.w[j];
+        if (fmt_of(w->type) != fmt || w->ne1 != K) return KF_INVALID_ARGS;
+        if (((uintptr_t)w->data & 15) != 0) return KF_BLAS_UNALIGN;
+        GemvJob& jb = a.job[j];
+        jb.w = w->data;
+        jb.zero = jb.step = nullptr;
+        if (fmt >= FMT_Q4) {
+            if (!w->gama || w->lGroup <= 0 || (w->lGroup % epb) != 0 || ((long)w->ne0 * w->ne1) % w->lGroup != 0) return KF_QUANT_ERR;
+            jb.zero = w->gama + w->ne0 + w->ne1; /* gama_T(ZERO), GTensor.cpp:456-510 */
+            jb.step = jb.zero + (size_t)w->ne0 * w->ne1 / w->lGroup;
+            a.lGroup = w->lGroup;
+        }
+        jb.M = w->ne0;
+        jb.qBias = w->qBias;
+        jb.slot0 = (int)slots;
+        if (L.mode == GEMV_PAIRED) {
+            if (j == 1) {
+                if (w->ne0 != L.w[0]->ne0) return KF_INVALID_ARGS;
+                continue; /* job 1 rides on job 0's slots */
+            }
+        }
+        slots += (w->ne0 + RPS - 1) / RPS;
+    }
+    if (L.mode == GEMV_PAIRED) a.njobs = 1, a.job[1].slot0 = 0x7fffffff;
+    a.total_slots = (int)slots;
+    // one wave per spw slots; aim for ~2048 waves (8 per CU) on large matrices, never fewer than one slot each
+    long spw = (slots + 2047) / 2048;
+    if (spw < 1) spw = 1;
+    int G = spw >= 4 ? 4 : (spw >= 2 ? 2 : 1);
+    if (L.mode == GEMV_PAIRED && G > 2) G = 2; /* two weight streams per slot: keep register pressure down */
+    spw = (spw + G - 1) / G * G;
+    a.spw = (int)spw;
+    const long waves = (slots + spw - 1) / spw;
+    const int blocks = (int)((waves + 3) / 4);
+    if (L.mode == GEMV_ARGMAX && blocks > KF_MAX_ARGMAX_PARTIALS) return KF_INTERNAL_ERR;
+    const size_t smem = (size_t)K * 2 + 256;
+    if (smem > 160 * 1024) return KF_INVALID_ARGS;
+    dim3 grid(blocks);
+    switch (fmt) {
+        case FMT_BF16: launch_m<FMT_BF16>(a, L.mode, G, grid, smem, st); break;
+        case FMT_F8: launch_m<FMT_F8>(a, L.mode, G, grid, smem, st); break;
+        case FMT_Q4: launch_m<FMT_Q4>(a, L.mode, G, grid, smem, st); break;
+        case FMT_Q2: launch_m<FMT_Q2>(a, L.mode, G, grid, smem, st); break;
+        default: launch_m<FMT_Q1>(a, L.mode, G, grid, smem, st); break;
+    }
+    L.blocks = blocks;
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+
+void argmax_finish_launch(hipStream_t st, const float* val, const int* idx, int n, int32_t* d_argmax, int32_t* d_state, int32_t* d_tokens_out) {
+    hipLaunchKernelGGL(argmax_finish_kernel, dim3(1), dim3(256), 0, st, val, idx, n, d_argmax, d_state, d_tokens_out);
+}
+
+}  // namespace kf

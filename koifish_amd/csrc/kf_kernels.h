@@ -1,0 +1,82 @@
+// kf_kernels.h -- internal launch interfaces between the ABI layer (kf_abi.hip) and the kernel files.
+#pragma once
+#include "../../include/kf_abi.h"
+#include "kf_device.h"
+
+namespace kf {
+
+enum { FMT_BF16 = 0, FMT_F8 = 1, FMT_Q4 = 2, FMT_Q2 = 3, FMT_Q1 = 4 };
+enum { GEMV_PLAIN = 0, GEMV_PAIRED = 1, GEMV_ARGMAX = 2 };
+constexpr int KF_MAX_ARGMAX_PARTIALS = 4096;
+
+struct GemvJob {
+    const void* w;
+    const uint16_t* zero;
+    const uint16_t* step;
+    uint16_t* y;
+    long long y_pos_stride; /* elements added per position (KV-cache row aliasing), 0 otherwise */
+    int M;
+    int qBias;
+    int slot0;
+};
+
+struct GemvArgs {
+    GemvJob job[3];
+    int njobs;
+    int K, nBlk, lpr_log2, iters, lGroup;
+    int spw, total_slots;
+    const uint16_t* x;
+    const uint16_t* norm_w; /* non-NULL: RMSNorm prologue */
+    float eps, inv_dim;
+    const uint16_t* residual;
+    const uint16_t* bias;
+    float alpha, beta;
+    const int* d_pos;
+    int pos;
+    float* amax_val;
+    int* amax_idx;
+};
+
+struct GemvLaunch {
+    GemvArgs args;
+    const kf_weight* w[3];
+    int n;
+    int mode;
+    int blocks; /* out */
+};
+
+int gemv_launch(hipStream_t st, GemvLaunch& L);
+void argmax_finish_launch(hipStream_t st, const float* val, const int* idx, int n, int32_t* d_argmax, int32_t* d_state, int32_t* d_tokens_out);
+
+// ---- attention (kf_attn.hip)
+struct AttnArgs {
+    const uint16_t* q;     /* raw or prepared q [n_head*hd] */
+    const uint16_t* k_raw; /* NULL: keys come from the cache only */
+    uint16_t* kcache;
+    const uint16_t* vcache;
+    const uint16_t* wq_norm;
+    const uint16_t* wk_norm;
+    const float* rope_table; /* NULL: q is already normed+roped */
+    float* part;             /* [n_head][n_splits][hd + 2] fp32 partials */
+    uint16_t* out;
+    const int* d_pos;
+    int pos;
+    int n_head, n_kv, hd, kv_stride, n_splits;
+    float eps, inv_sqrt_hd_den;
+};
+constexpr int KF_ATTN_MAX_SPLITS = 64;
+int attn_launch(hipStream_t st, AttnArgs& a);
+int qknorm_rope_launch(hipStream_t st, uint16_t* q, uint16_t* k, const uint16_t* wq, const uint16_t* wk, const float* table, int pos,
+                       const int* d_pos, int n_head, int n_kv, int hd, float eps);
+
+// ---- small ops (kf_ops.hip)
+int rmsnorm_launch(hipStream_t st, const uint16_t* x, const uint16_t* w, uint16_t* y, int rows, int dim, float eps, float* rstd);
+int swiglu_launch(hipStream_t st, const uint16_t* gate, const uint16_t* up, uint16_t* out, int n);
+int add_launch(hipStream_t st, const uint16_t* a, const uint16_t* b, uint16_t* out, int n);
+int embed_launch(hipStream_t st, const kf_weight* w, int token, const int32_t* d_token, const int32_t* d_state, const int32_t* d_forced,
+                 uint16_t* out);
+int dequant_launch(hipStream_t st, const kf_weight* w, uint16_t* out);
+int quantize_launch(hipStream_t st, const kf_weight* w, const uint16_t* src, int symmetric);
+int set_state_launch(hipStream_t st, int32_t* d_state, int token, int pos);
+
+}  // namespace kf

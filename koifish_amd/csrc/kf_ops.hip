@@ -1,0 +1,223 @@
+// kf_ops.hip -- the small operators of the decode step and the (load-time) dequant / quantise kernels.
+#include "kf_kernels.h"
+
+namespace kf {
+
+// ---------------------------------------------------------------- RMSNorm: rms_norm_kernel (layernorm.cuh:800-847)
+__global__ void __launch_bounds__(256) rmsnorm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, uint16_t* __restrict__ y, int dim,
+                                                      float eps, float inv_dim, float* rstd) {
+    __shared__ double red[16];
+    const uint16_t* xr = x + (size_t)blockIdx.x * dim;
+    uint16_t* yr = y + (size_t)blockIdx.x * dim;
+    const double ss = block_sumsq_bf16(xr, dim, red);
+    const float mul = 1.0f / sqrtf(fmaf((float)ss, inv_dim, eps));
+    for (int i = threadIdx.x; i < dim; i += blockDim.x) yr[i] = f2bf((bf2f(xr[i]) * mul) * bf2f(w[i]));
+    if (rstd && threadIdx.x == 0) rstd[blockIdx.x] = mul;
+}
+int rmsnorm_launch(hipStream_t st, const uint16_t* x, const uint16_t* w, uint16_t* y, int rows, int dim, float eps, float* rstd) {
+    if (dim % 2 != 0 || rows <= 0) return KF_RMS_PARAMS; /* CU_rms_infer refuses odd dims (layernorm.cuh:851-854) */
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3(rows), dim3(256), 0, st, x, w, y, dim, eps, 1.0f / (float)dim, rstd);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+
+// ---------------------------------------------------------------- SwiGLU / add
+__global__ void swiglu_kernel(const uint16_t* __restrict__ gate, const uint16_t* __restrict__ up, uint16_t* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float g = bf2f(gate[i]), u = bf2f(up[i]);
+        out[i] = f2bf((g * u) / (1.0f + kf_expf(-g)));
+    }
+}
+int swiglu_launch(hipStream_t st, const uint16_t* gate, const uint16_t* up, uint16_t* out, int n) {
+    hipLaunchKernelGGL(swiglu_kernel, dim3((n + 255) / 256), dim3(256), 0, st, gate, up, out, n);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+__global__ void add_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b, uint16_t* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = f2bf(bf2f(a[i]) + bf2f(b[i]));
+}
+int add_launch(hipStream_t st, const uint16_t* a, const uint16_t* b, uint16_t* out, int n) {
+    hipLaunchKernelGGL(add_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, b, out, n);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+
+// ---------------------------------------------------------------- block dequant (CU_Q128toX_, T.cu:245-294; CU_F82Float)
+__device__ __forceinline__ float dq(float step, float zero, float qm) { return round_bf16(round_bf16(step * qm) - zero); }
+
+// one thread per 16-byte block; out points at the first element of the block
+__device__ __forceinline__ void dequant_block(int fmt, u32x4 w, float step, float zero, int qBias, uint16_t* out) {
+    const uint32_t d[4] = {w.w, w.z, w.y, w.x}; /* d[0] = first elements of a Packed128 */
+    if (fmt == FMT_BF16) {
+        *reinterpret_cast<u32x4*>(out) = w;
+    } else if (fmt == FMT_F8) {
+        const uint32_t e[4] = {w.x, w.y, w.z, w.w};
+        for (int k = 0; k < 16; k++) out[k] = f2bf(half_bits_to_f32(((e[k >> 2] >> (8 * (k & 3))) & 0xffu) << 8));
+    } else if (fmt == FMT_Q4) {
+        for (int k = 0; k < 32; k++) out[k] = f2bf(dq(step, zero, (float)((int)((d[k >> 3] >> (28 - 4 * (k & 7))) & 0xFu) - qBias)));
+    } else if (fmt == FMT_Q2) {
+        for (int k = 0; k < 64; k++) out[k] = f2bf(dq(step, zero, (float)((int)((d[k >> 4] >> (30 - 2 * (k & 15))) & 0x3u) - qBias)));
+    } else {
+        for (int k = 0; k < 128; k++) out[k] = f2bf(dq(step, zero, (float)((int)((d[k >> 5] >> (31 - (k & 31))) & 0x1u) - qBias)));
+    }
+}
+static int fmt_of(int type, int* epb) {
+    switch (type) {
+        case KF_BF16: *epb = 8; return FMT_BF16;
+        case KF_F8E5M2: *epb = 16; return FMT_F8;
+        case KF_Q4: *epb = 32; return FMT_Q4;
+        case KF_T_SIGN: *epb = 64; return FMT_Q2;
+        case KF_BOOL1: case KF_T_BINARY: *epb = 128; return FMT_Q1;
+        default: *epb = 0; return -1;
+    }
+}
+__global__ void dequant_kernel(int fmt, int epb, const u32x4* __restrict__ data, const uint16_t* __restrict__ zero, const uint16_t* __restrict__ step, int lGroup,
+                               int qBias, size_t nblocks, size_t block0, uint16_t* __restrict__ out) {
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    const size_t gb = block0 + b;
+    float st = 0.f, ze = 0.f;
+    if (zero) {
+        const size_t gi = gb * epb / lGroup;
+        st = bf2f(step[gi]), ze = bf2f(zero[gi]);
+    }
+    dequant_block(fmt, data[gb], st, ze, qBias, out + b * epb);
+}
+int dequant_launch(hipStream_t st, const kf_weight* w, uint16_t* out) {
+    int epb;
+    const int fmt = fmt_of(w->type, &epb);
+    if (fmt < 0) return KF_UNSUPPORTED_DATATYPE;
+    const size_t n = (size_t)w->ne0 * w->ne1;
+    if (n % epb) return KF_INVALID_ARGS;
+    const uint16_t *zero = nullptr, *step = nullptr;
+    if (fmt >= FMT_Q4) {
+        if (!w->gama || w->lGroup <= 0) return KF_QUANT_ERR;
+        zero = w->gama + w->ne0 + w->ne1;
+        step = zero + n / w->lGroup;
+    }
+    const size_t nb = n / epb;
+    hipLaunchKernelGGL(dequant_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, fmt, epb, (const u32x4*)w->data, zero, step, w->lGroup, w->qBias, nb,
+                       (size_t)0, out);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+
+// ---------------------------------------------------------------- embedding row (CU_embed_forw_1/_q4, embed.cuh:54-132)
+__global__ void embed_kernel(int fmt, int epb, const u32x4* __restrict__ data, const uint16_t* __restrict__ zero, const uint16_t* __restrict__ step, int lGroup,
+                             int qBias, int nBlk, int token_, const int32_t* d_token, const int32_t* d_state, const int32_t* d_forced,
+                             uint16_t* __restrict__ out) {
+    int token = token_;
+    if (d_token) token = *d_token;
+    if (d_state) {
+        token = d_state[0];
+        if (d_forced) {
+            const int f = d_forced[d_state[1]];
+            if (f >= 0) token = f;
+        }
+    }
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nBlk) return;
+    const size_t gb = (size_t)token * nBlk + b;
+    float st = 0.f, ze = 0.f;
+    if (zero) {
+        const size_t gi = gb * epb / lGroup;
+        st = bf2f(step[gi]), ze = bf2f(zero[gi]);
+    }
+    dequant_block(fmt, data[gb], st, ze, qBias, out + (size_t)b * epb);
+}
+int embed_launch(hipStream_t st, const kf_weight* w, int token, const int32_t* d_token, const int32_t* d_state, const int32_t* d_forced, uint16_t* out) {
+    int epb;
+    const int fmt = fmt_of(w->type, &epb);
+    if (fmt < 0) return KF_UNSUPPORTED_DATATYPE;
+    if (w->ne1 % epb) return KF_INVALID_ARGS;
+    if (!d_token && !d_state && (token < 0 || token >= w->ne0)) return KF_INVALID_ARGS;
+    const uint16_t *zero = nullptr, *step = nullptr;
+    if (fmt >= FMT_Q4) {
+        if (!w->gama || w->lGroup <= 0) return KF_QUANT_ERR;
+        zero = w->gama + w->ne0 + w->ne1;
+        step = zero + (size_t)w->ne0 * w->ne1 / w->lGroup;
+    }
+    const int nBlk = w->ne1 / epb;
+    hipLaunchKernelGGL(embed_kernel, dim3((nBlk + 63) / 64), dim3(64), 0, st, fmt, epb, (const u32x4*)w->data, zero, step, w->lGroup, w->qBias, nBlk, token,
+                       d_token, d_state, d_forced, out);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+
+// ---------------------------------------------------------------- quantiser: GeQuant::RTN_x / YinYang (GeQuant.cpp:428-628)
+// One wave per group of lGroup (<= 128... any multiple of 64 up to 1024) consecutive elements.
+// mode 0: RTN asymmetric, 1: RTN symmetric, 2: YinYang (step = max(1e-5, sqrt(mean(relu(a)^2))), zero = 0)
+__global__ void __launch_bounds__(256) quantize_kernel(const uint16_t* __restrict__ src, unsigned char* __restrict__ packed, uint16_t* __restrict__ zero_out,
+                                                       uint16_t* __restrict__ step_out, size_t nGroup, int lGroup, int bits, int mode, int qMin, int qMax,
+                                                       int qBias) {
+    const int lane = threadIdx.x & 63;
+    const size_t g = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (g >= nGroup) return;
+    const uint16_t* dat = src + g * lGroup;
+    float vmax = -3.402823466e+38f, vmin = 3.402823466e+38f;
+    double vsum = 0.0;
+    for (int i = lane; i < lGroup; i += 64) {
+        const float a = bf2f(dat[i]);
+        vmax = fmaxf(vmax, a), vmin = fminf(vmin, a);
+        vsum += (a < 0.0f) ? 0.0 : (double)(a * a);
+    }
+    for (int m = 32; m > 0; m >>= 1) {
+        vmax = fmaxf(vmax, __shfl_xor(vmax, m, 64));
+        vmin = fminf(vmin, __shfl_xor(vmin, m, 64));
+    }
+    float step, zero;
+    if (mode == 2) {
+        vsum = wave_sum_f64(vsum);
+        step = fmaxf(1e-5f, (float)sqrt(vsum / (double)lGroup));
+        zero = 0.f;
+    } else if (mode == 1) {
+        step = fmaxf(fabsf(vmax), fabsf(vmin)) / (float)qMax;
+        zero = 0.f;
+    } else {
+        step = (vmax - vmin) / (float)(qMax - qMin);
+        zero = -vmin;
+    }
+    if (lane == 0) zero_out[g] = f2bf(zero), step_out[g] = f2bf(step);
+    // pack: lane b < nblk builds Packed128 block b (MSB-first within high then low; PackedQ.hpp:99-239)
+    const int per = 128 / bits, nblk = lGroup / per;
+    unsigned char* dst = packed + g * ((size_t)lGroup * bits / 8);
+    for (int b = lane; b < nblk; b += 64) {
+        unsigned long long high = 0, low = 0;
+        for (int i = 0; i < per; i++) {
+            const float a = bf2f(dat[b * per + i]);
+            int q = (int)roundf((a + zero) / step);
+            q = q < qMin ? qMin : (q > qMax ? qMax : q);
+            const unsigned long long v = (unsigned long long)((q + qBias) & ((1 << bits) - 1));
+            const int half = per / 2, ii = i < half ? i : i - half;
+            const int sh = 64 - bits * (ii + 1);
+            if (i < half)
+                high |= v << sh;
+            else
+                low |= v << sh;
+        }
+        reinterpret_cast<unsigned long long*>(dst + 16 * b)[0] = low;
+        reinterpret_cast<unsigned long long*>(dst + 16 * b)[1] = high;
+    }
+}
+int quantize_launch(hipStream_t st, const kf_weight* w, const uint16_t* src, int symmetric) {
+    int bits, mode = symmetric ? 1 : 0;
+    switch (w->type) {
+        case KF_Q4: bits = 4; break;
+        case KF_T_SIGN: bits = 2, mode = 2; break;
+        case KF_BOOL1: case KF_T_BINARY: bits = 1, mode = 2; break;
+        default: return KF_UNSUPPORTED_DATATYPE;
+    }
+    const size_t n = (size_t)w->ne0 * w->ne1;
+    if (!w->gama || w->lGroup <= 0 || n % w->lGroup || w->lGroup % (128 / bits)) return KF_QUANT_ERR;
+    const size_t nGroup = n / w->lGroup;
+    uint16_t* zero = const_cast<uint16_t*>(w->gama) + w->ne0 + w->ne1;
+    uint16_t* step = zero + nGroup;
+    hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)((nGroup + 3) / 4)), dim3(256), 0, st, src, (unsigned char*)const_cast<void*>(w->data), zero, step, nGroup,
+                       w->lGroup, bits, mode, w->qMin, w->qMax, w->qBias);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+
+__global__ void set_state_kernel(int32_t* st, int token, int pos) { st[0] = token, st[1] = pos; }
+int set_state_launch(hipStream_t st, int32_t* d_state, int token, int pos) {
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, d_state, token, pos);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+
+}  // namespace kf

@@ -1,0 +1,484 @@
+// kf_host.cpp -- see kf_host.hpp.  Plain C++17, no HIP headers; every device action is a kf_* ABI call.
+#include "kf_host.hpp"
+
+#include <cassert>
+#include <cstdio>
+#include <cstring>
+
+namespace koifish {
+
+#define KF_TRY(expr)                 \
+    do {                             \
+        int rc_ = (expr);            \
+        if (rc_ != KF_OK) return rc_; \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------ GTensor
+GTensor::~GTensor() {
+    if (owned && data && ctx) kf_free(ctx, data);
+}
+kf_weight GTensor::desc() const {
+    kf_weight w;
+    std::memset(&w, 0, sizeof(w));
+    w.data = data;
+    w.gama = gama_T();
+    w.type = (int32_t)type;
+    w.ne0 = ne[0], w.ne1 = ne[1];
+    w.lGroup = quant.T_group;
+    w.nGroup = nGroup();
+    w.qMin = quant.qMin, w.qMax = quant.qMax, w.qBias = quant.qBias;
+    return w;
+}
+int GTensor::Alloc(kf_ctx* c, size_t nbytes) {
+    ctx = c;
+    KF_TRY(kf_malloc(c, nbytes, &data));
+    owned = true;
+    return KF_OK;
+}
+int GTensor::LoadBlob(kf_ctx* c, const void* h_blob, size_t nbytes) {
+    KF_TRY(Alloc(c, nbytes));
+    return kf_h2d(c, data, h_blob, nbytes);
+}
+hGTensor GT(kf_ctx* c, const std::string& name, typNUMBER tp, int n0, int n1) {
+    auto t = std::make_shared<GTensor>();
+    t->name = name, t->type = tp, t->ne[0] = n0, t->ne[1] = n1;
+    size_t bytes = (size_t)n0 * n1 * (tp == typNUMBER::F32 || tp == typNUMBER::I32 ? 4 : 2);
+    t->szData = bytes;
+    if (t->Alloc(c, bytes) != KF_OK) return nullptr;
+    kf_memset(c, t->data, 0, bytes);
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------------ KVCache
+int KVCache::Init(kf_ctx* c, int nl, int ms, int kvd) {
+    n_layer = nl, max_seq_len = ms, kv_dim = kvd;
+    key = GT(c, "kv.key", typNUMBER::BF16, nl * ms, kvd);
+    val = GT(c, "kv.val", typNUMBER::BF16, nl * ms, kvd);
+    return (key && val) ? KF_OK : KF_OUTOF_GPUMEMORY;
+}
+void* KVCache::Get(CTYPE type, int layer, int pos) const {
+    floatX* base = ToX(type == KV_KEY ? key : val);
+    return base + ((size_t)layer * max_seq_len + pos) * kv_dim;
+}
+
+// ------------------------------------------------------------------------------------------------ neurons
+hGTensor LayerNormal::cuFlow(hGTensor inp, int) {
+    // P_CHAT_1 && nHead == 0  ->  CU_rms_infer (T.cu:569-573)
+    if (kf_rmsnorm(hFish->ctx, ToX(inp), ToX(w), ToX(out), 1, ldTH, rms_eps, nullptr) != KF_OK) return nullptr;
+    return out;
+}
+int Relu::Forw(hGTensor out, hGTensor gate, hGTensor inp, int) {
+    return kf_swiglu(hFish->ctx, ToX(gate), ToX(inp), ToX(out), inp->ne[0]) == KF_OK ? 0 : -1;
+}
+int SLP::Forw(floatX* rhs, const floatX* lhs, uint32_t epilogue, const floatX* residual) {
+    kf_weight wd = w->desc();
+    return kf_linear(hFish->ctx, &wd, lhs, rhs, b ? ToX(b) : nullptr, 1, 1.0f, 0.0f, epilogue, residual) == KF_OK ? 0 : -1;
+}
+int SLP::Forw(hGTensor rhs, hGTensor lhs, hGTensor toGelu, Relu*, int) {
+    floatX* dst = toGelu ? ToX(toGelu) : ToX(rhs);  // rhs = to_gelu ? to_gelu : rhs (NeuronFuse.cu:332)
+    return Forw(dst, ToX(lhs));
+}
+
+hGTensor ROPE::cuInfer(SelfAttention* hQKV, uint32_t, int pos, int) {
+    Fish* f = hFish;
+    floatX* q = ToX(hQKV->Q.out);
+    floatX* k = reinterpret_cast<floatX*>(hQKV->hCache->Get(KVCache::KV_KEY, hQKV->layid - 1, pos));
+    int rc = kf_qknorm_rope(f->ctx, q, k, hnQ ? ToX(hnQ->w) : nullptr, hnK ? ToX(hnK->w) : nullptr, f->rope_table, pos, nullptr, n_head, n_head_kv, head_dim,
+                            hnQ ? hnQ->rms_eps : 1e-6f);
+    return rc == KF_OK ? hQKV->Q.out : nullptr;
+}
+
+void SelfAttention::_devQKV(int) { /* K.out/V.out are resolved per launch from the cache base + pos (see cuInfer) */ }
+
+hGTensor SelfAttention::cuInfer(hGTensor inpL, int) {
+    Fish* f = hFish;
+    kf_ctx* c = f->ctx;
+    const int pos = f->tok_pos, L = layid - 1;
+    floatX* key_cache = reinterpret_cast<floatX*>(hCache->Get(KVCache::KV_KEY, L, 0));
+    floatX* val_cache = reinterpret_cast<floatX*>(hCache->Get(KVCache::KV_VAL, L, 0));
+    f->gBUFF.residual = inpL;
+    const int32_t* d_pos = f->graph_mode ? f->d_state + 1 : nullptr;
+    const int bound = f->graph_mode ? f->pos_bound() : pos;
+    if (f->fuse_level == 0) {
+        if (f->graph_mode) return nullptr;  // the per-kernel path resolves cache rows on the host
+        hGTensor inpQ = norm.cuFlow(inpL);
+        if (!inpQ) return nullptr;
+        floatX* krow = key_cache + (size_t)pos * kv_dim;
+        floatX* vrow = val_cache + (size_t)pos * kv_dim;
+        if (Q.Forw(ToX(Q.out), ToX(inpQ)) || K.Forw(krow, ToX(inpQ)) || V.Forw(vrow, ToX(inpQ))) return nullptr;
+        if (!rope.cuInfer(this, 42, pos)) return nullptr;
+        if (kf_attn_decode(c, ToX(Q.out), key_cache, val_cache, ToX(Q.out), pos, nullptr, n_head, n_head_kv, head_dim, kv_dim, f->gBUFF.attn_ws->data) != KF_OK)
+            return nullptr;
+        if (proj_cat.Forw(ToX(f->gBUFF.scratch), ToX(Q.out))) return nullptr;
+        if (kf_add(c, ToX(f->gBUFF.residual), ToX(f->gBUFF.scratch), ToX(out), f->config.nEmbed) != KF_OK) return nullptr;  // CU_add3
+        return out;
+    }
+    // fused: [norm + Q,K,V] -> [q/k-norm + RoPE + attention] -> [proj_cat + residual]
+    kf_weight wq = Q.w->desc(), wk = K.w->desc(), wv = V.w->desc(), wo = proj_cat.w->desc();
+    const kf_weight* ws[3] = {&wq, &wk, &wv};
+    kf_bf16* ys[3] = {ToX(Q.out), ToX(f->gBUFF.kraw), val_cache};
+    const int64_t strides[3] = {0, 0, (int64_t)kv_dim};
+    if (kf_norm_linear(c, ToX(inpL), ToX(norm.w), norm.rms_eps, 3, ws, ys, strides, bound, d_pos) != KF_OK) return nullptr;
+    if (kf_attn_block(c, ToX(Q.out), ToX(f->gBUFF.kraw), key_cache, val_cache, ToX(f->gBUFF.scratch), normQ.w ? ToX(normQ.w) : nullptr,
+                      normK.w ? ToX(normK.w) : nullptr, f->rope_table, bound, d_pos, n_head, n_head_kv, head_dim, kv_dim, normQ.rms_eps,
+                      f->gBUFF.attn_ws->data) != KF_OK)
+        return nullptr;
+    if (kf_linear(c, &wo, ToX(f->gBUFF.scratch), ToX(out), nullptr, 1, 1.0f, 0.0f, KF_EPI_RESIDUAL, ToX(inpL)) != KF_OK) return nullptr;
+    return out;
+}
+
+hGTensor FFN::cuInfer(hGTensor hIn, int) {
+    Fish* f = hFish;
+    kf_ctx* c = f->ctx;
+    f->gBUFF.residual = hIn;
+    if (f->fuse_level == 0) {
+        hGTensor xn = norm.cuFlow(hIn);
+        if (!xn) return nullptr;
+        hGTensor tGelu = f->gBUFF.scratch, up_out = f->gBUFF.upOut;
+        if (gate.Forw(tGelu, xn) || up.Forw(up_out, xn)) return nullptr;
+        if (relu.Forw(tGelu, tGelu, up_out)) return nullptr;
+        if (down.Forw(ToX(f->gBUFF.delta), ToX(tGelu))) return nullptr;
+        if (kf_add(c, ToX(f->gBUFF.residual), ToX(f->gBUFF.delta), ToX(out), f->config.nEmbed) != KF_OK) return nullptr;
+        return out;
+    }
+    kf_weight wg = gate.w->desc(), wu = up.w->desc(), wd = down.w->desc();
+    if (kf_norm_gateup_swiglu(c, ToX(hIn), ToX(norm.w), norm.rms_eps, &wg, &wu, ToX(f->gBUFF.scratch)) != KF_OK) return nullptr;
+    if (kf_linear(c, &wd, ToX(f->gBUFF.scratch), ToX(out), nullptr, 1, 1.0f, 0.0f, KF_EPI_RESIDUAL, ToX(hIn)) != KF_OK) return nullptr;
+    return out;
+}
+
+hGTensor TokenEmbed::cuInfer(int token, int) {
+    Fish* f = hFish;
+    kf_weight wd = w->desc();
+    int rc = f->graph_mode ? kf_embed_state(f->ctx, &wd, f->d_state, f->d_forced, ToX(out)) : kf_embed(f->ctx, &wd, token, nullptr, ToX(out));
+    return rc == KF_OK ? out : nullptr;
+}
+
+hGTensor Head4Token::cuInfer_1(hGTensor inp_, int) {
+    Fish* f = hFish;
+    kf_weight wd = proj.w->desc();
+    int rc;
+    if (f->fuse_level == 0) {
+        hGTensor xn = f->final_norm.cuFlow(inp_);
+        if (!xn) return nullptr;
+        rc = kf_lm_head(f->ctx, &wd, ToX(xn), ToX(preLogits), f->d_state + 2, f->gBUFF.head_ws->data);
+    } else {
+        rc = kf_norm_lm_head(f->ctx, ToX(inp_), ToX(f->final_norm.w), f->final_norm.rms_eps, &wd, ToX(preLogits), f->d_state, f->d_tokens_out,
+                             f->gBUFF.head_ws->data);
+    }
+    return rc == KF_OK ? preLogits : nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------ Fish
+Fish::~Fish() {
+    for (auto g : graphs) kf_graph_destroy(g);
+    if (ctx) {
+        if (rope_table) kf_free(ctx, rope_table);
+        if (d_state) kf_free(ctx, d_state);
+        if (d_forced) kf_free(ctx, d_forced);
+        if (d_tokens_out) kf_free(ctx, d_tokens_out);
+    }
+    attn.clear(), ffn.clear();
+    embed = TokenEmbed(), head = Head4Token(), final_norm = LayerNormal();
+    gBUFF = MemBuffer(), cache = KVCache(), x.reset();
+    if (ctx) kf_destroy(ctx);
+}
+
+int Fish::Build(const MODEL_CARD& card, int device, void* stream) {
+    config = card;
+    KF_TRY(kf_init(device, stream, &ctx));
+    const int C = card.nEmbed, hd = card.head_dim, qd = card.n_head * hd, kvd = card.n_head_kv * hd;
+    KF_TRY(cache.Init(ctx, card.nLayer, card.n_ctx, kvd));
+    x = GT(ctx, "x", typNUMBER::BF16, C);
+    gBUFF.tmpFF1 = GT(ctx, "tmpFF1", typNUMBER::BF16, qd);
+    gBUFF.kraw = GT(ctx, "kraw", typNUMBER::BF16, kvd);
+    gBUFF.scratch = GT(ctx, "scratch", typNUMBER::BF16, std::max(std::max(qd, C), card.n_ff));
+    gBUFF.delta = GT(ctx, "delta", typNUMBER::BF16, C);
+    gBUFF.upOut = GT(ctx, "upOut", typNUMBER::BF16, card.n_ff);
+    gBUFF.normed = GT(ctx, "normed", typNUMBER::BF16, C);
+    gBUFF.attn_ws = GT(ctx, "attn_ws", typNUMBER::F32, (int)(kf_attn_scratch_bytes(card.n_head, hd) / 4));
+    gBUFF.head_ws = GT(ctx, "head_ws", typNUMBER::F32, (int)(kf_head_scratch_bytes() / 4));
+    if (!x || !gBUFF.tmpFF1 || !gBUFF.kraw || !gBUFF.scratch || !gBUFF.delta || !gBUFF.upOut || !gBUFF.normed || !gBUFF.attn_ws || !gBUFF.head_ws)
+        return KF_OUTOF_GPUMEMORY;
+    // RoPE (cos,sin) table on the host libm, uploaded once
+    {
+        std::vector<float> tab((size_t)card.n_ctx * hd);
+        KF_TRY(kf_rope_table_host(tab.data(), card.n_ctx, hd, card.rope_theta));
+        KF_TRY(kf_malloc(ctx, tab.size() * 4, (void**)&rope_table));
+        KF_TRY(kf_h2d(ctx, rope_table, tab.data(), tab.size() * 4));
+    }
+    KF_TRY(kf_malloc(ctx, 16, (void**)&d_state));
+    KF_TRY(kf_memset(ctx, d_state, 0, 16));
+    KF_TRY(kf_malloc(ctx, (size_t)card.n_ctx * 4, (void**)&d_forced));
+    KF_TRY(kf_memset(ctx, d_forced, 0xff, (size_t)card.n_ctx * 4));
+    KF_TRY(kf_malloc(ctx, (size_t)card.n_ctx * 4, (void**)&d_tokens_out));
+    KF_TRY(kf_memset(ctx, d_tokens_out, 0xff, (size_t)card.n_ctx * 4));
+
+    embed.hFish = this, embed.name = "embed_tokens", embed.out = x;
+    for (int l = 0; l < card.nLayer; l++) {
+        auto a = std::make_unique<SelfAttention>();
+        a->hFish = this, a->layid = l + 1, a->name = "layers." + std::to_string(l) + ".self_attn";
+        a->n_head = card.n_head, a->n_head_kv = card.n_head_kv, a->head_dim = hd, a->q_dim = qd, a->kv_dim = kvd;
+        a->hCache = &cache, a->out = x;
+        a->norm.hFish = this, a->norm.ldTH = C, a->norm.rms_eps = card.rms_eps, a->norm.out = gBUFF.normed;
+        a->normQ.hFish = a->normK.hFish = this, a->normQ.nHead = card.n_head, a->normK.nHead = card.n_head_kv;
+        a->normQ.ldTH = a->normK.ldTH = hd, a->normQ.rms_eps = a->normK.rms_eps = card.qk_eps;
+        for (SLP* s : {&a->Q, &a->K, &a->V, &a->proj_cat}) s->hFish = this;
+        a->Q.out = gBUFF.tmpFF1, a->Q.nIn = C, a->Q.nOut = qd;
+        a->rope.hFish = this, a->rope.hnQ = &a->normQ, a->rope.hnK = &a->normK;
+        a->rope.n_head = card.n_head, a->rope.n_head_kv = card.n_head_kv, a->rope.head_dim = hd, a->rope.theta = card.rope_theta;
+        attn.push_back(std::move(a));
+        auto m = std::make_unique<FFN>();
+        m->hFish = this, m->layid = l + 1, m->name = "layers." + std::to_string(l) + ".mlp", m->latent = card.n_ff, m->out = x;
+        m->norm.hFish = this, m->norm.ldTH = C, m->norm.rms_eps = card.rms_eps, m->norm.out = gBUFF.normed;
+        for (SLP* s : {&m->gate, &m->up, &m->down}) s->hFish = this;
+        m->relu.hFish = this;
+        ffn.push_back(std::move(m));
+    }
+    final_norm.hFish = this, final_norm.ldTH = C, final_norm.rms_eps = card.rms_eps, final_norm.out = gBUFF.normed;
+    head.hFish = this, head.proj.hFish = this;
+    head.preLogits = GT(ctx, "preLogits", typNUMBER::BF16, card.vocab);
+    return head.preLogits ? KF_OK : KF_OUTOF_GPUMEMORY;
+}
+
+// position buckets: one captured graph each; the bound fixes the attention slice count of that graph
+static const int kBuckets[] = {64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072};
+static int bucket_of(int pos) {
+    int i = 0;
+    while (kBuckets[i] <= pos) i++;
+    return i;
+}
+int Fish::pos_bound() const {
+    int b = kBuckets[bucket_of(tok_pos)] - 1;
+    return b < config.n_ctx - 1 ? b : config.n_ctx - 1;
+}
+
+int Fish::EnqueueStep(int) {
+    hGTensor cur = embed.cuInfer(-1);
+    if (!cur) return KF_INTERNAL_ERR;
+    for (int l = 0; l < config.nLayer; l++) {
+        cur = attn[l]->cuInfer(cur);
+        if (!cur) return KF_INTERNAL_ERR;
+        cur = ffn[l]->cuInfer(cur);
+        if (!cur) return KF_INTERNAL_ERR;
+    }
+    return head.cuInfer_1(cur) ? KF_OK : KF_INTERNAL_ERR;
+}
+
+int Fish::ForwardOnRLS(int token, int pos) {
+    if (pos < 0 || pos >= config.n_ctx || token < 0 || token >= config.vocab) return KF_INVALID_ARGS;
+    tok_pos = pos;
+    graph_mode = false;
+    KF_TRY(kf_set_state(ctx, d_state, token, pos));
+    hGTensor cur = embed.cuInfer(token);
+    if (!cur) return KF_INTERNAL_ERR;
+    for (int l = 0; l < config.nLayer; l++) {
+        cur = attn[l]->cuInfer(cur);
+        if (!cur) return KF_INTERNAL_ERR;
+        cur = ffn[l]->cuInfer(cur);
+        if (!cur) return KF_INTERNAL_ERR;
+    }
+    return head.cuInfer_1(cur) ? KF_OK : KF_INTERNAL_ERR;
+}
+
+int Fish::SetState(int token, int pos) { return kf_set_state(ctx, d_state, token, pos); }
+
+kf_graph* Fish::GraphFor(int pos) {
+    const int b = bucket_of(pos);
+    if ((int)graphs.size() <= b) graphs.resize(b + 1, nullptr), graph_bound.resize(b + 1, 0);
+    if (!graphs[b]) {
+        tok_pos = pos;
+        graph_mode = true;
+        const int save = fuse_level;
+        fuse_level = 1;
+        if (kf_graph_begin(ctx) != KF_OK) return nullptr;
+        int rc = EnqueueStep(pos_bound());
+        kf_graph* g = nullptr;
+        int rc2 = kf_graph_end(ctx, &g);
+        fuse_level = save;
+        graph_mode = false;
+        if (rc != KF_OK || rc2 != KF_OK) return nullptr;
+        graphs[b] = g, graph_bound[b] = pos_bound();
+    }
+    return graphs[b];
+}
+
+int Fish::RunSteps(int pos, int n, bool use_graph) {
+    if (pos < 0 || pos + n > config.n_ctx) return KF_INVALID_ARGS;
+    for (int i = 0; i < n; i++) {
+        const int p = pos + i;
+        if (use_graph) {
+            kf_graph* g = GraphFor(p);
+            if (!g) return KF_INTERNAL_ERR;
+            KF_TRY(kf_graph_launch(ctx, g));
+        } else {
+            tok_pos = p;
+            graph_mode = true;  // positions/tokens still come from d_state, launches are eager
+            const int save = fuse_level;
+            fuse_level = 1;
+            int rc = EnqueueStep(pos_bound());
+            fuse_level = save;
+            graph_mode = false;
+            KF_TRY(rc);
+        }
+    }
+    return KF_OK;
+}
+
+int Fish::Generate(const int* prompt, int n_prompt, int n_new, int* out, bool use_graph) {
+    if (n_prompt < 1 || n_new < 1 || n_prompt + n_new - 1 > config.n_ctx) return KF_INVALID_ARGS;
+    std::vector<int32_t> forced(config.n_ctx, -1);
+    for (int i = 0; i < n_prompt; i++) forced[i] = prompt[i];
+    KF_TRY(kf_h2d(ctx, d_forced, forced.data(), forced.size() * 4));
+    KF_TRY(SetState(prompt[0], 0));
+    const int total = n_prompt + n_new - 1;
+    KF_TRY(RunSteps(0, total, use_graph));
+    std::vector<int32_t> toks(config.n_ctx);
+    KF_TRY(kf_d2h(ctx, toks.data(), d_tokens_out, toks.size() * 4));
+    for (int i = 0; i < n_new; i++) out[i] = toks[n_prompt - 1 + i];
+    return KF_OK;
+}
+
+}  // namespace koifish
+
+// ================================================================================================ C entry points
+// Flat C surface over the classes above for ctypes (tests, bench.py) -- host-side convenience, not part of the
+// kernel ABI.  Handles are koifish::Fish*.
+using namespace koifish;
+extern "C" {
+
+void* kfh_create(int device, void* stream, int dim, int n_layer, int n_head, int n_kv, int head_dim, int ffn, int vocab, int n_ctx, float rms_eps, float qk_eps,
+                 float theta, int* rc_out) {
+    Fish* f = new Fish();
+    MODEL_CARD c;
+    c.nEmbed = dim, c.nLayer = n_layer, c.n_head = n_head, c.n_head_kv = n_kv, c.head_dim = head_dim, c.n_ff = ffn, c.vocab = vocab, c.n_ctx = n_ctx;
+    c.rms_eps = rms_eps, c.qk_eps = qk_eps, c.rope_theta = theta;
+    int rc = f->Build(c, device, stream);
+    if (rc_out) *rc_out = rc;
+    if (rc != KF_OK) {
+        delete f;
+        return nullptr;
+    }
+    return f;
+}
+void kfh_destroy(void* h) { delete reinterpret_cast<Fish*>(h); }
+void* kfh_ctx(void* h) { return reinterpret_cast<Fish*>(h)->ctx; }
+int kfh_set_fuse_level(void* h, int lvl) {
+    reinterpret_cast<Fish*>(h)->fuse_level = lvl;
+    return KF_OK;
+}
+
+static SLP* slot_of(Fish* f, int layer, int slot) {
+    if (layer < 0) return slot == 1 ? &f->head.proj : nullptr;
+    if (layer >= f->config.nLayer) return nullptr;
+    SelfAttention* a = f->attn[layer].get();
+    FFN* m = f->ffn[layer].get();
+    switch (slot) {
+        case 0: return &a->Q;
+        case 1: return &a->K;
+        case 2: return &a->V;
+        case 3: return &a->proj_cat;
+        case 4: return &m->gate;
+        case 5: return &m->up;
+        case 6: return &m->down;
+    }
+    return nullptr;
+}
+
+// slot: 0 q,1 k,2 v,3 o,4 gate,5 up,6 down (layer >= 0); layer = -1: slot 0 embed_tokens, 1 lm_head.
+// Either a host blob (`data||gama`, copied to a fresh device allocation) or an existing device pointer.
+int kfh_set_weight(void* h, int layer, int slot, int type, int ne0, int ne1, const void* blob, size_t blob_bytes, size_t szData, int is_device, int lGroup,
+                   int qMin, int qMax, int qBias) {
+    Fish* f = reinterpret_cast<Fish*>(h);
+    auto t = std::make_shared<GTensor>();
+    t->type = (typNUMBER)type, t->ne[0] = ne0, t->ne[1] = ne1;
+    t->szData = szData, t->szGama = blob_bytes - szData;
+    t->quant.T_group = lGroup, t->quant.qMin = qMin, t->quant.qMax = qMax, t->quant.qBias = qBias;
+    if (is_device) {
+        t->data = const_cast<void*>(blob), t->ctx = f->ctx, t->owned = false;
+    } else {
+        int rc = t->LoadBlob(f->ctx, blob, blob_bytes);
+        if (rc != KF_OK) return rc;
+    }
+    if (layer < 0 && slot == 0) {
+        f->embed.w = t;
+        return KF_OK;
+    }
+    SLP* s = slot_of(f, layer, slot);
+    if (!s) return KF_INVALID_ARGS;
+    s->w = t, s->nOut = ne0, s->nIn = ne1;
+    return KF_OK;
+}
+// tie_word_embeddings: lm_head shares embed_tokens' tensor (Neuron.cpp:349-356)
+int kfh_tie_head(void* h) {
+    Fish* f = reinterpret_cast<Fish*>(h);
+    if (!f->embed.w) return KF_INVALID_ARGS;
+    f->head.proj.w = f->embed.w, f->head.proj.nOut = f->embed.w->ne[0], f->head.proj.nIn = f->embed.w->ne[1];
+    return KF_OK;
+}
+// slot: 0 input_layernorm, 1 post_attention_layernorm, 2 q_norm, 3 k_norm; layer = -1: final norm.  bf16 [n]
+int kfh_set_norm(void* h, int layer, int slot, const void* w, int n, int is_device) {
+    Fish* f = reinterpret_cast<Fish*>(h);
+    auto t = std::make_shared<GTensor>();
+    t->type = typNUMBER::BF16, t->ne[0] = n, t->szData = (size_t)n * 2;
+    if (is_device) {
+        t->data = const_cast<void*>(w), t->ctx = f->ctx;
+    } else {
+        int rc = t->LoadBlob(f->ctx, w, (size_t)n * 2);
+        if (rc != KF_OK) return rc;
+    }
+    if (layer < 0) {
+        f->final_norm.w = t;
+        return KF_OK;
+    }
+    if (layer >= f->config.nLayer) return KF_INVALID_ARGS;
+    SelfAttention* a = f->attn[layer].get();
+    switch (slot) {
+        case 0: a->norm.w = t; break;
+        case 1: f->ffn[layer]->norm.w = t; break;
+        case 2: a->normQ.w = t; break;
+        case 3: a->normK.w = t; break;
+        default: return KF_INVALID_ARGS;
+    }
+    return KF_OK;
+}
+
+// one eager step; logits (bf16[vocab]) and hidden copied to host when non-null; returns the greedy id or < 0
+int kfh_forward(void* h, int token, int pos, uint16_t* h_logits) {
+    Fish* f = reinterpret_cast<Fish*>(h);
+    int rc = f->ForwardOnRLS(token, pos);
+    if (rc != KF_OK) return rc;
+    int32_t st[4];
+    rc = kf_d2h(f->ctx, st, f->d_state, 16);
+    if (rc != KF_OK) return rc;
+    if (h_logits) {
+        rc = kf_d2h(f->ctx, h_logits, f->head.preLogits->data, (size_t)f->config.vocab * 2);
+        if (rc != KF_OK) return rc;
+    }
+    return f->fuse_level == 0 ? st[2] : st[0];
+}
+int kfh_generate(void* h, const int* prompt, int n_prompt, int n_new, int* out, int use_graph) {
+    return reinterpret_cast<Fish*>(h)->Generate(prompt, n_prompt, n_new, out, use_graph != 0);
+}
+int kfh_set_forced(void* h, const int32_t* forced, int n) {
+    Fish* f = reinterpret_cast<Fish*>(h);
+    if (n > f->config.n_ctx) return KF_INVALID_ARGS;
+    return kf_h2d(f->ctx, f->d_forced, forced, (size_t)n * 4);
+}
+int kfh_set_state(void* h, int token, int pos) { return reinterpret_cast<Fish*>(h)->SetState(token, pos); }
+int kfh_run_steps(void* h, int pos, int n, int use_graph) { return reinterpret_cast<Fish*>(h)->RunSteps(pos, n, use_graph != 0); }
+int kfh_sync(void* h) { return kf_sync(reinterpret_cast<Fish*>(h)->ctx); }
+int kfh_get_tokens(void* h, int32_t* out, int n) {
+    Fish* f = reinterpret_cast<Fish*>(h);
+    return kf_d2h(f->ctx, out, f->d_tokens_out, (size_t)n * 4);
+}
+void* kfh_kcache(void* h) { return reinterpret_cast<Fish*>(h)->cache.key->data; }
+void* kfh_vcache(void* h) { return reinterpret_cast<Fish*>(h)->cache.val->data; }
+void* kfh_logits(void* h) { return reinterpret_cast<Fish*>(h)->head.preLogits->data; }
+void* kfh_hidden(void* h) { return reinterpret_cast<Fish*>(h)->x->data; }
+int kfh_num_graphs(void* h) {
+    int n = 0;
+    for (auto g : reinterpret_cast<Fish*>(h)->graphs) n += g != nullptr;
+    return n;
+}
+}

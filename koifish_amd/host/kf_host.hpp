@@ -1,0 +1,188 @@
+// kf_host.hpp -- host side of the decode path, ABOVE the C ABI (include/kf_abi.h): a C++ mirror of the
+// reference's neuron / tensor interface for this path.  Class and method names, argument meaning and error
+// behaviour follow gruai/koifish so that a maintainer can read one against the other:
+//   GTensor            src/Tensor/GTensor.hpp:168-490        (data||gama blob, type, ne[], quant card)
+//   KVCache            src/Utils/Cache.{hpp,cpp}:14-57       ([n_layer, max_seq, kv_dim] bf16 pair)
+//   LayerNormal::cuFlow src/Manifold/Neuron.hpp:438-458, src/Device/CUDA/T.cu:561-573
+//   SLP::Forw          src/Manifold/Neuron.hpp:397-430, src/Device/CUDA/NeuronFuse.cu:305-381
+//   ROPE::cuInfer      src/Device/CUDA/kernel/rope.cu:645-672
+//   SelfAttention::cuInfer / _devQKV   src/Device/CUDA/QKV.cu:617-702, src/Manifold/TGraph.cpp:198-207
+//   FFN::cuInfer       src/Device/CUDA/NeuronFuse.cu:615-656
+//   TokenEmbed::cuInfer src/Device/CUDA/NeuronFuse.cu:176-218
+//   Head4Token::cuInfer_1 src/Device/CUDA/NeuronFuse.cu:842-862
+//   Fish::ForwardOnRLS / Chat  src/Manifold/gLLM.cpp:722-787, src/Manifold/GoPT.cpp:1111-1235
+// No HIP headers here: device memory and launches go through the kf_* C ABI only (plain g++ builds this file).
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/kf_abi.h"
+
+namespace koifish {
+
+using floatX = kf_bf16;
+enum class typNUMBER : uint8_t { F32 = 0, F64, F16, BF16, F8E5M2, F8E4M3, U8, I8, U16, I16, U32, I32, U64, I64, Q4, Q3, Q2, T_SIGN, T_SEQ, BOOL1, T_BINARY };
+
+struct Fish;
+
+// Quant card fields that cross the kernel seam (QUANT_CARD / GeQuant, GeQuant.cpp:107-124)
+struct QuantCard {
+    int bits = 16, T_group = 128, qMin = 0, qMax = 0, qBias = 0;
+};
+
+// A device tensor: `data||gama` in one allocation, as huTensor::Alloc lays it out (GTensor.cpp:456-510).
+struct GTensor {
+    std::string name;
+    void* data = nullptr;
+    size_t szData = 0, szGama = 0;
+    typNUMBER type = typNUMBER::BF16;
+    int ne[4] = {1, 1, 1, 1};
+    QuantCard quant;
+    bool owned = false;
+    kf_ctx* ctx = nullptr;
+
+    ~GTensor();
+    size_t size() const { return (size_t)ne[0] * ne[1] * ne[2] * ne[3]; }
+    int nGroup() const { return szGama ? (int)(size() / quant.T_group) : 0; }
+    floatX* gama_T() const { return szGama ? reinterpret_cast<floatX*>(reinterpret_cast<uint8_t*>(data) + szData) : nullptr; }
+    kf_weight desc() const;  // what TASKA_quant / TASKA_AxB hand to the kernels
+    // SerialGamaData H2D (huTensor.cu:413-458): allocate and copy a host `data||gama` blob
+    int LoadBlob(kf_ctx* c, const void* h_blob, size_t nbytes);
+    int Alloc(kf_ctx* c, size_t nbytes);
+};
+using hGTensor = std::shared_ptr<GTensor>;
+hGTensor GT(kf_ctx* c, const std::string& name, typNUMBER tp, int n0, int n1 = 1);
+inline floatX* ToX(const hGTensor& t) { return t ? reinterpret_cast<floatX*>(t->data) : nullptr; }
+
+struct KVCache {
+    enum CTYPE { KV_KEY = 0, KV_VAL };
+    hGTensor key, val;
+    int n_layer = 0, max_seq_len = 0, kv_dim = 0;
+    int Init(kf_ctx* c, int n_layer, int max_seq, int kv_dim);
+    void* Get(CTYPE type, int layer, int pos) const;  // Cache.cpp:42-57
+};
+
+struct GeNeuron {
+    std::string name;
+    Fish* hFish = nullptr;
+    int layid = 0;  // 1-based like the reference (hCache->Get(.., layid - 1, 0))
+    virtual ~GeNeuron() {}
+};
+
+struct LayerNormal : GeNeuron {
+    hGTensor w, out;
+    float rms_eps = 1e-6f;
+    int nHead = 0, ldTH = 0;
+    hGTensor cuFlow(hGTensor inpDelta, int flag = 0);
+};
+
+struct Relu : GeNeuron {
+    int Forw(hGTensor out, hGTensor gate, hGTensor inp, int flag = 0);  // CU_swiglu_v0
+};
+
+struct SLP : GeNeuron {
+    hGTensor w, b, out;
+    int nIn = 0, nOut = 0;
+    bool Empty() const { return !w; }
+    // rhs = W.lhs (+b);  returns 0 or -1 like the reference (NeuronFuse.cu:305-381)
+    int Forw(hGTensor rhs, hGTensor lhs, hGTensor toGelu = nullptr, Relu* hRelu = nullptr, int flag = 0);
+    int Forw(floatX* rhs, const floatX* lhs, uint32_t epilogue = 0, const floatX* residual = nullptr);
+};
+
+struct SelfAttention;
+struct ROPE : GeNeuron {
+    LayerNormal *hnQ = nullptr, *hnK = nullptr;
+    int n_head = 0, n_head_kv = 0, head_dim = 0;
+    float theta = 1e6f;
+    hGTensor cuInfer(SelfAttention* hQKV, uint32_t seed, int pos, int flag = 0);
+};
+
+struct SelfAttention : GeNeuron {
+    LayerNormal norm, normQ, normK;
+    SLP Q, K, V, proj_cat;
+    ROPE rope;
+    KVCache* hCache = nullptr;
+    hGTensor out;
+    int n_head = 0, n_head_kv = 0, head_dim = 0, q_dim = 0, kv_dim = 0;
+    bool isSeparateQKV = true;
+    void _devQKV(int pos);  // K.out / V.out alias the KV-cache row (TGraph.cpp:198-207)
+    hGTensor cuInfer(hGTensor inpL, int flag = 0);
+};
+
+struct FFN : GeNeuron {
+    LayerNormal norm;
+    SLP gate, up, down;
+    Relu relu;
+    hGTensor out;
+    int latent = 0;
+    hGTensor cuInfer(hGTensor hIn, int flag = 0);
+};
+
+struct TokenEmbed : GeNeuron {
+    hGTensor w, out;
+    hGTensor cuInfer(int token, int flag = 0);
+};
+
+struct Head4Token : GeNeuron {
+    SLP proj;
+    hGTensor preLogits;
+    hGTensor cuInfer_1(hGTensor inp_, int flag = 0);
+};
+
+struct MODEL_CARD {  // the fields of CLI_params / MODEL_CARD this path reads (CLI_params.hpp, cases/qwen3/*.json)
+    int nEmbed = 0, nLayer = 0, n_head = 0, n_head_kv = 0, head_dim = 0, n_ff = 0, vocab = 0, n_ctx = 0;
+    float rms_eps = 1e-6f, qk_eps = 1e-6f, rope_theta = 1e6f;
+    bool tie_word_embeddings = true;
+};
+
+// Shared scratch, named after GST_MemBuffer's gBUFF members (GST_MemBuffer.hpp:46-48)
+struct MemBuffer {
+    hGTensor tmpFF1;    // Q.out
+    hGTensor kraw;      // new key before norm/rope (fused path)
+    hGTensor scratch;   // proj_cat out / gate-act
+    hGTensor delta;     // down out
+    hGTensor upOut;     // up out (unfused path)
+    hGTensor normed;    // norm.out
+    hGTensor attn_ws;   // split-KV partials
+    hGTensor head_ws;   // arg-max partials
+    hGTensor residual;  // alias, not owned
+};
+
+struct Fish {
+    MODEL_CARD config;
+    kf_ctx* ctx = nullptr;
+    int fuse_level = 1;  // 0: one launch per reference kernel; 1: fused launches
+    KVCache cache;
+    MemBuffer gBUFF;
+    TokenEmbed embed;
+    std::vector<std::unique_ptr<SelfAttention>> attn;
+    std::vector<std::unique_ptr<FFN>> ffn;
+    LayerNormal final_norm;
+    Head4Token head;
+    float* rope_table = nullptr;  // device [n_ctx][hd/2][2]
+    int32_t* d_state = nullptr;   // {token, pos, 0, 0}
+    int32_t* d_forced = nullptr;  // [n_ctx] teacher-forced ids, -1 = free running
+    int32_t* d_tokens_out = nullptr;  // [n_ctx] greedy id produced at each position
+    int tok_pos = 0;              // hBatch->tok_pos
+    bool graph_mode = false;      // launches take position/token from d_state
+    std::vector<kf_graph*> graphs;  // one per position bucket
+    std::vector<int> graph_bound;
+    hGTensor x;                   // residual stream
+
+    ~Fish();
+    int Build(const MODEL_CARD& card, int device, void* stream);
+    int pos_bound() const;  // launch-geometry bound for the current bucket
+    // one token through every neuron (Fish::ForwardOnRLS, gLLM.cpp:722-787)
+    int ForwardOnRLS(int token, int pos);
+    int EnqueueStep(int bound);  // the launch sequence of one step, positions/tokens from d_state
+    kf_graph* GraphFor(int pos);
+    int SetState(int token, int pos);
+    // token-serial prefill then greedy decode (Fish::Chat, GoPT.cpp:1139-1159); ids of the new tokens to out
+    int Generate(const int* prompt, int n_prompt, int n_new, int* out, bool use_graph);
+    // replay n decode steps starting at `pos` with whatever d_forced holds (bench / long runs); no host sync
+    int RunSteps(int pos, int n, bool use_graph);
+};
+
+}  // namespace koifish

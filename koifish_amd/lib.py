@@ -1,0 +1,102 @@
+"""ctypes loader for libkf_hip.so / libkf_host.so (built in-tree by koifish_amd/build.py)."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_HIP = os.path.join(HERE, "libkf_hip.so")
+LIB_HOST = os.path.join(HERE, "libkf_host.so")
+
+# typNUMBER (src/g_float.hpp:84-117)
+F32, F64, F16, BF16, F8E5M2, F8E4M3, U8, I8, U16, I16, U32, I32, U64, I64, Q4, Q3, Q2, T_SIGN, T_SEQ, BOOL1, T_BINARY, T_BINARY_3, T_BINARY_TILE = range(23)
+BITS = {BF16: 16, F8E5M2: 8, Q4: 4, T_SIGN: 2, BOOL1: 1, T_BINARY: 1}
+KF_EPI_RESIDUAL = 1
+
+# every symbol include/kf_abi.h declares (tests/test_abi_symbols.py checks the header against this list and the .so)
+ABI_SYMBOLS = [
+    "kf_init", "kf_destroy", "kf_sync", "kf_last_error", "kf_version", "kf_malloc", "kf_free", "kf_memset", "kf_h2d", "kf_d2h", "kf_d2d",
+    "kf_graph_begin", "kf_graph_end", "kf_graph_launch", "kf_graph_destroy", "kf_event_create", "kf_event_record", "kf_event_elapsed_ms",
+    "kf_event_destroy", "kf_dequant", "kf_quantize", "kf_linear", "kf_rmsnorm", "kf_qknorm_rope", "kf_rope_table_host", "kf_attn_decode",
+    "kf_attn_scratch_bytes", "kf_swiglu", "kf_add", "kf_embed", "kf_lm_head", "kf_head_scratch_bytes", "kf_norm_linear",
+    "kf_norm_gateup_swiglu", "kf_attn_block", "kf_norm_lm_head", "kf_set_state", "kf_embed_state",
+]
+
+
+class KFError(RuntimeError):
+    pass
+
+
+class Weight(C.Structure):
+    """struct kf_weight (include/kf_abi.h)"""
+    _fields_ = [("data", C.c_void_p), ("gama", C.c_void_p), ("type", C.c_int32), ("ne0", C.c_int32), ("ne1", C.c_int32), ("nGroup", C.c_int32),
+                ("lGroup", C.c_int32), ("qMin", C.c_int32), ("qMax", C.c_int32), ("qBias", C.c_int32)]
+
+
+_libs = None
+
+
+def load():
+    """Returns (hip, host) CDLLs.  No fallback: a missing library is an error the caller must see."""
+    global _libs
+    if _libs is None:
+        for p in (LIB_HIP, LIB_HOST):
+            if not os.path.exists(p):
+                raise KFError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+                              "koifish_amd has no CPU fallback." % p)
+        hip = C.CDLL(LIB_HIP, mode=C.RTLD_GLOBAL)
+        host = C.CDLL(LIB_HOST)
+        hip.kf_last_error.restype = C.c_char_p
+        hip.kf_version.restype = C.c_char_p
+        hip.kf_attn_scratch_bytes.restype = C.c_size_t
+        hip.kf_head_scratch_bytes.restype = C.c_size_t
+        hip.kf_linear.argtypes = [C.c_void_p, C.POINTER(Weight), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_void_p]
+        hip.kf_rmsnorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]
+        hip.kf_qknorm_rope.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float]
+        hip.kf_rope_table_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float]
+        hip.kf_attn_decode.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        hip.kf_attn_block.argtypes = [C.c_void_p] * 9 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
+        hip.kf_norm_linear.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        hip.kf_norm_gateup_swiglu.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.POINTER(Weight), C.POINTER(Weight), C.c_void_p]
+        hip.kf_norm_lm_head.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.POINTER(Weight), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        hip.kf_lm_head.argtypes = [C.c_void_p, C.POINTER(Weight), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        hip.kf_embed.argtypes = [C.c_void_p, C.POINTER(Weight), C.c_int, C.c_void_p, C.c_void_p]
+        hip.kf_swiglu.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        hip.kf_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        hip.kf_dequant.argtypes = [C.c_void_p, C.POINTER(Weight), C.c_void_p]
+        hip.kf_quantize.argtypes = [C.c_void_p, C.POINTER(Weight), C.c_void_p, C.c_int]
+        hip.kf_init.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        hip.kf_destroy.argtypes = [C.c_void_p]
+        hip.kf_sync.argtypes = [C.c_void_p]
+        hip.kf_event_create.argtypes = [C.POINTER(C.c_void_p)]
+        hip.kf_event_record.argtypes = [C.c_void_p, C.c_void_p]
+        hip.kf_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+        hip.kf_event_destroy.argtypes = [C.c_void_p]
+        host.kfh_create.restype = C.c_void_p
+        host.kfh_create.argtypes = [C.c_int, C.c_void_p] + [C.c_int] * 8 + [C.c_float] * 3 + [C.POINTER(C.c_int)]
+        host.kfh_destroy.argtypes = [C.c_void_p]
+        host.kfh_ctx.restype = C.c_void_p
+        host.kfh_ctx.argtypes = [C.c_void_p]
+        host.kfh_set_fuse_level.argtypes = [C.c_void_p, C.c_int]
+        host.kfh_set_weight.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_int]
+        host.kfh_tie_head.argtypes = [C.c_void_p]
+        host.kfh_set_norm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        host.kfh_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        host.kfh_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        host.kfh_set_forced.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        host.kfh_set_state.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        host.kfh_run_steps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        host.kfh_sync.argtypes = [C.c_void_p]
+        host.kfh_get_tokens.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        for f in ("kfh_kcache", "kfh_vcache", "kfh_logits", "kfh_hidden"):
+            getattr(host, f).restype = C.c_void_p
+            getattr(host, f).argtypes = [C.c_void_p]
+        host.kfh_num_graphs.argtypes = [C.c_void_p]
+        _libs = (hip, host)
+    return _libs
+
+
+def check(rc, what=""):
+    if rc != 0:
+        hip, _ = load()
+        raise KFError("%s failed: code %d: %s" % (what, rc, hip.kf_last_error().decode()))
+    return rc

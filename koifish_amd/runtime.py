@@ -1,0 +1,330 @@
+"""Python plumbing over the C ABI: device memory comes from torch tensors, every computation is a kf_* / kfh_* call.
+
+Nothing here computes on the CPU and nothing imports oracle/.  bf16 tensors are torch.bfloat16 on the GPU;
+packed weights are torch.uint8 blobs laid out `data || gama` exactly as the reference allocates them
+(GTensor.cpp:456-510).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+SLOTS = ("q", "k", "v", "o", "gate", "up", "down")
+NORMS = ("norm_in", "norm_post", "qn", "kn")
+
+
+def quant_range(type_, symmetric=False):
+    """qMin, qMax, qBias as the GeQuant ctor sets them (GeQuant.cpp:107-124)."""
+    if type_ == L.T_SIGN:
+        return -1, 1, 1
+    if type_ in (L.BOOL1, L.T_BINARY):
+        return 0, 1, 0
+    if type_ == L.Q4:
+        return (-8, 7, 8) if symmetric else (0, 15, 0)
+    return 0, 0, 0
+
+
+class DevWeight:
+    """A weight resident in HBM: blob = torch.uint8 [szData + szGama]."""
+
+    def __init__(self, type_, ne0, ne1, blob, lGroup=128, symmetric=False):
+        self.type, self.ne0, self.ne1, self.blob, self.lGroup = type_, ne0, ne1, blob, lGroup
+        bits = L.BITS[type_]
+        self.szData = ne0 * ne1 * bits // 8
+        self.quantised = bits < 8
+        self.nGroup = ne0 * ne1 // lGroup if self.quantised else 0
+        self.szGama = (ne0 + ne1 + 2 * self.nGroup) * 2 if self.quantised else 0
+        assert blob.numel() == self.szData + self.szGama, (blob.numel(), self.szData, self.szGama)
+        self.qMin, self.qMax, self.qBias = quant_range(type_, symmetric)
+
+    @staticmethod
+    def blob_bytes(type_, ne0, ne1, lGroup=128):
+        bits = L.BITS[type_]
+        n = ne0 * ne1 * bits // 8
+        if bits < 8:
+            n += (ne0 + ne1 + 2 * (ne0 * ne1 // lGroup)) * 2
+        return n
+
+    def desc(self):
+        p = self.blob.data_ptr()
+        return L.Weight(p, (p + self.szData) if self.quantised else None, self.type, self.ne0, self.ne1, self.nGroup, self.lGroup, self.qMin, self.qMax,
+                        self.qBias)
+
+    def algorithmic_bytes(self):
+        """what a mat-vec has to read: packed data + zero/step"""
+        return self.szData + 4 * self.nGroup
+
+    def zero_step(self):
+        g = self.blob[self.szData:].view(torch.bfloat16)
+        z0 = self.ne0 + self.ne1
+        return g[z0:z0 + self.nGroup], g[z0 + self.nGroup:z0 + 2 * self.nGroup]
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """kf_ctx bound to torch's current stream on `device`."""
+
+    def __init__(self, device=0):
+        self.hip, self.host = L.load()
+        if not torch.cuda.is_available():
+            raise L.KFError("no GPU visible: koifish_amd runs on MI355X only (no CPU fallback)")
+        torch.cuda.set_device(device)
+        self.device = torch.device("cuda", device)
+        self.h = C.c_void_p()
+        L.check(self.hip.kf_init(device, C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(self.h)), "kf_init")
+        self._attn_ws = None
+        self._head_ws = torch.empty(self.hip.kf_head_scratch_bytes(), dtype=torch.uint8, device=self.device)
+
+    def close(self):
+        if self.h:
+            self.hip.kf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        L.check(self.hip.kf_sync(self.h), "kf_sync")
+
+    # ---- weights
+    def upload_blob(self, type_, ne0, ne1, blob_np, lGroup=128, symmetric=False):
+        t = torch.from_numpy(np.ascontiguousarray(blob_np).view(np.uint8).reshape(-1).copy()).to(self.device)
+        return DevWeight(type_, ne0, ne1, t, lGroup, symmetric)
+
+    def quantize(self, w_bf16, type_, lGroup=128, symmetric=False):
+        """w_bf16: torch.bfloat16 [ne0, ne1] on the GPU -> DevWeight (kf_quantize: GeQuant::RTN_x / YinYang on device)."""
+        ne0, ne1 = w_bf16.shape
+        w_bf16 = w_bf16.contiguous()
+        if type_ == L.BF16:
+            return DevWeight(L.BF16, ne0, ne1, w_bf16.view(torch.uint8).reshape(-1))
+        if type_ == L.F8E5M2:
+            # Float2T<f8e5> (g_float.hpp:433-443): float -> half (RNE) -> keep the high byte
+            h = w_bf16.to(torch.float32).to(torch.float16).view(torch.int16)
+            b = ((h.to(torch.int32) >> 8) & 0xFF).to(torch.uint8)
+            return DevWeight(L.F8E5M2, ne0, ne1, b.reshape(-1).contiguous())
+        blob = torch.zeros(DevWeight.blob_bytes(type_, ne0, ne1, lGroup), dtype=torch.uint8, device=self.device)
+        dw = DevWeight(type_, ne0, ne1, blob, lGroup, symmetric)
+        g = blob[dw.szData:].view(torch.bfloat16)
+        g[:ne0 + ne1] = 1.0  # R_SCALE / C_SCALE (unused: rc_normal = 0)
+        d = dw.desc()
+        L.check(self.hip.kf_quantize(self.h, C.byref(d), _ptr(w_bf16), int(symmetric)), "kf_quantize")
+        return dw
+
+    # ---- operators (each one ABI call)
+    def dequant(self, w):
+        out = torch.empty(w.ne0, w.ne1, dtype=torch.bfloat16, device=self.device)
+        d = w.desc()
+        L.check(self.hip.kf_dequant(self.h, C.byref(d), _ptr(out)), "kf_dequant")
+        return out
+
+    def linear(self, w, x, bias=None, alpha=1.0, beta=0.0, residual=None, y=None):
+        y = torch.zeros(w.ne0, dtype=torch.bfloat16, device=self.device) if y is None else y
+        d = w.desc()
+        epi = L.KF_EPI_RESIDUAL if residual is not None else 0
+        L.check(self.hip.kf_linear(self.h, C.byref(d), _ptr(x), _ptr(y), _ptr(bias), 1, alpha, beta, epi, _ptr(residual)), "kf_linear")
+        return y
+
+    def rmsnorm(self, x, w, eps=1e-6):
+        y = torch.empty_like(x)
+        rows = 1 if x.dim() == 1 else x.shape[0]
+        L.check(self.hip.kf_rmsnorm(self.h, _ptr(x), _ptr(w), _ptr(y), rows, x.shape[-1], eps, None), "kf_rmsnorm")
+        return y
+
+    def rope_table(self, n_pos, hd, theta):
+        t = np.zeros((n_pos, hd // 2, 2), dtype=np.float32)
+        L.check(self.hip.kf_rope_table_host(t.ctypes.data_as(C.c_void_p), n_pos, hd, theta), "kf_rope_table_host")
+        return torch.from_numpy(t).to(self.device)
+
+    def qknorm_rope(self, q, k, wq, wk, table, pos, n_head, n_kv, hd, eps=1e-6):
+        """in place on q and k"""
+        L.check(self.hip.kf_qknorm_rope(self.h, _ptr(q), _ptr(k), _ptr(wq), _ptr(wk), _ptr(table), pos, None, n_head, n_kv, hd, eps), "kf_qknorm_rope")
+
+    def _ws(self, n_head, hd):
+        n = self.hip.kf_attn_scratch_bytes(n_head, hd)
+        if self._attn_ws is None or self._attn_ws.numel() < n:
+            self._attn_ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+        return self._attn_ws
+
+    def attn_decode(self, q, kc, vc, pos, n_head, n_kv, hd, kv_stride=None):
+        out = torch.empty(n_head * hd, dtype=torch.bfloat16, device=self.device)
+        L.check(self.hip.kf_attn_decode(self.h, _ptr(q), _ptr(kc), _ptr(vc), _ptr(out), pos, None, n_head, n_kv, hd, kv_stride or n_kv * hd,
+                                        _ptr(self._ws(n_head, hd))), "kf_attn_decode")
+        return out
+
+    def attn_block(self, q_raw, k_raw, kc, vc, wq, wk, table, pos, n_head, n_kv, hd, eps=1e-6, kv_stride=None):
+        out = torch.empty(n_head * hd, dtype=torch.bfloat16, device=self.device)
+        L.check(self.hip.kf_attn_block(self.h, _ptr(q_raw), _ptr(k_raw), _ptr(kc), _ptr(vc), _ptr(out), _ptr(wq), _ptr(wk), _ptr(table), pos, None, n_head,
+                                       n_kv, hd, kv_stride or n_kv * hd, eps, _ptr(self._ws(n_head, hd))), "kf_attn_block")
+        return out
+
+    def swiglu(self, gate, up):
+        out = torch.empty_like(gate)
+        L.check(self.hip.kf_swiglu(self.h, _ptr(gate), _ptr(up), _ptr(out), gate.numel()), "kf_swiglu")
+        return out
+
+    def add(self, a, b):
+        out = torch.empty_like(a)
+        L.check(self.hip.kf_add(self.h, _ptr(a), _ptr(b), _ptr(out), a.numel()), "kf_add")
+        return out
+
+    def embed(self, w, token):
+        out = torch.empty(w.ne1, dtype=torch.bfloat16, device=self.device)
+        d = w.desc()
+        L.check(self.hip.kf_embed(self.h, C.byref(d), int(token), None, _ptr(out)), "kf_embed")
+        return out
+
+    def lm_head(self, w, x):
+        logits = torch.empty(w.ne0, dtype=torch.bfloat16, device=self.device)
+        am = torch.zeros(1, dtype=torch.int32, device=self.device)
+        d = w.desc()
+        L.check(self.hip.kf_lm_head(self.h, C.byref(d), _ptr(x), _ptr(logits), _ptr(am), _ptr(self._head_ws)), "kf_lm_head")
+        return logits, int(am.item())
+
+    def norm_linear(self, x, norm_w, ws, eps=1e-6):
+        ys = [torch.zeros(w.ne0, dtype=torch.bfloat16, device=self.device) for w in ws]
+        descs = [w.desc() for w in ws]
+        wp = (C.c_void_p * len(ws))(*[C.addressof(d) for d in descs])
+        yp = (C.c_void_p * len(ws))(*[y.data_ptr() for y in ys])
+        L.check(self.hip.kf_norm_linear(self.h, _ptr(x), _ptr(norm_w), eps, len(ws), wp, yp, None, 0, None), "kf_norm_linear")
+        return ys
+
+    def norm_gateup_swiglu(self, x, norm_w, gate, up, eps=1e-6):
+        act = torch.zeros(gate.ne0, dtype=torch.bfloat16, device=self.device)
+        dg, du = gate.desc(), up.desc()
+        L.check(self.hip.kf_norm_gateup_swiglu(self.h, _ptr(x), _ptr(norm_w), eps, C.byref(dg), C.byref(du), _ptr(act)), "kf_norm_gateup_swiglu")
+        return act
+
+    # ---- HIP events on the ctx stream
+    def event(self):
+        e = C.c_void_p()
+        L.check(self.hip.kf_event_create(C.byref(e)), "kf_event_create")
+        return e
+
+    def record(self, e):
+        L.check(self.hip.kf_event_record(self.h, e), "kf_event_record")
+
+    def elapsed_ms(self, a, b):
+        ms = C.c_float()
+        L.check(self.hip.kf_event_elapsed_ms(a, b, C.byref(ms)), "kf_event_elapsed_ms")
+        return ms.value
+
+
+class Qwen3:
+    """The host-side Fish (koifish_amd/host/kf_host.cpp) for a Qwen3-shaped decoder."""
+
+    def __init__(self, cfg, device=0):
+        self.hip, self.host = L.load()
+        if not torch.cuda.is_available():
+            raise L.KFError("no GPU visible: koifish_amd runs on MI355X only (no CPU fallback)")
+        torch.cuda.set_device(device)
+        self.cfg, self.device = dict(cfg), torch.device("cuda", device)
+        rc = C.c_int(0)
+        self.h = self.host.kfh_create(device, C.c_void_p(torch.cuda.current_stream().cuda_stream), cfg["dim"], cfg["n_layer"], cfg["n_head"], cfg["n_kv"],
+                                      cfg["head_dim"], cfg["ffn"], cfg["vocab"], cfg["max_seq"], cfg.get("rms_eps", 1e-6), cfg.get("qk_eps", 1e-6),
+                                      cfg.get("theta", 1e6), C.byref(rc))
+        if not self.h:
+            L.check(rc.value or -1, "kfh_create")
+        self.h = C.c_void_p(self.h)
+        self._keep = []
+        self.weights = {}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.host.kfh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_weight(self, layer, slot, w):
+        """w: DevWeight (already in HBM)."""
+        self._keep.append(w)
+        self.weights[(layer, slot)] = w
+        L.check(self.host.kfh_set_weight(self.h, layer, slot, w.type, w.ne0, w.ne1, C.c_void_p(w.blob.data_ptr()), w.blob.numel(), w.szData, 1, w.lGroup,
+                                         w.qMin, w.qMax, w.qBias), "kfh_set_weight")
+
+    def tie_head(self):
+        L.check(self.host.kfh_tie_head(self.h), "kfh_tie_head")
+        self.weights[(-1, 1)] = self.weights[(-1, 0)]
+
+    def set_norm(self, layer, slot, w_bf16):
+        w_bf16 = w_bf16.contiguous()
+        self._keep.append(w_bf16)
+        L.check(self.host.kfh_set_norm(self.h, layer, slot, C.c_void_p(w_bf16.data_ptr()), w_bf16.numel(), 1), "kfh_set_norm")
+
+    def set_fuse_level(self, lvl):
+        self.host.kfh_set_fuse_level(self.h, lvl)
+
+    def forward(self, token, pos, want_logits=True):
+        logits = np.zeros(self.cfg["vocab"], dtype=np.uint16) if want_logits else None
+        r = self.host.kfh_forward(self.h, int(token), int(pos), None if logits is None else logits.ctypes.data_as(C.c_void_p))
+        if r < 0:
+            L.check(r, "kfh_forward")
+        return r, logits
+
+    def generate(self, prompt, n_new, use_graph=True):
+        p = np.ascontiguousarray(prompt, dtype=np.int32)
+        out = np.zeros(n_new, dtype=np.int32)
+        L.check(self.host.kfh_generate(self.h, p.ctypes.data_as(C.c_void_p), p.size, n_new, out.ctypes.data_as(C.c_void_p), int(use_graph)), "kfh_generate")
+        return out.tolist()
+
+    def set_forced(self, ids):
+        a = np.ascontiguousarray(ids, dtype=np.int32)
+        L.check(self.host.kfh_set_forced(self.h, a.ctypes.data_as(C.c_void_p), a.size), "kfh_set_forced")
+
+    def set_state(self, token, pos):
+        L.check(self.host.kfh_set_state(self.h, int(token), int(pos)), "kfh_set_state")
+
+    def run_steps(self, pos, n, use_graph=True):
+        L.check(self.host.kfh_run_steps(self.h, int(pos), int(n), int(use_graph)), "kfh_run_steps")
+
+    def sync(self):
+        L.check(self.host.kfh_sync(self.h), "kfh_sync")
+
+    def tokens_out(self, n):
+        out = np.zeros(n, dtype=np.int32)
+        L.check(self.host.kfh_get_tokens(self.h, out.ctypes.data_as(C.c_void_p), n), "kfh_get_tokens")
+        return out
+
+    def kv_to_host(self):
+        """KV cache copied to host as uint16 arrays [n_layer, max_seq, kv_dim]."""
+        c = self.cfg
+        kvd = c["n_kv"] * c["head_dim"]
+        n = c["n_layer"] * c["max_seq"] * kvd
+        k = np.zeros(n, dtype=np.uint16)
+        v = np.zeros(n, dtype=np.uint16)
+        ctx = C.c_void_p(self.host.kfh_ctx(self.h))
+        L.check(self.hip.kf_d2h(ctx, k.ctypes.data_as(C.c_void_p), C.c_void_p(self.host.kfh_kcache(self.h)), C.c_size_t(n * 2)), "kf_d2h")
+        L.check(self.hip.kf_d2h(ctx, v.ctypes.data_as(C.c_void_p), C.c_void_p(self.host.kfh_vcache(self.h)), C.c_size_t(n * 2)), "kf_d2h")
+        shp = (c["n_layer"], c["max_seq"], kvd)
+        return k.reshape(shp), v.reshape(shp)
+
+    def num_graphs(self):
+        return self.host.kfh_num_graphs(self.h)
+
+    def step_bytes(self, pos):
+        """Algorithmic HBM bytes of one decode step at position `pos`: every weight's packed data +
+        zero/step once, the norm vectors, and the KV rows 0..pos read once plus the new row written."""
+        c = self.cfg
+        kvd = c["n_kv"] * c["head_dim"]
+        wb = 0
+        for (layer, slot), w in self.weights.items():
+            if layer == -1 and slot == 0:
+                continue  # embedding: one row
+            wb += w.algorithmic_bytes()
+        emb = self.weights[(-1, 0)]
+        wb += emb.algorithmic_bytes() // emb.ne0
+        norms = (c["n_layer"] * (2 * c["dim"] + 2 * c["head_dim"]) + c["dim"]) * 2
+        kv = 2 * c["n_layer"] * (pos + 1) * kvd * 2 + 2 * c["n_layer"] * kvd * 2
+        return wb + norms + kv

@@ -1,0 +1,729 @@
+/*
+ * oracle/kf_oracle.c -- CPU restatement ("oracle") of Koifish's quantized transformer forward path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may load this library, and only as the checker / reported baseline.  The product path
+ * (koifish_amd/) never calls into oracle/ and fails loudly when its HIP library is missing.
+ *
+ * PARITY PINNING.  The reference ships no runnable CPU forward (DeepSeek.cpp:160-209 is a stub,
+ * Generate.cu:351-353 commented out) and its sources do not compile here (g_float.hpp:210-243
+ * hard-includes CUDA headers; no nvcc) -- see SURVEY.md section 8c.  What the reference's own tree
+ * pins, and this oracle is checked against in tests/test_oracle_layout.py:
+ *   - the PACK_/UNPACK_ macro bit positions of src/PackedQ.hpp:99-239 (restated below AND,
+ *     independently, in numpy in tests/ -- the two must agree on random and on hand-built blocks),
+ *   - BIT_SET_k/BIT_GET_k (src/Utils/CLI_params.cpp:2177-2207),
+ *   - NF4/NF3 tables (src/g_float.hpp:542-569), AWQ nibble order (kernel/packedN.cuh:109-116).
+ * For the mat-vec / attention ARITHMETIC the reference holds no golden vector, fixture or
+ * known-answer test (cases/test_lite.py needs real weights + CUDA): **parity unpinned** there.
+ * Those functions follow the cited CUDA kernels line by line with every bf16 store made
+ * round-to-nearest-even, and are cross-checked against an independent numpy restatement and (model
+ * semantics only) HF transformers' Qwen3 at tiny random shapes (tests/golden/make_golden.py).
+ *
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off -fopenmp; contraction must stay off so that
+ * mul+add pairs written below stay two roundings, as _mm256_add_ps(_mm256_mul_ps()) does in
+ * src/Utils/GST_float.cpp:75-101).
+ */
+#include "kfo_math.h"
+
+#include <float.h>
+#include <stdio.h>
+#include <stdlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define KFO_API __attribute__((visibility("default")))
+
+/* typNUMBER values restated from the NUMBER_DISPATCH order, src/g_float.hpp:84-117 */
+enum {
+    KFO_F32 = 0, KFO_F64, KFO_F16, KFO_BF16, KFO_F8E5M2, KFO_F8E4M3, KFO_U8, KFO_I8, KFO_U16, KFO_I16,
+    KFO_U32, KFO_I32, KFO_U64, KFO_I64, KFO_Q4, KFO_Q3, KFO_Q2, KFO_T_SIGN, KFO_T_SEQ, KFO_BOOL1,
+    KFO_T_BINARY, KFO_T_BINARY_3, KFO_T_BINARY_TILE
+};
+
+/* ------------------------------------------------------------------------------------------------
+ * 1. Packed128 bit layout -- src/PackedQ.hpp:28-60 (struct{u64 low; u64 high;}), little-endian host.
+ *    bytes 0..7 = low, bytes 8..15 = high.
+ * ---------------------------------------------------------------------------------------------- */
+static inline void put_u64(uint8_t* p, uint64_t v) { memcpy(p, &v, 8); }
+static inline uint64_t get_u64(const uint8_t* p) {
+    uint64_t v;
+    memcpy(&v, p, 8);
+    return v;
+}
+
+/* PACK_4to128_ (PackedQ.hpp:99-141): arr[0..15] -> high, MSB-first; arr[16..31] -> low */
+KFO_API void kfo_pack4_128(const int32_t* q, uint8_t* dst) {
+    uint64_t high = 0, low = 0;
+    for (int i = 0; i < 16; i++) {
+        high |= (uint64_t)(q[i] & 0x0F) << (60 - 4 * i);
+        low |= (uint64_t)(q[i + 16] & 0x0F) << (60 - 4 * i);
+    }
+    put_u64(dst, low);
+    put_u64(dst + 8, high);
+}
+/* UNPACK_128to4_UNSIGNED_ (PackedQ.hpp:143-183) */
+KFO_API void kfo_unpack4_128(const uint8_t* src, int32_t* q) {
+    uint64_t low = get_u64(src), high = get_u64(src + 8);
+    for (int i = 0; i < 16; i++) {
+        q[i]      = (int32_t)((high >> (60 - 4 * i)) & 0x0F);
+        q[i + 16] = (int32_t)((low >> (60 - 4 * i)) & 0x0F);
+    }
+}
+/* PACK_2to128_ (PackedQ.hpp:185-198) */
+KFO_API void kfo_pack2_128(const int32_t* q, uint8_t* dst) {
+    uint64_t high = 0, low = 0;
+    for (int i = 0; i < 32; i++) {
+        high |= (uint64_t)(q[i] & 0x3) << (62 - 2 * i);
+        low |= (uint64_t)(q[i + 32] & 0x3) << (62 - 2 * i);
+    }
+    put_u64(dst, low);
+    put_u64(dst + 8, high);
+}
+/* UNPACK_128to2_UNSIGNED_ (PackedQ.hpp:214-226) */
+KFO_API void kfo_unpack2_128(const uint8_t* src, int32_t* q) {
+    uint64_t low = get_u64(src), high = get_u64(src + 8);
+    for (int i = 0; i < 32; i++) {
+        q[i]      = (int32_t)((high >> (62 - 2 * i)) & 0x3);
+        q[i + 32] = (int32_t)((low >> (62 - 2 * i)) & 0x3);
+    }
+}
+/* PACK_1to128_ (PackedQ.hpp:200-212) */
+KFO_API void kfo_pack1_128(const int32_t* q, uint8_t* dst) {
+    uint64_t high = 0, low = 0;
+    for (int i = 0; i < 64; i++) {
+        high |= (uint64_t)(q[i] & 0x1) << (63 - i);
+        low |= (uint64_t)(q[i + 64] & 0x1) << (63 - i);
+    }
+    put_u64(dst, low);
+    put_u64(dst + 8, high);
+}
+/* UNPACK_128to1_UNSIGNED_ (PackedQ.hpp:227-239) */
+KFO_API void kfo_unpack1_128(const uint8_t* src, int32_t* q) {
+    uint64_t low = get_u64(src), high = get_u64(src + 8);
+    for (int i = 0; i < 64; i++) {
+        q[i]      = (int32_t)((high >> (63 - i)) & 0x1);
+        q[i + 64] = (int32_t)((low >> (63 - i)) & 0x1);
+    }
+}
+
+/* BIT_SET_k / BIT_GET_k (src/Utils/CLI_params.cpp:2177-2207): MSB-first bit stream; 2-bit values are
+ * stored biased by +1 */
+KFO_API void kfo_bit_set_k(uint8_t* array, size_t offset, int elem_, int bits) {
+    int elem = elem_;
+    if (bits == 2) elem = (uint8_t)(elem_ + 1);
+    size_t boff = offset * (size_t)bits;
+    for (int i = 0; i < bits; i++, boff++) {
+        size_t id = boff / 8, shift = 7 - boff % 8;
+        int bit = (elem >> (bits - 1 - i)) & 0x1;
+        if (bit)
+            array[id] |= (uint8_t)(1u << shift);
+        else
+            array[id] &= (uint8_t)~(1u << shift);
+    }
+}
+KFO_API int kfo_bit_get_k(const uint8_t* array, size_t offset, int bits) {
+    int elem = 0;
+    size_t boff = offset * (size_t)bits;
+    for (int i = 0; i < bits; i++, boff++) {
+        size_t id = boff / 8, shift = 7 - boff % 8;
+        if ((array[id] >> shift) & 0x1) elem |= 1 << (bits - 1 - i);
+    }
+    if (bits == 2) elem = (int8_t)(elem - 1);
+    return elem;
+}
+
+static void pack_block(int bits, const int32_t* q, uint8_t* dst) {
+    if (bits == 4)
+        kfo_pack4_128(q, dst);
+    else if (bits == 2)
+        kfo_pack2_128(q, dst);
+    else
+        kfo_pack1_128(q, dst);
+}
+static void unpack_block(int bits, const uint8_t* src, int32_t* q) {
+    if (bits == 4)
+        kfo_unpack4_128(src, q);
+    else if (bits == 2)
+        kfo_unpack2_128(src, q);
+    else
+        kfo_unpack1_128(src, q);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * 2. Quantiser -- GeQuant ctor (src/Tensor/GeQuant.cpp:107-124), RTN_x (:428-533), YinYang (:536-628)
+ * ---------------------------------------------------------------------------------------------- */
+/* yyang: 0 = I_OFF, else on.  Returns qMin/qMax/qBias exactly as the ctor sets them. */
+KFO_API void kfo_quant_range(int bits, int isSymmetric, int yyang, int* qMin, int* qMax, int* qBias) {
+    *qBias = 0;
+    if (yyang) {
+        if (bits == 2) {
+            *qMax = 1, *qMin = -1, *qBias = 1; /* ternary */
+        } else {
+            *qMax = 1, *qMin = 0, *qBias = 0; /* 1-bit {0,1} */
+        }
+    } else if (isSymmetric) {
+        *qMin = -(1 << (bits - 1));
+        *qMax = (1 << (bits - 1)) - 1;
+        *qBias = -*qMin;
+    } else {
+        *qMin = 0;
+        *qMax = (1 << bits) - 1;
+    }
+}
+
+/*
+ * RTN_x (GeQuant.cpp:428-533).  w: bf16 [nGroup*lGroup] (row-major flattened weight, groups of
+ * lGroup consecutive elements, GroupShapeOfT :375-404).  packed: nGroup*lGroup*bits/8 bytes.
+ * zero/step: bf16 per group (gamaZero[row] = zero is an implicit float->bf16, :474).
+ * yyang != 0 selects the "vMean" step of the RTN_x yyang branch (:463-465) -- the dedicated
+ * YinYang() below is what the 1-bit / ternary cards actually call.
+ * Returns err_2 = sqrt(mean((a - (step*q - zero))^2)) as the reference does (:518-530).
+ */
+KFO_API float kfo_rtn_x(const uint16_t* w, size_t nGroup, int lGroup, int bits, int isSymmetric, int yyang, uint8_t* packed,
+                        uint16_t* zero_out, uint16_t* step_out) {
+    int qMin, qMax, qBias;
+    kfo_quant_range(bits, isSymmetric, yyang, &qMin, &qMax, &qBias);
+    const int nPer128 = 128 / bits;
+    double err_2 = 0;
+#pragma omp parallel for schedule(static) reduction(+ : err_2)
+    for (long row = 0; row < (long)nGroup; row++) {
+        float vmax = -FLT_MAX, vmin = FLT_MAX, a;
+        double vSum = 0.0;
+        const uint16_t* dat = w + (size_t)row * lGroup;
+        for (int i = 0; i < lGroup; i++) {
+            a = kfo_bf16_to_f32(dat[i]); /* sR = sC = 1 (isSinkNormal=false, :441) */
+            vmax = fmaxf(vmax, a), vmin = fminf(vmin, a);
+            vSum += fabs(a);
+        }
+        float vMean = (float)(vSum / lGroup);
+        float step = (vmax - vmin) / (float)(qMax - qMin), zero = -vmin;
+        if (yyang) {
+            step = fmaxf(1e-5f, vMean);
+            zero = 0;
+        } else if (isSymmetric) {
+            step = fmaxf(fabsf(vmax), fabsf(vmin)) / (float)qMax, zero = 0;
+        }
+        zero_out[row] = kfo_f32_to_bf16(zero), step_out[row] = kfo_f32_to_bf16(step);
+        uint8_t* quanti = packed + (size_t)lGroup * row * bits / 8;
+        int32_t qq[128];
+        for (int i = 0; i < lGroup / nPer128; i++) {
+            for (int pos = 0; pos < nPer128; pos++) {
+                a = kfo_bf16_to_f32(dat[pos + i * nPer128]);
+                int qid = (int)roundf((a + zero) / step); /* std::round: half away from zero (:479) */
+                if (yyang) {
+                    qid = qid < qMin ? qMin : qid;
+                    qid = qid > qMax ? qMax : qid;
+                }
+                /* reference: assert(qid >= qMin && qid <= qMax) (:485) -- clamp instead of aborting so a
+                 * degenerate group cannot take the test process down; never taken on finite data */
+                if (qid < qMin) qid = qMin;
+                if (qid > qMax) qid = qMax;
+                qq[pos] = qid + qBias;
+                float e = a - (step * qid - zero);
+                err_2 += (double)e * e;
+            }
+            pack_block(bits, qq, quanti + 16 * i);
+        }
+    }
+    return (float)sqrt(err_2 / ((double)nGroup * lGroup));
+}
+
+/* YinYang (GeQuant.cpp:536-628): step = max(1e-5, sqrt(mean(relu(a)^2))), zero = 0 */
+KFO_API float kfo_yinyang(const uint16_t* w, size_t nGroup, int lGroup, int bits, uint8_t* packed, uint16_t* zero_out,
+                          uint16_t* step_out) {
+    int qMin, qMax, qBias;
+    kfo_quant_range(bits, 0, 1, &qMin, &qMax, &qBias);
+    const int nPer128 = 128 / bits;
+    double err_2 = 0;
+#pragma omp parallel for schedule(static) reduction(+ : err_2)
+    for (long row = 0; row < (long)nGroup; row++) {
+        float a;
+        double vSum = 0.0;
+        const uint16_t* dat = w + (size_t)row * lGroup;
+        for (int i = 0; i < lGroup; i++) {
+            a = kfo_bf16_to_f32(dat[i]);
+            vSum += a < 0.0 ? 0.0 : a * a; /* float product promoted to double, as the reference (:572) */
+        }
+        float vMean = (float)sqrt(vSum / lGroup);
+        float step = fmaxf(1e-5f, vMean), zero = 0;
+        zero_out[row] = kfo_f32_to_bf16(zero), step_out[row] = kfo_f32_to_bf16(step);
+        uint8_t* quanti = packed + (size_t)lGroup * row * bits / 8;
+        int32_t qq[128];
+        for (int i = 0; i < lGroup / nPer128; i++) {
+            for (int pos = 0; pos < nPer128; pos++) {
+                a = kfo_bf16_to_f32(dat[pos + i * nPer128]);
+                int qid = (int)roundf((a + zero) / step);
+                qid = qid < qMin ? qMin : qid;
+                qid = qid > qMax ? qMax : qid;
+                qq[pos] = qid + qBias;
+                float e = a - (step * qid - zero);
+                err_2 += (double)e * e;
+            }
+            pack_block(bits, qq, quanti + 16 * i);
+        }
+    }
+    return (float)sqrt(err_2 / ((double)nGroup * lGroup));
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * 3. Dequant -- CU_Q128toX_<bf16,32/64/128> (src/Device/CUDA/T.cu:245-294), bf16-stepwise:
+ *    g0 = (step * (bf16)(q - qBias) - zero) * sR   with every operator a bf16 operator (floatGama=bf16):
+ *    bf16(bf16(step*q') - zero), sR = 1 (rc_normal = 0).
+ * ---------------------------------------------------------------------------------------------- */
+static inline float dequant_one(float step, float zero, int qm) {
+    float t = kfo_round_bf16(step * kfo_round_bf16((float)qm));
+    return kfo_round_bf16(t - zero);
+}
+
+KFO_API void kfo_dequant_q128(const uint8_t* packed, const uint16_t* zero, const uint16_t* step, size_t nGroup, int lGroup, int bits,
+                              int qBias, uint16_t* out) {
+    const int nQuant = 128 / bits;
+#pragma omp parallel for schedule(static)
+    for (long g = 0; g < (long)nGroup; g++) {
+        float z = kfo_bf16_to_f32(zero[g]), s = kfo_bf16_to_f32(step[g]);
+        const uint8_t* q128 = packed + (size_t)g * lGroup * bits / 8;
+        uint16_t* x0 = out + (size_t)g * lGroup;
+        int32_t qq[128];
+        for (int k = 0; k < lGroup / nQuant; k++, x0 += nQuant) {
+            unpack_block(bits, q128 + 16 * k, qq);
+            for (int i = 0; i < nQuant; i++) x0[i] = kfo_f32_to_bf16(dequant_one(s, z, qq[i] - qBias));
+        }
+    }
+}
+
+/* CU_F82Float (kernel/operator.cuh:536-543): dst = T(float(f8e5m2)) */
+KFO_API void kfo_f8e5m2_to_bf16(const uint8_t* src, size_t n, uint16_t* dst) {
+    for (size_t i = 0; i < n; i++) dst[i] = kfo_f32_to_bf16(kfo_f8e5m2_to_f32(src[i]));
+}
+KFO_API void kfo_bf16_to_f8e5m2(const uint16_t* src, size_t n, uint8_t* dst) {
+    for (size_t i = 0; i < n; i++) dst[i] = kfo_f32_to_f8e5m2(kfo_bf16_to_f32(src[i]));
+}
+KFO_API float kfo_expf_export(float x) { return kfo_expf(x); }
+
+/* ------------------------------------------------------------------------------------------------
+ * 4. Weight descriptor + W.x  -- SLP::Forw -> TASKA_AxB::blasLt (NeuronFuse.cu:305-381,
+ *    GTensor.hpp:703-741): rhs[OC] = W[OC,IC] . lhs[IC], bf16 in, fp32 accumulate, bf16 out
+ *    (gemm.cu:126 CUBLAS_COMPUTE_32F).  cuBLASLt's summation order is unspecified; the oracle uses the
+ *    order of the reference's own CPU primitive dotprod_fp16 (src/Utils/GST_float.cpp:75-101):
+ *    16 strided partial sums (two 8-lane accumulators), each updated as acc = acc + x*w (mul, then add),
+ *    folded 16 -> 8 -> 4 -> (s0+s1)+(s2+s3) (_mm_dp_ps).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int type;             /* KFO_BF16 / KFO_F8E5M2 / KFO_Q4 / KFO_T_SIGN / KFO_BOOL1 / KFO_T_BINARY */
+    int ne0, ne1;         /* out, in  (GTensor ne[0], ne[1]) */
+    const void* data;     /* bf16 elements, f8 bytes, or Packed128 stream */
+    const uint16_t* zero; /* gama_T(ZERO)  bf16[nGroup] */
+    const uint16_t* step; /* gama_T(STEP)  bf16[nGroup] */
+    int lGroup;           /* T_group (128) */
+    int qBias;
+} kfo_weight;
+
+static int bits_of(int type) {
+    switch (type) {
+        case KFO_Q4: return 4;
+        case KFO_T_SIGN: case KFO_Q2: return 2;
+        case KFO_BOOL1: case KFO_T_BINARY: return 1;
+        case KFO_F8E5M2: return 8;
+        default: return 16;
+    }
+}
+
+/* dequantise one row of W to f32 (values are exactly bf16-representable) */
+static void weight_row_f32(const kfo_weight* w, long r, float* out) {
+    const int K = w->ne1;
+    if (w->type == KFO_BF16) {
+        const uint16_t* p = (const uint16_t*)w->data + (size_t)r * K;
+        for (int c = 0; c < K; c++) out[c] = kfo_bf16_to_f32(p[c]);
+    } else if (w->type == KFO_F8E5M2) {
+        const uint8_t* p = (const uint8_t*)w->data + (size_t)r * K;
+        for (int c = 0; c < K; c++) out[c] = kfo_round_bf16(kfo_f8e5m2_to_f32(p[c]));
+    } else {
+        const int bits = bits_of(w->type), lG = w->lGroup, nQuant = 128 / bits, nLevel = 1 << bits;
+        size_t e0 = (size_t)r * K; /* flattened element offset; K % lGroup == 0 so rows start on a group */
+        int32_t qq[128];
+        float lut[16];
+        for (int c = 0; c < K; c += lG) {
+            size_t g = (e0 + c) / lG;
+            float z = kfo_bf16_to_f32(w->zero[g]), s = kfo_bf16_to_f32(w->step[g]);
+            for (int v = 0; v < nLevel; v++) lut[v] = dequant_one(s, z, v - w->qBias);
+            const uint8_t* q128 = (const uint8_t*)w->data + g * lG * bits / 8;
+            for (int k = 0; k < lG / nQuant; k++) {
+                unpack_block(bits, q128 + 16 * k, qq);
+                for (int i = 0; i < nQuant; i++) out[c + k * nQuant + i] = lut[qq[i]];
+            }
+        }
+    }
+}
+
+static float dot16(const float* w, const float* x, int n) {
+    float s[16];
+    for (int i = 0; i < 16; i++) s[i] = 0.f;
+    int j = 0;
+    for (; j + 16 <= n; j += 16)
+        for (int i = 0; i < 16; i++) s[i] = x[j + i] * w[j + i] + s[i];
+    for (int i = 0; j < n; j++, i++) s[i] = x[j] * w[j] + s[i]; /* tail (reference asserts n%16==0) */
+    float s8[8], s4[4];
+    for (int i = 0; i < 8; i++) s8[i] = s[i] + s[i + 8];
+    for (int i = 0; i < 4; i++) s4[i] = s8[i] + s8[i + 4];
+    return (s4[0] + s4[1]) + (s4[2] + s4[3]);
+}
+
+/* y[r] = bf16( alpha * W[r,:].x  (+ bias[r]) (+ beta*y[r]) ),  rows [r0,r1) only (TP shards use it) */
+KFO_API void kfo_linear_rows(const kfo_weight* w, const uint16_t* x, uint16_t* y, const uint16_t* bias, float alpha, float beta, int r0,
+                             int r1) {
+    const int K = w->ne1;
+    float* xf = (float*)malloc(sizeof(float) * K);
+    for (int c = 0; c < K; c++) xf[c] = kfo_bf16_to_f32(x[c]);
+#pragma omp parallel
+    {
+        float* row = (float*)malloc(sizeof(float) * K);
+#pragma omp for schedule(static)
+        for (long r = r0; r < r1; r++) {
+            weight_row_f32(w, r, row);
+            float v = dot16(row, xf, K);
+            if (alpha != 1.0f) v = alpha * v;
+            if (beta != 0.0f) v = v + beta * kfo_bf16_to_f32(y[r]);
+            if (bias) v = v + kfo_bf16_to_f32(bias[r]);
+            y[r] = kfo_f32_to_bf16(v);
+        }
+        free(row);
+    }
+    free(xf);
+}
+KFO_API void kfo_linear(const kfo_weight* w, const uint16_t* x, uint16_t* y, const uint16_t* bias, float alpha, float beta) {
+    kfo_linear_rows(w, x, y, bias, alpha, beta, 0, w->ne0);
+}
+/* fp32 (un-rounded) row dots, for the TP partial-sum path and tolerance analysis */
+KFO_API void kfo_linear_f32(const kfo_weight* w, const uint16_t* x, float* y, int c0, int c1) {
+    const int K = w->ne1;
+    float* xf = (float*)calloc(K, sizeof(float));
+    for (int c = c0; c < c1; c++) xf[c] = kfo_bf16_to_f32(x[c]);
+#pragma omp parallel
+    {
+        float* row = (float*)malloc(sizeof(float) * K);
+#pragma omp for schedule(static)
+        for (long r = 0; r < w->ne0; r++) {
+            weight_row_f32(w, r, row);
+            y[r] = dot16(row + c0, xf + c0, c1 - c0);
+        }
+        free(row);
+    }
+    free(xf);
+}
+KFO_API void kfo_dequant_weight(const kfo_weight* w, uint16_t* out) {
+    const int K = w->ne1;
+#pragma omp parallel
+    {
+        float* row = (float*)malloc(sizeof(float) * K);
+#pragma omp for schedule(static)
+        for (long r = 0; r < w->ne0; r++) {
+            weight_row_f32(w, r, row);
+            for (int c = 0; c < K; c++) out[(size_t)r * K + c] = kfo_f32_to_bf16(row[c]);
+        }
+        free(row);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * 5. Small ops
+ * ---------------------------------------------------------------------------------------------- */
+/* rms_norm_kernel (kernel/layernorm.cuh:800-847): y = bf16((x * rsqrt(fma(sum, 1/D, eps))) * w).
+ * Deliberate: the sum of squares is accumulated in fp64 (reference: fp32 in its launch-geometry order)
+ * so that the result does not depend on the reduction order -- the HIP kernel does the same. */
+KFO_API void kfo_rmsnorm(const uint16_t* x, const uint16_t* w, uint16_t* y, int rows, int dim, float eps) {
+    for (int r = 0; r < rows; r++) {
+        const uint16_t* xr = x + (size_t)r * dim;
+        double acc = 0.0;
+        for (int i = 0; i < dim; i++) {
+            double a = kfo_bf16_to_f32(xr[i]);
+            acc += a * a;
+        }
+        float val = fmaf((float)acc, 1.0f / (float)dim, eps);
+        float mul = 1.0f / sqrtf(val);
+        for (int i = 0; i < dim; i++) {
+            float v = (kfo_bf16_to_f32(xr[i]) * mul) * kfo_bf16_to_f32(w[i]);
+            y[(size_t)r * dim + i] = kfo_f32_to_bf16(v);
+        }
+    }
+}
+
+/* q/k-norm: CU_rms_forward_v2 (layernorm.cuh:129-167): s0 = rsqrt(sum/ld + eps); s = bf16(s0);
+ * out = bf16(a * float(s) * w) (Hadamard, packedN.cuh:412-419; RN instead of its stochastic store). */
+KFO_API void kfo_headnorm(uint16_t* x, const uint16_t* w, int nHead, int hd, float eps) {
+    for (int h = 0; h < nHead; h++) {
+        uint16_t* xh = x + (size_t)h * hd;
+        double acc = 0.0;
+        for (int i = 0; i < hd; i++) {
+            double a = kfo_bf16_to_f32(xh[i]);
+            acc += a * a;
+        }
+        float s0 = 1.0f / sqrtf((float)acc / (float)hd + eps);
+        float s = kfo_round_bf16(s0);
+        for (int i = 0; i < hd; i++) {
+            float res = kfo_bf16_to_f32(xh[i]) * s * kfo_bf16_to_f32(w[i]);
+            xh[i] = kfo_f32_to_bf16(res);
+        }
+    }
+}
+
+/* RoPE table entry, CU_rope2_v0 (kernel/operator.cuh:734-772): inv_freq = 1/powf(theta, 2j/hd),
+ * angle = pos*inv_freq, sincosf.  Host libm. */
+KFO_API void kfo_rope_table(int pos, int hd, float theta, float* cos_out, float* sin_out) {
+    for (int j = 0; j < hd / 2; j++) {
+        float inv_freq = 1.0f / powf(theta, (float)(j * 2) / (float)hd);
+        float angle = (float)pos * inv_freq;
+        sin_out[j] = sinf(angle);
+        cos_out[j] = cosf(angle);
+    }
+}
+/* rotate-half pairs (j, j+hd/2), in place, RN bf16 stores */
+KFO_API void kfo_rope(uint16_t* x, int nHead, int hd, int pos, float theta) {
+    float cs[512], sn[512];
+    kfo_rope_table(pos, hd, theta, cs, sn);
+    for (int h = 0; h < nHead; h++) {
+        uint16_t* xh = x + (size_t)h * hd;
+        for (int j = 0; j < hd / 2; j++) {
+            float re = kfo_bf16_to_f32(xh[j]), im = kfo_bf16_to_f32(xh[j + hd / 2]);
+            float a = re * cs[j], b = im * sn[j], c = re * sn[j], d = im * cs[j];
+            xh[j] = kfo_f32_to_bf16(a - b);
+            xh[j + hd / 2] = kfo_f32_to_bf16(c + d);
+        }
+    }
+}
+
+/* CU_swiglu_v0 (Activation.cu:85-93): out = bf16((g*u)/(1+expf(-g))) */
+KFO_API void kfo_swiglu(const uint16_t* gate, const uint16_t* up, uint16_t* out, int n) {
+    for (int i = 0; i < n; i++) {
+        float g = kfo_bf16_to_f32(gate[i]), u = kfo_bf16_to_f32(up[i]);
+        out[i] = kfo_f32_to_bf16((g * u) / (1.0f + kfo_expf(-g)));
+    }
+}
+/* CU_add3 / Add2 (packedN.cuh:446-453,866-875): out = bf16(a + b) (RN instead of stochastic) */
+KFO_API void kfo_add(const uint16_t* a, const uint16_t* b, uint16_t* out, int n) {
+    for (int i = 0; i < n; i++) out[i] = kfo_f32_to_bf16(kfo_bf16_to_f32(a[i]) + kfo_bf16_to_f32(b[i]));
+}
+/* CU_embed_forw_1 (embed.cuh:123-132): one-row gather (+dequant for quantised tables) */
+KFO_API void kfo_embed(const kfo_weight* w, int token, uint16_t* out) {
+    float* row = (float*)malloc(sizeof(float) * w->ne1);
+    weight_row_f32(w, token, row);
+    for (int c = 0; c < w->ne1; c++) out[c] = kfo_f32_to_bf16(row[c]);
+    free(row);
+}
+/* sample_argmax (src/Manifold/GoPT.cpp:602-612): first index of the maximum */
+KFO_API int kfo_argmax_bf16(const uint16_t* logits, int n) {
+    int best = 0;
+    float bv = kfo_bf16_to_f32(logits[0]);
+    for (int i = 1; i < n; i++) {
+        float v = kfo_bf16_to_f32(logits[i]);
+        if (v > bv) bv = v, best = i;
+    }
+    return best;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * 6. Decode attention (GQA), full causal over t = 0..pos.
+ *    mode 0 "REF":   the reference's rounding chain -- attention_qk_kernel / CU_softmax_multihead /
+ *                    attention_v_kernel (operator.cuh:572-632, 251-277, 649-668) with scores and
+ *                    probabilities held in bf16 (qk_v is floatX, TGraph.cpp:124).
+ *    mode 1 "FUSED": what the fused HIP kernel computes: bf16 scores (same store as REF), then an fp32
+ *                    softmax, out = (sum_t e_t v_t) * (1/sum_t e_t) in fp32, one bf16 store.
+ *    q: bf16 [n_head*hd]; kc/vc: layer base, rows of kv_stride elements; out: bf16 [n_head*hd].
+ * ---------------------------------------------------------------------------------------------- */
+KFO_API void kfo_attn_decode(const uint16_t* q, const uint16_t* kc, const uint16_t* vc, uint16_t* out, int pos, int n_head, int n_kv, int hd,
+                             int kv_stride, int mode) {
+    const int kv_mul = n_head / n_kv, len = pos + 1;
+    const float scale_den = sqrtf((float)hd);
+#pragma omp parallel for schedule(static)
+    for (int h = 0; h < n_head; h++) {
+        const int kvh = h / kv_mul;
+        const uint16_t* qh = q + (size_t)h * hd;
+        float* att = (float*)malloc(sizeof(float) * len);
+        float* acc = (float*)calloc(hd, sizeof(float));
+        float m = -1e9f;
+        for (int t = 0; t < len; t++) {
+            const uint16_t* kt = kc + (size_t)t * kv_stride + (size_t)kvh * hd;
+            float score = 0.0f;
+            for (int i = 0; i < hd; i++) score = fmaf(kfo_bf16_to_f32(qh[i]), kfo_bf16_to_f32(kt[i]), score);
+            score /= scale_den;
+            att[t] = kfo_round_bf16(score);
+            if (att[t] > m) m = att[t];
+        }
+        if (mode == 0) {
+            m = kfo_round_bf16(m); /* T max_val = -1e9f: a bf16 */
+            float sum = 0.0f;
+            for (int t = 0; t < len; t++) {
+                float a = kfo_expf(kfo_round_bf16(att[t] - m)); /* bf16 subtract, then expf(float) */
+                sum += a;
+                att[t] = kfo_round_bf16(a);
+            }
+            float inv = kfo_round_bf16(1.0f / sum); /* scores[i] *= inv_sum: float -> bf16, bf16*bf16 */
+            for (int t = 0; t < len; t++) att[t] = kfo_round_bf16(att[t] * inv);
+            for (int t = 0; t < len; t++) {
+                const uint16_t* vt = vc + (size_t)t * kv_stride + (size_t)kvh * hd;
+                for (int i = 0; i < hd; i++) acc[i] = fmaf(att[t], kfo_bf16_to_f32(vt[i]), acc[i]);
+            }
+            for (int i = 0; i < hd; i++) out[(size_t)h * hd + i] = kfo_f32_to_bf16(acc[i]);
+        } else {
+            float sum = 0.0f;
+            for (int t = 0; t < len; t++) {
+                float a = kfo_expf(att[t] - m);
+                sum += a;
+                att[t] = a;
+            }
+            float inv = 1.0f / sum;
+            for (int t = 0; t < len; t++) {
+                const uint16_t* vt = vc + (size_t)t * kv_stride + (size_t)kvh * hd;
+                for (int i = 0; i < hd; i++) acc[i] = fmaf(att[t], kfo_bf16_to_f32(vt[i]), acc[i]);
+            }
+            for (int i = 0; i < hd; i++) out[(size_t)h * hd + i] = kfo_f32_to_bf16(acc[i] * inv);
+        }
+        free(att);
+        free(acc);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * 7. Qwen3 decoder: op order of SelfAttention::cuInfer (QKV.cu:617-702), ROPE::cuInfer
+ *    (kernel/rope.cu:645-672), FFN::cuInfer (NeuronFuse.cu:615-656), Head4Token::cuInfer_1
+ *    (NeuronFuse.cu:842-862); SURVEY.md section 9 lists every rounding point.
+ *    Tensor-parallel emulation (tp > 1): q/k/v/gate/up split by output rows, o/down by input columns
+ *    with fp32 partials summed in rank order 0..tp-1 and one bf16 store.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    const uint16_t *norm_in, *norm_post, *qn, *kn;
+    kfo_weight q, k, v, o, gate, up, down;
+} kfo_layer;
+
+typedef struct {
+    int dim, n_layer, n_head, n_kv, head_dim, ffn, vocab, max_seq;
+    float rms_eps, qk_eps, theta;
+    int attn_mode, tp;
+    kfo_weight embed, head;
+    const uint16_t* final_norm;
+    kfo_layer* layers;
+    uint16_t *kcache, *vcache; /* [n_layer, max_seq, kv_dim] bf16 (src/Utils/Cache.cpp:14-26) */
+} kfo_qwen3;
+
+KFO_API kfo_qwen3* kfo_qwen3_new(int dim, int n_layer, int n_head, int n_kv, int head_dim, int ffn, int vocab, int max_seq, float rms_eps,
+                                 float qk_eps, float theta, int attn_mode) {
+    kfo_qwen3* m = (kfo_qwen3*)calloc(1, sizeof(kfo_qwen3));
+    m->dim = dim, m->n_layer = n_layer, m->n_head = n_head, m->n_kv = n_kv, m->head_dim = head_dim, m->ffn = ffn, m->vocab = vocab;
+    m->max_seq = max_seq, m->rms_eps = rms_eps, m->qk_eps = qk_eps, m->theta = theta, m->attn_mode = attn_mode, m->tp = 1;
+    m->layers = (kfo_layer*)calloc(n_layer, sizeof(kfo_layer));
+    size_t n = (size_t)n_layer * max_seq * n_kv * head_dim;
+    m->kcache = (uint16_t*)calloc(n, 2);
+    m->vcache = (uint16_t*)calloc(n, 2);
+    return m;
+}
+KFO_API void kfo_qwen3_free(kfo_qwen3* m) {
+    if (!m) return;
+    free(m->layers), free(m->kcache), free(m->vcache), free(m);
+}
+KFO_API void kfo_qwen3_set_tp(kfo_qwen3* m, int tp) { m->tp = tp; }
+KFO_API void kfo_qwen3_set_attn_mode(kfo_qwen3* m, int mode) { m->attn_mode = mode; }
+KFO_API uint16_t* kfo_qwen3_kcache(kfo_qwen3* m) { return m->kcache; }
+KFO_API uint16_t* kfo_qwen3_vcache(kfo_qwen3* m) { return m->vcache; }
+
+/* slot: 0 q,1 k,2 v,3 o,4 gate,5 up,6 down (layer>=0);  layer=-1: slot 0 embed, 1 head */
+KFO_API int kfo_qwen3_set_weight(kfo_qwen3* m, int layer, int slot, int type, int ne0, int ne1, const void* data, const uint16_t* zero,
+                                 const uint16_t* step, int lGroup, int qBias) {
+    kfo_weight w = {type, ne0, ne1, data, zero, step, lGroup, qBias};
+    if (layer < 0) {
+        if (slot == 0)
+            m->embed = w;
+        else
+            m->head = w;
+        return 0;
+    }
+    if (layer >= m->n_layer || slot < 0 || slot > 6) return -1;
+    kfo_weight* dst[7] = {&m->layers[layer].q, &m->layers[layer].k, &m->layers[layer].v, &m->layers[layer].o,
+                          &m->layers[layer].gate, &m->layers[layer].up, &m->layers[layer].down};
+    *dst[slot] = w;
+    return 0;
+}
+/* slot: 0 input_layernorm, 1 post_attention_layernorm, 2 q_norm, 3 k_norm; layer=-1: final norm */
+KFO_API int kfo_qwen3_set_norm(kfo_qwen3* m, int layer, int slot, const uint16_t* w) {
+    if (layer < 0) {
+        m->final_norm = w;
+        return 0;
+    }
+    if (layer >= m->n_layer) return -1;
+    kfo_layer* L = &m->layers[layer];
+    if (slot == 0) L->norm_in = w;
+    else if (slot == 1) L->norm_post = w;
+    else if (slot == 2) L->qn = w;
+    else if (slot == 3) L->kn = w;
+    else return -1;
+    return 0;
+}
+
+/* row-split weights: plain rows.  column-split weights: fp32 partials per rank, summed in rank order. */
+static void linear_colsplit(const kfo_weight* w, const uint16_t* x, uint16_t* y, int tp) {
+    if (tp <= 1) {
+        kfo_linear(w, x, y, NULL, 1.0f, 0.0f);
+        return;
+    }
+    const int M = w->ne0, K = w->ne1, kc = K / tp;
+    float* part = (float*)malloc(sizeof(float) * M);
+    float* tot = (float*)calloc(M, sizeof(float));
+    for (int r = 0; r < tp; r++) {
+        kfo_linear_f32(w, x, part, r * kc, (r + 1) * kc);
+        for (int i = 0; i < M; i++) tot[i] = (r == 0) ? part[i] : tot[i] + part[i];
+    }
+    for (int i = 0; i < M; i++) y[i] = kfo_f32_to_bf16(tot[i]);
+    free(part), free(tot);
+}
+
+/* One decode step.  logits_out (bf16[vocab]) may be NULL.  hidden_out (bf16[dim], after the final
+ * norm) may be NULL.  Returns the greedy token id. */
+KFO_API int kfo_qwen3_decode(kfo_qwen3* m, int token, int pos, uint16_t* logits_out, uint16_t* hidden_out) {
+    const int D = m->dim, hd = m->head_dim, qd = m->n_head * hd, kvd = m->n_kv * hd, F = m->ffn;
+    uint16_t* x = (uint16_t*)malloc(2 * D);
+    uint16_t* xb = (uint16_t*)malloc(2 * D);
+    uint16_t* q = (uint16_t*)malloc(2 * qd);
+    uint16_t* att = (uint16_t*)malloc(2 * qd);
+    uint16_t* p = (uint16_t*)malloc(2 * D);
+    uint16_t* gt = (uint16_t*)malloc(2 * F);
+    uint16_t* up = (uint16_t*)malloc(2 * F);
+    kfo_embed(&m->embed, token, x);
+    for (int l = 0; l < m->n_layer; l++) {
+        kfo_layer* L = &m->layers[l];
+        uint16_t* kc = m->kcache + (size_t)l * m->max_seq * kvd;
+        uint16_t* vc = m->vcache + (size_t)l * m->max_seq * kvd;
+        uint16_t *krow = kc + (size_t)pos * kvd, *vrow = vc + (size_t)pos * kvd; /* _devQKV: TGraph.cpp:198-207 */
+        kfo_rmsnorm(x, L->norm_in, xb, 1, D, m->rms_eps);
+        kfo_linear(&L->q, xb, q, NULL, 1.0f, 0.0f);
+        kfo_linear(&L->k, xb, krow, NULL, 1.0f, 0.0f);
+        kfo_linear(&L->v, xb, vrow, NULL, 1.0f, 0.0f);
+        if (L->qn) kfo_headnorm(q, L->qn, m->n_head, hd, m->qk_eps);
+        if (L->kn) kfo_headnorm(krow, L->kn, m->n_kv, hd, m->qk_eps);
+        kfo_rope(q, m->n_head, hd, pos, m->theta);
+        kfo_rope(krow, m->n_kv, hd, pos, m->theta);
+        kfo_attn_decode(q, kc, vc, att, pos, m->n_head, m->n_kv, hd, kvd, m->attn_mode);
+        linear_colsplit(&L->o, att, p, m->tp);
+        kfo_add(x, p, x, D);
+        kfo_rmsnorm(x, L->norm_post, xb, 1, D, m->rms_eps);
+        kfo_linear(&L->gate, xb, gt, NULL, 1.0f, 0.0f);
+        kfo_linear(&L->up, xb, up, NULL, 1.0f, 0.0f);
+        kfo_swiglu(gt, up, gt, F);
+        linear_colsplit(&L->down, gt, p, m->tp);
+        kfo_add(x, p, x, D);
+    }
+    kfo_rmsnorm(x, m->final_norm, xb, 1, D, m->rms_eps);
+    if (hidden_out) memcpy(hidden_out, xb, 2 * D);
+    uint16_t* logits = logits_out ? logits_out : (uint16_t*)malloc(2 * (size_t)m->vocab);
+    kfo_linear(&m->head, xb, logits, NULL, 1.0f, 0.0f);
+    int next = kfo_argmax_bf16(logits, m->vocab);
+    if (!logits_out) free(logits);
+    free(x), free(xb), free(q), free(att), free(p), free(gt), free(up);
+    return next;
+}
+
+KFO_API int kfo_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

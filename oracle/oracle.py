@@ -1,0 +1,334 @@
+"""ctypes front-end of the CPU oracle (oracle/kf_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package (koifish_amd/) never imports this module.
+
+All tensors are numpy arrays; bf16 is carried as uint16 bit patterns.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+# typNUMBER order restated from src/g_float.hpp:84-117
+F32, F64, F16, BF16, F8E5M2, F8E4M3, U8, I8, U16, I16, U32, I32, U64, I64, Q4, Q3, Q2, T_SIGN, T_SEQ, BOOL1, T_BINARY, T_BINARY_3, T_BINARY_TILE = range(23)
+BITS = {BF16: 16, F8E5M2: 8, Q4: 4, T_SIGN: 2, Q2: 2, BOOL1: 1, T_BINARY: 1}
+
+ATTN_REF, ATTN_FUSED = 0, 1
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libkf_oracle.so")
+    src = [os.path.join(_HERE, f) for f in ("kf_oracle.c", "kfo_math.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B" if force else "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        L = _LIB
+        L.kfo_rtn_x.restype = C.c_float
+        L.kfo_yinyang.restype = C.c_float
+        L.kfo_expf_export.restype = C.c_float
+        L.kfo_expf_export.argtypes = [C.c_float]
+        L.kfo_qwen3_new.restype = C.c_void_p
+        L.kfo_qwen3_new.argtypes = [C.c_int] * 8 + [C.c_float] * 3 + [C.c_int]
+        L.kfo_qwen3_kcache.restype = C.c_void_p
+        L.kfo_qwen3_vcache.restype = C.c_void_p
+        L.kfo_qwen3_kcache.argtypes = [C.c_void_p]
+        L.kfo_qwen3_vcache.argtypes = [C.c_void_p]
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+# ---------------------------------------------------------------- bf16 helpers (numpy, RNE)
+def f32_to_bf16(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    u = x.view(np.uint32)
+    nan = (u & 0x7FFFFFFF) > 0x7F800000
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+    r[nan] = ((u[nan] >> 16) | 0x40).astype(np.uint16)
+    return r
+
+
+def bf16_to_f32(h):
+    return (np.ascontiguousarray(h, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+# ---------------------------------------------------------------- layout
+def pack(q, bits):
+    """q: int32[..., n] with n % (128/bits) == 0 -> uint8 packed stream (Packed128 blocks)."""
+    q = np.ascontiguousarray(q, dtype=np.int32).reshape(-1)
+    per = 128 // bits
+    assert q.size % per == 0
+    out = np.zeros(q.size // per * 16, dtype=np.uint8)
+    fn = getattr(lib(), "kfo_pack%d_128" % bits)
+    for b in range(q.size // per):
+        fn(_p(q[b * per:]), C.c_void_p(out.ctypes.data + 16 * b))
+    return out
+
+
+def unpack(packed, bits):
+    packed = np.ascontiguousarray(packed, dtype=np.uint8).reshape(-1)
+    per = 128 // bits
+    nb = packed.size // 16
+    out = np.zeros(nb * per, dtype=np.int32)
+    fn = getattr(lib(), "kfo_unpack%d_128" % bits)
+    for b in range(nb):
+        fn(C.c_void_p(packed.ctypes.data + 16 * b), C.c_void_p(out.ctypes.data + 4 * per * b))
+    return out
+
+
+def quant_range(bits, symmetric=False, yyang=False):
+    a, b, c = C.c_int(), C.c_int(), C.c_int()
+    lib().kfo_quant_range(bits, int(symmetric), int(yyang), C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+class QWeight:
+    """A weight as the reference holds it: `data||gama` (GTensor.cpp:456-510) + quant card fields."""
+
+    def __init__(self, type_, ne0, ne1, data, zero=None, step=None, lGroup=128, qBias=0):
+        self.type, self.ne0, self.ne1 = type_, ne0, ne1
+        self.data = np.ascontiguousarray(data)
+        self.zero = None if zero is None else np.ascontiguousarray(zero, dtype=np.uint16)
+        self.step = None if step is None else np.ascontiguousarray(step, dtype=np.uint16)
+        self.lGroup, self.qBias = lGroup, qBias
+
+    @property
+    def bits(self):
+        return BITS[self.type]
+
+    @property
+    def nGroup(self):
+        return 0 if self.zero is None else self.zero.size
+
+    def blob(self):
+        """bytes of `data || R_SCALE[ne0] C_SCALE[ne1] ZERO[nGroup] STEP[nGroup]` (bf16), gama_T layout."""
+        if self.zero is None:
+            return self.data.view(np.uint8).reshape(-1).copy()
+        rc = np.full(self.ne0 + self.ne1, 0x3F80, dtype=np.uint16)  # 1.0; unused when rc_normal == 0
+        return np.concatenate([self.data.view(np.uint8).reshape(-1), rc.view(np.uint8), self.zero.view(np.uint8), self.step.view(np.uint8)])
+
+    def nbytes_algorithmic(self):
+        """bytes a GEMV must read: packed data + zero/step (R/C scales are never read)."""
+        n = self.data.nbytes
+        if self.zero is not None:
+            n += self.zero.nbytes + self.step.nbytes
+        return n
+
+    def cdesc(self):
+        class _W(C.Structure):
+            _fields_ = [("type", C.c_int), ("ne0", C.c_int), ("ne1", C.c_int), ("data", C.c_void_p), ("zero", C.c_void_p),
+                        ("step", C.c_void_p), ("lGroup", C.c_int), ("qBias", C.c_int)]
+        return _W(self.type, self.ne0, self.ne1, _p(self.data), _p(self.zero), _p(self.step), self.lGroup, self.qBias)
+
+
+def quantize(w_bf16, ne0, ne1, type_, lGroup=128, symmetric=False):
+    """GeQuant::RTN_x (4/2-bit RTN) or GeQuant::YinYang (T_SIGN ternary / BOOL1 1-bit)."""
+    w_bf16 = np.ascontiguousarray(w_bf16, dtype=np.uint16).reshape(-1)
+    assert w_bf16.size == ne0 * ne1 and (ne0 * ne1) % lGroup == 0
+    if type_ == BF16:
+        return QWeight(BF16, ne0, ne1, w_bf16.copy())
+    if type_ == F8E5M2:
+        out = np.zeros(w_bf16.size, dtype=np.uint8)
+        lib().kfo_bf16_to_f8e5m2(_p(w_bf16), C.c_size_t(w_bf16.size), _p(out))
+        return QWeight(F8E5M2, ne0, ne1, out)
+    bits = BITS[type_]
+    nG = w_bf16.size // lGroup
+    packed = np.zeros(w_bf16.size * bits // 8, dtype=np.uint8)
+    zero = np.zeros(nG, dtype=np.uint16)
+    step = np.zeros(nG, dtype=np.uint16)
+    yy = type_ in (T_SIGN, BOOL1, T_BINARY)
+    if yy:
+        lib().kfo_yinyang(_p(w_bf16), C.c_size_t(nG), lGroup, bits, _p(packed), _p(zero), _p(step))
+    else:
+        lib().kfo_rtn_x(_p(w_bf16), C.c_size_t(nG), lGroup, bits, int(symmetric), 0, _p(packed), _p(zero), _p(step))
+    _, _, qBias = quant_range(bits, symmetric, yy)
+    return QWeight(type_, ne0, ne1, packed, zero, step, lGroup, qBias)
+
+
+def dequant(w):
+    out = np.zeros(w.ne0 * w.ne1, dtype=np.uint16)
+    d = w.cdesc()
+    lib().kfo_dequant_weight(C.byref(d), _p(out))
+    return out.reshape(w.ne0, w.ne1)
+
+
+def dequant_q128(packed, zero, step, lGroup, bits, qBias):
+    out = np.zeros(zero.size * lGroup, dtype=np.uint16)
+    lib().kfo_dequant_q128(_p(packed), _p(zero), _p(step), C.c_size_t(zero.size), lGroup, bits, qBias, _p(out))
+    return out
+
+
+def linear(w, x, bias=None, alpha=1.0, beta=0.0, y=None):
+    x = np.ascontiguousarray(x, dtype=np.uint16)
+    y = np.zeros(w.ne0, dtype=np.uint16) if y is None else np.ascontiguousarray(y, dtype=np.uint16).copy()
+    d = w.cdesc()
+    lib().kfo_linear(C.byref(d), _p(x), _p(y), _p(bias), C.c_float(alpha), C.c_float(beta))
+    return y
+
+
+def linear_f32(w, x, c0=0, c1=None):
+    x = np.ascontiguousarray(x, dtype=np.uint16)
+    y = np.zeros(w.ne0, dtype=np.float32)
+    d = w.cdesc()
+    lib().kfo_linear_f32(C.byref(d), _p(x), _p(y), c0, w.ne1 if c1 is None else c1)
+    return y
+
+
+def rmsnorm(x, w, eps=1e-6):
+    x = np.ascontiguousarray(x, dtype=np.uint16)
+    rows = 1 if x.ndim == 1 else x.shape[0]
+    dim = x.shape[-1]
+    y = np.zeros_like(x)
+    lib().kfo_rmsnorm(_p(x), _p(np.ascontiguousarray(w, dtype=np.uint16)), _p(y), rows, dim, C.c_float(eps))
+    return y
+
+
+def headnorm(x, w, nHead, hd, eps=1e-6):
+    x = np.ascontiguousarray(x, dtype=np.uint16).copy()
+    lib().kfo_headnorm(_p(x), _p(np.ascontiguousarray(w, dtype=np.uint16)), nHead, hd, C.c_float(eps))
+    return x
+
+
+def rope_table(pos, hd, theta):
+    c = np.zeros(hd // 2, dtype=np.float32)
+    s = np.zeros(hd // 2, dtype=np.float32)
+    lib().kfo_rope_table(pos, hd, C.c_float(theta), _p(c), _p(s))
+    return c, s
+
+
+def rope(x, nHead, hd, pos, theta):
+    x = np.ascontiguousarray(x, dtype=np.uint16).copy()
+    lib().kfo_rope(_p(x), nHead, hd, pos, C.c_float(theta))
+    return x
+
+
+def swiglu(gate, up):
+    gate = np.ascontiguousarray(gate, dtype=np.uint16)
+    out = np.zeros_like(gate)
+    lib().kfo_swiglu(_p(gate), _p(np.ascontiguousarray(up, dtype=np.uint16)), _p(out), gate.size)
+    return out
+
+
+def add(a, b):
+    a = np.ascontiguousarray(a, dtype=np.uint16)
+    out = np.zeros_like(a)
+    lib().kfo_add(_p(a), _p(np.ascontiguousarray(b, dtype=np.uint16)), _p(out), a.size)
+    return out
+
+
+def embed(w, token):
+    out = np.zeros(w.ne1, dtype=np.uint16)
+    d = w.cdesc()
+    lib().kfo_embed(C.byref(d), int(token), _p(out))
+    return out
+
+
+def argmax_bf16(logits):
+    logits = np.ascontiguousarray(logits, dtype=np.uint16)
+    return int(lib().kfo_argmax_bf16(_p(logits), logits.size))
+
+
+def attn_decode(q, kc, vc, pos, n_head, n_kv, hd, kv_stride=None, mode=ATTN_FUSED):
+    q = np.ascontiguousarray(q, dtype=np.uint16)
+    kc = np.ascontiguousarray(kc, dtype=np.uint16)
+    vc = np.ascontiguousarray(vc, dtype=np.uint16)
+    out = np.zeros(n_head * hd, dtype=np.uint16)
+    lib().kfo_attn_decode(_p(q), _p(kc), _p(vc), _p(out), pos, n_head, n_kv, hd, kv_stride or n_kv * hd, mode)
+    return out
+
+
+def expf(x):
+    return np.array([lib().kfo_expf_export(float(v)) for v in np.asarray(x, dtype=np.float32).reshape(-1)], dtype=np.float32)
+
+
+# ---------------------------------------------------------------- Qwen3 decoder
+SLOTS = ("q", "k", "v", "o", "gate", "up", "down")
+NORMS = ("norm_in", "norm_post", "qn", "kn")
+
+
+class Qwen3Oracle:
+    """weights: dict with 'embed', 'head' (QWeight; may be the same object when tied), 'final_norm' (uint16[dim]),
+    'layers': list of dicts with QWeight q,k,v,o,gate,up,down and uint16 norm_in,norm_post,qn,kn."""
+
+    def __init__(self, cfg, weights, attn_mode=ATTN_FUSED, tp=1):
+        self.cfg, self.w = cfg, weights
+        L = lib()
+        self.h = L.kfo_qwen3_new(cfg["dim"], cfg["n_layer"], cfg["n_head"], cfg["n_kv"], cfg["head_dim"], cfg["ffn"], cfg["vocab"],
+                                 cfg["max_seq"], cfg.get("rms_eps", 1e-6), cfg.get("qk_eps", 1e-6), cfg.get("theta", 1e6), attn_mode)
+        self.h = C.c_void_p(self.h)
+        L.kfo_qwen3_set_tp(self.h, tp)
+        self._keep = []
+
+        def setw(layer, slot, w):
+            self._keep.append(w)
+            r = L.kfo_qwen3_set_weight(self.h, layer, slot, w.type, w.ne0, w.ne1, _p(w.data), _p(w.zero), _p(w.step), w.lGroup, w.qBias)
+            assert r == 0
+
+        setw(-1, 0, weights["embed"])
+        setw(-1, 1, weights["head"])
+        fn = np.ascontiguousarray(weights["final_norm"], dtype=np.uint16)
+        self._keep.append(fn)
+        L.kfo_qwen3_set_norm(self.h, -1, 0, _p(fn))
+        for li, lw in enumerate(weights["layers"]):
+            for si, s in enumerate(SLOTS):
+                setw(li, si, lw[s])
+            for si, s in enumerate(NORMS):
+                if lw.get(s) is not None:
+                    a = np.ascontiguousarray(lw[s], dtype=np.uint16)
+                    self._keep.append(a)
+                    L.kfo_qwen3_set_norm(self.h, li, si, _p(a))
+
+    def decode(self, token, pos, want_logits=True, want_hidden=False):
+        logits = np.zeros(self.cfg["vocab"], dtype=np.uint16) if want_logits else None
+        hidden = np.zeros(self.cfg["dim"], dtype=np.uint16) if want_hidden else None
+        nxt = lib().kfo_qwen3_decode(self.h, int(token), int(pos), _p(logits), _p(hidden))
+        return int(nxt), logits, hidden
+
+    def kv(self):
+        c = self.cfg
+        n = c["n_layer"] * c["max_seq"] * c["n_kv"] * c["head_dim"]
+        k = np.ctypeslib.as_array(C.cast(lib().kfo_qwen3_kcache(self.h), C.POINTER(C.c_uint16)), shape=(n,))
+        v = np.ctypeslib.as_array(C.cast(lib().kfo_qwen3_vcache(self.h), C.POINTER(C.c_uint16)), shape=(n,))
+        shp = (c["n_layer"], c["max_seq"], c["n_kv"] * c["head_dim"])
+        return k.reshape(shp), v.reshape(shp)
+
+    def generate(self, prompt, n_new):
+        """Token-serial prefill (Fish::Chat, GoPT.cpp:1139-1146) then greedy decode. Returns new ids."""
+        pos, nxt = 0, None
+        for t in prompt:
+            nxt, _, _ = self.decode(t, pos, want_logits=False)
+            pos += 1
+        out = []
+        for _ in range(n_new):
+            out.append(nxt)
+            nxt, _, _ = self.decode(nxt, pos, want_logits=False)
+            pos += 1
+        return out
+
+    def close(self):
+        if self.h:
+            lib().kfo_qwen3_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def num_threads():
+    return int(lib().kfo_num_threads())

@@ -1,0 +1,65 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def O():
+    """the CPU oracle (checker only)"""
+    from oracle import oracle
+    oracle.lib()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    from koifish_amd.runtime import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def bf16_t(a_u16, device):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a_u16).view(np.int16)).to(device).view(torch.bfloat16)
+
+
+def u16(t):
+    """torch bf16 tensor -> numpy uint16 bit patterns"""
+    import torch
+    return t.detach().contiguous().view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+def ulp_diff_bf16(a_u16, b_u16):
+    """distance in bf16 ulps between two bit-pattern arrays (sign-magnitude -> ordered ints)"""
+    def key(x):
+        x = x.astype(np.int32)
+        return np.where(x & 0x8000, -(x & 0x7FFF), x & 0x7FFF)
+    return np.abs(key(np.asarray(a_u16)) - key(np.asarray(b_u16)))
