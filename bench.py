@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- tokens/s of the Qwen3-0.6B 4-bit PackedQ decode path on MI355X (BASELINE.json configs[1]).
+
+A "step" is one decode token: embed -> 28 x (norm+QKV, q/k-norm+RoPE+attention, o_proj+residual, norm+gate/up+SwiGLU,
+down+residual) -> final norm + LM head + greedy pick, replayed from hipGraphs with token and position held on the
+device (no host round trip per token).  Workload: synthetic weights of the 0.6B architecture (N(0,0.02), RTN 4-bit g128
+layers, bf16 tied LM head), a 2048-position sequence: positions [0, 2048-W-K) are set-up, the next W are warm-up, the
+last K are timed (default W=128 = the prompt, K=1920 = decode to position 2047).
+
+  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run; independent replicas,
+                                                       no data-path collective -- "scaling": "weak")
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy achieves
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1920)
+    ap.add_argument("--warmup", type=int, default=128)
+    ap.add_argument("--config", default="qwen3-0.6b")
+    ap.add_argument("--head", default="bf16", choices=["bf16", "q4"])
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from koifish_amd import lib as L
+    from koifish_amd import synth
+    from koifish_amd.runtime import stream
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = local if world > 1 else 0
+    torch.cuda.set_device(dev)
+    stream(dev)
+
+    cfg = dict(synth.CONFIGS[args.config])
+    S = cfg["max_seq"]
+    K, W = args.steps, args.warmup
+    if K < 1 or W < 0:
+        raise SystemExit("steps >= 1, warmup >= 0")
+    head_type = L.BF16 if args.head == "bf16" else L.Q4
+    m = synth.build_on_gpu(cfg, seed=1234 + rank, layer_type=L.Q4, head_type=head_type, device=dev)
+    ctx = m._ctx
+    use_graph = not args.no_graph
+
+    # synthetic prompt: 128 ids, then free-running greedy decode
+    n_prompt = 128
+    forced = np.full(S, -1, dtype=np.int32)
+    forced[:n_prompt] = np.random.default_rng(7 + rank).integers(0, cfg["vocab"], size=n_prompt)
+    m.set_forced(forced)
+
+    def run_span(p0, n):
+        """n consecutive decode steps starting at position p0, wrapping to a fresh sequence at the end of the cache"""
+        done = 0
+        while done < n:
+            p = (p0 + done) % S
+            c = min(n - done, S - p)
+            if p == 0:
+                m.set_state(int(forced[0]), 0)
+            m.run_steps(p, c, use_graph)
+            done += c
+        return (p0 + n) % S
+
+    # lay the timed window at the end of the sequence: [setup | warmup W | timed K] ends at position S-1
+    span = (W + K) % S if (W + K) % S else min(W + K, S)
+    start = (S - span) % S
+    m.set_state(int(forced[0]), 0)
+    pos = run_span(0, start) if start else 0
+    pos = run_span(pos, W)
+    timed_positions = [(pos + i) % S for i in range(K)]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    e0, e1 = ctx.event(), ctx.event()
+    barrier()
+    t0 = time.perf_counter()
+    ctx.record(e0)
+    run_span(pos, K)
+    ctx.record(e1)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    dt = t1 - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    dev_ms = ctx.elapsed_ms(e0, e1)
+    ms_per_step = dt * 1e3 / K
+    value = world * K / dt
+
+    out = None
+    if rank == 0:
+        bytes_steps = [m.step_bytes(p) for p in timed_positions]
+        mean_bytes = float(np.mean(bytes_steps))
+        out = {
+            "metric": "tokens/sec/GPU Qwen3 4-bit prefill+decode; achieved HBM GB/s vs peak",
+            "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u4 weights (PackedQ RTN g128) x bf16 activations, fp32 accumulate; bf16 KV",
+            "data": "synthetic",
+            "config": {"workload": "Qwen3-0.6B 4-bit PackedQ greedy decode, 1xMI355X per replica, seq=2048: prompt 128, timed positions %d..%d"
+                                   % (timed_positions[0], timed_positions[-1]),
+                       "lm_head": args.head, "replicas": world, "hipgraph": use_graph, "device_ms_per_step": round(dev_ms / K, 5)},
+            "step_roofline": {"bound": "hbm", "bytes_per_step": int(mean_bytes), "achieved": round(mean_bytes * (value / world) / 1e9, 1),
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(mean_bytes * (value / world) / 1e9 / HBM_PEAK_GBS, 4)},
+        }
+        out["roofline"] = kernel_roofline(m, ctx, cfg)
+        out["cpu_baseline"] = cpu_baseline(m, cfg, forced, args.cpu_seconds) if (world == 1 and args.cpu_seconds > 0) else None
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def kernel_roofline(m, ctx, cfg, reps=200):
+    """The dominant kernel of the step by bytes and by time: the LM-head mat-vec (kf::gemv_kernel<BF16, ., ARGMAX>, 311 MB of
+    bf16 rows read once).  Timed alone with HIP events on the launch stream; achieved = algorithmic bytes / mean duration."""
+    import ctypes as C
+    import torch
+    from koifish_amd import lib as L
+    head = m.weights[(-1, 1)]
+    x = torch.randn(cfg["dim"], device=ctx.device).to(torch.bfloat16)
+    nw = torch.ones(cfg["dim"], device=ctx.device, dtype=torch.bfloat16)
+    logits = torch.empty(head.ne0, dtype=torch.bfloat16, device=ctx.device)
+    state = torch.zeros(4, dtype=torch.int32, device=ctx.device)
+    d = head.desc()
+
+    def launch():
+        L.check(ctx.hip.kf_norm_lm_head(ctx.h, x.data_ptr(), nw.data_ptr(), 1e-6, C.byref(d), logits.data_ptr(), state.data_ptr(), None,
+                                        ctx._head_ws.data_ptr()), "kf_norm_lm_head")
+    for _ in range(10):
+        launch()
+    e0, e1 = ctx.event(), ctx.event()
+    ctx.record(e0)
+    for _ in range(reps):
+        launch()
+    ctx.record(e1)
+    ms = ctx.elapsed_ms(e0, e1) / reps
+    nbytes = head.algorithmic_bytes() + cfg["dim"] * 4 + head.ne0 * 2  # weights + x + norm weight + logits written
+    ach = nbytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "kf::gemv_kernel<bf16, argmax> (final norm + LM head 151936x1024 + greedy pick)", "achieved": round(ach, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": int(nbytes),
+            "us_per_launch": round(ms * 1e3, 2)}
+
+
+def cpu_baseline(m, cfg, forced, budget_s):
+    """The CPU oracle (a port: no runnable CPU forward exists in the reference) decoding the SAME 4-bit model on this host's
+    cores: weights and the KV rows of a 128-token prompt are copied from the GPU model, then it decodes from position 128 until
+    the time budget is used."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from koifish_amd import lib as L
+    from oracle import oracle as O
+
+    def host_weight(w):
+        blob = w.blob.cpu().numpy()
+        data = blob[:w.szData]
+        if w.type == L.BF16:
+            return O.QWeight(O.BF16, w.ne0, w.ne1, data.view(np.uint16))
+        g = blob[w.szData:].view(np.uint16)
+        z0 = w.ne0 + w.ne1
+        return O.QWeight(w.type, w.ne0, w.ne1, data, g[z0:z0 + w.nGroup].copy(), g[z0 + w.nGroup:z0 + 2 * w.nGroup].copy(), w.lGroup, w.qBias)
+
+    def host_norm(t):
+        return t.view(torch.int16).cpu().numpy().view(np.uint16)
+
+    # norms were registered in order: final, then per layer 4
+    norms = [t for t in m._keep if isinstance(t, torch.Tensor) and t.dtype == torch.bfloat16 and t.dim() == 1]
+    ow = {"embed": host_weight(m.weights[(-1, 0)]), "final_norm": host_norm(norms[0]), "layers": []}
+    ow["head"] = ow["embed"] if m.weights[(-1, 1)] is m.weights[(-1, 0)] else host_weight(m.weights[(-1, 1)])
+    for li in range(cfg["n_layer"]):
+        d = {s: host_weight(m.weights[(li, si)]) for si, s in enumerate(O.SLOTS)}
+        for si, s in enumerate(O.NORMS):
+            d[s] = host_norm(norms[1 + 4 * li + si])
+        ow["layers"].append(d)
+    om = O.Qwen3Oracle(cfg, ow)
+    p0 = 128
+    gk, gv = m.kv_to_host()
+    ok, ov = om.kv()
+    ok[:, :p0] = gk[:, :p0]
+    ov[:, :p0] = gv[:, :p0]
+    gpu_ids = m.tokens_out(cfg["max_seq"])
+    tok, n, match = int(gpu_ids[p0 - 1]), 0, True
+    t0 = time.perf_counter()
+    while True:
+        nxt, _, _ = om.decode(tok, p0 + n, want_logits=False)
+        match = match and (nxt == int(gpu_ids[p0 + n]))
+        tok = int(gpu_ids[p0 + n])  # teacher-forced on the GPU's ids so both decode the same sequence
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or p0 + n >= cfg["max_seq"] - 1:
+            break
+    return {"value": round(n / el, 3), "unit": "tokens/s", "cores": O.num_threads(), "kind": "port",
+            "sample": "%d decode steps at positions %d..%d of the same 4-bit model, OpenMP over output rows" % (n, p0, p0 + n - 1),
+            "greedy_ids_match_gpu": bool(match)}
+
+
+if __name__ == "__main__":
+    main()

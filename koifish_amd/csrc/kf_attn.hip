@@ -15,6 +15,19 @@
 
 namespace kf {
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// sum over the 2^lg (<= 16) lanes of each aligned lane group, DPP only
+__device__ __forceinline__ float group_sum16(float v, int lg) {
+    if (lg >= 1) v += dpp_f<0xB1>(v);
+    if (lg >= 2) v += dpp_f<0x4E>(v);
+    if (lg >= 3) v += dpp_f<0x141>(v);
+    if (lg >= 4) v += dpp_f<0x140>(v);
+    return v;
+}
+
 // Prepare one head: optional per-head RMSNorm (s rounded to bf16 first, then (a*s)*w, RN store) and rotate-half
 // RoPE from the host-built (cos,sin) table.  One wave per head; lane j handles the pair (j, j + hd/2).
 // Result: bf16-rounded values as floats in dst[hd].
@@ -45,13 +58,15 @@ __device__ __forceinline__ void prep_head(const uint16_t* __restrict__ src, cons
     }
 }
 
+constexpr int ATTN_U = 4; /* key tiles kept in flight per wave */
+
 template <int GQ>
 __global__ void __launch_bounds__(256) attn_partial_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int hd = a.hd, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* qf = reinterpret_cast<float*>(smem_raw);  // [GQ][hd]
     float* knew = qf + GQ * hd;                      // [hd]
-    float* comb = knew + hd;                         // [16][GQ][hd+2]
+    float* comb = knew + hd;                         // [4*KPW][GQ][PS]
 
     const int pos = a.d_pos ? *a.d_pos : a.pos;
     const int len = pos + 1;
@@ -61,7 +76,7 @@ __global__ void __launch_bounds__(256) attn_partial_kernel(const AttnArgs a) {
     int t1 = t0 + chunk;
     if (t1 > len) t1 = len;
     const int h0 = kvh * GQ;
-    const int PS = hd + 2;
+    const int PS = hd + 4; /* {acc[hd], m, l, pad, pad}: keeps every partial 16-byte aligned */
 
     if (t0 >= len) { /* empty slice: neutral partial */
         for (int i = tid; i < GQ * PS; i += blockDim.x) {
@@ -71,10 +86,32 @@ __global__ void __launch_bounds__(256) attn_partial_kernel(const AttnArgs a) {
         return;
     }
 
+    // LPK lanes per key (8 dims each), KPW keys per wave step, 4 waves interleaved over the slice
+    const int LPK = hd >> 3, KPW = 64 / LPK, lpk_log2 = __builtin_ctz(LPK);
+    const int grp = lane / LPK, d0 = (lane - grp * LPK) * 8;
+    const bool has_new = a.k_raw != nullptr;
+    const int tstart = t0 + wave * KPW + grp, tstride = 4 * KPW;
+
+    // ---- issue the first K/V tiles before anything that depends on the previous kernel's q
+    u32x4 kk[ATTN_U], vv[ATTN_U];
+    auto issue = [&](int tb) {
+#pragma unroll
+        for (int u = 0; u < ATTN_U; u++) {
+            const int t = tb + u * tstride;
+            kk[u] = u32x4{0, 0, 0, 0}, vv[u] = u32x4{0, 0, 0, 0};
+            if (t < t1) {
+                const size_t off = (size_t)t * a.kv_stride + (size_t)kvh * hd + d0;
+                vv[u] = *reinterpret_cast<const u32x4*>(a.vcache + off);
+                if (!(has_new && t == pos)) kk[u] = *reinterpret_cast<const u32x4*>(a.kcache + off);
+            }
+        }
+    };
+    issue(tstart);
+
     // ---- prologue: q heads of this group, and the new key when it lies in this slice
     const float* tab_pos = a.rope_table ? a.rope_table + (size_t)pos * hd : nullptr;
     for (int hq = wave; hq < GQ; hq += 4) prep_head(a.q + (size_t)(h0 + hq) * hd, a.rope_table ? a.wq_norm : nullptr, tab_pos, hd, a.eps, qf + hq * hd);
-    const bool own_new = a.k_raw && (pos >= t0) && (pos < t1);
+    const bool own_new = has_new && (pos >= t0) && (pos < t1);
     if (own_new && wave == (GQ & 3)) prep_head(a.k_raw + (size_t)kvh * hd, a.wk_norm, tab_pos, hd, a.eps, knew);
     __syncthreads();
     if (own_new) {
@@ -82,9 +119,6 @@ __global__ void __launch_bounds__(256) attn_partial_kernel(const AttnArgs a) {
         for (int i = tid; i < hd; i += blockDim.x) krow[i] = f2bf(knew[i]);
     }
 
-    // ---- main loop: LPK lanes per key (8 dims each), KPW keys per wave step
-    const int LPK = hd >> 3, KPW = 64 / LPK;
-    const int grp = lane / LPK, d0 = (lane - grp * LPK) * 8;
     float qreg[GQ][8];
 #pragma unroll
     for (int hq = 0; hq < GQ; hq++)
@@ -99,48 +133,47 @@ __global__ void __launch_bounds__(256) attn_partial_kernel(const AttnArgs a) {
         for (int i = 0; i < 8; i++) acc[hq][i] = 0.f;
     }
     const float den = a.inv_sqrt_hd_den; /* sqrtf(hd): score /= sqrtf(head_dim) (operator.cuh:630) */
-    for (int tb = t0 + wave * KPW; tb < t1; tb += 4 * KPW) {
-        const int t = tb + grp;
-        const bool valid = t < t1;
-        float kf_[8], vf_[8];
-        if (valid) {
-            const size_t off = (size_t)t * a.kv_stride + (size_t)kvh * hd + d0;
-            const u32x4 vv = *reinterpret_cast<const u32x4*>(a.vcache + off);
-            const uint32_t vw[4] = {vv.x, vv.y, vv.z, vv.w};
+    for (int tb = tstart; tb - grp < t1; tb += ATTN_U * tstride) {
+        u32x4 ck[ATTN_U], cv[ATTN_U];
 #pragma unroll
-            for (int i = 0; i < 4; i++) vf_[2 * i] = bf_lo(vw[i]), vf_[2 * i + 1] = bf_hi(vw[i]);
-            if (a.k_raw && t == pos) {
+        for (int u = 0; u < ATTN_U; u++) ck[u] = kk[u], cv[u] = vv[u];
+        if (tb - grp + ATTN_U * tstride < t1) issue(tb + ATTN_U * tstride);
+#pragma unroll
+        for (int u = 0; u < ATTN_U; u++) {
+            const int t = tb + u * tstride;
+            const bool valid = t < t1;
+            float kf_[8], vf_[8];
+            const uint32_t vw[4] = {cv[u].x, cv[u].y, cv[u].z, cv[u].w}, kw[4] = {ck[u].x, ck[u].y, ck[u].z, ck[u].w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                vf_[2 * i] = bf_lo(vw[i]), vf_[2 * i + 1] = bf_hi(vw[i]);
+                kf_[2 * i] = bf_lo(kw[i]), kf_[2 * i + 1] = bf_hi(kw[i]);
+            }
+            if (has_new && valid && t == pos) {
 #pragma unroll
                 for (int i = 0; i < 8; i++) kf_[i] = knew[d0 + i];
-            } else {
-                const u32x4 kk = *reinterpret_cast<const u32x4*>(a.kcache + off);
-                const uint32_t kw[4] = {kk.x, kk.y, kk.z, kk.w};
-#pragma unroll
-                for (int i = 0; i < 4; i++) kf_[2 * i] = bf_lo(kw[i]), kf_[2 * i + 1] = bf_hi(kw[i]);
             }
-        } else {
+            if (tb - grp + u * tstride >= t1) continue; /* wave-uniform: the whole tile is past the slice */
 #pragma unroll
-            for (int i = 0; i < 8; i++) kf_[i] = 0.f, vf_[i] = 0.f;
-        }
+            for (int hq = 0; hq < GQ; hq++) {
+                float s = 0.f;
 #pragma unroll
-        for (int hq = 0; hq < GQ; hq++) {
-            float s = 0.f;
+                for (int i = 0; i < 8; i++) s = fmaf(qreg[hq][i], kf_[i], s);
+                s = group_sum16(s, lpk_log2);
+                s = round_bf16(s / den);
+                if (valid) {
+                    if (s > m[hq]) {
+                        const float sc = kf_expf(m[hq] - s);
+                        l[hq] *= sc;
 #pragma unroll
-            for (int i = 0; i < 8; i++) s = fmaf(qreg[hq][i], kf_[i], s);
-            for (int mk = LPK >> 1; mk > 0; mk >>= 1) s += __shfl_xor(s, mk, 64);
-            s = round_bf16(s / den);
-            if (valid) {
-                if (s > m[hq]) {
-                    const float sc = kf_expf(m[hq] - s);
-                    l[hq] *= sc;
+                        for (int i = 0; i < 8; i++) acc[hq][i] *= sc;
+                        m[hq] = s;
+                    }
+                    const float p = kf_expf(s - m[hq]);
+                    l[hq] += p;
 #pragma unroll
-                    for (int i = 0; i < 8; i++) acc[hq][i] *= sc;
-                    m[hq] = s;
+                    for (int i = 0; i < 8; i++) acc[hq][i] = fmaf(p, vf_[i], acc[hq][i]);
                 }
-                const float p = kf_expf(s - m[hq]);
-                l[hq] += p;
-#pragma unroll
-                for (int i = 0; i < 8; i++) acc[hq][i] = fmaf(p, vf_[i], acc[hq][i]);
             }
         }
     }
@@ -174,19 +207,24 @@ __global__ void __launch_bounds__(256) attn_partial_kernel(const AttnArgs a) {
     }
 }
 
-// merge the per-slice partials: grid = n_head, block = hd
+// merge the per-slice partials: grid = n_head, block = hd.  (The decode step folds this into the o_proj mat-vec's
+// prologue -- kf_gemv.hip -- with the same operation order; this kernel serves the stand-alone kf_attn_decode.)
 __global__ void attn_merge_kernel(const float* __restrict__ part, uint16_t* __restrict__ out, int hd, int nsp) {
-    const int h = blockIdx.x, d = threadIdx.x, PS = hd + 2;
+    __shared__ float ms[KF_ATTN_MAX_SPLITS], sc[KF_ATTN_MAX_SPLITS], ls[KF_ATTN_MAX_SPLITS];
+    const int h = blockIdx.x, d = threadIdx.x, PS = hd + 4;
     const float* p = part + (size_t)h * nsp * PS;
+    for (int s = d; s < nsp; s += blockDim.x) ms[s] = p[(size_t)s * PS + hd], ls[s] = p[(size_t)s * PS + hd + 1];
+    __syncthreads();
     float M = -__builtin_inff();
-    for (int s = 0; s < nsp; s++) M = fmaxf(M, p[(size_t)s * PS + hd]);
+    for (int s = 0; s < nsp; s++) M = fmaxf(M, ms[s]);
+    for (int s = d; s < nsp; s += blockDim.x) sc[s] = (ms[s] == -__builtin_inff()) ? 0.f : kf_expf(ms[s] - M);
+    __syncthreads();
     float o = 0.f, L = 0.f;
+#pragma unroll 4
     for (int s = 0; s < nsp; s++) {
-        const float ms = p[(size_t)s * PS + hd];
-        if (ms == -__builtin_inff()) continue;
-        const float sc = kf_expf(ms - M);
-        o = fmaf(p[(size_t)s * PS + d], sc, o);
-        L = fmaf(p[(size_t)s * PS + hd + 1], sc, L);
+        if (ms[s] == -__builtin_inff()) continue;
+        o = fmaf(p[(size_t)s * PS + d], sc[s], o);
+        L = fmaf(ls[s], sc[s], L);
     }
     const float inv = 1.0f / L;
     out[(size_t)h * hd + d] = f2bf(o * inv);
@@ -205,23 +243,27 @@ __global__ void __launch_bounds__(64) qknorm_rope_kernel(uint16_t* q, uint16_t* 
     for (int i = threadIdx.x; i < hd; i += 64) src[i] = f2bf(buf[i]);
 }
 
-int attn_launch(hipStream_t st, AttnArgs& a) {
-    const int hd = a.hd;
-    if (hd < 64 || hd > 128 || (hd & (hd - 1)) != 0) return KF_INVALID_ARGS; /* 8 dims per lane, one RoPE trip per wave */
-    if (a.n_kv <= 0 || a.n_head % a.n_kv != 0) return KF_INVALID_ARGS;
-    const int GQ = a.n_head / a.n_kv;
-    // slices: ~64 keys each, enough workgroups to cover the chip, bounded by the scratch layout
-    const int len_bound = a.pos + 1;
-    int nsp = (len_bound + 63) / 64;
-    int cap = 512 / a.n_kv;
+// slices: ~64 keys each, enough workgroups to cover the chip, bounded by the scratch layout
+int attn_splits(int pos_bound, int n_kv) {
+    int nsp = (pos_bound + 1 + 63) / 64;
+    int cap = 512 / n_kv;
     if (cap < 1) cap = 1;
     if (nsp > cap) nsp = cap;
     if (nsp > KF_ATTN_MAX_SPLITS) nsp = KF_ATTN_MAX_SPLITS;
     if (nsp < 1) nsp = 1;
+    return nsp;
+}
+
+int attn_launch(hipStream_t st, AttnArgs& a, bool merge) {
+    const int hd = a.hd;
+    if (hd < 64 || hd > 128 || (hd & (hd - 1)) != 0) return KF_INVALID_ARGS; /* 8 dims per lane, one RoPE trip per wave */
+    if (a.n_kv <= 0 || a.n_head % a.n_kv != 0) return KF_INVALID_ARGS;
+    const int GQ = a.n_head / a.n_kv;
+    const int nsp = attn_splits(a.pos, a.n_kv);
     a.n_splits = nsp;
     a.inv_sqrt_hd_den = sqrtf((float)hd);
     const int KPW = 64 / (hd >> 3);
-    const size_t smem = sizeof(float) * ((size_t)GQ * hd + hd + (size_t)4 * KPW * GQ * (hd + 2));
+    const size_t smem = sizeof(float) * ((size_t)GQ * hd + hd + (size_t)4 * KPW * GQ * (hd + 4));
     dim3 grid(nsp, a.n_kv);
     switch (GQ) {
         case 1: hipLaunchKernelGGL((attn_partial_kernel<1>), grid, dim3(256), smem, st, a); break;
@@ -230,7 +272,7 @@ int attn_launch(hipStream_t st, AttnArgs& a) {
         case 8: hipLaunchKernelGGL((attn_partial_kernel<8>), grid, dim3(256), smem, st, a); break;
         default: return KF_INVALID_ARGS;
     }
-    hipLaunchKernelGGL(attn_merge_kernel, dim3(a.n_head), dim3(hd), 0, st, a.part, a.out, hd, nsp);
+    if (merge) hipLaunchKernelGGL(attn_merge_kernel, dim3(a.n_head), dim3(hd), 0, st, a.part, a.out, hd, nsp);
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 

@@ -155,149 +155,243 @@ struct BlockDot<FMT_Q1> {
 };
 
 // ------------------------------------------------------------------------------------------------ kernel
-// LDS: x as u32x4 chunks [XCH][nBlk]  (K*2 bytes) + reduction scratch.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// sum over the 2^lg lanes of each aligned lane group (lg wave-uniform); every lane of the group gets the sum.
+// DPP inside a 16-lane row (quad_perm xor1, xor2, row_half_mirror, row_mirror), two cross-row exchanges above it.
+__device__ __forceinline__ float group_sum(float v, int lg) {
+    if (lg >= 1) v += dpp_f<0xB1>(v);
+    if (lg >= 2) v += dpp_f<0x4E>(v);
+    if (lg >= 3) v += dpp_f<0x141>(v);
+    if (lg >= 4) v += dpp_f<0x140>(v);
+    if (lg >= 5) v += __shfl_xor(v, 16, 64);
+    if (lg >= 6) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+template <int G, bool PAIRED>
+struct Batch {
+    u32x4 w[G];
+    u32x4 w2[PAIRED ? G : 1];
+    float st[G], ze[G];
+    float st2[PAIRED ? G : 1], ze2[PAIRED ? G : 1];
+};
+
+// LDS: x as u32x4 chunks [XCH][nBlk] (K*2 bytes) | 256 B reduction scratch | attention-merge scratch.
+// Each wave keeps two batches of G blocks in flight: the first batch is issued BEFORE the x prologue so that the
+// weight stream's HBM latency overlaps the (dependent) activation load + norm.
 template <int FMT, int G, int MODE>
 __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     using BD = BlockDot<FMT>;
+    constexpr bool PAIRED = (MODE == GEMV_PAIRED);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);
     double* red = reinterpret_cast<double*>(smem_raw + (size_t)a.K * 2);
 
     const int tid = threadIdx.x, lane = tid & 63, wave_in_blk = tid >> 6;
-    const int nBlk = a.nBlk;
-    const int pos = a.d_pos ? *a.d_pos : a.pos;
-
-    // ---- prologue: stage x (optionally RMS-normalised: rms_norm_kernel, layernorm.cuh:800-847) into LDS
-    {
-        float mul = 1.0f;
-        if (a.norm_w) {
-            double ss = block_sumsq_bf16(a.x, a.K, red);
-            float val = fmaf((float)ss, a.inv_dim, a.eps);
-            mul = 1.0f / sqrtf(val);
-        }
-        uint16_t* xs16 = reinterpret_cast<uint16_t*>(xs);
-        constexpr int XCH = BD::XCH;
-        // element e of block column c, chunk j (e = c*EPB + j*8 + i)  ->  LDS halfword ((j*nBlk + c)*8 + i)
-        for (int e8 = tid; e8 < a.K / 8; e8 += blockDim.x) {
-            const int c = e8 / XCH, j = e8 - c * XCH;
-            const u32x4 raw = *reinterpret_cast<const u32x4*>(a.x + (size_t)e8 * 8);
-            u32x4 o = raw;
-            if (a.norm_w) {
-                const u32x4 nw = *reinterpret_cast<const u32x4*>(a.norm_w + (size_t)e8 * 8);
-                const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w}, ww[4] = {nw.x, nw.y, nw.z, nw.w};
-                uint32_t ow[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    float v0 = (bf_lo(rw[k]) * mul) * bf_lo(ww[k]), v1 = (bf_hi(rw[k]) * mul) * bf_hi(ww[k]);
-                    ow[k] = pack_bf16x2(v0, v1);
-                }
-                o.x = ow[0], o.y = ow[1], o.z = ow[2], o.w = ow[3];
-            }
-            xs[j * nBlk + c] = o;
-            (void)xs16;
-        }
-        __syncthreads();
-    }
-
-    // ---- main: this wave's slots
+    const int nBlk = a.nBlk, iters = a.iters;
     const int LPR = 1 << a.lpr_log2, RPS = 64 >> a.lpr_log2;
     const int sub = lane >> a.lpr_log2, ll = lane & (LPR - 1);
     const long gwave = (long)blockIdx.x * (blockDim.x >> 6) + wave_in_blk;
     const long s_begin = gwave * a.spw;
     long s_end = s_begin + a.spw;
     if (s_end > a.total_slots) s_end = a.total_slots;
+    const int nbatch = s_end > s_begin ? (int)((s_end - s_begin + G - 1) / G) : 0;
+    const int nsteps = nbatch * iters;
 
+    // Job fields are picked with selects on constant indices (kernel arguments live in SGPRs); indexing a.job[]
+    // with a run-time value would turn every access into a vector load from the kernarg segment, and the waits for
+    // those loads serialise the weight stream.  Slots are wave-uniform, so the job index is made scalar.
+    auto jsel = [&](long s) -> int {
+        int j = 0;
+        if (a.njobs > 1 && s >= a.job[1].slot0) j = 1;
+        if (a.njobs > 2 && s >= a.job[2].slot0) j = 2;
+        return __builtin_amdgcn_readfirstlane(j);
+    };
+#define JF(j, f) ((j) == 0 ? a.job[0].f : ((j) == 1 ? a.job[1].f : a.job[2].f))
+    auto slot = [&](long s, int& j, int& row) -> bool {
+        j = jsel(s);
+        row = (int)(s - JF(j, slot0)) * RPS + sub;
+        return (s < s_end) && (row < JF(j, M));
+    };
+    auto load = [&](int bi, int it, Batch<G, PAIRED>& b) {
+        const long s0 = s_begin + (long)bi * G;
+        const int col = it * LPR + ll;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            int j, row;
+            const bool ok = slot(s0 + g, j, row) && (col < nBlk);
+            b.w[g] = u32x4{0, 0, 0, 0};
+            b.st[g] = b.ze[g] = 0.f;
+            if (PAIRED) b.w2[g] = u32x4{0, 0, 0, 0}, b.st2[g] = b.ze2[g] = 0.f;
+            if (ok) {
+                const size_t bidx = (size_t)row * nBlk + col;
+                b.w[g] = ld_nt(reinterpret_cast<const u32x4*>(JF(j, w)) + bidx);
+                if (PAIRED) b.w2[g] = ld_nt(reinterpret_cast<const u32x4*>(a.job[1].w) + bidx);
+                if (BD::HAS_GAMA) {
+                    const size_t gi = bidx >> a.gshift; /* group = element / lGroup, lGroup / EPB a power of two */
+                    b.st[g] = bf2f(JF(j, step)[gi]), b.ze[g] = bf2f(JF(j, zero)[gi]);
+                    if (PAIRED) b.st2[g] = bf2f(a.job[1].step[gi]), b.ze2[g] = bf2f(a.job[1].zero[gi]);
+                }
+            }
+        }
+    };
+
+    Batch<G, PAIRED> cur, nxt;
+    if (nsteps > 0) load(0, 0, cur);
+    const int pos = a.d_pos ? *a.d_pos : a.pos;
+
+    // ---- prologue: stage x into LDS as packed bf16 chunks
+    {
+        constexpr int XCH = BD::XCH;
+        if (a.attn_part) {
+            // x = merged attention output: the split-KV partials {acc[hd], m, l} per (head, slice) are combined exactly as
+            // attn_merge_kernel does (same order over slices), rounded to bf16 once.
+            const int H = a.attn_heads, nsp = a.attn_nsp, hd = a.attn_hd, PS = hd + 4; /* partial stride of kf_attn.hip */
+            float* ms = reinterpret_cast<float*>(smem_raw + (size_t)a.K * 2 + 256);
+            float* ls = ms + H * nsp;
+            float* sc = ls + H * nsp;
+            float* invL = sc + H * nsp;
+            for (int i = tid; i < H * nsp; i += blockDim.x) {
+                const float* p = a.attn_part + (size_t)i * PS;
+                ms[i] = p[hd], ls[i] = p[hd + 1];
+            }
+            __syncthreads();
+            for (int i = tid; i < H * nsp; i += blockDim.x) {
+                const int h = i / nsp;
+                float M = -__builtin_inff();
+                for (int t = 0; t < nsp; t++) M = fmaxf(M, ms[h * nsp + t]);
+                sc[i] = (ms[i] == -__builtin_inff()) ? 0.f : kf_expf(ms[i] - M);
+            }
+            __syncthreads();
+            for (int h = tid; h < H; h += blockDim.x) {
+                float L = 0.f;
+                for (int t = 0; t < nsp; t++)
+                    if (ms[h * nsp + t] != -__builtin_inff()) L = fmaf(ls[h * nsp + t], sc[h * nsp + t], L);
+                invL[h] = 1.0f / L;
+            }
+            __syncthreads();
+            for (int e8 = tid; e8 < a.K / 8; e8 += blockDim.x) {
+                const int h = (e8 * 8) / hd, d0 = (e8 * 8) - h * hd;
+                float o[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) o[i] = 0.f;
+                const float* pb = a.attn_part + (size_t)h * nsp * PS + d0;
+#pragma unroll 4
+                for (int t = 0; t < nsp; t++) {
+                    const float scl = sc[h * nsp + t];
+                    if (ms[h * nsp + t] == -__builtin_inff()) continue;
+                    const float4 p0 = *reinterpret_cast<const float4*>(pb + (size_t)t * PS);
+                    const float4 p1 = *reinterpret_cast<const float4*>(pb + (size_t)t * PS + 4);
+                    o[0] = fmaf(p0.x, scl, o[0]), o[1] = fmaf(p0.y, scl, o[1]), o[2] = fmaf(p0.z, scl, o[2]), o[3] = fmaf(p0.w, scl, o[3]);
+                    o[4] = fmaf(p1.x, scl, o[4]), o[5] = fmaf(p1.y, scl, o[5]), o[6] = fmaf(p1.z, scl, o[6]), o[7] = fmaf(p1.w, scl, o[7]);
+                }
+                const float il = invL[h];
+                u32x4 ov;
+                ov.x = pack_bf16x2(o[0] * il, o[1] * il), ov.y = pack_bf16x2(o[2] * il, o[3] * il);
+                ov.z = pack_bf16x2(o[4] * il, o[5] * il), ov.w = pack_bf16x2(o[6] * il, o[7] * il);
+                const int c = e8 / XCH, j = e8 - c * XCH;
+                xs[j * nBlk + c] = ov;
+                if (a.attn_out && blockIdx.x == 0) *reinterpret_cast<u32x4*>(a.attn_out + (size_t)e8 * 8) = ov;
+            }
+        } else {
+            float mul = 1.0f;
+            if (a.norm_w) { /* rms_norm_kernel, layernorm.cuh:800-847 */
+                double ss = block_sumsq_bf16(a.x, a.K, red);
+                float val = fmaf((float)ss, a.inv_dim, a.eps);
+                mul = 1.0f / sqrtf(val);
+            }
+            // element e of block column c, chunk j (e = c*EPB + j*8 + i)  ->  LDS chunk (j*nBlk + c)
+            for (int e8 = tid; e8 < a.K / 8; e8 += blockDim.x) {
+                const int c = e8 / XCH, j = e8 - c * XCH;
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(a.x + (size_t)e8 * 8);
+                u32x4 o = raw;
+                if (a.norm_w) {
+                    const u32x4 nw = *reinterpret_cast<const u32x4*>(a.norm_w + (size_t)e8 * 8);
+                    const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w}, ww[4] = {nw.x, nw.y, nw.z, nw.w};
+                    uint32_t ow[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        float v0 = (bf_lo(rw[k]) * mul) * bf_lo(ww[k]), v1 = (bf_hi(rw[k]) * mul) * bf_hi(ww[k]);
+                        ow[k] = pack_bf16x2(v0, v1);
+                    }
+                    o.x = ow[0], o.y = ow[1], o.z = ow[2], o.w = ow[3];
+                }
+                xs[j * nBlk + c] = o;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- main: pipelined over (batch, iteration) steps
     float best_v = -__builtin_inff();
     int best_i = 0x7fffffff;
-
-    for (long s0 = s_begin; s0 < s_end; s0 += G) {
-        float acc[G], acc2[G];
-        int row[G], jb[G];
-        bool ok[G];
-#pragma unroll
-        for (int g = 0; g < G; g++) {
-            acc[g] = 0.f, acc2[g] = 0.f;
-            long s = s0 + g;
-            int j = 0;
-            if (a.njobs > 1 && s >= a.job[1].slot0) j = 1;
-            if (a.njobs > 2 && s >= a.job[2].slot0) j = 2;
-            jb[g] = j;
-            row[g] = (int)(s - a.job[j].slot0) * RPS + sub;
-            ok[g] = (s < s_end) && (row[g] < a.job[j].M);
+    float acc[G], acc2[PAIRED ? G : 1];
+    int bi = 0, it = 0;       // the step being computed
+    int nbi = 0, nit = 0;     // the step being loaded
+    for (int k = 0; k < nsteps; k++) {
+        if (k + 1 < nsteps) {
+            if (++nit == iters) nit = 0, nbi++;
+            load(nbi, nit, nxt);
         }
-        for (int it = 0; it < a.iters; it++) {
-            const int col = it * LPR + ll;
-            const bool cok = col < nBlk;
-            u32x4 w[G], w2[G];
-            float st[G], ze[G], st2[G], ze2[G];
+        if (it == 0) {
 #pragma unroll
             for (int g = 0; g < G; g++) {
-                w[g] = u32x4{0, 0, 0, 0}, w2[g] = u32x4{0, 0, 0, 0};
-                st[g] = ze[g] = st2[g] = ze2[g] = 0.f;
-                if (ok[g] && cok) {
-                    const GemvJob& jj = a.job[jb[g]];
-                    const size_t bidx = (size_t)row[g] * nBlk + col;
-                    w[g] = ld_nt(reinterpret_cast<const u32x4*>(jj.w) + bidx);
-                    if (BD::HAS_GAMA) {
-                        const size_t gi = bidx * BD::EPB / a.lGroup;
-                        st[g] = bf2f(jj.step[gi]), ze[g] = bf2f(jj.zero[gi]);
-                    }
-                    if (MODE == GEMV_PAIRED) {
-                        const GemvJob& j2 = a.job[1];
-                        w2[g] = ld_nt(reinterpret_cast<const u32x4*>(j2.w) + bidx);
-                        if (BD::HAS_GAMA) {
-                            const size_t gi = bidx * BD::EPB / a.lGroup;
-                            st2[g] = bf2f(j2.step[gi]), ze2[g] = bf2f(j2.zero[gi]);
-                        }
-                    }
+                acc[g] = 0.f;
+                if (PAIRED) acc2[g] = 0.f;
+            }
+        }
+        {
+            int col = it * LPR + ll;
+            if (col >= nBlk) col = nBlk - 1; /* masked lanes carry zero weights; keep their LDS reads in range */
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                int j, row;
+                slot(s_begin + (long)bi * G + g, j, row);
+                const float qb = (float)JF(j, qBias);
+                acc[g] = BD::run(cur.w[g], xs, col, nBlk, cur.st[g], cur.ze[g], -(qb * cur.st[g]), acc[g]);
+                if (PAIRED) {
+                    const float qb2 = (float)a.job[1].qBias;
+                    acc2[g] = BD::run(cur.w2[g], xs, col, nBlk, cur.st2[g], cur.ze2[g], -(qb2 * cur.st2[g]), acc2[g]);
                 }
             }
-            if (cok) {
+        }
+        if (it == iters - 1) {
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                acc[g] = group_sum(acc[g], a.lpr_log2);
+                if (PAIRED) acc2[g] = group_sum(acc2[g], a.lpr_log2);
+            }
+            if (ll == 0) {
 #pragma unroll
                 for (int g = 0; g < G; g++) {
-                    const float qb = (float)a.job[jb[g]].qBias;
-                    acc[g] = BD::run(w[g], xs, col, nBlk, st[g], ze[g], -(qb * st[g]), acc[g]);
-                    if (MODE == GEMV_PAIRED) {
-                        const float qb2 = (float)a.job[1].qBias;
-                        acc2[g] = BD::run(w2[g], xs, col, nBlk, st2[g], ze2[g], -(qb2 * st2[g]), acc2[g]);
+                    int j, r;
+                    if (!slot(s_begin + (long)bi * G + g, j, r)) continue;
+                    uint16_t* y = JF(j, y) + (size_t)pos * JF(j, y_pos_stride);
+                    float v = acc[g];
+                    if (PAIRED) {
+                        // SwiGLU of the two bf16-rounded projections (CU_swiglu_v0, Activation.cu:85-93)
+                        const float gt = round_bf16(v), up = round_bf16(acc2[g]);
+                        y[r] = f2bf((gt * up) / (1.0f + kf_expf(-gt)));
+                        continue;
+                    }
+                    if (a.alpha != 1.0f) v = a.alpha * v;
+                    if (a.beta != 0.0f) v = v + a.beta * bf2f(y[r]);
+                    if (a.bias) v = v + bf2f(a.bias[r]);
+                    uint16_t o = f2bf(v);
+                    if (a.residual) o = f2bf(bf2f(a.residual[r]) + bf2f(o)); /* CU_add3: bf16(x + bf16(W.x)) */
+                    y[r] = o;
+                    if (MODE == GEMV_ARGMAX) {
+                        const float fv = bf2f(o);
+                        if (fv > best_v || (fv == best_v && r < best_i)) best_v = fv, best_i = r;
                     }
                 }
             }
         }
-        // reduce over the LPR lanes of each row
-#pragma unroll
-        for (int g = 0; g < G; g++) {
-            for (int m = LPR >> 1; m > 0; m >>= 1) {
-                acc[g] += __shfl_xor(acc[g], m, 64);
-                if (MODE == GEMV_PAIRED) acc2[g] += __shfl_xor(acc2[g], m, 64);
-            }
-        }
-        if (ll == 0) {
-#pragma unroll
-            for (int g = 0; g < G; g++) {
-                if (!ok[g]) continue;
-                const GemvJob& jj = a.job[jb[g]];
-                const int r = row[g];
-                uint16_t* y = jj.y + (size_t)pos * jj.y_pos_stride;
-                float v = acc[g];
-                if (MODE == GEMV_PAIRED) {
-                    // SwiGLU of the two bf16-rounded projections (CU_swiglu_v0, Activation.cu:85-93)
-                    const float gt = round_bf16(v), up = round_bf16(acc2[g]);
-                    y[r] = f2bf((gt * up) / (1.0f + kf_expf(-gt)));
-                    continue;
-                }
-                if (a.alpha != 1.0f) v = a.alpha * v;
-                if (a.beta != 0.0f) v = v + a.beta * bf2f(y[r]);
-                if (a.bias) v = v + bf2f(a.bias[r]);
-                uint16_t o = f2bf(v);
-                if (a.residual) o = f2bf(bf2f(a.residual[r]) + bf2f(o)); /* CU_add3: bf16(x + bf16(W.x)) */
-                y[r] = o;
-                if (MODE == GEMV_ARGMAX) {
-                    const float fv = bf2f(o);
-                    if (fv > best_v || (fv == best_v && r < best_i)) best_v = fv, best_i = r;
-                }
-            }
-        }
+        cur = nxt;
+        if (++it == iters) it = 0, bi++;
     }
 
     if (MODE == GEMV_ARGMAX) {
@@ -320,6 +414,7 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
             a.amax_idx[blockIdx.x] = best_i;
         }
     }
+#undef JF
 }
 
 // Final pick over the per-workgroup partial maxima, then the decode-state update for graph replay.
@@ -428,6 +523,9 @@ int gemv_launch(hipStream_t st, GemvLaunch& L) {
             jb.zero = w->gama + w->ne0 + w->ne1; /* gama_T(ZERO), GTensor.cpp:456-510 */
             jb.step = jb.zero + (size_t)w->ne0 * w->ne1 / w->lGroup;
             a.lGroup = w->lGroup;
+            const int bpg = w->lGroup / epb; /* blocks per group: must be a power of two (128-element groups always are) */
+            if (bpg < 1 || (bpg & (bpg - 1)) != 0) return KF_QUANT_ERR;
+            a.gshift = __builtin_ctz(bpg);
         }
         jb.M = w->ne0;
         jb.qBias = w->qBias;
@@ -442,8 +540,9 @@ int gemv_launch(hipStream_t st, GemvLaunch& L) {
     }
     if (L.mode == GEMV_PAIRED) a.njobs = 1, a.job[1].slot0 = 0x7fffffff;
     a.total_slots = (int)slots;
-    // one wave per spw slots; aim for ~2048 waves (8 per CU) on large matrices, never fewer than one slot each
-    long spw = (slots + 2047) / 2048;
+    // one wave per spw slots; aim for ~4096 waves (16 per CU) on large matrices, never fewer than one slot each
+    const long target_waves = L.target_waves > 0 ? L.target_waves : 4096;
+    long spw = (slots + target_waves - 1) / target_waves;
     if (spw < 1) spw = 1;
     int G = spw >= 4 ? 4 : (spw >= 2 ? 2 : 1);
     if (L.mode == GEMV_PAIRED && G > 2) G = 2; /* two weight streams per slot: keep register pressure down */
@@ -452,7 +551,11 @@ int gemv_launch(hipStream_t st, GemvLaunch& L) {
     const long waves = (slots + spw - 1) / spw;
     const int blocks = (int)((waves + 3) / 4);
     if (L.mode == GEMV_ARGMAX && blocks > KF_MAX_ARGMAX_PARTIALS) return KF_INTERNAL_ERR;
-    const size_t smem = (size_t)K * 2 + 256;
+    size_t smem = (size_t)K * 2 + 256;
+    if (a.attn_part) {
+        if (a.attn_heads * a.attn_hd != K || a.attn_nsp < 1 || a.attn_nsp > KF_ATTN_MAX_SPLITS) return KF_INVALID_ARGS;
+        smem += sizeof(float) * ((size_t)3 * a.attn_heads * a.attn_nsp + a.attn_heads);
+    }
     if (smem > 160 * 1024) return KF_INVALID_ARGS;
     dim3 grid(blocks);
     switch (fmt) {

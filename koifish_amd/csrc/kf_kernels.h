@@ -8,6 +8,7 @@ namespace kf {
 enum { FMT_BF16 = 0, FMT_F8 = 1, FMT_Q4 = 2, FMT_Q2 = 3, FMT_Q1 = 4 };
 enum { GEMV_PLAIN = 0, GEMV_PAIRED = 1, GEMV_ARGMAX = 2 };
 constexpr int KF_MAX_ARGMAX_PARTIALS = 4096;
+constexpr int KF_ATTN_MAX_SPLITS = 64;
 
 struct GemvJob {
     const void* w;
@@ -23,7 +24,7 @@ struct GemvJob {
 struct GemvArgs {
     GemvJob job[3];
     int njobs;
-    int K, nBlk, lpr_log2, iters, lGroup;
+    int K, nBlk, lpr_log2, iters, lGroup, gshift;
     int spw, total_slots;
     const uint16_t* x;
     const uint16_t* norm_w; /* non-NULL: RMSNorm prologue */
@@ -35,6 +36,10 @@ struct GemvArgs {
     int pos;
     float* amax_val;
     int* amax_idx;
+    /* x = merged split-KV attention partials instead of a.x (o_proj fused with the attention merge) */
+    const float* attn_part;
+    uint16_t* attn_out; /* optional copy of the merged bf16 attention output (workgroup 0 writes it) */
+    int attn_heads, attn_nsp, attn_hd;
 };
 
 struct GemvLaunch {
@@ -42,7 +47,8 @@ struct GemvLaunch {
     const kf_weight* w[3];
     int n;
     int mode;
-    int blocks; /* out */
+    long target_waves; /* 0: default */
+    int blocks;        /* out */
 };
 
 int gemv_launch(hipStream_t st, GemvLaunch& L);
@@ -64,8 +70,8 @@ struct AttnArgs {
     int n_head, n_kv, hd, kv_stride, n_splits;
     float eps, inv_sqrt_hd_den;
 };
-constexpr int KF_ATTN_MAX_SPLITS = 64;
-int attn_launch(hipStream_t st, AttnArgs& a);
+int attn_launch(hipStream_t st, AttnArgs& a, bool merge);
+int attn_splits(int pos_bound, int n_kv);
 int qknorm_rope_launch(hipStream_t st, uint16_t* q, uint16_t* k, const uint16_t* wq, const uint16_t* wk, const float* table, int pos,
                        const int* d_pos, int n_head, int n_kv, int hd, float eps);
 

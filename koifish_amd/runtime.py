@@ -66,6 +66,20 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_STREAM = {}
+
+
+def stream(device=0):
+    """One dedicated (non-default) HIP stream per device, made torch's current stream, so that torch's allocations /
+    copies and the kf_* launches are ordered on the same queue and the queue can be captured into a hipGraph
+    (the legacy default stream cannot)."""
+    if device not in _STREAM:
+        torch.cuda.set_device(device)
+        _STREAM[device] = torch.cuda.Stream(device=device)
+        torch.cuda.set_stream(_STREAM[device])
+    return _STREAM[device]
+
+
 class Context:
     """kf_ctx bound to torch's current stream on `device`."""
 
@@ -76,7 +90,7 @@ class Context:
         torch.cuda.set_device(device)
         self.device = torch.device("cuda", device)
         self.h = C.c_void_p()
-        L.check(self.hip.kf_init(device, C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(self.h)), "kf_init")
+        L.check(self.hip.kf_init(device, C.c_void_p(stream(device).cuda_stream), C.byref(self.h)), "kf_init")
         self._attn_ws = None
         self._head_ws = torch.empty(self.hip.kf_head_scratch_bytes(), dtype=torch.uint8, device=self.device)
 
@@ -227,7 +241,7 @@ class Qwen3:
         torch.cuda.set_device(device)
         self.cfg, self.device = dict(cfg), torch.device("cuda", device)
         rc = C.c_int(0)
-        self.h = self.host.kfh_create(device, C.c_void_p(torch.cuda.current_stream().cuda_stream), cfg["dim"], cfg["n_layer"], cfg["n_head"], cfg["n_kv"],
+        self.h = self.host.kfh_create(device, C.c_void_p(stream(device).cuda_stream), cfg["dim"], cfg["n_layer"], cfg["n_head"], cfg["n_kv"],
                                       cfg["head_dim"], cfg["ffn"], cfg["vocab"], cfg["max_seq"], cfg.get("rms_eps", 1e-6), cfg.get("qk_eps", 1e-6),
                                       cfg.get("theta", 1e6), C.byref(rc))
         if not self.h:

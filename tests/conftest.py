@@ -63,3 +63,11 @@ def ulp_diff_bf16(a_u16, b_u16):
         x = x.astype(np.int32)
         return np.where(x & 0x8000, -(x & 0x7FFF), x & 0x7FFF)
     return np.abs(key(np.asarray(a_u16)) - key(np.asarray(b_u16)))
+
+
+def close_bf16(a_u16, b_u16, rel_of_max=2.0 ** -10):
+    """True where two bf16 arrays agree to <= 1 ulp, or -- for elements that are small against the vector's scale,
+    where an ulp is far below the fp32 accumulation noise of the whole sum -- to rel_of_max * max|b|."""
+    a = (np.asarray(a_u16).astype(np.uint32) << 16).view(np.float32)
+    b = (np.asarray(b_u16).astype(np.uint32) << 16).view(np.float32)
+    return (ulp_diff_bf16(a_u16, b_u16) <= 1) | (np.abs(a - b) <= rel_of_max * np.abs(b).max())

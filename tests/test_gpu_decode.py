@@ -43,11 +43,13 @@ def test_teacher_forced_logits_and_ids(cfg_name, layer_type, head_type):
         assert g_next == O.argmax_bf16(g_logits), "device arg-max is not the first maximum of its own logits"
         assert g_next == o_next, "step %d: greedy id %d vs oracle %d" % (pos, g_next, o_next)
         tok = int(prompt[pos + 1]) if pos + 1 < len(prompt) else o_next
-    # KV cache rows written so far agree with the oracle's to <= 1 bf16 ulp
+    # KV cache rows written so far agree with the oracle's within the same relative bound as the logits
     gk, gv = gm.kv_to_host()
     ok, ov = om.kv()
-    assert ulp_diff_bf16(gk[:, :steps], ok[:, :steps]).max() <= 1
-    assert ulp_diff_bf16(gv[:, :steps], ov[:, :steps]).max() <= 1
+    for g, o in ((gk, ok), (gv, ov)):
+        for l in range(cfg["n_layer"]):
+            a, b = O.bf16_to_f32(g[l, :steps]), O.bf16_to_f32(o[l, :steps])
+            assert np.abs(a - b).max() <= LOGIT_TOL * np.abs(b).max(), "layer %d KV rows differ" % l
     gm.close()
 
 

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import bf16_t, u16, ulp_diff_bf16
+from conftest import bf16_t, u16, ulp_diff_bf16, close_bf16
 from koifish_amd import lib as L
 
 pytestmark = pytest.mark.gpu
@@ -201,7 +201,7 @@ def test_attn_decode_vs_oracle(ctx, O, cfg, pos):
     out = u16(ctx.attn_decode(bf16_t(q, ctx.device), bf16_t(kc, ctx.device), bf16_t(vc, ctx.device), pos, nh, nkv, hd))
     ref = O.attn_decode(q, kc, vc, pos, nh, nkv, hd, mode=O.ATTN_FUSED)
     d = ulp_diff_bf16(out, ref)
-    assert d.max() <= 1 and (d > 0).mean() <= 0.02, (d.max(), (d > 0).mean())
+    assert close_bf16(out, ref).all() and (d > 0).mean() <= 0.02, (d.max(), (d > 0).mean())
     # against the reference's own (bf16 score / bf16 probability) rounding chain: stated tolerance 2^-6 of max|out|
     refc = O.bf16_to_f32(O.attn_decode(q, kc, vc, pos, nh, nkv, hd, mode=O.ATTN_REF))
     assert np.abs(O.bf16_to_f32(out) - refc).max() <= 2.0 ** -6 * np.abs(refc).max()
