@@ -117,7 +117,8 @@ int kf_rope_table_host(float* h_table, int n_pos, int hd, float theta);
 
 /* attention triple of SelfAttention::cuInfer (QKV.cu:669-673; operator.cuh:572-632,251-277,649-668), fused,
  * full causal length.  q bf16 [n_head*hd] (already normed+roped), kcache/vcache: layer base, row t at
- * t*kv_stride elements; out bf16 [n_head*hd]; scratch: kf_attn_scratch_bytes(). */
+ * t*kv_stride elements; out bf16 [n_head*hd]; scratch: kf_attn_scratch_bytes(), zero-filled ONCE by the caller (the
+ * kernel keeps its arrival counters at zero between launches). */
 int kf_attn_decode(kf_ctx* ctx, const kf_bf16* q, const kf_bf16* kcache, const kf_bf16* vcache, kf_bf16* out, int pos, const int32_t* d_pos,
                    int n_head, int n_kv, int hd, int kv_stride, void* scratch);
 size_t kf_attn_scratch_bytes(int n_head, int hd);
@@ -142,16 +143,10 @@ int kf_norm_linear(kf_ctx* ctx, const kf_bf16* x, const kf_bf16* norm_w_or_null,
 int kf_norm_gateup_swiglu(kf_ctx* ctx, const kf_bf16* x, const kf_bf16* norm_w_or_null, float eps, const kf_weight* gate, const kf_weight* up,
                           kf_bf16* act);
 /* q/k-norm + RoPE + attention in one pass: q raw [n_head*hd], k_raw [n_kv*hd] (the new key before norm/rope,
- * written normed+roped into kcache row pos), v row must already sit in vcache row pos.  out == NULL: leave the
- * partials in scratch for kf_attn_out_linear. */
+ * written normed+roped into kcache row pos), v row must already sit in vcache row pos. */
 int kf_attn_block(kf_ctx* ctx, const kf_bf16* q_raw, const kf_bf16* k_raw, kf_bf16* kcache, const kf_bf16* vcache, kf_bf16* out,
                   const kf_bf16* wq_norm, const kf_bf16* wk_norm, const float* rope_table, int pos, const int32_t* d_pos, int n_head, int n_kv,
                   int hd, int kv_stride, float eps, void* scratch);
-/* kf_attn_block with out == NULL leaves the split-KV partials in `scratch`; this call merges them (same operation order
- * as the stand-alone merge), rounds to bf16 and applies proj_cat + residual in the same launch:
- * y = bf16(residual + bf16(Wo . attn)).  pos_bound must be the `pos` argument given to kf_attn_block. */
-int kf_attn_out_linear(kf_ctx* ctx, const kf_weight* wo, const void* attn_scratch, int pos_bound, int n_head, int n_kv, int hd, kf_bf16* y,
-                       const kf_bf16* residual, kf_bf16* attn_out_or_null);
 /* [final RMSNorm] + LM head + greedy pick; then state update for graph replay: d_state[0] = next token,
  * d_state[1] += 1 (position), d_tokens_out[old pos] = next token (when non-NULL). */
 int kf_norm_lm_head(kf_ctx* ctx, const kf_bf16* x, const kf_bf16* norm_w_or_null, float eps, const kf_weight* w, kf_bf16* logits,

@@ -291,7 +291,8 @@ int kf_qknorm_rope(kf_ctx* c, kf_bf16* q, kf_bf16* k, const kf_bf16* wq, const k
     RET(kf::qknorm_rope_launch(c->stream, q, k, wq, wk, table, pos, d_pos, n_head, n_kv, hd, eps));
 }
 
-size_t kf_attn_scratch_bytes(int n_head, int hd) { return sizeof(float) * (size_t)n_head * kf::KF_ATTN_MAX_SPLITS * (hd + 4); }
+static size_t attn_part_bytes(int n_head, int hd) { return sizeof(float) * (size_t)n_head * kf::KF_ATTN_MAX_SPLITS * (hd + 4); }
+size_t kf_attn_scratch_bytes(int n_head, int hd) { return attn_part_bytes(n_head, hd) + 1024; /* + arrival counters */ }
 
 int kf_attn_decode(kf_ctx* c, const kf_bf16* q, const kf_bf16* kc, const kf_bf16* vc, kf_bf16* out, int pos, const int32_t* d_pos, int n_head, int n_kv, int hd,
                    int kv_stride, void* scratch) {
@@ -300,39 +301,24 @@ int kf_attn_decode(kf_ctx* c, const kf_bf16* q, const kf_bf16* kc, const kf_bf16
     if (!al16(kc) || !al16(vc) || (kv_stride % 8)) return fail(KF_BLAS_UNALIGN, "kf_attn_decode: cache not 16-byte aligned");
     kf::AttnArgs a;
     memset(&a, 0, sizeof(a));
-    a.q = q, a.kcache = const_cast<kf_bf16*>(kc), a.vcache = vc, a.out = out, a.part = (float*)scratch;
+    a.q = q, a.kcache = const_cast<kf_bf16*>(kc), a.vcache = vc, a.out = out, a.part = (float*)((char*)scratch + 1024);
     a.pos = pos, a.d_pos = d_pos, a.n_head = n_head, a.n_kv = n_kv, a.hd = hd, a.kv_stride = kv_stride;
-    RET(kf::attn_launch(c->stream, a, true));
+    a.counters = (int*)scratch; /* the first 1024 bytes: arrival counters (fixed place whatever the shape) */
+    RET(kf::attn_launch(c->stream, a));
 }
 
 int kf_attn_block(kf_ctx* c, const kf_bf16* q_raw, const kf_bf16* k_raw, kf_bf16* kc, const kf_bf16* vc, kf_bf16* out, const kf_bf16* wq, const kf_bf16* wk,
                   const float* table, int pos, const int32_t* d_pos, int n_head, int n_kv, int hd, int kv_stride, float eps, void* scratch) {
     CHKCTX(c);
-    if (!q_raw || !k_raw || !kc || !vc || !scratch || !table) return fail(KF_INVALID_ARGS, "kf_attn_block: null pointer");
+    if (!q_raw || !k_raw || !kc || !vc || !out || !scratch || !table) return fail(KF_INVALID_ARGS, "kf_attn_block: null pointer");
     if (!al16(kc) || !al16(vc) || (kv_stride % 8)) return fail(KF_BLAS_UNALIGN, "kf_attn_block: cache not 16-byte aligned");
     kf::AttnArgs a;
     memset(&a, 0, sizeof(a));
-    a.q = q_raw, a.k_raw = k_raw, a.kcache = kc, a.vcache = vc, a.out = out, a.part = (float*)scratch;
+    a.q = q_raw, a.k_raw = k_raw, a.kcache = kc, a.vcache = vc, a.out = out, a.part = (float*)((char*)scratch + 1024);
     a.wq_norm = wq, a.wk_norm = wk, a.rope_table = table, a.eps = eps;
     a.pos = pos, a.d_pos = d_pos, a.n_head = n_head, a.n_kv = n_kv, a.hd = hd, a.kv_stride = kv_stride;
-    RET(kf::attn_launch(c->stream, a, out != nullptr));
-}
-
-int kf_attn_out_linear(kf_ctx* c, const kf_weight* wo, const void* attn_scratch, int pos_bound, int n_head, int n_kv, int hd, kf_bf16* y,
-                       const kf_bf16* residual, kf_bf16* attn_out_or_null) {
-    CHKCTX(c);
-    int r = check_weight(wo, "kf_attn_out_linear");
-    if (r) return r;
-    if (!attn_scratch || !y || n_kv <= 0) return fail(KF_INVALID_ARGS, "kf_attn_out_linear: null pointer");
-    if (wo->ne1 != n_head * hd) return fail(KF_INVALID_ARGS, "kf_attn_out_linear: o_proj has %d inputs, attention gives %d", wo->ne1, n_head * hd);
-    kf::GemvLaunch L;
-    init_args(L);
-    L.n = 1, L.w[0] = wo, L.mode = kf::GEMV_PLAIN;
-    L.target_waves = 512; /* every workgroup re-reads all partials from L2: keep the grid small */
-    L.args.job[0].y = y, L.args.residual = residual;
-    L.args.attn_part = (const float*)attn_scratch, L.args.attn_out = attn_out_or_null;
-    L.args.attn_heads = n_head, L.args.attn_hd = hd, L.args.attn_nsp = kf::attn_splits(pos_bound, n_kv);
-    RET(kf::gemv_launch(c->stream, L));
+    a.counters = (int*)scratch;
+    RET(kf::attn_launch(c->stream, a));
 }
 
 int kf_swiglu(kf_ctx* c, const kf_bf16* gate, const kf_bf16* up, kf_bf16* out, int n) {

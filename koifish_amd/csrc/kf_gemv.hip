@@ -179,7 +179,7 @@ struct Batch {
     float st2[PAIRED ? G : 1], ze2[PAIRED ? G : 1];
 };
 
-// LDS: x as u32x4 chunks [XCH][nBlk] (K*2 bytes) | 256 B reduction scratch | attention-merge scratch.
+// LDS: x as u32x4 chunks [XCH][nBlk] (K*2 bytes) | 256 B reduction scratch.
 // Each wave keeps two batches of G blocks in flight: the first batch is issued BEFORE the x prologue so that the
 // weight stream's HBM latency overlaps the (dependent) activation load + norm.
 template <int FMT, int G, int MODE>
@@ -246,57 +246,7 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     // ---- prologue: stage x into LDS as packed bf16 chunks
     {
         constexpr int XCH = BD::XCH;
-        if (a.attn_part) {
-            // x = merged attention output: the split-KV partials {acc[hd], m, l} per (head, slice) are combined exactly as
-            // attn_merge_kernel does (same order over slices), rounded to bf16 once.
-            const int H = a.attn_heads, nsp = a.attn_nsp, hd = a.attn_hd, PS = hd + 4; /* partial stride of kf_attn.hip */
-            float* ms = reinterpret_cast<float*>(smem_raw + (size_t)a.K * 2 + 256);
-            float* ls = ms + H * nsp;
-            float* sc = ls + H * nsp;
-            float* invL = sc + H * nsp;
-            for (int i = tid; i < H * nsp; i += blockDim.x) {
-                const float* p = a.attn_part + (size_t)i * PS;
-                ms[i] = p[hd], ls[i] = p[hd + 1];
-            }
-            __syncthreads();
-            for (int i = tid; i < H * nsp; i += blockDim.x) {
-                const int h = i / nsp;
-                float M = -__builtin_inff();
-                for (int t = 0; t < nsp; t++) M = fmaxf(M, ms[h * nsp + t]);
-                sc[i] = (ms[i] == -__builtin_inff()) ? 0.f : kf_expf(ms[i] - M);
-            }
-            __syncthreads();
-            for (int h = tid; h < H; h += blockDim.x) {
-                float L = 0.f;
-                for (int t = 0; t < nsp; t++)
-                    if (ms[h * nsp + t] != -__builtin_inff()) L = fmaf(ls[h * nsp + t], sc[h * nsp + t], L);
-                invL[h] = 1.0f / L;
-            }
-            __syncthreads();
-            for (int e8 = tid; e8 < a.K / 8; e8 += blockDim.x) {
-                const int h = (e8 * 8) / hd, d0 = (e8 * 8) - h * hd;
-                float o[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) o[i] = 0.f;
-                const float* pb = a.attn_part + (size_t)h * nsp * PS + d0;
-#pragma unroll 4
-                for (int t = 0; t < nsp; t++) {
-                    const float scl = sc[h * nsp + t];
-                    if (ms[h * nsp + t] == -__builtin_inff()) continue;
-                    const float4 p0 = *reinterpret_cast<const float4*>(pb + (size_t)t * PS);
-                    const float4 p1 = *reinterpret_cast<const float4*>(pb + (size_t)t * PS + 4);
-                    o[0] = fmaf(p0.x, scl, o[0]), o[1] = fmaf(p0.y, scl, o[1]), o[2] = fmaf(p0.z, scl, o[2]), o[3] = fmaf(p0.w, scl, o[3]);
-                    o[4] = fmaf(p1.x, scl, o[4]), o[5] = fmaf(p1.y, scl, o[5]), o[6] = fmaf(p1.z, scl, o[6]), o[7] = fmaf(p1.w, scl, o[7]);
-                }
-                const float il = invL[h];
-                u32x4 ov;
-                ov.x = pack_bf16x2(o[0] * il, o[1] * il), ov.y = pack_bf16x2(o[2] * il, o[3] * il);
-                ov.z = pack_bf16x2(o[4] * il, o[5] * il), ov.w = pack_bf16x2(o[6] * il, o[7] * il);
-                const int c = e8 / XCH, j = e8 - c * XCH;
-                xs[j * nBlk + c] = ov;
-                if (a.attn_out && blockIdx.x == 0) *reinterpret_cast<u32x4*>(a.attn_out + (size_t)e8 * 8) = ov;
-            }
-        } else {
+        {
             float mul = 1.0f;
             if (a.norm_w) { /* rms_norm_kernel, layernorm.cuh:800-847 */
                 double ss = block_sumsq_bf16(a.x, a.K, red);
@@ -551,11 +501,7 @@ int gemv_launch(hipStream_t st, GemvLaunch& L) {
     const long waves = (slots + spw - 1) / spw;
     const int blocks = (int)((waves + 3) / 4);
     if (L.mode == GEMV_ARGMAX && blocks > KF_MAX_ARGMAX_PARTIALS) return KF_INTERNAL_ERR;
-    size_t smem = (size_t)K * 2 + 256;
-    if (a.attn_part) {
-        if (a.attn_heads * a.attn_hd != K || a.attn_nsp < 1 || a.attn_nsp > KF_ATTN_MAX_SPLITS) return KF_INVALID_ARGS;
-        smem += sizeof(float) * ((size_t)3 * a.attn_heads * a.attn_nsp + a.attn_heads);
-    }
+    const size_t smem = (size_t)K * 2 + 256;
     if (smem > 160 * 1024) return KF_INVALID_ARGS;
     dim3 grid(blocks);
     switch (fmt) {

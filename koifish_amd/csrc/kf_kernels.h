@@ -36,10 +36,6 @@ struct GemvArgs {
     int pos;
     float* amax_val;
     int* amax_idx;
-    /* x = merged split-KV attention partials instead of a.x (o_proj fused with the attention merge) */
-    const float* attn_part;
-    uint16_t* attn_out; /* optional copy of the merged bf16 attention output (workgroup 0 writes it) */
-    int attn_heads, attn_nsp, attn_hd;
 };
 
 struct GemvLaunch {
@@ -63,14 +59,15 @@ struct AttnArgs {
     const uint16_t* wq_norm;
     const uint16_t* wk_norm;
     const float* rope_table; /* NULL: q is already normed+roped */
-    float* part;             /* [n_head][n_splits][hd + 2] fp32 partials */
+    float* part;             /* [n_head][n_splits][hd + 4] fp32 partials {acc, m, l, pad, pad} */
+    int* counters;           /* [n_kv] arrival counters, zero between launches */
     uint16_t* out;
     const int* d_pos;
     int pos;
     int n_head, n_kv, hd, kv_stride, n_splits;
     float eps, inv_sqrt_hd_den;
 };
-int attn_launch(hipStream_t st, AttnArgs& a, bool merge);
+int attn_launch(hipStream_t st, AttnArgs& a);
 int attn_splits(int pos_bound, int n_kv);
 int qknorm_rope_launch(hipStream_t st, uint16_t* q, uint16_t* k, const uint16_t* wq, const uint16_t* wk, const float* table, int pos,
                        const int* d_pos, int n_head, int n_kv, int hd, float eps);

@@ -119,11 +119,11 @@ hGTensor SelfAttention::cuInfer(hGTensor inpL, int) {
     kf_bf16* ys[3] = {ToX(Q.out), ToX(f->gBUFF.kraw), val_cache};
     const int64_t strides[3] = {0, 0, (int64_t)kv_dim};
     if (kf_norm_linear(c, ToX(inpL), ToX(norm.w), norm.rms_eps, 3, ws, ys, strides, bound, d_pos) != KF_OK) return nullptr;
-    if (kf_attn_block(c, ToX(Q.out), ToX(f->gBUFF.kraw), key_cache, val_cache, nullptr, normQ.w ? ToX(normQ.w) : nullptr,
+    if (kf_attn_block(c, ToX(Q.out), ToX(f->gBUFF.kraw), key_cache, val_cache, ToX(f->gBUFF.scratch), normQ.w ? ToX(normQ.w) : nullptr,
                       normK.w ? ToX(normK.w) : nullptr, f->rope_table, bound, d_pos, n_head, n_head_kv, head_dim, kv_dim, normQ.rms_eps,
                       f->gBUFF.attn_ws->data) != KF_OK)
         return nullptr;
-    if (kf_attn_out_linear(c, &wo, f->gBUFF.attn_ws->data, bound, n_head, n_head_kv, head_dim, ToX(out), ToX(inpL), nullptr) != KF_OK) return nullptr;
+    if (kf_linear(c, &wo, ToX(f->gBUFF.scratch), ToX(out), nullptr, 1, 1.0f, 0.0f, KF_EPI_RESIDUAL, ToX(inpL)) != KF_OK) return nullptr;
     return out;
 }
 

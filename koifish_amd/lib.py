@@ -17,7 +17,7 @@ ABI_SYMBOLS = [
     "kf_graph_begin", "kf_graph_end", "kf_graph_launch", "kf_graph_destroy", "kf_event_create", "kf_event_record", "kf_event_elapsed_ms",
     "kf_event_destroy", "kf_dequant", "kf_quantize", "kf_linear", "kf_rmsnorm", "kf_qknorm_rope", "kf_rope_table_host", "kf_attn_decode",
     "kf_attn_scratch_bytes", "kf_swiglu", "kf_add", "kf_embed", "kf_lm_head", "kf_head_scratch_bytes", "kf_norm_linear",
-    "kf_norm_gateup_swiglu", "kf_attn_block", "kf_attn_out_linear", "kf_norm_lm_head", "kf_set_state", "kf_embed_state",
+    "kf_norm_gateup_swiglu", "kf_attn_block", "kf_norm_lm_head", "kf_set_state", "kf_embed_state",
 ]
 
 

@@ -164,7 +164,7 @@ class Context:
     def _ws(self, n_head, hd):
         n = self.hip.kf_attn_scratch_bytes(n_head, hd)
         if self._attn_ws is None or self._attn_ws.numel() < n:
-            self._attn_ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._attn_ws = torch.zeros(n, dtype=torch.uint8, device=self.device)  # arrival counters start at zero
         return self._attn_ws
 
     def attn_decode(self, q, kc, vc, pos, n_head, n_kv, hd, kv_stride=None):
