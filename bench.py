@@ -173,34 +173,9 @@ def cpu_baseline(m, cfg, forced, budget_s):
     """The CPU oracle (a port: no runnable CPU forward exists in the reference) decoding the SAME 4-bit model on this host's
     cores: weights and the KV rows of a 128-token prompt are copied from the GPU model, then it decodes from position 128 until
     the time budget is used."""
-    import ctypes as C
-    import numpy as np
-    import torch
-    from koifish_amd import lib as L
     from oracle import oracle as O
 
-    def host_weight(w):
-        blob = w.blob.cpu().numpy()
-        data = blob[:w.szData]
-        if w.type == L.BF16:
-            return O.QWeight(O.BF16, w.ne0, w.ne1, data.view(np.uint16))
-        g = blob[w.szData:].view(np.uint16)
-        z0 = w.ne0 + w.ne1
-        return O.QWeight(w.type, w.ne0, w.ne1, data, g[z0:z0 + w.nGroup].copy(), g[z0 + w.nGroup:z0 + 2 * w.nGroup].copy(), w.lGroup, w.qBias)
-
-    def host_norm(t):
-        return t.view(torch.int16).cpu().numpy().view(np.uint16)
-
-    # norms were registered in order: final, then per layer 4
-    norms = [t for t in m._keep if isinstance(t, torch.Tensor) and t.dtype == torch.bfloat16 and t.dim() == 1]
-    ow = {"embed": host_weight(m.weights[(-1, 0)]), "final_norm": host_norm(norms[0]), "layers": []}
-    ow["head"] = ow["embed"] if m.weights[(-1, 1)] is m.weights[(-1, 0)] else host_weight(m.weights[(-1, 1)])
-    for li in range(cfg["n_layer"]):
-        d = {s: host_weight(m.weights[(li, si)]) for si, s in enumerate(O.SLOTS)}
-        for si, s in enumerate(O.NORMS):
-            d[s] = host_norm(norms[1 + 4 * li + si])
-        ow["layers"].append(d)
-    om = O.Qwen3Oracle(cfg, ow)
+    om = O.from_device_model(m)
     p0 = 128
     gk, gv = m.kv_to_host()
     ok, ov = om.kv()

@@ -249,6 +249,7 @@ class Qwen3:
         self.h = C.c_void_p(self.h)
         self._keep = []
         self.weights = {}
+        self._norms = {}
 
     def close(self):
         if getattr(self, "h", None):
@@ -275,6 +276,7 @@ class Qwen3:
     def set_norm(self, layer, slot, w_bf16):
         w_bf16 = w_bf16.contiguous()
         self._keep.append(w_bf16)
+        self._norms[(layer, slot)] = w_bf16
         L.check(self.host.kfh_set_norm(self.h, layer, slot, C.c_void_p(w_bf16.data_ptr()), w_bf16.numel(), 1), "kfh_set_norm")
 
     def set_fuse_level(self, lvl):

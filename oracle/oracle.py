@@ -330,5 +330,36 @@ class Qwen3Oracle:
             pass
 
 
+def from_device_model(m, attn_mode=ATTN_FUSED):
+    """Builds the CPU decoder from a koifish_amd.runtime.Qwen3 (duck-typed: .cfg, .weights[(layer, slot)] with .blob/.szData/
+    .type/.ne0/.ne1/.nGroup/.lGroup/.qBias, ._norms[(layer, slot)]): copies the SAME packed weights D2H, so GPU and CPU decode
+    one model.  Used by tests and by bench.py's cpu_baseline leg."""
+    import torch
+
+    def host_weight(w):
+        blob = w.blob.cpu().numpy()
+        data = blob[:w.szData]
+        if w.type == BF16:
+            return QWeight(BF16, w.ne0, w.ne1, data.view(np.uint16))
+        if w.type == F8E5M2:
+            return QWeight(F8E5M2, w.ne0, w.ne1, data)
+        g = blob[w.szData:].view(np.uint16)
+        z0 = w.ne0 + w.ne1
+        return QWeight(w.type, w.ne0, w.ne1, data, g[z0:z0 + w.nGroup].copy(), g[z0 + w.nGroup:z0 + 2 * w.nGroup].copy(), w.lGroup, w.qBias)
+
+    def host_norm(t):
+        return t.view(torch.int16).cpu().numpy().view(np.uint16)
+
+    cfg = m.cfg
+    ow = {"embed": host_weight(m.weights[(-1, 0)]), "final_norm": host_norm(m._norms[(-1, 0)]), "layers": []}
+    ow["head"] = ow["embed"] if m.weights[(-1, 1)] is m.weights[(-1, 0)] else host_weight(m.weights[(-1, 1)])
+    for li in range(cfg["n_layer"]):
+        d = {s: host_weight(m.weights[(li, si)]) for si, s in enumerate(SLOTS)}
+        for si, s in enumerate(NORMS):
+            d[s] = host_norm(m._norms[(li, si)])
+        ow["layers"].append(d)
+    return Qwen3Oracle(cfg, ow, attn_mode=attn_mode)
+
+
 def num_threads():
     return int(lib().kfo_num_threads())

@@ -1,0 +1,70 @@
+"""Qwen3-0.6B at full size (BASELINE.json configs[1] shapes) on the GPU: parity against the CPU oracle on a few steps (the
+oracle needs ~0.2 s per token per 100 cores, so the sample is small), and size-independent properties over a long run."""
+import numpy as np
+import pytest
+
+from koifish_amd import lib as L
+from koifish_amd import synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL = 2.0 ** -6
+
+
+@pytest.fixture(scope="module")
+def model():
+    cfg = dict(synth.CONFIGS["qwen3-0.6b"])
+    m = synth.build_on_gpu(cfg, seed=1234, layer_type=L.Q4, head_type=L.BF16)
+    yield cfg, m
+    m.close()
+
+
+def test_full_size_logits_and_ids_vs_oracle(model):
+    cfg, m = model
+    om = O.from_device_model(m)
+    ids = np.random.default_rng(7).integers(0, cfg["vocab"], size=6)
+    for pos, tok in enumerate(ids):
+        g_next, g_logits = m.forward(int(tok), pos)
+        o_next, o_logits, _ = om.decode(int(tok), pos)
+        gl, ol = O.bf16_to_f32(g_logits), O.bf16_to_f32(o_logits)
+        err = np.abs(gl - ol).max() / np.abs(ol).max()
+        assert err <= LOGIT_TOL, "pos %d: logits off by %g of max" % (pos, err)
+        assert g_next == O.argmax_bf16(g_logits)
+        top2 = np.sort(ol)[-2:]
+        if top2[1] - top2[0] > 2 * LOGIT_TOL * np.abs(ol).max():
+            assert g_next == o_next
+    om.close()
+
+
+def test_full_size_graph_equals_eager_and_is_deterministic(model):
+    cfg, m = model
+    prompt = np.random.default_rng(3).integers(0, cfg["vocab"], size=100)
+    a = m.generate(prompt, 200, use_graph=True)      # crosses the 64 / 128 / 256 buckets
+    b = m.generate(prompt, 200, use_graph=True)
+    c = m.generate(prompt, 40, use_graph=False)
+    assert a == b, "two identical runs differ: a kernel is not deterministic"
+    assert a[:40] == c, "hipGraph replay and eager launches disagree"
+
+
+def test_full_size_linearity_and_dequant_roundtrip(model):
+    """properties that need no CPU run: W.(2x) == 2*(W.x) exactly in bf16 (power-of-two scaling commutes with every rounding),
+    and every dequantised value lies on its group's 16-level bf16-stepwise grid."""
+    import torch
+    cfg, m = model
+    ctx = m._ctx
+    w = m.weights[(3, 4)]                            # layer 3 gate_proj, 3072 x 1024, Q4
+    x = torch.randn(cfg["dim"], device=ctx.device).to(torch.bfloat16)
+    y1 = ctx.linear(w, x)
+    y2 = ctx.linear(w, (x.float() * 2).to(torch.bfloat16))
+    assert torch.equal((y1.float() * 2).to(torch.bfloat16), y2)
+    deq = ctx.dequant(w).view(-1, 128)               # every 128-element group sits on its own <= 16-level grid {bf16(bf16(step*q) - zero)}
+    z, s = w.zero_step()
+    lut = (s.float()[:, None] * torch.arange(16, device=ctx.device)[None, :]).to(torch.bfloat16).float() - z.float()[:, None]
+    lut = lut.to(torch.bfloat16)
+    hit = (deq[:, :, None] == lut[:, None, :]).any(-1)
+    assert bool(hit.all()), "a dequantised value is off its group's grid"
+    # the LM head's device arg-max equals torch's first arg-max over the logits it wrote
+    head = m.weights[(-1, 1)]
+    logits, am = ctx.lm_head(head, x)
+    lf = logits.float()
+    assert am == int((lf == lf.max()).nonzero()[0])
