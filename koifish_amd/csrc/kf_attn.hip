@@ -12,12 +12,15 @@
 //
 // Arithmetic (= oracle/kf_oracle.c kfo_attn_decode mode FUSED up to fp32 summation order): score =
 // bf16(dot / sqrtf(hd)) -- the same bf16 store the reference makes (qk_v is floatX) -- then an fp32 softmax with
-// the fixed kf_expf and a single bf16 store of out = (sum e_t v_t) * (1 / sum e_t).
+// exp evaluated as v_exp_f32(x * log2 e) (<= 2 ulp from the oracle's exp: far inside the attention tolerance) and a single
+// bf16 store of out = (sum e_t v_t) * (1 / sum e_t).
 //
 // Cross-workgroup hand-off (MI355X_MICROARCH.md "Valid forms", table row 1): partials are written with
 // agent-scope relaxed atomic stores (write-through `sc1`), every storing wave drains vmcnt, the workgroup
 // barriers, ONE lane adds to the kv-head's arrival counter (agent-scope atomic); the workgroup whose add returned
 // nsp-1 reads every partial with agent-scope relaxed atomic loads (`sc1`) after a barrier, and re-zeroes the counter.
+#include <stdlib.h>
+
 #include "kf_kernels.h"
 
 namespace kf {
@@ -79,6 +82,9 @@ __device__ __forceinline__ void prep_head(const uint16_t* __restrict__ src, cons
     if (act) dst[j] = x0, dst[j + half] = x1;
 }
 
+// e^x for x <= 0 through the hardware exp2 (v_exp_f32); exp2(-inf) = 0
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269502162933349609375f); }
+
 constexpr int ATTN_U = 4; /* key tiles kept in flight per wave */
 
 __device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -96,15 +102,10 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
     int* flag = reinterpret_cast<int*>(mrg + 3 * GQ * KF_ATTN_MAX_SPLITS);
     float* comb = reinterpret_cast<float*>(flag + 4);  // [4*KPW][GQ][PS]
 
-    const int pos = a.d_pos ? *a.d_pos : a.pos;
-    const int len = pos + 1;
     const int split = blockIdx.x, kvh = blockIdx.y, nsp = a.n_splits;
-    const int chunk = (len + nsp - 1) / nsp;
+    const int chunk = a.chunk; /* keys per slice, fixed by the launch bound so that the K/V stream can start before pos is known */
     const int t0 = split * chunk;
-    int t1 = t0 + chunk;
-    if (t1 > len) t1 = len;
     const int h0 = kvh * GQ;
-    const bool empty = t0 >= len;
 
     // LPK lanes per key (8 dims each), KPW keys per wave step, 4 waves interleaved over the slice
     const int LPK = hd >> 3, KPW = 64 / LPK, lpk_log2 = __builtin_ctz(LPK);
@@ -112,25 +113,37 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
     const bool has_new = a.k_raw != nullptr;
     const int tstart = t0 + wave * KPW + grp, tstride = 4 * KPW;
 
+    // ---- issue the first K/V tiles before anything else: they depend neither on the position (read from device memory in
+    // graph replay) nor on the previous kernel's q.  Rows up to the launch bound exist in the cache; rows past the real position
+    // are masked later, and the row AT the position is replaced by the freshly normed+roped key.
+    u32x4 kk[ATTN_U], vv[ATTN_U];
+    auto issue = [&](int tb, int tend) {
+#pragma unroll
+        for (int u = 0; u < ATTN_U; u++) {
+            const int t = tb + u * tstride;
+            kk[u] = u32x4{0, 0, 0, 0}, vv[u] = u32x4{0, 0, 0, 0};
+            if (t < tend) {
+                const size_t off = (size_t)t * a.kv_stride + (size_t)kvh * hd + d0;
+                vv[u] = *reinterpret_cast<const u32x4*>(a.vcache + off);
+                kk[u] = *reinterpret_cast<const u32x4*>(a.kcache + off);
+            }
+        }
+    };
+    {
+        int tb_end = t0 + chunk;
+        if (tb_end > a.pos + 1) tb_end = a.pos + 1; /* a.pos is the launch bound here */
+        issue(tstart, tb_end);
+    }
+
+    const int pos = a.d_pos ? *a.d_pos : a.pos;
+    const int len = pos + 1;
+    int t1 = t0 + chunk;
+    if (t1 > len) t1 = len;
+    const bool empty = t0 >= len;
+
     float o_fin = 0.f, M_fin = -__builtin_inff(), L_fin = 0.f; /* this workgroup's partial: thread i = (hq, d) */
 
     if (!empty) {
-        // ---- issue the first K/V tiles before anything that depends on the previous kernel's q
-        u32x4 kk[ATTN_U], vv[ATTN_U];
-        auto issue = [&](int tb) {
-#pragma unroll
-            for (int u = 0; u < ATTN_U; u++) {
-                const int t = tb + u * tstride;
-                kk[u] = u32x4{0, 0, 0, 0}, vv[u] = u32x4{0, 0, 0, 0};
-                if (t < t1) {
-                    const size_t off = (size_t)t * a.kv_stride + (size_t)kvh * hd + d0;
-                    vv[u] = *reinterpret_cast<const u32x4*>(a.vcache + off);
-                    if (!(has_new && t == pos)) kk[u] = *reinterpret_cast<const u32x4*>(a.kcache + off);
-                }
-            }
-        };
-        issue(tstart);
-
         // ---- prologue: q heads of this group, and the new key when it lies in this slice
         const float* tab_pos = a.rope_table ? a.rope_table + (size_t)pos * hd : nullptr;
         for (int hq = wave; hq < GQ; hq += 4)
@@ -156,12 +169,12 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
 #pragma unroll
             for (int i = 0; i < 8; i++) acc[hq][i] = 0.f;
         }
-        const float den = a.inv_sqrt_hd_den; /* sqrtf(hd): score /= sqrtf(head_dim) (operator.cuh:630) */
+        const float rden = 1.0f / a.inv_sqrt_hd_den; /* score /= sqrtf(head_dim) (operator.cuh:630), as a multiply by the rounded reciprocal */
         for (int tb = tstart; tb - grp - wave * KPW < t1; tb += ATTN_U * tstride) { /* workgroup-uniform trip count */
             u32x4 ck[ATTN_U], cv[ATTN_U];
 #pragma unroll
             for (int u = 0; u < ATTN_U; u++) ck[u] = kk[u], cv[u] = vv[u];
-            if (tb - grp - wave * KPW + ATTN_U * tstride < t1) issue(tb + ATTN_U * tstride);
+            if (tb - grp - wave * KPW + ATTN_U * tstride < t1) issue(tb + ATTN_U * tstride, t1);
             // scores of this batch
             float s[ATTN_U][GQ], bm[GQ];
 #pragma unroll
@@ -184,7 +197,7 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
 #pragma unroll
                     for (int i = 0; i < 8; i++) d = fmaf(qreg[hq][i], kf_[i], d);
                     d = group_sum16(d, lpk_log2);
-                    d = round_bf16(d / den);
+                    d = round_bf16(d * rden);
                     s[u][hq] = valid ? d : -__builtin_inff();
                     bm[hq] = fmaxf(bm[hq], s[u][hq]);
                 }
@@ -206,7 +219,7 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
             for (int hq = 0; hq < GQ; hq++) {
                 const float Mb = fmaxf(fmaxf(wmax[hq], wmax[GQ + hq]), fmaxf(wmax[2 * GQ + hq], wmax[3 * GQ + hq]));
                 if (Mb > M[hq]) {
-                    const float sc = kf_expf(M[hq] - Mb);
+                    const float sc = fast_exp(M[hq] - Mb);
                     l[hq] *= sc;
 #pragma unroll
                     for (int i = 0; i < 8; i++) acc[hq][i] *= sc;
@@ -221,7 +234,7 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
                 for (int i = 0; i < 4; i++) vf_[2 * i] = bf_lo(vw[i]), vf_[2 * i + 1] = bf_hi(vw[i]);
 #pragma unroll
                 for (int hq = 0; hq < GQ; hq++) {
-                    const float p = (s[u][hq] == -__builtin_inff()) ? 0.f : kf_expf(s[u][hq] - M[hq]);
+                    const float p = fast_exp(s[u][hq] - M[hq]); /* -inf (masked key) -> 0 */
                     l[hq] += p;
 #pragma unroll
                     for (int i = 0; i < 8; i++) acc[hq][i] = fmaf(p, vf_[i], acc[hq][i]);
@@ -282,6 +295,7 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
     __syncthreads();
     if (!flag[0]) return;
 
+    // one round of loads: every thread fetches its output element from all slices while (m, l) of the slices go to LDS
     float* ms = mrg;
     float* ls = mrg + GQ * KF_ATTN_MAX_SPLITS;
     float* sc = mrg + 2 * GQ * KF_ATTN_MAX_SPLITS;
@@ -291,33 +305,37 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
         ms[hq * KF_ATTN_MAX_SPLITS + sp] = ld_sc1(p + hd);
         ls[hq * KF_ATTN_MAX_SPLITS + sp] = ld_sc1(p + hd + 1);
     }
+    constexpr int NV = (GQ * 128 + 255) / 256; /* output elements per thread (hd <= 128) */
+    float v[NV][KF_ATTN_MAX_SPLITS];
+#pragma unroll
+    for (int e = 0; e < NV; e++) {
+        const int i = tid + e * 256;
+        const int hq = i / hd, d = i - hq * hd;
+        const float* p = a.part + (size_t)(h0 + hq) * nsp * PS + d;
+#pragma unroll
+        for (int sp = 0; sp < KF_ATTN_MAX_SPLITS; sp++) v[e][sp] = (i < GQ * hd && sp < nsp) ? ld_sc1(p + (size_t)sp * PS) : 0.f;
+    }
     __syncthreads();
     for (int i = tid; i < GQ * nsp; i += blockDim.x) {
         const int hq = i / nsp, sp = i - hq * nsp;
         float Mx = -__builtin_inff();
         for (int t = 0; t < nsp; t++) Mx = fmaxf(Mx, ms[hq * KF_ATTN_MAX_SPLITS + t]);
         const float m = ms[hq * KF_ATTN_MAX_SPLITS + sp];
-        sc[hq * KF_ATTN_MAX_SPLITS + sp] = (m == -__builtin_inff()) ? 0.f : kf_expf(m - Mx);
+        sc[hq * KF_ATTN_MAX_SPLITS + sp] = (m == -__builtin_inff()) ? 0.f : fast_exp(m - Mx);
     }
     __syncthreads();
-    for (int i = tid; i < GQ * hd; i += blockDim.x) {
+#pragma unroll
+    for (int e = 0; e < NV; e++) {
+        const int i = tid + e * 256;
+        if (i >= GQ * hd) break;
         const int hq = i / hd, d = i - hq * hd;
-        const float* p = a.part + (size_t)(h0 + hq) * nsp * PS + d;
         float o = 0.f, L = 0.f;
-        int sp = 0;
-        for (; sp + 8 <= nsp; sp += 8) {
-            float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = ld_sc1(p + (size_t)(sp + u) * PS);
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                o = fmaf(v[u], sc[hq * KF_ATTN_MAX_SPLITS + sp + u], o);
-                L = fmaf(ls[hq * KF_ATTN_MAX_SPLITS + sp + u], sc[hq * KF_ATTN_MAX_SPLITS + sp + u], L);
+        for (int sp = 0; sp < KF_ATTN_MAX_SPLITS; sp++) {
+            if (sp < nsp) {
+                o = fmaf(v[e][sp], sc[hq * KF_ATTN_MAX_SPLITS + sp], o);
+                L = fmaf(ls[hq * KF_ATTN_MAX_SPLITS + sp], sc[hq * KF_ATTN_MAX_SPLITS + sp], L);
             }
-        }
-        for (; sp < nsp; sp++) {
-            o = fmaf(ld_sc1(p + (size_t)sp * PS), sc[hq * KF_ATTN_MAX_SPLITS + sp], o);
-            L = fmaf(ls[hq * KF_ATTN_MAX_SPLITS + sp], sc[hq * KF_ATTN_MAX_SPLITS + sp], L);
         }
         a.out[(size_t)(h0 + hq) * hd + d] = f2bf(o * (1.0f / L));
     }
@@ -339,7 +357,18 @@ __global__ void __launch_bounds__(64) qknorm_rope_kernel(uint16_t* q, uint16_t* 
 
 // slices: ~64 keys each, enough workgroups to cover the chip, bounded by the scratch layout
 int attn_splits(int pos_bound, int n_kv) {
-    int nsp = (pos_bound + 1 + 63) / 64;
+    // keys per slice: one workgroup streams a slice in batches of 64 keys (hd 128); short contexts stay in ONE slice per
+    // kv-head (no cross-workgroup hand-off at all), long ones are cut so that the chip is covered.
+    static int slice = 0, single = 0;
+    if (!slice) {
+        const char* e = getenv("KF_ATTN_SLICE");
+        slice = e ? atoi(e) : 128;
+        const char* f = getenv("KF_ATTN_SINGLE");
+        single = f ? atoi(f) : 192;
+    }
+    const int len = pos_bound + 1;
+    if (len <= single) return 1;
+    int nsp = (len + slice - 1) / slice;
     int cap = 512 / n_kv;
     if (cap < 1) cap = 1;
     if (nsp > cap) nsp = cap;
@@ -355,6 +384,7 @@ int attn_launch(hipStream_t st, AttnArgs& a) {
     const int GQ = a.n_head / a.n_kv;
     const int nsp = attn_splits(a.pos, a.n_kv);
     a.n_splits = nsp;
+    a.chunk = (a.pos + 1 + nsp - 1) / nsp;
     a.inv_sqrt_hd_den = sqrtf((float)hd);
     const int KPW = 64 / (hd >> 3);
     const size_t smem = sizeof(float) * ((size_t)GQ * hd + hd + 4 * GQ + 3 * GQ * KF_ATTN_MAX_SPLITS + 4 + (size_t)4 * KPW * GQ * (hd + 4));

@@ -11,6 +11,8 @@
 // Each wave owns SPW consecutive slots and keeps G of them in flight.  x sits in LDS as 16-byte chunks laid
 // out [chunk j of block][block column] so that consecutive lanes read consecutive 16-byte words (no bank
 // conflicts for ds_read_b128).
+#include <stdlib.h>
+
 #include "kf_kernels.h"
 
 namespace kf {
@@ -201,38 +203,46 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     const int nbatch = s_end > s_begin ? (int)((s_end - s_begin + G - 1) / G) : 0;
     const int nsteps = nbatch * iters;
 
-    // Job fields are picked with selects on constant indices (kernel arguments live in SGPRs); indexing a.job[]
-    // with a run-time value would turn every access into a vector load from the kernarg segment, and the waits for
-    // those loads serialise the weight stream.  Slots are wave-uniform, so the job index is made scalar.
-    auto jsel = [&](long s) -> int {
-        int j = 0;
-        if (a.njobs > 1 && s >= a.job[1].slot0) j = 1;
-        if (a.njobs > 2 && s >= a.job[2].slot0) j = 2;
-        return __builtin_amdgcn_readfirstlane(j);
-    };
-#define JF(j, f) ((j) == 0 ? a.job[0].f : ((j) == 1 ? a.job[1].f : a.job[2].f))
-    auto slot = [&](long s, int& j, int& row) -> bool {
-        j = jsel(s);
-        row = (int)(s - JF(j, slot0)) * RPS + sub;
-        return (s < s_end) && (row < JF(j, M));
+    // Every wave works inside ONE job (the launcher pads each job's slot range to a multiple of spw), so the job's fields are
+    // selected once, with constant indices into the kernel arguments (SGPRs), and stay scalar for the whole loop.  Indexing
+    // a.job[] with a run-time value inside the loop would turn each access into a load from the kernarg segment whose wait
+    // serialises the weight stream.
+    int jx = 0;
+    if (a.njobs > 1 && s_begin >= a.job[1].slot0) jx = 1;
+    if (a.njobs > 2 && s_begin >= a.job[2].slot0) jx = 2;
+    jx = __builtin_amdgcn_readfirstlane(jx);
+#define JF(f) (jx == 0 ? a.job[0].f : (jx == 1 ? a.job[1].f : a.job[2].f))
+    const u32x4* const jw = reinterpret_cast<const u32x4*>(JF(w));
+    const u32x4* const jw2 = reinterpret_cast<const u32x4*>(a.job[1].w);
+    const uint16_t* const jstep = JF(step);
+    const uint16_t* const jzero = JF(zero);
+    uint16_t* const jy = JF(y);
+    const long long jystride = JF(y_pos_stride);
+    const int jM = JF(M), jslot0 = JF(slot0);
+    const float jqb = (float)JF(qBias), jqb2 = (float)a.job[1].qBias;
+#undef JF
+    const int gshift = a.gshift;
+    auto slot = [&](long s, int& row) -> bool {
+        row = (int)(s - jslot0) * RPS + sub;
+        return (s < s_end) && (row < jM);
     };
     auto load = [&](int bi, int it, Batch<G, PAIRED>& b) {
         const long s0 = s_begin + (long)bi * G;
         const int col = it * LPR + ll;
 #pragma unroll
         for (int g = 0; g < G; g++) {
-            int j, row;
-            const bool ok = slot(s0 + g, j, row) && (col < nBlk);
+            int row;
+            const bool ok = slot(s0 + g, row) && (col < nBlk);
             b.w[g] = u32x4{0, 0, 0, 0};
             b.st[g] = b.ze[g] = 0.f;
             if (PAIRED) b.w2[g] = u32x4{0, 0, 0, 0}, b.st2[g] = b.ze2[g] = 0.f;
             if (ok) {
-                const size_t bidx = (size_t)row * nBlk + col;
-                b.w[g] = ld_nt(reinterpret_cast<const u32x4*>(JF(j, w)) + bidx);
-                if (PAIRED) b.w2[g] = ld_nt(reinterpret_cast<const u32x4*>(a.job[1].w) + bidx);
+                const uint32_t bidx = (uint32_t)row * (uint32_t)nBlk + (uint32_t)col; /* < 2^32 blocks = 64 GiB per tensor */
+                b.w[g] = ld_nt(jw + bidx);
+                if (PAIRED) b.w2[g] = ld_nt(jw2 + bidx);
                 if (BD::HAS_GAMA) {
-                    const size_t gi = bidx >> a.gshift; /* group = element / lGroup, lGroup / EPB a power of two */
-                    b.st[g] = bf2f(JF(j, step)[gi]), b.ze[g] = bf2f(JF(j, zero)[gi]);
+                    const uint32_t gi = bidx >> gshift; /* group = element / lGroup, lGroup / EPB a power of two */
+                    b.st[g] = bf2f(jstep[gi]), b.ze[g] = bf2f(jzero[gi]);
                     if (PAIRED) b.st2[g] = bf2f(a.job[1].step[gi]), b.ze2[g] = bf2f(a.job[1].zero[gi]);
                 }
             }
@@ -298,14 +308,8 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
             if (col >= nBlk) col = nBlk - 1; /* masked lanes carry zero weights; keep their LDS reads in range */
 #pragma unroll
             for (int g = 0; g < G; g++) {
-                int j, row;
-                slot(s_begin + (long)bi * G + g, j, row);
-                const float qb = (float)JF(j, qBias);
-                acc[g] = BD::run(cur.w[g], xs, col, nBlk, cur.st[g], cur.ze[g], -(qb * cur.st[g]), acc[g]);
-                if (PAIRED) {
-                    const float qb2 = (float)a.job[1].qBias;
-                    acc2[g] = BD::run(cur.w2[g], xs, col, nBlk, cur.st2[g], cur.ze2[g], -(qb2 * cur.st2[g]), acc2[g]);
-                }
+                acc[g] = BD::run(cur.w[g], xs, col, nBlk, cur.st[g], cur.ze[g], -(jqb * cur.st[g]), acc[g]);
+                if (PAIRED) acc2[g] = BD::run(cur.w2[g], xs, col, nBlk, cur.st2[g], cur.ze2[g], -(jqb2 * cur.st2[g]), acc2[g]);
             }
         }
         if (it == iters - 1) {
@@ -317,9 +321,9 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
             if (ll == 0) {
 #pragma unroll
                 for (int g = 0; g < G; g++) {
-                    int j, r;
-                    if (!slot(s_begin + (long)bi * G + g, j, r)) continue;
-                    uint16_t* y = JF(j, y) + (size_t)pos * JF(j, y_pos_stride);
+                    int r;
+                    if (!slot(s_begin + (long)bi * G + g, r)) continue;
+                    uint16_t* y = jy + (size_t)pos * jystride;
                     float v = acc[g];
                     if (PAIRED) {
                         // SwiGLU of the two bf16-rounded projections (CU_swiglu_v0, Activation.cu:85-93)
@@ -364,7 +368,6 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
             a.amax_idx[blockIdx.x] = best_i;
         }
     }
-#undef JF
 }
 
 // Final pick over the per-workgroup partial maxima, then the decode-state update for graph replay.
@@ -460,11 +463,12 @@ int gemv_launch(hipStream_t st, GemvLaunch& L) {
     a.K = K, a.nBlk = nBlk, a.lpr_log2 = lpr_log2, a.iters = (nBlk + LPR - 1) / LPR;
     a.inv_dim = 1.0f / (float)K;
     a.njobs = L.n;
-    long slots = 0;
+    long rows_slots[3] = {0, 0, 0}, raw_slots = 0;
     for (int j = 0; j < L.n; j++) {
         const kf_weight* w = L.w[j];
         if (fmt_of(w->type) != fmt || w->ne1 != K) return KF_INVALID_ARGS;
         if (((uintptr_t)w->data & 15) != 0) return KF_BLAS_UNALIGN;
+        if ((unsigned long long)w->ne0 * (unsigned long long)nBlk >= (1ull << 32)) return KF_INVALID_ARGS;
         GemvJob& jb = a.job[j];
         jb.w = w->data;
         jb.zero = jb.step = nullptr;
@@ -479,25 +483,32 @@ int gemv_launch(hipStream_t st, GemvLaunch& L) {
         }
         jb.M = w->ne0;
         jb.qBias = w->qBias;
-        jb.slot0 = (int)slots;
-        if (L.mode == GEMV_PAIRED) {
-            if (j == 1) {
-                if (w->ne0 != L.w[0]->ne0) return KF_INVALID_ARGS;
-                continue; /* job 1 rides on job 0's slots */
-            }
+        if (L.mode == GEMV_PAIRED && j == 1) {
+            if (w->ne0 != L.w[0]->ne0) return KF_INVALID_ARGS;
+            continue; /* job 1 rides on job 0's slots */
         }
-        slots += (w->ne0 + RPS - 1) / RPS;
+        rows_slots[j] = (w->ne0 + RPS - 1) / RPS;
+        raw_slots += rows_slots[j];
     }
-    if (L.mode == GEMV_PAIRED) a.njobs = 1, a.job[1].slot0 = 0x7fffffff;
-    a.total_slots = (int)slots;
+    if (L.mode == GEMV_PAIRED) a.njobs = 1;
     // one wave per spw slots; aim for ~4096 waves (16 per CU) on large matrices, never fewer than one slot each
-    const long target_waves = L.target_waves > 0 ? L.target_waves : 4096;
-    long spw = (slots + target_waves - 1) / target_waves;
+    long target_waves = L.target_waves > 0 ? L.target_waves : 4096;
+    if (const char* e = getenv("KF_GEMV_WAVES")) target_waves = atol(e); /* tuning knob */
+    long spw = (raw_slots + target_waves - 1) / target_waves;
     if (spw < 1) spw = 1;
     int G = spw >= 4 ? 4 : (spw >= 2 ? 2 : 1);
+    if (const char* e = getenv("KF_GEMV_G")) G = atoi(e) < G ? atoi(e) : G;
     if (L.mode == GEMV_PAIRED && G > 2) G = 2; /* two weight streams per slot: keep register pressure down */
     spw = (spw + G - 1) / G * G;
     a.spw = (int)spw;
+    // every job starts on a wave boundary, so a wave never straddles two jobs
+    long slots = 0;
+    for (int j = 0; j < a.njobs; j++) {
+        a.job[j].slot0 = (int)slots;
+        slots += (rows_slots[j] + spw - 1) / spw * spw;
+    }
+    for (int j = a.njobs; j < 3; j++) a.job[j].slot0 = 0x7fffffff;
+    a.total_slots = (int)slots;
     const long waves = (slots + spw - 1) / spw;
     const int blocks = (int)((waves + 3) / 4);
     if (L.mode == GEMV_ARGMAX && blocks > KF_MAX_ARGMAX_PARTIALS) return KF_INTERNAL_ERR;

@@ -8,7 +8,7 @@ namespace kf {
 enum { FMT_BF16 = 0, FMT_F8 = 1, FMT_Q4 = 2, FMT_Q2 = 3, FMT_Q1 = 4 };
 enum { GEMV_PLAIN = 0, GEMV_PAIRED = 1, GEMV_ARGMAX = 2 };
 constexpr int KF_MAX_ARGMAX_PARTIALS = 4096;
-constexpr int KF_ATTN_MAX_SPLITS = 64;
+constexpr int KF_ATTN_MAX_SPLITS = 32;
 
 struct GemvJob {
     const void* w;
@@ -64,7 +64,7 @@ struct AttnArgs {
     uint16_t* out;
     const int* d_pos;
     int pos;
-    int n_head, n_kv, hd, kv_stride, n_splits;
+    int n_head, n_kv, hd, kv_stride, n_splits, chunk;
     float eps, inv_sqrt_hd_den;
 };
 int attn_launch(hipStream_t st, AttnArgs& a);
