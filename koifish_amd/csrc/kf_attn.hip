@@ -25,17 +25,6 @@
 
 namespace kf {
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-template <int CTRL>
-__device__ __forceinline__ double dpp_d(double v) {
-    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, true);
-    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
 // sum over the 2^lg (<= 16) lanes of each aligned lane group, DPP only
 __device__ __forceinline__ float group_sum16(float v, int lg) {
     if (lg >= 1) v += dpp_f<0xB1>(v);
@@ -44,17 +33,6 @@ __device__ __forceinline__ float group_sum16(float v, int lg) {
     if (lg >= 4) v += dpp_f<0x140>(v);
     return v;
 }
-// fp64 sum over the whole wave (order-independent for our inputs: see block_sumsq_bf16)
-__device__ __forceinline__ double wave_sum_f64_fast(double v) {
-    v += dpp_d<0xB1>(v);
-    v += dpp_d<0x4E>(v);
-    v += dpp_d<0x141>(v);
-    v += dpp_d<0x140>(v);
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
-}
-
 // Prepare one head: optional per-head RMSNorm (s rounded to bf16 first, then (a*s)*w, RN store) and rotate-half
 // RoPE from the host-built (cos,sin) table.  One wave per head; lane j handles the pair (j, j + hd/2).
 // Result: bf16-rounded values as floats in dst[hd].

@@ -157,10 +157,6 @@ struct BlockDot<FMT_Q1> {
 };
 
 // ------------------------------------------------------------------------------------------------ kernel
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
 // sum over the 2^lg lanes of each aligned lane group (lg wave-uniform); every lane of the group gets the sum.
 // DPP inside a 16-lane row (quad_perm xor1, xor2, row_half_mirror, row_mirror), two cross-row exchanges above it.
 __device__ __forceinline__ float group_sum(float v, int lg) {
@@ -256,15 +252,50 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     // ---- prologue: stage x into LDS as packed bf16 chunks
     {
         constexpr int XCH = BD::XCH;
-        {
+        const int nch = a.K >> 3;
+        if (a.norm_w && nch <= 512) {
+            // RMSNorm prologue, one pass (rms_norm_kernel, layernorm.cuh:800-847): every thread holds <= 2 chunks of 8 elements in
+            // registers, fp64 sum of squares over the workgroup, then the normalised chunks go to LDS.
+            const bool h0 = tid < nch, h1 = tid + 256 < nch;
+            u32x4 r0 = u32x4{0, 0, 0, 0}, r1 = r0, n0 = r0, n1 = r0;
+            if (h0) r0 = *reinterpret_cast<const u32x4*>(a.x + (size_t)tid * 8), n0 = *reinterpret_cast<const u32x4*>(a.norm_w + (size_t)tid * 8);
+            if (h1) r1 = *reinterpret_cast<const u32x4*>(a.x + (size_t)(tid + 256) * 8), n1 = *reinterpret_cast<const u32x4*>(a.norm_w + (size_t)(tid + 256) * 8);
+            const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w}, ww[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+            double ss = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const double lo = (double)bf_lo(rw[k]), hi = (double)bf_hi(rw[k]);
+                ss = fma(lo, lo, ss);
+                ss = fma(hi, hi, ss);
+            }
+            ss = wave_sum_f64_fast(ss);
+            if (lane == 0) red[wave_in_blk] = ss;
+            __syncthreads();
+            const double tot = (red[0] + red[1]) + (red[2] + red[3]);
+            const float mul = 1.0f / sqrtf(fmaf((float)tot, a.inv_dim, a.eps));
+            uint32_t ow[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float v0 = (bf_lo(rw[k]) * mul) * bf_lo(ww[k]), v1 = (bf_hi(rw[k]) * mul) * bf_hi(ww[k]);
+                ow[k] = pack_bf16x2(v0, v1);
+            }
+            if (h0) {
+                const int c = tid / XCH, j = tid - c * XCH;
+                xs[j * nBlk + c] = u32x4{ow[0], ow[1], ow[2], ow[3]};
+            }
+            if (h1) {
+                const int e8 = tid + 256, c = e8 / XCH, j = e8 - c * XCH;
+                xs[j * nBlk + c] = u32x4{ow[4], ow[5], ow[6], ow[7]};
+            }
+        } else {
             float mul = 1.0f;
-            if (a.norm_w) { /* rms_norm_kernel, layernorm.cuh:800-847 */
+            if (a.norm_w) { /* large K: two passes */
                 double ss = block_sumsq_bf16(a.x, a.K, red);
                 float val = fmaf((float)ss, a.inv_dim, a.eps);
                 mul = 1.0f / sqrtf(val);
             }
             // element e of block column c, chunk j (e = c*EPB + j*8 + i)  ->  LDS chunk (j*nBlk + c)
-            for (int e8 = tid; e8 < a.K / 8; e8 += blockDim.x) {
+            for (int e8 = tid; e8 < nch; e8 += blockDim.x) {
                 const int c = e8 / XCH, j = e8 - c * XCH;
                 const u32x4 raw = *reinterpret_cast<const u32x4*>(a.x + (size_t)e8 * 8);
                 u32x4 o = raw;
