@@ -164,8 +164,15 @@ def kernel_roofline(m, ctx, cfg, reps=200):
     ms = ctx.elapsed_ms(e0, e1) / reps
     nbytes = head.algorithmic_bytes() + cfg["dim"] * 4 + head.ne0 * 2  # weights + x + norm weight + logits written
     ach = nbytes / (ms * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this process): FETCH_SIZE x 2
+    # (gfx950 correction) + WRITE_SIZE, collected by `rocprofv3 --pmc ... -- python3 scratch/ub_head.py`
+    traffic = None
+    try:
+        traffic = int(json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_lm_head.json")))["hbm_bytes_per_launch"])
+    except Exception:
+        pass
     return {"bound": "hbm", "kernel": "kf::gemv_kernel<bf16, argmax> (final norm + LM head 151936x1024 + greedy pick)", "achieved": round(ach, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": int(nbytes),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "bytes_per_launch": int(nbytes),
             "us_per_launch": round(ms * 1e3, 2)}
 
 
