@@ -104,6 +104,12 @@ int kf_quantize(kf_ctx* ctx, const kf_weight* w, const kf_bf16* src, int symmetr
 int kf_linear(kf_ctx* ctx, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const kf_bf16* bias, int nTok, float alpha, float beta,
               uint32_t epilogue, const kf_bf16* residual);
 
+/* ---- tensor parallel (no counterpart in the reference, which is single-GPU: QKV.cu:503) ----
+ * column-split projections (o_proj, down_proj) give un-rounded fp32 partial row dots per rank ... */
+int kf_linear_f32(kf_ctx* ctx, const kf_weight* w_shard, const kf_bf16* x_shard, float* y_partial);
+/* ... that are combined in rank order after an all-gather: out = bf16(residual + bf16(sum_r partials[r][:])) */
+int kf_tp_reduce(kf_ctx* ctx, const float* partials, int n_ranks, int n, const kf_bf16* residual_or_null, kf_bf16* out);
+
 /* LayerNormal::cuFlow -> CU_rms_infer (Neuron.hpp:453, T.cu:561-573, layernorm.cuh:800-859) */
 int kf_rmsnorm(kf_ctx* ctx, const kf_bf16* x, const kf_bf16* w, kf_bf16* y, int rows, int dim, float eps, float* rstd_or_null);
 

@@ -231,6 +231,23 @@ int kf_linear(kf_ctx* c, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const
     RET(kf::gemv_launch(c->stream, L));
 }
 
+int kf_linear_f32(kf_ctx* c, const kf_weight* w, const kf_bf16* x, float* y) {
+    CHKCTX(c);
+    int r = check_weight(w, "kf_linear_f32");
+    if (r) return r;
+    if (!x || !y || !al16(x)) return fail(KF_BLAS_UNALIGN, "kf_linear_f32: x/y null or x unaligned");
+    kf::GemvLaunch L;
+    init_args(L);
+    L.n = 1, L.w[0] = w, L.mode = kf::GEMV_PLAIN;
+    L.args.x = x, L.args.yf = y, L.args.job[0].y = nullptr;
+    RET(kf::gemv_launch(c->stream, L));
+}
+int kf_tp_reduce(kf_ctx* c, const float* partials, int n_ranks, int n, const kf_bf16* residual, kf_bf16* out) {
+    CHKCTX(c);
+    if (!partials || !out || n_ranks < 1 || n < 1) return fail(KF_INVALID_ARGS, "kf_tp_reduce: bad args");
+    RET(kf::tp_reduce_launch(c->stream, partials, n_ranks, n, residual, out));
+}
+
 int kf_norm_linear(kf_ctx* c, const kf_bf16* x, const kf_bf16* norm_w, float eps, int n_w, const kf_weight* const* w, kf_bf16* const* y,
                    const int64_t* y_pos_stride, int pos, const int32_t* d_pos) {
     CHKCTX(c);

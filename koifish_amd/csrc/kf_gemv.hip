@@ -362,6 +362,10 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
                         y[r] = f2bf((gt * up) / (1.0f + kf_expf(-gt)));
                         continue;
                     }
+                    if (a.yf) { /* un-rounded fp32 row dots: tensor-parallel partial sums (column-split o_proj / down_proj) */
+                        a.yf[r] = v;
+                        continue;
+                    }
                     if (a.alpha != 1.0f) v = a.alpha * v;
                     if (a.beta != 0.0f) v = v + a.beta * bf2f(y[r]);
                     if (a.bias) v = v + bf2f(a.bias[r]);

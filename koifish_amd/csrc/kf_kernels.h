@@ -31,6 +31,7 @@ struct GemvArgs {
     float eps, inv_dim;
     const uint16_t* residual;
     const uint16_t* bias;
+    float* yf; /* non-NULL: write fp32 row dots here instead of bf16 outputs (single job) */
     float alpha, beta;
     const int* d_pos;
     int pos;
@@ -81,5 +82,6 @@ int embed_launch(hipStream_t st, const kf_weight* w, int token, const int32_t* d
 int dequant_launch(hipStream_t st, const kf_weight* w, uint16_t* out);
 int quantize_launch(hipStream_t st, const kf_weight* w, const uint16_t* src, int symmetric);
 int set_state_launch(hipStream_t st, int32_t* d_state, int token, int pos);
+int tp_reduce_launch(hipStream_t st, const float* partials, int R, int n, const uint16_t* residual, uint16_t* out);
 
 }  // namespace kf

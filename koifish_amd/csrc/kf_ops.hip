@@ -214,6 +214,22 @@ int quantize_launch(hipStream_t st, const kf_weight* w, const uint16_t* src, int
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 
+// Tensor-parallel combine: out = bf16(residual + bf16(sum_r partial[r])) with the partial sums added in rank order 0..R-1
+// (fixed order: every rank computes the same bits).  residual may be NULL.
+__global__ void tp_reduce_kernel(const float* __restrict__ partials, int R, int n, const uint16_t* __restrict__ residual, uint16_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float tot = partials[i];
+    for (int r = 1; r < R; r++) tot = tot + partials[(size_t)r * n + i];
+    uint16_t o = f2bf(tot);
+    if (residual) o = f2bf(bf2f(residual[i]) + bf2f(o));
+    out[i] = o;
+}
+int tp_reduce_launch(hipStream_t st, const float* partials, int R, int n, const uint16_t* residual, uint16_t* out) {
+    hipLaunchKernelGGL(tp_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, partials, R, n, residual, out);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+
 __global__ void set_state_kernel(int32_t* st, int token, int pos) { st[0] = token, st[1] = pos; }
 int set_state_launch(hipStream_t st, int32_t* d_state, int token, int pos) {
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, d_state, token, pos);

@@ -16,7 +16,7 @@ ABI_SYMBOLS = [
     "kf_init", "kf_destroy", "kf_sync", "kf_last_error", "kf_version", "kf_malloc", "kf_free", "kf_memset", "kf_h2d", "kf_d2h", "kf_d2d",
     "kf_graph_begin", "kf_graph_end", "kf_graph_launch", "kf_graph_destroy", "kf_event_create", "kf_event_record", "kf_event_elapsed_ms",
     "kf_event_destroy", "kf_dequant", "kf_quantize", "kf_linear", "kf_rmsnorm", "kf_qknorm_rope", "kf_rope_table_host", "kf_attn_decode",
-    "kf_attn_scratch_bytes", "kf_swiglu", "kf_add", "kf_embed", "kf_lm_head", "kf_head_scratch_bytes", "kf_norm_linear",
+    "kf_attn_scratch_bytes", "kf_linear_f32", "kf_tp_reduce", "kf_swiglu", "kf_add", "kf_embed", "kf_lm_head", "kf_head_scratch_bytes", "kf_norm_linear",
     "kf_norm_gateup_swiglu", "kf_attn_block", "kf_norm_lm_head", "kf_set_state", "kf_embed_state",
 ]
 
@@ -49,6 +49,8 @@ def load():
         hip.kf_attn_scratch_bytes.restype = C.c_size_t
         hip.kf_head_scratch_bytes.restype = C.c_size_t
         hip.kf_linear.argtypes = [C.c_void_p, C.POINTER(Weight), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_void_p]
+        hip.kf_linear_f32.argtypes = [C.c_void_p, C.POINTER(Weight), C.c_void_p, C.c_void_p]
+        hip.kf_tp_reduce.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         hip.kf_rmsnorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]
         hip.kf_qknorm_rope.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float]
         hip.kf_rope_table_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float]
