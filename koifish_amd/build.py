@@ -19,7 +19,9 @@ LIB_HOST = os.path.join(HERE, "libkf_host.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the kernels spell every fma they want; an implicit contraction would change the rounding
 # points that the oracle pins (RoPE, kf_expf, RMSNorm).
-HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+# -fno-slp-vectorize: keeps the dequant chain in plain v_fma/v_sub (the packed-f32 forms the SLP pass picks cost more issue
+# slots, need s_nop hazard padding and 40 % more registers on this kernel)
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
 def _stale(target, deps):
