@@ -68,15 +68,15 @@ constexpr int ATTN_U = 4; /* key tiles kept in flight per wave */
 __device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <int GQ>
-__global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
+template <int GQ, int NW>
+__global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int hd = a.hd, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int PS = hd + 4; /* {acc[hd], m, l, pad, pad} */
     float* qf = reinterpret_cast<float*>(smem_raw);  // [GQ][hd]
     float* knew = qf + GQ * hd;                      // [hd]
-    float* wmax = knew + hd;                         // [4][GQ]
-    float* mrg = wmax + 4 * GQ;                      // [3][GQ][KF_ATTN_MAX_SPLITS]  (m, l, scale of every slice)
+    float* wmax = knew + hd;                         // [NW][GQ]
+    float* mrg = wmax + NW * GQ;                      // [3][GQ][KF_ATTN_MAX_SPLITS]  (m, l, scale of every slice)
     int* flag = reinterpret_cast<int*>(mrg + 3 * GQ * KF_ATTN_MAX_SPLITS);
     float* comb = reinterpret_cast<float*>(flag + 4);  // [4*KPW][GQ][PS]
 
@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
     const int LPK = hd >> 3, KPW = 64 / LPK, lpk_log2 = __builtin_ctz(LPK);
     const int grp = lane / LPK, d0 = (lane - grp * LPK) * 8;
     const bool has_new = a.k_raw != nullptr;
-    const int tstart = t0 + wave * KPW + grp, tstride = 4 * KPW;
+    const int tstart = t0 + wave * KPW + grp, tstride = NW * KPW;
 
     // ---- issue the first K/V tiles before anything else: they depend neither on the position (read from device memory in
     // graph replay) nor on the previous kernel's q.  Rows up to the launch bound exist in the cache; rows past the real position
@@ -124,10 +124,10 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
     if (!empty) {
         // ---- prologue: q heads of this group, and the new key when it lies in this slice
         const float* tab_pos = a.rope_table ? a.rope_table + (size_t)pos * hd : nullptr;
-        for (int hq = wave; hq < GQ; hq += 4)
+        for (int hq = wave; hq < GQ; hq += NW)
             prep_head(a.q + (size_t)(h0 + hq) * hd, a.rope_table ? a.wq_norm : nullptr, tab_pos, hd, a.eps, qf + hq * hd);
         const bool own_new = has_new && (pos >= t0) && (pos < t1);
-        if (own_new && wave == (GQ & 3)) prep_head(a.k_raw + (size_t)kvh * hd, a.wk_norm, tab_pos, hd, a.eps, knew);
+        if (own_new && wave == (GQ % NW)) prep_head(a.k_raw + (size_t)kvh * hd, a.wk_norm, tab_pos, hd, a.eps, knew);
         __syncthreads();
         if (own_new) {
             uint16_t* krow = a.kcache + (size_t)pos * a.kv_stride + (size_t)kvh * hd;
@@ -195,7 +195,9 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
             __syncthreads();
 #pragma unroll
             for (int hq = 0; hq < GQ; hq++) {
-                const float Mb = fmaxf(fmaxf(wmax[hq], wmax[GQ + hq]), fmaxf(wmax[2 * GQ + hq], wmax[3 * GQ + hq]));
+                float Mb = wmax[hq];
+#pragma unroll
+                for (int w2 = 1; w2 < NW; w2++) Mb = fmaxf(Mb, wmax[w2 * GQ + hq]);
                 if (Mb > M[hq]) {
                     const float sc = fast_exp(M[hq] - Mb);
                     l[hq] *= sc;
@@ -221,7 +223,7 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
         }
 
         // ---- sum the 4*KPW key groups of this workgroup (same reference maximum everywhere: plain sums)
-        const int slot = wave * KPW + grp, nslot = 4 * KPW;
+        const int slot = wave * KPW + grp, nslot = NW * KPW;
 #pragma unroll
         for (int hq = 0; hq < GQ; hq++) {
             float* c = comb + ((size_t)slot * GQ + hq) * PS;
@@ -230,8 +232,6 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
             if (d0 == 0) c[hd] = l[hq];
         }
         __syncthreads();
-        if (tid < GQ * hd) { /* GQ*hd <= 1024; for GQ*hd > 256 the loop below covers the rest */
-        }
         for (int i = tid; i < GQ * hd; i += blockDim.x) {
             const int hq = i / hd, d = i - hq * hd;
             float o = 0.f, L = 0.f;
@@ -283,11 +283,12 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
         ms[hq * KF_ATTN_MAX_SPLITS + sp] = ld_sc1(p + hd);
         ls[hq * KF_ATTN_MAX_SPLITS + sp] = ld_sc1(p + hd + 1);
     }
-    constexpr int NV = (GQ * 128 + 255) / 256; /* output elements per thread (hd <= 128) */
+    constexpr int NT = NW * 64;
+    constexpr int NV = (GQ * 128 + NT - 1) / NT; /* output elements per thread (hd <= 128) */
     float v[NV][KF_ATTN_MAX_SPLITS];
 #pragma unroll
     for (int e = 0; e < NV; e++) {
-        const int i = tid + e * 256;
+        const int i = tid + e * NT;
         const int hq = i / hd, d = i - hq * hd;
         const float* p = a.part + (size_t)(h0 + hq) * nsp * PS + d;
 #pragma unroll
@@ -304,7 +305,7 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs a) {
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < NV; e++) {
-        const int i = tid + e * 256;
+        const int i = tid + e * NT;
         if (i >= GQ * hd) break;
         const int hq = i / hd, d = i - hq * hd;
         float o = 0.f, L = 0.f;
@@ -365,13 +366,15 @@ int attn_launch(hipStream_t st, AttnArgs& a) {
     a.chunk = (a.pos + 1 + nsp - 1) / nsp;
     a.inv_sqrt_hd_den = sqrtf((float)hd);
     const int KPW = 64 / (hd >> 3);
-    const size_t smem = sizeof(float) * ((size_t)GQ * hd + hd + 4 * GQ + 3 * GQ * KF_ATTN_MAX_SPLITS + 4 + (size_t)4 * KPW * GQ * (hd + 4));
+    // 8 waves per workgroup while the per-slot combine buffer fits comfortably in LDS (GQ <= 2), else 4
+    const int NW = GQ <= 2 ? 8 : 4;
+    const size_t smem = sizeof(float) * ((size_t)GQ * hd + hd + NW * GQ + 3 * GQ * KF_ATTN_MAX_SPLITS + 4 + (size_t)NW * KPW * GQ * (hd + 4));
     dim3 grid(nsp, a.n_kv);
     switch (GQ) {
-        case 1: hipLaunchKernelGGL((attn_kernel<1>), grid, dim3(256), smem, st, a); break;
-        case 2: hipLaunchKernelGGL((attn_kernel<2>), grid, dim3(256), smem, st, a); break;
-        case 4: hipLaunchKernelGGL((attn_kernel<4>), grid, dim3(256), smem, st, a); break;
-        case 8: hipLaunchKernelGGL((attn_kernel<8>), grid, dim3(256), smem, st, a); break;
+        case 1: hipLaunchKernelGGL((attn_kernel<1, 8>), grid, dim3(512), smem, st, a); break;
+        case 2: hipLaunchKernelGGL((attn_kernel<2, 8>), grid, dim3(512), smem, st, a); break;
+        case 4: hipLaunchKernelGGL((attn_kernel<4, 4>), grid, dim3(256), smem, st, a); break;
+        case 8: hipLaunchKernelGGL((attn_kernel<8, 4>), grid, dim3(256), smem, st, a); break;
         default: return KF_INVALID_ARGS;
     }
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
