@@ -189,19 +189,28 @@ def cpu_baseline(m, cfg, forced, budget_s):
     ok[:, :p0] = gk[:, :p0]
     ov[:, :p0] = gv[:, :p0]
     gpu_ids = m.tokens_out(cfg["max_seq"])
-    tok, n, match = int(gpu_ids[p0 - 1]), 0, True
+    tok, n, same, near_tie = int(gpu_ids[p0 - 1]), 0, 0, 0
     t0 = time.perf_counter()
+    t_decode = 0.0
     while True:
-        nxt, _, _ = om.decode(tok, p0 + n, want_logits=False)
-        match = match and (nxt == int(gpu_ids[p0 + n]))
-        tok = int(gpu_ids[p0 + n])  # teacher-forced on the GPU's ids so both decode the same sequence
+        t1 = time.perf_counter()
+        nxt, lg, _ = om.decode(tok, p0 + n)
+        t_decode += time.perf_counter() - t1
+        g = int(gpu_ids[p0 + n])
+        if nxt == g:
+            same += 1
+        else:
+            # the oracle's logit of the GPU's pick against its own maximum: a difference of <= 2 bf16 ulps of the maximum is a tie
+            # inside the stated tolerance (bf16 logits, fp32 sums in a different order), not a parity failure
+            l = O.bf16_to_f32(lg)
+            near_tie += int(l[nxt] - l[g] <= 2.0 ** -6 * abs(l[nxt]))
+        tok = g  # teacher-forced on the GPU's ids so both decode the same sequence
         n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or p0 + n >= cfg["max_seq"] - 1:
+        if time.perf_counter() - t0 > budget_s or p0 + n >= cfg["max_seq"] - 1:
             break
-    return {"value": round(n / el, 3), "unit": "tokens/s", "cores": O.num_threads(), "kind": "port",
+    return {"value": round(n / t_decode, 3), "unit": "tokens/s", "cores": O.num_threads(), "kind": "port",
             "sample": "%d decode steps at positions %d..%d of the same 4-bit model, OpenMP over output rows" % (n, p0, p0 + n - 1),
-            "greedy_ids_match_gpu": bool(match)}
+            "greedy_ids_equal_gpu": same, "mismatches_that_are_ties_within_tolerance": near_tie, "mismatches_beyond_tolerance": n - same - near_tie}
 
 
 if __name__ == "__main__":
