@@ -151,9 +151,8 @@ def kernel_roofline(m, ctx, cfg, reps=200):
     state = torch.zeros(4, dtype=torch.int32, device=ctx.device)
     d = head.desc()
 
-    def launch():
-        L.check(ctx.hip.kf_norm_lm_head(ctx.h, x.data_ptr(), nw.data_ptr(), 1e-6, C.byref(d), logits.data_ptr(), state.data_ptr(), None,
-                                        ctx._head_ws.data_ptr()), "kf_norm_lm_head")
+    def launch():   # the head mat-vec alone (no arg-max finish launch): what rocprofv3 lists as kf::gemv_kernel<0, 4, 2>
+        L.check(ctx.hip.kf_lm_head(ctx.h, C.byref(d), x.data_ptr(), logits.data_ptr(), None, ctx._head_ws.data_ptr()), "kf_lm_head")
     for _ in range(10):
         launch()
     e0, e1 = ctx.event(), ctx.event()
@@ -162,7 +161,7 @@ def kernel_roofline(m, ctx, cfg, reps=200):
         launch()
     ctx.record(e1)
     ms = ctx.elapsed_ms(e0, e1) / reps
-    nbytes = head.algorithmic_bytes() + cfg["dim"] * 4 + head.ne0 * 2  # weights + x + norm weight + logits written
+    nbytes = head.algorithmic_bytes() + cfg["dim"] * 2 + head.ne0 * 2  # weights + x + logits written
     ach = nbytes / (ms * 1e-3) / 1e9
     # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this process): FETCH_SIZE x 2
     # (gfx950 correction) + WRITE_SIZE, collected by `rocprofv3 --pmc ... -- python3 scratch/ub_head.py`
@@ -171,7 +170,7 @@ def kernel_roofline(m, ctx, cfg, reps=200):
         traffic = int(json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_lm_head.json")))["hbm_bytes_per_launch"])
     except Exception:
         pass
-    return {"bound": "hbm", "kernel": "kf::gemv_kernel<bf16, argmax> (final norm + LM head 151936x1024 + greedy pick)", "achieved": round(ach, 1),
+    return {"bound": "hbm", "kernel": "kf::gemv_kernel<0, 4, 2> = bf16 LM head 151936x1024 mat-vec + per-workgroup arg-max partials", "achieved": round(ach, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "bytes_per_launch": int(nbytes),
             "us_per_launch": round(ms * 1e3, 2)}
 

@@ -55,6 +55,11 @@ typedef struct kf_weight {
     int32_t nGroup; /* ne0*ne1/lGroup */
     int32_t lGroup; /* T_group, 128 */
     int32_t qMin, qMax, qBias;
+    /* Vendor AutoAWQ tensors (GTensor::qZero / qScale, GeQuant.cpp:410; CU_Q42X_awq quantizer.cu:131-156).  Both non-NULL select the
+     * AWQ GEMM layout: type = KF_Q4, data = qweight int32 [ne1, ne0/8] (TRANSPOSED: input rows), qzeros int32 [ne1/128, ne0/8],
+     * qscales fp16 [ne1/128, ne0]; gama is unused.  Served by kf_linear and kf_dequant (which then writes [ne1, ne0], TransA = 0). */
+    const void* qzeros;
+    const void* qscales;
 } kf_weight;
 
 /* kf_linear epilogue flags */
@@ -99,7 +104,8 @@ int kf_quantize(kf_ctx* ctx, const kf_weight* w, const kf_bf16* src, int symmetr
 
 /* SLP::Forw -> TASKA_AxB::blasLt -> CU_mm_blasLt (Neuron.hpp:418, NeuronFuse.cu:305-381, GTensor.hpp:703-741,
  * gemm.cu:93-214): y[nTok, ne0] = alpha * x[nTok, ne1] . W^T (+ beta*y) (+ bias), fp32 accumulate, bf16 out,
- * computed straight from the packed stream (no GetDataX round trip).  nTok == 1 in round 1.
+ * computed straight from the packed stream (no GetDataX round trip).  x [nTok, ne1], y [nTok, ne0] row-major; nTok > 1 is served by
+ * one mat-vec per token row for now.
  * epilogue KF_EPI_RESIDUAL adds `residual` [ne0]. */
 int kf_linear(kf_ctx* ctx, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const kf_bf16* bias, int nTok, float alpha, float beta,
               uint32_t epilogue, const kf_bf16* residual);
@@ -136,7 +142,7 @@ int kf_add(kf_ctx* ctx, const kf_bf16* a, const kf_bf16* b, kf_bf16* out, int n)
 /* TokenEmbed::cuInfer/OnEmbed (NeuronFuse.cu:176-218, embed.cuh:54-132).  token by value, or *d_token */
 int kf_embed(kf_ctx* ctx, const kf_weight* w, int token, const int32_t* d_token, kf_bf16* out);
 /* Head4Token::cuInfer_1 + sample_argmax (NeuronFuse.cu:842-862, GoPT.cpp:602-612): logits bf16 [ne0] (required) and
- * the greedy id (first maximum) to d_argmax_out (device int32).  scratch: kf_head_scratch_bytes(). */
+ * the greedy id (first maximum) to d_argmax_out (device int32; NULL: logits only, no pick).  scratch: kf_head_scratch_bytes(). */
 int kf_lm_head(kf_ctx* ctx, const kf_weight* w, const kf_bf16* x, kf_bf16* logits, int32_t* d_argmax_out, void* scratch_or_null);
 size_t kf_head_scratch_bytes(void);
 

@@ -15,6 +15,8 @@ struct kf_ctx {
     bool capturing;
     float* amax_val; /* per-workgroup partial maxima for kf_lm_head when the caller passes no scratch */
     int* amax_idx;
+    float* awq_ws; /* slice partials of the AWQ mat-vec, grown on demand (never while capturing) */
+    size_t awq_ws_bytes;
 };
 struct kf_graph {
     hipGraph_t graph;
@@ -68,6 +70,7 @@ int kf_init(int device, void* stream, kf_ctx** out) {
     }
     HIPCHK(hipMalloc(&c->amax_val, sizeof(float) * kf::KF_MAX_ARGMAX_PARTIALS));
     HIPCHK(hipMalloc(&c->amax_idx, sizeof(int) * kf::KF_MAX_ARGMAX_PARTIALS));
+    c->awq_ws = nullptr, c->awq_ws_bytes = 0;
     *out = c;
     return KF_OK;
 }
@@ -76,6 +79,7 @@ int kf_destroy(kf_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->amax_val), (void)hipFree(c->amax_idx);
+    if (c->awq_ws) (void)hipFree(c->awq_ws);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return KF_OK;
@@ -186,6 +190,11 @@ static int check_weight(const kf_weight* w, const char* who) {
     if (!w || !w->data) return fail(KF_INVALID_ARGS, "%s: null weight", who);
     if (w->ne0 <= 0 || w->ne1 <= 0) return fail(KF_INVALID_ARGS, "%s: bad shape %d x %d", who, w->ne0, w->ne1);
     if (!al16(w->data)) return fail(KF_BLAS_UNALIGN, "%s: weight data not 16-byte aligned", who);
+    if (w->qzeros || w->qscales) { /* AutoAWQ layout */
+        if (!w->qzeros || !w->qscales || w->type != KF_Q4 || w->lGroup != 128 || (w->ne0 % 8) || (w->ne1 % 128) || !al16(w->qscales))
+            return fail(KF_QUANT_ERR, "%s: malformed AWQ weight (%d x %d, group %d)", who, w->ne0, w->ne1, w->lGroup);
+        return KF_OK;
+    }
     switch (w->type) {
         case KF_BF16: case KF_F8E5M2: break;
         case KF_Q4: case KF_T_SIGN: case KF_BOOL1: case KF_T_BINARY:
@@ -202,6 +211,7 @@ int kf_dequant(kf_ctx* c, const kf_weight* w, kf_bf16* out) {
     int r = check_weight(w, "kf_dequant");
     if (r) return r;
     if (!out || !al16(out)) return fail(KF_BLAS_UNALIGN, "kf_dequant: out null/unaligned");
+    if (w->qzeros) RET(kf::awq_dequant_launch(c->stream, w, out));
     RET(kf::dequant_launch(c->stream, w, out));
 }
 int kf_quantize(kf_ctx* c, const kf_weight* w, const kf_bf16* src, int symmetric) {
@@ -219,16 +229,38 @@ int kf_linear(kf_ctx* c, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const
     CHKCTX(c);
     int r = check_weight(w, "kf_linear");
     if (r) return r;
-    if (nTok != 1) return fail(KF_INVALID_ARGS, "kf_linear: nTok=%d (the decode path is nTok=1; batched prefill is a later round)", nTok);
+    if (nTok < 1) return fail(KF_INVALID_ARGS, "kf_linear: nTok=%d", nTok);
     if (!x || !y || !al16(x)) return fail(KF_BLAS_UNALIGN, "kf_linear: x/y null or x unaligned");
     if ((epilogue & KF_EPI_RESIDUAL) && !residual) return fail(KF_INVALID_ARGS, "kf_linear: residual epilogue without residual");
-    kf::GemvLaunch L;
-    init_args(L);
-    L.n = 1, L.w[0] = w, L.mode = kf::GEMV_PLAIN;
-    L.args.x = x, L.args.job[0].y = y;
-    L.args.bias = bias, L.args.alpha = alpha, L.args.beta = beta;
-    L.args.residual = (epilogue & KF_EPI_RESIDUAL) ? residual : nullptr;
-    RET(kf::gemv_launch(c->stream, L));
+    if (nTok > 1 && ((w->ne1 * 2) % 16 != 0)) return fail(KF_BLAS_UNALIGN, "kf_linear: token rows of x are not 16-byte aligned");
+    // nTok > 1 (SLP::Forw with a batch of tokens: x [nTok, ne1] row-major, y [nTok, ne0]): one mat-vec launch per token row.  Correct for
+    // every weight type; the weight stream is re-read per token (a tiled MFMA kernel for prefill is the next step).
+    if (w->qzeros) { /* AutoAWQ layout: its own transposed mat-vec */
+        const size_t need = kf::awq_scratch_bytes(w);
+        if (need > c->awq_ws_bytes) {
+            if (c->capturing) return fail(KF_INVALID_ARGS, "kf_linear: the AWQ workspace must be sized by one eager call before graph capture");
+            if (c->awq_ws) HIPCHK(hipFree(c->awq_ws));
+            HIPCHK(hipMalloc(&c->awq_ws, need));
+            c->awq_ws_bytes = need;
+        }
+        for (int t = 0; t < nTok; t++) {
+            int rc = kf::awq_linear_launch(c->stream, w, x + (size_t)t * w->ne1, y + (size_t)t * w->ne0, bias, alpha, beta,
+                                           (epilogue & KF_EPI_RESIDUAL) ? residual + (size_t)t * w->ne0 : nullptr, c->awq_ws);
+            if (rc != KF_OK) return fail(rc, "kf_linear (AWQ) failed with %d", rc);
+        }
+        return KF_OK;
+    }
+    for (int t = 0; t < nTok; t++) {
+        kf::GemvLaunch L;
+        init_args(L);
+        L.n = 1, L.w[0] = w, L.mode = kf::GEMV_PLAIN;
+        L.args.x = x + (size_t)t * w->ne1, L.args.job[0].y = y + (size_t)t * w->ne0;
+        L.args.bias = bias, L.args.alpha = alpha, L.args.beta = beta;
+        L.args.residual = (epilogue & KF_EPI_RESIDUAL) ? residual + (size_t)t * w->ne0 : nullptr;
+        int rc = kf::gemv_launch(c->stream, L);
+        if (rc != KF_OK) return fail(rc, "kf_linear failed with %d", rc);
+    }
+    return KF_OK;
 }
 
 int kf_linear_f32(kf_ctx* c, const kf_weight* w, const kf_bf16* x, float* y) {
@@ -388,7 +420,7 @@ static int head_impl(kf_ctx* c, const kf_bf16* x, const kf_bf16* norm_w, float e
     L.args.amax_val = av, L.args.amax_idx = ai;
     r = kf::gemv_launch(c->stream, L);
     if (r) return fail(r, "%s: gemv failed with %d", who, r);
-    kf::argmax_finish_launch(c->stream, av, ai, L.blocks, d_argmax, d_state, d_tokens_out);
+    if (d_argmax || d_state) kf::argmax_finish_launch(c->stream, av, ai, L.blocks, d_argmax, d_state, d_tokens_out); /* both NULL: logits only */
     return hipGetLastError() == hipSuccess ? KF_OK : fail(KF_HIP_CHECK, "%s: launch failed", who);
 }
 int kf_lm_head(kf_ctx* c, const kf_weight* w, const kf_bf16* x, kf_bf16* logits, int32_t* d_argmax_out, void* scratch) {

@@ -505,6 +505,7 @@ int gemv_launch(hipStream_t st, GemvLaunch& L) {
     for (int j = 0; j < L.n; j++) {
         const kf_weight* w = L.w[j];
         if (fmt_of(w->type) != fmt || w->ne1 != K) return KF_INVALID_ARGS;
+        if (w->qzeros || w->qscales) return KF_UNSUPPORTED_DATATYPE; /* AutoAWQ layout: kf_linear only */
         if (((uintptr_t)w->data & 15) != 0) return KF_BLAS_UNALIGN;
         if ((unsigned long long)w->ne0 * (unsigned long long)nBlk >= (1ull << 32)) return KF_INVALID_ARGS;
         GemvJob& jb = a.job[j];

@@ -81,6 +81,12 @@ int embed_launch(hipStream_t st, const kf_weight* w, int token, const int32_t* d
                  uint16_t* out);
 int dequant_launch(hipStream_t st, const kf_weight* w, uint16_t* out);
 int quantize_launch(hipStream_t st, const kf_weight* w, const uint16_t* src, int symmetric);
+// ---- AutoAWQ layout (kf_awq.hip)
+size_t awq_scratch_bytes(const kf_weight* w);
+int awq_linear_launch(hipStream_t st, const kf_weight* w, const uint16_t* x, uint16_t* y, const uint16_t* bias, float alpha, float beta,
+                      const uint16_t* residual, float* scratch);
+int awq_dequant_launch(hipStream_t st, const kf_weight* w, uint16_t* out);
+
 int set_state_launch(hipStream_t st, int32_t* d_state, int token, int pos);
 int tp_reduce_launch(hipStream_t st, const float* partials, int R, int n, const uint16_t* residual, uint16_t* out);
 

@@ -28,7 +28,7 @@ class KFError(RuntimeError):
 class Weight(C.Structure):
     """struct kf_weight (include/kf_abi.h)"""
     _fields_ = [("data", C.c_void_p), ("gama", C.c_void_p), ("type", C.c_int32), ("ne0", C.c_int32), ("ne1", C.c_int32), ("nGroup", C.c_int32),
-                ("lGroup", C.c_int32), ("qMin", C.c_int32), ("qMax", C.c_int32), ("qBias", C.c_int32)]
+                ("lGroup", C.c_int32), ("qMin", C.c_int32), ("qMax", C.c_int32), ("qBias", C.c_int32), ("qzeros", C.c_void_p), ("qscales", C.c_void_p)]
 
 
 _libs = None

@@ -50,7 +50,7 @@ class DevWeight:
     def desc(self):
         p = self.blob.data_ptr()
         return L.Weight(p, (p + self.szData) if self.quantised else None, self.type, self.ne0, self.ne1, self.nGroup, self.lGroup, self.qMin, self.qMax,
-                        self.qBias)
+                        self.qBias, None, None)
 
     def algorithmic_bytes(self):
         """what a mat-vec has to read: packed data + zero/step"""
@@ -60,6 +60,21 @@ class DevWeight:
         g = self.blob[self.szData:].view(torch.bfloat16)
         z0 = self.ne0 + self.ne1
         return g[z0:z0 + self.nGroup], g[z0 + self.nGroup:z0 + 2 * self.nGroup]
+
+
+class AWQDevWeight:
+    """Vendor AutoAWQ tensors in HBM: qweight int32 [in, out/8], qzeros int32 [in/128, out/8], scales fp16 [in/128, out]."""
+
+    def __init__(self, n_out, n_in, qweight, qzeros, scales):
+        self.type, self.ne0, self.ne1, self.lGroup = L.Q4, n_out, n_in, 128
+        self.qweight, self.qzeros, self.scales = qweight.contiguous(), qzeros.contiguous(), scales.contiguous()
+
+    def desc(self):
+        return L.Weight(self.qweight.data_ptr(), None, L.Q4, self.ne0, self.ne1, self.ne0 * self.ne1 // 128, 128, 0, 15, 0, self.qzeros.data_ptr(),
+                        self.scales.data_ptr())
+
+    def algorithmic_bytes(self):
+        return self.qweight.numel() * 4 + self.qzeros.numel() * 4 + self.scales.numel() * 2
 
 
 def _ptr(t):
@@ -134,7 +149,8 @@ class Context:
 
     # ---- operators (each one ABI call)
     def dequant(self, w):
-        out = torch.empty(w.ne0, w.ne1, dtype=torch.bfloat16, device=self.device)
+        shape = (w.ne1, w.ne0) if isinstance(w, AWQDevWeight) else (w.ne0, w.ne1)   # AWQ: [in, out] (TransA = 0)
+        out = torch.empty(*shape, dtype=torch.bfloat16, device=self.device)
         d = w.desc()
         L.check(self.hip.kf_dequant(self.h, C.byref(d), _ptr(out)), "kf_dequant")
         return out

@@ -38,7 +38,9 @@
 enum {
     KFO_F32 = 0, KFO_F64, KFO_F16, KFO_BF16, KFO_F8E5M2, KFO_F8E4M3, KFO_U8, KFO_I8, KFO_U16, KFO_I16,
     KFO_U32, KFO_I32, KFO_U64, KFO_I64, KFO_Q4, KFO_Q3, KFO_Q2, KFO_T_SIGN, KFO_T_SEQ, KFO_BOOL1,
-    KFO_T_BINARY, KFO_T_BINARY_3, KFO_T_BINARY_TILE
+    KFO_T_BINARY, KFO_T_BINARY_3, KFO_T_BINARY_TILE,
+    /* oracle-internal tag (not a typNUMBER): a Q4 tensor in the vendor AutoAWQ GEMM layout, see section 3b */
+    KFO_Q4_AWQ = 100
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -292,6 +294,28 @@ KFO_API void kfo_dequant_q128(const uint8_t* packed, const uint16_t* zero, const
     }
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * 3b. AutoAWQ GEMM format -- CU_Q42X_awq + CU_I2Q4_unpack (kernel/quantizer.cu:131-156, kernel/packedN.cuh:109-116;
+ *     the same unpack is spelled in the reference's src/Python/test_awq.py:32-66 as shifts [0,4,..,28] re-ordered by
+ *     AWQ_REVERSE_ORDER = {0,4,1,5,2,6,3,7}).  qweight int32 [in, out/8], qzeros int32 [in/128, out/8], scales fp16 [in/128, out];
+ *     element k of a word sits at bits 4*ORDER[k]; W^T[i, o] = bf16( (q - z) * float(scale) )  (TransA = 0: the dequantised
+ *     matrix is [in, out], GeQuant.cpp:989-992).
+ * ---------------------------------------------------------------------------------------------- */
+static const int KFO_AWQ_ORDER[8] = {0, 4, 1, 5, 2, 6, 3, 7};
+static inline int awq_nibble(uint32_t word, int k) { return (int)((word >> (KFO_AWQ_ORDER[k] * 4)) & 0x0F); }
+static inline float awq_weight(const uint32_t* qweight, const uint32_t* qzeros, const uint16_t* scales, int n_out, int i, int o) {
+    const int g = i / 128, w8 = n_out / 8;
+    const int q = awq_nibble(qweight[(size_t)i * w8 + o / 8], o % 8), z = awq_nibble(qzeros[(size_t)g * w8 + o / 8], o % 8);
+    const float g0 = (float)(q - z) * kfo_half_to_f32(scales[(size_t)g * n_out + o]);
+    return kfo_round_bf16(g0);
+}
+/* mat0 [in, out] exactly as the reference's GetDataX leaves it in tmpTernary */
+KFO_API void kfo_dequant_awq(const uint32_t* qweight, const uint32_t* qzeros, const uint16_t* scales, int n_in, int n_out, uint16_t* out) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n_in; i++)
+        for (int o = 0; o < n_out; o++) out[(size_t)i * n_out + o] = kfo_f32_to_bf16(awq_weight(qweight, qzeros, scales, n_out, i, o));
+}
+
 /* CU_F82Float (kernel/operator.cuh:536-543): dst = T(float(f8e5m2)) */
 KFO_API void kfo_f8e5m2_to_bf16(const uint8_t* src, size_t n, uint16_t* dst) {
     for (size_t i = 0; i < n; i++) dst[i] = kfo_f32_to_bf16(kfo_f8e5m2_to_f32(src[i]));
@@ -321,7 +345,7 @@ typedef struct {
 
 static int bits_of(int type) {
     switch (type) {
-        case KFO_Q4: return 4;
+        case KFO_Q4: case KFO_Q4_AWQ: return 4;
         case KFO_T_SIGN: case KFO_Q2: return 2;
         case KFO_BOOL1: case KFO_T_BINARY: return 1;
         case KFO_F8E5M2: return 8;
@@ -338,6 +362,9 @@ static void weight_row_f32(const kfo_weight* w, long r, float* out) {
     } else if (w->type == KFO_F8E5M2) {
         const uint8_t* p = (const uint8_t*)w->data + (size_t)r * K;
         for (int c = 0; c < K; c++) out[c] = kfo_round_bf16(kfo_f8e5m2_to_f32(p[c]));
+    } else if (w->type == KFO_Q4_AWQ) { /* logical W[out = ne0, in = ne1]; data = qweight, zero = qzeros, step = fp16 scales */
+        for (int c = 0; c < K; c++)
+            out[c] = awq_weight((const uint32_t*)w->data, (const uint32_t*)w->zero, w->step, w->ne0, c, (int)r);
     } else {
         const int bits = bits_of(w->type), lG = w->lGroup, nQuant = 128 / bits, nLevel = 1 << bits;
         size_t e0 = (size_t)r * K; /* flattened element offset; K % lGroup == 0 so rows start on a group */

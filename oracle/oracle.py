@@ -18,6 +18,7 @@ _LIB = None
 F32, F64, F16, BF16, F8E5M2, F8E4M3, U8, I8, U16, I16, U32, I32, U64, I64, Q4, Q3, Q2, T_SIGN, T_SEQ, BOOL1, T_BINARY, T_BINARY_3, T_BINARY_TILE = range(23)
 BITS = {BF16: 16, F8E5M2: 8, Q4: 4, T_SIGN: 2, Q2: 2, BOOL1: 1, T_BINARY: 1}
 
+Q4_AWQ = 100  # oracle-internal tag: Q4 in the AutoAWQ GEMM layout
 ATTN_REF, ATTN_FUSED = 0, 1
 
 
@@ -163,6 +164,48 @@ def dequant(w):
     d = w.cdesc()
     lib().kfo_dequant_weight(C.byref(d), _p(out))
     return out.reshape(w.ne0, w.ne1)
+
+
+class AWQWeight(QWeight):
+    """qweight int32 [in, out/8], qzeros int32 [in/128, out/8], scales fp16 [in/128, out]; logical W[out, in]."""
+
+    def __init__(self, n_out, n_in, qweight, qzeros, scales):
+        self.type, self.ne0, self.ne1 = Q4_AWQ, n_out, n_in
+        self.data = np.ascontiguousarray(qweight, dtype=np.uint32)
+        self.qzeros = np.ascontiguousarray(qzeros, dtype=np.uint32)
+        self.scales = np.ascontiguousarray(scales, dtype=np.float16)
+        self.zero, self.step = self.qzeros, self.scales  # carried in the zero/step slots of the C descriptor
+        self.lGroup, self.qBias = 128, 0
+
+    @property
+    def bits(self):
+        return 4
+
+    def cdesc(self):
+        class _W(C.Structure):
+            _fields_ = [("type", C.c_int), ("ne0", C.c_int), ("ne1", C.c_int), ("data", C.c_void_p), ("zero", C.c_void_p),
+                        ("step", C.c_void_p), ("lGroup", C.c_int), ("qBias", C.c_int)]
+        return _W(self.type, self.ne0, self.ne1, _p(self.data), _p(self.qzeros), _p(self.scales), 128, 0)
+
+    def nbytes_algorithmic(self):
+        return self.data.nbytes + self.qzeros.nbytes + self.scales.nbytes
+
+
+def dequant_awq(w):
+    """[in, out] bf16, as the reference's GetDataX leaves it (TransA = 0)"""
+    out = np.zeros((w.ne1, w.ne0), dtype=np.uint16)
+    lib().kfo_dequant_awq(_p(w.data), _p(w.qzeros), _p(w.scales), w.ne1, w.ne0, _p(out))
+    return out
+
+
+def awq_pack(q_int, order=(0, 2, 4, 6, 1, 3, 5, 7)):
+    """int array [..., n] (values 0..15) -> uint32 [..., n/8] in AutoAWQ nibble order (AWQ_ORDER of src/Python/test_awq.py:50)"""
+    q = np.asarray(q_int, dtype=np.uint32)
+    q = q.reshape(q.shape[:-1] + (-1, 8))
+    out = np.zeros(q.shape[:-1], dtype=np.uint32)
+    for pos, k in enumerate(order):    # nibble `pos` of the word holds element order[pos]
+        out |= (q[..., k] & 0xF) << np.uint32(4 * pos)
+    return out
 
 
 def dequant_q128(packed, zero, step, lGroup, bits, qBias):

@@ -110,7 +110,7 @@ def test_linear_rejects_bad_args(ctx, O):
     x = torch.zeros(256, dtype=torch.bfloat16, device=ctx.device)
     y = torch.zeros(16, dtype=torch.bfloat16, device=ctx.device)
     d = dw.desc()
-    assert ctx.hip.kf_linear(ctx.h, C.byref(d), x.data_ptr(), y.data_ptr(), None, 2, 1.0, 0.0, 0, None) == -20  # nTok != 1
+    assert ctx.hip.kf_linear(ctx.h, C.byref(d), x.data_ptr(), y.data_ptr(), None, 0, 1.0, 0.0, 0, None) == -20  # nTok < 1
     d.type = L.Q3
     assert ctx.hip.kf_linear(ctx.h, C.byref(d), x.data_ptr(), y.data_ptr(), None, 1, 1.0, 0.0, 0, None) == -1000
     d = dw.desc()
@@ -263,3 +263,53 @@ def test_fused_launches_equal_unfused(ctx, O):
     u = ctx.quantize(bf16_t(rand_w(rng, ffn, dim), ctx.device), L.Q4)
     act = ctx.norm_gateup_swiglu(x, nw, g, u)
     assert torch.equal(act, ctx.swiglu(ctx.linear(g, xn), ctx.linear(u, xn)))
+
+
+def test_linear_batch_of_tokens(ctx, O):
+    """SLP::Forw with nToken > 1: y[t] = W . x[t] for every token row"""
+    import ctypes as C
+    rng = np.random.default_rng(41)
+    m, k, nt = 192, 512, 5
+    w = rand_w(rng, m, k)
+    x = O.f32_to_bf16(rng.normal(0, 1.0, size=(nt, k)).astype(np.float32))
+    ow = oracle_weight(O, w, m, k, L.Q4)
+    dw = ctx.upload_blob(L.Q4, m, k, ow.blob())
+    xd = bf16_t(x, ctx.device)
+    y = torch.zeros(nt, m, dtype=torch.bfloat16, device=ctx.device)
+    d = dw.desc()
+    assert ctx.hip.kf_linear(ctx.h, C.byref(d), xd.data_ptr(), y.data_ptr(), None, nt, 1.0, 0.0, 0, None) == 0
+    for t in range(nt):
+        assert close_bf16(u16(y[t]), O.linear(ow, x[t])).all()
+
+
+def _awq_case(O, rng, n_in, n_out):
+    q = rng.integers(0, 16, size=(n_in, n_out))
+    z = rng.integers(0, 16, size=(n_in // 128, n_out))
+    s = rng.uniform(0.003, 0.012, size=(n_in // 128, n_out)).astype(np.float16)
+    return O.AWQWeight(n_out, n_in, O.awq_pack(q), O.awq_pack(z), s)
+
+
+@pytest.mark.parametrize("shape", [(1024, 2048), (2048, 1024), (3072, 1024), (256, 64)])
+def test_awq_layout_dequant_and_linear(ctx, O, shape):
+    """vendor AutoAWQ GEMM format (CU_Q42X_awq): dequant bit-exact, mat-vec within 1 ulp of the oracle"""
+    from koifish_amd.runtime import AWQDevWeight
+    n_in, n_out = shape
+    rng = np.random.default_rng(n_in + n_out)
+    ow = _awq_case(O, rng, n_in, n_out)
+    dw = AWQDevWeight(n_out, n_in, torch.from_numpy(ow.data.view(np.int32)).to(ctx.device), torch.from_numpy(ow.qzeros.view(np.int32)).to(ctx.device),
+                      torch.from_numpy(ow.scales.view(np.int16)).to(ctx.device))
+    assert np.array_equal(u16(ctx.dequant(dw)), O.dequant_awq(ow))
+    x = O.f32_to_bf16(rng.normal(0, 1.0, size=n_in).astype(np.float32))
+    y = u16(ctx.linear(dw, bf16_t(x, ctx.device)))
+    ref = O.linear(ow, x)
+    assert close_bf16(y, ref).all() and (ulp_diff_bf16(y, ref) > 0).mean() <= 5e-3
+    res = O.f32_to_bf16(rng.normal(0, 0.5, size=n_out).astype(np.float32))
+    y2 = u16(ctx.linear(dw, bf16_t(x, ctx.device), residual=bf16_t(res, ctx.device)))
+    assert close_bf16(y2, O.add(res, ref)).all()
+    # the fused entry points refuse this layout instead of misreading it
+    import ctypes as C
+    d = dw.desc()
+    wp = (C.c_void_p * 1)(C.addressof(d))
+    yy = torch.zeros(n_out, dtype=torch.bfloat16, device=ctx.device)
+    yp = (C.c_void_p * 1)(yy.data_ptr())
+    assert ctx.hip.kf_norm_linear(ctx.h, bf16_t(x, ctx.device).data_ptr(), None, 1e-6, 1, wp, yp, None, 0, None) == -1000

@@ -106,3 +106,27 @@ def test_linear_dot_order_is_the_16_lane_order(O):
         s4 = s8[:4] + s8[4:]
         ref = np.float32(np.float32(s4[0] + s4[1]) + np.float32(s4[2] + s4[3]))
         assert got[r] == ref
+
+
+def test_awq_unpack_matches_the_reference_script_semantics(O):
+    """src/Python/test_awq.py:32-66 (unpack_awq + reverse_awq_order) restated in numpy: shifts [0,4,..,28], columns re-ordered by
+    AWQ_REVERSE_ORDER = [0,4,1,5,2,6,3,7]; packing uses AWQ_ORDER = [0,2,4,6,1,3,5,7]; dequant (q - z) * scale -> bf16
+    (CU_Q42X_awq, quantizer.cu:131-156)."""
+    rng = np.random.default_rng(17)
+    n_in, n_out = 256, 64
+    q = rng.integers(0, 16, size=(n_in, n_out))
+    z = rng.integers(0, 16, size=(n_in // 128, n_out))
+    s = rng.uniform(0.003, 0.012, size=(n_in // 128, n_out)).astype(np.float16)
+    w = O.AWQWeight(n_out, n_in, O.awq_pack(q), O.awq_pack(z), s)
+    shifts = np.arange(0, 32, 4)
+    rev = np.arange(n_out).reshape(-1, 8)[:, [0, 4, 1, 5, 2, 6, 3, 7]].reshape(-1)
+    iw = ((w.data[:, :, None] >> shifts[None, None, :]) & 0xF).reshape(n_in, -1)[:, rev]
+    iz = ((w.qzeros[:, :, None] >> shifts[None, None, :]) & 0xF).reshape(n_in // 128, -1)[:, rev]
+    assert np.array_equal(iw, q) and np.array_equal(iz, z)
+    # a word whose elements are 0..7 packs to 0x75316420 (element k at nibble AWQ_REVERSE_ORDER[k])
+    assert O.awq_pack(np.arange(8))[0] == 0x75316420
+    ref = (q - np.repeat(z, 128, axis=0)).astype(np.float32) * np.repeat(s.astype(np.float32), 128, axis=0)
+    assert np.array_equal(O.dequant_awq(w), O.f32_to_bf16(ref).reshape(n_in, n_out))
+    x = O.f32_to_bf16(rng.normal(0, 1, size=n_in).astype(np.float32))
+    exact = O.bf16_to_f32(O.dequant_awq(w)).astype(np.float64).T @ O.bf16_to_f32(x).astype(np.float64)
+    assert np.abs(O.bf16_to_f32(O.linear(w, x)) - exact).max() <= 2.0 ** -8 * np.abs(exact).max() + 1e-6
