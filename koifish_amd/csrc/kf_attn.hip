@@ -367,12 +367,12 @@ int attn_launch(hipStream_t st, AttnArgs& a) {
     a.inv_sqrt_hd_den = sqrtf((float)hd);
     const int KPW = 64 / (hd >> 3);
     // 8 waves per workgroup while the per-slot combine buffer fits comfortably in LDS (GQ <= 2), else 4
-    const int NW = GQ <= 2 ? 8 : 4;
+    const int NW = (GQ <= 2 && a.pos >= 256) ? 8 : 4; /* measured: 4 waves win below ~256 keys, 8 above; 16 lose everywhere */
     const size_t smem = sizeof(float) * ((size_t)GQ * hd + hd + NW * GQ + 3 * GQ * KF_ATTN_MAX_SPLITS + 4 + (size_t)NW * KPW * GQ * (hd + 4));
     dim3 grid(nsp, a.n_kv);
     switch (GQ) {
-        case 1: hipLaunchKernelGGL((attn_kernel<1, 8>), grid, dim3(512), smem, st, a); break;
-        case 2: hipLaunchKernelGGL((attn_kernel<2, 8>), grid, dim3(512), smem, st, a); break;
+        case 1: if (NW == 8) hipLaunchKernelGGL((attn_kernel<1, 8>), grid, dim3(512), smem, st, a); else hipLaunchKernelGGL((attn_kernel<1, 4>), grid, dim3(256), smem, st, a); break;
+        case 2: if (NW == 8) hipLaunchKernelGGL((attn_kernel<2, 8>), grid, dim3(512), smem, st, a); else hipLaunchKernelGGL((attn_kernel<2, 4>), grid, dim3(256), smem, st, a); break;
         case 4: hipLaunchKernelGGL((attn_kernel<4, 4>), grid, dim3(256), smem, st, a); break;
         case 8: hipLaunchKernelGGL((attn_kernel<8, 4>), grid, dim3(256), smem, st, a); break;
         default: return KF_INVALID_ARGS;
