@@ -49,6 +49,7 @@ struct GemvLaunch {
 };
 
 int gemv_launch(hipStream_t st, GemvLaunch& L);
+int gemv_q4lut_launch(hipStream_t st, GemvLaunch& L, bool* used); /* kf_gemv_lut.hip: table-lookup form for large 4-bit matrices */
 void argmax_finish_launch(hipStream_t st, const float* val, const int* idx, int n, int32_t* d_argmax, int32_t* d_state, int32_t* d_tokens_out);
 
 // ---- attention (kf_attn.hip)
