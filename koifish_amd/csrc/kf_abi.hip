@@ -250,6 +250,16 @@ int kf_linear(kf_ctx* c, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const
         }
         return KF_OK;
     }
+    static int gemm_min = -1; /* token rows from which the MFMA tile kernel replaces the per-token mat-vec loop */
+    if (gemm_min < 0) {
+        const char* e = getenv("KF_GEMM_MIN");
+        gemm_min = e ? atoi(e) : 8;
+    }
+    if (nTok >= gemm_min) {
+        const int rc = kf::gemm_launch(c->stream, w, x, w->ne1, nTok, y, w->ne0, bias, alpha, beta, (epilogue & KF_EPI_RESIDUAL) ? residual : nullptr, w->ne0);
+        if (rc < 0) return fail(rc, "kf_linear (token-batch GEMM) failed with %d", rc);
+        if (rc == KF_OK) return KF_OK;
+    }
     for (int t = 0; t < nTok; t++) {
         kf::GemvLaunch L;
         init_args(L);

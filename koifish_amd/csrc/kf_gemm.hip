@@ -1,0 +1,387 @@
+// kf_gemm.hip -- fused PackedQ unpack + MFMA GEMM for a batch of tokens (prefill, SLP::Forw with nToken > 1), gfx950 / wave64.
+//
+// Reference: SLP::Forw (NeuronFuse.cu:305-381) -> GTensor::GetDataX dequantises the WHOLE weight to bf16 in gBUFF->tmpTernary
+// (quantizer.cu:249-392), then cuBLASLt multiplies (gemm.cu:93-214); Fish::Chat feeds the prompt one token at a time through it
+// (GoPT.cpp:1139-1146).  Here y[n, M] = x[n, K] . W[M, K]^T reads the packed stream once per 128-token tile, dequantises 8 weights
+// per lane in registers with the reference's bf16-stepwise arithmetic (T.cu:274) straight into an MFMA A-fragment, and contracts on
+// v_mfma_f32_32x32x16_bf16 against x fragments staged through LDS.
+//
+// Fragment mapping (cdna_hip_programming.md section 3): for the 32x32x16 bf16 MFMA lane l (r = l & 31, h = l >> 5) holds
+// A[row r][k = 8h + j] and B[k = 8h + j][col r], j = 0..7; D has col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 h.
+// A = weights (rows = output features), B = x^T (cols = tokens).  The contraction index may be visited in any order as long as A and B
+// agree, so the two lane halves do not take k and k+8 of one 16-wide step: over a staged tile of 128 k, half h owns whole 16-byte
+// packed blocks (4-bit: blocks 2p + h; 2-bit: block h; 1-bit: the 8-byte half h of the block; bf16 / f8: the same element ranges) and
+// walks them 8 elements per MFMA step.  Every lane therefore issues plain 16-byte (8-byte for 1-bit) loads of the packed stream and
+// never exchanges data with another lane; the x fragment of a step is read from LDS at the matching element offset.
+//
+// Workgroup = 4 waves = RBW row blocks of 32 output rows x KS halves of the staged k tile (KS = 1: 128 rows; KS = 2: 64 rows, each k
+// half on its own wave, partial sums combined through LDS in a fixed order).  Grid = (row tiles, 128-token tiles).
+// fp32 accumulation inside the MFMA, one bf16 round-to-nearest store; epilogue order as the mat-vec (alpha, beta*y, bias, store,
+// residual add + store).  Differs from the token-serial mat-vec only in fp32 summation order.
+#include "kf_kernels.h"
+
+namespace kf {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GM_TOK = 128;         /* tokens per workgroup tile (4 MFMA column blocks) */
+constexpr int GM_KT = 128;          /* k per staged x tile */
+constexpr int GM_XS = GM_KT + 8;    /* padded LDS row in bf16 elements: 272 B, ds_read_b128 of 32 rows is conflict-free */
+
+struct GemmArgs {
+    const unsigned char* w;
+    const uint16_t* zero;
+    const uint16_t* step;
+    float qBias;
+    int M, K, nBlk, gshift;
+    const uint16_t* x;
+    long long ldx;
+    int n;
+    uint16_t* y;
+    long long ldy;
+    const uint16_t* bias;
+    const uint16_t* residual;
+    long long ldr;
+    float alpha, beta;
+};
+
+// ---- 8 consecutive weights -> 4 packed bf16 pairs (element 2i in the low half of word i)
+__device__ __forceinline__ u32x4 frag_q4(uint32_t D, float step, float step16, float nb, float zero) {
+    uint32_t H = D & 0xF0F0F0F0u, L = D & 0x0F0F0F0Fu;
+    asm("" : "+v"(H)); /* opaque masks keep the byte extractions as v_cvt_f32_ubyteN (see kf_gemv.hip) */
+    asm("" : "+v"(L));
+    u32x4 o;
+    uint32_t r;
+    r = pack_bf16x2(fmaf((float)(H >> 24), step16, nb), fmaf((float)(L >> 24), step, nb));
+    o.x = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
+    r = pack_bf16x2(fmaf((float)((H >> 16) & 0xffu), step16, nb), fmaf((float)((L >> 16) & 0xffu), step, nb));
+    o.y = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
+    r = pack_bf16x2(fmaf((float)((H >> 8) & 0xffu), step16, nb), fmaf((float)((L >> 8) & 0xffu), step, nb));
+    o.z = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
+    r = pack_bf16x2(fmaf((float)(H & 0xffu), step16, nb), fmaf((float)(L & 0xffu), step, nb));
+    o.w = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
+    return o;
+}
+// 16 bits, element 0 in bits 15..14
+__device__ __forceinline__ u32x4 frag_q2(uint32_t v, float step, float nb, float zero) {
+    uint32_t o[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const float q0 = (float)((v >> (14 - 4 * p)) & 3u), q1 = (float)((v >> (12 - 4 * p)) & 3u);
+        const uint32_t r = pack_bf16x2(fmaf(q0, step, nb), fmaf(q1, step, nb));
+        o[p] = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
+    }
+    return u32x4{o[0], o[1], o[2], o[3]};
+}
+// 8 bits, element 0 in bit 7; w0 / w1 = dequant(0) / dequant(1) as bf16 bit patterns
+__device__ __forceinline__ u32x4 frag_q1(uint32_t b, uint32_t w0, uint32_t w1) {
+    uint32_t o[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const uint32_t lo = ((b >> (7 - 2 * p)) & 1u) ? w1 : w0, hi = ((b >> (6 - 2 * p)) & 1u) ? w1 : w0;
+        o[p] = lo | (hi << 16);
+    }
+    return u32x4{o[0], o[1], o[2], o[3]};
+}
+// 8 f8e5m2 bytes (element i = byte i): value = half(byte << 8), exact in bf16
+__device__ __forceinline__ u32x4 frag_f8(uint32_t D0, uint32_t D1) {
+    u32x4 o;
+    o.x = pack_bf16x2(half_bits_to_f32((D0 << 8) & 0xff00u), half_bits_to_f32(D0 & 0xff00u));
+    o.y = pack_bf16x2(half_bits_to_f32((D0 >> 8) & 0xff00u), half_bits_to_f32((D0 >> 16) & 0xff00u));
+    o.z = pack_bf16x2(half_bits_to_f32((D1 << 8) & 0xff00u), half_bits_to_f32(D1 & 0xff00u));
+    o.w = pack_bf16x2(half_bits_to_f32((D1 >> 8) & 0xff00u), half_bits_to_f32((D1 >> 16) & 0xff00u));
+    return o;
+}
+
+// ---- the weights one lane needs for one staged tile: NS = 8 / KS MFMA steps
+// step sl of wave-half ks: elements [koff, koff + 8) of the 128-wide tile
+template <int FMT, int KS>
+struct WTile;
+
+// 4-bit, bf16, f8 share the element ranges: pair P = ks * NP + p (NP = 2 / KS), lane half h owns elements (2P + h) * 32 .. + 32
+template <int KS>
+struct WTile<FMT_Q4, KS> {
+    static constexpr int NP = 2 / KS;
+    u32x4 b[NP];
+    float st[NP], ze[NP];
+    __device__ __forceinline__ void load(const GemmArgs& a, int row, int it, int h, int ks) {
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const uint32_t bidx = (uint32_t)row * (uint32_t)a.nBlk + (uint32_t)(it * 4 + 2 * (ks * NP + p) + h);
+            b[p] = ld_nt(reinterpret_cast<const u32x4*>(a.w) + bidx);
+            const uint32_t gi = bidx >> a.gshift;
+            st[p] = bf2f(a.step[gi]), ze[p] = bf2f(a.zero[gi]);
+        }
+    }
+    static __device__ __forceinline__ int koff(int sl, int h, int ks) { return (2 * (ks * NP + (sl >> 2)) + h) * 32 + 8 * (sl & 3); }
+    __device__ __forceinline__ u32x4 frag(int sl, const GemmArgs& a) const {
+        const int p = sl >> 2, c = sl & 3;
+        const uint32_t D = c == 0 ? b[p].w : (c == 1 ? b[p].z : (c == 2 ? b[p].y : b[p].x));
+        const float s = st[p];
+        return frag_q4(D, s, s * 0.0625f, -a.qBias * s, ze[p]);
+    }
+};
+template <int KS>
+struct WTile<FMT_BF16, KS> {
+    static constexpr int NP = 2 / KS;
+    u32x4 b[NP][4];
+    __device__ __forceinline__ void load(const GemmArgs& a, int row, int it, int h, int ks) {
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const u32x4* src = reinterpret_cast<const u32x4*>(a.w + ((size_t)row * a.K + (size_t)it * GM_KT + (size_t)(2 * (ks * NP + p) + h) * 32) * 2);
+#pragma unroll
+            for (int c = 0; c < 4; c++) b[p][c] = ld_nt(src + c);
+        }
+    }
+    static __device__ __forceinline__ int koff(int sl, int h, int ks) { return (2 * (ks * NP + (sl >> 2)) + h) * 32 + 8 * (sl & 3); }
+    __device__ __forceinline__ u32x4 frag(int sl, const GemmArgs&) const { return b[sl >> 2][sl & 3]; }
+};
+template <int KS>
+struct WTile<FMT_F8, KS> {
+    static constexpr int NP = 2 / KS;
+    u32x4 b[NP][2];
+    __device__ __forceinline__ void load(const GemmArgs& a, int row, int it, int h, int ks) {
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const u32x4* src = reinterpret_cast<const u32x4*>(a.w + (size_t)row * a.K + (size_t)it * GM_KT + (size_t)(2 * (ks * NP + p) + h) * 32);
+            b[p][0] = ld_nt(src), b[p][1] = ld_nt(src + 1);
+        }
+    }
+    static __device__ __forceinline__ int koff(int sl, int h, int ks) { return (2 * (ks * NP + (sl >> 2)) + h) * 32 + 8 * (sl & 3); }
+    __device__ __forceinline__ u32x4 frag(int sl, const GemmArgs&) const {
+        const int p = sl >> 2, c = sl & 3;
+        const u32x4 v = b[p][c >> 1];
+        return (c & 1) ? frag_f8(v.z, v.w) : frag_f8(v.x, v.y);
+    }
+};
+// 2-bit: the staged tile is two 64-element blocks, lane half h owns block h; global step s = ks * NS + sl covers elements 8s..8s+7
+template <int KS>
+struct WTile<FMT_Q2, KS> {
+    static constexpr int NS = 8 / KS;
+    u32x4 b;
+    float st, ze;
+    __device__ __forceinline__ void load(const GemmArgs& a, int row, int it, int h, int) {
+        const uint32_t bidx = (uint32_t)row * (uint32_t)a.nBlk + (uint32_t)(it * 2 + h);
+        b = ld_nt(reinterpret_cast<const u32x4*>(a.w) + bidx);
+        const uint32_t gi = bidx >> a.gshift;
+        st = bf2f(a.step[gi]), ze = bf2f(a.zero[gi]);
+    }
+    static __device__ __forceinline__ int koff(int sl, int h, int ks) { return 64 * h + 8 * (ks * NS + sl); }
+    __device__ __forceinline__ u32x4 frag(int sl, const GemmArgs& a, int ks) const {
+        const uint32_t dw[4] = {b.w, b.z, b.y, b.x}; /* dword3 holds elements 0..15 */
+        uint32_t D = dw[sl >> 1];
+        if (KS == 2) D = ks ? dw[2 + (sl >> 1)] : D;
+        const uint32_t v = (sl & 1) ? (D & 0xffffu) : (D >> 16);
+        return frag_q2(v, st, -a.qBias * st, ze);
+    }
+};
+// 1-bit: the staged tile is one 128-element block, lane half h owns its 8-byte half (elements 64h .. 64h+63)
+template <int KS>
+struct WTile<FMT_Q1, KS> {
+    static constexpr int NS = 8 / KS;
+    u32x2 b; /* b.y: first 32 elements of the half, b.x: next 32 */
+    uint32_t w0, w1;
+    __device__ __forceinline__ void load(const GemmArgs& a, int row, int it, int h, int) {
+        const uint32_t bidx = (uint32_t)row * (uint32_t)a.nBlk + (uint32_t)it;
+        b = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(a.w) + (size_t)bidx * 2 + (1 - h));
+        const uint32_t gi = bidx >> a.gshift;
+        const float st = bf2f(a.step[gi]), ze = bf2f(a.zero[gi]), nb = -a.qBias * st;
+        const uint32_t r = pack_bf16x2(fmaf(0.0f, st, nb), fmaf(1.0f, st, nb));
+        const uint32_t ww = pack_bf16x2(bf_lo(r) - ze, bf_hi(r) - ze);
+        w0 = ww & 0xffffu, w1 = ww >> 16;
+    }
+    static __device__ __forceinline__ int koff(int sl, int h, int ks) { return 64 * h + 8 * (ks * NS + sl); }
+    __device__ __forceinline__ u32x4 frag(int sl, const GemmArgs&, int ks) const {
+        const uint32_t D = (KS == 2) ? (ks ? b.x : b.y) : ((sl >> 2) ? b.x : b.y);
+        const uint32_t byte = (D >> (24 - 8 * (sl & 3))) & 0xffu;
+        return frag_q1(byte, w0, w1);
+    }
+};
+
+template <int FMT, int KS>
+__device__ __forceinline__ u32x4 get_frag(const WTile<FMT, KS>& t, int sl, const GemmArgs& a, int ks) {
+    if constexpr (FMT == FMT_Q2 || FMT == FMT_Q1)
+        return t.frag(sl, a, ks);
+    else
+        return t.frag(sl, a);
+}
+
+template <int FMT, int KS>
+__global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint16_t* xs = reinterpret_cast<uint16_t*>(smem_raw); /* 2 x [GM_TOK][GM_XS] bf16; reused as the k-half combine buffer at the end */
+    constexpr int RBW = 4 / KS, NS = 8 / KS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int rb = wave % RBW, ks = wave / RBW;
+    const int row_base = (blockIdx.x * RBW + rb) * 32;
+    int row = row_base + r;
+    if (row >= a.M) row = a.M - 1; /* rows past the end recompute the last row; their results are not stored */
+    const int tok0 = blockIdx.y * GM_TOK;
+    const int nit = a.K / GM_KT;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int tb = 0; tb < 4; tb++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[tb][i] = 0.f;
+
+    // x staging: 16 threads cover one token row of 256 B, 16 rows per pass, 8 passes
+    const int trow = tid >> 4, seg = tid & 15;
+    u32x4 xr[8];
+    auto xload = [&](int it) {
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            const int tok = tok0 + p * 16 + trow;
+            xr[p] = u32x4{0, 0, 0, 0};
+            if (tok < a.n) xr[p] = *reinterpret_cast<const u32x4*>(a.x + (size_t)tok * a.ldx + (size_t)it * GM_KT + seg * 8);
+        }
+    };
+    auto xstore = [&](int buf) {
+        uint16_t* dst = xs + (size_t)buf * GM_TOK * GM_XS;
+#pragma unroll
+        for (int p = 0; p < 8; p++) *reinterpret_cast<u32x4*>(dst + (p * 16 + trow) * GM_XS + seg * 8) = xr[p];
+    };
+
+    WTile<FMT, KS> wc, wn;
+    wc.load(a, row, 0, h, ks);
+    xload(0);
+    xstore(0);
+    __syncthreads();
+    for (int it = 0; it < nit; it++) {
+        const bool more = it + 1 < nit;
+        if (more) {
+            wn.load(a, row, it + 1, h, ks);
+            xload(it + 1);
+        }
+        const uint16_t* xb = xs + (size_t)(it & 1) * GM_TOK * GM_XS;
+#pragma unroll
+        for (int sl = 0; sl < NS; sl++) {
+            const bf16x8 A = __builtin_bit_cast(bf16x8, get_frag<FMT, KS>(wc, sl, a, ks));
+            const int ko = WTile<FMT, KS>::koff(sl, h, ks);
+#pragma unroll
+            for (int tb = 0; tb < 4; tb++) {
+                const u32x4 B = *reinterpret_cast<const u32x4*>(xb + (tb * 32 + r) * GM_XS + ko);
+                acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(bf16x8, B), acc[tb], 0, 0, 0);
+            }
+        }
+        if (more) {
+            xstore((it + 1) & 1);
+            wc = wn;
+        }
+        __syncthreads();
+    }
+
+    if (KS == 2) { /* the k-halves of a row block: upper half hands its sums over, fixed order (lower + upper) */
+        float* red = reinterpret_cast<float*>(smem_raw);
+        if (ks == 1) {
+#pragma unroll
+            for (int tb = 0; tb < 4; tb++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) red[((rb * 4 + tb) * 16 + i) * 64 + lane] = acc[tb][i];
+        }
+        __syncthreads();
+        if (ks == 1) return;
+#pragma unroll
+        for (int tb = 0; tb < 4; tb++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[tb][i] = acc[tb][i] + red[((rb * 4 + tb) * 16 + i) * 64 + lane];
+    }
+
+    // ---- epilogue: lane holds token (tb*32 + r), rows row_base + 8g + 4h + j
+    const bool vec_ok = ((a.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 7) == 0);
+#pragma unroll
+    for (int tb = 0; tb < 4; tb++) {
+        const int tok = tok0 + tb * 32 + r;
+        if (tok >= a.n) continue;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int rg = row_base + 8 * g + 4 * h;
+            if (rg >= a.M) continue;
+            uint16_t* yp = a.y + (size_t)tok * a.ldy + rg;
+            uint16_t o[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float v = acc[tb][4 * g + j];
+                if (rg + j < a.M) {
+                    if (a.alpha != 1.0f) v = a.alpha * v;
+                    if (a.beta != 0.0f) v = v + a.beta * bf2f(yp[j]);
+                    if (a.bias) v = v + bf2f(a.bias[rg + j]);
+                    uint16_t q = f2bf(v);
+                    if (a.residual) q = f2bf(bf2f(a.residual[(size_t)tok * a.ldr + rg + j]) + bf2f(q));
+                    o[j] = q;
+                } else {
+                    o[j] = 0;
+                }
+            }
+            if (vec_ok && rg + 3 < a.M) {
+                *reinterpret_cast<u32x2*>(yp) = u32x2{(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16)};
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (rg + j < a.M) yp[j] = o[j];
+            }
+        }
+    }
+}
+
+static int gm_fmt_of(int type) {
+    switch (type) {
+        case KF_BF16: return FMT_BF16;
+        case KF_F8E5M2: return FMT_F8;
+        case KF_Q4: return FMT_Q4;
+        case KF_T_SIGN: return FMT_Q2;
+        case KF_BOOL1: case KF_T_BINARY: return FMT_Q1;
+        default: return -1;
+    }
+}
+
+template <int FMT>
+static void gm_launch(const GemmArgs& a, int KS, dim3 grid, size_t smem, hipStream_t st) {
+    if (KS == 2)
+        hipLaunchKernelGGL((gemm_kernel<FMT, 2>), grid, dim3(256), smem, st, a);
+    else
+        hipLaunchKernelGGL((gemm_kernel<FMT, 1>), grid, dim3(256), smem, st, a);
+}
+
+// Returns KF_OK when launched, 1 when the shape is not eligible (the caller then loops the mat-vec), < 0 on error.
+int gemm_launch(hipStream_t st, const kf_weight* w, const uint16_t* x, long long ldx, int n, uint16_t* y, long long ldy, const uint16_t* bias, float alpha,
+                float beta, const uint16_t* residual, long long ldr) {
+    const int fmt = gm_fmt_of(w->type);
+    if (fmt < 0 || w->qzeros || w->qscales) return 1;
+    const int M = w->ne0, K = w->ne1;
+    if (K % GM_KT != 0 || K < GM_KT || M < 1) return 1;
+    if ((ldx & 7) != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0 || (reinterpret_cast<uintptr_t>(w->data) & 15) != 0) return 1;
+    static const int epb[5] = {8, 16, 32, 64, 128};
+    GemmArgs a;
+    a.w = reinterpret_cast<const unsigned char*>(w->data);
+    a.zero = a.step = nullptr;
+    a.qBias = (float)w->qBias;
+    a.M = M, a.K = K, a.nBlk = K / epb[fmt], a.gshift = 0;
+    if ((unsigned long long)M * (unsigned long long)a.nBlk >= (1ull << 32)) return 1;
+    if (fmt >= FMT_Q4) {
+        if (!w->gama || w->lGroup <= 0 || (w->lGroup % epb[fmt]) != 0 || ((long)M * K) % w->lGroup != 0) return KF_QUANT_ERR;
+        const int bpg = w->lGroup / epb[fmt];
+        if (bpg < 1 || (bpg & (bpg - 1)) != 0) return KF_QUANT_ERR;
+        a.gshift = __builtin_ctz(bpg);
+        a.zero = w->gama + w->ne0 + w->ne1;
+        a.step = a.zero + (size_t)M * K / w->lGroup;
+    }
+    a.x = x, a.ldx = ldx, a.n = n, a.y = y, a.ldy = ldy, a.bias = bias, a.residual = residual, a.ldr = ldr, a.alpha = alpha, a.beta = beta;
+    const int ttiles = (n + GM_TOK - 1) / GM_TOK;
+    const int KS = ((long)((M + 127) / 128) * ttiles < 512) ? 2 : 1;
+    const int rows_per_wg = 32 * (4 / KS);
+    dim3 grid((M + rows_per_wg - 1) / rows_per_wg, ttiles);
+    const size_t smem = (size_t)2 * GM_TOK * GM_XS * sizeof(uint16_t);
+    switch (fmt) {
+        case FMT_BF16: gm_launch<FMT_BF16>(a, KS, grid, smem, st); break;
+        case FMT_F8: gm_launch<FMT_F8>(a, KS, grid, smem, st); break;
+        case FMT_Q4: gm_launch<FMT_Q4>(a, KS, grid, smem, st); break;
+        case FMT_Q2: gm_launch<FMT_Q2>(a, KS, grid, smem, st); break;
+        default: gm_launch<FMT_Q1>(a, KS, grid, smem, st); break;
+    }
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+
+}  // namespace kf

@@ -52,6 +52,10 @@ int gemv_launch(hipStream_t st, GemvLaunch& L);
 int gemv_q4lut_launch(hipStream_t st, GemvLaunch& L, bool* used); /* kf_gemv_lut.hip: table-lookup form for large 4-bit matrices */
 void argmax_finish_launch(hipStream_t st, const float* val, const int* idx, int n, int32_t* d_argmax, int32_t* d_state, int32_t* d_tokens_out);
 
+// ---- token-batch GEMM on MFMA (kf_gemm.hip): KF_OK launched, 1 = shape not eligible (caller loops the mat-vec), < 0 error
+int gemm_launch(hipStream_t st, const kf_weight* w, const uint16_t* x, long long ldx, int n, uint16_t* y, long long ldy, const uint16_t* bias, float alpha,
+                float beta, const uint16_t* residual, long long ldr);
+
 // ---- attention (kf_attn.hip)
 struct AttnArgs {
     const uint16_t* q;     /* raw or prepared q [n_head*hd] */

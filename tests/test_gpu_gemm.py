@@ -1,0 +1,89 @@
+"""Token-batch linear (SLP::Forw with nToken > 1) on the MFMA tile kernel vs the oracle's token-serial mat-vec.
+
+Tolerance: the tile kernel accumulates in fp32 like the mat-vec but in the MFMA's order, so results agree with the oracle to
+<= 1 bf16 ulp (or 2^-10 of the row scale for elements near zero), and with the exact fp64 product of the dequantised weights
+to 2^-8 of the largest output."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from koifish_amd import lib as L
+from tests.conftest import bf16_t, close_bf16, u16, ulp_diff_bf16
+
+pytestmark = pytest.mark.gpu
+TYPES = [L.BF16, L.F8E5M2, L.Q4, L.T_SIGN, L.BOOL1]
+
+
+def _case(ctx, O, t, m, k, nt, seed, std=0.02):
+    rng = np.random.default_rng(seed)
+    w = O.f32_to_bf16(rng.normal(0, std, size=(m, k)).astype(np.float32))
+    x = O.f32_to_bf16(rng.normal(0, 1.0, size=(nt, k)).astype(np.float32))
+    ow = O.quantize(w, m, k, t)
+    dw = ctx.upload_blob(t, m, k, ow.blob())
+    return ow, dw, x
+
+
+def _run(ctx, dw, x, nt, m, bias=None, alpha=1.0, beta=0.0, y0=None, residual=None):
+    xd = bf16_t(x, ctx.device)
+    y = torch.zeros(nt, m, dtype=torch.bfloat16, device=ctx.device) if y0 is None else bf16_t(y0, ctx.device).clone()
+    d = dw.desc()
+    rc = ctx.hip.kf_linear(ctx.h, C.byref(d), xd.data_ptr(), y.data_ptr(), bias.data_ptr() if bias is not None else None, nt, alpha, beta,
+                           1 if residual is not None else 0, residual.data_ptr() if residual is not None else None)
+    assert rc == 0, ctx.hip.kf_last_error()
+    ctx.sync()
+    return u16(y)
+
+
+@pytest.mark.parametrize("t", TYPES)
+@pytest.mark.parametrize("shape", [(2048, 1024, 128), (1024, 3072, 37), (96, 256, 8), (3072, 1024, 200), (40, 128, 129), (1000, 512, 64)])
+def test_gemm_vs_oracle(ctx, O, t, shape):
+    m, k, nt = shape
+    ow, dw, x = _case(ctx, O, t, m, k, nt, hash((t, shape)) & 0xFFFF)
+    y = _run(ctx, dw, x, nt, m)
+    deq = O.bf16_to_f32(O.dequant(ow)).astype(np.float64)
+    exact = O.bf16_to_f32(x).astype(np.float64) @ deq.T
+    assert np.abs(O.bf16_to_f32(y) - exact).max() <= 2.0 ** -8 * np.abs(exact).max() + 1e-6
+    for tt in sorted({0, 1, nt // 2, nt - 1}):
+        ref = O.linear(ow, x[tt])
+        assert close_bf16(y[tt], ref).all(), "token %d: max ulp %d" % (tt, ulp_diff_bf16(y[tt], ref).max())
+
+
+def test_gemm_equals_matvec_loop_within_one_ulp(ctx, O, monkeypatch):
+    """same call through the per-token mat-vec loop (KF_GEMM_MIN is read once per process: compare against ctx.linear per row)"""
+    m, k, nt = 512, 1024, 48
+    ow, dw, x = _case(ctx, O, L.Q4, m, k, nt, 77)
+    y = _run(ctx, dw, x, nt, m)
+    for tt in range(nt):
+        yv = u16(ctx.linear(dw, bf16_t(x[tt], ctx.device)))
+        assert close_bf16(y[tt], yv).all()
+
+
+def test_gemm_epilogues(ctx, O):
+    m, k, nt = 256, 1024, 40
+    ow, dw, x = _case(ctx, O, L.Q4, m, k, nt, 5)
+    rng = np.random.default_rng(6)
+    b = O.f32_to_bf16(rng.normal(0, 0.1, size=m).astype(np.float32))
+    y0 = O.f32_to_bf16(rng.normal(0, 0.5, size=(nt, m)).astype(np.float32))
+    res = O.f32_to_bf16(rng.normal(0, 0.5, size=(nt, m)).astype(np.float32))
+    y = _run(ctx, dw, x, nt, m, bias=bf16_t(b, ctx.device), alpha=0.5, beta=2.0, y0=y0)
+    for tt in (0, 17, nt - 1):
+        assert close_bf16(y[tt], O.linear(ow, x[tt], bias=b, alpha=0.5, beta=2.0, y=y0[tt])).all()
+    y = _run(ctx, dw, x, nt, m, residual=bf16_t(res, ctx.device))
+    for tt in (0, 17, nt - 1):
+        assert close_bf16(y[tt], O.add(res[tt], O.linear(ow, x[tt]))).all()
+
+
+def test_gemm_linearity_full_size(ctx, O):
+    """size-independent property at a Qwen3-32B shard shape: W(x1 + x2) = W x1 + W x2 up to bf16 stores"""
+    m, k, nt = 6400, 5120, 256
+    rng = np.random.default_rng(3)
+    w = torch.randn(m, k, device=ctx.device, dtype=torch.float32).mul_(0.02).to(torch.bfloat16)
+    dw = ctx.quantize(w, L.Q4)
+    x1 = O.f32_to_bf16(rng.integers(-8, 9, size=(nt, k)).astype(np.float32) / 8)
+    x2 = O.f32_to_bf16(rng.integers(-8, 9, size=(nt, k)).astype(np.float32) / 8)
+    xs = O.f32_to_bf16(O.bf16_to_f32(x1) + O.bf16_to_f32(x2))  # exact in bf16
+    y1, y2, ysum = (O.bf16_to_f32(_run(ctx, dw, v, nt, m)) for v in (x1, x2, xs))
+    scale = np.abs(ysum).max()
+    assert np.abs(ysum - (y1 + y2)).max() <= 2.0 ** -6 * scale
