@@ -168,6 +168,21 @@ int kf_set_state(kf_ctx* ctx, int32_t* d_state, int token, int pos);
 /* embed lookup driven by device state: token = (d_forced && d_forced[pos] >= 0) ? d_forced[pos] : d_state[0] */
 int kf_embed_state(kf_ctx* ctx, const kf_weight* w, const int32_t* d_state, const int32_t* d_forced, kf_bf16* out);
 
+/* ---- token batch (prompt prefill).  The reference feeds the prompt one token at a time through the decode path (Fish::Chat,
+ * GoPT.cpp:1139-1146); its batched forward exists only on the training side (SelfAttention::cuFlow / ROPE::cuFlow,
+ * NeuronFuse.cu:692-731, rope.cu).  These entries run the same per-token arithmetic for n_tok consecutive positions at once;
+ * kf_linear / kf_rmsnorm / kf_swiglu already take row batches. */
+/* out[t] = row d_tokens[t] of the table, t < n_tok (TokenEmbed::OnEmbed for a batch, NeuronFuse.cu:176-207) */
+int kf_embed_batch(kf_ctx* ctx, const kf_weight* w, const int32_t* d_tokens, int n_tok, kf_bf16* out);
+/* kf_qknorm_rope for tokens t < n_tok at positions pos0 + t: q + t*q_stride, k + t*k_stride (k may be cache rows: k_stride = kv_stride) */
+int kf_qknorm_rope_batch(kf_ctx* ctx, kf_bf16* q, kf_bf16* k, const kf_bf16* wq_norm, const kf_bf16* wk_norm, const float* rope_table, int pos0, int n_tok,
+                         int64_t q_stride, int64_t k_stride, int n_head, int n_kv, int hd, float eps);
+/* causal attention of tokens t < n_tok (position pos0 + t attends to cache rows 0 .. pos0 + t, which must already hold the prepared
+ * keys / values of the batch); q and out rows are q_stride elements apart; same arithmetic as kf_attn_decode, one workgroup per
+ * (kv-head, token), no scratch. */
+int kf_attn_prefill(kf_ctx* ctx, const kf_bf16* q, const kf_bf16* kcache, const kf_bf16* vcache, kf_bf16* out, int pos0, int n_tok, int64_t q_stride,
+                    int n_head, int n_kv, int hd, int kv_stride);
+
 #ifdef __cplusplus
 }
 #endif

@@ -406,6 +406,34 @@ int kf_embed_state(kf_ctx* c, const kf_weight* w, const int32_t* d_state, const 
     RET(kf::embed_launch(c->stream, w, 0, nullptr, d_state, d_forced, out));
 }
 
+// ---- token batch (prefill)
+int kf_embed_batch(kf_ctx* c, const kf_weight* w, const int32_t* d_tokens, int n_tok, kf_bf16* out) {
+    CHKCTX(c);
+    int r = check_weight(w, "kf_embed_batch");
+    if (r) return r;
+    if (!out || !al16(out) || !d_tokens || n_tok < 1) return fail(KF_INVALID_ARGS, "kf_embed_batch: bad args");
+    RET(kf::embed_launch(c->stream, w, 0, d_tokens, nullptr, nullptr, out, n_tok));
+}
+int kf_qknorm_rope_batch(kf_ctx* c, kf_bf16* q, kf_bf16* k, const kf_bf16* wq, const kf_bf16* wk, const float* table, int pos0, int n_tok, int64_t q_stride,
+                         int64_t k_stride, int n_head, int n_kv, int hd, float eps) {
+    CHKCTX(c);
+    if (!q || n_tok < 1 || pos0 < 0) return fail(KF_INVALID_ARGS, "kf_qknorm_rope_batch: bad args");
+    if (hd % 2) return fail(KF_RMS_PARAMS, "head_dim %d is not divisible by 2", hd);
+    RET(kf::qknorm_rope_launch(c->stream, q, k, wq, wk, table, pos0, nullptr, n_head, n_kv, hd, eps, n_tok, q_stride, k_stride));
+}
+int kf_attn_prefill(kf_ctx* c, const kf_bf16* q, const kf_bf16* kc, const kf_bf16* vc, kf_bf16* out, int pos0, int n_tok, int64_t q_stride, int n_head, int n_kv,
+                    int hd, int kv_stride) {
+    CHKCTX(c);
+    if (!q || !kc || !vc || !out || n_tok < 1 || pos0 < 0) return fail(KF_INVALID_ARGS, "kf_attn_prefill: bad args");
+    if (!al16(kc) || !al16(vc) || (kv_stride % 8)) return fail(KF_BLAS_UNALIGN, "kf_attn_prefill: cache not 16-byte aligned");
+    kf::AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = q, a.kcache = const_cast<kf_bf16*>(kc), a.vcache = vc, a.out = out;
+    a.pos = pos0, a.n_head = n_head, a.n_kv = n_kv, a.hd = hd, a.kv_stride = kv_stride;
+    a.n_tok = n_tok, a.q_stride = q_stride, a.one_slice = 1;
+    RET(kf::attn_launch(c->stream, a));
+}
+
 int kf_set_state(kf_ctx* c, int32_t* d_state, int token, int pos) {
     CHKCTX(c);
     if (!d_state) return fail(KF_INVALID_ARGS, "kf_set_state: null state");

@@ -81,6 +81,10 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
     float* comb = reinterpret_cast<float*>(flag + 4);  // [4*KPW][GQ][PS]
 
     const int split = blockIdx.x, kvh = blockIdx.y, nsp = a.n_splits;
+    // token batch (prefill): blockIdx.z = token, one slice per kv-head, position pos0 + token, q / out rows q_stride apart
+    const int pos_l = a.pos + (int)blockIdx.z;
+    const uint16_t* const qsrc = a.q + (size_t)blockIdx.z * a.q_stride;
+    uint16_t* const odst = a.out + (size_t)blockIdx.z * a.q_stride;
     const int chunk = a.chunk; /* keys per slice, fixed by the launch bound so that the K/V stream can start before pos is known */
     const int t0 = split * chunk;
     const int h0 = kvh * GQ;
@@ -109,11 +113,11 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
     };
     {
         int tb_end = t0 + chunk;
-        if (tb_end > a.pos + 1) tb_end = a.pos + 1; /* a.pos is the launch bound here */
+        if (tb_end > pos_l + 1) tb_end = pos_l + 1; /* a.pos is the launch bound here */
         issue(tstart, tb_end);
     }
 
-    const int pos = a.d_pos ? *a.d_pos : a.pos;
+    const int pos = a.d_pos ? *a.d_pos : pos_l;
     const int len = pos + 1;
     int t1 = t0 + chunk;
     if (t1 > len) t1 = len;
@@ -125,7 +129,7 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
         // ---- prologue: q heads of this group, and the new key when it lies in this slice
         const float* tab_pos = a.rope_table ? a.rope_table + (size_t)pos * hd : nullptr;
         for (int hq = wave; hq < GQ; hq += NW)
-            prep_head(a.q + (size_t)(h0 + hq) * hd, a.rope_table ? a.wq_norm : nullptr, tab_pos, hd, a.eps, qf + hq * hd);
+            prep_head(qsrc + (size_t)(h0 + hq) * hd, a.rope_table ? a.wq_norm : nullptr, tab_pos, hd, a.eps, qf + hq * hd);
         const bool own_new = has_new && (pos >= t0) && (pos < t1);
         if (own_new && wave == (GQ % NW)) prep_head(a.k_raw + (size_t)kvh * hd, a.wk_norm, tab_pos, hd, a.eps, knew);
         __syncthreads();
@@ -244,7 +248,7 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
 #pragma unroll
             for (int q2 = 1; q2 < GQ; q2++) Mh = (hq == q2) ? M[q2] : Mh;
             if (nsp == 1) {
-                a.out[(size_t)(h0 + hq) * hd + d] = f2bf(o * (1.0f / L));
+                odst[(size_t)(h0 + hq) * hd + d] = f2bf(o * (1.0f / L));
             } else {
                 float* dst = a.part + ((size_t)(h0 + hq) * nsp + split) * PS;
                 st_sc1(dst + d, o);
@@ -316,18 +320,18 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
                 L = fmaf(ls[hq * KF_ATTN_MAX_SPLITS + sp], sc[hq * KF_ATTN_MAX_SPLITS + sp], L);
             }
         }
-        a.out[(size_t)(h0 + hq) * hd + d] = f2bf(o * (1.0f / L));
+        odst[(size_t)(h0 + hq) * hd + d] = f2bf(o * (1.0f / L));
     }
     if (tid == 0) __hip_atomic_store(a.counters + kvh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // standalone ROPE::cuInfer: grid = n_head + n_kv, one wave each
 __global__ void __launch_bounds__(64) qknorm_rope_kernel(uint16_t* q, uint16_t* k, const uint16_t* wq, const uint16_t* wk, const float* table, int pos_,
-                                                         const int* d_pos, int n_head, int n_kv, int hd, float eps) {
+                                                         const int* d_pos, int n_head, int n_kv, int hd, float eps, long long q_stride, long long k_stride) {
     __shared__ float buf[256];
-    const int pos = d_pos ? *d_pos : pos_;
+    const int pos = (d_pos ? *d_pos : pos_) + (int)blockIdx.y; /* blockIdx.y = token of a batch */
     const int b = blockIdx.x;
-    uint16_t* src = b < n_head ? q + (size_t)b * hd : k + (size_t)(b - n_head) * hd;
+    uint16_t* src = b < n_head ? q + (size_t)blockIdx.y * q_stride + (size_t)b * hd : k + (size_t)blockIdx.y * k_stride + (size_t)(b - n_head) * hd;
     const uint16_t* wn = b < n_head ? wq : wk;
     prep_head(src, wn, table ? table + (size_t)pos * hd : nullptr, hd, eps, buf);
     __syncthreads();
@@ -361,15 +365,19 @@ int attn_launch(hipStream_t st, AttnArgs& a) {
     if (hd < 64 || hd > 128 || (hd & (hd - 1)) != 0) return KF_INVALID_ARGS; /* 8 dims per lane, one RoPE trip per wave */
     if (a.n_kv <= 0 || a.n_head % a.n_kv != 0) return KF_INVALID_ARGS;
     const int GQ = a.n_head / a.n_kv;
-    const int nsp = attn_splits(a.pos, a.n_kv);
+    const bool batch = a.one_slice != 0;
+    if (a.n_tok < 1) a.n_tok = 1;
+    if (!batch) a.n_tok = 1, a.q_stride = 0;
+    const int pos_max = a.pos + a.n_tok - 1;
+    const int nsp = batch ? 1 : attn_splits(a.pos, a.n_kv);
     a.n_splits = nsp;
-    a.chunk = (a.pos + 1 + nsp - 1) / nsp;
+    a.chunk = (pos_max + 1 + nsp - 1) / nsp;
     a.inv_sqrt_hd_den = sqrtf((float)hd);
     const int KPW = 64 / (hd >> 3);
     // 8 waves per workgroup while the per-slot combine buffer fits comfortably in LDS (GQ <= 2), else 4
-    const int NW = (GQ <= 2 && a.pos >= 256) ? 8 : 4; /* measured: 4 waves win below ~256 keys, 8 above; 16 lose everywhere */
+    const int NW = (GQ <= 2 && pos_max >= 256) ? 8 : 4; /* measured: 4 waves win below ~256 keys, 8 above; 16 lose everywhere */
     const size_t smem = sizeof(float) * ((size_t)GQ * hd + hd + NW * GQ + 3 * GQ * KF_ATTN_MAX_SPLITS + 4 + (size_t)NW * KPW * GQ * (hd + 4));
-    dim3 grid(nsp, a.n_kv);
+    dim3 grid(nsp, a.n_kv, a.n_tok);
     switch (GQ) {
         case 1: if (NW == 8) hipLaunchKernelGGL((attn_kernel<1, 8>), grid, dim3(512), smem, st, a); else hipLaunchKernelGGL((attn_kernel<1, 4>), grid, dim3(256), smem, st, a); break;
         case 2: if (NW == 8) hipLaunchKernelGGL((attn_kernel<2, 8>), grid, dim3(512), smem, st, a); else hipLaunchKernelGGL((attn_kernel<2, 4>), grid, dim3(256), smem, st, a); break;
@@ -381,9 +389,10 @@ int attn_launch(hipStream_t st, AttnArgs& a) {
 }
 
 int qknorm_rope_launch(hipStream_t st, uint16_t* q, uint16_t* k, const uint16_t* wq, const uint16_t* wk, const float* table, int pos,
-                       const int* d_pos, int n_head, int n_kv, int hd, float eps) {
-    if (hd < 64 || hd > 128 || (hd & (hd - 1)) != 0) return KF_INVALID_ARGS;
-    hipLaunchKernelGGL(qknorm_rope_kernel, dim3(n_head + (k ? n_kv : 0)), dim3(64), 0, st, q, k, wq, wk, table, pos, d_pos, n_head, n_kv, hd, eps);
+                       const int* d_pos, int n_head, int n_kv, int hd, float eps, int n_tok, long long q_stride, long long k_stride) {
+    if (hd < 64 || hd > 128 || (hd & (hd - 1)) != 0 || n_tok < 1) return KF_INVALID_ARGS;
+    hipLaunchKernelGGL(qknorm_rope_kernel, dim3(n_head + (k ? n_kv : 0), n_tok), dim3(64), 0, st, q, k, wq, wk, table, pos, d_pos, n_head, n_kv, hd, eps,
+                       q_stride, k_stride);
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 

@@ -18,6 +18,8 @@
 // half on its own wave, partial sums combined through LDS in a fixed order).  Grid = (row tiles, 128-token tiles).
 // fp32 accumulation inside the MFMA, one bf16 round-to-nearest store; epilogue order as the mat-vec (alpha, beta*y, bias, store,
 // residual add + store).  Differs from the token-serial mat-vec only in fp32 summation order.
+#include <stdlib.h>
+
 #include "kf_kernels.h"
 
 namespace kf {
@@ -207,6 +209,9 @@ __device__ __forceinline__ u32x4 get_frag(const WTile<FMT, KS>& t, int sl, const
         return t.frag(sl, a);
 }
 
+template <int TB>
+__device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[TB], const GemmArgs& a, int tok0, int row_base, int r, int h);
+
 template <int FMT, int KS>
 __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -289,10 +294,101 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
             for (int i = 0; i < 16; i++) acc[tb][i] = acc[tb][i] + red[((rb * 4 + tb) * 16 + i) * 64 + lane];
     }
 
-    // ---- epilogue: lane holds token (tb*32 + r), rows row_base + 8g + 4h + j
+    gemm_epilogue<4>(acc, a, tok0, row_base, r, h);
+}
+
+// ---- small token counts: every wave is independent.  Workgroup = one block of 32 output rows x TB*32 tokens, its 4 waves take the
+// 64-element k units u = wave, wave+4, ... (for 2-bit / 1-bit the two halves of a 128-element unit), read their x fragments straight
+// from global memory (x is n*K*2 bytes: L2-resident) and meet once, at the end, to add their sums in wave order.  No LDS staging and no
+// barrier inside the k loop, 4x the waves of the staged kernel per output row: the prompt-sized GEMMs of a 0.6B model are latency-bound
+// (a 1024 x 1024 4-bit matrix is 0.5 MB), so what matters is how many independent load streams are in flight.
+template <int FMT, int TB>
+__global__ void __launch_bounds__(256) gemm_direct_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* red = reinterpret_cast<float*>(smem_raw); /* [3][TB][16][64] */
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int row_base = blockIdx.x * 32;
+    int row = row_base + r;
+    if (row >= a.M) row = a.M - 1;
+    const int tok0 = blockIdx.y * (TB * 32);
+    const int nunit = a.K / 64;
+
+    f32x16 acc[TB];
+#pragma unroll
+    for (int tb = 0; tb < TB; tb++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[tb][i] = 0.f;
+
+    // x rows of this lane's tokens (rows past n read row n-1: their results are not stored)
+    const uint16_t* xrow[TB];
+#pragma unroll
+    for (int tb = 0; tb < TB; tb++) {
+        int tok = tok0 + tb * 32 + r;
+        if (tok >= a.n) tok = a.n - 1;
+        xrow[tb] = a.x + (size_t)tok * a.ldx;
+    }
+    u32x4 xc[4][TB], xn[4][TB];
+    auto xload = [&](int u, u32x4 (&dst)[4][TB]) {
+        const int it = u >> 1, ks = u & 1;
+#pragma unroll
+        for (int sl = 0; sl < 4; sl++) {
+            const int ko = it * GM_KT + WTile<FMT, 2>::koff(sl, h, ks);
+#pragma unroll
+            for (int tb = 0; tb < TB; tb++) dst[sl][tb] = *reinterpret_cast<const u32x4*>(xrow[tb] + ko);
+        }
+    };
+    WTile<FMT, 2> wc, wn;
+    int u = wave;
+    if (u < nunit) {
+        wc.load(a, row, u >> 1, h, u & 1);
+        xload(u, xc);
+    }
+    for (; u < nunit; u += 4) {
+        const bool more = u + 4 < nunit;
+        if (more) {
+            wn.load(a, row, (u + 4) >> 1, h, (u + 4) & 1);
+            xload(u + 4, xn);
+        }
+#pragma unroll
+        for (int sl = 0; sl < 4; sl++) {
+            const bf16x8 A = __builtin_bit_cast(bf16x8, get_frag<FMT, 2>(wc, sl, a, u & 1));
+#pragma unroll
+            for (int tb = 0; tb < TB; tb++)
+                acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(bf16x8, xc[sl][tb]), acc[tb], 0, 0, 0);
+        }
+        if (more) {
+            wc = wn;
+#pragma unroll
+            for (int sl = 0; sl < 4; sl++)
+#pragma unroll
+                for (int tb = 0; tb < TB; tb++) xc[sl][tb] = xn[sl][tb];
+        }
+    }
+    // fixed-order sum over the 4 k-slices: ((w0 + w1) + w2) + w3
+    if (wave > 0) {
+#pragma unroll
+        for (int tb = 0; tb < TB; tb++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) red[(((wave - 1) * TB + tb) * 16 + i) * 64 + lane] = acc[tb][i];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; w++)
+#pragma unroll
+        for (int tb = 0; tb < TB; tb++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[tb][i] = acc[tb][i] + red[((w * TB + tb) * 16 + i) * 64 + lane];
+    gemm_epilogue<TB>(acc, a, tok0, row_base, r, h);
+}
+
+// ---- epilogue: lane holds token (tb*32 + r), rows row_base + 8g + 4h + j
+template <int TB>
+__device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[TB], const GemmArgs& a, int tok0, int row_base, int r, int h) {
     const bool vec_ok = ((a.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 7) == 0);
 #pragma unroll
-    for (int tb = 0; tb < 4; tb++) {
+    for (int tb = 0; tb < TB; tb++) {
         const int tok = tok0 + tb * 32 + r;
         if (tok >= a.n) continue;
 #pragma unroll
@@ -339,7 +435,12 @@ static int gm_fmt_of(int type) {
 
 template <int FMT>
 static void gm_launch(const GemmArgs& a, int KS, dim3 grid, size_t smem, hipStream_t st) {
-    if (KS == 2)
+    if (KS == 0) { /* direct kernel: grid.y tiles of 64 (TB = 2) or 32 (TB = 1) tokens */
+        if (a.n > 32)
+            hipLaunchKernelGGL((gemm_direct_kernel<FMT, 2>), grid, dim3(256), (size_t)3 * 2 * 16 * 64 * 4, st, a);
+        else
+            hipLaunchKernelGGL((gemm_direct_kernel<FMT, 1>), grid, dim3(256), (size_t)3 * 1 * 16 * 64 * 4, st, a);
+    } else if (KS == 2)
         hipLaunchKernelGGL((gemm_kernel<FMT, 2>), grid, dim3(256), smem, st, a);
     else
         hipLaunchKernelGGL((gemm_kernel<FMT, 1>), grid, dim3(256), smem, st, a);
@@ -370,9 +471,21 @@ int gemm_launch(hipStream_t st, const kf_weight* w, const uint16_t* x, long long
     }
     a.x = x, a.ldx = ldx, a.n = n, a.y = y, a.ldy = ldy, a.bias = bias, a.residual = residual, a.ldr = ldr, a.alpha = alpha, a.beta = beta;
     const int ttiles = (n + GM_TOK - 1) / GM_TOK;
-    const int KS = ((long)((M + 127) / 128) * ttiles < 512) ? 2 : 1;
-    const int rows_per_wg = 32 * (4 / KS);
-    dim3 grid((M + rows_per_wg - 1) / rows_per_wg, ttiles);
+    // few workgroups (prompt-sized batches on small matrices): the wave-independent kernel; otherwise the LDS-staged tiles
+    static int direct_max = -1;
+    if (direct_max < 0) {
+        const char* e = getenv("KF_GEMM_DIRECT_MAX");
+        direct_max = e ? atoi(e) : 256;
+    }
+    int KS = ((long)((M + 127) / 128) * ttiles < 512) ? 2 : 1;
+    dim3 grid;
+    if ((long)((M + 127) / 128) * ttiles < direct_max) {
+        KS = 0;
+        grid = dim3((M + 31) / 32, n > 32 ? (n + 63) / 64 : 1);
+    } else {
+        const int rows_per_wg = 32 * (4 / KS);
+        grid = dim3((M + rows_per_wg - 1) / rows_per_wg, ttiles);
+    }
     const size_t smem = (size_t)2 * GM_TOK * GM_XS * sizeof(uint16_t);
     switch (fmt) {
         case FMT_BF16: gm_launch<FMT_BF16>(a, KS, grid, smem, st); break;

@@ -72,18 +72,21 @@ struct AttnArgs {
     int pos;
     int n_head, n_kv, hd, kv_stride, n_splits, chunk;
     float eps, inv_sqrt_hd_den;
+    int n_tok;          /* token batch (prefill): position pos + token */
+    int one_slice;      /* every (kv-head, token) is handled by one workgroup: no scratch, no hand-off */
+    long long q_stride; /* elements between the q (and out) rows of consecutive tokens */
 };
 int attn_launch(hipStream_t st, AttnArgs& a);
 int attn_splits(int pos_bound, int n_kv);
 int qknorm_rope_launch(hipStream_t st, uint16_t* q, uint16_t* k, const uint16_t* wq, const uint16_t* wk, const float* table, int pos,
-                       const int* d_pos, int n_head, int n_kv, int hd, float eps);
+                       const int* d_pos, int n_head, int n_kv, int hd, float eps, int n_tok = 1, long long q_stride = 0, long long k_stride = 0);
 
 // ---- small ops (kf_ops.hip)
 int rmsnorm_launch(hipStream_t st, const uint16_t* x, const uint16_t* w, uint16_t* y, int rows, int dim, float eps, float* rstd);
 int swiglu_launch(hipStream_t st, const uint16_t* gate, const uint16_t* up, uint16_t* out, int n);
 int add_launch(hipStream_t st, const uint16_t* a, const uint16_t* b, uint16_t* out, int n);
 int embed_launch(hipStream_t st, const kf_weight* w, int token, const int32_t* d_token, const int32_t* d_state, const int32_t* d_forced,
-                 uint16_t* out);
+                 uint16_t* out, int n_tok = 1);
 int dequant_launch(hipStream_t st, const kf_weight* w, uint16_t* out);
 int quantize_launch(hipStream_t st, const kf_weight* w, const uint16_t* src, int symmetric);
 // ---- AutoAWQ layout (kf_awq.hip)

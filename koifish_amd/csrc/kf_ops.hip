@@ -103,15 +103,18 @@ int dequant_launch(hipStream_t st, const kf_weight* w, uint16_t* out) {
 // ---------------------------------------------------------------- embedding row (CU_embed_forw_1/_q4, embed.cuh:54-132)
 __global__ void embed_kernel(int fmt, int epb, const u32x4* __restrict__ data, const uint16_t* __restrict__ zero, const uint16_t* __restrict__ step, int lGroup,
                              int qBias, int nBlk, int token_, const int32_t* d_token, const int32_t* d_state, const int32_t* d_forced,
-                             uint16_t* __restrict__ out) {
+                             uint16_t* __restrict__ out, int n_rows) {
     int token = token_;
-    if (d_token) token = *d_token;
+    if (d_token) token = d_token[blockIdx.y]; /* blockIdx.y = row of a token batch (0 for a single token) */
+    if (token < 0 || token >= n_rows) token = 0; /* ids come from device memory: never index outside the table */
+    out += (size_t)blockIdx.y * nBlk * epb;
     if (d_state) {
         token = d_state[0];
         if (d_forced) {
             const int f = d_forced[d_state[1]];
             if (f >= 0) token = f;
         }
+        if (token < 0 || token >= n_rows) token = 0;
     }
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nBlk) return;
@@ -123,7 +126,8 @@ __global__ void embed_kernel(int fmt, int epb, const u32x4* __restrict__ data, c
     }
     dequant_block(fmt, data[gb], st, ze, qBias, out + (size_t)b * epb);
 }
-int embed_launch(hipStream_t st, const kf_weight* w, int token, const int32_t* d_token, const int32_t* d_state, const int32_t* d_forced, uint16_t* out) {
+int embed_launch(hipStream_t st, const kf_weight* w, int token, const int32_t* d_token, const int32_t* d_state, const int32_t* d_forced, uint16_t* out,
+                 int n_tok) {
     int epb;
     const int fmt = fmt_of(w->type, &epb);
     if (fmt < 0) return KF_UNSUPPORTED_DATATYPE;
@@ -136,8 +140,9 @@ int embed_launch(hipStream_t st, const kf_weight* w, int token, const int32_t* d
         step = zero + (size_t)w->ne0 * w->ne1 / w->lGroup;
     }
     const int nBlk = w->ne1 / epb;
-    hipLaunchKernelGGL(embed_kernel, dim3((nBlk + 63) / 64), dim3(64), 0, st, fmt, epb, (const u32x4*)w->data, zero, step, w->lGroup, w->qBias, nBlk, token,
-                       d_token, d_state, d_forced, out);
+    if (n_tok < 1 || (n_tok > 1 && !d_token)) return KF_INVALID_ARGS;
+    hipLaunchKernelGGL(embed_kernel, dim3((nBlk + 63) / 64, n_tok), dim3(64), 0, st, fmt, epb, (const u32x4*)w->data, zero, step, w->lGroup, w->qBias, nBlk, token,
+                       d_token, d_state, d_forced, out, w->ne0);
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 

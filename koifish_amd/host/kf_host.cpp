@@ -147,6 +147,40 @@ hGTensor FFN::cuInfer(hGTensor hIn, int) {
     return out;
 }
 
+// ---- token batches (prefill)
+int SelfAttention::cuFlow(floatX* bx, int pos0, int n) {
+    Fish* f = hFish;
+    kf_ctx* c = f->ctx;
+    const int L = layid - 1, C = f->config.nEmbed;
+    floatX* key_cache = reinterpret_cast<floatX*>(hCache->Get(KVCache::KV_KEY, L, 0));
+    floatX* val_cache = reinterpret_cast<floatX*>(hCache->Get(KVCache::KV_VAL, L, 0));
+    floatX* krows = key_cache + (size_t)pos0 * kv_dim;
+    floatX* vrows = val_cache + (size_t)pos0 * kv_dim;
+    floatX *bn = ToX(f->gBUFF.bNorm), *bq = ToX(f->gBUFF.bQ), *ba = ToX(f->gBUFF.bAttn);
+    kf_weight wq = Q.w->desc(), wk = K.w->desc(), wv = V.w->desc(), wo = proj_cat.w->desc();
+    KF_TRY(kf_rmsnorm(c, bx, ToX(norm.w), bn, n, C, norm.rms_eps, nullptr));
+    KF_TRY(kf_linear(c, &wq, bn, bq, nullptr, n, 1.0f, 0.0f, KF_EPI_NONE, nullptr));
+    KF_TRY(kf_linear(c, &wk, bn, krows, nullptr, n, 1.0f, 0.0f, KF_EPI_NONE, nullptr));  // K.out / V.out alias the cache rows (_devQKV)
+    KF_TRY(kf_linear(c, &wv, bn, vrows, nullptr, n, 1.0f, 0.0f, KF_EPI_NONE, nullptr));
+    KF_TRY(kf_qknorm_rope_batch(c, bq, krows, normQ.w ? ToX(normQ.w) : nullptr, normK.w ? ToX(normK.w) : nullptr, f->rope_table, pos0, n, q_dim, kv_dim, n_head,
+                               n_head_kv, head_dim, normQ.rms_eps));
+    KF_TRY(kf_attn_prefill(c, bq, key_cache, val_cache, ba, pos0, n, q_dim, n_head, n_head_kv, head_dim, kv_dim));
+    return kf_linear(c, &wo, ba, bx, nullptr, n, 1.0f, 0.0f, KF_EPI_RESIDUAL, bx);
+}
+
+int FFN::cuFlow(floatX* bx, int n) {
+    Fish* f = hFish;
+    kf_ctx* c = f->ctx;
+    const int C = f->config.nEmbed;
+    floatX *bn = ToX(f->gBUFF.bNorm), *bg = ToX(f->gBUFF.bGate), *bu = ToX(f->gBUFF.bUp);
+    kf_weight wg = gate.w->desc(), wu = up.w->desc(), wd = down.w->desc();
+    KF_TRY(kf_rmsnorm(c, bx, ToX(norm.w), bn, n, C, norm.rms_eps, nullptr));
+    KF_TRY(kf_linear(c, &wg, bn, bg, nullptr, n, 1.0f, 0.0f, KF_EPI_NONE, nullptr));
+    KF_TRY(kf_linear(c, &wu, bn, bu, nullptr, n, 1.0f, 0.0f, KF_EPI_NONE, nullptr));
+    KF_TRY(kf_swiglu(c, bg, bu, bg, n * latent));
+    return kf_linear(c, &wd, bg, bx, nullptr, n, 1.0f, 0.0f, KF_EPI_RESIDUAL, bx);
+}
+
 hGTensor TokenEmbed::cuInfer(int token, int) {
     Fish* f = hFish;
     kf_weight wd = w->desc();
@@ -177,6 +211,7 @@ Fish::~Fish() {
         if (d_state) kf_free(ctx, d_state);
         if (d_forced) kf_free(ctx, d_forced);
         if (d_tokens_out) kf_free(ctx, d_tokens_out);
+        if (gBUFF.d_ptok) kf_free(ctx, gBUFF.d_ptok);
     }
     attn.clear(), ffn.clear();
     embed = TokenEmbed(), head = Head4Token(), final_norm = LayerNormal();
@@ -325,14 +360,54 @@ int Fish::RunSteps(int pos, int n, bool use_graph) {
     return KF_OK;
 }
 
+int Fish::Prefill(const int* tokens, int n, int pos0) {
+    if (n < 1 || pos0 < 0 || pos0 + n > config.n_ctx) return KF_INVALID_ARGS;
+    for (int i = 0; i < n; i++)
+        if (tokens[i] < 0 || tokens[i] >= config.vocab) return KF_INVALID_ARGS;
+    const int PC = prefill_chunk, C = config.nEmbed, qd = config.n_head * config.head_dim;
+    if (!gBUFF.bX) {
+        gBUFF.bX = GT(ctx, "bX", typNUMBER::BF16, C, PC);
+        gBUFF.bNorm = GT(ctx, "bNorm", typNUMBER::BF16, C, PC);
+        gBUFF.bQ = GT(ctx, "bQ", typNUMBER::BF16, qd, PC);
+        gBUFF.bAttn = GT(ctx, "bAttn", typNUMBER::BF16, qd, PC);
+        gBUFF.bGate = GT(ctx, "bGate", typNUMBER::BF16, config.n_ff, PC);
+        gBUFF.bUp = GT(ctx, "bUp", typNUMBER::BF16, config.n_ff, PC);
+        if (!gBUFF.bX || !gBUFF.bNorm || !gBUFF.bQ || !gBUFF.bAttn || !gBUFF.bGate || !gBUFF.bUp) return KF_OUTOF_GPUMEMORY;
+        KF_TRY(kf_malloc(ctx, (size_t)PC * 4, (void**)&gBUFF.d_ptok));
+    }
+    floatX* bx = ToX(gBUFF.bX);
+    kf_weight we = embed.w->desc();
+    int m = 0;
+    for (int c0 = 0; c0 < n; c0 += PC) {
+        m = n - c0 < PC ? n - c0 : PC;
+        KF_TRY(kf_h2d(ctx, gBUFF.d_ptok, tokens + c0, (size_t)m * 4));
+        KF_TRY(kf_embed_batch(ctx, &we, gBUFF.d_ptok, m, bx));
+        for (int l = 0; l < config.nLayer; l++) {
+            KF_TRY(attn[l]->cuFlow(bx, pos0 + c0, m));
+            KF_TRY(ffn[l]->cuFlow(bx, m));
+        }
+    }
+    // head on the last token; the state update leaves {next token, pos0 + n}
+    KF_TRY(kf_d2d(ctx, x->data, bx + (size_t)(m - 1) * C, (size_t)C * 2));
+    KF_TRY(SetState(tokens[n - 1], pos0 + n - 1));
+    kf_weight wh = head.proj.w->desc();
+    tok_pos = pos0 + n - 1;
+    return kf_norm_lm_head(ctx, ToX(x), ToX(final_norm.w), final_norm.rms_eps, &wh, ToX(head.preLogits), d_state, d_tokens_out, gBUFF.head_ws->data);
+}
+
 int Fish::Generate(const int* prompt, int n_prompt, int n_new, int* out, bool use_graph) {
     if (n_prompt < 1 || n_new < 1 || n_prompt + n_new - 1 > config.n_ctx) return KF_INVALID_ARGS;
     std::vector<int32_t> forced(config.n_ctx, -1);
     for (int i = 0; i < n_prompt; i++) forced[i] = prompt[i];
     KF_TRY(kf_h2d(ctx, d_forced, forced.data(), forced.size() * 4));
-    KF_TRY(SetState(prompt[0], 0));
     const int total = n_prompt + n_new - 1;
-    KF_TRY(RunSteps(0, total, use_graph));
+    if (prefill_mode == 1 && n_prompt > 1) {
+        KF_TRY(Prefill(prompt, n_prompt, 0));
+        if (n_new > 1) KF_TRY(RunSteps(n_prompt, n_new - 1, use_graph));
+    } else {
+        KF_TRY(SetState(prompt[0], 0));
+        KF_TRY(RunSteps(0, total, use_graph));
+    }
     std::vector<int32_t> toks(config.n_ctx);
     KF_TRY(kf_d2h(ctx, toks.data(), d_tokens_out, toks.size() * 4));
     for (int i = 0; i < n_new; i++) out[i] = toks[n_prompt - 1 + i];
@@ -464,6 +539,13 @@ int kfh_set_forced(void* h, const int32_t* forced, int n) {
     Fish* f = reinterpret_cast<Fish*>(h);
     if (n > f->config.n_ctx) return KF_INVALID_ARGS;
     return kf_h2d(f->ctx, f->d_forced, forced, (size_t)n * 4);
+}
+int kfh_prefill(void* h, const int* tokens, int n, int pos0) { return reinterpret_cast<Fish*>(h)->Prefill(tokens, n, pos0); }
+int kfh_set_prefill_mode(void* h, int mode, int chunk) {
+    Fish* f = reinterpret_cast<Fish*>(h);
+    f->prefill_mode = mode;
+    if (chunk > 0 && !f->gBUFF.bX) f->prefill_chunk = chunk;
+    return KF_OK;
 }
 int kfh_set_state(void* h, int token, int pos) { return reinterpret_cast<Fish*>(h)->SetState(token, pos); }
 int kfh_run_steps(void* h, int pos, int n, int use_graph) { return reinterpret_cast<Fish*>(h)->RunSteps(pos, n, use_graph != 0); }

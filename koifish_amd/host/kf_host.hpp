@@ -109,6 +109,8 @@ struct SelfAttention : GeNeuron {
     bool isSeparateQKV = true;
     void _devQKV(int pos);  // K.out / V.out alias the KV-cache row (TGraph.cpp:198-207)
     hGTensor cuInfer(hGTensor inpL, int flag = 0);
+    // n tokens at positions pos0.. in one pass (the forward of SelfAttention::cuFlow, NeuronFuse.cu:692-731, with the decode arithmetic)
+    int cuFlow(floatX* bx, int pos0, int n);
 };
 
 struct FFN : GeNeuron {
@@ -118,6 +120,7 @@ struct FFN : GeNeuron {
     hGTensor out;
     int latent = 0;
     hGTensor cuInfer(hGTensor hIn, int flag = 0);
+    int cuFlow(floatX* bx, int n);
 };
 
 struct TokenEmbed : GeNeuron {
@@ -148,6 +151,9 @@ struct MemBuffer {
     hGTensor attn_ws;   // split-KV partials
     hGTensor head_ws;   // arg-max partials
     hGTensor residual;  // alias, not owned
+    // token-batch (prefill) activations, [prefill_chunk, .] rows, allocated by the first Prefill
+    hGTensor bX, bNorm, bQ, bAttn, bGate, bUp;
+    int32_t* d_ptok = nullptr;
 };
 
 struct Fish {
@@ -183,6 +189,12 @@ struct Fish {
     int Generate(const int* prompt, int n_prompt, int n_new, int* out, bool use_graph);
     // replay n decode steps starting at `pos` with whatever d_forced holds (bench / long runs); no host sync
     int RunSteps(int pos, int n, bool use_graph);
+    // n prompt tokens at positions pos0.. through every layer as token batches (MFMA tile kernels), then the head on the last one:
+    // afterwards the KV cache holds rows pos0..pos0+n-1, d_state = {greedy next token, pos0+n}, d_tokens_out[pos0+n-1] = that token.
+    // The reference prefills token by token (Fish::Chat, GoPT.cpp:1139-1146); same arithmetic per token, fp32 sums in MFMA order.
+    int Prefill(const int* tokens, int n, int pos0);
+    int prefill_chunk = 256;
+    int prefill_mode = 0;  // Generate: 0 token-serial prefill like the reference, 1 batched
 };
 
 }  // namespace koifish

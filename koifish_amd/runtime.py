@@ -311,6 +311,22 @@ class Qwen3:
         L.check(self.host.kfh_generate(self.h, p.ctypes.data_as(C.c_void_p), p.size, n_new, out.ctypes.data_as(C.c_void_p), int(use_graph)), "kfh_generate")
         return out.tolist()
 
+    def set_prefill_mode(self, mode, chunk=0):
+        """generate(): 0 = token-serial prefill through the decode path (like the reference), 1 = token batches on the MFMA kernels"""
+        L.check(self.host.kfh_set_prefill_mode(self.h, int(mode), int(chunk)), "kfh_set_prefill_mode")
+
+    def prefill(self, tokens, pos0=0, want_logits=True):
+        """Batched prefill of `tokens` at positions pos0..; returns (greedy next id, logits of the last token as uint16 or None)."""
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        L.check(self.host.kfh_prefill(self.h, t.ctypes.data_as(C.c_void_p), t.size, int(pos0)), "kfh_prefill")
+        nxt = int(self.tokens_out(pos0 + t.size)[pos0 + t.size - 1])
+        logits = None
+        if want_logits:
+            logits = np.zeros(self.cfg["vocab"], dtype=np.uint16)
+            ctx = C.c_void_p(self.host.kfh_ctx(self.h))
+            L.check(self.hip.kf_d2h(ctx, logits.ctypes.data_as(C.c_void_p), C.c_void_p(self.host.kfh_logits(self.h)), C.c_size_t(logits.size * 2)), "kf_d2h")
+        return nxt, logits
+
     def set_forced(self, ids):
         a = np.ascontiguousarray(ids, dtype=np.int32)
         L.check(self.host.kfh_set_forced(self.h, a.ctypes.data_as(C.c_void_p), a.size), "kfh_set_forced")

@@ -68,3 +68,40 @@ def test_full_size_linearity_and_dequant_roundtrip(model):
     logits, am = ctx.lm_head(head, x)
     lf = logits.float()
     assert am == int((lf == lf.max()).nonzero()[0])
+
+
+def test_full_size_batched_prefill_vs_token_serial(model):
+    """128-token prompt: token batches (MFMA) vs the token-serial decode path on the same device model -- logits of the last
+    prompt token within the oracle tolerance of each other, KV rows likewise, and the ids that follow agree unless the first
+    differing step was a near-tie inside that tolerance."""
+    cfg, m = model
+    prompt = np.random.default_rng(11).integers(0, cfg["vocab"], size=128)
+    m.set_prefill_mode(0)
+    serial = m.generate(prompt, 24, use_graph=True)
+    ks, vs = m.kv_to_host()
+    ks, vs = ks[:, :128].copy(), vs[:, :128].copy()
+    nxt, logits = m.prefill(prompt)
+    kb, vb = m.kv_to_host()
+    for a, b in ((kb[:, :128], ks), (vb[:, :128], vs)):
+        fa, fb = O.bf16_to_f32(a), O.bf16_to_f32(b)
+        for l in range(cfg["n_layer"]):
+            # two fp32 summation orders, 28 layers deep on random weights: rounding differences of one bf16 ulp (2^-8) are amplified
+            # layer by layer (measured: max 0.0002 of the row scale at layer 0, 0.018 at layer 27, rms 0.003); the bound is on the rms,
+            # with a loose cap on the single worst element
+            d = np.abs(fa[l] - fb[l])
+            scale = np.abs(fb[l]).max()
+            assert np.sqrt((d ** 2).mean()) <= 2.0 ** -8 * scale, "layer %d rms" % l
+            assert d.max() <= 2.0 ** -5 * scale, "layer %d max" % l
+    assert nxt == O.argmax_bf16(logits)
+    m.set_prefill_mode(1)
+    batched = m.generate(prompt, 24, use_graph=True)
+    m.set_prefill_mode(0)
+    if batched != serial:
+        first = next(i for i in range(24) if batched[i] != serial[i])
+        # replay the serial path up to the first difference and look at the margin there
+        toks = list(prompt) + serial[:first]
+        lg = None
+        for pos, t in enumerate(toks):
+            _, lg = m.forward(int(t), pos)
+        fl = O.bf16_to_f32(lg)
+        assert abs(fl[batched[first]] - fl[serial[first]]) <= 2 * LOGIT_TOL * np.abs(fl).max(), "ids diverge at step %d beyond a near-tie" % first
