@@ -297,15 +297,16 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
     gemm_epilogue<4>(acc, a, tok0, row_base, r, h);
 }
 
-// ---- small token counts: every wave is independent.  Workgroup = one block of 32 output rows x TB*32 tokens, its 4 waves take the
-// 64-element k units u = wave, wave+4, ... (for 2-bit / 1-bit the two halves of a 128-element unit), read their x fragments straight
-// from global memory (x is n*K*2 bytes: L2-resident) and meet once, at the end, to add their sums in wave order.  No LDS staging and no
-// barrier inside the k loop, 4x the waves of the staged kernel per output row: the prompt-sized GEMMs of a 0.6B model are latency-bound
-// (a 1024 x 1024 4-bit matrix is 0.5 MB), so what matters is how many independent load streams are in flight.
-template <int FMT, int TB>
-__global__ void __launch_bounds__(256) gemm_direct_kernel(const GemmArgs a) {
+// ---- small token counts: every wave is independent.  Workgroup = one block of 32 output rows x TB*32 tokens; its NW waves split k in
+// groups of UPG consecutive 64-element units (for 2-bit / 1-bit: halves of a 128-element unit): wave w takes groups w, w + NW, ...,
+// reads its x fragments straight from global memory (x is n*K*2 bytes: L2-resident) and meets the others once, at the end, where
+// wave 0 adds the sums in wave order.  All loads of a group are issued before any of its arithmetic and the next group's loads before
+// the current group's arithmetic: the prompt-sized GEMMs of a 0.6B model are latency-bound (a 1024 x 1024 4-bit matrix is 0.5 MB,
+// far fewer waves than SIMDs), so the k loop is kept as short as the register file allows (K = 1024: one group per wave, no loop).
+template <int FMT, int TB, int UPG, int NW>
+__global__ void __launch_bounds__(NW * 64) gemm_direct_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float* red = reinterpret_cast<float*>(smem_raw); /* [3][TB][16][64] */
+    float* red = reinterpret_cast<float*>(smem_raw); /* [NW-1][TB][16][64] */
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int row_base = blockIdx.x * 32;
@@ -328,44 +329,46 @@ __global__ void __launch_bounds__(256) gemm_direct_kernel(const GemmArgs a) {
         if (tok >= a.n) tok = a.n - 1;
         xrow[tb] = a.x + (size_t)tok * a.ldx;
     }
-    u32x4 xc[4][TB], xn[4][TB];
-    auto xload = [&](int u, u32x4 (&dst)[4][TB]) {
-        const int it = u >> 1, ks = u & 1;
+    struct Group {
+        WTile<FMT, 2> w[UPG];
+        u32x4 x[UPG][4][TB];
+    };
+    auto gload = [&](int u0, Group& g) { /* units u0 .. u0+UPG-1; units past the end repeat the last one and are skipped in the arithmetic */
 #pragma unroll
-        for (int sl = 0; sl < 4; sl++) {
-            const int ko = it * GM_KT + WTile<FMT, 2>::koff(sl, h, ks);
+        for (int j = 0; j < UPG; j++) {
+            int u = u0 + j;
+            if (u >= nunit) u = nunit - 1;
+            const int it = u >> 1, ks = u & 1;
+            g.w[j].load(a, row, it, h, ks);
 #pragma unroll
-            for (int tb = 0; tb < TB; tb++) dst[sl][tb] = *reinterpret_cast<const u32x4*>(xrow[tb] + ko);
+            for (int sl = 0; sl < 4; sl++) {
+                const int ko = it * GM_KT + WTile<FMT, 2>::koff(sl, h, ks);
+#pragma unroll
+                for (int tb = 0; tb < TB; tb++) g.x[j][sl][tb] = *reinterpret_cast<const u32x4*>(xrow[tb] + ko);
+            }
         }
     };
-    WTile<FMT, 2> wc, wn;
-    int u = wave;
-    if (u < nunit) {
-        wc.load(a, row, u >> 1, h, u & 1);
-        xload(u, xc);
+    Group gc, gn;
+    int u0 = wave * UPG;
+    if (u0 < nunit) gload(u0, gc);
+    for (; u0 < nunit; u0 += NW * UPG) {
+        const bool more = u0 + NW * UPG < nunit;
+        if (more) gload(u0 + NW * UPG, gn);
+#pragma unroll
+        for (int j = 0; j < UPG; j++) {
+            if (u0 + j < nunit) {
+#pragma unroll
+                for (int sl = 0; sl < 4; sl++) {
+                    const bf16x8 A = __builtin_bit_cast(bf16x8, get_frag<FMT, 2>(gc.w[j], sl, a, (u0 + j) & 1));
+#pragma unroll
+                    for (int tb = 0; tb < TB; tb++)
+                        acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(bf16x8, gc.x[j][sl][tb]), acc[tb], 0, 0, 0);
+                }
+            }
+        }
+        if (more) gc = gn;
     }
-    for (; u < nunit; u += 4) {
-        const bool more = u + 4 < nunit;
-        if (more) {
-            wn.load(a, row, (u + 4) >> 1, h, (u + 4) & 1);
-            xload(u + 4, xn);
-        }
-#pragma unroll
-        for (int sl = 0; sl < 4; sl++) {
-            const bf16x8 A = __builtin_bit_cast(bf16x8, get_frag<FMT, 2>(wc, sl, a, u & 1));
-#pragma unroll
-            for (int tb = 0; tb < TB; tb++)
-                acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(bf16x8, xc[sl][tb]), acc[tb], 0, 0, 0);
-        }
-        if (more) {
-            wc = wn;
-#pragma unroll
-            for (int sl = 0; sl < 4; sl++)
-#pragma unroll
-                for (int tb = 0; tb < TB; tb++) xc[sl][tb] = xn[sl][tb];
-        }
-    }
-    // fixed-order sum over the 4 k-slices: ((w0 + w1) + w2) + w3
+    // fixed-order sum over the k-slices: ((w0 + w1) + w2) + ...
     if (wave > 0) {
 #pragma unroll
         for (int tb = 0; tb < TB; tb++)
@@ -375,7 +378,7 @@ __global__ void __launch_bounds__(256) gemm_direct_kernel(const GemmArgs a) {
     __syncthreads();
     if (wave > 0) return;
 #pragma unroll
-    for (int w = 0; w < 3; w++)
+    for (int w = 0; w < NW - 1; w++)
 #pragma unroll
         for (int tb = 0; tb < TB; tb++)
 #pragma unroll
@@ -435,11 +438,12 @@ static int gm_fmt_of(int type) {
 
 template <int FMT>
 static void gm_launch(const GemmArgs& a, int KS, dim3 grid, size_t smem, hipStream_t st) {
-    if (KS == 0) { /* direct kernel: grid.y tiles of 64 (TB = 2) or 32 (TB = 1) tokens */
-        if (a.n > 32)
-            hipLaunchKernelGGL((gemm_direct_kernel<FMT, 2>), grid, dim3(256), (size_t)3 * 2 * 16 * 64 * 4, st, a);
+    if (KS == 0) { /* direct kernel: 8 waves, grid.y tiles of 64 (TB = 2) or 32 (TB = 1) tokens */
+        constexpr int NW = 8, UPG = 2;
+        if (grid.y * 32 < (unsigned)a.n) /* launcher chose 64-token tiles */
+            hipLaunchKernelGGL((gemm_direct_kernel<FMT, 2, UPG, NW>), grid, dim3(NW * 64), (size_t)(NW - 1) * 2 * 16 * 64 * 4, st, a);
         else
-            hipLaunchKernelGGL((gemm_direct_kernel<FMT, 1>), grid, dim3(256), (size_t)3 * 1 * 16 * 64 * 4, st, a);
+            hipLaunchKernelGGL((gemm_direct_kernel<FMT, 1, UPG, NW>), grid, dim3(NW * 64), (size_t)(NW - 1) * 1 * 16 * 64 * 4, st, a);
     } else if (KS == 2)
         hipLaunchKernelGGL((gemm_kernel<FMT, 2>), grid, dim3(256), smem, st, a);
     else
@@ -481,7 +485,9 @@ int gemm_launch(hipStream_t st, const kf_weight* w, const uint16_t* x, long long
     dim3 grid;
     if ((long)((M + 127) / 128) * ttiles < direct_max) {
         KS = 0;
-        grid = dim3((M + 31) / 32, n > 32 ? (n + 63) / 64 : 1);
+        static int tb1 = -1; /* 32-token tiles (measured 7 us vs 10.8 us for 64-token tiles on 1024 x 1024, n = 128); KF_GEMM_TB1=0 for 64 */
+        if (tb1 < 0) tb1 = getenv("KF_GEMM_TB1") ? atoi(getenv("KF_GEMM_TB1")) : 1;
+        grid = dim3((M + 31) / 32, (n > 32 && !tb1) ? (n + 63) / 64 : (n + 31) / 32);
     } else {
         const int rows_per_wg = 32 * (4 / KS);
         grid = dim3((M + rows_per_wg - 1) / rows_per_wg, ttiles);

@@ -193,7 +193,7 @@ struct Fish {
     // afterwards the KV cache holds rows pos0..pos0+n-1, d_state = {greedy next token, pos0+n}, d_tokens_out[pos0+n-1] = that token.
     // The reference prefills token by token (Fish::Chat, GoPT.cpp:1139-1146); same arithmetic per token, fp32 sums in MFMA order.
     int Prefill(const int* tokens, int n, int pos0);
-    int prefill_chunk = 256;
+    int prefill_chunk = 1024;
     int prefill_mode = 0;  // Generate: 0 token-serial prefill like the reference, 1 batched
 };
 
