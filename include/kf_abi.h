@@ -160,13 +160,24 @@ int kf_attn_block(kf_ctx* ctx, const kf_bf16* q_raw, const kf_bf16* k_raw, kf_bf
                   const kf_bf16* wq_norm, const kf_bf16* wk_norm, const float* rope_table, int pos, const int32_t* d_pos, int n_head, int n_kv,
                   int hd, int kv_stride, float eps, void* scratch);
 /* [final RMSNorm] + LM head + greedy pick; then state update for graph replay: d_state[0] = next token,
- * d_state[1] += 1 (position), d_tokens_out[old pos] = next token (when non-NULL). */
+ * d_state[1] += 1 (position), d_tokens_out[old pos] = next token (when non-NULL).  d_state == NULL: logits only (kf_sample follows). */
 int kf_norm_lm_head(kf_ctx* ctx, const kf_bf16* x, const kf_bf16* norm_w_or_null, float eps, const kf_weight* w, kf_bf16* logits,
                     int32_t* d_state, int32_t* d_tokens_out, void* scratch);
 /* writes the decode state {token, pos} (a one-thread kernel: capturable, no host staging buffer) */
 int kf_set_state(kf_ctx* ctx, int32_t* d_state, int token, int pos);
 /* embed lookup driven by device state: token = (d_forced && d_forced[pos] >= 0) ? d_forced[pos] : d_state[0] */
 int kf_embed_state(kf_ctx* ctx, const kf_weight* w, const int32_t* d_state, const int32_t* d_forced, kf_bf16* out);
+
+/* GeneratOnPrompt::Sample, non-greedy branch (GoPT.cpp:614-630; LogitsInfo::TopK / UpdateLogits / TopP / Qu_FlipCoin, GoPT.cpp:632-790):
+ * picks the next token from bf16 logits[n] on the device -- candidate set exactly as TOPK_heap::Select builds it (indices
+ * 0..k-2 plus the first maximum over i >= k-1), softmax with temperature, top-p cut, xorshift64* coin.  d_rng_state: one uint64 in device
+ * memory (LogitsInfo::rng_state, seeded with config.common.seed), advanced once per call.  Writes *d_token (when non-NULL) and, when
+ * d_state is non-NULL, the decode-state update of kf_norm_lm_head.  temperature == 0 or top_k == 1 is the greedy path: use kf_lm_head.
+ * d_forced (optional, n_forced entries, -1 = free): when the token of the NEXT position is teacher-forced (prompt prefill through the
+ * decode path) nothing is drawn and the rng state is left alone, as the reference's prefill loop never samples (GoPT.cpp:1139-1146).
+ * KF_INVALID_ARGS unless 2 <= top_k < n/2 (the reference asserts it), top_k <= 1024, temperature > 0, top_p > 0. */
+int kf_sample(kf_ctx* ctx, const kf_bf16* logits, int n, int top_k, float temperature, float top_p, uint64_t* d_rng_state, int32_t* d_token,
+              int32_t* d_state, int32_t* d_tokens_out, const int32_t* d_forced, int n_forced);
 
 /* ---- token batch (prompt prefill).  The reference feeds the prompt one token at a time through the decode path (Fish::Chat,
  * GoPT.cpp:1139-1146); its batched forward exists only on the training side (SelfAttention::cuFlow / ROPE::cuFlow,

@@ -468,8 +468,18 @@ int kf_lm_head(kf_ctx* c, const kf_weight* w, const kf_bf16* x, kf_bf16* logits,
 int kf_norm_lm_head(kf_ctx* c, const kf_bf16* x, const kf_bf16* norm_w, float eps, const kf_weight* w, kf_bf16* logits, int32_t* d_state, int32_t* d_tokens_out,
                     void* scratch) {
     CHKCTX(c);
-    if (!d_state) return fail(KF_INVALID_ARGS, "kf_norm_lm_head: d_state is null");
     return head_impl(c, x, norm_w, eps, w, logits, nullptr, d_state, d_tokens_out, scratch, "kf_norm_lm_head");
+}
+
+int kf_sample(kf_ctx* c, const kf_bf16* logits, int n, int top_k, float temperature, float top_p, uint64_t* d_rng_state, int32_t* d_token, int32_t* d_state,
+              int32_t* d_tokens_out, const int32_t* d_forced, int n_forced) {
+    CHKCTX(c);
+    if (!logits || !d_rng_state || (!d_token && !d_state)) return fail(KF_INVALID_ARGS, "kf_sample: null pointer");
+    int r = kf::sample_launch(c->stream, logits, n, top_k, temperature, top_p, (unsigned long long*)d_rng_state, d_token, d_state, d_tokens_out, d_forced, n_forced);
+    if (r == KF_INVALID_ARGS)
+        return fail(r, "kf_sample: needs 2 <= top_k < n/2 (TOPK_heap::Select asserts it), top_k <= 1024, temperature > 0, top_p > 0 (got k=%d n=%d T=%g p=%g)",
+                    top_k, n, temperature, top_p);
+    RET(r);
 }
 
 }  // extern "C"

@@ -88,6 +88,8 @@ int add_launch(hipStream_t st, const uint16_t* a, const uint16_t* b, uint16_t* o
 int embed_launch(hipStream_t st, const kf_weight* w, int token, const int32_t* d_token, const int32_t* d_state, const int32_t* d_forced,
                  uint16_t* out, int n_tok = 1);
 int dequant_launch(hipStream_t st, const kf_weight* w, uint16_t* out);
+int sample_launch(hipStream_t st, const uint16_t* logits, int n, int top_k, float temperature, float top_p, unsigned long long* rng, int32_t* d_token,
+                  int32_t* d_state, int32_t* d_tokens_out, const int32_t* d_forced, int n_forced);
 int quantize_launch(hipStream_t st, const kf_weight* w, const uint16_t* src, int symmetric);
 // ---- AutoAWQ layout (kf_awq.hip)
 size_t awq_scratch_bytes(const kf_weight* w);

@@ -146,6 +146,139 @@ int embed_launch(hipStream_t st, const kf_weight* w, int token, const int32_t* d
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 
+// ---------------------------------------------------------------- GeneratOnPrompt::Sample, non-greedy branch (GoPT.cpp:614-630), on the device
+// One workgroup.  Candidate set exactly as TOPK_heap::Select builds it (GoPT.cpp:666-704: the std::priority_queue<int> is ordered by
+// token index, so indices 0..k-2 stay and only the newest entry is ever replaced): {0..k-2} + first maximum over i >= k-1; stable
+// descending order by logit; p = expf((a - max)/T) / sum with the sequential fp32 sum of UpdateLogits (GoPT.cpp:754-769); TopP cut
+// (GoPT.cpp:729-751; top_p >= 1 keeps all k); coin from xorshift64* (GoPT.cpp:594-600) walked along the CDF (GoPT.cpp:771-790).
+// The rng state lives in device memory and advances once per call, so a captured graph replays a fresh coin every step.
+// Same operation sequence as oracle/kf_oracle.c kfo_sample: token ids agree bit for bit.
+constexpr int KF_SAMPLE_MAX_K = 1024;
+__global__ void __launch_bounds__(1024) sample_kernel(const uint16_t* __restrict__ logits, int n, int k, float temperature, float top_p,
+                                                      unsigned long long* rng, int32_t* d_token, int32_t* d_state, int32_t* d_tokens_out,
+                                                      const int32_t* d_forced, int n_forced) {
+    __shared__ float sv[KF_SAMPLE_MAX_K];
+    __shared__ int si[KF_SAMPLE_MAX_K];
+    __shared__ float pv[KF_SAMPLE_MAX_K];
+    __shared__ int picks[KF_SAMPLE_MAX_K];
+    __shared__ float s_sum;
+    const int tid = threadIdx.x;
+    // teacher-forced next token (prompt prefill through the decode path): the reference's prefill loop never samples (GoPT.cpp:1139-1146),
+    // so no coin is drawn; only the position advances
+    if (d_state && d_forced) {
+        const int p = d_state[1];
+        if (p + 1 < n_forced && d_forced[p + 1] >= 0) {
+            __syncthreads();
+            if (tid == 0) {
+                if (d_tokens_out) d_tokens_out[p] = d_forced[p + 1];
+                d_state[0] = d_forced[p + 1];
+                d_state[1] = p + 1;
+            }
+            return;
+        }
+    }
+    // first maximum over i >= k-1
+    float bv = -__builtin_inff();
+    int bi = 0x7fffffff;
+    for (int i = k - 1 + tid; i < n; i += blockDim.x) {
+        const float v = bf2f(logits[i]);
+        if (v > bv) bv = v, bi = i;
+    }
+    sv[tid] = bv, si[tid] = bi;
+    __syncthreads();
+    for (int m = blockDim.x >> 1; m > 0; m >>= 1) {
+        if (tid < m) {
+            const float ov = sv[tid + m];
+            const int oi = si[tid + m];
+            if (ov > sv[tid] || (ov == sv[tid] && oi < si[tid])) sv[tid] = ov, si[tid] = oi;
+        }
+        __syncthreads();
+    }
+    const int last = si[0];
+    __syncthreads();
+    // extraction order: last, k-2, .., 0; stable rank sort, descending by logit
+    int my = 0;
+    float mv = 0.f;
+    if (tid < k) {
+        my = tid == 0 ? last : k - 1 - tid;
+        mv = bf2f(logits[my]);
+        sv[tid] = mv;
+    }
+    __syncthreads();
+    if (tid < k) {
+        int rank = 0;
+        for (int m = 0; m < k; m++) {
+            const float o = sv[m];
+            rank += (o > mv || (o == mv && m < tid)) ? 1 : 0;
+        }
+        picks[rank] = my;
+        pv[rank] = mv;
+    }
+    __syncthreads();
+    const float maxLogit = pv[0];
+    float e = 0.f;
+    if (tid < k) e = kf_expf(__fdiv_rn(pv[tid] - maxLogit, temperature));
+    __syncthreads();
+    if (tid < k) pv[tid] = e;
+    __syncthreads();
+    if (tid == 0) {
+        float sum = 0.f;
+        for (int j = 0; j < k; j++) sum += pv[j];
+        s_sum = sum;
+    }
+    __syncthreads();
+    if (tid < k) pv[tid] = __fdiv_rn(pv[tid], s_sum);
+    __syncthreads();
+    if (tid == 0) {
+        int nPick = k;
+        if (top_p < 1.0f) {
+            float cum = 0.f;
+            int last_idx = k - 1;
+            for (int j = 0; j < k; j++) {
+                cum += pv[j];
+                if (cum > top_p) {
+                    last_idx = j;
+                    break;
+                }
+            }
+            nPick = last_idx + 1;
+        }
+        float ps = 0.f;
+        for (int j = 0; j < nPick; j++) ps += pv[j];
+        unsigned long long st = *rng;
+        st ^= st >> 12;
+        st ^= st << 25;
+        st ^= st >> 27;
+        *rng = st;
+        const unsigned int u = (unsigned int)((st * 0x2545F4914F6CDD1Dull) >> 32);
+        const float coin = ((float)(u >> 8) / 16777216.0f) * ps;
+        float cdf = 0.f;
+        int qu = picks[nPick - 1];
+        for (int j = 0; j < nPick; j++) {
+            cdf += pv[j];
+            if (coin < cdf) {
+                qu = picks[j];
+                break;
+            }
+        }
+        if (d_token) *d_token = qu;
+        if (d_state) {
+            const int p = d_state[1];
+            if (d_tokens_out) d_tokens_out[p] = qu;
+            d_state[0] = qu;
+            d_state[1] = p + 1;
+        }
+    }
+}
+int sample_launch(hipStream_t st, const uint16_t* logits, int n, int top_k, float temperature, float top_p, unsigned long long* rng, int32_t* d_token,
+                  int32_t* d_state, int32_t* d_tokens_out, const int32_t* d_forced, int n_forced) {
+    const int k = top_k < n ? top_k : n;
+    if (k < 2 || k >= n / 2 || k > KF_SAMPLE_MAX_K || !(temperature > 0.0f) || !(top_p > 0.0f)) return KF_INVALID_ARGS;
+    hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(1024), 0, st, logits, n, k, temperature, top_p, rng, d_token, d_state, d_tokens_out,
+                       d_forced, n_forced);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+
 // ---------------------------------------------------------------- quantiser: GeQuant::RTN_x / YinYang (GeQuant.cpp:428-628)
 // One wave per group of lGroup (<= 128... any multiple of 64 up to 1024) consecutive elements.
 // mode 0: RTN asymmetric, 1: RTN symmetric, 2: YinYang (step = max(1e-5, sqrt(mean(relu(a)^2))), zero = 0)

@@ -197,8 +197,7 @@ hGTensor Head4Token::cuInfer_1(hGTensor inp_, int) {
         if (!xn) return nullptr;
         rc = kf_lm_head(f->ctx, &wd, ToX(xn), ToX(preLogits), f->d_state + 2, f->gBUFF.head_ws->data);
     } else {
-        rc = kf_norm_lm_head(f->ctx, ToX(inp_), ToX(f->final_norm.w), f->final_norm.rms_eps, &wd, ToX(preLogits), f->d_state, f->d_tokens_out,
-                             f->gBUFF.head_ws->data);
+        rc = f->HeadAndPick(ToX(inp_));
     }
     return rc == KF_OK ? preLogits : nullptr;
 }
@@ -212,6 +211,7 @@ Fish::~Fish() {
         if (d_forced) kf_free(ctx, d_forced);
         if (d_tokens_out) kf_free(ctx, d_tokens_out);
         if (gBUFF.d_ptok) kf_free(ctx, gBUFF.d_ptok);
+        if (d_rng) kf_free(ctx, d_rng);
     }
     attn.clear(), ffn.clear();
     embed = TokenEmbed(), head = Head4Token(), final_norm = LayerNormal();
@@ -390,9 +390,32 @@ int Fish::Prefill(const int* tokens, int n, int pos0) {
     // head on the last token; the state update leaves {next token, pos0 + n}
     KF_TRY(kf_d2d(ctx, x->data, bx + (size_t)(m - 1) * C, (size_t)C * 2));
     KF_TRY(SetState(tokens[n - 1], pos0 + n - 1));
-    kf_weight wh = head.proj.w->desc();
     tok_pos = pos0 + n - 1;
-    return kf_norm_lm_head(ctx, ToX(x), ToX(final_norm.w), final_norm.rms_eps, &wh, ToX(head.preLogits), d_state, d_tokens_out, gBUFF.head_ws->data);
+    return HeadAndPick(ToX(x));
+}
+
+int Fish::HeadAndPick(const floatX* x_last) {
+    kf_weight wh = head.proj.w->desc();
+    if (samp_params.greedy())
+        return kf_norm_lm_head(ctx, x_last, ToX(final_norm.w), final_norm.rms_eps, &wh, ToX(head.preLogits), d_state, d_tokens_out, gBUFF.head_ws->data);
+    KF_TRY(kf_norm_lm_head(ctx, x_last, ToX(final_norm.w), final_norm.rms_eps, &wh, ToX(head.preLogits), nullptr, nullptr, gBUFF.head_ws->data));
+    return kf_sample(ctx, ToX(head.preLogits), config.vocab, samp_params.top_k, samp_params.temperature, samp_params.top_p, d_rng, nullptr, d_state, d_tokens_out,
+                     d_forced, config.n_ctx);
+}
+
+int Fish::SetSampler(const CHAT_SAMPLER& s) {
+    if (!s.greedy()) {
+        const int k = s.top_k < config.vocab ? s.top_k : config.vocab;
+        if (k < 2 || k >= config.vocab / 2 || k > 1024 || !(s.temperature > 0.0f) || !(s.top_p > 0.0f)) return KF_INVALID_ARGS;
+    }
+    const bool was_greedy = samp_params.greedy();
+    samp_params = s;
+    if (!was_greedy || !s.greedy()) { /* the captured step graphs end in a different pick, or hold the old sampler arguments */
+        for (auto& g : graphs)
+            if (g) kf_graph_destroy(g), g = nullptr;
+    }
+    if (!d_rng) KF_TRY(kf_malloc(ctx, 8, (void**)&d_rng));
+    return kf_h2d(ctx, d_rng, &samp_params.seed, 8);
 }
 
 int Fish::Generate(const int* prompt, int n_prompt, int n_new, int* out, bool use_graph) {
@@ -546,6 +569,11 @@ int kfh_set_prefill_mode(void* h, int mode, int chunk) {
     f->prefill_mode = mode;
     if (chunk > 0 && !f->gBUFF.bX) f->prefill_chunk = chunk;
     return KF_OK;
+}
+int kfh_set_sampler(void* h, float temperature, float top_p, int top_k, uint64_t seed) {
+    CHAT_SAMPLER s;
+    s.temperature = temperature, s.top_p = top_p, s.top_k = top_k, s.seed = seed;
+    return reinterpret_cast<Fish*>(h)->SetSampler(s);
 }
 int kfh_set_state(void* h, int token, int pos) { return reinterpret_cast<Fish*>(h)->SetState(token, pos); }
 int kfh_run_steps(void* h, int pos, int n, int use_graph) { return reinterpret_cast<Fish*>(h)->RunSteps(pos, n, use_graph != 0); }

@@ -156,8 +156,22 @@ struct MemBuffer {
     int32_t* d_ptok = nullptr;
 };
 
+// CHAT_SAMPLER (CLI_params.hpp:663-683): the fields GeneratOnPrompt::Sample reads.  temperature == 0 or top_k == 1 -> sample_argmax.
+// (The reference defaults to temperature 0.6; this host defaults to greedy, the mode every parity test and the bench use.)
+struct CHAT_SAMPLER {
+    float temperature = 0.0f;
+    float top_p = 0.95f;
+    int top_k = 50;
+    uint64_t seed = 42;
+    bool greedy() const { return temperature == 0.0f || top_k == 1; }
+};
+
 struct Fish {
     MODEL_CARD config;
+    CHAT_SAMPLER samp_params;
+    uint64_t* d_rng = nullptr;  // LogitsInfo::rng_state on the device
+    int SetSampler(const CHAT_SAMPLER& s);  // also (re)seeds the device rng state
+    int HeadAndPick(const floatX* x_last);  // [final norm + LM head] then arg-max or Sample, and the decode-state update
     kf_ctx* ctx = nullptr;
     int fuse_level = 1;  // 0: one launch per reference kernel; 1: fused launches
     KVCache cache;

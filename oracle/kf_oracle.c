@@ -548,6 +548,94 @@ KFO_API int kfo_argmax_bf16(const uint16_t* logits, int n) {
     return best;
 }
 
+/* GeneratOnPrompt::Sample, non-greedy branch (src/Manifold/GoPT.cpp:614-630), restated step by step:
+ *   LogitsInfo::TopK -> TOPK_heap::Select (GoPT.cpp:666-704): `heap` is a std::priority_queue<int> with the DEFAULT ordering, i.e. it is
+ *     ordered by token index, not by logit: heap.top() is the largest index pushed so far.  The loop therefore keeps indices
+ *     0 .. k-2 for good and only ever replaces the most recent entry: the candidate set is {0, .., k-2} plus the first maximum
+ *     over i >= k-1.  This is what the reference computes, so it is what is restated here (not a true top-k).
+ *     Extraction pops in descending index order; ver == 1 then sorts by logit, descending, with std::sort -- whose order among
+ *     EQUAL logits is unspecified: restated as a stable insertion sort of the extraction order (= libstdc++ for k <= 16).
+ *   UpdateLogits (GoPT.cpp:754-769): p_i = expf((a_i - maxLogit) / temperature), then p_i /= sum (sequential fp32 sum).
+ *   TopP (GoPT.cpp:729-751): nPick = 1 + first i with cumulative p > top_p; for top_p >= 1 the reference returns before
+ *     setting nPick (it then reads picks[-2]): restated with the evident intent nPick = k.
+ *   Qu_FlipCoin (GoPT.cpp:771-790) with random_f32 / random_u32 (GoPT.cpp:594-600; xorshift64*).
+ * expf: the reference calls libm; here kfo_expf (<= 2 ulp from it, tests/test_oracle_math.py) so that the HIP kernel can agree bit
+ * for bit.  Returns the token id, or -1 for arguments the reference asserts against (k < 2, k >= n/2, temperature <= 0). */
+static inline uint32_t kfo_random_u32(uint64_t* state) {
+    *state ^= *state >> 12;
+    *state ^= *state << 25;
+    *state ^= *state >> 27;
+    return (uint32_t)((*state * 0x2545F4914F6CDD1Dull) >> 32);
+}
+KFO_API float kfo_random_f32(uint64_t* state) { return (float)(kfo_random_u32(state) >> 8) / 16777216.0f; }
+
+KFO_API int kfo_sample(const uint16_t* logits, int n, int top_k, float temperature, float top_p, uint64_t* rng_state, int* picks_out, float* probs_out,
+                       int* npick_out) {
+    const int k = top_k < n ? top_k : n;
+    if (k < 2 || k >= n / 2 || !(temperature > 0.0f) || !(top_p > 0.0f)) return -1;
+    int* picks = (int*)malloc(sizeof(int) * k);
+    float* p = (float*)malloc(sizeof(float) * k);
+    /* Select */
+    int last = k - 1;
+    for (int i = k; i < n; i++)
+        if (kfo_bf16_to_f32(logits[i]) > kfo_bf16_to_f32(logits[last])) last = i;
+    picks[0] = last;
+    for (int j = 1; j < k; j++) picks[j] = k - 1 - j; /* k-2, k-3, .., 0 */
+    float maxLogit = -3.402823466e+38f;
+    for (int j = 0; j < k; j++) {
+        const float a = kfo_bf16_to_f32(logits[picks[j]]);
+        if (a > maxLogit) maxLogit = a;
+    }
+    for (int j = 1; j < k; j++) { /* stable insertion sort, descending by logit */
+        const int pj = picks[j];
+        const float vj = kfo_bf16_to_f32(logits[pj]);
+        int q = j - 1;
+        while (q >= 0 && vj > kfo_bf16_to_f32(logits[picks[q]])) picks[q + 1] = picks[q], q--;
+        picks[q + 1] = pj;
+    }
+    /* UpdateLogits */
+    float prob_sum = 0.0f;
+    for (int j = 0; j < k; j++) {
+        const float a = kfo_bf16_to_f32(logits[picks[j]]);
+        p[j] = kfo_expf((a - maxLogit) / temperature);
+        prob_sum += p[j];
+    }
+    for (int j = 0; j < k; j++) p[j] /= prob_sum;
+    /* TopP */
+    int nPick = k;
+    if (top_p < 1.0f) {
+        float cum = 0.0f;
+        int last_idx = k - 1;
+        for (int j = 0; j < k; j++) {
+            cum += p[j];
+            if (cum > top_p) {
+                last_idx = j;
+                break;
+            }
+        }
+        nPick = last_idx + 1;
+    }
+    /* Qu_FlipCoin */
+    float ps = 0.0f;
+    for (int j = 0; j < nPick; j++) ps += p[j];
+    const float coin = kfo_random_f32(rng_state) * ps;
+    float cdf = 0.0f;
+    int qu = picks[nPick - 1];
+    for (int j = 0; j < nPick; j++) {
+        cdf += p[j];
+        if (coin < cdf) {
+            qu = picks[j];
+            break;
+        }
+    }
+    if (picks_out) memcpy(picks_out, picks, sizeof(int) * k);
+    if (probs_out) memcpy(probs_out, p, sizeof(float) * k);
+    if (npick_out) *npick_out = nPick;
+    free(picks);
+    free(p);
+    return qu;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * 6. Decode attention (GQA), full causal over t = 0..pos.
  *    mode 0 "REF":   the reference's rounding chain -- attention_qk_kernel / CU_softmax_multihead /

@@ -284,6 +284,22 @@ def argmax_bf16(logits):
     return int(lib().kfo_argmax_bf16(_p(logits), logits.size))
 
 
+def sample(logits, top_k, temperature, top_p, rng_state, want_detail=False):
+    """GeneratOnPrompt::Sample (non-greedy branch); rng_state is a 1-element uint64 array advanced in place."""
+    logits = np.ascontiguousarray(logits, dtype=np.uint16)
+    assert rng_state.dtype == np.uint64 and rng_state.size == 1
+    k = min(top_k, logits.size)
+    picks = np.zeros(max(k, 1), dtype=np.int32)
+    probs = np.zeros(max(k, 1), dtype=np.float32)
+    npick = C.c_int(0)
+    fn = lib().kfo_sample
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    tok = int(fn(_p(logits), logits.size, int(top_k), float(temperature), float(top_p), _p(rng_state), _p(picks), _p(probs), C.byref(npick)))
+    if want_detail:
+        return tok, picks, probs, npick.value
+    return tok
+
+
 def attn_decode(q, kc, vc, pos, n_head, n_kv, hd, kv_stride=None, mode=ATTN_FUSED):
     q = np.ascontiguousarray(q, dtype=np.uint16)
     kc = np.ascontiguousarray(kc, dtype=np.uint16)
@@ -348,16 +364,27 @@ class Qwen3Oracle:
         shp = (c["n_layer"], c["max_seq"], c["n_kv"] * c["head_dim"])
         return k.reshape(shp), v.reshape(shp)
 
-    def generate(self, prompt, n_new):
-        """Token-serial prefill (Fish::Chat, GoPT.cpp:1139-1146) then greedy decode. Returns new ids."""
+    def generate(self, prompt, n_new, sampler=None):
+        """Token-serial prefill (Fish::Chat, GoPT.cpp:1139-1146) then decode. Returns new ids.
+        sampler = None: greedy; else dict(top_k, temperature, top_p, seed) -> GeneratOnPrompt::Sample on every step's logits
+        (the coin is drawn once per sampled token, starting with the token that follows the prompt)."""
+        greedy = sampler is None or sampler["temperature"] == 0.0 or sampler["top_k"] == 1
+        rng = None if greedy else np.array([sampler["seed"]], dtype=np.uint64)
+
+        def pick(nxt, logits):
+            return nxt if greedy else sample(logits, sampler["top_k"], sampler["temperature"], sampler["top_p"], rng)
         pos, nxt = 0, None
-        for t in prompt:
-            nxt, _, _ = self.decode(t, pos, want_logits=False)
+        for i, t in enumerate(prompt):
+            last = i == len(prompt) - 1
+            nxt, lg, _ = self.decode(t, pos, want_logits=(last and not greedy))
+            if last:
+                nxt = pick(nxt, lg)
             pos += 1
         out = []
         for _ in range(n_new):
             out.append(nxt)
-            nxt, _, _ = self.decode(nxt, pos, want_logits=False)
+            nxt, lg, _ = self.decode(nxt, pos, want_logits=not greedy)
+            nxt = pick(nxt, lg)
             pos += 1
         return out
 
