@@ -129,6 +129,7 @@ def main():
             "step_roofline": {"bound": "hbm", "bytes_per_step": int(mean_bytes), "achieved": round(mean_bytes * (value / world) / 1e9, 1),
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(mean_bytes * (value / world) / 1e9 / HBM_PEAK_GBS, 4)},
         }
+        out["prefill"] = prefill_rate(m, forced[:n_prompt], ms_per_step)
         out["roofline"] = kernel_roofline(m, ctx, cfg)
         out["cpu_baseline"] = cpu_baseline(m, cfg, forced, args.cpu_seconds) if (world == 1 and args.cpu_seconds > 0) else None
     if world > 1:
@@ -136,6 +137,24 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def prefill_rate(m, prompt, decode_ms_per_step, reps=5):
+    """The prompt half of the metric, reported beside the decode rate (never inside `value`): the 128-token prompt through
+    Fish::Prefill (token batches on the MFMA tile kernels) -- wall time of `reps` calls after one warm-up, each ending with the
+    head + pick of the first generated token.  The reference prefills token by token through the decode path (GoPT.cpp:1139-1146),
+    which here costs one decode step per prompt token."""
+    import time
+    m.prefill(prompt, want_logits=False)
+    m.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        m.prefill(prompt, want_logits=False)
+    m.sync()
+    ms = (time.perf_counter() - t0) * 1e3 / reps
+    n = int(len(prompt))
+    return {"prompt_tokens": n, "ms": round(ms, 3), "tokens_per_s": round(n / ms * 1e3, 1), "mode": "token batches, MFMA 32x32x16 bf16 on unpacked 4-bit tiles",
+            "token_serial_ms": round(decode_ms_per_step * n, 3)}
 
 
 def kernel_roofline(m, ctx, cfg, reps=200):
