@@ -426,6 +426,13 @@ int kf_attn_prefill(kf_ctx* c, const kf_bf16* q, const kf_bf16* kc, const kf_bf1
     CHKCTX(c);
     if (!q || !kc || !vc || !out || n_tok < 1 || pos0 < 0) return fail(KF_INVALID_ARGS, "kf_attn_prefill: bad args");
     if (!al16(kc) || !al16(vc) || (kv_stride % 8)) return fail(KF_BLAS_UNALIGN, "kf_attn_prefill: cache not 16-byte aligned");
+    static int use_mfma = -1; /* KF_ATTN_PREFILL_MFMA=0: the per-token form of the decode kernel (fp32 probabilities) */
+    if (use_mfma < 0) use_mfma = getenv("KF_ATTN_PREFILL_MFMA") ? atoi(getenv("KF_ATTN_PREFILL_MFMA")) : 1;
+    if (use_mfma && n_tok >= 8) {
+        const int rc = kf::attn_prefill_mfma_launch(c->stream, q, kc, vc, out, pos0, n_tok, q_stride, n_head, n_kv, hd, kv_stride);
+        if (rc < 0) return fail(rc, "kf_attn_prefill: launch failed (%d)", rc);
+        if (rc == KF_OK) return KF_OK;
+    }
     kf::AttnArgs a;
     memset(&a, 0, sizeof(a));
     a.q = q, a.kcache = const_cast<kf_bf16*>(kc), a.vcache = vc, a.out = out;

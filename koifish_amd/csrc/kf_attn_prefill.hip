@@ -1,0 +1,227 @@
+// kf_attn_prefill.hip -- causal GQA attention for a batch of prompt tokens on MFMA (flash form), gfx950 / wave64.
+//
+// Reference: none on the inference side (Fish::Chat prefills token by token through attention_qk_kernel / CU_softmax_multihead /
+// attention_v_kernel, QKV.cu:669-673); its batched forward is cuDNN SDPA on the training side (QKV.cu:130-315), removed here.
+// Same arithmetic contract as the decode kernel (kf_attn.hip): score = bf16(dot / sqrt(hd)) -- the store the reference makes --, fp32
+// softmax statistics with exp as v_exp_f32(x * log2 e), out = (sum_t p_t v_t) / (sum_t p_t) with one bf16 store; the probabilities
+// enter the P.V product as a bf16 pair (high part + remainder, ~16 significant bits; the reference keeps them in plain bf16,
+// operator.cuh:251-277), the sum of p stays fp32.
+//
+// Workgroup = one kv-head x TQ = 128/GQ consecutive tokens: 128 "columns" (token, query head of the group), 32 per wave.
+// Per 32-key tile, staged once in LDS for the 4 waves (K row-major with padded 272-byte rows, V TRANSPOSED [d][key] with 72-byte rows):
+//   S^T[key][col] = sum_d K[key][d] Q[col][d]      v_mfma_f32_32x32x16_bf16, A = K rows (ds_read_b128), B = Q rows (registers, loaded once)
+//   -> a column's 32 scores sit in ONE lane pair (lane l and l^32, 16 registers each): max / exp / sum need no cross-lane traffic
+//      beyond one lane-pair exchange of the tile maximum;
+//   O^T[d][col]  += sum_key V^T[d][key] P^T[key][col]   the S^T accumulator registers, packed to bf16, ARE the B operand (the contraction
+//      index may be visited in any order: slot (step s, half h, j) <-> key 16 s + (j & 3) + 8 (j >> 2) + 4 h on both operands), A = V^T
+//      rows read with two ds_read_b64 per fragment.
+// Online softmax: running maximum per column, O and l rescaled when it moves.  HBM/L2 bytes: K and V once per 128 columns.
+#include "kf_kernels.h"
+
+namespace kf {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int AP_KT = 32;        /* keys per tile */
+constexpr int AP_VS = AP_KT + 4; /* padded V^T row, elements (72 B) */
+
+struct AttnPrefillArgs {
+    const uint16_t* q;
+    const uint16_t* kcache;
+    const uint16_t* vcache;
+    uint16_t* out;
+    int pos0, n_tok, n_kv, kv_stride;
+    long long q_stride;
+    float rden;
+};
+
+__device__ __forceinline__ float ap_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+constexpr bool PSPLIT = true; /* probabilities enter P.V as bf16 high + bf16 remainder (two MFMAs) */
+
+template <int HD, int GQ>
+__global__ void __launch_bounds__(256) attn_prefill_kernel(const AttnPrefillArgs a) {
+    constexpr int NS = HD / 16;   /* MFMA steps over d for S^T */
+    constexpr int NDB = HD / 32;  /* 32-row blocks of O^T */
+    constexpr int KS = HD + 8;    /* padded K row, elements */
+    constexpr int TQ = 128 / GQ;  /* tokens per workgroup */
+    constexpr int KCH = AP_KT * HD / 8; /* 16-byte chunks per K (or V) tile */
+    constexpr int CPT = KCH / 256;      /* chunks per thread */
+    static_assert(KCH % 256 == 0, "tile chunks must divide among 256 threads");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint16_t* ks = reinterpret_cast<uint16_t*>(smem_raw);  // 2 x [AP_KT][KS]
+    uint16_t* vt = ks + 2 * AP_KT * KS;                    // 2 x [HD][AP_VS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int g = blockIdx.y, tok0 = blockIdx.x * TQ;
+    const int col = wave * 32 + r;
+    const int tq = col / GQ, hq = col - tq * GQ;
+    int tok = tok0 + tq;
+    const bool col_ok = tok < a.n_tok;
+    if (!col_ok) tok = a.n_tok - 1;
+    const int pos_q = a.pos0 + tok; /* last key this column attends to */
+    int tok_last = tok0 + TQ - 1;
+    if (tok_last > a.n_tok - 1) tok_last = a.n_tok - 1;
+    const int kmax = a.pos0 + tok_last; /* last key any column of this workgroup needs */
+    const int ntile = kmax / AP_KT + 1;
+
+    // Q fragments: B operand of S^T, lane (col, h) holds Q[col][16 s + 8 h .. + 8]
+    u32x4 qf[NS];
+    {
+        const uint16_t* qrow = a.q + (size_t)tok * a.q_stride + (size_t)(g * GQ + hq) * HD;
+#pragma unroll
+        for (int s = 0; s < NS; s++) qf[s] = *reinterpret_cast<const u32x4*>(qrow + 16 * s + 8 * h);
+    }
+
+    u32x4 kr[CPT], vr[CPT];
+    auto tload = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < CPT; i++) {
+            const int c = tid + 256 * i, key = c / (HD / 8), dc = c - key * (HD / 8);
+            int kk = t * AP_KT + key;
+            if (kk > kmax) kk = kmax; /* rows past the last needed key are masked below; never read past it */
+            const size_t off = (size_t)kk * a.kv_stride + (size_t)g * HD + dc * 8;
+            kr[i] = *reinterpret_cast<const u32x4*>(a.kcache + off);
+            vr[i] = *reinterpret_cast<const u32x4*>(a.vcache + off);
+        }
+    };
+    auto tstore = [&](int buf) {
+        uint16_t* kd = ks + (size_t)buf * AP_KT * KS;
+        uint16_t* vd = vt + (size_t)buf * HD * AP_VS;
+#pragma unroll
+        for (int i = 0; i < CPT; i++) {
+            const int c = tid + 256 * i, key = c / (HD / 8), dc = c - key * (HD / 8);
+            *reinterpret_cast<u32x4*>(kd + key * KS + dc * 8) = kr[i];
+            const uint32_t vw[4] = {vr[i].x, vr[i].y, vr[i].z, vr[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                vd[(dc * 8 + 2 * e) * AP_VS + key] = (uint16_t)(vw[e] & 0xffffu);
+                vd[(dc * 8 + 2 * e + 1) * AP_VS + key] = (uint16_t)(vw[e] >> 16);
+            }
+        }
+    };
+
+    f32x16 o[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; db++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) o[db][i] = 0.f;
+    float M = -__builtin_inff(), l = 0.f;
+    const float LOG2E = 1.44269502162933349609375f;
+
+    tload(0);
+    tstore(0);
+    __syncthreads();
+    for (int t = 0; t < ntile; t++) {
+        const bool more = t + 1 < ntile;
+        if (more) tload(t + 1);
+        const uint16_t* kb = ks + (size_t)(t & 1) * AP_KT * KS;
+        const uint16_t* vb = vt + (size_t)(t & 1) * HD * AP_VS;
+        // ---- S^T tile
+        f32x16 st;
+#pragma unroll
+        for (int i = 0; i < 16; i++) st[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const u32x4 A = *reinterpret_cast<const u32x4*>(kb + r * KS + 16 * s + 8 * h);
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, qf[s]), st, 0, 0, 0);
+        }
+        // ---- scores: bf16 store, causal mask, tile maximum of this column
+        const int k0 = t * AP_KT + 4 * h;
+        float sc[16];
+        float mt = -__builtin_inff();
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int key = k0 + (i & 3) + 8 * (i >> 2);
+            const float v = round_bf16(st[i] * a.rden);
+            sc[i] = key <= pos_q ? v : -__builtin_inff();
+            mt = fmaxf(mt, sc[i]);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        if (mt > M) { /* the column's running maximum moves: rescale what has been accumulated */
+            const float alpha = ap_exp2((M - mt) * LOG2E); /* M = -inf on the first tile: 0 */
+            l *= alpha;
+#pragma unroll
+            for (int db = 0; db < NDB; db++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) o[db][i] *= alpha;
+            M = mt;
+        }
+        // p as a bf16 pair (high part + rounded remainder): the P.V product then carries ~16 significant bits of p, which keeps the batch
+        // form within rounding noise of the decode kernel's fp32 probabilities (bf16 alone: up to 4 bf16 ulps on the next layer's K rows)
+        uint32_t pw[8], pl[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float p0 = ap_exp2((sc[2 * i] - M) * LOG2E), p1 = ap_exp2((sc[2 * i + 1] - M) * LOG2E); /* masked: exp2(-inf) = 0 */
+            l += p0;
+            l += p1;
+            pw[i] = pack_bf16x2(p0, p1);
+            if (PSPLIT) pl[i] = pack_bf16x2(p0 - bf_lo(pw[i]), p1 - bf_hi(pw[i]));
+        }
+        // ---- O^T += V^T . P^T : step s2 takes accumulator registers 8 s2 .. 8 s2 + 7 = keys 16 s2 + {0..3, 8..11} + 4 h
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+            const u32x4 B = u32x4{pw[4 * s2], pw[4 * s2 + 1], pw[4 * s2 + 2], pw[4 * s2 + 3]};
+#pragma unroll
+            for (int db = 0; db < NDB; db++) {
+                const uint16_t* vrow = vb + (db * 32 + r) * AP_VS + 16 * s2 + 4 * h;
+                const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow), hi = *reinterpret_cast<const u32x2*>(vrow + 8);
+                const u32x4 A = u32x4{lo.x, lo.y, hi.x, hi.y};
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), o[db], 0, 0, 0);
+                if (PSPLIT) {
+                    const u32x4 B2 = u32x4{pl[4 * s2], pl[4 * s2 + 1], pl[4 * s2 + 2], pl[4 * s2 + 3]};
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B2), o[db], 0, 0, 0);
+                }
+            }
+        }
+        if (more) tstore((t + 1) & 1);
+        __syncthreads();
+    }
+    // ---- out[col][d] = O^T[d][col] / l ; lane (col, h) holds d = 32 db + (i & 3) + 8 (i >> 2) + 4 h
+    l += __shfl_xor(l, 32, 64);
+    if (!col_ok) return;
+    const float inv = 1.0f / l;
+    uint16_t* orow = a.out + (size_t)tok * a.q_stride + (size_t)(g * GQ + hq) * HD;
+#pragma unroll
+    for (int db = 0; db < NDB; db++)
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) {
+            const int d = 32 * db + 8 * gq + 4 * h;
+            const uint32_t w0 = pack_bf16x2(o[db][4 * gq] * inv, o[db][4 * gq + 1] * inv), w1 = pack_bf16x2(o[db][4 * gq + 2] * inv, o[db][4 * gq + 3] * inv);
+            *reinterpret_cast<u32x2*>(orow + d) = u32x2{w0, w1};
+        }
+}
+
+template <int HD>
+static int ap_launch_gq(hipStream_t st, const AttnPrefillArgs& a, int GQ, dim3 grid, size_t smem) {
+    switch (GQ) {
+        case 1: hipLaunchKernelGGL((attn_prefill_kernel<HD, 1>), grid, dim3(256), smem, st, a); break;
+        case 2: hipLaunchKernelGGL((attn_prefill_kernel<HD, 2>), grid, dim3(256), smem, st, a); break;
+        case 4: hipLaunchKernelGGL((attn_prefill_kernel<HD, 4>), grid, dim3(256), smem, st, a); break;
+        case 8: hipLaunchKernelGGL((attn_prefill_kernel<HD, 8>), grid, dim3(256), smem, st, a); break;
+        default: return 1;
+    }
+    return 0;
+}
+
+// KF_OK launched; 1 = shape not covered (the caller falls back to the per-token kernel)
+int attn_prefill_mfma_launch(hipStream_t st, const uint16_t* q, const uint16_t* kc, const uint16_t* vc, uint16_t* out, int pos0, int n_tok, long long q_stride,
+                             int n_head, int n_kv, int hd, int kv_stride) {
+    if ((hd != 64 && hd != 128) || n_kv <= 0 || n_head % n_kv != 0) return 1;
+    if ((q_stride & 7) != 0 || (kv_stride & 7) != 0 || (reinterpret_cast<uintptr_t>(q) & 15) != 0 || (reinterpret_cast<uintptr_t>(out) & 7) != 0) return 1;
+    const int GQ = n_head / n_kv;
+    if (GQ != 1 && GQ != 2 && GQ != 4 && GQ != 8) return 1;
+    AttnPrefillArgs a;
+    a.q = q, a.kcache = kc, a.vcache = vc, a.out = out, a.pos0 = pos0, a.n_tok = n_tok, a.n_kv = n_kv, a.kv_stride = kv_stride, a.q_stride = q_stride;
+    a.rden = 1.0f / sqrtf((float)hd);
+    const int TQ = 128 / GQ;
+    dim3 grid((n_tok + TQ - 1) / TQ, n_kv);
+    const size_t smem = sizeof(uint16_t) * (2 * (size_t)AP_KT * (hd + 8) + 2 * (size_t)hd * AP_VS);
+    const int rc = hd == 128 ? ap_launch_gq<128>(st, a, GQ, grid, smem) : ap_launch_gq<64>(st, a, GQ, grid, smem);
+    if (rc) return rc;
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+
+}  // namespace kf

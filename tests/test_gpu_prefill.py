@@ -91,3 +91,33 @@ def test_prefill_bad_args():
     assert gm.host.kfh_prefill(gm.h, t.ctypes.data_as(C.c_void_p), 2, cfg["max_seq"] - 1) == -20  # runs past the context
     assert gm.host.kfh_prefill(gm.h, t.ctypes.data_as(C.c_void_p), 0, 0) == -20
     gm.close()
+
+
+@pytest.mark.parametrize("nh,nkv,hd", [(16, 8, 128), (4, 2, 64), (8, 1, 128), (4, 4, 64), (8, 2, 128)])
+@pytest.mark.parametrize("pos0,n", [(0, 128), (0, 37), (100, 70), (0, 300)])
+def test_attn_prefill_kernel_vs_oracle(ctx, nh, nkv, hd, pos0, n):
+    """kf_attn_prefill (MFMA flash form): every token against the oracle's decode attention at its position.  bf16 scores as the
+    reference stores them; the probabilities enter P.V as bf16 (the reference's CU_softmax_multihead stores them in bf16 too), so
+    the bound is the one the decode kernel is held to against the reference's chain: 2^-6 of max|out| vs REF, and 2^-7 vs FUSED."""
+    import ctypes as C
+    import torch
+    from tests.conftest import bf16_t, u16
+    rng = np.random.default_rng(pos0 * 31 + n + nh)
+    kvd, qd = nkv * hd, nh * hd
+    tot = pos0 + n
+    q = O.f32_to_bf16(rng.normal(0, 1.0, size=(n, qd)).astype(np.float32))
+    kc = O.f32_to_bf16(rng.normal(0, 1.0, size=(tot, kvd)).astype(np.float32))
+    vc = O.f32_to_bf16(rng.normal(0, 1.0, size=(tot, kvd)).astype(np.float32))
+    qd_t, kc_t, vc_t = bf16_t(q, ctx.device), bf16_t(kc, ctx.device), bf16_t(vc, ctx.device)
+    out_t = torch.zeros(n, qd, dtype=torch.bfloat16, device=ctx.device)
+    rc = ctx.hip.kf_attn_prefill(ctx.h, qd_t.data_ptr(), kc_t.data_ptr(), vc_t.data_ptr(), out_t.data_ptr(), pos0, n, qd, nh, nkv, hd, kvd)
+    assert rc == 0, ctx.hip.kf_last_error()
+    ctx.sync()
+    out = u16(out_t)
+    for t in sorted({0, 1, n // 3, n // 2, n - 2, n - 1}):
+        pos = pos0 + t
+        ref = O.bf16_to_f32(O.attn_decode(q[t], kc[:pos + 1], vc[:pos + 1], pos, nh, nkv, hd, mode=O.ATTN_FUSED))
+        refc = O.bf16_to_f32(O.attn_decode(q[t], kc[:pos + 1], vc[:pos + 1], pos, nh, nkv, hd, mode=O.ATTN_REF))
+        got = O.bf16_to_f32(out[t])
+        assert np.abs(got - ref).max() <= 2.0 ** -7 * np.abs(ref).max(), "token %d vs FUSED" % t
+        assert np.abs(got - refc).max() <= 2.0 ** -6 * np.abs(refc).max(), "token %d vs REF" % t
