@@ -475,15 +475,16 @@ int gemm_launch(hipStream_t st, const kf_weight* w, const uint16_t* x, long long
     }
     a.x = x, a.ldx = ldx, a.n = n, a.y = y, a.ldy = ldy, a.bias = bias, a.residual = residual, a.ldr = ldr, a.alpha = alpha, a.beta = beta;
     const int ttiles = (n + GM_TOK - 1) / GM_TOK;
-    // few workgroups (prompt-sized batches on small matrices): the wave-independent kernel; otherwise the LDS-staged tiles
+    // prompt-sized batches on small matrices: the wave-independent kernel while its 32 x 32 workgroups fit ~2-3 rounds of the chip
+    // (measured crossover against the staged tiles, scratch/ub_gemm.py: 1024 rows up to n ~ 1024, 2048 up to ~ 600, 3072 up to ~ 400)
     static int direct_max = -1;
     if (direct_max < 0) {
         const char* e = getenv("KF_GEMM_DIRECT_MAX");
-        direct_max = e ? atoi(e) : 256;
+        direct_max = e ? atoi(e) : 1280;
     }
     int KS = ((long)((M + 127) / 128) * ttiles < 512) ? 2 : 1;
     dim3 grid;
-    if ((long)((M + 127) / 128) * ttiles < direct_max) {
+    if ((long)((M + 31) / 32) * ((n + 31) / 32) <= direct_max) {
         KS = 0;
         static int tb1 = -1; /* 32-token tiles (measured 7 us vs 10.8 us for 64-token tiles on 1024 x 1024, n = 128); KF_GEMM_TB1=0 for 64 */
         if (tb1 < 0) tb1 = getenv("KF_GEMM_TB1") ? atoi(getenv("KF_GEMM_TB1")) : 1;
