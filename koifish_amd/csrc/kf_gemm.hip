@@ -238,9 +238,9 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
     auto xload = [&](int it) {
 #pragma unroll
         for (int p = 0; p < 8; p++) {
-            const int tok = tok0 + p * 16 + trow;
-            xr[p] = u32x4{0, 0, 0, 0};
-            if (tok < a.n) xr[p] = *reinterpret_cast<const u32x4*>(a.x + (size_t)tok * a.ldx + (size_t)it * GM_KT + seg * 8);
+            int tok = tok0 + p * 16 + trow;
+            if (tok >= a.n) tok = a.n - 1; /* rows past the batch repeat the last token: loaded unconditionally, never stored */
+            xr[p] = *reinterpret_cast<const u32x4*>(a.x + (size_t)tok * a.ldx + (size_t)it * GM_KT + seg * 8);
         }
     };
     auto xstore = [&](int buf) {
@@ -249,31 +249,68 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
         for (int p = 0; p < 8; p++) *reinterpret_cast<u32x4*>(dst + (p * 16 + trow) * GM_XS + seg * 8) = xr[p];
     };
 
-    WTile<FMT, KS> wc, wn;
+    // Two tiles in flight: while tile `it` is multiplied out of LDS, tile it+1 waits in registers (loaded during the previous iteration,
+    // written to the other LDS buffer at the end of this one) and tile it+2's loads are issued -- a load has a whole iteration of
+    // arithmetic plus a barrier to land before anything waits for it (one tile ahead left ~2 us of latency exposed per iteration).
+    WTile<FMT, KS> wc, w1, w2;
+    u32x4 xr2[8];
+    auto xload2 = [&](int it) {
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            int tok = tok0 + p * 16 + trow;
+            if (tok >= a.n) tok = a.n - 1;
+            xr2[p] = *reinterpret_cast<const u32x4*>(a.x + (size_t)tok * a.ldx + (size_t)it * GM_KT + seg * 8);
+        }
+    };
     wc.load(a, row, 0, h, ks);
     xload(0);
     xstore(0);
+    // every load below is unconditional (past the last tile the last one is simply fetched again): with branches around them hipcc
+    // cannot count the loads in flight and falls back to s_waitcnt vmcnt(0), which waits for the NEWEST tile as well
+    {
+        const int i1 = nit > 1 ? 1 : 0;
+        w1.load(a, row, i1, h, ks);
+        xload(i1);
+    }
     __syncthreads();
     for (int it = 0; it < nit; it++) {
-        const bool more = it + 1 < nit;
-        if (more) {
-            wn.load(a, row, it + 1, h, ks);
-            xload(it + 1);
+        const bool more = it + 1 < nit, more2 = true;
+        {
+            const int i2 = it + 2 < nit ? it + 2 : nit - 1;
+            w2.load(a, row, i2, h, ks);
+            xload2(i2);
         }
         const uint16_t* xb = xs + (size_t)(it & 1) * GM_TOK * GM_XS;
+        // x fragments of step sl+1 are read from LDS while the weights of step sl are unpacked and multiplied (read just before
+        // each MFMA, every ds_read_b128 round trip sat in front of its MFMA)
+        u32x4 Bc[4], Bn[4];
+        {
+            const int ko = WTile<FMT, KS>::koff(0, h, ks);
+#pragma unroll
+            for (int tb = 0; tb < 4; tb++) Bc[tb] = *reinterpret_cast<const u32x4*>(xb + (tb * 32 + r) * GM_XS + ko);
+        }
 #pragma unroll
         for (int sl = 0; sl < NS; sl++) {
-            const bf16x8 A = __builtin_bit_cast(bf16x8, get_frag<FMT, KS>(wc, sl, a, ks));
-            const int ko = WTile<FMT, KS>::koff(sl, h, ks);
+            if (sl + 1 < NS) {
+                const int ko = WTile<FMT, KS>::koff(sl + 1, h, ks);
 #pragma unroll
-            for (int tb = 0; tb < 4; tb++) {
-                const u32x4 B = *reinterpret_cast<const u32x4*>(xb + (tb * 32 + r) * GM_XS + ko);
-                acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(bf16x8, B), acc[tb], 0, 0, 0);
+                for (int tb = 0; tb < 4; tb++) Bn[tb] = *reinterpret_cast<const u32x4*>(xb + (tb * 32 + r) * GM_XS + ko);
             }
+            __builtin_amdgcn_sched_barrier(0); /* keep the reads up here: left alone, the scheduler sinks each one next to its MFMA */
+            const bf16x8 A = __builtin_bit_cast(bf16x8, get_frag<FMT, KS>(wc, sl, a, ks));
+#pragma unroll
+            for (int tb = 0; tb < 4; tb++) acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(bf16x8, Bc[tb]), acc[tb], 0, 0, 0);
+#pragma unroll
+            for (int tb = 0; tb < 4; tb++) Bc[tb] = Bn[tb];
         }
         if (more) {
             xstore((it + 1) & 1);
-            wc = wn;
+            wc = w1;
+        }
+        if (more2) {
+            w1 = w2;
+#pragma unroll
+            for (int p = 0; p < 8; p++) xr[p] = xr2[p];
         }
         __syncthreads();
     }
