@@ -183,6 +183,13 @@ int kf_sample(kf_ctx* ctx, const kf_bf16* logits, int n, int top_k, float temper
  * GoPT.cpp:1139-1146); its batched forward exists only on the training side (SelfAttention::cuFlow / ROPE::cuFlow,
  * NeuronFuse.cu:692-731, rope.cu).  These entries run the same per-token arithmetic for n_tok consecutive positions at once;
  * kf_linear / kf_rmsnorm / kf_swiglu already take row batches. */
+/* n_w <= 3 matrices that share the input rows x [nTok, ne1] (Q, K, V): y[i] [nTok, w[i]->ne0].  One launch when the tile kernel
+ * covers the shape, otherwise kf_linear per matrix -- the same values either way. */
+int kf_linear_multi(kf_ctx* ctx, int n_w, const kf_weight* const* w, const kf_bf16* x, kf_bf16* const* y, int nTok);
+/* act [nTok, ne0] = silu(x . gate^T) * (x . up^T) for nTok rows (FFN::cuFlow: gate.Forw, up.Forw, Relu::Forw SWIG,
+ * NeuronFuse.cu:615-656 with a batch): one launch, bit-identical to kf_linear x 2 + kf_swiglu; up_scratch [nTok, ne0] is used only by
+ * the unfused fallback. */
+int kf_gateup_swiglu_batch(kf_ctx* ctx, const kf_weight* gate, const kf_weight* up, const kf_bf16* x, kf_bf16* act, kf_bf16* up_scratch, int nTok);
 /* out[t] = row d_tokens[t] of the table, t < n_tok (TokenEmbed::OnEmbed for a batch, NeuronFuse.cu:176-207) */
 int kf_embed_batch(kf_ctx* ctx, const kf_weight* w, const int32_t* d_tokens, int n_tok, kf_bf16* out);
 /* kf_qknorm_rope for tokens t < n_tok at positions pos0 + t: q + t*q_stride, k + t*k_stride (k may be cache rows: k_stride = kv_stride) */

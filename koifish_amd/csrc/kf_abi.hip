@@ -414,6 +414,45 @@ int kf_embed_batch(kf_ctx* c, const kf_weight* w, const int32_t* d_tokens, int n
     if (!out || !al16(out) || !d_tokens || n_tok < 1) return fail(KF_INVALID_ARGS, "kf_embed_batch: bad args");
     RET(kf::embed_launch(c->stream, w, 0, d_tokens, nullptr, nullptr, out, n_tok));
 }
+int kf_linear_multi(kf_ctx* c, int n_w, const kf_weight* const* w, const kf_bf16* x, kf_bf16* const* y, int nTok) {
+    CHKCTX(c);
+    if (n_w < 1 || n_w > 3 || !w || !y || !x || nTok < 1) return fail(KF_INVALID_ARGS, "kf_linear_multi: bad args (n_w=%d nTok=%d)", n_w, nTok);
+    for (int i = 0; i < n_w; i++) {
+        int r = check_weight(w[i], "kf_linear_multi");
+        if (r) return r;
+        if (!y[i]) return fail(KF_INVALID_ARGS, "kf_linear_multi: y[%d] null", i);
+        if (w[i]->ne1 != w[0]->ne1) return fail(KF_INVALID_ARGS, "kf_linear_multi: the matrices do not share the input width");
+    }
+    if (n_w > 1 && nTok >= 8) {
+        const int rc = kf::gemm_multi_launch(c->stream, n_w, w, x, w[0]->ne1, nTok, y);
+        if (rc < 0) return fail(rc, "kf_linear_multi failed with %d", rc);
+        if (rc == KF_OK) return KF_OK;
+    }
+    for (int i = 0; i < n_w; i++) {
+        int r = kf_linear(c, w[i], x, y[i], nullptr, nTok, 1.0f, 0.0f, KF_EPI_NONE, nullptr);
+        if (r) return r;
+    }
+    return KF_OK;
+}
+int kf_gateup_swiglu_batch(kf_ctx* c, const kf_weight* gate, const kf_weight* up, const kf_bf16* x, kf_bf16* act, kf_bf16* up_scratch, int nTok) {
+    CHKCTX(c);
+    int r = check_weight(gate, "kf_gateup_swiglu_batch");
+    if (r) return r;
+    r = check_weight(up, "kf_gateup_swiglu_batch");
+    if (r) return r;
+    if (!x || !act || !up_scratch || nTok < 1) return fail(KF_INVALID_ARGS, "kf_gateup_swiglu_batch: bad args");
+    if (gate->ne0 != up->ne0 || gate->ne1 != up->ne1) return fail(KF_INVALID_ARGS, "kf_gateup_swiglu_batch: gate and up shapes differ");
+    if (nTok >= 8) {
+        const int rc = kf::gemm_paired_launch(c->stream, gate, up, x, gate->ne1, nTok, act);
+        if (rc < 0) return fail(rc, "kf_gateup_swiglu_batch failed with %d", rc);
+        if (rc == KF_OK) return KF_OK;
+    }
+    r = kf_linear(c, gate, x, act, nullptr, nTok, 1.0f, 0.0f, KF_EPI_NONE, nullptr);
+    if (r) return r;
+    r = kf_linear(c, up, x, up_scratch, nullptr, nTok, 1.0f, 0.0f, KF_EPI_NONE, nullptr);
+    if (r) return r;
+    return kf_swiglu(c, act, up_scratch, act, nTok * gate->ne0);
+}
 int kf_qknorm_rope_batch(kf_ctx* c, kf_bf16* q, kf_bf16* k, const kf_bf16* wq, const kf_bf16* wk, const float* table, int pos0, int n_tok, int64_t q_stride,
                          int64_t k_stride, int n_head, int n_kv, int hd, float eps) {
     CHKCTX(c);

@@ -19,6 +19,7 @@
 // fp32 accumulation inside the MFMA, one bf16 round-to-nearest store; epilogue order as the mat-vec (alpha, beta*y, bias, store,
 // residual add + store).  Differs from the token-serial mat-vec only in fp32 summation order.
 #include <stdlib.h>
+#include <string.h>
 
 #include "kf_kernels.h"
 
@@ -46,6 +47,16 @@ struct GemmArgs {
     const uint16_t* residual;
     long long ldr;
     float alpha, beta;
+    // direct kernel only: further weights sharing x and K -- jobs 1, 2 of one launch (Q/K/V), or the `up` matrix of a paired SwiGLU launch
+    int njobs;      /* 1..3 */
+    int rb_end[3];  /* cumulative count of 32-row blocks per job */
+    const unsigned char* xw[2];
+    const uint16_t* xzero[2];
+    const uint16_t* xstep[2];
+    float xqBias[2];
+    int xM[2];
+    uint16_t* xy[2];
+    long long xldy[2];
 };
 
 // ---- 8 consecutive weights -> 4 packed bf16 pairs (element 2i in the low half of word i)
@@ -340,23 +351,44 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
 // wave 0 adds the sums in wave order.  All loads of a group are issued before any of its arithmetic and the next group's loads before
 // the current group's arithmetic: the prompt-sized GEMMs of a 0.6B model are latency-bound (a 1024 x 1024 4-bit matrix is 0.5 MB,
 // far fewer waves than SIMDs), so the k loop is kept as short as the register file allows (K = 1024: one group per wave, no loop).
-template <int FMT, int TB, int UPG, int NW>
-__global__ void __launch_bounds__(NW * 64) gemm_direct_kernel(const GemmArgs a) {
+// PAIRED: the workgroup multiplies the same x fragments against TWO matrices (gate, up) and stores silu(gate) * up: the bf16 stores of
+// gate and up and the SwiGLU expression are the ones of the separate launches (kf_linear x 2 + kf_swiglu), so the result is bit-identical.
+// Otherwise a launch may carry up to three matrices that share x (Q, K, V): blockIdx.x walks their 32-row blocks one job after the other.
+template <int FMT, int TB, int UPG, int NW, bool PAIRED>
+__global__ void __launch_bounds__(NW * 64) gemm_direct_kernel(const GemmArgs a0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float* red = reinterpret_cast<float*>(smem_raw); /* [NW-1][TB][16][64] */
+    float* red = reinterpret_cast<float*>(smem_raw); /* [NW-1][PAIRED ? 2 : 1][TB][16][64] */
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int row_base = blockIdx.x * 32;
+    GemmArgs a = a0;
+    int rb = blockIdx.x;
+    if (!PAIRED && a0.njobs > 1 && rb >= a0.rb_end[0]) { /* workgroup-uniform: the fields below stay scalar */
+        const bool j2 = a0.njobs > 2 && rb >= a0.rb_end[1];
+        rb -= j2 ? a0.rb_end[1] : a0.rb_end[0];
+        a.w = j2 ? a0.xw[1] : a0.xw[0];
+        a.zero = j2 ? a0.xzero[1] : a0.xzero[0];
+        a.step = j2 ? a0.xstep[1] : a0.xstep[0];
+        a.qBias = j2 ? a0.xqBias[1] : a0.xqBias[0];
+        a.M = j2 ? a0.xM[1] : a0.xM[0];
+        a.y = j2 ? a0.xy[1] : a0.xy[0];
+        a.ldy = j2 ? a0.xldy[1] : a0.xldy[0];
+    }
+    GemmArgs b = a0; /* PAIRED: the second matrix */
+    if (PAIRED) b.w = a0.xw[0], b.zero = a0.xzero[0], b.step = a0.xstep[0], b.qBias = a0.xqBias[0];
+    const int row_base = rb * 32;
     int row = row_base + r;
     if (row >= a.M) row = a.M - 1;
     const int tok0 = blockIdx.y * (TB * 32);
     const int nunit = a.K / 64;
 
-    f32x16 acc[TB];
+    f32x16 acc[TB], acc2[PAIRED ? TB : 1];
 #pragma unroll
     for (int tb = 0; tb < TB; tb++)
 #pragma unroll
-        for (int i = 0; i < 16; i++) acc[tb][i] = 0.f;
+        for (int i = 0; i < 16; i++) {
+            acc[tb][i] = 0.f;
+            if (PAIRED) acc2[tb][i] = 0.f;
+        }
 
     // x rows of this lane's tokens (rows past n read row n-1: their results are not stored)
     const uint16_t* xrow[TB];
@@ -368,6 +400,7 @@ __global__ void __launch_bounds__(NW * 64) gemm_direct_kernel(const GemmArgs a) 
     }
     struct Group {
         WTile<FMT, 2> w[UPG];
+        WTile<FMT, 2> w2[PAIRED ? UPG : 1];
         u32x4 x[UPG][4][TB];
     };
     auto gload = [&](int u0, Group& g) { /* units u0 .. u0+UPG-1; units past the end repeat the last one and are skipped in the arithmetic */
@@ -377,6 +410,7 @@ __global__ void __launch_bounds__(NW * 64) gemm_direct_kernel(const GemmArgs a) 
             if (u >= nunit) u = nunit - 1;
             const int it = u >> 1, ks = u & 1;
             g.w[j].load(a, row, it, h, ks);
+            if (PAIRED) g.w2[j].load(b, row, it, h, ks);
 #pragma unroll
             for (int sl = 0; sl < 4; sl++) {
                 const int ko = it * GM_KT + WTile<FMT, 2>::koff(sl, h, ks);
@@ -400,6 +434,12 @@ __global__ void __launch_bounds__(NW * 64) gemm_direct_kernel(const GemmArgs a) 
 #pragma unroll
                     for (int tb = 0; tb < TB; tb++)
                         acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(bf16x8, gc.x[j][sl][tb]), acc[tb], 0, 0, 0);
+                    if (PAIRED) {
+                        const bf16x8 A2 = __builtin_bit_cast(bf16x8, get_frag<FMT, 2>(gc.w2[j], sl, b, (u0 + j) & 1));
+#pragma unroll
+                        for (int tb = 0; tb < TB; tb++)
+                            acc2[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, __builtin_bit_cast(bf16x8, gc.x[j][sl][tb]), acc2[tb], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -410,17 +450,41 @@ __global__ void __launch_bounds__(NW * 64) gemm_direct_kernel(const GemmArgs a) 
 #pragma unroll
         for (int tb = 0; tb < TB; tb++)
 #pragma unroll
-            for (int i = 0; i < 16; i++) red[(((wave - 1) * TB + tb) * 16 + i) * 64 + lane] = acc[tb][i];
+            for (int i = 0; i < 16; i++) {
+                red[(((wave - 1) * TB + tb) * 16 + i) * 64 + lane] = acc[tb][i];
+                if (PAIRED) red[((((NW - 1) + (wave - 1)) * TB + tb) * 16 + i) * 64 + lane] = acc2[tb][i];
+            }
     }
     __syncthreads();
     if (wave > 0) return;
-#pragma unroll
+#pragma unroll 1 /* one partial at a time: fully unrolled, the (NW-1) x 32 LDS reads are all hoisted and spill */
     for (int w = 0; w < NW - 1; w++)
 #pragma unroll
         for (int tb = 0; tb < TB; tb++)
 #pragma unroll
-            for (int i = 0; i < 16; i++) acc[tb][i] = acc[tb][i] + red[((w * TB + tb) * 16 + i) * 64 + lane];
-    gemm_epilogue<TB>(acc, a, tok0, row_base, r, h);
+            for (int i = 0; i < 16; i++) {
+                acc[tb][i] = acc[tb][i] + red[((w * TB + tb) * 16 + i) * 64 + lane];
+                if (PAIRED) acc2[tb][i] = acc2[tb][i] + red[((((NW - 1) + w) * TB + tb) * 16 + i) * 64 + lane];
+            }
+    if (!PAIRED) {
+        gemm_epilogue<TB>(acc, a, tok0, row_base, r, h);
+    } else { /* act = silu(gate) * up on the bf16-rounded gate / up (Relu::Forw SWIG, Activation.cu:85-93; the expression of kf_swiglu) */
+#pragma unroll
+        for (int tb = 0; tb < TB; tb++) {
+            const int tok = tok0 + tb * 32 + r;
+            if (tok >= a.n) continue;
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                const int rg = row_base + 8 * gq + 4 * h;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (rg + j >= a.M) continue;
+                    const float g = round_bf16(acc[tb][4 * gq + j]), u = round_bf16(acc2[tb][4 * gq + j]);
+                    a.y[(size_t)tok * a.ldy + rg + j] = f2bf((g * u) / (1.0f + kf_expf(-g)));
+                }
+            }
+        }
+    }
 }
 
 // ---- epilogue: lane holds token (tb*32 + r), rows row_base + 8g + 4h + j
@@ -473,44 +537,120 @@ static int gm_fmt_of(int type) {
     }
 }
 
+constexpr int GD_NW = 8, GD_UPG = 2; /* direct kernel: 8 waves, groups of two 64-element units, 32-token tiles */
+
 template <int FMT>
 static void gm_launch(const GemmArgs& a, int KS, dim3 grid, size_t smem, hipStream_t st) {
-    if (KS == 0) { /* direct kernel: 8 waves, grid.y tiles of 64 (TB = 2) or 32 (TB = 1) tokens */
-        constexpr int NW = 8, UPG = 2;
-        if (grid.y * 32 < (unsigned)a.n) /* launcher chose 64-token tiles */
-            hipLaunchKernelGGL((gemm_direct_kernel<FMT, 2, UPG, NW>), grid, dim3(NW * 64), (size_t)(NW - 1) * 2 * 16 * 64 * 4, st, a);
-        else
-            hipLaunchKernelGGL((gemm_direct_kernel<FMT, 1, UPG, NW>), grid, dim3(NW * 64), (size_t)(NW - 1) * 1 * 16 * 64 * 4, st, a);
-    } else if (KS == 2)
+    if (KS == 0)
+        hipLaunchKernelGGL((gemm_direct_kernel<FMT, 1, GD_UPG, GD_NW, false>), grid, dim3(GD_NW * 64), (size_t)(GD_NW - 1) * 16 * 64 * 4, st, a);
+    else if (KS == -1) /* paired SwiGLU */
+        hipLaunchKernelGGL((gemm_direct_kernel<FMT, 1, GD_UPG, GD_NW, true>), grid, dim3(GD_NW * 64), (size_t)(GD_NW - 1) * 2 * 16 * 64 * 4, st, a);
+    else if (KS == 2)
         hipLaunchKernelGGL((gemm_kernel<FMT, 2>), grid, dim3(256), smem, st, a);
     else
         hipLaunchKernelGGL((gemm_kernel<FMT, 1>), grid, dim3(256), smem, st, a);
+}
+static void gm_dispatch(int fmt, const GemmArgs& a, int KS, dim3 grid, size_t smem, hipStream_t st) {
+    switch (fmt) {
+        case FMT_BF16: gm_launch<FMT_BF16>(a, KS, grid, smem, st); break;
+        case FMT_F8: gm_launch<FMT_F8>(a, KS, grid, smem, st); break;
+        case FMT_Q4: gm_launch<FMT_Q4>(a, KS, grid, smem, st); break;
+        case FMT_Q2: gm_launch<FMT_Q2>(a, KS, grid, smem, st); break;
+        default: gm_launch<FMT_Q1>(a, KS, grid, smem, st); break;
+    }
+}
+
+static const int gm_epb[5] = {8, 16, 32, 64, 128};
+struct GmWeight {
+    const unsigned char* w;
+    const uint16_t *zero, *step;
+    float qBias;
+    int M, K, fmt, gshift;
+};
+// 0 ok, 1 not eligible for the tile kernels, < 0 error
+static int gm_weight(const kf_weight* w, GmWeight& o) {
+    o.fmt = gm_fmt_of(w->type);
+    if (o.fmt < 0 || w->qzeros || w->qscales) return 1;
+    o.M = w->ne0, o.K = w->ne1;
+    if (o.K % GM_KT != 0 || o.K < GM_KT || o.M < 1 || (reinterpret_cast<uintptr_t>(w->data) & 15) != 0) return 1;
+    if ((unsigned long long)o.M * (unsigned long long)(o.K / gm_epb[o.fmt]) >= (1ull << 32)) return 1;
+    o.w = reinterpret_cast<const unsigned char*>(w->data);
+    o.zero = o.step = nullptr, o.qBias = (float)w->qBias, o.gshift = 0;
+    if (o.fmt >= FMT_Q4) {
+        if (!w->gama || w->lGroup <= 0 || (w->lGroup % gm_epb[o.fmt]) != 0 || ((long)o.M * o.K) % w->lGroup != 0) return KF_QUANT_ERR;
+        const int bpg = w->lGroup / gm_epb[o.fmt];
+        if (bpg < 1 || (bpg & (bpg - 1)) != 0) return KF_QUANT_ERR;
+        o.gshift = __builtin_ctz(bpg);
+        o.zero = w->gama + w->ne0 + w->ne1;
+        o.step = o.zero + (size_t)o.M * o.K / w->lGroup;
+    }
+    return 0;
+}
+static void gm_base(GemmArgs& a, const GmWeight& g, const uint16_t* x, long long ldx, int n, uint16_t* y, long long ldy) {
+    memset(&a, 0, sizeof(a));
+    a.w = g.w, a.zero = g.zero, a.step = g.step, a.qBias = g.qBias;
+    a.M = g.M, a.K = g.K, a.nBlk = g.K / gm_epb[g.fmt], a.gshift = g.gshift;
+    a.x = x, a.ldx = ldx, a.n = n, a.y = y, a.ldy = ldy, a.alpha = 1.0f, a.njobs = 1;
+    a.rb_end[0] = a.rb_end[1] = a.rb_end[2] = (g.M + 31) / 32;
+}
+static bool gm_x_ok(const uint16_t* x, long long ldx) { return (ldx & 7) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0; }
+constexpr long GD_FUSED_MAX = 2048; /* workgroups up to which the fused direct launches beat separate (staged) ones */
+
+// up to three matrices sharing x (Q, K, V) in ONE direct launch: KF_OK, 1 = not eligible (the caller launches them one by one), < 0 error
+int gemm_multi_launch(hipStream_t st, int n_w, const kf_weight* const* w, const uint16_t* x, long long ldx, int n, uint16_t* const* y) {
+    if (n_w < 2 || n_w > 3 || !gm_x_ok(x, ldx)) return 1;
+    GmWeight g[3];
+    long rbs = 0;
+    for (int i = 0; i < n_w; i++) {
+        const int rc = gm_weight(w[i], g[i]);
+        if (rc) return rc;
+        if (g[i].fmt != g[0].fmt || g[i].K != g[0].K || g[i].gshift != g[0].gshift) return 1;
+        rbs += (g[i].M + 31) / 32;
+    }
+    if (rbs * ((n + 31) / 32) > GD_FUSED_MAX) return 1;
+    GemmArgs a;
+    gm_base(a, g[0], x, ldx, n, y[0], g[0].M);
+    a.njobs = n_w;
+    int end = 0;
+    for (int i = 0; i < 3; i++) {
+        if (i < n_w) end += (g[i].M + 31) / 32;
+        a.rb_end[i] = end;
+        if (i >= 1 && i < n_w)
+            a.xw[i - 1] = g[i].w, a.xzero[i - 1] = g[i].zero, a.xstep[i - 1] = g[i].step, a.xqBias[i - 1] = g[i].qBias, a.xM[i - 1] = g[i].M, a.xy[i - 1] = y[i],
+                     a.xldy[i - 1] = g[i].M;
+    }
+    gm_dispatch(g[0].fmt, a, 0, dim3(end, (n + 31) / 32), 0, st);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+
+// act[n, M] = silu(x . gate^T) * (x . up^T) in one direct launch: KF_OK, 1 = not eligible, < 0 error
+int gemm_paired_launch(hipStream_t st, const kf_weight* gate, const kf_weight* up, const uint16_t* x, long long ldx, int n, uint16_t* act) {
+    if (!gm_x_ok(x, ldx)) return 1;
+    GmWeight g, u;
+    int rc = gm_weight(gate, g);
+    if (rc) return rc;
+    rc = gm_weight(up, u);
+    if (rc) return rc;
+    if (g.fmt != u.fmt || g.K != u.K || g.M != u.M || g.gshift != u.gshift) return 1;
+    if ((long)((g.M + 31) / 32) * ((n + 31) / 32) > GD_FUSED_MAX) return 1;
+    GemmArgs a;
+    gm_base(a, g, x, ldx, n, act, g.M);
+    a.xw[0] = u.w, a.xzero[0] = u.zero, a.xstep[0] = u.step, a.xqBias[0] = u.qBias;
+    gm_dispatch(g.fmt, a, -1, dim3((g.M + 31) / 32, (n + 31) / 32), 0, st);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 
 // Returns KF_OK when launched, 1 when the shape is not eligible (the caller then loops the mat-vec), < 0 on error.
 int gemm_launch(hipStream_t st, const kf_weight* w, const uint16_t* x, long long ldx, int n, uint16_t* y, long long ldy, const uint16_t* bias, float alpha,
                 float beta, const uint16_t* residual, long long ldr) {
-    const int fmt = gm_fmt_of(w->type);
-    if (fmt < 0 || w->qzeros || w->qscales) return 1;
-    const int M = w->ne0, K = w->ne1;
-    if (K % GM_KT != 0 || K < GM_KT || M < 1) return 1;
-    if ((ldx & 7) != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0 || (reinterpret_cast<uintptr_t>(w->data) & 15) != 0) return 1;
-    static const int epb[5] = {8, 16, 32, 64, 128};
+    GmWeight g;
+    const int rc = gm_weight(w, g);
+    if (rc) return rc;
+    if (!gm_x_ok(x, ldx)) return 1;
+    const int M = g.M;
     GemmArgs a;
-    a.w = reinterpret_cast<const unsigned char*>(w->data);
-    a.zero = a.step = nullptr;
-    a.qBias = (float)w->qBias;
-    a.M = M, a.K = K, a.nBlk = K / epb[fmt], a.gshift = 0;
-    if ((unsigned long long)M * (unsigned long long)a.nBlk >= (1ull << 32)) return 1;
-    if (fmt >= FMT_Q4) {
-        if (!w->gama || w->lGroup <= 0 || (w->lGroup % epb[fmt]) != 0 || ((long)M * K) % w->lGroup != 0) return KF_QUANT_ERR;
-        const int bpg = w->lGroup / epb[fmt];
-        if (bpg < 1 || (bpg & (bpg - 1)) != 0) return KF_QUANT_ERR;
-        a.gshift = __builtin_ctz(bpg);
-        a.zero = w->gama + w->ne0 + w->ne1;
-        a.step = a.zero + (size_t)M * K / w->lGroup;
-    }
-    a.x = x, a.ldx = ldx, a.n = n, a.y = y, a.ldy = ldy, a.bias = bias, a.residual = residual, a.ldr = ldr, a.alpha = alpha, a.beta = beta;
+    gm_base(a, g, x, ldx, n, y, ldy);
+    a.bias = bias, a.residual = residual, a.ldr = ldr, a.alpha = alpha, a.beta = beta;
     const int ttiles = (n + GM_TOK - 1) / GM_TOK;
     // prompt-sized batches on small matrices: the wave-independent kernel while its 32 x 32 workgroups fit ~2-3 rounds of the chip
     // (measured crossover against the staged tiles, scratch/ub_gemm.py: 1024 rows up to n ~ 1024, 2048 up to ~ 600, 3072 up to ~ 400)
@@ -523,21 +663,12 @@ int gemm_launch(hipStream_t st, const kf_weight* w, const uint16_t* x, long long
     dim3 grid;
     if ((long)((M + 31) / 32) * ((n + 31) / 32) <= direct_max) {
         KS = 0;
-        static int tb1 = -1; /* 32-token tiles (measured 7 us vs 10.8 us for 64-token tiles on 1024 x 1024, n = 128); KF_GEMM_TB1=0 for 64 */
-        if (tb1 < 0) tb1 = getenv("KF_GEMM_TB1") ? atoi(getenv("KF_GEMM_TB1")) : 1;
-        grid = dim3((M + 31) / 32, (n > 32 && !tb1) ? (n + 63) / 64 : (n + 31) / 32);
+        grid = dim3((M + 31) / 32, (n + 31) / 32);
     } else {
         const int rows_per_wg = 32 * (4 / KS);
         grid = dim3((M + rows_per_wg - 1) / rows_per_wg, ttiles);
     }
-    const size_t smem = (size_t)2 * GM_TOK * GM_XS * sizeof(uint16_t);
-    switch (fmt) {
-        case FMT_BF16: gm_launch<FMT_BF16>(a, KS, grid, smem, st); break;
-        case FMT_F8: gm_launch<FMT_F8>(a, KS, grid, smem, st); break;
-        case FMT_Q4: gm_launch<FMT_Q4>(a, KS, grid, smem, st); break;
-        case FMT_Q2: gm_launch<FMT_Q2>(a, KS, grid, smem, st); break;
-        default: gm_launch<FMT_Q1>(a, KS, grid, smem, st); break;
-    }
+    gm_dispatch(g.fmt, a, KS, grid, (size_t)2 * GM_TOK * GM_XS * sizeof(uint16_t), st);
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 

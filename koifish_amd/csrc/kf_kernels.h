@@ -56,6 +56,9 @@ void argmax_finish_launch(hipStream_t st, const float* val, const int* idx, int 
 int gemm_launch(hipStream_t st, const kf_weight* w, const uint16_t* x, long long ldx, int n, uint16_t* y, long long ldy, const uint16_t* bias, float alpha,
                 float beta, const uint16_t* residual, long long ldr);
 
+int gemm_multi_launch(hipStream_t st, int n_w, const kf_weight* const* w, const uint16_t* x, long long ldx, int n, uint16_t* const* y);
+int gemm_paired_launch(hipStream_t st, const kf_weight* gate, const kf_weight* up, const uint16_t* x, long long ldx, int n, uint16_t* act);
+
 // ---- attention (kf_attn.hip)
 struct AttnArgs {
     const uint16_t* q;     /* raw or prepared q [n_head*hd] */

@@ -159,9 +159,9 @@ int SelfAttention::cuFlow(floatX* bx, int pos0, int n) {
     floatX *bn = ToX(f->gBUFF.bNorm), *bq = ToX(f->gBUFF.bQ), *ba = ToX(f->gBUFF.bAttn);
     kf_weight wq = Q.w->desc(), wk = K.w->desc(), wv = V.w->desc(), wo = proj_cat.w->desc();
     KF_TRY(kf_rmsnorm(c, bx, ToX(norm.w), bn, n, C, norm.rms_eps, nullptr));
-    KF_TRY(kf_linear(c, &wq, bn, bq, nullptr, n, 1.0f, 0.0f, KF_EPI_NONE, nullptr));
-    KF_TRY(kf_linear(c, &wk, bn, krows, nullptr, n, 1.0f, 0.0f, KF_EPI_NONE, nullptr));  // K.out / V.out alias the cache rows (_devQKV)
-    KF_TRY(kf_linear(c, &wv, bn, vrows, nullptr, n, 1.0f, 0.0f, KF_EPI_NONE, nullptr));
+    const kf_weight* ws[3] = {&wq, &wk, &wv};
+    kf_bf16* ys[3] = {bq, krows, vrows};  // K.out / V.out alias the cache rows (_devQKV)
+    KF_TRY(kf_linear_multi(c, 3, ws, bn, ys, n));
     KF_TRY(kf_qknorm_rope_batch(c, bq, krows, normQ.w ? ToX(normQ.w) : nullptr, normK.w ? ToX(normK.w) : nullptr, f->rope_table, pos0, n, q_dim, kv_dim, n_head,
                                n_head_kv, head_dim, normQ.rms_eps));
     KF_TRY(kf_attn_prefill(c, bq, key_cache, val_cache, ba, pos0, n, q_dim, n_head, n_head_kv, head_dim, kv_dim));
@@ -175,9 +175,7 @@ int FFN::cuFlow(floatX* bx, int n) {
     floatX *bn = ToX(f->gBUFF.bNorm), *bg = ToX(f->gBUFF.bGate), *bu = ToX(f->gBUFF.bUp);
     kf_weight wg = gate.w->desc(), wu = up.w->desc(), wd = down.w->desc();
     KF_TRY(kf_rmsnorm(c, bx, ToX(norm.w), bn, n, C, norm.rms_eps, nullptr));
-    KF_TRY(kf_linear(c, &wg, bn, bg, nullptr, n, 1.0f, 0.0f, KF_EPI_NONE, nullptr));
-    KF_TRY(kf_linear(c, &wu, bn, bu, nullptr, n, 1.0f, 0.0f, KF_EPI_NONE, nullptr));
-    KF_TRY(kf_swiglu(c, bg, bu, bg, n * latent));
+    KF_TRY(kf_gateup_swiglu_batch(c, &wg, &wu, bn, bg, bu, n));
     return kf_linear(c, &wd, bg, bx, nullptr, n, 1.0f, 0.0f, KF_EPI_RESIDUAL, bx);
 }
 

@@ -87,3 +87,39 @@ def test_gemm_linearity_full_size(ctx, O):
     y1, y2, ysum = (O.bf16_to_f32(_run(ctx, dw, v, nt, m)) for v in (x1, x2, xs))
     scale = np.abs(ysum).max()
     assert np.abs(ysum - (y1 + y2)).max() <= 2.0 ** -6 * scale
+
+
+@pytest.mark.parametrize("t", [L.Q4, L.BF16, L.BOOL1])
+@pytest.mark.parametrize("nt", [8, 100, 300])
+def test_multi_and_paired_launches_equal_separate_ones(ctx, O, t, nt):
+    """kf_linear_multi (Q, K, V in one launch) and kf_gateup_swiglu_batch are the same arithmetic as kf_linear per matrix (+ kf_swiglu):
+    bit-identical outputs"""
+    k = 1024
+    rng = np.random.default_rng(nt + t)
+    x = O.f32_to_bf16(rng.normal(0, 1.0, size=(nt, k)).astype(np.float32))
+    xd = bf16_t(x, ctx.device)
+    ms = (2048, 1024, 1000)
+    dws = []
+    for i, m in enumerate(ms):
+        w = O.f32_to_bf16(rng.normal(0, 0.02, size=(m, k)).astype(np.float32))
+        dws.append(ctx.upload_blob(t, m, k, O.quantize(w, m, k, t).blob()))
+    descs = [d.desc() for d in dws]
+    ys = [torch.zeros(nt, m, dtype=torch.bfloat16, device=ctx.device) for m in ms]
+    wp = (C.c_void_p * 3)(*[C.addressof(d) for d in descs])
+    yp = (C.c_void_p * 3)(*[y.data_ptr() for y in ys])
+    assert ctx.hip.kf_linear_multi(ctx.h, 3, wp, xd.data_ptr(), yp, nt) == 0, ctx.hip.kf_last_error()
+    ctx.sync()
+    for d, y, m in zip(dws, ys, ms):
+        assert np.array_equal(u16(y), _run(ctx, d, x, nt, m))
+    # gate/up pair
+    m = 3072
+    g = ctx.upload_blob(t, m, k, O.quantize(O.f32_to_bf16(rng.normal(0, 0.05, size=(m, k)).astype(np.float32)), m, k, t).blob())
+    u = ctx.upload_blob(t, m, k, O.quantize(O.f32_to_bf16(rng.normal(0, 0.05, size=(m, k)).astype(np.float32)), m, k, t).blob())
+    act = torch.zeros(nt, m, dtype=torch.bfloat16, device=ctx.device)
+    tmp = torch.zeros(nt, m, dtype=torch.bfloat16, device=ctx.device)
+    gd, ud = g.desc(), u.desc()
+    assert ctx.hip.kf_gateup_swiglu_batch(ctx.h, C.byref(gd), C.byref(ud), xd.data_ptr(), act.data_ptr(), tmp.data_ptr(), nt) == 0, ctx.hip.kf_last_error()
+    ctx.sync()
+    yg, yu = _run(ctx, g, x, nt, m), _run(ctx, u, x, nt, m)
+    want = ctx.swiglu(bf16_t(yg, ctx.device).view(-1), bf16_t(yu, ctx.device).view(-1))
+    assert np.array_equal(u16(act).reshape(-1), u16(want).reshape(-1))
