@@ -99,13 +99,15 @@ int kf_event_destroy(void* ev);
 int kf_dequant(kf_ctx* ctx, const kf_weight* w, kf_bf16* out);
 
 /* device quantiser, GeQuant::RTN_x / YinYang (GeQuant.cpp:428-628; device twin CU_XtoQ128_ T.cu:105-175):
- * src bf16 [ne0*ne1] -> w->data (packed) and w->gama zero/step.  `w` must be fully described. symmetric: RTN only */
+ * src bf16 [ne0*ne1] -> w->data (packed) and w->gama zero/step.  `w` must be fully described. symmetric: RTN only.
+ * KF_F8E5M2: the storage conversion of Float2T<f8e5> (g_float.hpp:433-443): float -> half (RNE) -> high byte. */
 int kf_quantize(kf_ctx* ctx, const kf_weight* w, const kf_bf16* src, int symmetric);
 
 /* SLP::Forw -> TASKA_AxB::blasLt -> CU_mm_blasLt (Neuron.hpp:418, NeuronFuse.cu:305-381, GTensor.hpp:703-741,
  * gemm.cu:93-214): y[nTok, ne0] = alpha * x[nTok, ne1] . W^T (+ beta*y) (+ bias), fp32 accumulate, bf16 out,
- * computed straight from the packed stream (no GetDataX round trip).  x [nTok, ne1], y [nTok, ne0] row-major; nTok > 1 is served by
- * one mat-vec per token row for now.
+ * computed straight from the packed stream (no GetDataX round trip).  x [nTok, ne1], y [nTok, ne0] row-major; from 8 token rows up
+ * the product runs on MFMA tiles fed by in-register unpack (kf_gemm.hip), below that (or for K not a multiple of 128) one mat-vec per row:
+ * the same values up to fp32 summation order.
  * epilogue KF_EPI_RESIDUAL adds `residual` [ne0]. */
 int kf_linear(kf_ctx* ctx, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const kf_bf16* bias, int nTok, float alpha, float beta,
               uint32_t epilogue, const kf_bf16* residual);

@@ -53,9 +53,10 @@ def build_hip(force=False, verbose=False):
 
 def build_host(force=False, verbose=False):
     src = os.path.join(HOST, "kf_host.cpp")
-    deps = [src, os.path.join(HOST, "kf_host.hpp"), os.path.join(HERE, "..", "include", "kf_abi.h"), LIB_HIP]
+    src2 = os.path.join(HOST, "kf_safetensors.cpp")
+    deps = [src, src2, os.path.join(HOST, "kf_safetensors.hpp"), os.path.join(HOST, "kf_host.hpp"), os.path.join(HERE, "..", "include", "kf_abi.h"), LIB_HIP]
     if force or _stale(LIB_HOST, deps):
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", LIB_HOST, src, "-L" + HERE, "-lkf_hip", "-Wl,-rpath,$ORIGIN"]
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", LIB_HOST, src, src2, "-L" + HERE, "-lkf_hip", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -233,8 +233,8 @@ int kf_linear(kf_ctx* c, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const
     if (!x || !y || !al16(x)) return fail(KF_BLAS_UNALIGN, "kf_linear: x/y null or x unaligned");
     if ((epilogue & KF_EPI_RESIDUAL) && !residual) return fail(KF_INVALID_ARGS, "kf_linear: residual epilogue without residual");
     if (nTok > 1 && ((w->ne1 * 2) % 16 != 0)) return fail(KF_BLAS_UNALIGN, "kf_linear: token rows of x are not 16-byte aligned");
-    // nTok > 1 (SLP::Forw with a batch of tokens: x [nTok, ne1] row-major, y [nTok, ne0]): one mat-vec launch per token row.  Correct for
-    // every weight type; the weight stream is re-read per token (a tiled MFMA kernel for prefill is the next step).
+    // nTok > 1 (SLP::Forw with a batch of tokens: x [nTok, ne1] row-major, y [nTok, ne0]): the MFMA tile kernels of kf_gemm.hip from 8 rows
+    // up when the shape is covered (K a multiple of 128, 16-byte aligned rows), otherwise one mat-vec launch per token row.
     if (w->qzeros) { /* AutoAWQ layout: its own transposed mat-vec */
         const size_t need = kf::awq_scratch_bytes(w);
         if (need > c->awq_ws_bytes) {

@@ -334,7 +334,18 @@ __global__ void __launch_bounds__(256) quantize_kernel(const uint16_t* __restric
         reinterpret_cast<unsigned long long*>(dst + 16 * b)[1] = high;
     }
 }
+// bf16 -> f8e5m2 storage (Float2T<f8e5>, g_float.hpp:433-443; ToF8Ex huTensor.cu:821): float -> half round-to-nearest-even, keep the high byte
+__global__ void to_f8e5m2_kernel(const uint16_t* __restrict__ src, unsigned char* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (unsigned char)(__builtin_bit_cast(unsigned short, (_Float16)bf2f(src[i])) >> 8);
+}
+
 int quantize_launch(hipStream_t st, const kf_weight* w, const uint16_t* src, int symmetric) {
+    if (w->type == KF_F8E5M2) {
+        const size_t n = (size_t)w->ne0 * w->ne1;
+        hipLaunchKernelGGL(to_f8e5m2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, (unsigned char*)const_cast<void*>(w->data), n);
+        return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+    }
     int bits, mode = symmetric ? 1 : 0;
     switch (w->type) {
         case KF_Q4: bits = 4; break;

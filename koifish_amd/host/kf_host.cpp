@@ -7,12 +7,6 @@
 
 namespace koifish {
 
-#define KF_TRY(expr)                 \
-    do {                             \
-        int rc_ = (expr);            \
-        if (rc_ != KF_OK) return rc_; \
-    } while (0)
-
 // ------------------------------------------------------------------------------------------------ GTensor
 GTensor::~GTensor() {
     if (owned && data && ctx) kf_free(ctx, data);
@@ -27,6 +21,7 @@ kf_weight GTensor::desc() const {
     w.lGroup = quant.T_group;
     w.nGroup = nGroup();
     w.qMin = quant.qMin, w.qMax = quant.qMax, w.qBias = quant.qBias;
+    if (qZero && qScale) w.qzeros = qZero->data, w.qscales = qScale->data, w.nGroup = (int)(size() / 128), w.gama = nullptr;
     return w;
 }
 int GTensor::Alloc(kf_ctx* c, size_t nbytes) {
@@ -182,7 +177,7 @@ int FFN::cuFlow(floatX* bx, int n) {
 hGTensor TokenEmbed::cuInfer(int token, int) {
     Fish* f = hFish;
     kf_weight wd = w->desc();
-    int rc = f->graph_mode ? kf_embed_state(f->ctx, &wd, f->d_state, f->d_forced, ToX(out)) : kf_embed(f->ctx, &wd, token, nullptr, ToX(out));
+    int rc = (f->graph_mode || f->state_tokens) ? kf_embed_state(f->ctx, &wd, f->d_state, f->d_forced, ToX(out)) : kf_embed(f->ctx, &wd, token, nullptr, ToX(out));
     return rc == KF_OK ? out : nullptr;
 }
 
@@ -190,7 +185,7 @@ hGTensor Head4Token::cuInfer_1(hGTensor inp_, int) {
     Fish* f = hFish;
     kf_weight wd = proj.w->desc();
     int rc;
-    if (f->fuse_level == 0) {
+    if (f->fuse_level == 0 && !f->state_tokens) {
         hGTensor xn = f->final_norm.cuFlow(inp_);
         if (!xn) return nullptr;
         rc = kf_lm_head(f->ctx, &wd, ToX(xn), ToX(preLogits), f->d_state + 2, f->gBUFF.head_ws->data);
@@ -340,7 +335,13 @@ int Fish::RunSteps(int pos, int n, bool use_graph) {
     if (pos < 0 || pos + n > config.n_ctx) return KF_INVALID_ARGS;
     for (int i = 0; i < n; i++) {
         const int p = pos + i;
-        if (use_graph) {
+        if (fuse_level == 0) {  // per-kernel launches only (AutoAWQ weights): eager, position from the host, token from the device state
+            tok_pos = p;
+            graph_mode = false, state_tokens = true;
+            int rc = EnqueueStep(pos_bound());
+            state_tokens = false;
+            KF_TRY(rc);
+        } else if (use_graph) {
             kf_graph* g = GraphFor(p);
             if (!g) return KF_INTERNAL_ERR;
             KF_TRY(kf_graph_launch(ctx, g));

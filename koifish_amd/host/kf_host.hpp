@@ -27,6 +27,12 @@ enum class typNUMBER : uint8_t { F32 = 0, F64, F16, BF16, F8E5M2, F8E4M3, U8, I8
 
 struct Fish;
 
+#define KF_TRY(expr)                 \
+    do {                             \
+        int rc_ = (expr);            \
+        if (rc_ != KF_OK) return rc_; \
+    } while (0)
+
 // Quant card fields that cross the kernel seam (QUANT_CARD / GeQuant, GeQuant.cpp:107-124)
 struct QuantCard {
     int bits = 16, T_group = 128, qMin = 0, qMax = 0, qBias = 0;
@@ -42,6 +48,7 @@ struct GTensor {
     QuantCard quant;
     bool owned = false;
     kf_ctx* ctx = nullptr;
+    std::shared_ptr<GTensor> qZero, qScale;  // vendor AutoAWQ tensors (GeQuant.cpp:410): data = qweight [in, out/8]; ne = {out, in}
 
     ~GTensor();
     size_t size() const { return (size_t)ne[0] * ne[1] * ne[2] * ne[3]; }
@@ -187,6 +194,7 @@ struct Fish {
     int32_t* d_tokens_out = nullptr;  // [n_ctx] greedy id produced at each position
     int tok_pos = 0;              // hBatch->tok_pos
     bool graph_mode = false;      // launches take position/token from d_state
+    bool state_tokens = false;    // eager per-kernel steps (fuse_level 0, e.g. AutoAWQ weights): position from the host, token from d_state
     std::vector<kf_graph*> graphs;  // one per position bucket
     std::vector<int> graph_bound;
     hGTensor x;                   // residual stream

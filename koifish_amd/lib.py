@@ -92,6 +92,16 @@ def load():
         host.kfh_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
         host.kfh_set_forced.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         host.kfh_set_state.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        host.kfh_last_error.restype = C.c_char_p
+        host.kfh_st_open.restype = C.c_void_p
+        host.kfh_st_open.argtypes = [C.c_char_p, C.c_int]
+        host.kfh_st_close.argtypes = [C.c_void_p]
+        host.kfh_st_count.argtypes = [C.c_void_p]
+        host.kfh_st_info.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        host.kfh_st_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
+        host.kfh_load_hf.restype = C.c_void_p
+        host.kfh_load_hf.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        host.kfh_get_config.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         host.kfh_set_sampler.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_uint64]
         host.kfh_prefill.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         host.kfh_set_prefill_mode.argtypes = [C.c_void_p, C.c_int, C.c_int]

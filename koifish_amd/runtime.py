@@ -267,6 +267,33 @@ class Qwen3:
         self.weights = {}
         self._norms = {}
 
+    @classmethod
+    def from_hf(cls, path, layer_type=L.Q4, head_type=L.BF16, device=0, lGroup=128, max_seq=0):
+        """Hugging Face directory (config.json + model.safetensors[.index.json]; dense BF16/F16/F32 tensors are quantised on the GPU to
+        `layer_type` / `head_type`, AutoAWQ qweight/qzeros/scales triples are taken as they are) -> a ready model.  The C++ loader is
+        koifish_amd/host/kf_safetensors.cpp (K_SafeTensors, Serialize.cpp:849-976 read side)."""
+        self = cls.__new__(cls)
+        self.hip, self.host = L.load()
+        if not torch.cuda.is_available():
+            raise L.KFError("no GPU visible: koifish_amd runs on MI355X only (no CPU fallback)")
+        torch.cuda.set_device(device)
+        rc = C.c_int(0)
+        self.device = torch.device("cuda", device)
+        self.h = self.host.kfh_load_hf(str(path).encode(), device, C.c_void_p(stream(device).cuda_stream), int(layer_type), int(head_type), int(lGroup), int(max_seq),
+                                       C.byref(rc))
+        if not self.h:
+            raise L.KFError("kfh_load_hf(%s) failed with %d: %s" % (path, rc.value, self.host.kfh_last_error().decode()))
+        self.h = C.c_void_p(self.h)
+        iv = (C.c_int * 10)()
+        fv = (C.c_float * 2)()
+        L.check(self.host.kfh_get_config(self.h, iv, fv), "kfh_get_config")
+        self.cfg = dict(dim=iv[0], n_layer=iv[1], n_head=iv[2], n_kv=iv[3], head_dim=iv[4], ffn=iv[5], vocab=iv[6], max_seq=iv[7], tied=bool(iv[8]),
+                        theta=float(fv[1]))
+        self.fuse_level = iv[9]
+        self._keep, self.weights, self._norms = [], {}, {}
+        self._ctx = None
+        return self
+
     def close(self):
         if getattr(self, "h", None):
             self.host.kfh_destroy(self.h)
