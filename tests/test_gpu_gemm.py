@@ -123,3 +123,20 @@ def test_multi_and_paired_launches_equal_separate_ones(ctx, O, t, nt):
     yg, yu = _run(ctx, g, x, nt, m), _run(ctx, u, x, nt, m)
     want = ctx.swiglu(bf16_t(yg, ctx.device).view(-1), bf16_t(yu, ctx.device).view(-1))
     assert np.array_equal(u16(act).reshape(-1), u16(want).reshape(-1))
+
+
+@pytest.mark.parametrize("t", [L.Q4, L.BF16, L.T_SIGN])
+def test_gemm_many_token_tiles_vs_exact(ctx, O, t):
+    """a batch of 17 token tiles on the staged kernel (ragged tail): exact fp64 product of the dequantised weights"""
+    m, k, nt = 4096, 512, 2100
+    rng = np.random.default_rng(17 + t)
+    w = (torch.randn(m, k, device=ctx.device) * 0.02).to(torch.bfloat16)
+    dw = ctx.quantize(w, t)
+    x = O.f32_to_bf16(rng.normal(0, 1.0, size=(nt, k)).astype(np.float32))
+    y = O.bf16_to_f32(_run(ctx, dw, x, nt, m))
+    deq = ctx.dequant(dw).float().cpu().numpy().astype(np.float64)
+    exact = O.bf16_to_f32(x).astype(np.float64) @ deq.T
+    assert np.abs(y - exact).max() <= 2.0 ** -8 * np.abs(exact).max() + 1e-6
+    # and the last rows as a batch of their own: <= 1 bf16 ulp apart
+    y2 = _run(ctx, dw, x[-100:], 100, m)
+    assert close_bf16(O.f32_to_bf16(y[-100:].astype(np.float32)), y2).all()
