@@ -127,9 +127,9 @@ def main():
             "dtype": {"q4": "u4 weights (PackedQ RTN g128)", "bf16": "bf16 weights", "f8": "f8e5m2 weights", "ternary": "2-bit ternary weights (PackedQ YinYang g128)",
                       "1bit": "1-bit weights (PackedQ YinYang g128)"}[args.layers] + " x bf16 activations, fp32 accumulate; bf16 KV",
             "data": "synthetic",
-            "config": {"workload": "Qwen3-0.6B %s greedy decode, 1xMI355X per replica, seq=2048: prompt 128, timed positions %d..%d"
-                                   % ({"q4": "4-bit PackedQ", "bf16": "bf16", "f8": "f8e5m2", "ternary": "2-bit ternary PackedQ", "1bit": "1-bit PackedQ"}[args.layers],
-                                      timed_positions[0], timed_positions[-1]),
+            "config": {"workload": "%s %s greedy decode, 1xMI355X per replica, seq=%d: prompt 128, timed positions %d..%d"
+                                   % ({"qwen3-0.6b": "Qwen3-0.6B", "qwen3-32b": "Qwen3-32B"}.get(args.config, args.config), {"q4": "4-bit PackedQ", "bf16": "bf16", "f8": "f8e5m2", "ternary": "2-bit ternary PackedQ", "1bit": "1-bit PackedQ"}[args.layers],
+                                      S, timed_positions[0], timed_positions[-1]),
                        "lm_head": args.head, "replicas": world, "hipgraph": use_graph, "device_ms_per_step": round(dev_ms / K, 5)},
             "step_roofline": {"bound": "hbm", "bytes_per_step": int(mean_bytes), "achieved": round(mean_bytes * (value / world) / 1e9, 1),
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(mean_bytes * (value / world) / 1e9 / HBM_PEAK_GBS, 4)},
@@ -190,11 +190,13 @@ def kernel_roofline(m, ctx, cfg, reps=200):
     # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this process): FETCH_SIZE x 2
     # (gfx950 correction) + WRITE_SIZE, collected by `rocprofv3 --pmc ... -- python3 scratch/ub_head.py`
     traffic = None
-    try:
-        traffic = int(json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_lm_head.json")))["hbm_bytes_per_launch"])
-    except Exception:
-        pass
-    return {"bound": "hbm", "kernel": "kf::gemv_kernel<0, 4, 2> = bf16 LM head 151936x1024 mat-vec + per-workgroup arg-max partials", "achieved": round(ach, 1),
+    if (head.ne0, head.ne1, head.type) == (151936, 1024, L.BF16):   # the PMC passes were taken on this shape
+        try:
+            traffic = int(json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_lm_head.json")))["hbm_bytes_per_launch"])
+        except Exception:
+            pass
+    return {"bound": "hbm", "kernel": "kf::gemv_kernel<%d, 4, 2> = LM head %dx%d mat-vec + per-workgroup arg-max partials"
+                                      % ({L.BF16: 0, L.F8E5M2: 1, L.Q4: 2}.get(head.type, 0), head.ne0, head.ne1), "achieved": round(ach, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "bytes_per_launch": int(nbytes),
             "us_per_launch": round(ms * 1e3, 2)}
 
