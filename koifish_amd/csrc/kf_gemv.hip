@@ -537,8 +537,9 @@ int gemv_launch(hipStream_t st, GemvLaunch& L) {
     if (L.mode == GEMV_PAIRED) a.njobs = 1;
     // one wave per spw slots; aim for ~4096 waves (16 per CU) on large matrices, never fewer than one slot each
     // small problems: one slot per wave (latency-bound, as many waves as slots); large ones: several rounds of resident waves so that
-    // memory waits of one wave are covered by the dequant arithmetic of the others (measured: 25600x5120 q4 41 -> 33 us)
-    long target_waves = L.target_waves > 0 ? L.target_waves : (raw_slots * (long)nBlk * (64 / (1 << lpr_log2)) >= (1L << 21) ? 16384 : 4096);
+    // memory waits of one wave are covered by the dequant arithmetic of the others (measured: 25600x5120 q4 41 -> 33 us; the Qwen3-32B
+    // q/k/v and o_proj launches, 22-28 MB each, 21.8 -> 19.1 and 16.1 -> 13.2 us; the 0.6B launches stay below the threshold)
+    long target_waves = L.target_waves > 0 ? L.target_waves : (raw_slots * (long)nBlk * (64 / (1 << lpr_log2)) >= (1L << 19) ? 16384 : 4096);
     if (const char* e = getenv("KF_GEMV_WAVES")) target_waves = atol(e); /* tuning knob */
     long spw = (raw_slots + target_waves - 1) / target_waves;
     if (spw < 1) spw = 1;
