@@ -30,6 +30,7 @@ typedef struct kf_graph kf_graph;
 #define KF_QUANT_ERR (-701)            /* KOIFISH_QUANT_ERR */
 #define KF_UNSUPPORTED_DATATYPE (-1000) /* KOIFISH_UNSUPPORTED_DATATYPE */
 #define KF_HIP_CHECK (-1400)           /* KOIFISH_CUDA_CHECK */
+#define KF_ADAMW_MV (-5100)            /* KOIFISH_ADAMW_MV: a non-finite parameter or step met by kf_adamw (written to *d_status) */
 #define KF_BLAS_UNALIGN (-2000)        /* KOIFISH_BLAS_UNALIGN: a pointer is not 16-byte aligned (gemm.cu:119-122) */
 #define KF_RMS_PARAMS (-2100)          /* KOIFISH_RMS_PARAMS */
 
@@ -180,6 +181,17 @@ int kf_embed_state(kf_ctx* ctx, const kf_weight* w, const int32_t* d_state, cons
  * KF_INVALID_ARGS unless 2 <= top_k < n/2 (the reference asserts it), top_k <= 1024, temperature > 0, top_p > 0. */
 int kf_sample(kf_ctx* ctx, const kf_bf16* logits, int n, int top_k, float temperature, float top_p, uint64_t* d_rng_state, int32_t* d_token,
               int32_t* d_state, int32_t* d_tokens_out, const int32_t* d_forced, int n_forced);
+
+/* ---- training kernel path (BASELINE config 3), first piece: the AdamW parameter update CU_adamw_p (src/Device/CUDA/Optimizer.cu:393-442)
+ * as PIPE_Adamw::Update launches it (Optimizer.cu:630-646; TASKA_1p1, packedN.cuh:612-643: 512 threads x 8 bf16 per thread).
+ * params / grads bf16 [n] (grads are zeroed), gm / gv: first and second moments, mv_type KF_BF16 (floatMV = bf16) or KF_F32.
+ * g = grad_scale*grad; m = sAtB(g, m, beta1); v = sAtB(g*g, v, beta2); step = (m/beta1_correction) / (sqrtf(v/beta2_correction) + eps);
+ * p -= lr*weight_decay*p + lr*step.  bf16 stores use the reference's seeded stochastic rounding (CU_Float2T<bf16>, packedN.cuh:62-72;
+ * SquirrelNoise5 keyed on the launch geometry, which this entry reproduces), so results are bit-identical to the restatement in oracle/.
+ * n must be a multiple of 8.  A thread that meets a non-finite parameter or step stores nothing and writes KF_ADAMW_MV to *d_status
+ * (device int32, optional). */
+int kf_adamw(kf_ctx* ctx, kf_bf16* params, kf_bf16* grads, void* gm, void* gv, size_t n, int mv_type, float learning_rate, float beta1, float beta2,
+             float beta1_correction, float beta2_correction, float eps, float weight_decay, float grad_scale, uint32_t seed, int32_t* d_status);
 
 /* ---- token batch (prompt prefill).  The reference feeds the prompt one token at a time through the decode path (Fish::Chat,
  * GoPT.cpp:1139-1146); its batched forward exists only on the training side (SelfAttention::cuFlow / ROPE::cuFlow,

@@ -528,4 +528,15 @@ int kf_sample(kf_ctx* c, const kf_bf16* logits, int n, int top_k, float temperat
     RET(r);
 }
 
+int kf_adamw(kf_ctx* c, kf_bf16* params, kf_bf16* grads, void* gm, void* gv, size_t n, int mv_type, float learning_rate, float beta1, float beta2,
+             float beta1_correction, float beta2_correction, float eps, float weight_decay, float grad_scale, uint32_t seed, int32_t* d_status) {
+    CHKCTX(c);
+    if (!params || !grads || !gm || !gv) return fail(KF_INVALID_ARGS, "kf_adamw: null pointer");
+    if (mv_type != KF_BF16 && mv_type != KF_F32) return fail(KF_UNSUPPORTED_DATATYPE, "kf_adamw: moments must be bf16 or f32 (got %d)", mv_type);
+    if (n == 0 || n % 8) return fail(KF_INVALID_ARGS, "kf_adamw: n = %zu is not a positive multiple of 8 (TASKA_1p1 asserts N %% typ128::size == 0)", n);
+    if (!al16(params) || !al16(grads) || !al16(gm) || !al16(gv)) return fail(KF_BLAS_UNALIGN, "kf_adamw: tensors must be 16-byte aligned");
+    RET(kf::adamw_launch(c->stream, params, grads, gm, gv, n, mv_type == KF_BF16, learning_rate, beta1, beta2, beta1_correction, beta2_correction, eps,
+                         weight_decay, grad_scale, seed, d_status));
+}
+
 }  // extern "C"

@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(1024) sample_kernel(const uint16_t* __restrict
     __syncthreads();
     const float maxLogit = pv[0];
     float e = 0.f;
-    if (tid < k) e = kf_expf(__fdiv_rn(pv[tid] - maxLogit, temperature));
+    if (tid < k) e = kf_expf((pv[tid] - maxLogit) / temperature);
     __syncthreads();
     if (tid < k) pv[tid] = e;
     __syncthreads();
@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(1024) sample_kernel(const uint16_t* __restrict
         s_sum = sum;
     }
     __syncthreads();
-    if (tid < k) pv[tid] = __fdiv_rn(pv[tid], s_sum);
+    if (tid < k) pv[tid] = pv[tid] / s_sum;
     __syncthreads();
     if (tid == 0) {
         int nPick = k;
@@ -360,6 +360,104 @@ int quantize_launch(hipStream_t st, const kf_weight* w, const uint16_t* src, int
     uint16_t* step = zero + nGroup;
     hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)((nGroup + 3) / 4)), dim3(256), 0, st, src, (unsigned char*)const_cast<void*>(w->data), zero, step, nGroup,
                        w->lGroup, bits, mode, w->qMin, w->qMax, w->qBias);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+
+// ---------------------------------------------------------------- AdamW update (CU_adamw_p, Optimizer.cu:393-442; training kernel path)
+// Launched exactly as the reference's TASKA_1p1 (packedN.cuh:612-643): blocks of 512 threads, 8 bf16 parameters per thread (one 16-byte
+// load / store per tensor per thread), because the stochastic rounding of the stores (CU_Float2T<bf16>, packedN.cuh:62-72) draws ONE
+// 16-bit threshold per thread from SquirrelNoise5(threadIdx.x + PRIME * (blockIdx.x * blockDim.x), seed) (utils.cuh:296-326): with the
+// same geometry the update is bit-identical to the oracle's restatement.  HBM-bound: 16 B per parameter with bf16 moments
+// (p, g, m, v read and written), 24 B with fp32 moments.
+__device__ __forceinline__ unsigned int squirrel5(unsigned int pos, unsigned int seed) {
+    unsigned int b = pos;
+    b *= 0xd2a80a3fu;
+    b += seed;
+    b ^= (b >> 9);
+    b += 0xa884f197u;
+    b ^= (b >> 11);
+    b *= 0x6C736F4Bu;
+    b ^= (b >> 13);
+    b += 0xB79F3ABBu;
+    b ^= (b >> 15);
+    b *= 0x1b56c4f5u;
+    b ^= (b >> 17);
+    return b;
+}
+__device__ __forceinline__ uint16_t stochastic_bf16(float a, unsigned int threshold) {
+    unsigned int u = __float_as_uint(a);
+    u = ((u & 0xFFFFu) > threshold) ? (u | 0xFFFFu) : (u & ~0xFFFFu);
+    return f2bf(__uint_as_float(u));
+}
+template <bool MV_BF16>
+__global__ void __launch_bounds__(512) adamw_kernel(uint16_t* __restrict__ params, uint16_t* __restrict__ grads, void* __restrict__ gm_, void* __restrict__ gv_, size_t n,
+                                                    float lr, float beta1, float beta2, float b1c, float b2c, float eps, float wd, float grad_scale, unsigned int seed,
+                                                    int* __restrict__ status) {
+    const size_t idx = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (idx >= n) return;
+    const unsigned int thr = squirrel5(threadIdx.x + 198491317u * (blockIdx.x * blockDim.x), seed) & 0xFFFFu;
+    const u32x4 P = *reinterpret_cast<const u32x4*>(params + idx), G = *reinterpret_cast<const u32x4*>(grads + idx);
+    const uint32_t pw[4] = {P.x, P.y, P.z, P.w}, gw[4] = {G.x, G.y, G.z, G.w};
+    float m[8], v[8], p[8];
+    if (MV_BF16) {
+        const u32x4 M = *reinterpret_cast<const u32x4*>(reinterpret_cast<uint16_t*>(gm_) + idx), V = *reinterpret_cast<const u32x4*>(reinterpret_cast<uint16_t*>(gv_) + idx);
+        const uint32_t mw[4] = {M.x, M.y, M.z, M.w}, vw[4] = {V.x, V.y, V.z, V.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) m[2 * i] = bf_lo(mw[i]), m[2 * i + 1] = bf_hi(mw[i]), v[2 * i] = bf_lo(vw[i]), v[2 * i + 1] = bf_hi(vw[i]);
+    } else {
+        const float* fm = reinterpret_cast<const float*>(gm_) + idx;
+        const float* fv = reinterpret_cast<const float*>(gv_) + idx;
+#pragma unroll
+        for (int i = 0; i < 8; i++) m[i] = fm[i], v[i] = fv[i];
+    }
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const float g = grad_scale * ((i & 1) ? bf_hi(gw[i >> 1]) : bf_lo(gw[i >> 1]));
+        m[i] = fmaf(beta1, m[i], fmaf(-beta1, g, g));
+        const float g2 = g * g;
+        v[i] = fmaf(beta2, v[i], fmaf(-beta2, g2, g2));
+        const float mh = m[i] / b1c, vh = v[i] / b2c; /* `/` and sqrtf are correctly rounded under hipcc's defaults (checked against the host over
+                                                         2^24 random operands); __fsqrt_rn is NOT (1 ulp low on 0x397d20ce) */
+        const float step = mh / (sqrtf(vh) + eps);
+        const float old = (i & 1) ? bf_hi(pw[i >> 1]) : bf_lo(pw[i >> 1]);
+        bad = bad || !isfinite(old) || !isfinite(step);
+        p[i] = old - lr * wd * old - lr * step;
+    }
+    if (bad) { /* the reference thread returns before any store and raises KOIFISH_ADAMW_MV through its prober */
+        if (status) *status = KF_ADAMW_MV;
+        return;
+    }
+    uint32_t po[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) po[i] = (uint32_t)stochastic_bf16(p[2 * i], thr) | ((uint32_t)stochastic_bf16(p[2 * i + 1], thr) << 16);
+    *reinterpret_cast<u32x4*>(params + idx) = u32x4{po[0], po[1], po[2], po[3]};
+    *reinterpret_cast<u32x4*>(grads + idx) = u32x4{0, 0, 0, 0};
+    if (MV_BF16) {
+        uint32_t mo[4], vo[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            mo[i] = (uint32_t)stochastic_bf16(m[2 * i], thr) | ((uint32_t)stochastic_bf16(m[2 * i + 1], thr) << 16);
+            vo[i] = (uint32_t)stochastic_bf16(v[2 * i], thr) | ((uint32_t)stochastic_bf16(v[2 * i + 1], thr) << 16);
+        }
+        *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(gm_) + idx) = u32x4{mo[0], mo[1], mo[2], mo[3]};
+        *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(gv_) + idx) = u32x4{vo[0], vo[1], vo[2], vo[3]};
+    } else {
+        float* fm = reinterpret_cast<float*>(gm_) + idx;
+        float* fv = reinterpret_cast<float*>(gv_) + idx;
+#pragma unroll
+        for (int i = 0; i < 8; i++) fm[i] = m[i], fv[i] = v[i];
+    }
+}
+int adamw_launch(hipStream_t st, uint16_t* params, uint16_t* grads, void* gm, void* gv, size_t n, int mv_bf16, float lr, float beta1, float beta2, float b1c,
+                 float b2c, float eps, float wd, float grad_scale, unsigned int seed, int* status) {
+    if (n == 0 || n % 8) return KF_INVALID_ARGS;
+    const size_t nthread = n / 8;
+    const unsigned blocks = (unsigned)((nthread + 511) / 512);
+    if (mv_bf16)
+        hipLaunchKernelGGL(adamw_kernel<true>, dim3(blocks), dim3(512), 0, st, params, grads, gm, gv, n, lr, beta1, beta2, b1c, b2c, eps, wd, grad_scale, seed, status);
+    else
+        hipLaunchKernelGGL(adamw_kernel<false>, dim3(blocks), dim3(512), 0, st, params, grads, gm, gv, n, lr, beta1, beta2, b1c, b2c, eps, wd, grad_scale, seed, status);
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 

@@ -636,6 +636,85 @@ KFO_API int kfo_sample(const uint16_t* logits, int n, int top_k, float temperatu
     return qu;
 }
 
+/* AdamW parameter update, CU_adamw_p (src/Device/CUDA/Optimizer.cu:393-442) launched as TASKA_1p1 (kernel/packedN.cuh:612-643): blocks of
+ * 512 threads, 8 bf16 elements per thread.  Per element (all fp32): g = grad_scale * grad; m = sAtB(g, m, beta1) = fma(beta1, m, fma(-beta1, g, g))
+ * (kernel/utils.cuh:26-31); v likewise with g*g and beta2; m_hat = m / beta1_correction, v_hat = v / beta2_correction;
+ * step = m_hat / (sqrtf(v_hat) + eps); p = p - lr*wd*p - lr*step; grads are zeroed.  A thread that meets a non-finite parameter or step
+ * stores nothing (and reports KOIFISH_ADAMW_MV through the prober: status_out here).
+ * Stores go through PackedN(config, f256) -> CU_Float2T<bf16>(x, seed) (packedN.cuh:360-363, 62-72): SEEDED STOCHASTIC ROUNDING -- one
+ * 16-bit threshold per thread from SquirrelNoise5 keyed on (threadIdx.x, blockIdx.x * blockDim.x + blockIdx.y, seed) (utils.cuh:296-326),
+ * low 16 bits of the fp32 compared with it, then round-to-nearest of the all-ones / all-zeros padded value.  It is a pure function of the
+ * launch geometry and the seed, so it is restated exactly.  m and v are stored the same way when they are bf16 (floatMV = bf16), plainly
+ * when they are fp32. */
+static inline uint32_t kfo_squirrel5(uint32_t pos, uint32_t seed) {
+    uint32_t b = pos;
+    b *= 0xd2a80a3fu;
+    b += seed;
+    b ^= (b >> 9);
+    b += 0xa884f197u;
+    b ^= (b >> 11);
+    b *= 0x6C736F4Bu;
+    b ^= (b >> 13);
+    b += 0xB79F3ABBu;
+    b ^= (b >> 15);
+    b *= 0x1b56c4f5u;
+    b ^= (b >> 17);
+    return b;
+}
+KFO_API uint32_t kfo_noise2d(int x, int y, uint32_t seed) { return kfo_squirrel5((uint32_t)x + 198491317u * (uint32_t)y, seed); }
+static inline uint16_t kfo_stochastic_bf16(float a, uint32_t threshold) {
+    uint32_t u;
+    memcpy(&u, &a, 4);
+    u = ((u & 0xFFFFu) > threshold) ? (u | 0xFFFFu) : (u & ~0xFFFFu);
+    float f;
+    memcpy(&f, &u, 4);
+    return kfo_f32_to_bf16(f);
+}
+KFO_API int kfo_adamw(uint16_t* params, uint16_t* grads, void* gm, void* gv, size_t n, int mv_bf16, float lr, float beta1, float beta2, float b1c, float b2c,
+                      float eps, float wd, float grad_scale, uint32_t seed) {
+    if (n % 8) return -1;
+    int status = 0;
+    const size_t nthread = n / 8;
+    for (size_t t = 0; t < nthread; t++) {
+        const int tx = (int)(t % 512), bx = (int)(t / 512);
+        const uint32_t thr = kfo_noise2d(tx, bx * 512, seed) & 0xFFFFu;
+        float pm[8], pv[8], pp[8];
+        int bad = 0;
+        for (int i = 0; i < 8 && !bad; i++) {
+            const size_t idx = t * 8 + i;
+            const float g = grad_scale * kfo_bf16_to_f32(grads[idx]);
+            float m = mv_bf16 ? kfo_bf16_to_f32(((uint16_t*)gm)[idx]) : ((float*)gm)[idx];
+            float v = mv_bf16 ? kfo_bf16_to_f32(((uint16_t*)gv)[idx]) : ((float*)gv)[idx];
+            m = fmaf(beta1, m, fmaf(-beta1, g, g));
+            const float g2 = g * g;
+            v = fmaf(beta2, v, fmaf(-beta2, g2, g2));
+            pm[i] = m, pv[i] = v;
+            const float mh = m / b1c, vh = v / b2c;
+            const float step = mh / (sqrtf(vh) + eps);
+            const float old = kfo_bf16_to_f32(params[idx]);
+            if (!isfinite(old) || !isfinite(step)) {
+                bad = 1;
+                break;
+            }
+            pp[i] = old - lr * wd * old - lr * step;
+        }
+        if (bad) {
+            status = -1;
+            continue;
+        }
+        for (int i = 0; i < 8; i++) {
+            const size_t idx = t * 8 + i;
+            if (mv_bf16)
+                ((uint16_t*)gm)[idx] = kfo_stochastic_bf16(pm[i], thr), ((uint16_t*)gv)[idx] = kfo_stochastic_bf16(pv[i], thr);
+            else
+                ((float*)gm)[idx] = pm[i], ((float*)gv)[idx] = pv[i];
+            params[idx] = kfo_stochastic_bf16(pp[i], thr);
+            grads[idx] = 0;
+        }
+    }
+    return status;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * 6. Decode attention (GQA), full causal over t = 0..pos.
  *    mode 0 "REF":   the reference's rounding chain -- attention_qk_kernel / CU_softmax_multihead /

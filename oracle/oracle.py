@@ -300,6 +300,17 @@ def sample(logits, top_k, temperature, top_p, rng_state, want_detail=False):
     return tok
 
 
+def adamw(params, grads, m, v, lr, beta1, beta2, b1c, b2c, eps, wd, grad_scale, seed):
+    """CU_adamw_p in place on uint16 (bf16) params / grads and bf16 (uint16) or float32 m / v arrays. Returns 0, or -1 when a thread met a
+    non-finite value (KOIFISH_ADAMW_MV)."""
+    for a in (params, grads):
+        assert a.dtype == np.uint16 and a.flags.c_contiguous
+    assert m.dtype == v.dtype and m.dtype in (np.uint16, np.float32)
+    fn = lib().kfo_adamw
+    fn.argtypes = [C.c_void_p] * 4 + [C.c_size_t, C.c_int] + [C.c_float] * 8 + [C.c_uint32]
+    return int(fn(_p(params), _p(grads), _p(m), _p(v), params.size, int(m.dtype == np.uint16), lr, beta1, beta2, b1c, b2c, eps, wd, grad_scale, seed))
+
+
 def attn_decode(q, kc, vc, pos, n_head, n_kv, hd, kv_stride=None, mode=ATTN_FUSED):
     q = np.ascontiguousarray(q, dtype=np.uint16)
     kc = np.ascontiguousarray(kc, dtype=np.uint16)
