@@ -182,6 +182,14 @@ int kf_embed_state(kf_ctx* ctx, const kf_weight* w, const int32_t* d_state, cons
 int kf_sample(kf_ctx* ctx, const kf_bf16* logits, int n, int top_k, float temperature, float top_p, uint64_t* d_rng_state, int32_t* d_token,
               int32_t* d_state, int32_t* d_tokens_out, const int32_t* d_forced, int n_forced);
 
+/* ---- GPT-2 family forward pieces (BASELINE config 3) */
+/* LayerNorm forward with affine weight and bias (LayerNormal::cuFlow for the GPT-2 family -> CU_lm_forward, layernorm.cuh:226-300):
+ * y = bf16((x - mean) * rstd * w + b), rstd = 1/sqrtf(var + eps); bias may be NULL; mean / rstd [rows] fp32 are optional outputs. */
+int kf_layernorm(kf_ctx* ctx, const kf_bf16* x, const kf_bf16* w, const kf_bf16* bias_or_null, kf_bf16* y, int rows, int dim, float eps, float* mean_or_null,
+                 float* rstd_or_null);
+/* GELU, tanh form (Relu::Forw GELU -> gelu_forward_kernel2, Activation.cu:23-40) */
+int kf_gelu(kf_ctx* ctx, const kf_bf16* x, kf_bf16* y, size_t n);
+
 /* ---- training kernel path (BASELINE config 3), first piece: the AdamW parameter update CU_adamw_p (src/Device/CUDA/Optimizer.cu:393-442)
  * as PIPE_Adamw::Update launches it (Optimizer.cu:630-646; TASKA_1p1, packedN.cuh:612-643: 512 threads x 8 bf16 per thread).
  * params / grads bf16 [n] (grads are zeroed), gm / gv: first and second moments, mv_type KF_BF16 (floatMV = bf16) or KF_F32.

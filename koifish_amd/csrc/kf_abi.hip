@@ -528,6 +528,16 @@ int kf_sample(kf_ctx* c, const kf_bf16* logits, int n, int top_k, float temperat
     RET(r);
 }
 
+int kf_layernorm(kf_ctx* c, const kf_bf16* x, const kf_bf16* w, const kf_bf16* bias, kf_bf16* y, int rows, int dim, float eps, float* mean, float* rstd) {
+    CHKCTX(c);
+    if (!x || !w || !y || rows < 1 || dim < 1) return fail(KF_INVALID_ARGS, "kf_layernorm: bad args");
+    RET(kf::layernorm_launch(c->stream, x, w, bias, y, rows, dim, eps, mean, rstd));
+}
+int kf_gelu(kf_ctx* c, const kf_bf16* x, kf_bf16* y, size_t n) {
+    CHKCTX(c);
+    if (!x || !y || n == 0) return fail(KF_INVALID_ARGS, "kf_gelu: bad args");
+    RET(kf::gelu_launch(c->stream, x, y, n));
+}
 int kf_adamw(kf_ctx* c, kf_bf16* params, kf_bf16* grads, void* gm, void* gv, size_t n, int mv_type, float learning_rate, float beta1, float beta2,
              float beta1_correction, float beta2_correction, float eps, float weight_decay, float grad_scale, uint32_t seed, int32_t* d_status) {
     CHKCTX(c);

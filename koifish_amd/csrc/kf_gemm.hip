@@ -572,7 +572,10 @@ static int gm_weight(const kf_weight* w, GmWeight& o) {
     o.fmt = gm_fmt_of(w->type);
     if (o.fmt < 0 || w->qzeros || w->qscales) return 1;
     o.M = w->ne0, o.K = w->ne1;
-    if (o.K % GM_KT != 0 || o.K < GM_KT || o.M < 1 || (reinterpret_cast<uintptr_t>(w->data) & 15) != 0) return 1;
+    // K a multiple of 128 for every kernel; a multiple of 64 is enough for the direct kernel on the formats whose 64-element unit is made of
+    // whole blocks (bf16, f8, 4-bit) -- GPT-2's n_embd = 1600
+    if (o.K % 64 != 0 || o.K < GM_KT || o.M < 1 || (reinterpret_cast<uintptr_t>(w->data) & 15) != 0) return 1;
+    if (o.K % GM_KT != 0 && o.fmt > FMT_Q4) return 1;
     if ((unsigned long long)o.M * (unsigned long long)(o.K / gm_epb[o.fmt]) >= (1ull << 32)) return 1;
     o.w = reinterpret_cast<const unsigned char*>(w->data);
     o.zero = o.step = nullptr, o.qBias = (float)w->qBias, o.gshift = 0;
@@ -661,7 +664,7 @@ int gemm_launch(hipStream_t st, const kf_weight* w, const uint16_t* x, long long
     }
     int KS = ((long)((M + 127) / 128) * ttiles < 512) ? 2 : 1;
     dim3 grid;
-    if ((long)((M + 31) / 32) * ((n + 31) / 32) <= direct_max) {
+    if ((long)((M + 31) / 32) * ((n + 31) / 32) <= direct_max || g.K % GM_KT != 0) {
         KS = 0;
         grid = dim3((M + 31) / 32, (n + 31) / 32);
     } else {

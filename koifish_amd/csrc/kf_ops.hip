@@ -20,6 +20,67 @@ int rmsnorm_launch(hipStream_t st, const uint16_t* x, const uint16_t* w, uint16_
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 
+// ---------------------------------------------------------------- LayerNorm forward (CU_lm_forward, layernorm.cuh:226-300; GPT-2 family) and GELU
+// One workgroup per row; the two sums in fp64 (order-independent, like RMSNorm), s = 1/sqrtf(v + eps) with IEEE ops, out = bf16(s*(x-m)*w + b).
+__device__ __forceinline__ double block_sum_f64(double acc, double* red) {
+    acc = wave_sum_f64(acc);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    double tot = 0.0;
+    for (int w = 0; w < nw; w++) tot += red[w];
+    __syncthreads();
+    return tot;
+}
+__global__ void __launch_bounds__(256) layernorm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ b,
+                                                        uint16_t* __restrict__ y, int dim, float eps, float* mean, float* rstd) {
+    __shared__ double red[16];
+    const uint16_t* xr = x + (size_t)blockIdx.x * dim;
+    uint16_t* yr = y + (size_t)blockIdx.x * dim;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < dim; i += blockDim.x) acc += (double)bf2f(xr[i]);
+    const float m = (float)block_sum_f64(acc, red) / (float)dim;
+    acc = 0.0;
+    for (int i = threadIdx.x; i < dim; i += blockDim.x) {
+        const float d = bf2f(xr[i]) - m;
+        acc = fma((double)d, (double)d, acc);
+    }
+    const float v = (float)block_sum_f64(acc, red) / (float)dim;
+    const float s = 1.0f / sqrtf(v + eps);
+    for (int i = threadIdx.x; i < dim; i += blockDim.x) {
+        const float n = s * (bf2f(xr[i]) - m);
+        const float o = n * bf2f(w[i]) + (b ? bf2f(b[i]) : 0.0f);
+        yr[i] = f2bf(o);
+    }
+    if (threadIdx.x == 0) {
+        if (mean) mean[blockIdx.x] = m;
+        if (rstd) rstd[blockIdx.x] = s;
+    }
+}
+int layernorm_launch(hipStream_t st, const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* y, int rows, int dim, float eps, float* mean, float* rstd) {
+    if (rows <= 0 || dim <= 0) return KF_INVALID_ARGS;
+    hipLaunchKernelGGL(layernorm_kernel, dim3(rows), dim3(256), 0, st, x, w, b, y, dim, eps, mean, rstd);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+// GELU (tanh form), gelu_forward_kernel2 (Activation.cu:23-40); tanh from the fixed exp recipe, as oracle/kf_oracle.c kfo_gelu
+__device__ __forceinline__ float kf_tanhf(float z) {
+    if (z > 10.0f) return 1.0f;
+    if (z < -10.0f) return -1.0f;
+    const float e = kf_expf(2.0f * z);
+    return (e - 1.0f) / (e + 1.0f);
+}
+__global__ void gelu_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float xi = bf2f(x[i]);
+    const float cube = 0.044715f * xi * xi * xi;
+    y[i] = f2bf(0.5f * xi * (1.0f + kf_tanhf(0.797884583473205566406250f * (xi + cube))));
+}
+int gelu_launch(hipStream_t st, const uint16_t* x, uint16_t* y, size_t n) {
+    hipLaunchKernelGGL(gelu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+
 // ---------------------------------------------------------------- SwiGLU / add
 __global__ void swiglu_kernel(const uint16_t* __restrict__ gate, const uint16_t* __restrict__ up, uint16_t* __restrict__ out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

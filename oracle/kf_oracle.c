@@ -366,18 +366,24 @@ static void weight_row_f32(const kfo_weight* w, long r, float* out) {
         for (int c = 0; c < K; c++)
             out[c] = awq_weight((const uint32_t*)w->data, (const uint32_t*)w->zero, w->step, w->ne0, c, (int)r);
     } else {
+        /* groups of lGroup CONSECUTIVE elements of the flattened tensor (GeQuant.cpp:428-533): a row need not start on a group (GPT-2's
+         * n_embd = 1600 gives 12.5 groups per row), so walk the 16-byte blocks that overlap [r*K, (r+1)*K) */
         const int bits = bits_of(w->type), lG = w->lGroup, nQuant = 128 / bits, nLevel = 1 << bits;
-        size_t e0 = (size_t)r * K; /* flattened element offset; K % lGroup == 0 so rows start on a group */
+        const size_t e0 = (size_t)r * K, e1 = e0 + (size_t)K;
         int32_t qq[128];
         float lut[16];
-        for (int c = 0; c < K; c += lG) {
-            size_t g = (e0 + c) / lG;
-            float z = kfo_bf16_to_f32(w->zero[g]), s = kfo_bf16_to_f32(w->step[g]);
-            for (int v = 0; v < nLevel; v++) lut[v] = dequant_one(s, z, v - w->qBias);
-            const uint8_t* q128 = (const uint8_t*)w->data + g * lG * bits / 8;
-            for (int k = 0; k < lG / nQuant; k++) {
-                unpack_block(bits, q128 + 16 * k, qq);
-                for (int i = 0; i < nQuant; i++) out[c + k * nQuant + i] = lut[qq[i]];
+        size_t g_cur = (size_t)-1;
+        for (size_t bl = e0 / nQuant; bl * nQuant < e1; bl++) {
+            const size_t eb = bl * nQuant, g = eb / lG; /* lGroup is a multiple of the block length: a block lies in one group */
+            if (g != g_cur) {
+                const float z = kfo_bf16_to_f32(w->zero[g]), s = kfo_bf16_to_f32(w->step[g]);
+                for (int v = 0; v < nLevel; v++) lut[v] = dequant_one(s, z, v - w->qBias);
+                g_cur = g;
+            }
+            unpack_block(bits, (const uint8_t*)w->data + bl * 16, qq);
+            for (int i = 0; i < nQuant; i++) {
+                const size_t e = eb + i;
+                if (e >= e0 && e < e1) out[e - e0] = lut[qq[i]];
             }
         }
     }
@@ -634,6 +640,50 @@ KFO_API int kfo_sample(const uint16_t* logits, int n, int top_k, float temperatu
     free(picks);
     free(p);
     return qu;
+}
+
+/* LayerNorm forward, CU_lm_forward (src/Device/CUDA/kernel/layernorm.cuh:226-300; GPT-2 family): m = sum(x)/C, v = sum((x-m)^2)/C,
+ * s = rsqrtf(v + eps), out = bf16(s*(x-m)*w + b).  Restated with the sums in fp64 (the reference adds in warp order; fp64 makes the result
+ * independent of any order, as for RMSNorm), s = 1/sqrtf(v + eps) with IEEE ops in place of the approximate rsqrtf, and the scale-and-shift
+ * as a multiply then an add (no contraction).  mean / rstd (fp32 per row) are the values the backward pass caches; either may be NULL. */
+KFO_API void kfo_layernorm(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* y, int rows, int C, float eps, float* mean, float* rstd) {
+    for (int r = 0; r < rows; r++) {
+        const uint16_t* xr = x + (size_t)r * C;
+        double sum = 0.0;
+        for (int c = 0; c < C; c++) sum += (double)kfo_bf16_to_f32(xr[c]);
+        const float m = (float)sum / (float)C;
+        double sq = 0.0;
+        for (int c = 0; c < C; c++) {
+            const float d = kfo_bf16_to_f32(xr[c]) - m;
+            sq += (double)d * (double)d;
+        }
+        const float v = (float)sq / (float)C;
+        const float s = 1.0f / sqrtf(v + eps);
+        for (int c = 0; c < C; c++) {
+            const float n = s * (kfo_bf16_to_f32(xr[c]) - m);
+            const float o = n * kfo_bf16_to_f32(w[c]) + (b ? kfo_bf16_to_f32(b[c]) : 0.0f);
+            y[(size_t)r * C + c] = kfo_f32_to_bf16(o);
+        }
+        if (mean) mean[r] = m;
+        if (rstd) rstd[r] = s;
+    }
+}
+/* GELU, tanh form, gelu_forward_kernel2 (src/Device/CUDA/Activation.cu:23-40): 0.5*x*(1 + tanhf(sqrtf(2/pi)*(x + 0.044715*x*x*x))), bf16 store.
+ * tanhf: the reference calls the CUDA libm; here tanh(z) = (e - 1)/(e + 1), e = kfo_expf(2z), saturated to +-1 beyond |z| = 10 -- one fixed
+ * recipe shared with the HIP kernel (absolute error < 2e-7, far below the bf16 store). */
+static inline float kfo_tanhf(float z) {
+    if (z > 10.0f) return 1.0f;
+    if (z < -10.0f) return -1.0f;
+    const float e = kfo_expf(2.0f * z);
+    return (e - 1.0f) / (e + 1.0f);
+}
+KFO_API void kfo_gelu(const uint16_t* x, uint16_t* y, size_t n) {
+    const float c = 0.797884583473205566406250f; /* sqrtf(2.0f / M_PI) */
+    for (size_t i = 0; i < n; i++) {
+        const float xi = kfo_bf16_to_f32(x[i]);
+        const float cube = 0.044715f * xi * xi * xi;
+        y[i] = kfo_f32_to_bf16(0.5f * xi * (1.0f + kfo_tanhf(c * (xi + cube))));
+    }
 }
 
 /* AdamW parameter update, CU_adamw_p (src/Device/CUDA/Optimizer.cu:393-442) launched as TASKA_1p1 (kernel/packedN.cuh:612-643): blocks of

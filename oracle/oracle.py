@@ -300,6 +300,27 @@ def sample(logits, top_k, temperature, top_p, rng_state, want_detail=False):
     return tok
 
 
+def layernorm(x, w, b, eps=1e-5, want_stats=False):
+    x = np.ascontiguousarray(x, dtype=np.uint16)
+    rows, dim = (1, x.size) if x.ndim == 1 else x.shape
+    y = np.zeros_like(x)
+    mean, rstd = np.zeros(rows, np.float32), np.zeros(rows, np.float32)
+    fn = lib().kfo_layernorm
+    fn.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    fn(_p(x), _p(np.ascontiguousarray(w, dtype=np.uint16)), _p(np.ascontiguousarray(b, dtype=np.uint16)) if b is not None else None, _p(y), rows, dim, eps,
+       _p(mean), _p(rstd))
+    return (y, mean, rstd) if want_stats else y
+
+
+def gelu(x):
+    x = np.ascontiguousarray(x, dtype=np.uint16)
+    y = np.zeros_like(x)
+    fn = lib().kfo_gelu
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    fn(_p(x), _p(y), x.size)
+    return y
+
+
 def adamw(params, grads, m, v, lr, beta1, beta2, b1c, b2c, eps, wd, grad_scale, seed):
     """CU_adamw_p in place on uint16 (bf16) params / grads and bf16 (uint16) or float32 m / v arrays. Returns 0, or -1 when a thread met a
     non-finite value (KOIFISH_ADAMW_MV)."""

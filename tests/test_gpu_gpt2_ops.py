@@ -1,0 +1,117 @@
+"""GPT-2 family forward pieces (BASELINE config 3): LayerNorm, GELU, the K = 1600 GEMM, and one transformer block assembled from the ABI
+(LayerNorm -> fused QKV GEMM + bias -> causal MHA -> projection + bias + residual -> LayerNorm -> FC + bias -> GELU -> projection + bias +
+residual) against the same block assembled from the oracle's operators."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from koifish_amd import lib as L
+from oracle import oracle as O
+from tests.conftest import bf16_t, close_bf16, u16
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("rows,dim", [(1, 768), (5, 1600), (64, 4096), (3, 50)])
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_layernorm_bit_exact(ctx, rows, dim, with_bias):
+    rng = np.random.default_rng(rows * dim)
+    x = O.f32_to_bf16(rng.normal(0.3, 2.0, size=(rows, dim)).astype(np.float32))
+    w = O.f32_to_bf16((1 + rng.normal(0, 0.1, size=dim)).astype(np.float32))
+    b = O.f32_to_bf16(rng.normal(0, 0.1, size=dim).astype(np.float32)) if with_bias else None
+    y = torch.zeros(rows, dim, dtype=torch.bfloat16, device=ctx.device)
+    mean = torch.zeros(rows, dtype=torch.float32, device=ctx.device)
+    rstd = torch.zeros(rows, dtype=torch.float32, device=ctx.device)
+    xd, wd = bf16_t(x, ctx.device), bf16_t(w, ctx.device)
+    bd = bf16_t(b, ctx.device) if with_bias else None
+    assert ctx.hip.kf_layernorm(ctx.h, xd.data_ptr(), wd.data_ptr(), bd.data_ptr() if with_bias else None, y.data_ptr(), rows, dim, 1e-5, mean.data_ptr(),
+                                rstd.data_ptr()) == 0
+    ctx.sync()
+    ry, rm, rs = O.layernorm(x, w, b, 1e-5, want_stats=True)
+    assert np.array_equal(u16(y), ry)
+    assert np.array_equal(mean.cpu().numpy(), rm) and np.array_equal(rstd.cpu().numpy(), rs)
+
+
+def test_gelu_bit_exact(ctx):
+    rng = np.random.default_rng(5)
+    x = O.f32_to_bf16(np.concatenate([rng.normal(0, 3, 70000), [0.0, -0.0, 12.0, -12.0, 1e-30, 40.0, -40.0]]).astype(np.float32))
+    y = torch.zeros(x.size, dtype=torch.bfloat16, device=ctx.device)
+    assert ctx.hip.kf_gelu(ctx.h, bf16_t(x, ctx.device).data_ptr(), y.data_ptr(), x.size) == 0
+    ctx.sync()
+    assert np.array_equal(u16(y), O.gelu(x))
+    xf = O.bf16_to_f32(x).astype(np.float64)
+    exact = 0.5 * xf * (1 + np.tanh(np.sqrt(2 / np.pi) * (xf + 0.044715 * xf ** 3)))
+    assert np.abs(O.bf16_to_f32(u16(y)) - exact).max() <= 2.0 ** -8 * np.abs(exact).max()
+
+
+def _linear(ctx, dw, x, n, m, bias=None, residual=None):
+    y = torch.zeros(n, m, dtype=torch.bfloat16, device=ctx.device)
+    d = dw.desc()
+    rc = ctx.hip.kf_linear(ctx.h, C.byref(d), x.data_ptr(), y.data_ptr(), bias.data_ptr() if bias is not None else None, n, 1.0, 0.0,
+                           1 if residual is not None else 0, residual.data_ptr() if residual is not None else None)
+    assert rc == 0, ctx.hip.kf_last_error()
+    return y
+
+
+@pytest.mark.parametrize("t", [L.Q4, L.F8E5M2, L.BF16])
+def test_gemm_k1600(ctx, t):
+    """n_embd = 1600: K is a multiple of 64 but not of 128 (4-bit groups straddle rows: 12.5 groups per row)"""
+    m, k, n = 4800, 1600, 96
+    rng = np.random.default_rng(t)
+    w = O.f32_to_bf16(rng.normal(0, 0.02, size=(m, k)).astype(np.float32))
+    x = O.f32_to_bf16(rng.normal(0, 1.0, size=(n, k)).astype(np.float32))
+    ow = O.quantize(w, m, k, t)
+    dw = ctx.upload_blob(t, m, k, ow.blob())
+    y = u16(_linear(ctx, dw, bf16_t(x, ctx.device), n, m))
+    exact = O.bf16_to_f32(x).astype(np.float64) @ O.bf16_to_f32(O.dequant(ow)).astype(np.float64).T
+    assert np.abs(O.bf16_to_f32(y) - exact).max() <= 2.0 ** -8 * np.abs(exact).max() + 1e-6
+    for tt in (0, n - 1):
+        assert close_bf16(y[tt], O.linear(ow, x[tt])).all()
+
+
+def test_gpt2_block_forward(ctx):
+    """one GPT-2 block, hybrid storage as in cases/gpt2/1558M_F8_B80: attention matrices f8e5m2, MLP matrices RTN 4-bit; T = 96 tokens"""
+    C_, H, T = 256, 4, 96
+    hd = C_ // H
+    rng = np.random.default_rng(2)
+    mk = lambda *s, std=0.05: O.f32_to_bf16(rng.normal(0, std, size=s).astype(np.float32))
+    x = mk(T, C_, std=1.0)
+    ln1w, ln1b, ln2w, ln2b = (O.f32_to_bf16((1 + rng.normal(0, 0.1, C_)).astype(np.float32)), mk(C_), O.f32_to_bf16((1 + rng.normal(0, 0.1, C_)).astype(np.float32)), mk(C_))
+    W = {"qkv": (mk(3 * C_, C_), mk(3 * C_), L.F8E5M2), "proj": (mk(C_, C_), mk(C_), L.F8E5M2), "fc": (mk(4 * C_, C_), mk(4 * C_), L.Q4), "proj2": (mk(C_, 4 * C_), mk(C_), L.Q4)}
+    ow = {k: O.quantize(v[0], v[0].shape[0], v[0].shape[1], v[2]) for k, v in W.items()}
+    dw = {k: ctx.upload_blob(W[k][2], W[k][0].shape[0], W[k][0].shape[1], ow[k].blob()) for k in W}
+    db = {k: bf16_t(W[k][1], ctx.device) for k in W}
+    dev = ctx.device
+    # ---- device
+    xd = bf16_t(x, dev)
+    h1 = torch.zeros(T, C_, dtype=torch.bfloat16, device=dev)
+    assert ctx.hip.kf_layernorm(ctx.h, xd.data_ptr(), bf16_t(ln1w, dev).data_ptr(), bf16_t(ln1b, dev).data_ptr(), h1.data_ptr(), T, C_, 1e-5, None, None) == 0
+    qkv = _linear(ctx, dw["qkv"], h1, T, 3 * C_, bias=db["qkv"])
+    att = torch.zeros(T, C_, dtype=torch.bfloat16, device=dev)
+    q, k, v = qkv[:, :C_], qkv[:, C_:2 * C_], qkv[:, 2 * C_:]
+    # q rows are 3C apart inside the fused buffer; the attention entry takes one stride for q and out, so q goes through a compact copy
+    qc = q.contiguous()
+    assert ctx.hip.kf_attn_prefill(ctx.h, qc.data_ptr(), k.data_ptr(), v.data_ptr(), att.data_ptr(), 0, T, C_, H, H, hd, 3 * C_) == 0, ctx.hip.kf_last_error()
+    x2 = _linear(ctx, dw["proj"], att, T, C_, bias=db["proj"], residual=xd)
+    h2 = torch.zeros(T, C_, dtype=torch.bfloat16, device=dev)
+    assert ctx.hip.kf_layernorm(ctx.h, x2.data_ptr(), bf16_t(ln2w, dev).data_ptr(), bf16_t(ln2b, dev).data_ptr(), h2.data_ptr(), T, C_, 1e-5, None, None) == 0
+    f = _linear(ctx, dw["fc"], h2, T, 4 * C_, bias=db["fc"])
+    g = torch.zeros_like(f)
+    assert ctx.hip.kf_gelu(ctx.h, f.data_ptr(), g.data_ptr(), f.numel()) == 0
+    out = u16(_linear(ctx, dw["proj2"], g, T, C_, bias=db["proj2"], residual=x2))
+    ctx.sync()
+    # ---- oracle, token by token
+    r1 = O.layernorm(x, ln1w, ln1b, 1e-5)
+    rqkv = np.stack([O.linear(ow["qkv"], r1[t], bias=W["qkv"][1]) for t in range(T)])
+    rq, rk, rv = rqkv[:, :C_], rqkv[:, C_:2 * C_], rqkv[:, 2 * C_:]
+    ratt = np.stack([O.attn_decode(rq[t], rk[:t + 1], rv[:t + 1], t, H, H, hd, mode=O.ATTN_FUSED) for t in range(T)])
+    rx2 = np.stack([O.add(x[t], O.linear(ow["proj"], ratt[t], bias=W["proj"][1])) for t in range(T)])
+    r2 = O.layernorm(rx2, ln2w, ln2b, 1e-5)
+    rf = np.stack([O.linear(ow["fc"], r2[t], bias=W["fc"][1]) for t in range(T)])
+    rg = O.gelu(rf)
+    rout = np.stack([O.add(rx2[t], O.linear(ow["proj2"], rg[t], bias=W["proj2"][1])) for t in range(T)])
+    a, b = O.bf16_to_f32(out), O.bf16_to_f32(rout)
+    assert np.abs(a - b).max() <= 2.0 ** -6 * np.abs(b).max()
+    assert np.sqrt(((a - b) ** 2).mean()) <= 2.0 ** -9 * np.abs(b).max()
