@@ -121,10 +121,15 @@ struct WTile<FMT_Q4, KS> {
     __device__ __forceinline__ void load(const GemmArgs& a, int row, int it, int h, int ks) {
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-            const uint32_t bidx = (uint32_t)row * (uint32_t)a.nBlk + (uint32_t)(it * 4 + 2 * (ks * NP + p) + h);
+            // a row's last staged tile may be half empty (K a multiple of 64 only): blocks past the row end are read from the last valid
+            // block (no branch around the load) and given step = zero = 0, which unpacks to weights of 0
+            int bi = it * 4 + 2 * (ks * NP + p) + h;
+            const bool in_row = bi < a.nBlk;
+            if (!in_row) bi = a.nBlk - 1;
+            const uint32_t bidx = (uint32_t)row * (uint32_t)a.nBlk + (uint32_t)bi;
             b[p] = ld_nt(reinterpret_cast<const u32x4*>(a.w) + bidx);
             const uint32_t gi = bidx >> a.gshift;
-            st[p] = bf2f(a.step[gi]), ze[p] = bf2f(a.zero[gi]);
+            st[p] = in_row ? bf2f(a.step[gi]) : 0.f, ze[p] = in_row ? bf2f(a.zero[gi]) : 0.f;
         }
     }
     static __device__ __forceinline__ int koff(int sl, int h, int ks) { return (2 * (ks * NP + (sl >> 2)) + h) * 32 + 8 * (sl & 3); }
@@ -142,9 +147,15 @@ struct WTile<FMT_BF16, KS> {
     __device__ __forceinline__ void load(const GemmArgs& a, int row, int it, int h, int ks) {
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-            const u32x4* src = reinterpret_cast<const u32x4*>(a.w + ((size_t)row * a.K + (size_t)it * GM_KT + (size_t)(2 * (ks * NP + p) + h) * 32) * 2);
+            int e = it * GM_KT + (2 * (ks * NP + p) + h) * 32; /* first of this lane's 32 elements; past the row end: zeros (address clamped) */
+            const uint32_t keep = e < a.K ? 0xffffffffu : 0u;
+            if (e >= a.K) e = a.K - 32;
+            const u32x4* src = reinterpret_cast<const u32x4*>(a.w + ((size_t)row * a.K + (size_t)e) * 2);
 #pragma unroll
-            for (int c = 0; c < 4; c++) b[p][c] = ld_nt(src + c);
+            for (int c = 0; c < 4; c++) {
+                const u32x4 v = ld_nt(src + c);
+                b[p][c] = u32x4{v.x & keep, v.y & keep, v.z & keep, v.w & keep};
+            }
         }
     }
     static __device__ __forceinline__ int koff(int sl, int h, int ks) { return (2 * (ks * NP + (sl >> 2)) + h) * 32 + 8 * (sl & 3); }
@@ -157,8 +168,15 @@ struct WTile<FMT_F8, KS> {
     __device__ __forceinline__ void load(const GemmArgs& a, int row, int it, int h, int ks) {
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-            const u32x4* src = reinterpret_cast<const u32x4*>(a.w + (size_t)row * a.K + (size_t)it * GM_KT + (size_t)(2 * (ks * NP + p) + h) * 32);
-            b[p][0] = ld_nt(src), b[p][1] = ld_nt(src + 1);
+            int e = it * GM_KT + (2 * (ks * NP + p) + h) * 32;
+            const uint32_t keep = e < a.K ? 0xffffffffu : 0u;
+            if (e >= a.K) e = a.K - 32;
+            const u32x4* src = reinterpret_cast<const u32x4*>(a.w + (size_t)row * a.K + (size_t)e);
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const u32x4 v = ld_nt(src + c);
+                b[p][c] = u32x4{v.x & keep, v.y & keep, v.z & keep, v.w & keep};
+            }
         }
     }
     static __device__ __forceinline__ int koff(int sl, int h, int ks) { return (2 * (ks * NP + (sl >> 2)) + h) * 32 + 8 * (sl & 3); }
@@ -235,7 +253,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
     int row = row_base + r;
     if (row >= a.M) row = a.M - 1; /* rows past the end recompute the last row; their results are not stored */
     const int tok0 = blockIdx.y * GM_TOK;
-    const int nit = a.K / GM_KT;
+    const int nit = (a.K + GM_KT - 1) / GM_KT;
 
     f32x16 acc[4];
 #pragma unroll
@@ -251,7 +269,9 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
         for (int p = 0; p < 8; p++) {
             int tok = tok0 + p * 16 + trow;
             if (tok >= a.n) tok = a.n - 1; /* rows past the batch repeat the last token: loaded unconditionally, never stored */
-            xr[p] = *reinterpret_cast<const u32x4*>(a.x + (size_t)tok * a.ldx + (size_t)it * GM_KT + seg * 8);
+            int col = it * GM_KT + seg * 8;
+            if (col >= a.K) col = a.K - 8; /* half-empty last tile: the weights there are 0, any finite x will do */
+            xr[p] = *reinterpret_cast<const u32x4*>(a.x + (size_t)tok * a.ldx + col);
         }
     };
     auto xstore = [&](int buf) {
@@ -270,7 +290,9 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
         for (int p = 0; p < 8; p++) {
             int tok = tok0 + p * 16 + trow;
             if (tok >= a.n) tok = a.n - 1;
-            xr2[p] = *reinterpret_cast<const u32x4*>(a.x + (size_t)tok * a.ldx + (size_t)it * GM_KT + seg * 8);
+            int col = it * GM_KT + seg * 8;
+            if (col >= a.K) col = a.K - 8;
+            xr2[p] = *reinterpret_cast<const u32x4*>(a.x + (size_t)tok * a.ldx + col);
         }
     };
     wc.load(a, row, 0, h, ks);
@@ -664,7 +686,7 @@ int gemm_launch(hipStream_t st, const kf_weight* w, const uint16_t* x, long long
     }
     int KS = ((long)((M + 127) / 128) * ttiles < 512) ? 2 : 1;
     dim3 grid;
-    if ((long)((M + 31) / 32) * ((n + 31) / 32) <= direct_max || g.K % GM_KT != 0) {
+    if ((long)((M + 31) / 32) * ((n + 31) / 32) <= direct_max) {
         KS = 0;
         grid = dim3((M + 31) / 32, (n + 31) / 32);
     } else {

@@ -9,7 +9,7 @@ shapes = [(2048, 1024), (1024, 1024), (1024, 2048), (3072, 1024), (1024, 3072), 
 ns = [int(a) for a in sys.argv[1:]] or [32, 64, 128, 256, 1024]
 for (m, k) in shapes:
     w = torch.randn(m, k, device=ctx.device).mul_(0.02).to(torch.bfloat16)
-    dw = ctx.quantize(w, L.Q4)
+    dw = ctx.quantize(w, {"q4": L.Q4, "bf16": L.BF16, "f8": L.F8E5M2}[os.environ.get("UB_TYPE", "q4")])
     d = dw.desc()
     for n in ns:
         x = torch.randn(n, k, device=ctx.device).to(torch.bfloat16)

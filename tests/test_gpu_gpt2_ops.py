@@ -56,9 +56,11 @@ def _linear(ctx, dw, x, n, m, bias=None, residual=None):
 
 
 @pytest.mark.parametrize("t", [L.Q4, L.F8E5M2, L.BF16])
-def test_gemm_k1600(ctx, t):
-    """n_embd = 1600: K is a multiple of 64 but not of 128 (4-bit groups straddle rows: 12.5 groups per row)"""
-    m, k, n = 4800, 1600, 96
+@pytest.mark.parametrize("n", [96, 700])
+def test_gemm_k1600(ctx, t, n):
+    """n_embd = 1600: K is a multiple of 64 but not of 128 (4-bit groups straddle rows: 12.5 groups per row); 96 rows take the direct kernel,
+    700 the staged tiles with a half-empty last k tile"""
+    m, k = 4800, 1600
     rng = np.random.default_rng(t)
     w = O.f32_to_bf16(rng.normal(0, 0.02, size=(m, k)).astype(np.float32))
     x = O.f32_to_bf16(rng.normal(0, 1.0, size=(n, k)).astype(np.float32))
