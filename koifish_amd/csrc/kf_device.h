@@ -118,4 +118,53 @@ __device__ __forceinline__ double block_sumsq_bf16(const uint16_t* __restrict__ 
     return tot;
 }
 
+// ---- 16-entry bf16 table in registers, looked up with v_perm_b32 (4-bit weights; see kf_gemv_lut.hip / kf_gemv.hip)
+struct PermLut {
+    uint32_t tl[4], th[4];
+};
+__device__ __forceinline__ void build_perm_lut(PermLut& t, float step, float zero, float nb) {
+    uint32_t P[8];
+#pragma unroll
+    for (int q2 = 0; q2 < 8; q2++) {
+        const uint32_t r = pack_bf16x2(fmaf((float)(2 * q2), step, nb), fmaf((float)(2 * q2 + 1), step, nb));
+        P[q2] = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        t.tl[k] = __builtin_amdgcn_perm(P[2 * k + 1], P[2 * k], 0x06040200u);
+        t.th[k] = __builtin_amdgcn_perm(P[2 * k + 1], P[2 * k], 0x07050301u);
+    }
+}
+// s: four indices 0..15, one per byte -> the four entries as a low-byte word and a high-byte word (same byte positions)
+__device__ __forceinline__ void perm_lookup4(uint32_t s, const PermLut& t, uint32_t& lo, uint32_t& hi) {
+    const uint32_t idx = s & 0x07070707u;
+    const uint32_t b3 = (s >> 3) & 0x01010101u;
+    const uint32_t m = (b3 << 8) - b3; /* 0xFF per byte with bit 3 set; a multiply by 0xFF would be a quarter-rate v_mul_lo_u32 */
+    const uint32_t la = __builtin_amdgcn_perm(t.tl[1], t.tl[0], idx), lb = __builtin_amdgcn_perm(t.tl[3], t.tl[2], idx);
+    const uint32_t ha = __builtin_amdgcn_perm(t.th[1], t.th[0], idx), hb = __builtin_amdgcn_perm(t.th[3], t.th[2], idx);
+    lo = (lb & m) | (la & ~m);
+    hi = (hb & m) | (ha & ~m);
+}
+// X here is staged as {(x0,x2), (x4,x6), (x1,x3), (x5,x7)}
+__device__ __forceinline__ float perm_dot_dword(uint32_t D, u32x4 X, const PermLut& t, float acc) {
+    uint32_t lo, hi;
+    perm_lookup4((D >> 4) & 0x0F0F0F0Fu, t, lo, hi); /* bytes 3..0 = elements 0, 2, 4, 6 */
+    acc = dot2_bf16(__builtin_amdgcn_perm(hi, lo, 0x06020703u), X.x, acc);
+    acc = dot2_bf16(__builtin_amdgcn_perm(hi, lo, 0x04000501u), X.y, acc);
+    perm_lookup4(D & 0x0F0F0F0Fu, t, lo, hi); /* elements 1, 3, 5, 7 */
+    acc = dot2_bf16(__builtin_amdgcn_perm(hi, lo, 0x06020703u), X.z, acc);
+    acc = dot2_bf16(__builtin_amdgcn_perm(hi, lo, 0x04000501u), X.w, acc);
+    return acc;
+}
+__device__ __forceinline__ u32x4 perm_x_order(u32x4 o) {
+    return u32x4{__builtin_amdgcn_perm(o.y, o.x, 0x05040100u), __builtin_amdgcn_perm(o.w, o.z, 0x05040100u), __builtin_amdgcn_perm(o.y, o.x, 0x07060302u),
+                 __builtin_amdgcn_perm(o.w, o.z, 0x07060302u)};
+}
+
+// quad broadcast (DPP quad_perm k,k,k,k): every lane of an aligned group of 4 gets lane k's value
+template <int K>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, K | (K << 2) | (K << 4) | (K << 6), 0xF, 0xF, true);
+}
+
 }  // namespace kf

@@ -99,6 +99,33 @@ struct BlockDot<FMT_Q4> {
     }
 };
 
+// 4-bit through a per-group table (register byte planes + v_perm_b32, kf_device.h): the 4 lanes that hold the 4 blocks of a 128-weight group
+// build the 16 entries together -- lane i of the quad forms entries 4i..4i+3 with the arithmetic above, packs them into one low-byte and one
+// high-byte plane word and the quad exchanges the 8 plane words by DPP broadcasts -- then every weight costs a lookup instead of the
+// fma / round / subtract / round chain: ~4.7 VALU instructions per weight instead of 6.25.  The launcher picks this form only when a group
+// is exactly one aligned lane quad (lGroup 128, K a multiple of 128, at least 4 lanes per row); x is staged in the pair order the lookup emits.
+template <>
+struct BlockDot<FMT_Q4P> {
+    static constexpr int EPB = 32, XCH = 4;
+    static constexpr bool HAS_GAMA = true;
+    __device__ static __forceinline__ float run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, float acc) {
+        const float q0 = (float)((threadIdx.x & 3) << 2);
+        uint32_t r = pack_bf16x2(fmaf(q0, step, nb), fmaf(q0 + 1.0f, step, nb));
+        const uint32_t P0 = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
+        r = pack_bf16x2(fmaf(q0 + 2.0f, step, nb), fmaf(q0 + 3.0f, step, nb));
+        const uint32_t P1 = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
+        const uint32_t tlm = __builtin_amdgcn_perm(P1, P0, 0x06040200u), thm = __builtin_amdgcn_perm(P1, P0, 0x07050301u);
+        PermLut t;
+        t.tl[0] = quad_bcast<0>(tlm), t.tl[1] = quad_bcast<1>(tlm), t.tl[2] = quad_bcast<2>(tlm), t.tl[3] = quad_bcast<3>(tlm);
+        t.th[0] = quad_bcast<0>(thm), t.th[1] = quad_bcast<1>(thm), t.th[2] = quad_bcast<2>(thm), t.th[3] = quad_bcast<3>(thm);
+        acc = perm_dot_dword(w.w, xs[col], t, acc);
+        acc = perm_dot_dword(w.z, xs[nBlk + col], t, acc);
+        acc = perm_dot_dword(w.y, xs[2 * nBlk + col], t, acc);
+        acc = perm_dot_dword(w.x, xs[3 * nBlk + col], t, acc);
+        return acc;
+    }
+};
+
 // 2-bit (T_SIGN ternary / generic CU_Q128toX_<T,64>): element i < 32 at high >> (62-2i) (PackedQ.hpp:185-226):
 // dword3 -> elements 0..15 (element 0 in bits 30..31), dword2 -> 16..31, dword1 -> 32..47, dword0 -> 48..63.
 __device__ __forceinline__ float dot_q2_dword(uint32_t D, u32x4 Xa, u32x4 Xb, float step, float nb, float zero, float acc) {
@@ -284,11 +311,11 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
             }
             if (h0) {
                 const int c = tid / XCH, j = tid - c * XCH;
-                xs[j * nBlk + c] = u32x4{ow[0], ow[1], ow[2], ow[3]};
+                xs[j * nBlk + c] = FMT == FMT_Q4P ? perm_x_order(u32x4{ow[0], ow[1], ow[2], ow[3]}) : u32x4{ow[0], ow[1], ow[2], ow[3]};
             }
             if (h1) {
                 const int e8 = tid + 256, c = e8 / XCH, j = e8 - c * XCH;
-                xs[j * nBlk + c] = u32x4{ow[4], ow[5], ow[6], ow[7]};
+                xs[j * nBlk + c] = FMT == FMT_Q4P ? perm_x_order(u32x4{ow[4], ow[5], ow[6], ow[7]}) : u32x4{ow[4], ow[5], ow[6], ow[7]};
             }
         } else {
             float mul = 1.0f;
@@ -313,7 +340,7 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
                     }
                     o.x = ow[0], o.y = ow[1], o.z = ow[2], o.w = ow[3];
                 }
-                xs[j * nBlk + c] = o;
+                xs[j * nBlk + c] = FMT == FMT_Q4P ? perm_x_order(o) : o;
             }
         }
         __syncthreads();
@@ -565,7 +592,19 @@ int gemv_launch(hipStream_t st, GemvLaunch& L) {
     switch (fmt) {
         case FMT_BF16: launch_m<FMT_BF16>(a, L.mode, G, grid, smem, st); break;
         case FMT_F8: launch_m<FMT_F8>(a, L.mode, G, grid, smem, st); break;
-        case FMT_Q4: launch_m<FMT_Q4>(a, L.mode, G, grid, smem, st); break;
+        case FMT_Q4: {
+            // table-lookup form when a 128-weight group is exactly one aligned quad of lanes and the launch is large enough to be bound by
+            // the unpack arithmetic (KF_Q4_PERM: 0 never, 1 whenever the geometry allows, default -1 = from 0.5 M blocks up)
+            static int q4perm = -2;
+            if (q4perm == -2) q4perm = getenv("KF_Q4_PERM") ? atoi(getenv("KF_Q4_PERM")) : -1;
+            const bool geom_ok = a.lGroup == 128 && (K % 128) == 0 && lpr_log2 >= 2;
+            const bool big = raw_slots * (long)nBlk * (64 / (1 << lpr_log2)) >= (1L << 19);
+            if (geom_ok && (q4perm == 1 || (q4perm == -1 && big)))
+                launch_m<FMT_Q4P>(a, L.mode, G, grid, smem, st);
+            else
+                launch_m<FMT_Q4>(a, L.mode, G, grid, smem, st);
+            break;
+        }
         case FMT_Q2: launch_m<FMT_Q2>(a, L.mode, G, grid, smem, st); break;
         default: launch_m<FMT_Q1>(a, L.mode, G, grid, smem, st); break;
     }

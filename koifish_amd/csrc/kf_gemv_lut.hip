@@ -53,13 +53,19 @@ __device__ __forceinline__ float lut_dot_dword(uint32_t D, u32x4 X, uint32_t bas
     return acc;
 }
 
+// ---- the same table in REGISTERS, looked up with v_perm_b32 (KF_Q4_LUT=2): the 16 bf16 entries of a group as two byte planes
+// (low bytes tl[0..3], high bytes th[0..3]; plane word k holds entries 4k..4k+3).  A v_perm_b32 picks 4 bytes out of 8, so an
+// index word (one 4-bit index per byte) is looked up in entries 0..7 and in entries 8..15 with its low 3 bits, and bit 3 selects
+// per byte between the two (v_bfi_b32); two more perms interleave the planes into bf16 pairs.  3.9 VALU instructions per weight
+// instead of 5.75 + dot, no LDS traffic; the pairs come out as (e0,e2) (e4,e6) (e1,e3) (e5,e7), so x is staged in that order.
 // LDS: tables NW x 4 KiB (first: 4 KiB alignment) | x as u32x4 chunks [16 chunks of a group][nGrp] (K*2 bytes) | reduce scratch
-template <int NW, int MODE>
+template <int NW, int MODE, bool PERM>
 __global__ void __launch_bounds__(NW * 64) gemv_q4lut_kernel(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(4096))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    u32x4* xs = reinterpret_cast<u32x4*>(smem_raw + NW * 4096);
-    float* red = reinterpret_cast<float*>(smem_raw + NW * 4096 + (size_t)a.K * 2); /* [NW][8 rows] floats, also fp64 scratch */
+    constexpr size_t TAB = PERM ? 0 : (size_t)NW * 4096; /* the register-table form keeps no tables in LDS */
+    u32x4* xs = reinterpret_cast<u32x4*>(smem_raw + TAB);
+    float* red = reinterpret_cast<float*>(smem_raw + TAB + (size_t)a.K * 2); /* [NW][8 rows] floats, also fp64 scratch */
     const uint32_t lds0 = (uint32_t)(size_t)((lds_u32*)smem_raw); /* LDS byte address of the dynamic segment */
     const uint32_t base = lds0 + wave * 4096 + lane * 4;
 
@@ -114,7 +120,7 @@ __global__ void __launch_bounds__(NW * 64) gemv_q4lut_kernel(const GemvArgs a) {
                 for (int k = 0; k < 4; k++) ow[k] = pack_bf16x2((bf_lo(rw[k]) * mul) * bf_lo(ww[k]), (bf_hi(rw[k]) * mul) * bf_hi(ww[k]));
                 o = u32x4{ow[0], ow[1], ow[2], ow[3]};
             }
-            xs[j * nGrp + c] = o;
+            xs[j * nGrp + c] = PERM ? perm_x_order(o) : o;
         }
         __syncthreads();
     }
@@ -130,14 +136,27 @@ __global__ void __launch_bounds__(NW * 64) gemv_q4lut_kernel(const GemvArgs a) {
             if (nit >= iters) ns = s + 1, nit = wave;
             if (ns < s_end) load(ns, nit, nxt);
             const int c = it * 8 + ll;
-            build_lut(base, cur.st, cur.ze, -(jqb * cur.st));
+            if constexpr (PERM) {
+                PermLut t;
+                build_perm_lut(t, cur.st, cur.ze, -(jqb * cur.st));
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const u32x4 w = cur.w[b];
-                acc = lut_dot_dword(w.w, xs[(4 * b + 0) * nGrp + c], base, acc);
-                acc = lut_dot_dword(w.z, xs[(4 * b + 1) * nGrp + c], base, acc);
-                acc = lut_dot_dword(w.y, xs[(4 * b + 2) * nGrp + c], base, acc);
-                acc = lut_dot_dword(w.x, xs[(4 * b + 3) * nGrp + c], base, acc);
+                for (int b = 0; b < 4; b++) {
+                    const u32x4 w = cur.w[b];
+                    acc = perm_dot_dword(w.w, xs[(4 * b + 0) * nGrp + c], t, acc);
+                    acc = perm_dot_dword(w.z, xs[(4 * b + 1) * nGrp + c], t, acc);
+                    acc = perm_dot_dword(w.y, xs[(4 * b + 2) * nGrp + c], t, acc);
+                    acc = perm_dot_dword(w.x, xs[(4 * b + 3) * nGrp + c], t, acc);
+                }
+            } else {
+                build_lut(base, cur.st, cur.ze, -(jqb * cur.st));
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const u32x4 w = cur.w[b];
+                    acc = lut_dot_dword(w.w, xs[(4 * b + 0) * nGrp + c], base, acc);
+                    acc = lut_dot_dword(w.z, xs[(4 * b + 1) * nGrp + c], base, acc);
+                    acc = lut_dot_dword(w.y, xs[(4 * b + 2) * nGrp + c], base, acc);
+                    acc = lut_dot_dword(w.x, xs[(4 * b + 3) * nGrp + c], base, acc);
+                }
             }
             cur = nxt;
         }
@@ -186,11 +205,138 @@ __global__ void __launch_bounds__(NW * 64) gemv_q4lut_kernel(const GemvArgs a) {
     }
 }
 
+// ---- register-table form without any cross-wave step (KF_Q4_LUT=3): every wave walks whole rows on its own -- 8 lanes per row, 8 rows
+// per slot, all K/1024 iterations of the slot, a 3-step DPP sum at the end -- so the only barrier is the one after x is staged.
+template <int MODE>
+__global__ void __launch_bounds__(256) gemv_q4perm_kernel(const GemvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);
+    double* red = reinterpret_cast<double*>(smem_raw + (size_t)a.K * 2);
+    const int nGrp = a.nBlk, iters = a.iters;
+    const int sub = lane >> 3, ll = lane & 7;
+    const long gwave = (long)blockIdx.x * 4 + wave;
+    const long s_begin = gwave * a.spw;
+    long s_end = s_begin + a.spw;
+    if (s_end > a.total_slots) s_end = a.total_slots;
+    const u32x4* const jw = reinterpret_cast<const u32x4*>(a.job[0].w);
+    const uint16_t* const jstep = a.job[0].step;
+    const uint16_t* const jzero = a.job[0].zero;
+    const int jM = a.job[0].M;
+    const float jqb = (float)a.job[0].qBias;
+    auto load = [&](long s, int it, LutStep& b) {
+        int row = (int)s * 8 + sub;
+        if (row >= jM) row = jM - 1; /* rows past the end recompute the last row (no branch around the loads); never stored */
+        const uint32_t g = (uint32_t)row * (uint32_t)nGrp + (uint32_t)(it * 8 + ll);
+        const u32x4* p = jw + (size_t)g * 4;
+        b.w[0] = ld_nt(p), b.w[1] = ld_nt(p + 1), b.w[2] = ld_nt(p + 2), b.w[3] = ld_nt(p + 3);
+        b.st = bf2f(jstep[g]), b.ze = bf2f(jzero[g]);
+    };
+    // two groups in flight behind the one being multiplied (one was not enough: the waves sat on s_waitcnt)
+    LutStep cur, nxt, nx2;
+    const long nstep = (s_end > s_begin ? (s_end - s_begin) : 0) * iters;
+    auto load_step = [&](long k, LutStep& b) { /* step k of this wave = (slot s_begin + k / iters, iteration k % iters); clamped past the end */
+        if (k >= nstep) k = nstep - 1;
+        load(s_begin + k / iters, (int)(k % iters), b);
+    };
+    if (nstep > 0) {
+        load_step(0, cur);
+        load_step(1, nxt);
+    }
+    const int pos = a.d_pos ? *a.d_pos : a.pos;
+    {
+        const int nch = a.K >> 3;
+        float mul = 1.0f;
+        if (a.norm_w) {
+            const double ss = block_sumsq_bf16(a.x, a.K, red);
+            mul = 1.0f / sqrtf(fmaf((float)ss, a.inv_dim, a.eps));
+        }
+        for (int e8 = tid; e8 < nch; e8 += 256) {
+            const int c = e8 >> 4, j = e8 & 15;
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(a.x + (size_t)e8 * 8);
+            u32x4 o = raw;
+            if (a.norm_w) {
+                const u32x4 nw = *reinterpret_cast<const u32x4*>(a.norm_w + (size_t)e8 * 8);
+                const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w}, ww[4] = {nw.x, nw.y, nw.z, nw.w};
+                uint32_t ow[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) ow[k] = pack_bf16x2((bf_lo(rw[k]) * mul) * bf_lo(ww[k]), (bf_hi(rw[k]) * mul) * bf_hi(ww[k]));
+                o = u32x4{ow[0], ow[1], ow[2], ow[3]};
+            }
+            xs[j * nGrp + c] = perm_x_order(o);
+        }
+        __syncthreads();
+    }
+    float best_v = -__builtin_inff();
+    int best_i = 0x7fffffff;
+    long kstep = 0;
+    for (long s = s_begin; s < s_end; s++) {
+        float acc = 0.f;
+        for (int it = 0; it < iters; it++, kstep++) {
+            load_step(kstep + 2, nx2);
+            const int c = it * 8 + ll;
+            PermLut t;
+            build_perm_lut(t, cur.st, cur.ze, -(jqb * cur.st));
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const u32x4 w = cur.w[b];
+                acc = perm_dot_dword(w.w, xs[(4 * b + 0) * nGrp + c], t, acc);
+                acc = perm_dot_dword(w.z, xs[(4 * b + 1) * nGrp + c], t, acc);
+                acc = perm_dot_dword(w.y, xs[(4 * b + 2) * nGrp + c], t, acc);
+                acc = perm_dot_dword(w.x, xs[(4 * b + 3) * nGrp + c], t, acc);
+            }
+            cur = nxt;
+            nxt = nx2;
+        }
+        acc += dppf<0xB1>(acc);
+        acc += dppf<0x4E>(acc);
+        acc += dppf<0x141>(acc);
+        const int r = (int)s * 8 + sub;
+        if (ll == 0 && r < jM) {
+            float v = acc;
+            if (a.yf) {
+                a.yf[r] = v;
+            } else {
+                uint16_t* y = a.job[0].y + (size_t)pos * a.job[0].y_pos_stride;
+                if (a.alpha != 1.0f) v = a.alpha * v;
+                if (a.beta != 0.0f) v = v + a.beta * bf2f(y[r]);
+                if (a.bias) v = v + bf2f(a.bias[r]);
+                uint16_t o = f2bf(v);
+                if (a.residual) o = f2bf(bf2f(a.residual[r]) + bf2f(o));
+                y[r] = o;
+                if (MODE == GEMV_ARGMAX) {
+                    const float fv = bf2f(o);
+                    if (fv > best_v || (fv == best_v && r < best_i)) best_v = fv, best_i = r;
+                }
+            }
+        }
+    }
+    if (MODE == GEMV_ARGMAX) {
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) {
+            const float ov = __shfl_xor(best_v, m, 64);
+            const int oi = __shfl_xor(best_i, m, 64);
+            if (ov > best_v || (ov == best_v && oi < best_i)) best_v = ov, best_i = oi;
+        }
+        float* rv = reinterpret_cast<float*>(red);
+        int* ri = reinterpret_cast<int*>(rv + 16);
+        __syncthreads();
+        if (lane == 0) rv[wave] = best_v, ri[wave] = best_i;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; w++)
+                if (rv[w] > best_v || (rv[w] == best_v && ri[w] < best_i)) best_v = rv[w], best_i = ri[w];
+            a.amax_val[blockIdx.x] = best_v;
+            a.amax_idx[blockIdx.x] = best_i;
+        }
+    }
+}
+
 // Returns KF_OK and sets *used when the table kernel took the launch; *used = false means "not applicable, use the arithmetic kernel".
 int gemv_q4lut_launch(hipStream_t st, GemvLaunch& L, bool* used) {
     *used = false;
-    static int knob = -2;
-    if (knob == -2) {
+    static int knob = -99;
+    if (knob == -99) {
         const char* e = getenv("KF_Q4_LUT");
         knob = e ? atoi(e) : 0; /* 0 (default) never, 1 whenever applicable, -1 by size.  Measured on 25600x5120: 33 us vs 30 us for the
                                     arithmetic kernel -- 3.7 instead of 7.7 VALU per weight, but the lookups leave the waves latency-bound
@@ -201,7 +347,7 @@ int gemv_q4lut_launch(hipStream_t st, GemvLaunch& L, bool* used) {
     if (knob == 0 || L.n != 1 || L.mode == GEMV_PAIRED || w->type != KF_Q4 || w->qzeros || w->lGroup != 128) return KF_OK;
     const int K = w->ne1, M = w->ne0;
     if (K % 1024 || !w->gama) return KF_OK; /* 8 lanes x 128 weights per row step */
-    if (knob == -1 && K < 4096) return KF_OK; /* short rows: too few iterations to split; the arithmetic kernel is latency-optimal there */
+    if (knob < 0 && K < 4096) return KF_OK; /* short rows: too few iterations to split; the arithmetic kernel is latency-optimal there */
     if (((uintptr_t)w->data & 15) != 0) return KF_BLAS_UNALIGN;
     const int nGrp = K / 128;
     if ((unsigned long long)M * (unsigned long long)nGrp >= (1ull << 30)) return KF_OK;
@@ -214,6 +360,25 @@ int gemv_q4lut_launch(hipStream_t st, GemvLaunch& L, bool* used) {
     a.job[0].M = M, a.job[0].qBias = w->qBias, a.job[0].slot0 = 0;
     a.lGroup = 128, a.gshift = 0;
     const long slots = (M + 7) / 8;
+    if (knob == 3 || knob == -3) { /* wave-independent register-table kernel */
+        long tw = 16384;
+        if (const char* e = getenv("KF_GEMV_WAVES")) tw = atol(e);
+        long spw = (slots + tw - 1) / tw;
+        if (spw < 1) spw = 1;
+        a.spw = (int)spw, a.total_slots = (int)slots;
+        const long waves = (slots + spw - 1) / spw;
+        const int blocks = (int)((waves + 3) / 4);
+        if (L.mode == GEMV_ARGMAX && blocks > KF_MAX_ARGMAX_PARTIALS) return KF_OK;
+        const size_t smem = (size_t)K * 2 + 256;
+        if (smem > 160 * 1024) return KF_OK;
+        if (L.mode == GEMV_ARGMAX)
+            hipLaunchKernelGGL((gemv_q4perm_kernel<GEMV_ARGMAX>), dim3(blocks), dim3(256), smem, st, a);
+        else
+            hipLaunchKernelGGL((gemv_q4perm_kernel<GEMV_PLAIN>), dim3(blocks), dim3(256), smem, st, a);
+        L.blocks = blocks;
+        *used = true;
+        return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+    }
     const int NW = (slots < 2048 && a.iters >= 8) ? 8 : 4;
     long target_blocks = 4096;
     if (const char* e = getenv("KF_LUT_BLOCKS")) target_blocks = atol(e);
@@ -222,19 +387,28 @@ int gemv_q4lut_launch(hipStream_t st, GemvLaunch& L, bool* used) {
     a.spw = (int)spb, a.total_slots = (int)slots;
     const int blocks = (int)((slots + spb - 1) / spb);
     if (L.mode == GEMV_ARGMAX && blocks > KF_MAX_ARGMAX_PARTIALS) return KF_OK;
-    const size_t smem = (size_t)NW * 4096 + (size_t)K * 2 + 256;
+    const bool perm = knob == 2 || knob == -2;
+    const size_t smem = (perm ? 0 : (size_t)NW * 4096) + (size_t)K * 2 + 256;
     if (smem > 160 * 1024) return KF_OK;
+#define KF_LUT_LAUNCH(NWV, MODEV)                                                                                                 \
+    do {                                                                                                                          \
+        if (perm)                                                                                                                 \
+            hipLaunchKernelGGL((gemv_q4lut_kernel<NWV, MODEV, true>), dim3(blocks), dim3(NWV * 64), smem, st, a);                 \
+        else                                                                                                                      \
+            hipLaunchKernelGGL((gemv_q4lut_kernel<NWV, MODEV, false>), dim3(blocks), dim3(NWV * 64), smem, st, a);                \
+    } while (0)
     if (NW == 8) {
         if (L.mode == GEMV_ARGMAX)
-            hipLaunchKernelGGL((gemv_q4lut_kernel<8, GEMV_ARGMAX>), dim3(blocks), dim3(512), smem, st, a);
+            KF_LUT_LAUNCH(8, GEMV_ARGMAX);
         else
-            hipLaunchKernelGGL((gemv_q4lut_kernel<8, GEMV_PLAIN>), dim3(blocks), dim3(512), smem, st, a);
+            KF_LUT_LAUNCH(8, GEMV_PLAIN);
     } else {
         if (L.mode == GEMV_ARGMAX)
-            hipLaunchKernelGGL((gemv_q4lut_kernel<4, GEMV_ARGMAX>), dim3(blocks), dim3(256), smem, st, a);
+            KF_LUT_LAUNCH(4, GEMV_ARGMAX);
         else
-            hipLaunchKernelGGL((gemv_q4lut_kernel<4, GEMV_PLAIN>), dim3(blocks), dim3(256), smem, st, a);
+            KF_LUT_LAUNCH(4, GEMV_PLAIN);
     }
+#undef KF_LUT_LAUNCH
     L.blocks = blocks;
     *used = true;
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;

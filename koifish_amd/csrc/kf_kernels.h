@@ -5,7 +5,7 @@
 
 namespace kf {
 
-enum { FMT_BF16 = 0, FMT_F8 = 1, FMT_Q4 = 2, FMT_Q2 = 3, FMT_Q1 = 4 };
+enum { FMT_BF16 = 0, FMT_F8 = 1, FMT_Q4 = 2, FMT_Q2 = 3, FMT_Q1 = 4, FMT_Q4P = 5 /* 4-bit through the register-table lookup (mat-vec only) */ };
 enum { GEMV_PLAIN = 0, GEMV_PAIRED = 1, GEMV_ARGMAX = 2 };
 constexpr int KF_MAX_ARGMAX_PARTIALS = 4096;
 constexpr int KF_ATTN_MAX_SPLITS = 32;
