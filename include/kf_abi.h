@@ -182,6 +182,12 @@ int kf_embed_state(kf_ctx* ctx, const kf_weight* w, const int32_t* d_state, cons
 int kf_sample(kf_ctx* ctx, const kf_bf16* logits, int n, int top_k, float temperature, float top_p, uint64_t* d_rng_state, int32_t* d_token,
               int32_t* d_state, int32_t* d_tokens_out, const int32_t* d_forced, int n_forced);
 
+/* kf_sample with the candidate set the reference's TopK is evidently meant to keep: the top_k LARGEST logits (ties at the k-th value towards the
+ * lower token index; candidates ordered by logit, equal logits by index).  Not what the reference computes (its heap keeps indices 0..k-2, see
+ * kf_sample); offered beside it.  Everything else -- softmax with temperature, top-p cut, xorshift coin, state update -- is identical. */
+int kf_sample_topk(kf_ctx* ctx, const kf_bf16* logits, int n, int top_k, float temperature, float top_p, uint64_t* d_rng_state, int32_t* d_token,
+                   int32_t* d_state, int32_t* d_tokens_out, const int32_t* d_forced, int n_forced);
+
 /* ---- GPT-2 family forward pieces (BASELINE config 3) */
 /* LayerNorm forward with affine weight and bias (LayerNormal::cuFlow for the GPT-2 family -> CU_lm_forward, layernorm.cuh:226-300):
  * y = bf16((x - mean) * rstd * w + b), rstd = 1/sqrtf(var + eps); bias may be NULL; mean / rstd [rows] fp32 are optional outputs. */

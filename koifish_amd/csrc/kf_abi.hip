@@ -528,6 +528,14 @@ int kf_sample(kf_ctx* c, const kf_bf16* logits, int n, int top_k, float temperat
     RET(r);
 }
 
+int kf_sample_topk(kf_ctx* c, const kf_bf16* logits, int n, int top_k, float temperature, float top_p, uint64_t* d_rng_state, int32_t* d_token, int32_t* d_state,
+                   int32_t* d_tokens_out, const int32_t* d_forced, int n_forced) {
+    CHKCTX(c);
+    if (!logits || !d_rng_state || (!d_token && !d_state)) return fail(KF_INVALID_ARGS, "kf_sample_topk: null pointer");
+    int r = kf::sample_launch(c->stream, logits, n, top_k, temperature, top_p, (unsigned long long*)d_rng_state, d_token, d_state, d_tokens_out, d_forced, n_forced, 1);
+    if (r == KF_INVALID_ARGS) return fail(r, "kf_sample_topk: needs 2 <= top_k < n/2, top_k <= 1024, temperature > 0, top_p > 0 (got k=%d n=%d T=%g p=%g)", top_k, n, temperature, top_p);
+    RET(r);
+}
 int kf_layernorm(kf_ctx* c, const kf_bf16* x, const kf_bf16* w, const kf_bf16* bias, kf_bf16* y, int rows, int dim, float eps, float* mean, float* rstd) {
     CHKCTX(c);
     if (!x || !w || !y || rows < 1 || dim < 1) return fail(KF_INVALID_ARGS, "kf_layernorm: bad args");

@@ -99,7 +99,7 @@ int dequant_launch(hipStream_t st, const kf_weight* w, uint16_t* out);
 int adamw_launch(hipStream_t st, uint16_t* params, uint16_t* grads, void* gm, void* gv, size_t n, int mv_bf16, float lr, float beta1, float beta2, float b1c,
                  float b2c, float eps, float wd, float grad_scale, unsigned int seed, int* status);
 int sample_launch(hipStream_t st, const uint16_t* logits, int n, int top_k, float temperature, float top_p, unsigned long long* rng, int32_t* d_token,
-                  int32_t* d_state, int32_t* d_tokens_out, const int32_t* d_forced, int n_forced);
+                  int32_t* d_state, int32_t* d_tokens_out, const int32_t* d_forced, int n_forced, int true_topk = 0);
 int quantize_launch(hipStream_t st, const kf_weight* w, const uint16_t* src, int symmetric);
 // ---- AutoAWQ layout (kf_awq.hip)
 size_t awq_scratch_bytes(const kf_weight* w);

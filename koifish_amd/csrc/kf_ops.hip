@@ -215,6 +215,12 @@ int embed_launch(hipStream_t st, const kf_weight* w, int token, const int32_t* d
 // The rng state lives in device memory and advances once per call, so a captured graph replays a fresh coin every step.
 // Same operation sequence as oracle/kf_oracle.c kfo_sample: token ids agree bit for bit.
 constexpr int KF_SAMPLE_MAX_K = 1024;
+// TRUE_TOPK (kf_sample_topk): the k LARGEST logits instead -- what the reference's TopK evidently means to keep -- found with a two-level
+// radix select on the order-preserving 16-bit key of a bf16 (high byte, then low byte: two 256-bin histograms), ties at the threshold
+// resolved towards the lower token index; everything after the candidate set is the same code.
+__device__ __forceinline__ unsigned int bf16_key(uint16_t u) { return (u & 0x8000u) ? (~(unsigned int)u & 0xFFFFu) : ((unsigned int)u | 0x8000u); }
+
+template <bool TRUE_TOPK>
 __global__ void __launch_bounds__(1024) sample_kernel(const uint16_t* __restrict__ logits, int n, int k, float temperature, float top_p,
                                                       unsigned long long* rng, int32_t* d_token, int32_t* d_state, int32_t* d_tokens_out,
                                                       const int32_t* d_forced, int n_forced) {
@@ -238,44 +244,116 @@ __global__ void __launch_bounds__(1024) sample_kernel(const uint16_t* __restrict
             return;
         }
     }
-    // first maximum over i >= k-1
-    float bv = -__builtin_inff();
-    int bi = 0x7fffffff;
-    for (int i = k - 1 + tid; i < n; i += blockDim.x) {
-        const float v = bf2f(logits[i]);
-        if (v > bv) bv = v, bi = i;
-    }
-    sv[tid] = bv, si[tid] = bi;
-    __syncthreads();
-    for (int m = blockDim.x >> 1; m > 0; m >>= 1) {
-        if (tid < m) {
-            const float ov = sv[tid + m];
-            const int oi = si[tid + m];
-            if (ov > sv[tid] || (ov == sv[tid] && oi < si[tid])) sv[tid] = ov, si[tid] = oi;
+    if constexpr (!TRUE_TOPK) {
+        // first maximum over i >= k-1
+        float bv = -__builtin_inff();
+        int bi = 0x7fffffff;
+        for (int i = k - 1 + tid; i < n; i += blockDim.x) {
+            const float v = bf2f(logits[i]);
+            if (v > bv) bv = v, bi = i;
+        }
+        sv[tid] = bv, si[tid] = bi;
+        __syncthreads();
+        for (int m = blockDim.x >> 1; m > 0; m >>= 1) {
+            if (tid < m) {
+                const float ov = sv[tid + m];
+                const int oi = si[tid + m];
+                if (ov > sv[tid] || (ov == sv[tid] && oi < si[tid])) sv[tid] = ov, si[tid] = oi;
+            }
+            __syncthreads();
+        }
+        const int last = si[0];
+        __syncthreads();
+        // extraction order: last, k-2, .., 0; stable rank sort, descending by logit
+        int my = 0;
+        float mv = 0.f;
+        if (tid < k) {
+            my = tid == 0 ? last : k - 1 - tid;
+            mv = bf2f(logits[my]);
+            sv[tid] = mv;
+        }
+        __syncthreads();
+        if (tid < k) {
+            int rank = 0;
+            for (int m = 0; m < k; m++) {
+                const float o = sv[m];
+                rank += (o > mv || (o == mv && m < tid)) ? 1 : 0;
+            }
+            picks[rank] = my;
+            pv[rank] = mv;
+        }
+        __syncthreads();
+    } else {
+        __shared__ int hist[256];
+        __shared__ int scan[1024];
+        __shared__ int sel[4]; /* {bin, count above, appended so far, -} */
+        // ---- level 1: high byte of the key
+        auto select_bin = [&](int want) { /* hist filled; thread 0 finds the bin holding the want-th largest, sel = {bin, count above it} */
+            __syncthreads();
+            if (tid == 0) {
+                int cum = 0, b = 255;
+                for (; b > 0; b--) {
+                    if (cum + hist[b] >= want) break;
+                    cum += hist[b];
+                }
+                sel[0] = b, sel[1] = cum;
+            }
+            __syncthreads();
+        };
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += blockDim.x) atomicAdd(&hist[bf16_key(logits[i]) >> 8], 1);
+        select_bin(k);
+        const int b1 = sel[0], above1 = sel[1];
+        __syncthreads();
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += blockDim.x) {
+            const unsigned int key = bf16_key(logits[i]);
+            if ((int)(key >> 8) == b1) atomicAdd(&hist[key & 0xFF], 1);
+        }
+        select_bin(k - above1);
+        const unsigned int T = ((unsigned int)b1 << 8) | (unsigned int)sel[0];
+        const int n_gt = above1 + sel[1], r_eq = k - n_gt; /* keys > T: all n_gt of them; keys == T: the r_eq with the lowest indices */
+        __syncthreads();
+        if (tid == 0) sel[2] = 0;
+        // every thread owns a contiguous index range, so the running count of == T keys gives their order by index
+        const int chunk = (n + (int)blockDim.x - 1) / (int)blockDim.x, i0 = tid * chunk, i1 = min(n, i0 + chunk);
+        int eq = 0;
+        for (int i = i0; i < i1; i++) eq += bf16_key(logits[i]) == T ? 1 : 0;
+        scan[tid] = eq;
+        __syncthreads();
+        for (int off = 1; off < (int)blockDim.x; off <<= 1) { /* inclusive Hillis-Steele scan */
+            const int v = tid >= off ? scan[tid - off] : 0;
+            __syncthreads();
+            scan[tid] += v;
+            __syncthreads();
+        }
+        int eq_rank = scan[tid] - eq; /* == T keys before this thread's range */
+        for (int i = i0; i < i1; i++) {
+            const unsigned int key = bf16_key(logits[i]);
+            int slot = -1;
+            if (key > T)
+                slot = atomicAdd(&sel[2], 1); /* any order: sorted below */
+            else if (key == T && eq_rank++ < r_eq)
+                slot = n_gt + eq_rank - 1;
+            if (slot >= 0) si[slot] = i, sv[slot] = bf2f(logits[i]);
+        }
+        __syncthreads();
+        // descending by logit, equal logits by ascending token index
+        if (tid < k) {
+            const float mv = sv[tid];
+            const int my = si[tid];
+            int rank = 0;
+            for (int m = 0; m < k; m++) {
+                const float o = sv[m];
+                rank += (o > mv || (o == mv && si[m] < my)) ? 1 : 0;
+            }
+            picks[rank] = my;
+            pv[rank] = mv;
         }
         __syncthreads();
     }
-    const int last = si[0];
-    __syncthreads();
-    // extraction order: last, k-2, .., 0; stable rank sort, descending by logit
-    int my = 0;
-    float mv = 0.f;
-    if (tid < k) {
-        my = tid == 0 ? last : k - 1 - tid;
-        mv = bf2f(logits[my]);
-        sv[tid] = mv;
-    }
-    __syncthreads();
-    if (tid < k) {
-        int rank = 0;
-        for (int m = 0; m < k; m++) {
-            const float o = sv[m];
-            rank += (o > mv || (o == mv && m < tid)) ? 1 : 0;
-        }
-        picks[rank] = my;
-        pv[rank] = mv;
-    }
-    __syncthreads();
     const float maxLogit = pv[0];
     float e = 0.f;
     if (tid < k) e = kf_expf((pv[tid] - maxLogit) / temperature);
@@ -332,11 +410,15 @@ __global__ void __launch_bounds__(1024) sample_kernel(const uint16_t* __restrict
     }
 }
 int sample_launch(hipStream_t st, const uint16_t* logits, int n, int top_k, float temperature, float top_p, unsigned long long* rng, int32_t* d_token,
-                  int32_t* d_state, int32_t* d_tokens_out, const int32_t* d_forced, int n_forced) {
+                  int32_t* d_state, int32_t* d_tokens_out, const int32_t* d_forced, int n_forced, int true_topk) {
     const int k = top_k < n ? top_k : n;
     if (k < 2 || k >= n / 2 || k > KF_SAMPLE_MAX_K || !(temperature > 0.0f) || !(top_p > 0.0f)) return KF_INVALID_ARGS;
-    hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(1024), 0, st, logits, n, k, temperature, top_p, rng, d_token, d_state, d_tokens_out,
-                       d_forced, n_forced);
+    if (true_topk)
+        hipLaunchKernelGGL(sample_kernel<true>, dim3(1), dim3(1024), 0, st, logits, n, k, temperature, top_p, rng, d_token, d_state, d_tokens_out, d_forced,
+                           n_forced);
+    else
+        hipLaunchKernelGGL(sample_kernel<false>, dim3(1), dim3(1024), 0, st, logits, n, k, temperature, top_p, rng, d_token, d_state, d_tokens_out, d_forced,
+                           n_forced);
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 

@@ -398,8 +398,8 @@ int Fish::HeadAndPick(const floatX* x_last) {
     if (samp_params.greedy())
         return kf_norm_lm_head(ctx, x_last, ToX(final_norm.w), final_norm.rms_eps, &wh, ToX(head.preLogits), d_state, d_tokens_out, gBUFF.head_ws->data);
     KF_TRY(kf_norm_lm_head(ctx, x_last, ToX(final_norm.w), final_norm.rms_eps, &wh, ToX(head.preLogits), nullptr, nullptr, gBUFF.head_ws->data));
-    return kf_sample(ctx, ToX(head.preLogits), config.vocab, samp_params.top_k, samp_params.temperature, samp_params.top_p, d_rng, nullptr, d_state, d_tokens_out,
-                     d_forced, config.n_ctx);
+    return (samp_params.true_topk ? kf_sample_topk : kf_sample)(ctx, ToX(head.preLogits), config.vocab, samp_params.top_k, samp_params.temperature, samp_params.top_p,
+                                                                 d_rng, nullptr, d_state, d_tokens_out, d_forced, config.n_ctx);
 }
 
 int Fish::SetSampler(const CHAT_SAMPLER& s) {
@@ -571,7 +571,8 @@ int kfh_set_prefill_mode(void* h, int mode, int chunk) {
 }
 int kfh_set_sampler(void* h, float temperature, float top_p, int top_k, uint64_t seed) {
     CHAT_SAMPLER s;
-    s.temperature = temperature, s.top_p = top_p, s.top_k = top_k, s.seed = seed;
+    s.temperature = temperature, s.top_p = top_p, s.top_k = top_k & 0xFFFF, s.seed = seed;
+    s.true_topk = (top_k & 0x10000) != 0;  // bit 16 of top_k: candidates = the k largest logits (kf_sample_topk)
     return reinterpret_cast<Fish*>(h)->SetSampler(s);
 }
 int kfh_set_state(void* h, int token, int pos) { return reinterpret_cast<Fish*>(h)->SetState(token, pos); }

@@ -170,6 +170,7 @@ struct CHAT_SAMPLER {
     float top_p = 0.95f;
     int top_k = 50;
     uint64_t seed = 42;
+    bool true_topk = false;  // false: the candidate set the reference's TOPK_heap keeps (kf_sample); true: the k largest logits (kf_sample_topk)
     bool greedy() const { return temperature == 0.0f || top_k == 1; }
 };
 

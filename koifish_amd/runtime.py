@@ -338,9 +338,10 @@ class Qwen3:
         L.check(self.host.kfh_generate(self.h, p.ctypes.data_as(C.c_void_p), p.size, n_new, out.ctypes.data_as(C.c_void_p), int(use_graph)), "kfh_generate")
         return out.tolist()
 
-    def set_sampler(self, temperature=0.0, top_p=0.95, top_k=50, seed=42):
-        """CHAT_SAMPLER: temperature 0 (or top_k 1) = greedy; otherwise GeneratOnPrompt::Sample on the device, rng reseeded here"""
-        L.check(self.host.kfh_set_sampler(self.h, float(temperature), float(top_p), int(top_k), int(seed)), "kfh_set_sampler")
+    def set_sampler(self, temperature=0.0, top_p=0.95, top_k=50, seed=42, true_topk=False):
+        """CHAT_SAMPLER: temperature 0 (or top_k 1) = greedy; otherwise GeneratOnPrompt::Sample on the device, rng reseeded here.
+        true_topk: candidates = the k largest logits (kf_sample_topk) instead of the set the reference's heap keeps (kf_sample)."""
+        L.check(self.host.kfh_set_sampler(self.h, float(temperature), float(top_p), int(top_k) | (0x10000 if true_topk else 0), int(seed)), "kfh_set_sampler")
 
     def set_prefill_mode(self, mode, chunk=0):
         """generate(): 0 = token-serial prefill through the decode path (like the reference), 1 = token batches on the MFMA kernels"""

@@ -575,31 +575,13 @@ static inline uint32_t kfo_random_u32(uint64_t* state) {
 }
 KFO_API float kfo_random_f32(uint64_t* state) { return (float)(kfo_random_u32(state) >> 8) / 16777216.0f; }
 
-KFO_API int kfo_sample(const uint16_t* logits, int n, int top_k, float temperature, float top_p, uint64_t* rng_state, int* picks_out, float* probs_out,
-                       int* npick_out) {
-    const int k = top_k < n ? top_k : n;
-    if (k < 2 || k >= n / 2 || !(temperature > 0.0f) || !(top_p > 0.0f)) return -1;
-    int* picks = (int*)malloc(sizeof(int) * k);
-    float* p = (float*)malloc(sizeof(float) * k);
-    /* Select */
-    int last = k - 1;
-    for (int i = k; i < n; i++)
-        if (kfo_bf16_to_f32(logits[i]) > kfo_bf16_to_f32(logits[last])) last = i;
-    picks[0] = last;
-    for (int j = 1; j < k; j++) picks[j] = k - 1 - j; /* k-2, k-3, .., 0 */
+/* candidates `picks` (already ordered) -> UpdateLogits, TopP, Qu_FlipCoin */
+static int sample_tail(const uint16_t* logits, int* picks, int k, float temperature, float top_p, uint64_t* rng_state, float* p, int* npick_out) {
     float maxLogit = -3.402823466e+38f;
     for (int j = 0; j < k; j++) {
         const float a = kfo_bf16_to_f32(logits[picks[j]]);
         if (a > maxLogit) maxLogit = a;
     }
-    for (int j = 1; j < k; j++) { /* stable insertion sort, descending by logit */
-        const int pj = picks[j];
-        const float vj = kfo_bf16_to_f32(logits[pj]);
-        int q = j - 1;
-        while (q >= 0 && vj > kfo_bf16_to_f32(logits[picks[q]])) picks[q + 1] = picks[q], q--;
-        picks[q + 1] = pj;
-    }
-    /* UpdateLogits */
     float prob_sum = 0.0f;
     for (int j = 0; j < k; j++) {
         const float a = kfo_bf16_to_f32(logits[picks[j]]);
@@ -607,7 +589,6 @@ KFO_API int kfo_sample(const uint16_t* logits, int n, int top_k, float temperatu
         prob_sum += p[j];
     }
     for (int j = 0; j < k; j++) p[j] /= prob_sum;
-    /* TopP */
     int nPick = k;
     if (top_p < 1.0f) {
         float cum = 0.0f;
@@ -621,7 +602,6 @@ KFO_API int kfo_sample(const uint16_t* logits, int n, int top_k, float temperatu
         }
         nPick = last_idx + 1;
     }
-    /* Qu_FlipCoin */
     float ps = 0.0f;
     for (int j = 0; j < nPick; j++) ps += p[j];
     const float coin = kfo_random_f32(rng_state) * ps;
@@ -634,9 +614,57 @@ KFO_API int kfo_sample(const uint16_t* logits, int n, int top_k, float temperatu
             break;
         }
     }
+    if (npick_out) *npick_out = nPick;
+    return qu;
+}
+
+KFO_API int kfo_sample(const uint16_t* logits, int n, int top_k, float temperature, float top_p, uint64_t* rng_state, int* picks_out, float* probs_out,
+                       int* npick_out) {
+    const int k = top_k < n ? top_k : n;
+    if (k < 2 || k >= n / 2 || !(temperature > 0.0f) || !(top_p > 0.0f)) return -1;
+    int* picks = (int*)malloc(sizeof(int) * k);
+    float* p = (float*)malloc(sizeof(float) * k);
+    /* Select */
+    int last = k - 1;
+    for (int i = k; i < n; i++)
+        if (kfo_bf16_to_f32(logits[i]) > kfo_bf16_to_f32(logits[last])) last = i;
+    picks[0] = last;
+    for (int j = 1; j < k; j++) picks[j] = k - 1 - j; /* k-2, k-3, .., 0 */
+    for (int j = 1; j < k; j++) { /* stable insertion sort, descending by logit */
+        const int pj = picks[j];
+        const float vj = kfo_bf16_to_f32(logits[pj]);
+        int q = j - 1;
+        while (q >= 0 && vj > kfo_bf16_to_f32(logits[picks[q]])) picks[q + 1] = picks[q], q--;
+        picks[q + 1] = pj;
+    }
+    const int qu = sample_tail(logits, picks, k, temperature, top_p, rng_state, p, npick_out);
     if (picks_out) memcpy(picks_out, picks, sizeof(int) * k);
     if (probs_out) memcpy(probs_out, p, sizeof(float) * k);
-    if (npick_out) *npick_out = nPick;
+    free(picks);
+    free(p);
+    return qu;
+}
+
+/* The candidate set TopK is evidently meant to keep (not what the reference's heap keeps, see above): the k largest logits, equal logits
+ * towards the lower token index, ordered by (logit descending, index ascending); then the same UpdateLogits / TopP / Qu_FlipCoin. */
+KFO_API int kfo_sample_topk(const uint16_t* logits, int n, int top_k, float temperature, float top_p, uint64_t* rng_state, int* picks_out, float* probs_out,
+                            int* npick_out) {
+    const int k = top_k < n ? top_k : n;
+    if (k < 2 || k >= n / 2 || !(temperature > 0.0f) || !(top_p > 0.0f)) return -1;
+    int* picks = (int*)malloc(sizeof(int) * (k + 1));
+    float* p = (float*)malloc(sizeof(float) * k);
+    int cnt = 0;
+    for (int i = 0; i < n; i++) { /* insertion into the running top-k list; a later equal logit never displaces an earlier one */
+        const float v = kfo_bf16_to_f32(logits[i]);
+        if (cnt == k && !(v > kfo_bf16_to_f32(logits[picks[k - 1]]))) continue;
+        int q = cnt < k ? cnt : k - 1;
+        while (q > 0 && v > kfo_bf16_to_f32(logits[picks[q - 1]])) picks[q] = picks[q - 1], q--;
+        picks[q] = i;
+        if (cnt < k) cnt++;
+    }
+    const int qu = sample_tail(logits, picks, k, temperature, top_p, rng_state, p, npick_out);
+    if (picks_out) memcpy(picks_out, picks, sizeof(int) * k);
+    if (probs_out) memcpy(probs_out, p, sizeof(float) * k);
     free(picks);
     free(p);
     return qu;

@@ -284,15 +284,16 @@ def argmax_bf16(logits):
     return int(lib().kfo_argmax_bf16(_p(logits), logits.size))
 
 
-def sample(logits, top_k, temperature, top_p, rng_state, want_detail=False):
-    """GeneratOnPrompt::Sample (non-greedy branch); rng_state is a 1-element uint64 array advanced in place."""
+def sample(logits, top_k, temperature, top_p, rng_state, want_detail=False, true_topk=False):
+    """GeneratOnPrompt::Sample (non-greedy branch); rng_state is a 1-element uint64 array advanced in place.
+    true_topk: the k largest logits as candidates instead of the set the reference's heap keeps (kfo_sample_topk)."""
     logits = np.ascontiguousarray(logits, dtype=np.uint16)
     assert rng_state.dtype == np.uint64 and rng_state.size == 1
     k = min(top_k, logits.size)
     picks = np.zeros(max(k, 1), dtype=np.int32)
     probs = np.zeros(max(k, 1), dtype=np.float32)
     npick = C.c_int(0)
-    fn = lib().kfo_sample
+    fn = lib().kfo_sample_topk if true_topk else lib().kfo_sample
     fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     tok = int(fn(_p(logits), logits.size, int(top_k), float(temperature), float(top_p), _p(rng_state), _p(picks), _p(probs), C.byref(npick)))
     if want_detail:

@@ -89,3 +89,39 @@ def test_pick_is_exact_on_device_logits():
         assert nxt == want, "step %d" % pos
         tok = nxt
     gm.close()
+
+
+@pytest.mark.parametrize("n,k,temp,top_p", [(151936, 50, 0.7, 0.95), (4096, 1024, 1.2, 1.0), (2100, 9, 0.5, 0.8), (512, 2, 1.0, 0.9)])
+def test_sample_true_topk_matches_oracle(ctx, n, k, temp, top_p):
+    """kf_sample_topk: radix select of the k largest logits (ties towards the lower index), then the same pick"""
+    rng = np.random.default_rng(n * 3 + k)
+    for trial in range(6):
+        coarse = trial % 2 == 1
+        lg = O.f32_to_bf16(rng.normal(0, 0.4 if coarse else 3.0, size=n).astype(np.float32))
+        if trial == 4:
+            lg[:] = lg[0]                      # every logit equal: the candidates are tokens 0..k-1
+        seed = int(rng.integers(1, 2 ** 62))
+        st = np.array([seed], dtype=np.uint64)
+        lg_t = torch.from_numpy(lg.view(np.int16)).to(ctx.device)
+        rng_t = torch.from_numpy(st.view(np.int64).copy()).to(ctx.device)
+        tok_t = torch.zeros(1, dtype=torch.int32, device=ctx.device)
+        for draw in range(6):
+            want = O.sample(lg, k, temp, top_p, st, true_topk=True)
+            assert ctx.hip.kf_sample_topk(ctx.h, lg_t.data_ptr(), n, k, temp, top_p, rng_t.data_ptr(), tok_t.data_ptr(), None, None, None, 0) == 0
+            ctx.sync()
+            assert int(tok_t.item()) == want, "trial %d draw %d" % (trial, draw)
+
+
+def test_generate_true_topk_pick_on_device_logits():
+    cfg = synth.CONFIGS["tiny"]
+    raw = synth.raw_weights_numpy(cfg, 1234, w_std=0.1)
+    gm = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
+    samp = dict(top_k=12, temperature=0.8, top_p=0.9, seed=5)
+    gm.set_sampler(true_topk=True, **samp)
+    st = np.array([5], dtype=np.uint64)
+    tok = 3
+    for pos in range(30):
+        nxt, logits = gm.forward(tok, pos)
+        assert nxt == O.sample(logits, samp["top_k"], samp["temperature"], samp["top_p"], st, true_topk=True), "step %d" % pos
+        tok = nxt
+    gm.close()

@@ -112,3 +112,14 @@ def test_empirical_frequencies_follow_the_probabilities():
         counts[t] = counts.get(t, 0) + 1
     for p, pr in zip(picks, probs):
         assert abs(counts.get(int(p), 0) / draws - pr) < 0.02
+
+
+def test_true_topk_candidates():
+    rng = np.random.default_rng(8)
+    for n, k, coarse in ((4096, 50, False), (4096, 50, True), (600, 7, True)):
+        lg = _bf16_logits(rng, n, coarse)
+        vals = O.bf16_to_f32(lg)
+        tok, picks, probs, npick = O.sample(lg, k, 0.9, 0.95, np.array([3], dtype=np.uint64), want_detail=True, true_topk=True)
+        want = sorted(range(n), key=lambda i: (-vals[i], i))[:k]          # k largest, ties to the lower index, ordered the same way
+        assert picks.tolist() == want
+        assert abs(probs.sum() - 1.0) < 1e-5 and tok in picks[:npick]
