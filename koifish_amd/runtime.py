@@ -250,14 +250,18 @@ class Context:
 class Qwen3:
     """The host-side Fish (koifish_amd/host/kf_host.cpp) for a Qwen3-shaped decoder."""
 
-    def __init__(self, cfg, device=0):
+    def __init__(self, cfg, device=0, own_stream=False):
+        """own_stream: this decoder launches on a HIP stream of its own (several decoders then overlap on the GPU); otherwise on the
+        device's shared stream."""
         self.hip, self.host = L.load()
         if not torch.cuda.is_available():
             raise L.KFError("no GPU visible: koifish_amd runs on MI355X only (no CPU fallback)")
         torch.cuda.set_device(device)
         self.cfg, self.device = dict(cfg), torch.device("cuda", device)
         rc = C.c_int(0)
-        self.h = self.host.kfh_create(device, C.c_void_p(stream(device).cuda_stream), cfg["dim"], cfg["n_layer"], cfg["n_head"], cfg["n_kv"],
+        shared = stream(device)
+        self._stream = torch.cuda.Stream(device=device) if own_stream else shared
+        self.h = self.host.kfh_create(device, C.c_void_p(self._stream.cuda_stream), cfg["dim"], cfg["n_layer"], cfg["n_head"], cfg["n_kv"],
                                       cfg["head_dim"], cfg["ffn"], cfg["vocab"], cfg["max_seq"], cfg.get("rms_eps", 1e-6), cfg.get("qk_eps", 1e-6),
                                       cfg.get("theta", 1e6), C.byref(rc))
         if not self.h:

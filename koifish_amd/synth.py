@@ -85,10 +85,10 @@ def build_from_raw(cfg, raw, layer_type=L.Q4, head_type=L.BF16, device=0, lGroup
     return m
 
 
-def build_on_gpu(cfg, seed=1234, layer_type=L.Q4, head_type=L.BF16, device=0, lGroup=128, w_std=0.02):
+def build_on_gpu(cfg, seed=1234, layer_type=L.Q4, head_type=L.BF16, device=0, lGroup=128, w_std=0.02, own_stream=False):
     """Full-size synthetic model drawn on the GPU (torch generator), quantised by kf_quantize."""
     ctx = Context(device)
-    m = Qwen3(cfg, device)
+    m = Qwen3(cfg, device, own_stream=own_stream)
     m._ctx = ctx
     g = torch.Generator(device=ctx.device)
     g.manual_seed(seed)
