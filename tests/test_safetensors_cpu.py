@@ -98,3 +98,29 @@ def test_missing_paths(host, tmp_path):
     assert not host.kfh_st_open(str(tmp_path / "nope.safetensors").encode(), 0)
     assert not host.kfh_st_open(str(tmp_path).encode(), 1)
     assert b"neither" in host.kfh_last_error()
+
+
+def test_reader_survives_mutated_headers(host, tmp_path):
+    """random byte flips / truncations of a valid file are either read consistently or refused -- never a crash or an out-of-file offset"""
+    import random
+    save_file({"a.weight": torch.ones(8, 8, dtype=torch.bfloat16), "b": torch.zeros(3, dtype=torch.float32)}, str(tmp_path / "ok.safetensors"))
+    good = (tmp_path / "ok.safetensors").read_bytes()
+    rnd = random.Random(7)
+    p = tmp_path / "mut.safetensors"
+    for trial in range(300):
+        b = bytearray(good)
+        kind = trial % 3
+        if kind == 0:
+            for _ in range(rnd.randint(1, 4)):
+                b[rnd.randrange(len(b))] = rnd.randrange(256)
+        elif kind == 1:
+            b = b[:rnd.randrange(1, len(b))]
+        else:
+            i = rnd.randrange(8, len(b))
+            b[i:i] = bytes(rnd.randrange(256) for _ in range(rnd.randint(1, 16)))
+        p.write_bytes(bytes(b))
+        h = host.kfh_st_open(str(p).encode(), 0)
+        if h:
+            for name, (dt, shape, b0, b1) in _list(host, C.c_void_p(h)).items():
+                assert b0 <= b1 <= len(b)
+            host.kfh_st_close(C.c_void_p(h))
