@@ -25,7 +25,7 @@ def _list(host, h):
         shape = (C.c_int64 * 4)()
         nd, b, e = C.c_int(0), C.c_uint64(0), C.c_uint64(0)
         assert host.kfh_st_info(h, i, name, 256, dt, 16, shape, C.byref(nd), C.byref(b), C.byref(e)) == 0
-        out[name.value.decode()] = (dt.value.decode(), tuple(shape[:nd.value]), b.value, e.value)
+        out[name.value.decode(errors="replace")] = (dt.value.decode(errors="replace"), tuple(shape[:nd.value]), b.value, e.value)
     return out
 
 
