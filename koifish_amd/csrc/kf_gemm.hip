@@ -21,91 +21,9 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "kf_kernels.h"
+#include "kf_gemm_common.h"
 
 namespace kf {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int GM_TOK = 128;         /* tokens per workgroup tile (4 MFMA column blocks) */
-constexpr int GM_KT = 128;          /* k per staged x tile */
-constexpr int GM_XS = GM_KT + 8;    /* padded LDS row in bf16 elements: 272 B, ds_read_b128 of 32 rows is conflict-free */
-
-struct GemmArgs {
-    const unsigned char* w;
-    const uint16_t* zero;
-    const uint16_t* step;
-    float qBias;
-    int M, K, nBlk, gshift;
-    const uint16_t* x;
-    long long ldx;
-    int n;
-    uint16_t* y;
-    long long ldy;
-    const uint16_t* bias;
-    const uint16_t* residual;
-    long long ldr;
-    float alpha, beta;
-    // direct kernel only: further weights sharing x and K -- jobs 1, 2 of one launch (Q/K/V), or the `up` matrix of a paired SwiGLU launch
-    int njobs;      /* 1..3 */
-    int rb_end[3];  /* cumulative count of 32-row blocks per job */
-    const unsigned char* xw[2];
-    const uint16_t* xzero[2];
-    const uint16_t* xstep[2];
-    float xqBias[2];
-    int xM[2];
-    uint16_t* xy[2];
-    long long xldy[2];
-};
-
-// ---- 8 consecutive weights -> 4 packed bf16 pairs (element 2i in the low half of word i)
-__device__ __forceinline__ u32x4 frag_q4(uint32_t D, float step, float step16, float nb, float zero) {
-    uint32_t H = D & 0xF0F0F0F0u, L = D & 0x0F0F0F0Fu;
-    asm("" : "+v"(H)); /* opaque masks keep the byte extractions as v_cvt_f32_ubyteN (see kf_gemv.hip) */
-    asm("" : "+v"(L));
-    u32x4 o;
-    uint32_t r;
-    r = pack_bf16x2(fmaf((float)(H >> 24), step16, nb), fmaf((float)(L >> 24), step, nb));
-    o.x = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
-    r = pack_bf16x2(fmaf((float)((H >> 16) & 0xffu), step16, nb), fmaf((float)((L >> 16) & 0xffu), step, nb));
-    o.y = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
-    r = pack_bf16x2(fmaf((float)((H >> 8) & 0xffu), step16, nb), fmaf((float)((L >> 8) & 0xffu), step, nb));
-    o.z = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
-    r = pack_bf16x2(fmaf((float)(H & 0xffu), step16, nb), fmaf((float)(L & 0xffu), step, nb));
-    o.w = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
-    return o;
-}
-// 16 bits, element 0 in bits 15..14
-__device__ __forceinline__ u32x4 frag_q2(uint32_t v, float step, float nb, float zero) {
-    uint32_t o[4];
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-        const float q0 = (float)((v >> (14 - 4 * p)) & 3u), q1 = (float)((v >> (12 - 4 * p)) & 3u);
-        const uint32_t r = pack_bf16x2(fmaf(q0, step, nb), fmaf(q1, step, nb));
-        o[p] = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
-    }
-    return u32x4{o[0], o[1], o[2], o[3]};
-}
-// 8 bits, element 0 in bit 7; w0 / w1 = dequant(0) / dequant(1) as bf16 bit patterns
-__device__ __forceinline__ u32x4 frag_q1(uint32_t b, uint32_t w0, uint32_t w1) {
-    uint32_t o[4];
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-        const uint32_t lo = ((b >> (7 - 2 * p)) & 1u) ? w1 : w0, hi = ((b >> (6 - 2 * p)) & 1u) ? w1 : w0;
-        o[p] = lo | (hi << 16);
-    }
-    return u32x4{o[0], o[1], o[2], o[3]};
-}
-// 8 f8e5m2 bytes (element i = byte i): value = half(byte << 8), exact in bf16
-__device__ __forceinline__ u32x4 frag_f8(uint32_t D0, uint32_t D1) {
-    u32x4 o;
-    o.x = pack_bf16x2(half_bits_to_f32((D0 << 8) & 0xff00u), half_bits_to_f32(D0 & 0xff00u));
-    o.y = pack_bf16x2(half_bits_to_f32((D0 >> 8) & 0xff00u), half_bits_to_f32((D0 >> 16) & 0xff00u));
-    o.z = pack_bf16x2(half_bits_to_f32((D1 << 8) & 0xff00u), half_bits_to_f32(D1 & 0xff00u));
-    o.w = pack_bf16x2(half_bits_to_f32((D1 >> 8) & 0xff00u), half_bits_to_f32((D1 >> 16) & 0xff00u));
-    return o;
-}
 
 // ---- the weights one lane needs for one staged tile: NS = 8 / KS MFMA steps
 // step sl of wave-half ks: elements [koff, koff + 8) of the 128-wide tile
@@ -237,9 +155,6 @@ __device__ __forceinline__ u32x4 get_frag(const WTile<FMT, KS>& t, int sl, const
     else
         return t.frag(sl, a);
 }
-
-template <int TB>
-__device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[TB], const GemmArgs& a, int tok0, int row_base, int r, int h);
 
 template <int FMT, int KS>
 __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs a) {
@@ -509,45 +424,6 @@ __global__ void __launch_bounds__(NW * 64) gemm_direct_kernel(const GemmArgs a0)
     }
 }
 
-// ---- epilogue: lane holds token (tb*32 + r), rows row_base + 8g + 4h + j
-template <int TB>
-__device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[TB], const GemmArgs& a, int tok0, int row_base, int r, int h) {
-    const bool vec_ok = ((a.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 7) == 0);
-#pragma unroll
-    for (int tb = 0; tb < TB; tb++) {
-        const int tok = tok0 + tb * 32 + r;
-        if (tok >= a.n) continue;
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const int rg = row_base + 8 * g + 4 * h;
-            if (rg >= a.M) continue;
-            uint16_t* yp = a.y + (size_t)tok * a.ldy + rg;
-            uint16_t o[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                float v = acc[tb][4 * g + j];
-                if (rg + j < a.M) {
-                    if (a.alpha != 1.0f) v = a.alpha * v;
-                    if (a.beta != 0.0f) v = v + a.beta * bf2f(yp[j]);
-                    if (a.bias) v = v + bf2f(a.bias[rg + j]);
-                    uint16_t q = f2bf(v);
-                    if (a.residual) q = f2bf(bf2f(a.residual[(size_t)tok * a.ldr + rg + j]) + bf2f(q));
-                    o[j] = q;
-                } else {
-                    o[j] = 0;
-                }
-            }
-            if (vec_ok && rg + 3 < a.M) {
-                *reinterpret_cast<u32x2*>(yp) = u32x2{(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16)};
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (rg + j < a.M) yp[j] = o[j];
-            }
-        }
-    }
-}
-
 static int gm_fmt_of(int type) {
     switch (type) {
         case KF_BF16: return FMT_BF16;
@@ -690,6 +566,8 @@ int gemm_launch(hipStream_t st, const kf_weight* w, const uint16_t* x, long long
         KS = 0;
         grid = dim3((M + 31) / 32, (n + 31) / 32);
     } else {
+        const int rc2 = gemm2_launch(st, g.fmt, a); /* large batches: the producer / consumer tile kernel when it applies */
+        if (rc2 != 1) return rc2;
         const int rows_per_wg = 32 * (4 / KS);
         grid = dim3((M + rows_per_wg - 1) / rows_per_wg, ttiles);
     }
