@@ -203,8 +203,10 @@ template <int G, bool PAIRED>
 struct Batch {
     u32x4 w[G];
     u32x4 w2[PAIRED ? G : 1];
-    float st[G], ze[G];
-    float st2[PAIRED ? G : 1], ze2[PAIRED ? G : 1];
+    // zero / step stay raw bf16 bits until the block is multiplied: converted when loaded, the shift makes the wave wait for the loads it has
+    // just issued (s_waitcnt vmcnt right behind the prefetch) instead of overlapping them with the current batch's arithmetic
+    uint16_t st[G], ze[G];
+    uint16_t st2[PAIRED ? G : 1], ze2[PAIRED ? G : 1];
 };
 
 // LDS: x as u32x4 chunks [XCH][nBlk] (K*2 bytes) | 256 B reduction scratch.
@@ -260,16 +262,16 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
             int row;
             const bool ok = slot(s0 + g, row) && (col < nBlk);
             b.w[g] = u32x4{0, 0, 0, 0};
-            b.st[g] = b.ze[g] = 0.f;
-            if (PAIRED) b.w2[g] = u32x4{0, 0, 0, 0}, b.st2[g] = b.ze2[g] = 0.f;
+            b.st[g] = b.ze[g] = 0;
+            if (PAIRED) b.w2[g] = u32x4{0, 0, 0, 0}, b.st2[g] = b.ze2[g] = 0;
             if (ok) {
                 const uint32_t bidx = (uint32_t)row * (uint32_t)nBlk + (uint32_t)col; /* < 2^32 blocks = 64 GiB per tensor */
                 b.w[g] = ld_nt(jw + bidx);
                 if (PAIRED) b.w2[g] = ld_nt(jw2 + bidx);
                 if (BD::HAS_GAMA) {
                     const uint32_t gi = bidx >> gshift; /* group = element / lGroup, lGroup / EPB a power of two */
-                    b.st[g] = bf2f(jstep[gi]), b.ze[g] = bf2f(jzero[gi]);
-                    if (PAIRED) b.st2[g] = bf2f(a.job[1].step[gi]), b.ze2[g] = bf2f(a.job[1].zero[gi]);
+                    b.st[g] = jstep[gi], b.ze[g] = jzero[gi];
+                    if (PAIRED) b.st2[g] = a.job[1].step[gi], b.ze2[g] = a.job[1].zero[gi];
                 }
             }
         }
@@ -369,8 +371,12 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
             if (col >= nBlk) col = nBlk - 1; /* masked lanes carry zero weights; keep their LDS reads in range */
 #pragma unroll
             for (int g = 0; g < G; g++) {
-                acc[g] = BD::run(cur.w[g], xs, col, nBlk, cur.st[g], cur.ze[g], -(jqb * cur.st[g]), acc[g]);
-                if (PAIRED) acc2[g] = BD::run(cur.w2[g], xs, col, nBlk, cur.st2[g], cur.ze2[g], -(jqb2 * cur.st2[g]), acc2[g]);
+                const float st = bf2f(cur.st[g]);
+                acc[g] = BD::run(cur.w[g], xs, col, nBlk, st, bf2f(cur.ze[g]), -(jqb * st), acc[g]);
+                if (PAIRED) {
+                    const float st2 = bf2f(cur.st2[g]);
+                    acc2[g] = BD::run(cur.w2[g], xs, col, nBlk, st2, bf2f(cur.ze2[g]), -(jqb2 * st2), acc2[g]);
+                }
             }
         }
         if (it == iters - 1) {
