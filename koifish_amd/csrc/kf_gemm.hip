@@ -35,7 +35,8 @@ template <int KS>
 struct WTile<FMT_Q4, KS> {
     static constexpr int NP = 2 / KS;
     u32x4 b[NP];
-    float st[NP], ze[NP];
+    uint16_t st[NP], ze[NP]; /* raw bf16 bits: converted at use, so that nothing waits on the loads right behind their issue */
+    bool in[NP];
     __device__ __forceinline__ void load(const GemmArgs& a, int row, int it, int h, int ks) {
 #pragma unroll
         for (int p = 0; p < NP; p++) {
@@ -47,15 +48,15 @@ struct WTile<FMT_Q4, KS> {
             const uint32_t bidx = (uint32_t)row * (uint32_t)a.nBlk + (uint32_t)bi;
             b[p] = ld_nt(reinterpret_cast<const u32x4*>(a.w) + bidx);
             const uint32_t gi = bidx >> a.gshift;
-            st[p] = in_row ? bf2f(a.step[gi]) : 0.f, ze[p] = in_row ? bf2f(a.zero[gi]) : 0.f;
+            st[p] = a.step[gi], ze[p] = a.zero[gi], in[p] = in_row;
         }
     }
     static __device__ __forceinline__ int koff(int sl, int h, int ks) { return (2 * (ks * NP + (sl >> 2)) + h) * 32 + 8 * (sl & 3); }
     __device__ __forceinline__ u32x4 frag(int sl, const GemmArgs& a) const {
         const int p = sl >> 2, c = sl & 3;
         const uint32_t D = c == 0 ? b[p].w : (c == 1 ? b[p].z : (c == 2 ? b[p].y : b[p].x));
-        const float s = st[p];
-        return frag_q4(D, s, s * 0.0625f, -a.qBias * s, ze[p]);
+        const float s = in[p] ? bf2f(st[p]) : 0.f, z = in[p] ? bf2f(ze[p]) : 0.f;
+        return frag_q4(D, s, s * 0.0625f, -a.qBias * s, z);
     }
 };
 template <int KS>
@@ -109,12 +110,12 @@ template <int KS>
 struct WTile<FMT_Q2, KS> {
     static constexpr int NS = 8 / KS;
     u32x4 b;
-    float st, ze;
+    uint16_t st, ze;
     __device__ __forceinline__ void load(const GemmArgs& a, int row, int it, int h, int) {
         const uint32_t bidx = (uint32_t)row * (uint32_t)a.nBlk + (uint32_t)(it * 2 + h);
         b = ld_nt(reinterpret_cast<const u32x4*>(a.w) + bidx);
         const uint32_t gi = bidx >> a.gshift;
-        st = bf2f(a.step[gi]), ze = bf2f(a.zero[gi]);
+        st = a.step[gi], ze = a.zero[gi];
     }
     static __device__ __forceinline__ int koff(int sl, int h, int ks) { return 64 * h + 8 * (ks * NS + sl); }
     __device__ __forceinline__ u32x4 frag(int sl, const GemmArgs& a, int ks) const {
@@ -122,7 +123,8 @@ struct WTile<FMT_Q2, KS> {
         uint32_t D = dw[sl >> 1];
         if (KS == 2) D = ks ? dw[2 + (sl >> 1)] : D;
         const uint32_t v = (sl & 1) ? (D & 0xffffu) : (D >> 16);
-        return frag_q2(v, st, -a.qBias * st, ze);
+        const float s = bf2f(st);
+        return frag_q2(v, s, -a.qBias * s, bf2f(ze));
     }
 };
 // 1-bit: the staged tile is one 128-element block, lane half h owns its 8-byte half (elements 64h .. 64h+63)
@@ -130,21 +132,21 @@ template <int KS>
 struct WTile<FMT_Q1, KS> {
     static constexpr int NS = 8 / KS;
     u32x2 b; /* b.y: first 32 elements of the half, b.x: next 32 */
-    uint32_t w0, w1;
+    uint16_t st, ze;
     __device__ __forceinline__ void load(const GemmArgs& a, int row, int it, int h, int) {
         const uint32_t bidx = (uint32_t)row * (uint32_t)a.nBlk + (uint32_t)it;
         b = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(a.w) + (size_t)bidx * 2 + (1 - h));
         const uint32_t gi = bidx >> a.gshift;
-        const float st = bf2f(a.step[gi]), ze = bf2f(a.zero[gi]), nb = -a.qBias * st;
-        const uint32_t r = pack_bf16x2(fmaf(0.0f, st, nb), fmaf(1.0f, st, nb));
-        const uint32_t ww = pack_bf16x2(bf_lo(r) - ze, bf_hi(r) - ze);
-        w0 = ww & 0xffffu, w1 = ww >> 16;
+        st = a.step[gi], ze = a.zero[gi];
     }
     static __device__ __forceinline__ int koff(int sl, int h, int ks) { return 64 * h + 8 * (ks * NS + sl); }
-    __device__ __forceinline__ u32x4 frag(int sl, const GemmArgs&, int ks) const {
+    __device__ __forceinline__ u32x4 frag(int sl, const GemmArgs& a, int ks) const {
         const uint32_t D = (KS == 2) ? (ks ? b.x : b.y) : ((sl >> 2) ? b.x : b.y);
         const uint32_t byte = (D >> (24 - 8 * (sl & 3))) & 0xffu;
-        return frag_q1(byte, w0, w1);
+        const float s = bf2f(st), z = bf2f(ze), nb = -a.qBias * s; /* dequant(0), dequant(1): loop-invariant, hoisted by the compiler */
+        const uint32_t r = pack_bf16x2(fmaf(0.0f, s, nb), fmaf(1.0f, s, nb));
+        const uint32_t ww = pack_bf16x2(bf_lo(r) - z, bf_hi(r) - z);
+        return frag_q1(byte, ww & 0xffffu, ww >> 16);
     }
 };
 
