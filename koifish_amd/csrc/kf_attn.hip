@@ -33,19 +33,44 @@ __device__ __forceinline__ float group_sum16(float v, int lg) {
     if (lg >= 4) v += dpp_f<0x140>(v);
     return v;
 }
+// sums over lanes l ^ 32 and l ^ 16 without LDS (gfx950 row swaps: with both operands equal the two results are the two halves /
+// row pairs broadcast, so their sum is the butterfly sum in every lane)
+__device__ __forceinline__ float xsum32(float v) {
+    const uint32_t u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xsum16(float v) {
+    const uint32_t u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// One head as loaded (raw bf16 bits, so that the loads can be issued long before their use): lane j holds the pair (j, j + hd/2)
+struct HeadRaw {
+    uint16_t x0, x1, w0, w1;
+};
+__device__ __forceinline__ HeadRaw load_head(const uint16_t* __restrict__ src, const uint16_t* __restrict__ wn, int hd) {
+    const int j = threadIdx.x & 63, half = hd >> 1;
+    HeadRaw r{0, 0, 0x3f80, 0x3f80};
+    if (j < half) {
+        r.x0 = src[j], r.x1 = src[j + half];
+        if (wn) r.w0 = wn[j], r.w1 = wn[j + half];
+    }
+    return r;
+}
 // Prepare one head: optional per-head RMSNorm (s rounded to bf16 first, then (a*s)*w, RN store) and rotate-half
 // RoPE from the host-built (cos,sin) table.  One wave per head; lane j handles the pair (j, j + hd/2).
 // Result: bf16-rounded values as floats in dst[hd].
-__device__ __forceinline__ void prep_head(const uint16_t* __restrict__ src, const uint16_t* __restrict__ wn, const float* __restrict__ tab_pos,
-                                          int hd, float eps, float* dst) {
+__device__ __forceinline__ void prep_head(const HeadRaw r, bool norm, const float* __restrict__ tab_pos, int hd, float eps, float* dst) {
     const int lane = threadIdx.x & 63, half = hd >> 1;
     const int j = lane; /* hd <= 128: one trip covers the head */
     const bool act = j < half;
-    float x0 = act ? bf2f(src[j]) : 0.f, x1 = act ? bf2f(src[j + half]) : 0.f;
-    float w0 = 1.f, w1 = 1.f, c = 1.f, sn = 0.f;
-    if (wn && act) w0 = bf2f(wn[j]), w1 = bf2f(wn[j + half]);
+    float c = 1.f, sn = 0.f;
     if (tab_pos && act) c = tab_pos[2 * j], sn = tab_pos[2 * j + 1];
-    if (wn) {
+    float x0 = bf2f(r.x0), x1 = bf2f(r.x1);
+    if (norm) {
+        const float w0 = bf2f(r.w0), w1 = bf2f(r.w1);
         const double ss = wave_sum_f64_fast(fma((double)x0, (double)x0, (double)x1 * (double)x1));
         const float s0 = 1.0f / sqrtf((float)ss / (float)hd + eps);
         const float s = round_bf16(s0);
@@ -78,7 +103,7 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
     float* wmax = knew + hd;                         // [NW][GQ]
     float* mrg = wmax + NW * GQ;                      // [3][GQ][KF_ATTN_MAX_SPLITS]  (m, l, scale of every slice)
     int* flag = reinterpret_cast<int*>(mrg + 3 * GQ * KF_ATTN_MAX_SPLITS);
-    float* comb = reinterpret_cast<float*>(flag + 4);  // [4*KPW][GQ][PS]
+    float* comb = reinterpret_cast<float*>(flag + 4);  // [NW][GQ][PS]
 
     const int split = blockIdx.x, kvh = blockIdx.y, nsp = a.n_splits;
     // token batch (prefill): blockIdx.z = token, one slice per kv-head, position pos0 + token, q / out rows q_stride apart
@@ -116,6 +141,16 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
         if (tb_end > pos_l + 1) tb_end = pos_l + 1; /* a.pos is the launch bound here */
         issue(tstart, tb_end);
     }
+    // ... and the q heads (+ the raw new key) this wave will prepare: they do not depend on the position either
+    constexpr int NQ = (GQ + NW - 1) / NW;
+    const bool qnorm = a.rope_table && a.wq_norm;
+    HeadRaw qraw[NQ], kraw{};
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        const int hq = wave + i * NW;
+        qraw[i] = load_head(qsrc + (size_t)(h0 + (hq < GQ ? hq : 0)) * hd, qnorm ? a.wq_norm : nullptr, hd);
+    }
+    if (has_new && wave == (GQ % NW)) kraw = load_head(a.k_raw + (size_t)kvh * hd, a.wk_norm, hd);
 
     const int pos = a.d_pos ? *a.d_pos : pos_l;
     const int len = pos + 1;
@@ -128,10 +163,11 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
     if (!empty) {
         // ---- prologue: q heads of this group, and the new key when it lies in this slice
         const float* tab_pos = a.rope_table ? a.rope_table + (size_t)pos * hd : nullptr;
-        for (int hq = wave; hq < GQ; hq += NW)
-            prep_head(qsrc + (size_t)(h0 + hq) * hd, a.rope_table ? a.wq_norm : nullptr, tab_pos, hd, a.eps, qf + hq * hd);
+#pragma unroll
+        for (int i = 0; i < NQ; i++)
+            if (wave + i * NW < GQ) prep_head(qraw[i], qnorm, tab_pos, hd, a.eps, qf + (wave + i * NW) * hd);
         const bool own_new = has_new && (pos >= t0) && (pos < t1);
-        if (own_new && wave == (GQ % NW)) prep_head(a.k_raw + (size_t)kvh * hd, a.wk_norm, tab_pos, hd, a.eps, knew);
+        if (own_new && wave == (GQ % NW)) prep_head(kraw, a.wk_norm != nullptr, tab_pos, hd, a.eps, knew);
         __syncthreads();
         if (own_new) {
             uint16_t* krow = a.kcache + (size_t)pos * a.kv_stride + (size_t)kvh * hd;
@@ -226,20 +262,34 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
             }
         }
 
-        // ---- sum the 4*KPW key groups of this workgroup (same reference maximum everywhere: plain sums)
-        const int slot = wave * KPW + grp, nslot = NW * KPW;
+        // ---- sum the key groups: inside the wave by row swaps (same reference maximum everywhere: plain sums), across waves in LDS
 #pragma unroll
         for (int hq = 0; hq < GQ; hq++) {
-            float* c = comb + ((size_t)slot * GQ + hq) * PS;
 #pragma unroll
-            for (int i = 0; i < 8; i++) c[d0 + i] = acc[hq][i];
-            if (d0 == 0) c[hd] = l[hq];
+            for (int i = 0; i < 8; i++) {
+                float v = xsum16(xsum32(acc[hq][i]));
+                if (LPK < 16) v += dpp_f<0x128>(v); /* row_ror:8 */
+                acc[hq][i] = v;
+            }
+            float v = xsum16(xsum32(l[hq]));
+            if (LPK < 16) v += dpp_f<0x128>(v);
+            l[hq] = v;
+        }
+        if (grp == 0) {
+#pragma unroll
+            for (int hq = 0; hq < GQ; hq++) {
+                float* c = comb + ((size_t)wave * GQ + hq) * PS;
+                *reinterpret_cast<f32x4*>(c + d0) = f32x4{acc[hq][0], acc[hq][1], acc[hq][2], acc[hq][3]};
+                *reinterpret_cast<f32x4*>(c + d0 + 4) = f32x4{acc[hq][4], acc[hq][5], acc[hq][6], acc[hq][7]};
+                if (d0 == 0) c[hd] = l[hq];
+            }
         }
         __syncthreads();
         for (int i = tid; i < GQ * hd; i += blockDim.x) {
             const int hq = i / hd, d = i - hq * hd;
             float o = 0.f, L = 0.f;
-            for (int sl = 0; sl < nslot; sl++) {
+#pragma unroll
+            for (int sl = 0; sl < NW; sl++) {
                 const float* c = comb + ((size_t)sl * GQ + hq) * PS;
                 o += c[d];
                 L += c[hd];
@@ -333,7 +383,7 @@ __global__ void __launch_bounds__(64) qknorm_rope_kernel(uint16_t* q, uint16_t* 
     const int b = blockIdx.x;
     uint16_t* src = b < n_head ? q + (size_t)blockIdx.y * q_stride + (size_t)b * hd : k + (size_t)blockIdx.y * k_stride + (size_t)(b - n_head) * hd;
     const uint16_t* wn = b < n_head ? wq : wk;
-    prep_head(src, wn, table ? table + (size_t)pos * hd : nullptr, hd, eps, buf);
+    prep_head(load_head(src, wn, hd), wn != nullptr, table ? table + (size_t)pos * hd : nullptr, hd, eps, buf);
     __syncthreads();
     for (int i = threadIdx.x; i < hd; i += 64) src[i] = f2bf(buf[i]);
 }
@@ -373,10 +423,9 @@ int attn_launch(hipStream_t st, AttnArgs& a) {
     a.n_splits = nsp;
     a.chunk = (pos_max + 1 + nsp - 1) / nsp;
     a.inv_sqrt_hd_den = sqrtf((float)hd);
-    const int KPW = 64 / (hd >> 3);
     // 8 waves per workgroup while the per-slot combine buffer fits comfortably in LDS (GQ <= 2), else 4
     const int NW = (GQ <= 2 && pos_max >= 256) ? 8 : 4; /* measured: 4 waves win below ~256 keys, 8 above; 16 lose everywhere */
-    const size_t smem = sizeof(float) * ((size_t)GQ * hd + hd + NW * GQ + 3 * GQ * KF_ATTN_MAX_SPLITS + 4 + (size_t)NW * KPW * GQ * (hd + 4));
+    const size_t smem = sizeof(float) * ((size_t)GQ * hd + hd + NW * GQ + 3 * GQ * KF_ATTN_MAX_SPLITS + 4 + (size_t)NW * GQ * (hd + 4));
     dim3 grid(nsp, a.n_kv, a.n_tok);
     switch (GQ) {
         case 1: if (NW == 8) hipLaunchKernelGGL((attn_kernel<1, 8>), grid, dim3(512), smem, st, a); else hipLaunchKernelGGL((attn_kernel<1, 4>), grid, dim3(256), smem, st, a); break;

@@ -6,6 +6,7 @@
 namespace kf {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
