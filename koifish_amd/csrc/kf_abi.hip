@@ -351,7 +351,7 @@ int kf_qknorm_rope(kf_ctx* c, kf_bf16* q, kf_bf16* k, const kf_bf16* wq, const k
 }
 
 static size_t attn_part_bytes(int n_head, int hd) { return sizeof(float) * (size_t)n_head * kf::KF_ATTN_MAX_SPLITS * (hd + 4); }
-size_t kf_attn_scratch_bytes(int n_head, int hd) { return attn_part_bytes(n_head, hd) + 1024; /* + arrival counters */ }
+size_t kf_attn_scratch_bytes(int n_head, int hd) { return attn_part_bytes(n_head, hd) + kf::KF_ATTN_CNT_BYTES; /* + arrival counters */ }
 
 int kf_attn_decode(kf_ctx* c, const kf_bf16* q, const kf_bf16* kc, const kf_bf16* vc, kf_bf16* out, int pos, const int32_t* d_pos, int n_head, int n_kv, int hd,
                    int kv_stride, void* scratch) {
@@ -360,9 +360,9 @@ int kf_attn_decode(kf_ctx* c, const kf_bf16* q, const kf_bf16* kc, const kf_bf16
     if (!al16(kc) || !al16(vc) || (kv_stride % 8)) return fail(KF_BLAS_UNALIGN, "kf_attn_decode: cache not 16-byte aligned");
     kf::AttnArgs a;
     memset(&a, 0, sizeof(a));
-    a.q = q, a.kcache = const_cast<kf_bf16*>(kc), a.vcache = vc, a.out = out, a.part = (float*)((char*)scratch + 1024);
+    a.q = q, a.kcache = const_cast<kf_bf16*>(kc), a.vcache = vc, a.out = out, a.part = (float*)((char*)scratch + kf::KF_ATTN_CNT_BYTES);
     a.pos = pos, a.d_pos = d_pos, a.n_head = n_head, a.n_kv = n_kv, a.hd = hd, a.kv_stride = kv_stride;
-    a.counters = (int*)scratch; /* the first 1024 bytes: arrival counters (fixed place whatever the shape) */
+    a.counters = (int*)scratch; /* the first KF_ATTN_CNT_BYTES: arrival counters (fixed place whatever the shape) */
     RET(kf::attn_launch(c->stream, a));
 }
 
@@ -373,7 +373,7 @@ int kf_attn_block(kf_ctx* c, const kf_bf16* q_raw, const kf_bf16* k_raw, kf_bf16
     if (!al16(kc) || !al16(vc) || (kv_stride % 8)) return fail(KF_BLAS_UNALIGN, "kf_attn_block: cache not 16-byte aligned");
     kf::AttnArgs a;
     memset(&a, 0, sizeof(a));
-    a.q = q_raw, a.k_raw = k_raw, a.kcache = kc, a.vcache = vc, a.out = out, a.part = (float*)((char*)scratch + 1024);
+    a.q = q_raw, a.k_raw = k_raw, a.kcache = kc, a.vcache = vc, a.out = out, a.part = (float*)((char*)scratch + kf::KF_ATTN_CNT_BYTES);
     a.wq_norm = wq, a.wk_norm = wk, a.rope_table = table, a.eps = eps;
     a.pos = pos, a.d_pos = d_pos, a.n_head = n_head, a.n_kv = n_kv, a.hd = hd, a.kv_stride = kv_stride;
     a.counters = (int*)scratch;

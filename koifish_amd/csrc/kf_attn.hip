@@ -33,19 +33,6 @@ __device__ __forceinline__ float group_sum16(float v, int lg) {
     if (lg >= 4) v += dpp_f<0x140>(v);
     return v;
 }
-// sums over lanes l ^ 32 and l ^ 16 without LDS (gfx950 row swaps: with both operands equal the two results are the two halves /
-// row pairs broadcast, so their sum is the butterfly sum in every lane)
-__device__ __forceinline__ float xsum32(float v) {
-    const uint32_t u = __float_as_uint(v);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float xsum16(float v) {
-    const uint32_t u = __float_as_uint(v);
-    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
 // One head as loaded (raw bf16 bits, so that the loads can be issued long before their use): lane j holds the pair (j, j + hd/2)
 struct HeadRaw {
     uint16_t x0, x1, w0, w1;
@@ -61,8 +48,8 @@ __device__ __forceinline__ HeadRaw load_head(const uint16_t* __restrict__ src, c
 }
 // Prepare one head: optional per-head RMSNorm (s rounded to bf16 first, then (a*s)*w, RN store) and rotate-half
 // RoPE from the host-built (cos,sin) table.  One wave per head; lane j handles the pair (j, j + hd/2).
-// Result: bf16-rounded values as floats in dst[hd].
-__device__ __forceinline__ void prep_head(const HeadRaw r, bool norm, const float* __restrict__ tab_pos, int hd, float eps, float* dst) {
+// Result: bf16 bits in dst[hd].
+__device__ __forceinline__ void prep_head(const HeadRaw r, bool norm, const float* __restrict__ tab_pos, int hd, float eps, uint16_t* dst) {
     const int lane = threadIdx.x & 63, half = hd >> 1;
     const int j = lane; /* hd <= 128: one trip covers the head */
     const bool act = j < half;
@@ -82,7 +69,7 @@ __device__ __forceinline__ void prep_head(const HeadRaw r, bool norm, const floa
         x0 = round_bf16(a - b);
         x1 = round_bf16(cc + d);
     }
-    if (act) dst[j] = x0, dst[j + half] = x1;
+    if (act) dst[j] = f2bf(x0), dst[j + half] = f2bf(x1);
 }
 
 // e^x for x <= 0 through the hardware exp2 (v_exp_f32); exp2(-inf) = 0
@@ -97,12 +84,12 @@ template <int GQ, int NW>
 __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int hd = a.hd, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hd_log2 = 31 - __builtin_clz(hd);
     const int PS = hd + 4; /* {acc[hd], m, l, pad, pad} */
-    float* qf = reinterpret_cast<float*>(smem_raw);  // [GQ][hd]
-    float* knew = qf + GQ * hd;                      // [hd]
-    float* wmax = knew + hd;                         // [NW][GQ]
-    float* mrg = wmax + NW * GQ;                      // [3][GQ][KF_ATTN_MAX_SPLITS]  (m, l, scale of every slice)
-    int* flag = reinterpret_cast<int*>(mrg + 3 * GQ * KF_ATTN_MAX_SPLITS);
+    uint16_t* qb = reinterpret_cast<uint16_t*>(smem_raw);  // [GQ][hd] prepared q, bf16 bits
+    uint16_t* knew = qb + GQ * hd;                         // [hd]
+    float* wmax = reinterpret_cast<float*>(knew + hd);     // [NW][GQ]
+    int* flag = reinterpret_cast<int*>(wmax + NW * GQ);
     float* comb = reinterpret_cast<float*>(flag + 4);  // [NW][GQ][PS]
 
     const int split = blockIdx.x, kvh = blockIdx.y, nsp = a.n_splits;
@@ -114,9 +101,9 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
     const int t0 = split * chunk;
     const int h0 = kvh * GQ;
 
-    // LPK lanes per key (8 dims each), KPW keys per wave step, 4 waves interleaved over the slice
+    // LPK lanes per key (8 dims each), KPW keys per wave step, the waves interleaved over the slice
     const int LPK = hd >> 3, KPW = 64 / LPK, lpk_log2 = __builtin_ctz(LPK);
-    const int grp = lane / LPK, d0 = (lane - grp * LPK) * 8;
+    const int grp = lane >> lpk_log2, d0 = (lane & (LPK - 1)) * 8;
     const bool has_new = a.k_raw != nullptr;
     const int tstart = t0 + wave * KPW + grp, tstride = NW * KPW;
 
@@ -131,8 +118,8 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
             kk[u] = u32x4{0, 0, 0, 0}, vv[u] = u32x4{0, 0, 0, 0};
             if (t < tend) {
                 const size_t off = (size_t)t * a.kv_stride + (size_t)kvh * hd + d0;
-                vv[u] = *reinterpret_cast<const u32x4*>(a.vcache + off);
                 kk[u] = *reinterpret_cast<const u32x4*>(a.kcache + off);
+                vv[u] = *reinterpret_cast<const u32x4*>(a.vcache + off);
             }
         }
     };
@@ -158,27 +145,22 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
     if (t1 > len) t1 = len;
     const bool empty = t0 >= len;
 
-    float o_fin = 0.f, M_fin = -__builtin_inff(), L_fin = 0.f; /* this workgroup's partial: thread i = (hq, d) */
-
     if (!empty) {
         // ---- prologue: q heads of this group, and the new key when it lies in this slice
         const float* tab_pos = a.rope_table ? a.rope_table + (size_t)pos * hd : nullptr;
 #pragma unroll
         for (int i = 0; i < NQ; i++)
-            if (wave + i * NW < GQ) prep_head(qraw[i], qnorm, tab_pos, hd, a.eps, qf + (wave + i * NW) * hd);
+            if (wave + i * NW < GQ) prep_head(qraw[i], qnorm, tab_pos, hd, a.eps, qb + (wave + i * NW) * hd);
         const bool own_new = has_new && (pos >= t0) && (pos < t1);
         if (own_new && wave == (GQ % NW)) prep_head(kraw, a.wk_norm != nullptr, tab_pos, hd, a.eps, knew);
         __syncthreads();
         if (own_new) {
             uint16_t* krow = a.kcache + (size_t)pos * a.kv_stride + (size_t)kvh * hd;
-            for (int i = tid; i < hd; i += blockDim.x) krow[i] = f2bf(knew[i]);
+            for (int i = tid; i < hd; i += blockDim.x) krow[i] = knew[i];
         }
-
-        float qreg[GQ][8];
+        u32x4 qreg[GQ]; /* this lane's 8 dims of every q head, packed bf16 */
 #pragma unroll
-        for (int hq = 0; hq < GQ; hq++)
-#pragma unroll
-            for (int i = 0; i < 8; i++) qreg[hq][i] = qf[hq * hd + d0 + i];
+        for (int hq = 0; hq < GQ; hq++) qreg[hq] = *reinterpret_cast<const u32x4*>(qb + hq * hd + d0);
 
         float M[GQ], l[GQ], acc[GQ][8];
 #pragma unroll
@@ -201,19 +183,14 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
             for (int u = 0; u < ATTN_U; u++) {
                 const int t = tb + u * tstride;
                 const bool valid = t < t1;
-                float kf_[8];
-                const uint32_t kw[4] = {ck[u].x, ck[u].y, ck[u].z, ck[u].w};
-#pragma unroll
-                for (int i = 0; i < 4; i++) kf_[2 * i] = bf_lo(kw[i]), kf_[2 * i + 1] = bf_hi(kw[i]);
-                if (has_new && valid && t == pos) {
-#pragma unroll
-                    for (int i = 0; i < 8; i++) kf_[i] = knew[d0 + i];
-                }
+                u32x4 kw = ck[u];
+                if (has_new && valid && t == pos) kw = *reinterpret_cast<const u32x4*>(knew + d0);
 #pragma unroll
                 for (int hq = 0; hq < GQ; hq++) {
-                    float d = 0.f;
-#pragma unroll
-                    for (int i = 0; i < 8; i++) d = fmaf(qreg[hq][i], kf_[i], d);
+                    float d = dot2_bf16(qreg[hq].x, kw.x, 0.f);
+                    d = dot2_bf16(qreg[hq].y, kw.y, d);
+                    d = dot2_bf16(qreg[hq].z, kw.z, d);
+                    d = dot2_bf16(qreg[hq].w, kw.w, d);
                     d = group_sum16(d, lpk_log2);
                     d = round_bf16(d * rden);
                     s[u][hq] = valid ? d : -__builtin_inff();
@@ -262,31 +239,33 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
             }
         }
 
-        // ---- sum the key groups: inside the wave by row swaps (same reference maximum everywhere: plain sums), across waves in LDS
+        // ---- sum the key groups (same reference maximum everywhere: plain sums).  Inside the wave a reduce-scatter by row swaps:
+        // swapping the halves of (acc[i], acc[i+4]) and adding leaves dims i in lanes 0-31 and i+4 in lanes 32-63, the same on 16-lane
+        // rows leaves row R with the totals of dims 2R and 2R+1 -- 6 swaps + 6 adds per head instead of 8 butterflies
+        const int row = lane >> 4;
 #pragma unroll
         for (int hq = 0; hq < GQ; hq++) {
+            float s1[4], r2[2];
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                float v = xsum16(xsum32(acc[hq][i]));
-                if (LPK < 16) v += dpp_f<0x128>(v); /* row_ror:8 */
-                acc[hq][i] = v;
+            for (int i = 0; i < 4; i++) {
+                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[hq][i]), __float_as_uint(acc[hq][i + 4]), false, false);
+                s1[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
             }
-            float v = xsum16(xsum32(l[hq]));
-            if (LPK < 16) v += dpp_f<0x128>(v);
-            l[hq] = v;
-        }
-        if (grp == 0) {
 #pragma unroll
-            for (int hq = 0; hq < GQ; hq++) {
-                float* c = comb + ((size_t)wave * GQ + hq) * PS;
-                *reinterpret_cast<f32x4*>(c + d0) = f32x4{acc[hq][0], acc[hq][1], acc[hq][2], acc[hq][3]};
-                *reinterpret_cast<f32x4*>(c + d0 + 4) = f32x4{acc[hq][4], acc[hq][5], acc[hq][6], acc[hq][7]};
-                if (d0 == 0) c[hd] = l[hq];
+            for (int i = 0; i < 2; i++) {
+                const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(s1[i]), __float_as_uint(s1[i + 2]), false, false);
+                r2[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                if (LPK < 16) r2[i] += dpp_f<0x128>(r2[i]); /* two key groups per row: row_ror:8 */
             }
+            float lt = xsum16(xsum32(l[hq]));
+            if (LPK < 16) lt += dpp_f<0x128>(lt);
+            float* c = comb + ((size_t)wave * GQ + hq) * PS;
+            if (LPK == 16 || (lane & 8) == 0) *reinterpret_cast<float2*>(c + d0 + 2 * row) = float2{r2[0], r2[1]};
+            if (lane == 0) c[hd] = lt;
         }
         __syncthreads();
         for (int i = tid; i < GQ * hd; i += blockDim.x) {
-            const int hq = i / hd, d = i - hq * hd;
+            const int hq = i >> hd_log2, d = i & (hd - 1);
             float o = 0.f, L = 0.f;
 #pragma unroll
             for (int sl = 0; sl < NW; sl++) {
@@ -294,98 +273,81 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
                 o += c[d];
                 L += c[hd];
             }
-            float Mh = M[0];
-#pragma unroll
-            for (int q2 = 1; q2 < GQ; q2++) Mh = (hq == q2) ? M[q2] : Mh;
             if (nsp == 1) {
                 odst[(size_t)(h0 + hq) * hd + d] = f2bf(o * (1.0f / L));
             } else {
+                float Mh = M[0];
+#pragma unroll
+                for (int q2 = 1; q2 < GQ; q2++) Mh = (hq == q2) ? M[q2] : Mh;
                 float* dst = a.part + ((size_t)(h0 + hq) * nsp + split) * PS;
                 st_sc1(dst + d, o);
                 if (d == 0) st_sc1(dst + hd, Mh), st_sc1(dst + hd + 1, L);
             }
-            if (i == tid) o_fin = o, M_fin = Mh, L_fin = L;
         }
     } else if (nsp > 1) { /* empty slice: neutral partial, but it still arrives */
         for (int i = tid; i < GQ * hd; i += blockDim.x) {
-            const int hq = i / hd, d = i - hq * hd;
+            const int hq = i >> hd_log2, d = i & (hd - 1);
             float* dst = a.part + ((size_t)(h0 + hq) * nsp + split) * PS;
             st_sc1(dst + d, 0.f);
             if (d == 0) st_sc1(dst + hd, -__builtin_inff()), st_sc1(dst + hd + 1, 0.f);
         }
     }
-    (void)o_fin, (void)M_fin, (void)L_fin;
     if (nsp == 1) return;
 
     // ---- arrival; the last workgroup of this kv-head merges
+    int* const counter = a.counters + kvh * a.cnt_stride;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        const int old = __hip_atomic_fetch_add(a.counters + kvh, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         flag[0] = (old == nsp - 1);
     }
     __syncthreads();
     if (!flag[0]) return;
 
-    // one round of loads: every thread fetches its output element from all slices while (m, l) of the slices go to LDS
-    float* ms = mrg;
-    float* ls = mrg + GQ * KF_ATTN_MAX_SPLITS;
-    float* sc = mrg + 2 * GQ * KF_ATTN_MAX_SPLITS;
-    for (int i = tid; i < GQ * nsp; i += blockDim.x) {
-        const int hq = i / nsp, sp = i - hq * nsp;
-        const float* p = a.part + ((size_t)(h0 + hq) * nsp + sp) * PS;
-        ms[hq * KF_ATTN_MAX_SPLITS + sp] = ld_sc1(p + hd);
-        ls[hq * KF_ATTN_MAX_SPLITS + sp] = ld_sc1(p + hd + 1);
-    }
+    // Every thread fetches its output element from all slices in one round of loads; the head is the same for the whole wave
+    // (64 | hd), so lane sp of the wave fetches (m, l) of slice sp and the scales are made in registers: no LDS, no barrier.
     constexpr int NT = NW * 64;
     constexpr int NV = (GQ * 128 + NT - 1) / NT; /* output elements per thread (hd <= 128) */
-    float v[NV][KF_ATTN_MAX_SPLITS];
+    float v[NV][KF_ATTN_MAX_SPLITS], ms[NV], ls[NV];
 #pragma unroll
     for (int e = 0; e < NV; e++) {
         const int i = tid + e * NT;
-        const int hq = i / hd, d = i - hq * hd;
-        const float* p = a.part + (size_t)(h0 + hq) * nsp * PS + d;
+        const bool in = i < GQ * hd;
+        const int hq = in ? (i >> hd_log2) : 0, d = i & (hd - 1);
+        const float* p = a.part + (size_t)(h0 + hq) * nsp * PS;
+        const bool mine = in && lane < nsp;
+        ms[e] = mine ? ld_sc1(p + (size_t)lane * PS + hd) : -__builtin_inff();
+        ls[e] = mine ? ld_sc1(p + (size_t)lane * PS + hd + 1) : 0.f;
 #pragma unroll
-        for (int sp = 0; sp < KF_ATTN_MAX_SPLITS; sp++) v[e][sp] = (i < GQ * hd && sp < nsp) ? ld_sc1(p + (size_t)sp * PS) : 0.f;
+        for (int sp = 0; sp < KF_ATTN_MAX_SPLITS; sp++) v[e][sp] = (in && sp < nsp) ? ld_sc1(p + (size_t)sp * PS + d) : 0.f;
     }
-    __syncthreads();
-    for (int i = tid; i < GQ * nsp; i += blockDim.x) {
-        const int hq = i / nsp, sp = i - hq * nsp;
-        float Mx = -__builtin_inff();
-        for (int t = 0; t < nsp; t++) Mx = fmaxf(Mx, ms[hq * KF_ATTN_MAX_SPLITS + t]);
-        const float m = ms[hq * KF_ATTN_MAX_SPLITS + sp];
-        sc[hq * KF_ATTN_MAX_SPLITS + sp] = (m == -__builtin_inff()) ? 0.f : fast_exp(m - Mx);
-    }
-    __syncthreads();
 #pragma unroll
     for (int e = 0; e < NV; e++) {
         const int i = tid + e * NT;
-        if (i >= GQ * hd) break;
-        const int hq = i / hd, d = i - hq * hd;
-        float o = 0.f, L = 0.f;
+        const float Mx = wave_max(ms[e]);
+        const float sc = (ms[e] == -__builtin_inff()) ? 0.f : fast_exp(ms[e] - Mx);
+        const float L = wave_sum(ls[e] * sc);
+        float o = 0.f;
 #pragma unroll
-        for (int sp = 0; sp < KF_ATTN_MAX_SPLITS; sp++) {
-            if (sp < nsp) {
-                o = fmaf(v[e][sp], sc[hq * KF_ATTN_MAX_SPLITS + sp], o);
-                L = fmaf(ls[hq * KF_ATTN_MAX_SPLITS + sp], sc[hq * KF_ATTN_MAX_SPLITS + sp], L);
-            }
-        }
-        odst[(size_t)(h0 + hq) * hd + d] = f2bf(o * (1.0f / L));
+        for (int sp = 0; sp < KF_ATTN_MAX_SPLITS; sp++)
+            o = fmaf(v[e][sp], __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sc), sp)), o);
+        if (i < GQ * hd) odst[(size_t)(h0 + (i >> hd_log2)) * hd + (i & (hd - 1))] = f2bf(o * (1.0f / L));
     }
-    if (tid == 0) __hip_atomic_store(a.counters + kvh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // standalone ROPE::cuInfer: grid = n_head + n_kv, one wave each
 __global__ void __launch_bounds__(64) qknorm_rope_kernel(uint16_t* q, uint16_t* k, const uint16_t* wq, const uint16_t* wk, const float* table, int pos_,
                                                          const int* d_pos, int n_head, int n_kv, int hd, float eps, long long q_stride, long long k_stride) {
-    __shared__ float buf[256];
+    __shared__ uint16_t buf[256];
     const int pos = (d_pos ? *d_pos : pos_) + (int)blockIdx.y; /* blockIdx.y = token of a batch */
     const int b = blockIdx.x;
     uint16_t* src = b < n_head ? q + (size_t)blockIdx.y * q_stride + (size_t)b * hd : k + (size_t)blockIdx.y * k_stride + (size_t)(b - n_head) * hd;
     const uint16_t* wn = b < n_head ? wq : wk;
     prep_head(load_head(src, wn, hd), wn != nullptr, table ? table + (size_t)pos * hd : nullptr, hd, eps, buf);
     __syncthreads();
-    for (int i = threadIdx.x; i < hd; i += 64) src[i] = f2bf(buf[i]);
+    for (int i = threadIdx.x; i < hd; i += 64) src[i] = buf[i];
 }
 
 // slices: ~64 keys each, enough workgroups to cover the chip, bounded by the scratch layout
@@ -423,9 +385,12 @@ int attn_launch(hipStream_t st, AttnArgs& a) {
     a.n_splits = nsp;
     a.chunk = (pos_max + 1 + nsp - 1) / nsp;
     a.inv_sqrt_hd_den = sqrtf((float)hd);
+    a.cnt_stride = KF_ATTN_CNT_BYTES / 4 / a.n_kv; /* arrival counters of different kv-heads in different cache lines: atomics on one line serialise */
+    if (a.cnt_stride > 64) a.cnt_stride = 64;
+    if (a.cnt_stride < 1) return KF_INVALID_ARGS;
     // 8 waves per workgroup while the per-slot combine buffer fits comfortably in LDS (GQ <= 2), else 4
     const int NW = (GQ <= 2 && pos_max >= 256) ? 8 : 4; /* measured: 4 waves win below ~256 keys, 8 above; 16 lose everywhere */
-    const size_t smem = sizeof(float) * ((size_t)GQ * hd + hd + NW * GQ + 3 * GQ * KF_ATTN_MAX_SPLITS + 4 + (size_t)NW * GQ * (hd + 4));
+    const size_t smem = sizeof(uint16_t) * ((size_t)GQ * hd + hd) + sizeof(float) * (NW * GQ + 4 + (size_t)NW * GQ * (hd + 4));
     dim3 grid(nsp, a.n_kv, a.n_tok);
     switch (GQ) {
         case 1: if (NW == 8) hipLaunchKernelGGL((attn_kernel<1, 8>), grid, dim3(512), smem, st, a); else hipLaunchKernelGGL((attn_kernel<1, 4>), grid, dim3(256), smem, st, a); break;

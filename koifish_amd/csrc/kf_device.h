@@ -82,15 +82,38 @@ __device__ __forceinline__ double dpp_d(double v) {
     const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
-// fp64 sum over the whole wave: 4 DPP steps inside each 16-lane row, 2 cross-row exchanges
+// sums over lanes l ^ 32 and l ^ 16 without LDS (gfx950 row swaps: with both operands equal the two results are the two halves /
+// row pairs broadcast, so their sum is the butterfly sum in every lane)
+__device__ __forceinline__ float xsum32(float v) {
+    const uint32_t u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xsum16(float v) {
+    const uint32_t u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ double xsum32_d(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)u, (unsigned)u, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi[0] << 32) | lo[0]) + __builtin_bit_cast(double, ((unsigned long long)hi[1] << 32) | lo[1]);
+}
+__device__ __forceinline__ double xsum16_d(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)u, (unsigned)u, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi[0] << 32) | lo[0]) + __builtin_bit_cast(double, ((unsigned long long)hi[1] << 32) | lo[1]);
+}
+// fp64 sum over the whole wave: 4 DPP steps inside each 16-lane row, 2 cross-row swaps
 __device__ __forceinline__ double wave_sum_f64_fast(double v) {
     v += dpp_d<0xB1>(v);
     v += dpp_d<0x4E>(v);
     v += dpp_d<0x141>(v);
     v += dpp_d<0x140>(v);
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
+    return xsum32_d(xsum16_d(v));
 }
 
 __device__ __forceinline__ float wave_max(float v) {

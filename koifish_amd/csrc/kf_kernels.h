@@ -9,6 +9,7 @@ enum { FMT_BF16 = 0, FMT_F8 = 1, FMT_Q4 = 2, FMT_Q2 = 3, FMT_Q1 = 4, FMT_Q4P = 5
 enum { GEMV_PLAIN = 0, GEMV_PAIRED = 1, GEMV_ARGMAX = 2 };
 constexpr int KF_MAX_ARGMAX_PARTIALS = 4096;
 constexpr int KF_ATTN_MAX_SPLITS = 32;
+constexpr int KF_ATTN_CNT_BYTES = 16384; /* arrival counters at the head of the attention scratch */
 
 struct GemvJob {
     const void* w;
@@ -73,7 +74,7 @@ struct AttnArgs {
     uint16_t* out;
     const int* d_pos;
     int pos;
-    int n_head, n_kv, hd, kv_stride, n_splits, chunk;
+    int n_head, n_kv, hd, kv_stride, n_splits, chunk, cnt_stride;
     float eps, inv_sqrt_hd_den;
     int n_tok;          /* token batch (prefill): position pos + token */
     int one_slice;      /* every (kv-head, token) is handled by one workgroup: no scratch, no hand-off */
