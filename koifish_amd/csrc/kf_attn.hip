@@ -37,14 +37,14 @@ __device__ __forceinline__ float group_sum16(float v, int lg) {
 struct HeadRaw {
     uint16_t x0, x1, w0, w1;
 };
+// Unconditional loads (clamped lane, the head itself standing in for a missing norm weight): a conditional load into a preset
+// register makes the compiler wait for it -- and for every K/V load issued before it -- at the join.
 __device__ __forceinline__ HeadRaw load_head(const uint16_t* __restrict__ src, const uint16_t* __restrict__ wn, int hd) {
-    const int j = threadIdx.x & 63, half = hd >> 1;
-    HeadRaw r{0, 0, 0x3f80, 0x3f80};
-    if (j < half) {
-        r.x0 = src[j], r.x1 = src[j + half];
-        if (wn) r.w0 = wn[j], r.w1 = wn[j + half];
-    }
-    return r;
+    const int half = hd >> 1;
+    int j = threadIdx.x & 63;
+    j = j < half ? j : half - 1;
+    const uint16_t* w = wn ? wn : src;
+    return HeadRaw{src[j], src[j + half], w[j], w[j + half]};
 }
 // Prepare one head: optional per-head RMSNorm (s rounded to bf16 first, then (a*s)*w, RN store) and rotate-half
 // RoPE from the host-built (cos,sin) table.  One wave per head; lane j handles the pair (j, j + hd/2).
@@ -55,7 +55,7 @@ __device__ __forceinline__ void prep_head(const HeadRaw r, bool norm, const floa
     const bool act = j < half;
     float c = 1.f, sn = 0.f;
     if (tab_pos && act) c = tab_pos[2 * j], sn = tab_pos[2 * j + 1];
-    float x0 = bf2f(r.x0), x1 = bf2f(r.x1);
+    float x0 = act ? bf2f(r.x0) : 0.f, x1 = act ? bf2f(r.x1) : 0.f; /* lanes past hd/2 hold a clamped copy */
     if (norm) {
         const float w0 = bf2f(r.w0), w1 = bf2f(r.w1);
         const double ss = wave_sum_f64_fast(fma((double)x0, (double)x0, (double)x1 * (double)x1));
@@ -80,12 +80,12 @@ constexpr int ATTN_U = 4; /* key tiles kept in flight per wave */
 __device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <int GQ, int NW>
+template <int GQ, int NW, int HD>
 __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int hd = a.hd, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int hd_log2 = 31 - __builtin_clz(hd);
-    const int PS = hd + 4; /* {acc[hd], m, l, pad, pad} */
+    constexpr int hd = HD, hd_log2 = HD == 128 ? 7 : 6; /* head_dim 64 or 128: compile-time, so that the lane-group reductions are straight-line code */
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int PS = hd + 4; /* {acc[hd], m, l, pad, pad} */
     uint16_t* qb = reinterpret_cast<uint16_t*>(smem_raw);  // [GQ][hd] prepared q, bf16 bits
     uint16_t* knew = qb + GQ * hd;                         // [hd]
     float* wmax = reinterpret_cast<float*>(knew + hd);     // [NW][GQ]
@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
     const int h0 = kvh * GQ;
 
     // LPK lanes per key (8 dims each), KPW keys per wave step, the waves interleaved over the slice
-    const int LPK = hd >> 3, KPW = 64 / LPK, lpk_log2 = __builtin_ctz(LPK);
+    constexpr int LPK = hd >> 3, KPW = 64 / LPK, lpk_log2 = hd_log2 - 3;
     const int grp = lane >> lpk_log2, d0 = (lane & (LPK - 1)) * 8;
     const bool has_new = a.k_raw != nullptr;
     const int tstart = t0 + wave * KPW + grp, tstride = NW * KPW;
@@ -131,13 +131,13 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
     // ... and the q heads (+ the raw new key) this wave will prepare: they do not depend on the position either
     constexpr int NQ = (GQ + NW - 1) / NW;
     const bool qnorm = a.rope_table && a.wq_norm;
-    HeadRaw qraw[NQ], kraw{};
+    HeadRaw qraw[NQ];
 #pragma unroll
     for (int i = 0; i < NQ; i++) {
         const int hq = wave + i * NW;
         qraw[i] = load_head(qsrc + (size_t)(h0 + (hq < GQ ? hq : 0)) * hd, qnorm ? a.wq_norm : nullptr, hd);
     }
-    if (has_new && wave == (GQ % NW)) kraw = load_head(a.k_raw + (size_t)kvh * hd, a.wk_norm, hd);
+    const HeadRaw kraw = load_head(has_new ? a.k_raw + (size_t)kvh * hd : qsrc, a.wk_norm, hd);
 
     const int pos = a.d_pos ? *a.d_pos : pos_l;
     const int len = pos + 1;
@@ -200,9 +200,8 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
             // workgroup-wide maximum of the batch -> one running maximum shared by every lane
 #pragma unroll
             for (int hq = 0; hq < GQ; hq++) {
-                if (LPK < 32) bm[hq] = fmaxf(bm[hq], __shfl_xor(bm[hq], 16, 64));
-                bm[hq] = fmaxf(bm[hq], __shfl_xor(bm[hq], 32, 64));
-                if (LPK < 16) bm[hq] = fmaxf(bm[hq], __shfl_xor(bm[hq], 8, 64));
+                bm[hq] = xmax32(xmax16(bm[hq]));
+                if (LPK < 16) bm[hq] = fmaxf(bm[hq], dpp_f<0x128>(bm[hq]));
             }
             __syncthreads(); /* previous batch's readers of wmax are done */
             if (lane == 0) {
@@ -392,13 +391,19 @@ int attn_launch(hipStream_t st, AttnArgs& a) {
     const int NW = (GQ <= 2 && pos_max >= 256) ? 8 : 4; /* measured: 4 waves win below ~256 keys, 8 above; 16 lose everywhere */
     const size_t smem = sizeof(uint16_t) * ((size_t)GQ * hd + hd) + sizeof(float) * (NW * GQ + 4 + (size_t)NW * GQ * (hd + 4));
     dim3 grid(nsp, a.n_kv, a.n_tok);
+#define KF_ATTN_GO(gq, nw)                                                                              \
+    do {                                                                                               \
+        if (hd == 128) hipLaunchKernelGGL((attn_kernel<gq, nw, 128>), grid, dim3(nw * 64), smem, st, a); \
+        else hipLaunchKernelGGL((attn_kernel<gq, nw, 64>), grid, dim3(nw * 64), smem, st, a);            \
+    } while (0)
     switch (GQ) {
-        case 1: if (NW == 8) hipLaunchKernelGGL((attn_kernel<1, 8>), grid, dim3(512), smem, st, a); else hipLaunchKernelGGL((attn_kernel<1, 4>), grid, dim3(256), smem, st, a); break;
-        case 2: if (NW == 8) hipLaunchKernelGGL((attn_kernel<2, 8>), grid, dim3(512), smem, st, a); else hipLaunchKernelGGL((attn_kernel<2, 4>), grid, dim3(256), smem, st, a); break;
-        case 4: hipLaunchKernelGGL((attn_kernel<4, 4>), grid, dim3(256), smem, st, a); break;
-        case 8: hipLaunchKernelGGL((attn_kernel<8, 4>), grid, dim3(256), smem, st, a); break;
+        case 1: if (NW == 8) KF_ATTN_GO(1, 8); else KF_ATTN_GO(1, 4); break;
+        case 2: if (NW == 8) KF_ATTN_GO(2, 8); else KF_ATTN_GO(2, 4); break;
+        case 4: KF_ATTN_GO(4, 4); break;
+        case 8: KF_ATTN_GO(8, 4); break;
         default: return KF_INVALID_ARGS;
     }
+#undef KF_ATTN_GO
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 

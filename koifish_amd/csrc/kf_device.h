@@ -60,16 +60,6 @@ __device__ __forceinline__ float kf_expf(float x) {
     return (p * s1) * s2;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
 // DPP cross-lane moves (row = 16 lanes): quad_perm xor1 = 0xB1, xor2 = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
@@ -116,10 +106,31 @@ __device__ __forceinline__ double wave_sum_f64_fast(double v) {
     return xsum32_d(xsum16_d(v));
 }
 
+__device__ __forceinline__ double wave_sum_f64(double v) { return wave_sum_f64_fast(v); }
+// fp32 sum / max over the whole wave, VALU only (no LDS round trips): DPP inside the rows, row swaps across them
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_f<0xB1>(v);
+    v += dpp_f<0x4E>(v);
+    v += dpp_f<0x141>(v);
+    v += dpp_f<0x140>(v);
+    return xsum32(xsum16(v));
+}
+__device__ __forceinline__ float xmax32(float v) {
+    const uint32_t u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xmax16(float v) {
+    const uint32_t u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
-    return v;
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    return xmax32(xmax16(v));
 }
 
 // Sum of squares of a bf16 vector in fp64 over a whole workgroup (nthreads a multiple of 64, <= 1024).

@@ -188,14 +188,14 @@ struct BlockDot<FMT_Q1> {
 
 // ------------------------------------------------------------------------------------------------ kernel
 // sum over the 2^lg lanes of each aligned lane group (lg wave-uniform); every lane of the group gets the sum.
-// DPP inside a 16-lane row (quad_perm xor1, xor2, row_half_mirror, row_mirror), two cross-row exchanges above it.
+// DPP inside a 16-lane row (quad_perm xor1, xor2, row_half_mirror, row_mirror), two cross-row swaps above it.
 __device__ __forceinline__ float group_sum(float v, int lg) {
     if (lg >= 1) v += dpp_f<0xB1>(v);
     if (lg >= 2) v += dpp_f<0x4E>(v);
     if (lg >= 3) v += dpp_f<0x141>(v);
     if (lg >= 4) v += dpp_f<0x140>(v);
-    if (lg >= 5) v += __shfl_xor(v, 16, 64);
-    if (lg >= 6) v += __shfl_xor(v, 32, 64);
+    if (lg >= 5) v = xsum16(v);
+    if (lg >= 6) v = xsum32(v);
     return v;
 }
 
