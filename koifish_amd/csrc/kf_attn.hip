@@ -351,12 +351,12 @@ __global__ void __launch_bounds__(64) qknorm_rope_kernel(uint16_t* q, uint16_t* 
 
 // slices: ~64 keys each, enough workgroups to cover the chip, bounded by the scratch layout
 int attn_splits(int pos_bound, int n_kv) {
-    // keys per slice: one workgroup streams a slice in batches of 64 keys (hd 128); short contexts stay in ONE slice per
+    // keys per slice: one workgroup streams a slice in batches of 64 keys (hd 128, 4 waves); short contexts stay in ONE slice per
     // kv-head (no cross-workgroup hand-off at all), long ones are cut so that the chip is covered.
     static int slice = 0, single = 0;
     if (!slice) {
         const char* e = getenv("KF_ATTN_SLICE");
-        slice = e ? atoi(e) : 128;
+        slice = e ? atoi(e) : 64;
         const char* f = getenv("KF_ATTN_SINGLE");
         single = f ? atoi(f) : 192;
     }
@@ -387,8 +387,12 @@ int attn_launch(hipStream_t st, AttnArgs& a) {
     a.cnt_stride = KF_ATTN_CNT_BYTES / 4 / a.n_kv; /* arrival counters of different kv-heads in different cache lines: atomics on one line serialise */
     if (a.cnt_stride > 64) a.cnt_stride = 64;
     if (a.cnt_stride < 1) return KF_INVALID_ARGS;
-    // 8 waves per workgroup while the per-slot combine buffer fits comfortably in LDS (GQ <= 2), else 4
-    const int NW = (GQ <= 2 && pos_max >= 256) ? 8 : 4; /* measured: 4 waves win below ~256 keys, 8 above; 16 lose everywhere */
+    // one 64-key batch per 4-wave workgroup (one wave per SIMD: the kernel is bound by VALU issue inside a latency chain, so
+    // spreading the keys over more CUs beats more waves per CU); 8 waves once the slices have to grow past 128 keys
+    int NW = (GQ <= 2 && a.chunk > 128) ? 8 : 4;
+    static int nw_env = -1;
+    if (nw_env < 0) { const char* e = getenv("KF_ATTN_NW"); nw_env = e ? atoi(e) : 0; }
+    if (nw_env == 4 || (nw_env == 8 && GQ <= 2)) NW = nw_env;
     const size_t smem = sizeof(uint16_t) * ((size_t)GQ * hd + hd) + sizeof(float) * (NW * GQ + 4 + (size_t)NW * GQ * (hd + 4));
     dim3 grid(nsp, a.n_kv, a.n_tok);
 #define KF_ATTN_GO(gq, nw)                                                                              \

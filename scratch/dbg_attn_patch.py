@@ -17,8 +17,8 @@ S = '''
 #define STAMP(i) do { ts[i] = wall_clock64(); cs[i] = __builtin_readcyclecounter(); } while (0)
 #define FLUSH() do { if (a.dbg && tid == 0) for (int i_ = 0; i_ < 10; i_++) a.dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + i_] = (i_ == 0 || !ts[i_]) ? ts[i_] : ((cs[i_] - cs[i_ - 1]) << 32) | (ts[i_] - ts[0]); } while (0)
 '''
-rep("template <int GQ, int NW>\n__global__ void __launch_bounds__(NW * 64) attn_kernel", S + "template <int GQ, int NW>\n__global__ void __launch_bounds__(NW * 64) attn_kernel")
-rep("    const int hd = a.hd, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;\n", "    const int hd = a.hd, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;\n    long long ts[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, cs[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};\n    STAMP(0);\n")
+rep("template <int GQ, int NW, int HD>\n__global__ void __launch_bounds__(NW * 64) attn_kernel", S + "template <int GQ, int NW, int HD>\n__global__ void __launch_bounds__(NW * 64) attn_kernel")
+rep("    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;\n", "    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;\n    long long ts[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, cs[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};\n    STAMP(0);\n")
 rep("    const int len = pos + 1;\n", "    const int len = pos + 1;\n    STAMP(1);\n")
 rep("        __syncthreads();\n        if (own_new) {", "        __syncthreads();\n        STAMP(2);\n        if (own_new) {")
 rep("            __syncthreads(); /* previous batch's readers of wmax are done */\n", "            STAMP(3);\n            __syncthreads(); /* previous batch's readers of wmax are done */\n")
