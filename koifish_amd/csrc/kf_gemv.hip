@@ -535,6 +535,17 @@ int gemv_launch(hipStream_t st, GemvLaunch& L) {
         lpr_log2 = 6;
         while ((1 << lpr_log2) > nBlk) lpr_log2--;
     }
+    // short launches (fewer waves than the chip has SIMDs) are bound by the per-step dequant arithmetic of the longest wave, not by
+    // lanes: give a row more lanes, even with the tail of the last step masked, while that shortens the step count
+    // (down_proj of the 0.6B model, 1024 x 3072: 512 waves x 3 steps -> 1024 waves x 2 steps)
+    {
+        long rows = 0;
+        for (int j = 0; j < L.n; j++)
+            if (!(L.mode == GEMV_PAIRED && j == 1)) rows += L.w[j]->ne0;
+        while (lpr_log2 < 6 && nBlk > (1 << lpr_log2) && (rows << lpr_log2) / 64 < 1024 &&
+               (nBlk + (2 << lpr_log2) - 1) / (2 << lpr_log2) < (nBlk + (1 << lpr_log2) - 1) / (1 << lpr_log2))
+            lpr_log2++;
+    }
     const int LPR = 1 << lpr_log2, RPS = 64 / LPR;
     a.K = K, a.nBlk = nBlk, a.lpr_log2 = lpr_log2, a.iters = (nBlk + LPR - 1) / LPR;
     a.inv_dim = 1.0f / (float)K;
