@@ -254,17 +254,30 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
         row = (int)(s - jslot0) * RPS + sub;
         return (s < s_end) && (row < jM);
     };
+    // Two load policies.  LAT (one slot per wave: the short, latency-bound launches of decode): unconditional loads from clamped
+    // (row, column) -- a lane outside the matrix re-reads a valid block and is masked when the block is multiplied -- because loads under
+    // a lane condition make the number of loads in flight path-dependent and every wait behind them a drain (vmcnt(0)), including the
+    // wait for x, which is requested FIRST so that its staging overlaps the weights' HBM latency.  Long launches (G > 1) are bound by
+    // the dequant arithmetic and hide latency with resident waves: they keep the masked loads (no per-step mask arithmetic).
+    constexpr bool LAT = (G == 1);
     auto load = [&](int bi, int it, Batch<G, PAIRED>& b) {
         const long s0 = s_begin + (long)bi * G;
-        const int col = it * LPR + ll;
+        int col = it * LPR + ll;
+        const bool col_ok = col < nBlk;
+        col = col_ok ? col : nBlk - 1;
 #pragma unroll
         for (int g = 0; g < G; g++) {
             int row;
-            const bool ok = slot(s0 + g, row) && (col < nBlk);
-            b.w[g] = u32x4{0, 0, 0, 0};
-            b.st[g] = b.ze[g] = 0;
-            if (PAIRED) b.w2[g] = u32x4{0, 0, 0, 0}, b.st2[g] = b.ze2[g] = 0;
-            if (ok) {
+            const bool ok = slot(s0 + g, row) && col_ok;
+            if constexpr (LAT) {
+                row = row < jM ? row : jM - 1;
+                row = row > 0 ? row : 0;
+            } else {
+                b.w[g] = u32x4{0, 0, 0, 0};
+                b.st[g] = b.ze[g] = 0;
+                if (PAIRED) b.w2[g] = u32x4{0, 0, 0, 0}, b.st2[g] = b.ze2[g] = 0;
+            }
+            if (LAT || ok) {
                 const uint32_t bidx = (uint32_t)row * (uint32_t)nBlk + (uint32_t)col; /* < 2^32 blocks = 64 GiB per tensor */
                 b.w[g] = ld_nt(jw + bidx);
                 if (PAIRED) b.w2[g] = ld_nt(jw2 + bidx);
@@ -277,39 +290,49 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
         }
     };
 
+    // x (and the norm weight) of vectors up to 4096 elements: <= 2 chunks of 8 per thread, requested before the weights
+    const int nch = a.K >> 3;
+    const bool xreg = LAT && nch <= 512, has_norm = a.norm_w != nullptr;
+    const bool h0 = tid < nch, h1 = tid + 256 < nch;
+    u32x4 r0 = u32x4{0, 0, 0, 0}, r1 = r0, n0 = r0, n1 = r0;
+    if (xreg) {
+        const size_t c0 = h0 ? tid : 0, c1 = h1 ? tid + 256 : 0;
+        r0 = *reinterpret_cast<const u32x4*>(a.x + c0 * 8), r1 = *reinterpret_cast<const u32x4*>(a.x + c1 * 8);
+        if (has_norm) n0 = *reinterpret_cast<const u32x4*>(a.norm_w + c0 * 8), n1 = *reinterpret_cast<const u32x4*>(a.norm_w + c1 * 8);
+    }
+
     Batch<G, PAIRED> cur, nxt;
-    if (nsteps > 0) load(0, 0, cur);
+    if (LAT || nsteps > 0) load(0, 0, cur); /* LAT: waves without work re-read row 0 */
     const int pos = a.d_pos ? *a.d_pos : a.pos;
 
     // ---- prologue: stage x into LDS as packed bf16 chunks
     {
         constexpr int XCH = BD::XCH;
-        const int nch = a.K >> 3;
-        if (a.norm_w && nch <= 512) {
-            // RMSNorm prologue, one pass (rms_norm_kernel, layernorm.cuh:800-847): every thread holds <= 2 chunks of 8 elements in
-            // registers, fp64 sum of squares over the workgroup, then the normalised chunks go to LDS.
-            const bool h0 = tid < nch, h1 = tid + 256 < nch;
-            u32x4 r0 = u32x4{0, 0, 0, 0}, r1 = r0, n0 = r0, n1 = r0;
-            if (h0) r0 = *reinterpret_cast<const u32x4*>(a.x + (size_t)tid * 8), n0 = *reinterpret_cast<const u32x4*>(a.norm_w + (size_t)tid * 8);
-            if (h1) r1 = *reinterpret_cast<const u32x4*>(a.x + (size_t)(tid + 256) * 8), n1 = *reinterpret_cast<const u32x4*>(a.norm_w + (size_t)(tid + 256) * 8);
-            const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w}, ww[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
-            double ss = 0.0;
+        if (xreg) {
+            // RMSNorm prologue, one pass (rms_norm_kernel, layernorm.cuh:800-847): fp64 sum of squares over the workgroup, then the
+            // normalised chunks go to LDS; without a norm weight the chunks go to LDS as they are.
+            const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+            uint32_t ow[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+            if (has_norm) {
+                const uint32_t ww[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+                double ss0 = 0.0, ss1 = 0.0;
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const double lo = (double)bf_lo(rw[k]), hi = (double)bf_hi(rw[k]);
-                ss = fma(lo, lo, ss);
-                ss = fma(hi, hi, ss);
-            }
-            ss = wave_sum_f64_fast(ss);
-            if (lane == 0) red[wave_in_blk] = ss;
-            __syncthreads();
-            const double tot = (red[0] + red[1]) + (red[2] + red[3]);
-            const float mul = 1.0f / sqrtf(fmaf((float)tot, a.inv_dim, a.eps));
-            uint32_t ow[8];
+                for (int k = 0; k < 4; k++) {
+                    const double lo = (double)bf_lo(rw[k]), hi = (double)bf_hi(rw[k]), lo1 = (double)bf_lo(rw[4 + k]), hi1 = (double)bf_hi(rw[4 + k]);
+                    ss0 = fma(lo, lo, ss0), ss0 = fma(hi, hi, ss0);
+                    ss1 = fma(lo1, lo1, ss1), ss1 = fma(hi1, hi1, ss1);
+                }
+                double ss = (h0 ? ss0 : 0.0) + (h1 ? ss1 : 0.0); /* clamped lanes hold a copy of chunk 0 */
+                ss = wave_sum_f64_fast(ss);
+                if (lane == 0) red[wave_in_blk] = ss;
+                __syncthreads();
+                const double tot = (red[0] + red[1]) + (red[2] + red[3]);
+                const float mul = 1.0f / sqrtf(fmaf((float)tot, a.inv_dim, a.eps));
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const float v0 = (bf_lo(rw[k]) * mul) * bf_lo(ww[k]), v1 = (bf_hi(rw[k]) * mul) * bf_hi(ww[k]);
-                ow[k] = pack_bf16x2(v0, v1);
+                for (int k = 0; k < 8; k++) {
+                    const float v0 = (bf_lo(rw[k]) * mul) * bf_lo(ww[k]), v1 = (bf_hi(rw[k]) * mul) * bf_hi(ww[k]);
+                    ow[k] = pack_bf16x2(v0, v1);
+                }
             }
             if (h0) {
                 const int c = tid / XCH, j = tid - c * XCH;
@@ -368,14 +391,19 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
         }
         {
             int col = it * LPR + ll;
-            if (col >= nBlk) col = nBlk - 1; /* masked lanes carry zero weights; keep their LDS reads in range */
+            const bool col_ok = col < nBlk;
+            if (!col_ok) col = nBlk - 1; /* keep the LDS reads in range */
 #pragma unroll
             for (int g = 0; g < G; g++) {
+                int row;
+                const bool ok = !LAT || (slot(s_begin + (long)bi * G + g, row) && col_ok); /* masked loads carry zero weights */
                 const float st = bf2f(cur.st[g]);
-                acc[g] = BD::run(cur.w[g], xs, col, nBlk, st, bf2f(cur.ze[g]), -(jqb * st), acc[g]);
+                const float r = BD::run(cur.w[g], xs, col, nBlk, st, bf2f(cur.ze[g]), -(jqb * st), acc[g]);
+                acc[g] = ok ? r : acc[g];
                 if (PAIRED) {
                     const float st2 = bf2f(cur.st2[g]);
-                    acc2[g] = BD::run(cur.w2[g], xs, col, nBlk, st2, bf2f(cur.ze2[g]), -(jqb2 * st2), acc2[g]);
+                    const float r2 = BD::run(cur.w2[g], xs, col, nBlk, st2, bf2f(cur.ze2[g]), -(jqb2 * st2), acc2[g]);
+                    acc2[g] = ok ? r2 : acc2[g];
                 }
             }
         }
