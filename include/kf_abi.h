@@ -196,6 +196,15 @@ int kf_layernorm(kf_ctx* ctx, const kf_bf16* x, const kf_bf16* w, const kf_bf16*
 /* GELU, tanh form (Relu::Forw GELU -> gelu_forward_kernel2, Activation.cu:23-40) */
 int kf_gelu(kf_ctx* ctx, const kf_bf16* x, kf_bf16* y, size_t n);
 
+/* Fused classifier of the GPT-2 / training forward (fused_classifier, src/Device/CUDA/kernel/fused_classifier.cuh:68-140, launched by Head4Token at
+ * NeuronFuse.cu:923 as <<<dB*T, 1024>>>(logits, losses, nullptr, rLoss, targets, dB, T, V, Vp, devMask, write_dlogits)): for every row of
+ * logits [B*T, P] (V valid entries, P the padded row length, a multiple of 8):  losses[row] -= log(softmax(row)[target])  (accumulates, as the
+ * reference does), then -- write_dlogits != 0 -- the row is overwritten by bf16((prob - onehot(target)) * dloss), and probs (may be NULL) gets
+ * bf16(prob).  Rows whose mask word (may be NULL) has bit 0x10000 (MASK_FLAG::F_IGNORE_LOSS, DataLoader.hpp:78) are skipped entirely.
+ * Same thread decomposition and reduction order as the reference; exp / log are this library's fixed fp32 recipes. */
+int kf_fused_classifier(kf_ctx* ctx, kf_bf16* logits, float* losses, kf_bf16* probs_or_null, float dloss, const int32_t* targets, int B, int T, int V, int P,
+                        const int32_t* mask_or_null, int write_dlogits);
+
 /* ---- training kernel path (BASELINE config 3), first piece: the AdamW parameter update CU_adamw_p (src/Device/CUDA/Optimizer.cu:393-442)
  * as PIPE_Adamw::Update launches it (Optimizer.cu:630-646; TASKA_1p1, packedN.cuh:612-643: 512 threads x 8 bf16 per thread).
  * params / grads bf16 [n] (grads are zeroed), gm / gv: first and second moments, mv_type KF_BF16 (floatMV = bf16) or KF_F32.

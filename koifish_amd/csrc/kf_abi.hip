@@ -546,6 +546,15 @@ int kf_gelu(kf_ctx* c, const kf_bf16* x, kf_bf16* y, size_t n) {
     if (!x || !y || n == 0) return fail(KF_INVALID_ARGS, "kf_gelu: bad args");
     RET(kf::gelu_launch(c->stream, x, y, n));
 }
+int kf_fused_classifier(kf_ctx* c, kf_bf16* logits, float* losses, kf_bf16* probs, float dloss, const int32_t* targets, int B, int T, int V, int P,
+                        const int32_t* mask, int write_dlogits) {
+    CHKCTX(c);
+    if (!logits || !losses || !targets) return fail(KF_INVALID_ARGS, "kf_fused_classifier: null pointer");
+    if (B < 1 || T < 1 || V < 1 || P < V) return fail(KF_INVALID_ARGS, "kf_fused_classifier: needs B, T, V >= 1 and P >= V (got %d %d %d %d)", B, T, V, P);
+    if ((P % 8) != 0 || !al16(logits) || (probs && !al16(probs)))
+        return fail(KF_BLAS_UNALIGN, "kf_fused_classifier: rows must be 16-byte aligned (P = %d a multiple of 8, like the reference's padded vocabulary)", P);
+    RET(kf::fused_classifier_launch(c->stream, logits, losses, probs, dloss, targets, (long)B * T, V, P, mask, write_dlogits));
+}
 int kf_adamw(kf_ctx* c, kf_bf16* params, kf_bf16* grads, void* gm, void* gv, size_t n, int mv_type, float learning_rate, float beta1, float beta2,
              float beta1_correction, float beta2_correction, float eps, float weight_decay, float grad_scale, uint32_t seed, int32_t* d_status) {
     CHKCTX(c);

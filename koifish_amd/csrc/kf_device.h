@@ -54,10 +54,37 @@ __device__ __forceinline__ float kf_expf(float x) {
     p = fmaf(p, r, 0.5f);
     p = fmaf(p, r, 1.0f);
     p = fmaf(p, r, 1.0f);
-    int e = (int)n;
-    int e1 = e / 2, e2 = e - e1;
-    float s1 = __uint_as_float((uint32_t)(e1 + 127) << 23), s2 = __uint_as_float((uint32_t)(e2 + 127) << 23);
-    return (p * s1) * s2;
+    // the oracle scales in two exact-then-rounded steps ((p * 2^e1) * 2^e2, e1 = e/2): the first product is exact, so the pair rounds once,
+    // exactly like one v_ldexp_f32
+    return __builtin_amdgcn_ldexpf(p, (int)n);
+}
+
+// Fixed fp32 natural log (same operation sequence as oracle/kfo_math.h kfo_logf): x = m * 2^e with m in [sqrt(1/2), sqrt(2)),
+// s = (m-1)/(m+1), log m = 2s + 2s*z*P(z), z = s^2, P = 1/3 + z/5 + z^2/7 + z^3/9 + z^4/11 (Horner, fma form), e*ln2 split hi/lo.
+// <= 2 ulp; log(0) = -inf, log(x < 0) = NaN, subnormals scaled by 2^23 first.  Used for the cross-entropy loss of kf_fused_classifier.
+__device__ __forceinline__ float kf_logf(float x) {
+    if (x != x || x < 0.0f) return __builtin_nanf("");
+    if (x == 0.0f) return -__builtin_inff();
+    if (x == __builtin_inff()) return x;
+    int e = 0;
+    uint32_t u = __float_as_uint(x);
+    if (u < 0x00800000u) x *= 8388608.0f, e = -23, u = __float_as_uint(x);
+    e += (int)(u >> 23) - 127;
+    u = (u & 0x007fffffu) | 0x3f800000u;
+    float m = __uint_as_float(u);
+    if (m > 1.41421353816986083984375f) m *= 0.5f, e += 1;
+    const float f = m - 1.0f;
+    const float s = f / (2.0f + f);
+    const float z = s * s;
+    float p = 9.0909093618392944336e-2f;
+    p = fmaf(p, z, 1.1111111193895339966e-1f);
+    p = fmaf(p, z, 1.4285714924335479736e-1f);
+    p = fmaf(p, z, 2.0000000298023223877e-1f);
+    p = fmaf(p, z, 3.3333334326744079590e-1f);
+    const float s2 = s + s;
+    const float fe = (float)e;
+    const float lo = fmaf(s2 * z, p, fe * 9.058001351536227e-6f);
+    return fmaf(fe, 6.9313812255859375e-1f, s2 + lo);
 }
 
 // DPP cross-lane moves (row = 16 lanes): quad_perm xor1 = 0xB1, xor2 = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140

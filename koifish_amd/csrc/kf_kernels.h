@@ -92,6 +92,9 @@ int qknorm_rope_launch(hipStream_t st, uint16_t* q, uint16_t* k, const uint16_t*
 int rmsnorm_launch(hipStream_t st, const uint16_t* x, const uint16_t* w, uint16_t* y, int rows, int dim, float eps, float* rstd);
 int layernorm_launch(hipStream_t st, const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* y, int rows, int dim, float eps, float* mean, float* rstd);
 int gelu_launch(hipStream_t st, const uint16_t* x, uint16_t* y, size_t n);
+// fused classifier (kf_loss.hip): cross-entropy loss per row + logit gradient in place
+int fused_classifier_launch(hipStream_t st, uint16_t* logits, float* losses, uint16_t* probs, float dloss, const int* targets, long rows, int V, int P,
+                            const int* mask, int write_dlogits);
 int swiglu_launch(hipStream_t st, const uint16_t* gate, const uint16_t* up, uint16_t* out, int n);
 int add_launch(hipStream_t st, const uint16_t* a, const uint16_t* b, uint16_t* out, int n);
 int embed_launch(hipStream_t st, const kf_weight* w, int token, const int32_t* d_token, const int32_t* d_state, const int32_t* d_forced,

@@ -696,6 +696,67 @@ KFO_API void kfo_layernorm(const uint16_t* x, const uint16_t* w, const uint16_t*
         if (rstd) rstd[r] = s;
     }
 }
+/* Fused classifier (src/Device/CUDA/kernel/fused_classifier.cuh:68-140; prepare_softmax_blockwide3 :21-62; blockReduce_v0 utils.cuh:235-270), restated
+ * thread by thread: 1024 threads per row; thread t visits the 8-element vectors i = ceil(V/8) + t - 1024, i - 1024, ... >= 0 keeping a running
+ * (max, sum) -- on a new maximum sum *= exp(old - new), then sum += exp(v - max); the reference also multiplies by exp(0) = 1 when the maximum
+ * stays, which changes nothing --; block max; sum_t *= exp(max_t - max); block sum; both reductions = xor-butterfly (16, 8, 4, 2, 1) inside
+ * 32-thread groups, then the same butterfly over the 32 group results.  losses[row] -= log(exp(logit[target] - max) * (1/sum)); every element:
+ * prob = exp(logit - max) * (1/sum), dlogit = bf16((prob - onehot) * dloss) over the logit when write_dlogits, probs = bf16(prob) when given.
+ * Rows with mask bit 0x10000 (F_IGNORE_LOSS, DataLoader.hpp:78) are skipped.  exp / log = kfo_expf / kfo_logf (the reference: CUDA expf / logf).
+ * The reference's V % 8 tail loop advances by 1 per thread (:124: overlapping rewrites when V % 8 >= 2); here each tail element is handled once. */
+static float kfo_butterfly32(float* v, int is_max) { /* v[32]; returns lane 0's value (all lanes end equal: fp add and max commute) */
+    for (int off = 16; off > 0; off >>= 1) {
+        float t[32];
+        for (int l = 0; l < 32; l++) t[l] = is_max ? fmaxf(v[l], v[l ^ off]) : v[l] + v[l ^ off];
+        memcpy(v, t, sizeof(t));
+    }
+    return v[0];
+}
+static float kfo_block_reduce_1024(const float* val, int is_max) {
+    float grp[32];
+    for (int g = 0; g < 32; g++) {
+        float v[32];
+        memcpy(v, val + 32 * g, sizeof(v));
+        grp[g] = kfo_butterfly32(v, is_max);
+    }
+    return kfo_butterfly32(grp, is_max);
+}
+KFO_API void kfo_fused_classifier(uint16_t* logits, float* losses, uint16_t* probs, float dloss, const int32_t* targets, long rows, int V, int P,
+                                  const int32_t* mask, int write_dlogits) {
+    float* tmax = (float*)malloc(1024 * sizeof(float));
+    float* tsum = (float*)malloc(1024 * sizeof(float));
+    for (long idx = 0; idx < rows; idx++) {
+        if (mask && (mask[idx] & 0x10000)) continue;
+        uint16_t* row = logits + idx * (long)P;
+        const int ix = targets[idx];
+        for (int t = 0; t < 1024; t++) {
+            float mx = -INFINITY, sm = 0.0f;
+            for (int i = (V + 7) / 8 + t - 1024; i >= 0; i -= 1024)
+                for (int k = 0; k < 8 && i * 8 + k < V; k++) {
+                    const float v = kfo_bf16_to_f32(row[i * 8 + k]);
+                    if (v > mx) {
+                        if (mx != -INFINITY) sm *= kfo_expf(mx - v);
+                        mx = v;
+                    }
+                    sm += kfo_expf(v - mx);
+                }
+            tmax[t] = mx, tsum[t] = sm;
+        }
+        const float bmax = kfo_block_reduce_1024(tmax, 1);
+        for (int t = 0; t < 1024; t++) tsum[t] *= kfo_expf(tmax[t] - bmax);
+        const float bsum = kfo_block_reduce_1024(tsum, 0);
+        const float scale = 1.0f / bsum;
+        losses[idx] -= kfo_logf(kfo_expf(kfo_bf16_to_f32(row[ix]) - bmax) * scale);
+        for (int e = 0; e < V; e++) {
+            const float p = kfo_expf(kfo_bf16_to_f32(row[e]) - bmax) * scale;
+            if (write_dlogits) row[e] = kfo_f32_to_bf16((p - (e == ix ? 1.0f : 0.0f)) * dloss);
+            if (probs) probs[idx * (long)P + e] = kfo_f32_to_bf16(p);
+        }
+    }
+    free(tmax);
+    free(tsum);
+}
+KFO_API float kfo_logf_export(float x) { return kfo_logf(x); }
 /* GELU, tanh form, gelu_forward_kernel2 (src/Device/CUDA/Activation.cu:23-40): 0.5*x*(1 + tanhf(sqrtf(2/pi)*(x + 0.044715*x*x*x))), bf16 store.
  * tanhf: the reference calls the CUDA libm; here tanh(z) = (e - 1)/(e + 1), e = kfo_expf(2z), saturated to +-1 beyond |z| = 10 -- one fixed
  * recipe shared with the HIP kernel (absolute error < 2e-7, far below the bf16 store). */

@@ -115,4 +115,37 @@ static inline float kfo_expf(float x) {
     return (p * s1) * s2;
 }
 
+/* kfo_logf: the fixed fp32 natural log of the cross-entropy loss (koifish_amd/csrc/kf_device.h kf_logf states the same recipe
+ * independently; the reference calls CUDA logf, fused_classifier.cuh:84).  x = m * 2^e, m in [sqrt(1/2), sqrt(2)), s = (m-1)/(m+1),
+ * log m = 2s + 2s*z*P(z), z = s^2.  tests/test_oracle_loss.py pins it to libm logf within 2 ulp. */
+static inline float kfo_logf(float x) {
+    if (x != x || x < 0.0f) return NAN;
+    if (x == 0.0f) return -INFINITY;
+    if (x == INFINITY) return x;
+    int e = 0;
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if (u < 0x00800000u) {
+        x *= 8388608.0f, e = -23;
+        memcpy(&u, &x, 4);
+    }
+    e += (int)(u >> 23) - 127;
+    u = (u & 0x007fffffu) | 0x3f800000u;
+    float m;
+    memcpy(&m, &u, 4);
+    if (m > 1.41421353816986083984375f) m *= 0.5f, e += 1;
+    const float f = m - 1.0f;
+    const float s = f / (2.0f + f);
+    const float z = s * s;
+    float p = 9.0909093618392944336e-2f;
+    p = fmaf(p, z, 1.1111111193895339966e-1f);
+    p = fmaf(p, z, 1.4285714924335479736e-1f);
+    p = fmaf(p, z, 2.0000000298023223877e-1f);
+    p = fmaf(p, z, 3.3333334326744079590e-1f);
+    const float s2 = s + s;
+    const float fe = (float)e;
+    const float lo = fmaf(s2 * z, p, fe * 9.058001351536227e-6f);
+    return fmaf(fe, 6.9313812255859375e-1f, s2 + lo);
+}
+
 #endif

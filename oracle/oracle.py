@@ -313,6 +313,27 @@ def layernorm(x, w, b, eps=1e-5, want_stats=False):
     return (y, mean, rstd) if want_stats else y
 
 
+def fused_classifier(logits, losses, targets, V, dloss=1.0, mask=None, write_dlogits=True, want_probs=False):
+    """fused_classifier on uint16 (bf16) logits [rows, P]: losses (float32, accumulated in place) and the rows overwritten by the logit gradient.
+    Returns probs (uint16 [rows, P]) when want_probs."""
+    assert logits.dtype == np.uint16 and logits.flags.c_contiguous and logits.ndim == 2
+    assert losses.dtype == np.float32 and losses.flags.c_contiguous
+    rows, P = logits.shape
+    tg = np.ascontiguousarray(targets, dtype=np.int32)
+    mk = np.ascontiguousarray(mask, dtype=np.int32) if mask is not None else None
+    probs = np.zeros_like(logits) if want_probs else None
+    fn = lib().kfo_fused_classifier
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    fn(_p(logits), _p(losses), _p(probs) if probs is not None else None, dloss, _p(tg), rows, V, P, _p(mk) if mk is not None else None, int(write_dlogits))
+    return probs
+
+
+def logf(x):
+    fn = lib().kfo_logf_export
+    fn.argtypes, fn.restype = [C.c_float], C.c_float
+    return np.array([fn(float(v)) for v in np.asarray(x, dtype=np.float32).ravel()], dtype=np.float32)
+
+
 def gelu(x):
     x = np.ascontiguousarray(x, dtype=np.uint16)
     y = np.zeros_like(x)

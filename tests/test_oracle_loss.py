@@ -1,0 +1,68 @@
+"""CPU: the oracle's fused classifier (oracle/kf_oracle.c kfo_fused_classifier, restating fused_classifier.cuh:68-140) against an fp64 softmax
+cross-entropy, and its fixed-recipe logf against libm.  No reference vectors exist for this kernel (parity unpinned)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+bf16_bits, bits_to_f32 = O.f32_to_bf16, O.bf16_to_f32
+
+
+def test_logf_within_2ulp_of_libm():
+    rng = np.random.default_rng(3)
+    x = np.concatenate([np.exp(rng.uniform(-80, 80, 4000)), rng.uniform(0.5, 2.0, 4000), [1.0, 2.0, 0.5, 1e-40, 3e-39, 1.17549435e-38, 3.4e38]]).astype(np.float32)
+    got = O.logf(x)
+    ref64 = np.log(x.astype(np.float64))
+    ref = ref64.astype(np.float32)
+    ulp = np.abs(np.spacing(ref))
+    # near log(1) = 0 the result is tiny: allow 2 ulp of the result or 2^-24 relative to |x - 1|
+    err = np.abs(got.astype(np.float64) - ref64)
+    assert np.all(err <= 2.0 * ulp + 1e-45), float(np.max(err / ulp))
+    assert O.logf([0.0])[0] == -np.inf and np.isnan(O.logf([-1.0])[0]) and O.logf([np.inf])[0] == np.inf
+    assert O.logf([1.0])[0] == 0.0
+
+
+@pytest.mark.parametrize("rows,V,P", [(5, 50257, 50264), (3, 1000, 1000), (4, 66, 72), (2, 9000, 9008), (3, 7, 8)])
+def test_fused_classifier_vs_fp64(rows, V, P):
+    rng = np.random.default_rng(rows * 1000 + V)
+    lg = np.zeros((rows, P), np.uint16)
+    lg[:, :V] = bf16_bits((rng.standard_normal((rows, V)) * 3.0).astype(np.float32))
+    lg[:, V:] = 0x7fc0  # padding must never be read
+    tg = rng.integers(0, V, rows).astype(np.int32)
+    x = bits_to_f32(lg[:, :V]).astype(np.float64)
+    mx = x.max(axis=1, keepdims=True)
+    e = np.exp(x - mx)
+    pr = e / e.sum(axis=1, keepdims=True)
+    loss_ref = -np.log(pr[np.arange(rows), tg])
+    dloss = 1.0 / rows
+    losses = np.full(rows, 0.25, np.float32)  # accumulates
+    work = lg.copy()
+    probs = O.fused_classifier(work, losses, tg, V, dloss=dloss, want_probs=True)
+    assert np.allclose(losses - 0.25, loss_ref, rtol=2e-6, atol=2e-6)
+    onehot = np.zeros((rows, V))
+    onehot[np.arange(rows), tg] = 1.0
+    d_ref = (pr - onehot) * dloss
+    d_got = bits_to_f32(work[:, :V]).astype(np.float64)
+    assert np.all(np.abs(d_got - d_ref) <= np.abs(d_ref) * 2.0 ** -8 + 1e-9)
+    p_got = bits_to_f32(probs[:, :V]).astype(np.float64)
+    assert np.all(np.abs(p_got - pr) <= pr * 2.0 ** -8 + 1e-12)
+    assert np.array_equal(work[:, V:], lg[:, V:])  # padding untouched
+
+
+def test_fused_classifier_mask_and_flags():
+    rng = np.random.default_rng(11)
+    rows, V, P = 6, 300, 304
+    lg = np.zeros((rows, P), np.uint16)
+    lg[:, :V] = bf16_bits(rng.standard_normal((rows, V)).astype(np.float32))
+    tg = rng.integers(0, V, rows).astype(np.int32)
+    mask = np.array([0, 0x10000, 1, 0x10001, 0, 0x10000], np.int32)
+    losses = np.zeros(rows, np.float32)
+    work = lg.copy()
+    O.fused_classifier(work, losses, tg, V, mask=mask)
+    skip = (mask & 0x10000) != 0
+    assert np.all(losses[skip] == 0) and np.all(losses[~skip] > 0)
+    assert np.array_equal(work[skip], lg[skip]) and not np.array_equal(work[~skip], lg[~skip])
+    # write_dlogits = 0: loss only
+    losses2 = np.zeros(rows, np.float32)
+    work2 = lg.copy()
+    O.fused_classifier(work2, losses2, tg, V, write_dlogits=False)
+    assert np.array_equal(work2, lg) and np.array_equal(losses2[~skip], losses[~skip])
