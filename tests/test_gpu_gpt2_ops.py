@@ -117,3 +117,89 @@ def test_gpt2_block_forward(ctx):
     a, b = O.bf16_to_f32(out), O.bf16_to_f32(rout)
     assert np.abs(a - b).max() <= 2.0 ** -6 * np.abs(b).max()
     assert np.sqrt(((a - b) ** 2).mean()) <= 2.0 ** -9 * np.abs(b).max()
+
+
+def test_gpt2_tiny_step(ctx):
+    """BASELINE config 3 end to end at toy size: token + position embedding, two hybrid blocks (attention f8e5m2, MLP 4-bit), final LayerNorm, tied bf16
+    LM head, fused classifier (mean loss, logit gradients), then one AdamW step -- the ABI calls against the same chain of oracle operators."""
+    C_, H, T, NL, V, Vp = 128, 2, 48, 2, 203, 208
+    hd = C_ // H
+    rng = np.random.default_rng(31)
+    mk = lambda *s, std=0.08: O.f32_to_bf16(rng.normal(0, std, size=s).astype(np.float32))
+    lnw = lambda: O.f32_to_bf16((1 + rng.normal(0, 0.1, C_)).astype(np.float32))
+    dev = ctx.device
+    wte = np.zeros((Vp, C_), np.uint16)
+    wte[:V] = mk(V, C_, std=0.2)
+    wpe = mk(T, C_, std=0.05)
+    ids = rng.integers(0, V, T).astype(np.int32)
+    tgt = rng.integers(0, V, T).astype(np.int32)
+    blocks = []
+    for _ in range(NL):
+        W = {"qkv": (mk(3 * C_, C_), mk(3 * C_), L.F8E5M2), "proj": (mk(C_, C_), mk(C_), L.F8E5M2), "fc": (mk(4 * C_, C_), mk(4 * C_), L.Q4), "proj2": (mk(C_, 4 * C_), mk(C_), L.Q4)}
+        ow = {k: O.quantize(v[0], v[0].shape[0], v[0].shape[1], v[2]) for k, v in W.items()}
+        blocks.append(dict(W=W, ow=ow, ln=(lnw(), mk(C_), lnw(), mk(C_)), dw={k: ctx.upload_blob(W[k][2], W[k][0].shape[0], W[k][0].shape[1], ow[k].blob()) for k in W},
+                           db={k: bf16_t(W[k][1], dev) for k in W}))
+    lnf = (lnw(), mk(C_))
+    ohead = O.quantize(wte, Vp, C_, L.BF16)
+    dhead = ctx.upload_blob(L.BF16, Vp, C_, ohead.blob())
+    # ---- device
+    e_tok, e_pos = bf16_t(wte[ids], dev), bf16_t(wpe, dev)
+    x = torch.zeros(T, C_, dtype=torch.bfloat16, device=dev)
+    assert ctx.hip.kf_add(ctx.h, e_tok.data_ptr(), e_pos.data_ptr(), x.data_ptr(), T * C_) == 0
+    for b in blocks:
+        l1w, l1b, l2w, l2b = (bf16_t(a, dev) for a in b["ln"])
+        h1 = torch.zeros(T, C_, dtype=torch.bfloat16, device=dev)
+        assert ctx.hip.kf_layernorm(ctx.h, x.data_ptr(), l1w.data_ptr(), l1b.data_ptr(), h1.data_ptr(), T, C_, 1e-5, None, None) == 0
+        qkv = _linear(ctx, b["dw"]["qkv"], h1, T, 3 * C_, bias=b["db"]["qkv"])
+        att = torch.zeros(T, C_, dtype=torch.bfloat16, device=dev)
+        qc = qkv[:, :C_].contiguous()
+        assert ctx.hip.kf_attn_prefill(ctx.h, qc.data_ptr(), qkv[:, C_:2 * C_].data_ptr(), qkv[:, 2 * C_:].data_ptr(), att.data_ptr(), 0, T, C_, H, H, hd, 3 * C_) == 0
+        x2 = _linear(ctx, b["dw"]["proj"], att, T, C_, bias=b["db"]["proj"], residual=x)
+        h2 = torch.zeros(T, C_, dtype=torch.bfloat16, device=dev)
+        assert ctx.hip.kf_layernorm(ctx.h, x2.data_ptr(), l2w.data_ptr(), l2b.data_ptr(), h2.data_ptr(), T, C_, 1e-5, None, None) == 0
+        f = _linear(ctx, b["dw"]["fc"], h2, T, 4 * C_, bias=b["db"]["fc"])
+        g = torch.zeros_like(f)
+        assert ctx.hip.kf_gelu(ctx.h, f.data_ptr(), g.data_ptr(), f.numel()) == 0
+        x = _linear(ctx, b["dw"]["proj2"], g, T, C_, bias=b["db"]["proj2"], residual=x2)
+    hf = torch.zeros(T, C_, dtype=torch.bfloat16, device=dev)
+    assert ctx.hip.kf_layernorm(ctx.h, x.data_ptr(), bf16_t(lnf[0], dev).data_ptr(), bf16_t(lnf[1], dev).data_ptr(), hf.data_ptr(), T, C_, 1e-5, None, None) == 0
+    logits = _linear(ctx, dhead, hf, T, Vp)
+    logits_fwd = u16(logits).copy()
+    losses = torch.zeros(T, dtype=torch.float32, device=dev)
+    td = torch.from_numpy(tgt).to(dev)
+    assert ctx.hip.kf_fused_classifier(ctx.h, logits.data_ptr(), losses.data_ptr(), None, 1.0 / T, td.data_ptr(), 1, T, V, Vp, None, 1) == 0
+    ctx.sync()
+    # ---- oracle
+    rx = np.stack([O.add(wte[ids[t]], wpe[t]) for t in range(T)])
+    for b in blocks:
+        W, ow = b["W"], b["ow"]
+        r1 = O.layernorm(rx, b["ln"][0], b["ln"][1], 1e-5)
+        rqkv = np.stack([O.linear(ow["qkv"], r1[t], bias=W["qkv"][1]) for t in range(T)])
+        ratt = np.stack([O.attn_decode(rqkv[t, :C_], rqkv[:t + 1, C_:2 * C_], rqkv[:t + 1, 2 * C_:], t, H, H, hd, mode=O.ATTN_FUSED) for t in range(T)])
+        rx2 = np.stack([O.add(rx[t], O.linear(ow["proj"], ratt[t], bias=W["proj"][1])) for t in range(T)])
+        r2 = O.layernorm(rx2, b["ln"][2], b["ln"][3], 1e-5)
+        rg = O.gelu(np.stack([O.linear(ow["fc"], r2[t], bias=W["fc"][1]) for t in range(T)]))
+        rx = np.stack([O.add(rx2[t], O.linear(ow["proj2"], rg[t], bias=W["proj2"][1])) for t in range(T)])
+    rh = O.layernorm(rx, lnf[0], lnf[1], 1e-5)
+    rlog = np.ascontiguousarray(np.stack([O.linear(ohead, rh[t]) for t in range(T)]))
+    a, bb = O.bf16_to_f32(logits_fwd[:, :V]), O.bf16_to_f32(rlog[:, :V])
+    assert np.abs(a - bb).max() <= 2.0 ** -6 * np.abs(bb).max()
+    rloss = np.zeros(T, np.float32)
+    rgrad = rlog.copy()
+    O.fused_classifier(rgrad, rloss, tgt, V, dloss=1.0 / T)
+    got = losses.cpu().numpy()
+    assert abs(got.mean() - rloss.mean()) <= 2.0 ** -7 * rloss.mean()
+    # the classifier itself, on the device's own logits: bit for bit
+    rloss2, rgrad2 = np.zeros(T, np.float32), logits_fwd.copy()
+    O.fused_classifier(rgrad2, rloss2, tgt, V, dloss=1.0 / T)
+    assert np.array_equal(got, rloss2) and np.array_equal(u16(logits), rgrad2)
+    # ---- one AdamW step on the embedding table with a synthetic gradient (the backward GEMMs are not part of this round): bit for bit
+    n = Vp * C_
+    grad = O.f32_to_bf16(rng.normal(0, 0.01, n).astype(np.float32))
+    p_d, g_d = bf16_t(wte.reshape(-1), dev), bf16_t(grad, dev)
+    m_d, v_d = torch.zeros(n, dtype=torch.bfloat16, device=dev), torch.zeros(n, dtype=torch.bfloat16, device=dev)
+    assert ctx.hip.kf_adamw(ctx.h, p_d.data_ptr(), g_d.data_ptr(), m_d.data_ptr(), v_d.data_ptr(), n, L.BF16, 3e-4, 0.9, 0.95, 0.1, 0.05, 1e-8, 0.1, 1.0, 1234, None) == 0
+    ctx.sync()
+    rp, rg2, rm, rv = wte.reshape(-1).copy(), grad.copy(), np.zeros(n, np.uint16), np.zeros(n, np.uint16)
+    O.adamw(rp, rg2, rm, rv, 3e-4, 0.9, 0.95, 0.1, 0.05, 1e-8, 0.1, 1.0, 1234)
+    assert np.array_equal(u16(p_d), rp) and np.array_equal(u16(m_d), rm) and np.array_equal(u16(v_d), rv)
