@@ -322,9 +322,17 @@ def matvec_roofline(m, ctx, cfg, head_rl, reps=20):
     ms /= reps
     n = len(launches)
     ach = nbytes / (ms * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC passes committed under profiles/ (taken on the 0.6B shapes by scratch/ub_matvec_chain.py; rocprofv3 --pmc
+    # cannot run inside this process): FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, averaged over the three launch shapes
+    traffic = None
+    if (dim, nL, m.weights[(0, 6)].ne1) == (1024, 28, 3072):
+        try:
+            traffic = int(json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_matvec.json")))["hbm_bytes_per_launch"])
+        except Exception:
+            pass
     return {"bound": "hbm", "kernel": "kf::gemv_kernel<2, 1, 0> = 4-bit mat-vec of [norm+QKV], [o_proj+residual], [down_proj+residual]: %d launches per token, "
                                       "the largest share of the step's time (LM head: roofline_lm_head)" % n,
-            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
             "bytes_per_launch": int(nbytes / n), "us_per_launch": round(ms * 1e3 / n, 2), "launches": n,
             "note": "latency-bound: %.1f MB per launch is %.2f us at the HBM peak; the in-kernel time split is in DESIGN.md section 6" % (nbytes / n / 1e6, nbytes / n / HBM_PEAK_GBS / 1e3)}
 
