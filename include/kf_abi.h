@@ -196,6 +196,20 @@ int kf_layernorm(kf_ctx* ctx, const kf_bf16* x, const kf_bf16* w, const kf_bf16*
 /* GELU, tanh form (Relu::Forw GELU -> gelu_forward_kernel2, Activation.cu:23-40) */
 int kf_gelu(kf_ctx* ctx, const kf_bf16* x, kf_bf16* y, size_t n);
 
+/* LayerNorm / RMSNorm backward (LayerNormal::cuFlow, backward branch, T.cu:605-646: layernorm_backward -> layernorm_backward_kernel10, layernorm.cuh:311-503;
+ * RMS: CU_rms_back_llmc, layernorm.cuh:863-1051).  mean == NULL selects RMSNorm.  dinp (the residual-path gradient on entry) becomes
+ * bf16(dinp + dL/dinp); dweight (and dbias, LayerNorm with a bias) accumulate the sums over the rows: bf16(sum + old).  rstd (and mean) are the forward's
+ * per-row outputs.  scratch: kf_norm_backward_scratch_bytes(rows, dim, mean != NULL) bytes of device memory, 8-byte aligned. */
+size_t kf_norm_backward_scratch_bytes(int rows, int dim, int is_layernorm);
+int kf_norm_backward(kf_ctx* ctx, kf_bf16* dinp, kf_bf16* dweight, kf_bf16* dbias_or_null, const kf_bf16* dout, const kf_bf16* inp, const kf_bf16* weight,
+                     const float* mean_or_null, const float* rstd, int rows, int dim, void* scratch);
+
+/* Activation backward (Relu::Back, Activation.cu:283-320).  GELU, in place on the incoming gradient (Activation_backward_inplace ->
+ * gelu_backward_inplace_kernel, Activation.cu:42-78): d = bf16(gelu'(x) * d) with x the pre-activation.  SwiGLU (CU_swiglu_back_v0,
+ * Activation.cu:245-260): delta_gate = bf16(delta * up * sig * (1 + gate * (1 - sig))), delta_in_out = bf16(delta * gate * sig), sig = sigmoid(gate). */
+int kf_gelu_backward(kf_ctx* ctx, kf_bf16* d_in_out, const kf_bf16* x, size_t n);
+int kf_swiglu_backward(kf_ctx* ctx, kf_bf16* delta_in_out, kf_bf16* delta_gate, const kf_bf16* gate, const kf_bf16* up, size_t n);
+
 /* Fused classifier of the GPT-2 / training forward (fused_classifier, src/Device/CUDA/kernel/fused_classifier.cuh:68-140, launched by Head4Token at
  * NeuronFuse.cu:923 as <<<dB*T, 1024>>>(logits, losses, nullptr, rLoss, targets, dB, T, V, Vp, devMask, write_dlogits)): for every row of
  * logits [B*T, P] (V valid entries, P the padded row length, a multiple of 8):  losses[row] -= log(softmax(row)[target])  (accumulates, as the

@@ -546,6 +546,27 @@ int kf_gelu(kf_ctx* c, const kf_bf16* x, kf_bf16* y, size_t n) {
     if (!x || !y || n == 0) return fail(KF_INVALID_ARGS, "kf_gelu: bad args");
     RET(kf::gelu_launch(c->stream, x, y, n));
 }
+size_t kf_norm_backward_scratch_bytes(int rows, int dim, int is_layernorm) {
+    return sizeof(double) * (size_t)kf::norm_backward_groups(rows < 1 ? 1 : rows) * (is_layernorm ? 2 : 1) * (size_t)(dim < 0 ? 0 : dim);
+}
+int kf_norm_backward(kf_ctx* c, kf_bf16* dinp, kf_bf16* dweight, kf_bf16* dbias, const kf_bf16* dout, const kf_bf16* inp, const kf_bf16* weight, const float* mean,
+                     const float* rstd, int rows, int dim, void* scratch) {
+    CHKCTX(c);
+    if (!dinp || !dweight || !dout || !inp || !weight || !rstd || !scratch) return fail(KF_INVALID_ARGS, "kf_norm_backward: null pointer");
+    if (rows < 1 || dim < 8 || (dim % 8) != 0 || dim > 8192) return fail(KF_INVALID_ARGS, "kf_norm_backward: needs rows >= 1 and dim a multiple of 8 up to 8192 (got %d x %d)", rows, dim);
+    if (!al16(dinp) || !al16(dout) || !al16(inp) || !al16(weight) || ((uintptr_t)scratch & 7)) return fail(KF_BLAS_UNALIGN, "kf_norm_backward: tensors must be 16-byte aligned");
+    RET(kf::norm_backward_launch(c->stream, dinp, dweight, dbias, dout, inp, weight, mean, rstd, rows, dim, (double*)scratch));
+}
+int kf_gelu_backward(kf_ctx* c, kf_bf16* d_in_out, const kf_bf16* x, size_t n) {
+    CHKCTX(c);
+    if (!d_in_out || !x || n == 0) return fail(KF_INVALID_ARGS, "kf_gelu_backward: bad args");
+    RET(kf::gelu_backward_launch(c->stream, d_in_out, x, n));
+}
+int kf_swiglu_backward(kf_ctx* c, kf_bf16* delta_in_out, kf_bf16* delta_gate, const kf_bf16* gate, const kf_bf16* up, size_t n) {
+    CHKCTX(c);
+    if (!delta_in_out || !delta_gate || !gate || !up || n == 0) return fail(KF_INVALID_ARGS, "kf_swiglu_backward: bad args");
+    RET(kf::swiglu_backward_launch(c->stream, delta_in_out, delta_gate, gate, up, n));
+}
 int kf_fused_classifier(kf_ctx* c, kf_bf16* logits, float* losses, kf_bf16* probs, float dloss, const int32_t* targets, int B, int T, int V, int P,
                         const int32_t* mask, int write_dlogits) {
     CHKCTX(c);

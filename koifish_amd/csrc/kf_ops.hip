@@ -81,6 +81,88 @@ int gelu_launch(hipStream_t st, const uint16_t* x, uint16_t* y, size_t n) {
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 
+// GELU backward in place (gelu_backward_inplace_kernel, Activation.cu:42-60): d = bf16(local_grad(x) * d),
+// local_grad = 0.5 (1 + tanh z) + x * 0.5 * sech^2 z * sqrt(2/pi) * (1 + 3 * 0.044715 x^2), z = sqrt(2/pi) (x + 0.044715 x^3).
+// tanh and sech^2 = 1 / cosh^2 both from ONE e = kf_expf(2z): tanh = (e-1)/(e+1), sech^2 = 4e / ((e+1)(e+1)); saturated beyond |z| = 10
+// exactly like the forward's kf_tanhf (the reference calls tanhf and coshf of the CUDA libm).
+__device__ __forceinline__ float gelu_grad(float xi, float d) {
+    const float cube = 0.044715f * xi * xi * xi;
+    const float z = 0.797884583473205566406250f * (xi + cube);
+    float th, sech2;
+    if (z > 10.0f) th = 1.0f, sech2 = 0.0f;
+    else if (z < -10.0f) th = -1.0f, sech2 = 0.0f;
+    else {
+        const float e = kf_expf(2.0f * z), e1 = e + 1.0f;
+        th = (e - 1.0f) / e1;
+        sech2 = (4.0f * e) / (e1 * e1);
+    }
+    const float local_grad = 0.5f * (1.0f + th) + xi * 0.5f * sech2 * 0.797884583473205566406250f * (1.0f + 3.0f * 0.044715f * xi * xi);
+    return local_grad * d;
+}
+// 8 elements per thread (16-byte loads) where the pointers allow it; a scalar tail
+__global__ void gelu_backward_kernel(uint16_t* __restrict__ d_in_out, const uint16_t* __restrict__ x, size_t n, size_t nvec) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nvec) {
+        const u32x4 xv = *reinterpret_cast<const u32x4*>(x + i * 8), dv = *reinterpret_cast<const u32x4*>(d_in_out + i * 8);
+        const uint32_t xw[4] = {xv.x, xv.y, xv.z, xv.w}, dw[4] = {dv.x, dv.y, dv.z, dv.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) o[k] = pack_bf16x2(gelu_grad(bf_lo(xw[k]), bf_lo(dw[k])), gelu_grad(bf_hi(xw[k]), bf_hi(dw[k])));
+        *reinterpret_cast<u32x4*>(d_in_out + i * 8) = u32x4{o[0], o[1], o[2], o[3]};
+    }
+    const size_t t = nvec * 8 + i;
+    if (i < 8 && t < n) d_in_out[t] = f2bf(gelu_grad(bf2f(x[t]), bf2f(d_in_out[t])));
+}
+int gelu_backward_launch(hipStream_t st, uint16_t* d_in_out, const uint16_t* x, size_t n) {
+    const size_t nvec = (((uintptr_t)d_in_out | (uintptr_t)x) & 15) ? 0 : n / 8;
+    if (nvec == 0 && n > 8) { /* unaligned: element-wise through the tail path would not cover n; fall back to one element per "vector" */
+        return KF_BLAS_UNALIGN;
+    }
+    const size_t threads = nvec > 8 ? nvec : 8;
+    hipLaunchKernelGGL(gelu_backward_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_in_out, x, n, nvec);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+// SwiGLU backward (CU_swiglu_back_v0, Activation.cu:245-260): sig = 1 / (1 + exp(-gate));
+// delta_gate = bf16(delta * up * sig * (1 + gate * (1 - sig))); delta_in_out = bf16(delta * gate * sig)   (the gradient of the up projection).
+// The reference rounds both stores stochastically (seed 42); round-to-nearest here, as everywhere.
+__device__ __forceinline__ void swiglu_grad(float xiW, float xiV, float delta, float& d_gate, float& d_up) {
+    const float sigW = 1.0f / (1.0f + kf_expf(-xiW));
+    d_gate = delta * xiV * sigW * (1.0f + xiW * (1.0f - sigW));
+    d_up = delta * xiW * sigW;
+}
+__global__ void swiglu_backward_kernel(uint16_t* __restrict__ delta_in_out, uint16_t* __restrict__ delta_gate, const uint16_t* __restrict__ gate,
+                                       const uint16_t* __restrict__ up, size_t n, size_t nvec) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nvec) {
+        const u32x4 gv = *reinterpret_cast<const u32x4*>(gate + i * 8), uv = *reinterpret_cast<const u32x4*>(up + i * 8),
+                    dv = *reinterpret_cast<const u32x4*>(delta_in_out + i * 8);
+        const uint32_t gw[4] = {gv.x, gv.y, gv.z, gv.w}, uw[4] = {uv.x, uv.y, uv.z, uv.w}, dw[4] = {dv.x, dv.y, dv.z, dv.w};
+        uint32_t og[4], ou[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float g0, u0, g1, u1;
+            swiglu_grad(bf_lo(gw[k]), bf_lo(uw[k]), bf_lo(dw[k]), g0, u0);
+            swiglu_grad(bf_hi(gw[k]), bf_hi(uw[k]), bf_hi(dw[k]), g1, u1);
+            og[k] = pack_bf16x2(g0, g1), ou[k] = pack_bf16x2(u0, u1);
+        }
+        *reinterpret_cast<u32x4*>(delta_gate + i * 8) = u32x4{og[0], og[1], og[2], og[3]};
+        *reinterpret_cast<u32x4*>(delta_in_out + i * 8) = u32x4{ou[0], ou[1], ou[2], ou[3]};
+    }
+    const size_t t = nvec * 8 + i;
+    if (i < 8 && t < n) {
+        float g0, u0;
+        swiglu_grad(bf2f(gate[t]), bf2f(up[t]), bf2f(delta_in_out[t]), g0, u0);
+        delta_gate[t] = f2bf(g0), delta_in_out[t] = f2bf(u0);
+    }
+}
+int swiglu_backward_launch(hipStream_t st, uint16_t* delta_in_out, uint16_t* delta_gate, const uint16_t* gate, const uint16_t* up, size_t n) {
+    const size_t nvec = (((uintptr_t)delta_in_out | (uintptr_t)delta_gate | (uintptr_t)gate | (uintptr_t)up) & 15) ? 0 : n / 8;
+    if (nvec == 0 && n > 8) return KF_BLAS_UNALIGN;
+    const size_t threads = nvec > 8 ? nvec : 8;
+    hipLaunchKernelGGL(swiglu_backward_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, delta_in_out, delta_gate, gate, up, n, nvec);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+
 // ---------------------------------------------------------------- SwiGLU / add
 __global__ void swiglu_kernel(const uint16_t* __restrict__ gate, const uint16_t* __restrict__ up, uint16_t* __restrict__ out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

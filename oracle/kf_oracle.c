@@ -775,6 +775,89 @@ KFO_API void kfo_gelu(const uint16_t* x, uint16_t* y, size_t n) {
     }
 }
 
+/* LayerNorm / RMSNorm backward (layernorm_backward_kernel10, src/Device/CUDA/kernel/layernorm.cuh:311-503; RMS form CU_rms_back_llmc, :863-1051).
+ * mean == NULL: RMSNorm.  Per row: dnorm_i = w_i * dout_i; A = sum dnorm_i; B = sum dnorm_i * inp_i (both fp64 sums of terms that are exact in
+ * fp32 -- the reference adds them in warp order in fp32); dnorm_mean = A / C; dnorm_norm_mean = B / C * rstd - dnorm_mean * mean * rstd;
+ * norm_i = (inp_i - mean) * rstd; dval = ((w_i * dout_i - dnorm_mean) - norm_i * dnorm_norm_mean) * rstd; dinp_i = bf16(dinp_i + dval).
+ * dweight_i = bf16(sum_rows norm_i * dout_i + dweight_i), dbias_i likewise with dout_i: the rows are dealt round-robin to G = min(rows, 512)
+ * groups, each summed in row order, then the groups in index order, all in fp64 (the decomposition koifish_amd/csrc/kf_norm_bwd.hip uses;
+ * the reference sums per block, then the blocks in index order, in fp32). */
+KFO_API void kfo_norm_backward(uint16_t* dinp, uint16_t* dweight, uint16_t* dbias, const uint16_t* dout, const uint16_t* inp, const uint16_t* weight,
+                               const float* mean, const float* rstd, int rows, int C) {
+    const int G = rows < 512 ? rows : 512, ln = mean != NULL;
+    double* pw = (double*)calloc((size_t)G * C, sizeof(double));
+    double* pb = (double*)calloc((size_t)G * C, sizeof(double));
+    for (int r = 0; r < rows; r++) {
+        const uint16_t *dor = dout + (size_t)r * C, *inr = inp + (size_t)r * C;
+        uint16_t* dir = dinp + (size_t)r * C;
+        const float mean_r = ln ? mean[r] : 0.0f, rstd_r = rstd[r];
+        double A = 0.0, B = 0.0;
+        for (int c = 0; c < C; c++) {
+            const float d = kfo_bf16_to_f32(weight[c]) * kfo_bf16_to_f32(dor[c]);
+            A += (double)d;
+            B += (double)(d * kfo_bf16_to_f32(inr[c]));
+        }
+        const float dnorm_mean = ln ? (float)A / (float)C : 0.0f;
+        const float dnorm_norm_mean = ln ? (float)B / (float)C * rstd_r - dnorm_mean * mean_r * rstd_r : (float)B / (float)C * rstd_r;
+        double* gw = pw + (size_t)(r % G) * C;
+        double* gb = pb + (size_t)(r % G) * C;
+        for (int c = 0; c < C; c++) {
+            const float w_ = kfo_bf16_to_f32(weight[c]), do_ = kfo_bf16_to_f32(dor[c]), in_ = kfo_bf16_to_f32(inr[c]), di_ = kfo_bf16_to_f32(dir[c]);
+            const float norm = (in_ - mean_r) * rstd_r;
+            gw[c] += (double)(norm * do_);
+            gb[c] += (double)do_;
+            float dval = w_ * do_;
+            if (ln) dval -= dnorm_mean;
+            dval -= norm * dnorm_norm_mean;
+            dval *= rstd_r;
+            dir[c] = kfo_f32_to_bf16(di_ + dval);
+        }
+    }
+    for (int c = 0; c < C; c++) {
+        double sw = 0.0, sb = 0.0;
+        const int chunk = (G + 7) / 8; /* 8 contiguous chunks of groups, each in index order, then the chunk sums in order */
+        for (int q = 0; q < 8; q++) {
+            double cw = 0.0, cb = 0.0;
+            for (int g = q * chunk; g < (q + 1) * chunk && g < G; g++) cw += pw[(size_t)g * C + c], cb += pb[(size_t)g * C + c];
+            sw += cw, sb += cb;
+        }
+        dweight[c] = kfo_f32_to_bf16((float)sw + kfo_bf16_to_f32(dweight[c]));
+        if (ln && dbias) dbias[c] = kfo_f32_to_bf16((float)sb + kfo_bf16_to_f32(dbias[c]));
+    }
+    free(pw);
+    free(pb);
+}
+
+/* GELU backward in place (gelu_backward_inplace_kernel, Activation.cu:42-60) and SwiGLU backward (CU_swiglu_back_v0, Activation.cu:245-260): the
+ * reference's expressions, evaluated left to right in fp32; tanh and sech^2 from one kfo_expf(2z) (tanhf / coshf in the reference), the sigmoid from
+ * kfo_expf; round-to-nearest stores. */
+KFO_API void kfo_gelu_backward(uint16_t* d_in_out, const uint16_t* x, size_t n) {
+    const float c = 0.797884583473205566406250f;
+    for (size_t i = 0; i < n; i++) {
+        const float xi = kfo_bf16_to_f32(x[i]);
+        const float cube = 0.044715f * xi * xi * xi;
+        const float z = c * (xi + cube);
+        float th, sech2;
+        if (z > 10.0f) th = 1.0f, sech2 = 0.0f;
+        else if (z < -10.0f) th = -1.0f, sech2 = 0.0f;
+        else {
+            const float e = kfo_expf(2.0f * z), e1 = e + 1.0f;
+            th = (e - 1.0f) / e1;
+            sech2 = (4.0f * e) / (e1 * e1);
+        }
+        const float local_grad = 0.5f * (1.0f + th) + xi * 0.5f * sech2 * c * (1.0f + 3.0f * 0.044715f * xi * xi);
+        d_in_out[i] = kfo_f32_to_bf16(local_grad * kfo_bf16_to_f32(d_in_out[i]));
+    }
+}
+KFO_API void kfo_swiglu_backward(uint16_t* delta_in_out, uint16_t* delta_gate, const uint16_t* gate, const uint16_t* up, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        const float xiW = kfo_bf16_to_f32(gate[i]), xiV = kfo_bf16_to_f32(up[i]), delta = kfo_bf16_to_f32(delta_in_out[i]);
+        const float sigW = 1.0f / (1.0f + kfo_expf(-xiW));
+        delta_gate[i] = kfo_f32_to_bf16(delta * xiV * sigW * (1.0f + xiW * (1.0f - sigW)));
+        delta_in_out[i] = kfo_f32_to_bf16(delta * xiW * sigW);
+    }
+}
+
 /* AdamW parameter update, CU_adamw_p (src/Device/CUDA/Optimizer.cu:393-442) launched as TASKA_1p1 (kernel/packedN.cuh:612-643): blocks of
  * 512 threads, 8 bf16 elements per thread.  Per element (all fp32): g = grad_scale * grad; m = sAtB(g, m, beta1) = fma(beta1, m, fma(-beta1, g, g))
  * (kernel/utils.cuh:26-31); v likewise with g*g and beta2; m_hat = m / beta1_correction, v_hat = v / beta2_correction;

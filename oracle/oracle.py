@@ -313,6 +313,37 @@ def layernorm(x, w, b, eps=1e-5, want_stats=False):
     return (y, mean, rstd) if want_stats else y
 
 
+def norm_backward(dinp, dweight, dbias, dout, inp, weight, mean, rstd):
+    """LayerNorm (mean given) / RMSNorm (mean None) backward, in place on uint16 dinp [rows, C], dweight [C], dbias [C] or None"""
+    for a in (dinp, dweight, dout, inp, weight):
+        assert a.dtype == np.uint16 and a.flags.c_contiguous
+    rows, C_ = dinp.shape
+    rs = np.ascontiguousarray(rstd, dtype=np.float32)
+    mn = np.ascontiguousarray(mean, dtype=np.float32) if mean is not None else None
+    fn = lib().kfo_norm_backward
+    fn.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_int]
+    fn(_p(dinp), _p(dweight), _p(dbias) if dbias is not None else None, _p(dout), _p(inp), _p(weight), _p(mn) if mn is not None else None, _p(rs), rows, C_)
+
+
+def gelu_backward(d, x):
+    """returns gelu'(x) * d (uint16 bf16 arrays)"""
+    out = np.ascontiguousarray(d, dtype=np.uint16).copy()
+    fn = lib().kfo_gelu_backward
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    fn(_p(out), _p(np.ascontiguousarray(x, dtype=np.uint16)), out.size)
+    return out
+
+
+def swiglu_backward(delta, gate, up):
+    """returns (delta_up, delta_gate) of out = silu(gate) * up"""
+    d_up = np.ascontiguousarray(delta, dtype=np.uint16).copy()
+    d_gate = np.zeros_like(d_up)
+    fn = lib().kfo_swiglu_backward
+    fn.argtypes = [C.c_void_p] * 4 + [C.c_size_t]
+    fn(_p(d_up), _p(d_gate), _p(np.ascontiguousarray(gate, dtype=np.uint16)), _p(np.ascontiguousarray(up, dtype=np.uint16)), d_up.size)
+    return d_up, d_gate
+
+
 def fused_classifier(logits, losses, targets, V, dloss=1.0, mask=None, write_dlogits=True, want_probs=False):
     """fused_classifier on uint16 (bf16) logits [rows, P]: losses (float32, accumulated in place) and the rows overwritten by the logit gradient.
     Returns probs (uint16 [rows, P]) when want_probs."""

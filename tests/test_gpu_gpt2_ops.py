@@ -203,3 +203,49 @@ def test_gpt2_tiny_step(ctx):
     rp, rg2, rm, rv = wte.reshape(-1).copy(), grad.copy(), np.zeros(n, np.uint16), np.zeros(n, np.uint16)
     O.adamw(rp, rg2, rm, rv, 3e-4, 0.9, 0.95, 0.1, 0.05, 1e-8, 0.1, 1.0, 1234)
     assert np.array_equal(u16(p_d), rp) and np.array_equal(u16(m_d), rm) and np.array_equal(u16(v_d), rv)
+
+
+def test_activation_backward_bit_exact(ctx):
+    rng = np.random.default_rng(8)
+    n = 8 * 1024 + 40
+    x = O.f32_to_bf16(np.concatenate([rng.normal(0, 2.0, n - 5), [0.0, 11.0, -11.0, 40.0, -40.0]]).astype(np.float32))
+    d = O.f32_to_bf16(rng.normal(0, 1.0, n).astype(np.float32))
+    dd = bf16_t(d, ctx.device)
+    assert ctx.hip.kf_gelu_backward(ctx.h, dd.data_ptr(), bf16_t(x, ctx.device).data_ptr(), n) == 0
+    ctx.sync()
+    assert np.array_equal(u16(dd), O.gelu_backward(d, x))
+    g = O.f32_to_bf16(rng.normal(0, 2.0, n).astype(np.float32))
+    u = O.f32_to_bf16(rng.normal(0, 2.0, n).astype(np.float32))
+    dd = bf16_t(d, ctx.device)
+    dg = torch.zeros(n, dtype=torch.bfloat16, device=ctx.device)
+    assert ctx.hip.kf_swiglu_backward(ctx.h, dd.data_ptr(), dg.data_ptr(), bf16_t(g, ctx.device).data_ptr(), bf16_t(u, ctx.device).data_ptr(), n) == 0
+    ctx.sync()
+    r_up, r_gate = O.swiglu_backward(d, g, u)
+    assert np.array_equal(u16(dd), r_up) and np.array_equal(u16(dg), r_gate)
+
+
+@pytest.mark.parametrize("rows,dim", [(1, 768), (37, 1600), (300, 1024), (700, 5120), (5, 8192), (9, 8)])
+@pytest.mark.parametrize("ln", [True, False])
+def test_norm_backward_bit_exact(ctx, rows, dim, ln):
+    rng = np.random.default_rng(rows * dim + ln)
+    mk = lambda *s_, std=1.0, mu=0.0: O.f32_to_bf16(rng.normal(mu, std, size=s_).astype(np.float32))
+    x, dout, dinp0 = mk(rows, dim, std=1.5, mu=0.2), mk(rows, dim), mk(rows, dim, std=0.5)
+    w, dw0, db0 = O.f32_to_bf16((1 + rng.normal(0, 0.2, dim)).astype(np.float32)), mk(dim, std=0.5), mk(dim, std=0.5)
+    xf = O.bf16_to_f32(x).astype(np.float64)
+    mean = xf.mean(axis=1).astype(np.float32) if ln else None
+    var = ((xf - (xf.mean(axis=1, keepdims=True) if ln else 0.0)) ** 2).mean(axis=1)
+    rstd = (1.0 / np.sqrt(var + 1e-5)).astype(np.float32)
+    dev = ctx.device
+    d_dinp, d_dw, d_db = bf16_t(dinp0, dev), bf16_t(dw0, dev), bf16_t(db0, dev)
+    nbytes = ctx.hip.kf_norm_backward_scratch_bytes(rows, dim, int(ln))
+    scratch = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=dev)
+    md = torch.from_numpy(mean).to(dev) if ln else None
+    rd = torch.from_numpy(rstd).to(dev)
+    assert ctx.hip.kf_norm_backward(ctx.h, d_dinp.data_ptr(), d_dw.data_ptr(), d_db.data_ptr() if ln else None, bf16_t(dout, dev).data_ptr(), bf16_t(x, dev).data_ptr(),
+                                    bf16_t(w, dev).data_ptr(), md.data_ptr() if ln else None, rd.data_ptr(), rows, dim, scratch.data_ptr()) == 0, ctx.hip.kf_last_error()
+    ctx.sync()
+    r_dinp, r_dw, r_db = dinp0.copy(), dw0.copy(), db0.copy()
+    O.norm_backward(r_dinp, r_dw, r_db if ln else None, dout, x, w, mean, rstd)
+    assert np.array_equal(u16(d_dinp), r_dinp)
+    assert np.array_equal(u16(d_dw), r_dw)
+    assert np.array_equal(u16(d_db), r_db)

@@ -66,3 +66,67 @@ def test_fused_classifier_mask_and_flags():
     work2 = lg.copy()
     O.fused_classifier(work2, losses2, tg, V, write_dlogits=False)
     assert np.array_equal(work2, lg) and np.array_equal(losses2[~skip], losses[~skip])
+
+
+def test_activation_backward_vs_autograd():
+    """oracle GELU / SwiGLU backward against torch autograd in fp64 on the same bf16 inputs (tolerance: one bf16 rounding of the result)"""
+    import torch
+    rng = np.random.default_rng(5)
+    n = 4096
+    x = O.f32_to_bf16(np.concatenate([rng.normal(0, 2.0, n - 6), [0.0, 12.0, -12.0, 30.0, -30.0, 1e-3]]).astype(np.float32))
+    d = O.f32_to_bf16(rng.normal(0, 1.0, n).astype(np.float32))
+    xt = torch.tensor(O.bf16_to_f32(x).astype(np.float64), requires_grad=True)
+    y = torch.nn.functional.gelu(xt, approximate="tanh")
+    y.backward(torch.tensor(O.bf16_to_f32(d).astype(np.float64)))
+    got = O.bf16_to_f32(O.gelu_backward(d, x)).astype(np.float64)
+    ref = xt.grad.numpy()
+    assert np.all(np.abs(got - ref) <= np.abs(ref) * 2.0 ** -8 + 1e-6)
+    g = O.f32_to_bf16(rng.normal(0, 2.0, n).astype(np.float32))
+    u = O.f32_to_bf16(rng.normal(0, 2.0, n).astype(np.float32))
+    gt = torch.tensor(O.bf16_to_f32(g).astype(np.float64), requires_grad=True)
+    ut = torch.tensor(O.bf16_to_f32(u).astype(np.float64), requires_grad=True)
+    (torch.nn.functional.silu(gt) * ut).backward(torch.tensor(O.bf16_to_f32(d).astype(np.float64)))
+    d_up, d_gate = O.swiglu_backward(d, g, u)
+    for got_b, ref in ((d_up, ut.grad.numpy()), (d_gate, gt.grad.numpy())):
+        got = O.bf16_to_f32(got_b).astype(np.float64)
+        assert np.all(np.abs(got - ref) <= np.abs(ref) * 2.0 ** -8 + 1e-6)
+
+
+@pytest.mark.parametrize("ln", [True, False])
+def test_norm_backward_vs_autograd(ln):
+    """oracle LayerNorm / RMSNorm backward against torch autograd in fp64 (same bf16 inputs, forward statistics from the fp64 forward)"""
+    import torch
+    rng = np.random.default_rng(17 + ln)
+    rows, C_ = 37, 264
+    x = O.f32_to_bf16(rng.normal(0.2, 1.5, (rows, C_)).astype(np.float32))
+    w = O.f32_to_bf16((1 + rng.normal(0, 0.2, C_)).astype(np.float32))
+    dout = O.f32_to_bf16(rng.normal(0, 1.0, (rows, C_)).astype(np.float32))
+    xt = torch.tensor(O.bf16_to_f32(x).astype(np.float64), requires_grad=True)
+    wt = torch.tensor(O.bf16_to_f32(w).astype(np.float64), requires_grad=True)
+    bt = torch.zeros(C_, dtype=torch.float64, requires_grad=True)
+    eps = 1e-5
+    if ln:
+        mean = xt.mean(dim=1, keepdim=True)
+        rstd = 1.0 / torch.sqrt(((xt - mean) ** 2).mean(dim=1, keepdim=True) + eps)
+        y = (xt - mean) * rstd * wt + bt
+    else:
+        mean = None
+        rstd = 1.0 / torch.sqrt((xt ** 2).mean(dim=1, keepdim=True) + eps)
+        y = xt * rstd * wt
+    y.backward(torch.tensor(O.bf16_to_f32(dout).astype(np.float64)))
+    dinp0 = O.f32_to_bf16(rng.normal(0, 0.5, (rows, C_)).astype(np.float32))
+    dw0 = O.f32_to_bf16(rng.normal(0, 0.5, C_).astype(np.float32))
+    db0 = O.f32_to_bf16(rng.normal(0, 0.5, C_).astype(np.float32))
+    dinp, dw, db = dinp0.copy(), dw0.copy(), db0.copy()
+    O.norm_backward(dinp, dw, db if ln else None, dout, x, w, mean.detach().numpy().ravel().astype(np.float32) if ln else None,
+                    rstd.detach().numpy().ravel().astype(np.float32))
+    f = lambda a: O.bf16_to_f32(a).astype(np.float64)
+    ref_dinp = f(dinp0) + xt.grad.numpy()
+    assert np.all(np.abs(f(dinp) - ref_dinp) <= np.abs(ref_dinp) * 2.0 ** -8 + 2e-3 * np.abs(xt.grad.numpy()).max())
+    ref_dw = f(dw0) + wt.grad.numpy()
+    assert np.all(np.abs(f(dw) - ref_dw) <= np.abs(ref_dw) * 2.0 ** -8 + 1e-2)
+    if ln:
+        ref_db = f(db0) + bt.grad.numpy()
+        assert np.all(np.abs(f(db) - ref_db) <= np.abs(ref_db) * 2.0 ** -8 + 1e-2)
+    else:
+        assert np.array_equal(db, db0)
