@@ -196,6 +196,17 @@ int kf_layernorm(kf_ctx* ctx, const kf_bf16* x, const kf_bf16* w, const kf_bf16*
 /* GELU, tanh form (Relu::Forw GELU -> gelu_forward_kernel2, Activation.cu:23-40) */
 int kf_gelu(kf_ctx* ctx, const kf_bf16* x, kf_bf16* y, size_t n);
 
+/* Linear layer backward (SLP::Back, NeuronFuse.cu:495-547; matmul_backward, kernel/gemm.cu:326-370).  w [OC, IC] in any PackedQ / f8 / bf16 storage,
+ * dequantised to bf16 first exactly as the reference's GetDataX does; deltaIn [n, OC] is the gradient of the layer's output, inp [n, IC] its input:
+ *   delta [n, IC]  = (accumulate_delta ? delta : 0) + deltaIn . W        (NULL: skipped)
+ *   gW    [OC, IC] += deltaIn^T . inp                                     (NULL: skipped -- isFixWeight; the bf16 gradient of a quantised weight's master copy)
+ *   gBias [OC]     += column sums of deltaIn                              (NULL: no bias)
+ * fp32 accumulation, bf16 stores (beta = 1 adds the stored bf16 value).  OC a multiple of 64 and >= 128 (so is n when gW is wanted), IC a multiple of 8.
+ * scratch: kf_linear_backward_scratch_bytes(OC, IC, n) bytes of device memory, 256-byte aligned. */
+size_t kf_linear_backward_scratch_bytes(int OC, int IC, int n);
+int kf_linear_backward(kf_ctx* ctx, const kf_weight* w, const kf_bf16* deltaIn, const kf_bf16* inp_or_null, kf_bf16* delta_or_null, kf_bf16* gW_or_null,
+                       kf_bf16* gBias_or_null, int n, int accumulate_delta, void* scratch);
+
 /* LayerNorm / RMSNorm backward (LayerNormal::cuFlow, backward branch, T.cu:605-646: layernorm_backward -> layernorm_backward_kernel10, layernorm.cuh:311-503;
  * RMS: CU_rms_back_llmc, layernorm.cuh:863-1051).  mean == NULL selects RMSNorm.  dinp (the residual-path gradient on entry) becomes
  * bf16(dinp + dL/dinp); dweight (and dbias, LayerNorm with a bias) accumulate the sums over the rows: bf16(sum + old).  rstd (and mean) are the forward's

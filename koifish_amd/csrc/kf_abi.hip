@@ -546,6 +546,58 @@ int kf_gelu(kf_ctx* c, const kf_bf16* x, kf_bf16* y, size_t n) {
     if (!x || !y || n == 0) return fail(KF_INVALID_ARGS, "kf_gelu: bad args");
     RET(kf::gelu_launch(c->stream, x, y, n));
 }
+// scratch layout of kf_linear_backward: [W bf16 OC*IC][W^T bf16 IC*OC][deltaIn^T bf16 OC*n][inp^T bf16 IC*n][bias slabs fp64 ceil(n/256)*OC], each 256-B aligned
+static size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+size_t kf_linear_backward_scratch_bytes(int OC, int IC, int n) {
+    if (OC < 1 || IC < 1 || n < 1) return 0;
+    return 2 * up256((size_t)OC * IC * 2) + up256((size_t)OC * n * 2) + up256((size_t)IC * n * 2) + up256((size_t)((n + 255) / 256) * OC * 8);
+}
+int kf_linear_backward(kf_ctx* c, const kf_weight* w, const kf_bf16* deltaIn, const kf_bf16* inp, kf_bf16* delta, kf_bf16* gW, kf_bf16* gBias, int n, int accumulate_delta,
+                       void* scratch) {
+    CHKCTX(c);
+    int r = check_weight(w, "kf_linear_backward");
+    if (r) return r;
+    if (w->qzeros) return fail(KF_UNSUPPORTED_DATATYPE, "kf_linear_backward: AutoAWQ-layout weights are inference-only");
+    if (!deltaIn || !scratch || n < 1) return fail(KF_INVALID_ARGS, "kf_linear_backward: null deltaIn / scratch or n < 1");
+    if ((gW && !inp) || (!delta && !gW && !gBias)) return fail(KF_INVALID_ARGS, "kf_linear_backward: gW needs inp; nothing to compute");
+    const int OC = w->ne0, IC = w->ne1;
+    // the MFMA kernels contract over multiples of 64 and want 16-byte aligned rows
+    if ((OC % 64) || OC < 128 || (IC % 8) || (gW && ((n % 64) || n < 128)))
+        return fail(KF_INVALID_ARGS, "kf_linear_backward: OC (and n, for the weight gradient) must be multiples of 64 and >= 128, IC a multiple of 8 (got %d %d %d)", OC, IC, n);
+    if (!al16(deltaIn) || (inp && !al16(inp)) || (delta && !al16(delta)) || (gW && !al16(gW)) || ((uintptr_t)scratch & 255))
+        return fail(KF_BLAS_UNALIGN, "kf_linear_backward: tensors must be 16-byte aligned, scratch 256-byte aligned");
+    char* p = (char*)scratch;
+    uint16_t* Wd = (uint16_t*)p;    p += up256((size_t)OC * IC * 2);
+    uint16_t* WdT = (uint16_t*)p;   p += up256((size_t)OC * IC * 2);
+    uint16_t* dInT = (uint16_t*)p;  p += up256((size_t)OC * n * 2);
+    uint16_t* inpT = (uint16_t*)p;  p += up256((size_t)IC * n * 2);
+    double* slabs = (double*)p;
+    if (gBias) {
+        r = kf::colsum_add_launch(c->stream, deltaIn, gBias, n, OC, slabs);
+        if (r != KF_OK) return fail(r, "kf_linear_backward: bias column sums failed with %d", r);
+    }
+    if (delta) { /* delta [n, IC] (+)= deltaIn [n, OC] . W [OC, IC]: rows of W^T are contiguous in the contraction index OC */
+        r = kf::dequant_launch(c->stream, w, Wd);
+        if (r == KF_OK) r = kf::transpose_bf16_launch(c->stream, Wd, WdT, OC, IC);
+        if (r != KF_OK) return fail(r, "kf_linear_backward: dequantise / transpose of the weight failed with %d", r);
+        kf_weight wt;
+        memset(&wt, 0, sizeof(wt));
+        wt.data = WdT, wt.type = KF_BF16, wt.ne0 = IC, wt.ne1 = OC;
+        r = kf::gemm_launch(c->stream, &wt, deltaIn, OC, n, delta, IC, nullptr, 1.0f, accumulate_delta ? 1.0f : 0.0f, nullptr, IC);
+        if (r != KF_OK) return fail(r < 0 ? r : KF_INVALID_ARGS, "kf_linear_backward: input-gradient GEMM not covered (%d)", r);
+    }
+    if (gW) { /* gW [OC, IC] += deltaIn^T [OC, n] . inp [n, IC]: "weight" = inp^T [IC, n], "tokens" = the OC rows of deltaIn^T, contraction over n */
+        r = kf::transpose_bf16_launch(c->stream, deltaIn, dInT, n, OC);
+        if (r == KF_OK) r = kf::transpose_bf16_launch(c->stream, inp, inpT, n, IC);
+        if (r != KF_OK) return fail(r, "kf_linear_backward: operand transposes failed with %d", r);
+        kf_weight xt;
+        memset(&xt, 0, sizeof(xt));
+        xt.data = inpT, xt.type = KF_BF16, xt.ne0 = IC, xt.ne1 = n;
+        r = kf::gemm_launch(c->stream, &xt, dInT, n, OC, gW, IC, nullptr, 1.0f, 1.0f, nullptr, IC);
+        if (r != KF_OK) return fail(r < 0 ? r : KF_INVALID_ARGS, "kf_linear_backward: weight-gradient GEMM not covered (%d)", r);
+    }
+    return KF_OK;
+}
 size_t kf_norm_backward_scratch_bytes(int rows, int dim, int is_layernorm) {
     return sizeof(double) * (size_t)kf::norm_backward_groups(rows < 1 ? 1 : rows) * (is_layernorm ? 2 : 1) * (size_t)(dim < 0 ? 0 : dim);
 }

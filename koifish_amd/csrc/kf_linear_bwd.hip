@@ -1,0 +1,60 @@
+// kf_linear_bwd.hip -- helpers of the linear layer's backward pass (SLP::Back, src/Device/CUDA/NeuronFuse.cu:495-547):
+//   delta  [n, IC] (=|+=) deltaIn [n, OC] . W [OC, IC]          (TASKA_AxB(nIn, B*T, nOut).blasLt(delta, wX, deltaIn), wX = w->GetDataX())
+//   gW     [OC, IC] +=     deltaIn^T [OC, n] . inp [n, IC]       (TASKA_AxB(nIn, nOut, B*T, ..., beta 1).blasLt(ToG(w), inp, deltaIn))
+//   dbias  [OC]     +=     column sums of deltaIn                (matmul_backward_bias_kernel9 + reduce_add_sum_kernel)
+// Like the reference, the weight is first dequantised to bf16 (GetDataX); the three contractions then run on the token-batch MFMA kernels of
+// kf_gemm.hip / kf_gemm2.hip, which contract over the contiguous index of both operands -- so the operands are brought into that form by the
+// tiled bf16 transpose below: delta = gemm(W^T as [IC, OC] rows, deltaIn), gW = gemm(inp^T as [IC, n] rows, deltaIn^T [OC, n]) with beta = 1.
+// This file: the transpose, and the bias column sums (fp64 per 256-row slab, slabs in index order: oracle/kf_oracle.c kfo_colsum_add).
+#include "kf_kernels.h"
+
+namespace kf {
+
+// out[c][r] = in[r][c] for bf16 [R, C] -> [C, R]; 64 x 64 tiles through LDS (rows padded to 66 halfwords: conflict-free column reads)
+__global__ void __launch_bounds__(256) transpose_bf16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int R, int C) {
+    __shared__ uint16_t tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int r = r0 + ty * 16 + i, c = c0 + tx;
+        if (r < R && c < C) tile[ty * 16 + i][tx] = in[(size_t)r * C + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int c = c0 + ty * 16 + i, r = r0 + tx;
+        if (r < R && c < C) out[(size_t)c * R + r] = tile[tx][ty * 16 + i];
+    }
+}
+int transpose_bf16_launch(hipStream_t st, const uint16_t* in, uint16_t* out, int R, int C) {
+    if (R < 1 || C < 1) return KF_INVALID_ARGS;
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, st, in, out, R, C);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+
+// column sums of x [n, C]: slab s = rows 256 s .. 256 s + 255 summed in row order in fp64 -> part[s][C]; then the slabs in index order and
+// bf16(fp32 sum + old) in a second launch
+__global__ void __launch_bounds__(256) colsum_part_kernel(const uint16_t* __restrict__ x, double* __restrict__ part, int n, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
+    if (c >= C) return;
+    const int r1 = (s + 1) * 256 < n ? (s + 1) * 256 : n;
+    double acc = 0.0;
+    for (int r = s * 256; r < r1; r++) acc += (double)bf2f(x[(size_t)r * C + c]);
+    part[(size_t)s * C + c] = acc;
+}
+__global__ void __launch_bounds__(256) colsum_finish_kernel(uint16_t* __restrict__ dst, const double* __restrict__ part, int nslab, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double acc = 0.0;
+    for (int s = 0; s < nslab; s++) acc += part[(size_t)s * C + c];
+    dst[c] = f2bf((float)acc + bf2f(dst[c]));
+}
+int colsum_add_launch(hipStream_t st, const uint16_t* x, uint16_t* dst, int n, int C, double* scratch) {
+    if (n < 1 || C < 1) return KF_INVALID_ARGS;
+    const int nslab = (n + 255) / 256;
+    hipLaunchKernelGGL(colsum_part_kernel, dim3((C + 255) / 256, nslab), dim3(256), 0, st, x, scratch, n, C);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, dst, scratch, nslab, C);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+
+}  // namespace kf

@@ -828,6 +828,21 @@ KFO_API void kfo_norm_backward(uint16_t* dinp, uint16_t* dweight, uint16_t* dbia
     free(pb);
 }
 
+/* Bias gradient of SLP::Back (matmul_backward_bias_kernel9 + reduce_add_sum_kernel, NeuronFuse.cu:511-530): dst[c] = bf16(sum_rows x[r][c] + dst[c]).
+ * The sum: slabs of 256 rows in row order, then the slabs in index order, in fp64 (koifish_amd/csrc/kf_linear_bwd.hip; the reference adds per
+ * block in fp32 and the blocks in index order). */
+KFO_API void kfo_colsum_add(const uint16_t* x, uint16_t* dst, int n, int C) {
+    for (int c = 0; c < C; c++) {
+        double acc = 0.0;
+        for (int s = 0; s * 256 < n; s++) {
+            double a = 0.0;
+            for (int r = s * 256; r < (s + 1) * 256 && r < n; r++) a += (double)kfo_bf16_to_f32(x[(size_t)r * C + c]);
+            acc += a;
+        }
+        dst[c] = kfo_f32_to_bf16((float)acc + kfo_bf16_to_f32(dst[c]));
+    }
+}
+
 /* GELU backward in place (gelu_backward_inplace_kernel, Activation.cu:42-60) and SwiGLU backward (CU_swiglu_back_v0, Activation.cu:245-260): the
  * reference's expressions, evaluated left to right in fp32; tanh and sech^2 from one kfo_expf(2z) (tanhf / coshf in the reference), the sigmoid from
  * kfo_expf; round-to-nearest stores. */

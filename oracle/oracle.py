@@ -325,6 +325,14 @@ def norm_backward(dinp, dweight, dbias, dout, inp, weight, mean, rstd):
     fn(_p(dinp), _p(dweight), _p(dbias) if dbias is not None else None, _p(dout), _p(inp), _p(weight), _p(mn) if mn is not None else None, _p(rs), rows, C_)
 
 
+def colsum_add(x, dst):
+    """dst[c] = bf16(sum_r x[r, c] + dst[c]) in place (uint16 arrays)"""
+    assert x.dtype == np.uint16 and dst.dtype == np.uint16 and x.flags.c_contiguous and dst.flags.c_contiguous
+    fn = lib().kfo_colsum_add
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    fn(_p(x), _p(dst), x.shape[0], x.shape[1])
+
+
 def gelu_backward(d, x):
     """returns gelu'(x) * d (uint16 bf16 arrays)"""
     out = np.ascontiguousarray(d, dtype=np.uint16).copy()

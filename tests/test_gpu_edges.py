@@ -118,12 +118,14 @@ def test_tp_reduce_rank_order(ctx):
     ref = O.add(res, O.f32_to_bf16(tot))
     out = torch.zeros(n, dtype=torch.bfloat16, device=ctx.device)
     pd = torch.from_numpy(p).to(ctx.device)
-    assert ctx.hip.kf_tp_reduce(ctx.h, pd.data_ptr(), R, n, bf16_t(res, ctx.device).data_ptr(), out.data_ptr()) == 0
+    res_d = bf16_t(res, ctx.device)   # named: a temporary is freed as soon as data_ptr() returns
+    assert ctx.hip.kf_tp_reduce(ctx.h, pd.data_ptr(), R, n, res_d.data_ptr(), out.data_ptr()) == 0
     assert np.array_equal(u16(out), ref)
     y = torch.zeros(64, dtype=torch.float32, device=ctx.device)
     ow = O.quantize(rand_w(rng, 64, 512), 64, 512, L.Q4)
     dw = ctx.upload_blob(L.Q4, 64, 512, ow.blob())
     x = O.f32_to_bf16(rng.normal(0, 1, size=512).astype(np.float32))
-    assert ctx.hip.kf_linear_f32(ctx.h, C.byref(dw.desc()), bf16_t(x, ctx.device).data_ptr(), y.data_ptr()) == 0
+    x_d, desc_ = bf16_t(x, ctx.device), dw.desc()
+    assert ctx.hip.kf_linear_f32(ctx.h, C.byref(desc_), x_d.data_ptr(), y.data_ptr()) == 0
     ref32 = O.linear_f32(ow, x)
     assert np.abs(y.cpu().numpy() - ref32).max() <= 1e-5 * np.abs(ref32).max() + 1e-6

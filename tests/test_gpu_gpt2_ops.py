@@ -38,7 +38,8 @@ def test_gelu_bit_exact(ctx):
     rng = np.random.default_rng(5)
     x = O.f32_to_bf16(np.concatenate([rng.normal(0, 3, 70000), [0.0, -0.0, 12.0, -12.0, 1e-30, 40.0, -40.0]]).astype(np.float32))
     y = torch.zeros(x.size, dtype=torch.bfloat16, device=ctx.device)
-    assert ctx.hip.kf_gelu(ctx.h, bf16_t(x, ctx.device).data_ptr(), y.data_ptr(), x.size) == 0
+    xd_ = bf16_t(x, ctx.device)   # named: a temporary is freed as soon as data_ptr() returns
+    assert ctx.hip.kf_gelu(ctx.h, xd_.data_ptr(), y.data_ptr(), x.size) == 0
     ctx.sync()
     assert np.array_equal(u16(y), O.gelu(x))
     xf = O.bf16_to_f32(x).astype(np.float64)
@@ -89,7 +90,8 @@ def test_gpt2_block_forward(ctx):
     # ---- device
     xd = bf16_t(x, dev)
     h1 = torch.zeros(T, C_, dtype=torch.bfloat16, device=dev)
-    assert ctx.hip.kf_layernorm(ctx.h, xd.data_ptr(), bf16_t(ln1w, dev).data_ptr(), bf16_t(ln1b, dev).data_ptr(), h1.data_ptr(), T, C_, 1e-5, None, None) == 0
+    l1w_d, l1b_d, l2w_d, l2b_d = (bf16_t(a_, dev) for a_ in (ln1w, ln1b, ln2w, ln2b))
+    assert ctx.hip.kf_layernorm(ctx.h, xd.data_ptr(), l1w_d.data_ptr(), l1b_d.data_ptr(), h1.data_ptr(), T, C_, 1e-5, None, None) == 0
     qkv = _linear(ctx, dw["qkv"], h1, T, 3 * C_, bias=db["qkv"])
     att = torch.zeros(T, C_, dtype=torch.bfloat16, device=dev)
     q, k, v = qkv[:, :C_], qkv[:, C_:2 * C_], qkv[:, 2 * C_:]
@@ -98,7 +100,7 @@ def test_gpt2_block_forward(ctx):
     assert ctx.hip.kf_attn_prefill(ctx.h, qc.data_ptr(), k.data_ptr(), v.data_ptr(), att.data_ptr(), 0, T, C_, H, H, hd, 3 * C_) == 0, ctx.hip.kf_last_error()
     x2 = _linear(ctx, dw["proj"], att, T, C_, bias=db["proj"], residual=xd)
     h2 = torch.zeros(T, C_, dtype=torch.bfloat16, device=dev)
-    assert ctx.hip.kf_layernorm(ctx.h, x2.data_ptr(), bf16_t(ln2w, dev).data_ptr(), bf16_t(ln2b, dev).data_ptr(), h2.data_ptr(), T, C_, 1e-5, None, None) == 0
+    assert ctx.hip.kf_layernorm(ctx.h, x2.data_ptr(), l2w_d.data_ptr(), l2b_d.data_ptr(), h2.data_ptr(), T, C_, 1e-5, None, None) == 0
     f = _linear(ctx, dw["fc"], h2, T, 4 * C_, bias=db["fc"])
     g = torch.zeros_like(f)
     assert ctx.hip.kf_gelu(ctx.h, f.data_ptr(), g.data_ptr(), f.numel()) == 0
@@ -162,7 +164,8 @@ def test_gpt2_tiny_step(ctx):
         assert ctx.hip.kf_gelu(ctx.h, f.data_ptr(), g.data_ptr(), f.numel()) == 0
         x = _linear(ctx, b["dw"]["proj2"], g, T, C_, bias=b["db"]["proj2"], residual=x2)
     hf = torch.zeros(T, C_, dtype=torch.bfloat16, device=dev)
-    assert ctx.hip.kf_layernorm(ctx.h, x.data_ptr(), bf16_t(lnf[0], dev).data_ptr(), bf16_t(lnf[1], dev).data_ptr(), hf.data_ptr(), T, C_, 1e-5, None, None) == 0
+    lnf_w, lnf_b = bf16_t(lnf[0], dev), bf16_t(lnf[1], dev)
+    assert ctx.hip.kf_layernorm(ctx.h, x.data_ptr(), lnf_w.data_ptr(), lnf_b.data_ptr(), hf.data_ptr(), T, C_, 1e-5, None, None) == 0
     logits = _linear(ctx, dhead, hf, T, Vp)
     logits_fwd = u16(logits).copy()
     losses = torch.zeros(T, dtype=torch.float32, device=dev)
@@ -211,14 +214,16 @@ def test_activation_backward_bit_exact(ctx):
     x = O.f32_to_bf16(np.concatenate([rng.normal(0, 2.0, n - 5), [0.0, 11.0, -11.0, 40.0, -40.0]]).astype(np.float32))
     d = O.f32_to_bf16(rng.normal(0, 1.0, n).astype(np.float32))
     dd = bf16_t(d, ctx.device)
-    assert ctx.hip.kf_gelu_backward(ctx.h, dd.data_ptr(), bf16_t(x, ctx.device).data_ptr(), n) == 0
+    xd_ = bf16_t(x, ctx.device)
+    assert ctx.hip.kf_gelu_backward(ctx.h, dd.data_ptr(), xd_.data_ptr(), n) == 0
     ctx.sync()
     assert np.array_equal(u16(dd), O.gelu_backward(d, x))
     g = O.f32_to_bf16(rng.normal(0, 2.0, n).astype(np.float32))
     u = O.f32_to_bf16(rng.normal(0, 2.0, n).astype(np.float32))
     dd = bf16_t(d, ctx.device)
     dg = torch.zeros(n, dtype=torch.bfloat16, device=ctx.device)
-    assert ctx.hip.kf_swiglu_backward(ctx.h, dd.data_ptr(), dg.data_ptr(), bf16_t(g, ctx.device).data_ptr(), bf16_t(u, ctx.device).data_ptr(), n) == 0
+    gd_, ud_ = bf16_t(g, ctx.device), bf16_t(u, ctx.device)
+    assert ctx.hip.kf_swiglu_backward(ctx.h, dd.data_ptr(), dg.data_ptr(), gd_.data_ptr(), ud_.data_ptr(), n) == 0
     ctx.sync()
     r_up, r_gate = O.swiglu_backward(d, g, u)
     assert np.array_equal(u16(dd), r_up) and np.array_equal(u16(dg), r_gate)
@@ -241,8 +246,9 @@ def test_norm_backward_bit_exact(ctx, rows, dim, ln):
     scratch = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=dev)
     md = torch.from_numpy(mean).to(dev) if ln else None
     rd = torch.from_numpy(rstd).to(dev)
-    assert ctx.hip.kf_norm_backward(ctx.h, d_dinp.data_ptr(), d_dw.data_ptr(), d_db.data_ptr() if ln else None, bf16_t(dout, dev).data_ptr(), bf16_t(x, dev).data_ptr(),
-                                    bf16_t(w, dev).data_ptr(), md.data_ptr() if ln else None, rd.data_ptr(), rows, dim, scratch.data_ptr()) == 0, ctx.hip.kf_last_error()
+    do_d, x_d, w_d = bf16_t(dout, dev), bf16_t(x, dev), bf16_t(w, dev)
+    assert ctx.hip.kf_norm_backward(ctx.h, d_dinp.data_ptr(), d_dw.data_ptr(), d_db.data_ptr() if ln else None, do_d.data_ptr(), x_d.data_ptr(),
+                                    w_d.data_ptr(), md.data_ptr() if ln else None, rd.data_ptr(), rows, dim, scratch.data_ptr()) == 0, ctx.hip.kf_last_error()
     ctx.sync()
     r_dinp, r_dw, r_db = dinp0.copy(), dw0.copy(), db0.copy()
     O.norm_backward(r_dinp, r_dw, r_db if ln else None, dout, x, w, mean, rstd)

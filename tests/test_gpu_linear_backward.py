@@ -1,0 +1,78 @@
+"""Linear layer backward (kf_linear_backward; SLP::Back, NeuronFuse.cu:495-547) through the C-ABI: input gradient, weight gradient and bias gradient
+against fp64 products of the oracle's dequantised weights (the tolerance of the forward GEMM tests: 2^-8 of the output scale, which covers the bf16
+store and any fp32 summation order), the bias gradient bit for bit against the oracle's fixed-order column sums; accumulation into existing
+gradients; the shapes of the GPT-2 and Qwen3 layers."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from koifish_amd import lib as L
+from oracle import oracle as O
+from tests.conftest import bf16_t, u16
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(ctx, t, OC, IC, n, accumulate, with_bias=True, want_gw=True):
+    rng = np.random.default_rng(OC * 7 + IC * 3 + n + t)
+    w = O.f32_to_bf16(rng.normal(0, 0.05, (OC, IC)).astype(np.float32))
+    ow = O.quantize(w, OC, IC, t)
+    dw = ctx.upload_blob(t, OC, IC, ow.blob())
+    dIn = O.f32_to_bf16(rng.normal(0, 1.0, (n, OC)).astype(np.float32))
+    inp = O.f32_to_bf16(rng.normal(0, 1.0, (n, IC)).astype(np.float32))
+    delta0 = O.f32_to_bf16(rng.normal(0, 1.0, (n, IC)).astype(np.float32))
+    gW0 = O.f32_to_bf16(rng.normal(0, 1.0, (OC, IC)).astype(np.float32))
+    gb0 = O.f32_to_bf16(rng.normal(0, 1.0, OC).astype(np.float32))
+    dev = ctx.device
+    d_delta, d_gW, d_gb = bf16_t(delta0, dev), bf16_t(gW0, dev), bf16_t(gb0, dev)
+    nb = ctx.hip.kf_linear_backward_scratch_bytes(OC, IC, n)
+    scratch = torch.empty(nb + 256, dtype=torch.uint8, device=dev)
+    sp = (scratch.data_ptr() + 255) & ~255
+    desc = dw.desc()
+    d_dIn, d_inp = bf16_t(dIn, dev), bf16_t(inp, dev)   # named: a temporary would be freed (and its block reused) as soon as data_ptr() returns
+    rc = ctx.hip.kf_linear_backward(ctx.h, C.byref(desc), d_dIn.data_ptr(), d_inp.data_ptr(), d_delta.data_ptr(), d_gW.data_ptr() if want_gw else None,
+                                    d_gb.data_ptr() if with_bias else None, n, int(accumulate), sp)
+    assert rc == 0, ctx.hip.kf_last_error()
+    ctx.sync()
+    f = lambda a: O.bf16_to_f32(a).astype(np.float64)
+    Wd = f(O.dequant(ow)).reshape(OC, IC)
+    ref_delta = f(dIn) @ Wd + (f(delta0) if accumulate else 0.0)
+    assert np.abs(f(u16(d_delta)) - ref_delta).max() <= 2.0 ** -8 * np.abs(ref_delta).max() + 1e-6
+    if want_gw:
+        ref_gW = f(dIn).T @ f(inp) + f(gW0)
+        assert np.abs(f(u16(d_gW)) - ref_gW).max() <= 2.0 ** -8 * np.abs(ref_gW).max() + 1e-6
+    else:
+        assert np.array_equal(u16(d_gW), gW0)
+    if with_bias:
+        ref_gb = gb0.copy()
+        O.colsum_add(dIn, ref_gb)
+        assert np.array_equal(u16(d_gb), ref_gb)
+    else:
+        assert np.array_equal(u16(d_gb), gb0)
+
+
+@pytest.mark.parametrize("t", [L.Q4, L.F8E5M2, L.BF16])
+@pytest.mark.parametrize("shape", [(256, 128, 128), (1024, 3072, 128), (4800, 1600, 192), (1600, 6400, 320), (1024, 1024, 1024)])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_linear_backward(ctx, t, shape, accumulate):
+    OC, IC, n = shape
+    if t == L.Q4 and (OC * IC) % 128:
+        pytest.skip("group size")
+    _run(ctx, t, OC, IC, n, accumulate)
+
+
+def test_linear_backward_fixed_weight_and_no_bias(ctx):
+    _run(ctx, L.Q4, 512, 1024, 96, False, with_bias=False, want_gw=False)   # isFixWeight: input gradient only; n need not be a multiple of 64 then
+
+
+def test_linear_backward_rejects(ctx):
+    w = O.f32_to_bf16(np.zeros((96, 128), np.float32))
+    ow = O.quantize(w, 96, 128, L.BF16)
+    dw = ctx.upload_blob(L.BF16, 96, 128, ow.blob())
+    desc = dw.desc()
+    z = torch.zeros(64 * 128, dtype=torch.bfloat16, device=ctx.device)
+    scratch = torch.empty(1 << 20, dtype=torch.uint8, device=ctx.device)
+    sp = (scratch.data_ptr() + 255) & ~255
+    assert ctx.hip.kf_linear_backward(ctx.h, C.byref(desc), z.data_ptr(), z.data_ptr(), z.data_ptr(), None, None, 64, 0, sp) == -20   # OC = 96 is not a multiple of 64
