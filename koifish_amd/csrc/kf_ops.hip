@@ -69,15 +69,28 @@ __device__ __forceinline__ float kf_tanhf(float z) {
     const float e = kf_expf(2.0f * z);
     return (e - 1.0f) / (e + 1.0f);
 }
-__global__ void gelu_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, size_t n) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float xi = bf2f(x[i]);
+__device__ __forceinline__ float gelu_f(float xi) {
     const float cube = 0.044715f * xi * xi * xi;
-    y[i] = f2bf(0.5f * xi * (1.0f + kf_tanhf(0.797884583473205566406250f * (xi + cube))));
+    return 0.5f * xi * (1.0f + kf_tanhf(0.797884583473205566406250f * (xi + cube)));
+}
+// 8 elements per thread (16-byte loads and stores) when both pointers are 16-byte aligned, one element per thread otherwise
+__global__ void gelu_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, size_t n, size_t nvec) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nvec) {
+        const u32x4 xv = *reinterpret_cast<const u32x4*>(x + i * 8);
+        const uint32_t xw[4] = {xv.x, xv.y, xv.z, xv.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) o[k] = pack_bf16x2(gelu_f(bf_lo(xw[k])), gelu_f(bf_hi(xw[k])));
+        *reinterpret_cast<u32x4*>(y + i * 8) = u32x4{o[0], o[1], o[2], o[3]};
+    }
+    const size_t t = nvec * 8 + i;
+    if (t < n && (nvec == 0 || i < 8)) y[t] = f2bf(gelu_f(bf2f(x[t])));
 }
 int gelu_launch(hipStream_t st, const uint16_t* x, uint16_t* y, size_t n) {
-    hipLaunchKernelGGL(gelu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n);
+    const size_t nvec = (((uintptr_t)x | (uintptr_t)y) & 15) ? 0 : n / 8;
+    const size_t threads = nvec ? (nvec > 8 ? nvec : 8) : n;
+    hipLaunchKernelGGL(gelu_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, x, y, n, nvec);
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 
@@ -111,14 +124,11 @@ __global__ void gelu_backward_kernel(uint16_t* __restrict__ d_in_out, const uint
         *reinterpret_cast<u32x4*>(d_in_out + i * 8) = u32x4{o[0], o[1], o[2], o[3]};
     }
     const size_t t = nvec * 8 + i;
-    if (i < 8 && t < n) d_in_out[t] = f2bf(gelu_grad(bf2f(x[t]), bf2f(d_in_out[t])));
+    if (t < n && (nvec == 0 || i < 8)) d_in_out[t] = f2bf(gelu_grad(bf2f(x[t]), bf2f(d_in_out[t])));
 }
 int gelu_backward_launch(hipStream_t st, uint16_t* d_in_out, const uint16_t* x, size_t n) {
-    const size_t nvec = (((uintptr_t)d_in_out | (uintptr_t)x) & 15) ? 0 : n / 8;
-    if (nvec == 0 && n > 8) { /* unaligned: element-wise through the tail path would not cover n; fall back to one element per "vector" */
-        return KF_BLAS_UNALIGN;
-    }
-    const size_t threads = nvec > 8 ? nvec : 8;
+    const size_t nvec = (((uintptr_t)d_in_out | (uintptr_t)x) & 15) ? 0 : n / 8; /* unaligned: one element per thread */
+    const size_t threads = nvec ? (nvec > 8 ? nvec : 8) : n;
     hipLaunchKernelGGL(gelu_backward_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_in_out, x, n, nvec);
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
@@ -149,7 +159,7 @@ __global__ void swiglu_backward_kernel(uint16_t* __restrict__ delta_in_out, uint
         *reinterpret_cast<u32x4*>(delta_in_out + i * 8) = u32x4{ou[0], ou[1], ou[2], ou[3]};
     }
     const size_t t = nvec * 8 + i;
-    if (i < 8 && t < n) {
+    if (t < n && (nvec == 0 || i < 8)) {
         float g0, u0;
         swiglu_grad(bf2f(gate[t]), bf2f(up[t]), bf2f(delta_in_out[t]), g0, u0);
         delta_gate[t] = f2bf(g0), delta_in_out[t] = f2bf(u0);
@@ -157,8 +167,7 @@ __global__ void swiglu_backward_kernel(uint16_t* __restrict__ delta_in_out, uint
 }
 int swiglu_backward_launch(hipStream_t st, uint16_t* delta_in_out, uint16_t* delta_gate, const uint16_t* gate, const uint16_t* up, size_t n) {
     const size_t nvec = (((uintptr_t)delta_in_out | (uintptr_t)delta_gate | (uintptr_t)gate | (uintptr_t)up) & 15) ? 0 : n / 8;
-    if (nvec == 0 && n > 8) return KF_BLAS_UNALIGN;
-    const size_t threads = nvec > 8 ? nvec : 8;
+    const size_t threads = nvec ? (nvec > 8 ? nvec : 8) : n;
     hipLaunchKernelGGL(swiglu_backward_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, delta_in_out, delta_gate, gate, up, n, nvec);
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }

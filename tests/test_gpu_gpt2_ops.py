@@ -255,3 +255,21 @@ def test_norm_backward_bit_exact(ctx, rows, dim, ln):
     assert np.array_equal(u16(d_dinp), r_dinp)
     assert np.array_equal(u16(d_dw), r_dw)
     assert np.array_equal(u16(d_db), r_db)
+
+
+def test_activation_kernels_unaligned_and_tails(ctx):
+    """the vectorised element-wise kernels on pointers that are not 16-byte aligned (one element per thread) and on lengths with a tail"""
+    rng = np.random.default_rng(12)
+    for n, off in ((1, 0), (7, 0), (8, 0), (1031, 0), (1031, 3), (4096, 5)):
+        x = O.f32_to_bf16(rng.normal(0, 2.0, n).astype(np.float32))
+        d = O.f32_to_bf16(rng.normal(0, 1.0, n).astype(np.float32))
+        xb = torch.zeros(n + 16, dtype=torch.bfloat16, device=ctx.device)
+        db = torch.zeros(n + 16, dtype=torch.bfloat16, device=ctx.device)
+        yb = torch.zeros(n + 16, dtype=torch.bfloat16, device=ctx.device)
+        xb[off:off + n] = bf16_t(x, ctx.device)
+        db[off:off + n] = bf16_t(d, ctx.device)
+        assert ctx.hip.kf_gelu(ctx.h, xb[off:].data_ptr(), yb[off:].data_ptr(), n) == 0
+        assert ctx.hip.kf_gelu_backward(ctx.h, db[off:].data_ptr(), xb[off:].data_ptr(), n) == 0
+        ctx.sync()
+        assert np.array_equal(u16(yb)[off:off + n], O.gelu(x)) and not u16(yb)[off + n:].any() and not u16(yb)[:off].any()
+        assert np.array_equal(u16(db)[off:off + n], O.gelu_backward(d, x)) and not u16(db)[off + n:].any()
