@@ -196,6 +196,12 @@ int kf_layernorm(kf_ctx* ctx, const kf_bf16* x, const kf_bf16* w, const kf_bf16*
 /* GELU, tanh form (Relu::Forw GELU -> gelu_forward_kernel2, Activation.cu:23-40) */
 int kf_gelu(kf_ctx* ctx, const kf_bf16* x, kf_bf16* y, size_t n);
 
+/* Embedding backward (encoder_backward, kernel/embed.cuh:380-470): dout [B*T, C] is the gradient of  wte[tokens[bt]] + wpe[t].
+ *   dwpe [T, C]        += sum over the batch                         (NULL: no position table, e.g. a RoPE model)
+ *   dwte [V, ldw >= C] += the rows of every position holding that token, in ascending position order   (NULL: skipped)
+ * fp32 sums, bf16(sum + old) stores; tokens outside [0, V) are skipped.  Deterministic (no atomics), all on the device. */
+int kf_embed_backward(kf_ctx* ctx, kf_bf16* dwte_or_null, long long ldw, kf_bf16* dwpe_or_null, const kf_bf16* dout, const int32_t* tokens, int B, int T, int C, int V);
+
 /* Linear layer backward (SLP::Back, NeuronFuse.cu:495-547; matmul_backward, kernel/gemm.cu:326-370).  w [OC, IC] in any PackedQ / f8 / bf16 storage,
  * dequantised to bf16 first exactly as the reference's GetDataX does; deltaIn [n, OC] is the gradient of the layer's output, inp [n, IC] its input:
  *   delta [n, IC]  = (accumulate_delta ? delta : 0) + deltaIn . W        (NULL: skipped)

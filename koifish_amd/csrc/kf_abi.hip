@@ -598,6 +598,14 @@ int kf_linear_backward(kf_ctx* c, const kf_weight* w, const kf_bf16* deltaIn, co
     }
     return KF_OK;
 }
+int kf_embed_backward(kf_ctx* c, kf_bf16* dwte, long long ldw, kf_bf16* dwpe, const kf_bf16* dout, const int32_t* tokens, int B, int T, int C, int V) {
+    CHKCTX(c);
+    if (!dout || !tokens || (!dwte && !dwpe)) return fail(KF_INVALID_ARGS, "kf_embed_backward: null pointer");
+    if (!al16(dout) || (dwte && !al16(dwte)) || (dwpe && !al16(dwpe))) return fail(KF_BLAS_UNALIGN, "kf_embed_backward: tensors must be 16-byte aligned");
+    const int r = kf::embed_backward_launch(c->stream, dwte, ldw, dwpe, dout, tokens, B, T, C, V);
+    if (r == KF_INVALID_ARGS) return fail(r, "kf_embed_backward: needs B, T, V >= 1, C a multiple of 8 up to 8192, ldw >= C a multiple of 8 (got %d %d %d %d %lld)", B, T, C, V, ldw);
+    RET(r);
+}
 size_t kf_norm_backward_scratch_bytes(int rows, int dim, int is_layernorm) {
     return sizeof(double) * (size_t)kf::norm_backward_groups(rows < 1 ? 1 : rows) * (is_layernorm ? 2 : 1) * (size_t)(dim < 0 ? 0 : dim);
 }

@@ -101,6 +101,8 @@ int norm_backward_launch(hipStream_t st, uint16_t* dinp, uint16_t* dweight, uint
 // linear backward helpers (kf_linear_bwd.hip)
 int transpose_bf16_launch(hipStream_t st, const uint16_t* in, uint16_t* out, int R, int C);
 int colsum_add_launch(hipStream_t st, const uint16_t* x, uint16_t* dst, int n, int C, double* scratch); /* scratch: ceil(n / 256) * C doubles */
+// embedding backward (kf_embed_bwd.hip)
+int embed_backward_launch(hipStream_t st, uint16_t* dwte, long long ldw, uint16_t* dwpe, const uint16_t* dout, const int* tokens, int B, int T, int C, int V);
 // fused classifier (kf_loss.hip): cross-entropy loss per row + logit gradient in place
 int fused_classifier_launch(hipStream_t st, uint16_t* logits, float* losses, uint16_t* probs, float dloss, const int* targets, long rows, int V, int P,
                             const int* mask, int write_dlogits);

@@ -828,6 +828,35 @@ KFO_API void kfo_norm_backward(uint16_t* dinp, uint16_t* dweight, uint16_t* dbia
     free(pb);
 }
 
+/* Embedding backward (encoder_backward, kernel/embed.cuh:380-470; wpe_backward_kernel :333-366, wte_backward_kernel :257-331): fp32 sums over the batch
+ * (b ascending) / over the positions holding a token (ascending), then bf16(sum + old).  Tokens outside [0, V) are skipped. */
+KFO_API void kfo_embed_backward(uint16_t* dwte, long long ldw, uint16_t* dwpe, const uint16_t* dout, const int32_t* tokens, int B, int T, int C, int V) {
+    if (dwpe)
+        for (int t = 0; t < T; t++)
+            for (int c = 0; c < C; c++) {
+                float acc = 0.0f;
+                for (int b = 0; b < B; b++) acc += kfo_bf16_to_f32(dout[((size_t)b * T + t) * C + c]);
+                dwpe[(size_t)t * C + c] = kfo_f32_to_bf16(acc + kfo_bf16_to_f32(dwpe[(size_t)t * C + c]));
+            }
+    if (dwte) {
+        const int N = B * T;
+        float* acc = (float*)malloc(sizeof(float) * C);
+        for (int bt = 0; bt < N; bt++) {
+            const int tok = tokens[bt];
+            if (tok < 0 || tok >= V) continue;
+            int lead = 1;
+            for (int i = 0; i < bt && lead; i++) lead = tokens[i] != tok;
+            if (!lead) continue;
+            for (int c = 0; c < C; c++) acc[c] = 0.0f;
+            for (int i = bt; i < N; i++)
+                if (tokens[i] == tok)
+                    for (int c = 0; c < C; c++) acc[c] += kfo_bf16_to_f32(dout[(size_t)i * C + c]);
+            for (int c = 0; c < C; c++) dwte[(size_t)tok * ldw + c] = kfo_f32_to_bf16(acc[c] + kfo_bf16_to_f32(dwte[(size_t)tok * ldw + c]));
+        }
+        free(acc);
+    }
+}
+
 /* Bias gradient of SLP::Back (matmul_backward_bias_kernel9 + reduce_add_sum_kernel, NeuronFuse.cu:511-530): dst[c] = bf16(sum_rows x[r][c] + dst[c]).
  * The sum: slabs of 256 rows in row order, then the slabs in index order, in fp64 (koifish_amd/csrc/kf_linear_bwd.hip; the reference adds per
  * block in fp32 and the blocks in index order). */

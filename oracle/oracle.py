@@ -325,6 +325,16 @@ def norm_backward(dinp, dweight, dbias, dout, inp, weight, mean, rstd):
     fn(_p(dinp), _p(dweight), _p(dbias) if dbias is not None else None, _p(dout), _p(inp), _p(weight), _p(mn) if mn is not None else None, _p(rs), rows, C_)
 
 
+def embed_backward(dwte, dwpe, dout, tokens, B, T, V):
+    """in place on uint16 dwte [V, ldw] (or None) and dwpe [T, C] (or None); dout [B*T, C]"""
+    assert dout.dtype == np.uint16 and dout.flags.c_contiguous
+    C_ = dout.shape[1]
+    tk = np.ascontiguousarray(tokens, dtype=np.int32)
+    fn = lib().kfo_embed_backward
+    fn.argtypes = [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    fn(_p(dwte) if dwte is not None else None, dwte.shape[1] if dwte is not None else C_, _p(dwpe) if dwpe is not None else None, _p(dout), _p(tk), B, T, C_, V)
+
+
 def colsum_add(x, dst):
     """dst[c] = bf16(sum_r x[r, c] + dst[c]) in place (uint16 arrays)"""
     assert x.dtype == np.uint16 and dst.dtype == np.uint16 and x.flags.c_contiguous and dst.flags.c_contiguous

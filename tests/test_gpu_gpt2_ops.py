@@ -273,3 +273,31 @@ def test_activation_kernels_unaligned_and_tails(ctx):
         ctx.sync()
         assert np.array_equal(u16(yb)[off:off + n], O.gelu(x)) and not u16(yb)[off + n:].any() and not u16(yb)[:off].any()
         assert np.array_equal(u16(db)[off:off + n], O.gelu_backward(d, x)) and not u16(db)[off + n:].any()
+
+
+@pytest.mark.parametrize("B,T,C_,V,ldw", [(2, 48, 128, 61, 128), (4, 96, 1600, 300, 1600), (3, 40, 2056, 17, 2064), (1, 300, 64, 5, 64)])
+def test_embed_backward_bit_exact(ctx, B, T, C_, V, ldw):
+    rng = np.random.default_rng(B * T + C_)
+    N = B * T
+    dout = O.f32_to_bf16(rng.normal(0, 1.0, (N, C_)).astype(np.float32))
+    tokens = rng.integers(0, V, N).astype(np.int32)
+    tokens[rng.integers(0, N, 3)] = -1   # masked positions are skipped
+    dwte0 = O.f32_to_bf16(rng.normal(0, 1.0, (V, ldw)).astype(np.float32))
+    dwpe0 = O.f32_to_bf16(rng.normal(0, 1.0, (T, C_)).astype(np.float32))
+    dev = ctx.device
+    d_wte, d_wpe, d_out = bf16_t(dwte0, dev), bf16_t(dwpe0, dev), bf16_t(dout, dev)
+    d_tok = torch.from_numpy(tokens).to(dev)
+    assert ctx.hip.kf_embed_backward(ctx.h, d_wte.data_ptr(), ldw, d_wpe.data_ptr(), d_out.data_ptr(), d_tok.data_ptr(), B, T, C_, V) == 0, ctx.hip.kf_last_error()
+    ctx.sync()
+    r_wte, r_wpe = dwte0.copy(), dwpe0.copy()
+    O.embed_backward(r_wte, r_wpe, dout, tokens, B, T, V)
+    assert np.array_equal(u16(d_wte), r_wte)
+    assert np.array_equal(u16(d_wpe), r_wpe)
+    # independent check of the oracle itself: fp64 scatter-add
+    f = lambda a: O.bf16_to_f32(a).astype(np.float64)
+    ref = f(dwte0)[:, :C_].copy()
+    for i, tk in enumerate(tokens):
+        if 0 <= tk < V:
+            ref[tk] += f(dout[i])
+    assert np.abs(f(r_wte)[:, :C_] - ref).max() <= 2.0 ** -8 * np.abs(ref).max() + 1e-6
+    assert np.array_equal(r_wte[:, C_:], dwte0[:, C_:])
