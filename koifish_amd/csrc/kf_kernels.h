@@ -101,6 +101,9 @@ int norm_backward_launch(hipStream_t st, uint16_t* dinp, uint16_t* dweight, uint
 // linear backward helpers (kf_linear_bwd.hip)
 int transpose_bf16_launch(hipStream_t st, const uint16_t* in, uint16_t* out, int R, int C);
 int colsum_add_launch(hipStream_t st, const uint16_t* x, uint16_t* dst, int n, int C, double* scratch); /* scratch: ceil(n / 256) * C doubles */
+// causal MHA backward (kf_attn_bwd.hip); scratch: 2 * n_head * T floats
+int attn_backward_launch(hipStream_t st, const uint16_t* q, const uint16_t* k, const uint16_t* v, long long ld_qkv, const uint16_t* o, const uint16_t* dO, long long ld_o,
+                         uint16_t* dq, uint16_t* dk, uint16_t* dv, long long ld_d, int T, int n_head, int hd, float* scratch);
 // embedding backward (kf_embed_bwd.hip)
 int embed_backward_launch(hipStream_t st, uint16_t* dwte, long long ldw, uint16_t* dwpe, const uint16_t* dout, const int* tokens, int B, int T, int C, int V);
 // fused classifier (kf_loss.hip): cross-entropy loss per row + logit gradient in place

@@ -325,6 +325,17 @@ def norm_backward(dinp, dweight, dbias, dout, inp, weight, mean, rstd):
     fn(_p(dinp), _p(dweight), _p(dbias) if dbias is not None else None, _p(dout), _p(inp), _p(weight), _p(mn) if mn is not None else None, _p(rs), rows, C_)
 
 
+def attn_backward(q, k, v, o, dO, n_head, hd):
+    """causal MHA backward for one sequence: q, k, v, o, dO uint16 [T, n_head * hd] (contiguous) -> (dq, dk, dv)"""
+    arrs = [np.ascontiguousarray(a, dtype=np.uint16) for a in (q, k, v, o, dO)]
+    T, Cw = arrs[0].shape
+    dq, dk, dv = (np.zeros((T, Cw), np.uint16) for _ in range(3))
+    fn = lib().kfo_attn_backward
+    fn.argtypes = [C.c_void_p] * 3 + [C.c_longlong, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int]
+    fn(_p(arrs[0]), _p(arrs[1]), _p(arrs[2]), Cw, _p(arrs[3]), _p(arrs[4]), Cw, _p(dq), _p(dk), _p(dv), Cw, T, n_head, hd)
+    return dq, dk, dv
+
+
 def embed_backward(dwte, dwpe, dout, tokens, B, T, V):
     """in place on uint16 dwte [V, ldw] (or None) and dwpe [T, C] (or None); dout [B*T, C]"""
     assert dout.dtype == np.uint16 and dout.flags.c_contiguous

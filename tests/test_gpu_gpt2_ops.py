@@ -301,3 +301,47 @@ def test_embed_backward_bit_exact(ctx, B, T, C_, V, ldw):
             ref[tk] += f(dout[i])
     assert np.abs(f(r_wte)[:, :C_] - ref).max() <= 2.0 ** -8 * np.abs(ref).max() + 1e-6
     assert np.array_equal(r_wte[:, C_:], dwte0[:, C_:])
+
+
+@pytest.mark.parametrize("T,H", [(48, 2), (64, 1), (130, 3), (257, 2)])
+@pytest.mark.parametrize("fused_layout", [False, True])
+def test_attn_backward_vs_oracle(ctx, T, H, fused_layout):
+    """causal MHA backward, head_dim 64: separate [T, C] tensors, and q / k / v (and their gradients) as the column blocks of fused [T, 3C] buffers"""
+    hd = 64
+    C_ = H * hd
+    rng = np.random.default_rng(T * 13 + H)
+    mk = lambda: O.f32_to_bf16(rng.normal(0, 1.0, (T, C_)).astype(np.float32))
+    q, k, v, dO = mk(), mk(), mk(), mk()
+    dev = ctx.device
+    if fused_layout:
+        qkv = bf16_t(np.concatenate([q, k, v], axis=1), dev)
+        qd, kd, vd, ld = qkv[:, :C_], qkv[:, C_:2 * C_], qkv[:, 2 * C_:], 3 * C_
+        dqkv = torch.zeros(T, 3 * C_, dtype=torch.bfloat16, device=dev)
+        dqd, dkd, dvd, ldd = dqkv[:, :C_], dqkv[:, C_:2 * C_], dqkv[:, 2 * C_:], 3 * C_
+    else:
+        qd, kd, vd, ld = bf16_t(q, dev), bf16_t(k, dev), bf16_t(v, dev), C_
+        dqd, dkd, dvd = (torch.zeros(T, C_, dtype=torch.bfloat16, device=dev) for _ in range(3))
+        ldd = C_
+    od = torch.zeros(T, C_, dtype=torch.bfloat16, device=dev)
+    qc = qd.contiguous()
+    assert ctx.hip.kf_attn_prefill(ctx.h, qc.data_ptr(), kd.data_ptr(), vd.data_ptr(), od.data_ptr(), 0, T, C_, H, H, hd, ld) == 0, ctx.hip.kf_last_error()
+    dOd = bf16_t(dO, dev)
+    scratch = torch.zeros(ctx.hip.kf_attn_backward_scratch_bytes(T, H) // 4 + 1, dtype=torch.float32, device=dev)
+    assert ctx.hip.kf_attn_backward(ctx.h, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), ld, od.data_ptr(), dOd.data_ptr(), C_, dqd.data_ptr(), dkd.data_ptr(), dvd.data_ptr(), ldd,
+                                    T, H, hd, scratch.data_ptr()) == 0, ctx.hip.kf_last_error()
+    ctx.sync()
+    r_dq, r_dk, r_dv = O.attn_backward(q, k, v, u16(od), dO, H, hd)
+    f = lambda a: O.bf16_to_f32(a).astype(np.float64)
+    for name, got, ref in (("dq", dqd, r_dq), ("dk", dkd, r_dk), ("dv", dvd, r_dv)):
+        g, r = f(u16(got)), f(ref)
+        assert np.abs(g - r).max() <= 2.0 ** -7 * np.abs(r).max(), name
+        assert np.sqrt(((g - r) ** 2).mean()) <= 2.0 ** -9 * np.abs(r).max(), name
+
+
+def test_attn_backward_rejects(ctx):
+    z = torch.zeros(64 * 128, dtype=torch.bfloat16, device=ctx.device)
+    s = torch.zeros(1024, dtype=torch.float32, device=ctx.device)
+    p = z.data_ptr()
+    assert ctx.hip.kf_attn_backward(ctx.h, p, p, p, 128, p, p, 128, p, p, p, 128, 16, 1, 128, s.data_ptr()) == -30000 or \
+        ctx.hip.kf_attn_backward(ctx.h, p, p, p, 128, p, p, 128, p, p, p, 128, 16, 1, 128, s.data_ptr()) < 0   # head_dim 128: not covered yet
+    assert ctx.hip.kf_attn_backward(ctx.h, p, p, p, 32, p, p, 128, p, p, p, 128, 16, 1, 64, s.data_ptr()) == -20     # stride below n_head * head_dim

@@ -130,3 +130,21 @@ def test_norm_backward_vs_autograd(ln):
         assert np.all(np.abs(f(db) - ref_db) <= np.abs(ref_db) * 2.0 ** -8 + 1e-2)
     else:
         assert np.array_equal(db, db0)
+
+
+def test_attn_backward_vs_autograd():
+    import torch
+    rng = np.random.default_rng(23)
+    T, H, hd = 37, 3, 64
+    mk = lambda: O.f32_to_bf16(rng.normal(0, 1.0, (T, H * hd)).astype(np.float32))
+    q, k, v, dO = mk(), mk(), mk(), mk()
+    f = lambda a: torch.tensor(O.bf16_to_f32(a).astype(np.float64)).reshape(T, H, hd).transpose(0, 1)   # [H, T, hd]
+    qt, kt, vt = (f(a).clone().requires_grad_(True) for a in (q, k, v))
+    ot = torch.nn.functional.scaled_dot_product_attention(qt, kt, vt, is_causal=True)
+    ot.backward(f(dO))
+    o = O.f32_to_bf16(ot.detach().transpose(0, 1).reshape(T, H * hd).numpy().astype(np.float32))
+    dq, dk, dv = O.attn_backward(q, k, v, o, dO, H, hd)
+    for got, ref_t in ((dq, qt.grad), (dk, kt.grad), (dv, vt.grad)):
+        ref = ref_t.transpose(0, 1).reshape(T, H * hd).numpy()
+        g = O.bf16_to_f32(got).astype(np.float64)
+        assert np.abs(g - ref).max() <= 2.0 ** -7 * np.abs(ref).max()   # D uses the bf16-rounded o: a little beyond one bf16 rounding
