@@ -1,0 +1,167 @@
+"""BASELINE config 3 as a whole training step at toy size, every operator through the C-ABI: forward (token + position embedding, two hybrid GPT-2 blocks
+-- attention matrices f8e5m2, MLP matrices 4-bit --, final LayerNorm, tied bf16 head, fused classifier) and backward (head, LayerNorm, MLP, GELU,
+attention, QKV, embedding), against torch autograd in fp64 on the dequantised weights.  bf16 activations and gradients against fp64: the
+gradients must agree to a few percent of their scale (max 2^-5, rms 2^-7; observed: max 0.9 %, rms 0.2 %)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from koifish_amd import lib as L
+from oracle import oracle as O
+from tests.conftest import bf16_t, u16
+
+pytestmark = pytest.mark.gpu
+
+
+def _lin(ctx, dw, x, n, m, bias=None, residual=None):
+    y = torch.zeros(n, m, dtype=torch.bfloat16, device=ctx.device)
+    d = dw.desc()
+    assert ctx.hip.kf_linear(ctx.h, C.byref(d), x.data_ptr(), y.data_ptr(), bias.data_ptr() if bias is not None else None, n, 1.0, 0.0, 1 if residual is not None else 0,
+                             residual.data_ptr() if residual is not None else None) == 0, ctx.hip.kf_last_error()
+    return y
+
+
+def test_gpt2_toy_training_step_vs_autograd(ctx):
+    Bn, T, C_, H, NL, V, Vp = 2, 64, 128, 2, 2, 250, 256
+    hd, N = C_ // H, Bn * T
+    dev = ctx.device
+    rng = np.random.default_rng(71)
+    mk = lambda *s, std=0.08: O.f32_to_bf16(rng.normal(0, std, size=s).astype(np.float32))
+    lnw = lambda: O.f32_to_bf16((1 + rng.normal(0, 0.1, C_)).astype(np.float32))
+    f64 = lambda a: torch.tensor(O.bf16_to_f32(a).astype(np.float64))
+    wte = np.zeros((Vp, C_), np.uint16)
+    wte[:V] = mk(V, C_, std=0.2)
+    wpe = mk(T, C_, std=0.05)
+    ids = rng.integers(0, V, N).astype(np.int32)
+    tgt = rng.integers(0, V, N).astype(np.int32)
+    blocks = []
+    for _ in range(NL):
+        W = {"qkv": (mk(3 * C_, C_), mk(3 * C_), L.F8E5M2), "proj": (mk(C_, C_), mk(C_), L.F8E5M2), "fc": (mk(4 * C_, C_), mk(4 * C_), L.Q4), "proj2": (mk(C_, 4 * C_), mk(C_), L.Q4)}
+        ow = {k: O.quantize(v_[0], v_[0].shape[0], v_[0].shape[1], v_[2]) for k, v_ in W.items()}
+        blocks.append(dict(W=W, ow=ow, ln=(lnw(), mk(C_), lnw(), mk(C_)), dw={k: ctx.upload_blob(W[k][2], W[k][0].shape[0], W[k][0].shape[1], ow[k].blob()) for k in W},
+                           db={k: bf16_t(W[k][1], dev) for k in W}, lnd=None))
+    lnf = (lnw(), mk(C_))
+    dhead = ctx.upload_blob(L.BF16, Vp, C_, O.quantize(wte, Vp, C_, L.BF16).blob())
+    zeros = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device=dev)
+    stat = lambda: torch.zeros(N, dtype=torch.float32, device=dev)
+
+    # ------------------------------------------------------------------ forward on the device
+    pos = np.tile(np.arange(T), Bn)
+    e_tok, e_pos = bf16_t(wte[ids], dev), bf16_t(wpe[pos], dev)
+    x = zeros(N, C_)
+    assert ctx.hip.kf_add(ctx.h, e_tok.data_ptr(), e_pos.data_ptr(), x.data_ptr(), N * C_) == 0
+    saved = []
+    for b in blocks:
+        l1w, l1b, l2w, l2b = (bf16_t(a, dev) for a in b["ln"])
+        b["lnd"] = (l1w, l1b, l2w, l2b)
+        h1, m1, r1 = zeros(N, C_), stat(), stat()
+        assert ctx.hip.kf_layernorm(ctx.h, x.data_ptr(), l1w.data_ptr(), l1b.data_ptr(), h1.data_ptr(), N, C_, 1e-5, m1.data_ptr(), r1.data_ptr()) == 0
+        qkv = _lin(ctx, b["dw"]["qkv"], h1, N, 3 * C_, bias=b["db"]["qkv"])
+        att = zeros(N, C_)
+        for s_ in range(Bn):
+            sl = slice(s_ * T, (s_ + 1) * T)
+            qc = qkv[sl, :C_].contiguous()
+            assert ctx.hip.kf_attn_prefill(ctx.h, qc.data_ptr(), qkv[sl, C_:2 * C_].data_ptr(), qkv[sl, 2 * C_:].data_ptr(), att[sl].data_ptr(), 0, T, C_, H, H, hd, 3 * C_) == 0
+        x2 = _lin(ctx, b["dw"]["proj"], att, N, C_, bias=b["db"]["proj"], residual=x)
+        h2, m2, r2 = zeros(N, C_), stat(), stat()
+        assert ctx.hip.kf_layernorm(ctx.h, x2.data_ptr(), l2w.data_ptr(), l2b.data_ptr(), h2.data_ptr(), N, C_, 1e-5, m2.data_ptr(), r2.data_ptr()) == 0
+        fpre = _lin(ctx, b["dw"]["fc"], h2, N, 4 * C_, bias=b["db"]["fc"])
+        g = torch.zeros_like(fpre)
+        assert ctx.hip.kf_gelu(ctx.h, fpre.data_ptr(), g.data_ptr(), fpre.numel()) == 0
+        xo = _lin(ctx, b["dw"]["proj2"], g, N, C_, bias=b["db"]["proj2"], residual=x2)
+        saved.append(dict(x=x, h1=h1, m1=m1, r1=r1, qkv=qkv, att=att, x2=x2, h2=h2, m2=m2, r2=r2, fpre=fpre, g=g))
+        x = xo
+    lfw, lfb = bf16_t(lnf[0], dev), bf16_t(lnf[1], dev)
+    hf, mf, rf = zeros(N, C_), stat(), stat()
+    assert ctx.hip.kf_layernorm(ctx.h, x.data_ptr(), lfw.data_ptr(), lfb.data_ptr(), hf.data_ptr(), N, C_, 1e-5, mf.data_ptr(), rf.data_ptr()) == 0
+    logits = _lin(ctx, dhead, hf, N, Vp)
+    losses = torch.zeros(N, dtype=torch.float32, device=dev)
+    td = torch.from_numpy(tgt).to(dev)
+    assert ctx.hip.kf_fused_classifier(ctx.h, logits.data_ptr(), losses.data_ptr(), None, 1.0 / N, td.data_ptr(), Bn, T, V, Vp, None, 1) == 0
+    # the padded vocabulary columns carry no gradient (the reference's head GEMM runs over V, not Vp, columns of the logit gradient)
+    logits[:, V:] = 0
+
+    # ------------------------------------------------------------------ backward on the device
+    def lin_bwd(dw, dIn, inp, n_out_cols, want_bias=True):
+        d = dw.desc()
+        OC, IC = dIn.shape[1], inp.shape[1]
+        delta, gW, gB = zeros(N, IC), zeros(OC, IC), zeros(OC)
+        sc = torch.empty(ctx.hip.kf_linear_backward_scratch_bytes(OC, IC, N) + 256, dtype=torch.uint8, device=dev)
+        sp = (sc.data_ptr() + 255) & ~255
+        assert ctx.hip.kf_linear_backward(ctx.h, C.byref(d), dIn.data_ptr(), inp.data_ptr(), delta.data_ptr(), gW.data_ptr(), gB.data_ptr() if want_bias else None, N, 0, sp) == 0, \
+            ctx.hip.kf_last_error()
+        return delta, gW, gB
+
+    def ln_bwd(dx, dout, inp, w, mean, rstd):
+        gw, gb = zeros(C_), zeros(C_)
+        sc = torch.empty(ctx.hip.kf_norm_backward_scratch_bytes(N, C_, 1) // 8 + 1, dtype=torch.float64, device=dev)
+        assert ctx.hip.kf_norm_backward(ctx.h, dx.data_ptr(), gw.data_ptr(), gb.data_ptr(), dout.data_ptr(), inp.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(), N, C_,
+                                        sc.data_ptr()) == 0, ctx.hip.kf_last_error()
+        return gw, gb
+
+    grads = {}
+    dhf, g_wte, _ = lin_bwd(dhead, logits, hf, C_, want_bias=False)
+    dx = zeros(N, C_)
+    grads["lnf.w"], grads["lnf.b"] = ln_bwd(dx, dhf, x, lfw, mf, rf)
+    att_sc = torch.zeros(ctx.hip.kf_attn_backward_scratch_bytes(T, H) // 4 + 1, dtype=torch.float32, device=dev)
+    for li in reversed(range(NL)):
+        b, s_ = blocks[li], saved[li]
+        dg, grads["%d.proj2.w" % li], grads["%d.proj2.b" % li] = lin_bwd(b["dw"]["proj2"], dx, s_["g"], 4 * C_)
+        assert ctx.hip.kf_gelu_backward(ctx.h, dg.data_ptr(), s_["fpre"].data_ptr(), dg.numel()) == 0
+        dh2, grads["%d.fc.w" % li], grads["%d.fc.b" % li] = lin_bwd(b["dw"]["fc"], dg, s_["h2"], C_)
+        grads["%d.ln2.w" % li], grads["%d.ln2.b" % li] = ln_bwd(dx, dh2, s_["x2"], b["lnd"][2], s_["m2"], s_["r2"])
+        datt, grads["%d.proj.w" % li], grads["%d.proj.b" % li] = lin_bwd(b["dw"]["proj"], dx, s_["att"], C_)
+        dqkv = zeros(N, 3 * C_)
+        qkv = s_["qkv"]
+        for sq in range(Bn):
+            sl = slice(sq * T, (sq + 1) * T)
+            assert ctx.hip.kf_attn_backward(ctx.h, qkv[sl, :C_].data_ptr(), qkv[sl, C_:2 * C_].data_ptr(), qkv[sl, 2 * C_:].data_ptr(), 3 * C_, s_["att"][sl].data_ptr(),
+                                            datt[sl].data_ptr(), C_, dqkv[sl, :C_].data_ptr(), dqkv[sl, C_:2 * C_].data_ptr(), dqkv[sl, 2 * C_:].data_ptr(), 3 * C_, T, H, hd,
+                                            att_sc.data_ptr()) == 0, ctx.hip.kf_last_error()
+        dh1, grads["%d.qkv.w" % li], grads["%d.qkv.b" % li] = lin_bwd(b["dw"]["qkv"], dqkv, s_["h1"], C_)
+        grads["%d.ln1.w" % li], grads["%d.ln1.b" % li] = ln_bwd(dx, dh1, s_["x"], b["lnd"][0], s_["m1"], s_["r1"])
+    g_wpe = zeros(T, C_)
+    idd = torch.from_numpy(ids).to(dev)
+    assert ctx.hip.kf_embed_backward(ctx.h, g_wte.data_ptr(), C_, g_wpe.data_ptr(), dx.data_ptr(), idd.data_ptr(), Bn, T, C_, Vp) == 0   # tied: on top of the head's gradient
+    ctx.sync()
+    grads["wte"], grads["wpe"] = g_wte, g_wpe
+    dev_loss = float(losses.mean())
+
+    # ------------------------------------------------------------------ the same model in torch, fp64, on the dequantised weights
+    P = {}
+    leaf = lambda a: a.clone().requires_grad_(True)
+    P["wte"], P["wpe"] = leaf(f64(wte)), leaf(f64(wpe))
+    P["lnf.w"], P["lnf.b"] = leaf(f64(lnf[0])), leaf(f64(lnf[1]))
+    for li, b in enumerate(blocks):
+        for k in ("qkv", "proj", "fc", "proj2"):
+            P["%d.%s.w" % (li, k)] = leaf(f64(O.dequant(b["ow"][k])).reshape(b["W"][k][0].shape))
+            P["%d.%s.b" % (li, k)] = leaf(f64(b["W"][k][1]))
+        for j, nm in enumerate(("ln1.w", "ln1.b", "ln2.w", "ln2.b")):
+            P["%d.%s" % (li, nm)] = leaf(f64(b["ln"][j]))
+    F = torch.nn.functional
+    xt = P["wte"][torch.from_numpy(ids).long()] + P["wpe"][torch.from_numpy(pos).long()]
+    for li in range(NL):
+        g_ = lambda nm: P["%d.%s" % (li, nm)]
+        h1 = F.layer_norm(xt, (C_,), g_("ln1.w"), g_("ln1.b"), 1e-5)
+        qkv = h1 @ g_("qkv.w").T + g_("qkv.b")
+        sp4 = lambda t_: t_.reshape(Bn, T, H, hd).transpose(1, 2)
+        at = F.scaled_dot_product_attention(sp4(qkv[:, :C_]), sp4(qkv[:, C_:2 * C_]), sp4(qkv[:, 2 * C_:]), is_causal=True).transpose(1, 2).reshape(N, C_)
+        x2 = xt + at @ g_("proj.w").T + g_("proj.b")
+        h2 = F.layer_norm(x2, (C_,), g_("ln2.w"), g_("ln2.b"), 1e-5)
+        xt = x2 + F.gelu(h2 @ g_("fc.w").T + g_("fc.b"), approximate="tanh") @ g_("proj2.w").T + g_("proj2.b")
+    hft = F.layer_norm(xt, (C_,), P["lnf.w"], P["lnf.b"], 1e-5)
+    loss = F.cross_entropy((hft @ P["wte"].T)[:, :V], torch.from_numpy(tgt).long())
+    loss.backward()
+    ref_loss = float(loss.detach())
+    assert abs(dev_loss - ref_loss) <= 2.0 ** -7 * ref_loss
+    worst = []
+    for name, gd in grads.items():
+        ref = P[name].grad.numpy()
+        got = O.bf16_to_f32(u16(gd)).astype(np.float64).reshape(ref.shape)
+        sc_ = np.abs(ref).max()
+        mx, rms = np.abs(got - ref).max() / sc_, np.sqrt(((got - ref) ** 2).mean()) / sc_
+        worst.append((mx, rms, name))
+        assert mx <= 2.0 ** -5 and rms <= 2.0 ** -7, "%s: max %.4f rms %.4f of scale" % (name, mx, rms)
+    print("largest gradient deviations (max, rms, tensor):", sorted(worst, reverse=True)[:3])
