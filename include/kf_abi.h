@@ -199,8 +199,7 @@ int kf_gelu(kf_ctx* ctx, const kf_bf16* x, kf_bf16* y, size_t n);
 /* Causal multi-head attention backward for one sequence of T tokens (the training path's SDPA backward: cudnn-frontend in the reference,
  * QKV.cu:130-315, 427-447).  q, k, v: rows of n_head * head_dim with row stride ld_qkv (e.g. the three column blocks of a fused [T, 3C] buffer);
  * o (the forward output) and dO with stride ld_o; dq, dk, dv with stride ld_d (e.g. the column blocks of the gradient of the fused buffer).
- * scale 1/sqrt(head_dim), fp32 softmax recomputed from q and k, bf16 stores.  head_dim 64 in this version (KF_UNSUPPORTED_DATATYPE otherwise);
- * n_kv == n_head.  scratch: kf_attn_backward_scratch_bytes(T, n_head) bytes (the rows' log-sum-exp and dO.O). */
+ * scale 1/sqrt(head_dim), fp32 softmax recomputed from q and k, bf16 stores.  head_dim 64 or 128 (KF_UNSUPPORTED_DATATYPE otherwise); n_kv == n_head.  scratch: kf_attn_backward_scratch_bytes(T, n_head) bytes (the rows' log-sum-exp and dO.O). */
 size_t kf_attn_backward_scratch_bytes(int T, int n_head);
 int kf_attn_backward(kf_ctx* ctx, const kf_bf16* q, const kf_bf16* k, const kf_bf16* v, long long ld_qkv, const kf_bf16* o, const kf_bf16* dO, long long ld_o, kf_bf16* dq,
                      kf_bf16* dk, kf_bf16* dv, long long ld_d, int T, int n_head, int head_dim, void* scratch);

@@ -4,12 +4,15 @@
 // what is restated is the mathematics of softmax attention (scale = 1/sqrt(hd), causal mask, fp32 softmax, bf16 tensors):
 //   S = scale Q K^T,  P = softmax_causal(S),  O = P V
 //   D_i = sum_d dO_i[d] O_i[d];  dV = P^T dO;  dP = dO V^T;  dS = P o (dP - D);  dQ = scale dS K;  dK = scale dS^T Q.
-// First version, VALU arithmetic on LDS tiles (the MFMA flash form is the follow-up), two launches per (sequence):
+// This file: the first version, VALU arithmetic on LDS tiles (KF_ATTN_BWD=valu; the default is the MFMA flash form of kf_attn_bwd_mfma.hip,
+// which attn_backward_launch below tries first), two launches per sequence:
 //   attn_bwd_dq_kernel : one workgroup per (64-query tile, head); thread = (query row, quarter of the key tile).  Pass A over the key tiles gives the
 //                        row's log-sum-exp L, pass B recomputes P and accumulates dQ; L and D go to scratch for the second launch.
 //   attn_bwd_dkv_kernel: one workgroup per (64-key tile, head); thread = (key row, half of head_dim, half of the query tile); walks the query tiles
 //                        from the diagonal down, recomputes P from L, accumulates dK and dV.
 // Scores are recomputed in fp32 (no bf16 rounding of S), exp through v_exp_f32; outputs are single bf16 stores.  head_dim 64.
+#include <stdlib.h>
+
 #include "kf_kernels.h"
 
 namespace kf {
@@ -228,6 +231,15 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const uint16_t* __res
 int attn_backward_launch(hipStream_t st, const uint16_t* q, const uint16_t* k, const uint16_t* v, long long ld_qkv, const uint16_t* o, const uint16_t* dO, long long ld_o,
                          uint16_t* dq, uint16_t* dk, uint16_t* dv, long long ld_d, int T, int n_head, int hd, float* scratch) {
     if (T < 1 || n_head < 1) return KF_INVALID_ARGS;
+    static int form = -1; /* KF_ATTN_BWD=valu keeps this file's first version (head_dim 64 only); default: the MFMA form of kf_attn_bwd_mfma.hip */
+    if (form < 0) {
+        const char* e = getenv("KF_ATTN_BWD");
+        form = (e && e[0] == 'v') ? 0 : 1;
+    }
+    if (form == 1) {
+        const int rc = attn_backward_mfma_launch(st, q, k, v, ld_qkv, o, dO, ld_o, dq, dk, dv, ld_d, T, n_head, hd, scratch);
+        if (rc != 1) return rc;
+    }
     if (hd != 64) return KF_UNSUPPORTED_DATATYPE;
     const float scale = 1.0f / sqrtf((float)hd);
     float* Lb = scratch;

@@ -1,0 +1,263 @@
+// kf_attn_bwd_mfma.hip -- causal multi-head attention backward on MFMA (flash form), gfx950 / wave64.  Same contract as kf_attn_bwd.hip (its
+// header has the mathematics and the reference), same two-launch split, the tile algebra of the forward kernel (kf_attn_prefill.hip):
+//
+//   dQ launch, workgroup = 128 query columns (32 per wave), key tiles of 32 staged in LDS (K and V row-major, K also transposed):
+//     pass A   S^T[key][col] = K . Q^T                      -> the column's log-sum-exp L (and D = dO . O from registers), kept for launch 2
+//     pass B   S^T again, dP^T[key][col] = V . dO^T         A = K / V rows (ds_read_b128), B = Q / dO rows (registers, loaded once)
+//              dS^T = exp(scale S^T - L) o (dP^T - D)       element-wise on the accumulators: a column lives in one lane pair
+//              dQ^T[d][col] += K^T[d][key] . dS^T[key][col] the dS^T registers, packed to bf16, ARE the B operand (free contraction order)
+//   dK/dV launch, workgroup = 128 key columns, query tiles of 32 from the diagonal down (Q and dO row-major and transposed, L and D of the tile):
+//              S[q][key] = Q . K^T, dP[q][key] = dO . V^T   A = Q / dO rows, B = K / V rows of the column (registers)
+//              P = exp(scale S - L_q), dS = P o (dP - D_q)  L, D per accumulator ROW: four ds_read_b128 each
+//              dV^T[d][key] += dO^T[d][q] . P[q][key],  dK^T[d][key] += Q^T[d][q] . dS[q][key]
+// P and dS enter their products as single bf16 values (gradients are compared at 2^-7 of scale); everything else fp32.
+#include "kf_kernels.h"
+
+namespace kf {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int AB_T = 32;        /* tile of keys (dQ launch) / queries (dK/dV launch) */
+constexpr int AB_TS = AB_T + 4; /* padded transposed row, elements (72 B) */
+constexpr float AB_LOG2E = 1.44269502162933349609375f;
+
+__device__ __forceinline__ f32x16 ab_zero() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; i++) z[i] = 0.f;
+    return z;
+}
+__device__ __forceinline__ f32x16 ab_mfma(u32x4 A, u32x4 B, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), c, 0, 0, 0);
+}
+// stage a [32][HD] tile of rows (row index clamped to T - 1) row-major (padded rows) and, optionally, transposed [HD][AB_TS]
+template <int HD, bool TRANSPOSE>
+__device__ __forceinline__ void ab_stage(const uint16_t* __restrict__ src, long long ld, size_t hoff, int row0, int T, uint16_t* rows, uint16_t* tr) {
+    constexpr int KS = HD + 8, CH = AB_T * HD / 8;
+    for (int c = threadIdx.x; c < CH; c += 256) {
+        const int row = c / (HD / 8), dc = c - row * (HD / 8);
+        int rr = row0 + row;
+        rr = rr < T ? rr : T - 1;
+        const u32x4 x = *reinterpret_cast<const u32x4*>(src + (size_t)rr * ld + hoff + dc * 8);
+        *reinterpret_cast<u32x4*>(rows + row * KS + dc * 8) = x;
+        if (TRANSPOSE) {
+            const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                tr[(dc * 8 + 2 * e) * AB_TS + row] = (uint16_t)(w[e] & 0xffffu);
+                tr[(dc * 8 + 2 * e + 1) * AB_TS + row] = (uint16_t)(w[e] >> 16);
+            }
+        }
+    }
+}
+// A fragment of a transposed tile for contraction step s2: row (d), slots (j) <-> tile index 16 s2 + (j & 3) + 8 (j >> 2) + 4 h
+__device__ __forceinline__ u32x4 ab_tfrag(const uint16_t* tr, int drow, int s2, int h) {
+    const uint16_t* p = tr + drow * AB_TS + 16 * s2 + 4 * h;
+    const u32x2 lo = *reinterpret_cast<const u32x2*>(p), hi = *reinterpret_cast<const u32x2*>(p + 8);
+    return u32x4{lo.x, lo.y, hi.x, hi.y};
+}
+
+template <int HD>
+__global__ void __launch_bounds__(256) attn_bwd_dq_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v, long long ld_qkv,
+                                                               const uint16_t* __restrict__ o, const uint16_t* __restrict__ dO, long long ld_o, uint16_t* __restrict__ dq,
+                                                               long long ld_d, float* __restrict__ Lbuf, float* __restrict__ Dbuf, int T, float scale) {
+    constexpr int NS = HD / 16, NDB = HD / 32, KS = HD + 8;
+    __shared__ __attribute__((aligned(16))) uint16_t ks[AB_T * KS], vs[AB_T * KS], kt[HD * AB_TS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y, tok0 = blockIdx.x * 128;
+    const size_t hoff = (size_t)head * HD;
+    int tok = tok0 + wave * 32 + r;
+    const bool col_ok = tok < T;
+    if (!col_ok) tok = T - 1;
+    int tok_last = tok0 + 127;
+    tok_last = tok_last < T ? tok_last : T - 1;
+    const int ntile = tok_last / AB_T + 1;
+
+    u32x4 qf[NS], dof[NS];
+    float Dp = 0.f;
+    {
+        const uint16_t* qrow = q + (size_t)tok * ld_qkv + hoff;
+        const uint16_t* drow = dO + (size_t)tok * ld_o + hoff;
+        const uint16_t* orow = o + (size_t)tok * ld_o + hoff;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            qf[s] = *reinterpret_cast<const u32x4*>(qrow + 16 * s + 8 * h);
+            dof[s] = *reinterpret_cast<const u32x4*>(drow + 16 * s + 8 * h);
+            const u32x4 of = *reinterpret_cast<const u32x4*>(orow + 16 * s + 8 * h);
+            const uint32_t a[4] = {dof[s].x, dof[s].y, dof[s].z, dof[s].w}, b[4] = {of.x, of.y, of.z, of.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) Dp = fmaf(bf_lo(a[e]), bf_lo(b[e]), Dp), Dp = fmaf(bf_hi(a[e]), bf_hi(b[e]), Dp);
+        }
+    }
+    const float D = Dp + __shfl_xor(Dp, 32, 64);
+
+    // ---- pass A: log-sum-exp of every column
+    float M = -__builtin_inff(), l = 0.f;
+    for (int t = 0; t < ntile; t++) {
+        __syncthreads();
+        ab_stage<HD, false>(k, ld_qkv, hoff, t * AB_T, T, ks, nullptr);
+        __syncthreads();
+        f32x16 st = ab_zero();
+#pragma unroll
+        for (int s = 0; s < NS; s++) st = ab_mfma(*reinterpret_cast<const u32x4*>(ks + r * KS + 16 * s + 8 * h), qf[s], st);
+        float sc[16], mt = -__builtin_inff();
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int key = t * AB_T + 4 * h + (i & 3) + 8 * (i >> 2);
+            sc[i] = key <= tok ? st[i] * scale : -__builtin_inff();
+            mt = fmaxf(mt, sc[i]);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        if (mt > M) l *= __builtin_amdgcn_exp2f((M - mt) * AB_LOG2E), M = mt;
+#pragma unroll
+        for (int i = 0; i < 16; i++) l += __builtin_amdgcn_exp2f((sc[i] - M) * AB_LOG2E);
+    }
+    l += __shfl_xor(l, 32, 64);
+    const float L = M + __logf(l);
+    if (col_ok && h == 0) Lbuf[(size_t)head * T + tok] = L, Dbuf[(size_t)head * T + tok] = D;
+
+    // ---- pass B: dQ^T
+    f32x16 acc[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; db++) acc[db] = ab_zero();
+    for (int t = 0; t < ntile; t++) {
+        __syncthreads();
+        ab_stage<HD, true>(k, ld_qkv, hoff, t * AB_T, T, ks, kt);
+        ab_stage<HD, false>(v, ld_qkv, hoff, t * AB_T, T, vs, nullptr);
+        __syncthreads();
+        f32x16 st = ab_zero(), dpt = ab_zero();
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            st = ab_mfma(*reinterpret_cast<const u32x4*>(ks + r * KS + 16 * s + 8 * h), qf[s], st);
+            dpt = ab_mfma(*reinterpret_cast<const u32x4*>(vs + r * KS + 16 * s + 8 * h), dof[s], dpt);
+        }
+        uint32_t dw[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            float ds[2];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int ii = 2 * i + e, key = t * AB_T + 4 * h + (ii & 3) + 8 * (ii >> 2);
+                const float p = key <= tok ? __builtin_amdgcn_exp2f((st[ii] * scale - L) * AB_LOG2E) : 0.f;
+                ds[e] = p * (dpt[ii] - D);
+            }
+            dw[i] = pack_bf16x2(ds[0], ds[1]);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+            const u32x4 B = u32x4{dw[4 * s2], dw[4 * s2 + 1], dw[4 * s2 + 2], dw[4 * s2 + 3]};
+#pragma unroll
+            for (int db = 0; db < NDB; db++) acc[db] = ab_mfma(ab_tfrag(kt, db * 32 + r, s2, h), B, acc[db]);
+        }
+    }
+    if (!col_ok) return;
+    uint16_t* out = dq + (size_t)tok * ld_d + hoff;
+#pragma unroll
+    for (int db = 0; db < NDB; db++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int d = 32 * db + 8 * g + 4 * h;
+            *reinterpret_cast<u32x2*>(out + d) = u32x2{pack_bf16x2(acc[db][4 * g] * scale, acc[db][4 * g + 1] * scale), pack_bf16x2(acc[db][4 * g + 2] * scale, acc[db][4 * g + 3] * scale)};
+        }
+}
+
+template <int HD>
+__global__ void __launch_bounds__(256) attn_bwd_dkv_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v, long long ld_qkv,
+                                                                const uint16_t* __restrict__ dO, long long ld_o, uint16_t* __restrict__ dk, uint16_t* __restrict__ dv,
+                                                                long long ld_d, const float* __restrict__ Lbuf, const float* __restrict__ Dbuf, int T, float scale) {
+    constexpr int NS = HD / 16, NDB = HD / 32, KS = HD + 8;
+    __shared__ __attribute__((aligned(16))) uint16_t qs[AB_T * KS], os[AB_T * KS], qt[HD * AB_TS], ot[HD * AB_TS];
+    __shared__ __attribute__((aligned(16))) float Ls[AB_T], Ds[AB_T];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y, key0 = blockIdx.x * 128;
+    const size_t hoff = (size_t)head * HD;
+    int key = key0 + wave * 32 + r;
+    const bool key_ok = key < T;
+    if (!key_ok) key = T - 1;
+    const int wave_key0 = key0 + wave * 32;
+
+    u32x4 kf_[NS], vf[NS];
+    {
+        const uint16_t* krow = k + (size_t)key * ld_qkv + hoff;
+        const uint16_t* vrow = v + (size_t)key * ld_qkv + hoff;
+#pragma unroll
+        for (int s = 0; s < NS; s++) kf_[s] = *reinterpret_cast<const u32x4*>(krow + 16 * s + 8 * h), vf[s] = *reinterpret_cast<const u32x4*>(vrow + 16 * s + 8 * h);
+    }
+    f32x16 dka[NDB], dva[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; db++) dka[db] = ab_zero(), dva[db] = ab_zero();
+    const int ntq = (T + AB_T - 1) / AB_T;
+    for (int t = key0 / AB_T; t < ntq; t++) {
+        __syncthreads();
+        ab_stage<HD, true>(q, ld_qkv, hoff, t * AB_T, T, qs, qt);
+        ab_stage<HD, true>(dO, ld_o, hoff, t * AB_T, T, os, ot);
+        if (tid < AB_T) {
+            const int qi = t * AB_T + tid;
+            Ls[tid] = qi < T ? Lbuf[(size_t)head * T + qi] : 0.f, Ds[tid] = qi < T ? Dbuf[(size_t)head * T + qi] : 0.f;
+        }
+        __syncthreads();
+        if (t * AB_T + AB_T - 1 < wave_key0) continue; /* every query of the tile precedes this wave's keys (barriers are at the loop top) */
+        f32x16 st = ab_zero(), dpt = ab_zero();
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            st = ab_mfma(*reinterpret_cast<const u32x4*>(qs + r * KS + 16 * s + 8 * h), kf_[s], st);
+            dpt = ab_mfma(*reinterpret_cast<const u32x4*>(os + r * KS + 16 * s + 8 * h), vf[s], dpt);
+        }
+        uint32_t pw[8], dw[8];
+#pragma unroll
+        for (int g = 0; g < 4; g++) { /* accumulator rows 8 g + 4 h + {0..3}: one 16-byte read of L and of D */
+            const f32x4 Lq = *reinterpret_cast<const f32x4*>(Ls + 8 * g + 4 * h), Dq = *reinterpret_cast<const f32x4*>(Ds + 8 * g + 4 * h);
+            float p[4], ds[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int qi = t * AB_T + 8 * g + 4 * h + e;
+                const bool valid = key_ok && qi < T && qi >= key;
+                p[e] = valid ? __builtin_amdgcn_exp2f((st[4 * g + e] * scale - Lq[e]) * AB_LOG2E) : 0.f;
+                ds[e] = p[e] * (dpt[4 * g + e] - Dq[e]);
+            }
+            pw[2 * g] = pack_bf16x2(p[0], p[1]), pw[2 * g + 1] = pack_bf16x2(p[2], p[3]);
+            dw[2 * g] = pack_bf16x2(ds[0], ds[1]), dw[2 * g + 1] = pack_bf16x2(ds[2], ds[3]);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+            const u32x4 BP = u32x4{pw[4 * s2], pw[4 * s2 + 1], pw[4 * s2 + 2], pw[4 * s2 + 3]}, BS = u32x4{dw[4 * s2], dw[4 * s2 + 1], dw[4 * s2 + 2], dw[4 * s2 + 3]};
+#pragma unroll
+            for (int db = 0; db < NDB; db++) {
+                dva[db] = ab_mfma(ab_tfrag(ot, db * 32 + r, s2, h), BP, dva[db]);
+                dka[db] = ab_mfma(ab_tfrag(qt, db * 32 + r, s2, h), BS, dka[db]);
+            }
+        }
+    }
+    if (!key_ok) return;
+    uint16_t* okp = dk + (size_t)key * ld_d + hoff;
+    uint16_t* ovp = dv + (size_t)key * ld_d + hoff;
+#pragma unroll
+    for (int db = 0; db < NDB; db++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int d = 32 * db + 8 * g + 4 * h;
+            *reinterpret_cast<u32x2*>(okp + d) = u32x2{pack_bf16x2(dka[db][4 * g] * scale, dka[db][4 * g + 1] * scale), pack_bf16x2(dka[db][4 * g + 2] * scale, dka[db][4 * g + 3] * scale)};
+            *reinterpret_cast<u32x2*>(ovp + d) = u32x2{pack_bf16x2(dva[db][4 * g], dva[db][4 * g + 1]), pack_bf16x2(dva[db][4 * g + 2], dva[db][4 * g + 3])};
+        }
+}
+
+// KF_OK launched; 1 = shape not covered by the MFMA form
+int attn_backward_mfma_launch(hipStream_t st, const uint16_t* q, const uint16_t* k, const uint16_t* v, long long ld_qkv, const uint16_t* o, const uint16_t* dO, long long ld_o,
+                              uint16_t* dq, uint16_t* dk, uint16_t* dv, long long ld_d, int T, int n_head, int hd, float* scratch) {
+    if (hd != 64 && hd != 128) return 1;
+    const float scale = 1.0f / sqrtf((float)hd);
+    float* Lb = scratch;
+    float* Db = scratch + (size_t)n_head * T;
+    const dim3 grid((T + 127) / 128, n_head);
+    if (hd == 64) {
+        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<64>), grid, dim3(256), 0, st, q, k, v, ld_qkv, o, dO, ld_o, dq, ld_d, Lb, Db, T, scale);
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<64>), grid, dim3(256), 0, st, q, k, v, ld_qkv, dO, ld_o, dk, dv, ld_d, Lb, Db, T, scale);
+    } else {
+        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<128>), grid, dim3(256), 0, st, q, k, v, ld_qkv, o, dO, ld_o, dq, ld_d, Lb, Db, T, scale);
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<128>), grid, dim3(256), 0, st, q, k, v, ld_qkv, dO, ld_o, dk, dv, ld_d, Lb, Db, T, scale);
+    }
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+
+}  // namespace kf

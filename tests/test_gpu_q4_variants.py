@@ -17,3 +17,13 @@ def test_q4_matvec_form(knobs):
     env.update(knobs)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_q4_variant_child.py")], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, "%s\n%s\n%s" % (knobs, r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_attention_backward_first_version():
+    """KF_ATTN_BWD=valu selects the first (VALU on LDS tiles, head_dim 64) attention backward of kf_attn_bwd.hip instead of the MFMA form: same tests"""
+    env = dict(os.environ)
+    env["KF_ATTN_BWD"] = "valu"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_gpt2_ops.py"), "-q", "-m", "gpu", "-x", "-k", "attn_backward_vs_oracle and 64"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "passed" in r.stdout
