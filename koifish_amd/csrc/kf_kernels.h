@@ -98,6 +98,7 @@ int swiglu_backward_launch(hipStream_t st, uint16_t* delta_in_out, uint16_t* del
 int norm_backward_groups(int rows);
 int norm_backward_launch(hipStream_t st, uint16_t* dinp, uint16_t* dweight, uint16_t* dbias, const uint16_t* dout, const uint16_t* inp, const uint16_t* weight,
                          const float* mean, const float* rstd, int rows, int C, double* scratch);
+int bias_residual_launch(hipStream_t st, uint16_t* y, const uint16_t* bias, const uint16_t* residual, size_t n, int M); /* kf_ops.hip */
 // linear backward helpers (kf_linear_bwd.hip)
 int transpose_bf16_launch(hipStream_t st, const uint16_t* in, uint16_t* out, int R, int C);
 int colsum_add_launch(hipStream_t st, const uint16_t* x, uint16_t* dst, int n, int C, double* scratch); /* scratch: ceil(n / 256) * C doubles */

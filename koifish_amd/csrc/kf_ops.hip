@@ -193,6 +193,35 @@ int add_launch(hipStream_t st, const uint16_t* a, const uint16_t* b, uint16_t* o
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 
+// epilogue of the library GEMM path (kf_abi.hip lib_gemm): y[t][m] = bf16(y + bias[m]), then bf16(residual + y) -- the order of the fused
+// epilogue (bias, store, residual; kf_gemm_common.h), applied to the GEMM's bf16 result
+__global__ void bias_residual_kernel(uint16_t* __restrict__ y, const uint16_t* __restrict__ bias, const uint16_t* __restrict__ residual, size_t nvec, int M) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvec) return;
+    const int m0 = (int)((i * 8) % (size_t)M);
+    const u32x4 yv = *reinterpret_cast<const u32x4*>(y + i * 8);
+    uint32_t w[4] = {yv.x, yv.y, yv.z, yv.w};
+    if (bias) {
+        const u32x4 bv = *reinterpret_cast<const u32x4*>(bias + m0);
+        const uint32_t b[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) w[k] = pack_bf16x2(bf_lo(w[k]) + bf_lo(b[k]), bf_hi(w[k]) + bf_hi(b[k]));
+    }
+    if (residual) {
+        const u32x4 rv = *reinterpret_cast<const u32x4*>(residual + i * 8);
+        const uint32_t r[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) w[k] = pack_bf16x2(bf_lo(r[k]) + bf_lo(w[k]), bf_hi(r[k]) + bf_hi(w[k]));
+    }
+    *reinterpret_cast<u32x4*>(y + i * 8) = u32x4{w[0], w[1], w[2], w[3]};
+}
+int bias_residual_launch(hipStream_t st, uint16_t* y, const uint16_t* bias, const uint16_t* residual, size_t n, int M) {
+    if ((M % 8) != 0) return KF_INVALID_ARGS;
+    const size_t nvec = n * (size_t)M / 8;
+    hipLaunchKernelGGL(bias_residual_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, st, y, bias, residual, nvec, M);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+
 // ---------------------------------------------------------------- block dequant (CU_Q128toX_, T.cu:245-294; CU_F82Float)
 __device__ __forceinline__ float dq(float step, float zero, float qm) { return round_bf16(round_bf16(step * qm) - zero); }
 

@@ -54,13 +54,38 @@ def _run(ctx, t, OC, IC, n, accumulate, with_bias=True, want_gw=True):
 
 
 @pytest.mark.parametrize("t", [L.Q4, L.F8E5M2, L.BF16])
-@pytest.mark.parametrize("shape", [(256, 128, 128), (1024, 3072, 128), (4800, 1600, 192), (1600, 6400, 320), (1024, 1024, 1024)])
+@pytest.mark.parametrize("shape", [(256, 128, 128), (1024, 3072, 128), (4800, 1600, 192), (1600, 6400, 320), (1024, 1024, 1024), (1600, 1600, 2048), (200, 64, 2112)])
 @pytest.mark.parametrize("accumulate", [False, True])
 def test_linear_backward(ctx, t, shape, accumulate):
     OC, IC, n = shape
     if t == L.Q4 and (OC * IC) % 128:
         pytest.skip("group size")
     _run(ctx, t, OC, IC, n, accumulate)
+
+
+def test_linear_forward_large_batch(ctx):
+    """n >= 2048 rows: the dequantise + vendor-GEMM path of kf_linear (bias and residual applied in a second pass) against the oracle's rows"""
+    rng = np.random.default_rng(4)
+    OC, IC, n = 1600, 1600, 2048
+    for t in (L.Q4, L.F8E5M2, L.BF16):
+        w = O.f32_to_bf16(rng.normal(0, 0.05, (OC, IC)).astype(np.float32))
+        ow = O.quantize(w, OC, IC, t)
+        dw = ctx.upload_blob(t, OC, IC, ow.blob())
+        x = O.f32_to_bf16(rng.normal(0, 1.0, (n, IC)).astype(np.float32))
+        b = O.f32_to_bf16(rng.normal(0, 0.5, OC).astype(np.float32))
+        res = O.f32_to_bf16(rng.normal(0, 1.0, (n, OC)).astype(np.float32))
+        xd, bd, rd = bf16_t(x, ctx.device), bf16_t(b, ctx.device), bf16_t(res, ctx.device)
+        y = torch.zeros(n, OC, dtype=torch.bfloat16, device=ctx.device)
+        desc = dw.desc()
+        assert ctx.hip.kf_linear(ctx.h, C.byref(desc), xd.data_ptr(), y.data_ptr(), bd.data_ptr(), n, 1.0, 0.0, 1, rd.data_ptr()) == 0, ctx.hip.kf_last_error()
+        ctx.sync()
+        f = lambda a: O.bf16_to_f32(a).astype(np.float64)
+        ref = f(x) @ f(O.dequant(ow)).reshape(OC, IC).T + f(b) + f(res)
+        assert np.abs(f(u16(y)) - ref).max() <= 2.0 ** -7 * np.abs(ref).max()
+        rows = [0, 1, 777, n - 1]
+        for r_ in rows:   # and against the oracle's own epilogue order on a few rows: within the double rounding of the two-pass epilogue
+            o_row = O.add(res[r_], O.linear(ow, x[r_], bias=b))
+            assert (np.abs(f(u16(y)[r_]) - f(o_row)) <= 2.0 ** -6 * np.abs(f(o_row)).max()).all()   # up to three bf16 roundings apart at the top of the range
 
 
 def test_linear_backward_fixed_weight_and_no_bias(ctx):

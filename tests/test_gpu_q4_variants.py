@@ -27,3 +27,14 @@ def test_attention_backward_first_version():
                        env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "passed" in r.stdout
+
+
+def test_large_batch_gemm_without_the_vendor_library():
+    """KF_GEMM_LIB=0: token batches of >= 2048 rows stay on the hand-written dequant-GEMM kernels (forward) and on dequantise + transposes + those
+    kernels (backward): the same tests as with the library"""
+    env = dict(os.environ)
+    env["KF_GEMM_LIB"] = "0"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_linear_backward.py"), "-q", "-m", "gpu", "-x", "-k", "2048 or large_batch"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "passed" in r.stdout
