@@ -229,24 +229,29 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const uint16_t* __res
 }
 
 int attn_backward_launch(hipStream_t st, const uint16_t* q, const uint16_t* k, const uint16_t* v, long long ld_qkv, const uint16_t* o, const uint16_t* dO, long long ld_o,
-                         uint16_t* dq, uint16_t* dk, uint16_t* dv, long long ld_d, int T, int n_head, int hd, float* scratch) {
-    if (T < 1 || n_head < 1) return KF_INVALID_ARGS;
+                         uint16_t* dq, uint16_t* dk, uint16_t* dv, long long ld_d, int T, int n_head, int hd, int n_seq, float* scratch) {
+    if (T < 1 || n_head < 1 || n_seq < 1) return KF_INVALID_ARGS;
     static int form = -1; /* KF_ATTN_BWD=valu keeps this file's first version (head_dim 64 only); default: the MFMA form of kf_attn_bwd_mfma.hip */
     if (form < 0) {
         const char* e = getenv("KF_ATTN_BWD");
         form = (e && e[0] == 'v') ? 0 : 1;
     }
     if (form == 1) {
-        const int rc = attn_backward_mfma_launch(st, q, k, v, ld_qkv, o, dO, ld_o, dq, dk, dv, ld_d, T, n_head, hd, scratch);
+        const int rc = attn_backward_mfma_launch(st, q, k, v, ld_qkv, o, dO, ld_o, dq, dk, dv, ld_d, T, n_head, hd, n_seq, scratch);
         if (rc != 1) return rc;
     }
     if (hd != 64) return KF_UNSUPPORTED_DATATYPE;
     const float scale = 1.0f / sqrtf((float)hd);
-    float* Lb = scratch;
-    float* Db = scratch + (size_t)n_head * T;
     const dim3 grid((T + 63) / 64, n_head);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), grid, dim3(256), 0, st, q, k, v, ld_qkv, o, dO, ld_o, dq, ld_d, Lb, Db, T, scale);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<64>), grid, dim3(256), 0, st, q, k, v, ld_qkv, dO, ld_o, dk, dv, ld_d, Lb, Db, T, scale);
+    for (int b = 0; b < n_seq; b++) { /* one sequence per launch pair in this form */
+        const size_t ro = (size_t)b * T;
+        float* Lb = scratch + (size_t)b * 2 * n_head * T;
+        float* Db = Lb + (size_t)n_head * T;
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), grid, dim3(256), 0, st, q + ro * ld_qkv, k + ro * ld_qkv, v + ro * ld_qkv, ld_qkv, o + ro * ld_o, dO + ro * ld_o, ld_o,
+                           dq + ro * ld_d, ld_d, Lb, Db, T, scale);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<64>), grid, dim3(256), 0, st, q + ro * ld_qkv, k + ro * ld_qkv, v + ro * ld_qkv, ld_qkv, dO + ro * ld_o, ld_o, dk + ro * ld_d,
+                           dv + ro * ld_d, ld_d, Lb, Db, T, scale);
+    }
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 

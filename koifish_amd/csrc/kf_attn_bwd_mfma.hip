@@ -59,14 +59,18 @@ __device__ __forceinline__ u32x4 ab_tfrag(const uint16_t* tr, int drow, int s2, 
 }
 
 template <int HD>
-__global__ void __launch_bounds__(256) attn_bwd_dq_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v, long long ld_qkv,
-                                                               const uint16_t* __restrict__ o, const uint16_t* __restrict__ dO, long long ld_o, uint16_t* __restrict__ dq,
-                                                               long long ld_d, float* __restrict__ Lbuf, float* __restrict__ Dbuf, int T, float scale) {
+__global__ void __launch_bounds__(256) attn_bwd_dq_mfma_kernel(const uint16_t* q, const uint16_t* k, const uint16_t* v, long long ld_qkv, const uint16_t* o, const uint16_t* dO, long long ld_o,
+                                                               uint16_t* dq, long long ld_d, float* Lbuf, float* Dbuf, int T, float scale) {
     constexpr int NS = HD / 16, NDB = HD / 32, KS = HD + 8;
     __shared__ __attribute__((aligned(16))) uint16_t ks[AB_T * KS], vs[AB_T * KS], kt[HD * AB_TS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y, tok0 = blockIdx.x * 128;
+    const int head = blockIdx.y, tok0 = (gridDim.x - 1 - blockIdx.x) * 128; /* the longest columns first */
     const size_t hoff = (size_t)head * HD;
+    { /* sequence blockIdx.z: T rows further on in every tensor */
+        const size_t ro = (size_t)blockIdx.z * T;
+        q += ro * ld_qkv, k += ro * ld_qkv, v += ro * ld_qkv, o += ro * ld_o, dO += ro * ld_o, dq += ro * ld_d;
+        Lbuf += (size_t)blockIdx.z * gridDim.y * T, Dbuf += (size_t)blockIdx.z * gridDim.y * T;
+    }
     int tok = tok0 + wave * 32 + r;
     const bool col_ok = tok < T;
     if (!col_ok) tok = T - 1;
@@ -163,15 +167,19 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_mfma_kernel(const uint16_t* _
 }
 
 template <int HD>
-__global__ void __launch_bounds__(256) attn_bwd_dkv_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v, long long ld_qkv,
-                                                                const uint16_t* __restrict__ dO, long long ld_o, uint16_t* __restrict__ dk, uint16_t* __restrict__ dv,
-                                                                long long ld_d, const float* __restrict__ Lbuf, const float* __restrict__ Dbuf, int T, float scale) {
+__global__ void __launch_bounds__(256) attn_bwd_dkv_mfma_kernel(const uint16_t* q, const uint16_t* k, const uint16_t* v, long long ld_qkv, const uint16_t* dO, long long ld_o, uint16_t* dk,
+                                                                uint16_t* dv, long long ld_d, const float* Lbuf, const float* Dbuf, int T, float scale) {
     constexpr int NS = HD / 16, NDB = HD / 32, KS = HD + 8;
     __shared__ __attribute__((aligned(16))) uint16_t qs[AB_T * KS], os[AB_T * KS], qt[HD * AB_TS], ot[HD * AB_TS];
     __shared__ __attribute__((aligned(16))) float Ls[AB_T], Ds[AB_T];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y, key0 = blockIdx.x * 128;
+    const int head = blockIdx.y, key0 = blockIdx.x * 128; /* the first key columns see the most query tiles: already first */
     const size_t hoff = (size_t)head * HD;
+    {
+        const size_t ro = (size_t)blockIdx.z * T;
+        q += ro * ld_qkv, k += ro * ld_qkv, v += ro * ld_qkv, dO += ro * ld_o, dk += ro * ld_d, dv += ro * ld_d;
+        Lbuf += (size_t)blockIdx.z * gridDim.y * T, Dbuf += (size_t)blockIdx.z * gridDim.y * T;
+    }
     int key = key0 + wave * 32 + r;
     const bool key_ok = key < T;
     if (!key_ok) key = T - 1;
@@ -244,12 +252,12 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_mfma_kernel(const uint16_t* 
 
 // KF_OK launched; 1 = shape not covered by the MFMA form
 int attn_backward_mfma_launch(hipStream_t st, const uint16_t* q, const uint16_t* k, const uint16_t* v, long long ld_qkv, const uint16_t* o, const uint16_t* dO, long long ld_o,
-                              uint16_t* dq, uint16_t* dk, uint16_t* dv, long long ld_d, int T, int n_head, int hd, float* scratch) {
+                              uint16_t* dq, uint16_t* dk, uint16_t* dv, long long ld_d, int T, int n_head, int hd, int n_seq, float* scratch) {
     if (hd != 64 && hd != 128) return 1;
     const float scale = 1.0f / sqrtf((float)hd);
     float* Lb = scratch;
-    float* Db = scratch + (size_t)n_head * T;
-    const dim3 grid((T + 127) / 128, n_head);
+    float* Db = scratch + (size_t)n_seq * n_head * T;
+    const dim3 grid((T + 127) / 128, n_head, n_seq);
     if (hd == 64) {
         hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<64>), grid, dim3(256), 0, st, q, k, v, ld_qkv, o, dO, ld_o, dq, ld_d, Lb, Db, T, scale);
         hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<64>), grid, dim3(256), 0, st, q, k, v, ld_qkv, dO, ld_o, dk, dv, ld_d, Lb, Db, T, scale);

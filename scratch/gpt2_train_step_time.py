@@ -56,7 +56,7 @@ g_lnw, g_lnb, g_wte, g_wpe = z(Cn), z(Cn), z(Vp, Cn), z(T, Cn)
 sc_lin = torch.empty(max(ctx.hip.kf_linear_backward_scratch_bytes(oc, ic, N) for oc, ic in ((3 * Cn, Cn), (Cn, Cn), (4 * Cn, Cn), (Cn, 4 * Cn), (Vp, Cn))) + 256, dtype=torch.uint8, device=dev)
 sp_lin = (sc_lin.data_ptr() + 255) & ~255
 sc_ln = torch.empty(ctx.hip.kf_norm_backward_scratch_bytes(N, Cn, 1) // 8 + 1, dtype=torch.float64, device=dev)
-sc_at = torch.empty(ctx.hip.kf_attn_backward_scratch_bytes(T, H) // 4 + 1, dtype=torch.float32, device=dev)
+sc_at = torch.empty(ctx.hip.kf_attn_backward_scratch_bytes(T, H, B) // 4 + 1, dtype=torch.float32, device=dev)
 def lin_bwd(w, dIn, inp, delta, gw, gb, acc=0):
     d = w.desc()
     L.check(ctx.hip.kf_linear_backward(ctx.h, C.byref(d), dIn.data_ptr(), inp.data_ptr(), delta.data_ptr(), gw.data_ptr(), gb.data_ptr() if gb is not None else None, N, acc, sp_lin), "lin_bwd")
@@ -74,10 +74,8 @@ def backward():
         lin_bwd(wfc, d4, a["h2"], dh, gW["fc"], gB["fc"])
         ln_bwd(dx, dh, a["x2"], a["m2"], a["r2"])
         lin_bwd(wproj, dx, a["att"], datt, gW["proj"], gB["proj"])
-        for b in range(B):
-            s = slice(b * T, (b + 1) * T)
-            L.check(ctx.hip.kf_attn_backward(ctx.h, a["qkv"][s, :Cn].data_ptr(), a["qkv"][s, Cn:2 * Cn].data_ptr(), a["qkv"][s, 2 * Cn:].data_ptr(), 3 * Cn, a["att"][s].data_ptr(),
-                                             datt[s].data_ptr(), Cn, dqkv[s, :Cn].data_ptr(), dqkv[s, Cn:2 * Cn].data_ptr(), dqkv[s, 2 * Cn:].data_ptr(), 3 * Cn, T, H, hd, sc_at.data_ptr()), "attn_bwd")
+        L.check(ctx.hip.kf_attn_backward(ctx.h, a["qkv"][:, :Cn].data_ptr(), a["qkv"][:, Cn:2 * Cn].data_ptr(), a["qkv"][:, 2 * Cn:].data_ptr(), 3 * Cn, a["att"].data_ptr(), datt.data_ptr(), Cn,
+                                         dqkv[:, :Cn].data_ptr(), dqkv[:, Cn:2 * Cn].data_ptr(), dqkv[:, 2 * Cn:].data_ptr(), 3 * Cn, T, H, hd, B, sc_at.data_ptr()), "attn_bwd")
         lin_bwd(wqkv, dqkv, a["h1"], dh, gW["qkv"], gB["qkv"])
         ln_bwd(dx, dh, a["x"], a["m1"], a["r1"])
     L.check(ctx.hip.kf_embed_backward(ctx.h, g_wte.data_ptr(), Cn, g_wpe.data_ptr(), dx.data_ptr(), ids.data_ptr(), B, T, Cn, Vp), "embed_bwd")

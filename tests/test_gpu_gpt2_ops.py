@@ -325,9 +325,9 @@ def test_attn_backward_vs_oracle(ctx, T, H, hd, fused_layout):
     qc = qd.contiguous()
     assert ctx.hip.kf_attn_prefill(ctx.h, qc.data_ptr(), kd.data_ptr(), vd.data_ptr(), od.data_ptr(), 0, T, C_, H, H, hd, ld) == 0, ctx.hip.kf_last_error()
     dOd = bf16_t(dO, dev)
-    scratch = torch.zeros(ctx.hip.kf_attn_backward_scratch_bytes(T, H) // 4 + 1, dtype=torch.float32, device=dev)
+    scratch = torch.zeros(ctx.hip.kf_attn_backward_scratch_bytes(T, H, 1) // 4 + 1, dtype=torch.float32, device=dev)
     assert ctx.hip.kf_attn_backward(ctx.h, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), ld, od.data_ptr(), dOd.data_ptr(), C_, dqd.data_ptr(), dkd.data_ptr(), dvd.data_ptr(), ldd,
-                                    T, H, hd, scratch.data_ptr()) == 0, ctx.hip.kf_last_error()
+                                    T, H, hd, 1, scratch.data_ptr()) == 0, ctx.hip.kf_last_error()
     ctx.sync()
     r_dq, r_dk, r_dv = O.attn_backward(q, k, v, u16(od), dO, H, hd)
     f = lambda a: O.bf16_to_f32(a).astype(np.float64)
@@ -341,5 +341,35 @@ def test_attn_backward_rejects(ctx):
     z = torch.zeros(64 * 128, dtype=torch.bfloat16, device=ctx.device)
     s = torch.zeros(1024, dtype=torch.float32, device=ctx.device)
     p = z.data_ptr()
-    assert ctx.hip.kf_attn_backward(ctx.h, p, p, p, 96, p, p, 96, p, p, p, 96, 16, 1, 96, s.data_ptr()) < 0   # head_dim 96: not covered
-    assert ctx.hip.kf_attn_backward(ctx.h, p, p, p, 32, p, p, 128, p, p, p, 128, 16, 1, 64, s.data_ptr()) == -20     # stride below n_head * head_dim
+    assert ctx.hip.kf_attn_backward(ctx.h, p, p, p, 96, p, p, 96, p, p, p, 96, 16, 1, 96, 1, s.data_ptr()) < 0   # head_dim 96: not covered
+    assert ctx.hip.kf_attn_backward(ctx.h, p, p, p, 32, p, p, 128, p, p, p, 128, 16, 1, 64, 1, s.data_ptr()) == -20     # stride below n_head * head_dim
+
+
+def test_attn_backward_batched_sequences(ctx):
+    """n_seq sequences in one call == the sequences one by one"""
+    T, H, hd, Bn = 96, 2, 64, 3
+    C_ = H * hd
+    rng = np.random.default_rng(3)
+    dev = ctx.device
+    mk = lambda: bf16_t(O.f32_to_bf16(rng.normal(0, 1.0, (Bn * T, C_)).astype(np.float32)), dev)
+    q, k, v, dO = mk(), mk(), mk(), mk()
+    o = torch.zeros(Bn * T, C_, dtype=torch.bfloat16, device=dev)
+    for b in range(Bn):
+        sl = slice(b * T, (b + 1) * T)
+        assert ctx.hip.kf_attn_prefill(ctx.h, q[sl].data_ptr(), k[sl].data_ptr(), v[sl].data_ptr(), o[sl].data_ptr(), 0, T, C_, H, H, hd, C_) == 0
+    outs = []
+    for mode in ("batched", "single"):
+        dq, dk, dv = (torch.zeros(Bn * T, C_, dtype=torch.bfloat16, device=dev) for _ in range(3))
+        sc = torch.zeros(ctx.hip.kf_attn_backward_scratch_bytes(T, H, Bn) // 4 + 1, dtype=torch.float32, device=dev)
+        if mode == "batched":
+            assert ctx.hip.kf_attn_backward(ctx.h, q.data_ptr(), k.data_ptr(), v.data_ptr(), C_, o.data_ptr(), dO.data_ptr(), C_, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), C_, T, H, hd, Bn,
+                                            sc.data_ptr()) == 0
+        else:
+            for b in range(Bn):
+                sl = slice(b * T, (b + 1) * T)
+                assert ctx.hip.kf_attn_backward(ctx.h, q[sl].data_ptr(), k[sl].data_ptr(), v[sl].data_ptr(), C_, o[sl].data_ptr(), dO[sl].data_ptr(), C_, dq[sl].data_ptr(), dk[sl].data_ptr(),
+                                                dv[sl].data_ptr(), C_, T, H, hd, 1, sc.data_ptr()) == 0
+        ctx.sync()
+        outs.append((u16(dq), u16(dk), u16(dv)))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)

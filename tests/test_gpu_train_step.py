@@ -105,7 +105,7 @@ def test_gpt2_toy_training_step_vs_autograd(ctx):
     dhf, g_wte, _ = lin_bwd(dhead, logits, hf, C_, want_bias=False)
     dx = zeros(N, C_)
     grads["lnf.w"], grads["lnf.b"] = ln_bwd(dx, dhf, x, lfw, mf, rf)
-    att_sc = torch.zeros(ctx.hip.kf_attn_backward_scratch_bytes(T, H) // 4 + 1, dtype=torch.float32, device=dev)
+    att_sc = torch.zeros(ctx.hip.kf_attn_backward_scratch_bytes(T, H, Bn) // 4 + 1, dtype=torch.float32, device=dev)
     for li in reversed(range(NL)):
         b, s_ = blocks[li], saved[li]
         dg, grads["%d.proj2.w" % li], grads["%d.proj2.b" % li] = lin_bwd(b["dw"]["proj2"], dx, s_["g"], 4 * C_)
@@ -115,11 +115,8 @@ def test_gpt2_toy_training_step_vs_autograd(ctx):
         datt, grads["%d.proj.w" % li], grads["%d.proj.b" % li] = lin_bwd(b["dw"]["proj"], dx, s_["att"], C_)
         dqkv = zeros(N, 3 * C_)
         qkv = s_["qkv"]
-        for sq in range(Bn):
-            sl = slice(sq * T, (sq + 1) * T)
-            assert ctx.hip.kf_attn_backward(ctx.h, qkv[sl, :C_].data_ptr(), qkv[sl, C_:2 * C_].data_ptr(), qkv[sl, 2 * C_:].data_ptr(), 3 * C_, s_["att"][sl].data_ptr(),
-                                            datt[sl].data_ptr(), C_, dqkv[sl, :C_].data_ptr(), dqkv[sl, C_:2 * C_].data_ptr(), dqkv[sl, 2 * C_:].data_ptr(), 3 * C_, T, H, hd,
-                                            att_sc.data_ptr()) == 0, ctx.hip.kf_last_error()
+        assert ctx.hip.kf_attn_backward(ctx.h, qkv[:, :C_].data_ptr(), qkv[:, C_:2 * C_].data_ptr(), qkv[:, 2 * C_:].data_ptr(), 3 * C_, s_["att"].data_ptr(), datt.data_ptr(), C_,
+                                        dqkv[:, :C_].data_ptr(), dqkv[:, C_:2 * C_].data_ptr(), dqkv[:, 2 * C_:].data_ptr(), 3 * C_, T, H, hd, Bn, att_sc.data_ptr()) == 0, ctx.hip.kf_last_error()
         dh1, grads["%d.qkv.w" % li], grads["%d.qkv.b" % li] = lin_bwd(b["dw"]["qkv"], dqkv, s_["h1"], C_)
         grads["%d.ln1.w" % li], grads["%d.ln1.b" % li] = ln_bwd(dx, dh1, s_["x"], b["lnd"][0], s_["m1"], s_["r1"])
     g_wpe = zeros(T, C_)
