@@ -34,7 +34,37 @@ int transpose_bf16_launch(hipStream_t st, const uint16_t* in, uint16_t* out, int
 
 // column sums of x [n, C]: slab s = rows 256 s .. 256 s + 255 summed in row order in fp64 -> part[s][C]; then the slabs in index order and
 // bf16(fp32 sum + old) in a second launch
+// thread = (8-column vector cv, row group g): rows 32 g .. 32 g + 31 of the slab with 16-byte loads, then the 8 row groups in LDS.  fp64 sums of
+// bf16 values are exact (8 significant bits each, far fewer than 2^44 of them), so the grouping changes no bit of the slab's sum.
 __global__ void __launch_bounds__(256) colsum_part_kernel(const uint16_t* __restrict__ x, double* __restrict__ part, int n, int C) {
+    __shared__ double red[8][256];
+    const int cv = threadIdx.x & 31, g = threadIdx.x >> 5, s = blockIdx.y;
+    const int c0 = blockIdx.x * 256 + cv * 8;
+    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (c0 < C) { /* C is a multiple of 8: the vector is inside the row */
+        const int r0 = s * 256 + g * 32;
+        int r1 = r0 + 32;
+        r1 = r1 < n ? r1 : n;
+        for (int r = r0; r < r1; r++) {
+            const u32x4 q = *reinterpret_cast<const u32x4*>(x + (size_t)r * C + c0);
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[2 * k] += (double)bf_lo(w[k]), acc[2 * k + 1] += (double)bf_hi(w[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) red[g][cv * 8 + k] = acc[k];
+    __syncthreads();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < C) {
+        double t = 0.0;
+#pragma unroll
+        for (int gg = 0; gg < 8; gg++) t += red[gg][threadIdx.x];
+        part[(size_t)s * C + c] = t;
+    }
+}
+// any C (scalar loads): used when C is not a multiple of 8 or x is not 16-byte aligned
+__global__ void __launch_bounds__(256) colsum_part_scalar_kernel(const uint16_t* __restrict__ x, double* __restrict__ part, int n, int C) {
     const int c = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
     if (c >= C) return;
     const int r1 = (s + 1) * 256 < n ? (s + 1) * 256 : n;
@@ -52,7 +82,10 @@ __global__ void __launch_bounds__(256) colsum_finish_kernel(uint16_t* __restrict
 int colsum_add_launch(hipStream_t st, const uint16_t* x, uint16_t* dst, int n, int C, double* scratch) {
     if (n < 1 || C < 1) return KF_INVALID_ARGS;
     const int nslab = (n + 255) / 256;
-    hipLaunchKernelGGL(colsum_part_kernel, dim3((C + 255) / 256, nslab), dim3(256), 0, st, x, scratch, n, C);
+    if ((C % 8) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+        hipLaunchKernelGGL(colsum_part_kernel, dim3((C + 255) / 256, nslab), dim3(256), 0, st, x, scratch, n, C);
+    else
+        hipLaunchKernelGGL(colsum_part_scalar_kernel, dim3((C + 255) / 256, nslab), dim3(256), 0, st, x, scratch, n, C);
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, dst, scratch, nslab, C);
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
