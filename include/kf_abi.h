@@ -196,6 +196,12 @@ int kf_layernorm(kf_ctx* ctx, const kf_bf16* x, const kf_bf16* w, const kf_bf16*
 /* GELU, tanh form (Relu::Forw GELU -> gelu_forward_kernel2, Activation.cu:23-40) */
 int kf_gelu(kf_ctx* ctx, const kf_bf16* x, kf_bf16* y, size_t n);
 
+/* kf_attn_prefill for n_seq independent sequences of n_tok tokens each (a training batch), positions 0 .. n_tok - 1, in ONE launch: sequence s owns rows
+ * s * n_tok .. (s + 1) * n_tok - 1 of q / out (row stride q_stride) and of k / v (row stride kv_stride; e.g. the column blocks of a fused [B*T, 3C] buffer).
+ * Same arithmetic as kf_attn_prefill (the MFMA tile kernel).  head_dim 64 or 128. */
+int kf_attn_prefill_batch(kf_ctx* ctx, const kf_bf16* q, const kf_bf16* k, const kf_bf16* v, kf_bf16* out, int n_tok, int64_t q_stride, int n_head, int n_kv, int head_dim,
+                          int kv_stride, int n_seq);
+
 /* Causal multi-head attention backward for n_seq sequences of T tokens each, stored back to back in every tensor (the training path's SDPA
  * backward: cudnn-frontend in the reference,
  * QKV.cu:130-315, 427-447).  q, k, v: rows of n_head * head_dim with row stride ld_qkv (e.g. the three column blocks of a fused [T, 3C] buffer);

@@ -580,6 +580,16 @@ int kf_attn_prefill(kf_ctx* c, const kf_bf16* q, const kf_bf16* kc, const kf_bf1
     RET(kf::attn_launch(c->stream, a));
 }
 
+int kf_attn_prefill_batch(kf_ctx* c, const kf_bf16* q, const kf_bf16* k, const kf_bf16* v, kf_bf16* out, int n_tok, int64_t q_stride, int n_head, int n_kv, int hd,
+                          int kv_stride, int n_seq) {
+    CHKCTX(c);
+    if (!q || !k || !v || !out || n_tok < 1 || n_seq < 1) return fail(KF_INVALID_ARGS, "kf_attn_prefill_batch: bad args");
+    if (!al16(k) || !al16(v) || (kv_stride % 8)) return fail(KF_BLAS_UNALIGN, "kf_attn_prefill_batch: k / v rows not 16-byte aligned");
+    const int rc = kf::attn_prefill_mfma_launch(c->stream, q, k, v, out, 0, n_tok, q_stride, n_head, n_kv, hd, kv_stride, n_seq);
+    if (rc == 1) return fail(KF_INVALID_ARGS, "kf_attn_prefill_batch: shape not covered by the tile kernel (head_dim 64 / 128, n_head / n_kv in 1, 2, 4, 8, 16-byte aligned rows)");
+    RET(rc);
+}
+
 int kf_set_state(kf_ctx* c, int32_t* d_state, int token, int pos) {
     CHKCTX(c);
     if (!d_state) return fail(KF_INVALID_ARGS, "kf_set_state: null state");

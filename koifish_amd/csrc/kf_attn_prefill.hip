@@ -32,6 +32,7 @@ struct AttnPrefillArgs {
     const uint16_t* vcache;
     uint16_t* out;
     int pos0, n_tok, n_kv, kv_stride;
+    int n_seq; /* sequences of n_tok rows each, back to back in q / out and in the K / V rows (blockIdx.z); 1 for prompt prefill */
     long long q_stride;
     float rden;
 };
@@ -55,7 +56,8 @@ __global__ void __launch_bounds__(256) attn_prefill_kernel(const AttnPrefillArgs
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int g = blockIdx.y, tok0 = blockIdx.x * TQ;
+    const int g = blockIdx.y, tok0 = (gridDim.x - 1 - blockIdx.x) * TQ; /* the columns with the most keys first */
+    const size_t seq_row = (size_t)blockIdx.z * a.n_tok;
     const int col = wave * 32 + r;
     const int tq = col / GQ, hq = col - tq * GQ;
     int tok = tok0 + tq;
@@ -70,7 +72,7 @@ __global__ void __launch_bounds__(256) attn_prefill_kernel(const AttnPrefillArgs
     // Q fragments: B operand of S^T, lane (col, h) holds Q[col][16 s + 8 h .. + 8]
     u32x4 qf[NS];
     {
-        const uint16_t* qrow = a.q + (size_t)tok * a.q_stride + (size_t)(g * GQ + hq) * HD;
+        const uint16_t* qrow = a.q + (seq_row + tok) * a.q_stride + (size_t)(g * GQ + hq) * HD;
 #pragma unroll
         for (int s = 0; s < NS; s++) qf[s] = *reinterpret_cast<const u32x4*>(qrow + 16 * s + 8 * h);
     }
@@ -82,7 +84,7 @@ __global__ void __launch_bounds__(256) attn_prefill_kernel(const AttnPrefillArgs
             const int c = tid + 256 * i, key = c / (HD / 8), dc = c - key * (HD / 8);
             int kk = t * AP_KT + key;
             if (kk > kmax) kk = kmax; /* rows past the last needed key are masked below; never read past it */
-            const size_t off = (size_t)kk * a.kv_stride + (size_t)g * HD + dc * 8;
+            const size_t off = (seq_row + kk) * a.kv_stride + (size_t)g * HD + dc * 8;
             kr[i] = *reinterpret_cast<const u32x4*>(a.kcache + off);
             vr[i] = *reinterpret_cast<const u32x4*>(a.vcache + off);
         }
@@ -183,7 +185,7 @@ __global__ void __launch_bounds__(256) attn_prefill_kernel(const AttnPrefillArgs
     l += __shfl_xor(l, 32, 64);
     if (!col_ok) return;
     const float inv = 1.0f / l;
-    uint16_t* orow = a.out + (size_t)tok * a.q_stride + (size_t)(g * GQ + hq) * HD;
+    uint16_t* orow = a.out + (seq_row + tok) * a.q_stride + (size_t)(g * GQ + hq) * HD;
 #pragma unroll
     for (int db = 0; db < NDB; db++)
 #pragma unroll
@@ -208,7 +210,7 @@ static int ap_launch_gq(hipStream_t st, const AttnPrefillArgs& a, int GQ, dim3 g
 
 // KF_OK launched; 1 = shape not covered (the caller falls back to the per-token kernel)
 int attn_prefill_mfma_launch(hipStream_t st, const uint16_t* q, const uint16_t* kc, const uint16_t* vc, uint16_t* out, int pos0, int n_tok, long long q_stride,
-                             int n_head, int n_kv, int hd, int kv_stride) {
+                             int n_head, int n_kv, int hd, int kv_stride, int n_seq) {
     if ((hd != 64 && hd != 128) || n_kv <= 0 || n_head % n_kv != 0) return 1;
     if ((q_stride & 7) != 0 || (kv_stride & 7) != 0 || (reinterpret_cast<uintptr_t>(q) & 15) != 0 || (reinterpret_cast<uintptr_t>(out) & 7) != 0) return 1;
     const int GQ = n_head / n_kv;
@@ -216,8 +218,9 @@ int attn_prefill_mfma_launch(hipStream_t st, const uint16_t* q, const uint16_t* 
     AttnPrefillArgs a;
     a.q = q, a.kcache = kc, a.vcache = vc, a.out = out, a.pos0 = pos0, a.n_tok = n_tok, a.n_kv = n_kv, a.kv_stride = kv_stride, a.q_stride = q_stride;
     a.rden = 1.0f / sqrtf((float)hd);
+    a.n_seq = n_seq;
     const int TQ = 128 / GQ;
-    dim3 grid((n_tok + TQ - 1) / TQ, n_kv);
+    dim3 grid((n_tok + TQ - 1) / TQ, n_kv, n_seq);
     const size_t smem = sizeof(uint16_t) * (2 * (size_t)AP_KT * (hd + 8) + 2 * (size_t)hd * AP_VS);
     const int rc = hd == 128 ? ap_launch_gq<128>(st, a, GQ, grid, smem) : ap_launch_gq<64>(st, a, GQ, grid, smem);
     if (rc) return rc;

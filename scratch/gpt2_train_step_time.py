@@ -36,9 +36,7 @@ def forward():
         ln(a["x"], a["h1"], a["m1"], a["r1"])
         lin(wqkv, a["h1"], a["qkv"], N, bq)
         qc.copy_(a["qkv"][:, :Cn])
-        for b in range(B):
-            s = slice(b * T, (b + 1) * T)
-            L.check(ctx.hip.kf_attn_prefill(ctx.h, qc[s].data_ptr(), a["qkv"][s, Cn:].data_ptr(), a["qkv"][s, 2 * Cn:].data_ptr(), a["att"][s].data_ptr(), 0, T, Cn, H, H, hd, 3 * Cn), "attn")
+        L.check(ctx.hip.kf_attn_prefill_batch(ctx.h, qc.data_ptr(), a["qkv"][:, Cn:].data_ptr(), a["qkv"][:, 2 * Cn:].data_ptr(), a["att"].data_ptr(), T, Cn, H, H, hd, 3 * Cn, B), "attn")
         lin(wproj, a["att"], a["x2"], N, bp, a["x"])
         ln(a["x2"], a["h2"], a["m2"], a["r2"])
         lin(wfc, a["h2"], a["f"], N, bfc)

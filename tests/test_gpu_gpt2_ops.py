@@ -373,3 +373,19 @@ def test_attn_backward_batched_sequences(ctx):
         outs.append((u16(dq), u16(dk), u16(dv)))
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
+
+
+def test_attn_prefill_batch_equals_per_sequence(ctx):
+    T, H, hd, Bn = 100, 2, 64, 3
+    C_ = H * hd
+    rng = np.random.default_rng(9)
+    dev = ctx.device
+    qkv = bf16_t(O.f32_to_bf16(rng.normal(0, 1.0, (Bn * T, 3 * C_)).astype(np.float32)), dev)
+    qc = qkv[:, :C_].contiguous()
+    o1, o2 = (torch.zeros(Bn * T, C_, dtype=torch.bfloat16, device=dev) for _ in range(2))
+    assert ctx.hip.kf_attn_prefill_batch(ctx.h, qc.data_ptr(), qkv[:, C_:].data_ptr(), qkv[:, 2 * C_:].data_ptr(), o1.data_ptr(), T, C_, H, H, hd, 3 * C_, Bn) == 0, ctx.hip.kf_last_error()
+    for b in range(Bn):
+        sl = slice(b * T, (b + 1) * T)
+        assert ctx.hip.kf_attn_prefill(ctx.h, qc[sl].data_ptr(), qkv[sl, C_:2 * C_].data_ptr(), qkv[sl, 2 * C_:].data_ptr(), o2[sl].data_ptr(), 0, T, C_, H, H, hd, 3 * C_) == 0
+    ctx.sync()
+    assert np.array_equal(u16(o1), u16(o2))
