@@ -5,6 +5,8 @@
 #include <string.h>
 
 #include <dlfcn.h>
+
+#include <mutex>
 #include <math.h>
 #include <stdlib.h>
 
@@ -105,6 +107,8 @@ static bool lib_blas_ready(kf_ctx* c) {
     }
     c->blas = (void*)-1;
     if (!enabled) return false;
+    static std::mutex rb_mu; /* contexts of different host threads may get here at the same time */
+    std::lock_guard<std::mutex> lock(rb_mu);
     if (!g_rb.so) {
         g_rb.so = dlopen("librocblas.so.5", RTLD_NOW | RTLD_LOCAL);
         if (!g_rb.so) g_rb.so = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
