@@ -3,6 +3,96 @@
 
 namespace kf {
 
+// ---------------------------------------------------------------- token-batch norms: one WAVE per row
+// RMSNorm / LayerNorm of many rows (prefill chunks, training batches): a workgroup of 4 waves takes 4 rows, lane l holds the 8-element vectors
+// l, l + 64, ... of its row in registers (dim a multiple of 8, <= 512 * NV), the fp64 row sums need only the wave's own reduction -- no LDS, no
+// barrier, one pass over the row.  Same arithmetic as the one-workgroup-per-row kernels below (fp64 sums are order-free: identical bits).
+template <bool IS_LN, int NV>
+__global__ void __launch_bounds__(256) norm_rows_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ b,
+                                                        uint16_t* __restrict__ y, int rows, int dim, float eps, float* __restrict__ mean, float* __restrict__ rstd) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nvec = dim >> 3;
+    const uint16_t* xr = x + (size_t)row * dim;
+    u32x4 xv[NV];
+    bool has[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        has[j] = lane + 64 * j < nvec;
+        xv[j] = *reinterpret_cast<const u32x4*>(xr + (size_t)(has[j] ? lane + 64 * j : 0) * 8);
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        if (!has[j]) continue;
+        const uint32_t q[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const double lo = (double)bf_lo(q[k]), hi = (double)bf_hi(q[k]);
+            if (IS_LN) acc += lo + hi;
+            else acc = fma(lo, lo, acc), acc = fma(hi, hi, acc);
+        }
+    }
+    acc = wave_sum_f64_fast(acc);
+    float m = 0.0f, s;
+    if (IS_LN) {
+        m = (float)acc / (float)dim;
+        double sq = 0.0;
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            if (!has[j]) continue;
+            const uint32_t q[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float d0 = bf_lo(q[k]) - m, d1 = bf_hi(q[k]) - m;
+                sq = fma((double)d0, (double)d0, sq), sq = fma((double)d1, (double)d1, sq);
+            }
+        }
+        sq = wave_sum_f64_fast(sq);
+        s = 1.0f / sqrtf((float)sq / (float)dim + eps);
+    } else {
+        s = 1.0f / sqrtf(fmaf((float)acc, 1.0f / (float)dim, eps));
+    }
+    uint16_t* yr = y + (size_t)row * dim;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        if (!has[j]) continue;
+        const size_t o = (size_t)(lane + 64 * j) * 8;
+        const u32x4 wv = *reinterpret_cast<const u32x4*>(w + o);
+        u32x4 bv = u32x4{0, 0, 0, 0};
+        if (IS_LN && b) bv = *reinterpret_cast<const u32x4*>(b + o);
+        const uint32_t q[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w}, ww[4] = {wv.x, wv.y, wv.z, wv.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
+        uint32_t r[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float o0, o1;
+            if (IS_LN) {
+                const float n0 = s * (bf_lo(q[k]) - m), n1 = s * (bf_hi(q[k]) - m);
+                o0 = n0 * bf_lo(ww[k]) + bf_lo(bb[k]), o1 = n1 * bf_hi(ww[k]) + bf_hi(bb[k]);
+            } else {
+                o0 = (bf_lo(q[k]) * s) * bf_lo(ww[k]), o1 = (bf_hi(q[k]) * s) * bf_hi(ww[k]);
+            }
+            r[k] = pack_bf16x2(o0, o1);
+        }
+        *reinterpret_cast<u32x4*>(yr + o) = u32x4{r[0], r[1], r[2], r[3]};
+    }
+    if (lane == 0) {
+        if (IS_LN && mean) mean[row] = m;
+        if (rstd) rstd[row] = s;
+    }
+}
+template <bool IS_LN>
+static bool norm_rows_launch(hipStream_t st, const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* y, int rows, int dim, float eps, float* mean, float* rstd) {
+    if (rows < 16 || (dim % 8) != 0 || dim > 4096 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(b)) & 15))
+        return false;
+    const dim3 grid((rows + 3) / 4);
+    const int nv = (dim / 8 + 63) / 64;
+    if (nv <= 2) hipLaunchKernelGGL((norm_rows_kernel<IS_LN, 2>), grid, dim3(256), 0, st, x, w, b, y, rows, dim, eps, mean, rstd);
+    else if (nv <= 4) hipLaunchKernelGGL((norm_rows_kernel<IS_LN, 4>), grid, dim3(256), 0, st, x, w, b, y, rows, dim, eps, mean, rstd);
+    else hipLaunchKernelGGL((norm_rows_kernel<IS_LN, 8>), grid, dim3(256), 0, st, x, w, b, y, rows, dim, eps, mean, rstd);
+    return true;
+}
+
 // ---------------------------------------------------------------- RMSNorm: rms_norm_kernel (layernorm.cuh:800-847)
 __global__ void __launch_bounds__(256) rmsnorm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, uint16_t* __restrict__ y, int dim,
                                                       float eps, float inv_dim, float* rstd) {
@@ -16,6 +106,7 @@ __global__ void __launch_bounds__(256) rmsnorm_kernel(const uint16_t* __restrict
 }
 int rmsnorm_launch(hipStream_t st, const uint16_t* x, const uint16_t* w, uint16_t* y, int rows, int dim, float eps, float* rstd) {
     if (dim % 2 != 0 || rows <= 0) return KF_RMS_PARAMS; /* CU_rms_infer refuses odd dims (layernorm.cuh:851-854) */
+    if (norm_rows_launch<false>(st, x, w, nullptr, y, rows, dim, eps, nullptr, rstd)) return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
     hipLaunchKernelGGL(rmsnorm_kernel, dim3(rows), dim3(256), 0, st, x, w, y, dim, eps, 1.0f / (float)dim, rstd);
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
@@ -59,6 +150,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const uint16_t* __restri
 }
 int layernorm_launch(hipStream_t st, const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* y, int rows, int dim, float eps, float* mean, float* rstd) {
     if (rows <= 0 || dim <= 0) return KF_INVALID_ARGS;
+    if (norm_rows_launch<true>(st, x, w, b, y, rows, dim, eps, mean, rstd)) return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
     hipLaunchKernelGGL(layernorm_kernel, dim3(rows), dim3(256), 0, st, x, w, b, y, dim, eps, mean, rstd);
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
