@@ -23,8 +23,9 @@ def _lin(ctx, dw, x, n, m, bias=None, residual=None):
     return y
 
 
-def test_gpt2_toy_training_step_vs_autograd(ctx):
-    Bn, T, C_, H, NL, V, Vp = 2, 64, 128, 2, 2, 250, 256
+@pytest.mark.parametrize("Bn,T", [(2, 64), (8, 256)])   # 128 rows: the hand-written GEMM kernels; 2048 rows: the dequantise + vendor-GEMM path
+def test_gpt2_toy_training_step_vs_autograd(ctx, Bn, T):
+    C_, H, NL, V, Vp = 128, 2, 2, 250, 256
     hd, N = C_ // H, Bn * T
     dev = ctx.device
     rng = np.random.default_rng(71)
