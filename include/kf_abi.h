@@ -202,15 +202,15 @@ int kf_gelu(kf_ctx* ctx, const kf_bf16* x, kf_bf16* y, size_t n);
 int kf_attn_prefill_batch(kf_ctx* ctx, const kf_bf16* q, const kf_bf16* k, const kf_bf16* v, kf_bf16* out, int n_tok, int64_t q_stride, int n_head, int n_kv, int head_dim,
                           int kv_stride, int n_seq);
 
-/* Causal multi-head attention backward for n_seq sequences of T tokens each, stored back to back in every tensor (the training path's SDPA
- * backward: cudnn-frontend in the reference,
- * QKV.cu:130-315, 427-447).  q, k, v: rows of n_head * head_dim with row stride ld_qkv (e.g. the three column blocks of a fused [T, 3C] buffer);
- * o (the forward output) and dO with stride ld_o; dq, dk, dv with stride ld_d (e.g. the column blocks of the gradient of the fused buffer).
- * scale 1/sqrt(head_dim), fp32 softmax recomputed from q and k, bf16 stores.  head_dim 64 or 128 (KF_UNSUPPORTED_DATATYPE otherwise);  n_kv == n_head.
+/* Causal attention backward for n_seq sequences of T tokens each, stored back to back in every tensor (the training path's SDPA backward:
+ * cudnn-frontend in the reference, QKV.cu:130-315, 427-447).  q: rows of n_head * head_dim, k / v: rows of n_kv * head_dim (GQA: n_head a multiple of
+ * n_kv), all with row stride ld_qkv (e.g. the column blocks of a fused q|k|v buffer); o (the forward output) and dO: n_head * head_dim with stride ld_o;
+ * dq (n_head heads) and dk, dv (n_kv heads, summed over the query heads of a group) with stride ld_d.  scale 1/sqrt(head_dim), fp32 softmax recomputed
+ * from q and k, bf16 stores.  head_dim 64 or 128 (KF_UNSUPPORTED_DATATYPE otherwise).
  * scratch: kf_attn_backward_scratch_bytes(T, n_head, n_seq) bytes (the rows' log-sum-exp and dO.O). */
 size_t kf_attn_backward_scratch_bytes(int T, int n_head, int n_seq);
 int kf_attn_backward(kf_ctx* ctx, const kf_bf16* q, const kf_bf16* k, const kf_bf16* v, long long ld_qkv, const kf_bf16* o, const kf_bf16* dO, long long ld_o, kf_bf16* dq,
-                     kf_bf16* dk, kf_bf16* dv, long long ld_d, int T, int n_head, int head_dim, int n_seq, void* scratch);
+                     kf_bf16* dk, kf_bf16* dv, long long ld_d, int T, int n_head, int n_kv, int head_dim, int n_seq, void* scratch);
 
 /* Embedding backward (encoder_backward, kernel/embed.cuh:380-470): dout [B*T, C] is the gradient of  wte[tokens[bt]] + wpe[t].
  *   dwpe [T, C]        += sum over the batch                         (NULL: no position table, e.g. a RoPE model)

@@ -735,13 +735,13 @@ int kf_linear_backward(kf_ctx* c, const kf_weight* w, const kf_bf16* deltaIn, co
 }
 size_t kf_attn_backward_scratch_bytes(int T, int n_head, int n_seq) { return (T < 1 || n_head < 1 || n_seq < 1) ? 0 : sizeof(float) * 2 * (size_t)T * n_head * n_seq; }
 int kf_attn_backward(kf_ctx* c, const kf_bf16* q, const kf_bf16* k, const kf_bf16* v, long long ld_qkv, const kf_bf16* o, const kf_bf16* dO, long long ld_o, kf_bf16* dq,
-                     kf_bf16* dk, kf_bf16* dv, long long ld_d, int T, int n_head, int hd, int n_seq, void* scratch) {
+                     kf_bf16* dk, kf_bf16* dv, long long ld_d, int T, int n_head, int n_kv, int hd, int n_seq, void* scratch) {
     CHKCTX(c);
-    if (!q || !k || !v || !o || !dO || !dq || !dk || !dv || !scratch || n_seq < 1) return fail(KF_INVALID_ARGS, "kf_attn_backward: null pointer or n_seq < 1");
+    if (!q || !k || !v || !o || !dO || !dq || !dk || !dv || !scratch || n_seq < 1 || n_kv < 1 || n_head % n_kv) return fail(KF_INVALID_ARGS, "kf_attn_backward: null pointer, n_seq < 1 or n_head not a multiple of n_kv");
     if (!al16(q) || !al16(k) || !al16(v) || !al16(o) || !al16(dO) || !al16(dq) || !al16(dk) || !al16(dv) || (ld_qkv % 8) || (ld_o % 8) || (ld_d % 8) || ((uintptr_t)scratch & 3))
         return fail(KF_BLAS_UNALIGN, "kf_attn_backward: rows must be 16-byte aligned");
     if (ld_qkv < (long long)n_head * hd || ld_o < (long long)n_head * hd || ld_d < (long long)n_head * hd) return fail(KF_INVALID_ARGS, "kf_attn_backward: row stride below n_head * head_dim");
-    const int r = kf::attn_backward_launch(c->stream, q, k, v, ld_qkv, o, dO, ld_o, dq, dk, dv, ld_d, T, n_head, hd, n_seq, (float*)scratch);
+    const int r = kf::attn_backward_launch(c->stream, q, k, v, ld_qkv, o, dO, ld_o, dq, dk, dv, ld_d, T, n_head, n_kv, hd, n_seq, (float*)scratch);
     if (r == KF_UNSUPPORTED_DATATYPE) return fail(r, "kf_attn_backward: head_dim %d not covered (64, 128)", hd);
     RET(r);
 }

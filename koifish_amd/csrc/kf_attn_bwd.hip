@@ -229,18 +229,18 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const uint16_t* __res
 }
 
 int attn_backward_launch(hipStream_t st, const uint16_t* q, const uint16_t* k, const uint16_t* v, long long ld_qkv, const uint16_t* o, const uint16_t* dO, long long ld_o,
-                         uint16_t* dq, uint16_t* dk, uint16_t* dv, long long ld_d, int T, int n_head, int hd, int n_seq, float* scratch) {
-    if (T < 1 || n_head < 1 || n_seq < 1) return KF_INVALID_ARGS;
+                         uint16_t* dq, uint16_t* dk, uint16_t* dv, long long ld_d, int T, int n_head, int n_kv, int hd, int n_seq, float* scratch) {
+    if (T < 1 || n_head < 1 || n_seq < 1 || n_kv < 1 || n_head % n_kv != 0) return KF_INVALID_ARGS;
     static int form = -1; /* KF_ATTN_BWD=valu keeps this file's first version (head_dim 64 only); default: the MFMA form of kf_attn_bwd_mfma.hip */
     if (form < 0) {
         const char* e = getenv("KF_ATTN_BWD");
         form = (e && e[0] == 'v') ? 0 : 1;
     }
     if (form == 1) {
-        const int rc = attn_backward_mfma_launch(st, q, k, v, ld_qkv, o, dO, ld_o, dq, dk, dv, ld_d, T, n_head, hd, n_seq, scratch);
+        const int rc = attn_backward_mfma_launch(st, q, k, v, ld_qkv, o, dO, ld_o, dq, dk, dv, ld_d, T, n_head, hd, n_seq, scratch, n_kv, ld_qkv, ld_d);
         if (rc != 1) return rc;
     }
-    if (hd != 64) return KF_UNSUPPORTED_DATATYPE;
+    if (hd != 64 || n_kv != n_head) return KF_UNSUPPORTED_DATATYPE; /* the first version: head_dim 64, no GQA */
     const float scale = 1.0f / sqrtf((float)hd);
     const dim3 grid((T + 63) / 64, n_head);
     for (int b = 0; b < n_seq; b++) { /* one sequence per launch pair in this form */

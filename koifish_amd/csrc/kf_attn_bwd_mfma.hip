@@ -60,15 +60,15 @@ __device__ __forceinline__ u32x4 ab_tfrag(const uint16_t* tr, int drow, int s2, 
 
 template <int HD>
 __global__ void __launch_bounds__(256) attn_bwd_dq_mfma_kernel(const uint16_t* q, const uint16_t* k, const uint16_t* v, long long ld_qkv, const uint16_t* o, const uint16_t* dO, long long ld_o,
-                                                               uint16_t* dq, long long ld_d, float* Lbuf, float* Dbuf, int T, float scale) {
+                                                               uint16_t* dq, long long ld_d, float* Lbuf, float* Dbuf, int T, float scale, int gq, long long ld_kv) {
     constexpr int NS = HD / 16, NDB = HD / 32, KS = HD + 8;
     __shared__ __attribute__((aligned(16))) uint16_t ks[AB_T * KS], vs[AB_T * KS], kt[HD * AB_TS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int head = blockIdx.y, tok0 = (gridDim.x - 1 - blockIdx.x) * 128; /* the longest columns first */
-    const size_t hoff = (size_t)head * HD;
+    const size_t hoff = (size_t)head * HD, hoff_kv = (size_t)(head / gq) * HD; /* GQA: gq query heads share a kv head */
     { /* sequence blockIdx.z: T rows further on in every tensor */
         const size_t ro = (size_t)blockIdx.z * T;
-        q += ro * ld_qkv, k += ro * ld_qkv, v += ro * ld_qkv, o += ro * ld_o, dO += ro * ld_o, dq += ro * ld_d;
+        q += ro * ld_qkv, k += ro * ld_kv, v += ro * ld_kv, o += ro * ld_o, dO += ro * ld_o, dq += ro * ld_d;
         Lbuf += (size_t)blockIdx.z * gridDim.y * T, Dbuf += (size_t)blockIdx.z * gridDim.y * T;
     }
     int tok = tok0 + wave * 32 + r;
@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_mfma_kernel(const uint16_t* q
     float M = -__builtin_inff(), l = 0.f;
     for (int t = 0; t < ntile; t++) {
         __syncthreads();
-        ab_stage<HD, false>(k, ld_qkv, hoff, t * AB_T, T, ks, nullptr);
+        ab_stage<HD, false>(k, ld_kv, hoff_kv, t * AB_T, T, ks, nullptr);
         __syncthreads();
         f32x16 st = ab_zero();
 #pragma unroll
@@ -127,8 +127,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_mfma_kernel(const uint16_t* q
     for (int db = 0; db < NDB; db++) acc[db] = ab_zero();
     for (int t = 0; t < ntile; t++) {
         __syncthreads();
-        ab_stage<HD, true>(k, ld_qkv, hoff, t * AB_T, T, ks, kt);
-        ab_stage<HD, false>(v, ld_qkv, hoff, t * AB_T, T, vs, nullptr);
+        ab_stage<HD, true>(k, ld_kv, hoff_kv, t * AB_T, T, ks, kt);
+        ab_stage<HD, false>(v, ld_kv, hoff_kv, t * AB_T, T, vs, nullptr);
         __syncthreads();
         f32x16 st = ab_zero(), dpt = ab_zero();
 #pragma unroll
@@ -168,17 +168,17 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_mfma_kernel(const uint16_t* q
 
 template <int HD>
 __global__ void __launch_bounds__(256) attn_bwd_dkv_mfma_kernel(const uint16_t* q, const uint16_t* k, const uint16_t* v, long long ld_qkv, const uint16_t* dO, long long ld_o, uint16_t* dk,
-                                                                uint16_t* dv, long long ld_d, const float* Lbuf, const float* Dbuf, int T, float scale) {
+                                                                uint16_t* dv, long long ld_d, const float* Lbuf, const float* Dbuf, int T, float scale, int gq, long long ld_kv, long long ld_dkv) {
     constexpr int NS = HD / 16, NDB = HD / 32, KS = HD + 8;
     __shared__ __attribute__((aligned(16))) uint16_t qs[AB_T * KS], os[AB_T * KS], qt[HD * AB_TS], ot[HD * AB_TS];
     __shared__ __attribute__((aligned(16))) float Ls[AB_T], Ds[AB_T];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y, key0 = blockIdx.x * 128; /* the first key columns see the most query tiles: already first */
-    const size_t hoff = (size_t)head * HD;
+    const int kvh = blockIdx.y, key0 = blockIdx.x * 128; /* blockIdx.y = kv head; the first key columns see the most query tiles: already first */
+    const size_t hoff = (size_t)kvh * HD;
     {
         const size_t ro = (size_t)blockIdx.z * T;
-        q += ro * ld_qkv, k += ro * ld_qkv, v += ro * ld_qkv, dO += ro * ld_o, dk += ro * ld_d, dv += ro * ld_d;
-        Lbuf += (size_t)blockIdx.z * gridDim.y * T, Dbuf += (size_t)blockIdx.z * gridDim.y * T;
+        q += ro * ld_qkv, k += ro * ld_kv, v += ro * ld_kv, dO += ro * ld_o, dk += ro * ld_dkv, dv += ro * ld_dkv;
+        Lbuf += (size_t)blockIdx.z * gridDim.y * gq * T, Dbuf += (size_t)blockIdx.z * gridDim.y * gq * T;
     }
     int key = key0 + wave * 32 + r;
     const bool key_ok = key < T;
@@ -187,8 +187,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_mfma_kernel(const uint16_t* 
 
     u32x4 kf_[NS], vf[NS];
     {
-        const uint16_t* krow = k + (size_t)key * ld_qkv + hoff;
-        const uint16_t* vrow = v + (size_t)key * ld_qkv + hoff;
+        const uint16_t* krow = k + (size_t)key * ld_kv + hoff;
+        const uint16_t* vrow = v + (size_t)key * ld_kv + hoff;
 #pragma unroll
         for (int s = 0; s < NS; s++) kf_[s] = *reinterpret_cast<const u32x4*>(krow + 16 * s + 8 * h), vf[s] = *reinterpret_cast<const u32x4*>(vrow + 16 * s + 8 * h);
     }
@@ -196,10 +196,12 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_mfma_kernel(const uint16_t* 
 #pragma unroll
     for (int db = 0; db < NDB; db++) dka[db] = ab_zero(), dva[db] = ab_zero();
     const int ntq = (T + AB_T - 1) / AB_T;
-    for (int t = key0 / AB_T; t < ntq; t++) {
+    for (int tg = (key0 / AB_T) * gq; tg < ntq * gq; tg++) { /* (query tile, query head of the group) pairs */
+        const int t = tg / gq, head = kvh * gq + (tg - t * gq);
+        const size_t hq = (size_t)head * HD;
         __syncthreads();
-        ab_stage<HD, true>(q, ld_qkv, hoff, t * AB_T, T, qs, qt);
-        ab_stage<HD, true>(dO, ld_o, hoff, t * AB_T, T, os, ot);
+        ab_stage<HD, true>(q, ld_qkv, hq, t * AB_T, T, qs, qt);
+        ab_stage<HD, true>(dO, ld_o, hq, t * AB_T, T, os, ot);
         if (tid < AB_T) {
             const int qi = t * AB_T + tid;
             Ls[tid] = qi < T ? Lbuf[(size_t)head * T + qi] : 0.f, Ds[tid] = qi < T ? Dbuf[(size_t)head * T + qi] : 0.f;
@@ -238,8 +240,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_mfma_kernel(const uint16_t* 
         }
     }
     if (!key_ok) return;
-    uint16_t* okp = dk + (size_t)key * ld_d + hoff;
-    uint16_t* ovp = dv + (size_t)key * ld_d + hoff;
+    uint16_t* okp = dk + (size_t)key * ld_dkv + hoff;
+    uint16_t* ovp = dv + (size_t)key * ld_dkv + hoff;
 #pragma unroll
     for (int db = 0; db < NDB; db++)
 #pragma unroll
@@ -252,18 +254,19 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_mfma_kernel(const uint16_t* 
 
 // KF_OK launched; 1 = shape not covered by the MFMA form
 int attn_backward_mfma_launch(hipStream_t st, const uint16_t* q, const uint16_t* k, const uint16_t* v, long long ld_qkv, const uint16_t* o, const uint16_t* dO, long long ld_o,
-                              uint16_t* dq, uint16_t* dk, uint16_t* dv, long long ld_d, int T, int n_head, int hd, int n_seq, float* scratch) {
-    if (hd != 64 && hd != 128) return 1;
+                              uint16_t* dq, uint16_t* dk, uint16_t* dv, long long ld_d, int T, int n_head, int hd, int n_seq, float* scratch, int n_kv, long long ld_kv, long long ld_dkv) {
+    if ((hd != 64 && hd != 128) || n_kv < 1 || n_head % n_kv != 0) return 1;
+    const int gq = n_head / n_kv;
     const float scale = 1.0f / sqrtf((float)hd);
     float* Lb = scratch;
     float* Db = scratch + (size_t)n_seq * n_head * T;
-    const dim3 grid((T + 127) / 128, n_head, n_seq);
+    const dim3 grid((T + 127) / 128, n_head, n_seq), grid_kv((T + 127) / 128, n_kv, n_seq);
     if (hd == 64) {
-        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<64>), grid, dim3(256), 0, st, q, k, v, ld_qkv, o, dO, ld_o, dq, ld_d, Lb, Db, T, scale);
-        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<64>), grid, dim3(256), 0, st, q, k, v, ld_qkv, dO, ld_o, dk, dv, ld_d, Lb, Db, T, scale);
+        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<64>), grid, dim3(256), 0, st, q, k, v, ld_qkv, o, dO, ld_o, dq, ld_d, Lb, Db, T, scale, gq, ld_kv);
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<64>), grid_kv, dim3(256), 0, st, q, k, v, ld_qkv, dO, ld_o, dk, dv, ld_d, Lb, Db, T, scale, gq, ld_kv, ld_dkv);
     } else {
-        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<128>), grid, dim3(256), 0, st, q, k, v, ld_qkv, o, dO, ld_o, dq, ld_d, Lb, Db, T, scale);
-        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<128>), grid, dim3(256), 0, st, q, k, v, ld_qkv, dO, ld_o, dk, dv, ld_d, Lb, Db, T, scale);
+        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<128>), grid, dim3(256), 0, st, q, k, v, ld_qkv, o, dO, ld_o, dq, ld_d, Lb, Db, T, scale, gq, ld_kv);
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<128>), grid_kv, dim3(256), 0, st, q, k, v, ld_qkv, dO, ld_o, dk, dv, ld_d, Lb, Db, T, scale, gq, ld_kv, ld_dkv);
     }
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }

@@ -104,9 +104,10 @@ int transpose_bf16_launch(hipStream_t st, const uint16_t* in, uint16_t* out, int
 int colsum_add_launch(hipStream_t st, const uint16_t* x, uint16_t* dst, int n, int C, double* scratch); /* scratch: ceil(n / 256) * C doubles */
 // causal MHA backward (kf_attn_bwd.hip); scratch: 2 * n_seq * n_head * T floats
 int attn_backward_launch(hipStream_t st, const uint16_t* q, const uint16_t* k, const uint16_t* v, long long ld_qkv, const uint16_t* o, const uint16_t* dO, long long ld_o,
-                         uint16_t* dq, uint16_t* dk, uint16_t* dv, long long ld_d, int T, int n_head, int hd, int n_seq, float* scratch);
+                         uint16_t* dq, uint16_t* dk, uint16_t* dv, long long ld_d, int T, int n_head, int n_kv, int hd, int n_seq, float* scratch);
 int attn_backward_mfma_launch(hipStream_t st, const uint16_t* q, const uint16_t* k, const uint16_t* v, long long ld_qkv, const uint16_t* o, const uint16_t* dO, long long ld_o,
-                              uint16_t* dq, uint16_t* dk, uint16_t* dv, long long ld_d, int T, int n_head, int hd, int n_seq, float* scratch); /* kf_attn_bwd_mfma.hip: 1 = not covered */
+                              uint16_t* dq, uint16_t* dk, uint16_t* dv, long long ld_d, int T, int n_head, int hd, int n_seq, float* scratch, int n_kv, long long ld_kv,
+                              long long ld_dkv); /* kf_attn_bwd_mfma.hip: 1 = not covered */
 // embedding backward (kf_embed_bwd.hip)
 int embed_backward_launch(hipStream_t st, uint16_t* dwte, long long ldw, uint16_t* dwpe, const uint16_t* dout, const int* tokens, int B, int T, int C, int V);
 // fused classifier (kf_loss.hip): cross-entropy loss per row + logit gradient in place

@@ -63,7 +63,7 @@ def load():
         hip.kf_sample_topk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         hip.kf_layernorm.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
         hip.kf_attn_prefill_batch.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
-        hip.kf_attn_backward.argtypes = [C.c_void_p] * 4 + [C.c_longlong, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        hip.kf_attn_backward.argtypes = [C.c_void_p] * 4 + [C.c_longlong, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         hip.kf_attn_backward_scratch_bytes.argtypes, hip.kf_attn_backward_scratch_bytes.restype = [C.c_int, C.c_int, C.c_int], C.c_size_t
         hip.kf_embed_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         hip.kf_linear_backward.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p]

@@ -832,49 +832,59 @@ KFO_API void kfo_norm_backward(uint16_t* dinp, uint16_t* dweight, uint16_t* dbia
  * unpinned): S = scale Q K^T, P = softmax over the keys j <= i, O = P V; D_i = dO_i . O_i (with the STORED bf16 O, as the kernels use it);
  * dV = P^T dO, dP = dO V^T, dS = P o (dP - D), dQ = scale dS K, dK = scale dS^T Q.  Everything in fp64 from the bf16 inputs, bf16 stores. */
 KFO_API void kfo_attn_backward(const uint16_t* q, const uint16_t* k, const uint16_t* v, long long ld_qkv, const uint16_t* o, const uint16_t* dO, long long ld_o,
-                               uint16_t* dq, uint16_t* dk, uint16_t* dv, long long ld_d, int T, int n_head, int hd) {
+                               uint16_t* dq, uint16_t* dk, uint16_t* dv, long long ld_d, int T, int n_head, int n_kv, int hd) {
     const double scale = 1.0 / sqrt((double)hd);
+    const int gq = n_head / n_kv; /* GQA: gq query heads share kv head h / gq; dk, dv sum over them */
     double* P = (double*)malloc(sizeof(double) * (size_t)T * T);
     double* dS = (double*)malloc(sizeof(double) * (size_t)T * T);
-    for (int h = 0; h < n_head; h++) {
-        const size_t ho = (size_t)h * hd;
-        for (int i = 0; i < T; i++) {
-            double mx = -INFINITY;
-            for (int j = 0; j <= i; j++) {
-                double s = 0.0;
-                for (int d = 0; d < hd; d++) s += (double)kfo_bf16_to_f32(q[(size_t)i * ld_qkv + ho + d]) * (double)kfo_bf16_to_f32(k[(size_t)j * ld_qkv + ho + d]);
-                P[(size_t)i * T + j] = s * scale;
-                if (s * scale > mx) mx = s * scale;
+    double* ak = (double*)malloc(sizeof(double) * (size_t)T * hd);
+    double* av = (double*)malloc(sizeof(double) * (size_t)T * hd);
+    for (int kvh = 0; kvh < n_kv; kvh++) {
+        const size_t hk = (size_t)kvh * hd;
+        for (size_t i = 0; i < (size_t)T * hd; i++) ak[i] = av[i] = 0.0;
+        for (int h = kvh * gq; h < (kvh + 1) * gq; h++) {
+            const size_t ho = (size_t)h * hd;
+            for (int i = 0; i < T; i++) {
+                double mx = -INFINITY;
+                for (int j = 0; j <= i; j++) {
+                    double s = 0.0;
+                    for (int d = 0; d < hd; d++) s += (double)kfo_bf16_to_f32(q[(size_t)i * ld_qkv + ho + d]) * (double)kfo_bf16_to_f32(k[(size_t)j * ld_qkv + hk + d]);
+                    P[(size_t)i * T + j] = s * scale;
+                    if (s * scale > mx) mx = s * scale;
+                }
+                double sum = 0.0;
+                for (int j = 0; j <= i; j++) sum += (P[(size_t)i * T + j] = exp(P[(size_t)i * T + j] - mx));
+                double D = 0.0;
+                for (int d = 0; d < hd; d++) D += (double)kfo_bf16_to_f32(dO[(size_t)i * ld_o + ho + d]) * (double)kfo_bf16_to_f32(o[(size_t)i * ld_o + ho + d]);
+                for (int j = 0; j <= i; j++) {
+                    const double p = (P[(size_t)i * T + j] /= sum);
+                    double dp = 0.0;
+                    for (int d = 0; d < hd; d++) dp += (double)kfo_bf16_to_f32(dO[(size_t)i * ld_o + ho + d]) * (double)kfo_bf16_to_f32(v[(size_t)j * ld_qkv + hk + d]);
+                    dS[(size_t)i * T + j] = p * (dp - D);
+                }
+                for (int d = 0; d < hd; d++) {
+                    double a = 0.0;
+                    for (int j = 0; j <= i; j++) a += dS[(size_t)i * T + j] * (double)kfo_bf16_to_f32(k[(size_t)j * ld_qkv + hk + d]);
+                    dq[(size_t)i * ld_d + ho + d] = kfo_f32_to_bf16((float)(a * scale));
+                }
             }
-            double sum = 0.0;
-            for (int j = 0; j <= i; j++) sum += (P[(size_t)i * T + j] = exp(P[(size_t)i * T + j] - mx));
-            double D = 0.0;
-            for (int d = 0; d < hd; d++) D += (double)kfo_bf16_to_f32(dO[(size_t)i * ld_o + ho + d]) * (double)kfo_bf16_to_f32(o[(size_t)i * ld_o + ho + d]);
-            for (int j = 0; j <= i; j++) {
-                const double p = (P[(size_t)i * T + j] /= sum);
-                double dp = 0.0;
-                for (int d = 0; d < hd; d++) dp += (double)kfo_bf16_to_f32(dO[(size_t)i * ld_o + ho + d]) * (double)kfo_bf16_to_f32(v[(size_t)j * ld_qkv + ho + d]);
-                dS[(size_t)i * T + j] = p * (dp - D);
-            }
-            for (int d = 0; d < hd; d++) {
-                double a = 0.0;
-                for (int j = 0; j <= i; j++) a += dS[(size_t)i * T + j] * (double)kfo_bf16_to_f32(k[(size_t)j * ld_qkv + ho + d]);
-                dq[(size_t)i * ld_d + ho + d] = kfo_f32_to_bf16((float)(a * scale));
-            }
+            for (int j = 0; j < T; j++)
+                for (int d = 0; d < hd; d++)
+                    for (int i = j; i < T; i++) {
+                        ak[(size_t)j * hd + d] += dS[(size_t)i * T + j] * (double)kfo_bf16_to_f32(q[(size_t)i * ld_qkv + ho + d]);
+                        av[(size_t)j * hd + d] += P[(size_t)i * T + j] * (double)kfo_bf16_to_f32(dO[(size_t)i * ld_o + ho + d]);
+                    }
         }
         for (int j = 0; j < T; j++)
             for (int d = 0; d < hd; d++) {
-                double ak = 0.0, av = 0.0;
-                for (int i = j; i < T; i++) {
-                    ak += dS[(size_t)i * T + j] * (double)kfo_bf16_to_f32(q[(size_t)i * ld_qkv + ho + d]);
-                    av += P[(size_t)i * T + j] * (double)kfo_bf16_to_f32(dO[(size_t)i * ld_o + ho + d]);
-                }
-                dk[(size_t)j * ld_d + ho + d] = kfo_f32_to_bf16((float)(ak * scale));
-                dv[(size_t)j * ld_d + ho + d] = kfo_f32_to_bf16((float)av);
+                dk[(size_t)j * ld_d + hk + d] = kfo_f32_to_bf16((float)(ak[(size_t)j * hd + d] * scale));
+                dv[(size_t)j * ld_d + hk + d] = kfo_f32_to_bf16((float)av[(size_t)j * hd + d]);
             }
     }
     free(P);
     free(dS);
+    free(ak);
+    free(av);
 }
 
 /* Embedding backward (encoder_backward, kernel/embed.cuh:380-470; wpe_backward_kernel :333-366, wte_backward_kernel :257-331): fp32 sums over the batch

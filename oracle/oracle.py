@@ -325,15 +325,19 @@ def norm_backward(dinp, dweight, dbias, dout, inp, weight, mean, rstd):
     fn(_p(dinp), _p(dweight), _p(dbias) if dbias is not None else None, _p(dout), _p(inp), _p(weight), _p(mn) if mn is not None else None, _p(rs), rows, C_)
 
 
-def attn_backward(q, k, v, o, dO, n_head, hd):
-    """causal MHA backward for one sequence: q, k, v, o, dO uint16 [T, n_head * hd] (contiguous) -> (dq, dk, dv)"""
-    arrs = [np.ascontiguousarray(a, dtype=np.uint16) for a in (q, k, v, o, dO)]
-    T, Cw = arrs[0].shape
+def attn_backward(q, k, v, o, dO, n_head, hd, n_kv=None):
+    """causal attention backward for one sequence.  MHA (n_kv None): q, k, v, o, dO uint16 [T, n_head * hd] -> (dq, dk, dv) of the same shape.
+    GQA: k, v [T, n_kv * hd]; every tensor is laid into a common row width internally."""
+    n_kv = n_kv or n_head
+    T = q.shape[0]
+    Cw = n_head * hd
+    pad = lambda a: np.ascontiguousarray(np.pad(np.asarray(a, dtype=np.uint16), ((0, 0), (0, Cw - a.shape[1]))))
+    qa, ka, va, oa, da = (pad(a) for a in (q, k, v, o, dO))
     dq, dk, dv = (np.zeros((T, Cw), np.uint16) for _ in range(3))
     fn = lib().kfo_attn_backward
-    fn.argtypes = [C.c_void_p] * 3 + [C.c_longlong, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int]
-    fn(_p(arrs[0]), _p(arrs[1]), _p(arrs[2]), Cw, _p(arrs[3]), _p(arrs[4]), Cw, _p(dq), _p(dk), _p(dv), Cw, T, n_head, hd)
-    return dq, dk, dv
+    fn.argtypes = [C.c_void_p] * 3 + [C.c_longlong, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int]
+    fn(_p(qa), _p(ka), _p(va), Cw, _p(oa), _p(da), Cw, _p(dq), _p(dk), _p(dv), Cw, T, n_head, n_kv, hd)
+    return dq, dk[:, :n_kv * hd].copy(), dv[:, :n_kv * hd].copy()
 
 
 def embed_backward(dwte, dwpe, dout, tokens, B, T, V):

@@ -73,7 +73,7 @@ def backward():
         ln_bwd(dx, dh, a["x2"], a["m2"], a["r2"])
         lin_bwd(wproj, dx, a["att"], datt, gW["proj"], gB["proj"])
         L.check(ctx.hip.kf_attn_backward(ctx.h, a["qkv"][:, :Cn].data_ptr(), a["qkv"][:, Cn:2 * Cn].data_ptr(), a["qkv"][:, 2 * Cn:].data_ptr(), 3 * Cn, a["att"].data_ptr(), datt.data_ptr(), Cn,
-                                         dqkv[:, :Cn].data_ptr(), dqkv[:, Cn:2 * Cn].data_ptr(), dqkv[:, 2 * Cn:].data_ptr(), 3 * Cn, T, H, hd, B, sc_at.data_ptr()), "attn_bwd")
+                                         dqkv[:, :Cn].data_ptr(), dqkv[:, Cn:2 * Cn].data_ptr(), dqkv[:, 2 * Cn:].data_ptr(), 3 * Cn, T, H, H, hd, B, sc_at.data_ptr()), "attn_bwd")
         lin_bwd(wqkv, dqkv, a["h1"], dh, gW["qkv"], gB["qkv"])
         ln_bwd(dx, dh, a["x"], a["m1"], a["r1"])
     L.check(ctx.hip.kf_embed_backward(ctx.h, g_wte.data_ptr(), Cn, g_wpe.data_ptr(), dx.data_ptr(), ids.data_ptr(), B, T, Cn, Vp), "embed_bwd")

@@ -10,5 +10,5 @@ dqkv = torch.zeros_like(qkv); sc = torch.zeros(ctx.hip.kf_attn_backward_scratch_
 for _ in range(3):
     assert ctx.hip.kf_attn_prefill_batch(ctx.h, qc.data_ptr(), qkv[:, C:].data_ptr(), qkv[:, 2 * C:].data_ptr(), o.data_ptr(), T, C, H, H, hd, 3 * C, B) == 0
     assert ctx.hip.kf_attn_backward(ctx.h, qkv[:, :C].data_ptr(), qkv[:, C:2 * C].data_ptr(), qkv[:, 2 * C:].data_ptr(), 3 * C, o.data_ptr(), dO.data_ptr(), C,
-                                    dqkv[:, :C].data_ptr(), dqkv[:, C:2 * C].data_ptr(), dqkv[:, 2 * C:].data_ptr(), 3 * C, T, H, hd, B, sc.data_ptr()) == 0
+                                    dqkv[:, :C].data_ptr(), dqkv[:, C:2 * C].data_ptr(), dqkv[:, 2 * C:].data_ptr(), 3 * C, T, H, H, hd, B, sc.data_ptr()) == 0
 ctx.sync()

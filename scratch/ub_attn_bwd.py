@@ -9,7 +9,7 @@ qkv = torch.randn(B * T, 3 * C, device=dev).to(torch.bfloat16); o = torch.randn(
 dqkv = torch.zeros_like(qkv); sc = torch.zeros(ctx.hip.kf_attn_backward_scratch_bytes(T, H, B) // 4 + 1, dtype=torch.float32, device=dev)
 def run():   # the 8 sequences in one call
     assert ctx.hip.kf_attn_backward(ctx.h, qkv[:, :C].data_ptr(), qkv[:, C:2 * C].data_ptr(), qkv[:, 2 * C:].data_ptr(), 3 * C, o.data_ptr(), dO.data_ptr(), C,
-                                    dqkv[:, :C].data_ptr(), dqkv[:, C:2 * C].data_ptr(), dqkv[:, 2 * C:].data_ptr(), 3 * C, T, H, hd, B, sc.data_ptr()) == 0
+                                    dqkv[:, :C].data_ptr(), dqkv[:, C:2 * C].data_ptr(), dqkv[:, 2 * C:].data_ptr(), 3 * C, T, H, H, hd, B, sc.data_ptr()) == 0
 for _ in range(2): run()
 ctx.sync(); e0, e1 = ctx.event(), ctx.event(); ctx.record(e0)
 for _ in range(3): run()

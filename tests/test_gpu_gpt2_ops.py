@@ -327,7 +327,7 @@ def test_attn_backward_vs_oracle(ctx, T, H, hd, fused_layout):
     dOd = bf16_t(dO, dev)
     scratch = torch.zeros(ctx.hip.kf_attn_backward_scratch_bytes(T, H, 1) // 4 + 1, dtype=torch.float32, device=dev)
     assert ctx.hip.kf_attn_backward(ctx.h, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), ld, od.data_ptr(), dOd.data_ptr(), C_, dqd.data_ptr(), dkd.data_ptr(), dvd.data_ptr(), ldd,
-                                    T, H, hd, 1, scratch.data_ptr()) == 0, ctx.hip.kf_last_error()
+                                    T, H, H, hd, 1, scratch.data_ptr()) == 0, ctx.hip.kf_last_error()
     ctx.sync()
     r_dq, r_dk, r_dv = O.attn_backward(q, k, v, u16(od), dO, H, hd)
     f = lambda a: O.bf16_to_f32(a).astype(np.float64)
@@ -341,8 +341,8 @@ def test_attn_backward_rejects(ctx):
     z = torch.zeros(64 * 128, dtype=torch.bfloat16, device=ctx.device)
     s = torch.zeros(1024, dtype=torch.float32, device=ctx.device)
     p = z.data_ptr()
-    assert ctx.hip.kf_attn_backward(ctx.h, p, p, p, 96, p, p, 96, p, p, p, 96, 16, 1, 96, 1, s.data_ptr()) < 0   # head_dim 96: not covered
-    assert ctx.hip.kf_attn_backward(ctx.h, p, p, p, 32, p, p, 128, p, p, p, 128, 16, 1, 64, 1, s.data_ptr()) == -20     # stride below n_head * head_dim
+    assert ctx.hip.kf_attn_backward(ctx.h, p, p, p, 96, p, p, 96, p, p, p, 96, 16, 1, 1, 96, 1, s.data_ptr()) < 0   # head_dim 96: not covered
+    assert ctx.hip.kf_attn_backward(ctx.h, p, p, p, 32, p, p, 128, p, p, p, 128, 16, 1, 1, 64, 1, s.data_ptr()) == -20     # stride below n_head * head_dim
 
 
 def test_attn_backward_batched_sequences(ctx):
@@ -362,13 +362,13 @@ def test_attn_backward_batched_sequences(ctx):
         dq, dk, dv = (torch.zeros(Bn * T, C_, dtype=torch.bfloat16, device=dev) for _ in range(3))
         sc = torch.zeros(ctx.hip.kf_attn_backward_scratch_bytes(T, H, Bn) // 4 + 1, dtype=torch.float32, device=dev)
         if mode == "batched":
-            assert ctx.hip.kf_attn_backward(ctx.h, q.data_ptr(), k.data_ptr(), v.data_ptr(), C_, o.data_ptr(), dO.data_ptr(), C_, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), C_, T, H, hd, Bn,
+            assert ctx.hip.kf_attn_backward(ctx.h, q.data_ptr(), k.data_ptr(), v.data_ptr(), C_, o.data_ptr(), dO.data_ptr(), C_, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), C_, T, H, H, hd, Bn,
                                             sc.data_ptr()) == 0
         else:
             for b in range(Bn):
                 sl = slice(b * T, (b + 1) * T)
                 assert ctx.hip.kf_attn_backward(ctx.h, q[sl].data_ptr(), k[sl].data_ptr(), v[sl].data_ptr(), C_, o[sl].data_ptr(), dO[sl].data_ptr(), C_, dq[sl].data_ptr(), dk[sl].data_ptr(),
-                                                dv[sl].data_ptr(), C_, T, H, hd, 1, sc.data_ptr()) == 0
+                                                dv[sl].data_ptr(), C_, T, H, H, hd, 1, sc.data_ptr()) == 0
         ctx.sync()
         outs.append((u16(dq), u16(dk), u16(dv)))
     for a, b in zip(*outs):
@@ -389,3 +389,31 @@ def test_attn_prefill_batch_equals_per_sequence(ctx):
         assert ctx.hip.kf_attn_prefill(ctx.h, qc[sl].data_ptr(), qkv[sl, C_:2 * C_].data_ptr(), qkv[sl, 2 * C_:].data_ptr(), o2[sl].data_ptr(), 0, T, C_, H, H, hd, 3 * C_) == 0
     ctx.sync()
     assert np.array_equal(u16(o1), u16(o2))
+
+
+@pytest.mark.parametrize("T,H,KV,hd", [(96, 4, 2, 64), (130, 8, 2, 128), (70, 2, 1, 64)])
+def test_attn_backward_gqa_vs_oracle(ctx, T, H, KV, hd):
+    """grouped-query attention backward: q | k | v as column blocks of one fused buffer with H + 2 KV heads per row; dk, dv sum over the group"""
+    Cq, Ck = H * hd, KV * hd
+    W = Cq + 2 * Ck
+    rng = np.random.default_rng(T + H)
+    dev = ctx.device
+    qkv_h = O.f32_to_bf16(rng.normal(0, 1.0, (T, W)).astype(np.float32))
+    dO_h = O.f32_to_bf16(rng.normal(0, 1.0, (T, Cq)).astype(np.float32))
+    qkv = bf16_t(qkv_h, dev)
+    qc = qkv[:, :Cq].contiguous()
+    o = torch.zeros(T, Cq, dtype=torch.bfloat16, device=dev)
+    assert ctx.hip.kf_attn_prefill_batch(ctx.h, qc.data_ptr(), qkv[:, Cq:].data_ptr(), qkv[:, Cq + Ck:].data_ptr(), o.data_ptr(), T, Cq, H, KV, hd, W, 1) == 0, ctx.hip.kf_last_error()
+    dO = bf16_t(dO_h, dev)
+    dqkv = torch.zeros(T, W, dtype=torch.bfloat16, device=dev)
+    sc = torch.zeros(ctx.hip.kf_attn_backward_scratch_bytes(T, H, 1) // 4 + 1, dtype=torch.float32, device=dev)
+    assert ctx.hip.kf_attn_backward(ctx.h, qkv[:, :Cq].data_ptr(), qkv[:, Cq:].data_ptr(), qkv[:, Cq + Ck:].data_ptr(), W, o.data_ptr(), dO.data_ptr(), Cq,
+                                    dqkv[:, :Cq].data_ptr(), dqkv[:, Cq:].data_ptr(), dqkv[:, Cq + Ck:].data_ptr(), W, T, H, KV, hd, 1, sc.data_ptr()) == 0, ctx.hip.kf_last_error()
+    ctx.sync()
+    r_dq, r_dk, r_dv = O.attn_backward(qkv_h[:, :Cq], qkv_h[:, Cq:Cq + Ck], qkv_h[:, Cq + Ck:], u16(o), dO_h, H, hd, n_kv=KV)
+    got = u16(dqkv)
+    f = lambda a: O.bf16_to_f32(a).astype(np.float64)
+    for name, g_, r_ in (("dq", got[:, :Cq], r_dq), ("dk", got[:, Cq:Cq + Ck], r_dk), ("dv", got[:, Cq + Ck:], r_dv)):
+        g, r = f(g_), f(r_)
+        assert np.abs(g - r).max() <= 2.0 ** -7 * np.abs(r).max(), name
+        assert np.sqrt(((g - r) ** 2).mean()) <= 2.0 ** -9 * np.abs(r).max(), name

@@ -117,7 +117,7 @@ def test_gpt2_toy_training_step_vs_autograd(ctx, Bn, T):
         dqkv = zeros(N, 3 * C_)
         qkv = s_["qkv"]
         assert ctx.hip.kf_attn_backward(ctx.h, qkv[:, :C_].data_ptr(), qkv[:, C_:2 * C_].data_ptr(), qkv[:, 2 * C_:].data_ptr(), 3 * C_, s_["att"].data_ptr(), datt.data_ptr(), C_,
-                                        dqkv[:, :C_].data_ptr(), dqkv[:, C_:2 * C_].data_ptr(), dqkv[:, 2 * C_:].data_ptr(), 3 * C_, T, H, hd, Bn, att_sc.data_ptr()) == 0, ctx.hip.kf_last_error()
+                                        dqkv[:, :C_].data_ptr(), dqkv[:, C_:2 * C_].data_ptr(), dqkv[:, 2 * C_:].data_ptr(), 3 * C_, T, H, H, hd, Bn, att_sc.data_ptr()) == 0, ctx.hip.kf_last_error()
         dh1, grads["%d.qkv.w" % li], grads["%d.qkv.b" % li] = lin_bwd(b["dw"]["qkv"], dqkv, s_["h1"], C_)
         grads["%d.ln1.w" % li], grads["%d.ln1.b" % li] = ln_bwd(dx, dh1, s_["x"], b["lnd"][0], s_["m1"], s_["r1"])
     g_wpe = zeros(T, C_)
