@@ -237,6 +237,12 @@ size_t kf_norm_backward_scratch_bytes(int rows, int dim, int is_layernorm);
 int kf_norm_backward(kf_ctx* ctx, kf_bf16* dinp, kf_bf16* dweight, kf_bf16* dbias_or_null, const kf_bf16* dout, const kf_bf16* inp, const kf_bf16* weight,
                      const float* mean_or_null, const float* rstd, int rows, int dim, void* scratch);
 
+/* RoPE backward (the transpose of the rotate-half rotation of kf_qknorm_rope), in place on a gradient d [n_tok rows of n_head * head_dim, row stride
+ * `stride`]: row t belongs to position pos0 + t % seq_len (seq_len = n_tok for one sequence; a batch of equal-length sequences stored back to back
+ * passes its sequence length).  The q/k-norm that precedes RoPE in the forward is an RMSNorm over head_dim: its backward is kf_norm_backward with
+ * rows = n_tok * n_head and dim = head_dim. */
+int kf_rope_backward(kf_ctx* ctx, kf_bf16* d, const float* rope_table, int pos0, int n_tok, int seq_len, long long stride, int n_head, int head_dim);
+
 /* Activation backward (Relu::Back, Activation.cu:283-320).  GELU, in place on the incoming gradient (Activation_backward_inplace ->
  * gelu_backward_inplace_kernel, Activation.cu:42-78): d = bf16(gelu'(x) * d) with x the pre-activation.  SwiGLU (CU_swiglu_back_v0,
  * Activation.cu:245-260): delta_gate = bf16(delta * up * sig * (1 + gate * (1 - sig))), delta_in_out = bf16(delta * gate * sig), sig = sigmoid(gate). */

@@ -764,6 +764,11 @@ int kf_norm_backward(kf_ctx* c, kf_bf16* dinp, kf_bf16* dweight, kf_bf16* dbias,
     if (!al16(dinp) || !al16(dout) || !al16(inp) || !al16(weight) || ((uintptr_t)scratch & 7)) return fail(KF_BLAS_UNALIGN, "kf_norm_backward: tensors must be 16-byte aligned");
     RET(kf::norm_backward_launch(c->stream, dinp, dweight, dbias, dout, inp, weight, mean, rstd, rows, dim, (double*)scratch));
 }
+int kf_rope_backward(kf_ctx* c, kf_bf16* d, const float* rope_table, int pos0, int n_tok, int seq_len, long long stride, int n_head, int hd) {
+    CHKCTX(c);
+    if (!d || !rope_table || pos0 < 0) return fail(KF_INVALID_ARGS, "kf_rope_backward: bad args");
+    RET(kf::rope_backward_launch(c->stream, d, rope_table, pos0, n_tok, seq_len, stride, n_head, hd));
+}
 int kf_gelu_backward(kf_ctx* c, kf_bf16* d_in_out, const kf_bf16* x, size_t n) {
     CHKCTX(c);
     if (!d_in_out || !x || n == 0) return fail(KF_INVALID_ARGS, "kf_gelu_backward: bad args");

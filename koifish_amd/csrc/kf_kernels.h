@@ -92,6 +92,7 @@ int qknorm_rope_launch(hipStream_t st, uint16_t* q, uint16_t* k, const uint16_t*
 int rmsnorm_launch(hipStream_t st, const uint16_t* x, const uint16_t* w, uint16_t* y, int rows, int dim, float eps, float* rstd);
 int layernorm_launch(hipStream_t st, const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* y, int rows, int dim, float eps, float* mean, float* rstd);
 int gelu_launch(hipStream_t st, const uint16_t* x, uint16_t* y, size_t n);
+int rope_backward_launch(hipStream_t st, uint16_t* d, const float* table, int pos0, int n_tok, int seq_len, long long stride, int n_head, int hd);
 int gelu_backward_launch(hipStream_t st, uint16_t* d_in_out, const uint16_t* x, size_t n);
 int swiglu_backward_launch(hipStream_t st, uint16_t* delta_in_out, uint16_t* delta_gate, const uint16_t* gate, const uint16_t* up, size_t n);
 // LayerNorm / RMSNorm backward (kf_norm_bwd.hip); scratch: norm_backward_groups(rows) * (mean ? 2 : 1) * C doubles

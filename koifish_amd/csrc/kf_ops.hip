@@ -264,6 +264,26 @@ int swiglu_backward_launch(hipStream_t st, uint16_t* delta_in_out, uint16_t* del
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 
+// RoPE backward, rotate-half form (the transpose of CU_rope2_v0, operator.cuh:734-772), in place on a gradient with rows of n_head * hd:
+// (g_j, g_{j+hd/2}) -> (g_j c + g_{j+hd/2} s, g_{j+hd/2} c - g_j s) with (c, s) = table[pos][j]; position of row t = pos0 + t % seq_len.
+__global__ void rope_backward_kernel(uint16_t* __restrict__ d, const float* __restrict__ table, int pos0, int seq_len, long long stride, int n_head, int hd) {
+    const int half = hd >> 1, t = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x; /* (head, pair) */
+    if (i >= n_head * half) return;
+    const int h = i / half, j = i - h * half;
+    const float* cs = table + ((size_t)(pos0 + t % seq_len) * half + j) * 2;
+    uint16_t* p = d + (size_t)t * stride + (size_t)h * hd + j;
+    const float g0 = bf2f(p[0]), g1 = bf2f(p[half]), c = cs[0], sn = cs[1];
+    const float a = g0 * c, b = g1 * sn, cc = g1 * c, dd = g0 * sn;
+    p[0] = f2bf(a + b);
+    p[half] = f2bf(cc - dd);
+}
+int rope_backward_launch(hipStream_t st, uint16_t* d, const float* table, int pos0, int n_tok, int seq_len, long long stride, int n_head, int hd) {
+    if (n_tok < 1 || seq_len < 1 || n_head < 1 || hd < 2 || (hd & 1)) return KF_INVALID_ARGS;
+    hipLaunchKernelGGL(rope_backward_kernel, dim3((n_head * (hd / 2) + 255) / 256, n_tok), dim3(256), 0, st, d, table, pos0, seq_len, stride, n_head, hd);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+
 // ---------------------------------------------------------------- SwiGLU / add
 __global__ void swiglu_kernel(const uint16_t* __restrict__ gate, const uint16_t* __restrict__ up, uint16_t* __restrict__ out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -931,6 +931,20 @@ KFO_API void kfo_colsum_add(const uint16_t* x, uint16_t* dst, int n, int C) {
     }
 }
 
+/* RoPE backward, rotate-half (the transpose of kfo_rope / CU_rope2_v0, operator.cuh:734-772), in place on one row of n_head * hd gradients at `pos`:
+ * (g_j, g_{j+hd/2}) -> (g_j c + g_{j+hd/2} s, g_{j+hd/2} c - g_j s), products and sum in fp32 without contraction, bf16 stores. */
+KFO_API void kfo_rope_backward(uint16_t* d, int n_head, int hd, const float* cos_t, const float* sin_t) {
+    const int half = hd / 2;
+    for (int h = 0; h < n_head; h++)
+        for (int j = 0; j < half; j++) {
+            uint16_t* p = d + (size_t)h * hd + j;
+            const float g0 = kfo_bf16_to_f32(p[0]), g1 = kfo_bf16_to_f32(p[half]), c = cos_t[j], sn = sin_t[j];
+            const float a = g0 * c, b = g1 * sn, cc = g1 * c, dd = g0 * sn;
+            p[0] = kfo_f32_to_bf16(a + b);
+            p[half] = kfo_f32_to_bf16(cc - dd);
+        }
+}
+
 /* GELU backward in place (gelu_backward_inplace_kernel, Activation.cu:42-60) and SwiGLU backward (CU_swiglu_back_v0, Activation.cu:245-260): the
  * reference's expressions, evaluated left to right in fp32; tanh and sech^2 from one kfo_expf(2z) (tanhf / coshf in the reference), the sigmoid from
  * kfo_expf; round-to-nearest stores. */

@@ -358,6 +358,16 @@ def colsum_add(x, dst):
     fn(_p(x), _p(dst), x.shape[0], x.shape[1])
 
 
+def rope_backward(d, nHead, hd, pos, theta):
+    """transpose of rope(): gradient row d (uint16 [nHead * hd]) at position pos"""
+    out = np.ascontiguousarray(d, dtype=np.uint16).copy()
+    c, s_ = rope_table(pos, hd, theta)
+    fn = lib().kfo_rope_backward
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    fn(_p(out), nHead, hd, _p(c), _p(s_))
+    return out
+
+
 def gelu_backward(d, x):
     """returns gelu'(x) * d (uint16 bf16 arrays)"""
     out = np.ascontiguousarray(d, dtype=np.uint16).copy()

@@ -417,3 +417,23 @@ def test_attn_backward_gqa_vs_oracle(ctx, T, H, KV, hd):
         g, r = f(g_), f(r_)
         assert np.abs(g - r).max() <= 2.0 ** -7 * np.abs(r).max(), name
         assert np.sqrt(((g - r) ** 2).mean()) <= 2.0 ** -9 * np.abs(r).max(), name
+
+
+def test_rope_backward_bit_exact(ctx):
+    T, H, hd, theta = 37, 3, 64, 1e6
+    rng = np.random.default_rng(6)
+    d = O.f32_to_bf16(rng.normal(0, 1.0, (2 * T, H * hd + 16)).astype(np.float32))   # two sequences of T rows, padded row stride
+    dd = bf16_t(d, ctx.device)
+    table = ctx.rope_table(T, hd, theta)
+    assert ctx.hip.kf_rope_backward(ctx.h, dd.data_ptr(), table.data_ptr(), 0, 2 * T, T, H * hd + 16, H, hd) == 0
+    ctx.sync()
+    got = u16(dd)
+    for t in range(2 * T):
+        assert np.array_equal(got[t, :H * hd], O.rope_backward(d[t, :H * hd], H, hd, t % T, theta)), t
+    assert np.array_equal(got[:, H * hd:], d[:, H * hd:])
+    # the transpose property: <rope(x), g> == <x, rope_backward(g)> up to bf16 rounding
+    x = O.f32_to_bf16(rng.normal(0, 1.0, H * hd).astype(np.float32))
+    g = d[5, :H * hd]
+    f = lambda a: O.bf16_to_f32(a).astype(np.float64)
+    lhs, rhs = float(f(O.rope(x, H, hd, 5, theta)) @ f(g)), float(f(x) @ f(O.rope_backward(g, H, hd, 5, theta)))
+    assert abs(lhs - rhs) <= 2.0 ** -6 * (abs(lhs) + 1.0)

@@ -163,3 +163,174 @@ def test_gpt2_toy_training_step_vs_autograd(ctx, Bn, T):
         worst.append((mx, rms, name))
         assert mx <= 2.0 ** -5 and rms <= 2.0 ** -7, "%s: max %.4f rms %.4f of scale" % (name, mx, rms)
     print("largest gradient deviations (max, rms, tensor):", sorted(worst, reverse=True)[:3])
+
+
+def test_qwen3_toy_training_step_vs_autograd(ctx):
+    """The Qwen3 family's training step at toy size through the ABI: RMSNorm, Q / K / V (4-bit), per-head q/k RMSNorm + rotate-half RoPE, grouped-query
+    causal attention, o_proj + residual, RMSNorm, gate / up / SwiGLU / down + residual, final RMSNorm, tied head, loss -- and the backward of each --
+    against torch autograd in fp64 on the dequantised weights."""
+    Bn, T, dim, H, KV, hd, ffn, NL, V, Vp, theta, eps = 2, 64, 128, 4, 2, 64, 256, 2, 250, 256, 10000.0, 1e-6
+    N, Cq, Ck = Bn * T, H * hd, KV * hd
+    dev = ctx.device
+    rng = np.random.default_rng(91)
+    mk = lambda *s, std=0.08: O.f32_to_bf16(rng.normal(0, std, size=s).astype(np.float32))
+    nw = lambda n: O.f32_to_bf16((1 + rng.normal(0, 0.1, n)).astype(np.float32))
+    f64 = lambda a: torch.tensor(O.bf16_to_f32(a).astype(np.float64))
+    zeros = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device=dev)
+    wte = np.zeros((Vp, dim), np.uint16)
+    wte[:V] = mk(V, dim, std=0.2)
+    ids = rng.integers(0, V, N).astype(np.int32)
+    tgt = rng.integers(0, V, N).astype(np.int32)
+    shapes = {"q": (Cq, dim), "k": (Ck, dim), "v": (Ck, dim), "o": (dim, Cq), "gate": (ffn, dim), "up": (ffn, dim), "down": (dim, ffn)}
+    layers = []
+    for _ in range(NL):
+        W = {k_: mk(*sh) for k_, sh in shapes.items()}
+        ow = {k_: O.quantize(W[k_], shapes[k_][0], shapes[k_][1], L.Q4) for k_ in W}
+        norms = {"n1": nw(dim), "n2": nw(dim), "qn": nw(hd), "kn": nw(hd)}
+        layers.append(dict(ow=ow, dw={k_: ctx.upload_blob(L.Q4, shapes[k_][0], shapes[k_][1], ow[k_].blob()) for k_ in W}, norms=norms,
+                           nd={k_: bf16_t(v_, dev) for k_, v_ in norms.items()}))
+    nf = nw(dim)
+    nf_d = bf16_t(nf, dev)
+    dhead = ctx.upload_blob(L.BF16, Vp, dim, O.quantize(wte, Vp, dim, L.BF16).blob())
+    table = ctx.rope_table(T, hd, theta)
+    stat = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
+
+    def rms(x, w, rows, d_):
+        y, r = zeros(rows, d_), stat(rows)
+        assert ctx.hip.kf_rmsnorm(ctx.h, x.data_ptr(), w.data_ptr(), y.data_ptr(), rows, d_, eps, r.data_ptr()) == 0
+        return y, r
+
+    # ------------------------------------------------------------------ forward
+    x = bf16_t(wte[ids], dev)
+    saved = []
+    for ly in layers:
+        h1, r1 = rms(x, ly["nd"]["n1"], N, dim)
+        qkv = zeros(N, Cq + 2 * Ck)   # q | k | v column blocks
+        for nm, c0, w_ in (("q", 0, Cq), ("k", Cq, Ck), ("v", Cq + Ck, Ck)):
+            qkv[:, c0:c0 + w_] = _lin(ctx, ly["dw"][nm], h1, N, w_)
+        raw = qkv.clone()   # pre-norm q / k for the backward
+        _, rq = rms(raw[:, :Cq].contiguous().view(N * H, hd), ly["nd"]["qn"], N * H, hd)
+        _, rk = rms(raw[:, Cq:Cq + Ck].contiguous().view(N * KV, hd), ly["nd"]["kn"], N * KV, hd)
+        for s_ in range(Bn):   # the fused per-head RMSNorm + RoPE of the inference path, positions 0 .. T - 1 of every sequence
+            sl = slice(s_ * T, (s_ + 1) * T)
+            assert ctx.hip.kf_qknorm_rope_batch(ctx.h, qkv[sl, :Cq].data_ptr(), qkv[sl, Cq:].data_ptr(), ly["nd"]["qn"].data_ptr(), ly["nd"]["kn"].data_ptr(), table.data_ptr(), 0, T,
+                                                Cq + 2 * Ck, Cq + 2 * Ck, H, KV, hd, eps) == 0
+        qc = qkv[:, :Cq].contiguous()
+        att = zeros(N, Cq)
+        assert ctx.hip.kf_attn_prefill_batch(ctx.h, qc.data_ptr(), qkv[:, Cq:].data_ptr(), qkv[:, Cq + Ck:].data_ptr(), att.data_ptr(), T, Cq, H, KV, hd, Cq + 2 * Ck, Bn) == 0
+        x2 = _lin(ctx, ly["dw"]["o"], att, N, dim, residual=x)
+        h2, r2 = rms(x2, ly["nd"]["n2"], N, dim)
+        gate, up = _lin(ctx, ly["dw"]["gate"], h2, N, ffn), _lin(ctx, ly["dw"]["up"], h2, N, ffn)
+        act = zeros(N, ffn)
+        assert ctx.hip.kf_swiglu(ctx.h, gate.data_ptr(), up.data_ptr(), act.data_ptr(), N * ffn) == 0
+        xo = _lin(ctx, ly["dw"]["down"], act, N, dim, residual=x2)
+        saved.append(dict(x=x, h1=h1, r1=r1, raw=raw, rq=rq, rk=rk, qkv=qkv, att=att, x2=x2, h2=h2, r2=r2, gate=gate, up=up, act=act))
+        x = xo
+    hf, rf = rms(x, nf_d, N, dim)
+    logits = _lin(ctx, dhead, hf, N, Vp)
+    losses = torch.zeros(N, dtype=torch.float32, device=dev)
+    td = torch.from_numpy(tgt).to(dev)
+    assert ctx.hip.kf_fused_classifier(ctx.h, logits.data_ptr(), losses.data_ptr(), None, 1.0 / N, td.data_ptr(), Bn, T, V, Vp, None, 1) == 0
+    logits[:, V:] = 0
+
+    # ------------------------------------------------------------------ backward
+    def lin_bwd(dw, dIn, inp, delta=None, acc=0):
+        d = dw.desc()
+        OC, IC = dIn.shape[1], inp.shape[1]
+        delta = delta if delta is not None else zeros(N, IC)
+        gW = zeros(OC, IC)
+        sc = torch.empty(ctx.hip.kf_linear_backward_scratch_bytes(OC, IC, N) + 256, dtype=torch.uint8, device=dev)
+        assert ctx.hip.kf_linear_backward(ctx.h, C.byref(d), dIn.data_ptr(), inp.data_ptr(), delta.data_ptr(), gW.data_ptr(), None, N, acc, (sc.data_ptr() + 255) & ~255) == 0, \
+            ctx.hip.kf_last_error()
+        return delta, gW
+
+    def rms_bwd(dx, dout, inp, w, rstd, rows, d_):
+        gw = zeros(d_)
+        sc = torch.empty(ctx.hip.kf_norm_backward_scratch_bytes(rows, d_, 0) // 8 + 1, dtype=torch.float64, device=dev)
+        assert ctx.hip.kf_norm_backward(ctx.h, dx.data_ptr(), gw.data_ptr(), None, dout.data_ptr(), inp.data_ptr(), w.data_ptr(), None, rstd.data_ptr(), rows, d_, sc.data_ptr()) == 0, \
+            ctx.hip.kf_last_error()
+        return gw
+
+    grads = {}
+    dhf, g_wte = lin_bwd(dhead, logits, hf)
+    dx = zeros(N, dim)
+    grads["nf"] = rms_bwd(dx, dhf, x, nf_d, rf, N, dim)
+    att_sc = torch.zeros(ctx.hip.kf_attn_backward_scratch_bytes(T, H, Bn) // 4 + 1, dtype=torch.float32, device=dev)
+    W_ = Cq + 2 * Ck
+    for li in reversed(range(NL)):
+        ly, s_ = layers[li], saved[li]
+        dact, grads["%d.down" % li] = lin_bwd(ly["dw"]["down"], dx, s_["act"])
+        dgate = zeros(N, ffn)
+        assert ctx.hip.kf_swiglu_backward(ctx.h, dact.data_ptr(), dgate.data_ptr(), s_["gate"].data_ptr(), s_["up"].data_ptr(), N * ffn) == 0   # dact becomes d(up)
+        dh2, grads["%d.up" % li] = lin_bwd(ly["dw"]["up"], dact, s_["h2"])
+        _, grads["%d.gate" % li] = lin_bwd(ly["dw"]["gate"], dgate, s_["h2"], delta=dh2, acc=1)
+        grads["%d.n2" % li] = rms_bwd(dx, dh2, s_["x2"], ly["nd"]["n2"], s_["r2"], N, dim)
+        datt, grads["%d.o" % li] = lin_bwd(ly["dw"]["o"], dx, s_["att"])
+        dqkv = zeros(N, W_)
+        qkv = s_["qkv"]
+        assert ctx.hip.kf_attn_backward(ctx.h, qkv[:, :Cq].data_ptr(), qkv[:, Cq:].data_ptr(), qkv[:, Cq + Ck:].data_ptr(), W_, s_["att"].data_ptr(), datt.data_ptr(), Cq,
+                                        dqkv[:, :Cq].data_ptr(), dqkv[:, Cq:].data_ptr(), dqkv[:, Cq + Ck:].data_ptr(), W_, T, H, KV, hd, Bn, att_sc.data_ptr()) == 0, ctx.hip.kf_last_error()
+        # RoPE backward on dq, dk (in place), then the q/k-norm backward per head row
+        assert ctx.hip.kf_rope_backward(ctx.h, dqkv[:, :Cq].data_ptr(), table.data_ptr(), 0, N, T, W_, H, hd) == 0
+        assert ctx.hip.kf_rope_backward(ctx.h, dqkv[:, Cq:].data_ptr(), table.data_ptr(), 0, N, T, W_, KV, hd) == 0
+        dq_post, dk_post = dqkv[:, :Cq].contiguous().view(N * H, hd), dqkv[:, Cq:Cq + Ck].contiguous().view(N * KV, hd)
+        dq_raw, dk_raw = zeros(N * H, hd), zeros(N * KV, hd)
+        grads["%d.qn" % li] = rms_bwd(dq_raw, dq_post, s_["raw"][:, :Cq].contiguous().view(N * H, hd), ly["nd"]["qn"], s_["rq"], N * H, hd)
+        grads["%d.kn" % li] = rms_bwd(dk_raw, dk_post, s_["raw"][:, Cq:Cq + Ck].contiguous().view(N * KV, hd), ly["nd"]["kn"], s_["rk"], N * KV, hd)
+        dh1, grads["%d.q" % li] = lin_bwd(ly["dw"]["q"], dq_raw.view(N, Cq), s_["h1"])
+        _, grads["%d.k" % li] = lin_bwd(ly["dw"]["k"], dk_raw.view(N, Ck), s_["h1"], delta=dh1, acc=1)
+        _, grads["%d.v" % li] = lin_bwd(ly["dw"]["v"], dqkv[:, Cq + Ck:].contiguous(), s_["h1"], delta=dh1, acc=1)
+        grads["%d.n1" % li] = rms_bwd(dx, dh1, s_["x"], ly["nd"]["n1"], s_["r1"], N, dim)
+    idd = torch.from_numpy(ids).to(dev)
+    assert ctx.hip.kf_embed_backward(ctx.h, g_wte.data_ptr(), dim, None, dx.data_ptr(), idd.data_ptr(), Bn, T, dim, Vp) == 0
+    ctx.sync()
+    grads["wte"] = g_wte
+    dev_loss = float(losses.mean())
+
+    # ------------------------------------------------------------------ torch, fp64
+    P = {"wte": f64(wte).clone().requires_grad_(True), "nf": f64(nf).clone().requires_grad_(True)}
+    for li, ly in enumerate(layers):
+        for k_ in shapes:
+            P["%d.%s" % (li, k_)] = f64(O.dequant(ly["ow"][k_])).reshape(shapes[k_]).clone().requires_grad_(True)
+        for k_ in ("n1", "n2", "qn", "kn"):
+            P["%d.%s" % (li, k_)] = f64(ly["norms"][k_]).clone().requires_grad_(True)
+    F = torch.nn.functional
+    rmsn = lambda t_, w_: t_ * torch.rsqrt((t_ * t_).mean(-1, keepdim=True) + eps) * w_
+    posv = torch.arange(T, dtype=torch.float64)
+    inv = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.float64) / hd))
+    ang = posv[:, None] * inv[None, :]
+    cs, sn = torch.cos(ang), torch.sin(ang)   # [T, hd/2]
+
+    def rope(t_):   # [Bn, T, heads, hd], rotate-half
+        a, b = t_[..., :hd // 2], t_[..., hd // 2:]
+        c_, s2 = cs[None, :, None, :], sn[None, :, None, :]
+        return torch.cat([a * c_ - b * s2, a * s2 + b * c_], dim=-1)
+
+    xt = P["wte"][torch.from_numpy(ids).long()]
+    for li in range(NL):
+        g_ = lambda nm: P["%d.%s" % (li, nm)]
+        h1 = rmsn(xt, g_("n1"))
+        q = rope(rmsn((h1 @ g_("q").T).reshape(Bn, T, H, hd), g_("qn"))).transpose(1, 2)
+        k = rope(rmsn((h1 @ g_("k").T).reshape(Bn, T, KV, hd), g_("kn"))).transpose(1, 2)
+        v = (h1 @ g_("v").T).reshape(Bn, T, KV, hd).transpose(1, 2)
+        k, v = k.repeat_interleave(H // KV, dim=1), v.repeat_interleave(H // KV, dim=1)
+        at = F.scaled_dot_product_attention(q, k, v, is_causal=True).transpose(1, 2).reshape(N, Cq)
+        x2 = xt + at @ g_("o").T
+        h2 = rmsn(x2, g_("n2"))
+        xt = x2 + (F.silu(h2 @ g_("gate").T) * (h2 @ g_("up").T)) @ g_("down").T
+    loss = F.cross_entropy((rmsn(xt, P["nf"]) @ P["wte"].T)[:, :V], torch.from_numpy(tgt).long())
+    loss.backward()
+    ref_loss = float(loss.detach())
+    assert abs(dev_loss - ref_loss) <= 2.0 ** -7 * ref_loss
+    worst = []
+    for name, gd in grads.items():
+        ref = P[name].grad.numpy()
+        got = O.bf16_to_f32(u16(gd)).astype(np.float64).reshape(ref.shape)
+        sc_ = np.abs(ref).max()
+        mx, rms_ = np.abs(got - ref).max() / sc_, np.sqrt(((got - ref) ** 2).mean()) / sc_
+        worst.append((round(mx, 4), round(rms_, 5), name))
+        # the 64-element q/k-norm weight gradients sum bf16-rounded rows over all tokens and heads (and the forward rounds their rstd to bf16, as
+        # the reference does): twice the rms allowance of the matrices
+        rms_tol = 2.0 ** -6 if name.endswith(("qn", "kn")) else 2.0 ** -7
+        assert mx <= 2.0 ** -5 and rms_ <= rms_tol, "%s: max %.4f rms %.4f of scale" % (name, mx, rms_)
+    print("largest gradient deviations (max, rms, tensor):", sorted(worst, reverse=True)[:3])
