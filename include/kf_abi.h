@@ -196,6 +196,12 @@ int kf_layernorm(kf_ctx* ctx, const kf_bf16* x, const kf_bf16* w, const kf_bf16*
 /* GELU, tanh form (Relu::Forw GELU -> gelu_forward_kernel2, Activation.cu:23-40) */
 int kf_gelu(kf_ctx* ctx, const kf_bf16* x, kf_bf16* y, size_t n);
 
+/* kf_qknorm_rope_batch for a training batch: n_tok rows = sequences of seq_len tokens back to back, positions 0 .. seq_len - 1 in each; the per-head
+ * 1/rms of the q / k norms (fp32, before the bf16 rounding the forward applies to it) go to rstd_q [n_tok * n_head] / rstd_k [n_tok * n_kv] when given:
+ * what kf_norm_backward needs for the q/k-norm backward. */
+int kf_qknorm_rope_train(kf_ctx* ctx, kf_bf16* q, kf_bf16* k, const kf_bf16* wq_norm, const kf_bf16* wk_norm, const float* rope_table, int n_tok, int seq_len, int64_t q_stride,
+                         int64_t k_stride, int n_head, int n_kv, int head_dim, float eps, float* rstd_q_or_null, float* rstd_k_or_null);
+
 /* kf_attn_prefill for n_seq independent sequences of n_tok tokens each (a training batch), positions 0 .. n_tok - 1, in ONE launch: sequence s owns rows
  * s * n_tok .. (s + 1) * n_tok - 1 of q / out (row stride q_stride) and of k / v (row stride kv_stride; e.g. the column blocks of a fused [B*T, 3C] buffer).
  * Same arithmetic as kf_attn_prefill (the MFMA tile kernel).  head_dim 64 or 128. */

@@ -564,6 +564,13 @@ int kf_qknorm_rope_batch(kf_ctx* c, kf_bf16* q, kf_bf16* k, const kf_bf16* wq, c
     if (hd % 2) return fail(KF_RMS_PARAMS, "head_dim %d is not divisible by 2", hd);
     RET(kf::qknorm_rope_launch(c->stream, q, k, wq, wk, table, pos0, nullptr, n_head, n_kv, hd, eps, n_tok, q_stride, k_stride));
 }
+int kf_qknorm_rope_train(kf_ctx* c, kf_bf16* q, kf_bf16* k, const kf_bf16* wq, const kf_bf16* wk, const float* table, int n_tok, int seq_len, int64_t q_stride,
+                         int64_t k_stride, int n_head, int n_kv, int hd, float eps, float* rstd_q, float* rstd_k) {
+    CHKCTX(c);
+    if (!q || n_tok < 1 || seq_len < 1) return fail(KF_INVALID_ARGS, "kf_qknorm_rope_train: bad args");
+    if (hd % 2) return fail(KF_RMS_PARAMS, "head_dim %d is not divisible by 2", hd);
+    RET(kf::qknorm_rope_launch(c->stream, q, k, wq, wk, table, 0, nullptr, n_head, n_kv, hd, eps, n_tok, q_stride, k_stride, seq_len, rstd_q, rstd_k));
+}
 int kf_attn_prefill(kf_ctx* c, const kf_bf16* q, const kf_bf16* kc, const kf_bf16* vc, kf_bf16* out, int pos0, int n_tok, int64_t q_stride, int n_head, int n_kv,
                     int hd, int kv_stride) {
     CHKCTX(c);

@@ -49,7 +49,7 @@ __device__ __forceinline__ HeadRaw load_head(const uint16_t* __restrict__ src, c
 // Prepare one head: optional per-head RMSNorm (s rounded to bf16 first, then (a*s)*w, RN store) and rotate-half
 // RoPE from the host-built (cos,sin) table.  One wave per head; lane j handles the pair (j, j + hd/2).
 // Result: bf16 bits in dst[hd].
-__device__ __forceinline__ void prep_head(const HeadRaw r, bool norm, const float* __restrict__ tab_pos, int hd, float eps, uint16_t* dst) {
+__device__ __forceinline__ void prep_head(const HeadRaw r, bool norm, const float* __restrict__ tab_pos, int hd, float eps, uint16_t* dst, float* rstd_out = nullptr) {
     const int lane = threadIdx.x & 63, half = hd >> 1;
     const int j = lane; /* hd <= 128: one trip covers the head */
     const bool act = j < half;
@@ -61,6 +61,7 @@ __device__ __forceinline__ void prep_head(const HeadRaw r, bool norm, const floa
         const double ss = wave_sum_f64_fast(fma((double)x0, (double)x0, (double)x1 * (double)x1));
         const float s0 = 1.0f / sqrtf((float)ss / (float)hd + eps);
         const float s = round_bf16(s0);
+        if (rstd_out && lane == 0) *rstd_out = s0; /* the un-rounded 1/rms, for the training path's backward */
         x0 = round_bf16(x0 * s * w0);
         x1 = round_bf16(x1 * s * w1);
     }
@@ -338,13 +339,16 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
 
 // standalone ROPE::cuInfer: grid = n_head + n_kv, one wave each
 __global__ void __launch_bounds__(64) qknorm_rope_kernel(uint16_t* q, uint16_t* k, const uint16_t* wq, const uint16_t* wk, const float* table, int pos_,
-                                                         const int* d_pos, int n_head, int n_kv, int hd, float eps, long long q_stride, long long k_stride) {
+                                                         const int* d_pos, int n_head, int n_kv, int hd, float eps, long long q_stride, long long k_stride, int seq_len, float* rstd_q,
+                                                         float* rstd_k) {
     __shared__ uint16_t buf[256];
-    const int pos = (d_pos ? *d_pos : pos_) + (int)blockIdx.y; /* blockIdx.y = token of a batch */
+    /* blockIdx.y = token of a batch; seq_len > 0: sequences of seq_len tokens back to back, positions restart at pos_ in each */
+    const int pos = (d_pos ? *d_pos : pos_) + (seq_len > 0 ? (int)blockIdx.y % seq_len : (int)blockIdx.y);
     const int b = blockIdx.x;
     uint16_t* src = b < n_head ? q + (size_t)blockIdx.y * q_stride + (size_t)b * hd : k + (size_t)blockIdx.y * k_stride + (size_t)(b - n_head) * hd;
     const uint16_t* wn = b < n_head ? wq : wk;
-    prep_head(load_head(src, wn, hd), wn != nullptr, table ? table + (size_t)pos * hd : nullptr, hd, eps, buf);
+    float* ro = b < n_head ? (rstd_q ? rstd_q + (size_t)blockIdx.y * n_head + b : nullptr) : (rstd_k ? rstd_k + (size_t)blockIdx.y * n_kv + (b - n_head) : nullptr);
+    prep_head(load_head(src, wn, hd), wn != nullptr, table ? table + (size_t)pos * hd : nullptr, hd, eps, buf, ro);
     __syncthreads();
     for (int i = threadIdx.x; i < hd; i += 64) src[i] = buf[i];
 }
@@ -412,10 +416,10 @@ int attn_launch(hipStream_t st, AttnArgs& a) {
 }
 
 int qknorm_rope_launch(hipStream_t st, uint16_t* q, uint16_t* k, const uint16_t* wq, const uint16_t* wk, const float* table, int pos,
-                       const int* d_pos, int n_head, int n_kv, int hd, float eps, int n_tok, long long q_stride, long long k_stride) {
+                       const int* d_pos, int n_head, int n_kv, int hd, float eps, int n_tok, long long q_stride, long long k_stride, int seq_len, float* rstd_q, float* rstd_k) {
     if (hd < 64 || hd > 128 || (hd & (hd - 1)) != 0 || n_tok < 1) return KF_INVALID_ARGS;
     hipLaunchKernelGGL(qknorm_rope_kernel, dim3(n_head + (k ? n_kv : 0), n_tok), dim3(64), 0, st, q, k, wq, wk, table, pos, d_pos, n_head, n_kv, hd, eps,
-                       q_stride, k_stride);
+                       q_stride, k_stride, seq_len, rstd_q, rstd_k);
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 

@@ -86,7 +86,8 @@ int attn_splits(int pos_bound, int n_kv);
 int attn_prefill_mfma_launch(hipStream_t st, const uint16_t* q, const uint16_t* kc, const uint16_t* vc, uint16_t* out, int pos0, int n_tok, long long q_stride,
                              int n_head, int n_kv, int hd, int kv_stride, int n_seq = 1);
 int qknorm_rope_launch(hipStream_t st, uint16_t* q, uint16_t* k, const uint16_t* wq, const uint16_t* wk, const float* table, int pos,
-                       const int* d_pos, int n_head, int n_kv, int hd, float eps, int n_tok = 1, long long q_stride = 0, long long k_stride = 0);
+                       const int* d_pos, int n_head, int n_kv, int hd, float eps, int n_tok = 1, long long q_stride = 0, long long k_stride = 0, int seq_len = 0,
+                       float* rstd_q = nullptr, float* rstd_k = nullptr);
 
 // ---- small ops (kf_ops.hip)
 int rmsnorm_launch(hipStream_t st, const uint16_t* x, const uint16_t* w, uint16_t* y, int rows, int dim, float eps, float* rstd);

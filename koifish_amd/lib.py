@@ -17,7 +17,7 @@ ABI_SYMBOLS = [
     "kf_graph_begin", "kf_graph_end", "kf_graph_launch", "kf_graph_destroy", "kf_event_create", "kf_event_record", "kf_event_elapsed_ms",
     "kf_event_destroy", "kf_dequant", "kf_quantize", "kf_linear", "kf_rmsnorm", "kf_qknorm_rope", "kf_rope_table_host", "kf_attn_decode",
     "kf_attn_scratch_bytes", "kf_linear_f32", "kf_tp_reduce", "kf_swiglu", "kf_add", "kf_embed", "kf_lm_head", "kf_head_scratch_bytes", "kf_norm_linear",
-    "kf_norm_gateup_swiglu", "kf_attn_block", "kf_norm_lm_head", "kf_set_state", "kf_embed_state", "kf_embed_batch", "kf_qknorm_rope_batch", "kf_attn_prefill", "kf_sample", "kf_linear_multi", "kf_gateup_swiglu_batch", "kf_adamw", "kf_layernorm", "kf_gelu", "kf_sample_topk", "kf_fused_classifier", "kf_gelu_backward", "kf_swiglu_backward", "kf_rope_backward", "kf_norm_backward", "kf_norm_backward_scratch_bytes", "kf_linear_backward", "kf_linear_backward_scratch_bytes", "kf_embed_backward", "kf_attn_backward", "kf_attn_backward_scratch_bytes", "kf_attn_prefill_batch",
+    "kf_norm_gateup_swiglu", "kf_attn_block", "kf_norm_lm_head", "kf_set_state", "kf_embed_state", "kf_embed_batch", "kf_qknorm_rope_batch", "kf_attn_prefill", "kf_sample", "kf_linear_multi", "kf_gateup_swiglu_batch", "kf_adamw", "kf_layernorm", "kf_gelu", "kf_sample_topk", "kf_fused_classifier", "kf_gelu_backward", "kf_swiglu_backward", "kf_rope_backward", "kf_norm_backward", "kf_norm_backward_scratch_bytes", "kf_linear_backward", "kf_linear_backward_scratch_bytes", "kf_embed_backward", "kf_attn_backward", "kf_attn_backward_scratch_bytes", "kf_attn_prefill_batch", "kf_qknorm_rope_train",
 ]
 
 
@@ -62,6 +62,7 @@ def load():
         hip.kf_adamw.argtypes = [C.c_void_p] * 5 + [C.c_size_t, C.c_int] + [C.c_float] * 8 + [C.c_uint32, C.c_void_p]
         hip.kf_sample_topk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         hip.kf_layernorm.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+        hip.kf_qknorm_rope_train.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
         hip.kf_attn_prefill_batch.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         hip.kf_attn_backward.argtypes = [C.c_void_p] * 4 + [C.c_longlong, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         hip.kf_attn_backward_scratch_bytes.argtypes, hip.kf_attn_backward_scratch_bytes.restype = [C.c_int, C.c_int, C.c_int], C.c_size_t

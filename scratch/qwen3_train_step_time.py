@@ -37,10 +37,8 @@ def forward():
         lin(w["q"], a["h1"], tmp_q); lin(w["k"], a["h1"], tmp_k); lin(w["v"], a["h1"], tmp_v)
         a["qkv"][:, :Cq] = tmp_q; a["qkv"][:, Cq:Cq + Ck] = tmp_k; a["qkv"][:, Cq + Ck:] = tmp_v
         a["raw"].copy_(a["qkv"])
-        rms(tmp_q.view(N * H, hd), nh, tq, a["rq"], N * H, hd); rms(tmp_k.view(N * KV, hd), nh, tk, a["rk"], N * KV, hd)   # rstd of the per-head norms for the backward
-        for b in range(B):
-            s = slice(b * T, (b + 1) * T)
-            L.check(ctx.hip.kf_qknorm_rope_batch(ctx.h, a["qkv"][s, :Cq].data_ptr(), a["qkv"][s, Cq:].data_ptr(), nh.data_ptr(), nh.data_ptr(), table.data_ptr(), 0, T, W_, W_, H, KV, hd, eps), "rope")
+        L.check(ctx.hip.kf_qknorm_rope_train(ctx.h, a["qkv"][:, :Cq].data_ptr(), a["qkv"][:, Cq:].data_ptr(), nh.data_ptr(), nh.data_ptr(), table.data_ptr(), N, T, W_, W_, H, KV, hd, eps,
+                                             a["rq"].data_ptr(), a["rk"].data_ptr()), "rope")
         qc.copy_(a["qkv"][:, :Cq])
         L.check(ctx.hip.kf_attn_prefill_batch(ctx.h, qc.data_ptr(), a["qkv"][:, Cq:].data_ptr(), a["qkv"][:, Cq + Ck:].data_ptr(), a["att"].data_ptr(), T, Cq, H, KV, hd, W_, B), "attn")
         lin(w["o"], a["att"], a["x2"], a["x"])

@@ -209,12 +209,10 @@ def test_qwen3_toy_training_step_vs_autograd(ctx):
         for nm, c0, w_ in (("q", 0, Cq), ("k", Cq, Ck), ("v", Cq + Ck, Ck)):
             qkv[:, c0:c0 + w_] = _lin(ctx, ly["dw"][nm], h1, N, w_)
         raw = qkv.clone()   # pre-norm q / k for the backward
-        _, rq = rms(raw[:, :Cq].contiguous().view(N * H, hd), ly["nd"]["qn"], N * H, hd)
-        _, rk = rms(raw[:, Cq:Cq + Ck].contiguous().view(N * KV, hd), ly["nd"]["kn"], N * KV, hd)
-        for s_ in range(Bn):   # the fused per-head RMSNorm + RoPE of the inference path, positions 0 .. T - 1 of every sequence
-            sl = slice(s_ * T, (s_ + 1) * T)
-            assert ctx.hip.kf_qknorm_rope_batch(ctx.h, qkv[sl, :Cq].data_ptr(), qkv[sl, Cq:].data_ptr(), ly["nd"]["qn"].data_ptr(), ly["nd"]["kn"].data_ptr(), table.data_ptr(), 0, T,
-                                                Cq + 2 * Ck, Cq + 2 * Ck, H, KV, hd, eps) == 0
+        rq, rk = stat(N * H), stat(N * KV)
+        # the fused per-head RMSNorm + RoPE of the inference path, positions 0 .. T - 1 of every sequence, with the per-head 1/rms kept for the backward
+        assert ctx.hip.kf_qknorm_rope_train(ctx.h, qkv[:, :Cq].data_ptr(), qkv[:, Cq:].data_ptr(), ly["nd"]["qn"].data_ptr(), ly["nd"]["kn"].data_ptr(), table.data_ptr(), N, T,
+                                            Cq + 2 * Ck, Cq + 2 * Ck, H, KV, hd, eps, rq.data_ptr(), rk.data_ptr()) == 0
         qc = qkv[:, :Cq].contiguous()
         att = zeros(N, Cq)
         assert ctx.hip.kf_attn_prefill_batch(ctx.h, qc.data_ptr(), qkv[:, Cq:].data_ptr(), qkv[:, Cq + Ck:].data_ptr(), att.data_ptr(), T, Cq, H, KV, hd, Cq + 2 * Ck, Bn) == 0
