@@ -119,6 +119,95 @@ __global__ void __launch_bounds__(256) norm_backward_kernel(uint16_t* __restrict
     }
 }
 
+// Narrow rows (dim = 64 .. 512, a power of two: the per-head q/k-norm of attention, rows = tokens x heads): LPR = dim / 8 lanes per row, 64 / LPR rows
+// per wave and 4 x that per workgroup at once; the row sums stay inside the row's lanes (DPP / row swaps on fp64 halves), the column partials are
+// combined over the wave's rows and the 4 waves at the end.  Same group decomposition (rows r = w + G i belong to workgroup w) as the wide form; inside
+// a group the fp64 sums of fp32 terms are exact, so visiting its rows 4 x 64 / LPR at a time instead of one by one changes no bit.
+__device__ __forceinline__ double nb_lanes_sum(double v, int lpr_log2) { /* over the 2^lpr_log2 (8 .. 64) lanes of a row */
+    v += dpp_d<0xB1>(v);
+    v += dpp_d<0x4E>(v);
+    v += dpp_d<0x141>(v);
+    if (lpr_log2 >= 4) v += dpp_d<0x140>(v);
+    if (lpr_log2 >= 5) v = xsum16_d(v);
+    if (lpr_log2 >= 6) v = xsum32_d(v);
+    return v;
+}
+template <bool IS_LN>
+__global__ void __launch_bounds__(256) norm_backward_narrow_kernel(uint16_t* __restrict__ dinp, const uint16_t* __restrict__ dout, const uint16_t* __restrict__ inp,
+                                                                   const uint16_t* __restrict__ weight, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                   double* __restrict__ part, int rows, int C, int lpr_log2) {
+    __shared__ double red[4][64][8 * (IS_LN ? 2 : 1)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = gridDim.x;
+    const int LPR = 1 << lpr_log2, RPW = 64 >> lpr_log2; /* lanes per row, rows per wave */
+    const int ll = lane & (LPR - 1), slot = wave * RPW + (lane >> lpr_log2), nslot = 4 * RPW;
+    const u32x4 wv = *reinterpret_cast<const u32x4*>(weight + (size_t)ll * 8);
+    const uint32_t wq[4] = {wv.x, wv.y, wv.z, wv.w};
+    double dw[8], db[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) dw[k] = 0.0, db[k] = 0.0;
+    for (long i = 0;; i++) {
+        const long r0 = (long)blockIdx.x + (long)G * (i * nslot); /* the first row of this round: workgroup-uniform exit */
+        if (r0 >= rows) break;
+        const long r = r0 + (long)G * slot;
+        const bool ok = r < rows;
+        const size_t base = (size_t)(ok ? r : r0) * C + (size_t)ll * 8;
+        const u32x4 dov = *reinterpret_cast<const u32x4*>(dout + base), inv = *reinterpret_cast<const u32x4*>(inp + base), div = *reinterpret_cast<const u32x4*>(dinp + base);
+        const float mean_r = IS_LN ? mean[ok ? r : r0] : 0.0f, rstd_r = rstd[ok ? r : r0];
+        const uint32_t dq_[4] = {dov.x, dov.y, dov.z, dov.w}, iq[4] = {inv.x, inv.y, inv.z, inv.w}, gq[4] = {div.x, div.y, div.z, div.w};
+        double sa = 0.0, sb = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float d0 = bf_lo(wq[k]) * bf_lo(dq_[k]), d1 = bf_hi(wq[k]) * bf_hi(dq_[k]);
+            if (IS_LN) sa += (double)d0 + (double)d1;
+            sb += (double)(d0 * bf_lo(iq[k])) + (double)(d1 * bf_hi(iq[k]));
+        }
+        if (IS_LN) sa = nb_lanes_sum(sa, lpr_log2);
+        sb = nb_lanes_sum(sb, lpr_log2);
+        const float dnorm_mean = IS_LN ? (float)sa / (float)C : 0.0f;
+        const float dnorm_norm_mean = IS_LN ? (float)sb / (float)C * rstd_r - dnorm_mean * mean_r * rstd_r : (float)sb / (float)C * rstd_r;
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float res[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const float w_ = h ? bf_hi(wq[k]) : bf_lo(wq[k]), do_ = h ? bf_hi(dq_[k]) : bf_lo(dq_[k]), in_ = h ? bf_hi(iq[k]) : bf_lo(iq[k]), di_ = h ? bf_hi(gq[k]) : bf_lo(gq[k]);
+                const float norm = (in_ - mean_r) * rstd_r;
+                if (ok) {
+                    dw[2 * k + h] += (double)(norm * do_);
+                    if (IS_LN) db[2 * k + h] += (double)do_;
+                }
+                float dval = w_ * do_;
+                if (IS_LN) dval -= dnorm_mean;
+                dval -= norm * dnorm_norm_mean;
+                dval *= rstd_r;
+                res[h] = di_ + dval;
+            }
+            o[k] = pack_bf16x2(res[0], res[1]);
+        }
+        if (ok) *reinterpret_cast<u32x4*>(dinp + base) = u32x4{o[0], o[1], o[2], o[3]};
+    }
+    // column partials: every lane to LDS, then thread c < C sums the lanes that hold column c (RPW per wave, 4 waves) in a fixed order
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        red[wave][lane][k] = dw[k];
+        if (IS_LN) red[wave][lane][8 + k] = db[k];
+    }
+    __syncthreads();
+    double* pw = part + (size_t)blockIdx.x * (IS_LN ? 2 : 1) * C;
+    for (int c = tid; c < C; c += 256) {
+        const int l0 = c >> 3, k = c & 7;
+        double tw = 0.0, tb = 0.0;
+        for (int w2 = 0; w2 < 4; w2++)
+            for (int rr = 0; rr < RPW; rr++) {
+                tw += red[w2][rr * LPR + l0][k];
+                if (IS_LN) tb += red[w2][rr * LPR + l0][8 + k];
+            }
+        pw[c] = tw;
+        if (IS_LN) pw[C + c] = tb;
+    }
+}
+
 // second launch: the G partials of a column -- 8 contiguous chunks of ceil(G / 8) workgroups summed in index order by 8 threads, the 8 chunk
 // sums added in chunk order -- then bf16(fp32 sum + old gradient).  (One thread walking all G partials is a chain of G dependent loads.)
 __global__ void __launch_bounds__(256) norm_backward_reduce_kernel(uint16_t* __restrict__ dweight, uint16_t* __restrict__ dbias, const double* __restrict__ part,
@@ -152,6 +241,13 @@ int norm_backward_launch(hipStream_t st, uint16_t* dinp, uint16_t* dweight, uint
     if (rows < 1 || C < 8 || (C % 8) != 0 || C > NB_MAXV * 2048) return KF_INVALID_ARGS;
     const int G = norm_backward_groups(rows), nv = (C / 8 + 255) / 256;
     const bool ln = mean != nullptr;
+    if (C >= 64 && C <= 512 && (C & (C - 1)) == 0 && rows >= 4096) { /* narrow rows, many of them: several rows per wave */
+        const int lpr_log2 = __builtin_ctz(C) - 3;
+        if (ln) hipLaunchKernelGGL((norm_backward_narrow_kernel<true>), dim3(G), dim3(256), 0, st, dinp, dout, inp, weight, mean, rstd, scratch, rows, C, lpr_log2);
+        else hipLaunchKernelGGL((norm_backward_narrow_kernel<false>), dim3(G), dim3(256), 0, st, dinp, dout, inp, weight, mean, rstd, scratch, rows, C, lpr_log2);
+        hipLaunchKernelGGL(norm_backward_reduce_kernel, dim3((C + 31) / 32), dim3(256), 0, st, dweight, dbias, scratch, G, C, ln ? 1 : 0);
+        return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+    }
 #define KF_NB_GO(NV)                                                                                                                             \
     do {                                                                                                                                         \
         if (ln) hipLaunchKernelGGL((norm_backward_kernel<true, NV>), dim3(G), dim3(256), 0, st, dinp, dout, inp, weight, mean, rstd, scratch, rows, C); \

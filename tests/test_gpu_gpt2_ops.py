@@ -229,7 +229,7 @@ def test_activation_backward_bit_exact(ctx):
     assert np.array_equal(u16(dd), r_up) and np.array_equal(u16(dg), r_gate)
 
 
-@pytest.mark.parametrize("rows,dim", [(1, 768), (37, 1600), (300, 1024), (700, 5120), (5, 8192), (9, 8)])
+@pytest.mark.parametrize("rows,dim", [(1, 768), (37, 1600), (300, 1024), (700, 5120), (5, 8192), (9, 8), (4100, 128), (8200, 64), (5000, 512), (4097, 256)])
 @pytest.mark.parametrize("ln", [True, False])
 def test_norm_backward_bit_exact(ctx, rows, dim, ln):
     rng = np.random.default_rng(rows * dim + ln)
