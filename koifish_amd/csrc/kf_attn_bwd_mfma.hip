@@ -51,6 +51,35 @@ __device__ __forceinline__ void ab_stage(const uint16_t* __restrict__ src, long 
         }
     }
 }
+// the same in two halves, so that a tile's global loads can be in flight while the previous tile is multiplied: registers <- global, LDS <- registers
+template <int HD>
+__device__ __forceinline__ void ab_load(const uint16_t* __restrict__ src, long long ld, size_t hoff, int row0, int T, u32x4* regs) {
+    constexpr int CH = AB_T * HD / 8;
+#pragma unroll
+    for (int i = 0; i < CH / 256; i++) {
+        const int c = threadIdx.x + 256 * i, row = c / (HD / 8), dc = c - row * (HD / 8);
+        int rr = row0 + row;
+        rr = rr < T ? rr : T - 1;
+        regs[i] = *reinterpret_cast<const u32x4*>(src + (size_t)rr * ld + hoff + dc * 8);
+    }
+}
+template <int HD, bool TRANSPOSE>
+__device__ __forceinline__ void ab_store(const u32x4* regs, uint16_t* rows, uint16_t* tr) {
+    constexpr int KS = HD + 8, CH = AB_T * HD / 8;
+#pragma unroll
+    for (int i = 0; i < CH / 256; i++) {
+        const int c = threadIdx.x + 256 * i, row = c / (HD / 8), dc = c - row * (HD / 8);
+        *reinterpret_cast<u32x4*>(rows + row * KS + dc * 8) = regs[i];
+        if (TRANSPOSE) {
+            const uint32_t w[4] = {regs[i].x, regs[i].y, regs[i].z, regs[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                tr[(dc * 8 + 2 * e) * AB_TS + row] = (uint16_t)(w[e] & 0xffffu);
+                tr[(dc * 8 + 2 * e + 1) * AB_TS + row] = (uint16_t)(w[e] >> 16);
+            }
+        }
+    }
+}
 // A fragment of a transposed tile for contraction step s2: row (d), slots (j) <-> tile index 16 s2 + (j & 3) + 8 (j >> 2) + 4 h
 __device__ __forceinline__ u32x4 ab_tfrag(const uint16_t* tr, int drow, int s2, int h) {
     const uint16_t* p = tr + drow * AB_TS + 16 * s2 + 4 * h;
@@ -105,31 +134,44 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_mfma_kernel(const uint16_t* q
         f32x16 st = ab_zero();
 #pragma unroll
         for (int s = 0; s < NS; s++) st = ab_mfma(*reinterpret_cast<const u32x4*>(ks + r * KS + 16 * s + 8 * h), qf[s], st);
+        // scores in log2 units (scale * log2 e folded in): M, l are the running maximum / sum of 2^(s - M)
         float sc[16], mt = -__builtin_inff();
+        const bool full = t * AB_T + AB_T - 1 <= tok0 + wave * 32;
+        const float c1 = scale * AB_LOG2E;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const int key = t * AB_T + 4 * h + (i & 3) + 8 * (i >> 2);
-            sc[i] = key <= tok ? st[i] * scale : -__builtin_inff();
+            sc[i] = st[i] * c1;
+            if (!full) sc[i] = key <= tok ? sc[i] : -__builtin_inff();
             mt = fmaxf(mt, sc[i]);
         }
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        if (mt > M) l *= __builtin_amdgcn_exp2f((M - mt) * AB_LOG2E), M = mt;
+        if (mt > M) l *= __builtin_amdgcn_exp2f(M - mt), M = mt;
 #pragma unroll
-        for (int i = 0; i < 16; i++) l += __builtin_amdgcn_exp2f((sc[i] - M) * AB_LOG2E);
+        for (int i = 0; i < 16; i++) l += __builtin_amdgcn_exp2f(sc[i] - M);
     }
     l += __shfl_xor(l, 32, 64);
-    const float L = M + __logf(l);
+    const float L = (M + __log2f(l)) * 0.693147182464599609375f; /* back to natural units: log-sum-exp of the scaled scores */
     if (col_ok && h == 0) Lbuf[(size_t)head * T + tok] = L, Dbuf[(size_t)head * T + tok] = D;
 
     // ---- pass B: dQ^T
     f32x16 acc[NDB];
 #pragma unroll
     for (int db = 0; db < NDB; db++) acc[db] = ab_zero();
+    constexpr int CPT = AB_T * HD / 8 / 256;
+    u32x4 kreg[CPT], vreg[CPT];
+    __syncthreads(); /* pass A's last readers of ks are done */
+    ab_load<HD>(k, ld_kv, hoff_kv, 0, T, kreg);
+    ab_load<HD>(v, ld_kv, hoff_kv, 0, T, vreg);
+    ab_store<HD, true>(kreg, ks, kt);
+    ab_store<HD, false>(vreg, vs, nullptr);
+    __syncthreads();
     for (int t = 0; t < ntile; t++) {
-        __syncthreads();
-        ab_stage<HD, true>(k, ld_kv, hoff_kv, t * AB_T, T, ks, kt);
-        ab_stage<HD, false>(v, ld_kv, hoff_kv, t * AB_T, T, vs, nullptr);
-        __syncthreads();
+        const bool more = t + 1 < ntile;
+        if (more) { /* the next tile's rows travel while this one is multiplied */
+            ab_load<HD>(k, ld_kv, hoff_kv, (t + 1) * AB_T, T, kreg);
+            ab_load<HD>(v, ld_kv, hoff_kv, (t + 1) * AB_T, T, vreg);
+        }
         f32x16 st = ab_zero(), dpt = ab_zero();
 #pragma unroll
         for (int s = 0; s < NS; s++) {
@@ -137,13 +179,16 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_mfma_kernel(const uint16_t* q
             dpt = ab_mfma(*reinterpret_cast<const u32x4*>(vs + r * KS + 16 * s + 8 * h), dof[s], dpt);
         }
         uint32_t dw[8];
+        const bool full = t * AB_T + AB_T - 1 <= tok0 + wave * 32; /* every key of the tile precedes every column of this wave: no mask */
+        const float c1 = scale * AB_LOG2E, L2 = L * AB_LOG2E;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             float ds[2];
 #pragma unroll
             for (int e = 0; e < 2; e++) {
                 const int ii = 2 * i + e, key = t * AB_T + 4 * h + (ii & 3) + 8 * (ii >> 2);
-                const float p = key <= tok ? __builtin_amdgcn_exp2f((st[ii] * scale - L) * AB_LOG2E) : 0.f;
+                float p = __builtin_amdgcn_exp2f(fmaf(st[ii], c1, -L2));
+                if (!full) p = key <= tok ? p : 0.f;
                 ds[e] = p * (dpt[ii] - D);
             }
             dw[i] = pack_bf16x2(ds[0], ds[1]);
@@ -154,6 +199,12 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_mfma_kernel(const uint16_t* q
 #pragma unroll
             for (int db = 0; db < NDB; db++) acc[db] = ab_mfma(ab_tfrag(kt, db * 32 + r, s2, h), B, acc[db]);
         }
+        __syncthreads(); /* everyone has read this tile */
+        if (more) {
+            ab_store<HD, true>(kreg, ks, kt);
+            ab_store<HD, false>(vreg, vs, nullptr);
+        }
+        __syncthreads();
     }
     if (!col_ok) return;
     uint16_t* out = dq + (size_t)tok * ld_d + hoff;
@@ -196,18 +247,32 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_mfma_kernel(const uint16_t* 
 #pragma unroll
     for (int db = 0; db < NDB; db++) dka[db] = ab_zero(), dva[db] = ab_zero();
     const int ntq = (T + AB_T - 1) / AB_T;
-    for (int tg = (key0 / AB_T) * gq; tg < ntq * gq; tg++) { /* (query tile, query head of the group) pairs */
+    constexpr int CPT = AB_T * HD / 8 / 256;
+    u32x4 qreg[CPT], oreg[CPT];
+    float lreg = 0.f, dreg = 0.f;
+    const int tg0 = (key0 / AB_T) * gq, tg1 = ntq * gq;
+    auto fetch = [&](int tg) { /* (query tile, query head of the group) pair tg: rows of Q and dO, L and D of the tile's queries */
         const int t = tg / gq, head = kvh * gq + (tg - t * gq);
-        const size_t hq = (size_t)head * HD;
-        __syncthreads();
-        ab_stage<HD, true>(q, ld_qkv, hq, t * AB_T, T, qs, qt);
-        ab_stage<HD, true>(dO, ld_o, hq, t * AB_T, T, os, ot);
+        ab_load<HD>(q, ld_qkv, (size_t)head * HD, t * AB_T, T, qreg);
+        ab_load<HD>(dO, ld_o, (size_t)head * HD, t * AB_T, T, oreg);
         if (tid < AB_T) {
             const int qi = t * AB_T + tid;
-            Ls[tid] = qi < T ? Lbuf[(size_t)head * T + qi] : 0.f, Ds[tid] = qi < T ? Dbuf[(size_t)head * T + qi] : 0.f;
+            lreg = qi < T ? Lbuf[(size_t)head * T + qi] * AB_LOG2E : 0.f, dreg = qi < T ? Dbuf[(size_t)head * T + qi] : 0.f;
         }
-        __syncthreads();
-        if (t * AB_T + AB_T - 1 < wave_key0) continue; /* every query of the tile precedes this wave's keys (barriers are at the loop top) */
+    };
+    auto put = [&]() {
+        ab_store<HD, true>(qreg, qs, qt);
+        ab_store<HD, true>(oreg, os, ot);
+        if (tid < AB_T) Ls[tid] = lreg, Ds[tid] = dreg;
+    };
+    if (tg0 < tg1) fetch(tg0);
+    put();
+    __syncthreads();
+    for (int tg = tg0; tg < tg1; tg++) {
+        const int t = tg / gq;
+        const bool more = tg + 1 < tg1;
+        if (more) fetch(tg + 1);
+        if (t * AB_T + AB_T - 1 >= wave_key0) { /* else: every query of the tile precedes this wave's keys */
         f32x16 st = ab_zero(), dpt = ab_zero();
 #pragma unroll
         for (int s = 0; s < NS; s++) {
@@ -215,6 +280,9 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_mfma_kernel(const uint16_t* 
             dpt = ab_mfma(*reinterpret_cast<const u32x4*>(os + r * KS + 16 * s + 8 * h), vf[s], dpt);
         }
         uint32_t pw[8], dw[8];
+        /* every query of the tile follows every key of this wave and lies inside the sequence: no mask */
+        const bool full = t * AB_T >= wave_key0 + 31 && t * AB_T + AB_T <= T && wave_key0 + 31 < T;
+        const float c1 = scale * AB_LOG2E;
 #pragma unroll
         for (int g = 0; g < 4; g++) { /* accumulator rows 8 g + 4 h + {0..3}: one 16-byte read of L and of D */
             const f32x4 Lq = *reinterpret_cast<const f32x4*>(Ls + 8 * g + 4 * h), Dq = *reinterpret_cast<const f32x4*>(Ds + 8 * g + 4 * h);
@@ -222,8 +290,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_mfma_kernel(const uint16_t* 
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const int qi = t * AB_T + 8 * g + 4 * h + e;
-                const bool valid = key_ok && qi < T && qi >= key;
-                p[e] = valid ? __builtin_amdgcn_exp2f((st[4 * g + e] * scale - Lq[e]) * AB_LOG2E) : 0.f;
+                p[e] = __builtin_amdgcn_exp2f(fmaf(st[4 * g + e], c1, -Lq[e])); /* Ls holds L * log2 e */
+                if (!full) p[e] = (key_ok && qi < T && qi >= key) ? p[e] : 0.f;
                 ds[e] = p[e] * (dpt[4 * g + e] - Dq[e]);
             }
             pw[2 * g] = pack_bf16x2(p[0], p[1]), pw[2 * g + 1] = pack_bf16x2(p[2], p[3]);
@@ -238,6 +306,10 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_mfma_kernel(const uint16_t* 
                 dka[db] = ab_mfma(ab_tfrag(qt, db * 32 + r, s2, h), BS, dka[db]);
             }
         }
+        } /* wave has work on this tile */
+        __syncthreads();
+        if (more) put();
+        __syncthreads();
     }
     if (!key_ok) return;
     uint16_t* okp = dk + (size_t)key * ld_dkv + hoff;
