@@ -61,7 +61,17 @@ typedef struct kf_weight {
      * qscales fp16 [ne1/128, ne0]; gama is unused.  Served by kf_linear and kf_dequant (which then writes [ne1, ne0], TransA = 0). */
     const void* qzeros;
     const void* qscales;
+    /* Quant card mode (QUANT_MODE, GeQuant.hpp).  0 = KF_QUANT_GROUP: everything above.  KF_QUANT_ROW_LUT: the row-codebook 4-bit storage of
+     * GeQuant::RT_NormalF / _row_lut (GeQuant.cpp:696-755; QUANT_MODE::RTNf "NF4" and the generic LUT mode share it): type = KF_Q4,
+     * data = the nibble stream BIT_SET_k writes (CLI_params.cpp:2177-2190: element i of the row-major matrix in byte i/2, even i in the HIGH nibble),
+     * gama = bf16 [R_SCALE ne0][C_SCALE ne1][LUT ne0 x 16] (GTensor.cpp:456-510 with the LUT at +ne0+ne1); a weight is lut[row][nibble]
+     * (CU_Q42X_NF4 / CU_Q42X_lut, quantizer.cu:583-652, rc_normal = 0 as LowBit_worker's only sweep entry leaves it, GeQuant.cpp:844).
+     * lGroup / nGroup / qMin / qMax / qBias are not used.  ne1 must be a multiple of 32. */
+    int32_t quant;
+    int32_t reserved_;
 } kf_weight;
+#define KF_QUANT_GROUP 0
+#define KF_QUANT_ROW_LUT 1
 
 /* kf_linear epilogue flags */
 #define KF_EPI_NONE 0u

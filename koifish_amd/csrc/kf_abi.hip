@@ -288,6 +288,13 @@ static int check_weight(const kf_weight* w, const char* who) {
             return fail(KF_QUANT_ERR, "%s: malformed AWQ weight (%d x %d, group %d)", who, w->ne0, w->ne1, w->lGroup);
         return KF_OK;
     }
+    if (w->quant == KF_QUANT_ROW_LUT) { /* row-codebook 4-bit storage (GeQuant::RT_NormalF): nibble stream + 16 table entries per row */
+        if (w->type != KF_Q4 || !w->gama) return fail(KF_QUANT_ERR, "%s: malformed row-LUT weight (type %d)", who, w->type);
+        if (w->ne1 % 32) return fail(KF_BLAS_UNALIGN, "%s: row-LUT rows of %d weights are not 16-byte aligned", who, w->ne1);
+        if (!al16(w->gama + w->ne0 + w->ne1)) return fail(KF_BLAS_UNALIGN, "%s: row-LUT tables not 16-byte aligned (ne0 = %d must be a multiple of 8)", who, w->ne0);
+        return KF_OK;
+    }
+    if (w->quant != KF_QUANT_GROUP) return fail(KF_UNSUPPORTED_DATATYPE, "%s: unknown quant mode %d", who, w->quant);
     switch (w->type) {
         case KF_BF16: case KF_F8E5M2: break;
         case KF_Q4: case KF_T_SIGN: case KF_BOOL1: case KF_T_BINARY:
@@ -358,6 +365,19 @@ int kf_linear(kf_ctx* c, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const
     if (gemm_min < 0) {
         const char* e = getenv("KF_GEMM_MIN");
         gemm_min = e ? atoi(e) : 8;
+    }
+    if (nTok >= gemm_min && w->quant == KF_QUANT_ROW_LUT && !(c->capturing && (size_t)w->ne0 * w->ne1 * 2 > c->wd_ws_bytes)) {
+        // row-codebook storage with a token batch: the reference's own order -- GetDataX into the scratch, then the bf16 product (the tile kernel on
+        // the dequantised copy).  Mat-vecs (below) read the nibble stream directly.
+        const uint16_t* Wd = nullptr;
+        r = lib_weight_bf16(c, w, &Wd);
+        if (r != KF_OK) return fail(r, "kf_linear (row-LUT dequant) failed with %d", r);
+        kf_weight wb;
+        memset(&wb, 0, sizeof(wb));
+        wb.data = Wd, wb.type = KF_BF16, wb.ne0 = w->ne0, wb.ne1 = w->ne1;
+        const int rc = kf::gemm_launch(c->stream, &wb, x, w->ne1, nTok, y, w->ne0, bias, alpha, beta, (epilogue & KF_EPI_RESIDUAL) ? residual : nullptr, w->ne0);
+        if (rc < 0) return fail(rc, "kf_linear (row-LUT token-batch GEMM) failed with %d", rc);
+        if (rc == KF_OK) return KF_OK;
     }
     if (nTok >= gemm_min) {
         const int rc = kf::gemm_launch(c->stream, w, x, w->ne1, nTok, y, w->ne0, bias, alpha, beta, (epilogue & KF_EPI_RESIDUAL) ? residual : nullptr, w->ne0);

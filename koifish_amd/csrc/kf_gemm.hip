@@ -470,7 +470,7 @@ struct GmWeight {
 // 0 ok, 1 not eligible for the tile kernels, < 0 error
 static int gm_weight(const kf_weight* w, GmWeight& o) {
     o.fmt = gm_fmt_of(w->type);
-    if (o.fmt < 0 || w->qzeros || w->qscales) return 1;
+    if (o.fmt < 0 || w->qzeros || w->qscales || is_row_lut(w)) return 1; /* row-codebook storage: the caller dequantises first */
     o.M = w->ne0, o.K = w->ne1;
     // K a multiple of 128 for every kernel; a multiple of 64 is enough for the direct kernel on the formats whose 64-element unit is made of
     // whole blocks (bf16, f8, 4-bit) -- GPT-2's n_embd = 1600

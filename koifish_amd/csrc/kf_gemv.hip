@@ -126,6 +126,30 @@ struct BlockDot<FMT_Q4P> {
     }
 };
 
+// 4-bit row codebook (KF_QUANT_ROW_LUT; CU_Q42X_NF4 / CU_Q42X_lut, quantizer.cu:583-652): the row's nibbles as BIT_SET_k streams them
+// (element 2b in the high nibble of byte b), a weight = lut[row][nibble].  The 16 bf16 entries sit in two 16-byte words per row; they
+// become the byte planes of the register lookup above, and a byte swap turns a stream dword into the Packed128 nibble order it expects.
+template <>
+struct BlockDot<FMT_Q4R> {
+    static constexpr int EPB = 32, XCH = 4;
+    static constexpr bool HAS_GAMA = false;
+    __device__ static __forceinline__ float run(u32x4, const u32x4*, int, int, float, float, float, float acc) { return acc; }
+    __device__ static __forceinline__ float run_lut(u32x4 w, const u32x4* xs, int col, int nBlk, u32x4 ta, u32x4 tb, float acc) {
+        const uint32_t P[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+        PermLut t;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            t.tl[k] = __builtin_amdgcn_perm(P[2 * k + 1], P[2 * k], 0x06040200u);
+            t.th[k] = __builtin_amdgcn_perm(P[2 * k + 1], P[2 * k], 0x07050301u);
+        }
+        acc = perm_dot_dword(__builtin_amdgcn_perm(0u, w.x, 0x00010203u), xs[col], t, acc);
+        acc = perm_dot_dword(__builtin_amdgcn_perm(0u, w.y, 0x00010203u), xs[nBlk + col], t, acc);
+        acc = perm_dot_dword(__builtin_amdgcn_perm(0u, w.z, 0x00010203u), xs[2 * nBlk + col], t, acc);
+        acc = perm_dot_dword(__builtin_amdgcn_perm(0u, w.w, 0x00010203u), xs[3 * nBlk + col], t, acc);
+        return acc;
+    }
+};
+
 // 2-bit (T_SIGN ternary / generic CU_Q128toX_<T,64>): element i < 32 at high >> (62-2i) (PackedQ.hpp:185-226):
 // dword3 -> elements 0..15 (element 0 in bits 30..31), dword2 -> 16..31, dword1 -> 32..47, dword0 -> 48..63.
 __device__ __forceinline__ float dot_q2_dword(uint32_t D, u32x4 Xa, u32x4 Xb, float step, float nb, float zero, float acc) {
@@ -199,10 +223,12 @@ __device__ __forceinline__ float group_sum(float v, int lg) {
     return v;
 }
 
-template <int G, bool PAIRED>
+template <int G, bool PAIRED, bool LUT>
 struct Batch {
     u32x4 w[G];
     u32x4 w2[PAIRED ? G : 1];
+    u32x4 ta[LUT ? G : 1], tb[LUT ? G : 1];                       /* row codebook (FMT_Q4R) */
+    u32x4 ta2[LUT && PAIRED ? G : 1], tb2[LUT && PAIRED ? G : 1];
     // zero / step stay raw bf16 bits until the block is multiplied: converted when loaded, the shift makes the wave wait for the loads it has
     // just issued (s_waitcnt vmcnt right behind the prefetch) instead of overlapping them with the current batch's arithmetic
     uint16_t st[G], ze[G];
@@ -215,7 +241,7 @@ struct Batch {
 template <int FMT, int G, int MODE>
 __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     using BD = BlockDot<FMT>;
-    constexpr bool PAIRED = (MODE == GEMV_PAIRED);
+    constexpr bool PAIRED = (MODE == GEMV_PAIRED), LUT = (FMT == FMT_Q4R), XPERM = (FMT == FMT_Q4P || FMT == FMT_Q4R);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);
     double* red = reinterpret_cast<double*>(smem_raw + (size_t)a.K * 2);
@@ -260,7 +286,7 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     // wait for x, which is requested FIRST so that its staging overlaps the weights' HBM latency.  Long launches (G > 1) are bound by
     // the dequant arithmetic and hide latency with resident waves: they keep the masked loads (no per-step mask arithmetic).
     constexpr bool LAT = (G == 1);
-    auto load = [&](int bi, int it, Batch<G, PAIRED>& b) {
+    auto load = [&](int bi, int it, Batch<G, PAIRED, LUT>& b) {
         const long s0 = s_begin + (long)bi * G;
         int col = it * LPR + ll;
         const bool col_ok = col < nBlk;
@@ -276,6 +302,10 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
                 b.w[g] = u32x4{0, 0, 0, 0};
                 b.st[g] = b.ze[g] = 0;
                 if (PAIRED) b.w2[g] = u32x4{0, 0, 0, 0}, b.st2[g] = b.ze2[g] = 0;
+                if constexpr (LUT) {
+                    b.ta[g] = b.tb[g] = u32x4{0, 0, 0, 0};
+                    if constexpr (PAIRED) b.ta2[g] = b.tb2[g] = u32x4{0, 0, 0, 0};
+                }
             }
             if (LAT || ok) {
                 const uint32_t bidx = (uint32_t)row * (uint32_t)nBlk + (uint32_t)col; /* < 2^32 blocks = 64 GiB per tensor */
@@ -285,6 +315,14 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
                     const uint32_t gi = bidx >> gshift; /* group = element / lGroup, lGroup / EPB a power of two */
                     b.st[g] = jstep[gi], b.ze[g] = jzero[gi];
                     if (PAIRED) b.st2[g] = a.job[1].step[gi], b.ze2[g] = a.job[1].zero[gi];
+                }
+                if constexpr (LUT) { /* job.zero carries the table base: 16 bf16 per row */
+                    const u32x4* lt = reinterpret_cast<const u32x4*>(jzero) + 2 * (size_t)row;
+                    b.ta[g] = lt[0], b.tb[g] = lt[1];
+                    if constexpr (PAIRED) {
+                        const u32x4* lt2 = reinterpret_cast<const u32x4*>(a.job[1].zero) + 2 * (size_t)row;
+                        b.ta2[g] = lt2[0], b.tb2[g] = lt2[1];
+                    }
                 }
             }
         }
@@ -301,7 +339,7 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
         if (has_norm) n0 = *reinterpret_cast<const u32x4*>(a.norm_w + c0 * 8), n1 = *reinterpret_cast<const u32x4*>(a.norm_w + c1 * 8);
     }
 
-    Batch<G, PAIRED> cur, nxt;
+    Batch<G, PAIRED, LUT> cur, nxt;
     if (LAT || nsteps > 0) load(0, 0, cur); /* LAT: waves without work re-read row 0 */
     const int pos = a.d_pos ? *a.d_pos : a.pos;
 
@@ -336,11 +374,11 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
             }
             if (h0) {
                 const int c = tid / XCH, j = tid - c * XCH;
-                xs[j * nBlk + c] = FMT == FMT_Q4P ? perm_x_order(u32x4{ow[0], ow[1], ow[2], ow[3]}) : u32x4{ow[0], ow[1], ow[2], ow[3]};
+                xs[j * nBlk + c] = XPERM ? perm_x_order(u32x4{ow[0], ow[1], ow[2], ow[3]}) : u32x4{ow[0], ow[1], ow[2], ow[3]};
             }
             if (h1) {
                 const int e8 = tid + 256, c = e8 / XCH, j = e8 - c * XCH;
-                xs[j * nBlk + c] = FMT == FMT_Q4P ? perm_x_order(u32x4{ow[4], ow[5], ow[6], ow[7]}) : u32x4{ow[4], ow[5], ow[6], ow[7]};
+                xs[j * nBlk + c] = XPERM ? perm_x_order(u32x4{ow[4], ow[5], ow[6], ow[7]}) : u32x4{ow[4], ow[5], ow[6], ow[7]};
             }
         } else {
             float mul = 1.0f;
@@ -365,7 +403,7 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
                     }
                     o.x = ow[0], o.y = ow[1], o.z = ow[2], o.w = ow[3];
                 }
-                xs[j * nBlk + c] = FMT == FMT_Q4P ? perm_x_order(o) : o;
+                xs[j * nBlk + c] = XPERM ? perm_x_order(o) : o;
             }
         }
         __syncthreads();
@@ -397,13 +435,22 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
             for (int g = 0; g < G; g++) {
                 int row;
                 const bool ok = !LAT || (slot(s_begin + (long)bi * G + g, row) && col_ok); /* masked loads carry zero weights */
-                const float st = bf2f(cur.st[g]);
-                const float r = BD::run(cur.w[g], xs, col, nBlk, st, bf2f(cur.ze[g]), -(jqb * st), acc[g]);
-                acc[g] = ok ? r : acc[g];
-                if (PAIRED) {
-                    const float st2 = bf2f(cur.st2[g]);
-                    const float r2 = BD::run(cur.w2[g], xs, col, nBlk, st2, bf2f(cur.ze2[g]), -(jqb2 * st2), acc2[g]);
-                    acc2[g] = ok ? r2 : acc2[g];
+                if constexpr (LUT) {
+                    const float r = BD::run_lut(cur.w[g], xs, col, nBlk, cur.ta[g], cur.tb[g], acc[g]);
+                    acc[g] = ok ? r : acc[g];
+                    if constexpr (PAIRED) {
+                        const float r2 = BD::run_lut(cur.w2[g], xs, col, nBlk, cur.ta2[g], cur.tb2[g], acc2[g]);
+                        acc2[g] = ok ? r2 : acc2[g];
+                    }
+                } else {
+                    const float st = bf2f(cur.st[g]);
+                    const float r = BD::run(cur.w[g], xs, col, nBlk, st, bf2f(cur.ze[g]), -(jqb * st), acc[g]);
+                    acc[g] = ok ? r : acc[g];
+                    if (PAIRED) {
+                        const float st2 = bf2f(cur.st2[g]);
+                        const float r2 = BD::run(cur.w2[g], xs, col, nBlk, st2, bf2f(cur.ze2[g]), -(jqb2 * st2), acc2[g]);
+                        acc2[g] = ok ? r2 : acc2[g];
+                    }
                 }
             }
         }
@@ -513,11 +560,15 @@ static int fmt_of(int type) {
         default: return -1;
     }
 }
+static int fmt_of_w(const kf_weight* w) {
+    if (is_row_lut(w)) return w->type == KF_Q4 ? FMT_Q4R : -1;
+    return fmt_of(w->type);
+}
 static int epb_of(int fmt) {
     switch (fmt) {
         case FMT_BF16: return 8;
         case FMT_F8: return 16;
-        case FMT_Q4: return 32;
+        case FMT_Q4: case FMT_Q4R: return 32;
         case FMT_Q2: return 64;
         default: return 128;
     }
@@ -545,7 +596,7 @@ static void launch_m(const GemvArgs& a, int mode, int G, dim3 grid, size_t smem,
 int gemv_launch(hipStream_t st, GemvLaunch& L) {
     GemvArgs& a = L.args;
     const kf_weight* w0 = L.w[0];
-    const int fmt = fmt_of(w0->type);
+    const int fmt = fmt_of_w(w0);
     if (fmt < 0) return KF_UNSUPPORTED_DATATYPE;
     const int K = w0->ne1, epb = epb_of(fmt);
     if (K % epb != 0 || K % 8 != 0) return KF_INVALID_ARGS;
@@ -581,14 +632,18 @@ int gemv_launch(hipStream_t st, GemvLaunch& L) {
     long rows_slots[3] = {0, 0, 0}, raw_slots = 0;
     for (int j = 0; j < L.n; j++) {
         const kf_weight* w = L.w[j];
-        if (fmt_of(w->type) != fmt || w->ne1 != K) return KF_INVALID_ARGS;
+        if (fmt_of_w(w) != fmt || w->ne1 != K) return KF_INVALID_ARGS;
         if (w->qzeros || w->qscales) return KF_UNSUPPORTED_DATATYPE; /* AutoAWQ layout: kf_linear only */
         if (((uintptr_t)w->data & 15) != 0) return KF_BLAS_UNALIGN;
         if ((unsigned long long)w->ne0 * (unsigned long long)nBlk >= (1ull << 32)) return KF_INVALID_ARGS;
         GemvJob& jb = a.job[j];
         jb.w = w->data;
         jb.zero = jb.step = nullptr;
-        if (fmt >= FMT_Q4) {
+        if (fmt == FMT_Q4R) {
+            if (!w->gama) return KF_QUANT_ERR;
+            jb.zero = w->gama + w->ne0 + w->ne1; /* gama_T(LUT): 16 entries per row behind the row / column scales */
+            if (((uintptr_t)jb.zero & 15) != 0) return KF_BLAS_UNALIGN;
+        } else if (fmt >= FMT_Q4) {
             if (!w->gama || w->lGroup <= 0 || (w->lGroup % epb) != 0 || ((long)w->ne0 * w->ne1) % w->lGroup != 0) return KF_QUANT_ERR;
             jb.zero = w->gama + w->ne0 + w->ne1; /* gama_T(ZERO), GTensor.cpp:456-510 */
             jb.step = jb.zero + (size_t)w->ne0 * w->ne1 / w->lGroup;
@@ -651,6 +706,7 @@ int gemv_launch(hipStream_t st, GemvLaunch& L) {
             break;
         }
         case FMT_Q2: launch_m<FMT_Q2>(a, L.mode, G, grid, smem, st); break;
+        case FMT_Q4R: launch_m<FMT_Q4R>(a, L.mode, G, grid, smem, st); break;
         default: launch_m<FMT_Q1>(a, L.mode, G, grid, smem, st); break;
     }
     L.blocks = blocks;

@@ -5,7 +5,12 @@
 
 namespace kf {
 
-enum { FMT_BF16 = 0, FMT_F8 = 1, FMT_Q4 = 2, FMT_Q2 = 3, FMT_Q1 = 4, FMT_Q4P = 5 /* 4-bit through the register-table lookup (mat-vec only) */ };
+enum {
+    FMT_BF16 = 0, FMT_F8 = 1, FMT_Q4 = 2, FMT_Q2 = 3, FMT_Q1 = 4,
+    FMT_Q4P = 5, /* 4-bit through the register-table lookup (mat-vec only) */
+    FMT_Q4R = 6  /* 4-bit row codebook (KF_QUANT_ROW_LUT): byte-packed nibbles + 16 bf16 table entries per row */
+};
+inline bool is_row_lut(const kf_weight* w) { return w->quant == KF_QUANT_ROW_LUT; }
 enum { GEMV_PLAIN = 0, GEMV_PAIRED = 1, GEMV_ARGMAX = 2 };
 constexpr int KF_MAX_ARGMAX_PARTIALS = 4096;
 constexpr int KF_ATTN_MAX_SPLITS = 32;
@@ -125,6 +130,10 @@ int adamw_launch(hipStream_t st, uint16_t* params, uint16_t* grads, void* gm, vo
 int sample_launch(hipStream_t st, const uint16_t* logits, int n, int top_k, float temperature, float top_p, unsigned long long* rng, int32_t* d_token,
                   int32_t* d_state, int32_t* d_tokens_out, const int32_t* d_forced, int n_forced, int true_topk = 0);
 int quantize_launch(hipStream_t st, const kf_weight* w, const uint16_t* src, int symmetric);
+// row-codebook 4-bit storage (kf_lut.hip): NF4 quantiser, dequant, embedding rows
+int lut_quantize_launch(hipStream_t st, const kf_weight* w, const uint16_t* src);
+int lut_dequant_launch(hipStream_t st, const kf_weight* w, uint16_t* out);
+int lut_embed_launch(hipStream_t st, const kf_weight* w, int token, const int32_t* d_token, const int32_t* d_state, const int32_t* d_forced, uint16_t* out, int n_tok);
 // ---- AutoAWQ layout (kf_awq.hip)
 size_t awq_scratch_bytes(const kf_weight* w);
 int awq_linear_launch(hipStream_t st, const kf_weight* w, const uint16_t* x, uint16_t* y, const uint16_t* bias, float alpha, float beta,

@@ -376,6 +376,7 @@ __global__ void dequant_kernel(int fmt, int epb, const u32x4* __restrict__ data,
     dequant_block(fmt, data[gb], st, ze, qBias, out + b * epb);
 }
 int dequant_launch(hipStream_t st, const kf_weight* w, uint16_t* out) {
+    if (is_row_lut(w)) return lut_dequant_launch(st, w, out);
     int epb;
     const int fmt = fmt_of(w->type, &epb);
     if (fmt < 0) return KF_UNSUPPORTED_DATATYPE;
@@ -421,6 +422,7 @@ __global__ void embed_kernel(int fmt, int epb, const u32x4* __restrict__ data, c
 }
 int embed_launch(hipStream_t st, const kf_weight* w, int token, const int32_t* d_token, const int32_t* d_state, const int32_t* d_forced, uint16_t* out,
                  int n_tok) {
+    if (is_row_lut(w)) return lut_embed_launch(st, w, token, d_token, d_state, d_forced, out, n_tok);
     int epb;
     const int fmt = fmt_of(w->type, &epb);
     if (fmt < 0) return KF_UNSUPPORTED_DATATYPE;
@@ -716,6 +718,7 @@ __global__ void to_f8e5m2_kernel(const uint16_t* __restrict__ src, unsigned char
 }
 
 int quantize_launch(hipStream_t st, const kf_weight* w, const uint16_t* src, int symmetric) {
+    if (is_row_lut(w)) return lut_quantize_launch(st, w, src);
     if (w->type == KF_F8E5M2) {
         const size_t n = (size_t)w->ne0 * w->ne1;
         hipLaunchKernelGGL(to_f8e5m2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, (unsigned char*)const_cast<void*>(w->data), n);

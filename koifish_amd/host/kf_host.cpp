@@ -21,6 +21,7 @@ kf_weight GTensor::desc() const {
     w.lGroup = quant.T_group;
     w.nGroup = nGroup();
     w.qMin = quant.qMin, w.qMax = quant.qMax, w.qBias = quant.qBias;
+    if (quant.isNormalFloat) w.quant = KF_QUANT_ROW_LUT, w.nGroup = 0, w.lGroup = 0;
     if (qZero && qScale) w.qzeros = qZero->data, w.qscales = qScale->data, w.nGroup = (int)(size() / 128), w.gama = nullptr;
     return w;
 }
@@ -484,13 +485,24 @@ static SLP* slot_of(Fish* f, int layer, int slot) {
 
 // slot: 0 q,1 k,2 v,3 o,4 gate,5 up,6 down (layer >= 0); layer = -1: slot 0 embed_tokens, 1 lm_head.
 // Either a host blob (`data||gama`, copied to a fresh device allocation) or an existing device pointer.
+static int set_weight_impl(void* h, int layer, int slot, int type, int ne0, int ne1, const void* blob, size_t blob_bytes, size_t szData, int is_device, int lGroup,
+                           int qMin, int qMax, int qBias, bool normal_float);
 int kfh_set_weight(void* h, int layer, int slot, int type, int ne0, int ne1, const void* blob, size_t blob_bytes, size_t szData, int is_device, int lGroup,
                    int qMin, int qMax, int qBias) {
+    return set_weight_impl(h, layer, slot, type, ne0, ne1, blob, blob_bytes, szData, is_device, lGroup, qMin, qMax, qBias, false);
+}
+// the same for a tensor whose quant card says isNormalFloat (QUANT_MODE::RTNf): Q4 nibble stream || gama with a 16-entry table per row
+int kfh_set_weight_lut(void* h, int layer, int slot, int ne0, int ne1, const void* blob, size_t blob_bytes, size_t szData, int is_device) {
+    return set_weight_impl(h, layer, slot, (int)typNUMBER::Q4, ne0, ne1, blob, blob_bytes, szData, is_device, 0, 0, 15, 0, true);
+}
+static int set_weight_impl(void* h, int layer, int slot, int type, int ne0, int ne1, const void* blob, size_t blob_bytes, size_t szData, int is_device, int lGroup,
+                           int qMin, int qMax, int qBias, bool normal_float) {
     Fish* f = reinterpret_cast<Fish*>(h);
     auto t = std::make_shared<GTensor>();
     t->type = (typNUMBER)type, t->ne[0] = ne0, t->ne[1] = ne1;
     t->szData = szData, t->szGama = blob_bytes - szData;
     t->quant.T_group = lGroup, t->quant.qMin = qMin, t->quant.qMax = qMax, t->quant.qBias = qBias;
+    t->quant.isNormalFloat = normal_float;
     if (is_device) {
         t->data = const_cast<void*>(blob), t->ctx = f->ctx, t->owned = false;
     } else {

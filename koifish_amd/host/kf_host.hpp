@@ -36,6 +36,7 @@ struct Fish;
 // Quant card fields that cross the kernel seam (QUANT_CARD / GeQuant, GeQuant.cpp:107-124)
 struct QuantCard {
     int bits = 16, T_group = 128, qMin = 0, qMax = 0, qBias = 0;
+    bool isNormalFloat = false;  // QUANT_MODE::RTNf (GeQuant.cpp:853): row-codebook storage -> kf_weight.quant = KF_QUANT_ROW_LUT
 };
 
 // A device tensor: `data||gama` in one allocation, as huTensor::Alloc lays it out (GTensor.cpp:456-510).
@@ -52,7 +53,7 @@ struct GTensor {
 
     ~GTensor();
     size_t size() const { return (size_t)ne[0] * ne[1] * ne[2] * ne[3]; }
-    int nGroup() const { return szGama ? (int)(size() / quant.T_group) : 0; }
+    int nGroup() const { return (szGama && quant.T_group > 0) ? (int)(size() / quant.T_group) : 0; }
     floatX* gama_T() const { return szGama ? reinterpret_cast<floatX*>(reinterpret_cast<uint8_t*>(data) + szData) : nullptr; }
     kf_weight desc() const;  // what TASKA_quant / TASKA_AxB hand to the kernels
     // SerialGamaData H2D (huTensor.cu:413-458): allocate and copy a host `data||gama` blob

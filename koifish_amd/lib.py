@@ -10,6 +10,8 @@ LIB_HOST = os.path.join(HERE, "libkf_host.so")
 F32, F64, F16, BF16, F8E5M2, F8E4M3, U8, I8, U16, I16, U32, I32, U64, I64, Q4, Q3, Q2, T_SIGN, T_SEQ, BOOL1, T_BINARY, T_BINARY_3, T_BINARY_TILE = range(23)
 BITS = {BF16: 16, F8E5M2: 8, Q4: 4, T_SIGN: 2, BOOL1: 1, T_BINARY: 1}
 KF_EPI_RESIDUAL = 1
+QUANT_GROUP, QUANT_ROW_LUT = 0, 1  # kf_weight.quant
+NF4 = 1000  # not a typNUMBER: "Q4 with the normal-float quant card" (QUANT_MODE::RTNf) for the helpers that take a storage type
 
 # every symbol include/kf_abi.h declares (tests/test_abi_symbols.py checks the header against this list and the .so)
 ABI_SYMBOLS = [
@@ -28,7 +30,7 @@ class KFError(RuntimeError):
 class Weight(C.Structure):
     """struct kf_weight (include/kf_abi.h)"""
     _fields_ = [("data", C.c_void_p), ("gama", C.c_void_p), ("type", C.c_int32), ("ne0", C.c_int32), ("ne1", C.c_int32), ("nGroup", C.c_int32),
-                ("lGroup", C.c_int32), ("qMin", C.c_int32), ("qMax", C.c_int32), ("qBias", C.c_int32), ("qzeros", C.c_void_p), ("qscales", C.c_void_p)]
+                ("lGroup", C.c_int32), ("qMin", C.c_int32), ("qMax", C.c_int32), ("qBias", C.c_int32), ("qzeros", C.c_void_p), ("qscales", C.c_void_p), ("quant", C.c_int32), ("reserved_", C.c_int32)]
 
 
 _libs = None
@@ -103,6 +105,7 @@ def load():
         host.kfh_set_fuse_level.argtypes = [C.c_void_p, C.c_int]
         host.kfh_set_weight.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int]
+        host.kfh_set_weight_lut.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
         host.kfh_tie_head.argtypes = [C.c_void_p]
         host.kfh_set_norm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
         host.kfh_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]

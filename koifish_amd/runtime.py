@@ -62,6 +62,32 @@ class DevWeight:
         return g[z0:z0 + self.nGroup], g[z0 + self.nGroup:z0 + 2 * self.nGroup]
 
 
+class LutDevWeight:
+    """Row-codebook 4-bit weight in HBM (KF_QUANT_ROW_LUT; GeQuant::RT_NormalF): blob = nibble stream [ne0*ne1/2] ‖ bf16 gama [ne0 + ne1 + 16*ne0]."""
+
+    def __init__(self, ne0, ne1, blob):
+        self.type, self.ne0, self.ne1, self.blob, self.lGroup = L.Q4, ne0, ne1, blob, 0
+        self.szData = ne0 * ne1 // 2
+        self.szGama = (ne0 + ne1 + 16 * ne0) * 2
+        assert blob.numel() == self.szData + self.szGama, (blob.numel(), self.szData, self.szGama)
+
+    @staticmethod
+    def blob_bytes(ne0, ne1):
+        return ne0 * ne1 // 2 + (ne0 + ne1 + 16 * ne0) * 2
+
+    def desc(self):
+        p = self.blob.data_ptr()
+        return L.Weight(p, p + self.szData, L.Q4, self.ne0, self.ne1, 0, 0, 0, 15, 0, None, None, L.QUANT_ROW_LUT, 0)
+
+    def algorithmic_bytes(self):
+        """what a mat-vec has to read: the nibble stream + the rows' tables"""
+        return self.szData + 32 * self.ne0
+
+    def lut(self):
+        g = self.blob[self.szData:].view(torch.bfloat16)
+        return g[self.ne0 + self.ne1:].view(self.ne0, 16)
+
+
 class AWQDevWeight:
     """Vendor AutoAWQ tensors in HBM: qweight int32 [in, out/8], qzeros int32 [in/128, out/8], scales fp16 [in/128, out]."""
 
@@ -130,6 +156,8 @@ class Context:
 
     def quantize(self, w_bf16, type_, lGroup=128, symmetric=False):
         """w_bf16: torch.bfloat16 [ne0, ne1] on the GPU -> DevWeight (kf_quantize: GeQuant::RTN_x / YinYang on device)."""
+        if type_ == L.NF4:
+            return self.quantize_nf4(w_bf16)
         ne0, ne1 = w_bf16.shape
         w_bf16 = w_bf16.contiguous()
         if type_ == L.BF16:
@@ -145,6 +173,21 @@ class Context:
         g[:ne0 + ne1] = 1.0  # R_SCALE / C_SCALE (unused: rc_normal = 0)
         d = dw.desc()
         L.check(self.hip.kf_quantize(self.h, C.byref(d), _ptr(w_bf16), int(symmetric)), "kf_quantize")
+        return dw
+
+    def upload_lut_blob(self, ne0, ne1, blob_np):
+        t = torch.from_numpy(np.ascontiguousarray(blob_np).view(np.uint8).reshape(-1).copy()).to(self.device)
+        return LutDevWeight(ne0, ne1, t)
+
+    def quantize_nf4(self, w_bf16):
+        """w_bf16: torch.bfloat16 [ne0, ne1] on the GPU -> LutDevWeight (kf_quantize in KF_QUANT_ROW_LUT mode: GeQuant::RT_NormalF on device)."""
+        ne0, ne1 = w_bf16.shape
+        w_bf16 = w_bf16.contiguous()
+        blob = torch.zeros(LutDevWeight.blob_bytes(ne0, ne1), dtype=torch.uint8, device=self.device)
+        dw = LutDevWeight(ne0, ne1, blob)
+        blob[dw.szData:].view(torch.bfloat16)[:ne0 + ne1] = 1.0  # R_SCALE / C_SCALE (unused: rc_normal = 0)
+        d = dw.desc()
+        L.check(self.hip.kf_quantize(self.h, C.byref(d), _ptr(w_bf16), 0), "kf_quantize")
         return dw
 
     # ---- operators (each one ABI call)
@@ -313,6 +356,10 @@ class Qwen3:
         """w: DevWeight (already in HBM)."""
         self._keep.append(w)
         self.weights[(layer, slot)] = w
+        if isinstance(w, LutDevWeight):
+            L.check(self.host.kfh_set_weight_lut(self.h, layer, slot, w.ne0, w.ne1, C.c_void_p(w.blob.data_ptr()), C.c_size_t(w.blob.numel()), C.c_size_t(w.szData), 1),
+                    "kfh_set_weight_lut")
+            return
         L.check(self.host.kfh_set_weight(self.h, layer, slot, w.type, w.ne0, w.ne1, C.c_void_p(w.blob.data_ptr()), w.blob.numel(), w.szData, 1, w.lGroup,
                                          w.qMin, w.qMax, w.qBias), "kfh_set_weight")
 

@@ -40,7 +40,9 @@ enum {
     KFO_U32, KFO_I32, KFO_U64, KFO_I64, KFO_Q4, KFO_Q3, KFO_Q2, KFO_T_SIGN, KFO_T_SEQ, KFO_BOOL1,
     KFO_T_BINARY, KFO_T_BINARY_3, KFO_T_BINARY_TILE,
     /* oracle-internal tag (not a typNUMBER): a Q4 tensor in the vendor AutoAWQ GEMM layout, see section 3b */
-    KFO_Q4_AWQ = 100
+    KFO_Q4_AWQ = 100,
+    /* oracle-internal tag: a Q4 tensor in the row-codebook storage of GeQuant::RT_NormalF (QUANT_MODE::RTNf / LUT), see section 3c */
+    KFO_Q4_LUT = 101
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -326,6 +328,62 @@ KFO_API void kfo_bf16_to_f8e5m2(const uint16_t* src, size_t n, uint8_t* dst) {
 KFO_API float kfo_expf_export(float x) { return kfo_expf(x); }
 
 /* ------------------------------------------------------------------------------------------------
+ * 3c. Row-codebook 4-bit storage -- GeQuant::RT_NormalF / _row_lut (src/Tensor/GeQuant.cpp:696-755), Distri_PIPE::Next / Prepare /
+ *     X2NormalF (GTensor.hpp:141-148, GeQuant.cpp:641-694), unpacked on the device by CU_Q42X_NF4 / CU_Q42X_lut
+ *     (kernel/quantizer.cu:583-652) and CU_embed_forw_q4 / _nf4 (kernel/embed.cuh:54-121).
+ *     Per ROW (params.norm = NO_NORMAL: the only entry of LowBit_worker's sweep, GeQuant.cpp:844, so sR = sC = 1, rc_normal = 0):
+ *       abs_max = max(|vmin|, |vmax|) over the row's fp32 values;  scale = abs_max > 0 ? (float)(1.0f / (double)abs_max) : 1
+ *       (Prepare's `scale = 1.0f / abs_max` with abs_max a double member);  codebook[i] = table[i] / scale  (fp32 division);
+ *       stored table gama_[i] = bf16(codebook[i]);  element -> the FIRST index of minimal |a - codebook[i]| (strict <, fp32 codebook);
+ *       nibbles streamed by BIT_SET_k(quanti, i, qid, 4): element i in byte i/2, even i in the high nibble.
+ *     Dequant: lut[id] * sR with bf16 operators and sR = bf16(1) -> the table entry itself.
+ *     Pinned by the reference's own literals: NF4_LUT::table / NF3_LUT::table (src/g_float.hpp:543-569) and BIT_SET_k / BIT_GET_k.
+ * ---------------------------------------------------------------------------------------------- */
+static const float KFO_NF4[16] = {-1.0f, -0.6961928009986877f, -0.5250730514526367f, -0.39491748809814453f, -0.28444138169288635f, -0.18477343022823334f,
+                                  -0.09105003625154495f, 0.0f, 0.07958029955625534f, 0.16093020141124725f, 0.24611230194568634f, 0.33791524171829224f,
+                                  0.44070982933044434f, 0.5626170039176941f, 0.7229568362236023f, 1.0f};
+static const float KFO_NF3[8] = {-1.0f, -0.5350227355957031f, -0.2469314038753510f, 0.0f, 0.1833375245332718f, 0.3819939494132996f, 0.6229856610298157f, 1.0f};
+KFO_API const float* kfo_nf4_table(void) { return KFO_NF4; }
+KFO_API const float* kfo_nf3_table(void) { return KFO_NF3; }
+static inline int lut_nibble(const uint8_t* stream, size_t i) { return kfo_bit_get_k(stream, i, 4); }
+
+/* w bf16 [nRow, nCol] -> packed [nRow*nCol/2], lut bf16 [nRow*16]; returns disR.err summed over rows -> sqrt(err / nRow / nCol) as RT_NormalF does */
+KFO_API float kfo_lut_quantize_nf4(const uint16_t* w, int nRow, int nCol, uint8_t* packed, uint16_t* lut) {
+    double err = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : err)
+    for (int row = 0; row < nRow; row++) {
+        const uint16_t* dat = w + (size_t)row * nCol;
+        float vmin = FLT_MAX, vmax = -FLT_MAX;
+        for (int i = 0; i < nCol; i++) {
+            const float a = kfo_bf16_to_f32(dat[i]); /* / sR / sC with both 1 */
+            vmax = a > vmax ? a : vmax, vmin = a < vmin ? a : vmin;
+        }
+        const double abs_max = (double)fmaxf(fabsf(vmin), fabsf(vmax));
+        const float scale = abs_max > 0 ? (float)(1.0f / abs_max) : 1.0f;
+        float codebook[16];
+        for (int i = 0; i < 16; i++) {
+            codebook[i] = KFO_NF4[i] / scale;
+            lut[(size_t)row * 16 + i] = kfo_f32_to_bf16(codebook[i]);
+        }
+        double e2 = 0.0;
+        for (int i = 0; i < nCol; i++) {
+            const float a = kfo_bf16_to_f32(dat[i]);
+            float min_dist = FLT_MAX;
+            int best = 0;
+            for (int k = 0; k < 16; k++) {
+                const float dist = fabsf(a - codebook[k]);
+                if (dist < min_dist) min_dist = dist, best = k;
+            }
+            const float e = fabsf(a - codebook[best]);
+            e2 += (double)(e * e);
+            kfo_bit_set_k(packed, (size_t)row * nCol + i, best, 4);
+        }
+        err += e2;
+    }
+    return (float)sqrt(err / nRow / nCol);
+}
+
+/* ------------------------------------------------------------------------------------------------
  * 4. Weight descriptor + W.x  -- SLP::Forw -> TASKA_AxB::blasLt (NeuronFuse.cu:305-381,
  *    GTensor.hpp:703-741): rhs[OC] = W[OC,IC] . lhs[IC], bf16 in, fp32 accumulate, bf16 out
  *    (gemm.cu:126 CUBLAS_COMPUTE_32F).  cuBLASLt's summation order is unspecified; the oracle uses the
@@ -345,7 +403,7 @@ typedef struct {
 
 static int bits_of(int type) {
     switch (type) {
-        case KFO_Q4: case KFO_Q4_AWQ: return 4;
+        case KFO_Q4: case KFO_Q4_AWQ: case KFO_Q4_LUT: return 4;
         case KFO_T_SIGN: case KFO_Q2: return 2;
         case KFO_BOOL1: case KFO_T_BINARY: return 1;
         case KFO_F8E5M2: return 8;
@@ -362,6 +420,8 @@ static void weight_row_f32(const kfo_weight* w, long r, float* out) {
     } else if (w->type == KFO_F8E5M2) {
         const uint8_t* p = (const uint8_t*)w->data + (size_t)r * K;
         for (int c = 0; c < K; c++) out[c] = kfo_round_bf16(kfo_f8e5m2_to_f32(p[c]));
+    } else if (w->type == KFO_Q4_LUT) { /* data = BIT_SET_k nibble stream, zero = the rows' 16-entry tables (bf16) */
+        for (int c = 0; c < K; c++) out[c] = kfo_bf16_to_f32(w->zero[(size_t)r * 16 + lut_nibble((const uint8_t*)w->data, (size_t)r * K + c)]);
     } else if (w->type == KFO_Q4_AWQ) { /* logical W[out = ne0, in = ne1]; data = qweight, zero = qzeros, step = fp16 scales */
         for (int c = 0; c < K; c++)
             out[c] = awq_weight((const uint32_t*)w->data, (const uint32_t*)w->zero, w->step, w->ne0, c, (int)r);

@@ -19,6 +19,7 @@ F32, F64, F16, BF16, F8E5M2, F8E4M3, U8, I8, U16, I16, U32, I32, U64, I64, Q4, Q
 BITS = {BF16: 16, F8E5M2: 8, Q4: 4, T_SIGN: 2, Q2: 2, BOOL1: 1, T_BINARY: 1}
 
 Q4_AWQ = 100  # oracle-internal tag: Q4 in the AutoAWQ GEMM layout
+Q4_LUT = 101  # oracle-internal tag: Q4 in the row-codebook storage (GeQuant::RT_NormalF)
 ATTN_REF, ATTN_FUSED = 0, 1
 
 
@@ -189,6 +190,57 @@ class AWQWeight(QWeight):
 
     def nbytes_algorithmic(self):
         return self.data.nbytes + self.qzeros.nbytes + self.scales.nbytes
+
+
+class LutWeight(QWeight):
+    """Row-codebook 4-bit weight (GeQuant::RT_NormalF storage): BIT_SET_k nibble stream + a 16-entry bf16 table per row."""
+
+    def __init__(self, ne0, ne1, data, lut):
+        self.type, self.ne0, self.ne1 = Q4_LUT, ne0, ne1
+        self.data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
+        self.lut = np.ascontiguousarray(lut, dtype=np.uint16).reshape(ne0, 16)
+        self.zero, self.step = self.lut, None
+        self.lGroup, self.qBias = 0, 0
+
+    @property
+    def bits(self):
+        return 4
+
+    def blob(self):
+        """bytes of `data || R_SCALE[ne0] C_SCALE[ne1] LUT[ne0 x 16]` (bf16): gama_T layout with the LUT at +ne0+ne1 (GeQuant.cpp:710)"""
+        rc = np.full(self.ne0 + self.ne1, 0x3F80, dtype=np.uint16)
+        return np.concatenate([self.data, rc.view(np.uint8), self.lut.reshape(-1).view(np.uint8)])
+
+    def nbytes_algorithmic(self):
+        return self.data.nbytes + self.lut.nbytes
+
+    def cdesc(self):
+        class _W(C.Structure):
+            _fields_ = [("type", C.c_int), ("ne0", C.c_int), ("ne1", C.c_int), ("data", C.c_void_p), ("zero", C.c_void_p),
+                        ("step", C.c_void_p), ("lGroup", C.c_int), ("qBias", C.c_int)]
+        return _W(self.type, self.ne0, self.ne1, _p(self.data), _p(self.lut), None, 0, 0)
+
+
+def quantize_nf4(w_bf16, ne0, ne1, want_err=False):
+    """GeQuant::RT_NormalF (4-bit normal-float row codebooks)."""
+    w_bf16 = np.ascontiguousarray(w_bf16, dtype=np.uint16).reshape(-1)
+    assert w_bf16.size == ne0 * ne1 and ne1 % 2 == 0
+    packed = np.zeros(ne0 * ne1 // 2, dtype=np.uint8)
+    lut = np.zeros(ne0 * 16, dtype=np.uint16)
+    lib().kfo_lut_quantize_nf4.restype = C.c_float
+    err = lib().kfo_lut_quantize_nf4(_p(w_bf16), ne0, ne1, _p(packed), _p(lut))
+    w = LutWeight(ne0, ne1, packed, lut)
+    return (w, float(err)) if want_err else w
+
+
+def nf4_table():
+    lib().kfo_nf4_table.restype = C.POINTER(C.c_float)
+    return np.array([lib().kfo_nf4_table()[i] for i in range(16)], dtype=np.float32)
+
+
+def nf3_table():
+    lib().kfo_nf3_table.restype = C.POINTER(C.c_float)
+    return np.array([lib().kfo_nf3_table()[i] for i in range(8)], dtype=np.float32)
 
 
 def dequant_awq(w):
