@@ -29,8 +29,8 @@ def main():
     ap.add_argument("--steps", type=int, default=1920)
     ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--config", default="qwen3-0.6b")
-    ap.add_argument("--head", default="bf16", choices=["bf16", "q4"])
-    ap.add_argument("--layers", default="q4", choices=["q4", "bf16", "f8", "ternary", "1bit"],
+    ap.add_argument("--head", default="bf16", choices=["bf16", "q4", "nf4"])
+    ap.add_argument("--layers", default="q4", choices=["q4", "bf16", "f8", "ternary", "1bit", "nf4"],
                     help="weight type of the transformer layers (default: the metric's 4-bit PackedQ; the others are side measurements)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
@@ -65,8 +65,8 @@ def main():
     K, W = args.steps, args.warmup
     if K < 1 or W < 0:
         raise SystemExit("steps >= 1, warmup >= 0")
-    head_type = L.BF16 if args.head == "bf16" else L.Q4
-    layer_type = {"q4": L.Q4, "bf16": L.BF16, "f8": L.F8E5M2, "ternary": L.T_SIGN, "1bit": L.BOOL1}[args.layers]
+    head_type = {"bf16": L.BF16, "q4": L.Q4, "nf4": L.NF4}[args.head]
+    layer_type = {"q4": L.Q4, "bf16": L.BF16, "f8": L.F8E5M2, "ternary": L.T_SIGN, "1bit": L.BOOL1, "nf4": L.NF4}[args.layers]
     m = synth.build_on_gpu(cfg, seed=1234 + rank, layer_type=layer_type, head_type=head_type, device=dev)
     ctx = m._ctx
     use_graph = not args.no_graph
@@ -132,10 +132,10 @@ def main():
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"q4": "u4 weights (PackedQ RTN g128)", "bf16": "bf16 weights", "f8": "f8e5m2 weights", "ternary": "2-bit ternary weights (PackedQ YinYang g128)",
-                      "1bit": "1-bit weights (PackedQ YinYang g128)"}[args.layers] + " x bf16 activations, fp32 accumulate; bf16 KV",
+                      "1bit": "1-bit weights (PackedQ YinYang g128)", "nf4": "u4 weights (NF4 row codebooks)"}[args.layers] + " x bf16 activations, fp32 accumulate; bf16 KV",
             "data": "synthetic",
             "config": {"workload": "%s %s greedy decode, 1xMI355X per replica, seq=%d: prompt 128, timed positions %d..%d"
-                                   % ({"qwen3-0.6b": "Qwen3-0.6B", "qwen3-32b": "Qwen3-32B"}.get(args.config, args.config), {"q4": "4-bit PackedQ", "bf16": "bf16", "f8": "f8e5m2", "ternary": "2-bit ternary PackedQ", "1bit": "1-bit PackedQ"}[args.layers],
+                                   % ({"qwen3-0.6b": "Qwen3-0.6B", "qwen3-32b": "Qwen3-32B"}.get(args.config, args.config), {"q4": "4-bit PackedQ", "bf16": "bf16", "f8": "f8e5m2", "ternary": "2-bit ternary PackedQ", "1bit": "1-bit PackedQ", "nf4": "4-bit NF4 row-codebook"}[args.layers],
                                       S, timed_positions[0], timed_positions[-1]),
                        "lm_head": args.head, "replicas": world, "hipgraph": use_graph, "device_ms_per_step": round(dev_ms / K, 5)},
             "step_roofline": {"bound": "hbm", "bytes_per_step": int(mean_bytes), "achieved": round(mean_bytes * (value / world) / 1e9, 1),

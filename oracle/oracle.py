@@ -589,6 +589,9 @@ def from_device_model(m, attn_mode=ATTN_FUSED):
     def host_weight(w):
         blob = w.blob.cpu().numpy()
         data = blob[:w.szData]
+        if getattr(w, "lGroup", 128) == 0:  # LutDevWeight: nibble stream || bf16 [R][C][LUT ne0 x 16]
+            g = blob[w.szData:].view(np.uint16)
+            return LutWeight(w.ne0, w.ne1, data, g[w.ne0 + w.ne1:].copy())
         if w.type == BF16:
             return QWeight(BF16, w.ne0, w.ne1, data.view(np.uint16))
         if w.type == F8E5M2:
