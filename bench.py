@@ -265,7 +265,8 @@ def kernel_roofline(m, ctx, cfg, reps=200):
 
 
 def matvec_roofline(m, ctx, cfg, head_rl, reps=20):
-    """The kernel that takes most of the step's time (47 % in profiles/r01g): kf::gemv_kernel<2, 1, 0>, the 4-bit mat-vec behind
+    """The kernel that takes most of the step's time (47 % in profiles/r01g; 49 % in r01l): kf::gemv_kernel<5, 1, 0> (<2, 1, 0> before the register-table
+    form of the same arithmetic became the default; KF_Q4_PERM=0 still selects it), the 4-bit mat-vec behind
     [RMSNorm + Q/K/V], [o_proj + residual] and [down_proj + residual] -- 3 launches per layer, 84 per token.  All 84 launches with the
     decode step's own weights and arguments are captured in one graph (a dependent chain, like the step) and replayed; an untimed LM-head
     launch between replays pushes the layer weights out of L2 / Infinity Cache as the real step does.  achieved = algorithmic bytes of the
@@ -330,7 +331,7 @@ def matvec_roofline(m, ctx, cfg, head_rl, reps=20):
             traffic = int(json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_matvec.json")))["hbm_bytes_per_launch"])
         except Exception:
             pass
-    return {"bound": "hbm", "kernel": "kf::gemv_kernel<2, 1, 0> = 4-bit mat-vec of [norm+QKV], [o_proj+residual], [down_proj+residual]: %d launches per token, "
+    return {"bound": "hbm", "kernel": "kf::gemv_kernel<5, 1, 0> = 4-bit mat-vec of [norm+QKV], [o_proj+residual], [down_proj+residual]: %d launches per token, "
                                       "the largest share of the step's time (LM head: roofline_lm_head)" % n,
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
             "bytes_per_launch": int(nbytes / n), "us_per_launch": round(ms * 1e3 / n, 2), "launches": n,

@@ -218,6 +218,19 @@ __device__ __forceinline__ float perm_dot_dword(uint32_t D, u32x4 X, const PermL
     acc = dot2_bf16(__builtin_amdgcn_perm(hi, lo, 0x04000501u), X.w, acc);
     return acc;
 }
+// The same lookup with the weights paired as the arithmetic form pairs them -- (e0,e1), (e2,e3), (e4,e5), (e6,e7) against X.x .. X.w in natural
+// order -- so that the fp32 sum is formed in exactly the order of dot_q4_dword (kf_gemv.hip): two extra v_perm_b32 per dword gather the index bytes.
+__device__ __forceinline__ float perm_dot_dword_nat(uint32_t D, u32x4 X, const PermLut& t, float acc) {
+    const uint32_t even = (D >> 4) & 0x0F0F0F0Fu, odd = D & 0x0F0F0F0Fu; /* bytes 3..0 = elements 0,2,4,6 / 1,3,5,7 */
+    uint32_t lo, hi;
+    perm_lookup4(__builtin_amdgcn_perm(even, odd, 0x02060307u), t, lo, hi); /* bytes 0..3 = elements 0, 1, 2, 3 */
+    acc = dot2_bf16(__builtin_amdgcn_perm(hi, lo, 0x05010400u), X.x, acc);
+    acc = dot2_bf16(__builtin_amdgcn_perm(hi, lo, 0x07030602u), X.y, acc);
+    perm_lookup4(__builtin_amdgcn_perm(even, odd, 0x00040105u), t, lo, hi); /* elements 4, 5, 6, 7 */
+    acc = dot2_bf16(__builtin_amdgcn_perm(hi, lo, 0x05010400u), X.z, acc);
+    acc = dot2_bf16(__builtin_amdgcn_perm(hi, lo, 0x07030602u), X.w, acc);
+    return acc;
+}
 __device__ __forceinline__ u32x4 perm_x_order(u32x4 o) {
     return u32x4{__builtin_amdgcn_perm(o.y, o.x, 0x05040100u), __builtin_amdgcn_perm(o.w, o.z, 0x05040100u), __builtin_amdgcn_perm(o.y, o.x, 0x07060302u),
                  __builtin_amdgcn_perm(o.w, o.z, 0x07060302u)};

@@ -103,7 +103,8 @@ struct BlockDot<FMT_Q4> {
 // build the 16 entries together -- lane i of the quad forms entries 4i..4i+3 with the arithmetic above, packs them into one low-byte and one
 // high-byte plane word and the quad exchanges the 8 plane words by DPP broadcasts -- then every weight costs a lookup instead of the
 // fma / round / subtract / round chain: ~4.7 VALU instructions per weight instead of 6.25.  The launcher picks this form only when a group
-// is exactly one aligned lane quad (lGroup 128, K a multiple of 128, at least 4 lanes per row); x is staged in the pair order the lookup emits.
+// is exactly one aligned lane quad (lGroup 128, K a multiple of 128, at least 4 lanes per row).  The lookup pairs the weights as the arithmetic
+// form does (perm_dot_dword_nat), so the fp32 sums -- and every output bit -- are those of BlockDot<FMT_Q4>.
 template <>
 struct BlockDot<FMT_Q4P> {
     static constexpr int EPB = 32, XCH = 4;
@@ -118,10 +119,10 @@ struct BlockDot<FMT_Q4P> {
         PermLut t;
         t.tl[0] = quad_bcast<0>(tlm), t.tl[1] = quad_bcast<1>(tlm), t.tl[2] = quad_bcast<2>(tlm), t.tl[3] = quad_bcast<3>(tlm);
         t.th[0] = quad_bcast<0>(thm), t.th[1] = quad_bcast<1>(thm), t.th[2] = quad_bcast<2>(thm), t.th[3] = quad_bcast<3>(thm);
-        acc = perm_dot_dword(w.w, xs[col], t, acc);
-        acc = perm_dot_dword(w.z, xs[nBlk + col], t, acc);
-        acc = perm_dot_dword(w.y, xs[2 * nBlk + col], t, acc);
-        acc = perm_dot_dword(w.x, xs[3 * nBlk + col], t, acc);
+        acc = perm_dot_dword_nat(w.w, xs[col], t, acc);
+        acc = perm_dot_dword_nat(w.z, xs[nBlk + col], t, acc);
+        acc = perm_dot_dword_nat(w.y, xs[2 * nBlk + col], t, acc);
+        acc = perm_dot_dword_nat(w.x, xs[3 * nBlk + col], t, acc);
         return acc;
     }
 };
@@ -142,10 +143,10 @@ struct BlockDot<FMT_Q4R> {
             t.tl[k] = __builtin_amdgcn_perm(P[2 * k + 1], P[2 * k], 0x06040200u);
             t.th[k] = __builtin_amdgcn_perm(P[2 * k + 1], P[2 * k], 0x07050301u);
         }
-        acc = perm_dot_dword(__builtin_amdgcn_perm(0u, w.x, 0x00010203u), xs[col], t, acc);
-        acc = perm_dot_dword(__builtin_amdgcn_perm(0u, w.y, 0x00010203u), xs[nBlk + col], t, acc);
-        acc = perm_dot_dword(__builtin_amdgcn_perm(0u, w.z, 0x00010203u), xs[2 * nBlk + col], t, acc);
-        acc = perm_dot_dword(__builtin_amdgcn_perm(0u, w.w, 0x00010203u), xs[3 * nBlk + col], t, acc);
+        acc = perm_dot_dword_nat(__builtin_amdgcn_perm(0u, w.x, 0x00010203u), xs[col], t, acc);
+        acc = perm_dot_dword_nat(__builtin_amdgcn_perm(0u, w.y, 0x00010203u), xs[nBlk + col], t, acc);
+        acc = perm_dot_dword_nat(__builtin_amdgcn_perm(0u, w.z, 0x00010203u), xs[2 * nBlk + col], t, acc);
+        acc = perm_dot_dword_nat(__builtin_amdgcn_perm(0u, w.w, 0x00010203u), xs[3 * nBlk + col], t, acc);
         return acc;
     }
 };
@@ -241,7 +242,7 @@ struct Batch {
 template <int FMT, int G, int MODE>
 __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     using BD = BlockDot<FMT>;
-    constexpr bool PAIRED = (MODE == GEMV_PAIRED), LUT = (FMT == FMT_Q4R), XPERM = (FMT == FMT_Q4P || FMT == FMT_Q4R);
+    constexpr bool PAIRED = (MODE == GEMV_PAIRED), LUT = (FMT == FMT_Q4R);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);
     double* red = reinterpret_cast<double*>(smem_raw + (size_t)a.K * 2);
@@ -374,11 +375,11 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
             }
             if (h0) {
                 const int c = tid / XCH, j = tid - c * XCH;
-                xs[j * nBlk + c] = XPERM ? perm_x_order(u32x4{ow[0], ow[1], ow[2], ow[3]}) : u32x4{ow[0], ow[1], ow[2], ow[3]};
+                xs[j * nBlk + c] = u32x4{ow[0], ow[1], ow[2], ow[3]};
             }
             if (h1) {
                 const int e8 = tid + 256, c = e8 / XCH, j = e8 - c * XCH;
-                xs[j * nBlk + c] = XPERM ? perm_x_order(u32x4{ow[4], ow[5], ow[6], ow[7]}) : u32x4{ow[4], ow[5], ow[6], ow[7]};
+                xs[j * nBlk + c] = u32x4{ow[4], ow[5], ow[6], ow[7]};
             }
         } else {
             float mul = 1.0f;
@@ -403,7 +404,7 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
                     }
                     o.x = ow[0], o.y = ow[1], o.z = ow[2], o.w = ow[3];
                 }
-                xs[j * nBlk + c] = XPERM ? perm_x_order(o) : o;
+                xs[j * nBlk + c] = o;
             }
         }
         __syncthreads();
@@ -693,13 +694,12 @@ int gemv_launch(hipStream_t st, GemvLaunch& L) {
         case FMT_BF16: launch_m<FMT_BF16>(a, L.mode, G, grid, smem, st); break;
         case FMT_F8: launch_m<FMT_F8>(a, L.mode, G, grid, smem, st); break;
         case FMT_Q4: {
-            // table-lookup form when a 128-weight group is exactly one aligned quad of lanes and the launch is large enough to be bound by
-            // the unpack arithmetic (KF_Q4_PERM: 0 never, 1 whenever the geometry allows, default -1 = from 0.5 M blocks up)
+            // table-lookup form whenever a 128-weight group is exactly one aligned quad of lanes: bit-identical to the arithmetic form (same
+            // weights, same pairing, same summation order), 20 % fewer VALU instructions per weight (KF_Q4_PERM=0 switches it off)
             static int q4perm = -2;
             if (q4perm == -2) q4perm = getenv("KF_Q4_PERM") ? atoi(getenv("KF_Q4_PERM")) : -1;
             const bool geom_ok = a.lGroup == 128 && (K % 128) == 0 && lpr_log2 >= 2;
-            const bool big = raw_slots * (long)nBlk * (64 / (1 << lpr_log2)) >= (1L << 19);
-            if (geom_ok && (q4perm == 1 || (q4perm == -1 && big)))
+            if (geom_ok && q4perm != 0)
                 launch_m<FMT_Q4P>(a, L.mode, G, grid, smem, st);
             else
                 launch_m<FMT_Q4>(a, L.mode, G, grid, smem, st);

@@ -1,6 +1,6 @@
-"""The 4-bit mat-vec has one default form per launch size and three opt-in forms (environment knobs read once per process: KF_Q4_PERM = register
-table inside the main kernel -- the default for launches of >= 0.5 M blocks --, KF_Q4_LUT = 1 / 2 / 3 the lane-owns-a-group kernels of
-kf_gemv_lut.hip).  Every form must meet the same parity bar; each runs in a child process with its knob set."""
+"""The 4-bit mat-vec has a default form (the register table inside the main kernel wherever a group is one lane quad; KF_Q4_PERM=0 selects the
+arithmetic form it replaces, bit for bit) and three opt-in forms (KF_Q4_LUT = 1 / 2 / 3: the lane-owns-a-group kernels of kf_gemv_lut.hip); the
+knobs are read once per process.  Every form must meet the same parity bar; each runs in a child process with its knob set."""
 import os
 import subprocess
 import sys
@@ -17,6 +17,41 @@ def test_q4_matvec_form(knobs):
     env.update(knobs)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_q4_variant_child.py")], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, "%s\n%s\n%s" % (knobs, r.stdout[-2000:], r.stderr[-2000:])
+
+
+_DIGEST = r"""
+import sys, hashlib, torch
+sys.path.insert(0, %r)
+from koifish_amd.runtime import Context
+from koifish_amd import lib as L
+ctx = Context(0); dev = ctx.device
+g = torch.Generator(device=dev); g.manual_seed(5)
+h = hashlib.sha256()
+for (m, k) in [(4096, 1024), (1024, 3072), (1000, 2048), (40, 3200), (8192, 5120)]:
+    W = (torch.randn(m, k, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+    x = torch.randn(k, device=dev, generator=g).to(torch.bfloat16)
+    w = ctx.quantize(W, L.Q4)
+    y = ctx.linear(w, x)
+    a = ctx.norm_gateup_swiglu(x, torch.ones(k, device=dev, dtype=torch.bfloat16), w, w)
+    lg, am = ctx.lm_head(w, x)
+    ctx.sync()
+    for t in (y, a, lg):
+        h.update(t.view(torch.int16).cpu().numpy().tobytes())
+    h.update(str(am).encode())
+print("DIGEST", h.hexdigest())
+""" % ROOT
+
+
+def test_table_form_is_bit_identical_to_the_arithmetic_form():
+    """the default (register-table lookup, BlockDot<FMT_Q4P>) pairs and sums the weights exactly as the fma / round / subtract / round form does:
+    every output bit of the plain, paired-SwiGLU and arg-max launches is the same"""
+    digests = []
+    for v in ("0", "1"):
+        env = dict(os.environ, KF_Q4_PERM=v)
+        r = subprocess.run([sys.executable, "-c", _DIGEST], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        digests.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1])
+    assert digests[0] == digests[1]
 
 
 def test_attention_backward_first_version():
