@@ -66,12 +66,18 @@ typedef struct kf_weight {
      * data = the nibble stream BIT_SET_k writes (CLI_params.cpp:2177-2190: element i of the row-major matrix in byte i/2, even i in the HIGH nibble),
      * gama = bf16 [R_SCALE ne0][C_SCALE ne1][LUT ne0 x 16] (GTensor.cpp:456-510 with the LUT at +ne0+ne1); a weight is lut[row][nibble]
      * (CU_Q42X_NF4 / CU_Q42X_lut, quantizer.cu:583-652, rc_normal = 0 as LowBit_worker's only sweep entry leaves it, GeQuant.cpp:844).
-     * lGroup / nGroup / qMin / qMax / qBias are not used.  ne1 must be a multiple of 32. */
+     * lGroup / nGroup / qMin / qMax / qBias are not used.  ne1 must be a multiple of 32.
+     * The same mode with type = KF_Q3 / KF_Q2 is the 8- / 4-entry form (CU_Q32X_NF3 / CU_Q32X_ / CU_Q22X_, quantizer.cu:690-792): a 3- / 2-bit stream,
+     * most significant bit first, 8 weights per 3 / 2 bytes, [LUT ne0 x 8] / [LUT ne0 x 4]; ne1 a multiple of 8.  KF_QUANT_ROW_RTN (type = KF_Q2) is
+     * CU_Q22X_RTN (quantizer.cu:655-688): gama = [R][C][(zero, step) x ne0], weight = bf16(zero + bf16(step * id)).  These three are served the way the
+     * reference serves them -- kf_dequant (GetDataX), and kf_linear as dequant + the bf16 product; kf_quantize builds the 3-bit normal-float form
+     * (RT_NormalF asserts bits == 4 || 3).  CU_Q32X_RTN is not restated: it reads every row from row 0's stream (quantizer.cu:802, no row offset). */
     int32_t quant;
     int32_t reserved_;
 } kf_weight;
 #define KF_QUANT_GROUP 0
 #define KF_QUANT_ROW_LUT 1
+#define KF_QUANT_ROW_RTN 2
 
 /* kf_linear epilogue flags */
 #define KF_EPI_NONE 0u

@@ -288,6 +288,13 @@ static int check_weight(const kf_weight* w, const char* who) {
             return fail(KF_QUANT_ERR, "%s: malformed AWQ weight (%d x %d, group %d)", who, w->ne0, w->ne1, w->lGroup);
         return KF_OK;
     }
+    if ((w->quant == KF_QUANT_ROW_LUT && (w->type == KF_Q3 || w->type == KF_Q2)) || (w->quant == KF_QUANT_ROW_RTN && w->type == KF_Q2)) {
+        /* 3- / 2-bit row forms: dequant-only storage (kf_dequant, kf_linear through it, kf_quantize for NF3) */
+        if (!w->gama) return fail(KF_QUANT_ERR, "%s: row-quantised weight without gama", who);
+        if (w->ne1 % 8) return fail(KF_BLAS_UNALIGN, "%s: rows of %d weights are not whole 8-weight units", who, w->ne1);
+        return KF_OK;
+    }
+    if (w->quant == KF_QUANT_ROW_RTN) return fail(KF_QUANT_ERR, "%s: row-RTN storage exists for KF_Q2 only (type %d)", who, w->type);
     if (w->quant == KF_QUANT_ROW_LUT) { /* row-codebook 4-bit storage (GeQuant::RT_NormalF): nibble stream + 16 table entries per row */
         if (w->type != KF_Q4 || !w->gama) return fail(KF_QUANT_ERR, "%s: malformed row-LUT weight (type %d)", who, w->type);
         if (w->ne1 % 32) return fail(KF_BLAS_UNALIGN, "%s: row-LUT rows of %d weights are not 16-byte aligned", who, w->ne1);
@@ -365,6 +372,18 @@ int kf_linear(kf_ctx* c, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const
     if (gemm_min < 0) {
         const char* e = getenv("KF_GEMM_MIN");
         gemm_min = e ? atoi(e) : 8;
+    }
+    if (w->quant != KF_QUANT_GROUP && w->type != KF_Q4) {
+        // 3- / 2-bit row forms: GetDataX into the scratch, then the bf16 product, whatever the batch (the reference's own order; no in-place mat-vec)
+        if (c->capturing && (size_t)w->ne0 * w->ne1 * 2 > c->wd_ws_bytes)
+            return fail(KF_INVALID_ARGS, "kf_linear: the dequant workspace must be sized by one eager call before graph capture");
+        const uint16_t* Wd = nullptr;
+        r = lib_weight_bf16(c, w, &Wd);
+        if (r != KF_OK) return fail(r, "kf_linear (row-form dequant) failed with %d", r);
+        kf_weight wb;
+        memset(&wb, 0, sizeof(wb));
+        wb.data = Wd, wb.type = KF_BF16, wb.ne0 = w->ne0, wb.ne1 = w->ne1;
+        return kf_linear(c, &wb, x, y, bias, nTok, alpha, beta, epilogue, residual);
     }
     if (nTok >= gemm_min && w->quant == KF_QUANT_ROW_LUT && !(c->capturing && (size_t)w->ne0 * w->ne1 * 2 > c->wd_ws_bytes)) {
         // row-codebook storage with a token batch: the reference's own order -- GetDataX into the scratch, then the bf16 product (the tile kernel on

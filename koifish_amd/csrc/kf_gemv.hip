@@ -562,7 +562,7 @@ static int fmt_of(int type) {
     }
 }
 static int fmt_of_w(const kf_weight* w) {
-    if (is_row_lut(w)) return w->type == KF_Q4 ? FMT_Q4R : -1;
+    if (is_row_lut(w)) return (w->type == KF_Q4 && w->quant == KF_QUANT_ROW_LUT) ? FMT_Q4R : -1;
     return fmt_of(w->type);
 }
 static int epb_of(int fmt) {

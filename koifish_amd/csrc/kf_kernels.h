@@ -10,7 +10,7 @@ enum {
     FMT_Q4P = 5, /* 4-bit through the register-table lookup (mat-vec only) */
     FMT_Q4R = 6  /* 4-bit row codebook (KF_QUANT_ROW_LUT): byte-packed nibbles + 16 bf16 table entries per row */
 };
-inline bool is_row_lut(const kf_weight* w) { return w->quant == KF_QUANT_ROW_LUT; }
+inline bool is_row_lut(const kf_weight* w) { return w->quant != KF_QUANT_GROUP; } /* any row-wise card (kf_lut.hip); the mat-vec kernel takes Q4 + ROW_LUT only */
 enum { GEMV_PLAIN = 0, GEMV_PAIRED = 1, GEMV_ARGMAX = 2 };
 constexpr int KF_MAX_ARGMAX_PARTIALS = 4096;
 constexpr int KF_ATTN_MAX_SPLITS = 32;

@@ -58,8 +58,55 @@ __global__ void __launch_bounds__(256) lut_quantize_kernel(const uint16_t* __res
     }
 }
 
+// NF3_LUT::table (g_float.hpp:566)
+__constant__ float kNF3[8] = {-1.0f, -0.5350227355957031f, -0.2469314038753510f, 0.0f, 0.1833375245332718f, 0.3819939494132996f, 0.6229856610298157f, 1.0f};
+
+// the 3-bit form of the same quantiser (RT_NormalF with bits == 3): a lane packs 8 weights into 3 bytes, most significant bit first (BIT_SET_k)
+__global__ void __launch_bounds__(256) lut_quantize3_kernel(const uint16_t* __restrict__ src, unsigned char* __restrict__ packed, uint16_t* __restrict__ lut, int nRow,
+                                                            int nCol) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= nRow) return;
+    const uint16_t* dat = src + (size_t)row * nCol;
+    float vmax = -3.402823466e+38f, vmin = 3.402823466e+38f;
+    for (int i = lane; i < nCol; i += 64) {
+        const float a = bf2f(dat[i]);
+        vmax = fmaxf(vmax, a), vmin = fminf(vmin, a);
+    }
+    vmax = wave_max(vmax), vmin = -wave_max(-vmin);
+    const float abs_max = fmaxf(fabsf(vmin), fabsf(vmax));
+    const float scale = abs_max > 0.0f ? (float)(1.0 / (double)abs_max) : 1.0f;
+    float cb[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) cb[i] = kNF3[i] / scale;
+    if (lane < 8) lut[(size_t)row * 8 + lane] = f2bf(kNF3[lane] / scale);
+    unsigned char* dst = packed + (size_t)row * (nCol / 8) * 3;
+    for (int u = lane; u < nCol / 8; u += 64) {
+        unsigned int v = 0;
+#pragma unroll
+        for (int h = 0; h < 8; h++) {
+            const float w = bf2f(dat[8 * u + h]);
+            float best = 3.402823466e+38f;
+            unsigned int id = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const float d = fabsf(w - cb[i]);
+                if (d < best) best = d, id = i;
+            }
+            v = (v << 3) | id;
+        }
+        dst[3 * u] = (unsigned char)(v >> 16), dst[3 * u + 1] = (unsigned char)(v >> 8), dst[3 * u + 2] = (unsigned char)v;
+    }
+}
+
 int lut_quantize_launch(hipStream_t st, const kf_weight* w, const uint16_t* src) {
-    if (w->type != KF_Q4 || !w->gama) return KF_QUANT_ERR;
+    if (w->quant == KF_QUANT_ROW_LUT && w->type == KF_Q3 && w->gama) {
+        if (w->ne1 % 8) return KF_INVALID_ARGS;
+        hipLaunchKernelGGL(lut_quantize3_kernel, dim3((unsigned)((w->ne0 + 3) / 4)), dim3(256), 0, st, src, (unsigned char*)const_cast<void*>(w->data),
+                           const_cast<uint16_t*>(w->gama) + w->ne0 + w->ne1, w->ne0, w->ne1);
+        return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+    }
+    if (w->quant != KF_QUANT_ROW_LUT || w->type != KF_Q4 || !w->gama) return KF_QUANT_ERR; /* RT_NormalF: bits == 4 || 3 */
     if (w->ne1 % 2) return KF_INVALID_ARGS;
     uint16_t* lut = const_cast<uint16_t*>(w->gama) + w->ne0 + w->ne1;
     hipLaunchKernelGGL(lut_quantize_kernel, dim3((unsigned)((w->ne0 + 3) / 4)), dim3(256), 0, st, src, (unsigned char*)const_cast<void*>(w->data), lut, w->ne0, w->ne1);
@@ -84,8 +131,54 @@ __global__ void __launch_bounds__(256) lut_dequant_kernel(const uint32_t* __rest
     const size_t row = i / (size_t)words_per_row;
     *reinterpret_cast<u32x4*>(out + i * 8) = lut_unpack8(data[i], lut + row * 16);
 }
+// 3- and 2-bit row forms (CU_Q32X_NF3 / CU_Q32X_ / CU_Q22X_ / CU_Q22X_RTN): one thread per 8 weights = BITS bytes of the stream, most significant bit first
+template <int BITS, bool RTN>
+__global__ void __launch_bounds__(256) row_dequant_kernel(const unsigned char* __restrict__ data, const uint16_t* __restrict__ tab, int units_per_row, size_t nunits,
+                                                          uint16_t* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nunits) return;
+    const size_t row = i / (size_t)units_per_row;
+    const unsigned char* q = data + i * BITS;
+    uint32_t v = 0;
+#pragma unroll
+    for (int b = 0; b < BITS; b++) v = (v << 8) | q[b];
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint16_t e[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t id = (v >> (BITS * (7 - (2 * k + h)))) & ((1u << BITS) - 1u);
+            if (RTN) { /* (zero + step * (floatGama)id) * sR, every operator a bf16 operator, sR = 1 */
+                const float zero = bf2f(tab[row * 2]), step = bf2f(tab[row * 2 + 1]);
+                e[h] = f2bf(zero + round_bf16(step * (float)id));
+            } else {
+                e[h] = tab[row * (1u << BITS) + id];
+            }
+        }
+        o[k] = (uint32_t)e[0] | ((uint32_t)e[1] << 16);
+    }
+    *reinterpret_cast<u32x4*>(out + i * 8) = u32x4{o[0], o[1], o[2], o[3]};
+}
+
 int lut_dequant_launch(hipStream_t st, const kf_weight* w, uint16_t* out) {
-    if (w->type != KF_Q4 || !w->gama) return KF_QUANT_ERR;
+    if (!w->gama) return KF_QUANT_ERR;
+    if (w->type != KF_Q4 || w->quant != KF_QUANT_ROW_LUT) {
+        if (w->ne1 % 8) return KF_INVALID_ARGS;
+        const size_t nunits = (size_t)w->ne0 * w->ne1 / 8;
+        const dim3 grid((unsigned)((nunits + 255) / 256));
+        const unsigned char* d = (const unsigned char*)w->data;
+        const uint16_t* tab = w->gama + w->ne0 + w->ne1;
+        if (w->quant == KF_QUANT_ROW_LUT && w->type == KF_Q3)
+            hipLaunchKernelGGL((row_dequant_kernel<3, false>), grid, dim3(256), 0, st, d, tab, w->ne1 / 8, nunits, out);
+        else if (w->quant == KF_QUANT_ROW_LUT && w->type == KF_Q2)
+            hipLaunchKernelGGL((row_dequant_kernel<2, false>), grid, dim3(256), 0, st, d, tab, w->ne1 / 8, nunits, out);
+        else if (w->quant == KF_QUANT_ROW_RTN && w->type == KF_Q2)
+            hipLaunchKernelGGL((row_dequant_kernel<2, true>), grid, dim3(256), 0, st, d, tab, w->ne1 / 8, nunits, out);
+        else
+            return KF_UNSUPPORTED_DATATYPE;
+        return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+    }
     if (w->ne1 % 8) return KF_INVALID_ARGS;
     const size_t nwords = (size_t)w->ne0 * w->ne1 / 8;
     hipLaunchKernelGGL(lut_dequant_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, st, (const uint32_t*)w->data, w->gama + w->ne0 + w->ne1, w->ne1 / 8, nwords,
@@ -112,7 +205,8 @@ __global__ void lut_embed_kernel(const uint32_t* __restrict__ data, const uint16
     *reinterpret_cast<u32x4*>(out + (size_t)i * 8) = lut_unpack8(data[(size_t)token * words_per_row + i], lut + (size_t)token * 16);
 }
 int lut_embed_launch(hipStream_t st, const kf_weight* w, int token, const int32_t* d_token, const int32_t* d_state, const int32_t* d_forced, uint16_t* out, int n_tok) {
-    if (w->type != KF_Q4 || !w->gama) return KF_QUANT_ERR;
+    if (w->type != KF_Q4 || w->quant != KF_QUANT_ROW_LUT) return KF_UNSUPPORTED_DATATYPE; /* TokenEmbed::cuInfer: Q4 only (Q3: assert(0), NeuronFuse.cu:187-192) */
+    if (!w->gama) return KF_QUANT_ERR;
     if (w->ne1 % 8) return KF_INVALID_ARGS;
     if (!d_token && !d_state && (token < 0 || token >= w->ne0)) return KF_INVALID_ARGS;
     if (n_tok < 1 || (n_tok > 1 && !d_token)) return KF_INVALID_ARGS;

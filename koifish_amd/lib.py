@@ -10,7 +10,7 @@ LIB_HOST = os.path.join(HERE, "libkf_host.so")
 F32, F64, F16, BF16, F8E5M2, F8E4M3, U8, I8, U16, I16, U32, I32, U64, I64, Q4, Q3, Q2, T_SIGN, T_SEQ, BOOL1, T_BINARY, T_BINARY_3, T_BINARY_TILE = range(23)
 BITS = {BF16: 16, F8E5M2: 8, Q4: 4, T_SIGN: 2, BOOL1: 1, T_BINARY: 1}
 KF_EPI_RESIDUAL = 1
-QUANT_GROUP, QUANT_ROW_LUT = 0, 1  # kf_weight.quant
+QUANT_GROUP, QUANT_ROW_LUT, QUANT_ROW_RTN = 0, 1, 2  # kf_weight.quant
 NF4 = 1000  # not a typNUMBER: "Q4 with the normal-float quant card" (QUANT_MODE::RTNf) for the helpers that take a storage type
 
 # every symbol include/kf_abi.h declares (tests/test_abi_symbols.py checks the header against this list and the .so)

@@ -63,21 +63,24 @@ class DevWeight:
 
 
 class LutDevWeight:
-    """Row-codebook 4-bit weight in HBM (KF_QUANT_ROW_LUT; GeQuant::RT_NormalF): blob = nibble stream [ne0*ne1/2] ‖ bf16 gama [ne0 + ne1 + 16*ne0]."""
+    """Row-codebook weight in HBM (KF_QUANT_ROW_LUT; GeQuant::RT_NormalF): blob = MSB-first `bits`-wide stream [ne0*ne1*bits/8] ‖ bf16 gama
+    [ne0 + ne1 + (2^bits)*ne0]; bits 4 (the mat-vec format), 3 or 2 (dequant-only); rtn=True (bits 2): (zero, step) per row, KF_QUANT_ROW_RTN."""
 
-    def __init__(self, ne0, ne1, blob):
-        self.type, self.ne0, self.ne1, self.blob, self.lGroup = L.Q4, ne0, ne1, blob, 0
-        self.szData = ne0 * ne1 // 2
-        self.szGama = (ne0 + ne1 + 16 * ne0) * 2
+    def __init__(self, ne0, ne1, blob, bits=4, rtn=False):
+        self.type, self.ne0, self.ne1, self.blob, self.lGroup = {4: L.Q4, 3: L.Q3, 2: L.Q2}[bits], ne0, ne1, blob, 0
+        self.bits, self.rtn = bits, rtn
+        self.szData = ne0 * ne1 * bits // 8
+        self.szGama = (ne0 + ne1 + (2 if rtn else 1 << bits) * ne0) * 2
         assert blob.numel() == self.szData + self.szGama, (blob.numel(), self.szData, self.szGama)
 
     @staticmethod
-    def blob_bytes(ne0, ne1):
-        return ne0 * ne1 // 2 + (ne0 + ne1 + 16 * ne0) * 2
+    def blob_bytes(ne0, ne1, bits=4):
+        return ne0 * ne1 * bits // 8 + (ne0 + ne1 + (1 << bits) * ne0) * 2
 
     def desc(self):
         p = self.blob.data_ptr()
-        return L.Weight(p, p + self.szData, L.Q4, self.ne0, self.ne1, 0, 0, 0, 15, 0, None, None, L.QUANT_ROW_LUT, 0)
+        return L.Weight(p, p + self.szData, self.type, self.ne0, self.ne1, 0, 0, 0, (1 << self.bits) - 1, 0, None, None,
+                        L.QUANT_ROW_RTN if self.rtn else L.QUANT_ROW_LUT, 0)
 
     def algorithmic_bytes(self):
         """what a mat-vec has to read: the nibble stream + the rows' tables"""
@@ -85,7 +88,7 @@ class LutDevWeight:
 
     def lut(self):
         g = self.blob[self.szData:].view(torch.bfloat16)
-        return g[self.ne0 + self.ne1:].view(self.ne0, 16)
+        return g[self.ne0 + self.ne1:].view(self.ne0, -1)
 
 
 class AWQDevWeight:
@@ -175,16 +178,16 @@ class Context:
         L.check(self.hip.kf_quantize(self.h, C.byref(d), _ptr(w_bf16), int(symmetric)), "kf_quantize")
         return dw
 
-    def upload_lut_blob(self, ne0, ne1, blob_np):
+    def upload_lut_blob(self, ne0, ne1, blob_np, bits=4, rtn=False):
         t = torch.from_numpy(np.ascontiguousarray(blob_np).view(np.uint8).reshape(-1).copy()).to(self.device)
-        return LutDevWeight(ne0, ne1, t)
+        return LutDevWeight(ne0, ne1, t, bits, rtn)
 
-    def quantize_nf4(self, w_bf16):
-        """w_bf16: torch.bfloat16 [ne0, ne1] on the GPU -> LutDevWeight (kf_quantize in KF_QUANT_ROW_LUT mode: GeQuant::RT_NormalF on device)."""
+    def quantize_nf4(self, w_bf16, bits=4):
+        """w_bf16: torch.bfloat16 [ne0, ne1] on the GPU -> LutDevWeight (kf_quantize in KF_QUANT_ROW_LUT mode: GeQuant::RT_NormalF on device; bits 4 or 3)."""
         ne0, ne1 = w_bf16.shape
         w_bf16 = w_bf16.contiguous()
-        blob = torch.zeros(LutDevWeight.blob_bytes(ne0, ne1), dtype=torch.uint8, device=self.device)
-        dw = LutDevWeight(ne0, ne1, blob)
+        blob = torch.zeros(LutDevWeight.blob_bytes(ne0, ne1, bits), dtype=torch.uint8, device=self.device)
+        dw = LutDevWeight(ne0, ne1, blob, bits)
         blob[dw.szData:].view(torch.bfloat16)[:ne0 + ne1] = 1.0  # R_SCALE / C_SCALE (unused: rc_normal = 0)
         d = dw.desc()
         L.check(self.hip.kf_quantize(self.h, C.byref(d), _ptr(w_bf16), 0), "kf_quantize")

@@ -42,7 +42,9 @@ enum {
     /* oracle-internal tag (not a typNUMBER): a Q4 tensor in the vendor AutoAWQ GEMM layout, see section 3b */
     KFO_Q4_AWQ = 100,
     /* oracle-internal tag: a Q4 tensor in the row-codebook storage of GeQuant::RT_NormalF (QUANT_MODE::RTNf / LUT), see section 3c */
-    KFO_Q4_LUT = 101
+    KFO_Q4_LUT = 101,
+    KFO_Q3_LUT = 102, KFO_Q2_LUT = 103, /* 8- / 4-entry row codebooks over a 3- / 2-bit stream (CU_Q32X_NF3 / CU_Q32X_ / CU_Q22X_) */
+    KFO_Q2_ROWRTN = 104                 /* CU_Q22X_RTN: (zero, step) per row */
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -346,9 +348,19 @@ static const float KFO_NF3[8] = {-1.0f, -0.5350227355957031f, -0.246931403875351
 KFO_API const float* kfo_nf4_table(void) { return KFO_NF4; }
 KFO_API const float* kfo_nf3_table(void) { return KFO_NF3; }
 static inline int lut_nibble(const uint8_t* stream, size_t i) { return kfo_bit_get_k(stream, i, 4); }
+/* element i of a `bits`-wide stream, most significant bit first, as CU_Q32X_* / CU_Q22X_* extract it (quantizer.cu:672-675, 727-731) */
+static inline int raw_bits(const uint8_t* stream, size_t i, int bits) {
+    int v = 0;
+    size_t boff = i * (size_t)bits;
+    for (int b = 0; b < bits; b++, boff++) v = (v << 1) | ((stream[boff / 8] >> (7 - boff % 8)) & 1);
+    return v;
+}
 
-/* w bf16 [nRow, nCol] -> packed [nRow*nCol/2], lut bf16 [nRow*16]; returns disR.err summed over rows -> sqrt(err / nRow / nCol) as RT_NormalF does */
-KFO_API float kfo_lut_quantize_nf4(const uint16_t* w, int nRow, int nCol, uint8_t* packed, uint16_t* lut) {
+/* w bf16 [nRow, nCol] -> packed [nRow*nCol*bits/8], lut bf16 [nRow << bits]; bits = 4 (NF4) or 3 (NF3), as RT_NormalF asserts.
+ * Returns disR.err summed over rows -> sqrt(err / nRow / nCol) as RT_NormalF does. */
+KFO_API float kfo_lut_quantize_nf(const uint16_t* w, int nRow, int nCol, int bits, uint8_t* packed, uint16_t* lut) {
+    const int nQuant = 1 << bits;
+    const float* table = bits == 4 ? KFO_NF4 : KFO_NF3;
     double err = 0.0;
 #pragma omp parallel for schedule(static) reduction(+ : err)
     for (int row = 0; row < nRow; row++) {
@@ -361,26 +373,29 @@ KFO_API float kfo_lut_quantize_nf4(const uint16_t* w, int nRow, int nCol, uint8_
         const double abs_max = (double)fmaxf(fabsf(vmin), fabsf(vmax));
         const float scale = abs_max > 0 ? (float)(1.0f / abs_max) : 1.0f;
         float codebook[16];
-        for (int i = 0; i < 16; i++) {
-            codebook[i] = KFO_NF4[i] / scale;
-            lut[(size_t)row * 16 + i] = kfo_f32_to_bf16(codebook[i]);
+        for (int i = 0; i < nQuant; i++) {
+            codebook[i] = table[i] / scale;
+            lut[(size_t)row * nQuant + i] = kfo_f32_to_bf16(codebook[i]);
         }
         double e2 = 0.0;
         for (int i = 0; i < nCol; i++) {
             const float a = kfo_bf16_to_f32(dat[i]);
             float min_dist = FLT_MAX;
             int best = 0;
-            for (int k = 0; k < 16; k++) {
+            for (int k = 0; k < nQuant; k++) {
                 const float dist = fabsf(a - codebook[k]);
                 if (dist < min_dist) min_dist = dist, best = k;
             }
             const float e = fabsf(a - codebook[best]);
             e2 += (double)(e * e);
-            kfo_bit_set_k(packed, (size_t)row * nCol + i, best, 4);
+            kfo_bit_set_k(packed, (size_t)row * nCol + i, best, bits); /* rows are whole bytes (nCol % 8 == 0): threads never share one */
         }
         err += e2;
     }
     return (float)sqrt(err / nRow / nCol);
+}
+KFO_API float kfo_lut_quantize_nf4(const uint16_t* w, int nRow, int nCol, uint8_t* packed, uint16_t* lut) {
+    return kfo_lut_quantize_nf(w, nRow, nCol, 4, packed, lut);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -404,7 +419,8 @@ typedef struct {
 static int bits_of(int type) {
     switch (type) {
         case KFO_Q4: case KFO_Q4_AWQ: case KFO_Q4_LUT: return 4;
-        case KFO_T_SIGN: case KFO_Q2: return 2;
+        case KFO_Q3_LUT: return 3;
+        case KFO_T_SIGN: case KFO_Q2: case KFO_Q2_LUT: case KFO_Q2_ROWRTN: return 2;
         case KFO_BOOL1: case KFO_T_BINARY: return 1;
         case KFO_F8E5M2: return 8;
         default: return 16;
@@ -420,6 +436,12 @@ static void weight_row_f32(const kfo_weight* w, long r, float* out) {
     } else if (w->type == KFO_F8E5M2) {
         const uint8_t* p = (const uint8_t*)w->data + (size_t)r * K;
         for (int c = 0; c < K; c++) out[c] = kfo_round_bf16(kfo_f8e5m2_to_f32(p[c]));
+    } else if (w->type == KFO_Q3_LUT || w->type == KFO_Q2_LUT) { /* raw ids, most significant bit first (the kernels read them without BIT_GET_k's 2-bit un-biasing) */
+        const int bits = w->type == KFO_Q3_LUT ? 3 : 2, nq = 1 << bits;
+        for (int c = 0; c < K; c++) out[c] = kfo_bf16_to_f32(w->zero[(size_t)r * nq + raw_bits((const uint8_t*)w->data, (size_t)r * K + c, bits)]);
+    } else if (w->type == KFO_Q2_ROWRTN) { /* CU_Q22X_RTN (quantizer.cu:655-688): (zero + step * (floatGama)id) * sR in bf16 operators, sR = 1 */
+        const float zero = kfo_bf16_to_f32(w->zero[(size_t)r * 2]), step = kfo_bf16_to_f32(w->zero[(size_t)r * 2 + 1]);
+        for (int c = 0; c < K; c++) out[c] = kfo_round_bf16(zero + kfo_round_bf16(step * (float)raw_bits((const uint8_t*)w->data, (size_t)r * K + c, 2)));
     } else if (w->type == KFO_Q4_LUT) { /* data = BIT_SET_k nibble stream, zero = the rows' 16-entry tables (bf16) */
         for (int c = 0; c < K; c++) out[c] = kfo_bf16_to_f32(w->zero[(size_t)r * 16 + lut_nibble((const uint8_t*)w->data, (size_t)r * K + c)]);
     } else if (w->type == KFO_Q4_AWQ) { /* logical W[out = ne0, in = ne1]; data = qweight, zero = qzeros, step = fp16 scales */

@@ -20,6 +20,7 @@ BITS = {BF16: 16, F8E5M2: 8, Q4: 4, T_SIGN: 2, Q2: 2, BOOL1: 1, T_BINARY: 1}
 
 Q4_AWQ = 100  # oracle-internal tag: Q4 in the AutoAWQ GEMM layout
 Q4_LUT = 101  # oracle-internal tag: Q4 in the row-codebook storage (GeQuant::RT_NormalF)
+Q3_LUT, Q2_LUT, Q2_ROWRTN = 102, 103, 104  # 8- / 4-entry row codebooks (3- / 2-bit streams); (zero, step) per row (CU_Q22X_RTN)
 ATTN_REF, ATTN_FUSED = 0, 1
 
 
@@ -193,18 +194,21 @@ class AWQWeight(QWeight):
 
 
 class LutWeight(QWeight):
-    """Row-codebook 4-bit weight (GeQuant::RT_NormalF storage): BIT_SET_k nibble stream + a 16-entry bf16 table per row."""
+    """Row-codebook weight (GeQuant::RT_NormalF storage): MSB-first `bits`-wide stream + a 2^bits-entry bf16 table per row (bits 4, 3 or 2);
+    rtn=True (bits 2): a (zero, step) pair per row instead of a table (CU_Q22X_RTN)."""
 
-    def __init__(self, ne0, ne1, data, lut):
-        self.type, self.ne0, self.ne1 = Q4_LUT, ne0, ne1
+    def __init__(self, ne0, ne1, data, lut, bits=4, rtn=False):
+        self.type = Q2_ROWRTN if rtn else {4: Q4_LUT, 3: Q3_LUT, 2: Q2_LUT}[bits]
+        self.ne0, self.ne1, self._bits, self.rtn = ne0, ne1, bits, rtn
         self.data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
-        self.lut = np.ascontiguousarray(lut, dtype=np.uint16).reshape(ne0, 16)
+        assert self.data.size == ne0 * ne1 * bits // 8
+        self.lut = np.ascontiguousarray(lut, dtype=np.uint16).reshape(ne0, 2 if rtn else 1 << bits)
         self.zero, self.step = self.lut, None
         self.lGroup, self.qBias = 0, 0
 
     @property
     def bits(self):
-        return 4
+        return self._bits
 
     def blob(self):
         """bytes of `data || R_SCALE[ne0] C_SCALE[ne1] LUT[ne0 x 16]` (bf16): gama_T layout with the LUT at +ne0+ne1 (GeQuant.cpp:710)"""
@@ -221,16 +225,20 @@ class LutWeight(QWeight):
         return _W(self.type, self.ne0, self.ne1, _p(self.data), _p(self.lut), None, 0, 0)
 
 
-def quantize_nf4(w_bf16, ne0, ne1, want_err=False):
-    """GeQuant::RT_NormalF (4-bit normal-float row codebooks)."""
+def quantize_nf4(w_bf16, ne0, ne1, want_err=False, bits=4):
+    """GeQuant::RT_NormalF (4- or 3-bit normal-float row codebooks)."""
     w_bf16 = np.ascontiguousarray(w_bf16, dtype=np.uint16).reshape(-1)
-    assert w_bf16.size == ne0 * ne1 and ne1 % 2 == 0
-    packed = np.zeros(ne0 * ne1 // 2, dtype=np.uint8)
-    lut = np.zeros(ne0 * 16, dtype=np.uint16)
-    lib().kfo_lut_quantize_nf4.restype = C.c_float
-    err = lib().kfo_lut_quantize_nf4(_p(w_bf16), ne0, ne1, _p(packed), _p(lut))
-    w = LutWeight(ne0, ne1, packed, lut)
+    assert bits in (4, 3) and w_bf16.size == ne0 * ne1 and ne1 % 8 == 0
+    packed = np.zeros(ne0 * ne1 * bits // 8, dtype=np.uint8)
+    lut = np.zeros(ne0 << bits, dtype=np.uint16)
+    lib().kfo_lut_quantize_nf.restype = C.c_float
+    err = lib().kfo_lut_quantize_nf(_p(w_bf16), ne0, ne1, bits, _p(packed), _p(lut))
+    w = LutWeight(ne0, ne1, packed, lut, bits)
     return (w, float(err)) if want_err else w
+
+
+def quantize_nf3(w_bf16, ne0, ne1, want_err=False):
+    return quantize_nf4(w_bf16, ne0, ne1, want_err, bits=3)
 
 
 def nf4_table():

@@ -175,3 +175,77 @@ def test_model_decode_and_prefill_with_nf4_layers(O, head_type):
     assert np.abs(O.bf16_to_f32(g_logits) - O.bf16_to_f32(o_logits)).max() <= LOGIT_TOL * np.abs(O.bf16_to_f32(o_logits)).max()
     assert g_next == o_next
     gm.close()
+
+
+# ---- 3- / 2-bit row forms (CU_Q32X_NF3 / CU_Q32X_ / CU_Q22X_ / CU_Q22X_RTN): dequant-only storage, kf_linear = GetDataX + the bf16 product
+@pytest.mark.parametrize("shape,std", [((64, 256), 0.02), ((9, 3072), 1.0), ((2048, 1024), 0.02)])
+def test_nf3_quantizer_and_dequant_bit_exact(ctx, O, shape, std):
+    rng = np.random.default_rng(31)
+    m, k = shape
+    w = rand_w(O, rng, m, k, std)
+    w.reshape(m, k)[2] = 0
+    ow = O.quantize_nf3(w, m, k)
+    dw = ctx.quantize_nf4(bf16_t(w, ctx.device).view(m, k), bits=3)
+    assert np.array_equal(dw.blob.cpu().numpy(), np.concatenate([ow.data, np.full(m + k, 0x3F80, np.uint16).view(np.uint8), ow.lut.reshape(-1).view(np.uint8)]))
+    assert np.array_equal(u16(ctx.dequant(dw)), O.dequant(ow))
+
+
+def _two_bit(O, rng, m, k):
+    ids = rng.integers(0, 4, size=(m, k)).astype(np.uint8)
+    data = np.packbits(((ids[..., None] >> np.array([1, 0])) & 1).astype(np.uint8).reshape(-1))
+    lut = O.f32_to_bf16(rng.normal(0, 0.1, size=(m, 4)).astype(np.float32))
+    zs = O.f32_to_bf16(np.stack([rng.normal(-0.1, 0.02, size=m), rng.uniform(0.03, 0.08, size=m)], axis=1).astype(np.float32))
+    return O.LutWeight(m, k, data, lut, bits=2), O.LutWeight(m, k, data, zs, bits=2, rtn=True)
+
+
+def _blob(ow, m, k):
+    return np.concatenate([ow.data, np.full(m + k, 0x3F80, np.uint16).view(np.uint8), ow.lut.reshape(-1).view(np.uint8)])
+
+
+def test_two_bit_row_forms_dequant_bit_exact(ctx, O):
+    rng = np.random.default_rng(32)
+    m, k = 40, 512
+    q, r = _two_bit(O, rng, m, k)
+    assert np.array_equal(u16(ctx.dequant(ctx.upload_lut_blob(m, k, _blob(q, m, k), bits=2))), O.dequant(q))
+    assert np.array_equal(u16(ctx.dequant(ctx.upload_lut_blob(m, k, _blob(r, m, k), bits=2, rtn=True))), O.dequant(r))
+
+
+@pytest.mark.parametrize("n_tok", [1, 5, 64])
+def test_row_forms_linear_through_dequant(ctx, O, n_tok):
+    rng = np.random.default_rng(33)
+    m, k = 256, 512
+    o3 = O.quantize_nf3(rand_w(O, rng, m, k), m, k)
+    o2, o2r = _two_bit(O, rng, m, k)
+    x = O.f32_to_bf16(rng.normal(0, 1.0, size=(n_tok, k)).astype(np.float32))
+    bias = O.f32_to_bf16(rng.normal(0, 0.1, size=m).astype(np.float32))
+    xt, bt = bf16_t(x, ctx.device), bf16_t(bias, ctx.device)
+    for ow, dw in ((o3, ctx.upload_lut_blob(m, k, _blob(o3, m, k), bits=3)), (o2, ctx.upload_lut_blob(m, k, _blob(o2, m, k), bits=2)),
+                   (o2r, ctx.upload_lut_blob(m, k, _blob(o2r, m, k), bits=2, rtn=True))):
+        y = torch.zeros(n_tok, m, dtype=torch.bfloat16, device=ctx.device)
+        d = dw.desc()
+        L.check(ctx.hip.kf_linear(ctx.h, C.byref(d), C.c_void_p(xt.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(bt.data_ptr()), n_tok, 1.0, 0.0, 0, None), "kf_linear")
+        W = O.bf16_to_f32(O.dequant(ow)).astype(np.float64)
+        exact = O.bf16_to_f32(x).astype(np.float64) @ W.T + O.bf16_to_f32(bias).astype(np.float64)
+        assert np.abs(O.bf16_to_f32(u16(y)) - exact).max() <= 2.0 ** -8 * np.abs(exact).max() + 1e-6
+        if n_tok == 1:   # the mat-vec over the dequantised copy is the bf16 mat-vec: within 1 ulp of the oracle's
+            assert ulp_diff_bf16(u16(y)[0], O.linear(ow, x[0], bias=bias)).max() <= 1
+
+
+def test_row_forms_refusals(ctx, O):
+    rng = np.random.default_rng(34)
+    m, k = 16, 64
+    o3 = O.quantize_nf3(rand_w(O, rng, m, k), m, k)
+    d3 = ctx.upload_lut_blob(m, k, _blob(o3, m, k), bits=3)
+    out = torch.zeros(k, dtype=torch.bfloat16, device=ctx.device)
+    d = d3.desc()
+    assert ctx.hip.kf_embed(ctx.h, C.byref(d), 1, None, C.c_void_p(out.data_ptr())) == -1000      # TokenEmbed::cuInfer: Q3 -> assert(0)
+    x = torch.zeros(k, dtype=torch.bfloat16, device=ctx.device)
+    with pytest.raises(L.KFError):
+        ctx.norm_linear(x, None, [d3])                                                             # no in-place mat-vec for the 3-bit stream
+    d = d3.desc()
+    d.quant = L.QUANT_ROW_RTN                                                                      # CU_Q32X_RTN is not restated (reads row 0's stream for every row)
+    assert ctx.hip.kf_dequant(ctx.h, C.byref(d), C.c_void_p(torch.zeros(m * k, dtype=torch.bfloat16, device=ctx.device).data_ptr())) == -701
+    q2, _ = _two_bit(O, rng, m, k)
+    d = ctx.upload_lut_blob(m, k, _blob(q2, m, k), bits=2).desc()
+    src = torch.zeros(m, k, dtype=torch.bfloat16, device=ctx.device)
+    assert ctx.hip.kf_quantize(ctx.h, C.byref(d), C.c_void_p(src.data_ptr()), 0) == -701          # RT_NormalF asserts bits == 4 || 3

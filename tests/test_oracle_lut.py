@@ -105,3 +105,59 @@ def test_linear_and_embed_read_the_table():
     dq = O.QWeight(O.BF16, m, k, O.dequant(q))
     assert np.array_equal(O.linear(q, x), O.linear(dq, x))
     assert np.array_equal(O.embed(q, 5), O.dequant(q)[5])
+
+
+def numpy_nf3(w_u16, ne0, ne1):
+    """the 3-bit form: 8-entry table, 8 ids -> 3 bytes, most significant bit first"""
+    w = O.bf16_to_f32(w_u16).reshape(ne0, ne1)
+    table = np.array(NF3, dtype=np.float32)
+    packed = np.zeros((ne0, ne1 // 8, 3), dtype=np.uint8)
+    lut = np.zeros((ne0, 8), dtype=np.uint16)
+    for r in range(ne0):
+        abs_max = max(abs(np.float32(w[r].min())), abs(np.float32(w[r].max())))
+        scale = np.float32(1.0 / np.float64(abs_max)) if abs_max > 0 else np.float32(1.0)
+        cb = (table / scale).astype(np.float32)
+        lut[r] = O.f32_to_bf16(cb)
+        idx = np.argmin(np.abs(w[r][:, None] - cb[None, :]).astype(np.float32), axis=1).astype(np.uint32).reshape(-1, 8)
+        v = np.zeros(ne1 // 8, dtype=np.uint32)
+        for h in range(8):
+            v = (v << 3) | idx[:, h]
+        packed[r, :, 0], packed[r, :, 1], packed[r, :, 2] = (v >> 16) & 255, (v >> 8) & 255, v & 255
+    return packed.reshape(-1), lut
+
+
+def unpack_ids(data, ne0, ne1, bits):
+    """MSB-first ids of a `bits`-wide stream, as CU_Q32X_* / CU_Q22X_* extract them (quantizer.cu:672-675, 727-731)"""
+    b = np.unpackbits(np.asarray(data, dtype=np.uint8)).reshape(ne0 * ne1, bits)
+    return (b * (1 << np.arange(bits - 1, -1, -1))).sum(axis=1).reshape(ne0, ne1)
+
+
+@pytest.mark.parametrize("shape,std,seed", [((16, 64), 0.02, 11), ((5, 1024), 1.0, 12)])
+def test_nf3_quantiser_matches_numpy_restatement(shape, std, seed):
+    rng = np.random.default_rng(seed)
+    m, k = shape
+    w = O.f32_to_bf16(rng.normal(0, std, size=(m, k)).astype(np.float32))
+    q = O.quantize_nf3(w, m, k)
+    packed, lut = numpy_nf3(w, m, k)
+    assert np.array_equal(q.lut, lut) and np.array_equal(q.data, packed)
+    ids = unpack_ids(q.data, m, k, 3)
+    assert np.array_equal(O.dequant(q), np.take_along_axis(lut, ids, axis=1))
+    x = O.f32_to_bf16(rng.normal(0, 1, size=k).astype(np.float32))
+    assert np.array_equal(O.linear(q, x), O.linear(O.QWeight(O.BF16, m, k, O.dequant(q)), x))
+
+
+def test_two_bit_row_forms():
+    """CU_Q22X_ (4-entry table per row) and CU_Q22X_RTN (zero + step * id per row, bf16 operators) over a raw 2-bit stream"""
+    rng = np.random.default_rng(13)
+    m, k = 6, 64
+    ids = rng.integers(0, 4, size=(m, k)).astype(np.uint8)
+    data = np.packbits(((ids[..., None] >> np.array([1, 0])) & 1).astype(np.uint8).reshape(-1))
+    assert np.array_equal(unpack_ids(data, m, k, 2), ids)
+    lut = O.f32_to_bf16(rng.normal(0, 0.1, size=(m, 4)).astype(np.float32))
+    q = O.LutWeight(m, k, data, lut, bits=2)
+    assert np.array_equal(O.dequant(q), np.take_along_axis(lut, ids.astype(np.int64), axis=1))
+    zs = O.f32_to_bf16(np.stack([rng.normal(-0.1, 0.02, size=m), rng.uniform(0.03, 0.08, size=m)], axis=1).astype(np.float32))
+    r = O.LutWeight(m, k, data, zs, bits=2, rtn=True)
+    z, s = O.bf16_to_f32(zs[:, 0])[:, None], O.bf16_to_f32(zs[:, 1])[:, None]
+    step_id = O.bf16_to_f32(O.f32_to_bf16((s * ids.astype(np.float32)).astype(np.float32)))
+    assert np.array_equal(O.dequant(r), O.f32_to_bf16((z + step_id).astype(np.float32)))
