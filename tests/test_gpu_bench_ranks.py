@@ -1,0 +1,38 @@
+"""bench.py as the driver launches it for N > 1: one process per rank under torch.distributed.run, barrier + max-over-ranks timing, rank 0 printing one
+JSON line whose value is the whole job's rate.  A 1-GPU box has no second device, so the two ranks share GPU 0 and rendezvous over gloo
+(KF_BENCH_BACKEND / KF_BENCH_DEVICE are test hooks; on the 8-GPU node the same code runs with the RCCL backend, one rank per GPU).  The decode path
+has no data-path collective: ranks are independent replicas ("scaling": "weak")."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_ranks_one_json_line():
+    env = dict(os.environ, KF_BENCH_BACKEND="gloo", KF_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "96", "--warmup", "16", "--cpu-seconds", "0", "--streams", "0", "--config", "small"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0): %r" % lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 96 and j["warmup"] == 16 and j["scaling"] == "weak" and j["higher_is_better"] is True
+    assert j["config"]["replicas"] == 2
+    # whole-job rate = units of all ranks / max-over-ranks time
+    assert abs(j["value"] - 2 * 96 / (j["ms_per_step"] * 96 / 1e3)) <= 1e-2 * j["value"]
+    assert "roofline" in j and j["vs_baseline"] is None
