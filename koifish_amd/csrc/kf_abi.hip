@@ -385,9 +385,14 @@ int kf_linear(kf_ctx* c, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const
         wb.data = Wd, wb.type = KF_BF16, wb.ne0 = w->ne0, wb.ne1 = w->ne1;
         return kf_linear(c, &wb, x, y, bias, nTok, alpha, beta, epilogue, residual);
     }
+    if (nTok >= gemm_min) {
+        const int rc = kf::gemm_launch(c->stream, w, x, w->ne1, nTok, y, w->ne0, bias, alpha, beta, (epilogue & KF_EPI_RESIDUAL) ? residual : nullptr, w->ne0);
+        if (rc < 0) return fail(rc, "kf_linear (token-batch GEMM) failed with %d", rc);
+        if (rc == KF_OK) return KF_OK;
+    }
     if (nTok >= gemm_min && w->quant == KF_QUANT_ROW_LUT && !(c->capturing && (size_t)w->ne0 * w->ne1 * 2 > c->wd_ws_bytes)) {
-        // row-codebook storage with a token batch: the reference's own order -- GetDataX into the scratch, then the bf16 product (the tile kernel on
-        // the dequantised copy).  Mat-vecs (below) read the nibble stream directly.
+        // row-codebook storage whose shape the in-register-unpack tile kernels do not cover: the reference's own order -- GetDataX into the scratch,
+        // then the bf16 product on the dequantised copy.  Mat-vecs (below) read the nibble stream directly.
         const uint16_t* Wd = nullptr;
         r = lib_weight_bf16(c, w, &Wd);
         if (r != KF_OK) return fail(r, "kf_linear (row-LUT dequant) failed with %d", r);
@@ -396,11 +401,6 @@ int kf_linear(kf_ctx* c, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const
         wb.data = Wd, wb.type = KF_BF16, wb.ne0 = w->ne0, wb.ne1 = w->ne1;
         const int rc = kf::gemm_launch(c->stream, &wb, x, w->ne1, nTok, y, w->ne0, bias, alpha, beta, (epilogue & KF_EPI_RESIDUAL) ? residual : nullptr, w->ne0);
         if (rc < 0) return fail(rc, "kf_linear (row-LUT token-batch GEMM) failed with %d", rc);
-        if (rc == KF_OK) return KF_OK;
-    }
-    if (nTok >= gemm_min) {
-        const int rc = kf::gemm_launch(c->stream, w, x, w->ne1, nTok, y, w->ne0, bias, alpha, beta, (epilogue & KF_EPI_RESIDUAL) ? residual : nullptr, w->ne0);
-        if (rc < 0) return fail(rc, "kf_linear (token-batch GEMM) failed with %d", rc);
         if (rc == KF_OK) return KF_OK;
     }
     for (int t = 0; t < nTok; t++) {

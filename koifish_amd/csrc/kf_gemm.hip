@@ -59,6 +59,34 @@ struct WTile<FMT_Q4, KS> {
         return frag_q4(D, s, s * 0.0625f, -a.qBias * s, z);
     }
 };
+// 4-bit row codebook: the same block ranges as the Packed128 form; the row's 16-entry table rides along (two 16-byte loads through the cache)
+template <int KS>
+struct WTile<FMT_Q4R, KS> {
+    static constexpr int NP = 2 / KS;
+    u32x4 b[NP];
+    u32x4 ta, tb;
+    bool in[NP];
+    __device__ __forceinline__ void load(const GemmArgs& a, int row, int it, int h, int ks) {
+        const u32x4* lt = reinterpret_cast<const u32x4*>(a.zero) + 2 * (size_t)row; /* a.zero carries the table base */
+        ta = lt[0], tb = lt[1];
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            int bi = it * 4 + 2 * (ks * NP + p) + h;
+            const bool in_row = bi < a.nBlk;
+            if (!in_row) bi = a.nBlk - 1;
+            b[p] = ld_nt(reinterpret_cast<const u32x4*>(a.w) + (uint32_t)row * (uint32_t)a.nBlk + (uint32_t)bi);
+            in[p] = in_row;
+        }
+    }
+    static __device__ __forceinline__ int koff(int sl, int h, int ks) { return (2 * (ks * NP + (sl >> 2)) + h) * 32 + 8 * (sl & 3); }
+    __device__ __forceinline__ u32x4 frag(int sl, const GemmArgs&) const {
+        const int p = sl >> 2, c = sl & 3;
+        const uint32_t D = c == 0 ? b[p].x : (c == 1 ? b[p].y : (c == 2 ? b[p].z : b[p].w)); /* stream order: dword 0 holds elements 0..7 */
+        const u32x4 o = frag_q4r(D, ta, tb);
+        const uint32_t keep = in[p] ? 0xffffffffu : 0u;
+        return u32x4{o.x & keep, o.y & keep, o.z & keep, o.w & keep};
+    }
+};
 template <int KS>
 struct WTile<FMT_BF16, KS> {
     static constexpr int NP = 2 / KS;
@@ -456,11 +484,12 @@ static void gm_dispatch(int fmt, const GemmArgs& a, int KS, dim3 grid, size_t sm
         case FMT_F8: gm_launch<FMT_F8>(a, KS, grid, smem, st); break;
         case FMT_Q4: gm_launch<FMT_Q4>(a, KS, grid, smem, st); break;
         case FMT_Q2: gm_launch<FMT_Q2>(a, KS, grid, smem, st); break;
+        case FMT_Q4R: gm_launch<FMT_Q4R>(a, KS, grid, smem, st); break;
         default: gm_launch<FMT_Q1>(a, KS, grid, smem, st); break;
     }
 }
 
-static const int gm_epb[5] = {8, 16, 32, 64, 128};
+static const int gm_epb[7] = {8, 16, 32, 64, 128, 32, 32};
 struct GmWeight {
     const unsigned char* w;
     const uint16_t *zero, *step;
@@ -470,16 +499,24 @@ struct GmWeight {
 // 0 ok, 1 not eligible for the tile kernels, < 0 error
 static int gm_weight(const kf_weight* w, GmWeight& o) {
     o.fmt = gm_fmt_of(w->type);
-    if (o.fmt < 0 || w->qzeros || w->qscales || is_row_lut(w)) return 1; /* row-codebook storage: the caller dequantises first */
+    if (is_row_lut(w)) { /* 4-bit row codebooks unpack in registers like the Packed128 form; the 3- / 2-bit row forms are dequantised by the caller */
+        if (w->type != KF_Q4 || w->quant != KF_QUANT_ROW_LUT) return 1;
+        o.fmt = FMT_Q4R;
+    }
+    if (o.fmt < 0 || w->qzeros || w->qscales) return 1;
     o.M = w->ne0, o.K = w->ne1;
     // K a multiple of 128 for every kernel; a multiple of 64 is enough for the direct kernel on the formats whose 64-element unit is made of
     // whole blocks (bf16, f8, 4-bit) -- GPT-2's n_embd = 1600
     if (o.K % 64 != 0 || o.K < GM_KT || o.M < 1 || (reinterpret_cast<uintptr_t>(w->data) & 15) != 0) return 1;
-    if (o.K % GM_KT != 0 && o.fmt > FMT_Q4) return 1;
+    if (o.K % GM_KT != 0 && o.fmt > FMT_Q4 && o.fmt != FMT_Q4R) return 1;
     if ((unsigned long long)o.M * (unsigned long long)(o.K / gm_epb[o.fmt]) >= (1ull << 32)) return 1;
     o.w = reinterpret_cast<const unsigned char*>(w->data);
     o.zero = o.step = nullptr, o.qBias = (float)w->qBias, o.gshift = 0;
-    if (o.fmt >= FMT_Q4) {
+    if (o.fmt == FMT_Q4R) {
+        if (!w->gama) return KF_QUANT_ERR;
+        o.zero = w->gama + w->ne0 + w->ne1; /* the rows' tables */
+        if ((reinterpret_cast<uintptr_t>(o.zero) & 15) != 0) return 1;
+    } else if (o.fmt >= FMT_Q4) {
         if (!w->gama || w->lGroup <= 0 || (w->lGroup % gm_epb[o.fmt]) != 0 || ((long)o.M * o.K) % w->lGroup != 0) return KF_QUANT_ERR;
         const int bpg = w->lGroup / gm_epb[o.fmt];
         if (bpg < 1 || (bpg & (bpg - 1)) != 0) return KF_QUANT_ERR;

@@ -55,6 +55,24 @@ __device__ __forceinline__ u32x4 frag_q4(uint32_t D, float step, float step16, f
     o.w = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
     return o;
 }
+// row-codebook 4-bit stream (KF_QUANT_ROW_LUT): D = 4 stream bytes (element 2b in the high nibble of byte b), ta / tb = the row's 16 bf16 entries
+__device__ __forceinline__ u32x4 frag_q4r(uint32_t D, u32x4 ta, u32x4 tb) {
+    const uint32_t P[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+    PermLut t;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        t.tl[k] = __builtin_amdgcn_perm(P[2 * k + 1], P[2 * k], 0x06040200u);
+        t.th[k] = __builtin_amdgcn_perm(P[2 * k + 1], P[2 * k], 0x07050301u);
+    }
+    const uint32_t even = (D >> 4) & 0x0F0F0F0Fu, odd = D & 0x0F0F0F0Fu; /* byte b: elements 2b / 2b + 1 */
+    u32x4 o;
+    uint32_t lo, hi;
+    perm_lookup4(__builtin_amdgcn_perm(even, odd, 0x01050004u), t, lo, hi); /* bytes 0..3 = elements 0, 1, 2, 3 */
+    o.x = __builtin_amdgcn_perm(hi, lo, 0x05010400u), o.y = __builtin_amdgcn_perm(hi, lo, 0x07030602u);
+    perm_lookup4(__builtin_amdgcn_perm(even, odd, 0x03070206u), t, lo, hi); /* elements 4, 5, 6, 7 */
+    o.z = __builtin_amdgcn_perm(hi, lo, 0x05010400u), o.w = __builtin_amdgcn_perm(hi, lo, 0x07030602u);
+    return o;
+}
 // 16 bits, element 0 in bits 15..14
 __device__ __forceinline__ u32x4 frag_q2(uint32_t v, float step, float nb, float zero) {
     uint32_t o[4];

@@ -115,11 +115,11 @@ def test_linear_epilogues_and_fused_forms(ctx, O):
         ctx.norm_linear(xt, None, [dw, dg])
 
 
-@pytest.mark.parametrize("n_tok", [3, 40, 300])
-def test_linear_token_batches(ctx, O, n_tok):
-    """nTok > 1: the reference's own order -- GetDataX into scratch, then the bf16 product -- checked against the exact fp64 product"""
+@pytest.mark.parametrize("n_tok,m,k", [(3, 384, 512), (40, 384, 512), (300, 384, 512), (1100, 256, 1024), (64, 128, 1600), (2100, 128, 512)])
+def test_linear_token_batches(ctx, O, n_tok, m, k):
+    """nTok > 1: the MFMA tile kernels with the nibble stream unpacked in registers through the row's table (mat-vec loop below 8 rows, the
+    vendor-library route from 2048 rows) -- checked against the exact fp64 product of the dequantised weights"""
     rng = np.random.default_rng(24)
-    m, k = 384, 512
     ow = O.quantize_nf4(rand_w(O, rng, m, k), m, k)
     dw = ctx.upload_lut_blob(m, k, ow.blob())
     x = O.f32_to_bf16(rng.normal(0, 1.0, size=(n_tok, k)).astype(np.float32))
@@ -129,7 +129,8 @@ def test_linear_token_batches(ctx, O, n_tok):
     d = dw.desc()
     L.check(ctx.hip.kf_linear(ctx.h, C.byref(d), C.c_void_p(xt.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(bt.data_ptr()), n_tok, 1.0, 0.0, 0, None), "kf_linear")
     exact = O.bf16_to_f32(x).astype(np.float64) @ O.bf16_to_f32(O.dequant(ow)).astype(np.float64).T + O.bf16_to_f32(bias).astype(np.float64)
-    assert np.abs(O.bf16_to_f32(u16(y)) - exact).max() <= 2.0 ** -8 * np.abs(exact).max() + 1e-6
+    tol = 2.0 ** -7 if n_tok >= 2048 else 2.0 ** -8   # the library route adds the bias to the GEMM's bf16 result: two roundings
+    assert np.abs(O.bf16_to_f32(u16(y)) - exact).max() <= tol * np.abs(exact).max() + 1e-6
 
 
 def test_rejects_malformed(ctx, O):
