@@ -16,10 +16,15 @@ pytestmark = pytest.mark.gpu
 
 
 def _run(ctx, t, OC, IC, n, accumulate, with_bias=True, want_gw=True):
-    rng = np.random.default_rng(OC * 7 + IC * 3 + n + t)
+    rng = np.random.default_rng(OC * 7 + IC * 3 + n + (t if isinstance(t, int) else len(t) + ord(t[-1])))
     w = O.f32_to_bf16(rng.normal(0, 0.05, (OC, IC)).astype(np.float32))
-    ow = O.quantize(w, OC, IC, t)
-    dw = ctx.upload_blob(t, OC, IC, ow.blob())
+    if t in ("nf4", "nf3"):      # row-codebook storage: GetDataX is the row-table lookup (kf_lut.hip), the GEMMs are the same
+        bits = 4 if t == "nf4" else 3
+        ow = O.quantize_nf4(w, OC, IC, bits=bits)
+        dw = ctx.upload_lut_blob(OC, IC, ow.blob(), bits=bits)
+    else:
+        ow = O.quantize(w, OC, IC, t)
+        dw = ctx.upload_blob(t, OC, IC, ow.blob())
     dIn = O.f32_to_bf16(rng.normal(0, 1.0, (n, OC)).astype(np.float32))
     inp = O.f32_to_bf16(rng.normal(0, 1.0, (n, IC)).astype(np.float32))
     delta0 = O.f32_to_bf16(rng.normal(0, 1.0, (n, IC)).astype(np.float32))
@@ -61,6 +66,13 @@ def test_linear_backward(ctx, t, shape, accumulate):
     if t == L.Q4 and (OC * IC) % 128:
         pytest.skip("group size")
     _run(ctx, t, OC, IC, n, accumulate)
+
+
+@pytest.mark.parametrize("t", ["nf4", "nf3"])
+@pytest.mark.parametrize("shape", [(256, 128, 128), (1024, 3072, 128), (1600, 1600, 2048)])
+def test_linear_backward_row_codebook_weights(ctx, t, shape):
+    OC, IC, n = shape
+    _run(ctx, t, OC, IC, n, True)
 
 
 def test_linear_forward_large_batch(ctx):
