@@ -435,7 +435,19 @@ struct Loader {
             KF_TRY(t->Alloc(f->ctx, t->szData));
             kf_weight d = t->desc();
             KF_TRY(kf_quantize(f->ctx, &d, d_src, 0));
+        } else if (tp == typNUMBER::Q4 && lGroup == 0) {
+            // quant card with isNormalFloat (QUANT_MODE::RTNf): GeQuant::RT_NormalF on the device -> nibble stream || [R][C][LUT ne0 x 16]
+            if ((ne1 % 32) || (ne0 % 8)) return fail(KF_QUANT_ERR, "tensor '" + name + "': the normal-float row form needs in % 32 == 0 and out % 8 == 0");
+            t->quant.isNormalFloat = true;
+            t->szData = n / 2;
+            t->szGama = ((size_t)ne0 + ne1 + 16 * (size_t)ne0) * 2;
+            KF_TRY(t->Alloc(f->ctx, t->szData + t->szGama));
+            std::vector<uint16_t> ones((size_t)ne0 + ne1, 0x3F80);
+            KF_TRY(kf_h2d(f->ctx, t->gama_T(), ones.data(), ones.size() * 2));
+            kf_weight d = t->desc();
+            KF_TRY(kf_quantize(f->ctx, &d, d_src, 0));
         } else {
+            if (lGroup <= 0) return fail(KF_QUANT_ERR, "tensor '" + name + "': group size " + std::to_string(lGroup));
             if (n % (size_t)lGroup) return fail(KF_QUANT_ERR, "tensor '" + name + "': size is not a multiple of the group " + std::to_string(lGroup));
             t->szData = n * t->quant.bits / 8;
             const size_t nGroup = n / lGroup;
@@ -497,7 +509,9 @@ struct Loader {
 }  // namespace
 
 // HF directory -> Fish.  layer_type / head_type: what the dense matrices are quantised to on load (BF16 keeps them).
-Fish* LoadHF(const std::string& dir, int device, void* stream, typNUMBER layer_type, typNUMBER head_type, int lGroup, int max_seq, int* rc_out, std::string& err) {
+Fish* LoadHF(const std::string& dir, int device, void* stream, typNUMBER layer_type, typNUMBER head_type, int lGroup, int max_seq, int* rc_out, std::string& err,
+             bool layer_nf, bool head_nf) {
+    const int lGroupL = layer_nf ? 0 : lGroup, lGroupH = head_nf ? 0 : lGroup; /* 0: normal-float row codebooks (Loader::dense) */
     auto bail = [&](int rc, const std::string& what) -> Fish* {
         if (rc_out) *rc_out = rc;
         err = what;
@@ -536,13 +550,13 @@ Fish* LoadHF(const std::string& dir, int device, void* stream, typNUMBER layer_t
     bool any_awq = false;
     auto check = [&](int r) { return r == KF_OK; };
     hGTensor emb;
-    if (!check(rc = L.dense("model.embed_tokens.weight", card.vocab, C, head_type, lGroup, &emb))) return bail(rc, err);
+    if (!check(rc = L.dense("model.embed_tokens.weight", card.vocab, C, head_type, lGroupH, &emb))) return bail(rc, err);
     f->embed.w = emb;
     if (card.tie_word_embeddings || !st.Find("lm_head.weight")) {
         f->head.proj.w = emb, f->head.proj.nOut = card.vocab, f->head.proj.nIn = C;  // Neuron.cpp:349-356
     } else {
         hGTensor hw;
-        if (!check(rc = L.dense("lm_head.weight", card.vocab, C, head_type, lGroup, &hw))) return bail(rc, err);
+        if (!check(rc = L.dense("lm_head.weight", card.vocab, C, head_type, lGroupH, &hw))) return bail(rc, err);
         f->head.proj.w = hw, f->head.proj.nOut = card.vocab, f->head.proj.nIn = C;
     }
     if (!check(rc = L.norm("model.norm.weight", C, &f->final_norm, true))) return bail(rc, err);
@@ -553,13 +567,13 @@ Fish* LoadHF(const std::string& dir, int device, void* stream, typNUMBER layer_t
         if (!check(rc = L.norm(p + "input_layernorm.weight", C, &a->norm, true)) || !check(rc = L.norm(p + "post_attention_layernorm.weight", C, &m->norm, true)) ||
             !check(rc = L.norm(p + "self_attn.q_norm.weight", card.head_dim, &a->normQ, false)) ||
             !check(rc = L.norm(p + "self_attn.k_norm.weight", card.head_dim, &a->normK, false)) ||
-            !check(rc = L.linear(p + "self_attn.q_proj", qd, C, layer_type, lGroup, &a->Q, &any_awq)) ||
-            !check(rc = L.linear(p + "self_attn.k_proj", kvd, C, layer_type, lGroup, &a->K, &any_awq)) ||
-            !check(rc = L.linear(p + "self_attn.v_proj", kvd, C, layer_type, lGroup, &a->V, &any_awq)) ||
-            !check(rc = L.linear(p + "self_attn.o_proj", C, qd, layer_type, lGroup, &a->proj_cat, &any_awq)) ||
-            !check(rc = L.linear(p + "mlp.gate_proj", card.n_ff, C, layer_type, lGroup, &m->gate, &any_awq)) ||
-            !check(rc = L.linear(p + "mlp.up_proj", card.n_ff, C, layer_type, lGroup, &m->up, &any_awq)) ||
-            !check(rc = L.linear(p + "mlp.down_proj", C, card.n_ff, layer_type, lGroup, &m->down, &any_awq)))
+            !check(rc = L.linear(p + "self_attn.q_proj", qd, C, layer_type, lGroupL, &a->Q, &any_awq)) ||
+            !check(rc = L.linear(p + "self_attn.k_proj", kvd, C, layer_type, lGroupL, &a->K, &any_awq)) ||
+            !check(rc = L.linear(p + "self_attn.v_proj", kvd, C, layer_type, lGroupL, &a->V, &any_awq)) ||
+            !check(rc = L.linear(p + "self_attn.o_proj", C, qd, layer_type, lGroupL, &a->proj_cat, &any_awq)) ||
+            !check(rc = L.linear(p + "mlp.gate_proj", card.n_ff, C, layer_type, lGroupL, &m->gate, &any_awq)) ||
+            !check(rc = L.linear(p + "mlp.up_proj", card.n_ff, C, layer_type, lGroupL, &m->up, &any_awq)) ||
+            !check(rc = L.linear(p + "mlp.down_proj", C, card.n_ff, layer_type, lGroupL, &m->down, &any_awq)))
             return bail(rc, err);
     }
     if (any_awq) f->fuse_level = 0;  // the AutoAWQ layout has its own mat-vec (kf_linear only): one launch per reference kernel
@@ -613,7 +627,10 @@ int kfh_st_read(void* h, const char* name, void* out, uint64_t nbytes) {
 // HF directory (config.json + model.safetensors[.index.json]) -> Fish handle usable with every kfh_* entry; NULL + *rc on failure
 void* kfh_load_hf(const char* dir, int device, void* stream, int layer_type, int head_type, int lGroup, int max_seq, int* rc) {
     std::string err;
-    Fish* f = LoadHF(dir, device, stream, (typNUMBER)layer_type, (typNUMBER)head_type, lGroup > 0 ? lGroup : 128, max_seq, rc, err);
+    // 1000 (koifish_amd.lib.NF4) is not a typNUMBER: "Q4 with the normal-float quant card" (QUANT_MODE::RTNf)
+    const bool lnf = layer_type == 1000, hnf = head_type == 1000;
+    Fish* f = LoadHF(dir, device, stream, lnf ? typNUMBER::Q4 : (typNUMBER)layer_type, hnf ? typNUMBER::Q4 : (typNUMBER)head_type, lGroup > 0 ? lGroup : 128, max_seq, rc, err,
+                     lnf, hnf);
     if (!f) g_st_err = err;
     return f;
 }

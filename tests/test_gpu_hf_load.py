@@ -49,7 +49,8 @@ def write_hf(path, cfg, raw, dtype=torch.bfloat16, sharded=False):
         (path / "model.safetensors.index.json").write_text(json.dumps({"metadata": {}, "weight_map": wm}))
 
 
-@pytest.mark.parametrize("layer_type,head_type,sharded", [(L.Q4, L.BF16, False), (L.BF16, L.BF16, True), (L.F8E5M2, L.BF16, False), (L.BOOL1, L.Q4, False)])
+@pytest.mark.parametrize("layer_type,head_type,sharded", [(L.Q4, L.BF16, False), (L.BF16, L.BF16, True), (L.F8E5M2, L.BF16, False), (L.BOOL1, L.Q4, False),
+                                                            (L.NF4, L.BF16, False), (L.NF4, L.NF4, True)])
 def test_hf_directory_builds_the_same_model(tmp_path, layer_type, head_type, sharded):
     cfg = synth.CONFIGS["tiny"]
     raw = synth.raw_weights_numpy(cfg, 4321, w_std=0.1)
