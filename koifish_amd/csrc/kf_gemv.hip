@@ -522,10 +522,24 @@ __global__ void __launch_bounds__(256) argmax_finish_kernel(const float* val, co
                                                             int32_t* d_tokens_out) {
     float bv = -__builtin_inff();
     int bi = 0x7fffffff;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        float v = val[i];
-        int ix = idx[i];
-        if (v > bv || (v == bv && ix < bi)) bv = v, bi = ix;
+    // all of a thread's partials are requested before the first compare (n <= KF_MAX_ARGMAX_PARTIALS = 16 per thread): one memory latency instead of 16
+    constexpr int PER = KF_MAX_ARGMAX_PARTIALS / 256;
+    float v[PER];
+    int ix[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int i = threadIdx.x + k * 256;
+        const int ic = i < n ? i : 0;
+        v[k] = val[ic], ix[k] = idx[ic];
+        if (i >= n) v[k] = -__builtin_inff(), ix[k] = 0x7fffffff;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; k++)
+        if (v[k] > bv || (v[k] == bv && ix[k] < bi)) bv = v[k], bi = ix[k];
+    for (int i = threadIdx.x + PER * 256; i < n; i += blockDim.x) { /* never taken: n <= KF_MAX_ARGMAX_PARTIALS */
+        const float w = val[i];
+        const int jx = idx[i];
+        if (w > bv || (w == bv && jx < bi)) bv = w, bi = jx;
     }
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) {
