@@ -211,6 +211,63 @@ struct BlockDot<FMT_Q1> {
     }
 };
 
+// 1-bit through a table: a weight byte (8 weights) indexes 16 v_perm_b32 selector bytes in LDS (256 entries x 16 B, filled by the workgroup
+// before the x prologue's barrier); each selector dword picks {w0, w1} for a weight pair out of the register (w1 << 16 | w0).  The same weights,
+// pairs and summation order as BlockDot<FMT_Q1> -- every output bit is equal -- at 1 ds_read_b128 + 4 v_perm + 4 dot2 per 8 weights instead of
+// ~32 VALU instructions.
+template <>
+struct BlockDot<FMT_Q1T> {
+    static constexpr int EPB = 128, XCH = 16;
+    static constexpr bool HAS_GAMA = true;
+    __device__ static __forceinline__ float run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, float acc) {
+        const uint32_t r = pack_bf16x2(fmaf(0.0f, step, nb), fmaf(1.0f, step, nb));
+        const uint32_t ww = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero); /* bytes 0,1 = dequant(0); bytes 2,3 = dequant(1) */
+        const u32x4* tab = xs + nBlk * 16 + 16;                            /* behind x (K * 2 bytes) and the 256-byte reduction scratch */
+        const uint32_t dw[4] = {w.w, w.z, w.y, w.x};                       /* dword3 holds elements 0..31, element 0 = bit 31 */
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const u32x4 S = tab[(dw[d] >> (24 - 8 * c)) & 0xffu];
+                const u32x4 X = xs[(4 * d + c) * nBlk + col];
+                acc = dot2_bf16(__builtin_amdgcn_perm(0u, ww, S.x), X.x, acc);
+                acc = dot2_bf16(__builtin_amdgcn_perm(0u, ww, S.y), X.y, acc);
+                acc = dot2_bf16(__builtin_amdgcn_perm(0u, ww, S.z), X.z, acc);
+                acc = dot2_bf16(__builtin_amdgcn_perm(0u, ww, S.w), X.w, acc);
+            }
+        return acc;
+    }
+};
+
+// 2-bit the same way: a weight byte (4 weights) indexes 8 selector bytes (256 entries x 8 B); the four dequantised levels sit in two registers
+// {dequant(1) << 16 | dequant(0)}, {dequant(3) << 16 | dequant(2)} that v_perm_b32 reads as one 8-byte source.  1 ds_read_b64 + 2 v_perm + 2 dot2
+// per 4 weights instead of ~22 VALU instructions; weights, pairs and summation order are those of BlockDot<FMT_Q2>.
+template <>
+struct BlockDot<FMT_Q2T> {
+    static constexpr int EPB = 64, XCH = 8;
+    static constexpr bool HAS_GAMA = true;
+    __device__ static __forceinline__ float run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, float acc) {
+        uint32_t r = pack_bf16x2(fmaf(0.0f, step, nb), fmaf(1.0f, step, nb));
+        const uint32_t T01 = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
+        r = pack_bf16x2(fmaf(2.0f, step, nb), fmaf(3.0f, step, nb));
+        const uint32_t T23 = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
+        const u32x2* tab = reinterpret_cast<const u32x2*>(xs + nBlk * 8 + 16); /* behind x (K * 2 bytes) and the 256-byte reduction scratch */
+        const uint32_t dw[4] = {w.w, w.z, w.y, w.x};                           /* dword3 holds elements 0..15, element 0 = bits 31..30 */
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const u32x4 Xa = xs[(2 * d) * nBlk + col], Xb = xs[(2 * d + 1) * nBlk + col];
+            const uint32_t xw[8] = {Xa.x, Xa.y, Xa.z, Xa.w, Xb.x, Xb.y, Xb.z, Xb.w};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const u32x2 S = tab[(dw[d] >> (24 - 8 * c)) & 0xffu];
+                acc = dot2_bf16(__builtin_amdgcn_perm(T23, T01, S.x), xw[2 * c], acc);
+                acc = dot2_bf16(__builtin_amdgcn_perm(T23, T01, S.y), xw[2 * c + 1], acc);
+            }
+        }
+        return acc;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------ kernel
 // sum over the 2^lg lanes of each aligned lane group (lg wave-uniform); every lane of the group gets the sum.
 // DPP inside a 16-lane row (quad_perm xor1, xor2, row_half_mirror, row_mirror), two cross-row swaps above it.
@@ -249,6 +306,18 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave_in_blk = tid >> 6;
     const int nBlk = a.nBlk, iters = a.iters;
+    if constexpr (FMT == FMT_Q2T) { /* selector table: entry B, dword p = bytes {2q, 2q+1, 2q', 2q'+1}, q / q' = the levels of elements 2p, 2p+1 of byte B */
+        uint32_t e[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++) e[p] = 0x01000100u + 0x0202u * ((tid >> (6 - 4 * p)) & 3u) + 0x02020000u * ((tid >> (4 - 4 * p)) & 3u);
+        reinterpret_cast<u32x2*>(xs + nBlk * 8 + 16)[tid] = u32x2{e[0], e[1]};
+    }
+    if constexpr (FMT == FMT_Q1T) { /* selector table: entry B, dword p = bytes {2a, 2a+1, 2b, 2b+1}, a / b = bits 7-2p / 6-2p of B (elements 2p, 2p+1) */
+        uint32_t e[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) e[p] = 0x01000100u + 0x0202u * ((tid >> (7 - 2 * p)) & 1u) + 0x02020000u * ((tid >> (6 - 2 * p)) & 1u);
+        (xs + nBlk * 16 + 16)[tid] = u32x4{e[0], e[1], e[2], e[3]}; /* 256 threads, 256 entries; visible after the prologue's barrier */
+    }
     const int LPR = 1 << a.lpr_log2, RPS = 64 >> a.lpr_log2;
     const int sub = lane >> a.lpr_log2, ll = lane & (LPR - 1);
     const long gwave = (long)blockIdx.x * (blockDim.x >> 6) + wave_in_blk;
@@ -719,9 +788,25 @@ int gemv_launch(hipStream_t st, GemvLaunch& L) {
                 launch_m<FMT_Q4>(a, L.mode, G, grid, smem, st);
             break;
         }
-        case FMT_Q2: launch_m<FMT_Q2>(a, L.mode, G, grid, smem, st); break;
+        case FMT_Q2: {
+            static int q2tab = -2; /* KF_Q2_TAB=0: the arithmetic form (same bits) */
+            if (q2tab == -2) q2tab = getenv("KF_Q2_TAB") ? atoi(getenv("KF_Q2_TAB")) : 1;
+            if (q2tab != 0 && smem + 2048 <= 160 * 1024)
+                launch_m<FMT_Q2T>(a, L.mode, G, grid, smem + 2048, st);
+            else
+                launch_m<FMT_Q2>(a, L.mode, G, grid, smem, st);
+            break;
+        }
         case FMT_Q4R: launch_m<FMT_Q4R>(a, L.mode, G, grid, smem, st); break;
-        default: launch_m<FMT_Q1>(a, L.mode, G, grid, smem, st); break;
+        default: {
+            static int q1tab = -2; /* KF_Q1_TAB=0: the per-bit select form (same bits) */
+            if (q1tab == -2) q1tab = getenv("KF_Q1_TAB") ? atoi(getenv("KF_Q1_TAB")) : 1;
+            if (q1tab != 0 && smem + 4096 <= 160 * 1024)
+                launch_m<FMT_Q1T>(a, L.mode, G, grid, smem + 4096, st);
+            else
+                launch_m<FMT_Q1>(a, L.mode, G, grid, smem, st);
+            break;
+        }
     }
     L.blocks = blocks;
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;

@@ -8,7 +8,9 @@ namespace kf {
 enum {
     FMT_BF16 = 0, FMT_F8 = 1, FMT_Q4 = 2, FMT_Q2 = 3, FMT_Q1 = 4,
     FMT_Q4P = 5, /* 4-bit through the register-table lookup (mat-vec only) */
-    FMT_Q4R = 6  /* 4-bit row codebook (KF_QUANT_ROW_LUT): byte-packed nibbles + 16 bf16 table entries per row */
+    FMT_Q4R = 6, /* 4-bit row codebook (KF_QUANT_ROW_LUT): byte-packed nibbles + 16 bf16 table entries per row */
+    FMT_Q1T = 7, /* 1-bit through an LDS table of v_perm selectors (mat-vec only; bit-identical to FMT_Q1) */
+    FMT_Q2T = 8  /* 2-bit, the same way (bit-identical to FMT_Q2) */
 };
 inline bool is_row_lut(const kf_weight* w) { return w->quant != KF_QUANT_GROUP; } /* any row-wise card (kf_lut.hip); the mat-vec kernel takes Q4 + ROW_LUT only */
 enum { GEMV_PLAIN = 0, GEMV_PAIRED = 1, GEMV_ARGMAX = 2 };

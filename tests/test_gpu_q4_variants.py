@@ -27,10 +27,10 @@ from koifish_amd import lib as L
 ctx = Context(0); dev = ctx.device
 g = torch.Generator(device=dev); g.manual_seed(5)
 h = hashlib.sha256()
-for (m, k) in [(4096, 1024), (1024, 3072), (1000, 2048), (40, 3200), (8192, 5120)]:
+for (m, k) in [(4096, 1024), (1024, 3072), (1000, 2048), (40, 3200 if sys.argv[1] == 'Q4' else 3072), (8192, 5120)]:
     W = (torch.randn(m, k, device=dev, generator=g) * 0.02).to(torch.bfloat16)
     x = torch.randn(k, device=dev, generator=g).to(torch.bfloat16)
-    w = ctx.quantize(W, L.Q4)
+    w = ctx.quantize(W, getattr(L, sys.argv[1]))
     y = ctx.linear(w, x)
     a = ctx.norm_gateup_swiglu(x, torch.ones(k, device=dev, dtype=torch.bfloat16), w, w)
     lg, am = ctx.lm_head(w, x)
@@ -42,13 +42,15 @@ print("DIGEST", h.hexdigest())
 """ % ROOT
 
 
-def test_table_form_is_bit_identical_to_the_arithmetic_form():
-    """the default (register-table lookup, BlockDot<FMT_Q4P>) pairs and sums the weights exactly as the fma / round / subtract / round form does:
-    every output bit of the plain, paired-SwiGLU and arg-max launches is the same"""
+@pytest.mark.parametrize("knob,type_name", [("KF_Q4_PERM", "Q4"), ("KF_Q2_TAB", "T_SIGN"), ("KF_Q1_TAB", "BOOL1")])
+def test_table_form_is_bit_identical_to_the_arithmetic_form(knob, type_name):
+    """the defaults -- 4-bit: register-table lookup (BlockDot<FMT_Q4P>); 2-bit / 1-bit: v_perm selectors from an LDS table indexed by a weight byte
+    (BlockDot<FMT_Q2T> / <FMT_Q1T>) -- form the same weights, pair them and sum them exactly as the per-weight arithmetic forms do: every output bit of
+    the plain, paired-SwiGLU and arg-max launches is the same"""
     digests = []
     for v in ("0", "1"):
-        env = dict(os.environ, KF_Q4_PERM=v)
-        r = subprocess.run([sys.executable, "-c", _DIGEST], env=env, capture_output=True, text=True, timeout=600)
+        env = dict(os.environ, **{knob: v})
+        r = subprocess.run([sys.executable, "-c", _DIGEST, type_name], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         digests.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1])
     assert digests[0] == digests[1]
