@@ -64,8 +64,11 @@ struct BlockDot<FMT_BF16> {
 // F8E5M2: byte i of the block = element i; value = half(byte << 8) (g_float.hpp:355-383), exact in bf16.
 __device__ __forceinline__ float f8_to_f32(uint32_t hbits) { return half_bits_to_f32(hbits); }
 __device__ __forceinline__ float dot_f8_dword(uint32_t D, uint32_t X0, uint32_t X1, float acc) {
-    uint32_t w0 = pack_bf16x2(f8_to_f32((D << 8) & 0xff00u), f8_to_f32(D & 0xff00u));
-    uint32_t w1 = pack_bf16x2(f8_to_f32((D >> 8) & 0xff00u), f8_to_f32((D >> 16) & 0xff00u));
+    // gfx950 converts two OCP E5M2 bytes to fp32 in one instruction (v_cvt_pk_f32_bf8): the same values as half(byte << 8), exactly
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_bf8((int)D, false), hi = __builtin_amdgcn_cvt_pk_f32_bf8((int)D, true);
+    uint32_t w0 = pack_bf16x2(lo.x, lo.y);
+    uint32_t w1 = pack_bf16x2(hi.x, hi.y);
     acc = dot2_bf16(w0, X0, acc);
     acc = dot2_bf16(w1, X1, acc);
     return acc;

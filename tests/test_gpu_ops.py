@@ -313,3 +313,24 @@ def test_awq_layout_dequant_and_linear(ctx, O, shape):
     yy = torch.zeros(n_out, dtype=torch.bfloat16, device=ctx.device)
     yp = (C.c_void_p * 1)(yy.data_ptr())
     assert ctx.hip.kf_norm_linear(ctx.h, bf16_t(x, ctx.device).data_ptr(), None, 1e-6, 1, wp, yp, None, 0, None) == -1000
+
+
+def test_f8e5m2_matvec_every_byte_value(ctx, O):
+    """the f8 mat-vec converts with gfx950's packed E5M2 -> fp32 instruction: every finite byte value (subnormals included) must come out as
+    half(byte << 8) does in the oracle -- row r holds byte r in its first column and x = e0, so y[r] is that weight"""
+    k = 32
+    w = np.zeros((256, k), dtype=np.uint8)
+    w[:, 0] = np.arange(256, dtype=np.uint8)
+    w[:, 1:] = 0x3C                      # 1.0: multiplied by x = 0
+    ow = O.QWeight(O.F8E5M2, 256, k, w.reshape(-1))
+    dw = ctx.upload_blob(L.F8E5M2, 256, k, ow.blob())
+    x = np.zeros(k, dtype=np.float32)
+    x[0] = 1.0
+    xb = O.f32_to_bf16(x)
+    y = u16(ctx.linear(dw, bf16_t(xb, ctx.device)))
+    ref = O.linear(ow, xb)
+    finite = (np.arange(256) & 0x7C) != 0x7C
+    assert np.array_equal(y[finite], ref[finite])
+    nz = finite & (np.arange(256) != 0x80)   # byte 0x80 is -0: the dot product 0 + (-0 * 1) is +0 on both sides
+    assert np.array_equal(y[nz], O.dequant(ow)[nz, 0])
+    assert y[0x80] == 0x0000 and O.bf16_to_f32(y[0x01:0x02])[0] == 2.0 ** -16   # the smallest subnormal
