@@ -96,12 +96,11 @@ __device__ __forceinline__ u32x4 frag_q1(uint32_t b, uint32_t w0, uint32_t w1) {
 }
 // 8 f8e5m2 bytes (element i = byte i): value = half(byte << 8), exact in bf16
 __device__ __forceinline__ u32x4 frag_f8(uint32_t D0, uint32_t D1) {
-    u32x4 o;
-    o.x = pack_bf16x2(half_bits_to_f32((D0 << 8) & 0xff00u), half_bits_to_f32(D0 & 0xff00u));
-    o.y = pack_bf16x2(half_bits_to_f32((D0 >> 8) & 0xff00u), half_bits_to_f32((D0 >> 16) & 0xff00u));
-    o.z = pack_bf16x2(half_bits_to_f32((D1 << 8) & 0xff00u), half_bits_to_f32(D1 & 0xff00u));
-    o.w = pack_bf16x2(half_bits_to_f32((D1 >> 8) & 0xff00u), half_bits_to_f32((D1 >> 16) & 0xff00u));
-    return o;
+    // v_cvt_pk_f32_bf8 (gfx950, OCP E5M2): two bytes -> two fp32, the same values as half(byte << 8)
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_bf8((int)D0, false), b = __builtin_amdgcn_cvt_pk_f32_bf8((int)D0, true);
+    const f32x2_t c = __builtin_amdgcn_cvt_pk_f32_bf8((int)D1, false), d = __builtin_amdgcn_cvt_pk_f32_bf8((int)D1, true);
+    return u32x4{pack_bf16x2(a.x, a.y), pack_bf16x2(b.x, b.y), pack_bf16x2(c.x, c.y), pack_bf16x2(d.x, d.y)};
 }
 
 // ---- epilogue: lane holds token (tb*32 + r), rows row_base + 8g + 4h + j
