@@ -1,5 +1,5 @@
 // kf_ops.hip -- the small operators of the decode step and the (load-time) dequant / quantise kernels.
-#include "kf_kernels.h"
+#include "kf_gemm_common.h"
 
 namespace kf {
 
@@ -342,11 +342,14 @@ __device__ __forceinline__ void dequant_block(int fmt, u32x4 w, float step, floa
     const uint32_t d[4] = {w.w, w.z, w.y, w.x}; /* d[0] = first elements of a Packed128 */
     if (fmt == FMT_BF16) {
         *reinterpret_cast<u32x4*>(out) = w;
-    } else if (fmt == FMT_F8) {
-        const uint32_t e[4] = {w.x, w.y, w.z, w.w};
-        for (int k = 0; k < 16; k++) out[k] = f2bf(half_bits_to_f32(((e[k >> 2] >> (8 * (k & 3))) & 0xffu) << 8));
-    } else if (fmt == FMT_Q4) {
-        for (int k = 0; k < 32; k++) out[k] = f2bf(dq(step, zero, (float)((int)((d[k >> 3] >> (28 - 4 * (k & 7))) & 0xFu) - qBias)));
+    } else if (fmt == FMT_F8) { /* 16 bytes -> two 16-byte stores (the tile kernels' conversion: v_cvt_pk_f32_bf8) */
+        u32x4* o = reinterpret_cast<u32x4*>(out);
+        o[0] = frag_f8(w.x, w.y), o[1] = frag_f8(w.z, w.w);
+    } else if (fmt == FMT_Q4) { /* 32 weights -> four 16-byte stores; frag_q4 forms step * (q - qBias) with one exact fma, then the two bf16 roundings of dq() */
+        u32x4* o = reinterpret_cast<u32x4*>(out);
+        const float nb = -((float)qBias * step), s16 = step * 0.0625f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) o[k] = frag_q4(d[k], step, s16, nb, zero);
     } else if (fmt == FMT_Q2) {
         for (int k = 0; k < 64; k++) out[k] = f2bf(dq(step, zero, (float)((int)((d[k >> 4] >> (30 - 2 * (k & 15))) & 0x3u) - qBias)));
     } else {
