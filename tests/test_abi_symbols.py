@@ -85,3 +85,26 @@ def test_rope_table_host_matches_libm():
         c, s = O.rope_table(p, 64, 1e6)
         assert np.array_equal(t[p, :, 0], c) and np.array_equal(t[p, :, 1], s)
     assert hip.kf_rope_table_host(None, 5, 64, 1e6) == -20
+
+
+def test_kf_weight_struct_matches_the_ctypes_mirror(tmp_path):
+    """struct kf_weight as the C compiler lays it out (offsets of every field, total size) == koifish_amd.lib.Weight: a field added to the header
+    without the Python mirror (or the other way round) fails here, not as silent garbage in a kernel argument"""
+    from koifish_amd import lib as L
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "kf_abi.h")).read(), flags=re.S)
+    body = re.search(r"typedef struct kf_weight \{(.*?)\} kf_weight;", hdr, flags=re.S).group(1)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            fields += [n.strip().lstrip("*") for n in decl.split(" ", 1)[1].replace("void*", "").replace("kf_bf16*", "").split(",")] if "," in decl \
+                else [decl.split()[-1].lstrip("*")]
+    assert fields == [n for n, _ in L.Weight._fields_], (fields, [n for n, _ in L.Weight._fields_])
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "kf_abi.h"\nint main(void) {\n' +
+                   "".join('  printf("%%zu\\n", offsetof(kf_weight, %s));\n' % f for f in fields) + '  printf("%zu\\n", sizeof(kf_weight));\n  return 0;\n}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    nums = [int(x) for x in subprocess.check_output([str(exe)]).decode().split()]
+    assert nums[:-1] == [getattr(L.Weight, f).offset for f in fields]
+    assert nums[-1] == C.sizeof(L.Weight)
