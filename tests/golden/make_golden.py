@@ -4,7 +4,8 @@
 The reference holds no golden vector for this path and cannot be built or imported here, so
 these fixtures pin the ORACLE (a regression anchor for oracle and kernels alike), not the reference.  Inputs are
 seeded numpy draws; everything the tests need is stored (inputs and expected outputs).
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py            # everything
+    python tests/golden/make_golden.py nf4        # only the fixtures whose name contains "nf4" (the others keep their bytes)
 """
 import os
 import sys
@@ -22,19 +23,30 @@ from oracle import oracle as O  # noqa: E402
 
 
 def main():
+    only = sys.argv[1] if len(sys.argv) > 1 else ""
     rng = np.random.default_rng(2024)
     m, k = 48, 512
     w = O.f32_to_bf16(rng.normal(0, 0.02, size=(m, k)).astype(np.float32))
     x = O.f32_to_bf16(rng.normal(0, 1, size=k).astype(np.float32))
     ow = O.quantize(w, m, k, O.Q4)
-    np.savez_compressed(os.path.join(HERE, "q4_linear.npz"), w=w, x=x, m=m, k=k, packed=ow.data.view(np.uint8), zero=ow.zero, step=ow.step,
-                        dequant=O.dequant(ow).reshape(-1), y=O.linear(ow, x))
+    if only in "q4_linear":
+        np.savez_compressed(os.path.join(HERE, "q4_linear.npz"), w=w, x=x, m=m, k=k, packed=ow.data.view(np.uint8), zero=ow.zero, step=ow.step,
+                            dequant=O.dequant(ow).reshape(-1), y=O.linear(ow, x))
+    if only in "nf4_linear":   # the row-codebook storage (GeQuant::RT_NormalF): same inputs, 4- and 3-bit normal-float forms
+        o4, o3 = O.quantize_nf4(w, m, k), O.quantize_nf3(w, m, k)
+        np.savez_compressed(os.path.join(HERE, "nf4_linear.npz"), w=w, x=x, m=m, k=k, packed4=o4.data, lut4=o4.lut, dequant4=O.dequant(o4).reshape(-1), y4=O.linear(o4, x),
+                            packed3=o3.data, lut3=o3.lut, dequant3=O.dequant(o3).reshape(-1), y3=O.linear(o3, x))
     # w_std 0.1 instead of the benchmark's 0.02: with 0.02 a free-running greedy decode of a random tied model collapses onto one
     # token, which would make "ids match" a vacuous check; at 0.1 the generated ids keep changing.
     for name, cfg_name, lt, ht, n_prompt, n_new, w_std in (("tiny_q4", "tiny", L.Q4, L.BF16, 16, 32, 0.1), ("tiny_bool1", "tiny", L.BOOL1, L.BF16, 8, 16, 0.1),
-                                                           ("small_q4", "small", L.Q4, L.BF16, 16, 16, 0.1), ("tiny_q4_std002", "tiny", L.Q4, L.BF16, 16, 16, 0.02)):
+                                                           ("small_q4", "small", L.Q4, L.BF16, 16, 16, 0.1), ("tiny_q4_std002", "tiny", L.Q4, L.BF16, 16, 16, 0.02),
+                                                           ("tiny_nf4", "tiny", L.NF4, L.NF4, 16, 24, 0.1)):
+        if only not in name:
+            continue
         cfg = dict(synth.CONFIGS[cfg_name])
-        seed = 1234
+        # tiny_nf4: with seed 1234 the 8th free-running step has its two best logits one bf16 ulp apart (4.9375 / 4.90625), so fp32 summation order
+        # decides the id there (within the logit tolerance, but useless as an id fixture); 1235 has no such near-tie in its 24 steps
+        seed = 1235 if name == "tiny_nf4" else 1234
         raw = synth.raw_weights_numpy(cfg, seed, w_std=w_std)
         om = oracle_model(cfg, raw, lt, ht)
         prompt = prompt_ids(cfg, n_prompt)

@@ -93,7 +93,7 @@ def test_bucket_boundaries_and_long_context():
     gm.close()
 
 
-@pytest.mark.parametrize("name", ["tiny_q4", "tiny_bool1", "small_q4", "tiny_q4_std002"])
+@pytest.mark.parametrize("name", ["tiny_q4", "tiny_bool1", "small_q4", "tiny_q4_std002", "tiny_nf4"])
 def test_golden_ids_on_gpu(name):
     """the committed fixtures (tests/golden, made by the oracle): the HIP path must reproduce the ids and the first logits"""
     import os

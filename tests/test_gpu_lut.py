@@ -250,3 +250,21 @@ def test_row_forms_refusals(ctx, O):
     d = ctx.upload_lut_blob(m, k, _blob(q2, m, k), bits=2).desc()
     src = torch.zeros(m, k, dtype=torch.bfloat16, device=ctx.device)
     assert ctx.hip.kf_quantize(ctx.h, C.byref(d), C.c_void_p(src.data_ptr()), 0) == -701          # RT_NormalF asserts bits == 4 || 3
+
+
+def test_golden_normal_float_fixture_on_gpu(ctx, O):
+    """tests/golden/nf4_linear.npz (made by the oracle, committed): the device quantiser must reproduce its streams and tables, the mat-vec its outputs"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nf4_linear.npz"))
+    m, k = int(g["m"]), int(g["k"])
+    wt = bf16_t(g["w"], ctx.device).view(m, k)
+    for bits in (4, 3):
+        dw = ctx.quantize_nf4(wt, bits=bits)
+        assert np.array_equal(dw.blob[:dw.szData].cpu().numpy(), g["packed%d" % bits])
+        assert np.array_equal(u16(dw.lut()), g["lut%d" % bits])
+        assert np.array_equal(u16(ctx.dequant(dw)).reshape(-1), g["dequant%d" % bits])
+        y = torch.zeros(m, dtype=torch.bfloat16, device=ctx.device)
+        xt = bf16_t(g["x"], ctx.device)
+        d = dw.desc()
+        L.check(ctx.hip.kf_linear(ctx.h, C.byref(d), C.c_void_p(xt.data_ptr()), C.c_void_p(y.data_ptr()), None, 1, 1.0, 0.0, 0, None), "kf_linear")
+        assert ulp_diff_bf16(u16(y), g["y%d" % bits]).max() <= 1

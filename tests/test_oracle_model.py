@@ -79,7 +79,17 @@ def test_golden_quant_and_linear():
     assert np.array_equal(O.linear(ow, g["x"]), g["y"])
 
 
-@pytest.mark.parametrize("name", ["tiny_q4", "tiny_bool1", "small_q4", "tiny_q4_std002"])
+def test_golden_normal_float_quant_and_linear():
+    g = _load("nf4_linear.npz")
+    m, k = int(g["m"]), int(g["k"])
+    for bits in (4, 3):
+        ow = O.quantize_nf4(g["w"], m, k, bits=bits)
+        assert np.array_equal(ow.data, g["packed%d" % bits]) and np.array_equal(ow.lut, g["lut%d" % bits])
+        assert np.array_equal(O.dequant(ow).reshape(-1), g["dequant%d" % bits])
+        assert np.array_equal(O.linear(ow, g["x"]), g["y%d" % bits])
+
+
+@pytest.mark.parametrize("name", ["tiny_q4", "tiny_bool1", "small_q4", "tiny_q4_std002", "tiny_nf4"])
 def test_golden_decode(name):
     g = _load("decode_%s.npz" % name)
     cfg = dict(synth.CONFIGS[str(g["cfg_name"])])
