@@ -313,6 +313,36 @@ int kf_qknorm_rope_batch(kf_ctx* ctx, kf_bf16* q, kf_bf16* k, const kf_bf16* wq_
 int kf_attn_prefill(kf_ctx* ctx, const kf_bf16* q, const kf_bf16* kcache, const kf_bf16* vcache, kf_bf16* out, int pos0, int n_tok, int64_t q_stride,
                     int n_head, int n_kv, int hd, int kv_stride);
 
+/* ---- the decode step's layer loop as ONE persistent launch (kf_engine.hip).  Replaces, for all layers of one token, the neuron walk of
+ * Fish::ForwardOnRLS (gLLM.cpp:755-771) over SelfAttention::cuInfer (QKV.cu:617-702) and FFN::cuInfer (NeuronFuse.cu:615-656): the same
+ * arithmetic as kf_norm_linear -> kf_attn_block -> kf_linear -> kf_norm_gateup_swiglu -> kf_linear per layer (every output bit equal), with the
+ * five launches per layer turned into phases of one resident kernel that hand their vectors over through tagged granules in `workspace`.
+ * One workgroup per CU; the launch must have the GPU's CUs to itself (every poll is bounded: a launch that cannot become fully resident sets the
+ * engine's error word instead of hanging; kf_engine_check reads it).  w[7] = q k v o gate up down; all layers the same shapes and storage.
+ * kf_engine_step returns KF_ENGINE_NOT_SERVED (1) when the position bound needs an attention slicing the engine does not restate: the caller
+ * then issues the per-layer calls.  x_in / x_out: plain bf16 [dim] (the embedding row in, the residual stream after the last layer out; they may
+ * alias).  pos_bound bounds the position as in the other decode entries (graph replay); the position itself is d_state[1]. */
+typedef struct kf_engine kf_engine;
+typedef struct kf_engine_layer {
+    kf_weight w[7];
+    const kf_bf16 *norm_in, *norm_post, *q_norm, *k_norm; /* q_norm / k_norm may be NULL */
+    kf_bf16 *kcache, *vcache;                            /* layer base; row t at t*kv_stride elements */
+} kf_engine_layer;
+typedef struct kf_engine_desc {
+    int32_t n_layer, dim, n_head, n_kv, head_dim, ffn, kv_stride, reserved_;
+    float rms_eps, qk_eps;
+    const float* rope_table;
+    const kf_engine_layer* layers; /* HOST array [n_layer] of device pointers */
+} kf_engine_desc;
+#define KF_ENGINE_NOT_SERVED 1
+size_t kf_engine_workspace_bytes(const kf_engine_desc* desc);
+/* workspace: device memory, 256-byte aligned, kf_engine_workspace_bytes(desc) bytes, owned by the caller, initialised here.
+ * KF_UNSUPPORTED_DATATYPE: shapes / storage outside what the engine serves (the per-layer calls remain). */
+int kf_engine_create(kf_ctx* ctx, const kf_engine_desc* desc, void* workspace, size_t workspace_bytes, kf_engine** out);
+int kf_engine_step(kf_ctx* ctx, kf_engine* e, const kf_bf16* x_in, kf_bf16* x_out, const int32_t* d_state, int pos_bound);
+int kf_engine_check(kf_ctx* ctx, kf_engine* e); /* synchronises; KF_INTERNAL_ERR when a hand-off poll has timed out since creation */
+int kf_engine_destroy(kf_engine* e);
+
 #ifdef __cplusplus
 }
 #endif

@@ -845,4 +845,45 @@ int kf_adamw(kf_ctx* c, kf_bf16* params, kf_bf16* grads, void* gm, void* gv, siz
                          weight_decay, grad_scale, seed, d_status));
 }
 
+// ---- persistent decode engine
+struct kf_engine {
+    kf::EngineHost* h;
+};
+size_t kf_engine_workspace_bytes(const kf_engine_desc* d) { return d ? kf::engine_ws_bytes(d) : 0; }
+int kf_engine_create(kf_ctx* c, const kf_engine_desc* d, void* ws, size_t ws_bytes, kf_engine** out) {
+    CHKCTX(c);
+    if (!d || !ws || !out) return fail(KF_INVALID_ARGS, "kf_engine_create: null argument");
+    if (c->capturing) return fail(KF_INVALID_ARGS, "kf_engine_create: not while capturing");
+    kf::EngineHost* h = nullptr;
+    const int rc = kf::engine_build(d, ws, ws_bytes, c->stream, &h);
+    if (rc != KF_OK) return fail(rc, "kf_engine_create: %s", rc == KF_UNSUPPORTED_DATATYPE ? "shapes / storage not served by the engine" : "bad arguments or HIP failure");
+    kf_engine* e = new kf_engine();
+    e->h = h;
+    *out = e;
+    return KF_OK;
+}
+int kf_engine_step(kf_ctx* c, kf_engine* e, const kf_bf16* x_in, kf_bf16* x_out, const int32_t* d_state, int pos_bound) {
+    CHKCTX(c);
+    if (!e || !e->h) return fail(KF_INVALID_ARGS, "kf_engine_step: null engine");
+    const int rc = kf::engine_step(e->h, c->stream, x_in, x_out, d_state, pos_bound);
+    if (rc < 0) return fail(rc, "kf_engine_step failed with %d", rc);
+    return rc;
+}
+int kf_engine_check(kf_ctx* c, kf_engine* e) {
+    CHKCTX(c);
+    if (!e || !e->h) return fail(KF_INVALID_ARGS, "kf_engine_check: null engine");
+    int err = 0;
+    const int rc = kf::engine_error_word(e->h, c->stream, &err);
+    if (rc != KF_OK) return fail(rc, "kf_engine_check: HIP failure");
+    if (err) return fail(KF_INTERNAL_ERR, "kf_engine: a hand-off poll timed out (error word 0x%x): the launch was not fully resident", err);
+    return KF_OK;
+}
+int kf_engine_destroy(kf_engine* e) {
+    if (e) {
+        kf::engine_free(e->h);
+        delete e;
+    }
+    return KF_OK;
+}
+
 }  // extern "C"

@@ -1,0 +1,905 @@
+// kf_engine.hip -- the decode step's layer loop as ONE persistent launch (gfx950 / wave64).
+//
+// Replaces the per-neuron walk of Fish::ForwardOnRLS (gLLM.cpp:755-771) over SelfAttention::cuInfer (QKV.cu:617-702) and
+// FFN::cuInfer (NeuronFuse.cu:615-656) for all layers of one token: what was 5 dependent launches per layer (kf_norm_linear,
+// kf_attn_block, kf_linear, kf_norm_gateup_swiglu, kf_linear) becomes 6 phases inside one kernel whose workgroups stay resident,
+//
+//   P1 [RMSNorm + Q,K,V]  P2 [q/k-norm + RoPE + attention slice]  P3 [slice merge]  P4 [o_proj + residual]
+//   P5 [RMSNorm + gate/up + SwiGLU]  P6 [down_proj + residual]
+//
+// because on this chip a dependent launch boundary plus the setup and first HBM miss of the next kernel costs ~3 us while a layer's
+// 8.4 MB of weights stream in ~1.3 us (scratch/ub_overlap.hip).  One workgroup of 16 waves per CU:
+//
+//   * wave 15 ("poller") does nothing but wait for the phase's input vector and stage it into LDS.  Producers publish every output
+//     as a tagged granule -- one aligned 4-byte {bf16 value, 16-bit generation} (attention partials: 8-byte {fp32, 32-bit generation})
+//     written by ONE sc1 (write-through) store -- and the poller sweeps the granules with sc1 loads, all loads of a sweep in flight,
+//     until every tag equals the generation it expects: the data is the flag (MI355X_MICROARCH.md "Valid forms", R2).  No counters,
+//     no fences, no grid barrier; nothing depends on dispatch order or placement, only on all workgroups being resident
+//     (grid <= number of CUs, one 1024-thread workgroup each).
+//   * waves 0..14 hold the phase's 16-byte weight blocks in registers -- requested one phase ahead, so HBM latency is off the chain --
+//     and multiply when the barrier behind the poller's staging opens.  The arithmetic is the mat-vec kernel's (kf_gemv_blocks.h:
+//     same lanes per row, same per-lane chain, same DPP tree) and the attention kernel's (kf_attn_common.h; same slices, same
+//     4-wave key interleave, same merge order), so every output bit equals the multi-launch path's.
+//
+// A workgroup polls a buffer only when it has work that needs it: then every reader of generation g has finished before any
+// producer of generation g+1 can have its own inputs complete, and buffers are reused across layers without a second handshake.
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "kf_attn_common.h"
+#include "kf_gemv_blocks.h"
+
+namespace kf {
+
+constexpr int ENG_MAXLD = 16;         /* 1 KiB granule pieces (256 values) per sweep: vectors up to 4096 */
+constexpr int ENG_SPIN_MAX = 1 << 17; /* sweeps before a poll gives up (~0.1 s): sets the error word, never hangs */
+
+struct EngMat {
+    const u32x4* w;
+    const uint16_t* zero;
+    const uint16_t* step;
+};
+struct EngLayer {
+    EngMat m[7]; /* q k v o gate up down */
+    const uint16_t *norm_in, *norm_post, *norm_q, *norm_k;
+    uint16_t *kcache, *vcache; /* layer base */
+};
+struct EngPlan { /* one mat-vec phase: the geometry gemv_launch would pick for the same matrices */
+    int K, nBlk, lpr_log2, iters, gshift, njobs;
+    int M[3], slot0[3], qBias[3];
+    int total_slots, spg; /* slots per workgroup (contiguous) */
+    int pad_[3];
+};
+struct EngArgs {
+    const EngLayer* layers;
+    const EngPlan* plans; /* device copy of the four plans: P1, P4, P5, P6 */
+    int n_layer, n_wg;
+    int dim, q_dim, kv_dim, ffn, n_head, n_kv, hd, kv_stride;
+    float eps, qk_eps;
+    const float* rope_table;
+    const int32_t* d_state; /* {token, pos} */
+    const uint16_t* x_in;   /* plain bf16 [dim]: the embedding row */
+    uint16_t* x_out;        /* plain bf16 [dim]: the residual stream after the last layer */
+    uint32_t *xA, *qkv, *ao, *xB, *act; /* granule buffers */
+    unsigned long long* part;          /* [n_head][nsp][hd + 4] 8-byte granules */
+    int* ws;                           /* [0] epoch, [1] error word */
+    int nsp, chunk, merge_e;           /* attention slices of this launch's position bound; merge elements per workgroup */
+    int lds_xs_bytes;                  /* bytes of one x staging buffer */
+    int spg[4], nslots[4], nblk[4];    /* per phase (P1, P4, P5, P6): slots per workgroup, slots in all, blocks per row */
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t eng_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void st_gran(uint32_t* p, uint32_t tag16, uint16_t v) {
+    __hip_atomic_store(p, (tag16 << 16) | (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_gran64(unsigned long long* p, uint32_t gen, float v) {
+    __hip_atomic_store(p, ((unsigned long long)gen << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_gran64(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// tag mismatch bits of one 16-byte piece (4 granules), kept in a vector register: comparing into lane masks would hold an SGPR pair per compare
+__device__ __forceinline__ uint32_t tags_bad(u32x4 g, uint32_t tag) { return ((g.x >> 16) ^ tag) | ((g.y >> 16) ^ tag) | ((g.z >> 16) ^ tag) | ((g.w >> 16) ^ tag); }
+
+// ---- poller: sweep the NLD * 256 granules of a vector until every tag matches, then stage the vector into LDS: xs in the mat-vec's
+// chunk layout [XCH][nBlk] (element e = c*EPB + j*8 + i -> chunk j*nBlk + c), optionally RMS-normalised (rms_norm_kernel,
+// layernorm.cuh:800-847: fp64 sum of squares, (x*mul)*w, one bf16 store), and the raw vector in natural order into xraw (the residual
+// the phase after next adds).  Lane l of load r owns elements 4*(64r + l) .. +3.  PLAIN: the vector is plain bf16 written by an
+// earlier launch (layer 0's embedding row).  Straight-line code: the vector lengths are template parameters of the kernel.
+template <int XCH, int NLD, bool NORM, bool PLAIN>
+__device__ __forceinline__ void eng_poll_stage(const uint32_t* gsrc, const uint16_t* plain, uint32_t tag, int nBlk, const uint16_t* norm_w, float eps, u32x4* xs,
+                                               uint16_t* xraw, int lane, int* ws, bool& dead) {
+    constexpr int n = NLD * 256;
+    uint32_t p0[NLD], p1[NLD], w0[NLD], w1[NLD];
+    if (NORM) { /* constants: requested in front of the sweep */
+#pragma unroll
+        for (int r = 0; r < NLD; r++) {
+            const u32x2 t = *reinterpret_cast<const u32x2*>(norm_w + 4 * (r * 64 + lane));
+            w0[r] = t.x, w1[r] = t.y;
+        }
+    }
+    if (PLAIN) {
+#pragma unroll
+        for (int r = 0; r < NLD; r++) {
+            const u32x2 t = *reinterpret_cast<const u32x2*>(plain + 4 * (r * 64 + lane));
+            p0[r] = t.x, p1[r] = t.y;
+        }
+    } else {
+        const __amdgpu_buffer_rsrc_t rs = eng_rsrc(gsrc, (uint32_t)n * 4u);
+        u32x4 g[NLD];
+        for (int spins = 0;; spins++) {
+            uint32_t bad = 0;
+#pragma unroll
+            for (int r = 0; r < NLD; r++) g[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (r * 64 + lane) * 16, 0, 16 /* sc1 */));
+#pragma unroll
+            for (int r = 0; r < NLD; r++) bad |= tags_bad(g[r], tag);
+            if (__all(bad == 0)) break;
+            if (dead || spins > ENG_SPIN_MAX) {
+                if (!dead && lane == 0) atomicOr(ws + 1, 1);
+                dead = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int r = 0; r < NLD; r++) p0[r] = (g[r].x & 0xffffu) | (g[r].y << 16), p1[r] = (g[r].z & 0xffffu) | (g[r].w << 16);
+    }
+    float mul = 1.0f;
+    if (NORM) {
+        double ss = 0.0;
+#pragma unroll
+        for (int r = 0; r < NLD; r++) {
+            const double a = (double)bf_lo(p0[r]), b = (double)bf_hi(p0[r]), c = (double)bf_lo(p1[r]), d = (double)bf_hi(p1[r]);
+            ss = fma(a, a, ss), ss = fma(b, b, ss), ss = fma(c, c, ss), ss = fma(d, d, ss);
+        }
+        const double tot = wave_sum_f64_fast(ss);
+        mul = 1.0f / sqrtf(fmaf((float)tot, 1.0f / (float)n, eps));
+    }
+#pragma unroll
+    for (int r = 0; r < NLD; r++) {
+        const int e0 = 4 * (r * 64 + lane);
+        uint32_t o0 = p0[r], o1 = p1[r];
+        if (xraw) *reinterpret_cast<u32x2*>(xraw + e0) = u32x2{o0, o1};
+        if (NORM) {
+            o0 = pack_bf16x2((bf_lo(o0) * mul) * bf_lo(w0[r]), (bf_hi(o0) * mul) * bf_hi(w0[r]));
+            o1 = pack_bf16x2((bf_lo(o1) * mul) * bf_lo(w1[r]), (bf_hi(o1) * mul) * bf_hi(w1[r]));
+        }
+        const int q = e0 >> 3, c = q / XCH, j = q - c * XCH;
+        reinterpret_cast<u32x2*>(xs + j * nBlk + c)[(e0 >> 2) & 1] = u32x2{o0, o1};
+    }
+}
+
+// ---- mat-vec phase pieces (compute waves).  The plan lives in LDS; a wave owns slots s_first, s_first + NCW, ... of its workgroup.
+template <bool PAIRED>
+struct MvStep {
+    u32x4 w, w2;
+    uint16_t st, ze, st2, ze2;
+};
+struct MvWave {
+    int s_first, nsteps;
+};
+template <int NCW>
+__device__ __forceinline__ MvWave mv_wave(const EngPlan* P, int wg, int cw) {
+    MvWave m;
+    const int spg = P->spg, s0 = wg * spg, s1 = min(s0 + spg, P->total_slots);
+    m.s_first = s0 + cw;
+    const int nsl = m.s_first < s1 ? (s1 - m.s_first + NCW - 1) / NCW : 0;
+    m.nsteps = __builtin_amdgcn_readfirstlane(nsl * P->iters);
+    return m;
+}
+struct MvPos { /* where step k of a wave sits */
+    int j, row, col, it;
+    bool ok;
+};
+template <int NCW>
+__device__ __forceinline__ MvPos mv_pos(const EngPlan* P, const MvWave& mw, int k, int lane) {
+    const int lpr_log2 = __builtin_amdgcn_readfirstlane(P->lpr_log2), iters = __builtin_amdgcn_readfirstlane(P->iters);
+    const int LPR = 1 << lpr_log2, RPS = 64 >> lpr_log2, sub = lane >> lpr_log2, ll = lane & (LPR - 1);
+    const int sl = k / iters;
+    MvPos q;
+    q.it = k - sl * iters;
+    const int s = mw.s_first + sl * NCW;
+    int j = 0;
+    if (P->njobs > 1 && s >= P->slot0[1]) j = 1;
+    if (P->njobs > 2 && s >= P->slot0[2]) j = 2;
+    q.j = __builtin_amdgcn_readfirstlane(j);
+    q.row = (s - P->slot0[q.j]) * RPS + sub;
+    q.col = q.it * LPR + ll;
+    q.ok = q.row < P->M[q.j] && q.col < P->nBlk;
+    return q;
+}
+// unconditional loads from clamped (row, column)
+template <int NCW, bool PAIRED, bool GAMA>
+__device__ __forceinline__ MvStep<PAIRED> mv_load(const EngPlan* P, const EngMat* jm, const MvWave& mw, int k, int lane) {
+    const MvPos q = mv_pos<NCW>(P, mw, k, lane);
+    const int M = P->M[q.j], nBlk = P->nBlk;
+    const int row = q.row < M ? q.row : M - 1, col = q.col < nBlk ? q.col : nBlk - 1;
+    const uint32_t bidx = (uint32_t)row * (uint32_t)nBlk + (uint32_t)col;
+    MvStep<PAIRED> o;
+    const EngMat mj = jm[q.j];
+    o.w = ld_nt(mj.w + bidx);
+    o.w2 = o.w, o.st = o.ze = o.st2 = o.ze2 = 0;
+    if (PAIRED) o.w2 = ld_nt(jm[1].w + bidx);
+    if (GAMA) {
+        const uint32_t gi = bidx >> P->gshift;
+        o.st = mj.step[gi], o.ze = mj.zero[gi];
+        if (PAIRED) o.st2 = jm[1].step[gi], o.ze2 = jm[1].zero[gi];
+    }
+    return o;
+}
+// one step of arithmetic; epi(job, row, v, v2) runs in the lane that owns a finished row
+template <int NCW, int FMT, bool PAIRED, typename Epi>
+__device__ __forceinline__ void mv_step(const EngPlan* P, const MvWave& mw, int k, const MvStep<PAIRED>& c, const u32x4* xs, int lane, float& acc, float& acc2, Epi&& epi) {
+    using BD = BlockDot<FMT>;
+    const MvPos q = mv_pos<NCW>(P, mw, k, lane);
+    const int nBlk = __builtin_amdgcn_readfirstlane(P->nBlk), lpr_log2 = __builtin_amdgcn_readfirstlane(P->lpr_log2),
+              iters = __builtin_amdgcn_readfirstlane(P->iters);
+    const int col = q.col < nBlk ? q.col : nBlk - 1;
+    if (q.it == 0) acc = 0.f, acc2 = 0.f;
+    const float st = bf2f(c.st);
+    const float r = BD::run(c.w, xs, col, nBlk, st, bf2f(c.ze), -((float)P->qBias[q.j] * st), acc);
+    acc = q.ok ? r : acc;
+    if (PAIRED) {
+        const float st2 = bf2f(c.st2);
+        const float r2 = BD::run(c.w2, xs, col, nBlk, st2, bf2f(c.ze2), -((float)P->qBias[1] * st2), acc2);
+        acc2 = q.ok ? r2 : acc2;
+    }
+    if (q.it == iters - 1) {
+        const float v = group_sum(acc, lpr_log2);
+        float v2 = 0.f;
+        if (PAIRED) v2 = group_sum(acc2, lpr_log2);
+        if ((lane & ((1 << lpr_log2) - 1)) == 0 && q.row < P->M[q.j]) epi(q.j, q.row, v, v2);
+    }
+}
+// a phase: the first two steps arrive prefetched (the 0.6B shapes need no more), further steps load in line
+template <int NCW, int FMT, bool PAIRED, typename Epi>
+__device__ __forceinline__ void mv_run(const EngPlan* P, const EngMat* jm, const MvWave& mw, const MvStep<PAIRED>& s0, const MvStep<PAIRED>& s1, const u32x4* xs, int lane,
+                                       Epi&& epi) {
+    constexpr bool GAMA = BlockDot<FMT>::HAS_GAMA;
+    float acc = 0.f, acc2 = 0.f;
+    if (mw.nsteps > 0) mv_step<NCW, FMT, PAIRED>(P, mw, 0, s0, xs, lane, acc, acc2, epi);
+    if (mw.nsteps > 1) mv_step<NCW, FMT, PAIRED>(P, mw, 1, s1, xs, lane, acc, acc2, epi);
+    if (mw.nsteps > 2) {
+        MvStep<PAIRED> cur = mv_load<NCW, PAIRED, GAMA>(P, jm, mw, 2, lane);
+        for (int k = 2; k < mw.nsteps; k++) {
+            MvStep<PAIRED> nxt = cur;
+            if (k + 1 < mw.nsteps) nxt = mv_load<NCW, PAIRED, GAMA>(P, jm, mw, k + 1, lane);
+            mv_step<NCW, FMT, PAIRED>(P, mw, k, cur, xs, lane, acc, acc2, epi);
+            cur = nxt;
+        }
+    }
+}
+template <int NCW, int FMT, bool PAIRED>
+__device__ __forceinline__ void mv_prefetch(const EngPlan* P, const EngMat* jm, const MvWave& mw, int lane, MvStep<PAIRED>& s0, MvStep<PAIRED>& s1) {
+    constexpr bool GAMA = BlockDot<FMT>::HAS_GAMA;
+    if (mw.nsteps > 0) s0 = mv_load<NCW, PAIRED, GAMA>(P, jm, mw, 0, lane);
+    if (mw.nsteps > 1) s1 = mv_load<NCW, PAIRED, GAMA>(P, jm, mw, 1, lane);
+}
+
+// ------------------------------------------------------------------------------------------------ the kernel
+// LDS: [4 plans] [layer table] [xs0] [xs1] [xrawA dim] [xrawB dim] [attention: qraw GQ*hd | kraw hd | vraw hd | qb GQ*hd | knew hd | wmax | comb]
+struct EngLds {
+    const EngPlan* plan;
+    const EngLayer* lay;
+    u32x4* xs[2];
+    uint16_t *xrawA, *xrawB, *qraw, *kraw, *vraw, *qb, *knew;
+    float *wmax, *comb;
+};
+struct EngSlice { /* this workgroup's attention slice and merge share */
+    int pos, len, nsp, kvh, split, h0, t0, t1, me0;
+    bool has_unit, empty, own_new, has_merge;
+};
+
+// the poller wave: per layer it stages P1's x, the slice's q/k/v heads, merges, stages P4's, P5's and P6's inputs
+template <int FMT, int GQ, int HD, int NWV, int ND, int NQD, int NF>
+__device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& L, const EngSlice& S, int epoch, int wg, int lane) {
+    constexpr int XCH = BlockDot<FMT>::XCH, hd = HD, hd_log2 = HD == 128 ? 7 : 6, NW = 4, PS = hd + 4, LPK = hd >> 3, KPW = 64 / LPK;
+    bool dead = false;
+    const bool has1 = wg * a.spg[0] < a.nslots[0], has4 = wg * a.spg[1] < a.nslots[1], has5 = wg * a.spg[2] < a.nslots[2], has6 = wg * a.spg[3] < a.nslots[3];
+    const int tstride = NW * KPW;
+    const int nbatch = S.has_unit && !S.empty ? (S.t1 - S.t0 + ATTN_U * tstride - 1) / (ATTN_U * tstride) : 0;
+    for (int l = 0; l < a.n_layer; l++) {
+        const EngLayer& ly = L.lay[l];
+        const uint32_t gen = (uint32_t)epoch * (uint32_t)a.n_layer + (uint32_t)l, tag = gen & 0xffffu;
+        // P1 (P4 adds this x as the residual)
+        if (has1 || has4) {
+            if (l == 0)
+                eng_poll_stage<XCH, ND, true, true>(nullptr, a.x_in, tag, a.nblk[0], ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead);
+            else
+                eng_poll_stage<XCH, ND, true, false>(a.xA, nullptr, tag, a.nblk[0], ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead);
+        }
+        __syncthreads();
+        // P2: q heads of the group (GQ*hd granules), then k and v of the kv-head side by side in one piece
+        if (S.has_unit) {
+            const __amdgpu_buffer_rsrc_t rs = eng_rsrc(a.qkv, (uint32_t)(a.q_dim + 2 * a.kv_dim) * 4u);
+            constexpr int NLQ = (GQ * hd + 255) / 256;
+            u32x4 g[NLQ], gk;
+            const int e_kv = 4 * lane; /* < hd: k, < 2hd: v */
+            const bool kv_in = e_kv < 2 * hd;
+            const int kv_src = e_kv < hd ? a.q_dim + S.kvh * hd + e_kv : a.q_dim + a.kv_dim + S.kvh * hd + (e_kv - hd);
+            for (int spins = 0;; spins++) {
+                uint32_t bad = 0;
+#pragma unroll
+                for (int r = 0; r < NLQ; r++) g[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (S.h0 * hd + 4 * (r * 64 + lane)) * 4, 0, 16));
+                gk = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (kv_in ? kv_src : 0) * 4, 0, 16));
+#pragma unroll
+                for (int r = 0; r < NLQ; r++) bad |= (4 * (r * 64 + lane) < GQ * hd) ? tags_bad(g[r], tag) : 0u;
+                bad |= kv_in ? tags_bad(gk, tag) : 0u;
+                if (__all(bad == 0)) break;
+                if (dead || spins > ENG_SPIN_MAX) {
+                    if (!dead && lane == 0) atomicOr(a.ws + 1, 2);
+                    dead = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int r = 0; r < NLQ; r++) {
+                const int e0 = 4 * (r * 64 + lane);
+                if (e0 < GQ * hd) *reinterpret_cast<u32x2*>(L.qraw + e0) = u32x2{(g[r].x & 0xffffu) | (g[r].y << 16), (g[r].z & 0xffffu) | (g[r].w << 16)};
+            }
+            if (kv_in) *reinterpret_cast<u32x2*>(L.kraw + e_kv) = u32x2{(gk.x & 0xffffu) | (gk.y << 16), (gk.z & 0xffffu) | (gk.w << 16)}; /* vraw = kraw + hd */
+            __syncthreads();
+            if (!S.empty) {
+                __syncthreads(); /* heads prepared */
+                for (int b = 0; b < nbatch; b++) {
+                    __syncthreads();
+                    __syncthreads();
+                }
+                __syncthreads(); /* key-group sums in LDS */
+            }
+        }
+        // P3: merge the slices of this workgroup's output elements (attention_v_kernel's division, once)
+        if (S.has_merge) {
+            const int nsp = S.nsp, h = S.me0 >> hd_log2, dd = S.me0 & (hd - 1);
+            const unsigned long long* base = a.part + (size_t)h * nsp * PS;
+            float ms = -__builtin_inff(), ls = 0.f, vsp[KF_ATTN_MAX_SPLITS];
+            const bool mine = lane < nsp, el = lane < a.merge_e;
+            for (int spins = 0;; spins++) {
+                uint32_t bad = 0;
+                const unsigned long long want = (unsigned long long)gen << 32; /* lanes and slices outside the work read as {0, gen}: clamped loads would cost more */
+                unsigned long long gm = want, gl = want, gv[KF_ATTN_MAX_SPLITS];
+                if (mine) gm = ld_gran64(base + (size_t)lane * PS + hd), gl = ld_gran64(base + (size_t)lane * PS + hd + 1);
+#pragma unroll
+                for (int sp = 0; sp < KF_ATTN_MAX_SPLITS; sp++) gv[sp] = (el && sp < nsp) ? ld_gran64(base + (size_t)sp * PS + dd + lane) : want;
+                bad |= ((uint32_t)(gm >> 32) ^ gen) | ((uint32_t)(gl >> 32) ^ gen);
+#pragma unroll
+                for (int sp = 0; sp < KF_ATTN_MAX_SPLITS; sp++) bad |= (uint32_t)(gv[sp] >> 32) ^ gen;
+                if (mine) ms = __uint_as_float((uint32_t)gm), ls = __uint_as_float((uint32_t)gl);
+#pragma unroll
+                for (int sp = 0; sp < KF_ATTN_MAX_SPLITS; sp++) vsp[sp] = __uint_as_float((uint32_t)gv[sp]);
+                if (__all(bad == 0)) break;
+                if (dead || spins > ENG_SPIN_MAX) {
+                    if (!dead && lane == 0) atomicOr(a.ws + 1, 4);
+                    dead = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const float Mx = wave_max(ms);
+            const float sc = (ms == -__builtin_inff()) ? 0.f : fast_exp(ms - Mx);
+            const float Lt = wave_sum(ls * sc);
+            float o = 0.f;
+#pragma unroll
+            for (int sp = 0; sp < KF_ATTN_MAX_SPLITS; sp++) o = fmaf(vsp[sp], __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sc), sp)), o);
+            if (el) st_gran(a.ao + S.me0 + lane, tag, f2bf(o * (1.0f / Lt)));
+        }
+        // P4, P5 (P6 adds that x as the residual), P6
+        if (has4) eng_poll_stage<XCH, NQD, false, false>(a.ao, nullptr, tag, a.nblk[1], nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead);
+        __syncthreads();
+        if (has5 || has6) eng_poll_stage<XCH, ND, true, false>(a.xB, nullptr, tag, a.nblk[2], ly.norm_post, a.eps, L.xs[0], L.xrawB, lane, a.ws, dead);
+        __syncthreads();
+        if (has6) eng_poll_stage<XCH, NF, false, false>(a.act, nullptr, tag, a.nblk[3], nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead);
+        __syncthreads();
+    }
+}
+
+// the compute waves
+template <int FMT, int GQ, int HD, int NWV>
+__device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds& L, const EngSlice& S, int epoch, int wg, int wave, int lane) {
+    constexpr int NCW = NWV - 1;
+    constexpr int hd = HD, hd_log2 = HD == 128 ? 7 : 6, NW = 4, PS = hd + 4;
+    constexpr int LPK = hd >> 3, KPW = 64 / LPK, lpk_log2 = hd_log2 - 3;
+    constexpr int NQ = (GQ + NW - 1) / NW;
+    const int tid = wave * 64 + lane;
+    const EngPlan *P1 = L.plan, *P4 = L.plan + 1, *P5 = L.plan + 2, *P6 = L.plan + 3;
+    const MvWave w1 = mv_wave<NCW>(P1, wg, wave), w4 = mv_wave<NCW>(P4, wg, wave), w5 = mv_wave<NCW>(P5, wg, wave), w6 = mv_wave<NCW>(P6, wg, wave);
+    const bool aw = wave < NW && S.has_unit; /* attention waves */
+    const int pos = S.pos, nsp = S.nsp, kvh = S.kvh, h0 = S.h0, t1 = S.t1;
+    const int grp = lane >> lpk_log2, d0 = (lane & (LPK - 1)) * 8;
+    const int tstart = S.t0 + wave * KPW + grp, tstride = NW * KPW;
+    const int nbatch = S.has_unit && !S.empty ? (S.t1 - S.t0 + ATTN_U * tstride - 1) / (ATTN_U * tstride) : 0;
+    const float* tab_pos = a.rope_table + (size_t)pos * hd;
+
+    MvStep<false> s1a, s1b, s4a, s4b, s6a, s6b;
+    MvStep<true> s5a, s5b;
+    s1a = s1b = s4a = s4b = s6a = s6b = MvStep<false>{};
+    s5a = s5b = MvStep<true>{};
+    u32x4 kk[ATTN_U], vv[ATTN_U];
+#pragma unroll
+    for (int u = 0; u < ATTN_U; u++) kk[u] = vv[u] = u32x4{0, 0, 0, 0};
+    auto issue_kv = [&](const EngLayer& ly, int tb, int tend) {
+#pragma unroll
+        for (int u = 0; u < ATTN_U; u++) {
+            const int t = tb + u * tstride;
+            kk[u] = u32x4{0, 0, 0, 0}, vv[u] = u32x4{0, 0, 0, 0};
+            if (t < tend) {
+                const size_t o = (size_t)t * a.kv_stride + (size_t)kvh * hd + d0;
+                kk[u] = *reinterpret_cast<const u32x4*>(ly.kcache + o);
+                vv[u] = *reinterpret_cast<const u32x4*>(ly.vcache + o);
+            }
+        }
+    };
+    mv_prefetch<NCW, FMT, false>(P1, L.lay[0].m, w1, lane, s1a, s1b);
+    if (aw && !S.empty) issue_kv(L.lay[0], tstart, t1);
+
+    for (int l = 0; l < a.n_layer; l++) {
+        const EngLayer& ly = L.lay[l];
+        const uint32_t gen = (uint32_t)epoch * (uint32_t)a.n_layer + (uint32_t)l, tag = gen & 0xffffu, tag_next = (gen + 1u) & 0xffffu;
+        const bool last = l == a.n_layer - 1;
+        uint16_t qw0 = 0, qw1 = 0, kw0 = 0, kw1 = 0; /* the q/k-norm weights of this lane's pair: constants, requested early */
+        if (aw && !S.empty) {
+            const int half = hd >> 1, j = lane < half ? lane : half - 1;
+            if (ly.norm_q) qw0 = ly.norm_q[j], qw1 = ly.norm_q[j + half];
+            if (ly.norm_k) kw0 = ly.norm_k[j], kw1 = ly.norm_k[j + half];
+        }
+        // ================= P1: RMSNorm(x) -> Q, K, V rows
+        __syncthreads();
+        mv_prefetch<NCW, FMT, false>(P4, ly.m + 3, w4, lane, s4a, s4b);
+        mv_run<NCW, FMT, false>(P1, ly.m, w1, s1a, s1b, L.xs[0], lane, [&](int j, int row, float v, float) {
+            const int idx = j == 0 ? row : (j == 1 ? a.q_dim + row : a.q_dim + a.kv_dim + row);
+            st_gran(a.qkv + idx, tag, f2bf(v));
+        });
+        // ================= P2: q/k-norm + RoPE + attention over this workgroup's slice
+        if (S.has_unit) {
+            __syncthreads(); /* raw heads staged */
+            if (!S.empty) {
+                if (aw) { /* prologue: q heads of this group, and the new key when it lies in this slice (ROPE::cuInfer) */
+                    const bool qnorm = ly.norm_q != nullptr;
+                    const int half = hd >> 1, j = lane < half ? lane : half - 1;
+#pragma unroll
+                    for (int i = 0; i < NQ; i++) {
+                        const int hq = wave + i * NW;
+                        if (hq < GQ) {
+                            HeadRaw r;
+                            r.x0 = L.qraw[hq * hd + j], r.x1 = L.qraw[hq * hd + j + half];
+                            r.w0 = qnorm ? qw0 : r.x0, r.w1 = qnorm ? qw1 : r.x1;
+                            prep_head(r, qnorm, tab_pos, hd, a.qk_eps, L.qb + hq * hd);
+                        }
+                    }
+                    if (S.own_new && wave == (GQ % NW)) {
+                        HeadRaw r;
+                        r.x0 = L.kraw[j], r.x1 = L.kraw[j + half];
+                        r.w0 = ly.norm_k ? kw0 : r.x0, r.w1 = ly.norm_k ? kw1 : r.x1;
+                        prep_head(r, ly.norm_k != nullptr, tab_pos, hd, a.qk_eps, L.knew);
+                    }
+                }
+                __syncthreads();
+                float M[GQ], lsum[GQ], acc[GQ][8];
+                u32x4 qreg[GQ];
+#pragma unroll
+                for (int hq = 0; hq < GQ; hq++) {
+                    M[hq] = -__builtin_inff(), lsum[hq] = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) acc[hq][i] = 0.f;
+                    qreg[hq] = u32x4{0, 0, 0, 0};
+                }
+                if (aw) {
+                    if (S.own_new) { /* the cache rows of this position: the prepared key, the raw value (K.out / V.out alias them in the reference) */
+                        uint16_t* krow = ly.kcache + (size_t)pos * a.kv_stride + (size_t)kvh * hd;
+                        uint16_t* vrow = ly.vcache + (size_t)pos * a.kv_stride + (size_t)kvh * hd;
+                        for (int i = tid; i < hd; i += NW * 64) krow[i] = L.knew[i], vrow[i] = L.vraw[i];
+                    }
+#pragma unroll
+                    for (int hq = 0; hq < GQ; hq++) qreg[hq] = *reinterpret_cast<const u32x4*>(L.qb + hq * hd + d0);
+                }
+                const float rden = 1.0f / sqrtf((float)hd);
+                for (int b = 0; b < nbatch; b++) {
+                    const int tb = tstart + b * ATTN_U * tstride;
+                    float s[ATTN_U][GQ], bm[GQ];
+                    u32x4 cv[ATTN_U];
+#pragma unroll
+                    for (int hq = 0; hq < GQ; hq++) bm[hq] = -__builtin_inff();
+                    if (aw) {
+                        u32x4 ck[ATTN_U];
+#pragma unroll
+                        for (int u = 0; u < ATTN_U; u++) ck[u] = kk[u], cv[u] = vv[u];
+                        if (b + 1 < nbatch) issue_kv(ly, tb + ATTN_U * tstride, t1);
+#pragma unroll
+                        for (int u = 0; u < ATTN_U; u++) {
+                            const int t = tb + u * tstride;
+                            const bool valid = t < t1;
+                            u32x4 kw = ck[u];
+                            if (valid && t == pos) kw = *reinterpret_cast<const u32x4*>(L.knew + d0), cv[u] = *reinterpret_cast<const u32x4*>(L.vraw + d0);
+#pragma unroll
+                            for (int hq = 0; hq < GQ; hq++) {
+                                float d = dot2_bf16(qreg[hq].x, kw.x, 0.f);
+                                d = dot2_bf16(qreg[hq].y, kw.y, d);
+                                d = dot2_bf16(qreg[hq].z, kw.z, d);
+                                d = dot2_bf16(qreg[hq].w, kw.w, d);
+                                d = group_sum16(d, lpk_log2);
+                                d = round_bf16(d * rden);
+                                s[u][hq] = valid ? d : -__builtin_inff();
+                                bm[hq] = fmaxf(bm[hq], s[u][hq]);
+                            }
+                        }
+#pragma unroll
+                        for (int hq = 0; hq < GQ; hq++) {
+                            bm[hq] = xmax32(xmax16(bm[hq]));
+                            if (LPK < 16) bm[hq] = fmaxf(bm[hq], dpp_f<0x128>(bm[hq]));
+                        }
+                    }
+                    __syncthreads();
+                    if (aw && lane == 0) {
+#pragma unroll
+                        for (int hq = 0; hq < GQ; hq++) L.wmax[wave * GQ + hq] = bm[hq];
+                    }
+                    __syncthreads();
+                    if (aw) {
+#pragma unroll
+                        for (int hq = 0; hq < GQ; hq++) {
+                            float Mb = L.wmax[hq];
+#pragma unroll
+                            for (int w2 = 1; w2 < NW; w2++) Mb = fmaxf(Mb, L.wmax[w2 * GQ + hq]);
+                            if (Mb > M[hq]) {
+                                const float sc = fast_exp(M[hq] - Mb);
+                                lsum[hq] *= sc;
+#pragma unroll
+                                for (int i = 0; i < 8; i++) acc[hq][i] *= sc;
+                                M[hq] = Mb;
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < ATTN_U; u++) {
+                            float vf_[8];
+                            const uint32_t vw[4] = {cv[u].x, cv[u].y, cv[u].z, cv[u].w};
+#pragma unroll
+                            for (int i = 0; i < 4; i++) vf_[2 * i] = bf_lo(vw[i]), vf_[2 * i + 1] = bf_hi(vw[i]);
+#pragma unroll
+                            for (int hq = 0; hq < GQ; hq++) {
+                                const float p = fast_exp(s[u][hq] - M[hq]);
+                                lsum[hq] += p;
+#pragma unroll
+                                for (int i = 0; i < 8; i++) acc[hq][i] = fmaf(p, vf_[i], acc[hq][i]);
+                            }
+                        }
+                    }
+                }
+                if (aw) { /* key-group sums (reduce-scatter by row swaps), waves through LDS */
+                    const int row = lane >> 4;
+#pragma unroll
+                    for (int hq = 0; hq < GQ; hq++) {
+                        float s1[4], r2[2];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[hq][i]), __float_as_uint(acc[hq][i + 4]), false, false);
+                            s1[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 2; i++) {
+                            const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(s1[i]), __float_as_uint(s1[i + 2]), false, false);
+                            r2[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                            if (LPK < 16) r2[i] += dpp_f<0x128>(r2[i]);
+                        }
+                        float lt = xsum16(xsum32(lsum[hq]));
+                        if (LPK < 16) lt += dpp_f<0x128>(lt);
+                        float* c = L.comb + ((size_t)wave * GQ + hq) * PS;
+                        if (LPK == 16 || (lane & 8) == 0) *reinterpret_cast<float2*>(c + d0 + 2 * row) = float2{r2[0], r2[1]};
+                        if (lane == 0) c[hd] = lt;
+                    }
+                }
+                __syncthreads();
+                if (aw) {
+                    for (int i = tid; i < GQ * hd; i += NW * 64) {
+                        const int hq = i >> hd_log2, d = i & (hd - 1);
+                        float o = 0.f, Ls = 0.f;
+#pragma unroll
+                        for (int sl = 0; sl < NW; sl++) {
+                            const float* c = L.comb + ((size_t)sl * GQ + hq) * PS;
+                            o += c[d];
+                            Ls += c[hd];
+                        }
+                        if (nsp == 1) {
+                            st_gran(a.ao + (size_t)(h0 + hq) * hd + d, tag, f2bf(o * (1.0f / Ls)));
+                        } else {
+                            float Mh = M[0];
+#pragma unroll
+                            for (int q2 = 1; q2 < GQ; q2++) Mh = (hq == q2) ? M[q2] : Mh;
+                            unsigned long long* dst = a.part + ((size_t)(h0 + hq) * nsp + S.split) * PS;
+                            st_gran64(dst + d, gen, o);
+                            if (d == 0) st_gran64(dst + hd, gen, Mh), st_gran64(dst + hd + 1, gen, Ls);
+                        }
+                    }
+                }
+            } else if (nsp > 1 && aw) { /* empty slice: neutral partial */
+                for (int i = tid; i < GQ * hd; i += NW * 64) {
+                    const int hq = i >> hd_log2, d = i & (hd - 1);
+                    unsigned long long* dst = a.part + ((size_t)(h0 + hq) * nsp + S.split) * PS;
+                    st_gran64(dst + d, gen, 0.f);
+                    if (d == 0) st_gran64(dst + hd, gen, -__builtin_inff()), st_gran64(dst + hd + 1, gen, 0.f);
+                }
+            }
+        }
+        // the next layer's K/V tiles of this slice (they do not depend on this token, except row `pos`, which is substituted)
+        if (aw && !S.empty && !last) issue_kv(L.lay[l + 1], tstart, t1);
+
+        // ================= P4: o_proj + residual -> xB
+        __syncthreads();
+        mv_prefetch<NCW, FMT, true>(P5, ly.m + 4, w5, lane, s5a, s5b);
+        mv_run<NCW, FMT, false>(P4, ly.m + 3, w4, s4a, s4b, L.xs[1], lane, [&](int, int row, float v, float) {
+            const uint16_t o = f2bf(v);
+            st_gran(a.xB + row, tag, f2bf(bf2f(L.xrawA[row]) + bf2f(o))); /* CU_add3: bf16(x + bf16(W.x)) */
+        });
+        // ================= P5: RMSNorm + gate/up + SwiGLU -> act
+        __syncthreads();
+        mv_prefetch<NCW, FMT, false>(P6, ly.m + 6, w6, lane, s6a, s6b);
+        mv_run<NCW, FMT, true>(P5, ly.m + 4, w5, s5a, s5b, L.xs[0], lane, [&](int, int row, float v, float v2) {
+            const float gt = round_bf16(v), up = round_bf16(v2); /* CU_swiglu_v0 on the two bf16-rounded projections */
+            st_gran(a.act + row, tag, f2bf((gt * up) / (1.0f + kf_expf(-gt))));
+        });
+        // ================= P6: down_proj + residual -> x of the next layer
+        __syncthreads();
+        if (!last) mv_prefetch<NCW, FMT, false>(P1, L.lay[l + 1].m, w1, lane, s1a, s1b);
+        mv_run<NCW, FMT, false>(P6, ly.m + 6, w6, s6a, s6b, L.xs[1], lane, [&](int, int row, float v, float) {
+            const uint16_t o = f2bf(v);
+            const uint16_t y = f2bf(bf2f(L.xrawB[row]) + bf2f(o));
+            if (last)
+                a.x_out[row] = y;
+            else
+                st_gran(a.xA + row, tag_next, y);
+        });
+    }
+}
+
+// ND, NQD, NF: dim / 256, q_dim / 256, ffn / 256 (the poller's sweeps are straight-line code)
+template <int FMT, int GQ, int HD, int NWV, int ND, int NQD, int NF>
+__global__ void __launch_bounds__(NWV * 64) engine_kernel(const EngArgs a) {
+    constexpr int hd = HD, NW = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
+    // ---- LDS carve
+    EngLds L;
+    EngPlan* plan = reinterpret_cast<EngPlan*>(smem);
+    EngLayer* lay = reinterpret_cast<EngLayer*>(smem + 4 * sizeof(EngPlan));
+    size_t off = (4 * sizeof(EngPlan) + (size_t)a.n_layer * sizeof(EngLayer) + 15) & ~(size_t)15;
+    L.plan = plan, L.lay = lay;
+    L.xs[0] = reinterpret_cast<u32x4*>(smem + off), off += a.lds_xs_bytes;
+    L.xs[1] = reinterpret_cast<u32x4*>(smem + off), off += a.lds_xs_bytes;
+    L.xrawA = reinterpret_cast<uint16_t*>(smem + off), off += ((size_t)a.dim * 2 + 15) & ~(size_t)15;
+    L.xrawB = reinterpret_cast<uint16_t*>(smem + off), off += ((size_t)a.dim * 2 + 15) & ~(size_t)15;
+    L.qraw = reinterpret_cast<uint16_t*>(smem + off); /* [GQ][hd] raw q heads of this workgroup's slice */
+    L.kraw = L.qraw + GQ * hd, L.vraw = L.kraw + hd, L.qb = L.vraw + hd, L.knew = L.qb + GQ * hd;
+    L.wmax = reinterpret_cast<float*>(L.knew + hd); /* [NW][GQ] */
+    L.comb = L.wmax + NW * GQ + 4;                  /* [NW][GQ][hd + 4] */
+    // ---- start: state, generation, tables
+    EngSlice S;
+    S.pos = a.d_state[1];
+    const int epoch = a.ws[0];
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.plans);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(plan);
+        for (int i = tid; i < (int)(4 * sizeof(EngPlan) / 4); i += NWV * 64) dst[i] = src[i];
+        src = reinterpret_cast<const uint32_t*>(a.layers), dst = reinterpret_cast<uint32_t*>(lay);
+        const int nw = a.n_layer * (int)(sizeof(EngLayer) / 4);
+        for (int i = tid; i < nw; i += NWV * 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    S.len = S.pos + 1, S.nsp = a.nsp;
+    S.has_unit = wg < a.n_kv * a.nsp;
+    S.kvh = S.has_unit ? wg / a.nsp : 0, S.split = S.has_unit ? wg - S.kvh * a.nsp : 0;
+    S.h0 = S.kvh * GQ, S.t0 = S.split * a.chunk;
+    S.t1 = S.t0 + a.chunk < S.len ? S.t0 + a.chunk : S.len;
+    S.empty = S.t0 >= S.len;
+    S.own_new = S.has_unit && S.pos >= S.t0 && S.pos < S.t1;
+    S.me0 = wg * a.merge_e;
+    S.has_merge = a.nsp > 1 && S.me0 < a.n_head * hd;
+    if (wave == NWV - 1)
+        eng_poller_main<FMT, GQ, HD, NWV, ND, NQD, NF>(a, L, S, epoch, wg, lane);
+    else
+        eng_compute_main<FMT, GQ, HD, NWV>(a, L, S, epoch, wg, wave, lane);
+    // the next launch's generation (workgroup 0 owns rows of the last phase, so every workgroup has read the epoch long before)
+    if (wg == 0 && tid == 0) a.ws[0] = epoch + 1;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct EngineHost {
+    EngArgs args;
+    EngPlan plans[4];
+    int fmt, GQ, hd, nwv, shape_class;
+    size_t smem;
+    int n_cu;
+};
+
+// the instantiated model shapes: {GQA group, head_dim, dim, q_dim, ffn}
+static int engine_shape_class(int GQ, int hd, int dim, int q_dim, int ffn) {
+    if (GQ == 2 && hd == 128 && dim == 1024 && q_dim == 2048 && ffn == 3072) return 1; /* Qwen3-0.6B (BASELINE config 2) */
+    if (GQ == 2 && hd == 64 && dim == 256 && q_dim == 256 && ffn == 512) return 2;     /* the small parity-test shape */
+    return 0;
+}
+static_assert(sizeof(EngPlan) == 80 && sizeof(EngLayer) == 216, "device table strides");
+static int eng_epb(int fmt) { return fmt == FMT_BF16 ? 8 : (fmt == FMT_F8 ? 16 : (fmt == FMT_Q4 || fmt == FMT_Q4P ? 32 : (fmt == FMT_Q2 ? 64 : 128))); }
+
+// geometry of one phase; returns false when the shape is outside what the engine serves
+static bool eng_plan(EngPlan& P, int fmt, int K, int njobs, const kf_weight* const* w, bool paired, int n_wg, bool& q4p_ok) {
+    const int epb = eng_epb(fmt);
+    if (K % epb != 0 || K % 8 != 0 || K > ENG_MAXLD * 256) return false;
+    memset(&P, 0, sizeof(P));
+    P.K = K, P.nBlk = K / epb;
+    long rows = 0;
+    for (int j = 0; j < njobs; j++)
+        if (!(paired && j == 1)) rows += w[j]->ne0;
+    P.lpr_log2 = gemv_lpr_log2(P.nBlk, rows);
+    const int LPR = 1 << P.lpr_log2, RPS = 64 / LPR;
+    P.iters = (P.nBlk + LPR - 1) / LPR;
+    P.njobs = paired ? 1 : njobs;
+    int slots = 0;
+    for (int j = 0; j < njobs; j++) {
+        const kf_weight* wj = w[j];
+        if (gemv_fmt_of(wj) != (fmt == FMT_Q4P ? FMT_Q4 : fmt) || wj->ne1 != K || wj->qzeros || wj->qscales) return false;
+        if (((uintptr_t)wj->data & 15) != 0) return false;
+        if (fmt >= FMT_Q4) {
+            if (!wj->gama || wj->lGroup <= 0 || (wj->lGroup % epb) != 0 || ((long)wj->ne0 * wj->ne1) % wj->lGroup != 0) return false;
+            const int bpg = wj->lGroup / epb;
+            if (bpg < 1 || (bpg & (bpg - 1)) != 0) return false;
+            P.gshift = __builtin_ctz(bpg);
+            if (!(wj->lGroup == 128 && (K % 128) == 0 && P.lpr_log2 >= 2)) q4p_ok = false;
+        }
+        P.M[j] = wj->ne0, P.qBias[j] = wj->qBias;
+        if (paired && j == 1) {
+            if (wj->ne0 != w[0]->ne0) return false;
+            continue;
+        }
+        P.slot0[j] = slots;
+        slots += (wj->ne0 + RPS - 1) / RPS;
+    }
+    for (int j = P.njobs; j < 3; j++) P.slot0[j] = 0x7fffffff;
+    P.total_slots = slots;
+    P.spg = (slots + n_wg - 1) / n_wg;
+    return true;
+}
+
+size_t engine_ws_bytes(const kf_engine_desc* d) {
+    // [ws: 64 B] [EngLayer table] [xA dim][qkv q+2kv][ao q][xB dim][act ffn] granules (4 B) [part: n_head*32*(hd+4) 8-byte granules] [EngineHost]
+    const size_t q_dim = (size_t)d->n_head * d->head_dim, kv_dim = (size_t)d->n_kv * d->head_dim;
+    size_t b = 256 + 512 + (((size_t)d->n_layer * sizeof(EngLayer) + 255) & ~(size_t)255);
+    b += 4 * (((size_t)d->dim * 2 + q_dim * 2 + 2 * kv_dim + d->ffn + 1023) & ~(size_t)255);
+    b += 8 * (size_t)d->n_head * KF_ATTN_MAX_SPLITS * (d->head_dim + 4) + 256;
+    return b;
+}
+
+int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t st, EngineHost** out) {
+    if (!d || !ws || !out || d->n_layer < 1 || !d->layers) return KF_INVALID_ARGS;
+    if (ws_bytes < engine_ws_bytes(d) || ((uintptr_t)ws & 255) != 0) return KF_INVALID_ARGS;
+    const int hd = d->head_dim;
+    if ((hd != 64 && hd != 128) || d->n_kv <= 0 || d->n_head % d->n_kv != 0) return KF_UNSUPPORTED_DATATYPE;
+    const int GQ = d->n_head / d->n_kv;
+    const int shape_class = engine_shape_class(GQ, hd, d->dim, d->n_head * hd, d->ffn);
+    if (!shape_class) return KF_UNSUPPORTED_DATATYPE; /* not one of the instantiated model shapes: the per-layer launches remain */
+    if (getenv("KF_ATTN_SLICE") || getenv("KF_ATTN_SINGLE") || getenv("KF_ATTN_NW")) return KF_UNSUPPORTED_DATATYPE; /* the engine restates the default slicing */
+    int dev = 0, n_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1) return KF_HIP_CHECK;
+    EngineHost* E = new EngineHost();
+    memset(E, 0, sizeof(*E));
+    EngArgs& a = E->args;
+    a.n_layer = d->n_layer, a.n_wg = n_cu;
+    a.dim = d->dim, a.n_head = d->n_head, a.n_kv = d->n_kv, a.hd = hd, a.q_dim = d->n_head * hd, a.kv_dim = d->n_kv * hd, a.ffn = d->ffn, a.kv_stride = d->kv_stride;
+    a.eps = d->rms_eps, a.qk_eps = d->qk_eps, a.rope_table = d->rope_table;
+    if (!a.rope_table || (a.kv_stride % 8) != 0 || a.dim % 4 || a.q_dim % 4 || a.ffn % 4) {
+        delete E;
+        return KF_INVALID_ARGS;
+    }
+    // phases: every layer must have the same shapes and storage
+    const kf_engine_layer& L0 = d->layers[0];
+    int fmt = gemv_fmt_of(&L0.w[0]);
+    if (fmt != FMT_Q4) { /* the engine is instantiated for the 4-bit PackedQ storage (BASELINE config 2); other storages keep the per-layer launches */
+        delete E;
+        return KF_UNSUPPORTED_DATATYPE;
+    }
+    bool q4p_ok = fmt == FMT_Q4;
+    std::vector<EngLayer> tab(d->n_layer);
+    for (int l = 0; l < d->n_layer; l++) {
+        const kf_engine_layer& L = d->layers[l];
+        const kf_weight* k1[3] = {&L.w[0], &L.w[1], &L.w[2]};
+        const kf_weight* k4[1] = {&L.w[3]};
+        const kf_weight* k5[2] = {&L.w[4], &L.w[5]};
+        const kf_weight* k6[1] = {&L.w[6]};
+        EngPlan p1, p4, p5, p6;
+        EngPlan* const pl = E->plans;
+        bool ok = eng_plan(p1, fmt, a.dim, 3, k1, false, n_cu, q4p_ok) && eng_plan(p4, fmt, a.q_dim, 1, k4, false, n_cu, q4p_ok) &&
+                  eng_plan(p5, fmt, a.dim, 2, k5, true, n_cu, q4p_ok) && eng_plan(p6, fmt, a.ffn, 1, k6, false, n_cu, q4p_ok);
+        ok = ok && L.w[0].ne0 == a.q_dim && L.w[1].ne0 == a.kv_dim && L.w[2].ne0 == a.kv_dim && L.w[3].ne0 == a.dim && L.w[4].ne0 == a.ffn && L.w[6].ne0 == a.dim;
+        ok = ok && L.norm_in && L.norm_post && L.kcache && L.vcache && (((uintptr_t)L.kcache | (uintptr_t)L.vcache) & 15) == 0;
+        if (l == 0) pl[0] = p1, pl[1] = p4, pl[2] = p5, pl[3] = p6;
+        if (ok && l > 0) ok = !memcmp(&p1, &pl[0], sizeof(p1)) && !memcmp(&p4, &pl[1], sizeof(p4)) && !memcmp(&p5, &pl[2], sizeof(p5)) && !memcmp(&p6, &pl[3], sizeof(p6));
+        if (!ok) {
+            delete E;
+            return KF_UNSUPPORTED_DATATYPE;
+        }
+        for (int j = 0; j < 7; j++) {
+            const kf_weight& w = L.w[j];
+            tab[l].m[j].w = reinterpret_cast<const u32x4*>(w.data);
+            tab[l].m[j].zero = tab[l].m[j].step = nullptr;
+            if (fmt >= FMT_Q4) {
+                tab[l].m[j].zero = w.gama + w.ne0 + w.ne1;
+                tab[l].m[j].step = tab[l].m[j].zero + (size_t)w.ne0 * w.ne1 / w.lGroup;
+            }
+        }
+        tab[l].norm_in = L.norm_in, tab[l].norm_post = L.norm_post, tab[l].norm_q = L.q_norm, tab[l].norm_k = L.k_norm;
+        tab[l].kcache = L.kcache, tab[l].vcache = L.vcache;
+    }
+    if (fmt == FMT_Q4 && q4p_ok && !(getenv("KF_Q4_PERM") && atoi(getenv("KF_Q4_PERM")) == 0)) fmt = FMT_Q4P;
+    E->fmt = fmt, E->GQ = GQ, E->hd = hd, E->n_cu = n_cu, E->nwv = 8, E->shape_class = shape_class;
+    for (int i = 0; i < 4; i++) a.spg[i] = E->plans[i].spg, a.nslots[i] = E->plans[i].total_slots, a.nblk[i] = E->plans[i].nBlk;
+    // workspace carve
+    char* p = reinterpret_cast<char*>(ws);
+    a.ws = reinterpret_cast<int*>(p), p += 256;
+    a.plans = reinterpret_cast<const EngPlan*>(p), p += 512;
+    a.layers = reinterpret_cast<const EngLayer*>(p), p += ((size_t)d->n_layer * sizeof(EngLayer) + 255) & ~(size_t)255;
+    auto gran = [&](size_t n) {
+        uint32_t* r = reinterpret_cast<uint32_t*>(p);
+        p += (n * 4 + 255) & ~(size_t)255;
+        return r;
+    };
+    a.xA = gran(a.dim), a.qkv = gran((size_t)a.q_dim + 2 * a.kv_dim), a.ao = gran(a.q_dim), a.xB = gran(a.dim), a.act = gran(a.ffn);
+    a.part = reinterpret_cast<unsigned long long*>(p);
+    if (hipMemsetAsync(ws, 0xff, ws_bytes, st) != hipSuccess) {
+        delete E;
+        return KF_HIP_CHECK;
+    }
+    const int init[2] = {1, 0}; /* epoch 1, no error */
+    if (hipMemcpyAsync(a.ws, init, sizeof(init), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(const_cast<EngPlan*>(a.plans), E->plans, sizeof(E->plans), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(const_cast<EngLayer*>(a.layers), tab.data(), tab.size() * sizeof(EngLayer), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+        delete E;
+        return KF_HIP_CHECK;
+    }
+    // LDS
+    int maxK = a.dim > a.q_dim ? a.dim : a.q_dim;
+    if (a.ffn > maxK) maxK = a.ffn;
+    a.lds_xs_bytes = (maxK * 2 + 15) & ~15;
+    size_t smem = ((4 * sizeof(EngPlan) + (size_t)d->n_layer * sizeof(EngLayer) + 15) & ~(size_t)15) + 2 * (size_t)a.lds_xs_bytes + 2 * (((size_t)a.dim * 2 + 15) & ~(size_t)15);
+    smem += sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + sizeof(float) * (4 * GQ + 4 + (size_t)4 * GQ * (hd + 4));
+    smem = (smem + 15) & ~(size_t)15;
+    if (smem > 160 * 1024) {
+        delete E;
+        return KF_UNSUPPORTED_DATATYPE;
+    }
+    E->smem = smem;
+    *out = E;
+    return KF_OK;
+}
+void engine_free(EngineHost* E) { delete E; }
+
+template <int FMT, int GQ, int HD, int NWV, int ND, int NQD, int NF>
+static int engine_go(EngineHost* E, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)engine_kernel<FMT, GQ, HD, NWV, ND, NQD, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return KF_HIP_CHECK;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((engine_kernel<FMT, GQ, HD, NWV, ND, NQD, NF>), dim3(E->args.n_wg), dim3(NWV * 64), E->smem, st, E->args);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+template <int FMT>
+static int engine_go_fmt(EngineHost* E, hipStream_t st) {
+    switch (E->shape_class) {
+        case 1: return engine_go<FMT, 2, 128, 8, 4, 8, 12>(E, st);
+        case 2: return engine_go<FMT, 2, 64, 8, 1, 1, 2>(E, st);
+        default: return 1;
+    }
+}
+
+// 1: this position bound is outside what the engine serves (the caller runs the multi-launch path), < 0 error
+int engine_step(EngineHost* E, hipStream_t st, const uint16_t* x_in, uint16_t* x_out, const int32_t* d_state, int pos_bound) {
+    EngArgs& a = E->args;
+    if (!x_in || !x_out || !d_state || pos_bound < 0) return KF_INVALID_ARGS;
+    const int nsp = attn_splits(pos_bound, a.n_kv);
+    const int chunk = (pos_bound + 1 + nsp - 1) / nsp;
+    const int NW = (E->GQ <= 2 && chunk > 128) ? 8 : 4;
+    if (NW != 4 || a.n_kv * nsp > a.n_wg) return 1; /* the 8-wave slice form and more slices than workgroups are not restated here */
+    a.nsp = nsp, a.chunk = chunk;
+    int e = (a.n_head * a.hd + a.n_wg - 1) / a.n_wg, me = 1;
+    while (me < e) me <<= 1;
+    if (me > a.hd || me > 64) return 1;
+    a.merge_e = me;
+    a.x_in = x_in, a.x_out = x_out, a.d_state = d_state;
+    switch (E->fmt) {
+        case FMT_Q4P: return engine_go_fmt<FMT_Q4P>(E, st);
+        case FMT_Q4: return engine_go_fmt<FMT_Q4>(E, st);
+        default: return 1;
+    }
+}
+int engine_error_word(EngineHost* E, hipStream_t st, int* h_err) {
+    int v[2] = {0, 0};
+    if (hipMemcpyAsync(v, E->args.ws, sizeof(v), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return KF_HIP_CHECK;
+    *h_err = v[1];
+    return KF_OK;
+}
+
+}  // namespace kf

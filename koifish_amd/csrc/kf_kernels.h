@@ -57,6 +57,8 @@ struct GemvLaunch {
 };
 
 int gemv_launch(hipStream_t st, GemvLaunch& L);
+int gemv_lpr_log2(int nBlk, long rows); /* lanes per row of a mat-vec launch (kf_gemv.hip) */
+int gemv_fmt_of(const kf_weight* w);    /* FMT_* of a weight, < 0: not served by the mat-vec kernel */
 int gemv_q4lut_launch(hipStream_t st, GemvLaunch& L, bool* used); /* kf_gemv_lut.hip: table-lookup form for large 4-bit matrices */
 void argmax_finish_launch(hipStream_t st, const float* val, const int* idx, int n, int32_t* d_argmax, int32_t* d_state, int32_t* d_tokens_out);
 
@@ -95,6 +97,14 @@ int attn_prefill_mfma_launch(hipStream_t st, const uint16_t* q, const uint16_t* 
 int qknorm_rope_launch(hipStream_t st, uint16_t* q, uint16_t* k, const uint16_t* wq, const uint16_t* wk, const float* table, int pos,
                        const int* d_pos, int n_head, int n_kv, int hd, float eps, int n_tok = 1, long long q_stride = 0, long long k_stride = 0, int seq_len = 0,
                        float* rstd_q = nullptr, float* rstd_k = nullptr);
+
+// ---- persistent decode engine (kf_engine.hip)
+struct EngineHost;
+size_t engine_ws_bytes(const kf_engine_desc* d);
+int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t st, EngineHost** out);
+int engine_step(EngineHost* E, hipStream_t st, const uint16_t* x_in, uint16_t* x_out, const int32_t* d_state, int pos_bound); /* 1: not served */
+int engine_error_word(EngineHost* E, hipStream_t st, int* h_err);
+void engine_free(EngineHost* E);
 
 // ---- small ops (kf_ops.hip)
 int rmsnorm_launch(hipStream_t st, const uint16_t* x, const uint16_t* w, uint16_t* y, int rows, int dim, float eps, float* rstd);

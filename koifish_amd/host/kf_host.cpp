@@ -199,6 +199,8 @@ hGTensor Head4Token::cuInfer_1(hGTensor inp_, int) {
 // ------------------------------------------------------------------------------------------------ Fish
 Fish::~Fish() {
     for (auto g : graphs) kf_graph_destroy(g);
+    if (engine) kf_engine_destroy(engine);
+    if (ctx && engine_ws) kf_free(ctx, engine_ws);
     if (ctx) {
         if (rope_table) kf_free(ctx, rope_table);
         if (d_state) kf_free(ctx, d_state);
@@ -282,9 +284,52 @@ int Fish::pos_bound() const {
     return b < config.n_ctx - 1 ? b : config.n_ctx - 1;
 }
 
-int Fish::EnqueueStep(int) {
+// The persistent decode engine over this model's layers: built on first use (every weight must be set), not while capturing.
+int Fish::EnsureEngine() {
+    if (engine_state != 0) return engine_state > 0 ? KF_OK : KF_ENGINE_NOT_SERVED;
+    engine_state = -1;
+    std::vector<kf_engine_layer> L(config.nLayer);
+    for (int l = 0; l < config.nLayer; l++) {
+        SelfAttention* a = attn[l].get();
+        FFN* m = ffn[l].get();
+        SLP* s[7] = {&a->Q, &a->K, &a->V, &a->proj_cat, &m->gate, &m->up, &m->down};
+        for (int j = 0; j < 7; j++) {
+            if (!s[j]->w || s[j]->b) return KF_ENGINE_NOT_SERVED;
+            L[l].w[j] = s[j]->w->desc();
+        }
+        if (!a->norm.w || !m->norm.w) return KF_ENGINE_NOT_SERVED;
+        L[l].norm_in = ToX(a->norm.w), L[l].norm_post = ToX(m->norm.w);
+        L[l].q_norm = a->normQ.w ? ToX(a->normQ.w) : nullptr, L[l].k_norm = a->normK.w ? ToX(a->normK.w) : nullptr;
+        L[l].kcache = reinterpret_cast<floatX*>(cache.Get(KVCache::KV_KEY, l, 0));
+        L[l].vcache = reinterpret_cast<floatX*>(cache.Get(KVCache::KV_VAL, l, 0));
+    }
+    kf_engine_desc d;
+    std::memset(&d, 0, sizeof(d));
+    d.n_layer = config.nLayer, d.dim = config.nEmbed, d.n_head = config.n_head, d.n_kv = config.n_head_kv, d.head_dim = config.head_dim, d.ffn = config.n_ff;
+    d.kv_stride = config.n_head_kv * config.head_dim;
+    d.rms_eps = config.rms_eps, d.qk_eps = config.qk_eps, d.rope_table = rope_table, d.layers = L.data();
+    const size_t bytes = kf_engine_workspace_bytes(&d);
+    if (kf_malloc(ctx, bytes, &engine_ws) != KF_OK) return KF_OUTOF_GPUMEMORY;
+    if (kf_engine_create(ctx, &d, engine_ws, bytes, &engine) != KF_OK) {
+        kf_free(ctx, engine_ws);
+        engine_ws = nullptr, engine = nullptr;
+        return KF_ENGINE_NOT_SERVED;
+    }
+    engine_state = 1;
+    return KF_OK;
+}
+
+int Fish::EnqueueStep(int bound) {
     hGTensor cur = embed.cuInfer(-1);
     if (!cur) return KF_INTERNAL_ERR;
+    if (use_engine && fuse_level >= 1 && engine_state > 0) {
+        const int rc = kf_engine_step(ctx, engine, ToX(cur), ToX(x), d_state, bound);
+        if (rc < 0) return rc;
+        if (rc == KF_OK) {
+            engine_steps++;
+            return head.cuInfer_1(x) ? KF_OK : KF_INTERNAL_ERR;
+        }
+    }
     for (int l = 0; l < config.nLayer; l++) {
         cur = attn[l]->cuInfer(cur);
         if (!cur) return KF_INTERNAL_ERR;
@@ -316,6 +361,7 @@ kf_graph* Fish::GraphFor(int pos) {
     const int b = bucket_of(pos);
     if ((int)graphs.size() <= b) graphs.resize(b + 1, nullptr), graph_bound.resize(b + 1, 0);
     if (!graphs[b]) {
+        if (use_engine && engine_state == 0) EnsureEngine(); /* not while capturing */
         tok_pos = pos;
         graph_mode = true;
         const int save = fuse_level;
@@ -347,6 +393,7 @@ int Fish::RunSteps(int pos, int n, bool use_graph) {
             if (!g) return KF_INTERNAL_ERR;
             KF_TRY(kf_graph_launch(ctx, g));
         } else {
+            if (use_engine && engine_state == 0) EnsureEngine();
             tok_pos = p;
             graph_mode = true;  // positions/tokens still come from d_state, launches are eager
             const int save = fuse_level;
@@ -464,6 +511,24 @@ void* kfh_ctx(void* h) { return reinterpret_cast<Fish*>(h)->ctx; }
 int kfh_set_fuse_level(void* h, int lvl) {
     reinterpret_cast<Fish*>(h)->fuse_level = lvl;
     return KF_OK;
+}
+// the persistent decode engine: on (default) / off; captured step graphs are dropped so that the next step is captured the new way
+int kfh_set_engine(void* h, int on) {
+    Fish* f = reinterpret_cast<Fish*>(h);
+    f->use_engine = on != 0;
+    for (auto& g : f->graphs)
+        if (g) kf_graph_destroy(g), g = nullptr;
+    return KF_OK;
+}
+// steps enqueued (or captured) through the engine so far; -1: the engine does not serve this model
+int kfh_engine_steps(void* h) {
+    Fish* f = reinterpret_cast<Fish*>(h);
+    return f->engine_state < 0 ? -1 : f->engine_steps;
+}
+// synchronises; KF_INTERNAL_ERR when one of the engine's hand-off polls has timed out
+int kfh_engine_check(void* h) {
+    Fish* f = reinterpret_cast<Fish*>(h);
+    return f->engine ? kf_engine_check(f->ctx, f->engine) : KF_OK;
 }
 
 static SLP* slot_of(Fish* f, int layer, int slot) {

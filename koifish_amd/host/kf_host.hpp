@@ -182,7 +182,15 @@ struct Fish {
     int SetSampler(const CHAT_SAMPLER& s);  // also (re)seeds the device rng state
     int HeadAndPick(const floatX* x_last);  // [final norm + LM head] then arg-max or Sample, and the decode-state update
     kf_ctx* ctx = nullptr;
-    int fuse_level = 1;  // 0: one launch per reference kernel; 1: fused launches
+    int fuse_level = 1;  // 0: one launch per reference kernel; 1: fused launches (5 per layer)
+    // the layer loop of a decode step as one persistent launch (kf_engine_*): used by EnqueueStep when fuse_level >= 1, the model's shapes and
+    // storage are served and the position bound is; otherwise the per-layer launches run.  Same arithmetic, bit for bit.
+    bool use_engine = true;
+    kf_engine* engine = nullptr;
+    void* engine_ws = nullptr;
+    int engine_state = 0;  // 0 not tried, 1 built, -1 not served
+    int EnsureEngine();
+    int engine_steps = 0;  // steps enqueued (or captured) through the engine
     KVCache cache;
     MemBuffer gBUFF;
     TokenEmbed embed;

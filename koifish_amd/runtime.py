@@ -379,6 +379,19 @@ class Qwen3:
     def set_fuse_level(self, lvl):
         self.host.kfh_set_fuse_level(self.h, lvl)
 
+    def set_engine(self, on):
+        """The persistent decode engine (kf_engine_*: all layers of a step in one launch) on / off; off = the five launches per layer.
+        Same arithmetic either way, bit for bit."""
+        L.check(self.host.kfh_set_engine(self.h, int(bool(on))), "kfh_set_engine")
+
+    def engine_steps(self):
+        """steps enqueued or captured through the engine so far (-1: the engine does not serve this model's shapes / storage)"""
+        return int(self.host.kfh_engine_steps(self.h))
+
+    def engine_check(self):
+        """synchronises; raises when one of the engine's hand-off polls timed out (the launch was not fully resident)"""
+        L.check(self.host.kfh_engine_check(self.h), "kfh_engine_check")
+
     def forward(self, token, pos, want_logits=True):
         logits = np.zeros(self.cfg["vocab"], dtype=np.uint16) if want_logits else None
         r = self.host.kfh_forward(self.h, int(token), int(pos), None if logits is None else logits.ctypes.data_as(C.c_void_p))
@@ -412,6 +425,13 @@ class Qwen3:
             ctx = C.c_void_p(self.host.kfh_ctx(self.h))
             L.check(self.hip.kf_d2h(ctx, logits.ctypes.data_as(C.c_void_p), C.c_void_p(self.host.kfh_logits(self.h)), C.c_size_t(logits.size * 2)), "kf_d2h")
         return nxt, logits
+
+    def logits(self):
+        """the last step's logits (bf16 bit patterns as uint16 [vocab])"""
+        out = np.zeros(self.cfg["vocab"], dtype=np.uint16)
+        ctx = C.c_void_p(self.host.kfh_ctx(self.h))
+        L.check(self.hip.kf_d2h(ctx, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.host.kfh_logits(self.h)), C.c_size_t(out.size * 2)), "kf_d2h")
+        return out
 
     def set_forced(self, ids):
         a = np.ascontiguousarray(ids, dtype=np.int32)

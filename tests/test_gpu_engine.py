@@ -1,0 +1,83 @@
+"""The persistent decode engine (kf_engine_*: all layers of a decode step in ONE launch, hand-offs through tagged granules) against the
+per-layer launches (kf_norm_linear -> kf_attn_block -> kf_linear -> kf_norm_gateup_swiglu -> kf_linear): the same arithmetic in the same
+order, so logits, greedy ids and KV-cache rows must be equal BIT FOR BIT at every position -- single-slice and multi-slice attention,
+hipGraph replay and eager launches."""
+import numpy as np
+import pytest
+
+from helpers import oracle_model, prompt_ids
+from koifish_amd import lib as L
+from koifish_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(name, max_seq=None):
+    cfg = dict(synth.CONFIGS[name])
+    if max_seq:
+        cfg["max_seq"] = max_seq
+    return cfg
+
+
+def _teacher_forced(m, forced, n, use_graph):
+    """decode positions 0..n-1 with the ids of `forced`; returns per-step (greedy id, logits)"""
+    m.set_forced(forced)
+    m.set_state(int(forced[0]), 0)
+    out = []
+    for p in range(n):
+        m.run_steps(p, 1, use_graph=use_graph)
+        m.sync()
+        out.append((int(m.tokens_out(p + 1)[p]), m.logits()))
+    return out
+
+
+@pytest.mark.parametrize("cfg_name,max_seq,n_steps", [("tiny", 96, 96), ("small", 160, 40), ("tiny", 700, 700), ("small", 320, 300)])
+def test_engine_equals_per_layer_launches_bit_for_bit(cfg_name, max_seq, n_steps):
+    cfg = _cfg(cfg_name, max_seq)
+    raw = synth.raw_weights_numpy(cfg, 4321, w_std=0.1)
+    forced = np.full(cfg["max_seq"], -1, dtype=np.int32)
+    forced[:n_steps] = prompt_ids(cfg, n_steps, seed=11)
+    ref_m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
+    ref_m.set_engine(False)
+    ref = _teacher_forced(ref_m, forced, n_steps, use_graph=True)
+    assert ref_m.engine_steps() == 0
+    rk, rv = ref_m.kv_to_host()
+    ref_m.close()
+    for use_graph in (True, False):
+        m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
+        got = _teacher_forced(m, forced, n_steps, use_graph=use_graph)
+        assert m.engine_steps() > 0, "the engine was not used (engine_steps = %d)" % m.engine_steps()
+        m.engine_check()
+        for p in range(n_steps):
+            assert got[p][0] == ref[p][0], "graph=%s position %d: greedy id %d vs %d" % (use_graph, p, got[p][0], ref[p][0])
+            assert np.array_equal(got[p][1], ref[p][1]), "graph=%s position %d: logits differ in %d places" % (
+                use_graph, p, int((got[p][1] != ref[p][1]).sum()))
+        k, v = m.kv_to_host()
+        assert np.array_equal(k[:, :n_steps], rk[:, :n_steps]) and np.array_equal(v[:, :n_steps], rv[:, :n_steps]), "KV-cache rows differ"
+        m.close()
+
+
+def test_engine_free_running_ids_match_oracle():
+    cfg = _cfg("small", 320)
+    raw = synth.raw_weights_numpy(cfg, 1234, w_std=0.1)
+    m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
+    om = oracle_model(cfg, raw, L.Q4, L.BF16)
+    prompt = prompt_ids(cfg, 16)
+    ref = om.generate(prompt.tolist(), 24)
+    got = m.generate(prompt, 24, use_graph=True)
+    assert m.engine_steps() > 0
+    m.engine_check()
+    assert got == ref, "greedy ids %s differ from the oracle's %s" % (got, ref)
+    m.close()
+
+
+def test_engine_not_served_shapes_fall_back():
+    cfg = dict(synth.CONFIGS["tiny"])
+    cfg["ffn"] = 768   # not one of the instantiated shapes
+    raw = synth.raw_weights_numpy(cfg, 5, w_std=0.1)
+    m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
+    om = oracle_model(cfg, raw, L.Q4, L.BF16)
+    prompt = prompt_ids(cfg, 8)
+    assert m.generate(prompt, 8, use_graph=True) == om.generate(prompt.tolist(), 8)
+    assert m.engine_steps() == -1
+    m.close()
