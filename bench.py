@@ -34,7 +34,8 @@ def main():
                     help="weight type of the transformer layers (default: the metric's 4-bit PackedQ; the others are side measurements)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--streams", type=int, default=8, help="side measurement after the timed region: this many INDEPENDENT decoders (own weights, own "
+    ap.add_argument("--engine", type=int, default=-1, help="1: the layer loop as one persistent launch (kf_engine_*); 0: five launches per layer; -1: the library default")
+    ap.add_argument("--streams", type=int, default=0, help="side measurement after the timed region: this many INDEPENDENT decoders (own weights, own "
                     "KV cache, own HIP stream) running concurrently on the GPU over the same positions; 0/1 = skip.  Never part of `value`.")
     args = ap.parse_args()
 
@@ -69,6 +70,8 @@ def main():
     layer_type = {"q4": L.Q4, "bf16": L.BF16, "f8": L.F8E5M2, "ternary": L.T_SIGN, "1bit": L.BOOL1, "nf4": L.NF4}[args.layers]
     m = synth.build_on_gpu(cfg, seed=1234 + rank, layer_type=layer_type, head_type=head_type, device=dev)
     ctx = m._ctx
+    if args.engine >= 0:
+        m.set_engine(bool(args.engine))
     use_graph = not args.no_graph
 
     # synthetic prompt: 128 ids, then free-running greedy decode
@@ -194,6 +197,7 @@ def concurrent_streams(cfg, layer_type, head_type, dev, S, forced, n_prompt, mea
     models = []
     for i in range(S):
         mm = synth.build_on_gpu(cfg, seed=4321 + i, layer_type=layer_type, head_type=head_type, device=dev, own_stream=True)
+        mm.set_engine(False)  # the persistent engine needs the CUs to itself; concurrent decoders use the per-layer launches
         f = forced.copy()
         f[:n_prompt] = np.random.default_rng(100 + i).integers(0, cfg["vocab"], size=n_prompt)
         mm.set_forced(f)

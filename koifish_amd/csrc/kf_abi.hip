@@ -878,6 +878,8 @@ int kf_engine_check(kf_ctx* c, kf_engine* e) {
     if (err) return fail(KF_INTERNAL_ERR, "kf_engine: a hand-off poll timed out (error word 0x%x): the launch was not fully resident", err);
     return KF_OK;
 }
+// diagnostic (not part of the ABI header): the per-phase stamps of a KF_ENG_DEBUG=<workgroup> run
+int kfdbg_engine_stamps(kf_engine* e, unsigned long long* h_out, int n_words) { return (e && e->h) ? kf::engine_debug_read(e->h, h_out, n_words) : -1; }
 int kf_engine_destroy(kf_engine* e) {
     if (e) {
         kf::engine_free(e->h);

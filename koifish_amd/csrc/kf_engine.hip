@@ -34,17 +34,25 @@
 namespace kf {
 
 constexpr int ENG_MAXLD = 16;         /* 1 KiB granule pieces (256 values) per sweep: vectors up to 4096 */
+constexpr int ENG_NWG = 256, ENG_NWV = 8; /* MI355X: 256 CUs, one 8-wave workgroup each (7 compute waves + the poller) */
+constexpr int ENG_GLS_MAX = 1056;     /* largest line stride of the granule buffers, in dwords (32 = dense) */
 constexpr int ENG_SPIN_MAX = 1 << 17; /* sweeps before a poll gives up (~0.1 s): sets the error word, never hangs */
 
+// device tables hold GLOBAL pointers (address space 1): read back from LDS they would otherwise be generic, and every access through them a
+// flat_load, which the hardware returns out of order, so every wait behind one is a drain (vmcnt(0) + lgkmcnt(0))
+#define KF_GLOBAL __attribute__((address_space(1)))
+typedef const u32x4 KF_GLOBAL* g_u32x4;
+typedef const uint16_t KF_GLOBAL* g_u16;
+typedef uint16_t KF_GLOBAL* g_u16w;
 struct EngMat {
-    const u32x4* w;
-    const uint16_t* zero;
-    const uint16_t* step;
+    g_u32x4 w;
+    g_u16 zero;
+    g_u16 step;
 };
 struct EngLayer {
     EngMat m[7]; /* q k v o gate up down */
-    const uint16_t *norm_in, *norm_post, *norm_q, *norm_k;
-    uint16_t *kcache, *vcache; /* layer base */
+    g_u16 norm_in, norm_post, norm_q, norm_k;
+    g_u16w kcache, vcache; /* layer base */
 };
 struct EngPlan { /* one mat-vec phase: the geometry gemv_launch would pick for the same matrices */
     int K, nBlk, lpr_log2, iters, gshift, njobs;
@@ -68,13 +76,36 @@ struct EngArgs {
     int nsp, chunk, merge_e;           /* attention slices of this launch's position bound; merge elements per workgroup */
     int lds_xs_bytes;                  /* bytes of one x staging buffer */
     int spg[4], nslots[4], nblk[4];    /* per phase (P1, P4, P5, P6): slots per workgroup, slots in all, blocks per row */
+    float qbias[7];                    /* qBias of q k v o gate up down */
+    int gls;                           /* dwords between the 128-byte lines (32 granules) of a granule buffer: 32 = dense */
+    int poll_sleep;                    /* s_sleep units between two sweeps of a poll */
+    int ncopy, cstride;                /* every granule buffer exists ncopy times (1 or 8), cstride dwords apart: producers write all copies, a consumer reads the copy of its XCD */
+    int exp_flags;                     /* timing experiments only (KF_ENG_EXP; results are wrong): 1 = every weight load from the matrix's first KB, 2 = K/V tiles from row 0 */
+    unsigned long long* dbg;           /* diagnostic runs only (KF_ENG_DEBUG): [layer][role][16] wall-clock stamps of workgroup dbg_wg */
+    int dbg_wg;
 };
+#define ENG_STAMP(role, k)                                                                                                         \
+    do {                                                                                                                       \
+        if (a.dbg && wg == a.dbg_wg && lane == 0) a.dbg[((size_t)l * 2 + (role)) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t eng_rsrc(const void* p, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
+// granule e of a buffer sits in 128-byte line e / 32; the lines are `gls` dwords apart so that a vector every CU polls at once is spread
+// over the memory channels instead of sitting in one 4 KB window
+__device__ __forceinline__ int goff(int e, int gls) { return (e >> 5) * gls + (e & 31); }
 __device__ __forceinline__ void st_gran(uint32_t* p, uint32_t tag16, uint16_t v) {
     __hip_atomic_store(p, (tag16 << 16) | (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// publish to every copy
+__device__ __forceinline__ void pub_gran(uint32_t* buf, int off, int ncopy, int cstride, uint32_t tag16, uint16_t v) {
+    for (int c = 0; c < ncopy; c++) st_gran(buf + (size_t)c * cstride + off, tag16, v);
+}
+__device__ __forceinline__ int eng_xcc() {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return (int)(x & 7u);
 }
 __device__ __forceinline__ void st_gran64(unsigned long long* p, uint32_t gen, float v) {
     __hip_atomic_store(p, ((unsigned long long)gen << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -91,14 +122,14 @@ __device__ __forceinline__ uint32_t tags_bad(u32x4 g, uint32_t tag) { return ((g
 // the phase after next adds).  Lane l of load r owns elements 4*(64r + l) .. +3.  PLAIN: the vector is plain bf16 written by an
 // earlier launch (layer 0's embedding row).  Straight-line code: the vector lengths are template parameters of the kernel.
 template <int XCH, int NLD, bool NORM, bool PLAIN>
-__device__ __forceinline__ void eng_poll_stage(const uint32_t* gsrc, const uint16_t* plain, uint32_t tag, int nBlk, const uint16_t* norm_w, float eps, u32x4* xs,
-                                               uint16_t* xraw, int lane, int* ws, bool& dead) {
+__device__ __forceinline__ void eng_poll_stage(const uint32_t* gsrc, const uint16_t* plain, uint32_t tag, int nBlk, g_u16 norm_w, float eps, u32x4* xs,
+                                               uint16_t* xraw, int lane, int* ws, bool& dead, int gls, int psleep, int* nsweeps, unsigned long long* tsw = nullptr) {
     constexpr int n = NLD * 256;
     uint32_t p0[NLD], p1[NLD], w0[NLD], w1[NLD];
     if (NORM) { /* constants: requested in front of the sweep */
 #pragma unroll
         for (int r = 0; r < NLD; r++) {
-            const u32x2 t = *reinterpret_cast<const u32x2*>(norm_w + 4 * (r * 64 + lane));
+            const u32x2 t = *reinterpret_cast<const u32x2 KF_GLOBAL*>(norm_w + 4 * (r * 64 + lane));
             w0[r] = t.x, w1[r] = t.y;
         }
     }
@@ -109,21 +140,28 @@ __device__ __forceinline__ void eng_poll_stage(const uint32_t* gsrc, const uint1
             p0[r] = t.x, p1[r] = t.y;
         }
     } else {
-        const __amdgpu_buffer_rsrc_t rs = eng_rsrc(gsrc, (uint32_t)n * 4u);
+        const __amdgpu_buffer_rsrc_t rs = eng_rsrc(gsrc, (uint32_t)(n / 32) * (uint32_t)gls * 4u);
         u32x4 g[NLD];
+        int voff[NLD];
+#pragma unroll
+        for (int r = 0; r < NLD; r++) voff[r] = goff(4 * (r * 64 + lane), gls) * 4;
         for (int spins = 0;; spins++) {
             uint32_t bad = 0;
 #pragma unroll
-            for (int r = 0; r < NLD; r++) g[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (r * 64 + lane) * 16, 0, 16 /* sc1 */));
+            for (int r = 0; r < NLD; r++) g[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[r], 0, 16 /* sc1 */));
 #pragma unroll
             for (int r = 0; r < NLD; r++) bad |= tags_bad(g[r], tag);
-            if (__all(bad == 0)) break;
+            if (tsw && spins < 7 && lane == 0) tsw[spins] = __builtin_amdgcn_s_memrealtime();
+            if (__all(bad == 0)) {
+                if (nsweeps) *nsweeps = spins + 1;
+                break;
+            }
             if (dead || spins > ENG_SPIN_MAX) {
                 if (!dead && lane == 0) atomicOr(ws + 1, 1);
                 dead = true;
                 break;
             }
-            __builtin_amdgcn_s_sleep(1);
+            for (int z = 0; z < psleep; z++) __builtin_amdgcn_s_sleep(1);
         }
 #pragma unroll
         for (int r = 0; r < NLD; r++) p0[r] = (g[r].x & 0xffffu) | (g[r].y << 16), p1[r] = (g[r].z & 0xffffu) | (g[r].w << 16);
@@ -153,149 +191,190 @@ __device__ __forceinline__ void eng_poll_stage(const uint32_t* gsrc, const uint1
     }
 }
 
-// ---- mat-vec phase pieces (compute waves).  The plan lives in LDS; a wave owns slots s_first, s_first + NCW, ... of its workgroup.
-template <bool PAIRED>
-struct MvStep {
-    u32x4 w, w2;
-    uint16_t st, ze, st2, ze2;
+// ---- mat-vec phase pieces (compute waves).  The geometry of every phase is a compile-time constant of the model shape (the same lanes per
+// row, rows per wave step and steps per row gemv_launch picks for these matrices: engine_build checks the two against each other), so a
+// wave's loads are unconditional, their number is static and the compiler can wait with counted vmcnt(N) instead of draining.
+constexpr int c_lpr_log2(int nBlk, long rows) { /* = gemv_lpr_log2 (kf_gemv.hip) */
+    int l = 6;
+    while (l > 0 && (nBlk % (1 << l)) != 0) l--;
+    if ((1 << l) < 16) {
+        l = 6;
+        while ((1 << l) > nBlk) l--;
+    }
+    while (l < 6 && nBlk > (1 << l) && (rows << l) / 64 < 1024 && (nBlk + (2 << l) - 1) / (2 << l) < (nBlk + (1 << l) - 1) / (1 << l)) l++;
+    return l;
+}
+struct CPlan {
+    int K, nBlk, lpr_log2, iters, njobs, M[3], slot0[3], total, spg;
 };
-struct MvWave {
-    int s_first, nsteps;
+constexpr CPlan c_plan(int K, int epb, int m0, int m1, int m2, bool paired, int nwg) {
+    CPlan P{};
+    P.K = K, P.nBlk = K / epb;
+    const long rows = (long)m0 + (paired ? 0 : m1 + m2);
+    P.lpr_log2 = c_lpr_log2(P.nBlk, rows);
+    const int LPR = 1 << P.lpr_log2, RPS = 64 / LPR;
+    P.iters = (P.nBlk + LPR - 1) / LPR;
+    P.njobs = paired ? 1 : (m2 > 0 ? 3 : (m1 > 0 ? 2 : 1));
+    P.M[0] = m0, P.M[1] = m1, P.M[2] = m2;
+    P.slot0[0] = 0;
+    P.slot0[1] = (m0 + RPS - 1) / RPS;
+    P.slot0[2] = P.slot0[1] + (paired ? 0 : (m1 + RPS - 1) / RPS);
+    P.total = paired ? P.slot0[1] : P.slot0[2] + (m2 + RPS - 1) / RPS;
+    if (P.njobs < 3) P.slot0[2] = 0x7fffffff;
+    if (P.njobs < 2) P.slot0[1] = 0x7fffffff;
+    P.spg = (P.total + nwg - 1) / nwg;
+    return P;
+}
+// the four phases of a model shape
+template <int FMT, int DIM, int QD, int KVD, int FFN, int NWG>
+struct EngShape {
+    static constexpr int EPB = BlockDot<FMT>::EPB;
+    static constexpr CPlan P1 = c_plan(DIM, EPB, QD, KVD, KVD, false, NWG), P4 = c_plan(QD, EPB, DIM, 0, 0, false, NWG), P5 = c_plan(DIM, EPB, FFN, FFN, 0, true, NWG),
+                           P6 = c_plan(FFN, EPB, DIM, 0, 0, false, NWG);
+};
+template <bool PAIRED, int MAXS>
+struct MvRegs {
+    u32x4 w[MAXS], w2[PAIRED ? MAXS : 1];
+    uint16_t st[MAXS], ze[MAXS], st2[PAIRED ? MAXS : 1], ze2[PAIRED ? MAXS : 1];
 };
 template <int NCW>
-__device__ __forceinline__ MvWave mv_wave(const EngPlan* P, int wg, int cw) {
-    MvWave m;
-    const int spg = P->spg, s0 = wg * spg, s1 = min(s0 + spg, P->total_slots);
-    m.s_first = s0 + cw;
-    const int nsl = m.s_first < s1 ? (s1 - m.s_first + NCW - 1) / NCW : 0;
-    m.nsteps = __builtin_amdgcn_readfirstlane(nsl * P->iters);
-    return m;
-}
-struct MvPos { /* where step k of a wave sits */
-    int j, row, col, it;
+constexpr int c_maxs(const CPlan& P) { return ((P.spg + NCW - 1) / NCW) * P.iters; }
+struct MvAt {
+    int j, row, col;
     bool ok;
 };
+// step k of compute wave cw in workgroup wg: slot wg*spg + cw + (k / iters)*NCW, iteration k % iters
 template <int NCW>
-__device__ __forceinline__ MvPos mv_pos(const EngPlan* P, const MvWave& mw, int k, int lane) {
-    const int lpr_log2 = __builtin_amdgcn_readfirstlane(P->lpr_log2), iters = __builtin_amdgcn_readfirstlane(P->iters);
-    const int LPR = 1 << lpr_log2, RPS = 64 >> lpr_log2, sub = lane >> lpr_log2, ll = lane & (LPR - 1);
-    const int sl = k / iters;
-    MvPos q;
-    q.it = k - sl * iters;
-    const int s = mw.s_first + sl * NCW;
+__device__ __forceinline__ MvAt mv_at(const CPlan& P, int k, int wg, int cw, int lane) {
+    const int LPR = 1 << P.lpr_log2, RPS = 64 >> P.lpr_log2, sub = lane >> P.lpr_log2, ll = lane & (LPR - 1);
+    const int sl = k / P.iters, it = k - sl * P.iters;
+    const int s_loc = cw + sl * NCW, s = wg * P.spg + s_loc;
     int j = 0;
-    if (P->njobs > 1 && s >= P->slot0[1]) j = 1;
-    if (P->njobs > 2 && s >= P->slot0[2]) j = 2;
-    q.j = __builtin_amdgcn_readfirstlane(j);
-    q.row = (s - P->slot0[q.j]) * RPS + sub;
-    q.col = q.it * LPR + ll;
-    q.ok = q.row < P->M[q.j] && q.col < P->nBlk;
+    if (P.njobs > 1 && s >= P.slot0[1]) j = 1;
+    if (P.njobs > 2 && s >= P.slot0[2]) j = 2;
+    MvAt q;
+    q.j = j;
+    q.row = (s - (j == 0 ? 0 : (j == 1 ? P.slot0[1] : P.slot0[2]))) * RPS + sub;
+    q.col = it * LPR + ll;
+    q.ok = s_loc < P.spg && s < P.total && q.row < (j == 0 ? P.M[0] : (j == 1 ? P.M[1] : P.M[2])) && q.col < P.nBlk;
     return q;
 }
-// unconditional loads from clamped (row, column)
-template <int NCW, bool PAIRED, bool GAMA>
-__device__ __forceinline__ MvStep<PAIRED> mv_load(const EngPlan* P, const EngMat* jm, const MvWave& mw, int k, int lane) {
-    const MvPos q = mv_pos<NCW>(P, mw, k, lane);
-    const int M = P->M[q.j], nBlk = P->nBlk;
-    const int row = q.row < M ? q.row : M - 1, col = q.col < nBlk ? q.col : nBlk - 1;
-    const uint32_t bidx = (uint32_t)row * (uint32_t)nBlk + (uint32_t)col;
-    MvStep<PAIRED> o;
-    const EngMat mj = jm[q.j];
-    o.w = ld_nt(mj.w + bidx);
-    o.w2 = o.w, o.st = o.ze = o.st2 = o.ze2 = 0;
-    if (PAIRED) o.w2 = ld_nt(jm[1].w + bidx);
-    if (GAMA) {
-        const uint32_t gi = bidx >> P->gshift;
-        o.st = mj.step[gi], o.ze = mj.zero[gi];
-        if (PAIRED) o.st2 = jm[1].step[gi], o.ze2 = jm[1].zero[gi];
-    }
-    return o;
-}
-// one step of arithmetic; epi(job, row, v, v2) runs in the lane that owns a finished row
-template <int NCW, int FMT, bool PAIRED, typename Epi>
-__device__ __forceinline__ void mv_step(const EngPlan* P, const MvWave& mw, int k, const MvStep<PAIRED>& c, const u32x4* xs, int lane, float& acc, float& acc2, Epi&& epi) {
-    using BD = BlockDot<FMT>;
-    const MvPos q = mv_pos<NCW>(P, mw, k, lane);
-    const int nBlk = __builtin_amdgcn_readfirstlane(P->nBlk), lpr_log2 = __builtin_amdgcn_readfirstlane(P->lpr_log2),
-              iters = __builtin_amdgcn_readfirstlane(P->iters);
-    const int col = q.col < nBlk ? q.col : nBlk - 1;
-    if (q.it == 0) acc = 0.f, acc2 = 0.f;
-    const float st = bf2f(c.st);
-    const float r = BD::run(c.w, xs, col, nBlk, st, bf2f(c.ze), -((float)P->qBias[q.j] * st), acc);
-    acc = q.ok ? r : acc;
-    if (PAIRED) {
-        const float st2 = bf2f(c.st2);
-        const float r2 = BD::run(c.w2, xs, col, nBlk, st2, bf2f(c.ze2), -((float)P->qBias[1] * st2), acc2);
-        acc2 = q.ok ? r2 : acc2;
-    }
-    if (q.it == iters - 1) {
-        const float v = group_sum(acc, lpr_log2);
-        float v2 = 0.f;
-        if (PAIRED) v2 = group_sum(acc2, lpr_log2);
-        if ((lane & ((1 << lpr_log2) - 1)) == 0 && q.row < P->M[q.j]) epi(q.j, q.row, v, v2);
-    }
-}
-// a phase: the first two steps arrive prefetched (the 0.6B shapes need no more), further steps load in line
-template <int NCW, int FMT, bool PAIRED, typename Epi>
-__device__ __forceinline__ void mv_run(const EngPlan* P, const EngMat* jm, const MvWave& mw, const MvStep<PAIRED>& s0, const MvStep<PAIRED>& s1, const u32x4* xs, int lane,
-                                       Epi&& epi) {
+template <int NCW, int FMT, bool PAIRED, int MAXS>
+__device__ __forceinline__ void mv_prefetch(const CPlan& P, const EngMat* jm, int wg, int cw, int lane, MvRegs<PAIRED, MAXS>& R, int exp_flags = 0) {
     constexpr bool GAMA = BlockDot<FMT>::HAS_GAMA;
-    float acc = 0.f, acc2 = 0.f;
-    if (mw.nsteps > 0) mv_step<NCW, FMT, PAIRED>(P, mw, 0, s0, xs, lane, acc, acc2, epi);
-    if (mw.nsteps > 1) mv_step<NCW, FMT, PAIRED>(P, mw, 1, s1, xs, lane, acc, acc2, epi);
-    if (mw.nsteps > 2) {
-        MvStep<PAIRED> cur = mv_load<NCW, PAIRED, GAMA>(P, jm, mw, 2, lane);
-        for (int k = 2; k < mw.nsteps; k++) {
-            MvStep<PAIRED> nxt = cur;
-            if (k + 1 < mw.nsteps) nxt = mv_load<NCW, PAIRED, GAMA>(P, jm, mw, k + 1, lane);
-            mv_step<NCW, FMT, PAIRED>(P, mw, k, cur, xs, lane, acc, acc2, epi);
-            cur = nxt;
+    constexpr int gshift = FMT >= FMT_Q4 ? (FMT == FMT_Q4 || FMT == FMT_Q4P ? 2 : (FMT == FMT_Q2 ? 1 : 0)) : 0; /* 128-weight groups */
+#pragma unroll
+    for (int k = 0; k < MAXS; k++) {
+        const MvAt q = mv_at<NCW>(P, k, wg, cw, lane);
+        const int Mj = q.j == 0 ? P.M[0] : (q.j == 1 ? P.M[1] : P.M[2]);
+        int row = q.row < Mj ? q.row : Mj - 1;
+        row = row > 0 ? row : 0;
+        const int col = q.col < P.nBlk ? q.col : P.nBlk - 1;
+        uint32_t bidx = (uint32_t)row * (uint32_t)P.nBlk + (uint32_t)col;
+        if (exp_flags & 1) bidx = (uint32_t)lane;
+        const EngMat mj = q.j == 0 ? jm[0] : (q.j == 1 ? jm[P.njobs > 1 ? 1 : 0] : jm[P.njobs > 2 ? 2 : 0]);
+        R.w[k] = __builtin_nontemporal_load(mj.w + bidx);
+        if (PAIRED) R.w2[k] = __builtin_nontemporal_load(jm[1].w + bidx);
+        if (GAMA) {
+            const uint32_t gi = bidx >> gshift;
+            R.st[k] = mj.step[gi], R.ze[k] = mj.zero[gi];
+            if (PAIRED) R.st2[k] = jm[1].step[gi], R.ze2[k] = jm[1].zero[gi];
         }
     }
 }
-template <int NCW, int FMT, bool PAIRED>
-__device__ __forceinline__ void mv_prefetch(const EngPlan* P, const EngMat* jm, const MvWave& mw, int lane, MvStep<PAIRED>& s0, MvStep<PAIRED>& s1) {
-    constexpr bool GAMA = BlockDot<FMT>::HAS_GAMA;
-    if (mw.nsteps > 0) s0 = mv_load<NCW, PAIRED, GAMA>(P, jm, mw, 0, lane);
-    if (mw.nsteps > 1) s1 = mv_load<NCW, PAIRED, GAMA>(P, jm, mw, 1, lane);
+// epi(job, row, v, v2) runs in the lane that owns a finished row
+template <int NCW, int FMT, bool PAIRED, int MAXS, typename Epi>
+__device__ __forceinline__ void mv_run(const CPlan& P, const float* qb, int wg, int cw, int lane, const MvRegs<PAIRED, MAXS>& R, const u32x4* xs, Epi&& epi) {
+    using BD = BlockDot<FMT>;
+    float acc = 0.f, acc2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXS; k++) {
+        const int sl = k / P.iters, it = k - sl * P.iters;
+        if (cw + sl * NCW >= P.spg) continue; /* wave-uniform: this wave has no such slot */
+        const MvAt q = mv_at<NCW>(P, k, wg, cw, lane);
+        const int col = q.col < P.nBlk ? q.col : P.nBlk - 1;
+        if (it == 0) acc = 0.f, acc2 = 0.f;
+        const float st = bf2f(R.st[k]);
+        const float qbj = q.j == 0 ? qb[0] : (q.j == 1 ? qb[P.njobs > 1 ? 1 : 0] : qb[P.njobs > 2 ? 2 : 0]);
+        const float r = BD::run(R.w[k], xs, col, P.nBlk, st, bf2f(R.ze[k]), -(qbj * st), acc);
+        acc = q.ok ? r : acc;
+        if (PAIRED) {
+            const float st2 = bf2f(R.st2[k]);
+            const float r2 = BD::run(R.w2[k], xs, col, P.nBlk, st2, bf2f(R.ze2[k]), -(qb[1] * st2), acc2);
+            acc2 = q.ok ? r2 : acc2;
+        }
+        if (it == P.iters - 1) {
+            const float v = group_sum(acc, P.lpr_log2);
+            float v2 = 0.f;
+            if (PAIRED) v2 = group_sum(acc2, P.lpr_log2);
+            if ((lane & ((1 << P.lpr_log2) - 1)) == 0 && q.ok) epi(q.j, q.row, v, v2);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ the kernel
 // LDS: [4 plans] [layer table] [xs0] [xs1] [xrawA dim] [xrawB dim] [attention: qraw GQ*hd | kraw hd | vraw hd | qb GQ*hd | knew hd | wmax | comb]
 struct EngLds {
-    const EngPlan* plan;
     const EngLayer* lay;
     u32x4* xs[2];
     uint16_t *xrawA, *xrawB, *qraw, *kraw, *vraw, *qb, *knew;
     float *wmax, *comb;
+    uint32_t* outb; /* [64] a phase's output granules of this workgroup, gathered so that ONE wave stores them 16 bytes per lane */
+    int* cnt;       /* arrival counter of the compute waves that own rows of the phase */
 };
 struct EngSlice { /* this workgroup's attention slice and merge share */
     int pos, len, nsp, kvh, split, h0, t0, t1, me0;
     bool has_unit, empty, own_new, has_merge;
 };
 
+// The compute waves that own rows of a phase leave their granules in LDS; the wave that arrives last stores the workgroup's rows with ONE
+// instruction, 16 bytes per lane: a 64-byte sector of the hand-off vector is then written by a few whole pieces instead of by sixteen
+// separate 4-byte write-through stores (each a read-modify-write at the memory side).
+__device__ __forceinline__ void st_gran16(uint32_t* p, u32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, eng_rsrc(p, 16), 0, 0, 16 /* sc1 */);
+}
+__device__ __forceinline__ void wg_publish(const EngLds& L, uint32_t* buf, int idx0, int nrows, int nwaves, int lane, int gls, int ncopy, int cstride) {
+    int old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(L.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old != nwaves - 1) return;
+    if (lane == 0) *L.cnt = 0;
+    if (4 * lane < nrows) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(L.outb + 4 * lane);
+        const int off = goff(idx0 + 4 * lane, gls);
+        for (int c = 0; c < ncopy; c++) st_gran16(buf + (size_t)c * cstride + off, v);
+    }
+}
+
 // the poller wave: per layer it stages P1's x, the slice's q/k/v heads, merges, stages P4's, P5's and P6's inputs
-template <int FMT, int GQ, int HD, int NWV, int ND, int NQD, int NF>
+template <int FMT, int GQ, int HD, int NWV, int DIM, int QD, int KVD, int FFN, int NWG>
 __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& L, const EngSlice& S, int epoch, int wg, int lane) {
+    using SH = EngShape<FMT, DIM, QD, KVD, FFN, NWG>;
+    constexpr int ND = DIM / 256, NQD = QD / 256, NF = FFN / 256;
     constexpr int XCH = BlockDot<FMT>::XCH, hd = HD, hd_log2 = HD == 128 ? 7 : 6, NW = 4, PS = hd + 4, LPK = hd >> 3, KPW = 64 / LPK;
     bool dead = false;
-    const bool has1 = wg * a.spg[0] < a.nslots[0], has4 = wg * a.spg[1] < a.nslots[1], has5 = wg * a.spg[2] < a.nslots[2], has6 = wg * a.spg[3] < a.nslots[3];
+    const bool has1 = wg * SH::P1.spg < SH::P1.total, has4 = wg * SH::P4.spg < SH::P4.total, has5 = wg * SH::P5.spg < SH::P5.total,
+               has6 = wg * SH::P6.spg < SH::P6.total;
     const int tstride = NW * KPW;
     const int nbatch = S.has_unit && !S.empty ? (S.t1 - S.t0 + ATTN_U * tstride - 1) / (ATTN_U * tstride) : 0;
+    int sw[4] = {0, 0, 0, 0};
+    const size_t cbase = a.ncopy > 1 ? (size_t)(eng_xcc() & (a.ncopy - 1)) * a.cstride : 0; /* this XCD's copy of the granule buffers */
     for (int l = 0; l < a.n_layer; l++) {
         const EngLayer& ly = L.lay[l];
         const uint32_t gen = (uint32_t)epoch * (uint32_t)a.n_layer + (uint32_t)l, tag = gen & 0xffffu;
         // P1 (P4 adds this x as the residual)
+        ENG_STAMP(0, 0);
         if (has1 || has4) {
             if (l == 0)
-                eng_poll_stage<XCH, ND, true, true>(nullptr, a.x_in, tag, a.nblk[0], ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead);
+                eng_poll_stage<XCH, ND, true, true>(nullptr, a.x_in, tag, SH::P1.nBlk, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, a.gls, a.poll_sleep, &sw[0]);
             else
-                eng_poll_stage<XCH, ND, true, false>(a.xA, nullptr, tag, a.nblk[0], ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead);
+                eng_poll_stage<XCH, ND, true, false>(a.xA + cbase, nullptr, tag, SH::P1.nBlk, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, a.gls, a.poll_sleep, &sw[0]);
         }
+        ENG_STAMP(0, 1);
         __syncthreads();
         // P2: q heads of the group (GQ*hd granules), then k and v of the kv-head side by side in one piece
         if (S.has_unit) {
-            const __amdgpu_buffer_rsrc_t rs = eng_rsrc(a.qkv, (uint32_t)(a.q_dim + 2 * a.kv_dim) * 4u);
+            const __amdgpu_buffer_rsrc_t rs = eng_rsrc(a.qkv + cbase, (uint32_t)((a.q_dim + 2 * a.kv_dim) / 32) * (uint32_t)a.gls * 4u);
             constexpr int NLQ = (GQ * hd + 255) / 256;
             u32x4 g[NLQ], gk;
             const int e_kv = 4 * lane; /* < hd: k, < 2hd: v */
@@ -304,8 +383,8 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
             for (int spins = 0;; spins++) {
                 uint32_t bad = 0;
 #pragma unroll
-                for (int r = 0; r < NLQ; r++) g[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (S.h0 * hd + 4 * (r * 64 + lane)) * 4, 0, 16));
-                gk = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (kv_in ? kv_src : 0) * 4, 0, 16));
+                for (int r = 0; r < NLQ; r++) g[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, goff(S.h0 * hd + 4 * (r * 64 + lane), a.gls) * 4, 0, 16));
+                gk = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, goff(kv_in ? kv_src : 0, a.gls) * 4, 0, 16));
 #pragma unroll
                 for (int r = 0; r < NLQ; r++) bad |= (4 * (r * 64 + lane) < GQ * hd) ? tags_bad(g[r], tag) : 0u;
                 bad |= kv_in ? tags_bad(gk, tag) : 0u;
@@ -315,7 +394,7 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
                     dead = true;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(1);
+                for (int z = 0; z < a.poll_sleep; z++) __builtin_amdgcn_s_sleep(1);
             }
 #pragma unroll
             for (int r = 0; r < NLQ; r++) {
@@ -323,6 +402,7 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
                 if (e0 < GQ * hd) *reinterpret_cast<u32x2*>(L.qraw + e0) = u32x2{(g[r].x & 0xffffu) | (g[r].y << 16), (g[r].z & 0xffffu) | (g[r].w << 16)};
             }
             if (kv_in) *reinterpret_cast<u32x2*>(L.kraw + e_kv) = u32x2{(gk.x & 0xffffu) | (gk.y << 16), (gk.z & 0xffffu) | (gk.w << 16)}; /* vraw = kraw + hd */
+            ENG_STAMP(0, 2);
             __syncthreads();
             if (!S.empty) {
                 __syncthreads(); /* heads prepared */
@@ -334,6 +414,7 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
             }
         }
         // P3: merge the slices of this workgroup's output elements (attention_v_kernel's division, once)
+        ENG_STAMP(0, 3);
         if (S.has_merge) {
             const int nsp = S.nsp, h = S.me0 >> hd_log2, dd = S.me0 & (hd - 1);
             const unsigned long long* base = a.part + (size_t)h * nsp * PS;
@@ -366,28 +447,45 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
             float o = 0.f;
 #pragma unroll
             for (int sp = 0; sp < KF_ATTN_MAX_SPLITS; sp++) o = fmaf(vsp[sp], __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sc), sp)), o);
-            if (el) st_gran(a.ao + S.me0 + lane, tag, f2bf(o * (1.0f / Lt)));
+            if (el) pub_gran(a.ao, goff(S.me0 + lane, a.gls), a.ncopy, a.cstride, tag, f2bf(o * (1.0f / Lt)));
         }
         // P4, P5 (P6 adds that x as the residual), P6
-        if (has4) eng_poll_stage<XCH, NQD, false, false>(a.ao, nullptr, tag, a.nblk[1], nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead);
+        ENG_STAMP(0, 4);
+        if (has4) eng_poll_stage<XCH, NQD, false, false>(a.ao + cbase, nullptr, tag, SH::P4.nBlk, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, a.gls, a.poll_sleep, &sw[1]);
+        ENG_STAMP(0, 5);
         __syncthreads();
-        if (has5 || has6) eng_poll_stage<XCH, ND, true, false>(a.xB, nullptr, tag, a.nblk[2], ly.norm_post, a.eps, L.xs[0], L.xrawB, lane, a.ws, dead);
+        if (has5 || has6) eng_poll_stage<XCH, ND, true, false>(a.xB + cbase, nullptr, tag, SH::P5.nBlk, ly.norm_post, a.eps, L.xs[0], L.xrawB, lane, a.ws, dead, a.gls, a.poll_sleep, &sw[2]);
+        ENG_STAMP(0, 6);
         __syncthreads();
-        if (has6) eng_poll_stage<XCH, NF, false, false>(a.act, nullptr, tag, a.nblk[3], nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead);
+        if (has6) eng_poll_stage<XCH, NF, false, false>(a.act + cbase, nullptr, tag, SH::P6.nBlk, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, a.gls, a.poll_sleep, &sw[3], (a.dbg && wg == a.dbg_wg) ? a.dbg + ((size_t)l * 2) * 16 + 9 : nullptr);
+        ENG_STAMP(0, 7);
+        if (a.dbg && wg == a.dbg_wg && lane == 0) a.dbg[((size_t)l * 2) * 16 + 8] = (unsigned long long)sw[0] | ((unsigned long long)sw[1] << 16) | ((unsigned long long)sw[2] << 32) | ((unsigned long long)sw[3] << 48);
         __syncthreads();
     }
 }
 
 // the compute waves
-template <int FMT, int GQ, int HD, int NWV>
+template <int FMT, int GQ, int HD, int NWV, int DIM, int QD, int KVD, int FFN, int NWG>
 __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds& L, const EngSlice& S, int epoch, int wg, int wave, int lane) {
+    using SH = EngShape<FMT, DIM, QD, KVD, FFN, NWG>;
     constexpr int NCW = NWV - 1;
+    constexpr CPlan P1 = SH::P1, P4 = SH::P4, P5 = SH::P5, P6 = SH::P6;
+    constexpr int S1 = c_maxs<NCW>(P1), S4 = c_maxs<NCW>(P4), S5 = c_maxs<NCW>(P5), S6 = c_maxs<NCW>(P6);
     constexpr int hd = HD, hd_log2 = HD == 128 ? 7 : 6, NW = 4, PS = hd + 4;
     constexpr int LPK = hd >> 3, KPW = 64 / LPK, lpk_log2 = hd_log2 - 3;
     constexpr int NQ = (GQ + NW - 1) / NW;
     const int tid = wave * 64 + lane;
-    const EngPlan *P1 = L.plan, *P4 = L.plan + 1, *P5 = L.plan + 2, *P6 = L.plan + 3;
-    const MvWave w1 = mv_wave<NCW>(P1, wg, wave), w4 = mv_wave<NCW>(P4, wg, wave), w5 = mv_wave<NCW>(P5, wg, wave), w6 = mv_wave<NCW>(P6, wg, wave);
+    const float qb1[3] = {a.qbias[0], a.qbias[1], a.qbias[2]}, qb4[1] = {a.qbias[3]}, qb5[2] = {a.qbias[4], a.qbias[5]}, qb6[1] = {a.qbias[6]};
+    // this workgroup's rows per phase (contiguous in the phase's output vector) and the waves that own some of them
+    constexpr int R1 = P1.spg * (64 >> P1.lpr_log2), R4 = P4.spg * (64 >> P4.lpr_log2), R5 = P5.spg * (64 >> P5.lpr_log2), R6 = P6.spg * (64 >> P6.lpr_log2);
+    static_assert(R1 % 4 == 0 && R4 % 4 == 0 && R5 % 4 == 0 && R6 % 4 == 0 && R1 <= 64 && R4 <= 64 && R5 <= 64 && R6 <= 64, "rows per workgroup");
+    static_assert(P1.total % P1.spg == 0 && P4.total % P4.spg == 0 && P5.total % P5.spg == 0 && P6.total % P6.spg == 0, "whole workgroups");
+    static_assert(P1.slot0[1] % P1.spg == 0 && P1.slot0[2] % P1.spg == 0, "a workgroup's P1 rows belong to one matrix");
+    constexpr int NWP1 = P1.spg < NCW ? P1.spg : NCW, NWP4 = P4.spg < NCW ? P4.spg : NCW, NWP5 = P5.spg < NCW ? P5.spg : NCW, NWP6 = P6.spg < NCW ? P6.spg : NCW;
+    const bool has1 = wg * P1.spg < P1.total, has4 = wg * P4.spg < P4.total, has5 = wg * P5.spg < P5.total, has6 = wg * P6.spg < P6.total;
+    // first index of this workgroup's P1 rows in the concatenated [q | k | v] vector
+    const int s1 = wg * P1.spg, j1 = s1 >= P1.slot0[2] ? 2 : (s1 >= P1.slot0[1] ? 1 : 0);
+    const int i1 = (j1 == 0 ? 0 : (j1 == 1 ? a.q_dim : a.q_dim + a.kv_dim)) + (s1 - (j1 == 0 ? 0 : (j1 == 1 ? P1.slot0[1] : P1.slot0[2]))) * (64 >> P1.lpr_log2);
     const bool aw = wave < NW && S.has_unit; /* attention waves */
     const int pos = S.pos, nsp = S.nsp, kvh = S.kvh, h0 = S.h0, t1 = S.t1;
     const int grp = lane >> lpk_log2, d0 = (lane & (LPK - 1)) * 8;
@@ -395,26 +493,33 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
     const int nbatch = S.has_unit && !S.empty ? (S.t1 - S.t0 + ATTN_U * tstride - 1) / (ATTN_U * tstride) : 0;
     const float* tab_pos = a.rope_table + (size_t)pos * hd;
 
-    MvStep<false> s1a, s1b, s4a, s4b, s6a, s6b;
-    MvStep<true> s5a, s5b;
-    s1a = s1b = s4a = s4b = s6a = s6b = MvStep<false>{};
-    s5a = s5b = MvStep<true>{};
+    MvRegs<false, S1> r1;
+    MvRegs<false, S4> r4;
+    MvRegs<true, S5> r5;
+    MvRegs<false, S6> r6;
     u32x4 kk[ATTN_U], vv[ATTN_U];
 #pragma unroll
     for (int u = 0; u < ATTN_U; u++) kk[u] = vv[u] = u32x4{0, 0, 0, 0};
-    auto issue_kv = [&](const EngLayer& ly, int tb, int tend) {
+    // K and V tiles are requested separately: a batch's keys are dead once its scores are formed, its values once P.V is summed, so the
+    // next batch's loads go straight into the same registers (no second copy of the tiles)
+    auto issue_k = [&](const EngLayer& ly, int tb, int tend) {
 #pragma unroll
         for (int u = 0; u < ATTN_U; u++) {
             const int t = tb + u * tstride;
-            kk[u] = u32x4{0, 0, 0, 0}, vv[u] = u32x4{0, 0, 0, 0};
-            if (t < tend) {
-                const size_t o = (size_t)t * a.kv_stride + (size_t)kvh * hd + d0;
-                kk[u] = *reinterpret_cast<const u32x4*>(ly.kcache + o);
-                vv[u] = *reinterpret_cast<const u32x4*>(ly.vcache + o);
-            }
+            kk[u] = u32x4{0, 0, 0, 0};
+            if (t < tend) kk[u] = *reinterpret_cast<const u32x4 KF_GLOBAL*>(ly.kcache + ((size_t)((a.exp_flags & 2) ? 0 : t) * a.kv_stride + (size_t)kvh * hd + d0));
         }
     };
-    mv_prefetch<NCW, FMT, false>(P1, L.lay[0].m, w1, lane, s1a, s1b);
+    auto issue_v = [&](const EngLayer& ly, int tb, int tend) {
+#pragma unroll
+        for (int u = 0; u < ATTN_U; u++) {
+            const int t = tb + u * tstride;
+            vv[u] = u32x4{0, 0, 0, 0};
+            if (t < tend) vv[u] = *reinterpret_cast<const u32x4 KF_GLOBAL*>(ly.vcache + ((size_t)((a.exp_flags & 2) ? 0 : t) * a.kv_stride + (size_t)kvh * hd + d0));
+        }
+    };
+    auto issue_kv = [&](const EngLayer& ly, int tb, int tend) { issue_k(ly, tb, tend), issue_v(ly, tb, tend); };
+    mv_prefetch<NCW, FMT, false, S1>(P1, L.lay[0].m, wg, wave, lane, r1, a.exp_flags);
     if (aw && !S.empty) issue_kv(L.lay[0], tstart, t1);
 
     for (int l = 0; l < a.n_layer; l++) {
@@ -429,14 +534,18 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         }
         // ================= P1: RMSNorm(x) -> Q, K, V rows
         __syncthreads();
-        mv_prefetch<NCW, FMT, false>(P4, ly.m + 3, w4, lane, s4a, s4b);
-        mv_run<NCW, FMT, false>(P1, ly.m, w1, s1a, s1b, L.xs[0], lane, [&](int j, int row, float v, float) {
+        if (wave == 0) ENG_STAMP(1, 0);
+        mv_prefetch<NCW, FMT, false, S4>(P4, ly.m + 3, wg, wave, lane, r4, a.exp_flags);
+        mv_run<NCW, FMT, false, S1>(P1, qb1, wg, wave, lane, r1, L.xs[0], [&](int j, int row, float v, float) {
             const int idx = j == 0 ? row : (j == 1 ? a.q_dim + row : a.q_dim + a.kv_dim + row);
-            st_gran(a.qkv + idx, tag, f2bf(v));
+            L.outb[idx - i1] = (tag << 16) | (uint32_t)f2bf(v);
         });
+        if (has1 && wave < NWP1) wg_publish(L, a.qkv, i1, R1, NWP1, lane, a.gls, a.ncopy, a.cstride);
         // ================= P2: q/k-norm + RoPE + attention over this workgroup's slice
+        if (wave == 0) ENG_STAMP(1, 1);
         if (S.has_unit) {
             __syncthreads(); /* raw heads staged */
+            if (wave == 0) ENG_STAMP(1, 2);
             if (!S.empty) {
                 if (aw) { /* prologue: q heads of this group, and the new key when it lies in this slice (ROPE::cuInfer) */
                     const bool qnorm = ly.norm_q != nullptr;
@@ -470,8 +579,8 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
                 }
                 if (aw) {
                     if (S.own_new) { /* the cache rows of this position: the prepared key, the raw value (K.out / V.out alias them in the reference) */
-                        uint16_t* krow = ly.kcache + (size_t)pos * a.kv_stride + (size_t)kvh * hd;
-                        uint16_t* vrow = ly.vcache + (size_t)pos * a.kv_stride + (size_t)kvh * hd;
+                        g_u16w krow = ly.kcache + (size_t)pos * a.kv_stride + (size_t)kvh * hd;
+                        g_u16w vrow = ly.vcache + (size_t)pos * a.kv_stride + (size_t)kvh * hd;
                         for (int i = tid; i < hd; i += NW * 64) krow[i] = L.knew[i], vrow[i] = L.vraw[i];
                     }
 #pragma unroll
@@ -481,20 +590,15 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
                 for (int b = 0; b < nbatch; b++) {
                     const int tb = tstart + b * ATTN_U * tstride;
                     float s[ATTN_U][GQ], bm[GQ];
-                    u32x4 cv[ATTN_U];
 #pragma unroll
                     for (int hq = 0; hq < GQ; hq++) bm[hq] = -__builtin_inff();
                     if (aw) {
-                        u32x4 ck[ATTN_U];
-#pragma unroll
-                        for (int u = 0; u < ATTN_U; u++) ck[u] = kk[u], cv[u] = vv[u];
-                        if (b + 1 < nbatch) issue_kv(ly, tb + ATTN_U * tstride, t1);
 #pragma unroll
                         for (int u = 0; u < ATTN_U; u++) {
                             const int t = tb + u * tstride;
                             const bool valid = t < t1;
-                            u32x4 kw = ck[u];
-                            if (valid && t == pos) kw = *reinterpret_cast<const u32x4*>(L.knew + d0), cv[u] = *reinterpret_cast<const u32x4*>(L.vraw + d0);
+                            u32x4 kw = kk[u];
+                            if (valid && t == pos) kw = *reinterpret_cast<const u32x4*>(L.knew + d0), vv[u] = *reinterpret_cast<const u32x4*>(L.vraw + d0);
 #pragma unroll
                             for (int hq = 0; hq < GQ; hq++) {
                                 float d = dot2_bf16(qreg[hq].x, kw.x, 0.f);
@@ -512,6 +616,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
                             bm[hq] = xmax32(xmax16(bm[hq]));
                             if (LPK < 16) bm[hq] = fmaxf(bm[hq], dpp_f<0x128>(bm[hq]));
                         }
+                        if (b + 1 < nbatch) issue_k(ly, tb + ATTN_U * tstride, t1);
                     }
                     __syncthreads();
                     if (aw && lane == 0) {
@@ -536,7 +641,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
 #pragma unroll
                         for (int u = 0; u < ATTN_U; u++) {
                             float vf_[8];
-                            const uint32_t vw[4] = {cv[u].x, cv[u].y, cv[u].z, cv[u].w};
+                            const uint32_t vw[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
 #pragma unroll
                             for (int i = 0; i < 4; i++) vf_[2 * i] = bf_lo(vw[i]), vf_[2 * i + 1] = bf_hi(vw[i]);
 #pragma unroll
@@ -547,6 +652,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
                                 for (int i = 0; i < 8; i++) acc[hq][i] = fmaf(p, vf_[i], acc[hq][i]);
                             }
                         }
+                        if (b + 1 < nbatch) issue_v(ly, tb + ATTN_U * tstride, t1);
                     }
                 }
                 if (aw) { /* key-group sums (reduce-scatter by row swaps), waves through LDS */
@@ -584,7 +690,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
                             Ls += c[hd];
                         }
                         if (nsp == 1) {
-                            st_gran(a.ao + (size_t)(h0 + hq) * hd + d, tag, f2bf(o * (1.0f / Ls)));
+                            pub_gran(a.ao, goff((h0 + hq) * hd + d, a.gls), a.ncopy, a.cstride, tag, f2bf(o * (1.0f / Ls)));
                         } else {
                             float Mh = M[0];
 #pragma unroll
@@ -605,48 +711,57 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
             }
         }
         // the next layer's K/V tiles of this slice (they do not depend on this token, except row `pos`, which is substituted)
+        if (wave == 0) ENG_STAMP(1, 3);
         if (aw && !S.empty && !last) issue_kv(L.lay[l + 1], tstart, t1);
 
         // ================= P4: o_proj + residual -> xB
         __syncthreads();
-        mv_prefetch<NCW, FMT, true>(P5, ly.m + 4, w5, lane, s5a, s5b);
-        mv_run<NCW, FMT, false>(P4, ly.m + 3, w4, s4a, s4b, L.xs[1], lane, [&](int, int row, float v, float) {
+        if (wave == 0) ENG_STAMP(1, 4);
+        mv_prefetch<NCW, FMT, true, S5>(P5, ly.m + 4, wg, wave, lane, r5, a.exp_flags);
+        mv_run<NCW, FMT, false, S4>(P4, qb4, wg, wave, lane, r4, L.xs[1], [&](int, int row, float v, float) {
             const uint16_t o = f2bf(v);
-            st_gran(a.xB + row, tag, f2bf(bf2f(L.xrawA[row]) + bf2f(o))); /* CU_add3: bf16(x + bf16(W.x)) */
+            L.outb[row - wg * R4] = (tag << 16) | (uint32_t)f2bf(bf2f(L.xrawA[row]) + bf2f(o)); /* CU_add3: bf16(x + bf16(W.x)) */
         });
+        if (has4 && wave < NWP4) wg_publish(L, a.xB, wg * R4, R4, NWP4, lane, a.gls, a.ncopy, a.cstride);
         // ================= P5: RMSNorm + gate/up + SwiGLU -> act
+        if (wave == 0) ENG_STAMP(1, 5);
         __syncthreads();
-        mv_prefetch<NCW, FMT, false>(P6, ly.m + 6, w6, lane, s6a, s6b);
-        mv_run<NCW, FMT, true>(P5, ly.m + 4, w5, s5a, s5b, L.xs[0], lane, [&](int, int row, float v, float v2) {
+        if (wave == 0) ENG_STAMP(1, 6);
+        mv_prefetch<NCW, FMT, false, S6>(P6, ly.m + 6, wg, wave, lane, r6, a.exp_flags);
+        mv_run<NCW, FMT, true, S5>(P5, qb5, wg, wave, lane, r5, L.xs[0], [&](int, int row, float v, float v2) {
             const float gt = round_bf16(v), up = round_bf16(v2); /* CU_swiglu_v0 on the two bf16-rounded projections */
-            st_gran(a.act + row, tag, f2bf((gt * up) / (1.0f + kf_expf(-gt))));
+            L.outb[row - wg * R5] = (tag << 16) | (uint32_t)f2bf((gt * up) / (1.0f + kf_expf(-gt)));
         });
+        if (has5 && wave < NWP5) wg_publish(L, a.act, wg * R5, R5, NWP5, lane, a.gls, a.ncopy, a.cstride);
         // ================= P6: down_proj + residual -> x of the next layer
+        if (wave == 0) ENG_STAMP(1, 7);
         __syncthreads();
-        if (!last) mv_prefetch<NCW, FMT, false>(P1, L.lay[l + 1].m, w1, lane, s1a, s1b);
-        mv_run<NCW, FMT, false>(P6, ly.m + 6, w6, s6a, s6b, L.xs[1], lane, [&](int, int row, float v, float) {
+        if (wave == 0) ENG_STAMP(1, 8);
+        if (!last) mv_prefetch<NCW, FMT, false, S1>(P1, L.lay[l + 1].m, wg, wave, lane, r1, a.exp_flags);
+        mv_run<NCW, FMT, false, S6>(P6, qb6, wg, wave, lane, r6, L.xs[1], [&](int, int row, float v, float) {
             const uint16_t o = f2bf(v);
             const uint16_t y = f2bf(bf2f(L.xrawB[row]) + bf2f(o));
             if (last)
                 a.x_out[row] = y;
             else
-                st_gran(a.xA + row, tag_next, y);
+                L.outb[row - wg * R6] = (tag_next << 16) | (uint32_t)y;
         });
+        if (!last && has6 && wave < NWP6) wg_publish(L, a.xA, wg * R6, R6, NWP6, lane, a.gls, a.ncopy, a.cstride);
+        if (wave == 0) ENG_STAMP(1, 9);
     }
 }
 
-// ND, NQD, NF: dim / 256, q_dim / 256, ffn / 256 (the poller's sweeps are straight-line code)
-template <int FMT, int GQ, int HD, int NWV, int ND, int NQD, int NF>
+// DIM, QD, KVD, FFN: the model's dim, q_dim, kv_dim, ffn; NWG: the grid (= CUs): sweeps and mat-vec geometry are straight-line code
+template <int FMT, int GQ, int HD, int NWV, int DIM, int QD, int KVD, int FFN, int NWG>
 __global__ void __launch_bounds__(NWV * 64) engine_kernel(const EngArgs a) {
     constexpr int hd = HD, NW = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
     // ---- LDS carve
     EngLds L;
-    EngPlan* plan = reinterpret_cast<EngPlan*>(smem);
-    EngLayer* lay = reinterpret_cast<EngLayer*>(smem + 4 * sizeof(EngPlan));
-    size_t off = (4 * sizeof(EngPlan) + (size_t)a.n_layer * sizeof(EngLayer) + 15) & ~(size_t)15;
-    L.plan = plan, L.lay = lay;
+    EngLayer* lay = reinterpret_cast<EngLayer*>(smem);
+    size_t off = ((size_t)a.n_layer * sizeof(EngLayer) + 15) & ~(size_t)15;
+    L.lay = lay;
     L.xs[0] = reinterpret_cast<u32x4*>(smem + off), off += a.lds_xs_bytes;
     L.xs[1] = reinterpret_cast<u32x4*>(smem + off), off += a.lds_xs_bytes;
     L.xrawA = reinterpret_cast<uint16_t*>(smem + off), off += ((size_t)a.dim * 2 + 15) & ~(size_t)15;
@@ -655,15 +770,16 @@ __global__ void __launch_bounds__(NWV * 64) engine_kernel(const EngArgs a) {
     L.kraw = L.qraw + GQ * hd, L.vraw = L.kraw + hd, L.qb = L.vraw + hd, L.knew = L.qb + GQ * hd;
     L.wmax = reinterpret_cast<float*>(L.knew + hd); /* [NW][GQ] */
     L.comb = L.wmax + NW * GQ + 4;                  /* [NW][GQ][hd + 4] */
+    L.outb = reinterpret_cast<uint32_t*>(L.comb + NW * GQ * (hd + 4));
+    L.cnt = reinterpret_cast<int*>(L.outb + 64);
+    if (tid == 0) *L.cnt = 0;
     // ---- start: state, generation, tables
     EngSlice S;
     S.pos = a.d_state[1];
     const int epoch = a.ws[0];
     {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.plans);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(plan);
-        for (int i = tid; i < (int)(4 * sizeof(EngPlan) / 4); i += NWV * 64) dst[i] = src[i];
-        src = reinterpret_cast<const uint32_t*>(a.layers), dst = reinterpret_cast<uint32_t*>(lay);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.layers);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(lay);
         const int nw = a.n_layer * (int)(sizeof(EngLayer) / 4);
         for (int i = tid; i < nw; i += NWV * 64) dst[i] = src[i];
     }
@@ -678,9 +794,9 @@ __global__ void __launch_bounds__(NWV * 64) engine_kernel(const EngArgs a) {
     S.me0 = wg * a.merge_e;
     S.has_merge = a.nsp > 1 && S.me0 < a.n_head * hd;
     if (wave == NWV - 1)
-        eng_poller_main<FMT, GQ, HD, NWV, ND, NQD, NF>(a, L, S, epoch, wg, lane);
+        eng_poller_main<FMT, GQ, HD, NWV, DIM, QD, KVD, FFN, NWG>(a, L, S, epoch, wg, lane);
     else
-        eng_compute_main<FMT, GQ, HD, NWV>(a, L, S, epoch, wg, wave, lane);
+        eng_compute_main<FMT, GQ, HD, NWV, DIM, QD, KVD, FFN, NWG>(a, L, S, epoch, wg, wave, lane);
     // the next launch's generation (workgroup 0 owns rows of the last phase, so every workgroup has read the epoch long before)
     if (wg == 0 && tid == 0) a.ws[0] = epoch + 1;
 }
@@ -695,7 +811,7 @@ struct EngineHost {
 };
 
 // the instantiated model shapes: {GQA group, head_dim, dim, q_dim, ffn}
-static int engine_shape_class(int GQ, int hd, int dim, int q_dim, int ffn) {
+static int engine_shape_class(int GQ, int hd, int dim, int q_dim, int ffn) { /* kv_dim = q_dim / GQ */
     if (GQ == 2 && hd == 128 && dim == 1024 && q_dim == 2048 && ffn == 3072) return 1; /* Qwen3-0.6B (BASELINE config 2) */
     if (GQ == 2 && hd == 64 && dim == 256 && q_dim == 256 && ffn == 512) return 2;     /* the small parity-test shape */
     return 0;
@@ -746,7 +862,7 @@ size_t engine_ws_bytes(const kf_engine_desc* d) {
     // [ws: 64 B] [EngLayer table] [xA dim][qkv q+2kv][ao q][xB dim][act ffn] granules (4 B) [part: n_head*32*(hd+4) 8-byte granules] [EngineHost]
     const size_t q_dim = (size_t)d->n_head * d->head_dim, kv_dim = (size_t)d->n_kv * d->head_dim;
     size_t b = 256 + 512 + (((size_t)d->n_layer * sizeof(EngLayer) + 255) & ~(size_t)255);
-    b += 4 * (((size_t)d->dim * 2 + q_dim * 2 + 2 * kv_dim + d->ffn + 1023) & ~(size_t)255);
+    b += 8 * ((size_t)ENG_GLS_MAX * 4 * (((size_t)d->dim * 2 + q_dim * 2 + 2 * kv_dim + d->ffn) / 32 + 8) + 2048);
     b += 8 * (size_t)d->n_head * KF_ATTN_MAX_SPLITS * (d->head_dim + 4) + 256;
     return b;
 }
@@ -765,6 +881,11 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     EngineHost* E = new EngineHost();
     memset(E, 0, sizeof(*E));
     EngArgs& a = E->args;
+    if (n_cu < ENG_NWG) {
+        delete E;
+        return KF_UNSUPPORTED_DATATYPE; /* one resident workgroup per CU is the engine's premise */
+    }
+    n_cu = ENG_NWG;
     a.n_layer = d->n_layer, a.n_wg = n_cu;
     a.dim = d->dim, a.n_head = d->n_head, a.n_kv = d->n_kv, a.hd = hd, a.q_dim = d->n_head * hd, a.kv_dim = d->n_kv * hd, a.ffn = d->ffn, a.kv_stride = d->kv_stride;
     a.eps = d->rms_eps, a.qk_eps = d->qk_eps, a.rope_table = d->rope_table;
@@ -801,15 +922,24 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
         }
         for (int j = 0; j < 7; j++) {
             const kf_weight& w = L.w[j];
-            tab[l].m[j].w = reinterpret_cast<const u32x4*>(w.data);
+            tab[l].m[j].w = (g_u32x4)(uintptr_t)w.data;
             tab[l].m[j].zero = tab[l].m[j].step = nullptr;
             if (fmt >= FMT_Q4) {
-                tab[l].m[j].zero = w.gama + w.ne0 + w.ne1;
-                tab[l].m[j].step = tab[l].m[j].zero + (size_t)w.ne0 * w.ne1 / w.lGroup;
+                tab[l].m[j].zero = (g_u16)(uintptr_t)(w.gama + w.ne0 + w.ne1);
+                tab[l].m[j].step = (g_u16)(uintptr_t)(w.gama + w.ne0 + w.ne1 + (size_t)w.ne0 * w.ne1 / w.lGroup);
             }
         }
-        tab[l].norm_in = L.norm_in, tab[l].norm_post = L.norm_post, tab[l].norm_q = L.q_norm, tab[l].norm_k = L.k_norm;
-        tab[l].kcache = L.kcache, tab[l].vcache = L.vcache;
+        if (l == 0)
+            for (int j = 0; j < 7; j++) a.qbias[j] = (float)L.w[j].qBias;
+        else
+            for (int j = 0; j < 7; j++)
+                if (a.qbias[j] != (float)L.w[j].qBias) {
+                    delete E;
+                    return KF_UNSUPPORTED_DATATYPE;
+                }
+        tab[l].norm_in = (g_u16)(uintptr_t)L.norm_in, tab[l].norm_post = (g_u16)(uintptr_t)L.norm_post;
+        tab[l].norm_q = (g_u16)(uintptr_t)L.q_norm, tab[l].norm_k = (g_u16)(uintptr_t)L.k_norm;
+        tab[l].kcache = (g_u16w)(uintptr_t)L.kcache, tab[l].vcache = (g_u16w)(uintptr_t)L.vcache;
     }
     if (fmt == FMT_Q4 && q4p_ok && !(getenv("KF_Q4_PERM") && atoi(getenv("KF_Q4_PERM")) == 0)) fmt = FMT_Q4P;
     E->fmt = fmt, E->GQ = GQ, E->hd = hd, E->n_cu = n_cu, E->nwv = 8, E->shape_class = shape_class;
@@ -819,12 +949,22 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     a.ws = reinterpret_cast<int*>(p), p += 256;
     a.plans = reinterpret_cast<const EngPlan*>(p), p += 512;
     a.layers = reinterpret_cast<const EngLayer*>(p), p += ((size_t)d->n_layer * sizeof(EngLayer) + 255) & ~(size_t)255;
+    a.gls = 32, a.poll_sleep = 1;
+    if (const char* e = getenv("KF_ENG_GLS")) a.gls = atoi(e); /* tuning knobs of the hand-off (scratch/eng_stamps.py) */
+    if (const char* e = getenv("KF_ENG_SLEEP")) a.poll_sleep = atoi(e);
+    if (const char* e = getenv("KF_ENG_EXP")) a.exp_flags = atoi(e);
+    if (a.gls < 32 || a.gls > ENG_GLS_MAX || a.poll_sleep < 0) a.gls = 32, a.poll_sleep = 1;
     auto gran = [&](size_t n) {
         uint32_t* r = reinterpret_cast<uint32_t*>(p);
-        p += (n * 4 + 255) & ~(size_t)255;
+        p += (((n + 31) / 32) * (size_t)a.gls * 4 + 255) & ~(size_t)255;
         return r;
     };
+    a.ncopy = 1;
+    if (const char* e = getenv("KF_ENG_COPIES")) a.ncopy = atoi(e) == 8 ? 8 : 1;
+    char* const g0 = p;
     a.xA = gran(a.dim), a.qkv = gran((size_t)a.q_dim + 2 * a.kv_dim), a.ao = gran(a.q_dim), a.xB = gran(a.dim), a.act = gran(a.ffn);
+    a.cstride = (int)((p - g0) / 4);
+    p = g0 + (size_t)a.ncopy * a.cstride * 4;
     a.part = reinterpret_cast<unsigned long long*>(p);
     if (hipMemsetAsync(ws, 0xff, ws_bytes, st) != hipSuccess) {
         delete E;
@@ -838,12 +978,17 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
         delete E;
         return KF_HIP_CHECK;
     }
+    if (const char* e = getenv("KF_ENG_DEBUG")) { /* diagnostic runs: per-phase wall-clock stamps of one workgroup */
+        if (hipMalloc(&a.dbg, (size_t)d->n_layer * 2 * 16 * 8) != hipSuccess) a.dbg = nullptr;
+        if (a.dbg) (void)hipMemset(a.dbg, 0, (size_t)d->n_layer * 2 * 16 * 8);
+        a.dbg_wg = atoi(e);
+    }
     // LDS
     int maxK = a.dim > a.q_dim ? a.dim : a.q_dim;
     if (a.ffn > maxK) maxK = a.ffn;
     a.lds_xs_bytes = (maxK * 2 + 15) & ~15;
-    size_t smem = ((4 * sizeof(EngPlan) + (size_t)d->n_layer * sizeof(EngLayer) + 15) & ~(size_t)15) + 2 * (size_t)a.lds_xs_bytes + 2 * (((size_t)a.dim * 2 + 15) & ~(size_t)15);
-    smem += sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + sizeof(float) * (4 * GQ + 4 + (size_t)4 * GQ * (hd + 4));
+    size_t smem = (((size_t)d->n_layer * sizeof(EngLayer) + 15) & ~(size_t)15) + 2 * (size_t)a.lds_xs_bytes + 2 * (((size_t)a.dim * 2 + 15) & ~(size_t)15);
+    smem += sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + sizeof(float) * (4 * GQ + 4 + (size_t)4 * GQ * (hd + 4)) + 4 * 64 + 16;
     smem = (smem + 15) & ~(size_t)15;
     if (smem > 160 * 1024) {
         delete E;
@@ -853,24 +998,52 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     *out = E;
     return KF_OK;
 }
-void engine_free(EngineHost* E) { delete E; }
+void engine_free(EngineHost* E) {
+    if (E && E->args.dbg) (void)hipFree(E->args.dbg);
+    delete E;
+}
+int engine_debug_read(EngineHost* E, unsigned long long* h_out, int n_words) {
+    if (!E->args.dbg) return 0;
+    const int have = E->args.n_layer * 2 * 16;
+    const int n = n_words < have ? n_words : have;
+    if (hipMemcpy(h_out, E->args.dbg, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return n;
+}
 
-template <int FMT, int GQ, int HD, int NWV, int ND, int NQD, int NF>
-static int engine_go(EngineHost* E, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)engine_kernel<FMT, GQ, HD, NWV, ND, NQD, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return KF_HIP_CHECK;
-        attr_done = true;
+template <int FMT, int GQ, int HD, int DIM, int QD, int KVD, int FFN>
+static bool engine_plans_match(const EngineHost* E) {
+    using SH = EngShape<FMT, DIM, QD, KVD, FFN, ENG_NWG>;
+    const CPlan c[4] = {SH::P1, SH::P4, SH::P5, SH::P6};
+    for (int i = 0; i < 4; i++) {
+        const EngPlan& r = E->plans[i];
+        if (r.K != c[i].K || r.nBlk != c[i].nBlk || r.lpr_log2 != c[i].lpr_log2 || r.iters != c[i].iters || r.total_slots != c[i].total || r.spg != c[i].spg ||
+            r.njobs != c[i].njobs)
+            return false;
+        for (int j = 0; j < r.njobs; j++)
+            if (r.slot0[j] != c[i].slot0[j] || r.M[j] != c[i].M[j]) return false;
     }
-    hipLaunchKernelGGL((engine_kernel<FMT, GQ, HD, NWV, ND, NQD, NF>), dim3(E->args.n_wg), dim3(NWV * 64), E->smem, st, E->args);
+    return true;
+}
+template <int FMT, int GQ, int HD, int DIM, int QD, int KVD, int FFN>
+static int engine_go(EngineHost* E, hipStream_t st) {
+    static int ready = 0; /* 1 ok, -1 the compile-time geometry is not the mat-vec launcher's */
+    if (!ready) {
+        if (!engine_plans_match<FMT, GQ, HD, DIM, QD, KVD, FFN>(E)) ready = -1;
+        else if (hipFuncSetAttribute((const void*)engine_kernel<FMT, GQ, HD, ENG_NWV, DIM, QD, KVD, FFN, ENG_NWG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+                 hipSuccess)
+            return KF_HIP_CHECK;
+        else
+            ready = 1;
+    }
+    if (ready < 0) return 1;
+    hipLaunchKernelGGL((engine_kernel<FMT, GQ, HD, ENG_NWV, DIM, QD, KVD, FFN, ENG_NWG>), dim3(ENG_NWG), dim3(ENG_NWV * 64), E->smem, st, E->args);
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 template <int FMT>
 static int engine_go_fmt(EngineHost* E, hipStream_t st) {
     switch (E->shape_class) {
-        case 1: return engine_go<FMT, 2, 128, 8, 4, 8, 12>(E, st);
-        case 2: return engine_go<FMT, 2, 64, 8, 1, 1, 2>(E, st);
+        case 1: return engine_go<FMT, 2, 128, 1024, 2048, 1024, 3072>(E, st);
+        case 2: return engine_go<FMT, 2, 64, 256, 256, 128, 512>(E, st);
         default: return 1;
     }
 }

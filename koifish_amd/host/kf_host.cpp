@@ -525,6 +525,11 @@ int kfh_engine_steps(void* h) {
     Fish* f = reinterpret_cast<Fish*>(h);
     return f->engine_state < 0 ? -1 : f->engine_steps;
 }
+extern "C" int kfdbg_engine_stamps(kf_engine* e, unsigned long long* h_out, int n_words);
+int kfh_engine_stamps(void* h, unsigned long long* out, int n) {
+    Fish* f = reinterpret_cast<Fish*>(h);
+    return f->engine ? kfdbg_engine_stamps(f->engine, out, n) : -1;
+}
 // synchronises; KF_INTERNAL_ERR when one of the engine's hand-off polls has timed out
 int kfh_engine_check(void* h) {
     Fish* f = reinterpret_cast<Fish*>(h);
