@@ -79,6 +79,10 @@ struct EngArgs {
     float qbias[7];                    /* qBias of q k v o gate up down */
     int gls;                           /* dwords between the 128-byte lines (32 granules) of a granule buffer: 32 = dense */
     int poll_sleep;                    /* s_sleep units between two sweeps of a poll */
+    int* tickets;                      /* XCD-mapped form: one ticket word per XCD, 128 bytes apart (zero between launches) */
+    uint32_t* lqkv;                    /* XCD-mapped form: [8][lq_stride] granules: q | k | v rows of the XCD's kv-head, written with plain stores (they stay in that XCD's L2) */
+    unsigned long long* lpart;         /* XCD-mapped form: [8][GQ][32][hd + 4] partial granules of the XCD's kv-head */
+    int lq_stride, lp_stride;
     int ncopy, cstride;                /* every granule buffer exists ncopy times (1 or 8), cstride dwords apart: producers write all copies, a consumer reads the copy of its XCD */
     int exp_flags;                     /* timing experiments only (KF_ENG_EXP; results are wrong): 1 = every weight load from the matrix's first KB, 2 = K/V tiles from row 0 */
     unsigned long long* dbg;           /* diagnostic runs only (KF_ENG_DEBUG): [layer][role][16] wall-clock stamps of workgroup dbg_wg */
@@ -245,10 +249,10 @@ struct MvAt {
 };
 // step k of compute wave cw in workgroup wg: slot wg*spg + cw + (k / iters)*NCW, iteration k % iters
 template <int NCW>
-__device__ __forceinline__ MvAt mv_at(const CPlan& P, int k, int wg, int cw, int lane) {
+__device__ __forceinline__ MvAt mv_at(const CPlan& P, int k, int s0, int cw, int lane) {
     const int LPR = 1 << P.lpr_log2, RPS = 64 >> P.lpr_log2, sub = lane >> P.lpr_log2, ll = lane & (LPR - 1);
     const int sl = k / P.iters, it = k - sl * P.iters;
-    const int s_loc = cw + sl * NCW, s = wg * P.spg + s_loc;
+    const int s_loc = cw + sl * NCW, s = s0 + s_loc;
     int j = 0;
     if (P.njobs > 1 && s >= P.slot0[1]) j = 1;
     if (P.njobs > 2 && s >= P.slot0[2]) j = 2;
@@ -260,12 +264,12 @@ __device__ __forceinline__ MvAt mv_at(const CPlan& P, int k, int wg, int cw, int
     return q;
 }
 template <int NCW, int FMT, bool PAIRED, int MAXS>
-__device__ __forceinline__ void mv_prefetch(const CPlan& P, const EngMat* jm, int wg, int cw, int lane, MvRegs<PAIRED, MAXS>& R, int exp_flags = 0) {
+__device__ __forceinline__ void mv_prefetch(const CPlan& P, const EngMat* jm, int s0, int cw, int lane, MvRegs<PAIRED, MAXS>& R, int exp_flags = 0) {
     constexpr bool GAMA = BlockDot<FMT>::HAS_GAMA;
     constexpr int gshift = FMT >= FMT_Q4 ? (FMT == FMT_Q4 || FMT == FMT_Q4P ? 2 : (FMT == FMT_Q2 ? 1 : 0)) : 0; /* 128-weight groups */
 #pragma unroll
     for (int k = 0; k < MAXS; k++) {
-        const MvAt q = mv_at<NCW>(P, k, wg, cw, lane);
+        const MvAt q = mv_at<NCW>(P, k, s0, cw, lane);
         const int Mj = q.j == 0 ? P.M[0] : (q.j == 1 ? P.M[1] : P.M[2]);
         int row = q.row < Mj ? q.row : Mj - 1;
         row = row > 0 ? row : 0;
@@ -284,14 +288,14 @@ __device__ __forceinline__ void mv_prefetch(const CPlan& P, const EngMat* jm, in
 }
 // epi(job, row, v, v2) runs in the lane that owns a finished row
 template <int NCW, int FMT, bool PAIRED, int MAXS, typename Epi>
-__device__ __forceinline__ void mv_run(const CPlan& P, const float* qb, int wg, int cw, int lane, const MvRegs<PAIRED, MAXS>& R, const u32x4* xs, Epi&& epi) {
+__device__ __forceinline__ void mv_run(const CPlan& P, const float* qb, int s0, int cw, int lane, const MvRegs<PAIRED, MAXS>& R, const u32x4* xs, Epi&& epi) {
     using BD = BlockDot<FMT>;
     float acc = 0.f, acc2 = 0.f;
 #pragma unroll
     for (int k = 0; k < MAXS; k++) {
         const int sl = k / P.iters, it = k - sl * P.iters;
         if (cw + sl * NCW >= P.spg) continue; /* wave-uniform: this wave has no such slot */
-        const MvAt q = mv_at<NCW>(P, k, wg, cw, lane);
+        const MvAt q = mv_at<NCW>(P, k, s0, cw, lane);
         const int col = q.col < P.nBlk ? q.col : P.nBlk - 1;
         if (it == 0) acc = 0.f, acc2 = 0.f;
         const float st = bf2f(R.st[k]);
@@ -325,6 +329,9 @@ struct EngLds {
 struct EngSlice { /* this workgroup's attention slice and merge share */
     int pos, len, nsp, kvh, split, h0, t0, t1, me0;
     bool has_unit, empty, own_new, has_merge;
+    int xcc, rank;  /* XCD-mapped form: the XCD this workgroup runs on and its ticket there */
+    int s1;         /* first P1 slot of this workgroup */
+    int q_out0;     /* index of its first P1 row in the vector its P1 rows are published to */
 };
 
 // The compute waves that own rows of a phase leave their granules in LDS; the wave that arrives last stores the workgroup's rows with ONE
@@ -333,7 +340,8 @@ struct EngSlice { /* this workgroup's attention slice and merge share */
 __device__ __forceinline__ void st_gran16(uint32_t* p, u32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(v, eng_rsrc(p, 16), 0, 0, 16 /* sc1 */);
 }
-__device__ __forceinline__ void wg_publish(const EngLds& L, uint32_t* buf, int idx0, int nrows, int nwaves, int lane, int gls, int ncopy, int cstride) {
+// local = true: plain stores into a buffer of this XCD (dense lines)
+__device__ __forceinline__ void wg_publish(const EngLds& L, uint32_t* buf, int idx0, int nrows, int nwaves, int lane, int gls, int ncopy, int cstride, bool local = false) {
     int old = 0;
     if (lane == 0) old = __hip_atomic_fetch_add(L.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     old = __builtin_amdgcn_readfirstlane(old);
@@ -341,22 +349,35 @@ __device__ __forceinline__ void wg_publish(const EngLds& L, uint32_t* buf, int i
     if (lane == 0) *L.cnt = 0;
     if (4 * lane < nrows) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(L.outb + 4 * lane);
+        if (local) {
+            *reinterpret_cast<u32x4*>(buf + idx0 + 4 * lane) = v;
+            return;
+        }
         const int off = goff(idx0 + 4 * lane, gls);
         for (int c = 0; c < ncopy; c++) st_gran16(buf + (size_t)c * cstride + off, v);
     }
 }
 
 // the poller wave: per layer it stages P1's x, the slice's q/k/v heads, merges, stages P4's, P5's and P6's inputs
-template <int FMT, int GQ, int HD, int NWV, int DIM, int QD, int KVD, int FFN, int NWG>
+template <int FMT, int GQ, int HD, int NWV, int DIM, int QD, int KVD, int FFN, int NWG, bool XMAP>
 __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& L, const EngSlice& S, int epoch, int wg, int lane) {
     using SH = EngShape<FMT, DIM, QD, KVD, FFN, NWG>;
     constexpr int ND = DIM / 256, NQD = QD / 256, NF = FFN / 256;
     constexpr int XCH = BlockDot<FMT>::XCH, hd = HD, hd_log2 = HD == 128 ? 7 : 6, NW = 4, PS = hd + 4, LPK = hd >> 3, KPW = 64 / LPK;
     bool dead = false;
-    const bool has1 = wg * SH::P1.spg < SH::P1.total, has4 = wg * SH::P4.spg < SH::P4.total, has5 = wg * SH::P5.spg < SH::P5.total,
+    const bool has1 = XMAP ? true : wg * SH::P1.spg < SH::P1.total, has4 = wg * SH::P4.spg < SH::P4.total, has5 = wg * SH::P5.spg < SH::P5.total,
                has6 = wg * SH::P6.spg < SH::P6.total;
     const int tstride = NW * KPW;
     const int nbatch = S.has_unit && !S.empty ? (S.t1 - S.t0 + ATTN_U * tstride - 1) / (ATTN_U * tstride) : 0;
+    // the poller's share of P1 (virtual compute wave NWV - 1)
+    constexpr CPlan P1 = SH::P1;
+    constexpr int NCW1 = NWV, S1 = c_maxs<NCW1>(P1), R1 = P1.spg * (64 >> P1.lpr_log2), NWP1 = P1.spg < NCW1 ? P1.spg : NCW1;
+    constexpr bool P1_SHARE = P1.spg >= NWV; /* the poller owns a slot */
+    const float qb1[3] = {a.qbias[0], a.qbias[1], a.qbias[2]};
+    const int j1 = S.s1 >= P1.slot0[2] ? 2 : (S.s1 >= P1.slot0[1] ? 1 : 0);
+    const int row0_1 = (S.s1 - (j1 == 0 ? 0 : (j1 == 1 ? P1.slot0[1] : P1.slot0[2]))) * (64 >> P1.lpr_log2);
+    MvRegs<false, S1> r1;
+    if (P1_SHARE && has1) mv_prefetch<NCW1, FMT, false, S1>(P1, L.lay[0].m, S.s1, NWV - 1, lane, r1, a.exp_flags);
     int sw[4] = {0, 0, 0, 0};
     const size_t cbase = a.ncopy > 1 ? (size_t)(eng_xcc() & (a.ncopy - 1)) * a.cstride : 0; /* this XCD's copy of the granule buffers */
     for (int l = 0; l < a.n_layer; l++) {
@@ -372,19 +393,31 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
         }
         ENG_STAMP(0, 1);
         __syncthreads();
+        if (P1_SHARE && has1) { /* this wave's P1 rows, then the workgroup's publish like every other owner */
+            mv_run<NCW1, FMT, false, S1>(P1, qb1, S.s1, NWV - 1, lane, r1, L.xs[0], [&](int, int row, float v, float) {
+                L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v);
+            });
+            if (XMAP)
+                wg_publish(L, a.lqkv + (size_t)S.xcc * a.lq_stride, S.q_out0, R1, NWP1, lane, 32, 1, 0, true);
+            else
+                wg_publish(L, a.qkv, S.q_out0, R1, NWP1, lane, a.gls, a.ncopy, a.cstride);
+        }
         // P2: q heads of the group (GQ*hd granules), then k and v of the kv-head side by side in one piece
         if (S.has_unit) {
-            const __amdgpu_buffer_rsrc_t rs = eng_rsrc(a.qkv + cbase, (uint32_t)((a.q_dim + 2 * a.kv_dim) / 32) * (uint32_t)a.gls * 4u);
+            // XCD-mapped form: the rows were published by workgroups of this XCD with plain stores into its own dense buffer [q GQ*hd | k hd | v hd]
+            const __amdgpu_buffer_rsrc_t rs = XMAP ? eng_rsrc(a.lqkv + (size_t)S.xcc * a.lq_stride, (uint32_t)(GQ * hd + 2 * hd) * 4u)
+                                                   : eng_rsrc(a.qkv + cbase, (uint32_t)((a.q_dim + 2 * a.kv_dim) / 32) * (uint32_t)a.gls * 4u);
+            const int gl = XMAP ? 32 : a.gls, q_src = XMAP ? 0 : S.h0 * hd;
             constexpr int NLQ = (GQ * hd + 255) / 256;
             u32x4 g[NLQ], gk;
             const int e_kv = 4 * lane; /* < hd: k, < 2hd: v */
             const bool kv_in = e_kv < 2 * hd;
-            const int kv_src = e_kv < hd ? a.q_dim + S.kvh * hd + e_kv : a.q_dim + a.kv_dim + S.kvh * hd + (e_kv - hd);
+            const int kv_src = XMAP ? GQ * hd + e_kv : (e_kv < hd ? a.q_dim + S.kvh * hd + e_kv : a.q_dim + a.kv_dim + S.kvh * hd + (e_kv - hd));
             for (int spins = 0;; spins++) {
                 uint32_t bad = 0;
 #pragma unroll
-                for (int r = 0; r < NLQ; r++) g[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, goff(S.h0 * hd + 4 * (r * 64 + lane), a.gls) * 4, 0, 16));
-                gk = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, goff(kv_in ? kv_src : 0, a.gls) * 4, 0, 16));
+                for (int r = 0; r < NLQ; r++) g[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, goff(q_src + 4 * (r * 64 + lane), gl) * 4, 0, 16));
+                gk = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, goff(kv_in ? kv_src : 0, gl) * 4, 0, 16));
 #pragma unroll
                 for (int r = 0; r < NLQ; r++) bad |= (4 * (r * 64 + lane) < GQ * hd) ? tags_bad(g[r], tag) : 0u;
                 bad |= kv_in ? tags_bad(gk, tag) : 0u;
@@ -416,8 +449,8 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
         // P3: merge the slices of this workgroup's output elements (attention_v_kernel's division, once)
         ENG_STAMP(0, 3);
         if (S.has_merge) {
-            const int nsp = S.nsp, h = S.me0 >> hd_log2, dd = S.me0 & (hd - 1);
-            const unsigned long long* base = a.part + (size_t)h * nsp * PS;
+            const int nsp = S.nsp, h = S.me0 >> hd_log2, dd = S.me0 & (hd - 1); /* XCD-mapped form: me0 counts inside the XCD's GQ heads */
+            const unsigned long long* base = XMAP ? a.lpart + (size_t)S.xcc * a.lp_stride + (size_t)h * nsp * PS : a.part + (size_t)h * nsp * PS;
             float ms = -__builtin_inff(), ls = 0.f, vsp[KF_ATTN_MAX_SPLITS];
             const bool mine = lane < nsp, el = lane < a.merge_e;
             for (int spins = 0;; spins++) {
@@ -447,7 +480,7 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
             float o = 0.f;
 #pragma unroll
             for (int sp = 0; sp < KF_ATTN_MAX_SPLITS; sp++) o = fmaf(vsp[sp], __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sc), sp)), o);
-            if (el) pub_gran(a.ao, goff(S.me0 + lane, a.gls), a.ncopy, a.cstride, tag, f2bf(o * (1.0f / Lt)));
+            if (el) pub_gran(a.ao, goff((XMAP ? S.h0 * hd : 0) + S.me0 + lane, a.gls), a.ncopy, a.cstride, tag, f2bf(o * (1.0f / Lt)));
         }
         // P4, P5 (P6 adds that x as the residual), P6
         ENG_STAMP(0, 4);
@@ -459,18 +492,22 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
         __syncthreads();
         if (has6) eng_poll_stage<XCH, NF, false, false>(a.act + cbase, nullptr, tag, SH::P6.nBlk, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, a.gls, a.poll_sleep, &sw[3], (a.dbg && wg == a.dbg_wg) ? a.dbg + ((size_t)l * 2) * 16 + 9 : nullptr);
         ENG_STAMP(0, 7);
+        if (P1_SHARE && has1 && l + 1 < a.n_layer) mv_prefetch<NCW1, FMT, false, S1>(P1, L.lay[l + 1].m, S.s1, NWV - 1, lane, r1, a.exp_flags);
         if (a.dbg && wg == a.dbg_wg && lane == 0) a.dbg[((size_t)l * 2) * 16 + 8] = (unsigned long long)sw[0] | ((unsigned long long)sw[1] << 16) | ((unsigned long long)sw[2] << 32) | ((unsigned long long)sw[3] << 48);
         __syncthreads();
     }
 }
 
 // the compute waves
-template <int FMT, int GQ, int HD, int NWV, int DIM, int QD, int KVD, int FFN, int NWG>
+template <int FMT, int GQ, int HD, int NWV, int DIM, int QD, int KVD, int FFN, int NWG, bool XMAP>
 __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds& L, const EngSlice& S, int epoch, int wg, int wave, int lane) {
     using SH = EngShape<FMT, DIM, QD, KVD, FFN, NWG>;
     constexpr int NCW = NWV - 1;
     constexpr CPlan P1 = SH::P1, P4 = SH::P4, P5 = SH::P5, P6 = SH::P6;
-    constexpr int S1 = c_maxs<NCW>(P1), S4 = c_maxs<NCW>(P4), S5 = c_maxs<NCW>(P5), S6 = c_maxs<NCW>(P6);
+    // P1 alone is shared with the poller wave (it is idle between staging x and the first q/k/v granules): NWV waves, so that the 0.6B shape's
+    // 8 row-slots per workgroup are one step for every wave instead of two for wave 0
+    constexpr int NCW1 = NWV;
+    constexpr int S1 = c_maxs<NCW1>(P1), S4 = c_maxs<NCW>(P4), S5 = c_maxs<NCW>(P5), S6 = c_maxs<NCW>(P6);
     constexpr int hd = HD, hd_log2 = HD == 128 ? 7 : 6, NW = 4, PS = hd + 4;
     constexpr int LPK = hd >> 3, KPW = 64 / LPK, lpk_log2 = hd_log2 - 3;
     constexpr int NQ = (GQ + NW - 1) / NW;
@@ -481,11 +518,11 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
     static_assert(R1 % 4 == 0 && R4 % 4 == 0 && R5 % 4 == 0 && R6 % 4 == 0 && R1 <= 64 && R4 <= 64 && R5 <= 64 && R6 <= 64, "rows per workgroup");
     static_assert(P1.total % P1.spg == 0 && P4.total % P4.spg == 0 && P5.total % P5.spg == 0 && P6.total % P6.spg == 0, "whole workgroups");
     static_assert(P1.slot0[1] % P1.spg == 0 && P1.slot0[2] % P1.spg == 0, "a workgroup's P1 rows belong to one matrix");
-    constexpr int NWP1 = P1.spg < NCW ? P1.spg : NCW, NWP4 = P4.spg < NCW ? P4.spg : NCW, NWP5 = P5.spg < NCW ? P5.spg : NCW, NWP6 = P6.spg < NCW ? P6.spg : NCW;
-    const bool has1 = wg * P1.spg < P1.total, has4 = wg * P4.spg < P4.total, has5 = wg * P5.spg < P5.total, has6 = wg * P6.spg < P6.total;
-    // first index of this workgroup's P1 rows in the concatenated [q | k | v] vector
-    const int s1 = wg * P1.spg, j1 = s1 >= P1.slot0[2] ? 2 : (s1 >= P1.slot0[1] ? 1 : 0);
-    const int i1 = (j1 == 0 ? 0 : (j1 == 1 ? a.q_dim : a.q_dim + a.kv_dim)) + (s1 - (j1 == 0 ? 0 : (j1 == 1 ? P1.slot0[1] : P1.slot0[2]))) * (64 >> P1.lpr_log2);
+    constexpr int NWP1 = P1.spg < NCW1 ? P1.spg : NCW1, NWP4 = P4.spg < NCW ? P4.spg : NCW, NWP5 = P5.spg < NCW ? P5.spg : NCW, NWP6 = P6.spg < NCW ? P6.spg : NCW;
+    const bool has1 = XMAP ? true : wg * P1.spg < P1.total, has4 = wg * P4.spg < P4.total, has5 = wg * P5.spg < P5.total, has6 = wg * P6.spg < P6.total;
+    // the first row (inside its matrix) of this workgroup's P1 rows
+    const int j1 = S.s1 >= P1.slot0[2] ? 2 : (S.s1 >= P1.slot0[1] ? 1 : 0);
+    const int row0_1 = (S.s1 - (j1 == 0 ? 0 : (j1 == 1 ? P1.slot0[1] : P1.slot0[2]))) * (64 >> P1.lpr_log2);
     const bool aw = wave < NW && S.has_unit; /* attention waves */
     const int pos = S.pos, nsp = S.nsp, kvh = S.kvh, h0 = S.h0, t1 = S.t1;
     const int grp = lane >> lpk_log2, d0 = (lane & (LPK - 1)) * 8;
@@ -519,7 +556,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         }
     };
     auto issue_kv = [&](const EngLayer& ly, int tb, int tend) { issue_k(ly, tb, tend), issue_v(ly, tb, tend); };
-    mv_prefetch<NCW, FMT, false, S1>(P1, L.lay[0].m, wg, wave, lane, r1, a.exp_flags);
+    mv_prefetch<NCW1, FMT, false, S1>(P1, L.lay[0].m, S.s1, wave, lane, r1, a.exp_flags);
     if (aw && !S.empty) issue_kv(L.lay[0], tstart, t1);
 
     for (int l = 0; l < a.n_layer; l++) {
@@ -535,12 +572,16 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         // ================= P1: RMSNorm(x) -> Q, K, V rows
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 0);
-        mv_prefetch<NCW, FMT, false, S4>(P4, ly.m + 3, wg, wave, lane, r4, a.exp_flags);
-        mv_run<NCW, FMT, false, S1>(P1, qb1, wg, wave, lane, r1, L.xs[0], [&](int j, int row, float v, float) {
-            const int idx = j == 0 ? row : (j == 1 ? a.q_dim + row : a.q_dim + a.kv_dim + row);
-            L.outb[idx - i1] = (tag << 16) | (uint32_t)f2bf(v);
+        mv_prefetch<NCW, FMT, false, S4>(P4, ly.m + 3, wg * P4.spg, wave, lane, r4, a.exp_flags);
+        mv_run<NCW1, FMT, false, S1>(P1, qb1, S.s1, wave, lane, r1, L.xs[0], [&](int j, int row, float v, float) {
+            L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); /* a workgroup's P1 rows belong to one matrix (j == j1) */
         });
-        if (has1 && wave < NWP1) wg_publish(L, a.qkv, i1, R1, NWP1, lane, a.gls, a.ncopy, a.cstride);
+        if (has1 && wave < NWP1) {
+            if (XMAP)
+                wg_publish(L, a.lqkv + (size_t)S.xcc * a.lq_stride, S.q_out0, R1, NWP1, lane, 32, 1, 0, true);
+            else
+                wg_publish(L, a.qkv, S.q_out0, R1, NWP1, lane, a.gls, a.ncopy, a.cstride);
+        }
         // ================= P2: q/k-norm + RoPE + attention over this workgroup's slice
         if (wave == 0) ENG_STAMP(1, 1);
         if (S.has_unit) {
@@ -695,18 +736,30 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
                             float Mh = M[0];
 #pragma unroll
                             for (int q2 = 1; q2 < GQ; q2++) Mh = (hq == q2) ? M[q2] : Mh;
-                            unsigned long long* dst = a.part + ((size_t)(h0 + hq) * nsp + S.split) * PS;
-                            st_gran64(dst + d, gen, o);
-                            if (d == 0) st_gran64(dst + hd, gen, Mh), st_gran64(dst + hd + 1, gen, Ls);
+                            if (XMAP) { /* plain 8-byte stores into this XCD's partial buffer */
+                                unsigned long long* dst = a.lpart + (size_t)S.xcc * a.lp_stride + ((size_t)hq * nsp + S.split) * PS;
+                                dst[d] = ((unsigned long long)gen << 32) | __float_as_uint(o);
+                                if (d == 0) dst[hd] = ((unsigned long long)gen << 32) | __float_as_uint(Mh), dst[hd + 1] = ((unsigned long long)gen << 32) | __float_as_uint(Ls);
+                            } else {
+                                unsigned long long* dst = a.part + ((size_t)(h0 + hq) * nsp + S.split) * PS;
+                                st_gran64(dst + d, gen, o);
+                                if (d == 0) st_gran64(dst + hd, gen, Mh), st_gran64(dst + hd + 1, gen, Ls);
+                            }
                         }
                     }
                 }
             } else if (nsp > 1 && aw) { /* empty slice: neutral partial */
                 for (int i = tid; i < GQ * hd; i += NW * 64) {
                     const int hq = i >> hd_log2, d = i & (hd - 1);
-                    unsigned long long* dst = a.part + ((size_t)(h0 + hq) * nsp + S.split) * PS;
-                    st_gran64(dst + d, gen, 0.f);
-                    if (d == 0) st_gran64(dst + hd, gen, -__builtin_inff()), st_gran64(dst + hd + 1, gen, 0.f);
+                    if (XMAP) {
+                        unsigned long long* dst = a.lpart + (size_t)S.xcc * a.lp_stride + ((size_t)hq * nsp + S.split) * PS;
+                        dst[d] = (unsigned long long)gen << 32;
+                        if (d == 0) dst[hd] = ((unsigned long long)gen << 32) | 0xff800000u, dst[hd + 1] = (unsigned long long)gen << 32;
+                    } else {
+                        unsigned long long* dst = a.part + ((size_t)(h0 + hq) * nsp + S.split) * PS;
+                        st_gran64(dst + d, gen, 0.f);
+                        if (d == 0) st_gran64(dst + hd, gen, -__builtin_inff()), st_gran64(dst + hd + 1, gen, 0.f);
+                    }
                 }
             }
         }
@@ -717,8 +770,8 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         // ================= P4: o_proj + residual -> xB
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 4);
-        mv_prefetch<NCW, FMT, true, S5>(P5, ly.m + 4, wg, wave, lane, r5, a.exp_flags);
-        mv_run<NCW, FMT, false, S4>(P4, qb4, wg, wave, lane, r4, L.xs[1], [&](int, int row, float v, float) {
+        mv_prefetch<NCW, FMT, true, S5>(P5, ly.m + 4, wg * P5.spg, wave, lane, r5, a.exp_flags);
+        mv_run<NCW, FMT, false, S4>(P4, qb4, wg * P4.spg, wave, lane, r4, L.xs[1], [&](int, int row, float v, float) {
             const uint16_t o = f2bf(v);
             L.outb[row - wg * R4] = (tag << 16) | (uint32_t)f2bf(bf2f(L.xrawA[row]) + bf2f(o)); /* CU_add3: bf16(x + bf16(W.x)) */
         });
@@ -727,8 +780,8 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         if (wave == 0) ENG_STAMP(1, 5);
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 6);
-        mv_prefetch<NCW, FMT, false, S6>(P6, ly.m + 6, wg, wave, lane, r6, a.exp_flags);
-        mv_run<NCW, FMT, true, S5>(P5, qb5, wg, wave, lane, r5, L.xs[0], [&](int, int row, float v, float v2) {
+        mv_prefetch<NCW, FMT, false, S6>(P6, ly.m + 6, wg * P6.spg, wave, lane, r6, a.exp_flags);
+        mv_run<NCW, FMT, true, S5>(P5, qb5, wg * P5.spg, wave, lane, r5, L.xs[0], [&](int, int row, float v, float v2) {
             const float gt = round_bf16(v), up = round_bf16(v2); /* CU_swiglu_v0 on the two bf16-rounded projections */
             L.outb[row - wg * R5] = (tag << 16) | (uint32_t)f2bf((gt * up) / (1.0f + kf_expf(-gt)));
         });
@@ -737,8 +790,8 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         if (wave == 0) ENG_STAMP(1, 7);
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 8);
-        if (!last) mv_prefetch<NCW, FMT, false, S1>(P1, L.lay[l + 1].m, wg, wave, lane, r1, a.exp_flags);
-        mv_run<NCW, FMT, false, S6>(P6, qb6, wg, wave, lane, r6, L.xs[1], [&](int, int row, float v, float) {
+        if (!last) mv_prefetch<NCW1, FMT, false, S1>(P1, L.lay[l + 1].m, S.s1, wave, lane, r1, a.exp_flags);
+        mv_run<NCW, FMT, false, S6>(P6, qb6, wg * P6.spg, wave, lane, r6, L.xs[1], [&](int, int row, float v, float) {
             const uint16_t o = f2bf(v);
             const uint16_t y = f2bf(bf2f(L.xrawB[row]) + bf2f(o));
             if (last)
@@ -752,7 +805,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
 }
 
 // DIM, QD, KVD, FFN: the model's dim, q_dim, kv_dim, ffn; NWG: the grid (= CUs): sweeps and mat-vec geometry are straight-line code
-template <int FMT, int GQ, int HD, int NWV, int DIM, int QD, int KVD, int FFN, int NWG>
+template <int FMT, int GQ, int HD, int NWV, int DIM, int QD, int KVD, int FFN, int NWG, bool XMAP>
 __global__ void __launch_bounds__(NWV * 64) engine_kernel(const EngArgs a) {
     constexpr int hd = HD, NW = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -771,7 +824,7 @@ __global__ void __launch_bounds__(NWV * 64) engine_kernel(const EngArgs a) {
     L.wmax = reinterpret_cast<float*>(L.knew + hd); /* [NW][GQ] */
     L.comb = L.wmax + NW * GQ + 4;                  /* [NW][GQ][hd + 4] */
     L.outb = reinterpret_cast<uint32_t*>(L.comb + NW * GQ * (hd + 4));
-    L.cnt = reinterpret_cast<int*>(L.outb + 64);
+    L.cnt = reinterpret_cast<int*>(L.outb + 64); /* [0] arrival counter, [1..2] XCD id and ticket */
     if (tid == 0) *L.cnt = 0;
     // ---- start: state, generation, tables
     EngSlice S;
@@ -785,27 +838,60 @@ __global__ void __launch_bounds__(NWV * 64) engine_kernel(const EngArgs a) {
     }
     __syncthreads();
     S.len = S.pos + 1, S.nsp = a.nsp;
-    S.has_unit = wg < a.n_kv * a.nsp;
-    S.kvh = S.has_unit ? wg / a.nsp : 0, S.split = S.has_unit ? wg - S.kvh * a.nsp : 0;
+    S.xcc = 0, S.rank = 0;
+    using SHK = EngShape<FMT, DIM, QD, KVD, FFN, NWG>;
+    constexpr int RPS1 = 64 >> SHK::P1.lpr_log2, R1K = SHK::P1.spg * RPS1;
+    if (XMAP) {
+        // kv-head k lives on XCD k: its q/k/v rows, its attention slices and its merge are exchanged through that XCD's L2 only.
+        // A workgroup learns its XCD from the hardware register and takes a ticket there (the tickets are zeroed again at the end).
+        static_assert(!XMAP || (GQ * HD + 2 * HD) == 32 * R1K, "an XCD's 32 workgroups share the q | k | v rows of one kv-head");
+        int* xi = L.cnt + 1;
+        if (tid == 0) {
+            const int x = eng_xcc();
+            xi[0] = x, xi[1] = __hip_atomic_fetch_add(a.tickets + x * 32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        S.xcc = xi[0], S.rank = xi[1];
+        if (S.rank >= 32 && tid == 0) atomicOr(a.ws + 1, 8); /* not 32 workgroups per XCD: the polls below time out and the host falls back */
+        const int r = S.rank & 31, lr0 = r * R1K; /* first of this workgroup's rows in the XCD's [q | k | v] list */
+        const int j = lr0 < GQ * hd ? 0 : (lr0 < GQ * hd + hd ? 1 : 2);
+        const int row = j == 0 ? S.xcc * GQ * hd + lr0 : (j == 1 ? S.xcc * hd + (lr0 - GQ * hd) : S.xcc * hd + (lr0 - GQ * hd - hd));
+        S.s1 = (j == 0 ? 0 : (j == 1 ? SHK::P1.slot0[1] : SHK::P1.slot0[2])) + row / RPS1;
+        S.q_out0 = lr0;
+        S.has_unit = r < a.nsp;
+        S.kvh = S.xcc, S.split = r;
+        S.me0 = r * a.merge_e;
+        S.has_merge = a.nsp > 1 && S.me0 < GQ * hd;
+    } else {
+        S.s1 = wg * SHK::P1.spg;
+        const int j = S.s1 >= SHK::P1.slot0[2] ? 2 : (S.s1 >= SHK::P1.slot0[1] ? 1 : 0);
+        S.q_out0 = (j == 0 ? 0 : (j == 1 ? a.q_dim : a.q_dim + a.kv_dim)) + (S.s1 - (j == 0 ? 0 : (j == 1 ? SHK::P1.slot0[1] : SHK::P1.slot0[2]))) * RPS1;
+        S.has_unit = wg < a.n_kv * a.nsp;
+        S.kvh = S.has_unit ? wg / a.nsp : 0, S.split = S.has_unit ? wg - S.kvh * a.nsp : 0;
+        S.me0 = wg * a.merge_e;
+        S.has_merge = a.nsp > 1 && S.me0 < a.n_head * hd;
+    }
     S.h0 = S.kvh * GQ, S.t0 = S.split * a.chunk;
     S.t1 = S.t0 + a.chunk < S.len ? S.t0 + a.chunk : S.len;
     S.empty = S.t0 >= S.len;
     S.own_new = S.has_unit && S.pos >= S.t0 && S.pos < S.t1;
-    S.me0 = wg * a.merge_e;
-    S.has_merge = a.nsp > 1 && S.me0 < a.n_head * hd;
     if (wave == NWV - 1)
-        eng_poller_main<FMT, GQ, HD, NWV, DIM, QD, KVD, FFN, NWG>(a, L, S, epoch, wg, lane);
+        eng_poller_main<FMT, GQ, HD, NWV, DIM, QD, KVD, FFN, NWG, XMAP>(a, L, S, epoch, wg, lane);
     else
-        eng_compute_main<FMT, GQ, HD, NWV, DIM, QD, KVD, FFN, NWG>(a, L, S, epoch, wg, wave, lane);
+        eng_compute_main<FMT, GQ, HD, NWV, DIM, QD, KVD, FFN, NWG, XMAP>(a, L, S, epoch, wg, wave, lane);
     // the next launch's generation (workgroup 0 owns rows of the last phase, so every workgroup has read the epoch long before)
-    if (wg == 0 && tid == 0) a.ws[0] = epoch + 1;
+    if (wg == 0 && tid == 0) {
+        a.ws[0] = epoch + 1;
+        if (XMAP)
+            for (int i = 0; i < 8; i++) a.tickets[i * 32] = 0; /* every workgroup took its ticket before any could finish a layer */
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
 struct EngineHost {
     EngArgs args;
     EngPlan plans[4];
-    int fmt, GQ, hd, nwv, shape_class;
+    int fmt, GQ, hd, nwv, shape_class, xmap;
     size_t smem;
     int n_cu;
 };
@@ -864,6 +950,7 @@ size_t engine_ws_bytes(const kf_engine_desc* d) {
     size_t b = 256 + 512 + (((size_t)d->n_layer * sizeof(EngLayer) + 255) & ~(size_t)255);
     b += 8 * ((size_t)ENG_GLS_MAX * 4 * (((size_t)d->dim * 2 + q_dim * 2 + 2 * kv_dim + d->ffn) / 32 + 8) + 2048);
     b += 8 * (size_t)d->n_head * KF_ATTN_MAX_SPLITS * (d->head_dim + 4) + 256;
+    b += 1024 + 8 * (4 * (size_t)(q_dim / d->n_kv + 2 * d->head_dim) + 256) + 8 * (8 * (size_t)(d->n_head / d->n_kv) * KF_ATTN_MAX_SPLITS * (d->head_dim + 4) + 256); /* XCD-mapped form */
     return b;
 }
 
@@ -943,6 +1030,7 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     }
     if (fmt == FMT_Q4 && q4p_ok && !(getenv("KF_Q4_PERM") && atoi(getenv("KF_Q4_PERM")) == 0)) fmt = FMT_Q4P;
     E->fmt = fmt, E->GQ = GQ, E->hd = hd, E->n_cu = n_cu, E->nwv = 8, E->shape_class = shape_class;
+    E->xmap = (shape_class == 1 && d->n_kv == 8 && !(getenv("KF_ENG_XMAP") && atoi(getenv("KF_ENG_XMAP")) == 0)) ? 1 : 0;
     for (int i = 0; i < 4; i++) a.spg[i] = E->plans[i].spg, a.nslots[i] = E->plans[i].total_slots, a.nblk[i] = E->plans[i].nBlk;
     // workspace carve
     char* p = reinterpret_cast<char*>(ws);
@@ -966,12 +1054,18 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     a.cstride = (int)((p - g0) / 4);
     p = g0 + (size_t)a.ncopy * a.cstride * 4;
     a.part = reinterpret_cast<unsigned long long*>(p);
+    p += (8 * (size_t)a.n_head * KF_ATTN_MAX_SPLITS * (hd + 4) + 255) & ~(size_t)255;
+    a.tickets = reinterpret_cast<int*>(p), p += 1024;
+    a.lq_stride = (int)(((size_t)(GQ * hd + 2 * hd) * 4 + 255) / 256 * 64);
+    a.lqkv = reinterpret_cast<uint32_t*>(p), p += (size_t)8 * a.lq_stride * 4;
+    a.lp_stride = (int)(((size_t)GQ * KF_ATTN_MAX_SPLITS * (hd + 4) * 8 + 255) / 256 * 32);
+    a.lpart = reinterpret_cast<unsigned long long*>(p), p += (size_t)8 * a.lp_stride * 8;
     if (hipMemsetAsync(ws, 0xff, ws_bytes, st) != hipSuccess) {
         delete E;
         return KF_HIP_CHECK;
     }
     const int init[2] = {1, 0}; /* epoch 1, no error */
-    if (hipMemcpyAsync(a.ws, init, sizeof(init), hipMemcpyHostToDevice, st) != hipSuccess ||
+    if (hipMemsetAsync(a.tickets, 0, 1024, st) != hipSuccess || hipMemcpyAsync(a.ws, init, sizeof(init), hipMemcpyHostToDevice, st) != hipSuccess ||
         hipMemcpyAsync(const_cast<EngPlan*>(a.plans), E->plans, sizeof(E->plans), hipMemcpyHostToDevice, st) != hipSuccess ||
         hipMemcpyAsync(const_cast<EngLayer*>(a.layers), tab.data(), tab.size() * sizeof(EngLayer), hipMemcpyHostToDevice, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess) {
@@ -1024,26 +1118,27 @@ static bool engine_plans_match(const EngineHost* E) {
     }
     return true;
 }
-template <int FMT, int GQ, int HD, int DIM, int QD, int KVD, int FFN>
+template <int FMT, int GQ, int HD, int DIM, int QD, int KVD, int FFN, bool XMAP>
 static int engine_go(EngineHost* E, hipStream_t st) {
     static int ready = 0; /* 1 ok, -1 the compile-time geometry is not the mat-vec launcher's */
     if (!ready) {
         if (!engine_plans_match<FMT, GQ, HD, DIM, QD, KVD, FFN>(E)) ready = -1;
-        else if (hipFuncSetAttribute((const void*)engine_kernel<FMT, GQ, HD, ENG_NWV, DIM, QD, KVD, FFN, ENG_NWG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+        else if (hipFuncSetAttribute((const void*)engine_kernel<FMT, GQ, HD, ENG_NWV, DIM, QD, KVD, FFN, ENG_NWG, XMAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
                  hipSuccess)
             return KF_HIP_CHECK;
         else
             ready = 1;
     }
     if (ready < 0) return 1;
-    hipLaunchKernelGGL((engine_kernel<FMT, GQ, HD, ENG_NWV, DIM, QD, KVD, FFN, ENG_NWG>), dim3(ENG_NWG), dim3(ENG_NWV * 64), E->smem, st, E->args);
+    hipLaunchKernelGGL((engine_kernel<FMT, GQ, HD, ENG_NWV, DIM, QD, KVD, FFN, ENG_NWG, XMAP>), dim3(ENG_NWG), dim3(ENG_NWV * 64), E->smem, st, E->args);
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 template <int FMT>
 static int engine_go_fmt(EngineHost* E, hipStream_t st) {
     switch (E->shape_class) {
-        case 1: return engine_go<FMT, 2, 128, 1024, 2048, 1024, 3072>(E, st);
-        case 2: return engine_go<FMT, 2, 64, 256, 256, 128, 512>(E, st);
+        case 1: /* 8 kv-heads on 8 XCDs: the attention chain of a kv-head stays inside one XCD (KF_ENG_XMAP=0: the placement-blind form) */
+            return E->xmap ? engine_go<FMT, 2, 128, 1024, 2048, 1024, 3072, true>(E, st) : engine_go<FMT, 2, 128, 1024, 2048, 1024, 3072, false>(E, st);
+        case 2: return engine_go<FMT, 2, 64, 256, 256, 128, 512, false>(E, st);
         default: return 1;
     }
 }

@@ -7,6 +7,9 @@
 //   1  one leader per XCD (elected by XCC_ID ticket) sweeps the global vector and republishes it with PLAIN 16-byte stores into a buffer of
 //      its XCD (the lines stay in that XCD's L2); the other workgroups of the XCD sweep that buffer with sc1 loads (L1 bypass, L2 hits)
 //   2  as 1, but the followers' sweeps only start after a 4-byte "ready" word of the XCD buffer carries the phase tag (one load per poll)
+//   3  no cross-XCD traffic at all: the workgroups of an XCD exchange an n-granule vector among themselves (rank r of the XCD publishes
+//      granules [r*n/32, (r+1)*n/32) with plain or sc1 stores, everyone sweeps with sc1 loads that hit the XCD's L2): the price of a hand-off
+//      that stays inside one XCD (what a tensor-parallel split of the layer over the 8 XCDs would pay for most of its phases)
 // Reported: microseconds per phase (wall clock over all phases / nphase).
 //   hipcc --offload-arch=gfx950 -O3 -o scratch/ub_handoff scratch/ub_handoff.hip && scratch/ub_handoff
 #include <hip/hip_runtime.h>
@@ -77,14 +80,25 @@ __global__ void __launch_bounds__(64) handoff_kernel(const Args a) {
         uint32_t* const gbuf = a.glob + (size_t)(p & 1) * n;
         uint32_t* const lbuf = myloc + (size_t)(p & 1) * (n + 32);
         // publish this workgroup's 4 granules (values: something that depends on the previous phase so nothing is hoisted)
-        if (lane < n / 1024) { /* n / 256 granules per workgroup, 16 bytes per lane */
+        if (a.mode < 3 && lane < n / 1024) { /* n / 256 granules per workgroup, 16 bytes per lane */
             const uint32_t v = (uint32_t)(wg * 7 + p + lane) & 0xfff0u;
             u32x4 o = {(tag << 16) | v, (tag << 16) | (v + 1), (tag << 16) | (v + 2), (tag << 16) | (v + 3)};
             __builtin_amdgcn_raw_buffer_store_b128(o, rsrc(gbuf + wg * (n / 256) + 4 * lane, 16), 0, 0, 16 /* sc1 */);
         }
         if (p == 4 && wg == 0 && lane == 0) t0 = __builtin_amdgcn_s_memrealtime();
         u32x4 g[NLD];
-        if (a.mode == 0 || leader) {
+        if (a.mode >= 3) { /* intra-XCD all-to-all: rank publishes n/32 granules into the XCD buffer (mode 3 plain stores, mode 4 sc1 stores) */
+            const int per = n / 32; /* granules per rank: 32 (n 1024) or 96 (n 3072) */
+            if (rank < 32 && 4 * lane < per) {
+                const uint32_t v = (uint32_t)(wg * 7 + p + lane) & 0xfff0u;
+                u32x4 o = {(tag << 16) | v, (tag << 16) | (v + 1), (tag << 16) | (v + 2), (tag << 16) | (v + 3)};
+                if (a.mode == 3)
+                    *reinterpret_cast<u32x4*>(lbuf + rank * per + 4 * lane) = o;
+                else
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rsrc(lbuf + rank * per + 4 * lane, 16), 0, 0, 16 /* sc1 */);
+            }
+            sweep<NLD>(lbuf, n, tag, g, lane, a.err);
+        } else if (a.mode == 0 || leader) {
             sweep<NLD>(gbuf, n, tag, g, lane, a.err);
             if (a.mode != 0) { /* republish into this XCD's L2: plain stores keep the lines there */
 #pragma unroll
@@ -136,7 +150,7 @@ int main(int argc, char** argv) {
     int epoch = 1;
     for (int n : {1024, 3072}) {
         for (int work : {0, 1000}) {
-            for (int mode = 0; mode < 3; mode++) {
+            for (int mode = 0; mode < 5; mode++) {
                 CK(hipMemset(err, 0, 64));
                 CK(hipMemset(glob, 0xff, 2 * 4096 * 4));
                 CK(hipMemset(loc, 0xff, 8 * 2 * (4096 + 32) * 4));
@@ -156,7 +170,7 @@ int main(int argc, char** argv) {
                 int e[2];
                 CK(hipMemcpy(e, err, 8, hipMemcpyDeviceToHost));
                 printf("n %4d  work %4d ns  mode %d (%s): %.3f us per phase  (hand-off alone %.3f)   timeouts %d\n", n, work, mode,
-                       mode == 0 ? "all 256 sweep the fabric" : (mode == 1 ? "XCD leaders sweep + republish in L2" : "leaders + ready word"), us / (reps - 2),
+                       mode == 0 ? "all 256 sweep the fabric" : (mode == 1 ? "XCD leaders sweep + republish in L2" : (mode == 2 ? "leaders + ready word" : (mode == 3 ? "inside each XCD, plain stores" : "inside each XCD, sc1 stores"))), us / (reps - 2),
                        us / (reps - 2) - work / 1000.0, e[0]);
                 fflush(stdout);
             }
