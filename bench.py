@@ -72,6 +72,8 @@ def main():
     ctx = m._ctx
     if args.engine >= 0:
         m.set_engine(bool(args.engine))
+    elif "KF_BENCH_DEVICE" in os.environ and world > 1:
+        m.set_engine(False)  # test hook: several ranks share one GPU; the persistent engine needs the CUs to itself
     use_graph = not args.no_graph
 
     # synthetic prompt: 128 ids, then free-running greedy decode
@@ -152,10 +154,14 @@ def main():
                 out["concurrent_streams"] = {"error": repr(e)[:200]}
         head_rl = kernel_roofline(m, ctx, cfg)
         try:   # the time-dominant kernel of the step; the LM head (the byte-dominant launch) is reported beside it
-            out["roofline"] = matvec_roofline(m, ctx, cfg, head_rl) if args.layers == "q4" else head_rl
+            eng = engine_roofline(m, ctx, cfg, forced, timed_positions) if m.engine_steps() > 0 else None
+            out["roofline"] = eng if eng else (matvec_roofline(m, ctx, cfg, head_rl) if args.layers == "q4" else head_rl)
+            out["config"]["decode_path"] = "persistent engine: embed, kf::engine_kernel (all layers), LM head, pick = 4 launches per token" if eng else \
+                "per-layer launches: 5 per layer"
         except Exception as e:
             out["roofline"] = head_rl
             out["roofline_error"] = repr(e)[:200]
+        m.engine_check()
         out["roofline_lm_head"] = head_rl
         out["cpu_baseline"] = cpu_baseline(m, cfg, forced, args.cpu_seconds) if (world == 1 and args.cpu_seconds > 0) else None
     if world > 1:
@@ -266,6 +272,52 @@ def kernel_roofline(m, ctx, cfg, reps=200):
                                       % ({L.BF16: 0, L.F8E5M2: 1, L.Q4: 2}.get(head.type, 0), head.ne0, head.ne1), "achieved": round(ach, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "bytes_per_launch": int(nbytes),
             "us_per_launch": round(ms * 1e3, 2)}
+
+
+def engine_roofline(m, ctx, cfg, forced, timed_positions, reps=12):
+    """The kernel that takes ~92 % of the step's time when the persistent decode engine serves the model: kf::engine_kernel, ONE launch per
+    token for all layers (RMSNorm, Q/K/V, q/k-norm + RoPE + attention, o_proj, gate/up + SwiGLU, down_proj of 28 layers).  Timed alone with HIP
+    events on the launch stream at positions spread over the timed region (the KV cache still holds the rows of the run); an LM-head launch
+    between launches streams 311 MB so that the layer weights come from HBM as in the real step.  achieved = algorithmic bytes of a launch
+    (packed weights + zero/step of every layer matrix, the layers' norm vectors, K/V rows 0..pos read, row pos written) / mean duration."""
+    import ctypes as C
+    import torch
+    from koifish_amd import lib as L
+    head = m.weights[(-1, 1)]
+    hd = head.desc()
+    hx = torch.randn(cfg["dim"], device=ctx.device).to(torch.bfloat16)
+    logits = torch.empty(head.ne0, dtype=torch.bfloat16, device=ctx.device)
+    kvd = cfg["n_kv"] * cfg["head_dim"]
+    wbytes = sum(w.algorithmic_bytes() for (layer, slot), w in m.weights.items() if layer >= 0)
+    wbytes += cfg["n_layer"] * (2 * cfg["dim"] + 2 * cfg["head_dim"]) * 2
+    pos_list = sorted(set(timed_positions[:: max(1, len(timed_positions) // 8)]))
+    tot_ms, tot_bytes, n = 0.0, 0.0, 0
+    for p in pos_list:
+        m.set_state(int(forced[p]) if forced[p] >= 0 else 1, p)
+        if not m.engine_only(1):
+            return None
+        for r in range(reps):
+            L.check(ctx.hip.kf_lm_head(ctx.h, C.byref(hd), hx.data_ptr(), logits.data_ptr(), None, ctx._head_ws.data_ptr()), "kf_lm_head")
+            e0, e1 = ctx.event(), ctx.event()
+            ctx.record(e0)
+            m.engine_only(1)
+            ctx.record(e1)
+            m.sync()
+            tot_ms += ctx.elapsed_ms(e0, e1)
+            tot_bytes += wbytes + 2 * cfg["n_layer"] * (p + 1) * kvd * 2 + 2 * cfg["n_layer"] * kvd * 2
+            n += 1
+    ms, nbytes = tot_ms / n, tot_bytes / n
+    ach = nbytes / (ms * 1e-3) / 1e9
+    traffic = None
+    try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside this process): FETCH_SIZE x 2 (gfx950) + WRITE_SIZE
+        traffic = int(json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_engine.json")))["hbm_bytes_per_launch"])
+    except Exception:
+        pass
+    return {"bound": "hbm", "kernel": "kf::engine_kernel = all %d layers of one decode step in one persistent launch (256 workgroups, hand-offs through tagged granules)" % cfg["n_layer"],
+            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "bytes_per_launch": int(nbytes), "us_per_launch": round(ms * 1e3, 2), "launches": 1, "positions": pos_list,
+            "note": "latency-bound: %d layers x 6 dependent all-to-all phases; a phase's hand-off costs 1.9-3.2 us on this chip whatever it carries "
+                    "(scratch/ub_handoff.hip), the layer's %.1f MB stream in %.1f us at the HBM peak" % (cfg["n_layer"], nbytes / cfg["n_layer"] / 1e6, nbytes / cfg["n_layer"] / HBM_PEAK_GBS / 1e3)}
 
 
 def matvec_roofline(m, ctx, cfg, head_rl, reps=20):

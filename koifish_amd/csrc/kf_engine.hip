@@ -830,6 +830,7 @@ __global__ void __launch_bounds__(NWV * 64) engine_kernel(const EngArgs a) {
     EngSlice S;
     S.pos = a.d_state[1];
     const int epoch = a.ws[0];
+    if (a.ws[1] != 0) return; /* an earlier launch timed out (it could not become resident): do nothing until the host has looked (kf_engine_check) */
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(a.layers);
         uint32_t* dst = reinterpret_cast<uint32_t*>(lay);

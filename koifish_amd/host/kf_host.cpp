@@ -480,6 +480,7 @@ int Fish::Generate(const int* prompt, int n_prompt, int n_new, int* out, bool us
     }
     std::vector<int32_t> toks(config.n_ctx);
     KF_TRY(kf_d2h(ctx, toks.data(), d_tokens_out, toks.size() * 4));
+    if (engine && engine_steps > 0) KF_TRY(kf_engine_check(ctx, engine)); /* a launch that could not become resident leaves an error word, never a hang */
     for (int i = 0; i < n_new; i++) out[i] = toks[n_prompt - 1 + i];
     return KF_OK;
 }
@@ -529,6 +530,21 @@ extern "C" int kfdbg_engine_stamps(kf_engine* e, unsigned long long* h_out, int 
 int kfh_engine_stamps(void* h, unsigned long long* out, int n) {
     Fish* f = reinterpret_cast<Fish*>(h);
     return f->engine ? kfdbg_engine_stamps(f->engine, out, n) : -1;
+}
+// n launches of the engine alone at the position d_state holds (bench.py times the kernel with events around this); the residual stream is
+// re-read from the embedding each time so that the values stay those of a real step
+int kfh_engine_only(void* h, int n) {
+    Fish* f = reinterpret_cast<Fish*>(h);
+    if (f->engine_state == 0) f->EnsureEngine();
+    if (f->engine_state <= 0) return KF_ENGINE_NOT_SERVED;
+    int32_t st[4];
+    KF_TRY(kf_d2h(f->ctx, st, f->d_state, 16));
+    f->tok_pos = st[1];
+    f->graph_mode = true;
+    int rc = KF_OK;
+    for (int i = 0; i < n && rc == KF_OK; i++) rc = kf_engine_step(f->ctx, f->engine, ToX(f->x), ToX(f->x), f->d_state, f->pos_bound());
+    f->graph_mode = false;
+    return rc;
 }
 // synchronises; KF_INTERNAL_ERR when one of the engine's hand-off polls has timed out
 int kfh_engine_check(void* h) {

@@ -136,6 +136,7 @@ def load():
         host.kfh_set_engine.argtypes = [C.c_void_p, C.c_int]
         host.kfh_engine_steps.argtypes = [C.c_void_p]
         host.kfh_engine_check.argtypes = [C.c_void_p]
+        host.kfh_engine_only.argtypes = [C.c_void_p, C.c_int]
         hip.kf_engine_workspace_bytes.argtypes, hip.kf_engine_workspace_bytes.restype = [C.c_void_p], C.c_size_t
         hip.kf_engine_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         hip.kf_engine_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]

@@ -388,6 +388,14 @@ class Qwen3:
         """steps enqueued or captured through the engine so far (-1: the engine does not serve this model's shapes / storage)"""
         return int(self.host.kfh_engine_steps(self.h))
 
+    def engine_only(self, n):
+        """n launches of the engine kernel alone at the position the device state holds (timing); returns False when the engine does not serve the model"""
+        rc = self.host.kfh_engine_only(self.h, int(n))
+        if rc == 1:
+            return False
+        L.check(rc, "kfh_engine_only")
+        return True
+
     def engine_check(self):
         """synchronises; raises when one of the engine's hand-off polls timed out (the launch was not fully resident)"""
         L.check(self.host.kfh_engine_check(self.h), "kfh_engine_check")
