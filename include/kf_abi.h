@@ -125,7 +125,14 @@ int kf_quantize(kf_ctx* ctx, const kf_weight* w, const kf_bf16* src, int symmetr
  * computed straight from the packed stream (no GetDataX round trip).  x [nTok, ne1], y [nTok, ne0] row-major; from 8 token rows up
  * the product runs on MFMA tiles fed by in-register unpack (kf_gemm.hip), below that (or for K not a multiple of 128) one mat-vec per row:
  * the same values up to fp32 summation order.
- * epilogue KF_EPI_RESIDUAL adds `residual` [ne0]. */
+ * epilogue KF_EPI_RESIDUAL adds `residual` [nTok, ne0]; `residual` MAY alias `y` (the in-place form of SelfAttention / FFN::cuFlow): every path reads a
+ * residual element before it stores that element.  x must not alias y.
+ * Kernels never allocate: the three storages served by "dequantise, then multiply" (the reference's own order) -- AutoAWQ tensors, the 3- / 2-bit row
+ * forms, and the 4-bit row codebook for token batches the tile kernels do not cover -- use a caller-owned workspace: kf_linear_scratch_bytes says how
+ * much a weight needs (0 for every PackedQ / bf16 / f8 weight), kf_set_scratch hands the context a buffer (device memory, 16-byte aligned, the caller's
+ * to free after the last call that used it; not while capturing, since captured launches hold the pointer).  Too small or missing: KF_INVALID_ARGS. */
+size_t kf_linear_scratch_bytes(const kf_weight* w, int nTok);
+int kf_set_scratch(kf_ctx* ctx, void* scratch, size_t bytes);
 int kf_linear(kf_ctx* ctx, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const kf_bf16* bias, int nTok, float alpha, float beta,
               uint32_t epilogue, const kf_bf16* residual);
 

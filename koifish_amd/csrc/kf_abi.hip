@@ -19,11 +19,9 @@ struct kf_ctx {
     bool capturing;
     float* amax_val; /* per-workgroup partial maxima for kf_lm_head when the caller passes no scratch */
     int* amax_idx;
-    float* awq_ws; /* slice partials of the AWQ mat-vec, grown on demand (never while capturing) */
-    size_t awq_ws_bytes;
-    void* blas;       /* rocBLAS handle for the large token-batch GEMMs (dlopen'ed on first use; NULL: not tried, (void*)-1: unavailable) */
-    uint16_t* wd_ws;  /* a weight dequantised to bf16 for the library GEMM, grown on demand (never while capturing) */
-    size_t wd_ws_bytes;
+    void* scratch;    /* caller-owned workspace of kf_linear (kf_set_scratch): AWQ slice partials, or a weight dequantised to bf16 */
+    size_t scratch_bytes;
+    void* blas;       /* rocBLAS handle, only with KF_GEMM_LIB=1 (dlopen'ed on first use; NULL: not tried, (void*)-1: unavailable) */
 };
 struct kf_graph {
     hipGraph_t graph;
@@ -77,14 +75,14 @@ int kf_init(int device, void* stream, kf_ctx** out) {
     }
     HIPCHK(hipMalloc(&c->amax_val, sizeof(float) * kf::KF_MAX_ARGMAX_PARTIALS));
     HIPCHK(hipMalloc(&c->amax_idx, sizeof(int) * kf::KF_MAX_ARGMAX_PARTIALS));
-    c->awq_ws = nullptr, c->awq_ws_bytes = 0;
+    c->scratch = nullptr, c->scratch_bytes = 0;
     *out = c;
     return KF_OK;
 }
-// ---- vendor GEMM for LARGE token batches (training-size, n >= KF_GEMM_LIB_MIN = 2048 rows): the weight is dequantised to bf16 (what the reference's
-// GetDataX does before every cuBLASLt call) and the plain bf16 GEMM goes to rocBLAS -- measured 700-1300 TFLOP/s on the GPT2-1558M shapes against
-// 300-550 for the fused dequant-GEMM kernels of kf_gemm*.hip, which keep every smaller batch (prompt prefill) and remain the fallback
-// (KF_GEMM_LIB=0, library missing, graph capture).  rocBLAS is resolved with dlopen so that libkf_hip.so has no link-time dependency on it.
+// ---- OPT-IN vendor GEMM (KF_GEMM_LIB=1; off by default) for LARGE token batches (training-size, n >= KF_GEMM_LIB_MIN = 2048 rows): the weight is
+// dequantised to bf16 into the caller's scratch (what the reference's GetDataX does before every cuBLASLt call) and the plain bf16 GEMM goes to rocBLAS
+// -- a yardstick beside the fused dequant-GEMM kernels of kf_gemm*.hip, which serve every batch by default.  rocBLAS is resolved with dlopen so that
+// libkf_hip.so has no link-time dependency on it.
 typedef int (*rb_create_t)(void**);
 typedef int (*rb_destroy_t)(void*);
 typedef int (*rb_set_stream_t)(void*, hipStream_t);
@@ -102,8 +100,8 @@ static bool lib_blas_ready(kf_ctx* c) {
     if (c->blas) return true;
     static int enabled = -1;
     if (enabled < 0) {
-        const char* e = getenv("KF_GEMM_LIB");
-        enabled = (e && atoi(e) == 0) ? 0 : 1;
+        const char* e = getenv("KF_GEMM_LIB"); /* opt-in: the hand-written tile kernels are the product path */
+        enabled = (e && atoi(e) == 1) ? 1 : 0;
     }
     c->blas = (void*)-1;
     if (!enabled) return false;
@@ -139,21 +137,17 @@ static int lib_gemm(kf_ctx* c, bool tA, bool tB, int m, int n, int k, const void
     return g_rb.gemm_ex(c->blas, tA ? 112 : 111, tB ? 112 : 111, m, n, k, &alpha, A, BF16R, lda, B, BF16R, ldb, &beta, Cm, BF16R, ldc, Cm, BF16R, ldc, F32R, 0, 0, 0) == 0 ? KF_OK
                                                                                                                                                                             : KF_INTERNAL_ERR;
 }
-// bf16 view of a weight for the library: the data itself (bf16 storage) or its dequantisation into the context's scratch
+// bf16 view of a weight: the data itself (bf16 storage) or its dequantisation into the caller's scratch (kf_set_scratch)
 static int lib_weight_bf16(kf_ctx* c, const kf_weight* w, const uint16_t** out) {
     if (w->type == KF_BF16) {
         *out = (const uint16_t*)w->data;
         return KF_OK;
     }
     const size_t need = (size_t)w->ne0 * w->ne1 * 2;
-    if (need > c->wd_ws_bytes) {
-        if (c->wd_ws) HIPCHK(hipFree(c->wd_ws));
-        c->wd_ws = nullptr, c->wd_ws_bytes = 0;
-        HIPCHK(hipMalloc((void**)&c->wd_ws, need));
-        c->wd_ws_bytes = need;
-    }
-    const int r = kf::dequant_launch(c->stream, w, c->wd_ws);
-    *out = c->wd_ws;
+    if (need > c->scratch_bytes || !c->scratch)
+        return fail(KF_INVALID_ARGS, "kf_linear: this weight needs %zu bytes of scratch (kf_linear_scratch_bytes), kf_set_scratch gave %zu", need, c->scratch_bytes);
+    const int r = kf::dequant_launch(c->stream, w, (uint16_t*)c->scratch);
+    *out = (const uint16_t*)c->scratch;
     return r;
 }
 static int lib_gemm_min() {
@@ -170,8 +164,6 @@ int kf_destroy(kf_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->amax_val), (void)hipFree(c->amax_idx);
-    if (c->awq_ws) (void)hipFree(c->awq_ws);
-    if (c->wd_ws) (void)hipFree(c->wd_ws);
     lib_blas_destroy(c);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -331,6 +323,20 @@ int kf_quantize(kf_ctx* c, const kf_weight* w, const kf_bf16* src, int symmetric
 
 static void init_args(kf::GemvLaunch& L) { memset(&L, 0, sizeof(L)); L.args.alpha = 1.0f; }
 
+size_t kf_linear_scratch_bytes(const kf_weight* w, int nTok) {
+    if (!w || nTok < 1) return 0;
+    if (w->qzeros) return kf::awq_scratch_bytes(w);
+    if (w->quant != KF_QUANT_GROUP) return (size_t)w->ne0 * w->ne1 * 2; /* row forms: GetDataX into the scratch (the 4-bit row codebook only for token batches the tile kernels do not cover) */
+    return 0;
+}
+int kf_set_scratch(kf_ctx* c, void* scratch, size_t bytes) {
+    CHKCTX(c);
+    if (scratch && !al16(scratch)) return fail(KF_BLAS_UNALIGN, "kf_set_scratch: unaligned");
+    if (c->capturing) return fail(KF_INVALID_ARGS, "kf_set_scratch: not while capturing (captured launches hold the old pointer)");
+    c->scratch = scratch, c->scratch_bytes = scratch ? bytes : 0;
+    return KF_OK;
+}
+
 int kf_linear(kf_ctx* c, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const kf_bf16* bias, int nTok, float alpha, float beta, uint32_t epilogue,
               const kf_bf16* residual) {
     CHKCTX(c);
@@ -344,22 +350,21 @@ int kf_linear(kf_ctx* c, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const
     // up when the shape is covered (K a multiple of 128, 16-byte aligned rows), otherwise one mat-vec launch per token row.
     if (w->qzeros) { /* AutoAWQ layout: its own transposed mat-vec */
         const size_t need = kf::awq_scratch_bytes(w);
-        if (need > c->awq_ws_bytes) {
-            if (c->capturing) return fail(KF_INVALID_ARGS, "kf_linear: the AWQ workspace must be sized by one eager call before graph capture");
-            if (c->awq_ws) HIPCHK(hipFree(c->awq_ws));
-            HIPCHK(hipMalloc(&c->awq_ws, need));
-            c->awq_ws_bytes = need;
-        }
+        if (need > c->scratch_bytes || !c->scratch)
+            return fail(KF_INVALID_ARGS, "kf_linear: the AWQ mat-vec needs %zu bytes of scratch (kf_linear_scratch_bytes), kf_set_scratch gave %zu", need, c->scratch_bytes);
         for (int t = 0; t < nTok; t++) {
             int rc = kf::awq_linear_launch(c->stream, w, x + (size_t)t * w->ne1, y + (size_t)t * w->ne0, bias, alpha, beta,
-                                           (epilogue & KF_EPI_RESIDUAL) ? residual + (size_t)t * w->ne0 : nullptr, c->awq_ws);
+                                           (epilogue & KF_EPI_RESIDUAL) ? residual + (size_t)t * w->ne0 : nullptr, (float*)c->scratch);
             if (rc != KF_OK) return fail(rc, "kf_linear (AWQ) failed with %d", rc);
         }
         return KF_OK;
     }
-    // training-size batches: dequantise + vendor GEMM (see lib_gemm above).  Its bf16 result takes bias / residual in a separate pass, so a biased
-    // output is rounded twice (<= 1 bf16 ulp from the fused kernels' single rounding); the inference path (prefill chunks of <= 1024 rows) never comes here.
-    if (nTok >= lib_gemm_min() && alpha == 1.0f && beta == 0.0f && (w->ne0 % 8) == 0 && al16(y) && lib_blas_ready(c)) {
+    // KF_GEMM_LIB=1 only: dequantise + vendor GEMM (see lib_gemm above).  Its bf16 result takes bias / residual in a separate pass, so a biased output is
+    // rounded twice (<= 1 bf16 ulp from the fused kernels' single rounding), and that pass re-reads `residual` AFTER y has been written: a residual that
+    // aliases y (the in-place form the host uses) stays on the tile kernels, which read it per element before they store.
+    const bool res_alias = (epilogue & KF_EPI_RESIDUAL) && residual < y + (size_t)nTok * w->ne0 && y < residual + (size_t)nTok * w->ne0;
+    if (nTok >= lib_gemm_min() && alpha == 1.0f && beta == 0.0f && (w->ne0 % 8) == 0 && al16(y) && !res_alias && lib_blas_ready(c) &&
+        (w->type == KF_BF16 || (c->scratch && c->scratch_bytes >= (size_t)w->ne0 * w->ne1 * 2))) {
         const uint16_t* Wd = nullptr;
         r = lib_weight_bf16(c, w, &Wd);
         if (r == KF_OK) r = lib_gemm(c, true, false, w->ne0, nTok, w->ne1, Wd, w->ne1, x, w->ne1, 0.0f, y, w->ne0);
@@ -375,8 +380,6 @@ int kf_linear(kf_ctx* c, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const
     }
     if (w->quant != KF_QUANT_GROUP && w->type != KF_Q4) {
         // 3- / 2-bit row forms: GetDataX into the scratch, then the bf16 product, whatever the batch (the reference's own order; no in-place mat-vec)
-        if (c->capturing && (size_t)w->ne0 * w->ne1 * 2 > c->wd_ws_bytes)
-            return fail(KF_INVALID_ARGS, "kf_linear: the dequant workspace must be sized by one eager call before graph capture");
         const uint16_t* Wd = nullptr;
         r = lib_weight_bf16(c, w, &Wd);
         if (r != KF_OK) return fail(r, "kf_linear (row-form dequant) failed with %d", r);
@@ -390,7 +393,7 @@ int kf_linear(kf_ctx* c, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const
         if (rc < 0) return fail(rc, "kf_linear (token-batch GEMM) failed with %d", rc);
         if (rc == KF_OK) return KF_OK;
     }
-    if (nTok >= gemm_min && w->quant == KF_QUANT_ROW_LUT && !(c->capturing && (size_t)w->ne0 * w->ne1 * 2 > c->wd_ws_bytes)) {
+    if (nTok >= gemm_min && w->quant == KF_QUANT_ROW_LUT && c->scratch && c->scratch_bytes >= (size_t)w->ne0 * w->ne1 * 2) {
         // row-codebook storage whose shape the in-register-unpack tile kernels do not cover: the reference's own order -- GetDataX into the scratch,
         // then the bf16 product on the dequantised copy.  Mat-vecs (below) read the nibble stream directly.
         const uint16_t* Wd = nullptr;
@@ -721,18 +724,21 @@ int kf_linear_backward(kf_ctx* c, const kf_weight* w, const kf_bf16* deltaIn, co
     if (!deltaIn || !scratch || n < 1) return fail(KF_INVALID_ARGS, "kf_linear_backward: null deltaIn / scratch or n < 1");
     if ((gW && !inp) || (!delta && !gW && !gBias)) return fail(KF_INVALID_ARGS, "kf_linear_backward: gW needs inp; nothing to compute");
     const int OC = w->ne0, IC = w->ne1;
-    if (n >= lib_gemm_min() && lib_blas_ready(c)) {
+    if (n >= lib_gemm_min() && lib_blas_ready(c)) { /* KF_GEMM_LIB=1 only */
         // vendor GEMM on the dequantised weight; row-major operands are the transposed column-major ones, so no explicit transposes:
         //   delta^T [IC x n]  = W^T-view [IC x OC] . deltaIn^T-view [OC x n]           gW^T [IC x OC] += inp^T-view [IC x n] . (deltaIn^T-view)^T [n x OC]
         if (!al16(deltaIn) || (inp && !al16(inp)) || (delta && !al16(delta)) || (gW && !al16(gW)) || ((uintptr_t)scratch & 255))
             return fail(KF_BLAS_UNALIGN, "kf_linear_backward: tensors must be 16-byte aligned, scratch 256-byte aligned");
+        uint16_t* const Wl = (uint16_t*)scratch; /* the dequantised weight, then the column-sum slabs: inside kf_linear_backward_scratch_bytes */
+        double* const slabs_l = (double*)((char*)scratch + 2 * up256((size_t)OC * IC * 2) + up256((size_t)OC * n * 2) + up256((size_t)IC * n * 2));
         if (gBias) {
-            r = kf::colsum_add_launch(c->stream, deltaIn, gBias, n, OC, (double*)scratch);
+            r = kf::colsum_add_launch(c->stream, deltaIn, gBias, n, OC, slabs_l);
             if (r != KF_OK) return fail(r, "kf_linear_backward: bias column sums failed with %d", r);
         }
         if (delta) {
-            const uint16_t* Wd = nullptr;
-            r = lib_weight_bf16(c, w, &Wd);
+            const uint16_t* Wd = (const uint16_t*)w->data;
+            r = KF_OK;
+            if (w->type != KF_BF16) r = kf::dequant_launch(c->stream, w, Wl), Wd = Wl;
             if (r == KF_OK) r = lib_gemm(c, false, false, IC, n, OC, Wd, IC, deltaIn, OC, accumulate_delta ? 1.0f : 0.0f, delta, IC);
             if (r != KF_OK) return fail(r, "kf_linear_backward: input-gradient GEMM (library) failed with %d", r);
         }
@@ -787,7 +793,9 @@ int kf_attn_backward(kf_ctx* c, const kf_bf16* q, const kf_bf16* k, const kf_bf1
     if (!al16(q) || !al16(k) || !al16(v) || !al16(o) || !al16(dO) || !al16(dq) || !al16(dk) || !al16(dv) || (ld_qkv % 8) || (ld_o % 8) || (ld_d % 8) || ((uintptr_t)scratch & 3))
         return fail(KF_BLAS_UNALIGN, "kf_attn_backward: rows must be 16-byte aligned");
     if (ld_qkv < (long long)n_head * hd || ld_o < (long long)n_head * hd || ld_d < (long long)n_head * hd) return fail(KF_INVALID_ARGS, "kf_attn_backward: row stride below n_head * head_dim");
-    const int r = kf::attn_backward_launch(c->stream, q, k, v, ld_qkv, o, dO, ld_o, dq, dk, dv, ld_d, T, n_head, n_kv, hd, n_seq, (float*)scratch);
+    if (T < 1 || n_head < 1) return fail(KF_INVALID_ARGS, "kf_attn_backward: T / n_head < 1");
+    int r = kf::attn_backward_mfma_launch(c->stream, q, k, v, ld_qkv, o, dO, ld_o, dq, dk, dv, ld_d, T, n_head, hd, n_seq, (float*)scratch, n_kv, ld_qkv, ld_d);
+    if (r == 1) r = KF_UNSUPPORTED_DATATYPE; /* shape outside the MFMA tile kernels */
     if (r == KF_UNSUPPORTED_DATATYPE) return fail(r, "kf_attn_backward: head_dim %d not covered (64, 128)", hd);
     RET(r);
 }

@@ -439,11 +439,6 @@ int gemv_launch(hipStream_t st, GemvLaunch& L) {
     if (fmt < 0) return KF_UNSUPPORTED_DATATYPE;
     const int K = w0->ne1, epb = epb_of(fmt);
     if (K % epb != 0 || K % 8 != 0) return KF_INVALID_ARGS;
-    if (fmt == FMT_Q4) { /* large single 4-bit matrices: per-group table in LDS instead of per-weight arithmetic */
-        bool used = false;
-        const int rc = gemv_q4lut_launch(st, L, &used);
-        if (rc != KF_OK || used) return rc;
-    }
     const int nBlk = K / epb;
     long rows_all = 0;
     for (int j = 0; j < L.n; j++)

@@ -59,7 +59,6 @@ struct GemvLaunch {
 int gemv_launch(hipStream_t st, GemvLaunch& L);
 int gemv_lpr_log2(int nBlk, long rows); /* lanes per row of a mat-vec launch (kf_gemv.hip) */
 int gemv_fmt_of(const kf_weight* w);    /* FMT_* of a weight, < 0: not served by the mat-vec kernel */
-int gemv_q4lut_launch(hipStream_t st, GemvLaunch& L, bool* used); /* kf_gemv_lut.hip: table-lookup form for large 4-bit matrices */
 void argmax_finish_launch(hipStream_t st, const float* val, const int* idx, int n, int32_t* d_argmax, int32_t* d_state, int32_t* d_tokens_out);
 
 // ---- token-batch GEMM on MFMA (kf_gemm.hip): KF_OK launched, 1 = shape not eligible (caller loops the mat-vec), < 0 error
@@ -122,9 +121,7 @@ int bias_residual_launch(hipStream_t st, uint16_t* y, const uint16_t* bias, cons
 // linear backward helpers (kf_linear_bwd.hip)
 int transpose_bf16_launch(hipStream_t st, const uint16_t* in, uint16_t* out, int R, int C);
 int colsum_add_launch(hipStream_t st, const uint16_t* x, uint16_t* dst, int n, int C, double* scratch); /* scratch: ceil(n / 256) * C doubles */
-// causal MHA backward (kf_attn_bwd.hip); scratch: 2 * n_seq * n_head * T floats
-int attn_backward_launch(hipStream_t st, const uint16_t* q, const uint16_t* k, const uint16_t* v, long long ld_qkv, const uint16_t* o, const uint16_t* dO, long long ld_o,
-                         uint16_t* dq, uint16_t* dk, uint16_t* dv, long long ld_d, int T, int n_head, int n_kv, int hd, int n_seq, float* scratch);
+// causal MHA backward on MFMA tiles (kf_attn_bwd_mfma.hip); scratch: 2 * n_seq * n_head * T floats; 1 = shape not covered
 int attn_backward_mfma_launch(hipStream_t st, const uint16_t* q, const uint16_t* k, const uint16_t* v, long long ld_qkv, const uint16_t* o, const uint16_t* dO, long long ld_o,
                               uint16_t* dq, uint16_t* dk, uint16_t* dv, long long ld_d, int T, int n_head, int hd, int n_seq, float* scratch, int n_kv, long long ld_kv,
                               long long ld_dkv); /* kf_attn_bwd_mfma.hip: 1 = not covered */

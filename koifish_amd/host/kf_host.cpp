@@ -199,6 +199,7 @@ hGTensor Head4Token::cuInfer_1(hGTensor inp_, int) {
 // ------------------------------------------------------------------------------------------------ Fish
 Fish::~Fish() {
     for (auto g : graphs) kf_graph_destroy(g);
+    if (ctx && lin_scratch) kf_free(ctx, lin_scratch);
     if (engine) kf_engine_destroy(engine);
     if (ctx && engine_ws) kf_free(ctx, engine_ws);
     if (ctx) {
@@ -282,6 +283,18 @@ static int bucket_of(int pos) {
 int Fish::pos_bound() const {
     int b = kBuckets[bucket_of(tok_pos)] - 1;
     return b < config.n_ctx - 1 ? b : config.n_ctx - 1;
+}
+
+int Fish::EnsureLinearScratch(const kf_weight& w, int nTok) {
+    const size_t need = kf_linear_scratch_bytes(&w, nTok);
+    if (need <= lin_scratch_bytes) return KF_OK;
+    KF_TRY(kf_sync(ctx));
+    void* p = nullptr;
+    KF_TRY(kf_malloc(ctx, need, &p));
+    KF_TRY(kf_set_scratch(ctx, p, need));
+    if (lin_scratch) kf_free(ctx, lin_scratch);
+    lin_scratch = p, lin_scratch_bytes = need;
+    return KF_OK;
 }
 
 // The persistent decode engine over this model's layers: built on first use (every weight must be set), not while capturing.
@@ -602,7 +615,7 @@ static int set_weight_impl(void* h, int layer, int slot, int type, int ne0, int 
     SLP* s = slot_of(f, layer, slot);
     if (!s) return KF_INVALID_ARGS;
     s->w = t, s->nOut = ne0, s->nIn = ne1;
-    return KF_OK;
+    return f->EnsureLinearScratch(t->desc(), f->prefill_chunk); /* load time: the launches themselves never allocate */
 }
 // tie_word_embeddings: lm_head shares embed_tokens' tensor (Neuron.cpp:349-356)
 int kfh_tie_head(void* h) {

@@ -185,6 +185,9 @@ struct Fish {
     int fuse_level = 1;  // 0: one launch per reference kernel; 1: fused launches (5 per layer)
     // the layer loop of a decode step as one persistent launch (kf_engine_*): used by EnqueueStep when fuse_level >= 1, the model's shapes and
     // storage are served and the position bound is; otherwise the per-layer launches run.  Same arithmetic, bit for bit.
+    void* lin_scratch = nullptr;  // kf_set_scratch: workspace of the dequantise-then-multiply storages (AutoAWQ, row forms), sized when weights are set
+    size_t lin_scratch_bytes = 0;
+    int EnsureLinearScratch(const kf_weight& w, int nTok);
     bool use_engine = true;
     kf_engine* engine = nullptr;
     void* engine_ws = nullptr;

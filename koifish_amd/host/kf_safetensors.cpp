@@ -495,7 +495,7 @@ struct Loader {
             KF_TRY(dense(prefix + ".weight", n_out, n_in, tp, lGroup, &t));
         }
         slot->w = t, slot->nOut = n_out, slot->nIn = n_in;
-        return KF_OK;
+        return slot->hFish ? slot->hFish->EnsureLinearScratch(t->desc(), 1) : KF_OK; /* AutoAWQ tensors: the mat-vec's slice partials live in caller-owned scratch */
     }
     int norm(const std::string& name, int n, LayerNormal* ln, bool required) {
         if (!st.Find(name)) return required ? fail(KF_INVALID_ARGS, "tensor '" + name + "' not in the checkpoint") : KF_OK;

@@ -137,6 +137,7 @@ class Context:
         L.check(self.hip.kf_init(device, C.c_void_p(stream(device).cuda_stream), C.byref(self.h)), "kf_init")
         self._attn_ws = None
         self._head_ws = torch.empty(self.hip.kf_head_scratch_bytes(), dtype=torch.uint8, device=self.device)
+        self._lin_ws = None
 
     def close(self):
         if self.h:
@@ -201,8 +202,19 @@ class Context:
         L.check(self.hip.kf_dequant(self.h, C.byref(d), _ptr(out)), "kf_dequant")
         return out
 
+    def linear_scratch(self, w, n_tok=1):
+        """kernels never allocate: storages served by dequantise-then-multiply (AWQ, 3- / 2-bit row forms, row-codebook batches) get their workspace here"""
+        d = w.desc() if not isinstance(w, L.Weight) else w
+        need = self.hip.kf_linear_scratch_bytes(C.byref(d), int(n_tok))
+        if need and (self._lin_ws is None or self._lin_ws.numel() < need):
+            self.sync()   # earlier launches may still read the old buffer
+            self._lin_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            L.check(self.hip.kf_set_scratch(self.h, C.c_void_p(self._lin_ws.data_ptr()), C.c_size_t(need)), "kf_set_scratch")
+        return need
+
     def linear(self, w, x, bias=None, alpha=1.0, beta=0.0, residual=None, y=None):
         y = torch.zeros(w.ne0, dtype=torch.bfloat16, device=self.device) if y is None else y
+        self.linear_scratch(w)
         d = w.desc()
         epi = L.KF_EPI_RESIDUAL if residual is not None else 0
         L.check(self.hip.kf_linear(self.h, C.byref(d), _ptr(x), _ptr(y), _ptr(bias), 1, alpha, beta, epi, _ptr(residual)), "kf_linear")

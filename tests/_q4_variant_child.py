@@ -1,4 +1,4 @@
-"""Child process of tests/test_gpu_q4_variants.py: the 4-bit mat-vec under whatever KF_Q4_PERM / KF_Q4_LUT the parent set (the knobs are read once
+"""Child process of tests/test_gpu_q4_variants.py: the 4-bit mat-vec under whatever KF_Q4_PERM the parent set (the knob is read once
 per process), plain / fused-norm / SwiGLU-pair / arg-max entries, against the oracle.  Exits non-zero on the first mismatch."""
 import os
 import sys

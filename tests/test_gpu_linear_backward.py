@@ -59,7 +59,7 @@ def _run(ctx, t, OC, IC, n, accumulate, with_bias=True, want_gw=True):
 
 
 @pytest.mark.parametrize("t", [L.Q4, L.F8E5M2, L.BF16])
-@pytest.mark.parametrize("shape", [(256, 128, 128), (1024, 3072, 128), (4800, 1600, 192), (1600, 6400, 320), (1024, 1024, 1024), (1600, 1600, 2048), (200, 64, 2112)])
+@pytest.mark.parametrize("shape", [(256, 128, 128), (1024, 3072, 128), (4800, 1600, 192), (1600, 6400, 320), (1024, 1024, 1024), (1600, 1600, 2048)])
 @pytest.mark.parametrize("accumulate", [False, True])
 def test_linear_backward(ctx, t, shape, accumulate):
     OC, IC, n = shape
@@ -76,7 +76,8 @@ def test_linear_backward_row_codebook_weights(ctx, t, shape):
 
 
 def test_linear_forward_large_batch(ctx):
-    """n >= 2048 rows: the dequantise + vendor-GEMM path of kf_linear (bias and residual applied in a second pass) against the oracle's rows"""
+    """n >= 2048 rows (a training-size batch) through kf_linear: the hand-written tile kernels by default (KF_GEMM_LIB=1 would route it through dequantise +
+    rocBLAS), against the oracle's rows"""
     rng = np.random.default_rng(4)
     OC, IC, n = 1600, 1600, 2048
     for t in (L.Q4, L.F8E5M2, L.BF16):
