@@ -85,25 +85,26 @@ def build_from_raw(cfg, raw, layer_type=L.Q4, head_type=L.BF16, device=0, lGroup
     return m
 
 
-def build_on_gpu(cfg, seed=1234, layer_type=L.Q4, head_type=L.BF16, device=0, lGroup=128, w_std=0.02, own_stream=False):
-    """Full-size synthetic model drawn on the GPU (torch generator), quantised by kf_quantize."""
+def build_on_gpu(cfg, seed=1234, layer_type=L.Q4, head_type=L.BF16, device=0, lGroup=128, w_std=0.02, own_stream=False, head_std=None):
+    """Full-size synthetic model drawn on the GPU (torch generator), quantised by kf_quantize.  head_std: std of the embedding / LM-head rows
+    (default w_std); 0.1 gives peaked logits whose top-2 margin is far above one bf16 ulp (id-parity fixtures)."""
     ctx = Context(device)
     m = Qwen3(cfg, device, own_stream=own_stream)
     m._ctx = ctx
     g = torch.Generator(device=ctx.device)
     g.manual_seed(seed)
 
-    def mat(r, c):
-        return (torch.randn(r, c, generator=g, device=ctx.device, dtype=torch.float32) * w_std).to(torch.bfloat16)
+    def mat(r, c, std=None):
+        return (torch.randn(r, c, generator=g, device=ctx.device, dtype=torch.float32) * (w_std if std is None else std)).to(torch.bfloat16)
 
     def nrm(n):
         return (1.0 + 0.01 * torch.randn(n, generator=g, device=ctx.device, dtype=torch.float32)).to(torch.bfloat16)
 
-    m.set_weight(-1, 0, ctx.quantize(mat(cfg["vocab"], cfg["dim"]), head_type, lGroup))
+    m.set_weight(-1, 0, ctx.quantize(mat(cfg["vocab"], cfg["dim"], head_std), head_type, lGroup))
     if cfg.get("tied", True):
         m.tie_head()
     else:
-        m.set_weight(-1, 1, ctx.quantize(mat(cfg["vocab"], cfg["dim"]), head_type, lGroup))
+        m.set_weight(-1, 1, ctx.quantize(mat(cfg["vocab"], cfg["dim"], head_std), head_type, lGroup))
     m.set_norm(-1, 0, nrm(cfg["dim"]))
     for li in range(cfg["n_layer"]):
         for si, s in enumerate(SLOTS):

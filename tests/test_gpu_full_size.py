@@ -31,9 +31,63 @@ def test_full_size_logits_and_ids_vs_oracle(model):
         assert err <= LOGIT_TOL, "pos %d: logits off by %g of max" % (pos, err)
         assert g_next == O.argmax_bf16(g_logits)
         top2 = np.sort(ol)[-2:]
-        if top2[1] - top2[0] > 2 * LOGIT_TOL * np.abs(ol).max():
+        if top2[1] - top2[0] > 2.0 ** -7 * np.abs(ol).max():   # two bf16 ulps of the logit scale
             assert g_next == o_next
     om.close()
+
+
+def _decode_after_prefill(m, om, cfg, P, n_follow, seed):
+    """Fills positions 0..P-1 with the batched prefill, hands the SAME KV rows to the oracle, then decodes positions P..P+n_follow-1 teacher-forced on
+    both (hipGraph replay of the position's bucket: the persistent engine where it serves the bound, with its multi-slice attention from 256 keys
+    up).  Returns per position (gpu id, oracle id, relative logit error, relative top-2 margin of the oracle's logits)."""
+    toks = np.random.default_rng(seed).integers(0, cfg["vocab"], size=P + n_follow).astype(np.int32)
+    m.prefill(toks[:P], want_logits=False)
+    gk, gv = m.kv_to_host()
+    ok, ov = om.kv()
+    ok[:, :P] = gk[:, :P]
+    ov[:, :P] = gv[:, :P]
+    forced = np.full(cfg["max_seq"], -1, dtype=np.int32)
+    forced[:P + n_follow] = toks
+    m.set_forced(forced)
+    m.set_state(int(toks[P - 1]), P - 1)   # the step at P reads forced[P]; the state only has to name a valid position below it
+    out = []
+    for p in range(P, P + n_follow):
+        m.set_state(int(toks[p]), p)
+        m.run_steps(p, 1, use_graph=True)
+        m.sync()
+        g_id, g_logits = int(m.tokens_out(p + 1)[p]), m.logits()
+        o_id, o_logits, _ = om.decode(int(toks[p]), p)
+        gl, ol = O.bf16_to_f32(g_logits), O.bf16_to_f32(o_logits)
+        top2 = np.sort(ol)[-2:]
+        out.append((g_id, o_id, float(np.abs(gl - ol).max() / np.abs(ol).max()), float((top2[1] - top2[0]) / np.abs(ol).max())))
+        assert g_id == O.argmax_bf16(g_logits), "device arg-max is not the first maximum of its own logits"
+    return out
+
+
+TIE = 2.0 ** -7   # two bf16 ulps at the top of the logit range: GPU and oracle each round their own fp32 sum to bf16 once, so a top-2 margin inside it may flip
+
+
+def test_full_size_every_bucket_logits_and_ids_vs_oracle(model):
+    """BASELINE config 2 at full size across the whole sequence: 6 positions behind prefills of 127, 255, 1023 and 2042 tokens -- every hipGraph bucket
+    (128, 256, 1024, 2048), multi-slice attention up to all 2048 keys, the persistent engine and its in-launch merge.  Logits within 2^-6 of the
+    oracle's at every position; every greedy id whose top-2 margin (of the oracle's logits) exceeds two bf16 ulps of the logit scale must equal the
+    oracle's.  The relative top-2 margin of 151 936 near-Gaussian logits does not depend on the weights' scale (mean ~ 1/24 of the maximum,
+    exponentially distributed), so some positions always fall inside the window; the rule is kept from being vacuous by requiring that at least
+    half of the 24 positions are decided by it."""
+    cfg, m = model
+    om = O.from_device_model(m)
+    n, decided = 0, 0
+    for P in (127, 255, 1023, 2042):
+        for i, (g_id, o_id, err, margin) in enumerate(_decode_after_prefill(m, om, cfg, P, 6, seed=100 + P)):
+            assert err <= LOGIT_TOL, "position %d: logits off by %g of max" % (P + i, err)
+            n += 1
+            if margin > TIE:
+                decided += 1
+                assert g_id == o_id, "position %d: greedy id %d vs oracle %d at margin %g of max" % (P + i, g_id, o_id, margin)
+    om.close()
+    assert m.engine_steps() > 0
+    m.engine_check()
+    assert decided >= n // 2, "only %d of %d positions have a top-2 margin above two bf16 ulps" % (decided, n)
 
 
 def test_full_size_graph_equals_eager_and_is_deterministic(model):
