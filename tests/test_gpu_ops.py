@@ -190,7 +190,7 @@ def test_lm_head_argmax_first_max(ctx, O):
 
 
 @pytest.mark.parametrize("cfg", [(16, 8, 128), (4, 2, 64), (8, 1, 128), (4, 4, 128)])
-@pytest.mark.parametrize("pos", [0, 3, 63, 64, 200, 1500])
+@pytest.mark.parametrize("pos", [0, 3, 63, 64, 200, 1500, 2047, 4095])
 def test_attn_decode_vs_oracle(ctx, O, cfg, pos):
     nh, nkv, hd = cfg
     rng = np.random.default_rng(pos * 7 + nh)
