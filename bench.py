@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--layers", default="q4", choices=["q4", "bf16", "f8", "ternary", "1bit", "nf4"],
                     help="weight type of the transformer layers (default: the metric's 4-bit PackedQ; the others are side measurements)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--sparse", type=float, default=0.0, help="BASELINE config 5 side measurement: this fraction of every layer's FFN rows hot (seeded mask, seed 5 + layer), the rest skipped (D_matmul_sparse); use with --layers 1bit")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--engine", type=int, default=-1, help="1: the layer loop as one persistent launch (kf_engine_*); 0: five launches per layer; -1: the library default")
     ap.add_argument("--streams", type=int, default=0, help="side measurement after the timed region: this many INDEPENDENT decoders (own weights, own "
@@ -70,6 +71,11 @@ def main():
     layer_type = {"q4": L.Q4, "bf16": L.BF16, "f8": L.F8E5M2, "ternary": L.T_SIGN, "1bit": L.BOOL1, "nf4": L.NF4}[args.layers]
     m = synth.build_on_gpu(cfg, seed=1234 + rank, layer_type=layer_type, head_type=head_type, device=dev)
     ctx = m._ctx
+    if args.sparse > 0.0:
+        for l in range(cfg["n_layer"]):
+            hot = np.zeros(cfg["ffn"], dtype=np.int32)
+            hot[np.random.default_rng(5 + l).permutation(cfg["ffn"])[: max(int(cfg["ffn"] * args.sparse), 16)]] = 1
+            m.set_hot(l, hot)
     if args.engine >= 0:
         m.set_engine(bool(args.engine))
     elif "KF_BENCH_DEVICE" in os.environ and world > 1:
@@ -142,7 +148,7 @@ def main():
             "config": {"workload": "%s %s greedy decode, 1xMI355X per replica, seq=%d: prompt 128, timed positions %d..%d"
                                    % ({"qwen3-0.6b": "Qwen3-0.6B", "qwen3-32b": "Qwen3-32B"}.get(args.config, args.config), {"q4": "4-bit PackedQ", "bf16": "bf16", "f8": "f8e5m2", "ternary": "2-bit ternary PackedQ", "1bit": "1-bit PackedQ", "nf4": "4-bit NF4 row-codebook"}[args.layers],
                                       S, timed_positions[0], timed_positions[-1]),
-                       "lm_head": args.head, "replicas": world, "hipgraph": use_graph, "device_ms_per_step": round(dev_ms / K, 5)},
+                       "lm_head": args.head, "sparse_ffn_rows_hot": args.sparse if args.sparse > 0 else None, "replicas": world, "hipgraph": use_graph, "device_ms_per_step": round(dev_ms / K, 5)},
             "step_roofline": {"bound": "hbm", "bytes_per_step": int(mean_bytes), "achieved": round(mean_bytes * (value / world) / 1e9, 1),
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(mean_bytes * (value / world) / 1e9 / HBM_PEAK_GBS, 4)},
         }

@@ -142,6 +142,16 @@ int kf_linear_f32(kf_ctx* ctx, const kf_weight* w_shard, const kf_bf16* x_shard,
 /* ... that are combined in rank order after an all-gather: out = bf16(residual + bf16(sum_r partials[r][:])) */
 int kf_tp_reduce(kf_ctx* ctx, const float* partials, int n_ranks, int n, const kf_bf16* residual_or_null, kf_bf16* out);
 
+/* ---- sparse ("EOE" / hot-neuron) forward: D_matmul_sparse (src/Utils/GST_float.cpp:306-318) with the hot[] array of CS_Picker
+ * (src/Manifold/SparseNeuron.cpp:20-29; Neuron.hpp:265-285: one int per FFN row, 1 = hot):  y[i] = (hot[i] == 1 ? W[i,:].x : 0) (+ bias[i]).
+ * The mask is turned into a list of hot rows once (kf_hot_rows: ascending indices, their number to *d_count) and the products walk that list, so
+ * cold rows cost no HBM traffic: algorithmic bytes = n_hot / ne0 of the dense product's.  Hot rows carry every bit of kf_linear's rows.
+ * kf_norm_gateup_swiglu_masked is the FFN form (FFN::cuInfer with the mask on the gate / up rows): cold rows of `act` are SwiGLU(0, 0) = 0. */
+int kf_hot_rows(kf_ctx* ctx, const int32_t* d_hot, int n, int32_t* d_rows, int32_t* d_count);
+int kf_linear_masked(kf_ctx* ctx, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const kf_bf16* bias_or_null, const int32_t* d_rows, int n_hot);
+int kf_norm_gateup_swiglu_masked(kf_ctx* ctx, const kf_bf16* x, const kf_bf16* norm_w_or_null, float eps, const kf_weight* gate, const kf_weight* up,
+                                 kf_bf16* act, const int32_t* d_rows, int n_hot);
+
 /* LayerNormal::cuFlow -> CU_rms_infer (Neuron.hpp:453, T.cu:561-573, layernorm.cuh:800-859) */
 int kf_rmsnorm(kf_ctx* ctx, const kf_bf16* x, const kf_bf16* w, kf_bf16* y, int rows, int dim, float eps, float* rstd_or_null);
 

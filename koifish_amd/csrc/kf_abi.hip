@@ -470,6 +470,43 @@ int kf_norm_gateup_swiglu(kf_ctx* c, const kf_bf16* x, const kf_bf16* norm_w, fl
     RET(kf::gemv_launch(c->stream, L));
 }
 
+// ---- sparse forward (hot rows)
+int kf_hot_rows(kf_ctx* c, const int32_t* d_hot, int n, int32_t* d_rows, int32_t* d_count) {
+    CHKCTX(c);
+    if (!d_hot || !d_rows || !d_count || n < 1) return fail(KF_INVALID_ARGS, "kf_hot_rows: null pointer or n < 1");
+    RET(kf::hot_rows_launch(c->stream, d_hot, n, d_rows, d_count));
+}
+int kf_linear_masked(kf_ctx* c, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const kf_bf16* bias, const int32_t* d_rows, int n_hot) {
+    CHKCTX(c);
+    int r = check_weight(w, "kf_linear_masked");
+    if (r) return r;
+    if (!x || !y || !al16(x) || !d_rows || n_hot < 0 || n_hot > w->ne0) return fail(KF_INVALID_ARGS, "kf_linear_masked: null / unaligned pointer or n_hot outside [0, ne0]");
+    if (w->qzeros) return fail(KF_UNSUPPORTED_DATATYPE, "kf_linear_masked: AutoAWQ-layout weights are served by kf_linear only");
+    r = kf::cold_fill_launch(c->stream, y, bias, w->ne0); /* cold rows: 0 (+ bias); the hot rows are overwritten below */
+    if (r != KF_OK || n_hot == 0) RET(r);
+    kf::GemvLaunch L;
+    init_args(L);
+    L.n = 1, L.w[0] = w, L.mode = kf::GEMV_PLAIN, L.n_hot = n_hot;
+    L.args.x = x, L.args.job[0].y = y, L.args.bias = bias, L.args.row_map = d_rows;
+    RET(kf::gemv_launch(c->stream, L));
+}
+int kf_norm_gateup_swiglu_masked(kf_ctx* c, const kf_bf16* x, const kf_bf16* norm_w, float eps, const kf_weight* gate, const kf_weight* up, kf_bf16* act,
+                                 const int32_t* d_rows, int n_hot) {
+    CHKCTX(c);
+    int r = check_weight(gate, "kf_norm_gateup_swiglu_masked");
+    if (r) return r;
+    r = check_weight(up, "kf_norm_gateup_swiglu_masked");
+    if (r) return r;
+    if (!x || !act || !al16(x) || !d_rows || n_hot < 0 || n_hot > gate->ne0) return fail(KF_INVALID_ARGS, "kf_norm_gateup_swiglu_masked: bad pointer or n_hot");
+    r = kf::cold_fill_launch(c->stream, act, nullptr, gate->ne0); /* SwiGLU of two zero projections is zero */
+    if (r != KF_OK || n_hot == 0) RET(r);
+    kf::GemvLaunch L;
+    init_args(L);
+    L.n = 2, L.w[0] = gate, L.w[1] = up, L.mode = kf::GEMV_PAIRED, L.n_hot = n_hot;
+    L.args.x = x, L.args.norm_w = norm_w, L.args.eps = eps, L.args.job[0].y = act, L.args.row_map = d_rows;
+    RET(kf::gemv_launch(c->stream, L));
+}
+
 int kf_rmsnorm(kf_ctx* c, const kf_bf16* x, const kf_bf16* w, kf_bf16* y, int rows, int dim, float eps, float* rstd) {
     CHKCTX(c);
     if (!x || !w || !y) return fail(KF_INVALID_ARGS, "kf_rmsnorm: null pointer");

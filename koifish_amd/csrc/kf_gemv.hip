@@ -114,6 +114,7 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
                 }
             }
             if (LAT || ok) {
+                if (a.row_map) row = a.row_map[row]; /* sparse forward: the slot's row is the row-th hot row (one dependent, wave-uniform-per-group load) */
                 const uint32_t bidx = (uint32_t)row * (uint32_t)nBlk + (uint32_t)col; /* < 2^32 blocks = 64 GiB per tensor */
                 b.w[g] = ld_nt(jw + bidx);
                 if (PAIRED) b.w2[g] = ld_nt(jw2 + bidx);
@@ -271,6 +272,7 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
                 for (int g = 0; g < G; g++) {
                     int r;
                     if (!slot(s_begin + (long)bi * G + g, r)) continue;
+                    if (a.row_map) r = a.row_map[r];
                     uint16_t* y = jy + (size_t)pos * jystride;
                     float v = acc[g];
                     if (PAIRED) {
@@ -471,13 +473,13 @@ int gemv_launch(hipStream_t st, GemvLaunch& L) {
             if (bpg < 1 || (bpg & (bpg - 1)) != 0) return KF_QUANT_ERR;
             a.gshift = __builtin_ctz(bpg);
         }
-        jb.M = w->ne0;
+        jb.M = a.row_map ? L.n_hot : w->ne0; /* sparse forward: only the hot rows get slots */
         jb.qBias = w->qBias;
         if (L.mode == GEMV_PAIRED && j == 1) {
             if (w->ne0 != L.w[0]->ne0) return KF_INVALID_ARGS;
             continue; /* job 1 rides on job 0's slots */
         }
-        rows_slots[j] = (w->ne0 + RPS - 1) / RPS;
+        rows_slots[j] = (jb.M + RPS - 1) / RPS;
         raw_slots += rows_slots[j];
     }
     if (L.mode == GEMV_PAIRED) a.njobs = 1;

@@ -45,6 +45,7 @@ struct GemvArgs {
     int pos;
     float* amax_val;
     int* amax_idx;
+    const int32_t* row_map; /* non-NULL: the sparse forward -- slot rows index this list of hot rows (job.M = their number); weights and outputs use row_map[row] */
 };
 
 struct GemvLaunch {
@@ -53,6 +54,7 @@ struct GemvLaunch {
     int n;
     int mode;
     long target_waves; /* 0: default */
+    int n_hot;         /* args.row_map != NULL: number of entries */
     int blocks;        /* out */
 };
 
@@ -151,6 +153,8 @@ int awq_linear_launch(hipStream_t st, const kf_weight* w, const uint16_t* x, uin
 int awq_dequant_launch(hipStream_t st, const kf_weight* w, uint16_t* out);
 
 int set_state_launch(hipStream_t st, int32_t* d_state, int token, int pos);
+int hot_rows_launch(hipStream_t st, const int32_t* hot, int n, int32_t* rows, int32_t* count);
+int cold_fill_launch(hipStream_t st, uint16_t* y, const uint16_t* bias, int n);
 int tp_reduce_launch(hipStream_t st, const float* partials, int R, int n, const uint16_t* residual, uint16_t* out);
 
 }  // namespace kf

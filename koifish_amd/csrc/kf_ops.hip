@@ -864,4 +864,44 @@ int set_state_launch(hipStream_t st, int32_t* d_state, int token, int pos) {
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 
+// ---- hot-row lists for the sparse forward (CS_Picker's `hot` array, SparseNeuron.cpp:20-29; D_matmul_sparse, GST_float.cpp:306-318)
+// rows[0 .. count) = the indices i with hot[i] == 1, ascending; one workgroup walks the mask in chunks of 1024 with a ballot-ordered compaction
+__global__ void __launch_bounds__(1024) hot_rows_kernel(const int32_t* hot, int n, int32_t* rows, int32_t* count) {
+    __shared__ int wsum[16], base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+        const int i = c0 + tid;
+        const bool h = i < n && hot[i] == 1;
+        const unsigned long long b = __ballot(h);
+        if (lane == 0) wsum[wave] = __popcll(b);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; w++) off += wsum[w];
+        if (h) rows[off + __popcll(b & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < 16; w++) t += wsum[w];
+            base += t;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *count = base;
+}
+int hot_rows_launch(hipStream_t st, const int32_t* hot, int n, int32_t* rows, int32_t* count) {
+    hipLaunchKernelGGL(hot_rows_kernel, dim3(1), dim3(1024), 0, st, hot, n, rows, count);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+// cold rows of a masked product: y[i] = bf16(0 + bias[i]) (val = 0, then the bias: D_matmul_sparse)
+__global__ void cold_fill_kernel(uint16_t* y, const uint16_t* bias, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = bias ? f2bf(0.0f + bf2f(bias[i])) : (uint16_t)0;
+}
+int cold_fill_launch(hipStream_t st, uint16_t* y, const uint16_t* bias, int n) {
+    hipLaunchKernelGGL(cold_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, st, y, bias, n);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+
 }  // namespace kf

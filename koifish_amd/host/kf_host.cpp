@@ -131,14 +131,25 @@ hGTensor FFN::cuInfer(hGTensor hIn, int) {
         hGTensor xn = norm.cuFlow(hIn);
         if (!xn) return nullptr;
         hGTensor tGelu = f->gBUFF.scratch, up_out = f->gBUFF.upOut;
-        if (gate.Forw(tGelu, xn) || up.Forw(up_out, xn)) return nullptr;
+        if (n_hot >= 0) {  // D_matmul_sparse on both projections
+            kf_weight wg = gate.w->desc(), wu = up.w->desc();
+            const int32_t* rows = reinterpret_cast<const int32_t*>(hot_rows->data);
+            if (kf_linear_masked(c, &wg, ToX(xn), ToX(tGelu), nullptr, rows, n_hot) != KF_OK || kf_linear_masked(c, &wu, ToX(xn), ToX(up_out), nullptr, rows, n_hot) != KF_OK)
+                return nullptr;
+        } else if (gate.Forw(tGelu, xn) || up.Forw(up_out, xn))
+            return nullptr;
         if (relu.Forw(tGelu, tGelu, up_out)) return nullptr;
         if (down.Forw(ToX(f->gBUFF.delta), ToX(tGelu))) return nullptr;
         if (kf_add(c, ToX(f->gBUFF.residual), ToX(f->gBUFF.delta), ToX(out), f->config.nEmbed) != KF_OK) return nullptr;
         return out;
     }
     kf_weight wg = gate.w->desc(), wu = up.w->desc(), wd = down.w->desc();
-    if (kf_norm_gateup_swiglu(c, ToX(hIn), ToX(norm.w), norm.rms_eps, &wg, &wu, ToX(f->gBUFF.scratch)) != KF_OK) return nullptr;
+    if (n_hot >= 0) {
+        if (kf_norm_gateup_swiglu_masked(c, ToX(hIn), ToX(norm.w), norm.rms_eps, &wg, &wu, ToX(f->gBUFF.scratch), reinterpret_cast<const int32_t*>(hot_rows->data),
+                                         n_hot) != KF_OK)
+            return nullptr;
+    } else if (kf_norm_gateup_swiglu(c, ToX(hIn), ToX(norm.w), norm.rms_eps, &wg, &wu, ToX(f->gBUFF.scratch)) != KF_OK)
+        return nullptr;
     if (kf_linear(c, &wd, ToX(f->gBUFF.scratch), ToX(out), nullptr, 1, 1.0f, 0.0f, KF_EPI_RESIDUAL, ToX(hIn)) != KF_OK) return nullptr;
     return out;
 }
@@ -310,7 +321,7 @@ int Fish::EnsureEngine() {
             if (!s[j]->w || s[j]->b) return KF_ENGINE_NOT_SERVED;
             L[l].w[j] = s[j]->w->desc();
         }
-        if (!a->norm.w || !m->norm.w) return KF_ENGINE_NOT_SERVED;
+        if (!a->norm.w || !m->norm.w || m->n_hot >= 0) return KF_ENGINE_NOT_SERVED; /* the sparse forward keeps the per-layer launches */
         L[l].norm_in = ToX(a->norm.w), L[l].norm_post = ToX(m->norm.w);
         L[l].q_norm = a->normQ.w ? ToX(a->normQ.w) : nullptr, L[l].k_norm = a->normK.w ? ToX(a->normK.w) : nullptr;
         L[l].kcache = reinterpret_cast<floatX*>(cache.Get(KVCache::KV_KEY, l, 0));
@@ -525,6 +536,33 @@ void* kfh_ctx(void* h) { return reinterpret_cast<Fish*>(h)->ctx; }
 int kfh_set_fuse_level(void* h, int lvl) {
     reinterpret_cast<Fish*>(h)->fuse_level = lvl;
     return KF_OK;
+}
+// sparse forward: h_hot[ffn] (1 = hot, CS_Picker::hot) for one layer's FFN, NULL = dense again.  The mask becomes a device row list here (load time).
+int kfh_set_hot(void* h, int layer, const int32_t* h_hot, int n) {
+    Fish* f = reinterpret_cast<Fish*>(h);
+    if (layer < 0 || layer >= f->config.nLayer) return KF_INVALID_ARGS;
+    FFN* m = f->ffn[layer].get();
+    for (auto& g : f->graphs)
+        if (g) kf_graph_destroy(g), g = nullptr;
+    if (!h_hot) {
+        m->n_hot = -1, m->hot_rows.reset();
+        return KF_OK;
+    }
+    if (n != f->config.n_ff) return KF_INVALID_ARGS;
+    hGTensor mask = GT(f->ctx, "hot", typNUMBER::I32, n), rows = GT(f->ctx, "hot_rows", typNUMBER::I32, n + 4);
+    if (!mask || !rows) return KF_OUTOF_GPUMEMORY;
+    KF_TRY(kf_h2d(f->ctx, mask->data, h_hot, (size_t)n * 4));
+    int32_t* d_count = reinterpret_cast<int32_t*>(rows->data) + n;
+    KF_TRY(kf_hot_rows(f->ctx, reinterpret_cast<const int32_t*>(mask->data), n, reinterpret_cast<int32_t*>(rows->data), d_count));
+    int32_t cnt = 0;
+    KF_TRY(kf_d2h(f->ctx, &cnt, d_count, 4));
+    m->hot_rows = rows, m->n_hot = cnt;
+    if (f->engine_state > 0) f->engine_state = -1; /* a built engine walks the dense FFN */
+    return KF_OK;
+}
+int kfh_n_hot(void* h, int layer) {
+    Fish* f = reinterpret_cast<Fish*>(h);
+    return (layer < 0 || layer >= f->config.nLayer) ? KF_INVALID_ARGS : f->ffn[layer]->n_hot;
 }
 // the persistent decode engine: on (default) / off; captured step graphs are dropped so that the next step is captured the new way
 int kfh_set_engine(void* h, int on) {

@@ -127,6 +127,9 @@ struct FFN : GeNeuron {
     Relu relu;
     hGTensor out;
     int latent = 0;
+    // sparse forward (CS_Picker::hot, SparseNeuron.cpp:20-29): the hot rows of gate / up as a device list; n_hot < 0 = dense
+    hGTensor hot_rows;
+    int n_hot = -1;
     hGTensor cuInfer(hGTensor hIn, int flag = 0);
     int cuFlow(floatX* bx, int n);
 };

@@ -391,6 +391,18 @@ class Qwen3:
     def set_fuse_level(self, lvl):
         self.host.kfh_set_fuse_level(self.h, lvl)
 
+    def set_hot(self, layer, hot):
+        """sparse forward (D_matmul_sparse / CS_Picker::hot): hot[ffn] int32 host array, 1 = the FFN row of gate / up is computed; None = dense"""
+        if hot is None:
+            L.check(self.host.kfh_set_hot(self.h, int(layer), None, 0), "kfh_set_hot")
+            self._hot.pop(layer, None) if hasattr(self, "_hot") else None
+            return
+        a = np.ascontiguousarray(hot, dtype=np.int32)
+        L.check(self.host.kfh_set_hot(self.h, int(layer), a.ctypes.data_as(C.c_void_p), a.size), "kfh_set_hot")
+        if not hasattr(self, "_hot"):
+            self._hot = {}
+        self._hot[layer] = int(self.host.kfh_n_hot(self.h, int(layer)))
+
     def set_engine(self, on):
         """The persistent decode engine (kf_engine_*: all layers of a step in one launch) on / off; off = the five launches per layer.
         Same arithmetic either way, bit for bit."""
@@ -493,9 +505,13 @@ class Qwen3:
         c = self.cfg
         kvd = c["n_kv"] * c["head_dim"]
         wb = 0
+        hot = getattr(self, "_hot", {})
         for (layer, slot), w in self.weights.items():
             if layer == -1 and slot == 0:
                 continue  # embedding: one row
+            if layer in hot and slot in (4, 5):   # sparse forward: only the hot rows of gate / up are read
+                wb += w.algorithmic_bytes() * hot[layer] // w.ne0
+                continue
             wb += w.algorithmic_bytes()
         emb = self.weights[(-1, 0)]
         wb += emb.algorithmic_bytes() // emb.ne0

@@ -509,6 +509,29 @@ KFO_API void kfo_linear_rows(const kfo_weight* w, const uint16_t* x, uint16_t* y
 KFO_API void kfo_linear(const kfo_weight* w, const uint16_t* x, uint16_t* y, const uint16_t* bias, float alpha, float beta) {
     kfo_linear_rows(w, x, y, bias, alpha, beta, 0, w->ne0);
 }
+/* D_matmul_sparse (src/Utils/GST_float.cpp:306-318): row i is computed only when hot[i] == 1 (CS_Picker's array, SparseNeuron.cpp:20-29);
+ * a cold row is val = 0, then the bias.  Hot rows: exactly kfo_linear's rows. */
+KFO_API void kfo_linear_masked(const kfo_weight* w, const uint16_t* x, uint16_t* y, const uint16_t* bias, const int32_t* hot) {
+    const int K = w->ne1;
+    float* xf = (float*)malloc(sizeof(float) * K);
+    for (int c = 0; c < K; c++) xf[c] = kfo_bf16_to_f32(x[c]);
+#pragma omp parallel
+    {
+        float* row = (float*)malloc(sizeof(float) * K);
+#pragma omp for schedule(dynamic, 16)
+        for (long r = 0; r < w->ne0; r++) {
+            float v = 0.f;
+            if (hot[r] == 1) {
+                weight_row_f32(w, r, row);
+                v = dot16(row, xf, K);
+            }
+            if (bias) v = v + kfo_bf16_to_f32(bias[r]);
+            y[r] = kfo_f32_to_bf16(v);
+        }
+        free(row);
+    }
+    free(xf);
+}
 /* fp32 (un-rounded) row dots, for the TP partial-sum path and tolerance analysis */
 KFO_API void kfo_linear_f32(const kfo_weight* w, const uint16_t* x, float* y, int c0, int c1) {
     const int K = w->ne1;
@@ -1208,6 +1231,7 @@ KFO_API void kfo_attn_decode(const uint16_t* q, const uint16_t* kc, const uint16
 typedef struct {
     const uint16_t *norm_in, *norm_post, *qn, *kn;
     kfo_weight q, k, v, o, gate, up, down;
+    const int32_t* hot; /* sparse forward: 1 = hot FFN row (CS_Picker::hot), NULL = dense */
 } kfo_layer;
 
 typedef struct {
@@ -1273,6 +1297,13 @@ KFO_API int kfo_qwen3_set_norm(kfo_qwen3* m, int layer, int slot, const uint16_t
     return 0;
 }
 
+/* hot[ffn] (1 = hot) for the layer's gate / up rows, NULL = dense; the array stays owned by the caller */
+KFO_API int kfo_qwen3_set_hot(kfo_qwen3* m, int layer, const int32_t* hot) {
+    if (layer < 0 || layer >= m->n_layer) return -1;
+    m->layers[layer].hot = hot;
+    return 0;
+}
+
 /* row-split weights: plain rows.  column-split weights: fp32 partials per rank, summed in rank order. */
 static void linear_colsplit(const kfo_weight* w, const uint16_t* x, uint16_t* y, int tp) {
     if (tp <= 1) {
@@ -1319,8 +1350,13 @@ KFO_API int kfo_qwen3_decode(kfo_qwen3* m, int token, int pos, uint16_t* logits_
         linear_colsplit(&L->o, att, p, m->tp);
         kfo_add(x, p, x, D);
         kfo_rmsnorm(x, L->norm_post, xb, 1, D, m->rms_eps);
-        kfo_linear(&L->gate, xb, gt, NULL, 1.0f, 0.0f);
-        kfo_linear(&L->up, xb, up, NULL, 1.0f, 0.0f);
+        if (L->hot) { /* the sparse forward: D_matmul_sparse on the FFN's rows */
+            kfo_linear_masked(&L->gate, xb, gt, NULL, L->hot);
+            kfo_linear_masked(&L->up, xb, up, NULL, L->hot);
+        } else {
+            kfo_linear(&L->gate, xb, gt, NULL, 1.0f, 0.0f);
+            kfo_linear(&L->up, xb, up, NULL, 1.0f, 0.0f);
+        }
         kfo_swiglu(gt, up, gt, F);
         linear_colsplit(&L->down, gt, p, m->tp);
         kfo_add(x, p, x, D);

@@ -282,6 +282,16 @@ def linear(w, x, bias=None, alpha=1.0, beta=0.0, y=None):
     return y
 
 
+def linear_masked(w, x, hot, bias=None):
+    """D_matmul_sparse: y[i] = (hot[i] == 1 ? W[i,:].x : 0) (+ bias[i])"""
+    x = np.ascontiguousarray(x, dtype=np.uint16)
+    hot = np.ascontiguousarray(hot, dtype=np.int32)
+    y = np.zeros(w.ne0, dtype=np.uint16)
+    d = w.cdesc()
+    lib().kfo_linear_masked(C.byref(d), _p(x), _p(y), _p(bias), _p(hot))
+    return y
+
+
 def linear_f32(w, x, c0=0, c1=None):
     x = np.ascontiguousarray(x, dtype=np.uint16)
     y = np.zeros(w.ne0, dtype=np.float32)
@@ -537,6 +547,18 @@ class Qwen3Oracle:
                     a = np.ascontiguousarray(lw[s], dtype=np.uint16)
                     self._keep.append(a)
                     L.kfo_qwen3_set_norm(self.h, li, si, _p(a))
+
+    def set_hot(self, layer, hot):
+        """sparse forward: hot[ffn] int32, 1 = the FFN row is computed (D_matmul_sparse); None = dense"""
+        if not hasattr(self, "_hot"):
+            self._hot = {}
+        if hot is None:
+            self._hot.pop(layer, None)
+            lib().kfo_qwen3_set_hot(self.h, int(layer), None)
+            return
+        a = np.ascontiguousarray(hot, dtype=np.int32)
+        self._hot[layer] = a   # the C side keeps the pointer
+        lib().kfo_qwen3_set_hot(self.h, int(layer), _p(a))
 
     def decode(self, token, pos, want_logits=True, want_hidden=False):
         logits = np.zeros(self.cfg["vocab"], dtype=np.uint16) if want_logits else None
