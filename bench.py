@@ -19,6 +19,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the CPU-baseline legs time an OpenMP mat-vec: one thread per core, pinned, so that the number is reproducible (set before libgomp starts)
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy achieves
 
@@ -33,6 +36,8 @@ def main():
     ap.add_argument("--layers", default="q4", choices=["q4", "bf16", "f8", "ternary", "1bit", "nf4"],
                     help="weight type of the transformer layers (default: the metric's 4-bit PackedQ; the others are side measurements)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-fp16-steps", type=int, default=64, help="BASELINE config 1 beside the line (never `value`): Qwen3-0.6B with IEEE-half weights decoded on the host cores -- a 128-token "
+                    "prompt fed token by token, then this many greedy steps (0 = skip)")
     ap.add_argument("--sparse", type=float, default=0.0, help="BASELINE config 5 side measurement: this fraction of every layer's FFN rows hot (seeded mask, seed 5 + layer), the rest skipped (D_matmul_sparse); use with --layers 1bit")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--engine", type=int, default=-1, help="1: the layer loop as one persistent launch (kf_engine_*); 0: five launches per layer; -1: the library default")
@@ -170,6 +175,11 @@ def main():
         m.engine_check()
         out["roofline_lm_head"] = head_rl
         out["cpu_baseline"] = cpu_baseline(m, cfg, forced, args.cpu_seconds) if (world == 1 and args.cpu_seconds > 0) else None
+        if world == 1 and args.cpu_seconds > 0 and args.cpu_fp16_steps > 0 and args.config == "qwen3-0.6b":
+            try:
+                out["cpu_baseline_fp16"] = cpu_fp16_decode(cfg, ctx.device, args.cpu_fp16_steps)
+            except Exception as e:   # a side measurement must never cost the bench line
+                out["cpu_baseline_fp16"] = {"error": repr(e)[:200]}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -400,13 +410,22 @@ def matvec_roofline(m, ctx, cfg, head_rl, reps=20):
             "note": "latency-bound: %.1f MB per launch is %.2f us at the HBM peak; the in-kernel time split is in DESIGN.md section 6" % (nbytes / n / 1e6, nbytes / n / HBM_PEAK_GBS / 1e3)}
 
 
-def cpu_baseline(m, cfg, forced, budget_s):
-    """The CPU oracle (a port: no runnable CPU forward exists in the reference) decoding the SAME 4-bit model on this host's
-    cores: weights and the KV rows of a 128-token prompt are copied from the GPU model, then it decodes from position 128 until
-    the time budget is used."""
+def _spread(step_s):
+    import numpy as np
+    a = np.sort(np.asarray(step_s))
+    return {"median_ms": round(float(np.median(a)) * 1e3, 3), "p10_ms": round(float(a[int(0.1 * (a.size - 1))]) * 1e3, 3), "p90_ms": round(float(a[int(0.9 * (a.size - 1))]) * 1e3, 3)}
+
+
+def cpu_baseline(m, cfg, forced, budget_s, min_steps=64, max_steps=256):
+    """The CPU oracle (a port: no runnable CPU forward exists in the reference) decoding the SAME 4-bit model on this host's cores: weights and the
+    KV rows of a 128-token prompt are copied from the GPU model, then it decodes from position 128 -- at least 64 steps (more while the time budget
+    lasts), teacher-forced on the GPU's ids so that both decode one sequence.  Mat-vec = the reference's own CPU idiom (two 8-lane AVX2 accumulators
+    over 16 consecutive elements, rows over OpenMP threads: dotprod_fp16 / D_matvec, GST_float.cpp:75-101, 293-304) on a bf16 copy of the dequantised
+    weights (what GetDataX produces), one pinned thread per core; `value` = 1 / median step time, with the 10th / 90th percentile beside it."""
     from oracle import oracle as O
 
     om = O.from_device_model(m)
+    prep = om.prepare_fast()
     p0 = 128
     gk, gv = m.kv_to_host()
     ok, ov = om.kv()
@@ -415,11 +434,11 @@ def cpu_baseline(m, cfg, forced, budget_s):
     gpu_ids = m.tokens_out(cfg["max_seq"])
     tok, n, same, near_tie = int(gpu_ids[p0 - 1]), 0, 0, 0
     t0 = time.perf_counter()
-    t_decode = 0.0
+    steps = []
     while True:
         t1 = time.perf_counter()
         nxt, lg, _ = om.decode(tok, p0 + n)
-        t_decode += time.perf_counter() - t1
+        steps.append(time.perf_counter() - t1)
         g = int(gpu_ids[p0 + n])
         if nxt == g:
             same += 1
@@ -430,11 +449,62 @@ def cpu_baseline(m, cfg, forced, budget_s):
             near_tie += int(l[nxt] - l[g] <= 2.0 ** -7 * abs(l[nxt]))
         tok = g  # teacher-forced on the GPU's ids so both decode the same sequence
         n += 1
-        if time.perf_counter() - t0 > budget_s or p0 + n >= cfg["max_seq"] - 1:
+        if n >= max_steps or p0 + n >= cfg["max_seq"] - 1 or (n >= min_steps and time.perf_counter() - t0 > budget_s):
             break
-    return {"value": round(n / t_decode, 3), "unit": "tokens/s", "cores": O.num_threads(), "kind": "port",
-            "sample": "%d decode steps at positions %d..%d of the same 4-bit model, OpenMP over output rows" % (n, p0, p0 + n - 1),
-            "greedy_ids_equal_gpu": same, "mismatches_that_are_ties_within_tolerance": near_tie, "mismatches_beyond_tolerance": n - same - near_tie}
+    sp = _spread(steps[2:] if n > 8 else steps)
+    om.close()
+    return {"value": round(1e3 / sp["median_ms"], 3), "unit": "tokens/s", "cores": O.num_threads(), "kind": "port",
+            "sample": "%d decode steps at positions %d..%d of the same 4-bit model; AVX2 two-accumulator dot on a bf16 dequantised copy (%d MB), OpenMP rows, "
+                      "threads pinned one per core" % (n, p0, p0 + n - 1, max(prep, 0) // 2 ** 20), "step_ms": sp,
+            "greedy_ids_equal_gpu": same, "mismatches_that_are_ties_within_2_bf16_ulps": near_tie, "mismatches_beyond_tolerance": n - same - near_tie}
+
+
+def cpu_fp16_decode(cfg, device, n_new, n_prompt=128):
+    """BASELINE config 1 (plumbing, no GPU work in the timed part): Qwen3-0.6B with IEEE-half weights -- N(0, 0.02) rows drawn once (seed 1234) and rounded
+    to half, norms 1 + N(0, 0.01) -- decoded by the CPU oracle on this host's cores: the 128-token prompt (ids randint, seed 7) is fed token by token
+    as the reference's chat loop does (GoPT.cpp:1139-1146), then n_new greedy steps.  Mat-vec = dotprod_fp16 restated (_mm256_cvtph_ps, two 8-lane
+    accumulators, GST_float.cpp:75-101) over OpenMP rows (D_matvec).  1.19 GB of weights per token."""
+    import numpy as np
+    import torch
+    from koifish_amd import synth
+    from oracle import oracle as O
+
+    g = torch.Generator(device=device)
+    g.manual_seed(1234)
+
+    def half(r, c):   # drawn on the GPU only because 596 M normal samples take the host ~10 s; the decode below touches no GPU
+        return O.QWeight(O.F16, r, c, (torch.randn(r, c, generator=g, device=device, dtype=torch.float32) * 0.02).to(torch.float16).cpu().numpy().view(np.uint16))
+
+    def nrm(n):
+        return O.f32_to_bf16((1.0 + 0.01 * torch.randn(n, generator=g, device=device, dtype=torch.float32)).cpu().numpy())
+
+    w = {"embed": half(cfg["vocab"], cfg["dim"]), "final_norm": nrm(cfg["dim"]), "layers": []}
+    w["head"] = w["embed"]
+    for _ in range(cfg["n_layer"]):
+        d = {s: half(*synth.SHAPES[s](cfg)) for s in synth.SLOTS}
+        d["norm_in"], d["norm_post"], d["qn"], d["kn"] = nrm(cfg["dim"]), nrm(cfg["dim"]), nrm(cfg["head_dim"]), nrm(cfg["head_dim"])
+        w["layers"].append(d)
+    om = O.Qwen3Oracle(cfg, w)
+    om.prepare_fast()
+    prompt = np.random.default_rng(7).integers(0, cfg["vocab"], size=n_prompt)
+    t0 = time.perf_counter()
+    nxt = 0
+    for p, t in enumerate(prompt):
+        nxt, _, _ = om.decode(int(t), p, want_logits=False)
+    t_prompt = time.perf_counter() - t0
+    steps, ids = [], []
+    for i in range(n_new):
+        t1 = time.perf_counter()
+        ids.append(nxt)
+        nxt, _, _ = om.decode(int(nxt), n_prompt + i, want_logits=False)
+        steps.append(time.perf_counter() - t1)
+    sp = _spread(steps)
+    nbytes = sum(x.data.nbytes for d in w["layers"] for x in (d[s] for s in synth.SLOTS)) + w["head"].data.nbytes
+    om.close()
+    return {"value": round(1e3 / sp["median_ms"], 3), "unit": "tokens/s", "cores": O.num_threads(), "kind": "port",
+            "workload": "Qwen3-0.6B fp16 greedy decode, 128-token prompt, CPU inference path (BASELINE.json configs[0])",
+            "sample": "%d-token prompt fed token by token (%.1f tokens/s), then %d greedy steps" % (n_prompt, n_prompt / t_prompt, n_new), "step_ms": sp,
+            "weight_bytes_per_token": int(nbytes), "host_GBs": round(nbytes / (sp["median_ms"] * 1e-3) / 1e9, 1), "distinct_ids": len(set(ids))}
 
 
 if __name__ == "__main__":

@@ -31,6 +31,7 @@
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+#include <immintrin.h> /* the vectorised mat-vec of section 4b: AVX2 + F16C, as the reference's own CPU dot products (GST_float.cpp:75-130) */
 
 #define KFO_API __attribute__((visibility("default")))
 
@@ -433,6 +434,9 @@ static void weight_row_f32(const kfo_weight* w, long r, float* out) {
     if (w->type == KFO_BF16) {
         const uint16_t* p = (const uint16_t*)w->data + (size_t)r * K;
         for (int c = 0; c < K; c++) out[c] = kfo_bf16_to_f32(p[c]);
+    } else if (w->type == KFO_F16) { /* IEEE half weights (BASELINE config 1): half_to_float = _cvtsh_ss (GST_float.cpp:60-62), exact */
+        const uint16_t* p = (const uint16_t*)w->data + (size_t)r * K;
+        for (int c = 0; c < K; c++) out[c] = _cvtsh_ss(p[c]);
     } else if (w->type == KFO_F8E5M2) {
         const uint8_t* p = (const uint8_t*)w->data + (size_t)r * K;
         for (int c = 0; c < K; c++) out[c] = kfo_round_bf16(kfo_f8e5m2_to_f32(p[c]));
@@ -562,6 +566,46 @@ KFO_API void kfo_dequant_weight(const kfo_weight* w, uint16_t* out) {
         free(row);
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * 4b. Vectorised mat-vec: the timed CPU baseline (bench.py cpu_baseline) and BASELINE config 1 (fp16 weights).
+ *     Structure of the reference's CPU dot products (dotprod_fp16 / dotprod_fp8, src/Utils/GST_float.cpp:75-130): two 8-lane accumulators over
+ *     16 consecutive elements per step, acc = x * w + acc as a multiply and an add (no fma), then acc0 + acc1, low + high 128 bits, and the
+ *     4-lane dot with ones -- (s0 + s1) + (s2 + s3).  That is dot16() above lane for lane, so every result bit equals the scalar path's
+ *     (tests/test_oracle_fast.py).  Rows over OpenMP threads like D_matvec (GST_float.cpp:293-304).
+ *     Weights are read as 16-bit values: IEEE half directly (_mm256_cvtph_ps, the reference's own conversion) or bf16 (shifted into the high
+ *     half of an fp32); quantised tensors are dequantised ONCE into a bf16 copy (kfo_qwen3_prepare_fast) -- what GetDataX produces.
+ * ---------------------------------------------------------------------------------------------- */
+static inline __m256 load8_w16(const uint16_t* p, int is_f16) {
+    const __m128i h = _mm_loadu_si128((const __m128i*)p);
+    if (is_f16) return _mm256_cvtph_ps(h);
+    return _mm256_castsi256_ps(_mm256_slli_epi32(_mm256_cvtepu16_epi32(h), 16));
+}
+static inline float dot16_w16(const uint16_t* w, const float* x, int n, int is_f16) { /* n a multiple of 16 */
+    __m256 acc0 = _mm256_setzero_ps(), acc1 = _mm256_setzero_ps();
+    for (int j = 0; j < n; j += 16) {
+        acc0 = _mm256_add_ps(_mm256_mul_ps(_mm256_loadu_ps(x + j), load8_w16(w + j, is_f16)), acc0);
+        acc1 = _mm256_add_ps(_mm256_mul_ps(_mm256_loadu_ps(x + j + 8), load8_w16(w + j + 8, is_f16)), acc1);
+    }
+    const __m256 acc8 = _mm256_add_ps(acc0, acc1);
+    const __m128 acc4 = _mm_add_ps(_mm256_castps256_ps128(acc8), _mm256_extractf128_ps(acc8, 1));
+    float s4[4];
+    _mm_storeu_ps(s4, acc4);
+    return (s4[0] + s4[1]) + (s4[2] + s4[3]);
+}
+/* y[r] = bf16(W[r,:].x) for rows [0, M) of a 16-bit weight copy; hot != NULL: D_matmul_sparse (cold rows 0) */
+static void linear_w16(const uint16_t* W, int is_f16, int M, int K, const uint16_t* x, uint16_t* y, const int32_t* hot) {
+    float* xf = (float*)malloc(sizeof(float) * K);
+    for (int c = 0; c < K; c++) xf[c] = kfo_bf16_to_f32(x[c]);
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < M; r++) {
+        float v = 0.f;
+        if (!hot || hot[r] == 1) v = dot16_w16(W + (size_t)r * K, xf, K, is_f16);
+        y[r] = kfo_f32_to_bf16(v);
+    }
+    free(xf);
+}
+KFO_API void kfo_linear_w16(const uint16_t* W, int is_f16, int M, int K, const uint16_t* x, uint16_t* y) { linear_w16(W, is_f16, M, K, x, y, NULL); }
 
 /* ------------------------------------------------------------------------------------------------
  * 5. Small ops
@@ -1242,6 +1286,10 @@ typedef struct {
     const uint16_t* final_norm;
     kfo_layer* layers;
     uint16_t *kcache, *vcache; /* [n_layer, max_seq, kv_dim] bf16 (src/Utils/Cache.cpp:14-26) */
+    /* kfo_qwen3_prepare_fast: 16-bit views of every mat-vec weight for the vectorised path (section 4b); [n_layer * 7 + 1] (last = head) */
+    const uint16_t** fast;
+    uint16_t** fast_own; /* the copies this model allocated (NULL where the tensor's own bf16 / f16 data is used) */
+    int* fast_f16;
 } kfo_qwen3;
 
 KFO_API kfo_qwen3* kfo_qwen3_new(int dim, int n_layer, int n_head, int n_kv, int head_dim, int ffn, int vocab, int max_seq, float rms_eps,
@@ -1257,6 +1305,9 @@ KFO_API kfo_qwen3* kfo_qwen3_new(int dim, int n_layer, int n_head, int n_kv, int
 }
 KFO_API void kfo_qwen3_free(kfo_qwen3* m) {
     if (!m) return;
+    if (m->fast_own)
+        for (int i = 0; i < m->n_layer * 7 + 1; i++) free(m->fast_own[i]);
+    free(m->fast), free(m->fast_own), free(m->fast_f16);
     free(m->layers), free(m->kcache), free(m->vcache), free(m);
 }
 KFO_API void kfo_qwen3_set_tp(kfo_qwen3* m, int tp) { m->tp = tp; }
@@ -1321,6 +1372,59 @@ static void linear_colsplit(const kfo_weight* w, const uint16_t* x, uint16_t* y,
     free(part), free(tot);
 }
 
+/* 16-bit views for the vectorised mat-vec: bf16 / f16 tensors as they are, everything else dequantised once into a bf16 copy (what GetDataX
+ * produces).  Returns the bytes allocated, < 0 when a tensor cannot take the path (K not a multiple of 16, AutoAWQ layout) -- then nothing changes. */
+KFO_API long long kfo_qwen3_prepare_fast(kfo_qwen3* m) {
+    if (m->fast) return 0;
+    const int n = m->n_layer * 7 + 1;
+    const kfo_weight** ws = (const kfo_weight**)malloc(sizeof(void*) * n);
+    for (int l = 0; l < m->n_layer; l++) {
+        kfo_layer* L = &m->layers[l];
+        const kfo_weight* w7[7] = {&L->q, &L->k, &L->v, &L->o, &L->gate, &L->up, &L->down};
+        for (int j = 0; j < 7; j++) ws[l * 7 + j] = w7[j];
+    }
+    ws[n - 1] = &m->head;
+    for (int i = 0; i < n; i++)
+        if (!ws[i]->data || ws[i]->ne1 % 16 != 0 || ws[i]->type == KFO_Q4_AWQ) {
+            free(ws);
+            return -1;
+        }
+    m->fast = (const uint16_t**)calloc(n, sizeof(void*));
+    m->fast_own = (uint16_t**)calloc(n, sizeof(void*));
+    m->fast_f16 = (int*)calloc(n, sizeof(int));
+    long long bytes = 0;
+    for (int i = 0; i < n; i++) {
+        const kfo_weight* w = ws[i];
+        if (w->type == KFO_BF16 || w->type == KFO_F16) {
+            m->fast[i] = (const uint16_t*)w->data, m->fast_f16[i] = w->type == KFO_F16;
+            continue;
+        }
+        int shared = -1; /* tied tensors: one copy */
+        for (int j = 0; j < i; j++)
+            if (ws[j]->data == w->data && ws[j]->type == w->type) shared = j;
+        if (shared >= 0) {
+            m->fast[i] = m->fast[shared];
+            continue;
+        }
+        const size_t ne = (size_t)w->ne0 * w->ne1;
+        m->fast_own[i] = (uint16_t*)malloc(ne * 2);
+        kfo_dequant_weight(w, m->fast_own[i]);
+        m->fast[i] = m->fast_own[i], bytes += (long long)ne * 2;
+    }
+    free(ws);
+    return bytes;
+}
+static void model_linear(kfo_qwen3* m, int layer, int slot, const kfo_weight* w, const uint16_t* x, uint16_t* y, const int32_t* hot) {
+    if (m->fast) {
+        const int i = layer < 0 ? m->n_layer * 7 : layer * 7 + slot;
+        linear_w16(m->fast[i], m->fast_f16[i], w->ne0, w->ne1, x, y, hot);
+    } else if (hot) {
+        kfo_linear_masked(w, x, y, NULL, hot);
+    } else {
+        kfo_linear(w, x, y, NULL, 1.0f, 0.0f);
+    }
+}
+
 /* One decode step.  logits_out (bf16[vocab]) may be NULL.  hidden_out (bf16[dim], after the final
  * norm) may be NULL.  Returns the greedy token id. */
 KFO_API int kfo_qwen3_decode(kfo_qwen3* m, int token, int pos, uint16_t* logits_out, uint16_t* hidden_out) {
@@ -1339,32 +1443,29 @@ KFO_API int kfo_qwen3_decode(kfo_qwen3* m, int token, int pos, uint16_t* logits_
         uint16_t* vc = m->vcache + (size_t)l * m->max_seq * kvd;
         uint16_t *krow = kc + (size_t)pos * kvd, *vrow = vc + (size_t)pos * kvd; /* _devQKV: TGraph.cpp:198-207 */
         kfo_rmsnorm(x, L->norm_in, xb, 1, D, m->rms_eps);
-        kfo_linear(&L->q, xb, q, NULL, 1.0f, 0.0f);
-        kfo_linear(&L->k, xb, krow, NULL, 1.0f, 0.0f);
-        kfo_linear(&L->v, xb, vrow, NULL, 1.0f, 0.0f);
+        model_linear(m, l, 0, &L->q, xb, q, NULL);
+        model_linear(m, l, 1, &L->k, xb, krow, NULL);
+        model_linear(m, l, 2, &L->v, xb, vrow, NULL);
         if (L->qn) kfo_headnorm(q, L->qn, m->n_head, hd, m->qk_eps);
         if (L->kn) kfo_headnorm(krow, L->kn, m->n_kv, hd, m->qk_eps);
         kfo_rope(q, m->n_head, hd, pos, m->theta);
         kfo_rope(krow, m->n_kv, hd, pos, m->theta);
         kfo_attn_decode(q, kc, vc, att, pos, m->n_head, m->n_kv, hd, kvd, m->attn_mode);
-        linear_colsplit(&L->o, att, p, m->tp);
+        if (m->tp <= 1) model_linear(m, l, 3, &L->o, att, p, NULL);
+        else linear_colsplit(&L->o, att, p, m->tp);
         kfo_add(x, p, x, D);
         kfo_rmsnorm(x, L->norm_post, xb, 1, D, m->rms_eps);
-        if (L->hot) { /* the sparse forward: D_matmul_sparse on the FFN's rows */
-            kfo_linear_masked(&L->gate, xb, gt, NULL, L->hot);
-            kfo_linear_masked(&L->up, xb, up, NULL, L->hot);
-        } else {
-            kfo_linear(&L->gate, xb, gt, NULL, 1.0f, 0.0f);
-            kfo_linear(&L->up, xb, up, NULL, 1.0f, 0.0f);
-        }
+        model_linear(m, l, 4, &L->gate, xb, gt, L->hot); /* L->hot: the sparse forward, D_matmul_sparse on the FFN's rows */
+        model_linear(m, l, 5, &L->up, xb, up, L->hot);
         kfo_swiglu(gt, up, gt, F);
-        linear_colsplit(&L->down, gt, p, m->tp);
+        if (m->tp <= 1) model_linear(m, l, 6, &L->down, gt, p, NULL);
+        else linear_colsplit(&L->down, gt, p, m->tp);
         kfo_add(x, p, x, D);
     }
     kfo_rmsnorm(x, m->final_norm, xb, 1, D, m->rms_eps);
     if (hidden_out) memcpy(hidden_out, xb, 2 * D);
     uint16_t* logits = logits_out ? logits_out : (uint16_t*)malloc(2 * (size_t)m->vocab);
-    kfo_linear(&m->head, xb, logits, NULL, 1.0f, 0.0f);
+    model_linear(m, -1, 1, &m->head, xb, logits, NULL);
     int next = kfo_argmax_bf16(logits, m->vocab);
     if (!logits_out) free(logits);
     free(x), free(xb), free(q), free(att), free(p), free(gt), free(up);

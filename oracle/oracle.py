@@ -16,7 +16,7 @@ _LIB = None
 
 # typNUMBER order restated from src/g_float.hpp:84-117
 F32, F64, F16, BF16, F8E5M2, F8E4M3, U8, I8, U16, I16, U32, I32, U64, I64, Q4, Q3, Q2, T_SIGN, T_SEQ, BOOL1, T_BINARY, T_BINARY_3, T_BINARY_TILE = range(23)
-BITS = {BF16: 16, F8E5M2: 8, Q4: 4, T_SIGN: 2, Q2: 2, BOOL1: 1, T_BINARY: 1}
+BITS = {BF16: 16, F16: 16, F8E5M2: 8, Q4: 4, T_SIGN: 2, Q2: 2, BOOL1: 1, T_BINARY: 1}
 
 Q4_AWQ = 100  # oracle-internal tag: Q4 in the AutoAWQ GEMM layout
 Q4_LUT = 101  # oracle-internal tag: Q4 in the row-codebook storage (GeQuant::RT_NormalF)
@@ -143,6 +143,8 @@ def quantize(w_bf16, ne0, ne1, type_, lGroup=128, symmetric=False):
     assert w_bf16.size == ne0 * ne1 and (ne0 * ne1) % lGroup == 0
     if type_ == BF16:
         return QWeight(BF16, ne0, ne1, w_bf16.copy())
+    if type_ == F16:   # BASELINE config 1: IEEE half weights (float_to_half = _cvtss_sh, round to nearest even; GST_float.cpp:60-62)
+        return QWeight(F16, ne0, ne1, bf16_to_f32(w_bf16).astype(np.float16).view(np.uint16))
     if type_ == F8E5M2:
         out = np.zeros(w_bf16.size, dtype=np.uint8)
         lib().kfo_bf16_to_f8e5m2(_p(w_bf16), C.c_size_t(w_bf16.size), _p(out))
@@ -547,6 +549,12 @@ class Qwen3Oracle:
                     a = np.ascontiguousarray(lw[s], dtype=np.uint16)
                     self._keep.append(a)
                     L.kfo_qwen3_set_norm(self.h, li, si, _p(a))
+
+    def prepare_fast(self):
+        """16-bit weight views for the vectorised (AVX2 / F16C) mat-vec: same bits as the scalar path, an order of magnitude faster (the timed CPU
+        baseline).  Returns the bytes allocated (quantised tensors are dequantised once into bf16 copies), or a negative value when not applicable."""
+        lib().kfo_qwen3_prepare_fast.restype = C.c_longlong
+        return int(lib().kfo_qwen3_prepare_fast(self.h))
 
     def set_hot(self, layer, hot):
         """sparse forward: hot[ffn] int32, 1 = the FFN row is computed (D_matmul_sparse); None = dense"""
