@@ -1472,6 +1472,37 @@ KFO_API int kfo_qwen3_decode(kfo_qwen3* m, int token, int pos, uint16_t* logits_
     return next;
 }
 
+/* thread count of the OpenMP regions, and a stand-alone mat-vec probe (M x K 16-bit weights, pages first touched by the threads that read them) that
+ * bench.py uses to pick the thread count the host actually sustains: containers often expose more logical CPUs than they may use, and a 2-socket host
+ * loses more to remote memory and barriers than it gains from the second socket on these small matrices */
+KFO_API void kfo_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+KFO_API double kfo_bench_matvec(int M, int K, int reps) {
+    uint16_t* W = (uint16_t*)malloc((size_t)M * K * 2);
+    uint16_t* x = (uint16_t*)malloc((size_t)K * 2);
+    uint16_t* y = (uint16_t*)malloc((size_t)M * 2);
+    if (!W || !x || !y) return -1.0;
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < M; r++)
+        for (int c = 0; c < K; c++) W[(size_t)r * K + c] = (uint16_t)(0x3c00 + ((r * 31 + c * 7) & 0xff));
+    for (int c = 0; c < K; c++) x[c] = 0x3f80;
+    linear_w16(W, 0, M, K, x, y, NULL);
+    double t0 = 0.0, t1 = 0.0;
+#ifdef _OPENMP
+    t0 = omp_get_wtime();
+#endif
+    for (int i = 0; i < reps; i++) linear_w16(W, 0, M, K, x, y, NULL);
+#ifdef _OPENMP
+    t1 = omp_get_wtime();
+#endif
+    free(W), free(x), free(y);
+    return (t1 - t0) / reps;
+}
 KFO_API int kfo_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

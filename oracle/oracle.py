@@ -652,5 +652,15 @@ def from_device_model(m, attn_mode=ATTN_FUSED):
     return Qwen3Oracle(cfg, ow, attn_mode=attn_mode)
 
 
+def set_num_threads(n):
+    lib().kfo_set_num_threads(int(n))
+
+
+def bench_matvec(M, K, reps=10):
+    """seconds per M x K 16-bit mat-vec at the current thread count (first-touch-local pages)"""
+    lib().kfo_bench_matvec.restype = C.c_double
+    return float(lib().kfo_bench_matvec(int(M), int(K), int(reps)))
+
+
 def num_threads():
     return int(lib().kfo_num_threads())
