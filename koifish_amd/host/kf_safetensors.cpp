@@ -148,6 +148,7 @@ struct Parser {
             char* e = nullptr;
             v.kind = JSON::NUM, v.num = strtod(buf, &e);
             if (e == buf) return fail("bad number");
+            v.is_int = !strpbrk(buf, ".eE");
             return true;
         }
         return fail("unexpected character");
@@ -183,6 +184,303 @@ double JSON::number_or(const std::string& key, double dflt) const {
 bool JSON::bool_or(const std::string& key, bool dflt) const {
     const JSON* v = get(key);
     return v && v->kind == BOOL ? v->b : dflt;
+}
+JSON JSON::Str(const std::string& s) {
+    JSON v;
+    v.kind = STR, v.str = s;
+    return v;
+}
+JSON JSON::Int(int64_t x) {
+    JSON v;
+    v.kind = NUM, v.num = (double)x, v.is_int = true;
+    return v;
+}
+JSON JSON::Real(double x) {
+    JSON v;
+    v.kind = NUM, v.num = x;
+    return v;
+}
+JSON JSON::Bool(bool x) {
+    JSON v;
+    v.kind = BOOL, v.b = x;
+    return v;
+}
+JSON JSON::Object() {
+    JSON v;
+    v.kind = OBJ;
+    return v;
+}
+JSON JSON::Array() {
+    JSON v;
+    v.kind = ARR;
+    return v;
+}
+JSON& JSON::operator[](const std::string& key) {
+    if (kind == NUL) kind = OBJ;
+    for (auto& kv : obj)
+        if (kv.first == key) return kv.second;
+    obj.emplace_back(key, JSON());
+    return obj.back().second;
+}
+const JSON* JSON::path(std::initializer_list<const char*> keys) const {
+    const JSON* v = this;
+    for (const char* k : keys) {
+        v = v->get(k);
+        if (!v) return nullptr;
+    }
+    return v;
+}
+
+namespace {
+void dump_string(const std::string& s, std::string& out) {
+    out += '"';
+    for (unsigned char c : s) {
+        switch (c) {
+            case '"': out += "\\\""; break;
+            case '\\': out += "\\\\"; break;
+            case '\n': out += "\\n"; break;
+            case '\t': out += "\\t"; break;
+            case '\r': out += "\\r"; break;
+            case '\b': out += "\\b"; break;
+            case '\f': out += "\\f"; break;
+            default:
+                if (c < 0x20) {
+                    char buf[8];
+                    snprintf(buf, sizeof(buf), "\\u%04x", c);
+                    out += buf;
+                } else {
+                    out += (char)c;
+                }
+        }
+    }
+    out += '"';
+}
+void dump_value(const JSON& v, std::string& out) {
+    char buf[40];
+    switch (v.kind) {
+        case JSON::NUL: out += "null"; break;
+        case JSON::BOOL: out += v.b ? "true" : "false"; break;
+        case JSON::NUM:
+            if (v.is_int) {
+                snprintf(buf, sizeof(buf), "%lld", (long long)v.num);
+            } else { /* shortest text that reads back to the same double */
+                for (int prec = 1; prec <= 17; prec++) {
+                    snprintf(buf, sizeof(buf), "%.*g", prec, v.num);
+                    if (strtod(buf, nullptr) == v.num) break;
+                }
+                if (!strpbrk(buf, ".eEn")) strcat(buf, ".0"); /* 2.0 stays a real */
+            }
+            out += buf;
+            break;
+        case JSON::STR: dump_string(v.str, out); break;
+        case JSON::ARR:
+            out += '[';
+            for (size_t i = 0; i < v.arr.size(); i++) {
+                if (i) out += ',';
+                dump_value(v.arr[i], out);
+            }
+            out += ']';
+            break;
+        case JSON::OBJ:
+            out += '{';
+            for (size_t i = 0; i < v.obj.size(); i++) {
+                if (i) out += ',';
+                dump_string(v.obj[i].first, out);
+                out += ':';
+                dump_value(v.obj[i].second, out);
+            }
+            out += '}';
+            break;
+    }
+}
+void be(std::vector<uint8_t>& o, uint64_t v, int nbytes) {
+    for (int i = nbytes - 1; i >= 0; i--) o.push_back((uint8_t)(v >> (8 * i)));
+}
+void mp_str(const std::string& s, std::vector<uint8_t>& o) {
+    const size_t n = s.size();
+    if (n <= 31) o.push_back((uint8_t)(0xa0 | n));
+    else if (n <= 0xff) o.push_back(0xd9), be(o, n, 1);
+    else if (n <= 0xffff) o.push_back(0xda), be(o, n, 2);
+    else o.push_back(0xdb), be(o, n, 4);
+    o.insert(o.end(), s.begin(), s.end());
+}
+void mp_value(const JSON& v, std::vector<uint8_t>& o) {
+    switch (v.kind) {
+        case JSON::NUL: o.push_back(0xc0); break;
+        case JSON::BOOL: o.push_back(v.b ? 0xc3 : 0xc2); break;
+        case JSON::NUM:
+            if (v.is_int) {
+                const int64_t i = (int64_t)v.num;
+                if (i >= 0) {
+                    const uint64_t u = (uint64_t)i;
+                    if (u <= 0x7f) o.push_back((uint8_t)u);
+                    else if (u <= 0xff) o.push_back(0xcc), be(o, u, 1);
+                    else if (u <= 0xffff) o.push_back(0xcd), be(o, u, 2);
+                    else if (u <= 0xffffffffull) o.push_back(0xce), be(o, u, 4);
+                    else o.push_back(0xcf), be(o, u, 8);
+                } else if (i >= -32) {
+                    o.push_back((uint8_t)(int8_t)i);
+                } else if (i >= -128) {
+                    o.push_back(0xd0), be(o, (uint64_t)i, 1);
+                } else if (i >= -32768) {
+                    o.push_back(0xd1), be(o, (uint64_t)i, 2);
+                } else if (i >= -2147483648ll) {
+                    o.push_back(0xd2), be(o, (uint64_t)i, 4);
+                } else {
+                    o.push_back(0xd3), be(o, (uint64_t)i, 8);
+                }
+            } else {
+                const float f = (float)v.num;
+                if (std::fabs(v.num) <= 3.4028234663852886e38 && (double)f == v.num) {
+                    uint32_t u;
+                    memcpy(&u, &f, 4);
+                    o.push_back(0xca), be(o, u, 4);
+                } else {
+                    uint64_t u;
+                    memcpy(&u, &v.num, 8);
+                    o.push_back(0xcb), be(o, u, 8);
+                }
+            }
+            break;
+        case JSON::STR: mp_str(v.str, o); break;
+        case JSON::ARR: {
+            const size_t n = v.arr.size();
+            if (n <= 15) o.push_back((uint8_t)(0x90 | n));
+            else if (n <= 0xffff) o.push_back(0xdc), be(o, n, 2);
+            else o.push_back(0xdd), be(o, n, 4);
+            for (const auto& c : v.arr) mp_value(c, o);
+            break;
+        }
+        case JSON::OBJ: {
+            const size_t n = v.obj.size();
+            if (n <= 15) o.push_back((uint8_t)(0x80 | n));
+            else if (n <= 0xffff) o.push_back(0xde), be(o, n, 2);
+            else o.push_back(0xdf), be(o, n, 4);
+            for (const auto& kv : v.obj) mp_str(kv.first, o), mp_value(kv.second, o);
+            break;
+        }
+    }
+}
+struct MpReader {
+    const uint8_t *p, *end, *base;
+    std::string err;
+    bool fail(const char* what) {
+        char buf[96];
+        snprintf(buf, sizeof(buf), "msgpack: %s at byte %zu", what, (size_t)(p - base));
+        err = buf;
+        return false;
+    }
+    bool need(size_t n) { return (size_t)(end - p) >= n ? true : fail("truncated"); }
+    uint64_t rd(int nbytes) {
+        uint64_t v = 0;
+        for (int i = 0; i < nbytes; i++) v = (v << 8) | *p++;
+        return v;
+    }
+    bool str(size_t n, std::string& out) {
+        if (!need(n)) return false;
+        out.assign(reinterpret_cast<const char*>(p), n);
+        p += n;
+        return true;
+    }
+    bool arr(size_t n, JSON& v, int depth) {
+        v.kind = JSON::ARR;
+        if (n > (size_t)(end - p)) return fail("array longer than the buffer");
+        v.arr.resize(n);
+        for (size_t i = 0; i < n; i++)
+            if (!value(v.arr[i], depth + 1)) return false;
+        return true;
+    }
+    bool map(size_t n, JSON& v, int depth) {
+        v.kind = JSON::OBJ;
+        if (n > (size_t)(end - p)) return fail("map longer than the buffer");
+        v.obj.resize(n);
+        for (size_t i = 0; i < n; i++) {
+            JSON k;
+            if (!value(k, depth + 1)) return false;
+            if (k.kind != JSON::STR) return fail("map key is not a string");
+            v.obj[i].first = std::move(k.str);
+            if (!value(v.obj[i].second, depth + 1)) return false;
+        }
+        return true;
+    }
+    bool value(JSON& v, int depth) {
+        if (depth > 64) return fail("nesting too deep");
+        if (!need(1)) return false;
+        const uint8_t t = *p++;
+        auto integer = [&](int64_t x) {
+            v.kind = JSON::NUM, v.is_int = true, v.num = (double)x;
+            return true;
+        };
+        if (t <= 0x7f) return integer(t);
+        if (t >= 0xe0) return integer((int8_t)t);
+        if ((t & 0xf0) == 0x80) return map(t & 15, v, depth);
+        if ((t & 0xf0) == 0x90) return arr(t & 15, v, depth);
+        if ((t & 0xe0) == 0xa0) {
+            v.kind = JSON::STR;
+            return str(t & 31, v.str);
+        }
+        switch (t) {
+            case 0xc0: v.kind = JSON::NUL; return true;
+            case 0xc2: v.kind = JSON::BOOL, v.b = false; return true;
+            case 0xc3: v.kind = JSON::BOOL, v.b = true; return true;
+            case 0xc4: case 0xc5: case 0xc6: case 0xd9: case 0xda: case 0xdb: { /* bin 8/16/32 (kept as a string) and str 8/16/32 */
+                const int lb = (t == 0xc4 || t == 0xd9) ? 1 : (t == 0xc5 || t == 0xda) ? 2 : 4;
+                if (!need(lb)) return false;
+                v.kind = JSON::STR;
+                return str((size_t)rd(lb), v.str);
+            }
+            case 0xca: {
+                if (!need(4)) return false;
+                const uint32_t u = (uint32_t)rd(4);
+                float f;
+                memcpy(&f, &u, 4);
+                v.kind = JSON::NUM, v.num = f;
+                return true;
+            }
+            case 0xcb: {
+                if (!need(8)) return false;
+                const uint64_t u = rd(8);
+                memcpy(&v.num, &u, 8);
+                v.kind = JSON::NUM;
+                return true;
+            }
+            case 0xcc: return need(1) && integer((int64_t)rd(1));
+            case 0xcd: return need(2) && integer((int64_t)rd(2));
+            case 0xce: return need(4) && integer((int64_t)rd(4));
+            case 0xcf: return need(8) && integer((int64_t)rd(8));
+            case 0xd0: return need(1) && integer((int8_t)rd(1));
+            case 0xd1: return need(2) && integer((int16_t)rd(2));
+            case 0xd2: return need(4) && integer((int32_t)rd(4));
+            case 0xd3: return need(8) && integer((int64_t)rd(8));
+            case 0xdc: return need(2) && arr((size_t)rd(2), v, depth);
+            case 0xdd: return need(4) && arr((size_t)rd(4), v, depth);
+            case 0xde: return need(2) && map((size_t)rd(2), v, depth);
+            case 0xdf: return need(4) && map((size_t)rd(4), v, depth);
+        }
+        return fail("unsupported type byte");
+    }
+};
+}  // namespace
+
+std::string JSON::Dump() const {
+    std::string out;
+    dump_value(*this, out);
+    return out;
+}
+void JSON::ToMsgpack(std::vector<uint8_t>& out) const { mp_value(*this, out); }
+bool JSON::FromMsgpack(const uint8_t* p, size_t n, JSON& out, std::string& err) {
+    MpReader r{p, p + n, p, {}};
+    out = JSON();
+    if (!r.value(out, 0)) {
+        err = r.err;
+        return false;
+    }
+    if (r.p != r.end) {
+        r.fail("trailing bytes");
+        err = r.err;
+        return false;
+    }
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------ safetensors
@@ -260,8 +558,10 @@ int K_SafeTensors::OpenFile(const std::string& path) {
             count *= (size_t)d.num;
         }
         t.begin = (size_t)off->arr[0].num, t.end = (size_t)off->arr[1].num;
-        const size_t eb = dtype_bytes(t.dtype);
-        if (t.begin > t.end || t.end > avail || (eb && t.end - t.begin != count * eb)) {
+        t.szData = (size_t)kv.second.number_or("szData", 0), t.szGama = (size_t)kv.second.number_or("szGama", 0);
+        const bool kun = t.szData + t.szGama > 0; /* GTensor::jDesc (Serialize.cpp:92-99): the entry spans data||gama, whatever dtype says */
+        const size_t eb = kun ? 0 : dtype_bytes(t.dtype);
+        if (t.begin > t.end || t.end > avail || (eb && t.end - t.begin != count * eb) || (kun && t.end - t.begin != t.szData + t.szGama)) {
             munmap(f.map, f.size), close(f.fd);
             err = path + ": data_offsets of '" + kv.first + "' do not fit its shape or the file";
             return KF_INVALID_ARGS;
@@ -327,6 +627,116 @@ const ST_Tensor* K_SafeTensors::Find(const std::string& name) const {
 const void* K_SafeTensors::Data(const ST_Tensor& t) const {
     const File& f = files[t.file];
     return reinterpret_cast<const unsigned char*>(f.map) + f.data_base + t.begin;
+}
+
+bool K_SafeTensors::Config(JSON& out, std::string& e) const {
+    const ST_Tensor* t = Find(config_key());
+    if (!t) {
+        e = "no " + std::string(config_key()) + " tensor";
+        return false;
+    }
+    return JSON::FromMsgpack(reinterpret_cast<const uint8_t*>(Data(*t)), t->end - t->begin, out, e);
+}
+
+// ------------------------------------------------------------------------------------------------ .kun writer
+// typNUMBER <-> K_FLOATS name (src/g_float.hpp:127-151); tpNumOf upper-cases and also accepts the aliases (GST_float.cpp:22-43)
+static const struct {
+    typNUMBER t;
+    const char *name, *alias;
+} kFloats[] = {{typNUMBER::F32, "FLOAT", "F32"},   {typNUMBER::F16, "F16(E5)", "F16"}, {typNUMBER::U8, "U8", nullptr},       {typNUMBER::I8, "I8", nullptr},
+               {typNUMBER::U16, "U16", nullptr},   {typNUMBER::I16, "I16", nullptr},   {typNUMBER::U32, "U32", nullptr},     {typNUMBER::I32, "I32", nullptr},
+               {typNUMBER::U64, "U64", nullptr},   {typNUMBER::I64, "I64", nullptr},   {typNUMBER::F64, "F64", nullptr},     {typNUMBER::BF16, "BF16(E8)", "BF16"},
+               {typNUMBER::F8E5M2, "F8E5M2", nullptr}, {typNUMBER::F8E4M3, "F8E4M3", nullptr}, {typNUMBER::Q4, "Q<4>", nullptr}, {typNUMBER::Q3, "Q<3>", nullptr},
+               {typNUMBER::Q2, "Q<2>", nullptr},   {typNUMBER::T_SIGN, "TERNARY", nullptr}, {typNUMBER::BOOL1, "BOOL<1>", nullptr}, {typNUMBER::T_BINARY, "BINARY", nullptr}};
+const char* K_FLOATS_name(int typ) {
+    for (const auto& k : kFloats)
+        if ((int)k.t == typ) return k.name;
+    return nullptr;
+}
+int K_FLOATS_type(const std::string& name) {
+    std::string u = name;
+    for (auto& c : u) c = (char)toupper((unsigned char)c);
+    for (const auto& k : kFloats)
+        if (u == k.name || (k.alias && u == k.alias)) return (int)k.t;
+    return -1;
+}
+
+size_t KunWriter::Register(const std::string& name, const std::string& dtype, const std::vector<int64_t>& shape, size_t szData, size_t szGama) {
+    Entry e;
+    e.name = name, e.dtype = dtype, e.shape = shape, e.szData = szData, e.szGama = szGama, e.begin = offset;
+    offset += szData + szGama;  // nByte_CKP (Serialize.cpp:226-250): nByte() + szGama for a checkpoint that is not a training state
+    entries.push_back(std::move(e));
+    return offset;
+}
+
+static JSON kun_desc(const std::string& dtype, const std::vector<int64_t>& shape, size_t b, size_t e, size_t szGama, size_t szData) {  // GTensor::jDesc
+    JSON d = JSON::Object();
+    d["dtype"] = JSON::Str(dtype);
+    JSON sh = JSON::Array();
+    for (int64_t x : shape) sh.arr.push_back(JSON::Int(x));
+    d["shape"] = sh;
+    JSON off = JSON::Array();
+    off.arr.push_back(JSON::Int((int64_t)b)), off.arr.push_back(JSON::Int((int64_t)e));
+    d["data_offsets"] = off;
+    d["loAB"] = JSON::Int(0);
+    d["szGama"] = JSON::Int((int64_t)szGama);
+    d["szData"] = JSON::Int((int64_t)szData);
+    return d;
+}
+
+static bool write_all(int fd, const void* p, size_t n) {
+    const char* c = reinterpret_cast<const char*>(p);
+    while (n) {
+        const ssize_t w = write(fd, c, n);
+        if (w <= 0) return false;
+        c += w, n -= (size_t)w;
+    }
+    return true;
+}
+
+int KunWriter::Save(const std::string& path, JSON jsConfig, const std::function<int(size_t, void*, size_t)>& fetch, std::string& err) {
+    JSON& jt = jsConfig["tensors"];
+    if (jt.kind == JSON::NUL) jt = JSON::Object();
+    for (const auto& e : entries) jt[e.name] = JSON::Int((int64_t)e.begin);
+    std::vector<uint8_t> pack;
+    jsConfig.ToMsgpack(pack);  // insertJS: the config rides as the last tensor, dtype U8, shape [bytes]
+    JSON hdr = JSON::Object();
+    JSON meta = JSON::Object();
+    meta["format"] = JSON::Str("pt"), meta["writer"] = JSON::Str("koifish");  // K_SafeTensors::UpdateMetaData (Serialize.cpp:842-847)
+    hdr["__metadata__"] = meta;
+    for (const auto& e : entries) hdr[e.name] = kun_desc(e.dtype, e.shape, e.begin, e.begin + e.szData + e.szGama, e.szGama, e.szData);
+    hdr[K_SafeTensors::config_key()] = kun_desc("U8", {(int64_t)pack.size()}, offset, offset + pack.size(), 0, 0);
+    const std::string text = hdr.Dump();
+    const std::string tmp = path + ".tmp";
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
+    if (fd < 0) {
+        err = "cannot create " + tmp;
+        return KF_INVALID_ARGS;
+    }
+    auto bail = [&](int rc, const std::string& what) {
+        close(fd), unlink(tmp.c_str());
+        err = what;
+        return rc;
+    };
+    const uint64_t hlen = text.size();  // little-endian u64 (this host is), no padding (_to_ofs: `if (0)` around the 8-byte pad)
+    if (!write_all(fd, &hlen, 8) || !write_all(fd, text.data(), text.size())) return bail(KF_INTERNAL_ERR, "write failed: " + tmp);
+    std::vector<uint8_t> buf;
+    for (size_t i = 0; i < entries.size(); i++) {
+        const size_t n = entries[i].szData + entries[i].szGama;
+        buf.resize(n);
+        const int rc = fetch(i, buf.data(), n);
+        if (rc != KF_OK) return bail(rc, "reading tensor '" + entries[i].name + "' failed");
+        if (!write_all(fd, buf.data(), n)) return bail(KF_INTERNAL_ERR, "write failed: " + tmp);
+    }
+    if (!write_all(fd, pack.data(), pack.size())) return bail(KF_INTERNAL_ERR, "write failed: " + tmp);
+    if (fsync(fd) != 0) return bail(KF_INTERNAL_ERR, "fsync failed: " + tmp);
+    close(fd);
+    if (rename(tmp.c_str(), path.c_str()) != 0) {
+        unlink(tmp.c_str());
+        err = "rename to " + path + " failed";
+        return KF_INTERNAL_ERR;
+    }
+    return KF_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ HF checkpoint -> Fish
@@ -581,6 +991,242 @@ Fish* LoadHF(const std::string& dir, int device, void* stream, typNUMBER layer_t
     return f.release();
 }
 
+// ------------------------------------------------------------------------------------------------ Fish <-> .kun
+namespace {
+struct KunSlot {
+    std::string name;
+    hGTensor t;
+};
+// the parameters of the decode path under their Hugging Face names, in the order the neurons are built (embed, layers, final norm, head)
+std::vector<KunSlot> kun_params(Fish* f) {
+    std::vector<KunSlot> v;
+    v.push_back({"model.embed_tokens.weight", f->embed.w});
+    for (int l = 0; l < f->config.nLayer; l++) {
+        const std::string p = "model.layers." + std::to_string(l) + ".";
+        SelfAttention* a = f->attn[l].get();
+        FFN* m = f->ffn[l].get();
+        v.push_back({p + "input_layernorm.weight", a->norm.w});
+        v.push_back({p + "self_attn.q_proj.weight", a->Q.w});
+        v.push_back({p + "self_attn.k_proj.weight", a->K.w});
+        v.push_back({p + "self_attn.v_proj.weight", a->V.w});
+        if (a->normQ.w) v.push_back({p + "self_attn.q_norm.weight", a->normQ.w});
+        if (a->normK.w) v.push_back({p + "self_attn.k_norm.weight", a->normK.w});
+        v.push_back({p + "self_attn.o_proj.weight", a->proj_cat.w});
+        v.push_back({p + "post_attention_layernorm.weight", m->norm.w});
+        v.push_back({p + "mlp.gate_proj.weight", m->gate.w});
+        v.push_back({p + "mlp.up_proj.weight", m->up.w});
+        v.push_back({p + "mlp.down_proj.weight", m->down.w});
+    }
+    v.push_back({"model.norm.weight", f->final_norm.w});
+    if (f->head.proj.w && f->head.proj.w != f->embed.w) v.push_back({"lm_head.weight", f->head.proj.w});  // a tied head "isRefer" and is skipped (Serialize.cpp:936)
+    return v;
+}
+// "quantizer" section for one family of tensors (QUANT_CARD::Init, GeQuant.cpp:1231-1282: quant_method "RTN" -> RTN, "yyang" -> the ternary /
+// binary forms, anything else -> RTNf for 4 bits and F8Ex for 8)
+JSON quant_section(const GTensor& t) {
+    JSON q = JSON::Object();
+    const bool lowbit = t.type == typNUMBER::T_SIGN || t.type == typNUMBER::T_BINARY || t.type == typNUMBER::BOOL1;
+    q["quant_method"] = JSON::Str(t.quant.isNormalFloat ? "NF" : lowbit ? "yyang" : t.type == typNUMBER::F8E5M2 ? "F8Ex" : "RTN");
+    QuantCard qc;
+    quant_range(t.type, false, qc);
+    q["bits"] = JSON::Int(qc.bits);
+    if (!t.quant.isNormalFloat && t.szGama) q["group_size"] = JSON::Int(t.quant.T_group);
+    if (t.type == typNUMBER::Q4 && t.quant.qBias != 0) q["symmetric"] = JSON::Bool(true);  // ours: QUANT_CARD::isSymmetric is not a JSON key of the reference
+    return q;
+}
+bool is_quant_type(typNUMBER t) { return t == typNUMBER::Q4 || t == typNUMBER::Q3 || t == typNUMBER::Q2 || t == typNUMBER::T_SIGN || t == typNUMBER::T_BINARY || t == typNUMBER::BOOL1; }
+}  // namespace
+
+// Fish -> `.kun` (the save branch of Fish::SAFETENSOR_Serialize, Serialize.cpp:911-963).  The config tensor carries what the reference's
+// does -- {"vendor", "CLI_params": {"config": {...}}, "tokenizer", "tensors"} -- with the model card under the keys CLI_params reads back
+// (CLI_params.cpp:368-432, cases/qwen3/qwen3_596M_q4.json) and two keys of ours under "parameter" (rope_theta, rms_norm_eps) that the
+// reference takes from the Hugging Face card instead.
+int SaveKun(Fish* f, const std::string& path, std::string& err) {
+    const MODEL_CARD& c = f->config;
+    std::vector<KunSlot> params = kun_params(f);
+    KunWriter w;
+    for (const auto& s : params) {
+        if (!s.t || !s.t->data) {
+            err = "tensor '" + s.name + "' is empty";  // "[ST_SERIALIZE] \"%s\" is empty!" (Serialize.cpp:634)
+            return KF_INVALID_ARGS;
+        }
+        if (s.t->qZero || s.t->qScale) {
+            err = "tensor '" + s.name + "': vendor AutoAWQ tensors (explicit zeros / scales) are not written to .kun";
+            return KF_UNSUPPORTED_DATATYPE;
+        }
+        const char* dn = K_FLOATS_name((int)s.t->type);
+        if (!dn) {
+            err = "tensor '" + s.name + "': type has no K_FLOATS name";
+            return KF_UNSUPPORTED_DATATYPE;
+        }
+        std::vector<int64_t> shape = {s.t->ne[0]};
+        if (s.t->ne[1] > 1) shape.push_back(s.t->ne[1]);
+        w.Register(s.name, dn, shape, s.t->szData, s.t->szGama);
+    }
+    JSON js = JSON::Object();
+    js["vendor"] = JSON::Str("gruai");
+    JSON& cfg = js["CLI_params"]["config"];
+    cfg["version"] = JSON::Str("0.1.0");
+    JSON& jq = cfg["quantizer"];
+    jq = JSON::Object();
+    const GTensor &tl = *f->attn[0]->Q.w, &tm = *f->ffn[0]->gate.w, &te = *f->embed.w;
+    if (is_quant_type(tl.type) || tl.type == typNUMBER::F8E5M2) {
+        if (tl.szGama && !tl.quant.isNormalFloat) jq["group_size"] = JSON::Int(tl.quant.T_group);
+        jq["self_attn"] = quant_section(tl);
+    }
+    if (is_quant_type(tm.type) || tm.type == typNUMBER::F8E5M2) jq["mlp"] = quant_section(tm);
+    if (is_quant_type(te.type) || te.type == typNUMBER::F8E5M2) jq["embed_tokens"] = quant_section(te);
+    if (f->head.proj.w && f->head.proj.w != f->embed.w && (is_quant_type(f->head.proj.w->type) || f->head.proj.w->type == typNUMBER::F8E5M2))
+        jq["lm_head"] = quant_section(*f->head.proj.w);
+    JSON& jm = cfg["model"];
+    jm["arch"] = JSON::Str("QWEN3");
+    jm["vocab_size"] = JSON::Int(c.vocab);
+    JSON& jp = jm["parameter"];
+    jp["Layer"] = JSON::Int(c.nLayer);
+    JSON& jt = jp["transformer"];
+    jt["Ctx"] = JSON::Int(c.n_ctx), jt["Embed"] = JSON::Int(c.nEmbed), jt["Ffn"] = JSON::Int(c.n_ff);
+    jt["Head"] = JSON::Int(c.n_head), jt["KVHead"] = JSON::Int(c.n_head_kv), jt["head_dim"] = JSON::Int(c.head_dim);
+    jp["tie_word_embeddings"] = JSON::Bool(f->head.proj.w == f->embed.w);
+    jp["max_pos_embeddings"] = JSON::Int(c.n_ctx);
+    jp["rope_theta"] = JSON::Real(c.rope_theta);
+    jp["rms_norm_eps"] = JSON::Real(c.rms_eps);
+    js["tokenizer"]["tokens"] = JSON::Str("");
+    kf_ctx* ctx = f->ctx;
+    KF_TRY(kf_sync(ctx));
+    return w.Save(path, js, [&](size_t i, void* dst, size_t n) { return kf_d2h(ctx, dst, params[i].t->data, n); }, err);  // SerialGamaData(toHost): data||gama in one copy
+}
+
+// `.kun` -> Fish (SAFETENSOR2Gensors + SerialGamaData H2D, Serialize.cpp:965, huTensor.cu:413-458): the blobs go to the device as they are,
+// nothing is re-quantised.
+Fish* LoadKun(const std::string& path, int device, void* stream, int max_seq, int* rc_out, std::string& err) {
+    auto bail = [&](int rc, const std::string& what) -> Fish* {
+        if (rc_out) *rc_out = rc;
+        err = what;
+        return nullptr;
+    };
+    K_SafeTensors st;
+    int rc = st.OpenFile(path);
+    if (rc != KF_OK) return bail(rc, st.err);
+    JSON js;
+    std::string jerr;
+    if (!st.Config(js, jerr)) return bail(KF_INVALID_ARGS, path + ": " + jerr);
+    const JSON* vendor = js.get("vendor");
+    if (!vendor || vendor->kind != JSON::STR || vendor->str != "gruai") return bail(KF_INVALID_ARGS, path + ": config lacks \"vendor\": \"gruai\"");
+    const JSON* cfg = js.path({"CLI_params", "config"});  // SAFETENSOR_Load_jconfig (Serialize.cpp:496-534)
+    const JSON* jp = cfg ? cfg->path({"model", "parameter"}) : nullptr;
+    const JSON* jt = jp ? jp->get("transformer") : nullptr;
+    if (!jt) return bail(KF_INVALID_ARGS, path + ": config lacks CLI_params.config.model.parameter.transformer");
+    MODEL_CARD card;
+    card.nLayer = (int)jp->number_or("Layer", 1);
+    card.nEmbed = (int)jt->number_or("Embed", 0), card.n_ff = (int)jt->number_or("Ffn", card.nEmbed * 4);
+    card.n_head = (int)jt->number_or("Head", 0), card.n_head_kv = (int)jt->number_or("KVHead", card.n_head);
+    card.head_dim = (int)jt->number_or("head_dim", card.n_head ? card.nEmbed / card.n_head : 0);
+    const int ctx_len = (int)jt->number_or("Ctx", 0);
+    card.tie_word_embeddings = jp->bool_or("tie_word_embeddings", true);
+    card.rope_theta = (float)jp->number_or("rope_theta", 1e6);
+    card.rms_eps = card.qk_eps = (float)jp->number_or("rms_norm_eps", 1e-6);
+    const ST_Tensor* emb_t = st.Find("model.embed_tokens.weight");
+    if (!emb_t || emb_t->shape.size() != 2) return bail(KF_INVALID_ARGS, path + ": model.embed_tokens.weight missing");
+    card.vocab = (int)cfg->path({"model"})->number_or("vocab_size", (double)emb_t->shape[0]);
+    card.n_ctx = max_seq > 0 ? max_seq : ctx_len;
+    if (card.nEmbed <= 0 || card.nLayer <= 0 || card.n_head <= 0 || card.n_head_kv <= 0 || card.head_dim <= 0 || card.n_ff <= 0 || card.vocab <= 0 || card.n_ctx <= 0)
+        return bail(KF_INVALID_ARGS, path + ": incomplete model card");
+    const JSON* jq = cfg->get("quantizer");
+    const int group_dflt = jq ? (int)jq->number_or("group_size", 128) : 128;
+
+    std::unique_ptr<Fish> f(new Fish());
+    rc = f->Build(card, device, stream);
+    if (rc != KF_OK) return bail(rc, "Fish::Build failed");
+    // one tensor: type from its K_FLOATS dtype, quant card from the quantizer section whose key its name contains (G_Has_, GeQuant.cpp:1231)
+    auto load = [&](const std::string& name, int ne0, int ne1, bool required, hGTensor* out) -> int {
+        const ST_Tensor* s = st.Find(name);
+        if (!s) {
+            if (!required) return KF_OK;
+            err = "tensor '" + name + "' not in " + path;
+            return KF_INVALID_ARGS;
+        }
+        const int tp = K_FLOATS_type(s->dtype);
+        const bool shape_ok = (s->shape.size() == 2 && s->shape[0] == ne0 && s->shape[1] == ne1) || (s->shape.size() == 1 && ne1 == 1 && s->shape[0] == ne0);
+        if (tp < 0 || !shape_ok) {
+            err = "tensor '" + name + "': unexpected dtype '" + s->dtype + "' or shape";
+            return KF_INVALID_ARGS;
+        }
+        auto t = std::make_shared<GTensor>();
+        t->name = name, t->type = (typNUMBER)tp, t->ne[0] = ne0, t->ne[1] = ne1;
+        t->szData = s->szData, t->szGama = s->szGama;
+        if (t->szData + t->szGama == 0) t->szData = s->end - s->begin;
+        const JSON* sec = nullptr;
+        if (jq)
+            for (const auto& kv : jq->obj)
+                if (kv.second.kind == JSON::OBJ && !kv.first.empty() && kv.first[0] != '#' && name.find(kv.first) != std::string::npos) sec = &kv.second;
+        quant_range(t->type, sec && sec->bool_or("symmetric", false), t->quant);
+        t->quant.T_group = sec ? (int)sec->number_or("group_size", group_dflt) : group_dflt;
+        if (sec && t->type == typNUMBER::Q4) {
+            const JSON* m = sec->get("quant_method");
+            const std::string ms = m && m->kind == JSON::STR ? m->str : "";
+            t->quant.isNormalFloat = ms.find("RTN") == std::string::npos && ms.find("AWQ") == std::string::npos && ms.find("yyang") == std::string::npos &&
+                                     ms.find("bitnet") == std::string::npos;  // GeQuant.cpp:1271-1279
+        }
+        const size_t n = (size_t)ne0 * ne1;
+        size_t want_data = n * 2, want_gama = 0;
+        if (is_quant_type(t->type)) {
+            want_data = n * t->quant.bits / 8;
+            if (t->quant.isNormalFloat) {
+                t->quant.T_group = 0;
+                want_gama = ((size_t)ne0 + ne1 + 16 * (size_t)ne0) * 2;
+            } else {
+                if (t->quant.T_group <= 0 || n % (size_t)t->quant.T_group) {
+                    err = "tensor '" + name + "': group size " + std::to_string(t->quant.T_group);
+                    return KF_QUANT_ERR;
+                }
+                want_gama = ((size_t)ne0 + ne1 + 2 * (n / t->quant.T_group)) * 2;
+            }
+        } else if (t->type == typNUMBER::F8E5M2) {
+            want_data = n;
+        } else if (t->type != typNUMBER::BF16) {
+            err = "tensor '" + name + "': dtype '" + s->dtype + "' is not served by the decode path";
+            return KF_UNSUPPORTED_DATATYPE;
+        }
+        if (t->szData != want_data || t->szGama != want_gama) {
+            err = "tensor '" + name + "': szData/szGama " + std::to_string(t->szData) + "/" + std::to_string(t->szGama) + " do not fit its type, shape and quant card (" +
+                  std::to_string(want_data) + "/" + std::to_string(want_gama) + ")";
+            return KF_INVALID_ARGS;
+        }
+        KF_TRY(t->LoadBlob(f->ctx, st.Data(*s), t->szData + t->szGama));
+        *out = t;
+        return KF_OK;
+    };
+    auto linear = [&](const std::string& name, int n_out, int n_in, SLP* slot) -> int {
+        hGTensor t;
+        KF_TRY(load(name, n_out, n_in, true, &t));
+        slot->w = t, slot->nOut = n_out, slot->nIn = n_in;
+        return f->EnsureLinearScratch(t->desc(), f->prefill_chunk);
+    };
+    const int C = card.nEmbed, qd = card.n_head * card.head_dim, kvd = card.n_head_kv * card.head_dim;
+    auto ok = [&](int r) { return (rc = r) == KF_OK; };
+    if (!ok(load("model.embed_tokens.weight", card.vocab, C, true, &f->embed.w))) return bail(rc, err);
+    if (st.Find("lm_head.weight")) {
+        if (!ok(linear("lm_head.weight", card.vocab, C, &f->head.proj))) return bail(rc, err);
+    } else {
+        f->head.proj.w = f->embed.w, f->head.proj.nOut = card.vocab, f->head.proj.nIn = C;
+    }
+    if (!ok(load("model.norm.weight", C, 1, true, &f->final_norm.w))) return bail(rc, err);
+    for (int l = 0; l < card.nLayer; l++) {
+        const std::string p = "model.layers." + std::to_string(l) + ".";
+        SelfAttention* a = f->attn[l].get();
+        FFN* m = f->ffn[l].get();
+        if (!ok(load(p + "input_layernorm.weight", C, 1, true, &a->norm.w)) || !ok(load(p + "post_attention_layernorm.weight", C, 1, true, &m->norm.w)) ||
+            !ok(load(p + "self_attn.q_norm.weight", card.head_dim, 1, false, &a->normQ.w)) || !ok(load(p + "self_attn.k_norm.weight", card.head_dim, 1, false, &a->normK.w)) ||
+            !ok(linear(p + "self_attn.q_proj.weight", qd, C, &a->Q)) || !ok(linear(p + "self_attn.k_proj.weight", kvd, C, &a->K)) ||
+            !ok(linear(p + "self_attn.v_proj.weight", kvd, C, &a->V)) || !ok(linear(p + "self_attn.o_proj.weight", C, qd, &a->proj_cat)) ||
+            !ok(linear(p + "mlp.gate_proj.weight", card.n_ff, C, &m->gate)) || !ok(linear(p + "mlp.up_proj.weight", card.n_ff, C, &m->up)) ||
+            !ok(linear(p + "mlp.down_proj.weight", C, card.n_ff, &m->down)))
+            return bail(rc, err);
+    }
+    if (rc_out) *rc_out = KF_OK;
+    return f.release();
+}
+
 }  // namespace koifish
 
 // ================================================================================================ C entry points (ctypes)
@@ -633,6 +1279,83 @@ void* kfh_load_hf(const char* dir, int device, void* stream, int layer_type, int
                      lnf, hnf);
     if (!f) g_st_err = err;
     return f;
+}
+// ---- `.kun` (the reference's own checkpoint container)
+// Fish -> file; 0 or a negative code with kfh_last_error() set
+int kfh_save_kun(void* h, const char* path) {
+    std::string err;
+    const int rc = SaveKun(reinterpret_cast<Fish*>(h), path, err);
+    if (rc != KF_OK) g_st_err = err;
+    return rc;
+}
+void* kfh_load_kun(const char* path, int device, void* stream, int max_seq, int* rc) {
+    std::string err;
+    Fish* f = LoadKun(path, device, stream, max_seq, rc, err);
+    if (!f) g_st_err = err;
+    return f;
+}
+// host-only writer (tests, tools): n entries with K_FLOATS dtype names, shapes as 4 int64 per entry (0 = unused), host `data||gama` blobs, and
+// the config as JSON text (packed to msgpack inside)
+int kfh_kun_write(const char* path, int n, const char* const* names, const char* const* dtypes, const int64_t* shape4, const uint64_t* szData, const uint64_t* szGama,
+                  const void* const* blobs, const char* config_json) {
+    JSON js;
+    std::string err;
+    if (!JSON::Parse(config_json, strlen(config_json), js, err) || js.kind != JSON::OBJ) {
+        g_st_err = "config: " + err;
+        return KF_INVALID_ARGS;
+    }
+    KunWriter w;
+    for (int i = 0; i < n; i++) {
+        std::vector<int64_t> shape;
+        for (int d = 0; d < 4 && shape4[4 * i + d] > 0; d++) shape.push_back(shape4[4 * i + d]);
+        w.Register(names[i], dtypes[i], shape, szData[i], szGama[i]);
+    }
+    const int rc = w.Save(path, js, [&](size_t i, void* dst, size_t nb) { memcpy(dst, blobs[i], nb); return (int)KF_OK; }, err);
+    if (rc != KF_OK) g_st_err = err;
+    return rc;
+}
+// the config tensor of an opened `.kun` as JSON text; returns the length needed (copy truncated to cap - 1), or a negative code
+int64_t kfh_st_config_json(void* h, char* out, int64_t cap) {
+    JSON js;
+    std::string err;
+    if (!reinterpret_cast<K_SafeTensors*>(h)->Config(js, err)) {
+        g_st_err = err;
+        return KF_INVALID_ARGS;
+    }
+    const std::string text = js.Dump();
+    if (out && cap > 0) snprintf(out, (size_t)cap, "%s", text.c_str());
+    return (int64_t)text.size() + 1;
+}
+// szData / szGama of entry i (0 / 0 for Hugging Face files)
+int kfh_st_blob_sizes(void* h, int i, uint64_t* szData, uint64_t* szGama) {
+    auto* st = reinterpret_cast<K_SafeTensors*>(h);
+    if (i < 0 || i >= (int)st->tensors.size()) return KF_INVALID_ARGS;
+    *szData = st->tensors[i].szData, *szGama = st->tensors[i].szGama;
+    return KF_OK;
+}
+// JSON text <-> msgpack round trips for the tests (python's msgpack is the independent checker)
+int64_t kfh_json_to_msgpack(const char* text, uint8_t* out, int64_t cap) {
+    JSON js;
+    std::string err;
+    if (!JSON::Parse(text, strlen(text), js, err)) {
+        g_st_err = err;
+        return KF_INVALID_ARGS;
+    }
+    std::vector<uint8_t> pack;
+    js.ToMsgpack(pack);
+    if (out && cap >= (int64_t)pack.size()) memcpy(out, pack.data(), pack.size());
+    return (int64_t)pack.size();
+}
+int64_t kfh_msgpack_to_json(const uint8_t* pack, int64_t n, char* out, int64_t cap) {
+    JSON js;
+    std::string err;
+    if (!JSON::FromMsgpack(pack, (size_t)n, js, err)) {
+        g_st_err = err;
+        return KF_INVALID_ARGS;
+    }
+    const std::string text = js.Dump();
+    if (out && cap > 0) snprintf(out, (size_t)cap, "%s", text.c_str());
+    return (int64_t)text.size() + 1;
 }
 // {dim, n_layer, n_head, n_kv, head_dim, ffn, vocab, n_ctx, tied, fuse_level} and {rms_eps, rope_theta}
 int kfh_get_config(void* h, int* out10, float* out2) {

@@ -123,6 +123,18 @@ def load():
         host.kfh_load_hf.restype = C.c_void_p
         host.kfh_load_hf.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
         host.kfh_get_config.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        host.kfh_save_kun.argtypes = [C.c_void_p, C.c_char_p]
+        host.kfh_load_kun.restype = C.c_void_p
+        host.kfh_load_kun.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        host.kfh_kun_write.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
+                                       C.c_char_p]
+        host.kfh_st_config_json.restype = C.c_int64
+        host.kfh_st_config_json.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        host.kfh_st_blob_sizes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        host.kfh_json_to_msgpack.restype = C.c_int64
+        host.kfh_json_to_msgpack.argtypes = [C.c_char_p, C.c_void_p, C.c_int64]
+        host.kfh_msgpack_to_json.restype = C.c_int64
+        host.kfh_msgpack_to_json.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.c_int64]
         host.kfh_set_sampler.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_uint64]
         host.kfh_prefill.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         host.kfh_set_prefill_mode.argtypes = [C.c_void_p, C.c_int, C.c_int]

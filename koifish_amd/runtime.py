@@ -346,6 +346,28 @@ class Qwen3:
         if not self.h:
             raise L.KFError("kfh_load_hf(%s) failed with %d: %s" % (path, rc.value, self.host.kfh_last_error().decode()))
         self.h = C.c_void_p(self.h)
+        self._read_config()
+        return self
+
+    @classmethod
+    def from_kun(cls, path, device=0, max_seq=0):
+        """A `.kun` checkpoint (the reference's container: safetensors header, `data||gama` blobs, msgpack config tensor; Serialize.cpp:849-976)
+        -> a ready model.  The blobs go to HBM as stored: nothing is re-quantised."""
+        self = cls.__new__(cls)
+        self.hip, self.host = L.load()
+        if not torch.cuda.is_available():
+            raise L.KFError("no GPU visible: koifish_amd runs on MI355X only (no CPU fallback)")
+        torch.cuda.set_device(device)
+        rc = C.c_int(0)
+        self.device = torch.device("cuda", device)
+        self.h = self.host.kfh_load_kun(str(path).encode(), device, C.c_void_p(stream(device).cuda_stream), int(max_seq), C.byref(rc))
+        if not self.h:
+            raise L.KFError("kfh_load_kun(%s) failed with %d: %s" % (path, rc.value, self.host.kfh_last_error().decode()))
+        self.h = C.c_void_p(self.h)
+        self._read_config()
+        return self
+
+    def _read_config(self):
         iv = (C.c_int * 10)()
         fv = (C.c_float * 2)()
         L.check(self.host.kfh_get_config(self.h, iv, fv), "kfh_get_config")
@@ -354,7 +376,12 @@ class Qwen3:
         self.fuse_level = iv[9]
         self._keep, self.weights, self._norms = [], {}, {}
         self._ctx = None
-        return self
+
+    def save_kun(self, path):
+        """Write every parameter of the model as its `data||gama` blob plus the config tensor (Fish::SAFETENSOR_Serialize, save branch)."""
+        rc = self.host.kfh_save_kun(self.h, str(path).encode())
+        if rc != 0:
+            raise L.KFError("kfh_save_kun(%s) failed with %d: %s" % (path, rc, self.host.kfh_last_error().decode()))
 
     def close(self):
         if getattr(self, "h", None):
