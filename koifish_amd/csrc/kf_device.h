@@ -197,36 +197,41 @@ __device__ __forceinline__ void build_perm_lut(PermLut& t, float step, float zer
         t.th[k] = __builtin_amdgcn_perm(P[2 * k + 1], P[2 * k], 0x07050301u);
     }
 }
-// s: four indices 0..15, one per byte -> the four entries as a low-byte word and a high-byte word (same byte positions)
+// s: four indices 0..15, one per byte (the high nibble of every byte may hold anything) -> the four entries as a low-byte word and a
+// high-byte word (same byte positions).  Two 8-entry v_perm_b32 per plane on index bits 0..2, then a third v_perm_b32 picks, byte by byte, the
+// lower or the upper half by index bit 3 (selector byte k = k + 4 * bit3_k, formed by one shift and one v_and_or_b32): 9 instructions per
+// 4 weights.  (The first version built a byte mask from bit 3 and merged with v_bfi_b32; the compiler turned the mask's shift-and-subtract into
+// a quarter-rate v_mul_lo_u32 by 255: 14 issue slots per 4 weights.)
 __device__ __forceinline__ void perm_lookup4(uint32_t s, const PermLut& t, uint32_t& lo, uint32_t& hi) {
     const uint32_t idx = s & 0x07070707u;
-    const uint32_t b3 = (s >> 3) & 0x01010101u;
-    const uint32_t m = (b3 << 8) - b3; /* 0xFF per byte with bit 3 set; a multiply by 0xFF would be a quarter-rate v_mul_lo_u32 */
+    uint32_t sel; /* ((s >> 1) & 0x04040404) | 0x03020100 as ONE v_and_or_b32: VOP3 takes no literals on gfx9, so the compiler would issue and + or */
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(sel) : "v"(s >> 1), "s"(0x04040404u), "v"(0x03020100u));
     const uint32_t la = __builtin_amdgcn_perm(t.tl[1], t.tl[0], idx), lb = __builtin_amdgcn_perm(t.tl[3], t.tl[2], idx);
     const uint32_t ha = __builtin_amdgcn_perm(t.th[1], t.th[0], idx), hb = __builtin_amdgcn_perm(t.th[3], t.th[2], idx);
-    lo = (lb & m) | (la & ~m);
-    hi = (hb & m) | (ha & ~m);
+    lo = __builtin_amdgcn_perm(lb, la, sel);
+    hi = __builtin_amdgcn_perm(hb, ha, sel);
 }
 // X here is staged as {(x0,x2), (x4,x6), (x1,x3), (x5,x7)}
 __device__ __forceinline__ float perm_dot_dword(uint32_t D, u32x4 X, const PermLut& t, float acc) {
     uint32_t lo, hi;
-    perm_lookup4((D >> 4) & 0x0F0F0F0Fu, t, lo, hi); /* bytes 3..0 = elements 0, 2, 4, 6 */
+    perm_lookup4(D >> 4, t, lo, hi); /* bytes 3..0 = elements 0, 2, 4, 6 */
     acc = dot2_bf16(__builtin_amdgcn_perm(hi, lo, 0x06020703u), X.x, acc);
     acc = dot2_bf16(__builtin_amdgcn_perm(hi, lo, 0x04000501u), X.y, acc);
-    perm_lookup4(D & 0x0F0F0F0Fu, t, lo, hi); /* elements 1, 3, 5, 7 */
+    perm_lookup4(D, t, lo, hi); /* elements 1, 3, 5, 7 */
     acc = dot2_bf16(__builtin_amdgcn_perm(hi, lo, 0x06020703u), X.z, acc);
     acc = dot2_bf16(__builtin_amdgcn_perm(hi, lo, 0x04000501u), X.w, acc);
     return acc;
 }
 // The same lookup with the weights paired as the arithmetic form pairs them -- (e0,e1), (e2,e3), (e4,e5), (e6,e7) against X.x .. X.w in natural
-// order -- so that the fp32 sum is formed in exactly the order of dot_q4_dword (kf_gemv.hip): two extra v_perm_b32 per dword gather the index bytes.
+// order -- so that the fp32 sum is formed in exactly the order of dot_q4_dword (kf_gemv.hip): two extra v_perm_b32 per dword gather the index bytes
+// (low nibble of a byte of D >> 4 = an even element, of D = an odd element; the lookup ignores the high nibbles).
 __device__ __forceinline__ float perm_dot_dword_nat(uint32_t D, u32x4 X, const PermLut& t, float acc) {
-    const uint32_t even = (D >> 4) & 0x0F0F0F0Fu, odd = D & 0x0F0F0F0Fu; /* bytes 3..0 = elements 0,2,4,6 / 1,3,5,7 */
+    const uint32_t even = D >> 4; /* bytes 3..0: elements 0,2,4,6 in the low nibbles; D itself: 1,3,5,7 */
     uint32_t lo, hi;
-    perm_lookup4(__builtin_amdgcn_perm(even, odd, 0x02060307u), t, lo, hi); /* bytes 0..3 = elements 0, 1, 2, 3 */
+    perm_lookup4(__builtin_amdgcn_perm(even, D, 0x02060307u), t, lo, hi); /* bytes 0..3 = elements 0, 1, 2, 3 */
     acc = dot2_bf16(__builtin_amdgcn_perm(hi, lo, 0x05010400u), X.x, acc);
     acc = dot2_bf16(__builtin_amdgcn_perm(hi, lo, 0x07030602u), X.y, acc);
-    perm_lookup4(__builtin_amdgcn_perm(even, odd, 0x00040105u), t, lo, hi); /* elements 4, 5, 6, 7 */
+    perm_lookup4(__builtin_amdgcn_perm(even, D, 0x00040105u), t, lo, hi); /* elements 4, 5, 6, 7 */
     acc = dot2_bf16(__builtin_amdgcn_perm(hi, lo, 0x05010400u), X.z, acc);
     acc = dot2_bf16(__builtin_amdgcn_perm(hi, lo, 0x07030602u), X.w, acc);
     return acc;

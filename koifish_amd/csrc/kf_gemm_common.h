@@ -64,7 +64,7 @@ __device__ __forceinline__ u32x4 frag_q4r(uint32_t D, u32x4 ta, u32x4 tb) {
         t.tl[k] = __builtin_amdgcn_perm(P[2 * k + 1], P[2 * k], 0x06040200u);
         t.th[k] = __builtin_amdgcn_perm(P[2 * k + 1], P[2 * k], 0x07050301u);
     }
-    const uint32_t even = (D >> 4) & 0x0F0F0F0Fu, odd = D & 0x0F0F0F0Fu; /* byte b: elements 2b / 2b + 1 */
+    const uint32_t even = D >> 4, odd = D; /* low nibble of byte b: element 2b / 2b + 1 (perm_lookup4 ignores the high nibbles) */
     u32x4 o;
     uint32_t lo, hi;
     perm_lookup4(__builtin_amdgcn_perm(even, odd, 0x01050004u), t, lo, hi); /* bytes 0..3 = elements 0, 1, 2, 3 */

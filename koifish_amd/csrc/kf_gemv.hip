@@ -32,7 +32,7 @@ struct Batch {
 // LDS: x as u32x4 chunks [XCH][nBlk] (K*2 bytes) | 256 B reduction scratch.
 // Each wave keeps two batches of G blocks in flight: the first batch is issued BEFORE the x prologue so that the
 // weight stream's HBM latency overlaps the (dependent) activation load + norm.
-template <int FMT, int G, int MODE>
+template <int FMT, int G, int MODE, bool SPARSE>
 __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     using BD = BlockDot<FMT>;
     constexpr bool PAIRED = (MODE == GEMV_PAIRED), LUT = (FMT == FMT_Q4R);
@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     }
     const int LPR = 1 << a.lpr_log2, RPS = 64 >> a.lpr_log2;
     const int sub = lane >> a.lpr_log2, ll = lane & (LPR - 1);
-    const long gwave = (long)blockIdx.x * (blockDim.x >> 6) + wave_in_blk;
+    const long gwave = (long)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(wave_in_blk); /* wave-uniform: the slot range and step count stay scalar */
     const long s_begin = gwave * a.spw;
     long s_end = s_begin + a.spw;
     if (s_end > a.total_slots) s_end = a.total_slots;
@@ -114,7 +114,8 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
                 }
             }
             if (LAT || ok) {
-                if (a.row_map) row = a.row_map[row]; /* sparse forward: the slot's row is the row-th hot row (one dependent, wave-uniform-per-group load) */
+                if constexpr (SPARSE) row = a.row_map[row]; /* sparse forward: the slot's row is the row-th hot row (one dependent, wave-uniform-per-group load).  A template
+                                                              parameter: as a run-time branch its join carried an s_waitcnt vmcnt(0) that drained the weight stream of every launch */
                 const uint32_t bidx = (uint32_t)row * (uint32_t)nBlk + (uint32_t)col; /* < 2^32 blocks = 64 GiB per tensor */
                 b.w[g] = ld_nt(jw + bidx);
                 if (PAIRED) b.w2[g] = ld_nt(jw2 + bidx);
@@ -135,6 +136,48 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
         }
     };
 
+    // STREAM (long dense launches, G > 1): the same blocks through buffer loads.  The G rows of a batch lie a constant number of bytes apart, so
+    // ONE lane offset serves all of them (the row stride rides in the instruction's scalar offset), rows past the matrix and columns past the row
+    // fall outside the buffer and read as zero (no lane branches, no zero fill), and the zero / step words come the same way.  The launcher
+    // sets stream_ok when every offset fits 31 bits and a group never straddles two rows.
+    constexpr bool STREAM = !LAT && !SPARSE && !LUT;
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rs_w, rs_w2, rs_st, rs_ze, rs_st2, rs_ze2;
+    [[maybe_unused]] uint32_t wbytes = 0, gbytes = 0, gstride_w = 0, gstride_g = 0;
+    if constexpr (STREAM) {
+        wbytes = (uint32_t)jM * (uint32_t)nBlk * 16u, gbytes = ((uint32_t)jM * (uint32_t)nBlk >> gshift) * 2u;
+        gstride_w = (uint32_t)RPS * (uint32_t)nBlk * 16u, gstride_g = ((uint32_t)RPS * (uint32_t)nBlk >> gshift) * 2u;
+        rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(jw), 0, (int)wbytes, 0x00020000);
+        if constexpr (PAIRED) rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(jw2), 0, (int)wbytes, 0x00020000);
+        if constexpr (BD::HAS_GAMA) {
+            rs_st = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(jstep), 0, (int)gbytes, 0x00020000);
+            rs_ze = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(jzero), 0, (int)gbytes, 0x00020000);
+            if constexpr (PAIRED) {
+                rs_st2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.job[1].step), 0, (int)gbytes, 0x00020000);
+                rs_ze2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.job[1].zero), 0, (int)gbytes, 0x00020000);
+            }
+        }
+    }
+    auto sload = [&](int bi, int it, Batch<G, PAIRED, LUT>& b) {
+        if constexpr (STREAM) {
+            const int col = it * LPR + ll;
+            const uint32_t row0 = (uint32_t)((int)(s_begin - jslot0) + bi * G) * (uint32_t)RPS + (uint32_t)sub;
+            const uint32_t bidx = row0 * (uint32_t)nBlk + (uint32_t)col;
+            const bool col_ok = col < nBlk;
+            const uint32_t vo = col_ok ? bidx * 16u : wbytes, go = col_ok ? (bidx >> gshift) * 2u : gbytes;
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                b.w[g] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, vo, g * gstride_w, 2 /* nt */));
+                if constexpr (PAIRED) b.w2[g] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, vo, g * gstride_w, 2));
+                if constexpr (BD::HAS_GAMA) {
+                    b.st[g] = __builtin_amdgcn_raw_buffer_load_b16(rs_st, go, g * gstride_g, 0), b.ze[g] = __builtin_amdgcn_raw_buffer_load_b16(rs_ze, go, g * gstride_g, 0);
+                    if constexpr (PAIRED)
+                        b.st2[g] = __builtin_amdgcn_raw_buffer_load_b16(rs_st2, go, g * gstride_g, 0), b.ze2[g] = __builtin_amdgcn_raw_buffer_load_b16(rs_ze2, go, g * gstride_g, 0);
+                }
+            }
+        }
+    };
+    const bool stream = STREAM && a.stream_ok;
+
     // x (and the norm weight) of vectors up to 4096 elements: <= 2 chunks of 8 per thread, requested before the weights
     const int nch = a.K >> 3;
     const bool xreg = LAT && nch <= 512, has_norm = a.norm_w != nullptr;
@@ -147,7 +190,11 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     }
 
     Batch<G, PAIRED, LUT> cur, nxt;
-    if (LAT || nsteps > 0) load(0, 0, cur); /* LAT: waves without work re-read row 0 */
+    if (stream) {
+        if (nsteps > 0) sload(0, 0, cur);
+    } else if (LAT || nsteps > 0) {
+        load(0, 0, cur); /* LAT: waves without work re-read row 0 */
+    }
     const int pos = a.d_pos ? *a.d_pos : a.pos;
 
     // ---- prologue: stage x into LDS as packed bf16 chunks
@@ -222,11 +269,7 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     float acc[G], acc2[PAIRED ? G : 1];
     int bi = 0, it = 0;       // the step being computed
     int nbi = 0, nit = 0;     // the step being loaded
-    for (int k = 0; k < nsteps; k++) {
-        if (k + 1 < nsteps) {
-            if (++nit == iters) nit = 0, nbi++;
-            load(nbi, nit, nxt);
-        }
+    auto compute = [&](const Batch<G, PAIRED, LUT>& bt) {
         if (it == 0) {
 #pragma unroll
             for (int g = 0; g < G; g++) {
@@ -243,19 +286,19 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
                 int row;
                 const bool ok = !LAT || (slot(s_begin + (long)bi * G + g, row) && col_ok); /* masked loads carry zero weights */
                 if constexpr (LUT) {
-                    const float r = BD::run_lut(cur.w[g], xs, col, nBlk, cur.ta[g], cur.tb[g], acc[g]);
+                    const float r = BD::run_lut(bt.w[g], xs, col, nBlk, bt.ta[g], bt.tb[g], acc[g]);
                     acc[g] = ok ? r : acc[g];
                     if constexpr (PAIRED) {
-                        const float r2 = BD::run_lut(cur.w2[g], xs, col, nBlk, cur.ta2[g], cur.tb2[g], acc2[g]);
+                        const float r2 = BD::run_lut(bt.w2[g], xs, col, nBlk, bt.ta2[g], bt.tb2[g], acc2[g]);
                         acc2[g] = ok ? r2 : acc2[g];
                     }
                 } else {
-                    const float st = bf2f(cur.st[g]);
-                    const float r = BD::run(cur.w[g], xs, col, nBlk, st, bf2f(cur.ze[g]), -(jqb * st), acc[g]);
+                    const float st = bf2f(bt.st[g]);
+                    const float r = BD::run(bt.w[g], xs, col, nBlk, st, bf2f(bt.ze[g]), -(jqb * st), acc[g]);
                     acc[g] = ok ? r : acc[g];
                     if (PAIRED) {
-                        const float st2 = bf2f(cur.st2[g]);
-                        const float r2 = BD::run(cur.w2[g], xs, col, nBlk, st2, bf2f(cur.ze2[g]), -(jqb2 * st2), acc2[g]);
+                        const float st2 = bf2f(bt.st2[g]);
+                        const float r2 = BD::run(bt.w2[g], xs, col, nBlk, st2, bf2f(bt.ze2[g]), -(jqb2 * st2), acc2[g]);
                         acc2[g] = ok ? r2 : acc2[g];
                     }
                 }
@@ -272,7 +315,7 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
                 for (int g = 0; g < G; g++) {
                     int r;
                     if (!slot(s_begin + (long)bi * G + g, r)) continue;
-                    if (a.row_map) r = a.row_map[r];
+                    if constexpr (SPARSE) r = a.row_map[r];
                     uint16_t* y = jy + (size_t)pos * jystride;
                     float v = acc[g];
                     if (PAIRED) {
@@ -298,8 +341,31 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
                 }
             }
         }
-        cur = nxt;
         if (++it == iters) it = 0, bi++;
+    };
+    if (stream) { /* two batches ping-pong: no register copies between steps */
+        for (int k = 0; k < nsteps; k += 2) {
+            if (k + 1 < nsteps) {
+                if (++nit == iters) nit = 0, nbi++;
+                sload(nbi, nit, nxt);
+            }
+            compute(cur);
+            if (k + 1 >= nsteps) break;
+            if (k + 2 < nsteps) {
+                if (++nit == iters) nit = 0, nbi++;
+                sload(nbi, nit, cur);
+            }
+            compute(nxt);
+        }
+    } else {
+        for (int k = 0; k < nsteps; k++) {
+            if (k + 1 < nsteps) {
+                if (++nit == iters) nit = 0, nbi++;
+                load(nbi, nit, nxt);
+            }
+            compute(cur);
+            cur = nxt;
+        }
     }
 
     if (MODE == GEMV_ARGMAX) {
@@ -415,23 +481,30 @@ int gemv_lpr_log2(int nBlk, long rows) {
     return lpr_log2;
 }
 
-template <int FMT, int MODE>
+template <int FMT, int MODE, bool SPARSE>
 static void launch_g(const GemvArgs& a, int G, dim3 grid, size_t smem, hipStream_t st) {
     if (G >= 4)
-        hipLaunchKernelGGL((gemv_kernel<FMT, 4, MODE>), grid, dim3(256), smem, st, a);
+        hipLaunchKernelGGL((gemv_kernel<FMT, 4, MODE, SPARSE>), grid, dim3(256), smem, st, a);
     else if (G == 2)
-        hipLaunchKernelGGL((gemv_kernel<FMT, 2, MODE>), grid, dim3(256), smem, st, a);
+        hipLaunchKernelGGL((gemv_kernel<FMT, 2, MODE, SPARSE>), grid, dim3(256), smem, st, a);
     else
-        hipLaunchKernelGGL((gemv_kernel<FMT, 1, MODE>), grid, dim3(256), smem, st, a);
+        hipLaunchKernelGGL((gemv_kernel<FMT, 1, MODE, SPARSE>), grid, dim3(256), smem, st, a);
 }
 template <int FMT>
 static void launch_m(const GemvArgs& a, int mode, int G, dim3 grid, size_t smem, hipStream_t st) {
+    if (a.row_map) { /* the sparse forward: kf_linear_masked (plain) and kf_norm_gateup_swiglu_masked (paired) */
+        if (mode == GEMV_PAIRED)
+            launch_g<FMT, GEMV_PAIRED, true>(a, G, grid, smem, st);
+        else
+            launch_g<FMT, GEMV_PLAIN, true>(a, G, grid, smem, st);
+        return;
+    }
     if (mode == GEMV_PAIRED)
-        launch_g<FMT, GEMV_PAIRED>(a, G, grid, smem, st);
+        launch_g<FMT, GEMV_PAIRED, false>(a, G, grid, smem, st);
     else if (mode == GEMV_ARGMAX)
-        launch_g<FMT, GEMV_ARGMAX>(a, G, grid, smem, st);
+        launch_g<FMT, GEMV_ARGMAX, false>(a, G, grid, smem, st);
     else
-        launch_g<FMT, GEMV_PLAIN>(a, G, grid, smem, st);
+        launch_g<FMT, GEMV_PLAIN, false>(a, G, grid, smem, st);
 }
 
 int gemv_launch(hipStream_t st, GemvLaunch& L) {
@@ -504,6 +577,17 @@ int gemv_launch(hipStream_t st, GemvLaunch& L) {
     }
     for (int j = a.njobs; j < 3; j++) a.job[j].slot0 = 0x7fffffff;
     a.total_slots = (int)slots;
+    // buffer-load form of the long launches (gemv_kernel, STREAM): every byte offset a wave can form -- rows of the padded slot range included -- below
+    // 2^31, and groups that never straddle two rows (then the G rows of a batch are a constant number of groups apart)
+    a.stream_ok = 0;
+    if (G > 1 && !a.row_map && fmt != FMT_Q4R) {
+        long max_rows = 0;
+        for (int j = 0; j < L.n; j++) max_rows = a.job[j].M > max_rows ? a.job[j].M : max_rows;
+        const unsigned long long reach = ((unsigned long long)max_rows + (unsigned long long)(spw + G) * RPS) * nBlk * 16ull;
+        const bool groups_ok = fmt < FMT_Q4 || (K % a.lGroup) == 0;
+        if (reach < (1ull << 31) && groups_ok) a.stream_ok = 1;
+        if (const char* e = getenv("KF_GEMV_STREAM")) a.stream_ok = a.stream_ok && atoi(e) != 0; /* A/B knob */
+    }
     const long waves = (slots + spw - 1) / spw;
     const int blocks = (int)((waves + 3) / 4);
     if (L.mode == GEMV_ARGMAX && blocks > KF_MAX_ARGMAX_PARTIALS) return KF_INTERNAL_ERR;

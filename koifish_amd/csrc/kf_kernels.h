@@ -45,6 +45,7 @@ struct GemvArgs {
     int pos;
     float* amax_val;
     int* amax_idx;
+    int stream_ok;          /* long dense launches: buffer-load form allowed (offsets < 2^31, groups inside rows) */
     const int32_t* row_map; /* non-NULL: the sparse forward -- slot rows index this list of hot rows (job.M = their number); weights and outputs use row_map[row] */
 };
 
