@@ -187,6 +187,9 @@ def main():
         print(json.dumps(out))
 
 
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak of MI355X (MI355X_MICROARCH.md); the prefill GEMMs multiply bf16 fragments unpacked from 4-bit tiles
+
+
 def prefill_rate(m, prompt, decode_ms_per_step, reps=5):
     """The prompt half of the metric, reported beside the decode rate (never inside `value`): the 128-token prompt through
     Fish::Prefill (token batches on the MFMA tile kernels) -- wall time of `reps` calls after one warm-up, each ending with the
@@ -201,8 +204,20 @@ def prefill_rate(m, prompt, decode_ms_per_step, reps=5):
     m.sync()
     ms = (time.perf_counter() - t0) * 1e3 / reps
     n = int(len(prompt))
+    cfg = m.cfg
+    # both roofs of the prefill: flops = 2 x tokens x (layer matrix elements) + causal attention (QK^T and PV over t <= s) + the head mat-vec of the last token;
+    # bytes = every packed weight once (layers + the embedding rows touched + the LM head) + K/V rows written and read once
+    w_elems = sum(w.ne0 * w.ne1 for (layer, slot), w in m.weights.items() if layer >= 0)
+    flops = 2.0 * n * w_elems + cfg["n_layer"] * 4.0 * cfg["n_head"] * cfg["head_dim"] * (n * (n + 1) / 2) + 2.0 * cfg["vocab"] * cfg["dim"]
+    kvd = cfg["n_kv"] * cfg["head_dim"]
+    nbytes = sum(w.algorithmic_bytes() for (layer, slot), w in m.weights.items() if layer >= 0) + m.weights[(-1, 1)].algorithmic_bytes() + n * cfg["dim"] * 2 \
+        + cfg["n_layer"] * n * kvd * 2 * 2 * 2
+    tf, gbs = flops / (ms * 1e-3) / 1e12, nbytes / (ms * 1e-3) / 1e9
     return {"prompt_tokens": n, "ms": round(ms, 3), "tokens_per_s": round(n / ms * 1e3, 1), "mode": "token batches, MFMA 32x32x16 bf16 on unpacked 4-bit tiles",
-            "token_serial_ms": round(decode_ms_per_step * n, 3)}
+            "token_serial_ms": round(decode_ms_per_step * n, 3),
+            "roofline": {"flops": int(flops), "bytes": int(nbytes), "achieved_TFLOPs": round(tf, 2), "mfma_peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS, "mfma_frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
+                         "achieved_GBs": round(gbs, 1), "hbm_peak_GBs": HBM_PEAK_GBS, "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                         "bound": "neither: %d dependent launches of ~10 us each (8 per layer); at this size the prompt is bound by launch + first-load latency" % (8 * cfg["n_layer"] + 3)}}
 
 
 def concurrent_streams(cfg, layer_type, head_type, dev, S, forced, n_prompt, mean_bytes):
