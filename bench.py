@@ -425,36 +425,6 @@ def matvec_roofline(m, ctx, cfg, head_rl, reps=20):
             "note": "latency-bound: %.1f MB per launch is %.2f us at the HBM peak; the in-kernel time split is in DESIGN.md section 6" % (nbytes / n / 1e6, nbytes / n / HBM_PEAK_GBS / 1e3)}
 
 
-def _pick_threads():
-    """the OpenMP thread count this host sustains on the decode's mat-vecs: probed on a 3072 x 1024 and a 151936 x 1024 product (the FFN and LM-head shapes)
-    over candidate counts -- a container may expose more logical CPUs than it can use, and the second socket costs more in remote memory and barriers
-    than it adds.  Set before the weights are first touched, so that pages land next to the threads that read them."""
-    from oracle import oracle as O
-    if "OMP_NUM_THREADS" in os.environ:
-        return O.num_threads()
-    top = O.num_threads()
-    try:   # a cgroup CPU quota below the visible CPU count: more busy threads than the quota are throttled in 100 ms periods (spikes of ~90 ms per step)
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-        if q != "max":
-            top = max(1, min(top, int(int(q) / int(per))))
-    except Exception:
-        pass
-    best, best_t = top, None
-    for c in sorted(set([c for c in (8, 16, 24, 32, 48, 64, 96, 128, 192, 256) if c <= top] + [top])):
-        O.set_num_threads(c)
-        t = 28 * 7 * O.bench_matvec(3072, 1024, 8) + O.bench_matvec(151936, 1024, 3)
-        if best_t is None or t < best_t:
-            best, best_t = c, t
-    O.set_num_threads(best)
-    return best
-
-
-def _spread(step_s):
-    import numpy as np
-    a = np.sort(np.asarray(step_s))
-    return {"median_ms": round(float(np.median(a)) * 1e3, 3), "p10_ms": round(float(a[int(0.1 * (a.size - 1))]) * 1e3, 3), "p90_ms": round(float(a[int(0.9 * (a.size - 1))]) * 1e3, 3)}
-
-
 def cpu_baseline(m, cfg, forced, budget_s, min_steps=64, max_steps=256):
     """The CPU oracle (a port: no runnable CPU forward exists in the reference) decoding the SAME 4-bit model on this host's cores: weights and the
     KV rows of a 128-token prompt are copied from the GPU model, then it decodes from position 128 -- at least 64 steps (more while the time budget
@@ -500,6 +470,36 @@ def cpu_baseline(m, cfg, forced, budget_s, min_steps=64, max_steps=256):
                       "threads pinned one per core" % (n, p0, p0 + n - 1, max(prep, 0) // 2 ** 20), "step_ms": sp,
             "greedy_ids_equal_gpu": same, "mismatches_that_are_ties_within_2_bf16_ulps": near_tie, "mismatches_inside_twice_the_logit_tolerance": in_tol,
             "mismatches_beyond_tolerance": n - same - near_tie - in_tol}
+
+
+def _pick_threads():
+    """the OpenMP thread count this host sustains on the decode's mat-vecs: probed on a 3072 x 1024 and a 151936 x 1024 product (the FFN and LM-head shapes)
+    over candidate counts -- a container may expose more logical CPUs than it can use, and the second socket costs more in remote memory and barriers
+    than it adds.  Set before the weights are first touched, so that pages land next to the threads that read them."""
+    from oracle import oracle as O
+    if "OMP_NUM_THREADS" in os.environ:
+        return O.num_threads()
+    top = O.num_threads()
+    try:   # a cgroup CPU quota below the visible CPU count: more busy threads than the quota are throttled in 100 ms periods (spikes of ~90 ms per step)
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            top = max(1, min(top, int(int(q) / int(per))))
+    except Exception:
+        pass
+    best, best_t = top, None
+    for c in sorted(set([c for c in (8, 16, 24, 32, 48, 64, 96, 128, 192, 256) if c <= top] + [top])):
+        O.set_num_threads(c)
+        t = 28 * 7 * O.bench_matvec(3072, 1024, 8) + O.bench_matvec(151936, 1024, 3)
+        if best_t is None or t < best_t:
+            best, best_t = c, t
+    O.set_num_threads(best)
+    return best
+
+
+def _spread(step_s):
+    import numpy as np
+    a = np.sort(np.asarray(step_s))
+    return {"median_ms": round(float(np.median(a)) * 1e3, 3), "p10_ms": round(float(a[int(0.1 * (a.size - 1))]) * 1e3, 3), "p90_ms": round(float(a[int(0.9 * (a.size - 1))]) * 1e3, 3)}
 
 
 def cpu_fp16_decode(cfg, device, n_new, n_prompt=128):

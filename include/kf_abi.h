@@ -142,6 +142,37 @@ int kf_linear_f32(kf_ctx* ctx, const kf_weight* w_shard, const kf_bf16* x_shard,
 /* ... that are combined in rank order after an all-gather: out = bf16(residual + bf16(sum_r partials[r][:])) */
 int kf_tp_reduce(kf_ctx* ctx, const float* partials, int n_ranks, int n, const kf_bf16* residual_or_null, kf_bf16* out);
 
+/* The exchange itself without a collective library: every rank owns a receive area that every other rank can address (xGMI peer-to-peer mapping
+ * of kf_tp_alloc memory, exported / opened with the kf_tp_ipc_* calls; ranks of one process just pass pointers).  kf_linear_f32_push is kf_linear_f32
+ * whose epilogue stores each fp32 row dot, tagged, into this rank's slot of EVERY rank's area (one 8-byte system-scope store per rank and row);
+ * kf_tp_reduce_recv waits for the tags of all ranks' slots and forms out = bf16(residual + bf16(sum_r partial_r)) in rank order -- the bits of
+ * kf_tp_reduce.  kf_tp_lm_head runs the LM head on this rank's vocabulary rows and pushes its first maximum (value, GLOBAL row) to every rank;
+ * kf_tp_pick takes the first maximum over the ranks, updates the decode state {token, pos + 1} like kf_norm_lm_head does, and advances the
+ * generation word.  All of it is plain kernel launches on the context's stream: the TP step captures into a hipGraph.
+ * Area layout (8-byte granules): [2 exchange buffers][world][n_max] vector slots, then [world][2] pick slots; kf_tp_recv_bytes gives the size;
+ * the area must be zero before the first step (kf_tp_alloc zeroes it).  `index` numbers the exchanges of one step (0 .. per_step - 2; the
+ * pick uses per_step - 1); exchanges with even index use buffer 0, odd ones buffer 1.  A poll that outlasts ~2^24 re-reads sets *d_err
+ * (1 + rank waited for) instead of hanging. */
+typedef struct kf_tp_comm {
+    int32_t rank, world; /* world <= 8 */
+    int32_t n_max;       /* rows of a vector slot */
+    uint32_t per_step;   /* exchanges per token including the pick */
+    void* recv;          /* this rank's receive area */
+    void* peer[8];       /* peer[r]: rank r's receive area as addressable from this process (peer[rank] == recv) */
+    uint32_t* d_step;    /* device word, zero at start: generation */
+    int32_t* d_err;      /* device word, zero at start */
+} kf_tp_comm;
+size_t kf_tp_recv_bytes(int world, int n_max);
+int kf_tp_alloc(kf_ctx* ctx, size_t bytes, void** out);              /* device memory other processes / devices may map; zeroed */
+int kf_tp_ipc_export(kf_ctx* ctx, void* p, unsigned char handle[64]); /* hipIpcGetMemHandle */
+int kf_tp_ipc_open(kf_ctx* ctx, const unsigned char handle[64], void** out);
+int kf_tp_ipc_close(kf_ctx* ctx, void* p);
+int kf_linear_f32_push(kf_ctx* ctx, const kf_weight* w_shard, const kf_bf16* x_shard, const kf_tp_comm* comm, uint32_t index);
+int kf_tp_reduce_recv(kf_ctx* ctx, const kf_tp_comm* comm, uint32_t index, int n, const kf_bf16* residual_or_null, kf_bf16* out);
+int kf_tp_lm_head(kf_ctx* ctx, const kf_bf16* x, const kf_bf16* norm_w, float eps, const kf_weight* w_shard, kf_bf16* logits_shard, int row0,
+                  const kf_tp_comm* comm, void* head_scratch);
+int kf_tp_pick(kf_ctx* ctx, const kf_tp_comm* comm, int32_t* d_state, int32_t* d_tokens_out);
+
 /* ---- sparse ("EOE" / hot-neuron) forward: D_matmul_sparse (src/Utils/GST_float.cpp:306-318) with the hot[] array of CS_Picker
  * (src/Manifold/SparseNeuron.cpp:20-29; Neuron.hpp:265-285: one int per FFN row, 1 = hot):  y[i] = (hot[i] == 1 ? W[i,:].x : 0) (+ bias[i]).
  * The mask is turned into a list of hot rows once (kf_hot_rows: ascending indices, their number to *d_count) and the products walk that list, so

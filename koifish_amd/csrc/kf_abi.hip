@@ -436,6 +436,101 @@ int kf_tp_reduce(kf_ctx* c, const float* partials, int n_ranks, int n, const kf_
     RET(kf::tp_reduce_launch(c->stream, partials, n_ranks, n, residual, out));
 }
 
+// ---- tensor-parallel exchange over peer-mapped receive areas (kf_tp.hip)
+static int tp_check(const kf_tp_comm* t, const char* who) {
+    if (!t || t->world < 1 || t->world > 8 || t->rank < 0 || t->rank >= t->world || t->n_max < 1 || t->per_step < 1 || !t->recv || !t->d_step || !t->d_err)
+        return fail(KF_INVALID_ARGS, "%s: bad kf_tp_comm", who);
+    for (int r = 0; r < t->world; r++)
+        if (!t->peer[r]) return fail(KF_INVALID_ARGS, "%s: peer %d not set", who, r);
+    return KF_OK;
+}
+static unsigned long long* tp_vec_slot(void* area, const kf_tp_comm* t, uint32_t index, int rank) {
+    return (unsigned long long*)area + ((size_t)(index & 1u) * t->world + rank) * t->n_max;
+}
+size_t kf_tp_recv_bytes(int world, int n_max) { return world < 1 || n_max < 1 ? 0 : ((size_t)2 * world * n_max + (size_t)2 * world) * 8; }
+int kf_tp_alloc(kf_ctx* c, size_t bytes, void** out) {
+    CHKCTX(c);
+    if (!out || !bytes) return fail(KF_INVALID_ARGS, "kf_tp_alloc: bad args");
+    // uncached (fine-grained) device memory: remote writes become visible to this device's polling loads inside a running kernel
+    hipError_t e = hipExtMallocWithFlags(out, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        e = hipMalloc(out, bytes);
+    }
+    if (e != hipSuccess) return fail(KF_OUTOF_GPUMEMORY, "kf_tp_alloc(%zu): %s", bytes, hipGetErrorString(e));
+    HIPCHK(hipMemset(*out, 0, bytes));
+    return KF_OK;
+}
+int kf_tp_ipc_export(kf_ctx* c, void* p, unsigned char handle[64]) {
+    CHKCTX(c);
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    hipIpcMemHandle_t h;
+    HIPCHK(hipIpcGetMemHandle(&h, p));
+    memcpy(handle, &h, 64);
+    return KF_OK;
+}
+int kf_tp_ipc_open(kf_ctx* c, const unsigned char handle[64], void** out) {
+    CHKCTX(c);
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, 64);
+    HIPCHK(hipIpcOpenMemHandle(out, h, hipIpcMemLazyEnablePeerAccess));
+    return KF_OK;
+}
+int kf_tp_ipc_close(kf_ctx* c, void* p) {
+    CHKCTX(c);
+    HIPCHK(hipIpcCloseMemHandle(p));
+    return KF_OK;
+}
+int kf_linear_f32_push(kf_ctx* c, const kf_weight* w, const kf_bf16* x, const kf_tp_comm* t, uint32_t index) {
+    CHKCTX(c);
+    int r = check_weight(w, "kf_linear_f32_push");
+    if (r) return r;
+    if ((r = tp_check(t, "kf_linear_f32_push"))) return r;
+    if (!x || !al16(x)) return fail(KF_BLAS_UNALIGN, "kf_linear_f32_push: x null or unaligned");
+    if (w->ne0 > t->n_max || index + 1 >= t->per_step) return fail(KF_INVALID_ARGS, "kf_linear_f32_push: %d rows / index %u do not fit the comm", w->ne0, index);
+    kf::GemvLaunch L;
+    init_args(L);
+    L.n = 1, L.w[0] = w, L.mode = kf::GEMV_PLAIN;
+    L.args.x = x, L.args.job[0].y = nullptr;
+    L.args.tp_world = t->world, L.args.tp_step = t->d_step, L.args.tp_per_step = t->per_step, L.args.tp_index = index;
+    for (int p = 0; p < t->world; p++) L.args.tp_peer[p] = tp_vec_slot(t->peer[p], t, index, t->rank);
+    RET(kf::gemv_launch(c->stream, L));
+}
+int kf_tp_reduce_recv(kf_ctx* c, const kf_tp_comm* t, uint32_t index, int n, const kf_bf16* residual, kf_bf16* out) {
+    CHKCTX(c);
+    int r = tp_check(t, "kf_tp_reduce_recv");
+    if (r) return r;
+    if (!out || n < 1 || n > t->n_max || index + 1 >= t->per_step) return fail(KF_INVALID_ARGS, "kf_tp_reduce_recv: bad args");
+    RET(kf::tp_reduce_recv_launch(c->stream, tp_vec_slot(t->recv, t, index, 0), t->world, t->n_max, n, t->d_step, t->per_step, index, residual, out, t->d_err));
+}
+int kf_tp_lm_head(kf_ctx* c, const kf_bf16* x, const kf_bf16* norm_w, float eps, const kf_weight* w, kf_bf16* logits, int row0, const kf_tp_comm* t, void* scratch) {
+    CHKCTX(c);
+    int r = tp_check(t, "kf_tp_lm_head");
+    if (r) return r;
+    if ((r = check_weight(w, "kf_tp_lm_head"))) return r;
+    if (!x || !al16(x) || !logits) return fail(KF_BLAS_UNALIGN, "kf_tp_lm_head: x null/unaligned or no logits buffer");
+    float* av = scratch ? (float*)scratch : c->amax_val;
+    int* ai = scratch ? (int*)((float*)scratch + kf::KF_MAX_ARGMAX_PARTIALS) : c->amax_idx;
+    kf::GemvLaunch L;
+    init_args(L);
+    L.n = 1, L.w[0] = w, L.mode = kf::GEMV_ARGMAX;
+    L.args.x = x, L.args.norm_w = norm_w, L.args.eps = eps, L.args.job[0].y = logits;
+    L.args.amax_val = av, L.args.amax_idx = ai;
+    r = kf::gemv_launch(c->stream, L);
+    if (r) return fail(r, "kf_tp_lm_head: gemv failed with %d", r);
+    unsigned long long* peers[8];
+    for (int p = 0; p < t->world; p++) peers[p] = (unsigned long long*)t->peer[p] + (size_t)2 * t->world * t->n_max + 2 * t->rank;
+    RET(kf::tp_argmax_push_launch(c->stream, av, ai, L.blocks, row0, peers, t->world, t->d_step, t->per_step, t->per_step - 1));
+}
+int kf_tp_pick(kf_ctx* c, const kf_tp_comm* t, int32_t* d_state, int32_t* d_tokens_out) {
+    CHKCTX(c);
+    int r = tp_check(t, "kf_tp_pick");
+    if (r) return r;
+    if (!d_state) return fail(KF_INVALID_ARGS, "kf_tp_pick: d_state is null");
+    RET(kf::tp_pick_launch(c->stream, (const unsigned long long*)t->recv + (size_t)2 * t->world * t->n_max, t->world, t->d_step, t->per_step, t->per_step - 1, d_state,
+                           d_tokens_out, t->d_err));
+}
+
 int kf_norm_linear(kf_ctx* c, const kf_bf16* x, const kf_bf16* norm_w, float eps, int n_w, const kf_weight* const* w, kf_bf16* const* y,
                    const int64_t* y_pos_stride, int pos, const int32_t* d_pos) {
     CHKCTX(c);

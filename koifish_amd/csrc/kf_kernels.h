@@ -45,6 +45,11 @@ struct GemvArgs {
     int pos;
     float* amax_val;
     int* amax_idx;
+    // tensor-parallel push (kf_linear_f32_push): the un-rounded fp32 row dot goes, tagged, into this rank's slot of every rank's receive area
+    unsigned long long* tp_peer[8];
+    int tp_world;            /* 0: no push */
+    const unsigned* tp_step; /* device word: generation */
+    unsigned tp_per_step, tp_index;
     int stream_ok;          /* long dense launches: buffer-load form allowed (offsets < 2^31, groups inside rows) */
     const int32_t* row_map; /* non-NULL: the sparse forward -- slot rows index this list of hot rows (job.M = their number); weights and outputs use row_map[row] */
 };
@@ -60,6 +65,13 @@ struct GemvLaunch {
 };
 
 int gemv_launch(hipStream_t st, GemvLaunch& L);
+// tensor-parallel exchange (kf_tp.hip)
+int tp_reduce_recv_launch(hipStream_t st, const unsigned long long* slots, int R, int n_max, int n, const unsigned* d_step, unsigned per_step, unsigned index,
+                          const uint16_t* residual, uint16_t* out, int* d_err);
+int tp_argmax_push_launch(hipStream_t st, const float* val, const int* idx, int n, int row0, unsigned long long* const* peers, int R, const unsigned* d_step,
+                          unsigned per_step, unsigned index);
+int tp_pick_launch(hipStream_t st, const unsigned long long* pairs, int R, unsigned* d_step, unsigned per_step, unsigned index, int32_t* d_state, int32_t* d_tokens_out,
+                   int* d_err);
 int gemv_lpr_log2(int nBlk, long rows); /* lanes per row of a mat-vec launch (kf_gemv.hip) */
 int gemv_fmt_of(const kf_weight* w);    /* FMT_* of a weight, < 0: not served by the mat-vec kernel */
 void argmax_finish_launch(hipStream_t st, const float* val, const int* idx, int n, int32_t* d_argmax, int32_t* d_state, int32_t* d_tokens_out);

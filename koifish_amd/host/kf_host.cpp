@@ -210,6 +210,12 @@ hGTensor Head4Token::cuInfer_1(hGTensor inp_, int) {
 // ------------------------------------------------------------------------------------------------ Fish
 Fish::~Fish() {
     for (auto g : graphs) kf_graph_destroy(g);
+    for (auto g : tp.group_graphs)
+        if (g) kf_graph_destroy(g);
+    if (ctx) {
+        for (void* p : tp.opened) kf_tp_ipc_close(ctx, p);
+        if (tp.area) kf_free(ctx, tp.area);
+    }
     if (ctx && lin_scratch) kf_free(ctx, lin_scratch);
     if (engine) kf_engine_destroy(engine);
     if (ctx && engine_ws) kf_free(ctx, engine_ws);
@@ -343,7 +349,81 @@ int Fish::EnsureEngine() {
     return KF_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ tensor parallel
+int Fish::TPInit(int rank, int world, int vocab_row0) {
+    if (world < 2 || world > 8 || rank < 0 || rank >= world) return KF_INVALID_ARGS;
+    std::memset(&tp.comm, 0, sizeof(tp.comm));
+    tp.rank = rank, tp.world = world, tp.vocab_row0 = vocab_row0;
+    tp.comm.rank = rank, tp.comm.world = world, tp.comm.n_max = config.nEmbed, tp.comm.per_step = 2u * (uint32_t)config.nLayer + 1u;
+    const size_t bytes = kf_tp_recv_bytes(world, config.nEmbed);
+    KF_TRY(kf_tp_alloc(ctx, bytes + 64, &tp.area)); /* + the generation and error words behind the area */
+    tp.comm.recv = tp.area, tp.comm.peer[rank] = tp.area;
+    tp.comm.d_step = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(tp.area) + bytes);
+    tp.comm.d_err = reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(tp.area) + bytes + 32);
+    use_engine = false; /* the persistent engine serves whole layers of one GPU */
+    return KF_OK;
+}
+int Fish::TPSetPeer(int r, void* area) {
+    if (tp.world < 2 || r < 0 || r >= tp.world || !area) return KF_INVALID_ARGS;
+    tp.comm.peer[r] = area;
+    return KF_OK;
+}
+int Fish::TPPhase(int phase, int l) {
+    const int32_t* d_pos = graph_mode ? d_state + 1 : nullptr;
+    const int bound = graph_mode ? pos_bound() : tok_pos;
+    const int C = config.nEmbed;
+    switch (phase) {
+        case 0: return embed.cuInfer(-1) ? KF_OK : KF_INTERNAL_ERR;
+        case 1: {  // [norm + q,k,v rows of this rank] -> [q/k-norm + RoPE + attention over the local kv heads] -> o_proj column shard, pushed
+            SelfAttention* a = attn[l].get();
+            floatX* key_cache = reinterpret_cast<floatX*>(cache.Get(KVCache::KV_KEY, l, 0));
+            floatX* val_cache = reinterpret_cast<floatX*>(cache.Get(KVCache::KV_VAL, l, 0));
+            kf_weight wq = a->Q.w->desc(), wk = a->K.w->desc(), wv = a->V.w->desc(), wo = a->proj_cat.w->desc();
+            const kf_weight* ws[3] = {&wq, &wk, &wv};
+            kf_bf16* ys[3] = {ToX(a->Q.out), ToX(gBUFF.kraw), val_cache};
+            const int64_t strides[3] = {0, 0, (int64_t)a->kv_dim};
+            KF_TRY(kf_norm_linear(ctx, ToX(x), ToX(a->norm.w), a->norm.rms_eps, 3, ws, ys, strides, bound, d_pos));
+            KF_TRY(kf_attn_block(ctx, ToX(a->Q.out), ToX(gBUFF.kraw), key_cache, val_cache, ToX(gBUFF.scratch), a->normQ.w ? ToX(a->normQ.w) : nullptr,
+                                 a->normK.w ? ToX(a->normK.w) : nullptr, rope_table, bound, d_pos, a->n_head, a->n_head_kv, a->head_dim, a->kv_dim, a->normQ.rms_eps,
+                                 gBUFF.attn_ws->data));
+            return kf_linear_f32_push(ctx, &wo, ToX(gBUFF.scratch), &tp.comm, 2u * (uint32_t)l);
+        }
+        case 2: return kf_tp_reduce_recv(ctx, &tp.comm, 2u * (uint32_t)l, C, ToX(x), ToX(x));
+        case 3: {
+            FFN* m = ffn[l].get();
+            kf_weight wg = m->gate.w->desc(), wu = m->up.w->desc(), wd = m->down.w->desc();
+            KF_TRY(kf_norm_gateup_swiglu(ctx, ToX(x), ToX(m->norm.w), m->norm.rms_eps, &wg, &wu, ToX(gBUFF.scratch)));
+            return kf_linear_f32_push(ctx, &wd, ToX(gBUFF.scratch), &tp.comm, 2u * (uint32_t)l + 1u);
+        }
+        case 4: return kf_tp_reduce_recv(ctx, &tp.comm, 2u * (uint32_t)l + 1u, C, ToX(x), ToX(x));
+        case 5: {
+            kf_weight wh = head.proj.w->desc();
+            return kf_tp_lm_head(ctx, ToX(x), ToX(final_norm.w), final_norm.rms_eps, &wh, ToX(head.preLogits), tp.vocab_row0, &tp.comm, gBUFF.head_ws->data);
+        }
+        case 6: return kf_tp_pick(ctx, &tp.comm, d_state, d_tokens_out);
+    }
+    return KF_INVALID_ARGS;
+}
+int Fish::EnqueueStepTP() {
+    KF_TRY(TPPhase(0, 0));
+    for (int l = 0; l < config.nLayer; l++)
+        for (int ph = 1; ph <= 4; ph++) KF_TRY(TPPhase(ph, l));
+    KF_TRY(TPPhase(5, 0));
+    return TPPhase(6, 0);
+}
+// ranks of one process on one stream: phase by phase across the ranks
+static int tp_group_enqueue(Fish** fs, int R) {
+    for (int r = 0; r < R; r++) KF_TRY(fs[r]->TPPhase(0, 0));
+    for (int l = 0; l < fs[0]->config.nLayer; l++)
+        for (int ph = 1; ph <= 4; ph++)
+            for (int r = 0; r < R; r++) KF_TRY(fs[r]->TPPhase(ph, l));
+    for (int r = 0; r < R; r++) KF_TRY(fs[r]->TPPhase(5, 0));
+    for (int r = 0; r < R; r++) KF_TRY(fs[r]->TPPhase(6, 0));
+    return KF_OK;
+}
+
 int Fish::EnqueueStep(int bound) {
+    if (tp.world > 1) return EnqueueStepTP();
     hGTensor cur = embed.cuInfer(-1);
     if (!cur) return KF_INTERNAL_ERR;
     if (use_engine && fuse_level >= 1 && engine_state > 0) {
@@ -735,6 +815,66 @@ void* kfh_kcache(void* h) { return reinterpret_cast<Fish*>(h)->cache.key->data; 
 void* kfh_vcache(void* h) { return reinterpret_cast<Fish*>(h)->cache.val->data; }
 void* kfh_logits(void* h) { return reinterpret_cast<Fish*>(h)->head.preLogits->data; }
 void* kfh_hidden(void* h) { return reinterpret_cast<Fish*>(h)->x->data; }
+// ---- tensor parallel
+int kfh_tp_init(void* h, int rank, int world, int vocab_row0) { return reinterpret_cast<Fish*>(h)->TPInit(rank, world, vocab_row0); }
+void* kfh_tp_area(void* h) { return reinterpret_cast<Fish*>(h)->tp.area; }
+int kfh_tp_set_peer(void* h, int r, void* area) { return reinterpret_cast<Fish*>(h)->TPSetPeer(r, area); }
+int kfh_tp_export(void* h, unsigned char* handle64) {
+    Fish* f = reinterpret_cast<Fish*>(h);
+    return f->tp.area ? kf_tp_ipc_export(f->ctx, f->tp.area, handle64) : KF_INVALID_ARGS;
+}
+int kfh_tp_open_peer(void* h, int r, const unsigned char* handle64) {
+    Fish* f = reinterpret_cast<Fish*>(h);
+    void* p = nullptr;
+    KF_TRY(kf_tp_ipc_open(f->ctx, handle64, &p));
+    f->tp.opened.push_back(p);
+    return f->TPSetPeer(r, p);
+}
+// synchronises; KF_INTERNAL_ERR when a poll of this rank ran out of spins (a peer never pushed)
+int kfh_tp_check(void* h) {
+    Fish* f = reinterpret_cast<Fish*>(h);
+    if (f->tp.world < 2) return KF_OK;
+    KF_TRY(kf_sync(f->ctx));
+    int32_t e = 0;
+    KF_TRY(kf_d2h(f->ctx, &e, f->tp.comm.d_err, 4));
+    return e == 0 ? KF_OK : KF_INTERNAL_ERR;
+}
+// R ranks of this process (all on the stream of rank 0) run n decode steps from `pos` in lock-step; tokens / positions come from each rank's d_state
+int kfh_tp_group_run(void** hs, int R, int pos, int n, int use_graph) {
+    if (R < 2 || R > 8) return KF_INVALID_ARGS;
+    Fish* fs[8];
+    for (int r = 0; r < R; r++) {
+        fs[r] = reinterpret_cast<Fish*>(hs[r]);
+        if (fs[r]->tp.world != R || fs[r]->tp.rank != r) return KF_INVALID_ARGS;
+    }
+    if (pos < 0 || pos + n > fs[0]->config.n_ctx) return KF_INVALID_ARGS;
+    auto& graphs = fs[0]->tp.group_graphs;
+    for (int i = 0; i < n; i++) {
+        for (int r = 0; r < R; r++) fs[r]->tok_pos = pos + i, fs[r]->graph_mode = true;
+        int rc = KF_OK;
+        if (use_graph) {
+            const int b = bucket_of(pos + i);
+            if ((int)graphs.size() <= b) graphs.resize(b + 1, nullptr);
+            if (!graphs[b]) {
+                rc = kf_graph_begin(fs[0]->ctx);
+                if (rc == KF_OK) {
+                    rc = tp_group_enqueue(fs, R);
+                    kf_graph* g = nullptr;
+                    const int rc2 = kf_graph_end(fs[0]->ctx, &g);
+                    if (rc == KF_OK) rc = rc2;
+                    if (rc == KF_OK) graphs[b] = g;
+                }
+            }
+            if (rc == KF_OK) rc = kf_graph_launch(fs[0]->ctx, graphs[b]);
+        } else {
+            rc = tp_group_enqueue(fs, R);
+        }
+        for (int r = 0; r < R; r++) fs[r]->graph_mode = false;
+        KF_TRY(rc);
+    }
+    return KF_OK;
+}
+
 int kfh_num_graphs(void* h) {
     int n = 0;
     for (auto g : reinterpret_cast<Fish*>(h)->graphs) n += g != nullptr;

@@ -178,8 +178,27 @@ struct CHAT_SAMPLER {
     bool greedy() const { return temperature == 0.0f || top_k == 1; }
 };
 
+// Tensor-parallel decode (no counterpart in the single-GPU reference, QKV.cu:503): this Fish holds ONE rank's shard -- the
+// card carries the LOCAL head / ffn / vocab counts and the full nEmbed -- and exchanges fp32 partials through peer-mapped receive areas
+// (kf_tp_* of the ABI).  q/k/v/gate/up are row shards, o_proj / down_proj column shards, the head a vocabulary shard, the embedding replicated.
+struct TPState {
+    int rank = 0, world = 1, vocab_row0 = 0;
+    kf_tp_comm comm;
+    void* area = nullptr;
+    std::vector<void*> opened;          // IPC mappings of other processes' areas (closed with the Fish)
+    std::vector<kf_graph*> group_graphs;  // ranks of ONE process stepped in lock-step on one stream: rank 0 keeps the group's graphs, one per bucket
+};
+
 struct Fish {
     MODEL_CARD config;
+    TPState tp;
+    int TPInit(int rank, int world, int vocab_row0);  // allocates this rank's receive area; peers are set afterwards
+    int TPSetPeer(int r, void* area);
+    // One phase of a TP step: 0 embed | 1 attention half of `layer` up to the o_proj push | 2 its reduce | 3 FFN half up to the down_proj push |
+    // 4 its reduce | 5 LM-head shard + arg-max push | 6 pick.  A rank that owns its GPU enqueues all of them in order (EnqueueStep); ranks that
+    // share one stream are enqueued phase by phase across ranks (a reduce must not sit in the queue ahead of the pushes it waits for).
+    int TPPhase(int phase, int layer);
+    int EnqueueStepTP();
     CHAT_SAMPLER samp_params;
     uint64_t* d_rng = nullptr;  // LogitsInfo::rng_state on the device
     int SetSampler(const CHAT_SAMPLER& s);  // also (re)seeds the device rng state

@@ -11,6 +11,11 @@ Attention is local to the kv-heads a rank owns.  The summation order is fixed so
 (kfo_qwen3_set_tp) produce the same bits.  One process per GPU; the collective is torch.distributed (backend "nccl" = RCCL
 over xGMI): two all-gathers of a dim-vector of fp32 per layer are latency-bound messages (20 KB per rank at dim 5120).
 
+`NativeTP` / `NativeRank` run the step in the C++ host (Fish::TPPhase, kf_host.cpp) with the exchange done by kernels: kf_linear_f32_push writes
+each fp32 partial row into every rank's receive area over the peer mapping, kf_tp_reduce_recv sums the slots in rank order, the (max, index)
+pairs of the vocabulary shards travel the same way -- no host round trip, no collective call, one hipGraph per position bucket.
+`DistributedTP` (two torch.distributed all-gathers per layer, stepped from Python) stays as the RCCL baseline beside it.
+
 `shard_rows` / `shard_cols` re-blob a `data || gama` weight (GTensor.cpp:456-510 layout) for one rank with torch indexing only,
 so they work on CPU tensors (planner tests, gloo) and on GPU tensors alike.  `VirtualTP` runs all R ranks of a plan on ONE GPU
 (lock-step, gathers done in process): it executes exactly the per-rank kernels and the rank-ordered combine, which is how the TP
@@ -248,3 +253,125 @@ class DistributedTP:
         self.dist.all_gather_into_tensor(self.pairs, self.pair, group=self.group)
         pp = self.pairs.view(self.world, 2).cpu().tolist()
         return pick_first_max([(a, int(b)) for a, b in pp])
+
+
+def local_cfg(cfg, plan):
+    """the card of one rank's Fish: local head / ffn / vocab counts, full embedding width"""
+    return dict(cfg, n_head=plan.n_head_l, n_kv=plan.n_kv_l, ffn=plan.ffn_l, vocab=plan.vocab_l)
+
+
+def build_native_rank(cfg, plan, rank, shards, norms, device=0):
+    """shards as TPRank takes them -> a Qwen3 (C++ Fish) holding this rank's slice, TP state initialised (peers still to be set)"""
+    from .runtime import Qwen3
+    m = Qwen3(local_cfg(cfg, plan), device)
+    m.set_weight(-1, 0, shards[(-1, 0)])          # replicated embedding table (rows of the FULL vocabulary)
+    m.set_weight(-1, 1, shards[(-1, 1)])          # vocabulary shard of the head
+    m.set_norm(-1, 0, norms[(-1, 0)])
+    for li in range(cfg["n_layer"]):
+        for si in range(len(SLOTS)):
+            m.set_weight(li, si, shards[(li, si)])
+        for si in range(len(NORMS)):
+            m.set_norm(li, si, norms[(li, si)])
+    L.check(m.host.kfh_tp_init(m.h, rank, plan.R, plan.head_rows(rank)[0]), "kfh_tp_init")
+    return m
+
+
+class NativeTP:
+    """All R ranks of a plan in ONE process on one GPU, stepped by the C++ host in lock-step on one stream (phase by phase across the ranks, so a
+    reduce never queues ahead of the pushes it waits for).  Same kernels, same exchange kernels, same graphs as one-rank-per-GPU; the peers' receive
+    areas are simply local pointers."""
+
+    def __init__(self, cfg, full_weights, norms, world, ctx):
+        self.cfg, self.ctx, self.world = cfg, ctx, world
+        self.plan = TPPlan(cfg, world)
+        self.ranks = []
+        for r in range(world):
+            w = {(-1, 0): full_weights[(-1, 0)], (-1, 1): shard_rows(full_weights[(-1, 1)], *self.plan.head_rows(r))}
+            for li in range(cfg["n_layer"]):
+                for si, s in enumerate(SLOTS):
+                    w[(li, si)] = self.plan.shard(s, full_weights[(li, si)], r)
+            self.ranks.append(build_native_rank(cfg, self.plan, r, w, norms, ctx.device.index or 0))
+        host = self.ranks[0].host
+        for a in self.ranks:
+            for r, b in enumerate(self.ranks):
+                L.check(host.kfh_tp_set_peer(a.h, r, C.c_void_p(host.kfh_tp_area(b.h))), "kfh_tp_set_peer")
+        self._hs = (C.c_void_p * world)(*[m.h for m in self.ranks])
+        self.host = host
+
+    def set_forced(self, forced):
+        for m in self.ranks:
+            m.set_forced(forced)
+
+    def set_state(self, token, pos):
+        for m in self.ranks:
+            m.set_state(token, pos)
+
+    def run_steps(self, pos, n, use_graph=True):
+        L.check(self.host.kfh_tp_group_run(self._hs, self.world, int(pos), int(n), int(use_graph)), "kfh_tp_group_run")
+
+    def check(self):
+        for m in self.ranks:
+            L.check(self.host.kfh_tp_check(m.h), "kfh_tp_check (a poll timed out)")
+
+    def step(self, token, pos, use_graph=False):
+        """one token through all ranks; returns the greedy id every rank agreed on"""
+        self.set_state(token, pos)
+        self.run_steps(pos, 1, use_graph)
+        self.check()
+        ids = {int(m.tokens_out(pos + 1)[pos]) for m in self.ranks}
+        assert len(ids) == 1, ids
+        return ids.pop()
+
+    def logits(self):
+        """the vocabulary shards of the last step's logits, concatenated in rank order (bf16 bit patterns)"""
+        import numpy as np
+        return np.concatenate([m.logits() for m in self.ranks])
+
+    def generate(self, prompt, n_new, use_graph=True):
+        import numpy as np
+        n_prompt = len(prompt)
+        forced = np.full(self.cfg["max_seq"], -1, dtype=np.int32)
+        forced[:n_prompt] = prompt
+        self.set_forced(forced)
+        self.set_state(int(prompt[0]), 0)
+        self.run_steps(0, n_prompt + n_new - 1, use_graph)
+        self.check()
+        toks = self.ranks[0].tokens_out(n_prompt + n_new - 1)
+        return [int(t) for t in toks[n_prompt - 1:]]
+
+    def close(self):
+        for m in self.ranks:
+            m.close()
+
+
+class NativeRank:
+    """One rank per process / GPU: the receive areas are exchanged as IPC handles through torch.distributed once, after that the step is the C++
+    host's graph (Fish::EnqueueStepTP) with no collective call."""
+
+    def __init__(self, cfg, plan, rank, shards, norms, device, group=None):
+        import torch.distributed as dist
+        self.m = build_native_rank(cfg, plan, rank, shards, norms, device)
+        self.cfg, self.plan, self.rank, self.world = cfg, plan, rank, plan.R
+        host = self.m.host
+        h = (C.c_ubyte * 64)()
+        L.check(host.kfh_tp_export(self.m.h, h), "kfh_tp_export")
+        handles = [None] * self.world
+        dist.all_gather_object(handles, bytes(h), group=group)
+        for r, hb in enumerate(handles):
+            if r == rank:
+                continue
+            buf = (C.c_ubyte * 64).from_buffer_copy(hb)
+            L.check(host.kfh_tp_open_peer(self.m.h, r, buf), "kfh_tp_open_peer(%d)" % r)
+        dist.barrier(group=group)
+
+    def set_forced(self, forced):
+        self.m.set_forced(forced)
+
+    def set_state(self, token, pos):
+        self.m.set_state(token, pos)
+
+    def run_steps(self, pos, n, use_graph=True):
+        self.m.run_steps(pos, n, use_graph)
+
+    def check(self):
+        L.check(self.m.host.kfh_tp_check(self.m.h), "kfh_tp_check (a poll timed out)")

@@ -92,3 +92,75 @@ def test_qwen3_32b_shapes_tp8_slice(ctx):
         if top2[1] - top2[0] > 2 * LOGIT_TOL * np.abs(ol).max():
             assert g_next == o_next
     om.close()
+
+
+# ---------------------------------------------------------------------------------------------- the C++ host's TP step (Fish::TPPhase + kf_tp_*)
+@pytest.mark.parametrize("cfg_name,world,use_graph", [("tiny", 2, False), ("small", 2, True), ("small", 8, True)])
+def test_native_tp_equals_python_stepped_tp_bit_for_bit(ctx, cfg_name, world, use_graph):
+    """The step in the C++ host with the exchange done by kernels (push into every rank's receive area, rank-ordered sum, arg-max pairs the
+    same way) against the Python-stepped VirtualTP with its in-process gathers: the same kernels and the same summation order, so logits and
+    ids are equal bit for bit -- eager and as one hipGraph per bucket -- and they follow the oracle's TP emulation."""
+    cfg = dict(synth.CONFIGS[cfg_name])
+    raw = synth.raw_weights_numpy(cfg, 31, w_std=0.1)
+    w, norms = full_weights_on_gpu(ctx, cfg, raw)
+    vt = TP.VirtualTP(cfg, w, norms, world, ctx)
+    nt = TP.NativeTP(cfg, w, norms, world, ctx)
+    prompt = prompt_ids(cfg, 10, seed=2)
+    tok = int(prompt[0])
+    for pos in range(14):
+        v_next = vt.step(tok, pos)
+        n_next = nt.step(tok, pos, use_graph=use_graph)
+        assert n_next == v_next, "pos %d" % pos
+        assert np.array_equal(u16(vt.logits()), nt.logits()), "pos %d" % pos
+        tok = int(prompt[pos + 1]) if pos + 1 < len(prompt) else v_next
+    om = oracle_model(cfg, raw, L.Q4, L.BF16, tp=world)
+    ids = nt.generate(prompt, 20, use_graph=True)
+    assert ids == vt.generate(prompt, 20)
+    assert ids == om.generate(prompt.tolist(), 20)
+    # a second run from position 0 reuses the same receive areas: tags never repeat, stale granules are never taken for fresh ones
+    assert nt.generate(prompt, 20, use_graph=True) == ids
+    assert nt.generate(prompt, 20, use_graph=False) == ids
+    nt.close()
+
+
+def test_native_tp8_on_32b_shaped_slice_long_context(ctx):
+    """Qwen3-32B shapes (2 layers, 8192-row vocabulary), TP=8, context 4096: ids at positions {128, 1024, 4095} after teacher-forced runs equal the
+    Python-stepped path's; every graph bucket up to 4096 is captured on the way."""
+    cfg = dict(synth.CONFIGS["qwen3-32b"], n_layer=2, vocab=8192, max_seq=4096, tied=True)
+    g = torch.Generator(device=ctx.device)
+    g.manual_seed(5)
+
+    def mat(r, c):
+        return (torch.randn(r, c, generator=g, device=ctx.device, dtype=torch.float32) * 0.05).to(torch.bfloat16)
+
+    def nrm(n):
+        return (1.0 + 0.01 * torch.randn(n, generator=g, device=ctx.device, dtype=torch.float32)).to(torch.bfloat16)
+    w, norms = {}, {}
+    w[(-1, 0)] = ctx.quantize(mat(cfg["vocab"], cfg["dim"]), L.BF16)
+    w[(-1, 1)] = w[(-1, 0)]
+    norms[(-1, 0)] = nrm(cfg["dim"])
+    for li in range(cfg["n_layer"]):
+        for si, s in enumerate(synth.SLOTS):
+            w[(li, si)] = ctx.quantize(mat(*synth.SHAPES[s](cfg)), L.Q4)
+        norms[(li, 0)], norms[(li, 1)], norms[(li, 2)], norms[(li, 3)] = nrm(cfg["dim"]), nrm(cfg["dim"]), nrm(128), nrm(128)
+    nt = TP.NativeTP(cfg, w, norms, 8, ctx)
+    forced = np.random.default_rng(11).integers(0, cfg["vocab"], size=cfg["max_seq"]).astype(np.int32)
+    nt.set_forced(forced)
+    nt.set_state(int(forced[0]), 0)
+    nt.run_steps(0, 4096, use_graph=True)
+    nt.check()
+    toks = [m.tokens_out(4096) for m in nt.ranks]
+    for t in toks[1:]:
+        assert np.array_equal(t, toks[0])                                  # every rank picked the same ids all the way
+    # the Python-stepped path on the same KV state: copy rank caches and replay single positions
+    vt = TP.VirtualTP(cfg, w, norms, 8, ctx)
+    for r, (a, b) in enumerate(zip(nt.ranks, vt.ranks)):
+        n = cfg["n_layer"] * cfg["max_seq"] * vt.plan.kvd_l * 2
+        cx = ctx.h
+        import ctypes as C
+        L.check(ctx.hip.kf_d2d(cx, C.c_void_p(b.kc.data_ptr()), C.c_void_p(a.host.kfh_kcache(a.h)), C.c_size_t(n)), "d2d")
+        L.check(ctx.hip.kf_d2d(cx, C.c_void_p(b.vc.data_ptr()), C.c_void_p(a.host.kfh_vcache(a.h)), C.c_size_t(n)), "d2d")
+    ctx.sync()
+    for pos in (128, 1024, 4095):
+        assert vt.step(int(forced[pos]), pos) == int(toks[0][pos]), "pos %d" % pos
+    nt.close()
