@@ -43,6 +43,11 @@ def main():
     ap.add_argument("--engine", type=int, default=-1, help="1: the layer loop as one persistent launch (kf_engine_*); 0: five launches per layer; -1: the library default")
     ap.add_argument("--streams", type=int, default=0, help="side measurement after the timed region: this many INDEPENDENT decoders (own weights, own "
                     "KV cache, own HIP stream) running concurrently on the GPU over the same positions; 0/1 = skip.  Never part of `value`.")
+    ap.add_argument("--tp-exchange", default="p2p", choices=["p2p", "rccl"], help="--config qwen3-32b --gpus N > 1 runs tensor parallel TP = N (BASELINE config 4): "
+                    "p2p = the C++ host's graph with kernel-side exchange over peer-mapped receive areas; rccl = the Python-stepped baseline with two "
+                    "torch.distributed all-gathers per layer")
+    ap.add_argument("--tp-virtual", type=int, default=0, help="side measurement on ONE GPU: this many TP ranks of qwen3-32b in one process, lock-step on one stream "
+                    "(the per-rank kernels and the exchange kernels of TP = R, serialised: R x the work of one rank's GPU, no xGMI)")
     args = ap.parse_args()
 
     import numpy as np
@@ -72,6 +77,8 @@ def main():
     K, W = args.steps, args.warmup
     if K < 1 or W < 0:
         raise SystemExit("steps >= 1, warmup >= 0")
+    if args.config == "qwen3-32b" and (world > 1 or args.tp_virtual > 1):
+        return tp_main(args, cfg, rank, world, dev)
     head_type = {"bf16": L.BF16, "q4": L.Q4, "nf4": L.NF4}[args.head]
     layer_type = {"q4": L.Q4, "bf16": L.BF16, "f8": L.F8E5M2, "ternary": L.T_SIGN, "1bit": L.BOOL1, "nf4": L.NF4}[args.layers]
     m = synth.build_on_gpu(cfg, seed=1234 + rank, layer_type=layer_type, head_type=head_type, device=dev)
@@ -188,6 +195,137 @@ def main():
 
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak of MI355X (MI355X_MICROARCH.md); the prefill GEMMs multiply bf16 fragments unpacked from 4-bit tiles
+
+
+def tp_main(args, cfg, rank, world, dev):
+    """BASELINE config 4: Qwen3-32B 4-bit greedy decode, tensor parallel over the GPUs of the node (TP = world; one process per GPU), or -- a
+    side measurement on one GPU -- R ranks of one process in lock-step (--tp-virtual R).  Every rank draws each full tensor on its own GPU from the
+    same seed and keeps its shard (koifish_amd.tp.TPPlan: q/k/v/gate/up by rows, o_proj/down_proj by columns, head by vocabulary rows).  The
+    timed region is K decode steps ending at the last position of the 4096-token context, after a token-serial run-up, with teacher-forced
+    ids for the first 128 positions.  `value` = tokens/s of the ONE sequence the node decodes (strong scaling: the model is split, not copied)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from koifish_amd import lib as L
+    from koifish_amd import synth
+    from koifish_amd import tp as TP
+    from koifish_amd.runtime import Context
+    virtual = world == 1
+    R = args.tp_virtual if virtual else world
+    if "KF_BENCH_TP_LAYERS" in os.environ:   # test hook only (tests/test_gpu_bench_ranks.py): a cut model; the line says so
+        cfg = dict(cfg, n_layer=int(os.environ["KF_BENCH_TP_LAYERS"]), vocab=int(os.environ.get("KF_BENCH_TP_VOCAB", cfg["vocab"])))
+    ctx = Context(dev)
+    plan = TP.TPPlan(cfg, R)
+    g = torch.Generator(device=ctx.device)
+    g.manual_seed(1234)
+
+    def mat(r, c):
+        return (torch.randn(r, c, generator=g, device=ctx.device, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+
+    def nrm(n):
+        return (1.0 + 0.01 * torch.randn(n, generator=g, device=ctx.device, dtype=torch.float32)).to(torch.bfloat16)
+
+    ranks = range(R) if virtual else [rank]
+    shards = {r: {} for r in ranks}
+    norms = {}
+    emb = ctx.quantize(mat(cfg["vocab"], cfg["dim"]), L.BF16)
+    head = emb if cfg.get("tied", True) else ctx.quantize(mat(cfg["vocab"], cfg["dim"]), L.BF16)
+    for r in ranks:
+        shards[r][(-1, 0)] = emb
+        shards[r][(-1, 1)] = TP.shard_rows(head, *plan.head_rows(r))
+    norms[(-1, 0)] = nrm(cfg["dim"])
+    for li in range(cfg["n_layer"]):
+        for si, s in enumerate(synth.SLOTS):
+            full = ctx.quantize(mat(*synth.SHAPES[s](cfg)), L.Q4)
+            for r in ranks:
+                shards[r][(li, si)] = plan.shard(s, full, r)
+            del full
+        norms[(li, 0)], norms[(li, 1)], norms[(li, 2)], norms[(li, 3)] = nrm(cfg["dim"]), nrm(cfg["dim"]), nrm(cfg["head_dim"]), nrm(cfg["head_dim"])
+    if head is not emb:
+        del head
+    torch.cuda.empty_cache()
+    S, K, W = cfg["max_seq"], args.steps, args.warmup
+    if W + K > S:
+        raise SystemExit("warmup + steps must fit the %d-token context of the TP run" % S)
+    forced = np.full(S, -1, dtype=np.int32)
+    forced[:128] = np.random.default_rng(7).integers(0, cfg["vocab"], size=128)
+    use_graph = not args.no_graph
+    bytes_rank = sum(x.algorithmic_bytes() for k, x in shards[ranks[0]].items() if k != (-1, 0)) + cfg["dim"] * 2
+    if args.tp_exchange == "rccl" and not virtual:
+        drv = TP.DistributedTP(TP.TPRank(plan, rank, ctx, shards[rank], norms))
+        tok, state = int(forced[0]), {"pos": 0}
+
+        def run(p0, n):
+            nonlocal tok
+            for p in range(p0, p0 + n):
+                nxt = drv.step(tok, p)
+                tok = int(forced[p + 1]) if p + 1 < S and forced[p + 1] >= 0 else nxt
+        check = lambda: None
+        path = "Python-stepped, 2 torch.distributed all_gather_into_tensor (RCCL) per layer + 1 per token, host pick"
+    else:
+        if virtual:
+            class _G:   # NativeTP wants the full weights; here the shards exist already
+                pass
+            nt = TP.NativeTP.__new__(TP.NativeTP)
+            nt.cfg, nt.ctx, nt.world, nt.plan = cfg, ctx, R, plan
+            nt.ranks = [TP.build_native_rank(cfg, plan, r, shards[r], norms, dev) for r in range(R)]
+            nt.host = nt.ranks[0].host
+            import ctypes as C
+            for a in nt.ranks:
+                for r, b in enumerate(nt.ranks):
+                    L.check(nt.host.kfh_tp_set_peer(a.h, r, C.c_void_p(nt.host.kfh_tp_area(b.h))), "kfh_tp_set_peer")
+            nt._hs = (C.c_void_p * R)(*[m.h for m in nt.ranks])
+            drv = nt
+        else:
+            drv = TP.NativeRank(cfg, plan, rank, shards[rank], norms, dev)
+        drv.set_forced(forced)
+        drv.set_state(int(forced[0]), 0)
+        run = lambda p0, n: drv.run_steps(p0, n, use_graph)
+        check = drv.check
+        path = "C++ host, one hipGraph per position bucket: per layer 2 x [mat-vec whose epilogue stores fp32 partials into every rank's peer-mapped receive area, " \
+               "rank-ordered sum kernel], arg-max pairs the same way; no collective call, no host round trip"
+    start = S - (W + K)
+    run(0, start)
+    run(start, W)
+    torch.cuda.synchronize()
+    if not virtual:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = ctx.event(), ctx.event()
+    t0 = time.perf_counter()
+    ctx.record(e0)
+    run(start + W, K)
+    ctx.record(e1)
+    torch.cuda.synchronize()
+    if not virtual:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    check()
+    if not virtual:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        ms = dt * 1e3 / K
+        kvd_l = plan.kvd_l
+        mean_pos = S - K / 2.0
+        step_bytes = bytes_rank + 2 * cfg["n_layer"] * mean_pos * kvd_l * 2
+        ach = step_bytes / (ms * 1e-3) / 1e9 * (R if virtual else 1)
+        out = {"metric": "tokens/sec/GPU Qwen3 4-bit prefill+decode; achieved HBM GB/s vs peak", "value": round(K / dt, 3), "unit": "tokens/s", "n_gpus": world, "steps": K,
+               "warmup": W, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "u4 weights (PackedQ RTN g128) x bf16 activations, fp32 accumulate; bf16 KV; fp32 partial sums exchanged", "data": "synthetic",
+               "config": {"workload": "Qwen3-32B 4-bit PackedQ greedy decode, tensor parallel TP=%d%s, context %d: timed positions %d..%d" % (
+                   R, " (all ranks on ONE GPU, lock-step: a side measurement, not a scaling point)" if virtual else " over %d MI355X" % world, S, S - K, S - 1),
+                   "layers": cfg["n_layer"], "vocab": cfg["vocab"], "tp": R, "exchange": args.tp_exchange if not virtual else "p2p (local pointers)", "decode_path": path, "hipgraph": use_graph,
+                   "device_ms_per_step": round(ctx.elapsed_ms(e0, e1) / K, 4), "weight_bytes_per_rank": int(bytes_rank)},
+               "roofline": {"bound": "hbm", "kernel": "one rank's decode step (its weight shards + its KV heads)", "bytes_per_step_per_rank": int(step_bytes),
+                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                            "note": "per GPU; %s" % ("R ranks share this GPU, so the per-rank rate is the step's bytes x R / time" if virtual else "every GPU streams its own shard")},
+               "scaling_curve": "none measured on hardware yet: this container's GPU boxes have one MI355X; the driver's N = 2, 4, 8 runs of this command produce it"}
+        print(json.dumps(out))
+    if not virtual and dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def prefill_rate(m, prompt, decode_ms_per_step, reps=5):

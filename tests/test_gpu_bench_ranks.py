@@ -36,3 +36,19 @@ def test_two_ranks_one_json_line():
     # whole-job rate = units of all ranks / max-over-ranks time
     assert abs(j["value"] - 2 * 96 / (j["ms_per_step"] * 96 / 1e3)) <= 1e-2 * j["value"]
     assert "roofline" in j and j["vs_baseline"] is None
+
+
+def test_two_ranks_tensor_parallel_line():
+    """`bench.py --config qwen3-32b --gpus 2` dispatches TP = 2 (BASELINE config 4) through the C++ host's graph with the kernel-side exchange; the two
+    ranks share GPU 0 here, their receive areas cross the process boundary as IPC handles.  Cut to 2 layers / 8192 vocabulary rows (test hook)."""
+    env = dict(os.environ, KF_BENCH_BACKEND="gloo", KF_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", KF_BENCH_TP_LAYERS="2", KF_BENCH_TP_VOCAB="8192")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "64", "--warmup", "16", "--config", "qwen3-32b"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0): %r" % lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 64 and j["scaling"] == "strong" and j["config"]["tp"] == 2 and j["config"]["exchange"] == "p2p"
+    assert abs(j["value"] - 64 / (j["ms_per_step"] * 64 / 1e3)) <= 1e-2 * j["value"]          # ONE sequence: tokens/s of the whole job
+    assert "roofline" in j and j["vs_baseline"] is None
