@@ -222,7 +222,10 @@ int kf_norm_linear(kf_ctx* ctx, const kf_bf16* x, const kf_bf16* norm_w_or_null,
 int kf_norm_gateup_swiglu(kf_ctx* ctx, const kf_bf16* x, const kf_bf16* norm_w_or_null, float eps, const kf_weight* gate, const kf_weight* up,
                           kf_bf16* act);
 /* q/k-norm + RoPE + attention in one pass: q raw [n_head*hd], k_raw [n_kv*hd] (the new key before norm/rope,
- * written normed+roped into kcache row pos), v row must already sit in vcache row pos. */
+ * written normed+roped into kcache row pos), v row must already sit in vcache row pos.
+ * Requirement on the caches (also kf_attn_decode, kf_engine_step): with d_pos the launch is laid out for positions up to `pos` (the bound) and loads K / V rows
+ * up to that bound before the device position is known; rows past the real position are masked by a zero probability, not by a select, so they must hold
+ * FINITE values (allocate the caches zero-filled, as KVCache::Init does: 0 * NaN would poison the output). */
 int kf_attn_block(kf_ctx* ctx, const kf_bf16* q_raw, const kf_bf16* k_raw, kf_bf16* kcache, const kf_bf16* vcache, kf_bf16* out,
                   const kf_bf16* wq_norm, const kf_bf16* wk_norm, const float* rope_table, int pos, const int32_t* d_pos, int n_head, int n_kv,
                   int hd, int kv_stride, float eps, void* scratch);

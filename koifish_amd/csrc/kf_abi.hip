@@ -79,7 +79,7 @@ int kf_init(int device, void* stream, kf_ctx** out) {
     *out = c;
     return KF_OK;
 }
-// ---- OPT-IN vendor GEMM (KF_GEMM_LIB=1; off by default) for LARGE token batches (training-size, n >= KF_GEMM_LIB_MIN = 2048 rows): the weight is
+// ---- OPT-IN vendor GEMM (KF_GEMM_LIB=1; off by default) for LARGE token batches (training-size, n >= 2048 rows): the weight is
 // dequantised to bf16 into the caller's scratch (what the reference's GetDataX does before every cuBLASLt call) and the plain bf16 GEMM goes to rocBLAS
 // -- a yardstick beside the fused dequant-GEMM kernels of kf_gemm*.hip, which serve every batch by default.  rocBLAS is resolved with dlopen so that
 // libkf_hip.so has no link-time dependency on it.
@@ -150,14 +150,7 @@ static int lib_weight_bf16(kf_ctx* c, const kf_weight* w, const uint16_t** out) 
     *out = (const uint16_t*)c->scratch;
     return r;
 }
-static int lib_gemm_min() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("KF_GEMM_LIB_MIN");
-        v = e ? atoi(e) : 2048;
-    }
-    return v;
-}
+static int lib_gemm_min() { return 2048; }
 
 int kf_destroy(kf_ctx* c) {
     if (!c) return KF_OK;
@@ -750,9 +743,7 @@ int kf_attn_prefill(kf_ctx* c, const kf_bf16* q, const kf_bf16* kc, const kf_bf1
     CHKCTX(c);
     if (!q || !kc || !vc || !out || n_tok < 1 || pos0 < 0) return fail(KF_INVALID_ARGS, "kf_attn_prefill: bad args");
     if (!al16(kc) || !al16(vc) || (kv_stride % 8)) return fail(KF_BLAS_UNALIGN, "kf_attn_prefill: cache not 16-byte aligned");
-    static int use_mfma = -1; /* KF_ATTN_PREFILL_MFMA=0: the per-token form of the decode kernel (fp32 probabilities) */
-    if (use_mfma < 0) use_mfma = getenv("KF_ATTN_PREFILL_MFMA") ? atoi(getenv("KF_ATTN_PREFILL_MFMA")) : 1;
-    if (use_mfma && n_tok >= 8) {
+    if (n_tok >= 8) { /* fewer tokens: the per-token form of the decode kernel */
         const int rc = kf::attn_prefill_mfma_launch(c->stream, q, kc, vc, out, pos0, n_tok, q_stride, n_head, n_kv, hd, kv_stride);
         if (rc < 0) return fail(rc, "kf_attn_prefill: launch failed (%d)", rc);
         if (rc == KF_OK) return KF_OK;

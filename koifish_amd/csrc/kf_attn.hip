@@ -301,13 +301,7 @@ __global__ void __launch_bounds__(64) qknorm_rope_kernel(uint16_t* q, uint16_t* 
 int attn_splits(int pos_bound, int n_kv) {
     // keys per slice: one workgroup streams a slice in batches of 64 keys (hd 128, 4 waves); short contexts stay in ONE slice per
     // kv-head (no cross-workgroup hand-off at all), long ones are cut so that the chip is covered.
-    static int slice = 0, single = 0;
-    if (!slice) {
-        const char* e = getenv("KF_ATTN_SLICE");
-        slice = e ? atoi(e) : 64;
-        const char* f = getenv("KF_ATTN_SINGLE");
-        single = f ? atoi(f) : 192;
-    }
+    constexpr int slice = 64, single = 192; /* keys per slice / longest context served by one slice (settled by the round-1 sweeps) */
     const int len = pos_bound + 1;
     if (len <= single) return 1;
     int nsp = (len + slice - 1) / slice;
@@ -338,9 +332,6 @@ int attn_launch(hipStream_t st, AttnArgs& a) {
     // one 64-key batch per 4-wave workgroup (one wave per SIMD: the kernel is bound by VALU issue inside a latency chain, so
     // spreading the keys over more CUs beats more waves per CU); 8 waves once the slices have to grow past 128 keys
     int NW = (GQ <= 2 && a.chunk > 128) ? 8 : 4;
-    static int nw_env = -1;
-    if (nw_env < 0) { const char* e = getenv("KF_ATTN_NW"); nw_env = e ? atoi(e) : 0; }
-    if (nw_env == 4 || (nw_env == 8 && GQ <= 2)) NW = nw_env;
     const size_t smem = sizeof(uint16_t) * ((size_t)GQ * hd + hd) + sizeof(float) * (NW * GQ + 4 + (size_t)NW * GQ * (hd + 4));
     dim3 grid(nsp, a.n_kv, a.n_tok);
 #define KF_ATTN_GO(gq, nw)                                                                              \

@@ -1031,25 +1031,20 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     }
     if (fmt == FMT_Q4 && q4p_ok && !(getenv("KF_Q4_PERM") && atoi(getenv("KF_Q4_PERM")) == 0)) fmt = FMT_Q4P;
     E->fmt = fmt, E->GQ = GQ, E->hd = hd, E->n_cu = n_cu, E->nwv = 8, E->shape_class = shape_class;
-    E->xmap = (shape_class == 1 && d->n_kv == 8 && !(getenv("KF_ENG_XMAP") && atoi(getenv("KF_ENG_XMAP")) == 0)) ? 1 : 0;
+    E->xmap = (shape_class == 1 && d->n_kv == 8) ? 1 : 0;
     for (int i = 0; i < 4; i++) a.spg[i] = E->plans[i].spg, a.nslots[i] = E->plans[i].total_slots, a.nblk[i] = E->plans[i].nBlk;
     // workspace carve
     char* p = reinterpret_cast<char*>(ws);
     a.ws = reinterpret_cast<int*>(p), p += 256;
     a.plans = reinterpret_cast<const EngPlan*>(p), p += 512;
     a.layers = reinterpret_cast<const EngLayer*>(p), p += ((size_t)d->n_layer * sizeof(EngLayer) + 255) & ~(size_t)255;
-    a.gls = 32, a.poll_sleep = 1;
-    if (const char* e = getenv("KF_ENG_GLS")) a.gls = atoi(e); /* tuning knobs of the hand-off (scratch/eng_stamps.py) */
-    if (const char* e = getenv("KF_ENG_SLEEP")) a.poll_sleep = atoi(e);
-    if (const char* e = getenv("KF_ENG_EXP")) a.exp_flags = atoi(e);
-    if (a.gls < 32 || a.gls > ENG_GLS_MAX || a.poll_sleep < 0) a.gls = 32, a.poll_sleep = 1;
+    a.gls = 32, a.poll_sleep = 1; /* granule line stride / sleep between sweeps: the sweeps over other values changed nothing */
     auto gran = [&](size_t n) {
         uint32_t* r = reinterpret_cast<uint32_t*>(p);
         p += (((n + 31) / 32) * (size_t)a.gls * 4 + 255) & ~(size_t)255;
         return r;
     };
-    a.ncopy = 1;
-    if (const char* e = getenv("KF_ENG_COPIES")) a.ncopy = atoi(e) == 8 ? 8 : 1;
+    a.ncopy = 1; /* replicated copies of the vectors (one per XCD) did not shorten a hand-off */
     char* const g0 = p;
     a.xA = gran(a.dim), a.qkv = gran((size_t)a.q_dim + 2 * a.kv_dim), a.ao = gran(a.q_dim), a.xB = gran(a.dim), a.act = gran(a.ffn);
     a.cstride = (int)((p - g0) / 4);

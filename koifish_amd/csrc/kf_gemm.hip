@@ -594,11 +594,7 @@ int gemm_launch(hipStream_t st, const kf_weight* w, const uint16_t* x, long long
     const int ttiles = (n + GM_TOK - 1) / GM_TOK;
     // prompt-sized batches on small matrices: the wave-independent kernel while its 32 x 32 workgroups fit ~2-3 rounds of the chip
     // (measured crossover against the staged tiles, scratch/ub_gemm.py: 1024 rows up to n ~ 1024, 2048 up to ~ 600, 3072 up to ~ 400)
-    static int direct_max = -1;
-    if (direct_max < 0) {
-        const char* e = getenv("KF_GEMM_DIRECT_MAX");
-        direct_max = e ? atoi(e) : 1280;
-    }
+    constexpr int direct_max = 1280;
     int KS = ((long)((M + 127) / 128) * ttiles < 512) ? 2 : 1;
     dim3 grid;
     if ((long)((M + 31) / 32) * ((n + 31) / 32) <= direct_max) {

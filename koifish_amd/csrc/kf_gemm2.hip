@@ -157,12 +157,8 @@ __global__ void __launch_bounds__(512) gemm2_kernel(const GemmArgs a) {
 
 // KF_OK launched, 1 = not for this kernel
 int gemm2_launch(hipStream_t st, int fmt, const GemmArgs& a) {
-    static int on = -1, min_wg = 0;
-    if (on < 0) {
-        on = getenv("KF_GEMM2") ? atoi(getenv("KF_GEMM2")) : 1;
-        min_wg = getenv("KF_GEMM2_MIN_WG") ? atoi(getenv("KF_GEMM2_MIN_WG")) : 128;
-    }
-    if (!on || (fmt != FMT_Q4 && fmt != FMT_BF16 && fmt != FMT_F8) || a.K % G2_BK != 0 || a.n < G2_BN) return 1;
+    constexpr int min_wg = 128; /* fewer workgroups than this: the staged / direct tiles of kf_gemm.hip fill the chip better */
+    if ((fmt != FMT_Q4 && fmt != FMT_BF16 && fmt != FMT_F8) || a.K % G2_BK != 0 || a.n < G2_BN) return 1;
     const dim3 grid((a.M + G2_BM - 1) / G2_BM, (a.n + G2_BN - 1) / G2_BN);
     if ((long)grid.x * grid.y < min_wg) return 1;
     const size_t smem = 2 * G2_STAGE;

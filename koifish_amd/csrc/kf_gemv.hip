@@ -565,12 +565,15 @@ int gemv_launch(hipStream_t st, GemvLaunch& L) {
     // small problems: one slot per wave (latency-bound, as many waves as slots); large ones: several rounds of resident waves so that
     // memory waits of one wave are covered by the dequant arithmetic of the others (measured: 25600x5120 q4 41 -> 33 us; the Qwen3-32B
     // q/k/v and o_proj launches, 22-28 MB each, 21.8 -> 19.1 and 16.1 -> 13.2 us; the 0.6B launches stay below the threshold)
-    long target_waves = L.target_waves > 0 ? L.target_waves : (raw_slots * (long)nBlk * (64 / (1 << lpr_log2)) >= (1L << 19) ? 16384 : 4096);
+    const long blocks_all = raw_slots * (long)nBlk * (64 / (1 << lpr_log2));
+    long target_waves = L.target_waves > 0 ? L.target_waves : (blocks_all >= (1L << 19) ? 16384 : 4096);
+    // the largest launches (>= 4 M blocks: the 25600-row FFN matrices of Qwen3-32B): two slots per wave through the buffer-load form, half the workgroups to
+    // start and half the x staging (25600 x 5120: 27.6 -> 26.4 us, A/B in one run; smaller launches lose more from the coarser tail than they gain)
+    if (L.target_waves <= 0 && blocks_all >= 4000000L && !a.row_map && fmt != FMT_Q4R) target_waves = 8192;
     if (const char* e = getenv("KF_GEMV_WAVES")) target_waves = atol(e); /* tuning knob */
     long spw = (raw_slots + target_waves - 1) / target_waves;
     if (spw < 1) spw = 1;
     int G = spw >= 4 ? 4 : (spw >= 2 ? 2 : 1);
-    if (const char* e = getenv("KF_GEMV_G")) G = atoi(e) < G ? atoi(e) : G;
     if (L.mode == GEMV_PAIRED && G > 2) G = 2; /* two weight streams per slot: keep register pressure down */
     spw = (spw + G - 1) / G * G;
     a.spw = (int)spw;

@@ -233,7 +233,28 @@ Fish::~Fish() {
     if (ctx) kf_destroy(ctx);
 }
 
+bool Fish::ShapeServed(const MODEL_CARD& c, std::string& why) {
+    const int gq = c.n_head_kv > 0 ? c.n_head / c.n_head_kv : 0;
+    if (c.n_head_kv <= 0 || c.n_head % c.n_head_kv != 0 || !(gq == 1 || gq == 2 || gq == 4 || gq == 8)) {
+        why = "query heads per kv head = " + std::to_string(c.n_head) + " / " + std::to_string(c.n_head_kv) + " (served: 1, 2, 4, 8)";
+        return false;
+    }
+    if (c.head_dim != 64 && c.head_dim != 128) {
+        why = "head_dim " + std::to_string(c.head_dim) + " (served: 64, 128)";
+        return false;
+    }
+    if (c.nEmbed % 8 != 0 || c.n_ff % 8 != 0) {
+        why = "hidden / intermediate size must be a multiple of 8";
+        return false;
+    }
+    return true;
+}
+static thread_local std::string g_host_err;
 int Fish::Build(const MODEL_CARD& card, int device, void* stream) {
+    if (!ShapeServed(card, g_host_err)) {
+        g_host_err = "Fish::Build: " + g_host_err;
+        return KF_UNSUPPORTED_DATATYPE;
+    }
     config = card;
     KF_TRY(kf_init(device, stream, &ctx));
     const int C = card.nEmbed, hd = card.head_dim, qd = card.n_head * hd, kvd = card.n_head_kv * hd;
@@ -612,6 +633,7 @@ void* kfh_create(int device, void* stream, int dim, int n_layer, int n_head, int
     return f;
 }
 void kfh_destroy(void* h) { delete reinterpret_cast<Fish*>(h); }
+const char* kfh_host_error(void) { return g_host_err.c_str(); } /* why the last kfh_create failed */
 void* kfh_ctx(void* h) { return reinterpret_cast<Fish*>(h)->ctx; }
 int kfh_set_fuse_level(void* h, int lvl) {
     reinterpret_cast<Fish*>(h)->fuse_level = lvl;

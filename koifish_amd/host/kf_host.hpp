@@ -235,6 +235,8 @@ struct Fish {
     hGTensor x;                   // residual stream
 
     ~Fish();
+    // the attention kernels are instantiated for query-group sizes 1, 2, 4, 8 and head_dim 64 / 128 (every Qwen3 size except the 14B's group of 5)
+    static bool ShapeServed(const MODEL_CARD& card, std::string& why);
     int Build(const MODEL_CARD& card, int device, void* stream);
     int pos_bound() const;  // launch-geometry bound for the current bucket
     // one token through every neuron (Fish::ForwardOnRLS, gLLM.cpp:722-787)

@@ -553,9 +553,22 @@ int K_SafeTensors::OpenFile(const std::string& path) {
         ST_Tensor t;
         t.name = kv.first, t.dtype = dt->str, t.file = file_id;
         size_t count = 1;
-        for (const auto& d : sh->arr) {
-            t.shape.push_back((int64_t)d.num);
-            count *= (size_t)d.num;
+        bool dims_ok = off->arr[0].kind == JSON::NUM && off->arr[1].kind == JSON::NUM && off->arr[0].num >= 0 && off->arr[1].num >= 0 && off->arr[0].num < 9.0e15 &&
+                       off->arr[1].num < 9.0e15;
+        for (const auto& d : sh->arr) { /* untrusted input: every dimension a non-negative integer, the element count without overflow */
+            if (d.kind != JSON::NUM || d.num < 0 || d.num > 1.0e15 || d.num != std::floor(d.num)) {
+                dims_ok = false;
+                break;
+            }
+            const size_t v = (size_t)d.num;
+            if (v != 0 && count > ((size_t)1 << 60) / v) dims_ok = false;
+            t.shape.push_back((int64_t)v);
+            count *= v;
+        }
+        if (!dims_ok) {
+            munmap(f.map, f.size), close(f.fd);
+            err = path + ": tensor entry '" + kv.first + "' has a malformed shape or data_offsets";
+            return KF_INVALID_ARGS;
         }
         t.begin = (size_t)off->arr[0].num, t.end = (size_t)off->arr[1].num;
         t.szData = (size_t)kv.second.number_or("szData", 0), t.szGama = (size_t)kv.second.number_or("szGama", 0);
@@ -947,10 +960,22 @@ Fish* LoadHF(const std::string& dir, int device, void* stream, typNUMBER layer_t
     card.n_ctx = max_seq > 0 ? max_seq : (max_pos < 4096 ? max_pos : 4096);
     if (card.nEmbed <= 0 || card.nLayer <= 0 || card.n_head <= 0 || card.n_head_kv <= 0 || card.head_dim <= 0 || card.n_ff <= 0 || card.vocab <= 0)
         return bail(KF_INVALID_ARGS, "config.json lacks hidden_size / num_hidden_layers / num_attention_heads / intermediate_size / vocab_size");
+    if (const JSON* mt = cfg.get("model_type"))
+        if (mt->kind == JSON::STR && mt->str != "qwen3")
+            return bail(KF_INVALID_ARGS, "config.json: model_type '" + mt->str + "' (this path builds the Qwen3 decoder: RMSNorm, q/k-norm, rotate-half RoPE, SwiGLU, no projection biases)");
+    {
+        std::string why;
+        if (!Fish::ShapeServed(card, why)) return bail(KF_UNSUPPORTED_DATATYPE, "config.json: " + why); /* before any tensor is quantised */
+    }
 
     K_SafeTensors st;
     int rc = st.OpenDir(dir);
     if (rc != KF_OK) return bail(rc, st.err);
+    for (const auto& t : st.tensors) { /* a Qwen2-style checkpoint would decode to wrong tokens with its biases dropped */
+        const std::string& n = t.name;
+        if (n.size() > 5 && n.compare(n.size() - 5, 5, ".bias") == 0 && (n.find("self_attn.") != std::string::npos || n.find("mlp.") != std::string::npos))
+            return bail(KF_INVALID_ARGS, "tensor '" + n + "': projection biases are not part of this decoder (Qwen3 has none)");
+    }
 
     std::unique_ptr<Fish> f(new Fish());
     rc = f->Build(card, device, stream);

@@ -115,6 +115,7 @@ def load():
         host.kfh_set_forced.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         host.kfh_set_state.argtypes = [C.c_void_p, C.c_int, C.c_int]
         host.kfh_last_error.restype = C.c_char_p
+        host.kfh_host_error.restype = C.c_char_p
         host.kfh_st_open.restype = C.c_void_p
         host.kfh_st_open.argtypes = [C.c_char_p, C.c_int]
         host.kfh_st_close.argtypes = [C.c_void_p]

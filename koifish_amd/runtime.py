@@ -323,6 +323,9 @@ class Qwen3:
                                       cfg["head_dim"], cfg["ffn"], cfg["vocab"], cfg["max_seq"], cfg.get("rms_eps", 1e-6), cfg.get("qk_eps", 1e-6),
                                       cfg.get("theta", 1e6), C.byref(rc))
         if not self.h:
+            why = self.host.kfh_host_error().decode()
+            if why:
+                raise L.KFError("kfh_create failed with %d: %s" % (rc.value, why))
             L.check(rc.value or -1, "kfh_create")
         self.h = C.c_void_p(self.h)
         self._keep = []

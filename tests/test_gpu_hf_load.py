@@ -144,3 +144,31 @@ def test_hf_autoawq_checkpoint(tmp_path):
     m.set_prefill_mode(1)
     assert m.generate(prompt, 8) == ids            # batched prefill falls back to the AWQ mat-vec per token row: same ids
     m.close()
+
+
+def test_unsupported_shapes_and_families_fail_early_with_a_reason(tmp_path):
+    """a group of 5 query heads per kv head (Qwen3-14B) or another model family is refused before any tensor is touched, with the reason"""
+    with pytest.raises(L.KFError, match="served: 1, 2, 4, 8"):
+        Qwen3(dict(synth.CONFIGS["tiny"], n_head=10, n_kv=2))
+    with pytest.raises(L.KFError, match="head_dim 96"):
+        Qwen3(dict(synth.CONFIGS["tiny"], head_dim=96))
+    cfg = synth.CONFIGS["tiny"]
+    raw = synth.raw_weights_numpy(cfg, 1, w_std=0.1)
+    write_hf(tmp_path, cfg, raw)
+    card = json.loads((tmp_path / "config.json").read_text())
+    (tmp_path / "config.json").write_text(json.dumps(dict(card, model_type="qwen2")))
+    with pytest.raises(L.KFError, match="model_type 'qwen2'"):
+        Qwen3.from_hf(tmp_path, max_seq=64)
+    (tmp_path / "config.json").write_text(json.dumps(dict(card, num_attention_heads=10)))
+    with pytest.raises(L.KFError, match="served: 1, 2, 4, 8"):
+        Qwen3.from_hf(tmp_path, max_seq=64)
+    # a checkpoint with projection biases (Qwen2 style) is refused rather than decoded without them
+    (tmp_path / "config.json").write_text(json.dumps(dict(card, model_type="qwen3")))
+    t = {"model.layers.0.self_attn.q_proj.bias": torch.zeros(cfg["n_head"] * cfg["head_dim"], dtype=torch.bfloat16)}
+    save_file(t, str(tmp_path / "extra.safetensors"))
+    import safetensors.torch as stt
+    allt = stt.load_file(str(tmp_path / "model.safetensors"))
+    allt.update(t)
+    save_file(allt, str(tmp_path / "model.safetensors"), metadata={"format": "pt"})
+    with pytest.raises(L.KFError, match="projection biases"):
+        Qwen3.from_hf(tmp_path, max_seq=64)

@@ -124,3 +124,19 @@ def test_reader_survives_mutated_headers(host, tmp_path):
             for name, (dt, shape, b0, b1) in _list(host, C.c_void_p(h)).items():
                 assert b0 <= b1 <= len(b)
             host.kfh_st_close(C.c_void_p(h))
+
+
+def test_malformed_shapes_and_offsets_are_refused(host, tmp_path):
+    """untrusted header numbers: negative, fractional, non-numeric or overflowing dimensions and offsets never reach the size arithmetic"""
+    def write(hdr, data=b"\x00" * 64):
+        text = json.dumps(hdr).encode()
+        p = tmp_path / "m.safetensors"
+        p.write_bytes(struct.pack("<Q", len(text)) + text + data)
+        return str(p).encode()
+    good = {"t": {"dtype": "F32", "shape": [4, 4], "data_offsets": [0, 64]}}
+    h = host.kfh_st_open(write(good), 0)
+    assert h
+    host.kfh_st_close(C.c_void_p(h))
+    for shape, off in (([-4, -4], [0, 64]), ([4.5, 4], [0, 64]), (["4", 4], [0, 64]), ([2 ** 40, 2 ** 40], [0, 64]), ([4, 4], [-1, 63]), ([4, 4], ["0", 64]),
+                       ([4, 4], [0, 1e300])):
+        assert not host.kfh_st_open(write({"t": {"dtype": "F32", "shape": shape, "data_offsets": off}}), 0), (shape, off)
