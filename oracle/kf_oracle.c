@@ -13,8 +13,12 @@
  *     independently, in numpy in tests/ -- the two must agree on random and on hand-built blocks),
  *   - BIT_SET_k/BIT_GET_k (src/Utils/CLI_params.cpp:2177-2207),
  *   - NF4/NF3 tables (src/g_float.hpp:542-569), AWQ nibble order (kernel/packedN.cuh:109-116).
- * For the mat-vec / attention ARITHMETIC the reference holds no golden vector, fixture or
- * known-answer test (cases/test_lite.py needs real weights + CUDA): **parity unpinned** there.
+ *   - outputs of the reference's own Python programs, executed in the build container and committed as vectors
+ *     (tests/golden/make_ref_python_vectors.py -> tests/test_oracle_ref_python.py): AutoAWQ unpack / order / dequant
+ *     (src/Python/test_awq.py), causal grouped-query attention (tile_wrapper/tl_qkv.py ref_program: score scale, mask,
+ *     which kv head a query head reads, softmax, PV), RMS normalisation (tile_wrapper/tl_norm.py ref_program).
+ * For the quantised mat-vec ARITHMETIC (and the bf16 rounding points of attention) the reference holds no golden vector,
+ * fixture or known-answer test (cases/test_lite.py needs real weights + CUDA): **parity unpinned** there.
  * Those functions follow the cited CUDA kernels line by line with every bf16 store made
  * round-to-nearest-even, and are cross-checked against an independent numpy restatement and (model
  * semantics only) HF transformers' Qwen3 at tiny random shapes (tests/golden/make_golden.py).
