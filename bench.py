@@ -174,7 +174,7 @@ def main():
         try:   # the time-dominant kernel of the step; the LM head (the byte-dominant launch) is reported beside it
             eng = engine_roofline(m, ctx, cfg, forced, timed_positions) if m.engine_steps() > 0 else None
             out["roofline"] = eng if eng else (matvec_roofline(m, ctx, cfg, head_rl) if args.layers == "q4" else head_rl)
-            out["config"]["decode_path"] = "persistent engine: embed, kf::engine_kernel (all layers), LM head, pick = 4 launches per token" if eng else \
+            out["config"]["decode_path"] = "persistent engine: kf::engine_kernel (embedding row + all layers), LM head, pick = 3 launches per token" if eng else \
                 "per-layer launches: 5 per layer"
         except Exception as e:
             out["roofline"] = head_rl

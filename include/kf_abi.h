@@ -391,6 +391,9 @@ size_t kf_engine_workspace_bytes(const kf_engine_desc* desc);
  * KF_UNSUPPORTED_DATATYPE: shapes / storage outside what the engine serves (the per-layer calls remain). */
 int kf_engine_create(kf_ctx* ctx, const kf_engine_desc* desc, void* workspace, size_t workspace_bytes, kf_engine** out);
 int kf_engine_step(kf_ctx* ctx, kf_engine* e, const kf_bf16* x_in, kf_bf16* x_out, const int32_t* d_state, int pos_bound);
+/* TokenEmbed::cuInfer inside the launch: with a bf16 embedding table set, kf_engine_step may be given x_in == NULL and reads the row of the state's token
+ * (or of d_forced[pos] when that is >= 0, as kf_embed_state does) itself.  NULL table: back to x_in.  KF_UNSUPPORTED_DATATYPE for other storages. */
+int kf_engine_set_embedding(kf_ctx* ctx, kf_engine* e, const kf_weight* embed_bf16_or_null, const int32_t* d_forced_or_null);
 int kf_engine_check(kf_ctx* ctx, kf_engine* e); /* synchronises; KF_INTERNAL_ERR when a hand-off poll has timed out since creation */
 int kf_engine_destroy(kf_engine* e);
 

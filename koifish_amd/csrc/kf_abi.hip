@@ -790,6 +790,8 @@ static int head_impl(kf_ctx* c, const kf_bf16* x, const kf_bf16* norm_w, float e
     L.args.amax_val = av, L.args.amax_idx = ai;
     r = kf::gemv_launch(c->stream, L);
     if (r) return fail(r, "%s: gemv failed with %d", who, r);
+    // (the pick stays its own 4-us launch: folded into this kernel behind an arrival ticket -- write-through partial stores, drained, one atomic per workgroup -- it
+    // measured 2-5 us SLOWER per step than the separate launch, and with a release fence per workgroup 170 us slower)
     if (d_argmax || d_state) kf::argmax_finish_launch(c->stream, av, ai, L.blocks, d_argmax, d_state, d_tokens_out); /* both NULL: logits only */
     return hipGetLastError() == hipSuccess ? KF_OK : fail(KF_HIP_CHECK, "%s: launch failed", who);
 }
@@ -999,6 +1001,14 @@ int kf_engine_step(kf_ctx* c, kf_engine* e, const kf_bf16* x_in, kf_bf16* x_out,
     const int rc = kf::engine_step(e->h, c->stream, x_in, x_out, d_state, pos_bound);
     if (rc < 0) return fail(rc, "kf_engine_step failed with %d", rc);
     return rc;
+}
+int kf_engine_set_embedding(kf_ctx* c, kf_engine* e, const kf_weight* embed_or_null, const int32_t* d_forced) {
+    CHKCTX(c);
+    if (!e || !e->h) return fail(KF_INVALID_ARGS, "kf_engine_set_embedding: null engine");
+    if (c->capturing) return fail(KF_INVALID_ARGS, "kf_engine_set_embedding: not while capturing");
+    const int rc = kf::engine_set_embedding(e->h, embed_or_null, d_forced);
+    if (rc != KF_OK) return fail(rc, "kf_engine_set_embedding: the fused row read takes a bf16 table of the engine's width (other storages keep kf_embed_state)");
+    return KF_OK;
 }
 int kf_engine_check(kf_ctx* c, kf_engine* e) {
     CHKCTX(c);

@@ -68,7 +68,10 @@ struct EngArgs {
     float eps, qk_eps;
     const float* rope_table;
     const int32_t* d_state; /* {token, pos} */
-    const uint16_t* x_in;   /* plain bf16 [dim]: the embedding row */
+    const uint16_t* x_in;   /* plain bf16 [dim]: the embedding row; NULL: the engine takes the row itself from `emb` (TokenEmbed::cuInfer inside the launch) */
+    const uint16_t* emb;    /* bf16 embedding table [emb_rows, dim] (engine_set_embedding) */
+    const int32_t* d_forced;
+    int emb_rows;
     uint16_t* x_out;        /* plain bf16 [dim]: the residual stream after the last layer */
     uint32_t *xA, *qkv, *ao, *xB, *act; /* granule buffers */
     unsigned long long* part;          /* [n_head][nsp][hd + 4] 8-byte granules */
@@ -386,10 +389,21 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
         // P1 (P4 adds this x as the residual)
         ENG_STAMP(0, 0);
         if (has1 || has4) {
-            if (l == 0)
-                eng_poll_stage<XCH, ND, true, true>(nullptr, a.x_in, tag, SH::P1.nBlk, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, a.gls, a.poll_sleep, &sw[0]);
-            else
+            if (l == 0) {
+                const uint16_t* x0 = a.x_in;
+                if (!x0) { /* embed_kernel's row choice: the state's token, overridden by a teacher-forced id at this position */
+                    int tok = a.d_state[0];
+                    if (a.d_forced) {
+                        const int f = a.d_forced[a.d_state[1]];
+                        if (f >= 0) tok = f;
+                    }
+                    if (tok < 0 || tok >= a.emb_rows) tok = 0;
+                    x0 = a.emb + (size_t)tok * a.dim;
+                }
+                eng_poll_stage<XCH, ND, true, true>(nullptr, x0, tag, SH::P1.nBlk, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, a.gls, a.poll_sleep, &sw[0]);
+            } else {
                 eng_poll_stage<XCH, ND, true, false>(a.xA + cbase, nullptr, tag, SH::P1.nBlk, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, a.gls, a.poll_sleep, &sw[0]);
+            }
         }
         ENG_STAMP(0, 1);
         __syncthreads();
@@ -1142,7 +1156,7 @@ static int engine_go_fmt(EngineHost* E, hipStream_t st) {
 // 1: this position bound is outside what the engine serves (the caller runs the multi-launch path), < 0 error
 int engine_step(EngineHost* E, hipStream_t st, const uint16_t* x_in, uint16_t* x_out, const int32_t* d_state, int pos_bound) {
     EngArgs& a = E->args;
-    if (!x_in || !x_out || !d_state || pos_bound < 0) return KF_INVALID_ARGS;
+    if ((!x_in && !a.emb) || !x_out || !d_state || pos_bound < 0) return KF_INVALID_ARGS;
     const int nsp = attn_splits(pos_bound, a.n_kv);
     const int chunk = (pos_bound + 1 + nsp - 1) / nsp;
     const int NW = (E->GQ <= 2 && chunk > 128) ? 8 : 4;
@@ -1158,6 +1172,16 @@ int engine_step(EngineHost* E, hipStream_t st, const uint16_t* x_in, uint16_t* x
         case FMT_Q4: return engine_go_fmt<FMT_Q4>(E, st);
         default: return 1;
     }
+}
+// bf16 embedding table for steps given x_in == NULL (the row is read inside the launch: one launch less per token)
+int engine_set_embedding(EngineHost* E, const kf_weight* w, const int32_t* d_forced) {
+    if (!w) {
+        E->args.emb = nullptr, E->args.d_forced = nullptr, E->args.emb_rows = 0;
+        return KF_OK;
+    }
+    if (w->type != KF_BF16 || w->quant != KF_QUANT_GROUP || w->qzeros || w->ne1 != E->args.dim || !w->data) return KF_UNSUPPORTED_DATATYPE;
+    E->args.emb = reinterpret_cast<const uint16_t*>(w->data), E->args.d_forced = d_forced, E->args.emb_rows = w->ne0;
+    return KF_OK;
 }
 int engine_error_word(EngineHost* E, hipStream_t st, int* h_err) {
     int v[2] = {0, 0};

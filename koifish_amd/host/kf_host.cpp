@@ -367,6 +367,9 @@ int Fish::EnsureEngine() {
         return KF_ENGINE_NOT_SERVED;
     }
     engine_state = 1;
+    // a bf16 embedding table is read inside the launch (graph-mode steps): one launch less per token; other storages keep kf_embed_state
+    kf_weight we = embed.w->desc();
+    engine_embed = kf_engine_set_embedding(ctx, engine, &we, d_forced) == KF_OK;
     return KF_OK;
 }
 
@@ -445,9 +448,17 @@ static int tp_group_enqueue(Fish** fs, int R) {
 
 int Fish::EnqueueStep(int bound) {
     if (tp.world > 1) return EnqueueStepTP();
+    if (use_engine && fuse_level >= 1 && engine_state > 0 && engine_embed && (graph_mode || state_tokens)) { /* embedding row read inside the launch */
+        const int rc = kf_engine_step(ctx, engine, nullptr, ToX(x), d_state, bound);
+        if (rc < 0) return rc;
+        if (rc == KF_OK) {
+            engine_steps++;
+            return head.cuInfer_1(x) ? KF_OK : KF_INTERNAL_ERR;
+        }
+    }
     hGTensor cur = embed.cuInfer(-1);
     if (!cur) return KF_INTERNAL_ERR;
-    if (use_engine && fuse_level >= 1 && engine_state > 0) {
+    if (use_engine && fuse_level >= 1 && engine_state > 0 && !(engine_embed && (graph_mode || state_tokens))) {
         const int rc = kf_engine_step(ctx, engine, ToX(cur), ToX(x), d_state, bound);
         if (rc < 0) return rc;
         if (rc == KF_OK) {

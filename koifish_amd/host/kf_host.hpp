@@ -214,6 +214,7 @@ struct Fish {
     kf_engine* engine = nullptr;
     void* engine_ws = nullptr;
     int engine_state = 0;  // 0 not tried, 1 built, -1 not served
+    bool engine_embed = false;  // the engine reads the (bf16) embedding row itself
     int EnsureEngine();
     int engine_steps = 0;  // steps enqueued (or captured) through the engine
     KVCache cache;
