@@ -477,13 +477,16 @@ def engine_roofline(m, ctx, cfg, forced, timed_positions, reps=12):
             n += 1
     ms, nbytes = tot_ms / n, tot_bytes / n
     ach = nbytes / (ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_src = None, None
     try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside this process): FETCH_SIZE x 2 (gfx950) + WRITE_SIZE
-        traffic = int(json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_engine.json")))["hbm_bytes_per_launch"])
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_engine.json")))
+        traffic = int(pj["hbm_bytes_per_launch"])
+        # a counter figure is only as fresh as its passes: say where it comes from and at what algorithmic size it was taken, so a stale one shows
+        traffic_src = "profiles/r02_pmc_engine.json: counter passes of scratch/ub_engine.py at position 1087 (%d algorithmic bytes there); not re-collected by this run" % int(pj["algorithmic_bytes_per_launch"])
     except Exception:
         pass
     return {"bound": "hbm", "kernel": "kf::engine_kernel = all %d layers of one decode step in one persistent launch (256 workgroups, hand-offs through tagged granules)" % cfg["n_layer"],
-            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "bytes_per_launch": int(nbytes), "us_per_launch": round(ms * 1e3, 2), "launches": 1, "positions": pos_list,
             "note": "latency-bound: %d layers x 6 dependent all-to-all phases; a phase's hand-off costs 1.9-3.2 us on this chip whatever it carries "
                     "(scratch/ub_handoff.hip), the layer's %.1f MB stream in %.1f us at the HBM peak" % (cfg["n_layer"], nbytes / cfg["n_layer"] / 1e6, nbytes / cfg["n_layer"] / HBM_PEAK_GBS / 1e3)}
