@@ -161,8 +161,11 @@ typedef struct kf_tp_comm {
     void* peer[8];       /* peer[r]: rank r's receive area as addressable from this process (peer[rank] == recv) */
     uint32_t* d_step;    /* device word, zero at start: generation */
     int32_t* d_err;      /* device word, zero at start */
+    void* d_push;        /* kf_tp_push_bytes(per_step) bytes of device memory: the push descriptors, written by kf_tp_commit */
 } kf_tp_comm;
 size_t kf_tp_recv_bytes(int world, int n_max);
+size_t kf_tp_push_bytes(uint32_t per_step);
+int kf_tp_commit(kf_ctx* ctx, const kf_tp_comm* comm); /* once every peer[] is set, before the first kf_linear_f32_push (not while capturing) */
 int kf_tp_alloc(kf_ctx* ctx, size_t bytes, void** out);              /* device memory other processes / devices may map; zeroed */
 int kf_tp_ipc_export(kf_ctx* ctx, void* p, unsigned char handle[64]); /* hipIpcGetMemHandle */
 int kf_tp_ipc_open(kf_ctx* ctx, const unsigned char handle[64], void** out);

@@ -10,6 +10,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <vector>
+
 #include "kf_kernels.h"
 
 struct kf_ctx {
@@ -440,6 +442,24 @@ static int tp_check(const kf_tp_comm* t, const char* who) {
 static unsigned long long* tp_vec_slot(void* area, const kf_tp_comm* t, uint32_t index, int rank) {
     return (unsigned long long*)area + ((size_t)(index & 1u) * t->world + rank) * t->n_max;
 }
+size_t kf_tp_push_bytes(uint32_t per_step) { return (size_t)per_step * sizeof(kf::TpPushDev); }
+int kf_tp_commit(kf_ctx* c, const kf_tp_comm* t) {
+    CHKCTX(c);
+    int r = tp_check(t, "kf_tp_commit");
+    if (r) return r;
+    if (!t->d_push) return fail(KF_INVALID_ARGS, "kf_tp_commit: d_push is null (kf_tp_push_bytes(per_step) bytes of device memory)");
+    if (c->capturing) return fail(KF_INVALID_ARGS, "kf_tp_commit: not while capturing");
+    std::vector<kf::TpPushDev> tab(t->per_step);
+    for (uint32_t i = 0; i < t->per_step; i++) {
+        kf::TpPushDev& d = tab[i];
+        memset(&d, 0, sizeof(d));
+        for (int p = 0; p < t->world; p++) d.peer[p] = tp_vec_slot(t->peer[p], t, i, t->rank);
+        d.step = t->d_step, d.per_step = t->per_step, d.index = i, d.world = t->world;
+    }
+    HIPCHK(hipMemcpyAsync(t->d_push, tab.data(), tab.size() * sizeof(kf::TpPushDev), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return KF_OK;
+}
 size_t kf_tp_recv_bytes(int world, int n_max) { return world < 1 || n_max < 1 ? 0 : ((size_t)2 * world * n_max + (size_t)2 * world) * 8; }
 int kf_tp_alloc(kf_ctx* c, size_t bytes, void** out) {
     CHKCTX(c);
@@ -485,8 +505,8 @@ int kf_linear_f32_push(kf_ctx* c, const kf_weight* w, const kf_bf16* x, const kf
     init_args(L);
     L.n = 1, L.w[0] = w, L.mode = kf::GEMV_PLAIN;
     L.args.x = x, L.args.job[0].y = nullptr;
-    L.args.tp_world = t->world, L.args.tp_step = t->d_step, L.args.tp_per_step = t->per_step, L.args.tp_index = index;
-    for (int p = 0; p < t->world; p++) L.args.tp_peer[p] = tp_vec_slot(t->peer[p], t, index, t->rank);
+    if (!t->d_push) return fail(KF_INVALID_ARGS, "kf_linear_f32_push: kf_tp_commit has not been called");
+    L.args.tp = reinterpret_cast<const kf::TpPushDev*>(t->d_push) + index;
     RET(kf::gemv_launch(c->stream, L));
 }
 int kf_tp_reduce_recv(kf_ctx* c, const kf_tp_comm* t, uint32_t index, int n, const kf_bf16* residual, kf_bf16* out) {

@@ -324,9 +324,10 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
                         y[r] = f2bf((gt * up) / (1.0f + kf_expf(-gt)));
                         continue;
                     }
-                    if (a.tp_world) { /* tensor-parallel push: one 8-byte {value | tag} granule into this rank's slot of every rank's receive area (kf_tp.hip) */
-                        const unsigned long long gr = ((unsigned long long)(*a.tp_step * a.tp_per_step + a.tp_index + 1u) << 32) | __float_as_uint(v);
-                        for (int p = 0; p < a.tp_world; p++) __hip_atomic_store(a.tp_peer[p] + r, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (a.tp) { /* tensor-parallel push: one 8-byte {value | tag} granule into this rank's slot of every rank's receive area (kf_tp.hip) */
+                        const TpPushDev& t = *a.tp;
+                        const unsigned long long gr = ((unsigned long long)(*t.step * t.per_step + t.index + 1u) << 32) | __float_as_uint(v);
+                        for (int p = 0; p < t.world; p++) __hip_atomic_store(t.peer[p] + r, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         continue;
                     }
                     if (a.yf) { /* un-rounded fp32 row dots: tensor-parallel partial sums (column-split o_proj / down_proj) */

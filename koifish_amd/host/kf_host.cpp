@@ -380,7 +380,9 @@ int Fish::TPInit(int rank, int world, int vocab_row0) {
     tp.rank = rank, tp.world = world, tp.vocab_row0 = vocab_row0;
     tp.comm.rank = rank, tp.comm.world = world, tp.comm.n_max = config.nEmbed, tp.comm.per_step = 2u * (uint32_t)config.nLayer + 1u;
     const size_t bytes = kf_tp_recv_bytes(world, config.nEmbed);
-    KF_TRY(kf_tp_alloc(ctx, bytes + 64, &tp.area)); /* + the generation and error words behind the area */
+    const size_t pbytes = kf_tp_push_bytes(tp.comm.per_step);
+    KF_TRY(kf_tp_alloc(ctx, bytes + 64 + pbytes, &tp.area)); /* + the generation and error words and the push descriptors behind the area */
+    tp.comm.d_push = reinterpret_cast<uint8_t*>(tp.area) + bytes + 64;
     tp.comm.recv = tp.area, tp.comm.peer[rank] = tp.area;
     tp.comm.d_step = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(tp.area) + bytes);
     tp.comm.d_err = reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(tp.area) + bytes + 32);
@@ -390,9 +392,19 @@ int Fish::TPInit(int rank, int world, int vocab_row0) {
 int Fish::TPSetPeer(int r, void* area) {
     if (tp.world < 2 || r < 0 || r >= tp.world || !area) return KF_INVALID_ARGS;
     tp.comm.peer[r] = area;
+    tp.committed = false;
+    return KF_OK;
+}
+int Fish::TPCommit() { /* the push descriptors are written once, when every peer's area is known (never inside a capture) */
+    if (tp.committed || tp.world < 2) return KF_OK;
+    for (int r = 0; r < tp.world; r++)
+        if (!tp.comm.peer[r]) return KF_INVALID_ARGS;
+    KF_TRY(kf_tp_commit(ctx, &tp.comm));
+    tp.committed = true;
     return KF_OK;
 }
 int Fish::TPPhase(int phase, int l) {
+    KF_TRY(TPCommit());
     const int32_t* d_pos = graph_mode ? d_state + 1 : nullptr;
     const int bound = graph_mode ? pos_bound() : tok_pos;
     const int C = config.nEmbed;
@@ -516,6 +528,7 @@ kf_graph* Fish::GraphFor(int pos) {
 
 int Fish::RunSteps(int pos, int n, bool use_graph) {
     if (pos < 0 || pos + n > config.n_ctx) return KF_INVALID_ARGS;
+    KF_TRY(TPCommit());
     for (int i = 0; i < n; i++) {
         const int p = pos + i;
         if (fuse_level == 0) {  // per-kernel launches only (AutoAWQ weights): eager, position from the host, token from the device state
@@ -881,6 +894,7 @@ int kfh_tp_group_run(void** hs, int R, int pos, int n, int use_graph) {
         if (fs[r]->tp.world != R || fs[r]->tp.rank != r) return KF_INVALID_ARGS;
     }
     if (pos < 0 || pos + n > fs[0]->config.n_ctx) return KF_INVALID_ARGS;
+    for (int r = 0; r < R; r++) KF_TRY(fs[r]->TPCommit());
     auto& graphs = fs[0]->tp.group_graphs;
     for (int i = 0; i < n; i++) {
         for (int r = 0; r < R; r++) fs[r]->tok_pos = pos + i, fs[r]->graph_mode = true;

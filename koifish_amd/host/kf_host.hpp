@@ -185,6 +185,7 @@ struct TPState {
     int rank = 0, world = 1, vocab_row0 = 0;
     kf_tp_comm comm;
     void* area = nullptr;
+    bool committed = false;             // kf_tp_commit done for the current peer set
     std::vector<void*> opened;          // IPC mappings of other processes' areas (closed with the Fish)
     std::vector<kf_graph*> group_graphs;  // ranks of ONE process stepped in lock-step on one stream: rank 0 keeps the group's graphs, one per bucket
 };
@@ -197,6 +198,7 @@ struct Fish {
     // One phase of a TP step: 0 embed | 1 attention half of `layer` up to the o_proj push | 2 its reduce | 3 FFN half up to the down_proj push |
     // 4 its reduce | 5 LM-head shard + arg-max push | 6 pick.  A rank that owns its GPU enqueues all of them in order (EnqueueStep); ranks that
     // share one stream are enqueued phase by phase across ranks (a reduce must not sit in the queue ahead of the pushes it waits for).
+    int TPCommit();
     int TPPhase(int phase, int layer);
     int EnqueueStepTP();
     CHAT_SAMPLER samp_params;
