@@ -318,10 +318,13 @@ int kf_quantize(kf_ctx* c, const kf_weight* w, const kf_bf16* src, int symmetric
 
 static void init_args(kf::GemvLaunch& L) { memset(&L, 0, sizeof(L)); L.args.alpha = 1.0f; }
 
+static const int KF_DEQ_GEMM_MIN = 2048; /* token rows from which a quantised weight is dequantised once and multiplied by the bf16 tile kernel (when scratch was handed over) */
 size_t kf_linear_scratch_bytes(const kf_weight* w, int nTok) {
     if (!w || nTok < 1) return 0;
     if (w->qzeros) return kf::awq_scratch_bytes(w);
     if (w->quant != KF_QUANT_GROUP) return (size_t)w->ne0 * w->ne1 * 2; /* row forms: GetDataX into the scratch (the 4-bit row codebook only for token batches the tile kernels do not cover) */
+    // training-size batches of a quantised weight: one dequantise pass (a few % of the product at >= 2048 rows) buys the 256 x 256 bf16 tile kernel (kf_gemm3.hip)
+    if (w->type != KF_BF16 && nTok >= KF_DEQ_GEMM_MIN && w->ne0 >= 256 && (w->ne1 % 64) == 0) return (size_t)w->ne0 * w->ne1 * 2;
     return 0;
 }
 int kf_set_scratch(kf_ctx* c, void* scratch, size_t bytes) {
@@ -382,6 +385,18 @@ int kf_linear(kf_ctx* c, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const
         memset(&wb, 0, sizeof(wb));
         wb.data = Wd, wb.type = KF_BF16, wb.ne0 = w->ne0, wb.ne1 = w->ne1;
         return kf_linear(c, &wb, x, y, bias, nTok, alpha, beta, epilogue, residual);
+    }
+    if (nTok >= KF_DEQ_GEMM_MIN && w->type != KF_BF16 && w->quant == KF_QUANT_GROUP && w->ne0 >= 256 && (w->ne1 % 64) == 0 && c->scratch &&
+        c->scratch_bytes >= (size_t)w->ne0 * w->ne1 * 2 && (long)((w->ne0 + 255) / 256) * ((nTok + 255) / 256) >= 128) {
+        // GetDataX into the caller's scratch, then the 256 x 256 bf16 tile kernel: the reference's own order, on our own kernels
+        r = kf::dequant_launch(c->stream, w, (uint16_t*)c->scratch);
+        if (r != KF_OK) return fail(r, "kf_linear (dequantise for the large-batch tile kernel) failed with %d", r);
+        kf_weight wb;
+        memset(&wb, 0, sizeof(wb));
+        wb.data = c->scratch, wb.type = KF_BF16, wb.ne0 = w->ne0, wb.ne1 = w->ne1;
+        const int rc = kf::gemm_launch(c->stream, &wb, x, w->ne1, nTok, y, w->ne0, bias, alpha, beta, (epilogue & KF_EPI_RESIDUAL) ? residual : nullptr, w->ne0);
+        if (rc < 0) return fail(rc, "kf_linear (large-batch bf16 tile GEMM) failed with %d", rc);
+        if (rc == KF_OK) return KF_OK;
     }
     if (nTok >= gemm_min) {
         const int rc = kf::gemm_launch(c->stream, w, x, w->ne1, nTok, y, w->ne0, bias, alpha, beta, (epilogue & KF_EPI_RESIDUAL) ? residual : nullptr, w->ne0);

@@ -601,6 +601,8 @@ int gemm_launch(hipStream_t st, const kf_weight* w, const uint16_t* x, long long
         KS = 0;
         grid = dim3((M + 31) / 32, (n + 31) / 32);
     } else {
+        const int rc3 = gemm3_launch(st, g.fmt, a); /* bf16 operands, >= 128 tiles of 256 x 256: the global_load_lds tile kernel (kf_gemm3.hip) */
+        if (rc3 != 1) return rc3;
         const int rc2 = gemm2_launch(st, g.fmt, a); /* large batches: the producer / consumer tile kernel when it applies */
         if (rc2 != 1) return rc2;
         const int rows_per_wg = 32 * (4 / KS);

@@ -144,5 +144,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[TB], const Gem
 
 // kf_gemm2.hip: large-batch tile kernel; KF_OK launched, 1 = not for this kernel
 int gemm2_launch(hipStream_t st, int fmt, const GemmArgs& a);
+// kf_gemm3.hip: 256 x 256 x 64 bf16 tiles staged by global_load_lds; KF_OK launched, 1 = not for this kernel
+int gemm3_launch(hipStream_t st, int fmt, const GemmArgs& a);
 
 }  // namespace kf

@@ -25,6 +25,7 @@ A = [dict(x=z(N, Cn), h1=z(N, Cn), m1=z(N, dt=torch.float32), r1=z(N, dt=torch.f
           r2=z(N, dt=torch.float32), f=z(N, 4 * Cn), g=z(N, 4 * Cn)) for _ in range(NL)]
 xf, hf, mf, rf = z(N, Cn), z(N, Cn), z(N, dt=torch.float32), z(N, dt=torch.float32)
 qc = z(N, Cn); logits = z(N, Vp); losses = z(N, dt=torch.float32)
+for _ws in layers[0]: ctx.linear_scratch(_ws, N)   # kernels never allocate: the dequantise-then-multiply workspace of training-size batches (kf_linear_scratch_bytes)
 def lin(w, xin, y, n, b, res=None):
     d = w.desc()
     L.check(ctx.hip.kf_linear(ctx.h, C.byref(d), xin.data_ptr(), y.data_ptr(), b.data_ptr() if b is not None else None, n, 1.0, 0.0, 1 if res is not None else 0, res.data_ptr() if res is not None else None), "lin")

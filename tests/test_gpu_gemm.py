@@ -140,3 +140,47 @@ def test_gemm_many_token_tiles_vs_exact(ctx, O, t):
     # and the last rows as a batch of their own: <= 1 bf16 ulp apart
     y2 = _run(ctx, dw, x[-100:], 100, m)
     assert close_bf16(O.f32_to_bf16(y[-100:].astype(np.float32)), y2).all()
+
+
+@pytest.mark.parametrize("m,k,nt", [(4096, 1024, 2048), (4100, 512, 2050), (8192, 64, 4096)])
+def test_large_batch_bf16_tile_kernel(ctx, O, m, k, nt):
+    """the 256 x 256 x 64 global_load_lds tile kernel (kf_gemm3.hip: bf16 operands, >= 128 tiles) against the fp32 product of the same bf16 values: ragged last tiles in
+    both dimensions, and the epilogue (alpha, beta, bias, residual) in gemm_epilogue's order"""
+    g = torch.Generator(device=ctx.device)
+    g.manual_seed(m + k + nt)
+    W = (torch.randn(m, k, generator=g, device=ctx.device) * 0.05).to(torch.bfloat16)
+    X = torch.randn(nt, k, generator=g, device=ctx.device).to(torch.bfloat16)
+    dw = ctx.quantize(W, L.BF16)
+    d = dw.desc()
+    y = torch.zeros(nt, m, dtype=torch.bfloat16, device=ctx.device)
+    assert ctx.hip.kf_linear(ctx.h, C.byref(d), X.data_ptr(), y.data_ptr(), None, nt, 1.0, 0.0, 0, None) == 0, ctx.hip.kf_last_error()
+    ref = X.float() @ W.float().t()
+    scale = ref.abs().max().item()
+    assert (y.float() - ref).abs().max().item() <= 2.0 ** -8 * scale
+    bias = (torch.randn(m, generator=g, device=ctx.device) * 0.1).to(torch.bfloat16)
+    res = torch.randn(nt, m, generator=g, device=ctx.device).to(torch.bfloat16)
+    y0 = torch.randn(nt, m, generator=g, device=ctx.device).to(torch.bfloat16)
+    y2 = y0.clone()
+    assert ctx.hip.kf_linear(ctx.h, C.byref(d), X.data_ptr(), y2.data_ptr(), bias.data_ptr(), nt, 0.5, 2.0, 1, res.data_ptr()) == 0, ctx.hip.kf_last_error()
+    want = (res.float() + (0.5 * ref + 2.0 * y0.float() + bias.float()).to(torch.bfloat16).float()).to(torch.bfloat16)
+    assert (y2.float() - want.float()).abs().max().item() <= 2.0 ** -6 * max(scale, want.float().abs().max().item())
+    ctx.sync()
+
+
+def test_training_size_batch_of_a_quantised_weight_takes_the_dequantise_then_tile_path(ctx, O):
+    """>= 2048 token rows with the caller's scratch set (kf_linear_scratch_bytes says how much): GetDataX into the scratch, then the bf16 tile kernel.  The product of the
+    SAME dequantised values, so it agrees with the fused dequant-GEMM kernels to the fp32 summation order (<= 1 bf16 ulp of the row scale)."""
+    m, k, nt = 4096, 1024, 2048
+    rng = np.random.default_rng(5)
+    w = O.f32_to_bf16(rng.normal(0, 0.02, size=(m, k)).astype(np.float32))
+    dw = ctx.upload_blob(L.Q4, m, k, O.quantize(w, m, k, L.Q4).blob())
+    x = O.f32_to_bf16(rng.normal(0, 1.0, size=(nt, k)).astype(np.float32))
+    d = dw.desc()
+    assert ctx.hip.kf_linear_scratch_bytes(C.byref(d), nt) == m * k * 2 and ctx.hip.kf_linear_scratch_bytes(C.byref(d), 1024) == 0
+    fused = _run(ctx, dw, x, nt, m)                       # no scratch handed over: the fused kernels
+    assert ctx.linear_scratch(dw, nt) == m * k * 2
+    tiled = _run(ctx, dw, x, nt, m)
+    a, b = O.bf16_to_f32(fused), O.bf16_to_f32(tiled)
+    assert np.abs(a - b).max() <= 2.0 ** -7 * np.abs(a).max() and (a != b).mean() < 0.2
+    L.check(ctx.hip.kf_set_scratch(ctx.h, None, 0), "kf_set_scratch")
+    ctx._lin_ws = None
