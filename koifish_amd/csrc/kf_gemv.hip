@@ -32,7 +32,9 @@ struct Batch {
 // LDS: x as u32x4 chunks [XCH][nBlk] (K*2 bytes) | 256 B reduction scratch.
 // Each wave keeps two batches of G blocks in flight: the first batch is issued BEFORE the x prologue so that the
 // weight stream's HBM latency overlaps the (dependent) activation load + norm.
-template <int FMT, int G, int MODE, bool SPARSE>
+// ONEJOB: a launch with a single matrix (o_proj, down_proj, LM head, sparse rows) never reads the descriptors of jobs 1 and 2: kernel arguments are fetched ahead of the
+// first load, and every one a launch touches is on its critical path
+template <int FMT, int G, int MODE, bool SPARSE, bool ONEJOB>
 __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     using BD = BlockDot<FMT>;
     constexpr bool PAIRED = (MODE == GEMV_PAIRED), LUT = (FMT == FMT_Q4R);
@@ -68,10 +70,12 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     // a.job[] with a run-time value inside the loop would turn each access into a load from the kernarg segment whose wait
     // serialises the weight stream.
     int jx = 0;
-    if (a.njobs > 1 && s_begin >= a.job[1].slot0) jx = 1;
-    if (a.njobs > 2 && s_begin >= a.job[2].slot0) jx = 2;
-    jx = __builtin_amdgcn_readfirstlane(jx);
-#define JF(f) (jx == 0 ? a.job[0].f : (jx == 1 ? a.job[1].f : a.job[2].f))
+    if constexpr (!ONEJOB) {
+        if (a.njobs > 1 && s_begin >= a.job[1].slot0) jx = 1;
+        if (a.njobs > 2 && s_begin >= a.job[2].slot0) jx = 2;
+        jx = __builtin_amdgcn_readfirstlane(jx);
+    }
+#define JF(f) (ONEJOB ? a.job[0].f : (jx == 0 ? a.job[0].f : (jx == 1 ? a.job[1].f : a.job[2].f)))
     const u32x4* const jw = reinterpret_cast<const u32x4*>(JF(w));
     const u32x4* const jw2 = reinterpret_cast<const u32x4*>(a.job[1].w);
     const uint16_t* const jstep = JF(step);
@@ -487,14 +491,28 @@ int gemv_lpr_log2(int nBlk, long rows) {
     return lpr_log2;
 }
 
+template <int FMT, int MODE, bool SPARSE, bool ONEJOB>
+static void launch_j(const GemvArgs& a, int G, dim3 grid, size_t smem, hipStream_t st) {
+    if (G >= 4)
+        hipLaunchKernelGGL((gemv_kernel<FMT, 4, MODE, SPARSE, ONEJOB>), grid, dim3(256), smem, st, a);
+    else if (G == 2)
+        hipLaunchKernelGGL((gemv_kernel<FMT, 2, MODE, SPARSE, ONEJOB>), grid, dim3(256), smem, st, a);
+    else
+        hipLaunchKernelGGL((gemv_kernel<FMT, 1, MODE, SPARSE, ONEJOB>), grid, dim3(256), smem, st, a);
+}
 template <int FMT, int MODE, bool SPARSE>
 static void launch_g(const GemvArgs& a, int G, dim3 grid, size_t smem, hipStream_t st) {
-    if (G >= 4)
-        hipLaunchKernelGGL((gemv_kernel<FMT, 4, MODE, SPARSE>), grid, dim3(256), smem, st, a);
-    else if (G == 2)
-        hipLaunchKernelGGL((gemv_kernel<FMT, 2, MODE, SPARSE>), grid, dim3(256), smem, st, a);
-    else
-        hipLaunchKernelGGL((gemv_kernel<FMT, 1, MODE, SPARSE>), grid, dim3(256), smem, st, a);
+    // paired launches read job 1 by name; the arg-max head and the sparse forms are single-matrix by construction
+    if constexpr (MODE == GEMV_PAIRED) {
+        launch_j<FMT, MODE, SPARSE, false>(a, G, grid, smem, st);
+    } else if constexpr (MODE == GEMV_ARGMAX || SPARSE) {
+        launch_j<FMT, MODE, SPARSE, true>(a, G, grid, smem, st);
+    } else {
+        if (a.njobs == 1)
+            launch_j<FMT, MODE, SPARSE, true>(a, G, grid, smem, st);
+        else
+            launch_j<FMT, MODE, SPARSE, false>(a, G, grid, smem, st);
+    }
 }
 template <int FMT>
 static void launch_m(const GemvArgs& a, int mode, int G, dim3 grid, size_t smem, hipStream_t st) {
