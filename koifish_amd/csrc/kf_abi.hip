@@ -869,11 +869,16 @@ int kf_gelu(kf_ctx* c, const kf_bf16* x, kf_bf16* y, size_t n) {
     if (!x || !y || n == 0) return fail(KF_INVALID_ARGS, "kf_gelu: bad args");
     RET(kf::gelu_launch(c->stream, x, y, n));
 }
-// scratch layout of kf_linear_backward: [W bf16 OC*IC][W^T bf16 IC*OC][deltaIn^T bf16 OC*n][inp^T bf16 IC*n][bias slabs fp64 ceil(n/256)*OC], each 256-B aligned
+// scratch layout of kf_linear_backward: [W bf16 OC*IC][middle][bias slabs fp64 ceil(n/256)*OC], each 256-B aligned; the middle region is either the transposed copies
+// [W^T bf16 IC*OC][deltaIn^T bf16 OC*n][inp^T bf16 IC*n] of the small-shape path or the partial-tile slots of the large tile kernel's stream-K form (kf_gemm3.hip)
 static size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+static size_t lbw_mid_bytes(int OC, int IC, int n) {
+    const size_t t = up256((size_t)OC * IC * 2) + up256((size_t)OC * n * 2) + up256((size_t)IC * n * 2), k = up256(kf::gemm3_sk_ws_bytes());
+    return t > k ? t : k;
+}
 size_t kf_linear_backward_scratch_bytes(int OC, int IC, int n) {
     if (OC < 1 || IC < 1 || n < 1) return 0;
-    return 2 * up256((size_t)OC * IC * 2) + up256((size_t)OC * n * 2) + up256((size_t)IC * n * 2) + up256((size_t)((n + 255) / 256) * OC * 8);
+    return up256((size_t)OC * IC * 2) + lbw_mid_bytes(OC, IC, n) + up256((size_t)((n + 255) / 256) * OC * 8);
 }
 int kf_linear_backward(kf_ctx* c, const kf_weight* w, const kf_bf16* deltaIn, const kf_bf16* inp, kf_bf16* delta, kf_bf16* gW, kf_bf16* gBias, int n, int accumulate_delta,
                        void* scratch) {
@@ -890,7 +895,7 @@ int kf_linear_backward(kf_ctx* c, const kf_weight* w, const kf_bf16* deltaIn, co
         if (!al16(deltaIn) || (inp && !al16(inp)) || (delta && !al16(delta)) || (gW && !al16(gW)) || ((uintptr_t)scratch & 255))
             return fail(KF_BLAS_UNALIGN, "kf_linear_backward: tensors must be 16-byte aligned, scratch 256-byte aligned");
         uint16_t* const Wl = (uint16_t*)scratch; /* the dequantised weight, then the column-sum slabs: inside kf_linear_backward_scratch_bytes */
-        double* const slabs_l = (double*)((char*)scratch + 2 * up256((size_t)OC * IC * 2) + up256((size_t)OC * n * 2) + up256((size_t)IC * n * 2));
+        double* const slabs_l = (double*)((char*)scratch + up256((size_t)OC * IC * 2) + lbw_mid_bytes(OC, IC, n));
         if (gBias) {
             r = kf::colsum_add_launch(c->stream, deltaIn, gBias, n, OC, slabs_l);
             if (r != KF_OK) return fail(r, "kf_linear_backward: bias column sums failed with %d", r);
@@ -917,14 +922,25 @@ int kf_linear_backward(kf_ctx* c, const kf_weight* w, const kf_bf16* deltaIn, co
     uint16_t* Wd = (uint16_t*)p;    p += up256((size_t)OC * IC * 2);
     uint16_t* WdT = (uint16_t*)p;   p += up256((size_t)OC * IC * 2);
     uint16_t* dInT = (uint16_t*)p;  p += up256((size_t)OC * n * 2);
-    uint16_t* inpT = (uint16_t*)p;  p += up256((size_t)IC * n * 2);
-    double* slabs = (double*)p;
+    uint16_t* inpT = (uint16_t*)p;
+    double* slabs = (double*)((char*)scratch + up256((size_t)OC * IC * 2) + lbw_mid_bytes(OC, IC, n));
+    void* const sk_ws = WdT; /* the middle region: stream-K slots when the large tile kernel takes the shape, the transposed copies otherwise */
+    const size_t sk_bytes = lbw_mid_bytes(OC, IC, n);
     if (gBias) {
         r = kf::colsum_add_launch(c->stream, deltaIn, gBias, n, OC, slabs);
         if (r != KF_OK) return fail(r, "kf_linear_backward: bias column sums failed with %d", r);
     }
     if (delta) { /* delta [n, IC] (+)= deltaIn [n, OC] . W [OC, IC]: rows of W^T are contiguous in the contraction index OC */
-        r = kf::dequant_launch(c->stream, w, Wd);
+        const uint16_t* Wsrc = (const uint16_t*)w->data;
+        r = KF_OK;
+        if (w->type != KF_BF16) r = kf::dequant_launch(c->stream, w, Wd), Wsrc = Wd;
+        if (r != KF_OK) return fail(r, "kf_linear_backward: dequantise of the weight failed with %d", r);
+        // large shapes: the 256x256 tile kernel reads W as the K-MAJOR operand it already is (contraction over its OC rows): no transpose
+        r = kf::gemm3_km_launch(c->stream, Wsrc, IC, true, deltaIn, OC, false, n, IC, OC, delta, IC, nullptr, 1.0f, accumulate_delta ? 1.0f : 0.0f, sk_ws, sk_bytes);
+        if (r < 0) return fail(r, "kf_linear_backward: input-gradient GEMM failed with %d", r);
+    }
+    if (delta && r == 1) {
+        r = w->type == KF_BF16 ? kf::dequant_launch(c->stream, w, Wd) : KF_OK;
         if (r == KF_OK) r = kf::transpose_bf16_launch(c->stream, Wd, WdT, OC, IC);
         if (r != KF_OK) return fail(r, "kf_linear_backward: dequantise / transpose of the weight failed with %d", r);
         kf_weight wt;
@@ -933,7 +949,12 @@ int kf_linear_backward(kf_ctx* c, const kf_weight* w, const kf_bf16* deltaIn, co
         r = kf::gemm_launch(c->stream, &wt, deltaIn, OC, n, delta, IC, nullptr, 1.0f, accumulate_delta ? 1.0f : 0.0f, nullptr, IC);
         if (r != KF_OK) return fail(r < 0 ? r : KF_INVALID_ARGS, "kf_linear_backward: input-gradient GEMM not covered (%d)", r);
     }
-    if (gW) { /* gW [OC, IC] += deltaIn^T [OC, n] . inp [n, IC]: "weight" = inp^T [IC, n], "tokens" = the OC rows of deltaIn^T, contraction over n */
+    int rg = 1;
+    if (gW) { /* both operands are k-major for the contraction over the n token rows: inp [n][IC] is the "weight" side, deltaIn [n][OC] the "token" side */
+        rg = kf::gemm3_km_launch(c->stream, inp, IC, true, deltaIn, OC, true, OC, IC, n, gW, IC, nullptr, 1.0f, 1.0f, sk_ws, sk_bytes);
+        if (rg < 0) return fail(rg, "kf_linear_backward: weight-gradient GEMM failed with %d", rg);
+    }
+    if (gW && rg == 1) { /* gW [OC, IC] += deltaIn^T [OC, n] . inp [n, IC]: "weight" = inp^T [IC, n], "tokens" = the OC rows of deltaIn^T, contraction over n */
         r = kf::transpose_bf16_launch(c->stream, deltaIn, dInT, n, OC);
         if (r == KF_OK) r = kf::transpose_bf16_launch(c->stream, inp, inpT, n, IC);
         if (r != KF_OK) return fail(r, "kf_linear_backward: operand transposes failed with %d", r);

@@ -10,6 +10,8 @@
 //   * workgroup order remapped so that the blocks an XCD runs back to back share their W row-tile in that XCD's L2.
 // Measured on random operands (scratch/ub_gemm3.hip): 4096^3 997 TFLOP/s, 8192^3 1029, GPT2-1558M shapes (8192 tokens) 726-843, head 50304 x 1600 831.
 // The epilogue is gemm_epilogue's (alpha, beta, bias, one bf16 store, residual added to the rounded value).
+#include <string.h>
+
 #include "kf_gemm_common.h"
 
 namespace kf {
@@ -30,35 +32,58 @@ __device__ __forceinline__ void g3_stage(const uint16_t* __restrict__ src, long 
     }
 }
 
-__global__ void __launch_bounds__(512) gemm3_kernel(const GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+// the same 32 KiB tile from a K-MAJOR operand (src[k][row], `row` contiguous: an activation or a weight as it lies in memory when the contraction runs over its ROWS --
+// both GEMMs of SLP::Back): the LDS image is [64 k][256 rows] (512-byte k-rows), one wave instruction = two k-rows; its 32-byte blocks are XOR-swizzled by k & 3 so
+// that the transposing fragment read below (4 k-rows x 32 bytes per 16 lanes) touches 4 different bank groups.
+__device__ __forceinline__ void g3_stage_km(const uint16_t* __restrict__ src, long long ld, int row0, int nrows, int k0, unsigned char* lds_tile, int wid, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int j = wid * 4 + i;                 /* k-rows 2j, 2j + 1 */
+        const int kr = 2 * j + (lane >> 5), p = lane & 31, c = p ^ ((kr & 3) << 1);
+        int col = row0 + c * 8;
+        col = col + 8 <= nrows ? col : (nrows - 8 > 0 ? nrows - 8 : 0); /* chunks past the end re-read the last whole chunk: their outputs are not stored (rows % 8 == 0) */
+        const uint16_t* g = src + (size_t)(k0 + kr) * ld + col;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(lds_tile + j * 1024), 16, 0, 0);
+    }
+}
+// fragment (8 consecutive k of row `row`, k = kbase .. kbase + 7) of a k-major tile: two ds_read_b64_tr_b16, each a 4 (k) x 16 (rows) block transposed across 16 lanes
+// (lane i of the 16 receives D[(i >> 2) + 4 j][i & 3], scratch/dbg/ds_read_tr_probe.hip): lane l16 reads k-row kbase + (l16 >> 2), 8-byte piece l16 & 3 of the 16-row block
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 g3_frag_km(const unsigned char* tile, int rowblk16, int kbase, int l16) {
+    bf16x4 h[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int k = kbase + 4 * t + (l16 >> 2);
+        const int byte_in_row = (rowblk16 * 16 + 4 * (l16 & 3)) * 2, c = byte_in_row >> 4, p = c ^ ((k & 3) << 1);
+        h[t] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(tile + k * 512 + p * 16 + (byte_in_row & 8)));
+    }
+    return bf16x8{h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
+}
+
+// k-tiles kt0 .. kt1 - 1 of the output tile at (m0, t0) accumulated into acc (the caller zeroes it)
+template <bool AKM, bool BKM>
+__device__ __forceinline__ void g3_mainloop(const GemmArgs& a, int m0, int t0, int kt0, int kt1, f32x4 (&acc)[8][4], unsigned char* smem_raw, int wid, int lane) {
     const int wm = wid >> 2, wn = wid & 3;
-    const int nbx = (a.M + G3_BM - 1) / G3_BM, nby = (a.n + G3_BN - 1) / G3_BN, nwg = nbx * nby;
-    // bijective XCD remap: the blocks with equal blockIdx % 8 (one XCD under round-robin placement) get consecutive tiles
-    const int orig = blockIdx.x, q = nwg / 8, rr = nwg % 8, xcd = orig % 8;
-    const int wg = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + orig / 8;
-    const int bx = wg % nbx, by = wg / nbx;
-    const int m0 = bx * G3_BM, t0 = by * G3_BN;
-    const int nkt = a.K / G3_BK;
     const uint16_t* const W = reinterpret_cast<const uint16_t*>(a.w);
     auto bufA = [&](int b) { return smem_raw + (size_t)b * 2 * G3_TILE; };
     auto bufB = [&](int b) { return smem_raw + (size_t)b * 2 * G3_TILE + G3_TILE; };
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    g3_stage(W, a.K, m0, a.M, 0, bufA(0), wid, lane);
-    g3_stage(a.x, a.ldx, t0, a.n, 0, bufB(0), wid, lane);
+    // AKM: W is [K][M] with row stride a.ldr (re-used field: the residual is not served by the k-major forms); BKM: x is [K][n] with row stride a.ldx
+    auto stageA = [&](int k0, unsigned char* dst) {
+        if constexpr (AKM) g3_stage_km(W, a.ldr, m0, a.M, k0, dst, wid, lane);
+        else g3_stage(W, a.K, m0, a.M, k0, dst, wid, lane);
+    };
+    auto stageB = [&](int k0, unsigned char* dst) {
+        if constexpr (BKM) g3_stage_km(a.x, a.ldx, t0, a.n, k0, dst, wid, lane);
+        else g3_stage(a.x, a.ldx, t0, a.n, k0, dst, wid, lane);
+    };
+    stageA(kt0 * G3_BK, bufA(0));
+    stageB(kt0 * G3_BK, bufB(0));
     const int r16 = lane & 15, q4 = lane >> 4;
-    for (int kt = 0; kt < nkt; kt++) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) {
-            g3_stage(W, a.K, m0, a.M, (kt + 1) * G3_BK, bufA(cur ^ 1), wid, lane);
-            g3_stage(a.x, a.ldx, t0, a.n, (kt + 1) * G3_BK, bufB(cur ^ 1), wid, lane);
+    for (int kt = kt0; kt < kt1; kt++) {
+        const int cur = (kt - kt0) & 1;
+        if (kt + 1 < kt1) {
+            stageA((kt + 1) * G3_BK, bufA(cur ^ 1));
+            stageB((kt + 1) * G3_BK, bufB(cur ^ 1));
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); /* k-tile kt has landed; the 8 loads of k-tile kt+1 stay in flight */
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -69,13 +94,21 @@ __global__ void __launch_bounds__(512) gemm3_kernel(const GemmArgs a) {
             bf16x8 af[8], bfr[4];
 #pragma unroll
             for (int nt = 0; nt < 4; nt++) {
-                const int row = wn * 64 + nt * 16 + r16, c = kk * 4 + q4;
-                bfr[nt] = *reinterpret_cast<const bf16x8*>(bufB(cur) + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+                if constexpr (BKM) {
+                    bfr[nt] = g3_frag_km(bufB(cur), wn * 4 + nt, kk * 32 + 8 * q4, r16);
+                } else {
+                    const int row = wn * 64 + nt * 16 + r16, c = kk * 4 + q4;
+                    bfr[nt] = *reinterpret_cast<const bf16x8*>(bufB(cur) + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+                }
             }
 #pragma unroll
             for (int mt = 0; mt < 8; mt++) {
-                const int row = wm * 128 + mt * 16 + r16, c = kk * 4 + q4;
-                af[mt] = *reinterpret_cast<const bf16x8*>(bufA(cur) + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+                if constexpr (AKM) {
+                    af[mt] = g3_frag_km(bufA(cur), wm * 8 + mt, kk * 32 + 8 * q4, r16);
+                } else {
+                    const int row = wm * 128 + mt * 16 + r16, c = kk * 4 + q4;
+                    af[mt] = *reinterpret_cast<const bf16x8*>(bufA(cur) + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+                }
             }
 #pragma unroll
             for (int mt = 0; mt < 8; mt++)
@@ -85,7 +118,11 @@ __global__ void __launch_bounds__(512) gemm3_kernel(const GemmArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier(); /* every wave is done reading buffer `cur`: the next iteration's loads may overwrite it */
     }
-    // epilogue (gemm_epilogue's order): lane holds rows m .. m+3 of a 16 x 16 tile for token column r16
+}
+// epilogue (gemm_epilogue's order): lane holds rows m .. m+3 of a 16 x 16 tile for token column r16
+template <bool AKM>
+__device__ __forceinline__ void g3_epilogue(const GemmArgs& a, int m0, int t0, const f32x4 (&acc)[8][4], int wid, int lane) {
+    const int wm = wid >> 2, wn = wid & 3, r16 = lane & 15, q4 = lane >> 4;
     const bool vec_ok = ((a.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 7) == 0);
 #pragma unroll
     for (int mt = 0; mt < 8; mt++)
@@ -105,7 +142,7 @@ __global__ void __launch_bounds__(512) gemm3_kernel(const GemmArgs a) {
                     if (a.beta != 0.0f) v = v + a.beta * bf2f(yp[j]);
                     if (a.bias) v = v + bf2f(a.bias[m + j]);
                     uint16_t qv = f2bf(v);
-                    if (a.residual) qv = f2bf(bf2f(a.residual[(size_t)tok * a.ldr + m + j]) + bf2f(qv));
+                    if (!AKM && a.residual) qv = f2bf(bf2f(a.residual[(size_t)tok * a.ldr + m + j]) + bf2f(qv));
                     o[j] = qv;
                 }
             }
@@ -118,20 +155,164 @@ __global__ void __launch_bounds__(512) gemm3_kernel(const GemmArgs a) {
             }
         }
 }
+// bijective XCD remap: the blocks with equal blockIdx % 8 (one XCD under round-robin placement) get consecutive logical indices
+__device__ __forceinline__ int g3_remap(int orig, int nwg) {
+    const int q = nwg / 8, rr = nwg % 8, xcd = orig % 8;
+    return (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + orig / 8;
+}
+
+template <bool AKM, bool BKM>
+__global__ void __launch_bounds__(512) gemm3_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nbx = (a.M + G3_BM - 1) / G3_BM, nby = (a.n + G3_BN - 1) / G3_BN, nwg = nbx * nby;
+    const int wg = g3_remap(blockIdx.x, nwg);
+    const int bx = wg % nbx, by = wg / nbx;
+    const int m0 = bx * G3_BM, t0 = by * G3_BN;
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    g3_mainloop<AKM, BKM>(a, m0, t0, 0, a.K / G3_BK, acc, smem_raw, wid, lane);
+    g3_epilogue<AKM>(a, m0, t0, acc, wid, lane);
+}
+
+// SPLIT-K forms for launches with fewer tiles than CUs (a weight gradient [OC, IC] is 49 .. 175 tiles, its contraction 8192 token rows long).  The pieces are cut so
+// that the workgroups an XCD runs side by side stay at the SAME k (they share operand strips in that XCD's L2; ranges of a plain stream-K cut drift apart in k and
+// every workgroup then streams its own strips through the fabric -- measured: 496 TFLOP/s):
+//   S >= 2 (2 P <= 256):  every tile's k-tiles are cut in S equal pieces, P S workgroups; piece 0 owns the tile;
+//   S == 1 (P < 256 < 2 P): workgroup t < P owns tile t and multiplies k-tiles [0, kp); H helpers take the tails [kp, nkt) of m tiles each, one after the other
+//                          (kp = nkt m / (m + 1): an owner and a helper finish together).
+// A non-owner leaves its fp32 partial in a slot of `ws` with write-through stores and raises the slot's flag; the owner adds the partials in slot order -- a fixed
+// order: the result does not depend on timing -- and runs the epilogue.  flags are zeroed by the host before the launch; all workgroups are resident (<= 256, one per CU).
+struct G3SkArgs {
+    float* ws;       /* [<= 256][256 * 256] */
+    uint32_t* flags; /* [<= 256] */
+    int P, S, m, kp;
+};
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t g3_rsrc(const void* p, uint32_t bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000); }
+template <bool AKM, bool BKM>
+__global__ void __launch_bounds__(512) gemm3_sk_kernel(const GemmArgs a, const G3SkArgs s) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nbx = (a.M + G3_BM - 1) / G3_BM, nkt = a.K / G3_BK;
+    const int w = g3_remap(blockIdx.x, gridDim.x);
+    int t_first, t_last, k0, k1, slot0, nparts;
+    bool owner;
+    if (s.S >= 2) {
+        const int sp = w / s.P;
+        t_first = t_last = w % s.P, k0 = (int)((long long)nkt * sp / s.S), k1 = (int)((long long)nkt * (sp + 1) / s.S);
+        owner = sp == 0, nparts = s.S - 1, slot0 = t_first * (s.S - 1) + (owner ? 0 : sp - 1);
+    } else if (w < s.P) {
+        t_first = t_last = w, k0 = 0, k1 = s.kp, owner = true, nparts = 1, slot0 = w;
+    } else {
+        t_first = (w - s.P) * s.m, t_last = t_first + s.m - 1 < s.P - 1 ? t_first + s.m - 1 : s.P - 1;
+        k0 = s.kp, k1 = nkt, owner = false, nparts = 0, slot0 = t_first;
+    }
+    for (int tile = t_first; tile <= t_last; tile++) {
+        const int bx = tile % nbx, by = tile / nbx, m0 = bx * G3_BM, t0 = by * G3_BN;
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        g3_mainloop<AKM, BKM>(a, m0, t0, k0, k1, acc, smem_raw, wid, lane);
+        if (!owner) {
+            const int slot = slot0 + (tile - t_first);
+            const __amdgpu_buffer_rsrc_t rs = g3_rsrc(s.ws + (size_t)slot * (G3_BM * G3_BN), G3_BM * G3_BN * 4);
+#pragma unroll
+            for (int i = 0; i < 32; i++) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i >> 2][i & 3]), rs, (i * 512 + tid) * 16, 0, 16 /* sc1 */);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(s.flags + slot, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            for (int j = 0; j < nparts; j++) {
+                const int slot = slot0 + j;
+                if (tid == 0) {
+                    for (int spins = 0; spins < (1 << 24); spins++) {
+                        if (__hip_atomic_load(s.flags + slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) break;
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                }
+                __syncthreads();
+                const __amdgpu_buffer_rsrc_t rs = g3_rsrc(s.ws + (size_t)slot * (G3_BM * G3_BN), G3_BM * G3_BN * 4);
+#pragma unroll
+                for (int g = 0; g < 4; g++) { /* 8 loads in flight at a time: the accumulators hold half the register file */
+                    f32x4 pv[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ((g * 8 + i) * 512 + tid) * 16, 0, 16 /* sc1 */));
+#pragma unroll
+                    for (int i = 0; i < 8; i++) acc[(g * 8 + i) >> 2][i & 3] += pv[i];
+                    asm volatile("" ::: "memory");
+                }
+            }
+            g3_epilogue<AKM>(a, m0, t0, acc, wid, lane);
+        }
+    }
+}
 
 // KF_OK launched, 1 = not for this kernel (the caller's other tile kernels take the shape), < 0 error.  bf16 "weights" only: quantised ones are dequantised first.
+template <bool AKM, bool BKM>
+static int g3_go(hipStream_t st, const GemmArgs& a, long nwg, void* ws, size_t ws_bytes) {
+    static int attr_set = 0;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)gemm3_kernel<AKM, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G3_TILE) != hipSuccess) return KF_HIP_CHECK;
+        if (hipFuncSetAttribute((const void*)gemm3_sk_kernel<AKM, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G3_TILE) != hipSuccess) return KF_HIP_CHECK;
+        attr_set = 1;
+    }
+    // split-K when the tiles are fewer than 4/5 of the CUs, the caller lent the workspace, and the pieces stay >= 8 k-tiles long
+    const int G = 256, nkt = a.K / G3_BK;
+    if (ws && ws_bytes >= gemm3_sk_ws_bytes() && 5 * nwg < 4 * G) {
+        G3SkArgs s;
+        s.ws = (float*)ws, s.flags = (uint32_t*)((char*)ws + (size_t)G * G3_BM * G3_BN * 4);
+        s.P = (int)nwg, s.S = G / s.P, s.m = 0, s.kp = 0;
+        int nlaunch;
+        if (s.S >= 2) {
+            while (s.S > 1 && nkt / s.S < 8) s.S--;
+            nlaunch = s.P * s.S;
+        } else {
+            s.m = (s.P + (G - s.P) - 1) / (G - s.P);
+            s.kp = (int)(((long long)nkt * s.m + s.m / 2) / (s.m + 1));
+            nlaunch = s.P + (s.P + s.m - 1) / s.m;
+            if (nkt - s.kp < 8) s.S = 0;
+        }
+        if ((s.S >= 2) || (s.S == 1 && s.m > 0)) {
+            if (hipMemsetAsync(s.flags, 0, G * sizeof(uint32_t), st) != hipSuccess) return KF_HIP_CHECK;
+            hipLaunchKernelGGL((gemm3_sk_kernel<AKM, BKM>), dim3(nlaunch), dim3(512), 4 * G3_TILE, st, a, s);
+            return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+        }
+    }
+    if (nwg < 64) return 1;
+    hipLaunchKernelGGL((gemm3_kernel<AKM, BKM>), dim3((unsigned)nwg), dim3(512), 4 * G3_TILE, st, a);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+size_t gemm3_sk_ws_bytes() { return (size_t)256 * G3_BM * G3_BN * 4 + 4096; }
 int gemm3_launch(hipStream_t st, int fmt, const GemmArgs& a) {
     if (fmt != FMT_BF16 || a.K % G3_BK != 0 || a.K < G3_BK || a.n < G3_BN || a.M < G3_BM) return 1;
     if ((a.ldx & 7) != 0 || (reinterpret_cast<uintptr_t>(a.x) & 15) != 0 || (reinterpret_cast<uintptr_t>(a.w) & 15) != 0 || (a.K & 7) != 0) return 1;
     const long nwg = (long)((a.M + G3_BM - 1) / G3_BM) * ((a.n + G3_BN - 1) / G3_BN);
     if (nwg < 128) return 1; /* fewer tiles than half the CUs: the 128-row tile kernels fill the chip better */
-    static int attr_set = 0;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G3_TILE) != hipSuccess) return KF_HIP_CHECK;
-        attr_set = 1;
-    }
-    hipLaunchKernelGGL(gemm3_kernel, dim3((unsigned)nwg), dim3(512), 4 * G3_TILE, st, a);
-    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+    return g3_go<false, false>(st, a, nwg, nullptr, 0);
+}
+// y[n, M] = alpha * sum_k B(k, tok) A(k, m) + beta * y (+ bias) with either operand stored K-MAJOR: akm: A = w[K][lda] (element (k, m) at k * lda + m), else w[M][K];
+// bkm: B = x[K][ldb], else x[n][ldb].  The two GEMMs of SLP::Back without a transpose of anything:  delta[n, IC] = deltaIn[n, OC] . W[OC, IC]  (A = W k-major),
+// gW[OC, IC] += deltaIn^T . inp  (A = inp[n][IC] k-major, B = deltaIn[n][OC] k-major, contraction over the n token rows).  1 = shape not served.
+// ws (gemm3_sk_ws_bytes() bytes, 16-byte aligned) lends the stream-K form its partial-tile slots; NULL = one workgroup per tile only.
+int gemm3_km_launch(hipStream_t st, const uint16_t* A, long long lda, bool akm, const uint16_t* B, long long ldb, bool bkm, int n, int M, int K, uint16_t* y, long long ldy,
+                    const uint16_t* bias, float alpha, float beta, void* ws, size_t ws_bytes) {
+    if (K % G3_BK != 0 || K < G3_BK || n < G3_BN || M < G3_BM || (M & 7) || (n & 7) || (lda & 7) || (ldb & 7)) return 1;
+    if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return 1;
+    const long nwg = (long)((M + G3_BM - 1) / G3_BM) * ((n + G3_BN - 1) / G3_BN);
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.w = reinterpret_cast<const unsigned char*>(A), a.M = M, a.K = K, a.x = B, a.ldx = ldb, a.n = n, a.y = y, a.ldy = ldy, a.bias = bias, a.alpha = alpha, a.beta = beta;
+    a.ldr = lda; /* the k-major A operand's row stride */
+    if (!akm && lda != K) return 1; /* the row-major A form reads rows of K */
+    if (akm && bkm) return g3_go<true, true>(st, a, nwg, ws, ws_bytes);
+    if (akm) return g3_go<true, false>(st, a, nwg, ws, ws_bytes);
+    if (bkm) return g3_go<false, true>(st, a, nwg, ws, ws_bytes);
+    return g3_go<false, false>(st, a, nwg, ws, ws_bytes);
 }
 
 }  // namespace kf

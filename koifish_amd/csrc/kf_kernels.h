@@ -82,6 +82,10 @@ int gemv_fmt_of(const kf_weight* w);    /* FMT_* of a weight, < 0: not served by
 void argmax_finish_launch(hipStream_t st, const float* val, const int* idx, int n, int32_t* d_argmax, int32_t* d_state, int32_t* d_tokens_out);
 
 // ---- token-batch GEMM on MFMA (kf_gemm.hip): KF_OK launched, 1 = shape not eligible (caller loops the mat-vec), < 0 error
+// the 256 x 256 tile kernel on K-MAJOR operands (kf_gemm3.hip): the two GEMMs of SLP::Back without transposes.  1 = shape not served
+int gemm3_km_launch(hipStream_t st, const uint16_t* A, long long lda, bool akm, const uint16_t* B, long long ldb, bool bkm, int n, int M, int K, uint16_t* y, long long ldy,
+                    const uint16_t* bias, float alpha, float beta, void* ws, size_t ws_bytes);
+size_t gemm3_sk_ws_bytes();
 int gemm_launch(hipStream_t st, const kf_weight* w, const uint16_t* x, long long ldx, int n, uint16_t* y, long long ldy, const uint16_t* bias, float alpha,
                 float beta, const uint16_t* residual, long long ldr);
 

@@ -101,6 +101,18 @@ def test_linear_forward_large_batch(ctx):
             assert (np.abs(f(u16(y)[r_]) - f(o_row)) <= 2.0 ** -6 * np.abs(f(o_row)).max()).all()   # up to three bf16 roundings apart at the top of the range
 
 
+@pytest.mark.parametrize("t", [L.Q4, L.BF16])
+@pytest.mark.parametrize("shape", [(2048, 2048, 2048), (1600, 6400, 2048), (4800, 1600, 4096), (1600, 1600, 8192), (2048, 2056, 2048)])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_linear_backward_large_k_major(ctx, t, shape, accumulate):
+    """shapes with >= 64 tiles of 256 x 256: both GEMMs run the large tile kernel on K-MAJOR operands (W as it lies for the input gradient; inp and deltaIn
+    as they lie for the weight gradient, contraction over the token rows) -- no transposes; ragged M (1600 = 6.25 tiles, 2056) included"""
+    OC, IC, n = shape
+    if t == L.Q4 and IC % 128:
+        pytest.skip("group size")
+    _run(ctx, t, OC, IC, n, accumulate)
+
+
 def test_linear_backward_fixed_weight_and_no_bias(ctx):
     _run(ctx, L.Q4, 512, 1024, 96, False, with_bias=False, want_gw=False)   # isFixWeight: input gradient only; n need not be a multiple of 64 then
 
