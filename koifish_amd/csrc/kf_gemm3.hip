@@ -12,6 +12,8 @@
 // The epilogue is gemm_epilogue's (alpha, beta, bias, one bf16 store, residual added to the rounded value).
 #include <string.h>
 
+#include <type_traits>
+
 #include "kf_gemm_common.h"
 
 namespace kf {
@@ -19,32 +21,35 @@ namespace kf {
 constexpr int G3_BM = 256, G3_BN = 256, G3_BK = 64;
 constexpr int G3_TILE = G3_BM * G3_BK * 2; /* 32 KiB per operand tile */
 
-// one operand tile (256 rows x 128 B) = 32 wave instructions of 1 KiB (8 rows each); wave `wid` issues instructions 4 wid .. 4 wid + 3
-__device__ __forceinline__ void g3_stage(const uint16_t* __restrict__ src, long long ld, int row0, int nrows, int k0, unsigned char* lds_tile, int wid, int lane) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int j = wid * 4 + i;
-        const int r = j * 8 + (lane >> 3), p = lane & 7, c = p ^ ((r >> 1) & 7);
-        int gr = row0 + r;
-        gr = gr < nrows ? gr : nrows - 1; /* rows past the end re-read the last row: their outputs are not stored */
-        const uint16_t* g = src + (size_t)gr * ld + k0 + c * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(lds_tile + j * 1024), 16, 0, 0);
-    }
+// one operand tile (256 rows x 2 BK bytes) = BK / 2 wave instructions of 1 KiB; wave `wid` issues BK / 16 of them.  BK = 64: 8 rows per instruction, chunk c of row r
+// at position c ^ ((r >> 1) & 7); BK = 32: 16 rows per instruction (64-byte rows), chunk c at position c ^ ((r >> 2) & 3) -- either way a fragment read
+// (16 rows x one 16-byte chunk) touches all 64 banks once.
+template <int BK>
+__device__ __forceinline__ const uint16_t* g3_src(const uint16_t* __restrict__ src, long long ld, int row0, int nrows, int i, int wid, int lane) {
+    constexpr int CPR = BK / 8, RPI = 64 / CPR; /* chunks per row, rows per instruction */
+    const int j = wid * (BK / 16) + i;
+    const int r = j * RPI + lane / CPR, p = lane % CPR, c = BK == 64 ? p ^ ((r >> 1) & 7) : p ^ ((r >> 2) & 3);
+    int gr = row0 + r;
+    gr = gr < nrows ? gr : nrows - 1; /* rows past the end re-read the last row: their outputs are not stored */
+    return src + (size_t)gr * ld + c * 8; /* + k0 per step */
+}
+template <int BK>
+__device__ __forceinline__ bf16x8 g3_frag(const unsigned char* tile, int row, int c) {
+    const int p = BK == 64 ? c ^ ((row >> 1) & 7) : c ^ ((row >> 2) & 3);
+    return *reinterpret_cast<const bf16x8*>(tile + row * (2 * BK) + (p << 4));
 }
 
-// the same 32 KiB tile from a K-MAJOR operand (src[k][row], `row` contiguous: an activation or a weight as it lies in memory when the contraction runs over its ROWS --
-// both GEMMs of SLP::Back): the LDS image is [64 k][256 rows] (512-byte k-rows), one wave instruction = two k-rows; its 32-byte blocks are XOR-swizzled by k & 3 so
-// that the transposing fragment read below (4 k-rows x 32 bytes per 16 lanes) touches 4 different bank groups.
-__device__ __forceinline__ void g3_stage_km(const uint16_t* __restrict__ src, long long ld, int row0, int nrows, int k0, unsigned char* lds_tile, int wid, int lane) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int j = wid * 4 + i;                 /* k-rows 2j, 2j + 1 */
-        const int kr = 2 * j + (lane >> 5), p = lane & 31, c = p ^ ((kr & 3) << 1);
-        int col = row0 + c * 8;
-        col = col + 8 <= nrows ? col : (nrows - 8 > 0 ? nrows - 8 : 0); /* chunks past the end re-read the last whole chunk: their outputs are not stored (rows % 8 == 0) */
-        const uint16_t* g = src + (size_t)(k0 + kr) * ld + col;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(lds_tile + j * 1024), 16, 0, 0);
-    }
+// the same tile from a K-MAJOR operand (src[k][row], `row` contiguous: an activation or a weight as it lies in memory when the contraction runs over its ROWS --
+// both GEMMs of SLP::Back): the LDS image is [BK k][256 rows] (512-byte k-rows), one wave instruction = two k-rows; its 32-byte blocks are XOR-swizzled by k & 3 and
+// its 128-byte quarters by bit 3 of k, so that the transposing fragment read below (per 32 lanes: k-rows k .. k+3 and k+8 .. k+11, 32 bytes of each) touches all 64
+// banks once (without the second term the two 16-lane halves meet in the same 32 banks: SQ_LDS_BANK_CONFLICT = 50 % of the LDS cycles, measured).
+template <int BK>
+__device__ __forceinline__ const uint16_t* g3_src_km(const uint16_t* __restrict__ src, long long ld, int row0, int nrows, int i, int wid, int lane) {
+    const int j = wid * (BK / 16) + i;         /* k-rows 2j, 2j + 1 */
+    const int kr = 2 * j + (lane >> 5), p = lane & 31, c = p ^ ((kr & 3) << 1) ^ (((kr >> 3) & 1) << 3);
+    int col = row0 + c * 8;
+    col = col + 8 <= nrows ? col : (nrows - 8 > 0 ? nrows - 8 : 0); /* chunks past the end re-read the last whole chunk: their outputs are not stored (rows % 8 == 0) */
+    return src + (size_t)kr * ld + col; /* + k0 * ld per step */
 }
 // fragment (8 consecutive k of row `row`, k = kbase .. kbase + 7) of a k-major tile: two ds_read_b64_tr_b16, each a 4 (k) x 16 (rows) block transposed across 16 lanes
 // (lane i of the 16 receives D[(i >> 2) + 4 j][i & 3], scratch/dbg/ds_read_tr_probe.hip): lane l16 reads k-row kbase + (l16 >> 2), 8-byte piece l16 & 3 of the 16-row block
@@ -54,61 +59,69 @@ __device__ __forceinline__ bf16x8 g3_frag_km(const unsigned char* tile, int rowb
 #pragma unroll
     for (int t = 0; t < 2; t++) {
         const int k = kbase + 4 * t + (l16 >> 2);
-        const int byte_in_row = (rowblk16 * 16 + 4 * (l16 & 3)) * 2, c = byte_in_row >> 4, p = c ^ ((k & 3) << 1);
+        const int byte_in_row = (rowblk16 * 16 + 4 * (l16 & 3)) * 2, c = byte_in_row >> 4, p = c ^ ((k & 3) << 1) ^ (((k >> 3) & 1) << 3);
         h[t] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(tile + k * 512 + p * 16 + (byte_in_row & 8)));
     }
     return bf16x8{h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
 }
 
-// k-tiles kt0 .. kt1 - 1 of the output tile at (m0, t0) accumulated into acc (the caller zeroes it)
-template <bool AKM, bool BKM>
+// k-steps kt0 .. kt1 - 1 (of BK) of the output tile at (m0, t0) accumulated into acc (the caller zeroes it).  NST = 128 KiB / stage LDS buffers: the loads of step
+// kt + NST - 1 are issued while step kt is multiplied and drained with a COUNTED s_waitcnt vmcnt + one raw s_barrier per step (a __syncthreads() would drain the loads
+// in flight): BK = 64 -> 2 buffers; BK = 32 -> 4 buffers, three steps in flight -- for operands that miss in L2 (the k-major strips of a weight gradient: 60-70 % hits,
+// measured) the iteration time of the 2-buffer form IS the miss latency.
+template <bool AKM, bool BKM, int BK>
 __device__ __forceinline__ void g3_mainloop(const GemmArgs& a, int m0, int t0, int kt0, int kt1, f32x4 (&acc)[8][4], unsigned char* smem_raw, int wid, int lane) {
+    constexpr int TILE = G3_BM * BK * 2, NST = (4 * G3_TILE) / (2 * TILE), LPW = 2 * (BK / 16); /* loads per wave and step */
     const int wm = wid >> 2, wn = wid & 3;
     const uint16_t* const W = reinterpret_cast<const uint16_t*>(a.w);
-    auto bufA = [&](int b) { return smem_raw + (size_t)b * 2 * G3_TILE; };
-    auto bufB = [&](int b) { return smem_raw + (size_t)b * 2 * G3_TILE + G3_TILE; };
-    // AKM: W is [K][M] with row stride a.ldr (re-used field: the residual is not served by the k-major forms); BKM: x is [K][n] with row stride a.ldx
-    auto stageA = [&](int k0, unsigned char* dst) {
-        if constexpr (AKM) g3_stage_km(W, a.ldr, m0, a.M, k0, dst, wid, lane);
-        else g3_stage(W, a.K, m0, a.M, k0, dst, wid, lane);
-    };
-    auto stageB = [&](int k0, unsigned char* dst) {
-        if constexpr (BKM) g3_stage_km(a.x, a.ldx, t0, a.n, k0, dst, wid, lane);
-        else g3_stage(a.x, a.ldx, t0, a.n, k0, dst, wid, lane);
-    };
-    stageA(kt0 * G3_BK, bufA(0));
-    stageB(kt0 * G3_BK, bufB(0));
-    const int r16 = lane & 15, q4 = lane >> 4;
-    for (int kt = kt0; kt < kt1; kt++) {
-        const int cur = (kt - kt0) & 1;
-        if (kt + 1 < kt1) {
-            stageA((kt + 1) * G3_BK, bufA(cur ^ 1));
-            stageB((kt + 1) * G3_BK, bufB(cur ^ 1));
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); /* k-tile kt has landed; the 8 loads of k-tile kt+1 stay in flight */
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
+    auto bufA = [&](int b) { return smem_raw + (size_t)b * 2 * TILE; };
+    auto bufB = [&](int b) { return smem_raw + (size_t)b * 2 * TILE + TILE; };
+    // AKM: W is [K][M] with row stride a.ldr (re-used field: the residual is not served by the k-major forms); BKM: x is [K][n] with row stride a.ldx.
+    // Per-lane source pointers are set up once; a step adds a uniform offset (a 64-bit multiply per load and step was a tenth of the loop's issue slots).
+    constexpr int NI = BK / 16;
+    const uint16_t *pa[NI], *pb[NI];
 #pragma unroll
-        for (int kk = 0; kk < 2; kk++) {
+    for (int i = 0; i < NI; i++) {
+        pa[i] = AKM ? g3_src_km<BK>(W, a.ldr, m0, a.M, i, wid, lane) : g3_src<BK>(W, a.K, m0, a.M, i, wid, lane);
+        pb[i] = BKM ? g3_src_km<BK>(a.x, a.ldx, t0, a.n, i, wid, lane) : g3_src<BK>(a.x, a.ldx, t0, a.n, i, wid, lane);
+    }
+    const long long stepA = AKM ? (long long)BK * a.ldr : BK, stepB = BKM ? (long long)BK * a.ldx : BK;
+    auto stage = [&](int kt, int b) {
+        const long long oa = stepA * kt, ob = stepB * kt;
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[i] + oa),
+                                             (__attribute__((address_space(3))) void*)(bufA(b) + (wid * NI + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[i] + ob),
+                                             (__attribute__((address_space(3))) void*)(bufB(b) + (wid * NI + i) * 1024), 16, 0, 0);
+    };
+#pragma unroll
+    for (int st = 0; st < NST - 1; st++)
+        if (kt0 + st < kt1) stage(kt0 + st, st);
+    const int r16 = lane & 15, q4 = lane >> 4;
+    // the steps are unrolled by the NST buffers so that every LDS address of a step is base + an immediate
+    auto step = [&](int kt, auto cur_c) {
+        constexpr int cur = decltype(cur_c)::value;
+        const int left = kt1 - 1 - kt; /* steps issued after kt that may stay in flight */
+        if (NST >= 4 && left >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW) : "memory");
+        else if (NST >= 3 && left >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier(); /* step kt has landed for every wave, and every wave is done reading the buffer of step kt - 1: the next loads overwrite that one */
+        if (kt + NST - 1 < kt1) stage(kt + NST - 1, (cur + NST - 1) % NST);
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; kk++) {
             bf16x8 af[8], bfr[4];
 #pragma unroll
             for (int nt = 0; nt < 4; nt++) {
-                if constexpr (BKM) {
-                    bfr[nt] = g3_frag_km(bufB(cur), wn * 4 + nt, kk * 32 + 8 * q4, r16);
-                } else {
-                    const int row = wn * 64 + nt * 16 + r16, c = kk * 4 + q4;
-                    bfr[nt] = *reinterpret_cast<const bf16x8*>(bufB(cur) + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-                }
+                if constexpr (BKM) bfr[nt] = g3_frag_km(bufB(cur), wn * 4 + nt, kk * 32 + 8 * q4, r16);
+                else bfr[nt] = g3_frag<BK>(bufB(cur), wn * 64 + nt * 16 + r16, kk * 4 + q4);
             }
 #pragma unroll
             for (int mt = 0; mt < 8; mt++) {
-                if constexpr (AKM) {
-                    af[mt] = g3_frag_km(bufA(cur), wm * 8 + mt, kk * 32 + 8 * q4, r16);
-                } else {
-                    const int row = wm * 128 + mt * 16 + r16, c = kk * 4 + q4;
-                    af[mt] = *reinterpret_cast<const bf16x8*>(bufA(cur) + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-                }
+                if constexpr (AKM) af[mt] = g3_frag_km(bufA(cur), wm * 8 + mt, kk * 32 + 8 * q4, r16);
+                else af[mt] = g3_frag<BK>(bufA(cur), wm * 128 + mt * 16 + r16, kk * 4 + q4);
             }
 #pragma unroll
             for (int mt = 0; mt < 8; mt++)
@@ -116,8 +129,16 @@ __device__ __forceinline__ void g3_mainloop(const GemmArgs& a, int m0, int t0, i
                 for (int nt = 0; nt < 4; nt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier(); /* every wave is done reading buffer `cur`: the next iteration's loads may overwrite it */
+    };
+    for (int kt = kt0; kt < kt1; kt += NST) {
+        step(kt, std::integral_constant<int, 0>{});
+        if (kt + 1 < kt1) step(kt + 1, std::integral_constant<int, 1>{});
+        if constexpr (NST == 4) {
+            if (kt + 2 < kt1) step(kt + 2, std::integral_constant<int, 2>{});
+            if (kt + 3 < kt1) step(kt + 3, std::integral_constant<int, 3>{});
+        }
     }
+    __builtin_amdgcn_s_barrier(); /* a following segment's first loads must not overtake the last reads */
 }
 // epilogue (gemm_epilogue's order): lane holds rows m .. m+3 of a 16 x 16 tile for token column r16
 template <bool AKM>
@@ -161,7 +182,7 @@ __device__ __forceinline__ int g3_remap(int orig, int nwg) {
     return (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + orig / 8;
 }
 
-template <bool AKM, bool BKM>
+template <bool AKM, bool BKM, int BK>
 __global__ void __launch_bounds__(512) gemm3_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -174,118 +195,139 @@ __global__ void __launch_bounds__(512) gemm3_kernel(const GemmArgs a) {
     for (int i = 0; i < 8; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    g3_mainloop<AKM, BKM>(a, m0, t0, 0, a.K / G3_BK, acc, smem_raw, wid, lane);
+    g3_mainloop<AKM, BKM, BK>(a, m0, t0, 0, a.K / BK, acc, smem_raw, wid, lane);
     g3_epilogue<AKM>(a, m0, t0, acc, wid, lane);
 }
 
 // SPLIT-K forms for launches with fewer tiles than CUs (a weight gradient [OC, IC] is 49 .. 175 tiles, its contraction 8192 token rows long).  The pieces are cut so
-// that the workgroups an XCD runs side by side stay at the SAME k (they share operand strips in that XCD's L2; ranges of a plain stream-K cut drift apart in k and
-// every workgroup then streams its own strips through the fabric -- measured: 496 TFLOP/s):
-//   S >= 2 (2 P <= 256):  every tile's k-tiles are cut in S equal pieces, P S workgroups; piece 0 owns the tile;
-//   S == 1 (P < 256 < 2 P): workgroup t < P owns tile t and multiplies k-tiles [0, kp); H helpers take the tails [kp, nkt) of m tiles each, one after the other
-//                          (kp = nkt m / (m + 1): an owner and a helper finish together).
-// A non-owner leaves its fp32 partial in a slot of `ws` with write-through stores and raises the slot's flag; the owner adds the partials in slot order -- a fixed
-// order: the result does not depend on timing -- and runs the epilogue.  flags are zeroed by the host before the launch; all workgroups are resident (<= 256, one per CU).
+// that the workgroups an XCD runs side by side stay at (nearly) the SAME k: they share operand strips in that XCD's L2.  (Ranges of a plain stream-K cut drift apart
+// in k and every workgroup then streams its own strips through the fabric -- measured: 496 TFLOP/s.)
+//   S >= 2 (2 P <= 256):  every tile's k-steps are cut in S equal pieces, P S workgroups; piece 0 owns the tile;
+//   S == 1 (P < 256 < 2 P): workgroup t < P owns tile t and multiplies k-steps [0, kp), kp = nkt P / 256; the 256 - P helpers cut the tails [kp, nkt) of all tiles,
+//                          laid end to end, into equal ranges (a helper's range covers pieces of 2 .. 5 tiles; neighbours start a few steps apart).  Owners and
+//                          helpers finish together.
+// A non-owner leaves each fp32 partial in a slot of `ws` with write-through stores and raises the slot's flag; the owner adds its tile's partials in slot order -- a
+// fixed order: the result does not depend on timing -- and runs the epilogue.  flags are zeroed by the host before the launch; all workgroups are resident (<= 256,
+// one per CU), and only owners wait (for helpers, which wait for nobody).
 struct G3SkArgs {
     float* ws;       /* [<= 256][256 * 256] */
     uint32_t* flags; /* [<= 256] */
-    int P, S, m, kp;
+    int P, S, kp, R;
 };
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t g3_rsrc(const void* p, uint32_t bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000); }
-template <bool AKM, bool BKM>
+__device__ __forceinline__ void g3_publish(const G3SkArgs& s, int slot, const f32x4 (&acc)[8][4], int tid) {
+    const __amdgpu_buffer_rsrc_t rs = g3_rsrc(s.ws + (size_t)slot * (G3_BM * G3_BN), G3_BM * G3_BN * 4);
+#pragma unroll
+    for (int i = 0; i < 32; i++) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i >> 2][i & 3]), rs, (i * 512 + tid) * 16, 0, 16 /* sc1 */);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(s.flags + slot, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void g3_collect(const G3SkArgs& s, int slot, f32x4 (&acc)[8][4], int tid) {
+    if (tid == 0) {
+        for (int spins = 0; spins < (1 << 24); spins++) {
+            if (__hip_atomic_load(s.flags + slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs = g3_rsrc(s.ws + (size_t)slot * (G3_BM * G3_BN), G3_BM * G3_BN * 4);
+#pragma unroll
+    for (int g = 0; g < 4; g++) { /* 8 loads in flight at a time: the accumulators hold half the register file */
+        f32x4 pv[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ((g * 8 + i) * 512 + tid) * 16, 0, 16 /* sc1 */));
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[(g * 8 + i) >> 2][i & 3] += pv[i];
+        asm volatile("" ::: "memory");
+    }
+}
+template <bool AKM, bool BKM, int BK>
 __global__ void __launch_bounds__(512) gemm3_sk_kernel(const GemmArgs a, const G3SkArgs s) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int nbx = (a.M + G3_BM - 1) / G3_BM, nkt = a.K / G3_BK;
+    const int nbx = (a.M + G3_BM - 1) / G3_BM, nkt = a.K / BK;
     const int w = g3_remap(blockIdx.x, gridDim.x);
-    int t_first, t_last, k0, k1, slot0, nparts;
-    bool owner;
-    if (s.S >= 2) {
-        const int sp = w / s.P;
-        t_first = t_last = w % s.P, k0 = (int)((long long)nkt * sp / s.S), k1 = (int)((long long)nkt * (sp + 1) / s.S);
-        owner = sp == 0, nparts = s.S - 1, slot0 = t_first * (s.S - 1) + (owner ? 0 : sp - 1);
-    } else if (w < s.P) {
-        t_first = t_last = w, k0 = 0, k1 = s.kp, owner = true, nparts = 1, slot0 = w;
-    } else {
-        t_first = (w - s.P) * s.m, t_last = t_first + s.m - 1 < s.P - 1 ? t_first + s.m - 1 : s.P - 1;
-        k0 = s.kp, k1 = nkt, owner = false, nparts = 0, slot0 = t_first;
-    }
-    for (int tile = t_first; tile <= t_last; tile++) {
+    const bool helper = s.S < 2 && w >= s.P;
+    // tail mode: tail length L, T = P L tail steps in all, cut into ranges of R = s.R steps (the host's ceil(T / helpers)); 32-bit: the host checks T < 2^31
+    const int L = nkt - s.kp, T = s.P * L, R = s.R;
+    int hb = 0, he = 1; /* a helper's range of tail steps; the other roles make one pass */
+    if (helper) hb = (w - s.P) * R, he = hb + R < T ? hb + R : T;
+    for (int it = hb; it < he;) {
+        int tile, k0, k1, slot = 0, c0 = 0, c1 = 0; /* c0 .. c1 - 1: the slots an owner collects */
+        bool owner;
+        if (s.S >= 2) {
+            const int sp = w / s.P;
+            tile = w % s.P, k0 = (int)((long long)nkt * sp / s.S), k1 = (int)((long long)nkt * (sp + 1) / s.S);
+            owner = sp == 0, slot = tile * (s.S - 1) + sp - 1, c0 = tile * (s.S - 1), c1 = c0 + s.S - 1;
+        } else if (!helper) {
+            tile = w, k0 = 0, k1 = s.kp, owner = true;
+            const int lo = tile * L; /* helpers lo / R .. (lo + L - 1) / R meet this tile's tail; the piece of helper h in tile t has slot h + t */
+            c0 = lo / R + tile, c1 = (lo + L - 1) / R + tile + 1;
+        } else {
+            tile = it / L;
+            const int o = it - tile * L, len = L - o < he - it ? L - o : he - it;
+            k0 = s.kp + o, k1 = k0 + len, owner = false, slot = (w - s.P) + tile; /* pieces in range order: one slot each, < P + helpers */
+        }
+        c0 = __builtin_amdgcn_readfirstlane(c0), c1 = __builtin_amdgcn_readfirstlane(c1), slot = __builtin_amdgcn_readfirstlane(slot);
         const int bx = tile % nbx, by = tile / nbx, m0 = bx * G3_BM, t0 = by * G3_BN;
         f32x4 acc[8][4];
 #pragma unroll
         for (int i = 0; i < 8; i++)
 #pragma unroll
             for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        g3_mainloop<AKM, BKM>(a, m0, t0, k0, k1, acc, smem_raw, wid, lane);
+        g3_mainloop<AKM, BKM, BK>(a, m0, t0, k0, k1, acc, smem_raw, wid, lane);
         if (!owner) {
-            const int slot = slot0 + (tile - t_first);
-            const __amdgpu_buffer_rsrc_t rs = g3_rsrc(s.ws + (size_t)slot * (G3_BM * G3_BN), G3_BM * G3_BN * 4);
-#pragma unroll
-            for (int i = 0; i < 32; i++) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i >> 2][i & 3]), rs, (i * 512 + tid) * 16, 0, 16 /* sc1 */);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(s.flags + slot, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            g3_publish(s, slot, acc, tid);
         } else {
-            for (int j = 0; j < nparts; j++) {
-                const int slot = slot0 + j;
-                if (tid == 0) {
-                    for (int spins = 0; spins < (1 << 24); spins++) {
-                        if (__hip_atomic_load(s.flags + slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) break;
-                        __builtin_amdgcn_s_sleep(4);
-                    }
-                }
-                __syncthreads();
-                const __amdgpu_buffer_rsrc_t rs = g3_rsrc(s.ws + (size_t)slot * (G3_BM * G3_BN), G3_BM * G3_BN * 4);
-#pragma unroll
-                for (int g = 0; g < 4; g++) { /* 8 loads in flight at a time: the accumulators hold half the register file */
-                    f32x4 pv[8];
-#pragma unroll
-                    for (int i = 0; i < 8; i++) pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ((g * 8 + i) * 512 + tid) * 16, 0, 16 /* sc1 */));
-#pragma unroll
-                    for (int i = 0; i < 8; i++) acc[(g * 8 + i) >> 2][i & 3] += pv[i];
-                    asm volatile("" ::: "memory");
-                }
-            }
+            for (int c = c0; c < c1; c++) g3_collect(s, c, acc, tid);
             g3_epilogue<AKM>(a, m0, t0, acc, wid, lane);
         }
+        it += helper ? k1 - k0 : 1;
     }
 }
 
 // KF_OK launched, 1 = not for this kernel (the caller's other tile kernels take the shape), < 0 error.  bf16 "weights" only: quantised ones are dequantised first.
-template <bool AKM, bool BKM>
-static int g3_go(hipStream_t st, const GemmArgs& a, long nwg, void* ws, size_t ws_bytes) {
+template <bool AKM, bool BKM, int BK>
+static int g3_go_bk(hipStream_t st, const GemmArgs& a, long nwg, void* ws, size_t ws_bytes) {
     static int attr_set = 0;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm3_kernel<AKM, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G3_TILE) != hipSuccess) return KF_HIP_CHECK;
-        if (hipFuncSetAttribute((const void*)gemm3_sk_kernel<AKM, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G3_TILE) != hipSuccess) return KF_HIP_CHECK;
+        if (hipFuncSetAttribute((const void*)gemm3_kernel<AKM, BKM, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G3_TILE) != hipSuccess) return KF_HIP_CHECK;
+        if (hipFuncSetAttribute((const void*)gemm3_sk_kernel<AKM, BKM, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G3_TILE) != hipSuccess) return KF_HIP_CHECK;
         attr_set = 1;
     }
-    // split-K when the tiles are fewer than 4/5 of the CUs, the caller lent the workspace, and the pieces stay >= 8 k-tiles long
-    const int G = 256, nkt = a.K / G3_BK;
+    // split-K when the tiles are fewer than 4/5 of the CUs, the caller lent the workspace, and the pieces stay >= 512 deep in k
+    const int G = 256, nkt = a.K / BK, min_steps = 512 / BK;
     if (ws && ws_bytes >= gemm3_sk_ws_bytes() && 5 * nwg < 4 * G) {
         G3SkArgs s;
         s.ws = (float*)ws, s.flags = (uint32_t*)((char*)ws + (size_t)G * G3_BM * G3_BN * 4);
-        s.P = (int)nwg, s.S = G / s.P, s.m = 0, s.kp = 0;
+        s.P = (int)nwg, s.S = G / s.P, s.kp = 0, s.R = 1;
         int nlaunch;
         if (s.S >= 2) {
-            while (s.S > 1 && nkt / s.S < 8) s.S--;
+            while (s.S > 1 && nkt / s.S < min_steps) s.S--;
             nlaunch = s.P * s.S;
         } else {
-            s.m = (s.P + (G - s.P) - 1) / (G - s.P);
-            s.kp = (int)(((long long)nkt * s.m + s.m / 2) / (s.m + 1));
-            nlaunch = s.P + (s.P + s.m - 1) / s.m;
-            if (nkt - s.kp < 8) s.S = 0;
+            s.kp = (int)(((long long)nkt * s.P + G / 2) / G);
+            nlaunch = G;
+            const long long T = (long long)s.P * (nkt - s.kp);
+            s.R = (int)((T + (G - s.P) - 1) / (G - s.P));
+            if (nkt - s.kp < 1 || nkt < 4 * min_steps || T * 2 >= (1LL << 31)) s.S = 0;
         }
-        if ((s.S >= 2) || (s.S == 1 && s.m > 0)) {
+        if (s.S >= 1 && (s.S >= 2 || s.kp > 0)) {
             if (hipMemsetAsync(s.flags, 0, G * sizeof(uint32_t), st) != hipSuccess) return KF_HIP_CHECK;
-            hipLaunchKernelGGL((gemm3_sk_kernel<AKM, BKM>), dim3(nlaunch), dim3(512), 4 * G3_TILE, st, a, s);
+            hipLaunchKernelGGL((gemm3_sk_kernel<AKM, BKM, BK>), dim3(nlaunch), dim3(512), 4 * G3_TILE, st, a, s);
             return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
         }
     }
     if (nwg < 64) return 1;
-    hipLaunchKernelGGL((gemm3_kernel<AKM, BKM>), dim3((unsigned)nwg), dim3(512), 4 * G3_TILE, st, a);
+    hipLaunchKernelGGL((gemm3_kernel<AKM, BKM, BK>), dim3((unsigned)nwg), dim3(512), 4 * G3_TILE, st, a);
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+// BK = 32 (4 LDS buffers, three steps in flight) was measured 8-10 % slower than BK = 64 (2 buffers) on every shape, forward and backward: the per-step costs
+// (barrier, counted wait, loop) double, and the loop is not waiting for memory.  Only BK = 64 is instantiated.
+template <bool AKM, bool BKM>
+static int g3_go(hipStream_t st, const GemmArgs& a, long nwg, void* ws, size_t ws_bytes) {
+    return g3_go_bk<AKM, BKM, 64>(st, a, nwg, ws, ws_bytes);
 }
 size_t gemm3_sk_ws_bytes() { return (size_t)256 * G3_BM * G3_BN * 4 + 4096; }
 int gemm3_launch(hipStream_t st, int fmt, const GemmArgs& a) {
