@@ -660,7 +660,7 @@ int sample_launch(hipStream_t st, const uint16_t* logits, int n, int top_k, floa
 }
 
 // ---------------------------------------------------------------- quantiser: GeQuant::RTN_x / YinYang (GeQuant.cpp:428-628)
-// One wave per group of lGroup (<= 128... any multiple of 64 up to 1024) consecutive elements.
+// One wave per group of lGroup consecutive elements (any multiple of the 128 / bits elements of a Packed128 block).
 // mode 0: RTN asymmetric, 1: RTN symmetric, 2: YinYang (step = max(1e-5, sqrt(mean(relu(a)^2))), zero = 0)
 __global__ void __launch_bounds__(256) quantize_kernel(const uint16_t* __restrict__ src, unsigned char* __restrict__ packed, uint16_t* __restrict__ zero_out,
                                                        uint16_t* __restrict__ step_out, size_t nGroup, int lGroup, int bits, int mode, int qMin, int qMax,
@@ -693,25 +693,24 @@ __global__ void __launch_bounds__(256) quantize_kernel(const uint16_t* __restric
         zero = -vmin;
     }
     if (lane == 0) zero_out[g] = f2bf(zero), step_out[g] = f2bf(step);
-    // pack: lane b < nblk builds Packed128 block b (MSB-first within high then low; PackedQ.hpp:99-239)
-    const int per = 128 / bits, nblk = lGroup / per;
+    // pack (Packed128 blocks, MSB-first within high then low; PackedQ.hpp:99-239): every lane quantises elements lane, lane + 64, ...; the 64 / bits lanes whose
+    // codes share a 64-bit word OR them together with xor-shuffles and the first of them stores the word (even words are `high` = bytes 8..15 of the block)
+    const int epw = 64 / bits; /* elements per 64-bit word: 16 / 32 / 64 lanes side by side */
     unsigned char* dst = packed + g * ((size_t)lGroup * bits / 8);
-    for (int b = lane; b < nblk; b += 64) {
-        unsigned long long high = 0, low = 0;
-        for (int i = 0; i < per; i++) {
-            const float a = bf2f(dat[b * per + i]);
+    for (int e0 = 0; e0 < lGroup; e0 += 64) {
+        const int e = e0 + lane;
+        unsigned long long word = 0; /* lanes past a group that is not a multiple of 64 long (32, 96 at 4 bits) take part in the shuffles with nothing */
+        if (e < lGroup) {
+            const float a = bf2f(dat[e]);
             int q = (int)roundf((a + zero) / step);
             q = q < qMin ? qMin : (q > qMax ? qMax : q);
-            const unsigned long long v = (unsigned long long)((q + qBias) & ((1 << bits) - 1));
-            const int half = per / 2, ii = i < half ? i : i - half;
-            const int sh = 64 - bits * (ii + 1);
-            if (i < half)
-                high |= v << sh;
-            else
-                low |= v << sh;
+            word = (unsigned long long)((q + qBias) & ((1 << bits) - 1)) << (64 - bits * ((e % epw) + 1));
         }
-        reinterpret_cast<unsigned long long*>(dst + 16 * b)[0] = low;
-        reinterpret_cast<unsigned long long*>(dst + 16 * b)[1] = high;
+        for (int m = 1; m < epw; m <<= 1) word |= __shfl_xor(word, m, 64);
+        if (e < lGroup && (lane & (epw - 1)) == 0) {
+            const int wi = e / epw; /* word wi: block wi / 2, high first */
+            reinterpret_cast<unsigned long long*>(dst + 16 * (wi >> 1))[(wi & 1) ^ 1] = word;
+        }
     }
 }
 // bf16 -> f8e5m2 storage (Float2T<f8e5>, g_float.hpp:433-443; ToF8Ex huTensor.cu:821): float -> half round-to-nearest-even, keep the high byte

@@ -113,6 +113,30 @@ def test_linear_backward_large_k_major(ctx, t, shape, accumulate):
     _run(ctx, t, OC, IC, n, accumulate)
 
 
+def test_linear_backward_split_k_is_deterministic(ctx):
+    """the split-K forms add a tile's partial sums in slot order, not in arrival order: two runs give the same bits (49-tile weight gradient = 5 pieces per
+    tile; 133 tiles = owners + helpers on tails)"""
+    rng = np.random.default_rng(77)
+    for OC, IC, n in ((1600, 1600, 8192), (4800, 1600, 4096)):
+        w = O.f32_to_bf16(rng.normal(0, 0.05, (OC, IC)).astype(np.float32))
+        dw = ctx.upload_blob(L.BF16, OC, IC, O.quantize(w, OC, IC, L.BF16).blob())
+        dIn = bf16_t(O.f32_to_bf16(rng.normal(0, 1.0, (n, OC)).astype(np.float32)), ctx.device)
+        inp = bf16_t(O.f32_to_bf16(rng.normal(0, 1.0, (n, IC)).astype(np.float32)), ctx.device)
+        scratch = torch.empty(ctx.hip.kf_linear_backward_scratch_bytes(OC, IC, n) + 256, dtype=torch.uint8, device=ctx.device)
+        sp = (scratch.data_ptr() + 255) & ~255
+        desc = dw.desc()
+        outs = []
+        for _ in range(3):
+            delta = torch.zeros(n, IC, dtype=torch.bfloat16, device=ctx.device)
+            gW = torch.zeros(OC, IC, dtype=torch.bfloat16, device=ctx.device)
+            scratch.random_(0, 255)   # stale partials / flags from the run before must not matter
+            assert ctx.hip.kf_linear_backward(ctx.h, C.byref(desc), dIn.data_ptr(), inp.data_ptr(), delta.data_ptr(), gW.data_ptr(), None, n, 0, sp) == 0, ctx.hip.kf_last_error()
+            ctx.sync()
+            outs.append((u16(delta).copy(), u16(gW).copy()))
+        for d_, g_ in outs[1:]:
+            assert np.array_equal(d_, outs[0][0]) and np.array_equal(g_, outs[0][1])
+
+
 def test_linear_backward_fixed_weight_and_no_bias(ctx):
     _run(ctx, L.Q4, 512, 1024, 96, False, with_bias=False, want_gw=False)   # isFixWeight: input gradient only; n need not be a multiple of 64 then
 

@@ -42,6 +42,19 @@ def test_quantizer_bytes_match_oracle(ctx, O, t, shape):
     assert np.array_equal(u16(z), ow.zero) and np.array_equal(u16(s), ow.step)
 
 
+@pytest.mark.parametrize("t,lg", [(L.Q4, 32), (L.Q4, 96), (L.Q4, 256), (L.Q4, 1024), (L.T_SIGN, 64), (L.T_SIGN, 192), (L.BOOL1, 384)])
+def test_quantizer_group_sizes(ctx, O, t, lg):
+    """group lengths other than 128 (any multiple of a Packed128 block's 128 / bits elements): the lanes past a short group, and groups several wave passes long"""
+    rng = np.random.default_rng(13 + lg)
+    m, k = 24, 3072
+    w = rand_w(rng, m, k)
+    ow = O.quantize(w, m, k, t, lGroup=lg)
+    dw = ctx.quantize(bf16_t(w, ctx.device), t, lGroup=lg)
+    assert np.array_equal(dw.blob.cpu().numpy()[:dw.szData], ow.data.view(np.uint8)), "packed stream differs"
+    z, s_ = dw.zero_step()
+    assert np.array_equal(u16(z), ow.zero) and np.array_equal(u16(s_), ow.step)
+
+
 def test_quantizer_symmetric_q4(ctx, O):
     rng = np.random.default_rng(12)
     w = rand_w(rng, 32, 512)
