@@ -300,7 +300,9 @@ int kf_embed_backward(kf_ctx* ctx, kf_bf16* dwte_or_null, long long ldw, kf_bf16
  *   gW    [OC, IC] += deltaIn^T . inp                                     (NULL: skipped -- isFixWeight; the bf16 gradient of a quantised weight's master copy)
  *   gBias [OC]     += column sums of deltaIn                              (NULL: no bias)
  * fp32 accumulation, bf16 stores (beta = 1 adds the stored bf16 value).  OC a multiple of 64 and >= 128 (so is n when gW is wanted), IC a multiple of 8.
- * scratch: kf_linear_backward_scratch_bytes(OC, IC, n) bytes of device memory, 256-byte aligned. */
+ * scratch: kf_linear_backward_scratch_bytes(OC, IC, n) bytes of device memory, 256-byte aligned (the dequantised weight; the fp32 partial tiles of the split-K weight-gradient
+ * launch, >= 64 MiB, or the transposed copies of shapes too small for the 256 x 256 tile kernel; the bias column-sum slabs).  Contents need not be initialised and
+ * are not kept between calls; results do not depend on them (the split-K partial sums are added in a fixed order). */
 size_t kf_linear_backward_scratch_bytes(int OC, int IC, int n);
 int kf_linear_backward(kf_ctx* ctx, const kf_weight* w, const kf_bf16* deltaIn, const kf_bf16* inp_or_null, kf_bf16* delta_or_null, kf_bf16* gW_or_null,
                        kf_bf16* gBias_or_null, int n, int accumulate_delta, void* scratch);
