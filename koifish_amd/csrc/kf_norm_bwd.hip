@@ -218,11 +218,23 @@ __global__ void __launch_bounds__(256) norm_backward_reduce_kernel(uint16_t* __r
     const size_t stride = (size_t)(is_ln ? 2 : 1) * C;
     const int chunk = (G + 7) / 8, g0 = q * chunk, g1 = g0 + chunk < G ? g0 + chunk : G;
     double sw = 0.0, sbias = 0.0;
-    if (c < C)
-        for (int g = g0; g < g1; g++) {
+    if (c < C) { /* the same index order, eight partials' loads in flight at a time (one at a time this launch took 24 us for 512 partials of 1600 columns) */
+        int g = g0;
+        for (; g + 8 <= g1; g += 8) {
+            double vw[8], vb[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                vw[u] = part[(g + u) * stride + c];
+                vb[u] = is_ln ? part[(g + u) * stride + C + c] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) sw += vw[u], sbias += vb[u];
+        }
+        for (; g < g1; g++) {
             sw += part[g * stride + c];
             if (is_ln) sbias += part[g * stride + C + c];
         }
+    }
     sw_[q][cl] = sw, sb_[q][cl] = sbias;
     __syncthreads();
     if (q == 0 && c < C) {
