@@ -22,6 +22,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-slp-vectorize: keeps the dequant chain in plain v_fma/v_sub (the packed-f32 forms the SLP pass picks cost more issue
 # slots, need s_nop hazard padding and 40 % more registers on this kernel)
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
+# MFMA results that the VALU works on next (attention scores, the epilogues of the token-batch GEMMs): with the default AGPR form of the MFMA destination the
+# compiler moves every such value AGPR -> VGPR (v_accvgpr_read) and zero-fills accumulators through v_accvgpr_write -- 160 of the ~330 vector instructions of a
+# key tile in the attention backward.  The VGPR form has none of them (and the files below stay inside 256 VGPRs where it matters).
+HIP_FILE_FLAGS = {f: ["-mllvm", "-amdgpu-mfma-vgpr-form=1"] for f in os.environ.get("KF_VGPR_FORM", "kf_attn_prefill.hip,kf_attn_bwd_mfma.hip,kf_gemm.hip").split(",") if f}
 
 
 def _stale(target, deps):
@@ -39,7 +43,7 @@ def build_hip(force=False, verbose=False):
         o = s[:-4] + ".o"
         objs.append(o)
         if force or _stale(o, [s] + deps[len(srcs):]):
-            cmd = [HIPCC] + HIP_FLAGS + ["-c", s, "-o", o]
+            cmd = [HIPCC] + HIP_FLAGS + HIP_FILE_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
