@@ -1,12 +1,12 @@
 // kf_attn_bwd_mfma.hip -- causal multi-head attention backward on MFMA (flash form), gfx950 / wave64.  Same contract as kf_attn_bwd.hip (its
 // header has the mathematics and the reference), same two-launch split, the tile algebra of the forward kernel (kf_attn_prefill.hip):
 //
-//   dQ launch, workgroup = 128 query columns (32 per wave), key tiles of 32 staged in LDS (K and V row-major, K also transposed):
+//   dQ launch, workgroup = 128 query columns (32 per wave), key tiles of 32 staged in LDS (K and V row-major, K a second time with the row stride the transposing reads want):
 //     pass A   S^T[key][col] = K . Q^T                      -> the column's log-sum-exp L (and D = dO . O from registers), kept for launch 2
 //     pass B   S^T again, dP^T[key][col] = V . dO^T         A = K / V rows (ds_read_b128), B = Q / dO rows (registers, loaded once)
 //              dS^T = exp(scale S^T - L) o (dP^T - D)       element-wise on the accumulators: a column lives in one lane pair
 //              dQ^T[d][col] += K^T[d][key] . dS^T[key][col] the dS^T registers, packed to bf16, ARE the B operand (free contraction order)
-//   dK/dV launch, workgroup = 128 key columns, query tiles of 32 from the diagonal down (Q and dO row-major and transposed, L and D of the tile):
+//   dK/dV launch, workgroup = 128 key columns, query tiles of 32 from the diagonal down (Q and dO row-major, twice: row reads / transposing reads; L and D of the tile):
 //              S[q][key] = Q . K^T, dP[q][key] = dO . V^T   A = Q / dO rows, B = K / V rows of the column (registers)
 //              P = exp(scale S - L_q), dS = P o (dP - D_q)  L, D per accumulator ROW: four ds_read_b128 each
 //              dV^T[d][key] += dO^T[d][q] . P[q][key],  dK^T[d][key] += Q^T[d][q] . dS[q][key]
@@ -19,7 +19,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int AB_T = 32;        /* tile of keys (dQ launch) / queries (dK/dV launch) */
-constexpr int AB_TS = AB_T + 4; /* padded transposed row, elements (72 B) */
+constexpr int AB_PAD2 = 32;     /* row padding (elements, 64 B) of the second row-major copy that the transposing reads use: 4 rows of a 32-lane pass -> distinct 16-bank groups */
 constexpr float AB_LOG2E = 1.44269502162933349609375f;
 
 __device__ __forceinline__ f32x16 ab_zero() {
@@ -31,7 +31,7 @@ __device__ __forceinline__ f32x16 ab_zero() {
 __device__ __forceinline__ f32x16 ab_mfma(u32x4 A, u32x4 B, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), c, 0, 0, 0);
 }
-// stage a [32][HD] tile of rows (row index clamped to T - 1) row-major (padded rows) and, optionally, transposed [HD][AB_TS]
+// stage a [32][HD] tile of rows (row index clamped to T - 1) row-major (padded rows) and, optionally, a second time with AB_PAD2 row padding (ab_tfrag's operand)
 template <int HD, bool TRANSPOSE>
 __device__ __forceinline__ void ab_stage(const uint16_t* __restrict__ src, long long ld, size_t hoff, int row0, int T, uint16_t* rows, uint16_t* tr) {
     constexpr int KS = HD + 8, CH = AB_T * HD / 8;
@@ -41,14 +41,7 @@ __device__ __forceinline__ void ab_stage(const uint16_t* __restrict__ src, long 
         rr = rr < T ? rr : T - 1;
         const u32x4 x = *reinterpret_cast<const u32x4*>(src + (size_t)rr * ld + hoff + dc * 8);
         *reinterpret_cast<u32x4*>(rows + row * KS + dc * 8) = x;
-        if (TRANSPOSE) {
-            const uint32_t w[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                tr[(dc * 8 + 2 * e) * AB_TS + row] = (uint16_t)(w[e] & 0xffffu);
-                tr[(dc * 8 + 2 * e + 1) * AB_TS + row] = (uint16_t)(w[e] >> 16);
-            }
-        }
+        if (TRANSPOSE) *reinterpret_cast<u32x4*>(tr + row * (HD + AB_PAD2) + dc * 8) = x;
     }
 }
 // the same in two halves, so that a tile's global loads can be in flight while the previous tile is multiplied: registers <- global, LDS <- registers
@@ -70,28 +63,27 @@ __device__ __forceinline__ void ab_store(const u32x4* regs, uint16_t* rows, uint
     for (int i = 0; i < CH / 256; i++) {
         const int c = threadIdx.x + 256 * i, row = c / (HD / 8), dc = c - row * (HD / 8);
         *reinterpret_cast<u32x4*>(rows + row * KS + dc * 8) = regs[i];
-        if (TRANSPOSE) {
-            const uint32_t w[4] = {regs[i].x, regs[i].y, regs[i].z, regs[i].w};
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                tr[(dc * 8 + 2 * e) * AB_TS + row] = (uint16_t)(w[e] & 0xffffu);
-                tr[(dc * 8 + 2 * e + 1) * AB_TS + row] = (uint16_t)(w[e] >> 16);
-            }
-        }
+        if (TRANSPOSE) *reinterpret_cast<u32x4*>(tr + row * (HD + AB_PAD2) + dc * 8) = regs[i];
     }
 }
-// A fragment of a transposed tile for contraction step s2: row (d), slots (j) <-> tile index 16 s2 + (j & 3) + 8 (j >> 2) + 4 h
-__device__ __forceinline__ u32x4 ab_tfrag(const uint16_t* tr, int drow, int s2, int h) {
-    const uint16_t* p = tr + drow * AB_TS + 16 * s2 + 4 * h;
-    const u32x2 lo = *reinterpret_cast<const u32x2*>(p), hi = *reinterpret_cast<const u32x2*>(p + 8);
-    return u32x4{lo.x, lo.y, hi.x, hi.y};
+// A fragment of X^T (row d = 32 db + (lane & 31), contraction slots j <-> tile rows 16 s2 + (j & 3) + 8 (j >> 2) + 4 h) read straight from the second row-major
+// copy of the tile with two transposing ds_read_b64_tr_b16: lane l16 of a 16-lane group addresses tile row (l16 >> 2) of its 4 and d-piece 4 (l16 & 3) of the
+// group's 16 d, and receives the 4 rows' values of d = l16 (scratch/dbg/ds_read_tr_probe.hip).  No transposed copy, no 16-bit scatter stores.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+template <int HD>
+__device__ __forceinline__ u32x4 ab_tfrag(const uint16_t* rows2, int db, int s2, int lane) {
+    constexpr int VS = HD + AB_PAD2;
+    const uint16_t* p = rows2 + (16 * s2 + 4 * (lane >> 5) + ((lane & 15) >> 2)) * VS + db * 32 + (lane & 16) + 4 * (lane & 3);
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p + 8 * VS));
+    return __builtin_bit_cast(u32x4, bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
 }
 
 template <int HD>
 __global__ void __launch_bounds__(256) attn_bwd_dq_mfma_kernel(const uint16_t* q, const uint16_t* k, const uint16_t* v, long long ld_qkv, const uint16_t* o, const uint16_t* dO, long long ld_o,
                                                                uint16_t* dq, long long ld_d, float* Lbuf, float* Dbuf, int T, float scale, int gq, long long ld_kv) {
     constexpr int NS = HD / 16, NDB = HD / 32, KS = HD + 8;
-    __shared__ __attribute__((aligned(16))) uint16_t ks[AB_T * KS], vs[AB_T * KS], kt[HD * AB_TS];
+    __shared__ __attribute__((aligned(16))) uint16_t ks[AB_T * KS], vs[AB_T * KS], kt[AB_T * (HD + AB_PAD2)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int head = blockIdx.y, tok0 = (gridDim.x - 1 - blockIdx.x) * 128; /* the longest columns first */
     const size_t hoff = (size_t)head * HD, hoff_kv = (size_t)(head / gq) * HD; /* GQA: gq query heads share a kv head */
@@ -197,7 +189,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_mfma_kernel(const uint16_t* q
         for (int s2 = 0; s2 < 2; s2++) {
             const u32x4 B = u32x4{dw[4 * s2], dw[4 * s2 + 1], dw[4 * s2 + 2], dw[4 * s2 + 3]};
 #pragma unroll
-            for (int db = 0; db < NDB; db++) acc[db] = ab_mfma(ab_tfrag(kt, db * 32 + r, s2, h), B, acc[db]);
+            for (int db = 0; db < NDB; db++) acc[db] = ab_mfma(ab_tfrag<HD>(kt, db, s2, lane), B, acc[db]);
         }
         __syncthreads(); /* everyone has read this tile */
         if (more) {
@@ -221,7 +213,7 @@ template <int HD>
 __global__ void __launch_bounds__(256) attn_bwd_dkv_mfma_kernel(const uint16_t* q, const uint16_t* k, const uint16_t* v, long long ld_qkv, const uint16_t* dO, long long ld_o, uint16_t* dk,
                                                                 uint16_t* dv, long long ld_d, const float* Lbuf, const float* Dbuf, int T, float scale, int gq, long long ld_kv, long long ld_dkv) {
     constexpr int NS = HD / 16, NDB = HD / 32, KS = HD + 8;
-    __shared__ __attribute__((aligned(16))) uint16_t qs[AB_T * KS], os[AB_T * KS], qt[HD * AB_TS], ot[HD * AB_TS];
+    __shared__ __attribute__((aligned(16))) uint16_t qs[AB_T * KS], os[AB_T * KS], qt[AB_T * (HD + AB_PAD2)], ot[AB_T * (HD + AB_PAD2)];
     __shared__ __attribute__((aligned(16))) float Ls[AB_T], Ds[AB_T];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int kvh = blockIdx.y, key0 = blockIdx.x * 128; /* blockIdx.y = kv head; the first key columns see the most query tiles: already first */
@@ -302,8 +294,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_mfma_kernel(const uint16_t* 
             const u32x4 BP = u32x4{pw[4 * s2], pw[4 * s2 + 1], pw[4 * s2 + 2], pw[4 * s2 + 3]}, BS = u32x4{dw[4 * s2], dw[4 * s2 + 1], dw[4 * s2 + 2], dw[4 * s2 + 3]};
 #pragma unroll
             for (int db = 0; db < NDB; db++) {
-                dva[db] = ab_mfma(ab_tfrag(ot, db * 32 + r, s2, h), BP, dva[db]);
-                dka[db] = ab_mfma(ab_tfrag(qt, db * 32 + r, s2, h), BS, dka[db]);
+                dva[db] = ab_mfma(ab_tfrag<HD>(ot, db, s2, lane), BP, dva[db]);
+                dka[db] = ab_mfma(ab_tfrag<HD>(qt, db, s2, lane), BS, dka[db]);
             }
         }
         } /* wave has work on this tile */

@@ -8,23 +8,25 @@
 // operator.cuh:251-277), the sum of p stays fp32.
 //
 // Workgroup = one kv-head x TQ = 128/GQ consecutive tokens: 128 "columns" (token, query head of the group), 32 per wave.
-// Per 32-key tile, staged once in LDS for the 4 waves (K row-major with padded 272-byte rows, V TRANSPOSED [d][key] with 72-byte rows):
+// Per 32-key tile, staged once in LDS for the 4 waves (K row-major with 16 bytes of row padding, V row-major too with 64 bytes of padding):
 //   S^T[key][col] = sum_d K[key][d] Q[col][d]      v_mfma_f32_32x32x16_bf16, A = K rows (ds_read_b128), B = Q rows (registers, loaded once)
 //   -> a column's 32 scores sit in ONE lane pair (lane l and l^32, 16 registers each): max / exp / sum need no cross-lane traffic
 //      beyond one lane-pair exchange of the tile maximum;
 //   O^T[d][col]  += sum_key V^T[d][key] P^T[key][col]   the S^T accumulator registers, packed to bf16, ARE the B operand (the contraction
 //      index may be visited in any order: slot (step s, half h, j) <-> key 16 s + (j & 3) + 8 (j >> 2) + 4 h on both operands), A = V^T
-//      rows read with two ds_read_b64 per fragment.
+//      fragments read straight from the row-major V tile with two transposing ds_read_b64_tr_b16 (4 keys x 16 d per 16 lanes; the 192- / 320-byte row
+//      stride puts the 4 rows of a 32-lane pass on different banks) -- no transposed copy, no 16-bit scatter stores.
 // Online softmax: running maximum per column, O and l rescaled when it moves.  HBM/L2 bytes: K and V once per 128 columns.
 #include "kf_kernels.h"
 
 namespace kf {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int AP_KT = 32;        /* keys per tile */
-constexpr int AP_VS = AP_KT + 4; /* padded V^T row, elements (72 B) */
+constexpr int AP_VPAD = 32;      /* V row padding, elements (64 B): rows 4 apart in a transposing read land on distinct 16-bank groups */
 
 struct AttnPrefillArgs {
     const uint16_t* q;
@@ -52,7 +54,8 @@ __global__ void __launch_bounds__(256) attn_prefill_kernel(const AttnPrefillArgs
     static_assert(KCH % 256 == 0, "tile chunks must divide among 256 threads");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint16_t* ks = reinterpret_cast<uint16_t*>(smem_raw);  // 2 x [AP_KT][KS]
-    uint16_t* vt = ks + 2 * AP_KT * KS;                    // 2 x [HD][AP_VS]
+    constexpr int VS = HD + AP_VPAD; /* V row stride, elements */
+    uint16_t* vt = ks + 2 * AP_KT * KS;                    // 2 x [AP_KT][VS]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -91,17 +94,12 @@ __global__ void __launch_bounds__(256) attn_prefill_kernel(const AttnPrefillArgs
     };
     auto tstore = [&](int buf) {
         uint16_t* kd = ks + (size_t)buf * AP_KT * KS;
-        uint16_t* vd = vt + (size_t)buf * HD * AP_VS;
+        uint16_t* vd = vt + (size_t)buf * AP_KT * VS;
 #pragma unroll
         for (int i = 0; i < CPT; i++) {
             const int c = tid + 256 * i, key = c / (HD / 8), dc = c - key * (HD / 8);
             *reinterpret_cast<u32x4*>(kd + key * KS + dc * 8) = kr[i];
-            const uint32_t vw[4] = {vr[i].x, vr[i].y, vr[i].z, vr[i].w};
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                vd[(dc * 8 + 2 * e) * AP_VS + key] = (uint16_t)(vw[e] & 0xffffu);
-                vd[(dc * 8 + 2 * e + 1) * AP_VS + key] = (uint16_t)(vw[e] >> 16);
-            }
+            *reinterpret_cast<u32x4*>(vd + key * VS + dc * 8) = vr[i];
         }
     };
 
@@ -120,7 +118,7 @@ __global__ void __launch_bounds__(256) attn_prefill_kernel(const AttnPrefillArgs
         const bool more = t + 1 < ntile;
         if (more) tload(t + 1);
         const uint16_t* kb = ks + (size_t)(t & 1) * AP_KT * KS;
-        const uint16_t* vb = vt + (size_t)(t & 1) * HD * AP_VS;
+        const uint16_t* vb = vt + (size_t)(t & 1) * AP_KT * VS;
         // ---- S^T tile
         f32x16 st;
 #pragma unroll
@@ -134,12 +132,22 @@ __global__ void __launch_bounds__(256) attn_prefill_kernel(const AttnPrefillArgs
         const int k0 = t * AP_KT + 4 * h;
         float sc[16];
         float mt = -__builtin_inff();
+        // every key of the tile precedes every column of this wave (its first token is tok0 + wave * 32 / GQ): no mask -- all tiles but the last few
+        const bool full = t * AP_KT + AP_KT - 1 <= a.pos0 + tok0 + (wave * 32) / GQ && tok0 + TQ <= a.n_tok;
+        if (full) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int key = k0 + (i & 3) + 8 * (i >> 2);
-            const float v = round_bf16(st[i] * a.rden);
-            sc[i] = key <= pos_q ? v : -__builtin_inff();
-            mt = fmaxf(mt, sc[i]);
+            for (int i = 0; i < 16; i++) {
+                sc[i] = round_bf16(st[i] * a.rden);
+                mt = fmaxf(mt, sc[i]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int key = k0 + (i & 3) + 8 * (i >> 2);
+                const float v = round_bf16(st[i] * a.rden);
+                sc[i] = key <= pos_q ? v : -__builtin_inff();
+                mt = fmaxf(mt, sc[i]);
+            }
         }
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         if (mt > M) { /* the column's running maximum moves: rescale what has been accumulated */
@@ -168,9 +176,12 @@ __global__ void __launch_bounds__(256) attn_prefill_kernel(const AttnPrefillArgs
             const u32x4 B = u32x4{pw[4 * s2], pw[4 * s2 + 1], pw[4 * s2 + 2], pw[4 * s2 + 3]};
 #pragma unroll
             for (int db = 0; db < NDB; db++) {
-                const uint16_t* vrow = vb + (db * 32 + r) * AP_VS + 16 * s2 + 4 * h;
-                const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow), hi = *reinterpret_cast<const u32x2*>(vrow + 8);
-                const u32x4 A = u32x4{lo.x, lo.y, hi.x, hi.y};
+                // lane l16 of a 16-lane group addresses key-row (l16 >> 2) of its 4, d-piece 4 (l16 & 3) of the group's 16 d; it receives the 4 keys of d = l16
+                const uint16_t* vp = vb + (16 * s2 + 4 * h + ((lane & 15) >> 2)) * VS + db * 32 + (lane & 16) + 4 * (lane & 3);
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vp));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vp + 8 * VS));
+                const bf16x8 A8 = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const u32x4 A = __builtin_bit_cast(u32x4, A8);
                 o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), o[db], 0, 0, 0);
                 if (PSPLIT) {
                     const u32x4 B2 = u32x4{pl[4 * s2], pl[4 * s2 + 1], pl[4 * s2 + 2], pl[4 * s2 + 3]};
@@ -221,7 +232,7 @@ int attn_prefill_mfma_launch(hipStream_t st, const uint16_t* q, const uint16_t* 
     a.n_seq = n_seq;
     const int TQ = 128 / GQ;
     dim3 grid((n_tok + TQ - 1) / TQ, n_kv, n_seq);
-    const size_t smem = sizeof(uint16_t) * (2 * (size_t)AP_KT * (hd + 8) + 2 * (size_t)hd * AP_VS);
+    const size_t smem = sizeof(uint16_t) * (2 * (size_t)AP_KT * (hd + 8) + 2 * (size_t)AP_KT * (hd + AP_VPAD));
     const int rc = hd == 128 ? ap_launch_gq<128>(st, a, GQ, grid, smem) : ap_launch_gq<64>(st, a, GQ, grid, smem);
     if (rc) return rc;
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
