@@ -182,6 +182,14 @@ def main():
         m.engine_check()
         out["roofline_lm_head"] = head_rl
         out["cpu_baseline"] = cpu_baseline(m, cfg, forced, args.cpu_seconds) if (world == 1 and args.cpu_seconds > 0) else None
+        if args.config == "qwen3-0.6b":   # last (it overwrites the KV rows and ids the checks above read): the prompt half through a prompt that fills the context, one token batch
+            try:
+                long_prompt = np.random.default_rng(7).integers(0, cfg["vocab"], size=S - 1).astype(np.int32)
+                out["prefill"]["long_prompt"] = prefill_rate(m, long_prompt, ms_per_step, reps=3,
+                                                             bound="mfma (token-batch GEMMs with in-register 4-bit unpack over all rows of the prompt + flash attention); far from the peak at this "
+                                                                   "model size: the per-layer products are 4-13 GFLOP each")
+            except Exception as e:   # a side measurement must never cost the bench line
+                out["prefill"]["long_prompt"] = {"error": repr(e)[:200]}
         if world == 1 and args.cpu_seconds > 0 and args.cpu_fp16_steps > 0 and args.config == "qwen3-0.6b":
             try:
                 out["cpu_baseline_fp16"] = cpu_fp16_decode(cfg, ctx.device, args.cpu_fp16_steps)
@@ -328,7 +336,7 @@ def tp_main(args, cfg, rank, world, dev):
         dist.destroy_process_group()
 
 
-def prefill_rate(m, prompt, decode_ms_per_step, reps=5):
+def prefill_rate(m, prompt, decode_ms_per_step, reps=5, bound=None):
     """The prompt half of the metric, reported beside the decode rate (never inside `value`): the 128-token prompt through
     Fish::Prefill (token batches on the MFMA tile kernels) -- wall time of `reps` calls after one warm-up, each ending with the
     head + pick of the first generated token.  The reference prefills token by token through the decode path (GoPT.cpp:1139-1146),
@@ -355,7 +363,7 @@ def prefill_rate(m, prompt, decode_ms_per_step, reps=5):
             "token_serial_ms": round(decode_ms_per_step * n, 3),
             "roofline": {"flops": int(flops), "bytes": int(nbytes), "achieved_TFLOPs": round(tf, 2), "mfma_peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS, "mfma_frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
                          "achieved_GBs": round(gbs, 1), "hbm_peak_GBs": HBM_PEAK_GBS, "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
-                         "bound": "neither: %d dependent launches of ~10 us each (8 per layer); at this size the prompt is bound by launch + first-load latency" % (8 * cfg["n_layer"] + 3)}}
+                         "bound": bound or "neither: %d dependent launches of ~10 us each (8 per layer); at this size the prompt is bound by launch + first-load latency" % (8 * cfg["n_layer"] + 3)}}
 
 
 def concurrent_streams(cfg, layer_type, head_type, dev, S, forced, n_prompt, mean_bytes):

@@ -560,7 +560,7 @@ int Fish::Prefill(const int* tokens, int n, int pos0) {
     if (n < 1 || pos0 < 0 || pos0 + n > config.n_ctx) return KF_INVALID_ARGS;
     for (int i = 0; i < n; i++)
         if (tokens[i] < 0 || tokens[i] >= config.vocab) return KF_INVALID_ARGS;
-    const int PC = prefill_chunk, C = config.nEmbed, qd = config.n_head * config.head_dim;
+    const int PC = prefill_chunk < config.n_ctx ? prefill_chunk : config.n_ctx, C = config.nEmbed, qd = config.n_head * config.head_dim;
     if (!gBUFF.bX) {
         gBUFF.bX = GT(ctx, "bX", typNUMBER::BF16, C, PC);
         gBUFF.bNorm = GT(ctx, "bNorm", typNUMBER::BF16, C, PC);

@@ -255,7 +255,9 @@ struct Fish {
     // afterwards the KV cache holds rows pos0..pos0+n-1, d_state = {greedy next token, pos0+n}, d_tokens_out[pos0+n-1] = that token.
     // The reference prefills token by token (Fish::Chat, GoPT.cpp:1139-1146); same arithmetic per token, fp32 sums in MFMA order.
     int Prefill(const int* tokens, int n, int pos0);
-    int prefill_chunk = 1024;
+    // rows per token batch (clamped to n_ctx).  Measured, Qwen3-0.6B 4-bit, prompt filling the context: 2047 tokens 20.9 / 15.5 / 9.8 ms at 512 / 1024 / 2048 rows,
+    // 8191 tokens 92.3 / 53.9 / 42.7 / 36.6 ms at 1024 / 2048 / 4096 / 8192 (scratch/prefill_chunk.py): the tile kernels want many rows per launch.
+    int prefill_chunk = 8192;
     int prefill_mode = 0;  // Generate: 0 token-serial prefill like the reference, 1 batched
 };
 
