@@ -720,6 +720,43 @@ int kf_embed_batch(kf_ctx* c, const kf_weight* w, const int32_t* d_tokens, int n
     if (!out || !al16(out) || !d_tokens || n_tok < 1) return fail(KF_INVALID_ARGS, "kf_embed_batch: bad args");
     RET(kf::embed_launch(c->stream, w, 0, d_tokens, nullptr, nullptr, out, n_tok));
 }
+// Large token batches of matrices that share their input (Q | K | V, gate | up): GetDataX of each into the caller's scratch, back to back, then ONE launch of the
+// 256 x 256 bf16 tile kernel over the stacked rows (each matrix a multiple of 256 rows; its rows go to its own output).  A 1024-row K or V projection alone is 4 x 8
+// tiles at 2048 tokens -- an eighth of the chip -- and took 32 us on the in-register-unpack kernels; stacked with Q it is 128 tiles.
+static const int KF_MULTI_DEQ_MIN = 1024; /* token rows from which the stacked route is taken */
+static size_t up256z(size_t v) { return (v + 255) & ~(size_t)255; } /* a no-op on these sizes (multiples of 256 rows x 64 columns): the stacked rows are contiguous */
+static bool multi_deq_ok(int n_w, const kf_weight* const* w, int nTok, size_t* need) {
+    size_t tot = 0;
+    long rows = 0;
+    if (n_w < 2 || n_w > 3 || nTok < KF_MULTI_DEQ_MIN) return false;
+    for (int i = 0; i < n_w; i++) {
+        if (w[i]->qzeros || w[i]->quant != KF_QUANT_GROUP || w[i]->ne0 < 256 || (w[i]->ne0 % 256) != 0 || (w[i]->ne1 % 64) != 0 || w[i]->ne1 != w[0]->ne1) return false;
+        tot += up256z((size_t)w[i]->ne0 * w[i]->ne1 * 2), rows += w[i]->ne0;
+    }
+    if ((rows / 256) * ((nTok + 255) / 256) < 64) return false;
+    *need = tot;
+    return true;
+}
+size_t kf_linear_multi_scratch_bytes(int n_w, const kf_weight* const* w, int nTok) {
+    size_t need = 0;
+    if (!w) return 0;
+    for (int i = 0; i < n_w; i++)
+        if (!w[i]) return 0;
+    return multi_deq_ok(n_w, w, nTok, &need) ? need : 0;
+}
+// KF_OK done, 1 not this route, < 0 error
+static int multi_deq_route(kf_ctx* c, int n_w, const kf_weight* const* w, const kf_bf16* x, kf_bf16* const* y, int nTok) {
+    size_t need = 0;
+    if (!multi_deq_ok(n_w, w, nTok, &need) || !c->scratch || c->scratch_bytes < need || !al16(x)) return 1;
+    int M[3] = {0, 0, 0};
+    size_t off = 0;
+    for (int i = 0; i < n_w; i++) {
+        const int r = kf::dequant_launch(c->stream, w[i], (uint16_t*)((char*)c->scratch + off));
+        if (r != KF_OK) return r < 0 ? r : KF_HIP_CHECK;
+        M[i] = w[i]->ne0, off += up256z((size_t)w[i]->ne0 * w[i]->ne1 * 2);
+    }
+    return kf::gemm3_multi_launch(c->stream, n_w, (const uint16_t*)c->scratch, M, w[0]->ne1, x, w[0]->ne1, nTok, y);
+}
 int kf_linear_multi(kf_ctx* c, int n_w, const kf_weight* const* w, const kf_bf16* x, kf_bf16* const* y, int nTok) {
     CHKCTX(c);
     if (n_w < 1 || n_w > 3 || !w || !y || !x || nTok < 1) return fail(KF_INVALID_ARGS, "kf_linear_multi: bad args (n_w=%d nTok=%d)", n_w, nTok);
@@ -728,6 +765,11 @@ int kf_linear_multi(kf_ctx* c, int n_w, const kf_weight* const* w, const kf_bf16
         if (r) return r;
         if (!y[i]) return fail(KF_INVALID_ARGS, "kf_linear_multi: y[%d] null", i);
         if (w[i]->ne1 != w[0]->ne1) return fail(KF_INVALID_ARGS, "kf_linear_multi: the matrices do not share the input width");
+    }
+    if (n_w > 1 && nTok >= KF_MULTI_DEQ_MIN) {
+        const int rc = multi_deq_route(c, n_w, w, x, y, nTok);
+        if (rc < 0) return fail(rc, "kf_linear_multi (dequantise + stacked tile GEMM) failed with %d", rc);
+        if (rc == KF_OK) return KF_OK;
     }
     if (n_w > 1 && nTok >= 8) {
         const int rc = kf::gemm_multi_launch(c->stream, n_w, w, x, w[0]->ne1, nTok, y);
@@ -748,6 +790,13 @@ int kf_gateup_swiglu_batch(kf_ctx* c, const kf_weight* gate, const kf_weight* up
     if (r) return r;
     if (!x || !act || !up_scratch || nTok < 1) return fail(KF_INVALID_ARGS, "kf_gateup_swiglu_batch: bad args");
     if (gate->ne0 != up->ne0 || gate->ne1 != up->ne1) return fail(KF_INVALID_ARGS, "kf_gateup_swiglu_batch: gate and up shapes differ");
+    if (nTok >= KF_MULTI_DEQ_MIN) { /* gate | up stacked in one large-batch launch, then the SwiGLU expression on the two bf16 results (what the paired kernel computes too) */
+        const kf_weight* ws[2] = {gate, up};
+        kf_bf16* ys[2] = {act, up_scratch};
+        const int rc = multi_deq_route(c, 2, ws, x, ys, nTok);
+        if (rc < 0) return fail(rc, "kf_gateup_swiglu_batch (dequantise + stacked tile GEMM) failed with %d", rc);
+        if (rc == KF_OK) return kf_swiglu(c, act, up_scratch, act, (size_t)nTok * gate->ne0);
+    }
     if (nTok >= 8) {
         const int rc = kf::gemm_paired_launch(c->stream, gate, up, x, gate->ne1, nTok, act);
         if (rc < 0) return fail(rc, "kf_gateup_swiglu_batch failed with %d", rc);

@@ -145,21 +145,32 @@ __device__ __forceinline__ void g3_mainloop(const GemmArgs& a, int m0, int t0, i
 template <bool AKM>
 __device__ __forceinline__ void g3_epilogue(const GemmArgs& a, int m0, int t0, const f32x4 (&acc)[8][4], int wid, int lane) {
     const int wm = wid >> 2, wn = wid & 3, r16 = lane & 15, q4 = lane >> 4;
-    const bool vec_ok = ((a.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.y) & 7) == 0);
+    // up to three matrices stacked along M (Q | K | V or gate | up, each a multiple of the 256-row tile: a.rb_end[j] = cumulative rows / 32): the tile's rows go to
+    // that matrix's own output (the K and V rows of a prompt land in the cache, Q in its buffer)
+    uint16_t* ybase = a.y;
+    long long ldy = a.ldy;
+    int mshift = 0, Mlim = a.M;
+    if (a.njobs > 1) {
+        const int e0 = a.rb_end[0] * 32, e1 = a.rb_end[1] * 32;
+        if (m0 >= e1 && a.njobs > 2) ybase = a.xy[1], ldy = a.xldy[1], mshift = e1, Mlim = a.rb_end[2] * 32;
+        else if (m0 >= e0) ybase = a.xy[0], ldy = a.xldy[0], mshift = e0, Mlim = e1;
+        else Mlim = e0;
+    }
+    const bool vec_ok = ((ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(ybase) & 7) == 0);
 #pragma unroll
     for (int mt = 0; mt < 8; mt++)
 #pragma unroll
         for (int nt = 0; nt < 4; nt++) {
             const int tok = t0 + wn * 64 + nt * 16 + r16, m = m0 + wm * 128 + mt * 16 + 4 * q4;
-            if (tok >= a.n || m >= a.M) continue;
-            uint16_t* yp = a.y + (size_t)tok * a.ldy + m;
+            if (tok >= a.n || m >= Mlim) continue;
+            uint16_t* yp = ybase + (size_t)tok * ldy + (m - mshift);
             const float vv[4] = {acc[mt][nt].x, acc[mt][nt].y, acc[mt][nt].z, acc[mt][nt].w};
             uint16_t o[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 float v = vv[j];
                 o[j] = 0;
-                if (m + j < a.M) {
+                if (m + j < Mlim) {
                     if (a.alpha != 1.0f) v = a.alpha * v;
                     if (a.beta != 0.0f) v = v + a.beta * bf2f(yp[j]);
                     if (a.bias) v = v + bf2f(a.bias[m + j]);
@@ -168,12 +179,12 @@ __device__ __forceinline__ void g3_epilogue(const GemmArgs& a, int m0, int t0, c
                     o[j] = qv;
                 }
             }
-            if (vec_ok && m + 3 < a.M) {
+            if (vec_ok && m + 3 < Mlim) {
                 *reinterpret_cast<u32x2*>(yp) = u32x2{(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16)};
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    if (m + j < a.M) yp[j] = o[j];
+                    if (m + j < Mlim) yp[j] = o[j];
             }
         }
 }
@@ -356,6 +367,28 @@ int gemm3_km_launch(hipStream_t st, const uint16_t* A, long long lda, bool akm, 
     if (akm) return g3_go<true, false>(st, a, nwg, ws, ws_bytes);
     if (bkm) return g3_go<false, true>(st, a, nwg, ws, ws_bytes);
     return g3_go<false, false>(st, a, nwg, ws, ws_bytes);
+}
+
+// up to three bf16 matrices stacked along M in ONE contiguous buffer (the caller dequantised them back to back: Q | K | V, or gate | up), each a multiple of 256
+// rows, multiplied by the same x in one launch; matrix j's rows go to y[j] (row stride M[j]).  1 = shape not served.
+int gemm3_multi_launch(hipStream_t st, int n_w, const uint16_t* Wcat, const int* M, int K, const uint16_t* x, long long ldx, int n, uint16_t* const* y) {
+    if (n_w < 2 || n_w > 3 || K % G3_BK != 0 || K < G3_BK || n < G3_BN || (ldx & 7) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(Wcat) & 15)) return 1;
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    int tot = 0;
+    for (int j = 0; j < 3; j++) {
+        if (j < n_w) {
+            if (M[j] < G3_BM || M[j] % G3_BM != 0) return 1;
+            tot += M[j];
+        }
+        a.rb_end[j] = tot / 32;
+        if (j >= 1 && j < n_w) a.xy[j - 1] = y[j], a.xldy[j - 1] = M[j];
+    }
+    a.njobs = n_w;
+    a.w = reinterpret_cast<const unsigned char*>(Wcat), a.M = tot, a.K = K, a.x = x, a.ldx = ldx, a.n = n, a.y = y[0], a.ldy = M[0], a.alpha = 1.0f, a.beta = 0.0f;
+    const long nwg = (long)(tot / G3_BM) * ((n + G3_BN - 1) / G3_BN);
+    if (nwg < 64) return 1;
+    return g3_go<false, false>(st, a, nwg, nullptr, 0);
 }
 
 }  // namespace kf

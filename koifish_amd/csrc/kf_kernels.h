@@ -86,6 +86,7 @@ void argmax_finish_launch(hipStream_t st, const float* val, const int* idx, int 
 int gemm3_km_launch(hipStream_t st, const uint16_t* A, long long lda, bool akm, const uint16_t* B, long long ldb, bool bkm, int n, int M, int K, uint16_t* y, long long ldy,
                     const uint16_t* bias, float alpha, float beta, void* ws, size_t ws_bytes);
 size_t gemm3_sk_ws_bytes();
+int gemm3_multi_launch(hipStream_t st, int n_w, const uint16_t* Wcat, const int* M, int K, const uint16_t* x, long long ldx, int n, uint16_t* const* y);
 int gemm_launch(hipStream_t st, const kf_weight* w, const uint16_t* x, long long ldx, int n, uint16_t* y, long long ldy, const uint16_t* bias, float alpha,
                 float beta, const uint16_t* residual, long long ldr);
 

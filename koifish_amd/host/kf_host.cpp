@@ -570,6 +570,23 @@ int Fish::Prefill(const int* tokens, int n, int pos0) {
         gBUFF.bUp = GT(ctx, "bUp", typNUMBER::BF16, config.n_ff, PC);
         if (!gBUFF.bX || !gBUFF.bNorm || !gBUFF.bQ || !gBUFF.bAttn || !gBUFF.bGate || !gBUFF.bUp) return KF_OUTOF_GPUMEMORY;
         KF_TRY(kf_malloc(ctx, (size_t)PC * 4, (void**)&gBUFF.d_ptok));
+        // the stacked large-batch routes (Q | K | V and gate | up dequantised back to back, one tile-GEMM launch each): their workspace, sized here -- the first
+        // Prefill allocates the batch buffers anyway; the launches themselves never allocate
+        for (int l = 0; l < config.nLayer; l++) {
+            kf_weight wq = attn[l]->Q.w->desc(), wk = attn[l]->K.w->desc(), wv = attn[l]->V.w->desc(), wg = ffn[l]->gate.w->desc(), wu = ffn[l]->up.w->desc();
+            const kf_weight* qkv[3] = {&wq, &wk, &wv};
+            const kf_weight* gu[2] = {&wg, &wu};
+            size_t need = kf_linear_multi_scratch_bytes(3, qkv, PC), need2 = kf_linear_multi_scratch_bytes(2, gu, PC);
+            need = need > need2 ? need : need2;
+            if (need > lin_scratch_bytes) {
+                KF_TRY(kf_sync(ctx));
+                void* p = nullptr;
+                KF_TRY(kf_malloc(ctx, need, &p));
+                KF_TRY(kf_set_scratch(ctx, p, need));
+                if (lin_scratch) kf_free(ctx, lin_scratch);
+                lin_scratch = p, lin_scratch_bytes = need;
+            }
+        }
     }
     floatX* bx = ToX(gBUFF.bX);
     kf_weight we = embed.w->desc();

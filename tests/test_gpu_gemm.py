@@ -125,6 +125,51 @@ def test_multi_and_paired_launches_equal_separate_ones(ctx, O, t, nt):
     assert np.array_equal(u16(act).reshape(-1), u16(want).reshape(-1))
 
 
+@pytest.mark.parametrize("t", [L.Q4, L.F8E5M2])
+@pytest.mark.parametrize("nt", [1100, 2048])
+def test_stacked_large_batch_route_vs_exact(ctx, O, t, nt):
+    """kf_linear_multi / kf_gateup_swiglu_batch at >= 1024 rows with the workspace kf_linear_multi_scratch_bytes asks for: Q | K | V (gate | up) are dequantised back
+    to back and multiplied by ONE launch of the 256 x 256 bf16 tile kernel, each matrix's rows landing in its own output -- against the exact fp64 products of the
+    dequantised weights (the tolerance of the other token-batch GEMM tests)"""
+    k = 1024
+    rng = np.random.default_rng(nt + t)
+    x = O.f32_to_bf16(rng.normal(0, 1.0, size=(nt, k)).astype(np.float32))
+    xd = bf16_t(x, ctx.device)
+    ms = (2048, 1024, 1024)
+    ows = [O.quantize(O.f32_to_bf16(rng.normal(0, 0.02, size=(m, k)).astype(np.float32)), m, k, t) for m in ms]
+    dws = [ctx.upload_blob(t, m, k, ow.blob()) for m, ow in zip(ms, ows)]
+    descs = [d.desc() for d in dws]
+    wp = (C.c_void_p * 3)(*[C.addressof(d) for d in descs])
+    need = ctx.hip.kf_linear_multi_scratch_bytes(3, wp, nt)
+    assert need == sum(m * k * 2 for m in ms)
+    assert ctx.hip.kf_linear_multi_scratch_bytes(3, wp, 512) == 0      # small batches: the in-register-unpack kernels, no workspace
+    ctx.sync()
+    ctx._lin_ws = torch.empty(max(need, 3072 * k * 4), dtype=torch.uint8, device=ctx.device)
+    L.check(ctx.hip.kf_set_scratch(ctx.h, C.c_void_p(ctx._lin_ws.data_ptr()), C.c_size_t(ctx._lin_ws.numel())), "kf_set_scratch")
+    ys = [torch.full((nt, m), 7.0, dtype=torch.bfloat16, device=ctx.device) for m in ms]
+    yp = (C.c_void_p * 3)(*[y.data_ptr() for y in ys])
+    assert ctx.hip.kf_linear_multi(ctx.h, 3, wp, xd.data_ptr(), yp, nt) == 0, ctx.hip.kf_last_error()
+    ctx.sync()
+    f = lambda a: O.bf16_to_f32(a).astype(np.float64)
+    for ow, y, m in zip(ows, ys, ms):
+        ref = f(x) @ f(O.dequant(ow)).reshape(m, k).T
+        assert np.abs(f(u16(y)) - ref).max() <= 2.0 ** -7 * np.abs(ref).max()
+    m = 3072
+    og, ou = (O.quantize(O.f32_to_bf16(rng.normal(0, 0.05, size=(m, k)).astype(np.float32)), m, k, t) for _ in range(2))
+    g, u = ctx.upload_blob(t, m, k, og.blob()), ctx.upload_blob(t, m, k, ou.blob())
+    act = torch.zeros(nt, m, dtype=torch.bfloat16, device=ctx.device)
+    tmp = torch.zeros(nt, m, dtype=torch.bfloat16, device=ctx.device)
+    gd, ud = g.desc(), u.desc()
+    assert ctx.hip.kf_gateup_swiglu_batch(ctx.h, C.byref(gd), C.byref(ud), xd.data_ptr(), act.data_ptr(), tmp.data_ptr(), nt) == 0, ctx.hip.kf_last_error()
+    ctx.sync()
+    yg = f(x) @ f(O.dequant(og)).reshape(m, k).T
+    yu = f(x) @ f(O.dequant(ou)).reshape(m, k).T
+    ref = yg / (1.0 + np.exp(-yg)) * yu
+    assert np.abs(f(u16(act)) - ref).max() <= 2.0 ** -6 * np.abs(ref).max()
+    # and exactly the SwiGLU expression of the two bf16 products the launch left (gate in act before the element-wise pass is gone; up is in tmp)
+    assert np.abs(f(u16(tmp)) - yu).max() <= 2.0 ** -7 * np.abs(yu).max()
+
+
 @pytest.mark.parametrize("t", [L.Q4, L.BF16, L.T_SIGN])
 def test_gemm_many_token_tiles_vs_exact(ctx, O, t):
     """a batch of 17 token tiles on the staged kernel (ragged tail): exact fp64 product of the dequantised weights"""
