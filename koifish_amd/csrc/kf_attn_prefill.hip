@@ -43,8 +43,11 @@ __device__ __forceinline__ float ap_exp2(float x) { return __builtin_amdgcn_exp2
 
 constexpr bool PSPLIT = true; /* probabilities enter P.V as bf16 high + bf16 remainder (two MFMAs) */
 
-template <int HD, int GQ>
-__global__ void __launch_bounds__(256) attn_prefill_kernel(const AttnPrefillArgs a) {
+// KH = 2: eight waves; waves 0-3 walk the even key tiles, waves 4-7 the odd ones (each half with its own pair of LDS tile buffers), and the two partial softmaxes
+// (O, running maximum, sum) of a column are merged through LDS at the end.  A workgroup's time is the walk of its longest column over its keys: halved -- which is
+// what a prompt of a few thousand tokens needs, where there is about one workgroup per CU and the launch lasts as long as the last query block.
+template <int HD, int GQ, int KH>
+__global__ void __launch_bounds__(256 * KH) attn_prefill_kernel(const AttnPrefillArgs a) {
     constexpr int NS = HD / 16;   /* MFMA steps over d for S^T */
     constexpr int NDB = HD / 32;  /* 32-row blocks of O^T */
     constexpr int KS = HD + 8;    /* padded K row, elements */
@@ -53,11 +56,13 @@ __global__ void __launch_bounds__(256) attn_prefill_kernel(const AttnPrefillArgs
     constexpr int CPT = KCH / 256;      /* chunks per thread */
     static_assert(KCH % 256 == 0, "tile chunks must divide among 256 threads");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint16_t* ks = reinterpret_cast<uint16_t*>(smem_raw);  // 2 x [AP_KT][KS]
     constexpr int VS = HD + AP_VPAD; /* V row stride, elements */
-    uint16_t* vt = ks + 2 * AP_KT * KS;                    // 2 x [AP_KT][VS]
+    constexpr int HALF_EL = 2 * AP_KT * KS + 2 * AP_KT * VS; /* one key-half's buffers, elements */
+    const int kh = KH == 2 ? (int)(threadIdx.x >> 8) : 0; /* which key tiles this wave walks: t = kh, kh + KH, ... */
+    uint16_t* ks = reinterpret_cast<uint16_t*>(smem_raw) + (size_t)kh * HALF_EL;  // 2 x [AP_KT][KS]
+    uint16_t* vt = ks + 2 * AP_KT * KS;                                           // 2 x [AP_KT][VS]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int g = blockIdx.y, tok0 = (gridDim.x - 1 - blockIdx.x) * TQ; /* the columns with the most keys first */
     const size_t seq_row = (size_t)blockIdx.z * a.n_tok;
@@ -111,14 +116,17 @@ __global__ void __launch_bounds__(256) attn_prefill_kernel(const AttnPrefillArgs
     float M = -__builtin_inff(), l = 0.f;
     const float LOG2E = 1.44269502162933349609375f;
 
-    tload(0);
+    const int nstep = (ntile + KH - 1) / KH; /* both halves make the same number of steps (and barriers); the odd half may find its last one empty */
+    if (kh < ntile) tload(kh);
     tstore(0);
     __syncthreads();
-    for (int t = 0; t < ntile; t++) {
-        const bool more = t + 1 < ntile;
-        if (more) tload(t + 1);
-        const uint16_t* kb = ks + (size_t)(t & 1) * AP_KT * KS;
-        const uint16_t* vb = vt + (size_t)(t & 1) * AP_KT * VS;
+    for (int j = 0; j < nstep; j++) {
+        const int t = kh + KH * j;
+        const bool more = t + KH < ntile;
+        if (more) tload(t + KH);
+        if (t < ntile) {
+        const uint16_t* kb = ks + (size_t)(j & 1) * AP_KT * KS;
+        const uint16_t* vb = vt + (size_t)(j & 1) * AP_KT * VS;
         // ---- S^T tile
         f32x16 st;
 #pragma unroll
@@ -161,10 +169,12 @@ __global__ void __launch_bounds__(256) attn_prefill_kernel(const AttnPrefillArgs
         }
         // p as a bf16 pair (high part + rounded remainder): the P.V product then carries ~16 significant bits of p, which keeps the batch
         // form within rounding noise of the decode kernel's fp32 probabilities (bf16 alone: up to 4 bf16 ulps on the next layer's K rows)
+        // (KH = 2: a column whose keys all lie in the other half's tiles has seen nothing yet -- M = -inf; its p must be 0, not exp2(-inf + inf))
+        const float Mref = (KH == 2 && M == -__builtin_inff()) ? 0.f : M;
         uint32_t pw[8], pl[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const float p0 = ap_exp2((sc[2 * i] - M) * LOG2E), p1 = ap_exp2((sc[2 * i + 1] - M) * LOG2E); /* masked: exp2(-inf) = 0 */
+            const float p0 = ap_exp2((sc[2 * i] - Mref) * LOG2E), p1 = ap_exp2((sc[2 * i + 1] - Mref) * LOG2E); /* masked: exp2(-inf) = 0 */
             l += p0;
             l += p1;
             pw[i] = pack_bf16x2(p0, p1);
@@ -189,8 +199,30 @@ __global__ void __launch_bounds__(256) attn_prefill_kernel(const AttnPrefillArgs
                 }
             }
         }
-        if (more) tstore((t + 1) & 1);
+        } /* t < ntile */
+        if (more) tstore((j + 1) & 1);
         __syncthreads();
+    }
+    if (KH == 2) { /* the odd half hands (O, M, l) over, register-major rows of 256 lanes; the even half merges and finishes */
+        float* ex = reinterpret_cast<float*>(smem_raw);
+        constexpr int NR = NDB * 16;
+        if (kh == 1) {
+#pragma unroll
+            for (int db = 0; db < NDB; db++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) ex[(db * 16 + i) * 256 + tid] = o[db][i];
+            ex[NR * 256 + tid] = M, ex[(NR + 1) * 256 + tid] = l;
+        }
+        __syncthreads();
+        if (kh == 1) return;
+        const float M1 = ex[NR * 256 + tid], l1 = ex[(NR + 1) * 256 + tid];
+        const float Mm = fmaxf(M, M1); /* the even half has seen key 0: finite */
+        const float a0 = ap_exp2((M - Mm) * LOG2E), a1 = ap_exp2((M1 - Mm) * LOG2E);
+        l = l * a0 + l1 * a1;
+#pragma unroll
+        for (int db = 0; db < NDB; db++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) o[db][i] = o[db][i] * a0 + ex[(db * 16 + i) * 256 + tid] * a1;
     }
     // ---- out[col][d] = O^T[d][col] / l ; lane (col, h) holds d = 32 db + (i & 3) + 8 (i >> 2) + 4 h
     l += __shfl_xor(l, 32, 64);
@@ -207,16 +239,25 @@ __global__ void __launch_bounds__(256) attn_prefill_kernel(const AttnPrefillArgs
         }
 }
 
+template <int HD, int GQ, int KH>
+static int ap_go(hipStream_t st, const AttnPrefillArgs& a, dim3 grid, size_t smem) {
+    static int attr_set = 0;
+    if (!attr_set && smem * KH > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)attn_prefill_kernel<HD, GQ, KH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem * KH)) != hipSuccess) return KF_HIP_CHECK;
+        attr_set = 1;
+    }
+    hipLaunchKernelGGL((attn_prefill_kernel<HD, GQ, KH>), grid, dim3(256 * KH), smem * KH, st, a);
+    return 0;
+}
 template <int HD>
-static int ap_launch_gq(hipStream_t st, const AttnPrefillArgs& a, int GQ, dim3 grid, size_t smem) {
+static int ap_launch_gq(hipStream_t st, const AttnPrefillArgs& a, int GQ, dim3 grid, size_t smem, int kh) {
     switch (GQ) {
-        case 1: hipLaunchKernelGGL((attn_prefill_kernel<HD, 1>), grid, dim3(256), smem, st, a); break;
-        case 2: hipLaunchKernelGGL((attn_prefill_kernel<HD, 2>), grid, dim3(256), smem, st, a); break;
-        case 4: hipLaunchKernelGGL((attn_prefill_kernel<HD, 4>), grid, dim3(256), smem, st, a); break;
-        case 8: hipLaunchKernelGGL((attn_prefill_kernel<HD, 8>), grid, dim3(256), smem, st, a); break;
+        case 1: return kh == 2 ? ap_go<HD, 1, 2>(st, a, grid, smem) : ap_go<HD, 1, 1>(st, a, grid, smem);
+        case 2: return kh == 2 ? ap_go<HD, 2, 2>(st, a, grid, smem) : ap_go<HD, 2, 1>(st, a, grid, smem);
+        case 4: return kh == 2 ? ap_go<HD, 4, 2>(st, a, grid, smem) : ap_go<HD, 4, 1>(st, a, grid, smem);
+        case 8: return kh == 2 ? ap_go<HD, 8, 2>(st, a, grid, smem) : ap_go<HD, 8, 1>(st, a, grid, smem);
         default: return 1;
     }
-    return 0;
 }
 
 // KF_OK launched; 1 = shape not covered (the caller falls back to the per-token kernel)
@@ -233,7 +274,10 @@ int attn_prefill_mfma_launch(hipStream_t st, const uint16_t* q, const uint16_t* 
     const int TQ = 128 / GQ;
     dim3 grid((n_tok + TQ - 1) / TQ, n_kv, n_seq);
     const size_t smem = sizeof(uint16_t) * (2 * (size_t)AP_KT * (hd + 8) + 2 * (size_t)AP_KT * (hd + AP_VPAD));
-    const int rc = hd == 128 ? ap_launch_gq<128>(st, a, GQ, grid, smem) : ap_launch_gq<64>(st, a, GQ, grid, smem);
+    // about one workgroup per CU or fewer: the launch lasts as long as its last query block -- two key halves per workgroup (2047 tokens, 16 / 8 heads x 128:
+    // 81 -> 67 us); with more workgroups than that the halves only compete for the CU (8 x 1024 x 25 x 64: 130 vs 143 us; 4095 tokens: 15.9 vs 16.4 ms per prompt)
+    const int kh = ((long)grid.x * grid.y * grid.z <= 320 && n_tok >= 1024) ? 2 : 1; /* short prompts: the launch is a few microseconds either way */
+    const int rc = hd == 128 ? ap_launch_gq<128>(st, a, GQ, grid, smem, kh) : ap_launch_gq<64>(st, a, GQ, grid, smem, kh);
     if (rc) return rc;
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
