@@ -69,7 +69,8 @@ __device__ __forceinline__ bf16x8 g3_frag_km(const unsigned char* tile, int rowb
 // kt + NST - 1 are issued while step kt is multiplied and drained with a COUNTED s_waitcnt vmcnt + one raw s_barrier per step (a __syncthreads() would drain the loads
 // in flight): BK = 64 -> 2 buffers; BK = 32 -> 4 buffers, three steps in flight (measured slower, see g3_go).  Also measured and dropped: the barrier moved into
 // the middle of the step's MFMA stream (the last 16 MFMAs of a step held back behind it, the first fragments of the next step read under them): 979 TFLOP/s against
-// 1000 on the forward shapes at 246 VGPRs, and the k-major forms spill.
+// 1000 on the forward shapes at 246 VGPRs, and the k-major forms spill; four waves of 128 x 128 outputs each (256 accumulator AGPRs, a third less LDS traffic per MFMA,
+// the vendor library's shape): the compiler fills all 512 registers and still spills inside the loop, 228 TFLOP/s -- that form needs a hand-scheduled loop.
 template <bool AKM, bool BKM, int BK>
 __device__ __forceinline__ void g3_mainloop(const GemmArgs& a, int m0, int t0, int kt0, int kt1, f32x4 (&acc)[8][4], unsigned char* smem_raw, int wid, int lane) {
     constexpr int TILE = G3_BM * BK * 2, NST = (4 * G3_TILE) / (2 * TILE), LPW = 2 * (BK / 16); /* loads per wave and step */
