@@ -20,14 +20,25 @@ namespace kf {
 
 constexpr int G3_BM = 256, G3_BN = 256, G3_BK = 64;
 constexpr int G3_TILE = G3_BM * G3_BK * 2; /* 32 KiB per operand tile */
+// the workgroup tile: BM rows x BN tokens, NW waves as 2 (rows) x NW / 2 (tokens).  Big = the 256 x 256 tile of the header (8 waves, 128 x 64 outputs each, 128 KiB of
+// LDS: one workgroup per CU); Small = 128 x 128 on 4 waves (64 x 64 outputs each, 64 KiB: two workgroups per CU) for products with too few 256 x 256 tiles to fill the
+// chip -- the o_proj / down projections of a 1-2 k token prompt (M = 1024: 32 big tiles), with the split-K form below on top.  K-contiguous operands only.
+template <int BM_, int BN_, int NW_>
+struct G3Cfg {
+    static constexpr int BM = BM_, BN = BN_, NW = NW_, WN = NW_ / 2, MT = BM_ / 32, NT = BN_ / (16 * (NW_ / 2));
+    static constexpr int NIA = BM_ / (8 * NW_), NIB = BN_ / (8 * NW_); /* global_load_lds instructions per wave, operand and k-step (8 rows of 128 bytes each) */
+    static constexpr int STAGE = (BM_ + BN_) * G3_BK * 2, NTH = 64 * NW_, WGS_PER_CU = (160 * 1024) / (2 * STAGE);
+};
+using G3Big = G3Cfg<256, 256, 8>;
+using G3Small = G3Cfg<128, 128, 4>;
 
 // one operand tile (256 rows x 2 BK bytes) = BK / 2 wave instructions of 1 KiB; wave `wid` issues BK / 16 of them.  BK = 64: 8 rows per instruction, chunk c of row r
 // at position c ^ ((r >> 1) & 7); BK = 32: 16 rows per instruction (64-byte rows), chunk c at position c ^ ((r >> 2) & 3) -- either way a fragment read
 // (16 rows x one 16-byte chunk) touches all 64 banks once.
-template <int BK>
+template <int BK, int NI>
 __device__ __forceinline__ const uint16_t* g3_src(const uint16_t* __restrict__ src, long long ld, int row0, int nrows, int i, int wid, int lane) {
     constexpr int CPR = BK / 8, RPI = 64 / CPR; /* chunks per row, rows per instruction */
-    const int j = wid * (BK / 16) + i;
+    const int j = wid * NI + i;
     const int r = j * RPI + lane / CPR, p = lane % CPR, c = BK == 64 ? p ^ ((r >> 1) & 7) : p ^ ((r >> 2) & 3);
     int gr = row0 + r;
     gr = gr < nrows ? gr : nrows - 1; /* rows past the end re-read the last row: their outputs are not stored */
@@ -71,33 +82,32 @@ __device__ __forceinline__ bf16x8 g3_frag_km(const unsigned char* tile, int rowb
 // the middle of the step's MFMA stream (the last 16 MFMAs of a step held back behind it, the first fragments of the next step read under them): 979 TFLOP/s against
 // 1000 on the forward shapes at 246 VGPRs, and the k-major forms spill; four waves of 128 x 128 outputs each (256 accumulator AGPRs, a third less LDS traffic per MFMA,
 // the vendor library's shape): the compiler fills all 512 registers and still spills inside the loop, 228 TFLOP/s -- that form needs a hand-scheduled loop.
-template <bool AKM, bool BKM, int BK>
-__device__ __forceinline__ void g3_mainloop(const GemmArgs& a, int m0, int t0, int kt0, int kt1, f32x4 (&acc)[8][4], unsigned char* smem_raw, int wid, int lane) {
-    constexpr int TILE = G3_BM * BK * 2, NST = (4 * G3_TILE) / (2 * TILE), LPW = 2 * (BK / 16); /* loads per wave and step */
-    const int wm = wid >> 2, wn = wid & 3;
+template <bool AKM, bool BKM, int BK, class C>
+__device__ __forceinline__ void g3_mainloop(const GemmArgs& a, int m0, int t0, int kt0, int kt1, f32x4 (&acc)[C::MT][C::NT], unsigned char* smem_raw, int wid, int lane) {
+    static_assert(BK == G3_BK && (!(AKM || BKM) || C::BM == 256), "the k-major LDS image is 256 rows wide");
+    constexpr int NST = 2, LPW = C::NIA + C::NIB; /* loads per wave and step */
+    const int wm = wid / C::WN, wn = wid % C::WN;
     const uint16_t* const W = reinterpret_cast<const uint16_t*>(a.w);
-    auto bufA = [&](int b) { return smem_raw + (size_t)b * 2 * TILE; };
-    auto bufB = [&](int b) { return smem_raw + (size_t)b * 2 * TILE + TILE; };
+    auto bufA = [&](int b) { return smem_raw + (size_t)b * C::STAGE; };
+    auto bufB = [&](int b) { return smem_raw + (size_t)b * C::STAGE + C::BM * BK * 2; };
     // AKM: W is [K][M] with row stride a.ldr (re-used field: the residual is not served by the k-major forms); BKM: x is [K][n] with row stride a.ldx.
     // Per-lane source pointers are set up once; a step adds a uniform offset (a 64-bit multiply per load and step was a tenth of the loop's issue slots).
-    constexpr int NI = BK / 16;
-    const uint16_t *pa[NI], *pb[NI];
+    const uint16_t *pa[C::NIA], *pb[C::NIB];
 #pragma unroll
-    for (int i = 0; i < NI; i++) {
-        pa[i] = AKM ? g3_src_km<BK>(W, a.ldr, m0, a.M, i, wid, lane) : g3_src<BK>(W, a.K, m0, a.M, i, wid, lane);
-        pb[i] = BKM ? g3_src_km<BK>(a.x, a.ldx, t0, a.n, i, wid, lane) : g3_src<BK>(a.x, a.ldx, t0, a.n, i, wid, lane);
-    }
+    for (int i = 0; i < C::NIA; i++) pa[i] = AKM ? g3_src_km<BK>(W, a.ldr, m0, a.M, i, wid, lane) : g3_src<BK, C::NIA>(W, a.K, m0, a.M, i, wid, lane);
+#pragma unroll
+    for (int i = 0; i < C::NIB; i++) pb[i] = BKM ? g3_src_km<BK>(a.x, a.ldx, t0, a.n, i, wid, lane) : g3_src<BK, C::NIB>(a.x, a.ldx, t0, a.n, i, wid, lane);
     const long long stepA = AKM ? (long long)BK * a.ldr : BK, stepB = BKM ? (long long)BK * a.ldx : BK;
     auto stage = [&](int kt, int b) {
         const long long oa = stepA * kt, ob = stepB * kt;
 #pragma unroll
-        for (int i = 0; i < NI; i++)
+        for (int i = 0; i < C::NIA; i++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[i] + oa),
-                                             (__attribute__((address_space(3))) void*)(bufA(b) + (wid * NI + i) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(bufA(b) + (wid * C::NIA + i) * 1024), 16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < NI; i++)
+        for (int i = 0; i < C::NIB; i++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[i] + ob),
-                                             (__attribute__((address_space(3))) void*)(bufB(b) + (wid * NI + i) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(bufB(b) + (wid * C::NIB + i) * 1024), 16, 0, 0);
     };
 #pragma unroll
     for (int st = 0; st < NST - 1; st++)
@@ -114,38 +124,34 @@ __device__ __forceinline__ void g3_mainloop(const GemmArgs& a, int m0, int t0, i
         if (kt + NST - 1 < kt1) stage(kt + NST - 1, (cur + NST - 1) % NST);
 #pragma unroll
         for (int kk = 0; kk < BK / 32; kk++) {
-            bf16x8 af[8], bfr[4];
+            bf16x8 af[C::MT], bfr[C::NT];
 #pragma unroll
-            for (int nt = 0; nt < 4; nt++) {
-                if constexpr (BKM) bfr[nt] = g3_frag_km(bufB(cur), wn * 4 + nt, kk * 32 + 8 * q4, r16);
-                else bfr[nt] = g3_frag<BK>(bufB(cur), wn * 64 + nt * 16 + r16, kk * 4 + q4);
+            for (int nt = 0; nt < C::NT; nt++) {
+                if constexpr (BKM) bfr[nt] = g3_frag_km(bufB(cur), wn * C::NT + nt, kk * 32 + 8 * q4, r16);
+                else bfr[nt] = g3_frag<BK>(bufB(cur), wn * (16 * C::NT) + nt * 16 + r16, kk * 4 + q4);
             }
 #pragma unroll
-            for (int mt = 0; mt < 8; mt++) {
-                if constexpr (AKM) af[mt] = g3_frag_km(bufA(cur), wm * 8 + mt, kk * 32 + 8 * q4, r16);
-                else af[mt] = g3_frag<BK>(bufA(cur), wm * 128 + mt * 16 + r16, kk * 4 + q4);
+            for (int mt = 0; mt < C::MT; mt++) {
+                if constexpr (AKM) af[mt] = g3_frag_km(bufA(cur), wm * C::MT + mt, kk * 32 + 8 * q4, r16);
+                else af[mt] = g3_frag<BK>(bufA(cur), wm * (16 * C::MT) + mt * 16 + r16, kk * 4 + q4);
             }
 #pragma unroll
-            for (int mt = 0; mt < 8; mt++)
+            for (int mt = 0; mt < C::MT; mt++)
 #pragma unroll
-                for (int nt = 0; nt < 4; nt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < C::NT; nt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
     for (int kt = kt0; kt < kt1; kt += NST) {
         step(kt, std::integral_constant<int, 0>{});
         if (kt + 1 < kt1) step(kt + 1, std::integral_constant<int, 1>{});
-        if constexpr (NST == 4) {
-            if (kt + 2 < kt1) step(kt + 2, std::integral_constant<int, 2>{});
-            if (kt + 3 < kt1) step(kt + 3, std::integral_constant<int, 3>{});
-        }
     }
     __builtin_amdgcn_s_barrier(); /* a following segment's first loads must not overtake the last reads */
 }
 // epilogue (gemm_epilogue's order): lane holds rows m .. m+3 of a 16 x 16 tile for token column r16
-template <bool AKM>
-__device__ __forceinline__ void g3_epilogue(const GemmArgs& a, int m0, int t0, const f32x4 (&acc)[8][4], int wid, int lane) {
-    const int wm = wid >> 2, wn = wid & 3, r16 = lane & 15, q4 = lane >> 4;
+template <bool AKM, class C>
+__device__ __forceinline__ void g3_epilogue(const GemmArgs& a, int m0, int t0, const f32x4 (&acc)[C::MT][C::NT], int wid, int lane) {
+    const int wm = wid / C::WN, wn = wid % C::WN, r16 = lane & 15, q4 = lane >> 4;
     // up to three matrices stacked along M (Q | K | V or gate | up, each a multiple of the 256-row tile: a.rb_end[j] = cumulative rows / 32): the tile's rows go to
     // that matrix's own output (the K and V rows of a prompt land in the cache, Q in its buffer)
     uint16_t* ybase = a.y;
@@ -159,10 +165,10 @@ __device__ __forceinline__ void g3_epilogue(const GemmArgs& a, int m0, int t0, c
     }
     const bool vec_ok = ((ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(ybase) & 7) == 0);
 #pragma unroll
-    for (int mt = 0; mt < 8; mt++)
+    for (int mt = 0; mt < C::MT; mt++)
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++) {
-            const int tok = t0 + wn * 64 + nt * 16 + r16, m = m0 + wm * 128 + mt * 16 + 4 * q4;
+        for (int nt = 0; nt < C::NT; nt++) {
+            const int tok = t0 + wn * (16 * C::NT) + nt * 16 + r16, m = m0 + wm * (16 * C::MT) + mt * 16 + 4 * q4;
             if (tok >= a.n || m >= Mlim) continue;
             uint16_t* yp = ybase + (size_t)tok * ldy + (m - mshift);
             const float vv[4] = {acc[mt][nt].x, acc[mt][nt].y, acc[mt][nt].z, acc[mt][nt].w};
@@ -195,21 +201,21 @@ __device__ __forceinline__ int g3_remap(int orig, int nwg) {
     return (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + orig / 8;
 }
 
-template <bool AKM, bool BKM, int BK>
-__global__ void __launch_bounds__(512) gemm3_kernel(const GemmArgs a) {
+template <bool AKM, bool BKM, int BK, class C>
+__global__ void __launch_bounds__(C::NTH, C::WGS_PER_CU * C::NW / 4) gemm3_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int nbx = (a.M + G3_BM - 1) / G3_BM, nby = (a.n + G3_BN - 1) / G3_BN, nwg = nbx * nby;
+    const int nbx = (a.M + C::BM - 1) / C::BM, nby = (a.n + C::BN - 1) / C::BN, nwg = nbx * nby;
     const int wg = g3_remap(blockIdx.x, nwg);
     const int bx = wg % nbx, by = wg / nbx;
-    const int m0 = bx * G3_BM, t0 = by * G3_BN;
-    f32x4 acc[8][4];
+    const int m0 = bx * C::BM, t0 = by * C::BN;
+    f32x4 acc[C::MT][C::NT];
 #pragma unroll
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < C::MT; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    g3_mainloop<AKM, BKM, BK>(a, m0, t0, 0, a.K / BK, acc, smem_raw, wid, lane);
-    g3_epilogue<AKM>(a, m0, t0, acc, wid, lane);
+        for (int j = 0; j < C::NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    g3_mainloop<AKM, BKM, BK, C>(a, m0, t0, 0, a.K / BK, acc, smem_raw, wid, lane);
+    g3_epilogue<AKM, C>(a, m0, t0, acc, wid, lane);
 }
 
 // SPLIT-K forms for launches with fewer tiles than CUs (a weight gradient [OC, IC] is 49 .. 175 tiles, its contraction 8192 token rows long).  The pieces are cut so
@@ -228,38 +234,45 @@ struct G3SkArgs {
     int P, S, kp, R;
 };
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t g3_rsrc(const void* p, uint32_t bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000); }
-__device__ __forceinline__ void g3_publish(const G3SkArgs& s, int slot, const f32x4 (&acc)[8][4], int tid) {
-    const __amdgpu_buffer_rsrc_t rs = g3_rsrc(s.ws + (size_t)slot * (G3_BM * G3_BN), G3_BM * G3_BN * 4);
+template <class C>
+__device__ __forceinline__ void g3_publish(const G3SkArgs& s, int slot, const f32x4 (&acc)[C::MT][C::NT], int tid) {
+    const __amdgpu_buffer_rsrc_t rs = g3_rsrc(s.ws + (size_t)slot * (C::BM * C::BN), C::BM * C::BN * 4);
 #pragma unroll
-    for (int i = 0; i < 32; i++) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i >> 2][i & 3]), rs, (i * 512 + tid) * 16, 0, 16 /* sc1 */);
+    for (int i = 0; i < C::MT * C::NT; i++)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i / C::NT][i % C::NT]), rs, (i * C::NTH + tid) * 16, 0, 16 /* sc1 */);
+    // the partial went out with write-through (sc1) stores and every lane has their acknowledgements (vmcnt 0) before the flag is raised -- itself a write-through
+    // store.  A release fence here (buffer_wbl2) would write back every dirty line of this XCD's L2, the finished output tiles of its other workgroups included:
+    // measured 37 vs 27 us on a 128-tile product.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(s.flags + slot, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __builtin_amdgcn_raw_buffer_store_b32(1u, g3_rsrc(s.flags + slot, 4), 0, 0, 16 /* sc1 */);
 }
-__device__ __forceinline__ void g3_collect(const G3SkArgs& s, int slot, f32x4 (&acc)[8][4], int tid) {
+template <class C>
+__device__ __forceinline__ void g3_collect(const G3SkArgs& s, int slot, f32x4 (&acc)[C::MT][C::NT], int tid) {
     if (tid == 0) {
         for (int spins = 0; spins < (1 << 24); spins++) {
-            if (__hip_atomic_load(s.flags + slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) break;
+            if (__builtin_amdgcn_raw_buffer_load_b32(g3_rsrc(s.flags + slot, 4), 0, 0, 16 /* sc1 */)) break; /* the partial is read with sc1 loads too: nothing cached to invalidate */
+            asm volatile("" ::: "memory");
             __builtin_amdgcn_s_sleep(4);
         }
     }
     __syncthreads();
-    const __amdgpu_buffer_rsrc_t rs = g3_rsrc(s.ws + (size_t)slot * (G3_BM * G3_BN), G3_BM * G3_BN * 4);
+    const __amdgpu_buffer_rsrc_t rs = g3_rsrc(s.ws + (size_t)slot * (C::BM * C::BN), C::BM * C::BN * 4);
 #pragma unroll
-    for (int g = 0; g < 4; g++) { /* 8 loads in flight at a time: the accumulators hold half the register file */
+    for (int g = 0; g < C::MT * C::NT / 8; g++) { /* 8 loads in flight at a time: the accumulators hold half the register file */
         f32x4 pv[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ((g * 8 + i) * 512 + tid) * 16, 0, 16 /* sc1 */));
+        for (int i = 0; i < 8; i++) pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ((g * 8 + i) * C::NTH + tid) * 16, 0, 16 /* sc1 */));
 #pragma unroll
-        for (int i = 0; i < 8; i++) acc[(g * 8 + i) >> 2][i & 3] += pv[i];
+        for (int i = 0; i < 8; i++) acc[(g * 8 + i) / C::NT][(g * 8 + i) % C::NT] += pv[i];
         asm volatile("" ::: "memory");
     }
 }
-template <bool AKM, bool BKM, int BK>
-__global__ void __launch_bounds__(512) gemm3_sk_kernel(const GemmArgs a, const G3SkArgs s) {
+template <bool AKM, bool BKM, int BK, class C>
+__global__ void __launch_bounds__(C::NTH, C::WGS_PER_CU * C::NW / 4) gemm3_sk_kernel(const GemmArgs a, const G3SkArgs s) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int nbx = (a.M + G3_BM - 1) / G3_BM, nkt = a.K / BK;
+    const int nbx = (a.M + C::BM - 1) / C::BM, nkt = a.K / BK;
     const int w = g3_remap(blockIdx.x, gridDim.x);
     const bool helper = s.S < 2 && w >= s.P;
     // tail mode: tail length L, T = P L tail steps in all, cut into ranges of R = s.R steps (the host's ceil(T / helpers)); 32-bit: the host checks T < 2^31
@@ -283,37 +296,40 @@ __global__ void __launch_bounds__(512) gemm3_sk_kernel(const GemmArgs a, const G
             k0 = s.kp + o, k1 = k0 + len, owner = false, slot = (w - s.P) + tile; /* pieces in range order: one slot each, < P + helpers */
         }
         c0 = __builtin_amdgcn_readfirstlane(c0), c1 = __builtin_amdgcn_readfirstlane(c1), slot = __builtin_amdgcn_readfirstlane(slot);
-        const int bx = tile % nbx, by = tile / nbx, m0 = bx * G3_BM, t0 = by * G3_BN;
-        f32x4 acc[8][4];
+        const int bx = tile % nbx, by = tile / nbx, m0 = bx * C::BM, t0 = by * C::BN;
+        f32x4 acc[C::MT][C::NT];
 #pragma unroll
-        for (int i = 0; i < 8; i++)
+        for (int i = 0; i < C::MT; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        g3_mainloop<AKM, BKM, BK>(a, m0, t0, k0, k1, acc, smem_raw, wid, lane);
+            for (int j = 0; j < C::NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        g3_mainloop<AKM, BKM, BK, C>(a, m0, t0, k0, k1, acc, smem_raw, wid, lane);
         if (!owner) {
-            g3_publish(s, slot, acc, tid);
+            g3_publish<C>(s, slot, acc, tid);
         } else {
-            for (int c = c0; c < c1; c++) g3_collect(s, c, acc, tid);
-            g3_epilogue<AKM>(a, m0, t0, acc, wid, lane);
+            for (int c = c0; c < c1; c++) g3_collect<C>(s, c, acc, tid);
+            g3_epilogue<AKM, C>(a, m0, t0, acc, wid, lane);
         }
         it += helper ? k1 - k0 : 1;
     }
 }
 
 // KF_OK launched, 1 = not for this kernel (the caller's other tile kernels take the shape), < 0 error.  bf16 "weights" only: quantised ones are dequantised first.
-template <bool AKM, bool BKM, int BK>
-static int g3_go_bk(hipStream_t st, const GemmArgs& a, long nwg, void* ws, size_t ws_bytes) {
+// BK = 32 (4 LDS buffers, three steps in flight) was measured 8-10 % slower than BK = 64 (2 buffers) on every shape, forward and backward: the per-step costs
+// (barrier, counted wait, loop) double, and the loop is not waiting for memory.  Only BK = 64 is instantiated.
+template <bool AKM, bool BKM, class C>
+static int g3_go_c(hipStream_t st, const GemmArgs& a, long nwg, void* ws, size_t ws_bytes, long min_plain) {
+    constexpr int BK = G3_BK, SMEM = 2 * C::STAGE;
     static int attr_set = 0;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm3_kernel<AKM, BKM, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G3_TILE) != hipSuccess) return KF_HIP_CHECK;
-        if (hipFuncSetAttribute((const void*)gemm3_sk_kernel<AKM, BKM, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G3_TILE) != hipSuccess) return KF_HIP_CHECK;
+    if (!attr_set && SMEM > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)gemm3_kernel<AKM, BKM, BK, C>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return KF_HIP_CHECK;
+        if (hipFuncSetAttribute((const void*)gemm3_sk_kernel<AKM, BKM, BK, C>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return KF_HIP_CHECK;
         attr_set = 1;
     }
-    // split-K when the tiles are fewer than 4/5 of the CUs, the caller lent the workspace, and the pieces stay >= 512 deep in k
-    const int G = 256, nkt = a.K / BK, min_steps = 512 / BK;
+    // split-K when the tiles are fewer than 4/5 of the resident workgroups, the caller lent the workspace, and the pieces stay >= 512 deep in k
+    const int G = 256 * C::WGS_PER_CU, nkt = a.K / BK, min_steps = 512 / BK;
     if (ws && ws_bytes >= gemm3_sk_ws_bytes() && 5 * nwg < 4 * G) {
         G3SkArgs s;
-        s.ws = (float*)ws, s.flags = (uint32_t*)((char*)ws + (size_t)G * G3_BM * G3_BN * 4);
+        s.ws = (float*)ws, s.flags = (uint32_t*)((char*)ws + (size_t)G * C::BM * C::BN * 4);
         s.P = (int)nwg, s.S = G / s.P, s.kp = 0, s.R = 1;
         int nlaunch;
         if (s.S >= 2) {
@@ -328,27 +344,33 @@ static int g3_go_bk(hipStream_t st, const GemmArgs& a, long nwg, void* ws, size_
         }
         if (s.S >= 1 && (s.S >= 2 || s.kp > 0)) {
             if (hipMemsetAsync(s.flags, 0, G * sizeof(uint32_t), st) != hipSuccess) return KF_HIP_CHECK;
-            hipLaunchKernelGGL((gemm3_sk_kernel<AKM, BKM, BK>), dim3(nlaunch), dim3(512), 4 * G3_TILE, st, a, s);
+            hipLaunchKernelGGL((gemm3_sk_kernel<AKM, BKM, BK, C>), dim3(nlaunch), dim3(C::NTH), SMEM, st, a, s);
             return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
         }
     }
-    if (nwg < 64) return 1;
-    hipLaunchKernelGGL((gemm3_kernel<AKM, BKM, BK>), dim3((unsigned)nwg), dim3(512), 4 * G3_TILE, st, a);
+    if (nwg < min_plain) return 1;
+    hipLaunchKernelGGL((gemm3_kernel<AKM, BKM, BK, C>), dim3((unsigned)nwg), dim3(C::NTH), SMEM, st, a);
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
-// BK = 32 (4 LDS buffers, three steps in flight) was measured 8-10 % slower than BK = 64 (2 buffers) on every shape, forward and backward: the per-step costs
-// (barrier, counted wait, loop) double, and the loop is not waiting for memory.  Only BK = 64 is instantiated.
 template <bool AKM, bool BKM>
 static int g3_go(hipStream_t st, const GemmArgs& a, long nwg, void* ws, size_t ws_bytes) {
-    return g3_go_bk<AKM, BKM, 64>(st, a, nwg, ws, ws_bytes);
+    return g3_go_c<AKM, BKM, G3Big>(st, a, nwg, ws, ws_bytes, 64);
 }
 size_t gemm3_sk_ws_bytes() { return (size_t)256 * G3_BM * G3_BN * 4 + 4096; }
-int gemm3_launch(hipStream_t st, int fmt, const GemmArgs& a) {
-    if (fmt != FMT_BF16 || a.K % G3_BK != 0 || a.K < G3_BK || a.n < G3_BN || a.M < G3_BM) return 1;
+int gemm3_launch(hipStream_t st, int fmt, const GemmArgs& a, void* ws, size_t ws_bytes) {
+    if (fmt != FMT_BF16 || a.K % G3_BK != 0 || a.K < G3_BK) return 1;
     if ((a.ldx & 7) != 0 || (reinterpret_cast<uintptr_t>(a.x) & 15) != 0 || (reinterpret_cast<uintptr_t>(a.w) & 15) != 0 || (a.K & 7) != 0) return 1;
-    const long nwg = (long)((a.M + G3_BM - 1) / G3_BM) * ((a.n + G3_BN - 1) / G3_BN);
-    if (nwg < 128) return 1; /* fewer tiles than half the CUs: the 128-row tile kernels fill the chip better */
-    return g3_go<false, false>(st, a, nwg, nullptr, 0);
+    if (a.n >= G3_BN && a.M >= G3_BM) {
+        const long nwg = (long)((a.M + G3_BM - 1) / G3_BM) * ((a.n + G3_BN - 1) / G3_BN);
+        if (nwg >= 128) return g3_go<false, false>(st, a, nwg, nullptr, 0); /* fewer tiles than half the CUs: smaller tiles fill the chip better */
+    }
+    // 128 x 128 tiles, two workgroups per CU: bf16 products of 1-4 k rows whose M is 1024-3072 (M 1024 x K 2048 at 2048 rows: 36.9 -> 27.4 us, 3072 x 1024: 35.6 -> 23.9;
+    // 4096 rows: 583-656 TFLOP/s).  For QUANTISED weights of that size dequantise + this kernel only ties with the in-register-unpack kernels (the 5 us dequantise pass
+    // and, with split-K, the flag memset eat the gain): kf_linear keeps those on kf_gemm.hip.
+    if (a.n < 128 || a.M < 128) return 1;
+    const long nwg = (long)((a.M + 127) / 128) * ((a.n + 127) / 128);
+    if (nwg < 32) return 1;
+    return g3_go_c<false, false, G3Small>(st, a, nwg, ws, ws_bytes, 128);
 }
 // y[n, M] = alpha * sum_k B(k, tok) A(k, m) + beta * y (+ bias) with either operand stored K-MAJOR: akm: A = w[K][lda] (element (k, m) at k * lda + m), else w[M][K];
 // bkm: B = x[K][ldb], else x[n][ldb].  The two GEMMs of SLP::Back without a transpose of anything:  delta[n, IC] = deltaIn[n, OC] . W[OC, IC]  (A = W k-major),

@@ -145,6 +145,6 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[TB], const Gem
 // kf_gemm2.hip: large-batch tile kernel; KF_OK launched, 1 = not for this kernel
 int gemm2_launch(hipStream_t st, int fmt, const GemmArgs& a);
 // kf_gemm3.hip: 256 x 256 x 64 bf16 tiles staged by global_load_lds; KF_OK launched, 1 = not for this kernel
-int gemm3_launch(hipStream_t st, int fmt, const GemmArgs& a);
+int gemm3_launch(hipStream_t st, int fmt, const GemmArgs& a, void* ws = nullptr, size_t ws_bytes = 0); /* ws: lends the 128 x 128 form its split-K slots (gemm3_sk_ws_bytes) */
 
 }  // namespace kf

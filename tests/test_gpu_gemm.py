@@ -187,10 +187,10 @@ def test_gemm_many_token_tiles_vs_exact(ctx, O, t):
     assert close_bf16(O.f32_to_bf16(y[-100:].astype(np.float32)), y2).all()
 
 
-@pytest.mark.parametrize("m,k,nt", [(4096, 1024, 2048), (4100, 512, 2050), (8192, 64, 4096)])
+@pytest.mark.parametrize("m,k,nt", [(4096, 1024, 2048), (4100, 512, 2050), (8192, 64, 4096), (1024, 2048, 2048), (1032, 3072, 2000), (3072, 1024, 1500)])
 def test_large_batch_bf16_tile_kernel(ctx, O, m, k, nt):
-    """the 256 x 256 x 64 global_load_lds tile kernel (kf_gemm3.hip: bf16 operands, >= 128 tiles) against the fp32 product of the same bf16 values: ragged last tiles in
-    both dimensions, and the epilogue (alpha, beta, bias, residual) in gemm_epilogue's order"""
+    """the global_load_lds tile kernels (kf_gemm3.hip: bf16 operands; 256 x 256 tiles from 128 tiles up, else 128 x 128 tiles on four waves -- the last three shapes)
+    against the fp32 product of the same bf16 values: ragged last tiles in both dimensions, and the epilogue (alpha, beta, bias, residual) in gemm_epilogue's order"""
     g = torch.Generator(device=ctx.device)
     g.manual_seed(m + k + nt)
     W = (torch.randn(m, k, generator=g, device=ctx.device) * 0.05).to(torch.bfloat16)
