@@ -362,7 +362,8 @@ int gemm3_launch(hipStream_t st, int fmt, const GemmArgs& a, void* ws, size_t ws
     if ((a.ldx & 7) != 0 || (reinterpret_cast<uintptr_t>(a.x) & 15) != 0 || (reinterpret_cast<uintptr_t>(a.w) & 15) != 0 || (a.K & 7) != 0) return 1;
     if (a.n >= G3_BN && a.M >= G3_BM) {
         const long nwg = (long)((a.M + G3_BM - 1) / G3_BM) * ((a.n + G3_BN - 1) / G3_BN);
-        if (nwg >= 128) return g3_go<false, false>(st, a, nwg, nullptr, 0); /* fewer tiles than half the CUs: smaller tiles fill the chip better */
+        // (M 1024 x K 3072 at 8192 rows, 128 big tiles: 83 -> 57 us = 890 TFLOP/s on the small ones; from 400 big tiles up the big tile is 8-12 % faster)
+        if (nwg >= 160) return g3_go<false, false>(st, a, nwg, nullptr, 0); /* fewer big tiles than that: four times as many small ones fill the chip better */
     }
     // 128 x 128 tiles, two workgroups per CU: bf16 products of 1-4 k rows whose M is 1024-3072 (M 1024 x K 2048 at 2048 rows: 36.9 -> 27.4 us, 3072 x 1024: 35.6 -> 23.9;
     // 4096 rows: 583-656 TFLOP/s).  For QUANTISED weights of that size dequantise + this kernel only ties with the in-register-unpack kernels (the 5 us dequantise pass
