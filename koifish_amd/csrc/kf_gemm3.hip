@@ -51,13 +51,16 @@ __device__ __forceinline__ bf16x8 g3_frag(const unsigned char* tile, int row, in
 }
 
 // the same tile from a K-MAJOR operand (src[k][row], `row` contiguous: an activation or a weight as it lies in memory when the contraction runs over its ROWS --
-// both GEMMs of SLP::Back): the LDS image is [BK k][256 rows] (512-byte k-rows), one wave instruction = two k-rows; its 32-byte blocks are XOR-swizzled by k & 3 and
+// both GEMMs of SLP::Back): the LDS image is [BK k][ROWS rows] (512- or 256-byte k-rows), one wave instruction = two or four k-rows; its 32-byte blocks are XOR-swizzled by k & 3 and
 // its 128-byte quarters by bit 3 of k, so that the transposing fragment read below (per 32 lanes: k-rows k .. k+3 and k+8 .. k+11, 32 bytes of each) touches all 64
 // banks once (without the second term the two 16-lane halves meet in the same 32 banks: SQ_LDS_BANK_CONFLICT = 50 % of the LDS cycles, measured).
-template <int BK>
+// ROWS = the tile's rows (256 or 128): a k-row of the image is 2 ROWS bytes = CPK chunks of 16 bytes, one wave instruction covers 64 / CPK k-rows, wave `wid` issues
+// instructions NI wid .. NI wid + NI - 1 of the ROWS / 8
+template <int BK, int ROWS, int NI>
 __device__ __forceinline__ const uint16_t* g3_src_km(const uint16_t* __restrict__ src, long long ld, int row0, int nrows, int i, int wid, int lane) {
-    const int j = wid * (BK / 16) + i;         /* k-rows 2j, 2j + 1 */
-    const int kr = 2 * j + (lane >> 5), p = lane & 31, c = p ^ ((kr & 3) << 1) ^ (((kr >> 3) & 1) << 3);
+    constexpr int CPK = ROWS / 8, KPI = 64 / CPK;
+    const int j = wid * NI + i;
+    const int kr = j * KPI + lane / CPK, p = lane % CPK, c = p ^ ((kr & 3) << 1) ^ (((kr >> 3) & 1) << 3);
     int col = row0 + c * 8;
     col = col + 8 <= nrows ? col : (nrows - 8 > 0 ? nrows - 8 : 0); /* chunks past the end re-read the last whole chunk: their outputs are not stored (rows % 8 == 0) */
     return src + (size_t)kr * ld + col; /* + k0 * ld per step */
@@ -65,13 +68,14 @@ __device__ __forceinline__ const uint16_t* g3_src_km(const uint16_t* __restrict_
 // fragment (8 consecutive k of row `row`, k = kbase .. kbase + 7) of a k-major tile: two ds_read_b64_tr_b16, each a 4 (k) x 16 (rows) block transposed across 16 lanes
 // (lane i of the 16 receives D[(i >> 2) + 4 j][i & 3], scratch/dbg/ds_read_tr_probe.hip): lane l16 reads k-row kbase + (l16 >> 2), 8-byte piece l16 & 3 of the 16-row block
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+template <int ROWS>
 __device__ __forceinline__ bf16x8 g3_frag_km(const unsigned char* tile, int rowblk16, int kbase, int l16) {
     bf16x4 h[2];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
         const int k = kbase + 4 * t + (l16 >> 2);
         const int byte_in_row = (rowblk16 * 16 + 4 * (l16 & 3)) * 2, c = byte_in_row >> 4, p = c ^ ((k & 3) << 1) ^ (((k >> 3) & 1) << 3);
-        h[t] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(tile + k * 512 + p * 16 + (byte_in_row & 8)));
+        h[t] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(tile + k * (2 * ROWS) + p * 16 + (byte_in_row & 8)));
     }
     return bf16x8{h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
 }
@@ -84,7 +88,7 @@ __device__ __forceinline__ bf16x8 g3_frag_km(const unsigned char* tile, int rowb
 // the vendor library's shape): the compiler fills all 512 registers and still spills inside the loop, 228 TFLOP/s -- that form needs a hand-scheduled loop.
 template <bool AKM, bool BKM, int BK, class C>
 __device__ __forceinline__ void g3_mainloop(const GemmArgs& a, int m0, int t0, int kt0, int kt1, f32x4 (&acc)[C::MT][C::NT], unsigned char* smem_raw, int wid, int lane) {
-    static_assert(BK == G3_BK && (!(AKM || BKM) || C::BM == 256), "the k-major LDS image is 256 rows wide");
+    static_assert(BK == G3_BK, "two k-halves of 32 per step");
     constexpr int NST = 2, LPW = C::NIA + C::NIB; /* loads per wave and step */
     const int wm = wid / C::WN, wn = wid % C::WN;
     const uint16_t* const W = reinterpret_cast<const uint16_t*>(a.w);
@@ -94,9 +98,9 @@ __device__ __forceinline__ void g3_mainloop(const GemmArgs& a, int m0, int t0, i
     // Per-lane source pointers are set up once; a step adds a uniform offset (a 64-bit multiply per load and step was a tenth of the loop's issue slots).
     const uint16_t *pa[C::NIA], *pb[C::NIB];
 #pragma unroll
-    for (int i = 0; i < C::NIA; i++) pa[i] = AKM ? g3_src_km<BK>(W, a.ldr, m0, a.M, i, wid, lane) : g3_src<BK, C::NIA>(W, a.K, m0, a.M, i, wid, lane);
+    for (int i = 0; i < C::NIA; i++) pa[i] = AKM ? g3_src_km<BK, C::BM, C::NIA>(W, a.ldr, m0, a.M, i, wid, lane) : g3_src<BK, C::NIA>(W, a.K, m0, a.M, i, wid, lane);
 #pragma unroll
-    for (int i = 0; i < C::NIB; i++) pb[i] = BKM ? g3_src_km<BK>(a.x, a.ldx, t0, a.n, i, wid, lane) : g3_src<BK, C::NIB>(a.x, a.ldx, t0, a.n, i, wid, lane);
+    for (int i = 0; i < C::NIB; i++) pb[i] = BKM ? g3_src_km<BK, C::BN, C::NIB>(a.x, a.ldx, t0, a.n, i, wid, lane) : g3_src<BK, C::NIB>(a.x, a.ldx, t0, a.n, i, wid, lane);
     const long long stepA = AKM ? (long long)BK * a.ldr : BK, stepB = BKM ? (long long)BK * a.ldx : BK;
     auto stage = [&](int kt, int b) {
         const long long oa = stepA * kt, ob = stepB * kt;
@@ -127,12 +131,12 @@ __device__ __forceinline__ void g3_mainloop(const GemmArgs& a, int m0, int t0, i
             bf16x8 af[C::MT], bfr[C::NT];
 #pragma unroll
             for (int nt = 0; nt < C::NT; nt++) {
-                if constexpr (BKM) bfr[nt] = g3_frag_km(bufB(cur), wn * C::NT + nt, kk * 32 + 8 * q4, r16);
+                if constexpr (BKM) bfr[nt] = g3_frag_km<C::BN>(bufB(cur), wn * C::NT + nt, kk * 32 + 8 * q4, r16);
                 else bfr[nt] = g3_frag<BK>(bufB(cur), wn * (16 * C::NT) + nt * 16 + r16, kk * 4 + q4);
             }
 #pragma unroll
             for (int mt = 0; mt < C::MT; mt++) {
-                if constexpr (AKM) af[mt] = g3_frag_km(bufA(cur), wm * C::MT + mt, kk * 32 + 8 * q4, r16);
+                if constexpr (AKM) af[mt] = g3_frag_km<C::BM>(bufA(cur), wm * C::MT + mt, kk * 32 + 8 * q4, r16);
                 else af[mt] = g3_frag<BK>(bufA(cur), wm * (16 * C::MT) + mt * 16 + r16, kk * 4 + q4);
             }
 #pragma unroll
@@ -387,6 +391,12 @@ int gemm3_km_launch(hipStream_t st, const uint16_t* A, long long lda, bool akm, 
     a.w = reinterpret_cast<const unsigned char*>(A), a.M = M, a.K = K, a.x = B, a.ldx = ldb, a.n = n, a.y = y, a.ldy = ldy, a.bias = bias, a.alpha = alpha, a.beta = beta;
     a.ldr = lda; /* the k-major A operand's row stride */
     if (!akm && lda != K) return 1; /* the row-major A form reads rows of K */
+    // big tiles that fill less than 4/5 of the CUs: 128 x 128 tiles instead when they make (nearly) whole rounds of the 512 resident workgroups, or -- with the
+    // workspace -- their split-K form (partials of 64 KiB instead of 256 KiB, twice the workgroups)
+    // (measured: Qwen3-0.6B training step 99.3 -> 95.7 ms with the first rule alone, -> 87.2 ms with both; GPT2-1558M 166.0 -> 163.7 -> 161.2 ms)
+    const long nws = (long)((M + 127) / 128) * ((n + 127) / 128), rounds = (nws + 511) / 512;
+    const bool small = 5 * nwg < 4 * 256 && akm && (20 * nws >= 17 * rounds * 512 || (ws && ws_bytes >= gemm3_sk_ws_bytes() && 5 * nws < 4 * 512));
+    if (small) return bkm ? g3_go_c<true, true, G3Small>(st, a, nws, ws, ws_bytes, 1) : g3_go_c<true, false, G3Small>(st, a, nws, ws, ws_bytes, 1);
     if (akm && bkm) return g3_go<true, true>(st, a, nwg, ws, ws_bytes);
     if (akm) return g3_go<true, false>(st, a, nwg, ws, ws_bytes);
     if (bkm) return g3_go<false, true>(st, a, nwg, ws, ws_bytes);
