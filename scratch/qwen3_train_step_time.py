@@ -24,6 +24,7 @@ A = [dict(x=z(N, dim), h1=z(N, dim), r1=f32(N), raw=z(N, W_), rq=f32(N * H), rk=
 xf, hf, rf = z(N, dim), z(N, dim), f32(N)
 qc, tq, tk = z(N, Cq), z(N * H, hd), z(N * KV, hd)
 logits = z(N, V); losses = f32(N)
+for _w in layers[0].values(): ctx.linear_scratch(_w, N)   # kernels never allocate: the dequantise-then-multiply workspace of training-size batches (kf_linear_scratch_bytes)
 def lin(w, xin, y, res=None):
     d = w.desc()
     L.check(ctx.hip.kf_linear(ctx.h, C.byref(d), xin.data_ptr(), y.data_ptr(), None, N, 1.0, 0.0, 1 if res is not None else 0, res.data_ptr() if res is not None else None), "lin")
