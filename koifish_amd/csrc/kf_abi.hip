@@ -387,7 +387,8 @@ int kf_linear(kf_ctx* c, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const
         return kf_linear(c, &wb, x, y, bias, nTok, alpha, beta, epilogue, residual);
     }
     if (nTok >= KF_DEQ_GEMM_MIN && w->type != KF_BF16 && w->quant == KF_QUANT_GROUP && w->ne0 >= 256 && (w->ne1 % 64) == 0 && c->scratch &&
-        c->scratch_bytes >= (size_t)w->ne0 * w->ne1 * 2 && (long)((w->ne0 + 255) / 256) * ((nTok + 255) / 256) >= 128) {
+        c->scratch_bytes >= (size_t)w->ne0 * w->ne1 * 2 &&
+        ((long)((w->ne0 + 255) / 256) * ((nTok + 255) / 256) >= 128 || (long)((w->ne0 + 127) / 128) * ((nTok + 127) / 128) >= 256 /* the 128 x 128 form: M 1024 from 4096 rows */)) {
         // GetDataX into the caller's scratch, then the 256 x 256 bf16 tile kernel: the reference's own order, on our own kernels
         r = kf::dequant_launch(c->stream, w, (uint16_t*)c->scratch);
         if (r != KF_OK) return fail(r, "kf_linear (dequantise for the large-batch tile kernel) failed with %d", r);
