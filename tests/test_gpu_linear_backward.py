@@ -117,7 +117,7 @@ def test_linear_backward_split_k_is_deterministic(ctx):
     """the split-K forms add a tile's partial sums in slot order, not in arrival order: two runs give the same bits (49-tile weight gradient = 5 pieces per
     tile; 133 tiles = owners + helpers on tails)"""
     rng = np.random.default_rng(77)
-    for OC, IC, n in ((1600, 1600, 8192), (4800, 1600, 4096)):
+    for OC, IC, n in ((1600, 1600, 8192), (4800, 1600, 4096), (1024, 3072, 8192)):
         w = O.f32_to_bf16(rng.normal(0, 0.05, (OC, IC)).astype(np.float32))
         dw = ctx.upload_blob(L.BF16, OC, IC, O.quantize(w, OC, IC, L.BF16).blob())
         dIn = bf16_t(O.f32_to_bf16(rng.normal(0, 1.0, (n, OC)).astype(np.float32)), ctx.device)
@@ -135,6 +135,18 @@ def test_linear_backward_split_k_is_deterministic(ctx):
             outs.append((u16(delta).copy(), u16(gW).copy()))
         for d_, g_ in outs[1:]:
             assert np.array_equal(d_, outs[0][0]) and np.array_equal(g_, outs[0][1])
+        # other operands through the same slots in between: a partial tile left by that launch (the slots are read with write-through-coherent loads, no
+        # fence) must not reach the next one -- A, B, A gives A's bits again
+        dIn2 = bf16_t(O.f32_to_bf16(rng.normal(0, 1.0, (n, OC)).astype(np.float32)), ctx.device)
+        res = []
+        for src in (dIn, dIn2, dIn):
+            delta = torch.zeros(n, IC, dtype=torch.bfloat16, device=ctx.device)
+            gW = torch.zeros(OC, IC, dtype=torch.bfloat16, device=ctx.device)
+            assert ctx.hip.kf_linear_backward(ctx.h, C.byref(desc), src.data_ptr(), inp.data_ptr(), delta.data_ptr(), gW.data_ptr(), None, n, 0, sp) == 0, ctx.hip.kf_last_error()
+            ctx.sync()
+            res.append((u16(delta).copy(), u16(gW).copy()))
+        assert np.array_equal(res[0][1], outs[0][1]) and np.array_equal(res[2][1], outs[0][1]) and not np.array_equal(res[1][1], outs[0][1])
+        assert np.array_equal(res[2][0], outs[0][0])
 
 
 def test_linear_backward_fixed_weight_and_no_bias(ctx):
