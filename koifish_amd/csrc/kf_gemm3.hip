@@ -1,14 +1,19 @@
-// kf_gemm3.hip -- large-batch bf16 GEMM on 256 x 256 x 64 tiles: y[n, M] (+)= x[n, K] . W[M, K]^T with both operands K-contiguous (SLP::Forw's product
-// for a dequantised or bf16 weight, and -- with the transposed copies kf_linear_backward already makes -- both GEMMs of SLP::Back).  This is the tile
-// the LDS accounting of DESIGN.md section 8 asked for, built MI355X-first:
+// kf_gemm3.hip -- large-batch bf16 GEMM on 256 x 256 x 64 (or 128 x 128 x 64) tiles: y[n, M] (+)= x[n, K] . W[M, K]^T (SLP::Forw's product for a dequantised or bf16
+// weight) and, with either operand stored K-MAJOR, both GEMMs of SLP::Back without a transpose of anything.  The tile the LDS accounting of DESIGN.md section 8 asked
+// for, built MI355X-first:
 //   * both operand tiles go global -> LDS with global_load_lds_dwordx4 (16 bytes per lane, no VGPR round trip).  The LDS image of such a load is
 //     lane-linear, so the bank-conflict-free layout is produced on the SOURCE side: a tile row is 128 bytes = 8 chunks of 16 bytes, chunk c of row r
 //     is stored at position c ^ ((r >> 1) & 7); a fragment read (16 rows x one chunk, ds_read_b128) then touches all 64 banks exactly once;
-//   * two LDS buffers (4 x 32 KiB): the loads of k-tile t+1 are issued before k-tile t is multiplied and drained with a COUNTED s_waitcnt vmcnt(8)
-//     and raw s_barrier (a __syncthreads() would drain the loads in flight);
-//   * 8 waves as 2 (rows) x 4 (tokens), 128 x 64 outputs per wave = 32 accumulator tiles of v_mfma_f32_16x16x32_bf16, 64 MFMAs per wave and k-tile;
-//   * workgroup order remapped so that the blocks an XCD runs back to back share their W row-tile in that XCD's L2.
-// Measured on random operands (scratch/ub_gemm3.hip): 4096^3 997 TFLOP/s, 8192^3 1029, GPT2-1558M shapes (8192 tokens) 726-843, head 50304 x 1600 831.
+//     a k-major operand's image is [64 k][rows], two-term swizzle, fragments by the transposing ds_read_b64_tr_b16 (g3_src_km / g3_frag_km);
+//   * two LDS buffers: the loads of k-step t+1 are issued while k-step t is multiplied and drained with a COUNTED s_waitcnt vmcnt and ONE raw s_barrier per
+//     step (a __syncthreads() would drain the loads in flight); per-lane source pointers set up once, LDS buffer indices compile-time;
+//   * 256 x 256: 8 waves as 2 (rows) x 4 (tokens), 128 x 64 outputs per wave = 32 accumulator tiles of v_mfma_f32_16x16x32_bf16, one workgroup per CU;
+//     128 x 128: 4 waves as 2 x 2, 64 x 64 outputs per wave, two workgroups per CU -- for products with too few big tiles to fill the chip;
+//   * workgroup order remapped so that the blocks an XCD runs back to back share their W row-tile in that XCD's L2;
+//   * split-K forms (gemm3_sk_kernel) with an ordered in-kernel fix-up for launches with fewer tiles than resident workgroups: deterministic, no atomics on data;
+//   * up to three matrices stacked along M (Q | K | V, gate | up) in one launch, each tile's rows routed to its matrix's output (gemm3_multi_launch).
+// Measured (MI355X): 8192 x 6400 x 5120 993-1009 TFLOP/s; M 1024 x K 3072 at 8192 rows 890 on the small tile; GPT2-1558M weight gradients 540-740; per-shape numbers
+// and the measured dead ends (stream-K ranges, BK = 32 / 4 buffers, mid-step barrier, 4 waves x 128 x 128) are in DESIGN.md section 0 (3).
 // The epilogue is gemm_epilogue's (alpha, beta, bias, one bf16 store, residual added to the rounded value).
 #include <string.h>
 
