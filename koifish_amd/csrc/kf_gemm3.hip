@@ -24,7 +24,6 @@
 namespace kf {
 
 constexpr int G3_BM = 256, G3_BN = 256, G3_BK = 64;
-constexpr int G3_TILE = G3_BM * G3_BK * 2; /* 32 KiB per operand tile */
 // the workgroup tile: BM rows x BN tokens, NW waves as 2 (rows) x NW / 2 (tokens).  Big = the 256 x 256 tile of the header (8 waves, 128 x 64 outputs each, 128 KiB of
 // LDS: one workgroup per CU); Small = 128 x 128 on 4 waves (64 x 64 outputs each, 64 KiB: two workgroups per CU) for products with too few 256 x 256 tiles to fill the
 // chip -- the o_proj / down projections of a 1-2 k token prompt (M = 1024: 32 big tiles), with the split-K form below on top.  K-contiguous operands only.
