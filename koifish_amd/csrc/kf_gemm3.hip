@@ -234,8 +234,8 @@ __global__ void __launch_bounds__(C::NTH, C::WGS_PER_CU * C::NW / 4) gemm3_kerne
 //                          laid end to end, into equal ranges (a helper's range covers pieces of 2 .. 5 tiles; neighbours start a few steps apart).  Owners and
 //                          helpers finish together.
 // A non-owner leaves each fp32 partial in a slot of `ws` with write-through stores and raises the slot's flag; the owner adds its tile's partials in slot order -- a
-// fixed order: the result does not depend on timing -- and runs the epilogue.  flags are zeroed by the host before the launch; all workgroups are resident (<= 256,
-// one per CU), and only owners wait (for helpers, which wait for nobody).
+// fixed order: the result does not depend on timing -- and runs the epilogue.  flags are zeroed by the host before the launch; only owners wait, for pieces that
+// were dispatched before them and wait for nobody.
 struct G3SkArgs {
     float* ws;       /* [<= 256][256 * 256] */
     uint32_t* flags; /* [<= 256] */
@@ -281,8 +281,14 @@ __global__ void __launch_bounds__(C::NTH, C::WGS_PER_CU * C::NW / 4) gemm3_sk_ke
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int nbx = (a.M + C::BM - 1) / C::BM, nkt = a.K / BK;
-    const int w = g3_remap(blockIdx.x, gridDim.x);
-    const bool helper = s.S < 2 && w >= s.P;
+    // Roles by DISPATCH order: every non-owner piece of a tile has a smaller blockIdx than the tile's owner, and non-owners wait for nobody -- so when an owner runs, the
+    // pieces it waits for have at least started, whatever else occupies the chip (a collective on another stream): the waits end, no residency assumption.
+    // S >= 2: blockIdx group g = blockIdx / P holds piece S - 1 - g of every tile (the owners, piece 0, are the last group); S == 1: the helpers first, then the owners.
+    // Inside a group the XCD remap keeps neighbouring tiles on one XCD (the group offset only rotates the XCD labels).
+    const int nhelp = (int)gridDim.x - s.P; /* S == 1 */
+    const bool helper = s.S < 2 && (int)blockIdx.x < nhelp;
+    const int w = s.S >= 2 ? (s.S - 1 - (int)blockIdx.x / s.P) * s.P + g3_remap((int)blockIdx.x % s.P, s.P)
+                           : (helper ? s.P + g3_remap((int)blockIdx.x, nhelp) : g3_remap((int)blockIdx.x - nhelp, s.P));
     // tail mode: tail length L, T = P L tail steps in all, cut into ranges of R = s.R steps (the host's ceil(T / helpers)); 32-bit: the host checks T < 2^31
     const int L = nkt - s.kp, T = s.P * L, R = s.R;
     int hb = 0, he = 1; /* a helper's range of tail steps; the other roles make one pass */
