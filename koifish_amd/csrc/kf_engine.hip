@@ -977,7 +977,6 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     const int GQ = d->n_head / d->n_kv;
     const int shape_class = engine_shape_class(GQ, hd, d->dim, d->n_head * hd, d->ffn);
     if (!shape_class) return KF_UNSUPPORTED_DATATYPE; /* not one of the instantiated model shapes: the per-layer launches remain */
-    if (getenv("KF_ATTN_SLICE") || getenv("KF_ATTN_SINGLE") || getenv("KF_ATTN_NW")) return KF_UNSUPPORTED_DATATYPE; /* the engine restates the default slicing */
     int dev = 0, n_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1) return KF_HIP_CHECK;
     EngineHost* E = new EngineHost();

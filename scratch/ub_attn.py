@@ -22,4 +22,4 @@ ws=ctx._ws(nh,hd); out=torch.zeros(nh*hd,dtype=torch.bfloat16,device=dev)
 dp=torch.zeros(1,dtype=torch.int32,device=dev)
 for pos in (255,383,511,767,1023,1535,2047):
     dp[0]=pos
-    timeit(f"attn_block pos={pos} slice={os.environ.get('KF_ATTN_SLICE')} single={os.environ.get('KF_ATTN_SINGLE')}", lambda: L.check(ctx.hip.kf_attn_block(ctx.h,_ptr(q),_ptr(kraw),_ptr(kc),_ptr(vc),_ptr(out),_ptr(qn),_ptr(qn),_ptr(table),pos,_ptr(dp),nh,nkv,hd,nkv*hd,1e-6,_ptr(ws))))
+    timeit(f"attn_block pos={pos}", lambda: L.check(ctx.hip.kf_attn_block(ctx.h,_ptr(q),_ptr(kraw),_ptr(kc),_ptr(vc),_ptr(out),_ptr(qn),_ptr(qn),_ptr(table),pos,_ptr(dp),nh,nkv,hd,nkv*hd,1e-6,_ptr(ws))))
