@@ -212,10 +212,10 @@ def test_large_batch_bf16_tile_kernel(ctx, O, m, k, nt):
     ctx.sync()
 
 
-def test_training_size_batch_of_a_quantised_weight_takes_the_dequantise_then_tile_path(ctx, O):
+@pytest.mark.parametrize("m,k,nt", [(4096, 1024, 2048), (1024, 2048, 4096)])   # 128 big tiles; 32 big = 256 small tiles (the 128 x 128 form from 4096 rows at M 1024)
+def test_training_size_batch_of_a_quantised_weight_takes_the_dequantise_then_tile_path(ctx, O, m, k, nt):
     """>= 2048 token rows with the caller's scratch set (kf_linear_scratch_bytes says how much): GetDataX into the scratch, then the bf16 tile kernel.  The product of the
     SAME dequantised values, so it agrees with the fused dequant-GEMM kernels to the fp32 summation order (<= 1 bf16 ulp of the row scale)."""
-    m, k, nt = 4096, 1024, 2048
     rng = np.random.default_rng(5)
     w = O.f32_to_bf16(rng.normal(0, 0.02, size=(m, k)).astype(np.float32))
     dw = ctx.upload_blob(L.Q4, m, k, O.quantize(w, m, k, L.Q4).blob())
