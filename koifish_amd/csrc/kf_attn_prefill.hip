@@ -47,7 +47,9 @@ constexpr bool PSPLIT = true; /* probabilities enter P.V as bf16 high + bf16 rem
 // (O, running maximum, sum) of a column are merged through LDS at the end.  A workgroup's time is the walk of its longest column over its keys: halved -- which is
 // what a prompt of a few thousand tokens needs, where there is about one workgroup per CU and the launch lasts as long as the last query block.
 // (Halving the columns per workgroup instead -- 64 columns, twice the workgroups -- was measured too: 72.8 vs 67.3 us at 2047 tokens; a workgroup's time is its
-// key walk, not its column count, and the second workgroup of a heavy block does not land on an idle CU.)
+// key walk, not its column count, and the second workgroup of a heavy block does not land on an idle CU.  Cutting the late blocks' KEY ranges into pieces for other
+// workgroups -- partial (O, max, sum) through memory, owners dispatched last and merging in key order -- was built and measured as well: 70.7 us in the 2047-token
+// prefill against 67 us without, so it is not in the tree; the launch behaves throughput-bound at ~250 TFLOP/s of causal flops rather than tail-bound.)
 template <int HD, int GQ, int KH>
 __global__ void __launch_bounds__(256 * KH) attn_prefill_kernel(const AttnPrefillArgs a) {
     constexpr int NS = HD / 16;   /* MFMA steps over d for S^T */
