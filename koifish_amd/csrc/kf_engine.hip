@@ -82,6 +82,9 @@ struct EngArgs {
     float qbias[7];                    /* qBias of q k v o gate up down */
     int gls;                           /* dwords between the 128-byte lines (32 granules) of a granule buffer: 32 = dense */
     int poll_sleep;                    /* s_sleep units between two sweeps of a poll */
+    int delay[6];                      /* s_sleep units between "this workgroup's own rows of the feeding phase are published" and the first sweep of: x (P1), q|k|v (P2), slice
+                                          partials (P3), ao (P4), xB (P5), act (P6).  A sweep that comes too early fails, costs its whole round trip and slows the stores it waits for
+                                          (scratch/ub_handoff3.hip: 1.2 us per edge with the first sweep ~0.4 us behind the publish against 2.1-2.3 us with sweeps from the start) */
     int* tickets;                      /* XCD-mapped form: one ticket word per XCD, 128 bytes apart (zero between launches) */
     uint32_t* lqkv;                    /* XCD-mapped form: [8][lq_stride] granules: q | k | v rows of the XCD's kv-head, written with plain stores (they stay in that XCD's L2) */
     unsigned long long* lpart;         /* XCD-mapped form: [8][GQ][32][hd + 4] partial granules of the XCD's kv-head */
@@ -128,9 +131,20 @@ __device__ __forceinline__ uint32_t tags_bad(u32x4 g, uint32_t tag) { return ((g
 // layernorm.cuh:800-847: fp64 sum of squares, (x*mul)*w, one bf16 store), and the raw vector in natural order into xraw (the residual
 // the phase after next adds).  Lane l of load r owns elements 4*(64r + l) .. +3.  PLAIN: the vector is plain bf16 written by an
 // earlier launch (layer 0's embedding row).  Straight-line code: the vector lengths are template parameters of the kernel.
+// wait until this workgroup's own counter `pub` has reached `want` (its rows of the feeding phase are on their way), then `delay` sleep units
+__device__ __forceinline__ void eng_wait_pub(const int* pub, int want, int delay, bool& dead) {
+    if (pub) {
+        for (int spins = 0; spins < (1 << 22) && !dead; spins++) {
+            if (__hip_atomic_load(pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    for (int z = 0; z < delay; z++) __builtin_amdgcn_s_sleep(1);
+}
 template <int XCH, int NLD, bool NORM, bool PLAIN>
 __device__ __forceinline__ void eng_poll_stage(const uint32_t* gsrc, const uint16_t* plain, uint32_t tag, int nBlk, g_u16 norm_w, float eps, u32x4* xs,
-                                               uint16_t* xraw, int lane, int* ws, bool& dead, int gls, int psleep, int* nsweeps, unsigned long long* tsw = nullptr) {
+                                               uint16_t* xraw, int lane, int* ws, bool& dead, int gls, int psleep, int* nsweeps, const int* pub, int want, int delay,
+                                               unsigned long long* tsw = nullptr) {
     constexpr int n = NLD * 256;
     uint32_t p0[NLD], p1[NLD], w0[NLD], w1[NLD];
     if (NORM) { /* constants: requested in front of the sweep */
@@ -152,6 +166,7 @@ __device__ __forceinline__ void eng_poll_stage(const uint32_t* gsrc, const uint1
         int voff[NLD];
 #pragma unroll
         for (int r = 0; r < NLD; r++) voff[r] = goff(4 * (r * 64 + lane), gls) * 4;
+        eng_wait_pub(pub, want, delay, dead);
         for (int spins = 0;; spins++) {
             uint32_t bad = 0;
 #pragma unroll
@@ -328,6 +343,7 @@ struct EngLds {
     float *wmax, *comb;
     uint32_t* outb; /* [64] a phase's output granules of this workgroup, gathered so that ONE wave stores them 16 bytes per lane */
     int* cnt;       /* arrival counter of the compute waves that own rows of the phase */
+    int* pub;       /* [4] layers of P1 / P4 / P5 / P6 rows this workgroup has published so far: the poller starts sweeping for the phase's consumers' vector behind it */
 };
 struct EngSlice { /* this workgroup's attention slice and merge share */
     int pos, len, nsp, kvh, split, h0, t0, t1, me0;
@@ -344,7 +360,7 @@ __device__ __forceinline__ void st_gran16(uint32_t* p, u32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(v, eng_rsrc(p, 16), 0, 0, 16 /* sc1 */);
 }
 // local = true: plain stores into a buffer of this XCD (dense lines)
-__device__ __forceinline__ void wg_publish(const EngLds& L, uint32_t* buf, int idx0, int nrows, int nwaves, int lane, int gls, int ncopy, int cstride, bool local = false) {
+__device__ __forceinline__ void wg_publish(const EngLds& L, int phase, uint32_t* buf, int idx0, int nrows, int nwaves, int lane, int gls, int ncopy, int cstride, bool local = false) {
     int old = 0;
     if (lane == 0) old = __hip_atomic_fetch_add(L.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     old = __builtin_amdgcn_readfirstlane(old);
@@ -354,11 +370,12 @@ __device__ __forceinline__ void wg_publish(const EngLds& L, uint32_t* buf, int i
         const u32x4 v = *reinterpret_cast<const u32x4*>(L.outb + 4 * lane);
         if (local) {
             *reinterpret_cast<u32x4*>(buf + idx0 + 4 * lane) = v;
-            return;
+        } else {
+            const int off = goff(idx0 + 4 * lane, gls);
+            for (int c = 0; c < ncopy; c++) st_gran16(buf + (size_t)c * cstride + off, v);
         }
-        const int off = goff(idx0 + 4 * lane, gls);
-        for (int c = 0; c < ncopy; c++) st_gran16(buf + (size_t)c * cstride + off, v);
     }
+    if (lane == 0) __hip_atomic_fetch_add(L.pub + phase, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); /* the poller may start to sweep for what the consumers of these rows produce */
 }
 
 // the poller wave: per layer it stages P1's x, the slice's q/k/v heads, merges, stages P4's, P5's and P6's inputs
@@ -400,9 +417,10 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
                     if (tok < 0 || tok >= a.emb_rows) tok = 0;
                     x0 = a.emb + (size_t)tok * a.dim;
                 }
-                eng_poll_stage<XCH, ND, true, true>(nullptr, x0, tag, SH::P1.nBlk, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, a.gls, a.poll_sleep, &sw[0]);
+                eng_poll_stage<XCH, ND, true, true>(nullptr, x0, tag, SH::P1.nBlk, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, a.gls, a.poll_sleep, &sw[0], nullptr, 0, 0);
             } else {
-                eng_poll_stage<XCH, ND, true, false>(a.xA + cbase, nullptr, tag, SH::P1.nBlk, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, a.gls, a.poll_sleep, &sw[0]);
+                eng_poll_stage<XCH, ND, true, false>(a.xA + cbase, nullptr, tag, SH::P1.nBlk, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, a.gls, a.poll_sleep, &sw[0],
+                                                     has6 ? L.pub + 3 : nullptr, l, a.delay[0]);
             }
         }
         ENG_STAMP(0, 1);
@@ -412,9 +430,9 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
                 L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v);
             });
             if (XMAP)
-                wg_publish(L, a.lqkv + (size_t)S.xcc * a.lq_stride, S.q_out0, R1, NWP1, lane, 32, 1, 0, true);
+                wg_publish(L, 0, a.lqkv + (size_t)S.xcc * a.lq_stride, S.q_out0, R1, NWP1, lane, 32, 1, 0, true);
             else
-                wg_publish(L, a.qkv, S.q_out0, R1, NWP1, lane, a.gls, a.ncopy, a.cstride);
+                wg_publish(L, 0, a.qkv, S.q_out0, R1, NWP1, lane, a.gls, a.ncopy, a.cstride);
         }
         // P2: q heads of the group (GQ*hd granules), then k and v of the kv-head side by side in one piece
         if (S.has_unit) {
@@ -427,6 +445,7 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
             const int e_kv = 4 * lane; /* < hd: k, < 2hd: v */
             const bool kv_in = e_kv < 2 * hd;
             const int kv_src = XMAP ? GQ * hd + e_kv : (e_kv < hd ? a.q_dim + S.kvh * hd + e_kv : a.q_dim + a.kv_dim + S.kvh * hd + (e_kv - hd));
+            eng_wait_pub(has1 ? L.pub + 0 : nullptr, l + 1, a.delay[1], dead);
             for (int spins = 0;; spins++) {
                 uint32_t bad = 0;
 #pragma unroll
@@ -467,6 +486,7 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
             const unsigned long long* base = XMAP ? a.lpart + (size_t)S.xcc * a.lp_stride + (size_t)h * nsp * PS : a.part + (size_t)h * nsp * PS;
             float ms = -__builtin_inff(), ls = 0.f, vsp[KF_ATTN_MAX_SPLITS];
             const bool mine = lane < nsp, el = lane < a.merge_e;
+            eng_wait_pub(nullptr, 0, a.delay[2], dead);
             for (int spins = 0;; spins++) {
                 uint32_t bad = 0;
                 const unsigned long long want = (unsigned long long)gen << 32; /* lanes and slices outside the work read as {0, gen}: clamped loads would cost more */
@@ -498,13 +518,15 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
         }
         // P4, P5 (P6 adds that x as the residual), P6
         ENG_STAMP(0, 4);
-        if (has4) eng_poll_stage<XCH, NQD, false, false>(a.ao + cbase, nullptr, tag, SH::P4.nBlk, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, a.gls, a.poll_sleep, &sw[1]);
+        if (has4) eng_poll_stage<XCH, NQD, false, false>(a.ao + cbase, nullptr, tag, SH::P4.nBlk, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, a.gls, a.poll_sleep, &sw[1], nullptr, 0, a.delay[3]);
         ENG_STAMP(0, 5);
         __syncthreads();
-        if (has5 || has6) eng_poll_stage<XCH, ND, true, false>(a.xB + cbase, nullptr, tag, SH::P5.nBlk, ly.norm_post, a.eps, L.xs[0], L.xrawB, lane, a.ws, dead, a.gls, a.poll_sleep, &sw[2]);
+        if (has5 || has6) eng_poll_stage<XCH, ND, true, false>(a.xB + cbase, nullptr, tag, SH::P5.nBlk, ly.norm_post, a.eps, L.xs[0], L.xrawB, lane, a.ws, dead, a.gls, a.poll_sleep, &sw[2],
+                                                                          has4 ? L.pub + 1 : nullptr, l + 1, a.delay[4]);
         ENG_STAMP(0, 6);
         __syncthreads();
-        if (has6) eng_poll_stage<XCH, NF, false, false>(a.act + cbase, nullptr, tag, SH::P6.nBlk, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, a.gls, a.poll_sleep, &sw[3], (a.dbg && wg == a.dbg_wg) ? a.dbg + ((size_t)l * 2) * 16 + 9 : nullptr);
+        if (has6) eng_poll_stage<XCH, NF, false, false>(a.act + cbase, nullptr, tag, SH::P6.nBlk, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, a.gls, a.poll_sleep, &sw[3], has5 ? L.pub + 2 : nullptr, l + 1,
+                                                                 a.delay[5], (a.dbg && wg == a.dbg_wg) ? a.dbg + ((size_t)l * 2) * 16 + 9 : nullptr);
         ENG_STAMP(0, 7);
         if (P1_SHARE && has1 && l + 1 < a.n_layer) mv_prefetch<NCW1, FMT, false, S1>(P1, L.lay[l + 1].m, S.s1, NWV - 1, lane, r1, a.exp_flags);
         if (a.dbg && wg == a.dbg_wg && lane == 0) a.dbg[((size_t)l * 2) * 16 + 8] = (unsigned long long)sw[0] | ((unsigned long long)sw[1] << 16) | ((unsigned long long)sw[2] << 32) | ((unsigned long long)sw[3] << 48);
@@ -592,9 +614,9 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         });
         if (has1 && wave < NWP1) {
             if (XMAP)
-                wg_publish(L, a.lqkv + (size_t)S.xcc * a.lq_stride, S.q_out0, R1, NWP1, lane, 32, 1, 0, true);
+                wg_publish(L, 0, a.lqkv + (size_t)S.xcc * a.lq_stride, S.q_out0, R1, NWP1, lane, 32, 1, 0, true);
             else
-                wg_publish(L, a.qkv, S.q_out0, R1, NWP1, lane, a.gls, a.ncopy, a.cstride);
+                wg_publish(L, 0, a.qkv, S.q_out0, R1, NWP1, lane, a.gls, a.ncopy, a.cstride);
         }
         // ================= P2: q/k-norm + RoPE + attention over this workgroup's slice
         if (wave == 0) ENG_STAMP(1, 1);
@@ -789,7 +811,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
             const uint16_t o = f2bf(v);
             L.outb[row - wg * R4] = (tag << 16) | (uint32_t)f2bf(bf2f(L.xrawA[row]) + bf2f(o)); /* CU_add3: bf16(x + bf16(W.x)) */
         });
-        if (has4 && wave < NWP4) wg_publish(L, a.xB, wg * R4, R4, NWP4, lane, a.gls, a.ncopy, a.cstride);
+        if (has4 && wave < NWP4) wg_publish(L, 1, a.xB, wg * R4, R4, NWP4, lane, a.gls, a.ncopy, a.cstride);
         // ================= P5: RMSNorm + gate/up + SwiGLU -> act
         if (wave == 0) ENG_STAMP(1, 5);
         __syncthreads();
@@ -799,7 +821,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
             const float gt = round_bf16(v), up = round_bf16(v2); /* CU_swiglu_v0 on the two bf16-rounded projections */
             L.outb[row - wg * R5] = (tag << 16) | (uint32_t)f2bf((gt * up) / (1.0f + kf_expf(-gt)));
         });
-        if (has5 && wave < NWP5) wg_publish(L, a.act, wg * R5, R5, NWP5, lane, a.gls, a.ncopy, a.cstride);
+        if (has5 && wave < NWP5) wg_publish(L, 2, a.act, wg * R5, R5, NWP5, lane, a.gls, a.ncopy, a.cstride);
         // ================= P6: down_proj + residual -> x of the next layer
         if (wave == 0) ENG_STAMP(1, 7);
         __syncthreads();
@@ -813,7 +835,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
             else
                 L.outb[row - wg * R6] = (tag_next << 16) | (uint32_t)y;
         });
-        if (!last && has6 && wave < NWP6) wg_publish(L, a.xA, wg * R6, R6, NWP6, lane, a.gls, a.ncopy, a.cstride);
+        if (!last && has6 && wave < NWP6) wg_publish(L, 3, a.xA, wg * R6, R6, NWP6, lane, a.gls, a.ncopy, a.cstride);
         if (wave == 0) ENG_STAMP(1, 9);
     }
 }
@@ -839,7 +861,9 @@ __global__ void __launch_bounds__(NWV * 64) engine_kernel(const EngArgs a) {
     L.comb = L.wmax + NW * GQ + 4;                  /* [NW][GQ][hd + 4] */
     L.outb = reinterpret_cast<uint32_t*>(L.comb + NW * GQ * (hd + 4));
     L.cnt = reinterpret_cast<int*>(L.outb + 64); /* [0] arrival counter, [1..2] XCD id and ticket */
+    L.pub = L.cnt + 4;
     if (tid == 0) *L.cnt = 0;
+    if (tid < 4) L.pub[tid] = 0;
     // ---- start: state, generation, tables
     EngSlice S;
     S.pos = a.d_state[1];
@@ -909,6 +933,7 @@ struct EngineHost {
     int fmt, GQ, hd, nwv, shape_class, xmap;
     size_t smem;
     int n_cu;
+    void* xmem; /* the hand-off vectors every CU sweeps: device memory that is cached nowhere (hipDeviceMallocUncached), owned by the engine */
 };
 
 // the instantiated model shapes: {GQA group, head_dim, dim, q_dim, ffn}
@@ -1052,6 +1077,33 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     a.plans = reinterpret_cast<const EngPlan*>(p), p += 512;
     a.layers = reinterpret_cast<const EngLayer*>(p), p += ((size_t)d->n_layer * sizeof(EngLayer) + 255) & ~(size_t)255;
     a.gls = 32, a.poll_sleep = 1; /* granule line stride / sleep between sweeps: the sweeps over other values changed nothing */
+    {
+        const int dflt[6] = {12, 4, 8, 10, 12, 12}; /* x, q|k|v, slice partials, ao, xB, act: s_sleep units (~30 ns each) behind the own publish */
+        for (int i = 0; i < 6; i++) a.delay[i] = dflt[i];
+        if (const char* e = getenv("KF_ENG_DELAY")) { /* tuning runs */
+            int i = 0;
+            for (const char* q = e; *q && i < 6; i++) {
+                a.delay[i] = atoi(q);
+                while (*q && *q != ',') q++;
+                if (*q == ',') q++;
+            }
+        }
+    }
+    // The vectors that cross XCDs live in uncached device memory: an sc1 sweep of a cached (hipMalloc) line costs 75 ns per KB and CU, of an uncached one 43
+    // (scratch/ub_handoff3.hip).  The XCD-local vectors (lqkv, lpart) stay in the caller's cached workspace: they are meant to live in that XCD's L2.
+    const size_t part_bytes = (8 * (size_t)a.n_head * KF_ATTN_MAX_SPLITS * (hd + 4) + 255) & ~(size_t)255;
+    size_t xbytes = 0;
+    for (size_t n : {(size_t)a.dim, (size_t)a.q_dim + 2 * a.kv_dim, (size_t)a.q_dim, (size_t)a.dim, (size_t)a.ffn}) xbytes += (((n + 31) / 32) * (size_t)a.gls * 4 + 255) & ~(size_t)255;
+    xbytes += part_bytes;
+    E->xmem = nullptr;
+    if (!(getenv("KF_ENG_UNCACHED") && atoi(getenv("KF_ENG_UNCACHED")) == 0)) {
+        if (hipExtMallocWithFlags(&E->xmem, xbytes, hipDeviceMallocUncached) != hipSuccess) {
+            (void)hipGetLastError();
+            E->xmem = nullptr; /* the cached workspace serves (slower sweeps, same protocol) */
+        }
+    }
+    char* const p_ws = p;
+    if (E->xmem) p = reinterpret_cast<char*>(E->xmem);
     auto gran = [&](size_t n) {
         uint32_t* r = reinterpret_cast<uint32_t*>(p);
         p += (((n + 31) / 32) * (size_t)a.gls * 4 + 255) & ~(size_t)255;
@@ -1063,13 +1115,22 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     a.cstride = (int)((p - g0) / 4);
     p = g0 + (size_t)a.ncopy * a.cstride * 4;
     a.part = reinterpret_cast<unsigned long long*>(p);
-    p += (8 * (size_t)a.n_head * KF_ATTN_MAX_SPLITS * (hd + 4) + 255) & ~(size_t)255;
+    p += part_bytes;
+    if (E->xmem) {
+        if (hipMemsetAsync(E->xmem, 0xff, xbytes, st) != hipSuccess) {
+            (void)hipFree(E->xmem);
+            delete E;
+            return KF_HIP_CHECK;
+        }
+        p = p_ws;
+    }
     a.tickets = reinterpret_cast<int*>(p), p += 1024;
     a.lq_stride = (int)(((size_t)(GQ * hd + 2 * hd) * 4 + 255) / 256 * 64);
     a.lqkv = reinterpret_cast<uint32_t*>(p), p += (size_t)8 * a.lq_stride * 4;
     a.lp_stride = (int)(((size_t)GQ * KF_ATTN_MAX_SPLITS * (hd + 4) * 8 + 255) / 256 * 32);
     a.lpart = reinterpret_cast<unsigned long long*>(p), p += (size_t)8 * a.lp_stride * 8;
     if (hipMemsetAsync(ws, 0xff, ws_bytes, st) != hipSuccess) {
+        if (E->xmem) (void)hipFree(E->xmem);
         delete E;
         return KF_HIP_CHECK;
     }
@@ -1078,6 +1139,7 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
         hipMemcpyAsync(const_cast<EngPlan*>(a.plans), E->plans, sizeof(E->plans), hipMemcpyHostToDevice, st) != hipSuccess ||
         hipMemcpyAsync(const_cast<EngLayer*>(a.layers), tab.data(), tab.size() * sizeof(EngLayer), hipMemcpyHostToDevice, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess) {
+        if (E->xmem) (void)hipFree(E->xmem);
         delete E;
         return KF_HIP_CHECK;
     }
@@ -1091,9 +1153,10 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     if (a.ffn > maxK) maxK = a.ffn;
     a.lds_xs_bytes = (maxK * 2 + 15) & ~15;
     size_t smem = (((size_t)d->n_layer * sizeof(EngLayer) + 15) & ~(size_t)15) + 2 * (size_t)a.lds_xs_bytes + 2 * (((size_t)a.dim * 2 + 15) & ~(size_t)15);
-    smem += sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + sizeof(float) * (4 * GQ + 4 + (size_t)4 * GQ * (hd + 4)) + 4 * 64 + 16;
+    smem += sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + sizeof(float) * (4 * GQ + 4 + (size_t)4 * GQ * (hd + 4)) + 4 * 64 + 32;
     smem = (smem + 15) & ~(size_t)15;
     if (smem > 160 * 1024) {
+        if (E->xmem) (void)hipFree(E->xmem);
         delete E;
         return KF_UNSUPPORTED_DATATYPE;
     }
@@ -1103,6 +1166,7 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
 }
 void engine_free(EngineHost* E) {
     if (E && E->args.dbg) (void)hipFree(E->args.dbg);
+    if (E && E->xmem) (void)hipFree(E->xmem);
     delete E;
 }
 int engine_debug_read(EngineHost* E, unsigned long long* h_out, int n_words) {
