@@ -8,21 +8,29 @@
 //   P5 [RMSNorm + gate/up + SwiGLU]  P6 [down_proj + residual]
 //
 // because on this chip a dependent launch boundary plus the setup and first HBM miss of the next kernel costs ~3 us while a layer's
-// 8.4 MB of weights stream in ~1.3 us (scratch/ub_overlap.hip).  One workgroup of 16 waves per CU:
+// 8.4 MB of weights stream in ~1.3 us (scratch/ub_overlap.hip).  One workgroup of 8 waves per CU:
 //
-//   * wave 15 ("poller") does nothing but wait for the phase's input vector and stage it into LDS.  Producers publish every output
-//     as a tagged granule -- one aligned 4-byte {bf16 value, 16-bit generation} (attention partials: 8-byte {fp32, 32-bit generation})
-//     written by ONE sc1 (write-through) store -- and the poller sweeps the granules with sc1 loads, all loads of a sweep in flight,
-//     until every tag equals the generation it expects: the data is the flag (MI355X_MICROARCH.md "Valid forms", R2).  No counters,
-//     no fences, no grid barrier; nothing depends on dispatch order or placement, only on all workgroups being resident
-//     (grid <= number of CUs, one 1024-thread workgroup each).
-//   * waves 0..14 hold the phase's 16-byte weight blocks in registers -- requested one phase ahead, so HBM latency is off the chain --
-//     and multiply when the barrier behind the poller's staging opens.  The arithmetic is the mat-vec kernel's (kf_gemv_blocks.h:
-//     same lanes per row, same per-lane chain, same DPP tree) and the attention kernel's (kf_attn_common.h; same slices, same
-//     4-wave key interleave, same merge order), so every output bit equals the multi-launch path's.
+//   * wave 7 ("poller") waits for the phase's input vector and stages it into LDS.  Producers publish every output as a tagged
+//     granule -- one aligned 4-byte {bf16 value, 16-bit generation} (attention partials: 8-byte {fp32, 32-bit generation}) written by
+//     sc1 (write-through) stores, 16 bytes per lane -- and the poller sweeps the granules with sc1 loads, all loads of a sweep in
+//     flight, until every tag equals the generation it expects: the data is the flag (MI355X_MICROARCH.md "Valid forms", R2).  No
+//     counters, no fences, no grid barrier; nothing depends on dispatch order or placement, only on all workgroups being resident
+//     (grid <= number of CUs).  A sweep costs its whole round trip whether it succeeds or not and slows the stores it is waiting for,
+//     so the FIRST sweep of a hand-off is issued a fixed delay behind the moment this workgroup's own rows of the feeding phase were
+//     published (all workgroups do the same work in step): scratch/ub_handoff3.hip, 1.2 us per edge instead of 2.1-2.3.
+//     The vectors that cross XCDs live in uncached device memory (an sc1 sweep costs 43 ns per KB there, 75 in cached memory).
+//   * waves 0..6 hold the phase's 16-byte weight blocks in registers -- requested one phase ahead, unconditionally, so HBM latency is
+//     off the chain and every wait is a counted s_waitcnt vmcnt(N) -- and multiply when the barrier behind the poller's staging opens.
+//     The arithmetic is the mat-vec kernel's (kf_gemv_blocks.h: same lanes per row, same per-lane chain, same DPP tree) and the
+//     attention kernel's (kf_attn_common.h; same slices, same 4-wave key interleave, same merge order), so every output bit equals the
+//     multi-launch path's.
 //
 // A workgroup polls a buffer only when it has work that needs it: then every reader of generation g has finished before any
 // producer of generation g+1 can have its own inputs complete, and buffers are reused across layers without a second handshake.
+//
+// Every geometry figure of a phase is a compile-time constant of the model shape (PlanT below: types with static members, never
+// objects -- an object indexed by a run-time job number becomes a table in constant memory, and the load from it a vmcnt(0) drain
+// of the weight prefetch that was just issued).
 #include <stdlib.h>
 #include <string.h>
 
@@ -33,10 +41,9 @@
 
 namespace kf {
 
-constexpr int ENG_MAXLD = 16;         /* 1 KiB granule pieces (256 values) per sweep: vectors up to 4096 */
+constexpr int ENG_MAXLD = 16;             /* 1 KiB granule pieces (256 values) per sweep: vectors up to 4096 */
 constexpr int ENG_NWG = 256, ENG_NWV = 8; /* MI355X: 256 CUs, one 8-wave workgroup each (7 compute waves + the poller) */
-constexpr int ENG_GLS_MAX = 1056;     /* largest line stride of the granule buffers, in dwords (32 = dense) */
-constexpr int ENG_SPIN_MAX = 1 << 17; /* sweeps before a poll gives up (~0.1 s): sets the error word, never hangs */
+constexpr int ENG_SPIN_MAX = 1 << 17;     /* sweeps before a poll gives up (~0.1 s): sets the error word, never hangs */
 
 // device tables hold GLOBAL pointers (address space 1): read back from LDS they would otherwise be generic, and every access through them a
 // flat_load, which the hardware returns out of order, so every wait behind one is a drain (vmcnt(0) + lgkmcnt(0))
@@ -54,17 +61,33 @@ struct EngLayer {
     g_u16 norm_in, norm_post, norm_q, norm_k;
     g_u16w kcache, vcache; /* layer base */
 };
-struct EngPlan { /* one mat-vec phase: the geometry gemv_launch would pick for the same matrices */
+struct EngPlan { /* host copy of one mat-vec phase: the geometry gemv_launch would pick for the same matrices (checked against PlanT) */
     int K, nBlk, lpr_log2, iters, gshift, njobs;
     int M[3], slot0[3], qBias[3];
     int total_slots, spg; /* slots per workgroup (contiguous) */
     int pad_[3];
 };
+
+// ---- the exchange area (uncached memory): granule vectors at compile-time offsets (dwords), 256-byte aligned
+constexpr int eng_gran_dw(int n) { return ((n * 4 + 255) & ~255) / 4; }
+struct EngXOff {
+    int xA, qkv, ao, xB, act, part, end; /* part: 8-byte granules [n_head][KF_ATTN_MAX_SPLITS][hd + 4] */
+};
+constexpr EngXOff eng_xoff(int dim, int qd, int kvd, int ffn, int hd) {
+    EngXOff o{};
+    o.xA = 0, o.qkv = o.xA + eng_gran_dw(dim), o.ao = o.qkv + eng_gran_dw(qd + 2 * kvd), o.xB = o.ao + eng_gran_dw(qd), o.act = o.xB + eng_gran_dw(dim);
+    o.part = o.act + eng_gran_dw(ffn);
+    o.end = o.part + eng_gran_dw(2 * (qd / hd) * KF_ATTN_MAX_SPLITS * (hd + 4));
+    return o;
+}
+// ---- the XCD-local area (cached memory, plain stores: the lines stay in that XCD's L2): [tickets 1 KiB] [lqkv 8 x lq dwords] [lpart 8 x lp qwords]
+constexpr int eng_lq_stride(int gq, int hd) { return ((gq * hd + 2 * hd) * 4 + 255) / 256 * 64; }                   /* dwords */
+constexpr int eng_lp_stride(int gq, int hd) { return (gq * KF_ATTN_MAX_SPLITS * (hd + 4) * 8 + 255) / 256 * 32; } /* qwords */
+constexpr size_t eng_loc_bytes(int gq, int hd) { return 1024 + (size_t)8 * eng_lq_stride(gq, hd) * 4 + (size_t)8 * eng_lp_stride(gq, hd) * 8; }
+
 struct EngArgs {
     const EngLayer* layers;
-    const EngPlan* plans; /* device copy of the four plans: P1, P4, P5, P6 */
-    int n_layer, n_wg;
-    int dim, q_dim, kv_dim, ffn, n_head, n_kv, hd, kv_stride;
+    int n_layer;
     float eps, qk_eps;
     const float* rope_table;
     const int32_t* d_state; /* {token, pos} */
@@ -73,44 +96,27 @@ struct EngArgs {
     const int32_t* d_forced;
     int emb_rows;
     uint16_t* x_out;        /* plain bf16 [dim]: the residual stream after the last layer */
-    uint32_t *xA, *qkv, *ao, *xB, *act; /* granule buffers */
-    unsigned long long* part;          /* [n_head][nsp][hd + 4] 8-byte granules */
-    int* ws;                           /* [0] epoch, [1] error word */
-    int nsp, chunk, merge_e;           /* attention slices of this launch's position bound; merge elements per workgroup */
-    int lds_xs_bytes;                  /* bytes of one x staging buffer */
-    int spg[4], nslots[4], nblk[4];    /* per phase (P1, P4, P5, P6): slots per workgroup, slots in all, blocks per row */
-    float qbias[7];                    /* qBias of q k v o gate up down */
-    int gls;                           /* dwords between the 128-byte lines (32 granules) of a granule buffer: 32 = dense */
-    int poll_sleep;                    /* s_sleep units between two sweeps of a poll */
-    int delay[6];                      /* s_sleep units between "this workgroup's own rows of the feeding phase are published" and the first sweep of: x (P1), q|k|v (P2), slice
-                                          partials (P3), ao (P4), xB (P5), act (P6).  A sweep that comes too early fails, costs its whole round trip and slows the stores it waits for
-                                          (scratch/ub_handoff3.hip: 1.2 us per edge with the first sweep ~0.4 us behind the publish against 2.1-2.3 us with sweeps from the start) */
-    int* tickets;                      /* XCD-mapped form: one ticket word per XCD, 128 bytes apart (zero between launches) */
-    uint32_t* lqkv;                    /* XCD-mapped form: [8][lq_stride] granules: q | k | v rows of the XCD's kv-head, written with plain stores (they stay in that XCD's L2) */
-    unsigned long long* lpart;         /* XCD-mapped form: [8][GQ][32][hd + 4] partial granules of the XCD's kv-head */
-    int lq_stride, lp_stride;
-    int ncopy, cstride;                /* every granule buffer exists ncopy times (1 or 8), cstride dwords apart: producers write all copies, a consumer reads the copy of its XCD */
-    int exp_flags;                     /* timing experiments only (KF_ENG_EXP; results are wrong): 1 = every weight load from the matrix's first KB, 2 = K/V tiles from row 0 */
-    unsigned long long* dbg;           /* diagnostic runs only (KF_ENG_DEBUG): [layer][role][16] wall-clock stamps of workgroup dbg_wg */
+    uint32_t* xch;          /* exchange area (EngXOff) */
+    int* ws;                /* [0] epoch, [1] error word */
+    char* loc;              /* XCD-local area */
+    int nsp, chunk, merge_e; /* attention slices of this launch's position bound; merge elements per workgroup */
+    int kv_stride;
+    float qbias[7];         /* qBias of q k v o gate up down */
+    int delay[6];           /* s_sleep units between "this workgroup's own rows of the feeding phase are published" and the first sweep of: x (P1), q|k|v (P2), slice
+                               partials (P3), ao (P4), xB (P5), act (P6) */
+    unsigned long long* dbg; /* diagnostic instantiation only (KF_ENG_DEBUG): [layer][role][16] wall-clock stamps of workgroup dbg_wg */
     int dbg_wg;
 };
-#define ENG_STAMP(role, k)                                                                                                         \
-    do {                                                                                                                       \
-        if (a.dbg && wg == a.dbg_wg && lane == 0) a.dbg[((size_t)l * 2 + (role)) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+#define ENG_STAMP(role, k)                                                                                                           \
+    do {                                                                                                                         \
+        if (DBG && wg == a.dbg_wg && lane == 0) a.dbg[((size_t)l * 2 + (role)) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t eng_rsrc(const void* p, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
-// granule e of a buffer sits in 128-byte line e / 32; the lines are `gls` dwords apart so that a vector every CU polls at once is spread
-// over the memory channels instead of sitting in one 4 KB window
-__device__ __forceinline__ int goff(int e, int gls) { return (e >> 5) * gls + (e & 31); }
 __device__ __forceinline__ void st_gran(uint32_t* p, uint32_t tag16, uint16_t v) {
     __hip_atomic_store(p, (tag16 << 16) | (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// publish to every copy
-__device__ __forceinline__ void pub_gran(uint32_t* buf, int off, int ncopy, int cstride, uint32_t tag16, uint16_t v) {
-    for (int c = 0; c < ncopy; c++) st_gran(buf + (size_t)c * cstride + off, tag16, v);
 }
 __device__ __forceinline__ int eng_xcc() {
     unsigned x;
@@ -123,14 +129,20 @@ __device__ __forceinline__ void st_gran64(unsigned long long* p, uint32_t gen, f
 __device__ __forceinline__ unsigned long long ld_gran64(const unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// tag mismatch bits of one 16-byte piece (4 granules), kept in a vector register: comparing into lane masks would hold an SGPR pair per compare
-__device__ __forceinline__ uint32_t tags_bad(u32x4 g, uint32_t tag) { return ((g.x >> 16) ^ tag) | ((g.y >> 16) ^ tag) | ((g.z >> 16) ^ tag) | ((g.w >> 16) ^ tag); }
+// tag mismatch bits of one 16-byte piece (4 granules), accumulated in a vector register (tagw = tag << 16): as compares into lane masks the
+// compiler issues a v_cmp + s_and pair per granule, each a VALU -> SALU hand-over
+__device__ __forceinline__ uint32_t tags_bad(u32x4 g, uint32_t tagw, uint32_t bad) {
+    bad |= (g.x ^ tagw) & 0xffff0000u;
+    bad |= (g.y ^ tagw) & 0xffff0000u;
+    bad |= (g.z ^ tagw) & 0xffff0000u;
+    bad |= (g.w ^ tagw) & 0xffff0000u;
+    return bad;
+}
+__device__ __forceinline__ bool all_good(uint32_t bad) {
+    asm volatile("" : "+v"(bad)); /* keep the accumulated word opaque: one compare per sweep */
+    return __all(bad == 0);
+}
 
-// ---- poller: sweep the NLD * 256 granules of a vector until every tag matches, then stage the vector into LDS: xs in the mat-vec's
-// chunk layout [XCH][nBlk] (element e = c*EPB + j*8 + i -> chunk j*nBlk + c), optionally RMS-normalised (rms_norm_kernel,
-// layernorm.cuh:800-847: fp64 sum of squares, (x*mul)*w, one bf16 store), and the raw vector in natural order into xraw (the residual
-// the phase after next adds).  Lane l of load r owns elements 4*(64r + l) .. +3.  PLAIN: the vector is plain bf16 written by an
-// earlier launch (layer 0's embedding row).  Straight-line code: the vector lengths are template parameters of the kernel.
 // wait until this workgroup's own counter `pub` has reached `want` (its rows of the feeding phase are on their way), then `delay` sleep units
 __device__ __forceinline__ void eng_wait_pub(const int* pub, int want, int delay, bool& dead) {
     if (pub) {
@@ -141,10 +153,15 @@ __device__ __forceinline__ void eng_wait_pub(const int* pub, int want, int delay
     }
     for (int z = 0; z < delay; z++) __builtin_amdgcn_s_sleep(1);
 }
-template <int XCH, int NLD, bool NORM, bool PLAIN>
-__device__ __forceinline__ void eng_poll_stage(const uint32_t* gsrc, const uint16_t* plain, uint32_t tag, int nBlk, g_u16 norm_w, float eps, u32x4* xs,
-                                               uint16_t* xraw, int lane, int* ws, bool& dead, int gls, int psleep, int* nsweeps, const int* pub, int want, int delay,
-                                               unsigned long long* tsw = nullptr) {
+
+// ---- poller: sweep the NLD * 256 granules of a vector until every tag matches, then stage the vector into LDS: xs in the mat-vec's
+// chunk layout [XCH][nBlk] (element e = c*EPB + j*8 + i -> chunk j*nBlk + c), optionally RMS-normalised (rms_norm_kernel,
+// layernorm.cuh:800-847: fp64 sum of squares, (x*mul)*w, one bf16 store), and the raw vector in natural order into xraw (the residual
+// the phase after next adds).  Lane l of load r owns elements 4*(64r + l) .. +3.  PLAIN: the vector is plain bf16 written by an
+// earlier launch (layer 0's embedding row).  Straight-line code: the vector lengths are template parameters of the kernel.
+template <int XCH, int NLD, int NBLK, bool NORM, bool PLAIN>
+__device__ __forceinline__ void eng_poll_stage(const uint32_t* gsrc, const uint16_t* plain, uint32_t tag, g_u16 norm_w, float eps, u32x4* xs, uint16_t* xraw, int lane, int* ws,
+                                               bool& dead, int* nsweeps, const int* pub, int want, int delay) {
     constexpr int n = NLD * 256;
     uint32_t p0[NLD], p1[NLD], w0[NLD], w1[NLD];
     if (NORM) { /* constants: requested in front of the sweep */
@@ -161,20 +178,17 @@ __device__ __forceinline__ void eng_poll_stage(const uint32_t* gsrc, const uint1
             p0[r] = t.x, p1[r] = t.y;
         }
     } else {
-        const __amdgpu_buffer_rsrc_t rs = eng_rsrc(gsrc, (uint32_t)(n / 32) * (uint32_t)gls * 4u);
+        const __amdgpu_buffer_rsrc_t rs = eng_rsrc(gsrc, (uint32_t)n * 4u);
         u32x4 g[NLD];
-        int voff[NLD];
-#pragma unroll
-        for (int r = 0; r < NLD; r++) voff[r] = goff(4 * (r * 64 + lane), gls) * 4;
+        const uint32_t tagw = tag << 16;
         eng_wait_pub(pub, want, delay, dead);
         for (int spins = 0;; spins++) {
             uint32_t bad = 0;
 #pragma unroll
-            for (int r = 0; r < NLD; r++) g[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[r], 0, 16 /* sc1 */));
+            for (int r = 0; r < NLD; r++) g[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (r * 64 + lane) * 16, 0, 16 /* sc1 */));
 #pragma unroll
-            for (int r = 0; r < NLD; r++) bad |= tags_bad(g[r], tag);
-            if (tsw && spins < 7 && lane == 0) tsw[spins] = __builtin_amdgcn_s_memrealtime();
-            if (__all(bad == 0)) {
+            for (int r = 0; r < NLD; r++) bad = tags_bad(g[r], tagw, bad);
+            if (all_good(bad)) {
                 if (nsweeps) *nsweeps = spins + 1;
                 break;
             }
@@ -183,7 +197,7 @@ __device__ __forceinline__ void eng_poll_stage(const uint32_t* gsrc, const uint1
                 dead = true;
                 break;
             }
-            for (int z = 0; z < psleep; z++) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(1);
         }
 #pragma unroll
         for (int r = 0; r < NLD; r++) p0[r] = (g[r].x & 0xffffu) | (g[r].y << 16), p1[r] = (g[r].z & 0xffffu) | (g[r].w << 16);
@@ -209,13 +223,13 @@ __device__ __forceinline__ void eng_poll_stage(const uint32_t* gsrc, const uint1
             o1 = pack_bf16x2((bf_lo(o1) * mul) * bf_lo(w1[r]), (bf_hi(o1) * mul) * bf_hi(w1[r]));
         }
         const int q = e0 >> 3, c = q / XCH, j = q - c * XCH;
-        reinterpret_cast<u32x2*>(xs + j * nBlk + c)[(e0 >> 2) & 1] = u32x2{o0, o1};
+        reinterpret_cast<u32x2*>(xs + j * NBLK + c)[(e0 >> 2) & 1] = u32x2{o0, o1};
     }
 }
 
-// ---- mat-vec phase pieces (compute waves).  The geometry of every phase is a compile-time constant of the model shape (the same lanes per
-// row, rows per wave step and steps per row gemv_launch picks for these matrices: engine_build checks the two against each other), so a
-// wave's loads are unconditional, their number is static and the compiler can wait with counted vmcnt(N) instead of draining.
+// ---- mat-vec phase geometry: compile-time constants of the model shape (the same lanes per row, rows per wave step and steps per row
+// gemv_launch picks for these matrices: engine_build checks the two against each other), so a wave's loads are unconditional, their number
+// is static and the compiler can wait with counted vmcnt(N) instead of draining.
 constexpr int c_lpr_log2(int nBlk, long rows) { /* = gemv_lpr_log2 (kf_gemv.hip) */
     int l = 6;
     while (l > 0 && (nBlk % (1 << l)) != 0) l--;
@@ -247,95 +261,105 @@ constexpr CPlan c_plan(int K, int epb, int m0, int m1, int m2, bool paired, int 
     P.spg = (P.total + nwg - 1) / nwg;
     return P;
 }
+// the plan as a TYPE: every figure a static constant (no object, nothing to index at run time)
+template <int K_, int EPB_, int M0_, int M1_, int M2_, bool PAIRED_, int NWG_>
+struct PlanT {
+    static constexpr int K = K_, nBlk = K_ / EPB_;
+    static constexpr int lpr_log2 = c_plan(K_, EPB_, M0_, M1_, M2_, PAIRED_, NWG_).lpr_log2, LPR = 1 << lpr_log2, RPS = 64 >> lpr_log2;
+    static constexpr int iters = c_plan(K_, EPB_, M0_, M1_, M2_, PAIRED_, NWG_).iters, njobs = c_plan(K_, EPB_, M0_, M1_, M2_, PAIRED_, NWG_).njobs;
+    static constexpr int M0 = M0_, M1 = M1_, M2 = M2_;
+    static constexpr int S1 = c_plan(K_, EPB_, M0_, M1_, M2_, PAIRED_, NWG_).slot0[1], S2 = c_plan(K_, EPB_, M0_, M1_, M2_, PAIRED_, NWG_).slot0[2];
+    static constexpr int total = c_plan(K_, EPB_, M0_, M1_, M2_, PAIRED_, NWG_).total, spg = c_plan(K_, EPB_, M0_, M1_, M2_, PAIRED_, NWG_).spg;
+    static constexpr int R = spg * RPS; /* rows of one workgroup (contiguous in the phase's output vector) */
+    static constexpr bool PAIRED = PAIRED_;
+    static constexpr CPlan plan() { return c_plan(K_, EPB_, M0_, M1_, M2_, PAIRED_, NWG_); }
+};
 // the four phases of a model shape
 template <int FMT, int DIM, int QD, int KVD, int FFN, int NWG>
 struct EngShape {
     static constexpr int EPB = BlockDot<FMT>::EPB;
-    static constexpr CPlan P1 = c_plan(DIM, EPB, QD, KVD, KVD, false, NWG), P4 = c_plan(QD, EPB, DIM, 0, 0, false, NWG), P5 = c_plan(DIM, EPB, FFN, FFN, 0, true, NWG),
-                           P6 = c_plan(FFN, EPB, DIM, 0, 0, false, NWG);
+    using P1 = PlanT<DIM, EPB, QD, KVD, KVD, false, NWG>;
+    using P4 = PlanT<QD, EPB, DIM, 0, 0, false, NWG>;
+    using P5 = PlanT<DIM, EPB, FFN, FFN, 0, true, NWG>;
+    using P6 = PlanT<FFN, EPB, DIM, 0, 0, false, NWG>;
 };
 template <bool PAIRED, int MAXS>
 struct MvRegs {
     u32x4 w[MAXS], w2[PAIRED ? MAXS : 1];
     uint16_t st[MAXS], ze[MAXS], st2[PAIRED ? MAXS : 1], ze2[PAIRED ? MAXS : 1];
 };
-template <int NCW>
-constexpr int c_maxs(const CPlan& P) { return ((P.spg + NCW - 1) / NCW) * P.iters; }
+template <class PL, int NCW>
+constexpr int c_maxs() { return ((PL::spg + NCW - 1) / NCW) * PL::iters; }
 struct MvAt {
-    int j, row, col;
+    int row, col;
     bool ok;
 };
-// step k of compute wave cw in workgroup wg: slot wg*spg + cw + (k / iters)*NCW, iteration k % iters
-template <int NCW>
-__device__ __forceinline__ MvAt mv_at(const CPlan& P, int k, int s0, int cw, int lane) {
-    const int LPR = 1 << P.lpr_log2, RPS = 64 >> P.lpr_log2, sub = lane >> P.lpr_log2, ll = lane & (LPR - 1);
-    const int sl = k / P.iters, it = k - sl * P.iters;
-    const int s_loc = cw + sl * NCW, s = s0 + s_loc;
-    int j = 0;
-    if (P.njobs > 1 && s >= P.slot0[1]) j = 1;
-    if (P.njobs > 2 && s >= P.slot0[2]) j = 2;
+// step k of compute wave cw: slot s0 + cw + (k / iters)*NCW of the job (matrix) the workgroup's rows belong to, iteration k % iters;
+// s0 = the workgroup's first slot counted inside that matrix, Mj = its rows (a workgroup's slots never straddle two matrices)
+template <class PL, int NCW>
+__device__ __forceinline__ MvAt mv_at(int k, int s0, int cw, int lane, int Mj) {
+    const int sub = lane >> PL::lpr_log2, ll = lane & (PL::LPR - 1);
+    const int sl = k / PL::iters, it = k - sl * PL::iters;
+    const int s_loc = cw + sl * NCW;
     MvAt q;
-    q.j = j;
-    q.row = (s - (j == 0 ? 0 : (j == 1 ? P.slot0[1] : P.slot0[2]))) * RPS + sub;
-    q.col = it * LPR + ll;
-    q.ok = s_loc < P.spg && s < P.total && q.row < (j == 0 ? P.M[0] : (j == 1 ? P.M[1] : P.M[2])) && q.col < P.nBlk;
+    q.row = (s0 + s_loc) * PL::RPS + sub;
+    q.col = it * PL::LPR + ll;
+    q.ok = s_loc < PL::spg && q.row < Mj && q.col < PL::nBlk;
     return q;
 }
-template <int NCW, int FMT, bool PAIRED, int MAXS>
-__device__ __forceinline__ void mv_prefetch(const CPlan& P, const EngMat* jm, int s0, int cw, int lane, MvRegs<PAIRED, MAXS>& R, int exp_flags = 0) {
+// unconditional loads of the wave's blocks (clamped indices; masks are applied at the multiply): m = the matrix of the workgroup's rows, m2 = the
+// paired one (up_proj beside gate_proj)
+template <class PL, int NCW, int FMT, int MAXS>
+__device__ __forceinline__ void mv_prefetch(const EngMat m, const EngMat m2, int s0, int cw, int lane, int Mj, MvRegs<PL::PAIRED, MAXS>& R) {
     constexpr bool GAMA = BlockDot<FMT>::HAS_GAMA;
     constexpr int gshift = FMT >= FMT_Q4 ? (FMT == FMT_Q4 || FMT == FMT_Q4P ? 2 : (FMT == FMT_Q2 ? 1 : 0)) : 0; /* 128-weight groups */
 #pragma unroll
     for (int k = 0; k < MAXS; k++) {
-        const MvAt q = mv_at<NCW>(P, k, s0, cw, lane);
-        const int Mj = q.j == 0 ? P.M[0] : (q.j == 1 ? P.M[1] : P.M[2]);
+        const MvAt q = mv_at<PL, NCW>(k, s0, cw, lane, Mj);
         int row = q.row < Mj ? q.row : Mj - 1;
         row = row > 0 ? row : 0;
-        const int col = q.col < P.nBlk ? q.col : P.nBlk - 1;
-        uint32_t bidx = (uint32_t)row * (uint32_t)P.nBlk + (uint32_t)col;
-        if (exp_flags & 1) bidx = (uint32_t)lane;
-        const EngMat mj = q.j == 0 ? jm[0] : (q.j == 1 ? jm[P.njobs > 1 ? 1 : 0] : jm[P.njobs > 2 ? 2 : 0]);
-        R.w[k] = __builtin_nontemporal_load(mj.w + bidx);
-        if (PAIRED) R.w2[k] = __builtin_nontemporal_load(jm[1].w + bidx);
+        const int col = q.col < PL::nBlk ? q.col : PL::nBlk - 1;
+        const uint32_t bidx = (uint32_t)row * (uint32_t)PL::nBlk + (uint32_t)col;
+        R.w[k] = __builtin_nontemporal_load(m.w + bidx);
+        if (PL::PAIRED) R.w2[k] = __builtin_nontemporal_load(m2.w + bidx);
         if (GAMA) {
             const uint32_t gi = bidx >> gshift;
-            R.st[k] = mj.step[gi], R.ze[k] = mj.zero[gi];
-            if (PAIRED) R.st2[k] = jm[1].step[gi], R.ze2[k] = jm[1].zero[gi];
+            R.st[k] = m.step[gi], R.ze[k] = m.zero[gi];
+            if (PL::PAIRED) R.st2[k] = m2.step[gi], R.ze2[k] = m2.zero[gi];
         }
     }
 }
-// epi(job, row, v, v2) runs in the lane that owns a finished row
-template <int NCW, int FMT, bool PAIRED, int MAXS, typename Epi>
-__device__ __forceinline__ void mv_run(const CPlan& P, const float* qb, int s0, int cw, int lane, const MvRegs<PAIRED, MAXS>& R, const u32x4* xs, Epi&& epi) {
+// epi(row, v, v2) runs in the lane that owns a finished row (row counted inside the matrix)
+template <class PL, int NCW, int FMT, int MAXS, typename Epi>
+__device__ __forceinline__ void mv_run(float qb, float qb2, int s0, int cw, int lane, int Mj, const MvRegs<PL::PAIRED, MAXS>& R, const u32x4* xs, Epi&& epi) {
     using BD = BlockDot<FMT>;
     float acc = 0.f, acc2 = 0.f;
 #pragma unroll
     for (int k = 0; k < MAXS; k++) {
-        const int sl = k / P.iters, it = k - sl * P.iters;
-        if (cw + sl * NCW >= P.spg) continue; /* wave-uniform: this wave has no such slot */
-        const MvAt q = mv_at<NCW>(P, k, s0, cw, lane);
-        const int col = q.col < P.nBlk ? q.col : P.nBlk - 1;
+        const int sl = k / PL::iters, it = k - sl * PL::iters;
+        if (cw + sl * NCW >= PL::spg) continue; /* wave-uniform: this wave has no such slot */
+        const MvAt q = mv_at<PL, NCW>(k, s0, cw, lane, Mj);
+        const int col = q.col < PL::nBlk ? q.col : PL::nBlk - 1;
         if (it == 0) acc = 0.f, acc2 = 0.f;
         const float st = bf2f(R.st[k]);
-        const float qbj = q.j == 0 ? qb[0] : (q.j == 1 ? qb[P.njobs > 1 ? 1 : 0] : qb[P.njobs > 2 ? 2 : 0]);
-        const float r = BD::run(R.w[k], xs, col, P.nBlk, st, bf2f(R.ze[k]), -(qbj * st), acc);
+        const float r = BD::run(R.w[k], xs, col, PL::nBlk, st, bf2f(R.ze[k]), -(qb * st), acc);
         acc = q.ok ? r : acc;
-        if (PAIRED) {
+        if (PL::PAIRED) {
             const float st2 = bf2f(R.st2[k]);
-            const float r2 = BD::run(R.w2[k], xs, col, P.nBlk, st2, bf2f(R.ze2[k]), -(qb[1] * st2), acc2);
+            const float r2 = BD::run(R.w2[k], xs, col, PL::nBlk, st2, bf2f(R.ze2[k]), -(qb2 * st2), acc2);
             acc2 = q.ok ? r2 : acc2;
         }
-        if (it == P.iters - 1) {
-            const float v = group_sum(acc, P.lpr_log2);
+        if (it == PL::iters - 1) {
+            const float v = group_sum(acc, PL::lpr_log2);
             float v2 = 0.f;
-            if (PAIRED) v2 = group_sum(acc2, P.lpr_log2);
-            if ((lane & ((1 << P.lpr_log2) - 1)) == 0 && q.ok) epi(q.j, q.row, v, v2);
+            if (PL::PAIRED) v2 = group_sum(acc2, PL::lpr_log2);
+            if ((lane & (PL::LPR - 1)) == 0 && q.ok) epi(q.row, v, v2);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ the kernel
-// LDS: [4 plans] [layer table] [xs0] [xs1] [xrawA dim] [xrawB dim] [attention: qraw GQ*hd | kraw hd | vraw hd | qb GQ*hd | knew hd | wmax | comb]
+// LDS: [layer table] [xs0] [xs1] [xrawA dim] [xrawB dim] [attention: qraw GQ*hd | kraw hd | vraw hd | qb GQ*hd | knew hd | wmax | comb] [outb] [cnt, pub]
 struct EngLds {
     const EngLayer* lay;
     u32x4* xs[2];
@@ -349,7 +373,9 @@ struct EngSlice { /* this workgroup's attention slice and merge share */
     int pos, len, nsp, kvh, split, h0, t0, t1, me0;
     bool has_unit, empty, own_new, has_merge;
     int xcc, rank;  /* XCD-mapped form: the XCD this workgroup runs on and its ticket there */
-    int s1;         /* first P1 slot of this workgroup */
+    int j1;         /* the matrix (0 q, 1 k, 2 v) this workgroup's P1 rows belong to */
+    int s1;         /* first P1 slot of this workgroup, counted inside that matrix */
+    int M1;         /* rows of that matrix */
     int q_out0;     /* index of its first P1 row in the vector its P1 rows are published to */
 };
 
@@ -359,8 +385,8 @@ struct EngSlice { /* this workgroup's attention slice and merge share */
 __device__ __forceinline__ void st_gran16(uint32_t* p, u32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(v, eng_rsrc(p, 16), 0, 0, 16 /* sc1 */);
 }
-// local = true: plain stores into a buffer of this XCD (dense lines)
-__device__ __forceinline__ void wg_publish(const EngLds& L, int phase, uint32_t* buf, int idx0, int nrows, int nwaves, int lane, int gls, int ncopy, int cstride, bool local = false) {
+// local = true: plain stores into a buffer of this XCD
+__device__ __forceinline__ void wg_publish(const EngLds& L, int phase, uint32_t* buf, int idx0, int nrows, int nwaves, int lane, bool local = false) {
     int old = 0;
     if (lane == 0) old = __hip_atomic_fetch_add(L.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     old = __builtin_amdgcn_readfirstlane(old);
@@ -368,38 +394,58 @@ __device__ __forceinline__ void wg_publish(const EngLds& L, int phase, uint32_t*
     if (lane == 0) *L.cnt = 0;
     if (4 * lane < nrows) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(L.outb + 4 * lane);
-        if (local) {
+        if (local)
             *reinterpret_cast<u32x4*>(buf + idx0 + 4 * lane) = v;
-        } else {
-            const int off = goff(idx0 + 4 * lane, gls);
-            for (int c = 0; c < ncopy; c++) st_gran16(buf + (size_t)c * cstride + off, v);
-        }
+        else
+            st_gran16(buf + idx0 + 4 * lane, v);
     }
     if (lane == 0) __hip_atomic_fetch_add(L.pub + phase, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); /* the poller may start to sweep for what the consumers of these rows produce */
 }
 
+template <int FMT_, int GQ_, int HD_, int NWV_, int DIM_, int QD_, int KVD_, int FFN_, int NWG_, bool XMAP_, bool DBG_>
+struct EngCfg {
+    static constexpr int FMT = FMT_, GQ = GQ_, HD = HD_, NWV = NWV_, DIM = DIM_, QD = QD_, KVD = KVD_, FFN = FFN_, NWG = NWG_;
+    static constexpr bool XMAP = XMAP_, DBG = DBG_;
+    static constexpr int n_head = QD_ / HD_, n_kv = KVD_ / HD_;
+    using SH = EngShape<FMT_, DIM_, QD_, KVD_, FFN_, NWG_>;
+    static constexpr int xA = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).xA, qkv = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).qkv, ao = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).ao,
+                         xB = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).xB, act = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).act, part = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).part;
+    static constexpr int lq_stride = eng_lq_stride(GQ_, HD_), lp_stride = eng_lp_stride(GQ_, HD_);
+};
+template <class C>
+__device__ __forceinline__ uint32_t* eng_lqkv(const EngArgs& a, int xcc) { return reinterpret_cast<uint32_t*>(a.loc + 1024) + (size_t)xcc * C::lq_stride; }
+template <class C>
+__device__ __forceinline__ unsigned long long* eng_lpart(const EngArgs& a, int xcc) {
+    return reinterpret_cast<unsigned long long*>(a.loc + 1024 + (size_t)8 * C::lq_stride * 4) + (size_t)xcc * C::lp_stride;
+}
+
 // the poller wave: per layer it stages P1's x, the slice's q/k/v heads, merges, stages P4's, P5's and P6's inputs
-template <int FMT, int GQ, int HD, int NWV, int DIM, int QD, int KVD, int FFN, int NWG, bool XMAP>
+template <class C>
 __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& L, const EngSlice& S, int epoch, int wg, int lane) {
-    using SH = EngShape<FMT, DIM, QD, KVD, FFN, NWG>;
-    constexpr int ND = DIM / 256, NQD = QD / 256, NF = FFN / 256;
+    using SH = typename C::SH;
+    using P1 = typename SH::P1;
+    using P4 = typename SH::P4;
+    using P5 = typename SH::P5;
+    using P6 = typename SH::P6;
+    constexpr int FMT = C::FMT, GQ = C::GQ, HD = C::HD, NWV = C::NWV;
+    constexpr bool XMAP = C::XMAP, DBG = C::DBG;
+    constexpr int ND = C::DIM / 256, NQD = C::QD / 256, NF = C::FFN / 256;
     constexpr int XCH = BlockDot<FMT>::XCH, hd = HD, hd_log2 = HD == 128 ? 7 : 6, NW = 4, PS = hd + 4, LPK = hd >> 3, KPW = 64 / LPK;
     bool dead = false;
-    const bool has1 = XMAP ? true : wg * SH::P1.spg < SH::P1.total, has4 = wg * SH::P4.spg < SH::P4.total, has5 = wg * SH::P5.spg < SH::P5.total,
-               has6 = wg * SH::P6.spg < SH::P6.total;
+    const bool has1 = XMAP ? true : wg * P1::spg < P1::total, has4 = wg * P4::spg < P4::total, has5 = wg * P5::spg < P5::total, has6 = wg * P6::spg < P6::total;
     const int tstride = NW * KPW;
     const int nbatch = S.has_unit && !S.empty ? (S.t1 - S.t0 + ATTN_U * tstride - 1) / (ATTN_U * tstride) : 0;
     // the poller's share of P1 (virtual compute wave NWV - 1)
-    constexpr CPlan P1 = SH::P1;
-    constexpr int NCW1 = NWV, S1 = c_maxs<NCW1>(P1), R1 = P1.spg * (64 >> P1.lpr_log2), NWP1 = P1.spg < NCW1 ? P1.spg : NCW1;
-    constexpr bool P1_SHARE = P1.spg >= NWV; /* the poller owns a slot */
-    const float qb1[3] = {a.qbias[0], a.qbias[1], a.qbias[2]};
-    const int j1 = S.s1 >= P1.slot0[2] ? 2 : (S.s1 >= P1.slot0[1] ? 1 : 0);
-    const int row0_1 = (S.s1 - (j1 == 0 ? 0 : (j1 == 1 ? P1.slot0[1] : P1.slot0[2]))) * (64 >> P1.lpr_log2);
+    constexpr int NCW1 = NWV, S1 = c_maxs<P1, NCW1>(), NWP1 = P1::spg < NCW1 ? P1::spg : NCW1;
+    constexpr bool P1_SHARE = P1::spg >= NWV; /* the poller owns a slot */
+    const float qb1 = S.j1 == 0 ? a.qbias[0] : (S.j1 == 1 ? a.qbias[1] : a.qbias[2]);
+    const int row0_1 = S.s1 * P1::RPS;
     MvRegs<false, S1> r1;
-    if (P1_SHARE && has1) mv_prefetch<NCW1, FMT, false, S1>(P1, L.lay[0].m, S.s1, NWV - 1, lane, r1, a.exp_flags);
+    auto mat1 = [&](int l) { /* the matrix of this workgroup's P1 rows in layer l */
+        return L.lay[l].m[S.j1];
+    };
+    if (P1_SHARE) mv_prefetch<P1, NCW1, FMT, S1>(mat1(0), mat1(0), S.s1, NWV - 1, lane, S.M1, r1);
     int sw[4] = {0, 0, 0, 0};
-    const size_t cbase = a.ncopy > 1 ? (size_t)(eng_xcc() & (a.ncopy - 1)) * a.cstride : 0; /* this XCD's copy of the granule buffers */
     for (int l = 0; l < a.n_layer; l++) {
         const EngLayer& ly = L.lay[l];
         const uint32_t gen = (uint32_t)epoch * (uint32_t)a.n_layer + (uint32_t)l, tag = gen & 0xffffu;
@@ -415,52 +461,50 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
                         if (f >= 0) tok = f;
                     }
                     if (tok < 0 || tok >= a.emb_rows) tok = 0;
-                    x0 = a.emb + (size_t)tok * a.dim;
+                    x0 = a.emb + (size_t)tok * C::DIM;
                 }
-                eng_poll_stage<XCH, ND, true, true>(nullptr, x0, tag, SH::P1.nBlk, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, a.gls, a.poll_sleep, &sw[0], nullptr, 0, 0);
+                eng_poll_stage<XCH, ND, P1::nBlk, true, true>(nullptr, x0, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, &sw[0], nullptr, 0, 0);
             } else {
-                eng_poll_stage<XCH, ND, true, false>(a.xA + cbase, nullptr, tag, SH::P1.nBlk, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, a.gls, a.poll_sleep, &sw[0],
-                                                     has6 ? L.pub + 3 : nullptr, l, a.delay[0]);
+                eng_poll_stage<XCH, ND, P1::nBlk, true, false>(a.xch + C::xA, nullptr, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, &sw[0], has6 ? L.pub + 3 : nullptr, l,
+                                                               a.delay[0]);
             }
         }
         ENG_STAMP(0, 1);
         __syncthreads();
         if (P1_SHARE && has1) { /* this wave's P1 rows, then the workgroup's publish like every other owner */
-            mv_run<NCW1, FMT, false, S1>(P1, qb1, S.s1, NWV - 1, lane, r1, L.xs[0], [&](int, int row, float v, float) {
-                L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v);
-            });
+            mv_run<P1, NCW1, FMT, S1>(qb1, 0.f, S.s1, NWV - 1, lane, S.M1, r1, L.xs[0], [&](int row, float v, float) { L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); });
             if (XMAP)
-                wg_publish(L, 0, a.lqkv + (size_t)S.xcc * a.lq_stride, S.q_out0, R1, NWP1, lane, 32, 1, 0, true);
+                wg_publish(L, 0, eng_lqkv<C>(a, S.xcc), S.q_out0, P1::R, NWP1, lane, true);
             else
-                wg_publish(L, 0, a.qkv, S.q_out0, R1, NWP1, lane, a.gls, a.ncopy, a.cstride);
+                wg_publish(L, 0, a.xch + C::qkv, S.q_out0, P1::R, NWP1, lane);
         }
         // P2: q heads of the group (GQ*hd granules), then k and v of the kv-head side by side in one piece
         if (S.has_unit) {
             // XCD-mapped form: the rows were published by workgroups of this XCD with plain stores into its own dense buffer [q GQ*hd | k hd | v hd]
-            const __amdgpu_buffer_rsrc_t rs = XMAP ? eng_rsrc(a.lqkv + (size_t)S.xcc * a.lq_stride, (uint32_t)(GQ * hd + 2 * hd) * 4u)
-                                                   : eng_rsrc(a.qkv + cbase, (uint32_t)((a.q_dim + 2 * a.kv_dim) / 32) * (uint32_t)a.gls * 4u);
-            const int gl = XMAP ? 32 : a.gls, q_src = XMAP ? 0 : S.h0 * hd;
+            const __amdgpu_buffer_rsrc_t rs = XMAP ? eng_rsrc(eng_lqkv<C>(a, S.xcc), (uint32_t)(GQ * hd + 2 * hd) * 4u) : eng_rsrc(a.xch + C::qkv, (uint32_t)(C::QD + 2 * C::KVD) * 4u);
+            const int q_src = XMAP ? 0 : S.h0 * hd;
             constexpr int NLQ = (GQ * hd + 255) / 256;
             u32x4 g[NLQ], gk;
             const int e_kv = 4 * lane; /* < hd: k, < 2hd: v */
             const bool kv_in = e_kv < 2 * hd;
-            const int kv_src = XMAP ? GQ * hd + e_kv : (e_kv < hd ? a.q_dim + S.kvh * hd + e_kv : a.q_dim + a.kv_dim + S.kvh * hd + (e_kv - hd));
+            const int kv_src = XMAP ? GQ * hd + e_kv : (e_kv < hd ? C::QD + S.kvh * hd + e_kv : C::QD + C::KVD + S.kvh * hd + (e_kv - hd));
+            const uint32_t tagw = tag << 16;
             eng_wait_pub(has1 ? L.pub + 0 : nullptr, l + 1, a.delay[1], dead);
             for (int spins = 0;; spins++) {
                 uint32_t bad = 0;
 #pragma unroll
-                for (int r = 0; r < NLQ; r++) g[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, goff(q_src + 4 * (r * 64 + lane), gl) * 4, 0, 16));
-                gk = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, goff(kv_in ? kv_src : 0, gl) * 4, 0, 16));
+                for (int r = 0; r < NLQ; r++) g[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (q_src + 4 * (r * 64 + lane)) * 4, 0, 16));
+                gk = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (kv_in ? kv_src : 0) * 4, 0, 16));
 #pragma unroll
-                for (int r = 0; r < NLQ; r++) bad |= (4 * (r * 64 + lane) < GQ * hd) ? tags_bad(g[r], tag) : 0u;
-                bad |= kv_in ? tags_bad(gk, tag) : 0u;
-                if (__all(bad == 0)) break;
+                for (int r = 0; r < NLQ; r++) bad = (4 * (r * 64 + lane) < GQ * hd) ? tags_bad(g[r], tagw, bad) : bad;
+                bad = kv_in ? tags_bad(gk, tagw, bad) : bad;
+                if (all_good(bad)) break;
                 if (dead || spins > ENG_SPIN_MAX) {
                     if (!dead && lane == 0) atomicOr(a.ws + 1, 2);
                     dead = true;
                     break;
                 }
-                for (int z = 0; z < a.poll_sleep; z++) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(1);
             }
 #pragma unroll
             for (int r = 0; r < NLQ; r++) {
@@ -483,7 +527,8 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
         ENG_STAMP(0, 3);
         if (S.has_merge) {
             const int nsp = S.nsp, h = S.me0 >> hd_log2, dd = S.me0 & (hd - 1); /* XCD-mapped form: me0 counts inside the XCD's GQ heads */
-            const unsigned long long* base = XMAP ? a.lpart + (size_t)S.xcc * a.lp_stride + (size_t)h * nsp * PS : a.part + (size_t)h * nsp * PS;
+            const unsigned long long* base =
+                XMAP ? eng_lpart<C>(a, S.xcc) + (size_t)h * nsp * PS : reinterpret_cast<const unsigned long long*>(a.xch + C::part) + (size_t)h * nsp * PS;
             float ms = -__builtin_inff(), ls = 0.f, vsp[KF_ATTN_MAX_SPLITS];
             const bool mine = lane < nsp, el = lane < a.merge_e;
             eng_wait_pub(nullptr, 0, a.delay[2], dead);
@@ -500,7 +545,7 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
                 if (mine) ms = __uint_as_float((uint32_t)gm), ls = __uint_as_float((uint32_t)gl);
 #pragma unroll
                 for (int sp = 0; sp < KF_ATTN_MAX_SPLITS; sp++) vsp[sp] = __uint_as_float((uint32_t)gv[sp]);
-                if (__all(bad == 0)) break;
+                if (all_good(bad)) break;
                 if (dead || spins > ENG_SPIN_MAX) {
                     if (!dead && lane == 0) atomicOr(a.ws + 1, 4);
                     dead = true;
@@ -514,57 +559,66 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
             float o = 0.f;
 #pragma unroll
             for (int sp = 0; sp < KF_ATTN_MAX_SPLITS; sp++) o = fmaf(vsp[sp], __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sc), sp)), o);
-            if (el) pub_gran(a.ao, goff((XMAP ? S.h0 * hd : 0) + S.me0 + lane, a.gls), a.ncopy, a.cstride, tag, f2bf(o * (1.0f / Lt)));
+            if (el) st_gran(a.xch + C::ao + (XMAP ? S.h0 * hd : 0) + S.me0 + lane, tag, f2bf(o * (1.0f / Lt)));
         }
         // P4, P5 (P6 adds that x as the residual), P6
         ENG_STAMP(0, 4);
-        if (has4) eng_poll_stage<XCH, NQD, false, false>(a.ao + cbase, nullptr, tag, SH::P4.nBlk, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, a.gls, a.poll_sleep, &sw[1], nullptr, 0, a.delay[3]);
+        if (has4) eng_poll_stage<XCH, NQD, P4::nBlk, false, false>(a.xch + C::ao, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, &sw[1], nullptr, 0, a.delay[3]);
         ENG_STAMP(0, 5);
         __syncthreads();
-        if (has5 || has6) eng_poll_stage<XCH, ND, true, false>(a.xB + cbase, nullptr, tag, SH::P5.nBlk, ly.norm_post, a.eps, L.xs[0], L.xrawB, lane, a.ws, dead, a.gls, a.poll_sleep, &sw[2],
-                                                                          has4 ? L.pub + 1 : nullptr, l + 1, a.delay[4]);
+        if (has5 || has6)
+            eng_poll_stage<XCH, ND, P5::nBlk, true, false>(a.xch + C::xB, nullptr, tag, ly.norm_post, a.eps, L.xs[0], L.xrawB, lane, a.ws, dead, &sw[2], has4 ? L.pub + 1 : nullptr, l + 1,
+                                                           a.delay[4]);
         ENG_STAMP(0, 6);
         __syncthreads();
-        if (has6) eng_poll_stage<XCH, NF, false, false>(a.act + cbase, nullptr, tag, SH::P6.nBlk, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, a.gls, a.poll_sleep, &sw[3], has5 ? L.pub + 2 : nullptr, l + 1,
-                                                                 a.delay[5], (a.dbg && wg == a.dbg_wg) ? a.dbg + ((size_t)l * 2) * 16 + 9 : nullptr);
+        if (has6) eng_poll_stage<XCH, NF, P6::nBlk, false, false>(a.xch + C::act, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, &sw[3], has5 ? L.pub + 2 : nullptr, l + 1, a.delay[5]);
         ENG_STAMP(0, 7);
-        if (P1_SHARE && has1 && l + 1 < a.n_layer) mv_prefetch<NCW1, FMT, false, S1>(P1, L.lay[l + 1].m, S.s1, NWV - 1, lane, r1, a.exp_flags);
-        if (a.dbg && wg == a.dbg_wg && lane == 0) a.dbg[((size_t)l * 2) * 16 + 8] = (unsigned long long)sw[0] | ((unsigned long long)sw[1] << 16) | ((unsigned long long)sw[2] << 32) | ((unsigned long long)sw[3] << 48);
+        if (P1_SHARE) { /* unconditional (the last layer requests its own blocks again): a conditional request would turn the waits behind it into drains */
+            const int ln = l + 1 < a.n_layer ? l + 1 : l;
+            mv_prefetch<P1, NCW1, FMT, S1>(mat1(ln), mat1(ln), S.s1, NWV - 1, lane, S.M1, r1);
+        }
+        if (DBG && wg == a.dbg_wg && lane == 0)
+            a.dbg[((size_t)l * 2) * 16 + 8] = (unsigned long long)sw[0] | ((unsigned long long)sw[1] << 16) | ((unsigned long long)sw[2] << 32) | ((unsigned long long)sw[3] << 48);
         __syncthreads();
     }
 }
 
 // the compute waves
-template <int FMT, int GQ, int HD, int NWV, int DIM, int QD, int KVD, int FFN, int NWG, bool XMAP>
+template <class C>
 __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds& L, const EngSlice& S, int epoch, int wg, int wave, int lane) {
-    using SH = EngShape<FMT, DIM, QD, KVD, FFN, NWG>;
+    using SH = typename C::SH;
+    using P1 = typename SH::P1;
+    using P4 = typename SH::P4;
+    using P5 = typename SH::P5;
+    using P6 = typename SH::P6;
+    constexpr int FMT = C::FMT, GQ = C::GQ, HD = C::HD, NWV = C::NWV;
+    constexpr bool XMAP = C::XMAP, DBG = C::DBG;
     constexpr int NCW = NWV - 1;
-    constexpr CPlan P1 = SH::P1, P4 = SH::P4, P5 = SH::P5, P6 = SH::P6;
     // P1 alone is shared with the poller wave (it is idle between staging x and the first q/k/v granules): NWV waves, so that the 0.6B shape's
     // 8 row-slots per workgroup are one step for every wave instead of two for wave 0
     constexpr int NCW1 = NWV;
-    constexpr int S1 = c_maxs<NCW1>(P1), S4 = c_maxs<NCW>(P4), S5 = c_maxs<NCW>(P5), S6 = c_maxs<NCW>(P6);
+    constexpr int S1 = c_maxs<P1, NCW1>(), S4 = c_maxs<P4, NCW>(), S5 = c_maxs<P5, NCW>(), S6 = c_maxs<P6, NCW>();
     constexpr int hd = HD, hd_log2 = HD == 128 ? 7 : 6, NW = 4, PS = hd + 4;
     constexpr int LPK = hd >> 3, KPW = 64 / LPK, lpk_log2 = hd_log2 - 3;
     constexpr int NQ = (GQ + NW - 1) / NW;
     const int tid = wave * 64 + lane;
-    const float qb1[3] = {a.qbias[0], a.qbias[1], a.qbias[2]}, qb4[1] = {a.qbias[3]}, qb5[2] = {a.qbias[4], a.qbias[5]}, qb6[1] = {a.qbias[6]};
     // this workgroup's rows per phase (contiguous in the phase's output vector) and the waves that own some of them
-    constexpr int R1 = P1.spg * (64 >> P1.lpr_log2), R4 = P4.spg * (64 >> P4.lpr_log2), R5 = P5.spg * (64 >> P5.lpr_log2), R6 = P6.spg * (64 >> P6.lpr_log2);
-    static_assert(R1 % 4 == 0 && R4 % 4 == 0 && R5 % 4 == 0 && R6 % 4 == 0 && R1 <= 64 && R4 <= 64 && R5 <= 64 && R6 <= 64, "rows per workgroup");
-    static_assert(P1.total % P1.spg == 0 && P4.total % P4.spg == 0 && P5.total % P5.spg == 0 && P6.total % P6.spg == 0, "whole workgroups");
-    static_assert(P1.slot0[1] % P1.spg == 0 && P1.slot0[2] % P1.spg == 0, "a workgroup's P1 rows belong to one matrix");
-    constexpr int NWP1 = P1.spg < NCW1 ? P1.spg : NCW1, NWP4 = P4.spg < NCW ? P4.spg : NCW, NWP5 = P5.spg < NCW ? P5.spg : NCW, NWP6 = P6.spg < NCW ? P6.spg : NCW;
-    const bool has1 = XMAP ? true : wg * P1.spg < P1.total, has4 = wg * P4.spg < P4.total, has5 = wg * P5.spg < P5.total, has6 = wg * P6.spg < P6.total;
-    // the first row (inside its matrix) of this workgroup's P1 rows
-    const int j1 = S.s1 >= P1.slot0[2] ? 2 : (S.s1 >= P1.slot0[1] ? 1 : 0);
-    const int row0_1 = (S.s1 - (j1 == 0 ? 0 : (j1 == 1 ? P1.slot0[1] : P1.slot0[2]))) * (64 >> P1.lpr_log2);
+    static_assert(P1::R % 4 == 0 && P4::R % 4 == 0 && P5::R % 4 == 0 && P6::R % 4 == 0 && P1::R <= 64 && P4::R <= 64 && P5::R <= 64 && P6::R <= 64, "rows per workgroup");
+    static_assert(P1::total % P1::spg == 0 && P4::total % P4::spg == 0 && P5::total % P5::spg == 0 && P6::total % P6::spg == 0, "whole workgroups");
+    static_assert(P1::S1 % P1::spg == 0 && P1::S2 % P1::spg == 0, "a workgroup's P1 rows belong to one matrix");
+    constexpr int NWP1 = P1::spg < NCW1 ? P1::spg : NCW1, NWP4 = P4::spg < NCW ? P4::spg : NCW, NWP5 = P5::spg < NCW ? P5::spg : NCW, NWP6 = P6::spg < NCW ? P6::spg : NCW;
+    const bool has1 = XMAP ? true : wg * P1::spg < P1::total, has4 = wg * P4::spg < P4::total, has5 = wg * P5::spg < P5::total, has6 = wg * P6::spg < P6::total;
+    const float qb1 = S.j1 == 0 ? a.qbias[0] : (S.j1 == 1 ? a.qbias[1] : a.qbias[2]);
+    const int row0_1 = S.s1 * P1::RPS;
     const bool aw = wave < NW && S.has_unit; /* attention waves */
     const int pos = S.pos, nsp = S.nsp, kvh = S.kvh, h0 = S.h0, t1 = S.t1;
     const int grp = lane >> lpk_log2, d0 = (lane & (LPK - 1)) * 8;
     const int tstart = S.t0 + wave * KPW + grp, tstride = NW * KPW;
     const int nbatch = S.has_unit && !S.empty ? (S.t1 - S.t0 + ATTN_U * tstride - 1) / (ATTN_U * tstride) : 0;
     const float* tab_pos = a.rope_table + (size_t)pos * hd;
+    auto mat1 = [&](int l) {
+        return L.lay[l].m[S.j1];
+    };
 
     MvRegs<false, S1> r1;
     MvRegs<false, S4> r4;
@@ -580,7 +634,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         for (int u = 0; u < ATTN_U; u++) {
             const int t = tb + u * tstride;
             kk[u] = u32x4{0, 0, 0, 0};
-            if (t < tend) kk[u] = *reinterpret_cast<const u32x4 KF_GLOBAL*>(ly.kcache + ((size_t)((a.exp_flags & 2) ? 0 : t) * a.kv_stride + (size_t)kvh * hd + d0));
+            if (t < tend) kk[u] = *reinterpret_cast<const u32x4 KF_GLOBAL*>(ly.kcache + ((size_t)t * a.kv_stride + (size_t)kvh * hd + d0));
         }
     };
     auto issue_v = [&](const EngLayer& ly, int tb, int tend) {
@@ -588,17 +642,18 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         for (int u = 0; u < ATTN_U; u++) {
             const int t = tb + u * tstride;
             vv[u] = u32x4{0, 0, 0, 0};
-            if (t < tend) vv[u] = *reinterpret_cast<const u32x4 KF_GLOBAL*>(ly.vcache + ((size_t)((a.exp_flags & 2) ? 0 : t) * a.kv_stride + (size_t)kvh * hd + d0));
+            if (t < tend) vv[u] = *reinterpret_cast<const u32x4 KF_GLOBAL*>(ly.vcache + ((size_t)t * a.kv_stride + (size_t)kvh * hd + d0));
         }
     };
     auto issue_kv = [&](const EngLayer& ly, int tb, int tend) { issue_k(ly, tb, tend), issue_v(ly, tb, tend); };
-    mv_prefetch<NCW1, FMT, false, S1>(P1, L.lay[0].m, S.s1, wave, lane, r1, a.exp_flags);
+    mv_prefetch<P1, NCW1, FMT, S1>(mat1(0), mat1(0), S.s1, wave, lane, S.M1, r1);
     if (aw && !S.empty) issue_kv(L.lay[0], tstart, t1);
 
     for (int l = 0; l < a.n_layer; l++) {
         const EngLayer& ly = L.lay[l];
         const uint32_t gen = (uint32_t)epoch * (uint32_t)a.n_layer + (uint32_t)l, tag = gen & 0xffffu, tag_next = (gen + 1u) & 0xffffu;
         const bool last = l == a.n_layer - 1;
+        const int ln = last ? l : l + 1; /* the layer whose blocks are requested next: the last layer asks for its own again (unconditional requests keep every wait counted) */
         uint16_t qw0 = 0, qw1 = 0, kw0 = 0, kw1 = 0; /* the q/k-norm weights of this lane's pair: constants, requested early */
         if (aw && !S.empty) {
             const int half = hd >> 1, j = lane < half ? lane : half - 1;
@@ -608,15 +663,13 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         // ================= P1: RMSNorm(x) -> Q, K, V rows
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 0);
-        mv_prefetch<NCW, FMT, false, S4>(P4, ly.m + 3, wg * P4.spg, wave, lane, r4, a.exp_flags);
-        mv_run<NCW1, FMT, false, S1>(P1, qb1, S.s1, wave, lane, r1, L.xs[0], [&](int j, int row, float v, float) {
-            L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); /* a workgroup's P1 rows belong to one matrix (j == j1) */
-        });
+        mv_prefetch<P4, NCW, FMT, S4>(ly.m[3], ly.m[3], wg * P4::spg, wave, lane, P4::M0, r4);
+        mv_run<P1, NCW1, FMT, S1>(qb1, 0.f, S.s1, wave, lane, S.M1, r1, L.xs[0], [&](int row, float v, float) { L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); });
         if (has1 && wave < NWP1) {
             if (XMAP)
-                wg_publish(L, 0, a.lqkv + (size_t)S.xcc * a.lq_stride, S.q_out0, R1, NWP1, lane, 32, 1, 0, true);
+                wg_publish(L, 0, eng_lqkv<C>(a, S.xcc), S.q_out0, P1::R, NWP1, lane, true);
             else
-                wg_publish(L, 0, a.qkv, S.q_out0, R1, NWP1, lane, a.gls, a.ncopy, a.cstride);
+                wg_publish(L, 0, a.xch + C::qkv, S.q_out0, P1::R, NWP1, lane);
         }
         // ================= P2: q/k-norm + RoPE + attention over this workgroup's slice
         if (wave == 0) ENG_STAMP(1, 1);
@@ -767,17 +820,17 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
                             Ls += c[hd];
                         }
                         if (nsp == 1) {
-                            pub_gran(a.ao, goff((h0 + hq) * hd + d, a.gls), a.ncopy, a.cstride, tag, f2bf(o * (1.0f / Ls)));
+                            st_gran(a.xch + C::ao + (h0 + hq) * hd + d, tag, f2bf(o * (1.0f / Ls)));
                         } else {
                             float Mh = M[0];
 #pragma unroll
                             for (int q2 = 1; q2 < GQ; q2++) Mh = (hq == q2) ? M[q2] : Mh;
                             if (XMAP) { /* plain 8-byte stores into this XCD's partial buffer */
-                                unsigned long long* dst = a.lpart + (size_t)S.xcc * a.lp_stride + ((size_t)hq * nsp + S.split) * PS;
+                                unsigned long long* dst = eng_lpart<C>(a, S.xcc) + ((size_t)hq * nsp + S.split) * PS;
                                 dst[d] = ((unsigned long long)gen << 32) | __float_as_uint(o);
                                 if (d == 0) dst[hd] = ((unsigned long long)gen << 32) | __float_as_uint(Mh), dst[hd + 1] = ((unsigned long long)gen << 32) | __float_as_uint(Ls);
                             } else {
-                                unsigned long long* dst = a.part + ((size_t)(h0 + hq) * nsp + S.split) * PS;
+                                unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.xch + C::part) + ((size_t)(h0 + hq) * nsp + S.split) * PS;
                                 st_gran64(dst + d, gen, o);
                                 if (d == 0) st_gran64(dst + hd, gen, Mh), st_gran64(dst + hd + 1, gen, Ls);
                             }
@@ -788,73 +841,78 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
                 for (int i = tid; i < GQ * hd; i += NW * 64) {
                     const int hq = i >> hd_log2, d = i & (hd - 1);
                     if (XMAP) {
-                        unsigned long long* dst = a.lpart + (size_t)S.xcc * a.lp_stride + ((size_t)hq * nsp + S.split) * PS;
+                        unsigned long long* dst = eng_lpart<C>(a, S.xcc) + ((size_t)hq * nsp + S.split) * PS;
                         dst[d] = (unsigned long long)gen << 32;
                         if (d == 0) dst[hd] = ((unsigned long long)gen << 32) | 0xff800000u, dst[hd + 1] = (unsigned long long)gen << 32;
                     } else {
-                        unsigned long long* dst = a.part + ((size_t)(h0 + hq) * nsp + S.split) * PS;
+                        unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.xch + C::part) + ((size_t)(h0 + hq) * nsp + S.split) * PS;
                         st_gran64(dst + d, gen, 0.f);
                         if (d == 0) st_gran64(dst + hd, gen, -__builtin_inff()), st_gran64(dst + hd + 1, gen, 0.f);
                     }
                 }
             }
         }
-        // the next layer's K/V tiles of this slice (they do not depend on this token, except row `pos`, which is substituted)
+        // the next layer's K/V tiles of this slice (they do not depend on this token, except row `pos`, which is substituted); the last layer
+        // requests its own again
         if (wave == 0) ENG_STAMP(1, 3);
-        if (aw && !S.empty && !last) issue_kv(L.lay[l + 1], tstart, t1);
+        if (aw && !S.empty) issue_kv(L.lay[ln], tstart, t1);
 
         // ================= P4: o_proj + residual -> xB
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 4);
-        mv_prefetch<NCW, FMT, true, S5>(P5, ly.m + 4, wg * P5.spg, wave, lane, r5, a.exp_flags);
-        mv_run<NCW, FMT, false, S4>(P4, qb4, wg * P4.spg, wave, lane, r4, L.xs[1], [&](int, int row, float v, float) {
+        mv_prefetch<P5, NCW, FMT, S5>(ly.m[4], ly.m[5], wg * P5::spg, wave, lane, P5::M0, r5);
+        mv_run<P4, NCW, FMT, S4>(a.qbias[3], 0.f, wg * P4::spg, wave, lane, P4::M0, r4, L.xs[1], [&](int row, float v, float) {
             const uint16_t o = f2bf(v);
-            L.outb[row - wg * R4] = (tag << 16) | (uint32_t)f2bf(bf2f(L.xrawA[row]) + bf2f(o)); /* CU_add3: bf16(x + bf16(W.x)) */
+            L.outb[row - wg * P4::R] = (tag << 16) | (uint32_t)f2bf(bf2f(L.xrawA[row]) + bf2f(o)); /* CU_add3: bf16(x + bf16(W.x)) */
         });
-        if (has4 && wave < NWP4) wg_publish(L, 1, a.xB, wg * R4, R4, NWP4, lane, a.gls, a.ncopy, a.cstride);
+        if (has4 && wave < NWP4) wg_publish(L, 1, a.xch + C::xB, wg * P4::R, P4::R, NWP4, lane);
         // ================= P5: RMSNorm + gate/up + SwiGLU -> act
         if (wave == 0) ENG_STAMP(1, 5);
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 6);
-        mv_prefetch<NCW, FMT, false, S6>(P6, ly.m + 6, wg * P6.spg, wave, lane, r6, a.exp_flags);
-        mv_run<NCW, FMT, true, S5>(P5, qb5, wg * P5.spg, wave, lane, r5, L.xs[0], [&](int, int row, float v, float v2) {
+        mv_prefetch<P6, NCW, FMT, S6>(ly.m[6], ly.m[6], wg * P6::spg, wave, lane, P6::M0, r6);
+        mv_run<P5, NCW, FMT, S5>(a.qbias[4], a.qbias[5], wg * P5::spg, wave, lane, P5::M0, r5, L.xs[0], [&](int row, float v, float v2) {
             const float gt = round_bf16(v), up = round_bf16(v2); /* CU_swiglu_v0 on the two bf16-rounded projections */
-            L.outb[row - wg * R5] = (tag << 16) | (uint32_t)f2bf((gt * up) / (1.0f + kf_expf(-gt)));
+            L.outb[row - wg * P5::R] = (tag << 16) | (uint32_t)f2bf((gt * up) / (1.0f + kf_expf(-gt)));
         });
-        if (has5 && wave < NWP5) wg_publish(L, 2, a.act, wg * R5, R5, NWP5, lane, a.gls, a.ncopy, a.cstride);
+        if (has5 && wave < NWP5) wg_publish(L, 2, a.xch + C::act, wg * P5::R, P5::R, NWP5, lane);
         // ================= P6: down_proj + residual -> x of the next layer
         if (wave == 0) ENG_STAMP(1, 7);
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 8);
-        if (!last) mv_prefetch<NCW1, FMT, false, S1>(P1, L.lay[l + 1].m, S.s1, wave, lane, r1, a.exp_flags);
-        mv_run<NCW, FMT, false, S6>(P6, qb6, wg * P6.spg, wave, lane, r6, L.xs[1], [&](int, int row, float v, float) {
+        mv_prefetch<P1, NCW1, FMT, S1>(mat1(ln), mat1(ln), S.s1, wave, lane, S.M1, r1);
+        mv_run<P6, NCW, FMT, S6>(a.qbias[6], 0.f, wg * P6::spg, wave, lane, P6::M0, r6, L.xs[1], [&](int row, float v, float) {
             const uint16_t o = f2bf(v);
             const uint16_t y = f2bf(bf2f(L.xrawB[row]) + bf2f(o));
             if (last)
                 a.x_out[row] = y;
             else
-                L.outb[row - wg * R6] = (tag_next << 16) | (uint32_t)y;
+                L.outb[row - wg * P6::R] = (tag_next << 16) | (uint32_t)y;
         });
-        if (!last && has6 && wave < NWP6) wg_publish(L, 3, a.xA, wg * R6, R6, NWP6, lane, a.gls, a.ncopy, a.cstride);
+        if (!last && has6 && wave < NWP6) wg_publish(L, 3, a.xch + C::xA, wg * P6::R, P6::R, NWP6, lane);
         if (wave == 0) ENG_STAMP(1, 9);
     }
 }
 
 // DIM, QD, KVD, FFN: the model's dim, q_dim, kv_dim, ffn; NWG: the grid (= CUs): sweeps and mat-vec geometry are straight-line code
-template <int FMT, int GQ, int HD, int NWV, int DIM, int QD, int KVD, int FFN, int NWG, bool XMAP>
-__global__ void __launch_bounds__(NWV * 64) engine_kernel(const EngArgs a) {
-    constexpr int hd = HD, NW = 4;
+template <class C>
+__global__ void __launch_bounds__(C::NWV * 64) engine_kernel(const EngArgs a) {
+    constexpr int hd = C::HD, NW = 4, GQ = C::GQ, NWV = C::NWV;
+    constexpr bool XMAP = C::XMAP;
+    using P1 = typename C::SH::P1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
     // ---- LDS carve
     EngLds L;
     EngLayer* lay = reinterpret_cast<EngLayer*>(smem);
+    constexpr int maxK = C::DIM > C::QD ? (C::DIM > C::FFN ? C::DIM : C::FFN) : (C::QD > C::FFN ? C::QD : C::FFN);
+    constexpr int xs_bytes = (maxK * 2 + 15) & ~15, xr_bytes = (C::DIM * 2 + 15) & ~15;
     size_t off = ((size_t)a.n_layer * sizeof(EngLayer) + 15) & ~(size_t)15;
     L.lay = lay;
-    L.xs[0] = reinterpret_cast<u32x4*>(smem + off), off += a.lds_xs_bytes;
-    L.xs[1] = reinterpret_cast<u32x4*>(smem + off), off += a.lds_xs_bytes;
-    L.xrawA = reinterpret_cast<uint16_t*>(smem + off), off += ((size_t)a.dim * 2 + 15) & ~(size_t)15;
-    L.xrawB = reinterpret_cast<uint16_t*>(smem + off), off += ((size_t)a.dim * 2 + 15) & ~(size_t)15;
+    L.xs[0] = reinterpret_cast<u32x4*>(smem + off), off += xs_bytes;
+    L.xs[1] = reinterpret_cast<u32x4*>(smem + off), off += xs_bytes;
+    L.xrawA = reinterpret_cast<uint16_t*>(smem + off), off += xr_bytes;
+    L.xrawB = reinterpret_cast<uint16_t*>(smem + off), off += xr_bytes;
     L.qraw = reinterpret_cast<uint16_t*>(smem + off); /* [GQ][hd] raw q heads of this workgroup's slice */
     L.kraw = L.qraw + GQ * hd, L.vraw = L.kraw + hd, L.qb = L.vraw + hd, L.knew = L.qb + GQ * hd;
     L.wmax = reinterpret_cast<float*>(L.knew + hd); /* [NW][GQ] */
@@ -868,7 +926,7 @@ __global__ void __launch_bounds__(NWV * 64) engine_kernel(const EngArgs a) {
     EngSlice S;
     S.pos = a.d_state[1];
     const int epoch = a.ws[0];
-    if (a.ws[1] != 0) return; /* an earlier launch timed out (it could not become resident): do nothing until the host has looked (kf_engine_check) */
+    if (a.ws[1] != 0) return; /* an earlier launch timed out (it could not become resident): nothing runs until the host has cleared the word (engine_reset) */
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(a.layers);
         uint32_t* dst = reinterpret_cast<uint32_t*>(lay);
@@ -878,51 +936,55 @@ __global__ void __launch_bounds__(NWV * 64) engine_kernel(const EngArgs a) {
     __syncthreads();
     S.len = S.pos + 1, S.nsp = a.nsp;
     S.xcc = 0, S.rank = 0;
-    using SHK = EngShape<FMT, DIM, QD, KVD, FFN, NWG>;
-    constexpr int RPS1 = 64 >> SHK::P1.lpr_log2, R1K = SHK::P1.spg * RPS1;
+    int s1_abs; /* first P1 slot of this workgroup in the q | k | v slot order */
     if (XMAP) {
         // kv-head k lives on XCD k: its q/k/v rows, its attention slices and its merge are exchanged through that XCD's L2 only.
         // A workgroup learns its XCD from the hardware register and takes a ticket there (the tickets are zeroed again at the end).
-        static_assert(!XMAP || (GQ * HD + 2 * HD) == 32 * R1K, "an XCD's 32 workgroups share the q | k | v rows of one kv-head");
+        static_assert(!XMAP || (GQ * hd + 2 * hd) == (C::NWG / 8) * P1::R, "an XCD's workgroups share the q | k | v rows of one kv-head");
+        int* tickets = reinterpret_cast<int*>(a.loc);
         int* xi = L.cnt + 1;
         if (tid == 0) {
             const int x = eng_xcc();
-            xi[0] = x, xi[1] = __hip_atomic_fetch_add(a.tickets + x * 32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            xi[0] = x, xi[1] = __hip_atomic_fetch_add(tickets + x * 32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         S.xcc = xi[0], S.rank = xi[1];
-        if (S.rank >= 32 && tid == 0) atomicOr(a.ws + 1, 8); /* not 32 workgroups per XCD: the polls below time out and the host falls back */
-        const int r = S.rank & 31, lr0 = r * R1K; /* first of this workgroup's rows in the XCD's [q | k | v] list */
+        if (S.rank >= C::NWG / 8 && tid == 0) atomicOr(a.ws + 1, 8); /* not NWG / 8 workgroups per XCD: the polls below time out, the error word says why */
+        const int r = S.rank & (C::NWG / 8 - 1), lr0 = r * P1::R; /* first of this workgroup's rows in the XCD's [q | k | v] list */
         const int j = lr0 < GQ * hd ? 0 : (lr0 < GQ * hd + hd ? 1 : 2);
         const int row = j == 0 ? S.xcc * GQ * hd + lr0 : (j == 1 ? S.xcc * hd + (lr0 - GQ * hd) : S.xcc * hd + (lr0 - GQ * hd - hd));
-        S.s1 = (j == 0 ? 0 : (j == 1 ? SHK::P1.slot0[1] : SHK::P1.slot0[2])) + row / RPS1;
+        s1_abs = (j == 0 ? 0 : (j == 1 ? P1::S1 : P1::S2)) + row / P1::RPS;
         S.q_out0 = lr0;
         S.has_unit = r < a.nsp;
         S.kvh = S.xcc, S.split = r;
         S.me0 = r * a.merge_e;
         S.has_merge = a.nsp > 1 && S.me0 < GQ * hd;
     } else {
-        S.s1 = wg * SHK::P1.spg;
-        const int j = S.s1 >= SHK::P1.slot0[2] ? 2 : (S.s1 >= SHK::P1.slot0[1] ? 1 : 0);
-        S.q_out0 = (j == 0 ? 0 : (j == 1 ? a.q_dim : a.q_dim + a.kv_dim)) + (S.s1 - (j == 0 ? 0 : (j == 1 ? SHK::P1.slot0[1] : SHK::P1.slot0[2]))) * RPS1;
-        S.has_unit = wg < a.n_kv * a.nsp;
+        s1_abs = wg * P1::spg;
+        const int j = s1_abs >= P1::S2 ? 2 : (s1_abs >= P1::S1 ? 1 : 0);
+        S.q_out0 = (j == 0 ? 0 : (j == 1 ? C::QD : C::QD + C::KVD)) + (s1_abs - (j == 0 ? 0 : (j == 1 ? P1::S1 : P1::S2))) * P1::RPS;
+        S.has_unit = wg < C::n_kv * a.nsp;
         S.kvh = S.has_unit ? wg / a.nsp : 0, S.split = S.has_unit ? wg - S.kvh * a.nsp : 0;
         S.me0 = wg * a.merge_e;
-        S.has_merge = a.nsp > 1 && S.me0 < a.n_head * hd;
+        S.has_merge = a.nsp > 1 && S.me0 < C::n_head * hd;
     }
+    S.j1 = s1_abs >= P1::S2 ? 2 : (s1_abs >= P1::S1 ? 1 : 0);
+    S.s1 = s1_abs - (S.j1 == 0 ? 0 : (S.j1 == 1 ? P1::S1 : P1::S2));
+    S.M1 = S.j1 == 0 ? P1::M0 : (S.j1 == 1 ? P1::M1 : P1::M2);
+    if (s1_abs >= P1::total) S.M1 = 0; /* a workgroup without P1 rows (shapes with fewer slots than workgroups): every step masked */
     S.h0 = S.kvh * GQ, S.t0 = S.split * a.chunk;
     S.t1 = S.t0 + a.chunk < S.len ? S.t0 + a.chunk : S.len;
     S.empty = S.t0 >= S.len;
     S.own_new = S.has_unit && S.pos >= S.t0 && S.pos < S.t1;
     if (wave == NWV - 1)
-        eng_poller_main<FMT, GQ, HD, NWV, DIM, QD, KVD, FFN, NWG, XMAP>(a, L, S, epoch, wg, lane);
+        eng_poller_main<C>(a, L, S, epoch, wg, lane);
     else
-        eng_compute_main<FMT, GQ, HD, NWV, DIM, QD, KVD, FFN, NWG, XMAP>(a, L, S, epoch, wg, wave, lane);
+        eng_compute_main<C>(a, L, S, epoch, wg, wave, lane);
     // the next launch's generation (workgroup 0 owns rows of the last phase, so every workgroup has read the epoch long before)
     if (wg == 0 && tid == 0) {
         a.ws[0] = epoch + 1;
         if (XMAP)
-            for (int i = 0; i < 8; i++) a.tickets[i * 32] = 0; /* every workgroup took its ticket before any could finish a layer */
+            for (int i = 0; i < 8; i++) reinterpret_cast<int*>(a.loc)[i * 32] = 0; /* every workgroup took its ticket before any could finish a layer */
     }
 }
 
@@ -931,9 +993,13 @@ struct EngineHost {
     EngArgs args;
     EngPlan plans[4];
     int fmt, GQ, hd, nwv, shape_class, xmap;
+    int dim, q_dim, kv_dim, ffn, n_kv, n_head;
     size_t smem;
     int n_cu;
-    void* xmem; /* the hand-off vectors every CU sweeps: device memory that is cached nowhere (hipDeviceMallocUncached), owned by the engine */
+    void* xmem;     /* the hand-off vectors every CU sweeps: device memory that is cached nowhere (hipDeviceMallocUncached), owned by the engine */
+    size_t xbytes;
+    void* ws;
+    size_t ws_bytes;
 };
 
 // the instantiated model shapes: {GQA group, head_dim, dim, q_dim, ffn}
@@ -984,14 +1050,34 @@ static bool eng_plan(EngPlan& P, int fmt, int K, int njobs, const kf_weight* con
     return true;
 }
 
+// caller's workspace (cached device memory): [ws words 256 B] [EngLayer table] [XCD-local area: tickets | lqkv | lpart] [room for the exchange vectors, used
+// only when the uncached allocation is refused]
 size_t engine_ws_bytes(const kf_engine_desc* d) {
-    // [ws: 64 B] [EngLayer table] [xA dim][qkv q+2kv][ao q][xB dim][act ffn] granules (4 B) [part: n_head*32*(hd+4) 8-byte granules] [EngineHost]
-    const size_t q_dim = (size_t)d->n_head * d->head_dim, kv_dim = (size_t)d->n_kv * d->head_dim;
-    size_t b = 256 + 512 + (((size_t)d->n_layer * sizeof(EngLayer) + 255) & ~(size_t)255);
-    b += 8 * ((size_t)ENG_GLS_MAX * 4 * (((size_t)d->dim * 2 + q_dim * 2 + 2 * kv_dim + d->ffn) / 32 + 8) + 2048);
-    b += 8 * (size_t)d->n_head * KF_ATTN_MAX_SPLITS * (d->head_dim + 4) + 256;
-    b += 1024 + 8 * (4 * (size_t)(q_dim / d->n_kv + 2 * d->head_dim) + 256) + 8 * (8 * (size_t)(d->n_head / d->n_kv) * KF_ATTN_MAX_SPLITS * (d->head_dim + 4) + 256); /* XCD-mapped form */
+    const int q_dim = d->n_head * d->head_dim, kv_dim = d->n_kv * d->head_dim, GQ = d->n_kv > 0 ? d->n_head / d->n_kv : 1;
+    size_t b = 256 + (((size_t)d->n_layer * sizeof(EngLayer) + 255) & ~(size_t)255);
+    b += (eng_loc_bytes(GQ, d->head_dim) + 255) & ~(size_t)255;
+    b += (size_t)eng_xoff(d->dim, q_dim, kv_dim, d->ffn, d->head_dim).end * 4 + 256;
     return b;
+}
+
+static void engine_release(EngineHost* E) {
+    if (!E) return;
+    if (E->args.dbg) (void)hipFree(E->args.dbg);
+    if (E->xmem) (void)hipFree(E->xmem);
+    delete E;
+}
+
+// the state every launch starts from: all granules "not written" (tags of generation 0xffff.., which no epoch below 2^16 / n_layer reaches soon), epoch 1, no
+// error, tickets zero
+static int engine_init_state(EngineHost* E, hipStream_t st) {
+    EngArgs& a = E->args;
+    if (E->xmem && hipMemsetAsync(E->xmem, 0xff, E->xbytes, st) != hipSuccess) return KF_HIP_CHECK;
+    char* const loc0 = a.loc;
+    char* const end = reinterpret_cast<char*>(E->ws) + E->ws_bytes;
+    if (hipMemsetAsync(loc0, 0xff, (size_t)(end - loc0), st) != hipSuccess) return KF_HIP_CHECK;
+    const int init[2] = {1, 0};
+    if (hipMemsetAsync(a.loc, 0, 1024, st) != hipSuccess || hipMemcpyAsync(a.ws, init, sizeof(init), hipMemcpyHostToDevice, st) != hipSuccess) return KF_HIP_CHECK;
+    return KF_OK;
 }
 
 int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t st, EngineHost** out) {
@@ -1004,18 +1090,16 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     if (!shape_class) return KF_UNSUPPORTED_DATATYPE; /* not one of the instantiated model shapes: the per-layer launches remain */
     int dev = 0, n_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1) return KF_HIP_CHECK;
+    if (n_cu < ENG_NWG) return KF_UNSUPPORTED_DATATYPE; /* one resident workgroup per CU is the engine's premise */
+    n_cu = ENG_NWG;
     EngineHost* E = new EngineHost();
     memset(E, 0, sizeof(*E));
     EngArgs& a = E->args;
-    if (n_cu < ENG_NWG) {
-        delete E;
-        return KF_UNSUPPORTED_DATATYPE; /* one resident workgroup per CU is the engine's premise */
-    }
-    n_cu = ENG_NWG;
-    a.n_layer = d->n_layer, a.n_wg = n_cu;
-    a.dim = d->dim, a.n_head = d->n_head, a.n_kv = d->n_kv, a.hd = hd, a.q_dim = d->n_head * hd, a.kv_dim = d->n_kv * hd, a.ffn = d->ffn, a.kv_stride = d->kv_stride;
+    a.n_layer = d->n_layer;
+    E->dim = d->dim, E->n_head = d->n_head, E->n_kv = d->n_kv, E->q_dim = d->n_head * hd, E->kv_dim = d->n_kv * hd, E->ffn = d->ffn;
+    a.kv_stride = d->kv_stride;
     a.eps = d->rms_eps, a.qk_eps = d->qk_eps, a.rope_table = d->rope_table;
-    if (!a.rope_table || (a.kv_stride % 8) != 0 || a.dim % 4 || a.q_dim % 4 || a.ffn % 4) {
+    if (!a.rope_table || (a.kv_stride % 8) != 0) {
         delete E;
         return KF_INVALID_ARGS;
     }
@@ -1036,9 +1120,9 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
         const kf_weight* k6[1] = {&L.w[6]};
         EngPlan p1, p4, p5, p6;
         EngPlan* const pl = E->plans;
-        bool ok = eng_plan(p1, fmt, a.dim, 3, k1, false, n_cu, q4p_ok) && eng_plan(p4, fmt, a.q_dim, 1, k4, false, n_cu, q4p_ok) &&
-                  eng_plan(p5, fmt, a.dim, 2, k5, true, n_cu, q4p_ok) && eng_plan(p6, fmt, a.ffn, 1, k6, false, n_cu, q4p_ok);
-        ok = ok && L.w[0].ne0 == a.q_dim && L.w[1].ne0 == a.kv_dim && L.w[2].ne0 == a.kv_dim && L.w[3].ne0 == a.dim && L.w[4].ne0 == a.ffn && L.w[6].ne0 == a.dim;
+        bool ok = eng_plan(p1, fmt, E->dim, 3, k1, false, n_cu, q4p_ok) && eng_plan(p4, fmt, E->q_dim, 1, k4, false, n_cu, q4p_ok) &&
+                  eng_plan(p5, fmt, E->dim, 2, k5, true, n_cu, q4p_ok) && eng_plan(p6, fmt, E->ffn, 1, k6, false, n_cu, q4p_ok);
+        ok = ok && L.w[0].ne0 == E->q_dim && L.w[1].ne0 == E->kv_dim && L.w[2].ne0 == E->kv_dim && L.w[3].ne0 == E->dim && L.w[4].ne0 == E->ffn && L.w[6].ne0 == E->dim;
         ok = ok && L.norm_in && L.norm_post && L.kcache && L.vcache && (((uintptr_t)L.kcache | (uintptr_t)L.vcache) & 15) == 0;
         if (l == 0) pl[0] = p1, pl[1] = p4, pl[2] = p5, pl[3] = p6;
         if (ok && l > 0) ok = !memcmp(&p1, &pl[0], sizeof(p1)) && !memcmp(&p4, &pl[1], sizeof(p4)) && !memcmp(&p5, &pl[2], sizeof(p5)) && !memcmp(&p6, &pl[3], sizeof(p6));
@@ -1067,18 +1151,19 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
         tab[l].norm_q = (g_u16)(uintptr_t)L.q_norm, tab[l].norm_k = (g_u16)(uintptr_t)L.k_norm;
         tab[l].kcache = (g_u16w)(uintptr_t)L.kcache, tab[l].vcache = (g_u16w)(uintptr_t)L.vcache;
     }
-    if (fmt == FMT_Q4 && q4p_ok && !(getenv("KF_Q4_PERM") && atoi(getenv("KF_Q4_PERM")) == 0)) fmt = FMT_Q4P;
-    E->fmt = fmt, E->GQ = GQ, E->hd = hd, E->n_cu = n_cu, E->nwv = 8, E->shape_class = shape_class;
-    E->xmap = (shape_class == 1 && d->n_kv == 8) ? 1 : 0;
-    for (int i = 0; i < 4; i++) a.spg[i] = E->plans[i].spg, a.nslots[i] = E->plans[i].total_slots, a.nblk[i] = E->plans[i].nBlk;
+    if (fmt == FMT_Q4 && q4p_ok) fmt = FMT_Q4P;
+    E->fmt = fmt, E->GQ = GQ, E->hd = hd, E->n_cu = n_cu, E->nwv = ENG_NWV, E->shape_class = shape_class;
+    E->xmap = shape_class == 1 ? 1 : 0; /* 8 kv-heads on 8 XCDs */
     // workspace carve
     char* p = reinterpret_cast<char*>(ws);
+    E->ws = ws, E->ws_bytes = ws_bytes;
     a.ws = reinterpret_cast<int*>(p), p += 256;
-    a.plans = reinterpret_cast<const EngPlan*>(p), p += 512;
     a.layers = reinterpret_cast<const EngLayer*>(p), p += ((size_t)d->n_layer * sizeof(EngLayer) + 255) & ~(size_t)255;
-    a.gls = 32, a.poll_sleep = 1; /* granule line stride / sleep between sweeps: the sweeps over other values changed nothing */
+    a.loc = p, p += (eng_loc_bytes(GQ, hd) + 255) & ~(size_t)255;
     {
-        const int dflt[6] = {12, 4, 8, 10, 12, 12}; /* x, q|k|v, slice partials, ao, xB, act: s_sleep units (~30 ns each) behind the own publish */
+        /* s_sleep units (one trip of the wait loop ~ 40 ns) behind the own publish: x, q|k|v, slice partials, ao, xB, act.  Tuned on the 0.6B shape at 2 k keys
+           (scratch/eng_ab.py): 0 everywhere 0.607 ms/step, 12,4,8,10,12,12 0.593, 20,12,16,20,20,20 0.558, 32,12,20,28,32,32 0.567 */
+        const int dflt[6] = {20, 12, 16, 20, 20, 20};
         for (int i = 0; i < 6; i++) a.delay[i] = dflt[i];
         if (const char* e = getenv("KF_ENG_DELAY")) { /* tuning runs */
             int i = 0;
@@ -1091,84 +1176,39 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     }
     // The vectors that cross XCDs live in uncached device memory: an sc1 sweep of a cached (hipMalloc) line costs 75 ns per KB and CU, of an uncached one 43
     // (scratch/ub_handoff3.hip).  The XCD-local vectors (lqkv, lpart) stay in the caller's cached workspace: they are meant to live in that XCD's L2.
-    const size_t part_bytes = (8 * (size_t)a.n_head * KF_ATTN_MAX_SPLITS * (hd + 4) + 255) & ~(size_t)255;
-    size_t xbytes = 0;
-    for (size_t n : {(size_t)a.dim, (size_t)a.q_dim + 2 * a.kv_dim, (size_t)a.q_dim, (size_t)a.dim, (size_t)a.ffn}) xbytes += (((n + 31) / 32) * (size_t)a.gls * 4 + 255) & ~(size_t)255;
-    xbytes += part_bytes;
+    E->xbytes = (size_t)eng_xoff(E->dim, E->q_dim, E->kv_dim, E->ffn, hd).end * 4;
     E->xmem = nullptr;
-    if (!(getenv("KF_ENG_UNCACHED") && atoi(getenv("KF_ENG_UNCACHED")) == 0)) {
-        if (hipExtMallocWithFlags(&E->xmem, xbytes, hipDeviceMallocUncached) != hipSuccess) {
-            (void)hipGetLastError();
-            E->xmem = nullptr; /* the cached workspace serves (slower sweeps, same protocol) */
-        }
+    if (hipExtMallocWithFlags(&E->xmem, E->xbytes, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        E->xmem = nullptr; /* the cached workspace serves (slower sweeps, same protocol) */
     }
-    char* const p_ws = p;
-    if (E->xmem) p = reinterpret_cast<char*>(E->xmem);
-    auto gran = [&](size_t n) {
-        uint32_t* r = reinterpret_cast<uint32_t*>(p);
-        p += (((n + 31) / 32) * (size_t)a.gls * 4 + 255) & ~(size_t)255;
-        return r;
-    };
-    a.ncopy = 1; /* replicated copies of the vectors (one per XCD) did not shorten a hand-off */
-    char* const g0 = p;
-    a.xA = gran(a.dim), a.qkv = gran((size_t)a.q_dim + 2 * a.kv_dim), a.ao = gran(a.q_dim), a.xB = gran(a.dim), a.act = gran(a.ffn);
-    a.cstride = (int)((p - g0) / 4);
-    p = g0 + (size_t)a.ncopy * a.cstride * 4;
-    a.part = reinterpret_cast<unsigned long long*>(p);
-    p += part_bytes;
-    if (E->xmem) {
-        if (hipMemsetAsync(E->xmem, 0xff, xbytes, st) != hipSuccess) {
-            (void)hipFree(E->xmem);
-            delete E;
-            return KF_HIP_CHECK;
-        }
-        p = p_ws;
-    }
-    a.tickets = reinterpret_cast<int*>(p), p += 1024;
-    a.lq_stride = (int)(((size_t)(GQ * hd + 2 * hd) * 4 + 255) / 256 * 64);
-    a.lqkv = reinterpret_cast<uint32_t*>(p), p += (size_t)8 * a.lq_stride * 4;
-    a.lp_stride = (int)(((size_t)GQ * KF_ATTN_MAX_SPLITS * (hd + 4) * 8 + 255) / 256 * 32);
-    a.lpart = reinterpret_cast<unsigned long long*>(p), p += (size_t)8 * a.lp_stride * 8;
-    if (hipMemsetAsync(ws, 0xff, ws_bytes, st) != hipSuccess) {
-        if (E->xmem) (void)hipFree(E->xmem);
-        delete E;
+    a.xch = reinterpret_cast<uint32_t*>(E->xmem ? E->xmem : (void*)p);
+    if (engine_init_state(E, st) != KF_OK ||
+        hipMemcpyAsync(const_cast<EngLayer*>(a.layers), tab.data(), tab.size() * sizeof(EngLayer), hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        engine_release(E);
         return KF_HIP_CHECK;
     }
-    const int init[2] = {1, 0}; /* epoch 1, no error */
-    if (hipMemsetAsync(a.tickets, 0, 1024, st) != hipSuccess || hipMemcpyAsync(a.ws, init, sizeof(init), hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipMemcpyAsync(const_cast<EngPlan*>(a.plans), E->plans, sizeof(E->plans), hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipMemcpyAsync(const_cast<EngLayer*>(a.layers), tab.data(), tab.size() * sizeof(EngLayer), hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess) {
-        if (E->xmem) (void)hipFree(E->xmem);
-        delete E;
-        return KF_HIP_CHECK;
-    }
-    if (const char* e = getenv("KF_ENG_DEBUG")) { /* diagnostic runs: per-phase wall-clock stamps of one workgroup */
+    if (const char* e = getenv("KF_ENG_DEBUG")) { /* diagnostic runs: per-phase wall-clock stamps of one workgroup (the DBG instantiation of the kernel) */
         if (hipMalloc(&a.dbg, (size_t)d->n_layer * 2 * 16 * 8) != hipSuccess) a.dbg = nullptr;
         if (a.dbg) (void)hipMemset(a.dbg, 0, (size_t)d->n_layer * 2 * 16 * 8);
         a.dbg_wg = atoi(e);
     }
     // LDS
-    int maxK = a.dim > a.q_dim ? a.dim : a.q_dim;
-    if (a.ffn > maxK) maxK = a.ffn;
-    a.lds_xs_bytes = (maxK * 2 + 15) & ~15;
-    size_t smem = (((size_t)d->n_layer * sizeof(EngLayer) + 15) & ~(size_t)15) + 2 * (size_t)a.lds_xs_bytes + 2 * (((size_t)a.dim * 2 + 15) & ~(size_t)15);
+    int maxK = E->dim > E->q_dim ? E->dim : E->q_dim;
+    if (E->ffn > maxK) maxK = E->ffn;
+    const size_t xs_bytes = ((size_t)maxK * 2 + 15) & ~(size_t)15;
+    size_t smem = (((size_t)d->n_layer * sizeof(EngLayer) + 15) & ~(size_t)15) + 2 * xs_bytes + 2 * (((size_t)E->dim * 2 + 15) & ~(size_t)15);
     smem += sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + sizeof(float) * (4 * GQ + 4 + (size_t)4 * GQ * (hd + 4)) + 4 * 64 + 32;
     smem = (smem + 15) & ~(size_t)15;
     if (smem > 160 * 1024) {
-        if (E->xmem) (void)hipFree(E->xmem);
-        delete E;
+        engine_release(E);
         return KF_UNSUPPORTED_DATATYPE;
     }
     E->smem = smem;
     *out = E;
     return KF_OK;
 }
-void engine_free(EngineHost* E) {
-    if (E && E->args.dbg) (void)hipFree(E->args.dbg);
-    if (E && E->xmem) (void)hipFree(E->xmem);
-    delete E;
-}
+void engine_free(EngineHost* E) { engine_release(E); }
 int engine_debug_read(EngineHost* E, unsigned long long* h_out, int n_words) {
     if (!E->args.dbg) return 0;
     const int have = E->args.n_layer * 2 * 16;
@@ -1177,10 +1217,10 @@ int engine_debug_read(EngineHost* E, unsigned long long* h_out, int n_words) {
     return n;
 }
 
-template <int FMT, int GQ, int HD, int DIM, int QD, int KVD, int FFN>
+template <class C>
 static bool engine_plans_match(const EngineHost* E) {
-    using SH = EngShape<FMT, DIM, QD, KVD, FFN, ENG_NWG>;
-    const CPlan c[4] = {SH::P1, SH::P4, SH::P5, SH::P6};
+    using SH = typename C::SH;
+    const CPlan c[4] = {SH::P1::plan(), SH::P4::plan(), SH::P5::plan(), SH::P6::plan()};
     for (int i = 0; i < 4; i++) {
         const EngPlan& r = E->plans[i];
         if (r.K != c[i].K || r.nBlk != c[i].nBlk || r.lpr_log2 != c[i].lpr_log2 || r.iters != c[i].iters || r.total_slots != c[i].total || r.spg != c[i].spg ||
@@ -1191,27 +1231,28 @@ static bool engine_plans_match(const EngineHost* E) {
     }
     return true;
 }
-template <int FMT, int GQ, int HD, int DIM, int QD, int KVD, int FFN, bool XMAP>
+template <class C>
 static int engine_go(EngineHost* E, hipStream_t st) {
     static int ready = 0; /* 1 ok, -1 the compile-time geometry is not the mat-vec launcher's */
     if (!ready) {
-        if (!engine_plans_match<FMT, GQ, HD, DIM, QD, KVD, FFN>(E)) ready = -1;
-        else if (hipFuncSetAttribute((const void*)engine_kernel<FMT, GQ, HD, ENG_NWV, DIM, QD, KVD, FFN, ENG_NWG, XMAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-                 hipSuccess)
+        if (!engine_plans_match<C>(E))
+            ready = -1;
+        else if (hipFuncSetAttribute((const void*)engine_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return KF_HIP_CHECK;
         else
             ready = 1;
     }
     if (ready < 0) return 1;
-    hipLaunchKernelGGL((engine_kernel<FMT, GQ, HD, ENG_NWV, DIM, QD, KVD, FFN, ENG_NWG, XMAP>), dim3(ENG_NWG), dim3(ENG_NWV * 64), E->smem, st, E->args);
+    hipLaunchKernelGGL((engine_kernel<C>), dim3(C::NWG), dim3(C::NWV * 64), E->smem, st, E->args);
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 template <int FMT>
 static int engine_go_fmt(EngineHost* E, hipStream_t st) {
     switch (E->shape_class) {
-        case 1: /* 8 kv-heads on 8 XCDs: the attention chain of a kv-head stays inside one XCD (KF_ENG_XMAP=0: the placement-blind form) */
-            return E->xmap ? engine_go<FMT, 2, 128, 1024, 2048, 1024, 3072, true>(E, st) : engine_go<FMT, 2, 128, 1024, 2048, 1024, 3072, false>(E, st);
-        case 2: return engine_go<FMT, 2, 64, 256, 256, 128, 512, false>(E, st);
+        case 1: /* 8 kv-heads on 8 XCDs: the attention chain of a kv-head stays inside one XCD */
+            if (E->args.dbg && FMT == FMT_Q4P) return engine_go<EngCfg<FMT_Q4P, 2, 128, ENG_NWV, 1024, 2048, 1024, 3072, ENG_NWG, true, true>>(E, st);
+            return engine_go<EngCfg<FMT, 2, 128, ENG_NWV, 1024, 2048, 1024, 3072, ENG_NWG, true, false>>(E, st);
+        case 2: return engine_go<EngCfg<FMT, 2, 64, ENG_NWV, 256, 256, 128, 512, ENG_NWG, false, false>>(E, st);
         default: return 1;
     }
 }
@@ -1220,14 +1261,14 @@ static int engine_go_fmt(EngineHost* E, hipStream_t st) {
 int engine_step(EngineHost* E, hipStream_t st, const uint16_t* x_in, uint16_t* x_out, const int32_t* d_state, int pos_bound) {
     EngArgs& a = E->args;
     if ((!x_in && !a.emb) || !x_out || !d_state || pos_bound < 0) return KF_INVALID_ARGS;
-    const int nsp = attn_splits(pos_bound, a.n_kv);
+    const int nsp = attn_splits(pos_bound, E->n_kv);
     const int chunk = (pos_bound + 1 + nsp - 1) / nsp;
     const int NW = (E->GQ <= 2 && chunk > 128) ? 8 : 4;
-    if (NW != 4 || a.n_kv * nsp > a.n_wg) return 1; /* the 8-wave slice form and more slices than workgroups are not restated here */
+    if (NW != 4 || E->n_kv * nsp > E->n_cu) return 1; /* the 8-wave slice form and more slices than workgroups are not restated here */
     a.nsp = nsp, a.chunk = chunk;
-    int e = (a.n_head * a.hd + a.n_wg - 1) / a.n_wg, me = 1;
+    int e = (E->n_head * E->hd + E->n_cu - 1) / E->n_cu, me = 1;
     while (me < e) me <<= 1;
-    if (me > a.hd || me > 64) return 1;
+    if (me > E->hd || me > 64) return 1;
     a.merge_e = me;
     a.x_in = x_in, a.x_out = x_out, a.d_state = d_state;
     switch (E->fmt) {
@@ -1242,7 +1283,7 @@ int engine_set_embedding(EngineHost* E, const kf_weight* w, const int32_t* d_for
         E->args.emb = nullptr, E->args.d_forced = nullptr, E->args.emb_rows = 0;
         return KF_OK;
     }
-    if (w->type != KF_BF16 || w->quant != KF_QUANT_GROUP || w->qzeros || w->ne1 != E->args.dim || !w->data) return KF_UNSUPPORTED_DATATYPE;
+    if (w->type != KF_BF16 || w->quant != KF_QUANT_GROUP || w->qzeros || w->ne1 != E->dim || !w->data) return KF_UNSUPPORTED_DATATYPE;
     E->args.emb = reinterpret_cast<const uint16_t*>(w->data), E->args.d_forced = d_forced, E->args.emb_rows = w->ne0;
     return KF_OK;
 }
@@ -1251,6 +1292,12 @@ int engine_error_word(EngineHost* E, hipStream_t st, int* h_err) {
     if (hipMemcpyAsync(v, E->args.ws, sizeof(v), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return KF_HIP_CHECK;
     *h_err = v[1];
     return KF_OK;
+}
+// after a timed-out poll (the error word latches and every later launch returns at once): all granules back to "not written", epoch 1, error word cleared
+int engine_reset(EngineHost* E, hipStream_t st) {
+    const int rc = engine_init_state(E, st);
+    if (rc != KF_OK) return rc;
+    return hipStreamSynchronize(st) == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 
 }  // namespace kf

@@ -129,6 +129,7 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
 int engine_step(EngineHost* E, hipStream_t st, const uint16_t* x_in, uint16_t* x_out, const int32_t* d_state, int pos_bound); /* 1: not served */
 int engine_set_embedding(EngineHost* E, const kf_weight* w, const int32_t* d_forced);
 int engine_error_word(EngineHost* E, hipStream_t st, int* h_err);
+int engine_reset(EngineHost* E, hipStream_t st); /* after a timed-out poll: exchange state re-initialised, error word cleared */
 void engine_free(EngineHost* E);
 int engine_debug_read(EngineHost* E, unsigned long long* h_out, int n_words); /* KF_ENG_DEBUG runs */
 
