@@ -403,7 +403,17 @@ int kf_engine_step(kf_ctx* ctx, kf_engine* e, const kf_bf16* x_in, kf_bf16* x_ou
 /* TokenEmbed::cuInfer inside the launch: with a bf16 embedding table set, kf_engine_step may be given x_in == NULL and reads the row of the state's token
  * (or of d_forced[pos] when that is >= 0, as kf_embed_state does) itself.  NULL table: back to x_in.  KF_UNSUPPORTED_DATATYPE for other storages. */
 int kf_engine_set_embedding(kf_ctx* ctx, kf_engine* e, const kf_weight* embed_bf16_or_null, const int32_t* d_forced_or_null);
-int kf_engine_check(kf_ctx* ctx, kf_engine* e); /* synchronises; KF_INTERNAL_ERR when a hand-off poll has timed out since creation */
+/* Head4Token::cuInfer_1 (NeuronFuse.cu:842-862) + sample_argmax (GoPT.cpp:602-612) as trailing phases of the same launch: with a bf16 head [vocab, dim] and
+ * the final RMSNorm weight set, kf_engine_step_head runs the layers, the final norm, the LM-head mat-vec (logits [vocab] bf16, every bit equal to
+ * kf_norm_lm_head's) and -- pick != 0 -- the greedy first-maximum pick with the decode-state update of kf_norm_lm_head (d_tokens_out[pos] = id,
+ * d_state = {id, pos + 1}): one launch per token instead of three.  A launch whose error word is set never advances the state.  NULL head: removed.
+ * KF_UNSUPPORTED_DATATYPE for other head storages (the caller keeps kf_norm_lm_head). */
+int kf_engine_set_head(kf_ctx* ctx, kf_engine* e, const kf_weight* head_bf16_or_null, const kf_bf16* final_norm_w, kf_bf16* logits, int32_t* d_tokens_out_or_null);
+int kf_engine_step_head(kf_ctx* ctx, kf_engine* e, const kf_bf16* x_in, kf_bf16* x_out, int32_t* d_state, int pos_bound, int pick);
+int kf_engine_check(kf_ctx* ctx, kf_engine* e); /* synchronises; KF_INTERNAL_ERR when a hand-off poll has timed out since creation or the last kf_engine_reset */
+/* After KF_INTERNAL_ERR from kf_engine_check: the error word latches and every later launch of the engine returns at once without output.  kf_engine_reset
+ * synchronises, puts the hand-off state back to its initial one and clears the word; the steps since the failure have to be redone. */
+int kf_engine_reset(kf_ctx* ctx, kf_engine* e);
 int kf_engine_destroy(kf_engine* e);
 
 #ifdef __cplusplus

@@ -1108,6 +1108,30 @@ int kf_engine_step(kf_ctx* c, kf_engine* e, const kf_bf16* x_in, kf_bf16* x_out,
     if (rc < 0) return fail(rc, "kf_engine_step failed with %d", rc);
     return rc;
 }
+int kf_engine_step_head(kf_ctx* c, kf_engine* e, const kf_bf16* x_in, kf_bf16* x_out, int32_t* d_state, int pos_bound, int pick) {
+    CHKCTX(c);
+    if (!e || !e->h) return fail(KF_INVALID_ARGS, "kf_engine_step_head: null engine");
+    const int rc = kf::engine_step(e->h, c->stream, x_in, x_out, d_state, pos_bound, pick ? 2 : 1);
+    if (rc < 0) return fail(rc, "kf_engine_step_head failed with %d (no head set?)", rc);
+    return rc;
+}
+int kf_engine_set_head(kf_ctx* c, kf_engine* e, const kf_weight* head_or_null, const kf_bf16* final_norm_w, kf_bf16* logits, int32_t* d_tokens_out) {
+    CHKCTX(c);
+    if (!e || !e->h) return fail(KF_INVALID_ARGS, "kf_engine_set_head: null engine");
+    if (c->capturing) return fail(KF_INVALID_ARGS, "kf_engine_set_head: not while capturing");
+    const int rc = kf::engine_set_head(e->h, head_or_null, final_norm_w, logits, d_tokens_out);
+    if (rc != KF_OK) return fail(rc, "kf_engine_set_head: the in-launch head takes a bf16 [vocab, dim] matrix of the engine's width, a norm weight and a logits buffer");
+    return KF_OK;
+}
+int kf_engine_reset(kf_ctx* c, kf_engine* e) {
+    CHKCTX(c);
+    if (!e || !e->h) return fail(KF_INVALID_ARGS, "kf_engine_reset: null engine");
+    if (c->capturing) return fail(KF_INVALID_ARGS, "kf_engine_reset: not while capturing");
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(KF_HIP_CHECK, "kf_engine_reset: HIP failure");
+    const int rc = kf::engine_reset(e->h, c->stream);
+    if (rc != KF_OK) return fail(rc, "kf_engine_reset: HIP failure");
+    return KF_OK;
+}
 int kf_engine_set_embedding(kf_ctx* c, kf_engine* e, const kf_weight* embed_or_null, const int32_t* d_forced) {
     CHKCTX(c);
     if (!e || !e->h) return fail(KF_INVALID_ARGS, "kf_engine_set_embedding: null engine");

@@ -71,13 +71,14 @@ struct EngPlan { /* host copy of one mat-vec phase: the geometry gemv_launch wou
 // ---- the exchange area (uncached memory): granule vectors at compile-time offsets (dwords), 256-byte aligned
 constexpr int eng_gran_dw(int n) { return ((n * 4 + 255) & ~255) / 4; }
 struct EngXOff {
-    int xA, qkv, ao, xB, act, part, end; /* part: 8-byte granules [n_head][KF_ATTN_MAX_SPLITS][hd + 4] */
+    int xA, qkv, ao, xB, act, part, hbest, end; /* part: 8-byte granules [n_head][KF_ATTN_MAX_SPLITS][hd + 4]; hbest: 8-byte granules [ENG_NWG]: the head's per-workgroup maxima */
 };
 constexpr EngXOff eng_xoff(int dim, int qd, int kvd, int ffn, int hd) {
     EngXOff o{};
     o.xA = 0, o.qkv = o.xA + eng_gran_dw(dim), o.ao = o.qkv + eng_gran_dw(qd + 2 * kvd), o.xB = o.ao + eng_gran_dw(qd), o.act = o.xB + eng_gran_dw(dim);
     o.part = o.act + eng_gran_dw(ffn);
-    o.end = o.part + eng_gran_dw(2 * (qd / hd) * KF_ATTN_MAX_SPLITS * (hd + 4));
+    o.hbest = o.part + eng_gran_dw(2 * (qd / hd) * KF_ATTN_MAX_SPLITS * (hd + 4));
+    o.end = o.hbest + eng_gran_dw(2 * ENG_NWG);
     return o;
 }
 // ---- the XCD-local area (cached memory, plain stores: the lines stay in that XCD's L2): [tickets 1 KiB] [lqkv 8 x lq dwords] [lpart 8 x lp qwords]
@@ -104,6 +105,13 @@ struct EngArgs {
     float qbias[7];         /* qBias of q k v o gate up down */
     int delay[6];           /* s_sleep units between "this workgroup's own rows of the feeding phase are published" and the first sweep of: x (P1), q|k|v (P2), slice
                                partials (P3), ao (P4), xB (P5), act (P6) */
+    // the LM head + greedy pick as trailing phases (engine_set_head; head_w == NULL: the launch ends with x_out)
+    g_u32x4 head_w;          /* bf16 [vocab, dim] */
+    g_u16 head_norm;         /* final RMSNorm weight */
+    uint16_t* logits;        /* bf16 [vocab] */
+    int32_t* d_state_w;      /* {token, pos}: advanced by the pick (NULL: logits only) */
+    int32_t* d_tokens_out;
+    int vocab, head_on;
     unsigned long long* dbg; /* diagnostic instantiation only (KF_ENG_DEBUG): [layer][role][16] wall-clock stamps of workgroup dbg_wg */
     int dbg_wg;
 };
@@ -409,7 +417,10 @@ struct EngCfg {
     static constexpr int n_head = QD_ / HD_, n_kv = KVD_ / HD_;
     using SH = EngShape<FMT_, DIM_, QD_, KVD_, FFN_, NWG_>;
     static constexpr int xA = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).xA, qkv = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).qkv, ao = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).ao,
-                         xB = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).xB, act = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).act, part = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).part;
+                         xB = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).xB, act = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).act, part = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).part,
+                         hbest = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).hbest;
+    // the LM head (bf16 [vocab, DIM]) as trailing phases of the same launch: the geometry gemv_launch picks for a many-row bf16 matrix of this width
+    static constexpr int HnBlk = DIM_ / 8, Hlpr_log2 = c_lpr_log2(DIM_ / 8, 1L << 20), HLPR = 1 << Hlpr_log2, HRPS = 64 >> Hlpr_log2, Hiters = (HnBlk + HLPR - 1) / HLPR;
     static constexpr int lq_stride = eng_lq_stride(GQ_, HD_), lp_stride = eng_lp_stride(GQ_, HD_);
 };
 template <class C>
@@ -884,13 +895,153 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         mv_run<P6, NCW, FMT, S6>(a.qbias[6], 0.f, wg * P6::spg, wave, lane, P6::M0, r6, L.xs[1], [&](int row, float v, float) {
             const uint16_t o = f2bf(v);
             const uint16_t y = f2bf(bf2f(L.xrawB[row]) + bf2f(o));
-            if (last)
-                a.x_out[row] = y;
-            else
-                L.outb[row - wg * P6::R] = (tag_next << 16) | (uint32_t)y;
+            if (last) a.x_out[row] = y;
+            L.outb[row - wg * P6::R] = (tag_next << 16) | (uint32_t)y;
         });
-        if (!last && has6 && wave < NWP6) wg_publish(L, 3, a.xch + C::xA, wg * P6::R, P6::R, NWP6, lane);
+        if ((!last || a.head_on) && has6 && wave < NWP6) wg_publish(L, 3, a.xch + C::xA, wg * P6::R, P6::R, NWP6, lane);
         if (wave == 0) ENG_STAMP(1, 9);
+    }
+}
+
+
+// ---- the LM head as trailing phases of the launch (Head4Token::cuInfer_1, NeuronFuse.cu:842-862: final RMSNorm, the [vocab, dim] mat-vec, first-maximum arg-max,
+// GoPT.cpp:602-612): what kf_norm_lm_head + argmax_finish_kernel do as two more launches.  All 8 waves stream: a wave owns the row slots wave, wave + 8, ... of the
+// workgroup's contiguous slot range, keeps HG slots (2 * HG 16-byte loads per lane) in flight, and holds its two x blocks in registers (a lane multiplies the same
+// block columns of every row).  The arithmetic is gemv_kernel<FMT_BF16>'s: same lanes per row, same per-lane chain, same tree, bf16 store, arg-max over the stored values.
+template <class C>
+__device__ __forceinline__ void eng_head_main(const EngArgs& a, const EngLds& L, int epoch, int wg, int wave, int lane) {
+    constexpr int NWV = C::NWV, NWG = C::NWG, nBlk = C::HnBlk, LPR = C::HLPR, RPS = C::HRPS, ITERS = C::Hiters, HG = 4;
+    constexpr int ND = C::DIM / 256;
+    using BD = BlockDot<FMT_BF16>;
+    const int sub = lane >> C::Hlpr_log2, ll = lane & (LPR - 1);
+    const int total = (a.vocab + RPS - 1) / RPS, spg = (total + NWG - 1) / NWG; /* slots in all, per workgroup */
+    const int s_wg = wg * spg;
+    int s_end = s_wg + spg;
+    s_end = s_end < total ? s_end : total;
+    const int nmine = s_end > s_wg + wave ? (s_end - s_wg - wave + NWV - 1) / NWV : 0; /* this wave's slots: s_wg + wave + NWV * i */
+    const int nbatch = (nmine + HG - 1) / HG;
+    u32x4 w[2][HG][ITERS];
+    auto issue = [&](int b, int buf) {
+#pragma unroll
+        for (int g = 0; g < HG; g++) {
+            int i = b * HG + g;
+            i = i < nmine ? i : (nmine > 0 ? nmine - 1 : 0); /* unconditional requests (a conditional one would turn the waits behind it into drains): the tail re-reads the wave's last rows */
+            int row = (s_wg + wave + NWV * i) * RPS + sub;
+            row = row < a.vocab ? row : a.vocab - 1;
+#pragma unroll
+            for (int it = 0; it < ITERS; it++) {
+                int col = it * LPR + ll;
+                col = col < nBlk ? col : nBlk - 1;
+                w[buf][g][it] = __builtin_nontemporal_load(a.head_w + (size_t)row * nBlk + col);
+            }
+        }
+    };
+    issue(0, 0); /* ahead of the hand-off of x: the first rows' HBM latency runs under it */
+    const uint32_t gen = (uint32_t)(epoch + 1) * (uint32_t)a.n_layer, tag = gen & 0xffffu; /* the generation the last layer's down_proj published its rows with */
+    if (wave == NWV - 1) {
+        bool dead = false;
+        const bool has6 = wg * C::SH::P6::spg < C::SH::P6::total;
+        eng_poll_stage<1, ND, nBlk, true, false>(a.xch + C::xA, nullptr, tag, a.head_norm, a.eps, L.xs[0], nullptr, lane, a.ws, dead, nullptr, has6 ? L.pub + 3 : nullptr, a.n_layer,
+                                                 a.delay[0]);
+    }
+    __syncthreads();
+    u32x4 xr[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        int col = it * LPR + ll;
+        col = col < nBlk ? col : nBlk - 1;
+        xr[it] = L.xs[0][col];
+    }
+    float best_v = -__builtin_inff();
+    int best_i = 0x7fffffff;
+    auto compute = [&](int b, int buf) {
+#pragma unroll
+        for (int g = 0; g < HG; g++) {
+            const int i = b * HG + g;
+            const int row = (s_wg + wave + NWV * i) * RPS + sub;
+            float acc = 0.f;
+#pragma unroll
+            for (int it = 0; it < ITERS; it++) {
+                const float r = BD::run(w[buf][g][it], xr + it, 0, 0, 0.f, 0.f, 0.f, acc);
+                acc = (it * LPR + ll < nBlk) ? r : acc;
+            }
+            const float v = group_sum(acc, C::Hlpr_log2);
+            if (ll == 0 && i < nmine && row < a.vocab) {
+                const uint16_t o = f2bf(v);
+                a.logits[row] = o;
+                const float fv = bf2f(o);
+                if (fv > best_v || (fv == best_v && row < best_i)) best_v = fv, best_i = row;
+            }
+        }
+    };
+    for (int b = 0; b < nbatch; b += 2) { /* two batches ping-pong: no register copies between steps */
+        issue(b + 1, 1);
+        compute(b, 0);
+        if (b + 1 >= nbatch) break;
+        issue(b + 2, 0);
+        compute(b + 1, 1);
+    }
+    // first maximum over the workgroup's rows, published as one 8-byte granule {tag, bf16 value, row}; workgroup 0's poller picks over all of them
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        const float ov = __shfl_xor(best_v, m, 64);
+        const int oi = __shfl_xor(best_i, m, 64);
+        if (ov > best_v || (ov == best_v && oi < best_i)) best_v = ov, best_i = oi;
+    }
+    float* rv = L.wmax; /* [NWV] values, [NWV] rows behind them (the attention scratch is free now) */
+    int* ri = reinterpret_cast<int*>(L.wmax + NWV);
+    if (lane == 0) rv[wave] = best_v, ri[wave] = best_i;
+    __syncthreads();
+    unsigned long long* hb = reinterpret_cast<unsigned long long*>(a.xch + C::hbest);
+    if (wave == 0 && lane == 0) {
+        for (int k = 1; k < NWV; k++)
+            if (rv[k] > best_v || (rv[k] == best_v && ri[k] < best_i)) best_v = rv[k], best_i = ri[k];
+        /* a workgroup without rows publishes (-inf, 0x7fffffff): it never wins */
+        const unsigned long long gr = ((unsigned long long)((tag << 16) | (uint32_t)f2bf(best_v)) << 32) | (unsigned long long)(uint32_t)best_i;
+        __hip_atomic_store(hb + wg, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (wg == 0 && wave == NWV - 1 && a.d_state_w) { /* the pick (argmax_finish_kernel): NWG granules, 4 per lane */
+        static_assert(NWG == 256, "four granules per lane");
+        const __amdgpu_buffer_rsrc_t rs = eng_rsrc(hb, NWG * 8u);
+        u32x4 g0, g1;
+        bool ok = false;
+        for (int z = 0; z < 24; z++) __builtin_amdgcn_s_sleep(1);
+        for (int spins = 0; spins <= ENG_SPIN_MAX; spins++) {
+            g0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 32, 0, 16 /* sc1 */));
+            g1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 32 + 16, 0, 16));
+            uint32_t bad = ((g0.y >> 16) ^ tag) | ((g0.w >> 16) ^ tag) | ((g1.y >> 16) ^ tag) | ((g1.w >> 16) ^ tag);
+            if (all_good(bad)) {
+                ok = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        float bv = -__builtin_inff();
+        int bi = 0x7fffffff;
+        const uint32_t hv[4] = {g0.y, g0.w, g1.y, g1.w}, hi[4] = {g0.x, g0.z, g1.x, g1.z};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float fv = bf2f((uint16_t)(hv[k] & 0xffffu));
+            const int ix = (int)hi[k];
+            if (fv > bv || (fv == bv && ix < bi)) bv = fv, bi = ix;
+        }
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) {
+            const float ov = __shfl_xor(bv, m, 64);
+            const int oi = __shfl_xor(bi, m, 64);
+            if (ov > bv || (ov == bv && oi < bi)) bv = ov, bi = oi;
+        }
+        if (lane == 0) {
+            const int err = __hip_atomic_load(a.ws + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ok && err == 0 && bi >= 0 && bi < a.vocab) { /* never advance the decode state on a timed-out hand-off */
+                const int p = a.d_state_w[1];
+                if (a.d_tokens_out) a.d_tokens_out[p] = bi;
+                a.d_state_w[0] = bi;
+                a.d_state_w[1] = p + 1;
+            } else if (err == 0) {
+                atomicOr(a.ws + 1, 16);
+            }
+        }
     }
 }
 
@@ -980,6 +1131,7 @@ __global__ void __launch_bounds__(C::NWV * 64) engine_kernel(const EngArgs a) {
         eng_poller_main<C>(a, L, S, epoch, wg, lane);
     else
         eng_compute_main<C>(a, L, S, epoch, wg, wave, lane);
+    if (a.head_on) eng_head_main<C>(a, L, epoch, wg, wave, lane);
     // the next launch's generation (workgroup 0 owns rows of the last phase, so every workgroup has read the epoch long before)
     if (wg == 0 && tid == 0) {
         a.ws[0] = epoch + 1;
@@ -1162,8 +1314,8 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     a.loc = p, p += (eng_loc_bytes(GQ, hd) + 255) & ~(size_t)255;
     {
         /* s_sleep units (one trip of the wait loop ~ 40 ns) behind the own publish: x, q|k|v, slice partials, ao, xB, act.  Tuned on the 0.6B shape at 2 k keys
-           (scratch/eng_ab.py): 0 everywhere 0.607 ms/step, 12,4,8,10,12,12 0.593, 20,12,16,20,20,20 0.558, 32,12,20,28,32,32 0.567 */
-        const int dflt[6] = {20, 12, 16, 20, 20, 20};
+           (scratch/eng_ab.py): after the drains were removed 12,8,12,12,12,12 0.455 ms/step, 16,8,12,16,16,16 0.452, 20,12,16,20,20,20 0.464, 24,12,16,24,24,24 0.474 */
+        const int dflt[6] = {16, 8, 12, 16, 16, 16};
         for (int i = 0; i < 6; i++) a.delay[i] = dflt[i];
         if (const char* e = getenv("KF_ENG_DELAY")) { /* tuning runs */
             int i = 0;
@@ -1258,9 +1410,12 @@ static int engine_go_fmt(EngineHost* E, hipStream_t st) {
 }
 
 // 1: this position bound is outside what the engine serves (the caller runs the multi-launch path), < 0 error
-int engine_step(EngineHost* E, hipStream_t st, const uint16_t* x_in, uint16_t* x_out, const int32_t* d_state, int pos_bound) {
+int engine_step(EngineHost* E, hipStream_t st, const uint16_t* x_in, uint16_t* x_out, const int32_t* d_state, int pos_bound, int with_head) {
     EngArgs& a = E->args;
     if ((!x_in && !a.emb) || !x_out || !d_state || pos_bound < 0) return KF_INVALID_ARGS;
+    if (with_head && !a.head_w) return KF_INVALID_ARGS;
+    a.head_on = with_head ? 1 : 0;
+    a.d_state_w = with_head == 2 ? const_cast<int32_t*>(d_state) : nullptr; /* 2: head + greedy pick + state update; 1: logits only */
     const int nsp = attn_splits(pos_bound, E->n_kv);
     const int chunk = (pos_bound + 1 + nsp - 1) / nsp;
     const int NW = (E->GQ <= 2 && chunk > 128) ? 8 : 4;
@@ -1285,6 +1440,21 @@ int engine_set_embedding(EngineHost* E, const kf_weight* w, const int32_t* d_for
     }
     if (w->type != KF_BF16 || w->quant != KF_QUANT_GROUP || w->qzeros || w->ne1 != E->dim || !w->data) return KF_UNSUPPORTED_DATATYPE;
     E->args.emb = reinterpret_cast<const uint16_t*>(w->data), E->args.d_forced = d_forced, E->args.emb_rows = w->ne0;
+    return KF_OK;
+}
+// The LM head (bf16 [vocab, dim]) + final norm as trailing phases of the launch (engine_step with_head); NULL removes it.
+int engine_set_head(EngineHost* E, const kf_weight* w, const uint16_t* norm_w, uint16_t* logits, int32_t* d_tokens_out) {
+    EngArgs& a = E->args;
+    if (!w) {
+        a.head_w = nullptr, a.head_norm = nullptr, a.logits = nullptr, a.d_tokens_out = nullptr, a.vocab = 0;
+        return KF_OK;
+    }
+    if (w->type != KF_BF16 || w->quant != KF_QUANT_GROUP || w->qzeros || w->ne1 != E->dim || !w->data || ((uintptr_t)w->data & 15) != 0 || !norm_w || !logits || w->ne0 < 64)
+        return KF_UNSUPPORTED_DATATYPE;
+    // the compile-time geometry of the head phases must be the mat-vec launcher's for this matrix (same lanes per row: same summation order)
+    const int nBlk = E->dim / 8;
+    if (gemv_lpr_log2(nBlk, w->ne0) != c_lpr_log2(nBlk, 1L << 20)) return KF_UNSUPPORTED_DATATYPE;
+    a.head_w = (g_u32x4)(uintptr_t)w->data, a.head_norm = (g_u16)(uintptr_t)norm_w, a.logits = logits, a.d_tokens_out = d_tokens_out, a.vocab = w->ne0;
     return KF_OK;
 }
 int engine_error_word(EngineHost* E, hipStream_t st, int* h_err) {

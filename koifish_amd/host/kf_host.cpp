@@ -370,7 +370,34 @@ int Fish::EnsureEngine() {
     // a bf16 embedding table is read inside the launch (graph-mode steps): one launch less per token; other storages keep kf_embed_state
     kf_weight we = embed.w->desc();
     engine_embed = kf_engine_set_embedding(ctx, engine, &we, d_forced) == KF_OK;
+    // final norm + bf16 LM head + greedy pick as trailing phases of the same launch (other head storages keep kf_norm_lm_head)
+    engine_head = false;
+    if (head.proj.w && final_norm.w && head.preLogits && final_norm.rms_eps == config.rms_eps) {
+        kf_weight wh = head.proj.w->desc();
+        engine_head = kf_engine_set_head(ctx, engine, &wh, ToX(final_norm.w), ToX(head.preLogits), d_tokens_out) == KF_OK;
+    }
     return KF_OK;
+}
+void Fish::DropEngine() {
+    for (auto& g : graphs)
+        if (g) kf_graph_destroy(g), g = nullptr;
+    if (engine) {
+        kf_sync(ctx);
+        kf_engine_destroy(engine);
+        engine = nullptr;
+    }
+    if (engine_ws) kf_free(ctx, engine_ws), engine_ws = nullptr;
+    engine_state = 0, engine_embed = engine_head = false;
+}
+int Fish::EngineCheck() {
+    if (!engine || engine_steps == 0) return KF_OK;
+    const int rc = kf_engine_check(ctx, engine);
+    if (rc == KF_INTERNAL_ERR) { /* the word latches: every launch since the failure was a no-op.  Report it once, start over from a clean hand-off state */
+        for (auto& g : graphs)
+            if (g) kf_graph_destroy(g), g = nullptr;
+        kf_engine_reset(ctx, engine);
+    }
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------ tensor parallel
@@ -461,11 +488,22 @@ static int tp_group_enqueue(Fish** fs, int R) {
 int Fish::EnqueueStep(int bound) {
     if (tp.world > 1) return EnqueueStepTP();
     if (use_engine && fuse_level >= 1 && engine_state > 0 && engine_embed && (graph_mode || state_tokens)) { /* embedding row read inside the launch */
-        const int rc = kf_engine_step(ctx, engine, nullptr, ToX(x), d_state, bound);
-        if (rc < 0) return rc;
-        if (rc == KF_OK) {
-            engine_steps++;
-            return head.cuInfer_1(x) ? KF_OK : KF_INTERNAL_ERR;
+        if (engine_head) { /* ... and the final norm, the LM head and the greedy pick: ONE launch per token */
+            const int rc = kf_engine_step_head(ctx, engine, nullptr, ToX(x), d_state, bound, samp_params.greedy() ? 1 : 0);
+            if (rc < 0) return rc;
+            if (rc == KF_OK) {
+                engine_steps++;
+                if (samp_params.greedy()) return KF_OK;
+                return (samp_params.true_topk ? kf_sample_topk : kf_sample)(ctx, ToX(head.preLogits), config.vocab, samp_params.top_k, samp_params.temperature, samp_params.top_p,
+                                                                             d_rng, nullptr, d_state, d_tokens_out, d_forced, config.n_ctx);
+            }
+        } else {
+            const int rc = kf_engine_step(ctx, engine, nullptr, ToX(x), d_state, bound);
+            if (rc < 0) return rc;
+            if (rc == KF_OK) {
+                engine_steps++;
+                return head.cuInfer_1(x) ? KF_OK : KF_INTERNAL_ERR;
+            }
         }
     }
     hGTensor cur = embed.cuInfer(-1);
@@ -646,7 +684,7 @@ int Fish::Generate(const int* prompt, int n_prompt, int n_new, int* out, bool us
     }
     std::vector<int32_t> toks(config.n_ctx);
     KF_TRY(kf_d2h(ctx, toks.data(), d_tokens_out, toks.size() * 4));
-    if (engine && engine_steps > 0) KF_TRY(kf_engine_check(ctx, engine)); /* a launch that could not become resident leaves an error word, never a hang */
+    KF_TRY(EngineCheck()); /* a launch that could not become resident leaves an error word, never a hang */
     for (int i = 0; i < n_new; i++) out[i] = toks[n_prompt - 1 + i];
     return KF_OK;
 }
@@ -688,7 +726,9 @@ int kfh_set_hot(void* h, int layer, const int32_t* h_hot, int n) {
     for (auto& g : f->graphs)
         if (g) kf_graph_destroy(g), g = nullptr;
     if (!h_hot) {
+        if (m->n_hot >= 0) f->masked_layers--;
         m->n_hot = -1, m->hot_rows.reset();
+        if (f->masked_layers == 0 && f->engine_state < 0) f->engine_state = f->engine ? 1 : 0; /* dense again: the built engine serves (or is built on the next step) */
         return KF_OK;
     }
     if (n != f->config.n_ff) return KF_INVALID_ARGS;
@@ -699,6 +739,7 @@ int kfh_set_hot(void* h, int layer, const int32_t* h_hot, int n) {
     KF_TRY(kf_hot_rows(f->ctx, reinterpret_cast<const int32_t*>(mask->data), n, reinterpret_cast<int32_t*>(rows->data), d_count));
     int32_t cnt = 0;
     KF_TRY(kf_d2h(f->ctx, &cnt, d_count, 4));
+    if (m->n_hot < 0) f->masked_layers++;
     m->hot_rows = rows, m->n_hot = cnt;
     if (f->engine_state > 0) f->engine_state = -1; /* a built engine walks the dense FFN */
     return KF_OK;
@@ -743,7 +784,7 @@ int kfh_engine_only(void* h, int n) {
 // synchronises; KF_INTERNAL_ERR when one of the engine's hand-off polls has timed out
 int kfh_engine_check(void* h) {
     Fish* f = reinterpret_cast<Fish*>(h);
-    return f->engine ? kf_engine_check(f->ctx, f->engine) : KF_OK;
+    return f->EngineCheck();
 }
 
 static SLP* slot_of(Fish* f, int layer, int slot) {
@@ -789,6 +830,7 @@ static int set_weight_impl(void* h, int layer, int slot, int type, int ne0, int 
         int rc = t->LoadBlob(f->ctx, blob, blob_bytes);
         if (rc != KF_OK) return rc;
     }
+    f->DropEngine(); /* the engine's device table (and every captured graph) holds the old tensors' addresses */
     if (layer < 0 && slot == 0) {
         f->embed.w = t;
         return KF_OK;
@@ -802,6 +844,7 @@ static int set_weight_impl(void* h, int layer, int slot, int type, int ne0, int 
 int kfh_tie_head(void* h) {
     Fish* f = reinterpret_cast<Fish*>(h);
     if (!f->embed.w) return KF_INVALID_ARGS;
+    f->DropEngine();
     f->head.proj.w = f->embed.w, f->head.proj.nOut = f->embed.w->ne[0], f->head.proj.nIn = f->embed.w->ne[1];
     return KF_OK;
 }
@@ -816,6 +859,7 @@ int kfh_set_norm(void* h, int layer, int slot, const void* w, int n, int is_devi
         int rc = t->LoadBlob(f->ctx, w, (size_t)n * 2);
         if (rc != KF_OK) return rc;
     }
+    f->DropEngine();
     if (layer < 0) {
         f->final_norm.w = t;
         return KF_OK;
@@ -870,8 +914,10 @@ int kfh_set_sampler(void* h, float temperature, float top_p, int top_k, uint64_t
 int kfh_set_state(void* h, int token, int pos) { return reinterpret_cast<Fish*>(h)->SetState(token, pos); }
 int kfh_run_steps(void* h, int pos, int n, int use_graph) { return reinterpret_cast<Fish*>(h)->RunSteps(pos, n, use_graph != 0); }
 int kfh_sync(void* h) { return kf_sync(reinterpret_cast<Fish*>(h)->ctx); }
+// the ids of the steps run so far; KF_INTERNAL_ERR (once) when a hand-off of the persistent engine timed out since the last check: the ids behind the failure are not valid
 int kfh_get_tokens(void* h, int32_t* out, int n) {
     Fish* f = reinterpret_cast<Fish*>(h);
+    KF_TRY(f->EngineCheck());
     return kf_d2h(f->ctx, out, f->d_tokens_out, (size_t)n * 4);
 }
 void* kfh_kcache(void* h) { return reinterpret_cast<Fish*>(h)->cache.key->data; }

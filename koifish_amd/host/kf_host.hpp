@@ -217,7 +217,11 @@ struct Fish {
     void* engine_ws = nullptr;
     int engine_state = 0;  // 0 not tried, 1 built, -1 not served
     bool engine_embed = false;  // the engine reads the (bf16) embedding row itself
+    bool engine_head = false;   // ... and runs the final norm, the (bf16) LM head and the greedy pick as trailing phases of its launch
+    int masked_layers = 0;      // layers with a hot-row mask (kfh_set_hot): the engine walks dense FFNs only
     int EnsureEngine();
+    void DropEngine();          // weights / norms / caches changed: the engine's device table and the captured graphs hold stale pointers
+    int EngineCheck();          // synchronises; a timed-out hand-off is reported ONCE (KF_INTERNAL_ERR), the engine reset so that later steps run again
     int engine_steps = 0;  // steps enqueued (or captured) through the engine
     KVCache cache;
     MemBuffer gBUFF;
