@@ -70,6 +70,11 @@ struct EngPlan { /* host copy of one mat-vec phase: the geometry gemv_launch wou
 
 // ---- the exchange area (uncached memory): granule vectors at compile-time offsets (dwords), 256-byte aligned
 constexpr int eng_gran_dw(int n) { return ((n * 4 + 255) & ~255) / 4; }
+constexpr int pow2_ceil(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
 struct EngXOff {
     int xA, qkv, ao, xB, act, part, hbest, end; /* part: 8-byte granules [n_head][KF_ATTN_MAX_SPLITS][hd + 4]; hbest: 8-byte granules [ENG_NWG]: the head's per-workgroup maxima */
 };
@@ -375,6 +380,7 @@ struct EngLds {
     float *wmax, *comb;
     uint32_t* outb; /* [64] a phase's output granules of this workgroup, gathered so that ONE wave stores them 16 bytes per lane */
     int* cnt;       /* arrival counter of the compute waves that own rows of the phase */
+    float* msc;     /* [ME][KF_ATTN_MAX_SPLITS] the slice partials of this workgroup's merge elements, transposed for the per-element chains; [ME] dwords behind it: its ao granules */
     int* pub;       /* [4] layers of P1 / P4 / P5 / P6 rows this workgroup has published so far: the poller starts sweeping for the phase's consumers' vector behind it */
 };
 struct EngSlice { /* this workgroup's attention slice and merge share */
@@ -422,6 +428,11 @@ struct EngCfg {
     // the LM head (bf16 [vocab, DIM]) as trailing phases of the same launch: the geometry gemv_launch picks for a many-row bf16 matrix of this width
     static constexpr int HnBlk = DIM_ / 8, Hlpr_log2 = c_lpr_log2(DIM_ / 8, 1L << 20), HLPR = 1 << Hlpr_log2, HRPS = 64 >> Hlpr_log2, Hiters = (HnBlk + HLPR - 1) / HLPR;
     static constexpr int lq_stride = eng_lq_stride(GQ_, HD_), lp_stride = eng_lp_stride(GQ_, HD_);
+    // slice merge: every workgroup merges ME consecutive elements of one head (ME = the power of two >= q_dim / NWG).  A head's slice partials lie as
+    // [hd / ME element groups][KF_ATTN_MAX_SPLITS slices][ME] 8-byte {fp32, generation} granules + [KF_ATTN_MAX_SPLITS][2] {max, sum}: the nsp * ME granules a
+    // workgroup merges are contiguous (two 16-byte loads per lane at 2 k keys instead of 32 eight-byte ones)
+    static constexpr int ME = pow2_ceil((QD_ + NWG_ - 1) / NWG_), PSH = KF_ATTN_MAX_SPLITS * (HD_ + 2), NLM = (KF_ATTN_MAX_SPLITS * ME + 127) / 128;
+    static_assert(ME <= 64 && ME <= HD_, "merge elements per workgroup");
 };
 template <class C>
 __device__ __forceinline__ uint32_t* eng_lqkv(const EngArgs& a, int xcc) { return reinterpret_cast<uint32_t*>(a.loc + 1024) + (size_t)xcc * C::lq_stride; }
@@ -441,7 +452,7 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
     constexpr int FMT = C::FMT, GQ = C::GQ, HD = C::HD, NWV = C::NWV;
     constexpr bool XMAP = C::XMAP, DBG = C::DBG;
     constexpr int ND = C::DIM / 256, NQD = C::QD / 256, NF = C::FFN / 256;
-    constexpr int XCH = BlockDot<FMT>::XCH, hd = HD, hd_log2 = HD == 128 ? 7 : 6, NW = 4, PS = hd + 4, LPK = hd >> 3, KPW = 64 / LPK;
+    constexpr int XCH = BlockDot<FMT>::XCH, hd = HD, hd_log2 = HD == 128 ? 7 : 6, NW = 4, LPK = hd >> 3, KPW = 64 / LPK;
     bool dead = false;
     const bool has1 = XMAP ? true : wg * P1::spg < P1::total, has4 = wg * P4::spg < P4::total, has5 = wg * P5::spg < P5::total, has6 = wg * P6::spg < P6::total;
     const int tstride = NW * KPW;
@@ -537,25 +548,29 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
         // P3: merge the slices of this workgroup's output elements (attention_v_kernel's division, once)
         ENG_STAMP(0, 3);
         if (S.has_merge) {
+            constexpr int ME = C::ME, NLM = C::NLM, MAXSP = KF_ATTN_MAX_SPLITS;
             const int nsp = S.nsp, h = S.me0 >> hd_log2, dd = S.me0 & (hd - 1); /* XCD-mapped form: me0 counts inside the XCD's GQ heads */
-            const unsigned long long* base =
-                XMAP ? eng_lpart<C>(a, S.xcc) + (size_t)h * nsp * PS : reinterpret_cast<const unsigned long long*>(a.xch + C::part) + (size_t)h * nsp * PS;
-            float ms = -__builtin_inff(), ls = 0.f, vsp[KF_ATTN_MAX_SPLITS];
-            const bool mine = lane < nsp, el = lane < a.merge_e;
+            const unsigned long long* hbase = XMAP ? eng_lpart<C>(a, S.xcc) + (size_t)h * C::PSH : reinterpret_cast<const unsigned long long*>(a.xch + C::part) + (size_t)h * C::PSH;
+            const __amdgpu_buffer_rsrc_t rs_o = eng_rsrc(hbase + (size_t)(dd / ME) * (MAXSP * ME), (uint32_t)(MAXSP * ME) * 8u);
+            const __amdgpu_buffer_rsrc_t rs_ml = eng_rsrc(hbase + (size_t)hd * MAXSP, (uint32_t)MAXSP * 16u);
+            const int cnt = nsp * ME; /* granules of this workgroup's elements: index sp * ME + e */
+            u32x4 go[NLM], gml;
+            const bool mine = lane < nsp, el = lane < ME;
             eng_wait_pub(nullptr, 0, a.delay[2], dead);
+            ENG_STAMP(0, 9);
+            int msw = 0;
             for (int spins = 0;; spins++) {
                 uint32_t bad = 0;
-                const unsigned long long want = (unsigned long long)gen << 32; /* lanes and slices outside the work read as {0, gen}: clamped loads would cost more */
-                unsigned long long gm = want, gl = want, gv[KF_ATTN_MAX_SPLITS];
-                if (mine) gm = ld_gran64(base + (size_t)lane * PS + hd), gl = ld_gran64(base + (size_t)lane * PS + hd + 1);
+                msw = spins + 1;
 #pragma unroll
-                for (int sp = 0; sp < KF_ATTN_MAX_SPLITS; sp++) gv[sp] = (el && sp < nsp) ? ld_gran64(base + (size_t)sp * PS + dd + lane) : want;
-                bad |= ((uint32_t)(gm >> 32) ^ gen) | ((uint32_t)(gl >> 32) ^ gen);
+                for (int r = 0; r < NLM; r++) go[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_o, (r * 64 + lane) * 16, 0, XMAP ? 16 : 16 /* sc1 */));
+                gml = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ml, (mine ? lane : 0) * 16, 0, 16));
 #pragma unroll
-                for (int sp = 0; sp < KF_ATTN_MAX_SPLITS; sp++) bad |= (uint32_t)(gv[sp] >> 32) ^ gen;
-                if (mine) ms = __uint_as_float((uint32_t)gm), ls = __uint_as_float((uint32_t)gl);
-#pragma unroll
-                for (int sp = 0; sp < KF_ATTN_MAX_SPLITS; sp++) vsp[sp] = __uint_as_float((uint32_t)gv[sp]);
+                for (int r = 0; r < NLM; r++) {
+                    const int i0 = 2 * (r * 64 + lane);
+                    bad |= (i0 < cnt ? (go[r].y ^ gen) : 0u) | (i0 + 1 < cnt ? (go[r].w ^ gen) : 0u);
+                }
+                bad |= mine ? ((gml.y ^ gen) | (gml.w ^ gen)) : 0u;
                 if (all_good(bad)) break;
                 if (dead || spins > ENG_SPIN_MAX) {
                     if (!dead && lane == 0) atomicOr(a.ws + 1, 4);
@@ -564,13 +579,35 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
                 }
                 __builtin_amdgcn_s_sleep(1);
             }
+            ENG_STAMP(0, 11);
+            if (DBG && wg == a.dbg_wg && lane == 0) a.dbg[((size_t)l * 2) * 16 + 10] = (unsigned long long)msw;
+            // transpose through LDS: element e's MAXSP values (slices past nsp: 0, as the round-2 chain added them) contiguous for lane e
+#pragma unroll
+            for (int r = 0; r < NLM; r++) {
+                const int i0 = 2 * (r * 64 + lane);
+                if (i0 < MAXSP * ME) {
+                    const int sp0 = i0 / ME, e0 = i0 - sp0 * ME, sp1 = (i0 + 1) / ME, e1 = (i0 + 1) - sp1 * ME;
+                    L.msc[e0 * MAXSP + sp0] = i0 < cnt ? __uint_as_float(go[r].x) : 0.f;
+                    L.msc[e1 * MAXSP + sp1] = i0 + 1 < cnt ? __uint_as_float(go[r].z) : 0.f;
+                }
+            }
+            const float ms = mine ? __uint_as_float(gml.x) : -__builtin_inff(), ls = mine ? __uint_as_float(gml.z) : 0.f;
             const float Mx = wave_max(ms);
             const float sc = (ms == -__builtin_inff()) ? 0.f : fast_exp(ms - Mx);
             const float Lt = wave_sum(ls * sc);
             float o = 0.f;
+            const float* mv = L.msc + (el ? lane : 0) * MAXSP;
 #pragma unroll
-            for (int sp = 0; sp < KF_ATTN_MAX_SPLITS; sp++) o = fmaf(vsp[sp], __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sc), sp)), o);
-            if (el) st_gran(a.xch + C::ao + (XMAP ? S.h0 * hd : 0) + S.me0 + lane, tag, f2bf(o * (1.0f / Lt)));
+            for (int sp = 0; sp < MAXSP; sp++) o = fmaf(mv[sp], __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sc), sp)), o);
+            uint32_t* const ao_dst = a.xch + C::ao + (XMAP ? S.h0 * hd : 0) + S.me0;
+            const uint32_t gr = (tag << 16) | (uint32_t)f2bf(o * (1.0f / Lt));
+            if (ME >= 4) { /* 16 bytes per lane: a 4-byte write-through store is a read-modify-write at the memory side */
+                uint32_t* mo = reinterpret_cast<uint32_t*>(L.msc + ME * MAXSP);
+                if (el) mo[lane] = gr;
+                if (4 * lane < ME) st_gran16(ao_dst + 4 * lane, *reinterpret_cast<const u32x4*>(mo + 4 * lane));
+            } else if (el) {
+                __hip_atomic_store(ao_dst + lane, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         // P4, P5 (P6 adds that x as the residual), P6
         ENG_STAMP(0, 4);
@@ -836,14 +873,16 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
                             float Mh = M[0];
 #pragma unroll
                             for (int q2 = 1; q2 < GQ; q2++) Mh = (hq == q2) ? M[q2] : Mh;
+                            constexpr int ME = C::ME, MAXSP = KF_ATTN_MAX_SPLITS;
+                            const size_t oi = (size_t)(d / ME) * (MAXSP * ME) + (size_t)S.split * ME + (d & (ME - 1)), mi = (size_t)hd * MAXSP + (size_t)S.split * 2;
                             if (XMAP) { /* plain 8-byte stores into this XCD's partial buffer */
-                                unsigned long long* dst = eng_lpart<C>(a, S.xcc) + ((size_t)hq * nsp + S.split) * PS;
-                                dst[d] = ((unsigned long long)gen << 32) | __float_as_uint(o);
-                                if (d == 0) dst[hd] = ((unsigned long long)gen << 32) | __float_as_uint(Mh), dst[hd + 1] = ((unsigned long long)gen << 32) | __float_as_uint(Ls);
+                                unsigned long long* dst = eng_lpart<C>(a, S.xcc) + (size_t)hq * C::PSH;
+                                dst[oi] = ((unsigned long long)gen << 32) | __float_as_uint(o);
+                                if (d == 0) dst[mi] = ((unsigned long long)gen << 32) | __float_as_uint(Mh), dst[mi + 1] = ((unsigned long long)gen << 32) | __float_as_uint(Ls);
                             } else {
-                                unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.xch + C::part) + ((size_t)(h0 + hq) * nsp + S.split) * PS;
-                                st_gran64(dst + d, gen, o);
-                                if (d == 0) st_gran64(dst + hd, gen, Mh), st_gran64(dst + hd + 1, gen, Ls);
+                                unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.xch + C::part) + (size_t)(h0 + hq) * C::PSH;
+                                st_gran64(dst + oi, gen, o);
+                                if (d == 0) st_gran64(dst + mi, gen, Mh), st_gran64(dst + mi + 1, gen, Ls);
                             }
                         }
                     }
@@ -851,14 +890,16 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
             } else if (nsp > 1 && aw) { /* empty slice: neutral partial */
                 for (int i = tid; i < GQ * hd; i += NW * 64) {
                     const int hq = i >> hd_log2, d = i & (hd - 1);
+                    constexpr int ME = C::ME, MAXSP = KF_ATTN_MAX_SPLITS;
+                    const size_t oi = (size_t)(d / ME) * (MAXSP * ME) + (size_t)S.split * ME + (d & (ME - 1)), mi = (size_t)hd * MAXSP + (size_t)S.split * 2;
                     if (XMAP) {
-                        unsigned long long* dst = eng_lpart<C>(a, S.xcc) + ((size_t)hq * nsp + S.split) * PS;
-                        dst[d] = (unsigned long long)gen << 32;
-                        if (d == 0) dst[hd] = ((unsigned long long)gen << 32) | 0xff800000u, dst[hd + 1] = (unsigned long long)gen << 32;
+                        unsigned long long* dst = eng_lpart<C>(a, S.xcc) + (size_t)hq * C::PSH;
+                        dst[oi] = (unsigned long long)gen << 32;
+                        if (d == 0) dst[mi] = ((unsigned long long)gen << 32) | 0xff800000u, dst[mi + 1] = (unsigned long long)gen << 32;
                     } else {
-                        unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.xch + C::part) + ((size_t)(h0 + hq) * nsp + S.split) * PS;
-                        st_gran64(dst + d, gen, 0.f);
-                        if (d == 0) st_gran64(dst + hd, gen, -__builtin_inff()), st_gran64(dst + hd + 1, gen, 0.f);
+                        unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.xch + C::part) + (size_t)(h0 + hq) * C::PSH;
+                        st_gran64(dst + oi, gen, 0.f);
+                        if (d == 0) st_gran64(dst + mi, gen, -__builtin_inff()), st_gran64(dst + mi + 1, gen, 0.f);
                     }
                 }
             }
@@ -866,6 +907,10 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         // the next layer's K/V tiles of this slice (they do not depend on this token, except row `pos`, which is substituted); the last layer
         // requests its own again
         if (wave == 0) ENG_STAMP(1, 3);
+        if (DBG && wave == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ENG_STAMP(1, 10); /* partial stores acknowledged */
+        }
         if (aw && !S.empty) issue_kv(L.lay[ln], tstart, t1);
 
         // ================= P4: o_proj + residual -> xB
@@ -1071,6 +1116,7 @@ __global__ void __launch_bounds__(C::NWV * 64) engine_kernel(const EngArgs a) {
     L.outb = reinterpret_cast<uint32_t*>(L.comb + NW * GQ * (hd + 4));
     L.cnt = reinterpret_cast<int*>(L.outb + 64); /* [0] arrival counter, [1..2] XCD id and ticket */
     L.pub = L.cnt + 4;
+    L.msc = reinterpret_cast<float*>(L.cnt + 8);
     if (tid == 0) *L.cnt = 0;
     if (tid < 4) L.pub[tid] = 0;
     // ---- start: state, generation, tables
@@ -1350,7 +1396,7 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     if (E->ffn > maxK) maxK = E->ffn;
     const size_t xs_bytes = ((size_t)maxK * 2 + 15) & ~(size_t)15;
     size_t smem = (((size_t)d->n_layer * sizeof(EngLayer) + 15) & ~(size_t)15) + 2 * xs_bytes + 2 * (((size_t)E->dim * 2 + 15) & ~(size_t)15);
-    smem += sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + sizeof(float) * (4 * GQ + 4 + (size_t)4 * GQ * (hd + 4)) + 4 * 64 + 32;
+    smem += sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + sizeof(float) * (4 * GQ + 4 + (size_t)4 * GQ * (hd + 4)) + 4 * 64 + 32 + 4 * (64 * KF_ATTN_MAX_SPLITS + 64);
     smem = (smem + 15) & ~(size_t)15;
     if (smem > 160 * 1024) {
         engine_release(E);
@@ -1424,7 +1470,7 @@ int engine_step(EngineHost* E, hipStream_t st, const uint16_t* x_in, uint16_t* x
     int e = (E->n_head * E->hd + E->n_cu - 1) / E->n_cu, me = 1;
     while (me < e) me <<= 1;
     if (me > E->hd || me > 64) return 1;
-    a.merge_e = me;
+    a.merge_e = me; /* = EngCfg::ME of the instantiated shapes (whole workgroups: q_dim / n_cu) */
     a.x_in = x_in, a.x_out = x_out, a.d_state = d_state;
     switch (E->fmt) {
         case FMT_Q4P: return engine_go_fmt<FMT_Q4P>(E, st);

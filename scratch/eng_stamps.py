@@ -35,8 +35,9 @@ for l in range(8, 8 + int(os.environ.get('STAMP_LAYERS', '1'))):
 sw = a[4:, 0, 8]
 print("sweeps per poll (mean): P1 %.1f  P4 %.1f  P5 %.1f  P6 %.1f" % tuple(((sw >> (16 * i)) & 0xffff).mean() for i in range(4)))
 for l in range(8, 12):
-    n6 = int((a[l, 0, 8] >> 48) & 0xffff)
-    print('  layer %d P6 poll: start %+.2f, sweeps return at' % (l, (a[l, 0, 6] - a[l, 0, 0]) / 100.0), ' '.join('%+.2f' % ((a[l, 0, 9 + k] - a[l, 0, 0]) / 100.0) for k in range(min(n6, 7))), '; staged %+.2f ; wave0 P5 done %+.2f' % ((a[l, 0, 7] - a[l, 0, 0]) / 100.0, (a[l, 1, 7] - a[l, 0, 0]) / 100.0))
+    print('  layer %d merge: barriers done %+.2f, first sweep issued %+.2f, sweeps %d, good %+.2f, merge done %+.2f | wave0: attention done (stores issued) %+.2f, stores acknowledged %+.2f' % (
+        l, (a[l, 0, 3] - a[l, 0, 0]) / 100.0, (a[l, 0, 9] - a[l, 0, 0]) / 100.0, a[l, 0, 10], (a[l, 0, 11] - a[l, 0, 0]) / 100.0, (a[l, 0, 4] - a[l, 0, 0]) / 100.0,
+        (a[l, 1, 3] - a[l, 0, 0]) / 100.0, (a[l, 1, 10] - a[l, 0, 0]) / 100.0))
 d = (a[1:, 0, 0] - a[:-1, 0, 0]) / 100.0
 print("layer period (us): mean %.2f  min %.2f  max %.2f" % (d[2:].mean(), d[2:].min(), d[2:].max()))
 # per-phase durations averaged over layers 4..27 (poller view)
