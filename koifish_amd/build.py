@@ -67,9 +67,29 @@ def build_host(force=False, verbose=False):
     return LIB_HOST
 
 
+def build_host_asan(verbose=False):
+    """CPU-only sanitizer build of the host library (AddressSanitizer + UBSan): the JSON / msgpack / mmap parsers of kf_safetensors.cpp read untrusted
+    files.  Written to libkf_host_asan.so; tests/test_host_asan_cpu.py runs the checkpoint tests under it (LD_PRELOAD of libasan, KF_HOST_LIB).
+    Never for the GPU box: sanitizers run on the CPU build only."""
+    out = os.path.join(HERE, "libkf_host_asan.so")
+    src = os.path.join(HOST, "kf_host.cpp")
+    src2 = os.path.join(HOST, "kf_safetensors.cpp")
+    deps = [src, src2, os.path.join(HOST, "kf_safetensors.hpp"), os.path.join(HOST, "kf_host.hpp"), os.path.join(HERE, "..", "include", "kf_abi.h"), LIB_HIP]
+    if _stale(out, deps):
+        cmd = ["g++", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-std=c++17", "-fPIC", "-shared", "-Wall",
+               "-o", out, src, src2, "-L" + HERE, "-lkf_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return out
+
+
 def build_all(force=False, verbose=False):
     return build_hip(force, verbose), build_host(force, verbose)
 
 
 if __name__ == "__main__":
-    print(build_all(force="--force" in sys.argv, verbose=True))
+    if "asan" in sys.argv:   # python -m koifish_amd.build asan
+        print(build_host_asan(verbose=True))
+    else:
+        print(build_all(force="--force" in sys.argv, verbose=True))

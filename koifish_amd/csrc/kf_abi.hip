@@ -4,7 +4,6 @@
 #include <stdio.h>
 #include <string.h>
 
-#include <dlfcn.h>
 
 #include <mutex>
 #include <math.h>
@@ -23,7 +22,6 @@ struct kf_ctx {
     int* amax_idx;
     void* scratch;    /* caller-owned workspace of kf_linear (kf_set_scratch): AWQ slice partials, or a weight dequantised to bf16 */
     size_t scratch_bytes;
-    void* blas;       /* rocBLAS handle, only with KF_GEMM_LIB=1 (dlopen'ed on first use; NULL: not tried, (void*)-1: unavailable) */
 };
 struct kf_graph {
     hipGraph_t graph;
@@ -81,64 +79,6 @@ int kf_init(int device, void* stream, kf_ctx** out) {
     *out = c;
     return KF_OK;
 }
-// ---- OPT-IN vendor GEMM (KF_GEMM_LIB=1; off by default) for LARGE token batches (training-size, n >= 2048 rows): the weight is
-// dequantised to bf16 into the caller's scratch (what the reference's GetDataX does before every cuBLASLt call) and the plain bf16 GEMM goes to rocBLAS
-// -- a yardstick beside the fused dequant-GEMM kernels of kf_gemm*.hip, which serve every batch by default.  rocBLAS is resolved with dlopen so that
-// libkf_hip.so has no link-time dependency on it.
-typedef int (*rb_create_t)(void**);
-typedef int (*rb_destroy_t)(void*);
-typedef int (*rb_set_stream_t)(void*, hipStream_t);
-typedef int (*rb_gemm_ex_t)(void*, int, int, int, int, int, const void*, const void*, int, int, const void*, int, int, const void*, const void*, int, int, void*, int, int, int,
-                            int, int32_t, uint32_t);
-static struct {
-    void* so;
-    rb_create_t create;
-    rb_destroy_t destroy;
-    rb_set_stream_t set_stream;
-    rb_gemm_ex_t gemm_ex;
-} g_rb;
-static bool lib_blas_ready(kf_ctx* c) {
-    if (c->blas == (void*)-1 || c->capturing) return false;
-    if (c->blas) return true;
-    static int enabled = -1;
-    if (enabled < 0) {
-        const char* e = getenv("KF_GEMM_LIB"); /* opt-in: the hand-written tile kernels are the product path */
-        enabled = (e && atoi(e) == 1) ? 1 : 0;
-    }
-    c->blas = (void*)-1;
-    if (!enabled) return false;
-    static std::mutex rb_mu; /* contexts of different host threads may get here at the same time */
-    std::lock_guard<std::mutex> lock(rb_mu);
-    if (!g_rb.so) {
-        g_rb.so = dlopen("librocblas.so.5", RTLD_NOW | RTLD_LOCAL);
-        if (!g_rb.so) g_rb.so = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
-        if (!g_rb.so) return false;
-        g_rb.create = (rb_create_t)dlsym(g_rb.so, "rocblas_create_handle");
-        g_rb.destroy = (rb_destroy_t)dlsym(g_rb.so, "rocblas_destroy_handle");
-        g_rb.set_stream = (rb_set_stream_t)dlsym(g_rb.so, "rocblas_set_stream");
-        g_rb.gemm_ex = (rb_gemm_ex_t)dlsym(g_rb.so, "rocblas_gemm_ex");
-    }
-    if (!g_rb.create || !g_rb.destroy || !g_rb.set_stream || !g_rb.gemm_ex) return false;
-    void* h = nullptr;
-    if (g_rb.create(&h) != 0 || !h) return false;
-    if (g_rb.set_stream(h, c->stream) != 0) {
-        g_rb.destroy(h);
-        return false;
-    }
-    c->blas = h;
-    return true;
-}
-static void lib_blas_destroy(kf_ctx* c) {
-    if (c->blas && c->blas != (void*)-1 && g_rb.destroy) g_rb.destroy(c->blas);
-    c->blas = nullptr;
-}
-// column-major C[m x n] = alpha op(A) op(B) + beta C, bf16 operands and result, fp32 accumulation (rocblas_gemm_ex)
-static int lib_gemm(kf_ctx* c, bool tA, bool tB, int m, int n, int k, const void* A, int lda, const void* B, int ldb, float beta, void* Cm, int ldc) {
-    const float alpha = 1.0f;
-    const int BF16R = 168, F32R = 151;
-    return g_rb.gemm_ex(c->blas, tA ? 112 : 111, tB ? 112 : 111, m, n, k, &alpha, A, BF16R, lda, B, BF16R, ldb, &beta, Cm, BF16R, ldc, Cm, BF16R, ldc, F32R, 0, 0, 0) == 0 ? KF_OK
-                                                                                                                                                                            : KF_INTERNAL_ERR;
-}
 // bf16 view of a weight: the data itself (bf16 storage) or its dequantisation into the caller's scratch (kf_set_scratch)
 static int lib_weight_bf16(kf_ctx* c, const kf_weight* w, const uint16_t** out) {
     if (w->type == KF_BF16) {
@@ -152,14 +92,12 @@ static int lib_weight_bf16(kf_ctx* c, const kf_weight* w, const uint16_t** out) 
     *out = (const uint16_t*)c->scratch;
     return r;
 }
-static int lib_gemm_min() { return 2048; }
 
 int kf_destroy(kf_ctx* c) {
     if (!c) return KF_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->amax_val), (void)hipFree(c->amax_idx);
-    lib_blas_destroy(c);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return KF_OK;
@@ -357,25 +295,7 @@ int kf_linear(kf_ctx* c, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const
         }
         return KF_OK;
     }
-    // KF_GEMM_LIB=1 only: dequantise + vendor GEMM (see lib_gemm above).  Its bf16 result takes bias / residual in a separate pass, so a biased output is
-    // rounded twice (<= 1 bf16 ulp from the fused kernels' single rounding), and that pass re-reads `residual` AFTER y has been written: a residual that
-    // aliases y (the in-place form the host uses) stays on the tile kernels, which read it per element before they store.
-    const bool res_alias = (epilogue & KF_EPI_RESIDUAL) && residual < y + (size_t)nTok * w->ne0 && y < residual + (size_t)nTok * w->ne0;
-    if (nTok >= lib_gemm_min() && alpha == 1.0f && beta == 0.0f && (w->ne0 % 8) == 0 && al16(y) && !res_alias && lib_blas_ready(c) &&
-        (w->type == KF_BF16 || (c->scratch && c->scratch_bytes >= (size_t)w->ne0 * w->ne1 * 2))) {
-        const uint16_t* Wd = nullptr;
-        r = lib_weight_bf16(c, w, &Wd);
-        if (r == KF_OK) r = lib_gemm(c, true, false, w->ne0, nTok, w->ne1, Wd, w->ne1, x, w->ne1, 0.0f, y, w->ne0);
-        if (r == KF_OK && (bias || (epilogue & KF_EPI_RESIDUAL)))
-            r = kf::bias_residual_launch(c->stream, y, bias, (epilogue & KF_EPI_RESIDUAL) ? residual : nullptr, (size_t)nTok, w->ne0);
-        if (r != KF_OK) return fail(r, "kf_linear (library GEMM) failed with %d", r);
-        return KF_OK;
-    }
-    static int gemm_min = -1; /* token rows from which the MFMA tile kernel replaces the per-token mat-vec loop */
-    if (gemm_min < 0) {
-        const char* e = getenv("KF_GEMM_MIN");
-        gemm_min = e ? atoi(e) : 8;
-    }
+    const int gemm_min = kf::g_knobs.gemm_min; /* token rows from which the MFMA tile kernel replaces the per-token mat-vec loop (8) */
     if (w->quant != KF_QUANT_GROUP && w->type != KF_Q4) {
         // 3- / 2-bit row forms: GetDataX into the scratch, then the bf16 product, whatever the batch (the reference's own order; no in-place mat-vec)
         const uint16_t* Wd = nullptr;
@@ -481,12 +401,14 @@ int kf_tp_alloc(kf_ctx* c, size_t bytes, void** out) {
     CHKCTX(c);
     if (!out || !bytes) return fail(KF_INVALID_ARGS, "kf_tp_alloc: bad args");
     // uncached (fine-grained) device memory: remote writes become visible to this device's polling loads inside a running kernel
+    // No fallback to cached (coarse-grained) memory: a peer's stores into it are not guaranteed to reach a running kernel's polls, and every exchange would end in
+    // a 2^24-spin timeout with no hint of the cause.
     hipError_t e = hipExtMallocWithFlags(out, bytes, hipDeviceMallocUncached);
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        e = hipMalloc(out, bytes);
+        *out = nullptr;
+        return fail(KF_OUTOF_GPUMEMORY, "kf_tp_alloc(%zu): uncached device memory refused (%s); a cached allocation cannot serve as a receive area", bytes, hipGetErrorString(e));
     }
-    if (e != hipSuccess) return fail(KF_OUTOF_GPUMEMORY, "kf_tp_alloc(%zu): %s", bytes, hipGetErrorString(e));
     HIPCHK(hipMemset(*out, 0, bytes));
     return KF_OK;
 }
@@ -557,7 +479,7 @@ int kf_tp_pick(kf_ctx* c, const kf_tp_comm* t, int32_t* d_state, int32_t* d_toke
     if (r) return r;
     if (!d_state) return fail(KF_INVALID_ARGS, "kf_tp_pick: d_state is null");
     RET(kf::tp_pick_launch(c->stream, (const unsigned long long*)t->recv + (size_t)2 * t->world * t->n_max, t->world, t->d_step, t->per_step, t->per_step - 1, d_state,
-                           d_tokens_out, t->d_err));
+                           d_tokens_out, t->d_err, 0x7fffffff));
 }
 
 int kf_norm_linear(kf_ctx* c, const kf_bf16* x, const kf_bf16* norm_w, float eps, int n_w, const kf_weight* const* w, kf_bf16* const* y,
@@ -939,30 +861,6 @@ int kf_linear_backward(kf_ctx* c, const kf_weight* w, const kf_bf16* deltaIn, co
     if (!deltaIn || !scratch || n < 1) return fail(KF_INVALID_ARGS, "kf_linear_backward: null deltaIn / scratch or n < 1");
     if ((gW && !inp) || (!delta && !gW && !gBias)) return fail(KF_INVALID_ARGS, "kf_linear_backward: gW needs inp; nothing to compute");
     const int OC = w->ne0, IC = w->ne1;
-    if (n >= lib_gemm_min() && lib_blas_ready(c)) { /* KF_GEMM_LIB=1 only */
-        // vendor GEMM on the dequantised weight; row-major operands are the transposed column-major ones, so no explicit transposes:
-        //   delta^T [IC x n]  = W^T-view [IC x OC] . deltaIn^T-view [OC x n]           gW^T [IC x OC] += inp^T-view [IC x n] . (deltaIn^T-view)^T [n x OC]
-        if (!al16(deltaIn) || (inp && !al16(inp)) || (delta && !al16(delta)) || (gW && !al16(gW)) || ((uintptr_t)scratch & 255))
-            return fail(KF_BLAS_UNALIGN, "kf_linear_backward: tensors must be 16-byte aligned, scratch 256-byte aligned");
-        uint16_t* const Wl = (uint16_t*)scratch; /* the dequantised weight, then the column-sum slabs: inside kf_linear_backward_scratch_bytes */
-        double* const slabs_l = (double*)((char*)scratch + up256((size_t)OC * IC * 2) + lbw_mid_bytes(OC, IC, n));
-        if (gBias) {
-            r = kf::colsum_add_launch(c->stream, deltaIn, gBias, n, OC, slabs_l);
-            if (r != KF_OK) return fail(r, "kf_linear_backward: bias column sums failed with %d", r);
-        }
-        if (delta) {
-            const uint16_t* Wd = (const uint16_t*)w->data;
-            r = KF_OK;
-            if (w->type != KF_BF16) r = kf::dequant_launch(c->stream, w, Wl), Wd = Wl;
-            if (r == KF_OK) r = lib_gemm(c, false, false, IC, n, OC, Wd, IC, deltaIn, OC, accumulate_delta ? 1.0f : 0.0f, delta, IC);
-            if (r != KF_OK) return fail(r, "kf_linear_backward: input-gradient GEMM (library) failed with %d", r);
-        }
-        if (gW) {
-            r = lib_gemm(c, false, true, IC, OC, n, inp, IC, deltaIn, OC, 1.0f, gW, IC);
-            if (r != KF_OK) return fail(r, "kf_linear_backward: weight-gradient GEMM (library) failed with %d", r);
-        }
-        return KF_OK;
-    }
     // the MFMA kernels contract over multiples of 64 and want 16-byte aligned rows
     if ((OC % 64) || OC < 128 || (IC % 8) || (gW && ((n % 64) || n < 128)))
         return fail(KF_INVALID_ARGS, "kf_linear_backward: OC (and n, for the weight gradient) must be multiples of 64 and >= 128, IC a multiple of 8 (got %d %d %d)", OC, IC, n);
@@ -1149,8 +1047,28 @@ int kf_engine_check(kf_ctx* c, kf_engine* e) {
     if (err) return fail(KF_INTERNAL_ERR, "kf_engine: a hand-off poll timed out (error word 0x%x): the launch was not fully resident", err);
     return KF_OK;
 }
-// diagnostic (not part of the ABI header): the per-phase stamps of a KF_ENG_DEBUG=<workgroup> run
+// ---- diagnostics (NOT part of the ABI header; tests and scratch/ only)
+// the per-phase stamps of one workgroup of the engine: enable (the diagnostic instantiation of the kernel serves the next launches), read
+int kfdbg_engine_stamps_enable(kf_engine* e, int wg) { return (e && e->h) ? kf::engine_debug_enable(e->h, wg) : -1; }
 int kfdbg_engine_stamps(kf_engine* e, unsigned long long* h_out, int n_words) { return (e && e->h) ? kf::engine_debug_read(e->h, h_out, n_words) : -1; }
+int kfdbg_engine_set_delays(kf_engine* e, const int* d6) {
+    if (!e || !e->h || !d6) return -1;
+    kf::engine_set_delays(e->h, d6);
+    return 0;
+}
+// development knobs (kf::Knobs): a kernel form against the form it replaces, inside one process
+int kfdbg_set_knob(const char* name, long value) {
+    if (!name) return -1;
+    kf::Knobs& k = kf::g_knobs;
+    if (!strcmp(name, "q4_perm")) k.q4_perm = (int)value;
+    else if (!strcmp(name, "q2_tab")) k.q2_tab = (int)value;
+    else if (!strcmp(name, "q1_tab")) k.q1_tab = (int)value;
+    else if (!strcmp(name, "gemv_waves")) k.gemv_waves = value;
+    else if (!strcmp(name, "gemv_stream")) k.gemv_stream = (int)value;
+    else if (!strcmp(name, "gemm_min")) k.gemm_min = (int)value;
+    else return -1;
+    return 0;
+}
 int kf_engine_destroy(kf_engine* e) {
     if (e) {
         kf::engine_free(e->h);

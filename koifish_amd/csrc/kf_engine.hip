@@ -1363,14 +1363,6 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
            (scratch/eng_ab.py): after the drains were removed 12,8,12,12,12,12 0.455 ms/step, 16,8,12,16,16,16 0.452, 20,12,16,20,20,20 0.464, 24,12,16,24,24,24 0.474 */
         const int dflt[6] = {16, 8, 12, 16, 16, 16};
         for (int i = 0; i < 6; i++) a.delay[i] = dflt[i];
-        if (const char* e = getenv("KF_ENG_DELAY")) { /* tuning runs */
-            int i = 0;
-            for (const char* q = e; *q && i < 6; i++) {
-                a.delay[i] = atoi(q);
-                while (*q && *q != ',') q++;
-                if (*q == ',') q++;
-            }
-        }
     }
     // The vectors that cross XCDs live in uncached device memory: an sc1 sweep of a cached (hipMalloc) line costs 75 ns per KB and CU, of an uncached one 43
     // (scratch/ub_handoff3.hip).  The XCD-local vectors (lqkv, lpart) stay in the caller's cached workspace: they are meant to live in that XCD's L2.
@@ -1385,11 +1377,6 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
         hipMemcpyAsync(const_cast<EngLayer*>(a.layers), tab.data(), tab.size() * sizeof(EngLayer), hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
         engine_release(E);
         return KF_HIP_CHECK;
-    }
-    if (const char* e = getenv("KF_ENG_DEBUG")) { /* diagnostic runs: per-phase wall-clock stamps of one workgroup (the DBG instantiation of the kernel) */
-        if (hipMalloc(&a.dbg, (size_t)d->n_layer * 2 * 16 * 8) != hipSuccess) a.dbg = nullptr;
-        if (a.dbg) (void)hipMemset(a.dbg, 0, (size_t)d->n_layer * 2 * 16 * 8);
-        a.dbg_wg = atoi(e);
     }
     // LDS
     int maxK = E->dim > E->q_dim ? E->dim : E->q_dim;
@@ -1407,6 +1394,22 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     return KF_OK;
 }
 void engine_free(EngineHost* E) { engine_release(E); }
+// diagnostic runs: per-phase wall-clock stamps of one workgroup (the DBG instantiation of the kernel)
+int engine_debug_enable(EngineHost* E, int wg) {
+    EngArgs& a = E->args;
+    if (!a.dbg) {
+        if (hipMalloc(&a.dbg, (size_t)a.n_layer * 2 * 16 * 8) != hipSuccess) {
+            a.dbg = nullptr;
+            return KF_HIP_CHECK;
+        }
+    }
+    (void)hipMemset(a.dbg, 0, (size_t)a.n_layer * 2 * 16 * 8);
+    a.dbg_wg = wg;
+    return KF_OK;
+}
+void engine_set_delays(EngineHost* E, const int* d6) {
+    for (int i = 0; i < 6; i++) E->args.delay[i] = d6[i];
+}
 int engine_debug_read(EngineHost* E, unsigned long long* h_out, int n_words) {
     if (!E->args.dbg) return 0;
     const int have = E->args.n_layer * 2 * 16;

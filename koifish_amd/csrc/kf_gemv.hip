@@ -17,6 +17,8 @@
 
 namespace kf {
 
+Knobs g_knobs;
+
 template <int G, bool PAIRED, bool LUT>
 struct Batch {
     u32x4 w[G];
@@ -589,7 +591,7 @@ int gemv_launch(hipStream_t st, GemvLaunch& L) {
     // the largest launches (>= 4 M blocks: the 25600-row FFN matrices of Qwen3-32B): two slots per wave through the buffer-load form, half the workgroups to
     // start and half the x staging (25600 x 5120: 27.6 -> 26.4 us, A/B in one run; smaller launches lose more from the coarser tail than they gain)
     if (L.target_waves <= 0 && blocks_all >= 4000000L && !a.row_map && fmt != FMT_Q4R) target_waves = 8192;
-    if (const char* e = getenv("KF_GEMV_WAVES")) target_waves = atol(e); /* tuning knob */
+    if (g_knobs.gemv_waves > 0) target_waves = g_knobs.gemv_waves;
     long spw = (raw_slots + target_waves - 1) / target_waves;
     if (spw < 1) spw = 1;
     int G = spw >= 4 ? 4 : (spw >= 2 ? 2 : 1);
@@ -613,7 +615,7 @@ int gemv_launch(hipStream_t st, GemvLaunch& L) {
         const unsigned long long reach = ((unsigned long long)max_rows + (unsigned long long)(spw + G) * RPS) * nBlk * 16ull;
         const bool groups_ok = fmt < FMT_Q4 || (K % a.lGroup) == 0;
         if (reach < (1ull << 31) && groups_ok) a.stream_ok = 1;
-        if (const char* e = getenv("KF_GEMV_STREAM")) a.stream_ok = a.stream_ok && atoi(e) != 0; /* A/B knob */
+        a.stream_ok = a.stream_ok && g_knobs.gemv_stream != 0;
     }
     const long waves = (slots + spw - 1) / spw;
     const int blocks = (int)((waves + 3) / 4);
@@ -626,20 +628,16 @@ int gemv_launch(hipStream_t st, GemvLaunch& L) {
         case FMT_F8: launch_m<FMT_F8>(a, L.mode, G, grid, smem, st); break;
         case FMT_Q4: {
             // table-lookup form whenever a 128-weight group is exactly one aligned quad of lanes: bit-identical to the arithmetic form (same
-            // weights, same pairing, same summation order), 20 % fewer VALU instructions per weight (KF_Q4_PERM=0 switches it off)
-            static int q4perm = -2;
-            if (q4perm == -2) q4perm = getenv("KF_Q4_PERM") ? atoi(getenv("KF_Q4_PERM")) : -1;
+            // weights, same pairing, same summation order), 20 % fewer VALU instructions per weight
             const bool geom_ok = a.lGroup == 128 && (K % 128) == 0 && lpr_log2 >= 2;
-            if (geom_ok && q4perm != 0)
+            if (geom_ok && g_knobs.q4_perm != 0)
                 launch_m<FMT_Q4P>(a, L.mode, G, grid, smem, st);
             else
                 launch_m<FMT_Q4>(a, L.mode, G, grid, smem, st);
             break;
         }
         case FMT_Q2: {
-            static int q2tab = -2; /* KF_Q2_TAB=0: the arithmetic form (same bits) */
-            if (q2tab == -2) q2tab = getenv("KF_Q2_TAB") ? atoi(getenv("KF_Q2_TAB")) : 1;
-            if (q2tab != 0 && smem + 2048 <= 160 * 1024)
+            if (g_knobs.q2_tab != 0 && smem + 2048 <= 160 * 1024)
                 launch_m<FMT_Q2T>(a, L.mode, G, grid, smem + 2048, st);
             else
                 launch_m<FMT_Q2>(a, L.mode, G, grid, smem, st);
@@ -647,9 +645,7 @@ int gemv_launch(hipStream_t st, GemvLaunch& L) {
         }
         case FMT_Q4R: launch_m<FMT_Q4R>(a, L.mode, G, grid, smem, st); break;
         default: {
-            static int q1tab = -2; /* KF_Q1_TAB=0: the per-bit select form (same bits) */
-            if (q1tab == -2) q1tab = getenv("KF_Q1_TAB") ? atoi(getenv("KF_Q1_TAB")) : 1;
-            if (q1tab != 0 && smem + 4096 <= 160 * 1024)
+            if (g_knobs.q1_tab != 0 && smem + 4096 <= 160 * 1024)
                 launch_m<FMT_Q1T>(a, L.mode, G, grid, smem + 4096, st);
             else
                 launch_m<FMT_Q1>(a, L.mode, G, grid, smem, st);

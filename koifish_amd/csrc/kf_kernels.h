@@ -76,7 +76,7 @@ int tp_reduce_recv_launch(hipStream_t st, const unsigned long long* slots, int R
 int tp_argmax_push_launch(hipStream_t st, const float* val, const int* idx, int n, int row0, unsigned long long* const* peers, int R, const unsigned* d_step,
                           unsigned per_step, unsigned index);
 int tp_pick_launch(hipStream_t st, const unsigned long long* pairs, int R, unsigned* d_step, unsigned per_step, unsigned index, int32_t* d_state, int32_t* d_tokens_out,
-                   int* d_err);
+                   int* d_err, int vocab);
 int gemv_lpr_log2(int nBlk, long rows); /* lanes per row of a mat-vec launch (kf_gemv.hip) */
 int gemv_fmt_of(const kf_weight* w);    /* FMT_* of a weight, < 0: not served by the mat-vec kernel */
 void argmax_finish_launch(hipStream_t st, const float* val, const int* idx, int n, int32_t* d_argmax, int32_t* d_state, int32_t* d_tokens_out);
@@ -124,6 +124,17 @@ int qknorm_rope_launch(hipStream_t st, uint16_t* q, uint16_t* k, const uint16_t*
 
 // ---- persistent decode engine (kf_engine.hip)
 struct EngineHost;
+// Development knobs (process-wide, default = the product's choice).  Not part of the ABI and never read from the environment: tests and the scripts under
+// scratch/ set them through kfdbg_set_knob (kf_abi.hip) to compare a kernel form with the form it replaces inside one process.
+struct Knobs {
+    int q4_perm = 1;      /* 4-bit mat-vec through the register-table lookup (0: the arithmetic form; same bits) */
+    int q2_tab = 1;       /* 2-bit mat-vec through the LDS selector table (0: the arithmetic form; same bits) */
+    int q1_tab = 1;       /* 1-bit mat-vec through the LDS selector table (0: the per-bit select form; same bits) */
+    long gemv_waves = 0;  /* > 0: waves a mat-vec launch aims for (0: the launcher's rule) */
+    int gemv_stream = 1;  /* buffer-load form of the long mat-vec launches (0: off) */
+    int gemm_min = 8;     /* token rows from which the MFMA tile kernels replace the per-token mat-vec loop */
+};
+extern Knobs g_knobs;
 size_t engine_ws_bytes(const kf_engine_desc* d);
 int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t st, EngineHost** out);
 int engine_step(EngineHost* E, hipStream_t st, const uint16_t* x_in, uint16_t* x_out, const int32_t* d_state, int pos_bound, int with_head = 0); /* 1: not served */
@@ -132,7 +143,9 @@ int engine_set_embedding(EngineHost* E, const kf_weight* w, const int32_t* d_for
 int engine_error_word(EngineHost* E, hipStream_t st, int* h_err);
 int engine_reset(EngineHost* E, hipStream_t st); /* after a timed-out poll: exchange state re-initialised, error word cleared */
 void engine_free(EngineHost* E);
-int engine_debug_read(EngineHost* E, unsigned long long* h_out, int n_words); /* KF_ENG_DEBUG runs */
+int engine_debug_read(EngineHost* E, unsigned long long* h_out, int n_words);
+int engine_debug_enable(EngineHost* E, int wg);       /* per-phase stamps of workgroup wg from the next launch on (the diagnostic instantiation of the kernel) */
+void engine_set_delays(EngineHost* E, const int* d6); /* tuning runs */
 
 // ---- small ops (kf_ops.hip)
 int rmsnorm_launch(hipStream_t st, const uint16_t* x, const uint16_t* w, uint16_t* y, int rows, int dim, float eps, float* rstd);

@@ -96,7 +96,7 @@ int tp_argmax_push_launch(hipStream_t st, const float* val, const int* idx, int 
 // (max, index) pairs of all ranks -> first maximum (lowest index among equals; sample_argmax, GoPT.cpp:602-612), the decode-state update of
 // argmax_finish_kernel, and the generation word moves on.
 __global__ void tp_pick_kernel(const unsigned long long* __restrict__ pairs, int R, unsigned* __restrict__ d_step, unsigned per_step, unsigned index,
-                               int32_t* __restrict__ d_state, int32_t* __restrict__ d_tokens_out, int* __restrict__ d_err) {
+                               int32_t* __restrict__ d_state, int32_t* __restrict__ d_tokens_out, int* __restrict__ d_err, int vocab) {
     if (threadIdx.x != 0) return;
     const unsigned tag = *d_step * per_step + index + 1u;
     float bv = -__builtin_inff();
@@ -118,16 +118,24 @@ __global__ void tp_pick_kernel(const unsigned long long* __restrict__ pairs, int
         const int i = (int)(unsigned)g[1];
         if (v > bv || (v == bv && i < bi)) bv = v, bi = i;
     }
-    const int p = d_state[1];
-    if (d_tokens_out) d_tokens_out[p] = bi;
-    d_state[0] = bi;
-    d_state[1] = p + 1;
-    d_state[2] = bi;
+    // A timed-out exchange (this poll or an earlier one of the step: d_err is set) leaves stale pairs: the decode state is NOT advanced with them -- the id would
+    // feed the next step's embedding lookup -- and an index outside the vocabulary is refused the same way.  The generation word still advances, so that every
+    // rank keeps forming the same tags; the host sees the error word at its next check (kfh_tp_check) and the ids behind it are void.
+    const int err = __hip_atomic_load(d_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (err == 0 && bi >= 0 && bi < vocab) {
+        const int p = d_state[1];
+        if (d_tokens_out) d_tokens_out[p] = bi;
+        d_state[0] = bi;
+        d_state[1] = p + 1;
+        d_state[2] = bi;
+    } else if (err == 0) {
+        atomicExch(d_err, 201);
+    }
     *d_step = *d_step + 1u;
 }
 int tp_pick_launch(hipStream_t st, const unsigned long long* pairs, int R, unsigned* d_step, unsigned per_step, unsigned index, int32_t* d_state, int32_t* d_tokens_out,
-                   int* d_err) {
-    hipLaunchKernelGGL(tp_pick_kernel, dim3(1), dim3(64), 0, st, pairs, R, d_step, per_step, index, d_state, d_tokens_out, d_err);
+                   int* d_err, int vocab) {
+    hipLaunchKernelGGL(tp_pick_kernel, dim3(1), dim3(64), 0, st, pairs, R, d_step, per_step, index, d_state, d_tokens_out, d_err, vocab);
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 

@@ -761,10 +761,27 @@ int kfh_engine_steps(void* h) {
     Fish* f = reinterpret_cast<Fish*>(h);
     return f->engine_state < 0 ? -1 : f->engine_steps;
 }
+// diagnostics (scratch/eng_stamps.py, scratch/eng_ab.py): per-phase stamps of one workgroup of the engine; the first-sweep delays of its hand-offs
 extern "C" int kfdbg_engine_stamps(kf_engine* e, unsigned long long* h_out, int n_words);
+extern "C" int kfdbg_engine_stamps_enable(kf_engine* e, int wg);
+extern "C" int kfdbg_engine_set_delays(kf_engine* e, const int* d6);
 int kfh_engine_stamps(void* h, unsigned long long* out, int n) {
     Fish* f = reinterpret_cast<Fish*>(h);
     return f->engine ? kfdbg_engine_stamps(f->engine, out, n) : -1;
+}
+int kfh_engine_stamps_enable(void* h, int wg) {
+    Fish* f = reinterpret_cast<Fish*>(h);
+    if (f->engine_state == 0) f->EnsureEngine();
+    for (auto& g : f->graphs)
+        if (g) kf_graph_destroy(g), g = nullptr; /* captured launches hold the product instantiation */
+    return f->engine ? kfdbg_engine_stamps_enable(f->engine, wg) : -1;
+}
+int kfh_engine_set_delays(void* h, const int* d6) {
+    Fish* f = reinterpret_cast<Fish*>(h);
+    if (f->engine_state == 0) f->EnsureEngine();
+    for (auto& g : f->graphs)
+        if (g) kf_graph_destroy(g), g = nullptr;
+    return f->engine ? kfdbg_engine_set_delays(f->engine, d6) : -1;
 }
 // n launches of the engine alone at the position d_state holds (bench.py times the kernel with events around this); the residual stream is
 // re-read from the embedding each time so that the values stay those of a real step

@@ -47,7 +47,7 @@ def load():
                 raise KFError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
                               "koifish_amd has no CPU fallback." % p)
         hip = C.CDLL(LIB_HIP, mode=C.RTLD_GLOBAL)
-        host = C.CDLL(LIB_HOST)
+        host = C.CDLL(os.environ.get("KF_HOST_LIB", LIB_HOST))   # KF_HOST_LIB: the sanitizer build of the host library (tests/test_host_asan_cpu.py)
         hip.kf_last_error.restype = C.c_char_p
         hip.kf_version.restype = C.c_char_p
         hip.kf_attn_scratch_bytes.restype = C.c_size_t

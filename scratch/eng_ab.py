@@ -1,5 +1,5 @@
 """A/B of engine knobs inside ONE box: decode ms/step and engine-only us per launch at the long positions, per environment setting.
-   python scratch/eng_ab.py "KF_ENG_DELAY=0,0,0,0,0,0" "KF_ENG_DELAY=12,4,8,10,12,12" ...   (each argument: space-separated NAME=VALUE pairs; '-' = no change)
+   python scratch/eng_ab.py "ENG_DELAY=0,0,0,0,0,0" "ENG_DELAY=12,4,8,10,12,12" ...   (each argument: space-separated NAME=VALUE pairs; '-' = no change)
 Every setting runs in a child process (the knobs are read when the engine is built)."""
 import json
 import os
@@ -18,6 +18,13 @@ cfg = synth.CONFIGS["qwen3-0.6b"]
 m = synth.build_on_gpu(cfg, seed=1234)
 forced = np.random.default_rng(7).integers(0, cfg["vocab"], size=cfg["max_seq"]).astype(np.int32)
 m.set_forced(forced)
+if os.environ.get("ENG_DELAY"):
+    d = (C.c_int * 6)(*[int(v) for v in os.environ["ENG_DELAY"].split(",")])
+    assert m.host.kfh_engine_set_delays(m.h, d) == 0
+for kv in os.environ.get("KF_KNOBS", "").split():
+    k, v = kv.split("=")
+    m.hip.kfdbg_set_knob.argtypes = [C.c_char_p, C.c_long]
+    assert m.hip.kfdbg_set_knob(k.encode(), int(v)) == 0
 pos0 = 1900
 m.set_state(int(forced[pos0]), pos0)
 m.run_steps(pos0, 20, True)   # warm: graph of the bucket

@@ -1,5 +1,5 @@
-"""Per-phase wall-clock stamps of one workgroup of the persistent decode engine (KF_ENG_DEBUG=<workgroup id>): where a layer's time goes.
-   KF_ENG_DEBUG=77 python scratch/eng_stamps.py [pos]"""
+"""Per-phase wall-clock stamps of one workgroup of the persistent decode engine (the diagnostic instantiation of the kernel): where a layer's time goes.
+   STAMP_WG=77 [ENG_DELAY=16,8,12,16,16,16] python scratch/eng_stamps.py [pos]"""
 import ctypes as C
 import os
 import sys
@@ -16,6 +16,10 @@ cfg = synth.CONFIGS["qwen3-0.6b"]
 m = synth.build_on_gpu(cfg, seed=1234)
 forced = np.random.default_rng(7).integers(0, cfg["vocab"], size=cfg["max_seq"]).astype(np.int32)
 m.set_forced(forced)
+if os.environ.get("ENG_DELAY"):
+    d = (C.c_int * 6)(*[int(v) for v in os.environ["ENG_DELAY"].split(",")])
+    assert m.host.kfh_engine_set_delays(m.h, d) == 0
+assert m.host.kfh_engine_stamps_enable(m.h, int(os.environ.get("STAMP_WG", "77"))) == 0
 m.set_state(int(forced[pos - 4]), pos - 4)
 m.run_steps(pos - 4, 4, True)
 m.sync()

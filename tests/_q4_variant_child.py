@@ -1,5 +1,5 @@
-"""Child process of tests/test_gpu_q4_variants.py: the 4-bit mat-vec under whatever KF_Q4_PERM the parent set (the knob is read once
-per process), plain / fused-norm / SwiGLU-pair / arg-max entries, against the oracle.  Exits non-zero on the first mismatch."""
+"""Child process of tests/test_gpu_q4_variants.py: the 4-bit mat-vec in the form argv[1] selects (kfdbg_set_knob("q4_perm", 0 | 1)),
+plain / fused-norm / SwiGLU-pair / arg-max entries, against the oracle.  Exits non-zero on the first mismatch."""
 import os
 import sys
 
@@ -21,7 +21,10 @@ def ulp(a, b):
 
 
 def main():
+    import ctypes as C
     ctx = Context(0)
+    ctx.hip.kfdbg_set_knob.argtypes = [C.c_char_p, C.c_long]
+    assert ctx.hip.kfdbg_set_knob(b"q4_perm", int(sys.argv[1]) if len(sys.argv) > 1 else 1) == 0
     dev = ctx.device
     rng = np.random.default_rng(77)
     bf = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int16)).to(dev).view(torch.bfloat16)

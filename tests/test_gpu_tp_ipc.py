@@ -3,6 +3,7 @@ as it does across xGMI -- kernels of one process storing into memory another pro
 (and therefore the oracle's TP emulation, tests/test_gpu_tp.py)."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -17,10 +18,21 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def test_two_processes_exchange_through_ipc_mapped_areas(tmp_path):
     out = str(tmp_path / "ids.json")
+    for r in range(2):   # a stale result of an earlier (timed-out) run must not pass for this one's
+        if os.path.exists("%s.%d" % (out, r)):
+            os.remove("%s.%d" % (out, r))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "_tp_ipc_child.py"), out]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
