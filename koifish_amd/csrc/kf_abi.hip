@@ -20,6 +20,7 @@ struct kf_ctx {
     bool capturing;
     float* amax_val; /* per-workgroup partial maxima for kf_lm_head when the caller passes no scratch */
     int* amax_idx;
+    int canonical;    /* 1 (default): the decode kernels sum in the canonical order of oracle/kf_oracle.c section 4c (bit-exact against the oracle); 0: v_dot2c forms */
     void* scratch;    /* caller-owned workspace of kf_linear (kf_set_scratch): AWQ slice partials, or a weight dequantised to bf16 */
     size_t scratch_bytes;
 };
@@ -76,6 +77,7 @@ int kf_init(int device, void* stream, kf_ctx** out) {
     HIPCHK(hipMalloc(&c->amax_val, sizeof(float) * kf::KF_MAX_ARGMAX_PARTIALS));
     HIPCHK(hipMalloc(&c->amax_idx, sizeof(int) * kf::KF_MAX_ARGMAX_PARTIALS));
     c->scratch = nullptr, c->scratch_bytes = 0;
+    c->canonical = 1;
     *out = c;
     return KF_OK;
 }
@@ -254,7 +256,7 @@ int kf_quantize(kf_ctx* c, const kf_weight* w, const kf_bf16* src, int symmetric
     RET(kf::quantize_launch(c->stream, w, src, symmetric));
 }
 
-static void init_args(kf::GemvLaunch& L) { memset(&L, 0, sizeof(L)); L.args.alpha = 1.0f; }
+static void init_args(kf_ctx* c, kf::GemvLaunch& L) { memset(&L, 0, sizeof(L)); L.args.alpha = 1.0f; L.canon = c->canonical; }
 
 static const int KF_DEQ_GEMM_MIN = 2048; /* token rows from which a quantised weight is dequantised once and multiplied by the bf16 tile kernel (when scratch was handed over) */
 size_t kf_linear_scratch_bytes(const kf_weight* w, int nTok) {
@@ -265,6 +267,13 @@ size_t kf_linear_scratch_bytes(const kf_weight* w, int nTok) {
     if (w->type != KF_BF16 && nTok >= KF_DEQ_GEMM_MIN && w->ne0 >= 256 && (w->ne1 % 64) == 0) return (size_t)w->ne0 * w->ne1 * 2;
     return 0;
 }
+int kf_set_canonical(kf_ctx* c, int on) {
+    CHKCTX(c);
+    if (c->capturing) return fail(KF_INVALID_ARGS, "kf_set_canonical: not while capturing");
+    c->canonical = on ? 1 : 0;
+    return KF_OK;
+}
+int kf_get_canonical(kf_ctx* c) { return c ? c->canonical : 0; }
 int kf_set_scratch(kf_ctx* c, void* scratch, size_t bytes) {
     CHKCTX(c);
     if (scratch && !al16(scratch)) return fail(KF_BLAS_UNALIGN, "kf_set_scratch: unaligned");
@@ -339,7 +348,7 @@ int kf_linear(kf_ctx* c, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const
     }
     for (int t = 0; t < nTok; t++) {
         kf::GemvLaunch L;
-        init_args(L);
+        init_args(c, L);
         L.n = 1, L.w[0] = w, L.mode = kf::GEMV_PLAIN;
         L.args.x = x + (size_t)t * w->ne1, L.args.job[0].y = y + (size_t)t * w->ne0;
         L.args.bias = bias, L.args.alpha = alpha, L.args.beta = beta;
@@ -356,7 +365,7 @@ int kf_linear_f32(kf_ctx* c, const kf_weight* w, const kf_bf16* x, float* y) {
     if (r) return r;
     if (!x || !y || !al16(x)) return fail(KF_BLAS_UNALIGN, "kf_linear_f32: x/y null or x unaligned");
     kf::GemvLaunch L;
-    init_args(L);
+    init_args(c, L);
     L.n = 1, L.w[0] = w, L.mode = kf::GEMV_PLAIN;
     L.args.x = x, L.args.yf = y, L.args.job[0].y = nullptr;
     RET(kf::gemv_launch(c->stream, L));
@@ -440,7 +449,7 @@ int kf_linear_f32_push(kf_ctx* c, const kf_weight* w, const kf_bf16* x, const kf
     if (!x || !al16(x)) return fail(KF_BLAS_UNALIGN, "kf_linear_f32_push: x null or unaligned");
     if (w->ne0 > t->n_max || index + 1 >= t->per_step) return fail(KF_INVALID_ARGS, "kf_linear_f32_push: %d rows / index %u do not fit the comm", w->ne0, index);
     kf::GemvLaunch L;
-    init_args(L);
+    init_args(c, L);
     L.n = 1, L.w[0] = w, L.mode = kf::GEMV_PLAIN;
     L.args.x = x, L.args.job[0].y = nullptr;
     if (!t->d_push) return fail(KF_INVALID_ARGS, "kf_linear_f32_push: kf_tp_commit has not been called");
@@ -463,7 +472,7 @@ int kf_tp_lm_head(kf_ctx* c, const kf_bf16* x, const kf_bf16* norm_w, float eps,
     float* av = scratch ? (float*)scratch : c->amax_val;
     int* ai = scratch ? (int*)((float*)scratch + kf::KF_MAX_ARGMAX_PARTIALS) : c->amax_idx;
     kf::GemvLaunch L;
-    init_args(L);
+    init_args(c, L);
     L.n = 1, L.w[0] = w, L.mode = kf::GEMV_ARGMAX;
     L.args.x = x, L.args.norm_w = norm_w, L.args.eps = eps, L.args.job[0].y = logits;
     L.args.amax_val = av, L.args.amax_idx = ai;
@@ -488,7 +497,7 @@ int kf_norm_linear(kf_ctx* c, const kf_bf16* x, const kf_bf16* norm_w, float eps
     if (n_w < 1 || n_w > 3 || !w || !y) return fail(KF_INVALID_ARGS, "kf_norm_linear: n_w=%d", n_w);
     if (!x || !al16(x) || (norm_w && !al16(norm_w))) return fail(KF_BLAS_UNALIGN, "kf_norm_linear: x/norm_w null or unaligned");
     kf::GemvLaunch L;
-    init_args(L);
+    init_args(c, L);
     L.n = n_w, L.mode = kf::GEMV_PLAIN;
     for (int i = 0; i < n_w; i++) {
         int r = check_weight(w[i], "kf_norm_linear");
@@ -510,7 +519,7 @@ int kf_norm_gateup_swiglu(kf_ctx* c, const kf_bf16* x, const kf_bf16* norm_w, fl
     if (r) return r;
     if (!x || !act || !al16(x)) return fail(KF_BLAS_UNALIGN, "kf_norm_gateup_swiglu: x/act");
     kf::GemvLaunch L;
-    init_args(L);
+    init_args(c, L);
     L.n = 2, L.w[0] = gate, L.w[1] = up, L.mode = kf::GEMV_PAIRED;
     L.args.x = x, L.args.norm_w = norm_w, L.args.eps = eps, L.args.job[0].y = act;
     RET(kf::gemv_launch(c->stream, L));
@@ -531,7 +540,7 @@ int kf_linear_masked(kf_ctx* c, const kf_weight* w, const kf_bf16* x, kf_bf16* y
     r = kf::cold_fill_launch(c->stream, y, bias, w->ne0); /* cold rows: 0 (+ bias); the hot rows are overwritten below */
     if (r != KF_OK || n_hot == 0) RET(r);
     kf::GemvLaunch L;
-    init_args(L);
+    init_args(c, L);
     L.n = 1, L.w[0] = w, L.mode = kf::GEMV_PLAIN, L.n_hot = n_hot;
     L.args.x = x, L.args.job[0].y = y, L.args.bias = bias, L.args.row_map = d_rows;
     RET(kf::gemv_launch(c->stream, L));
@@ -547,7 +556,7 @@ int kf_norm_gateup_swiglu_masked(kf_ctx* c, const kf_bf16* x, const kf_bf16* nor
     r = kf::cold_fill_launch(c->stream, act, nullptr, gate->ne0); /* SwiGLU of two zero projections is zero */
     if (r != KF_OK || n_hot == 0) RET(r);
     kf::GemvLaunch L;
-    init_args(L);
+    init_args(c, L);
     L.n = 2, L.w[0] = gate, L.w[1] = up, L.mode = kf::GEMV_PAIRED, L.n_hot = n_hot;
     L.args.x = x, L.args.norm_w = norm_w, L.args.eps = eps, L.args.job[0].y = act, L.args.row_map = d_rows;
     RET(kf::gemv_launch(c->stream, L));
@@ -579,7 +588,7 @@ int kf_qknorm_rope(kf_ctx* c, kf_bf16* q, kf_bf16* k, const kf_bf16* wq, const k
     RET(kf::qknorm_rope_launch(c->stream, q, k, wq, wk, table, pos, d_pos, n_head, n_kv, hd, eps));
 }
 
-static size_t attn_part_bytes(int n_head, int hd) { return sizeof(float) * (size_t)n_head * kf::KF_ATTN_MAX_SPLITS * (hd + 4); }
+static size_t attn_part_bytes(int n_head, int hd) { return sizeof(double) * (size_t)n_head * kf::KF_ATTN_MAX_SPLITS * (hd + 2); } /* {O[hd], L, m} fp64 per (head, slice) */
 size_t kf_attn_scratch_bytes(int n_head, int hd) { return attn_part_bytes(n_head, hd) + kf::KF_ATTN_CNT_BYTES; /* + arrival counters */ }
 
 int kf_attn_decode(kf_ctx* c, const kf_bf16* q, const kf_bf16* kc, const kf_bf16* vc, kf_bf16* out, int pos, const int32_t* d_pos, int n_head, int n_kv, int hd,
@@ -791,7 +800,7 @@ static int head_impl(kf_ctx* c, const kf_bf16* x, const kf_bf16* norm_w, float e
     kf_bf16* lg = logits;
     if (!lg) return fail(KF_INVALID_ARGS, "%s: logits buffer required (vocab*2 bytes)", who);
     kf::GemvLaunch L;
-    init_args(L);
+    init_args(c, L);
     L.n = 1, L.w[0] = w, L.mode = kf::GEMV_ARGMAX;
     L.args.x = x, L.args.norm_w = norm_w, L.args.eps = eps, L.args.job[0].y = lg;
     L.args.amax_val = av, L.args.amax_idx = ai;

@@ -10,10 +10,9 @@
 // CU_rope2_v0 operator.cuh:734-772) is folded into the prologue; the workgroup whose slice holds the new
 // position writes the normed+roped key into the cache row.  HBM-bound: bytes = 2 * (pos+1) * kv_dim * 2.
 //
-// Arithmetic (= oracle/kf_oracle.c kfo_attn_decode mode FUSED up to fp32 summation order): score =
-// bf16(dot / sqrtf(hd)) -- the same bf16 store the reference makes (qk_v is floatX) -- then an fp32 softmax with
-// exp evaluated as v_exp_f32(x * log2 e) (<= 2 ulp from the oracle's exp: far inside the attention tolerance) and a single
-// bf16 store of out = (sum e_t v_t) * (1 / sum e_t).
+// Arithmetic (= oracle/kf_oracle.c kfo_attn_decode mode CANON, bit for bit; kf_attn_common.h states it): score = bf16(dot * (1 / sqrtf(hd))) -- the same
+// bf16 store the reference makes (qk_v is floatX) -- with the dot as per-lane chains of v_fma_f32 + a tree; softmax weights as f * 2^(n - m) from a fixed
+// polynomial with exact power-of-two rescales between lanes, waves and slices; fp64 sums; one bf16 store of out = (float)(O / L).
 //
 // Cross-workgroup hand-off (MI355X_MICROARCH.md "Valid forms", table row 1): partials are written with
 // agent-scope relaxed atomic stores (write-through `sc1`), every storing wave drains vmcnt, the workgroup
@@ -30,12 +29,11 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int hd = HD, hd_log2 = HD == 128 ? 7 : 6; /* head_dim 64 or 128: compile-time, so that the lane-group reductions are straight-line code */
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int PS = hd + 4; /* {acc[hd], m, l, pad, pad} */
-    uint16_t* qb = reinterpret_cast<uint16_t*>(smem_raw);  // [GQ][hd] prepared q, bf16 bits
+    constexpr int PS = hd + 2; /* {O[hd], L, m} as doubles */
+    double* comb = reinterpret_cast<double*>(smem_raw);        // [NW][GQ][PS]
+    uint16_t* qb = reinterpret_cast<uint16_t*>(comb + NW * GQ * PS);  // [GQ][hd] prepared q, bf16 bits
     uint16_t* knew = qb + GQ * hd;                         // [hd]
-    float* wmax = reinterpret_cast<float*>(knew + hd);     // [NW][GQ]
-    int* flag = reinterpret_cast<int*>(wmax + NW * GQ);
-    float* comb = reinterpret_cast<float*>(flag + 4);  // [NW][GQ][PS]
+    int* flag = reinterpret_cast<int*>(knew + hd);
 
     const int split = blockIdx.x, kvh = blockIdx.y, nsp = a.n_splits;
     // token batch (prefill): blockIdx.z = token, one slice per kv-head, position pos0 + token, q / out rows q_stride apart
@@ -89,6 +87,7 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
     int t1 = t0 + chunk;
     if (t1 > len) t1 = len;
     const bool empty = t0 >= len;
+    double* const part = reinterpret_cast<double*>(a.part); /* [n_head][n_splits][PS] doubles */
 
     if (!empty) {
         // ---- prologue: q heads of this group, and the new key when it lies in this slice
@@ -103,137 +102,59 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
             uint16_t* krow = a.kcache + (size_t)pos * a.kv_stride + (size_t)kvh * hd;
             for (int i = tid; i < hd; i += blockDim.x) krow[i] = knew[i];
         }
-        u32x4 qreg[GQ]; /* this lane's 8 dims of every q head, packed bf16 */
-#pragma unroll
-        for (int hq = 0; hq < GQ; hq++) qreg[hq] = *reinterpret_cast<const u32x4*>(qb + hq * hd + d0);
-
-        float M[GQ], l[GQ], acc[GQ][8];
+        float qf[GQ][8]; /* this lane's 8 dims of every q head */
 #pragma unroll
         for (int hq = 0; hq < GQ; hq++) {
-            M[hq] = -__builtin_inff(), l[hq] = 0.f;
+            const u32x4 qv = *reinterpret_cast<const u32x4*>(qb + hq * hd + d0);
+            const uint32_t q4[4] = {qv.x, qv.y, qv.z, qv.w};
 #pragma unroll
-            for (int i = 0; i < 8; i++) acc[hq][i] = 0.f;
+            for (int i = 0; i < 4; i++) qf[hq][2 * i] = bf_lo(q4[i]), qf[hq][2 * i + 1] = bf_hi(q4[i]);
         }
+        CanonAcc<GQ> A;
+        A.init();
         const float rden = 1.0f / a.inv_sqrt_hd_den; /* score /= sqrtf(head_dim) (operator.cuh:630), as a multiply by the rounded reciprocal */
         for (int tb = tstart; tb - grp - wave * KPW < t1; tb += ATTN_U * tstride) { /* workgroup-uniform trip count */
             u32x4 ck[ATTN_U], cv[ATTN_U];
-#pragma unroll
-            for (int u = 0; u < ATTN_U; u++) ck[u] = kk[u], cv[u] = vv[u];
-            if (tb - grp - wave * KPW + ATTN_U * tstride < t1) issue(tb + ATTN_U * tstride, t1);
-            // scores of this batch
-            float s[ATTN_U][GQ], bm[GQ];
-#pragma unroll
-            for (int hq = 0; hq < GQ; hq++) bm[hq] = -__builtin_inff();
+            bool valid[ATTN_U];
 #pragma unroll
             for (int u = 0; u < ATTN_U; u++) {
                 const int t = tb + u * tstride;
-                const bool valid = t < t1;
-                u32x4 kw = ck[u];
-                if (has_new && valid && t == pos) kw = *reinterpret_cast<const u32x4*>(knew + d0);
-#pragma unroll
-                for (int hq = 0; hq < GQ; hq++) {
-                    float d = dot2_bf16(qreg[hq].x, kw.x, 0.f);
-                    d = dot2_bf16(qreg[hq].y, kw.y, d);
-                    d = dot2_bf16(qreg[hq].z, kw.z, d);
-                    d = dot2_bf16(qreg[hq].w, kw.w, d);
-                    d = group_sum16(d, lpk_log2);
-                    d = round_bf16(d * rden);
-                    s[u][hq] = valid ? d : -__builtin_inff();
-                    bm[hq] = fmaxf(bm[hq], s[u][hq]);
-                }
+                ck[u] = kk[u], cv[u] = vv[u], valid[u] = t < t1;
+                if (has_new && valid[u] && t == pos) ck[u] = *reinterpret_cast<const u32x4*>(knew + d0);
             }
-            // workgroup-wide maximum of the batch -> one running maximum shared by every lane
-#pragma unroll
-            for (int hq = 0; hq < GQ; hq++) {
-                bm[hq] = xmax32(xmax16(bm[hq]));
-                if (LPK < 16) bm[hq] = fmaxf(bm[hq], dpp_f<0x128>(bm[hq]));
-            }
-            __syncthreads(); /* previous batch's readers of wmax are done */
-            if (lane == 0) {
-#pragma unroll
-                for (int hq = 0; hq < GQ; hq++) wmax[wave * GQ + hq] = bm[hq];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int hq = 0; hq < GQ; hq++) {
-                float Mb = wmax[hq];
-#pragma unroll
-                for (int w2 = 1; w2 < NW; w2++) Mb = fmaxf(Mb, wmax[w2 * GQ + hq]);
-                if (Mb > M[hq]) {
-                    const float sc = fast_exp(M[hq] - Mb);
-                    l[hq] *= sc;
-#pragma unroll
-                    for (int i = 0; i < 8; i++) acc[hq][i] *= sc;
-                    M[hq] = Mb;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < ATTN_U; u++) {
-                float vf_[8];
-                const uint32_t vw[4] = {cv[u].x, cv[u].y, cv[u].z, cv[u].w};
-#pragma unroll
-                for (int i = 0; i < 4; i++) vf_[2 * i] = bf_lo(vw[i]), vf_[2 * i + 1] = bf_hi(vw[i]);
-#pragma unroll
-                for (int hq = 0; hq < GQ; hq++) {
-                    const float p = fast_exp(s[u][hq] - M[hq]); /* -inf (masked key) -> 0 */
-                    l[hq] += p;
-#pragma unroll
-                    for (int i = 0; i < 8; i++) acc[hq][i] = fmaf(p, vf_[i], acc[hq][i]);
-                }
-            }
+            if (tb - grp - wave * KPW + ATTN_U * tstride < t1) issue(tb + ATTN_U * tstride, t1);
+            canon_batch<GQ, LPK>(A, qf, ck, cv, valid, lpk_log2, rden);
         }
-
-        // ---- sum the key groups (same reference maximum everywhere: plain sums).  Inside the wave a reduce-scatter by row swaps:
-        // swapping the halves of (acc[i], acc[i+4]) and adding leaves dims i in lanes 0-31 and i+4 in lanes 32-63, the same on 16-lane
-        // rows leaves row R with the totals of dims 2R and 2R+1 -- 6 swaps + 6 adds per head instead of 8 butterflies
-        const int row = lane >> 4;
-#pragma unroll
-        for (int hq = 0; hq < GQ; hq++) {
-            float s1[4], r2[2];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[hq][i]), __float_as_uint(acc[hq][i + 4]), false, false);
-                s1[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(s1[i]), __float_as_uint(s1[i + 2]), false, false);
-                r2[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-                if (LPK < 16) r2[i] += dpp_f<0x128>(r2[i]); /* two key groups per row: row_ror:8 */
-            }
-            float lt = xsum16(xsum32(l[hq]));
-            if (LPK < 16) lt += dpp_f<0x128>(lt);
-            float* c = comb + ((size_t)wave * GQ + hq) * PS;
-            if (LPK == 16 || (lane & 8) == 0) *reinterpret_cast<float2*>(c + d0 + 2 * row) = float2{r2[0], r2[1]};
-            if (lane == 0) c[hd] = lt;
-        }
+        // ---- the wave's key groups summed (reduce-scatter by row swaps), the waves through LDS: exact rescales to the slice's maximum exponent
+        canon_wave_to_lds<GQ, LPK>(A, comb + (size_t)wave * GQ * PS, hd, lane, d0);
         __syncthreads();
         for (int i = tid; i < GQ * hd; i += blockDim.x) {
             const int hq = i >> hd_log2, d = i & (hd - 1);
-            float o = 0.f, L = 0.f;
+            float ms = -__builtin_inff();
+#pragma unroll
+            for (int sl = 0; sl < NW; sl++) ms = fmaxf(ms, (float)comb[((size_t)sl * GQ + hq) * PS + hd + 1]);
+            double o = 0.0, L = 0.0;
 #pragma unroll
             for (int sl = 0; sl < NW; sl++) {
-                const float* c = comb + ((size_t)sl * GQ + hq) * PS;
-                o += c[d];
-                L += c[hd];
+                const double* c = comb + ((size_t)sl * GQ + hq) * PS;
+                const int e = canon_shift((float)c[hd + 1] - ms);
+                o += ldexp_d(c[d], e);
+                L += ldexp_d(c[hd], e);
             }
             if (nsp == 1) {
-                odst[(size_t)(h0 + hq) * hd + d] = f2bf(o * (1.0f / L));
+                odst[(size_t)(h0 + hq) * hd + d] = f2bf((float)(o / L));
             } else {
-                float Mh = M[0];
-#pragma unroll
-                for (int q2 = 1; q2 < GQ; q2++) Mh = (hq == q2) ? M[q2] : Mh;
-                float* dst = a.part + ((size_t)(h0 + hq) * nsp + split) * PS;
-                st_sc1(dst + d, o);
-                if (d == 0) st_sc1(dst + hd, Mh), st_sc1(dst + hd + 1, L);
+                double* dst = part + ((size_t)(h0 + hq) * nsp + split) * PS;
+                __hip_atomic_store(dst + d, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (d == 0) __hip_atomic_store(dst + hd, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_store(dst + hd + 1, (double)ms, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     } else if (nsp > 1) { /* empty slice: neutral partial, but it still arrives */
         for (int i = tid; i < GQ * hd; i += blockDim.x) {
             const int hq = i >> hd_log2, d = i & (hd - 1);
-            float* dst = a.part + ((size_t)(h0 + hq) * nsp + split) * PS;
-            st_sc1(dst + d, 0.f);
-            if (d == 0) st_sc1(dst + hd, -__builtin_inff()), st_sc1(dst + hd + 1, 0.f);
+            double* dst = part + ((size_t)(h0 + hq) * nsp + split) * PS;
+            __hip_atomic_store(dst + d, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == 0) __hip_atomic_store(dst + hd, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_store(dst + hd + 1, -(double)__builtin_inff(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (nsp == 1) return;
@@ -249,34 +170,28 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
     __syncthreads();
     if (!flag[0]) return;
 
-    // Every thread fetches its output element from all slices in one round of loads; the head is the same for the whole wave
-    // (64 | hd), so lane sp of the wave fetches (m, l) of slice sp and the scales are made in registers: no LDS, no barrier.
+    // Every thread merges its output elements over the slices: the head is the same for the whole wave (64 | hd), lane sp of the wave fetches (m, L) of slice sp,
+    // the maximum exponent and the rescaled L are formed in registers; the element's own chain walks the slices in order (fp64: the order does not matter).
     constexpr int NT = NW * 64;
     constexpr int NV = (GQ * 128 + NT - 1) / NT; /* output elements per thread (hd <= 128) */
-    float v[NV][KF_ATTN_MAX_SPLITS], ms[NV], ls[NV];
 #pragma unroll
     for (int e = 0; e < NV; e++) {
         const int i = tid + e * NT;
         const bool in = i < GQ * hd;
         const int hq = in ? (i >> hd_log2) : 0, d = i & (hd - 1);
-        const float* p = a.part + (size_t)(h0 + hq) * nsp * PS;
+        const double* p = part + (size_t)(h0 + hq) * nsp * PS;
         const bool mine = in && lane < nsp;
-        ms[e] = mine ? ld_sc1(p + (size_t)lane * PS + hd) : -__builtin_inff();
-        ls[e] = mine ? ld_sc1(p + (size_t)lane * PS + hd + 1) : 0.f;
-#pragma unroll
-        for (int sp = 0; sp < KF_ATTN_MAX_SPLITS; sp++) v[e][sp] = (in && sp < nsp) ? ld_sc1(p + (size_t)sp * PS + d) : 0.f;
-    }
-#pragma unroll
-    for (int e = 0; e < NV; e++) {
-        const int i = tid + e * NT;
-        const float Mx = wave_max(ms[e]);
-        const float sc = (ms[e] == -__builtin_inff()) ? 0.f : fast_exp(ms[e] - Mx);
-        const float L = wave_sum(ls[e] * sc);
-        float o = 0.f;
-#pragma unroll
-        for (int sp = 0; sp < KF_ATTN_MAX_SPLITS; sp++)
-            o = fmaf(v[e][sp], __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sc), sp)), o);
-        if (i < GQ * hd) odst[(size_t)(h0 + (i >> hd_log2)) * hd + (i & (hd - 1))] = f2bf(o * (1.0f / L));
+        const float ms = mine ? (float)__hip_atomic_load(p + (size_t)lane * PS + hd + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -__builtin_inff();
+        const double ls = mine ? __hip_atomic_load(p + (size_t)lane * PS + hd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        const float Mx = wave_max(ms);
+        const int sh = canon_shift(ms - Mx);
+        const double L = wave_sum_f64_fast(ldexp_d(ls, sh));
+        double o = 0.0;
+        for (int sp = 0; sp < nsp; sp++) {
+            const double v = in ? __hip_atomic_load(p + (size_t)sp * PS + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            o += ldexp_d(v, __builtin_amdgcn_readlane(sh, sp));
+        }
+        if (in) odst[(size_t)(h0 + hq) * hd + d] = f2bf((float)(o / L));
     }
     if (tid == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -332,7 +247,7 @@ int attn_launch(hipStream_t st, AttnArgs& a) {
     // one 64-key batch per 4-wave workgroup (one wave per SIMD: the kernel is bound by VALU issue inside a latency chain, so
     // spreading the keys over more CUs beats more waves per CU); 8 waves once the slices have to grow past 128 keys
     int NW = (GQ <= 2 && a.chunk > 128) ? 8 : 4;
-    const size_t smem = sizeof(uint16_t) * ((size_t)GQ * hd + hd) + sizeof(float) * (NW * GQ + 4 + (size_t)NW * GQ * (hd + 4));
+    const size_t smem = sizeof(double) * ((size_t)NW * GQ * (hd + 2)) + sizeof(uint16_t) * ((size_t)GQ * hd + hd) + 16;
     dim3 grid(nsp, a.n_kv, a.n_tok);
 #define KF_ATTN_GO(gq, nw)                                                                              \
     do {                                                                                               \

@@ -58,6 +58,121 @@ __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp
 
 constexpr int ATTN_U = 4; /* key tiles kept in flight per wave */
 
+// ------------------------------------------------------------------------------------------------ canonical decode attention
+// The order kernels and oracle share (oracle/kf_oracle.c section 6, mode CANON), free of launch geometry:
+//   score   s = bf16(d * (1 / sqrtf(hd))), d = this key's q.k dot: per lane a chain of 8 fused multiply-adds over its 8 elements, joined over the key's
+//           hd / 8 lanes by the balanced tree of group_sum16;
+//   weight  p = f * 2^(n - m), (f, n) = kf_exp2_parts(s * log2 e); m = ANY integer >= every n it is compared with: a power of two rescales exactly, so every
+//           lane / wave / slice works against a maximum of its own and the partial sums are rescaled when they meet;
+//   sums    fp64 (every term p and p * v is exact in fp64: the sums do not depend on their order to far below an fp32 ulp), out = bf16((float)(O / L)).
+constexpr float KF_LOG2E = 1.44269502162933349609375f;
+__device__ __forceinline__ float canon_score(const float (&q)[8], u32x4 kw, int lpk_log2, float rden) {
+    const uint32_t k4[4] = {kw.x, kw.y, kw.z, kw.w};
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        d = fmaf(q[2 * i], bf_lo(k4[i]), d);
+        d = fmaf(q[2 * i + 1], bf_hi(k4[i]), d);
+    }
+    d = group_sum16(d, lpk_log2);
+    return round_bf16(d * rden);
+}
+// exponent of an exact rescale: d = n - m <= 0 (integer-valued), -inf or NaN (both sides -inf): clamped so that the scaled value underflows to 0
+__device__ __forceinline__ int canon_shift(float d) { return (int)fmaxf(d, -1022.0f); }
+__device__ __forceinline__ double ldexp_d(double v, int e) { return __builtin_ldexp(v, e); }
+// a + b of the two halves of a 32-lane / 16-lane swap, fp64 (the row-swap reduce-scatter of the key-group sums)
+__device__ __forceinline__ double swap32_add_d(double a, double b) {
+    const unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)ua, (unsigned)ub, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi[0] << 32) | lo[0]) + __builtin_bit_cast(double, ((unsigned long long)hi[1] << 32) | lo[1]);
+}
+__device__ __forceinline__ double swap16_add_d(double a, double b) {
+    const unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)ua, (unsigned)ub, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi[0] << 32) | lo[0]) + __builtin_bit_cast(double, ((unsigned long long)hi[1] << 32) | lo[1]);
+}
+// One wave's share of a slice: running fp64 sums of its keys against the wave's own reference exponent.
+template <int GQ>
+struct CanonAcc {
+    double o[GQ][8], l[GQ];
+    float m[GQ]; /* integer-valued, -inf before the first valid key */
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int hq = 0; hq < GQ; hq++) {
+            m[hq] = -__builtin_inff(), l[hq] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) o[hq][i] = 0.0;
+        }
+    }
+};
+// one batch of ATTN_U key tiles of this lane's key group: k / v tiles (8 elements of this lane), validity per tile; q as 8 floats per head
+template <int GQ, int LPK>
+__device__ __forceinline__ void canon_batch(CanonAcc<GQ>& A, const float (&qf)[GQ][8], const u32x4 (&kk)[ATTN_U], const u32x4 (&vv)[ATTN_U], const bool (&valid)[ATTN_U], int lpk_log2,
+                                            float rden) {
+    float f[ATTN_U][GQ], n[ATTN_U][GQ], bn[GQ];
+#pragma unroll
+    for (int hq = 0; hq < GQ; hq++) bn[hq] = -__builtin_inff();
+#pragma unroll
+    for (int u = 0; u < ATTN_U; u++) {
+#pragma unroll
+        for (int hq = 0; hq < GQ; hq++) {
+            const float s = canon_score(qf[hq], kk[u], lpk_log2, rden);
+            kf_exp2_parts(s * KF_LOG2E, f[u][hq], n[u][hq]);
+            n[u][hq] = valid[u] ? n[u][hq] : -__builtin_inff();
+            bn[hq] = fmaxf(bn[hq], n[u][hq]);
+        }
+    }
+#pragma unroll
+    for (int hq = 0; hq < GQ; hq++) { /* the wave's maximum exponent of this batch */
+        bn[hq] = xmax32(xmax16(bn[hq]));
+        if (LPK < 16) bn[hq] = fmaxf(bn[hq], dpp_f<0x128>(bn[hq]));
+        if (bn[hq] > A.m[hq]) { /* exact rescale of what has been summed so far (nothing yet: the sums are 0) */
+            const int e = canon_shift(A.m[hq] - bn[hq]);
+            A.l[hq] = ldexp_d(A.l[hq], e);
+#pragma unroll
+            for (int i = 0; i < 8; i++) A.o[hq][i] = ldexp_d(A.o[hq][i], e);
+            A.m[hq] = bn[hq];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < ATTN_U; u++) {
+        const uint32_t vw[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+        double vd[8];
+#pragma unroll
+        for (int i = 0; i < 4; i++) vd[2 * i] = (double)bf_lo(vw[i]), vd[2 * i + 1] = (double)bf_hi(vw[i]);
+#pragma unroll
+        for (int hq = 0; hq < GQ; hq++) {
+            const double p = valid[u] ? ldexp_d((double)f[u][hq], canon_shift(n[u][hq] - A.m[hq])) : 0.0;
+            A.l[hq] += p;
+#pragma unroll
+            for (int i = 0; i < 8; i++) A.o[hq][i] = fma(p, vd[i], A.o[hq][i]);
+        }
+    }
+}
+// sums over the wave's key groups, left in LDS: c[d] for d < hd, c[hd] = l, c[hd + 1] = m (as a double); c = this wave's [hq] row of hd + 2 doubles
+template <int GQ, int LPK>
+__device__ __forceinline__ void canon_wave_to_lds(const CanonAcc<GQ>& A, double* comb_wave /* [GQ][hd + 2] */, int hd, int lane, int d0) {
+    const int row = lane >> 4;
+#pragma unroll
+    for (int hq = 0; hq < GQ; hq++) {
+        double s1[4], r2[2];
+#pragma unroll
+        for (int i = 0; i < 4; i++) s1[i] = swap32_add_d(A.o[hq][i], A.o[hq][i + 4]);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            r2[i] = swap16_add_d(s1[i], s1[i + 2]);
+            if (LPK < 16) r2[i] += dpp_d<0x128>(r2[i]); /* two key groups per row: row_ror:8 */
+        }
+        double lt = xsum16_d(xsum32_d(A.l[hq]));
+        if (LPK < 16) lt += dpp_d<0x128>(lt);
+        double* c = comb_wave + (size_t)hq * (hd + 2);
+        if (LPK == 16 || (lane & 8) == 0) c[d0 + 2 * row] = r2[0], c[d0 + 2 * row + 1] = r2[1];
+        if (lane == 0) c[hd] = lt, c[hd + 1] = (double)A.m[hq];
+    }
+}
+
 __device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 

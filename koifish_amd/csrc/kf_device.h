@@ -87,6 +87,22 @@ __device__ __forceinline__ float kf_logf(float x) {
     return fmaf(fe, 6.9313812255859375e-1f, s2 + lo);
 }
 
+// 2^y as f * 2^n: n = the integer nearest to y (ties to even), f = 2^(y - n) from a fixed degree-7 polynomial (the recipe of oracle/kfo_math.h kfo_exp2_parts,
+// stated independently).  The canonical softmax of the decode attention keeps the parts apart: a power of two rescales exactly.
+__device__ __forceinline__ void kf_exp2_parts(float y, float& f, float& n) {
+    const float nn = (y + 12582912.0f) - 12582912.0f;
+    const float r = y - nn;
+    float p = 1.52527338e-5f;
+    p = fmaf(p, r, 1.54035304e-4f);
+    p = fmaf(p, r, 1.33335581e-3f);
+    p = fmaf(p, r, 9.61812911e-3f);
+    p = fmaf(p, r, 5.55041087e-2f);
+    p = fmaf(p, r, 2.40226507e-1f);
+    p = fmaf(p, r, 6.93147181e-1f);
+    p = fmaf(p, r, 1.0f);
+    f = p, n = nn;
+}
+
 // DPP cross-lane moves (row = 16 lanes): quad_perm xor1 = 0xB1, xor2 = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
@@ -225,15 +241,26 @@ __device__ __forceinline__ float perm_dot_dword(uint32_t D, u32x4 X, const PermL
 // The same lookup with the weights paired as the arithmetic form pairs them -- (e0,e1), (e2,e3), (e4,e5), (e6,e7) against X.x .. X.w in natural
 // order -- so that the fp32 sum is formed in exactly the order of dot_q4_dword (kf_gemv.hip): two extra v_perm_b32 per dword gather the index bytes
 // (low nibble of a byte of D >> 4 = an even element, of D = an odd element; the lookup ignores the high nibbles).
+// (the pair product of kf_gemv_blocks.h, stated here for the lookup below)
+template <bool CANON>
+__device__ __forceinline__ float dotp_dev(uint32_t w, uint32_t x, float acc) {
+    if constexpr (CANON) {
+        acc = fmaf(bf_lo(w), bf_lo(x), acc);
+        return fmaf(bf_hi(w), bf_hi(x), acc);
+    } else {
+        return dot2_bf16(w, x, acc);
+    }
+}
+template <bool CANON = false>
 __device__ __forceinline__ float perm_dot_dword_nat(uint32_t D, u32x4 X, const PermLut& t, float acc) {
     const uint32_t even = D >> 4; /* bytes 3..0: elements 0,2,4,6 in the low nibbles; D itself: 1,3,5,7 */
     uint32_t lo, hi;
     perm_lookup4(__builtin_amdgcn_perm(even, D, 0x02060307u), t, lo, hi); /* bytes 0..3 = elements 0, 1, 2, 3 */
-    acc = dot2_bf16(__builtin_amdgcn_perm(hi, lo, 0x05010400u), X.x, acc);
-    acc = dot2_bf16(__builtin_amdgcn_perm(hi, lo, 0x07030602u), X.y, acc);
+    acc = dotp_dev<CANON>(__builtin_amdgcn_perm(hi, lo, 0x05010400u), X.x, acc);
+    acc = dotp_dev<CANON>(__builtin_amdgcn_perm(hi, lo, 0x07030602u), X.y, acc);
     perm_lookup4(__builtin_amdgcn_perm(even, D, 0x00040105u), t, lo, hi); /* elements 4, 5, 6, 7 */
-    acc = dot2_bf16(__builtin_amdgcn_perm(hi, lo, 0x05010400u), X.z, acc);
-    acc = dot2_bf16(__builtin_amdgcn_perm(hi, lo, 0x07030602u), X.w, acc);
+    acc = dotp_dev<CANON>(__builtin_amdgcn_perm(hi, lo, 0x05010400u), X.z, acc);
+    acc = dotp_dev<CANON>(__builtin_amdgcn_perm(hi, lo, 0x07030602u), X.w, acc);
     return acc;
 }
 __device__ __forceinline__ u32x4 perm_x_order(u32x4 o) {

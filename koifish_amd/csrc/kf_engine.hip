@@ -76,19 +76,19 @@ constexpr int pow2_ceil(int v) {
     return p;
 }
 struct EngXOff {
-    int xA, qkv, ao, xB, act, part, hbest, end; /* part: 8-byte granules [n_head][KF_ATTN_MAX_SPLITS][hd + 4]; hbest: 8-byte granules [ENG_NWG]: the head's per-workgroup maxima */
+    int xA, qkv, ao, xB, act, part, hbest, end; /* part: 8-byte granules, KF_ATTN_MAX_SPLITS * (2 hd + 4) per head (EngCfg::PSH); hbest: 8-byte granules [ENG_NWG]: the head's per-workgroup maxima */
 };
 constexpr EngXOff eng_xoff(int dim, int qd, int kvd, int ffn, int hd) {
     EngXOff o{};
     o.xA = 0, o.qkv = o.xA + eng_gran_dw(dim), o.ao = o.qkv + eng_gran_dw(qd + 2 * kvd), o.xB = o.ao + eng_gran_dw(qd), o.act = o.xB + eng_gran_dw(dim);
     o.part = o.act + eng_gran_dw(ffn);
-    o.hbest = o.part + eng_gran_dw(2 * (qd / hd) * KF_ATTN_MAX_SPLITS * (hd + 4));
+    o.hbest = o.part + eng_gran_dw(2 * (qd / hd) * KF_ATTN_MAX_SPLITS * (2 * hd + 4));
     o.end = o.hbest + eng_gran_dw(2 * ENG_NWG);
     return o;
 }
 // ---- the XCD-local area (cached memory, plain stores: the lines stay in that XCD's L2): [tickets 1 KiB] [lqkv 8 x lq dwords] [lpart 8 x lp qwords]
 constexpr int eng_lq_stride(int gq, int hd) { return ((gq * hd + 2 * hd) * 4 + 255) / 256 * 64; }                   /* dwords */
-constexpr int eng_lp_stride(int gq, int hd) { return (gq * KF_ATTN_MAX_SPLITS * (hd + 4) * 8 + 255) / 256 * 32; } /* qwords */
+constexpr int eng_lp_stride(int gq, int hd) { return (gq * KF_ATTN_MAX_SPLITS * (2 * hd + 4) * 8 + 255) / 256 * 32; } /* qwords */
 constexpr size_t eng_loc_bytes(int gq, int hd) { return 1024 + (size_t)8 * eng_lq_stride(gq, hd) * 4 + (size_t)8 * eng_lp_stride(gq, hd) * 8; }
 
 struct EngArgs {
@@ -345,7 +345,7 @@ __device__ __forceinline__ void mv_prefetch(const EngMat m, const EngMat m2, int
 // epi(row, v, v2) runs in the lane that owns a finished row (row counted inside the matrix)
 template <class PL, int NCW, int FMT, int MAXS, typename Epi>
 __device__ __forceinline__ void mv_run(float qb, float qb2, int s0, int cw, int lane, int Mj, const MvRegs<PL::PAIRED, MAXS>& R, const u32x4* xs, Epi&& epi) {
-    using BD = BlockDot<FMT>;
+    using BD = BlockDot<FMT, true>; /* the canonical order (oracle/kf_oracle.c section 4c): v_fma_f32 per product, same lanes / chain / tree as gemv_kernel's canonical form */
     float acc = 0.f, acc2 = 0.f;
 #pragma unroll
     for (int k = 0; k < MAXS; k++) {
@@ -377,10 +377,11 @@ struct EngLds {
     const EngLayer* lay;
     u32x4* xs[2];
     uint16_t *xrawA, *xrawB, *qraw, *kraw, *vraw, *qb, *knew;
-    float *wmax, *comb;
+    float* wmax;   /* [16] scratch of the head's arg-max */
+    double* comb;  /* [NW][GQ][hd + 2] the attention waves' fp64 sums {O[hd], L, m} */
     uint32_t* outb; /* [64] a phase's output granules of this workgroup, gathered so that ONE wave stores them 16 bytes per lane */
     int* cnt;       /* arrival counter of the compute waves that own rows of the phase */
-    float* msc;     /* [ME][KF_ATTN_MAX_SPLITS] the slice partials of this workgroup's merge elements, transposed for the per-element chains; [ME] dwords behind it: its ao granules */
+    double* msc;    /* [ME][KF_ATTN_MAX_SPLITS] the slice partials of this workgroup's merge elements, transposed for the per-element chains; [ME] dwords behind it: its ao granules */
     int* pub;       /* [4] layers of P1 / P4 / P5 / P6 rows this workgroup has published so far: the poller starts sweeping for the phase's consumers' vector behind it */
 };
 struct EngSlice { /* this workgroup's attention slice and merge share */
@@ -428,10 +429,10 @@ struct EngCfg {
     // the LM head (bf16 [vocab, DIM]) as trailing phases of the same launch: the geometry gemv_launch picks for a many-row bf16 matrix of this width
     static constexpr int HnBlk = DIM_ / 8, Hlpr_log2 = c_lpr_log2(DIM_ / 8, 1L << 20), HLPR = 1 << Hlpr_log2, HRPS = 64 >> Hlpr_log2, Hiters = (HnBlk + HLPR - 1) / HLPR;
     static constexpr int lq_stride = eng_lq_stride(GQ_, HD_), lp_stride = eng_lp_stride(GQ_, HD_);
-    // slice merge: every workgroup merges ME consecutive elements of one head (ME = the power of two >= q_dim / NWG).  A head's slice partials lie as
-    // [hd / ME element groups][KF_ATTN_MAX_SPLITS slices][ME] 8-byte {fp32, generation} granules + [KF_ATTN_MAX_SPLITS][2] {max, sum}: the nsp * ME granules a
-    // workgroup merges are contiguous (two 16-byte loads per lane at 2 k keys instead of 32 eight-byte ones)
-    static constexpr int ME = pow2_ceil((QD_ + NWG_ - 1) / NWG_), PSH = KF_ATTN_MAX_SPLITS * (HD_ + 2), NLM = (KF_ATTN_MAX_SPLITS * ME + 127) / 128;
+    // slice merge: every workgroup merges ME consecutive elements of one head (ME = the power of two >= q_dim / NWG).  A head's slice partials (fp64 sums of the
+    // canonical softmax, kf_attn_common.h) lie as [hd / ME element groups][KF_ATTN_MAX_SPLITS slices][ME] values, a value = two 8-byte {32 bits, generation}
+    // granules (low word, high word), then [KF_ATTN_MAX_SPLITS][4] granules {m, L low, L high, unused}: what a workgroup merges is contiguous
+    static constexpr int ME = pow2_ceil((QD_ + NWG_ - 1) / NWG_), PSH = KF_ATTN_MAX_SPLITS * (2 * HD_ + 4), NLM = (KF_ATTN_MAX_SPLITS * ME * 2 + 127) / 128;
     static_assert(ME <= 64 && ME <= HD_, "merge elements per workgroup");
 };
 template <class C>
@@ -452,11 +453,9 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
     constexpr int FMT = C::FMT, GQ = C::GQ, HD = C::HD, NWV = C::NWV;
     constexpr bool XMAP = C::XMAP, DBG = C::DBG;
     constexpr int ND = C::DIM / 256, NQD = C::QD / 256, NF = C::FFN / 256;
-    constexpr int XCH = BlockDot<FMT>::XCH, hd = HD, hd_log2 = HD == 128 ? 7 : 6, NW = 4, LPK = hd >> 3, KPW = 64 / LPK;
+    constexpr int XCH = BlockDot<FMT>::XCH, hd = HD, hd_log2 = HD == 128 ? 7 : 6;
     bool dead = false;
     const bool has1 = XMAP ? true : wg * P1::spg < P1::total, has4 = wg * P4::spg < P4::total, has5 = wg * P5::spg < P5::total, has6 = wg * P6::spg < P6::total;
-    const int tstride = NW * KPW;
-    const int nbatch = S.has_unit && !S.empty ? (S.t1 - S.t0 + ATTN_U * tstride - 1) / (ATTN_U * tstride) : 0;
     // the poller's share of P1 (virtual compute wave NWV - 1)
     constexpr int NCW1 = NWV, S1 = c_maxs<P1, NCW1>(), NWP1 = P1::spg < NCW1 ? P1::spg : NCW1;
     constexpr bool P1_SHARE = P1::spg >= NWV; /* the poller owns a slot */
@@ -538,23 +537,19 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
             __syncthreads();
             if (!S.empty) {
                 __syncthreads(); /* heads prepared */
-                for (int b = 0; b < nbatch; b++) {
-                    __syncthreads();
-                    __syncthreads();
-                }
-                __syncthreads(); /* key-group sums in LDS */
+                __syncthreads(); /* the waves' fp64 sums in LDS */
             }
         }
-        // P3: merge the slices of this workgroup's output elements (attention_v_kernel's division, once)
+        // P3: merge the slices of this workgroup's output elements: exact rescales to the largest exponent, fp64 sums, one division (kf_attn_common.h)
         ENG_STAMP(0, 3);
         if (S.has_merge) {
             constexpr int ME = C::ME, NLM = C::NLM, MAXSP = KF_ATTN_MAX_SPLITS;
             const int nsp = S.nsp, h = S.me0 >> hd_log2, dd = S.me0 & (hd - 1); /* XCD-mapped form: me0 counts inside the XCD's GQ heads */
             const unsigned long long* hbase = XMAP ? eng_lpart<C>(a, S.xcc) + (size_t)h * C::PSH : reinterpret_cast<const unsigned long long*>(a.xch + C::part) + (size_t)h * C::PSH;
-            const __amdgpu_buffer_rsrc_t rs_o = eng_rsrc(hbase + (size_t)(dd / ME) * (MAXSP * ME), (uint32_t)(MAXSP * ME) * 8u);
-            const __amdgpu_buffer_rsrc_t rs_ml = eng_rsrc(hbase + (size_t)hd * MAXSP, (uint32_t)MAXSP * 16u);
-            const int cnt = nsp * ME; /* granules of this workgroup's elements: index sp * ME + e */
-            u32x4 go[NLM], gml;
+            const __amdgpu_buffer_rsrc_t rs_o = eng_rsrc(hbase + (size_t)(dd / ME) * (MAXSP * ME * 2), (uint32_t)(MAXSP * ME * 2) * 8u);
+            const __amdgpu_buffer_rsrc_t rs_ml = eng_rsrc(hbase + (size_t)hd * MAXSP * 2, (uint32_t)MAXSP * 32u);
+            const int cnt = nsp * ME; /* values of this workgroup's elements: index sp * ME + e, two granules each */
+            u32x4 go[NLM], gm0, gm1;
             const bool mine = lane < nsp, el = lane < ME;
             eng_wait_pub(nullptr, 0, a.delay[2], dead);
             ENG_STAMP(0, 9);
@@ -563,14 +558,12 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
                 uint32_t bad = 0;
                 msw = spins + 1;
 #pragma unroll
-                for (int r = 0; r < NLM; r++) go[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_o, (r * 64 + lane) * 16, 0, XMAP ? 16 : 16 /* sc1 */));
-                gml = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ml, (mine ? lane : 0) * 16, 0, 16));
+                for (int r = 0; r < NLM; r++) go[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_o, (r * 64 + lane) * 16, 0, 16 /* sc1 */));
+                gm0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ml, (mine ? lane : 0) * 32, 0, 16));
+                gm1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ml, (mine ? lane : 0) * 32 + 16, 0, 16));
 #pragma unroll
-                for (int r = 0; r < NLM; r++) {
-                    const int i0 = 2 * (r * 64 + lane);
-                    bad |= (i0 < cnt ? (go[r].y ^ gen) : 0u) | (i0 + 1 < cnt ? (go[r].w ^ gen) : 0u);
-                }
-                bad |= mine ? ((gml.y ^ gen) | (gml.w ^ gen)) : 0u;
+                for (int r = 0; r < NLM; r++) bad |= (r * 64 + lane) < cnt ? ((go[r].y ^ gen) | (go[r].w ^ gen)) : 0u;
+                bad |= mine ? ((gm0.y ^ gen) | (gm0.w ^ gen) | (gm1.y ^ gen)) : 0u;
                 if (all_good(bad)) break;
                 if (dead || spins > ENG_SPIN_MAX) {
                     if (!dead && lane == 0) atomicOr(a.ws + 1, 4);
@@ -581,26 +574,26 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
             }
             ENG_STAMP(0, 11);
             if (DBG && wg == a.dbg_wg && lane == 0) a.dbg[((size_t)l * 2) * 16 + 10] = (unsigned long long)msw;
-            // transpose through LDS: element e's MAXSP values (slices past nsp: 0, as the round-2 chain added them) contiguous for lane e
+            // transpose through LDS: element e's values over the slices contiguous for lane e (slices past nsp: 0)
 #pragma unroll
             for (int r = 0; r < NLM; r++) {
-                const int i0 = 2 * (r * 64 + lane);
-                if (i0 < MAXSP * ME) {
-                    const int sp0 = i0 / ME, e0 = i0 - sp0 * ME, sp1 = (i0 + 1) / ME, e1 = (i0 + 1) - sp1 * ME;
-                    L.msc[e0 * MAXSP + sp0] = i0 < cnt ? __uint_as_float(go[r].x) : 0.f;
-                    L.msc[e1 * MAXSP + sp1] = i0 + 1 < cnt ? __uint_as_float(go[r].z) : 0.f;
+                const int vi = r * 64 + lane;
+                if (vi < MAXSP * ME) {
+                    const int sp = vi / ME, e = vi - sp * ME;
+                    L.msc[e * MAXSP + sp] = vi < cnt ? __builtin_bit_cast(double, ((unsigned long long)go[r].z << 32) | go[r].x) : 0.0;
                 }
             }
-            const float ms = mine ? __uint_as_float(gml.x) : -__builtin_inff(), ls = mine ? __uint_as_float(gml.z) : 0.f;
+            const float ms = mine ? __uint_as_float(gm0.x) : -__builtin_inff();
+            const double ls = mine ? __builtin_bit_cast(double, ((unsigned long long)gm1.x << 32) | gm0.z) : 0.0;
             const float Mx = wave_max(ms);
-            const float sc = (ms == -__builtin_inff()) ? 0.f : fast_exp(ms - Mx);
-            const float Lt = wave_sum(ls * sc);
-            float o = 0.f;
-            const float* mv = L.msc + (el ? lane : 0) * MAXSP;
+            const int sh = canon_shift(ms - Mx);
+            const double Lt = wave_sum_f64_fast(ldexp_d(ls, sh));
+            double o = 0.0;
+            const double* mv = L.msc + (el ? lane : 0) * MAXSP;
 #pragma unroll
-            for (int sp = 0; sp < MAXSP; sp++) o = fmaf(mv[sp], __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sc), sp)), o);
+            for (int sp = 0; sp < MAXSP; sp++) o += ldexp_d(mv[sp], __builtin_amdgcn_readlane(sh, sp));
             uint32_t* const ao_dst = a.xch + C::ao + (XMAP ? S.h0 * hd : 0) + S.me0;
-            const uint32_t gr = (tag << 16) | (uint32_t)f2bf(o * (1.0f / Lt));
+            const uint32_t gr = (tag << 16) | (uint32_t)f2bf((float)(o / Lt));
             if (ME >= 4) { /* 16 bytes per lane: a 4-byte write-through store is a read-modify-write at the memory side */
                 uint32_t* mo = reinterpret_cast<uint32_t*>(L.msc + ME * MAXSP);
                 if (el) mo[lane] = gr;
@@ -646,7 +639,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
     // 8 row-slots per workgroup are one step for every wave instead of two for wave 0
     constexpr int NCW1 = NWV;
     constexpr int S1 = c_maxs<P1, NCW1>(), S4 = c_maxs<P4, NCW>(), S5 = c_maxs<P5, NCW>(), S6 = c_maxs<P6, NCW>();
-    constexpr int hd = HD, hd_log2 = HD == 128 ? 7 : 6, NW = 4, PS = hd + 4;
+    constexpr int hd = HD, hd_log2 = HD == 128 ? 7 : 6, NW = 4;
     constexpr int LPK = hd >> 3, KPW = 64 / LPK, lpk_log2 = hd_log2 - 3;
     constexpr int NQ = (GQ + NW - 1) / NW;
     const int tid = wave * 64 + lane;
@@ -746,15 +739,15 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
                     }
                 }
                 __syncthreads();
-                float M[GQ], lsum[GQ], acc[GQ][8];
-                u32x4 qreg[GQ];
+                // the canonical softmax (kf_attn_common.h): every wave sums its keys in fp64 against its own maximum exponent; no workgroup-wide maximum, no
+                // barrier inside the key loop
+                CanonAcc<GQ> A;
+                A.init();
+                float qf[GQ][8];
 #pragma unroll
-                for (int hq = 0; hq < GQ; hq++) {
-                    M[hq] = -__builtin_inff(), lsum[hq] = 0.f;
+                for (int hq = 0; hq < GQ; hq++)
 #pragma unroll
-                    for (int i = 0; i < 8; i++) acc[hq][i] = 0.f;
-                    qreg[hq] = u32x4{0, 0, 0, 0};
-                }
+                    for (int i = 0; i < 8; i++) qf[hq][i] = 0.f;
                 if (aw) {
                     if (S.own_new) { /* the cache rows of this position: the prepared key, the raw value (K.out / V.out alias them in the reference) */
                         g_u16w krow = ly.kcache + (size_t)pos * a.kv_stride + (size_t)kvh * hd;
@@ -762,144 +755,80 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
                         for (int i = tid; i < hd; i += NW * 64) krow[i] = L.knew[i], vrow[i] = L.vraw[i];
                     }
 #pragma unroll
-                    for (int hq = 0; hq < GQ; hq++) qreg[hq] = *reinterpret_cast<const u32x4*>(L.qb + hq * hd + d0);
-                }
-                const float rden = 1.0f / sqrtf((float)hd);
-                for (int b = 0; b < nbatch; b++) {
-                    const int tb = tstart + b * ATTN_U * tstride;
-                    float s[ATTN_U][GQ], bm[GQ];
+                    for (int hq = 0; hq < GQ; hq++) {
+                        const u32x4 qv = *reinterpret_cast<const u32x4*>(L.qb + hq * hd + d0);
+                        const uint32_t q4[4] = {qv.x, qv.y, qv.z, qv.w};
 #pragma unroll
-                    for (int hq = 0; hq < GQ; hq++) bm[hq] = -__builtin_inff();
-                    if (aw) {
+                        for (int i = 0; i < 4; i++) qf[hq][2 * i] = bf_lo(q4[i]), qf[hq][2 * i + 1] = bf_hi(q4[i]);
+                    }
+                    const float rden = 1.0f / sqrtf((float)hd);
+                    for (int b = 0; b < nbatch; b++) {
+                        const int tb = tstart + b * ATTN_U * tstride;
+                        u32x4 ck[ATTN_U], cv[ATTN_U];
+                        bool valid[ATTN_U];
 #pragma unroll
                         for (int u = 0; u < ATTN_U; u++) {
                             const int t = tb + u * tstride;
-                            const bool valid = t < t1;
-                            u32x4 kw = kk[u];
-                            if (valid && t == pos) kw = *reinterpret_cast<const u32x4*>(L.knew + d0), vv[u] = *reinterpret_cast<const u32x4*>(L.vraw + d0);
-#pragma unroll
-                            for (int hq = 0; hq < GQ; hq++) {
-                                float d = dot2_bf16(qreg[hq].x, kw.x, 0.f);
-                                d = dot2_bf16(qreg[hq].y, kw.y, d);
-                                d = dot2_bf16(qreg[hq].z, kw.z, d);
-                                d = dot2_bf16(qreg[hq].w, kw.w, d);
-                                d = group_sum16(d, lpk_log2);
-                                d = round_bf16(d * rden);
-                                s[u][hq] = valid ? d : -__builtin_inff();
-                                bm[hq] = fmaxf(bm[hq], s[u][hq]);
-                            }
+                            valid[u] = t < t1;
+                            ck[u] = kk[u], cv[u] = vv[u];
+                            if (valid[u] && t == pos) ck[u] = *reinterpret_cast<const u32x4*>(L.knew + d0), cv[u] = *reinterpret_cast<const u32x4*>(L.vraw + d0);
                         }
-#pragma unroll
-                        for (int hq = 0; hq < GQ; hq++) {
-                            bm[hq] = xmax32(xmax16(bm[hq]));
-                            if (LPK < 16) bm[hq] = fmaxf(bm[hq], dpp_f<0x128>(bm[hq]));
-                        }
-                        if (b + 1 < nbatch) issue_k(ly, tb + ATTN_U * tstride, t1);
+                        if (b + 1 < nbatch) issue_kv(ly, tb + ATTN_U * tstride, t1);
+                        canon_batch<GQ, LPK>(A, qf, ck, cv, valid, lpk_log2, rden);
                     }
-                    __syncthreads();
-                    if (aw && lane == 0) {
-#pragma unroll
-                        for (int hq = 0; hq < GQ; hq++) L.wmax[wave * GQ + hq] = bm[hq];
-                    }
-                    __syncthreads();
-                    if (aw) {
-#pragma unroll
-                        for (int hq = 0; hq < GQ; hq++) {
-                            float Mb = L.wmax[hq];
-#pragma unroll
-                            for (int w2 = 1; w2 < NW; w2++) Mb = fmaxf(Mb, L.wmax[w2 * GQ + hq]);
-                            if (Mb > M[hq]) {
-                                const float sc = fast_exp(M[hq] - Mb);
-                                lsum[hq] *= sc;
-#pragma unroll
-                                for (int i = 0; i < 8; i++) acc[hq][i] *= sc;
-                                M[hq] = Mb;
-                            }
-                        }
-#pragma unroll
-                        for (int u = 0; u < ATTN_U; u++) {
-                            float vf_[8];
-                            const uint32_t vw[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
-#pragma unroll
-                            for (int i = 0; i < 4; i++) vf_[2 * i] = bf_lo(vw[i]), vf_[2 * i + 1] = bf_hi(vw[i]);
-#pragma unroll
-                            for (int hq = 0; hq < GQ; hq++) {
-                                const float p = fast_exp(s[u][hq] - M[hq]);
-                                lsum[hq] += p;
-#pragma unroll
-                                for (int i = 0; i < 8; i++) acc[hq][i] = fmaf(p, vf_[i], acc[hq][i]);
-                            }
-                        }
-                        if (b + 1 < nbatch) issue_v(ly, tb + ATTN_U * tstride, t1);
-                    }
-                }
-                if (aw) { /* key-group sums (reduce-scatter by row swaps), waves through LDS */
-                    const int row = lane >> 4;
-#pragma unroll
-                    for (int hq = 0; hq < GQ; hq++) {
-                        float s1[4], r2[2];
-#pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[hq][i]), __float_as_uint(acc[hq][i + 4]), false, false);
-                            s1[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-                        }
-#pragma unroll
-                        for (int i = 0; i < 2; i++) {
-                            const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(s1[i]), __float_as_uint(s1[i + 2]), false, false);
-                            r2[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-                            if (LPK < 16) r2[i] += dpp_f<0x128>(r2[i]);
-                        }
-                        float lt = xsum16(xsum32(lsum[hq]));
-                        if (LPK < 16) lt += dpp_f<0x128>(lt);
-                        float* c = L.comb + ((size_t)wave * GQ + hq) * PS;
-                        if (LPK == 16 || (lane & 8) == 0) *reinterpret_cast<float2*>(c + d0 + 2 * row) = float2{r2[0], r2[1]};
-                        if (lane == 0) c[hd] = lt;
-                    }
+                    canon_wave_to_lds<GQ, LPK>(A, L.comb + (size_t)wave * GQ * (hd + 2), hd, lane, d0);
                 }
                 __syncthreads();
                 if (aw) {
+                    constexpr int PSD = hd + 2;
                     for (int i = tid; i < GQ * hd; i += NW * 64) {
                         const int hq = i >> hd_log2, d = i & (hd - 1);
-                        float o = 0.f, Ls = 0.f;
+                        float ms = -__builtin_inff();
+#pragma unroll
+                        for (int sl = 0; sl < NW; sl++) ms = fmaxf(ms, (float)L.comb[((size_t)sl * GQ + hq) * PSD + hd + 1]);
+                        double o = 0.0, Ls = 0.0;
 #pragma unroll
                         for (int sl = 0; sl < NW; sl++) {
-                            const float* c = L.comb + ((size_t)sl * GQ + hq) * PS;
-                            o += c[d];
-                            Ls += c[hd];
+                            const double* c = L.comb + ((size_t)sl * GQ + hq) * PSD;
+                            const int e = canon_shift((float)c[hd + 1] - ms);
+                            o += ldexp_d(c[d], e);
+                            Ls += ldexp_d(c[hd], e);
                         }
                         if (nsp == 1) {
-                            st_gran(a.xch + C::ao + (h0 + hq) * hd + d, tag, f2bf(o * (1.0f / Ls)));
+                            st_gran(a.xch + C::ao + (h0 + hq) * hd + d, tag, f2bf((float)(o / Ls)));
                         } else {
-                            float Mh = M[0];
-#pragma unroll
-                            for (int q2 = 1; q2 < GQ; q2++) Mh = (hq == q2) ? M[q2] : Mh;
                             constexpr int ME = C::ME, MAXSP = KF_ATTN_MAX_SPLITS;
-                            const size_t oi = (size_t)(d / ME) * (MAXSP * ME) + (size_t)S.split * ME + (d & (ME - 1)), mi = (size_t)hd * MAXSP + (size_t)S.split * 2;
-                            if (XMAP) { /* plain 8-byte stores into this XCD's partial buffer */
+                            const size_t oi = ((size_t)(d / ME) * (MAXSP * ME) + (size_t)S.split * ME + (d & (ME - 1))) * 2, mi = (size_t)hd * MAXSP * 2 + (size_t)S.split * 4;
+                            const unsigned long long ob = __builtin_bit_cast(unsigned long long, o), lb = __builtin_bit_cast(unsigned long long, Ls), gg = (unsigned long long)gen << 32;
+                            if (XMAP) { /* plain stores into this XCD's partial buffer: a value = two {32 bits, generation} granules */
                                 unsigned long long* dst = eng_lpart<C>(a, S.xcc) + (size_t)hq * C::PSH;
-                                dst[oi] = ((unsigned long long)gen << 32) | __float_as_uint(o);
-                                if (d == 0) dst[mi] = ((unsigned long long)gen << 32) | __float_as_uint(Mh), dst[mi + 1] = ((unsigned long long)gen << 32) | __float_as_uint(Ls);
+                                *reinterpret_cast<ulonglong2*>(dst + oi) = ulonglong2{gg | (ob & 0xffffffffull), gg | (ob >> 32)};
+                                if (d == 0) {
+                                    *reinterpret_cast<ulonglong2*>(dst + mi) = ulonglong2{gg | __float_as_uint(ms), gg | (lb & 0xffffffffull)};
+                                    dst[mi + 2] = gg | (lb >> 32);
+                                }
                             } else {
                                 unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.xch + C::part) + (size_t)(h0 + hq) * C::PSH;
-                                st_gran64(dst + oi, gen, o);
-                                if (d == 0) st_gran64(dst + mi, gen, Mh), st_gran64(dst + mi + 1, gen, Ls);
+                                st_gran64(dst + oi, gen, __uint_as_float((uint32_t)ob)), st_gran64(dst + oi + 1, gen, __uint_as_float((uint32_t)(ob >> 32)));
+                                if (d == 0) st_gran64(dst + mi, gen, ms), st_gran64(dst + mi + 1, gen, __uint_as_float((uint32_t)lb)), st_gran64(dst + mi + 2, gen, __uint_as_float((uint32_t)(lb >> 32)));
                             }
                         }
                     }
                 }
-            } else if (nsp > 1 && aw) { /* empty slice: neutral partial */
+            } else if (nsp > 1 && aw) { /* empty slice: neutral partial (sums 0, exponent -inf) */
                 for (int i = tid; i < GQ * hd; i += NW * 64) {
                     const int hq = i >> hd_log2, d = i & (hd - 1);
                     constexpr int ME = C::ME, MAXSP = KF_ATTN_MAX_SPLITS;
-                    const size_t oi = (size_t)(d / ME) * (MAXSP * ME) + (size_t)S.split * ME + (d & (ME - 1)), mi = (size_t)hd * MAXSP + (size_t)S.split * 2;
+                    const size_t oi = ((size_t)(d / ME) * (MAXSP * ME) + (size_t)S.split * ME + (d & (ME - 1))) * 2, mi = (size_t)hd * MAXSP * 2 + (size_t)S.split * 4;
+                    const unsigned long long gg = (unsigned long long)gen << 32;
                     if (XMAP) {
                         unsigned long long* dst = eng_lpart<C>(a, S.xcc) + (size_t)hq * C::PSH;
-                        dst[oi] = (unsigned long long)gen << 32;
-                        if (d == 0) dst[mi] = ((unsigned long long)gen << 32) | 0xff800000u, dst[mi + 1] = (unsigned long long)gen << 32;
+                        dst[oi] = gg, dst[oi + 1] = gg;
+                        if (d == 0) dst[mi] = gg | 0xff800000u, dst[mi + 1] = gg, dst[mi + 2] = gg;
                     } else {
                         unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.xch + C::part) + (size_t)(h0 + hq) * C::PSH;
-                        st_gran64(dst + oi, gen, 0.f);
-                        if (d == 0) st_gran64(dst + mi, gen, -__builtin_inff()), st_gran64(dst + mi + 1, gen, 0.f);
+                        st_gran64(dst + oi, gen, 0.f), st_gran64(dst + oi + 1, gen, 0.f);
+                        if (d == 0) st_gran64(dst + mi, gen, -__builtin_inff()), st_gran64(dst + mi + 1, gen, 0.f), st_gran64(dst + mi + 2, gen, 0.f);
                     }
                 }
             }
@@ -957,7 +886,7 @@ template <class C>
 __device__ __forceinline__ void eng_head_main(const EngArgs& a, const EngLds& L, int epoch, int wg, int wave, int lane) {
     constexpr int NWV = C::NWV, NWG = C::NWG, nBlk = C::HnBlk, LPR = C::HLPR, RPS = C::HRPS, ITERS = C::Hiters, HG = 4;
     constexpr int ND = C::DIM / 256;
-    using BD = BlockDot<FMT_BF16>;
+    using BD = BlockDot<FMT_BF16, true>;
     const int sub = lane >> C::Hlpr_log2, ll = lane & (LPR - 1);
     const int total = (a.vocab + RPS - 1) / RPS, spg = (total + NWG - 1) / NWG; /* slots in all, per workgroup */
     const int s_wg = wg * spg;
@@ -1111,12 +1040,12 @@ __global__ void __launch_bounds__(C::NWV * 64) engine_kernel(const EngArgs a) {
     L.xrawB = reinterpret_cast<uint16_t*>(smem + off), off += xr_bytes;
     L.qraw = reinterpret_cast<uint16_t*>(smem + off); /* [GQ][hd] raw q heads of this workgroup's slice */
     L.kraw = L.qraw + GQ * hd, L.vraw = L.kraw + hd, L.qb = L.vraw + hd, L.knew = L.qb + GQ * hd;
-    L.wmax = reinterpret_cast<float*>(L.knew + hd); /* [NW][GQ] */
-    L.comb = L.wmax + NW * GQ + 4;                  /* [NW][GQ][hd + 4] */
-    L.outb = reinterpret_cast<uint32_t*>(L.comb + NW * GQ * (hd + 4));
+    L.comb = reinterpret_cast<double*>(L.knew + hd); /* [NW][GQ][hd + 2] doubles (the offset is a multiple of 16 bytes) */
+    L.msc = L.comb + NW * GQ * (hd + 2);              /* [ME][MAXSP] doubles + [64] dwords */
+    L.wmax = reinterpret_cast<float*>(L.msc + C::ME * KF_ATTN_MAX_SPLITS + 32);
+    L.outb = reinterpret_cast<uint32_t*>(L.wmax + 16);
     L.cnt = reinterpret_cast<int*>(L.outb + 64); /* [0] arrival counter, [1..2] XCD id and ticket */
     L.pub = L.cnt + 4;
-    L.msc = reinterpret_cast<float*>(L.cnt + 8);
     if (tid == 0) *L.cnt = 0;
     if (tid < 4) L.pub[tid] = 0;
     // ---- start: state, generation, tables
@@ -1383,7 +1312,7 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     if (E->ffn > maxK) maxK = E->ffn;
     const size_t xs_bytes = ((size_t)maxK * 2 + 15) & ~(size_t)15;
     size_t smem = (((size_t)d->n_layer * sizeof(EngLayer) + 15) & ~(size_t)15) + 2 * xs_bytes + 2 * (((size_t)E->dim * 2 + 15) & ~(size_t)15);
-    smem += sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + sizeof(float) * (4 * GQ + 4 + (size_t)4 * GQ * (hd + 4)) + 4 * 64 + 32 + 4 * (64 * KF_ATTN_MAX_SPLITS + 64);
+    smem += sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + sizeof(double) * ((size_t)4 * GQ * (hd + 2) + 64 * KF_ATTN_MAX_SPLITS + 32) + 4 * 16 + 4 * 64 + 32;
     smem = (smem + 15) & ~(size_t)15;
     if (smem > 160 * 1024) {
         engine_release(E);

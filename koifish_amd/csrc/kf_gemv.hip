@@ -15,9 +15,19 @@
 
 #include "kf_gemv_blocks.h"
 
+// This file is compiled twice: as it stands (the v_dot2c_f32_bf16 forms) and through kf_gemv_canon.hip with KF_GEMV_CANON = 1 (the canonical order of
+// oracle/kf_oracle.c section 4c: two v_fma_f32 per weight pair, every output bit reproducible with fmaf on the host).  Same kernels, same geometry, same
+// launcher; gemv_launch picks by GemvLaunch::canon (the context's flag, kf_set_canonical).
+#ifndef KF_GEMV_CANON
+#define KF_GEMV_CANON 0
+#endif
+
 namespace kf {
 
+constexpr bool GEMV_CANON = KF_GEMV_CANON != 0;
+#if !KF_GEMV_CANON
 Knobs g_knobs;
+#endif
 
 template <int G, bool PAIRED, bool LUT>
 struct Batch {
@@ -36,9 +46,9 @@ struct Batch {
 // weight stream's HBM latency overlaps the (dependent) activation load + norm.
 // ONEJOB: a launch with a single matrix (o_proj, down_proj, LM head, sparse rows) never reads the descriptors of jobs 1 and 2: kernel arguments are fetched ahead of the
 // first load, and every one a launch touches is on its critical path
-template <int FMT, int G, int MODE, bool SPARSE, bool ONEJOB>
+template <int FMT, int G, int MODE, bool SPARSE, bool ONEJOB, bool CANON>
 __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
-    using BD = BlockDot<FMT>;
+    using BD = BlockDot<FMT, CANON>;
     constexpr bool PAIRED = (MODE == GEMV_PAIRED), LUT = (FMT == FMT_Q4R);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);
@@ -402,6 +412,7 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     }
 }
 
+#if !KF_GEMV_CANON
 // Final pick over the per-workgroup partial maxima, then the decode-state update for graph replay.
 __global__ void __launch_bounds__(256) argmax_finish_kernel(const float* val, const int* idx, int n, int32_t* d_argmax, int32_t* d_state,
                                                             int32_t* d_tokens_out) {
@@ -449,6 +460,7 @@ __global__ void __launch_bounds__(256) argmax_finish_kernel(const float* val, co
     }
 }
 
+#endif
 // ------------------------------------------------------------------------------------------------ launcher
 static int fmt_of(int type) {
     switch (type) {
@@ -464,7 +476,9 @@ static int fmt_of_w(const kf_weight* w) {
     if (is_row_lut(w)) return (w->type == KF_Q4 && w->quant == KF_QUANT_ROW_LUT) ? FMT_Q4R : -1;
     return fmt_of(w->type);
 }
+#if !KF_GEMV_CANON
 int gemv_fmt_of(const kf_weight* w) { return fmt_of_w(w); }
+#endif
 static int epb_of(int fmt) {
     switch (fmt) {
         case FMT_BF16: return 8;
@@ -475,6 +489,7 @@ static int epb_of(int fmt) {
     }
 }
 
+#if !KF_GEMV_CANON
 // Lanes per row of a launch (shared with the persistent decode engine, kf_engine.hip, so that both sum a row in the same order).
 // LPR: the largest power of two <= 64 dividing nBlk when that is >= 16 (no idle lanes), else the largest power of two <= min(64, nBlk)
 // with the row tail masked.  Short launches (fewer waves than the chip has SIMDs) are bound by the per-step dequant arithmetic of the
@@ -492,15 +507,16 @@ int gemv_lpr_log2(int nBlk, long rows) {
         lpr_log2++;
     return lpr_log2;
 }
+#endif
 
 template <int FMT, int MODE, bool SPARSE, bool ONEJOB>
 static void launch_j(const GemvArgs& a, int G, dim3 grid, size_t smem, hipStream_t st) {
     if (G >= 4)
-        hipLaunchKernelGGL((gemv_kernel<FMT, 4, MODE, SPARSE, ONEJOB>), grid, dim3(256), smem, st, a);
+        hipLaunchKernelGGL((gemv_kernel<FMT, 4, MODE, SPARSE, ONEJOB, GEMV_CANON>), grid, dim3(256), smem, st, a);
     else if (G == 2)
-        hipLaunchKernelGGL((gemv_kernel<FMT, 2, MODE, SPARSE, ONEJOB>), grid, dim3(256), smem, st, a);
+        hipLaunchKernelGGL((gemv_kernel<FMT, 2, MODE, SPARSE, ONEJOB, GEMV_CANON>), grid, dim3(256), smem, st, a);
     else
-        hipLaunchKernelGGL((gemv_kernel<FMT, 1, MODE, SPARSE, ONEJOB>), grid, dim3(256), smem, st, a);
+        hipLaunchKernelGGL((gemv_kernel<FMT, 1, MODE, SPARSE, ONEJOB, GEMV_CANON>), grid, dim3(256), smem, st, a);
 }
 template <int FMT, int MODE, bool SPARSE>
 static void launch_g(const GemvArgs& a, int G, dim3 grid, size_t smem, hipStream_t st) {
@@ -533,7 +549,12 @@ static void launch_m(const GemvArgs& a, int mode, int G, dim3 grid, size_t smem,
         launch_g<FMT, GEMV_PLAIN, false>(a, G, grid, smem, st);
 }
 
-int gemv_launch(hipStream_t st, GemvLaunch& L) {
+#if KF_GEMV_CANON
+int gemv_launch_canon(hipStream_t st, GemvLaunch& L) {
+#else
+int gemv_launch(hipStream_t st, GemvLaunch& L) { return L.canon ? gemv_launch_canon(st, L) : gemv_launch_dot2(st, L); }
+int gemv_launch_dot2(hipStream_t st, GemvLaunch& L) {
+#endif
     GemvArgs& a = L.args;
     const kf_weight* w0 = L.w[0];
     const int fmt = fmt_of_w(w0);
@@ -656,8 +677,10 @@ int gemv_launch(hipStream_t st, GemvLaunch& L) {
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 
+#if !KF_GEMV_CANON
 void argmax_finish_launch(hipStream_t st, const float* val, const int* idx, int n, int32_t* d_argmax, int32_t* d_state, int32_t* d_tokens_out) {
     hipLaunchKernelGGL(argmax_finish_kernel, dim3(1), dim3(256), 0, st, val, idx, n, d_argmax, d_state, d_tokens_out);
 }
+#endif
 
 }  // namespace kf

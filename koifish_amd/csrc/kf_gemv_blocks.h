@@ -6,12 +6,27 @@
 
 namespace kf {
 
+// One pair of products added to an accumulator.  CANON = false: v_dot2c_f32_bf16 (one instruction; its internal rounding has no bit-exact CPU model).
+// CANON = true: the canonical order kernels and oracle share (oracle/kf_oracle.c section 4c): two fused multiply-adds, low element first -- every bit
+// reproducible with fmaf on the host.  All block dots below add their pairs in element order, so the per-lane chain of the canonical order is "the
+// elements of a block in index order, block after block".
+template <bool CANON>
+__device__ __forceinline__ float dotp(uint32_t w, uint32_t x, float acc) {
+    if constexpr (CANON) {
+        acc = fmaf(bf_lo(w), bf_lo(x), acc);
+        return fmaf(bf_hi(w), bf_hi(x), acc);
+    } else {
+        return dot2_bf16(w, x, acc);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ block dots
 // Q4: Packed128 memory image (PackedQ.hpp:99-183): dword3 (bytes 12..15) holds elements 0..7 with element 0 in
 // bits 28..31; dword2 -> 8..15; dword1 -> 16..23; dword0 -> 24..31.
 // dequant (T.cu:274, all bf16 operators):  w = bf16( bf16(step * (q - qBias)) - zero ).
 //   step*(q-qBias) is formed exactly in fp32 by one fma (q <= 15, step has 8 significant bits), rounded to
 //   bf16 by v_cvt_pk_bf16_f32 (two at a time), widened, zero subtracted in fp32 (exact operands), rounded again.
+template <bool CANON>
 __device__ __forceinline__ float dot_q4_dword(uint32_t D, u32x4 X, float step, float step16, float nb, float zero, float acc) {
     uint32_t H = D & 0xF0F0F0F0u, L = D & 0x0F0F0F0Fu;
     // keep the two masks opaque: folded into the byte extraction below they would defeat v_cvt_f32_ubyte1..3 (one op per nibble)
@@ -20,73 +35,74 @@ __device__ __forceinline__ float dot_q4_dword(uint32_t D, u32x4 X, float step, f
     uint32_t r, w;
     r = pack_bf16x2(fmaf((float)(H >> 24), step16, nb), fmaf((float)(L >> 24), step, nb));
     w = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
-    acc = dot2_bf16(w, X.x, acc);
+    acc = dotp<CANON>(w, X.x, acc);
     r = pack_bf16x2(fmaf((float)((H >> 16) & 0xffu), step16, nb), fmaf((float)((L >> 16) & 0xffu), step, nb));
     w = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
-    acc = dot2_bf16(w, X.y, acc);
+    acc = dotp<CANON>(w, X.y, acc);
     r = pack_bf16x2(fmaf((float)((H >> 8) & 0xffu), step16, nb), fmaf((float)((L >> 8) & 0xffu), step, nb));
     w = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
-    acc = dot2_bf16(w, X.z, acc);
+    acc = dotp<CANON>(w, X.z, acc);
     r = pack_bf16x2(fmaf((float)(H & 0xffu), step16, nb), fmaf((float)(L & 0xffu), step, nb));
     w = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
-    acc = dot2_bf16(w, X.w, acc);
+    acc = dotp<CANON>(w, X.w, acc);
     return acc;
 }
 
-template <int FMT>
+template <int FMT, bool CANON = false>
 struct BlockDot;
 
-template <>
-struct BlockDot<FMT_BF16> {
+template <bool CANON>
+struct BlockDot<FMT_BF16, CANON> {
     static constexpr int EPB = 8, XCH = 1;
     static constexpr bool HAS_GAMA = false;
     __device__ static __forceinline__ float run(u32x4 w, const u32x4* xs, int col, int nBlk, float, float, float, float acc) {
         u32x4 X = xs[col];
-        acc = dot2_bf16(w.x, X.x, acc);
-        acc = dot2_bf16(w.y, X.y, acc);
-        acc = dot2_bf16(w.z, X.z, acc);
-        acc = dot2_bf16(w.w, X.w, acc);
+        acc = dotp<CANON>(w.x, X.x, acc);
+        acc = dotp<CANON>(w.y, X.y, acc);
+        acc = dotp<CANON>(w.z, X.z, acc);
+        acc = dotp<CANON>(w.w, X.w, acc);
         return acc;
     }
 };
 
 // F8E5M2: byte i of the block = element i; value = half(byte << 8) (g_float.hpp:355-383), exact in bf16.
 __device__ __forceinline__ float f8_to_f32(uint32_t hbits) { return half_bits_to_f32(hbits); }
+template <bool CANON>
 __device__ __forceinline__ float dot_f8_dword(uint32_t D, uint32_t X0, uint32_t X1, float acc) {
     // gfx950 converts two OCP E5M2 bytes to fp32 in one instruction (v_cvt_pk_f32_bf8): the same values as half(byte << 8), exactly
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
     const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_bf8((int)D, false), hi = __builtin_amdgcn_cvt_pk_f32_bf8((int)D, true);
     uint32_t w0 = pack_bf16x2(lo.x, lo.y);
     uint32_t w1 = pack_bf16x2(hi.x, hi.y);
-    acc = dot2_bf16(w0, X0, acc);
-    acc = dot2_bf16(w1, X1, acc);
+    acc = dotp<CANON>(w0, X0, acc);
+    acc = dotp<CANON>(w1, X1, acc);
     return acc;
 }
-template <>
-struct BlockDot<FMT_F8> {
+template <bool CANON>
+struct BlockDot<FMT_F8, CANON> {
     static constexpr int EPB = 16, XCH = 2;
     static constexpr bool HAS_GAMA = false;
     __device__ static __forceinline__ float run(u32x4 w, const u32x4* xs, int col, int nBlk, float, float, float, float acc) {
         u32x4 X0 = xs[col], X1 = xs[nBlk + col];
-        acc = dot_f8_dword(w.x, X0.x, X0.y, acc);
-        acc = dot_f8_dword(w.y, X0.z, X0.w, acc);
-        acc = dot_f8_dword(w.z, X1.x, X1.y, acc);
-        acc = dot_f8_dword(w.w, X1.z, X1.w, acc);
+        acc = dot_f8_dword<CANON>(w.x, X0.x, X0.y, acc);
+        acc = dot_f8_dword<CANON>(w.y, X0.z, X0.w, acc);
+        acc = dot_f8_dword<CANON>(w.z, X1.x, X1.y, acc);
+        acc = dot_f8_dword<CANON>(w.w, X1.z, X1.w, acc);
         return acc;
     }
 };
 
-template <>
-struct BlockDot<FMT_Q4> {
+template <bool CANON>
+struct BlockDot<FMT_Q4, CANON> {
     static constexpr int EPB = 32, XCH = 4;
     static constexpr bool HAS_GAMA = true;
     // nb = -qBias*step (exact)
     __device__ static __forceinline__ float run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, float acc) {
         const float step16 = step * 0.0625f;
-        acc = dot_q4_dword(w.w, xs[col], step, step16, nb, zero, acc);
-        acc = dot_q4_dword(w.z, xs[nBlk + col], step, step16, nb, zero, acc);
-        acc = dot_q4_dword(w.y, xs[2 * nBlk + col], step, step16, nb, zero, acc);
-        acc = dot_q4_dword(w.x, xs[3 * nBlk + col], step, step16, nb, zero, acc);
+        acc = dot_q4_dword<CANON>(w.w, xs[col], step, step16, nb, zero, acc);
+        acc = dot_q4_dword<CANON>(w.z, xs[nBlk + col], step, step16, nb, zero, acc);
+        acc = dot_q4_dword<CANON>(w.y, xs[2 * nBlk + col], step, step16, nb, zero, acc);
+        acc = dot_q4_dword<CANON>(w.x, xs[3 * nBlk + col], step, step16, nb, zero, acc);
         return acc;
     }
 };
@@ -97,8 +113,8 @@ struct BlockDot<FMT_Q4> {
 // fma / round / subtract / round chain: ~4.7 VALU instructions per weight instead of 6.25.  The launcher picks this form only when a group
 // is exactly one aligned lane quad (lGroup 128, K a multiple of 128, at least 4 lanes per row).  The lookup pairs the weights as the arithmetic
 // form does (perm_dot_dword_nat), so the fp32 sums -- and every output bit -- are those of BlockDot<FMT_Q4>.
-template <>
-struct BlockDot<FMT_Q4P> {
+template <bool CANON>
+struct BlockDot<FMT_Q4P, CANON> {
     static constexpr int EPB = 32, XCH = 4;
     static constexpr bool HAS_GAMA = true;
     __device__ static __forceinline__ float run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, float acc) {
@@ -111,10 +127,10 @@ struct BlockDot<FMT_Q4P> {
         PermLut t;
         t.tl[0] = quad_bcast<0>(tlm), t.tl[1] = quad_bcast<1>(tlm), t.tl[2] = quad_bcast<2>(tlm), t.tl[3] = quad_bcast<3>(tlm);
         t.th[0] = quad_bcast<0>(thm), t.th[1] = quad_bcast<1>(thm), t.th[2] = quad_bcast<2>(thm), t.th[3] = quad_bcast<3>(thm);
-        acc = perm_dot_dword_nat(w.w, xs[col], t, acc);
-        acc = perm_dot_dword_nat(w.z, xs[nBlk + col], t, acc);
-        acc = perm_dot_dword_nat(w.y, xs[2 * nBlk + col], t, acc);
-        acc = perm_dot_dword_nat(w.x, xs[3 * nBlk + col], t, acc);
+        acc = perm_dot_dword_nat<CANON>(w.w, xs[col], t, acc);
+        acc = perm_dot_dword_nat<CANON>(w.z, xs[nBlk + col], t, acc);
+        acc = perm_dot_dword_nat<CANON>(w.y, xs[2 * nBlk + col], t, acc);
+        acc = perm_dot_dword_nat<CANON>(w.x, xs[3 * nBlk + col], t, acc);
         return acc;
     }
 };
@@ -122,8 +138,8 @@ struct BlockDot<FMT_Q4P> {
 // 4-bit row codebook (KF_QUANT_ROW_LUT; CU_Q42X_NF4 / CU_Q42X_lut, quantizer.cu:583-652): the row's nibbles as BIT_SET_k streams them
 // (element 2b in the high nibble of byte b), a weight = lut[row][nibble].  The 16 bf16 entries sit in two 16-byte words per row; they
 // become the byte planes of the register lookup above, and a byte swap turns a stream dword into the Packed128 nibble order it expects.
-template <>
-struct BlockDot<FMT_Q4R> {
+template <bool CANON>
+struct BlockDot<FMT_Q4R, CANON> {
     static constexpr int EPB = 32, XCH = 4;
     static constexpr bool HAS_GAMA = false;
     __device__ static __forceinline__ float run(u32x4, const u32x4*, int, int, float, float, float, float acc) { return acc; }
@@ -135,16 +151,17 @@ struct BlockDot<FMT_Q4R> {
             t.tl[k] = __builtin_amdgcn_perm(P[2 * k + 1], P[2 * k], 0x06040200u);
             t.th[k] = __builtin_amdgcn_perm(P[2 * k + 1], P[2 * k], 0x07050301u);
         }
-        acc = perm_dot_dword_nat(__builtin_amdgcn_perm(0u, w.x, 0x00010203u), xs[col], t, acc);
-        acc = perm_dot_dword_nat(__builtin_amdgcn_perm(0u, w.y, 0x00010203u), xs[nBlk + col], t, acc);
-        acc = perm_dot_dword_nat(__builtin_amdgcn_perm(0u, w.z, 0x00010203u), xs[2 * nBlk + col], t, acc);
-        acc = perm_dot_dword_nat(__builtin_amdgcn_perm(0u, w.w, 0x00010203u), xs[3 * nBlk + col], t, acc);
+        acc = perm_dot_dword_nat<CANON>(__builtin_amdgcn_perm(0u, w.x, 0x00010203u), xs[col], t, acc);
+        acc = perm_dot_dword_nat<CANON>(__builtin_amdgcn_perm(0u, w.y, 0x00010203u), xs[nBlk + col], t, acc);
+        acc = perm_dot_dword_nat<CANON>(__builtin_amdgcn_perm(0u, w.z, 0x00010203u), xs[2 * nBlk + col], t, acc);
+        acc = perm_dot_dword_nat<CANON>(__builtin_amdgcn_perm(0u, w.w, 0x00010203u), xs[3 * nBlk + col], t, acc);
         return acc;
     }
 };
 
 // 2-bit (T_SIGN ternary / generic CU_Q128toX_<T,64>): element i < 32 at high >> (62-2i) (PackedQ.hpp:185-226):
 // dword3 -> elements 0..15 (element 0 in bits 30..31), dword2 -> 16..31, dword1 -> 32..47, dword0 -> 48..63.
+template <bool CANON>
 __device__ __forceinline__ float dot_q2_dword(uint32_t D, u32x4 Xa, u32x4 Xb, float step, float nb, float zero, float acc) {
     const uint32_t xw[8] = {Xa.x, Xa.y, Xa.z, Xa.w, Xb.x, Xb.y, Xb.z, Xb.w};
 #pragma unroll
@@ -152,19 +169,19 @@ __device__ __forceinline__ float dot_q2_dword(uint32_t D, u32x4 Xa, u32x4 Xb, fl
         float q0 = (float)((D >> (30 - 4 * p)) & 3u), q1 = (float)((D >> (28 - 4 * p)) & 3u);
         uint32_t r = pack_bf16x2(fmaf(q0, step, nb), fmaf(q1, step, nb));
         uint32_t w = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
-        acc = dot2_bf16(w, xw[p], acc);
+        acc = dotp<CANON>(w, xw[p], acc);
     }
     return acc;
 }
-template <>
-struct BlockDot<FMT_Q2> {
+template <bool CANON>
+struct BlockDot<FMT_Q2, CANON> {
     static constexpr int EPB = 64, XCH = 8;
     static constexpr bool HAS_GAMA = true;
     __device__ static __forceinline__ float run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, float acc) {
-        acc = dot_q2_dword(w.w, xs[col], xs[nBlk + col], step, nb, zero, acc);
-        acc = dot_q2_dword(w.z, xs[2 * nBlk + col], xs[3 * nBlk + col], step, nb, zero, acc);
-        acc = dot_q2_dword(w.y, xs[4 * nBlk + col], xs[5 * nBlk + col], step, nb, zero, acc);
-        acc = dot_q2_dword(w.x, xs[6 * nBlk + col], xs[7 * nBlk + col], step, nb, zero, acc);
+        acc = dot_q2_dword<CANON>(w.w, xs[col], xs[nBlk + col], step, nb, zero, acc);
+        acc = dot_q2_dword<CANON>(w.z, xs[2 * nBlk + col], xs[3 * nBlk + col], step, nb, zero, acc);
+        acc = dot_q2_dword<CANON>(w.y, xs[4 * nBlk + col], xs[5 * nBlk + col], step, nb, zero, acc);
+        acc = dot_q2_dword<CANON>(w.x, xs[6 * nBlk + col], xs[7 * nBlk + col], step, nb, zero, acc);
         return acc;
     }
 };
@@ -172,6 +189,7 @@ struct BlockDot<FMT_Q2> {
 // 1-bit (BOOL1 / T_BINARY, CU_Q128toX_<T,128>): element i < 64 at high >> (63-i) (PackedQ.hpp:200-239):
 // dword3 -> elements 0..31 (element 0 = bit 31), dword2 -> 32..63, dword1 -> 64..95, dword0 -> 96..127.
 // w in {w0, w1} = {dequant(0), dequant(1)}: both are formed once per block, then selected per bit.
+template <bool CANON>
 __device__ __forceinline__ float dot_q1_dword(uint32_t D, const u32x4* xs, int base, int nBlk, int col, uint32_t w0, uint32_t w1, float acc) {
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -181,13 +199,13 @@ __device__ __forceinline__ float dot_q1_dword(uint32_t D, const u32x4* xs, int b
         for (int p = 0; p < 4; p++) {
             const int k = c * 8 + p * 2; /* elements k, k+1 of this dword */
             uint32_t lo = ((D >> (31 - k)) & 1u) ? w1 : w0, hi = ((D >> (30 - k)) & 1u) ? w1 : w0;
-            acc = dot2_bf16((lo & 0xffffu) | (hi << 16), xw[p], acc);
+            acc = dotp<CANON>((lo & 0xffffu) | (hi << 16), xw[p], acc);
         }
     }
     return acc;
 }
-template <>
-struct BlockDot<FMT_Q1> {
+template <bool CANON>
+struct BlockDot<FMT_Q1, CANON> {
     static constexpr int EPB = 128, XCH = 16;
     static constexpr bool HAS_GAMA = true;
     __device__ static __forceinline__ float run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, float acc) {
@@ -195,10 +213,10 @@ struct BlockDot<FMT_Q1> {
         uint32_t r = pack_bf16x2(fmaf(0.0f, step, nb), fmaf(1.0f, step, nb));
         uint32_t ww = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
         const uint32_t w0 = ww & 0xffffu, w1 = ww >> 16;
-        acc = dot_q1_dword(w.w, xs, 0, nBlk, col, w0, w1, acc);
-        acc = dot_q1_dword(w.z, xs, 4, nBlk, col, w0, w1, acc);
-        acc = dot_q1_dword(w.y, xs, 8, nBlk, col, w0, w1, acc);
-        acc = dot_q1_dword(w.x, xs, 12, nBlk, col, w0, w1, acc);
+        acc = dot_q1_dword<CANON>(w.w, xs, 0, nBlk, col, w0, w1, acc);
+        acc = dot_q1_dword<CANON>(w.z, xs, 4, nBlk, col, w0, w1, acc);
+        acc = dot_q1_dword<CANON>(w.y, xs, 8, nBlk, col, w0, w1, acc);
+        acc = dot_q1_dword<CANON>(w.x, xs, 12, nBlk, col, w0, w1, acc);
         return acc;
     }
 };
@@ -207,8 +225,8 @@ struct BlockDot<FMT_Q1> {
 // before the x prologue's barrier); each selector dword picks {w0, w1} for a weight pair out of the register (w1 << 16 | w0).  The same weights,
 // pairs and summation order as BlockDot<FMT_Q1> -- every output bit is equal -- at 1 ds_read_b128 + 4 v_perm + 4 dot2 per 8 weights instead of
 // ~32 VALU instructions.
-template <>
-struct BlockDot<FMT_Q1T> {
+template <bool CANON>
+struct BlockDot<FMT_Q1T, CANON> {
     static constexpr int EPB = 128, XCH = 16;
     static constexpr bool HAS_GAMA = true;
     __device__ static __forceinline__ float run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, float acc) {
@@ -222,10 +240,10 @@ struct BlockDot<FMT_Q1T> {
             for (int c = 0; c < 4; c++) {
                 const u32x4 S = tab[(dw[d] >> (24 - 8 * c)) & 0xffu];
                 const u32x4 X = xs[(4 * d + c) * nBlk + col];
-                acc = dot2_bf16(__builtin_amdgcn_perm(0u, ww, S.x), X.x, acc);
-                acc = dot2_bf16(__builtin_amdgcn_perm(0u, ww, S.y), X.y, acc);
-                acc = dot2_bf16(__builtin_amdgcn_perm(0u, ww, S.z), X.z, acc);
-                acc = dot2_bf16(__builtin_amdgcn_perm(0u, ww, S.w), X.w, acc);
+                acc = dotp<CANON>(__builtin_amdgcn_perm(0u, ww, S.x), X.x, acc);
+                acc = dotp<CANON>(__builtin_amdgcn_perm(0u, ww, S.y), X.y, acc);
+                acc = dotp<CANON>(__builtin_amdgcn_perm(0u, ww, S.z), X.z, acc);
+                acc = dotp<CANON>(__builtin_amdgcn_perm(0u, ww, S.w), X.w, acc);
             }
         return acc;
     }
@@ -234,8 +252,8 @@ struct BlockDot<FMT_Q1T> {
 // 2-bit the same way: a weight byte (4 weights) indexes 8 selector bytes (256 entries x 8 B); the four dequantised levels sit in two registers
 // {dequant(1) << 16 | dequant(0)}, {dequant(3) << 16 | dequant(2)} that v_perm_b32 reads as one 8-byte source.  1 ds_read_b64 + 2 v_perm + 2 dot2
 // per 4 weights instead of ~22 VALU instructions; weights, pairs and summation order are those of BlockDot<FMT_Q2>.
-template <>
-struct BlockDot<FMT_Q2T> {
+template <bool CANON>
+struct BlockDot<FMT_Q2T, CANON> {
     static constexpr int EPB = 64, XCH = 8;
     static constexpr bool HAS_GAMA = true;
     __device__ static __forceinline__ float run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, float acc) {
@@ -252,8 +270,8 @@ struct BlockDot<FMT_Q2T> {
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const u32x2 S = tab[(dw[d] >> (24 - 8 * c)) & 0xffu];
-                acc = dot2_bf16(__builtin_amdgcn_perm(T23, T01, S.x), xw[2 * c], acc);
-                acc = dot2_bf16(__builtin_amdgcn_perm(T23, T01, S.y), xw[2 * c + 1], acc);
+                acc = dotp<CANON>(__builtin_amdgcn_perm(T23, T01, S.x), xw[2 * c], acc);
+                acc = dotp<CANON>(__builtin_amdgcn_perm(T23, T01, S.y), xw[2 * c + 1], acc);
             }
         }
         return acc;

@@ -66,10 +66,13 @@ struct GemvLaunch {
     int mode;
     long target_waves; /* 0: default */
     int n_hot;         /* args.row_map != NULL: number of entries */
+    int canon;         /* the canonical summation order (two v_fma_f32 per weight pair; oracle/kf_oracle.c section 4c) instead of v_dot2c_f32_bf16 */
     int blocks;        /* out */
 };
 
 int gemv_launch(hipStream_t st, GemvLaunch& L);
+int gemv_launch_dot2(hipStream_t st, GemvLaunch& L);  /* kf_gemv.hip */
+int gemv_launch_canon(hipStream_t st, GemvLaunch& L); /* kf_gemv_canon.hip: the same file, canonical instantiation */
 // tensor-parallel exchange (kf_tp.hip)
 int tp_reduce_recv_launch(hipStream_t st, const unsigned long long* slots, int R, int n_max, int n, const unsigned* d_step, unsigned per_step, unsigned index,
                           const uint16_t* residual, uint16_t* out, int* d_err);
@@ -102,7 +105,7 @@ struct AttnArgs {
     const uint16_t* wq_norm;
     const uint16_t* wk_norm;
     const float* rope_table; /* NULL: q is already normed+roped */
-    float* part;             /* [n_head][n_splits][hd + 4] fp32 partials {acc, m, l, pad, pad} */
+    float* part;             /* [n_head][n_splits][hd + 2] fp64 partials {O, L, m} (kf_attn.hip reads it as doubles) */
     int* counters;           /* [n_kv] arrival counters, zero between launches */
     uint16_t* out;
     const int* d_pos;

@@ -492,10 +492,71 @@ static float dot16(const float* w, const float* x, int n) {
     return (s4[0] + s4[1]) + (s4[2] + s4[3]);
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * 4c. The CANONICAL summation order of the mat-vec (round 3).  cuBLASLt's order is unspecified (gemm.cu:126), so any fixed fp32 order is
+ *     a faithful SLP::Forw; sections 4 / 4b use the order of the reference's CPU primitive (dotprod_fp16).  The HIP kernels cannot follow
+ *     that one cheaply, and their v_dot2c_f32_bf16 has no bit-exact CPU model -- so kernels and oracle share THIS order instead, built
+ *     from single fp32 fused multiply-adds only (v_fma_f32 on the GPU, fmaf here), which makes every logit and every greedy id equal
+ *     bit for bit (tests/test_gpu_canonical.py; bench.py cpu_baseline.mismatches_* = 0):
+ *       - a row is cut into 16-byte storage blocks of EPB elements (8 bf16 / 16 f8 / 32 four-bit / 64 two-bit / 128 one-bit);
+ *       - LPR = 2^lpr_log2 "lanes" walk the row: lane l owns blocks l, l + LPR, l + 2 LPR, ... and keeps ONE accumulator through all of
+ *         them, acc = fmaf(w[i], x[i], acc) over the elements of a block in index order;
+ *       - the LPR accumulators are added by a balanced binary tree (lanes 2j + 2j+1, then pairs of pairs, ...).
+ *     lpr_log2 = kfo_lpr_log2(blocks per row, rows of the launch): the rule of kf::gemv_lpr_log2 (koifish_amd/csrc/kf_gemv.hip), restated.
+ *     `rows` = the rows of ALL matrices a launch multiplies (Q | K | V together; gate alone for the paired gate / up launch).
+ * ---------------------------------------------------------------------------------------------- */
+static int g_order = 0; /* 0: the dot16 order of sections 4 / 4b; 1: canonical */
+KFO_API void kfo_set_order(int o) { g_order = o; }
+KFO_API int kfo_get_order(void) { return g_order; }
+KFO_API int kfo_lpr_log2(int nBlk, long rows) {
+    int l = 6;
+    while (l > 0 && (nBlk % (1 << l)) != 0) l--;
+    if ((1 << l) < 16) {
+        l = 6;
+        while ((1 << l) > nBlk) l--;
+    }
+    while (l < 6 && nBlk > (1 << l) && (rows << l) / 64 < 1024 && (nBlk + (2 << l) - 1) / (2 << l) < (nBlk + (1 << l) - 1) / (1 << l)) l++;
+    return l;
+}
+static int epb_of_type(int type) { /* elements per 16-byte storage block; 0: the canonical order is not defined for this storage */
+    switch (type) {
+        case KFO_BF16: return 8;
+        case KFO_F8E5M2: return 16;
+        case KFO_Q4: case KFO_Q4_LUT: return 32;
+        case KFO_T_SIGN: case KFO_Q2: return 64;
+        case KFO_BOOL1: case KFO_T_BINARY: return 128;
+        default: return 0;
+    }
+}
+static float dot_canon(const float* w, const float* x, int K, int epb, int lpr_log2) {
+    const int nBlk = K / epb, LPR = 1 << lpr_log2;
+    float lane[64];
+    for (int l = 0; l < LPR; l++) {
+        float acc = 0.f;
+        for (int c = l; c < nBlk; c += LPR) {
+            const float *wb = w + (size_t)c * epb, *xb = x + (size_t)c * epb;
+            for (int i = 0; i < epb; i++) acc = fmaf(wb[i], xb[i], acc);
+        }
+        lane[l] = acc;
+    }
+    for (int s = 1; s < LPR; s <<= 1)
+        for (int l = 0; l < LPR; l += 2 * s) lane[l] = lane[l] + lane[l + s];
+    return lane[0];
+}
+/* row dot in the order the library is set to; `rows` only matters for the canonical order */
+static float row_dot(const kfo_weight* w, const float* row, const float* xf, int c0, int c1, long rows) {
+    const int epb = epb_of_type(w->type);
+    if (g_order == 1 && epb > 0 && (c1 - c0) % epb == 0) return dot_canon(row + c0, xf + c0, c1 - c0, epb, kfo_lpr_log2((c1 - c0) / epb, rows));
+    return dot16(row + c0, xf + c0, c1 - c0);
+}
+static long g_launch_rows = 0; /* rows of the launch the next kfo_linear* calls belong to (0: the matrix's own rows) */
+KFO_API void kfo_set_launch_rows(long rows) { g_launch_rows = rows; }
+
 /* y[r] = bf16( alpha * W[r,:].x  (+ bias[r]) (+ beta*y[r]) ),  rows [r0,r1) only (TP shards use it) */
 KFO_API void kfo_linear_rows(const kfo_weight* w, const uint16_t* x, uint16_t* y, const uint16_t* bias, float alpha, float beta, int r0,
                              int r1) {
     const int K = w->ne1;
+    const long lrows = g_launch_rows > 0 ? g_launch_rows : w->ne0;
     float* xf = (float*)malloc(sizeof(float) * K);
     for (int c = 0; c < K; c++) xf[c] = kfo_bf16_to_f32(x[c]);
 #pragma omp parallel
@@ -504,7 +565,7 @@ KFO_API void kfo_linear_rows(const kfo_weight* w, const uint16_t* x, uint16_t* y
 #pragma omp for schedule(static)
         for (long r = r0; r < r1; r++) {
             weight_row_f32(w, r, row);
-            float v = dot16(row, xf, K);
+            float v = row_dot(w, row, xf, 0, K, lrows);
             if (alpha != 1.0f) v = alpha * v;
             if (beta != 0.0f) v = v + beta * kfo_bf16_to_f32(y[r]);
             if (bias) v = v + kfo_bf16_to_f32(bias[r]);
@@ -531,7 +592,7 @@ KFO_API void kfo_linear_masked(const kfo_weight* w, const uint16_t* x, uint16_t*
             float v = 0.f;
             if (hot[r] == 1) {
                 weight_row_f32(w, r, row);
-                v = dot16(row, xf, K);
+                v = row_dot(w, row, xf, 0, K, g_launch_rows > 0 ? g_launch_rows : w->ne0);
             }
             if (bias) v = v + kfo_bf16_to_f32(bias[r]);
             y[r] = kfo_f32_to_bf16(v);
@@ -551,7 +612,7 @@ KFO_API void kfo_linear_f32(const kfo_weight* w, const uint16_t* x, float* y, in
 #pragma omp for schedule(static)
         for (long r = 0; r < w->ne0; r++) {
             weight_row_f32(w, r, row);
-            y[r] = dot16(row + c0, xf + c0, c1 - c0);
+            y[r] = row_dot(w, row, xf, c0, c1, g_launch_rows > 0 ? g_launch_rows : w->ne0);
         }
         free(row);
     }
@@ -610,6 +671,27 @@ static void linear_w16(const uint16_t* W, int is_f16, int M, int K, const uint16
     free(xf);
 }
 KFO_API void kfo_linear_w16(const uint16_t* W, int is_f16, int M, int K, const uint16_t* x, uint16_t* y) { linear_w16(W, is_f16, M, K, x, y, NULL); }
+/* the same 16-bit view multiplied in the canonical order of section 4c (epb = the blocks of the tensor's OWN storage, not of the bf16 view) */
+static void linear_canon_w16(const uint16_t* W, int M, int K, int epb, int lpr_log2, const uint16_t* x, uint16_t* y, const int32_t* hot) {
+    float* xf = (float*)malloc(sizeof(float) * K);
+    for (int c = 0; c < K; c++) xf[c] = kfo_bf16_to_f32(x[c]);
+#pragma omp parallel
+    {
+        float* row = (float*)malloc(sizeof(float) * K);
+#pragma omp for schedule(static)
+        for (long r = 0; r < M; r++) {
+            float v = 0.f;
+            if (!hot || hot[r] == 1) {
+                const uint16_t* p = W + (size_t)r * K;
+                for (int c = 0; c < K; c++) row[c] = kfo_bf16_to_f32(p[c]);
+                v = dot_canon(row, xf, K, epb, lpr_log2);
+            }
+            y[r] = kfo_f32_to_bf16(v);
+        }
+        free(row);
+    }
+    free(xf);
+}
 
 /* ------------------------------------------------------------------------------------------------
  * 5. Small ops
@@ -1214,10 +1296,59 @@ KFO_API int kfo_adamw(uint16_t* params, uint16_t* grads, void* gm, void* gv, siz
  *                    probabilities held in bf16 (qk_v is floatX, TGraph.cpp:124).
  *    mode 1 "FUSED": what the fused HIP kernel computes: bf16 scores (same store as REF), then an fp32
  *                    softmax, out = (sum_t e_t v_t) * (1/sum_t e_t) in fp32, one bf16 store.
+ *    mode 2 "CANON": the order kernels and oracle share (round 3), free of any launch geometry:
+ *                    score  s_t = bf16( d_t * (1/sqrtf(hd)) ), d_t = the q.k dot summed as hd/8 chains of 8 fused multiply-adds (elements
+ *                           8j .. 8j+7 in order) joined by a balanced binary tree -- the 16 (8) lanes of a key on the GPU;
+ *                    weight p_t = f_t * 2^(n_t - m), (f_t, n_t) = kfo_exp2_parts(s_t * log2 e), m = max_t n_t: an exact power-of-two scaling,
+ *                           so slices / waves / lanes of the GPU may each work against a maximum of their own and rescale exactly;
+ *                    sums   L = sum_t p_t and O_i = sum_t p_t v_t,i in fp64 (every term is exact in fp64; the sums are then independent of their
+ *                           order far below an fp32 ulp -- the argument of the fp64 RMSNorm sum), out_i = bf16( (float)(O_i / L) ).
  *    q: bf16 [n_head*hd]; kc/vc: layer base, rows of kv_stride elements; out: bf16 [n_head*hd].
  * ---------------------------------------------------------------------------------------------- */
+static void attn_decode_canon(const uint16_t* q, const uint16_t* kc, const uint16_t* vc, uint16_t* out, int pos, int n_head, int n_kv, int hd, int kv_stride) {
+    const int kv_mul = n_head / n_kv, len = pos + 1, LPK = hd / 8;
+    const float rden = 1.0f / sqrtf((float)hd);
+#pragma omp parallel for schedule(static)
+    for (int h = 0; h < n_head; h++) {
+        const int kvh = h / kv_mul;
+        float qf[128];
+        for (int i = 0; i < hd; i++) qf[i] = kfo_bf16_to_f32(q[(size_t)h * hd + i]);
+        float* ff = (float*)malloc(sizeof(float) * len);
+        float* nn = (float*)malloc(sizeof(float) * len);
+        double* O = (double*)calloc(hd, sizeof(double));
+        float m = -INFINITY;
+        for (int t = 0; t < len; t++) {
+            const uint16_t* kt = kc + (size_t)t * kv_stride + (size_t)kvh * hd;
+            float lane[16];
+            for (int j = 0; j < LPK; j++) {
+                float acc = 0.f;
+                for (int i = 0; i < 8; i++) acc = fmaf(qf[8 * j + i], kfo_bf16_to_f32(kt[8 * j + i]), acc);
+                lane[j] = acc;
+            }
+            for (int s = 1; s < LPK; s <<= 1)
+                for (int j = 0; j < LPK; j += 2 * s) lane[j] = lane[j] + lane[j + s];
+            const float sc = kfo_round_bf16(lane[0] * rden);
+            kfo_exp2_parts(sc * 1.44269502162933349609375f, &ff[t], &nn[t]);
+            if (nn[t] > m) m = nn[t];
+        }
+        double L = 0.0;
+        for (int t = 0; t < len; t++) {
+            const uint16_t* vt = vc + (size_t)t * kv_stride + (size_t)kvh * hd;
+            const double p = ldexp((double)ff[t], (int)fmaxf(nn[t] - m, -1022.0f));
+            L += p;
+            for (int i = 0; i < hd; i++) O[i] = fma(p, (double)kfo_bf16_to_f32(vt[i]), O[i]);
+        }
+        for (int i = 0; i < hd; i++) out[(size_t)h * hd + i] = kfo_f32_to_bf16((float)(O[i] / L));
+        free(ff), free(nn), free(O);
+    }
+}
+
 KFO_API void kfo_attn_decode(const uint16_t* q, const uint16_t* kc, const uint16_t* vc, uint16_t* out, int pos, int n_head, int n_kv, int hd,
                              int kv_stride, int mode) {
+    if (mode == 2) {
+        attn_decode_canon(q, kc, vc, out, pos, n_head, n_kv, hd, kv_stride);
+        return;
+    }
     const int kv_mul = n_head / n_kv, len = pos + 1;
     const float scale_den = sqrtf((float)hd);
 #pragma omp parallel for schedule(static)
@@ -1368,10 +1499,12 @@ static void linear_colsplit(const kfo_weight* w, const uint16_t* x, uint16_t* y,
     const int M = w->ne0, K = w->ne1, kc = K / tp;
     float* part = (float*)malloc(sizeof(float) * M);
     float* tot = (float*)calloc(M, sizeof(float));
+    kfo_set_launch_rows(M); /* canonical order: each rank's launch multiplies its column shard of all M rows */
     for (int r = 0; r < tp; r++) {
         kfo_linear_f32(w, x, part, r * kc, (r + 1) * kc);
         for (int i = 0; i < M; i++) tot[i] = (r == 0) ? part[i] : tot[i] + part[i];
     }
+    kfo_set_launch_rows(0);
     for (int i = 0; i < M; i++) y[i] = kfo_f32_to_bf16(tot[i]);
     free(part), free(tot);
 }
@@ -1418,7 +1551,20 @@ KFO_API long long kfo_qwen3_prepare_fast(kfo_qwen3* m) {
     free(ws);
     return bytes;
 }
-static void model_linear(kfo_qwen3* m, int layer, int slot, const kfo_weight* w, const uint16_t* x, uint16_t* y, const int32_t* hot) {
+static void model_linear(kfo_qwen3* m, int layer, int slot, const kfo_weight* w, const uint16_t* x, uint16_t* y, const int32_t* hot, long rows) {
+    const int epb = epb_of_type(w->type);
+    if (g_order == 1 && epb > 0 && w->ne1 % epb == 0) { /* canonical order: `rows` = the rows of the launch this matrix is multiplied in */
+        const int i = layer < 0 ? m->n_layer * 7 : layer * 7 + slot;
+        if (m->fast && !m->fast_f16[i]) {
+            linear_canon_w16(m->fast[i], w->ne0, w->ne1, epb, kfo_lpr_log2(w->ne1 / epb, rows), x, y, hot);
+        } else {
+            kfo_set_launch_rows(rows);
+            if (hot) kfo_linear_masked(w, x, y, NULL, hot);
+            else kfo_linear(w, x, y, NULL, 1.0f, 0.0f);
+            kfo_set_launch_rows(0);
+        }
+        return;
+    }
     if (m->fast) {
         const int i = layer < 0 ? m->n_layer * 7 : layer * 7 + slot;
         linear_w16(m->fast[i], m->fast_f16[i], w->ne0, w->ne1, x, y, hot);
@@ -1447,29 +1593,30 @@ KFO_API int kfo_qwen3_decode(kfo_qwen3* m, int token, int pos, uint16_t* logits_
         uint16_t* vc = m->vcache + (size_t)l * m->max_seq * kvd;
         uint16_t *krow = kc + (size_t)pos * kvd, *vrow = vc + (size_t)pos * kvd; /* _devQKV: TGraph.cpp:198-207 */
         kfo_rmsnorm(x, L->norm_in, xb, 1, D, m->rms_eps);
-        model_linear(m, l, 0, &L->q, xb, q, NULL);
-        model_linear(m, l, 1, &L->k, xb, krow, NULL);
-        model_linear(m, l, 2, &L->v, xb, vrow, NULL);
+        const int tp = m->tp > 1 ? m->tp : 1;
+        model_linear(m, l, 0, &L->q, xb, q, NULL, (qd + 2 * kvd) / tp); /* Q | K | V are one launch (per rank: its shard of each) */
+        model_linear(m, l, 1, &L->k, xb, krow, NULL, (qd + 2 * kvd) / tp);
+        model_linear(m, l, 2, &L->v, xb, vrow, NULL, (qd + 2 * kvd) / tp);
         if (L->qn) kfo_headnorm(q, L->qn, m->n_head, hd, m->qk_eps);
         if (L->kn) kfo_headnorm(krow, L->kn, m->n_kv, hd, m->qk_eps);
         kfo_rope(q, m->n_head, hd, pos, m->theta);
         kfo_rope(krow, m->n_kv, hd, pos, m->theta);
         kfo_attn_decode(q, kc, vc, att, pos, m->n_head, m->n_kv, hd, kvd, m->attn_mode);
-        if (m->tp <= 1) model_linear(m, l, 3, &L->o, att, p, NULL);
+        if (m->tp <= 1) model_linear(m, l, 3, &L->o, att, p, NULL, D);
         else linear_colsplit(&L->o, att, p, m->tp);
         kfo_add(x, p, x, D);
         kfo_rmsnorm(x, L->norm_post, xb, 1, D, m->rms_eps);
-        model_linear(m, l, 4, &L->gate, xb, gt, L->hot); /* L->hot: the sparse forward, D_matmul_sparse on the FFN's rows */
-        model_linear(m, l, 5, &L->up, xb, up, L->hot);
+        model_linear(m, l, 4, &L->gate, xb, gt, L->hot, F / tp); /* L->hot: the sparse forward, D_matmul_sparse on the FFN's rows; gate | up: the paired launch counts gate's rows */
+        model_linear(m, l, 5, &L->up, xb, up, L->hot, F / tp);
         kfo_swiglu(gt, up, gt, F);
-        if (m->tp <= 1) model_linear(m, l, 6, &L->down, gt, p, NULL);
+        if (m->tp <= 1) model_linear(m, l, 6, &L->down, gt, p, NULL, D);
         else linear_colsplit(&L->down, gt, p, m->tp);
         kfo_add(x, p, x, D);
     }
     kfo_rmsnorm(x, m->final_norm, xb, 1, D, m->rms_eps);
     if (hidden_out) memcpy(hidden_out, xb, 2 * D);
     uint16_t* logits = logits_out ? logits_out : (uint16_t*)malloc(2 * (size_t)m->vocab);
-    model_linear(m, -1, 1, &m->head, xb, logits, NULL);
+    model_linear(m, -1, 1, &m->head, xb, logits, NULL, m->vocab / (m->tp > 1 ? m->tp : 1));
     int next = kfo_argmax_bf16(logits, m->vocab);
     if (!logits_out) free(logits);
     free(x), free(xb), free(q), free(att), free(p), free(gt), free(up);

@@ -115,6 +115,24 @@ static inline float kfo_expf(float x) {
     return (p * s1) * s2;
 }
 
+/* kfo_exp2_parts: 2^y as f * 2^n with n = the integer nearest to y (ties to even) and f = 2^(y - n) in [2^-1/2, 2^1/2] from a fixed degree-7
+ * polynomial (Taylor coefficients ln2^k / k!, Horner in fma form; relative error 5e-9).  The decode attention's canonical softmax (kf_oracle.c
+ * section 6, mode CANON; koifish_amd/csrc/kf_device.h kf_exp2_parts states the same recipe) keeps the two parts apart: a power of two rescales
+ * exactly, so e^(s - m) needs no agreed-upon maximum m between the slices of a sequence. */
+static inline void kfo_exp2_parts(float y, float* f, float* n) {
+    const float nn = (y + 12582912.0f) - 12582912.0f; /* RNE to integer, |y| < 2^22 (larger |y|: nn = y, r = 0) */
+    const float r = y - nn;                            /* exact */
+    float p = 1.52527338e-5f;        /* ln2^7 / 5040 */
+    p = fmaf(p, r, 1.54035304e-4f);  /* ln2^6 / 720 */
+    p = fmaf(p, r, 1.33335581e-3f);  /* ln2^5 / 120 */
+    p = fmaf(p, r, 9.61812911e-3f);  /* ln2^4 / 24 */
+    p = fmaf(p, r, 5.55041087e-2f);  /* ln2^3 / 6 */
+    p = fmaf(p, r, 2.40226507e-1f);  /* ln2^2 / 2 */
+    p = fmaf(p, r, 6.93147181e-1f);  /* ln2 */
+    p = fmaf(p, r, 1.0f);
+    *f = p, *n = nn;
+}
+
 /* kfo_logf: the fixed fp32 natural log of the cross-entropy loss (koifish_amd/csrc/kf_device.h kf_logf states the same recipe
  * independently; the reference calls CUDA logf, fused_classifier.cuh:84).  x = m * 2^e, m in [sqrt(1/2), sqrt(2)), s = (m-1)/(m+1),
  * log m = 2s + 2s*z*P(z), z = s^2.  tests/test_oracle_loss.py pins it to libm logf within 2 ulp. */

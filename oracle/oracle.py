@@ -21,7 +21,8 @@ BITS = {BF16: 16, F16: 16, F8E5M2: 8, Q4: 4, T_SIGN: 2, Q2: 2, BOOL1: 1, T_BINAR
 Q4_AWQ = 100  # oracle-internal tag: Q4 in the AutoAWQ GEMM layout
 Q4_LUT = 101  # oracle-internal tag: Q4 in the row-codebook storage (GeQuant::RT_NormalF)
 Q3_LUT, Q2_LUT, Q2_ROWRTN = 102, 103, 104  # 8- / 4-entry row codebooks (3- / 2-bit streams); (zero, step) per row (CU_Q22X_RTN)
-ATTN_REF, ATTN_FUSED = 0, 1
+ATTN_REF, ATTN_FUSED, ATTN_CANON = 0, 1, 2
+ORDER_DOT16, ORDER_CANON = 0, 1  # summation order of the mat-vec: the reference's CPU primitive (dotprod_fp16) / the canonical order kernels and oracle share
 
 
 def build(force=False):
@@ -52,6 +53,37 @@ def lib():
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def set_order(order):
+    """ORDER_DOT16 (default) or ORDER_CANON: the canonical mat-vec order (kf_oracle.c section 4c).  Process-wide."""
+    lib().kfo_set_order(int(order))
+
+
+def get_order():
+    return int(lib().kfo_get_order())
+
+
+def lpr_log2(n_blk, rows):
+    return int(lib().kfo_lpr_log2(int(n_blk), C.c_long(int(rows))))
+
+
+class canonical:
+    """with O.canonical(rows=...): the canonical order for the mat-vecs inside; rows = the rows of ALL matrices of the launch being mirrored
+    (None: each matrix's own rows)"""
+
+    def __init__(self, rows=None):
+        self.rows = rows
+
+    def __enter__(self):
+        self.prev = get_order()
+        set_order(ORDER_CANON)
+        lib().kfo_set_launch_rows(C.c_long(int(self.rows or 0)))
+        return self
+
+    def __exit__(self, *a):
+        lib().kfo_set_launch_rows(C.c_long(0))
+        set_order(self.prev)
 
 
 # ---------------------------------------------------------------- bf16 helpers (numpy, RNE)
