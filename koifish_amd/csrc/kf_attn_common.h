@@ -107,15 +107,14 @@ struct CanonAcc {
         }
     }
 };
-// one batch of ATTN_U key tiles of this lane's key group: k / v tiles (8 elements of this lane), validity per tile; q as 8 floats per head
-template <int GQ, int LPK>
-__device__ __forceinline__ void canon_batch(CanonAcc<GQ>& A, const float (&qf)[GQ][8], const u32x4 (&kk)[ATTN_U], const u32x4 (&vv)[ATTN_U], const bool (&valid)[ATTN_U], int lpk_log2,
-                                            float rden) {
-    float f[ATTN_U][GQ], n[ATTN_U][GQ], bn[GQ];
+// one batch of U key tiles of this lane's key group: k / v tiles (8 elements of this lane), validity per tile; q as 8 floats per head
+template <int GQ, int LPK, int U = ATTN_U>
+__device__ __forceinline__ void canon_batch(CanonAcc<GQ>& A, const float (&qf)[GQ][8], const u32x4 (&kk)[U], const u32x4 (&vv)[U], const bool (&valid)[U], int lpk_log2, float rden) {
+    float f[U][GQ], n[U][GQ], bn[GQ];
 #pragma unroll
     for (int hq = 0; hq < GQ; hq++) bn[hq] = -__builtin_inff();
 #pragma unroll
-    for (int u = 0; u < ATTN_U; u++) {
+    for (int u = 0; u < U; u++) {
 #pragma unroll
         for (int hq = 0; hq < GQ; hq++) {
             const float s = canon_score(qf[hq], kk[u], lpk_log2, rden);
@@ -128,16 +127,18 @@ __device__ __forceinline__ void canon_batch(CanonAcc<GQ>& A, const float (&qf)[G
     for (int hq = 0; hq < GQ; hq++) { /* the wave's maximum exponent of this batch */
         bn[hq] = xmax32(xmax16(bn[hq]));
         if (LPK < 16) bn[hq] = fmaxf(bn[hq], dpp_f<0x128>(bn[hq]));
-        if (bn[hq] > A.m[hq]) { /* exact rescale of what has been summed so far (nothing yet: the sums are 0) */
-            const int e = canon_shift(A.m[hq] - bn[hq]);
-            A.l[hq] = ldexp_d(A.l[hq], e);
+        if (bn[hq] > A.m[hq]) { /* exact rescale of what has been summed so far (wave-uniform branch; the first batch has nothing to rescale) */
+            if (A.m[hq] > -__builtin_inff()) {
+                const int e = canon_shift(A.m[hq] - bn[hq]);
+                A.l[hq] = ldexp_d(A.l[hq], e);
 #pragma unroll
-            for (int i = 0; i < 8; i++) A.o[hq][i] = ldexp_d(A.o[hq][i], e);
+                for (int i = 0; i < 8; i++) A.o[hq][i] = ldexp_d(A.o[hq][i], e);
+            }
             A.m[hq] = bn[hq];
         }
     }
 #pragma unroll
-    for (int u = 0; u < ATTN_U; u++) {
+    for (int u = 0; u < U; u++) {
         const uint32_t vw[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
         double vd[8];
 #pragma unroll

@@ -378,7 +378,7 @@ struct EngLds {
     u32x4* xs[2];
     uint16_t *xrawA, *xrawB, *qraw, *kraw, *vraw, *qb, *knew;
     float* wmax;   /* [16] scratch of the head's arg-max */
-    double* comb;  /* [NW][GQ][hd + 2] the attention waves' fp64 sums {O[hd], L, m} */
+    double* comb;  /* [NWV][GQ][hd + 2] the waves' fp64 sums {O[hd], L, m} of the attention slice */
     uint32_t* outb; /* [64] a phase's output granules of this workgroup, gathered so that ONE wave stores them 16 bytes per lane */
     int* cnt;       /* arrival counter of the compute waves that own rows of the phase */
     double* msc;    /* [ME][KF_ATTN_MAX_SPLITS] the slice partials of this workgroup's merge elements, transposed for the per-element chains; [ME] dwords behind it: its ao granules */
@@ -442,6 +442,163 @@ __device__ __forceinline__ unsigned long long* eng_lpart(const EngArgs& a, int x
     return reinterpret_cast<unsigned long long*>(a.loc + 1024 + (size_t)8 * C::lq_stride * 4) + (size_t)xcc * C::lp_stride;
 }
 
+// ---- P2 for one wave: q/k-norm + RoPE + the canonical attention over this workgroup's slice, run by ALL 8 waves of the workgroup (the poller too: it has nothing
+// to wait for between the staging of the raw heads and the slice partials).  The canonical softmax sums in fp64 against per-wave exponents (kf_attn_common.h), so
+// how the keys are dealt to waves and lanes does not show in the result: wave w takes the keys t0 + w * KPW + group + 8 * KPW * u.
+template <class C>
+struct EngAttnState { /* the wave's K / V tiles of the slice, requested a layer ahead */
+    static constexpr int U = 2; /* tiles per batch: 8 waves x (64 / LPK) keys x 2 = 64 keys (hd 128) */
+    u32x4 kk[U], vv[U];
+    uint16_t qw0, qw1, kw0, kw1; /* the q / k-norm weights of this lane's pair: constants, requested at the top of the layer */
+};
+template <class C>
+__device__ __forceinline__ void eng_attn_normw(const EngLayer& ly, int lane, EngAttnState<C>& T) {
+    const int half = C::HD >> 1, j = lane < half ? lane : half - 1;
+    T.qw0 = T.qw1 = T.kw0 = T.kw1 = 0;
+    if (ly.norm_q) T.qw0 = ly.norm_q[j], T.qw1 = ly.norm_q[j + half];
+    if (ly.norm_k) T.kw0 = ly.norm_k[j], T.kw1 = ly.norm_k[j + half];
+}
+template <class C>
+__device__ __forceinline__ void eng_attn_issue(const EngArgs& a, const EngLayer& ly, const EngSlice& S, int wave, int lane, EngAttnState<C>& T, int b) {
+    constexpr int hd = C::HD, LPK = hd >> 3, KPW = 64 / LPK, lpk_log2 = (C::HD == 128 ? 7 : 6) - 3, NWA = C::NWV, U = EngAttnState<C>::U;
+    const int grp = lane >> lpk_log2, d0 = (lane & (LPK - 1)) * 8;
+    const int tb = S.t0 + wave * KPW + grp + b * U * NWA * KPW;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int t = tb + u * NWA * KPW;
+        T.kk[u] = T.vv[u] = u32x4{0, 0, 0, 0};
+        if (t < S.t1) {
+            const size_t off = (size_t)t * a.kv_stride + (size_t)S.kvh * hd + d0;
+            T.kk[u] = *reinterpret_cast<const u32x4 KF_GLOBAL*>(ly.kcache + off);
+            T.vv[u] = *reinterpret_cast<const u32x4 KF_GLOBAL*>(ly.vcache + off);
+        }
+    }
+}
+template <class C>
+__device__ __forceinline__ void eng_attn_phase(const EngArgs& a, const EngLds& L, const EngSlice& S, const EngLayer& ly, uint32_t gen, uint32_t tag, int wave, int lane,
+                                               EngAttnState<C>& T, int l, int wg) {
+    constexpr bool DBG = C::DBG;
+    constexpr int GQ = C::GQ, hd = C::HD, hd_log2 = C::HD == 128 ? 7 : 6, LPK = hd >> 3, KPW = 64 / LPK, lpk_log2 = hd_log2 - 3, NWA = C::NWV, U = EngAttnState<C>::U;
+    constexpr bool XMAP = C::XMAP;
+    constexpr int NQ = (GQ + NWA - 1) / NWA;
+    const int tid = wave * 64 + lane, pos = S.pos, nsp = S.nsp, kvh = S.kvh, h0 = S.h0, t1 = S.t1;
+    const int grp = lane >> lpk_log2, d0 = (lane & (LPK - 1)) * 8;
+    const int tstride = NWA * KPW, tstart = S.t0 + wave * KPW + grp;
+    const int nbatch = (S.t1 - S.t0 + U * tstride - 1) / (U * tstride);
+    __syncthreads(); /* raw heads staged */
+    if (wave == 0) ENG_STAMP(1, 2);
+    if (!S.empty) {
+        { /* prologue: q heads of this group, and the new key when it lies in this slice (ROPE::cuInfer) */
+            const float* tab_pos = a.rope_table + (size_t)pos * hd;
+            const bool qnorm = ly.norm_q != nullptr;
+            const int half = hd >> 1, j = lane < half ? lane : half - 1;
+#pragma unroll
+            for (int i = 0; i < NQ; i++) {
+                const int hq = wave + i * NWA;
+                if (hq < GQ) {
+                    HeadRaw r;
+                    r.x0 = L.qraw[hq * hd + j], r.x1 = L.qraw[hq * hd + j + half];
+                    r.w0 = qnorm ? T.qw0 : r.x0, r.w1 = qnorm ? T.qw1 : r.x1;
+                    prep_head(r, qnorm, tab_pos, hd, a.qk_eps, L.qb + hq * hd);
+                }
+            }
+            if (S.own_new && wave == (GQ % NWA)) {
+                HeadRaw r;
+                r.x0 = L.kraw[j], r.x1 = L.kraw[j + half];
+                r.w0 = ly.norm_k ? T.kw0 : r.x0, r.w1 = ly.norm_k ? T.kw1 : r.x1;
+                prep_head(r, ly.norm_k != nullptr, tab_pos, hd, a.qk_eps, L.knew);
+            }
+        }
+        __syncthreads(); /* heads prepared */
+        if (wave == 0) ENG_STAMP(1, 11);
+        if (S.own_new) { /* the cache rows of this position: the prepared key, the raw value (K.out / V.out alias them in the reference) */
+            g_u16w krow = ly.kcache + (size_t)pos * a.kv_stride + (size_t)kvh * hd;
+            g_u16w vrow = ly.vcache + (size_t)pos * a.kv_stride + (size_t)kvh * hd;
+            for (int i = tid; i < hd; i += NWA * 64) krow[i] = L.knew[i], vrow[i] = L.vraw[i];
+        }
+        CanonAcc<GQ> A;
+        A.init();
+        float qf[GQ][8];
+#pragma unroll
+        for (int hq = 0; hq < GQ; hq++) {
+            const u32x4 qv = *reinterpret_cast<const u32x4*>(L.qb + hq * hd + d0);
+            const uint32_t q4[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) qf[hq][2 * i] = bf_lo(q4[i]), qf[hq][2 * i + 1] = bf_hi(q4[i]);
+        }
+        const float rden = 1.0f / sqrtf((float)hd);
+        for (int b = 0; b < nbatch; b++) {
+            const int tb = tstart + b * U * tstride;
+            u32x4 ck[U], cv[U];
+            bool valid[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int t = tb + u * tstride;
+                valid[u] = t < t1;
+                ck[u] = T.kk[u], cv[u] = T.vv[u];
+                if (valid[u] && t == pos) ck[u] = *reinterpret_cast<const u32x4*>(L.knew + d0), cv[u] = *reinterpret_cast<const u32x4*>(L.vraw + d0);
+            }
+            if (b + 1 < nbatch) eng_attn_issue<C>(a, ly, S, wave, lane, T, b + 1);
+            canon_batch<GQ, LPK, U>(A, qf, ck, cv, valid, lpk_log2, rden);
+        }
+        if (wave == 0) ENG_STAMP(1, 12);
+        canon_wave_to_lds<GQ, LPK>(A, L.comb + (size_t)wave * GQ * (hd + 2), hd, lane, d0);
+        if (wave == 0) ENG_STAMP(1, 13);
+        __syncthreads(); /* the waves' fp64 sums in LDS */
+        if (wave == 0) ENG_STAMP(1, 14);
+        constexpr int PSD = hd + 2;
+        for (int i = tid; i < GQ * hd; i += NWA * 64) {
+            const int hq = i >> hd_log2, d = i & (hd - 1);
+            float ms = -__builtin_inff();
+#pragma unroll
+            for (int sl = 0; sl < NWA; sl++) ms = fmaxf(ms, (float)L.comb[((size_t)sl * GQ + hq) * PSD + hd + 1]);
+            double o = 0.0, Ls = 0.0;
+#pragma unroll
+            for (int sl = 0; sl < NWA; sl++) {
+                const double* c = L.comb + ((size_t)sl * GQ + hq) * PSD;
+                const int e = canon_shift((float)c[hd + 1] - ms);
+                o += ldexp_d(c[d], e);
+                Ls += ldexp_d(c[hd], e);
+            }
+            if (nsp == 1) {
+                st_gran(a.xch + C::ao + (h0 + hq) * hd + d, tag, f2bf((float)(o / Ls)));
+            } else {
+                constexpr int ME = C::ME, MAXSP = KF_ATTN_MAX_SPLITS;
+                const size_t oi = ((size_t)(d / ME) * (MAXSP * ME) + (size_t)S.split * ME + (d & (ME - 1))) * 2, mi = (size_t)hd * MAXSP * 2 + (size_t)S.split * 4;
+                const unsigned long long ob = __builtin_bit_cast(unsigned long long, o), lb = __builtin_bit_cast(unsigned long long, Ls), gg = (unsigned long long)gen << 32;
+                if (XMAP) { /* plain stores into this XCD's partial buffer: a value = two {32 bits, generation} granules */
+                    unsigned long long* dst = eng_lpart<C>(a, S.xcc) + (size_t)hq * C::PSH;
+                    *reinterpret_cast<ulonglong2*>(dst + oi) = ulonglong2{gg | (ob & 0xffffffffull), gg | (ob >> 32)};
+                    if (d == 0) {
+                        *reinterpret_cast<ulonglong2*>(dst + mi) = ulonglong2{gg | __float_as_uint(ms), gg | (lb & 0xffffffffull)};
+                        dst[mi + 2] = gg | (lb >> 32);
+                    }
+                } else {
+                    unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.xch + C::part) + (size_t)(h0 + hq) * C::PSH;
+                    st_gran64(dst + oi, gen, __uint_as_float((uint32_t)ob)), st_gran64(dst + oi + 1, gen, __uint_as_float((uint32_t)(ob >> 32)));
+                    if (d == 0) st_gran64(dst + mi, gen, ms), st_gran64(dst + mi + 1, gen, __uint_as_float((uint32_t)lb)), st_gran64(dst + mi + 2, gen, __uint_as_float((uint32_t)(lb >> 32)));
+                }
+            }
+        }
+    } else if (nsp > 1) { /* empty slice: neutral partial (sums 0, exponent -inf) */
+        for (int i = tid; i < GQ * hd; i += NWA * 64) {
+            const int hq = i >> hd_log2, d = i & (hd - 1);
+            constexpr int ME = C::ME, MAXSP = KF_ATTN_MAX_SPLITS;
+            const size_t oi = ((size_t)(d / ME) * (MAXSP * ME) + (size_t)S.split * ME + (d & (ME - 1))) * 2, mi = (size_t)hd * MAXSP * 2 + (size_t)S.split * 4;
+            const unsigned long long gg = (unsigned long long)gen << 32;
+            if (XMAP) {
+                unsigned long long* dst = eng_lpart<C>(a, S.xcc) + (size_t)hq * C::PSH;
+                dst[oi] = gg, dst[oi + 1] = gg;
+                if (d == 0) dst[mi] = gg | 0xff800000u, dst[mi + 1] = gg, dst[mi + 2] = gg;
+            } else {
+                unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.xch + C::part) + (size_t)(h0 + hq) * C::PSH;
+                st_gran64(dst + oi, gen, 0.f), st_gran64(dst + oi + 1, gen, 0.f);
+                if (d == 0) st_gran64(dst + mi, gen, -__builtin_inff()), st_gran64(dst + mi + 1, gen, 0.f), st_gran64(dst + mi + 2, gen, 0.f);
+            }
+        }
+    }
+}
+
 // the poller wave: per layer it stages P1's x, the slice's q/k/v heads, merges, stages P4's, P5's and P6's inputs
 template <class C>
 __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& L, const EngSlice& S, int epoch, int wg, int lane) {
@@ -466,10 +623,15 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
         return L.lay[l].m[S.j1];
     };
     if (P1_SHARE) mv_prefetch<P1, NCW1, FMT, S1>(mat1(0), mat1(0), S.s1, NWV - 1, lane, S.M1, r1);
+    EngAttnState<C> T;
+#pragma unroll
+    for (int u = 0; u < EngAttnState<C>::U; u++) T.kk[u] = T.vv[u] = u32x4{0, 0, 0, 0};
+    if (S.has_unit && !S.empty) eng_attn_issue<C>(a, L.lay[0], S, NWV - 1, lane, T, 0);
     int sw[4] = {0, 0, 0, 0};
     for (int l = 0; l < a.n_layer; l++) {
         const EngLayer& ly = L.lay[l];
         const uint32_t gen = (uint32_t)epoch * (uint32_t)a.n_layer + (uint32_t)l, tag = gen & 0xffffu;
+        if (S.has_unit && !S.empty) eng_attn_normw<C>(ly, lane, T);
         // P1 (P4 adds this x as the residual)
         ENG_STAMP(0, 0);
         if (has1 || has4) {
@@ -534,11 +696,8 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
             }
             if (kv_in) *reinterpret_cast<u32x2*>(L.kraw + e_kv) = u32x2{(gk.x & 0xffffu) | (gk.y << 16), (gk.z & 0xffffu) | (gk.w << 16)}; /* vraw = kraw + hd */
             ENG_STAMP(0, 2);
-            __syncthreads();
-            if (!S.empty) {
-                __syncthreads(); /* heads prepared */
-                __syncthreads(); /* the waves' fp64 sums in LDS */
-            }
+            eng_attn_phase<C>(a, L, S, ly, gen, tag, NWV - 1, lane, T, l, wg);
+            if (!S.empty) eng_attn_issue<C>(a, L.lay[l + 1 < a.n_layer ? l + 1 : l], S, NWV - 1, lane, T, 0); /* the next layer's tiles (the last layer asks for its own again) */
         }
         // P3: merge the slices of this workgroup's output elements: exact rescales to the largest exponent, fp64 sums, one division (kf_attn_common.h)
         ENG_STAMP(0, 3);
@@ -550,7 +709,7 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
             const __amdgpu_buffer_rsrc_t rs_ml = eng_rsrc(hbase + (size_t)hd * MAXSP * 2, (uint32_t)MAXSP * 32u);
             const int cnt = nsp * ME; /* values of this workgroup's elements: index sp * ME + e, two granules each */
             u32x4 go[NLM], gm0, gm1;
-            const bool mine = lane < nsp, el = lane < ME;
+            const bool mine = lane < nsp;
             eng_wait_pub(nullptr, 0, a.delay[2], dead);
             ENG_STAMP(0, 9);
             int msw = 0;
@@ -588,18 +747,37 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
             const float Mx = wave_max(ms);
             const int sh = canon_shift(ms - Mx);
             const double Lt = wave_sum_f64_fast(ldexp_d(ls, sh));
+            // element e's sum over the slices by FOUR lanes (lane = 4 e + quarter: 8 slices each, then two quad adds): fp64 sums do not depend on their order
+            int* shl = reinterpret_cast<int*>(L.msc + ME * MAXSP + 32); /* the slices' shifts, for lanes that walk other slices than their own */
+            if (lane < MAXSP) shl[lane] = sh;
             double o = 0.0;
-            const double* mv = L.msc + (el ? lane : 0) * MAXSP;
+            {
+                constexpr int QS = MAXSP / 4;
+                const int e = (4 * ME <= 64) ? (lane >> 2) : lane, qq = (4 * ME <= 64) ? (lane & 3) : 0;
+                const bool on = e < ME;
+                const double* mv = L.msc + (on ? e : 0) * MAXSP + qq * QS;
+                const int* sv = shl + qq * QS;
+                if (4 * ME <= 64) {
 #pragma unroll
-            for (int sp = 0; sp < MAXSP; sp++) o += ldexp_d(mv[sp], __builtin_amdgcn_readlane(sh, sp));
-            uint32_t* const ao_dst = a.xch + C::ao + (XMAP ? S.h0 * hd : 0) + S.me0;
+                    for (int k = 0; k < QS; k++) o += ldexp_d(mv[k], sv[k]);
+                    o += dpp_d<0xB1>(o); /* quad_perm xor 1 */
+                    o += dpp_d<0x4E>(o); /* quad_perm xor 2 */
+                } else {
+#pragma unroll
+                    for (int k = 0; k < MAXSP; k++) o += ldexp_d(mv[k], shl[k]);
+                }
+            }
             const uint32_t gr = (tag << 16) | (uint32_t)f2bf((float)(o / Lt));
+            // lane 4 e (or e) holds element e's granule
+            const bool holder = (4 * ME <= 64) ? ((lane & 3) == 0 && (lane >> 2) < ME) : (lane < ME);
+            const int he = (4 * ME <= 64) ? (lane >> 2) : lane;
+            uint32_t* const ao_dst = a.xch + C::ao + (XMAP ? S.h0 * hd : 0) + S.me0;
             if (ME >= 4) { /* 16 bytes per lane: a 4-byte write-through store is a read-modify-write at the memory side */
                 uint32_t* mo = reinterpret_cast<uint32_t*>(L.msc + ME * MAXSP);
-                if (el) mo[lane] = gr;
+                if (holder) mo[he] = gr;
                 if (4 * lane < ME) st_gran16(ao_dst + 4 * lane, *reinterpret_cast<const u32x4*>(mo + 4 * lane));
-            } else if (el) {
-                __hip_atomic_store(ao_dst + lane, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (holder) {
+                __hip_atomic_store(ao_dst + he, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         // P4, P5 (P6 adds that x as the residual), P6
@@ -632,17 +810,13 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
     using P4 = typename SH::P4;
     using P5 = typename SH::P5;
     using P6 = typename SH::P6;
-    constexpr int FMT = C::FMT, GQ = C::GQ, HD = C::HD, NWV = C::NWV;
+    constexpr int FMT = C::FMT, NWV = C::NWV;
     constexpr bool XMAP = C::XMAP, DBG = C::DBG;
     constexpr int NCW = NWV - 1;
     // P1 alone is shared with the poller wave (it is idle between staging x and the first q/k/v granules): NWV waves, so that the 0.6B shape's
     // 8 row-slots per workgroup are one step for every wave instead of two for wave 0
     constexpr int NCW1 = NWV;
     constexpr int S1 = c_maxs<P1, NCW1>(), S4 = c_maxs<P4, NCW>(), S5 = c_maxs<P5, NCW>(), S6 = c_maxs<P6, NCW>();
-    constexpr int hd = HD, hd_log2 = HD == 128 ? 7 : 6, NW = 4;
-    constexpr int LPK = hd >> 3, KPW = 64 / LPK, lpk_log2 = hd_log2 - 3;
-    constexpr int NQ = (GQ + NW - 1) / NW;
-    const int tid = wave * 64 + lane;
     // this workgroup's rows per phase (contiguous in the phase's output vector) and the waves that own some of them
     static_assert(P1::R % 4 == 0 && P4::R % 4 == 0 && P5::R % 4 == 0 && P6::R % 4 == 0 && P1::R <= 64 && P4::R <= 64 && P5::R <= 64 && P6::R <= 64, "rows per workgroup");
     static_assert(P1::total % P1::spg == 0 && P4::total % P4::spg == 0 && P5::total % P5::spg == 0 && P6::total % P6::spg == 0, "whole workgroups");
@@ -651,12 +825,6 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
     const bool has1 = XMAP ? true : wg * P1::spg < P1::total, has4 = wg * P4::spg < P4::total, has5 = wg * P5::spg < P5::total, has6 = wg * P6::spg < P6::total;
     const float qb1 = S.j1 == 0 ? a.qbias[0] : (S.j1 == 1 ? a.qbias[1] : a.qbias[2]);
     const int row0_1 = S.s1 * P1::RPS;
-    const bool aw = wave < NW && S.has_unit; /* attention waves */
-    const int pos = S.pos, nsp = S.nsp, kvh = S.kvh, h0 = S.h0, t1 = S.t1;
-    const int grp = lane >> lpk_log2, d0 = (lane & (LPK - 1)) * 8;
-    const int tstart = S.t0 + wave * KPW + grp, tstride = NW * KPW;
-    const int nbatch = S.has_unit && !S.empty ? (S.t1 - S.t0 + ATTN_U * tstride - 1) / (ATTN_U * tstride) : 0;
-    const float* tab_pos = a.rope_table + (size_t)pos * hd;
     auto mat1 = [&](int l) {
         return L.lay[l].m[S.j1];
     };
@@ -665,42 +833,18 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
     MvRegs<false, S4> r4;
     MvRegs<true, S5> r5;
     MvRegs<false, S6> r6;
-    u32x4 kk[ATTN_U], vv[ATTN_U];
+    EngAttnState<C> T;
 #pragma unroll
-    for (int u = 0; u < ATTN_U; u++) kk[u] = vv[u] = u32x4{0, 0, 0, 0};
-    // K and V tiles are requested separately: a batch's keys are dead once its scores are formed, its values once P.V is summed, so the
-    // next batch's loads go straight into the same registers (no second copy of the tiles)
-    auto issue_k = [&](const EngLayer& ly, int tb, int tend) {
-#pragma unroll
-        for (int u = 0; u < ATTN_U; u++) {
-            const int t = tb + u * tstride;
-            kk[u] = u32x4{0, 0, 0, 0};
-            if (t < tend) kk[u] = *reinterpret_cast<const u32x4 KF_GLOBAL*>(ly.kcache + ((size_t)t * a.kv_stride + (size_t)kvh * hd + d0));
-        }
-    };
-    auto issue_v = [&](const EngLayer& ly, int tb, int tend) {
-#pragma unroll
-        for (int u = 0; u < ATTN_U; u++) {
-            const int t = tb + u * tstride;
-            vv[u] = u32x4{0, 0, 0, 0};
-            if (t < tend) vv[u] = *reinterpret_cast<const u32x4 KF_GLOBAL*>(ly.vcache + ((size_t)t * a.kv_stride + (size_t)kvh * hd + d0));
-        }
-    };
-    auto issue_kv = [&](const EngLayer& ly, int tb, int tend) { issue_k(ly, tb, tend), issue_v(ly, tb, tend); };
+    for (int u = 0; u < EngAttnState<C>::U; u++) T.kk[u] = T.vv[u] = u32x4{0, 0, 0, 0};
     mv_prefetch<P1, NCW1, FMT, S1>(mat1(0), mat1(0), S.s1, wave, lane, S.M1, r1);
-    if (aw && !S.empty) issue_kv(L.lay[0], tstart, t1);
+    if (S.has_unit && !S.empty) eng_attn_issue<C>(a, L.lay[0], S, wave, lane, T, 0);
 
     for (int l = 0; l < a.n_layer; l++) {
         const EngLayer& ly = L.lay[l];
         const uint32_t gen = (uint32_t)epoch * (uint32_t)a.n_layer + (uint32_t)l, tag = gen & 0xffffu, tag_next = (gen + 1u) & 0xffffu;
         const bool last = l == a.n_layer - 1;
         const int ln = last ? l : l + 1; /* the layer whose blocks are requested next: the last layer asks for its own again (unconditional requests keep every wait counted) */
-        uint16_t qw0 = 0, qw1 = 0, kw0 = 0, kw1 = 0; /* the q/k-norm weights of this lane's pair: constants, requested early */
-        if (aw && !S.empty) {
-            const int half = hd >> 1, j = lane < half ? lane : half - 1;
-            if (ly.norm_q) qw0 = ly.norm_q[j], qw1 = ly.norm_q[j + half];
-            if (ly.norm_k) kw0 = ly.norm_k[j], kw1 = ly.norm_k[j + half];
-        }
+        if (S.has_unit && !S.empty) eng_attn_normw<C>(ly, lane, T);
         // ================= P1: RMSNorm(x) -> Q, K, V rows
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 0);
@@ -712,135 +856,18 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
             else
                 wg_publish(L, 0, a.xch + C::qkv, S.q_out0, P1::R, NWP1, lane);
         }
-        // ================= P2: q/k-norm + RoPE + attention over this workgroup's slice
+        // ================= P2: q/k-norm + RoPE + attention over this workgroup's slice (all 8 waves: eng_attn_phase), then the next layer's K/V tiles of the
+        // slice (they do not depend on this token, except row `pos`, which is substituted; the last layer requests its own again)
         if (wave == 0) ENG_STAMP(1, 1);
         if (S.has_unit) {
-            __syncthreads(); /* raw heads staged */
-            if (wave == 0) ENG_STAMP(1, 2);
-            if (!S.empty) {
-                if (aw) { /* prologue: q heads of this group, and the new key when it lies in this slice (ROPE::cuInfer) */
-                    const bool qnorm = ly.norm_q != nullptr;
-                    const int half = hd >> 1, j = lane < half ? lane : half - 1;
-#pragma unroll
-                    for (int i = 0; i < NQ; i++) {
-                        const int hq = wave + i * NW;
-                        if (hq < GQ) {
-                            HeadRaw r;
-                            r.x0 = L.qraw[hq * hd + j], r.x1 = L.qraw[hq * hd + j + half];
-                            r.w0 = qnorm ? qw0 : r.x0, r.w1 = qnorm ? qw1 : r.x1;
-                            prep_head(r, qnorm, tab_pos, hd, a.qk_eps, L.qb + hq * hd);
-                        }
-                    }
-                    if (S.own_new && wave == (GQ % NW)) {
-                        HeadRaw r;
-                        r.x0 = L.kraw[j], r.x1 = L.kraw[j + half];
-                        r.w0 = ly.norm_k ? kw0 : r.x0, r.w1 = ly.norm_k ? kw1 : r.x1;
-                        prep_head(r, ly.norm_k != nullptr, tab_pos, hd, a.qk_eps, L.knew);
-                    }
-                }
-                __syncthreads();
-                // the canonical softmax (kf_attn_common.h): every wave sums its keys in fp64 against its own maximum exponent; no workgroup-wide maximum, no
-                // barrier inside the key loop
-                CanonAcc<GQ> A;
-                A.init();
-                float qf[GQ][8];
-#pragma unroll
-                for (int hq = 0; hq < GQ; hq++)
-#pragma unroll
-                    for (int i = 0; i < 8; i++) qf[hq][i] = 0.f;
-                if (aw) {
-                    if (S.own_new) { /* the cache rows of this position: the prepared key, the raw value (K.out / V.out alias them in the reference) */
-                        g_u16w krow = ly.kcache + (size_t)pos * a.kv_stride + (size_t)kvh * hd;
-                        g_u16w vrow = ly.vcache + (size_t)pos * a.kv_stride + (size_t)kvh * hd;
-                        for (int i = tid; i < hd; i += NW * 64) krow[i] = L.knew[i], vrow[i] = L.vraw[i];
-                    }
-#pragma unroll
-                    for (int hq = 0; hq < GQ; hq++) {
-                        const u32x4 qv = *reinterpret_cast<const u32x4*>(L.qb + hq * hd + d0);
-                        const uint32_t q4[4] = {qv.x, qv.y, qv.z, qv.w};
-#pragma unroll
-                        for (int i = 0; i < 4; i++) qf[hq][2 * i] = bf_lo(q4[i]), qf[hq][2 * i + 1] = bf_hi(q4[i]);
-                    }
-                    const float rden = 1.0f / sqrtf((float)hd);
-                    for (int b = 0; b < nbatch; b++) {
-                        const int tb = tstart + b * ATTN_U * tstride;
-                        u32x4 ck[ATTN_U], cv[ATTN_U];
-                        bool valid[ATTN_U];
-#pragma unroll
-                        for (int u = 0; u < ATTN_U; u++) {
-                            const int t = tb + u * tstride;
-                            valid[u] = t < t1;
-                            ck[u] = kk[u], cv[u] = vv[u];
-                            if (valid[u] && t == pos) ck[u] = *reinterpret_cast<const u32x4*>(L.knew + d0), cv[u] = *reinterpret_cast<const u32x4*>(L.vraw + d0);
-                        }
-                        if (b + 1 < nbatch) issue_kv(ly, tb + ATTN_U * tstride, t1);
-                        canon_batch<GQ, LPK>(A, qf, ck, cv, valid, lpk_log2, rden);
-                    }
-                    canon_wave_to_lds<GQ, LPK>(A, L.comb + (size_t)wave * GQ * (hd + 2), hd, lane, d0);
-                }
-                __syncthreads();
-                if (aw) {
-                    constexpr int PSD = hd + 2;
-                    for (int i = tid; i < GQ * hd; i += NW * 64) {
-                        const int hq = i >> hd_log2, d = i & (hd - 1);
-                        float ms = -__builtin_inff();
-#pragma unroll
-                        for (int sl = 0; sl < NW; sl++) ms = fmaxf(ms, (float)L.comb[((size_t)sl * GQ + hq) * PSD + hd + 1]);
-                        double o = 0.0, Ls = 0.0;
-#pragma unroll
-                        for (int sl = 0; sl < NW; sl++) {
-                            const double* c = L.comb + ((size_t)sl * GQ + hq) * PSD;
-                            const int e = canon_shift((float)c[hd + 1] - ms);
-                            o += ldexp_d(c[d], e);
-                            Ls += ldexp_d(c[hd], e);
-                        }
-                        if (nsp == 1) {
-                            st_gran(a.xch + C::ao + (h0 + hq) * hd + d, tag, f2bf((float)(o / Ls)));
-                        } else {
-                            constexpr int ME = C::ME, MAXSP = KF_ATTN_MAX_SPLITS;
-                            const size_t oi = ((size_t)(d / ME) * (MAXSP * ME) + (size_t)S.split * ME + (d & (ME - 1))) * 2, mi = (size_t)hd * MAXSP * 2 + (size_t)S.split * 4;
-                            const unsigned long long ob = __builtin_bit_cast(unsigned long long, o), lb = __builtin_bit_cast(unsigned long long, Ls), gg = (unsigned long long)gen << 32;
-                            if (XMAP) { /* plain stores into this XCD's partial buffer: a value = two {32 bits, generation} granules */
-                                unsigned long long* dst = eng_lpart<C>(a, S.xcc) + (size_t)hq * C::PSH;
-                                *reinterpret_cast<ulonglong2*>(dst + oi) = ulonglong2{gg | (ob & 0xffffffffull), gg | (ob >> 32)};
-                                if (d == 0) {
-                                    *reinterpret_cast<ulonglong2*>(dst + mi) = ulonglong2{gg | __float_as_uint(ms), gg | (lb & 0xffffffffull)};
-                                    dst[mi + 2] = gg | (lb >> 32);
-                                }
-                            } else {
-                                unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.xch + C::part) + (size_t)(h0 + hq) * C::PSH;
-                                st_gran64(dst + oi, gen, __uint_as_float((uint32_t)ob)), st_gran64(dst + oi + 1, gen, __uint_as_float((uint32_t)(ob >> 32)));
-                                if (d == 0) st_gran64(dst + mi, gen, ms), st_gran64(dst + mi + 1, gen, __uint_as_float((uint32_t)lb)), st_gran64(dst + mi + 2, gen, __uint_as_float((uint32_t)(lb >> 32)));
-                            }
-                        }
-                    }
-                }
-            } else if (nsp > 1 && aw) { /* empty slice: neutral partial (sums 0, exponent -inf) */
-                for (int i = tid; i < GQ * hd; i += NW * 64) {
-                    const int hq = i >> hd_log2, d = i & (hd - 1);
-                    constexpr int ME = C::ME, MAXSP = KF_ATTN_MAX_SPLITS;
-                    const size_t oi = ((size_t)(d / ME) * (MAXSP * ME) + (size_t)S.split * ME + (d & (ME - 1))) * 2, mi = (size_t)hd * MAXSP * 2 + (size_t)S.split * 4;
-                    const unsigned long long gg = (unsigned long long)gen << 32;
-                    if (XMAP) {
-                        unsigned long long* dst = eng_lpart<C>(a, S.xcc) + (size_t)hq * C::PSH;
-                        dst[oi] = gg, dst[oi + 1] = gg;
-                        if (d == 0) dst[mi] = gg | 0xff800000u, dst[mi + 1] = gg, dst[mi + 2] = gg;
-                    } else {
-                        unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.xch + C::part) + (size_t)(h0 + hq) * C::PSH;
-                        st_gran64(dst + oi, gen, 0.f), st_gran64(dst + oi + 1, gen, 0.f);
-                        if (d == 0) st_gran64(dst + mi, gen, -__builtin_inff()), st_gran64(dst + mi + 1, gen, 0.f), st_gran64(dst + mi + 2, gen, 0.f);
-                    }
-                }
+            eng_attn_phase<C>(a, L, S, ly, gen, tag, wave, lane, T, l, wg);
+            if (wave == 0) ENG_STAMP(1, 3);
+            if (DBG && wave == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                ENG_STAMP(1, 10); /* partial stores acknowledged */
             }
+            if (!S.empty) eng_attn_issue<C>(a, L.lay[ln], S, wave, lane, T, 0);
         }
-        // the next layer's K/V tiles of this slice (they do not depend on this token, except row `pos`, which is substituted); the last layer
-        // requests its own again
-        if (wave == 0) ENG_STAMP(1, 3);
-        if (DBG && wave == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            ENG_STAMP(1, 10); /* partial stores acknowledged */
-        }
-        if (aw && !S.empty) issue_kv(L.lay[ln], tstart, t1);
 
         // ================= P4: o_proj + residual -> xB
         __syncthreads();
@@ -1022,7 +1049,7 @@ __device__ __forceinline__ void eng_head_main(const EngArgs& a, const EngLds& L,
 // DIM, QD, KVD, FFN: the model's dim, q_dim, kv_dim, ffn; NWG: the grid (= CUs): sweeps and mat-vec geometry are straight-line code
 template <class C>
 __global__ void __launch_bounds__(C::NWV * 64) engine_kernel(const EngArgs a) {
-    constexpr int hd = C::HD, NW = 4, GQ = C::GQ, NWV = C::NWV;
+    constexpr int hd = C::HD, GQ = C::GQ, NWV = C::NWV;
     constexpr bool XMAP = C::XMAP;
     using P1 = typename C::SH::P1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1040,9 +1067,9 @@ __global__ void __launch_bounds__(C::NWV * 64) engine_kernel(const EngArgs a) {
     L.xrawB = reinterpret_cast<uint16_t*>(smem + off), off += xr_bytes;
     L.qraw = reinterpret_cast<uint16_t*>(smem + off); /* [GQ][hd] raw q heads of this workgroup's slice */
     L.kraw = L.qraw + GQ * hd, L.vraw = L.kraw + hd, L.qb = L.vraw + hd, L.knew = L.qb + GQ * hd;
-    L.comb = reinterpret_cast<double*>(L.knew + hd); /* [NW][GQ][hd + 2] doubles (the offset is a multiple of 16 bytes) */
-    L.msc = L.comb + NW * GQ * (hd + 2);              /* [ME][MAXSP] doubles + [64] dwords */
-    L.wmax = reinterpret_cast<float*>(L.msc + C::ME * KF_ATTN_MAX_SPLITS + 32);
+    L.comb = reinterpret_cast<double*>(L.knew + hd); /* [NWV][GQ][hd + 2] doubles (the offset is a multiple of 16 bytes) */
+    L.msc = L.comb + NWV * GQ * (hd + 2);             /* [ME][MAXSP] doubles + [64] dwords */
+    L.wmax = reinterpret_cast<float*>(L.msc + C::ME * KF_ATTN_MAX_SPLITS + 64);
     L.outb = reinterpret_cast<uint32_t*>(L.wmax + 16);
     L.cnt = reinterpret_cast<int*>(L.outb + 64); /* [0] arrival counter, [1..2] XCD id and ticket */
     L.pub = L.cnt + 4;
@@ -1312,7 +1339,7 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     if (E->ffn > maxK) maxK = E->ffn;
     const size_t xs_bytes = ((size_t)maxK * 2 + 15) & ~(size_t)15;
     size_t smem = (((size_t)d->n_layer * sizeof(EngLayer) + 15) & ~(size_t)15) + 2 * xs_bytes + 2 * (((size_t)E->dim * 2 + 15) & ~(size_t)15);
-    smem += sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + sizeof(double) * ((size_t)4 * GQ * (hd + 2) + 64 * KF_ATTN_MAX_SPLITS + 32) + 4 * 16 + 4 * 64 + 32;
+    smem += sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + sizeof(double) * ((size_t)ENG_NWV * GQ * (hd + 2) + 64 * KF_ATTN_MAX_SPLITS + 64) + 4 * 16 + 4 * 64 + 32;
     smem = (smem + 15) & ~(size_t)15;
     if (smem > 160 * 1024) {
         engine_release(E);

@@ -42,6 +42,9 @@ for l in range(8, 12):
     print('  layer %d merge: barriers done %+.2f, first sweep issued %+.2f, sweeps %d, good %+.2f, merge done %+.2f | wave0: attention done (stores issued) %+.2f, stores acknowledged %+.2f' % (
         l, (a[l, 0, 3] - a[l, 0, 0]) / 100.0, (a[l, 0, 9] - a[l, 0, 0]) / 100.0, a[l, 0, 10], (a[l, 0, 11] - a[l, 0, 0]) / 100.0, (a[l, 0, 4] - a[l, 0, 0]) / 100.0,
         (a[l, 1, 3] - a[l, 0, 0]) / 100.0, (a[l, 1, 10] - a[l, 0, 0]) / 100.0))
+for l in range(8, 10):
+    print('  layer %d attention (wave 0): raw heads staged %+.2f, heads prepared %+.2f, keys summed %+.2f, wave sums in LDS %+.2f, barrier %+.2f, partial stores issued %+.2f' % (
+        l, *[(a[l, 1, k] - a[l, 0, 0]) / 100.0 for k in (2, 11, 12, 13, 14, 3)]))
 d = (a[1:, 0, 0] - a[:-1, 0, 0]) / 100.0
 print("layer period (us): mean %.2f  min %.2f  max %.2f" % (d[2:].mean(), d[2:].min(), d[2:].max()))
 # per-phase durations averaged over layers 4..27 (poller view)
