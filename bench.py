@@ -48,7 +48,14 @@ def main():
                     "torch.distributed all-gathers per layer")
     ap.add_argument("--tp-virtual", type=int, default=0, help="side measurement on ONE GPU: this many TP ranks of qwen3-32b in one process, lock-step on one stream "
                     "(the per-rank kernels and the exchange kernels of TP = R, serialised: R x the work of one rank's GPU, no xGMI)")
+    ap.add_argument("--lean", action="store_true", help="only the timed decode and step_roofline (what the side legs run in their child processes)")
+    ap.add_argument("--leg", default="", choices=["", "config3"], help="run ONE side leg and print its JSON (child processes of the main run)")
+    ap.add_argument("--side-legs", default="config3,config5,config4", help="side objects beside the line, each measured in a child process after the main measurements "
+                    "(never `value`): config3 = GPT2-1558M training step, config5 = 1-bit layers + 20 %% hot FFN rows, config4 = Qwen3-32B on ONE GPU; '' = none")
     args = ap.parse_args()
+    if args.leg == "config3":
+        print(json.dumps(config3_train_step()))
+        return
 
     import numpy as np
     import torch
@@ -164,6 +171,34 @@ def main():
             "step_roofline": {"bound": "hbm", "bytes_per_step": int(mean_bytes), "achieved": round(mean_bytes * (value / world) / 1e9, 1),
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(mean_bytes * (value / world) / 1e9 / HBM_PEAK_GBS, 4)},
         }
+        if args.lean:
+            m.engine_check()
+            out["config"]["decode_path"] = "persistent engine, one launch per token" if m.engine_steps() > 0 else "per-layer launches: 5 per layer"
+            print(json.dumps(out))
+            return
+        try:   # the same positions with the v_dot2c_f32_bf16 mat-vec forms (kf_set_canonical(ctx, 0)): faster, <= 1 bf16 ulp per output from the oracle instead of bit-exact
+            ids0 = m.tokens_out(S)
+
+            def rewind():   # the device state back at the first timed position (token = what the run picked before it)
+                m.set_state(int(ids0[pos - 1]) if pos > 0 else int(forced[0]), pos)
+            m.set_canonical(False)
+            rewind()
+            run_span(pos, min(K, 64))   # graphs of the bucket re-captured
+            rewind()
+            torch.cuda.synchronize()
+            tf0 = time.perf_counter()
+            run_span(pos, K)
+            torch.cuda.synchronize()
+            dtf = time.perf_counter() - tf0
+            out["dot2_mode"] = {"tokens_per_s": round(K / dtf, 2), "ms_per_step": round(dtf * 1e3 / K, 5),
+                                "note": "kf_set_canonical(ctx, 0): mat-vec products by v_dot2c_f32_bf16 instead of the canonical v_fma_f32 chains; same positions; never `value`"}
+        except Exception as e:
+            out["dot2_mode"] = {"error": repr(e)[:200]}
+        finally:
+            m.set_canonical(True)
+            m.set_state(int(m.tokens_out(S)[pos - 1]) if pos > 0 else int(forced[0]), pos)
+            run_span(pos, K)   # the ids, logits and KV rows the legs below read are those of the canonical run again
+            torch.cuda.synchronize()
         out["prefill"] = prefill_rate(m, forced[:n_prompt], ms_per_step)
         if world == 1 and args.streams > 1 and args.config == "qwen3-0.6b":
             try:
@@ -174,7 +209,7 @@ def main():
         try:   # the time-dominant kernel of the step; the LM head (the byte-dominant launch) is reported beside it
             eng = engine_roofline(m, ctx, cfg, forced, timed_positions) if m.engine_steps() > 0 else None
             out["roofline"] = eng if eng else (matvec_roofline(m, ctx, cfg, head_rl) if args.layers == "q4" else head_rl)
-            out["config"]["decode_path"] = "persistent engine: kf::engine_kernel (embedding row + all layers), LM head, pick = 3 launches per token" if eng else \
+            out["config"]["decode_path"] = "persistent engine: kf::engine_kernel (embedding row + all layers + final norm + LM head + greedy pick) = ONE launch per token" if eng else \
                 "per-layer launches: 5 per layer"
         except Exception as e:
             out["roofline"] = head_rl
@@ -195,11 +230,185 @@ def main():
                 out["cpu_baseline_fp16"] = cpu_fp16_decode(cfg, ctx.device, args.cpu_fp16_steps)
             except Exception as e:   # a side measurement must never cost the bench line
                 out["cpu_baseline_fp16"] = {"error": repr(e)[:200]}
+        if world == 1 and args.config == "qwen3-0.6b" and args.layers == "q4" and args.sparse == 0.0:
+            m.close()
+            del m
+            torch.cuda.empty_cache()
+            out.update(side_legs([l for l in args.side_legs.split(",") if l]))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def _child(argv, timeout_s):
+    """one side leg in a child process (its own HIP context and memory; a failure or a timeout costs only that object): the last JSON line it prints"""
+    import subprocess
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=timeout_s)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": (r.stderr or r.stdout)[-300:]}
+        d = json.loads(lines[-1])
+        d["leg_wall_s"] = round(time.perf_counter() - t0, 1)
+        return d
+    except Exception as e:   # a side measurement must never cost the bench line
+        return {"error": repr(e)[:300]}
+
+
+def side_legs(which):
+    """The other single-GPU configurations of BASELINE.json beside the line (never `value`), each re-derivable from the profile named in it."""
+    out = {}
+    if "config3" in which:
+        out["config3_train_step"] = _child(["--leg", "config3"], 420)
+    if "config5" in which:
+        d = _child(["--layers", "1bit", "--sparse", "0.2", "--steps", "512", "--warmup", "64", "--lean"], 300)
+        out["config5_sparse_1bit"] = d if "error" in d else {
+            "workload": "Qwen3-0.6B, 1-bit PackedQ layers (YinYang), 20 % of every FFN's rows hot (D_matmul_sparse: cold rows cost no HBM), bf16 head; positions %s" % d["config"]["workload"].split("timed positions ")[-1],
+            "tokens_per_s": d["value"], "ms_per_step": d["ms_per_step"], "bytes_per_step": d["step_roofline"]["bytes_per_step"], "frac": d["step_roofline"]["frac"],
+            "decode_path": d["config"]["decode_path"], "profile": "profiles/r03_config5_sparse_1bit_kernel_stats.csv", "leg_wall_s": d.get("leg_wall_s")}
+    if "config4" in which:
+        d = _child(["--config", "qwen3-32b", "--steps", "64", "--warmup", "16", "--lean"], 600)
+        out["config4_one_gpu"] = d if "error" in d else {
+            "workload": "Qwen3-32B 4-bit PackedQ greedy decode on ONE MI355X (the reference shards it over 8 GPUs for memory): %s" % d["config"]["workload"].split("seq=")[-1],
+            "tokens_per_s": d["value"], "ms_per_step": d["ms_per_step"], "bytes_per_step": d["step_roofline"]["bytes_per_step"], "frac": d["step_roofline"]["frac"],
+            "decode_path": d["config"]["decode_path"], "profile": "profiles/r03_config4_one_gpu_kernel_stats.csv", "leg_wall_s": d.get("leg_wall_s"),
+            "note": "TP = 8 over xGMI needs an 8-GPU node: bench.py --config qwen3-32b --gpus 8 (no scaling curve has been measured on hardware)"}
+    return out
+
+
+def config3_train_step():
+    """BASELINE config 3 as one whole training step on one MI355X: GPT2-1558M (n_embd 1600, 48 layers, 25 heads, ffn 6400, vocab 50257 padded to 50304), hybrid
+    storage (attention matrices f8e5m2, MLP matrices RTN 4-bit, tied bf16 wte), batch 8 x 1024 random ids: forward with every activation kept, fused classifier
+    loss, backward through every operator of the ABI (gradients of the quantised layers = bf16 gradients of their dequantised weights), AdamW over 1.558 G
+    parameters (timed on a full-size vector; the blocks' gradient buffers are shared between layers).  Hand-written kernels only.  The reference's figure for
+    this configuration: 48.8 k tokens/s on an RTX 4090 (cases/gpt2/1558M_F8_B80/F8_B80.info:2928-2951)."""
+    import ctypes as C
+    import torch
+    from koifish_amd import lib as L, runtime as R
+    ctx = R.Context(0)
+    dev = ctx.device
+    Cn, H, T, B, NL, V, Vp = 1600, 25, 1024, 8, 48, 50257, 50304
+    hd = Cn // H
+    N = B * T
+    bf = torch.bfloat16
+    mk = lambda m, k, t: ctx.quantize((torch.randn(m, k, device=dev) * 0.02).to(bf), t)
+    layers = [(mk(3 * Cn, Cn, L.F8E5M2), mk(Cn, Cn, L.F8E5M2), mk(4 * Cn, Cn, L.Q4), mk(Cn, 4 * Cn, L.Q4)) for _ in range(NL)]
+    z = lambda *s, dt=bf: torch.zeros(*s, device=dev, dtype=dt)
+    bq, bp, bfc, bp2 = z(3 * Cn), z(Cn), z(4 * Cn), z(Cn)
+    lnw, lnb = torch.ones(Cn, device=dev, dtype=bf), z(Cn)
+    wte_t = z(Vp, Cn)
+    wte_t[:V] = (torch.randn(V, Cn, device=dev) * 0.02).to(bf)
+    wte = ctx.quantize(wte_t, L.BF16)
+    wpe = (torch.randn(T, Cn, device=dev) * 0.01).to(bf)
+    ids = torch.randint(0, V, (N,), device=dev, dtype=torch.int32)
+    tgt = torch.randint(0, V, (N,), device=dev, dtype=torch.int32)
+    A = [dict(x=z(N, Cn), h1=z(N, Cn), m1=z(N, dt=torch.float32), r1=z(N, dt=torch.float32), qkv=z(N, 3 * Cn), att=z(N, Cn), x2=z(N, Cn), h2=z(N, Cn), m2=z(N, dt=torch.float32),
+              r2=z(N, dt=torch.float32), f=z(N, 4 * Cn), g=z(N, 4 * Cn)) for _ in range(NL)]
+    xf, hf, mf, rf = z(N, Cn), z(N, Cn), z(N, dt=torch.float32), z(N, dt=torch.float32)
+    qc, logits, losses = z(N, Cn), z(N, Vp), z(N, dt=torch.float32)
+    for w_ in layers[0]:
+        ctx.linear_scratch(w_, N)
+
+    def lin(w, xin, y, n, b, res=None):
+        d = w.desc()
+        L.check(ctx.hip.kf_linear(ctx.h, C.byref(d), xin.data_ptr(), y.data_ptr(), b.data_ptr() if b is not None else None, n, 1.0, 0.0, 1 if res is not None else 0,
+                                  res.data_ptr() if res is not None else None), "kf_linear")
+
+    def ln(x, y, m_, r_):
+        L.check(ctx.hip.kf_layernorm(ctx.h, x.data_ptr(), lnw.data_ptr(), lnb.data_ptr(), y.data_ptr(), N, Cn, 1e-5, m_.data_ptr(), r_.data_ptr()), "kf_layernorm")
+
+    def forward():
+        A[0]["x"].copy_(wte_t[ids.long()])
+        A[0]["x"].add_(wpe.repeat(B, 1))
+        for l in range(NL):
+            a = A[l]
+            wqkv, wproj, wfc, wproj2 = layers[l]
+            ln(a["x"], a["h1"], a["m1"], a["r1"])
+            lin(wqkv, a["h1"], a["qkv"], N, bq)
+            qc.copy_(a["qkv"][:, :Cn])
+            L.check(ctx.hip.kf_attn_prefill_batch(ctx.h, qc.data_ptr(), a["qkv"][:, Cn:].data_ptr(), a["qkv"][:, 2 * Cn:].data_ptr(), a["att"].data_ptr(), T, Cn, H, H, hd, 3 * Cn, B), "attn")
+            lin(wproj, a["att"], a["x2"], N, bp, a["x"])
+            ln(a["x2"], a["h2"], a["m2"], a["r2"])
+            lin(wfc, a["h2"], a["f"], N, bfc)
+            L.check(ctx.hip.kf_gelu(ctx.h, a["f"].data_ptr(), a["g"].data_ptr(), a["f"].numel()), "kf_gelu")
+            lin(wproj2, a["g"], A[l + 1]["x"] if l + 1 < NL else xf, N, bp2, a["x2"])
+        ln(xf, hf, mf, rf)
+        lin(wte, hf, logits, N, None)
+        losses.zero_()
+        L.check(ctx.hip.kf_fused_classifier(ctx.h, logits.data_ptr(), losses.data_ptr(), None, 1.0 / N, tgt.data_ptr(), B, T, V, Vp, None, 1), "kf_fused_classifier")
+
+    dx, dh, dqkv, datt, d4 = z(N, Cn), z(N, Cn), z(N, 3 * Cn), z(N, Cn), z(N, 4 * Cn)
+    gW = {"qkv": z(3 * Cn, Cn), "proj": z(Cn, Cn), "fc": z(4 * Cn, Cn), "proj2": z(Cn, 4 * Cn)}
+    gB = {"qkv": z(3 * Cn), "proj": z(Cn), "fc": z(4 * Cn), "proj2": z(Cn)}
+    g_lnw, g_lnb, g_wte, g_wpe = z(Cn), z(Cn), z(Vp, Cn), z(T, Cn)
+    sc_lin = torch.empty(max(ctx.hip.kf_linear_backward_scratch_bytes(oc, ic, N) for oc, ic in ((3 * Cn, Cn), (Cn, Cn), (4 * Cn, Cn), (Cn, 4 * Cn), (Vp, Cn))) + 256, dtype=torch.uint8, device=dev)
+    sp_lin = (sc_lin.data_ptr() + 255) & ~255
+    sc_ln = torch.empty(ctx.hip.kf_norm_backward_scratch_bytes(N, Cn, 1) // 8 + 1, dtype=torch.float64, device=dev)
+    sc_at = torch.empty(ctx.hip.kf_attn_backward_scratch_bytes(T, H, B) // 4 + 1, dtype=torch.float32, device=dev)
+
+    def lin_bwd(w, dIn, inp, delta, gw, gb, acc=0):
+        d = w.desc()
+        L.check(ctx.hip.kf_linear_backward(ctx.h, C.byref(d), dIn.data_ptr(), inp.data_ptr(), delta.data_ptr(), gw.data_ptr(), gb.data_ptr() if gb is not None else None, N, acc, sp_lin),
+                "kf_linear_backward")
+
+    def ln_bwd(dxx, dout, inp, m_, r_):
+        L.check(ctx.hip.kf_norm_backward(ctx.h, dxx.data_ptr(), g_lnw.data_ptr(), g_lnb.data_ptr(), dout.data_ptr(), inp.data_ptr(), lnw.data_ptr(), m_.data_ptr(), r_.data_ptr(), N, Cn,
+                                         sc_ln.data_ptr()), "kf_norm_backward")
+
+    def backward():
+        logits[:, V:].zero_()
+        lin_bwd(wte, logits, hf, dh, g_wte, None)
+        dx.zero_()
+        ln_bwd(dx, dh, xf, mf, rf)
+        for l in reversed(range(NL)):
+            a = A[l]
+            wqkv, wproj, wfc, wproj2 = layers[l]
+            lin_bwd(wproj2, dx, a["g"], d4, gW["proj2"], gB["proj2"])
+            L.check(ctx.hip.kf_gelu_backward(ctx.h, d4.data_ptr(), a["f"].data_ptr(), d4.numel()), "kf_gelu_backward")
+            lin_bwd(wfc, d4, a["h2"], dh, gW["fc"], gB["fc"])
+            ln_bwd(dx, dh, a["x2"], a["m2"], a["r2"])
+            lin_bwd(wproj, dx, a["att"], datt, gW["proj"], gB["proj"])
+            L.check(ctx.hip.kf_attn_backward(ctx.h, a["qkv"][:, :Cn].data_ptr(), a["qkv"][:, Cn:2 * Cn].data_ptr(), a["qkv"][:, 2 * Cn:].data_ptr(), 3 * Cn, a["att"].data_ptr(), datt.data_ptr(),
+                                             Cn, dqkv[:, :Cn].data_ptr(), dqkv[:, Cn:2 * Cn].data_ptr(), dqkv[:, 2 * Cn:].data_ptr(), 3 * Cn, T, H, H, hd, B, sc_at.data_ptr()), "kf_attn_backward")
+            lin_bwd(wqkv, dqkv, a["h1"], dh, gW["qkv"], gB["qkv"])
+            ln_bwd(dx, dh, a["x"], a["m1"], a["r1"])
+        L.check(ctx.hip.kf_embed_backward(ctx.h, g_wte.data_ptr(), Cn, g_wpe.data_ptr(), dx.data_ptr(), ids.data_ptr(), B, T, Cn, Vp), "kf_embed_backward")
+
+    def timed(fn, reps=2):
+        fn()
+        ctx.sync()
+        e0, e1 = ctx.event(), ctx.event()
+        ctx.record(e0)
+        for _ in range(reps):
+            fn()
+        ctx.record(e1)
+        return ctx.elapsed_ms(e0, e1) / reps
+    t_f = timed(forward)
+    forward()
+    ctx.sync()
+    loss = float(losses.mean())
+    t_b = timed(backward)
+    del A, layers, logits
+    torch.cuda.empty_cache()
+    npar = 1_558_000_000 // 8 * 8
+    p_ = (torch.randn(npar, device=dev) * 0.02).to(bf)
+    gr = (torch.randn(npar, device=dev) * 0.01).to(bf)
+    m1, m2 = z(npar), z(npar)
+    t_a = timed(lambda: L.check(ctx.hip.kf_adamw(ctx.h, p_.data_ptr(), gr.data_ptr(), m1.data_ptr(), m2.data_ptr(), npar, L.BF16, 3e-4, 0.9, 0.95, 0.1, 0.05, 1e-8, 0.1, 1.0, 7, None), "kf_adamw"))
+    ms = t_f + t_b + t_a
+    # flops of the step: 2 x (block matrices 12 C^2 x 48 + head V C) per token forward + causal attention (QK^T and PV, half the square), x 3 for forward + backward
+    w_el = NL * 12 * Cn * Cn + Vp * Cn
+    fwd = 2.0 * N * w_el + NL * 4.0 * Cn * (T * (T + 1) / 2) * B
+    flops = 3.0 * fwd
+    return {"workload": "GPT2-1558M (48 layers, n_embd 1600, 25 heads, ffn 6400, vocab 50257), hybrid f8e5m2 / 4-bit blocks, tied bf16 head: forward + loss + backward + AdamW, "
+                        "8 x 1024 random tokens, every activation kept, hand-written kernels only",
+            "ms": round(ms, 2), "tokens_per_s": round(N / ms * 1e3, 1), "forward_loss_ms": round(t_f, 2), "backward_ms": round(t_b, 2), "adamw_ms": round(t_a, 2),
+            "mean_loss": round(loss, 4), "flops": int(flops), "achieved_TFLOPs": round(flops / (ms * 1e-3) / 1e12, 1), "mfma_peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS,
+            "mfma_frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "reference": "48.8 k tokens/s on an RTX 4090 (cases/gpt2/1558M_F8_B80/F8_B80.info:2928-2951, BASELINE.md)", "profile": "profiles/r03_config3_train_step_kernel_stats.csv"}
 
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak of MI355X (MI355X_MICROARCH.md); the prefill GEMMs multiply bf16 fragments unpacked from 4-bit tiles
@@ -359,7 +568,7 @@ def prefill_rate(m, prompt, decode_ms_per_step, reps=5, bound=None):
     nbytes = sum(w.algorithmic_bytes() for (layer, slot), w in m.weights.items() if layer >= 0) + m.weights[(-1, 1)].algorithmic_bytes() + n * cfg["dim"] * 2 \
         + cfg["n_layer"] * n * kvd * 2 * 2 * 2
     tf, gbs = flops / (ms * 1e-3) / 1e12, nbytes / (ms * 1e-3) / 1e9
-    return {"prompt_tokens": n, "ms": round(ms, 3), "tokens_per_s": round(n / ms * 1e3, 1), "mode": "token batches, MFMA 32x32x16 bf16 on unpacked 4-bit tiles",
+    return {"prompt_tokens": n, "ms": round(ms, 3), "tokens_per_s": round(n / ms * 1e3, 1), "mode": "token batches: < 1024 rows MFMA 32x32x16 bf16 on 4-bit tiles unpacked in registers; >= 1024 rows Q|K|V and gate|up dequantised once + the 256x256 / 128x128 bf16 tile kernel (MFMA 16x16x32); flash attention tile",
             "token_serial_ms": round(decode_ms_per_step * n, 3),
             "roofline": {"flops": int(flops), "bytes": int(nbytes), "achieved_TFLOPs": round(tf, 2), "mfma_peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS, "mfma_frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
                          "achieved_GBs": round(gbs, 1), "hbm_peak_GBs": HBM_PEAK_GBS, "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
@@ -451,53 +660,48 @@ def kernel_roofline(m, ctx, cfg, reps=200):
             "us_per_launch": round(ms * 1e3, 2)}
 
 
-def engine_roofline(m, ctx, cfg, forced, timed_positions, reps=12):
-    """The kernel that takes ~92 % of the step's time when the persistent decode engine serves the model: kf::engine_kernel, ONE launch per
-    token for all layers (RMSNorm, Q/K/V, q/k-norm + RoPE + attention, o_proj, gate/up + SwiGLU, down_proj of 28 layers).  Timed alone with HIP
-    events on the launch stream at positions spread over the timed region (the KV cache still holds the rows of the run); an LM-head launch
-    between launches streams 311 MB so that the layer weights come from HBM as in the real step.  achieved = algorithmic bytes of a launch
-    (packed weights + zero/step of every layer matrix, the layers' norm vectors, K/V rows 0..pos read, row pos written) / mean duration."""
-    import ctypes as C
-    import torch
-    from koifish_amd import lib as L
-    head = m.weights[(-1, 1)]
-    hd = head.desc()
-    hx = torch.randn(cfg["dim"], device=ctx.device).to(torch.bfloat16)
-    logits = torch.empty(head.ne0, dtype=torch.bfloat16, device=ctx.device)
-    kvd = cfg["n_kv"] * cfg["head_dim"]
-    wbytes = sum(w.algorithmic_bytes() for (layer, slot), w in m.weights.items() if layer >= 0)
-    wbytes += cfg["n_layer"] * (2 * cfg["dim"] + 2 * cfg["head_dim"]) * 2
+def engine_roofline(m, ctx, cfg, forced, timed_positions, reps=6):
+    """The kernel that IS the decode step when the persistent engine serves the model: kf::engine_kernel, ONE launch per token -- the embedding row, all layers
+    (RMSNorm, Q/K/V, q/k-norm + RoPE + attention, o_proj, gate/up + SwiGLU, down_proj), the final norm, the LM head and the greedy pick.  Timed with HIP events
+    on the launch stream around single eager launches at positions spread over the timed region (the KV cache still holds the rows of the run; consecutive
+    launches stream 545 MB + KV each, so nothing comes from a cache).  achieved = algorithmic bytes of a launch (packed weights + zero / step
+    of every layer matrix, the norm vectors, the bf16 head, K/V rows 0..pos read and row pos written) / mean duration.  traffic = HBM bytes per launch from the
+    rocprofv3 --pmc passes committed under profiles/ (collected on the same launch at the position named there; rocprofv3 cannot run inside this process)."""
     pos_list = sorted(set(timed_positions[:: max(1, len(timed_positions) // 8)]))
     tot_ms, tot_bytes, n = 0.0, 0.0, 0
     for p in pos_list:
+        if p + 1 >= cfg["max_seq"]:
+            continue
         m.set_state(int(forced[p]) if forced[p] >= 0 else 1, p)
-        if not m.engine_only(1):
-            return None
+        m.run_steps(p, 1, False)   # warm: the eager path of this position
         for r in range(reps):
-            L.check(ctx.hip.kf_lm_head(ctx.h, C.byref(hd), hx.data_ptr(), logits.data_ptr(), None, ctx._head_ws.data_ptr()), "kf_lm_head")
+            m.set_state(int(forced[p]) if forced[p] >= 0 else 1, p)
             e0, e1 = ctx.event(), ctx.event()
             ctx.record(e0)
-            m.engine_only(1)
+            m.run_steps(p, 1, False)
             ctx.record(e1)
             m.sync()
             tot_ms += ctx.elapsed_ms(e0, e1)
-            tot_bytes += wbytes + 2 * cfg["n_layer"] * (p + 1) * kvd * 2 + 2 * cfg["n_layer"] * kvd * 2
+            tot_bytes += m.step_bytes(p)
             n += 1
+    if n == 0 or m.engine_steps() <= 0:
+        return None
     ms, nbytes = tot_ms / n, tot_bytes / n
     ach = nbytes / (ms * 1e-3) / 1e9
     traffic, traffic_src = None, None
-    try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside this process): FETCH_SIZE x 2 (gfx950) + WRITE_SIZE
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_engine.json")))
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_engine.json")))
         traffic = int(pj["hbm_bytes_per_launch"])
-        # a counter figure is only as fresh as its passes: say where it comes from and at what algorithmic size it was taken, so a stale one shows
-        traffic_src = "profiles/r02_pmc_engine.json: counter passes of scratch/ub_engine.py at position 1087 (%d algorithmic bytes there); not re-collected by this run" % int(pj["algorithmic_bytes_per_launch"])
+        traffic_src = "profiles/r03_pmc_engine.json: counter passes of scratch/ub_engine.py at position %d (%d algorithmic bytes there); not re-collected by this run" % (
+            int(pj.get("position", -1)), int(pj["algorithmic_bytes_per_launch"]))
     except Exception:
         pass
-    return {"bound": "hbm", "kernel": "kf::engine_kernel = all %d layers of one decode step in one persistent launch (256 workgroups, hand-offs through tagged granules)" % cfg["n_layer"],
+    return {"bound": "hbm", "kernel": "kf::engine_kernel = one decode step in one persistent launch: embedding row + %d layers + final norm + LM head + greedy pick (256 workgroups, "
+                                      "hand-offs through tagged granules)" % cfg["n_layer"],
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "bytes_per_launch": int(nbytes), "us_per_launch": round(ms * 1e3, 2), "launches": 1, "positions": pos_list,
-            "note": "latency-bound: %d layers x 6 dependent all-to-all phases; a phase's hand-off costs 1.9-3.2 us on this chip whatever it carries "
-                    "(scratch/ub_handoff.hip), the layer's %.1f MB stream in %.1f us at the HBM peak" % (cfg["n_layer"], nbytes / cfg["n_layer"] / 1e6, nbytes / cfg["n_layer"] / HBM_PEAK_GBS / 1e3)}
+            "note": "latency-bound: %d layers x 6 dependent hand-offs (4 cross the XCDs: ~1.3 us each with the first sweep timed behind the own publish, scratch/ub_handoff3.hip) + "
+                    "~5 us of phase arithmetic per layer; the head's %.0f MB stream at ~6 TB/s inside the same launch" % (cfg["n_layer"], m.weights[(-1, 1)].algorithmic_bytes() / 1e6)}
 
 
 def matvec_roofline(m, ctx, cfg, head_rl, reps=20):
@@ -574,16 +778,18 @@ def matvec_roofline(m, ctx, cfg, head_rl, reps=20):
             "note": "latency-bound: %.1f MB per launch is %.2f us at the HBM peak; the in-kernel time split is in DESIGN.md section 6" % (nbytes / n / 1e6, nbytes / n / HBM_PEAK_GBS / 1e3)}
 
 
-def cpu_baseline(m, cfg, forced, budget_s, min_steps=64, max_steps=256):
-    """The CPU oracle (a port: no runnable CPU forward exists in the reference) decoding the SAME 4-bit model on this host's cores: weights and the
-    KV rows of a 128-token prompt are copied from the GPU model, then it decodes from position 128 -- at least 64 steps (more while the time budget
-    lasts), teacher-forced on the GPU's ids so that both decode one sequence.  Mat-vec = the reference's own CPU idiom (two 8-lane AVX2 accumulators
-    over 16 consecutive elements, rows over OpenMP threads: dotprod_fp16 / D_matvec, GST_float.cpp:75-101, 293-304) on a bf16 copy of the dequantised
-    weights (what GetDataX produces), one pinned thread per core; `value` = 1 / median step time, with the 10th / 90th percentile beside it."""
+def cpu_baseline(m, cfg, forced, budget_s, min_steps=64, max_steps=256, canon_steps=48):
+    """The CPU oracle (a port: no runnable CPU forward exists in the reference) decoding the SAME 4-bit model on this host's cores: weights and the KV rows of the
+    128-token prompt are copied from the GPU model, then it decodes from position 128, teacher-forced on the GPU's ids so that both decode one sequence.
+    Two passes.  (1) PARITY: `canon_steps` steps in the canonical summation order kernels and oracle share (oracle/kf_oracle.c sections 4c, 6 CANON): every greedy
+    id AND every logit must equal the GPU's bit for bit -- mismatches_* are counts of that pass and must be 0.  (2) TIMING: at least 64 steps (more while the
+    budget lasts) with the mat-vec in the reference's own CPU idiom (two 8-lane AVX2 accumulators over 16 consecutive elements, rows over OpenMP threads:
+    dotprod_fp16 / D_matvec, GST_float.cpp:75-101, 293-304) on a bf16 copy of the dequantised weights (what GetDataX produces), one pinned thread per core;
+    `value` = 1 / median step time, with the 10th / 90th percentile beside it."""
     from oracle import oracle as O
 
     _pick_threads()
-    om = O.from_device_model(m)
+    om = O.from_device_model(m, attn_mode=O.ATTN_CANON)
     prep = om.prepare_fast()
     p0 = 128
     gk, gv = m.kv_to_host()
@@ -591,24 +797,37 @@ def cpu_baseline(m, cfg, forced, budget_s, min_steps=64, max_steps=256):
     ok[:, :p0] = gk[:, :p0]
     ov[:, :p0] = gv[:, :p0]
     gpu_ids = m.tokens_out(cfg["max_seq"])
-    tok, n, same, near_tie, in_tol = int(gpu_ids[p0 - 1]), 0, 0, 0, 0
+    # ---- (1) parity pass, canonical order
+    O.set_order(O.ORDER_CANON)
+    same, logits_equal, n_c = 0, 0, 0
+    try:
+        tok = int(gpu_ids[p0 - 1])
+        for i in range(canon_steps):
+            nxt, lg, _ = om.decode(tok, p0 + i)
+            g = int(gpu_ids[p0 + i])
+            same += int(nxt == g)
+            n_c += 1
+            tok = g
+        # logits of one more position, bit for bit: the GPU repeats the step at that position (its KV rows are those of the run)
+        pl = p0 + canon_steps
+        m.set_state(int(gpu_ids[pl - 1]), pl)
+        m.run_steps(pl, 1, True)
+        m.sync()
+        g_logits = m.logits()
+        _, o_logits, _ = om.decode(int(gpu_ids[pl - 1]), pl)
+        logits_equal = int((g_logits == o_logits).sum())
+        n_logits = int(g_logits.size)
+    finally:
+        O.set_order(O.ORDER_DOT16)
+    # ---- (2) timing pass, the reference's CPU dot-product order
+    tok, n = int(gpu_ids[p0 - 1]), 0
     t0 = time.perf_counter()
     steps = []
     while True:
         t1 = time.perf_counter()
-        nxt, lg, _ = om.decode(tok, p0 + n)
+        om.decode(tok, p0 + n, want_logits=False)
         steps.append(time.perf_counter() - t1)
-        g = int(gpu_ids[p0 + n])
-        if nxt == g:
-            same += 1
-        else:
-            # the oracle's logit of the GPU's pick against its own maximum: a difference of <= 2 bf16 ulps of the maximum (2^-7 relative: each side
-            # rounds its own fp32 sum to bf16 once) is a tie inside the stated tolerance, not a parity failure
-            l = O.bf16_to_f32(lg)
-            gap = float(l[nxt] - l[g]) / abs(float(l[nxt]))
-            near_tie += int(gap <= 2.0 ** -7)
-            in_tol += int(2.0 ** -7 < gap <= 2.0 ** -5)   # inside twice the stated logit tolerance (each side may be 2^-6 of the scale off)
-        tok = g  # teacher-forced on the GPU's ids so both decode the same sequence
+        tok = int(gpu_ids[p0 + n])
         n += 1
         if n >= max_steps or p0 + n >= cfg["max_seq"] - 1 or (n >= min_steps and time.perf_counter() - t0 > budget_s):
             break
@@ -617,8 +836,11 @@ def cpu_baseline(m, cfg, forced, budget_s, min_steps=64, max_steps=256):
     return {"value": round(1e3 / sp["median_ms"], 3), "unit": "tokens/s", "cores": O.num_threads(), "kind": "port",
             "sample": "%d decode steps at positions %d..%d of the same 4-bit model; AVX2 two-accumulator dot on a bf16 dequantised copy (%d MB), OpenMP rows, "
                       "threads pinned one per core" % (n, p0, p0 + n - 1, max(prep, 0) // 2 ** 20), "step_ms": sp,
-            "greedy_ids_equal_gpu": same, "mismatches_that_are_ties_within_2_bf16_ulps": near_tie, "mismatches_inside_twice_the_logit_tolerance": in_tol,
-            "mismatches_beyond_tolerance": n - same - near_tie - in_tol}
+            "parity_pass": "%d steps at positions %d..%d in the canonical summation order (kernels and oracle bit for bit), then all %d logits of position %d" % (
+                n_c, p0, p0 + n_c - 1, n_logits, p0 + canon_steps),
+            "greedy_ids_equal_gpu": same, "greedy_ids_compared": n_c, "logits_equal_bit_for_bit": logits_equal, "logits_compared": n_logits,
+            "mismatches_that_are_ties_within_2_bf16_ulps": 0 if same == n_c else None, "mismatches_inside_twice_the_logit_tolerance": 0 if same == n_c else None,
+            "mismatches_beyond_tolerance": n_c - same}
 
 
 def _pick_threads():

@@ -1011,6 +1011,7 @@ int kf_engine_create(kf_ctx* c, const kf_engine_desc* d, void* ws, size_t ws_byt
 int kf_engine_step(kf_ctx* c, kf_engine* e, const kf_bf16* x_in, kf_bf16* x_out, const int32_t* d_state, int pos_bound) {
     CHKCTX(c);
     if (!e || !e->h) return fail(KF_INVALID_ARGS, "kf_engine_step: null engine");
+    kf::engine_set_canonical(e->h, c->canonical);
     const int rc = kf::engine_step(e->h, c->stream, x_in, x_out, d_state, pos_bound);
     if (rc < 0) return fail(rc, "kf_engine_step failed with %d", rc);
     return rc;
@@ -1018,6 +1019,7 @@ int kf_engine_step(kf_ctx* c, kf_engine* e, const kf_bf16* x_in, kf_bf16* x_out,
 int kf_engine_step_head(kf_ctx* c, kf_engine* e, const kf_bf16* x_in, kf_bf16* x_out, int32_t* d_state, int pos_bound, int pick) {
     CHKCTX(c);
     if (!e || !e->h) return fail(KF_INVALID_ARGS, "kf_engine_step_head: null engine");
+    kf::engine_set_canonical(e->h, c->canonical);
     const int rc = kf::engine_step(e->h, c->stream, x_in, x_out, d_state, pos_bound, pick ? 2 : 1);
     if (rc < 0) return fail(rc, "kf_engine_step_head failed with %d (no head set?)", rc);
     return rc;

@@ -167,12 +167,12 @@ __device__ __forceinline__ void eng_wait_pub(const int* pub, int want, int delay
     for (int z = 0; z < delay; z++) __builtin_amdgcn_s_sleep(1);
 }
 
-// ---- poller: sweep the NLD * 256 granules of a vector until every tag matches, then stage the vector into LDS: xs in the mat-vec's
-// chunk layout [XCH][nBlk] (element e = c*EPB + j*8 + i -> chunk j*nBlk + c), optionally RMS-normalised (rms_norm_kernel,
+// ---- poller: sweep the NLD * 256 granules of a vector until every tag matches, then stage the vector into LDS: xs as fp32 in the engine's
+// chunk layout [XCH][nBlk] (element e = c*EPB + j*4 + i -> chunk j*nBlk + c; F32X = false: bf16 chunks of 8, the mat-vec kernel's layout), optionally RMS-normalised (rms_norm_kernel,
 // layernorm.cuh:800-847: fp64 sum of squares, (x*mul)*w, one bf16 store), and the raw vector in natural order into xraw (the residual
 // the phase after next adds).  Lane l of load r owns elements 4*(64r + l) .. +3.  PLAIN: the vector is plain bf16 written by an
 // earlier launch (layer 0's embedding row).  Straight-line code: the vector lengths are template parameters of the kernel.
-template <int XCH, int NLD, int NBLK, bool NORM, bool PLAIN>
+template <int XCH, int NLD, int NBLK, bool NORM, bool PLAIN, bool F32X = true>
 __device__ __forceinline__ void eng_poll_stage(const uint32_t* gsrc, const uint16_t* plain, uint32_t tag, g_u16 norm_w, float eps, u32x4* xs, uint16_t* xraw, int lane, int* ws,
                                                bool& dead, int* nsweeps, const int* pub, int want, int delay) {
     constexpr int n = NLD * 256;
@@ -235,8 +235,13 @@ __device__ __forceinline__ void eng_poll_stage(const uint32_t* gsrc, const uint1
             o0 = pack_bf16x2((bf_lo(o0) * mul) * bf_lo(w0[r]), (bf_hi(o0) * mul) * bf_hi(w0[r]));
             o1 = pack_bf16x2((bf_lo(o1) * mul) * bf_lo(w1[r]), (bf_hi(o1) * mul) * bf_hi(w1[r]));
         }
-        const int q = e0 >> 3, c = q / XCH, j = q - c * XCH;
-        reinterpret_cast<u32x2*>(xs + j * NBLK + c)[(e0 >> 2) & 1] = u32x2{o0, o1};
+        if (F32X) { /* the mat-vec phases multiply fp32 activations (BlockDotF): chunk = these 4 elements as floats, [XCH chunks per block][NBLK] */
+            const int q = e0 >> 2, c = q / XCH, j = q - c * XCH;
+            xs[j * NBLK + c] = u32x4{o0 << 16, o0 & 0xffff0000u, o1 << 16, o1 & 0xffff0000u};
+        } else {
+            const int q = e0 >> 3, c = q / XCH, j = q - c * XCH;
+            reinterpret_cast<u32x2*>(xs + j * NBLK + c)[(e0 >> 2) & 1] = u32x2{o0, o1};
+        }
     }
 }
 
@@ -343,9 +348,9 @@ __device__ __forceinline__ void mv_prefetch(const EngMat m, const EngMat m2, int
     }
 }
 // epi(row, v, v2) runs in the lane that owns a finished row (row counted inside the matrix)
-template <class PL, int NCW, int FMT, int MAXS, typename Epi>
+template <class PL, int NCW, int FMT, int MAXS, bool CANON, typename Epi>
 __device__ __forceinline__ void mv_run(float qb, float qb2, int s0, int cw, int lane, int Mj, const MvRegs<PL::PAIRED, MAXS>& R, const u32x4* xs, Epi&& epi) {
-    using BD = BlockDot<FMT, true>; /* the canonical order (oracle/kf_oracle.c section 4c): v_fma_f32 per product, same lanes / chain / tree as gemv_kernel's canonical form */
+    /* CANON: the canonical order (oracle/kf_oracle.c section 4c), one v_fma_f32 per product on fp32 operands; same lanes / chain / tree as gemv_kernel either way */
     float acc = 0.f, acc2 = 0.f;
 #pragma unroll
     for (int k = 0; k < MAXS; k++) {
@@ -355,11 +360,15 @@ __device__ __forceinline__ void mv_run(float qb, float qb2, int s0, int cw, int 
         const int col = q.col < PL::nBlk ? q.col : PL::nBlk - 1;
         if (it == 0) acc = 0.f, acc2 = 0.f;
         const float st = bf2f(R.st[k]);
-        const float r = BD::run(R.w[k], xs, col, PL::nBlk, st, bf2f(R.ze[k]), -(qb * st), acc);
+        float r;
+        if constexpr (CANON) r = BlockDotF<FMT>::run(R.w[k], reinterpret_cast<const f32x4*>(xs), col, PL::nBlk, st, bf2f(R.ze[k]), -(qb * st), acc);
+        else r = BlockDot<FMT, false>::run(R.w[k], xs, col, PL::nBlk, st, bf2f(R.ze[k]), -(qb * st), acc);
         acc = q.ok ? r : acc;
         if (PL::PAIRED) {
             const float st2 = bf2f(R.st2[k]);
-            const float r2 = BD::run(R.w2[k], xs, col, PL::nBlk, st2, bf2f(R.ze2[k]), -(qb2 * st2), acc2);
+            float r2;
+            if constexpr (CANON) r2 = BlockDotF<FMT>::run(R.w2[k], reinterpret_cast<const f32x4*>(xs), col, PL::nBlk, st2, bf2f(R.ze2[k]), -(qb2 * st2), acc2);
+            else r2 = BlockDot<FMT, false>::run(R.w2[k], xs, col, PL::nBlk, st2, bf2f(R.ze2[k]), -(qb2 * st2), acc2);
             acc2 = q.ok ? r2 : acc2;
         }
         if (it == PL::iters - 1) {
@@ -417,10 +426,14 @@ __device__ __forceinline__ void wg_publish(const EngLds& L, int phase, uint32_t*
     if (lane == 0) __hip_atomic_fetch_add(L.pub + phase, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); /* the poller may start to sweep for what the consumers of these rows produce */
 }
 
-template <int FMT_, int GQ_, int HD_, int NWV_, int DIM_, int QD_, int KVD_, int FFN_, int NWG_, bool XMAP_, bool DBG_>
+template <int FMT_, int GQ_, int HD_, int NWV_, int DIM_, int QD_, int KVD_, int FFN_, int NWG_, bool XMAP_, bool DBG_, bool CANON_ = true>
 struct EngCfg {
     static constexpr int FMT = FMT_, GQ = GQ_, HD = HD_, NWV = NWV_, DIM = DIM_, QD = QD_, KVD = KVD_, FFN = FFN_, NWG = NWG_;
     static constexpr bool XMAP = XMAP_, DBG = DBG_;
+    // CANON: the mat-vec phases and the head in the canonical order (one v_fma_f32 per product on fp32 operands: bit-exact against the oracle); false: v_dot2c_f32_bf16 on
+    // bf16 pairs (kf_set_canonical(ctx, 0): <= 1 bf16 ulp per output from the oracle, fewer vector instructions).  The attention is canonical either way.
+    static constexpr bool CANON = CANON_;
+    static constexpr int XCH = CANON_ ? BlockDotF<FMT_>::XCH : BlockDot<FMT_>::XCH;
     static constexpr int n_head = QD_ / HD_, n_kv = KVD_ / HD_;
     using SH = EngShape<FMT_, DIM_, QD_, KVD_, FFN_, NWG_>;
     static constexpr int xA = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).xA, qkv = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).qkv, ao = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).ao,
@@ -610,7 +623,7 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
     constexpr int FMT = C::FMT, GQ = C::GQ, HD = C::HD, NWV = C::NWV;
     constexpr bool XMAP = C::XMAP, DBG = C::DBG;
     constexpr int ND = C::DIM / 256, NQD = C::QD / 256, NF = C::FFN / 256;
-    constexpr int XCH = BlockDot<FMT>::XCH, hd = HD, hd_log2 = HD == 128 ? 7 : 6;
+    constexpr int XCH = C::XCH, hd = HD, hd_log2 = HD == 128 ? 7 : 6;
     bool dead = false;
     const bool has1 = XMAP ? true : wg * P1::spg < P1::total, has4 = wg * P4::spg < P4::total, has5 = wg * P5::spg < P5::total, has6 = wg * P6::spg < P6::total;
     // the poller's share of P1 (virtual compute wave NWV - 1)
@@ -646,16 +659,16 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
                     if (tok < 0 || tok >= a.emb_rows) tok = 0;
                     x0 = a.emb + (size_t)tok * C::DIM;
                 }
-                eng_poll_stage<XCH, ND, P1::nBlk, true, true>(nullptr, x0, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, &sw[0], nullptr, 0, 0);
+                eng_poll_stage<XCH, ND, P1::nBlk, true, true, C::CANON>(nullptr, x0, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, &sw[0], nullptr, 0, 0);
             } else {
-                eng_poll_stage<XCH, ND, P1::nBlk, true, false>(a.xch + C::xA, nullptr, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, &sw[0], has6 ? L.pub + 3 : nullptr, l,
+                eng_poll_stage<XCH, ND, P1::nBlk, true, false, C::CANON>(a.xch + C::xA, nullptr, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, &sw[0], has6 ? L.pub + 3 : nullptr, l,
                                                                a.delay[0]);
             }
         }
         ENG_STAMP(0, 1);
         __syncthreads();
         if (P1_SHARE && has1) { /* this wave's P1 rows, then the workgroup's publish like every other owner */
-            mv_run<P1, NCW1, FMT, S1>(qb1, 0.f, S.s1, NWV - 1, lane, S.M1, r1, L.xs[0], [&](int row, float v, float) { L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); });
+            mv_run<P1, NCW1, FMT, S1, C::CANON>(qb1, 0.f, S.s1, NWV - 1, lane, S.M1, r1, L.xs[0], [&](int row, float v, float) { L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); });
             if (XMAP)
                 wg_publish(L, 0, eng_lqkv<C>(a, S.xcc), S.q_out0, P1::R, NWP1, lane, true);
             else
@@ -782,15 +795,15 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
         }
         // P4, P5 (P6 adds that x as the residual), P6
         ENG_STAMP(0, 4);
-        if (has4) eng_poll_stage<XCH, NQD, P4::nBlk, false, false>(a.xch + C::ao, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, &sw[1], nullptr, 0, a.delay[3]);
+        if (has4) eng_poll_stage<XCH, NQD, P4::nBlk, false, false, C::CANON>(a.xch + C::ao, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, &sw[1], nullptr, 0, a.delay[3]);
         ENG_STAMP(0, 5);
         __syncthreads();
         if (has5 || has6)
-            eng_poll_stage<XCH, ND, P5::nBlk, true, false>(a.xch + C::xB, nullptr, tag, ly.norm_post, a.eps, L.xs[0], L.xrawB, lane, a.ws, dead, &sw[2], has4 ? L.pub + 1 : nullptr, l + 1,
+            eng_poll_stage<XCH, ND, P5::nBlk, true, false, C::CANON>(a.xch + C::xB, nullptr, tag, ly.norm_post, a.eps, L.xs[0], L.xrawB, lane, a.ws, dead, &sw[2], has4 ? L.pub + 1 : nullptr, l + 1,
                                                            a.delay[4]);
         ENG_STAMP(0, 6);
         __syncthreads();
-        if (has6) eng_poll_stage<XCH, NF, P6::nBlk, false, false>(a.xch + C::act, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, &sw[3], has5 ? L.pub + 2 : nullptr, l + 1, a.delay[5]);
+        if (has6) eng_poll_stage<XCH, NF, P6::nBlk, false, false, C::CANON>(a.xch + C::act, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, &sw[3], has5 ? L.pub + 2 : nullptr, l + 1, a.delay[5]);
         ENG_STAMP(0, 7);
         if (P1_SHARE) { /* unconditional (the last layer requests its own blocks again): a conditional request would turn the waits behind it into drains */
             const int ln = l + 1 < a.n_layer ? l + 1 : l;
@@ -849,7 +862,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 0);
         mv_prefetch<P4, NCW, FMT, S4>(ly.m[3], ly.m[3], wg * P4::spg, wave, lane, P4::M0, r4);
-        mv_run<P1, NCW1, FMT, S1>(qb1, 0.f, S.s1, wave, lane, S.M1, r1, L.xs[0], [&](int row, float v, float) { L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); });
+        mv_run<P1, NCW1, FMT, S1, C::CANON>(qb1, 0.f, S.s1, wave, lane, S.M1, r1, L.xs[0], [&](int row, float v, float) { L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); });
         if (has1 && wave < NWP1) {
             if (XMAP)
                 wg_publish(L, 0, eng_lqkv<C>(a, S.xcc), S.q_out0, P1::R, NWP1, lane, true);
@@ -873,7 +886,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 4);
         mv_prefetch<P5, NCW, FMT, S5>(ly.m[4], ly.m[5], wg * P5::spg, wave, lane, P5::M0, r5);
-        mv_run<P4, NCW, FMT, S4>(a.qbias[3], 0.f, wg * P4::spg, wave, lane, P4::M0, r4, L.xs[1], [&](int row, float v, float) {
+        mv_run<P4, NCW, FMT, S4, C::CANON>(a.qbias[3], 0.f, wg * P4::spg, wave, lane, P4::M0, r4, L.xs[1], [&](int row, float v, float) {
             const uint16_t o = f2bf(v);
             L.outb[row - wg * P4::R] = (tag << 16) | (uint32_t)f2bf(bf2f(L.xrawA[row]) + bf2f(o)); /* CU_add3: bf16(x + bf16(W.x)) */
         });
@@ -883,7 +896,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 6);
         mv_prefetch<P6, NCW, FMT, S6>(ly.m[6], ly.m[6], wg * P6::spg, wave, lane, P6::M0, r6);
-        mv_run<P5, NCW, FMT, S5>(a.qbias[4], a.qbias[5], wg * P5::spg, wave, lane, P5::M0, r5, L.xs[0], [&](int row, float v, float v2) {
+        mv_run<P5, NCW, FMT, S5, C::CANON>(a.qbias[4], a.qbias[5], wg * P5::spg, wave, lane, P5::M0, r5, L.xs[0], [&](int row, float v, float v2) {
             const float gt = round_bf16(v), up = round_bf16(v2); /* CU_swiglu_v0 on the two bf16-rounded projections */
             L.outb[row - wg * P5::R] = (tag << 16) | (uint32_t)f2bf((gt * up) / (1.0f + kf_expf(-gt)));
         });
@@ -893,7 +906,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 8);
         mv_prefetch<P1, NCW1, FMT, S1>(mat1(ln), mat1(ln), S.s1, wave, lane, S.M1, r1);
-        mv_run<P6, NCW, FMT, S6>(a.qbias[6], 0.f, wg * P6::spg, wave, lane, P6::M0, r6, L.xs[1], [&](int row, float v, float) {
+        mv_run<P6, NCW, FMT, S6, C::CANON>(a.qbias[6], 0.f, wg * P6::spg, wave, lane, P6::M0, r6, L.xs[1], [&](int row, float v, float) {
             const uint16_t o = f2bf(v);
             const uint16_t y = f2bf(bf2f(L.xrawB[row]) + bf2f(o));
             if (last) a.x_out[row] = y;
@@ -913,7 +926,6 @@ template <class C>
 __device__ __forceinline__ void eng_head_main(const EngArgs& a, const EngLds& L, int epoch, int wg, int wave, int lane) {
     constexpr int NWV = C::NWV, NWG = C::NWG, nBlk = C::HnBlk, LPR = C::HLPR, RPS = C::HRPS, ITERS = C::Hiters, HG = 4;
     constexpr int ND = C::DIM / 256;
-    using BD = BlockDot<FMT_BF16, true>;
     const int sub = lane >> C::Hlpr_log2, ll = lane & (LPR - 1);
     const int total = (a.vocab + RPS - 1) / RPS, spg = (total + NWG - 1) / NWG; /* slots in all, per workgroup */
     const int s_wg = wg * spg;
@@ -942,16 +954,20 @@ __device__ __forceinline__ void eng_head_main(const EngArgs& a, const EngLds& L,
     if (wave == NWV - 1) {
         bool dead = false;
         const bool has6 = wg * C::SH::P6::spg < C::SH::P6::total;
-        eng_poll_stage<1, ND, nBlk, true, false>(a.xch + C::xA, nullptr, tag, a.head_norm, a.eps, L.xs[0], nullptr, lane, a.ws, dead, nullptr, has6 ? L.pub + 3 : nullptr, a.n_layer,
+        eng_poll_stage<1, ND, nBlk, true, false, false>(a.xch + C::xA, nullptr, tag, a.head_norm, a.eps, L.xs[0], nullptr, lane, a.ws, dead, nullptr, has6 ? L.pub + 3 : nullptr, a.n_layer,
                                                  a.delay[0]);
     }
     __syncthreads();
-    u32x4 xr[ITERS];
+    float xf[ITERS][8]; /* this lane's block columns of the normed x, widened once: the lane multiplies the same columns of every row */
+    uint32_t xp[ITERS][4]; /* the same as bf16 pairs (the v_dot2c form) */
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
         int col = it * LPR + ll;
         col = col < nBlk ? col : nBlk - 1;
-        xr[it] = L.xs[0][col];
+        const u32x4 xv = L.xs[0][col];
+        const uint32_t x4[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) xf[it][2 * i] = bf_lo(x4[i]), xf[it][2 * i + 1] = bf_hi(x4[i]), xp[it][i] = x4[i];
     }
     float best_v = -__builtin_inff();
     int best_i = 0x7fffffff;
@@ -962,8 +978,14 @@ __device__ __forceinline__ void eng_head_main(const EngArgs& a, const EngLds& L,
             const int row = (s_wg + wave + NWV * i) * RPS + sub;
             float acc = 0.f;
 #pragma unroll
-            for (int it = 0; it < ITERS; it++) {
-                const float r = BD::run(w[buf][g][it], xr + it, 0, 0, 0.f, 0.f, 0.f, acc);
+            for (int it = 0; it < ITERS; it++) { /* BlockDot<FMT_BF16, true>: the block's 8 elements in order, one v_fma_f32 each */
+                const uint32_t w4[4] = {w[buf][g][it].x, w[buf][g][it].y, w[buf][g][it].z, w[buf][g][it].w};
+                float r = acc;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if constexpr (C::CANON) r = fmaf(bf_lo(w4[i]), xf[it][2 * i], r), r = fmaf(bf_hi(w4[i]), xf[it][2 * i + 1], r);
+                    else r = dot2_bf16(w4[i], xp[it][i], r);
+                }
                 acc = (it * LPR + ll < nBlk) ? r : acc;
             }
             const float v = group_sum(acc, C::Hlpr_log2);
@@ -1058,7 +1080,7 @@ __global__ void __launch_bounds__(C::NWV * 64) engine_kernel(const EngArgs a) {
     EngLds L;
     EngLayer* lay = reinterpret_cast<EngLayer*>(smem);
     constexpr int maxK = C::DIM > C::QD ? (C::DIM > C::FFN ? C::DIM : C::FFN) : (C::QD > C::FFN ? C::QD : C::FFN);
-    constexpr int xs_bytes = (maxK * 2 + 15) & ~15, xr_bytes = (C::DIM * 2 + 15) & ~15;
+    constexpr int xs_bytes = (maxK * 4 + 15) & ~15, xr_bytes = (C::DIM * 2 + 15) & ~15; /* xs: fp32 activations */
     size_t off = ((size_t)a.n_layer * sizeof(EngLayer) + 15) & ~(size_t)15;
     L.lay = lay;
     L.xs[0] = reinterpret_cast<u32x4*>(smem + off), off += xs_bytes;
@@ -1147,6 +1169,7 @@ struct EngineHost {
     EngArgs args;
     EngPlan plans[4];
     int fmt, GQ, hd, nwv, shape_class, xmap;
+    int canon; /* 1: mat-vec phases in the canonical order (engine_set_canonical) */
     int dim, q_dim, kv_dim, ffn, n_kv, n_head;
     size_t smem;
     int n_cu;
@@ -1307,6 +1330,7 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     }
     if (fmt == FMT_Q4 && q4p_ok) fmt = FMT_Q4P;
     E->fmt = fmt, E->GQ = GQ, E->hd = hd, E->n_cu = n_cu, E->nwv = ENG_NWV, E->shape_class = shape_class;
+    E->canon = 1;
     E->xmap = shape_class == 1 ? 1 : 0; /* 8 kv-heads on 8 XCDs */
     // workspace carve
     char* p = reinterpret_cast<char*>(ws);
@@ -1337,7 +1361,7 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     // LDS
     int maxK = E->dim > E->q_dim ? E->dim : E->q_dim;
     if (E->ffn > maxK) maxK = E->ffn;
-    const size_t xs_bytes = ((size_t)maxK * 2 + 15) & ~(size_t)15;
+    const size_t xs_bytes = ((size_t)maxK * 4 + 15) & ~(size_t)15;
     size_t smem = (((size_t)d->n_layer * sizeof(EngLayer) + 15) & ~(size_t)15) + 2 * xs_bytes + 2 * (((size_t)E->dim * 2 + 15) & ~(size_t)15);
     smem += sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + sizeof(double) * ((size_t)ENG_NWV * GQ * (hd + 2) + 64 * KF_ATTN_MAX_SPLITS + 64) + 4 * 16 + 4 * 64 + 32;
     smem = (smem + 15) & ~(size_t)15;
@@ -1407,9 +1431,12 @@ template <int FMT>
 static int engine_go_fmt(EngineHost* E, hipStream_t st) {
     switch (E->shape_class) {
         case 1: /* 8 kv-heads on 8 XCDs: the attention chain of a kv-head stays inside one XCD */
-            if (E->args.dbg && FMT == FMT_Q4P) return engine_go<EngCfg<FMT_Q4P, 2, 128, ENG_NWV, 1024, 2048, 1024, 3072, ENG_NWG, true, true>>(E, st);
-            return engine_go<EngCfg<FMT, 2, 128, ENG_NWV, 1024, 2048, 1024, 3072, ENG_NWG, true, false>>(E, st);
-        case 2: return engine_go<EngCfg<FMT, 2, 64, ENG_NWV, 256, 256, 128, 512, ENG_NWG, false, false>>(E, st);
+            if (E->args.dbg && FMT == FMT_Q4P && E->canon) return engine_go<EngCfg<FMT_Q4P, 2, 128, ENG_NWV, 1024, 2048, 1024, 3072, ENG_NWG, true, true, true>>(E, st);
+            if (!E->canon) return engine_go<EngCfg<FMT, 2, 128, ENG_NWV, 1024, 2048, 1024, 3072, ENG_NWG, true, false, false>>(E, st);
+            return engine_go<EngCfg<FMT, 2, 128, ENG_NWV, 1024, 2048, 1024, 3072, ENG_NWG, true, false, true>>(E, st);
+        case 2:
+            if (!E->canon) return engine_go<EngCfg<FMT, 2, 64, ENG_NWV, 256, 256, 128, 512, ENG_NWG, false, false, false>>(E, st);
+            return engine_go<EngCfg<FMT, 2, 64, ENG_NWV, 256, 256, 128, 512, ENG_NWG, false, false, true>>(E, st);
         default: return 1;
     }
 }
@@ -1468,6 +1495,7 @@ int engine_error_word(EngineHost* E, hipStream_t st, int* h_err) {
     *h_err = v[1];
     return KF_OK;
 }
+void engine_set_canonical(EngineHost* E, int on) { E->canon = on ? 1 : 0; }
 // after a timed-out poll (the error word latches and every later launch returns at once): all granules back to "not written", epoch 1, error word cleared
 int engine_reset(EngineHost* E, hipStream_t st) {
     const int rc = engine_init_state(E, st);

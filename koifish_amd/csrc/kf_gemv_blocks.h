@@ -278,6 +278,80 @@ struct BlockDot<FMT_Q2T, CANON> {
     }
 };
 
+
+// ------------------------------------------------------------------------------------------------ canonical block dots on fp32 activations
+// The persistent engine's form of the canonical order (same products, same chain: element after element of a block, one v_fma_f32 each): the activation
+// vector is staged in LDS as fp32 -- chunks of 4 floats laid out [EPB / 4][nBlk] -- and a weight is formed as an fp32 register directly (the table lookup
+// assembles {0, 0, low byte, high byte} with one v_perm_b32), so neither operand is unpacked from a bf16 pair per product.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float perm_fma_dword(uint32_t D, f32x4 X0, f32x4 X1, const PermLut& t, float acc) {
+    const uint32_t even = D >> 4; /* bytes 3..0: elements 0,2,4,6 in the low nibbles; D itself: 1,3,5,7 */
+    uint32_t lo, hi;
+    perm_lookup4(__builtin_amdgcn_perm(even, D, 0x02060307u), t, lo, hi); /* bytes 0..3 = elements 0, 1, 2, 3 */
+    acc = fmaf(__uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x04000c0cu)), X0.x, acc);
+    acc = fmaf(__uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x05010c0cu)), X0.y, acc);
+    acc = fmaf(__uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x06020c0cu)), X0.z, acc);
+    acc = fmaf(__uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x07030c0cu)), X0.w, acc);
+    perm_lookup4(__builtin_amdgcn_perm(even, D, 0x00040105u), t, lo, hi); /* elements 4, 5, 6, 7 */
+    acc = fmaf(__uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x04000c0cu)), X1.x, acc);
+    acc = fmaf(__uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x05010c0cu)), X1.y, acc);
+    acc = fmaf(__uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x06020c0cu)), X1.z, acc);
+    acc = fmaf(__uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x07030c0cu)), X1.w, acc);
+    return acc;
+}
+// arithmetic form: w = bf16(bf16(step * (q - qBias)) - zero) per nibble, as dot_q4_dword forms it, kept as fp32
+__device__ __forceinline__ float arith_fma_dword(uint32_t D, f32x4 X0, f32x4 X1, float step, float step16, float nb, float zero, float acc) {
+    uint32_t H = D & 0xF0F0F0F0u, Lw = D & 0x0F0F0F0Fu;
+    asm("" : "+v"(H));
+    asm("" : "+v"(Lw));
+    const float xs8[8] = {X0.x, X0.y, X0.z, X0.w, X1.x, X1.y, X1.z, X1.w};
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int sh = 24 - 8 * p;
+        const uint32_t r = pack_bf16x2(fmaf((float)((H >> sh) & 0xffu), step16, nb), fmaf((float)((Lw >> sh) & 0xffu), step, nb));
+        const uint32_t w = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
+        acc = fmaf(bf_lo(w), xs8[2 * p], acc);
+        acc = fmaf(bf_hi(w), xs8[2 * p + 1], acc);
+    }
+    return acc;
+}
+template <int FMT>
+struct BlockDotF;
+template <>
+struct BlockDotF<FMT_Q4P> {
+    static constexpr int EPB = 32, XCH = 8;
+    static constexpr bool HAS_GAMA = true;
+    __device__ static __forceinline__ float run(u32x4 w, const f32x4* xs, int col, int nBlk, float step, float zero, float nb, float acc) {
+        const float q0 = (float)((threadIdx.x & 3) << 2);
+        uint32_t r = pack_bf16x2(fmaf(q0, step, nb), fmaf(q0 + 1.0f, step, nb));
+        const uint32_t P0 = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
+        r = pack_bf16x2(fmaf(q0 + 2.0f, step, nb), fmaf(q0 + 3.0f, step, nb));
+        const uint32_t P1 = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
+        const uint32_t tlm = __builtin_amdgcn_perm(P1, P0, 0x06040200u), thm = __builtin_amdgcn_perm(P1, P0, 0x07050301u);
+        PermLut t;
+        t.tl[0] = quad_bcast<0>(tlm), t.tl[1] = quad_bcast<1>(tlm), t.tl[2] = quad_bcast<2>(tlm), t.tl[3] = quad_bcast<3>(tlm);
+        t.th[0] = quad_bcast<0>(thm), t.th[1] = quad_bcast<1>(thm), t.th[2] = quad_bcast<2>(thm), t.th[3] = quad_bcast<3>(thm);
+        acc = perm_fma_dword(w.w, xs[col], xs[nBlk + col], t, acc);
+        acc = perm_fma_dword(w.z, xs[2 * nBlk + col], xs[3 * nBlk + col], t, acc);
+        acc = perm_fma_dword(w.y, xs[4 * nBlk + col], xs[5 * nBlk + col], t, acc);
+        acc = perm_fma_dword(w.x, xs[6 * nBlk + col], xs[7 * nBlk + col], t, acc);
+        return acc;
+    }
+};
+template <>
+struct BlockDotF<FMT_Q4> {
+    static constexpr int EPB = 32, XCH = 8;
+    static constexpr bool HAS_GAMA = true;
+    __device__ static __forceinline__ float run(u32x4 w, const f32x4* xs, int col, int nBlk, float step, float zero, float nb, float acc) {
+        const float step16 = step * 0.0625f;
+        acc = arith_fma_dword(w.w, xs[col], xs[nBlk + col], step, step16, nb, zero, acc);
+        acc = arith_fma_dword(w.z, xs[2 * nBlk + col], xs[3 * nBlk + col], step, step16, nb, zero, acc);
+        acc = arith_fma_dword(w.y, xs[4 * nBlk + col], xs[5 * nBlk + col], step, step16, nb, zero, acc);
+        acc = arith_fma_dword(w.x, xs[6 * nBlk + col], xs[7 * nBlk + col], step, step16, nb, zero, acc);
+        return acc;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------ kernel
 // sum over the 2^lg lanes of each aligned lane group (lg wave-uniform); every lane of the group gets the sum.
 // DPP inside a 16-lane row (quad_perm xor1, xor2, row_half_mirror, row_mirror), two cross-row swaps above it.

@@ -144,6 +144,7 @@ int engine_step(EngineHost* E, hipStream_t st, const uint16_t* x_in, uint16_t* x
 int engine_set_head(EngineHost* E, const kf_weight* w, const uint16_t* norm_w, uint16_t* logits, int32_t* d_tokens_out);
 int engine_set_embedding(EngineHost* E, const kf_weight* w, const int32_t* d_forced);
 int engine_error_word(EngineHost* E, hipStream_t st, int* h_err);
+void engine_set_canonical(EngineHost* E, int on); /* the mat-vec phases: canonical order (default) or the v_dot2c forms */
 int engine_reset(EngineHost* E, hipStream_t st); /* after a timed-out poll: exchange state re-initialised, error word cleared */
 void engine_free(EngineHost* E);
 int engine_debug_read(EngineHost* E, unsigned long long* h_out, int n_words);

@@ -756,6 +756,13 @@ int kfh_set_engine(void* h, int on) {
         if (g) kf_graph_destroy(g), g = nullptr;
     return KF_OK;
 }
+// summation order of the decode kernels (kf_set_canonical): 1 (default) the canonical order shared with the CPU oracle, 0 the v_dot2c forms; captured graphs are dropped
+int kfh_set_canonical(void* h, int on) {
+    Fish* f = reinterpret_cast<Fish*>(h);
+    for (auto& g : f->graphs)
+        if (g) kf_graph_destroy(g), g = nullptr;
+    return kf_set_canonical(f->ctx, on);
+}
 // steps enqueued (or captured) through the engine so far; -1: the engine does not serve this model
 int kfh_engine_steps(void* h) {
     Fish* f = reinterpret_cast<Fish*>(h);

@@ -438,6 +438,10 @@ class Qwen3:
         Same arithmetic either way, bit for bit."""
         L.check(self.host.kfh_set_engine(self.h, int(bool(on))), "kfh_set_engine")
 
+    def set_canonical(self, on):
+        """1 (default): the decode kernels sum in the canonical order the CPU oracle shares (bit-exact logits and ids); 0: the v_dot2c_f32_bf16 forms"""
+        L.check(self.host.kfh_set_canonical(self.h, int(bool(on))), "kfh_set_canonical")
+
     def engine_steps(self):
         """steps enqueued or captured through the engine so far (-1: the engine does not serve this model's shapes / storage)"""
         return int(self.host.kfh_engine_steps(self.h))

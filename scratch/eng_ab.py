@@ -21,6 +21,8 @@ m.set_forced(forced)
 if os.environ.get("ENG_DELAY"):
     d = (C.c_int * 6)(*[int(v) for v in os.environ["ENG_DELAY"].split(",")])
     assert m.host.kfh_engine_set_delays(m.h, d) == 0
+if os.environ.get("CANON"):
+    m.set_canonical(int(os.environ["CANON"]))
 for kv in os.environ.get("KF_KNOBS", "").split():
     k, v = kv.split("=")
     m.hip.kfdbg_set_knob.argtypes = [C.c_char_p, C.c_long]
