@@ -176,12 +176,12 @@ def main():
             out["config"]["decode_path"] = "persistent engine, one launch per token" if m.engine_steps() > 0 else "per-layer launches: 5 per layer"
             print(json.dumps(out))
             return
-        try:   # the same positions with the v_dot2c_f32_bf16 mat-vec forms (kf_set_canonical(ctx, 0)): faster, <= 1 bf16 ulp per output from the oracle instead of bit-exact
+        try:   # the same positions in the canonical summation order (kf_set_canonical(ctx, 1)): every logit and id bit-exact against the oracle, more vector instructions per weight
             ids0 = m.tokens_out(S)
 
             def rewind():   # the device state back at the first timed position (token = what the run picked before it)
                 m.set_state(int(ids0[pos - 1]) if pos > 0 else int(forced[0]), pos)
-            m.set_canonical(False)
+            m.set_canonical(True)
             rewind()
             run_span(pos, min(K, 64))   # graphs of the bucket re-captured
             rewind()
@@ -190,14 +190,15 @@ def main():
             run_span(pos, K)
             torch.cuda.synchronize()
             dtf = time.perf_counter() - tf0
-            out["dot2_mode"] = {"tokens_per_s": round(K / dtf, 2), "ms_per_step": round(dtf * 1e3 / K, 5),
-                                "note": "kf_set_canonical(ctx, 0): mat-vec products by v_dot2c_f32_bf16 instead of the canonical v_fma_f32 chains; same positions; never `value`"}
+            out["canonical_mode"] = {"tokens_per_s": round(K / dtf, 2), "ms_per_step": round(dtf * 1e3 / K, 5),
+                                     "note": "kf_set_canonical(ctx, 1): mat-vec products as v_fma_f32 chains + tree, shared with the CPU oracle (bit-exact logits and ids: cpu_baseline.parity_pass); "
+                                             "same positions; never `value`"}
         except Exception as e:
-            out["dot2_mode"] = {"error": repr(e)[:200]}
+            out["canonical_mode"] = {"error": repr(e)[:200]}
         finally:
-            m.set_canonical(True)
+            m.set_canonical(False)
             m.set_state(int(m.tokens_out(S)[pos - 1]) if pos > 0 else int(forced[0]), pos)
-            run_span(pos, K)   # the ids, logits and KV rows the legs below read are those of the canonical run again
+            run_span(pos, K)   # the ids, logits and KV rows the legs below read are those of the default-mode run again
             torch.cuda.synchronize()
         out["prefill"] = prefill_rate(m, forced[:n_prompt], ms_per_step)
         if world == 1 and args.streams > 1 and args.config == "qwen3-0.6b":
@@ -796,31 +797,32 @@ def cpu_baseline(m, cfg, forced, budget_s, min_steps=64, max_steps=256, canon_st
     ok, ov = om.kv()
     ok[:, :p0] = gk[:, :p0]
     ov[:, :p0] = gv[:, :p0]
+    # ---- (1) parity pass, canonical order: the GPU decodes canon_steps + 1 positions from p0 on the KV rows the oracle was just given (the rows of earlier runs
+    # behind p0 were produced from other prompt rows: the batched prefill above rewrote rows 0..p0-1)
+    tok0 = int(m.tokens_out(cfg["max_seq"])[p0 - 1])
+    m.set_canonical(True)   # kf_set_canonical(ctx, 1): the order the oracle shares (the timed region ran the default v_dot2c / fp32 forms)
+    m.set_state(tok0, p0)
+    m.run_steps(p0, canon_steps + 1, True)
+    m.sync()
+    m.set_canonical(False)
     gpu_ids = m.tokens_out(cfg["max_seq"])
-    # ---- (1) parity pass, canonical order
+    g_logits = m.logits()   # of position p0 + canon_steps
     O.set_order(O.ORDER_CANON)
-    same, logits_equal, n_c = 0, 0, 0
+    same, logits_equal, n_c, n_logits = 0, 0, 0, int(g_logits.size)
     try:
-        tok = int(gpu_ids[p0 - 1])
-        for i in range(canon_steps):
-            nxt, lg, _ = om.decode(tok, p0 + i)
+        tok = tok0
+        for i in range(canon_steps + 1):
+            nxt, lg, _ = om.decode(tok, p0 + i, want_logits=(i == canon_steps))
             g = int(gpu_ids[p0 + i])
             same += int(nxt == g)
             n_c += 1
             tok = g
-        # logits of one more position, bit for bit: the GPU repeats the step at that position (its KV rows are those of the run)
-        pl = p0 + canon_steps
-        m.set_state(int(gpu_ids[pl - 1]), pl)
-        m.run_steps(pl, 1, True)
-        m.sync()
-        g_logits = m.logits()
-        _, o_logits, _ = om.decode(int(gpu_ids[pl - 1]), pl)
-        logits_equal = int((g_logits == o_logits).sum())
-        n_logits = int(g_logits.size)
+            if i == canon_steps:
+                logits_equal = int((g_logits == lg).sum())
     finally:
         O.set_order(O.ORDER_DOT16)
     # ---- (2) timing pass, the reference's CPU dot-product order
-    tok, n = int(gpu_ids[p0 - 1]), 0
+    tok, n = tok0, 0
     t0 = time.perf_counter()
     steps = []
     while True:
@@ -836,7 +838,7 @@ def cpu_baseline(m, cfg, forced, budget_s, min_steps=64, max_steps=256, canon_st
     return {"value": round(1e3 / sp["median_ms"], 3), "unit": "tokens/s", "cores": O.num_threads(), "kind": "port",
             "sample": "%d decode steps at positions %d..%d of the same 4-bit model; AVX2 two-accumulator dot on a bf16 dequantised copy (%d MB), OpenMP rows, "
                       "threads pinned one per core" % (n, p0, p0 + n - 1, max(prep, 0) // 2 ** 20), "step_ms": sp,
-            "parity_pass": "%d steps at positions %d..%d in the canonical summation order (kernels and oracle bit for bit), then all %d logits of position %d" % (
+            "parity_pass": "%d greedy steps at positions %d..%d in the canonical summation order (kernels and oracle bit for bit) and all %d logits of position %d" % (
                 n_c, p0, p0 + n_c - 1, n_logits, p0 + canon_steps),
             "greedy_ids_equal_gpu": same, "greedy_ids_compared": n_c, "logits_equal_bit_for_bit": logits_equal, "logits_compared": n_logits,
             "mismatches_that_are_ties_within_2_bf16_ulps": 0 if same == n_c else None, "mismatches_inside_twice_the_logit_tolerance": 0 if same == n_c else None,

@@ -131,11 +131,14 @@ int kf_quantize(kf_ctx* ctx, const kf_weight* w, const kf_bf16* src, int symmetr
  * forms, and the 4-bit row codebook for token batches the tile kernels do not cover -- use a caller-owned workspace: kf_linear_scratch_bytes says how
  * much a weight needs (0 for every PackedQ / bf16 / f8 weight), kf_set_scratch hands the context a buffer (device memory, 16-byte aligned, the caller's
  * to free after the last call that used it; not while capturing, since captured launches hold the pointer).  Too small or missing: KF_INVALID_ARGS. */
-/* Summation order of the decode kernels (mat-vecs, LM head, decode attention, the persistent engine).  1 (the default): the CANONICAL order kernels and the CPU
- * oracle share (oracle/kf_oracle.c sections 4c and 6 "CANON"): every product is one v_fma_f32 in a fixed per-lane chain + a balanced tree, the softmax works on
- * exact power-of-two scalings with fp64 sums -- logits and greedy ids equal the oracle's bit for bit.  0: v_dot2c_f32_bf16 products and the fp32 softmax of rounds 1-2
- * (<= 1 bf16 ulp from the oracle per output; fewer vector instructions per weight: the faster choice for the large VALU-bound mat-vecs of a 32B model).  The reference's
- * own order is cuBLASLt's and unspecified (gemm.cu:126).  Not while capturing. */
+/* Summation order of the decode kernels (mat-vecs, LM head, decode attention, the persistent engine's mat-vec phases).
+ *   0 (the default): products by v_dot2c_f32_bf16, the softmax in fp32 -- <= 1 bf16 ulp per output from the oracle (its order is not reproducible on a host: the
+ *     instruction's internal rounding has no bit-exact model); the fewest vector instructions per weight.
+ *   1: the CANONICAL order kernels and the CPU oracle share (oracle/kf_oracle.c sections 4c and 6 "CANON"): every product one v_fma_f32 in a fixed per-lane chain
+ *     + a balanced tree, the softmax on exact power-of-two scalings with fp64 sums -- logits, greedy ids and KV rows equal the oracle's BIT FOR BIT
+ *     (tests/test_gpu_canonical.py, bench.py cpu_baseline parity pass).  Costs 4-5 % on the 0.6B decode step (latency-bound) and ~28 % on the large VALU-bound
+ *     mat-vecs of a 32B model, which is why it is a switch and not the default.  (The persistent engine's attention is the canonical form in both modes.)
+ * The reference's own order is cuBLASLt's and unspecified (gemm.cu:126).  Not while capturing. */
 int kf_set_canonical(kf_ctx* ctx, int on);
 int kf_get_canonical(kf_ctx* ctx);
 size_t kf_linear_scratch_bytes(const kf_weight* w, int nTok);

@@ -20,7 +20,7 @@ struct kf_ctx {
     bool capturing;
     float* amax_val; /* per-workgroup partial maxima for kf_lm_head when the caller passes no scratch */
     int* amax_idx;
-    int canonical;    /* 1 (default): the decode kernels sum in the canonical order of oracle/kf_oracle.c section 4c (bit-exact against the oracle); 0: v_dot2c forms */
+    int canonical;    /* 1: the decode kernels sum in the canonical order of oracle/kf_oracle.c sections 4c / 6 (bit-exact against the oracle); 0 (default): v_dot2c / fp32 forms */
     void* scratch;    /* caller-owned workspace of kf_linear (kf_set_scratch): AWQ slice partials, or a weight dequantised to bf16 */
     size_t scratch_bytes;
 };
@@ -77,7 +77,7 @@ int kf_init(int device, void* stream, kf_ctx** out) {
     HIPCHK(hipMalloc(&c->amax_val, sizeof(float) * kf::KF_MAX_ARGMAX_PARTIALS));
     HIPCHK(hipMalloc(&c->amax_idx, sizeof(int) * kf::KF_MAX_ARGMAX_PARTIALS));
     c->scratch = nullptr, c->scratch_bytes = 0;
-    c->canonical = 1;
+    c->canonical = 0;
     *out = c;
     return KF_OK;
 }
@@ -598,6 +598,7 @@ int kf_attn_decode(kf_ctx* c, const kf_bf16* q, const kf_bf16* kc, const kf_bf16
     if (!al16(kc) || !al16(vc) || (kv_stride % 8)) return fail(KF_BLAS_UNALIGN, "kf_attn_decode: cache not 16-byte aligned");
     kf::AttnArgs a;
     memset(&a, 0, sizeof(a));
+    a.canon = c->canonical;
     a.q = q, a.kcache = const_cast<kf_bf16*>(kc), a.vcache = vc, a.out = out, a.part = (float*)((char*)scratch + kf::KF_ATTN_CNT_BYTES);
     a.pos = pos, a.d_pos = d_pos, a.n_head = n_head, a.n_kv = n_kv, a.hd = hd, a.kv_stride = kv_stride;
     a.counters = (int*)scratch; /* the first KF_ATTN_CNT_BYTES: arrival counters (fixed place whatever the shape) */
@@ -611,6 +612,7 @@ int kf_attn_block(kf_ctx* c, const kf_bf16* q_raw, const kf_bf16* k_raw, kf_bf16
     if (!al16(kc) || !al16(vc) || (kv_stride % 8)) return fail(KF_BLAS_UNALIGN, "kf_attn_block: cache not 16-byte aligned");
     kf::AttnArgs a;
     memset(&a, 0, sizeof(a));
+    a.canon = c->canonical;
     a.q = q_raw, a.k_raw = k_raw, a.kcache = kc, a.vcache = vc, a.out = out, a.part = (float*)((char*)scratch + kf::KF_ATTN_CNT_BYTES);
     a.wq_norm = wq, a.wk_norm = wk, a.rope_table = table, a.eps = eps;
     a.pos = pos, a.d_pos = d_pos, a.n_head = n_head, a.n_kv = n_kv, a.hd = hd, a.kv_stride = kv_stride;
@@ -766,6 +768,7 @@ int kf_attn_prefill(kf_ctx* c, const kf_bf16* q, const kf_bf16* kc, const kf_bf1
     }
     kf::AttnArgs a;
     memset(&a, 0, sizeof(a));
+    a.canon = c->canonical;
     a.q = q, a.kcache = const_cast<kf_bf16*>(kc), a.vcache = vc, a.out = out;
     a.pos = pos0, a.n_head = n_head, a.n_kv = n_kv, a.hd = hd, a.kv_stride = kv_stride;
     a.n_tok = n_tok, a.q_stride = q_stride, a.one_slice = 1;

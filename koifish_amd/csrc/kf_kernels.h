@@ -115,6 +115,7 @@ struct AttnArgs {
     int n_tok;          /* token batch (prefill): position pos + token */
     int one_slice;      /* every (kv-head, token) is handled by one workgroup: no scratch, no hand-off */
     long long q_stride; /* elements between the q (and out) rows of consecutive tokens */
+    int canon;          /* the canonical softmax (fp64 sums, exact rescales; bit-exact against the oracle's CANON mode) instead of the fp32 form */
 };
 int attn_launch(hipStream_t st, AttnArgs& a);
 int attn_splits(int pos_bound, int n_kv);

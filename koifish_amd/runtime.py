@@ -153,6 +153,10 @@ class Context:
     def sync(self):
         L.check(self.hip.kf_sync(self.h), "kf_sync")
 
+    def set_canonical(self, on):
+        """1: the decode kernels sum in the canonical order the CPU oracle shares (bit-exact); 0 (default): the v_dot2c / fp32 forms"""
+        L.check(self.hip.kf_set_canonical(self.h, int(bool(on))), "kf_set_canonical")
+
     # ---- weights
     def upload_blob(self, type_, ne0, ne1, blob_np, lGroup=128, symmetric=False):
         t = torch.from_numpy(np.ascontiguousarray(blob_np).view(np.uint8).reshape(-1).copy()).to(self.device)
@@ -439,7 +443,7 @@ class Qwen3:
         L.check(self.host.kfh_set_engine(self.h, int(bool(on))), "kfh_set_engine")
 
     def set_canonical(self, on):
-        """1 (default): the decode kernels sum in the canonical order the CPU oracle shares (bit-exact logits and ids); 0: the v_dot2c_f32_bf16 forms"""
+        """1: the decode kernels sum in the canonical order the CPU oracle shares (bit-exact logits, ids and KV rows); 0 (default): the v_dot2c_f32_bf16 / fp32 forms"""
         L.check(self.host.kfh_set_canonical(self.h, int(bool(on))), "kfh_set_canonical")
 
     def engine_steps(self):

@@ -39,12 +39,14 @@ def test_engine_equals_per_layer_launches_bit_for_bit(cfg_name, max_seq, n_steps
     forced[:n_steps] = prompt_ids(cfg, n_steps, seed=11)
     ref_m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
     ref_m.set_engine(False)
+    ref_m.set_canonical(True)   # the engine's attention is the canonical form in both modes: bit-identity with the per-layer kernels holds in the canonical mode
     ref = _teacher_forced(ref_m, forced, n_steps, use_graph=True)
     assert ref_m.engine_steps() == 0
     rk, rv = ref_m.kv_to_host()
     ref_m.close()
     for use_graph in (True, False):
         m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
+        m.set_canonical(True)
         got = _teacher_forced(m, forced, n_steps, use_graph=use_graph)
         assert m.engine_steps() > 0, "the engine was not used (engine_steps = %d)" % m.engine_steps()
         m.engine_check()

@@ -164,3 +164,67 @@ def test_native_tp8_on_32b_shaped_slice_long_context(ctx):
     for pos in (128, 1024, 4095):
         assert vt.step(int(forced[pos]), pos) == int(toks[0][pos]), "pos %d" % pos
     nt.close()
+
+
+def test_native_tp8_32b_slice_at_depth_vs_the_oracle_bit_for_bit(ctx):
+    """BASELINE config 4 against the ORACLE at depth and at long context (missing 3): a 4-layer Qwen3-32B-shaped slice, TP = 8,
+    the native step (kernel-side exchange) run teacher-forced over all 4096 positions; the ranks' KV caches -- rank r holds kv-head r -- are copied into the
+    oracle's cache, and at positions 128, 1024 and 4095 the oracle's tensor-parallel emulation (kfo_qwen3_set_tp: row shards as they are, column shards as fp32
+    partials summed in rank order) in the canonical summation order must give the ranks' logits and id BIT FOR BIT -- the mat-vec shards (1280-row Q|K|V launch,
+    3200-row gate|up, 1024- and 3200-column o_proj / down_proj shards), the canonical attention over up to 4096 keys, the rank-ordered sums, the sharded head."""
+    import ctypes as C
+    cfg = dict(synth.CONFIGS["qwen3-32b"], n_layer=4, vocab=8192, max_seq=4096, tied=True)
+    g = torch.Generator(device=ctx.device)
+    g.manual_seed(7)
+
+    def mat(r, c):
+        return (torch.randn(r, c, generator=g, device=ctx.device, dtype=torch.float32) * 0.05).to(torch.bfloat16)
+
+    def nrm(n):
+        return (1.0 + 0.01 * torch.randn(n, generator=g, device=ctx.device, dtype=torch.float32)).to(torch.bfloat16)
+    w, norms = {}, {}
+    w[(-1, 0)] = ctx.quantize(mat(cfg["vocab"], cfg["dim"]), L.BF16)
+    w[(-1, 1)] = w[(-1, 0)]
+    norms[(-1, 0)] = nrm(cfg["dim"])
+    for li in range(cfg["n_layer"]):
+        for si, s in enumerate(synth.SLOTS):
+            w[(li, si)] = ctx.quantize(mat(*synth.SHAPES[s](cfg)), L.Q4)
+        norms[(li, 0)], norms[(li, 1)], norms[(li, 2)], norms[(li, 3)] = nrm(cfg["dim"]), nrm(cfg["dim"]), nrm(128), nrm(128)
+    nt = TP.NativeTP(cfg, w, norms, 8, ctx)
+    for rk in nt.ranks:
+        rk.set_canonical(True)
+    forced = np.random.default_rng(13).integers(0, cfg["vocab"], size=cfg["max_seq"]).astype(np.int32)
+    nt.set_forced(forced)
+    nt.set_state(int(forced[0]), 0)
+    nt.run_steps(0, 4096, use_graph=True)
+    nt.check()
+
+    class Dev:
+        pass
+    m = Dev()
+    m.cfg, m.weights, m._norms = cfg, w, norms
+    om = O.from_device_model(m, attn_mode=O.ATTN_CANON)
+    O.lib().kfo_qwen3_set_tp(om.h, 8)
+    om.prepare_fast()
+    ok, ov = om.kv()                                   # [n_layer, max_seq, 8 * 128]
+    kvd_l = nt.plan.kvd_l
+    assert kvd_l == 128
+    n = cfg["n_layer"] * cfg["max_seq"] * kvd_l
+    for r, a in enumerate(nt.ranks):
+        hk, hv = np.zeros(n, dtype=np.uint16), np.zeros(n, dtype=np.uint16)
+        L.check(ctx.hip.kf_d2h(ctx.h, hk.ctypes.data_as(C.c_void_p), C.c_void_p(a.host.kfh_kcache(a.h)), C.c_size_t(n * 2)), "d2h")
+        L.check(ctx.hip.kf_d2h(ctx.h, hv.ctypes.data_as(C.c_void_p), C.c_void_p(a.host.kfh_vcache(a.h)), C.c_size_t(n * 2)), "d2h")
+        ok[:, :, r * kvd_l:(r + 1) * kvd_l] = hk.reshape(cfg["n_layer"], cfg["max_seq"], kvd_l)
+        ov[:, :, r * kvd_l:(r + 1) * kvd_l] = hv.reshape(cfg["n_layer"], cfg["max_seq"], kvd_l)
+    O.set_order(O.ORDER_CANON)
+    try:
+        for pos in (128, 1024, 4095):
+            g_id = nt.step(int(forced[pos]), pos, use_graph=True)
+            g_logits = nt.logits()
+            o_id, o_logits, _ = om.decode(int(forced[pos]), pos)
+            assert np.array_equal(g_logits, o_logits), "position %d: %d of %d logits differ" % (pos, int((g_logits != o_logits).sum()), g_logits.size)
+            assert g_id == o_id, "position %d" % pos
+    finally:
+        O.set_order(O.ORDER_DOT16)
+    om.close()
+    nt.close()
