@@ -171,11 +171,6 @@ def main():
             "step_roofline": {"bound": "hbm", "bytes_per_step": int(mean_bytes), "achieved": round(mean_bytes * (value / world) / 1e9, 1),
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(mean_bytes * (value / world) / 1e9 / HBM_PEAK_GBS, 4)},
         }
-        if args.lean:
-            m.engine_check()
-            out["config"]["decode_path"] = "persistent engine, one launch per token" if m.engine_steps() > 0 else "per-layer launches: 5 per layer"
-            print(json.dumps(out))
-            return
         try:   # the same positions in the canonical summation order (kf_set_canonical(ctx, 1)): every logit and id bit-exact against the oracle, more vector instructions per weight
             ids0 = m.tokens_out(S)
 
@@ -200,6 +195,11 @@ def main():
             m.set_state(int(m.tokens_out(S)[pos - 1]) if pos > 0 else int(forced[0]), pos)
             run_span(pos, K)   # the ids, logits and KV rows the legs below read are those of the default-mode run again
             torch.cuda.synchronize()
+        if args.lean:
+            m.engine_check()
+            out["config"]["decode_path"] = "persistent engine, one launch per token" if m.engine_steps() > 0 else "per-layer launches: 5 per layer"
+            print(json.dumps(out))
+            return
         out["prefill"] = prefill_rate(m, forced[:n_prompt], ms_per_step)
         if world == 1 and args.streams > 1 and args.config == "qwen3-0.6b":
             try:
@@ -235,7 +235,10 @@ def main():
             m.close()
             del m
             torch.cuda.empty_cache()
-            out.update(side_legs([l for l in args.side_legs.split(",") if l]))
+            try:
+                out.update(side_legs([l for l in args.side_legs.split(",") if l]))
+            except Exception as e:   # side objects must never cost the bench line
+                out["side_legs_error"] = repr(e)[:300]
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -267,14 +270,16 @@ def side_legs(which):
     if "config5" in which:
         d = _child(["--layers", "1bit", "--sparse", "0.2", "--steps", "512", "--warmup", "64", "--lean"], 300)
         out["config5_sparse_1bit"] = d if "error" in d else {
-            "workload": "Qwen3-0.6B, 1-bit PackedQ layers (YinYang), 20 % of every FFN's rows hot (D_matmul_sparse: cold rows cost no HBM), bf16 head; positions %s" % d["config"]["workload"].split("timed positions ")[-1],
+            "workload": "Qwen3-0.6B, 1-bit PackedQ layers (YinYang), 20 %% of every FFN's rows hot (D_matmul_sparse: cold rows cost no HBM), bf16 head; positions %s" % d["config"]["workload"].split("timed positions ")[-1],
             "tokens_per_s": d["value"], "ms_per_step": d["ms_per_step"], "bytes_per_step": d["step_roofline"]["bytes_per_step"], "frac": d["step_roofline"]["frac"],
+            "canonical_mode_tokens_per_s": d.get("canonical_mode", {}).get("tokens_per_s"),
             "decode_path": d["config"]["decode_path"], "profile": "profiles/r03_config5_sparse_1bit_kernel_stats.csv", "leg_wall_s": d.get("leg_wall_s")}
     if "config4" in which:
         d = _child(["--config", "qwen3-32b", "--steps", "64", "--warmup", "16", "--lean"], 600)
         out["config4_one_gpu"] = d if "error" in d else {
             "workload": "Qwen3-32B 4-bit PackedQ greedy decode on ONE MI355X (the reference shards it over 8 GPUs for memory): %s" % d["config"]["workload"].split("seq=")[-1],
             "tokens_per_s": d["value"], "ms_per_step": d["ms_per_step"], "bytes_per_step": d["step_roofline"]["bytes_per_step"], "frac": d["step_roofline"]["frac"],
+            "canonical_mode_tokens_per_s": d.get("canonical_mode", {}).get("tokens_per_s"),
             "decode_path": d["config"]["decode_path"], "profile": "profiles/r03_config4_one_gpu_kernel_stats.csv", "leg_wall_s": d.get("leg_wall_s"),
             "note": "TP = 8 over xGMI needs an 8-GPU node: bench.py --config qwen3-32b --gpus 8 (no scaling curve has been measured on hardware)"}
     return out
