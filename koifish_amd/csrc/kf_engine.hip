@@ -1432,6 +1432,7 @@ static int engine_go_fmt(EngineHost* E, hipStream_t st) {
     switch (E->shape_class) {
         case 1: /* 8 kv-heads on 8 XCDs: the attention chain of a kv-head stays inside one XCD */
             if (E->args.dbg && FMT == FMT_Q4P && E->canon) return engine_go<EngCfg<FMT_Q4P, 2, 128, ENG_NWV, 1024, 2048, 1024, 3072, ENG_NWG, true, true, true>>(E, st);
+            if (E->args.dbg && FMT == FMT_Q4P) return engine_go<EngCfg<FMT_Q4P, 2, 128, ENG_NWV, 1024, 2048, 1024, 3072, ENG_NWG, true, true, false>>(E, st);
             if (!E->canon) return engine_go<EngCfg<FMT, 2, 128, ENG_NWV, 1024, 2048, 1024, 3072, ENG_NWG, true, false, false>>(E, st);
             return engine_go<EngCfg<FMT, 2, 128, ENG_NWV, 1024, 2048, 1024, 3072, ENG_NWG, true, false, true>>(E, st);
         case 2:

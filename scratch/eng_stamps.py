@@ -16,6 +16,8 @@ cfg = synth.CONFIGS["qwen3-0.6b"]
 m = synth.build_on_gpu(cfg, seed=1234)
 forced = np.random.default_rng(7).integers(0, cfg["vocab"], size=cfg["max_seq"]).astype(np.int32)
 m.set_forced(forced)
+if os.environ.get("CANON"):
+    m.set_canonical(int(os.environ["CANON"]))
 if os.environ.get("ENG_DELAY"):
     d = (C.c_int * 6)(*[int(v) for v in os.environ["ENG_DELAY"].split(",")])
     assert m.host.kfh_engine_set_delays(m.h, d) == 0
