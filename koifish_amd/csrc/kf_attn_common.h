@@ -29,12 +29,11 @@ __device__ __forceinline__ HeadRaw load_head(const uint16_t* __restrict__ src, c
 // Prepare one head: optional per-head RMSNorm (s rounded to bf16 first, then (a*s)*w, RN store) and rotate-half
 // RoPE from the host-built (cos,sin) table.  One wave per head; lane j handles the pair (j, j + hd/2).
 // Result: bf16 bits in dst[hd].
-__device__ __forceinline__ void prep_head(const HeadRaw r, bool norm, const float* __restrict__ tab_pos, int hd, float eps, uint16_t* dst, float* rstd_out = nullptr) {
-    const int lane = threadIdx.x & 63, half = hd >> 1;
+// (c, sn) = the table's pair for (position, j), already in registers; rope = false: no rotation
+__device__ __forceinline__ void prep_head_cs(const HeadRaw r, bool norm, bool rope, float c, float sn, int hd, float eps, uint16_t* dst, float* rstd_out = nullptr, int lane_in = -1) {
+    const int lane = lane_in >= 0 ? lane_in : (int)(threadIdx.x & 63), half = hd >> 1;
     const int j = lane; /* hd <= 128: one trip covers the head */
     const bool act = j < half;
-    float c = 1.f, sn = 0.f;
-    if (tab_pos && act) c = tab_pos[2 * j], sn = tab_pos[2 * j + 1];
     float x0 = act ? bf2f(r.x0) : 0.f, x1 = act ? bf2f(r.x1) : 0.f; /* lanes past hd/2 hold a clamped copy */
     if (norm) {
         const float w0 = bf2f(r.w0), w1 = bf2f(r.w1);
@@ -45,12 +44,18 @@ __device__ __forceinline__ void prep_head(const HeadRaw r, bool norm, const floa
         x0 = round_bf16(x0 * s * w0);
         x1 = round_bf16(x1 * s * w1);
     }
-    if (tab_pos) {
+    if (rope) {
         const float a = x0 * c, b = x1 * sn, cc = x0 * sn, d = x1 * c;
         x0 = round_bf16(a - b);
         x1 = round_bf16(cc + d);
     }
     if (act) dst[j] = f2bf(x0), dst[j + half] = f2bf(x1);
+}
+__device__ __forceinline__ void prep_head(const HeadRaw r, bool norm, const float* __restrict__ tab_pos, int hd, float eps, uint16_t* dst, float* rstd_out = nullptr) {
+    const int j = threadIdx.x & 63;
+    float c = 1.f, sn = 0.f;
+    if (tab_pos && j < (hd >> 1)) c = tab_pos[2 * j], sn = tab_pos[2 * j + 1];
+    prep_head_cs(r, norm, tab_pos != nullptr, c, sn, hd, eps, dst, rstd_out);
 }
 
 // e^x for x <= 0 through the hardware exp2 (v_exp_f32); exp2(-inf) = 0

@@ -380,6 +380,60 @@ __device__ __forceinline__ void mv_run(float qb, float qb2, int s0, int cw, int 
     }
 }
 
+#ifndef ENG_P1_SHARE
+#define ENG_P1_SHARE 1 /* the poller wave computes one of the workgroup's P1 row slots (0: seven waves, wave 0 takes two slots -- its second block of pair words costs 16 more registers and spills) */
+#endif
+#ifndef ENG_DEQ_MASK
+#define ENG_DEQ_MASK 15 /* phases (1 P1, 2 P4, 4 P5, 8 P6) whose blocks are dequantised in front of the barrier */
+#endif
+// the wave's blocks as bf16 pair words (BlockPrep): formed while the wave waits for the phase's activations
+template <bool PAIRED, int MAXS>
+struct MvDeq {
+    uint32_t p[MAXS][16], p2[PAIRED ? MAXS : 1][16];
+};
+template <class PL, int NCW, int FMT, int MAXS>
+__device__ __forceinline__ void mv_dequant(float qb, float qb2, int cw, int lane, const MvRegs<PL::PAIRED, MAXS>& R, MvDeq<PL::PAIRED, MAXS>& D) {
+#pragma unroll
+    for (int k = 0; k < MAXS; k++) {
+        if (cw + (k / PL::iters) * NCW >= PL::spg) continue; /* wave-uniform: this wave has no such slot */
+        const float st = bf2f(R.st[k]);
+        BlockPrep<FMT>::prep(R.w[k], st, bf2f(R.ze[k]), -(qb * st), lane, D.p[k]);
+#pragma unroll
+        for (int i = 0; i < 16; i++) asm volatile("" : "+v"(D.p[k][i])); /* formed HERE, in front of the barrier, not sunk to the first use behind it */
+        if (PL::PAIRED) {
+            const float st2 = bf2f(R.st2[k]);
+            BlockPrep<FMT>::prep(R.w2[k], st2, bf2f(R.ze2[k]), -(qb2 * st2), lane, D.p2[k]);
+#pragma unroll
+            for (int i = 0; i < 16; i++) asm volatile("" : "+v"(D.p2[k][i]));
+        }
+    }
+}
+// mv_run on dequantised blocks: the same lanes, chains and tree
+template <class PL, int NCW, int MAXS, bool CANON, typename Epi>
+__device__ __forceinline__ void mv_run_deq(int s0, int cw, int lane, int Mj, const MvDeq<PL::PAIRED, MAXS>& D, const u32x4* xs, Epi&& epi) {
+    float acc = 0.f, acc2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXS; k++) {
+        const int sl = k / PL::iters, it = k - sl * PL::iters;
+        if (cw + sl * NCW >= PL::spg) continue;
+        const MvAt q = mv_at<PL, NCW>(k, s0, cw, lane, Mj);
+        const int col = q.col < PL::nBlk ? q.col : PL::nBlk - 1;
+        if (it == 0) acc = 0.f, acc2 = 0.f;
+        const float r = pairs_dot<CANON>(D.p[k], xs, col, PL::nBlk, acc);
+        acc = q.ok ? r : acc;
+        if (PL::PAIRED) {
+            const float r2 = pairs_dot<CANON>(D.p2[k], xs, col, PL::nBlk, acc2);
+            acc2 = q.ok ? r2 : acc2;
+        }
+        if (it == PL::iters - 1) {
+            const float v = group_sum(acc, PL::lpr_log2);
+            float v2 = 0.f;
+            if (PL::PAIRED) v2 = group_sum(acc2, PL::lpr_log2);
+            if ((lane & (PL::LPR - 1)) == 0 && q.ok) epi(q.row, v, v2);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ the kernel
 // LDS: [layer table] [xs0] [xs1] [xrawA dim] [xrawB dim] [attention: qraw GQ*hd | kraw hd | vraw hd | qb GQ*hd | knew hd | wmax | comb] [outb] [cnt, pub]
 struct EngLds {
@@ -463,7 +517,16 @@ struct EngAttnState { /* the wave's K / V tiles of the slice, requested a layer 
     static constexpr int U = 2; /* tiles per batch: 8 waves x (64 / LPK) keys x 2 = 64 keys (hd 128) */
     u32x4 kk[U], vv[U];
     uint16_t qw0, qw1, kw0, kw1; /* the q / k-norm weights of this lane's pair: constants, requested at the top of the layer */
+    float rc, rs;                /* the RoPE table's (cos, sin) of this lane's pair at the step's position: the same for every layer, read once */
 };
+template <class C>
+__device__ __forceinline__ void eng_attn_rope(const EngArgs& a, const EngSlice& S, int lane, EngAttnState<C>& T) {
+    T.rc = 1.f, T.rs = 0.f;
+    if (a.rope_table && lane < (C::HD >> 1)) {
+        const float* tab_pos = a.rope_table + (size_t)S.pos * C::HD;
+        T.rc = tab_pos[2 * lane], T.rs = tab_pos[2 * lane + 1];
+    }
+}
 template <class C>
 __device__ __forceinline__ void eng_attn_normw(const EngLayer& ly, int lane, EngAttnState<C>& T) {
     const int half = C::HD >> 1, j = lane < half ? lane : half - 1;
@@ -494,7 +557,7 @@ __device__ __forceinline__ void eng_attn_phase(const EngArgs& a, const EngLds& L
     constexpr int GQ = C::GQ, hd = C::HD, hd_log2 = C::HD == 128 ? 7 : 6, LPK = hd >> 3, KPW = 64 / LPK, lpk_log2 = hd_log2 - 3, NWA = C::NWV, U = EngAttnState<C>::U;
     constexpr bool XMAP = C::XMAP;
     constexpr int NQ = (GQ + NWA - 1) / NWA;
-    const int tid = wave * 64 + lane, pos = S.pos, nsp = S.nsp, kvh = S.kvh, h0 = S.h0, t1 = S.t1;
+    const int tid = (wave << 6) | lane, pos = S.pos, nsp = S.nsp, kvh = S.kvh, h0 = S.h0, t1 = S.t1; /* | not +: with an opaque lane the sum would be re-associated and its invariant part kept in a register */
     const int grp = lane >> lpk_log2, d0 = (lane & (LPK - 1)) * 8;
     const int tstride = NWA * KPW, tstart = S.t0 + wave * KPW + grp;
     const int nbatch = (S.t1 - S.t0 + U * tstride - 1) / (U * tstride);
@@ -502,7 +565,7 @@ __device__ __forceinline__ void eng_attn_phase(const EngArgs& a, const EngLds& L
     if (wave == 0) ENG_STAMP(1, 2);
     if (!S.empty) {
         { /* prologue: q heads of this group, and the new key when it lies in this slice (ROPE::cuInfer) */
-            const float* tab_pos = a.rope_table + (size_t)pos * hd;
+            const bool rope = a.rope_table != nullptr;
             const bool qnorm = ly.norm_q != nullptr;
             const int half = hd >> 1, j = lane < half ? lane : half - 1;
 #pragma unroll
@@ -512,14 +575,14 @@ __device__ __forceinline__ void eng_attn_phase(const EngArgs& a, const EngLds& L
                     HeadRaw r;
                     r.x0 = L.qraw[hq * hd + j], r.x1 = L.qraw[hq * hd + j + half];
                     r.w0 = qnorm ? T.qw0 : r.x0, r.w1 = qnorm ? T.qw1 : r.x1;
-                    prep_head(r, qnorm, tab_pos, hd, a.qk_eps, L.qb + hq * hd);
+                    prep_head_cs(r, qnorm, rope, T.rc, T.rs, hd, a.qk_eps, L.qb + hq * hd, nullptr, lane);
                 }
             }
             if (S.own_new && wave == (GQ % NWA)) {
                 HeadRaw r;
                 r.x0 = L.kraw[j], r.x1 = L.kraw[j + half];
                 r.w0 = ly.norm_k ? T.kw0 : r.x0, r.w1 = ly.norm_k ? T.kw1 : r.x1;
-                prep_head(r, ly.norm_k != nullptr, tab_pos, hd, a.qk_eps, L.knew);
+                prep_head_cs(r, ly.norm_k != nullptr, rope, T.rc, T.rs, hd, a.qk_eps, L.knew, nullptr, lane);
             }
         }
         __syncthreads(); /* heads prepared */
@@ -627,8 +690,8 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
     bool dead = false;
     const bool has1 = XMAP ? true : wg * P1::spg < P1::total, has4 = wg * P4::spg < P4::total, has5 = wg * P5::spg < P5::total, has6 = wg * P6::spg < P6::total;
     // the poller's share of P1 (virtual compute wave NWV - 1)
-    constexpr int NCW1 = NWV, S1 = c_maxs<P1, NCW1>(), NWP1 = P1::spg < NCW1 ? P1::spg : NCW1;
-    constexpr bool P1_SHARE = P1::spg >= NWV; /* the poller owns a slot */
+    constexpr int NCW1 = ENG_P1_SHARE ? NWV : NWV - 1, S1 = c_maxs<P1, NCW1>(), NWP1 = P1::spg < NCW1 ? P1::spg : NCW1;
+    constexpr bool P1_SHARE = ENG_P1_SHARE && P1::spg >= NWV; /* the poller owns a slot */
     const float qb1 = S.j1 == 0 ? a.qbias[0] : (S.j1 == 1 ? a.qbias[1] : a.qbias[2]);
     const int row0_1 = S.s1 * P1::RPS;
     MvRegs<false, S1> r1;
@@ -639,12 +702,15 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
     EngAttnState<C> T;
 #pragma unroll
     for (int u = 0; u < EngAttnState<C>::U; u++) T.kk[u] = T.vv[u] = u32x4{0, 0, 0, 0};
+    eng_attn_rope<C>(a, S, lane, T);
     if (S.has_unit && !S.empty) eng_attn_issue<C>(a, L.lay[0], S, NWV - 1, lane, T, 0);
     int sw[4] = {0, 0, 0, 0};
     for (int l = 0; l < a.n_layer; l++) {
         const EngLayer& ly = L.lay[l];
         const uint32_t gen = (uint32_t)epoch * (uint32_t)a.n_layer + (uint32_t)l, tag = gen & 0xffffu;
         if (S.has_unit && !S.empty) eng_attn_normw<C>(ly, lane, T);
+        MvDeq<false, S1> d1;
+        if (P1_SHARE) mv_dequant<P1, NCW1, FMT, S1>(qb1, 0.f, NWV - 1, lane, r1, d1); /* its blocks were requested behind the previous layer's attention phase */
         // P1 (P4 adds this x as the residual)
         ENG_STAMP(0, 0);
         if (has1 || has4) {
@@ -668,7 +734,7 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
         ENG_STAMP(0, 1);
         __syncthreads();
         if (P1_SHARE && has1) { /* this wave's P1 rows, then the workgroup's publish like every other owner */
-            mv_run<P1, NCW1, FMT, S1, C::CANON>(qb1, 0.f, S.s1, NWV - 1, lane, S.M1, r1, L.xs[0], [&](int row, float v, float) { L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); });
+            mv_run_deq<P1, NCW1, S1, C::CANON>(S.s1, NWV - 1, lane, S.M1, d1, L.xs[0], [&](int row, float v, float) { L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); });
             if (XMAP)
                 wg_publish(L, 0, eng_lqkv<C>(a, S.xcc), S.q_out0, P1::R, NWP1, lane, true);
             else
@@ -709,8 +775,16 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
             }
             if (kv_in) *reinterpret_cast<u32x2*>(L.kraw + e_kv) = u32x2{(gk.x & 0xffffu) | (gk.y << 16), (gk.z & 0xffffu) | (gk.w << 16)}; /* vraw = kraw + hd */
             ENG_STAMP(0, 2);
+            if (P1_SHARE) { /* the next layer's P1 blocks of this wave: unconditional (the last layer requests its own again), and HERE -- loads return in order, so a
+                               request in front of a poll holds that poll's sweep back by an HBM latency; the attention phase waits for nothing younger than its tiles */
+                const int ln = l + 1 < a.n_layer ? l + 1 : l;
+                mv_prefetch<P1, NCW1, FMT, S1>(mat1(ln), mat1(ln), S.s1, NWV - 1, lane, S.M1, r1);
+            }
             eng_attn_phase<C>(a, L, S, ly, gen, tag, NWV - 1, lane, T, l, wg);
             if (!S.empty) eng_attn_issue<C>(a, L.lay[l + 1 < a.n_layer ? l + 1 : l], S, NWV - 1, lane, T, 0); /* the next layer's tiles (the last layer asks for its own again) */
+        } else if (P1_SHARE) { /* a workgroup without an attention slice at this position: the same request, nothing to poll in front of it */
+            const int ln = l + 1 < a.n_layer ? l + 1 : l;
+            mv_prefetch<P1, NCW1, FMT, S1>(mat1(ln), mat1(ln), S.s1, NWV - 1, lane, S.M1, r1);
         }
         // P3: merge the slices of this workgroup's output elements: exact rescales to the largest exponent, fp64 sums, one division (kf_attn_common.h)
         ENG_STAMP(0, 3);
@@ -805,10 +879,6 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
         __syncthreads();
         if (has6) eng_poll_stage<XCH, NF, P6::nBlk, false, false, C::CANON>(a.xch + C::act, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, &sw[3], has5 ? L.pub + 2 : nullptr, l + 1, a.delay[5]);
         ENG_STAMP(0, 7);
-        if (P1_SHARE) { /* unconditional (the last layer requests its own blocks again): a conditional request would turn the waits behind it into drains */
-            const int ln = l + 1 < a.n_layer ? l + 1 : l;
-            mv_prefetch<P1, NCW1, FMT, S1>(mat1(ln), mat1(ln), S.s1, NWV - 1, lane, S.M1, r1);
-        }
         if (DBG && wg == a.dbg_wg && lane == 0)
             a.dbg[((size_t)l * 2) * 16 + 8] = (unsigned long long)sw[0] | ((unsigned long long)sw[1] << 16) | ((unsigned long long)sw[2] << 32) | ((unsigned long long)sw[3] << 48);
         __syncthreads();
@@ -828,7 +898,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
     constexpr int NCW = NWV - 1;
     // P1 alone is shared with the poller wave (it is idle between staging x and the first q/k/v granules): NWV waves, so that the 0.6B shape's
     // 8 row-slots per workgroup are one step for every wave instead of two for wave 0
-    constexpr int NCW1 = NWV;
+    constexpr int NCW1 = ENG_P1_SHARE ? NWV : NWV - 1;
     constexpr int S1 = c_maxs<P1, NCW1>(), S4 = c_maxs<P4, NCW>(), S5 = c_maxs<P5, NCW>(), S6 = c_maxs<P6, NCW>();
     // this workgroup's rows per phase (contiguous in the phase's output vector) and the waves that own some of them
     static_assert(P1::R % 4 == 0 && P4::R % 4 == 0 && P5::R % 4 == 0 && P6::R % 4 == 0 && P1::R <= 64 && P4::R <= 64 && P5::R <= 64 && P6::R <= 64, "rows per workgroup");
@@ -850,6 +920,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
 #pragma unroll
     for (int u = 0; u < EngAttnState<C>::U; u++) T.kk[u] = T.vv[u] = u32x4{0, 0, 0, 0};
     mv_prefetch<P1, NCW1, FMT, S1>(mat1(0), mat1(0), S.s1, wave, lane, S.M1, r1);
+    eng_attn_rope<C>(a, S, lane, T);
     if (S.has_unit && !S.empty) eng_attn_issue<C>(a, L.lay[0], S, wave, lane, T, 0);
 
     for (int l = 0; l < a.n_layer; l++) {
@@ -857,62 +928,82 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         const uint32_t gen = (uint32_t)epoch * (uint32_t)a.n_layer + (uint32_t)l, tag = gen & 0xffffu, tag_next = (gen + 1u) & 0xffffu;
         const bool last = l == a.n_layer - 1;
         const int ln = last ? l : l + 1; /* the layer whose blocks are requested next: the last layer asks for its own again (unconditional requests keep every wait counted) */
-        if (S.has_unit && !S.empty) eng_attn_normw<C>(ly, lane, T);
-        // ================= P1: RMSNorm(x) -> Q, K, V rows
+        int lzm;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(lzm));
+        const int lane_m = lane + lzm; /* as for the attention phase below: the mat-vec phases' per-lane indices are recomputed per layer rather than held in registers */
+        if (S.has_unit && !S.empty) eng_attn_normw<C>(ly, lane_m, T);
+        // ================= P1: RMSNorm(x) -> Q, K, V rows  (every phase: the blocks are dequantised in front of the barrier the activations arrive behind)
+        MvDeq<false, S1> d1; /* declared per layer: nothing of it is carried around the loop */
+        if (ENG_DEQ_MASK & 1) mv_dequant<P1, NCW1, FMT, S1>(qb1, 0.f, wave, lane_m, r1, d1);
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 0);
-        mv_prefetch<P4, NCW, FMT, S4>(ly.m[3], ly.m[3], wg * P4::spg, wave, lane, P4::M0, r4);
-        mv_run<P1, NCW1, FMT, S1, C::CANON>(qb1, 0.f, S.s1, wave, lane, S.M1, r1, L.xs[0], [&](int row, float v, float) { L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); });
+        if (!(ENG_DEQ_MASK & 1)) mv_dequant<P1, NCW1, FMT, S1>(qb1, 0.f, wave, lane_m, r1, d1);
+        mv_prefetch<P4, NCW, FMT, S4>(ly.m[3], ly.m[3], wg * P4::spg, wave, lane_m, P4::M0, r4);
+        mv_run_deq<P1, NCW1, S1, C::CANON>(S.s1, wave, lane_m, S.M1, d1, L.xs[0], [&](int row, float v, float) { L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); });
         if (has1 && wave < NWP1) {
             if (XMAP)
-                wg_publish(L, 0, eng_lqkv<C>(a, S.xcc), S.q_out0, P1::R, NWP1, lane, true);
+                wg_publish(L, 0, eng_lqkv<C>(a, S.xcc), S.q_out0, P1::R, NWP1, lane_m, true);
             else
-                wg_publish(L, 0, a.xch + C::qkv, S.q_out0, P1::R, NWP1, lane);
+                wg_publish(L, 0, a.xch + C::qkv, S.q_out0, P1::R, NWP1, lane_m);
         }
         // ================= P2: q/k-norm + RoPE + attention over this workgroup's slice (all 8 waves: eng_attn_phase), then the next layer's K/V tiles of the
         // slice (they do not depend on this token, except row `pos`, which is substituted; the last layer requests its own again)
         if (wave == 0) ENG_STAMP(1, 1);
         if (S.has_unit) {
-            eng_attn_phase<C>(a, L, S, ly, gen, tag, wave, lane, T, l, wg);
+            // the attention phase's per-lane addresses and offsets are layer-invariant, and hoisted out of the layer loop they would occupy ~50 registers through the
+            // mat-vec phases (which then spill): an opaque zero added to the lane id makes them a few dozen instructions per layer instead
+            int lz;
+            asm volatile("s_mov_b32 %0, 0" : "=s"(lz));
+            const int lane_a = lane + lz;
+            eng_attn_phase<C>(a, L, S, ly, gen, tag, wave, lane_a, T, l, wg);
             if (wave == 0) ENG_STAMP(1, 3);
             if (DBG && wave == 0) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 ENG_STAMP(1, 10); /* partial stores acknowledged */
             }
-            if (!S.empty) eng_attn_issue<C>(a, L.lay[ln], S, wave, lane, T, 0);
+            if (!S.empty) eng_attn_issue<C>(a, L.lay[ln], S, wave, lane_a, T, 0);
         }
 
         // ================= P4: o_proj + residual -> xB
+        MvDeq<false, S4> d4;
+        if (ENG_DEQ_MASK & 2) mv_dequant<P4, NCW, FMT, S4>(a.qbias[3], 0.f, wave, lane_m, r4, d4);
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 4);
-        mv_prefetch<P5, NCW, FMT, S5>(ly.m[4], ly.m[5], wg * P5::spg, wave, lane, P5::M0, r5);
-        mv_run<P4, NCW, FMT, S4, C::CANON>(a.qbias[3], 0.f, wg * P4::spg, wave, lane, P4::M0, r4, L.xs[1], [&](int row, float v, float) {
+        if (!(ENG_DEQ_MASK & 2)) mv_dequant<P4, NCW, FMT, S4>(a.qbias[3], 0.f, wave, lane_m, r4, d4);
+        mv_prefetch<P5, NCW, FMT, S5>(ly.m[4], ly.m[5], wg * P5::spg, wave, lane_m, P5::M0, r5);
+        mv_run_deq<P4, NCW, S4, C::CANON>(wg * P4::spg, wave, lane_m, P4::M0, d4, L.xs[1], [&](int row, float v, float) {
             const uint16_t o = f2bf(v);
             L.outb[row - wg * P4::R] = (tag << 16) | (uint32_t)f2bf(bf2f(L.xrawA[row]) + bf2f(o)); /* CU_add3: bf16(x + bf16(W.x)) */
         });
-        if (has4 && wave < NWP4) wg_publish(L, 1, a.xch + C::xB, wg * P4::R, P4::R, NWP4, lane);
+        if (has4 && wave < NWP4) wg_publish(L, 1, a.xch + C::xB, wg * P4::R, P4::R, NWP4, lane_m);
         // ================= P5: RMSNorm + gate/up + SwiGLU -> act
         if (wave == 0) ENG_STAMP(1, 5);
+        MvDeq<true, S5> d5;
+        if (ENG_DEQ_MASK & 4) mv_dequant<P5, NCW, FMT, S5>(a.qbias[4], a.qbias[5], wave, lane_m, r5, d5);
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 6);
-        mv_prefetch<P6, NCW, FMT, S6>(ly.m[6], ly.m[6], wg * P6::spg, wave, lane, P6::M0, r6);
-        mv_run<P5, NCW, FMT, S5, C::CANON>(a.qbias[4], a.qbias[5], wg * P5::spg, wave, lane, P5::M0, r5, L.xs[0], [&](int row, float v, float v2) {
+        if (!(ENG_DEQ_MASK & 4)) mv_dequant<P5, NCW, FMT, S5>(a.qbias[4], a.qbias[5], wave, lane_m, r5, d5);
+        mv_prefetch<P6, NCW, FMT, S6>(ly.m[6], ly.m[6], wg * P6::spg, wave, lane_m, P6::M0, r6);
+        mv_run_deq<P5, NCW, S5, C::CANON>(wg * P5::spg, wave, lane_m, P5::M0, d5, L.xs[0], [&](int row, float v, float v2) {
             const float gt = round_bf16(v), up = round_bf16(v2); /* CU_swiglu_v0 on the two bf16-rounded projections */
             L.outb[row - wg * P5::R] = (tag << 16) | (uint32_t)f2bf((gt * up) / (1.0f + kf_expf(-gt)));
         });
-        if (has5 && wave < NWP5) wg_publish(L, 2, a.xch + C::act, wg * P5::R, P5::R, NWP5, lane);
+        if (has5 && wave < NWP5) wg_publish(L, 2, a.xch + C::act, wg * P5::R, P5::R, NWP5, lane_m);
         // ================= P6: down_proj + residual -> x of the next layer
         if (wave == 0) ENG_STAMP(1, 7);
+        MvDeq<false, S6> d6;
+        if (ENG_DEQ_MASK & 8) mv_dequant<P6, NCW, FMT, S6>(a.qbias[6], 0.f, wave, lane_m, r6, d6);
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 8);
-        mv_prefetch<P1, NCW1, FMT, S1>(mat1(ln), mat1(ln), S.s1, wave, lane, S.M1, r1);
-        mv_run<P6, NCW, FMT, S6, C::CANON>(a.qbias[6], 0.f, wg * P6::spg, wave, lane, P6::M0, r6, L.xs[1], [&](int row, float v, float) {
+        if (!(ENG_DEQ_MASK & 8)) mv_dequant<P6, NCW, FMT, S6>(a.qbias[6], 0.f, wave, lane_m, r6, d6);
+        mv_prefetch<P1, NCW1, FMT, S1>(mat1(ln), mat1(ln), S.s1, wave, lane_m, S.M1, r1);
+        mv_run_deq<P6, NCW, S6, C::CANON>(wg * P6::spg, wave, lane_m, P6::M0, d6, L.xs[1], [&](int row, float v, float) {
             const uint16_t o = f2bf(v);
             const uint16_t y = f2bf(bf2f(L.xrawB[row]) + bf2f(o));
             if (last) a.x_out[row] = y;
             L.outb[row - wg * P6::R] = (tag_next << 16) | (uint32_t)y;
         });
-        if ((!last || a.head_on) && has6 && wave < NWP6) wg_publish(L, 3, a.xch + C::xA, wg * P6::R, P6::R, NWP6, lane);
+        if ((!last || a.head_on) && has6 && wave < NWP6) wg_publish(L, 3, a.xch + C::xA, wg * P6::R, P6::R, NWP6, lane_m);
         if (wave == 0) ENG_STAMP(1, 9);
     }
 }
@@ -1077,16 +1168,19 @@ __global__ void __launch_bounds__(C::NWV * 64) engine_kernel(const EngArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
     // ---- LDS carve
+    // every buffer at a compile-time offset (the addresses fold into the LDS instructions' offset fields instead of living in registers through the whole launch);
+    // the layer table, whose size is a run-time figure, lies behind them
     EngLds L;
-    EngLayer* lay = reinterpret_cast<EngLayer*>(smem);
     constexpr int maxK = C::DIM > C::QD ? (C::DIM > C::FFN ? C::DIM : C::FFN) : (C::QD > C::FFN ? C::QD : C::FFN);
     constexpr int xs_bytes = (maxK * 4 + 15) & ~15, xr_bytes = (C::DIM * 2 + 15) & ~15; /* xs: fp32 activations */
-    size_t off = ((size_t)a.n_layer * sizeof(EngLayer) + 15) & ~(size_t)15;
+    constexpr size_t off = (size_t)2 * xs_bytes + 2 * xr_bytes;
+    constexpr size_t fixed_bytes = (off + sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + sizeof(double) * ((size_t)NWV * GQ * (hd + 2) + (size_t)C::ME * KF_ATTN_MAX_SPLITS + 64) + 4 * 16 + 4 * 64 + 32 + 15) & ~(size_t)15;
+    EngLayer* lay = reinterpret_cast<EngLayer*>(smem + fixed_bytes);
     L.lay = lay;
-    L.xs[0] = reinterpret_cast<u32x4*>(smem + off), off += xs_bytes;
-    L.xs[1] = reinterpret_cast<u32x4*>(smem + off), off += xs_bytes;
-    L.xrawA = reinterpret_cast<uint16_t*>(smem + off), off += xr_bytes;
-    L.xrawB = reinterpret_cast<uint16_t*>(smem + off), off += xr_bytes;
+    L.xs[0] = reinterpret_cast<u32x4*>(smem);
+    L.xs[1] = reinterpret_cast<u32x4*>(smem + xs_bytes);
+    L.xrawA = reinterpret_cast<uint16_t*>(smem + 2 * xs_bytes);
+    L.xrawB = reinterpret_cast<uint16_t*>(smem + 2 * xs_bytes + xr_bytes);
     L.qraw = reinterpret_cast<uint16_t*>(smem + off); /* [GQ][hd] raw q heads of this workgroup's slice */
     L.kraw = L.qraw + GQ * hd, L.vraw = L.kraw + hd, L.qb = L.vraw + hd, L.knew = L.qb + GQ * hd;
     L.comb = reinterpret_cast<double*>(L.knew + hd); /* [NWV][GQ][hd + 2] doubles (the offset is a multiple of 16 bytes) */
@@ -1341,7 +1435,7 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     {
         /* s_sleep units (one trip of the wait loop ~ 40 ns) behind the own publish: x, q|k|v, slice partials, ao, xB, act.  Tuned on the 0.6B shape at 2 k keys
            (scratch/eng_ab.py): after the drains were removed 12,8,12,12,12,12 0.455 ms/step, 16,8,12,16,16,16 0.452, 20,12,16,20,20,20 0.464, 24,12,16,24,24,24 0.474 */
-        const int dflt[6] = {16, 8, 12, 16, 16, 16};
+        const int dflt[6] = {16, 8, 8, 24, 16, 16};
         for (int i = 0; i < 6; i++) a.delay[i] = dflt[i];
     }
     // The vectors that cross XCDs live in uncached device memory: an sc1 sweep of a cached (hipMalloc) line costs 75 ns per KB and CU, of an uncached one 43
