@@ -623,7 +623,7 @@ __device__ __forceinline__ void eng_attn_phase(const EngArgs& a, const EngLds& L
         __syncthreads(); /* the waves' fp64 sums in LDS */
         if (wave == 0) ENG_STAMP(1, 14);
         constexpr int PSD = hd + 2;
-        for (int i = tid; i < GQ * hd; i += NWA * 64) {
+        for (int i = tid; i < GQ * hd; i += NWA * 64) { /* (two or four threads per element with DPP joins was measured: slower, 378 vs 370 us per step) */
             const int hq = i >> hd_log2, d = i & (hd - 1);
             float ms = -__builtin_inff();
 #pragma unroll
@@ -1435,7 +1435,7 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     {
         /* s_sleep units (one trip of the wait loop ~ 40 ns) behind the own publish: x, q|k|v, slice partials, ao, xB, act.  Tuned on the 0.6B shape at 2 k keys
            (scratch/eng_ab.py): after the drains were removed 12,8,12,12,12,12 0.455 ms/step, 16,8,12,16,16,16 0.452, 20,12,16,20,20,20 0.464, 24,12,16,24,24,24 0.474 */
-        const int dflt[6] = {16, 8, 8, 24, 16, 16};
+        const int dflt[6] = {16, 8, 20, 24, 16, 16};
         for (int i = 0; i < 6; i++) a.delay[i] = dflt[i];
     }
     // The vectors that cross XCDs live in uncached device memory: an sc1 sweep of a cached (hipMalloc) line costs 75 ns per KB and CU, of an uncached one 43

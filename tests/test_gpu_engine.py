@@ -59,6 +59,45 @@ def test_engine_equals_per_layer_launches_bit_for_bit(cfg_name, max_seq, n_steps
         m.close()
 
 
+def test_full_size_engine_equals_per_layer_launches_bit_for_bit():
+    """The 0.6B instantiation itself (engine_kernel<EngCfg<5, 2, 128, 8, 1024, 2048, 1024, 3072, 256, ...>>, 28 layers, vocab 151 936, in-launch head and pick) against
+    the per-layer launches of the SAME model object, teacher-forced over positions 0..63, 250..260, 1020..1030 and 2040..2047 (one slice ... 32 slices, every graph
+    bucket): logits, greedy ids and the K / V rows each step writes, bit for bit.  A hand-off race that corrupted one granule in one layer would show here."""
+    cfg = dict(synth.CONFIGS["qwen3-0.6b"])
+    m = synth.build_on_gpu(cfg, seed=4242, layer_type=L.Q4, head_type=L.BF16)
+    m.set_canonical(True)   # the engine's attention phase is the canonical form in both modes
+    rng = np.random.default_rng(77)
+    toks = rng.integers(0, cfg["vocab"], size=cfg["max_seq"]).astype(np.int32)
+    forced = toks.copy()
+    m.set_forced(forced)
+    total = 0
+    for p0, p1 in ((0, 64), (250, 261), (1020, 1031), (2040, 2048)):
+        if p0 > 0:
+            m.prefill(toks[:p0], want_logits=False)   # rows 0..p0-1 of the cache, shared by both passes
+        res = {}
+        for engine in (True, False):
+            m.set_engine(engine)
+            steps0 = m.engine_steps()
+            m.set_state(int(toks[p0]), p0)
+            out = []
+            for p in range(p0, p1):
+                m.run_steps(p, 1, use_graph=True)
+                m.sync()
+                out.append((int(m.tokens_out(p + 1)[p]), m.logits().copy()))
+            assert (m.engine_steps() > steps0) == engine
+            m.engine_check()
+            k, v = m.kv_to_host()
+            res[engine] = (out, k[:, p0:p1].copy(), v[:, p0:p1].copy())
+        for i, p in enumerate(range(p0, p1)):
+            a, b = res[True][0][i], res[False][0][i]
+            assert a[0] == b[0], "position %d: greedy id %d vs %d" % (p, a[0], b[0])
+            assert np.array_equal(a[1], b[1]), "position %d: %d of %d logits differ" % (p, int((a[1] != b[1]).sum()), a[1].size)
+        assert np.array_equal(res[True][1], res[False][1]) and np.array_equal(res[True][2], res[False][2]), "K / V rows of positions %d..%d differ" % (p0, p1 - 1)
+        total += p1 - p0
+    assert total == 94
+    m.close()
+
+
 def test_engine_free_running_ids_match_oracle():
     cfg = _cfg("small", 320)
     raw = synth.raw_weights_numpy(cfg, 1234, w_std=0.1)
