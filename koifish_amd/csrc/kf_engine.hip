@@ -245,6 +245,48 @@ __device__ __forceinline__ void eng_poll_stage(const uint32_t* gsrc, const uint1
     }
 }
 
+// ---- the same for a vector that needs no norm, swept by ALL waves of the workgroup: wave w takes the loads w, w + NWV, ... (a kilobyte each), repeats
+// only its own until their tags match and stages them; the caller's barrier behind it makes the vector whole.  A sweep by one wave costs ~43 ns per kilobyte on
+// top of the round trip (scratch/ub_handoff3.hip): eight waves divide that, and a stale piece is re-read alone instead of with the eleven others.
+template <int XCH, int NLD, int NBLK, int NWV, bool F32X = true>
+__device__ __forceinline__ void eng_poll_stage_part(const uint32_t* gsrc, uint32_t tag, u32x4* xs, int wave, int lane, int* ws, bool& dead) {
+    constexpr int n = NLD * 256, NR = (NLD + NWV - 1) / NWV;
+    const __amdgpu_buffer_rsrc_t rs = eng_rsrc(gsrc, (uint32_t)n * 4u);
+    const uint32_t tagw = tag << 16;
+    u32x4 g[NR];
+    for (int spins = 0;; spins++) {
+        uint32_t bad = 0;
+#pragma unroll
+        for (int i = 0; i < NR; i++) {
+            const int r = wave + i * NWV; /* wave-uniform */
+            g[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ((r < NLD ? r : wave) * 64 + lane) * 16, 0, 16 /* sc1 */));
+        }
+#pragma unroll
+        for (int i = 0; i < NR; i++) bad = (wave + i * NWV < NLD) ? tags_bad(g[i], tagw, bad) : bad;
+        if (wave >= NLD || all_good(bad)) break;
+        if (dead || spins > ENG_SPIN_MAX) {
+            if (!dead && lane == 0) atomicOr(ws + 1, 1);
+            dead = true;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int i = 0; i < NR; i++) {
+        const int r = wave + i * NWV;
+        if (r >= NLD) continue;
+        const int e0 = 4 * (r * 64 + lane);
+        const uint32_t o0 = (g[i].x & 0xffffu) | (g[i].y << 16), o1 = (g[i].z & 0xffffu) | (g[i].w << 16);
+        if (F32X) {
+            const int q = e0 >> 2, c = q / XCH, j = q - c * XCH;
+            xs[j * NBLK + c] = u32x4{o0 << 16, o0 & 0xffff0000u, o1 << 16, o1 & 0xffff0000u};
+        } else {
+            const int q = e0 >> 3, c = q / XCH, j = q - c * XCH;
+            reinterpret_cast<u32x2*>(xs + j * NBLK + c)[(e0 >> 2) & 1] = u32x2{o0, o1};
+        }
+    }
+}
+
 // ---- mat-vec phase geometry: compile-time constants of the model shape (the same lanes per row, rows per wave step and steps per row
 // gemv_launch picks for these matrices: engine_build checks the two against each other), so a wave's loads are unconditional, their number
 // is static and the compiler can wait with counted vmcnt(N) instead of draining.
@@ -383,6 +425,9 @@ __device__ __forceinline__ void mv_run(float qb, float qb2, int s0, int cw, int 
 #ifndef ENG_P1_SHARE
 #define ENG_P1_SHARE 1 /* the poller wave computes one of the workgroup's P1 row slots (0: seven waves, wave 0 takes two slots -- its second block of pair words costs 16 more registers and spills) */
 #endif
+#ifndef ENG_COOP
+#define ENG_COOP 1 /* the norm-free vectors (ao, act) are swept by all eight waves */
+#endif
 #ifndef ENG_DEQ_MASK
 #define ENG_DEQ_MASK 15 /* phases (1 P1, 2 P4, 4 P5, 8 P6) whose blocks are dequantised in front of the barrier */
 #endif
@@ -516,7 +561,7 @@ template <class C>
 struct EngAttnState { /* the wave's K / V tiles of the slice, requested a layer ahead */
     static constexpr int U = 2; /* tiles per batch: 8 waves x (64 / LPK) keys x 2 = 64 keys (hd 128) */
     u32x4 kk[U], vv[U];
-    uint16_t qw0, qw1, kw0, kw1; /* the q / k-norm weights of this lane's pair: constants, requested at the top of the layer */
+    uint16_t nw0, nw1; /* the q-norm (waves 0 .. GQ - 1: they prepare the q heads) or k-norm (wave GQ % NWV: the new key) weights of this lane's pair, requested at the top of the layer */
     float rc, rs;                /* the RoPE table's (cos, sin) of this lane's pair at the step's position: the same for every layer, read once */
 };
 template <class C>
@@ -528,11 +573,12 @@ __device__ __forceinline__ void eng_attn_rope(const EngArgs& a, const EngSlice& 
     }
 }
 template <class C>
-__device__ __forceinline__ void eng_attn_normw(const EngLayer& ly, int lane, EngAttnState<C>& T) {
+__device__ __forceinline__ void eng_attn_normw(const EngLayer& ly, int wave, int lane, EngAttnState<C>& T) {
     const int half = C::HD >> 1, j = lane < half ? lane : half - 1;
-    T.qw0 = T.qw1 = T.kw0 = T.kw1 = 0;
-    if (ly.norm_q) T.qw0 = ly.norm_q[j], T.qw1 = ly.norm_q[j + half];
-    if (ly.norm_k) T.kw0 = ly.norm_k[j], T.kw1 = ly.norm_k[j + half];
+    static_assert(C::GQ < C::NWV, "the q heads and the new key are prepared by different waves");
+    g_u16 np = wave < C::GQ ? ly.norm_q : ly.norm_k; /* wave-uniform */
+    T.nw0 = T.nw1 = 0;
+    if (np) T.nw0 = np[j], T.nw1 = np[j + half];
 }
 template <class C>
 __device__ __forceinline__ void eng_attn_issue(const EngArgs& a, const EngLayer& ly, const EngSlice& S, int wave, int lane, EngAttnState<C>& T, int b) {
@@ -574,14 +620,14 @@ __device__ __forceinline__ void eng_attn_phase(const EngArgs& a, const EngLds& L
                 if (hq < GQ) {
                     HeadRaw r;
                     r.x0 = L.qraw[hq * hd + j], r.x1 = L.qraw[hq * hd + j + half];
-                    r.w0 = qnorm ? T.qw0 : r.x0, r.w1 = qnorm ? T.qw1 : r.x1;
+                    r.w0 = qnorm ? T.nw0 : r.x0, r.w1 = qnorm ? T.nw1 : r.x1;
                     prep_head_cs(r, qnorm, rope, T.rc, T.rs, hd, a.qk_eps, L.qb + hq * hd, nullptr, lane);
                 }
             }
             if (S.own_new && wave == (GQ % NWA)) {
                 HeadRaw r;
                 r.x0 = L.kraw[j], r.x1 = L.kraw[j + half];
-                r.w0 = ly.norm_k ? T.kw0 : r.x0, r.w1 = ly.norm_k ? T.kw1 : r.x1;
+                r.w0 = ly.norm_k ? T.nw0 : r.x0, r.w1 = ly.norm_k ? T.nw1 : r.x1;
                 prep_head_cs(r, ly.norm_k != nullptr, rope, T.rc, T.rs, hd, a.qk_eps, L.knew, nullptr, lane);
             }
         }
@@ -708,7 +754,7 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
     for (int l = 0; l < a.n_layer; l++) {
         const EngLayer& ly = L.lay[l];
         const uint32_t gen = (uint32_t)epoch * (uint32_t)a.n_layer + (uint32_t)l, tag = gen & 0xffffu;
-        if (S.has_unit && !S.empty) eng_attn_normw<C>(ly, lane, T);
+        if (S.has_unit && !S.empty) eng_attn_normw<C>(ly, NWV - 1, lane, T);
         MvDeq<false, S1> d1;
         if (P1_SHARE) mv_dequant<P1, NCW1, FMT, S1>(qb1, 0.f, NWV - 1, lane, r1, d1); /* its blocks were requested behind the previous layer's attention phase */
         // P1 (P4 adds this x as the residual)
@@ -869,7 +915,13 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
         }
         // P4, P5 (P6 adds that x as the residual), P6
         ENG_STAMP(0, 4);
-        if (has4) eng_poll_stage<XCH, NQD, P4::nBlk, false, false, C::CANON>(a.xch + C::ao, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, &sw[1], nullptr, 0, a.delay[3]);
+        if (ENG_COOP) { /* the ao vector: timed by this wave, swept by all eight */
+            if (has4) eng_wait_pub(nullptr, 0, a.delay[3], dead);
+            __syncthreads();
+            if (has4) eng_poll_stage_part<XCH, NQD, P4::nBlk, NWV, C::CANON>(a.xch + C::ao, tag, L.xs[1], NWV - 1, lane, a.ws, dead);
+        } else if (has4) {
+            eng_poll_stage<XCH, NQD, P4::nBlk, false, false, C::CANON>(a.xch + C::ao, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, &sw[1], nullptr, 0, a.delay[3]);
+        }
         ENG_STAMP(0, 5);
         __syncthreads();
         if (has5 || has6)
@@ -877,7 +929,13 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
                                                            a.delay[4]);
         ENG_STAMP(0, 6);
         __syncthreads();
-        if (has6) eng_poll_stage<XCH, NF, P6::nBlk, false, false, C::CANON>(a.xch + C::act, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, &sw[3], has5 ? L.pub + 2 : nullptr, l + 1, a.delay[5]);
+        if (ENG_COOP) {
+            if (has6) eng_wait_pub(has5 ? L.pub + 2 : nullptr, l + 1, a.delay[5], dead);
+            __syncthreads();
+            if (has6) eng_poll_stage_part<XCH, NF, P6::nBlk, NWV, C::CANON>(a.xch + C::act, tag, L.xs[1], NWV - 1, lane, a.ws, dead);
+        } else if (has6) {
+            eng_poll_stage<XCH, NF, P6::nBlk, false, false, C::CANON>(a.xch + C::act, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, &sw[3], has5 ? L.pub + 2 : nullptr, l + 1, a.delay[5]);
+        }
         ENG_STAMP(0, 7);
         if (DBG && wg == a.dbg_wg && lane == 0)
             a.dbg[((size_t)l * 2) * 16 + 8] = (unsigned long long)sw[0] | ((unsigned long long)sw[1] << 16) | ((unsigned long long)sw[2] << 32) | ((unsigned long long)sw[3] << 48);
@@ -912,6 +970,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         return L.lay[l].m[S.j1];
     };
 
+    bool dead = false; /* a timed-out sweep of this wave: the error word is set, later sweeps return at once */
     MvRegs<false, S1> r1;
     MvRegs<false, S4> r4;
     MvRegs<true, S5> r5;
@@ -931,7 +990,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         int lzm;
         asm volatile("s_mov_b32 %0, 0" : "=s"(lzm));
         const int lane_m = lane + lzm; /* as for the attention phase below: the mat-vec phases' per-lane indices are recomputed per layer rather than held in registers */
-        if (S.has_unit && !S.empty) eng_attn_normw<C>(ly, lane_m, T);
+        if (S.has_unit && !S.empty) eng_attn_normw<C>(ly, wave, lane_m, T);
         // ================= P1: RMSNorm(x) -> Q, K, V rows  (every phase: the blocks are dequantised in front of the barrier the activations arrive behind)
         MvDeq<false, S1> d1; /* declared per layer: nothing of it is carried around the loop */
         if (ENG_DEQ_MASK & 1) mv_dequant<P1, NCW1, FMT, S1>(qb1, 0.f, wave, lane_m, r1, d1);
@@ -967,6 +1026,10 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         // ================= P4: o_proj + residual -> xB
         MvDeq<false, S4> d4;
         if (ENG_DEQ_MASK & 2) mv_dequant<P4, NCW, FMT, S4>(a.qbias[3], 0.f, wave, lane_m, r4, d4);
+        if (ENG_COOP) {
+            __syncthreads(); /* the poller has timed the first sweep */
+            if (has4) eng_poll_stage_part<C::XCH, C::QD / 256, P4::nBlk, NWV, C::CANON>(a.xch + C::ao, tag, L.xs[1], wave, lane_m, a.ws, dead);
+        }
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 4);
         if (!(ENG_DEQ_MASK & 2)) mv_dequant<P4, NCW, FMT, S4>(a.qbias[3], 0.f, wave, lane_m, r4, d4);
@@ -993,6 +1056,10 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         if (wave == 0) ENG_STAMP(1, 7);
         MvDeq<false, S6> d6;
         if (ENG_DEQ_MASK & 8) mv_dequant<P6, NCW, FMT, S6>(a.qbias[6], 0.f, wave, lane_m, r6, d6);
+        if (ENG_COOP) {
+            __syncthreads();
+            if (has6) eng_poll_stage_part<C::XCH, C::FFN / 256, P6::nBlk, NWV, C::CANON>(a.xch + C::act, tag, L.xs[1], wave, lane_m, a.ws, dead);
+        }
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 8);
         if (!(ENG_DEQ_MASK & 8)) mv_dequant<P6, NCW, FMT, S6>(a.qbias[6], 0.f, wave, lane_m, r6, d6);
@@ -1166,7 +1233,7 @@ __global__ void __launch_bounds__(C::NWV * 64) engine_kernel(const EngArgs a) {
     constexpr bool XMAP = C::XMAP;
     using P1 = typename C::SH::P1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6) /* scalar: everything derived from it stays out of the vector registers */, wg = blockIdx.x;
     // ---- LDS carve
     // every buffer at a compile-time offset (the addresses fold into the LDS instructions' offset fields instead of living in registers through the whole launch);
     // the layer table, whose size is a run-time figure, lies behind them
