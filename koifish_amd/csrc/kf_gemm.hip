@@ -490,6 +490,8 @@ template <int FMT>
 static void gm_launch(const GemmArgs& a, int KS, dim3 grid, size_t smem, hipStream_t st) {
     if (KS == 0)
         hipLaunchKernelGGL((gemm_direct_kernel<FMT, 1, GD_UPG, GD_NW, false>), grid, dim3(GD_NW * 64), (size_t)GD_NW * 16 * 64 * 4, st, a);
+    else if (KS == -2) /* 64-token tiles: every weight block is unpacked for two token blocks */
+        hipLaunchKernelGGL((gemm_direct_kernel<FMT, 2, GD_UPG, GD_NW, false>), grid, dim3(GD_NW * 64), (size_t)GD_NW * 2 * 16 * 64 * 4, st, a);
     else if (KS == -1) /* paired SwiGLU */
         hipLaunchKernelGGL((gemm_direct_kernel<FMT, 1, GD_UPG, GD_NW, true>), grid, dim3(GD_NW * 64), (size_t)GD_NW * 2 * 16 * 64 * 4, st, a);
     else if (KS == 2)
@@ -578,7 +580,10 @@ int gemm_multi_launch(hipStream_t st, int n_w, const kf_weight* const* w, const 
             a.xw[i - 1] = g[i].w, a.xzero[i - 1] = g[i].zero, a.xstep[i - 1] = g[i].step, a.xqBias[i - 1] = g[i].qBias, a.xM[i - 1] = g[i].M, a.xy[i - 1] = y[i],
                      a.xldy[i - 1] = g[i].M;
     }
-    gm_dispatch(g[0].fmt, a, 0, dim3(end, (n + 31) / 32), 0, st);
+    if (n >= 64 && (long)end * ((n + 63) / 64) >= 256)
+        gm_dispatch(g[0].fmt, a, -2, dim3(end, (n + 63) / 64), 0, st);
+    else
+        gm_dispatch(g[0].fmt, a, 0, dim3(end, (n + 31) / 32), 0, st);
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 
