@@ -696,9 +696,9 @@ def engine_roofline(m, ctx, cfg, forced, timed_positions, reps=6):
     ach = nbytes / (ms * 1e-3) / 1e9
     traffic, traffic_src = None, None
     try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_engine.json")))
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r03c_pmc_engine.json")))
         traffic = int(pj["hbm_bytes_per_launch"])
-        traffic_src = "profiles/r03_pmc_engine.json: counter passes of scratch/ub_engine.py at position %d (%d algorithmic bytes there); not re-collected by this run" % (
+        traffic_src = "profiles/r03c_pmc_engine.json: counter passes of scratch/ub_engine.py at position %d (%d algorithmic bytes there); not re-collected by this run" % (
             int(pj.get("position", -1)), int(pj["algorithmic_bytes_per_launch"]))
     except Exception:
         pass
