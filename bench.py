@@ -167,7 +167,9 @@ def main():
             "config": {"workload": "%s %s greedy decode, 1xMI355X per replica, seq=%d: prompt 128, timed positions %d..%d"
                                    % ({"qwen3-0.6b": "Qwen3-0.6B", "qwen3-32b": "Qwen3-32B"}.get(args.config, args.config), {"q4": "4-bit PackedQ", "bf16": "bf16", "f8": "f8e5m2", "ternary": "2-bit ternary PackedQ", "1bit": "1-bit PackedQ", "nf4": "4-bit NF4 row-codebook"}[args.layers],
                                       S, timed_positions[0], timed_positions[-1]),
-                       "lm_head": args.head, "sparse_ffn_rows_hot": args.sparse if args.sparse > 0 else None, "replicas": world, "hipgraph": use_graph, "device_ms_per_step": round(dev_ms / K, 5)},
+                       "lm_head": args.head, "sparse_ffn_rows_hot": args.sparse if args.sparse > 0 else None, "replicas": world,
+                       "hipgraph": bool(use_graph and m.num_graphs() > 0),  # a step that is ONE launch (the engine with head and pick) is launched directly: a one-node graph only adds replay cost
+                       "device_ms_per_step": round(dev_ms / K, 5)},
             "step_roofline": {"bound": "hbm", "bytes_per_step": int(mean_bytes), "achieved": round(mean_bytes * (value / world) / 1e9, 1),
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(mean_bytes * (value / world) / 1e9 / HBM_PEAK_GBS, 4)},
         }

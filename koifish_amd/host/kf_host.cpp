@@ -564,6 +564,14 @@ kf_graph* Fish::GraphFor(int pos) {
     return graphs[b];
 }
 
+// A step that is ONE kernel launch (the engine with the embedding row, the LM head and the greedy pick inside) gains nothing from a captured graph: replaying a
+// one-node graph costs ~6 us more per step than the launch itself (measured, scratch/graph_vs_eager.py: 0.4222 vs 0.4158 ms at positions 1900-2040).
+bool Fish::OneLaunchStep() {
+    if (tp.world > 1 || !use_engine || fuse_level == 0) return false;
+    if (engine_state == 0) EnsureEngine();
+    return engine_state > 0 && engine_embed && engine_head && samp_params.greedy();
+}
+
 int Fish::RunSteps(int pos, int n, bool use_graph) {
     if (pos < 0 || pos + n > config.n_ctx) return KF_INVALID_ARGS;
     KF_TRY(TPCommit());
@@ -575,7 +583,7 @@ int Fish::RunSteps(int pos, int n, bool use_graph) {
             int rc = EnqueueStep(pos_bound());
             state_tokens = false;
             KF_TRY(rc);
-        } else if (use_graph) {
+        } else if (use_graph && !OneLaunchStep()) {
             kf_graph* g = GraphFor(p);
             if (!g) return KF_INTERNAL_ERR;
             KF_TRY(kf_graph_launch(ctx, g));

@@ -254,6 +254,7 @@ struct Fish {
     // token-serial prefill then greedy decode (Fish::Chat, GoPT.cpp:1139-1159); ids of the new tokens to out
     int Generate(const int* prompt, int n_prompt, int n_new, int* out, bool use_graph);
     // replay n decode steps starting at `pos` with whatever d_forced holds (bench / long runs); no host sync
+    bool OneLaunchStep(); /* the decode step is one kernel launch: launched directly, no graph */
     int RunSteps(int pos, int n, bool use_graph);
     // n prompt tokens at positions pos0.. through every layer as token batches (MFMA tile kernels), then the head on the last one:
     // afterwards the KV cache holds rows pos0..pos0+n-1, d_state = {greedy next token, pos0+n}, d_tokens_out[pos0+n-1] = that token.

@@ -58,10 +58,14 @@ def test_generate_ids_match_oracle_and_paths_agree(cfg_name):
     cfg, gm, om, prompt = _run_pair(cfg_name, L.Q4, L.BF16, 16, 0, w_std=0.1)   # 0.1: the free-running ids keep changing
     n_new = 32 if cfg_name == "tiny" else 16
     ref = om.generate(prompt.tolist(), n_new)
+    ids_engine = gm.generate(prompt, n_new, use_graph=True)   # the persistent engine: a step is ONE launch, launched directly (a one-node graph would only add replay cost)
+    gm.set_engine(False)                                       # the per-layer launches: one captured graph per position bucket
     ids_graph = gm.generate(prompt, n_new, use_graph=True)
     assert gm.num_graphs() >= 1
     ids_eager = gm.generate(prompt, n_new, use_graph=False)
+    gm.set_engine(True)
     assert ids_graph == ids_eager, "hipGraph replay and eager launches disagree"
+    assert ids_engine == ids_graph, "engine and per-layer launches disagree"
     assert ids_graph == ref, "greedy ids differ from the oracle"
     assert len(set(ref)) > n_new // 2, "degenerate fixture: the ids do not vary"
     # per-kernel (reference-shaped, ~12 launches/layer) path == fused path, bit for bit
@@ -88,7 +92,9 @@ def test_bucket_boundaries_and_long_context():
     om = oracle_model(cfg, raw, L.Q4, L.BF16)
     prompt = prompt_ids(cfg, 140, seed=3)
     ref = om.generate(prompt.tolist(), 12)
-    assert gm.generate(prompt, 12, use_graph=True) == ref
+    assert gm.generate(prompt, 12, use_graph=True) == ref      # engine (one launch per step)
+    gm.set_engine(False)
+    assert gm.generate(prompt, 12, use_graph=True) == ref      # per-layer launches replayed from the buckets' graphs
     assert gm.num_graphs() >= 3
     gm.close()
 
