@@ -179,6 +179,101 @@ __device__ __forceinline__ void canon_wave_to_lds(const CanonAcc<GQ>& A, double*
     }
 }
 
+// ------------------------------------------------------------------------------------------------ the same slice bookkeeping in fp32 (the engine's default mode)
+// Scores on packed bf16 pairs (v_dot2c_f32_bf16), weights p = v_exp_f32(s * log2 e - m) against an INTEGER reference exponent m (the ceiling of the wave's largest
+// s * log2 e), fp32 sums.  Integer exponents keep every rescale an exact power of two, so a wave's (O, L, m) meets the other waves' -- and the slices' in the fp64
+// merge, which takes them converted -- exactly as the canonical form's do; what differs from it is the approximate exponential and fp32 summation (the decode
+// kernel's default arithmetic, held to the tolerance tests).
+template <int GQ>
+struct FastAcc {
+    float o[GQ][8], l[GQ], m[GQ];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int hq = 0; hq < GQ; hq++) {
+            m[hq] = -__builtin_inff(), l[hq] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; i++) o[hq][i] = 0.f;
+        }
+    }
+};
+__device__ __forceinline__ int fast_shift(float d) { return (int)fmaxf(d, -200.0f); } /* d = m_a - m_b <= 0, integer-valued, -inf or NaN: clamped so that the scaled value underflows to 0 */
+template <int GQ, int LPK, int U>
+__device__ __forceinline__ void fast_batch(FastAcc<GQ>& A, const u32x4 (&q)[GQ], const u32x4 (&kk)[U], const u32x4 (&vv)[U], const bool (&valid)[U], int lpk_log2, float rden) {
+    float t[U][GQ], bn[GQ];
+#pragma unroll
+    for (int hq = 0; hq < GQ; hq++) bn[hq] = -__builtin_inff();
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int hq = 0; hq < GQ; hq++) {
+            float d = dot2_bf16(q[hq].x, kk[u].x, 0.f);
+            d = dot2_bf16(q[hq].y, kk[u].y, d);
+            d = dot2_bf16(q[hq].z, kk[u].z, d);
+            d = dot2_bf16(q[hq].w, kk[u].w, d);
+            d = group_sum16(d, lpk_log2);
+            t[u][hq] = valid[u] ? round_bf16(d * rden) * KF_LOG2E : -__builtin_inff();
+            bn[hq] = fmaxf(bn[hq], t[u][hq]);
+        }
+#pragma unroll
+    for (int hq = 0; hq < GQ; hq++) {
+        bn[hq] = xmax32(xmax16(bn[hq]));
+        if (LPK < 16) bn[hq] = fmaxf(bn[hq], dpp_f<0x128>(bn[hq]));
+        bn[hq] = ceilf(bn[hq]);
+        if (bn[hq] > A.m[hq]) { /* wave-uniform */
+            if (A.m[hq] > -__builtin_inff()) {
+                const int e = fast_shift(A.m[hq] - bn[hq]);
+                A.l[hq] = __builtin_ldexpf(A.l[hq], e);
+#pragma unroll
+                for (int i = 0; i < 8; i++) A.o[hq][i] = __builtin_ldexpf(A.o[hq][i], e);
+            }
+            A.m[hq] = bn[hq];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const uint32_t vw[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+        float vf[8];
+#pragma unroll
+        for (int i = 0; i < 4; i++) vf[2 * i] = bf_lo(vw[i]), vf[2 * i + 1] = bf_hi(vw[i]);
+#pragma unroll
+        for (int hq = 0; hq < GQ; hq++) {
+            const float p = valid[u] ? __builtin_amdgcn_exp2f(t[u][hq] - A.m[hq]) : 0.f;
+            A.l[hq] += p;
+#pragma unroll
+            for (int i = 0; i < 8; i++) A.o[hq][i] = fmaf(p, vf[i], A.o[hq][i]);
+        }
+    }
+}
+__device__ __forceinline__ float swap32_add_f(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swap16_add_f(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// sums over the wave's key groups, left in LDS: c[d] for d < hd, c[hd] = l, c[hd + 1] = m; c = this wave's [hq] row of hd + 2 floats (canon_wave_to_lds in fp32)
+template <int GQ, int LPK>
+__device__ __forceinline__ void fast_wave_to_lds(const FastAcc<GQ>& A, float* comb_wave /* [GQ][hd + 2] */, int hd, int lane, int d0) {
+    const int row = lane >> 4;
+#pragma unroll
+    for (int hq = 0; hq < GQ; hq++) {
+        float s1[4], r2[2];
+#pragma unroll
+        for (int i = 0; i < 4; i++) s1[i] = swap32_add_f(A.o[hq][i], A.o[hq][i + 4]);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            r2[i] = swap16_add_f(s1[i], s1[i + 2]);
+            if (LPK < 16) r2[i] += dpp_f<0x128>(r2[i]); /* two key groups per row: row_ror:8 */
+        }
+        float lt = xsum16(xsum32(A.l[hq]));
+        if (LPK < 16) lt += dpp_f<0x128>(lt);
+        float* c = comb_wave + (size_t)hq * (hd + 2);
+        if (LPK == 16 || (lane & 8) == 0) *reinterpret_cast<float2*>(c + d0 + 2 * row) = float2{r2[0], r2[1]};
+        if (lane == 0) c[hd] = lt, c[hd + 1] = A.m[hq];
+    }
+}
+
 __device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 

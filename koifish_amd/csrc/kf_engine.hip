@@ -36,6 +36,8 @@
 
 #include <vector>
 
+#include <type_traits>
+
 #include "kf_attn_common.h"
 #include "kf_gemv_blocks.h"
 
@@ -638,13 +640,19 @@ __device__ __forceinline__ void eng_attn_phase(const EngArgs& a, const EngLds& L
             g_u16w vrow = ly.vcache + (size_t)pos * a.kv_stride + (size_t)kvh * hd;
             for (int i = tid; i < hd; i += NWA * 64) krow[i] = L.knew[i], vrow[i] = L.vraw[i];
         }
-        CanonAcc<GQ> A;
+        // the slice's sums: canonical (fp64 sums of exact weights: bit-exact against the oracle) when the mat-vec phases are, else the decode kernel's default arithmetic
+        // (v_dot2c scores, v_exp_f32, fp32 sums); both keep integer reference exponents, so the combine below and the merge treat them alike
+        using Acc = std::conditional_t<C::CANON, CanonAcc<GQ>, FastAcc<GQ>>;
+        using Sum = std::conditional_t<C::CANON, double, float>;
+        Acc A;
         A.init();
         float qf[GQ][8];
+        u32x4 qp[GQ];
 #pragma unroll
         for (int hq = 0; hq < GQ; hq++) {
             const u32x4 qv = *reinterpret_cast<const u32x4*>(L.qb + hq * hd + d0);
             const uint32_t q4[4] = {qv.x, qv.y, qv.z, qv.w};
+            qp[hq] = qv;
 #pragma unroll
             for (int i = 0; i < 4; i++) qf[hq][2 * i] = bf_lo(q4[i]), qf[hq][2 * i + 1] = bf_hi(q4[i]);
         }
@@ -661,26 +669,42 @@ __device__ __forceinline__ void eng_attn_phase(const EngArgs& a, const EngLds& L
                 if (valid[u] && t == pos) ck[u] = *reinterpret_cast<const u32x4*>(L.knew + d0), cv[u] = *reinterpret_cast<const u32x4*>(L.vraw + d0);
             }
             if (b + 1 < nbatch) eng_attn_issue<C>(a, ly, S, wave, lane, T, b + 1);
-            canon_batch<GQ, LPK, U>(A, qf, ck, cv, valid, lpk_log2, rden);
+            if constexpr (C::CANON) canon_batch<GQ, LPK, U>(A, qf, ck, cv, valid, lpk_log2, rden);
+            else fast_batch<GQ, LPK, U>(A, qp, ck, cv, valid, lpk_log2, rden);
         }
         if (wave == 0) ENG_STAMP(1, 12);
-        canon_wave_to_lds<GQ, LPK>(A, L.comb + (size_t)wave * GQ * (hd + 2), hd, lane, d0);
+        Sum* const comb = reinterpret_cast<Sum*>(L.comb);
+        if constexpr (C::CANON) canon_wave_to_lds<GQ, LPK>(A, comb + (size_t)wave * GQ * (hd + 2), hd, lane, d0);
+        else fast_wave_to_lds<GQ, LPK>(A, comb + (size_t)wave * GQ * (hd + 2), hd, lane, d0);
         if (wave == 0) ENG_STAMP(1, 13);
-        __syncthreads(); /* the waves' fp64 sums in LDS */
+        __syncthreads(); /* the waves' sums in LDS */
         if (wave == 0) ENG_STAMP(1, 14);
         constexpr int PSD = hd + 2;
         for (int i = tid; i < GQ * hd; i += NWA * 64) { /* (two or four threads per element with DPP joins was measured: slower, 378 vs 370 us per step) */
             const int hq = i >> hd_log2, d = i & (hd - 1);
             float ms = -__builtin_inff();
 #pragma unroll
-            for (int sl = 0; sl < NWA; sl++) ms = fmaxf(ms, (float)L.comb[((size_t)sl * GQ + hq) * PSD + hd + 1]);
-            double o = 0.0, Ls = 0.0;
+            for (int sl = 0; sl < NWA; sl++) ms = fmaxf(ms, (float)comb[((size_t)sl * GQ + hq) * PSD + hd + 1]);
+            double o, Ls;
+            if constexpr (C::CANON) {
+                o = 0.0, Ls = 0.0;
 #pragma unroll
-            for (int sl = 0; sl < NWA; sl++) {
-                const double* c = L.comb + ((size_t)sl * GQ + hq) * PSD;
-                const int e = canon_shift((float)c[hd + 1] - ms);
-                o += ldexp_d(c[d], e);
-                Ls += ldexp_d(c[hd], e);
+                for (int sl = 0; sl < NWA; sl++) {
+                    const double* c = L.comb + ((size_t)sl * GQ + hq) * PSD;
+                    const int e = canon_shift((float)c[hd + 1] - ms);
+                    o += ldexp_d(c[d], e);
+                    Ls += ldexp_d(c[hd], e);
+                }
+            } else {
+                float of = 0.f, lf = 0.f;
+#pragma unroll
+                for (int sl = 0; sl < NWA; sl++) {
+                    const float* c = comb + ((size_t)sl * GQ + hq) * PSD;
+                    const int e = fast_shift(c[hd + 1] - ms);
+                    of += __builtin_ldexpf(c[d], e);
+                    lf += __builtin_ldexpf(c[hd], e);
+                }
+                o = (double)of, Ls = (double)lf; /* the merge takes the slice's sums as doubles either way */
             }
             if (nsp == 1) {
                 st_gran(a.xch + C::ao + (h0 + hq) * hd + d, tag, f2bf((float)(o / Ls)));

@@ -24,3 +24,21 @@ def oracle_model(cfg, raw, layer_type=L.Q4, head_type=L.BF16, attn_mode=O.ATTN_F
 
 def prompt_ids(cfg, n, seed=7):
     return np.random.default_rng(seed).integers(0, cfg["vocab"], size=n).astype(np.int32)
+
+
+def ids_agree_up_to_a_near_tie(om, prompt, got, ref, ulps=2):
+    """Free-running greedy ids in the DEFAULT order (fp32 sums, within the logit tolerance of the oracle): equal to the oracle's `ref`, or first different at a step
+    where the oracle's own two best logits lie within `ulps` bf16 ulps of each other -- there the fp32 summation order legitimately decides the id (the canonical order,
+    kf_set_canonical, is the mode in which ids are equal by construction).  `om`: a fresh oracle model of the same weights; returns (ok, message)."""
+    if list(got) == list(ref):
+        return True, "equal"
+    i = next(k for k, (a, b) in enumerate(zip(got, ref)) if a != b)
+    seq = list(prompt) + list(ref)
+    logits = None
+    for p in range(len(prompt) + i):          # teacher-forced along the oracle's ids up to the step that produced ref[i]
+        _, logits, _ = om.decode(int(seq[p]), p)
+    f = O.bf16_to_f32(logits)
+    top = np.sort(f)[-2:]
+    margin = float(top[1] - top[0])
+    tol = ulps * 2.0 ** -7 * max(abs(float(top[1])), 1e-9)   # a bf16 ulp is 2^-8 .. 2^-7 of the value
+    return margin <= tol, "first difference at generated id %d (%d vs %d): the oracle's top-2 margin there is %g, %d bf16 ulps are %g" % (i, got[i], ref[i], margin, ulps, tol)

@@ -98,6 +98,14 @@ def test_golden_decode(name):
     prompt = g["prompt"]
     ids = om.generate(prompt.tolist(), len(g["ids"]))
     assert ids == g["ids"].tolist()
+    # the canonical order (the one the kernels reproduce bit for bit) generates the same ids: the GPU test asserts them exactly in that order
+    O.set_order(O.ORDER_CANON)
+    try:
+        omc = oracle_model(cfg, raw, int(g["layer_type"]), int(g["head_type"]), attn_mode=O.ATTN_CANON)
+        assert omc.generate(prompt.tolist(), len(g["ids"])) == g["ids"].tolist()
+        omc.close()
+    finally:
+        O.set_order(O.ORDER_DOT16)
     om2 = oracle_model(cfg, raw, int(g["layer_type"]), int(g["head_type"]))
     _, logits, _ = om2.decode(int(prompt[0]), 0)
     assert np.array_equal(logits, g["logits0"])
