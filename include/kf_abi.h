@@ -420,6 +420,11 @@ int kf_engine_set_embedding(kf_ctx* ctx, kf_engine* e, const kf_weight* embed_bf
  * KF_UNSUPPORTED_DATATYPE for other head storages (the caller keeps kf_norm_lm_head). */
 int kf_engine_set_head(kf_ctx* ctx, kf_engine* e, const kf_weight* head_bf16_or_null, const kf_bf16* final_norm_w, kf_bf16* logits, int32_t* d_tokens_out_or_null);
 int kf_engine_step_head(kf_ctx* ctx, kf_engine* e, const kf_bf16* x_in, kf_bf16* x_out, int32_t* d_state, int pos_bound, int pick);
+/* n_steps consecutive greedy decode steps in ONE launch (Fish::ForwardOnRLS + Head4Token::cuInfer_1 + sample_argmax, n_steps times: GoPT.cpp:1155-1180): the step of
+ * kf_engine_step_head(x_in = NULL, pick = 1) repeated inside the kernel -- the id a step picks reaches the next step's embedding read as a tagged granule instead of
+ * through a launch boundary (~8 us per step).  Every position d_state[1] .. d_state[1] + n_steps - 1 must lie under pos_bound (the bound fixes the attention slicing of
+ * the launch); d_tokens_out, d_forced and d_state are read and written per step as by the single step; logits / x_out hold the last step's.  Same bits as n_steps launches. */
+int kf_engine_steps_head(kf_ctx* ctx, kf_engine* e, kf_bf16* x_out, int32_t* d_state, int pos_bound, int n_steps);
 int kf_engine_check(kf_ctx* ctx, kf_engine* e); /* synchronises; KF_INTERNAL_ERR when a hand-off poll has timed out since creation or the last kf_engine_reset */
 /* After KF_INTERNAL_ERR from kf_engine_check: the error word latches and every later launch of the engine returns at once without output.  kf_engine_reset
  * synchronises, puts the hand-off state back to its initial one and clears the word; the steps since the failure have to be redone. */

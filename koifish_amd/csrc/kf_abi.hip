@@ -1027,6 +1027,15 @@ int kf_engine_step_head(kf_ctx* c, kf_engine* e, const kf_bf16* x_in, kf_bf16* x
     if (rc < 0) return fail(rc, "kf_engine_step_head failed with %d (no head set?)", rc);
     return rc;
 }
+int kf_engine_steps_head(kf_ctx* c, kf_engine* e, kf_bf16* x_out, int32_t* d_state, int pos_bound, int n_steps) {
+    CHKCTX(c);
+    if (!e || !e->h) return fail(KF_INVALID_ARGS, "kf_engine_steps_head: null engine");
+    if (n_steps < 1) return fail(KF_INVALID_ARGS, "kf_engine_steps_head: n_steps %d", n_steps);
+    kf::engine_set_canonical(e->h, c->canonical);
+    const int rc = kf::engine_step(e->h, c->stream, nullptr, x_out, d_state, pos_bound, 2, n_steps);
+    if (rc < 0) return fail(rc, "kf_engine_steps_head failed with %d (no head / embedding set?)", rc);
+    return rc;
+}
 int kf_engine_set_head(kf_ctx* c, kf_engine* e, const kf_weight* head_or_null, const kf_bf16* final_norm_w, kf_bf16* logits, int32_t* d_tokens_out) {
     CHKCTX(c);
     if (!e || !e->h) return fail(KF_INVALID_ARGS, "kf_engine_set_head: null engine");

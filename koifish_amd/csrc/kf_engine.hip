@@ -78,14 +78,15 @@ constexpr int pow2_ceil(int v) {
     return p;
 }
 struct EngXOff {
-    int xA, qkv, ao, xB, act, part, hbest, end; /* part: 8-byte granules, KF_ATTN_MAX_SPLITS * (2 hd + 4) per head (EngCfg::PSH); hbest: 8-byte granules [ENG_NWG]: the head's per-workgroup maxima */
+    int xA, qkv, ao, xB, act, part, hbest, tokg, end; /* tokg: one 8-byte granule {token id, epoch}: the id workgroup 0 picked, for the next step of a multi-step launch; */ /* part: 8-byte granules, KF_ATTN_MAX_SPLITS * (2 hd + 4) per head (EngCfg::PSH); hbest: 8-byte granules [ENG_NWG]: the head's per-workgroup maxima */
 };
 constexpr EngXOff eng_xoff(int dim, int qd, int kvd, int ffn, int hd) {
     EngXOff o{};
     o.xA = 0, o.qkv = o.xA + eng_gran_dw(dim), o.ao = o.qkv + eng_gran_dw(qd + 2 * kvd), o.xB = o.ao + eng_gran_dw(qd), o.act = o.xB + eng_gran_dw(dim);
     o.part = o.act + eng_gran_dw(ffn);
     o.hbest = o.part + eng_gran_dw(2 * (qd / hd) * KF_ATTN_MAX_SPLITS * (2 * hd + 4));
-    o.end = o.hbest + eng_gran_dw(2 * ENG_NWG);
+    o.tokg = o.hbest + eng_gran_dw(2 * ENG_NWG);
+    o.end = o.tokg + eng_gran_dw(2);
     return o;
 }
 // ---- the XCD-local area (cached memory, plain stores: the lines stay in that XCD's L2): [tickets 1 KiB] [lqkv 8 x lq dwords] [lpart 8 x lp qwords]
@@ -96,6 +97,7 @@ constexpr size_t eng_loc_bytes(int gq, int hd) { return 1024 + (size_t)8 * eng_l
 struct EngArgs {
     const EngLayer* layers;
     int n_layer;
+    int n_steps; /* decode steps of this launch (>= 2 only with the head and the pick inside: the picked id reaches the other workgroups as a tagged granule) */
     float eps, qk_eps;
     const float* rope_table;
     const int32_t* d_state; /* {token, pos} */
@@ -539,7 +541,7 @@ struct EngCfg {
     using SH = EngShape<FMT_, DIM_, QD_, KVD_, FFN_, NWG_>;
     static constexpr int xA = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).xA, qkv = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).qkv, ao = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).ao,
                          xB = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).xB, act = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).act, part = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).part,
-                         hbest = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).hbest;
+                         hbest = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).hbest, tokg = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).tokg;
     // the LM head (bf16 [vocab, DIM]) as trailing phases of the same launch: the geometry gemv_launch picks for a many-row bf16 matrix of this width
     static constexpr int HnBlk = DIM_ / 8, Hlpr_log2 = c_lpr_log2(DIM_ / 8, 1L << 20), HLPR = 1 << Hlpr_log2, HRPS = 64 >> Hlpr_log2, Hiters = (HnBlk + HLPR - 1) / HLPR;
     static constexpr int lq_stride = eng_lq_stride(GQ_, HD_), lp_stride = eng_lp_stride(GQ_, HD_);
@@ -747,7 +749,7 @@ __device__ __forceinline__ void eng_attn_phase(const EngArgs& a, const EngLds& L
 
 // the poller wave: per layer it stages P1's x, the slice's q/k/v heads, merges, stages P4's, P5's and P6's inputs
 template <class C>
-__device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& L, const EngSlice& S, int epoch, int wg, int lane) {
+__device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& L, const EngSlice& S, int epoch, int step, int wg, int lane) {
     using SH = typename C::SH;
     using P1 = typename SH::P1;
     using P4 = typename SH::P4;
@@ -788,8 +790,24 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
                 const uint16_t* x0 = a.x_in;
                 if (!x0) { /* embed_kernel's row choice: the state's token, overridden by a teacher-forced id at this position */
                     int tok = a.d_state[0];
+                    if (step > 0) { /* a later step of a multi-step launch: the id workgroup 0 picked at the end of the previous step, {id, epoch of this step} */
+                        const __amdgpu_buffer_rsrc_t rt = eng_rsrc(a.xch + C::tokg, 8u);
+                        for (int spins = 0;; spins++) {
+                            const u32x2 g = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rt, 0, 0, 16 /* sc1 */));
+                            if (g.y == (uint32_t)epoch) {
+                                tok = (int)g.x;
+                                break;
+                            }
+                            if (dead || spins > ENG_SPIN_MAX) {
+                                if (!dead && lane == 0) atomicOr(a.ws + 1, 32);
+                                dead = true;
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
                     if (a.d_forced) {
-                        const int f = a.d_forced[a.d_state[1]];
+                        const int f = a.d_forced[S.pos];
                         if (f >= 0) tok = f;
                     }
                     if (tok < 0 || tok >= a.emb_rows) tok = 0;
@@ -1105,7 +1123,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
 // workgroup's contiguous slot range, keeps HG slots (2 * HG 16-byte loads per lane) in flight, and holds its two x blocks in registers (a lane multiplies the same
 // block columns of every row).  The arithmetic is gemv_kernel<FMT_BF16>'s: same lanes per row, same per-lane chain, same tree, bf16 store, arg-max over the stored values.
 template <class C>
-__device__ __forceinline__ void eng_head_main(const EngArgs& a, const EngLds& L, int epoch, int wg, int wave, int lane) {
+__device__ __forceinline__ void eng_head_main(const EngArgs& a, const EngLds& L, int epoch, bool more_steps, int wg, int wave, int lane) {
     constexpr int NWV = C::NWV, NWG = C::NWG, nBlk = C::HnBlk, LPR = C::HLPR, RPS = C::HRPS, ITERS = C::Hiters, HG = 4;
     constexpr int ND = C::DIM / 256;
     const int sub = lane >> C::Hlpr_log2, ll = lane & (LPR - 1);
@@ -1243,6 +1261,8 @@ __device__ __forceinline__ void eng_head_main(const EngArgs& a, const EngLds& L,
                 if (a.d_tokens_out) a.d_tokens_out[p] = bi;
                 a.d_state_w[0] = bi;
                 a.d_state_w[1] = p + 1;
+                if (more_steps) /* the next step of this launch starts from this id */
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{(uint32_t)bi, (uint32_t)(epoch + 1)}, eng_rsrc(a.xch + C::tokg, 8u), 0, 0, 16 /* sc1 */);
             } else if (err == 0) {
                 atomicOr(a.ws + 1, 16);
             }
@@ -1284,8 +1304,9 @@ __global__ void __launch_bounds__(C::NWV * 64) engine_kernel(const EngArgs a) {
     if (tid < 4) L.pub[tid] = 0;
     // ---- start: state, generation, tables
     EngSlice S;
-    S.pos = a.d_state[1];
-    const int epoch = a.ws[0];
+    const int pos0 = a.d_state[1];
+    S.pos = pos0;
+    const int epoch0 = a.ws[0];
     if (a.ws[1] != 0) return; /* an earlier launch timed out (it could not become resident): nothing runs until the host has cleared the word (engine_reset) */
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(a.layers);
@@ -1333,17 +1354,34 @@ __global__ void __launch_bounds__(C::NWV * 64) engine_kernel(const EngArgs a) {
     S.M1 = S.j1 == 0 ? P1::M0 : (S.j1 == 1 ? P1::M1 : P1::M2);
     if (s1_abs >= P1::total) S.M1 = 0; /* a workgroup without P1 rows (shapes with fewer slots than workgroups): every step masked */
     S.h0 = S.kvh * GQ, S.t0 = S.split * a.chunk;
-    S.t1 = S.t0 + a.chunk < S.len ? S.t0 + a.chunk : S.len;
-    S.empty = S.t0 >= S.len;
-    S.own_new = S.has_unit && S.pos >= S.t0 && S.pos < S.t1;
-    if (wave == NWV - 1)
-        eng_poller_main<C>(a, L, S, epoch, wg, lane);
-    else
-        eng_compute_main<C>(a, L, S, epoch, wg, wave, lane);
-    if (a.head_on) eng_head_main<C>(a, L, epoch, wg, wave, lane);
+    // the steps of this launch: positions pos0, pos0 + 1, ... with the slice geometry of the launch bound; a step's id reaches the next step's layer 0 as a tagged
+    // granule (eng_poller_main), everything else a step needs from its predecessor is in the KV cache
+    const int nst = a.n_steps > 1 ? a.n_steps : 1;
+    for (int step = 0; step < nst; step++) {
+        const int epoch = epoch0 + step;
+        S.pos = pos0 + step, S.len = S.pos + 1;
+        S.t1 = S.t0 + a.chunk < S.len ? S.t0 + a.chunk : S.len;
+        S.empty = S.t0 >= S.len;
+        S.own_new = S.has_unit && S.pos >= S.t0 && S.pos < S.t1;
+        if (step > 0) { /* the workgroup's own publish counters count layers of ONE step; a step behind a timed-out one does not start */
+            __syncthreads();
+            if (tid < 4) L.pub[tid] = 0;
+            if (tid == 0) L.cnt[3] = __hip_atomic_load(a.ws + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (L.cnt[3] != 0) break;
+        }
+        int sz; /* as inside the layer loop: nothing derived from the lane id is to be hoisted out of the step loop and held in registers across a whole step */
+        asm volatile("s_mov_b32 %0, 0" : "=s"(sz));
+        const int lane_s = lane + sz;
+        if (wave == NWV - 1)
+            eng_poller_main<C>(a, L, S, epoch, step, wg, lane_s);
+        else
+            eng_compute_main<C>(a, L, S, epoch, wg, wave, lane_s);
+        if (a.head_on) eng_head_main<C>(a, L, epoch, step + 1 < nst, wg, wave, lane_s);
+    }
     // the next launch's generation (workgroup 0 owns rows of the last phase, so every workgroup has read the epoch long before)
     if (wg == 0 && tid == 0) {
-        a.ws[0] = epoch + 1;
+        a.ws[0] = epoch0 + nst;
         if (XMAP)
             for (int i = 0; i < 8; i++) reinterpret_cast<int*>(a.loc)[i * 32] = 0; /* every workgroup took its ticket before any could finish a layer */
     }
@@ -1628,10 +1666,12 @@ static int engine_go_fmt(EngineHost* E, hipStream_t st) {
 }
 
 // 1: this position bound is outside what the engine serves (the caller runs the multi-launch path), < 0 error
-int engine_step(EngineHost* E, hipStream_t st, const uint16_t* x_in, uint16_t* x_out, const int32_t* d_state, int pos_bound, int with_head) {
+int engine_step(EngineHost* E, hipStream_t st, const uint16_t* x_in, uint16_t* x_out, const int32_t* d_state, int pos_bound, int with_head, int n_steps) {
     EngArgs& a = E->args;
     if ((!x_in && !a.emb) || !x_out || !d_state || pos_bound < 0) return KF_INVALID_ARGS;
     if (with_head && !a.head_w) return KF_INVALID_ARGS;
+    if (n_steps < 1 || (n_steps > 1 && (with_head != 2 || x_in))) return KF_INVALID_ARGS; /* several steps per launch: only with the pick inside and the embedding row read inside */
+    a.n_steps = n_steps;
     a.head_on = with_head ? 1 : 0;
     a.d_state_w = with_head == 2 ? const_cast<int32_t*>(d_state) : nullptr; /* 2: head + greedy pick + state update; 1: logits only */
     const int nsp = attn_splits(pos_bound, E->n_kv);

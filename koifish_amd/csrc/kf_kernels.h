@@ -141,7 +141,7 @@ struct Knobs {
 extern Knobs g_knobs;
 size_t engine_ws_bytes(const kf_engine_desc* d);
 int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t st, EngineHost** out);
-int engine_step(EngineHost* E, hipStream_t st, const uint16_t* x_in, uint16_t* x_out, const int32_t* d_state, int pos_bound, int with_head = 0); /* 1: not served */
+int engine_step(EngineHost* E, hipStream_t st, const uint16_t* x_in, uint16_t* x_out, const int32_t* d_state, int pos_bound, int with_head = 0, int n_steps = 1); /* 1: not served */
 int engine_set_head(EngineHost* E, const kf_weight* w, const uint16_t* norm_w, uint16_t* logits, int32_t* d_tokens_out);
 int engine_set_embedding(EngineHost* E, const kf_weight* w, const int32_t* d_forced);
 int engine_error_word(EngineHost* E, hipStream_t st, int* h_err);

@@ -575,6 +575,23 @@ bool Fish::OneLaunchStep() {
 int Fish::RunSteps(int pos, int n, bool use_graph) {
     if (pos < 0 || pos + n > config.n_ctx) return KF_INVALID_ARGS;
     KF_TRY(TPCommit());
+    if (use_graph && n > 1 && OneLaunchStep()) { /* runs of steps inside one position bucket: ONE launch each (kf_engine_steps_head), at most kStepsPerLaunch steps */
+        constexpr int kStepsPerLaunch = 16;
+        int i = 0;
+        while (i < n) {
+            const int p = pos + i, b = bucket_of(p);
+            int m = 1;
+            while (i + m < n && m < kStepsPerLaunch && bucket_of(pos + i + m) == b) m++;
+            tok_pos = p;
+            const int rc = kf_engine_steps_head(ctx, engine, ToX(x), d_state, pos_bound(), m);
+            if (rc < 0) return rc;
+            if (rc != KF_OK) break; /* not served at this position: the per-step path below takes the rest */
+            engine_steps += m;
+            i += m;
+        }
+        if (i == n) return KF_OK;
+        pos += i, n -= i;
+    }
     for (int i = 0; i < n; i++) {
         const int p = pos + i;
         if (fuse_level == 0) {  // per-kernel launches only (AutoAWQ weights): eager, position from the host, token from the device state

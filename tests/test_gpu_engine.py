@@ -98,6 +98,39 @@ def test_full_size_engine_equals_per_layer_launches_bit_for_bit():
     m.close()
 
 
+@pytest.mark.parametrize("canonical", [True, False])
+def test_several_steps_per_launch_equal_single_steps(canonical):
+    """kf_engine_steps_head: runs of steps inside ONE launch (the picked id handed to the next step's embedding read as a tagged granule) against one launch per step --
+    free-running and teacher-forced stretches, across position buckets: ids, the last step's logits and every K / V row, bit for bit, in both summation orders."""
+    cfg = _cfg("small", 320)
+    raw = synth.raw_weights_numpy(cfg, 777, w_std=0.1)
+    n = 150
+    forced = np.full(cfg["max_seq"], -1, dtype=np.int32)
+    forced[:20] = prompt_ids(cfg, 20, seed=3)            # a forced prefix, then free running, then a forced island
+    forced[100:110] = prompt_ids(cfg, 10, seed=4)
+    res = []
+    for multi in (False, True):
+        m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
+        m.set_canonical(canonical)
+        m.set_forced(forced)
+        m.set_state(int(forced[0]), 0)
+        if multi:
+            m.run_steps(0, 37, use_graph=True)           # 37 + 113: launches of up to 16 steps, cut at the bucket boundaries
+            m.run_steps(37, n - 37, use_graph=True)
+        else:
+            for p in range(n):
+                m.run_steps(p, 1, use_graph=True)
+        m.sync()
+        assert m.engine_steps() == n
+        m.engine_check()
+        k, v = m.kv_to_host()
+        res.append((m.tokens_out(n).tolist(), m.logits().copy(), k[:, :n].copy(), v[:, :n].copy()))
+        m.close()
+    assert res[0][0] == res[1][0], "ids differ"
+    assert len(set(res[0][0][20:100])) > 20, "degenerate fixture: the free-running ids do not vary"
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
+
+
 def test_engine_free_running_ids_match_oracle():
     cfg = _cfg("small", 320)
     raw = synth.raw_weights_numpy(cfg, 1234, w_std=0.1)
