@@ -1357,6 +1357,10 @@ __global__ void __launch_bounds__(C::NWV * 64) engine_kernel(const EngArgs a) {
     // the steps of this launch: positions pos0, pos0 + 1, ... with the slice geometry of the launch bound; a step's id reaches the next step's layer 0 as a tagged
     // granule (eng_poller_main), everything else a step needs from its predecessor is in the KV cache
     const int nst = a.n_steps > 1 ? a.n_steps : 1;
+    if (pos0 + nst > a.nsp * a.chunk) { /* a position of this launch lies beyond the keys its slices cover (the caller's pos_bound does not hold): refuse, loudly */
+        if (tid == 0) atomicOr(a.ws + 1, 64);
+        return;
+    }
     for (int step = 0; step < nst; step++) {
         const int epoch = epoch0 + step;
         S.pos = pos0 + step, S.len = S.pos + 1;
