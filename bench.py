@@ -212,7 +212,7 @@ def main():
         try:   # the time-dominant kernel of the step; the LM head (the byte-dominant launch) is reported beside it
             eng = engine_roofline(m, ctx, cfg, forced, timed_positions) if m.engine_steps() > 0 else None
             out["roofline"] = eng if eng else (matvec_roofline(m, ctx, cfg, head_rl) if args.layers == "q4" else head_rl)
-            out["config"]["decode_path"] = "persistent engine: kf::engine_kernel (embedding row + all layers + final norm + LM head + greedy pick) = ONE launch per token" if eng else \
+            out["config"]["decode_path"] = "persistent engine: kf::engine_kernel (embedding row + all layers + final norm + LM head + greedy pick) = ONE launch per token, runs of up to 16 tokens of a position bucket in one launch" if eng else \
                 "per-layer launches: 5 per layer"
         except Exception as e:
             out["roofline"] = head_rl
@@ -709,7 +709,8 @@ def engine_roofline(m, ctx, cfg, forced, timed_positions, reps=6):
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "bytes_per_launch": int(nbytes), "us_per_launch": round(ms * 1e3, 2), "launches": 1, "positions": pos_list,
             "note": "latency-bound: %d layers x 6 dependent hand-offs (4 cross the XCDs: ~1.3 us each with the first sweep timed behind the own publish, scratch/ub_handoff3.hip) + "
-                    "~5 us of phase arithmetic per layer; the head's %.0f MB stream at ~6 TB/s inside the same launch" % (cfg["n_layer"], m.weights[(-1, 1)].algorithmic_bytes() / 1e6)}
+                    "~5 us of phase arithmetic per layer; the head's %.0f MB stream at ~6 TB/s inside the same launch.  Timed here as single-step launches; the timed region of `value` "
+                    "launches runs of up to 16 steps (kf_engine_steps_head), which saves the launch boundary per step" % (cfg["n_layer"], m.weights[(-1, 1)].algorithmic_bytes() / 1e6)}
 
 
 def matvec_roofline(m, ctx, cfg, head_rl, reps=20):
