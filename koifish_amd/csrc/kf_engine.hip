@@ -509,9 +509,6 @@ struct EngSlice { /* this workgroup's attention slice and merge share */
 // The compute waves that own rows of a phase leave their granules in LDS; the wave that arrives last stores the workgroup's rows with ONE
 // instruction, 16 bytes per lane: a 64-byte sector of the hand-off vector is then written by a few whole pieces instead of by sixteen
 // separate 4-byte write-through stores (each a read-modify-write at the memory side).
-__device__ __forceinline__ void st_gran16(uint32_t* p, u32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, eng_rsrc(p, 16), 0, 0, 16 /* sc1 */);
-}
 // local = true: plain stores into a buffer of this XCD
 __device__ __forceinline__ void wg_publish(const EngLds& L, int phase, uint32_t* buf, int idx0, int nrows, int nwaves, int lane, bool local = false) {
     int old = 0;
@@ -523,8 +520,8 @@ __device__ __forceinline__ void wg_publish(const EngLds& L, int phase, uint32_t*
         const u32x4 v = *reinterpret_cast<const u32x4*>(L.outb + 4 * lane);
         if (local)
             *reinterpret_cast<u32x4*>(buf + idx0 + 4 * lane) = v;
-        else
-            st_gran16(buf + idx0 + 4 * lane, v);
+        else /* one descriptor for the workgroup's piece, the lane's 16 bytes as an offset (a per-lane base pointer would be served lane by lane) */
+            __builtin_amdgcn_raw_buffer_store_b128(v, eng_rsrc(buf + idx0, (uint32_t)nrows * 4u), lane * 16, 0, 16 /* sc1 */);
     }
     if (lane == 0) __hip_atomic_fetch_add(L.pub + phase, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); /* the poller may start to sweep for what the consumers of these rows produce */
 }
@@ -950,7 +947,7 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
             if (ME >= 4) { /* 16 bytes per lane: a 4-byte write-through store is a read-modify-write at the memory side */
                 uint32_t* mo = reinterpret_cast<uint32_t*>(L.msc + ME * MAXSP);
                 if (holder) mo[he] = gr;
-                if (4 * lane < ME) st_gran16(ao_dst + 4 * lane, *reinterpret_cast<const u32x4*>(mo + 4 * lane));
+                if (4 * lane < ME) __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(mo + 4 * lane), eng_rsrc(ao_dst, (uint32_t)ME * 4u), lane * 16, 0, 16 /* sc1 */);
             } else if (holder) {
                 __hip_atomic_store(ao_dst + he, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
