@@ -637,7 +637,10 @@ __device__ __forceinline__ void eng_attn_phase(const EngArgs& a, const EngLds& L
         if (S.own_new) { /* the cache rows of this position: the prepared key, the raw value (K.out / V.out alias them in the reference) */
             g_u16w krow = ly.kcache + (size_t)pos * a.kv_stride + (size_t)kvh * hd;
             g_u16w vrow = ly.vcache + (size_t)pos * a.kv_stride + (size_t)kvh * hd;
-            for (int i = tid; i < hd; i += NWA * 64) krow[i] = L.knew[i], vrow[i] = L.vraw[i];
+            if (tid < hd / 8) { /* 16 bytes per lane (the rows are 16-byte aligned: kv_stride and hd are multiples of 8) instead of a 2-byte store per thread */
+                *reinterpret_cast<u32x4 KF_GLOBAL*>(const_cast<uint16_t KF_GLOBAL*>(krow) + 8 * tid) = *reinterpret_cast<const u32x4*>(L.knew + 8 * tid);
+                *reinterpret_cast<u32x4 KF_GLOBAL*>(const_cast<uint16_t KF_GLOBAL*>(vrow) + 8 * tid) = *reinterpret_cast<const u32x4*>(L.vraw + 8 * tid);
+            }
         }
         // the slice's sums: canonical (fp64 sums of exact weights: bit-exact against the oracle) when the mat-vec phases are, else the decode kernel's default arithmetic
         // (v_dot2c scores, v_exp_f32, fp32 sums); both keep integer reference exponents, so the combine below and the merge treat them alike
