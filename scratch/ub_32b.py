@@ -3,7 +3,9 @@ import os, sys, ctypes as C
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from koifish_amd import lib as L, runtime as R
+import _knobs
 ctx = R.Context(0); dev = ctx.device
+_knobs.apply(ctx.hip)   # KF_GEMV_WAVES / KF_Q4_PERM ... (scratch/_knobs.py)
 dim, qd, kvd, ffn = 5120, 8192, 1024, 25600
 NS = 6
 def mk(m, k): return [ctx.quantize((torch.randn(m, k, device=dev) * 0.02).to(torch.bfloat16), L.Q4) for _ in range(NS)]
