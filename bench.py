@@ -696,6 +696,29 @@ def engine_roofline(m, ctx, cfg, forced, timed_positions, reps=6):
         return None
     ms, nbytes = tot_ms / n, tot_bytes / n
     ach = nbytes / (ms * 1e-3) / 1e9
+    # what the timed region launches: runs of up to 16 steps in ONE engine_kernel launch (kf_engine_steps_head).  In a rocprofv3 --kernel-trace of this command the kernel's
+    # MinNs is a single-step launch and its MaxNs a 16-step run; AverageNs mixes both.
+    run = None
+    try:
+        p0 = timed_positions[0]
+        R = min(16, len(timed_positions), cfg["max_seq"] - 1 - p0)
+        if R >= 2:
+            rms = 0.0
+            for r in range(4):
+                m.set_state(int(forced[p0]) if forced[p0] >= 0 else 1, p0)
+                e0, e1 = ctx.event(), ctx.event()
+                ctx.record(e0)
+                m.run_steps(p0, R, True)
+                ctx.record(e1)
+                m.sync()
+                if r > 0:
+                    rms += ctx.elapsed_ms(e0, e1) / 3
+            rbytes = float(sum(m.step_bytes(p0 + i) for i in range(R)))
+            rach = rbytes / (rms * 1e-3) / 1e9
+            run = {"steps_per_launch": R, "positions": [p0, p0 + R - 1], "us_per_launch": round(rms * 1e3, 1), "us_per_step": round(rms * 1e3 / R, 2), "bytes_per_launch": int(rbytes),
+                   "achieved": round(rach, 1), "frac": round(rach / HBM_PEAK_GBS, 4)}
+    except Exception as e:
+        run = {"error": repr(e)[:160]}
     traffic, traffic_src = None, None
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", "r03c_pmc_engine.json")))
@@ -707,7 +730,7 @@ def engine_roofline(m, ctx, cfg, forced, timed_positions, reps=6):
     return {"bound": "hbm", "kernel": "kf::engine_kernel = one decode step in one persistent launch: embedding row + %d layers + final norm + LM head + greedy pick (256 workgroups, "
                                       "hand-offs through tagged granules)" % cfg["n_layer"],
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-            "bytes_per_launch": int(nbytes), "us_per_launch": round(ms * 1e3, 2), "launches": 1, "positions": pos_list,
+            "bytes_per_launch": int(nbytes), "us_per_launch": round(ms * 1e3, 2), "launches": 1, "positions": pos_list, "run_of_steps": run,
             "note": "latency-bound: %d layers x 6 dependent hand-offs (4 cross the XCDs: ~1.3 us each with the first sweep timed behind the own publish, scratch/ub_handoff3.hip) + "
                     "~5 us of phase arithmetic per layer; the head's %.0f MB stream at ~6 TB/s inside the same launch.  Timed here as single-step launches; the timed region of `value` "
                     "launches runs of up to 16 steps (kf_engine_steps_head), which saves the launch boundary per step" % (cfg["n_layer"], m.weights[(-1, 1)].algorithmic_bytes() / 1e6)}
