@@ -136,8 +136,8 @@ int kf_quantize(kf_ctx* ctx, const kf_weight* w, const kf_bf16* src, int symmetr
  *     instruction's internal rounding has no bit-exact model); the fewest vector instructions per weight.
  *   1: the CANONICAL order kernels and the CPU oracle share (oracle/kf_oracle.c sections 4c and 6 "CANON"): every product one v_fma_f32 in a fixed per-lane chain
  *     + a balanced tree, the softmax on exact power-of-two scalings with fp64 sums -- logits, greedy ids and KV rows equal the oracle's BIT FOR BIT
- *     (tests/test_gpu_canonical.py, bench.py cpu_baseline parity pass).  Costs 4-5 % on the 0.6B decode step (latency-bound) and ~28 % on the large VALU-bound
- *     mat-vecs of a 32B model, which is why it is a switch and not the default.  (The persistent engine's attention is the canonical form in both modes.)
+ *     (tests/test_gpu_canonical.py, bench.py cpu_baseline parity pass).  Costs 6-7 % on the 0.6B decode step (latency-bound) and ~28 % on the large VALU-bound
+ *     mat-vecs of a 32B model, which is why it is a switch and not the default.  (The persistent engine follows the switch in every phase: mat-vecs, attention slice, head.)
  * The reference's own order is cuBLASLt's and unspecified (gemm.cu:126).  Not while capturing. */
 int kf_set_canonical(kf_ctx* ctx, int on);
 int kf_get_canonical(kf_ctx* ctx);

@@ -39,7 +39,7 @@ def test_engine_equals_per_layer_launches_bit_for_bit(cfg_name, max_seq, n_steps
     forced[:n_steps] = prompt_ids(cfg, n_steps, seed=11)
     ref_m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
     ref_m.set_engine(False)
-    ref_m.set_canonical(True)   # the engine's attention is the canonical form in both modes: bit-identity with the per-layer kernels holds in the canonical mode
+    ref_m.set_canonical(True)   # bit-identity with the per-layer kernels holds in the canonical order (in the default order the engine's fp32 attention sums are its own)
     ref = _teacher_forced(ref_m, forced, n_steps, use_graph=True)
     assert ref_m.engine_steps() == 0
     rk, rv = ref_m.kv_to_host()
@@ -65,7 +65,7 @@ def test_full_size_engine_equals_per_layer_launches_bit_for_bit():
     bucket): logits, greedy ids and the K / V rows each step writes, bit for bit.  A hand-off race that corrupted one granule in one layer would show here."""
     cfg = dict(synth.CONFIGS["qwen3-0.6b"])
     m = synth.build_on_gpu(cfg, seed=4242, layer_type=L.Q4, head_type=L.BF16)
-    m.set_canonical(True)   # the engine's attention phase is the canonical form in both modes
+    m.set_canonical(True)   # bit-identity with the per-layer kernels holds in the canonical order
     rng = np.random.default_rng(77)
     toks = rng.integers(0, cfg["vocab"], size=cfg["max_seq"]).astype(np.int32)
     forced = toks.copy()
