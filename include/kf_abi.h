@@ -132,12 +132,13 @@ int kf_quantize(kf_ctx* ctx, const kf_weight* w, const kf_bf16* src, int symmetr
  * much a weight needs (0 for every PackedQ / bf16 / f8 weight), kf_set_scratch hands the context a buffer (device memory, 16-byte aligned, the caller's
  * to free after the last call that used it; not while capturing, since captured launches hold the pointer).  Too small or missing: KF_INVALID_ARGS. */
 /* Summation order of the decode kernels (mat-vecs, LM head, decode attention, the persistent engine's mat-vec phases).
- *   0 (the default): products by v_dot2c_f32_bf16, the softmax in fp32 -- <= 1 bf16 ulp per output from the oracle (its order is not reproducible on a host: the
- *     instruction's internal rounding has no bit-exact model); the fewest vector instructions per weight.
- *   1: the CANONICAL order kernels and the CPU oracle share (oracle/kf_oracle.c sections 4c and 6 "CANON"): every product one v_fma_f32 in a fixed per-lane chain
- *     + a balanced tree, the softmax on exact power-of-two scalings with fp64 sums -- logits, greedy ids and KV rows equal the oracle's BIT FOR BIT
- *     (tests/test_gpu_canonical.py, bench.py cpu_baseline parity pass).  Costs 6-7 % on the 0.6B decode step (latency-bound) and ~28 % on the large VALU-bound
- *     mat-vecs of a 32B model, which is why it is a switch and not the default.  (The persistent engine follows the switch in every phase: mat-vecs, attention slice, head.)
+ *   1 (the default since round 4): the CANONICAL order kernels and the CPU oracle share (oracle/kf_oracle.c sections 4c and 6 "CANON"): every lane keeps two fused
+ *     multiply-add chains (even / odd elements: one v_pk_fma_f32 per weight pair) joined by a balanced tree, the softmax works on exact power-of-two scalings with
+ *     fp64 sums -- logits, greedy ids and KV rows equal the oracle's BIT FOR BIT (tests/test_gpu_canonical.py, bench.py cpu_baseline parity pass).  It is the order
+ *     bench.py times.  (The persistent engine follows the switch in every phase: mat-vecs, attention slice, head.)
+ *   0: products by v_dot2c_f32_bf16, the softmax in fp32 -- <= 1 bf16 ulp per output from the oracle (its order is not reproducible on a host: the instruction's
+ *     internal rounding has no bit-exact model); the fewest vector instructions per weight: a few per cent faster on the latency-bound 0.6B step, ~25 % on the
+ *     VALU-bound mat-vecs of a 32B model.  Greedy ids may differ from the oracle's at near-ties of the two best logits.
  * The reference's own order is cuBLASLt's and unspecified (gemm.cu:126).  Not while capturing. */
 int kf_set_canonical(kf_ctx* ctx, int on);
 int kf_get_canonical(kf_ctx* ctx);
@@ -399,7 +400,8 @@ typedef struct kf_engine_layer {
     kf_bf16 *kcache, *vcache;                            /* layer base; row t at t*kv_stride elements */
 } kf_engine_layer;
 typedef struct kf_engine_desc {
-    int32_t n_layer, dim, n_head, n_kv, head_dim, ffn, kv_stride, reserved_;
+    int32_t n_layer, dim, n_head, n_kv, head_dim, ffn, kv_stride;
+    int32_t max_seq; /* rows of every layer's K / V cache (> 0): a launch whose positions reach past it is refused (KF_INVALID_ARGS from the bound, error word bit 64 from the state) */
     float rms_eps, qk_eps;
     const float* rope_table;
     const kf_engine_layer* layers; /* HOST array [n_layer] of device pointers */

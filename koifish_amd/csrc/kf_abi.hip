@@ -20,7 +20,7 @@ struct kf_ctx {
     bool capturing;
     float* amax_val; /* per-workgroup partial maxima for kf_lm_head when the caller passes no scratch */
     int* amax_idx;
-    int canonical;    /* 1: the decode kernels sum in the canonical order of oracle/kf_oracle.c sections 4c / 6 (bit-exact against the oracle); 0 (default): v_dot2c / fp32 forms */
+    int canonical;    /* 1: the decode kernels sum in the canonical order of oracle/kf_oracle.c sections 4c / 6 (bit-exact against the oracle; the default); 0: v_dot2c / fp32 forms */
     void* scratch;    /* caller-owned workspace of kf_linear (kf_set_scratch): AWQ slice partials, or a weight dequantised to bf16 */
     size_t scratch_bytes;
 };
@@ -77,7 +77,7 @@ int kf_init(int device, void* stream, kf_ctx** out) {
     HIPCHK(hipMalloc(&c->amax_val, sizeof(float) * kf::KF_MAX_ARGMAX_PARTIALS));
     HIPCHK(hipMalloc(&c->amax_idx, sizeof(int) * kf::KF_MAX_ARGMAX_PARTIALS));
     c->scratch = nullptr, c->scratch_bytes = 0;
-    c->canonical = 0;
+    c->canonical = 1;
     *out = c;
     return KF_OK;
 }

@@ -242,17 +242,34 @@ __device__ __forceinline__ float perm_dot_dword(uint32_t D, u32x4 X, const PermL
 // order -- so that the fp32 sum is formed in exactly the order of dot_q4_dword (kf_gemv.hip): two extra v_perm_b32 per dword gather the index bytes
 // (low nibble of a byte of D >> 4 = an even element, of D = an odd element; the lookup ignores the high nibbles).
 // (the pair product of kf_gemv_blocks.h, stated here for the lookup below)
+// ---- the accumulator of one lane's mat-vec chain.  Default order: one float fed by v_dot2c_f32_bf16.  Canonical order (oracle/kf_oracle.c section 4c, round 4):
+// TWO fused multiply-add chains per lane -- the even-indexed elements of the lane's blocks into .x, the odd-indexed into .y, both through one v_pk_fma_f32 per
+// weight pair (each half is an IEEE fma: fmaf on the host) -- joined as x + y in front of the lane tree.
 template <bool CANON>
-__device__ __forceinline__ float dotp_dev(uint32_t w, uint32_t x, float acc) {
+struct AccOf {
+    typedef float T;
+};
+template <>
+struct AccOf<true> {
+    typedef f32x2_t T;
+};
+template <bool CANON>
+using acc_t = typename AccOf<CANON>::T;
+__device__ __forceinline__ float acc_join(float a) { return a; }
+__device__ __forceinline__ float acc_join(f32x2_t a) { return a.x + a.y; }
+__device__ __forceinline__ float acc_pick(bool c, float a, float b) { return c ? a : b; }
+__device__ __forceinline__ f32x2_t acc_pick(bool c, f32x2_t a, f32x2_t b) { return f32x2_t{c ? a.x : b.x, c ? a.y : b.y}; }
+__device__ __forceinline__ f32x2_t pk_fma(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
+template <bool CANON>
+__device__ __forceinline__ acc_t<CANON> dotp_dev(uint32_t w, uint32_t x, acc_t<CANON> acc) {
     if constexpr (CANON) {
-        acc = fmaf(bf_lo(w), bf_lo(x), acc);
-        return fmaf(bf_hi(w), bf_hi(x), acc);
+        return pk_fma(f32x2_t{bf_lo(w), bf_hi(w)}, f32x2_t{bf_lo(x), bf_hi(x)}, acc);
     } else {
         return dot2_bf16(w, x, acc);
     }
 }
 template <bool CANON = false>
-__device__ __forceinline__ float perm_dot_dword_nat(uint32_t D, u32x4 X, const PermLut& t, float acc) {
+__device__ __forceinline__ acc_t<CANON> perm_dot_dword_nat(uint32_t D, u32x4 X, const PermLut& t, acc_t<CANON> acc) {
     const uint32_t even = D >> 4; /* bytes 3..0: elements 0,2,4,6 in the low nibbles; D itself: 1,3,5,7 */
     uint32_t lo, hi;
     perm_lookup4(__builtin_amdgcn_perm(even, D, 0x02060307u), t, lo, hi); /* bytes 0..3 = elements 0, 1, 2, 3 */

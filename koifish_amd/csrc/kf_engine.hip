@@ -111,6 +111,7 @@ struct EngArgs {
     char* loc;              /* XCD-local area */
     int nsp, chunk, merge_e; /* attention slices of this launch's position bound; merge elements per workgroup */
     int kv_stride;
+    int max_seq;            /* rows of a layer's K / V cache: no position of a launch may reach past it */
     float qbias[7];         /* qBias of q k v o gate up down */
     int delay[6];           /* s_sleep units between "this workgroup's own rows of the feeding phase are published" and the first sweep of: x (P1), q|k|v (P2), slice
                                partials (P3), ao (P4), xB (P5), act (P6) */
@@ -396,31 +397,31 @@ __device__ __forceinline__ void mv_prefetch(const EngMat m, const EngMat m2, int
 // epi(row, v, v2) runs in the lane that owns a finished row (row counted inside the matrix)
 template <class PL, int NCW, int FMT, int MAXS, bool CANON, typename Epi>
 __device__ __forceinline__ void mv_run(float qb, float qb2, int s0, int cw, int lane, int Mj, const MvRegs<PL::PAIRED, MAXS>& R, const u32x4* xs, Epi&& epi) {
-    /* CANON: the canonical order (oracle/kf_oracle.c section 4c), one v_fma_f32 per product on fp32 operands; same lanes / chain / tree as gemv_kernel either way */
-    float acc = 0.f, acc2 = 0.f;
+    /* CANON: the canonical order (oracle/kf_oracle.c section 4c), one v_pk_fma_f32 per weight pair on fp32 operands; same lanes / chains / tree as gemv_kernel either way */
+    acc_t<CANON> acc{}, acc2{};
 #pragma unroll
     for (int k = 0; k < MAXS; k++) {
         const int sl = k / PL::iters, it = k - sl * PL::iters;
         if (cw + sl * NCW >= PL::spg) continue; /* wave-uniform: this wave has no such slot */
         const MvAt q = mv_at<PL, NCW>(k, s0, cw, lane, Mj);
         const int col = q.col < PL::nBlk ? q.col : PL::nBlk - 1;
-        if (it == 0) acc = 0.f, acc2 = 0.f;
+        if (it == 0) acc = acc_t<CANON>{}, acc2 = acc_t<CANON>{};
         const float st = bf2f(R.st[k]);
-        float r;
+        acc_t<CANON> r;
         if constexpr (CANON) r = BlockDotF<FMT>::run(R.w[k], reinterpret_cast<const f32x4*>(xs), col, PL::nBlk, st, bf2f(R.ze[k]), -(qb * st), acc);
         else r = BlockDot<FMT, false>::run(R.w[k], xs, col, PL::nBlk, st, bf2f(R.ze[k]), -(qb * st), acc);
-        acc = q.ok ? r : acc;
+        acc = acc_pick(q.ok, r, acc);
         if (PL::PAIRED) {
             const float st2 = bf2f(R.st2[k]);
-            float r2;
+            acc_t<CANON> r2;
             if constexpr (CANON) r2 = BlockDotF<FMT>::run(R.w2[k], reinterpret_cast<const f32x4*>(xs), col, PL::nBlk, st2, bf2f(R.ze2[k]), -(qb2 * st2), acc2);
             else r2 = BlockDot<FMT, false>::run(R.w2[k], xs, col, PL::nBlk, st2, bf2f(R.ze2[k]), -(qb2 * st2), acc2);
-            acc2 = q.ok ? r2 : acc2;
+            acc2 = acc_pick(q.ok, r2, acc2);
         }
         if (it == PL::iters - 1) {
-            const float v = group_sum(acc, PL::lpr_log2);
+            const float v = group_sum(acc_join(acc), PL::lpr_log2);
             float v2 = 0.f;
-            if (PL::PAIRED) v2 = group_sum(acc2, PL::lpr_log2);
+            if (PL::PAIRED) v2 = group_sum(acc_join(acc2), PL::lpr_log2);
             if ((lane & (PL::LPR - 1)) == 0 && q.ok) epi(q.row, v, v2);
         }
     }
@@ -429,55 +430,108 @@ __device__ __forceinline__ void mv_run(float qb, float qb2, int s0, int cw, int 
 #ifndef ENG_P1_SHARE
 #define ENG_P1_SHARE 1 /* the poller wave computes one of the workgroup's P1 row slots (0: seven waves, wave 0 takes two slots -- its second block of pair words costs 16 more registers and spills) */
 #endif
+#ifndef ENG_KV_LATE
+#define ENG_KV_LATE 1 /* the poller requests the next layer's K / V tiles BEHIND the merge's sweep: loads return in order, so requested in front of it (round 3) the sweep's answer
+                         waited for sixteen HBM lines first */
+#endif
+#ifndef ENG_PREP_POLLER
+#define ENG_PREP_POLLER 1 /* q/k-norm + RoPE by the poller, in the registers its sweep of q | k | v filled (lane = two rotation pairs of one head), prepared heads straight into LDS: the raw
+                             heads' LDS round trip, a barrier and the three preparing waves' wave-wide fp64 sums leave the chain (round 3: raw heads staged, barrier, waves 0 .. GQ prepare, barrier) */
+#endif
 #ifndef ENG_COOP
 #define ENG_COOP 1 /* the norm-free vectors (ao, act) are swept by all eight waves */
 #endif
 #ifndef ENG_DEQ_MASK
 #define ENG_DEQ_MASK 15 /* phases (1 P1, 2 P4, 4 P5, 8 P6) whose blocks are dequantised in front of the barrier */
 #endif
-// the wave's blocks as bf16 pair words (BlockPrep): formed while the wave waits for the phase's activations
-template <bool PAIRED, int MAXS>
+#ifndef ENG_WIDEN
+#define ENG_WIDEN 0 /* canonical order: phases (1 P1, 2 P4, 4 P5, 8 P6) whose dequantised weights are widened to fp32 pairs in front of the barrier too (behind it: one v_pk_fma_f32 per
+                       pair, as many instructions as v_dot2c); 32 registers per block: all four phases spill (P6 alone holds 3 blocks per lane) */
+#endif
+// the wave's blocks as bf16 pair words (BlockPrep): formed while the wave waits for the phase's activations.  WIDE (canonical order): every pair word as the two
+// fp32 operands of its v_pk_fma_f32
+template <bool PAIRED, int MAXS, bool WIDE = false>
 struct MvDeq {
-    uint32_t p[MAXS][16], p2[PAIRED ? MAXS : 1][16];
+    uint32_t p[WIDE ? 1 : MAXS][16], p2[PAIRED && !WIDE ? MAXS : 1][16];
+    f32x2_t f[WIDE ? MAXS : 1][16], f2[PAIRED && WIDE ? MAXS : 1][16];
 };
-template <class PL, int NCW, int FMT, int MAXS>
-__device__ __forceinline__ void mv_dequant(float qb, float qb2, int cw, int lane, const MvRegs<PL::PAIRED, MAXS>& R, MvDeq<PL::PAIRED, MAXS>& D) {
+template <class PL, int NCW, int FMT, int MAXS, bool WIDE>
+__device__ __forceinline__ void mv_dequant(float qb, float qb2, int cw, int lane, const MvRegs<PL::PAIRED, MAXS>& R, MvDeq<PL::PAIRED, MAXS, WIDE>& D) {
 #pragma unroll
     for (int k = 0; k < MAXS; k++) {
         if (cw + (k / PL::iters) * NCW >= PL::spg) continue; /* wave-uniform: this wave has no such slot */
         const float st = bf2f(R.st[k]);
-        BlockPrep<FMT>::prep(R.w[k], st, bf2f(R.ze[k]), -(qb * st), lane, D.p[k]);
+        if constexpr (WIDE) {
+            uint32_t t[16];
+            BlockPrep<FMT>::prep(R.w[k], st, bf2f(R.ze[k]), -(qb * st), lane, t);
 #pragma unroll
-        for (int i = 0; i < 16; i++) asm volatile("" : "+v"(D.p[k][i])); /* formed HERE, in front of the barrier, not sunk to the first use behind it */
-        if (PL::PAIRED) {
-            const float st2 = bf2f(R.st2[k]);
-            BlockPrep<FMT>::prep(R.w2[k], st2, bf2f(R.ze2[k]), -(qb2 * st2), lane, D.p2[k]);
+            for (int i = 0; i < 16; i++) {
+                float lo = bf_lo(t[i]), hi = bf_hi(t[i]);
+                asm volatile("" : "+v"(lo), "+v"(hi)); /* formed HERE, in front of the barrier, not sunk to the first use behind it */
+                D.f[k][i] = f32x2_t{lo, hi};
+            }
+            if (PL::PAIRED) {
+                const float st2 = bf2f(R.st2[k]);
+                BlockPrep<FMT>::prep(R.w2[k], st2, bf2f(R.ze2[k]), -(qb2 * st2), lane, t);
 #pragma unroll
-            for (int i = 0; i < 16; i++) asm volatile("" : "+v"(D.p2[k][i]));
+                for (int i = 0; i < 16; i++) {
+                    float lo = bf_lo(t[i]), hi = bf_hi(t[i]);
+                    asm volatile("" : "+v"(lo), "+v"(hi));
+                    D.f2[k][i] = f32x2_t{lo, hi};
+                }
+            }
+        } else {
+            BlockPrep<FMT>::prep(R.w[k], st, bf2f(R.ze[k]), -(qb * st), lane, D.p[k]);
+#pragma unroll
+            for (int i = 0; i < 16; i++) asm volatile("" : "+v"(D.p[k][i])); /* formed HERE, in front of the barrier, not sunk to the first use behind it */
+            if (PL::PAIRED) {
+                const float st2 = bf2f(R.st2[k]);
+                BlockPrep<FMT>::prep(R.w2[k], st2, bf2f(R.ze2[k]), -(qb2 * st2), lane, D.p2[k]);
+#pragma unroll
+                for (int i = 0; i < 16; i++) asm volatile("" : "+v"(D.p2[k][i]));
+            }
         }
     }
 }
+// the canonical pair products on widened weights: the chains of pairs_dot<true>
+__device__ __forceinline__ f32x2_t wide_dot(const f32x2_t (&f)[16], const u32x4* xs, int col, int nBlk, f32x2_t acc) {
+    const f32x4* xf = reinterpret_cast<const f32x4*>(xs);
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const f32x4 X0 = xf[(2 * d) * nBlk + col], X1 = xf[(2 * d + 1) * nBlk + col];
+        acc = pk_fma(f[4 * d], f32x2_t{X0.x, X0.y}, acc);
+        acc = pk_fma(f[4 * d + 1], f32x2_t{X0.z, X0.w}, acc);
+        acc = pk_fma(f[4 * d + 2], f32x2_t{X1.x, X1.y}, acc);
+        acc = pk_fma(f[4 * d + 3], f32x2_t{X1.z, X1.w}, acc);
+    }
+    return acc;
+}
 // mv_run on dequantised blocks: the same lanes, chains and tree
-template <class PL, int NCW, int MAXS, bool CANON, typename Epi>
-__device__ __forceinline__ void mv_run_deq(int s0, int cw, int lane, int Mj, const MvDeq<PL::PAIRED, MAXS>& D, const u32x4* xs, Epi&& epi) {
-    float acc = 0.f, acc2 = 0.f;
+template <class PL, int NCW, int MAXS, bool CANON, bool WIDE, typename Epi>
+__device__ __forceinline__ void mv_run_deq(int s0, int cw, int lane, int Mj, const MvDeq<PL::PAIRED, MAXS, WIDE>& D, const u32x4* xs, Epi&& epi) {
+    static_assert(!WIDE || CANON, "widened weights are the canonical order's");
+    acc_t<CANON> acc{}, acc2{};
 #pragma unroll
     for (int k = 0; k < MAXS; k++) {
         const int sl = k / PL::iters, it = k - sl * PL::iters;
         if (cw + sl * NCW >= PL::spg) continue;
         const MvAt q = mv_at<PL, NCW>(k, s0, cw, lane, Mj);
         const int col = q.col < PL::nBlk ? q.col : PL::nBlk - 1;
-        if (it == 0) acc = 0.f, acc2 = 0.f;
-        const float r = pairs_dot<CANON>(D.p[k], xs, col, PL::nBlk, acc);
-        acc = q.ok ? r : acc;
+        if (it == 0) acc = acc_t<CANON>{}, acc2 = acc_t<CANON>{};
+        acc_t<CANON> r;
+        if constexpr (WIDE) r = wide_dot(D.f[k], xs, col, PL::nBlk, acc);
+        else r = pairs_dot<CANON>(D.p[k], xs, col, PL::nBlk, acc);
+        acc = acc_pick(q.ok, r, acc);
         if (PL::PAIRED) {
-            const float r2 = pairs_dot<CANON>(D.p2[k], xs, col, PL::nBlk, acc2);
-            acc2 = q.ok ? r2 : acc2;
+            acc_t<CANON> r2;
+            if constexpr (WIDE) r2 = wide_dot(D.f2[k], xs, col, PL::nBlk, acc2);
+            else r2 = pairs_dot<CANON>(D.p2[k], xs, col, PL::nBlk, acc2);
+            acc2 = acc_pick(q.ok, r2, acc2);
         }
         if (it == PL::iters - 1) {
-            const float v = group_sum(acc, PL::lpr_log2);
+            const float v = group_sum(acc_join(acc), PL::lpr_log2);
             float v2 = 0.f;
-            if (PL::PAIRED) v2 = group_sum(acc2, PL::lpr_log2);
+            if (PL::PAIRED) v2 = group_sum(acc_join(acc2), PL::lpr_log2);
             if ((lane & (PL::LPR - 1)) == 0 && q.ok) epi(q.row, v, v2);
         }
     }
@@ -608,10 +662,11 @@ __device__ __forceinline__ void eng_attn_phase(const EngArgs& a, const EngLds& L
     const int grp = lane >> lpk_log2, d0 = (lane & (LPK - 1)) * 8;
     const int tstride = NWA * KPW, tstart = S.t0 + wave * KPW + grp;
     const int nbatch = (S.t1 - S.t0 + U * tstride - 1) / (U * tstride);
-    __syncthreads(); /* raw heads staged */
+    constexpr bool PREP = ENG_PREP_POLLER && GQ * hd <= 256; /* the poller left PREPARED heads in qb / knew / vraw */
+    if (!PREP) __syncthreads(); /* raw heads staged */
     if (wave == 0) ENG_STAMP(1, 2);
     if (!S.empty) {
-        { /* prologue: q heads of this group, and the new key when it lies in this slice (ROPE::cuInfer) */
+        if constexpr (!PREP) { /* prologue: q heads of this group, and the new key when it lies in this slice (ROPE::cuInfer) */
             const bool rope = a.rope_table != nullptr;
             const bool qnorm = ly.norm_q != nullptr;
             const int half = hd >> 1, j = lane < half ? lane : half - 1;
@@ -756,7 +811,7 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
     using P5 = typename SH::P5;
     using P6 = typename SH::P6;
     constexpr int FMT = C::FMT, GQ = C::GQ, HD = C::HD, NWV = C::NWV;
-    constexpr bool XMAP = C::XMAP, DBG = C::DBG;
+    constexpr bool XMAP = C::XMAP, DBG = C::DBG, W1 = C::CANON && (ENG_WIDEN & 1), W4 = C::CANON && (ENG_WIDEN & 2), W5 = C::CANON && (ENG_WIDEN & 4), W6 = C::CANON && (ENG_WIDEN & 8);
     constexpr int ND = C::DIM / 256, NQD = C::QD / 256, NF = C::FFN / 256;
     constexpr int XCH = C::XCH, hd = HD, hd_log2 = HD == 128 ? 7 : 6;
     bool dead = false;
@@ -775,14 +830,22 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
 #pragma unroll
     for (int u = 0; u < EngAttnState<C>::U; u++) T.kk[u] = T.vv[u] = u32x4{0, 0, 0, 0};
     eng_attn_rope<C>(a, S, lane, T);
+    f32x4 rcs = f32x4{1.f, 0.f, 1.f, 0.f}; /* the preparing poller's RoPE pairs 2 j2, 2 j2 + 1 at the step's position: (cos, sin, cos, sin) */
+    if (ENG_PREP_POLLER && GQ * hd <= 256 && a.rope_table) rcs = *reinterpret_cast<const f32x4*>(a.rope_table + (size_t)S.pos * HD + 4 * (lane & (hd / 4 - 1)));
     if (S.has_unit && !S.empty) eng_attn_issue<C>(a, L.lay[0], S, NWV - 1, lane, T, 0);
     int sw[4] = {0, 0, 0, 0};
     for (int l = 0; l < a.n_layer; l++) {
         const EngLayer& ly = L.lay[l];
         const uint32_t gen = (uint32_t)epoch * (uint32_t)a.n_layer + (uint32_t)l, tag = gen & 0xffffu;
         if (S.has_unit && !S.empty) eng_attn_normw<C>(ly, NWV - 1, lane, T);
-        MvDeq<false, S1> d1;
-        if (P1_SHARE) mv_dequant<P1, NCW1, FMT, S1>(qb1, 0.f, NWV - 1, lane, r1, d1); /* its blocks were requested behind the previous layer's attention phase */
+        uint32_t nq0 = 0, nq1 = 0, nk0 = 0, nk1 = 0; /* the preparing poller's norm weights: elements 2 j2, 2 j2 + 1 | half + 2 j2, half + 2 j2 + 1 of a head */
+        if (ENG_PREP_POLLER && GQ * hd <= 256 && S.has_unit && !S.empty) {
+            const int j2 = lane & (hd / 4 - 1);
+            if (ly.norm_q) nq0 = *reinterpret_cast<const uint32_t KF_GLOBAL*>(ly.norm_q + 2 * j2), nq1 = *reinterpret_cast<const uint32_t KF_GLOBAL*>(ly.norm_q + hd / 2 + 2 * j2);
+            if (ly.norm_k) nk0 = *reinterpret_cast<const uint32_t KF_GLOBAL*>(ly.norm_k + 2 * j2), nk1 = *reinterpret_cast<const uint32_t KF_GLOBAL*>(ly.norm_k + hd / 2 + 2 * j2);
+        }
+        MvDeq<false, S1, W1> d1;
+        if (P1_SHARE) mv_dequant<P1, NCW1, FMT, S1, W1>(qb1, 0.f, NWV - 1, lane, r1, d1); /* its blocks were requested behind the previous layer's attention phase */
         // P1 (P4 adds this x as the residual)
         ENG_STAMP(0, 0);
         if (has1 || has4) {
@@ -822,7 +885,7 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
         ENG_STAMP(0, 1);
         __syncthreads();
         if (P1_SHARE && has1) { /* this wave's P1 rows, then the workgroup's publish like every other owner */
-            mv_run_deq<P1, NCW1, S1, C::CANON>(S.s1, NWV - 1, lane, S.M1, d1, L.xs[0], [&](int row, float v, float) { L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); });
+            mv_run_deq<P1, NCW1, S1, C::CANON, W1>(S.s1, NWV - 1, lane, S.M1, d1, L.xs[0], [&](int row, float v, float) { L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); });
             if (XMAP)
                 wg_publish(L, 0, eng_lqkv<C>(a, S.xcc), S.q_out0, P1::R, NWP1, lane, true);
             else
@@ -833,12 +896,82 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
             // XCD-mapped form: the rows were published by workgroups of this XCD with plain stores into its own dense buffer [q GQ*hd | k hd | v hd]
             const __amdgpu_buffer_rsrc_t rs = XMAP ? eng_rsrc(eng_lqkv<C>(a, S.xcc), (uint32_t)(GQ * hd + 2 * hd) * 4u) : eng_rsrc(a.xch + C::qkv, (uint32_t)(C::QD + 2 * C::KVD) * 4u);
             const int q_src = XMAP ? 0 : S.h0 * hd;
+            const uint32_t tagw = tag << 16;
+          if constexpr (ENG_PREP_POLLER && GQ * hd <= 256) {
+            // ---- sweep AND prepare (ROPE::cuInfer: CU_rms_forward_v2 + CU_rope2_v0, the arithmetic of prep_head_cs): lane = head lane / LPH, rotation pairs 2 j2 and 2 j2 + 1 of that
+            // head, i.e. elements 2 j2, 2 j2 + 1, half + 2 j2, half + 2 j2 + 1 -- two 8-byte pieces; the new key the same way in lanes 0 .. LPH - 1, the new value as 4 elements in lanes
+            // 32 .. 32 + LPH - 1 (two 8-byte pieces too: every lane issues the same four loads).  Only the slice that holds the position needs k | v.
+            constexpr int LPH = hd / 4, half = hd / 2;
+            const int hq = lane / LPH, j2 = lane & (LPH - 1);
+            const bool q_in = hq < GQ, k_in = lane < LPH, v_in = lane >= 32 && lane < 32 + LPH, own = S.own_new && !S.empty;
+            const int qa = q_src + (q_in ? hq : 0) * hd + 2 * j2;
+            const int k_src = XMAP ? GQ * hd : C::QD + S.kvh * hd, v_src = XMAP ? GQ * hd + hd : C::QD + C::KVD + S.kvh * hd;
+            const int ka = k_in ? k_src + 2 * j2 : (v_in ? v_src + 4 * (lane - 32) : k_src), kb = k_in ? k_src + half + 2 * j2 : (v_in ? v_src + 4 * (lane - 32) + 2 : k_src);
+            u32x2 gq0, gq1, gk0 = u32x2{0, 0}, gk1 = u32x2{0, 0};
+            eng_wait_pub(has1 ? L.pub + 0 : nullptr, l + 1, a.delay[1], dead);
+            for (int spins = 0;; spins++) {
+                gq0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, qa * 4, 0, 16 /* sc1 */));
+                gq1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (qa + half) * 4, 0, 16));
+                if (own) { /* workgroup-uniform */
+                    gk0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, ka * 4, 0, 16));
+                    gk1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, kb * 4, 0, 16));
+                }
+                uint32_t bad = q_in ? (((gq0.x ^ tagw) | (gq0.y ^ tagw) | (gq1.x ^ tagw) | (gq1.y ^ tagw)) & 0xffff0000u) : 0u;
+                bad |= (own && (k_in || v_in)) ? (((gk0.x ^ tagw) | (gk0.y ^ tagw) | (gk1.x ^ tagw) | (gk1.y ^ tagw)) & 0xffff0000u) : 0u;
+                if (all_good(bad)) break;
+                if (dead || spins > ENG_SPIN_MAX) {
+                    if (!dead && lane == 0) atomicOr(a.ws + 1, 2);
+                    dead = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            ENG_STAMP(0, 12);
+            if (!S.empty) {
+                const bool rope = a.rope_table != nullptr;
+                auto lane_sum = [&](double v) { /* over the LPH lanes of a head */
+                    v += dpp_d<0xB1>(v), v += dpp_d<0x4E>(v), v += dpp_d<0x141>(v), v += dpp_d<0x140>(v);
+                    if (LPH == 32) v = xsum16_d(v);
+                    return v;
+                };
+                auto prepare = [&](u32x2 g0, u32x2 g1, bool norm, uint32_t w0, uint32_t w1, uint32_t& o0, uint32_t& o1) { /* g0 = elements e, e + 1; g1 = e + half, e + half + 1 */
+                    float xa0 = bf2f((uint16_t)g0.x), xa1 = bf2f((uint16_t)g0.y), xb0 = bf2f((uint16_t)g1.x), xb1 = bf2f((uint16_t)g1.y);
+                    if (norm) {
+                        double ss = (double)xa0 * (double)xa0;
+                        ss = fma((double)xa1, (double)xa1, ss), ss = fma((double)xb0, (double)xb0, ss), ss = fma((double)xb1, (double)xb1, ss);
+                        ss = lane_sum(ss);
+                        const float s = round_bf16(1.0f / sqrtf((float)ss / (float)hd + a.qk_eps));
+                        xa0 = round_bf16(xa0 * s * bf_lo(w0)), xa1 = round_bf16(xa1 * s * bf_hi(w0));
+                        xb0 = round_bf16(xb0 * s * bf_lo(w1)), xb1 = round_bf16(xb1 * s * bf_hi(w1));
+                    }
+                    if (rope) { /* pair (j, j + half): x_j c - x_{j+half} s, x_j s + x_{j+half} c, each product and each sum rounded once (operator.cuh:734-772) */
+                        const float a0 = xa0 * rcs.x, b0 = xb0 * rcs.y, c0 = xa0 * rcs.y, d0 = xb0 * rcs.x;
+                        const float a1 = xa1 * rcs.z, b1 = xb1 * rcs.w, c1 = xa1 * rcs.w, d1 = xb1 * rcs.z;
+                        xa0 = a0 - b0, xb0 = c0 + d0, xa1 = a1 - b1, xb1 = c1 + d1;
+                    }
+                    o0 = pack_bf16x2(xa0, xa1), o1 = pack_bf16x2(xb0, xb1);
+                };
+                uint32_t o0, o1;
+                prepare(gq0, gq1, ly.norm_q != nullptr, nq0, nq1, o0, o1);
+                if (q_in) {
+                    uint32_t* qd = reinterpret_cast<uint32_t*>(L.qb + hq * hd);
+                    qd[j2] = o0, qd[(half >> 1) + j2] = o1;
+                }
+                if (own) {
+                    prepare(gk0, gk1, ly.norm_k != nullptr, nk0, nk1, o0, o1);
+                    if (k_in) {
+                        uint32_t* kd = reinterpret_cast<uint32_t*>(L.knew);
+                        kd[j2] = o0, kd[(half >> 1) + j2] = o1;
+                    }
+                    if (v_in) *reinterpret_cast<u32x2*>(L.vraw + 4 * (lane - 32)) = u32x2{(gk0.x & 0xffffu) | (gk0.y << 16), (gk1.x & 0xffffu) | (gk1.y << 16)};
+                }
+            }
+          } else {
             constexpr int NLQ = (GQ * hd + 255) / 256;
             u32x4 g[NLQ], gk;
             const int e_kv = 4 * lane; /* < hd: k, < 2hd: v */
             const bool kv_in = e_kv < 2 * hd;
             const int kv_src = XMAP ? GQ * hd + e_kv : (e_kv < hd ? C::QD + S.kvh * hd + e_kv : C::QD + C::KVD + S.kvh * hd + (e_kv - hd));
-            const uint32_t tagw = tag << 16;
             eng_wait_pub(has1 ? L.pub + 0 : nullptr, l + 1, a.delay[1], dead);
             for (int spins = 0;; spins++) {
                 uint32_t bad = 0;
@@ -862,6 +995,7 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
                 if (e0 < GQ * hd) *reinterpret_cast<u32x2*>(L.qraw + e0) = u32x2{(g[r].x & 0xffffu) | (g[r].y << 16), (g[r].z & 0xffffu) | (g[r].w << 16)};
             }
             if (kv_in) *reinterpret_cast<u32x2*>(L.kraw + e_kv) = u32x2{(gk.x & 0xffffu) | (gk.y << 16), (gk.z & 0xffffu) | (gk.w << 16)}; /* vraw = kraw + hd */
+          }
             ENG_STAMP(0, 2);
             if (P1_SHARE) { /* the next layer's P1 blocks of this wave: unconditional (the last layer requests its own again), and HERE -- loads return in order, so a
                                request in front of a poll holds that poll's sweep back by an HBM latency; the attention phase waits for nothing younger than its tiles */
@@ -869,7 +1003,7 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
                 mv_prefetch<P1, NCW1, FMT, S1>(mat1(ln), mat1(ln), S.s1, NWV - 1, lane, S.M1, r1);
             }
             eng_attn_phase<C>(a, L, S, ly, gen, tag, NWV - 1, lane, T, l, wg);
-            if (!S.empty) eng_attn_issue<C>(a, L.lay[l + 1 < a.n_layer ? l + 1 : l], S, NWV - 1, lane, T, 0); /* the next layer's tiles (the last layer asks for its own again) */
+            if (!S.empty && !(ENG_KV_LATE && S.has_merge)) eng_attn_issue<C>(a, L.lay[l + 1 < a.n_layer ? l + 1 : l], S, NWV - 1, lane, T, 0); /* the next layer's tiles (the last layer asks for its own again) */
         } else if (P1_SHARE) { /* a workgroup without an attention slice at this position: the same request, nothing to poll in front of it */
             const int ln = l + 1 < a.n_layer ? l + 1 : l;
             mv_prefetch<P1, NCW1, FMT, S1>(mat1(ln), mat1(ln), S.s1, NWV - 1, lane, S.M1, r1);
@@ -908,6 +1042,7 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
             }
             ENG_STAMP(0, 11);
             if (DBG && wg == a.dbg_wg && lane == 0) a.dbg[((size_t)l * 2) * 16 + 10] = (unsigned long long)msw;
+            if (ENG_KV_LATE && S.has_unit && !S.empty) eng_attn_issue<C>(a, L.lay[l + 1 < a.n_layer ? l + 1 : l], S, NWV - 1, lane, T, 0); /* the next layer's tiles, behind the sweep */
             // transpose through LDS: element e's values over the slices contiguous for lane e (slices past nsp: 0)
 #pragma unroll
             for (int r = 0; r < NLM; r++) {
@@ -994,7 +1129,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
     using P5 = typename SH::P5;
     using P6 = typename SH::P6;
     constexpr int FMT = C::FMT, NWV = C::NWV;
-    constexpr bool XMAP = C::XMAP, DBG = C::DBG;
+    constexpr bool XMAP = C::XMAP, DBG = C::DBG, W1 = C::CANON && (ENG_WIDEN & 1), W4 = C::CANON && (ENG_WIDEN & 2), W5 = C::CANON && (ENG_WIDEN & 4), W6 = C::CANON && (ENG_WIDEN & 8);
     constexpr int NCW = NWV - 1;
     // P1 alone is shared with the poller wave (it is idle between staging x and the first q/k/v granules): NWV waves, so that the 0.6B shape's
     // 8 row-slots per workgroup are one step for every wave instead of two for wave 0
@@ -1034,13 +1169,13 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         const int lane_m = lane + lzm; /* as for the attention phase below: the mat-vec phases' per-lane indices are recomputed per layer rather than held in registers */
         if (S.has_unit && !S.empty) eng_attn_normw<C>(ly, wave, lane_m, T);
         // ================= P1: RMSNorm(x) -> Q, K, V rows  (every phase: the blocks are dequantised in front of the barrier the activations arrive behind)
-        MvDeq<false, S1> d1; /* declared per layer: nothing of it is carried around the loop */
-        if (ENG_DEQ_MASK & 1) mv_dequant<P1, NCW1, FMT, S1>(qb1, 0.f, wave, lane_m, r1, d1);
+        MvDeq<false, S1, W1> d1; /* declared per layer: nothing of it is carried around the loop */
+        if (ENG_DEQ_MASK & 1) mv_dequant<P1, NCW1, FMT, S1, W1>(qb1, 0.f, wave, lane_m, r1, d1);
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 0);
-        if (!(ENG_DEQ_MASK & 1)) mv_dequant<P1, NCW1, FMT, S1>(qb1, 0.f, wave, lane_m, r1, d1);
+        if (!(ENG_DEQ_MASK & 1)) mv_dequant<P1, NCW1, FMT, S1, W1>(qb1, 0.f, wave, lane_m, r1, d1);
         mv_prefetch<P4, NCW, FMT, S4>(ly.m[3], ly.m[3], wg * P4::spg, wave, lane_m, P4::M0, r4);
-        mv_run_deq<P1, NCW1, S1, C::CANON>(S.s1, wave, lane_m, S.M1, d1, L.xs[0], [&](int row, float v, float) { L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); });
+        mv_run_deq<P1, NCW1, S1, C::CANON, W1>(S.s1, wave, lane_m, S.M1, d1, L.xs[0], [&](int row, float v, float) { L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); });
         if (has1 && wave < NWP1) {
             if (XMAP)
                 wg_publish(L, 0, eng_lqkv<C>(a, S.xcc), S.q_out0, P1::R, NWP1, lane_m, true);
@@ -1066,47 +1201,47 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         }
 
         // ================= P4: o_proj + residual -> xB
-        MvDeq<false, S4> d4;
-        if (ENG_DEQ_MASK & 2) mv_dequant<P4, NCW, FMT, S4>(a.qbias[3], 0.f, wave, lane_m, r4, d4);
+        MvDeq<false, S4, W4> d4;
+        if (ENG_DEQ_MASK & 2) mv_dequant<P4, NCW, FMT, S4, W4>(a.qbias[3], 0.f, wave, lane_m, r4, d4);
         if (ENG_COOP) {
             __syncthreads(); /* the poller has timed the first sweep */
             if (has4) eng_poll_stage_part<C::XCH, C::QD / 256, P4::nBlk, NWV, C::CANON>(a.xch + C::ao, tag, L.xs[1], wave, lane_m, a.ws, dead);
         }
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 4);
-        if (!(ENG_DEQ_MASK & 2)) mv_dequant<P4, NCW, FMT, S4>(a.qbias[3], 0.f, wave, lane_m, r4, d4);
+        if (!(ENG_DEQ_MASK & 2)) mv_dequant<P4, NCW, FMT, S4, W4>(a.qbias[3], 0.f, wave, lane_m, r4, d4);
         mv_prefetch<P5, NCW, FMT, S5>(ly.m[4], ly.m[5], wg * P5::spg, wave, lane_m, P5::M0, r5);
-        mv_run_deq<P4, NCW, S4, C::CANON>(wg * P4::spg, wave, lane_m, P4::M0, d4, L.xs[1], [&](int row, float v, float) {
+        mv_run_deq<P4, NCW, S4, C::CANON, W4>(wg * P4::spg, wave, lane_m, P4::M0, d4, L.xs[1], [&](int row, float v, float) {
             const uint16_t o = f2bf(v);
             L.outb[row - wg * P4::R] = (tag << 16) | (uint32_t)f2bf(bf2f(L.xrawA[row]) + bf2f(o)); /* CU_add3: bf16(x + bf16(W.x)) */
         });
         if (has4 && wave < NWP4) wg_publish(L, 1, a.xch + C::xB, wg * P4::R, P4::R, NWP4, lane_m);
         // ================= P5: RMSNorm + gate/up + SwiGLU -> act
         if (wave == 0) ENG_STAMP(1, 5);
-        MvDeq<true, S5> d5;
-        if (ENG_DEQ_MASK & 4) mv_dequant<P5, NCW, FMT, S5>(a.qbias[4], a.qbias[5], wave, lane_m, r5, d5);
+        MvDeq<true, S5, W5> d5;
+        if (ENG_DEQ_MASK & 4) mv_dequant<P5, NCW, FMT, S5, W5>(a.qbias[4], a.qbias[5], wave, lane_m, r5, d5);
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 6);
-        if (!(ENG_DEQ_MASK & 4)) mv_dequant<P5, NCW, FMT, S5>(a.qbias[4], a.qbias[5], wave, lane_m, r5, d5);
+        if (!(ENG_DEQ_MASK & 4)) mv_dequant<P5, NCW, FMT, S5, W5>(a.qbias[4], a.qbias[5], wave, lane_m, r5, d5);
         mv_prefetch<P6, NCW, FMT, S6>(ly.m[6], ly.m[6], wg * P6::spg, wave, lane_m, P6::M0, r6);
-        mv_run_deq<P5, NCW, S5, C::CANON>(wg * P5::spg, wave, lane_m, P5::M0, d5, L.xs[0], [&](int row, float v, float v2) {
+        mv_run_deq<P5, NCW, S5, C::CANON, W5>(wg * P5::spg, wave, lane_m, P5::M0, d5, L.xs[0], [&](int row, float v, float v2) {
             const float gt = round_bf16(v), up = round_bf16(v2); /* CU_swiglu_v0 on the two bf16-rounded projections */
             L.outb[row - wg * P5::R] = (tag << 16) | (uint32_t)f2bf((gt * up) / (1.0f + kf_expf(-gt)));
         });
         if (has5 && wave < NWP5) wg_publish(L, 2, a.xch + C::act, wg * P5::R, P5::R, NWP5, lane_m);
         // ================= P6: down_proj + residual -> x of the next layer
         if (wave == 0) ENG_STAMP(1, 7);
-        MvDeq<false, S6> d6;
-        if (ENG_DEQ_MASK & 8) mv_dequant<P6, NCW, FMT, S6>(a.qbias[6], 0.f, wave, lane_m, r6, d6);
+        MvDeq<false, S6, W6> d6;
+        if (ENG_DEQ_MASK & 8) mv_dequant<P6, NCW, FMT, S6, W6>(a.qbias[6], 0.f, wave, lane_m, r6, d6);
         if (ENG_COOP) {
             __syncthreads();
             if (has6) eng_poll_stage_part<C::XCH, C::FFN / 256, P6::nBlk, NWV, C::CANON>(a.xch + C::act, tag, L.xs[1], wave, lane_m, a.ws, dead);
         }
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 8);
-        if (!(ENG_DEQ_MASK & 8)) mv_dequant<P6, NCW, FMT, S6>(a.qbias[6], 0.f, wave, lane_m, r6, d6);
+        if (!(ENG_DEQ_MASK & 8)) mv_dequant<P6, NCW, FMT, S6, W6>(a.qbias[6], 0.f, wave, lane_m, r6, d6);
         mv_prefetch<P1, NCW1, FMT, S1>(mat1(ln), mat1(ln), S.s1, wave, lane_m, S.M1, r1);
-        mv_run_deq<P6, NCW, S6, C::CANON>(wg * P6::spg, wave, lane_m, P6::M0, d6, L.xs[1], [&](int row, float v, float) {
+        mv_run_deq<P6, NCW, S6, C::CANON, W6>(wg * P6::spg, wave, lane_m, P6::M0, d6, L.xs[1], [&](int row, float v, float) {
             const uint16_t o = f2bf(v);
             const uint16_t y = f2bf(bf2f(L.xrawB[row]) + bf2f(o));
             if (last) a.x_out[row] = y;
@@ -1176,19 +1311,19 @@ __device__ __forceinline__ void eng_head_main(const EngArgs& a, const EngLds& L,
         for (int g = 0; g < HG; g++) {
             const int i = b * HG + g;
             const int row = (s_wg + wave + NWV * i) * RPS + sub;
-            float acc = 0.f;
+            acc_t<C::CANON> acc{};
 #pragma unroll
-            for (int it = 0; it < ITERS; it++) { /* BlockDot<FMT_BF16, true>: the block's 8 elements in order, one v_fma_f32 each */
+            for (int it = 0; it < ITERS; it++) { /* BlockDot<FMT_BF16, CANON>: the block's 4 pairs in order (canonical: the even / odd chains, one v_pk_fma_f32 per pair) */
                 const uint32_t w4[4] = {w[buf][g][it].x, w[buf][g][it].y, w[buf][g][it].z, w[buf][g][it].w};
-                float r = acc;
+                acc_t<C::CANON> r = acc;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    if constexpr (C::CANON) r = fmaf(bf_lo(w4[i]), xf[it][2 * i], r), r = fmaf(bf_hi(w4[i]), xf[it][2 * i + 1], r);
+                    if constexpr (C::CANON) r = pk_fma(f32x2_t{bf_lo(w4[i]), bf_hi(w4[i])}, f32x2_t{xf[it][2 * i], xf[it][2 * i + 1]}, r);
                     else r = dot2_bf16(w4[i], xp[it][i], r);
                 }
-                acc = (it * LPR + ll < nBlk) ? r : acc;
+                acc = acc_pick(it * LPR + ll < nBlk, r, acc);
             }
-            const float v = group_sum(acc, C::Hlpr_log2);
+            const float v = group_sum(acc_join(acc), C::Hlpr_log2);
             if (ll == 0 && i < nmine && row < a.vocab) {
                 const uint16_t o = f2bf(v);
                 a.logits[row] = o;
@@ -1357,7 +1492,8 @@ __global__ void __launch_bounds__(C::NWV * 64) engine_kernel(const EngArgs a) {
     // the steps of this launch: positions pos0, pos0 + 1, ... with the slice geometry of the launch bound; a step's id reaches the next step's layer 0 as a tagged
     // granule (eng_poller_main), everything else a step needs from its predecessor is in the KV cache
     const int nst = a.n_steps > 1 ? a.n_steps : 1;
-    if (pos0 + nst > a.nsp * a.chunk) { /* a position of this launch lies beyond the keys its slices cover (the caller's pos_bound does not hold): refuse, loudly */
+    if (pos0 + nst > a.nsp * a.chunk || pos0 + nst > a.max_seq) { /* a position of this launch lies beyond the keys its slices cover (the caller's pos_bound does not hold) or beyond the
+                                                                      cache rows (nsp * chunk rounds the bound up): refuse, loudly */
         if (tid == 0) atomicOr(a.ws + 1, 64);
         return;
     }
@@ -1502,8 +1638,9 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     a.n_layer = d->n_layer;
     E->dim = d->dim, E->n_head = d->n_head, E->n_kv = d->n_kv, E->q_dim = d->n_head * hd, E->kv_dim = d->n_kv * hd, E->ffn = d->ffn;
     a.kv_stride = d->kv_stride;
+    a.max_seq = d->max_seq;
     a.eps = d->rms_eps, a.qk_eps = d->qk_eps, a.rope_table = d->rope_table;
-    if (!a.rope_table || (a.kv_stride % 8) != 0) {
+    if (!a.rope_table || (a.kv_stride % 8) != 0 || a.max_seq < 1) {
         delete E;
         return KF_INVALID_ARGS;
     }
@@ -1672,7 +1809,7 @@ static int engine_go_fmt(EngineHost* E, hipStream_t st) {
 // 1: this position bound is outside what the engine serves (the caller runs the multi-launch path), < 0 error
 int engine_step(EngineHost* E, hipStream_t st, const uint16_t* x_in, uint16_t* x_out, const int32_t* d_state, int pos_bound, int with_head, int n_steps) {
     EngArgs& a = E->args;
-    if ((!x_in && !a.emb) || !x_out || !d_state || pos_bound < 0) return KF_INVALID_ARGS;
+    if ((!x_in && !a.emb) || !x_out || !d_state || pos_bound < 0 || pos_bound >= a.max_seq) return KF_INVALID_ARGS;
     if (with_head && !a.head_w) return KF_INVALID_ARGS;
     if (n_steps < 1 || (n_steps > 1 && (with_head != 2 || x_in))) return KF_INVALID_ARGS; /* several steps per launch: only with the pick inside and the embedding row read inside */
     a.n_steps = n_steps;

@@ -282,15 +282,16 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     // ---- main: pipelined over (batch, iteration) steps
     float best_v = -__builtin_inff();
     int best_i = 0x7fffffff;
-    float acc[G], acc2[PAIRED ? G : 1];
+    acc_t<CANON> acc[G], acc2[PAIRED ? G : 1]; /* per-lane chains (canonical: an even and an odd one) */
+    float sum[G], sum2[PAIRED ? G : 1];
     int bi = 0, it = 0;       // the step being computed
     int nbi = 0, nit = 0;     // the step being loaded
     auto compute = [&](const Batch<G, PAIRED, LUT>& bt) {
         if (it == 0) {
 #pragma unroll
             for (int g = 0; g < G; g++) {
-                acc[g] = 0.f;
-                if (PAIRED) acc2[g] = 0.f;
+                acc[g] = acc_t<CANON>{};
+                if (PAIRED) acc2[g] = acc_t<CANON>{};
             }
         }
         {
@@ -302,20 +303,20 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
                 int row;
                 const bool ok = !LAT || (slot(s_begin + (long)bi * G + g, row) && col_ok); /* masked loads carry zero weights */
                 if constexpr (LUT) {
-                    const float r = BD::run_lut(bt.w[g], xs, col, nBlk, bt.ta[g], bt.tb[g], acc[g]);
-                    acc[g] = ok ? r : acc[g];
+                    const acc_t<CANON> r = BD::run_lut(bt.w[g], xs, col, nBlk, bt.ta[g], bt.tb[g], acc[g]);
+                    acc[g] = acc_pick(ok, r, acc[g]);
                     if constexpr (PAIRED) {
-                        const float r2 = BD::run_lut(bt.w2[g], xs, col, nBlk, bt.ta2[g], bt.tb2[g], acc2[g]);
-                        acc2[g] = ok ? r2 : acc2[g];
+                        const acc_t<CANON> r2 = BD::run_lut(bt.w2[g], xs, col, nBlk, bt.ta2[g], bt.tb2[g], acc2[g]);
+                        acc2[g] = acc_pick(ok, r2, acc2[g]);
                     }
                 } else {
                     const float st = bf2f(bt.st[g]);
-                    const float r = BD::run(bt.w[g], xs, col, nBlk, st, bf2f(bt.ze[g]), -(jqb * st), acc[g]);
-                    acc[g] = ok ? r : acc[g];
+                    const acc_t<CANON> r = BD::run(bt.w[g], xs, col, nBlk, st, bf2f(bt.ze[g]), -(jqb * st), acc[g]);
+                    acc[g] = acc_pick(ok, r, acc[g]);
                     if (PAIRED) {
                         const float st2 = bf2f(bt.st2[g]);
-                        const float r2 = BD::run(bt.w2[g], xs, col, nBlk, st2, bf2f(bt.ze2[g]), -(jqb2 * st2), acc2[g]);
-                        acc2[g] = ok ? r2 : acc2[g];
+                        const acc_t<CANON> r2 = BD::run(bt.w2[g], xs, col, nBlk, st2, bf2f(bt.ze2[g]), -(jqb2 * st2), acc2[g]);
+                        acc2[g] = acc_pick(ok, r2, acc2[g]);
                     }
                 }
             }
@@ -323,8 +324,8 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
         if (it == iters - 1) {
 #pragma unroll
             for (int g = 0; g < G; g++) {
-                acc[g] = group_sum(acc[g], a.lpr_log2);
-                if (PAIRED) acc2[g] = group_sum(acc2[g], a.lpr_log2);
+                sum[g] = group_sum(acc_join(acc[g]), a.lpr_log2);
+                if (PAIRED) sum2[g] = group_sum(acc_join(acc2[g]), a.lpr_log2);
             }
             if (ll == 0) {
 #pragma unroll
@@ -333,10 +334,10 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
                     if (!slot(s_begin + (long)bi * G + g, r)) continue;
                     if constexpr (SPARSE) r = a.row_map[r];
                     uint16_t* y = jy + (size_t)pos * jystride;
-                    float v = acc[g];
+                    float v = sum[g];
                     if (PAIRED) {
                         // SwiGLU of the two bf16-rounded projections (CU_swiglu_v0, Activation.cu:85-93)
-                        const float gt = round_bf16(v), up = round_bf16(acc2[g]);
+                        const float gt = round_bf16(v), up = round_bf16(sum2[g]);
                         y[r] = f2bf((gt * up) / (1.0f + kf_expf(-gt)));
                         continue;
                     }

@@ -6,18 +6,13 @@
 
 namespace kf {
 
-// One pair of products added to an accumulator.  CANON = false: v_dot2c_f32_bf16 (one instruction; its internal rounding has no bit-exact CPU model).
-// CANON = true: the canonical order kernels and oracle share (oracle/kf_oracle.c section 4c): two fused multiply-adds, low element first -- every bit
-// reproducible with fmaf on the host.  All block dots below add their pairs in element order, so the per-lane chain of the canonical order is "the
-// elements of a block in index order, block after block".
+// One pair of products added to an accumulator (acc_t, kf_device.h).  CANON = false: v_dot2c_f32_bf16 (one instruction; its internal rounding has no bit-exact
+// CPU model).  CANON = true: the canonical order kernels and oracle share (oracle/kf_oracle.c section 4c): the pair's low (even-indexed) element goes into the
+// lane's even chain, its high element into the odd chain -- one v_pk_fma_f32, each half an IEEE fma, every bit reproducible with fmaf on the host.  All block
+// dots below add their pairs in element order, so the two chains of a lane are "the even / the odd elements of a block in index order, block after block".
 template <bool CANON>
-__device__ __forceinline__ float dotp(uint32_t w, uint32_t x, float acc) {
-    if constexpr (CANON) {
-        acc = fmaf(bf_lo(w), bf_lo(x), acc);
-        return fmaf(bf_hi(w), bf_hi(x), acc);
-    } else {
-        return dot2_bf16(w, x, acc);
-    }
+__device__ __forceinline__ acc_t<CANON> dotp(uint32_t w, uint32_t x, acc_t<CANON> acc) {
+    return dotp_dev<CANON>(w, x, acc);
 }
 
 // ------------------------------------------------------------------------------------------------ block dots
@@ -27,7 +22,7 @@ __device__ __forceinline__ float dotp(uint32_t w, uint32_t x, float acc) {
 //   step*(q-qBias) is formed exactly in fp32 by one fma (q <= 15, step has 8 significant bits), rounded to
 //   bf16 by v_cvt_pk_bf16_f32 (two at a time), widened, zero subtracted in fp32 (exact operands), rounded again.
 template <bool CANON>
-__device__ __forceinline__ float dot_q4_dword(uint32_t D, u32x4 X, float step, float step16, float nb, float zero, float acc) {
+__device__ __forceinline__ acc_t<CANON> dot_q4_dword(uint32_t D, u32x4 X, float step, float step16, float nb, float zero, acc_t<CANON> acc) {
     uint32_t H = D & 0xF0F0F0F0u, L = D & 0x0F0F0F0Fu;
     // keep the two masks opaque: folded into the byte extraction below they would defeat v_cvt_f32_ubyte1..3 (one op per nibble)
     asm("" : "+v"(H));
@@ -55,7 +50,7 @@ template <bool CANON>
 struct BlockDot<FMT_BF16, CANON> {
     static constexpr int EPB = 8, XCH = 1;
     static constexpr bool HAS_GAMA = false;
-    __device__ static __forceinline__ float run(u32x4 w, const u32x4* xs, int col, int nBlk, float, float, float, float acc) {
+    __device__ static __forceinline__ acc_t<CANON> run(u32x4 w, const u32x4* xs, int col, int nBlk, float, float, float, acc_t<CANON> acc) {
         u32x4 X = xs[col];
         acc = dotp<CANON>(w.x, X.x, acc);
         acc = dotp<CANON>(w.y, X.y, acc);
@@ -68,7 +63,7 @@ struct BlockDot<FMT_BF16, CANON> {
 // F8E5M2: byte i of the block = element i; value = half(byte << 8) (g_float.hpp:355-383), exact in bf16.
 __device__ __forceinline__ float f8_to_f32(uint32_t hbits) { return half_bits_to_f32(hbits); }
 template <bool CANON>
-__device__ __forceinline__ float dot_f8_dword(uint32_t D, uint32_t X0, uint32_t X1, float acc) {
+__device__ __forceinline__ acc_t<CANON> dot_f8_dword(uint32_t D, uint32_t X0, uint32_t X1, acc_t<CANON> acc) {
     // gfx950 converts two OCP E5M2 bytes to fp32 in one instruction (v_cvt_pk_f32_bf8): the same values as half(byte << 8), exactly
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
     const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_bf8((int)D, false), hi = __builtin_amdgcn_cvt_pk_f32_bf8((int)D, true);
@@ -82,7 +77,7 @@ template <bool CANON>
 struct BlockDot<FMT_F8, CANON> {
     static constexpr int EPB = 16, XCH = 2;
     static constexpr bool HAS_GAMA = false;
-    __device__ static __forceinline__ float run(u32x4 w, const u32x4* xs, int col, int nBlk, float, float, float, float acc) {
+    __device__ static __forceinline__ acc_t<CANON> run(u32x4 w, const u32x4* xs, int col, int nBlk, float, float, float, acc_t<CANON> acc) {
         u32x4 X0 = xs[col], X1 = xs[nBlk + col];
         acc = dot_f8_dword<CANON>(w.x, X0.x, X0.y, acc);
         acc = dot_f8_dword<CANON>(w.y, X0.z, X0.w, acc);
@@ -97,7 +92,7 @@ struct BlockDot<FMT_Q4, CANON> {
     static constexpr int EPB = 32, XCH = 4;
     static constexpr bool HAS_GAMA = true;
     // nb = -qBias*step (exact)
-    __device__ static __forceinline__ float run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, float acc) {
+    __device__ static __forceinline__ acc_t<CANON> run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, acc_t<CANON> acc) {
         const float step16 = step * 0.0625f;
         acc = dot_q4_dword<CANON>(w.w, xs[col], step, step16, nb, zero, acc);
         acc = dot_q4_dword<CANON>(w.z, xs[nBlk + col], step, step16, nb, zero, acc);
@@ -117,7 +112,7 @@ template <bool CANON>
 struct BlockDot<FMT_Q4P, CANON> {
     static constexpr int EPB = 32, XCH = 4;
     static constexpr bool HAS_GAMA = true;
-    __device__ static __forceinline__ float run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, float acc) {
+    __device__ static __forceinline__ acc_t<CANON> run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, acc_t<CANON> acc) {
         const float q0 = (float)((threadIdx.x & 3) << 2);
         uint32_t r = pack_bf16x2(fmaf(q0, step, nb), fmaf(q0 + 1.0f, step, nb));
         const uint32_t P0 = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
@@ -142,8 +137,8 @@ template <bool CANON>
 struct BlockDot<FMT_Q4R, CANON> {
     static constexpr int EPB = 32, XCH = 4;
     static constexpr bool HAS_GAMA = false;
-    __device__ static __forceinline__ float run(u32x4, const u32x4*, int, int, float, float, float, float acc) { return acc; }
-    __device__ static __forceinline__ float run_lut(u32x4 w, const u32x4* xs, int col, int nBlk, u32x4 ta, u32x4 tb, float acc) {
+    __device__ static __forceinline__ acc_t<CANON> run(u32x4, const u32x4*, int, int, float, float, float, acc_t<CANON> acc) { return acc; }
+    __device__ static __forceinline__ acc_t<CANON> run_lut(u32x4 w, const u32x4* xs, int col, int nBlk, u32x4 ta, u32x4 tb, acc_t<CANON> acc) {
         const uint32_t P[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
         PermLut t;
 #pragma unroll
@@ -162,7 +157,7 @@ struct BlockDot<FMT_Q4R, CANON> {
 // 2-bit (T_SIGN ternary / generic CU_Q128toX_<T,64>): element i < 32 at high >> (62-2i) (PackedQ.hpp:185-226):
 // dword3 -> elements 0..15 (element 0 in bits 30..31), dword2 -> 16..31, dword1 -> 32..47, dword0 -> 48..63.
 template <bool CANON>
-__device__ __forceinline__ float dot_q2_dword(uint32_t D, u32x4 Xa, u32x4 Xb, float step, float nb, float zero, float acc) {
+__device__ __forceinline__ acc_t<CANON> dot_q2_dword(uint32_t D, u32x4 Xa, u32x4 Xb, float step, float nb, float zero, acc_t<CANON> acc) {
     const uint32_t xw[8] = {Xa.x, Xa.y, Xa.z, Xa.w, Xb.x, Xb.y, Xb.z, Xb.w};
 #pragma unroll
     for (int p = 0; p < 8; p++) {
@@ -177,7 +172,7 @@ template <bool CANON>
 struct BlockDot<FMT_Q2, CANON> {
     static constexpr int EPB = 64, XCH = 8;
     static constexpr bool HAS_GAMA = true;
-    __device__ static __forceinline__ float run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, float acc) {
+    __device__ static __forceinline__ acc_t<CANON> run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, acc_t<CANON> acc) {
         acc = dot_q2_dword<CANON>(w.w, xs[col], xs[nBlk + col], step, nb, zero, acc);
         acc = dot_q2_dword<CANON>(w.z, xs[2 * nBlk + col], xs[3 * nBlk + col], step, nb, zero, acc);
         acc = dot_q2_dword<CANON>(w.y, xs[4 * nBlk + col], xs[5 * nBlk + col], step, nb, zero, acc);
@@ -190,7 +185,7 @@ struct BlockDot<FMT_Q2, CANON> {
 // dword3 -> elements 0..31 (element 0 = bit 31), dword2 -> 32..63, dword1 -> 64..95, dword0 -> 96..127.
 // w in {w0, w1} = {dequant(0), dequant(1)}: both are formed once per block, then selected per bit.
 template <bool CANON>
-__device__ __forceinline__ float dot_q1_dword(uint32_t D, const u32x4* xs, int base, int nBlk, int col, uint32_t w0, uint32_t w1, float acc) {
+__device__ __forceinline__ acc_t<CANON> dot_q1_dword(uint32_t D, const u32x4* xs, int base, int nBlk, int col, uint32_t w0, uint32_t w1, acc_t<CANON> acc) {
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         u32x4 X = xs[(base + c) * nBlk + col];
@@ -208,7 +203,7 @@ template <bool CANON>
 struct BlockDot<FMT_Q1, CANON> {
     static constexpr int EPB = 128, XCH = 16;
     static constexpr bool HAS_GAMA = true;
-    __device__ static __forceinline__ float run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, float acc) {
+    __device__ static __forceinline__ acc_t<CANON> run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, acc_t<CANON> acc) {
         // dequant(q) for q = 0, 1 (q - qBias folded into nb)
         uint32_t r = pack_bf16x2(fmaf(0.0f, step, nb), fmaf(1.0f, step, nb));
         uint32_t ww = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
@@ -229,7 +224,7 @@ template <bool CANON>
 struct BlockDot<FMT_Q1T, CANON> {
     static constexpr int EPB = 128, XCH = 16;
     static constexpr bool HAS_GAMA = true;
-    __device__ static __forceinline__ float run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, float acc) {
+    __device__ static __forceinline__ acc_t<CANON> run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, acc_t<CANON> acc) {
         const uint32_t r = pack_bf16x2(fmaf(0.0f, step, nb), fmaf(1.0f, step, nb));
         const uint32_t ww = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero); /* bytes 0,1 = dequant(0); bytes 2,3 = dequant(1) */
         const u32x4* tab = xs + nBlk * 16 + 16;                            /* behind x (K * 2 bytes) and the 256-byte reduction scratch */
@@ -256,7 +251,7 @@ template <bool CANON>
 struct BlockDot<FMT_Q2T, CANON> {
     static constexpr int EPB = 64, XCH = 8;
     static constexpr bool HAS_GAMA = true;
-    __device__ static __forceinline__ float run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, float acc) {
+    __device__ static __forceinline__ acc_t<CANON> run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, acc_t<CANON> acc) {
         uint32_t r = pack_bf16x2(fmaf(0.0f, step, nb), fmaf(1.0f, step, nb));
         const uint32_t T01 = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
         r = pack_bf16x2(fmaf(2.0f, step, nb), fmaf(3.0f, step, nb));
@@ -284,23 +279,19 @@ struct BlockDot<FMT_Q2T, CANON> {
 // vector is staged in LDS as fp32 -- chunks of 4 floats laid out [EPB / 4][nBlk] -- and a weight is formed as an fp32 register directly (the table lookup
 // assembles {0, 0, low byte, high byte} with one v_perm_b32), so neither operand is unpacked from a bf16 pair per product.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float perm_fma_dword(uint32_t D, f32x4 X0, f32x4 X1, const PermLut& t, float acc) {
+__device__ __forceinline__ f32x2_t perm_fma_dword(uint32_t D, f32x4 X0, f32x4 X1, const PermLut& t, f32x2_t acc) {
     const uint32_t even = D >> 4; /* bytes 3..0: elements 0,2,4,6 in the low nibbles; D itself: 1,3,5,7 */
     uint32_t lo, hi;
     perm_lookup4(__builtin_amdgcn_perm(even, D, 0x02060307u), t, lo, hi); /* bytes 0..3 = elements 0, 1, 2, 3 */
-    acc = fmaf(__uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x04000c0cu)), X0.x, acc);
-    acc = fmaf(__uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x05010c0cu)), X0.y, acc);
-    acc = fmaf(__uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x06020c0cu)), X0.z, acc);
-    acc = fmaf(__uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x07030c0cu)), X0.w, acc);
+    acc = pk_fma(f32x2_t{__uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x04000c0cu)), __uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x05010c0cu))}, f32x2_t{X0.x, X0.y}, acc);
+    acc = pk_fma(f32x2_t{__uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x06020c0cu)), __uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x07030c0cu))}, f32x2_t{X0.z, X0.w}, acc);
     perm_lookup4(__builtin_amdgcn_perm(even, D, 0x00040105u), t, lo, hi); /* elements 4, 5, 6, 7 */
-    acc = fmaf(__uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x04000c0cu)), X1.x, acc);
-    acc = fmaf(__uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x05010c0cu)), X1.y, acc);
-    acc = fmaf(__uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x06020c0cu)), X1.z, acc);
-    acc = fmaf(__uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x07030c0cu)), X1.w, acc);
+    acc = pk_fma(f32x2_t{__uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x04000c0cu)), __uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x05010c0cu))}, f32x2_t{X1.x, X1.y}, acc);
+    acc = pk_fma(f32x2_t{__uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x06020c0cu)), __uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x07030c0cu))}, f32x2_t{X1.z, X1.w}, acc);
     return acc;
 }
 // arithmetic form: w = bf16(bf16(step * (q - qBias)) - zero) per nibble, as dot_q4_dword forms it, kept as fp32
-__device__ __forceinline__ float arith_fma_dword(uint32_t D, f32x4 X0, f32x4 X1, float step, float step16, float nb, float zero, float acc) {
+__device__ __forceinline__ f32x2_t arith_fma_dword(uint32_t D, f32x4 X0, f32x4 X1, float step, float step16, float nb, float zero, f32x2_t acc) {
     uint32_t H = D & 0xF0F0F0F0u, Lw = D & 0x0F0F0F0Fu;
     asm("" : "+v"(H));
     asm("" : "+v"(Lw));
@@ -310,8 +301,7 @@ __device__ __forceinline__ float arith_fma_dword(uint32_t D, f32x4 X0, f32x4 X1,
         const int sh = 24 - 8 * p;
         const uint32_t r = pack_bf16x2(fmaf((float)((H >> sh) & 0xffu), step16, nb), fmaf((float)((Lw >> sh) & 0xffu), step, nb));
         const uint32_t w = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
-        acc = fmaf(bf_lo(w), xs8[2 * p], acc);
-        acc = fmaf(bf_hi(w), xs8[2 * p + 1], acc);
+        acc = pk_fma(f32x2_t{bf_lo(w), bf_hi(w)}, f32x2_t{xs8[2 * p], xs8[2 * p + 1]}, acc);
     }
     return acc;
 }
@@ -321,7 +311,7 @@ template <>
 struct BlockDotF<FMT_Q4P> {
     static constexpr int EPB = 32, XCH = 8;
     static constexpr bool HAS_GAMA = true;
-    __device__ static __forceinline__ float run(u32x4 w, const f32x4* xs, int col, int nBlk, float step, float zero, float nb, float acc) {
+    __device__ static __forceinline__ f32x2_t run(u32x4 w, const f32x4* xs, int col, int nBlk, float step, float zero, float nb, f32x2_t acc) {
         const float q0 = (float)((threadIdx.x & 3) << 2);
         uint32_t r = pack_bf16x2(fmaf(q0, step, nb), fmaf(q0 + 1.0f, step, nb));
         const uint32_t P0 = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
@@ -342,7 +332,7 @@ template <>
 struct BlockDotF<FMT_Q4> {
     static constexpr int EPB = 32, XCH = 8;
     static constexpr bool HAS_GAMA = true;
-    __device__ static __forceinline__ float run(u32x4 w, const f32x4* xs, int col, int nBlk, float step, float zero, float nb, float acc) {
+    __device__ static __forceinline__ f32x2_t run(u32x4 w, const f32x4* xs, int col, int nBlk, float step, float zero, float nb, f32x2_t acc) {
         const float step16 = step * 0.0625f;
         acc = arith_fma_dword(w.w, xs[col], xs[nBlk + col], step, step16, nb, zero, acc);
         acc = arith_fma_dword(w.z, xs[2 * nBlk + col], xs[3 * nBlk + col], step, step16, nb, zero, acc);
@@ -404,16 +394,16 @@ struct BlockPrep<FMT_Q4> {
     }
 };
 template <bool CANON>
-__device__ __forceinline__ float pairs_dot(const uint32_t (&p)[16], const u32x4* xs, int col, int nBlk, float acc) {
+__device__ __forceinline__ acc_t<CANON> pairs_dot(const uint32_t (&p)[16], const u32x4* xs, int col, int nBlk, acc_t<CANON> acc) {
     if constexpr (CANON) {
         const f32x4* xf = reinterpret_cast<const f32x4*>(xs);
 #pragma unroll
         for (int d = 0; d < 4; d++) {
             const f32x4 X0 = xf[(2 * d) * nBlk + col], X1 = xf[(2 * d + 1) * nBlk + col];
-            acc = fmaf(bf_lo(p[4 * d]), X0.x, acc), acc = fmaf(bf_hi(p[4 * d]), X0.y, acc);
-            acc = fmaf(bf_lo(p[4 * d + 1]), X0.z, acc), acc = fmaf(bf_hi(p[4 * d + 1]), X0.w, acc);
-            acc = fmaf(bf_lo(p[4 * d + 2]), X1.x, acc), acc = fmaf(bf_hi(p[4 * d + 2]), X1.y, acc);
-            acc = fmaf(bf_lo(p[4 * d + 3]), X1.z, acc), acc = fmaf(bf_hi(p[4 * d + 3]), X1.w, acc);
+            acc = pk_fma(f32x2_t{bf_lo(p[4 * d]), bf_hi(p[4 * d])}, f32x2_t{X0.x, X0.y}, acc);
+            acc = pk_fma(f32x2_t{bf_lo(p[4 * d + 1]), bf_hi(p[4 * d + 1])}, f32x2_t{X0.z, X0.w}, acc);
+            acc = pk_fma(f32x2_t{bf_lo(p[4 * d + 2]), bf_hi(p[4 * d + 2])}, f32x2_t{X1.x, X1.y}, acc);
+            acc = pk_fma(f32x2_t{bf_lo(p[4 * d + 3]), bf_hi(p[4 * d + 3])}, f32x2_t{X1.z, X1.w}, acc);
         }
     } else {
 #pragma unroll

@@ -66,7 +66,7 @@ struct GemvLaunch {
     int mode;
     long target_waves; /* 0: default */
     int n_hot;         /* args.row_map != NULL: number of entries */
-    int canon;         /* the canonical summation order (two v_fma_f32 per weight pair; oracle/kf_oracle.c section 4c) instead of v_dot2c_f32_bf16 */
+    int canon;         /* the canonical summation order (one v_pk_fma_f32 per weight pair: an even and an odd chain per lane; oracle/kf_oracle.c section 4c) instead of v_dot2c_f32_bf16 */
     int blocks;        /* out */
 };
 

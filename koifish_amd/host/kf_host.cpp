@@ -358,6 +358,7 @@ int Fish::EnsureEngine() {
     std::memset(&d, 0, sizeof(d));
     d.n_layer = config.nLayer, d.dim = config.nEmbed, d.n_head = config.n_head, d.n_kv = config.n_head_kv, d.head_dim = config.head_dim, d.ffn = config.n_ff;
     d.kv_stride = config.n_head_kv * config.head_dim;
+    d.max_seq = config.n_ctx;
     d.rms_eps = config.rms_eps, d.qk_eps = config.qk_eps, d.rope_table = rope_table, d.layers = L.data();
     const size_t bytes = kf_engine_workspace_bytes(&d);
     if (kf_malloc(ctx, bytes, &engine_ws) != KF_OK) return KF_OUTOF_GPUMEMORY;

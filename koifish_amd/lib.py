@@ -3,8 +3,9 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_HIP = os.path.join(HERE, "libkf_hip.so")
-LIB_HOST = os.path.join(HERE, "libkf_host.so")
+# KF_LIB_DIR (development only: scratch/build_variant.py): a directory holding an A/B build of the two libraries
+LIB_HIP = os.path.join(os.environ.get("KF_LIB_DIR", HERE), "libkf_hip.so")
+LIB_HOST = os.path.join(os.environ.get("KF_LIB_DIR", HERE), "libkf_host.so")
 
 # typNUMBER (src/g_float.hpp:84-117)
 F32, F64, F16, BF16, F8E5M2, F8E4M3, U8, I8, U16, I16, U32, I32, U64, I64, Q4, Q3, Q2, T_SIGN, T_SEQ, BOOL1, T_BINARY, T_BINARY_3, T_BINARY_TILE = range(23)

@@ -124,6 +124,12 @@ def stream(device=0):
     return _STREAM[device]
 
 
+# Test hook (Python side only; the library reads no environment): the summation order every Context / Qwen3 created from here on is switched to right after its
+# creation.  None = the library's own default (canonical, kf_abi.h).  tests/conftest.py sets False: the tolerance tests were written against the v_dot2c order and keep
+# covering it, the canonical order is asserted bit for bit by the tests that switch it on themselves.
+DEFAULT_CANONICAL = None
+
+
 class Context:
     """kf_ctx bound to torch's current stream on `device`."""
 
@@ -138,6 +144,8 @@ class Context:
         self._attn_ws = None
         self._head_ws = torch.empty(self.hip.kf_head_scratch_bytes(), dtype=torch.uint8, device=self.device)
         self._lin_ws = None
+        if DEFAULT_CANONICAL is not None:
+            self.set_canonical(DEFAULT_CANONICAL)
 
     def close(self):
         if self.h:
@@ -154,7 +162,7 @@ class Context:
         L.check(self.hip.kf_sync(self.h), "kf_sync")
 
     def set_canonical(self, on):
-        """1: the decode kernels sum in the canonical order the CPU oracle shares (bit-exact); 0 (default): the v_dot2c / fp32 forms"""
+        """1 (the library default): the decode kernels sum in the canonical order the CPU oracle shares (bit-exact); 0: the v_dot2c / fp32 forms"""
         L.check(self.hip.kf_set_canonical(self.h, int(bool(on))), "kf_set_canonical")
 
     # ---- weights
@@ -332,6 +340,8 @@ class Qwen3:
                 raise L.KFError("kfh_create failed with %d: %s" % (rc.value, why))
             L.check(rc.value or -1, "kfh_create")
         self.h = C.c_void_p(self.h)
+        if DEFAULT_CANONICAL is not None:
+            L.check(self.host.kfh_set_canonical(self.h, int(bool(DEFAULT_CANONICAL))), "kfh_set_canonical")
         self._keep = []
         self.weights = {}
         self._norms = {}
@@ -353,6 +363,8 @@ class Qwen3:
         if not self.h:
             raise L.KFError("kfh_load_hf(%s) failed with %d: %s" % (path, rc.value, self.host.kfh_last_error().decode()))
         self.h = C.c_void_p(self.h)
+        if DEFAULT_CANONICAL is not None:
+            L.check(self.host.kfh_set_canonical(self.h, int(bool(DEFAULT_CANONICAL))), "kfh_set_canonical")
         self._read_config()
         return self
 
@@ -371,6 +383,8 @@ class Qwen3:
         if not self.h:
             raise L.KFError("kfh_load_kun(%s) failed with %d: %s" % (path, rc.value, self.host.kfh_last_error().decode()))
         self.h = C.c_void_p(self.h)
+        if DEFAULT_CANONICAL is not None:
+            L.check(self.host.kfh_set_canonical(self.h, int(bool(DEFAULT_CANONICAL))), "kfh_set_canonical")
         self._read_config()
         return self
 
@@ -439,11 +453,11 @@ class Qwen3:
 
     def set_engine(self, on):
         """The persistent decode engine (kf_engine_*: all layers of a step in one launch) on / off; off = the five launches per layer.
-        Same arithmetic either way, bit for bit."""
+        Same arithmetic either way, bit for bit, in the canonical order (the default); in the v_dot2c order the engine's fp32 attention sums are its own (tolerances)."""
         L.check(self.host.kfh_set_engine(self.h, int(bool(on))), "kfh_set_engine")
 
     def set_canonical(self, on):
-        """1: the decode kernels sum in the canonical order the CPU oracle shares (bit-exact logits, ids and KV rows); 0 (default): the v_dot2c_f32_bf16 / fp32 forms"""
+        """1 (the library default): the decode kernels sum in the canonical order the CPU oracle shares (bit-exact logits, ids and KV rows); 0: the v_dot2c_f32_bf16 / fp32 forms"""
         L.check(self.host.kfh_set_canonical(self.h, int(bool(on))), "kfh_set_canonical")
 
     def engine_steps(self):

@@ -499,9 +499,11 @@ static float dot16(const float* w, const float* x, int n) {
  *     from single fp32 fused multiply-adds only (v_fma_f32 on the GPU, fmaf here), which makes every logit and every greedy id equal
  *     bit for bit (tests/test_gpu_canonical.py; bench.py cpu_baseline.mismatches_* = 0):
  *       - a row is cut into 16-byte storage blocks of EPB elements (8 bf16 / 16 f8 / 32 four-bit / 64 two-bit / 128 one-bit);
- *       - LPR = 2^lpr_log2 "lanes" walk the row: lane l owns blocks l, l + LPR, l + 2 LPR, ... and keeps ONE accumulator through all of
- *         them, acc = fmaf(w[i], x[i], acc) over the elements of a block in index order;
- *       - the LPR accumulators are added by a balanced binary tree (lanes 2j + 2j+1, then pairs of pairs, ...).
+ *       - LPR = 2^lpr_log2 "lanes" walk the row: lane l owns blocks l, l + LPR, l + 2 LPR, ... and keeps TWO accumulators through all of
+ *         them (round 4; one before): e = fmaf(w[i], x[i], e) over the even-indexed elements of a block in index order, o = fmaf(w[i], x[i], o)
+ *         over the odd-indexed ones -- the two halves of one v_pk_fma_f32 per weight pair on the GPU, half the dependent chain of the
+ *         single-accumulator form -- and the lane's value is e + o;
+ *       - the LPR lane values are added by a balanced binary tree (lanes 2j + 2j+1, then pairs of pairs, ...).
  *     lpr_log2 = kfo_lpr_log2(blocks per row, rows of the launch): the rule of kf::gemv_lpr_log2 (koifish_amd/csrc/kf_gemv.hip), restated.
  *     `rows` = the rows of ALL matrices a launch multiplies (Q | K | V together; gate alone for the paired gate / up launch).
  * ---------------------------------------------------------------------------------------------- */
@@ -532,12 +534,12 @@ static float dot_canon(const float* w, const float* x, int K, int epb, int lpr_l
     const int nBlk = K / epb, LPR = 1 << lpr_log2;
     float lane[64];
     for (int l = 0; l < LPR; l++) {
-        float acc = 0.f;
+        float e = 0.f, o = 0.f; /* the even / odd chain of this lane (every epb is even) */
         for (int c = l; c < nBlk; c += LPR) {
             const float *wb = w + (size_t)c * epb, *xb = x + (size_t)c * epb;
-            for (int i = 0; i < epb; i++) acc = fmaf(wb[i], xb[i], acc);
+            for (int i = 0; i < epb; i += 2) e = fmaf(wb[i], xb[i], e), o = fmaf(wb[i + 1], xb[i + 1], o);
         }
-        lane[l] = acc;
+        lane[l] = e + o;
     }
     for (int s = 1; s < LPR; s <<= 1)
         for (int l = 0; l < LPR; l += 2 * s) lane[l] = lane[l] + lane[l + s];

@@ -173,3 +173,64 @@ def test_full_size_steps_are_bit_exact(canon):
     m.engine_check()
     om.close()
     m.close()
+
+
+def test_library_default_is_the_canonical_order(canon):
+    """kf_init hands out a context in the canonical order (round 4: the bit-exact order is the default and the one bench.py times): no switch is touched here, and whole
+    decode steps -- persistent engine, in-launch head and pick -- equal the oracle bit for bit."""
+    from koifish_amd import runtime
+    saved, runtime.DEFAULT_CANONICAL = runtime.DEFAULT_CANONICAL, None   # conftest starts this suite's contexts in the v_dot2c order: take the library as it is
+    try:
+        c = runtime.Context(0)
+        assert c.hip.kf_get_canonical(c.h) == 1
+        c.close()
+        cfg = dict(synth.CONFIGS["small"], max_seq=320)
+        raw = synth.raw_weights_numpy(cfg, 777, w_std=0.1)
+        n = 40
+        forced = np.full(cfg["max_seq"], -1, dtype=np.int32)
+        forced[:n] = prompt_ids(cfg, n, seed=3)
+        m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
+    finally:
+        runtime.DEFAULT_CANONICAL = saved
+    om = oracle_model(cfg, raw, L.Q4, L.BF16, attn_mode=O.ATTN_CANON)
+    _steps(m, om, cfg, n, forced, use_graph=True)
+    assert m.engine_steps() > 0
+    m.engine_check()
+    om.close()
+    m.close()
+
+
+def test_full_size_sixteen_step_launch_is_bit_exact(canon):
+    """The form bench.py times: ONE launch of 16 decode steps at positions 2028 .. 2043 of Qwen3-0.6B (kf_engine_steps_head: the picked id reaches the next step's
+    embedding read as a tagged granule), free running behind a 2028-token prefill -- the 16 greedy ids, the last step's logits and the 16 new KV rows equal the oracle's."""
+    cfg = dict(synth.CONFIGS["qwen3-0.6b"])
+    m = synth.build_on_gpu(cfg, seed=1234, layer_type=L.Q4, head_type=L.BF16, head_std=0.1)
+    m.set_canonical(True)
+    om = O.from_device_model(m, attn_mode=O.ATTN_CANON)
+    om.prepare_fast()
+    P, n = 2028, 16
+    toks = np.random.default_rng(2028).integers(0, cfg["vocab"], size=P + 1).astype(np.int32)
+    m.prefill(toks[:P], want_logits=False)
+    gk, gv = m.kv_to_host()
+    ok, ov = om.kv()
+    ok[:, :P] = gk[:, :P]
+    ov[:, :P] = gv[:, :P]
+    m.set_forced(np.full(cfg["max_seq"], -1, dtype=np.int32))
+    m.set_state(int(toks[P]), P)
+    steps0 = m.engine_steps()
+    m.run_steps(P, n, use_graph=True)   # one position bucket: one launch of 16 steps
+    m.sync()
+    m.engine_check()
+    assert m.engine_steps() - steps0 == n
+    g_ids = m.tokens_out(P + n)[P:P + n].tolist()
+    tok, o_ids, o_logits = int(toks[P]), [], None
+    for p in range(P, P + n):
+        o_id, o_logits, _ = om.decode(tok, p)
+        o_ids.append(int(o_id))
+        tok = int(o_id)
+    assert g_ids == o_ids
+    assert np.array_equal(m.logits(), o_logits)
+    gk, gv = m.kv_to_host()
+    assert np.array_equal(gk[:, P:P + n], om.kv()[0][:, P:P + n]) and np.array_equal(gv[:, P:P + n], om.kv()[1][:, P:P + n])
+    om.close()
+    m.close()
