@@ -427,6 +427,22 @@ int kf_engine_step_head(kf_ctx* ctx, kf_engine* e, const kf_bf16* x_in, kf_bf16*
  * through a launch boundary (~8 us per step).  Every position d_state[1] .. d_state[1] + n_steps - 1 must lie under pos_bound (the bound fixes the attention slicing of
  * the launch); d_tokens_out, d_forced and d_state are read and written per step as by the single step; logits / x_out hold the last step's.  Same bits as n_steps launches. */
 int kf_engine_steps_head(kf_ctx* ctx, kf_engine* e, kf_bf16* x_out, int32_t* d_state, int pos_bound, int n_steps);
+/* Why a model is (not) served: KF_OK, or KF_ENGINE_NOT_SERVED with the reason in `why` (shape not instantiated, storage, device too small, ...): validation only, nothing is
+ * allocated (desc->layers as for kf_engine_create).  Fish::EnsureEngine logs it once. */
+int kf_engine_served(kf_ctx* ctx, const kf_engine_desc* desc, char* why, size_t why_bytes);
+/* First-sweep delays of the hand-offs, measured on THIS device.  A consumer's first sweep of a hand-off vector is issued a fixed delay behind the moment its own workgroup
+ * published its rows of the feeding phase; too early costs a second sweep, too late its lateness.  kf_engine_tune times the layers-only launch at the position d_state holds
+ * (reads the state's token, rewrites that position's K / V rows with the values the real step is about to write; the state does not advance) and walks the six delays by
+ * coordinate descent (`passes` <= 3 rounds of 8, 4, 2 sleep units; ~100 launches per round), for the attention slice count of `pos_bound`.  Results never depend on the
+ * delays.  Needs the embedding table (kf_engine_set_embedding).  us_before / us_after (optional): mean launch time with the old and the chosen delays. */
+int kf_engine_tune(kf_ctx* ctx, kf_engine* e, kf_bf16* x_out, const int32_t* d_state, int pos_bound, int passes, float* us_before, float* us_after);
+typedef struct kf_engine_statistics {
+    int32_t sweeps[6]; /* sweeps the poller of workgroup 0 issued since creation / reset, per hand-off: x (P1), q|k|v (P2), slice partials (P3), ao (P4), xB (P5), act (P6) */
+    int32_t polls;     /* polls per hand-off in the same span (= layers stepped): sweeps[i] / polls = sweeps per poll, 1.0 when every first sweep came back complete */
+    int32_t delay[6];  /* the delays in use at pos_bound's slice count (s_sleep units) */
+    int32_t tuned;     /* 1: measured by kf_engine_tune on this device, 0: the built-in defaults */
+} kf_engine_statistics;
+int kf_engine_stats(kf_ctx* ctx, kf_engine* e, int pos_bound, kf_engine_statistics* out);
 int kf_engine_check(kf_ctx* ctx, kf_engine* e); /* synchronises; KF_INTERNAL_ERR when a hand-off poll has timed out since creation or the last kf_engine_reset */
 /* After KF_INTERNAL_ERR from kf_engine_check: the error word latches and every later launch of the engine returns at once without output.  kf_engine_reset
  * synchronises, puts the hand-off state back to its initial one and clears the word; the steps since the failure have to be redone. */

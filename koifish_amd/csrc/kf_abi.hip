@@ -1004,8 +1004,9 @@ int kf_engine_create(kf_ctx* c, const kf_engine_desc* d, void* ws, size_t ws_byt
     if (!d || !ws || !out) return fail(KF_INVALID_ARGS, "kf_engine_create: null argument");
     if (c->capturing) return fail(KF_INVALID_ARGS, "kf_engine_create: not while capturing");
     kf::EngineHost* h = nullptr;
-    const int rc = kf::engine_build(d, ws, ws_bytes, c->stream, &h);
-    if (rc != KF_OK) return fail(rc, "kf_engine_create: %s", rc == KF_UNSUPPORTED_DATATYPE ? "shapes / storage not served by the engine" : "bad arguments or HIP failure");
+    const char* why = "";
+    const int rc = kf::engine_build(d, ws, ws_bytes, c->stream, &h, &why);
+    if (rc != KF_OK) return fail(rc, "kf_engine_create: %s", why);
     kf_engine* e = new kf_engine();
     e->h = h;
     *out = e;
@@ -1059,6 +1060,33 @@ int kf_engine_set_embedding(kf_ctx* c, kf_engine* e, const kf_weight* embed_or_n
     if (c->capturing) return fail(KF_INVALID_ARGS, "kf_engine_set_embedding: not while capturing");
     const int rc = kf::engine_set_embedding(e->h, embed_or_null, d_forced);
     if (rc != KF_OK) return fail(rc, "kf_engine_set_embedding: the fused row read takes a bf16 table of the engine's width (other storages keep kf_embed_state)");
+    return KF_OK;
+}
+int kf_engine_served(kf_ctx* c, const kf_engine_desc* d, char* why, size_t why_bytes) {
+    CHKCTX(c);
+    const char* w = "";
+    const int rc = kf::engine_build(d, nullptr, 0, c->stream, nullptr, &w, true);
+    if (why && why_bytes > 0) snprintf(why, why_bytes, "%s", w);
+    if (rc == KF_OK) return KF_OK;
+    return rc == KF_UNSUPPORTED_DATATYPE ? KF_ENGINE_NOT_SERVED : fail(rc, "kf_engine_served: %s", w);
+}
+int kf_engine_tune(kf_ctx* c, kf_engine* e, kf_bf16* x_out, const int32_t* d_state, int pos_bound, int passes, float* us_before, float* us_after) {
+    CHKCTX(c);
+    if (!e || !e->h) return fail(KF_INVALID_ARGS, "kf_engine_tune: null engine");
+    if (c->capturing) return fail(KF_INVALID_ARGS, "kf_engine_tune: not while capturing");
+    kf::engine_set_canonical(e->h, c->canonical);
+    const int rc = kf::engine_tune(e->h, c->stream, x_out, d_state, pos_bound, passes, us_before, us_after);
+    if (rc < 0) return fail(rc, "kf_engine_tune failed with %d (no embedding table set, or a poll timed out)", rc);
+    return rc;
+}
+int kf_engine_stats(kf_ctx* c, kf_engine* e, int pos_bound, kf_engine_statistics* out) {
+    CHKCTX(c);
+    if (!e || !e->h || !out) return fail(KF_INVALID_ARGS, "kf_engine_stats: null argument");
+    int w[14];
+    const int rc = kf::engine_stats(e->h, c->stream, pos_bound, w);
+    if (rc != KF_OK) return fail(rc, "kf_engine_stats: HIP failure");
+    for (int i = 0; i < 6; i++) out->sweeps[i] = w[i], out->delay[i] = w[7 + i];
+    out->polls = w[6], out->tuned = w[13];
     return KF_OK;
 }
 int kf_engine_check(kf_ctx* c, kf_engine* e) {

@@ -254,7 +254,7 @@ __device__ __forceinline__ void eng_poll_stage(const uint32_t* gsrc, const uint1
 // only its own until their tags match and stages them; the caller's barrier behind it makes the vector whole.  A sweep by one wave costs ~43 ns per kilobyte on
 // top of the round trip (scratch/ub_handoff3.hip): eight waves divide that, and a stale piece is re-read alone instead of with the eleven others.
 template <int XCH, int NLD, int NBLK, int NWV, bool F32X = true>
-__device__ __forceinline__ void eng_poll_stage_part(const uint32_t* gsrc, uint32_t tag, u32x4* xs, int wave, int lane, int* ws, bool& dead) {
+__device__ __forceinline__ void eng_poll_stage_part(const uint32_t* gsrc, uint32_t tag, u32x4* xs, int wave, int lane, int* ws, bool& dead, int* nsweeps = nullptr) {
     constexpr int n = NLD * 256, NR = (NLD + NWV - 1) / NWV;
     const __amdgpu_buffer_rsrc_t rs = eng_rsrc(gsrc, (uint32_t)n * 4u);
     const uint32_t tagw = tag << 16;
@@ -268,7 +268,10 @@ __device__ __forceinline__ void eng_poll_stage_part(const uint32_t* gsrc, uint32
         }
 #pragma unroll
         for (int i = 0; i < NR; i++) bad = (wave + i * NWV < NLD) ? tags_bad(g[i], tagw, bad) : bad;
-        if (wave >= NLD || all_good(bad)) break;
+        if (wave >= NLD || all_good(bad)) {
+            if (nsweeps) *nsweeps = spins + 1;
+            break;
+        }
         if (dead || spins > ENG_SPIN_MAX) {
             if (!dead && lane == 0) atomicOr(ws + 1, 1);
             dead = true;
@@ -431,12 +434,16 @@ __device__ __forceinline__ void mv_run(float qb, float qb2, int s0, int cw, int 
 #define ENG_P1_SHARE 1 /* the poller wave computes one of the workgroup's P1 row slots (0: seven waves, wave 0 takes two slots -- its second block of pair words costs 16 more registers and spills) */
 #endif
 #ifndef ENG_KV_LATE
-#define ENG_KV_LATE 1 /* the poller requests the next layer's K / V tiles BEHIND the merge's sweep: loads return in order, so requested in front of it (round 3) the sweep's answer
+#define ENG_KV_LATE 0 /* the poller requests the next layer's K / V tiles BEHIND the merge's sweep: loads return in order, so requested in front of it (round 3) the sweep's answer
                          waited for sixteen HBM lines first */
 #endif
 #ifndef ENG_PREP_POLLER
-#define ENG_PREP_POLLER 1 /* q/k-norm + RoPE by the poller, in the registers its sweep of q | k | v filled (lane = two rotation pairs of one head), prepared heads straight into LDS: the raw
+#define ENG_PREP_POLLER 0 /* q/k-norm + RoPE by the poller, in the registers its sweep of q | k | v filled (lane = two rotation pairs of one head), prepared heads straight into LDS: the raw
                              heads' LDS round trip, a barrier and the three preparing waves' wave-wide fp64 sums leave the chain (round 3: raw heads staged, barrier, waves 0 .. GQ prepare, barrier) */
+#endif
+#ifndef ENG_KV_EARLY
+#define ENG_KV_EARLY 1 /* the poller requests the next layer's K / V tiles IN FRONT of the attention phase, into a second set of registers (it carries no P4 / P5 / P6 blocks): its merge
+                          sweep, ~3 us later, no longer waits for them -- loads return in order (round 3: requested right in front of that sweep) */
 #endif
 #ifndef ENG_COOP
 #define ENG_COOP 1 /* the norm-free vectors (ao, act) are swept by all eight waves */
@@ -834,6 +841,7 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
     if (ENG_PREP_POLLER && GQ * hd <= 256 && a.rope_table) rcs = *reinterpret_cast<const f32x4*>(a.rope_table + (size_t)S.pos * HD + 4 * (lane & (hd / 4 - 1)));
     if (S.has_unit && !S.empty) eng_attn_issue<C>(a, L.lay[0], S, NWV - 1, lane, T, 0);
     int sw[4] = {0, 0, 0, 0};
+    int swt[6] = {0, 0, 0, 0, 0, 0}; /* this step's sweeps of the poller per hand-off (x, q|k|v, slice partials, ao, xB, act): workgroup 0 adds them to the engine's statistics */
     for (int l = 0; l < a.n_layer; l++) {
         const EngLayer& ly = L.lay[l];
         const uint32_t gen = (uint32_t)epoch * (uint32_t)a.n_layer + (uint32_t)l, tag = gen & 0xffffu;
@@ -918,7 +926,10 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
                 }
                 uint32_t bad = q_in ? (((gq0.x ^ tagw) | (gq0.y ^ tagw) | (gq1.x ^ tagw) | (gq1.y ^ tagw)) & 0xffff0000u) : 0u;
                 bad |= (own && (k_in || v_in)) ? (((gk0.x ^ tagw) | (gk0.y ^ tagw) | (gk1.x ^ tagw) | (gk1.y ^ tagw)) & 0xffff0000u) : 0u;
-                if (all_good(bad)) break;
+                if (all_good(bad)) {
+                    swt[1] += spins + 1;
+                    break;
+                }
                 if (dead || spins > ENG_SPIN_MAX) {
                     if (!dead && lane == 0) atomicOr(a.ws + 1, 2);
                     dead = true;
@@ -981,7 +992,10 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
 #pragma unroll
                 for (int r = 0; r < NLQ; r++) bad = (4 * (r * 64 + lane) < GQ * hd) ? tags_bad(g[r], tagw, bad) : bad;
                 bad = kv_in ? tags_bad(gk, tagw, bad) : bad;
-                if (all_good(bad)) break;
+                if (all_good(bad)) {
+                    swt[1] += spins + 1;
+                    break;
+                }
                 if (dead || spins > ENG_SPIN_MAX) {
                     if (!dead && lane == 0) atomicOr(a.ws + 1, 2);
                     dead = true;
@@ -1002,8 +1016,15 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
                 const int ln = l + 1 < a.n_layer ? l + 1 : l;
                 mv_prefetch<P1, NCW1, FMT, S1>(mat1(ln), mat1(ln), S.s1, NWV - 1, lane, S.M1, r1);
             }
+            EngAttnState<C> T2 = T;
+            if (ENG_KV_EARLY && !S.empty) eng_attn_issue<C>(a, L.lay[l + 1 < a.n_layer ? l + 1 : l], S, NWV - 1, lane, T2, 0); /* the next layer's tiles (the last layer asks for its own again) */
             eng_attn_phase<C>(a, L, S, ly, gen, tag, NWV - 1, lane, T, l, wg);
-            if (!S.empty && !(ENG_KV_LATE && S.has_merge)) eng_attn_issue<C>(a, L.lay[l + 1 < a.n_layer ? l + 1 : l], S, NWV - 1, lane, T, 0); /* the next layer's tiles (the last layer asks for its own again) */
+            if (ENG_KV_EARLY) {
+#pragma unroll
+                for (int u = 0; u < EngAttnState<C>::U; u++) T.kk[u] = T2.kk[u], T.vv[u] = T2.vv[u];
+            } else if (!S.empty && !(ENG_KV_LATE && S.has_merge)) {
+                eng_attn_issue<C>(a, L.lay[l + 1 < a.n_layer ? l + 1 : l], S, NWV - 1, lane, T, 0);
+            }
         } else if (P1_SHARE) { /* a workgroup without an attention slice at this position: the same request, nothing to poll in front of it */
             const int ln = l + 1 < a.n_layer ? l + 1 : l;
             mv_prefetch<P1, NCW1, FMT, S1>(mat1(ln), mat1(ln), S.s1, NWV - 1, lane, S.M1, r1);
@@ -1041,8 +1062,9 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
                 __builtin_amdgcn_s_sleep(1);
             }
             ENG_STAMP(0, 11);
+            swt[2] += msw;
             if (DBG && wg == a.dbg_wg && lane == 0) a.dbg[((size_t)l * 2) * 16 + 10] = (unsigned long long)msw;
-            if (ENG_KV_LATE && S.has_unit && !S.empty) eng_attn_issue<C>(a, L.lay[l + 1 < a.n_layer ? l + 1 : l], S, NWV - 1, lane, T, 0); /* the next layer's tiles, behind the sweep */
+            if (ENG_KV_LATE && !ENG_KV_EARLY && S.has_unit && !S.empty) eng_attn_issue<C>(a, L.lay[l + 1 < a.n_layer ? l + 1 : l], S, NWV - 1, lane, T, 0); /* the next layer's tiles, behind the sweep */
             // transpose through LDS: element e's values over the slices contiguous for lane e (slices past nsp: 0)
 #pragma unroll
             for (int r = 0; r < NLM; r++) {
@@ -1095,7 +1117,7 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
         if (ENG_COOP) { /* the ao vector: timed by this wave, swept by all eight */
             if (has4) eng_wait_pub(nullptr, 0, a.delay[3], dead);
             __syncthreads();
-            if (has4) eng_poll_stage_part<XCH, NQD, P4::nBlk, NWV, C::CANON>(a.xch + C::ao, tag, L.xs[1], NWV - 1, lane, a.ws, dead);
+            if (has4) eng_poll_stage_part<XCH, NQD, P4::nBlk, NWV, C::CANON>(a.xch + C::ao, tag, L.xs[1], NWV - 1, lane, a.ws, dead, &sw[1]);
         } else if (has4) {
             eng_poll_stage<XCH, NQD, P4::nBlk, false, false, C::CANON>(a.xch + C::ao, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, &sw[1], nullptr, 0, a.delay[3]);
         }
@@ -1109,14 +1131,21 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
         if (ENG_COOP) {
             if (has6) eng_wait_pub(has5 ? L.pub + 2 : nullptr, l + 1, a.delay[5], dead);
             __syncthreads();
-            if (has6) eng_poll_stage_part<XCH, NF, P6::nBlk, NWV, C::CANON>(a.xch + C::act, tag, L.xs[1], NWV - 1, lane, a.ws, dead);
+            if (has6) eng_poll_stage_part<XCH, NF, P6::nBlk, NWV, C::CANON>(a.xch + C::act, tag, L.xs[1], NWV - 1, lane, a.ws, dead, &sw[3]);
         } else if (has6) {
             eng_poll_stage<XCH, NF, P6::nBlk, false, false, C::CANON>(a.xch + C::act, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, &sw[3], has5 ? L.pub + 2 : nullptr, l + 1, a.delay[5]);
         }
         ENG_STAMP(0, 7);
+        swt[0] += sw[0], swt[3] += sw[1], swt[4] += sw[2], swt[5] += sw[3];
         if (DBG && wg == a.dbg_wg && lane == 0)
             a.dbg[((size_t)l * 2) * 16 + 8] = (unsigned long long)sw[0] | ((unsigned long long)sw[1] << 16) | ((unsigned long long)sw[2] << 32) | ((unsigned long long)sw[3] << 48);
         __syncthreads();
+    }
+    // the engine's statistics (kf_engine_stats): sweeps the pollers of workgroup 0 (cross-XCD view) needed per hand-off, and the layers they cover
+    if (wg == 0 && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) atomicAdd(a.ws + 8 + i, swt[i]);
+        atomicAdd(a.ws + 14, a.n_layer);
     }
 }
 
@@ -1540,6 +1569,10 @@ struct EngineHost {
     size_t xbytes;
     void* ws;
     size_t ws_bytes;
+    // first-sweep delays per attention slice count (the hand-offs' timing changes with the number of slices a launch cuts the context into): [nsp][6], and whether
+    // engine_tune has measured that row on this device (else: the defaults)
+    int delay_tab[KF_ATTN_MAX_SPLITS + 1][6];
+    unsigned char tuned[KF_ATTN_MAX_SPLITS + 1];
 };
 
 // the instantiated model shapes: {GQA group, head_dim, dim, q_dim, ffn}
@@ -1615,21 +1648,29 @@ static int engine_init_state(EngineHost* E, hipStream_t st) {
     char* const loc0 = a.loc;
     char* const end = reinterpret_cast<char*>(E->ws) + E->ws_bytes;
     if (hipMemsetAsync(loc0, 0xff, (size_t)(end - loc0), st) != hipSuccess) return KF_HIP_CHECK;
-    const int init[2] = {1, 0};
+    static const int init[16] = {1, 0}; /* epoch 1, no error, statistics (words 8 .. 14) zero */
     if (hipMemsetAsync(a.loc, 0, 1024, st) != hipSuccess || hipMemcpyAsync(a.ws, init, sizeof(init), hipMemcpyHostToDevice, st) != hipSuccess) return KF_HIP_CHECK;
     return KF_OK;
 }
 
-int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t st, EngineHost** out) {
-    if (!d || !ws || !out || d->n_layer < 1 || !d->layers) return KF_INVALID_ARGS;
-    if (ws_bytes < engine_ws_bytes(d) || ((uintptr_t)ws & 255) != 0) return KF_INVALID_ARGS;
+// why != NULL: *why names the reason of a refusal; dry: validation only (kf_engine_served) -- nothing is allocated, ws may be NULL
+int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t st, EngineHost** out, const char** why, bool dry) {
+    const char* dummy;
+    if (!why) why = &dummy;
+    *why = "bad arguments";
+    if (!d || (!dry && (!ws || !out)) || d->n_layer < 1 || !d->layers) return KF_INVALID_ARGS;
+    if (!dry && (ws_bytes < engine_ws_bytes(d) || ((uintptr_t)ws & 255) != 0)) return KF_INVALID_ARGS;
     const int hd = d->head_dim;
+    *why = "head_dim must be 64 or 128 and n_head a multiple of n_kv";
     if ((hd != 64 && hd != 128) || d->n_kv <= 0 || d->n_head % d->n_kv != 0) return KF_UNSUPPORTED_DATATYPE;
     const int GQ = d->n_head / d->n_kv;
     const int shape_class = engine_shape_class(GQ, hd, d->dim, d->n_head * hd, d->ffn);
+    *why = "model shape not instantiated: the engine's phase plans are compile-time types; built for Qwen3-0.6B (dim 1024, 16/8 heads of 128, ffn 3072) and the 256-wide test shape (dim 256, 4/2 heads of 64, ffn 512)";
     if (!shape_class) return KF_UNSUPPORTED_DATATYPE; /* not one of the instantiated model shapes: the per-layer launches remain */
     int dev = 0, n_cu = 0;
+    *why = "HIP failure";
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1) return KF_HIP_CHECK;
+    *why = "the device has fewer than 256 compute units: one resident workgroup per CU is the engine's premise";
     if (n_cu < ENG_NWG) return KF_UNSUPPORTED_DATATYPE; /* one resident workgroup per CU is the engine's premise */
     n_cu = ENG_NWG;
     EngineHost* E = new EngineHost();
@@ -1640,6 +1681,7 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     a.kv_stride = d->kv_stride;
     a.max_seq = d->max_seq;
     a.eps = d->rms_eps, a.qk_eps = d->qk_eps, a.rope_table = d->rope_table;
+    *why = "rope_table missing, kv_stride not a multiple of 8, or max_seq < 1";
     if (!a.rope_table || (a.kv_stride % 8) != 0 || a.max_seq < 1) {
         delete E;
         return KF_INVALID_ARGS;
@@ -1647,10 +1689,12 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     // phases: every layer must have the same shapes and storage
     const kf_engine_layer& L0 = d->layers[0];
     int fmt = gemv_fmt_of(&L0.w[0]);
+    *why = "layer storage not served: the engine is instantiated for 4-bit PackedQ (RTN, groups of 128) layers; other storages keep the per-layer launches";
     if (fmt != FMT_Q4) { /* the engine is instantiated for the 4-bit PackedQ storage (BASELINE config 2); other storages keep the per-layer launches */
         delete E;
         return KF_UNSUPPORTED_DATATYPE;
     }
+    *why = "a layer's matrices differ from layer 0's in shape, storage, grouping or alignment, or a norm weight / cache pointer is missing";
     bool q4p_ok = fmt == FMT_Q4;
     std::vector<EngLayer> tab(d->n_layer);
     for (int l = 0; l < d->n_layer; l++) {
@@ -1692,6 +1736,11 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
         tab[l].norm_q = (g_u16)(uintptr_t)L.q_norm, tab[l].norm_k = (g_u16)(uintptr_t)L.k_norm;
         tab[l].kcache = (g_u16w)(uintptr_t)L.kcache, tab[l].vcache = (g_u16w)(uintptr_t)L.vcache;
     }
+    if (dry) {
+        delete E;
+        *why = "";
+        return KF_OK;
+    }
     if (fmt == FMT_Q4 && q4p_ok) fmt = FMT_Q4P;
     E->fmt = fmt, E->GQ = GQ, E->hd = hd, E->n_cu = n_cu, E->nwv = ENG_NWV, E->shape_class = shape_class;
     E->canon = 1;
@@ -1707,6 +1756,8 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
            (scratch/eng_ab.py): after the drains were removed 12,8,12,12,12,12 0.455 ms/step, 16,8,12,16,16,16 0.452, 20,12,16,20,20,20 0.464, 24,12,16,24,24,24 0.474 */
         const int dflt[6] = {16, 8, 20, 24, 16, 16};
         for (int i = 0; i < 6; i++) a.delay[i] = dflt[i];
+        for (int n = 0; n <= KF_ATTN_MAX_SPLITS; n++)
+            for (int i = 0; i < 6; i++) E->delay_tab[n][i] = dflt[i];
     }
     // The vectors that cross XCDs live in uncached device memory: an sc1 sweep of a cached (hipMalloc) line costs 75 ns per KB and CU, of an uncached one 43
     // (scratch/ub_handoff3.hip).  The XCD-local vectors (lqkv, lpart) stay in the caller's cached workspace: they are meant to live in that XCD's L2.
@@ -1720,6 +1771,7 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     if (engine_init_state(E, st) != KF_OK ||
         hipMemcpyAsync(const_cast<EngLayer*>(a.layers), tab.data(), tab.size() * sizeof(EngLayer), hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
         engine_release(E);
+        *why = "HIP failure while initialising the workspace";
         return KF_HIP_CHECK;
     }
     // LDS
@@ -1731,10 +1783,12 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     smem = (smem + 15) & ~(size_t)15;
     if (smem > 160 * 1024) {
         engine_release(E);
+        *why = "the layer table and the staging buffers exceed 160 KB of LDS (too many layers)";
         return KF_UNSUPPORTED_DATATYPE;
     }
     E->smem = smem;
     *out = E;
+    *why = "";
     return KF_OK;
 }
 void engine_free(EngineHost* E) { engine_release(E); }
@@ -1751,8 +1805,9 @@ int engine_debug_enable(EngineHost* E, int wg) {
     a.dbg_wg = wg;
     return KF_OK;
 }
-void engine_set_delays(EngineHost* E, const int* d6) {
-    for (int i = 0; i < 6; i++) E->args.delay[i] = d6[i];
+void engine_set_delays(EngineHost* E, const int* d6) { /* every slice count */
+    for (int n = 0; n <= KF_ATTN_MAX_SPLITS; n++)
+        for (int i = 0; i < 6; i++) E->delay_tab[n][i] = d6[i];
 }
 int engine_debug_read(EngineHost* E, unsigned long long* h_out, int n_words) {
     if (!E->args.dbg) return 0;
@@ -1820,6 +1875,7 @@ int engine_step(EngineHost* E, hipStream_t st, const uint16_t* x_in, uint16_t* x
     const int NW = (E->GQ <= 2 && chunk > 128) ? 8 : 4;
     if (NW != 4 || E->n_kv * nsp > E->n_cu) return 1; /* the 8-wave slice form and more slices than workgroups are not restated here */
     a.nsp = nsp, a.chunk = chunk;
+    for (int i = 0; i < 6; i++) a.delay[i] = E->delay_tab[nsp][i];
     int e = (E->n_head * E->hd + E->n_cu - 1) / E->n_cu, me = 1;
     while (me < e) me <<= 1;
     if (me > E->hd || me > 64) return 1;
@@ -1863,6 +1919,85 @@ int engine_error_word(EngineHost* E, hipStream_t st, int* h_err) {
     return KF_OK;
 }
 void engine_set_canonical(EngineHost* E, int on) { E->canon = on ? 1 : 0; }
+
+// ---- self-calibration of the first-sweep delays.  The hand-off protocol is correct for ANY delay -- a sweep that comes too early is repeated -- but a
+// repeated sweep costs its whole round trip on the critical path and a late one its lateness, and the best values depend on the device (clocks, fabric) and on how many
+// slices the context is cut into.  engine_tune times the layers-only launch at the position the decode state holds (it reads the state's token and writes that position's
+// K / V rows, as the real step is about to: idempotent, nothing advances) and walks the six delays by coordinate descent, smallest mean launch time wins.
+static float eng_time_launches(EngineHost* E, hipStream_t st, uint16_t* x_out, const int32_t* d_state, int pos_bound, int reps, hipEvent_t e0, hipEvent_t e1) {
+    if (hipEventRecord(e0, st) != hipSuccess) return -1.f;
+    for (int i = 0; i < reps; i++)
+        if (engine_step(E, st, nullptr, x_out, d_state, pos_bound, 0, 1) != KF_OK) return -1.f;
+    float ms = 0.f;
+    if (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return -1.f;
+    return ms * 1e3f / (float)reps;
+}
+int engine_tune(EngineHost* E, hipStream_t st, uint16_t* x_out, const int32_t* d_state, int pos_bound, int passes, float* us_before, float* us_after) {
+    if (!E->args.emb || !x_out || !d_state || pos_bound < 0 || pos_bound >= E->args.max_seq) return KF_INVALID_ARGS;
+    const int nsp = attn_splits(pos_bound, E->n_kv);
+    if (nsp < 1 || nsp > KF_ATTN_MAX_SPLITS) return KF_INVALID_ARGS;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess) return KF_HIP_CHECK;
+    if (hipEventCreate(&e1) != hipSuccess) {
+        (void)hipEventDestroy(e0);
+        return KF_HIP_CHECK;
+    }
+    int* d = E->delay_tab[nsp];
+    int saved[6];
+    for (int i = 0; i < 6; i++) saved[i] = d[i];
+    constexpr int REPS = 6;
+    auto measure = [&]() { /* the smaller of two batches: the first launches after a change of rhythm run slow */
+        const float a0 = eng_time_launches(E, st, x_out, d_state, pos_bound, REPS, e0, e1), a1 = eng_time_launches(E, st, x_out, d_state, pos_bound, REPS, e0, e1);
+        return (a0 < 0.f || a1 < 0.f) ? -1.f : (a0 < a1 ? a0 : a1);
+    };
+    int rc = KF_OK;
+    float best = measure();
+    if (us_before) *us_before = best;
+    if (best < 0.f) rc = 1; /* not served at this position (or a HIP failure): nothing to tune */
+    static const int kStep[3] = {8, 4, 2};
+    for (int pass = 0; rc == KF_OK && pass < passes && pass < 3; pass++) {
+        for (int i = 0; rc == KF_OK && i < 6; i++) {
+            const int cur = d[i];
+            int best_v = cur;
+            for (int s = -2; s <= 2; s++) {
+                if (s == 0) continue;
+                const int v = cur + s * kStep[pass];
+                if (v < 0 || v > 96) continue;
+                d[i] = v;
+                const float t = measure();
+                if (t < 0.f) {
+                    rc = KF_HIP_CHECK;
+                    break;
+                }
+                if (t < best * 0.998f) best = t, best_v = v; /* keep the old value unless the gain is above the timing noise */
+            }
+            d[i] = best_v;
+        }
+    }
+    int err = 0;
+    if (engine_error_word(E, st, &err) != KF_OK || err != 0 || rc != KF_OK) { /* a timed-out poll while tuning: the defaults stay, the caller sees the error word through engine_check */
+        for (int i = 0; i < 6; i++) d[i] = saved[i];
+        if (rc == KF_OK) rc = KF_INTERNAL_ERR;
+    } else {
+        E->tuned[nsp] = 1;
+    }
+    if (us_after) *us_after = best;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+// statistics since creation / the last reset: out[0..5] = sweeps the poller of workgroup 0 issued per hand-off (x, q|k|v, slice partials, ao, xB, act), out[6] = polls per
+// hand-off (layers stepped), out[7..12] = the delays in use at `pos_bound`, out[13] = 1 when engine_tune measured them
+int engine_stats(EngineHost* E, hipStream_t st, int pos_bound, int* out14) {
+    int w[16];
+    if (hipMemcpyAsync(w, E->args.ws, sizeof(w), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return KF_HIP_CHECK;
+    for (int i = 0; i < 7; i++) out14[i] = w[8 + i];
+    int nsp = attn_splits(pos_bound < 0 ? 0 : pos_bound, E->n_kv);
+    if (nsp < 1 || nsp > KF_ATTN_MAX_SPLITS) nsp = 1;
+    for (int i = 0; i < 6; i++) out14[7 + i] = E->delay_tab[nsp][i];
+    out14[13] = E->tuned[nsp];
+    return KF_OK;
+}
 // after a timed-out poll (the error word latches and every later launch returns at once): all granules back to "not written", epoch 1, error word cleared
 int engine_reset(EngineHost* E, hipStream_t st) {
     const int rc = engine_init_state(E, st);

@@ -140,12 +140,14 @@ struct Knobs {
 };
 extern Knobs g_knobs;
 size_t engine_ws_bytes(const kf_engine_desc* d);
-int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t st, EngineHost** out);
+int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t st, EngineHost** out, const char** why = nullptr, bool dry = false);
+int engine_tune(EngineHost* E, hipStream_t st, uint16_t* x_out, const int32_t* d_state, int pos_bound, int passes, float* us_before, float* us_after);
+int engine_stats(EngineHost* E, hipStream_t st, int pos_bound, int* out14);
 int engine_step(EngineHost* E, hipStream_t st, const uint16_t* x_in, uint16_t* x_out, const int32_t* d_state, int pos_bound, int with_head = 0, int n_steps = 1); /* 1: not served */
 int engine_set_head(EngineHost* E, const kf_weight* w, const uint16_t* norm_w, uint16_t* logits, int32_t* d_tokens_out);
 int engine_set_embedding(EngineHost* E, const kf_weight* w, const int32_t* d_forced);
 int engine_error_word(EngineHost* E, hipStream_t st, int* h_err);
-void engine_set_canonical(EngineHost* E, int on); /* the mat-vec phases: canonical order (default) or the v_dot2c forms */
+void engine_set_canonical(EngineHost* E, int on); /* every phase: canonical order (1, the default) or the v_dot2c / fp32 forms */
 int engine_reset(EngineHost* E, hipStream_t st); /* after a timed-out poll: exchange state re-initialised, error word cleared */
 void engine_free(EngineHost* E);
 int engine_debug_read(EngineHost* E, unsigned long long* h_out, int n_words);

@@ -345,10 +345,16 @@ int Fish::EnsureEngine() {
         FFN* m = ffn[l].get();
         SLP* s[7] = {&a->Q, &a->K, &a->V, &a->proj_cat, &m->gate, &m->up, &m->down};
         for (int j = 0; j < 7; j++) {
-            if (!s[j]->w || s[j]->b) return KF_ENGINE_NOT_SERVED;
+            if (!s[j]->w || s[j]->b) {
+                engine_why = "a layer matrix is missing or carries a bias";
+                return KF_ENGINE_NOT_SERVED;
+            }
             L[l].w[j] = s[j]->w->desc();
         }
-        if (!a->norm.w || !m->norm.w || m->n_hot >= 0) return KF_ENGINE_NOT_SERVED; /* the sparse forward keeps the per-layer launches */
+        if (!a->norm.w || !m->norm.w || m->n_hot >= 0) { /* the sparse forward keeps the per-layer launches */
+            engine_why = m->n_hot >= 0 ? "sparse forward (hot-row lists): the per-layer launches serve it" : "a norm weight is missing";
+            return KF_ENGINE_NOT_SERVED;
+        }
         L[l].norm_in = ToX(a->norm.w), L[l].norm_post = ToX(m->norm.w);
         L[l].q_norm = a->normQ.w ? ToX(a->normQ.w) : nullptr, L[l].k_norm = a->normK.w ? ToX(a->normK.w) : nullptr;
         L[l].kcache = reinterpret_cast<floatX*>(cache.Get(KVCache::KV_KEY, l, 0));
@@ -360,6 +366,13 @@ int Fish::EnsureEngine() {
     d.kv_stride = config.n_head_kv * config.head_dim;
     d.max_seq = config.n_ctx;
     d.rms_eps = config.rms_eps, d.qk_eps = config.qk_eps, d.rope_table = rope_table, d.layers = L.data();
+    {
+        char why[320];
+        why[0] = 0;
+        const int served = kf_engine_served(ctx, &d, why, sizeof(why));
+        engine_why = why;
+        if (served != KF_OK) return KF_ENGINE_NOT_SERVED;
+    }
     const size_t bytes = kf_engine_workspace_bytes(&d);
     if (kf_malloc(ctx, bytes, &engine_ws) != KF_OK) return KF_OUTOF_GPUMEMORY;
     if (kf_engine_create(ctx, &d, engine_ws, bytes, &engine) != KF_OK) {
@@ -584,6 +597,14 @@ int Fish::RunSteps(int pos, int n, bool use_graph) {
             int m = 1;
             while (i + m < n && m < kStepsPerLaunch && bucket_of(pos + i + m) == b) m++;
             tok_pos = p;
+            if (engine_autotune > 0 && engine_embed) { /* once per position bucket: the hand-off delays measured at the first step inside it */
+                if (bucket_tuned.empty()) bucket_tuned.assign((size_t)bucket_of(config.n_ctx - 1) + 1, 0);
+                if (!bucket_tuned[b]) {
+                    bucket_tuned[b] = 1;
+                    const int trc = kf_engine_tune(ctx, engine, ToX(x), d_state, pos_bound(), engine_autotune, nullptr, nullptr);
+                    if (trc < 0) return trc;
+                }
+            }
             const int rc = kf_engine_steps_head(ctx, engine, ToX(x), d_state, pos_bound(), m);
             if (rc < 0) return rc;
             if (rc != KF_OK) break; /* not served at this position: the per-step path below takes the rest */
@@ -815,6 +836,41 @@ int kfh_engine_set_delays(void* h, const int* d6) {
     for (auto& g : f->graphs)
         if (g) kf_graph_destroy(g), g = nullptr;
     return f->engine ? kfdbg_engine_set_delays(f->engine, d6) : -1;
+}
+// why the engine does not serve this model ("" when it does; valid once a step has been tried or kfh_engine_stamps_enable / kfh_engine_only forced the build)
+const char* kfh_engine_why(void* h) {
+    Fish* f = reinterpret_cast<Fish*>(h);
+    if (f->engine_state == 0) f->EnsureEngine();
+    return f->engine_why.c_str();
+}
+// kf_engine_tune at the position the decode state holds; us[0] / us[1] = mean launch time before / after
+int kfh_engine_tune(void* h, int passes, float* us2) {
+    Fish* f = reinterpret_cast<Fish*>(h);
+    if (f->engine_state == 0) f->EnsureEngine();
+    if (f->engine_state <= 0 || !f->engine_embed) return KF_ENGINE_NOT_SERVED;
+    int32_t st[4];
+    KF_TRY(kf_d2h(f->ctx, st, f->d_state, 16));
+    f->tok_pos = st[1];
+    float b = 0.f, a = 0.f;
+    const int rc = kf_engine_tune(f->ctx, f->engine, ToX(f->x), f->d_state, f->pos_bound(), passes, &b, &a);
+    if (us2) us2[0] = b, us2[1] = a;
+    return rc;
+}
+int kfh_set_engine_autotune(void* h, int passes) {
+    Fish* f = reinterpret_cast<Fish*>(h);
+    f->engine_autotune = passes < 0 ? 0 : passes;
+    return KF_OK;
+}
+// statistics of the engine's hand-offs at `pos` (kf_engine_statistics as 14 ints: sweeps[6], polls, delay[6], tuned)
+int kfh_engine_stats(void* h, int pos, int32_t* out14) {
+    Fish* f = reinterpret_cast<Fish*>(h);
+    if (!f->engine) return KF_ENGINE_NOT_SERVED;
+    kf_engine_statistics s;
+    f->tok_pos = pos;
+    KF_TRY(kf_engine_stats(f->ctx, f->engine, f->pos_bound(), &s));
+    for (int i = 0; i < 6; i++) out14[i] = s.sweeps[i], out14[7 + i] = s.delay[i];
+    out14[6] = s.polls, out14[13] = s.tuned;
+    return KF_OK;
 }
 // n launches of the engine alone at the position d_state holds (bench.py times the kernel with events around this); the residual stream is
 // re-read from the embedding each time so that the values stay those of a real step

@@ -223,6 +223,9 @@ struct Fish {
     void DropEngine();          // weights / norms / caches changed: the engine's device table and the captured graphs hold stale pointers
     int EngineCheck();          // synchronises; a timed-out hand-off is reported ONCE (KF_INTERNAL_ERR), the engine reset so that later steps run again
     int engine_steps = 0;  // steps enqueued (or captured) through the engine
+    std::string engine_why;  // why the engine does not serve this model (kf_engine_served), "" when it does
+    int engine_autotune = 0;  // > 0: passes of kf_engine_tune run once per position bucket, at the first step inside it (kfh_set_engine_autotune)
+    std::vector<unsigned char> bucket_tuned;
     KVCache cache;
     MemBuffer gBUFF;
     TokenEmbed embed;

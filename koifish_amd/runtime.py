@@ -460,6 +460,28 @@ class Qwen3:
         """1 (the library default): the decode kernels sum in the canonical order the CPU oracle shares (bit-exact logits, ids and KV rows); 0: the v_dot2c_f32_bf16 / fp32 forms"""
         L.check(self.host.kfh_set_canonical(self.h, int(bool(on))), "kfh_set_canonical")
 
+    def engine_why(self):
+        """why the persistent engine does not serve this model ("" when it does)"""
+        self.host.kfh_engine_why.restype = C.c_char_p
+        return self.host.kfh_engine_why(self.h).decode()
+
+    def engine_tune(self, passes=2):
+        """kf_engine_tune at the position the decode state holds: (mean launch us before, after)"""
+        us = (C.c_float * 2)()
+        L.check(self.host.kfh_engine_tune(self.h, int(passes), us), "kfh_engine_tune")
+        return float(us[0]), float(us[1])
+
+    def set_engine_autotune(self, passes):
+        """> 0: the hand-off delays are measured once per position bucket, at the first multi-step launch inside it (passes of kf_engine_tune)"""
+        L.check(self.host.kfh_set_engine_autotune(self.h, int(passes)), "kfh_set_engine_autotune")
+
+    def engine_stats(self, pos):
+        """kf_engine_stats: {'sweeps_per_poll': [6], 'polls', 'delay': [6], 'tuned'} for the hand-offs x, q|k|v, slice partials, ao, xB, act"""
+        w = (C.c_int32 * 14)()
+        L.check(self.host.kfh_engine_stats(self.h, int(pos), w), "kfh_engine_stats")
+        polls = max(int(w[6]), 1)
+        return {"sweeps_per_poll": [round(int(w[i]) / polls, 3) for i in range(6)], "polls": int(w[6]), "delay": [int(w[7 + i]) for i in range(6)], "tuned": int(w[13])}
+
     def engine_steps(self):
         """steps enqueued or captured through the engine so far (-1: the engine does not serve this model's shapes / storage)"""
         return int(self.host.kfh_engine_steps(self.h))

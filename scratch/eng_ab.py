@@ -27,6 +27,8 @@ for kv in os.environ.get("KF_KNOBS", "").split():
     k, v = kv.split("=")
     m.hip.kfdbg_set_knob.argtypes = [C.c_char_p, C.c_long]
     assert m.hip.kfdbg_set_knob(k.encode(), int(v)) == 0
+if os.environ.get("TUNE"):
+    m.set_engine_autotune(int(os.environ["TUNE"]))
 pos0 = 1900
 m.set_state(int(forced[pos0]), pos0)
 m.run_steps(pos0, 20, True)   # warm: graph of the bucket
@@ -51,7 +53,8 @@ m._ctx.record(e1)
 m.sync()
 us = m._ctx.elapsed_ms(e0, e1) / 50 * 1e3
 m.engine_check()
-print("RESULT %%.4f %%.1f %%d" %% (dt, us, dig))
+st = m.engine_stats(2040)
+print("RESULT %%.4f %%.1f %%d %%s" %% (dt, us, dig, ("delays=%%s tuned=%%d sweeps/poll=%%s" %% (",".join(map(str, st["delay"])), st["tuned"], ",".join("%%.2f" %% v for v in st["sweeps_per_poll"]))).replace(" ", "_")))
 """ % (HERE,)
 
 
@@ -68,8 +71,8 @@ def main():
         if not res:
             print("%-60s FAILED: %s" % (s, (out.stderr or out.stdout)[-400:]))
             continue
-        dt, us, dig = res[-1].split()[1:]
-        print("%-60s %s ms/step (%.0f tok/s)  engine-only %s us  ids digest %s" % (s, dt, 1e3 / float(dt), us, dig), flush=True)
+        dt, us, dig, st = res[-1].split()[1:]
+        print("%-60s %s ms/step (%.0f tok/s)  engine-only %s us  ids digest %s  %s" % (s, dt, 1e3 / float(dt), us, dig, st), flush=True)
 
 
 if __name__ == "__main__":
