@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--sparse", type=float, default=0.0, help="BASELINE config 5 side measurement: this fraction of every layer's FFN rows hot (seeded mask, seed 5 + layer), the rest skipped (D_matmul_sparse); use with --layers 1bit")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--engine", type=int, default=-1, help="1: the layer loop as one persistent launch (kf_engine_*); 0: five launches per layer; -1: the library default")
+    ap.add_argument("--autotune", type=int, default=2, help="passes of kf_engine_tune (self-calibrated first-sweep delays of the engine's hand-offs) per position bucket; 0 = the built-in delays")
     ap.add_argument("--streams", type=int, default=0, help="side measurement after the timed region: this many INDEPENDENT decoders (own weights, own "
                     "KV cache, own HIP stream) running concurrently on the GPU over the same positions; 0/1 = skip.  Never part of `value`.")
     ap.add_argument("--tp-exchange", default="p2p", choices=["p2p", "rccl"], help="--config qwen3-32b --gpus N > 1 runs tensor parallel TP = N (BASELINE config 4): "
@@ -95,6 +96,7 @@ def main():
             hot = np.zeros(cfg["ffn"], dtype=np.int32)
             hot[np.random.default_rng(5 + l).permutation(cfg["ffn"])[: max(int(cfg["ffn"] * args.sparse), 16)]] = 1
             m.set_hot(l, hot)
+    m.set_engine_autotune(args.autotune)   # kf_engine_tune once per position bucket, at the first multi-step launch inside it (set-up span: never inside the timed region)
     if args.engine >= 0:
         m.set_engine(bool(args.engine))
     elif "KF_BENCH_DEVICE" in os.environ and world > 1:
@@ -200,6 +202,13 @@ def main():
             m.set_state(int(m.tokens_out(S)[pos - 1]) if pos > 0 else int(forced[0]), pos)
             run_span(pos, K)   # the ids, logits and KV rows the legs below read are those of the timed (canonical) run again
             torch.cuda.synchronize()
+        try:   # sweeps per poll of the engine's six hand-offs over everything run so far, and the delays in use in the timed bucket (kf_engine_stats)
+            if m.engine_steps() > 0:
+                st = m.engine_stats(timed_positions[-1])
+                out["engine_handoffs"] = dict(st, order="x (P1), q|k|v (P2), slice partials (P3), ao (P4), xB (P5), act (P6)", delays_unit="s_sleep(1) trips behind the own publish",
+                                              autotune_passes=args.autotune)
+        except Exception as e:
+            out["engine_handoffs"] = {"error": repr(e)[:160]}
         if args.lean:
             m.engine_check()
             out["config"]["decode_path"] = "persistent engine, one launch per token" if m.engine_steps() > 0 else "per-layer launches: 5 per layer"

@@ -398,6 +398,8 @@ typedef struct kf_engine_layer {
     kf_weight w[7];
     const kf_bf16 *norm_in, *norm_post, *q_norm, *k_norm; /* q_norm / k_norm may be NULL */
     kf_bf16 *kcache, *vcache;                            /* layer base; row t at t*kv_stride elements */
+    const int32_t* hot_ffn; /* sparse forward (D_matmul_sparse, GST_float.cpp:306-318): CS_Picker's hot[ffn] on the DEVICE, 1 = the gate / up row is computed, anything else = 0
+                               (SwiGLU(0, 0) = 0: that element of the FFN's hidden vector is zero); cold rows are never read.  NULL: dense.  Read once per launch. */
 } kf_engine_layer;
 typedef struct kf_engine_desc {
     int32_t n_layer, dim, n_head, n_kv, head_dim, ffn, kv_stride;

@@ -53,6 +53,7 @@ constexpr int ENG_SPIN_MAX = 1 << 17;     /* sweeps before a poll gives up (~0.1
 typedef const u32x4 KF_GLOBAL* g_u32x4;
 typedef const uint16_t KF_GLOBAL* g_u16;
 typedef uint16_t KF_GLOBAL* g_u16w;
+typedef const int32_t KF_GLOBAL* g_i32;
 struct EngMat {
     g_u32x4 w;
     g_u16 zero;
@@ -62,6 +63,7 @@ struct EngLayer {
     EngMat m[7]; /* q k v o gate up down */
     g_u16 norm_in, norm_post, norm_q, norm_k;
     g_u16w kcache, vcache; /* layer base */
+    g_i32 hot;             /* sparse forward: CS_Picker's hot[ffn] (1 = the gate / up row is computed, D_matmul_sparse); NULL: dense */
 };
 struct EngPlan { /* host copy of one mat-vec phase: the geometry gemv_launch would pick for the same matrices (checked against PlanT) */
     int K, nBlk, lpr_log2, iters, gshift, njobs;
@@ -377,8 +379,9 @@ __device__ __forceinline__ MvAt mv_at(int k, int s0, int cw, int lane, int Mj) {
 }
 // unconditional loads of the wave's blocks (clamped indices; masks are applied at the multiply): m = the matrix of the workgroup's rows, m2 = the
 // paired one (up_proj beside gate_proj)
+// hotbits: the sparse forward's mask of this workgroup's rows (bit r = row s0 * RPS + r is computed): a cold row's blocks are never read (row 0's stand in; the product is masked)
 template <class PL, int NCW, int FMT, int MAXS>
-__device__ __forceinline__ void mv_prefetch(const EngMat m, const EngMat m2, int s0, int cw, int lane, int Mj, MvRegs<PL::PAIRED, MAXS>& R) {
+__device__ __forceinline__ void mv_prefetch(const EngMat m, const EngMat m2, int s0, int cw, int lane, int Mj, MvRegs<PL::PAIRED, MAXS>& R, uint32_t hotbits = 0xffffffffu) {
     constexpr bool GAMA = BlockDot<FMT>::HAS_GAMA;
     constexpr int gshift = FMT >= FMT_Q4 ? (FMT == FMT_Q4 || FMT == FMT_Q4P ? 2 : (FMT == FMT_Q2 ? 1 : 0)) : 0; /* 128-weight groups */
 #pragma unroll
@@ -386,6 +389,7 @@ __device__ __forceinline__ void mv_prefetch(const EngMat m, const EngMat m2, int
         const MvAt q = mv_at<PL, NCW>(k, s0, cw, lane, Mj);
         int row = q.row < Mj ? q.row : Mj - 1;
         row = row > 0 ? row : 0;
+        row = ((hotbits >> ((q.row - s0 * PL::RPS) & 31)) & 1u) ? row : 0;
         const int col = q.col < PL::nBlk ? q.col : PL::nBlk - 1;
         const uint32_t bidx = (uint32_t)row * (uint32_t)PL::nBlk + (uint32_t)col;
         R.w[k] = __builtin_nontemporal_load(m.w + bidx);
@@ -398,8 +402,10 @@ __device__ __forceinline__ void mv_prefetch(const EngMat m, const EngMat m2, int
     }
 }
 // epi(row, v, v2) runs in the lane that owns a finished row (row counted inside the matrix)
-template <class PL, int NCW, int FMT, int MAXS, bool CANON, typename Epi>
-__device__ __forceinline__ void mv_run(float qb, float qb2, int s0, int cw, int lane, int Mj, const MvRegs<PL::PAIRED, MAXS>& R, const u32x4* xs, Epi&& epi) {
+// F32X: the activations are staged as fp32 chunks (the canonical 4-bit forms, BlockDotF); tab: the 1-bit selector table (FMT_Q1T); hotbits: as for mv_prefetch -- a cold row's
+// products are masked, its epilogue runs on zeros (D_matmul_sparse: val = 0)
+template <class PL, int NCW, int FMT, int MAXS, bool CANON, bool F32X, typename Epi>
+__device__ __forceinline__ void mv_run(float qb, float qb2, int s0, int cw, int lane, int Mj, const MvRegs<PL::PAIRED, MAXS>& R, const u32x4* xs, const u32x4* tab, uint32_t hotbits, Epi&& epi) {
     /* CANON: the canonical order (oracle/kf_oracle.c section 4c), one v_pk_fma_f32 per weight pair on fp32 operands; same lanes / chains / tree as gemv_kernel either way */
     acc_t<CANON> acc{}, acc2{};
 #pragma unroll
@@ -409,17 +415,20 @@ __device__ __forceinline__ void mv_run(float qb, float qb2, int s0, int cw, int 
         const MvAt q = mv_at<PL, NCW>(k, s0, cw, lane, Mj);
         const int col = q.col < PL::nBlk ? q.col : PL::nBlk - 1;
         if (it == 0) acc = acc_t<CANON>{}, acc2 = acc_t<CANON>{};
+        const bool on = q.ok && ((hotbits >> ((q.row - s0 * PL::RPS) & 31)) & 1u);
         const float st = bf2f(R.st[k]);
         acc_t<CANON> r;
-        if constexpr (CANON) r = BlockDotF<FMT>::run(R.w[k], reinterpret_cast<const f32x4*>(xs), col, PL::nBlk, st, bf2f(R.ze[k]), -(qb * st), acc);
-        else r = BlockDot<FMT, false>::run(R.w[k], xs, col, PL::nBlk, st, bf2f(R.ze[k]), -(qb * st), acc);
-        acc = acc_pick(q.ok, r, acc);
+        if constexpr (F32X) r = BlockDotF<FMT>::run(R.w[k], reinterpret_cast<const f32x4*>(xs), col, PL::nBlk, st, bf2f(R.ze[k]), -(qb * st), acc);
+        else if constexpr (FMT == FMT_Q1T) r = BlockDot<FMT, CANON>::run_tab(R.w[k], xs, col, PL::nBlk, st, bf2f(R.ze[k]), -(qb * st), tab, acc);
+        else r = BlockDot<FMT, CANON>::run(R.w[k], xs, col, PL::nBlk, st, bf2f(R.ze[k]), -(qb * st), acc);
+        acc = acc_pick(on, r, acc);
         if (PL::PAIRED) {
             const float st2 = bf2f(R.st2[k]);
             acc_t<CANON> r2;
-            if constexpr (CANON) r2 = BlockDotF<FMT>::run(R.w2[k], reinterpret_cast<const f32x4*>(xs), col, PL::nBlk, st2, bf2f(R.ze2[k]), -(qb2 * st2), acc2);
-            else r2 = BlockDot<FMT, false>::run(R.w2[k], xs, col, PL::nBlk, st2, bf2f(R.ze2[k]), -(qb2 * st2), acc2);
-            acc2 = acc_pick(q.ok, r2, acc2);
+            if constexpr (F32X) r2 = BlockDotF<FMT>::run(R.w2[k], reinterpret_cast<const f32x4*>(xs), col, PL::nBlk, st2, bf2f(R.ze2[k]), -(qb2 * st2), acc2);
+            else if constexpr (FMT == FMT_Q1T) r2 = BlockDot<FMT, CANON>::run_tab(R.w2[k], xs, col, PL::nBlk, st2, bf2f(R.ze2[k]), -(qb2 * st2), tab, acc2);
+            else r2 = BlockDot<FMT, CANON>::run(R.w2[k], xs, col, PL::nBlk, st2, bf2f(R.ze2[k]), -(qb2 * st2), acc2);
+            acc2 = acc_pick(on, r2, acc2);
         }
         if (it == PL::iters - 1) {
             const float v = group_sum(acc_join(acc), PL::lpr_log2);
@@ -433,90 +442,36 @@ __device__ __forceinline__ void mv_run(float qb, float qb2, int s0, int cw, int 
 #ifndef ENG_P1_SHARE
 #define ENG_P1_SHARE 1 /* the poller wave computes one of the workgroup's P1 row slots (0: seven waves, wave 0 takes two slots -- its second block of pair words costs 16 more registers and spills) */
 #endif
-#ifndef ENG_KV_LATE
-#define ENG_KV_LATE 0 /* the poller requests the next layer's K / V tiles BEHIND the merge's sweep: loads return in order, so requested in front of it (round 3) the sweep's answer
-                         waited for sixteen HBM lines first */
-#endif
-#ifndef ENG_PREP_POLLER
-#define ENG_PREP_POLLER 0 /* q/k-norm + RoPE by the poller, in the registers its sweep of q | k | v filled (lane = two rotation pairs of one head), prepared heads straight into LDS: the raw
-                             heads' LDS round trip, a barrier and the three preparing waves' wave-wide fp64 sums leave the chain (round 3: raw heads staged, barrier, waves 0 .. GQ prepare, barrier) */
-#endif
-#ifndef ENG_KV_EARLY
-#define ENG_KV_EARLY 1 /* the poller requests the next layer's K / V tiles IN FRONT of the attention phase, into a second set of registers (it carries no P4 / P5 / P6 blocks): its merge
-                          sweep, ~3 us later, no longer waits for them -- loads return in order (round 3: requested right in front of that sweep) */
-#endif
 #ifndef ENG_COOP
 #define ENG_COOP 1 /* the norm-free vectors (ao, act) are swept by all eight waves */
 #endif
-#ifndef ENG_DEQ_MASK
-#define ENG_DEQ_MASK 15 /* phases (1 P1, 2 P4, 4 P5, 8 P6) whose blocks are dequantised in front of the barrier */
-#endif
-#ifndef ENG_WIDEN
-#define ENG_WIDEN 0 /* canonical order: phases (1 P1, 2 P4, 4 P5, 8 P6) whose dequantised weights are widened to fp32 pairs in front of the barrier too (behind it: one v_pk_fma_f32 per
-                       pair, as many instructions as v_dot2c); 32 registers per block: all four phases spill (P6 alone holds 3 blocks per lane) */
-#endif
-// the wave's blocks as bf16 pair words (BlockPrep): formed while the wave waits for the phase's activations.  WIDE (canonical order): every pair word as the two
-// fp32 operands of its v_pk_fma_f32
-template <bool PAIRED, int MAXS, bool WIDE = false>
+// the wave's blocks as bf16 pair words (BlockPrep): formed while the wave waits for the phase's activations.  (Round 4 also widened them to the fp32 operand pairs of the
+// canonical v_pk_fma_f32 in front of the barrier: 32 registers per block -- the kernel spilled 30 - 180 registers and ran 20 % slower; the two conversions per pair stay behind
+// the barrier, where they fill the bubbles of the dependent fma chains.)
+template <bool PAIRED, int MAXS>
 struct MvDeq {
-    uint32_t p[WIDE ? 1 : MAXS][16], p2[PAIRED && !WIDE ? MAXS : 1][16];
-    f32x2_t f[WIDE ? MAXS : 1][16], f2[PAIRED && WIDE ? MAXS : 1][16];
+    uint32_t p[MAXS][16], p2[PAIRED ? MAXS : 1][16];
 };
-template <class PL, int NCW, int FMT, int MAXS, bool WIDE>
-__device__ __forceinline__ void mv_dequant(float qb, float qb2, int cw, int lane, const MvRegs<PL::PAIRED, MAXS>& R, MvDeq<PL::PAIRED, MAXS, WIDE>& D) {
+template <class PL, int NCW, int FMT, int MAXS>
+__device__ __forceinline__ void mv_dequant(float qb, float qb2, int cw, int lane, const MvRegs<PL::PAIRED, MAXS>& R, MvDeq<PL::PAIRED, MAXS>& D) {
 #pragma unroll
     for (int k = 0; k < MAXS; k++) {
         if (cw + (k / PL::iters) * NCW >= PL::spg) continue; /* wave-uniform: this wave has no such slot */
         const float st = bf2f(R.st[k]);
-        if constexpr (WIDE) {
-            uint32_t t[16];
-            BlockPrep<FMT>::prep(R.w[k], st, bf2f(R.ze[k]), -(qb * st), lane, t);
+        BlockPrep<FMT>::prep(R.w[k], st, bf2f(R.ze[k]), -(qb * st), lane, D.p[k]);
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                float lo = bf_lo(t[i]), hi = bf_hi(t[i]);
-                asm volatile("" : "+v"(lo), "+v"(hi)); /* formed HERE, in front of the barrier, not sunk to the first use behind it */
-                D.f[k][i] = f32x2_t{lo, hi};
-            }
-            if (PL::PAIRED) {
-                const float st2 = bf2f(R.st2[k]);
-                BlockPrep<FMT>::prep(R.w2[k], st2, bf2f(R.ze2[k]), -(qb2 * st2), lane, t);
+        for (int i = 0; i < 16; i++) asm volatile("" : "+v"(D.p[k][i])); /* formed HERE, in front of the barrier, not sunk to the first use behind it */
+        if (PL::PAIRED) {
+            const float st2 = bf2f(R.st2[k]);
+            BlockPrep<FMT>::prep(R.w2[k], st2, bf2f(R.ze2[k]), -(qb2 * st2), lane, D.p2[k]);
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    float lo = bf_lo(t[i]), hi = bf_hi(t[i]);
-                    asm volatile("" : "+v"(lo), "+v"(hi));
-                    D.f2[k][i] = f32x2_t{lo, hi};
-                }
-            }
-        } else {
-            BlockPrep<FMT>::prep(R.w[k], st, bf2f(R.ze[k]), -(qb * st), lane, D.p[k]);
-#pragma unroll
-            for (int i = 0; i < 16; i++) asm volatile("" : "+v"(D.p[k][i])); /* formed HERE, in front of the barrier, not sunk to the first use behind it */
-            if (PL::PAIRED) {
-                const float st2 = bf2f(R.st2[k]);
-                BlockPrep<FMT>::prep(R.w2[k], st2, bf2f(R.ze2[k]), -(qb2 * st2), lane, D.p2[k]);
-#pragma unroll
-                for (int i = 0; i < 16; i++) asm volatile("" : "+v"(D.p2[k][i]));
-            }
+            for (int i = 0; i < 16; i++) asm volatile("" : "+v"(D.p2[k][i]));
         }
     }
 }
-// the canonical pair products on widened weights: the chains of pairs_dot<true>
-__device__ __forceinline__ f32x2_t wide_dot(const f32x2_t (&f)[16], const u32x4* xs, int col, int nBlk, f32x2_t acc) {
-    const f32x4* xf = reinterpret_cast<const f32x4*>(xs);
-#pragma unroll
-    for (int d = 0; d < 4; d++) {
-        const f32x4 X0 = xf[(2 * d) * nBlk + col], X1 = xf[(2 * d + 1) * nBlk + col];
-        acc = pk_fma(f[4 * d], f32x2_t{X0.x, X0.y}, acc);
-        acc = pk_fma(f[4 * d + 1], f32x2_t{X0.z, X0.w}, acc);
-        acc = pk_fma(f[4 * d + 2], f32x2_t{X1.x, X1.y}, acc);
-        acc = pk_fma(f[4 * d + 3], f32x2_t{X1.z, X1.w}, acc);
-    }
-    return acc;
-}
 // mv_run on dequantised blocks: the same lanes, chains and tree
-template <class PL, int NCW, int MAXS, bool CANON, bool WIDE, typename Epi>
-__device__ __forceinline__ void mv_run_deq(int s0, int cw, int lane, int Mj, const MvDeq<PL::PAIRED, MAXS, WIDE>& D, const u32x4* xs, Epi&& epi) {
-    static_assert(!WIDE || CANON, "widened weights are the canonical order's");
+template <class PL, int NCW, int MAXS, bool CANON, typename Epi>
+__device__ __forceinline__ void mv_run_deq(int s0, int cw, int lane, int Mj, const MvDeq<PL::PAIRED, MAXS>& D, const u32x4* xs, uint32_t hotbits, Epi&& epi) {
     acc_t<CANON> acc{}, acc2{};
 #pragma unroll
     for (int k = 0; k < MAXS; k++) {
@@ -525,15 +480,12 @@ __device__ __forceinline__ void mv_run_deq(int s0, int cw, int lane, int Mj, con
         const MvAt q = mv_at<PL, NCW>(k, s0, cw, lane, Mj);
         const int col = q.col < PL::nBlk ? q.col : PL::nBlk - 1;
         if (it == 0) acc = acc_t<CANON>{}, acc2 = acc_t<CANON>{};
-        acc_t<CANON> r;
-        if constexpr (WIDE) r = wide_dot(D.f[k], xs, col, PL::nBlk, acc);
-        else r = pairs_dot<CANON>(D.p[k], xs, col, PL::nBlk, acc);
-        acc = acc_pick(q.ok, r, acc);
+        const bool on = q.ok && ((hotbits >> ((q.row - s0 * PL::RPS) & 31)) & 1u);
+        const acc_t<CANON> r = pairs_dot<CANON>(D.p[k], xs, col, PL::nBlk, acc);
+        acc = acc_pick(on, r, acc);
         if (PL::PAIRED) {
-            acc_t<CANON> r2;
-            if constexpr (WIDE) r2 = wide_dot(D.f2[k], xs, col, PL::nBlk, acc2);
-            else r2 = pairs_dot<CANON>(D.p2[k], xs, col, PL::nBlk, acc2);
-            acc2 = acc_pick(q.ok, r2, acc2);
+            const acc_t<CANON> r2 = pairs_dot<CANON>(D.p2[k], xs, col, PL::nBlk, acc2);
+            acc2 = acc_pick(on, r2, acc2);
         }
         if (it == PL::iters - 1) {
             const float v = group_sum(acc_join(acc), PL::lpr_log2);
@@ -543,6 +495,21 @@ __device__ __forceinline__ void mv_run_deq(int s0, int cw, int lane, int Mj, con
         }
     }
 }
+
+// One mat-vec phase of a wave: the 4-bit forms dequantise their blocks ahead of the hand-off (ahead) and multiply pair words behind it; the other storages (1-bit through the
+// LDS selector table) multiply straight from the packed blocks -- their 128-weight blocks would be 64 pair words each.
+template <class C, class PL, int NCW, int MAXS>
+struct MvPhase {
+    MvDeq<PL::PAIRED, MAXS> d; /* untouched (no registers) when the storage is not dequantised ahead */
+    __device__ __forceinline__ void ahead(float qb, float qb2, int cw, int lane, const MvRegs<PL::PAIRED, MAXS>& R) {
+        if constexpr (C::DEQ) mv_dequant<PL, NCW, C::FMT, MAXS>(qb, qb2, cw, lane, R, d);
+    }
+    template <typename Epi>
+    __device__ __forceinline__ void run(float qb, float qb2, int s0, int cw, int lane, int Mj, const MvRegs<PL::PAIRED, MAXS>& R, const u32x4* xs, const u32x4* tab, uint32_t hotbits, Epi&& epi) {
+        if constexpr (C::DEQ) mv_run_deq<PL, NCW, MAXS, C::CANON>(s0, cw, lane, Mj, d, xs, hotbits, epi);
+        else mv_run<PL, NCW, C::FMT, MAXS, C::CANON, C::F32X>(qb, qb2, s0, cw, lane, Mj, R, xs, tab, hotbits, epi);
+    }
+};
 
 // ------------------------------------------------------------------------------------------------ the kernel
 // LDS: [layer table] [xs0] [xs1] [xrawA dim] [xrawB dim] [attention: qraw GQ*hd | kraw hd | vraw hd | qb GQ*hd | knew hd | wmax | comb] [outb] [cnt, pub]
@@ -556,6 +523,8 @@ struct EngLds {
     int* cnt;       /* arrival counter of the compute waves that own rows of the phase */
     double* msc;    /* [ME][KF_ATTN_MAX_SPLITS] the slice partials of this workgroup's merge elements, transposed for the per-element chains; [ME] dwords behind it: its ao granules */
     int* pub;       /* [4] layers of P1 / P4 / P5 / P6 rows this workgroup has published so far: the poller starts sweeping for the phase's consumers' vector behind it */
+    const u32x4* q1tab;      /* FMT_Q1T: 256 x 16 B of v_perm selectors (BlockDot<FMT_Q1T>) */
+    const uint32_t* hotbits; /* [n_layer] sparse forward: bit r = this workgroup's r-th gate / up row is hot (all ones: dense) */
 };
 struct EngSlice { /* this workgroup's attention slice and merge share */
     int pos, len, nsp, kvh, split, h0, t0, t1, me0;
@@ -594,7 +563,10 @@ struct EngCfg {
     // CANON: the mat-vec phases and the head in the canonical order (one v_fma_f32 per product on fp32 operands: bit-exact against the oracle); false: v_dot2c_f32_bf16 on
     // bf16 pairs (kf_set_canonical(ctx, 0): <= 1 bf16 ulp per output from the oracle, fewer vector instructions).  The attention is canonical either way.
     static constexpr bool CANON = CANON_;
-    static constexpr int XCH = CANON_ ? BlockDotF<FMT_>::XCH : BlockDot<FMT_>::XCH;
+    static constexpr bool Q4F = FMT_ == FMT_Q4 || FMT_ == FMT_Q4P;
+    static constexpr bool DEQ = Q4F;           /* blocks dequantised ahead of the hand-off (16 pair words per block) */
+    static constexpr bool F32X = CANON_ && Q4F; /* activations staged as fp32 chunks (BlockDotF / the canonical pairs_dot) */
+    static constexpr int XCH = F32X ? 8 : BlockDot<FMT_>::XCH;
     static constexpr int n_head = QD_ / HD_, n_kv = KVD_ / HD_;
     using SH = EngShape<FMT_, DIM_, QD_, KVD_, FFN_, NWG_>;
     static constexpr int xA = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).xA, qkv = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).qkv, ao = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).ao,
@@ -669,11 +641,10 @@ __device__ __forceinline__ void eng_attn_phase(const EngArgs& a, const EngLds& L
     const int grp = lane >> lpk_log2, d0 = (lane & (LPK - 1)) * 8;
     const int tstride = NWA * KPW, tstart = S.t0 + wave * KPW + grp;
     const int nbatch = (S.t1 - S.t0 + U * tstride - 1) / (U * tstride);
-    constexpr bool PREP = ENG_PREP_POLLER && GQ * hd <= 256; /* the poller left PREPARED heads in qb / knew / vraw */
-    if (!PREP) __syncthreads(); /* raw heads staged */
+    __syncthreads(); /* raw heads staged */
     if (wave == 0) ENG_STAMP(1, 2);
     if (!S.empty) {
-        if constexpr (!PREP) { /* prologue: q heads of this group, and the new key when it lies in this slice (ROPE::cuInfer) */
+        { /* prologue: q heads of this group, and the new key when it lies in this slice (ROPE::cuInfer) */
             const bool rope = a.rope_table != nullptr;
             const bool qnorm = ly.norm_q != nullptr;
             const int half = hd >> 1, j = lane < half ? lane : half - 1;
@@ -818,7 +789,7 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
     using P5 = typename SH::P5;
     using P6 = typename SH::P6;
     constexpr int FMT = C::FMT, GQ = C::GQ, HD = C::HD, NWV = C::NWV;
-    constexpr bool XMAP = C::XMAP, DBG = C::DBG, W1 = C::CANON && (ENG_WIDEN & 1), W4 = C::CANON && (ENG_WIDEN & 2), W5 = C::CANON && (ENG_WIDEN & 4), W6 = C::CANON && (ENG_WIDEN & 8);
+    constexpr bool XMAP = C::XMAP, DBG = C::DBG;
     constexpr int ND = C::DIM / 256, NQD = C::QD / 256, NF = C::FFN / 256;
     constexpr int XCH = C::XCH, hd = HD, hd_log2 = HD == 128 ? 7 : 6;
     bool dead = false;
@@ -837,8 +808,6 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
 #pragma unroll
     for (int u = 0; u < EngAttnState<C>::U; u++) T.kk[u] = T.vv[u] = u32x4{0, 0, 0, 0};
     eng_attn_rope<C>(a, S, lane, T);
-    f32x4 rcs = f32x4{1.f, 0.f, 1.f, 0.f}; /* the preparing poller's RoPE pairs 2 j2, 2 j2 + 1 at the step's position: (cos, sin, cos, sin) */
-    if (ENG_PREP_POLLER && GQ * hd <= 256 && a.rope_table) rcs = *reinterpret_cast<const f32x4*>(a.rope_table + (size_t)S.pos * HD + 4 * (lane & (hd / 4 - 1)));
     if (S.has_unit && !S.empty) eng_attn_issue<C>(a, L.lay[0], S, NWV - 1, lane, T, 0);
     int sw[4] = {0, 0, 0, 0};
     int swt[6] = {0, 0, 0, 0, 0, 0}; /* this step's sweeps of the poller per hand-off (x, q|k|v, slice partials, ao, xB, act): workgroup 0 adds them to the engine's statistics */
@@ -846,14 +815,8 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
         const EngLayer& ly = L.lay[l];
         const uint32_t gen = (uint32_t)epoch * (uint32_t)a.n_layer + (uint32_t)l, tag = gen & 0xffffu;
         if (S.has_unit && !S.empty) eng_attn_normw<C>(ly, NWV - 1, lane, T);
-        uint32_t nq0 = 0, nq1 = 0, nk0 = 0, nk1 = 0; /* the preparing poller's norm weights: elements 2 j2, 2 j2 + 1 | half + 2 j2, half + 2 j2 + 1 of a head */
-        if (ENG_PREP_POLLER && GQ * hd <= 256 && S.has_unit && !S.empty) {
-            const int j2 = lane & (hd / 4 - 1);
-            if (ly.norm_q) nq0 = *reinterpret_cast<const uint32_t KF_GLOBAL*>(ly.norm_q + 2 * j2), nq1 = *reinterpret_cast<const uint32_t KF_GLOBAL*>(ly.norm_q + hd / 2 + 2 * j2);
-            if (ly.norm_k) nk0 = *reinterpret_cast<const uint32_t KF_GLOBAL*>(ly.norm_k + 2 * j2), nk1 = *reinterpret_cast<const uint32_t KF_GLOBAL*>(ly.norm_k + hd / 2 + 2 * j2);
-        }
-        MvDeq<false, S1, W1> d1;
-        if (P1_SHARE) mv_dequant<P1, NCW1, FMT, S1, W1>(qb1, 0.f, NWV - 1, lane, r1, d1); /* its blocks were requested behind the previous layer's attention phase */
+        MvPhase<C, P1, NCW1, S1> w1;
+        if (P1_SHARE) w1.ahead(qb1, 0.f, NWV - 1, lane, r1); /* its blocks were requested behind the previous layer's attention phase */
         // P1 (P4 adds this x as the residual)
         ENG_STAMP(0, 0);
         if (has1 || has4) {
@@ -884,16 +847,16 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
                     if (tok < 0 || tok >= a.emb_rows) tok = 0;
                     x0 = a.emb + (size_t)tok * C::DIM;
                 }
-                eng_poll_stage<XCH, ND, P1::nBlk, true, true, C::CANON>(nullptr, x0, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, &sw[0], nullptr, 0, 0);
+                eng_poll_stage<XCH, ND, P1::nBlk, true, true, C::F32X>(nullptr, x0, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, &sw[0], nullptr, 0, 0);
             } else {
-                eng_poll_stage<XCH, ND, P1::nBlk, true, false, C::CANON>(a.xch + C::xA, nullptr, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, &sw[0], has6 ? L.pub + 3 : nullptr, l,
+                eng_poll_stage<XCH, ND, P1::nBlk, true, false, C::F32X>(a.xch + C::xA, nullptr, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, &sw[0], has6 ? L.pub + 3 : nullptr, l,
                                                                a.delay[0]);
             }
         }
         ENG_STAMP(0, 1);
         __syncthreads();
         if (P1_SHARE && has1) { /* this wave's P1 rows, then the workgroup's publish like every other owner */
-            mv_run_deq<P1, NCW1, S1, C::CANON, W1>(S.s1, NWV - 1, lane, S.M1, d1, L.xs[0], [&](int row, float v, float) { L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); });
+            w1.run(qb1, 0.f, S.s1, NWV - 1, lane, S.M1, r1, L.xs[0], L.q1tab, 0xffffffffu, [&](int row, float v, float) { L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); });
             if (XMAP)
                 wg_publish(L, 0, eng_lqkv<C>(a, S.xcc), S.q_out0, P1::R, NWP1, lane, true);
             else
@@ -905,79 +868,6 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
             const __amdgpu_buffer_rsrc_t rs = XMAP ? eng_rsrc(eng_lqkv<C>(a, S.xcc), (uint32_t)(GQ * hd + 2 * hd) * 4u) : eng_rsrc(a.xch + C::qkv, (uint32_t)(C::QD + 2 * C::KVD) * 4u);
             const int q_src = XMAP ? 0 : S.h0 * hd;
             const uint32_t tagw = tag << 16;
-          if constexpr (ENG_PREP_POLLER && GQ * hd <= 256) {
-            // ---- sweep AND prepare (ROPE::cuInfer: CU_rms_forward_v2 + CU_rope2_v0, the arithmetic of prep_head_cs): lane = head lane / LPH, rotation pairs 2 j2 and 2 j2 + 1 of that
-            // head, i.e. elements 2 j2, 2 j2 + 1, half + 2 j2, half + 2 j2 + 1 -- two 8-byte pieces; the new key the same way in lanes 0 .. LPH - 1, the new value as 4 elements in lanes
-            // 32 .. 32 + LPH - 1 (two 8-byte pieces too: every lane issues the same four loads).  Only the slice that holds the position needs k | v.
-            constexpr int LPH = hd / 4, half = hd / 2;
-            const int hq = lane / LPH, j2 = lane & (LPH - 1);
-            const bool q_in = hq < GQ, k_in = lane < LPH, v_in = lane >= 32 && lane < 32 + LPH, own = S.own_new && !S.empty;
-            const int qa = q_src + (q_in ? hq : 0) * hd + 2 * j2;
-            const int k_src = XMAP ? GQ * hd : C::QD + S.kvh * hd, v_src = XMAP ? GQ * hd + hd : C::QD + C::KVD + S.kvh * hd;
-            const int ka = k_in ? k_src + 2 * j2 : (v_in ? v_src + 4 * (lane - 32) : k_src), kb = k_in ? k_src + half + 2 * j2 : (v_in ? v_src + 4 * (lane - 32) + 2 : k_src);
-            u32x2 gq0, gq1, gk0 = u32x2{0, 0}, gk1 = u32x2{0, 0};
-            eng_wait_pub(has1 ? L.pub + 0 : nullptr, l + 1, a.delay[1], dead);
-            for (int spins = 0;; spins++) {
-                gq0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, qa * 4, 0, 16 /* sc1 */));
-                gq1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (qa + half) * 4, 0, 16));
-                if (own) { /* workgroup-uniform */
-                    gk0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, ka * 4, 0, 16));
-                    gk1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, kb * 4, 0, 16));
-                }
-                uint32_t bad = q_in ? (((gq0.x ^ tagw) | (gq0.y ^ tagw) | (gq1.x ^ tagw) | (gq1.y ^ tagw)) & 0xffff0000u) : 0u;
-                bad |= (own && (k_in || v_in)) ? (((gk0.x ^ tagw) | (gk0.y ^ tagw) | (gk1.x ^ tagw) | (gk1.y ^ tagw)) & 0xffff0000u) : 0u;
-                if (all_good(bad)) {
-                    swt[1] += spins + 1;
-                    break;
-                }
-                if (dead || spins > ENG_SPIN_MAX) {
-                    if (!dead && lane == 0) atomicOr(a.ws + 1, 2);
-                    dead = true;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            ENG_STAMP(0, 12);
-            if (!S.empty) {
-                const bool rope = a.rope_table != nullptr;
-                auto lane_sum = [&](double v) { /* over the LPH lanes of a head */
-                    v += dpp_d<0xB1>(v), v += dpp_d<0x4E>(v), v += dpp_d<0x141>(v), v += dpp_d<0x140>(v);
-                    if (LPH == 32) v = xsum16_d(v);
-                    return v;
-                };
-                auto prepare = [&](u32x2 g0, u32x2 g1, bool norm, uint32_t w0, uint32_t w1, uint32_t& o0, uint32_t& o1) { /* g0 = elements e, e + 1; g1 = e + half, e + half + 1 */
-                    float xa0 = bf2f((uint16_t)g0.x), xa1 = bf2f((uint16_t)g0.y), xb0 = bf2f((uint16_t)g1.x), xb1 = bf2f((uint16_t)g1.y);
-                    if (norm) {
-                        double ss = (double)xa0 * (double)xa0;
-                        ss = fma((double)xa1, (double)xa1, ss), ss = fma((double)xb0, (double)xb0, ss), ss = fma((double)xb1, (double)xb1, ss);
-                        ss = lane_sum(ss);
-                        const float s = round_bf16(1.0f / sqrtf((float)ss / (float)hd + a.qk_eps));
-                        xa0 = round_bf16(xa0 * s * bf_lo(w0)), xa1 = round_bf16(xa1 * s * bf_hi(w0));
-                        xb0 = round_bf16(xb0 * s * bf_lo(w1)), xb1 = round_bf16(xb1 * s * bf_hi(w1));
-                    }
-                    if (rope) { /* pair (j, j + half): x_j c - x_{j+half} s, x_j s + x_{j+half} c, each product and each sum rounded once (operator.cuh:734-772) */
-                        const float a0 = xa0 * rcs.x, b0 = xb0 * rcs.y, c0 = xa0 * rcs.y, d0 = xb0 * rcs.x;
-                        const float a1 = xa1 * rcs.z, b1 = xb1 * rcs.w, c1 = xa1 * rcs.w, d1 = xb1 * rcs.z;
-                        xa0 = a0 - b0, xb0 = c0 + d0, xa1 = a1 - b1, xb1 = c1 + d1;
-                    }
-                    o0 = pack_bf16x2(xa0, xa1), o1 = pack_bf16x2(xb0, xb1);
-                };
-                uint32_t o0, o1;
-                prepare(gq0, gq1, ly.norm_q != nullptr, nq0, nq1, o0, o1);
-                if (q_in) {
-                    uint32_t* qd = reinterpret_cast<uint32_t*>(L.qb + hq * hd);
-                    qd[j2] = o0, qd[(half >> 1) + j2] = o1;
-                }
-                if (own) {
-                    prepare(gk0, gk1, ly.norm_k != nullptr, nk0, nk1, o0, o1);
-                    if (k_in) {
-                        uint32_t* kd = reinterpret_cast<uint32_t*>(L.knew);
-                        kd[j2] = o0, kd[(half >> 1) + j2] = o1;
-                    }
-                    if (v_in) *reinterpret_cast<u32x2*>(L.vraw + 4 * (lane - 32)) = u32x2{(gk0.x & 0xffffu) | (gk0.y << 16), (gk1.x & 0xffffu) | (gk1.y << 16)};
-                }
-            }
-          } else {
             constexpr int NLQ = (GQ * hd + 255) / 256;
             u32x4 g[NLQ], gk;
             const int e_kv = 4 * lane; /* < hd: k, < 2hd: v */
@@ -1009,22 +899,17 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
                 if (e0 < GQ * hd) *reinterpret_cast<u32x2*>(L.qraw + e0) = u32x2{(g[r].x & 0xffffu) | (g[r].y << 16), (g[r].z & 0xffffu) | (g[r].w << 16)};
             }
             if (kv_in) *reinterpret_cast<u32x2*>(L.kraw + e_kv) = u32x2{(gk.x & 0xffffu) | (gk.y << 16), (gk.z & 0xffffu) | (gk.w << 16)}; /* vraw = kraw + hd */
-          }
             ENG_STAMP(0, 2);
             if (P1_SHARE) { /* the next layer's P1 blocks of this wave: unconditional (the last layer requests its own again), and HERE -- loads return in order, so a
                                request in front of a poll holds that poll's sweep back by an HBM latency; the attention phase waits for nothing younger than its tiles */
                 const int ln = l + 1 < a.n_layer ? l + 1 : l;
                 mv_prefetch<P1, NCW1, FMT, S1>(mat1(ln), mat1(ln), S.s1, NWV - 1, lane, S.M1, r1);
             }
-            EngAttnState<C> T2 = T;
-            if (ENG_KV_EARLY && !S.empty) eng_attn_issue<C>(a, L.lay[l + 1 < a.n_layer ? l + 1 : l], S, NWV - 1, lane, T2, 0); /* the next layer's tiles (the last layer asks for its own again) */
             eng_attn_phase<C>(a, L, S, ly, gen, tag, NWV - 1, lane, T, l, wg);
-            if (ENG_KV_EARLY) {
-#pragma unroll
-                for (int u = 0; u < EngAttnState<C>::U; u++) T.kk[u] = T2.kk[u], T.vv[u] = T2.vv[u];
-            } else if (!S.empty && !(ENG_KV_LATE && S.has_merge)) {
-                eng_attn_issue<C>(a, L.lay[l + 1 < a.n_layer ? l + 1 : l], S, NWV - 1, lane, T, 0);
-            }
+            /* the next layer's tiles (the last layer asks for its own again).  Round 4 moved this request of the poller behind the merge's sweep (loads return in order: the sweep's
+               answer might wait for these sixteen HBM lines) and, with a second register set, in front of the attention phase: 387 / 392 us per launch against 383 / 390 here --
+               the ao store then queues behind the tile requests, and the earlier sweep mostly comes too early */
+            if (!S.empty) eng_attn_issue<C>(a, L.lay[l + 1 < a.n_layer ? l + 1 : l], S, NWV - 1, lane, T, 0);
         } else if (P1_SHARE) { /* a workgroup without an attention slice at this position: the same request, nothing to poll in front of it */
             const int ln = l + 1 < a.n_layer ? l + 1 : l;
             mv_prefetch<P1, NCW1, FMT, S1>(mat1(ln), mat1(ln), S.s1, NWV - 1, lane, S.M1, r1);
@@ -1064,7 +949,6 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
             ENG_STAMP(0, 11);
             swt[2] += msw;
             if (DBG && wg == a.dbg_wg && lane == 0) a.dbg[((size_t)l * 2) * 16 + 10] = (unsigned long long)msw;
-            if (ENG_KV_LATE && !ENG_KV_EARLY && S.has_unit && !S.empty) eng_attn_issue<C>(a, L.lay[l + 1 < a.n_layer ? l + 1 : l], S, NWV - 1, lane, T, 0); /* the next layer's tiles, behind the sweep */
             // transpose through LDS: element e's values over the slices contiguous for lane e (slices past nsp: 0)
 #pragma unroll
             for (int r = 0; r < NLM; r++) {
@@ -1117,23 +1001,23 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
         if (ENG_COOP) { /* the ao vector: timed by this wave, swept by all eight */
             if (has4) eng_wait_pub(nullptr, 0, a.delay[3], dead);
             __syncthreads();
-            if (has4) eng_poll_stage_part<XCH, NQD, P4::nBlk, NWV, C::CANON>(a.xch + C::ao, tag, L.xs[1], NWV - 1, lane, a.ws, dead, &sw[1]);
+            if (has4) eng_poll_stage_part<XCH, NQD, P4::nBlk, NWV, C::F32X>(a.xch + C::ao, tag, L.xs[1], NWV - 1, lane, a.ws, dead, &sw[1]);
         } else if (has4) {
-            eng_poll_stage<XCH, NQD, P4::nBlk, false, false, C::CANON>(a.xch + C::ao, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, &sw[1], nullptr, 0, a.delay[3]);
+            eng_poll_stage<XCH, NQD, P4::nBlk, false, false, C::F32X>(a.xch + C::ao, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, &sw[1], nullptr, 0, a.delay[3]);
         }
         ENG_STAMP(0, 5);
         __syncthreads();
         if (has5 || has6)
-            eng_poll_stage<XCH, ND, P5::nBlk, true, false, C::CANON>(a.xch + C::xB, nullptr, tag, ly.norm_post, a.eps, L.xs[0], L.xrawB, lane, a.ws, dead, &sw[2], has4 ? L.pub + 1 : nullptr, l + 1,
+            eng_poll_stage<XCH, ND, P5::nBlk, true, false, C::F32X>(a.xch + C::xB, nullptr, tag, ly.norm_post, a.eps, L.xs[0], L.xrawB, lane, a.ws, dead, &sw[2], has4 ? L.pub + 1 : nullptr, l + 1,
                                                            a.delay[4]);
         ENG_STAMP(0, 6);
         __syncthreads();
         if (ENG_COOP) {
             if (has6) eng_wait_pub(has5 ? L.pub + 2 : nullptr, l + 1, a.delay[5], dead);
             __syncthreads();
-            if (has6) eng_poll_stage_part<XCH, NF, P6::nBlk, NWV, C::CANON>(a.xch + C::act, tag, L.xs[1], NWV - 1, lane, a.ws, dead, &sw[3]);
+            if (has6) eng_poll_stage_part<XCH, NF, P6::nBlk, NWV, C::F32X>(a.xch + C::act, tag, L.xs[1], NWV - 1, lane, a.ws, dead, &sw[3]);
         } else if (has6) {
-            eng_poll_stage<XCH, NF, P6::nBlk, false, false, C::CANON>(a.xch + C::act, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, &sw[3], has5 ? L.pub + 2 : nullptr, l + 1, a.delay[5]);
+            eng_poll_stage<XCH, NF, P6::nBlk, false, false, C::F32X>(a.xch + C::act, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, &sw[3], has5 ? L.pub + 2 : nullptr, l + 1, a.delay[5]);
         }
         ENG_STAMP(0, 7);
         swt[0] += sw[0], swt[3] += sw[1], swt[4] += sw[2], swt[5] += sw[3];
@@ -1158,7 +1042,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
     using P5 = typename SH::P5;
     using P6 = typename SH::P6;
     constexpr int FMT = C::FMT, NWV = C::NWV;
-    constexpr bool XMAP = C::XMAP, DBG = C::DBG, W1 = C::CANON && (ENG_WIDEN & 1), W4 = C::CANON && (ENG_WIDEN & 2), W5 = C::CANON && (ENG_WIDEN & 4), W6 = C::CANON && (ENG_WIDEN & 8);
+    constexpr bool XMAP = C::XMAP, DBG = C::DBG;
     constexpr int NCW = NWV - 1;
     // P1 alone is shared with the poller wave (it is idle between staging x and the first q/k/v granules): NWV waves, so that the 0.6B shape's
     // 8 row-slots per workgroup are one step for every wave instead of two for wave 0
@@ -1198,13 +1082,12 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         const int lane_m = lane + lzm; /* as for the attention phase below: the mat-vec phases' per-lane indices are recomputed per layer rather than held in registers */
         if (S.has_unit && !S.empty) eng_attn_normw<C>(ly, wave, lane_m, T);
         // ================= P1: RMSNorm(x) -> Q, K, V rows  (every phase: the blocks are dequantised in front of the barrier the activations arrive behind)
-        MvDeq<false, S1, W1> d1; /* declared per layer: nothing of it is carried around the loop */
-        if (ENG_DEQ_MASK & 1) mv_dequant<P1, NCW1, FMT, S1, W1>(qb1, 0.f, wave, lane_m, r1, d1);
+        MvPhase<C, P1, NCW1, S1> w1; /* declared per layer: nothing of it is carried around the loop */
+        w1.ahead(qb1, 0.f, wave, lane_m, r1);
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 0);
-        if (!(ENG_DEQ_MASK & 1)) mv_dequant<P1, NCW1, FMT, S1, W1>(qb1, 0.f, wave, lane_m, r1, d1);
         mv_prefetch<P4, NCW, FMT, S4>(ly.m[3], ly.m[3], wg * P4::spg, wave, lane_m, P4::M0, r4);
-        mv_run_deq<P1, NCW1, S1, C::CANON, W1>(S.s1, wave, lane_m, S.M1, d1, L.xs[0], [&](int row, float v, float) { L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); });
+        w1.run(qb1, 0.f, S.s1, wave, lane_m, S.M1, r1, L.xs[0], L.q1tab, 0xffffffffu, [&](int row, float v, float) { L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); });
         if (has1 && wave < NWP1) {
             if (XMAP)
                 wg_publish(L, 0, eng_lqkv<C>(a, S.xcc), S.q_out0, P1::R, NWP1, lane_m, true);
@@ -1230,47 +1113,45 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         }
 
         // ================= P4: o_proj + residual -> xB
-        MvDeq<false, S4, W4> d4;
-        if (ENG_DEQ_MASK & 2) mv_dequant<P4, NCW, FMT, S4, W4>(a.qbias[3], 0.f, wave, lane_m, r4, d4);
+        MvPhase<C, P4, NCW, S4> w4;
+        w4.ahead(a.qbias[3], 0.f, wave, lane_m, r4);
         if (ENG_COOP) {
             __syncthreads(); /* the poller has timed the first sweep */
-            if (has4) eng_poll_stage_part<C::XCH, C::QD / 256, P4::nBlk, NWV, C::CANON>(a.xch + C::ao, tag, L.xs[1], wave, lane_m, a.ws, dead);
+            if (has4) eng_poll_stage_part<C::XCH, C::QD / 256, P4::nBlk, NWV, C::F32X>(a.xch + C::ao, tag, L.xs[1], wave, lane_m, a.ws, dead);
         }
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 4);
-        if (!(ENG_DEQ_MASK & 2)) mv_dequant<P4, NCW, FMT, S4, W4>(a.qbias[3], 0.f, wave, lane_m, r4, d4);
-        mv_prefetch<P5, NCW, FMT, S5>(ly.m[4], ly.m[5], wg * P5::spg, wave, lane_m, P5::M0, r5);
-        mv_run_deq<P4, NCW, S4, C::CANON, W4>(wg * P4::spg, wave, lane_m, P4::M0, d4, L.xs[1], [&](int row, float v, float) {
+        const uint32_t hot5 = L.hotbits[l]; /* the sparse forward's mask of this workgroup's gate / up rows (all ones: dense) */
+        mv_prefetch<P5, NCW, FMT, S5>(ly.m[4], ly.m[5], wg * P5::spg, wave, lane_m, P5::M0, r5, hot5);
+        w4.run(a.qbias[3], 0.f, wg * P4::spg, wave, lane_m, P4::M0, r4, L.xs[1], L.q1tab, 0xffffffffu, [&](int row, float v, float) {
             const uint16_t o = f2bf(v);
             L.outb[row - wg * P4::R] = (tag << 16) | (uint32_t)f2bf(bf2f(L.xrawA[row]) + bf2f(o)); /* CU_add3: bf16(x + bf16(W.x)) */
         });
         if (has4 && wave < NWP4) wg_publish(L, 1, a.xch + C::xB, wg * P4::R, P4::R, NWP4, lane_m);
         // ================= P5: RMSNorm + gate/up + SwiGLU -> act
         if (wave == 0) ENG_STAMP(1, 5);
-        MvDeq<true, S5, W5> d5;
-        if (ENG_DEQ_MASK & 4) mv_dequant<P5, NCW, FMT, S5, W5>(a.qbias[4], a.qbias[5], wave, lane_m, r5, d5);
+        MvPhase<C, P5, NCW, S5> w5;
+        w5.ahead(a.qbias[4], a.qbias[5], wave, lane_m, r5);
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 6);
-        if (!(ENG_DEQ_MASK & 4)) mv_dequant<P5, NCW, FMT, S5, W5>(a.qbias[4], a.qbias[5], wave, lane_m, r5, d5);
         mv_prefetch<P6, NCW, FMT, S6>(ly.m[6], ly.m[6], wg * P6::spg, wave, lane_m, P6::M0, r6);
-        mv_run_deq<P5, NCW, S5, C::CANON, W5>(wg * P5::spg, wave, lane_m, P5::M0, d5, L.xs[0], [&](int row, float v, float v2) {
+        w5.run(a.qbias[4], a.qbias[5], wg * P5::spg, wave, lane_m, P5::M0, r5, L.xs[0], L.q1tab, L.hotbits[l], [&](int row, float v, float v2) {
             const float gt = round_bf16(v), up = round_bf16(v2); /* CU_swiglu_v0 on the two bf16-rounded projections */
             L.outb[row - wg * P5::R] = (tag << 16) | (uint32_t)f2bf((gt * up) / (1.0f + kf_expf(-gt)));
         });
         if (has5 && wave < NWP5) wg_publish(L, 2, a.xch + C::act, wg * P5::R, P5::R, NWP5, lane_m);
         // ================= P6: down_proj + residual -> x of the next layer
         if (wave == 0) ENG_STAMP(1, 7);
-        MvDeq<false, S6, W6> d6;
-        if (ENG_DEQ_MASK & 8) mv_dequant<P6, NCW, FMT, S6, W6>(a.qbias[6], 0.f, wave, lane_m, r6, d6);
+        MvPhase<C, P6, NCW, S6> w6;
+        w6.ahead(a.qbias[6], 0.f, wave, lane_m, r6);
         if (ENG_COOP) {
             __syncthreads();
-            if (has6) eng_poll_stage_part<C::XCH, C::FFN / 256, P6::nBlk, NWV, C::CANON>(a.xch + C::act, tag, L.xs[1], wave, lane_m, a.ws, dead);
+            if (has6) eng_poll_stage_part<C::XCH, C::FFN / 256, P6::nBlk, NWV, C::F32X>(a.xch + C::act, tag, L.xs[1], wave, lane_m, a.ws, dead);
         }
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 8);
-        if (!(ENG_DEQ_MASK & 8)) mv_dequant<P6, NCW, FMT, S6, W6>(a.qbias[6], 0.f, wave, lane_m, r6, d6);
         mv_prefetch<P1, NCW1, FMT, S1>(mat1(ln), mat1(ln), S.s1, wave, lane_m, S.M1, r1);
-        mv_run_deq<P6, NCW, S6, C::CANON, W6>(wg * P6::spg, wave, lane_m, P6::M0, d6, L.xs[1], [&](int row, float v, float) {
+        w6.run(a.qbias[6], 0.f, wg * P6::spg, wave, lane_m, P6::M0, r6, L.xs[1], L.q1tab, 0xffffffffu, [&](int row, float v, float) {
             const uint16_t o = f2bf(v);
             const uint16_t y = f2bf(bf2f(L.xrawB[row]) + bf2f(o));
             if (last) a.x_out[row] = y;
@@ -1449,9 +1330,13 @@ __global__ void __launch_bounds__(C::NWV * 64) engine_kernel(const EngArgs a) {
     constexpr int maxK = C::DIM > C::QD ? (C::DIM > C::FFN ? C::DIM : C::FFN) : (C::QD > C::FFN ? C::QD : C::FFN);
     constexpr int xs_bytes = (maxK * 4 + 15) & ~15, xr_bytes = (C::DIM * 2 + 15) & ~15; /* xs: fp32 activations */
     constexpr size_t off = (size_t)2 * xs_bytes + 2 * xr_bytes;
-    constexpr size_t fixed_bytes = (off + sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + sizeof(double) * ((size_t)NWV * GQ * (hd + 2) + (size_t)C::ME * KF_ATTN_MAX_SPLITS + 64) + 4 * 16 + 4 * 64 + 32 + 15) & ~(size_t)15;
+    constexpr size_t fixed0 = (off + sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + sizeof(double) * ((size_t)NWV * GQ * (hd + 2) + (size_t)C::ME * KF_ATTN_MAX_SPLITS + 64) + 4 * 16 + 4 * 64 + 32 + 15) & ~(size_t)15;
+    constexpr size_t fixed_bytes = fixed0 + (C::FMT == FMT_Q1T ? 4096 : 0); /* the 1-bit selector table */
     EngLayer* lay = reinterpret_cast<EngLayer*>(smem + fixed_bytes);
     L.lay = lay;
+    L.q1tab = reinterpret_cast<const u32x4*>(smem + fixed0);
+    uint32_t* hotbits = reinterpret_cast<uint32_t*>(smem + fixed_bytes + (((size_t)a.n_layer * sizeof(EngLayer) + 15) & ~(size_t)15)); /* [n_layer], behind the layer table */
+    L.hotbits = hotbits;
     L.xs[0] = reinterpret_cast<u32x4*>(smem);
     L.xs[1] = reinterpret_cast<u32x4*>(smem + xs_bytes);
     L.xrawA = reinterpret_cast<uint16_t*>(smem + 2 * xs_bytes);
@@ -1477,6 +1362,30 @@ __global__ void __launch_bounds__(C::NWV * 64) engine_kernel(const EngArgs a) {
         uint32_t* dst = reinterpret_cast<uint32_t*>(lay);
         const int nw = a.n_layer * (int)(sizeof(EngLayer) / 4);
         for (int i = tid; i < nw; i += NWV * 64) dst[i] = src[i];
+    }
+    if constexpr (C::FMT == FMT_Q1T) { /* selector table of BlockDot<FMT_Q1T> (kf_gemv.hip fills the same): entry B, dword p = bytes {2a, 2a+1, 2b, 2b+1}, a / b = bits 7-2p / 6-2p of B */
+        if (tid < 256) {
+            uint32_t e[4];
+#pragma unroll
+            for (int p = 0; p < 4; p++) e[p] = 0x01000100u + 0x0202u * ((tid >> (7 - 2 * p)) & 1u) + 0x02020000u * ((tid >> (6 - 2 * p)) & 1u);
+            reinterpret_cast<u32x4*>(smem + fixed0)[tid] = u32x4{e[0], e[1], e[2], e[3]};
+        }
+    }
+    { /* sparse forward: the hot bits of this workgroup's gate / up rows, per layer (CS_Picker's hot[] read once per launch) */
+        using P5 = typename C::SH::P5;
+        static_assert(P5::R <= 32, "hot bits of a workgroup's gate / up rows in one word");
+        for (int l = tid; l < a.n_layer; l += NWV * 64) {
+            g_i32 hot = a.layers[l].hot;
+            uint32_t bits = 0xffffffffu;
+            if (hot) {
+                bits = 0;
+                for (int r = 0; r < P5::R; r++) {
+                    const int row = wg * P5::R + r;
+                    if (row < P5::M0 && hot[row] == 1) bits |= 1u << r;
+                }
+            }
+            hotbits[l] = bits;
+        }
     }
     __syncthreads();
     S.len = S.pos + 1, S.nsp = a.nsp;
@@ -1581,7 +1490,7 @@ static int engine_shape_class(int GQ, int hd, int dim, int q_dim, int ffn) { /* 
     if (GQ == 2 && hd == 64 && dim == 256 && q_dim == 256 && ffn == 512) return 2;     /* the small parity-test shape */
     return 0;
 }
-static_assert(sizeof(EngPlan) == 80 && sizeof(EngLayer) == 216, "device table strides");
+static_assert(sizeof(EngPlan) == 80 && sizeof(EngLayer) == 224, "device table strides");
 static int eng_epb(int fmt) { return fmt == FMT_BF16 ? 8 : (fmt == FMT_F8 ? 16 : (fmt == FMT_Q4 || fmt == FMT_Q4P ? 32 : (fmt == FMT_Q2 ? 64 : 128))); }
 
 // geometry of one phase; returns false when the shape is outside what the engine serves
@@ -1689,8 +1598,8 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     // phases: every layer must have the same shapes and storage
     const kf_engine_layer& L0 = d->layers[0];
     int fmt = gemv_fmt_of(&L0.w[0]);
-    *why = "layer storage not served: the engine is instantiated for 4-bit PackedQ (RTN, groups of 128) layers; other storages keep the per-layer launches";
-    if (fmt != FMT_Q4) { /* the engine is instantiated for the 4-bit PackedQ storage (BASELINE config 2); other storages keep the per-layer launches */
+    *why = "layer storage not served: the engine is instantiated for 4-bit PackedQ (RTN, groups of 128) and 1-bit PackedQ layers; other storages keep the per-layer launches";
+    if (fmt != FMT_Q4 && fmt != FMT_Q1) { /* the engine is instantiated for the 4-bit PackedQ storage (BASELINE config 2); other storages keep the per-layer launches */
         delete E;
         return KF_UNSUPPORTED_DATATYPE;
     }
@@ -1735,6 +1644,7 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
         tab[l].norm_in = (g_u16)(uintptr_t)L.norm_in, tab[l].norm_post = (g_u16)(uintptr_t)L.norm_post;
         tab[l].norm_q = (g_u16)(uintptr_t)L.q_norm, tab[l].norm_k = (g_u16)(uintptr_t)L.k_norm;
         tab[l].kcache = (g_u16w)(uintptr_t)L.kcache, tab[l].vcache = (g_u16w)(uintptr_t)L.vcache;
+        tab[l].hot = (g_i32)(uintptr_t)L.hot_ffn;
     }
     if (dry) {
         delete E;
@@ -1742,6 +1652,7 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
         return KF_OK;
     }
     if (fmt == FMT_Q4 && q4p_ok) fmt = FMT_Q4P;
+    if (fmt == FMT_Q1) fmt = FMT_Q1T; /* the LDS selector-table form (same bits as the per-bit select form) */
     E->fmt = fmt, E->GQ = GQ, E->hd = hd, E->n_cu = n_cu, E->nwv = ENG_NWV, E->shape_class = shape_class;
     E->canon = 1;
     E->xmap = shape_class == 1 ? 1 : 0; /* 8 kv-heads on 8 XCDs */
@@ -1780,6 +1691,7 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     const size_t xs_bytes = ((size_t)maxK * 4 + 15) & ~(size_t)15;
     size_t smem = (((size_t)d->n_layer * sizeof(EngLayer) + 15) & ~(size_t)15) + 2 * xs_bytes + 2 * (((size_t)E->dim * 2 + 15) & ~(size_t)15);
     smem += sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + sizeof(double) * ((size_t)ENG_NWV * GQ * (hd + 2) + 64 * KF_ATTN_MAX_SPLITS + 64) + 4 * 16 + 4 * 64 + 32;
+    smem += (fmt == FMT_Q1T ? 4096 : 0) + (size_t)d->n_layer * 4 + 64; /* the 1-bit selector table; the layers' hot bits */
     smem = (smem + 15) & ~(size_t)15;
     if (smem > 160 * 1024) {
         engine_release(E);
@@ -1850,8 +1762,10 @@ template <int FMT>
 static int engine_go_fmt(EngineHost* E, hipStream_t st) {
     switch (E->shape_class) {
         case 1: /* 8 kv-heads on 8 XCDs: the attention chain of a kv-head stays inside one XCD */
-            if (E->args.dbg && FMT == FMT_Q4P && E->canon) return engine_go<EngCfg<FMT_Q4P, 2, 128, ENG_NWV, 1024, 2048, 1024, 3072, ENG_NWG, true, true, true>>(E, st);
-            if (E->args.dbg && FMT == FMT_Q4P) return engine_go<EngCfg<FMT_Q4P, 2, 128, ENG_NWV, 1024, 2048, 1024, 3072, ENG_NWG, true, true, false>>(E, st);
+            if constexpr (FMT == FMT_Q4P) { /* the diagnostic (stamped) instantiations exist for the benchmark's storage only */
+                if (E->args.dbg && E->canon) return engine_go<EngCfg<FMT_Q4P, 2, 128, ENG_NWV, 1024, 2048, 1024, 3072, ENG_NWG, true, true, true>>(E, st);
+                if (E->args.dbg) return engine_go<EngCfg<FMT_Q4P, 2, 128, ENG_NWV, 1024, 2048, 1024, 3072, ENG_NWG, true, true, false>>(E, st);
+            }
             if (!E->canon) return engine_go<EngCfg<FMT, 2, 128, ENG_NWV, 1024, 2048, 1024, 3072, ENG_NWG, true, false, false>>(E, st);
             return engine_go<EngCfg<FMT, 2, 128, ENG_NWV, 1024, 2048, 1024, 3072, ENG_NWG, true, false, true>>(E, st);
         case 2:
@@ -1884,6 +1798,7 @@ int engine_step(EngineHost* E, hipStream_t st, const uint16_t* x_in, uint16_t* x
     switch (E->fmt) {
         case FMT_Q4P: return engine_go_fmt<FMT_Q4P>(E, st);
         case FMT_Q4: return engine_go_fmt<FMT_Q4>(E, st);
+        case FMT_Q1T: return engine_go_fmt<FMT_Q1T>(E, st);
         default: return 1;
     }
 }

@@ -225,9 +225,12 @@ struct BlockDot<FMT_Q1T, CANON> {
     static constexpr int EPB = 128, XCH = 16;
     static constexpr bool HAS_GAMA = true;
     __device__ static __forceinline__ acc_t<CANON> run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, acc_t<CANON> acc) {
+        return run_tab(w, xs, col, nBlk, step, zero, nb, xs + nBlk * 16 + 16 /* the mat-vec kernel keeps the table behind x (K * 2 bytes) and the 256-byte reduction scratch */, acc);
+    }
+    // tab: the 256-entry selector table, wherever the caller keeps it (the persistent engine: one table for all phases)
+    __device__ static __forceinline__ acc_t<CANON> run_tab(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, const u32x4* tab, acc_t<CANON> acc) {
         const uint32_t r = pack_bf16x2(fmaf(0.0f, step, nb), fmaf(1.0f, step, nb));
         const uint32_t ww = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero); /* bytes 0,1 = dequant(0); bytes 2,3 = dequant(1) */
-        const u32x4* tab = xs + nBlk * 16 + 16;                            /* behind x (K * 2 bytes) and the 256-byte reduction scratch */
         const uint32_t dw[4] = {w.w, w.z, w.y, w.x};                       /* dword3 holds elements 0..31, element 0 = bit 31 */
 #pragma unroll
         for (int d = 0; d < 4; d++)

@@ -351,10 +351,11 @@ int Fish::EnsureEngine() {
             }
             L[l].w[j] = s[j]->w->desc();
         }
-        if (!a->norm.w || !m->norm.w || m->n_hot >= 0) { /* the sparse forward keeps the per-layer launches */
-            engine_why = m->n_hot >= 0 ? "sparse forward (hot-row lists): the per-layer launches serve it" : "a norm weight is missing";
+        if (!a->norm.w || !m->norm.w) {
+            engine_why = "a norm weight is missing";
             return KF_ENGINE_NOT_SERVED;
         }
+        L[l].hot_ffn = m->n_hot >= 0 ? reinterpret_cast<const int32_t*>(m->hot_mask->data) : nullptr; /* the sparse forward inside the launch: cold gate / up rows never read, zeros published */
         L[l].norm_in = ToX(a->norm.w), L[l].norm_post = ToX(m->norm.w);
         L[l].q_norm = a->normQ.w ? ToX(a->normQ.w) : nullptr, L[l].k_norm = a->normK.w ? ToX(a->normK.w) : nullptr;
         L[l].kcache = reinterpret_cast<floatX*>(cache.Get(KVCache::KV_KEY, l, 0));
@@ -402,6 +403,7 @@ void Fish::DropEngine() {
     }
     if (engine_ws) kf_free(ctx, engine_ws), engine_ws = nullptr;
     engine_state = 0, engine_embed = engine_head = false;
+    bucket_tuned.clear(); /* the measured delays belonged to that engine */
 }
 int Fish::EngineCheck() {
     if (!engine || engine_steps == 0) return KF_OK;
@@ -772,10 +774,10 @@ int kfh_set_hot(void* h, int layer, const int32_t* h_hot, int n) {
     FFN* m = f->ffn[layer].get();
     for (auto& g : f->graphs)
         if (g) kf_graph_destroy(g), g = nullptr;
+    f->DropEngine(); /* the engine's layer table holds the masks: rebuilt on the next step */
     if (!h_hot) {
         if (m->n_hot >= 0) f->masked_layers--;
-        m->n_hot = -1, m->hot_rows.reset();
-        if (f->masked_layers == 0 && f->engine_state < 0) f->engine_state = f->engine ? 1 : 0; /* dense again: the built engine serves (or is built on the next step) */
+        m->n_hot = -1, m->hot_rows.reset(), m->hot_mask.reset();
         return KF_OK;
     }
     if (n != f->config.n_ff) return KF_INVALID_ARGS;
@@ -787,8 +789,7 @@ int kfh_set_hot(void* h, int layer, const int32_t* h_hot, int n) {
     int32_t cnt = 0;
     KF_TRY(kf_d2h(f->ctx, &cnt, d_count, 4));
     if (m->n_hot < 0) f->masked_layers++;
-    m->hot_rows = rows, m->n_hot = cnt;
-    if (f->engine_state > 0) f->engine_state = -1; /* a built engine walks the dense FFN */
+    m->hot_rows = rows, m->hot_mask = mask, m->n_hot = cnt;
     return KF_OK;
 }
 int kfh_n_hot(void* h, int layer) {

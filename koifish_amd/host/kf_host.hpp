@@ -128,7 +128,7 @@ struct FFN : GeNeuron {
     hGTensor out;
     int latent = 0;
     // sparse forward (CS_Picker::hot, SparseNeuron.cpp:20-29): the hot rows of gate / up as a device list; n_hot < 0 = dense
-    hGTensor hot_rows;
+    hGTensor hot_rows, hot_mask;  // hot_mask: CS_Picker's hot[ffn] itself on the device (the persistent engine reads the mask, the per-layer launches the list)
     int n_hot = -1;
     hGTensor cuInfer(hGTensor hIn, int flag = 0);
     int cuFlow(floatX* bx, int n);
@@ -224,7 +224,7 @@ struct Fish {
     int EngineCheck();          // synchronises; a timed-out hand-off is reported ONCE (KF_INTERNAL_ERR), the engine reset so that later steps run again
     int engine_steps = 0;  // steps enqueued (or captured) through the engine
     std::string engine_why;  // why the engine does not serve this model (kf_engine_served), "" when it does
-    int engine_autotune = 0;  // > 0: passes of kf_engine_tune run once per position bucket, at the first step inside it (kfh_set_engine_autotune)
+    int engine_autotune = 1;  // > 0: passes of kf_engine_tune run once per position bucket, at the first step inside it (kfh_set_engine_autotune)
     std::vector<unsigned char> bucket_tuned;
     KVCache cache;
     MemBuffer gBUFF;

@@ -91,7 +91,7 @@ def test_sparse_decode_vs_oracle(layer_type):
         tok = int(prompt[pos + 1]) if pos + 1 < len(prompt) else o_next
     ids_graph = m.generate(prompt, 16, use_graph=True)
     assert ids_graph == om.generate(prompt.tolist(), 16)
-    assert m.engine_steps() <= 0, "the sparse forward keeps the per-layer launches"
+    assert m.engine_steps() > 0, "the persistent engine serves the sparse forward (hot bits per workgroup, cold rows published as zeros)"
     m.set_fuse_level(0)
     tok = int(prompt[0])
     for pos in range(6):
@@ -129,4 +129,94 @@ def test_full_size_one_bit_sparse_step():
         m.set_hot(l, None)
     assert sparse_bytes < m.step_bytes(100), "cold rows must not be counted (nor read)"
     om.close()
+    m.close()
+
+
+@pytest.mark.parametrize("layer_type", [L.BOOL1, L.Q4])
+@pytest.mark.parametrize("hot_frac", [0.2, 1.0])
+def test_sparse_engine_equals_per_layer_launches_and_the_oracle_bit_for_bit(layer_type, hot_frac):
+    """The engine's sparse / 1-bit forms (round 4): 1-bit PackedQ layers through the LDS selector table inside the persistent launch, CS_Picker's hot[] as per-workgroup hot bits
+    (cold gate / up rows never read, zeros published by the owning workgroup -- no cold-fill launch).  Canonical order, teacher-forced steps across the single- and multi-slice
+    attention forms: logits, ids and K / V rows equal the per-layer masked launches' AND the oracle's sparse forward, bit for bit."""
+    cfg = dict(synth.CONFIGS["small"], max_seq=320)
+    raw = synth.raw_weights_numpy(cfg, 31, w_std=0.1)
+    n = 230
+    forced = np.full(cfg["max_seq"], -1, dtype=np.int32)
+    forced[:n] = prompt_ids(cfg, n, seed=13)
+    masks = [hot_mask(cfg["ffn"], hot_frac, seed=5 + l) if hot_frac < 1.0 else None for l in range(cfg["n_layer"])]
+    res = {}
+    for engine in (True, False):
+        m = synth.build_from_raw(cfg, raw, layer_type, L.BF16)
+        m.set_canonical(True)
+        m.set_engine(engine)
+        for l, hm in enumerate(masks):
+            if hm is not None:
+                m.set_hot(l, hm)
+        m.set_forced(forced)
+        m.set_state(int(forced[0]), 0)
+        logits = []
+        for p0 in (0, 37, 190, 200):   # runs of steps (several per launch through the engine) ending where logits are compared
+            p1 = {0: 37, 37: 190, 190: 200, 200: n}[p0]
+            m.run_steps(p0, p1 - p0, use_graph=True)
+            m.sync()
+            logits.append(m.logits().copy())
+        m.engine_check()
+        assert (m.engine_steps() > 0) == engine, m.engine_why()
+        k, v = m.kv_to_host()
+        res[engine] = (m.tokens_out(n).tolist(), logits, k[:, :n].copy(), v[:, :n].copy())
+        m.close()
+    assert res[True][0] == res[False][0]
+    for a, b in zip(res[True][1], res[False][1]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(res[True][2], res[False][2]) and np.array_equal(res[True][3], res[False][3])
+    O.set_order(O.ORDER_CANON)
+    try:
+        om = oracle_model(cfg, raw, layer_type, L.BF16, attn_mode=O.ATTN_CANON)
+        for l, hm in enumerate(masks):
+            if hm is not None:
+                om.set_hot(l, hm)
+        o_ids, o_logits = [], {}
+        for p in range(n):
+            nxt, lg, _ = om.decode(int(forced[p]), p, want_logits=(p + 1 in (37, 190, 200, n)))
+            o_ids.append(int(nxt))
+            if lg is not None:
+                o_logits[p + 1] = lg
+        assert res[True][0] == o_ids
+        for lg, end in zip(res[True][1], (37, 190, 200, n)):
+            assert np.array_equal(lg, o_logits[end]), "logits of position %d" % (end - 1)
+        ok, ov = om.kv()
+        assert np.array_equal(res[True][2], ok[:, :n]) and np.array_equal(res[True][3], ov[:, :n])
+        om.close()
+    finally:
+        O.set_order(O.ORDER_DOT16)
+
+
+def test_full_size_one_bit_sparse_engine_equals_per_layer_launches():
+    """BASELINE config 5 at full size through the engine: Qwen3-0.6B shapes, 1-bit layers, 20 % hot FFN rows -- 300 teacher-forced steps (position buckets 64 / 128 / 256 / 512,
+    one and several attention slices), engine against per-layer launches: ids, last logits and K / V rows bit for bit, in both summation orders."""
+    cfg = dict(synth.CONFIGS["qwen3-0.6b"])
+    n = 300
+    forced = np.full(cfg["max_seq"], -1, dtype=np.int32)
+    forced[:n] = np.random.default_rng(21).integers(0, cfg["vocab"], size=n)
+    m = synth.build_on_gpu(cfg, seed=55, layer_type=L.BOOL1, head_type=L.BF16)
+    for l in range(cfg["n_layer"]):
+        m.set_hot(l, hot_mask(cfg["ffn"], 0.2, seed=5 + l))
+    m.set_forced(forced)
+    for canonical in (True, False):
+        m.set_canonical(canonical)
+        res = {}
+        for engine in (True, False):
+            m.set_engine(engine)
+            steps0 = max(m.engine_steps(), 0)
+            m.set_state(int(forced[0]), 0)
+            m.run_steps(0, n, use_graph=True)
+            m.sync()
+            m.engine_check()
+            assert (max(m.engine_steps(), 0) - steps0 > 0) == engine, m.engine_why()
+            k, v = m.kv_to_host()
+            res[engine] = (m.tokens_out(n).tolist(), m.logits().copy(), k[:, :n].copy(), v[:, :n].copy())
+        assert res[True][0] == res[False][0]
+        if canonical:   # in the v_dot2c order the engine's fp32 attention sums are its own (tolerances, tests/test_gpu_engine.py)
+            assert np.array_equal(res[True][1], res[False][1])
+            assert np.array_equal(res[True][2], res[False][2]) and np.array_equal(res[True][3], res[False][3])
     m.close()
