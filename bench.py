@@ -49,13 +49,17 @@ def main():
                     "torch.distributed all-gathers per layer")
     ap.add_argument("--tp-virtual", type=int, default=0, help="side measurement on ONE GPU: this many TP ranks of qwen3-32b in one process, lock-step on one stream "
                     "(the per-rank kernels and the exchange kernels of TP = R, serialised: R x the work of one rank's GPU, no xGMI)")
+    ap.add_argument("--lean-cpu", type=float, default=0.0, help="with --lean: also the CPU-baseline leg (parity passes + a timed sample of this many seconds) of the model being run")
     ap.add_argument("--lean", action="store_true", help="only the timed decode and step_roofline (what the side legs run in their child processes)")
-    ap.add_argument("--leg", default="", choices=["", "config3"], help="run ONE side leg and print its JSON (child processes of the main run)")
+    ap.add_argument("--leg", default="", choices=["", "config3", "config4cpu"], help="run ONE side leg and print its JSON (child processes of the main run)")
     ap.add_argument("--side-legs", default="config3,config5,config4", help="side objects beside the line, each measured in a child process after the main measurements "
                     "(never `value`): config3 = GPT2-1558M operator path of a training step (sum of separately timed forward+loss, backward, AdamW phases; no parameter update), config5 = 1-bit layers + 20 %% hot FFN rows, config4 = Qwen3-32B on ONE GPU; '' = none")
     args = ap.parse_args()
     if args.leg == "config3":
         print(json.dumps(config3_train_step()))
+        return
+    if args.leg == "config4cpu":
+        print(json.dumps(config4_slice_cpu()))
         return
 
     import numpy as np
@@ -91,11 +95,13 @@ def main():
     layer_type = {"q4": L.Q4, "bf16": L.BF16, "f8": L.F8E5M2, "ternary": L.T_SIGN, "1bit": L.BOOL1, "nf4": L.NF4}[args.layers]
     m = synth.build_on_gpu(cfg, seed=1234 + rank, layer_type=layer_type, head_type=head_type, device=dev)
     ctx = m._ctx
+    hots = {}
     if args.sparse > 0.0:
         for l in range(cfg["n_layer"]):
             hot = np.zeros(cfg["ffn"], dtype=np.int32)
             hot[np.random.default_rng(5 + l).permutation(cfg["ffn"])[: max(int(cfg["ffn"] * args.sparse), 16)]] = 1
             m.set_hot(l, hot)
+            hots[l] = hot
     m.set_engine_autotune(args.autotune)   # kf_engine_tune once per position bucket, at the first multi-step launch inside it (set-up span: never inside the timed region)
     if args.engine >= 0:
         m.set_engine(bool(args.engine))
@@ -211,7 +217,12 @@ def main():
             out["engine_handoffs"] = {"error": repr(e)[:160]}
         if args.lean:
             m.engine_check()
-            out["config"]["decode_path"] = "persistent engine, one launch per token" if m.engine_steps() > 0 else "per-layer launches: 5 per layer"
+            out["config"]["decode_path"] = "persistent engine, one launch per token" if m.engine_steps() > 0 else "per-layer launches: 5 per layer (%s)" % (m.engine_why() or "engine off")
+            if args.lean_cpu > 0 and world == 1:
+                try:   # the oracle with the same weights (and the same hot-row masks) on this host's cores: parity passes + a bounded timed sample
+                    out["cpu_baseline"] = cpu_baseline(m, cfg, forced, args.lean_cpu, min_steps=16, max_steps=96, canon_steps=24, hots=hots)
+                except Exception as e:
+                    out["cpu_baseline"] = {"error": repr(e)[:300]}
             print(json.dumps(out))
             return
         out["prefill"] = prefill_rate(m, forced[:n_prompt], ms_per_step)
@@ -231,7 +242,7 @@ def main():
             out["roofline_error"] = repr(e)[:200]
         m.engine_check()
         out["roofline_lm_head"] = head_rl
-        out["cpu_baseline"] = cpu_baseline(m, cfg, forced, args.cpu_seconds) if (world == 1 and args.cpu_seconds > 0) else None
+        out["cpu_baseline"] = cpu_baseline(m, cfg, forced, args.cpu_seconds, hots=hots) if (world == 1 and args.cpu_seconds > 0) else None
         if args.config == "qwen3-0.6b":   # last (it overwrites the KV rows and ids the checks above read): the prompt half through a prompt that fills the context, one token batch
             try:
                 long_prompt = np.random.default_rng(7).integers(0, cfg["vocab"], size=S - 1).astype(np.int32)
@@ -282,19 +293,21 @@ def side_legs(which):
     if "config3" in which:
         out["config3_train_step"] = _child(["--leg", "config3"], 420)
     if "config5" in which:
-        d = _child(["--layers", "1bit", "--sparse", "0.2", "--steps", "512", "--warmup", "64", "--lean"], 300)
+        d = _child(["--layers", "1bit", "--sparse", "0.2", "--steps", "512", "--warmup", "64", "--lean", "--lean-cpu", "6"], 420)
         out["config5_sparse_1bit"] = d if "error" in d else {
             "workload": "Qwen3-0.6B, 1-bit PackedQ layers (YinYang), 20 %% of every FFN's rows hot (D_matmul_sparse: cold rows cost no HBM), bf16 head; positions %s" % d["config"]["workload"].split("timed positions ")[-1],
             "tokens_per_s": d["value"], "ms_per_step": d["ms_per_step"], "bytes_per_step": d["step_roofline"]["bytes_per_step"], "frac": d["step_roofline"]["frac"],
             "fast_order_tokens_per_s": d.get("fast_order_mode", {}).get("tokens_per_s"),
-            "decode_path": d["config"]["decode_path"], "profile": "profiles/r03_config5_sparse_1bit_kernel_stats.csv", "leg_wall_s": d.get("leg_wall_s")}
+            "summation_order": d["config"].get("summation_order"), "cpu_baseline": d.get("cpu_baseline"), "engine_handoffs": d.get("engine_handoffs"),
+            "decode_path": d["config"]["decode_path"], "profile": "profiles/r04_config5_sparse_1bit_kernel_stats.csv", "leg_wall_s": d.get("leg_wall_s")}
     if "config4" in which:
         d = _child(["--config", "qwen3-32b", "--steps", "64", "--warmup", "16", "--lean"], 600)
         out["config4_one_gpu"] = d if "error" in d else {
             "workload": "Qwen3-32B 4-bit PackedQ greedy decode on ONE MI355X (the reference shards it over 8 GPUs for memory): %s" % d["config"]["workload"].split("seq=")[-1],
             "tokens_per_s": d["value"], "ms_per_step": d["ms_per_step"], "bytes_per_step": d["step_roofline"]["bytes_per_step"], "frac": d["step_roofline"]["frac"],
             "fast_order_tokens_per_s": d.get("fast_order_mode", {}).get("tokens_per_s"),
-            "decode_path": d["config"]["decode_path"], "profile": "profiles/r03_config4_one_gpu_kernel_stats.csv", "leg_wall_s": d.get("leg_wall_s"),
+            "decode_path": d["config"]["decode_path"], "profile": "profiles/r04_config4_one_gpu_kernel_stats.csv", "leg_wall_s": d.get("leg_wall_s"),
+            "cpu_baseline_4_layer_slice": _child(["--leg", "config4cpu"], 420),
             "note": "TP = 8 over xGMI needs an 8-GPU node: bench.py --config qwen3-32b --gpus 8 (no scaling curve has been measured on hardware)"}
     return out
 
@@ -420,6 +433,30 @@ def config3_train_step():
     m1, m2 = z(npar), z(npar)
     t_a = timed(lambda: L.check(ctx.hip.kf_adamw(ctx.h, p_.data_ptr(), gr.data_ptr(), m1.data_ptr(), m2.data_ptr(), npar, L.BF16, 3e-4, 0.9, 0.95, 0.1, 0.05, 1e-8, 0.1, 1.0, 7, None), "kf_adamw"))
     ms = t_f + t_b + t_a
+    cpu_leg = None
+    try:   # "CPU fwd of 1 layer x 1 batch row only (extrapolated; stated as such)": plain fp32 torch on this host's cores, the same operator sequence
+        xc = torch.randn(T, Cn)
+        wq_, wp_, wf_, wp2_ = (torch.randn(3 * Cn, Cn) * 0.02, torch.randn(Cn, Cn) * 0.02, torch.randn(4 * Cn, Cn) * 0.02, torch.randn(Cn, 4 * Cn) * 0.02)
+
+        def cpu_layer():
+            h = torch.nn.functional.layer_norm(xc, (Cn,))
+            q, k, v = (h @ wq_.t()).view(T, 3, H, hd).permute(1, 2, 0, 3)
+            a_ = torch.nn.functional.scaled_dot_product_attention(q[None], k[None], v[None], is_causal=True)[0].permute(1, 0, 2).reshape(T, Cn)
+            x2 = xc + a_ @ wp_.t()
+            h2 = torch.nn.functional.layer_norm(x2, (Cn,))
+            return x2 + torch.nn.functional.gelu(h2 @ wf_.t()) @ wp2_.t()
+        cpu_layer()
+        tc = []
+        for _ in range(5):
+            t1 = time.perf_counter()
+            cpu_layer()
+            tc.append(time.perf_counter() - t1)
+        lay_ms = float(sorted(tc)[len(tc) // 2]) * 1e3
+        cpu_leg = {"value": round(lay_ms, 2), "unit": "ms per layer forward of ONE batch row (1024 tokens)", "cores": torch.get_num_threads(), "kind": "port",
+                   "sample": "one GPT2-1558M layer (LayerNorm, QKV, causal attention, proj, LayerNorm, fc, GELU, proj2), fp32 torch on the host cores, median of 5",
+                   "extrapolated_step_ms": round(lay_ms * NL * B * 3, 0), "extrapolation": "x 48 layers x 8 rows x 3 (forward + backward ~ 2 x forward); the head, the loss and AdamW not included: a lower bound, stated as such"}
+    except Exception as e:
+        cpu_leg = {"error": repr(e)[:200]}
     # flops of the step: 2 x (block matrices 12 C^2 x 48 + head V C) per token forward + causal attention (QK^T and PV, half the square), x 3 for forward + backward
     w_el = NL * 12 * Cn * Cn + Vp * Cn
     fwd = 2.0 * N * w_el + NL * 4.0 * Cn * (T * (T + 1) / 2) * B
@@ -428,10 +465,58 @@ def config3_train_step():
                         "kept: SUM of three separately timed phases -- forward + loss, backward (weight-gradient buffers shared between layers: no parameter update), AdamW on a "
                         "1.558 G-element random vector; embedding gather / add and zero fills are torch ops",
             "ms": round(ms, 2), "tokens_per_s": round(N / ms * 1e3, 1), "forward_loss_ms": round(t_f, 2), "backward_ms": round(t_b, 2), "adamw_ms": round(t_a, 2),
-            "mean_loss": round(loss, 4), "flops": int(flops), "achieved_TFLOPs": round(flops / (ms * 1e-3) / 1e12, 1), "mfma_peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS,
+            "cpu_baseline": cpu_leg, "mean_loss": round(loss, 4), "flops": int(flops), "achieved_TFLOPs": round(flops / (ms * 1e-3) / 1e12, 1), "mfma_peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS,
             "mfma_frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
             "reference": "48.8 k tokens/s END-TO-END training on an RTX 4090 (cases/gpt2/1558M_F8_B80/F8_B80.info:2928-2951, BASELINE.md): a real run with data loading and parameter "
-                         "updates; the figure here is the operator path only", "profile": "profiles/r03_config3_train_step_kernel_stats.csv"}
+                         "updates; the figure here is the operator path only", "profile": "profiles/r04_config3_train_step_kernel_stats.csv"}
+
+
+def config4_slice_cpu(n_layer=4, n_steps=24):
+    """SURVEY section 8d, config 4's CPU column: the oracle cannot hold Qwen3-32B (18 GB, minutes per token), so a 4-LAYER SLICE of the same shapes (dim 5120, 64 / 8 heads of 128,
+    ffn 25600, vocab 151936, untied bf16 head; RTN 4-bit g128 layers) is decoded on the GPU (canonical order) and by the oracle on this host's cores from the same device weights:
+    greedy ids and the last logits must be equal bit for bit; the oracle's AVX2 pass is timed.  Reported for the slice only; 64 / 4 of the layer time is what a full model would cost."""
+    import numpy as np
+    from koifish_amd import lib as L, synth
+    from oracle import oracle as O
+    cfg = dict(synth.CONFIGS["qwen3-32b"], n_layer=n_layer, max_seq=512)
+    m = synth.build_on_gpu(cfg, seed=1234, layer_type=L.Q4, head_type=L.BF16)
+    _pick_threads()
+    om = O.from_device_model(m, attn_mode=O.ATTN_CANON)
+    prep = om.prepare_fast()
+    forced = np.full(cfg["max_seq"], -1, dtype=np.int32)
+    forced[:128] = np.random.default_rng(7).integers(0, cfg["vocab"], size=128)
+    m.set_forced(forced)
+    m.set_state(int(forced[0]), 0)
+    m.run_steps(0, 128 + n_steps, True)
+    m.sync()
+    gpu_ids = m.tokens_out(cfg["max_seq"])
+    g_logits = m.logits().copy()
+    O.set_order(O.ORDER_CANON)
+    same, lg = 0, None
+    try:
+        tok = int(forced[0])
+        for p in range(128 + n_steps):   # canonical order, teacher-forced on the GPU's ids: the prompt, then the free-running stretch
+            nxt, lg, _ = om.decode(tok, p, want_logits=(p == 128 + n_steps - 1))
+            if p >= 127:
+                same += int(nxt == int(gpu_ids[p]))
+            tok = int(forced[p + 1]) if p + 1 < 128 else int(gpu_ids[p])
+    finally:
+        O.set_order(O.ORDER_DOT16)
+    steps = []
+    tok = int(gpu_ids[127])
+    for i in range(n_steps):   # timed: the reference's CPU dot-product idiom on the bf16 dequantised copy, positions 128 ..
+        t1 = time.perf_counter()
+        om.decode(tok, 128 + i, want_logits=False)
+        steps.append(time.perf_counter() - t1)
+        tok = int(gpu_ids[128 + i])
+    sp = _spread(steps[2:])
+    wbytes = sum(w.algorithmic_bytes() for (layer, slot), w in m.weights.items() if not (layer == -1 and slot == 0))
+    om.close()
+    m.close()
+    return {"value": round(1e3 / sp["median_ms"], 3), "unit": "tokens/s of the %d-layer slice" % n_layer, "cores": O.num_threads(), "kind": "port",
+            "sample": "%d decode steps at positions 128..%d of a %d-layer Qwen3-32B-shaped model (4-bit layers, bf16 head; %d MB dequantised copy); a full 64-layer model would take ~%.0f ms per token on these cores "
+                      "(layers x 16 + head)" % (n_steps, 127 + n_steps, n_layer, max(prep, 0) // 2 ** 20, sp["median_ms"] * 16), "step_ms": sp,
+            "weight_bytes_4bit": int(wbytes), "greedy_ids_compared": n_steps + 1, "greedy_ids_equal_gpu": same, "logits_equal_bit_for_bit": int((g_logits == lg).sum()), "logits_compared": int(g_logits.size)}
 
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak of MI355X (MI355X_MICROARCH.md); the prefill GEMMs multiply bf16 fragments unpacked from 4-bit tiles
@@ -825,7 +910,7 @@ def matvec_roofline(m, ctx, cfg, head_rl, reps=20):
             "note": "latency-bound: %.1f MB per launch is %.2f us at the HBM peak; the in-kernel time split is in DESIGN.md section 6" % (nbytes / n / 1e6, nbytes / n / HBM_PEAK_GBS / 1e3)}
 
 
-def cpu_baseline(m, cfg, forced, budget_s, min_steps=64, max_steps=256, canon_steps=48):
+def cpu_baseline(m, cfg, forced, budget_s, min_steps=64, max_steps=256, canon_steps=48, hots=None):
     """The CPU oracle (a port: no runnable CPU forward exists in the reference) decoding the SAME 4-bit model on this host's cores: weights and the KV rows of the
     128-token prompt are copied from the GPU model, then it decodes from position 128, teacher-forced on the GPU's ids so that both decode one sequence.
     (1) PARITY, once per summation order: `canon_steps` + 1 free-running steps.  In the order `value` is timed in -- the canonical one kernels and oracle share (oracle/kf_oracle.c
@@ -839,6 +924,8 @@ def cpu_baseline(m, cfg, forced, budget_s, min_steps=64, max_steps=256, canon_st
 
     _pick_threads()
     om = O.from_device_model(m, attn_mode=O.ATTN_CANON)
+    for l, hot in (hots or {}).items():   # the sparse forward's masks (D_matmul_sparse): the same rows hot on both sides
+        om.set_hot(l, hot)
     prep = om.prepare_fast()
     p0 = 128
     gk, gv = m.kv_to_host()

@@ -418,14 +418,16 @@ __device__ __forceinline__ void mv_run(float qb, float qb2, int s0, int cw, int 
         const bool on = q.ok && ((hotbits >> ((q.row - s0 * PL::RPS) & 31)) & 1u);
         const float st = bf2f(R.st[k]);
         acc_t<CANON> r;
-        if constexpr (F32X) r = BlockDotF<FMT>::run(R.w[k], reinterpret_cast<const f32x4*>(xs), col, PL::nBlk, st, bf2f(R.ze[k]), -(qb * st), acc);
+        if constexpr (F32X && FMT == FMT_Q1T) r = BlockDotF<FMT>::run_tab(R.w[k], reinterpret_cast<const f32x4*>(xs), col, PL::nBlk, st, bf2f(R.ze[k]), -(qb * st), tab, acc);
+        else if constexpr (F32X) r = BlockDotF<FMT>::run(R.w[k], reinterpret_cast<const f32x4*>(xs), col, PL::nBlk, st, bf2f(R.ze[k]), -(qb * st), acc);
         else if constexpr (FMT == FMT_Q1T) r = BlockDot<FMT, CANON>::run_tab(R.w[k], xs, col, PL::nBlk, st, bf2f(R.ze[k]), -(qb * st), tab, acc);
         else r = BlockDot<FMT, CANON>::run(R.w[k], xs, col, PL::nBlk, st, bf2f(R.ze[k]), -(qb * st), acc);
         acc = acc_pick(on, r, acc);
         if (PL::PAIRED) {
             const float st2 = bf2f(R.st2[k]);
             acc_t<CANON> r2;
-            if constexpr (F32X) r2 = BlockDotF<FMT>::run(R.w2[k], reinterpret_cast<const f32x4*>(xs), col, PL::nBlk, st2, bf2f(R.ze2[k]), -(qb2 * st2), acc2);
+            if constexpr (F32X && FMT == FMT_Q1T) r2 = BlockDotF<FMT>::run_tab(R.w2[k], reinterpret_cast<const f32x4*>(xs), col, PL::nBlk, st2, bf2f(R.ze2[k]), -(qb2 * st2), tab, acc2);
+            else if constexpr (F32X) r2 = BlockDotF<FMT>::run(R.w2[k], reinterpret_cast<const f32x4*>(xs), col, PL::nBlk, st2, bf2f(R.ze2[k]), -(qb2 * st2), acc2);
             else if constexpr (FMT == FMT_Q1T) r2 = BlockDot<FMT, CANON>::run_tab(R.w2[k], xs, col, PL::nBlk, st2, bf2f(R.ze2[k]), -(qb2 * st2), tab, acc2);
             else r2 = BlockDot<FMT, CANON>::run(R.w2[k], xs, col, PL::nBlk, st2, bf2f(R.ze2[k]), -(qb2 * st2), acc2);
             acc2 = acc_pick(on, r2, acc2);
@@ -565,8 +567,8 @@ struct EngCfg {
     static constexpr bool CANON = CANON_;
     static constexpr bool Q4F = FMT_ == FMT_Q4 || FMT_ == FMT_Q4P;
     static constexpr bool DEQ = Q4F;           /* blocks dequantised ahead of the hand-off (16 pair words per block) */
-    static constexpr bool F32X = CANON_ && Q4F; /* activations staged as fp32 chunks (BlockDotF / the canonical pairs_dot) */
-    static constexpr int XCH = F32X ? 8 : BlockDot<FMT_>::XCH;
+    static constexpr bool F32X = CANON_ && (Q4F || FMT_ == FMT_Q1T); /* activations staged as fp32 chunks (BlockDotF / the canonical pairs_dot): no conversion of the activation pair per product */
+    static constexpr int XCH = F32X ? BlockDot<FMT_>::EPB / 4 : BlockDot<FMT_>::XCH;
     static constexpr int n_head = QD_ / HD_, n_kv = KVD_ / HD_;
     using SH = EngShape<FMT_, DIM_, QD_, KVD_, FFN_, NWG_>;
     static constexpr int xA = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).xA, qkv = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).qkv, ao = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).ao,

@@ -345,6 +345,32 @@ struct BlockDotF<FMT_Q4> {
     }
 };
 
+// 1-bit through the selector table on fp32 activations (the engine's canonical 1-bit form): the pairs and chains of BlockDot<FMT_Q1T, true>, without the two conversions of
+// the activation pair per product
+template <>
+struct BlockDotF<FMT_Q1T> {
+    static constexpr int EPB = 128, XCH = 32;
+    static constexpr bool HAS_GAMA = true;
+    __device__ static __forceinline__ f32x2_t run_tab(u32x4 w, const f32x4* xs, int col, int nBlk, float step, float zero, float nb, const u32x4* tab, f32x2_t acc) {
+        const uint32_t r = pack_bf16x2(fmaf(0.0f, step, nb), fmaf(1.0f, step, nb));
+        const uint32_t ww = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero); /* bytes 0,1 = dequant(0); bytes 2,3 = dequant(1) */
+        const uint32_t dw[4] = {w.w, w.z, w.y, w.x};                       /* dword3 holds elements 0..31, element 0 = bit 31 */
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const u32x4 S = tab[(dw[d] >> (24 - 8 * c)) & 0xffu];
+                const f32x4 X0 = xs[(8 * d + 2 * c) * nBlk + col], X1 = xs[(8 * d + 2 * c + 1) * nBlk + col];
+                uint32_t p;
+                p = __builtin_amdgcn_perm(0u, ww, S.x), acc = pk_fma(f32x2_t{bf_lo(p), bf_hi(p)}, f32x2_t{X0.x, X0.y}, acc);
+                p = __builtin_amdgcn_perm(0u, ww, S.y), acc = pk_fma(f32x2_t{bf_lo(p), bf_hi(p)}, f32x2_t{X0.z, X0.w}, acc);
+                p = __builtin_amdgcn_perm(0u, ww, S.z), acc = pk_fma(f32x2_t{bf_lo(p), bf_hi(p)}, f32x2_t{X1.x, X1.y}, acc);
+                p = __builtin_amdgcn_perm(0u, ww, S.w), acc = pk_fma(f32x2_t{bf_lo(p), bf_hi(p)}, f32x2_t{X1.z, X1.w}, acc);
+            }
+        return acc;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------ dequantise ahead, multiply later
 // The persistent engine holds a phase's packed blocks in registers before the phase's activations exist.  Everything that does not depend on x -- the group
 // table, the lookups, the pairing -- can therefore run while the wave would otherwise wait for the hand-off: BlockPrep turns a block into its 16 bf16 pair
