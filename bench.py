@@ -471,54 +471,6 @@ def config3_train_step():
                          "updates; the figure here is the operator path only", "profile": "profiles/r04_config3_train_step_kernel_stats.csv"}
 
 
-def config4_slice_cpu(n_layer=4, n_steps=24):
-    """SURVEY section 8d, config 4's CPU column: the oracle cannot hold Qwen3-32B (18 GB, minutes per token), so a 4-LAYER SLICE of the same shapes (dim 5120, 64 / 8 heads of 128,
-    ffn 25600, vocab 151936, untied bf16 head; RTN 4-bit g128 layers) is decoded on the GPU (canonical order) and by the oracle on this host's cores from the same device weights:
-    greedy ids and the last logits must be equal bit for bit; the oracle's AVX2 pass is timed.  Reported for the slice only; 64 / 4 of the layer time is what a full model would cost."""
-    import numpy as np
-    from koifish_amd import lib as L, synth
-    from oracle import oracle as O
-    cfg = dict(synth.CONFIGS["qwen3-32b"], n_layer=n_layer, max_seq=512)
-    m = synth.build_on_gpu(cfg, seed=1234, layer_type=L.Q4, head_type=L.BF16)
-    _pick_threads()
-    om = O.from_device_model(m, attn_mode=O.ATTN_CANON)
-    prep = om.prepare_fast()
-    forced = np.full(cfg["max_seq"], -1, dtype=np.int32)
-    forced[:128] = np.random.default_rng(7).integers(0, cfg["vocab"], size=128)
-    m.set_forced(forced)
-    m.set_state(int(forced[0]), 0)
-    m.run_steps(0, 128 + n_steps, True)
-    m.sync()
-    gpu_ids = m.tokens_out(cfg["max_seq"])
-    g_logits = m.logits().copy()
-    O.set_order(O.ORDER_CANON)
-    same, lg = 0, None
-    try:
-        tok = int(forced[0])
-        for p in range(128 + n_steps):   # canonical order, teacher-forced on the GPU's ids: the prompt, then the free-running stretch
-            nxt, lg, _ = om.decode(tok, p, want_logits=(p == 128 + n_steps - 1))
-            if p >= 127:
-                same += int(nxt == int(gpu_ids[p]))
-            tok = int(forced[p + 1]) if p + 1 < 128 else int(gpu_ids[p])
-    finally:
-        O.set_order(O.ORDER_DOT16)
-    steps = []
-    tok = int(gpu_ids[127])
-    for i in range(n_steps):   # timed: the reference's CPU dot-product idiom on the bf16 dequantised copy, positions 128 ..
-        t1 = time.perf_counter()
-        om.decode(tok, 128 + i, want_logits=False)
-        steps.append(time.perf_counter() - t1)
-        tok = int(gpu_ids[128 + i])
-    sp = _spread(steps[2:])
-    wbytes = sum(w.algorithmic_bytes() for (layer, slot), w in m.weights.items() if not (layer == -1 and slot == 0))
-    om.close()
-    m.close()
-    return {"value": round(1e3 / sp["median_ms"], 3), "unit": "tokens/s of the %d-layer slice" % n_layer, "cores": O.num_threads(), "kind": "port",
-            "sample": "%d decode steps at positions 128..%d of a %d-layer Qwen3-32B-shaped model (4-bit layers, bf16 head; %d MB dequantised copy); a full 64-layer model would take ~%.0f ms per token on these cores "
-                      "(layers x 16 + head)" % (n_steps, 127 + n_steps, n_layer, max(prep, 0) // 2 ** 20, sp["median_ms"] * 16), "step_ms": sp,
-            "weight_bytes_4bit": int(wbytes), "greedy_ids_compared": n_steps + 1, "greedy_ids_equal_gpu": same, "logits_equal_bit_for_bit": int((g_logits == lg).sum()), "logits_compared": int(g_logits.size)}
-
-
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak of MI355X (MI355X_MICROARCH.md); the prefill GEMMs multiply bf16 fragments unpacked from 4-bit tiles
 
 
@@ -998,6 +950,54 @@ def cpu_baseline(m, cfg, forced, budget_s, min_steps=64, max_steps=256, canon_st
             "parity_timed_order": parity.get("timed_order"), "parity_fast_order": parity.get("fast_order"),
             "greedy_ids_equal_gpu": same, "greedy_ids_compared": n_c, "logits_equal_bit_for_bit": logits_equal, "logits_compared": n_logits,
             "mismatches_beyond_tolerance": n_c - same}
+
+
+def config4_slice_cpu(n_layer=4, n_steps=24):
+    """SURVEY section 8d, config 4's CPU column: the oracle cannot hold Qwen3-32B (18 GB, minutes per token), so a 4-LAYER SLICE of the same shapes (dim 5120, 64 / 8 heads of 128,
+    ffn 25600, vocab 151936, untied bf16 head; RTN 4-bit g128 layers) is decoded on the GPU (canonical order) and by the oracle on this host's cores from the same device weights:
+    greedy ids and the last logits must be equal bit for bit; the oracle's AVX2 pass is timed.  Reported for the slice only; 64 / 4 of the layer time is what a full model would cost."""
+    import numpy as np
+    from koifish_amd import lib as L, synth
+    from oracle import oracle as O
+    cfg = dict(synth.CONFIGS["qwen3-32b"], n_layer=n_layer, max_seq=512)
+    m = synth.build_on_gpu(cfg, seed=1234, layer_type=L.Q4, head_type=L.BF16)
+    _pick_threads()
+    om = O.from_device_model(m, attn_mode=O.ATTN_CANON)
+    prep = om.prepare_fast()
+    forced = np.full(cfg["max_seq"], -1, dtype=np.int32)
+    forced[:128] = np.random.default_rng(7).integers(0, cfg["vocab"], size=128)
+    m.set_forced(forced)
+    m.set_state(int(forced[0]), 0)
+    m.run_steps(0, 128 + n_steps, True)
+    m.sync()
+    gpu_ids = m.tokens_out(cfg["max_seq"])
+    g_logits = m.logits().copy()
+    O.set_order(O.ORDER_CANON)
+    same, lg = 0, None
+    try:
+        tok = int(forced[0])
+        for p in range(128 + n_steps):   # canonical order, teacher-forced on the GPU's ids: the prompt, then the free-running stretch
+            nxt, lg, _ = om.decode(tok, p, want_logits=(p == 128 + n_steps - 1))
+            if p >= 127:
+                same += int(nxt == int(gpu_ids[p]))
+            tok = int(forced[p + 1]) if p + 1 < 128 else int(gpu_ids[p])
+    finally:
+        O.set_order(O.ORDER_DOT16)
+    steps = []
+    tok = int(gpu_ids[127])
+    for i in range(n_steps):   # timed: the reference's CPU dot-product idiom on the bf16 dequantised copy, positions 128 ..
+        t1 = time.perf_counter()
+        om.decode(tok, 128 + i, want_logits=False)
+        steps.append(time.perf_counter() - t1)
+        tok = int(gpu_ids[128 + i])
+    sp = _spread(steps[2:])
+    wbytes = sum(w.algorithmic_bytes() for (layer, slot), w in m.weights.items() if not (layer == -1 and slot == 0))
+    om.close()
+    m.close()
+    return {"value": round(1e3 / sp["median_ms"], 3), "unit": "tokens/s of the %d-layer slice" % n_layer, "cores": O.num_threads(), "kind": "port",
+            "sample": "%d decode steps at positions 128..%d of a %d-layer Qwen3-32B-shaped model (4-bit layers, bf16 head; %d MB dequantised copy); a full 64-layer model would take ~%.0f ms per token on these cores "
+                      "(layers x 16 + head)" % (n_steps, 127 + n_steps, n_layer, max(prep, 0) // 2 ** 20, sp["median_ms"] * 16), "step_ms": sp,
+            "weight_bytes_4bit": int(wbytes), "greedy_ids_compared": n_steps + 1, "greedy_ids_equal_gpu": same, "logits_equal_bit_for_bit": int((g_logits == lg).sum()), "logits_compared": int(g_logits.size)}
 
 
 def _pick_threads():

@@ -378,6 +378,11 @@ int kf_embed_batch(kf_ctx* ctx, const kf_weight* w, const int32_t* d_tokens, int
 /* kf_qknorm_rope for tokens t < n_tok at positions pos0 + t: q + t*q_stride, k + t*k_stride (k may be cache rows: k_stride = kv_stride) */
 int kf_qknorm_rope_batch(kf_ctx* ctx, kf_bf16* q, kf_bf16* k, const kf_bf16* wq_norm, const kf_bf16* wk_norm, const float* rope_table, int pos0, int n_tok,
                          int64_t q_stride, int64_t k_stride, int n_head, int n_kv, int hd, float eps);
+/* SelfAttention::cuFlow's projection step for a token batch in one call: Q | K | V of the same x (K / V rows may be the cache rows themselves, TGraph.cpp:198-207) followed by
+ * ROPE::cuInfer on q and k (kf_qknorm_rope_batch).  For >= 1024 tokens and head_dim 128 both happen in ONE launch -- the stacked tile GEMM with the q/k-norm and the rotation in
+ * its epilogue (a 128-row tile is one head) -- otherwise kf_linear_multi + kf_qknorm_rope_batch.  Same arithmetic either way (token batches: MFMA summation order, tolerances). */
+int kf_qkv_rope_batch(kf_ctx* ctx, const kf_weight* wq, const kf_weight* wk, const kf_weight* wv, const kf_bf16* x, kf_bf16* q, kf_bf16* k, kf_bf16* v, int nTok,
+                      const kf_bf16* wq_norm_or_null, const kf_bf16* wk_norm_or_null, const float* rope_table_or_null, int pos0, int n_head, int n_kv, int head_dim, float eps);
 /* causal attention of tokens t < n_tok (position pos0 + t attends to cache rows 0 .. pos0 + t, which must already hold the prepared
  * keys / values of the batch); q and out rows are q_stride elements apart; same arithmetic as kf_attn_decode, one workgroup per
  * (kv-head, token), no scratch. */

@@ -679,7 +679,7 @@ size_t kf_linear_multi_scratch_bytes(int n_w, const kf_weight* const* w, int nTo
     return multi_deq_ok(n_w, w, nTok, &need) ? need : 0;
 }
 // KF_OK done, 1 not this route, < 0 error
-static int multi_deq_route(kf_ctx* c, int n_w, const kf_weight* const* w, const kf_bf16* x, kf_bf16* const* y, int nTok) {
+static int multi_deq_route(kf_ctx* c, int n_w, const kf_weight* const* w, const kf_bf16* x, kf_bf16* const* y, int nTok, const kf::G3Rope* rope = nullptr) {
     size_t need = 0;
     if (!multi_deq_ok(n_w, w, nTok, &need) || !c->scratch || c->scratch_bytes < need || !al16(x)) return 1;
     int M[3] = {0, 0, 0};
@@ -689,7 +689,27 @@ static int multi_deq_route(kf_ctx* c, int n_w, const kf_weight* const* w, const 
         if (r != KF_OK) return r < 0 ? r : KF_HIP_CHECK;
         M[i] = w[i]->ne0, off += up256z((size_t)w[i]->ne0 * w[i]->ne1 * 2);
     }
-    return kf::gemm3_multi_launch(c->stream, n_w, (const uint16_t*)c->scratch, M, w[0]->ne1, x, w[0]->ne1, nTok, y);
+    return kf::gemm3_multi_launch(c->stream, n_w, (const uint16_t*)c->scratch, M, w[0]->ne1, x, w[0]->ne1, nTok, y, rope);
+}
+int kf_qkv_rope_batch(kf_ctx* c, const kf_weight* wq, const kf_weight* wk, const kf_weight* wv, const kf_bf16* x, kf_bf16* q, kf_bf16* k, kf_bf16* v, int nTok, const kf_bf16* wq_norm,
+                      const kf_bf16* wk_norm, const float* rope_table, int pos0, int n_head, int n_kv, int hd, float eps) {
+    CHKCTX(c);
+    if (!wq || !wk || !wv || !x || !q || !k || !v || nTok < 1 || pos0 < 0) return fail(KF_INVALID_ARGS, "kf_qkv_rope_batch: bad args");
+    const kf_weight* ws[3] = {wq, wk, wv};
+    kf_bf16* ys[3] = {q, k, v};
+    if (hd == 128 && nTok >= KF_MULTI_DEQ_MIN && wq->ne0 == n_head * hd && wk->ne0 == n_kv * hd) { /* one launch: the stacked tile GEMM with q/k-norm + RoPE in its epilogue */
+        for (int i = 0; i < 3; i++) {
+            const int r = check_weight(ws[i], "kf_qkv_rope_batch");
+            if (r) return r;
+        }
+        const kf::G3Rope rp = {wq_norm, wk_norm, rope_table, pos0, eps};
+        const int rc = multi_deq_route(c, 3, ws, x, ys, nTok, &rp);
+        if (rc < 0) return fail(rc, "kf_qkv_rope_batch (stacked tile GEMM + RoPE epilogue) failed with %d", rc);
+        if (rc == KF_OK) return KF_OK;
+    }
+    const int r = kf_linear_multi(c, 3, ws, x, ys, nTok);
+    if (r) return r;
+    return kf_qknorm_rope_batch(c, q, k, wq_norm, wk_norm, rope_table, pos0, nTok, wq->ne0, wk->ne0, n_head, n_kv, hd, eps);
 }
 int kf_linear_multi(kf_ctx* c, int n_w, const kf_weight* const* w, const kf_bf16* x, kf_bf16* const* y, int nTok) {
     CHKCTX(c);
@@ -724,8 +744,16 @@ int kf_gateup_swiglu_batch(kf_ctx* c, const kf_weight* gate, const kf_weight* up
     if (r) return r;
     if (!x || !act || !up_scratch || nTok < 1) return fail(KF_INVALID_ARGS, "kf_gateup_swiglu_batch: bad args");
     if (gate->ne0 != up->ne0 || gate->ne1 != up->ne1) return fail(KF_INVALID_ARGS, "kf_gateup_swiglu_batch: gate and up shapes differ");
-    if (nTok >= KF_MULTI_DEQ_MIN) { /* gate | up stacked in one large-batch launch, then the SwiGLU expression on the two bf16 results (what the paired kernel computes too) */
+    if (nTok >= KF_MULTI_DEQ_MIN) { /* gate | up dequantised interleaved, ONE tile-GEMM launch with the SwiGLU expression in its epilogue (on the two bf16-rounded projections,
+                                       as the paired kernel and swiglu_kernel form it) */
         const kf_weight* ws[2] = {gate, up};
+        size_t need = 0;
+        if (multi_deq_ok(2, ws, nTok, &need) && c->scratch && c->scratch_bytes >= need && al16(x) && gate->ne0 % 128 == 0 &&
+            kf::dequant_launch(c->stream, gate, (uint16_t*)c->scratch, 2, 0) == KF_OK && kf::dequant_launch(c->stream, up, (uint16_t*)c->scratch, 2, 1) == KF_OK) {
+            const int rc = kf::gemm3_swiglu_launch(c->stream, (const uint16_t*)c->scratch, gate->ne0, gate->ne1, x, gate->ne1, nTok, act);
+            if (rc < 0) return fail(rc, "kf_gateup_swiglu_batch (interleaved dequantise + tile GEMM with SwiGLU epilogue) failed with %d", rc);
+            if (rc == KF_OK) return KF_OK;
+        }
         kf_bf16* ys[2] = {act, up_scratch};
         const int rc = multi_deq_route(c, 2, ws, x, ys, nTok);
         if (rc < 0) return fail(rc, "kf_gateup_swiglu_batch (dequantise + stacked tile GEMM) failed with %d", rc);

@@ -157,9 +157,111 @@ __device__ __forceinline__ void g3_mainloop(const GemmArgs& a, int m0, int t0, i
     __builtin_amdgcn_s_barrier(); /* a following segment's first loads must not overtake the last reads */
 }
 // epilogue (gemm_epilogue's order): lane holds rows m .. m+3 of a 16 x 16 tile for token column r16
-template <bool AKM, class C>
-__device__ __forceinline__ void g3_epilogue(const GemmArgs& a, int m0, int t0, const f32x4 (&acc)[C::MT][C::NT], int wid, int lane) {
+// ROPE::cuInfer on a 128-row tile that is one head (hd 128) of Q or K, in the epilogue of the stacked Q | K | V launch (the arithmetic of prep_head_cs, kf_attn_common.h: the
+// projection rounded to bf16 as the plain epilogue stores it, fp64 sum of squares, s rounded to bf16, (x s) w rounded, rotate-half pairs (j, j + 64) with every product and the
+// sum rounded once).  Wave (wm, wn) holds rows 64 wm .. + 63 x tokens 64 wn .. + 63: a token's 128 squares are summed over the 4 lanes of a column (row swaps) and the two wm
+// waves (LDS), and a rotation pair's other element sits in the other wm wave at the SAME lane and register: one exchange through the (now free) stage buffers.
+template <class C>
+__device__ __forceinline__ void g3_epilogue_qkrope(const GemmArgs& a, int m0, int t0, const f32x4 (&acc)[C::MT][C::NT], int wid, int lane, unsigned char* smem_raw, uint16_t* ybase, long long ldy,
+                                                   int mshift, const uint16_t* nw) {
+    static_assert(C::BM == 128 && C::MT == 4 && C::WN == 2, "one head per tile: 2 x 2 waves of 64 rows x 64 tokens");
     const int wm = wid / C::WN, wn = wid % C::WN, r16 = lane & 15, q4 = lane >> 4;
+    float x[C::MT][C::NT][4];
+    double ss[C::NT];
+#pragma unroll
+    for (int nt = 0; nt < C::NT; nt++) {
+        ss[nt] = 0.0;
+#pragma unroll
+        for (int mt = 0; mt < C::MT; mt++) {
+            const float vv[4] = {acc[mt][nt].x, acc[mt][nt].y, acc[mt][nt].z, acc[mt][nt].w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                x[mt][nt][j] = round_bf16(vv[j]); /* the value the plain epilogue stores (alpha 1, no bias) */
+                ss[nt] = fma((double)x[mt][nt][j], (double)x[mt][nt][j], ss[nt]);
+            }
+        }
+        ss[nt] = xsum32_d(xsum16_d(ss[nt])); /* the column's 4 lanes (l ^ 16, l ^ 32): this wave's 64 rows */
+    }
+    double* red = reinterpret_cast<double*>(smem_raw);                                  /* [2 wm][128 tokens] */
+    uint16_t* xch = reinterpret_cast<uint16_t*>(smem_raw + 2 * 128 * sizeof(double));   /* [4 waves][64 values][64 lanes] bf16 */
+    if (q4 == 0) {
+#pragma unroll
+        for (int nt = 0; nt < C::NT; nt++) red[wm * 128 + wn * 64 + nt * 16 + r16] = ss[nt];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < C::NT; nt++) {
+        const int tl = wn * 64 + nt * 16 + r16;
+        float s = 1.0f;
+        if (nw) s = round_bf16(1.0f / sqrtf((float)(red[tl] + red[128 + tl]) / 128.0f + a.qk_eps));
+#pragma unroll
+        for (int mt = 0; mt < C::MT; mt++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (nw) x[mt][nt][j] = round_bf16(x[mt][nt][j] * s * bf2f(nw[wm * 64 + mt * 16 + 4 * q4 + j]));
+                xch[((size_t)wid * 64 + (mt * C::NT + nt) * 4 + j) * 64 + lane] = f2bf(x[mt][nt][j]);
+            }
+    }
+    __syncthreads();
+    const int pw = (1 - wm) * C::WN + wn; /* the wave that holds the other element of every pair */
+#pragma unroll
+    for (int mt = 0; mt < C::MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < C::NT; nt++) {
+            const int tok = t0 + wn * 64 + nt * 16 + r16, jj = mt * 16 + 4 * q4; /* pair index 0 .. 63 of this lane's first row */
+            if (tok >= a.n) continue;
+            uint16_t o[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float other = bf2f(xch[((size_t)pw * 64 + (mt * C::NT + nt) * 4 + j) * 64 + lane]), own = x[mt][nt][j];
+                float v = own;
+                if (a.rope_table) {
+                    const float2 cs = *reinterpret_cast<const float2*>(a.rope_table + (size_t)(a.rope_pos0 + tok) * 128 + 2 * (jj + j));
+                    if (wm == 0) { /* x_j c - x_{j+64} s */
+                        const float p0 = own * cs.x, p1 = other * cs.y;
+                        v = p0 - p1;
+                    } else { /* x_j s + x_{j+64} c */
+                        const float p0 = other * cs.y, p1 = own * cs.x;
+                        v = p0 + p1;
+                    }
+                }
+                o[j] = f2bf(v);
+            }
+            uint16_t* yp = ybase + (size_t)tok * ldy + (m0 - mshift) + wm * 64 + jj;
+            *reinterpret_cast<u32x2*>(yp) = u32x2{(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16)};
+        }
+}
+
+template <bool AKM, class C>
+__device__ __forceinline__ void g3_epilogue(const GemmArgs& a, int m0, int t0, const f32x4 (&acc)[C::MT][C::NT], int wid, int lane, unsigned char* smem_raw = nullptr) {
+    const int wm = wid / C::WN, wn = wid % C::WN, r16 = lane & 15, q4 = lane >> 4;
+    if (a.swiglu) { /* Relu::Forw (CU_swiglu_v0, Activation.cu:85-93) on the two bf16-rounded projections, as swiglu_kernel: accumulator block 2i holds gate rows, block 2i + 1 the up rows of
+                       the same 16 FFN rows (the operand was dequantised interleaved), same lane, same register */
+        const int F = a.M >> 1;
+#pragma unroll
+        for (int mt = 0; mt < C::MT; mt += 2)
+#pragma unroll
+            for (int nt = 0; nt < C::NT; nt++) {
+                const int tok = t0 + wn * (16 * C::NT) + nt * 16 + r16, f = ((m0 + wm * (16 * C::MT)) >> 1) + (mt >> 1) * 16 + 4 * q4;
+                if (tok >= a.n || f >= F) continue;
+                const float gv[4] = {acc[mt][nt].x, acc[mt][nt].y, acc[mt][nt].z, acc[mt][nt].w}, uv[4] = {acc[mt + 1][nt].x, acc[mt + 1][nt].y, acc[mt + 1][nt].z, acc[mt + 1][nt].w};
+                uint16_t o[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float g = round_bf16(gv[j]), u = round_bf16(uv[j]);
+                    o[j] = f2bf((g * u) / (1.0f + kf_expf(-g)));
+                }
+                uint16_t* yp = a.y + (size_t)tok * a.ldy + f;
+                if (f + 3 < F && ((a.ldy & 3) == 0)) {
+                    *reinterpret_cast<u32x2*>(yp) = u32x2{(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16)};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (f + j < F) yp[j] = o[j];
+                }
+            }
+        return;
+    }
     // up to three matrices stacked along M (Q | K | V or gate | up, each a multiple of the 256-row tile: a.rb_end[j] = cumulative rows / 32): the tile's rows go to
     // that matrix's own output (the K and V rows of a prompt land in the cache, Q in its buffer)
     uint16_t* ybase = a.y;
@@ -170,6 +272,15 @@ __device__ __forceinline__ void g3_epilogue(const GemmArgs& a, int m0, int t0, c
         if (m0 >= e1 && a.njobs > 2) ybase = a.xy[1], ldy = a.xldy[1], mshift = e1, Mlim = a.rb_end[2] * 32;
         else if (m0 >= e0) ybase = a.xy[0], ldy = a.xldy[0], mshift = e0, Mlim = e1;
         else Mlim = e0;
+    }
+    if constexpr (!AKM && C::BM == 128) {
+        if (a.qkrope && smem_raw) { /* workgroup-uniform: a tile lies inside one job */
+            const int job = a.njobs > 1 ? (m0 >= a.rb_end[1] * 32 ? 2 : (m0 >= a.rb_end[0] * 32 ? 1 : 0)) : 0;
+            if (job < 2) {
+                g3_epilogue_qkrope<C>(a, m0, t0, acc, wid, lane, smem_raw, ybase, ldy, mshift, a.qk_norm[job]);
+                return;
+            }
+        }
     }
     const bool vec_ok = ((ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(ybase) & 7) == 0);
 #pragma unroll
@@ -223,7 +334,7 @@ __global__ void __launch_bounds__(C::NTH, C::WGS_PER_CU * C::NW / 4) gemm3_kerne
 #pragma unroll
         for (int j = 0; j < C::NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     g3_mainloop<AKM, BKM, BK, C>(a, m0, t0, 0, a.K / BK, acc, smem_raw, wid, lane);
-    g3_epilogue<AKM, C>(a, m0, t0, acc, wid, lane);
+    g3_epilogue<AKM, C>(a, m0, t0, acc, wid, lane, smem_raw);
 }
 
 // SPLIT-K forms for launches with fewer tiles than CUs (a weight gradient [OC, IC] is 49 .. 175 tiles, its contraction 8192 token rows long).  The pieces are cut so
@@ -321,7 +432,7 @@ __global__ void __launch_bounds__(C::NTH, C::WGS_PER_CU * C::NW / 4) gemm3_sk_ke
             g3_publish<C>(s, slot, acc, tid);
         } else {
             for (int c = c0; c < c1; c++) g3_collect<C>(s, c, acc, tid);
-            g3_epilogue<AKM, C>(a, m0, t0, acc, wid, lane);
+            g3_epilogue<AKM, C>(a, m0, t0, acc, wid, lane, smem_raw);
         }
         it += helper ? k1 - k0 : 1;
     }
@@ -415,7 +526,9 @@ int gemm3_km_launch(hipStream_t st, const uint16_t* A, long long lda, bool akm, 
 
 // up to three bf16 matrices stacked along M in ONE contiguous buffer (the caller dequantised them back to back: Q | K | V, or gate | up), each a multiple of 256
 // rows, multiplied by the same x in one launch; matrix j's rows go to y[j] (row stride M[j]).  1 = shape not served.
-int gemm3_multi_launch(hipStream_t st, int n_w, const uint16_t* Wcat, const int* M, int K, const uint16_t* x, long long ldx, int n, uint16_t* const* y) {
+// rope != NULL (n_w == 3: Q | K | V, head_dim 128): q/k-norm + RoPE in the epilogue (GemmArgs::qkrope); served on the 128 x 128 tile only -- 1 otherwise, the caller then
+// runs the plain stacked launch and qknorm_rope_launch
+int gemm3_multi_launch(hipStream_t st, int n_w, const uint16_t* Wcat, const int* M, int K, const uint16_t* x, long long ldx, int n, uint16_t* const* y, const G3Rope* rope) {
     if (n_w < 2 || n_w > 3 || K % G3_BK != 0 || K < G3_BK || n < G3_BN || (ldx & 7) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(Wcat) & 15)) return 1;
     GemmArgs a;
     memset(&a, 0, sizeof(a));
@@ -434,7 +547,29 @@ int gemm3_multi_launch(hipStream_t st, int n_w, const uint16_t* Wcat, const int*
     if (nwg < 64) return 1;
     // fewer than 160 big tiles (Q | K | V of a 0.6B model at 2047 tokens: 128): four times as many 128 x 128 tiles fill the chip better (2047-token prompt 8.20 -> 7.84 ms;
     // gate | up, 192 big tiles, is better left on them: 7.93 ms with both small)
+    if (rope) {
+        if (n_w != 3 || M[0] % 128 != 0 || M[1] % 128 != 0 || ((M[0] | M[1] | M[2]) & 3) || (reinterpret_cast<uintptr_t>(y[0]) & 7) || (reinterpret_cast<uintptr_t>(y[1]) & 7)) return 1;
+        a.qkrope = 1, a.qk_norm[0] = rope->wq, a.qk_norm[1] = rope->wk, a.rope_table = rope->table, a.rope_pos0 = rope->pos0, a.qk_eps = rope->eps;
+        return g3_go_c<false, false, G3Small>(st, a, (long)(tot / 128) * ((n + 127) / 128), nullptr, 0, 1); /* always the head-sized tile */
+    }
     if (nwg < 160) return g3_go_c<false, false, G3Small>(st, a, (long)(tot / 128) * ((n + 127) / 128), nullptr, 0, 1);
+    return g3_go<false, false>(st, a, nwg, nullptr, 0);
+}
+
+// gate | up dequantised INTERLEAVED in blocks of 16 rows (dequant_launch ilv_n = 2) x the same x, SwiGLU in the epilogue: act[n, ffn] in one launch (the stacked route
+// wrote both projections and ran swiglu_kernel over them: 12 us and 38 MB of traffic per layer of a 2047-token prompt).  1 = shape not served.
+int gemm3_swiglu_launch(hipStream_t st, const uint16_t* Wilv, int ffn, int K, const uint16_t* x, long long ldx, int n, uint16_t* act) {
+    const int M = 2 * ffn;
+    if (ffn % 16 != 0 || M % G3_BM != 0 || K % G3_BK != 0 || K < G3_BK || n < G3_BN || (ldx & 7) || (ffn & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(Wilv) & 15) ||
+        (reinterpret_cast<uintptr_t>(act) & 7))
+        return 1;
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.njobs = 1, a.swiglu = 1;
+    a.w = reinterpret_cast<const unsigned char*>(Wilv), a.M = M, a.K = K, a.x = x, a.ldx = ldx, a.n = n, a.y = act, a.ldy = ffn, a.alpha = 1.0f, a.beta = 0.0f;
+    const long nwg = (long)(M / G3_BM) * ((n + G3_BN - 1) / G3_BN);
+    if (nwg < 64) return 1;
+    if (nwg < 160) return g3_go_c<false, false, G3Small>(st, a, (long)(M / 128) * ((n + 127) / 128), nullptr, 0, 1);
     return g3_go<false, false>(st, a, nwg, nullptr, 0);
 }
 

@@ -36,6 +36,14 @@ struct GemmArgs {
     int xM[2];
     uint16_t* xy[2];
     long long xldy[2];
+    // kf_gemm3.hip only, the 128 x 128 tile, head_dim 128 (a tile = one head): ROPE::cuInfer (q/k-norm CU_rms_forward_v2 + rotate-half RoPE) in the epilogue of the stacked
+    // Q | K | V launch -- job 0's rows normed with qk_norm[0], job 1's with qk_norm[1], job 2 (V) stored as it is; position of token t = rope_pos0 + t
+    int qkrope;
+    const uint16_t* qk_norm[2];
+    const float* rope_table; /* [n_ctx][64][2] (cos, sin) */
+    int rope_pos0;
+    float qk_eps;
+    int swiglu; /* kf_gemm3.hip only: W = gate | up interleaved in blocks of 16 rows (dequant_launch ilv_n = 2), M = 2 ffn; the epilogue stores SwiGLU(gate, up) of every FFN row: y[n, ffn] */
 };
 
 // ---- 8 consecutive weights -> 4 packed bf16 pairs (element 2i in the low half of word i)

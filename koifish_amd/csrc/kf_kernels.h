@@ -89,7 +89,14 @@ void argmax_finish_launch(hipStream_t st, const float* val, const int* idx, int 
 int gemm3_km_launch(hipStream_t st, const uint16_t* A, long long lda, bool akm, const uint16_t* B, long long ldb, bool bkm, int n, int M, int K, uint16_t* y, long long ldy,
                     const uint16_t* bias, float alpha, float beta, void* ws, size_t ws_bytes);
 size_t gemm3_sk_ws_bytes();
-int gemm3_multi_launch(hipStream_t st, int n_w, const uint16_t* Wcat, const int* M, int K, const uint16_t* x, long long ldx, int n, uint16_t* const* y);
+struct G3Rope { /* ROPE::cuInfer folded into the stacked Q | K | V launch's epilogue (kf_gemm3.hip g3_epilogue_qkrope) */
+    const uint16_t *wq, *wk; /* q / k norm weights [128] or NULL */
+    const float* table;      /* RoPE (cos, sin) table or NULL */
+    int pos0;
+    float eps;
+};
+int gemm3_multi_launch(hipStream_t st, int n_w, const uint16_t* Wcat, const int* M, int K, const uint16_t* x, long long ldx, int n, uint16_t* const* y, const G3Rope* rope = nullptr);
+int gemm3_swiglu_launch(hipStream_t st, const uint16_t* Wilv, int ffn, int K, const uint16_t* x, long long ldx, int n, uint16_t* act); /* kf_gemm3.hip */
 int gemm_launch(hipStream_t st, const kf_weight* w, const uint16_t* x, long long ldx, int n, uint16_t* y, long long ldy, const uint16_t* bias, float alpha,
                 float beta, const uint16_t* residual, long long ldr);
 
@@ -182,7 +189,7 @@ int swiglu_launch(hipStream_t st, const uint16_t* gate, const uint16_t* up, uint
 int add_launch(hipStream_t st, const uint16_t* a, const uint16_t* b, uint16_t* out, int n);
 int embed_launch(hipStream_t st, const kf_weight* w, int token, const int32_t* d_token, const int32_t* d_state, const int32_t* d_forced,
                  uint16_t* out, int n_tok = 1);
-int dequant_launch(hipStream_t st, const kf_weight* w, uint16_t* out);
+int dequant_launch(hipStream_t st, const kf_weight* w, uint16_t* out, int ilv_n = 1, int ilv_i = 0); /* ilv_n > 1: rows interleaved with ilv_n - 1 other matrices in blocks of 16 (kf_ops.hip) */
 int adamw_launch(hipStream_t st, uint16_t* params, uint16_t* grads, void* gm, void* gv, size_t n, int mv_bf16, float lr, float beta1, float beta2, float b1c,
                  float b2c, float eps, float wd, float grad_scale, unsigned int seed, int* status);
 int sample_launch(hipStream_t st, const uint16_t* logits, int n, int top_k, float temperature, float top_p, unsigned long long* rng, int32_t* d_token,

@@ -366,8 +366,10 @@ static int fmt_of(int type, int* epb) {
         default: *epb = 0; return -1;
     }
 }
+// ilv_n > 1: the rows land INTERLEAVED with those of ilv_n - 1 other matrices of the same shape, in blocks of 16 rows: row r -> row (r / 16) * 16 * ilv_n + 16 * ilv_i + r % 16
+// of the stacked copy (gate | up side by side in every 32-row block of the tile GEMM's operand: its SwiGLU epilogue finds both projections of an FFN row in one lane)
 __global__ void dequant_kernel(int fmt, int epb, const u32x4* __restrict__ data, const uint16_t* __restrict__ zero, const uint16_t* __restrict__ step, int lGroup,
-                               int qBias, size_t nblocks, size_t block0, uint16_t* __restrict__ out) {
+                               int qBias, size_t nblocks, size_t block0, uint16_t* __restrict__ out, int bpr, int ilv_n, int ilv_i) {
     const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblocks) return;
     const size_t gb = block0 + b;
@@ -376,10 +378,15 @@ __global__ void dequant_kernel(int fmt, int epb, const u32x4* __restrict__ data,
         const size_t gi = gb * epb / lGroup;
         st = bf2f(step[gi]), ze = bf2f(zero[gi]);
     }
-    dequant_block(fmt, data[gb], st, ze, qBias, out + b * epb);
+    size_t ob = b;
+    if (ilv_n > 1) {
+        const size_t r = b / bpr, c = b - r * bpr;
+        ob = ((r >> 4) * 16 * ilv_n + 16 * ilv_i + (r & 15)) * bpr + c;
+    }
+    dequant_block(fmt, data[gb], st, ze, qBias, out + ob * epb);
 }
-int dequant_launch(hipStream_t st, const kf_weight* w, uint16_t* out) {
-    if (is_row_lut(w)) return lut_dequant_launch(st, w, out);
+int dequant_launch(hipStream_t st, const kf_weight* w, uint16_t* out, int ilv_n, int ilv_i) {
+    if (is_row_lut(w)) return ilv_n > 1 ? KF_UNSUPPORTED_DATATYPE : lut_dequant_launch(st, w, out);
     int epb;
     const int fmt = fmt_of(w->type, &epb);
     if (fmt < 0) return KF_UNSUPPORTED_DATATYPE;
@@ -392,8 +399,9 @@ int dequant_launch(hipStream_t st, const kf_weight* w, uint16_t* out) {
         step = zero + n / w->lGroup;
     }
     const size_t nb = n / epb;
+    if (ilv_n > 1 && (w->ne1 % epb != 0 || w->ne0 % 16 != 0)) return KF_INVALID_ARGS;
     hipLaunchKernelGGL(dequant_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, fmt, epb, (const u32x4*)w->data, zero, step, w->lGroup, w->qBias, nb,
-                       (size_t)0, out);
+                       (size_t)0, out, w->ne1 / epb, ilv_n, ilv_i);
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 

@@ -168,9 +168,9 @@ int SelfAttention::cuFlow(floatX* bx, int pos0, int n) {
     KF_TRY(kf_rmsnorm(c, bx, ToX(norm.w), bn, n, C, norm.rms_eps, nullptr));
     const kf_weight* ws[3] = {&wq, &wk, &wv};
     kf_bf16* ys[3] = {bq, krows, vrows};  // K.out / V.out alias the cache rows (_devQKV)
-    KF_TRY(kf_linear_multi(c, 3, ws, bn, ys, n));
-    KF_TRY(kf_qknorm_rope_batch(c, bq, krows, normQ.w ? ToX(normQ.w) : nullptr, normK.w ? ToX(normK.w) : nullptr, f->rope_table, pos0, n, q_dim, kv_dim, n_head,
-                               n_head_kv, head_dim, normQ.rms_eps));
+    (void)ws, (void)ys;
+    KF_TRY(kf_qkv_rope_batch(c, &wq, &wk, &wv, bn, bq, krows, vrows, n, normQ.w ? ToX(normQ.w) : nullptr, normK.w ? ToX(normK.w) : nullptr, f->rope_table, pos0, n_head, n_head_kv,
+                             head_dim, normQ.rms_eps));
     KF_TRY(kf_attn_prefill(c, bq, key_cache, val_cache, ba, pos0, n, q_dim, n_head, n_head_kv, head_dim, kv_dim));
     return kf_linear(c, &wo, ba, bx, nullptr, n, 1.0f, 0.0f, KF_EPI_RESIDUAL, bx);
 }
