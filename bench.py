@@ -23,6 +23,11 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("OMP_PROC_BIND", "close")
 os.environ.setdefault("OMP_PLACES", "cores")
 
+try:   # the CPUs this process may use, before an OpenMP runtime pins its initial thread to one core (OMP_PROC_BIND): child processes inherit the mask of the thread that spawns them
+    _ALL_CPUS = os.sched_getaffinity(0)
+except Exception:
+    _ALL_CPUS = None
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy achieves
 
 
@@ -276,7 +281,10 @@ def _child(argv, timeout_s):
     import subprocess
     t0 = time.perf_counter()
     try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=timeout_s)
+        def unpin():   # the parent's OpenMP runtime bound this thread to one core (2 hardware threads): the child's CPU legs would see 2 "cores"
+            if _ALL_CPUS:
+                os.sched_setaffinity(0, _ALL_CPUS)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=timeout_s, preexec_fn=unpin)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not lines:
             return {"error": (r.stderr or r.stdout)[-300:]}
