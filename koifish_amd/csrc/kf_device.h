@@ -260,6 +260,17 @@ __device__ __forceinline__ float acc_join(f32x2_t a) { return a.x + a.y; }
 __device__ __forceinline__ float acc_pick(bool c, float a, float b) { return c ? a : b; }
 __device__ __forceinline__ f32x2_t acc_pick(bool c, f32x2_t a, f32x2_t b) { return f32x2_t{c ? a.x : b.x, c ? a.y : b.y}; }
 __device__ __forceinline__ f32x2_t pk_fma(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
+// 1-bit storage, canonical order: one chain pair per dword position of the lane's 128-element blocks (oracle/kf_oracle.c section 4c); joined as a balanced tree
+struct Acc4 {
+    f32x2_t s[4];
+};
+__device__ __forceinline__ float acc_join(const Acc4& a) { return ((a.s[0].x + a.s[0].y) + (a.s[1].x + a.s[1].y)) + ((a.s[2].x + a.s[2].y) + (a.s[3].x + a.s[3].y)); }
+__device__ __forceinline__ Acc4 acc_pick(bool c, const Acc4& a, const Acc4& b) {
+    Acc4 r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) r.s[i] = acc_pick(c, a.s[i], b.s[i]);
+    return r;
+}
 template <bool CANON>
 __device__ __forceinline__ acc_t<CANON> dotp_dev(uint32_t w, uint32_t x, acc_t<CANON> acc) {
     if constexpr (CANON) {

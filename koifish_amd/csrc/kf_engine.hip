@@ -345,9 +345,13 @@ struct PlanT {
     static constexpr CPlan plan() { return c_plan(K_, EPB_, M0_, M1_, M2_, PAIRED_, NWG_); }
 };
 // the four phases of a model shape
+// elements per block as the engine walks a matrix: the storage's 16-byte block, except 1-bit -- one DWORD (32 weights) of a 128-element block per lane, so that a 1-bit
+// matrix has the lanes, slots and chains of a 4-bit one (BlockPrep<FMT_Q1T>)
+template <int FMT>
+constexpr int eng_vepb() { return FMT == FMT_Q1T ? 32 : BlockDot<FMT>::EPB; }
 template <int FMT, int DIM, int QD, int KVD, int FFN, int NWG>
 struct EngShape {
-    static constexpr int EPB = BlockDot<FMT>::EPB;
+    static constexpr int EPB = eng_vepb<FMT>();
     using P1 = PlanT<DIM, EPB, QD, KVD, KVD, false, NWG>;
     using P4 = PlanT<QD, EPB, DIM, 0, 0, false, NWG>;
     using P5 = PlanT<DIM, EPB, FFN, FFN, 0, true, NWG>;
@@ -383,7 +387,7 @@ __device__ __forceinline__ MvAt mv_at(int k, int s0, int cw, int lane, int Mj) {
 template <class PL, int NCW, int FMT, int MAXS>
 __device__ __forceinline__ void mv_prefetch(const EngMat m, const EngMat m2, int s0, int cw, int lane, int Mj, MvRegs<PL::PAIRED, MAXS>& R, uint32_t hotbits = 0xffffffffu) {
     constexpr bool GAMA = BlockDot<FMT>::HAS_GAMA;
-    constexpr int gshift = FMT >= FMT_Q4 ? (FMT == FMT_Q4 || FMT == FMT_Q4P ? 2 : (FMT == FMT_Q2 ? 1 : 0)) : 0; /* 128-weight groups */
+    constexpr int gshift = FMT >= FMT_Q4 ? (FMT == FMT_Q4 || FMT == FMT_Q4P || FMT == FMT_Q1T ? 2 : (FMT == FMT_Q2 ? 1 : 0)) : 0; /* 128-weight groups (1-bit: four dword "blocks") */
 #pragma unroll
     for (int k = 0; k < MAXS; k++) {
         const MvAt q = mv_at<PL, NCW>(k, s0, cw, lane, Mj);
@@ -392,8 +396,14 @@ __device__ __forceinline__ void mv_prefetch(const EngMat m, const EngMat m2, int
         row = ((hotbits >> ((q.row - s0 * PL::RPS) & 31)) & 1u) ? row : 0;
         const int col = q.col < PL::nBlk ? q.col : PL::nBlk - 1;
         const uint32_t bidx = (uint32_t)row * (uint32_t)PL::nBlk + (uint32_t)col;
-        R.w[k] = __builtin_nontemporal_load(m.w + bidx);
-        if (PL::PAIRED) R.w2[k] = __builtin_nontemporal_load(m2.w + bidx);
+        if constexpr (FMT == FMT_Q1T) { /* this lane's dword of the 16-byte block: dword 3 holds elements 0 .. 31 */
+            const uint32_t di = (bidx & ~3u) + (3u - (bidx & 3u));
+            R.w[k] = u32x4{__builtin_nontemporal_load(reinterpret_cast<const uint32_t KF_GLOBAL*>(m.w) + di), 0u, 0u, 0u};
+            if (PL::PAIRED) R.w2[k] = u32x4{__builtin_nontemporal_load(reinterpret_cast<const uint32_t KF_GLOBAL*>(m2.w) + di), 0u, 0u, 0u};
+        } else {
+            R.w[k] = __builtin_nontemporal_load(m.w + bidx);
+            if (PL::PAIRED) R.w2[k] = __builtin_nontemporal_load(m2.w + bidx);
+        }
         if (GAMA) {
             const uint32_t gi = bidx >> gshift;
             R.st[k] = m.step[gi], R.ze[k] = m.zero[gi];
@@ -402,45 +412,6 @@ __device__ __forceinline__ void mv_prefetch(const EngMat m, const EngMat m2, int
     }
 }
 // epi(row, v, v2) runs in the lane that owns a finished row (row counted inside the matrix)
-// F32X: the activations are staged as fp32 chunks (the canonical 4-bit forms, BlockDotF); tab: the 1-bit selector table (FMT_Q1T); hotbits: as for mv_prefetch -- a cold row's
-// products are masked, its epilogue runs on zeros (D_matmul_sparse: val = 0)
-template <class PL, int NCW, int FMT, int MAXS, bool CANON, bool F32X, typename Epi>
-__device__ __forceinline__ void mv_run(float qb, float qb2, int s0, int cw, int lane, int Mj, const MvRegs<PL::PAIRED, MAXS>& R, const u32x4* xs, const u32x4* tab, uint32_t hotbits, Epi&& epi) {
-    /* CANON: the canonical order (oracle/kf_oracle.c section 4c), one v_pk_fma_f32 per weight pair on fp32 operands; same lanes / chains / tree as gemv_kernel either way */
-    acc_t<CANON> acc{}, acc2{};
-#pragma unroll
-    for (int k = 0; k < MAXS; k++) {
-        const int sl = k / PL::iters, it = k - sl * PL::iters;
-        if (cw + sl * NCW >= PL::spg) continue; /* wave-uniform: this wave has no such slot */
-        const MvAt q = mv_at<PL, NCW>(k, s0, cw, lane, Mj);
-        const int col = q.col < PL::nBlk ? q.col : PL::nBlk - 1;
-        if (it == 0) acc = acc_t<CANON>{}, acc2 = acc_t<CANON>{};
-        const bool on = q.ok && ((hotbits >> ((q.row - s0 * PL::RPS) & 31)) & 1u);
-        const float st = bf2f(R.st[k]);
-        acc_t<CANON> r;
-        if constexpr (F32X && FMT == FMT_Q1T) r = BlockDotF<FMT>::run_tab(R.w[k], reinterpret_cast<const f32x4*>(xs), col, PL::nBlk, st, bf2f(R.ze[k]), -(qb * st), tab, acc);
-        else if constexpr (F32X) r = BlockDotF<FMT>::run(R.w[k], reinterpret_cast<const f32x4*>(xs), col, PL::nBlk, st, bf2f(R.ze[k]), -(qb * st), acc);
-        else if constexpr (FMT == FMT_Q1T) r = BlockDot<FMT, CANON>::run_tab(R.w[k], xs, col, PL::nBlk, st, bf2f(R.ze[k]), -(qb * st), tab, acc);
-        else r = BlockDot<FMT, CANON>::run(R.w[k], xs, col, PL::nBlk, st, bf2f(R.ze[k]), -(qb * st), acc);
-        acc = acc_pick(on, r, acc);
-        if (PL::PAIRED) {
-            const float st2 = bf2f(R.st2[k]);
-            acc_t<CANON> r2;
-            if constexpr (F32X && FMT == FMT_Q1T) r2 = BlockDotF<FMT>::run_tab(R.w2[k], reinterpret_cast<const f32x4*>(xs), col, PL::nBlk, st2, bf2f(R.ze2[k]), -(qb2 * st2), tab, acc2);
-            else if constexpr (F32X) r2 = BlockDotF<FMT>::run(R.w2[k], reinterpret_cast<const f32x4*>(xs), col, PL::nBlk, st2, bf2f(R.ze2[k]), -(qb2 * st2), acc2);
-            else if constexpr (FMT == FMT_Q1T) r2 = BlockDot<FMT, CANON>::run_tab(R.w2[k], xs, col, PL::nBlk, st2, bf2f(R.ze2[k]), -(qb2 * st2), tab, acc2);
-            else r2 = BlockDot<FMT, CANON>::run(R.w2[k], xs, col, PL::nBlk, st2, bf2f(R.ze2[k]), -(qb2 * st2), acc2);
-            acc2 = acc_pick(on, r2, acc2);
-        }
-        if (it == PL::iters - 1) {
-            const float v = group_sum(acc_join(acc), PL::lpr_log2);
-            float v2 = 0.f;
-            if (PL::PAIRED) v2 = group_sum(acc_join(acc2), PL::lpr_log2);
-            if ((lane & (PL::LPR - 1)) == 0 && q.ok) epi(q.row, v, v2);
-        }
-    }
-}
-
 #ifndef ENG_P1_SHARE
 #define ENG_P1_SHARE 1 /* the poller wave computes one of the workgroup's P1 row slots (0: seven waves, wave 0 takes two slots -- its second block of pair words costs 16 more registers and spills) */
 #endif
@@ -455,17 +426,17 @@ struct MvDeq {
     uint32_t p[MAXS][16], p2[PAIRED ? MAXS : 1][16];
 };
 template <class PL, int NCW, int FMT, int MAXS>
-__device__ __forceinline__ void mv_dequant(float qb, float qb2, int cw, int lane, const MvRegs<PL::PAIRED, MAXS>& R, MvDeq<PL::PAIRED, MAXS>& D) {
+__device__ __forceinline__ void mv_dequant(float qb, float qb2, int cw, int lane, const MvRegs<PL::PAIRED, MAXS>& R, MvDeq<PL::PAIRED, MAXS>& D, const u32x4* tab) {
 #pragma unroll
     for (int k = 0; k < MAXS; k++) {
         if (cw + (k / PL::iters) * NCW >= PL::spg) continue; /* wave-uniform: this wave has no such slot */
         const float st = bf2f(R.st[k]);
-        BlockPrep<FMT>::prep(R.w[k], st, bf2f(R.ze[k]), -(qb * st), lane, D.p[k]);
+        BlockPrep<FMT>::prep(R.w[k], st, bf2f(R.ze[k]), -(qb * st), lane, D.p[k], tab);
 #pragma unroll
         for (int i = 0; i < 16; i++) asm volatile("" : "+v"(D.p[k][i])); /* formed HERE, in front of the barrier, not sunk to the first use behind it */
         if (PL::PAIRED) {
             const float st2 = bf2f(R.st2[k]);
-            BlockPrep<FMT>::prep(R.w2[k], st2, bf2f(R.ze2[k]), -(qb2 * st2), lane, D.p2[k]);
+            BlockPrep<FMT>::prep(R.w2[k], st2, bf2f(R.ze2[k]), -(qb2 * st2), lane, D.p2[k], tab);
 #pragma unroll
             for (int i = 0; i < 16; i++) asm volatile("" : "+v"(D.p2[k][i]));
         }
@@ -498,18 +469,14 @@ __device__ __forceinline__ void mv_run_deq(int s0, int cw, int lane, int Mj, con
     }
 }
 
-// One mat-vec phase of a wave: the 4-bit forms dequantise their blocks ahead of the hand-off (ahead) and multiply pair words behind it; the other storages (1-bit through the
-// LDS selector table) multiply straight from the packed blocks -- their 128-weight blocks would be 64 pair words each.
+// One mat-vec phase of a wave: its blocks are dequantised into bf16 pair words ahead of the hand-off (ahead) and multiplied behind it (run).  tab: the 1-bit selector table
 template <class C, class PL, int NCW, int MAXS>
 struct MvPhase {
-    MvDeq<PL::PAIRED, MAXS> d; /* untouched (no registers) when the storage is not dequantised ahead */
-    __device__ __forceinline__ void ahead(float qb, float qb2, int cw, int lane, const MvRegs<PL::PAIRED, MAXS>& R) {
-        if constexpr (C::DEQ) mv_dequant<PL, NCW, C::FMT, MAXS>(qb, qb2, cw, lane, R, d);
-    }
+    MvDeq<PL::PAIRED, MAXS> d;
+    __device__ __forceinline__ void ahead(float qb, float qb2, int cw, int lane, const MvRegs<PL::PAIRED, MAXS>& R, const u32x4* tab) { mv_dequant<PL, NCW, C::FMT, MAXS>(qb, qb2, cw, lane, R, d, tab); }
     template <typename Epi>
-    __device__ __forceinline__ void run(float qb, float qb2, int s0, int cw, int lane, int Mj, const MvRegs<PL::PAIRED, MAXS>& R, const u32x4* xs, const u32x4* tab, uint32_t hotbits, Epi&& epi) {
-        if constexpr (C::DEQ) mv_run_deq<PL, NCW, MAXS, C::CANON>(s0, cw, lane, Mj, d, xs, hotbits, epi);
-        else mv_run<PL, NCW, C::FMT, MAXS, C::CANON, C::F32X>(qb, qb2, s0, cw, lane, Mj, R, xs, tab, hotbits, epi);
+    __device__ __forceinline__ void run(int s0, int cw, int lane, int Mj, const u32x4* xs, uint32_t hotbits, Epi&& epi) {
+        mv_run_deq<PL, NCW, MAXS, C::CANON>(s0, cw, lane, Mj, d, xs, hotbits, epi);
     }
 };
 
@@ -565,10 +532,9 @@ struct EngCfg {
     // CANON: the mat-vec phases and the head in the canonical order (one v_fma_f32 per product on fp32 operands: bit-exact against the oracle); false: v_dot2c_f32_bf16 on
     // bf16 pairs (kf_set_canonical(ctx, 0): <= 1 bf16 ulp per output from the oracle, fewer vector instructions).  The attention is canonical either way.
     static constexpr bool CANON = CANON_;
-    static constexpr bool Q4F = FMT_ == FMT_Q4 || FMT_ == FMT_Q4P;
-    static constexpr bool DEQ = Q4F;           /* blocks dequantised ahead of the hand-off (16 pair words per block) */
-    static constexpr bool F32X = CANON_ && (Q4F || FMT_ == FMT_Q1T); /* activations staged as fp32 chunks (BlockDotF / the canonical pairs_dot): no conversion of the activation pair per product */
-    static constexpr int XCH = F32X ? BlockDot<FMT_>::EPB / 4 : BlockDot<FMT_>::XCH;
+    static_assert(FMT_ == FMT_Q4 || FMT_ == FMT_Q4P || FMT_ == FMT_Q1T, "storages with a BlockPrep: 32-weight blocks dequantised ahead of the hand-off (16 pair words each)");
+    static constexpr bool F32X = CANON_; /* canonical order: activations staged as fp32 chunks (pairs_dot<true>: no conversion of the activation pair per product) */
+    static constexpr int XCH = F32X ? 8 : 4; /* 16-byte chunks of x per 32-weight block */
     static constexpr int n_head = QD_ / HD_, n_kv = KVD_ / HD_;
     using SH = EngShape<FMT_, DIM_, QD_, KVD_, FFN_, NWG_>;
     static constexpr int xA = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).xA, qkv = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).qkv, ao = eng_xoff(DIM_, QD_, KVD_, FFN_, HD_).ao,
@@ -818,7 +784,7 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
         const uint32_t gen = (uint32_t)epoch * (uint32_t)a.n_layer + (uint32_t)l, tag = gen & 0xffffu;
         if (S.has_unit && !S.empty) eng_attn_normw<C>(ly, NWV - 1, lane, T);
         MvPhase<C, P1, NCW1, S1> w1;
-        if (P1_SHARE) w1.ahead(qb1, 0.f, NWV - 1, lane, r1); /* its blocks were requested behind the previous layer's attention phase */
+        if (P1_SHARE) w1.ahead(qb1, 0.f, NWV - 1, lane, r1, L.q1tab); /* its blocks were requested behind the previous layer's attention phase */
         // P1 (P4 adds this x as the residual)
         ENG_STAMP(0, 0);
         if (has1 || has4) {
@@ -858,7 +824,7 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
         ENG_STAMP(0, 1);
         __syncthreads();
         if (P1_SHARE && has1) { /* this wave's P1 rows, then the workgroup's publish like every other owner */
-            w1.run(qb1, 0.f, S.s1, NWV - 1, lane, S.M1, r1, L.xs[0], L.q1tab, 0xffffffffu, [&](int row, float v, float) { L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); });
+            w1.run(S.s1, NWV - 1, lane, S.M1, L.xs[0], 0xffffffffu, [&](int row, float v, float) { L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); });
             if (XMAP)
                 wg_publish(L, 0, eng_lqkv<C>(a, S.xcc), S.q_out0, P1::R, NWP1, lane, true);
             else
@@ -1085,11 +1051,11 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         if (S.has_unit && !S.empty) eng_attn_normw<C>(ly, wave, lane_m, T);
         // ================= P1: RMSNorm(x) -> Q, K, V rows  (every phase: the blocks are dequantised in front of the barrier the activations arrive behind)
         MvPhase<C, P1, NCW1, S1> w1; /* declared per layer: nothing of it is carried around the loop */
-        w1.ahead(qb1, 0.f, wave, lane_m, r1);
+        w1.ahead(qb1, 0.f, wave, lane_m, r1, L.q1tab);
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 0);
         mv_prefetch<P4, NCW, FMT, S4>(ly.m[3], ly.m[3], wg * P4::spg, wave, lane_m, P4::M0, r4);
-        w1.run(qb1, 0.f, S.s1, wave, lane_m, S.M1, r1, L.xs[0], L.q1tab, 0xffffffffu, [&](int row, float v, float) { L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); });
+        w1.run(S.s1, wave, lane_m, S.M1, L.xs[0], 0xffffffffu, [&](int row, float v, float) { L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); });
         if (has1 && wave < NWP1) {
             if (XMAP)
                 wg_publish(L, 0, eng_lqkv<C>(a, S.xcc), S.q_out0, P1::R, NWP1, lane_m, true);
@@ -1116,7 +1082,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
 
         // ================= P4: o_proj + residual -> xB
         MvPhase<C, P4, NCW, S4> w4;
-        w4.ahead(a.qbias[3], 0.f, wave, lane_m, r4);
+        w4.ahead(a.qbias[3], 0.f, wave, lane_m, r4, L.q1tab);
         if (ENG_COOP) {
             __syncthreads(); /* the poller has timed the first sweep */
             if (has4) eng_poll_stage_part<C::XCH, C::QD / 256, P4::nBlk, NWV, C::F32X>(a.xch + C::ao, tag, L.xs[1], wave, lane_m, a.ws, dead);
@@ -1125,7 +1091,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         if (wave == 0) ENG_STAMP(1, 4);
         const uint32_t hot5 = L.hotbits[l]; /* the sparse forward's mask of this workgroup's gate / up rows (all ones: dense) */
         mv_prefetch<P5, NCW, FMT, S5>(ly.m[4], ly.m[5], wg * P5::spg, wave, lane_m, P5::M0, r5, hot5);
-        w4.run(a.qbias[3], 0.f, wg * P4::spg, wave, lane_m, P4::M0, r4, L.xs[1], L.q1tab, 0xffffffffu, [&](int row, float v, float) {
+        w4.run(wg * P4::spg, wave, lane_m, P4::M0, L.xs[1], 0xffffffffu, [&](int row, float v, float) {
             const uint16_t o = f2bf(v);
             L.outb[row - wg * P4::R] = (tag << 16) | (uint32_t)f2bf(bf2f(L.xrawA[row]) + bf2f(o)); /* CU_add3: bf16(x + bf16(W.x)) */
         });
@@ -1133,11 +1099,11 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         // ================= P5: RMSNorm + gate/up + SwiGLU -> act
         if (wave == 0) ENG_STAMP(1, 5);
         MvPhase<C, P5, NCW, S5> w5;
-        w5.ahead(a.qbias[4], a.qbias[5], wave, lane_m, r5);
+        w5.ahead(a.qbias[4], a.qbias[5], wave, lane_m, r5, L.q1tab);
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 6);
         mv_prefetch<P6, NCW, FMT, S6>(ly.m[6], ly.m[6], wg * P6::spg, wave, lane_m, P6::M0, r6);
-        w5.run(a.qbias[4], a.qbias[5], wg * P5::spg, wave, lane_m, P5::M0, r5, L.xs[0], L.q1tab, L.hotbits[l], [&](int row, float v, float v2) {
+        w5.run(wg * P5::spg, wave, lane_m, P5::M0, L.xs[0], L.hotbits[l], [&](int row, float v, float v2) {
             const float gt = round_bf16(v), up = round_bf16(v2); /* CU_swiglu_v0 on the two bf16-rounded projections */
             L.outb[row - wg * P5::R] = (tag << 16) | (uint32_t)f2bf((gt * up) / (1.0f + kf_expf(-gt)));
         });
@@ -1145,7 +1111,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         // ================= P6: down_proj + residual -> x of the next layer
         if (wave == 0) ENG_STAMP(1, 7);
         MvPhase<C, P6, NCW, S6> w6;
-        w6.ahead(a.qbias[6], 0.f, wave, lane_m, r6);
+        w6.ahead(a.qbias[6], 0.f, wave, lane_m, r6, L.q1tab);
         if (ENG_COOP) {
             __syncthreads();
             if (has6) eng_poll_stage_part<C::XCH, C::FFN / 256, P6::nBlk, NWV, C::F32X>(a.xch + C::act, tag, L.xs[1], wave, lane_m, a.ws, dead);
@@ -1153,7 +1119,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 8);
         mv_prefetch<P1, NCW1, FMT, S1>(mat1(ln), mat1(ln), S.s1, wave, lane_m, S.M1, r1);
-        w6.run(a.qbias[6], 0.f, wg * P6::spg, wave, lane_m, P6::M0, r6, L.xs[1], L.q1tab, 0xffffffffu, [&](int row, float v, float) {
+        w6.run(wg * P6::spg, wave, lane_m, P6::M0, L.xs[1], 0xffffffffu, [&](int row, float v, float) {
             const uint16_t o = f2bf(v);
             const uint16_t y = f2bf(bf2f(L.xrawB[row]) + bf2f(o));
             if (last) a.x_out[row] = y;
@@ -1493,7 +1459,7 @@ static int engine_shape_class(int GQ, int hd, int dim, int q_dim, int ffn) { /* 
     return 0;
 }
 static_assert(sizeof(EngPlan) == 80 && sizeof(EngLayer) == 224, "device table strides");
-static int eng_epb(int fmt) { return fmt == FMT_BF16 ? 8 : (fmt == FMT_F8 ? 16 : (fmt == FMT_Q4 || fmt == FMT_Q4P ? 32 : (fmt == FMT_Q2 ? 64 : 128))); }
+static int eng_epb(int fmt) { return fmt == FMT_BF16 ? 8 : (fmt == FMT_F8 ? 16 : (fmt == FMT_Q4 || fmt == FMT_Q4P ? 32 : (fmt == FMT_Q2 ? 64 : 32 /* 1-bit: the engine's lanes take a dword of a 128-element block each (eng_vepb) */))); }
 
 // geometry of one phase; returns false when the shape is outside what the engine serves
 static bool eng_plan(EngPlan& P, int fmt, int K, int njobs, const kf_weight* const* w, bool paired, int n_wg, bool& q4p_ok) {

@@ -282,7 +282,8 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     // ---- main: pipelined over (batch, iteration) steps
     float best_v = -__builtin_inff();
     int best_i = 0x7fffffff;
-    acc_t<CANON> acc[G], acc2[PAIRED ? G : 1]; /* per-lane chains (canonical: an even and an odd one) */
+    using Acc = typename BD::Acc;
+    Acc acc[G], acc2[PAIRED ? G : 1]; /* per-lane chains (canonical: an even and an odd one; four such pairs for 1-bit blocks) */
     float sum[G], sum2[PAIRED ? G : 1];
     int bi = 0, it = 0;       // the step being computed
     int nbi = 0, nit = 0;     // the step being loaded
@@ -290,8 +291,8 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
         if (it == 0) {
 #pragma unroll
             for (int g = 0; g < G; g++) {
-                acc[g] = acc_t<CANON>{};
-                if (PAIRED) acc2[g] = acc_t<CANON>{};
+                acc[g] = Acc{};
+                if (PAIRED) acc2[g] = Acc{};
             }
         }
         {
@@ -303,19 +304,19 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
                 int row;
                 const bool ok = !LAT || (slot(s_begin + (long)bi * G + g, row) && col_ok); /* masked loads carry zero weights */
                 if constexpr (LUT) {
-                    const acc_t<CANON> r = BD::run_lut(bt.w[g], xs, col, nBlk, bt.ta[g], bt.tb[g], acc[g]);
+                    const Acc r = BD::run_lut(bt.w[g], xs, col, nBlk, bt.ta[g], bt.tb[g], acc[g]);
                     acc[g] = acc_pick(ok, r, acc[g]);
                     if constexpr (PAIRED) {
-                        const acc_t<CANON> r2 = BD::run_lut(bt.w2[g], xs, col, nBlk, bt.ta2[g], bt.tb2[g], acc2[g]);
+                        const Acc r2 = BD::run_lut(bt.w2[g], xs, col, nBlk, bt.ta2[g], bt.tb2[g], acc2[g]);
                         acc2[g] = acc_pick(ok, r2, acc2[g]);
                     }
                 } else {
                     const float st = bf2f(bt.st[g]);
-                    const acc_t<CANON> r = BD::run(bt.w[g], xs, col, nBlk, st, bf2f(bt.ze[g]), -(jqb * st), acc[g]);
+                    const Acc r = BD::run(bt.w[g], xs, col, nBlk, st, bf2f(bt.ze[g]), -(jqb * st), acc[g]);
                     acc[g] = acc_pick(ok, r, acc[g]);
                     if (PAIRED) {
                         const float st2 = bf2f(bt.st2[g]);
-                        const acc_t<CANON> r2 = BD::run(bt.w2[g], xs, col, nBlk, st2, bf2f(bt.ze2[g]), -(jqb2 * st2), acc2[g]);
+                        const Acc r2 = BD::run(bt.w2[g], xs, col, nBlk, st2, bf2f(bt.ze2[g]), -(jqb2 * st2), acc2[g]);
                         acc2[g] = acc_pick(ok, r2, acc2[g]);
                     }
                 }
@@ -496,6 +497,15 @@ static int epb_of(int fmt) {
 // with the row tail masked.  Short launches (fewer waves than the chip has SIMDs) are bound by the per-step dequant arithmetic of the
 // longest wave, not by lanes: a row gets more lanes, even with the tail of the last step masked, while that shortens the step count
 // (down_proj of the 0.6B model, 1024 x 3072: 512 waves x 3 steps -> 1024 waves x 2 steps).  `rows` = the rows of every job of the launch.
+// the same per storage: 1-bit rows take the rule's figure for K / 32 "virtual" blocks -- the four dwords of a 128-element block are what four neighbouring lanes of the persistent
+// engine multiply side by side (canonical order: a chain pair per dword position, oracle/kf_oracle.c section 4c) -- divided by four: logical lanes, one whole block each, here
+int gemv_lpr_log2_fmt(int fmt, int K, long rows) {
+    if (fmt == FMT_Q1 || fmt == FMT_Q1T) {
+        const int l = gemv_lpr_log2(K / 32, rows) - 2;
+        return l > 0 ? l : 0;
+    }
+    return gemv_lpr_log2(K / epb_of(fmt), rows);
+}
 int gemv_lpr_log2(int nBlk, long rows) {
     int lpr_log2 = 6;
     while (lpr_log2 > 0 && (nBlk % (1 << lpr_log2)) != 0) lpr_log2--;
@@ -566,7 +576,7 @@ int gemv_launch_dot2(hipStream_t st, GemvLaunch& L) {
     long rows_all = 0;
     for (int j = 0; j < L.n; j++)
         if (!(L.mode == GEMV_PAIRED && j == 1)) rows_all += L.w[j]->ne0;
-    const int lpr_log2 = gemv_lpr_log2(nBlk, rows_all);
+    const int lpr_log2 = gemv_lpr_log2_fmt(fmt, K, rows_all);
     const int LPR = 1 << lpr_log2, RPS = 64 / LPR;
     a.K = K, a.nBlk = nBlk, a.lpr_log2 = lpr_log2, a.iters = (nBlk + LPR - 1) / LPR;
     a.inv_dim = 1.0f / (float)K;

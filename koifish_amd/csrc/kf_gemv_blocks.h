@@ -2,6 +2,8 @@
 // reduction shared by the mat-vec kernel (kf_gemv.hip) and the persistent decode engine (kf_engine.hip): ONE statement of the arithmetic,
 // so both paths form every output bit the same way.
 #pragma once
+#include <type_traits>
+
 #include "kf_kernels.h"
 
 namespace kf {
@@ -45,11 +47,14 @@ __device__ __forceinline__ acc_t<CANON> dot_q4_dword(uint32_t D, u32x4 X, float 
 
 template <int FMT, bool CANON = false>
 struct BlockDot;
+// BlockDot<FMT, CANON>::Acc: the lane's accumulator -- acc_t<CANON> (a float, or the canonical even / odd pair), except 1-bit storage in the canonical order: Acc4, a pair per
+// dword position of the block
 
 template <bool CANON>
 struct BlockDot<FMT_BF16, CANON> {
     static constexpr int EPB = 8, XCH = 1;
     static constexpr bool HAS_GAMA = false;
+    using Acc = acc_t<CANON>;
     __device__ static __forceinline__ acc_t<CANON> run(u32x4 w, const u32x4* xs, int col, int nBlk, float, float, float, acc_t<CANON> acc) {
         u32x4 X = xs[col];
         acc = dotp<CANON>(w.x, X.x, acc);
@@ -77,6 +82,7 @@ template <bool CANON>
 struct BlockDot<FMT_F8, CANON> {
     static constexpr int EPB = 16, XCH = 2;
     static constexpr bool HAS_GAMA = false;
+    using Acc = acc_t<CANON>;
     __device__ static __forceinline__ acc_t<CANON> run(u32x4 w, const u32x4* xs, int col, int nBlk, float, float, float, acc_t<CANON> acc) {
         u32x4 X0 = xs[col], X1 = xs[nBlk + col];
         acc = dot_f8_dword<CANON>(w.x, X0.x, X0.y, acc);
@@ -91,6 +97,7 @@ template <bool CANON>
 struct BlockDot<FMT_Q4, CANON> {
     static constexpr int EPB = 32, XCH = 4;
     static constexpr bool HAS_GAMA = true;
+    using Acc = acc_t<CANON>;
     // nb = -qBias*step (exact)
     __device__ static __forceinline__ acc_t<CANON> run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, acc_t<CANON> acc) {
         const float step16 = step * 0.0625f;
@@ -112,6 +119,7 @@ template <bool CANON>
 struct BlockDot<FMT_Q4P, CANON> {
     static constexpr int EPB = 32, XCH = 4;
     static constexpr bool HAS_GAMA = true;
+    using Acc = acc_t<CANON>;
     __device__ static __forceinline__ acc_t<CANON> run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, acc_t<CANON> acc) {
         const float q0 = (float)((threadIdx.x & 3) << 2);
         uint32_t r = pack_bf16x2(fmaf(q0, step, nb), fmaf(q0 + 1.0f, step, nb));
@@ -137,6 +145,7 @@ template <bool CANON>
 struct BlockDot<FMT_Q4R, CANON> {
     static constexpr int EPB = 32, XCH = 4;
     static constexpr bool HAS_GAMA = false;
+    using Acc = acc_t<CANON>;
     __device__ static __forceinline__ acc_t<CANON> run(u32x4, const u32x4*, int, int, float, float, float, acc_t<CANON> acc) { return acc; }
     __device__ static __forceinline__ acc_t<CANON> run_lut(u32x4 w, const u32x4* xs, int col, int nBlk, u32x4 ta, u32x4 tb, acc_t<CANON> acc) {
         const uint32_t P[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
@@ -172,6 +181,7 @@ template <bool CANON>
 struct BlockDot<FMT_Q2, CANON> {
     static constexpr int EPB = 64, XCH = 8;
     static constexpr bool HAS_GAMA = true;
+    using Acc = acc_t<CANON>;
     __device__ static __forceinline__ acc_t<CANON> run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, acc_t<CANON> acc) {
         acc = dot_q2_dword<CANON>(w.w, xs[col], xs[nBlk + col], step, nb, zero, acc);
         acc = dot_q2_dword<CANON>(w.z, xs[2 * nBlk + col], xs[3 * nBlk + col], step, nb, zero, acc);
@@ -203,15 +213,23 @@ template <bool CANON>
 struct BlockDot<FMT_Q1, CANON> {
     static constexpr int EPB = 128, XCH = 16;
     static constexpr bool HAS_GAMA = true;
-    __device__ static __forceinline__ acc_t<CANON> run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, acc_t<CANON> acc) {
+    using Acc = std::conditional_t<CANON, Acc4, float>;
+    __device__ static __forceinline__ Acc run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, Acc acc) {
         // dequant(q) for q = 0, 1 (q - qBias folded into nb)
         uint32_t r = pack_bf16x2(fmaf(0.0f, step, nb), fmaf(1.0f, step, nb));
         uint32_t ww = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
         const uint32_t w0 = ww & 0xffffu, w1 = ww >> 16;
-        acc = dot_q1_dword<CANON>(w.w, xs, 0, nBlk, col, w0, w1, acc);
-        acc = dot_q1_dword<CANON>(w.z, xs, 4, nBlk, col, w0, w1, acc);
-        acc = dot_q1_dword<CANON>(w.y, xs, 8, nBlk, col, w0, w1, acc);
-        acc = dot_q1_dword<CANON>(w.x, xs, 12, nBlk, col, w0, w1, acc);
+        if constexpr (CANON) { /* a chain pair per dword position */
+            acc.s[0] = dot_q1_dword<true>(w.w, xs, 0, nBlk, col, w0, w1, acc.s[0]);
+            acc.s[1] = dot_q1_dword<true>(w.z, xs, 4, nBlk, col, w0, w1, acc.s[1]);
+            acc.s[2] = dot_q1_dword<true>(w.y, xs, 8, nBlk, col, w0, w1, acc.s[2]);
+            acc.s[3] = dot_q1_dword<true>(w.x, xs, 12, nBlk, col, w0, w1, acc.s[3]);
+        } else {
+            acc = dot_q1_dword<false>(w.w, xs, 0, nBlk, col, w0, w1, acc);
+            acc = dot_q1_dword<false>(w.z, xs, 4, nBlk, col, w0, w1, acc);
+            acc = dot_q1_dword<false>(w.y, xs, 8, nBlk, col, w0, w1, acc);
+            acc = dot_q1_dword<false>(w.x, xs, 12, nBlk, col, w0, w1, acc);
+        }
         return acc;
     }
 };
@@ -224,11 +242,12 @@ template <bool CANON>
 struct BlockDot<FMT_Q1T, CANON> {
     static constexpr int EPB = 128, XCH = 16;
     static constexpr bool HAS_GAMA = true;
-    __device__ static __forceinline__ acc_t<CANON> run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, acc_t<CANON> acc) {
+    using Acc = std::conditional_t<CANON, Acc4, float>;
+    __device__ static __forceinline__ Acc run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, Acc acc) {
         return run_tab(w, xs, col, nBlk, step, zero, nb, xs + nBlk * 16 + 16 /* the mat-vec kernel keeps the table behind x (K * 2 bytes) and the 256-byte reduction scratch */, acc);
     }
-    // tab: the 256-entry selector table, wherever the caller keeps it (the persistent engine: one table for all phases)
-    __device__ static __forceinline__ acc_t<CANON> run_tab(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, const u32x4* tab, acc_t<CANON> acc) {
+    // tab: the 256-entry selector table
+    __device__ static __forceinline__ Acc run_tab(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, const u32x4* tab, Acc acc) {
         const uint32_t r = pack_bf16x2(fmaf(0.0f, step, nb), fmaf(1.0f, step, nb));
         const uint32_t ww = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero); /* bytes 0,1 = dequant(0); bytes 2,3 = dequant(1) */
         const uint32_t dw[4] = {w.w, w.z, w.y, w.x};                       /* dword3 holds elements 0..31, element 0 = bit 31 */
@@ -238,10 +257,17 @@ struct BlockDot<FMT_Q1T, CANON> {
             for (int c = 0; c < 4; c++) {
                 const u32x4 S = tab[(dw[d] >> (24 - 8 * c)) & 0xffu];
                 const u32x4 X = xs[(4 * d + c) * nBlk + col];
-                acc = dotp<CANON>(__builtin_amdgcn_perm(0u, ww, S.x), X.x, acc);
-                acc = dotp<CANON>(__builtin_amdgcn_perm(0u, ww, S.y), X.y, acc);
-                acc = dotp<CANON>(__builtin_amdgcn_perm(0u, ww, S.z), X.z, acc);
-                acc = dotp<CANON>(__builtin_amdgcn_perm(0u, ww, S.w), X.w, acc);
+                if constexpr (CANON) { /* dword d's chain pair */
+                    acc.s[d] = dotp<true>(__builtin_amdgcn_perm(0u, ww, S.x), X.x, acc.s[d]);
+                    acc.s[d] = dotp<true>(__builtin_amdgcn_perm(0u, ww, S.y), X.y, acc.s[d]);
+                    acc.s[d] = dotp<true>(__builtin_amdgcn_perm(0u, ww, S.z), X.z, acc.s[d]);
+                    acc.s[d] = dotp<true>(__builtin_amdgcn_perm(0u, ww, S.w), X.w, acc.s[d]);
+                } else {
+                    acc = dotp<false>(__builtin_amdgcn_perm(0u, ww, S.x), X.x, acc);
+                    acc = dotp<false>(__builtin_amdgcn_perm(0u, ww, S.y), X.y, acc);
+                    acc = dotp<false>(__builtin_amdgcn_perm(0u, ww, S.z), X.z, acc);
+                    acc = dotp<false>(__builtin_amdgcn_perm(0u, ww, S.w), X.w, acc);
+                }
             }
         return acc;
     }
@@ -254,6 +280,7 @@ template <bool CANON>
 struct BlockDot<FMT_Q2T, CANON> {
     static constexpr int EPB = 64, XCH = 8;
     static constexpr bool HAS_GAMA = true;
+    using Acc = acc_t<CANON>;
     __device__ static __forceinline__ acc_t<CANON> run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, acc_t<CANON> acc) {
         uint32_t r = pack_bf16x2(fmaf(0.0f, step, nb), fmaf(1.0f, step, nb));
         const uint32_t T01 = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
@@ -345,32 +372,6 @@ struct BlockDotF<FMT_Q4> {
     }
 };
 
-// 1-bit through the selector table on fp32 activations (the engine's canonical 1-bit form): the pairs and chains of BlockDot<FMT_Q1T, true>, without the two conversions of
-// the activation pair per product
-template <>
-struct BlockDotF<FMT_Q1T> {
-    static constexpr int EPB = 128, XCH = 32;
-    static constexpr bool HAS_GAMA = true;
-    __device__ static __forceinline__ f32x2_t run_tab(u32x4 w, const f32x4* xs, int col, int nBlk, float step, float zero, float nb, const u32x4* tab, f32x2_t acc) {
-        const uint32_t r = pack_bf16x2(fmaf(0.0f, step, nb), fmaf(1.0f, step, nb));
-        const uint32_t ww = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero); /* bytes 0,1 = dequant(0); bytes 2,3 = dequant(1) */
-        const uint32_t dw[4] = {w.w, w.z, w.y, w.x};                       /* dword3 holds elements 0..31, element 0 = bit 31 */
-#pragma unroll
-        for (int d = 0; d < 4; d++)
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const u32x4 S = tab[(dw[d] >> (24 - 8 * c)) & 0xffu];
-                const f32x4 X0 = xs[(8 * d + 2 * c) * nBlk + col], X1 = xs[(8 * d + 2 * c + 1) * nBlk + col];
-                uint32_t p;
-                p = __builtin_amdgcn_perm(0u, ww, S.x), acc = pk_fma(f32x2_t{bf_lo(p), bf_hi(p)}, f32x2_t{X0.x, X0.y}, acc);
-                p = __builtin_amdgcn_perm(0u, ww, S.y), acc = pk_fma(f32x2_t{bf_lo(p), bf_hi(p)}, f32x2_t{X0.z, X0.w}, acc);
-                p = __builtin_amdgcn_perm(0u, ww, S.z), acc = pk_fma(f32x2_t{bf_lo(p), bf_hi(p)}, f32x2_t{X1.x, X1.y}, acc);
-                p = __builtin_amdgcn_perm(0u, ww, S.w), acc = pk_fma(f32x2_t{bf_lo(p), bf_hi(p)}, f32x2_t{X1.z, X1.w}, acc);
-            }
-        return acc;
-    }
-};
-
 // ------------------------------------------------------------------------------------------------ dequantise ahead, multiply later
 // The persistent engine holds a phase's packed blocks in registers before the phase's activations exist.  Everything that does not depend on x -- the group
 // table, the lookups, the pairing -- can therefore run while the wave would otherwise wait for the hand-off: BlockPrep turns a block into its 16 bf16 pair
@@ -381,7 +382,7 @@ template <int FMT>
 struct BlockPrep;
 template <>
 struct BlockPrep<FMT_Q4P> {
-    __device__ static __forceinline__ void prep(u32x4 w, float step, float zero, float nb, int lane, uint32_t (&o)[16]) {
+    __device__ static __forceinline__ void prep(u32x4 w, float step, float zero, float nb, int lane, uint32_t (&o)[16], const u32x4* = nullptr) {
         const float q0 = (float)((lane & 3) << 2);
         uint32_t r = pack_bf16x2(fmaf(q0, step, nb), fmaf(q0 + 1.0f, step, nb));
         const uint32_t P0 = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
@@ -405,7 +406,7 @@ struct BlockPrep<FMT_Q4P> {
 };
 template <>
 struct BlockPrep<FMT_Q4> {
-    __device__ static __forceinline__ void prep(u32x4 w, float step, float zero, float nb, int, uint32_t (&o)[16]) {
+    __device__ static __forceinline__ void prep(u32x4 w, float step, float zero, float nb, int, uint32_t (&o)[16], const u32x4* = nullptr) {
         const float step16 = step * 0.0625f;
         const uint32_t dw[4] = {w.w, w.z, w.y, w.x};
 #pragma unroll
@@ -419,6 +420,22 @@ struct BlockPrep<FMT_Q4> {
                 const uint32_t r = pack_bf16x2(fmaf((float)((H >> sh) & 0xffu), step16, nb), fmaf((float)((Lw >> sh) & 0xffu), step, nb));
                 o[4 * d + p] = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
             }
+        }
+    }
+};
+// 1-bit through the selector table, for the persistent engine: ONE DWORD of a 128-element block (32 weights, element 0 = bit 31) per lane -- the engine deals the four dwords
+// of a block to four neighbouring lanes (the canonical order keeps a chain pair per dword position) and walks a 1-bit matrix with the geometry of a 4-bit one.
+// tab: the 256-entry table of BlockDot<FMT_Q1T> (a weight byte -> 4 selector dwords = 4 weight pairs)
+template <>
+struct BlockPrep<FMT_Q1T> {
+    __device__ static __forceinline__ void prep(u32x4 w, float step, float zero, float nb, int, uint32_t (&o)[16], const u32x4* tab) {
+        const uint32_t r = pack_bf16x2(fmaf(0.0f, step, nb), fmaf(1.0f, step, nb));
+        const uint32_t ww = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero); /* bytes 0,1 = dequant(0); bytes 2,3 = dequant(1) */
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const u32x4 S = tab[(w.x >> (24 - 8 * c)) & 0xffu];
+            o[4 * c] = __builtin_amdgcn_perm(0u, ww, S.x), o[4 * c + 1] = __builtin_amdgcn_perm(0u, ww, S.y);
+            o[4 * c + 2] = __builtin_amdgcn_perm(0u, ww, S.z), o[4 * c + 3] = __builtin_amdgcn_perm(0u, ww, S.w);
         }
     }
 };

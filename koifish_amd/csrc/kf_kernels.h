@@ -81,6 +81,7 @@ int tp_argmax_push_launch(hipStream_t st, const float* val, const int* idx, int 
 int tp_pick_launch(hipStream_t st, const unsigned long long* pairs, int R, unsigned* d_step, unsigned per_step, unsigned index, int32_t* d_state, int32_t* d_tokens_out,
                    int* d_err, int vocab);
 int gemv_lpr_log2(int nBlk, long rows); /* lanes per row of a mat-vec launch (kf_gemv.hip) */
+int gemv_lpr_log2_fmt(int fmt, int K, long rows); /* the same per storage (1-bit: K / 32 virtual blocks, divided by four) */
 int gemv_fmt_of(const kf_weight* w);    /* FMT_* of a weight, < 0: not served by the mat-vec kernel */
 void argmax_finish_launch(hipStream_t st, const float* val, const int* idx, int n, int32_t* d_argmax, int32_t* d_state, int32_t* d_tokens_out);
 

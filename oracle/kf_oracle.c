@@ -503,6 +503,10 @@ static float dot16(const float* w, const float* x, int n) {
  *         them (round 4; one before): e = fmaf(w[i], x[i], e) over the even-indexed elements of a block in index order, o = fmaf(w[i], x[i], o)
  *         over the odd-indexed ones -- the two halves of one v_pk_fma_f32 per weight pair on the GPU, half the dependent chain of the
  *         single-accumulator form -- and the lane's value is e + o;
+ *       - 1-bit storage (EPB = 128; round 4): a block is cut into its four 32-element dwords and every dword position s = 0..3 keeps its OWN (e_s, o_s) pair through all of
+ *         the lane's blocks; the lane's value is ((e0 + o0) + (e1 + o1)) + ((e2 + o2) + (e3 + o3)).  The four sub-chains are what four neighbouring hardware lanes compute
+ *         side by side in the persistent engine (a quarter of the dependent chain each); the mat-vec kernel keeps them as four register pairs.  The lanes-per-row figure of
+ *         such a row is the rule's value for K / 32 "virtual" blocks divided by four (kfo_lpr_log2_epb);
  *       - the LPR lane values are added by a balanced binary tree (lanes 2j + 2j+1, then pairs of pairs, ...).
  *     lpr_log2 = kfo_lpr_log2(blocks per row, rows of the launch): the rule of kf::gemv_lpr_log2 (koifish_amd/csrc/kf_gemv.hip), restated.
  *     `rows` = the rows of ALL matrices a launch multiplies (Q | K | V together; gate alone for the paired gate / up launch).
@@ -530,16 +534,25 @@ static int epb_of_type(int type) { /* elements per 16-byte storage block; 0: the
         default: return 0;
     }
 }
+/* lanes per row for a storage with `epb` elements per block: the rule itself, except for the 1-bit blocks (see above) */
+static int kfo_lpr_log2_epb(int epb, int K, long rows) {
+    if (epb == 128) {
+        const int l = kfo_lpr_log2(K / 32, rows) - 2;
+        return l > 0 ? l : 0;
+    }
+    return kfo_lpr_log2(K / epb, rows);
+}
 static float dot_canon(const float* w, const float* x, int K, int epb, int lpr_log2) {
-    const int nBlk = K / epb, LPR = 1 << lpr_log2;
+    const int nBlk = K / epb, LPR = 1 << lpr_log2, ns = epb == 128 ? 4 : 1, sb = epb / ns; /* sub-chains per lane, elements per sub-block */
     float lane[64];
     for (int l = 0; l < LPR; l++) {
-        float e = 0.f, o = 0.f; /* the even / odd chain of this lane (every epb is even) */
+        float e[4] = {0.f, 0.f, 0.f, 0.f}, o[4] = {0.f, 0.f, 0.f, 0.f}; /* the even / odd chains of this lane (every sub-block length is even) */
         for (int c = l; c < nBlk; c += LPR) {
             const float *wb = w + (size_t)c * epb, *xb = x + (size_t)c * epb;
-            for (int i = 0; i < epb; i += 2) e = fmaf(wb[i], xb[i], e), o = fmaf(wb[i + 1], xb[i + 1], o);
+            for (int s = 0; s < ns; s++)
+                for (int i = s * sb; i < (s + 1) * sb; i += 2) e[s] = fmaf(wb[i], xb[i], e[s]), o[s] = fmaf(wb[i + 1], xb[i + 1], o[s]);
         }
-        lane[l] = e + o;
+        lane[l] = ns == 1 ? e[0] + o[0] : ((e[0] + o[0]) + (e[1] + o[1])) + ((e[2] + o[2]) + (e[3] + o[3]));
     }
     for (int s = 1; s < LPR; s <<= 1)
         for (int l = 0; l < LPR; l += 2 * s) lane[l] = lane[l] + lane[l + s];
@@ -548,7 +561,7 @@ static float dot_canon(const float* w, const float* x, int K, int epb, int lpr_l
 /* row dot in the order the library is set to; `rows` only matters for the canonical order */
 static float row_dot(const kfo_weight* w, const float* row, const float* xf, int c0, int c1, long rows) {
     const int epb = epb_of_type(w->type);
-    if (g_order == 1 && epb > 0 && (c1 - c0) % epb == 0) return dot_canon(row + c0, xf + c0, c1 - c0, epb, kfo_lpr_log2((c1 - c0) / epb, rows));
+    if (g_order == 1 && epb > 0 && (c1 - c0) % epb == 0) return dot_canon(row + c0, xf + c0, c1 - c0, epb, kfo_lpr_log2_epb(epb, c1 - c0, rows));
     return dot16(row + c0, xf + c0, c1 - c0);
 }
 static long g_launch_rows = 0; /* rows of the launch the next kfo_linear* calls belong to (0: the matrix's own rows) */
@@ -1558,7 +1571,7 @@ static void model_linear(kfo_qwen3* m, int layer, int slot, const kfo_weight* w,
     if (g_order == 1 && epb > 0 && w->ne1 % epb == 0) { /* canonical order: `rows` = the rows of the launch this matrix is multiplied in */
         const int i = layer < 0 ? m->n_layer * 7 : layer * 7 + slot;
         if (m->fast && !m->fast_f16[i]) {
-            linear_canon_w16(m->fast[i], w->ne0, w->ne1, epb, kfo_lpr_log2(w->ne1 / epb, rows), x, y, hot);
+            linear_canon_w16(m->fast[i], w->ne0, w->ne1, epb, kfo_lpr_log2_epb(epb, w->ne1, rows), x, y, hot);
         } else {
             kfo_set_launch_rows(rows);
             if (hot) kfo_linear_masked(w, x, y, NULL, hot);

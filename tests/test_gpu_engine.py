@@ -184,3 +184,53 @@ def test_full_size_generations_repeat_bit_for_bit():
         assert np.array_equal(got[1], ref[canon][1])
     assert m.engine_steps() >= 4 * (S - 1)
     m.close()
+
+
+def test_engine_served_says_why_not():
+    """kf_engine_served / Fish::EnsureEngine: a model the engine does not serve gets the reason as text (VERDICT r03 item 8), a served one an empty string"""
+    cfg = dict(synth.CONFIGS["tiny"])
+    cfg["ffn"] = 768
+    raw = synth.raw_weights_numpy(cfg, 5, w_std=0.1)
+    m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
+    why = m.engine_why()
+    assert "shape not instantiated" in why, why
+    m.close()
+    cfg = _cfg("small", 320)
+    raw = synth.raw_weights_numpy(cfg, 5, w_std=0.1)
+    m = synth.build_from_raw(cfg, raw, L.T_SIGN, L.BF16)   # a storage the engine is not instantiated for
+    assert "storage not served" in m.engine_why(), m.engine_why()
+    m.close()
+    m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
+    assert m.engine_why() == ""
+    m.close()
+
+
+def test_engine_tune_changes_timing_not_results():
+    """kf_engine_tune (self-calibrated first-sweep delays) and kf_engine_stats: after tuning at several position buckets the decode reproduces the untuned decode's ids, logits
+    and K / V rows bit for bit -- the hand-off protocol is correct for any delay -- and the statistics report the delays as measured plus the sweeps per poll."""
+    cfg = _cfg("small", 320)
+    raw = synth.raw_weights_numpy(cfg, 4242, w_std=0.1)
+    n = 260
+    forced = np.full(cfg["max_seq"], -1, dtype=np.int32)
+    forced[:n:3] = prompt_ids(cfg, len(forced[:n:3]), seed=9)
+    res = []
+    for tune in (0, 3):
+        m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
+        m.set_canonical(True)
+        m.set_engine_autotune(tune)
+        m.set_forced(forced)
+        m.set_state(int(forced[0]), 0)
+        m.run_steps(0, n, use_graph=True)
+        m.sync()
+        m.engine_check()
+        st = m.engine_stats(n - 1)
+        assert st["tuned"] == (1 if tune else 0)
+        assert st["polls"] > 0 and all(v > 0 for v in st["sweeps_per_poll"][:1])
+        if tune:   # an explicit call at the position the state holds: launch time before / after
+            before, after = m.engine_tune(1)
+            assert before > 0 and after > 0 and after <= before * 1.05
+        k, v = m.kv_to_host()
+        res.append((m.tokens_out(n).tolist(), m.logits().copy(), k[:, :n].copy(), v[:, :n].copy()))
+        m.close()
+    assert res[0][0] == res[1][0]
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
