@@ -166,8 +166,8 @@ def test_stacked_large_batch_route_vs_exact(ctx, O, t, nt):
     yu = f(x) @ f(O.dequant(ou)).reshape(m, k).T
     ref = yg / (1.0 + np.exp(-yg)) * yu
     assert np.abs(f(u16(act)) - ref).max() <= 2.0 ** -6 * np.abs(ref).max()
-    # and exactly the SwiGLU expression of the two bf16 products the launch left (gate in act before the element-wise pass is gone; up is in tmp)
-    assert np.abs(f(u16(tmp)) - yu).max() <= 2.0 ** -7 * np.abs(yu).max()
+    # (round 4: gate | up are dequantised interleaved and the SwiGLU expression runs in the tile GEMM's epilogue -- the `up` projection is never written: up_scratch stays untouched)
+    assert not u16(tmp).any()
 
 
 @pytest.mark.parametrize("t", [L.Q4, L.BF16, L.T_SIGN])
