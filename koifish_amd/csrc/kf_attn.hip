@@ -35,14 +35,14 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
     uint16_t* knew = qb + GQ * hd;                         // [hd]
     int* flag = reinterpret_cast<int*>(knew + hd);
 
-    const int split = blockIdx.x, kvh = blockIdx.y, nsp = a.n_splits;
+    const int split = blockIdx.x, kvh = (int)blockIdx.y / a.gq_split, gpart = (int)blockIdx.y - kvh * a.gq_split, nsp = a.n_splits;
     // token batch (prefill): blockIdx.z = token, one slice per kv-head, position pos0 + token, q / out rows q_stride apart
     const int pos_l = a.pos + (int)blockIdx.z;
     const uint16_t* const qsrc = a.q + (size_t)blockIdx.z * a.q_stride;
     uint16_t* const odst = a.out + (size_t)blockIdx.z * a.q_stride;
     const int chunk = a.chunk; /* keys per slice, fixed by the launch bound so that the K/V stream can start before pos is known */
     const int t0 = split * chunk;
-    const int h0 = kvh * GQ;
+    const int h0 = (kvh * a.gq_split + gpart) * GQ; /* GQ = the heads of THIS workgroup */
 
     // LPK lanes per key (8 dims each), KPW keys per wave step, the waves interleaved over the slice
     constexpr int LPK = hd >> 3, KPW = 64 / LPK, lpk_log2 = hd_log2 - 3;
@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
         const bool own_new = has_new && (pos >= t0) && (pos < t1);
         if (own_new && wave == (GQ % NW)) prep_head(kraw, a.wk_norm != nullptr, tab_pos, hd, a.eps, knew);
         __syncthreads();
-        if (own_new) {
+        if (own_new && gpart == 0) {
             uint16_t* krow = a.kcache + (size_t)pos * a.kv_stride + (size_t)kvh * hd;
             for (int i = tid; i < hd; i += blockDim.x) krow[i] = knew[i];
         }
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnArgs a) {
     if (nsp == 1) return;
 
     // ---- arrival; the last workgroup of this kv-head merges
-    int* const counter = a.counters + kvh * a.cnt_stride;
+    int* const counter = a.counters + (int)blockIdx.y * a.cnt_stride; /* per (kv-head, part): its slices' workgroups meet here */
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
@@ -211,14 +211,14 @@ __global__ void __launch_bounds__(NW * 64) attn_fast_kernel(const AttnArgs a) {
     int* flag = reinterpret_cast<int*>(wmax + NW * GQ);
     float* comb = reinterpret_cast<float*>(flag + 4);  // [NW][GQ][PS]
 
-    const int split = blockIdx.x, kvh = blockIdx.y, nsp = a.n_splits;
+    const int split = blockIdx.x, kvh = (int)blockIdx.y / a.gq_split, gpart = (int)blockIdx.y - kvh * a.gq_split, nsp = a.n_splits;
     // token batch (prefill): blockIdx.z = token, one slice per kv-head, position pos0 + token, q / out rows q_stride apart
     const int pos_l = a.pos + (int)blockIdx.z;
     const uint16_t* const qsrc = a.q + (size_t)blockIdx.z * a.q_stride;
     uint16_t* const odst = a.out + (size_t)blockIdx.z * a.q_stride;
     const int chunk = a.chunk; /* keys per slice, fixed by the launch bound so that the K/V stream can start before pos is known */
     const int t0 = split * chunk;
-    const int h0 = kvh * GQ;
+    const int h0 = (kvh * a.gq_split + gpart) * GQ; /* GQ = the heads of THIS workgroup */
 
     // LPK lanes per key (8 dims each), KPW keys per wave step, the waves interleaved over the slice
     constexpr int LPK = hd >> 3, KPW = 64 / LPK, lpk_log2 = hd_log2 - 3;
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fast_kernel(const AttnArgs a) {
         const bool own_new = has_new && (pos >= t0) && (pos < t1);
         if (own_new && wave == (GQ % NW)) prep_head(kraw, a.wk_norm != nullptr, tab_pos, hd, a.eps, knew);
         __syncthreads();
-        if (own_new) {
+        if (own_new && gpart == 0) {
             uint16_t* krow = a.kcache + (size_t)pos * a.kv_stride + (size_t)kvh * hd;
             for (int i = tid; i < hd; i += blockDim.x) krow[i] = knew[i];
         }
@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fast_kernel(const AttnArgs a) {
     if (nsp == 1) return;
 
     // ---- arrival; the last workgroup of this kv-head merges
-    int* const counter = a.counters + kvh * a.cnt_stride;
+    int* const counter = a.counters + (int)blockIdx.y * a.cnt_stride; /* per (kv-head, part): its slices' workgroups meet here */
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
@@ -500,16 +500,18 @@ int attn_launch(hipStream_t st, AttnArgs& a) {
     a.n_splits = nsp;
     a.chunk = (pos_max + 1 + nsp - 1) / nsp;
     a.inv_sqrt_hd_den = sqrtf((float)hd);
-    a.cnt_stride = KF_ATTN_CNT_BYTES / 4 / a.n_kv; /* arrival counters of different kv-heads in different cache lines: atomics on one line serialise */
+    a.gq_split = (a.canon && GQ == 8) ? 2 : 1;
+    a.cnt_stride = KF_ATTN_CNT_BYTES / 4 / (a.n_kv * a.gq_split); /* arrival counters of different kv-heads in different cache lines: atomics on one line serialise */
     if (a.cnt_stride > 64) a.cnt_stride = 64;
     if (a.cnt_stride < 1) return KF_INVALID_ARGS;
     // one 64-key batch per 4-wave workgroup (one wave per SIMD: the kernel is bound by VALU issue inside a latency chain, so
     // spreading the keys over more CUs beats more waves per CU); 8 waves once the slices have to grow past 128 keys
     int NW = (GQ <= 2 && a.chunk > 128) ? 8 : 4;
-    size_t smem = sizeof(double) * ((size_t)NW * GQ * (hd + 2)) + sizeof(uint16_t) * ((size_t)GQ * hd + hd) + 16;
+    const int gq_wg = GQ / a.gq_split; /* query heads per workgroup */
+    size_t smem = sizeof(double) * ((size_t)NW * gq_wg * (hd + 2)) + sizeof(uint16_t) * ((size_t)gq_wg * hd + hd) + 16;
     const size_t smem_fast = sizeof(uint16_t) * ((size_t)GQ * hd + hd) + sizeof(float) * (NW * GQ + 4 + (size_t)NW * GQ * (hd + 4));
     if (!a.canon) smem = smem_fast;
-    dim3 grid(nsp, a.n_kv, a.n_tok);
+    dim3 grid(nsp, a.n_kv * a.gq_split, a.n_tok);
 #define KF_ATTN_GO(gq, nw)                                                                                       \
     do {                                                                                                        \
         if (a.canon) {                                                                                          \
@@ -524,7 +526,10 @@ int attn_launch(hipStream_t st, AttnArgs& a) {
         case 1: if (NW == 8) KF_ATTN_GO(1, 8); else KF_ATTN_GO(1, 4); break;
         case 2: if (NW == 8) KF_ATTN_GO(2, 8); else KF_ATTN_GO(2, 4); break;
         case 4: KF_ATTN_GO(4, 4); break;
-        case 8: KF_ATTN_GO(8, 4); break;
+        case 8:
+            if (a.gq_split == 2) KF_ATTN_GO(4, 4); /* two workgroups of four heads each (canonical order) */
+            else KF_ATTN_GO(8, 4);
+            break;
         default: return KF_INVALID_ARGS;
     }
 #undef KF_ATTN_GO

@@ -183,7 +183,7 @@ __device__ __forceinline__ void g3_epilogue_qkrope(const GemmArgs& a, int m0, in
         ss[nt] = xsum32_d(xsum16_d(ss[nt])); /* the column's 4 lanes (l ^ 16, l ^ 32): this wave's 64 rows */
     }
     double* red = reinterpret_cast<double*>(smem_raw);                                  /* [2 wm][128 tokens] */
-    uint16_t* xch = reinterpret_cast<uint16_t*>(smem_raw + 2 * 128 * sizeof(double));   /* [4 waves][64 values][64 lanes] bf16 */
+    uint32_t* xch = reinterpret_cast<uint32_t*>(smem_raw + 2 * 128 * sizeof(double));   /* [4 waves][32 bf16 pairs][64 lanes] */
     if (q4 == 0) {
 #pragma unroll
         for (int nt = 0; nt < C::NT; nt++) red[wm * 128 + wn * 64 + nt * 16 + r16] = ss[nt];
@@ -195,12 +195,15 @@ __device__ __forceinline__ void g3_epilogue_qkrope(const GemmArgs& a, int m0, in
         float s = 1.0f;
         if (nw) s = round_bf16(1.0f / sqrtf((float)(red[tl] + red[128 + tl]) / 128.0f + a.qk_eps));
 #pragma unroll
-        for (int mt = 0; mt < C::MT; mt++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (nw) x[mt][nt][j] = round_bf16(x[mt][nt][j] * s * bf2f(nw[wm * 64 + mt * 16 + 4 * q4 + j]));
-                xch[((size_t)wid * 64 + (mt * C::NT + nt) * 4 + j) * 64 + lane] = f2bf(x[mt][nt][j]);
+        for (int mt = 0; mt < C::MT; mt++) {
+            if (nw) {
+                const u32x2 w4 = *reinterpret_cast<const u32x2*>(nw + wm * 64 + mt * 16 + 4 * q4); /* this lane's four norm weights */
+                x[mt][nt][0] = round_bf16(x[mt][nt][0] * s * bf_lo(w4.x)), x[mt][nt][1] = round_bf16(x[mt][nt][1] * s * bf_hi(w4.x));
+                x[mt][nt][2] = round_bf16(x[mt][nt][2] * s * bf_lo(w4.y)), x[mt][nt][3] = round_bf16(x[mt][nt][3] * s * bf_hi(w4.y));
             }
+            xch[((size_t)wid * 32 + (mt * C::NT + nt) * 2) * 64 + lane] = pack_bf16x2(x[mt][nt][0], x[mt][nt][1]);
+            xch[((size_t)wid * 32 + (mt * C::NT + nt) * 2 + 1) * 64 + lane] = pack_bf16x2(x[mt][nt][2], x[mt][nt][3]);
+        }
     }
     __syncthreads();
     const int pw = (1 - wm) * C::WN + wn; /* the wave that holds the other element of every pair */
@@ -211,12 +214,20 @@ __device__ __forceinline__ void g3_epilogue_qkrope(const GemmArgs& a, int m0, in
             const int tok = t0 + wn * 64 + nt * 16 + r16, jj = mt * 16 + 4 * q4; /* pair index 0 .. 63 of this lane's first row */
             if (tok >= a.n) continue;
             uint16_t o[4];
+            const uint32_t op0 = xch[((size_t)pw * 32 + (mt * C::NT + nt) * 2) * 64 + lane], op1 = xch[((size_t)pw * 32 + (mt * C::NT + nt) * 2 + 1) * 64 + lane];
+            const float oth[4] = {bf_lo(op0), bf_hi(op0), bf_lo(op1), bf_hi(op1)};
+            f32x4 cs01 = f32x4{1.f, 0.f, 1.f, 0.f}, cs23 = cs01; /* (cos, sin) of the lane's four pairs jj .. jj + 3: 32 contiguous bytes of the table */
+            if (a.rope_table) {
+                const f32x4* tp = reinterpret_cast<const f32x4*>(a.rope_table + (size_t)(a.rope_pos0 + tok) * 128 + 2 * jj);
+                cs01 = tp[0], cs23 = tp[1];
+            }
+            const float csv[8] = {cs01.x, cs01.y, cs01.z, cs01.w, cs23.x, cs23.y, cs23.z, cs23.w};
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const float other = bf2f(xch[((size_t)pw * 64 + (mt * C::NT + nt) * 4 + j) * 64 + lane]), own = x[mt][nt][j];
+                const float other = oth[j], own = x[mt][nt][j];
                 float v = own;
                 if (a.rope_table) {
-                    const float2 cs = *reinterpret_cast<const float2*>(a.rope_table + (size_t)(a.rope_pos0 + tok) * 128 + 2 * (jj + j));
+                    const float2 cs = float2{csv[2 * j], csv[2 * j + 1]};
                     if (wm == 0) { /* x_j c - x_{j+64} s */
                         const float p0 = own * cs.x, p1 = other * cs.y;
                         v = p0 - p1;

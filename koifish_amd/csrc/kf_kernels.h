@@ -124,6 +124,8 @@ struct AttnArgs {
     int one_slice;      /* every (kv-head, token) is handled by one workgroup: no scratch, no hand-off */
     long long q_stride; /* elements between the q (and out) rows of consecutive tokens */
     int canon;          /* the canonical softmax (fp64 sums, exact rescales; bit-exact against the oracle's CANON mode) instead of the fp32 form */
+    int gq_split;       /* set by attn_launch: the query heads of a kv-head are dealt to this many workgroups (blockIdx.y = kv-head * gq_split + part), each with GQ / gq_split heads:
+                           the canonical form at 8 query heads per kv-head needs 411 registers in one workgroup (one wave per SIMD, accumulators in AGPRs), 224 in two */
 };
 int attn_launch(hipStream_t st, AttnArgs& a);
 int attn_splits(int pos_bound, int n_kv);
