@@ -54,6 +54,7 @@ def main():
                     "torch.distributed all-gathers per layer")
     ap.add_argument("--tp-virtual", type=int, default=0, help="side measurement on ONE GPU: this many TP ranks of qwen3-32b in one process, lock-step on one stream "
                     "(the per-rank kernels and the exchange kernels of TP = R, serialised: R x the work of one rank's GPU, no xGMI)")
+    ap.add_argument("--tp-layers", type=int, default=0, help="with --tp-virtual: this many of the model's layers (0 = all): bounds the side leg's wall time")
     ap.add_argument("--lean-cpu", type=float, default=0.0, help="with --lean: also the CPU-baseline leg (parity passes + a timed sample of this many seconds) of the model being run")
     ap.add_argument("--lean", action="store_true", help="only the timed decode and step_roofline (what the side legs run in their child processes)")
     ap.add_argument("--leg", default="", choices=["", "config3", "config4cpu"], help="run ONE side leg and print its JSON (child processes of the main run)")
@@ -295,6 +296,21 @@ def _child(argv, timeout_s):
         return {"error": repr(e)[:300]}
 
 
+def _tp_virtual_leg(layers=16):
+    """BASELINE config 4's rank step without an 8-GPU node: the 8 ranks of TP = 8 (8 q-heads + 1 kv-head + 3200 FFN rows + 18992 vocabulary rows each) in ONE process on ONE GPU,
+    lock-step on one stream with the kernel-side exchange through local pointers -- every rank's kernels and the exchange kernels run, serialised; no xGMI.  `layers` of the 64
+    layers (stated) bound the leg's wall time; per-rank figures scale with the layer count, the head does not."""
+    d = _child(["--config", "qwen3-32b", "--tp-virtual", "8", "--tp-layers", str(layers), "--steps", "32", "--warmup", "8"], 600)
+    if "error" in d:
+        return d
+    ms8 = d["ms_per_step"]   # 8 ranks serialised
+    return {"workload": d["config"]["workload"], "layers_run": layers, "layers_of_model": 64, "ms_per_step_8_ranks_serialised": ms8, "ms_per_rank_step": round(ms8 / 8, 4),
+            "bytes_per_step_per_rank": d["roofline"]["bytes_per_step_per_rank"], "achieved_GBs_per_rank_kernel_time": d["roofline"]["achieved"], "frac": d["roofline"]["frac"],
+            "decode_path": d["config"]["decode_path"], "summation_order": "canonical (library default)",
+            "note": "what ONE rank's GPU would spend per token at TP = 8 if the exchange cost nothing more than here: ms_per_rank_step x 64 / %d layers; no scaling curve has been measured on hardware" % layers,
+            "leg_wall_s": d.get("leg_wall_s")}
+
+
 def side_legs(which):
     """The other single-GPU configurations of BASELINE.json beside the line (never `value`), each re-derivable from the profile named in it."""
     out = {}
@@ -316,6 +332,7 @@ def side_legs(which):
             "fast_order_tokens_per_s": d.get("fast_order_mode", {}).get("tokens_per_s"),
             "decode_path": d["config"]["decode_path"], "profile": "profiles/r04_config4_one_gpu_kernel_stats.csv", "leg_wall_s": d.get("leg_wall_s"),
             "cpu_baseline_4_layer_slice": _child(["--leg", "config4cpu"], 420),
+            "tp8_virtual_ranks": _tp_virtual_leg(),
             "note": "TP = 8 over xGMI needs an 8-GPU node: bench.py --config qwen3-32b --gpus 8 (no scaling curve has been measured on hardware)"}
     return out
 
@@ -499,6 +516,8 @@ def tp_main(args, cfg, rank, world, dev):
     R = args.tp_virtual if virtual else world
     if "KF_BENCH_TP_LAYERS" in os.environ:   # test hook only (tests/test_gpu_bench_ranks.py): a cut model; the line says so
         cfg = dict(cfg, n_layer=int(os.environ["KF_BENCH_TP_LAYERS"]), vocab=int(os.environ.get("KF_BENCH_TP_VOCAB", cfg["vocab"])))
+    elif args.tp_layers > 0:                 # the side leg of the default run: a cut of the layer stack bounds its wall time; the line says so
+        cfg = dict(cfg, n_layer=args.tp_layers)
     ctx = Context(dev)
     plan = TP.TPPlan(cfg, R)
     g = torch.Generator(device=ctx.device)
@@ -781,9 +800,9 @@ def engine_roofline(m, ctx, cfg, forced, timed_positions, reps=6):
         run = {"error": repr(e)[:160]}
     traffic, traffic_src = None, None
     try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r03c_pmc_engine.json")))
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_engine.json")))
         traffic = int(pj["hbm_bytes_per_launch"])
-        traffic_src = "profiles/r03c_pmc_engine.json: counter passes of scratch/ub_engine.py at position %d (%d algorithmic bytes there); not re-collected by this run" % (
+        traffic_src = "profiles/r04_pmc_engine.json: counter passes of scratch/ub_engine.py at position %d (%d algorithmic bytes there); not re-collected by this run" % (
             int(pj.get("position", -1)), int(pj["algorithmic_bytes_per_launch"]))
     except Exception:
         pass

@@ -46,13 +46,15 @@ struct Batch {
 // weight stream's HBM latency overlaps the (dependent) activation load + norm.
 // ONEJOB: a launch with a single matrix (o_proj, down_proj, LM head, sparse rows) never reads the descriptors of jobs 1 and 2: kernel arguments are fetched ahead of the
 // first load, and every one a launch touches is on its critical path
-template <int FMT, int G, int MODE, bool SPARSE, bool ONEJOB, bool CANON>
+// XF (canonical 4-bit forms only, chosen by the launcher when K * 4 bytes of LDS leave the occupancy alone): x is staged as fp32 chunks [8][nBlk] and multiplied through
+// BlockDotF (the engine's form): a product is two conversions of the weight pair + one v_pk_fma_f32 instead of four conversions + one -- same chains, same bits
+template <int FMT, int G, int MODE, bool SPARSE, bool ONEJOB, bool CANON, bool XF_ = false>
 __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     using BD = BlockDot<FMT, CANON>;
-    constexpr bool PAIRED = (MODE == GEMV_PAIRED), LUT = (FMT == FMT_Q4R);
+    constexpr bool PAIRED = (MODE == GEMV_PAIRED), LUT = (FMT == FMT_Q4R), XF = XF_ && CANON && (FMT == FMT_Q4 || FMT == FMT_Q4P);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);
-    double* red = reinterpret_cast<double*>(smem_raw + (size_t)a.K * 2);
+    double* red = reinterpret_cast<double*>(smem_raw + (size_t)a.K * (XF ? 4 : 2));
 
     const int tid = threadIdx.x, lane = tid & 63, wave_in_blk = tid >> 6;
     const int nBlk = a.nBlk, iters = a.iters;
@@ -213,9 +215,17 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     }
     const int pos = a.d_pos ? *a.d_pos : a.pos;
 
-    // ---- prologue: stage x into LDS as packed bf16 chunks
+    // ---- prologue: stage x into LDS as packed bf16 chunks (XF: the same elements widened to fp32, two chunks of four)
     {
         constexpr int XCH = BD::XCH;
+        auto put = [&](int c, int j, u32x4 o) {
+            if constexpr (XF) {
+                xs[(2 * j) * nBlk + c] = u32x4{o.x << 16, o.x & 0xffff0000u, o.y << 16, o.y & 0xffff0000u};
+                xs[(2 * j + 1) * nBlk + c] = u32x4{o.z << 16, o.z & 0xffff0000u, o.w << 16, o.w & 0xffff0000u};
+            } else {
+                xs[j * nBlk + c] = o;
+            }
+        };
         if (xreg) {
             // RMSNorm prologue, one pass (rms_norm_kernel, layernorm.cuh:800-847): fp64 sum of squares over the workgroup, then the
             // normalised chunks go to LDS; without a norm weight the chunks go to LDS as they are.
@@ -244,11 +254,11 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
             }
             if (h0) {
                 const int c = tid / XCH, j = tid - c * XCH;
-                xs[j * nBlk + c] = u32x4{ow[0], ow[1], ow[2], ow[3]};
+                put(c, j, u32x4{ow[0], ow[1], ow[2], ow[3]});
             }
             if (h1) {
                 const int e8 = tid + 256, c = e8 / XCH, j = e8 - c * XCH;
-                xs[j * nBlk + c] = u32x4{ow[4], ow[5], ow[6], ow[7]};
+                put(c, j, u32x4{ow[4], ow[5], ow[6], ow[7]});
             }
         } else {
             float mul = 1.0f;
@@ -273,7 +283,7 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
                     }
                     o.x = ow[0], o.y = ow[1], o.z = ow[2], o.w = ow[3];
                 }
-                xs[j * nBlk + c] = o;
+                put(c, j, o);
             }
         }
         __syncthreads();
@@ -312,11 +322,15 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
                     }
                 } else {
                     const float st = bf2f(bt.st[g]);
-                    const Acc r = BD::run(bt.w[g], xs, col, nBlk, st, bf2f(bt.ze[g]), -(jqb * st), acc[g]);
+                    Acc r;
+                    if constexpr (XF) r = BlockDotF<FMT>::run(bt.w[g], reinterpret_cast<const f32x4*>(xs), col, nBlk, st, bf2f(bt.ze[g]), -(jqb * st), acc[g]);
+                    else r = BD::run(bt.w[g], xs, col, nBlk, st, bf2f(bt.ze[g]), -(jqb * st), acc[g]);
                     acc[g] = acc_pick(ok, r, acc[g]);
                     if (PAIRED) {
                         const float st2 = bf2f(bt.st2[g]);
-                        const Acc r2 = BD::run(bt.w2[g], xs, col, nBlk, st2, bf2f(bt.ze2[g]), -(jqb2 * st2), acc2[g]);
+                        Acc r2;
+                        if constexpr (XF) r2 = BlockDotF<FMT>::run(bt.w2[g], reinterpret_cast<const f32x4*>(xs), col, nBlk, st2, bf2f(bt.ze2[g]), -(jqb2 * st2), acc2[g]);
+                        else r2 = BD::run(bt.w2[g], xs, col, nBlk, st2, bf2f(bt.ze2[g]), -(jqb2 * st2), acc2[g]);
                         acc2[g] = acc_pick(ok, r2, acc2[g]);
                     }
                 }
@@ -520,14 +534,28 @@ int gemv_lpr_log2(int nBlk, long rows) {
 }
 #endif
 
+template <int FMT, int MODE, bool SPARSE, bool ONEJOB, bool XF>
+static void launch_x(const GemvArgs& a, int G, dim3 grid, size_t smem, hipStream_t st) {
+    if (G >= 4)
+        hipLaunchKernelGGL((gemv_kernel<FMT, 4, MODE, SPARSE, ONEJOB, GEMV_CANON, XF>), grid, dim3(256), smem, st, a);
+    else if (G == 2)
+        hipLaunchKernelGGL((gemv_kernel<FMT, 2, MODE, SPARSE, ONEJOB, GEMV_CANON, XF>), grid, dim3(256), smem, st, a);
+    else
+        hipLaunchKernelGGL((gemv_kernel<FMT, 1, MODE, SPARSE, ONEJOB, GEMV_CANON, XF>), grid, dim3(256), smem, st, a);
+}
+// the canonical 4-bit forms take x as fp32 in LDS while 4 K + 256 bytes stay inside 48 KiB (K <= 12224: every matrix of the 0.6B model, Q | K | V, o_proj and gate | up of
+// Qwen3-32B and all of its TP = 8 shards; not its 25600-wide down_proj, where 100 KiB per workgroup would halve the resident waves)
+constexpr size_t GEMV_XF_MAX_SMEM = 48 * 1024;
 template <int FMT, int MODE, bool SPARSE, bool ONEJOB>
 static void launch_j(const GemvArgs& a, int G, dim3 grid, size_t smem, hipStream_t st) {
-    if (G >= 4)
-        hipLaunchKernelGGL((gemv_kernel<FMT, 4, MODE, SPARSE, ONEJOB, GEMV_CANON>), grid, dim3(256), smem, st, a);
-    else if (G == 2)
-        hipLaunchKernelGGL((gemv_kernel<FMT, 2, MODE, SPARSE, ONEJOB, GEMV_CANON>), grid, dim3(256), smem, st, a);
-    else
-        hipLaunchKernelGGL((gemv_kernel<FMT, 1, MODE, SPARSE, ONEJOB, GEMV_CANON>), grid, dim3(256), smem, st, a);
+    if constexpr (GEMV_CANON && (FMT == FMT_Q4 || FMT == FMT_Q4P)) {
+        const size_t smem_f = smem + (size_t)a.K * 2;
+        if (smem_f <= GEMV_XF_MAX_SMEM) {
+            launch_x<FMT, MODE, SPARSE, ONEJOB, true>(a, G, grid, smem_f, st);
+            return;
+        }
+    }
+    launch_x<FMT, MODE, SPARSE, ONEJOB, false>(a, G, grid, smem, st);
 }
 template <int FMT, int MODE, bool SPARSE>
 static void launch_g(const GemvArgs& a, int G, dim3 grid, size_t smem, hipStream_t st) {
