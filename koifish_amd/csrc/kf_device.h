@@ -260,6 +260,12 @@ __device__ __forceinline__ float acc_join(f32x2_t a) { return a.x + a.y; }
 __device__ __forceinline__ float acc_pick(bool c, float a, float b) { return c ? a : b; }
 __device__ __forceinline__ f32x2_t acc_pick(bool c, f32x2_t a, f32x2_t b) { return f32x2_t{c ? a.x : b.x, c ? a.y : b.y}; }
 __device__ __forceinline__ f32x2_t pk_fma(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
+// 2-bit storage, canonical order: a chain pair per 32-element half of the lane's 64-element blocks
+struct Acc2 {
+    f32x2_t s[2];
+};
+__device__ __forceinline__ float acc_join(const Acc2& a) { return (a.s[0].x + a.s[0].y) + (a.s[1].x + a.s[1].y); }
+__device__ __forceinline__ Acc2 acc_pick(bool c, const Acc2& a, const Acc2& b) { return Acc2{{acc_pick(c, a.s[0], b.s[0]), acc_pick(c, a.s[1], b.s[1])}}; }
 // 1-bit storage, canonical order: one chain pair per dword position of the lane's 128-element blocks (oracle/kf_oracle.c section 4c); joined as a balanced tree
 struct Acc4 {
     f32x2_t s[4];

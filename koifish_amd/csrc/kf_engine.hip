@@ -345,10 +345,10 @@ struct PlanT {
     static constexpr CPlan plan() { return c_plan(K_, EPB_, M0_, M1_, M2_, PAIRED_, NWG_); }
 };
 // the four phases of a model shape
-// elements per block as the engine walks a matrix: the storage's 16-byte block, except 1-bit -- one DWORD (32 weights) of a 128-element block per lane, so that a 1-bit
-// matrix has the lanes, slots and chains of a 4-bit one (BlockPrep<FMT_Q1T>)
+// elements per block as the engine walks a matrix: the storage's 16-byte block, except 1-bit and 2-bit -- one DWORD of a 128-element block, resp. one 8-byte half of a
+// 64-element block (32 weights either way) per lane, so that such a matrix has the lanes, slots and chains of a 4-bit one (BlockPrep<FMT_Q1T>, <FMT_Q2T>)
 template <int FMT>
-constexpr int eng_vepb() { return FMT == FMT_Q1T ? 32 : BlockDot<FMT>::EPB; }
+constexpr int eng_vepb() { return (FMT == FMT_Q1T || FMT == FMT_Q2T) ? 32 : BlockDot<FMT>::EPB; }
 template <int FMT, int DIM, int QD, int KVD, int FFN, int NWG>
 struct EngShape {
     static constexpr int EPB = eng_vepb<FMT>();
@@ -387,7 +387,7 @@ __device__ __forceinline__ MvAt mv_at(int k, int s0, int cw, int lane, int Mj) {
 template <class PL, int NCW, int FMT, int MAXS>
 __device__ __forceinline__ void mv_prefetch(const EngMat m, const EngMat m2, int s0, int cw, int lane, int Mj, MvRegs<PL::PAIRED, MAXS>& R, uint32_t hotbits = 0xffffffffu) {
     constexpr bool GAMA = BlockDot<FMT>::HAS_GAMA;
-    constexpr int gshift = FMT >= FMT_Q4 ? (FMT == FMT_Q4 || FMT == FMT_Q4P || FMT == FMT_Q1T ? 2 : (FMT == FMT_Q2 ? 1 : 0)) : 0; /* 128-weight groups (1-bit: four dword "blocks") */
+    constexpr int gshift = FMT >= FMT_Q4 ? (FMT == FMT_Q4 || FMT == FMT_Q4P || FMT == FMT_Q1T || FMT == FMT_Q2T ? 2 : (FMT == FMT_Q2 ? 1 : 0)) : 0; /* 128-weight groups = four 32-weight blocks */
 #pragma unroll
     for (int k = 0; k < MAXS; k++) {
         const MvAt q = mv_at<PL, NCW>(k, s0, cw, lane, Mj);
@@ -400,6 +400,14 @@ __device__ __forceinline__ void mv_prefetch(const EngMat m, const EngMat m2, int
             const uint32_t di = (bidx & ~3u) + (3u - (bidx & 3u));
             R.w[k] = u32x4{__builtin_nontemporal_load(reinterpret_cast<const uint32_t KF_GLOBAL*>(m.w) + di), 0u, 0u, 0u};
             if (PL::PAIRED) R.w2[k] = u32x4{__builtin_nontemporal_load(reinterpret_cast<const uint32_t KF_GLOBAL*>(m2.w) + di), 0u, 0u, 0u};
+        } else if constexpr (FMT == FMT_Q2T) { /* this lane's half of the 16-byte block: bytes 8 .. 15 hold elements 0 .. 31 (dword 3 first), bytes 0 .. 7 elements 32 .. 63 */
+            const uint32_t qi = (bidx & ~1u) + (1u - (bidx & 1u));
+            const u32x2 h = __builtin_nontemporal_load(reinterpret_cast<const u32x2 KF_GLOBAL*>(m.w) + qi);
+            R.w[k] = u32x4{h.x, h.y, 0u, 0u}; /* .y = the half's first 16 elements, .x = its last 16 */
+            if (PL::PAIRED) {
+                const u32x2 h2 = __builtin_nontemporal_load(reinterpret_cast<const u32x2 KF_GLOBAL*>(m2.w) + qi);
+                R.w2[k] = u32x4{h2.x, h2.y, 0u, 0u};
+            }
         } else {
             R.w[k] = __builtin_nontemporal_load(m.w + bidx);
             if (PL::PAIRED) R.w2[k] = __builtin_nontemporal_load(m2.w + bidx);
@@ -532,7 +540,7 @@ struct EngCfg {
     // CANON: the mat-vec phases and the head in the canonical order (one v_fma_f32 per product on fp32 operands: bit-exact against the oracle); false: v_dot2c_f32_bf16 on
     // bf16 pairs (kf_set_canonical(ctx, 0): <= 1 bf16 ulp per output from the oracle, fewer vector instructions).  The attention is canonical either way.
     static constexpr bool CANON = CANON_;
-    static_assert(FMT_ == FMT_Q4 || FMT_ == FMT_Q4P || FMT_ == FMT_Q1T, "storages with a BlockPrep: 32-weight blocks dequantised ahead of the hand-off (16 pair words each)");
+    static_assert(FMT_ == FMT_Q4 || FMT_ == FMT_Q4P || FMT_ == FMT_Q1T || FMT_ == FMT_Q2T, "storages with a BlockPrep: 32-weight blocks dequantised ahead of the hand-off (16 pair words each)");
     static constexpr bool F32X = CANON_; /* canonical order: activations staged as fp32 chunks (pairs_dot<true>: no conversion of the activation pair per product) */
     static constexpr int XCH = F32X ? 8 : 4; /* 16-byte chunks of x per 32-weight block */
     static constexpr int n_head = QD_ / HD_, n_kv = KVD_ / HD_;
@@ -1299,7 +1307,7 @@ __global__ void __launch_bounds__(C::NWV * 64) engine_kernel(const EngArgs a) {
     constexpr int xs_bytes = (maxK * 4 + 15) & ~15, xr_bytes = (C::DIM * 2 + 15) & ~15; /* xs: fp32 activations */
     constexpr size_t off = (size_t)2 * xs_bytes + 2 * xr_bytes;
     constexpr size_t fixed0 = (off + sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + sizeof(double) * ((size_t)NWV * GQ * (hd + 2) + (size_t)C::ME * KF_ATTN_MAX_SPLITS + 64) + 4 * 16 + 4 * 64 + 32 + 15) & ~(size_t)15;
-    constexpr size_t fixed_bytes = fixed0 + (C::FMT == FMT_Q1T ? 4096 : 0); /* the 1-bit selector table */
+    constexpr size_t fixed_bytes = fixed0 + (C::FMT == FMT_Q1T ? 4096 : (C::FMT == FMT_Q2T ? 2048 : 0)); /* the 1-bit / 2-bit selector table */
     EngLayer* lay = reinterpret_cast<EngLayer*>(smem + fixed_bytes);
     L.lay = lay;
     L.q1tab = reinterpret_cast<const u32x4*>(smem + fixed0);
@@ -1337,6 +1345,14 @@ __global__ void __launch_bounds__(C::NWV * 64) engine_kernel(const EngArgs a) {
 #pragma unroll
             for (int p = 0; p < 4; p++) e[p] = 0x01000100u + 0x0202u * ((tid >> (7 - 2 * p)) & 1u) + 0x02020000u * ((tid >> (6 - 2 * p)) & 1u);
             reinterpret_cast<u32x4*>(smem + fixed0)[tid] = u32x4{e[0], e[1], e[2], e[3]};
+        }
+    }
+    if constexpr (C::FMT == FMT_Q2T) { /* selector table of BlockDot<FMT_Q2T> (kf_gemv.hip fills the same): entry B, dword p = bytes {2q, 2q+1, 2q', 2q'+1}, q / q' = the levels of elements 2p, 2p+1 of byte B */
+        if (tid < 256) {
+            uint32_t e[2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) e[p] = 0x01000100u + 0x0202u * ((tid >> (6 - 4 * p)) & 3u) + 0x02020000u * ((tid >> (4 - 4 * p)) & 3u);
+            reinterpret_cast<u32x2*>(smem + fixed0)[tid] = u32x2{e[0], e[1]};
         }
     }
     { /* sparse forward: the hot bits of this workgroup's gate / up rows, per layer (CS_Picker's hot[] read once per launch) */
@@ -1459,7 +1475,7 @@ static int engine_shape_class(int GQ, int hd, int dim, int q_dim, int ffn) { /* 
     return 0;
 }
 static_assert(sizeof(EngPlan) == 80 && sizeof(EngLayer) == 224, "device table strides");
-static int eng_epb(int fmt) { return fmt == FMT_BF16 ? 8 : (fmt == FMT_F8 ? 16 : (fmt == FMT_Q4 || fmt == FMT_Q4P ? 32 : (fmt == FMT_Q2 ? 64 : 32 /* 1-bit: the engine's lanes take a dword of a 128-element block each (eng_vepb) */))); }
+static int eng_epb(int fmt) { return fmt == FMT_BF16 ? 8 : (fmt == FMT_F8 ? 16 : (fmt == FMT_Q4 || fmt == FMT_Q4P ? 32 : (32 /* 2-bit / 1-bit: the engine's lanes take a 32-weight piece of a block each (eng_vepb) */))); }
 
 // geometry of one phase; returns false when the shape is outside what the engine serves
 static bool eng_plan(EngPlan& P, int fmt, int K, int njobs, const kf_weight* const* w, bool paired, int n_wg, bool& q4p_ok) {
@@ -1566,8 +1582,8 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     // phases: every layer must have the same shapes and storage
     const kf_engine_layer& L0 = d->layers[0];
     int fmt = gemv_fmt_of(&L0.w[0]);
-    *why = "layer storage not served: the engine is instantiated for 4-bit PackedQ (RTN, groups of 128) and 1-bit PackedQ layers; other storages keep the per-layer launches";
-    if (fmt != FMT_Q4 && fmt != FMT_Q1) { /* the engine is instantiated for the 4-bit PackedQ storage (BASELINE config 2); other storages keep the per-layer launches */
+    *why = "layer storage not served: the engine is instantiated for 4-bit (RTN), 2-bit and 1-bit PackedQ layers in groups of 128; other storages keep the per-layer launches";
+    if (fmt != FMT_Q4 && fmt != FMT_Q1 && fmt != FMT_Q2) { /* the engine is instantiated for the 4-bit PackedQ storage (BASELINE config 2); other storages keep the per-layer launches */
         delete E;
         return KF_UNSUPPORTED_DATATYPE;
     }
@@ -1620,7 +1636,8 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
         return KF_OK;
     }
     if (fmt == FMT_Q4 && q4p_ok) fmt = FMT_Q4P;
-    if (fmt == FMT_Q1) fmt = FMT_Q1T; /* the LDS selector-table form (same bits as the per-bit select form) */
+    if (fmt == FMT_Q1) fmt = FMT_Q1T; /* the LDS selector-table forms (same bits as the per-bit select forms) */
+    if (fmt == FMT_Q2) fmt = FMT_Q2T;
     E->fmt = fmt, E->GQ = GQ, E->hd = hd, E->n_cu = n_cu, E->nwv = ENG_NWV, E->shape_class = shape_class;
     E->canon = 1;
     E->xmap = shape_class == 1 ? 1 : 0; /* 8 kv-heads on 8 XCDs */
@@ -1659,7 +1676,7 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     const size_t xs_bytes = ((size_t)maxK * 4 + 15) & ~(size_t)15;
     size_t smem = (((size_t)d->n_layer * sizeof(EngLayer) + 15) & ~(size_t)15) + 2 * xs_bytes + 2 * (((size_t)E->dim * 2 + 15) & ~(size_t)15);
     smem += sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + sizeof(double) * ((size_t)ENG_NWV * GQ * (hd + 2) + 64 * KF_ATTN_MAX_SPLITS + 64) + 4 * 16 + 4 * 64 + 32;
-    smem += (fmt == FMT_Q1T ? 4096 : 0) + (size_t)d->n_layer * 4 + 64; /* the 1-bit selector table; the layers' hot bits */
+    smem += (fmt == FMT_Q1T ? 4096 : (fmt == FMT_Q2T ? 2048 : 0)) + (size_t)d->n_layer * 4 + 64; /* the 1-bit / 2-bit selector table; the layers' hot bits */
     smem = (smem + 15) & ~(size_t)15;
     if (smem > 160 * 1024) {
         engine_release(E);
@@ -1767,6 +1784,7 @@ int engine_step(EngineHost* E, hipStream_t st, const uint16_t* x_in, uint16_t* x
         case FMT_Q4P: return engine_go_fmt<FMT_Q4P>(E, st);
         case FMT_Q4: return engine_go_fmt<FMT_Q4>(E, st);
         case FMT_Q1T: return engine_go_fmt<FMT_Q1T>(E, st);
+        case FMT_Q2T: return engine_go_fmt<FMT_Q2T>(E, st);
         default: return 1;
     }
 }

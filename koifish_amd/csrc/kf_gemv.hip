@@ -514,8 +514,8 @@ static int epb_of(int fmt) {
 // the same per storage: 1-bit rows take the rule's figure for K / 32 "virtual" blocks -- the four dwords of a 128-element block are what four neighbouring lanes of the persistent
 // engine multiply side by side (canonical order: a chain pair per dword position, oracle/kf_oracle.c section 4c) -- divided by four: logical lanes, one whole block each, here
 int gemv_lpr_log2_fmt(int fmt, int K, long rows) {
-    if (fmt == FMT_Q1 || fmt == FMT_Q1T) {
-        const int l = gemv_lpr_log2(K / 32, rows) - 2;
+    if (fmt == FMT_Q1 || fmt == FMT_Q1T || fmt == FMT_Q2 || fmt == FMT_Q2T) { /* 4 / 2 sub-blocks of 32 per block */
+        const int l = gemv_lpr_log2(K / 32, rows) - ((fmt == FMT_Q1 || fmt == FMT_Q1T) ? 2 : 1);
         return l > 0 ? l : 0;
     }
     return gemv_lpr_log2(K / epb_of(fmt), rows);

@@ -181,12 +181,19 @@ template <bool CANON>
 struct BlockDot<FMT_Q2, CANON> {
     static constexpr int EPB = 64, XCH = 8;
     static constexpr bool HAS_GAMA = true;
-    using Acc = acc_t<CANON>;
-    __device__ static __forceinline__ acc_t<CANON> run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, acc_t<CANON> acc) {
-        acc = dot_q2_dword<CANON>(w.w, xs[col], xs[nBlk + col], step, nb, zero, acc);
-        acc = dot_q2_dword<CANON>(w.z, xs[2 * nBlk + col], xs[3 * nBlk + col], step, nb, zero, acc);
-        acc = dot_q2_dword<CANON>(w.y, xs[4 * nBlk + col], xs[5 * nBlk + col], step, nb, zero, acc);
-        acc = dot_q2_dword<CANON>(w.x, xs[6 * nBlk + col], xs[7 * nBlk + col], step, nb, zero, acc);
+    using Acc = std::conditional_t<CANON, Acc2, float>;
+    __device__ static __forceinline__ Acc run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, Acc acc) {
+        if constexpr (CANON) { /* a chain pair per 32-element half */
+            acc.s[0] = dot_q2_dword<true>(w.w, xs[col], xs[nBlk + col], step, nb, zero, acc.s[0]);
+            acc.s[0] = dot_q2_dword<true>(w.z, xs[2 * nBlk + col], xs[3 * nBlk + col], step, nb, zero, acc.s[0]);
+            acc.s[1] = dot_q2_dword<true>(w.y, xs[4 * nBlk + col], xs[5 * nBlk + col], step, nb, zero, acc.s[1]);
+            acc.s[1] = dot_q2_dword<true>(w.x, xs[6 * nBlk + col], xs[7 * nBlk + col], step, nb, zero, acc.s[1]);
+        } else {
+            acc = dot_q2_dword<false>(w.w, xs[col], xs[nBlk + col], step, nb, zero, acc);
+            acc = dot_q2_dword<false>(w.z, xs[2 * nBlk + col], xs[3 * nBlk + col], step, nb, zero, acc);
+            acc = dot_q2_dword<false>(w.y, xs[4 * nBlk + col], xs[5 * nBlk + col], step, nb, zero, acc);
+            acc = dot_q2_dword<false>(w.x, xs[6 * nBlk + col], xs[7 * nBlk + col], step, nb, zero, acc);
+        }
         return acc;
     }
 };
@@ -280,8 +287,8 @@ template <bool CANON>
 struct BlockDot<FMT_Q2T, CANON> {
     static constexpr int EPB = 64, XCH = 8;
     static constexpr bool HAS_GAMA = true;
-    using Acc = acc_t<CANON>;
-    __device__ static __forceinline__ acc_t<CANON> run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, acc_t<CANON> acc) {
+    using Acc = std::conditional_t<CANON, Acc2, float>;
+    __device__ static __forceinline__ Acc run(u32x4 w, const u32x4* xs, int col, int nBlk, float step, float zero, float nb, Acc acc) {
         uint32_t r = pack_bf16x2(fmaf(0.0f, step, nb), fmaf(1.0f, step, nb));
         const uint32_t T01 = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
         r = pack_bf16x2(fmaf(2.0f, step, nb), fmaf(3.0f, step, nb));
@@ -295,8 +302,13 @@ struct BlockDot<FMT_Q2T, CANON> {
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const u32x2 S = tab[(dw[d] >> (24 - 8 * c)) & 0xffu];
-                acc = dotp<CANON>(__builtin_amdgcn_perm(T23, T01, S.x), xw[2 * c], acc);
-                acc = dotp<CANON>(__builtin_amdgcn_perm(T23, T01, S.y), xw[2 * c + 1], acc);
+                if constexpr (CANON) { /* dwords 0, 1 -> the first half's chain pair; 2, 3 -> the second's */
+                    acc.s[d >> 1] = dotp<true>(__builtin_amdgcn_perm(T23, T01, S.x), xw[2 * c], acc.s[d >> 1]);
+                    acc.s[d >> 1] = dotp<true>(__builtin_amdgcn_perm(T23, T01, S.y), xw[2 * c + 1], acc.s[d >> 1]);
+                } else {
+                    acc = dotp<false>(__builtin_amdgcn_perm(T23, T01, S.x), xw[2 * c], acc);
+                    acc = dotp<false>(__builtin_amdgcn_perm(T23, T01, S.y), xw[2 * c + 1], acc);
+                }
             }
         }
         return acc;
@@ -437,6 +449,26 @@ struct BlockPrep<FMT_Q1T> {
             o[4 * c] = __builtin_amdgcn_perm(0u, ww, S.x), o[4 * c + 1] = __builtin_amdgcn_perm(0u, ww, S.y);
             o[4 * c + 2] = __builtin_amdgcn_perm(0u, ww, S.z), o[4 * c + 3] = __builtin_amdgcn_perm(0u, ww, S.w);
         }
+    }
+};
+// 2-bit the same way: one 32-element HALF of a 64-element block per lane (two dwords: w.y = elements 0 .. 15, element 0 in bits 31..30; w.x = elements 16 .. 31);
+// tab: the 256-entry table of BlockDot<FMT_Q2T> (a weight byte -> 2 selector dwords = 2 weight pairs out of the {T01, T23} pool)
+template <>
+struct BlockPrep<FMT_Q2T> {
+    __device__ static __forceinline__ void prep(u32x4 w, float step, float zero, float nb, int, uint32_t (&o)[16], const u32x4* tabv) {
+        uint32_t r = pack_bf16x2(fmaf(0.0f, step, nb), fmaf(1.0f, step, nb));
+        const uint32_t T01 = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
+        r = pack_bf16x2(fmaf(2.0f, step, nb), fmaf(3.0f, step, nb));
+        const uint32_t T23 = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
+        const u32x2* tab = reinterpret_cast<const u32x2*>(tabv);
+        const uint32_t dw[2] = {w.y, w.x};
+#pragma unroll
+        for (int d = 0; d < 2; d++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const u32x2 S = tab[(dw[d] >> (24 - 8 * c)) & 0xffu];
+                o[8 * d + 2 * c] = __builtin_amdgcn_perm(T23, T01, S.x), o[8 * d + 2 * c + 1] = __builtin_amdgcn_perm(T23, T01, S.y);
+            }
     }
 };
 template <bool CANON>

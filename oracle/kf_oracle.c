@@ -503,10 +503,11 @@ static float dot16(const float* w, const float* x, int n) {
  *         them (round 4; one before): e = fmaf(w[i], x[i], e) over the even-indexed elements of a block in index order, o = fmaf(w[i], x[i], o)
  *         over the odd-indexed ones -- the two halves of one v_pk_fma_f32 per weight pair on the GPU, half the dependent chain of the
  *         single-accumulator form -- and the lane's value is e + o;
- *       - 1-bit storage (EPB = 128; round 4): a block is cut into its four 32-element dwords and every dword position s = 0..3 keeps its OWN (e_s, o_s) pair through all of
- *         the lane's blocks; the lane's value is ((e0 + o0) + (e1 + o1)) + ((e2 + o2) + (e3 + o3)).  The four sub-chains are what four neighbouring hardware lanes compute
- *         side by side in the persistent engine (a quarter of the dependent chain each); the mat-vec kernel keeps them as four register pairs.  The lanes-per-row figure of
- *         such a row is the rule's value for K / 32 "virtual" blocks divided by four (kfo_lpr_log2_epb);
+ *       - 1-bit and 2-bit storage (EPB = 128 / 64; round 4): a block is cut into 32-element sub-blocks (the four dwords of a 1-bit block, the two dword pairs of a 2-bit
+ *         one) and every sub-block position s keeps its OWN (e_s, o_s) pair through all of the lane's blocks; the lane's value is ((e0 + o0) + (e1 + o1)) + ((e2 + o2) +
+ *         (e3 + o3)), resp. (e0 + o0) + (e1 + o1).  The sub-chains are what neighbouring hardware lanes compute side by side in the persistent engine (a fraction of the
+ *         dependent chain each); the mat-vec kernel keeps them as register pairs.  The lanes-per-row figure of such a row is the rule's value for K / 32 "virtual" blocks
+ *         divided by the sub-blocks per block (kfo_lpr_log2_epb);
  *       - the LPR lane values are added by a balanced binary tree (lanes 2j + 2j+1, then pairs of pairs, ...).
  *     lpr_log2 = kfo_lpr_log2(blocks per row, rows of the launch): the rule of kf::gemv_lpr_log2 (koifish_amd/csrc/kf_gemv.hip), restated.
  *     `rows` = the rows of ALL matrices a launch multiplies (Q | K | V together; gate alone for the paired gate / up launch).
@@ -536,14 +537,14 @@ static int epb_of_type(int type) { /* elements per 16-byte storage block; 0: the
 }
 /* lanes per row for a storage with `epb` elements per block: the rule itself, except for the 1-bit blocks (see above) */
 static int kfo_lpr_log2_epb(int epb, int K, long rows) {
-    if (epb == 128) {
-        const int l = kfo_lpr_log2(K / 32, rows) - 2;
+    if (epb == 128 || epb == 64) {
+        const int l = kfo_lpr_log2(K / 32, rows) - (epb == 128 ? 2 : 1);
         return l > 0 ? l : 0;
     }
     return kfo_lpr_log2(K / epb, rows);
 }
 static float dot_canon(const float* w, const float* x, int K, int epb, int lpr_log2) {
-    const int nBlk = K / epb, LPR = 1 << lpr_log2, ns = epb == 128 ? 4 : 1, sb = epb / ns; /* sub-chains per lane, elements per sub-block */
+    const int nBlk = K / epb, LPR = 1 << lpr_log2, ns = epb == 128 ? 4 : (epb == 64 ? 2 : 1), sb = epb / ns; /* sub-chains per lane, elements per sub-block */
     float lane[64];
     for (int l = 0; l < LPR; l++) {
         float e[4] = {0.f, 0.f, 0.f, 0.f}, o[4] = {0.f, 0.f, 0.f, 0.f}; /* the even / odd chains of this lane (every sub-block length is even) */
@@ -552,7 +553,7 @@ static float dot_canon(const float* w, const float* x, int K, int epb, int lpr_l
             for (int s = 0; s < ns; s++)
                 for (int i = s * sb; i < (s + 1) * sb; i += 2) e[s] = fmaf(wb[i], xb[i], e[s]), o[s] = fmaf(wb[i + 1], xb[i + 1], o[s]);
         }
-        lane[l] = ns == 1 ? e[0] + o[0] : ((e[0] + o[0]) + (e[1] + o[1])) + ((e[2] + o[2]) + (e[3] + o[3]));
+        lane[l] = ns == 1 ? e[0] + o[0] : (ns == 2 ? (e[0] + o[0]) + (e[1] + o[1]) : ((e[0] + o[0]) + (e[1] + o[1])) + ((e[2] + o[2]) + (e[3] + o[3])));
     }
     for (int s = 1; s < LPR; s <<= 1)
         for (int l = 0; l < LPR; l += 2 * s) lane[l] = lane[l] + lane[l + s];

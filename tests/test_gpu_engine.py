@@ -197,7 +197,7 @@ def test_engine_served_says_why_not():
     m.close()
     cfg = _cfg("small", 320)
     raw = synth.raw_weights_numpy(cfg, 5, w_std=0.1)
-    m = synth.build_from_raw(cfg, raw, L.T_SIGN, L.BF16)   # a storage the engine is not instantiated for
+    m = synth.build_from_raw(cfg, raw, L.F8E5M2, L.BF16)   # a storage the engine is not instantiated for
     assert "storage not served" in m.engine_why(), m.engine_why()
     m.close()
     m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)

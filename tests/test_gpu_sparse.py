@@ -132,10 +132,10 @@ def test_full_size_one_bit_sparse_step():
     m.close()
 
 
-@pytest.mark.parametrize("layer_type", [L.BOOL1, L.Q4])
+@pytest.mark.parametrize("layer_type", [L.BOOL1, L.T_SIGN, L.Q4])
 @pytest.mark.parametrize("hot_frac", [0.2, 1.0])
 def test_sparse_engine_equals_per_layer_launches_and_the_oracle_bit_for_bit(layer_type, hot_frac):
-    """The engine's sparse / 1-bit forms (round 4): 1-bit PackedQ layers through the LDS selector table inside the persistent launch, CS_Picker's hot[] as per-workgroup hot bits
+    """The engine's sparse / 1-bit / 2-bit forms (round 4): 1-bit and ternary PackedQ layers through the LDS selector tables inside the persistent launch, CS_Picker's hot[] as per-workgroup hot bits
     (cold gate / up rows never read, zeros published by the owning workgroup -- no cold-fill launch).  Canonical order, teacher-forced steps across the single- and multi-slice
     attention forms: logits, ids and K / V rows equal the per-layer masked launches' AND the oracle's sparse forward, bit for bit."""
     cfg = dict(synth.CONFIGS["small"], max_seq=320)
