@@ -84,6 +84,7 @@ def load():
         hip.kf_gelu.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         hip.kf_embed_batch.argtypes = [C.c_void_p, C.POINTER(Weight), C.c_void_p, C.c_int, C.c_void_p]
         hip.kf_qknorm_rope_batch.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float]
+        hip.kf_qkv_rope_batch.argtypes = [C.c_void_p] * 8 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]
         hip.kf_attn_prefill.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]
         hip.kf_norm_linear.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         hip.kf_norm_gateup_swiglu.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.POINTER(Weight), C.POINTER(Weight), C.c_void_p]

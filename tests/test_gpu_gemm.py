@@ -229,3 +229,46 @@ def test_training_size_batch_of_a_quantised_weight_takes_the_dequantise_then_til
     assert np.abs(a - b).max() <= 2.0 ** -7 * np.abs(a).max() and (a != b).mean() < 0.2
     L.check(ctx.hip.kf_set_scratch(ctx.h, None, 0), "kf_set_scratch")
     ctx._lin_ws = None
+
+
+@pytest.mark.parametrize("nt", [1100, 2047])
+def test_fused_qkv_rope_epilogue_equals_the_two_launch_route(ctx, O, nt):
+    """kf_qkv_rope_batch at >= 1024 tokens: Q | K | V stacked in ONE tile-GEMM launch with q/k-norm + RoPE in its epilogue (a 128-row tile is one head: the token's 128
+    squares meet through row swaps and LDS, a rotation pair's other element sits in the other wave at the same lane) against kf_linear_multi + kf_qknorm_rope_batch:
+    same tile kernel, same prep_head_cs arithmetic -- every bit of q, k (rotated) and v equal; plus the exact fp64 reference within the batch-GEMM tolerance."""
+    k, hd, n_head, n_kv, pos0, eps = 1024, 128, 16, 8, 3, 1e-6
+    rng = np.random.default_rng(nt)
+    x = O.f32_to_bf16(rng.normal(0, 1.0, size=(nt, k)).astype(np.float32))
+    xd = bf16_t(x, ctx.device)
+    ms = (n_head * hd, n_kv * hd, n_kv * hd)
+    ows = [O.quantize(O.f32_to_bf16(rng.normal(0, 0.03, size=(m, k)).astype(np.float32)), m, k, L.Q4) for m in ms]
+    dws = [ctx.upload_blob(L.Q4, m, k, ow.blob()) for m, ow in zip(ms, ows)]
+    descs = [d.desc() for d in dws]
+    wp = (C.c_void_p * 3)(*[C.addressof(d) for d in descs])
+    need = ctx.hip.kf_linear_multi_scratch_bytes(3, wp, nt)
+    assert need > 0
+    ctx.sync()
+    ctx._lin_ws = torch.empty(need, dtype=torch.uint8, device=ctx.device)
+    L.check(ctx.hip.kf_set_scratch(ctx.h, C.c_void_p(ctx._lin_ws.data_ptr()), C.c_size_t(ctx._lin_ws.numel())), "kf_set_scratch")
+    wq = bf16_t(O.f32_to_bf16((1 + rng.normal(0, 0.1, size=hd)).astype(np.float32)), ctx.device)
+    wk = bf16_t(O.f32_to_bf16((1 + rng.normal(0, 0.1, size=hd)).astype(np.float32)), ctx.device)
+    table = ctx.rope_table(pos0 + nt + 1, hd, 1e6)
+    outs = {}
+    for fused in (True, False):
+        ys = [torch.full((nt, m), 7.0, dtype=torch.bfloat16, device=ctx.device) for m in ms]
+        if fused:
+            L.check(ctx.hip.kf_qkv_rope_batch(ctx.h, C.byref(descs[0]), C.byref(descs[1]), C.byref(descs[2]), xd.data_ptr(), ys[0].data_ptr(), ys[1].data_ptr(), ys[2].data_ptr(), nt,
+                                              wq.data_ptr(), wk.data_ptr(), table.data_ptr(), pos0, n_head, n_kv, hd, eps), "kf_qkv_rope_batch")
+        else:
+            yp = (C.c_void_p * 3)(*[y.data_ptr() for y in ys])
+            L.check(ctx.hip.kf_linear_multi(ctx.h, 3, wp, xd.data_ptr(), yp, nt), "kf_linear_multi")
+            L.check(ctx.hip.kf_qknorm_rope_batch(ctx.h, ys[0].data_ptr(), ys[1].data_ptr(), wq.data_ptr(), wk.data_ptr(), table.data_ptr(), pos0, nt, ms[0], ms[1], n_head, n_kv, hd, eps),
+                    "kf_qknorm_rope_batch")
+        ctx.sync()
+        outs[fused] = [u16(y).copy() for y in ys]
+    for a, b, name in zip(outs[True], outs[False], "qkv"):
+        assert np.array_equal(a, b), "%s: %d of %d values differ between the fused epilogue and the two-launch route" % (name, int((a != b).sum()), a.size)
+    f = lambda a: O.bf16_to_f32(a).astype(np.float64)
+    v_ref = f(x) @ f(O.dequant(ows[2])).reshape(ms[2], k).T
+    assert np.abs(f(outs[True][2]) - v_ref).max() <= 2.0 ** -7 * np.abs(v_ref).max()
+    assert np.abs(f(outs[True][0])).max() > 0.1   # q really went through the norm (values of order one)
