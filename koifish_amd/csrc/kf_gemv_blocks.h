@@ -322,14 +322,15 @@ struct BlockDot<FMT_Q2T, CANON> {
 // assembles {0, 0, low byte, high byte} with one v_perm_b32), so neither operand is unpacked from a bf16 pair per product.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x2_t perm_fma_dword(uint32_t D, f32x4 X0, f32x4 X1, const PermLut& t, f32x2_t acc) {
-    const uint32_t even = D >> 4; /* bytes 3..0: elements 0,2,4,6 in the low nibbles; D itself: 1,3,5,7 */
-    uint32_t lo, hi;
-    perm_lookup4(__builtin_amdgcn_perm(even, D, 0x02060307u), t, lo, hi); /* bytes 0..3 = elements 0, 1, 2, 3 */
-    acc = pk_fma(f32x2_t{__uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x04000c0cu)), __uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x05010c0cu))}, f32x2_t{X0.x, X0.y}, acc);
-    acc = pk_fma(f32x2_t{__uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x06020c0cu)), __uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x07030c0cu))}, f32x2_t{X0.z, X0.w}, acc);
-    perm_lookup4(__builtin_amdgcn_perm(even, D, 0x00040105u), t, lo, hi); /* elements 4, 5, 6, 7 */
-    acc = pk_fma(f32x2_t{__uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x04000c0cu)), __uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x05010c0cu))}, f32x2_t{X1.x, X1.y}, acc);
-    acc = pk_fma(f32x2_t{__uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x06020c0cu)), __uint_as_float(__builtin_amdgcn_perm(hi, lo, 0x07030c0cu))}, f32x2_t{X1.z, X1.w}, acc);
+    // the even-indexed elements (low nibbles of D >> 4, element 0 in byte 3) and the odd-indexed ones (low nibbles of D) are looked up as they lie: a pair's two fp32
+    // operands come from the two lookups at the same byte position, so the index bytes need no gather (round 3 gathered elements 0..3 / 4..7 first: 2 perms more per dword)
+    uint32_t le, he, lo, ho;
+    perm_lookup4(D >> 4, t, le, he);
+    perm_lookup4(D, t, lo, ho);
+    acc = pk_fma(f32x2_t{__uint_as_float(__builtin_amdgcn_perm(he, le, 0x07030c0cu)), __uint_as_float(__builtin_amdgcn_perm(ho, lo, 0x07030c0cu))}, f32x2_t{X0.x, X0.y}, acc); /* elements 0, 1 */
+    acc = pk_fma(f32x2_t{__uint_as_float(__builtin_amdgcn_perm(he, le, 0x06020c0cu)), __uint_as_float(__builtin_amdgcn_perm(ho, lo, 0x06020c0cu))}, f32x2_t{X0.z, X0.w}, acc); /* 2, 3 */
+    acc = pk_fma(f32x2_t{__uint_as_float(__builtin_amdgcn_perm(he, le, 0x05010c0cu)), __uint_as_float(__builtin_amdgcn_perm(ho, lo, 0x05010c0cu))}, f32x2_t{X1.x, X1.y}, acc); /* 4, 5 */
+    acc = pk_fma(f32x2_t{__uint_as_float(__builtin_amdgcn_perm(he, le, 0x04000c0cu)), __uint_as_float(__builtin_amdgcn_perm(ho, lo, 0x04000c0cu))}, f32x2_t{X1.z, X1.w}, acc); /* 6, 7 */
     return acc;
 }
 // arithmetic form: w = bf16(bf16(step * (q - qBias)) - zero) per nibble, as dot_q4_dword forms it, kept as fp32
