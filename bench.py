@@ -136,6 +136,13 @@ def main():
     # lay the timed window at the end of the sequence: [setup | warmup W | timed K] ends at position S-1
     span = (W + K) % S if (W + K) % S else min(W + K, S)
     start = (S - span) % S
+    # one-time set-up of every position bucket the timed window enters AFTER its first step (the host tunes the engine's hand-off delays -- ~0.2 s of launches -- and captures
+    # graphs at the first multi-step launch inside a bucket; the warm-up covers the bucket it ends in): a few steps at each such boundary now, on a cache of zeros
+    first_timed = (start + W) % S
+    for b in (64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768):
+        if b < S - 16 and any((first_timed + i) % S == b for i in range(K)):
+            m.set_state(int(forced[0]), b)
+            m.run_steps(b, 16, use_graph)
     m.set_state(int(forced[0]), 0)
     pos = run_span(0, start) if start else 0
     pos = run_span(pos, W)
@@ -638,8 +645,11 @@ def prefill_rate(m, prompt, decode_ms_per_step, reps=5, bound=None):
     head + pick of the first generated token.  The reference prefills token by token through the decode path (GoPT.cpp:1139-1146),
     which here costs one decode step per prompt token."""
     import time
-    m.prefill(prompt, want_logits=False)
     m.sync()
+    t0 = time.perf_counter()
+    m.prefill(prompt, want_logits=False)  # the warm-up; the first prompt of >= 1024 tokens also fills the resident bf16 copies (kf_set_dequant_arena), reported as first_call_ms
+    m.sync()
+    first_ms = (time.perf_counter() - t0) * 1e3
     t0 = time.perf_counter()
     for _ in range(reps):
         m.prefill(prompt, want_logits=False)
@@ -655,7 +665,8 @@ def prefill_rate(m, prompt, decode_ms_per_step, reps=5, bound=None):
     nbytes = sum(w.algorithmic_bytes() for (layer, slot), w in m.weights.items() if layer >= 0) + m.weights[(-1, 1)].algorithmic_bytes() + n * cfg["dim"] * 2 \
         + cfg["n_layer"] * n * kvd * 2 * 2 * 2
     tf, gbs = flops / (ms * 1e-3) / 1e12, nbytes / (ms * 1e-3) / 1e9
-    return {"prompt_tokens": n, "ms": round(ms, 3), "tokens_per_s": round(n / ms * 1e3, 1), "mode": "token batches: < 1024 rows MFMA 32x32x16 bf16 on 4-bit tiles unpacked in registers; >= 1024 rows Q|K|V and gate|up dequantised once + the 256x256 / 128x128 bf16 tile kernel (MFMA 16x16x32); flash attention tile",
+    return {"prompt_tokens": n, "ms": round(ms, 3), "tokens_per_s": round(n / ms * 1e3, 1), "mode": "token batches: < 1024 rows MFMA 32x32x16 bf16 on 4-bit tiles unpacked in registers; >= 1024 rows the 256x256 / 128x128 bf16 tile kernels (MFMA 16x16x32; SwiGLU and q/k-norm + RoPE in their epilogues) on RESIDENT bf16 copies of the layer matrices (dequantised by the first such prompt, kept in HBM); flash attention tile",
+            "first_call_ms": round(first_ms, 3), "resident_copy_bytes": m.resident_bytes(),
             "token_serial_ms": round(decode_ms_per_step * n, 3),
             "roofline": {"flops": int(flops), "bytes": int(nbytes), "achieved_TFLOPs": round(tf, 2), "mfma_peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS, "mfma_frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
                          "achieved_GBs": round(gbs, 1), "hbm_peak_GBs": HBM_PEAK_GBS, "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),

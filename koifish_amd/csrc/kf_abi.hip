@@ -23,7 +23,18 @@ struct kf_ctx {
     int canonical;    /* 1: the decode kernels sum in the canonical order of oracle/kf_oracle.c sections 4c / 6 (bit-exact against the oracle; the default); 0: v_dot2c / fp32 forms */
     void* scratch;    /* caller-owned workspace of kf_linear (kf_set_scratch): AWQ slice partials, or a weight dequantised to bf16 */
     size_t scratch_bytes;
+    // resident GetDataX copies for token batches (kf_set_dequant_arena): caller-owned memory, filled on first use, keyed by the data pointers of the matrices a route
+    // multiplies in one launch and the form they are laid out in (DEQ_STACK: back to back; DEQ_ILV: gate | up interleaved in blocks of 16 rows)
+    struct DeqCopy {
+        const void* key[3];
+        int form;
+        size_t off;
+    };
+    void* arena;
+    size_t arena_bytes, arena_used;
+    std::vector<DeqCopy> copies;
 };
+enum { DEQ_STACK = 0, DEQ_ILV = 1 };
 struct kf_graph {
     hipGraph_t graph;
     hipGraphExec_t exec;
@@ -77,6 +88,7 @@ int kf_init(int device, void* stream, kf_ctx** out) {
     HIPCHK(hipMalloc(&c->amax_val, sizeof(float) * kf::KF_MAX_ARGMAX_PARTIALS));
     HIPCHK(hipMalloc(&c->amax_idx, sizeof(int) * kf::KF_MAX_ARGMAX_PARTIALS));
     c->scratch = nullptr, c->scratch_bytes = 0;
+    c->arena = nullptr, c->arena_bytes = c->arena_used = 0;
     c->canonical = 1;
     *out = c;
     return KF_OK;
@@ -93,6 +105,44 @@ static int lib_weight_bf16(kf_ctx* c, const kf_weight* w, const uint16_t** out) 
     const int r = kf::dequant_launch(c->stream, w, (uint16_t*)c->scratch);
     *out = (const uint16_t*)c->scratch;
     return r;
+}
+static size_t up256z(size_t v) { return (v + 255) & ~(size_t)255; }
+// The bf16 copies of n_w group-quantised matrices of one input width, laid out as `form` says: from the arena when the caller lent one (dequantised on first use and
+// kept), otherwise dequantised into the scratch for this call.  KF_OK: *out holds them; 1: no room in either; < 0 error.
+static int deq_copies(kf_ctx* c, int n_w, const kf_weight* const* w, int form, const uint16_t** out, bool* resident = nullptr, bool arena_only = false) {
+    size_t need = 0;
+    for (int i = 0; i < n_w; i++) need += up256z((size_t)w[i]->ne0 * w[i]->ne1 * 2);
+    if (resident) *resident = false;
+    if (c->arena) {
+        for (const kf_ctx::DeqCopy& e : c->copies) {
+            bool same = e.form == form;
+            for (int i = 0; i < 3; i++) same = same && e.key[i] == (i < n_w ? w[i]->data : nullptr);
+            if (same) {
+                *out = (const uint16_t*)((const char*)c->arena + e.off);
+                if (resident) *resident = true;
+                return KF_OK;
+            }
+        }
+    }
+    const bool keep = c->arena && !c->capturing && c->arena_used + need <= c->arena_bytes; /* a captured launch would replay the fill with every replay: those use the scratch */
+    char* dst = keep ? (char*)c->arena + c->arena_used : (char*)c->scratch;
+    if (!keep && (arena_only || !c->scratch || c->scratch_bytes < need)) return 1;
+    size_t off = 0;
+    for (int i = 0; i < n_w; i++) {
+        const int r = form == DEQ_ILV ? kf::dequant_launch(c->stream, w[i], (uint16_t*)dst, n_w, i) : kf::dequant_launch(c->stream, w[i], (uint16_t*)(dst + off));
+        if (r != KF_OK) return r < 0 ? r : KF_HIP_CHECK;
+        off += up256z((size_t)w[i]->ne0 * w[i]->ne1 * 2);
+    }
+    if (keep) {
+        kf_ctx::DeqCopy e;
+        for (int i = 0; i < 3; i++) e.key[i] = i < n_w ? w[i]->data : nullptr;
+        e.form = form, e.off = c->arena_used;
+        c->copies.push_back(e);
+        c->arena_used += need;
+        if (resident) *resident = true;
+    }
+    *out = (const uint16_t*)dst;
+    return KF_OK;
 }
 
 int kf_destroy(kf_ctx* c) {
@@ -258,6 +308,7 @@ int kf_quantize(kf_ctx* c, const kf_weight* w, const kf_bf16* src, int symmetric
 
 static void init_args(kf_ctx* c, kf::GemvLaunch& L) { memset(&L, 0, sizeof(L)); L.args.alpha = 1.0f; L.canon = c->canonical; }
 
+static const int KF_RESIDENT_GEMM_MIN = 1024; /* token rows from which kf_linear multiplies a RESIDENT dequantised copy (kf_set_dequant_arena) by the bf16 tile kernels */
 static const int KF_DEQ_GEMM_MIN = 2048; /* token rows from which a quantised weight is dequantised once and multiplied by the bf16 tile kernel (when scratch was handed over) */
 size_t kf_linear_scratch_bytes(const kf_weight* w, int nTok) {
     if (!w || nTok < 1) return 0;
@@ -274,6 +325,15 @@ int kf_set_canonical(kf_ctx* c, int on) {
     return KF_OK;
 }
 int kf_get_canonical(kf_ctx* c) { return c ? c->canonical : 0; }
+int kf_set_dequant_arena(kf_ctx* c, void* arena, size_t bytes) {
+    CHKCTX(c);
+    if (arena && !al16(arena)) return fail(KF_BLAS_UNALIGN, "kf_set_dequant_arena: unaligned");
+    if (c->capturing) return fail(KF_INVALID_ARGS, "kf_set_dequant_arena: not while capturing");
+    c->arena = arena, c->arena_bytes = arena ? bytes : 0, c->arena_used = 0;
+    c->copies.clear();
+    return KF_OK;
+}
+size_t kf_dequant_arena_used(kf_ctx* c) { return c ? c->arena_used : 0; }
 int kf_set_scratch(kf_ctx* c, void* scratch, size_t bytes) {
     CHKCTX(c);
     if (scratch && !al16(scratch)) return fail(KF_BLAS_UNALIGN, "kf_set_scratch: unaligned");
@@ -314,6 +374,22 @@ int kf_linear(kf_ctx* c, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const
         memset(&wb, 0, sizeof(wb));
         wb.data = Wd, wb.type = KF_BF16, wb.ne0 = w->ne0, wb.ne1 = w->ne1;
         return kf_linear(c, &wb, x, y, bias, nTok, alpha, beta, epilogue, residual);
+    }
+    if (c->arena && nTok >= KF_RESIDENT_GEMM_MIN && w->type != KF_BF16 && w->quant == KF_QUANT_GROUP && w->ne0 >= 128 && (w->ne1 % 64) == 0) {
+        // a resident copy (kf_set_dequant_arena): nothing to dequantise -- the bf16 tile kernels of kf_gemm3.hip from 1024 token rows (the 1024-row o_proj / down_proj of a
+        // long prompt as 256 tiles of 64 x 128 or 64 x 64)
+        const kf_weight* one[1] = {w};
+        const uint16_t* W = nullptr;
+        r = deq_copies(c, 1, one, DEQ_STACK, &W, nullptr, true);
+        if (r < 0) return fail(r, "kf_linear (resident dequantised copy) failed with %d", r);
+        if (r == KF_OK) {
+            kf_weight wb;
+            memset(&wb, 0, sizeof(wb));
+            wb.data = W, wb.type = KF_BF16, wb.ne0 = w->ne0, wb.ne1 = w->ne1;
+            const int rc = kf::gemm_launch(c->stream, &wb, x, w->ne1, nTok, y, w->ne0, bias, alpha, beta, (epilogue & KF_EPI_RESIDUAL) ? residual : nullptr, w->ne0);
+            if (rc < 0) return fail(rc, "kf_linear (bf16 tile GEMM on the resident copy) failed with %d", rc);
+            if (rc == KF_OK) return KF_OK;
+        }
     }
     if (nTok >= KF_DEQ_GEMM_MIN && w->type != KF_BF16 && w->quant == KF_QUANT_GROUP && w->ne0 >= 256 && (w->ne1 % 64) == 0 && c->scratch &&
         c->scratch_bytes >= (size_t)w->ne0 * w->ne1 * 2 &&
@@ -658,7 +734,7 @@ int kf_embed_batch(kf_ctx* c, const kf_weight* w, const int32_t* d_tokens, int n
 // 256 x 256 bf16 tile kernel over the stacked rows (each matrix a multiple of 256 rows; its rows go to its own output).  A 1024-row K or V projection alone is 4 x 8
 // tiles at 2048 tokens -- an eighth of the chip -- and took 32 us on the in-register-unpack kernels; stacked with Q it is 128 tiles.
 static const int KF_MULTI_DEQ_MIN = 1024; /* token rows from which the stacked route is taken */
-static size_t up256z(size_t v) { return (v + 255) & ~(size_t)255; } /* a no-op on these sizes (multiples of 256 rows x 64 columns): the stacked rows are contiguous */
+/* up256z: a no-op on these sizes (multiples of 256 rows x 64 columns): the stacked rows are contiguous */
 static bool multi_deq_ok(int n_w, const kf_weight* const* w, int nTok, size_t* need) {
     size_t tot = 0;
     long rows = 0;
@@ -681,15 +757,13 @@ size_t kf_linear_multi_scratch_bytes(int n_w, const kf_weight* const* w, int nTo
 // KF_OK done, 1 not this route, < 0 error
 static int multi_deq_route(kf_ctx* c, int n_w, const kf_weight* const* w, const kf_bf16* x, kf_bf16* const* y, int nTok, const kf::G3Rope* rope = nullptr) {
     size_t need = 0;
-    if (!multi_deq_ok(n_w, w, nTok, &need) || !c->scratch || c->scratch_bytes < need || !al16(x)) return 1;
+    if (!multi_deq_ok(n_w, w, nTok, &need) || !al16(x)) return 1;
     int M[3] = {0, 0, 0};
-    size_t off = 0;
-    for (int i = 0; i < n_w; i++) {
-        const int r = kf::dequant_launch(c->stream, w[i], (uint16_t*)((char*)c->scratch + off));
-        if (r != KF_OK) return r < 0 ? r : KF_HIP_CHECK;
-        M[i] = w[i]->ne0, off += up256z((size_t)w[i]->ne0 * w[i]->ne1 * 2);
-    }
-    return kf::gemm3_multi_launch(c->stream, n_w, (const uint16_t*)c->scratch, M, w[0]->ne1, x, w[0]->ne1, nTok, y, rope);
+    for (int i = 0; i < n_w; i++) M[i] = w[i]->ne0;
+    const uint16_t* W = nullptr;
+    const int r = deq_copies(c, n_w, w, DEQ_STACK, &W);
+    if (r != KF_OK) return r;
+    return kf::gemm3_multi_launch(c->stream, n_w, W, M, w[0]->ne1, x, w[0]->ne1, nTok, y, rope);
 }
 int kf_qkv_rope_batch(kf_ctx* c, const kf_weight* wq, const kf_weight* wk, const kf_weight* wv, const kf_bf16* x, kf_bf16* q, kf_bf16* k, kf_bf16* v, int nTok, const kf_bf16* wq_norm,
                       const kf_bf16* wk_norm, const float* rope_table, int pos0, int n_head, int n_kv, int hd, float eps) {
@@ -748,9 +822,9 @@ int kf_gateup_swiglu_batch(kf_ctx* c, const kf_weight* gate, const kf_weight* up
                                        as the paired kernel and swiglu_kernel form it) */
         const kf_weight* ws[2] = {gate, up};
         size_t need = 0;
-        if (multi_deq_ok(2, ws, nTok, &need) && c->scratch && c->scratch_bytes >= need && al16(x) && gate->ne0 % 128 == 0 &&
-            kf::dequant_launch(c->stream, gate, (uint16_t*)c->scratch, 2, 0) == KF_OK && kf::dequant_launch(c->stream, up, (uint16_t*)c->scratch, 2, 1) == KF_OK) {
-            const int rc = kf::gemm3_swiglu_launch(c->stream, (const uint16_t*)c->scratch, gate->ne0, gate->ne1, x, gate->ne1, nTok, act);
+        const uint16_t* W = nullptr;
+        if (multi_deq_ok(2, ws, nTok, &need) && al16(x) && gate->ne0 % 128 == 0 && deq_copies(c, 2, ws, DEQ_ILV, &W) == KF_OK) {
+            const int rc = kf::gemm3_swiglu_launch(c->stream, W, gate->ne0, gate->ne1, x, gate->ne1, nTok, act);
             if (rc < 0) return fail(rc, "kf_gateup_swiglu_batch (interleaved dequantise + tile GEMM with SwiGLU epilogue) failed with %d", rc);
             if (rc == KF_OK) return KF_OK;
         }
@@ -1145,6 +1219,8 @@ int kfdbg_set_knob(const char* name, long value) {
     else if (!strcmp(name, "gemv_waves")) k.gemv_waves = value;
     else if (!strcmp(name, "gemv_stream")) k.gemv_stream = (int)value;
     else if (!strcmp(name, "gemm_min")) k.gemm_min = (int)value;
+    else if (!strcmp(name, "g3_tiles")) k.g3_tiles = (int)value;
+    else if (!strcmp(name, "g3_first")) k.g3_first = (int)value;
     else return -1;
     return 0;
 }

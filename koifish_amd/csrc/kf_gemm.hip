@@ -621,6 +621,12 @@ int gemm_launch(hipStream_t st, const kf_weight* w, const uint16_t* x, long long
     constexpr int direct_max = 1280;
     int KS = ((long)((M + 127) / 128) * ttiles < 512) ? 2 : 1;
     dim3 grid;
+    // bf16 operands (weights stored as bf16, or the resident dequantised copies of a long prompt): the global_load_lds tile kernels first from g3_first token rows --
+    // the crossover above was measured on the 4-bit in-register unpack; on bf16 the direct kernel took 64 us for 1024 x 2048 at 1024 rows
+    if (g.fmt == FMT_BF16 && n >= g_knobs.g3_first) {
+        const int rc3 = gemm3_launch(st, g.fmt, a);
+        if (rc3 != 1) return rc3;
+    }
     if ((long)((M + 31) / 32) * ((n + 31) / 32) <= direct_max) {
         KS = 0;
         grid = dim3((M + 31) / 32, (n + 31) / 32);

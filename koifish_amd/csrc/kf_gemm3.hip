@@ -19,6 +19,8 @@
 
 #include <type_traits>
 
+#include <mutex>
+
 #include "kf_gemm_common.h"
 
 namespace kf {
@@ -35,6 +37,10 @@ struct G3Cfg {
 };
 using G3Big = G3Cfg<256, 256, 8>;
 using G3Small = G3Cfg<128, 128, 4>;
+// round 4: products whose 128 x 128 tiles do not fill the chip either (M = 1024 at 1-2 k tokens: 64-128 of them; split-K S = 4 measured 37.8 us against 27 plain: three
+// 64 KiB partials per tile through memory) get MORE, SMALLER tiles instead of k-pieces: 64 x 128 (48 KiB of LDS: three workgroups per CU) and 64 x 64 (32 KiB: five)
+using G3Mid = G3Cfg<64, 128, 4>;
+using G3Tiny = G3Cfg<64, 64, 4>;
 
 // one operand tile (256 rows x 2 BK bytes) = BK / 2 wave instructions of 1 KiB; wave `wid` issues BK / 16 of them.  BK = 64: 8 rows per instruction, chunk c of row r
 // at position c ^ ((r >> 1) & 7); BK = 32: 16 rows per instruction (64-byte rows), chunk c at position c ^ ((r >> 2) & 3) -- either way a fragment read
@@ -337,6 +343,8 @@ __global__ void __launch_bounds__(C::NTH, C::WGS_PER_CU * C::NW / 4) gemm3_kerne
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int nbx = (a.M + C::BM - 1) / C::BM, nby = (a.n + C::BN - 1) / C::BN, nwg = nbx * nby;
     const int wg = g3_remap(blockIdx.x, nwg);
+    // (round 4: the other orientation -- row tiles slow, so that an XCD's L2 fetches all of x and an eighth of W when W is the larger operand -- measured on the 2047-token
+    // prompt: gate | up 41.5 us either way, Q | K | V 34.1 vs 32.5: not the fabric traffic that bounds these launches)
     const int bx = wg % nbx, by = wg / nbx;
     const int m0 = bx * C::BM, t0 = by * C::BN;
     f32x4 acc[C::MT][C::NT];
@@ -356,12 +364,13 @@ __global__ void __launch_bounds__(C::NTH, C::WGS_PER_CU * C::NW / 4) gemm3_kerne
 //                          laid end to end, into equal ranges (a helper's range covers pieces of 2 .. 5 tiles; neighbours start a few steps apart).  Owners and
 //                          helpers finish together.
 // A non-owner leaves each fp32 partial in a slot of `ws` with write-through stores and raises the slot's flag; the owner adds its tile's partials in slot order -- a
-// fixed order: the result does not depend on timing -- and runs the epilogue.  flags are zeroed by the host before the launch; only owners wait, for pieces that
+// fixed order: the result does not depend on timing -- and runs the epilogue.  a raised flag holds the launch's own value (g3_sk_epoch below: no clearing between launches); only owners wait, for pieces that
 // were dispatched before them and wait for nobody.
 struct G3SkArgs {
     float* ws;       /* [<= 256][256 * 256] */
     uint32_t* flags; /* [<= 256] */
     int P, S, kp, R;
+    uint32_t epoch; /* the value a raised flag holds in THIS launch (g3_sk_epoch): no memset between launches */
 };
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t g3_rsrc(const void* p, uint32_t bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000); }
 template <class C>
@@ -375,13 +384,13 @@ __device__ __forceinline__ void g3_publish(const G3SkArgs& s, int slot, const f3
     // measured 37 vs 27 us on a 128-tile product.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __builtin_amdgcn_raw_buffer_store_b32(1u, g3_rsrc(s.flags + slot, 4), 0, 0, 16 /* sc1 */);
+    if (tid == 0) __builtin_amdgcn_raw_buffer_store_b32(s.epoch, g3_rsrc(s.flags + slot, 4), 0, 0, 16 /* sc1 */);
 }
 template <class C>
 __device__ __forceinline__ void g3_collect(const G3SkArgs& s, int slot, f32x4 (&acc)[C::MT][C::NT], int tid) {
     if (tid == 0) {
         for (int spins = 0; spins < (1 << 24); spins++) {
-            if (__builtin_amdgcn_raw_buffer_load_b32(g3_rsrc(s.flags + slot, 4), 0, 0, 16 /* sc1 */)) break; /* the partial is read with sc1 loads too: nothing cached to invalidate */
+            if (__builtin_amdgcn_raw_buffer_load_b32(g3_rsrc(s.flags + slot, 4), 0, 0, 16 /* sc1 */) == s.epoch) break; /* the partial is read with sc1 loads too: nothing cached to invalidate */
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_sleep(4);
         }
@@ -449,6 +458,34 @@ __global__ void __launch_bounds__(C::NTH, C::WGS_PER_CU * C::NW / 4) gemm3_sk_ke
     }
 }
 
+// The flag value of one split-K launch.  Launches outside a capture take a fresh value each (a process-wide counter from 2 up), so the flags of the launch before need
+// no clearing -- the memset was a dependent 2-3 us node in front of every such product; a flag area seen for the first time is cleared once.  A launch that is being
+// CAPTURED is replayed with the arguments it was recorded with: it keeps the clearing node and the value 1.
+static std::mutex g_sk_mu;
+static uint32_t g_sk_epoch = 1;
+static const void* g_sk_seen[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+static int g3_sk_epoch(hipStream_t st, uint32_t* flags, int n, uint32_t* epoch) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) return KF_HIP_CHECK;
+    std::lock_guard<std::mutex> lk(g_sk_mu);
+    bool seen = false;
+    for (int i = 0; i < 8; i++) seen = seen || g_sk_seen[i] == flags;
+    if (cs != hipStreamCaptureStatusNone || !seen) {
+        if (hipMemsetAsync(flags, 0, n * sizeof(uint32_t), st) != hipSuccess) return KF_HIP_CHECK;
+    }
+    if (cs != hipStreamCaptureStatusNone) {
+        *epoch = 1;
+        return KF_OK;
+    }
+    if (!seen) {
+        static int next = 0;
+        g_sk_seen[next] = flags, next = (next + 1) & 7;
+    }
+    if (++g_sk_epoch < 2) g_sk_epoch = 2;
+    *epoch = g_sk_epoch;
+    return KF_OK;
+}
+
 // KF_OK launched, 1 = not for this kernel (the caller's other tile kernels take the shape), < 0 error.  bf16 "weights" only: quantised ones are dequantised first.
 // BK = 32 (4 LDS buffers, three steps in flight) was measured 8-10 % slower than BK = 64 (2 buffers) on every shape, forward and backward: the per-step costs
 // (barrier, counted wait, loop) double, and the loop is not waiting for memory.  Only BK = 64 is instantiated.
@@ -479,7 +516,7 @@ static int g3_go_c(hipStream_t st, const GemmArgs& a, long nwg, void* ws, size_t
             if (nkt - s.kp < 1 || nkt < 4 * min_steps || T * 2 >= (1LL << 31)) s.S = 0;
         }
         if (s.S >= 1 && (s.S >= 2 || s.kp > 0)) {
-            if (hipMemsetAsync(s.flags, 0, G * sizeof(uint32_t), st) != hipSuccess) return KF_HIP_CHECK;
+            if (g3_sk_epoch(st, s.flags, G, &s.epoch) != KF_OK) return KF_HIP_CHECK;
             hipLaunchKernelGGL((gemm3_sk_kernel<AKM, BKM, BK, C>), dim3(nlaunch), dim3(C::NTH), SMEM, st, a, s);
             return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
         }
@@ -507,6 +544,11 @@ int gemm3_launch(hipStream_t st, int fmt, const GemmArgs& a, void* ws, size_t ws
     if (a.n < 128 || a.M < 128) return 1;
     const long nwg = (long)((a.M + 127) / 128) * ((a.n + 127) / 128);
     if (nwg < 32) return 1;
+    if (nwg < 256 && g_knobs.g3_tiles >= 1 && !a.swiglu && !a.qkrope) { /* fewer 128 x 128 tiles than CUs: twice or four times as many smaller ones, no k-pieces */
+        const long nmid = (long)((a.M + 63) / 64) * ((a.n + 127) / 128);
+        if (nmid >= 192 || g_knobs.g3_tiles < 3) return nmid >= 64 ? g3_go_c<false, false, G3Mid>(st, a, nmid, nullptr, 0, 64) : 1;
+        return g3_go_c<false, false, G3Tiny>(st, a, (long)((a.M + 63) / 64) * ((a.n + 63) / 64), nullptr, 0, 64);
+    }
     return g3_go_c<false, false, G3Small>(st, a, nwg, ws, ws_bytes, 128);
 }
 // y[n, M] = alpha * sum_k B(k, tok) A(k, m) + beta * y (+ bias) with either operand stored K-MAJOR: akm: A = w[K][lda] (element (k, m) at k * lda + m), else w[M][K];

@@ -143,6 +143,8 @@ struct EngineHost;
 struct Knobs {
     int q4_perm = 1;      /* 4-bit mat-vec through the register-table lookup (0: the arithmetic form; same bits) */
     int q2_tab = 1;       /* 2-bit mat-vec through the LDS selector table (0: the arithmetic form; same bits) */
+    int g3_tiles = 3;     /* smallest bf16 tile gemm3_launch may pick: 0 = 128 x 128 only (round 3), 1 = + 64 x 128, 3 = + 64 x 64 (kf_gemm3.hip) */
+    int g3_first = 512;   /* token rows from which bf16 operands try the kf_gemm3.hip tile kernels before the 32 x 32 direct kernel */
     int q1_tab = 1;       /* 1-bit mat-vec through the LDS selector table (0: the per-bit select form; same bits) */
     long gemv_waves = 0;  /* > 0: waves a mat-vec launch aims for (0: the launcher's rule) */
     int gemv_stream = 1;  /* buffer-load form of the long mat-vec launches (0: off) */

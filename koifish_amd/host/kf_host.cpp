@@ -217,6 +217,7 @@ Fish::~Fish() {
         if (tp.area) kf_free(ctx, tp.area);
     }
     if (ctx && lin_scratch) kf_free(ctx, lin_scratch);
+    if (ctx && deq_arena) kf_free(ctx, deq_arena);
     if (engine) kf_engine_destroy(engine);
     if (ctx && engine_ws) kf_free(ctx, engine_ws);
     if (ctx) {
@@ -404,6 +405,36 @@ void Fish::DropEngine() {
     if (engine_ws) kf_free(ctx, engine_ws), engine_ws = nullptr;
     engine_state = 0, engine_embed = engine_head = false;
     bucket_tuned.clear(); /* the measured delays belonged to that engine */
+    DropResident(); /* the resident bf16 copies are keyed by the old tensors' addresses too */
+}
+void Fish::DropResident() {
+    if (deq_arena) {
+        kf_sync(ctx);
+        kf_set_dequant_arena(ctx, nullptr, 0);
+        kf_free(ctx, deq_arena), deq_arena = nullptr, deq_arena_bytes = 0;
+    }
+    resident_tried = false;
+}
+// Resident bf16 copies of the layers' quantised matrices for long prompts (kf_set_dequant_arena): 2 bytes per weight -- 0.9 GB for Qwen3-0.6B, 62 GB for Qwen3-32B -- of a
+// 288 GB part, instead of five dequantise launches per layer and prompt.  Sized and allocated by the first Prefill after the weights were set (never inside a launch
+// sequence); skipped when the copies would not fit `resident_max_bytes` or the allocation fails (the per-call scratch route stays).
+int Fish::EnsureResident(int PC) {
+    if (deq_arena || resident_tried || !prefill_resident || PC < 1024) return KF_OK;
+    resident_tried = true;
+    size_t total = 0;
+    auto add = [&](const SLP& s) {
+        if (!s.w) return;
+        const kf_weight d = s.w->desc();
+        if (d.type != KF_BF16 && d.quant == KF_QUANT_GROUP && !d.qzeros) total += ((size_t)d.ne0 * d.ne1 * 2 + 255) & ~(size_t)255;
+    };
+    for (int l = 0; l < config.nLayer; l++) add(attn[l]->Q), add(attn[l]->K), add(attn[l]->V), add(attn[l]->proj_cat), add(ffn[l]->gate), add(ffn[l]->up), add(ffn[l]->down);
+    if (total == 0 || total > resident_max_bytes) return KF_OK;
+    KF_TRY(kf_sync(ctx));
+    void* p = nullptr;
+    if (kf_malloc(ctx, total, &p) != KF_OK) return KF_OK; /* no room: not an error, the scratch route serves */
+    deq_arena = p, deq_arena_bytes = total;
+    KF_TRY(kf_set_dequant_arena(ctx, p, total));
+    return KF_OK;
 }
 int Fish::EngineCheck() {
     if (!engine || engine_steps == 0) return KF_OK;
@@ -675,6 +706,7 @@ int Fish::Prefill(const int* tokens, int n, int pos0) {
             }
         }
     }
+    KF_TRY(EnsureResident(PC));
     floatX* bx = ToX(gBUFF.bX);
     kf_weight we = embed.w->desc();
     int m = 0;
@@ -856,6 +888,18 @@ int kfh_engine_tune(void* h, int passes, float* us2) {
     const int rc = kf_engine_tune(f->ctx, f->engine, ToX(f->x), f->d_state, f->pos_bound(), passes, &b, &a);
     if (us2) us2[0] = b, us2[1] = a;
     return rc;
+}
+// resident bf16 copies for long prompts: on (default) / off, and the byte budget above which a model goes without (0 keeps the current one); takes effect at the next Prefill
+int kfh_set_prefill_resident(void* h, int on, size_t max_bytes) {
+    Fish* f = reinterpret_cast<Fish*>(h);
+    f->DropResident();
+    f->prefill_resident = on ? 1 : 0;
+    if (max_bytes) f->resident_max_bytes = max_bytes;
+    return KF_OK;
+}
+size_t kfh_resident_bytes(void* h) {
+    Fish* f = reinterpret_cast<Fish*>(h);
+    return f->deq_arena ? kf_dequant_arena_used(f->ctx) : 0;
 }
 int kfh_set_engine_autotune(void* h, int passes) {
     Fish* f = reinterpret_cast<Fish*>(h);

@@ -211,6 +211,12 @@ struct Fish {
     // storage are served and the position bound is; otherwise the per-layer launches run.  Same arithmetic, bit for bit.
     void* lin_scratch = nullptr;  // kf_set_scratch: workspace of the dequantise-then-multiply storages (AutoAWQ, row forms), sized when weights are set
     size_t lin_scratch_bytes = 0;
+    void* deq_arena = nullptr;  // kf_set_dequant_arena: resident bf16 copies of the layers' quantised matrices for long prompts (EnsureResident)
+    size_t deq_arena_bytes = 0, resident_max_bytes = (size_t)96 << 30; /* a third of the part's 288 GB */
+    int prefill_resident = 1;
+    bool resident_tried = false;
+    int EnsureResident(int PC);
+    void DropResident();
     int EnsureLinearScratch(const kf_weight& w, int nTok);
     bool use_engine = true;
     kf_engine* engine = nullptr;

@@ -475,6 +475,14 @@ class Qwen3:
         """> 0: the hand-off delays are measured once per position bucket, at the first multi-step launch inside it (passes of kf_engine_tune)"""
         L.check(self.host.kfh_set_engine_autotune(self.h, int(passes)), "kfh_set_engine_autotune")
 
+    def set_prefill_resident(self, on, max_bytes=0):
+        """bf16 copies of the layers' quantised matrices kept in HBM for long prompts (kf_set_dequant_arena; default on, budget 96 GiB): takes effect at the next prefill"""
+        L.check(self.host.kfh_set_prefill_resident(self.h, int(bool(on)), int(max_bytes)), "kfh_set_prefill_resident")
+
+    def resident_bytes(self):
+        """bytes of resident dequantised copies the prefill has filled so far"""
+        return int(self.host.kfh_resident_bytes(self.h))
+
     def engine_stats(self, pos):
         """kf_engine_stats: {'sweeps_per_poll': [6], 'polls', 'delay': [6], 'tuned'} for the hand-offs x, q|k|v, slice partials, ao, xB, act"""
         w = (C.c_int32 * 14)()

@@ -5,7 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from koifish_amd import lib as L, runtime as R
 
 ctx = R.Context(0)
+import _knobs
+_knobs.apply(ctx.hip)   # KF_G3_TILES / KF_G3_FIRST ... (scratch/_knobs.py)
 shapes = [(2048, 1024), (1024, 1024), (1024, 2048), (3072, 1024), (1024, 3072), (6400, 5120), (5120, 3200)]
+if os.environ.get('UB_SHAPES'): shapes = [tuple(int(v) for v in sh.split('x')) for sh in os.environ['UB_SHAPES'].split(',')]
 ns = [int(a) for a in sys.argv[1:]] or [32, 64, 128, 256, 1024]
 for (m, k) in shapes:
     w = torch.randn(m, k, device=ctx.device).mul_(0.02).to(torch.bfloat16)

@@ -159,3 +159,45 @@ def test_full_size_batched_prefill_vs_token_serial(model):
             _, lg = m.forward(int(t), pos)
         fl = O.bf16_to_f32(lg)
         assert abs(fl[batched[first]] - fl[serial[first]]) <= 2 * LOGIT_TOL * np.abs(fl).max(), "ids diverge at step %d beyond a near-tie" % first
+
+
+def test_full_size_long_prompt_on_resident_copies_vs_the_scratch_route(model):
+    """A 1536-token prompt with the layers' bf16 copies kept resident (kf_set_dequant_arena through Fish::EnsureResident; the default) against the same prompt with
+    the copies dequantised into the scratch per call: Q | K | V and gate | up run the SAME launches on the same operand values, so layer 0's K / V rows are equal bit for
+    bit; o_proj / down_proj change kernel (bf16 tile GEMM in split-K pieces instead of the in-register unpack: another fp32 order), so deeper rows and the logits
+    agree within the token-batch tolerance.  The copies are filled by the first prompt only; a second one gives the first one's bits."""
+    cfg, m = model
+    n = 1536
+    prompt = np.random.default_rng(12).integers(0, cfg["vocab"], size=n)
+    try:
+        m.set_prefill_resident(False)
+        nxt0, lg0 = m.prefill(prompt)
+        assert m.resident_bytes() == 0
+        k0, v0 = m.kv_to_host()
+        k0, v0 = k0[:, :n].copy(), v0[:, :n].copy()
+        m.set_prefill_resident(True)
+        nxt1, lg1 = m.prefill(prompt)
+        filled = m.resident_bytes()
+        per_layer = 2 * sum(w.ne0 * w.ne1 for (layer, slot), w in m.weights.items() if layer == 0)
+        assert filled == per_layer * cfg["n_layer"]
+        k1, v1 = m.kv_to_host()
+        k1, v1 = k1[:, :n].copy(), v1[:, :n].copy()
+        nxt2, lg2 = m.prefill(prompt)
+        assert m.resident_bytes() == filled
+        k2, v2 = m.kv_to_host()
+        assert nxt2 == nxt1 and np.array_equal(lg1, lg2) and np.array_equal(k1, k2[:, :n]) and np.array_equal(v1, v2[:, :n])
+        assert np.array_equal(k0[0], k1[0]) and np.array_equal(v0[0], v1[0])
+        for a, b in ((k1, k0), (v1, v0)):
+            fa, fb = O.bf16_to_f32(a), O.bf16_to_f32(b)
+            for l in range(cfg["n_layer"]):
+                d = np.abs(fa[l] - fb[l])
+                scale = np.abs(fb[l]).max()
+                assert np.sqrt((d ** 2).mean()) <= 2.0 ** -8 * scale, "layer %d rms" % l
+                assert d.max() <= 2.0 ** -5 * scale, "layer %d max" % l
+        f0, f1 = O.bf16_to_f32(lg0), O.bf16_to_f32(lg1)
+        assert np.abs(f0 - f1).max() <= 2.0 ** -6 * np.abs(f0).max()
+        assert nxt1 == O.argmax_bf16(lg1)
+        if nxt1 != nxt0:  # a near-tie inside the tolerance
+            assert abs(f0[nxt0] - f0[nxt1]) <= 2 * 2.0 ** -6 * np.abs(f0).max()
+    finally:
+        m.set_prefill_resident(True)

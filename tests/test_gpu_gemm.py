@@ -272,3 +272,79 @@ def test_fused_qkv_rope_epilogue_equals_the_two_launch_route(ctx, O, nt):
     v_ref = f(x) @ f(O.dequant(ows[2])).reshape(ms[2], k).T
     assert np.abs(f(outs[True][2]) - v_ref).max() <= 2.0 ** -7 * np.abs(v_ref).max()
     assert np.abs(f(outs[True][0])).max() > 0.1   # q really went through the norm (values of order one)
+
+
+@pytest.mark.parametrize("t", [L.Q4, L.T_SIGN])
+def test_resident_dequantised_copies_give_the_scratch_routes_results(ctx, O, t):
+    """kf_set_dequant_arena: the stacked Q | K | V and the interleaved gate | up routes find their bf16 copies in the arena from the second call on (no dequantise launch) and
+    return what the per-call scratch route returns, bit for bit (same tile kernels, same operand values); kf_linear takes the bf16 tile kernels
+    on the resident copy from 1024 rows -- against the exact fp64 product, with residual; the arena fills once, an exhausted arena falls back to the scratch, and
+    setting it again forgets every copy"""
+    k, nt = 1024, 1536
+    rng = np.random.default_rng(77 + t)
+    x = O.f32_to_bf16(rng.normal(0, 1.0, size=(nt, k)).astype(np.float32))
+    xd = bf16_t(x, ctx.device)
+    ms = (2048, 1024, 1024)
+    ows = [O.quantize(O.f32_to_bf16(rng.normal(0, 0.02, size=(m, k)).astype(np.float32)), m, k, t) for m in ms]
+    dws = [ctx.upload_blob(t, m, k, ow.blob()) for m, ow in zip(ms, ows)]
+    descs = [d.desc() for d in dws]
+    wp = (C.c_void_p * 3)(*[C.addressof(d) for d in descs])
+    m = 3072
+    og, ou = (O.quantize(O.f32_to_bf16(rng.normal(0, 0.05, size=(m, k)).astype(np.float32)), m, k, t) for _ in range(2))
+    g, u = ctx.upload_blob(t, m, k, og.blob()), ctx.upload_blob(t, m, k, ou.blob())
+    gd, ud = g.desc(), u.desc()
+    ctx.sync()
+    ctx._lin_ws = torch.empty(2 * m * k * 2, dtype=torch.uint8, device=ctx.device)
+    L.check(ctx.hip.kf_set_scratch(ctx.h, C.c_void_p(ctx._lin_ws.data_ptr()), C.c_size_t(ctx._lin_ws.numel())), "kf_set_scratch")
+
+    def run():
+        ys = [torch.full((nt, mm), 7.0, dtype=torch.bfloat16, device=ctx.device) for mm in ms]
+        yp = (C.c_void_p * 3)(*[y.data_ptr() for y in ys])
+        assert ctx.hip.kf_linear_multi(ctx.h, 3, wp, xd.data_ptr(), yp, nt) == 0, ctx.hip.kf_last_error()
+        act = torch.zeros(nt, m, dtype=torch.bfloat16, device=ctx.device)
+        tmp = torch.zeros(nt, m, dtype=torch.bfloat16, device=ctx.device)
+        assert ctx.hip.kf_gateup_swiglu_batch(ctx.h, C.byref(gd), C.byref(ud), xd.data_ptr(), act.data_ptr(), tmp.data_ptr(), nt) == 0, ctx.hip.kf_last_error()
+        ctx.sync()
+        return [u16(y).copy() for y in ys] + [u16(act).copy()]
+
+    f = lambda a: O.bf16_to_f32(a).astype(np.float64)
+    try:
+        base = run()  # no arena: dequantise into the scratch, every call
+        total = sum(mm * k * 2 for mm in ms) + 2 * m * k * 2 + ms[1] * k * 2
+        arena = torch.empty(total, dtype=torch.uint8, device=ctx.device)
+        L.check(ctx.hip.kf_set_dequant_arena(ctx.h, C.c_void_p(arena.data_ptr()), C.c_size_t(total)), "kf_set_dequant_arena")
+        assert ctx.hip.kf_dequant_arena_used(ctx.h) == 0
+        first = run()   # fills
+        used = ctx.hip.kf_dequant_arena_used(ctx.h)
+        assert used == sum(mm * k * 2 for mm in ms) + 2 * m * k * 2
+        ctx._lin_ws.fill_(0x5a)  # the scratch holds nothing the second call could use
+        ctx.sync()
+        second = run()  # finds
+        assert ctx.hip.kf_dequant_arena_used(ctx.h) == used
+        for a, b, c_ in zip(base, first, second):
+            assert np.array_equal(a, b) and np.array_equal(a, c_)
+        # kf_linear on a resident copy: K's matrix again, alone (its own key), with the residual epilogue
+        res = O.f32_to_bf16(rng.normal(0, 1.0, size=(nt, ms[1])).astype(np.float32))
+        y = bf16_t(res, ctx.device)
+        for _ in range(2):
+            y.copy_(bf16_t(res, ctx.device))
+            assert ctx.hip.kf_linear(ctx.h, C.byref(descs[1]), xd.data_ptr(), y.data_ptr(), None, nt, 1.0, 0.0, L.KF_EPI_RESIDUAL, y.data_ptr()) == 0, ctx.hip.kf_last_error()
+            ctx.sync()
+            ref = f(x) @ f(O.dequant(ows[1])).reshape(ms[1], k).T
+            out = f(u16(y)) - f(res)
+            assert np.abs(out - ref).max() <= 2.0 ** -6 * max(np.abs(ref).max(), np.abs(f(res)).max())
+        assert ctx.hip.kf_dequant_arena_used(ctx.h) == total  # now full
+        # a full arena: other weights go through the scratch as before
+        w2 = ctx.upload_blob(t, ms[0], k, ows[0].blob())
+        d2 = w2.desc()
+        y2 = torch.zeros(nt, ms[0], dtype=torch.bfloat16, device=ctx.device)
+        assert ctx.hip.kf_linear(ctx.h, C.byref(d2), xd.data_ptr(), y2.data_ptr(), None, nt, 1.0, 0.0, 0, None) == 0, ctx.hip.kf_last_error()
+        ctx.sync()
+        ref = f(x) @ f(O.dequant(ows[0])).reshape(ms[0], k).T
+        assert np.abs(f(u16(y2)) - ref).max() <= 2.0 ** -7 * np.abs(ref).max()
+        assert ctx.hip.kf_dequant_arena_used(ctx.h) == total
+        L.check(ctx.hip.kf_set_dequant_arena(ctx.h, C.c_void_p(arena.data_ptr()), C.c_size_t(total)), "kf_set_dequant_arena")
+        assert ctx.hip.kf_dequant_arena_used(ctx.h) == 0  # forgotten
+    finally:
+        ctx.sync()
+        L.check(ctx.hip.kf_set_dequant_arena(ctx.h, None, 0), "kf_set_dequant_arena")

@@ -114,10 +114,42 @@ def test_attn_prefill_kernel_vs_oracle(ctx, nh, nkv, hd, pos0, n):
     assert rc == 0, ctx.hip.kf_last_error()
     ctx.sync()
     out = u16(out_t)
-    for t in sorted({0, 1, n // 3, n // 2, n - 2, n - 1}):
+    _check_attn_rows(q, kc, vc, out, pos0, sorted({0, 1, n // 3, n // 2, n - 2, n - 1}), nh, nkv, hd)
+
+
+def _check_attn_rows(q, kc, vc, out, pos0, rows, nh, nkv, hd):
+    for t in rows:
         pos = pos0 + t
         ref = O.bf16_to_f32(O.attn_decode(q[t], kc[:pos + 1], vc[:pos + 1], pos, nh, nkv, hd, mode=O.ATTN_FUSED))
         refc = O.bf16_to_f32(O.attn_decode(q[t], kc[:pos + 1], vc[:pos + 1], pos, nh, nkv, hd, mode=O.ATTN_REF))
         got = O.bf16_to_f32(out[t])
         assert np.abs(got - ref).max() <= 2.0 ** -7 * np.abs(ref).max(), "token %d vs FUSED" % t
         assert np.abs(got - refc).max() <= 2.0 ** -6 * np.abs(refc).max(), "token %d vs REF" % t
+
+
+@pytest.mark.parametrize("nh,nkv,hd", [(16, 8, 128), (8, 1, 128), (4, 4, 64), (8, 2, 64)])
+@pytest.mark.parametrize("pos0,n", [(0, 1024), (0, 1100), (5, 1031), (0, 2047)])
+def test_attn_prefill_long_prompt_form_vs_oracle(ctx, nh, nkv, hd, pos0, n):
+    """The form kf_attn_prefill takes from 1024 tokens when there is about one workgroup per CU: every workgroup holds a half block of tokens from the FRONT of the prompt
+    and one from the BACK (equal key walks under the causal mask), eight waves in two key halves merged at the end.  Rows at both ends of the prompt, at the half-block
+    seams (multiples of 64 / GQ tokens), in the middle block of an odd count and in the ragged last block -- against the oracle's decode attention, as the test above."""
+    import torch
+    from tests.conftest import bf16_t, u16
+    rng = np.random.default_rng(pos0 * 31 + n + nh)
+    kvd, qd = nkv * hd, nh * hd
+    tot = pos0 + n
+    q = O.f32_to_bf16(rng.normal(0, 1.0, size=(n, qd)).astype(np.float32))
+    kc = O.f32_to_bf16(rng.normal(0, 1.0, size=(tot, kvd)).astype(np.float32))
+    vc = O.f32_to_bf16(rng.normal(0, 1.0, size=(tot, kvd)).astype(np.float32))
+    qd_t, kc_t, vc_t = bf16_t(q, ctx.device), bf16_t(kc, ctx.device), bf16_t(vc, ctx.device)
+    out_t = torch.full((n, qd), 3.0, dtype=torch.bfloat16, device=ctx.device)
+    rc = ctx.hip.kf_attn_prefill(ctx.h, qd_t.data_ptr(), kc_t.data_ptr(), vc_t.data_ptr(), out_t.data_ptr(), pos0, n, qd, nh, nkv, hd, kvd)
+    assert rc == 0, ctx.hip.kf_last_error()
+    ctx.sync()
+    out = u16(out_t)
+    ht = 64 // (nh // nkv)  # tokens per half block
+    nsb = (n + ht - 1) // ht
+    rows = {0, 1, ht - 1, ht, n - 1, n - 2, (nsb // 2) * ht, (nsb // 2) * ht - 1, min(n - 1, (nsb // 2) * ht + ht - 1), (nsb - 1) * ht, (nsb - 1) * ht - 1, n // 3, 2 * n // 3}
+    _check_attn_rows(q, kc, vc, out, pos0, sorted(t for t in rows if 0 <= t < n), nh, nkv, hd)
+    # every row was written (the fill value 3.0 cannot survive: outputs are convex combinations of N(0, 1) values rounded to bf16 -- |.| = 3.0 exactly in all of a row has probability 0)
+    assert not (out == 0x4040).all(axis=1).any()
