@@ -82,7 +82,10 @@ __global__ void __launch_bounds__(256 * KH) attn_prefill_kernel(const AttnPrefil
 
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int g = blockIdx.y;
+    // workgroup -> (kv-head g, block bx): consecutive workgroups go to consecutive XCDs, so g = id mod n_kv puts all the workgroups of a kv-head on the same XCD(s) -- its K / V
+    // rows (1 MB at 2047 tokens) then stay in that XCD's 4 MB L2 instead of every XCD streaming all heads' rows through the fabric (199 MB per launch at 2047 tokens)
+    const int wg_id = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y;
+    const int g = wg_id % a.n_kv, bx = wg_id / a.n_kv;
     const size_t seq_row = (size_t)blockIdx.z * a.n_tok;
     // Which tokens a wave's 32 columns are.  KH = 1: the workgroup is TQ consecutive tokens, the blocks with the most keys dispatched first.  KH = 2 (about one workgroup per
     // CU: the launch lasts as long as its heaviest workgroup, and under the causal mask the last query block walks twice the keys of the average one -- measured at 2047 tokens:
@@ -97,13 +100,13 @@ __global__ void __launch_bounds__(256 * KH) attn_prefill_kernel(const AttnPrefil
     if constexpr (PAIR) {
         // (SIMD = wave % 4 holds wave w of the even key half and wave w of the odd one: the back half block -- the long walk -- sits on waves 2-3 of the even half and on
         // waves 0-1 of the odd half, so that every SIMD runs one long and one short walk; with both long walks on SIMDs 2-3 the launch took what it took unpaired.)
-        const int nsb = (a.n_tok + HT - 1) / HT, lo = blockIdx.x, hi = nsb - 1 - (int)blockIdx.x, half = ((wave >> 1) ^ kh) & 1;
+        const int nsb = (a.n_tok + HT - 1) / HT, lo = bx, hi = nsb - 1 - bx, half = ((wave >> 1) ^ kh) & 1;
         sb_first = (half ? hi : lo) * HT, sb_tokens = HT, col_in = (wave & 1) * 32;
         half_ok = half || lo != hi; /* an odd count's middle block belongs to the back half's waves alone */
         int last = hi * HT + HT - 1;
         kmax = a.pos0 + (last < a.n_tok - 1 ? last : a.n_tok - 1);
     } else {
-        sb_first = ((int)gridDim.x - 1 - (int)blockIdx.x) * TQ, sb_tokens = TQ, col_in = wave * 32;
+        sb_first = ((int)gridDim.x - 1 - bx) * TQ, sb_tokens = TQ, col_in = wave * 32;
         int last = sb_first + TQ - 1;
         kmax = a.pos0 + (last < a.n_tok - 1 ? last : a.n_tok - 1);
     }
@@ -170,7 +173,7 @@ __global__ void __launch_bounds__(256 * KH) attn_prefill_kernel(const AttnPrefil
     const float LOG2E = 1.44269502162933349609375f;
 
 #ifdef AP_STAMP
-    const bool stamping = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 128;
+    const bool stamping = bx == 0 && g == 0 && blockIdx.z == 0 && threadIdx.x == 128;
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = __builtin_amdgcn_s_memtime();
 #endif
     const int nstep = (ntile + KH - 1) / KH; /* both halves make the same number of steps (and barriers); the odd half may find its last one empty */
