@@ -5,6 +5,7 @@ outputs are stored (tests/golden/ref_python_vectors.npz).  Nothing of the refere
   src/Python/test_awq.py:32-66, 103-128   unpack_awq / reverse_awq_order / Dequant_1   (AutoAWQ GEMM layout -> bf16 weights)
   src/Python/tile_wrapper/tl_qkv.py:384-403   ref_program(Q, K, V, is_causal, groups)    (causal grouped-query attention; row a13)
   src/Python/tile_wrapper/tl_norm.py:62-63     ref_program(x)                              (RMS normalisation without a weight; row a9)
+  src/Python/tile_wrapper/tl_gemm.py:150-151   ref_program(A, B) = A @ B.T                 (the token-batch product SLP::Forw hands to cuBLASLt: x [n, K] . W [M, K]^T; row a8)
 
     python tests/golden/make_ref_python_vectors.py        (needs /root/reference)
 """
@@ -29,6 +30,17 @@ def take(path, names, extra=None):
     ns = {"torch": torch, "F": F, "np": np}
     ns.update(extra or {})
     exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def take_def(path, name):
+    """one top-level function of a reference file that this interpreter cannot parse as a whole (tl_gemm.py uses 3.12 f-string syntax further down): the lines from its
+    `def` to the next top-level statement, compiled alone"""
+    lines = open(path).read().split("\n")
+    i0 = next(i for i, l in enumerate(lines) if l.startswith("def %s(" % name))
+    i1 = next(i for i in range(i0 + 1, len(lines)) if lines[i] and not lines[i][0].isspace())
+    ns = {"torch": torch, "F": F, "np": np}
+    exec(compile("\n".join(lines[i0:i1]), path, "exec"), ns)
     return ns
 
 
@@ -64,6 +76,12 @@ def main():
     nrm = take(os.path.join(REF, "tile_wrapper", "tl_norm.py"), {"ref_program"})
     x = (torch.randn(7, 1024, generator=g) * 3.0).to(torch.bfloat16).float()
     out.update(rms_x=bf16_bits(x), rms_out=nrm["ref_program"](x).numpy().astype(np.float32))
+    # ---- the product y = x . W^T on bf16-exact operands (one token row, and a token batch), fp32 result; drawn AFTER everything above: the earlier vectors keep their bits
+    gm = take_def(os.path.join(REF, "tile_wrapper", "tl_gemm.py"), "ref_program")
+    for tag, (n, M, K) in (("a", (1, 96, 256)), ("b", (40, 64, 384))):
+        A = torch.randn(n, K, generator=g).to(torch.bfloat16).float()
+        B = (torch.randn(M, K, generator=g) * 0.05).to(torch.bfloat16).float()
+        out.update({"gemm_%s_x" % tag: bf16_bits(A), "gemm_%s_w" % tag: bf16_bits(B), "gemm_%s_out" % tag: gm["ref_program"](A, B).numpy().astype(np.float32)})
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, {k: v.shape for k, v in out.items()})
 

@@ -48,3 +48,21 @@ def test_rmsnorm(ctx, O, gold):
     ones = torch.ones(x.shape[1], dtype=torch.bfloat16, device=ctx.device)
     got = O.bf16_to_f32(u16(ctx.rmsnorm(bf16_t(x, ctx.device), ones, eps=1e-12)))
     assert np.abs(got - ref).max() <= 2.0 ** -8 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_linear(ctx, O, gold, tag):
+    """kf_linear on bf16 weights -- the mat-vec for one row, the token-batch kernels for 40 -- against the reference's own statement of the product (tl_gemm.py:150-151)"""
+    import ctypes as C
+    from koifish_amd import lib as L
+    x, w, ref = gold["gemm_%s_x" % tag], gold["gemm_%s_w" % tag], gold["gemm_%s_out" % tag]
+    n, (M, K) = x.shape[0], w.shape
+    dw = ctx.upload_blob(L.BF16, M, K, w)
+    d = dw.desc()
+    xd = bf16_t(x, ctx.device)
+    y = torch.zeros(n, M, dtype=torch.bfloat16, device=ctx.device)
+    assert ctx.hip.kf_linear(ctx.h, C.byref(d), xd.data_ptr(), y.data_ptr(), None, n, 1.0, 0.0, 0, None) == 0, ctx.hip.kf_last_error()
+    ctx.sync()
+    got = O.bf16_to_f32(u16(y))
+    assert np.abs(got - ref).max() <= 2.0 ** -8 * np.abs(ref).max() + 1e-6
+    assert np.allclose(got, ref, rtol=1e-2, atol=1e-2)

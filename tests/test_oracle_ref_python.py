@@ -1,8 +1,8 @@
-"""The oracle against outputs of the REFERENCE ITSELF: tests/golden/ref_python_vectors.npz holds inputs and outputs of three functions of the reference's
+"""The oracle against outputs of the REFERENCE ITSELF: tests/golden/ref_python_vectors.npz holds inputs and outputs of four functions of the reference's
 own Python files, executed in the build container by tests/golden/make_ref_python_vectors.py (AutoAWQ unpack / order / dequant of
-src/Python/test_awq.py, the attention `ref_program` of src/Python/tile_wrapper/tl_qkv.py, the RMS `ref_program` of tile_wrapper/tl_norm.py).  These pin
+src/Python/test_awq.py, the attention `ref_program` of src/Python/tile_wrapper/tl_qkv.py, the RMS `ref_program` of tile_wrapper/tl_norm.py, the product `ref_program` of tile_wrapper/tl_gemm.py).  These pin
 SURVEY 8a rows a7 (bit order exactly, values to the bf16 rounding of the script's fp16 product), a13 (score scale, causal mask, which kv head a query head
-reads, softmax, PV) and a9 (epsilon inside the root, mean over the row) to the reference's statements rather than to our reading of its CUDA."""
+reads, softmax, PV) a9 (epsilon inside the root, mean over the row) and a8 (y = x . W^T: the contracted index and the transposed operand) to the reference's statements rather than to our reading of its CUDA."""
 import os
 
 import numpy as np
@@ -57,3 +57,22 @@ def test_rmsnorm_follows_the_reference_program(O, gold):
     got = O.bf16_to_f32(O.rmsnorm(x, ones, eps=1e-12))
     assert np.abs(got - ref).max() <= 2.0 ** -8 * np.abs(ref).max()          # one bf16 rounding of the output
     assert np.array_equal(O.f32_to_bf16(ref), O.rmsnorm(x, ones, eps=1e-12)) or (O.f32_to_bf16(ref) != O.rmsnorm(x, ones, eps=1e-12)).mean() < 0.01
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_linear_follows_the_reference_program(O, gold, tag):
+    """SLP::Forw's product as the reference states it (tl_gemm.py:150-151, C = A @ B.T, checked there to rtol = atol = 1e-2): the oracle's mat-vec on bf16 weights, row
+    by row of x -- which operand is transposed, which index is contracted -- within one bf16 rounding of the program's fp32 result (row a8)."""
+    x, w, ref = gold["gemm_%s_x" % tag], gold["gemm_%s_w" % tag], gold["gemm_%s_out" % tag]
+    M, K = w.shape
+    ow = O.quantize(w, M, K, O.BF16)
+    for t in range(x.shape[0]):
+        got = O.bf16_to_f32(O.linear(ow, x[t]))
+        assert np.abs(got - ref[t]).max() <= 2.0 ** -8 * np.abs(ref[t]).max() + 1e-6, "row %d" % t
+        assert np.allclose(got, ref[t], rtol=1e-2, atol=1e-2)      # the reference's own bound
+    # the transposed reading (x . W instead of x . W^T) is a different shape altogether; a swapped contraction index on a square slice would be an O(1) error
+    sq = min(M, K)
+    f = lambda a: O.bf16_to_f32(a).astype(np.float64)
+    wrong = f(x[0][:sq]) @ f(w[:sq, :sq])
+    right = f(x[0][:sq]) @ f(w[:sq, :sq]).T
+    assert np.abs(wrong - right).max() > 0.1 * np.abs(right).max()
