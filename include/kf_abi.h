@@ -146,14 +146,16 @@ size_t kf_linear_scratch_bytes(const kf_weight* w, int nTok);
 int kf_set_scratch(kf_ctx* ctx, void* scratch, size_t bytes);
 /* RESIDENT dequantised copies for token batches (prompt prefill).  The reference dequantises a quantised weight in front of EVERY token-batch product
  * (GTensor::GetDataX -> cuBLASLt, SLP::Forw); with 288 GB of HBM the bf16 form of an inference model's matrices can simply stay: the routes of kf_linear,
- * kf_linear_multi, kf_qkv_rope_batch and kf_gateup_swiglu_batch that dequantise into the scratch (>= 1024 token rows) put the copy into `arena` instead the first
+ * kf_linear_multi, kf_qkv_rope_batch and kf_gateup_swiglu_batch that dequantise into the scratch (>= 1024 token rows; with an arena from 320) put the copy into `arena` instead the first
  * time they meet a weight (or a stacked Q | K | V / interleaved gate | up set) and find it there afterwards -- same values, same tile kernels, no dequantise
- * launches, and kf_linear takes the bf16 tile kernels from 1024 rows (o_proj / down_proj of a long prompt: 64 x 128 / 64 x 64 tiles of kf_gemm3.hip).
+ * launches, and kf_linear takes the bf16 tile kernels from 320 rows (o_proj / down_proj of a prompt: 64 x 128 / 64 x 64 tiles of kf_gemm3.hip, in k-pieces when a
+ * kf_set_scratch workspace of kf_resident_scratch_bytes() is lent).
  * Copies are keyed by the weights' data pointers: the caller promises the weights do not change while the arena holds them (inference; after a weight update
  * call kf_set_dequant_arena again -- it forgets every copy).  arena: device memory, 16-byte aligned, the caller's; NULL switches the feature off; when it is
  * full, further weights go through the scratch as before.  kf_dequant_arena_used: bytes filled so far.  Not while capturing. */
 int kf_set_dequant_arena(kf_ctx* ctx, void* arena, size_t bytes);
 size_t kf_dequant_arena_used(kf_ctx* ctx);
+size_t kf_resident_scratch_bytes(void); /* a kf_set_scratch workspace of at least this size lets kf_linear's resident-copy route cut short token batches into k-pieces */
 int kf_linear(kf_ctx* ctx, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const kf_bf16* bias, int nTok, float alpha, float beta,
               uint32_t epilogue, const kf_bf16* residual);
 

@@ -308,7 +308,6 @@ int kf_quantize(kf_ctx* c, const kf_weight* w, const kf_bf16* src, int symmetric
 
 static void init_args(kf_ctx* c, kf::GemvLaunch& L) { memset(&L, 0, sizeof(L)); L.args.alpha = 1.0f; L.canon = c->canonical; }
 
-static const int KF_RESIDENT_GEMM_MIN = 1024; /* token rows from which kf_linear multiplies a RESIDENT dequantised copy (kf_set_dequant_arena) by the bf16 tile kernels */
 static const int KF_DEQ_GEMM_MIN = 2048; /* token rows from which a quantised weight is dequantised once and multiplied by the bf16 tile kernel (when scratch was handed over) */
 size_t kf_linear_scratch_bytes(const kf_weight* w, int nTok) {
     if (!w || nTok < 1) return 0;
@@ -334,6 +333,7 @@ int kf_set_dequant_arena(kf_ctx* c, void* arena, size_t bytes) {
     return KF_OK;
 }
 size_t kf_dequant_arena_used(kf_ctx* c) { return c ? c->arena_used : 0; }
+size_t kf_resident_scratch_bytes(void) { return kf::gemm3_sk_ws_bytes(); }
 int kf_set_scratch(kf_ctx* c, void* scratch, size_t bytes) {
     CHKCTX(c);
     if (scratch && !al16(scratch)) return fail(KF_BLAS_UNALIGN, "kf_set_scratch: unaligned");
@@ -375,7 +375,7 @@ int kf_linear(kf_ctx* c, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const
         wb.data = Wd, wb.type = KF_BF16, wb.ne0 = w->ne0, wb.ne1 = w->ne1;
         return kf_linear(c, &wb, x, y, bias, nTok, alpha, beta, epilogue, residual);
     }
-    if (c->arena && nTok >= KF_RESIDENT_GEMM_MIN && w->type != KF_BF16 && w->quant == KF_QUANT_GROUP && w->ne0 >= 128 && (w->ne1 % 64) == 0) {
+    if (c->arena && nTok >= kf::g_knobs.resident_min && w->type != KF_BF16 && w->quant == KF_QUANT_GROUP && w->ne0 >= 128 && (w->ne1 % 64) == 0) {
         // a resident copy (kf_set_dequant_arena): nothing to dequantise -- the bf16 tile kernels of kf_gemm3.hip from 1024 token rows (the 1024-row o_proj / down_proj of a
         // long prompt as 256 tiles of 64 x 128 or 64 x 64)
         const kf_weight* one[1] = {w};
@@ -386,7 +386,9 @@ int kf_linear(kf_ctx* c, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const
             kf_weight wb;
             memset(&wb, 0, sizeof(wb));
             wb.data = W, wb.type = KF_BF16, wb.ne0 = w->ne0, wb.ne1 = w->ne1;
-            const int rc = kf::gemm_launch(c->stream, &wb, x, w->ne1, nTok, y, w->ne0, bias, alpha, beta, (epilogue & KF_EPI_RESIDUAL) ? residual : nullptr, w->ne0);
+            const bool lend = c->scratch && c->scratch_bytes >= kf::gemm3_sk_ws_bytes() && al16(c->scratch); /* the scratch holds no copy on this route: split-K slots */
+            const int rc = kf::gemm_launch(c->stream, &wb, x, w->ne1, nTok, y, w->ne0, bias, alpha, beta, (epilogue & KF_EPI_RESIDUAL) ? residual : nullptr, w->ne0, lend ? c->scratch : nullptr,
+                                           lend ? c->scratch_bytes : 0);
             if (rc < 0) return fail(rc, "kf_linear (bf16 tile GEMM on the resident copy) failed with %d", rc);
             if (rc == KF_OK) return KF_OK;
         }
@@ -733,17 +735,18 @@ int kf_embed_batch(kf_ctx* c, const kf_weight* w, const int32_t* d_tokens, int n
 // Large token batches of matrices that share their input (Q | K | V, gate | up): GetDataX of each into the caller's scratch, back to back, then ONE launch of the
 // 256 x 256 bf16 tile kernel over the stacked rows (each matrix a multiple of 256 rows; its rows go to its own output).  A 1024-row K or V projection alone is 4 x 8
 // tiles at 2048 tokens -- an eighth of the chip -- and took 32 us on the in-register-unpack kernels; stacked with Q it is 128 tiles.
-static const int KF_MULTI_DEQ_MIN = 1024; /* token rows from which the stacked route is taken */
+static const int KF_MULTI_DEQ_MIN = 1024; /* token rows from which the stacked route is taken (with a dequantise per call; resident copies: g_knobs.resident_min) */
+static int multi_min(const kf_ctx* c) { return c && c->arena && kf::g_knobs.resident_min < KF_MULTI_DEQ_MIN ? kf::g_knobs.resident_min : KF_MULTI_DEQ_MIN; }
 /* up256z: a no-op on these sizes (multiples of 256 rows x 64 columns): the stacked rows are contiguous */
-static bool multi_deq_ok(int n_w, const kf_weight* const* w, int nTok, size_t* need) {
+static bool multi_deq_ok(int n_w, const kf_weight* const* w, int nTok, size_t* need, const kf_ctx* c = nullptr) {
     size_t tot = 0;
     long rows = 0;
-    if (n_w < 2 || n_w > 3 || nTok < KF_MULTI_DEQ_MIN) return false;
+    if (n_w < 2 || n_w > 3 || nTok < multi_min(c)) return false;
     for (int i = 0; i < n_w; i++) {
         if (w[i]->qzeros || w[i]->quant != KF_QUANT_GROUP || w[i]->ne0 < 256 || (w[i]->ne0 % 256) != 0 || (w[i]->ne1 % 64) != 0 || w[i]->ne1 != w[0]->ne1) return false;
         tot += up256z((size_t)w[i]->ne0 * w[i]->ne1 * 2), rows += w[i]->ne0;
     }
-    if ((rows / 256) * ((nTok + 255) / 256) < 64) return false;
+    if ((rows / 256) * ((nTok + 255) / 256) < 64 && (rows / 128) * ((nTok + 127) / 128) < 64) return false; /* fewer tiles than that: the in-register-unpack kernels */
     *need = tot;
     return true;
 }
@@ -757,7 +760,7 @@ size_t kf_linear_multi_scratch_bytes(int n_w, const kf_weight* const* w, int nTo
 // KF_OK done, 1 not this route, < 0 error
 static int multi_deq_route(kf_ctx* c, int n_w, const kf_weight* const* w, const kf_bf16* x, kf_bf16* const* y, int nTok, const kf::G3Rope* rope = nullptr) {
     size_t need = 0;
-    if (!multi_deq_ok(n_w, w, nTok, &need) || !al16(x)) return 1;
+    if (!multi_deq_ok(n_w, w, nTok, &need, c) || !al16(x)) return 1;
     int M[3] = {0, 0, 0};
     for (int i = 0; i < n_w; i++) M[i] = w[i]->ne0;
     const uint16_t* W = nullptr;
@@ -771,7 +774,7 @@ int kf_qkv_rope_batch(kf_ctx* c, const kf_weight* wq, const kf_weight* wk, const
     if (!wq || !wk || !wv || !x || !q || !k || !v || nTok < 1 || pos0 < 0) return fail(KF_INVALID_ARGS, "kf_qkv_rope_batch: bad args");
     const kf_weight* ws[3] = {wq, wk, wv};
     kf_bf16* ys[3] = {q, k, v};
-    if (hd == 128 && nTok >= KF_MULTI_DEQ_MIN && wq->ne0 == n_head * hd && wk->ne0 == n_kv * hd) { /* one launch: the stacked tile GEMM with q/k-norm + RoPE in its epilogue */
+    if (hd == 128 && nTok >= multi_min(c) && wq->ne0 == n_head * hd && wk->ne0 == n_kv * hd) { /* one launch: the stacked tile GEMM with q/k-norm + RoPE in its epilogue */
         for (int i = 0; i < 3; i++) {
             const int r = check_weight(ws[i], "kf_qkv_rope_batch");
             if (r) return r;
@@ -794,12 +797,14 @@ int kf_linear_multi(kf_ctx* c, int n_w, const kf_weight* const* w, const kf_bf16
         if (!y[i]) return fail(KF_INVALID_ARGS, "kf_linear_multi: y[%d] null", i);
         if (w[i]->ne1 != w[0]->ne1) return fail(KF_INVALID_ARGS, "kf_linear_multi: the matrices do not share the input width");
     }
-    if (n_w > 1 && nTok >= KF_MULTI_DEQ_MIN) {
+    if (n_w > 1 && nTok >= multi_min(c)) {
         const int rc = multi_deq_route(c, n_w, w, x, y, nTok);
         if (rc < 0) return fail(rc, "kf_linear_multi (dequantise + stacked tile GEMM) failed with %d", rc);
         if (rc == KF_OK) return KF_OK;
     }
-    if (n_w > 1 && nTok >= 8) {
+    // (bf16 storage from g3_first rows: kf_linear multiplies each matrix on the kf_gemm3.hip tile kernels -- the stacked in-register launch would be another summation order)
+    const bool bf16_tiles = w[0]->type == KF_BF16 && nTok >= kf::g_knobs.g3_first;
+    if (n_w > 1 && nTok >= 8 && !bf16_tiles) {
         const int rc = kf::gemm_multi_launch(c->stream, n_w, w, x, w[0]->ne1, nTok, y);
         if (rc < 0) return fail(rc, "kf_linear_multi failed with %d", rc);
         if (rc == KF_OK) return KF_OK;
@@ -818,12 +823,12 @@ int kf_gateup_swiglu_batch(kf_ctx* c, const kf_weight* gate, const kf_weight* up
     if (r) return r;
     if (!x || !act || !up_scratch || nTok < 1) return fail(KF_INVALID_ARGS, "kf_gateup_swiglu_batch: bad args");
     if (gate->ne0 != up->ne0 || gate->ne1 != up->ne1) return fail(KF_INVALID_ARGS, "kf_gateup_swiglu_batch: gate and up shapes differ");
-    if (nTok >= KF_MULTI_DEQ_MIN) { /* gate | up dequantised interleaved, ONE tile-GEMM launch with the SwiGLU expression in its epilogue (on the two bf16-rounded projections,
+    if (nTok >= multi_min(c)) { /* gate | up dequantised interleaved, ONE tile-GEMM launch with the SwiGLU expression in its epilogue (on the two bf16-rounded projections,
                                        as the paired kernel and swiglu_kernel form it) */
         const kf_weight* ws[2] = {gate, up};
         size_t need = 0;
         const uint16_t* W = nullptr;
-        if (multi_deq_ok(2, ws, nTok, &need) && al16(x) && gate->ne0 % 128 == 0 && deq_copies(c, 2, ws, DEQ_ILV, &W) == KF_OK) {
+        if (multi_deq_ok(2, ws, nTok, &need, c) && al16(x) && gate->ne0 % 128 == 0 && deq_copies(c, 2, ws, DEQ_ILV, &W) == KF_OK) {
             const int rc = kf::gemm3_swiglu_launch(c->stream, W, gate->ne0, gate->ne1, x, gate->ne1, nTok, act);
             if (rc < 0) return fail(rc, "kf_gateup_swiglu_batch (interleaved dequantise + tile GEMM with SwiGLU epilogue) failed with %d", rc);
             if (rc == KF_OK) return KF_OK;
@@ -833,7 +838,7 @@ int kf_gateup_swiglu_batch(kf_ctx* c, const kf_weight* gate, const kf_weight* up
         if (rc < 0) return fail(rc, "kf_gateup_swiglu_batch (dequantise + stacked tile GEMM) failed with %d", rc);
         if (rc == KF_OK) return kf_swiglu(c, act, up_scratch, act, (size_t)nTok * gate->ne0);
     }
-    if (nTok >= 8) {
+    if (nTok >= 8 && !(gate->type == KF_BF16 && nTok >= kf::g_knobs.g3_first)) { /* bf16 storage from g3_first rows: two kf_linear (tile kernels) + kf_swiglu, as kf_linear_multi */
         const int rc = kf::gemm_paired_launch(c->stream, gate, up, x, gate->ne1, nTok, act);
         if (rc < 0) return fail(rc, "kf_gateup_swiglu_batch failed with %d", rc);
         if (rc == KF_OK) return KF_OK;
@@ -1221,6 +1226,8 @@ int kfdbg_set_knob(const char* name, long value) {
     else if (!strcmp(name, "gemm_min")) k.gemm_min = (int)value;
     else if (!strcmp(name, "g3_tiles")) k.g3_tiles = (int)value;
     else if (!strcmp(name, "g3_first")) k.g3_first = (int)value;
+    else if (!strcmp(name, "resident_min")) k.resident_min = (int)value;
+    else if (!strcmp(name, "attn_pair_min")) k.attn_pair_min = (int)value;
     else return -1;
     return 0;
 }

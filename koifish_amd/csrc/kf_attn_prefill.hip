@@ -379,7 +379,7 @@ int attn_prefill_mfma_launch(hipStream_t st, const uint16_t* q, const uint16_t* 
     const int nsb = (n_tok + TQ / 2 - 1) / (TQ / 2); /* the paired form (kh = 2): half blocks of TQ / 2 tokens, one from the front and one from the back per workgroup */
     // about one workgroup per CU or fewer: the launch lasts as long as its last query block -- two key halves per workgroup (2047 tokens, 16 / 8 heads x 128:
     // 81 -> 67 us); with more workgroups than that the halves only compete for the CU (8 x 1024 x 25 x 64: 130 vs 143 us; 4095 tokens: 15.9 vs 16.4 ms per prompt)
-    const int kh = ((long)grid.x * grid.y * grid.z <= 320 && n_tok >= 1024) ? 2 : 1; /* short prompts: the launch is a few microseconds either way */
+    const int kh = ((long)grid.x * grid.y * grid.z <= 320 && n_tok >= g_knobs.attn_pair_min) ? 2 : 1; /* short prompts: the launch is a few microseconds either way */
     if (kh == 2) grid.x = (nsb + 1) / 2;
     const int rc = hd == 128 ? ap_launch_gq<128>(st, a, GQ, grid, kh) : ap_launch_gq<64>(st, a, GQ, grid, kh);
     if (rc) return rc;

@@ -606,7 +606,7 @@ int gemm_paired_launch(hipStream_t st, const kf_weight* gate, const kf_weight* u
 
 // Returns KF_OK when launched, 1 when the shape is not eligible (the caller then loops the mat-vec), < 0 on error.
 int gemm_launch(hipStream_t st, const kf_weight* w, const uint16_t* x, long long ldx, int n, uint16_t* y, long long ldy, const uint16_t* bias, float alpha,
-                float beta, const uint16_t* residual, long long ldr) {
+                float beta, const uint16_t* residual, long long ldr, void* ws, size_t ws_bytes) {
     GmWeight g;
     const int rc = gm_weight(w, g);
     if (rc) return rc;
@@ -624,7 +624,7 @@ int gemm_launch(hipStream_t st, const kf_weight* w, const uint16_t* x, long long
     // bf16 operands (weights stored as bf16, or the resident dequantised copies of a long prompt): the global_load_lds tile kernels first from g3_first token rows --
     // the crossover above was measured on the 4-bit in-register unpack; on bf16 the direct kernel took 64 us for 1024 x 2048 at 1024 rows
     if (g.fmt == FMT_BF16 && n >= g_knobs.g3_first) {
-        const int rc3 = gemm3_launch(st, g.fmt, a);
+        const int rc3 = gemm3_launch(st, g.fmt, a, ws, ws_bytes);
         if (rc3 != 1) return rc3;
     }
     if ((long)((M + 31) / 32) * ((n + 31) / 32) <= direct_max) {

@@ -543,13 +543,15 @@ int gemm3_launch(hipStream_t st, int fmt, const GemmArgs& a, void* ws, size_t ws
     // and, with split-K, the flag memset eat the gain): kf_linear keeps those on kf_gemm.hip.
     if (a.n < 128 || a.M < 128) return 1;
     const long nwg = (long)((a.M + 127) / 128) * ((a.n + 127) / 128);
-    if (nwg < 32) return 1;
+    if (nwg < 32 && (g_knobs.g3_tiles < 3 || (long)((a.M + 63) / 64) * ((a.n + 63) / 64) < 64)) return 1;
     if (nwg < 256 && g_knobs.g3_tiles >= 1 && !a.swiglu && !a.qkrope) { /* fewer 128 x 128 tiles than CUs: twice or four times as many smaller ones, no k-pieces */
+        // with the caller's workspace these go in k-pieces when even the small tiles leave CUs idle (1024 rows x K 2048-3072 at 512 tokens: 128 tiles of 64 x 64, each a
+        // 32-48 step k-loop of ~0.7 us per step on its own CU: 31 us; a 16 KiB partial per piece is cheap where the 64 KiB ones of the 128 x 128 tile were not)
         const long nmid = (long)((a.M + 63) / 64) * ((a.n + 127) / 128);
-        if (nmid >= 192 || g_knobs.g3_tiles < 3) return nmid >= 64 ? g3_go_c<false, false, G3Mid>(st, a, nmid, nullptr, 0, 64) : 1;
-        return g3_go_c<false, false, G3Tiny>(st, a, (long)((a.M + 63) / 64) * ((a.n + 63) / 64), nullptr, 0, 64);
+        if (nmid >= 192 || g_knobs.g3_tiles < 3) return nmid >= 64 ? g3_go_c<false, false, G3Mid>(st, a, nmid, ws, ws_bytes, 64) : 1;
+        return g3_go_c<false, false, G3Tiny>(st, a, (long)((a.M + 63) / 64) * ((a.n + 63) / 64), ws, ws_bytes, 64);
     }
-    return g3_go_c<false, false, G3Small>(st, a, nwg, ws, ws_bytes, 128);
+    return g3_go_c<false, false, G3Small>(st, a, nwg, nullptr, 0, 128);
 }
 // y[n, M] = alpha * sum_k B(k, tok) A(k, m) + beta * y (+ bias) with either operand stored K-MAJOR: akm: A = w[K][lda] (element (k, m) at k * lda + m), else w[M][K];
 // bkm: B = x[K][ldb], else x[n][ldb].  The two GEMMs of SLP::Back without a transpose of anything:  delta[n, IC] = deltaIn[n, OC] . W[OC, IC]  (A = W k-major),
@@ -597,7 +599,7 @@ int gemm3_multi_launch(hipStream_t st, int n_w, const uint16_t* Wcat, const int*
     a.njobs = n_w;
     a.w = reinterpret_cast<const unsigned char*>(Wcat), a.M = tot, a.K = K, a.x = x, a.ldx = ldx, a.n = n, a.y = y[0], a.ldy = M[0], a.alpha = 1.0f, a.beta = 0.0f;
     const long nwg = (long)(tot / G3_BM) * ((n + G3_BN - 1) / G3_BN);
-    if (nwg < 64) return 1;
+    if (nwg < 64 && (long)(tot / 128) * ((n + 127) / 128) < 64) return 1;
     // fewer than 160 big tiles (Q | K | V of a 0.6B model at 2047 tokens: 128): four times as many 128 x 128 tiles fill the chip better (2047-token prompt 8.20 -> 7.84 ms;
     // gate | up, 192 big tiles, is better left on them: 7.93 ms with both small)
     if (rope) {
@@ -621,7 +623,7 @@ int gemm3_swiglu_launch(hipStream_t st, const uint16_t* Wilv, int ffn, int K, co
     a.njobs = 1, a.swiglu = 1;
     a.w = reinterpret_cast<const unsigned char*>(Wilv), a.M = M, a.K = K, a.x = x, a.ldx = ldx, a.n = n, a.y = act, a.ldy = ffn, a.alpha = 1.0f, a.beta = 0.0f;
     const long nwg = (long)(M / G3_BM) * ((n + G3_BN - 1) / G3_BN);
-    if (nwg < 64) return 1;
+    if (nwg < 64 && (long)(M / 128) * ((n + 127) / 128) < 64) return 1;
     if (nwg < 160) return g3_go_c<false, false, G3Small>(st, a, (long)(M / 128) * ((n + 127) / 128), nullptr, 0, 1);
     return g3_go<false, false>(st, a, nwg, nullptr, 0);
 }

@@ -99,7 +99,7 @@ struct G3Rope { /* ROPE::cuInfer folded into the stacked Q | K | V launch's epil
 int gemm3_multi_launch(hipStream_t st, int n_w, const uint16_t* Wcat, const int* M, int K, const uint16_t* x, long long ldx, int n, uint16_t* const* y, const G3Rope* rope = nullptr);
 int gemm3_swiglu_launch(hipStream_t st, const uint16_t* Wilv, int ffn, int K, const uint16_t* x, long long ldx, int n, uint16_t* act); /* kf_gemm3.hip */
 int gemm_launch(hipStream_t st, const kf_weight* w, const uint16_t* x, long long ldx, int n, uint16_t* y, long long ldy, const uint16_t* bias, float alpha,
-                float beta, const uint16_t* residual, long long ldr);
+                float beta, const uint16_t* residual, long long ldr, void* ws = nullptr, size_t ws_bytes = 0); /* ws: split-K slots of the small bf16 tiles (gemm3_sk_ws_bytes) */
 
 int gemm_multi_launch(hipStream_t st, int n_w, const kf_weight* const* w, const uint16_t* x, long long ldx, int n, uint16_t* const* y);
 int gemm_paired_launch(hipStream_t st, const kf_weight* gate, const kf_weight* up, const uint16_t* x, long long ldx, int n, uint16_t* act);
@@ -144,7 +144,9 @@ struct Knobs {
     int q4_perm = 1;      /* 4-bit mat-vec through the register-table lookup (0: the arithmetic form; same bits) */
     int q2_tab = 1;       /* 2-bit mat-vec through the LDS selector table (0: the arithmetic form; same bits) */
     int g3_tiles = 3;     /* smallest bf16 tile gemm3_launch may pick: 0 = 128 x 128 only (round 3), 1 = + 64 x 128, 3 = + 64 x 64 (kf_gemm3.hip) */
-    int g3_first = 512;   /* token rows from which bf16 operands try the kf_gemm3.hip tile kernels before the 32 x 32 direct kernel */
+    int resident_min = 320;  /* token rows from which the token-batch routes use RESIDENT dequantised copies (kf_set_dequant_arena) + the bf16 tile kernels; without an arena: 1024 */
+    int attn_pair_min = 256;  /* prompt tokens from which kf_attn_prefill takes its paired two-key-half form (when there is about one workgroup per CU or fewer) */
+    int g3_first = 256;   /* token rows from which bf16 operands try the kf_gemm3.hip tile kernels before the 32 x 32 direct kernel */
     int q1_tab = 1;       /* 1-bit mat-vec through the LDS selector table (0: the per-bit select form; same bits) */
     long gemv_waves = 0;  /* > 0: waves a mat-vec launch aims for (0: the launcher's rule) */
     int gemv_stream = 1;  /* buffer-load form of the long mat-vec launches (0: off) */

@@ -434,6 +434,14 @@ int Fish::EnsureResident(int PC) {
     if (kf_malloc(ctx, total, &p) != KF_OK) return KF_OK; /* no room: not an error, the scratch route serves */
     deq_arena = p, deq_arena_bytes = total;
     KF_TRY(kf_set_dequant_arena(ctx, p, total));
+    const size_t need = kf_resident_scratch_bytes(); /* the scratch holds no dequantised copy any more: it lends the small tile kernels their split-K slots */
+    if (need > lin_scratch_bytes) {
+        void* q = nullptr;
+        KF_TRY(kf_malloc(ctx, need, &q));
+        KF_TRY(kf_set_scratch(ctx, q, need));
+        if (lin_scratch) kf_free(ctx, lin_scratch);
+        lin_scratch = q, lin_scratch_bytes = need;
+    }
     return KF_OK;
 }
 int Fish::EngineCheck() {
