@@ -647,7 +647,7 @@ def prefill_rate(m, prompt, decode_ms_per_step, reps=5, bound=None):
     import time
     m.sync()
     t0 = time.perf_counter()
-    m.prefill(prompt, want_logits=False)  # the warm-up; the first prompt of >= 1024 tokens also fills the resident bf16 copies (kf_set_dequant_arena), reported as first_call_ms
+    m.prefill(prompt, want_logits=False)  # the warm-up; the first prompt of >= 320 tokens also fills the resident bf16 copies (kf_set_dequant_arena), reported as first_call_ms
     m.sync()
     first_ms = (time.perf_counter() - t0) * 1e3
     t0 = time.perf_counter()
@@ -665,7 +665,7 @@ def prefill_rate(m, prompt, decode_ms_per_step, reps=5, bound=None):
     nbytes = sum(w.algorithmic_bytes() for (layer, slot), w in m.weights.items() if layer >= 0) + m.weights[(-1, 1)].algorithmic_bytes() + n * cfg["dim"] * 2 \
         + cfg["n_layer"] * n * kvd * 2 * 2 * 2
     tf, gbs = flops / (ms * 1e-3) / 1e12, nbytes / (ms * 1e-3) / 1e9
-    return {"prompt_tokens": n, "ms": round(ms, 3), "tokens_per_s": round(n / ms * 1e3, 1), "mode": "token batches: < 1024 rows MFMA 32x32x16 bf16 on 4-bit tiles unpacked in registers; >= 1024 rows the 256x256 / 128x128 bf16 tile kernels (MFMA 16x16x32; SwiGLU and q/k-norm + RoPE in their epilogues) on RESIDENT bf16 copies of the layer matrices (dequantised by the first such prompt, kept in HBM); flash attention tile",
+    return {"prompt_tokens": n, "ms": round(ms, 3), "tokens_per_s": round(n / ms * 1e3, 1), "mode": "token batches: < 320 rows MFMA 32x32x16 bf16 on 4-bit tiles unpacked in registers; >= 320 rows the 256x256 / 128x128 bf16 tile kernels (MFMA 16x16x32; SwiGLU and q/k-norm + RoPE in their epilogues) on RESIDENT bf16 copies of the layer matrices (dequantised by the first such prompt, kept in HBM); flash attention tile",
             "first_call_ms": round(first_ms, 3), "resident_copy_bytes": m.resident_bytes(),
             "token_serial_ms": round(decode_ms_per_step * n, 3),
             "roofline": {"flops": int(flops), "bytes": int(nbytes), "achieved_TFLOPs": round(tf, 2), "mfma_peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS, "mfma_frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),

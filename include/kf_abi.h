@@ -375,7 +375,7 @@ int kf_adamw(kf_ctx* ctx, kf_bf16* params, kf_bf16* grads, void* gm, void* gv, s
  * NeuronFuse.cu:692-731, rope.cu).  These entries run the same per-token arithmetic for n_tok consecutive positions at once;
  * kf_linear / kf_rmsnorm / kf_swiglu already take row batches. */
 /* n_w <= 3 matrices that share the input rows x [nTok, ne1] (Q, K, V): y[i] [nTok, w[i]->ne0].  One launch when a tile kernel
- * covers the shape, otherwise kf_linear per matrix.  Batches of >= 1024 rows of group-quantised matrices whose row counts are multiples of
+ * covers the shape, otherwise kf_linear per matrix.  Batches of >= 1024 rows (>= 320 with resident copies, kf_set_dequant_arena) of group-quantised matrices whose row counts are multiples of
  * 256 are dequantised back to back into the kf_set_scratch workspace (kf_linear_multi_scratch_bytes says how large; 0 = route not taken)
  * and multiplied by ONE launch of the 256 x 256 bf16 tile kernel -- the reference's own order (GetDataX, then the GEMM); its fp32 summation
  * order differs from the in-register-unpack kernels of smaller batches, as kf_linear's own large-batch path does. */
@@ -383,7 +383,7 @@ size_t kf_linear_multi_scratch_bytes(int n_w, const kf_weight* const* w, int nTo
 int kf_linear_multi(kf_ctx* ctx, int n_w, const kf_weight* const* w, const kf_bf16* x, kf_bf16* const* y, int nTok);
 /* act [nTok, ne0] = silu(x . gate^T) * (x . up^T) for nTok rows (FFN::cuFlow: gate.Forw, up.Forw, Relu::Forw SWIG,
  * NeuronFuse.cu:615-656 with a batch): one launch, bit-identical to kf_linear x 2 + kf_swiglu; up_scratch [nTok, ne0] is used by
- * the unfused fallback and by the large-batch route (>= 1024 rows: gate | up stacked as in kf_linear_multi, then kf_swiglu). */
+ * the unfused fallback and by the large-batch route (>= 1024 rows, >= 320 with resident copies: gate | up interleaved, SwiGLU in the tile GEMM's epilogue; or stacked as in kf_linear_multi, then kf_swiglu). */
 int kf_gateup_swiglu_batch(kf_ctx* ctx, const kf_weight* gate, const kf_weight* up, const kf_bf16* x, kf_bf16* act, kf_bf16* up_scratch, int nTok);
 /* out[t] = row d_tokens[t] of the table, t < n_tok (TokenEmbed::OnEmbed for a batch, NeuronFuse.cu:176-207) */
 int kf_embed_batch(kf_ctx* ctx, const kf_weight* w, const int32_t* d_tokens, int n_tok, kf_bf16* out);
@@ -391,7 +391,7 @@ int kf_embed_batch(kf_ctx* ctx, const kf_weight* w, const int32_t* d_tokens, int
 int kf_qknorm_rope_batch(kf_ctx* ctx, kf_bf16* q, kf_bf16* k, const kf_bf16* wq_norm, const kf_bf16* wk_norm, const float* rope_table, int pos0, int n_tok,
                          int64_t q_stride, int64_t k_stride, int n_head, int n_kv, int hd, float eps);
 /* SelfAttention::cuFlow's projection step for a token batch in one call: Q | K | V of the same x (K / V rows may be the cache rows themselves, TGraph.cpp:198-207) followed by
- * ROPE::cuInfer on q and k (kf_qknorm_rope_batch).  For >= 1024 tokens and head_dim 128 both happen in ONE launch -- the stacked tile GEMM with the q/k-norm and the rotation in
+ * ROPE::cuInfer on q and k (kf_qknorm_rope_batch).  For >= 1024 tokens (>= 320 with resident copies) and head_dim 128 both happen in ONE launch -- the stacked tile GEMM with the q/k-norm and the rotation in
  * its epilogue (a 128-row tile is one head) -- otherwise kf_linear_multi + kf_qknorm_rope_batch.  Same arithmetic either way (token batches: MFMA summation order, tolerances). */
 int kf_qkv_rope_batch(kf_ctx* ctx, const kf_weight* wq, const kf_weight* wk, const kf_weight* wv, const kf_bf16* x, kf_bf16* q, kf_bf16* k, kf_bf16* v, int nTok,
                       const kf_bf16* wq_norm_or_null, const kf_bf16* wk_norm_or_null, const float* rope_table_or_null, int pos0, int n_head, int n_kv, int head_dim, float eps);

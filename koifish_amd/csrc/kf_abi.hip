@@ -376,7 +376,7 @@ int kf_linear(kf_ctx* c, const kf_weight* w, const kf_bf16* x, kf_bf16* y, const
         return kf_linear(c, &wb, x, y, bias, nTok, alpha, beta, epilogue, residual);
     }
     if (c->arena && nTok >= kf::g_knobs.resident_min && w->type != KF_BF16 && w->quant == KF_QUANT_GROUP && w->ne0 >= 128 && (w->ne1 % 64) == 0) {
-        // a resident copy (kf_set_dequant_arena): nothing to dequantise -- the bf16 tile kernels of kf_gemm3.hip from 1024 token rows (the 1024-row o_proj / down_proj of a
+        // a resident copy (kf_set_dequant_arena): nothing to dequantise -- the bf16 tile kernels of kf_gemm3.hip from g_knobs.resident_min token rows (the 1024-row o_proj / down_proj of a
         // long prompt as 256 tiles of 64 x 128 or 64 x 64)
         const kf_weight* one[1] = {w};
         const uint16_t* W = nullptr;
