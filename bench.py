@@ -56,6 +56,7 @@ def main():
                     "(the per-rank kernels and the exchange kernels of TP = R, serialised: R x the work of one rank's GPU, no xGMI)")
     ap.add_argument("--tp-layers", type=int, default=0, help="with --tp-virtual: this many of the model's layers (0 = all): bounds the side leg's wall time")
     ap.add_argument("--lean-cpu", type=float, default=0.0, help="with --lean: also the CPU-baseline leg (parity passes + a timed sample of this many seconds) of the model being run")
+    ap.add_argument("--lean-prefill", type=int, default=0, help="with --lean: also a prompt of this many tokens through Fish::Prefill (prefill_rate)")
     ap.add_argument("--lean", action="store_true", help="only the timed decode and step_roofline (what the side legs run in their child processes)")
     ap.add_argument("--leg", default="", choices=["", "config3", "config4cpu"], help="run ONE side leg and print its JSON (child processes of the main run)")
     ap.add_argument("--side-legs", default="config3,config5,config4", help="side objects beside the line, each measured in a child process after the main measurements "
@@ -236,6 +237,12 @@ def main():
                     out["cpu_baseline"] = cpu_baseline(m, cfg, forced, args.lean_cpu, min_steps=16, max_steps=96, canon_steps=24, hots=hots)
                 except Exception as e:
                     out["cpu_baseline"] = {"error": repr(e)[:300]}
+            if args.lean_prefill > 0 and world == 1:
+                try:
+                    lp = np.random.default_rng(7).integers(0, cfg["vocab"], size=min(args.lean_prefill, S - 1)).astype(np.int32)
+                    out["prefill"] = prefill_rate(m, lp, ms_per_step, reps=2, bound="mfma: 5-25 k row matrices on 256 x 256 bf16 tiles (resident copies) + flash attention")
+                except Exception as e:
+                    out["prefill"] = {"error": repr(e)[:200]}
             print(json.dumps(out))
             return
         out["prefill"] = prefill_rate(m, forced[:n_prompt], ms_per_step)
@@ -332,12 +339,13 @@ def side_legs(which):
             "summation_order": d["config"].get("summation_order"), "cpu_baseline": d.get("cpu_baseline"), "engine_handoffs": d.get("engine_handoffs"),
             "decode_path": d["config"]["decode_path"], "profile": "profiles/r04_config5_sparse_1bit_kernel_stats.csv", "leg_wall_s": d.get("leg_wall_s")}
     if "config4" in which:
-        d = _child(["--config", "qwen3-32b", "--steps", "64", "--warmup", "16", "--lean"], 600)
+        d = _child(["--config", "qwen3-32b", "--steps", "64", "--warmup", "16", "--lean", "--lean-prefill", "2047"], 600)
         out["config4_one_gpu"] = d if "error" in d else {
             "workload": "Qwen3-32B 4-bit PackedQ greedy decode on ONE MI355X (the reference shards it over 8 GPUs for memory): %s" % d["config"]["workload"].split("seq=")[-1],
             "tokens_per_s": d["value"], "ms_per_step": d["ms_per_step"], "bytes_per_step": d["step_roofline"]["bytes_per_step"], "frac": d["step_roofline"]["frac"],
             "fast_order_tokens_per_s": d.get("fast_order_mode", {}).get("tokens_per_s"),
             "decode_path": d["config"]["decode_path"], "profile": "profiles/r04_config4_one_gpu_kernel_stats.csv", "leg_wall_s": d.get("leg_wall_s"),
+            "prefill_2047_tokens": {k: (d.get("prefill") or {}).get(k) for k in ("ms", "tokens_per_s", "first_call_ms", "resident_copy_bytes", "roofline", "error") if (d.get("prefill") or {}).get(k) is not None},
             "cpu_baseline_4_layer_slice": _child(["--leg", "config4cpu"], 420),
             "tp8_virtual_ranks": _tp_virtual_leg(),
             "note": "TP = 8 over xGMI needs an 8-GPU node: bench.py --config qwen3-32b --gpus 8 (no scaling curve has been measured on hardware)"}
