@@ -41,6 +41,8 @@ using G3Small = G3Cfg<128, 128, 4>;
 // 64 KiB partials per tile through memory) get MORE, SMALLER tiles instead of k-pieces: 64 x 128 (48 KiB of LDS: three workgroups per CU) and 64 x 64 (32 KiB: five)
 using G3Mid = G3Cfg<64, 128, 4>;
 using G3Tiny = G3Cfg<64, 64, 4>;
+// 192 x 256: a product whose 256 x 256 tiles number 160-255 (gate | up of a 0.6B model at 2047 tokens: 24 x 8 = 192 tiles on 256 CUs) becomes 32 x 8 = 256 tiles of 3/4 the work
+using G3Wide = G3Cfg<192, 256, 8>;
 
 // one operand tile (256 rows x 2 BK bytes) = BK / 2 wave instructions of 1 KiB; wave `wid` issues BK / 16 of them.  BK = 64: 8 rows per instruction, chunk c of row r
 // at position c ^ ((r >> 1) & 7); BK = 32: 16 rows per instruction (64-byte rows), chunk c at position c ^ ((r >> 2) & 3) -- either way a fragment read
@@ -625,6 +627,8 @@ int gemm3_swiglu_launch(hipStream_t st, const uint16_t* Wilv, int ffn, int K, co
     const long nwg = (long)(M / G3_BM) * ((n + G3_BN - 1) / G3_BN);
     if (nwg < 64 && (long)(M / 128) * ((n + 127) / 128) < 64) return 1;
     if (nwg < 160) return g3_go_c<false, false, G3Small>(st, a, (long)(M / 128) * ((n + 127) / 128), nullptr, 0, 1);
+    if (g_knobs.g3_wide && nwg < 256 && M % 192 == 0 && (long)(M / 192) * ((n + G3_BN - 1) / G3_BN) <= 256)
+        return g3_go_c<false, false, G3Wide>(st, a, (long)(M / 192) * ((n + G3_BN - 1) / G3_BN), nullptr, 0, 1);
     return g3_go<false, false>(st, a, nwg, nullptr, 0);
 }
 
