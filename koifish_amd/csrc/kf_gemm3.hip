@@ -550,7 +550,7 @@ int gemm3_launch(hipStream_t st, int fmt, const GemmArgs& a, void* ws, size_t ws
         // with the caller's workspace these go in k-pieces when even the small tiles leave CUs idle (1024 rows x K 2048-3072 at 512 tokens: 128 tiles of 64 x 64, each a
         // 32-48 step k-loop of ~0.7 us per step on its own CU: 31 us; a 16 KiB partial per piece is cheap where the 64 KiB ones of the 128 x 128 tile were not)
         const long nmid = (long)((a.M + 63) / 64) * ((a.n + 127) / 128);
-        if (nmid >= 192 || g_knobs.g3_tiles < 3) return nmid >= 64 ? g3_go_c<false, false, G3Mid>(st, a, nmid, ws, ws_bytes, 64) : 1;
+        if (nmid >= g_knobs.g3_mid_min || g_knobs.g3_tiles < 3) return nmid >= 64 ? g3_go_c<false, false, G3Mid>(st, a, nmid, ws, ws_bytes, 64) : 1;
         return g3_go_c<false, false, G3Tiny>(st, a, (long)((a.M + 63) / 64) * ((a.n + 63) / 64), ws, ws_bytes, 64);
     }
     return g3_go_c<false, false, G3Small>(st, a, nwg, nullptr, 0, 128);
@@ -626,9 +626,11 @@ int gemm3_swiglu_launch(hipStream_t st, const uint16_t* Wilv, int ffn, int K, co
     a.w = reinterpret_cast<const unsigned char*>(Wilv), a.M = M, a.K = K, a.x = x, a.ldx = ldx, a.n = n, a.y = act, a.ldy = ffn, a.alpha = 1.0f, a.beta = 0.0f;
     const long nwg = (long)(M / G3_BM) * ((n + G3_BN - 1) / G3_BN);
     if (nwg < 64 && (long)(M / 128) * ((n + 127) / 128) < 64) return 1;
-    if (nwg < 160) return g3_go_c<false, false, G3Small>(st, a, (long)(M / 128) * ((n + 127) / 128), nullptr, 0, 1);
-    if (g_knobs.g3_wide && nwg < 256 && M % 192 == 0 && (long)(M / 192) * ((n + G3_BN - 1) / G3_BN) <= 256)
-        return g3_go_c<false, false, G3Wide>(st, a, (long)(M / 192) * ((n + G3_BN - 1) / G3_BN), nullptr, 0, 1);
+    const long nws = (long)(M / 128) * ((n + 127) / 128), nww = (long)(M / 192) * ((n + G3_BN - 1) / G3_BN);
+    const bool wide_ok = g_knobs.g3_wide && M % 192 == 0 && nww <= 256;
+    // fewer than 160 big tiles: four times as many 128 x 128 ones -- unless those spill into a second round of the 512 resident workgroups and the 192 x 256 ones make one round
+    if (nwg < 160 && !(wide_ok && nws > 512 && nww >= 160)) return g3_go_c<false, false, G3Small>(st, a, nws, nullptr, 0, 1);
+    if (wide_ok && nwg < 256) return g3_go_c<false, false, G3Wide>(st, a, nww, nullptr, 0, 1);
     return g3_go<false, false>(st, a, nwg, nullptr, 0);
 }
 

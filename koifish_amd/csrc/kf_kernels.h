@@ -147,6 +147,7 @@ struct Knobs {
     int resident_min = 320;  /* token rows from which the token-batch routes use RESIDENT dequantised copies (kf_set_dequant_arena) + the bf16 tile kernels; without an arena: 1024 */
     int attn_pair_min = 256;  /* prompt tokens from which kf_attn_prefill takes its paired two-key-half form (when there is about one workgroup per CU or fewer) */
     int g3_wide = 1;      /* gate | up + SwiGLU on 192 x 256 tiles when the 256 x 256 ones would leave CUs idle */
+    int g3_mid_min = 192; /* 64 x 128 tiles from this many of them, 64 x 64 below */
     int g3_first = 256;   /* token rows from which bf16 operands try the kf_gemm3.hip tile kernels before the 32 x 32 direct kernel */
     int q1_tab = 1;       /* 1-bit mat-vec through the LDS selector table (0: the per-bit select form; same bits) */
     long gemv_waves = 0;  /* > 0: waves a mat-vec launch aims for (0: the launcher's rule) */
