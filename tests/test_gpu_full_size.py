@@ -203,3 +203,29 @@ def test_full_size_long_prompt_on_resident_copies_vs_the_scratch_route(model):
             assert abs(f0[nxt0] - f0[nxt1]) <= 2 * 2.0 ** -6 * np.abs(f0).max()
     finally:
         m.set_prefill_resident(True)
+
+
+def test_resident_copy_routes_on_32b_shaped_layers():
+    """Two layers of the Qwen3-32B shape (5120 wide, 64 / 8 heads, ffn 25600: the 256 x 256 and 192 x 256 tiles, GQA 8 in the prompt attention): a 1100-token prompt on the
+    resident bf16 copies against the same prompt with a dequantise per call -- logits within the token-batch tolerance, the greedy id equal unless a near-tie, the copies'
+    size = 2 bytes per layer weight."""
+    cfg = dict(synth.CONFIGS["qwen3-32b"])
+    cfg["n_layer"] = 2
+    m = synth.build_on_gpu(cfg, seed=99, layer_type=L.Q4, head_type=L.BF16)
+    try:
+        prompt = np.random.default_rng(13).integers(0, cfg["vocab"], size=1100)
+        m.set_prefill_resident(False)
+        nxt0, lg0 = m.prefill(prompt)
+        assert m.resident_bytes() == 0
+        m.set_prefill_resident(True)
+        nxt1, lg1 = m.prefill(prompt)
+        assert m.resident_bytes() == 2 * sum(w.ne0 * w.ne1 for (layer, slot), w in m.weights.items() if layer >= 0)
+        nxt2, lg2 = m.prefill(prompt)
+        assert nxt2 == nxt1 and np.array_equal(lg1, lg2)
+        f0, f1 = O.bf16_to_f32(lg0), O.bf16_to_f32(lg1)
+        assert np.abs(f0 - f1).max() <= 2.0 ** -6 * np.abs(f0).max()
+        if nxt1 != nxt0:
+            assert abs(f0[nxt0] - f0[nxt1]) <= 2 * 2.0 ** -6 * np.abs(f0).max()
+        assert nxt1 == O.argmax_bf16(lg1)
+    finally:
+        m.close()
