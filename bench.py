@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--lean-prefill", type=int, default=0, help="with --lean: also a prompt of this many tokens through Fish::Prefill (prefill_rate)")
     ap.add_argument("--lean", action="store_true", help="only the timed decode and step_roofline (what the side legs run in their child processes)")
     ap.add_argument("--leg", default="", choices=["", "config3", "config4cpu"], help="run ONE side leg and print its JSON (child processes of the main run)")
-    ap.add_argument("--side-legs", default="config3,config5,config4", help="side objects beside the line, each measured in a child process after the main measurements "
+    ap.add_argument("--side-legs", default="config3,config5,config4,qwen3_1p7b", help="side objects beside the line, each measured in a child process after the main measurements "
                     "(never `value`): config3 = GPT2-1558M operator path of a training step (sum of separately timed forward+loss, backward, AdamW phases; no parameter update), config5 = 1-bit layers + 20 %% hot FFN rows, config4 = Qwen3-32B on ONE GPU; '' = none")
     args = ap.parse_args()
     if args.leg == "config3":
@@ -187,7 +187,7 @@ def main():
                       "1bit": "1-bit weights (PackedQ YinYang g128)", "nf4": "u4 weights (NF4 row codebooks)"}[args.layers] + " x bf16 activations, fp32 accumulate; bf16 KV",
             "data": "synthetic",
             "config": {"workload": "%s %s greedy decode, 1xMI355X per replica, seq=%d: prompt 128, timed positions %d..%d"
-                                   % ({"qwen3-0.6b": "Qwen3-0.6B", "qwen3-32b": "Qwen3-32B"}.get(args.config, args.config), {"q4": "4-bit PackedQ", "bf16": "bf16", "f8": "f8e5m2", "ternary": "2-bit ternary PackedQ", "1bit": "1-bit PackedQ", "nf4": "4-bit NF4 row-codebook"}[args.layers],
+                                   % ({"qwen3-0.6b": "Qwen3-0.6B", "qwen3-32b": "Qwen3-32B", "qwen3-1.7b": "Qwen3-1.7B"}.get(args.config, args.config), {"q4": "4-bit PackedQ", "bf16": "bf16", "f8": "f8e5m2", "ternary": "2-bit ternary PackedQ", "1bit": "1-bit PackedQ", "nf4": "4-bit NF4 row-codebook"}[args.layers],
                                       S, timed_positions[0], timed_positions[-1]),
                        "lm_head": args.head, "sparse_ffn_rows_hot": args.sparse if args.sparse > 0 else None, "replicas": world,
                        "hipgraph": bool(use_graph and m.num_graphs() > 0),  # a step that is ONE launch (the engine with head and pick) is launched directly: a one-node graph only adds replay cost
@@ -338,6 +338,14 @@ def side_legs(which):
             "fast_order_tokens_per_s": d.get("fast_order_mode", {}).get("tokens_per_s"),
             "summation_order": d["config"].get("summation_order"), "cpu_baseline": d.get("cpu_baseline"), "engine_handoffs": d.get("engine_handoffs"),
             "decode_path": d["config"]["decode_path"], "profile": "profiles/r04_config5_sparse_1bit_kernel_stats.csv", "leg_wall_s": d.get("leg_wall_s")}
+    if "qwen3_1p7b" in which:   # not a BASELINE configuration: the second model shape the persistent engine is instantiated for (round 4)
+        d = _child(["--config", "qwen3-1.7b", "--steps", "64", "--warmup", "16", "--lean"], 420)
+        e = _child(["--config", "qwen3-1.7b", "--steps", "64", "--warmup", "16", "--lean", "--engine", "0"], 420)
+        out["qwen3_1p7b_shape"] = d if "error" in d else {
+            "workload": "Qwen3-1.7B shape (dim 2048, 16 / 8 heads of 128, ffn 6144), 4-bit PackedQ greedy decode: %s" % d["config"]["workload"].split("seq=")[-1],
+            "tokens_per_s": d["value"], "ms_per_step": d["ms_per_step"], "bytes_per_step": d["step_roofline"]["bytes_per_step"], "frac": d["step_roofline"]["frac"],
+            "fast_order_tokens_per_s": d.get("fast_order_mode", {}).get("tokens_per_s"), "decode_path": d["config"]["decode_path"],
+            "per_layer_launches_tokens_per_s": e.get("value"), "per_layer_launches_ms_per_step": e.get("ms_per_step"), "leg_wall_s": d.get("leg_wall_s")}
     if "config4" in which:
         d = _child(["--config", "qwen3-32b", "--steps", "64", "--warmup", "16", "--lean", "--lean-prefill", "2047"], 600)
         out["config4_one_gpu"] = d if "error" in d else {

@@ -43,7 +43,7 @@
 
 namespace kf {
 
-constexpr int ENG_MAXLD = 16;             /* 1 KiB granule pieces (256 values) per sweep: vectors up to 4096 */
+constexpr int ENG_MAXLD = 24;             /* 1 KiB granule pieces (256 values) per sweep: vectors up to 6144 (Qwen3-1.7B's ffn) */
 constexpr int ENG_NWG = 256, ENG_NWV = 8; /* MI355X: 256 CUs, one 8-wave workgroup each (7 compute waves + the poller) */
 constexpr int ENG_SPIN_MAX = 1 << 17;     /* sweeps before a poll gives up (~0.1 s): sets the error word, never hangs */
 
@@ -423,6 +423,12 @@ __device__ __forceinline__ void mv_prefetch(const EngMat m, const EngMat m2, int
 #ifndef ENG_P1_SHARE
 #define ENG_P1_SHARE 1 /* the poller wave computes one of the workgroup's P1 row slots (0: seven waves, wave 0 takes two slots -- its second block of pair words costs 16 more registers and spills) */
 #endif
+#ifndef ENG_AH_REGS
+#define ENG_AH_REGS 64 /* registers of dequantised pair words a lane may hold across a hand-off (MvPhase::AH) */
+#endif
+#ifndef ENG_AH_REGS_WIDE
+#define ENG_AH_REGS_WIDE 16 /* the same for the 2048-wide shape, whose raw blocks in flight take 72 registers */
+#endif
 #ifndef ENG_COOP
 #define ENG_COOP 1 /* the norm-free vectors (ao, act) are swept by all eight waves */
 #endif
@@ -433,10 +439,12 @@ template <bool PAIRED, int MAXS>
 struct MvDeq {
     uint32_t p[MAXS][16], p2[PAIRED ? MAXS : 1][16];
 };
-template <class PL, int NCW, int FMT, int MAXS>
-__device__ __forceinline__ void mv_dequant(float qb, float qb2, int cw, int lane, const MvRegs<PL::PAIRED, MAXS>& R, MvDeq<PL::PAIRED, MAXS>& D, const u32x4* tab) {
+// AH <= MAXS: the wave's first AH blocks are dequantised ahead of the barrier (D), the others behind it, block by block in front of their products (shapes whose blocks per
+// lane do not fit the register file as pair words: Qwen3-1.7B's gate | up and down_proj phases hold 8 and 6 blocks per lane)
+template <class PL, int NCW, int FMT, int MAXS, int AH>
+__device__ __forceinline__ void mv_dequant(float qb, float qb2, int cw, int lane, const MvRegs<PL::PAIRED, MAXS>& R, MvDeq<PL::PAIRED, AH>& D, const u32x4* tab) {
 #pragma unroll
-    for (int k = 0; k < MAXS; k++) {
+    for (int k = 0; k < AH; k++) {
         if (cw + (k / PL::iters) * NCW >= PL::spg) continue; /* wave-uniform: this wave has no such slot */
         const float st = bf2f(R.st[k]);
         BlockPrep<FMT>::prep(R.w[k], st, bf2f(R.ze[k]), -(qb * st), lane, D.p[k], tab);
@@ -451,8 +459,9 @@ __device__ __forceinline__ void mv_dequant(float qb, float qb2, int cw, int lane
     }
 }
 // mv_run on dequantised blocks: the same lanes, chains and tree
-template <class PL, int NCW, int MAXS, bool CANON, typename Epi>
-__device__ __forceinline__ void mv_run_deq(int s0, int cw, int lane, int Mj, const MvDeq<PL::PAIRED, MAXS>& D, const u32x4* xs, uint32_t hotbits, Epi&& epi) {
+template <class PL, int NCW, int FMT, int MAXS, int AH, bool CANON, typename Epi>
+__device__ __forceinline__ void mv_run_deq(int s0, int cw, int lane, int Mj, const MvDeq<PL::PAIRED, AH>& D, const MvRegs<PL::PAIRED, MAXS>& R, float qb, float qb2, const u32x4* tab,
+                                           const u32x4* xs, uint32_t hotbits, Epi&& epi) {
     acc_t<CANON> acc{}, acc2{};
 #pragma unroll
     for (int k = 0; k < MAXS; k++) {
@@ -462,12 +471,28 @@ __device__ __forceinline__ void mv_run_deq(int s0, int cw, int lane, int Mj, con
         const int col = q.col < PL::nBlk ? q.col : PL::nBlk - 1;
         if (it == 0) acc = acc_t<CANON>{}, acc2 = acc_t<CANON>{};
         const bool on = q.ok && ((hotbits >> ((q.row - s0 * PL::RPS) & 31)) & 1u);
-        const acc_t<CANON> r = pairs_dot<CANON>(D.p[k], xs, col, PL::nBlk, acc);
-        acc = acc_pick(on, r, acc);
-        if (PL::PAIRED) {
-            const acc_t<CANON> r2 = pairs_dot<CANON>(D.p2[k], xs, col, PL::nBlk, acc2);
-            acc2 = acc_pick(on, r2, acc2);
+        acc_t<CANON> r, r2{};
+        if constexpr (AH == MAXS) {
+            r = pairs_dot<CANON>(D.p[k], xs, col, PL::nBlk, acc);
+            if (PL::PAIRED) r2 = pairs_dot<CANON>(D.p2[k], xs, col, PL::nBlk, acc2);
+        } else {
+            if (k < AH) {
+                r = pairs_dot<CANON>(D.p[k < AH ? k : 0], xs, col, PL::nBlk, acc);
+                if (PL::PAIRED) r2 = pairs_dot<CANON>(D.p2[PL::PAIRED && k < AH ? k : 0], xs, col, PL::nBlk, acc2);
+            } else { /* this block's pair words now (the same BlockPrep: same bits) */
+                uint32_t pw[16];
+                const float st = bf2f(R.st[k]);
+                BlockPrep<FMT>::prep(R.w[k], st, bf2f(R.ze[k]), -(qb * st), lane, pw, tab);
+                r = pairs_dot<CANON>(pw, xs, col, PL::nBlk, acc);
+                if (PL::PAIRED) {
+                    const float st2 = bf2f(R.st2[k]);
+                    BlockPrep<FMT>::prep(R.w2[k], st2, bf2f(R.ze2[k]), -(qb2 * st2), lane, pw, tab);
+                    r2 = pairs_dot<CANON>(pw, xs, col, PL::nBlk, acc2);
+                }
+            }
         }
+        acc = acc_pick(on, r, acc);
+        if (PL::PAIRED) acc2 = acc_pick(on, r2, acc2);
         if (it == PL::iters - 1) {
             const float v = group_sum(acc_join(acc), PL::lpr_log2);
             float v2 = 0.f;
@@ -480,11 +505,18 @@ __device__ __forceinline__ void mv_run_deq(int s0, int cw, int lane, int Mj, con
 // One mat-vec phase of a wave: its blocks are dequantised into bf16 pair words ahead of the hand-off (ahead) and multiplied behind it (run).  tab: the 1-bit selector table
 template <class C, class PL, int NCW, int MAXS>
 struct MvPhase {
-    MvDeq<PL::PAIRED, MAXS> d;
-    __device__ __forceinline__ void ahead(float qb, float qb2, int cw, int lane, const MvRegs<PL::PAIRED, MAXS>& R, const u32x4* tab) { mv_dequant<PL, NCW, C::FMT, MAXS>(qb, qb2, cw, lane, R, d, tab); }
+    // blocks dequantised ahead: all of them while a lane holds at most ENG_AH_REGS registers of pair words (16 per block, 32 per gate | up pair); Qwen3-0.6B: every phase
+    static constexpr int PER = PL::PAIRED ? 32 : 16, AH0 = C::AHR / PER, AH = MAXS <= AH0 ? MAXS : (AH0 < 1 ? 1 : AH0);
+    MvDeq<PL::PAIRED, AH> d;
+    float qb_, qb2_;
+    const u32x4* tab_;
+    __device__ __forceinline__ void ahead(float qb, float qb2, int cw, int lane, const MvRegs<PL::PAIRED, MAXS>& R, const u32x4* tab) {
+        qb_ = qb, qb2_ = qb2, tab_ = tab;
+        mv_dequant<PL, NCW, C::FMT, MAXS, AH>(qb, qb2, cw, lane, R, d, tab);
+    }
     template <typename Epi>
-    __device__ __forceinline__ void run(int s0, int cw, int lane, int Mj, const u32x4* xs, uint32_t hotbits, Epi&& epi) {
-        mv_run_deq<PL, NCW, MAXS, C::CANON>(s0, cw, lane, Mj, d, xs, hotbits, epi);
+    __device__ __forceinline__ void run(int s0, int cw, int lane, int Mj, const u32x4* xs, uint32_t hotbits, const MvRegs<PL::PAIRED, MAXS>& R, Epi&& epi) {
+        mv_run_deq<PL, NCW, C::FMT, MAXS, AH, C::CANON>(s0, cw, lane, Mj, d, R, qb_, qb2_, tab_, xs, hotbits, epi);
     }
 };
 
@@ -537,6 +569,7 @@ template <int FMT_, int GQ_, int HD_, int NWV_, int DIM_, int QD_, int KVD_, int
 struct EngCfg {
     static constexpr int FMT = FMT_, GQ = GQ_, HD = HD_, NWV = NWV_, DIM = DIM_, QD = QD_, KVD = KVD_, FFN = FFN_, NWG = NWG_;
     static constexpr bool XMAP = XMAP_, DBG = DBG_;
+    static constexpr int AHR = DIM_ > 1024 ? ENG_AH_REGS_WIDE : ENG_AH_REGS; /* MvPhase::AH: registers of pair words held across a hand-off */
     // CANON: the mat-vec phases and the head in the canonical order (one v_fma_f32 per product on fp32 operands: bit-exact against the oracle); false: v_dot2c_f32_bf16 on
     // bf16 pairs (kf_set_canonical(ctx, 0): <= 1 bf16 ulp per output from the oracle, fewer vector instructions).  The attention is canonical either way.
     static constexpr bool CANON = CANON_;
@@ -832,7 +865,7 @@ __device__ __forceinline__ void eng_poller_main(const EngArgs& a, const EngLds& 
         ENG_STAMP(0, 1);
         __syncthreads();
         if (P1_SHARE && has1) { /* this wave's P1 rows, then the workgroup's publish like every other owner */
-            w1.run(S.s1, NWV - 1, lane, S.M1, L.xs[0], 0xffffffffu, [&](int row, float v, float) { L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); });
+            w1.run(S.s1, NWV - 1, lane, S.M1, L.xs[0], 0xffffffffu, r1, [&](int row, float v, float) { L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); });
             if (XMAP)
                 wg_publish(L, 0, eng_lqkv<C>(a, S.xcc), S.q_out0, P1::R, NWP1, lane, true);
             else
@@ -1063,7 +1096,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 0);
         mv_prefetch<P4, NCW, FMT, S4>(ly.m[3], ly.m[3], wg * P4::spg, wave, lane_m, P4::M0, r4);
-        w1.run(S.s1, wave, lane_m, S.M1, L.xs[0], 0xffffffffu, [&](int row, float v, float) { L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); });
+        w1.run(S.s1, wave, lane_m, S.M1, L.xs[0], 0xffffffffu, r1, [&](int row, float v, float) { L.outb[row - row0_1] = (tag << 16) | (uint32_t)f2bf(v); });
         if (has1 && wave < NWP1) {
             if (XMAP)
                 wg_publish(L, 0, eng_lqkv<C>(a, S.xcc), S.q_out0, P1::R, NWP1, lane_m, true);
@@ -1099,7 +1132,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         if (wave == 0) ENG_STAMP(1, 4);
         const uint32_t hot5 = L.hotbits[l]; /* the sparse forward's mask of this workgroup's gate / up rows (all ones: dense) */
         mv_prefetch<P5, NCW, FMT, S5>(ly.m[4], ly.m[5], wg * P5::spg, wave, lane_m, P5::M0, r5, hot5);
-        w4.run(wg * P4::spg, wave, lane_m, P4::M0, L.xs[1], 0xffffffffu, [&](int row, float v, float) {
+        w4.run(wg * P4::spg, wave, lane_m, P4::M0, L.xs[1], 0xffffffffu, r4, [&](int row, float v, float) {
             const uint16_t o = f2bf(v);
             L.outb[row - wg * P4::R] = (tag << 16) | (uint32_t)f2bf(bf2f(L.xrawA[row]) + bf2f(o)); /* CU_add3: bf16(x + bf16(W.x)) */
         });
@@ -1111,7 +1144,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 6);
         mv_prefetch<P6, NCW, FMT, S6>(ly.m[6], ly.m[6], wg * P6::spg, wave, lane_m, P6::M0, r6);
-        w5.run(wg * P5::spg, wave, lane_m, P5::M0, L.xs[0], L.hotbits[l], [&](int row, float v, float v2) {
+        w5.run(wg * P5::spg, wave, lane_m, P5::M0, L.xs[0], L.hotbits[l], r5, [&](int row, float v, float v2) {
             const float gt = round_bf16(v), up = round_bf16(v2); /* CU_swiglu_v0 on the two bf16-rounded projections */
             L.outb[row - wg * P5::R] = (tag << 16) | (uint32_t)f2bf((gt * up) / (1.0f + kf_expf(-gt)));
         });
@@ -1127,7 +1160,7 @@ __device__ __forceinline__ void eng_compute_main(const EngArgs& a, const EngLds&
         __syncthreads();
         if (wave == 0) ENG_STAMP(1, 8);
         mv_prefetch<P1, NCW1, FMT, S1>(mat1(ln), mat1(ln), S.s1, wave, lane_m, S.M1, r1);
-        w6.run(wg * P6::spg, wave, lane_m, P6::M0, L.xs[1], 0xffffffffu, [&](int row, float v, float) {
+        w6.run(wg * P6::spg, wave, lane_m, P6::M0, L.xs[1], 0xffffffffu, r6, [&](int row, float v, float) {
             const uint16_t o = f2bf(v);
             const uint16_t y = f2bf(bf2f(L.xrawB[row]) + bf2f(o));
             if (last) a.x_out[row] = y;
@@ -1472,6 +1505,7 @@ struct EngineHost {
 static int engine_shape_class(int GQ, int hd, int dim, int q_dim, int ffn) { /* kv_dim = q_dim / GQ */
     if (GQ == 2 && hd == 128 && dim == 1024 && q_dim == 2048 && ffn == 3072) return 1; /* Qwen3-0.6B (BASELINE config 2) */
     if (GQ == 2 && hd == 64 && dim == 256 && q_dim == 256 && ffn == 512) return 2;     /* the small parity-test shape */
+    if (GQ == 2 && hd == 128 && dim == 2048 && q_dim == 2048 && ffn == 6144) return 3;  /* Qwen3-1.7B: the 0.6B head geometry on a 2048-wide stream (4-bit register-table storage only) */
     return 0;
 }
 static_assert(sizeof(EngPlan) == 80 && sizeof(EngLayer) == 224, "device table strides");
@@ -1558,7 +1592,7 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
     if ((hd != 64 && hd != 128) || d->n_kv <= 0 || d->n_head % d->n_kv != 0) return KF_UNSUPPORTED_DATATYPE;
     const int GQ = d->n_head / d->n_kv;
     const int shape_class = engine_shape_class(GQ, hd, d->dim, d->n_head * hd, d->ffn);
-    *why = "model shape not instantiated: the engine's phase plans are compile-time types; built for Qwen3-0.6B (dim 1024, 16/8 heads of 128, ffn 3072) and the 256-wide test shape (dim 256, 4/2 heads of 64, ffn 512)";
+    *why = "model shape not instantiated: the engine's phase plans are compile-time types; built for Qwen3-0.6B (dim 1024, 16/8 heads of 128, ffn 3072), Qwen3-1.7B (dim 2048, same heads, ffn 6144; 4-bit layers) and the 256-wide test shape (dim 256, 4/2 heads of 64, ffn 512)";
     if (!shape_class) return KF_UNSUPPORTED_DATATYPE; /* not one of the instantiated model shapes: the per-layer launches remain */
     int dev = 0, n_cu = 0;
     *why = "HIP failure";
@@ -1630,17 +1664,22 @@ int engine_build(const kf_engine_desc* d, void* ws, size_t ws_bytes, hipStream_t
         tab[l].kcache = (g_u16w)(uintptr_t)L.kcache, tab[l].vcache = (g_u16w)(uintptr_t)L.vcache;
         tab[l].hot = (g_i32)(uintptr_t)L.hot_ffn;
     }
+    if (fmt == FMT_Q4 && q4p_ok) fmt = FMT_Q4P;
+    if (fmt == FMT_Q1) fmt = FMT_Q1T; /* the LDS selector-table forms (same bits as the per-bit select forms) */
+    if (fmt == FMT_Q2) fmt = FMT_Q2T;
+    if (shape_class == 3 && fmt != FMT_Q4P) { /* the 2048-wide shape is instantiated for the register-table 4-bit storage only */
+        delete E;
+        *why = "the Qwen3-1.7B shape is instantiated for 4-bit (RTN, groups of 128) layers only";
+        return KF_UNSUPPORTED_DATATYPE;
+    }
     if (dry) {
         delete E;
         *why = "";
         return KF_OK;
     }
-    if (fmt == FMT_Q4 && q4p_ok) fmt = FMT_Q4P;
-    if (fmt == FMT_Q1) fmt = FMT_Q1T; /* the LDS selector-table forms (same bits as the per-bit select forms) */
-    if (fmt == FMT_Q2) fmt = FMT_Q2T;
     E->fmt = fmt, E->GQ = GQ, E->hd = hd, E->n_cu = n_cu, E->nwv = ENG_NWV, E->shape_class = shape_class;
     E->canon = 1;
-    E->xmap = shape_class == 1 ? 1 : 0; /* 8 kv-heads on 8 XCDs */
+    E->xmap = shape_class == 1 || shape_class == 3 ? 1 : 0; /* 8 kv-heads on 8 XCDs (informational: the mapping is a template parameter of the instantiation) */
     // workspace carve
     char* p = reinterpret_cast<char*>(ws);
     E->ws = ws, E->ws_bytes = ws_bytes;
@@ -1756,6 +1795,12 @@ static int engine_go_fmt(EngineHost* E, hipStream_t st) {
         case 2:
             if (!E->canon) return engine_go<EngCfg<FMT, 2, 64, ENG_NWV, 256, 256, 128, 512, ENG_NWG, false, false, false>>(E, st);
             return engine_go<EngCfg<FMT, 2, 64, ENG_NWV, 256, 256, 128, 512, ENG_NWG, false, false, true>>(E, st);
+        case 3: /* gate | up and down_proj hold 8 and 6 blocks per lane: part of them is dequantised behind the hand-off (MvPhase::AH) */
+            if constexpr (FMT == FMT_Q4P) {
+                if (!E->canon) return engine_go<EngCfg<FMT_Q4P, 2, 128, ENG_NWV, 2048, 2048, 1024, 6144, ENG_NWG, true, false, false>>(E, st);
+                return engine_go<EngCfg<FMT_Q4P, 2, 128, ENG_NWV, 2048, 2048, 1024, 6144, ENG_NWG, true, false, true>>(E, st);
+            }
+            return 1;
         default: return 1;
     }
 }

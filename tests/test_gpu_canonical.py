@@ -234,3 +234,32 @@ def test_full_size_sixteen_step_launch_is_bit_exact(canon):
     assert np.array_equal(gk[:, P:P + n], om.kv()[0][:, P:P + n]) and np.array_equal(gv[:, P:P + n], om.kv()[1][:, P:P + n])
     om.close()
     m.close()
+
+
+def test_qwen3_1p7b_shaped_engine_steps_equal_the_oracle(canon):
+    """Three layers of the Qwen3-1.7B shape (vocab 4096 so that the oracle steps in milliseconds) through the engine's 2048-wide instantiation: teacher-forced positions
+    0..40 and, behind a token-serial stretch, 300..305 -- logits, ids and KV rows equal the oracle's bit for bit."""
+    cfg = dict(synth.CONFIGS["qwen3-1.7b"], n_layer=3, vocab=4096, max_seq=320)
+    raw = synth.raw_weights_numpy(cfg, 1717, w_std=0.05)
+    m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
+    m.set_canonical(True)
+    om = oracle_model(cfg, raw, L.Q4, L.BF16, attn_mode=O.ATTN_CANON)
+    toks = prompt_ids(cfg, 320, seed=5)
+    forced = np.full(cfg["max_seq"], -1, dtype=np.int32)
+    forced[:320] = toks
+    m.set_forced(forced)
+    m.set_state(int(toks[0]), 0)
+    for p in range(306):
+        m.run_steps(p, 1, use_graph=True)
+        m.sync()
+        o_id, o_logits, _ = om.decode(int(toks[p]), p)
+        if p <= 40 or p >= 300:
+            g_logits = m.logits()
+            assert np.array_equal(g_logits, o_logits), "position %d: %d logits differ" % (p, int((g_logits != o_logits).sum()))
+            assert int(m.tokens_out(p + 1)[p]) == o_id
+    gk, gv = m.kv_to_host()
+    assert np.array_equal(gk[:, :306], om.kv()[0][:, :306]) and np.array_equal(gv[:, :306], om.kv()[1][:, :306])
+    assert m.engine_steps() > 0, m.engine_why()
+    m.engine_check()
+    om.close()
+    m.close()

@@ -234,3 +234,52 @@ def test_engine_tune_changes_timing_not_results():
         m.close()
     assert res[0][0] == res[1][0]
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
+
+
+def test_qwen3_1p7b_shape_engine_equals_per_layer_launches_bit_for_bit():
+    """The Qwen3-1.7B instantiation (engine_kernel<EngCfg<5, 2, 128, 8, 2048, 2048, 1024, 6144, 256, ...>>: the 0.6B head geometry on a 2048-wide stream; gate | up and
+    down_proj hold 8 and 6 blocks per lane, part of them dequantised behind the hand-off -- MvPhase::AH) at full size against the per-layer launches of the same model,
+    canonical order, teacher-forced over positions 0..31, 250..258 and 2040..2047: logits, greedy ids and the K / V rows each step writes, bit for bit."""
+    cfg = dict(synth.CONFIGS["qwen3-1.7b"])
+    m = synth.build_on_gpu(cfg, seed=4243, layer_type=L.Q4, head_type=L.BF16)
+    m.set_canonical(True)
+    assert m.engine_why() == "", m.engine_why()
+    toks = np.random.default_rng(78).integers(0, cfg["vocab"], size=cfg["max_seq"]).astype(np.int32)
+    m.set_forced(toks.copy())
+    for p0, p1 in ((0, 32), (250, 259), (2040, 2048)):
+        if p0 > 0:
+            m.prefill(toks[:p0], want_logits=False)
+        res = {}
+        for engine in (True, False):
+            m.set_engine(engine)
+            steps0 = m.engine_steps()
+            m.set_state(int(toks[p0]), p0)
+            out = []
+            for p in range(p0, p1):
+                m.run_steps(p, 1, use_graph=True)
+                m.sync()
+                out.append((int(m.tokens_out(p + 1)[p]), m.logits().copy()))
+            assert (m.engine_steps() > steps0) == engine
+            m.engine_check()
+            k, v = m.kv_to_host()
+            res[engine] = (out, k[:, p0:p1].copy(), v[:, p0:p1].copy())
+        for i, p in enumerate(range(p0, p1)):
+            a, b = res[True][0][i], res[False][0][i]
+            assert a[0] == b[0], "position %d: greedy id %d vs %d" % (p, a[0], b[0])
+            assert np.array_equal(a[1], b[1]), "position %d: %d of %d logits differ" % (p, int((a[1] != b[1]).sum()), a[1].size)
+        assert np.array_equal(res[True][1], res[False][1]) and np.array_equal(res[True][2], res[False][2]), "K / V rows of positions %d..%d differ" % (p0, p1 - 1)
+    # several steps per launch, free running: the same ids as one launch per step
+    m.set_engine(True)
+    forced = np.full(cfg["max_seq"], -1, dtype=np.int32)
+    forced[:1990] = toks[:1990]
+    m.set_forced(forced)
+    ids = {}
+    for per_launch in (1, 16):
+        m.set_state(int(toks[1984]), 1984)
+        for p in range(1984, 2040, per_launch):
+            m.run_steps(p, per_launch, use_graph=True)
+        m.sync()
+        m.engine_check()
+        ids[per_launch] = np.asarray(m.tokens_out(cfg["max_seq"])[1985:2040]).copy()
+    assert np.array_equal(ids[1], ids[16])
+    m.close()
