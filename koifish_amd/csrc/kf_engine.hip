@@ -426,6 +426,9 @@ __device__ __forceinline__ void mv_prefetch(const EngMat m, const EngMat m2, int
 #ifndef ENG_AH_REGS
 #define ENG_AH_REGS 64 /* registers of dequantised pair words a lane may hold across a hand-off (MvPhase::AH) */
 #endif
+#ifndef ENG_AH_PAIR_WIDE
+#define ENG_AH_PAIR_WIDE 0 /* the 2048-wide shape's gate | up phase: every block pair behind the barrier */
+#endif
 #ifndef ENG_AH_REGS_WIDE
 #define ENG_AH_REGS_WIDE 16 /* the same for the 2048-wide shape, whose raw blocks in flight take 72 registers */
 #endif
@@ -459,8 +462,8 @@ __device__ __forceinline__ void mv_dequant(float qb, float qb2, int cw, int lane
     }
 }
 // mv_run on dequantised blocks: the same lanes, chains and tree
-template <class PL, int NCW, int FMT, int MAXS, int AH, bool CANON, typename Epi>
-__device__ __forceinline__ void mv_run_deq(int s0, int cw, int lane, int Mj, const MvDeq<PL::PAIRED, AH>& D, const MvRegs<PL::PAIRED, MAXS>& R, float qb, float qb2, const u32x4* tab,
+template <class PL, int NCW, int FMT, int MAXS, int AH, int AHN, bool CANON, typename Epi>
+__device__ __forceinline__ void mv_run_deq(int s0, int cw, int lane, int Mj, const MvDeq<PL::PAIRED, AHN>& D, const MvRegs<PL::PAIRED, MAXS>& R, float qb, float qb2, const u32x4* tab,
                                            const u32x4* xs, uint32_t hotbits, Epi&& epi) {
     acc_t<CANON> acc{}, acc2{};
 #pragma unroll
@@ -506,17 +509,17 @@ __device__ __forceinline__ void mv_run_deq(int s0, int cw, int lane, int Mj, con
 template <class C, class PL, int NCW, int MAXS>
 struct MvPhase {
     // blocks dequantised ahead: all of them while a lane holds at most ENG_AH_REGS registers of pair words (16 per block, 32 per gate | up pair); Qwen3-0.6B: every phase
-    static constexpr int PER = PL::PAIRED ? 32 : 16, AH0 = C::AHR / PER, AH = MAXS <= AH0 ? MAXS : (AH0 < 1 ? 1 : AH0);
-    MvDeq<PL::PAIRED, AH> d;
+    static constexpr int PER = PL::PAIRED ? 32 : 16, AH0 = (PL::PAIRED ? C::AHR_P : C::AHR) / PER, AH = MAXS <= AH0 ? MAXS : AH0; /* 0: every block behind the barrier */
+    MvDeq<PL::PAIRED, (AH > 0 ? AH : 1)> d;
     float qb_, qb2_;
     const u32x4* tab_;
     __device__ __forceinline__ void ahead(float qb, float qb2, int cw, int lane, const MvRegs<PL::PAIRED, MAXS>& R, const u32x4* tab) {
         qb_ = qb, qb2_ = qb2, tab_ = tab;
-        mv_dequant<PL, NCW, C::FMT, MAXS, AH>(qb, qb2, cw, lane, R, d, tab);
+        if constexpr (AH > 0) mv_dequant<PL, NCW, C::FMT, MAXS, AH>(qb, qb2, cw, lane, R, d, tab);
     }
     template <typename Epi>
     __device__ __forceinline__ void run(int s0, int cw, int lane, int Mj, const u32x4* xs, uint32_t hotbits, const MvRegs<PL::PAIRED, MAXS>& R, Epi&& epi) {
-        mv_run_deq<PL, NCW, C::FMT, MAXS, AH, C::CANON>(s0, cw, lane, Mj, d, R, qb_, qb2_, tab_, xs, hotbits, epi);
+        mv_run_deq<PL, NCW, C::FMT, MAXS, AH, (AH > 0 ? AH : 1), C::CANON>(s0, cw, lane, Mj, d, R, qb_, qb2_, tab_, xs, hotbits, epi);
     }
 };
 
@@ -569,7 +572,8 @@ template <int FMT_, int GQ_, int HD_, int NWV_, int DIM_, int QD_, int KVD_, int
 struct EngCfg {
     static constexpr int FMT = FMT_, GQ = GQ_, HD = HD_, NWV = NWV_, DIM = DIM_, QD = QD_, KVD = KVD_, FFN = FFN_, NWG = NWG_;
     static constexpr bool XMAP = XMAP_, DBG = DBG_;
-    static constexpr int AHR = DIM_ > 1024 ? ENG_AH_REGS_WIDE : ENG_AH_REGS; /* MvPhase::AH: registers of pair words held across a hand-off */
+    static constexpr int AHR = DIM_ > 1024 ? ENG_AH_REGS_WIDE : ENG_AH_REGS; /* MvPhase::AH: registers of pair words held across a hand-off (single-matrix phases) */
+    static constexpr int AHR_P = DIM_ > 1024 ? ENG_AH_PAIR_WIDE : ENG_AH_REGS; /* the same for the gate | up phase (32 registers per block pair) */
     // CANON: the mat-vec phases and the head in the canonical order (one v_fma_f32 per product on fp32 operands: bit-exact against the oracle); false: v_dot2c_f32_bf16 on
     // bf16 pairs (kf_set_canonical(ctx, 0): <= 1 bf16 ulp per output from the oracle, fewer vector instructions).  The attention is canonical either way.
     static constexpr bool CANON = CANON_;
