@@ -109,6 +109,9 @@ struct BlockDot<FMT_Q4, CANON> {
     }
 };
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x2_t perm_fma_dword(uint32_t D, f32x4 X0, f32x4 X1, const PermLut& t, f32x2_t acc); /* below: the lookup with fp32 results */
+
 // 4-bit through a per-group table (register byte planes + v_perm_b32, kf_device.h): the 4 lanes that hold the 4 blocks of a 128-weight group
 // build the 16 entries together -- lane i of the quad forms entries 4i..4i+3 with the arithmetic above, packs them into one low-byte and one
 // high-byte plane word and the quad exchanges the 8 plane words by DPP broadcasts -- then every weight costs a lookup instead of the
@@ -130,11 +133,24 @@ struct BlockDot<FMT_Q4P, CANON> {
         PermLut t;
         t.tl[0] = quad_bcast<0>(tlm), t.tl[1] = quad_bcast<1>(tlm), t.tl[2] = quad_bcast<2>(tlm), t.tl[3] = quad_bcast<3>(tlm);
         t.th[0] = quad_bcast<0>(thm), t.th[1] = quad_bcast<1>(thm), t.th[2] = quad_bcast<2>(thm), t.th[3] = quad_bcast<3>(thm);
-        acc = perm_dot_dword_nat<CANON>(w.w, xs[col], t, acc);
-        acc = perm_dot_dword_nat<CANON>(w.z, xs[nBlk + col], t, acc);
-        acc = perm_dot_dword_nat<CANON>(w.y, xs[2 * nBlk + col], t, acc);
-        acc = perm_dot_dword_nat<CANON>(w.x, xs[3 * nBlk + col], t, acc);
-        return acc;
+#ifndef KF_Q4P_CANON_OLD
+#define KF_Q4P_CANON_OLD 0 /* scratch/build_variant.py A/B: 1 = the paired-word form (perm_dot_dword_nat) */
+#endif
+        if constexpr (CANON && !KF_Q4P_CANON_OLD) { /* canonical order on bf16 activations (vectors too long to stage as fp32: the 25600-wide down_proj of Qwen3-32B): the weights come out of the lookup
+                                  as fp32 operands of the two chains (perm_fma_dword: no index gather, no pair word to widen) -- only x is widened; same products, same chains */
+            const u32x4 X[4] = {xs[col], xs[nBlk + col], xs[2 * nBlk + col], xs[3 * nBlk + col]};
+            const uint32_t D[4] = {w.w, w.z, w.y, w.x};
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                acc = perm_fma_dword(D[i], f32x4{bf_lo(X[i].x), bf_hi(X[i].x), bf_lo(X[i].y), bf_hi(X[i].y)}, f32x4{bf_lo(X[i].z), bf_hi(X[i].z), bf_lo(X[i].w), bf_hi(X[i].w)}, t, acc);
+            return acc;
+        } else {
+            acc = perm_dot_dword_nat<CANON>(w.w, xs[col], t, acc);
+            acc = perm_dot_dword_nat<CANON>(w.z, xs[nBlk + col], t, acc);
+            acc = perm_dot_dword_nat<CANON>(w.y, xs[2 * nBlk + col], t, acc);
+            acc = perm_dot_dword_nat<CANON>(w.x, xs[3 * nBlk + col], t, acc);
+            return acc;
+        }
     }
 };
 
