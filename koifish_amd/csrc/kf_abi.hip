@@ -1227,6 +1227,7 @@ int kfdbg_set_knob(const char* name, long value) {
     else if (!strcmp(name, "g3_tiles")) k.g3_tiles = (int)value;
     else if (!strcmp(name, "g3_first")) k.g3_first = (int)value;
     else if (!strcmp(name, "g3_wide")) k.g3_wide = (int)value;
+    else if (!strcmp(name, "attn_gq_split")) k.attn_gq_split = (int)value;
     else if (!strcmp(name, "g3_mid_min")) k.g3_mid_min = (int)value;
     else if (!strcmp(name, "resident_min")) k.resident_min = (int)value;
     else if (!strcmp(name, "attn_pair_min")) k.attn_pair_min = (int)value;

@@ -148,6 +148,7 @@ struct Knobs {
     int attn_pair_min = 256;  /* prompt tokens from which kf_attn_prefill takes its paired two-key-half form (when there is about one workgroup per CU or fewer) */
     int g3_wide = 1;      /* gate | up + SwiGLU on 192 x 256 tiles when the 256 x 256 ones would leave CUs idle */
     int g3_mid_min = 192; /* 64 x 128 tiles from this many of them, 64 x 64 below */
+    int attn_gq_split = 4; /* canonical decode attention of a GQA-8 model: workgroups per (kv-head, slice), 2 or 4 */
     int g3_first = 256;   /* token rows from which bf16 operands try the kf_gemm3.hip tile kernels before the 32 x 32 direct kernel */
     int q1_tab = 1;       /* 1-bit mat-vec through the LDS selector table (0: the per-bit select form; same bits) */
     long gemv_waves = 0;  /* > 0: waves a mat-vec launch aims for (0: the launcher's rule) */
