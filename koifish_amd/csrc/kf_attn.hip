@@ -500,7 +500,7 @@ int attn_launch(hipStream_t st, AttnArgs& a) {
     a.n_splits = nsp;
     a.chunk = (pos_max + 1 + nsp - 1) / nsp;
     a.inv_sqrt_hd_den = sqrtf((float)hd);
-    a.gq_split = (a.canon && GQ == 8) ? (g_knobs.attn_gq_split == 4 ? 4 : 2) : 1;
+    a.gq_split = (a.canon && GQ == 8) ? (g_knobs.attn_gq_split == 8 ? 8 : (g_knobs.attn_gq_split == 4 ? 4 : 2)) : ((a.canon && GQ == 4 && g_knobs.attn_gq_split >= 4) ? 2 : 1);
     a.cnt_stride = KF_ATTN_CNT_BYTES / 4 / (a.n_kv * a.gq_split); /* arrival counters of different kv-heads in different cache lines: atomics on one line serialise */
     if (a.cnt_stride > 64) a.cnt_stride = 64;
     if (a.cnt_stride < 1) return KF_INVALID_ARGS;
@@ -525,9 +525,13 @@ int attn_launch(hipStream_t st, AttnArgs& a) {
     switch (GQ) {
         case 1: if (NW == 8) KF_ATTN_GO(1, 8); else KF_ATTN_GO(1, 4); break;
         case 2: if (NW == 8) KF_ATTN_GO(2, 8); else KF_ATTN_GO(2, 4); break;
-        case 4: KF_ATTN_GO(4, 4); break;
+        case 4:
+            if (a.gq_split == 2) KF_ATTN_GO(2, 4); /* canonical order: two workgroups of two heads each, as for GQA-8 */
+            else KF_ATTN_GO(4, 4);
+            break;
         case 8:
-            if (a.gq_split == 4) KF_ATTN_GO(2, 4); /* four workgroups of two heads each */
+            if (a.gq_split == 8) KF_ATTN_GO(1, 4); /* one head per workgroup */
+            else if (a.gq_split == 4) KF_ATTN_GO(2, 4); /* four workgroups of two heads each */
             else if (a.gq_split == 2) KF_ATTN_GO(4, 4); /* two workgroups of four heads each (canonical order) */
             else KF_ATTN_GO(8, 4);
             break;

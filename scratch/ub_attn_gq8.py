@@ -6,7 +6,7 @@ from koifish_amd import lib as L
 import _knobs
 ctx = Context(0); dev = ctx.device
 _knobs.apply(ctx.hip)
-nh, nkv, hd, S = 64, 8, 128, 4096
+nh, nkv, hd, S = int(os.environ.get('NH', '64')), 8, 128, 4096
 kc = torch.randn(S, nkv * hd, device=dev).to(torch.bfloat16); vc = torch.randn(S, nkv * hd, device=dev).to(torch.bfloat16)
 q = torch.randn(nh * hd, device=dev).to(torch.bfloat16); kraw = torch.randn(nkv * hd + nkv * hd, device=dev).to(torch.bfloat16)
 qn = torch.ones(hd, device=dev, dtype=torch.bfloat16); table = ctx.rope_table(S, hd, 1e6)

@@ -78,7 +78,7 @@ def test_fused_entries_are_bit_exact(cctx, canon):
     assert np.array_equal(u16(logits), ref) and am == O.argmax_bf16(ref)
 
 
-@pytest.mark.parametrize("n_head,n_kv,hd,pos", [(4, 2, 128, 0), (4, 2, 128, 63), (4, 2, 128, 191), (4, 2, 128, 300), (16, 8, 128, 2047), (8, 8, 64, 700), (8, 1, 128, 1029), (4, 1, 64, 4095)])
+@pytest.mark.parametrize("n_head,n_kv,hd,pos", [(4, 2, 128, 0), (4, 2, 128, 63), (4, 2, 128, 191), (4, 2, 128, 300), (16, 8, 128, 2047), (8, 8, 64, 700), (8, 1, 128, 1029), (4, 1, 64, 4095), (32, 8, 128, 2047), (64, 8, 128, 4095)])
 def test_decode_attention_is_bit_exact(cctx, n_head, n_kv, hd, pos):
     """kf_attn_decode against kfo_attn_decode mode CANON: one slice, several slices with the in-kernel merge, both head sizes, every GQA group size"""
     ctx = cctx
