@@ -135,11 +135,20 @@ def test_full_size_one_bit_sparse_step():
 @pytest.mark.parametrize("layer_type", [L.BOOL1, L.T_SIGN, L.Q4])
 @pytest.mark.parametrize("hot_frac", [0.2, 1.0])
 def test_sparse_engine_equals_per_layer_launches_and_the_oracle_bit_for_bit(layer_type, hot_frac):
+    _sparse_engine_case(dict(synth.CONFIGS["small"], max_seq=320), layer_type, hot_frac)
+
+
+def test_sparse_engine_on_the_1p7b_shape():
+    """the same through the engine's Qwen3-1.7B instantiation (two layers, vocab 4096): its gate | up blocks are all dequantised behind the hand-off (MvPhase::AH = 0), the hot
+    bits mask them there"""
+    _sparse_engine_case(dict(synth.CONFIGS["qwen3-1.7b"], n_layer=2, vocab=4096, max_seq=320), L.Q4, 0.2)
+
+
+def _sparse_engine_case(cfg, layer_type, hot_frac):
     """The engine's sparse / 1-bit / 2-bit forms (round 4): 1-bit and ternary PackedQ layers through the LDS selector tables inside the persistent launch, CS_Picker's hot[] as per-workgroup hot bits
     (cold gate / up rows never read, zeros published by the owning workgroup -- no cold-fill launch).  Canonical order, teacher-forced steps across the single- and multi-slice
     attention forms: logits, ids and K / V rows equal the per-layer masked launches' AND the oracle's sparse forward, bit for bit."""
-    cfg = dict(synth.CONFIGS["small"], max_seq=320)
-    raw = synth.raw_weights_numpy(cfg, 31, w_std=0.1)
+    raw = synth.raw_weights_numpy(cfg, 31, w_std=0.1 if cfg["dim"] <= 1024 else 0.05)
     n = 230
     forced = np.full(cfg["max_seq"], -1, dtype=np.int32)
     forced[:n] = prompt_ids(cfg, n, seed=13)
