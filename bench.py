@@ -62,6 +62,10 @@ def main():
     ap.add_argument("--side-legs", default="config3,config5,config4,qwen3_1p7b", help="side objects beside the line, each measured in a child process after the main measurements "
                     "(never `value`): config3 = GPT2-1558M operator path of a training step (sum of separately timed forward+loss, backward, AdamW phases; no parameter update), config5 = 1-bit layers + 20 %% hot FFN rows, config4 = Qwen3-32B on ONE GPU; '' = none")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` run bare: THIS process becomes the launcher of N rank processes -- before torch is imported or anything touches a GPU (a process
+        # that has initialised HIP must never exec or fork GPU work) -- and relays rank 0's single JSON line
+        sys.exit(launch_ranks(args))
     if args.leg == "config3":
         print(json.dumps(config3_train_step()))
         return
@@ -289,6 +293,56 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_ranks(n, argv, timeout_s):
+    """n fresh rank processes of this script under torch.distributed.run (one per GPU, rendezvous on 127.0.0.1): (return code, rank 0's JSON line or None, tail of stderr)"""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py")] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+    except subprocess.TimeoutExpired as e:
+        return 124, None, "timeout after %d s: %s" % (timeout_s, (e.stderr or b"")[-300:] if isinstance(e.stderr, (bytes, str)) else "")
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r.returncode, (lines[-1] if lines else None), r.stderr[-2000:]
+
+
+def launch_ranks(args):
+    """The parent of a bare `python bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment).  It never imports torch and never touches a GPU.  Two child jobs, each N
+    fresh rank processes: (1) the command line as given -- for the default config the 0.6B decode as N independent replicas (`value`, "scaling": "weak"); (2) when (1) was the
+    default config, BASELINE config 4 -- Qwen3-32B tensor parallel TP = N over the kernel-side exchange ("scaling": "strong") -- whose line rides inside (1)'s as
+    `config4_tp`, so that ONE driver command per N yields both curves north_star asks for.  A failure of (1) is this process's exit code; a failure of (2) costs only its object."""
+    argv = [a for a in sys.argv[1:]]
+    rc, line, err = _run_ranks(args.gpus, argv, 3000)
+    if rc != 0 or line is None:
+        sys.stderr.write(err + "\n")
+        return rc if rc != 0 else 1
+    out = json.loads(line)
+    if args.config == "qwen3-0.6b" and os.environ.get("KF_BENCH_NO_TP_LEG", "") != "1":
+        tp_argv = ["--gpus", str(args.gpus), "--config", "qwen3-32b", "--steps", "64", "--warmup", "16", "--tp-exchange", args.tp_exchange]
+        rc2, line2, err2 = _run_ranks(args.gpus, tp_argv, 1500)
+        if rc2 == 0 and line2:
+            d = json.loads(line2)
+            out["config4_tp"] = {"workload": d["config"]["workload"], "tokens_per_s": d["value"], "ms_per_step": d["ms_per_step"], "n_gpus": d["n_gpus"], "scaling": d["scaling"],
+                                 "tp": d["config"]["tp"], "exchange": d["config"]["exchange"], "ranks_in_process_group": d["config"].get("ranks_in_process_group"),
+                                 "decode_path": d["config"]["decode_path"], "layers": d["config"]["layers"], "roofline": d["roofline"], "steps": d["steps"], "warmup": d["warmup"]}
+        else:
+            out["config4_tp"] = {"error": (err2 or "")[-400:], "returncode": rc2}
+    print(json.dumps(out))
+    return 0
 
 
 def _child(argv, timeout_s):
@@ -645,6 +699,7 @@ def tp_main(args, cfg, rank, world, dev):
                "config": {"workload": "Qwen3-32B 4-bit PackedQ greedy decode, tensor parallel TP=%d%s, context %d: timed positions %d..%d" % (
                    R, " (all ranks on ONE GPU, lock-step: a side measurement, not a scaling point)" if virtual else " over %d MI355X" % world, S, S - K, S - 1),
                    "layers": cfg["n_layer"], "vocab": cfg["vocab"], "tp": R, "exchange": args.tp_exchange if not virtual else "p2p (local pointers)", "decode_path": path, "hipgraph": use_graph,
+                   "ranks_in_process_group": (dist.get_world_size() if dist.is_initialized() else 1), "process_group_backend": (dist.get_backend() if dist.is_initialized() else None),
                    "device_ms_per_step": round(ctx.elapsed_ms(e0, e1) / K, 4), "weight_bytes_per_rank": int(bytes_rank)},
                "roofline": {"bound": "hbm", "kernel": "one rank's decode step (its weight shards + its KV heads)", "bytes_per_step_per_rank": int(step_bytes),
                             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,

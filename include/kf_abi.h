@@ -468,6 +468,31 @@ int kf_engine_check(kf_ctx* ctx, kf_engine* e); /* synchronises; KF_INTERNAL_ERR
 int kf_engine_reset(kf_ctx* ctx, kf_engine* e);
 int kf_engine_destroy(kf_engine* e);
 
+/* ---- EIGHT independent decoders per GPU, one per XCD (kf_xengine.hip; round 5).  The reference decodes ONE sequence per process (Fish::Chat, GoPT.cpp:1139-1180) and
+ * scales a small model by running more processes; on this part a single sequence cannot keep the HBM busy (its step is a chain of hand-offs), so the replicas move
+ * INSIDE the package: the 32 workgroups of XCD s are the decoder of sequence s, every hand-off stays in that XCD's L2, and the chip streams eight sequences' bytes at
+ * once.  The sequences share the weights (the kf_engine_desc's layer table, the embedding, the head) and nothing else; per sequence: a K/V cache (sequence s at
+ * layers[].kcache + s * kv_seq_stride elements), a decode state {token, pos, -, -} (d_state + 4 s), forced ids (d_forced + s * forced_stride), ids out, logits
+ * (logits + s * vocab), the residual stream out (x_out + s * dim).  Each sequence's ids, logits and K/V rows are bit for bit those kf_engine_steps_head, the per-layer
+ * calls and the oracle give for that sequence alone (canonical order only: kf_set_canonical(ctx, 0) is refused).  One workgroup per CU, 32 per XCD: the launch must have
+ * the GPU to itself (bounded polls, error word, kf_xengine_check / _reset as for kf_engine).  Sequences may stand at different positions.
+ * Served: 4-bit PackedQ (RTN, groups of 128) layers of the Qwen3-0.6B shape (and the 256-wide test shape), bf16 embedding / head, dense FFNs. */
+typedef struct kf_xengine kf_xengine;
+#define KF_XENGINE_MAX_SEQ 8
+size_t kf_xengine_workspace_bytes(const kf_engine_desc* desc);
+int kf_xengine_create(kf_ctx* ctx, const kf_engine_desc* desc, int n_seq, int64_t kv_seq_stride, void* workspace, size_t workspace_bytes, kf_xengine** out);
+int kf_xengine_served(kf_ctx* ctx, const kf_engine_desc* desc, char* why, size_t why_bytes); /* KF_OK or KF_ENGINE_NOT_SERVED + the reason */
+/* TokenEmbed::cuInfer inside the launch (bf16 table, required); d_forced [n_seq][forced_stride] or NULL */
+int kf_xengine_set_embedding(kf_ctx* ctx, kf_xengine* e, const kf_weight* embed_bf16, const int32_t* d_forced_or_null, int forced_stride);
+/* Head4Token::cuInfer_1 + sample_argmax inside the launch: logits [n_seq][vocab] bf16, d_tokens_out [n_seq][tokens_stride] or NULL */
+int kf_xengine_set_head(kf_ctx* ctx, kf_xengine* e, const kf_weight* head_bf16_or_null, const kf_bf16* final_norm_w, kf_bf16* logits, int32_t* d_tokens_out_or_null, int tokens_stride);
+/* n_steps greedy decode steps of EVERY sequence in one launch (Fish::ForwardOnRLS + Head4Token::cuInfer_1 + sample_argmax per sequence and step): d_state [n_seq][4] is
+ * read and advanced per step, x_out [n_seq][dim] holds the last step's residual stream.  pick = 0 (n_steps = 1 only): logits without the pick, the state stays. */
+int kf_xengine_steps(kf_ctx* ctx, kf_xengine* e, kf_bf16* x_out, int32_t* d_state, int n_steps, int pick);
+int kf_xengine_check(kf_ctx* ctx, kf_xengine* e); /* synchronises; KF_INTERNAL_ERR when a hand-off poll has timed out since creation or the last kf_xengine_reset */
+int kf_xengine_reset(kf_ctx* ctx, kf_xengine* e);
+int kf_xengine_destroy(kf_xengine* e);
+
 #ifdef __cplusplus
 }
 #endif

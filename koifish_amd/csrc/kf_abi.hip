@@ -1205,6 +1205,90 @@ int kf_engine_check(kf_ctx* c, kf_engine* e) {
     if (err) return fail(KF_INTERNAL_ERR, "kf_engine: a hand-off poll timed out (error word 0x%x): the launch was not fully resident", err);
     return KF_OK;
 }
+// ---- XCD-confined decode engines (kf_xengine.hip)
+struct kf_xengine {
+    kf::XEngineHost* h;
+};
+size_t kf_xengine_workspace_bytes(const kf_engine_desc* d) { return d ? kf::xengine_ws_bytes(d) : 0; }
+int kf_xengine_create(kf_ctx* c, const kf_engine_desc* d, int n_seq, int64_t kv_seq_stride, void* ws, size_t ws_bytes, kf_xengine** out) {
+    CHKCTX(c);
+    if (!d || !ws || !out) return fail(KF_INVALID_ARGS, "kf_xengine_create: null argument");
+    if (c->capturing) return fail(KF_INVALID_ARGS, "kf_xengine_create: not while capturing");
+    if (n_seq < 1 || n_seq > KF_XENGINE_MAX_SEQ) return fail(KF_INVALID_ARGS, "kf_xengine_create: n_seq %d outside 1 .. %d (one sequence per XCD)", n_seq, KF_XENGINE_MAX_SEQ);
+    kf::XEngineHost* h = nullptr;
+    const char* why = "";
+    const int rc = kf::xengine_build(d, n_seq, (long long)kv_seq_stride, ws, ws_bytes, c->stream, &h, &why);
+    if (rc != KF_OK) return fail(rc, "kf_xengine_create: %s", why);
+    kf_xengine* e = new kf_xengine();
+    e->h = h;
+    *out = e;
+    return KF_OK;
+}
+int kf_xengine_served(kf_ctx* c, const kf_engine_desc* d, char* why, size_t why_bytes) {
+    CHKCTX(c);
+    if (!d) return fail(KF_INVALID_ARGS, "kf_xengine_served: null descriptor");
+    const char* w = "";
+    const int rc = kf::xengine_build(d, 1, 0, nullptr, 0, c->stream, nullptr, &w, true);
+    if (why && why_bytes) snprintf(why, why_bytes, "%s", w);
+    if (rc == KF_OK) return KF_OK;
+    return rc == KF_UNSUPPORTED_DATATYPE ? KF_ENGINE_NOT_SERVED : fail(rc, "kf_xengine_served: %s", w);
+}
+int kf_xengine_set_embedding(kf_ctx* c, kf_xengine* e, const kf_weight* embed, const int32_t* d_forced, int forced_stride) {
+    CHKCTX(c);
+    if (!e || !e->h || !embed) return fail(KF_INVALID_ARGS, "kf_xengine_set_embedding: null argument");
+    if (d_forced && forced_stride < 1) return fail(KF_INVALID_ARGS, "kf_xengine_set_embedding: forced_stride %d", forced_stride);
+    const int rc = kf::xengine_set_embedding(e->h, embed, d_forced, forced_stride);
+    if (rc != KF_OK) return fail(rc, "kf_xengine_set_embedding: the row read inside the launch takes a bf16 table of the engine's width");
+    return KF_OK;
+}
+int kf_xengine_set_head(kf_ctx* c, kf_xengine* e, const kf_weight* head_or_null, const kf_bf16* final_norm_w, kf_bf16* logits, int32_t* d_tokens_out, int tokens_stride) {
+    CHKCTX(c);
+    if (!e || !e->h) return fail(KF_INVALID_ARGS, "kf_xengine_set_head: null engine");
+    const int rc = kf::xengine_set_head(e->h, head_or_null, final_norm_w, logits, d_tokens_out, tokens_stride);
+    if (rc != KF_OK) return fail(rc, "kf_xengine_set_head: the in-launch head takes a bf16 [vocab, dim] matrix of the engine's width, a norm weight and a logits buffer");
+    return KF_OK;
+}
+int kf_xengine_steps(kf_ctx* c, kf_xengine* e, kf_bf16* x_out, int32_t* d_state, int n_steps, int pick) {
+    CHKCTX(c);
+    if (!e || !e->h) return fail(KF_INVALID_ARGS, "kf_xengine_steps: null engine");
+    if (!c->canonical) return fail(KF_UNSUPPORTED_DATATYPE, "kf_xengine_steps: the XCD-confined engines run the canonical summation order only (kf_set_canonical(ctx, 1))");
+    if (n_steps < 1 || (n_steps > 1 && !pick)) return fail(KF_INVALID_ARGS, "kf_xengine_steps: n_steps %d (several steps per launch need the pick inside)", n_steps);
+    const int rc = kf::xengine_steps(e->h, c->stream, d_state, x_out, pick ? 2 : 1, n_steps);
+    if (rc != KF_OK) return fail(rc, "kf_xengine_steps failed with %d (no embedding / head set?)", rc);
+    return KF_OK;
+}
+int kf_xengine_check(kf_ctx* c, kf_xengine* e) {
+    CHKCTX(c);
+    if (!e || !e->h) return fail(KF_INVALID_ARGS, "kf_xengine_check: null engine");
+    int err = 0;
+    const int rc = kf::xengine_error_word(e->h, c->stream, &err);
+    if (rc != KF_OK) return fail(rc, "kf_xengine_check: HIP failure");
+    if (err) return fail(KF_INTERNAL_ERR, "kf_xengine: error word 0x%x (8: an XCD did not get 32 workgroups; 64: a position beyond the cache rows; others: a hand-off poll timed out -- the launch was not fully resident)", err);
+    return KF_OK;
+}
+int kf_xengine_reset(kf_ctx* c, kf_xengine* e) {
+    CHKCTX(c);
+    if (!e || !e->h) return fail(KF_INVALID_ARGS, "kf_xengine_reset: null engine");
+    if (c->capturing) return fail(KF_INVALID_ARGS, "kf_xengine_reset: not while capturing");
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(KF_HIP_CHECK, "kf_xengine_reset: HIP failure");
+    const int rc = kf::xengine_reset(e->h, c->stream);
+    if (rc != KF_OK) return fail(rc, "kf_xengine_reset: HIP failure");
+    return KF_OK;
+}
+int kf_xengine_destroy(kf_xengine* e) {
+    if (e) {
+        kf::xengine_free(e->h);
+        delete e;
+    }
+    return KF_OK;
+}
+int kfdbg_xengine_variant(kf_xengine* e, int nwv, int depth) {
+    if (!e || !e->h) return -1;
+    kf::xengine_set_variant(e->h, nwv, depth);
+    return 0;
+}
+int kfdbg_xengine_stamps_enable(kf_xengine* e, int seq, int wg, int max_steps) { return (e && e->h) ? kf::xengine_debug_enable(e->h, seq, wg, max_steps) : -1; }
+int kfdbg_xengine_stamps(kf_xengine* e, unsigned long long* h_out, int n_words) { return (e && e->h) ? kf::xengine_debug_read(e->h, h_out, n_words) : -1; }
 // ---- diagnostics (NOT part of the ABI header; tests and scratch/ only)
 // the per-phase stamps of one workgroup of the engine: enable (the diagnostic instantiation of the kernel serves the next launches), read
 int kfdbg_engine_stamps_enable(kf_engine* e, int wg) { return (e && e->h) ? kf::engine_debug_enable(e->h, wg) : -1; }

@@ -171,6 +171,20 @@ int engine_debug_read(EngineHost* E, unsigned long long* h_out, int n_words);
 int engine_debug_enable(EngineHost* E, int wg);       /* per-phase stamps of workgroup wg from the next launch on (the diagnostic instantiation of the kernel) */
 void engine_set_delays(EngineHost* E, const int* d6); /* tuning runs */
 
+// ---- XCD-confined decode engines: up to eight independent sequences per launch, one per XCD (kf_xengine.hip)
+struct XEngineHost;
+size_t xengine_ws_bytes(const kf_engine_desc* d);
+int xengine_build(const kf_engine_desc* d, int n_seq, long long kv_seq_stride, void* ws, size_t ws_bytes, hipStream_t st, XEngineHost** out, const char** why = nullptr, bool dry = false);
+int xengine_steps(XEngineHost* E, hipStream_t st, int32_t* d_state, uint16_t* x_out, int with_head, int n_steps);
+int xengine_set_embedding(XEngineHost* E, const kf_weight* w, const int32_t* d_forced, int forced_stride);
+int xengine_set_head(XEngineHost* E, const kf_weight* w, const uint16_t* norm_w, uint16_t* logits, int32_t* d_tokens_out, int tokens_stride);
+int xengine_error_word(XEngineHost* E, hipStream_t st, int* h_err);
+int xengine_reset(XEngineHost* E, hipStream_t st);
+void xengine_free(XEngineHost* E);
+void xengine_set_variant(XEngineHost* E, int nwv, int depth);             /* tuning runs: waves per workgroup x ring depth (instantiated pairs only) */
+int xengine_debug_enable(XEngineHost* E, int seq, int wg, int max_steps); /* per-phase stamps of one workgroup of one decoder (seq < 0: off) */
+int xengine_debug_read(XEngineHost* E, unsigned long long* h_out, int n_words);
+
 // ---- small ops (kf_ops.hip)
 int rmsnorm_launch(hipStream_t st, const uint16_t* x, const uint16_t* w, uint16_t* y, int rows, int dim, float eps, float* rstd);
 int layernorm_launch(hipStream_t st, const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* y, int rows, int dim, float eps, float* mean, float* rstd);

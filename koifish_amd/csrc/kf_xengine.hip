@@ -1,0 +1,1094 @@
+// kf_xengine.hip -- EIGHT independent decoders per GPU, one per XCD: the decode step of kf_engine.hip re-shaped so that the CHIP streams bytes while each SEQUENCE
+// waits on its hand-offs (round 5).
+//
+// kf_engine.hip gives one sequence all 256 CUs: a layer's 8.4 MB of weights sit in registers before the activations arrive, and the step is bound by its six all-to-all
+// hand-offs per layer across 8 XCDs (0.22 of the HBM roofline, measured to be the floor of that design: DESIGN.md section 8.1).  The reference decodes one sequence per
+// process (GoPT.cpp:1139-1180) and SURVEY section 8e scales the 0.6B model as independent replicas; this file puts the replicas INSIDE the package:
+//
+//   * 256 workgroups, one per CU.  A workgroup reads its XCD from HW_REG_XCC_ID and takes a ticket there: the 32 workgroups of XCD s are the decoder of sequence s
+//     (placement-independent: nothing assumes which CU a block lands on, only that all 256 are resident).  The sequences share the weights and nothing else: own
+//     K/V cache, own decode state, own forced ids, own logits.
+//   * every hand-off vector of a decoder lives in cached memory that only its XCD touches: producers write tagged granules with PLAIN stores (they land in that XCD's
+//     L2), the poller wave sweeps them with sc1 loads -- "the data is the flag" exactly as in kf_engine.hip, but an edge costs ~0.7 us instead of 1.2-2.3.
+//   * 32 CUs cannot hold a layer in registers (261 KB of blocks per workgroup and layer), so the mat-vec phases STREAM: each compute wave walks its row slots with a ring
+//     of DEPTH 16-byte blocks in flight, and in the last round of a phase the ring is refilled with the first blocks of the NEXT phase -- they do not depend on the
+//     hand-off, so HBM latency stays off the chain.  The attention phase streams its K/V rows the same way (two batches of tiles in flight).
+//
+// The arithmetic is the canonical order of oracle/kf_oracle.c sections 4c and 6 (the library default): the same lanes per row, chain pairs and lane tree as
+// gemv_kernel<.., CANON> (the geometry is a property of the matrix shape: PlanT, kf_engine_common.h), the order-free fp64 softmax sums of kf_attn_common.h.  Every id,
+// logit and K/V row of every sequence equals what kf_engine.hip, the per-layer launches and the oracle produce for that sequence alone.
+//
+// Replaces, for eight sequences at once: Fish::ForwardOnRLS (gLLM.cpp:722-787) over TokenEmbed::cuInfer (NeuronFuse.cu:176-218), SelfAttention::cuInfer (QKV.cu:617-702),
+// FFN::cuInfer (NeuronFuse.cu:615-656), Head4Token::cuInfer_1 (NeuronFuse.cu:842-862) and sample_argmax (GoPT.cpp:602-612).
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "kf_engine_common.h"
+
+namespace kf {
+
+constexpr int XE_NWG = 32;   /* workgroups (= CUs) of one XCD: one decoder */
+constexpr int XE_NXCD = 8;
+constexpr int XE_GRID = XE_NWG * XE_NXCD;
+
+struct XArgs {
+    const EngLayer* layers; /* kcache / vcache = sequence 0's; sequence s at + s * kv_seq_stride elements */
+    int n_layer, n_steps, n_seq;
+    float eps, qk_eps;
+    const float* rope_table;
+    const uint16_t* emb; /* bf16 [emb_rows, DIM] */
+    int emb_rows;
+    int32_t* d_state;          /* [n_seq][4]: {token, pos, -, -} */
+    const int32_t* d_forced;   /* [n_seq][forced_stride] or NULL */
+    int32_t* d_tokens_out;     /* [n_seq][tokens_stride] or NULL */
+    int forced_stride, tokens_stride;
+    uint16_t* x_out;           /* [n_seq][DIM]: the residual stream after the last layer of the last step */
+    uint16_t* logits;          /* [n_seq][vocab] */
+    long long kv_seq_stride;
+    int kv_stride, max_seq;
+    float qbias[7];
+    g_u32x4 head_w;
+    g_u16 head_norm;
+    int vocab, pick; /* pick: the greedy pick and the state update run inside (needed for n_steps > 1) */
+    char* loc;       /* XCD-local exchange areas, loc_stride bytes each */
+    size_t loc_stride;
+    int* ws;         /* [0] epoch, [1] error word, [16 + 32 x] ticket of XCD x */
+    unsigned long long* dbg; /* diagnostic instantiation: [step][layer][16] stamps of (sequence dbg_seq, workgroup rank dbg_wg) */
+    int dbg_seq, dbg_wg, dbg_steps;
+};
+
+// error word bits: 1 x, 2 q|k|v, 4 partials, 8 workgroups per XCD != 32, 16 pick, 32 token granule, 64 position beyond the cache, 128 ao, 256 xB, 512 act, 1024 head x
+
+template <int FMT_, int GQ_, int HD_, int NWV_, int DIM_, int QD_, int KVD_, int FFN_, int DEPTH_, bool DBG_>
+struct XCfg {
+    static constexpr int FMT = FMT_, GQ = GQ_, HD = HD_, NWV = NWV_, NCW = NWV_ - 1, DIM = DIM_, QD = QD_, KVD = KVD_, FFN = FFN_, DEPTH = DEPTH_, NWG = XE_NWG;
+    static constexpr bool DBG = DBG_;
+    static_assert(FMT_ == FMT_Q4 || FMT_ == FMT_Q4P, "4-bit PackedQ layers (arithmetic or register-table unpack)");
+    static constexpr int n_head = QD_ / HD_, n_kv = KVD_ / HD_;
+    static_assert(XE_NWG % n_kv == 0, "whole workgroups per kv-head");
+    static constexpr int SPK = XE_NWG / n_kv; /* key slices (= workgroups) per kv-head */
+    using SH = EngShape<FMT_, DIM_, QD_, KVD_, FFN_, XE_NWG>;
+    static constexpr int ME = QD_ / XE_NWG; /* ao elements a workgroup merges */
+    static_assert(QD_ % XE_NWG == 0 && ME % 4 == 0 && ME <= HD_ && HD_ % ME == 0 && ME <= 128, "merge elements per workgroup");
+    static constexpr int PSH = SPK * (2 * HD_ + 4); /* 8-byte granules of one head's slice partials: [HD / ME][SPK][ME] values x 2, then [SPK][4] {m, L lo, L hi, -} */
+    // the XCD-local exchange area (dwords)
+    static constexpr int xA = 0, qkv = xA + eng_gran_dw(DIM_), ao = qkv + eng_gran_dw(QD_ + 2 * KVD_), xB = ao + eng_gran_dw(QD_), act = xB + eng_gran_dw(DIM_),
+                         part = act + eng_gran_dw(FFN_), hbest = part + eng_gran_dw(2 * n_head * PSH), tokg = hbest + eng_gran_dw(2 * XE_NWG), loc_dw = tokg + eng_gran_dw(2);
+    // LM head (bf16 [vocab, DIM]): the geometry gemv_launch picks for a many-row bf16 matrix of this width
+    static constexpr int HnBlk = DIM_ / 8, Hlpr_log2 = c_lpr_log2(DIM_ / 8, 1L << 20), HLPR = 1 << Hlpr_log2, HRPS = 64 >> Hlpr_log2, Hiters = (HnBlk + HLPR - 1) / HLPR;
+    static constexpr int XCH = 8; /* fp32 activations: 16-byte chunks per 32-weight block */
+    static constexpr int maxR = (SH::P1::R > SH::P5::R ? SH::P1::R : SH::P5::R) > (SH::P4::R > SH::P6::R ? SH::P4::R : SH::P6::R) ? (SH::P1::R > SH::P5::R ? SH::P1::R : SH::P5::R)
+                                                                                                                                      : (SH::P4::R > SH::P6::R ? SH::P4::R : SH::P6::R);
+};
+constexpr size_t xe_loc_stride(int loc_dw) { return ((size_t)loc_dw * 4 + 4095) & ~(size_t)4095; }
+
+#define XE_STAMP(k)                                                                                                                       \
+    do {                                                                                                                                  \
+        if (C::DBG && S.stamp && lane == 0) a.dbg[((size_t)S.step * a.n_layer + l) * 32 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+
+struct XLds {
+    const EngLayer* lay;
+    u32x4* xs[2];
+    uint16_t *xrawA, *xrawB, *qraw, *kraw, *vraw, *qb, *knew;
+    float* wmax;
+    double* comb; /* [NCW][GQ][hd + 2] */
+    double* msc;  /* [SPK][ME] + [SPK] shifts */
+    uint32_t* outb;
+    int* cnt;
+};
+struct XSeq { /* this workgroup's place in its decoder, and the step's slice */
+    int seq, r, step;
+    int pos, len, kvh, split, h0, t0, t1, me0;
+    bool empty, own_new, stamp;
+    int j1, s1, M1, q_out0;
+    long long kv_off; /* elements: this sequence's K/V cache behind sequence 0's */
+};
+
+// ---- ring of 16-byte blocks in flight (per lane), with their group's step / zero.  ONE ring serves every phase: entry e of a phase is the wave's block e (single-matrix
+// phases) or -- gate | up -- block e / 2 of gate_proj (e even) resp. up_proj (e odd), so a slot that falls idle in one phase's last round takes the next phase's entry of the
+// same index whatever the two phases are.
+template <int D>
+struct XRing {
+    u32x4 w[D];
+    uint16_t st[D], ze[D];
+};
+// One mat-vec phase as RUN-TIME parameters of one wave (all wave-uniform: scalar registers).  The geometry figures are the compile-time constants of PlanT (the lanes per row,
+// rows per wave step and steps per row gemv_launch picks for the matrices: the canonical summation order), handed to ONE copy of the streaming loop: four typed copies of the
+// DEPTH-times unrolled block code were 150 KB of instructions.
+struct XPhase {
+    EngMat m, m2;    /* m2: up_proj beside gate_proj (paired) */
+    float qb, qb2;
+    int nBlk, lpr_log2, iters, rps_log2;
+    int paired;
+    int s0, Mj;      /* the workgroup's first slot counted inside the matrix; the matrix's rows */
+    int n;           /* ring entries this wave walks: its slots x iters (x 2 paired) */
+    int row0;        /* first row of the workgroup's piece, counted inside the matrix */
+    uint32_t wbytes, gbytes;
+};
+template <class PL, int NCW>
+__device__ __forceinline__ XPhase xe_phase(const EngMat m, const EngMat m2, float qb, float qb2, int s0, int Mj, int cw) {
+    static_assert(PL::nBlk % 4 == 0 && PL::LPR % 4 == 0, "a group's four blocks start at a multiple of four");
+    XPhase P;
+    // the table entries come out of LDS as vector registers: said to be wave-uniform HERE, once per phase (a buffer load on a descriptor the compiler believes divergent is
+    // wrapped in a readfirstlane / compare / exec-mask loop -- per load)
+    auto uni = [](auto ptr) {
+        const unsigned long long v = (unsigned long long)(uintptr_t)ptr;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (decltype(ptr))(uintptr_t)(((unsigned long long)hi << 32) | lo);
+    };
+    P.m.w = uni(m.w), P.m.step = uni(m.step), P.m.zero = uni(m.zero), P.m2.w = uni(m2.w), P.m2.step = uni(m2.step), P.m2.zero = uni(m2.zero);
+    P.qb = qb, P.qb2 = qb2;
+    P.nBlk = PL::nBlk, P.lpr_log2 = PL::lpr_log2, P.iters = PL::iters, P.rps_log2 = 6 - PL::lpr_log2, P.paired = PL::PAIRED ? 1 : 0;
+    P.s0 = s0, P.Mj = Mj, P.row0 = s0 * PL::RPS;
+    P.n = cw < PL::spg ? ((PL::spg - cw + NCW - 1) / NCW) * PL::iters * (PL::PAIRED ? 2 : 1) : 0;
+    P.wbytes = (uint32_t)Mj * (uint32_t)PL::nBlk * 16u, P.gbytes = (uint32_t)Mj * (uint32_t)(PL::nBlk / 4) * 2u;
+    return P;
+}
+struct XLaneGeo { /* the lane's place in a phase's row slots */
+    uint32_t vblk; /* sub * nBlk + ll: the lane's block offset inside a slot's iteration */
+    int sub, ll;
+};
+__device__ __forceinline__ XLaneGeo xe_lane_geo(const XPhase& P, int lane) {
+    XLaneGeo g;
+    g.sub = lane >> P.lpr_log2, g.ll = lane & ((1 << P.lpr_log2) - 1);
+    g.vblk = (uint32_t)g.sub * (uint32_t)P.nBlk + (uint32_t)g.ll;
+    return g;
+}
+// entry e of phase P into ring slot d; on = false: a load that touches no memory (a zero-sized descriptor: every lane is out of range and reads 0) -- the ring slots are
+// assigned unconditionally in the streaming loop, so that the compiler keeps ONE register set per slot (a conditional refill inside the loop doubled them: 500 spilled registers)
+// Buffer loads: block index = [scalar: the slot's first row and the iteration] + [lane: sub * nBlk + ll]; rows past the matrix read zeros (the descriptor's bound), columns
+// past the row are masked at the multiply.
+template <int NCW, int D>
+__device__ __forceinline__ void xe_issue(const XPhase& P, const XLaneGeo& G, int e, int d, int cw, bool on, XRing<D>& R) {
+    const int k = P.paired ? e >> 1 : e;
+    const int sl = k / P.iters, it = k - sl * P.iters;
+    const uint32_t ublk = (uint32_t)(((P.s0 + cw + sl * NCW) << P.rps_log2) * P.nBlk + (it << P.lpr_log2)); /* wave-uniform; a multiple of 4 */
+    const bool second = P.paired && (e & 1);
+    const g_u32x4 pw = second ? P.m2.w : P.m.w;
+    const g_u16 ps = second ? P.m2.step : P.m.step, pz = second ? P.m2.zero : P.m.zero;
+    R.w[d] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(eng_rsrc((const void*)pw, on ? P.wbytes : 0u), G.vblk * 16u, ublk * 16u, 2 /* nt */));
+    R.st[d] = __builtin_amdgcn_raw_buffer_load_b16(eng_rsrc((const void*)ps, on ? P.gbytes : 0u), (G.vblk >> 2) * 2u, (ublk >> 2) * 2u, 0);
+    R.ze[d] = __builtin_amdgcn_raw_buffer_load_b16(eng_rsrc((const void*)pz, on ? P.gbytes : 0u), (G.vblk >> 2) * 2u, (ublk >> 2) * 2u, 0);
+}
+// a phase's first entries into an idle ring
+template <int NCW, int D>
+__device__ __forceinline__ void xe_fill(const XPhase& P, int cw, int lane, XRing<D>& R) {
+    const XLaneGeo G = xe_lane_geo(P, lane);
+#pragma unroll
+    for (int d = 0; d < D; d++) xe_issue<NCW, D>(P, G, d, d, cw, d < P.n, R);
+}
+// one block's 32 products into the lane's chain pair: BlockDotF<FMT> (kf_gemv_blocks.h) on the fp32 activation chunks [8][nBlk] in LDS
+template <int FMT>
+__device__ __forceinline__ f32x2_t xe_block(u32x4 w, uint16_t st16, uint16_t ze16, float qb, const f32x4* xf, int col, int nBlk, int lane, f32x2_t acc) {
+    const float step = bf2f(st16), zero = bf2f(ze16), nb = -(qb * step);
+    const uint32_t D[4] = {w.w, w.z, w.y, w.x};
+    const f32x4* xc = xf + col;
+    if constexpr (FMT == FMT_Q4P) {
+        const float q0 = (float)((lane & 3) << 2);
+        uint32_t r = pack_bf16x2(fmaf(q0, step, nb), fmaf(q0 + 1.0f, step, nb));
+        const uint32_t P0 = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
+        r = pack_bf16x2(fmaf(q0 + 2.0f, step, nb), fmaf(q0 + 3.0f, step, nb));
+        const uint32_t P1 = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
+        const uint32_t tlm = __builtin_amdgcn_perm(P1, P0, 0x06040200u), thm = __builtin_amdgcn_perm(P1, P0, 0x07050301u);
+        PermLut t;
+        t.tl[0] = quad_bcast<0>(tlm), t.tl[1] = quad_bcast<1>(tlm), t.tl[2] = quad_bcast<2>(tlm), t.tl[3] = quad_bcast<3>(tlm);
+        t.th[0] = quad_bcast<0>(thm), t.th[1] = quad_bcast<1>(thm), t.th[2] = quad_bcast<2>(thm), t.th[3] = quad_bcast<3>(thm);
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc = perm_fma_dword(D[i], xc[(2 * i) * nBlk], xc[(2 * i + 1) * nBlk], t, acc);
+    } else {
+        const float step16 = step * 0.0625f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc = arith_fma_dword(D[i], xc[(2 * i) * nBlk], xc[(2 * i + 1) * nBlk], step, step16, nb, zero, acc);
+    }
+    return acc;
+}
+// One mat-vec phase of a compute wave: ONE copy of this loop serves every phase.  The ring holds the wave's first min(D, n) entries on entry (xe_fill / the previous phase's
+// last round); entry e + D is requested when entry e has been multiplied, and in the last round slot d takes entry d of the NEXT phase NX (nx_on; they do not depend on the
+// hand-off that separates the phases).  epi(row, v, v2) runs in the lane that owns a finished row; tail0() once, when the last round begins.
+template <class C, int D, typename Epi, typename Tail0>
+__device__ __forceinline__ void xe_mv_run(const XPhase& P, const XPhase& NX, bool nx_on, int cw, int lane, const u32x4* xs, XRing<D>& R, Epi&& epi, Tail0&& tail0) {
+    constexpr int NCW = C::NCW;
+    static_assert((D % 2) == 0, "gate | up entries come in pairs");
+    const int n = P.n, n_pad = n > 0 ? (n + D - 1) / D * D : D; /* at least one round: the last round is where the next phase's entries are requested */
+    const f32x4* xf = reinterpret_cast<const f32x4*>(xs);
+    const XLaneGeo G = xe_lane_geo(P, lane), GN = xe_lane_geo(NX, lane);
+    f32x2_t acc{0.f, 0.f}, acc2{0.f, 0.f};
+    for (int e0 = 0; e0 < n_pad; e0 += D) {
+        const bool last = e0 + D >= n_pad;
+        if (last) tail0();
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const int e = e0 + d;
+            if (e < n) {
+                const int k = P.paired ? e >> 1 : e;
+                const int sl = k / P.iters, it = k - sl * P.iters;
+                const int row = ((P.s0 + cw + sl * NCW) << P.rps_log2) + G.sub, colr = (it << P.lpr_log2) + G.ll;
+                const bool ok = row < P.Mj && colr < P.nBlk;
+                const int col = colr < P.nBlk ? colr : P.nBlk - 1;
+                const bool second = P.paired && (d & 1);
+                if (it == 0) {
+                    if (second) acc2 = f32x2_t{0.f, 0.f};
+                    else acc = f32x2_t{0.f, 0.f};
+                }
+                const f32x2_t in = second ? acc2 : acc;
+                const f32x2_t r = xe_block<C::FMT>(R.w[d], R.st[d], R.ze[d], second ? P.qb2 : P.qb, xf, col, P.nBlk, lane, in);
+                const f32x2_t o = acc_pick(ok, r, in);
+                if (second) acc2 = o;
+                else acc = o;
+                if (it == P.iters - 1 && (!P.paired || second)) {
+                    const float v = group_sum(acc_join(acc), P.lpr_log2);
+                    float v2 = 0.f;
+                    if (P.paired) v2 = group_sum(acc_join(acc2), P.lpr_log2);
+                    if (G.ll == 0 && row < P.Mj) epi(row, v, v2);
+                }
+            }
+            // refill slot d (always a load: see xe_issue)
+            const bool more = e + D < n, nxt = !more && last && nx_on && d < NX.n;
+            if (more || !nxt) xe_issue<NCW, D>(P, G, more ? e + D : 0, d, cw, more, R);
+            else xe_issue<NCW, D>(NX, GN, d, d, cw, true, R);
+        }
+    }
+}
+// the waves that own rows of a phase leave their granules in LDS; the one that arrives last stores the workgroup's piece, 16 bytes per lane, with PLAIN stores (this XCD's L2)
+__device__ __forceinline__ void xe_publish(const XLds& L, uint32_t* dst, int nrows, int nwaves, int lane) {
+    int old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(L.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old != nwaves - 1) return;
+    if (lane == 0) *L.cnt = 0;
+    for (int i = 4 * lane; i < nrows; i += 256) *reinterpret_cast<u32x4*>(dst + i) = *reinterpret_cast<const u32x4*>(L.outb + i);
+}
+
+// ---- attention: the workgroup's key slice of its kv-head, streamed by the NCW compute waves (two batches of U tiles in flight per lane)
+template <class C>
+struct XAttn {
+    static constexpr int U = 2;
+    u32x4 kk[2][U], vv[2][U];
+    uint16_t nw0, nw1;
+    float rc, rs;
+};
+template <class C>
+__device__ __forceinline__ void xe_attn_issue(const XArgs& a, const EngLayer& ly, const XSeq& S, int cw, int lane, XAttn<C>& T, int b, int buf) {
+    constexpr int hd = C::HD, LPK = hd >> 3, KPW = 64 / LPK, lpk_log2 = (C::HD == 128 ? 7 : 6) - 3, NWA = C::NCW, U = XAttn<C>::U;
+    const int grp = lane >> lpk_log2, d0 = (lane & (LPK - 1)) * 8;
+    const int tb = S.t0 + cw * KPW + grp + b * U * NWA * KPW;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int t = tb + u * NWA * KPW;
+        T.kk[buf][u] = T.vv[buf][u] = u32x4{0, 0, 0, 0};
+        if (t < S.t1) {
+            const size_t off = (size_t)S.kv_off + (size_t)t * a.kv_stride + (size_t)S.kvh * hd + d0;
+            T.kk[buf][u] = *reinterpret_cast<const u32x4 KF_GLOBAL*>(ly.kcache + off);
+            T.vv[buf][u] = *reinterpret_cast<const u32x4 KF_GLOBAL*>(ly.vcache + off);
+        }
+    }
+}
+// compute waves only (the poller meets the three barriers in xe_poller_main).  p4_fill: requests the first o_proj blocks, called when the last batch's tiles are in registers
+template <class C, typename Fill>
+__device__ __forceinline__ void xe_attn_phase(const XArgs& a, const XLds& L, const XSeq& S, const EngLayer& ly, uint32_t gen, int cw, int lane, XAttn<C>& T, int l, Fill&& p4_fill) {
+    constexpr int GQ = C::GQ, hd = C::HD, hd_log2 = C::HD == 128 ? 7 : 6, LPK = hd >> 3, KPW = 64 / LPK, lpk_log2 = hd_log2 - 3, NWA = C::NCW, U = XAttn<C>::U;
+    constexpr int NQ = (GQ + NWA - 1) / NWA;
+    const int tid = (cw << 6) | lane, pos = S.pos, t1 = S.t1;
+    const int grp = lane >> lpk_log2, d0 = (lane & (LPK - 1)) * 8;
+    const int tstride = NWA * KPW, tstart = S.t0 + cw * KPW + grp;
+    const int nbatch = S.empty ? 0 : (S.t1 - S.t0 + U * tstride - 1) / (U * tstride);
+    __syncthreads(); /* raw heads staged */
+    if (!S.empty) {
+        const bool rope = a.rope_table != nullptr, qnorm = ly.norm_q != nullptr;
+        const int half = hd >> 1, j = lane < half ? lane : half - 1;
+#pragma unroll
+        for (int i = 0; i < NQ; i++) {
+            const int hq = cw + i * NWA;
+            if (hq < GQ) {
+                HeadRaw r;
+                r.x0 = L.qraw[hq * hd + j], r.x1 = L.qraw[hq * hd + j + half];
+                r.w0 = qnorm ? T.nw0 : r.x0, r.w1 = qnorm ? T.nw1 : r.x1;
+                prep_head_cs(r, qnorm, rope, T.rc, T.rs, hd, a.qk_eps, L.qb + hq * hd, nullptr, lane);
+            }
+        }
+        if (S.own_new && cw == (GQ % NWA)) {
+            HeadRaw r;
+            r.x0 = L.kraw[j], r.x1 = L.kraw[j + half];
+            r.w0 = ly.norm_k ? T.nw0 : r.x0, r.w1 = ly.norm_k ? T.nw1 : r.x1;
+            prep_head_cs(r, ly.norm_k != nullptr, rope, T.rc, T.rs, hd, a.qk_eps, L.knew, nullptr, lane);
+        }
+    }
+    __syncthreads(); /* heads prepared */
+    if (!S.empty) {
+        if (S.own_new && tid < hd / 8) { /* the cache rows of this position: the prepared key, the raw value (K.out / V.out alias them in the reference) */
+            g_u16w krow = ly.kcache + (size_t)S.kv_off + (size_t)pos * a.kv_stride + (size_t)S.kvh * hd;
+            g_u16w vrow = ly.vcache + (size_t)S.kv_off + (size_t)pos * a.kv_stride + (size_t)S.kvh * hd;
+            *reinterpret_cast<u32x4 KF_GLOBAL*>(const_cast<uint16_t KF_GLOBAL*>(krow) + 8 * tid) = *reinterpret_cast<const u32x4*>(L.knew + 8 * tid);
+            *reinterpret_cast<u32x4 KF_GLOBAL*>(const_cast<uint16_t KF_GLOBAL*>(vrow) + 8 * tid) = *reinterpret_cast<const u32x4*>(L.vraw + 8 * tid);
+        }
+        CanonAcc<GQ> A;
+        A.init();
+        float qf[GQ][8];
+#pragma unroll
+        for (int hq = 0; hq < GQ; hq++) {
+            const u32x4 qv = *reinterpret_cast<const u32x4*>(L.qb + hq * hd + d0);
+            const uint32_t q4[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) qf[hq][2 * i] = bf_lo(q4[i]), qf[hq][2 * i + 1] = bf_hi(q4[i]);
+        }
+        const float rden = 1.0f / sqrtf((float)hd);
+        auto batch = [&](int b, int buf) {
+            const int tb = tstart + b * U * tstride;
+            u32x4 ck[U], cv[U];
+            bool valid[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int t = tb + u * tstride;
+                valid[u] = t < t1;
+                ck[u] = T.kk[buf][u], cv[u] = T.vv[buf][u];
+                if (valid[u] && t == pos) ck[u] = *reinterpret_cast<const u32x4*>(L.knew + d0), cv[u] = *reinterpret_cast<const u32x4*>(L.vraw + d0);
+            }
+            canon_batch<GQ, LPK, U>(A, qf, ck, cv, valid, lpk_log2, rden);
+        };
+        for (int b = 0; b < nbatch; b += 2) { /* batch b sits in buffer 0 (requested by the phase before, or by the step below), b + 1 goes to buffer 1 */
+            if (b + 1 < nbatch) xe_attn_issue<C>(a, ly, S, cw, lane, T, b + 1, 1);
+            batch(b, 0);
+            if (b + 1 >= nbatch) break;
+            if (b + 2 < nbatch) xe_attn_issue<C>(a, ly, S, cw, lane, T, b + 2, 0);
+            batch(b + 1, 1);
+        }
+        canon_wave_to_lds<GQ, LPK>(A, L.comb + (size_t)cw * GQ * (hd + 2), hd, lane, d0);
+    }
+    p4_fill(); /* the first o_proj blocks: two hand-offs (slice partials, ao) lie between here and their use -- inside the key loop the ring would cost the loop 48 registers */
+    __syncthreads(); /* the waves' sums in LDS */
+    // the slice's partial {O[hd], L, m} per query head, as {32 bits, generation} granule pairs in this XCD's partial area (an empty slice: sums 0, exponent -inf)
+    constexpr int PSD = hd + 2, ME = C::ME, SPK = C::SPK;
+    unsigned long long* const pbase = reinterpret_cast<unsigned long long*>(reinterpret_cast<uint32_t*>(a.loc + (size_t)S.seq * a.loc_stride) + C::part);
+    const unsigned long long gg = (unsigned long long)gen << 32;
+    for (int i = tid; i < GQ * hd; i += NWA * 64) {
+        const int hq = i >> hd_log2, d = i & (hd - 1);
+        double o = 0.0, Ls = 0.0;
+        float ms = -__builtin_inff();
+        if (!S.empty) {
+#pragma unroll
+            for (int sl = 0; sl < NWA; sl++) ms = fmaxf(ms, (float)L.comb[((size_t)sl * GQ + hq) * PSD + hd + 1]);
+#pragma unroll
+            for (int sl = 0; sl < NWA; sl++) {
+                const double* c = L.comb + ((size_t)sl * GQ + hq) * PSD;
+                const int e = canon_shift((float)c[hd + 1] - ms);
+                o += ldexp_d(c[d], e);
+                Ls += ldexp_d(c[hd], e);
+            }
+        }
+        unsigned long long* dst = pbase + (size_t)(S.h0 + hq) * C::PSH;
+        const size_t oi = ((size_t)(d / ME) * (SPK * ME) + (size_t)S.split * ME + (d & (ME - 1))) * 2, mi = (size_t)hd * SPK * 2 + (size_t)S.split * 4;
+        const unsigned long long ob = __builtin_bit_cast(unsigned long long, o), lb = __builtin_bit_cast(unsigned long long, Ls);
+        *reinterpret_cast<ulonglong2*>(dst + oi) = ulonglong2{gg | (ob & 0xffffffffull), gg | (ob >> 32)};
+        if (d == 0) {
+            *reinterpret_cast<ulonglong2*>(dst + mi) = ulonglong2{gg | __float_as_uint(ms), gg | (lb & 0xffffffffull)};
+            dst[mi + 2] = gg | (lb >> 32);
+        }
+    }
+}
+
+// ---- the poller wave of a workgroup
+template <class C>
+__device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, const XSeq& S, int epoch, int lane) {
+    using SH = typename C::SH;
+    using P1 = typename SH::P1;
+    using P4 = typename SH::P4;
+    using P5 = typename SH::P5;
+    using P6 = typename SH::P6;
+    constexpr int GQ = C::GQ, hd = C::HD, XCH = C::XCH;
+    constexpr int ND = C::DIM / 256, NQD = C::QD / 256, NF = C::FFN / 256;
+    static_assert(C::DIM % 256 == 0 && C::QD % 256 == 0 && C::FFN % 256 == 0, "hand-off vectors in 1 KiB pieces");
+    uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)S.seq * a.loc_stride);
+    bool dead = false;
+    for (int l = 0; l < a.n_layer; l++) {
+        const EngLayer& ly = L.lay[l];
+        const uint32_t gen = (uint32_t)epoch * (uint32_t)a.n_layer + (uint32_t)l, tag = gen & 0xffffu;
+        XE_STAMP(0);
+        // P1's x (P4 adds it as the residual)
+        if (l == 0) {
+            int tok = a.d_state[S.seq * 4];
+            if (S.step > 0) { /* the id workgroup 0 of this decoder picked at the end of the previous step: {id, epoch of this step} */
+                const __amdgpu_buffer_rsrc_t rt = eng_rsrc(loc + C::tokg, 8u);
+                for (int spins = 0;; spins++) {
+                    const u32x2 g = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rt, 0, 0, 16 /* sc1 */));
+                    if (g.y == (uint32_t)epoch) {
+                        tok = (int)g.x;
+                        break;
+                    }
+                    if (dead || spins > ENG_SPIN_MAX) {
+                        if (!dead && lane == 0) atomicOr(a.ws + 1, 32);
+                        dead = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            if (a.d_forced) {
+                const int f = a.d_forced[(size_t)S.seq * a.forced_stride + S.pos];
+                if (f >= 0) tok = f;
+            }
+            if (tok < 0 || tok >= a.emb_rows) tok = 0;
+            eng_poll_stage<XCH, ND, P1::nBlk, true, true, true>(nullptr, a.emb + (size_t)tok * C::DIM, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, nullptr, nullptr, 0, 0);
+        } else {
+            eng_poll_stage<XCH, ND, P1::nBlk, true, false, true>(loc + C::xA, nullptr, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, nullptr, nullptr, 0, 0);
+        }
+        XE_STAMP(1);
+        __syncthreads(); /* B1 */
+        // P2: the raw q heads of this workgroup's kv-head, its k and v rows (only a slice with keys needs them)
+        if (!S.empty) {
+            const __amdgpu_buffer_rsrc_t rs = eng_rsrc(loc + C::qkv, (uint32_t)(C::QD + 2 * C::KVD) * 4u);
+            const uint32_t tagw = tag << 16;
+            constexpr int NLQ = (GQ * hd + 255) / 256;
+            u32x4 g[NLQ], gk;
+            const int e_kv = 4 * lane; /* < hd: k, < 2 hd: v */
+            const bool kv_in = e_kv < 2 * hd;
+            const int kv_src = e_kv < hd ? C::QD + S.kvh * hd + e_kv : C::QD + C::KVD + S.kvh * hd + (e_kv - hd);
+            for (int spins = 0;; spins++) {
+                uint32_t bad = 0;
+#pragma unroll
+                for (int r = 0; r < NLQ; r++) g[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (S.h0 * hd + 4 * (r * 64 + lane)) * 4, 0, 16));
+                gk = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (kv_in ? kv_src : 0) * 4, 0, 16));
+#pragma unroll
+                for (int r = 0; r < NLQ; r++) bad = (4 * (r * 64 + lane) < GQ * hd) ? tags_bad(g[r], tagw, bad) : bad;
+                bad = kv_in ? tags_bad(gk, tagw, bad) : bad;
+                if (all_good(bad)) break;
+                if (dead || spins > ENG_SPIN_MAX) {
+                    if (!dead && lane == 0) atomicOr(a.ws + 1, 2);
+                    dead = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int r = 0; r < NLQ; r++) {
+                const int e0 = 4 * (r * 64 + lane);
+                if (e0 < GQ * hd) *reinterpret_cast<u32x2*>(L.qraw + e0) = u32x2{(g[r].x & 0xffffu) | (g[r].y << 16), (g[r].z & 0xffffu) | (g[r].w << 16)};
+            }
+            if (kv_in) *reinterpret_cast<u32x2*>(L.kraw + e_kv) = u32x2{(gk.x & 0xffffu) | (gk.y << 16), (gk.z & 0xffffu) | (gk.w << 16)}; /* vraw = kraw + hd */
+        }
+        XE_STAMP(2);
+        __syncthreads(); /* raw heads staged */
+        __syncthreads(); /* heads prepared */
+        __syncthreads(); /* the waves' sums in LDS */
+        XE_STAMP(3);
+        // P3: merge the SPK slices of this workgroup's ME output elements (exact rescales to the largest exponent, fp64 sums, one division: kf_attn_common.h)
+        {
+            constexpr int ME = C::ME, SPK = C::SPK, NV = ME * SPK, NLM = (NV * 2 + 127) / 128; /* values; 16-byte loads (2 granules) per lane and sweep */
+            const int h = S.me0 >> (hd == 128 ? 7 : 6), dd = S.me0 & (hd - 1);
+            const unsigned long long* hbase = reinterpret_cast<const unsigned long long*>(loc + C::part) + (size_t)h * C::PSH;
+            const __amdgpu_buffer_rsrc_t rs_o = eng_rsrc(hbase + (size_t)(dd / ME) * (SPK * ME * 2), (uint32_t)(SPK * ME * 2) * 8u);
+            const __amdgpu_buffer_rsrc_t rs_ml = eng_rsrc(hbase + (size_t)hd * SPK * 2, (uint32_t)SPK * 32u);
+            u32x4 go[NLM], gm0, gm1;
+            const bool mine = lane < SPK;
+            for (int spins = 0;; spins++) {
+                uint32_t bad = 0;
+#pragma unroll
+                for (int r = 0; r < NLM; r++) go[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_o, (r * 64 + lane) * 16, 0, 16 /* sc1 */));
+                gm0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ml, (mine ? lane : 0) * 32, 0, 16));
+                gm1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ml, (mine ? lane : 0) * 32 + 16, 0, 16));
+#pragma unroll
+                for (int r = 0; r < NLM; r++) bad |= (r * 64 + lane) < NV ? ((go[r].y ^ gen) | (go[r].w ^ gen)) : 0u;
+                bad |= mine ? ((gm0.y ^ gen) | (gm0.w ^ gen) | (gm1.y ^ gen)) : 0u;
+                if (all_good(bad)) break;
+                if (dead || spins > ENG_SPIN_MAX) {
+                    if (!dead && lane == 0) atomicOr(a.ws + 1, 4);
+                    dead = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            XE_STAMP(4);
+#pragma unroll
+            for (int r = 0; r < NLM; r++) { /* value index vi = sp * ME + e */
+                const int vi = r * 64 + lane;
+                if (vi < NV) L.msc[vi] = __builtin_bit_cast(double, ((unsigned long long)go[r].z << 32) | go[r].x);
+            }
+            const float ms = mine ? __uint_as_float(gm0.x) : -__builtin_inff();
+            const double ls = mine ? __builtin_bit_cast(double, ((unsigned long long)gm1.x << 32) | gm0.z) : 0.0;
+            const float Mx = wave_max(ms);
+            const int sh = canon_shift(ms - Mx);
+            const double Lt = wave_sum_f64_fast(ldexp_d(ls, sh));
+            int* shl = reinterpret_cast<int*>(L.msc + NV);
+            if (mine) shl[lane] = sh;
+            uint32_t* mo = reinterpret_cast<uint32_t*>(L.msc + NV) + 64;
+#pragma unroll
+            for (int e0 = 0; e0 < ME; e0 += 64) {
+                const int e = e0 + lane;
+                if (e < ME) {
+                    double o = 0.0;
+#pragma unroll
+                    for (int sp = 0; sp < SPK; sp++) o += ldexp_d(L.msc[sp * ME + e], shl[sp]);
+                    mo[e] = (tag << 16) | (uint32_t)f2bf((float)(o / Lt));
+                }
+            }
+            if (4 * lane < ME) *reinterpret_cast<u32x4*>(loc + C::ao + S.me0 + 4 * lane) = *reinterpret_cast<const u32x4*>(mo + 4 * lane);
+        }
+        XE_STAMP(5);
+        // P4's ao, P5's xB (P6 adds it as the residual), P6's act
+        eng_poll_stage<XCH, NQD, P4::nBlk, false, false, true>(loc + C::ao, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, nullptr, nullptr, 0, 0);
+        XE_STAMP(6);
+        __syncthreads(); /* B4 */
+        eng_poll_stage<XCH, ND, P5::nBlk, true, false, true>(loc + C::xB, nullptr, tag, ly.norm_post, a.eps, L.xs[0], L.xrawB, lane, a.ws, dead, nullptr, nullptr, 0, 0);
+        XE_STAMP(7);
+        __syncthreads(); /* B5 */
+        eng_poll_stage<XCH, NF, P6::nBlk, false, false, true>(loc + C::act, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, nullptr, nullptr, 0, 0);
+        XE_STAMP(8);
+        __syncthreads(); /* B6 */
+    }
+}
+
+// ---- the compute waves
+template <class C>
+__device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, const XSeq& S, int epoch, int cw, int lane, XRing<C::DEPTH>& R) {
+    using SH = typename C::SH;
+    using P1 = typename SH::P1;
+    using P4 = typename SH::P4;
+    using P5 = typename SH::P5;
+    using P6 = typename SH::P6;
+    constexpr int NCW = C::NCW, D = C::DEPTH;
+    static_assert(P1::R % 4 == 0 && P4::R % 4 == 0 && P5::R % 4 == 0 && P6::R % 4 == 0, "16-byte pieces");
+    static_assert(P1::total == XE_NWG * P1::spg && P4::total == XE_NWG * P4::spg && P5::total == XE_NWG * P5::spg && P6::total == XE_NWG * P6::spg, "every workgroup owns rows of every phase");
+    static_assert(P1::S1 % P1::spg == 0 && P1::S2 % P1::spg == 0, "a workgroup's P1 rows belong to one matrix");
+    uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)S.seq * a.loc_stride);
+    const float qb1 = S.j1 == 0 ? a.qbias[0] : (S.j1 == 1 ? a.qbias[1] : a.qbias[2]);
+    const int wg = S.r;
+    XAttn<C> T;
+    {
+        T.rc = 1.f, T.rs = 0.f;
+        if (a.rope_table && lane < (C::HD >> 1)) {
+            const float* tab_pos = a.rope_table + (size_t)S.pos * C::HD;
+            T.rc = tab_pos[2 * lane], T.rs = tab_pos[2 * lane + 1];
+        }
+    }
+    auto phase_of = [&](int q, const EngLayer& ly) { /* 0: q | k | v, 1: o_proj, 2: gate | up, 3: down_proj */
+        if (q == 0) return xe_phase<P1, NCW>(ly.m[S.j1], ly.m[S.j1], qb1, 0.f, S.s1, S.M1, cw);
+        if (q == 1) return xe_phase<P4, NCW>(ly.m[3], ly.m[3], a.qbias[3], 0.f, wg * P4::spg, P4::M0, cw);
+        if (q == 2) return xe_phase<P5, NCW>(ly.m[4], ly.m[5], a.qbias[4], a.qbias[5], wg * P5::spg, P5::M0, cw);
+        return xe_phase<P6, NCW>(ly.m[6], ly.m[6], a.qbias[6], 0.f, wg * P6::spg, P6::M0, cw);
+    };
+    xe_fill<NCW, D>(phase_of(0, L.lay[0]), cw, lane, R);
+    for (int l = 0; l < a.n_layer; l++) {
+        const EngLayer& ly = L.lay[l];
+        const uint32_t gen = (uint32_t)epoch * (uint32_t)a.n_layer + (uint32_t)l, tag = gen & 0xffffu, tag_next = (gen + 1u) & 0xffffu;
+        const bool last = l == a.n_layer - 1;
+        const EngLayer& lyn = L.lay[last ? l : l + 1];
+        if (!S.empty) { /* q-norm (waves that prepare a q head) / k-norm (the wave that prepares the new key) weights of this lane's pair */
+            const int half = C::HD >> 1, j = lane < half ? lane : half - 1;
+            g_u16 np = cw < C::GQ ? ly.norm_q : ly.norm_k;
+            T.nw0 = T.nw1 = 0;
+            if (np) T.nw0 = np[j], T.nw1 = np[j + half];
+        }
+        for (int q = 0; q < 4; q++) {
+            // q = 0: RMSNorm(x) -> q | k | v rows, then (below) the attention; 1: o_proj + residual -> xB; 2: RMSNorm + gate | up + SwiGLU -> act; 3: down_proj + residual -> next x
+            const XPhase P = phase_of(q, ly);
+            const XPhase NX = phase_of(q == 3 ? 0 : q + 1, q == 3 ? lyn : ly);
+            const bool nx_on = q == 0 ? false : (q == 3 ? !last : true); /* behind q | k | v comes the attention (its first tiles are requested instead); the ring is not carried through the head phase */
+            const u32x4* xs = (q == 0 || q == 2) ? L.xs[0] : L.xs[1];
+            const int nrows = q == 0 ? P1::R : (q == 1 ? P4::R : (q == 2 ? P5::R : P6::R));
+            const int spg = q == 0 ? P1::spg : (q == 1 ? P4::spg : (q == 2 ? P5::spg : P6::spg));
+            const int nwp = spg < NCW ? spg : NCW;
+            uint32_t* const dst = loc + (q == 0 ? C::qkv + S.q_out0 : (q == 1 ? C::xB + wg * P4::R : (q == 2 ? C::act + wg * P5::R : C::xA + wg * P6::R)));
+            __syncthreads(); /* the phase's activations are staged (B1 / B4 / B5 / B6) */
+            if (cw == 0) XE_STAMP(16 + 2 * q);
+            xe_mv_run<C, D>(
+                P, NX, nx_on, cw, lane, xs, R,
+                [&](int row, float v, float v2) {
+                    uint32_t g;
+                    if (q == 0) {
+                        g = (tag << 16) | (uint32_t)f2bf(v);
+                    } else if (q == 1) {
+                        g = (tag << 16) | (uint32_t)f2bf(bf2f(L.xrawA[row]) + bf2f(f2bf(v))); /* CU_add3: bf16(x + bf16(W.x)) */
+                    } else if (q == 2) {
+                        const float gt = round_bf16(v), up = round_bf16(v2); /* CU_swiglu_v0 on the two bf16-rounded projections */
+                        g = (tag << 16) | (uint32_t)f2bf((gt * up) / (1.0f + kf_expf(-gt)));
+                    } else {
+                        const uint16_t y = f2bf(bf2f(L.xrawB[row]) + bf2f(f2bf(v)));
+                        if (last) a.x_out[(size_t)S.seq * C::DIM + row] = y;
+                        g = (tag_next << 16) | (uint32_t)y;
+                    }
+                    L.outb[row - P.row0] = g;
+                },
+                [&]() {
+                    if (q == 0 && !S.empty) xe_attn_issue<C>(a, ly, S, cw, lane, T, 0, 0); /* the slice's first tiles (rows of earlier positions; row `pos` is substituted) */
+                });
+            if (cw < nwp) xe_publish(L, dst, nrows, nwp, lane);
+            if (cw == 0) XE_STAMP(17 + 2 * q);
+            if (q == 0) { /* q/k-norm + RoPE + attention over the workgroup's key slice; the slice partial into the XCD's partial area; then the first o_proj blocks */
+                xe_attn_phase<C>(a, L, S, ly, gen, cw, lane, T, l, [&]() { xe_fill<NCW, D>(phase_of(1, ly), cw, lane, R); });
+                if (cw == 0) XE_STAMP(24);
+            }
+        }
+    }
+}
+
+// ---- the LM head + greedy pick as trailing phases (eng_head_main of kf_engine.hip on 32 workgroups): final RMSNorm, the [vocab, dim] bf16 mat-vec with the arithmetic
+// of gemv_kernel<FMT_BF16, .., CANON> (same lanes per row, chain pair, tree, bf16 store), first-maximum arg-max over the stored values
+template <class C>
+__device__ __forceinline__ void xe_head_main(const XArgs& a, const XLds& L, const XSeq& S, int epoch, bool more_steps, int wave, int lane) {
+    constexpr int NWV = C::NWV, NWG = XE_NWG, nBlk = C::HnBlk, LPR = C::HLPR, RPS = C::HRPS, ITERS = C::Hiters, HG = 4;
+    constexpr int ND = C::DIM / 256;
+    const int wg = S.r;
+    uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)S.seq * a.loc_stride);
+    uint16_t* const logits = a.logits + (size_t)S.seq * a.vocab;
+    const int sub = lane >> C::Hlpr_log2, ll = lane & (LPR - 1);
+    const int total = (a.vocab + RPS - 1) / RPS, spg = (total + NWG - 1) / NWG;
+    const int s_wg = wg * spg;
+    int s_end = s_wg + spg;
+    s_end = s_end < total ? s_end : total;
+    const int nmine = s_end > s_wg + wave ? (s_end - s_wg - wave + NWV - 1) / NWV : 0;
+    const int nbatch = (nmine + HG - 1) / HG;
+    u32x4 w[2][HG][ITERS];
+    auto issue = [&](int b, int buf) {
+#pragma unroll
+        for (int g = 0; g < HG; g++) {
+            int i = b * HG + g;
+            i = i < nmine ? i : (nmine > 0 ? nmine - 1 : 0);
+            int row = (s_wg + wave + NWV * i) * RPS + sub;
+            row = row < a.vocab ? row : a.vocab - 1;
+#pragma unroll
+            for (int it = 0; it < ITERS; it++) {
+                int col = it * LPR + ll;
+                col = col < nBlk ? col : nBlk - 1;
+                w[buf][g][it] = __builtin_nontemporal_load(a.head_w + (size_t)row * nBlk + col);
+            }
+        }
+    };
+    const uint32_t gen = (uint32_t)(epoch + 1) * (uint32_t)a.n_layer, tag = gen & 0xffffu; /* the generation the last layer's down_proj published its rows with */
+    if (wave == NWV - 1) {
+        bool dead = false;
+        eng_poll_stage<1, ND, nBlk, true, false, false>(loc + C::xA, nullptr, tag, a.head_norm, a.eps, L.xs[0], nullptr, lane, a.ws, dead, nullptr, nullptr, 0, 0);
+    } else {
+        issue(0, 0); /* ahead of the hand-off of x (the poller's own first rows are requested behind its sweep: loads return in order) */
+    }
+    __syncthreads();
+    if (wave == NWV - 1) issue(0, 0);
+    float xf[ITERS][8];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        int col = it * LPR + ll;
+        col = col < nBlk ? col : nBlk - 1;
+        const u32x4 xv = L.xs[0][col];
+        const uint32_t x4[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) xf[it][2 * i] = bf_lo(x4[i]), xf[it][2 * i + 1] = bf_hi(x4[i]);
+    }
+    float best_v = -__builtin_inff();
+    int best_i = 0x7fffffff;
+    auto compute = [&](int b, int buf) {
+#pragma unroll
+        for (int g = 0; g < HG; g++) {
+            const int i = b * HG + g;
+            const int row = (s_wg + wave + NWV * i) * RPS + sub;
+            f32x2_t acc{0.f, 0.f};
+#pragma unroll
+            for (int it = 0; it < ITERS; it++) {
+                const uint32_t w4[4] = {w[buf][g][it].x, w[buf][g][it].y, w[buf][g][it].z, w[buf][g][it].w};
+                f32x2_t r = acc;
+#pragma unroll
+                for (int i2 = 0; i2 < 4; i2++) r = pk_fma(f32x2_t{bf_lo(w4[i2]), bf_hi(w4[i2])}, f32x2_t{xf[it][2 * i2], xf[it][2 * i2 + 1]}, r);
+                acc = acc_pick(it * LPR + ll < nBlk, r, acc);
+            }
+            const float v = group_sum(acc_join(acc), C::Hlpr_log2);
+            if (ll == 0 && i < nmine && row < a.vocab) {
+                const uint16_t o = f2bf(v);
+                logits[row] = o;
+                const float fv = bf2f(o);
+                if (fv > best_v || (fv == best_v && row < best_i)) best_v = fv, best_i = row;
+            }
+        }
+    };
+    for (int b = 0; b < nbatch; b += 2) {
+        issue(b + 1, 1);
+        compute(b, 0);
+        if (b + 1 >= nbatch) break;
+        issue(b + 2, 0);
+        compute(b + 1, 1);
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        const float ov = __shfl_xor(best_v, m, 64);
+        const int oi = __shfl_xor(best_i, m, 64);
+        if (ov > best_v || (ov == best_v && oi < best_i)) best_v = ov, best_i = oi;
+    }
+    float* rv = L.wmax;
+    int* ri = reinterpret_cast<int*>(L.wmax + NWV);
+    if (lane == 0) rv[wave] = best_v, ri[wave] = best_i;
+    __syncthreads();
+    unsigned long long* hb = reinterpret_cast<unsigned long long*>(loc + C::hbest);
+    if (wave == 0 && lane == 0) {
+        for (int k = 1; k < NWV; k++)
+            if (rv[k] > best_v || (rv[k] == best_v && ri[k] < best_i)) best_v = rv[k], best_i = ri[k];
+        hb[wg] = ((unsigned long long)((tag << 16) | (uint32_t)f2bf(best_v)) << 32) | (unsigned long long)(uint32_t)best_i;
+    }
+    if (wg == 0 && wave == NWV - 1 && a.pick) { /* the pick over the decoder's 32 workgroup maxima: two granules per lane */
+        const __amdgpu_buffer_rsrc_t rs = eng_rsrc(hb, NWG * 8u);
+        u32x4 g0{0, 0, 0, 0};
+        bool ok = false;
+        const bool mine = lane < NWG / 2;
+        for (int spins = 0; spins <= ENG_SPIN_MAX; spins++) {
+            g0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (mine ? lane : 0) * 16, 0, 16 /* sc1 */));
+            const uint32_t bad = ((g0.y >> 16) ^ tag) | ((g0.w >> 16) ^ tag);
+            if (all_good(bad)) {
+                ok = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        float bv = -__builtin_inff();
+        int bi = 0x7fffffff;
+        if (mine) {
+            const uint32_t hv[2] = {g0.y, g0.w}, hi[2] = {g0.x, g0.z};
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const float fv = bf2f((uint16_t)(hv[k] & 0xffffu));
+                const int ix = (int)hi[k];
+                if (fv > bv || (fv == bv && ix < bi)) bv = fv, bi = ix;
+            }
+        }
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) {
+            const float ov = __shfl_xor(bv, m, 64);
+            const int oi = __shfl_xor(bi, m, 64);
+            if (ov > bv || (ov == bv && oi < bi)) bv = ov, bi = oi;
+        }
+        if (lane == 0) {
+            const int err = __hip_atomic_load(a.ws + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ok && err == 0 && bi >= 0 && bi < a.vocab) { /* never advance the decode state on a timed-out hand-off */
+                int32_t* st = a.d_state + S.seq * 4;
+                const int p = st[1];
+                if (a.d_tokens_out) a.d_tokens_out[(size_t)S.seq * a.tokens_stride + p] = bi;
+                st[0] = bi, st[1] = p + 1;
+                if (more_steps) *reinterpret_cast<u32x2*>(loc + C::tokg) = u32x2{(uint32_t)bi, (uint32_t)(epoch + 1)};
+            } else if (err == 0) {
+                atomicOr(a.ws + 1, 16);
+            }
+        }
+    }
+}
+
+template <class C>
+__global__ void __launch_bounds__(C::NWV * 64) xengine_kernel(const XArgs a) {
+    constexpr int hd = C::HD, GQ = C::GQ, NWV = C::NWV, NCW = C::NCW;
+    using P1 = typename C::SH::P1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ---- LDS carve (compile-time offsets; the layer table behind them)
+    XLds L;
+    constexpr int maxK = C::DIM > C::QD ? (C::DIM > C::FFN ? C::DIM : C::FFN) : (C::QD > C::FFN ? C::QD : C::FFN);
+    constexpr int xs_bytes = (maxK * 4 + 15) & ~15, xr_bytes = (C::DIM * 2 + 15) & ~15;
+    constexpr size_t o_attn = (size_t)2 * xs_bytes + 2 * xr_bytes;
+    constexpr size_t o_comb = (o_attn + sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + 15) & ~(size_t)15;
+    constexpr size_t o_msc = o_comb + sizeof(double) * (size_t)NCW * GQ * (hd + 2);
+    constexpr size_t o_wmax = o_msc + sizeof(double) * ((size_t)C::ME * C::SPK) + 4 * 64 + 4 * 128;
+    constexpr size_t o_outb = o_wmax + 4 * 2 * 16;
+    constexpr size_t o_cnt = o_outb + 4 * (size_t)((C::maxR + 63) & ~63);
+    constexpr size_t fixed_bytes = (o_cnt + 64 + 15) & ~(size_t)15;
+    static_assert(NWV <= 16, "wmax scratch");
+    EngLayer* lay = reinterpret_cast<EngLayer*>(smem + fixed_bytes);
+    L.lay = lay;
+    L.xs[0] = reinterpret_cast<u32x4*>(smem);
+    L.xs[1] = reinterpret_cast<u32x4*>(smem + xs_bytes);
+    L.xrawA = reinterpret_cast<uint16_t*>(smem + 2 * xs_bytes);
+    L.xrawB = reinterpret_cast<uint16_t*>(smem + 2 * xs_bytes + xr_bytes);
+    L.qraw = reinterpret_cast<uint16_t*>(smem + o_attn);
+    L.kraw = L.qraw + GQ * hd, L.vraw = L.kraw + hd, L.qb = L.vraw + hd, L.knew = L.qb + GQ * hd;
+    L.comb = reinterpret_cast<double*>(smem + o_comb);
+    L.msc = reinterpret_cast<double*>(smem + o_msc);
+    L.wmax = reinterpret_cast<float*>(smem + o_wmax);
+    L.outb = reinterpret_cast<uint32_t*>(smem + o_outb);
+    L.cnt = reinterpret_cast<int*>(smem + o_cnt);
+    if (tid == 0) *L.cnt = 0;
+    if (a.ws[1] != 0) return; /* an earlier launch timed out: nothing runs until the host has cleared the word (xengine_reset) */
+    // ---- which decoder, which place in it
+    XSeq S;
+    {
+        int* xi = L.cnt + 1;
+        if (tid == 0) {
+            const int x = eng_xcc();
+            xi[0] = x, xi[1] = __hip_atomic_fetch_add(a.ws + 16 + x * 32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        S.seq = xi[0], S.r = xi[1] & (XE_NWG - 1);
+        if (xi[1] >= XE_NWG && tid == 0) atomicOr(a.ws + 1, 8); /* not 32 workgroups on this XCD: the polls time out, the word says why */
+    }
+    const int epoch0 = a.ws[0];
+    if (S.seq >= a.n_seq) { /* an XCD without a sequence: its workgroups leave (the last one to arrive zeroes the ticket for the next launch) */
+        if (tid == 0 && L.cnt[2] == XE_NWG - 1) a.ws[16 + S.seq * 32] = 0;
+        return;
+    }
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.layers);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(lay);
+        const int nw = a.n_layer * (int)(sizeof(EngLayer) / 4);
+        for (int i = tid; i < nw; i += NWV * 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    S.kv_off = (long long)S.seq * a.kv_seq_stride;
+    {
+        const int s1_abs = S.r * P1::spg;
+        S.j1 = s1_abs >= P1::S2 ? 2 : (s1_abs >= P1::S1 ? 1 : 0);
+        S.s1 = s1_abs - (S.j1 == 0 ? 0 : (S.j1 == 1 ? P1::S1 : P1::S2));
+        S.M1 = S.j1 == 0 ? P1::M0 : (S.j1 == 1 ? P1::M1 : P1::M2);
+        S.q_out0 = (S.j1 == 0 ? 0 : (S.j1 == 1 ? C::QD : C::QD + C::KVD)) + S.s1 * P1::RPS;
+    }
+    S.kvh = S.r / C::SPK, S.split = S.r - S.kvh * C::SPK, S.h0 = S.kvh * GQ, S.me0 = S.r * C::ME;
+    const int pos0 = a.d_state[S.seq * 4 + 1];
+    const int nst = a.n_steps > 1 ? a.n_steps : 1;
+    if (pos0 < 0 || pos0 + nst > a.max_seq) { /* a position of this launch lies beyond the cache rows: refuse, loudly */
+        if (tid == 0) atomicOr(a.ws + 1, 64);
+        return;
+    }
+    XRing<C::DEPTH> R;
+    for (int step = 0; step < nst; step++) {
+        const int epoch = epoch0 + step;
+        S.step = step, S.pos = pos0 + step, S.len = S.pos + 1;
+        S.stamp = C::DBG && a.dbg && S.seq == a.dbg_seq && S.r == a.dbg_wg && step < a.dbg_steps;
+        const int chunk = (((S.len + C::SPK - 1) / C::SPK) + 63) & ~63; /* keys per slice: the context cut into SPK pieces, whole 64-key runs */
+        S.t0 = S.split * chunk;
+        S.t1 = S.t0 + chunk < S.len ? S.t0 + chunk : S.len;
+        S.empty = S.t0 >= S.len;
+        S.own_new = S.pos >= S.t0 && S.pos < S.t1;
+        if (step > 0) { /* a step behind a timed-out one does not start */
+            __syncthreads();
+            if (tid == 0) L.cnt[3] = __hip_atomic_load(a.ws + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (L.cnt[3] != 0) break;
+        }
+        if (wave == NWV - 1) xe_poller_main<C>(a, L, S, epoch, lane);
+        else xe_compute_main<C>(a, L, S, epoch, wave, lane, R);
+        if (a.head_w) xe_head_main<C>(a, L, S, epoch, step + 1 < nst, wave, lane);
+    }
+    if (S.r == 0 && tid == 0) { /* every workgroup of this decoder took its ticket before any could finish a layer */
+        a.ws[16 + S.seq * 32] = 0;
+        if (S.seq == 0) a.ws[0] = epoch0 + nst; /* the next launch's generation (every decoder advances by the same number of steps) */
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct XEngineHost {
+    XArgs args;
+    int shape_class, fmt;
+    int dim, q_dim, kv_dim, ffn, n_head, n_kv, hd;
+    size_t smem, loc_stride;
+    void* ws;
+    size_t ws_bytes;
+    int nwv, depth; /* the instantiation in use */
+};
+
+static int xe_shape_class(int GQ, int hd, int dim, int q_dim, int ffn) {
+    if (GQ == 2 && hd == 128 && dim == 1024 && q_dim == 2048 && ffn == 3072) return 1; /* Qwen3-0.6B (BASELINE config 2) */
+    if (GQ == 2 && hd == 64 && dim == 256 && q_dim == 256 && ffn == 512) return 2;     /* the small parity-test shape */
+    return 0;
+}
+template <int NWV, int DEPTH, bool DBG>
+using XC1 = XCfg<FMT_Q4P, 2, 128, NWV, 1024, 2048, 1024, 3072, DEPTH, DBG>;
+template <int NWV, int DEPTH, bool DBG>
+using XC2 = XCfg<FMT_Q4P, 2, 64, NWV, 256, 256, 128, 512, DEPTH, DBG>;
+static int xe_loc_dw(int shape_class) { return shape_class == 1 ? XC1<9, 8, false>::loc_dw : XC2<9, 8, false>::loc_dw; }
+
+size_t xengine_ws_bytes(const kf_engine_desc* d) {
+    const int hd = d->head_dim, GQ = d->n_kv > 0 ? d->n_head / d->n_kv : 1;
+    const int sc = xe_shape_class(GQ, hd, d->dim, d->n_head * hd, d->ffn);
+    size_t b = 4096 + (((size_t)d->n_layer * sizeof(EngLayer) + 255) & ~(size_t)255);
+    b += (size_t)XE_NXCD * xe_loc_stride(sc ? xe_loc_dw(sc) : 0) + 4096;
+    return b;
+}
+static int xengine_init_state(XEngineHost* E, hipStream_t st) {
+    XArgs& a = E->args;
+    if (hipMemsetAsync(a.loc, 0xff, (size_t)XE_NXCD * E->loc_stride, st) != hipSuccess) return KF_HIP_CHECK;
+    static int init[16 + 32 * XE_NXCD];
+    memset(init, 0, sizeof(init));
+    init[0] = 1; /* epoch 1, no error, tickets zero */
+    if (hipMemcpyAsync(a.ws, init, sizeof(init), hipMemcpyHostToDevice, st) != hipSuccess) return KF_HIP_CHECK;
+    return KF_OK;
+}
+void xengine_free(XEngineHost* E) {
+    if (!E) return;
+    if (E->args.dbg) (void)hipFree(E->args.dbg);
+    delete E;
+}
+int xengine_build(const kf_engine_desc* d, int n_seq, long long kv_seq_stride, void* ws, size_t ws_bytes, hipStream_t st, XEngineHost** out, const char** why, bool dry) {
+    const char* dummy;
+    if (!why) why = &dummy;
+    *why = "bad arguments";
+    if (!d || (!dry && (!ws || !out)) || d->n_layer < 1 || !d->layers || n_seq < 1 || n_seq > XE_NXCD || kv_seq_stride < 0) return KF_INVALID_ARGS;
+    const int hd = d->head_dim;
+    *why = "head_dim must be 64 or 128 and n_head a multiple of n_kv";
+    if ((hd != 64 && hd != 128) || d->n_kv <= 0 || d->n_head % d->n_kv != 0) return KF_UNSUPPORTED_DATATYPE;
+    const int GQ = d->n_head / d->n_kv, q_dim = d->n_head * hd, kv_dim = d->n_kv * hd;
+    const int sc = xe_shape_class(GQ, hd, d->dim, q_dim, d->ffn);
+    *why = "model shape not instantiated for the XCD-confined engine: built for Qwen3-0.6B (dim 1024, 16/8 heads of 128, ffn 3072) and the 256-wide test shape";
+    if (!sc) return KF_UNSUPPORTED_DATATYPE;
+    if (!dry && (ws_bytes < xengine_ws_bytes(d) || ((uintptr_t)ws & 255) != 0)) {
+        *why = "workspace too small or not 256-byte aligned";
+        return KF_INVALID_ARGS;
+    }
+    int dev = 0, n_cu = 0;
+    *why = "HIP failure";
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return KF_HIP_CHECK;
+    *why = "the device does not show 256 compute units (8 XCDs of 32): one resident workgroup per CU, 32 per XCD, is the premise";
+    if (n_cu != XE_GRID) return KF_UNSUPPORTED_DATATYPE;
+    *why = "rope_table missing, kv_stride not a multiple of 8, or max_seq < 1";
+    if (!d->rope_table || (d->kv_stride % 8) != 0 || d->max_seq < 1) return KF_INVALID_ARGS;
+    *why = "layer storage not served: 4-bit PackedQ (RTN) layers in groups of 128 with 16-byte aligned blocks, dense FFN, every layer the same shapes";
+    std::vector<EngLayer> tab(d->n_layer);
+    float qbias[7] = {0};
+    bool q4p_ok = true;
+    const int Ks[7] = {d->dim, d->dim, d->dim, q_dim, d->dim, d->dim, d->ffn}, Ms[7] = {q_dim, kv_dim, kv_dim, d->dim, d->ffn, d->ffn, d->dim};
+    for (int l = 0; l < d->n_layer; l++) {
+        const kf_engine_layer& Ly = d->layers[l];
+        if (Ly.hot_ffn) return KF_UNSUPPORTED_DATATYPE;
+        if (!Ly.norm_in || !Ly.norm_post || !Ly.kcache || !Ly.vcache || (((uintptr_t)Ly.kcache | (uintptr_t)Ly.vcache) & 15) != 0) return KF_UNSUPPORTED_DATATYPE;
+        for (int j = 0; j < 7; j++) {
+            const kf_weight& w = Ly.w[j];
+            if (gemv_fmt_of(&w) != FMT_Q4 || w.ne0 != Ms[j] || w.ne1 != Ks[j] || w.qzeros || w.qscales || !w.gama || w.lGroup != 128 || (Ks[j] % 128) != 0 || ((uintptr_t)w.data & 15) != 0)
+                return KF_UNSUPPORTED_DATATYPE;
+            const long rows = j < 3 ? (long)q_dim + 2 * kv_dim : (j == 4 || j == 5 ? (long)d->ffn : (long)Ms[j]);
+            if (gemv_lpr_log2(Ks[j] / 32, rows) < 2) q4p_ok = false; /* the register-table form needs a group's four blocks in one aligned lane quad */
+            tab[l].m[j].w = (g_u32x4)(uintptr_t)w.data;
+            tab[l].m[j].zero = (g_u16)(uintptr_t)(w.gama + w.ne0 + w.ne1);
+            tab[l].m[j].step = (g_u16)(uintptr_t)(w.gama + w.ne0 + w.ne1 + (size_t)w.ne0 * w.ne1 / w.lGroup);
+            if (l == 0) qbias[j] = (float)w.qBias;
+            else if (qbias[j] != (float)w.qBias) return KF_UNSUPPORTED_DATATYPE;
+        }
+        tab[l].norm_in = (g_u16)(uintptr_t)Ly.norm_in, tab[l].norm_post = (g_u16)(uintptr_t)Ly.norm_post;
+        tab[l].norm_q = (g_u16)(uintptr_t)Ly.q_norm, tab[l].norm_k = (g_u16)(uintptr_t)Ly.k_norm;
+        tab[l].kcache = (g_u16w)(uintptr_t)Ly.kcache, tab[l].vcache = (g_u16w)(uintptr_t)Ly.vcache;
+        tab[l].hot = nullptr;
+    }
+    if (!q4p_ok) return KF_UNSUPPORTED_DATATYPE;
+    if (dry) {
+        *why = "";
+        return KF_OK;
+    }
+    XEngineHost* E = new XEngineHost();
+    memset(E, 0, sizeof(*E));
+    XArgs& a = E->args;
+    E->shape_class = sc, E->fmt = FMT_Q4P, E->dim = d->dim, E->q_dim = q_dim, E->kv_dim = kv_dim, E->ffn = d->ffn, E->n_head = d->n_head, E->n_kv = d->n_kv, E->hd = hd;
+    E->nwv = 9, E->depth = 8;
+    a.n_layer = d->n_layer, a.n_seq = n_seq, a.kv_seq_stride = kv_seq_stride, a.kv_stride = d->kv_stride, a.max_seq = d->max_seq;
+    a.eps = d->rms_eps, a.qk_eps = d->qk_eps, a.rope_table = d->rope_table;
+    for (int j = 0; j < 7; j++) a.qbias[j] = qbias[j];
+    char* p = reinterpret_cast<char*>(ws);
+    E->ws = ws, E->ws_bytes = ws_bytes;
+    a.ws = reinterpret_cast<int*>(p), p += 4096;
+    a.layers = reinterpret_cast<const EngLayer*>(p), p += ((size_t)d->n_layer * sizeof(EngLayer) + 255) & ~(size_t)255;
+    p = reinterpret_cast<char*>(((uintptr_t)p + 4095) & ~(uintptr_t)4095);
+    E->loc_stride = xe_loc_stride(xe_loc_dw(sc));
+    a.loc = p, a.loc_stride = E->loc_stride;
+    if (xengine_init_state(E, st) != KF_OK || hipMemcpyAsync(const_cast<EngLayer*>(a.layers), tab.data(), tab.size() * sizeof(EngLayer), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+        xengine_free(E);
+        *why = "HIP failure while initialising the workspace";
+        return KF_HIP_CHECK;
+    }
+    *out = E;
+    *why = "";
+    return KF_OK;
+}
+template <class C>
+static size_t xe_smem(int n_layer) {
+    constexpr int hd = C::HD, GQ = C::GQ, NCW = C::NCW;
+    constexpr int maxK = C::DIM > C::QD ? (C::DIM > C::FFN ? C::DIM : C::FFN) : (C::QD > C::FFN ? C::QD : C::FFN);
+    constexpr int xs_bytes = (maxK * 4 + 15) & ~15, xr_bytes = (C::DIM * 2 + 15) & ~15;
+    constexpr size_t o_attn = (size_t)2 * xs_bytes + 2 * xr_bytes;
+    constexpr size_t o_comb = (o_attn + sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + 15) & ~(size_t)15;
+    constexpr size_t o_msc = o_comb + sizeof(double) * (size_t)NCW * GQ * (hd + 2);
+    constexpr size_t o_wmax = o_msc + sizeof(double) * ((size_t)C::ME * C::SPK) + 4 * 64 + 4 * 128;
+    constexpr size_t o_outb = o_wmax + 4 * 2 * 16;
+    constexpr size_t o_cnt = o_outb + 4 * (size_t)((C::maxR + 63) & ~63);
+    constexpr size_t fixed_bytes = (o_cnt + 64 + 15) & ~(size_t)15;
+    return fixed_bytes + (((size_t)n_layer * sizeof(EngLayer) + 15) & ~(size_t)15);
+}
+template <class C>
+static int xengine_go(XEngineHost* E, hipStream_t st) {
+    static int ready = 0;
+    if (!ready) {
+        if (hipFuncSetAttribute((const void*)xengine_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return KF_HIP_CHECK;
+        ready = 1;
+    }
+    const size_t smem = xe_smem<C>(E->args.n_layer);
+    if (smem > 160 * 1024) return KF_UNSUPPORTED_DATATYPE;
+    hipLaunchKernelGGL((xengine_kernel<C>), dim3(XE_GRID), dim3(C::NWV * 64), smem, st, E->args);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+#ifndef XE_VARIANTS
+#define XE_VARIANTS 1 /* the tuning instantiations (waves per workgroup x ring depth) beside the default */
+#endif
+template <template <int, int, bool> class XC>
+static int xengine_go_shape(XEngineHost* E, hipStream_t st) {
+#ifndef XE_ONLY_DEFAULT
+    const bool dbg = E->args.dbg != nullptr;
+    if (dbg) return xengine_go<XC<9, 8, true>>(E, st);
+#endif
+#if XE_VARIANTS && !defined(XE_ONLY_DEFAULT)
+    if (E->nwv == 13 && E->depth == 6) return xengine_go<XC<13, 6, false>>(E, st);
+    if (E->nwv == 16 && E->depth == 4) return xengine_go<XC<16, 4, false>>(E, st);
+    if (E->nwv == 9 && E->depth == 12) return xengine_go<XC<9, 12, false>>(E, st);
+#endif
+    return xengine_go<XC<9, 8, false>>(E, st);
+}
+// n_steps decode steps of every sequence in ONE launch; with_head: 0 layers only (x_out), 1 + logits, 2 + greedy pick and state update (needed for n_steps > 1)
+int xengine_steps(XEngineHost* E, hipStream_t st, int32_t* d_state, uint16_t* x_out, int with_head, int n_steps) {
+    XArgs& a = E->args;
+    if (!a.emb || !d_state || !x_out || n_steps < 1 || (n_steps > 1 && with_head != 2)) return KF_INVALID_ARGS;
+    if (with_head && !a.head_w) return KF_INVALID_ARGS;
+    XArgs save = a;
+    a.d_state = d_state, a.x_out = x_out, a.n_steps = n_steps, a.pick = with_head == 2 ? 1 : 0;
+    if (!with_head) a.head_w = nullptr;
+    const int rc = E->shape_class == 1 ? xengine_go_shape<XC1>(E, st) : xengine_go_shape<XC2>(E, st);
+    a.head_w = save.head_w;
+    return rc;
+}
+int xengine_set_embedding(XEngineHost* E, const kf_weight* w, const int32_t* d_forced, int forced_stride) {
+    if (!w || w->type != KF_BF16 || w->quant != KF_QUANT_GROUP || w->qzeros || w->ne1 != E->dim || !w->data) return KF_UNSUPPORTED_DATATYPE;
+    E->args.emb = reinterpret_cast<const uint16_t*>(w->data), E->args.emb_rows = w->ne0, E->args.d_forced = d_forced, E->args.forced_stride = forced_stride;
+    return KF_OK;
+}
+int xengine_set_head(XEngineHost* E, const kf_weight* w, const uint16_t* norm_w, uint16_t* logits, int32_t* d_tokens_out, int tokens_stride) {
+    XArgs& a = E->args;
+    if (!w) {
+        a.head_w = nullptr, a.head_norm = nullptr, a.logits = nullptr, a.d_tokens_out = nullptr, a.vocab = 0;
+        return KF_OK;
+    }
+    if (w->type != KF_BF16 || w->quant != KF_QUANT_GROUP || w->qzeros || w->ne1 != E->dim || !w->data || ((uintptr_t)w->data & 15) != 0 || !norm_w || !logits || w->ne0 < 64)
+        return KF_UNSUPPORTED_DATATYPE;
+    const int nBlk = E->dim / 8;
+    if (gemv_lpr_log2(nBlk, w->ne0) != c_lpr_log2(nBlk, 1L << 20)) return KF_UNSUPPORTED_DATATYPE; /* same lanes per row as the mat-vec launcher: same summation order */
+    a.head_w = (g_u32x4)(uintptr_t)w->data, a.head_norm = (g_u16)(uintptr_t)norm_w, a.logits = logits, a.d_tokens_out = d_tokens_out, a.tokens_stride = tokens_stride, a.vocab = w->ne0;
+    return KF_OK;
+}
+int xengine_error_word(XEngineHost* E, hipStream_t st, int* h_err) {
+    int v[2] = {0, 0};
+    if (hipMemcpyAsync(v, E->args.ws, sizeof(v), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return KF_HIP_CHECK;
+    *h_err = v[1];
+    return KF_OK;
+}
+int xengine_reset(XEngineHost* E, hipStream_t st) {
+    const int rc = xengine_init_state(E, st);
+    if (rc != KF_OK) return rc;
+    return hipStreamSynchronize(st) == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+void xengine_set_variant(XEngineHost* E, int nwv, int depth) { E->nwv = nwv, E->depth = depth; }
+int xengine_debug_enable(XEngineHost* E, int seq, int wg, int max_steps) {
+    XArgs& a = E->args;
+    const size_t bytes = (size_t)max_steps * a.n_layer * 32 * 8;
+    if (a.dbg) (void)hipFree(a.dbg), a.dbg = nullptr;
+    if (seq < 0) return KF_OK;
+    if (hipMalloc(&a.dbg, bytes) != hipSuccess) {
+        a.dbg = nullptr;
+        return KF_HIP_CHECK;
+    }
+    (void)hipMemset(a.dbg, 0, bytes);
+    a.dbg_seq = seq, a.dbg_wg = wg, a.dbg_steps = max_steps;
+    return KF_OK;
+}
+int xengine_debug_read(XEngineHost* E, unsigned long long* h_out, int n_words) {
+    if (!E->args.dbg) return 0;
+    if (hipMemcpy(h_out, E->args.dbg, (size_t)n_words * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return n_words;
+}
+
+}  // namespace kf

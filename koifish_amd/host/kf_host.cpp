@@ -778,6 +778,131 @@ int Fish::Generate(const int* prompt, int n_prompt, int n_new, int* out, bool us
     return KF_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ XCD-confined replicas
+XcdReplicas::~XcdReplicas() {
+    if (!hFish) return;
+    kf_ctx* ctx = hFish->ctx;
+    if (engine) {
+        kf_sync(ctx);
+        kf_xengine_destroy(engine);
+    }
+    if (engine_ws) kf_free(ctx, engine_ws);
+    if (d_state) kf_free(ctx, d_state);
+    if (d_forced) kf_free(ctx, d_forced);
+    if (d_tokens_out) kf_free(ctx, d_tokens_out);
+}
+size_t XcdReplicas::kv_seq_elems() const {
+    const MODEL_CARD& c = hFish->config;
+    return (size_t)c.nLayer * c.n_ctx * c.n_head_kv * c.head_dim;
+}
+int XcdReplicas::Build(Fish* f, int n_seq_) {
+    if (!f || n_seq_ < 1 || n_seq_ > KF_XENGINE_MAX_SEQ) return KF_INVALID_ARGS;
+    hFish = f, n_seq = n_seq_;
+    kf_ctx* ctx = f->ctx;
+    const MODEL_CARD& c = f->config;
+    const int kvd = c.n_head_kv * c.head_dim;
+    std::vector<kf_engine_layer> L(c.nLayer);
+    for (int l = 0; l < c.nLayer; l++) {
+        SelfAttention* a = f->attn[l].get();
+        FFN* m = f->ffn[l].get();
+        SLP* s[7] = {&a->Q, &a->K, &a->V, &a->proj_cat, &m->gate, &m->up, &m->down};
+        for (int j = 0; j < 7; j++) {
+            if (!s[j]->w || s[j]->b) {
+                why = "a layer matrix is missing or carries a bias";
+                return KF_ENGINE_NOT_SERVED;
+            }
+            L[l].w[j] = s[j]->w->desc();
+        }
+        if (!a->norm.w || !m->norm.w) {
+            why = "a norm weight is missing";
+            return KF_ENGINE_NOT_SERVED;
+        }
+        if (m->n_hot >= 0) {
+            why = "a hot-row mask is set: the XCD-confined engines walk dense FFNs only";
+            return KF_ENGINE_NOT_SERVED;
+        }
+        L[l].hot_ffn = nullptr;
+        L[l].norm_in = ToX(a->norm.w), L[l].norm_post = ToX(m->norm.w);
+        L[l].q_norm = a->normQ.w ? ToX(a->normQ.w) : nullptr, L[l].k_norm = a->normK.w ? ToX(a->normK.w) : nullptr;
+        L[l].kcache = L[l].vcache = reinterpret_cast<floatX*>(f->cache.Get(KVCache::KV_KEY, l, 0)); /* stand-ins for the validation call below; set after the allocation */
+    }
+    kf_engine_desc d;
+    std::memset(&d, 0, sizeof(d));
+    d.n_layer = c.nLayer, d.dim = c.nEmbed, d.n_head = c.n_head, d.n_kv = c.n_head_kv, d.head_dim = c.head_dim, d.ffn = c.n_ff;
+    d.kv_stride = kvd, d.max_seq = c.n_ctx;
+    d.rms_eps = c.rms_eps, d.qk_eps = c.qk_eps, d.rope_table = f->rope_table, d.layers = L.data();
+    {
+        char w[320];
+        w[0] = 0;
+        const int served = kf_xengine_served(ctx, &d, w, sizeof(w));
+        why = w;
+        if (served != KF_OK) return served < 0 ? served : KF_ENGINE_NOT_SERVED;
+    }
+    if (!f->embed.w || !f->head.proj.w || !f->final_norm.w || f->final_norm.rms_eps != c.rms_eps) {
+        why = "embedding / head / final norm missing";
+        return KF_ENGINE_NOT_SERVED;
+    }
+    // per sequence: K / V cache, state, forced ids, ids out, logits, residual stream
+    const size_t seq_elems = kv_seq_elems();
+    key = GT(ctx, "xr.key", typNUMBER::BF16, kvd, c.n_ctx * c.nLayer * n_seq);
+    val = GT(ctx, "xr.val", typNUMBER::BF16, kvd, c.n_ctx * c.nLayer * n_seq);
+    logits = GT(ctx, "xr.logits", typNUMBER::BF16, c.vocab, n_seq);
+    x = GT(ctx, "xr.x", typNUMBER::BF16, c.nEmbed, n_seq);
+    if (!key || !val || !logits || !x) return KF_OUTOF_GPUMEMORY;
+    KF_TRY(kf_memset(ctx, key->data, 0, seq_elems * n_seq * 2));
+    KF_TRY(kf_memset(ctx, val->data, 0, seq_elems * n_seq * 2));
+    KF_TRY(kf_malloc(ctx, (size_t)n_seq * 16, (void**)&d_state));
+    KF_TRY(kf_malloc(ctx, (size_t)n_seq * c.n_ctx * 4, (void**)&d_forced));
+    KF_TRY(kf_malloc(ctx, (size_t)n_seq * c.n_ctx * 4, (void**)&d_tokens_out));
+    KF_TRY(kf_memset(ctx, d_state, 0, (size_t)n_seq * 16));
+    KF_TRY(kf_memset(ctx, d_forced, 0xff, (size_t)n_seq * c.n_ctx * 4));
+    KF_TRY(kf_memset(ctx, d_tokens_out, 0, (size_t)n_seq * c.n_ctx * 4));
+    for (int l = 0; l < c.nLayer; l++) {
+        L[l].kcache = ToX(key) + (size_t)l * c.n_ctx * kvd;
+        L[l].vcache = ToX(val) + (size_t)l * c.n_ctx * kvd;
+    }
+    const size_t bytes = kf_xengine_workspace_bytes(&d);
+    KF_TRY(kf_malloc(ctx, bytes, &engine_ws));
+    int rc = kf_xengine_create(ctx, &d, n_seq, (int64_t)seq_elems, engine_ws, bytes, &engine);
+    if (rc != KF_OK) {
+        why = kf_last_error();
+        return rc;
+    }
+    kf_weight we = f->embed.w->desc(), wh = f->head.proj.w->desc();
+    rc = kf_xengine_set_embedding(ctx, engine, &we, d_forced, c.n_ctx);
+    if (rc == KF_OK) rc = kf_xengine_set_head(ctx, engine, &wh, ToX(f->final_norm.w), ToX(logits), d_tokens_out, c.n_ctx);
+    if (rc != KF_OK) {
+        why = "the embedding table and the LM head must be bf16 (read inside the launch)";
+        return rc == KF_UNSUPPORTED_DATATYPE ? KF_ENGINE_NOT_SERVED : rc;
+    }
+    return KF_OK;
+}
+int XcdReplicas::SetForced(int seq, const int32_t* ids, int n) {
+    if (seq < 0 || seq >= n_seq || n < 0 || n > hFish->config.n_ctx) return KF_INVALID_ARGS;
+    std::vector<int32_t> row(hFish->config.n_ctx, -1);
+    for (int i = 0; i < n; i++) row[i] = ids[i];
+    return kf_h2d(hFish->ctx, d_forced + (size_t)seq * hFish->config.n_ctx, row.data(), row.size() * 4);
+}
+int XcdReplicas::SetState(int seq, int token, int pos) {
+    if (seq < 0 || seq >= n_seq || pos < 0 || pos >= hFish->config.n_ctx || token < 0 || token >= hFish->config.vocab) return KF_INVALID_ARGS;
+    return kf_set_state(hFish->ctx, d_state + 4 * seq, token, pos);
+}
+int XcdReplicas::RunSteps(int n) {
+    if (!engine || n < 1) return KF_INVALID_ARGS;
+    for (int i = 0; i < n;) {
+        const int m = n - i < steps_per_launch ? n - i : steps_per_launch;
+        KF_TRY(kf_xengine_steps(hFish->ctx, engine, ToX(x), d_state, m, 1));
+        i += m, steps_run += m;
+    }
+    return KF_OK;
+}
+int XcdReplicas::Check() {
+    if (!engine) return KF_OK;
+    const int rc = kf_xengine_check(hFish->ctx, engine);
+    if (rc == KF_INTERNAL_ERR) kf_xengine_reset(hFish->ctx, engine);
+    return rc;
+}
+
 }  // namespace koifish
 
 // ================================================================================================ C entry points
@@ -1143,6 +1268,61 @@ int kfh_tp_group_run(void** hs, int R, int pos, int n, int use_graph) {
     }
     return KF_OK;
 }
+
+// ---- XCD-confined replicas: handles are koifish::XcdReplicas*
+void* kfh_xr_create(void* fish, int n_seq, int* rc_out) {
+    XcdReplicas* r = new XcdReplicas();
+    const int rc = r->Build(reinterpret_cast<Fish*>(fish), n_seq);
+    if (rc_out) *rc_out = rc;
+    if (rc != KF_OK) {
+        g_host_err = r->why;
+        delete r;
+        return nullptr;
+    }
+    return r;
+}
+void kfh_xr_destroy(void* h) { delete reinterpret_cast<XcdReplicas*>(h); }
+int kfh_xr_set_forced(void* h, int seq, const int32_t* ids, int n) { return reinterpret_cast<XcdReplicas*>(h)->SetForced(seq, ids, n); }
+int kfh_xr_set_state(void* h, int seq, int token, int pos) { return reinterpret_cast<XcdReplicas*>(h)->SetState(seq, token, pos); }
+int kfh_xr_run_steps(void* h, int n) { return reinterpret_cast<XcdReplicas*>(h)->RunSteps(n); }
+int kfh_xr_check(void* h) { return reinterpret_cast<XcdReplicas*>(h)->Check(); }
+int kfh_xr_set_steps_per_launch(void* h, int n) {
+    if (n < 1 || n > 4096) return KF_INVALID_ARGS;
+    reinterpret_cast<XcdReplicas*>(h)->steps_per_launch = n;
+    return KF_OK;
+}
+int kfh_xr_get_tokens(void* h, int seq, int32_t* out, int n) {
+    XcdReplicas* r = reinterpret_cast<XcdReplicas*>(h);
+    if (seq < 0 || seq >= r->n_seq || n < 0 || n > r->hFish->config.n_ctx) return KF_INVALID_ARGS;
+    return kf_d2h(r->hFish->ctx, out, r->d_tokens_out + (size_t)seq * r->hFish->config.n_ctx, (size_t)n * 4);
+}
+int kfh_xr_get_state(void* h, int seq, int32_t* out2) {
+    XcdReplicas* r = reinterpret_cast<XcdReplicas*>(h);
+    if (seq < 0 || seq >= r->n_seq) return KF_INVALID_ARGS;
+    return kf_d2h(r->hFish->ctx, out2, r->d_state + 4 * seq, 8);
+}
+void* kfh_xr_logits(void* h, int seq) {
+    XcdReplicas* r = reinterpret_cast<XcdReplicas*>(h);
+    return ToX(r->logits) + (size_t)seq * r->hFish->config.vocab;
+}
+void* kfh_xr_hidden(void* h, int seq) {
+    XcdReplicas* r = reinterpret_cast<XcdReplicas*>(h);
+    return ToX(r->x) + (size_t)seq * r->hFish->config.nEmbed;
+}
+void* kfh_xr_kcache(void* h, int seq) {
+    XcdReplicas* r = reinterpret_cast<XcdReplicas*>(h);
+    return ToX(r->key) + (size_t)seq * r->kv_seq_elems();
+}
+void* kfh_xr_vcache(void* h, int seq) {
+    XcdReplicas* r = reinterpret_cast<XcdReplicas*>(h);
+    return ToX(r->val) + (size_t)seq * r->kv_seq_elems();
+}
+extern "C" int kfdbg_xengine_variant(kf_xengine* e, int nwv, int depth);
+extern "C" int kfdbg_xengine_stamps_enable(kf_xengine* e, int seq, int wg, int max_steps);
+extern "C" int kfdbg_xengine_stamps(kf_xengine* e, unsigned long long* h_out, int n_words);
+int kfh_xr_variant(void* h, int nwv, int depth) { return kfdbg_xengine_variant(reinterpret_cast<XcdReplicas*>(h)->engine, nwv, depth); }
+int kfh_xr_stamps_enable(void* h, int seq, int wg, int max_steps) { return kfdbg_xengine_stamps_enable(reinterpret_cast<XcdReplicas*>(h)->engine, seq, wg, max_steps); }
+int kfh_xr_stamps(void* h, unsigned long long* out, int n) { return kfdbg_xengine_stamps(reinterpret_cast<XcdReplicas*>(h)->engine, out, n); }
 
 int kfh_num_graphs(void* h) {
     int n = 0;

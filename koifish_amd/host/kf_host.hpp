@@ -275,4 +275,30 @@ struct Fish {
     int prefill_mode = 0;  // Generate: 0 token-serial prefill like the reference, 1 batched
 };
 
+// Eight independent decoders on ONE GPU, one per XCD, sharing a Fish's weights (kf_xengine_* of the ABI; round 5).  The reference decodes one sequence per process
+// (Fish::Chat, GoPT.cpp:1139-1180) and scales a small model by running more processes; here the "processes" are the 32-workgroup halves of one launch: sequence s has its own
+// KVCache (Cache.cpp:14-57, one per sequence), decode state, forced ids, ids out and logits -- everything the reference's per-process Fish owns except the weights.
+// Every sequence's ids / logits / K / V rows are those Fish::RunSteps produces for it alone (canonical order), bit for bit.
+struct XcdReplicas {
+    Fish* hFish = nullptr;  // the weights (not owned)
+    int n_seq = 0;
+    kf_xengine* engine = nullptr;
+    void* engine_ws = nullptr;
+    hGTensor key, val;      // [n_seq][n_layer][n_ctx][kv_dim] bf16
+    hGTensor logits, x;     // [n_seq][vocab], [n_seq][nEmbed]
+    int32_t* d_state = nullptr;       // [n_seq][4]: {token, pos, -, -}
+    int32_t* d_forced = nullptr;      // [n_seq][n_ctx], -1 = free running
+    int32_t* d_tokens_out = nullptr;  // [n_seq][n_ctx]
+    std::string why;        // why the model is not served, "" when it is
+    int steps_per_launch = 32;
+    long long steps_run = 0;
+    ~XcdReplicas();
+    int Build(Fish* f, int n_seq_);
+    int SetForced(int seq, const int32_t* ids, int n);
+    int SetState(int seq, int token, int pos);
+    int RunSteps(int n);  // n greedy steps of EVERY sequence from wherever each stands; no host sync
+    int Check();          // synchronises; a timed-out hand-off is reported once (KF_INTERNAL_ERR) and the engine reset
+    size_t kv_seq_elems() const;
+};
+
 }  // namespace koifish

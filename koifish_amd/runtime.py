@@ -600,3 +600,88 @@ class Qwen3:
         norms = (c["n_layer"] * (2 * c["dim"] + 2 * c["head_dim"]) + c["dim"]) * 2
         kv = 2 * c["n_layer"] * (pos + 1) * kvd * 2 + 2 * c["n_layer"] * kvd * 2
         return wb + norms + kv
+
+
+class XcdReplicas:
+    """Up to eight independent decoders of ONE model on one GPU, one per XCD (koifish::XcdReplicas over kf_xengine_*): the sequences share the model's weights; each has its
+    own KV cache, decode state, forced ids, ids out and logits.  Every sequence's results are bit for bit those of `model.run_steps` for it alone (canonical order)."""
+
+    def __init__(self, model, n_seq=8):
+        self.m, self.n_seq = model, int(n_seq)
+        self.host, self.hip = model.host, model.hip
+        rc = C.c_int(0)
+        h = self.host.kfh_xr_create(model.h, self.n_seq, C.byref(rc))
+        if not h:
+            raise L.KFError("kfh_xr_create failed with %d: %s" % (rc.value, self.host.kfh_host_error().decode() or self.hip.kf_last_error().decode()))
+        self.h = C.c_void_p(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.host.kfh_xr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_forced(self, seq, ids):
+        a = np.ascontiguousarray(ids, dtype=np.int32)
+        L.check(self.host.kfh_xr_set_forced(self.h, int(seq), a.ctypes.data_as(C.c_void_p), a.size), "kfh_xr_set_forced")
+
+    def set_state(self, seq, token, pos):
+        L.check(self.host.kfh_xr_set_state(self.h, int(seq), int(token), int(pos)), "kfh_xr_set_state")
+
+    def run_steps(self, n):
+        """n greedy steps of EVERY sequence from wherever each stands; no host sync"""
+        L.check(self.host.kfh_xr_run_steps(self.h, int(n)), "kfh_xr_run_steps")
+
+    def set_steps_per_launch(self, n):
+        L.check(self.host.kfh_xr_set_steps_per_launch(self.h, int(n)), "kfh_xr_set_steps_per_launch")
+
+    def check(self):
+        L.check(self.host.kfh_xr_check(self.h), "kfh_xr_check")
+
+    def state(self, seq):
+        out = np.zeros(2, dtype=np.int32)
+        L.check(self.host.kfh_xr_get_state(self.h, int(seq), out.ctypes.data_as(C.c_void_p)), "kfh_xr_get_state")
+        return int(out[0]), int(out[1])
+
+    def tokens_out(self, seq, n):
+        out = np.zeros(n, dtype=np.int32)
+        L.check(self.host.kfh_xr_get_tokens(self.h, int(seq), out.ctypes.data_as(C.c_void_p), n), "kfh_xr_get_tokens")
+        return out
+
+    def _d2h(self, ptr, n_u16):
+        out = np.zeros(n_u16, dtype=np.uint16)
+        ctx = C.c_void_p(self.host.kfh_ctx(self.m.h))
+        L.check(self.hip.kf_d2h(ctx, out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(out.size * 2)), "kf_d2h")
+        return out
+
+    def logits(self, seq):
+        """the sequence's last logits (bf16 bit patterns as uint16 [vocab])"""
+        return self._d2h(self.host.kfh_xr_logits(self.h, int(seq)), self.m.cfg["vocab"])
+
+    def hidden(self, seq):
+        return self._d2h(self.host.kfh_xr_hidden(self.h, int(seq)), self.m.cfg["dim"])
+
+    def kv_to_host(self, seq):
+        c = self.m.cfg
+        kvd = c["n_kv"] * c["head_dim"]
+        n = c["n_layer"] * c["max_seq"] * kvd
+        shp = (c["n_layer"], c["max_seq"], kvd)
+        return self._d2h(self.host.kfh_xr_kcache(self.h, int(seq)), n).reshape(shp), self._d2h(self.host.kfh_xr_vcache(self.h, int(seq)), n).reshape(shp)
+
+    def variant(self, nwv, depth):
+        """tuning runs: waves per workgroup x ring depth of the next launches (instantiated pairs only)"""
+        self.host.kfh_xr_variant(self.h, int(nwv), int(depth))
+
+    def stamps(self, seq, wg, steps, n_layer):
+        """enable (steps > 0) / read the per-phase wall-clock stamps [step][layer][32] of one workgroup of one decoder (diagnostic instantiation)"""
+        if steps > 0:
+            L.check(self.host.kfh_xr_stamps_enable(self.h, int(seq), int(wg), int(steps)), "kfh_xr_stamps_enable")
+            return None
+        out = np.zeros((-steps) * n_layer * 32, dtype=np.uint64)
+        self.host.kfh_xr_stamps(self.h, out.ctypes.data_as(C.c_void_p), out.size)
+        return out.reshape(-steps, n_layer, 32)

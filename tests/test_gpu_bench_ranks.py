@@ -52,3 +52,18 @@ def test_two_ranks_tensor_parallel_line():
     assert j["n_gpus"] == 2 and j["steps"] == 64 and j["scaling"] == "strong" and j["config"]["tp"] == 2 and j["config"]["exchange"] == "p2p"
     assert abs(j["value"] - 64 / (j["ms_per_step"] * 64 / 1e3)) <= 1e-2 * j["value"]          # ONE sequence: tokens/s of the whole job
     assert "roofline" in j and j["vs_baseline"] is None
+
+
+def test_plain_gpus_2_launches_two_ranks():
+    """`python bench.py --gpus 2` run bare (no launcher around it, as the driver runs `--gpus 1`) starts the two rank processes itself -- the parent never touches the GPU --
+    and relays ONE line with n_gpus == 2.  The TP leg the launcher adds for the default config is switched off here (its own test is above): KF_BENCH_NO_TP_LEG."""
+    env = dict(os.environ, KF_BENCH_BACKEND="gloo", KF_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", KF_BENCH_NO_TP_LEG="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "64", "--warmup", "16", "--cpu-seconds", "0", "--streams", "0", "--config", "small"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line: %r" % lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 64 and j["warmup"] == 16 and j["scaling"] == "weak" and j["config"]["replicas"] == 2

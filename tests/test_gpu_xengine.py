@@ -1,0 +1,209 @@
+"""Eight independent decoders on one GPU, one per XCD (kf_xengine_*, koifish::XcdReplicas; round 5).  The reference decodes ONE sequence per process
+(Fish::Chat, GoPT.cpp:1139-1180); the replicas here share a model's weights and nothing else.  Parity: EVERY sequence's greedy ids, logits and K / V rows equal what the
+oracle gives for that sequence alone, bit for bit (canonical order) -- different prompts per sequence, sequences standing at different positions, several steps per launch --
+and, at the benchmark's own size (Qwen3-0.6B, 2 k context), what the single-sequence persistent engine (itself proven against the oracle in test_gpu_canonical.py) and the
+oracle produce."""
+import numpy as np
+import pytest
+
+from helpers import oracle_model, prompt_ids
+from koifish_amd import lib as L
+from koifish_amd import synth
+from koifish_amd.runtime import XcdReplicas
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def canon():
+    O.set_order(O.ORDER_CANON)
+    yield
+    O.set_order(O.ORDER_DOT16)
+
+
+def _oracle_run(cfg, raw, forced, n, pos0=0):
+    """the oracle alone on one sequence: teacher-forced where forced >= 0, free running elsewhere -> ids per position, last logits, K / V"""
+    om = oracle_model(cfg, raw, L.Q4, L.BF16, attn_mode=O.ATTN_CANON)
+    ids, logits, tok = [], None, int(forced[0])
+    for p in range(pos0 + n):
+        if forced[p] >= 0:
+            tok = int(forced[p])
+        o_id, logits, _ = om.decode(tok, p)
+        ids.append(int(o_id))
+        tok = int(o_id)
+    k, v = om.kv()
+    k, v = k.copy(), v.copy()
+    om.close()
+    return ids, logits, k, v
+
+
+@pytest.mark.parametrize("cfg_name,max_seq,n_steps,n_seq,spl", [("tiny", 96, 90, 8, 7), ("small", 320, 150, 8, 32), ("tiny", 700, 300, 3, 16)])
+def test_every_sequence_equals_the_oracle(canon, cfg_name, max_seq, n_steps, n_seq, spl):
+    """different prompts per sequence (the first 12 .. 40 ids forced, then free running), several steps per launch: ids at every position, the last logits and all K / V rows
+    of every sequence against the oracle run on that sequence alone; n_seq < 8 leaves XCDs idle"""
+    cfg = dict(synth.CONFIGS[cfg_name], max_seq=max_seq)
+    raw = synth.raw_weights_numpy(cfg, 4321, w_std=0.1)
+    m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
+    m.set_canonical(True)
+    xr = XcdReplicas(m, n_seq)
+    xr.set_steps_per_launch(spl)
+    forced = []
+    for s in range(n_seq):
+        f = np.full(max_seq, -1, dtype=np.int32)
+        npr = 12 + 4 * s
+        f[:npr] = prompt_ids(cfg, npr, seed=100 + s)
+        forced.append(f)
+        xr.set_forced(s, f)
+        xr.set_state(s, int(f[0]), 0)
+    xr.run_steps(n_steps)
+    m.sync()
+    xr.check()
+    for s in range(n_seq):
+        o_ids, o_logits, ok, ov = _oracle_run(cfg, raw, forced[s], n_steps)
+        g_ids = xr.tokens_out(s, n_steps).tolist()
+        assert g_ids == o_ids, "sequence %d: first differing position %d" % (s, next(i for i, (a, b) in enumerate(zip(g_ids, o_ids)) if a != b))
+        assert xr.state(s) == (o_ids[-1], n_steps)
+        g_logits = xr.logits(s)
+        assert np.array_equal(g_logits, o_logits), "sequence %d: %d logits differ" % (s, int((g_logits != o_logits).sum()))
+        gk, gv = xr.kv_to_host(s)
+        assert np.array_equal(gk[:, :n_steps], ok[:, :n_steps]) and np.array_equal(gv[:, :n_steps], ov[:, :n_steps]), "sequence %d: K / V rows" % s
+    xr.close()
+    m.close()
+
+
+def test_sequences_at_different_positions(canon):
+    """the sequences of one launch need not be in step: all eight are first decoded from position 0 (so that every cache holds its sequence's history), then each is put back
+    to a start of its own -- 0, 5, 63, 64, 65, 130, 257, 300: on both sides of the 64-key slice boundaries -- and all advance together; the slices of a sequence's attention
+    follow ITS position, and the rows past a start are rewritten with the same values"""
+    cfg = dict(synth.CONFIGS["tiny"], max_seq=400)
+    raw = synth.raw_weights_numpy(cfg, 99, w_std=0.1)
+    m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
+    m.set_canonical(True)
+    n_seq, together = 8, 40
+    starts = [0, 5, 63, 64, 65, 130, 257, 300]
+    xr = XcdReplicas(m, n_seq)
+    forced, o = [], []
+    for s in range(n_seq):
+        f = np.full(400, -1, dtype=np.int32)
+        f[:starts[s] + 3] = prompt_ids(cfg, starts[s] + 3, seed=7 + s)
+        forced.append(f)
+        o.append(_oracle_run(cfg, raw, f, together, pos0=starts[s]))
+        xr.set_forced(s, f)
+        xr.set_state(s, int(f[0]), 0)
+    xr.run_steps(max(starts))
+    m.sync()
+    for s in range(n_seq):
+        xr.set_state(s, int(forced[s][starts[s]]), starts[s])
+    xr.run_steps(together)
+    m.sync()
+    xr.check()
+    for s in range(n_seq):
+        o_ids, o_logits, ok, ov = o[s]
+        n = starts[s] + together
+        assert xr.state(s)[1] == n
+        g_ids = xr.tokens_out(s, n).tolist()
+        assert g_ids[starts[s]:n] == o_ids[starts[s]:n], "sequence %d (start %d)" % (s, starts[s])
+        assert np.array_equal(xr.logits(s), o_logits), "sequence %d" % s
+        gk, gv = xr.kv_to_host(s)
+        assert np.array_equal(gk[:, :n], ok[:, :n]) and np.array_equal(gv[:, :n], ov[:, :n])
+    xr.close()
+    m.close()
+
+
+def test_full_size_eight_sequences(canon):
+    """Qwen3-0.6B at the benchmark's positions: eight sequences with different histories (each prefilled with its own 2028-token prompt through the batched prefill, whose
+    K / V rows are copied into the sequence's cache) decode 2028 .. 2043 in one 16-step launch.  Sequence by sequence: the 16 ids, the last logits and the 16 new K / V rows
+    equal the single-sequence engine's on the same history; sequences 0 and 5 also equal the oracle's."""
+    import torch
+    cfg = dict(synth.CONFIGS["qwen3-0.6b"])
+    m = synth.build_on_gpu(cfg, seed=1234, layer_type=L.Q4, head_type=L.BF16, head_std=0.1)
+    m.set_canonical(True)
+    P, n, n_seq = 2028, 16, 8
+    kvd = cfg["n_kv"] * cfg["head_dim"]
+    xr = XcdReplicas(m, n_seq)
+    ref = []
+    hip, host = m.hip, m.host
+    import ctypes as C
+    ctx = C.c_void_p(host.kfh_ctx(m.h))
+    free = np.full(cfg["max_seq"], -1, dtype=np.int32)
+    for s in range(n_seq):
+        toks = np.random.default_rng(3000 + s).integers(0, cfg["vocab"], size=P + 1).astype(np.int32)
+        m.prefill(toks[:P], want_logits=False)
+        m.sync()
+        # the sequence's history: this model's K / V rows 0 .. P-1 into the replica's cache (device to device, layer by layer: same layout [layer][pos][kv_dim])
+        nbytes = cfg["n_layer"] * cfg["max_seq"] * kvd * 2
+        L.check(hip.kf_d2d(ctx, C.c_void_p(host.kfh_xr_kcache(xr.h, s)), C.c_void_p(host.kfh_kcache(m.h)), C.c_size_t(nbytes)), "kf_d2d")
+        L.check(hip.kf_d2d(ctx, C.c_void_p(host.kfh_xr_vcache(xr.h, s)), C.c_void_p(host.kfh_vcache(m.h)), C.c_size_t(nbytes)), "kf_d2d")
+        m.sync()
+        hist = m.kv_to_host() if s in (0, 5) else None
+        # the single-sequence engine on the same history
+        m.set_forced(free)
+        m.set_state(int(toks[P]), P)
+        m.run_steps(P, n, use_graph=True)
+        m.sync()
+        m.engine_check()
+        gk, gv = m.kv_to_host()
+        ref.append((m.tokens_out(P + n)[P:P + n].tolist(), m.logits().copy(), gk[:, P:P + n].copy(), gv[:, P:P + n].copy(), toks, hist))
+        xr.set_forced(s, free)
+        xr.set_state(s, int(toks[P]), P)
+    assert m.engine_steps() > 0, m.engine_why()
+    xr.set_steps_per_launch(n)
+    xr.run_steps(n)
+    m.sync()
+    xr.check()
+    for s in range(n_seq):
+        ids, logits, rk, rv, toks, hist = ref[s]
+        assert xr.tokens_out(s, P + n)[P:P + n].tolist() == ids, "sequence %d: ids" % s
+        assert np.array_equal(xr.logits(s), logits), "sequence %d: logits" % s
+        gk, gv = xr.kv_to_host(s)
+        assert np.array_equal(gk[:, P:P + n], rk) and np.array_equal(gv[:, P:P + n], rv), "sequence %d: K / V rows" % s
+    # two of them against the oracle itself
+    om = O.from_device_model(m, attn_mode=O.ATTN_CANON)
+    om.prepare_fast()
+    for s in (0, 5):
+        ids, logits, rk, rv, toks, hist = ref[s]
+        ok, ov = om.kv()
+        ok[:, :P] = hist[0][:, :P]
+        ov[:, :P] = hist[1][:, :P]
+        tok, o_ids, o_logits = int(toks[P]), [], None
+        for p in range(P, P + n):
+            o_id, o_logits, _ = om.decode(tok, p)
+            o_ids.append(int(o_id))
+            tok = int(o_id)
+        assert xr.tokens_out(s, P + n)[P:P + n].tolist() == o_ids, "sequence %d vs the oracle: ids" % s
+        assert np.array_equal(xr.logits(s), o_logits), "sequence %d vs the oracle: logits" % s
+        gk, gv = xr.kv_to_host(s)
+        assert np.array_equal(gk[:, P:P + n], om.kv()[0][:, P:P + n]) and np.array_equal(gv[:, P:P + n], om.kv()[1][:, P:P + n])
+    om.close()
+    xr.close()
+    m.close()
+
+
+def test_refusals():
+    """what the XCD-confined engines do not serve is refused with a reason, never silently routed elsewhere: other shapes, other storages, more than eight sequences, the
+    v_dot2c order"""
+    cfg = dict(synth.CONFIGS["tiny"], max_seq=96)
+    raw = synth.raw_weights_numpy(cfg, 1, w_std=0.1)
+    m = synth.build_from_raw(cfg, raw, L.T_SIGN, L.BF16)
+    with pytest.raises(L.KFError) as e:
+        XcdReplicas(m, 8)
+    assert "4-bit" in str(e.value)
+    m.close()
+    m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
+    with pytest.raises(L.KFError):
+        XcdReplicas(m, 9)
+    m.set_canonical(False)
+    xr = XcdReplicas(m, 2)
+    xr.set_state(0, 1, 0), xr.set_state(1, 2, 0)
+    with pytest.raises(L.KFError) as e:
+        xr.run_steps(1)
+    assert "canonical" in str(e.value)
+    xr.close()
+    m.close()
+    cfg2 = dict(synth.CONFIGS["qwen3-1.7b"], n_layer=2, vocab=4096, max_seq=128)
+    m = synth.build_from_raw(cfg2, synth.raw_weights_numpy(cfg2, 2, w_std=0.05), L.Q4, L.BF16)
+    with pytest.raises(L.KFError) as e:
+        XcdReplicas(m, 8)
+    assert "not instantiated" in str(e.value)
+    m.close()
