@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--autotune", type=int, default=2, help="passes of kf_engine_tune (self-calibrated first-sweep delays of the engine's hand-offs) per position bucket; 0 = the built-in delays")
     ap.add_argument("--streams", type=int, default=0, help="side measurement after the timed region: this many INDEPENDENT decoders (own weights, own "
                     "KV cache, own HIP stream) running concurrently on the GPU over the same positions; 0/1 = skip.  Never part of `value`.")
+    ap.add_argument("--xcd-replicas", type=int, default=8, help="side object beside the line (never `value`): this many INDEPENDENT sequences decoded by one launch, one per XCD (kf_xengine_*), over "
+                    "the same timed positions; 0 = skip")
     ap.add_argument("--tp-exchange", default="p2p", choices=["p2p", "rccl"], help="--config qwen3-32b --gpus N > 1 runs tensor parallel TP = N (BASELINE config 4): "
                     "p2p = the C++ host's graph with kernel-side exchange over peer-mapped receive areas; rccl = the Python-stepped baseline with two "
                     "torch.distributed all-gathers per layer")
@@ -202,6 +204,7 @@ def main():
         # `value` was timed in the library's default summation order: the CANONICAL one (kf_abi.h kf_set_canonical; round 4), every logit, greedy id and KV row bit-exact against
         # the CPU oracle (cpu_baseline.parity_timed_order).  Beside it, never `value`: the same positions in the v_dot2c / fp32 order (kf_set_canonical(ctx, 0)).
         out["config"]["summation_order"] = "canonical (the library default): two v_pk_fma_f32 chains per lane + tree, exact power-of-two softmax with fp64 sums -- bit-exact against the CPU oracle"
+        ids_timed_run = m.tokens_out(S).copy()   # the greedy ids of the timed (canonical) run at every position: what sequence 0 of the xcd_replicas leg must reproduce
         try:
             ids0 = m.tokens_out(S)
 
@@ -280,6 +283,11 @@ def main():
                 out["cpu_baseline_fp16"] = cpu_fp16_decode(cfg, ctx.device, args.cpu_fp16_steps)
             except Exception as e:   # a side measurement must never cost the bench line
                 out["cpu_baseline_fp16"] = {"error": repr(e)[:200]}
+        if args.config == "qwen3-0.6b" and args.layers == "q4" and args.sparse == 0.0 and args.xcd_replicas > 0:
+            try:   # eight independent decoders, one per XCD, sharing this model's weights (kf_xengine_*): the aggregate beside the single-sequence `value`
+                out["xcd_replicas"] = xcd_replicas(m, cfg, forced, timed_positions, W, args.xcd_replicas, ids_timed_run)
+            except Exception as e:   # a side measurement must never cost the bench line
+                out["xcd_replicas"] = {"error": repr(e)[:300]}
         if world == 1 and args.config == "qwen3-0.6b" and args.layers == "q4" and args.sparse == 0.0:
             m.close()
             del m
@@ -788,6 +796,60 @@ def concurrent_streams(cfg, layer_type, head_type, dev, S, forced, n_prompt, mea
     return {"streams": S, "steps_per_stream": K, "tokens_per_s": round(tps, 1), "ms_per_step_per_stream": round(dt * 1e3 / K, 4),
             "hbm_achieved_GBs": round(mean_bytes * tps / 1e9, 1), "hbm_frac": round(mean_bytes * tps / 1e9 / HBM_PEAK_GBS, 4),
             "note": "independent decoders, separate weight copies and HIP streams, positions %d..%d each" % (n_prompt, S_len - 1)}
+
+
+def xcd_replicas(m, cfg, forced, timed_positions, warmup, n_seq, ids_main):
+    """The chip's aggregate rate on INDEPENDENT sequences (never `value`, which stays the single-sequence rate): n_seq decoders inside one launch, one per XCD (32 workgroups
+    each, every hand-off in that XCD's L2: koifish_amd/csrc/kf_xengine.hip), sharing this model's weights; own K / V cache, state, prompt and logits per sequence.  The
+    reference decodes one sequence per process (GoPT.cpp:1139-1180) and scales a small model with more processes -- these are the processes, moved inside the package.
+    Every sequence is decoded token by token from position 0 through its own 128-token prompt to the end of the context by the replicas' engine itself; the timed span is the
+    positions of `value`.  Sequence 0 carries the main run's prompt: its ids at EVERY position must equal the single-sequence engine's (whose ids and logits the cpu_baseline
+    leg checks against the oracle bit for bit); tests/test_gpu_xengine.py holds the per-sequence oracle parity."""
+    import numpy as np
+    import torch
+    from koifish_amd.runtime import XcdReplicas
+    S = cfg["max_seq"]
+    K = len(timed_positions)
+    first = timed_positions[0]
+    if first + K != S or first - warmup < 1:
+        return {"skipped": "the timed window does not end at the last position of the context"}
+    xr = XcdReplicas(m, n_seq)
+    try:
+        for s in range(n_seq):
+            f = forced.copy()
+            if s > 0:
+                f[:128] = np.random.default_rng(200 + s).integers(0, cfg["vocab"], size=128)
+            xr.set_forced(s, f)
+            xr.set_state(s, int(f[0]), 0)
+        xr.run_steps(first - warmup)     # set-up: every sequence's own history
+        xr.run_steps(warmup)
+        torch.cuda.synchronize()
+        ctx = m._ctx
+        e0, e1 = ctx.event(), ctx.event()
+        t0 = time.perf_counter()
+        ctx.record(e0)
+        xr.run_steps(K)
+        ctx.record(e1)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        xr.check()
+        dev_ms = ctx.elapsed_ms(e0, e1)
+        ids0 = xr.tokens_out(0, S)
+        same = bool(np.array_equal(ids0, ids_main))
+        distinct = len({tuple(xr.tokens_out(s, S)[128:160].tolist()) for s in range(n_seq)})
+        tps = n_seq * K / dt
+        bytes_tok = float(np.mean([m.step_bytes(p) for p in timed_positions]))
+        return {"streams": n_seq, "one_per": "XCD (32 workgroups of the launch each; every hand-off inside that XCD's L2)", "tokens_per_s": round(tps, 1), "per_stream_tokens_per_s": round(tps / n_seq, 1),
+                "ms_per_step_all_streams": round(dt * 1e3 / K, 4), "device_ms_per_step": round(dev_ms / K, 4), "steps": K, "positions": "%d..%d" % (first, S - 1),
+                "bytes_per_token": int(bytes_tok), "achieved": round(bytes_tok * tps / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bytes_tok * tps / 1e9 / HBM_PEAK_GBS, 4),
+                "aggregate_of_independent_sequences": True,
+                "note": "algorithmic bytes of ONE sequence's step x aggregate tokens/s / 8 TB/s: every decoder reads the layer weights, its own K / V rows and the head (the weights are shared, so "
+                        "part of the eight reads is served by the 256 MB memory-side cache: profiles/r05_pmc_xengine.json holds the counter traffic); never `value`",
+                "summation_order": "canonical (the only order the XCD-confined engines run)", "kernel": "kf::xengine_kernel (koifish_amd/csrc/kf_xengine.hip)",
+                "parity": {"sequence_0_ids_equal_single_sequence_engine": same, "positions_compared": int(S), "distinct_continuations": distinct,
+                           "per_sequence_oracle_parity": "tests/test_gpu_xengine.py (ids, logits, K / V rows of every sequence, bit for bit)"}}
+    finally:
+        xr.close()
 
 
 def kernel_roofline(m, ctx, cfg, reps=200):

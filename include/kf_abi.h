@@ -468,7 +468,7 @@ int kf_engine_check(kf_ctx* ctx, kf_engine* e); /* synchronises; KF_INTERNAL_ERR
 int kf_engine_reset(kf_ctx* ctx, kf_engine* e);
 int kf_engine_destroy(kf_engine* e);
 
-/* ---- EIGHT independent decoders per GPU, one per XCD (kf_xengine.hip; round 5).  The reference decodes ONE sequence per process (Fish::Chat, GoPT.cpp:1139-1180) and
+/* ---- EIGHT (or SIXTEEN) independent decoders per GPU, one (two) per XCD (kf_xengine.hip; round 5).  The reference decodes ONE sequence per process (Fish::Chat, GoPT.cpp:1139-1180) and
  * scales a small model by running more processes; on this part a single sequence cannot keep the HBM busy (its step is a chain of hand-offs), so the replicas move
  * INSIDE the package: the 32 workgroups of XCD s are the decoder of sequence s, every hand-off stays in that XCD's L2, and the chip streams eight sequences' bytes at
  * once.  The sequences share the weights (the kf_engine_desc's layer table, the embedding, the head) and nothing else; per sequence: a K/V cache (sequence s at
@@ -476,9 +476,11 @@ int kf_engine_destroy(kf_engine* e);
  * (logits + s * vocab), the residual stream out (x_out + s * dim).  Each sequence's ids, logits and K/V rows are bit for bit those kf_engine_steps_head, the per-layer
  * calls and the oracle give for that sequence alone (canonical order only: kf_set_canonical(ctx, 0) is refused).  One workgroup per CU, 32 per XCD: the launch must have
  * the GPU to itself (bounded polls, error word, kf_xengine_check / _reset as for kf_engine).  Sequences may stand at different positions.
+ * n_seq <= 8: sequence s on XCD s, one workgroup per CU.  n_seq 9 .. 16: TWO decoders per XCD (sequences x and x + 8 on XCD x), two workgroups per CU -- while one
+ * decoder waits on a hand-off the hardware issues the other's arithmetic, so the aggregate rate nearly doubles (a decoder's own step gets slower).
  * Served: 4-bit PackedQ (RTN, groups of 128) layers of the Qwen3-0.6B shape (and the 256-wide test shape), bf16 embedding / head, dense FFNs. */
 typedef struct kf_xengine kf_xengine;
-#define KF_XENGINE_MAX_SEQ 8
+#define KF_XENGINE_MAX_SEQ 16
 size_t kf_xengine_workspace_bytes(const kf_engine_desc* desc);
 int kf_xengine_create(kf_ctx* ctx, const kf_engine_desc* desc, int n_seq, int64_t kv_seq_stride, void* workspace, size_t workspace_bytes, kf_xengine** out);
 int kf_xengine_served(kf_ctx* ctx, const kf_engine_desc* desc, char* why, size_t why_bytes); /* KF_OK or KF_ENGINE_NOT_SERVED + the reason */

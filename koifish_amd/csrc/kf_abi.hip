@@ -1214,7 +1214,7 @@ int kf_xengine_create(kf_ctx* c, const kf_engine_desc* d, int n_seq, int64_t kv_
     CHKCTX(c);
     if (!d || !ws || !out) return fail(KF_INVALID_ARGS, "kf_xengine_create: null argument");
     if (c->capturing) return fail(KF_INVALID_ARGS, "kf_xengine_create: not while capturing");
-    if (n_seq < 1 || n_seq > KF_XENGINE_MAX_SEQ) return fail(KF_INVALID_ARGS, "kf_xengine_create: n_seq %d outside 1 .. %d (one sequence per XCD)", n_seq, KF_XENGINE_MAX_SEQ);
+    if (n_seq < 1 || n_seq > KF_XENGINE_MAX_SEQ) return fail(KF_INVALID_ARGS, "kf_xengine_create: n_seq %d outside 1 .. %d (one or two sequences per XCD)", n_seq, KF_XENGINE_MAX_SEQ);
     kf::XEngineHost* h = nullptr;
     const char* why = "";
     const int rc = kf::xengine_build(d, n_seq, (long long)kv_seq_stride, ws, ws_bytes, c->stream, &h, &why);

@@ -29,9 +29,10 @@
 
 namespace kf {
 
-constexpr int XE_NWG = 32;   /* workgroups (= CUs) of one XCD: one decoder */
+constexpr int XE_NWG = 32;   /* workgroups of one decoder = the CUs of one XCD */
 constexpr int XE_NXCD = 8;
-constexpr int XE_GRID = XE_NWG * XE_NXCD;
+constexpr int XE_GRID = XE_NWG * XE_NXCD; /* workgroups of a launch with ONE decoder per XCD; two decoders per XCD (WPC = 2): twice that, two workgroups per CU */
+constexpr int XE_MAXSEQ = 16;
 
 struct XArgs {
     const EngLayer* layers; /* kcache / vcache = sequence 0's; sequence s at + s * kv_seq_stride elements */
@@ -54,15 +55,16 @@ struct XArgs {
     int vocab, pick; /* pick: the greedy pick and the state update run inside (needed for n_steps > 1) */
     char* loc;       /* XCD-local exchange areas, loc_stride bytes each */
     size_t loc_stride;
-    int* ws;         /* [0] epoch, [1] error word, [16 + 32 x] ticket of XCD x */
+    int* ws;         /* [0] epoch, [1] error word, [16 + 32 x] ticket of XCD x, [17 + 32 x] its workgroups that have left */
     unsigned long long* dbg; /* diagnostic instantiation: [step][layer][16] stamps of (sequence dbg_seq, workgroup rank dbg_wg) */
     int dbg_seq, dbg_wg, dbg_steps;
 };
 
 // error word bits: 1 x, 2 q|k|v, 4 partials, 8 workgroups per XCD != 32, 16 pick, 32 token granule, 64 position beyond the cache, 128 ao, 256 xB, 512 act, 1024 head x
 
-template <int FMT_, int GQ_, int HD_, int NWV_, int DIM_, int QD_, int KVD_, int FFN_, int DEPTH_, bool DBG_>
+template <int FMT_, int GQ_, int HD_, int NWV_, int DIM_, int QD_, int KVD_, int FFN_, int DEPTH_, bool DBG_, int WPC_ = 1>
 struct XCfg {
+    static constexpr int WPC = WPC_; /* decoders per XCD = workgroups per CU: 2 lets one decoder's hand-off waits run under the other's arithmetic (the hardware interleaves the two workgroups' waves) */
     static constexpr int FMT = FMT_, GQ = GQ_, HD = HD_, NWV = NWV_, NCW = NWV_ - 1, DIM = DIM_, QD = QD_, KVD = KVD_, FFN = FFN_, DEPTH = DEPTH_, NWG = XE_NWG;
     static constexpr bool DBG = DBG_;
     static_assert(FMT_ == FMT_Q4 || FMT_ == FMT_Q4P, "4-bit PackedQ layers (arithmetic or register-table unpack)");
@@ -86,7 +88,7 @@ constexpr size_t xe_loc_stride(int loc_dw) { return ((size_t)loc_dw * 4 + 4095) 
 
 #define XE_STAMP(k)                                                                                                                       \
     do {                                                                                                                                  \
-        if (C::DBG && S.stamp && lane == 0) a.dbg[((size_t)S.step * a.n_layer + l) * 32 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+        if (C::DBG && S.stamp && lane == 0) a.dbg[((size_t)S.step * a.n_layer + l) * 64 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 
 struct XLds {
@@ -98,6 +100,8 @@ struct XLds {
     double* msc;  /* [SPK][ME] + [SPK] shifts */
     uint32_t* outb;
     int* cnt;
+    int* pub; /* [4] pieces of q | k | v, xB, act, x this workgroup has published since the launch began: its poller sleeps until then instead of sweeping (a spinning poller takes
+                 issue slots from the two compute waves of its SIMD, which then finish last and hold the whole decoder's hand-off back) */
 };
 struct XSeq { /* this workgroup's place in its decoder, and the step's slice */
     int seq, r, step;
@@ -128,24 +132,20 @@ struct XPhase {
     int row0;        /* first row of the workgroup's piece, counted inside the matrix */
     uint32_t wbytes, gbytes;
 };
-template <class PL, int NCW>
-__device__ __forceinline__ XPhase xe_phase(const EngMat m, const EngMat m2, float qb, float qb2, int s0, int Mj, int cw) {
-    static_assert(PL::nBlk % 4 == 0 && PL::LPR % 4 == 0, "a group's four blocks start at a multiple of four");
-    XPhase P;
-    // the table entries come out of LDS as vector registers: said to be wave-uniform HERE, once per phase (a buffer load on a descriptor the compiler believes divergent is
-    // wrapped in a readfirstlane / compare / exec-mask loop -- per load)
-    auto uni = [](auto ptr) {
-        const unsigned long long v = (unsigned long long)(uintptr_t)ptr;
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-        return (decltype(ptr))(uintptr_t)(((unsigned long long)hi << 32) | lo);
-    };
-    P.m.w = uni(m.w), P.m.step = uni(m.step), P.m.zero = uni(m.zero), P.m2.w = uni(m2.w), P.m2.step = uni(m2.step), P.m2.zero = uni(m2.zero);
-    P.qb = qb, P.qb2 = qb2;
-    P.nBlk = PL::nBlk, P.lpr_log2 = PL::lpr_log2, P.iters = PL::iters, P.rps_log2 = 6 - PL::lpr_log2, P.paired = PL::PAIRED ? 1 : 0;
-    P.s0 = s0, P.Mj = Mj, P.row0 = s0 * PL::RPS;
-    P.n = cw < PL::spg ? ((PL::spg - cw + NCW - 1) / NCW) * PL::iters * (PL::PAIRED ? 2 : 1) : 0;
-    P.wbytes = (uint32_t)Mj * (uint32_t)PL::nBlk * 16u, P.gbytes = (uint32_t)Mj * (uint32_t)(PL::nBlk / 4) * 2u;
-    return P;
+// Which of a workgroup's row slots a compute wave walks.  Waves w and w + 4 share a SIMD (measured: HW_ID of waves 0 .. 7 = SIMD 1 3 0 2 1 3 0 2), and the SIMD's two or three
+// waves finish one after the other -- the phase lasts as long as the busiest SIMD -- so the slots are dealt to SIMDs first (slot s -> class s & 3), then round the waves of
+// the class: with 11 compute waves (12 with the poller: three per SIMD) the class of the poller has two compute waves that take half of its slots each, the others a third.
+// 8 compute waves: the plain deal, wave cw takes slots cw, cw + 8, ...
+template <int NCW>
+__device__ __forceinline__ int xe_slot(int cw, int k) { /* the wave's k-th slot inside the workgroup's piece */
+    const int cls = cw & 3, idx = cw >> 2, nw = (NCW - cls + 3) / 4;
+    return cls + 4 * (idx + k * nw);
+}
+template <int NCW>
+__device__ __forceinline__ int xe_nslots(int cw, int spg) {
+    const int cls = cw & 3, idx = cw >> 2, nw = (NCW - cls + 3) / 4;
+    const int per_cls = spg > cls ? (spg - cls + 3) / 4 : 0; /* slots of the class */
+    return per_cls > idx ? (per_cls - idx + nw - 1) / nw : 0;
 }
 struct XLaneGeo { /* the lane's place in a phase's row slots */
     uint32_t vblk; /* sub * nBlk + ll: the lane's block offset inside a slot's iteration */
@@ -157,28 +157,40 @@ __device__ __forceinline__ XLaneGeo xe_lane_geo(const XPhase& P, int lane) {
     g.vblk = (uint32_t)g.sub * (uint32_t)P.nBlk + (uint32_t)g.ll;
     return g;
 }
-// entry e of phase P into ring slot d; on = false: a load that touches no memory (a zero-sized descriptor: every lane is out of range and reads 0) -- the ring slots are
-// assigned unconditionally in the streaming loop, so that the compiler keeps ONE register set per slot (a conditional refill inside the loop doubled them: 500 spilled registers)
+// ONE unconditional set of loads into ring slot d: entry e of phase P (use_nx = false) or of the next phase NX (use_nx = true), or -- on = false -- a load that touches no memory
+// (a zero-sized descriptor: every lane is out of range and reads 0).  No branch around a load anywhere in the streaming loop: the compiler counts the loads in flight only along
+// straight-line code -- behind a conditional request it waits with vmcnt(0), i.e. for the block it has just asked for (measured: every entry then paid an HBM round trip).
 // Buffer loads: block index = [scalar: the slot's first row and the iteration] + [lane: sub * nBlk + ll]; rows past the matrix read zeros (the descriptor's bound), columns
 // past the row are masked at the multiply.
 template <int NCW, int D>
-__device__ __forceinline__ void xe_issue(const XPhase& P, const XLaneGeo& G, int e, int d, int cw, bool on, XRing<D>& R) {
-    const int k = P.paired ? e >> 1 : e;
-    const int sl = k / P.iters, it = k - sl * P.iters;
-    const uint32_t ublk = (uint32_t)(((P.s0 + cw + sl * NCW) << P.rps_log2) * P.nBlk + (it << P.lpr_log2)); /* wave-uniform; a multiple of 4 */
-    const bool second = P.paired && (e & 1);
-    const g_u32x4 pw = second ? P.m2.w : P.m.w;
-    const g_u16 ps = second ? P.m2.step : P.m.step, pz = second ? P.m2.zero : P.m.zero;
-    R.w[d] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(eng_rsrc((const void*)pw, on ? P.wbytes : 0u), G.vblk * 16u, ublk * 16u, 2 /* nt */));
-    R.st[d] = __builtin_amdgcn_raw_buffer_load_b16(eng_rsrc((const void*)ps, on ? P.gbytes : 0u), (G.vblk >> 2) * 2u, (ublk >> 2) * 2u, 0);
-    R.ze[d] = __builtin_amdgcn_raw_buffer_load_b16(eng_rsrc((const void*)pz, on ? P.gbytes : 0u), (G.vblk >> 2) * 2u, (ublk >> 2) * 2u, 0);
+__device__ __forceinline__ void xe_issue(const XPhase& P, const XLaneGeo& G, const XPhase& NX, const XLaneGeo& GN, bool use_nx, int e, int d, int cw, bool on, XRing<D>& R) {
+    // every field read into a value FIRST, then chosen: `c ? NX.f : P.f` on two lvalues is a choice between two ADDRESSES followed by one load, which keeps both structs
+    // in scratch memory (and every such read an indexed scratch load with a drain of the weight loads in front of it)
+    auto pick = [](bool c, auto x, auto y) { return c ? x : y; };
+    const int paired = pick(use_nx, +NX.paired, +P.paired), iters = pick(use_nx, +NX.iters, +P.iters), s0 = pick(use_nx, +NX.s0, +P.s0);
+    const int rps_log2 = pick(use_nx, +NX.rps_log2, +P.rps_log2), lpr_log2 = pick(use_nx, +NX.lpr_log2, +P.lpr_log2), nBlk = pick(use_nx, +NX.nBlk, +P.nBlk);
+    const int k = paired ? e >> 1 : e;
+    const int sl = k / iters, it = k - sl * iters;
+    const uint32_t ublk = (uint32_t)(((s0 + xe_slot<NCW>(cw, sl)) << rps_log2) * nBlk + (it << lpr_log2)); /* wave-uniform; a multiple of 4 */
+    const bool second = paired && (e & 1);
+    const g_u32x4 w_a = P.m.w, w_b = P.m2.w, w_c = NX.m.w, w_d = NX.m2.w;
+    const g_u16 s_a = P.m.step, s_b = P.m2.step, s_c = NX.m.step, s_d = NX.m2.step;
+    const g_u16 z_a = P.m.zero, z_b = P.m2.zero, z_c = NX.m.zero, z_d = NX.m2.zero;
+    const g_u32x4 pw = pick(use_nx, pick(second, w_d, w_c), pick(second, w_b, w_a));
+    const g_u16 ps = pick(use_nx, pick(second, s_d, s_c), pick(second, s_b, s_a));
+    const g_u16 pz = pick(use_nx, pick(second, z_d, z_c), pick(second, z_b, z_a));
+    const uint32_t wbytes = on ? pick(use_nx, +NX.wbytes, +P.wbytes) : 0u, gbytes = on ? pick(use_nx, +NX.gbytes, +P.gbytes) : 0u;
+    const uint32_t vblk = pick(use_nx, +GN.vblk, +G.vblk);
+    R.w[d] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(eng_rsrc((const void*)pw, wbytes), vblk * 16u, ublk * 16u, 2 /* nt */));
+    R.st[d] = __builtin_amdgcn_raw_buffer_load_b16(eng_rsrc((const void*)ps, gbytes), (vblk >> 2) * 2u, (ublk >> 2) * 2u, 0);
+    R.ze[d] = __builtin_amdgcn_raw_buffer_load_b16(eng_rsrc((const void*)pz, gbytes), (vblk >> 2) * 2u, (ublk >> 2) * 2u, 0);
 }
 // a phase's first entries into an idle ring
 template <int NCW, int D>
 __device__ __forceinline__ void xe_fill(const XPhase& P, int cw, int lane, XRing<D>& R) {
     const XLaneGeo G = xe_lane_geo(P, lane);
 #pragma unroll
-    for (int d = 0; d < D; d++) xe_issue<NCW, D>(P, G, d, d, cw, d < P.n, R);
+    for (int d = 0; d < D; d++) xe_issue<NCW, D>(P, G, P, G, false, d, d, cw, d < P.n, R);
 }
 // one block's 32 products into the lane's chain pair: BlockDotF<FMT> (kf_gemv_blocks.h) on the fp32 activation chunks [8][nBlk] in LDS
 template <int FMT>
@@ -207,9 +219,9 @@ __device__ __forceinline__ f32x2_t xe_block(u32x4 w, uint16_t st16, uint16_t ze1
 }
 // One mat-vec phase of a compute wave: ONE copy of this loop serves every phase.  The ring holds the wave's first min(D, n) entries on entry (xe_fill / the previous phase's
 // last round); entry e + D is requested when entry e has been multiplied, and in the last round slot d takes entry d of the NEXT phase NX (nx_on; they do not depend on the
-// hand-off that separates the phases).  epi(row, v, v2) runs in the lane that owns a finished row; tail0() once, when the last round begins.
-template <class C, int D, typename Epi, typename Tail0>
-__device__ __forceinline__ void xe_mv_run(const XPhase& P, const XPhase& NX, bool nx_on, int cw, int lane, const u32x4* xs, XRing<D>& R, Epi&& epi, Tail0&& tail0) {
+// hand-off that separates the phases).  epi(row, v, v2) runs in the lane that owns a finished row (LDS only: no memory operation inside the loop but the refills).
+template <class C, int D, typename Epi>
+__device__ __forceinline__ void xe_mv_run(const XPhase& P, const XPhase& NX, bool nx_on, int cw, int lane, const u32x4* xs, XRing<D>& R, Epi&& epi) {
     constexpr int NCW = C::NCW;
     static_assert((D % 2) == 0, "gate | up entries come in pairs");
     const int n = P.n, n_pad = n > 0 ? (n + D - 1) / D * D : D; /* at least one round: the last round is where the next phase's entries are requested */
@@ -218,14 +230,13 @@ __device__ __forceinline__ void xe_mv_run(const XPhase& P, const XPhase& NX, boo
     f32x2_t acc{0.f, 0.f}, acc2{0.f, 0.f};
     for (int e0 = 0; e0 < n_pad; e0 += D) {
         const bool last = e0 + D >= n_pad;
-        if (last) tail0();
 #pragma unroll
         for (int d = 0; d < D; d++) {
             const int e = e0 + d;
             if (e < n) {
                 const int k = P.paired ? e >> 1 : e;
                 const int sl = k / P.iters, it = k - sl * P.iters;
-                const int row = ((P.s0 + cw + sl * NCW) << P.rps_log2) + G.sub, colr = (it << P.lpr_log2) + G.ll;
+                const int row = ((P.s0 + xe_slot<NCW>(cw, sl)) << P.rps_log2) + G.sub, colr = (it << P.lpr_log2) + G.ll;
                 const bool ok = row < P.Mj && colr < P.nBlk;
                 const int col = colr < P.nBlk ? colr : P.nBlk - 1;
                 const bool second = P.paired && (d & 1);
@@ -234,7 +245,8 @@ __device__ __forceinline__ void xe_mv_run(const XPhase& P, const XPhase& NX, boo
                     else acc = f32x2_t{0.f, 0.f};
                 }
                 const f32x2_t in = second ? acc2 : acc;
-                const f32x2_t r = xe_block<C::FMT>(R.w[d], R.st[d], R.ze[d], second ? P.qb2 : P.qb, xf, col, P.nBlk, lane, in);
+                const float qb_a = P.qb, qb_b = P.qb2;
+                const f32x2_t r = xe_block<C::FMT>(R.w[d], R.st[d], R.ze[d], second ? qb_b : qb_a, xf, col, P.nBlk, lane, in);
                 const f32x2_t o = acc_pick(ok, r, in);
                 if (second) acc2 = o;
                 else acc = o;
@@ -245,21 +257,29 @@ __device__ __forceinline__ void xe_mv_run(const XPhase& P, const XPhase& NX, boo
                     if (G.ll == 0 && row < P.Mj) epi(row, v, v2);
                 }
             }
-            // refill slot d (always a load: see xe_issue)
+            // refill slot d (always ONE set of loads: see xe_issue)
             const bool more = e + D < n, nxt = !more && last && nx_on && d < NX.n;
-            if (more || !nxt) xe_issue<NCW, D>(P, G, more ? e + D : 0, d, cw, more, R);
-            else xe_issue<NCW, D>(NX, GN, d, d, cw, true, R);
+            xe_issue<NCW, D>(P, G, NX, GN, nxt, more ? e + D : (nxt ? d : 0), d, cw, more || nxt, R);
         }
     }
 }
 // the waves that own rows of a phase leave their granules in LDS; the one that arrives last stores the workgroup's piece, 16 bytes per lane, with PLAIN stores (this XCD's L2)
-__device__ __forceinline__ void xe_publish(const XLds& L, uint32_t* dst, int nrows, int nwaves, int lane) {
+// plain != NULL: the rows also as plain bf16 (the residual stream after the last layer: x_out)
+__device__ __forceinline__ void xe_publish(const XLds& L, int phase, uint32_t* dst, int nrows, int nwaves, int lane, uint16_t* plain = nullptr) {
     int old = 0;
     if (lane == 0) old = __hip_atomic_fetch_add(L.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     old = __builtin_amdgcn_readfirstlane(old);
     if (old != nwaves - 1) return;
     if (lane == 0) *L.cnt = 0;
-    for (int i = 4 * lane; i < nrows; i += 256) *reinterpret_cast<u32x4*>(dst + i) = *reinterpret_cast<const u32x4*>(L.outb + i);
+    // one descriptor for the piece, the lane's 16 bytes as an offset: no 64-bit per-lane address (it was spilled, and its reload in front of the store drained the next phase's
+    // weight loads in flight)
+    const __amdgpu_buffer_rsrc_t rd = eng_rsrc(dst, (uint32_t)nrows * 4u), rp = eng_rsrc(plain ? (const void*)plain : (const void*)dst, plain ? (uint32_t)nrows * 2u : 0u);
+    for (int i = 4 * lane; i < nrows; i += 256) {
+        const u32x4 g = *reinterpret_cast<const u32x4*>(L.outb + i);
+        __builtin_amdgcn_raw_buffer_store_b128(g, rd, i * 4, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{(g.x & 0xffffu) | (g.y << 16), (g.z & 0xffffu) | (g.w << 16)}, rp, i * 2, 0, 0); /* out of range (dropped) without `plain` */
+    }
+    if (lane == 0) __hip_atomic_fetch_add(L.pub + phase, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // ---- attention: the workgroup's key slice of its kv-head, streamed by the NCW compute waves (two batches of U tiles in flight per lane)
@@ -275,15 +295,14 @@ __device__ __forceinline__ void xe_attn_issue(const XArgs& a, const EngLayer& ly
     constexpr int hd = C::HD, LPK = hd >> 3, KPW = 64 / LPK, lpk_log2 = (C::HD == 128 ? 7 : 6) - 3, NWA = C::NCW, U = XAttn<C>::U;
     const int grp = lane >> lpk_log2, d0 = (lane & (LPK - 1)) * 8;
     const int tb = S.t0 + cw * KPW + grp + b * U * NWA * KPW;
+    const int tmax = S.t1 > 0 ? S.t1 - 1 : 0; /* unconditional requests (a conditional one turns the waits behind it into drains): rows past the slice re-read its last row, masked at the use */
 #pragma unroll
     for (int u = 0; u < U; u++) {
-        const int t = tb + u * NWA * KPW;
-        T.kk[buf][u] = T.vv[buf][u] = u32x4{0, 0, 0, 0};
-        if (t < S.t1) {
-            const size_t off = (size_t)S.kv_off + (size_t)t * a.kv_stride + (size_t)S.kvh * hd + d0;
-            T.kk[buf][u] = *reinterpret_cast<const u32x4 KF_GLOBAL*>(ly.kcache + off);
-            T.vv[buf][u] = *reinterpret_cast<const u32x4 KF_GLOBAL*>(ly.vcache + off);
-        }
+        int t = tb + u * NWA * KPW;
+        t = t < tmax ? t : tmax;
+        const size_t off = (size_t)S.kv_off + (size_t)t * a.kv_stride + (size_t)S.kvh * hd + d0;
+        T.kk[buf][u] = *reinterpret_cast<const u32x4 KF_GLOBAL*>(ly.kcache + off);
+        T.vv[buf][u] = *reinterpret_cast<const u32x4 KF_GLOBAL*>(ly.vcache + off);
     }
 }
 // compute waves only (the poller meets the three barriers in xe_poller_main).  p4_fill: requests the first o_proj blocks, called when the last batch's tiles are in registers
@@ -348,11 +367,11 @@ __device__ __forceinline__ void xe_attn_phase(const XArgs& a, const XLds& L, con
             }
             canon_batch<GQ, LPK, U>(A, qf, ck, cv, valid, lpk_log2, rden);
         };
-        for (int b = 0; b < nbatch; b += 2) { /* batch b sits in buffer 0 (requested by the phase before, or by the step below), b + 1 goes to buffer 1 */
-            if (b + 1 < nbatch) xe_attn_issue<C>(a, ly, S, cw, lane, T, b + 1, 1);
+        for (int b = 0; b < nbatch; b += 2) { /* batch b sits in buffer 0 (requested by the phase before, or by the step below), b + 1 goes to buffer 1; requests past the slice are clamped */
+            xe_attn_issue<C>(a, ly, S, cw, lane, T, b + 1, 1);
             batch(b, 0);
             if (b + 1 >= nbatch) break;
-            if (b + 2 < nbatch) xe_attn_issue<C>(a, ly, S, cw, lane, T, b + 2, 0);
+            xe_attn_issue<C>(a, ly, S, cw, lane, T, b + 2, 0);
             batch(b + 1, 1);
         }
         canon_wave_to_lds<GQ, LPK>(A, L.comb + (size_t)cw * GQ * (hd + 2), hd, lane, d0);
@@ -406,6 +425,7 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, co
         const EngLayer& ly = L.lay[l];
         const uint32_t gen = (uint32_t)epoch * (uint32_t)a.n_layer + (uint32_t)l, tag = gen & 0xffffu;
         XE_STAMP(0);
+        if (C::DBG && S.stamp && lane == 0) a.dbg[((size_t)S.step * a.n_layer + l) * 64 + 31] = __builtin_amdgcn_s_memtime(); /* the shader clock beside the 100 MHz stamp: the frequency the CU really runs at */
         // P1's x (P4 adds it as the residual)
         if (l == 0) {
             int tok = a.d_state[S.seq * 4];
@@ -432,6 +452,8 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, co
             if (tok < 0 || tok >= a.emb_rows) tok = 0;
             eng_poll_stage<XCH, ND, P1::nBlk, true, true, true>(nullptr, a.emb + (size_t)tok * C::DIM, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, nullptr, nullptr, 0, 0);
         } else {
+            eng_wait_pub(L.pub + 3, S.step * a.n_layer + l, 0, dead);
+            XE_STAMP(12);
             eng_poll_stage<XCH, ND, P1::nBlk, true, false, true>(loc + C::xA, nullptr, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, nullptr, nullptr, 0, 0);
         }
         XE_STAMP(1);
@@ -445,6 +467,8 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, co
             const int e_kv = 4 * lane; /* < hd: k, < 2 hd: v */
             const bool kv_in = e_kv < 2 * hd;
             const int kv_src = e_kv < hd ? C::QD + S.kvh * hd + e_kv : C::QD + C::KVD + S.kvh * hd + (e_kv - hd);
+            eng_wait_pub(L.pub + 0, S.step * a.n_layer + l + 1, 0, dead);
+            XE_STAMP(9);
             for (int spins = 0;; spins++) {
                 uint32_t bad = 0;
 #pragma unroll
@@ -530,10 +554,16 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, co
         eng_poll_stage<XCH, NQD, P4::nBlk, false, false, true>(loc + C::ao, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, nullptr, nullptr, 0, 0);
         XE_STAMP(6);
         __syncthreads(); /* B4 */
+        eng_wait_pub(L.pub + 1, S.step * a.n_layer + l + 1, 0, dead);
+        XE_STAMP(10);
         eng_poll_stage<XCH, ND, P5::nBlk, true, false, true>(loc + C::xB, nullptr, tag, ly.norm_post, a.eps, L.xs[0], L.xrawB, lane, a.ws, dead, nullptr, nullptr, 0, 0);
         XE_STAMP(7);
         __syncthreads(); /* B5 */
-        eng_poll_stage<XCH, NF, P6::nBlk, false, false, true>(loc + C::act, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, nullptr, nullptr, 0, 0);
+        eng_wait_pub(L.pub + 2, S.step * a.n_layer + l + 1, 0, dead);
+        XE_STAMP(11);
+        int nsw_act = 0;
+        eng_poll_stage<XCH, NF, P6::nBlk, false, false, true>(loc + C::act, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, &nsw_act, nullptr, 0, 0);
+        if (C::DBG && S.stamp && lane == 0) a.dbg[((size_t)S.step * a.n_layer + l) * 64 + 13] = (unsigned long long)nsw_act;
         XE_STAMP(8);
         __syncthreads(); /* B6 */
     }
@@ -562,12 +592,31 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
             T.rc = tab_pos[2 * lane], T.rs = tab_pos[2 * lane + 1];
         }
     }
-    auto phase_of = [&](int q, const EngLayer& ly) { /* 0: q | k | v, 1: o_proj, 2: gate | up, 3: down_proj */
-        if (q == 0) return xe_phase<P1, NCW>(ly.m[S.j1], ly.m[S.j1], qb1, 0.f, S.s1, S.M1, cw);
-        if (q == 1) return xe_phase<P4, NCW>(ly.m[3], ly.m[3], a.qbias[3], 0.f, wg * P4::spg, P4::M0, cw);
-        if (q == 2) return xe_phase<P5, NCW>(ly.m[4], ly.m[5], a.qbias[4], a.qbias[5], wg * P5::spg, P5::M0, cw);
-        return xe_phase<P6, NCW>(ly.m[6], ly.m[6], a.qbias[6], 0.f, wg * P6::spg, P6::M0, cw);
+    // phase q of a layer (0: q | k | v, 1: o_proj, 2: gate | up, 3: down_proj) as scalars: every field by a chain of selects on q -- never a struct chosen among four (the
+    // compiler keeps such a value in scratch memory and every later field read becomes an indexed scratch load, in front of which it drains the weight loads in flight)
+    auto sel4 = [](int q, auto v0, auto v1, auto v2, auto v3) { return q == 0 ? v0 : (q == 1 ? v1 : (q == 2 ? v2 : v3)); };
+    auto phase_of = [&](int q, const EngLayer& ly) {
+        auto uni = [](auto ptr) {
+            const unsigned long long v = (unsigned long long)(uintptr_t)ptr;
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+            return (decltype(ptr))(uintptr_t)(((unsigned long long)hi << 32) | lo);
+        };
+        const int j = sel4(q, S.j1, 3, 4, 6), j2 = q == 2 ? 5 : j;
+        XPhase P;
+        P.m.w = uni(ly.m[j].w), P.m.step = uni(ly.m[j].step), P.m.zero = uni(ly.m[j].zero);
+        P.m2.w = uni(ly.m[j2].w), P.m2.step = uni(ly.m[j2].step), P.m2.zero = uni(ly.m[j2].zero);
+        P.qb = sel4(q, qb1, a.qbias[3], a.qbias[4], a.qbias[6]), P.qb2 = a.qbias[5];
+        P.nBlk = sel4(q, P1::nBlk, P4::nBlk, P5::nBlk, P6::nBlk), P.lpr_log2 = sel4(q, P1::lpr_log2, P4::lpr_log2, P5::lpr_log2, P6::lpr_log2);
+        P.iters = sel4(q, P1::iters, P4::iters, P5::iters, P6::iters), P.rps_log2 = 6 - P.lpr_log2, P.paired = q == 2 ? 1 : 0;
+        P.s0 = sel4(q, S.s1, wg * P4::spg, wg * P5::spg, wg * P6::spg), P.Mj = sel4(q, S.M1, P4::M0, P5::M0, P6::M0);
+        P.row0 = P.s0 << P.rps_log2;
+        const int spg = sel4(q, P1::spg, P4::spg, P5::spg, P6::spg);
+        P.n = xe_nslots<NCW>(cw, spg) * P.iters * (P.paired ? 2 : 1);
+        P.wbytes = (uint32_t)P.Mj * (uint32_t)P.nBlk * 16u, P.gbytes = (uint32_t)P.Mj * (uint32_t)(P.nBlk / 4) * 2u;
+        return P;
     };
+    static_assert(P1::nBlk % 4 == 0 && P4::nBlk % 4 == 0 && P5::nBlk % 4 == 0 && P6::nBlk % 4 == 0 && P1::LPR % 4 == 0 && P4::LPR % 4 == 0 && P5::LPR % 4 == 0 && P6::LPR % 4 == 0,
+                  "a group's four blocks start at a multiple of four");
     xe_fill<NCW, D>(phase_of(0, L.lay[0]), cw, lane, R);
     for (int l = 0; l < a.n_layer; l++) {
         const EngLayer& ly = L.lay[l];
@@ -588,7 +637,9 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
             const u32x4* xs = (q == 0 || q == 2) ? L.xs[0] : L.xs[1];
             const int nrows = q == 0 ? P1::R : (q == 1 ? P4::R : (q == 2 ? P5::R : P6::R));
             const int spg = q == 0 ? P1::spg : (q == 1 ? P4::spg : (q == 2 ? P5::spg : P6::spg));
-            const int nwp = spg < NCW ? spg : NCW;
+            int nwp = 0; /* waves that own rows of the phase */
+#pragma unroll
+            for (int w = 0; w < NCW; w++) nwp += xe_nslots<NCW>(w, spg) > 0 ? 1 : 0;
             uint32_t* const dst = loc + (q == 0 ? C::qkv + S.q_out0 : (q == 1 ? C::xB + wg * P4::R : (q == 2 ? C::act + wg * P5::R : C::xA + wg * P6::R)));
             __syncthreads(); /* the phase's activations are staged (B1 / B4 / B5 / B6) */
             if (cw == 0) XE_STAMP(16 + 2 * q);
@@ -604,16 +655,18 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
                         const float gt = round_bf16(v), up = round_bf16(v2); /* CU_swiglu_v0 on the two bf16-rounded projections */
                         g = (tag << 16) | (uint32_t)f2bf((gt * up) / (1.0f + kf_expf(-gt)));
                     } else {
-                        const uint16_t y = f2bf(bf2f(L.xrawB[row]) + bf2f(f2bf(v)));
-                        if (last) a.x_out[(size_t)S.seq * C::DIM + row] = y;
-                        g = (tag_next << 16) | (uint32_t)y;
+                        g = (tag_next << 16) | (uint32_t)f2bf(bf2f(L.xrawB[row]) + bf2f(f2bf(v)));
                     }
                     L.outb[row - P.row0] = g;
-                },
-                [&]() {
-                    if (q == 0 && !S.empty) xe_attn_issue<C>(a, ly, S, cw, lane, T, 0, 0); /* the slice's first tiles (rows of earlier positions; row `pos` is substituted) */
                 });
-            if (cw < nwp) xe_publish(L, dst, nrows, nwp, lane);
+            XE_STAMP(32 + 8 * q + (cw & 7)); /* this wave's rows of the phase are done */
+            if (C::DBG && S.stamp && lane == 0 && q == 0) {
+                unsigned hw;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+                a.dbg[((size_t)S.step * a.n_layer + l) * 64 + ((cw & 7) < 2 ? 14 + (cw & 7) : 23 + (cw & 7))] = hw; /* slots 14, 15, 25 .. 30: where (SIMD, CU) the wave runs */
+            }
+            if (q == 0) xe_attn_issue<C>(a, ly, S, cw, lane, T, 0, 0); /* the slice's first tiles (rows of earlier positions; row `pos` is substituted): the q | k | v hand-off hides them */
+            if (xe_nslots<NCW>(cw, spg) > 0) xe_publish(L, q, dst, nrows, nwp, lane, (q == 3 && last) ? a.x_out + (size_t)S.seq * C::DIM + wg * P6::R : nullptr);
             if (cw == 0) XE_STAMP(17 + 2 * q);
             if (q == 0) { /* q/k-norm + RoPE + attention over the workgroup's key slice; the slice partial into the XCD's partial area; then the first o_proj blocks */
                 xe_attn_phase<C>(a, L, S, ly, gen, cw, lane, T, l, [&]() { xe_fill<NCW, D>(phase_of(1, ly), cw, lane, R); });
@@ -658,7 +711,7 @@ __device__ __forceinline__ void xe_head_main(const XArgs& a, const XLds& L, cons
     const uint32_t gen = (uint32_t)(epoch + 1) * (uint32_t)a.n_layer, tag = gen & 0xffffu; /* the generation the last layer's down_proj published its rows with */
     if (wave == NWV - 1) {
         bool dead = false;
-        eng_poll_stage<1, ND, nBlk, true, false, false>(loc + C::xA, nullptr, tag, a.head_norm, a.eps, L.xs[0], nullptr, lane, a.ws, dead, nullptr, nullptr, 0, 0);
+        eng_poll_stage<1, ND, nBlk, true, false, false>(loc + C::xA, nullptr, tag, a.head_norm, a.eps, L.xs[0], nullptr, lane, a.ws, dead, nullptr, L.pub + 3, (S.step + 1) * a.n_layer, 0);
     } else {
         issue(0, 0); /* ahead of the hand-off of x (the poller's own first rows are requested behind its sweep: loads return in order) */
     }
@@ -769,7 +822,7 @@ __device__ __forceinline__ void xe_head_main(const XArgs& a, const XLds& L, cons
 }
 
 template <class C>
-__global__ void __launch_bounds__(C::NWV * 64) xengine_kernel(const XArgs a) {
+__global__ void __launch_bounds__(C::NWV * 64, ((C::NWV + 3) / 4) * C::WPC /* waves per SIMD: the register budget that lets WPC workgroups share a CU */) xengine_kernel(const XArgs a) {
     constexpr int hd = C::HD, GQ = C::GQ, NWV = C::NWV, NCW = C::NCW;
     using P1 = typename C::SH::P1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -799,10 +852,14 @@ __global__ void __launch_bounds__(C::NWV * 64) xengine_kernel(const XArgs a) {
     L.wmax = reinterpret_cast<float*>(smem + o_wmax);
     L.outb = reinterpret_cast<uint32_t*>(smem + o_outb);
     L.cnt = reinterpret_cast<int*>(smem + o_cnt);
+    L.pub = L.cnt + 8;
     if (tid == 0) *L.cnt = 0;
+    if (tid < 4) L.pub[tid] = 0;
     if (a.ws[1] != 0) return; /* an earlier launch timed out: nothing runs until the host has cleared the word (xengine_reset) */
-    // ---- which decoder, which place in it
+    // ---- which decoder, which place in it: the XCD from the hardware register, a ticket there; with two decoders per XCD the first 32 tickets (the workgroups the
+    // dispatcher placed first: one per CU) are decoder 0, the next 32 decoder 1 -- sequences x and x + 8
     XSeq S;
+    int xcc;
     {
         int* xi = L.cnt + 1;
         if (tid == 0) {
@@ -810,12 +867,22 @@ __global__ void __launch_bounds__(C::NWV * 64) xengine_kernel(const XArgs a) {
             xi[0] = x, xi[1] = __hip_atomic_fetch_add(a.ws + 16 + x * 32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-        S.seq = xi[0], S.r = xi[1] & (XE_NWG - 1);
-        if (xi[1] >= XE_NWG && tid == 0) atomicOr(a.ws + 1, 8); /* not 32 workgroups on this XCD: the polls time out, the word says why */
+        xcc = xi[0];
+        S.seq = xcc + XE_NXCD * ((xi[1] / XE_NWG) % C::WPC), S.r = xi[1] & (XE_NWG - 1);
+        if (xi[1] >= XE_NWG * C::WPC && tid == 0) atomicOr(a.ws + 1, 8); /* not 32 (64) workgroups on this XCD: the polls time out, the word says why */
     }
+    auto leave = [&]() { /* the last workgroup of the XCD to leave zeroes its ticket counter for the next launch */
+        if (tid == 0) {
+            const int d = __hip_atomic_fetch_add(a.ws + 17 + xcc * 32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == XE_NWG * C::WPC - 1) {
+                __hip_atomic_store(a.ws + 16 + xcc * 32, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.ws + 17 + xcc * 32, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
     const int epoch0 = a.ws[0];
-    if (S.seq >= a.n_seq) { /* an XCD without a sequence: its workgroups leave (the last one to arrive zeroes the ticket for the next launch) */
-        if (tid == 0 && L.cnt[2] == XE_NWG - 1) a.ws[16 + S.seq * 32] = 0;
+    if (S.seq >= a.n_seq) { /* a decoder without a sequence: its workgroups leave */
+        leave();
         return;
     }
     {
@@ -860,10 +927,8 @@ __global__ void __launch_bounds__(C::NWV * 64) xengine_kernel(const XArgs a) {
         else xe_compute_main<C>(a, L, S, epoch, wave, lane, R);
         if (a.head_w) xe_head_main<C>(a, L, S, epoch, step + 1 < nst, wave, lane);
     }
-    if (S.r == 0 && tid == 0) { /* every workgroup of this decoder took its ticket before any could finish a layer */
-        a.ws[16 + S.seq * 32] = 0;
-        if (S.seq == 0) a.ws[0] = epoch0 + nst; /* the next launch's generation (every decoder advances by the same number of steps) */
-    }
+    if (S.seq == 0 && S.r == 0 && tid == 0) a.ws[0] = epoch0 + nst; /* the next launch's generation (every decoder advances by the same number of steps; every workgroup read it long ago) */
+    leave();
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -882,22 +947,22 @@ static int xe_shape_class(int GQ, int hd, int dim, int q_dim, int ffn) {
     if (GQ == 2 && hd == 64 && dim == 256 && q_dim == 256 && ffn == 512) return 2;     /* the small parity-test shape */
     return 0;
 }
-template <int NWV, int DEPTH, bool DBG>
-using XC1 = XCfg<FMT_Q4P, 2, 128, NWV, 1024, 2048, 1024, 3072, DEPTH, DBG>;
-template <int NWV, int DEPTH, bool DBG>
-using XC2 = XCfg<FMT_Q4P, 2, 64, NWV, 256, 256, 128, 512, DEPTH, DBG>;
-static int xe_loc_dw(int shape_class) { return shape_class == 1 ? XC1<9, 8, false>::loc_dw : XC2<9, 8, false>::loc_dw; }
+template <int NWV, int DEPTH, bool DBG, int WPC>
+using XC1 = XCfg<FMT_Q4P, 2, 128, NWV, 1024, 2048, 1024, 3072, DEPTH, DBG, WPC>;
+template <int NWV, int DEPTH, bool DBG, int WPC>
+using XC2 = XCfg<FMT_Q4P, 2, 64, NWV, 256, 256, 128, 512, DEPTH, DBG, WPC>;
+static int xe_loc_dw(int shape_class) { return shape_class == 1 ? XC1<9, 8, false, 1>::loc_dw : XC2<9, 8, false, 1>::loc_dw; }
 
 size_t xengine_ws_bytes(const kf_engine_desc* d) {
     const int hd = d->head_dim, GQ = d->n_kv > 0 ? d->n_head / d->n_kv : 1;
     const int sc = xe_shape_class(GQ, hd, d->dim, d->n_head * hd, d->ffn);
     size_t b = 4096 + (((size_t)d->n_layer * sizeof(EngLayer) + 255) & ~(size_t)255);
-    b += (size_t)XE_NXCD * xe_loc_stride(sc ? xe_loc_dw(sc) : 0) + 4096;
+    b += (size_t)XE_MAXSEQ * xe_loc_stride(sc ? xe_loc_dw(sc) : 0) + 4096;
     return b;
 }
 static int xengine_init_state(XEngineHost* E, hipStream_t st) {
     XArgs& a = E->args;
-    if (hipMemsetAsync(a.loc, 0xff, (size_t)XE_NXCD * E->loc_stride, st) != hipSuccess) return KF_HIP_CHECK;
+    if (hipMemsetAsync(a.loc, 0xff, (size_t)XE_MAXSEQ * E->loc_stride, st) != hipSuccess) return KF_HIP_CHECK;
     static int init[16 + 32 * XE_NXCD];
     memset(init, 0, sizeof(init));
     init[0] = 1; /* epoch 1, no error, tickets zero */
@@ -913,7 +978,7 @@ int xengine_build(const kf_engine_desc* d, int n_seq, long long kv_seq_stride, v
     const char* dummy;
     if (!why) why = &dummy;
     *why = "bad arguments";
-    if (!d || (!dry && (!ws || !out)) || d->n_layer < 1 || !d->layers || n_seq < 1 || n_seq > XE_NXCD || kv_seq_stride < 0) return KF_INVALID_ARGS;
+    if (!d || (!dry && (!ws || !out)) || d->n_layer < 1 || !d->layers || n_seq < 1 || n_seq > XE_MAXSEQ || kv_seq_stride < 0) return KF_INVALID_ARGS;
     const int hd = d->head_dim;
     *why = "head_dim must be 64 or 128 and n_head a multiple of n_kv";
     if ((hd != 64 && hd != 128) || d->n_kv <= 0 || d->n_head % d->n_kv != 0) return KF_UNSUPPORTED_DATATYPE;
@@ -1009,26 +1074,36 @@ static int xengine_go(XEngineHost* E, hipStream_t st) {
         if (hipFuncSetAttribute((const void*)xengine_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return KF_HIP_CHECK;
         ready = 1;
     }
-    const size_t smem = xe_smem<C>(E->args.n_layer);
-    if (smem > 160 * 1024) return KF_UNSUPPORTED_DATATYPE;
-    hipLaunchKernelGGL((xengine_kernel<C>), dim3(XE_GRID), dim3(C::NWV * 64), smem, st, E->args);
+    size_t smem = xe_smem<C>(E->args.n_layer);
+    if (C::WPC == 2 && smem < 54 * 1024) smem = 54 * 1024; /* two workgroups per CU, never three: a third would be a workgroup of some decoder queued behind its own peers */
+    if (smem * C::WPC > 160 * 1024) return KF_UNSUPPORTED_DATATYPE;
+    hipLaunchKernelGGL((xengine_kernel<C>), dim3(XE_GRID * C::WPC), dim3(C::NWV * 64), smem, st, E->args);
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 #ifndef XE_VARIANTS
-#define XE_VARIANTS 1 /* the tuning instantiations (waves per workgroup x ring depth) beside the default */
+#define XE_VARIANTS 1 /* the tuning instantiations (waves per workgroup x ring depth) beside the defaults */
 #endif
-template <template <int, int, bool> class XC>
+// n_seq <= 8: one decoder per XCD, 9 waves (8 compute + the poller; 168 registers); more: two per XCD, two workgroups of 8 waves per CU (128 registers)
+template <template <int, int, bool, int> class XC>
 static int xengine_go_shape(XEngineHost* E, hipStream_t st) {
+    const bool two = E->args.n_seq > XE_NXCD;
 #ifndef XE_ONLY_DEFAULT
     const bool dbg = E->args.dbg != nullptr;
-    if (dbg) return xengine_go<XC<9, 8, true>>(E, st);
+    if (dbg) return two ? xengine_go<XC<8, 8, true, 2>>(E, st) : xengine_go<XC<9, 8, true, 1>>(E, st);
 #endif
 #if XE_VARIANTS && !defined(XE_ONLY_DEFAULT)
-    if (E->nwv == 13 && E->depth == 6) return xengine_go<XC<13, 6, false>>(E, st);
-    if (E->nwv == 16 && E->depth == 4) return xengine_go<XC<16, 4, false>>(E, st);
-    if (E->nwv == 9 && E->depth == 12) return xengine_go<XC<9, 12, false>>(E, st);
+    if (!two) {
+        if (E->nwv == 13 && E->depth == 6) return xengine_go<XC<13, 6, false, 1>>(E, st);
+        if (E->nwv == 16 && E->depth == 4) return xengine_go<XC<16, 4, false, 1>>(E, st);
+        if (E->nwv == 8 && E->depth == 8) return xengine_go<XC<8, 8, false, 1>>(E, st);
+        if (E->nwv == 12 && E->depth == 6) return xengine_go<XC<12, 6, false, 1>>(E, st);
+        if (E->nwv == 12 && E->depth == 8) return xengine_go<XC<12, 8, false, 1>>(E, st);
+    } else {
+        if (E->nwv == 8 && E->depth == 6) return xengine_go<XC<8, 6, false, 2>>(E, st);
+        if (E->nwv == 8 && E->depth == 4) return xengine_go<XC<8, 4, false, 2>>(E, st);
+    }
 #endif
-    return xengine_go<XC<9, 8, false>>(E, st);
+    return two ? xengine_go<XC<8, 8, false, 2>>(E, st) : xengine_go<XC<9, 8, false, 1>>(E, st);
 }
 // n_steps decode steps of every sequence in ONE launch; with_head: 0 layers only (x_out), 1 + logits, 2 + greedy pick and state update (needed for n_steps > 1)
 int xengine_steps(XEngineHost* E, hipStream_t st, int32_t* d_state, uint16_t* x_out, int with_head, int n_steps) {
@@ -1074,7 +1149,7 @@ int xengine_reset(XEngineHost* E, hipStream_t st) {
 void xengine_set_variant(XEngineHost* E, int nwv, int depth) { E->nwv = nwv, E->depth = depth; }
 int xengine_debug_enable(XEngineHost* E, int seq, int wg, int max_steps) {
     XArgs& a = E->args;
-    const size_t bytes = (size_t)max_steps * a.n_layer * 32 * 8;
+    const size_t bytes = (size_t)max_steps * a.n_layer * 64 * 8;
     if (a.dbg) (void)hipFree(a.dbg), a.dbg = nullptr;
     if (seq < 0) return KF_OK;
     if (hipMalloc(&a.dbg, bytes) != hipSuccess) {

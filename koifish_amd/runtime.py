@@ -678,10 +678,10 @@ class XcdReplicas:
         self.host.kfh_xr_variant(self.h, int(nwv), int(depth))
 
     def stamps(self, seq, wg, steps, n_layer):
-        """enable (steps > 0) / read the per-phase wall-clock stamps [step][layer][32] of one workgroup of one decoder (diagnostic instantiation)"""
+        """enable (steps > 0) / read the per-phase wall-clock stamps [step][layer][64] of one workgroup of one decoder (diagnostic instantiation)"""
         if steps > 0:
             L.check(self.host.kfh_xr_stamps_enable(self.h, int(seq), int(wg), int(steps)), "kfh_xr_stamps_enable")
             return None
-        out = np.zeros((-steps) * n_layer * 32, dtype=np.uint64)
+        out = np.zeros((-steps) * n_layer * 64, dtype=np.uint64)
         self.host.kfh_xr_stamps(self.h, out.ctypes.data_as(C.c_void_p), out.size)
-        return out.reshape(-steps, n_layer, 32)
+        return out.reshape(-steps, n_layer, 64)

@@ -47,8 +47,8 @@ for n_seq in [int(x) for x in os.environ.get("NSEQ", "8").split(",")]:
         tps = n_seq * steps / best
         print("n_seq %d  waves %2d depth %2d  positions %d..%d: %.3f ms per step (all sequences), %.1f tokens/s aggregate, %.1f per sequence, %.1f GB/s = %.3f of 8 TB/s" % (
             n_seq, nwv, depth, pos0, pos0 + steps - 1, best * 1e3 / steps, tps, tps / n_seq, bytes_step * tps / 1e9, bytes_step * tps / 8e12), flush=True)
-    if os.environ.get("STAMPS") and n_seq == 8:
-        xr.variant(9, 8)
+    if os.environ.get("STAMPS") and n_seq in (8, 16):
+        xr.variant(9, 8) if n_seq == 8 else xr.variant(8, 8)
         nl = cfg["n_layer"]
         xr.stamps(int(os.environ.get("STAMP_SEQ", "3")), int(os.environ.get("STAMP_WG", "5")), 2, nl)
         for s in range(n_seq):
@@ -58,8 +58,9 @@ for n_seq in [int(x) for x in os.environ.get("NSEQ", "8").split(",")]:
         m.sync()
         st = xr.stamps(0, 0, -2, nl).astype(np.int64)
         names = {0: "poll x", 1: "x staged", 2: "qkv staged", 3: "sums in LDS", 4: "partials seen", 5: "ao stored", 6: "ao staged", 7: "xB staged", 8: "act staged",
-                 16: "P1 go", 17: "P1 pub", 24: "attn done", 18: "P4 go", 19: "P4 pub", 20: "P5 go", 21: "P5 pub", 22: "P6 go", 23: "P6 pub"}
-        order = [0, 1, 16, 17, 2, 3, 24, 4, 5, 6, 18, 19, 7, 20, 21, 8, 22, 23]
+                 16: "P1 go", 17: "P1 pub", 24: "attn done", 18: "P4 go", 19: "P4 pub", 20: "P5 go", 21: "P5 pub", 22: "P6 go", 23: "P6 pub",
+                 9: "own qkv out", 10: "own xB out", 11: "own act out", 12: "own x out"}
+        order = [0, 12, 1, 16, 17, 9, 2, 3, 24, 4, 5, 6, 18, 19, 10, 7, 20, 21, 11, 8, 22, 23]
         for step in (1,):
             acc = np.zeros(len(order))
             cnt = 0
@@ -74,5 +75,13 @@ for n_seq in [int(x) for x in os.environ.get("NSEQ", "8").split(",")]:
             print("stamps of sequence / workgroup (us from the layer's first poll, mean over layers; layer period %.2f us):" % nxt)
             for k, v in zip(order, acc / max(cnt, 1)):
                 print("   %-14s %7.2f" % (names[k], v))
+            print("   sweeps of the act poll: %.2f" % np.mean([st[step, l, 13] for l in range(2, nl - 1)]))
+            print("   shader clock: %.0f MHz" % (100.0 * (st[step, nl - 2, 31] - st[step, 2, 31]) / (st[step, nl - 2, 0] - st[step, 2, 0])))
+            hw = [int(st[step, 5, k]) for k in (14, 15, 25, 26, 27, 28, 29, 30)]
+            print("   compute waves 0..7: SIMD", [(h >> 4) & 3 for h in hw], "CU", [(h >> 8) & 15 for h in hw], "wave slot", [h & 15 for h in hw])
+            for q, nm in enumerate(("q|k|v", "o_proj", "gate|up", "down")):
+                go = {0: 16, 1: 18, 2: 20, 3: 22}[q]
+                fin = np.mean([[(st[step, l, 32 + 8 * q + w] - st[step, l, go]) / 100.0 for w in range(8)] for l in range(2, nl - 1)], axis=0)
+                print("   %-8s per-wave finish (us after the phase's barrier):" % nm, " ".join("%.2f" % v for v in fin))
     xr.close()
 m.close()

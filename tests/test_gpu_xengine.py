@@ -38,10 +38,11 @@ def _oracle_run(cfg, raw, forced, n, pos0=0):
     return ids, logits, k, v
 
 
-@pytest.mark.parametrize("cfg_name,max_seq,n_steps,n_seq,spl", [("tiny", 96, 90, 8, 7), ("small", 320, 150, 8, 32), ("tiny", 700, 300, 3, 16)])
+@pytest.mark.parametrize("cfg_name,max_seq,n_steps,n_seq,spl", [("tiny", 96, 90, 8, 7), ("small", 320, 150, 8, 32), ("tiny", 700, 300, 3, 16), ("small", 320, 150, 16, 32), ("tiny", 700, 200, 11, 9)])
 def test_every_sequence_equals_the_oracle(canon, cfg_name, max_seq, n_steps, n_seq, spl):
     """different prompts per sequence (the first 12 .. 40 ids forced, then free running), several steps per launch: ids at every position, the last logits and all K / V rows
-    of every sequence against the oracle run on that sequence alone; n_seq < 8 leaves XCDs idle"""
+    of every sequence against the oracle run on that sequence alone; n_seq < 8 leaves XCDs idle, n_seq > 8 runs TWO decoders per XCD (two workgroups per CU; 11: the second
+    decoder of five XCDs idles)"""
     cfg = dict(synth.CONFIGS[cfg_name], max_seq=max_seq)
     raw = synth.raw_weights_numpy(cfg, 4321, w_std=0.1)
     m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
@@ -192,7 +193,7 @@ def test_refusals():
     m.close()
     m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
     with pytest.raises(L.KFError):
-        XcdReplicas(m, 9)
+        XcdReplicas(m, 17)
     m.set_canonical(False)
     xr = XcdReplicas(m, 2)
     xr.set_state(0, 1, 0), xr.set_state(1, 2, 0)
