@@ -107,6 +107,7 @@ def main():
     head_type = {"bf16": L.BF16, "q4": L.Q4, "nf4": L.NF4}[args.head]
     layer_type = {"q4": L.Q4, "bf16": L.BF16, "f8": L.F8E5M2, "ternary": L.T_SIGN, "1bit": L.BOOL1, "nf4": L.NF4}[args.layers]
     m = synth.build_on_gpu(cfg, seed=1234 + rank, layer_type=layer_type, head_type=head_type, device=dev)
+    m.set_prefill_resident(True, 96 << 30)   # opt-in (library default: off): this run never changes a weight in place, so long prompts may keep bf16 copies of the layer matrices in HBM
     ctx = m._ctx
     hots = {}
     if args.sparse > 0.0:
@@ -423,126 +424,51 @@ def side_legs(which):
 
 
 def config3_train_step():
-    """BASELINE config 3, the KERNEL PATH of one training step on one MI355X, as a SUM OF SEPARATELY TIMED PHASES: GPT2-1558M shapes (n_embd 1600, 48 layers, 25 heads, ffn 6400,
-    vocab 50257 padded to 50304), hybrid storage (attention matrices f8e5m2, MLP matrices RTN 4-bit, tied bf16 wte), batch 8 x 1024 random ids: (a) forward with every activation
-    kept + fused classifier loss, (b) backward through every operator of the ABI (gradients of the quantised layers = bf16 gradients of their dequantised weights; the blocks'
-    weight-gradient buffers are SHARED between layers, so no parameter is updated), (c) AdamW over a 1.558 G-element vector of random parameters / gradients (not the model's).
-    The embedding gather / add, one q copy and the zero fills are torch ops; everything else is this library's kernels.  Not a trained model and not comparable one-to-one with
-    the reference's end-to-end training throughput (48.8 k tokens/s on an RTX 4090, cases/gpt2/1558M_F8_B80/F8_B80.info:2928-2951): it says what the operator path sustains."""
-    import ctypes as C
+    """BASELINE config 3: ONE whole training step of the hybrid-precision GPT2-1558M on one MI355X, in ONE timed region (koifish_amd/train_step.py, the loop
+    tests/test_gpu_train_step.py::test_gpt2_two_consecutive_steps_with_update checks against the oracle at toy size): n_embd 1600, 48 layers, 25 heads, ffn 6400, vocab 50257
+    padded to 50304; attention matrices f8e5m2, MLP matrices RTN 4-bit, tied bf16 wte; batch 8 x 1024 random ids.  forward (every activation kept) + fused classifier loss ->
+    backward through every operator into PER-TENSOR gradient buffers -> kf_adamw on the model's own bf16 masters and moments (seeded stochastic rounding) -> kf_quantize of every
+    matrix back into the blob the next forward reads.  The embedding gather / add, one q copy and the zero fills are torch ops; everything else is this library's kernels.
+    Synthetic data and weights: not comparable one-to-one with the reference's end-to-end training throughput (48.8 k tokens/s on an RTX 4090,
+    cases/gpt2/1558M_F8_B80/F8_B80.info:2928-2951: a real run with a data loader); it says what the step's kernel path sustains."""
     import torch
-    from koifish_amd import lib as L, runtime as R
+    from koifish_amd import runtime as R
+    from koifish_amd.train_step import GPT2Step
     ctx = R.Context(0)
     dev = ctx.device
     Cn, H, T, B, NL, V, Vp = 1600, 25, 1024, 8, 48, 50257, 50304
-    hd = Cn // H
-    N = B * T
-    bf = torch.bfloat16
-    mk = lambda m, k, t: ctx.quantize((torch.randn(m, k, device=dev) * 0.02).to(bf), t)
-    layers = [(mk(3 * Cn, Cn, L.F8E5M2), mk(Cn, Cn, L.F8E5M2), mk(4 * Cn, Cn, L.Q4), mk(Cn, 4 * Cn, L.Q4)) for _ in range(NL)]
-    z = lambda *s, dt=bf: torch.zeros(*s, device=dev, dtype=dt)
-    bq, bp, bfc, bp2 = z(3 * Cn), z(Cn), z(4 * Cn), z(Cn)
-    lnw, lnb = torch.ones(Cn, device=dev, dtype=bf), z(Cn)
-    wte_t = z(Vp, Cn)
-    wte_t[:V] = (torch.randn(V, Cn, device=dev) * 0.02).to(bf)
-    wte = ctx.quantize(wte_t, L.BF16)
-    wpe = (torch.randn(T, Cn, device=dev) * 0.01).to(bf)
+    N, hd = B * T, Cn // H
+    st = GPT2Step(ctx, Cn, H, NL, V, Vp, B, T, seed=3)
     ids = torch.randint(0, V, (N,), device=dev, dtype=torch.int32)
     tgt = torch.randint(0, V, (N,), device=dev, dtype=torch.int32)
-    A = [dict(x=z(N, Cn), h1=z(N, Cn), m1=z(N, dt=torch.float32), r1=z(N, dt=torch.float32), qkv=z(N, 3 * Cn), att=z(N, Cn), x2=z(N, Cn), h2=z(N, Cn), m2=z(N, dt=torch.float32),
-              r2=z(N, dt=torch.float32), f=z(N, 4 * Cn), g=z(N, 4 * Cn)) for _ in range(NL)]
-    xf, hf, mf, rf = z(N, Cn), z(N, Cn), z(N, dt=torch.float32), z(N, dt=torch.float32)
-    qc, logits, losses = z(N, Cn), z(N, Vp), z(N, dt=torch.float32)
-    for w_ in layers[0]:
-        ctx.linear_scratch(w_, N)
-
-    def lin(w, xin, y, n, b, res=None):
-        d = w.desc()
-        L.check(ctx.hip.kf_linear(ctx.h, C.byref(d), xin.data_ptr(), y.data_ptr(), b.data_ptr() if b is not None else None, n, 1.0, 0.0, 1 if res is not None else 0,
-                                  res.data_ptr() if res is not None else None), "kf_linear")
-
-    def ln(x, y, m_, r_):
-        L.check(ctx.hip.kf_layernorm(ctx.h, x.data_ptr(), lnw.data_ptr(), lnb.data_ptr(), y.data_ptr(), N, Cn, 1e-5, m_.data_ptr(), r_.data_ptr()), "kf_layernorm")
-
-    def forward():
-        A[0]["x"].copy_(wte_t[ids.long()])
-        A[0]["x"].add_(wpe.repeat(B, 1))
-        for l in range(NL):
-            a = A[l]
-            wqkv, wproj, wfc, wproj2 = layers[l]
-            ln(a["x"], a["h1"], a["m1"], a["r1"])
-            lin(wqkv, a["h1"], a["qkv"], N, bq)
-            qc.copy_(a["qkv"][:, :Cn])
-            L.check(ctx.hip.kf_attn_prefill_batch(ctx.h, qc.data_ptr(), a["qkv"][:, Cn:].data_ptr(), a["qkv"][:, 2 * Cn:].data_ptr(), a["att"].data_ptr(), T, Cn, H, H, hd, 3 * Cn, B), "attn")
-            lin(wproj, a["att"], a["x2"], N, bp, a["x"])
-            ln(a["x2"], a["h2"], a["m2"], a["r2"])
-            lin(wfc, a["h2"], a["f"], N, bfc)
-            L.check(ctx.hip.kf_gelu(ctx.h, a["f"].data_ptr(), a["g"].data_ptr(), a["f"].numel()), "kf_gelu")
-            lin(wproj2, a["g"], A[l + 1]["x"] if l + 1 < NL else xf, N, bp2, a["x2"])
-        ln(xf, hf, mf, rf)
-        lin(wte, hf, logits, N, None)
-        losses.zero_()
-        L.check(ctx.hip.kf_fused_classifier(ctx.h, logits.data_ptr(), losses.data_ptr(), None, 1.0 / N, tgt.data_ptr(), B, T, V, Vp, None, 1), "kf_fused_classifier")
-
-    dx, dh, dqkv, datt, d4 = z(N, Cn), z(N, Cn), z(N, 3 * Cn), z(N, Cn), z(N, 4 * Cn)
-    gW = {"qkv": z(3 * Cn, Cn), "proj": z(Cn, Cn), "fc": z(4 * Cn, Cn), "proj2": z(Cn, 4 * Cn)}
-    gB = {"qkv": z(3 * Cn), "proj": z(Cn), "fc": z(4 * Cn), "proj2": z(Cn)}
-    g_lnw, g_lnb, g_wte, g_wpe = z(Cn), z(Cn), z(Vp, Cn), z(T, Cn)
-    sc_lin = torch.empty(max(ctx.hip.kf_linear_backward_scratch_bytes(oc, ic, N) for oc, ic in ((3 * Cn, Cn), (Cn, Cn), (4 * Cn, Cn), (Cn, 4 * Cn), (Vp, Cn))) + 256, dtype=torch.uint8, device=dev)
-    sp_lin = (sc_lin.data_ptr() + 255) & ~255
-    sc_ln = torch.empty(ctx.hip.kf_norm_backward_scratch_bytes(N, Cn, 1) // 8 + 1, dtype=torch.float64, device=dev)
-    sc_at = torch.empty(ctx.hip.kf_attn_backward_scratch_bytes(T, H, B) // 4 + 1, dtype=torch.float32, device=dev)
-
-    def lin_bwd(w, dIn, inp, delta, gw, gb, acc=0):
-        d = w.desc()
-        L.check(ctx.hip.kf_linear_backward(ctx.h, C.byref(d), dIn.data_ptr(), inp.data_ptr(), delta.data_ptr(), gw.data_ptr(), gb.data_ptr() if gb is not None else None, N, acc, sp_lin),
-                "kf_linear_backward")
-
-    def ln_bwd(dxx, dout, inp, m_, r_):
-        L.check(ctx.hip.kf_norm_backward(ctx.h, dxx.data_ptr(), g_lnw.data_ptr(), g_lnb.data_ptr(), dout.data_ptr(), inp.data_ptr(), lnw.data_ptr(), m_.data_ptr(), r_.data_ptr(), N, Cn,
-                                         sc_ln.data_ptr()), "kf_norm_backward")
-
-    def backward():
-        logits[:, V:].zero_()
-        lin_bwd(wte, logits, hf, dh, g_wte, None)
-        dx.zero_()
-        ln_bwd(dx, dh, xf, mf, rf)
-        for l in reversed(range(NL)):
-            a = A[l]
-            wqkv, wproj, wfc, wproj2 = layers[l]
-            lin_bwd(wproj2, dx, a["g"], d4, gW["proj2"], gB["proj2"])
-            L.check(ctx.hip.kf_gelu_backward(ctx.h, d4.data_ptr(), a["f"].data_ptr(), d4.numel()), "kf_gelu_backward")
-            lin_bwd(wfc, d4, a["h2"], dh, gW["fc"], gB["fc"])
-            ln_bwd(dx, dh, a["x2"], a["m2"], a["r2"])
-            lin_bwd(wproj, dx, a["att"], datt, gW["proj"], gB["proj"])
-            L.check(ctx.hip.kf_attn_backward(ctx.h, a["qkv"][:, :Cn].data_ptr(), a["qkv"][:, Cn:2 * Cn].data_ptr(), a["qkv"][:, 2 * Cn:].data_ptr(), 3 * Cn, a["att"].data_ptr(), datt.data_ptr(),
-                                             Cn, dqkv[:, :Cn].data_ptr(), dqkv[:, Cn:2 * Cn].data_ptr(), dqkv[:, 2 * Cn:].data_ptr(), 3 * Cn, T, H, H, hd, B, sc_at.data_ptr()), "kf_attn_backward")
-            lin_bwd(wqkv, dqkv, a["h1"], dh, gW["qkv"], gB["qkv"])
-            ln_bwd(dx, dh, a["x"], a["m1"], a["r1"])
-        L.check(ctx.hip.kf_embed_backward(ctx.h, g_wte.data_ptr(), Cn, g_wpe.data_ptr(), dx.data_ptr(), ids.data_ptr(), B, T, Cn, Vp), "kf_embed_backward")
-
-    def timed(fn, reps=2):
-        fn()
-        ctx.sync()
-        e0, e1 = ctx.event(), ctx.event()
-        ctx.record(e0)
-        for _ in range(reps):
-            fn()
-        ctx.record(e1)
-        return ctx.elapsed_ms(e0, e1) / reps
-    t_f = timed(forward)
-    forward()
+    hp = dict(lr=3e-4, beta1=0.9, beta2=0.95, eps=1e-8, wd=0.1, seed=7)
+    loss_hist = []
+    st.step(ids, tgt, **hp)   # warm-up step (first-launch costs, scratch sizing)
     ctx.sync()
-    loss = float(losses.mean())
-    t_b = timed(backward)
-    del A, layers, logits
-    torch.cuda.empty_cache()
-    npar = 1_558_000_000 // 8 * 8
-    p_ = (torch.randn(npar, device=dev) * 0.02).to(bf)
-    gr = (torch.randn(npar, device=dev) * 0.01).to(bf)
-    m1, m2 = z(npar), z(npar)
-    t_a = timed(lambda: L.check(ctx.hip.kf_adamw(ctx.h, p_.data_ptr(), gr.data_ptr(), m1.data_ptr(), m2.data_ptr(), npar, L.BF16, 3e-4, 0.9, 0.95, 0.1, 0.05, 1e-8, 0.1, 1.0, 7, None), "kf_adamw"))
-    ms = t_f + t_b + t_a
+    loss_hist.append(float(st.losses.mean()))
+    probe = st.blocks[0]["fc"]["p"].view(torch.int16)[:4096].clone()
+    reps = 2
+    ev = [ctx.event() for _ in range(4 * reps + 1)]
+    ctx.record(ev[0])
+    for r in range(reps):   # ONE region: whole steps back to back; the events inside only split the report
+        st.forward(ids, tgt)
+        ctx.record(ev[4 * r + 1])
+        st.backward()
+        ctx.record(ev[4 * r + 2])
+        st.update(**hp)
+        ctx.record(ev[4 * r + 3])
+        ctx.record(ev[4 * r + 4])
+    ctx.sync()
+    ms = ctx.elapsed_ms(ev[0], ev[4 * reps]) / reps
+    t_f = sum(ctx.elapsed_ms(ev[4 * r], ev[4 * r + 1]) for r in range(reps)) / reps
+    t_b = sum(ctx.elapsed_ms(ev[4 * r + 1], ev[4 * r + 2]) for r in range(reps)) / reps
+    t_a = sum(ctx.elapsed_ms(ev[4 * r + 2], ev[4 * r + 3]) for r in range(reps)) / reps
+    st.forward(ids, tgt)
+    ctx.sync()
+    loss_hist.append(float(st.losses.mean()))
+    loss = loss_hist[-1]
+    moved = bool((st.blocks[0]["fc"]["p"].view(torch.int16)[:4096] != probe).any())
+    n_par = st.n_params()
     cpu_leg = None
     try:   # SURVEY section 8d: "CPU fwd of 1 layer x 1 batch row only (extrapolated; stated as such)": plain fp32 torch on this host's cores, the same operator sequence
         xc = torch.randn(T, Cn)
@@ -571,14 +497,17 @@ def config3_train_step():
     w_el = NL * 12 * Cn * Cn + Vp * Cn
     fwd = 2.0 * N * w_el + NL * 4.0 * Cn * (T * (T + 1) / 2) * B
     flops = 3.0 * fwd
-    return {"workload": "GPT2-1558M shapes (48 layers, n_embd 1600, 25 heads, ffn 6400, vocab 50257), hybrid f8e5m2 / 4-bit blocks, tied bf16 head, 8 x 1024 random tokens, every activation "
-                        "kept: SUM of three separately timed phases -- forward + loss, backward (weight-gradient buffers shared between layers: no parameter update), AdamW on a "
-                        "1.558 G-element random vector; embedding gather / add and zero fills are torch ops",
-            "ms": round(ms, 2), "tokens_per_s": round(N / ms * 1e3, 1), "forward_loss_ms": round(t_f, 2), "backward_ms": round(t_b, 2), "adamw_ms": round(t_a, 2),
+    return {"workload": "GPT2-1558M (48 layers, n_embd 1600, 25 heads, ffn 6400, vocab 50257), hybrid f8e5m2 / 4-bit blocks, tied bf16 head, 8 x 1024 random tokens, every activation kept: "
+                        "ONE timed region per step -- forward + loss, backward into per-tensor gradient buffers, AdamW on the model's own bf16 masters and moments, re-quantisation of "
+                        "every matrix into the blob the next forward reads; embedding gather / add and zero fills are torch ops",
+            "params_updated": moved, "one_timed_region": True, "parameters": int(n_par), "steps_timed": reps,
+            "ms": round(ms, 2), "tokens_per_s": round(N / ms * 1e3, 1), "forward_loss_ms": round(t_f, 2), "backward_ms": round(t_b, 2), "adamw_requantise_ms": round(t_a, 2),
+            "loss_after_1_and_%d_steps_on_one_batch" % (1 + reps): [round(v, 4) for v in loss_hist],
             "cpu_baseline": cpu_leg, "mean_loss": round(loss, 4), "flops": int(flops), "achieved_TFLOPs": round(flops / (ms * 1e-3) / 1e12, 1), "mfma_peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS,
             "mfma_frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-            "reference": "48.8 k tokens/s END-TO-END training on an RTX 4090 (cases/gpt2/1558M_F8_B80/F8_B80.info:2928-2951, BASELINE.md): a real run with data loading and parameter "
-                         "updates; the figure here is the operator path only", "profile": "profiles/r04_config3_train_step_kernel_stats.csv"}
+            "parity": "tests/test_gpu_train_step.py::test_gpt2_two_consecutive_steps_with_update: the same loop at toy size -- losses vs fp64, AdamW and re-quantisation vs the oracle bit for bit",
+            "reference": "48.8 k tokens/s END-TO-END training on an RTX 4090 (cases/gpt2/1558M_F8_B80/F8_B80.info:2928-2951, BASELINE.md): a real run with data loading; here synthetic "
+                         "data, the step's kernel path", "profile": "profiles/r05_config3_train_step_kernel_stats.csv"}
 
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak of MI355X (MI355X_MICROARCH.md); the prefill GEMMs multiply bf16 fragments unpacked from 4-bit tiles

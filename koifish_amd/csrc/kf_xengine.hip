@@ -81,6 +81,12 @@ struct XCfg {
     // LM head (bf16 [vocab, DIM]): the geometry gemv_launch picks for a many-row bf16 matrix of this width
     static constexpr int HnBlk = DIM_ / 8, Hlpr_log2 = c_lpr_log2(DIM_ / 8, 1L << 20), HLPR = 1 << Hlpr_log2, HRPS = 64 >> Hlpr_log2, Hiters = (HnBlk + HLPR - 1) / HLPR;
     static constexpr int XCH = 8; /* fp32 activations: 16-byte chunks per 32-weight block */
+    static constexpr int maxKc = DIM_ > QD_ ? (DIM_ > FFN_ ? DIM_ : FFN_) : (QD_ > FFN_ ? QD_ : FFN_);
+    static constexpr int XS = maxKc / 32; /* chunk stride of the staged activations (16-byte units): chunk j of block column c at [j * XS + c], whatever the phase's width */
+    // every phase in whole rows and whole iterations: no masks at the multiply
+    static constexpr bool EXACT = (QD_ + 2 * KVD_) % SH::P1::RPS == 0 && KVD_ % SH::P1::RPS == 0 && QD_ % SH::P1::RPS == 0 && DIM_ % SH::P4::RPS == 0 && FFN_ % SH::P5::RPS == 0 && DIM_ % SH::P6::RPS == 0 &&
+                                  SH::P1::nBlk == SH::P1::iters * SH::P1::LPR && SH::P4::nBlk == SH::P4::iters * SH::P4::LPR && SH::P5::nBlk == SH::P5::iters * SH::P5::LPR &&
+                                  SH::P6::nBlk == SH::P6::iters * SH::P6::LPR;
     static constexpr int maxR = (SH::P1::R > SH::P5::R ? SH::P1::R : SH::P5::R) > (SH::P4::R > SH::P6::R ? SH::P4::R : SH::P6::R) ? (SH::P1::R > SH::P5::R ? SH::P1::R : SH::P5::R)
                                                                                                                                       : (SH::P4::R > SH::P6::R ? SH::P4::R : SH::P6::R);
 };
@@ -192,12 +198,12 @@ __device__ __forceinline__ void xe_fill(const XPhase& P, int cw, int lane, XRing
 #pragma unroll
     for (int d = 0; d < D; d++) xe_issue<NCW, D>(P, G, P, G, false, d, d, cw, d < P.n, R);
 }
-// one block's 32 products into the lane's chain pair: BlockDotF<FMT> (kf_gemv_blocks.h) on the fp32 activation chunks [8][nBlk] in LDS
-template <int FMT>
-__device__ __forceinline__ f32x2_t xe_block(u32x4 w, uint16_t st16, uint16_t ze16, float qb, const f32x4* xf, int col, int nBlk, int lane, f32x2_t acc) {
+// one block's 32 products into the lane's chain pair: BlockDotF<FMT> (kf_gemv_blocks.h) on the fp32 activation chunks in LDS, chunk j of block column c at xf[j * XS + c]
+// (XS: the chunk stride, a compile-time constant of the model shape -- the same for every phase, so the eight reads of a block are one address and immediate offsets)
+template <int FMT, int XS>
+__device__ __forceinline__ f32x2_t xe_block(u32x4 w, uint16_t st16, uint16_t ze16, float qb, const f32x4* xc, int lane, f32x2_t acc) {
     const float step = bf2f(st16), zero = bf2f(ze16), nb = -(qb * step);
     const uint32_t D[4] = {w.w, w.z, w.y, w.x};
-    const f32x4* xc = xf + col;
     if constexpr (FMT == FMT_Q4P) {
         const float q0 = (float)((lane & 3) << 2);
         uint32_t r = pack_bf16x2(fmaf(q0, step, nb), fmaf(q0 + 1.0f, step, nb));
@@ -209,11 +215,11 @@ __device__ __forceinline__ f32x2_t xe_block(u32x4 w, uint16_t st16, uint16_t ze1
         t.tl[0] = quad_bcast<0>(tlm), t.tl[1] = quad_bcast<1>(tlm), t.tl[2] = quad_bcast<2>(tlm), t.tl[3] = quad_bcast<3>(tlm);
         t.th[0] = quad_bcast<0>(thm), t.th[1] = quad_bcast<1>(thm), t.th[2] = quad_bcast<2>(thm), t.th[3] = quad_bcast<3>(thm);
 #pragma unroll
-        for (int i = 0; i < 4; i++) acc = perm_fma_dword(D[i], xc[(2 * i) * nBlk], xc[(2 * i + 1) * nBlk], t, acc);
+        for (int i = 0; i < 4; i++) acc = perm_fma_dword(D[i], xc[(2 * i) * XS], xc[(2 * i + 1) * XS], t, acc);
     } else {
         const float step16 = step * 0.0625f;
 #pragma unroll
-        for (int i = 0; i < 4; i++) acc = arith_fma_dword(D[i], xc[(2 * i) * nBlk], xc[(2 * i + 1) * nBlk], step, step16, nb, zero, acc);
+        for (int i = 0; i < 4; i++) acc = arith_fma_dword(D[i], xc[(2 * i) * XS], xc[(2 * i + 1) * XS], step, step16, nb, zero, acc);
     }
     return acc;
 }
@@ -222,7 +228,7 @@ __device__ __forceinline__ f32x2_t xe_block(u32x4 w, uint16_t st16, uint16_t ze1
 // hand-off that separates the phases).  epi(row, v, v2) runs in the lane that owns a finished row (LDS only: no memory operation inside the loop but the refills).
 template <class C, int D, typename Epi>
 __device__ __forceinline__ void xe_mv_run(const XPhase& P, const XPhase& NX, bool nx_on, int cw, int lane, const u32x4* xs, XRing<D>& R, Epi&& epi) {
-    constexpr int NCW = C::NCW;
+    constexpr int NCW = C::NCW, XS = C::XS;
     static_assert((D % 2) == 0, "gate | up entries come in pairs");
     const int n = P.n, n_pad = n > 0 ? (n + D - 1) / D * D : D; /* at least one round: the last round is where the next phase's entries are requested */
     const f32x4* xf = reinterpret_cast<const f32x4*>(xs);
@@ -237,8 +243,6 @@ __device__ __forceinline__ void xe_mv_run(const XPhase& P, const XPhase& NX, boo
                 const int k = P.paired ? e >> 1 : e;
                 const int sl = k / P.iters, it = k - sl * P.iters;
                 const int row = ((P.s0 + xe_slot<NCW>(cw, sl)) << P.rps_log2) + G.sub, colr = (it << P.lpr_log2) + G.ll;
-                const bool ok = row < P.Mj && colr < P.nBlk;
-                const int col = colr < P.nBlk ? colr : P.nBlk - 1;
                 const bool second = P.paired && (d & 1);
                 if (it == 0) {
                     if (second) acc2 = f32x2_t{0.f, 0.f};
@@ -246,15 +250,21 @@ __device__ __forceinline__ void xe_mv_run(const XPhase& P, const XPhase& NX, boo
                 }
                 const f32x2_t in = second ? acc2 : acc;
                 const float qb_a = P.qb, qb_b = P.qb2;
-                const f32x2_t r = xe_block<C::FMT>(R.w[d], R.st[d], R.ze[d], second ? qb_b : qb_a, xf, col, P.nBlk, lane, in);
-                const f32x2_t o = acc_pick(ok, r, in);
+                f32x2_t o;
+                if constexpr (C::EXACT) { /* whole rows, whole iterations: nothing to mask */
+                    o = xe_block<C::FMT, XS>(R.w[d], R.st[d], R.ze[d], second ? qb_b : qb_a, xf + colr, lane, in);
+                } else {
+                    const bool ok = row < P.Mj && colr < P.nBlk;
+                    const int col = colr < P.nBlk ? colr : P.nBlk - 1;
+                    o = acc_pick(ok, xe_block<C::FMT, XS>(R.w[d], R.st[d], R.ze[d], second ? qb_b : qb_a, xf + col, lane, in), in);
+                }
                 if (second) acc2 = o;
                 else acc = o;
                 if (it == P.iters - 1 && (!P.paired || second)) {
                     const float v = group_sum(acc_join(acc), P.lpr_log2);
                     float v2 = 0.f;
                     if (P.paired) v2 = group_sum(acc_join(acc2), P.lpr_log2);
-                    if (G.ll == 0 && row < P.Mj) epi(row, v, v2);
+                    if (G.ll == 0 && (C::EXACT || row < P.Mj)) epi(row, v, v2);
                 }
             }
             // refill slot d (always ONE set of loads: see xe_issue)
@@ -450,11 +460,11 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, co
                 if (f >= 0) tok = f;
             }
             if (tok < 0 || tok >= a.emb_rows) tok = 0;
-            eng_poll_stage<XCH, ND, P1::nBlk, true, true, true>(nullptr, a.emb + (size_t)tok * C::DIM, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, nullptr, nullptr, 0, 0);
+            eng_poll_stage<XCH, ND, C::XS, true, true, true>(nullptr, a.emb + (size_t)tok * C::DIM, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, nullptr, nullptr, 0, 0);
         } else {
             eng_wait_pub(L.pub + 3, S.step * a.n_layer + l, 0, dead);
             XE_STAMP(12);
-            eng_poll_stage<XCH, ND, P1::nBlk, true, false, true>(loc + C::xA, nullptr, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, nullptr, nullptr, 0, 0);
+            eng_poll_stage<XCH, ND, C::XS, true, false, true>(loc + C::xA, nullptr, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, nullptr, nullptr, 0, 0);
         }
         XE_STAMP(1);
         __syncthreads(); /* B1 */
@@ -551,18 +561,18 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, co
         }
         XE_STAMP(5);
         // P4's ao, P5's xB (P6 adds it as the residual), P6's act
-        eng_poll_stage<XCH, NQD, P4::nBlk, false, false, true>(loc + C::ao, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, nullptr, nullptr, 0, 0);
+        eng_poll_stage<XCH, NQD, C::XS, false, false, true>(loc + C::ao, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, nullptr, nullptr, 0, 0);
         XE_STAMP(6);
         __syncthreads(); /* B4 */
         eng_wait_pub(L.pub + 1, S.step * a.n_layer + l + 1, 0, dead);
         XE_STAMP(10);
-        eng_poll_stage<XCH, ND, P5::nBlk, true, false, true>(loc + C::xB, nullptr, tag, ly.norm_post, a.eps, L.xs[0], L.xrawB, lane, a.ws, dead, nullptr, nullptr, 0, 0);
+        eng_poll_stage<XCH, ND, C::XS, true, false, true>(loc + C::xB, nullptr, tag, ly.norm_post, a.eps, L.xs[0], L.xrawB, lane, a.ws, dead, nullptr, nullptr, 0, 0);
         XE_STAMP(7);
         __syncthreads(); /* B5 */
         eng_wait_pub(L.pub + 2, S.step * a.n_layer + l + 1, 0, dead);
         XE_STAMP(11);
         int nsw_act = 0;
-        eng_poll_stage<XCH, NF, P6::nBlk, false, false, true>(loc + C::act, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, &nsw_act, nullptr, 0, 0);
+        eng_poll_stage<XCH, NF, C::XS, false, false, true>(loc + C::act, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, &nsw_act, nullptr, 0, 0);
         if (C::DBG && S.stamp && lane == 0) a.dbg[((size_t)S.step * a.n_layer + l) * 64 + 13] = (unsigned long long)nsw_act;
         XE_STAMP(8);
         __syncthreads(); /* B6 */

@@ -394,7 +394,7 @@ int Fish::EnsureEngine() {
     }
     return KF_OK;
 }
-void Fish::DropEngine() {
+void Fish::DropEngineTable() {
     for (auto& g : graphs)
         if (g) kf_graph_destroy(g), g = nullptr;
     if (engine) {
@@ -404,6 +404,9 @@ void Fish::DropEngine() {
     }
     if (engine_ws) kf_free(ctx, engine_ws), engine_ws = nullptr;
     engine_state = 0, engine_embed = engine_head = false;
+}
+void Fish::DropEngine() {
+    DropEngineTable();
     bucket_tuned.clear(); /* the measured delays belonged to that engine */
     DropResident(); /* the resident bf16 copies are keyed by the old tensors' addresses too */
 }
@@ -643,7 +646,11 @@ int Fish::RunSteps(int pos, int n, bool use_graph) {
                 if (!bucket_tuned[b]) {
                     bucket_tuned[b] = 1;
                     const int trc = kf_engine_tune(ctx, engine, ToX(x), d_state, pos_bound(), engine_autotune, nullptr, nullptr);
-                    if (trc < 0) return trc;
+                    if (trc < 0) { /* a tuning problem (a poll timed out while a delay was being tried) is not a decode error: the built-in delays stay (kf_engine_tune restored
+                                      them), the latched error word is cleared, and the step below runs */
+                        if (kf_engine_reset(ctx, engine) != KF_OK) return trc;
+                        engine_autotune = 0;
+                    }
                 }
             }
             const int rc = kf_engine_steps_head(ctx, engine, ToX(x), d_state, pos_bound(), m);
@@ -937,15 +944,14 @@ int kfh_set_hot(void* h, int layer, const int32_t* h_hot, int n) {
     Fish* f = reinterpret_cast<Fish*>(h);
     if (layer < 0 || layer >= f->config.nLayer) return KF_INVALID_ARGS;
     FFN* m = f->ffn[layer].get();
-    for (auto& g : f->graphs)
-        if (g) kf_graph_destroy(g), g = nullptr;
-    f->DropEngine(); /* the engine's layer table holds the masks: rebuilt on the next step */
+    if (h_hot && n != f->config.n_ff) return KF_INVALID_ARGS; /* arguments first: a rejected call changes nothing */
+    f->DropEngineTable(); /* the engine's layer table (and the captured graphs) hold the masks: rebuilt on the next step; the resident bf16 copies and the measured delays do not
+                             depend on them and stay */
     if (!h_hot) {
         if (m->n_hot >= 0) f->masked_layers--;
         m->n_hot = -1, m->hot_rows.reset(), m->hot_mask.reset();
         return KF_OK;
     }
-    if (n != f->config.n_ff) return KF_INVALID_ARGS;
     hGTensor mask = GT(f->ctx, "hot", typNUMBER::I32, n), rows = GT(f->ctx, "hot_rows", typNUMBER::I32, n + 4);
     if (!mask || !rows) return KF_OUTOF_GPUMEMORY;
     KF_TRY(kf_h2d(f->ctx, mask->data, h_hot, (size_t)n * 4));
@@ -1023,6 +1029,11 @@ int kfh_engine_tune(void* h, int passes, float* us2) {
     return rc;
 }
 // resident bf16 copies for long prompts: on (default) / off, and the byte budget above which a model goes without (0 keeps the current one); takes effect at the next Prefill
+/* after an IN-PLACE change of weight data this Fish was given as device pointers: every derived copy (resident bf16 copies, the engine's tables, captured graphs) is dropped */
+int kfh_weights_changed(void* h) {
+    reinterpret_cast<Fish*>(h)->DropEngine();
+    return KF_OK;
+}
 int kfh_set_prefill_resident(void* h, int on, size_t max_bytes) {
     Fish* f = reinterpret_cast<Fish*>(h);
     f->DropResident();

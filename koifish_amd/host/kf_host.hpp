@@ -212,8 +212,11 @@ struct Fish {
     void* lin_scratch = nullptr;  // kf_set_scratch: workspace of the dequantise-then-multiply storages (AutoAWQ, row forms), sized when weights are set
     size_t lin_scratch_bytes = 0;
     void* deq_arena = nullptr;  // kf_set_dequant_arena: resident bf16 copies of the layers' quantised matrices for long prompts (EnsureResident)
-    size_t deq_arena_bytes = 0, resident_max_bytes = (size_t)96 << 30; /* a third of the part's 288 GB */
-    int prefill_resident = 1;
+    size_t deq_arena_bytes = 0, resident_max_bytes = (size_t)16 << 30;
+    // OFF by default: the copies are keyed by the blobs' addresses, so a caller that hands weights over as device pointers (kfh_set_weight is_device = 1) and later
+    // re-quantises or updates them IN PLACE would prefill on stale bf16 copies while the decode reads the live data.  kfh_set_prefill_resident opts in and takes that promise
+    // ("the quantised data does not change under me"); kfh_weights_changed drops the copies (and the engine's table) after an in-place update.
+    int prefill_resident = 0;
     bool resident_tried = false;
     int EnsureResident(int PC);
     void DropResident();
@@ -226,11 +229,13 @@ struct Fish {
     bool engine_head = false;   // ... and runs the final norm, the (bf16) LM head and the greedy pick as trailing phases of its launch
     int masked_layers = 0;      // layers with a hot-row mask (kfh_set_hot): the engine walks dense FFNs only
     int EnsureEngine();
+    void DropEngineTable();     // the engine's device table and the captured graphs only (a hot-row mask changed)
     void DropEngine();          // weights / norms / caches changed: the engine's device table and the captured graphs hold stale pointers
     int EngineCheck();          // synchronises; a timed-out hand-off is reported ONCE (KF_INTERNAL_ERR), the engine reset so that later steps run again
     int engine_steps = 0;  // steps enqueued (or captured) through the engine
     std::string engine_why;  // why the engine does not serve this model (kf_engine_served), "" when it does
-    int engine_autotune = 1;  // > 0: passes of kf_engine_tune run once per position bucket, at the first step inside it (kfh_set_engine_autotune)
+    int engine_autotune = 0;  // > 0: passes of kf_engine_tune run once per position bucket, at the first step inside it (kfh_set_engine_autotune; off in the library: ~0.2 s of
+                              // host-blocking launches inside RunSteps -- bench.py opts in).  A failed tune is never fatal: the defaults stay, the engine is reset, the decode goes on.
     std::vector<unsigned char> bucket_tuned;
     KVCache cache;
     MemBuffer gBUFF;

@@ -174,6 +174,7 @@ def load():
         hip.kf_dequant_arena_used.argtypes, hip.kf_dequant_arena_used.restype = [C.c_void_p], C.c_size_t
         hip.kf_resident_scratch_bytes.argtypes, hip.kf_resident_scratch_bytes.restype = [], C.c_size_t
         host.kfh_set_prefill_resident.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        host.kfh_weights_changed.argtypes = [C.c_void_p]
         host.kfh_resident_bytes.argtypes, host.kfh_resident_bytes.restype = [C.c_void_p], C.c_size_t
         hip.kf_engine_workspace_bytes.argtypes, hip.kf_engine_workspace_bytes.restype = [C.c_void_p], C.c_size_t
         hip.kf_engine_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]

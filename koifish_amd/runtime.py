@@ -475,8 +475,14 @@ class Qwen3:
         """> 0: the hand-off delays are measured once per position bucket, at the first multi-step launch inside it (passes of kf_engine_tune)"""
         L.check(self.host.kfh_set_engine_autotune(self.h, int(passes)), "kfh_set_engine_autotune")
 
+    def weights_changed(self):
+        """after an IN-PLACE update of weight data handed over as device pointers: drops the resident bf16 copies, the engine's tables and the captured graphs"""
+        L.check(self.host.kfh_weights_changed(self.h), "kfh_weights_changed")
+
     def set_prefill_resident(self, on, max_bytes=0):
-        """bf16 copies of the layers' quantised matrices kept in HBM for long prompts (kf_set_dequant_arena; default on, budget 96 GiB): takes effect at the next prefill"""
+        """bf16 copies of the layers' quantised matrices kept in HBM for long prompts (kf_set_dequant_arena): takes effect at the next prefill.  OFF by default; turning it
+        on is the caller's promise that weight data given as device pointers is not changed in place afterwards (or that weights_changed() is called when it is): the
+        copies are keyed by the blobs' addresses.  max_bytes: budget (default 16 GiB; Qwen3-32B needs 62 GB)."""
         L.check(self.host.kfh_set_prefill_resident(self.h, int(bool(on)), int(max_bytes)), "kfh_set_prefill_resident")
 
     def resident_bytes(self):

@@ -332,3 +332,96 @@ def test_qwen3_toy_training_step_vs_autograd(ctx):
         rms_tol = 2.0 ** -6 if name.endswith(("qn", "kn")) else 2.0 ** -7
         assert mx <= 2.0 ** -5 and rms_ <= rms_tol, "%s: max %.4f rms %.4f of scale" % (name, mx, rms_)
     print("largest gradient deviations (max, rms, tensor):", sorted(worst, reverse=True)[:3])
+
+
+def _ref_loss_fp64(Cn, H, NL, V, Bn, T, P, ids, tgt):
+    """the toy GPT-2 in torch fp64 on given (already dequantised) parameters -> mean cross entropy"""
+    F = torch.nn.functional
+    hd, N = Cn // H, Bn * T
+    pos = np.tile(np.arange(T), Bn)
+    xt = P["wte"][torch.from_numpy(ids).long()] + P["wpe"][torch.from_numpy(pos).long()]
+    for li in range(NL):
+        g_ = lambda nm: P["%d.%s" % (li, nm)]
+        h1 = F.layer_norm(xt, (Cn,), g_("ln1.w"), g_("ln1.b"), 1e-5)
+        qkv = h1 @ g_("qkv.w").T + g_("qkv.b")
+        sp4 = lambda t_: t_.reshape(Bn, T, H, hd).transpose(1, 2)
+        at = F.scaled_dot_product_attention(sp4(qkv[:, :Cn]), sp4(qkv[:, Cn:2 * Cn]), sp4(qkv[:, 2 * Cn:]), is_causal=True).transpose(1, 2).reshape(N, Cn)
+        x2 = xt + at @ g_("proj.w").T + g_("proj.b")
+        h2 = F.layer_norm(x2, (Cn,), g_("ln2.w"), g_("ln2.b"), 1e-5)
+        xt = x2 + F.gelu(h2 @ g_("fc.w").T + g_("fc.b"), approximate="tanh") @ g_("proj2.w").T + g_("proj2.b")
+    hft = F.layer_norm(xt, (Cn,), P["lnf.w"], P["lnf.b"], 1e-5)
+    return F.cross_entropy((hft @ P["wte"].T)[:, :V], torch.from_numpy(tgt).long())
+
+
+def test_gpt2_two_consecutive_steps_with_update(ctx):
+    """BASELINE config 3 as ONE loop (koifish_amd/train_step.py, the code bench.py's config3 leg times at full size): forward + loss -> backward into per-tensor gradient
+    buffers -> kf_adamw on the model's own bf16 masters and moments (seeded stochastic rounding, Optimizer.cu:135-160) -> kf_quantize of every matrix back into its f8 / 4-bit
+    blob (T.cu:105-175) -- twice, on the same batch, so that the second step's loss depends on the first step's update.  Checked per step:
+      * the loss against torch fp64 on the oracle-dequantised blobs the step actually read (2^-7 relative),
+      * the update: every master, both moments and the zeroed gradient equal the ORACLE's CU_adamw restatement applied to the device's own gradients, bit for bit,
+      * the re-quantisation: every blob equals the oracle's quantiser applied to the updated master, byte for byte,
+    and the loss falls from step 1 to step 2 to step 3 (the parameters really moved)."""
+    from koifish_amd.train_step import GPT2Step, MATS
+    Cn, H, NL, V, Vp, Bn, T = 128, 2, 2, 250, 256, 2, 64
+    N = Bn * T
+    rng = np.random.default_rng(303)
+    bf = lambda a: torch.from_numpy(O.f32_to_bf16(a.astype(np.float32)).view(np.int16)).view(torch.bfloat16)
+    mk = lambda *s, std=0.08: bf(rng.normal(0, std, size=s))
+    lnw = lambda: bf(1 + rng.normal(0, 0.1, Cn))
+    shapes = dict(qkv=(3 * Cn, Cn), proj=(Cn, Cn), fc=(4 * Cn, Cn), proj2=(Cn, 4 * Cn))
+    wte = torch.zeros(Vp, Cn, dtype=torch.bfloat16)
+    wte[:V] = mk(V, Cn, std=0.2)
+    masters = dict(wte=wte, wpe=mk(T, Cn, std=0.05), lnf=(lnw(), mk(Cn)),
+                   blocks=[dict({k: (mk(*shapes[k]), mk(shapes[k][0])) for k in MATS}, ln=(lnw(), mk(Cn), lnw(), mk(Cn))) for _ in range(NL)])
+    st = GPT2Step(ctx, Cn, H, NL, V, Vp, Bn, T, masters=masters)
+    ids = rng.integers(0, V, N).astype(np.int32)
+    tgt = rng.integers(0, V, N).astype(np.int32)
+    d_ids, d_tgt = torch.from_numpy(ids).to(ctx.device), torch.from_numpy(tgt).to(ctx.device)
+    hp = dict(lr=2e-3, beta1=0.9, beta2=0.95, eps=1e-8, wd=0.1, seed=99)
+    f64 = lambda a_u16: torch.tensor(O.bf16_to_f32(a_u16).astype(np.float64))
+    TYPE_OF = {L.F8E5M2: L.F8E5M2, L.Q4: L.Q4}
+
+    def params_as_read():
+        """what the step's forward multiplies: the dequantised blobs (oracle dequantiser on the device's bytes) and the bf16 tensors"""
+        P = {}
+        for e in st.params:
+            nm = e["name"]
+            key = nm.replace("h", "", 1) if nm.startswith("h") and nm[1].isdigit() else nm
+            if e["type"] in TYPE_OF:
+                ne0, ne1 = e["p"].shape
+                P[key] = f64(u16(ctx.dequant(e["blob"]))).reshape(ne0, ne1)   # kf_dequant is itself bit-exact against the oracle (tests/test_gpu_ops.py)
+            else:
+                P[key] = f64(u16(e["p"])).reshape(tuple(e["p"].shape))
+        return P
+    losses = []
+    for step in range(3):
+        P = params_as_read()
+        ref = float(_ref_loss_fp64(Cn, H, NL, V, Bn, T, P, ids, tgt))
+        st.forward(d_ids, d_tgt)
+        ctx.sync()
+        dev_loss = float(st.losses.mean())
+        assert abs(dev_loss - ref) <= 2.0 ** -7 * ref, "step %d: loss %.5f vs fp64 %.5f" % (step, dev_loss, ref)
+        losses.append(dev_loss)
+        if step == 2:
+            break
+        st.backward()
+        ctx.sync()
+        before = [(u16(e["p"]).copy(), u16(e["g"]).copy(), u16(e["m"]).copy(), u16(e["v"]).copy()) for e in st.params]
+        assert all(g.any() for _, g, _, _ in before), "every tensor received a gradient"
+        st.update(**hp)
+        ctx.sync()
+        t = st.t
+        b1c, b2c = 1.0 - hp["beta1"] ** t, 1.0 - hp["beta2"] ** t
+        for i, (e, (p0, g0, m0, v0)) in enumerate(zip(st.params, before)):
+            p, g, m, v = (a.reshape(-1).copy() for a in (p0, g0, m0, v0))
+            assert O.adamw(p, g, m, v, hp["lr"], hp["beta1"], hp["beta2"], b1c, b2c, hp["eps"], hp["wd"] if e["wd"] else 0.0, 1.0, (hp["seed"] + 7919 * t + i) & 0xFFFFFFFF) == 0
+            assert np.array_equal(u16(e["p"]).reshape(-1), p), "step %d: master %s differs from the oracle's AdamW" % (step, e["name"])
+            assert np.array_equal(u16(e["m"]).reshape(-1), m) and np.array_equal(u16(e["v"]).reshape(-1), v), e["name"]
+            assert not u16(e["g"]).any()
+            assert not np.array_equal(p, p0.reshape(-1)), "%s did not move" % e["name"]
+            if e["type"] in TYPE_OF:   # the blob the next forward reads = the oracle's quantiser on the updated master
+                ne0, ne1 = e["p"].shape
+                ow = O.quantize(u16(e["p"]).reshape(ne0, ne1), ne0, ne1, e["type"])
+                assert np.array_equal(e["blob"].blob.cpu().numpy(), np.frombuffer(ow.blob(), dtype=np.uint8)), "step %d: blob of %s" % (step, e["name"])
+    assert losses[1] < losses[0] and losses[2] < losses[1], losses
+    print("toy losses over three forwards on one batch:", ["%.4f" % v for v in losses])
