@@ -62,8 +62,9 @@ struct XArgs {
 
 // error word bits: 1 x, 2 q|k|v, 4 partials, 8 workgroups per XCD != 32, 16 pick, 32 token granule, 64 position beyond the cache, 128 ao, 256 xB, 512 act, 1024 head x
 
-template <int FMT_, int GQ_, int HD_, int NWV_, int DIM_, int QD_, int KVD_, int FFN_, int DEPTH_, bool DBG_, int WPC_ = 1>
+template <int FMT_, int GQ_, int HD_, int NWV_, int DIM_, int QD_, int KVD_, int FFN_, int DEPTH_, bool DBG_, int WPC_ = 1, int AU_ = 2>
 struct XCfg {
+    static constexpr int AU = AU_; /* key tiles per attention batch and wave */
     static constexpr int WPC = WPC_; /* decoders per XCD = workgroups per CU: 2 lets one decoder's hand-off waits run under the other's arithmetic (the hardware interleaves the two workgroups' waves) */
     static constexpr int FMT = FMT_, GQ = GQ_, HD = HD_, NWV = NWV_, NCW = NWV_ - 1, DIM = DIM_, QD = QD_, KVD = KVD_, FFN = FFN_, DEPTH = DEPTH_, NWG = XE_NWG;
     static constexpr bool DBG = DBG_;
@@ -295,7 +296,7 @@ __device__ __forceinline__ void xe_publish(const XLds& L, int phase, uint32_t* d
 // ---- attention: the workgroup's key slice of its kv-head, streamed by the NCW compute waves (two batches of U tiles in flight per lane)
 template <class C>
 struct XAttn {
-    static constexpr int U = 2;
+    static constexpr int U = C::AU;
     u32x4 kk[2][U], vv[2][U];
     uint16_t nw0, nw1;
     float rc, rs;
@@ -955,13 +956,16 @@ struct XEngineHost {
 static int xe_shape_class(int GQ, int hd, int dim, int q_dim, int ffn) {
     if (GQ == 2 && hd == 128 && dim == 1024 && q_dim == 2048 && ffn == 3072) return 1; /* Qwen3-0.6B (BASELINE config 2) */
     if (GQ == 2 && hd == 64 && dim == 256 && q_dim == 256 && ffn == 512) return 2;     /* the small parity-test shape */
+    if (GQ == 2 && hd == 128 && dim == 2048 && q_dim == 2048 && ffn == 6144) return 3;  /* Qwen3-1.7B: the streaming phases do not care how many blocks a lane walks */
     return 0;
 }
-template <int NWV, int DEPTH, bool DBG, int WPC>
-using XC1 = XCfg<FMT_Q4P, 2, 128, NWV, 1024, 2048, 1024, 3072, DEPTH, DBG, WPC>;
-template <int NWV, int DEPTH, bool DBG, int WPC>
-using XC2 = XCfg<FMT_Q4P, 2, 64, NWV, 256, 256, 128, 512, DEPTH, DBG, WPC>;
-static int xe_loc_dw(int shape_class) { return shape_class == 1 ? XC1<9, 8, false, 1>::loc_dw : XC2<9, 8, false, 1>::loc_dw; }
+template <int NWV, int DEPTH, bool DBG, int WPC, int AU = 2>
+using XC3 = XCfg<FMT_Q4P, 2, 128, NWV, 2048, 2048, 1024, 6144, DEPTH, DBG, WPC, AU>;
+template <int NWV, int DEPTH, bool DBG, int WPC, int AU = 2>
+using XC1 = XCfg<FMT_Q4P, 2, 128, NWV, 1024, 2048, 1024, 3072, DEPTH, DBG, WPC, AU>;
+template <int NWV, int DEPTH, bool DBG, int WPC, int AU = 2>
+using XC2 = XCfg<FMT_Q4P, 2, 64, NWV, 256, 256, 128, 512, DEPTH, DBG, WPC, AU>;
+static int xe_loc_dw(int shape_class) { return shape_class == 1 ? XC1<9, 8, false, 1>::loc_dw : (shape_class == 3 ? XC3<9, 8, false, 1>::loc_dw : XC2<9, 8, false, 1>::loc_dw); }
 
 size_t xengine_ws_bytes(const kf_engine_desc* d) {
     const int hd = d->head_dim, GQ = d->n_kv > 0 ? d->n_head / d->n_kv : 1;
@@ -994,7 +998,7 @@ int xengine_build(const kf_engine_desc* d, int n_seq, long long kv_seq_stride, v
     if ((hd != 64 && hd != 128) || d->n_kv <= 0 || d->n_head % d->n_kv != 0) return KF_UNSUPPORTED_DATATYPE;
     const int GQ = d->n_head / d->n_kv, q_dim = d->n_head * hd, kv_dim = d->n_kv * hd;
     const int sc = xe_shape_class(GQ, hd, d->dim, q_dim, d->ffn);
-    *why = "model shape not instantiated for the XCD-confined engine: built for Qwen3-0.6B (dim 1024, 16/8 heads of 128, ffn 3072) and the 256-wide test shape";
+    *why = "model shape not instantiated for the XCD-confined engine: built for Qwen3-0.6B (dim 1024, 16/8 heads of 128, ffn 3072), Qwen3-1.7B (dim 2048, same heads, ffn 6144) and the 256-wide test shape";
     if (!sc) return KF_UNSUPPORTED_DATATYPE;
     if (!dry && (ws_bytes < xengine_ws_bytes(d) || ((uintptr_t)ws & 255) != 0)) {
         *why = "workspace too small or not 256-byte aligned";
@@ -1042,7 +1046,7 @@ int xengine_build(const kf_engine_desc* d, int n_seq, long long kv_seq_stride, v
     memset(E, 0, sizeof(*E));
     XArgs& a = E->args;
     E->shape_class = sc, E->fmt = FMT_Q4P, E->dim = d->dim, E->q_dim = q_dim, E->kv_dim = kv_dim, E->ffn = d->ffn, E->n_head = d->n_head, E->n_kv = d->n_kv, E->hd = hd;
-    E->nwv = 9, E->depth = 8;
+    E->nwv = 12, E->depth = 6; /* 11 compute waves + the poller: three waves per SIMD (measured best: 1.89 ms per step of eight sequences against 1.92 with 9 x 8) */
     a.n_layer = d->n_layer, a.n_seq = n_seq, a.kv_seq_stride = kv_seq_stride, a.kv_stride = d->kv_stride, a.max_seq = d->max_seq;
     a.eps = d->rms_eps, a.qk_eps = d->qk_eps, a.rope_table = d->rope_table;
     for (int j = 0; j < 7; j++) a.qbias[j] = qbias[j];
@@ -1091,29 +1095,28 @@ static int xengine_go(XEngineHost* E, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
 #ifndef XE_VARIANTS
-#define XE_VARIANTS 1 /* the tuning instantiations (waves per workgroup x ring depth) beside the defaults */
+#define XE_VARIANTS 1 /* the tuning instantiations (waves per workgroup x ring depth) beside the defaults.  Measured and dropped (ms per step of eight sequences at 2 k keys, default
+                         12 x 6: 1.89): 13 x 6 2.22, 16 x 4 2.17 (128 registers: spills), four key tiles per attention batch 2.29 - 2.37 (spills) */
 #endif
 // n_seq <= 8: one decoder per XCD, 9 waves (8 compute + the poller; 168 registers); more: two per XCD, two workgroups of 8 waves per CU (128 registers)
-template <template <int, int, bool, int> class XC>
+template <template <int, int, bool, int, int> class XC>
 static int xengine_go_shape(XEngineHost* E, hipStream_t st) {
     const bool two = E->args.n_seq > XE_NXCD;
 #ifndef XE_ONLY_DEFAULT
     const bool dbg = E->args.dbg != nullptr;
-    if (dbg) return two ? xengine_go<XC<8, 8, true, 2>>(E, st) : xengine_go<XC<9, 8, true, 1>>(E, st);
+    if (dbg) return two ? xengine_go<XC<8, 8, true, 2, 2>>(E, st) : xengine_go<XC<9, 8, true, 1, 2>>(E, st);
 #endif
 #if XE_VARIANTS && !defined(XE_ONLY_DEFAULT)
     if (!two) {
-        if (E->nwv == 13 && E->depth == 6) return xengine_go<XC<13, 6, false, 1>>(E, st);
-        if (E->nwv == 16 && E->depth == 4) return xengine_go<XC<16, 4, false, 1>>(E, st);
-        if (E->nwv == 8 && E->depth == 8) return xengine_go<XC<8, 8, false, 1>>(E, st);
-        if (E->nwv == 12 && E->depth == 6) return xengine_go<XC<12, 6, false, 1>>(E, st);
-        if (E->nwv == 12 && E->depth == 8) return xengine_go<XC<12, 8, false, 1>>(E, st);
+        if (E->nwv == 8 && E->depth == 8) return xengine_go<XC<8, 8, false, 1, 2>>(E, st);
+        if (E->nwv == 12 && E->depth == 6) return xengine_go<XC<12, 6, false, 1, 2>>(E, st);
+        if (E->nwv == 12 && E->depth == 8) return xengine_go<XC<12, 8, false, 1, 2>>(E, st);
+        if (E->nwv == 9 && E->depth == 6) return xengine_go<XC<9, 6, false, 1, 2>>(E, st);
     } else {
-        if (E->nwv == 8 && E->depth == 6) return xengine_go<XC<8, 6, false, 2>>(E, st);
-        if (E->nwv == 8 && E->depth == 4) return xengine_go<XC<8, 4, false, 2>>(E, st);
     }
 #endif
-    return two ? xengine_go<XC<8, 8, false, 2>>(E, st) : xengine_go<XC<9, 8, false, 1>>(E, st);
+    if (!two && E->nwv == 12) return xengine_go<XC<12, 6, false, 1, 2>>(E, st);
+    return two ? xengine_go<XC<8, 8, false, 2, 2>>(E, st) : xengine_go<XC<9, 8, false, 1, 2>>(E, st);
 }
 // n_steps decode steps of every sequence in ONE launch; with_head: 0 layers only (x_out), 1 + logits, 2 + greedy pick and state update (needed for n_steps > 1)
 int xengine_steps(XEngineHost* E, hipStream_t st, int32_t* d_state, uint16_t* x_out, int with_head, int n_steps) {
@@ -1123,7 +1126,11 @@ int xengine_steps(XEngineHost* E, hipStream_t st, int32_t* d_state, uint16_t* x_
     XArgs save = a;
     a.d_state = d_state, a.x_out = x_out, a.n_steps = n_steps, a.pick = with_head == 2 ? 1 : 0;
     if (!with_head) a.head_w = nullptr;
-    const int rc = E->shape_class == 1 ? xengine_go_shape<XC1>(E, st) : xengine_go_shape<XC2>(E, st);
+    int rc;
+    if (E->shape_class == 3) /* the default instantiations only (no tuning variants, no stamps) */
+        rc = a.n_seq > XE_NXCD ? xengine_go<XC3<8, 8, false, 2>>(E, st) : xengine_go<XC3<12, 6, false, 1>>(E, st);
+    else
+        rc = E->shape_class == 1 ? xengine_go_shape<XC1>(E, st) : xengine_go_shape<XC2>(E, st);
     a.head_w = save.head_w;
     return rc;
 }

@@ -202,9 +202,38 @@ def test_refusals():
     assert "canonical" in str(e.value)
     xr.close()
     m.close()
-    cfg2 = dict(synth.CONFIGS["qwen3-1.7b"], n_layer=2, vocab=4096, max_seq=128)
+    cfg2 = dict(synth.CONFIGS["qwen3-1.7b"], n_layer=2, vocab=4096, max_seq=128, ffn=4096)   # no such shape
     m = synth.build_from_raw(cfg2, synth.raw_weights_numpy(cfg2, 2, w_std=0.05), L.Q4, L.BF16)
     with pytest.raises(L.KFError) as e:
         XcdReplicas(m, 8)
     assert "not instantiated" in str(e.value)
+    m.close()
+
+
+def test_qwen3_1p7b_shape_equals_the_oracle(canon):
+    """three layers of the Qwen3-1.7B shape (dim 2048, ffn 6144; vocab 4096 so that the oracle steps in milliseconds) through the XCD-confined engines: eight sequences, ids at
+    every position, last logits and K / V rows against the oracle"""
+    cfg = dict(synth.CONFIGS["qwen3-1.7b"], n_layer=3, vocab=4096, max_seq=160)
+    raw = synth.raw_weights_numpy(cfg, 1717, w_std=0.05)
+    m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
+    m.set_canonical(True)
+    n_seq, n_steps = 8, 100
+    xr = XcdReplicas(m, n_seq)
+    forced = []
+    for s in range(n_seq):
+        f = np.full(160, -1, dtype=np.int32)
+        f[:10 + s] = prompt_ids(cfg, 10 + s, seed=40 + s)
+        forced.append(f)
+        xr.set_forced(s, f)
+        xr.set_state(s, int(f[0]), 0)
+    xr.run_steps(n_steps)
+    m.sync()
+    xr.check()
+    for s in (0, 3, 7):
+        o_ids, o_logits, ok, ov = _oracle_run(cfg, raw, forced[s], n_steps)
+        assert xr.tokens_out(s, n_steps).tolist() == o_ids, "sequence %d" % s
+        assert np.array_equal(xr.logits(s), o_logits)
+        gk, gv = xr.kv_to_host(s)
+        assert np.array_equal(gk[:, :n_steps], ok[:, :n_steps]) and np.array_equal(gv[:, :n_steps], ov[:, :n_steps])
+    xr.close()
     m.close()
