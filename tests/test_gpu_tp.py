@@ -228,3 +228,65 @@ def test_native_tp8_32b_slice_at_depth_vs_the_oracle_bit_for_bit(ctx):
         O.set_order(O.ORDER_DOT16)
     om.close()
     nt.close()
+
+
+def test_native_tp8_full_depth_qwen3_32b_vs_the_oracle(ctx):
+    """north_star's second target at FULL DEPTH (missing 5): all 64 layers of the Qwen3-32B shape (dim 5120, 64 / 8 heads of 128, ffn 25600, the 151936-row
+    vocabulary: 16.6 GB of 4-bit layers + a 1.56 GB head), tensor parallel TP = 8 as eight virtual ranks on this GPU (the ranks' kernels and the kernel-side exchange; no
+    xGMI), decoding a 6-token prompt and then 6 free-running greedy ids -- against the oracle's tensor-parallel emulation (row shards as they are, column shards as fp32
+    partials summed in rank order) in the canonical order: every id and the last position's 151936 logits bit for bit."""
+    cfg = dict(synth.CONFIGS["qwen3-32b"], max_seq=64)
+    g = torch.Generator(device=ctx.device)
+    g.manual_seed(32)
+
+    def mat(r, c, std=0.05):
+        return (torch.randn(r, c, generator=g, device=ctx.device, dtype=torch.float32) * std).to(torch.bfloat16)
+
+    def nrm(n):
+        return (1.0 + 0.01 * torch.randn(n, generator=g, device=ctx.device, dtype=torch.float32)).to(torch.bfloat16)
+    w, norms = {}, {}
+    w[(-1, 0)] = ctx.quantize(mat(cfg["vocab"], cfg["dim"]), L.BF16)
+    w[(-1, 1)] = ctx.quantize(mat(cfg["vocab"], cfg["dim"], std=0.1), L.BF16)   # untied head (the 32B card)
+    norms[(-1, 0)] = nrm(cfg["dim"])
+    for li in range(cfg["n_layer"]):
+        for si, s in enumerate(synth.SLOTS):
+            w[(li, si)] = ctx.quantize(mat(*synth.SHAPES[s](cfg), std=0.03), L.Q4)
+        norms[(li, 0)], norms[(li, 1)], norms[(li, 2)], norms[(li, 3)] = nrm(cfg["dim"]), nrm(cfg["dim"]), nrm(128), nrm(128)
+    nt = TP.NativeTP(cfg, w, norms, 8, ctx)
+    for rk in nt.ranks:
+        rk.set_canonical(True)
+    n_prompt, n_new = 6, 6
+    forced = np.full(cfg["max_seq"], -1, dtype=np.int32)
+    forced[:n_prompt] = np.random.default_rng(64).integers(0, cfg["vocab"], size=n_prompt)
+    nt.set_forced(forced)
+    nt.set_state(int(forced[0]), 0)
+    n = n_prompt + n_new - 1
+    nt.run_steps(0, n, use_graph=True)
+    nt.check()
+    toks = [m.tokens_out(n) for m in nt.ranks]
+    for t in toks[1:]:
+        assert np.array_equal(t, toks[0])
+    g_logits = nt.logits()
+
+    class Dev:
+        pass
+    m = Dev()
+    m.cfg, m.weights, m._norms = cfg, w, norms
+    om = O.from_device_model(m, attn_mode=O.ATTN_CANON)
+    O.lib().kfo_qwen3_set_tp(om.h, 8)
+    om.prepare_fast()
+    O.set_order(O.ORDER_CANON)
+    try:
+        tok, o_ids, o_logits = int(forced[0]), [], None
+        for pos in range(n):
+            if forced[pos] >= 0:
+                tok = int(forced[pos])
+            o_id, o_logits, _ = om.decode(tok, pos)
+            o_ids.append(int(o_id))
+            tok = int(o_id)
+    finally:
+        O.set_order(O.ORDER_DOT16)
+    assert toks[0].tolist() == o_ids, (toks[0].tolist(), o_ids)
+    assert np.array_equal(g_logits, o_logits), "%d of %d logits differ" % (int((g_logits != o_logits).sum()), g_logits.size)
+    om.close()
+    nt.close()
