@@ -58,6 +58,7 @@ struct XArgs {
     int* ws;         /* [0] epoch, [1] error word, [16 + 32 x] ticket of XCD x, [17 + 32 x] its workgroups that have left */
     unsigned long long* dbg; /* diagnostic instantiation: [step][layer][16] stamps of (sequence dbg_seq, workgroup rank dbg_wg) */
     int dbg_seq, dbg_wg, dbg_steps;
+    int stagger_us; /* two decoders per XCD: microseconds the second one starts behind the first */
 };
 
 // error word bits: 1 x, 2 q|k|v, 4 partials, 8 workgroups per XCD != 32, 16 pick, 32 token granule, 64 position beyond the cache, 128 ao, 256 xB, 512 act, 1024 head x
@@ -201,7 +202,7 @@ __device__ __forceinline__ void xe_fill(const XPhase& P, int cw, int lane, XRing
 }
 // one block's 32 products into the lane's chain pair: BlockDotF<FMT> (kf_gemv_blocks.h) on the fp32 activation chunks in LDS, chunk j of block column c at xf[j * XS + c]
 // (XS: the chunk stride, a compile-time constant of the model shape -- the same for every phase, so the eight reads of a block are one address and immediate offsets)
-template <int FMT, int XS>
+template <int FMT, int XS, bool LOW>
 __device__ __forceinline__ f32x2_t xe_block(u32x4 w, uint16_t st16, uint16_t ze16, float qb, const f32x4* xc, int lane, f32x2_t acc) {
     const float step = bf2f(st16), zero = bf2f(ze16), nb = -(qb * step);
     const uint32_t D[4] = {w.w, w.z, w.y, w.x};
@@ -216,7 +217,11 @@ __device__ __forceinline__ f32x2_t xe_block(u32x4 w, uint16_t st16, uint16_t ze1
         t.tl[0] = quad_bcast<0>(tlm), t.tl[1] = quad_bcast<1>(tlm), t.tl[2] = quad_bcast<2>(tlm), t.tl[3] = quad_bcast<3>(tlm);
         t.th[0] = quad_bcast<0>(thm), t.th[1] = quad_bcast<1>(thm), t.th[2] = quad_bcast<2>(thm), t.th[3] = quad_bcast<3>(thm);
 #pragma unroll
-        for (int i = 0; i < 4; i++) acc = perm_fma_dword(D[i], xc[(2 * i) * XS], xc[(2 * i + 1) * XS], t, acc);
+        for (int i = 0; i < 4; i++) {
+            acc = perm_fma_dword(D[i], xc[(2 * i) * XS], xc[(2 * i + 1) * XS], t, acc);
+            if constexpr (LOW) __builtin_amdgcn_sched_barrier(0); /* two workgroups per CU (128 registers): the next dword's activation chunks are read when this one's products are done, not
+                                                                     all eight chunks (32 registers) at the top of the block */
+        }
     } else {
         const float step16 = step * 0.0625f;
 #pragma unroll
@@ -253,11 +258,11 @@ __device__ __forceinline__ void xe_mv_run(const XPhase& P, const XPhase& NX, boo
                 const float qb_a = P.qb, qb_b = P.qb2;
                 f32x2_t o;
                 if constexpr (C::EXACT) { /* whole rows, whole iterations: nothing to mask */
-                    o = xe_block<C::FMT, XS>(R.w[d], R.st[d], R.ze[d], second ? qb_b : qb_a, xf + colr, lane, in);
+                    o = xe_block<C::FMT, XS, (C::WPC > 1)>(R.w[d], R.st[d], R.ze[d], second ? qb_b : qb_a, xf + colr, lane, in);
                 } else {
                     const bool ok = row < P.Mj && colr < P.nBlk;
                     const int col = colr < P.nBlk ? colr : P.nBlk - 1;
-                    o = acc_pick(ok, xe_block<C::FMT, XS>(R.w[d], R.st[d], R.ze[d], second ? qb_b : qb_a, xf + col, lane, in), in);
+                    o = acc_pick(ok, xe_block<C::FMT, XS, (C::WPC > 1)>(R.w[d], R.st[d], R.ze[d], second ? qb_b : qb_a, xf + col, lane, in), in);
                 }
                 if (second) acc2 = o;
                 else acc = o;
@@ -833,7 +838,7 @@ __device__ __forceinline__ void xe_head_main(const XArgs& a, const XLds& L, cons
 }
 
 template <class C>
-__global__ void __launch_bounds__(C::NWV * 64, ((C::NWV + 3) / 4) * C::WPC /* waves per SIMD: the register budget that lets WPC workgroups share a CU */) xengine_kernel(const XArgs a) {
+__global__ void __launch_bounds__(C::NWV * 64, (C::NWV * C::WPC + 3) / 4 /* waves per SIMD: the register budget that lets WPC workgroups share a CU */) xengine_kernel(const XArgs a) {
     constexpr int hd = C::HD, GQ = C::GQ, NWV = C::NWV, NCW = C::NCW;
     using P1 = typename C::SH::P1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -892,6 +897,11 @@ __global__ void __launch_bounds__(C::NWV * 64, ((C::NWV + 3) / 4) * C::WPC /* wa
         }
     };
     const int epoch0 = a.ws[0];
+    if (C::WPC == 2 && S.seq >= XE_NXCD && a.stagger_us > 0) { /* the second decoder of an XCD starts late: the two then stand in different phases, and one's hand-off waits and K / V streaming run
+                                                                  under the other's mat-vec arithmetic (started together they stay in lockstep: same phase, same wait, no overlap) */
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime() + (unsigned long long)a.stagger_us * 100ull;
+        while (__builtin_amdgcn_s_memrealtime() < t1) __builtin_amdgcn_s_sleep(8);
+    }
     if (S.seq >= a.n_seq) { /* a decoder without a sequence: its workgroups leave */
         leave();
         return;
@@ -1104,7 +1114,7 @@ static int xengine_go_shape(XEngineHost* E, hipStream_t st) {
     const bool two = E->args.n_seq > XE_NXCD;
 #ifndef XE_ONLY_DEFAULT
     const bool dbg = E->args.dbg != nullptr;
-    if (dbg) return two ? xengine_go<XC<8, 8, true, 2, 2>>(E, st) : xengine_go<XC<9, 8, true, 1, 2>>(E, st);
+    if (dbg) return two ? xengine_go<XC<8, 4, true, 2, 1>>(E, st) : xengine_go<XC<9, 8, true, 1, 2>>(E, st);
 #endif
 #if XE_VARIANTS && !defined(XE_ONLY_DEFAULT)
     if (!two) {
@@ -1116,7 +1126,11 @@ static int xengine_go_shape(XEngineHost* E, hipStream_t st) {
     }
 #endif
     if (!two && E->nwv == 12) return xengine_go<XC<12, 6, false, 1, 2>>(E, st);
-    return two ? xengine_go<XC<8, 8, false, 2, 2>>(E, st) : xengine_go<XC<9, 8, false, 1, 2>>(E, st);
+    if (two && E->nwv == 88) return xengine_go<XC<8, 8, false, 2, 2>>(E, st);
+    if (two && E->nwv == 82) return xengine_go<XC<8, 4, false, 2, 2>>(E, st);
+    if (two && E->nwv == 86) return xengine_go<XC<8, 6, false, 2, 1>>(E, st);
+    if (two && E->nwv == 81) return xengine_go<XC<8, 8, false, 2, 1>>(E, st);
+    return two ? xengine_go<XC<8, 4, false, 2, 1>>(E, st) : xengine_go<XC<9, 8, false, 1, 2>>(E, st);
 }
 // n_steps decode steps of every sequence in ONE launch; with_head: 0 layers only (x_out), 1 + logits, 2 + greedy pick and state update (needed for n_steps > 1)
 int xengine_steps(XEngineHost* E, hipStream_t st, int32_t* d_state, uint16_t* x_out, int with_head, int n_steps) {
@@ -1128,7 +1142,7 @@ int xengine_steps(XEngineHost* E, hipStream_t st, int32_t* d_state, uint16_t* x_
     if (!with_head) a.head_w = nullptr;
     int rc;
     if (E->shape_class == 3) /* the default instantiations only (no tuning variants, no stamps) */
-        rc = a.n_seq > XE_NXCD ? xengine_go<XC3<8, 8, false, 2>>(E, st) : xengine_go<XC3<12, 6, false, 1>>(E, st);
+        rc = a.n_seq > XE_NXCD ? xengine_go<XC3<8, 4, false, 2, 1>>(E, st) : xengine_go<XC3<12, 6, false, 1>>(E, st);
     else
         rc = E->shape_class == 1 ? xengine_go_shape<XC1>(E, st) : xengine_go_shape<XC2>(E, st);
     a.head_w = save.head_w;
@@ -1163,7 +1177,13 @@ int xengine_reset(XEngineHost* E, hipStream_t st) {
     if (rc != KF_OK) return rc;
     return hipStreamSynchronize(st) == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
-void xengine_set_variant(XEngineHost* E, int nwv, int depth) { E->nwv = nwv, E->depth = depth; }
+void xengine_set_variant(XEngineHost* E, int nwv, int depth) {
+    if (nwv == 0) { /* tuning hook: depth = the stagger of the second decoder in microseconds */
+        E->args.stagger_us = depth;
+        return;
+    }
+    E->nwv = nwv, E->depth = depth;
+}
 int xengine_debug_enable(XEngineHost* E, int seq, int wg, int max_steps) {
     XArgs& a = E->args;
     const size_t bytes = (size_t)max_steps * a.n_layer * 64 * 8;
