@@ -743,6 +743,13 @@ def xcd_replicas(m, cfg, forced, timed_positions, warmup, n_seq, ids_main):
     S = cfg["max_seq"]
     K = len(timed_positions)
     first = timed_positions[0]
+    traffic, traffic_src = None, None
+    try:   # counter passes of scratch/gpu_r05_profile.sh (not re-collected by this run: --pmc around bench.py itself crashes the profiler on this pool)
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_xengine_%d.json" % (16 if n_seq > 8 else 8))))
+        traffic = int(pj["hbm_bytes_per_launch"] / ((16 if n_seq > 8 else 8) * 4))
+        traffic_src = "profiles/r05_pmc_xengine_%d.json: FETCH_SIZE / WRITE_SIZE passes of scratch/ub_xengine.py (4 steps per launch at positions 2037..2040), per sequence and step" % (16 if n_seq > 8 else 8)
+    except Exception:
+        pass
     if first + K != S or first - warmup < 1:
         return {"skipped": "the timed window does not end at the last position of the context"}
     xr = XcdReplicas(m, n_seq)
@@ -778,8 +785,10 @@ def xcd_replicas(m, cfg, forced, timed_positions, warmup, n_seq, ids_main):
                 "ms_per_step_all_streams": round(dt * 1e3 / K, 4), "device_ms_per_step": round(dev_ms / K, 4), "steps": K, "positions": "%d..%d" % (first, S - 1),
                 "bytes_per_token": int(bytes_tok), "achieved": round(bytes_tok * tps / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bytes_tok * tps / 1e9 / HBM_PEAK_GBS, 4),
                 "aggregate_of_independent_sequences": True,
-                "note": "algorithmic bytes of ONE sequence's step x aggregate tokens/s / 8 TB/s: every decoder reads the layer weights, its own K / V rows and the head (the weights are shared, so "
-                        "part of the eight reads is served by the 256 MB memory-side cache: profiles/r05_pmc_xengine.json holds the counter traffic); never `value`",
+                "note": "algorithmic bytes of ONE sequence's step x aggregate tokens/s / 8 TB/s: every decoder streams the layer weights, its own K / V rows and the head through its own XCD's L2 "
+                        "(counter traffic at the L2s = 1.04 x the sum of the sequences' algorithmic bytes: profiles/r05_pmc_xengine_16.json; the weights are shared, so the memory-side "
+                        "cache may answer part of it); never `value`",
+                "traffic_per_sequence_step": traffic, "traffic_source": traffic_src,
                 "summation_order": "canonical (the only order the XCD-confined engines run)", "kernel": "kf::xengine_kernel (koifish_amd/csrc/kf_xengine.hip)",
                 "parity": {"sequence_0_ids_equal_single_sequence_engine": same, "positions_compared": int(S), "distinct_continuations": distinct,
                            "per_sequence_oracle_parity": "tests/test_gpu_xengine.py (ids, logits, K / V rows of every sequence, bit for bit)"}}

@@ -281,7 +281,7 @@ __device__ __forceinline__ void xe_mv_run(const XPhase& P, const XPhase& NX, boo
 }
 // the waves that own rows of a phase leave their granules in LDS; the one that arrives last stores the workgroup's piece, 16 bytes per lane, with PLAIN stores (this XCD's L2)
 // plain != NULL: the rows also as plain bf16 (the residual stream after the last layer: x_out)
-__device__ __forceinline__ void xe_publish(const XLds& L, int phase, uint32_t* dst, int nrows, int nwaves, int lane, uint16_t* plain = nullptr) {
+__device__ __forceinline__ void xe_publish(const XLds& L, int phase, uint32_t tag, uint32_t* dst, int nrows, int nwaves, int lane, uint16_t* plain = nullptr) {
     int old = 0;
     if (lane == 0) old = __hip_atomic_fetch_add(L.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     old = __builtin_amdgcn_readfirstlane(old);
@@ -290,6 +290,13 @@ __device__ __forceinline__ void xe_publish(const XLds& L, int phase, uint32_t* d
     // one descriptor for the piece, the lane's 16 bytes as an offset: no 64-bit per-lane address (it was spilled, and its reload in front of the store drained the next phase's
     // weight loads in flight)
     const __amdgpu_buffer_rsrc_t rd = eng_rsrc(dst, (uint32_t)nrows * 4u), rp = eng_rsrc(plain ? (const void*)plain : (const void*)dst, plain ? (uint32_t)nrows * 2u : 0u);
+    if (phase == 2) { /* gate | up: the rows were left as bf16 pairs {gate, up}: SwiGLU (CU_swiglu_v0) and the tag now */
+        for (int i = lane; i < nrows; i += 64) {
+            const uint32_t pr = L.outb[i];
+            const float gt = bf_lo(pr), up = bf_hi(pr);
+            L.outb[i] = (tag << 16) | (uint32_t)f2bf((gt * up) / (1.0f + kf_expf(-gt)));
+        }
+    }
     for (int i = 4 * lane; i < nrows; i += 256) {
         const u32x4 g = *reinterpret_cast<const u32x4*>(L.outb + i);
         __builtin_amdgcn_raw_buffer_store_b128(g, rd, i * 4, 0, 0);
@@ -668,8 +675,8 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
                     } else if (q == 1) {
                         g = (tag << 16) | (uint32_t)f2bf(bf2f(L.xrawA[row]) + bf2f(f2bf(v))); /* CU_add3: bf16(x + bf16(W.x)) */
                     } else if (q == 2) {
-                        const float gt = round_bf16(v), up = round_bf16(v2); /* CU_swiglu_v0 on the two bf16-rounded projections */
-                        g = (tag << 16) | (uint32_t)f2bf((gt * up) / (1.0f + kf_expf(-gt)));
+                        g = pack_bf16x2(v, v2); /* the two bf16-rounded projections; CU_swiglu_v0 on them runs in xe_publish, once per row with every lane busy (here: the whole wave would walk
+                                                   the exponential and the division for two rows) */
                     } else {
                         g = (tag_next << 16) | (uint32_t)f2bf(bf2f(L.xrawB[row]) + bf2f(f2bf(v)));
                     }
@@ -682,7 +689,7 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
                 a.dbg[((size_t)S.step * a.n_layer + l) * 64 + ((cw & 7) < 2 ? 14 + (cw & 7) : 23 + (cw & 7))] = hw; /* slots 14, 15, 25 .. 30: where (SIMD, CU) the wave runs */
             }
             if (q == 0) xe_attn_issue<C>(a, ly, S, cw, lane, T, 0, 0); /* the slice's first tiles (rows of earlier positions; row `pos` is substituted): the q | k | v hand-off hides them */
-            if (xe_nslots<NCW>(cw, spg) > 0) xe_publish(L, q, dst, nrows, nwp, lane, (q == 3 && last) ? a.x_out + (size_t)S.seq * C::DIM + wg * P6::R : nullptr);
+            if (xe_nslots<NCW>(cw, spg) > 0) xe_publish(L, q, tag, dst, nrows, nwp, lane, (q == 3 && last) ? a.x_out + (size_t)S.seq * C::DIM + wg * P6::R : nullptr);
             if (cw == 0) XE_STAMP(17 + 2 * q);
             if (q == 0) { /* q/k-norm + RoPE + attention over the workgroup's key slice; the slice partial into the XCD's partial area; then the first o_proj blocks */
                 xe_attn_phase<C>(a, L, S, ly, gen, cw, lane, T, l, [&]() { xe_fill<NCW, D>(phase_of(1, ly), cw, lane, R); });
