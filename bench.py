@@ -59,9 +59,10 @@ def main():
     ap.add_argument("--tp-layers", type=int, default=0, help="with --tp-virtual: this many of the model's layers (0 = all): bounds the side leg's wall time")
     ap.add_argument("--lean-cpu", type=float, default=0.0, help="with --lean: also the CPU-baseline leg (parity passes + a timed sample of this many seconds) of the model being run")
     ap.add_argument("--lean-prefill", type=int, default=0, help="with --lean: also a prompt of this many tokens through Fish::Prefill (prefill_rate)")
+    ap.add_argument("--lean-xcd", type=int, default=0, help="with --lean: also the XCD-confined engines on this many independent sequences of the model being run (xcd_replicas)")
     ap.add_argument("--lean", action="store_true", help="only the timed decode and step_roofline (what the side legs run in their child processes)")
     ap.add_argument("--leg", default="", choices=["", "config3", "config4cpu"], help="run ONE side leg and print its JSON (child processes of the main run)")
-    ap.add_argument("--side-legs", default="config3,config5,config4,qwen3_1p7b", help="side objects beside the line, each measured in a child process after the main measurements "
+    ap.add_argument("--side-legs", default="config3,config5,config4,qwen3_1p7b,qwen3_4b", help="side objects beside the line, each measured in a child process after the main measurements "
                     "(never `value`): config3 = GPT2-1558M operator path of a training step (sum of separately timed forward+loss, backward, AdamW phases; no parameter update), config5 = 1-bit layers + 20 %% hot FFN rows, config4 = Qwen3-32B on ONE GPU; '' = none")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -194,7 +195,7 @@ def main():
                       "1bit": "1-bit weights (PackedQ YinYang g128)", "nf4": "u4 weights (NF4 row codebooks)"}[args.layers] + " x bf16 activations, fp32 accumulate; bf16 KV",
             "data": "synthetic",
             "config": {"workload": "%s %s greedy decode, 1xMI355X per replica, seq=%d: prompt 128, timed positions %d..%d"
-                                   % ({"qwen3-0.6b": "Qwen3-0.6B", "qwen3-32b": "Qwen3-32B", "qwen3-1.7b": "Qwen3-1.7B"}.get(args.config, args.config), {"q4": "4-bit PackedQ", "bf16": "bf16", "f8": "f8e5m2", "ternary": "2-bit ternary PackedQ", "1bit": "1-bit PackedQ", "nf4": "4-bit NF4 row-codebook"}[args.layers],
+                                   % ({"qwen3-0.6b": "Qwen3-0.6B", "qwen3-32b": "Qwen3-32B", "qwen3-1.7b": "Qwen3-1.7B", "qwen3-4b": "Qwen3-4B", "qwen3-8b": "Qwen3-8B"}.get(args.config, args.config), {"q4": "4-bit PackedQ", "bf16": "bf16", "f8": "f8e5m2", "ternary": "2-bit ternary PackedQ", "1bit": "1-bit PackedQ", "nf4": "4-bit NF4 row-codebook"}[args.layers],
                                       S, timed_positions[0], timed_positions[-1]),
                        "lm_head": args.head, "sparse_ffn_rows_hot": args.sparse if args.sparse > 0 else None, "replicas": world,
                        "hipgraph": bool(use_graph and m.num_graphs() > 0),  # a step that is ONE launch (the engine with head and pick) is launched directly: a one-node graph only adds replay cost
@@ -245,6 +246,11 @@ def main():
                     out["cpu_baseline"] = cpu_baseline(m, cfg, forced, args.lean_cpu, min_steps=16, max_steps=96, canon_steps=24, hots=hots)
                 except Exception as e:
                     out["cpu_baseline"] = {"error": repr(e)[:300]}
+            if args.lean_xcd > 0 and world == 1:
+                try:
+                    out["xcd_replicas"] = xcd_replicas(m, cfg, forced, timed_positions, W, args.lean_xcd, ids_timed_run)
+                except Exception as e:
+                    out["xcd_replicas"] = {"error": repr(e)[:300]}
             if args.lean_prefill > 0 and world == 1:
                 try:
                     lp = np.random.default_rng(7).integers(0, cfg["vocab"], size=min(args.lean_prefill, S - 1)).astype(np.int32)
@@ -412,6 +418,13 @@ def side_legs(which):
             "tokens_per_s": d["value"], "ms_per_step": d["ms_per_step"], "bytes_per_step": d["step_roofline"]["bytes_per_step"], "frac": d["step_roofline"]["frac"],
             "fast_order_tokens_per_s": d.get("fast_order_mode", {}).get("tokens_per_s"), "decode_path": d["config"]["decode_path"],
             "per_layer_launches_tokens_per_s": e.get("value"), "per_layer_launches_ms_per_step": e.get("ms_per_step"), "leg_wall_s": d.get("leg_wall_s")}
+    for nm, title in (("qwen3_4b", "Qwen3-4B shape (dim 2560, 32 / 8 heads of 128, ffn 9728, 36 layers)"), ("qwen3_8b", "Qwen3-8B shape (dim 4096, 32 / 8 heads of 128, ffn 12288, 36 layers)")):
+        if nm in which:   # not BASELINE configurations: the GQA-4 models the reference lists as supported (cases/tutorial/history.md:4-6); round 5: served by the XCD-confined engines
+            d = _child(["--config", nm.replace("_", "-"), "--steps", "64", "--warmup", "16", "--lean", "--lean-xcd", "8"], 600)
+            out[nm + "_shape"] = d if "error" in d else {
+                "workload": "%s, 4-bit PackedQ greedy decode: %s" % (title, d["config"]["workload"].split("seq=")[-1]),
+                "tokens_per_s": d["value"], "ms_per_step": d["ms_per_step"], "bytes_per_step": d["step_roofline"]["bytes_per_step"], "frac": d["step_roofline"]["frac"],
+                "decode_path": d["config"]["decode_path"], "xcd_replicas": d.get("xcd_replicas"), "leg_wall_s": d.get("leg_wall_s")}
     if "config4" in which:
         d = _child(["--config", "qwen3-32b", "--steps", "64", "--warmup", "16", "--lean", "--lean-prefill", "2047"], 600)
         out["config4_one_gpu"] = d if "error" in d else {
@@ -745,6 +758,8 @@ def xcd_replicas(m, cfg, forced, timed_positions, warmup, n_seq, ids_main):
     first = timed_positions[0]
     traffic, traffic_src = None, None
     try:   # counter passes of scratch/gpu_r05_profile.sh (not re-collected by this run: --pmc around bench.py itself crashes the profiler on this pool)
+        if cfg["dim"] != 1024:
+            raise KeyError("the passes were taken on Qwen3-0.6B")
         pj = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_xengine_%d.json" % (16 if n_seq > 8 else 8))))
         traffic = int(pj["hbm_bytes_per_launch"] / ((16 if n_seq > 8 else 8) * 4))
         traffic_src = "profiles/r05_pmc_xengine_%d.json: FETCH_SIZE / WRITE_SIZE passes of scratch/ub_xengine.py (4 steps per launch at positions 2037..2040), per sequence and step" % (16 if n_seq > 8 else 8)

@@ -1307,6 +1307,7 @@ int kfdbg_set_knob(const char* name, long value) {
     else if (!strcmp(name, "q1_tab")) k.q1_tab = (int)value;
     else if (!strcmp(name, "gemv_waves")) k.gemv_waves = value;
     else if (!strcmp(name, "gemv_stream")) k.gemv_stream = (int)value;
+    else if (!strcmp(name, "gemv_xf2")) k.gemv_xf2 = (int)value;
     else if (!strcmp(name, "gemm_min")) k.gemm_min = (int)value;
     else if (!strcmp(name, "g3_tiles")) k.g3_tiles = (int)value;
     else if (!strcmp(name, "g3_first")) k.g3_first = (int)value;

@@ -166,6 +166,42 @@ __device__ __forceinline__ void eng_poll_stage(const uint32_t* gsrc, const uint1
     }
 }
 
+// a long vector without a norm (attention output, SwiGLU output), PIECE x 256 granules at a time: every piece swept until whole, then staged -- the sweep's registers are
+// those of one piece (a 9728-wide vector in one sweep: 152 registers)
+template <int XCH, int NLD, int NBLK, int PIECE, int R0 = 0>
+__device__ __forceinline__ void eng_poll_stage_long(const uint32_t* gsrc, uint32_t tag, u32x4* xs, int lane, int* ws, bool& dead, int* nsweeps) {
+    if constexpr (R0 < NLD) {
+        constexpr int NP = (NLD - R0) < PIECE ? (NLD - R0) : PIECE;
+        const __amdgpu_buffer_rsrc_t rs = eng_rsrc(gsrc + (size_t)R0 * 256, (uint32_t)NP * 1024u);
+        u32x4 g[NP];
+        const uint32_t tagw = tag << 16;
+        for (int spins = 0;; spins++) {
+            uint32_t bad = 0;
+#pragma unroll
+            for (int r = 0; r < NP; r++) g[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (r * 64 + lane) * 16, 0, 16 /* sc1 */));
+#pragma unroll
+            for (int r = 0; r < NP; r++) bad = tags_bad(g[r], tagw, bad);
+            if (all_good(bad)) {
+                if (nsweeps && R0 == 0) *nsweeps = spins + 1;
+                break;
+            }
+            if (dead || spins > ENG_SPIN_MAX) {
+                if (!dead && lane == 0) atomicOr(ws + 1, 1);
+                dead = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int r = 0; r < NP; r++) {
+            const int e0 = 4 * ((R0 + r) * 64 + lane), q = e0 >> 2, c = q / XCH, j = q - c * XCH;
+            const uint32_t o0 = (g[r].x & 0xffffu) | (g[r].y << 16), o1 = (g[r].z & 0xffffu) | (g[r].w << 16);
+            xs[j * NBLK + c] = u32x4{o0 << 16, o0 & 0xffff0000u, o1 << 16, o1 & 0xffff0000u};
+        }
+        eng_poll_stage_long<XCH, NLD, NBLK, PIECE, R0 + NP>(gsrc, tag, xs, lane, ws, dead, nsweeps);
+    }
+}
+
 struct MvAt {
     int row, col;
     bool ok;
@@ -222,10 +258,10 @@ struct PlanT {
 // 64-element block (32 weights either way) per lane, so that such a matrix has the lanes, slots and chains of a 4-bit one (BlockPrep<FMT_Q1T>, <FMT_Q2T>)
 template <int FMT>
 constexpr int eng_vepb() { return (FMT == FMT_Q1T || FMT == FMT_Q2T) ? 32 : BlockDot<FMT>::EPB; }
-template <int FMT, int DIM, int QD, int KVD, int FFN, int NWG>
+template <int FMT, int DIM, int QD, int KVD, int FFN, int NWG, int NWG1 = NWG> /* NWG1: the workgroups that own q | k | v rows (kf_xengine.hip: GQA-4 shapes) */
 struct EngShape {
     static constexpr int EPB = eng_vepb<FMT>();
-    using P1 = PlanT<DIM, EPB, QD, KVD, KVD, false, NWG>;
+    using P1 = PlanT<DIM, EPB, QD, KVD, KVD, false, NWG1>;
     using P4 = PlanT<QD, EPB, DIM, 0, 0, false, NWG>;
     using P5 = PlanT<DIM, EPB, FFN, FFN, 0, true, NWG>;
     using P6 = PlanT<FFN, EPB, DIM, 0, 0, false, NWG>;

@@ -48,13 +48,18 @@ struct Batch {
 // first load, and every one a launch touches is on its critical path
 // XF (canonical 4-bit forms only, chosen by the launcher when K * 4 bytes of LDS leave the occupancy alone): x is staged as fp32 chunks [8][nBlk] and multiplied through
 // BlockDotF (the engine's form): a product is two conversions of the weight pair + one v_pk_fma_f32 instead of four conversions + one -- same chains, same bits
-template <int FMT, int G, int MODE, bool SPARSE, bool ONEJOB, bool CANON, bool XF_ = false>
+// XF2 (XF of a row too long for that: the 25600-wide down_proj of Qwen3-32B, one row slot per wave): the fp32 chunks of HALF the block columns at a time -- the iterations
+// of the first half run against the first window, then the workgroup restages and the same chains go on over the second (weights stay in flight across the two barriers)
+template <int FMT, int G, int MODE, bool SPARSE, bool ONEJOB, bool CANON, bool XF_ = false, bool XF2_ = false>
 __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     using BD = BlockDot<FMT, CANON>;
     constexpr bool PAIRED = (MODE == GEMV_PAIRED), LUT = (FMT == FMT_Q4R), XF = XF_ && CANON && (FMT == FMT_Q4 || FMT == FMT_Q4P);
+    constexpr bool XF2 = XF2_ && XF && G == 1 && !PAIRED && !SPARSE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);
-    double* red = reinterpret_cast<double*>(smem_raw + (size_t)a.K * (XF ? 4 : 2));
+    const int it_half = XF2 ? (a.iters + 1) >> 1 : a.iters;               /* iterations against the first window */
+    const int wcols = XF2 ? it_half << a.lpr_log2 : a.nBlk;               /* block columns of a window = the chunk stride of the staged activations */
+    double* red = reinterpret_cast<double*>(smem_raw + (XF2 ? (size_t)wcols * 128 : (size_t)a.K * (XF ? 4 : 2)));
 
     const int tid = threadIdx.x, lane = tid & 63, wave_in_blk = tid >> 6;
     const int nBlk = a.nBlk, iters = a.iters;
@@ -220,8 +225,8 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
         constexpr int XCH = BD::XCH;
         auto put = [&](int c, int j, u32x4 o) {
             if constexpr (XF) {
-                xs[(2 * j) * nBlk + c] = u32x4{o.x << 16, o.x & 0xffff0000u, o.y << 16, o.y & 0xffff0000u};
-                xs[(2 * j + 1) * nBlk + c] = u32x4{o.z << 16, o.z & 0xffff0000u, o.w << 16, o.w & 0xffff0000u};
+                xs[(2 * j) * wcols + c] = u32x4{o.x << 16, o.x & 0xffff0000u, o.y << 16, o.y & 0xffff0000u};
+                xs[(2 * j + 1) * wcols + c] = u32x4{o.z << 16, o.z & 0xffff0000u, o.w << 16, o.w & 0xffff0000u};
             } else {
                 xs[j * nBlk + c] = o;
             }
@@ -268,7 +273,8 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
                 mul = 1.0f / sqrtf(val);
             }
             // element e of block column c, chunk j (e = c*EPB + j*8 + i)  ->  LDS chunk (j*nBlk + c)
-            for (int e8 = tid; e8 < nch; e8 += blockDim.x) {
+            const int nch_w = XF2 ? (wcols * XCH < nch ? wcols * XCH : nch) : nch; /* XF2: the first window (the launcher takes this form only without a norm) */
+            for (int e8 = tid; e8 < nch_w; e8 += blockDim.x) {
                 const int c = e8 / XCH, j = e8 - c * XCH;
                 const u32x4 raw = *reinterpret_cast<const u32x4*>(a.x + (size_t)e8 * 8);
                 u32x4 o = raw;
@@ -323,7 +329,8 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
                 } else {
                     const float st = bf2f(bt.st[g]);
                     Acc r;
-                    if constexpr (XF) r = BlockDotF<FMT>::run(bt.w[g], reinterpret_cast<const f32x4*>(xs), col, nBlk, st, bf2f(bt.ze[g]), -(jqb * st), acc[g]);
+                    if constexpr (XF2) r = BlockDotF<FMT>::run(bt.w[g], reinterpret_cast<const f32x4*>(xs), it >= it_half ? col - wcols : col, wcols, st, bf2f(bt.ze[g]), -(jqb * st), acc[g]);
+                    else if constexpr (XF) r = BlockDotF<FMT>::run(bt.w[g], reinterpret_cast<const f32x4*>(xs), col, nBlk, st, bf2f(bt.ze[g]), -(jqb * st), acc[g]);
                     else r = BD::run(bt.w[g], xs, col, nBlk, st, bf2f(bt.ze[g]), -(jqb * st), acc[g]);
                     acc[g] = acc_pick(ok, r, acc[g]);
                     if (PAIRED) {
@@ -395,6 +402,31 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
             }
             compute(nxt);
         }
+    } else if constexpr (XF2) { /* one row slot per wave (nsteps = iters, or 0 for a wave past the last slot: it still meets the two barriers) */
+        auto run = [&](int k0, int k1) {
+            for (int k = k0; k < k1; k++) {
+                if (k + 1 < nsteps) {
+                    if (++nit == iters) nit = 0, nbi++;
+                    load(nbi, nit, nxt);
+                }
+                compute(cur);
+                cur = nxt;
+            }
+        };
+        run(0, nsteps < it_half ? nsteps : it_half);
+        __syncthreads(); /* every wave has read the first window for the last time */
+        {
+            constexpr int XCH = BD::XCH;
+            const int e8_0 = wcols * XCH;
+            for (int e8 = e8_0 + tid; e8 < nch; e8 += blockDim.x) {
+                const int c = e8 / XCH, j = e8 - c * XCH;
+                const u32x4 o = *reinterpret_cast<const u32x4*>(a.x + (size_t)e8 * 8);
+                xs[(2 * j) * wcols + (c - wcols)] = u32x4{o.x << 16, o.x & 0xffff0000u, o.y << 16, o.y & 0xffff0000u};
+                xs[(2 * j + 1) * wcols + (c - wcols)] = u32x4{o.z << 16, o.z & 0xffff0000u, o.w << 16, o.w & 0xffff0000u};
+            }
+        }
+        __syncthreads();
+        run(it_half, nsteps);
     } else {
         for (int k = 0; k < nsteps; k++) {
             if (k + 1 < nsteps) {
@@ -553,6 +585,13 @@ static void launch_j(const GemvArgs& a, int G, dim3 grid, size_t smem, hipStream
         if (smem_f <= GEMV_XF_MAX_SMEM) {
             launch_x<FMT, MODE, SPARSE, ONEJOB, true>(a, G, grid, smem_f, st);
             return;
+        }
+        if constexpr (MODE == GEMV_PLAIN && !SPARSE && ONEJOB) { /* longer rows, one row slot per wave, no norm in front: half the block columns at a time (XF2) */
+            const size_t smem_2 = (size_t)(((a.iters + 1) >> 1) << a.lpr_log2) * 128 + 256;
+            if (G == 1 && a.spw == 1 && !a.norm_w && a.iters >= 2 && smem_2 <= 54 * 1024 && g_knobs.gemv_xf2 != 0) { /* 54 KiB: three workgroups per CU */
+                hipLaunchKernelGGL((gemv_kernel<FMT, 1, MODE, SPARSE, ONEJOB, GEMV_CANON, true, true>), grid, dim3(256), smem_2, st, a);
+                return;
+            }
         }
     }
     launch_x<FMT, MODE, SPARSE, ONEJOB, false>(a, G, grid, smem, st);

@@ -153,6 +153,7 @@ struct Knobs {
     int q1_tab = 1;       /* 1-bit mat-vec through the LDS selector table (0: the per-bit select form; same bits) */
     long gemv_waves = 0;  /* > 0: waves a mat-vec launch aims for (0: the launcher's rule) */
     int gemv_stream = 1;  /* buffer-load form of the long mat-vec launches (0: off) */
+    int gemv_xf2 = 1;     /* canonical 4-bit rows too long for fp32 activations in 48 KiB of LDS: two windows of half the block columns (0: bf16 activations, widened per product) */
     int gemm_min = 8;     /* token rows from which the MFMA tile kernels replace the per-token mat-vec loop */
 };
 extern Knobs g_knobs;

@@ -58,14 +58,23 @@ struct XArgs {
     int* ws;         /* [0] epoch, [1] error word, [16 + 32 x] ticket of XCD x, [17 + 32 x] its workgroups that have left */
     unsigned long long* dbg; /* diagnostic instantiation: [step][layer][16] stamps of (sequence dbg_seq, workgroup rank dbg_wg) */
     int dbg_seq, dbg_wg, dbg_steps;
+    int deal_wl;    /* weight (x 8) of the compute waves that share the poller's SIMD: see xe_deal */
     int stagger_us; /* two decoders per XCD: microseconds the second one starts behind the first */
 };
 
 // error word bits: 1 x, 2 q|k|v, 4 partials, 8 workgroups per XCD != 32, 16 pick, 32 token granule, 64 position beyond the cache, 128 ao, 256 xB, 512 act, 1024 head x
 
+constexpr int xe_p1_wgs(int dim, int epb, int qd, int kvd) { /* the most workgroups (of 32, 24, 16, 8) whose equal pieces of the q | k | v row slots do not straddle a matrix */
+    for (int w = 32; w >= 8; w -= 8) {
+        const CPlan p = c_plan(dim, epb, qd, kvd, kvd, false, w);
+        if (p.total == w * p.spg && p.slot0[1] % p.spg == 0 && p.slot0[2] % p.spg == 0) return w;
+    }
+    return 0;
+}
 template <int FMT_, int GQ_, int HD_, int NWV_, int DIM_, int QD_, int KVD_, int FFN_, int DEPTH_, bool DBG_, int WPC_ = 1, int AU_ = 2>
 struct XCfg {
     static constexpr int AU = AU_; /* key tiles per attention batch and wave */
+    static constexpr bool DEAL_CONTIG = WPC_ > 1 || NWV_ == 8; /* xe_deal: 7 compute waves = ONE beside the poller on its SIMD: a run per wave, that wave's shorter */
     static constexpr int WPC = WPC_; /* decoders per XCD = workgroups per CU: 2 lets one decoder's hand-off waits run under the other's arithmetic (the hardware interleaves the two workgroups' waves) */
     static constexpr int FMT = FMT_, GQ = GQ_, HD = HD_, NWV = NWV_, NCW = NWV_ - 1, DIM = DIM_, QD = QD_, KVD = KVD_, FFN = FFN_, DEPTH = DEPTH_, NWG = XE_NWG;
     static constexpr bool DBG = DBG_;
@@ -73,7 +82,11 @@ struct XCfg {
     static constexpr int n_head = QD_ / HD_, n_kv = KVD_ / HD_;
     static_assert(XE_NWG % n_kv == 0, "whole workgroups per kv-head");
     static constexpr int SPK = XE_NWG / n_kv; /* key slices (= workgroups) per kv-head */
-    using SH = EngShape<FMT_, DIM_, QD_, KVD_, FFN_, XE_NWG>;
+    // q | k | v rows: a workgroup's rows belong to ONE of the three matrices.  With 16 / 8 heads the 32 workgroups cut the row slots that way; the GQA-4 shapes (32 / 8 heads:
+    // 4 + 1 + 1 parts) do with 24 workgroups -- the other eight own no row of this phase (a fifth of a layer's weights at three quarters of the workgroups)
+    static constexpr int P1W = xe_p1_wgs(DIM_, eng_vepb<FMT_>(), QD_, KVD_);
+    static_assert(P1W > 0, "no cut of the q | k | v row slots into whole-matrix pieces");
+    using SH = EngShape<FMT_, DIM_, QD_, KVD_, FFN_, XE_NWG, P1W>;
     static constexpr int ME = QD_ / XE_NWG; /* ao elements a workgroup merges */
     static_assert(QD_ % XE_NWG == 0 && ME % 4 == 0 && ME <= HD_ && HD_ % ME == 0 && ME <= 128, "merge elements per workgroup");
     static constexpr int PSH = SPK * (2 * HD_ + 4); /* 8-byte granules of one head's slice partials: [HD / ME][SPK][ME] values x 2, then [SPK][4] {m, L lo, L hi, -} */
@@ -84,6 +97,11 @@ struct XCfg {
     static constexpr int HnBlk = DIM_ / 8, Hlpr_log2 = c_lpr_log2(DIM_ / 8, 1L << 20), HLPR = 1 << Hlpr_log2, HRPS = 64 >> Hlpr_log2, Hiters = (HnBlk + HLPR - 1) / HLPR;
     static constexpr int XCH = 8; /* fp32 activations: 16-byte chunks per 32-weight block */
     static constexpr int maxKc = DIM_ > QD_ ? (DIM_ > FFN_ ? DIM_ : FFN_) : (QD_ > FFN_ ? QD_ : FFN_);
+    // the waves' attention sums (fp64, [NCW][GQ][hd + 2]) in the second activation buffer when the two would not fit side by side (Qwen3-8B: 2 x 48 KB of activations): the
+    // buffer is idle between the barrier in front of q | k | v (down_proj of the layer before has read it) and the staging of the attention output, which waits for every
+    // slice partial of the XCD -- so for this workgroup's, written after the last read of the sums
+    static constexpr bool COMB_IN_XS1 = (size_t)maxKc * 8 + (size_t)DIM_ * 4 + sizeof(double) * (size_t)(NWV_ - 1) * GQ_ * (HD_ + 2) > 140 * 1024;
+    static_assert(!COMB_IN_XS1 || sizeof(double) * (size_t)(NWV_ - 1) * GQ_ * (HD_ + 2) <= (size_t)maxKc * 4, "the sums fit the buffer");
     static constexpr int XS = maxKc / 32; /* chunk stride of the staged activations (16-byte units): chunk j of block column c at [j * XS + c], whatever the phase's width */
     // every phase in whole rows and whole iterations: no masks at the multiply
     static constexpr bool EXACT = (QD_ + 2 * KVD_) % SH::P1::RPS == 0 && KVD_ % SH::P1::RPS == 0 && QD_ % SH::P1::RPS == 0 && DIM_ % SH::P4::RPS == 0 && FFN_ % SH::P5::RPS == 0 && DIM_ % SH::P6::RPS == 0 &&
@@ -135,25 +153,39 @@ struct XPhase {
     float qb, qb2;
     int nBlk, lpr_log2, iters, rps_log2;
     int paired;
-    int s0, Mj;      /* the workgroup's first slot counted inside the matrix; the matrix's rows */
+    int s0, Mj;      /* the workgroup's first slot counted inside the matrix, + the wave's first (XDeal::a); the matrix's rows */
+    int sl_b;        /* the wave's k-th slot: s0 + k * sl_b */
     int n;           /* ring entries this wave walks: its slots x iters (x 2 paired) */
     int row0;        /* first row of the workgroup's piece, counted inside the matrix */
     uint32_t wbytes, gbytes;
 };
-// Which of a workgroup's row slots a compute wave walks.  Waves w and w + 4 share a SIMD (measured: HW_ID of waves 0 .. 7 = SIMD 1 3 0 2 1 3 0 2), and the SIMD's two or three
-// waves finish one after the other -- the phase lasts as long as the busiest SIMD -- so the slots are dealt to SIMDs first (slot s -> class s & 3), then round the waves of
-// the class: with 11 compute waves (12 with the poller: three per SIMD) the class of the poller has two compute waves that take half of its slots each, the others a third.
-// 8 compute waves: the plain deal, wave cw takes slots cw, cw + 8, ...
+// Which of a workgroup's row slots a compute wave walks: slot sl_a + k * sl_b for k = 0 .. n - 1 (XPhase).  Waves w and w + 4 share a SIMD (measured: HW_ID of waves 0 .. 7 =
+// SIMD 1 3 0 2 1 3 0 2) and a SIMD's waves finish one after the other -- a phase lasts as long as the busiest SIMD.  The poller (wave NCW) sits on the SIMD of class NCW & 3,
+// whose compute waves are fewer (11 compute waves: two there, three elsewhere; 7: ONE there, two elsewhere).
+//  * one decoder per XCD: the slots are dealt to SIMDs first (slot s -> class s & 3), then round the waves of the class -- every SIMD the same share, and at any moment the
+//    workgroup's waves read neighbouring kilobytes (measured against contiguous runs per wave: 1.88 ms per step of eight sequences against 1.98)
+//  * two per XCD (7 compute waves; the other decoder's waves fill the idle issue slots, the order of the reads is mixed anyway): a contiguous run per wave, its length by the
+//    wave's weight -- `wl` / 8 of a plain wave's share for the wave beside the poller (XArgs::deal_wl; 16 = equal SIMD shares; measured 14: 3.449 ms per step of sixteen
+//    sequences, 16: 3.507, 8: 3.511)
+struct XDeal {
+    int a, b, n;
+};
 template <int NCW>
-__device__ __forceinline__ int xe_slot(int cw, int k) { /* the wave's k-th slot inside the workgroup's piece */
-    const int cls = cw & 3, idx = cw >> 2, nw = (NCW - cls + 3) / 4;
-    return cls + 4 * (idx + k * nw);
+__device__ __forceinline__ int xe_deal_cum(int cw, int wl) { /* weights of waves 0 .. cw - 1 */
+    const int pc = NCW & 3, npc = cw > pc ? (cw - pc + 3) >> 2 : 0; /* waves of the poller's class below cw */
+    return 8 * (cw - npc) + wl * npc;
 }
-template <int NCW>
-__device__ __forceinline__ int xe_nslots(int cw, int spg) {
-    const int cls = cw & 3, idx = cw >> 2, nw = (NCW - cls + 3) / 4;
-    const int per_cls = spg > cls ? (spg - cls + 3) / 4 : 0; /* slots of the class */
-    return per_cls > idx ? (per_cls - idx + nw - 1) / nw : 0;
+template <int NCW, bool CONTIG>
+__device__ __forceinline__ XDeal xe_deal(int cw, int spg, int wl) {
+    if constexpr (CONTIG) {
+        const int tot = xe_deal_cum<NCW>(NCW, wl);
+        const int f0 = (spg * xe_deal_cum<NCW>(cw, wl) + (tot >> 1)) / tot, f1 = (spg * xe_deal_cum<NCW>(cw + 1, wl) + (tot >> 1)) / tot;
+        return XDeal{f0, 1, f1 - f0};
+    } else {
+        const int cls = cw & 3, idx = cw >> 2, nw = (NCW - cls + 3) / 4;
+        const int per_cls = spg > cls ? (spg - cls + 3) / 4 : 0; /* slots of the class */
+        return XDeal{cls + 4 * idx, 4 * nw, per_cls > idx ? (per_cls - idx + nw - 1) / nw : 0};
+    }
 }
 struct XLaneGeo { /* the lane's place in a phase's row slots */
     uint32_t vblk; /* sub * nBlk + ll: the lane's block offset inside a slot's iteration */
@@ -175,11 +207,11 @@ __device__ __forceinline__ void xe_issue(const XPhase& P, const XLaneGeo& G, con
     // every field read into a value FIRST, then chosen: `c ? NX.f : P.f` on two lvalues is a choice between two ADDRESSES followed by one load, which keeps both structs
     // in scratch memory (and every such read an indexed scratch load with a drain of the weight loads in front of it)
     auto pick = [](bool c, auto x, auto y) { return c ? x : y; };
-    const int paired = pick(use_nx, +NX.paired, +P.paired), iters = pick(use_nx, +NX.iters, +P.iters), s0 = pick(use_nx, +NX.s0, +P.s0);
+    const int paired = pick(use_nx, +NX.paired, +P.paired), iters = pick(use_nx, +NX.iters, +P.iters), s0 = pick(use_nx, +NX.s0, +P.s0), sl_b = pick(use_nx, +NX.sl_b, +P.sl_b);
     const int rps_log2 = pick(use_nx, +NX.rps_log2, +P.rps_log2), lpr_log2 = pick(use_nx, +NX.lpr_log2, +P.lpr_log2), nBlk = pick(use_nx, +NX.nBlk, +P.nBlk);
     const int k = paired ? e >> 1 : e;
     const int sl = k / iters, it = k - sl * iters;
-    const uint32_t ublk = (uint32_t)(((s0 + xe_slot<NCW>(cw, sl)) << rps_log2) * nBlk + (it << lpr_log2)); /* wave-uniform; a multiple of 4 */
+    const uint32_t ublk = (uint32_t)(((s0 + sl * sl_b) << rps_log2) * nBlk + (it << lpr_log2)); /* wave-uniform; a multiple of 4 */
     const bool second = paired && (e & 1);
     const g_u32x4 w_a = P.m.w, w_b = P.m2.w, w_c = NX.m.w, w_d = NX.m2.w;
     const g_u16 s_a = P.m.step, s_b = P.m2.step, s_c = NX.m.step, s_d = NX.m2.step;
@@ -248,7 +280,7 @@ __device__ __forceinline__ void xe_mv_run(const XPhase& P, const XPhase& NX, boo
             if (e < n) {
                 const int k = P.paired ? e >> 1 : e;
                 const int sl = k / P.iters, it = k - sl * P.iters;
-                const int row = ((P.s0 + xe_slot<NCW>(cw, sl)) << P.rps_log2) + G.sub, colr = (it << P.lpr_log2) + G.ll;
+                const int row = ((P.s0 + sl * P.sl_b) << P.rps_log2) + G.sub, colr = (it << P.lpr_log2) + G.ll;
                 const bool second = P.paired && (d & 1);
                 if (it == 0) {
                     if (second) acc2 = f32x2_t{0.f, 0.f};
@@ -490,7 +522,7 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, co
             const int e_kv = 4 * lane; /* < hd: k, < 2 hd: v */
             const bool kv_in = e_kv < 2 * hd;
             const int kv_src = e_kv < hd ? C::QD + S.kvh * hd + e_kv : C::QD + C::KVD + S.kvh * hd + (e_kv - hd);
-            eng_wait_pub(L.pub + 0, S.step * a.n_layer + l + 1, 0, dead);
+            if (!(C::P1W < XE_NWG && S.r >= C::P1W)) eng_wait_pub(L.pub + 0, S.step * a.n_layer + l + 1, 0, dead); /* (a workgroup without q | k | v rows publishes none) */
             XE_STAMP(9);
             for (int spins = 0;; spins++) {
                 uint32_t bad = 0;
@@ -585,7 +617,8 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, co
         eng_wait_pub(L.pub + 2, S.step * a.n_layer + l + 1, 0, dead);
         XE_STAMP(11);
         int nsw_act = 0;
-        eng_poll_stage<XCH, NF, C::XS, false, false, true>(loc + C::act, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, &nsw_act, nullptr, 0, 0);
+        if constexpr (NF > 24) eng_poll_stage_long<XCH, NF, C::XS, 16>(loc + C::act, tag, L.xs[1], lane, a.ws, dead, &nsw_act); /* a 9728-wide vector in one sweep: 152 registers */
+        else eng_poll_stage<XCH, NF, C::XS, false, false, true>(loc + C::act, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, &nsw_act, nullptr, 0, 0);
         if (C::DBG && S.stamp && lane == 0) a.dbg[((size_t)S.step * a.n_layer + l) * 64 + 13] = (unsigned long long)nsw_act;
         XE_STAMP(8);
         __syncthreads(); /* B6 */
@@ -602,7 +635,7 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
     using P6 = typename SH::P6;
     constexpr int NCW = C::NCW, D = C::DEPTH;
     static_assert(P1::R % 4 == 0 && P4::R % 4 == 0 && P5::R % 4 == 0 && P6::R % 4 == 0, "16-byte pieces");
-    static_assert(P1::total == XE_NWG * P1::spg && P4::total == XE_NWG * P4::spg && P5::total == XE_NWG * P5::spg && P6::total == XE_NWG * P6::spg, "every workgroup owns rows of every phase");
+    static_assert(P1::total == C::P1W * P1::spg && P4::total == XE_NWG * P4::spg && P5::total == XE_NWG * P5::spg && P6::total == XE_NWG * P6::spg, "every workgroup owns rows of every phase");
     static_assert(P1::S1 % P1::spg == 0 && P1::S2 % P1::spg == 0, "a workgroup's P1 rows belong to one matrix");
     uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)S.seq * a.loc_stride);
     const float qb1 = S.j1 == 0 ? a.qbias[0] : (S.j1 == 1 ? a.qbias[1] : a.qbias[2]);
@@ -634,7 +667,10 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
         P.s0 = sel4(q, S.s1, wg * P4::spg, wg * P5::spg, wg * P6::spg), P.Mj = sel4(q, S.M1, P4::M0, P5::M0, P6::M0);
         P.row0 = P.s0 << P.rps_log2;
         const int spg = sel4(q, P1::spg, P4::spg, P5::spg, P6::spg);
-        P.n = xe_nslots<NCW>(cw, spg) * P.iters * (P.paired ? 2 : 1);
+        const XDeal dl = xe_deal<NCW, C::DEAL_CONTIG>(cw, spg, a.deal_wl);
+        P.s0 += __builtin_amdgcn_readfirstlane(dl.a), P.sl_b = __builtin_amdgcn_readfirstlane(dl.b);
+        P.n = __builtin_amdgcn_readfirstlane(dl.n) * P.iters * (P.paired ? 2 : 1);
+        if (C::P1W < XE_NWG && q == 0 && wg >= C::P1W) P.n = 0;
         P.wbytes = (uint32_t)P.Mj * (uint32_t)P.nBlk * 16u, P.gbytes = (uint32_t)P.Mj * (uint32_t)(P.nBlk / 4) * 2u;
         return P;
     };
@@ -662,7 +698,7 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
             const int spg = q == 0 ? P1::spg : (q == 1 ? P4::spg : (q == 2 ? P5::spg : P6::spg));
             int nwp = 0; /* waves that own rows of the phase */
 #pragma unroll
-            for (int w = 0; w < NCW; w++) nwp += xe_nslots<NCW>(w, spg) > 0 ? 1 : 0;
+            for (int w = 0; w < NCW; w++) nwp += xe_deal<NCW, C::DEAL_CONTIG>(w, spg, a.deal_wl).n > 0 ? 1 : 0;
             uint32_t* const dst = loc + (q == 0 ? C::qkv + S.q_out0 : (q == 1 ? C::xB + wg * P4::R : (q == 2 ? C::act + wg * P5::R : C::xA + wg * P6::R)));
             __syncthreads(); /* the phase's activations are staged (B1 / B4 / B5 / B6) */
             if (cw == 0) XE_STAMP(16 + 2 * q);
@@ -689,7 +725,7 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
                 a.dbg[((size_t)S.step * a.n_layer + l) * 64 + ((cw & 7) < 2 ? 14 + (cw & 7) : 23 + (cw & 7))] = hw; /* slots 14, 15, 25 .. 30: where (SIMD, CU) the wave runs */
             }
             if (q == 0) xe_attn_issue<C>(a, ly, S, cw, lane, T, 0, 0); /* the slice's first tiles (rows of earlier positions; row `pos` is substituted): the q | k | v hand-off hides them */
-            if (xe_nslots<NCW>(cw, spg) > 0) xe_publish(L, q, tag, dst, nrows, nwp, lane, (q == 3 && last) ? a.x_out + (size_t)S.seq * C::DIM + wg * P6::R : nullptr);
+            if (xe_deal<NCW, C::DEAL_CONTIG>(cw, spg, a.deal_wl).n > 0 && !(C::P1W < XE_NWG && q == 0 && wg >= C::P1W)) xe_publish(L, q, tag, dst, nrows, nwp, lane, (q == 3 && last) ? a.x_out + (size_t)S.seq * C::DIM + wg * P6::R : nullptr);
             if (cw == 0) XE_STAMP(17 + 2 * q);
             if (q == 0) { /* q/k-norm + RoPE + attention over the workgroup's key slice; the slice partial into the XCD's partial area; then the first o_proj blocks */
                 xe_attn_phase<C>(a, L, S, ly, gen, cw, lane, T, l, [&]() { xe_fill<NCW, D>(phase_of(1, ly), cw, lane, R); });
@@ -703,7 +739,8 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
 // of gemv_kernel<FMT_BF16, .., CANON> (same lanes per row, chain pair, tree, bf16 store), first-maximum arg-max over the stored values
 template <class C>
 __device__ __forceinline__ void xe_head_main(const XArgs& a, const XLds& L, const XSeq& S, int epoch, bool more_steps, int wave, int lane) {
-    constexpr int NWV = C::NWV, NWG = XE_NWG, nBlk = C::HnBlk, LPR = C::HLPR, RPS = C::HRPS, ITERS = C::Hiters, HG = 4;
+    constexpr int NWV = C::NWV, NWG = XE_NWG, nBlk = C::HnBlk, LPR = C::HLPR, RPS = C::HRPS, ITERS = C::Hiters;
+    constexpr int HG = ITERS <= 4 ? 4 : (ITERS <= 5 ? 2 : 1); /* row slots per batch and wave, two batches in flight: 2 x HG x ITERS x 4 registers (2560-wide rows: 80, 4096-wide: 64) */
     constexpr int ND = C::DIM / 256;
     const int wg = S.r;
     uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)S.seq * a.loc_stride);
@@ -856,7 +893,7 @@ __global__ void __launch_bounds__(C::NWV * 64, (C::NWV * C::WPC + 3) / 4 /* wave
     constexpr int xs_bytes = (maxK * 4 + 15) & ~15, xr_bytes = (C::DIM * 2 + 15) & ~15;
     constexpr size_t o_attn = (size_t)2 * xs_bytes + 2 * xr_bytes;
     constexpr size_t o_comb = (o_attn + sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + 15) & ~(size_t)15;
-    constexpr size_t o_msc = o_comb + sizeof(double) * (size_t)NCW * GQ * (hd + 2);
+    constexpr size_t o_msc = o_comb + (C::COMB_IN_XS1 ? 0 : sizeof(double) * (size_t)NCW * GQ * (hd + 2));
     constexpr size_t o_wmax = o_msc + sizeof(double) * ((size_t)C::ME * C::SPK) + 4 * 64 + 4 * 128;
     constexpr size_t o_outb = o_wmax + 4 * 2 * 16;
     constexpr size_t o_cnt = o_outb + 4 * (size_t)((C::maxR + 63) & ~63);
@@ -870,7 +907,7 @@ __global__ void __launch_bounds__(C::NWV * 64, (C::NWV * C::WPC + 3) / 4 /* wave
     L.xrawB = reinterpret_cast<uint16_t*>(smem + 2 * xs_bytes + xr_bytes);
     L.qraw = reinterpret_cast<uint16_t*>(smem + o_attn);
     L.kraw = L.qraw + GQ * hd, L.vraw = L.kraw + hd, L.qb = L.vraw + hd, L.knew = L.qb + GQ * hd;
-    L.comb = reinterpret_cast<double*>(smem + o_comb);
+    L.comb = reinterpret_cast<double*>(smem + (C::COMB_IN_XS1 ? (size_t)xs_bytes : o_comb));
     L.msc = reinterpret_cast<double*>(smem + o_msc);
     L.wmax = reinterpret_cast<float*>(smem + o_wmax);
     L.outb = reinterpret_cast<uint32_t*>(smem + o_outb);
@@ -968,12 +1005,15 @@ struct XEngineHost {
     void* ws;
     size_t ws_bytes;
     int nwv, depth; /* the instantiation in use */
+    int deal_wl;    /* 0: the form's default (xengine_go) */
 };
 
 static int xe_shape_class(int GQ, int hd, int dim, int q_dim, int ffn) {
     if (GQ == 2 && hd == 128 && dim == 1024 && q_dim == 2048 && ffn == 3072) return 1; /* Qwen3-0.6B (BASELINE config 2) */
     if (GQ == 2 && hd == 64 && dim == 256 && q_dim == 256 && ffn == 512) return 2;     /* the small parity-test shape */
     if (GQ == 2 && hd == 128 && dim == 2048 && q_dim == 2048 && ffn == 6144) return 3;  /* Qwen3-1.7B: the streaming phases do not care how many blocks a lane walks */
+    if (GQ == 4 && hd == 128 && dim == 2560 && q_dim == 4096 && ffn == 9728) return 4;  /* Qwen3-4B (32 / 8 heads; cases/tutorial/history.md:4-6) */
+    if (GQ == 4 && hd == 128 && dim == 4096 && q_dim == 4096 && ffn == 12288) return 5; /* Qwen3-8B */
     return 0;
 }
 template <int NWV, int DEPTH, bool DBG, int WPC, int AU = 2>
@@ -982,7 +1022,18 @@ template <int NWV, int DEPTH, bool DBG, int WPC, int AU = 2>
 using XC1 = XCfg<FMT_Q4P, 2, 128, NWV, 1024, 2048, 1024, 3072, DEPTH, DBG, WPC, AU>;
 template <int NWV, int DEPTH, bool DBG, int WPC, int AU = 2>
 using XC2 = XCfg<FMT_Q4P, 2, 64, NWV, 256, 256, 128, 512, DEPTH, DBG, WPC, AU>;
-static int xe_loc_dw(int shape_class) { return shape_class == 1 ? XC1<9, 8, false, 1>::loc_dw : (shape_class == 3 ? XC3<9, 8, false, 1>::loc_dw : XC2<9, 8, false, 1>::loc_dw); }
+// the GQA-4 shapes: one decoder per XCD, 8 waves (two per SIMD: 256 registers -- the attention sums of four query heads are 36 fp64 values per lane)
+using XC4 = XCfg<FMT_Q4P, 4, 128, 8, 2560, 4096, 1024, 9728, 8, false, 1, 2>;
+using XC5 = XCfg<FMT_Q4P, 4, 128, 8, 4096, 4096, 1024, 12288, 8, false, 1, 2>;
+static int xe_loc_dw(int shape_class) {
+    switch (shape_class) {
+        case 1: return XC1<9, 8, false, 1>::loc_dw;
+        case 3: return XC3<9, 8, false, 1>::loc_dw;
+        case 4: return XC4::loc_dw;
+        case 5: return XC5::loc_dw;
+    }
+    return XC2<9, 8, false, 1>::loc_dw;
+}
 
 size_t xengine_ws_bytes(const kf_engine_desc* d) {
     const int hd = d->head_dim, GQ = d->n_kv > 0 ? d->n_head / d->n_kv : 1;
@@ -1015,8 +1066,11 @@ int xengine_build(const kf_engine_desc* d, int n_seq, long long kv_seq_stride, v
     if ((hd != 64 && hd != 128) || d->n_kv <= 0 || d->n_head % d->n_kv != 0) return KF_UNSUPPORTED_DATATYPE;
     const int GQ = d->n_head / d->n_kv, q_dim = d->n_head * hd, kv_dim = d->n_kv * hd;
     const int sc = xe_shape_class(GQ, hd, d->dim, q_dim, d->ffn);
-    *why = "model shape not instantiated for the XCD-confined engine: built for Qwen3-0.6B (dim 1024, 16/8 heads of 128, ffn 3072), Qwen3-1.7B (dim 2048, same heads, ffn 6144) and the 256-wide test shape";
+    *why = "model shape not instantiated for the XCD-confined engine: built for Qwen3-0.6B (dim 1024, 16/8 heads of 128, ffn 3072), Qwen3-1.7B (dim 2048, same heads, ffn 6144), Qwen3-4B "
+           "(dim 2560, 32/8 heads, ffn 9728), Qwen3-8B (dim 4096, 32/8 heads, ffn 12288) and the 256-wide test shape";
     if (!sc) return KF_UNSUPPORTED_DATATYPE;
+    *why = "the GQA-4 shapes (Qwen3-4B / 8B) run one decoder per XCD: at most 8 sequences (two workgroups per CU would need 2 x 78 KB (2 x 98 KB) of activations in LDS)";
+    if (sc >= 4 && n_seq > XE_NXCD) return KF_UNSUPPORTED_DATATYPE;
     if (!dry && (ws_bytes < xengine_ws_bytes(d) || ((uintptr_t)ws & 255) != 0)) {
         *why = "workspace too small or not 256-byte aligned";
         return KF_INVALID_ARGS;
@@ -1091,7 +1145,7 @@ static size_t xe_smem(int n_layer) {
     constexpr int xs_bytes = (maxK * 4 + 15) & ~15, xr_bytes = (C::DIM * 2 + 15) & ~15;
     constexpr size_t o_attn = (size_t)2 * xs_bytes + 2 * xr_bytes;
     constexpr size_t o_comb = (o_attn + sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + 15) & ~(size_t)15;
-    constexpr size_t o_msc = o_comb + sizeof(double) * (size_t)NCW * GQ * (hd + 2);
+    constexpr size_t o_msc = o_comb + (C::COMB_IN_XS1 ? 0 : sizeof(double) * (size_t)NCW * GQ * (hd + 2));
     constexpr size_t o_wmax = o_msc + sizeof(double) * ((size_t)C::ME * C::SPK) + 4 * 64 + 4 * 128;
     constexpr size_t o_outb = o_wmax + 4 * 2 * 16;
     constexpr size_t o_cnt = o_outb + 4 * (size_t)((C::maxR + 63) & ~63);
@@ -1108,6 +1162,7 @@ static int xengine_go(XEngineHost* E, hipStream_t st) {
     size_t smem = xe_smem<C>(E->args.n_layer);
     if (C::WPC == 2 && smem < 54 * 1024) smem = 54 * 1024; /* two workgroups per CU, never three: a third would be a workgroup of some decoder queued behind its own peers */
     if (smem * C::WPC > 160 * 1024) return KF_UNSUPPORTED_DATATYPE;
+    E->args.deal_wl = E->deal_wl > 0 ? E->deal_wl : (C::WPC > 1 ? 14 : (C::NCW == 7 ? 11 : 16)); /* xe_deal: the share of the compute wave beside the poller (two decoders per XCD) */
     hipLaunchKernelGGL((xengine_kernel<C>), dim3(XE_GRID * C::WPC), dim3(C::NWV * 64), smem, st, E->args);
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
 }
@@ -1150,6 +1205,10 @@ int xengine_steps(XEngineHost* E, hipStream_t st, int32_t* d_state, uint16_t* x_
     int rc;
     if (E->shape_class == 3) /* the default instantiations only (no tuning variants, no stamps) */
         rc = a.n_seq > XE_NXCD ? xengine_go<XC3<8, 4, false, 2, 1>>(E, st) : xengine_go<XC3<12, 6, false, 1>>(E, st);
+    else if (E->shape_class == 4)
+        rc = xengine_go<XC4>(E, st);
+    else if (E->shape_class == 5)
+        rc = xengine_go<XC5>(E, st);
     else
         rc = E->shape_class == 1 ? xengine_go_shape<XC1>(E, st) : xengine_go_shape<XC2>(E, st);
     a.head_w = save.head_w;
@@ -1187,6 +1246,10 @@ int xengine_reset(XEngineHost* E, hipStream_t st) {
 void xengine_set_variant(XEngineHost* E, int nwv, int depth) {
     if (nwv == 0) { /* tuning hook: depth = the stagger of the second decoder in microseconds */
         E->args.stagger_us = depth;
+        return;
+    }
+    if (nwv == -1) { /* tuning hook: depth = XArgs::deal_wl (0: the default of the form) */
+        E->deal_wl = depth;
         return;
     }
     E->nwv = nwv, E->depth = depth;

@@ -16,6 +16,9 @@ CONFIGS = {
     "qwen3-0.6b": dict(dim=1024, n_layer=28, n_head=16, n_kv=8, head_dim=128, ffn=3072, vocab=151936, max_seq=2048, theta=1e6, tied=True),
     # Qwen3-1.7B: the 0.6B head geometry (16 / 8 heads of 128) on a 2048-wide stream, ffn 6144; tied embeddings
     "qwen3-1.7b": dict(dim=2048, n_layer=28, n_head=16, n_kv=8, head_dim=128, ffn=6144, vocab=151936, max_seq=2048, theta=1e6, tied=True),
+    # Qwen3-4B / Qwen3-8B (cases/tutorial/history.md:4-6): 32 query heads on 8 kv-heads (GQA-4)
+    "qwen3-4b": dict(dim=2560, n_layer=36, n_head=32, n_kv=8, head_dim=128, ffn=9728, vocab=151936, max_seq=2048, theta=1e6, tied=True),
+    "qwen3-8b": dict(dim=4096, n_layer=36, n_head=32, n_kv=8, head_dim=128, ffn=12288, vocab=151936, max_seq=2048, theta=1e6, tied=False),
     # Qwen3-32B
     "qwen3-32b": dict(dim=5120, n_layer=64, n_head=64, n_kv=8, head_dim=128, ffn=25600, vocab=151936, max_seq=4096, theta=1e6, tied=False),
     # small shapes for parity tests (same structure: GQA group 2, head_dim 128 / 64)

@@ -5,7 +5,7 @@ Call it once after koifish_amd.load(); a script that times `bench.py` in a child
 import ctypes as C
 import os
 
-_MAP = {"KF_Q4_PERM": "q4_perm", "KF_Q2_TAB": "q2_tab", "KF_Q1_TAB": "q1_tab", "KF_GEMV_WAVES": "gemv_waves", "KF_GEMV_STREAM": "gemv_stream", "KF_GEMM_MIN": "gemm_min", "KF_G3_TILES": "g3_tiles", "KF_G3_FIRST": "g3_first", "KF_RESIDENT_MIN": "resident_min", "KF_ATTN_PAIR_MIN": "attn_pair_min", "KF_G3_WIDE": "g3_wide", "KF_G3_MID_MIN": "g3_mid_min", "KF_ATTN_GQ_SPLIT": "attn_gq_split"}
+_MAP = {"KF_Q4_PERM": "q4_perm", "KF_Q2_TAB": "q2_tab", "KF_Q1_TAB": "q1_tab", "KF_GEMV_WAVES": "gemv_waves", "KF_GEMV_STREAM": "gemv_stream", "KF_GEMV_XF2": "gemv_xf2", "KF_GEMM_MIN": "gemm_min", "KF_G3_TILES": "g3_tiles", "KF_G3_FIRST": "g3_first", "KF_RESIDENT_MIN": "resident_min", "KF_ATTN_PAIR_MIN": "attn_pair_min", "KF_G3_WIDE": "g3_wide", "KF_G3_MID_MIN": "g3_mid_min", "KF_ATTN_GQ_SPLIT": "attn_gq_split"}
 
 
 def apply(hip, env=None):

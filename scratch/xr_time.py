@@ -1,6 +1,6 @@
 """Eight XCD-confined decoders (kf_xengine_*) on Qwen3-0.6B 4-bit: aggregate tokens/s at a position range, per variant (waves per workgroup x ring depth), n_seq sweep,
 and the per-phase stamps of one workgroup.
-  python scratch/xr_time.py [pos0=2028] [steps=20]      env: VARIANTS="9x8,13x6,16x4,9x12"  NSEQ="8,4,1"  STAMPS=1"""
+  python scratch/xr_time.py [pos0=2028] [steps=20]      env: VARIANTS="9x8,13x6,16x4,9x12"  NSEQ="8,4,1"  STAMPS=1  DEAL="0,8,11,16" (xe_first_slot's weight, 0 = default)"""
 import os
 import sys
 import time
@@ -27,8 +27,9 @@ for n_seq in [int(x) for x in os.environ.get("NSEQ", "8").split(",")]:
         f[:128] = np.random.default_rng(7 + s).integers(0, cfg["vocab"], size=128)
         xr.set_forced(s, f)
     bytes_step = m.step_bytes(pos0 + steps // 2)
-    for (nwv, depth) in variants:
+    for (nwv, depth, deal) in [(v[0], v[1], int(d)) for v in variants for d in os.environ.get("DEAL", "0").split(",")]:
         xr.variant(nwv, depth)
+        xr.variant(-1, deal)
         for s in range(n_seq):   # the K / V rows below pos0 hold whatever earlier runs left (zeros at first): the arithmetic does not care
             xr.set_state(s, 1 + s, pos0 - 4)
         xr.run_steps(4)
@@ -45,10 +46,11 @@ for n_seq in [int(x) for x in os.environ.get("NSEQ", "8").split(",")]:
             best = min(best, time.perf_counter() - t0)
         xr.check()
         tps = n_seq * steps / best
-        print("n_seq %d  waves %2d depth %2d  positions %d..%d: %.3f ms per step (all sequences), %.1f tokens/s aggregate, %.1f per sequence, %.1f GB/s = %.3f of 8 TB/s" % (
-            n_seq, nwv, depth, pos0, pos0 + steps - 1, best * 1e3 / steps, tps, tps / n_seq, bytes_step * tps / 1e9, bytes_step * tps / 8e12), flush=True)
+        print("n_seq %d  waves %2d depth %2d deal %2d  positions %d..%d: %.3f ms per step (all sequences), %.1f tokens/s aggregate, %.1f per sequence, %.1f GB/s = %.3f of 8 TB/s" % (
+            n_seq, nwv, depth, deal, pos0, pos0 + steps - 1, best * 1e3 / steps, tps, tps / n_seq, bytes_step * tps / 1e9, bytes_step * tps / 8e12), flush=True)
     if os.environ.get("STAMPS") and n_seq in (8, 16):
         xr.variant(9, 8) if n_seq == 8 else xr.variant(8, 8)
+        xr.variant(-1, int(os.environ.get("STAMP_DEAL", "0")))
         nl = cfg["n_layer"]
         xr.stamps(int(os.environ.get("STAMP_SEQ", "3")), int(os.environ.get("STAMP_WG", "5")), 2, nl)
         for s in range(n_seq):

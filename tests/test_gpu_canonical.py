@@ -49,6 +49,29 @@ def test_matvec_is_bit_exact(cctx, canon, type_name, m, k):
     assert np.array_equal(y, ref), "%s %dx%d: %d of %d outputs differ" % (type_name, m, k, int((y != ref).sum()), m)
 
 
+@pytest.mark.parametrize("m,k", [(96, 25600), (160, 16384), (2, 25600), (5120, 25600)])
+def test_long_4bit_rows_through_two_fp32_windows_are_bit_exact(cctx, canon, m, k):
+    """4-bit rows too long for fp32 activations in 48 KiB of LDS (the 25600-wide down_proj of Qwen3-32B): half the block columns staged at a time, the lane's chains
+    continued over the second window (gemv_kernel, XF2) -- every output equals the oracle's, and equals the form with bf16 activations widened per product (knob off)"""
+    import ctypes as C
+    ctx = cctx
+    rng = np.random.default_rng(m + k)
+    w = O.f32_to_bf16(rng.normal(0, 0.05, size=(m, k)).astype(np.float32))
+    x = O.f32_to_bf16(rng.normal(0, 1.0, size=k).astype(np.float32))
+    ow = O.quantize(w, m, k, L.Q4)
+    dw = ctx.upload_blob(L.Q4, m, k, ow.blob())
+    y = u16(ctx.linear(dw, bf16_t(x, ctx.device)))
+    ref = O.linear(ow, x)
+    assert np.array_equal(y, ref), "%dx%d: %d of %d outputs differ" % (m, k, int((y != ref).sum()), m)
+    ctx.hip.kfdbg_set_knob.argtypes = [C.c_char_p, C.c_long]
+    assert ctx.hip.kfdbg_set_knob(b"gemv_xf2", 0) == 0
+    try:
+        y0 = u16(ctx.linear(dw, bf16_t(x, ctx.device)))
+    finally:
+        ctx.hip.kfdbg_set_knob(b"gemv_xf2", 1)
+    assert np.array_equal(y0, ref)
+
+
 def test_fused_entries_are_bit_exact(cctx, canon):
     """fused RMSNorm + Q|K|V (rows of the launch = all three matrices), paired gate / up + SwiGLU, LM head + arg-max"""
     ctx = cctx

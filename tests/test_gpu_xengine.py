@@ -237,3 +237,51 @@ def test_qwen3_1p7b_shape_equals_the_oracle(canon):
         assert np.array_equal(gk[:, :n_steps], ok[:, :n_steps]) and np.array_equal(gv[:, :n_steps], ov[:, :n_steps])
     xr.close()
     m.close()
+
+
+GQA4_SHAPES = {  # cases/tutorial/history.md:4-6 -- the models the reference lists beside 0.6B / 1.7B / 32B
+    "qwen3-4b": dict(dim=2560, n_layer=3, n_head=32, n_kv=8, head_dim=128, ffn=9728, vocab=4096, max_seq=160, theta=1e6, tied=True),
+    "qwen3-8b": dict(dim=4096, n_layer=3, n_head=32, n_kv=8, head_dim=128, ffn=12288, vocab=4096, max_seq=160, theta=1e6, tied=True),
+}
+
+
+@pytest.mark.parametrize("name", ["qwen3-4b", "qwen3-8b"])
+def test_gqa4_shapes_equal_the_per_layer_launches_and_the_oracle(canon, name):
+    """three layers of the Qwen3-4B / Qwen3-8B shapes (32 query heads on 8 kv-heads: four query heads per key tile; 24 of the 32 workgroups own q | k | v rows; the 9728- /
+    12288-wide SwiGLU vector staged in pieces; 8B: the attention sums inside the second activation buffer) through the XCD-confined engines: eight sequences, ids at every
+    position, last logits and K / V rows against the oracle; sequence 0 also through the per-layer launches of the same library"""
+    cfg = dict(GQA4_SHAPES[name])
+    raw = synth.raw_weights_numpy(cfg, 4040, w_std=0.04)
+    m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
+    m.set_canonical(True)
+    n_seq, n_steps = 8, 90
+    xr = XcdReplicas(m, n_seq)
+    forced = []
+    for s in range(n_seq):
+        f = np.full(160, -1, dtype=np.int32)
+        f[:9 + 2 * s] = prompt_ids(cfg, 9 + 2 * s, seed=70 + s)
+        forced.append(f)
+        xr.set_forced(s, f)
+        xr.set_state(s, int(f[0]), 0)
+    xr.set_steps_per_launch(16)
+    xr.run_steps(n_steps)
+    m.sync()
+    xr.check()
+    for s in (0, 2, 5, 7):
+        o_ids, o_logits, ok, ov = _oracle_run(cfg, raw, forced[s], n_steps)
+        assert xr.tokens_out(s, n_steps).tolist() == o_ids, "sequence %d" % s
+        assert np.array_equal(xr.logits(s), o_logits)
+        gk, gv = xr.kv_to_host(s)
+        assert np.array_equal(gk[:, :n_steps], ok[:, :n_steps]) and np.array_equal(gv[:, :n_steps], ov[:, :n_steps])
+        if s == 0:
+            ids0, logits0 = o_ids, o_logits
+    xr.close()
+    # the per-layer launches (no persistent engine serves these shapes): the same ids and logits
+    m.set_forced(forced[0])
+    m.set_state(int(forced[0][0]), 0)
+    for p in range(n_steps):
+        m.run_steps(p, 1, use_graph=False)
+    m.sync()
+    assert m.tokens_out(n_steps)[:n_steps].tolist() == ids0
+    assert np.array_equal(m.logits(), logits0)
+    m.close()
