@@ -57,8 +57,10 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     constexpr bool XF2 = XF2_ && XF && G == 1 && !PAIRED && !SPARSE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);
-    const int it_half = XF2 ? (a.iters + 1) >> 1 : a.iters;               /* iterations against the first window */
-    const int wcols = XF2 ? it_half << a.lpr_log2 : a.nBlk;               /* block columns of a window = the chunk stride of the staged activations */
+    constexpr int RD = 4; /* XF2: a ring of four steps in flight per wave (25 steps per row behind ONE step of prefetch left the launch latency-bound: 1.7 TB/s) */
+    const int it_half = XF2 ? (a.iters >> 1) / RD * RD : a.iters;        /* iterations against the first window: whole ring rounds */
+    const int wcols = XF2 ? (a.iters - it_half) << a.lpr_log2 : a.nBlk;   /* block columns of the (larger, second) window = the chunk stride of the staged activations */
+    const int wcol0 = it_half << a.lpr_log2;                              /* first block column of the second window */
     double* red = reinterpret_cast<double*>(smem_raw + (XF2 ? (size_t)wcols * 128 : (size_t)a.K * (XF ? 4 : 2)));
 
     const int tid = threadIdx.x, lane = tid & 63, wave_in_blk = tid >> 6;
@@ -213,7 +215,11 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
     }
 
     Batch<G, PAIRED, LUT> cur, nxt;
-    if (stream) {
+    [[maybe_unused]] Batch<G, PAIRED, LUT> ring[XF2 ? RD : 1];
+    if constexpr (XF2) {
+#pragma unroll
+        for (int d = 0; d < RD; d++) load(0, d < iters ? d : iters - 1, ring[d]);
+    } else if (stream) {
         if (nsteps > 0) sload(0, 0, cur);
     } else if (LAT || nsteps > 0) {
         load(0, 0, cur); /* LAT: waves without work re-read row 0 */
@@ -273,7 +279,7 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
                 mul = 1.0f / sqrtf(val);
             }
             // element e of block column c, chunk j (e = c*EPB + j*8 + i)  ->  LDS chunk (j*nBlk + c)
-            const int nch_w = XF2 ? (wcols * XCH < nch ? wcols * XCH : nch) : nch; /* XF2: the first window (the launcher takes this form only without a norm) */
+            const int nch_w = XF2 ? wcol0 * XCH : nch; /* XF2: the first window (the launcher takes this form only without a norm) */
             for (int e8 = tid; e8 < nch_w; e8 += blockDim.x) {
                 const int c = e8 / XCH, j = e8 - c * XCH;
                 const u32x4 raw = *reinterpret_cast<const u32x4*>(a.x + (size_t)e8 * 8);
@@ -329,7 +335,7 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
                 } else {
                     const float st = bf2f(bt.st[g]);
                     Acc r;
-                    if constexpr (XF2) r = BlockDotF<FMT>::run(bt.w[g], reinterpret_cast<const f32x4*>(xs), it >= it_half ? col - wcols : col, wcols, st, bf2f(bt.ze[g]), -(jqb * st), acc[g]);
+                    if constexpr (XF2) r = BlockDotF<FMT>::run(bt.w[g], reinterpret_cast<const f32x4*>(xs), it >= it_half ? col - wcol0 : col, wcols, st, bf2f(bt.ze[g]), -(jqb * st), acc[g]);
                     else if constexpr (XF) r = BlockDotF<FMT>::run(bt.w[g], reinterpret_cast<const f32x4*>(xs), col, nBlk, st, bf2f(bt.ze[g]), -(jqb * st), acc[g]);
                     else r = BD::run(bt.w[g], xs, col, nBlk, st, bf2f(bt.ze[g]), -(jqb * st), acc[g]);
                     acc[g] = acc_pick(ok, r, acc[g]);
@@ -403,26 +409,24 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvArgs a) {
             compute(nxt);
         }
     } else if constexpr (XF2) { /* one row slot per wave (nsteps = iters, or 0 for a wave past the last slot: it still meets the two barriers) */
-        auto run = [&](int k0, int k1) {
-            for (int k = k0; k < k1; k++) {
-                if (k + 1 < nsteps) {
-                    if (++nit == iters) nit = 0, nbi++;
-                    load(nbi, nit, nxt);
+        auto run = [&](int k0, int k1) { /* k0: a multiple of RD */
+            for (int k = k0; k < k1; k += RD) {
+#pragma unroll
+                for (int d = 0; d < RD; d++) {
+                    if (k + d < k1) compute(ring[d]);
+                    load(0, k + d + RD < iters ? k + d + RD : iters - 1, ring[d]); /* unconditional (a request behind a branch turns the waits into drains); past the row: its last step again */
                 }
-                compute(cur);
-                cur = nxt;
             }
         };
         run(0, nsteps < it_half ? nsteps : it_half);
         __syncthreads(); /* every wave has read the first window for the last time */
         {
             constexpr int XCH = BD::XCH;
-            const int e8_0 = wcols * XCH;
-            for (int e8 = e8_0 + tid; e8 < nch; e8 += blockDim.x) {
-                const int c = e8 / XCH, j = e8 - c * XCH;
+            for (int e8 = wcol0 * XCH + tid; e8 < nch; e8 += blockDim.x) {
+                const int c = e8 / XCH - wcol0, j = e8 % XCH;
                 const u32x4 o = *reinterpret_cast<const u32x4*>(a.x + (size_t)e8 * 8);
-                xs[(2 * j) * wcols + (c - wcols)] = u32x4{o.x << 16, o.x & 0xffff0000u, o.y << 16, o.y & 0xffff0000u};
-                xs[(2 * j + 1) * wcols + (c - wcols)] = u32x4{o.z << 16, o.z & 0xffff0000u, o.w << 16, o.w & 0xffff0000u};
+                xs[(2 * j) * wcols + c] = u32x4{o.x << 16, o.x & 0xffff0000u, o.y << 16, o.y & 0xffff0000u};
+                xs[(2 * j + 1) * wcols + c] = u32x4{o.z << 16, o.z & 0xffff0000u, o.w << 16, o.w & 0xffff0000u};
             }
         }
         __syncthreads();
@@ -587,8 +591,9 @@ static void launch_j(const GemvArgs& a, int G, dim3 grid, size_t smem, hipStream
             return;
         }
         if constexpr (MODE == GEMV_PLAIN && !SPARSE && ONEJOB) { /* longer rows, one row slot per wave, no norm in front: half the block columns at a time (XF2) */
-            const size_t smem_2 = (size_t)(((a.iters + 1) >> 1) << a.lpr_log2) * 128 + 256;
-            if (G == 1 && a.spw == 1 && !a.norm_w && a.iters >= 2 && smem_2 <= 54 * 1024 && g_knobs.gemv_xf2 != 0) { /* 54 KiB: three workgroups per CU */
+            const int it_half = (a.iters >> 1) / 4 * 4; /* = the kernel's: whole rounds of its four-step ring against the first window */
+            const size_t smem_2 = (size_t)((a.iters - it_half) << a.lpr_log2) * 128 + 256;
+            if (G == 1 && a.spw == 1 && !a.norm_w && it_half >= 4 && smem_2 <= 54 * 1024 && g_knobs.gemv_xf2 != 0) { /* 54 KiB: three workgroups per CU */
                 hipLaunchKernelGGL((gemv_kernel<FMT, 1, MODE, SPARSE, ONEJOB, GEMV_CANON, true, true>), grid, dim3(256), smem_2, st, a);
                 return;
             }

@@ -1025,6 +1025,8 @@ using XC2 = XCfg<FMT_Q4P, 2, 64, NWV, 256, 256, 128, 512, DEPTH, DBG, WPC, AU>;
 // the GQA-4 shapes: one decoder per XCD, 8 waves (two per SIMD: 256 registers -- the attention sums of four query heads are 36 fp64 values per lane)
 using XC4 = XCfg<FMT_Q4P, 4, 128, 8, 2560, 4096, 1024, 9728, 8, false, 1, 2>;
 using XC5 = XCfg<FMT_Q4P, 4, 128, 8, 4096, 4096, 1024, 12288, 8, false, 1, 2>;
+using XC4W = XCfg<FMT_Q4P, 4, 128, 12, 2560, 4096, 1024, 9728, 6, false, 1, 1>; /* 11 compute waves at 168 registers: the attention loop spills, the mat-vec phases (nine tenths of the bytes) have the waves */
+using XC5W = XCfg<FMT_Q4P, 4, 128, 12, 4096, 4096, 1024, 12288, 6, false, 1, 1>;
 static int xe_loc_dw(int shape_class) {
     switch (shape_class) {
         case 1: return XC1<9, 8, false, 1>::loc_dw;
@@ -1206,9 +1208,9 @@ int xengine_steps(XEngineHost* E, hipStream_t st, int32_t* d_state, uint16_t* x_
     if (E->shape_class == 3) /* the default instantiations only (no tuning variants, no stamps) */
         rc = a.n_seq > XE_NXCD ? xengine_go<XC3<8, 4, false, 2, 1>>(E, st) : xengine_go<XC3<12, 6, false, 1>>(E, st);
     else if (E->shape_class == 4)
-        rc = xengine_go<XC4>(E, st);
+        rc = E->nwv == 8 ? xengine_go<XC4>(E, st) : xengine_go<XC4W>(E, st);
     else if (E->shape_class == 5)
-        rc = xengine_go<XC5>(E, st);
+        rc = E->nwv == 8 ? xengine_go<XC5>(E, st) : xengine_go<XC5W>(E, st);
     else
         rc = E->shape_class == 1 ? xengine_go_shape<XC1>(E, st) : xengine_go_shape<XC2>(E, st);
     a.head_w = save.head_w;

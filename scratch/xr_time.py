@@ -1,6 +1,6 @@
 """Eight XCD-confined decoders (kf_xengine_*) on Qwen3-0.6B 4-bit: aggregate tokens/s at a position range, per variant (waves per workgroup x ring depth), n_seq sweep,
 and the per-phase stamps of one workgroup.
-  python scratch/xr_time.py [pos0=2028] [steps=20]      env: VARIANTS="9x8,13x6,16x4,9x12"  NSEQ="8,4,1"  STAMPS=1  DEAL="0,8,11,16" (xe_first_slot's weight, 0 = default)"""
+  python scratch/xr_time.py [pos0=2028] [steps=20]      env: VARIANTS="9x8,13x6,16x4,9x12"  NSEQ="8,4,1"  STAMPS=1  DEAL="0,8,11,16" (xe_deal's weight, 0 = default)  CONFIG=qwen3-4b"""
 import os
 import sys
 import time
@@ -15,7 +15,7 @@ from koifish_amd.runtime import XcdReplicas
 
 pos0 = int(sys.argv[1]) if len(sys.argv) > 1 else 2028
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-cfg = dict(synth.CONFIGS["qwen3-0.6b"])
+cfg = dict(synth.CONFIGS[os.environ.get("CONFIG", "qwen3-0.6b")])
 m = synth.build_on_gpu(cfg, seed=1234, layer_type=L.Q4, head_type=L.BF16)
 m.set_canonical(True)
 S = cfg["max_seq"]

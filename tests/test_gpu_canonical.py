@@ -49,7 +49,7 @@ def test_matvec_is_bit_exact(cctx, canon, type_name, m, k):
     assert np.array_equal(y, ref), "%s %dx%d: %d of %d outputs differ" % (type_name, m, k, int((y != ref).sum()), m)
 
 
-@pytest.mark.parametrize("m,k", [(96, 25600), (160, 16384), (2, 25600), (5120, 25600)])
+@pytest.mark.parametrize("m,k", [(96, 25600), (160, 16384), (2, 25600), (2048, 25600), (5120, 25600)])
 def test_long_4bit_rows_through_two_fp32_windows_are_bit_exact(cctx, canon, m, k):
     """4-bit rows too long for fp32 activations in 48 KiB of LDS (the 25600-wide down_proj of Qwen3-32B): half the block columns staged at a time, the lane's chains
     continued over the second window (gemv_kernel, XF2) -- every output equals the oracle's, and equals the form with bf16 activations widened per product (knob off)"""

@@ -245,11 +245,12 @@ GQA4_SHAPES = {  # cases/tutorial/history.md:4-6 -- the models the reference lis
 }
 
 
-@pytest.mark.parametrize("name", ["qwen3-4b", "qwen3-8b"])
-def test_gqa4_shapes_equal_the_per_layer_launches_and_the_oracle(canon, name):
+@pytest.mark.parametrize("name,variant", [("qwen3-4b", None), ("qwen3-8b", None), ("qwen3-4b", (8, 8))])
+def test_gqa4_shapes_equal_the_per_layer_launches_and_the_oracle(canon, name, variant):
     """three layers of the Qwen3-4B / Qwen3-8B shapes (32 query heads on 8 kv-heads: four query heads per key tile; 24 of the 32 workgroups own q | k | v rows; the 9728- /
     12288-wide SwiGLU vector staged in pieces; 8B: the attention sums inside the second activation buffer) through the XCD-confined engines: eight sequences, ids at every
-    position, last logits and K / V rows against the oracle; sequence 0 also through the per-layer launches of the same library"""
+    position, last logits and K / V rows against the oracle; sequence 0 also through the per-layer launches of the same library.  variant: the 8-wave form (256 registers,
+    contiguous row runs per wave) instead of the default 12-wave one"""
     cfg = dict(GQA4_SHAPES[name])
     raw = synth.raw_weights_numpy(cfg, 4040, w_std=0.04)
     m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
@@ -264,6 +265,8 @@ def test_gqa4_shapes_equal_the_per_layer_launches_and_the_oracle(canon, name):
         xr.set_forced(s, f)
         xr.set_state(s, int(f[0]), 0)
     xr.set_steps_per_launch(16)
+    if variant:
+        xr.variant(*variant)
     xr.run_steps(n_steps)
     m.sync()
     xr.check()
