@@ -64,8 +64,8 @@ struct XArgs {
 
 // error word bits: 1 x, 2 q|k|v, 4 partials, 8 workgroups per XCD != 32, 16 pick, 32 token granule, 64 position beyond the cache, 128 ao, 256 xB, 512 act, 1024 head x
 
-constexpr int xe_p1_wgs(int dim, int epb, int qd, int kvd) { /* the most workgroups (of 32, 24, 16, 8) whose equal pieces of the q | k | v row slots do not straddle a matrix */
-    for (int w = 32; w >= 8; w -= 8) {
+constexpr int xe_p1_wgs(int dim, int epb, int qd, int kvd) { /* the most workgroups (32 ... 8) whose equal pieces of the q | k | v row slots do not straddle a matrix */
+    for (int w = 32; w >= 8; w--) {
         const CPlan p = c_plan(dim, epb, qd, kvd, kvd, false, w);
         if (p.total == w * p.spg && p.slot0[1] % p.spg == 0 && p.slot0[2] % p.spg == 0) return w;
     }
@@ -80,8 +80,11 @@ struct XCfg {
     static constexpr bool DBG = DBG_;
     static_assert(FMT_ == FMT_Q4 || FMT_ == FMT_Q4P, "4-bit PackedQ layers (arithmetic or register-table unpack)");
     static constexpr int n_head = QD_ / HD_, n_kv = KVD_ / HD_;
-    static_assert(XE_NWG % n_kv == 0, "whole workgroups per kv-head");
-    static constexpr int SPK = XE_NWG / n_kv; /* key slices (= workgroups) per kv-head */
+    // more than four query heads per kv-head (a TP rank of Qwen3-32B: 8 on 1): NG groups of GQW heads, each group its own workgroups over the same key slices (the fp64 sums
+    // of eight heads would be 144 registers per lane) -- K / V rows are then read NG times, from this XCD's L2
+    static constexpr int NG = GQ_ > 4 ? GQ_ / 4 : 1, GQW = GQ_ / NG;
+    static_assert(GQ_ % NG == 0 && XE_NWG % (n_kv * NG) == 0, "whole workgroups per kv-head and head group");
+    static constexpr int SPK = XE_NWG / (n_kv * NG); /* key slices (= workgroups) per kv-head and head group */
     // q | k | v rows: a workgroup's rows belong to ONE of the three matrices.  With 16 / 8 heads the 32 workgroups cut the row slots that way; the GQA-4 shapes (32 / 8 heads:
     // 4 + 1 + 1 parts) do with 24 workgroups -- the other eight own no row of this phase (a fifth of a layer's weights at three quarters of the workgroups)
     static constexpr int P1W = xe_p1_wgs(DIM_, eng_vepb<FMT_>(), QD_, KVD_);
@@ -100,8 +103,8 @@ struct XCfg {
     // the waves' attention sums (fp64, [NCW][GQ][hd + 2]) in the second activation buffer when the two would not fit side by side (Qwen3-8B: 2 x 48 KB of activations): the
     // buffer is idle between the barrier in front of q | k | v (down_proj of the layer before has read it) and the staging of the attention output, which waits for every
     // slice partial of the XCD -- so for this workgroup's, written after the last read of the sums
-    static constexpr bool COMB_IN_XS1 = (size_t)maxKc * 8 + (size_t)DIM_ * 4 + sizeof(double) * (size_t)(NWV_ - 1) * GQ_ * (HD_ + 2) > 140 * 1024;
-    static_assert(!COMB_IN_XS1 || sizeof(double) * (size_t)(NWV_ - 1) * GQ_ * (HD_ + 2) <= (size_t)maxKc * 4, "the sums fit the buffer");
+    static constexpr bool COMB_IN_XS1 = (size_t)maxKc * 8 + (size_t)DIM_ * 4 + sizeof(double) * (size_t)(NWV_ - 1) * GQW * (HD_ + 2) > 140 * 1024;
+    static_assert(!COMB_IN_XS1 || sizeof(double) * (size_t)(NWV_ - 1) * GQW * (HD_ + 2) <= (size_t)maxKc * 4, "the sums fit the buffer");
     static constexpr int XS = maxKc / 32; /* chunk stride of the staged activations (16-byte units): chunk j of block column c at [j * XS + c], whatever the phase's width */
     // every phase in whole rows and whole iterations: no masks at the multiply
     static constexpr bool EXACT = (QD_ + 2 * KVD_) % SH::P1::RPS == 0 && KVD_ % SH::P1::RPS == 0 && QD_ % SH::P1::RPS == 0 && DIM_ % SH::P4::RPS == 0 && FFN_ % SH::P5::RPS == 0 && DIM_ % SH::P6::RPS == 0 &&
@@ -132,7 +135,7 @@ struct XLds {
 struct XSeq { /* this workgroup's place in its decoder, and the step's slice */
     int seq, r, step;
     int pos, len, kvh, split, h0, t0, t1, me0;
-    bool empty, own_new, stamp;
+    bool empty, own_new, stamp, grp0; /* grp0: the first head group of its kv-head (it writes the new K / V row) */
     int j1, s1, M1, q_out0;
     long long kv_off; /* elements: this sequence's K/V cache behind sequence 0's */
 };
@@ -363,7 +366,7 @@ __device__ __forceinline__ void xe_attn_issue(const XArgs& a, const EngLayer& ly
 // compute waves only (the poller meets the three barriers in xe_poller_main).  p4_fill: requests the first o_proj blocks, called when the last batch's tiles are in registers
 template <class C, typename Fill>
 __device__ __forceinline__ void xe_attn_phase(const XArgs& a, const XLds& L, const XSeq& S, const EngLayer& ly, uint32_t gen, int cw, int lane, XAttn<C>& T, int l, Fill&& p4_fill) {
-    constexpr int GQ = C::GQ, hd = C::HD, hd_log2 = C::HD == 128 ? 7 : 6, LPK = hd >> 3, KPW = 64 / LPK, lpk_log2 = hd_log2 - 3, NWA = C::NCW, U = XAttn<C>::U;
+    constexpr int GQ = C::GQW /* the heads of this workgroup's group */, hd = C::HD, hd_log2 = C::HD == 128 ? 7 : 6, LPK = hd >> 3, KPW = 64 / LPK, lpk_log2 = hd_log2 - 3, NWA = C::NCW, U = XAttn<C>::U;
     constexpr int NQ = (GQ + NWA - 1) / NWA;
     const int tid = (cw << 6) | lane, pos = S.pos, t1 = S.t1;
     const int grp = lane >> lpk_log2, d0 = (lane & (LPK - 1)) * 8;
@@ -392,7 +395,7 @@ __device__ __forceinline__ void xe_attn_phase(const XArgs& a, const XLds& L, con
     }
     __syncthreads(); /* heads prepared */
     if (!S.empty) {
-        if (S.own_new && tid < hd / 8) { /* the cache rows of this position: the prepared key, the raw value (K.out / V.out alias them in the reference) */
+        if (S.own_new && S.grp0 && tid < hd / 8) { /* the cache rows of this position: the prepared key, the raw value (K.out / V.out alias them in the reference) */
             g_u16w krow = ly.kcache + (size_t)S.kv_off + (size_t)pos * a.kv_stride + (size_t)S.kvh * hd;
             g_u16w vrow = ly.vcache + (size_t)S.kv_off + (size_t)pos * a.kv_stride + (size_t)S.kvh * hd;
             *reinterpret_cast<u32x4 KF_GLOBAL*>(const_cast<uint16_t KF_GLOBAL*>(krow) + 8 * tid) = *reinterpret_cast<const u32x4*>(L.knew + 8 * tid);
@@ -471,7 +474,7 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, co
     using P4 = typename SH::P4;
     using P5 = typename SH::P5;
     using P6 = typename SH::P6;
-    constexpr int GQ = C::GQ, hd = C::HD, XCH = C::XCH;
+    constexpr int GQ = C::GQW, hd = C::HD, XCH = C::XCH;
     constexpr int ND = C::DIM / 256, NQD = C::QD / 256, NF = C::FFN / 256;
     static_assert(C::DIM % 256 == 0 && C::QD % 256 == 0 && C::FFN % 256 == 0, "hand-off vectors in 1 KiB pieces");
     uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)S.seq * a.loc_stride);
@@ -684,7 +687,7 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
         const EngLayer& lyn = L.lay[last ? l : l + 1];
         if (!S.empty) { /* q-norm (waves that prepare a q head) / k-norm (the wave that prepares the new key) weights of this lane's pair */
             const int half = C::HD >> 1, j = lane < half ? lane : half - 1;
-            g_u16 np = cw < C::GQ ? ly.norm_q : ly.norm_k;
+            g_u16 np = cw < C::GQW ? ly.norm_q : ly.norm_k;
             T.nw0 = T.nw1 = 0;
             if (np) T.nw0 = np[j], T.nw1 = np[j + half];
         }
@@ -883,7 +886,7 @@ __device__ __forceinline__ void xe_head_main(const XArgs& a, const XLds& L, cons
 
 template <class C>
 __global__ void __launch_bounds__(C::NWV * 64, (C::NWV * C::WPC + 3) / 4 /* waves per SIMD: the register budget that lets WPC workgroups share a CU */) xengine_kernel(const XArgs a) {
-    constexpr int hd = C::HD, GQ = C::GQ, NWV = C::NWV, NCW = C::NCW;
+    constexpr int hd = C::HD, GQ = C::GQW, NWV = C::NWV, NCW = C::NCW;
     using P1 = typename C::SH::P1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -965,7 +968,11 @@ __global__ void __launch_bounds__(C::NWV * 64, (C::NWV * C::WPC + 3) / 4 /* wave
         S.M1 = S.j1 == 0 ? P1::M0 : (S.j1 == 1 ? P1::M1 : P1::M2);
         S.q_out0 = (S.j1 == 0 ? 0 : (S.j1 == 1 ? C::QD : C::QD + C::KVD)) + S.s1 * P1::RPS;
     }
-    S.kvh = S.r / C::SPK, S.split = S.r - S.kvh * C::SPK, S.h0 = S.kvh * GQ, S.me0 = S.r * C::ME;
+    {
+        const int per_kv = C::SPK * C::NG, idx = S.r % per_kv, grp = idx / C::SPK;
+        S.kvh = S.r / per_kv, S.split = idx - grp * C::SPK, S.h0 = S.kvh * C::GQ + grp * C::GQW, S.me0 = S.r * C::ME;
+        S.grp0 = grp == 0;
+    }
     const int pos0 = a.d_state[S.seq * 4 + 1];
     const int nst = a.n_steps > 1 ? a.n_steps : 1;
     if (pos0 < 0 || pos0 + nst > a.max_seq) { /* a position of this launch lies beyond the cache rows: refuse, loudly */
@@ -1014,6 +1021,7 @@ static int xe_shape_class(int GQ, int hd, int dim, int q_dim, int ffn) {
     if (GQ == 2 && hd == 128 && dim == 2048 && q_dim == 2048 && ffn == 6144) return 3;  /* Qwen3-1.7B: the streaming phases do not care how many blocks a lane walks */
     if (GQ == 4 && hd == 128 && dim == 2560 && q_dim == 4096 && ffn == 9728) return 4;  /* Qwen3-4B (32 / 8 heads; cases/tutorial/history.md:4-6) */
     if (GQ == 4 && hd == 128 && dim == 4096 && q_dim == 4096 && ffn == 12288) return 5; /* Qwen3-8B */
+    if (GQ == 8 && hd == 64 && dim == 256 && q_dim == 512 && ffn == 512) return 6;      /* parity-test shape: 8 query heads on ONE kv-head (two head groups), 20 workgroups with q | k | v rows */
     return 0;
 }
 template <int NWV, int DEPTH, bool DBG, int WPC, int AU = 2>
@@ -1025,6 +1033,7 @@ using XC2 = XCfg<FMT_Q4P, 2, 64, NWV, 256, 256, 128, 512, DEPTH, DBG, WPC, AU>;
 // the GQA-4 shapes: one decoder per XCD, 8 waves (two per SIMD: 256 registers -- the attention sums of four query heads are 36 fp64 values per lane)
 using XC4 = XCfg<FMT_Q4P, 4, 128, 8, 2560, 4096, 1024, 9728, 8, false, 1, 2>;
 using XC5 = XCfg<FMT_Q4P, 4, 128, 8, 4096, 4096, 1024, 12288, 8, false, 1, 2>;
+using XC6 = XCfg<FMT_Q4P, 8, 64, 12, 256, 512, 64, 512, 6, false, 1, 2>;
 using XC4W = XCfg<FMT_Q4P, 4, 128, 12, 2560, 4096, 1024, 9728, 6, false, 1, 1>; /* 11 compute waves at 168 registers: the attention loop spills, the mat-vec phases (nine tenths of the bytes) have the waves */
 using XC5W = XCfg<FMT_Q4P, 4, 128, 12, 4096, 4096, 1024, 12288, 6, false, 1, 1>;
 static int xe_loc_dw(int shape_class) {
@@ -1033,6 +1042,7 @@ static int xe_loc_dw(int shape_class) {
         case 3: return XC3<9, 8, false, 1>::loc_dw;
         case 4: return XC4::loc_dw;
         case 5: return XC5::loc_dw;
+        case 6: return XC6::loc_dw;
     }
     return XC2<9, 8, false, 1>::loc_dw;
 }
@@ -1071,7 +1081,7 @@ int xengine_build(const kf_engine_desc* d, int n_seq, long long kv_seq_stride, v
     *why = "model shape not instantiated for the XCD-confined engine: built for Qwen3-0.6B (dim 1024, 16/8 heads of 128, ffn 3072), Qwen3-1.7B (dim 2048, same heads, ffn 6144), Qwen3-4B "
            "(dim 2560, 32/8 heads, ffn 9728), Qwen3-8B (dim 4096, 32/8 heads, ffn 12288) and the 256-wide test shape";
     if (!sc) return KF_UNSUPPORTED_DATATYPE;
-    *why = "the GQA-4 shapes (Qwen3-4B / 8B) run one decoder per XCD: at most 8 sequences (two workgroups per CU would need 2 x 78 KB (2 x 98 KB) of activations in LDS)";
+    *why = "the GQA-4 / GQA-8 shapes (Qwen3-4B / 8B, the 8-on-1 test shape) run one decoder per XCD: at most 8 sequences (two workgroups per CU would need 2 x 78 KB (2 x 98 KB) of activations in LDS)";
     if (sc >= 4 && n_seq > XE_NXCD) return KF_UNSUPPORTED_DATATYPE;
     if (!dry && (ws_bytes < xengine_ws_bytes(d) || ((uintptr_t)ws & 255) != 0)) {
         *why = "workspace too small or not 256-byte aligned";
@@ -1142,7 +1152,7 @@ int xengine_build(const kf_engine_desc* d, int n_seq, long long kv_seq_stride, v
 }
 template <class C>
 static size_t xe_smem(int n_layer) {
-    constexpr int hd = C::HD, GQ = C::GQ, NCW = C::NCW;
+    constexpr int hd = C::HD, GQ = C::GQW, NCW = C::NCW;
     constexpr int maxK = C::DIM > C::QD ? (C::DIM > C::FFN ? C::DIM : C::FFN) : (C::QD > C::FFN ? C::QD : C::FFN);
     constexpr int xs_bytes = (maxK * 4 + 15) & ~15, xr_bytes = (C::DIM * 2 + 15) & ~15;
     constexpr size_t o_attn = (size_t)2 * xs_bytes + 2 * xr_bytes;
@@ -1211,6 +1221,8 @@ int xengine_steps(XEngineHost* E, hipStream_t st, int32_t* d_state, uint16_t* x_
         rc = E->nwv == 8 ? xengine_go<XC4>(E, st) : xengine_go<XC4W>(E, st);
     else if (E->shape_class == 5)
         rc = E->nwv == 8 ? xengine_go<XC5>(E, st) : xengine_go<XC5W>(E, st);
+    else if (E->shape_class == 6)
+        rc = xengine_go<XC6>(E, st);
     else
         rc = E->shape_class == 1 ? xengine_go_shape<XC1>(E, st) : xengine_go_shape<XC2>(E, st);
     a.head_w = save.head_w;

@@ -1,5 +1,3 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-CONFIG=qwen3-4b VARIANTS="12x6,8x8" NSEQ="8" timeout 900 python3 scratch/xr_time.py 2028 20 2>&1 | grep -v amdgpu.ids
-CONFIG=qwen3-8b VARIANTS="12x6,8x8" NSEQ="8" timeout 900 python3 scratch/xr_time.py 2028 20 2>&1 | grep -v amdgpu.ids
-timeout 1200 python -m pytest tests/test_gpu_xengine.py -x -q -k "gqa4" 2>&1 | tail -3
+timeout 1200 python -m pytest tests/test_gpu_xengine.py -x -q -k "eight_query_heads or small-320-150-8 or tiny-96" 2>&1 | tail -8

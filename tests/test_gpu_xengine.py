@@ -288,3 +288,33 @@ def test_gqa4_shapes_equal_the_per_layer_launches_and_the_oracle(canon, name, va
     assert m.tokens_out(n_steps)[:n_steps].tolist() == ids0
     assert np.array_equal(m.logits(), logits0)
     m.close()
+
+
+def test_eight_query_heads_on_one_kv_head(canon):
+    """8 query heads on ONE kv-head (the head geometry of a TP = 8 rank of Qwen3-32B) through the XCD-confined engines: the heads in two groups of four, each group's
+    workgroups over the same 16 key slices; 20 of the 32 workgroups own q | k | v rows (8 + 1 + 1 parts).  Eight sequences against the oracle: ids, last logits, K / V rows"""
+    cfg = dict(dim=256, n_layer=3, n_head=8, n_kv=1, head_dim=64, ffn=512, vocab=512, max_seq=700, theta=1e6, tied=True)
+    raw = synth.raw_weights_numpy(cfg, 8181, w_std=0.1)
+    m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
+    m.set_canonical(True)
+    n_seq, n_steps = 8, 400
+    xr = XcdReplicas(m, n_seq)
+    forced = []
+    for s in range(n_seq):
+        f = np.full(700, -1, dtype=np.int32)
+        f[:11 + 3 * s] = prompt_ids(cfg, 11 + 3 * s, seed=300 + s)
+        forced.append(f)
+        xr.set_forced(s, f)
+        xr.set_state(s, int(f[0]), 0)
+    xr.set_steps_per_launch(25)
+    xr.run_steps(n_steps)
+    m.sync()
+    xr.check()
+    for s in (0, 4, 7):
+        o_ids, o_logits, ok, ov = _oracle_run(cfg, raw, forced[s], n_steps)
+        assert xr.tokens_out(s, n_steps).tolist() == o_ids, "sequence %d" % s
+        assert np.array_equal(xr.logits(s), o_logits)
+        gk, gv = xr.kv_to_host(s)
+        assert np.array_equal(gk[:, :n_steps], ok[:, :n_steps]) and np.array_equal(gv[:, :n_steps], ov[:, :n_steps])
+    xr.close()
+    m.close()
