@@ -494,6 +494,15 @@ int kf_xengine_steps(kf_ctx* ctx, kf_xengine* e, kf_bf16* x_out, int32_t* d_stat
 int kf_xengine_check(kf_ctx* ctx, kf_xengine* e); /* synchronises; KF_INTERNAL_ERR when a hand-off poll has timed out since creation or the last kf_xengine_reset */
 int kf_xengine_reset(kf_ctx* ctx, kf_xengine* e);
 int kf_xengine_destroy(kf_xengine* e);
+/* Tensor parallel over the XCDs (round 5): ONE sequence of a model whose TP = 8 ranks (koifish_amd/tp.py TPPlan; the partitioning of SURVEY 8e) run as the eight XCDs of one
+ * launch -- rank r's 32 workgroups stream rank r's shards; q | k | v, the attention of the rank's kv-head and gate | up stay inside the XCD; the column shards (o_proj, down_proj)
+ * leave as fp32 partials into every rank's receive area (the {value | generation} protocol of kf_tp_*, inside the launch), summed in rank order: the bits of kf_tp_reduce_recv.
+ * Served: the ranks of Qwen3-32B (per rank: dim 5120, 8 / 1 heads of 128, ffn 3200), 4-bit PackedQ layers, bf16 embedding (replicated) and head (vocabulary shards).
+ * rank_descs[r]: rank r's layers (its shards, its kv-head's cache rows: kv_stride = 128).  kf_xengine_set_embedding / _steps / _check / _reset / _destroy as above with
+ * n_seq = 1 (d_state [4], x_out [dim]); logits: the FULL vector, the shards' rows in rank order.  No reference counterpart (QKV.cu:503 is single-GPU). */
+size_t kf_xengine_workspace_bytes_tp(const kf_engine_desc* rank0_desc);
+int kf_xengine_create_tp(kf_ctx* ctx, const kf_engine_desc* const* rank_descs, int world, void* workspace, size_t workspace_bytes, kf_xengine** out);
+int kf_xengine_set_head_tp(kf_ctx* ctx, kf_xengine* e, const kf_weight* const* head_shards, const int32_t* row0, const kf_bf16* final_norm_w, kf_bf16* logits, int32_t* d_tokens_out_or_null, int tokens_stride);
 
 #ifdef __cplusplus
 }

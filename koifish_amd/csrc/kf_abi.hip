@@ -1224,6 +1224,27 @@ int kf_xengine_create(kf_ctx* c, const kf_engine_desc* d, int n_seq, int64_t kv_
     *out = e;
     return KF_OK;
 }
+size_t kf_xengine_workspace_bytes_tp(const kf_engine_desc* d) { return d ? kf::xengine_ws_bytes_tp(d) : 0; }
+int kf_xengine_create_tp(kf_ctx* c, const kf_engine_desc* const* ds, int world, void* ws, size_t ws_bytes, kf_xengine** out) {
+    CHKCTX(c);
+    if (!ds || !ws || !out) return fail(KF_INVALID_ARGS, "kf_xengine_create_tp: null argument");
+    if (c->capturing) return fail(KF_INVALID_ARGS, "kf_xengine_create_tp: not while capturing");
+    kf::XEngineHost* h = nullptr;
+    const char* why = "";
+    const int rc = kf::xengine_build_tp(ds, world, ws, ws_bytes, c->stream, &h, &why);
+    if (rc != KF_OK) return fail(rc, "kf_xengine_create_tp: %s", why);
+    kf_xengine* e = new kf_xengine();
+    e->h = h;
+    *out = e;
+    return KF_OK;
+}
+int kf_xengine_set_head_tp(kf_ctx* c, kf_xengine* e, const kf_weight* const* shards, const int32_t* row0, const kf_bf16* final_norm_w, kf_bf16* logits, int32_t* d_tokens_out, int tokens_stride) {
+    CHKCTX(c);
+    if (!e || !e->h) return fail(KF_INVALID_ARGS, "kf_xengine_set_head_tp: null engine");
+    const int rc = kf::xengine_set_head_tp(e->h, shards, row0, final_norm_w, logits, d_tokens_out, tokens_stride);
+    if (rc != KF_OK) return fail(rc, "kf_xengine_set_head_tp: eight bf16 [rows, dim] vocabulary shards in rank order (row0 = the rows before), a norm weight and a logits buffer");
+    return KF_OK;
+}
 int kf_xengine_served(kf_ctx* c, const kf_engine_desc* d, char* why, size_t why_bytes) {
     CHKCTX(c);
     if (!d) return fail(KF_INVALID_ARGS, "kf_xengine_served: null descriptor");

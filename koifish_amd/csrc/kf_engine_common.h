@@ -202,6 +202,74 @@ __device__ __forceinline__ void eng_poll_stage_long(const uint32_t* gsrc, uint32
     }
 }
 
+// a long vector WITH the RMS norm (a 5120-wide residual stream: the one-sweep form would hold 160 registers): pass 1 sweeps PIECE x 256 granules at a time (or reads the
+// plain bf16 row), leaves the raw vector in xraw (natural order, required) and sums the squares in the lane order of eng_poll_stage (load r = 0, 1, ... : the same fp64 sum);
+// pass 2 reads xraw back, normalises and stages (fp32 chunks, or bf16 chunks of 8: F32X = false)
+template <int XCH, int NLD, int NBLK, bool PLAIN, bool F32X, int PIECE, int R0 = 0>
+__device__ __forceinline__ void eng_norm_long_pass1(const uint32_t* gsrc, const uint16_t* plain, uint32_t tag, uint16_t* xraw, int lane, int* ws, bool& dead, double& ss) {
+    if constexpr (R0 < NLD) {
+        constexpr int NP = (NLD - R0) < PIECE ? (NLD - R0) : PIECE;
+        uint32_t p0[NP], p1[NP];
+        if constexpr (PLAIN) {
+#pragma unroll
+            for (int r = 0; r < NP; r++) {
+                const u32x2 t = *reinterpret_cast<const u32x2*>(plain + 4 * ((R0 + r) * 64 + lane));
+                p0[r] = t.x, p1[r] = t.y;
+            }
+        } else {
+            const __amdgpu_buffer_rsrc_t rs = eng_rsrc(gsrc + (size_t)R0 * 256, (uint32_t)NP * 1024u);
+            u32x4 g[NP];
+            const uint32_t tagw = tag << 16;
+            for (int spins = 0;; spins++) {
+                uint32_t bad = 0;
+#pragma unroll
+                for (int r = 0; r < NP; r++) g[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (r * 64 + lane) * 16, 0, 16 /* sc1 */));
+#pragma unroll
+                for (int r = 0; r < NP; r++) bad = tags_bad(g[r], tagw, bad);
+                if (all_good(bad)) break;
+                if (dead || spins > ENG_SPIN_MAX) {
+                    if (!dead && lane == 0) atomicOr(ws + 1, 1);
+                    dead = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int r = 0; r < NP; r++) p0[r] = (g[r].x & 0xffffu) | (g[r].y << 16), p1[r] = (g[r].z & 0xffffu) | (g[r].w << 16);
+        }
+#pragma unroll
+        for (int r = 0; r < NP; r++) {
+            const double a = (double)bf_lo(p0[r]), b = (double)bf_hi(p0[r]), c = (double)bf_lo(p1[r]), d = (double)bf_hi(p1[r]);
+            ss = fma(a, a, ss), ss = fma(b, b, ss), ss = fma(c, c, ss), ss = fma(d, d, ss);
+            *reinterpret_cast<u32x2*>(xraw + 4 * ((R0 + r) * 64 + lane)) = u32x2{p0[r], p1[r]};
+        }
+        eng_norm_long_pass1<XCH, NLD, NBLK, PLAIN, F32X, PIECE, R0 + NP>(gsrc, plain, tag, xraw, lane, ws, dead, ss);
+    }
+}
+template <int XCH, int NLD, int NBLK, bool PLAIN, bool F32X, int PIECE>
+__device__ __forceinline__ void eng_poll_stage_norm_long(const uint32_t* gsrc, const uint16_t* plain, uint32_t tag, g_u16 norm_w, float eps, u32x4* xs, uint16_t* xraw, int lane, int* ws, bool& dead) {
+    constexpr int n = NLD * 256;
+    double ss = 0.0;
+    eng_norm_long_pass1<XCH, NLD, NBLK, PLAIN, F32X, PIECE>(gsrc, plain, tag, xraw, lane, ws, dead, ss);
+    const double tot = wave_sum_f64_fast(ss);
+    const float mul = 1.0f / sqrtf(fmaf((float)tot, 1.0f / (float)n, eps));
+#pragma unroll 4
+    for (int r = 0; r < NLD; r++) {
+        const int e0 = 4 * (r * 64 + lane);
+        const u32x2 raw = *reinterpret_cast<const u32x2*>(xraw + e0); /* this lane's own words of pass 1 */
+        const u32x2 w = *reinterpret_cast<const u32x2 KF_GLOBAL*>(norm_w + e0);
+        const uint32_t o0 = pack_bf16x2((bf_lo(raw.x) * mul) * bf_lo(w.x), (bf_hi(raw.x) * mul) * bf_hi(w.x));
+        const uint32_t o1 = pack_bf16x2((bf_lo(raw.y) * mul) * bf_lo(w.y), (bf_hi(raw.y) * mul) * bf_hi(w.y));
+        if (F32X) {
+            const int q = e0 >> 2, c = q / XCH, j = q - c * XCH;
+            xs[j * NBLK + c] = u32x4{o0 << 16, o0 & 0xffff0000u, o1 << 16, o1 & 0xffff0000u};
+        } else {
+            const int q = e0 >> 3, c = q / XCH, j = q - c * XCH;
+            reinterpret_cast<u32x2*>(xs + j * NBLK + c)[(e0 >> 2) & 1] = u32x2{o0, o1};
+        }
+    }
+}
+
 struct MvAt {
     int row, col;
     bool ok;

@@ -177,6 +177,9 @@ struct XEngineHost;
 size_t xengine_ws_bytes(const kf_engine_desc* d);
 int xengine_build(const kf_engine_desc* d, int n_seq, long long kv_seq_stride, void* ws, size_t ws_bytes, hipStream_t st, XEngineHost** out, const char** why = nullptr, bool dry = false);
 int xengine_steps(XEngineHost* E, hipStream_t st, int32_t* d_state, uint16_t* x_out, int with_head, int n_steps);
+size_t xengine_ws_bytes_tp(const kf_engine_desc* rank0);                                /* tensor parallel over the XCDs: one sequence, rank r on XCD r */
+int xengine_build_tp(const kf_engine_desc* const* ranks, int world, void* ws, size_t ws_bytes, hipStream_t st, XEngineHost** out, const char** why = nullptr);
+int xengine_set_head_tp(XEngineHost* E, const kf_weight* const* shards, const int* row0, const uint16_t* norm_w, uint16_t* logits, int32_t* d_tokens_out, int tokens_stride);
 int xengine_set_embedding(XEngineHost* E, const kf_weight* w, const int32_t* d_forced, int forced_stride);
 int xengine_set_head(XEngineHost* E, const kf_weight* w, const uint16_t* norm_w, uint16_t* logits, int32_t* d_tokens_out, int tokens_stride);
 int xengine_error_word(XEngineHost* E, hipStream_t st, int* h_err);

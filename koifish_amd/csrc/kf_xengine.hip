@@ -59,6 +59,13 @@ struct XArgs {
     unsigned long long* dbg; /* diagnostic instantiation: [step][layer][16] stamps of (sequence dbg_seq, workgroup rank dbg_wg) */
     int dbg_seq, dbg_wg, dbg_steps;
     int deal_wl;    /* weight (x 8) of the compute waves that share the poller's SIMD: see xe_deal */
+    // tensor parallel over the XCDs (XCfg::TP): ONE sequence, XCD r = rank r.  `layers` = [rank][n_layer] (each rank's shards and its kv-head's cache rows); the head in
+    // vocabulary shards; head_w / logits / vocab above are unused
+    g_u32x4 head_w_r[XE_NXCD];
+    uint16_t* logits_r[XE_NXCD];
+    int vocab_r[XE_NXCD], row0_r[XE_NXCD];
+    unsigned long long* tp_recv; /* [rank][2][source rank][DIM] granules {fp32 partial | generation}: o_proj exchanges in buffer 0, down_proj exchanges in buffer 1 */
+    unsigned long long* tp_best; /* [rank][source rank] {global row | tag16, bf16 value} */
     int stagger_us; /* two decoders per XCD: microseconds the second one starts behind the first */
 };
 
@@ -71,8 +78,13 @@ constexpr int xe_p1_wgs(int dim, int epb, int qd, int kvd) { /* the most workgro
     }
     return 0;
 }
-template <int FMT_, int GQ_, int HD_, int NWV_, int DIM_, int QD_, int KVD_, int FFN_, int DEPTH_, bool DBG_, int WPC_ = 1, int AU_ = 2>
+template <int FMT_, int GQ_, int HD_, int NWV_, int DIM_, int QD_, int KVD_, int FFN_, int DEPTH_, bool DBG_, int WPC_ = 1, int AU_ = 2, bool TP_ = false>
 struct XCfg {
+    // TP: the eight XCDs are the eight ranks of ONE sequence (QD_, KVD_, FFN_: a rank's shard widths).  o_proj / down_proj are column shards: their rows leave as fp32
+    // partials into every rank's receive area (the protocol of kf_tp.hip, inside the launch), each workgroup sums its 1 / 32 of the rows over the ranks in rank order,
+    // adds the residual and publishes the slice inside its XCD -- from there on the hand-off is the local one.
+    static constexpr bool TP = TP_;
+    static constexpr int FFNP = (FFN_ + 255) & ~255; /* the SwiGLU vector's exchange area in whole 1 KiB sweeps (a rank's 3200: 128 granules of padding, published as zeros) */
     static constexpr int AU = AU_; /* key tiles per attention batch and wave */
     static constexpr bool DEAL_CONTIG = WPC_ > 1 || NWV_ == 8; /* xe_deal: 7 compute waves = ONE beside the poller on its SIMD: a run per wave, that wave's shorter */
     static constexpr int WPC = WPC_; /* decoders per XCD = workgroups per CU: 2 lets one decoder's hand-off waits run under the other's arithmetic (the hardware interleaves the two workgroups' waves) */
@@ -95,7 +107,7 @@ struct XCfg {
     static constexpr int PSH = SPK * (2 * HD_ + 4); /* 8-byte granules of one head's slice partials: [HD / ME][SPK][ME] values x 2, then [SPK][4] {m, L lo, L hi, -} */
     // the XCD-local exchange area (dwords)
     static constexpr int xA = 0, qkv = xA + eng_gran_dw(DIM_), ao = qkv + eng_gran_dw(QD_ + 2 * KVD_), xB = ao + eng_gran_dw(QD_), act = xB + eng_gran_dw(DIM_),
-                         part = act + eng_gran_dw(FFN_), hbest = part + eng_gran_dw(2 * n_head * PSH), tokg = hbest + eng_gran_dw(2 * XE_NWG), loc_dw = tokg + eng_gran_dw(2);
+                         part = act + eng_gran_dw(FFNP), hbest = part + eng_gran_dw(2 * n_head * PSH), tokg = hbest + eng_gran_dw(2 * XE_NWG), loc_dw = tokg + eng_gran_dw(2);
     // LM head (bf16 [vocab, DIM]): the geometry gemv_launch picks for a many-row bf16 matrix of this width
     static constexpr int HnBlk = DIM_ / 8, Hlpr_log2 = c_lpr_log2(DIM_ / 8, 1L << 20), HLPR = 1 << Hlpr_log2, HRPS = 64 >> Hlpr_log2, Hiters = (HnBlk + HLPR - 1) / HLPR;
     static constexpr int XCH = 8; /* fp32 activations: 16-byte chunks per 32-weight block */
@@ -133,7 +145,8 @@ struct XLds {
                  issue slots from the two compute waves of its SIMD, which then finish last and hold the whole decoder's hand-off back) */
 };
 struct XSeq { /* this workgroup's place in its decoder, and the step's slice */
-    int seq, r, step;
+    int seq, r, step; /* seq: the decoder (its exchange area, its XCD); TP: = the rank */
+    int sq;           /* the sequence whose state / forced ids / ids out this decoder follows (TP: 0) */
     int pos, len, kvh, split, h0, t0, t1, me0;
     bool empty, own_new, stamp, grp0; /* grp0: the first head group of its kv-head (it writes the new K / V row) */
     int j1, s1, M1, q_out0;
@@ -316,12 +329,26 @@ __device__ __forceinline__ void xe_mv_run(const XPhase& P, const XPhase& NX, boo
 }
 // the waves that own rows of a phase leave their granules in LDS; the one that arrives last stores the workgroup's piece, 16 bytes per lane, with PLAIN stores (this XCD's L2)
 // plain != NULL: the rows also as plain bf16 (the residual stream after the last layer: x_out)
-__device__ __forceinline__ void xe_publish(const XLds& L, int phase, uint32_t tag, uint32_t* dst, int nrows, int nwaves, int lane, uint16_t* plain = nullptr) {
+// push (TP, o_proj / down_proj): the rows are fp32 partials; they go as {fp32 | generation} granules into this rank's slot of EVERY rank's receive area (push: rank 0's
+// slot for these rows, push_stride granules from one rank's area to the next), agent-scope stores -- the areas are read from the other XCDs
+// pad: zero granules behind the piece (the SwiGLU vector of a rank is swept in whole 1 KiB units)
+__device__ __forceinline__ void xe_publish(const XLds& L, int phase, uint32_t tag, uint32_t* dst, int nrows, int nwaves, int lane, uint16_t* plain = nullptr,
+                                           unsigned long long* push = nullptr, size_t push_stride = 0, uint32_t tagx = 0, int pad = 0) {
     int old = 0;
     if (lane == 0) old = __hip_atomic_fetch_add(L.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     old = __builtin_amdgcn_readfirstlane(old);
     if (old != nwaves - 1) return;
     if (lane == 0) *L.cnt = 0;
+    if (push) {
+        for (int i = lane; i < nrows; i += 64) {
+            const float v = __uint_as_float(L.outb[i]);
+#pragma unroll
+            for (int d = 0; d < XE_NXCD; d++) st_gran64(push + (size_t)d * push_stride + i, tagx, v);
+        }
+        if (lane == 0) __hip_atomic_fetch_add(L.pub + phase, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+    }
+    for (int i = lane; i < pad; i += 64) dst[nrows + i] = tag << 16;
     // one descriptor for the piece, the lane's 16 bytes as an offset: no 64-bit per-lane address (it was spilled, and its reload in front of the store drained the next phase's
     // weight loads in flight)
     const __amdgpu_buffer_rsrc_t rd = eng_rsrc(dst, (uint32_t)nrows * 4u), rp = eng_rsrc(plain ? (const void*)plain : (const void*)dst, plain ? (uint32_t)nrows * 2u : 0u);
@@ -338,6 +365,49 @@ __device__ __forceinline__ void xe_publish(const XLds& L, int phase, uint32_t ta
         __builtin_amdgcn_raw_buffer_store_b64(u32x2{(g.x & 0xffffu) | (g.y << 16), (g.z & 0xffffu) | (g.w << 16)}, rp, i * 2, 0, 0); /* out of range (dropped) without `plain` */
     }
     if (lane == 0) __hip_atomic_fetch_add(L.pub + phase, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// ---- TP: this workgroup's 1 / 32 of a column-shard exchange.  Rows wg * R .. + R of the eight ranks' fp32 partials (this rank's receive area, buffer `which`) are swept until
+// every granule carries the exchange's generation, summed in rank order, rounded, added to the residual (tp_reduce_recv_kernel, kf_tp.hip: bf16(x + bf16(sum_r p_r))) and left
+// as tagged granules in this XCD's area -- where the ordinary local hand-off picks the whole vector up.  plain: the rows also as plain bf16 (x_out)
+template <class C>
+__device__ __forceinline__ void xe_tp_reduce(const XArgs& a, const XSeq& S, int which, uint32_t tagx, const uint16_t* resid, uint32_t* dst_local, uint32_t tag16, uint16_t* plain, int lane, bool& dead) {
+    constexpr int R = C::DIM / XE_NWG, NK = (R + 63) / 64;
+    const int row0 = S.r * R;
+    const unsigned long long* base = a.tp_recv + ((size_t)S.seq * 2 + which) * XE_NXCD * C::DIM + row0;
+    u32x2 g[XE_NXCD][NK];
+    for (int spins = 0;; spins++) {
+        uint32_t bad = 0;
+#pragma unroll
+        for (int s = 0; s < XE_NXCD; s++) {
+            const __amdgpu_buffer_rsrc_t rs = eng_rsrc(base + (size_t)s * C::DIM, (uint32_t)R * 8u);
+#pragma unroll
+            for (int k = 0; k < NK; k++) g[s][k] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (k * 64 + lane) * 8, 0, 16 /* sc1 */));
+        }
+#pragma unroll
+        for (int s = 0; s < XE_NXCD; s++)
+#pragma unroll
+            for (int k = 0; k < NK; k++) bad |= (k * 64 + lane) < R ? (g[s][k].y ^ tagx) : 0u;
+        if (all_good(bad)) break;
+        if (dead || spins > ENG_SPIN_MAX) {
+            if (!dead && lane == 0) atomicOr(a.ws + 1, 2048);
+            dead = true;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int k = 0; k < NK; k++) {
+        const int i = k * 64 + lane;
+        if (i < R) {
+            float tot = __uint_as_float(g[0][k].x);
+#pragma unroll
+            for (int s = 1; s < XE_NXCD; s++) tot = tot + __uint_as_float(g[s][k].x);
+            const uint16_t o = f2bf(bf2f(resid[row0 + i]) + bf2f(f2bf(tot)));
+            dst_local[i] = (tag16 << 16) | (uint32_t)o;
+            if (plain) plain[row0 + i] = o;
+        }
+    }
 }
 
 // ---- attention: the workgroup's key slice of its kv-head, streamed by the NCW compute waves (two batches of U tiles in flight per lane)
@@ -475,8 +545,9 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, co
     using P5 = typename SH::P5;
     using P6 = typename SH::P6;
     constexpr int GQ = C::GQW, hd = C::HD, XCH = C::XCH;
-    constexpr int ND = C::DIM / 256, NQD = C::QD / 256, NF = C::FFN / 256;
-    static_assert(C::DIM % 256 == 0 && C::QD % 256 == 0 && C::FFN % 256 == 0, "hand-off vectors in 1 KiB pieces");
+    constexpr int ND = C::DIM / 256, NQD = C::QD / 256, NF = C::FFNP / 256;
+    static_assert(C::DIM % 256 == 0 && C::QD % 256 == 0 && (C::TP || C::FFN % 256 == 0), "hand-off vectors in 1 KiB pieces");
+    constexpr int RT = C::DIM / XE_NWG; /* TP: the rows of an exchange this workgroup sums */
     uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)S.seq * a.loc_stride);
     bool dead = false;
     for (int l = 0; l < a.n_layer; l++) {
@@ -486,7 +557,7 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, co
         if (C::DBG && S.stamp && lane == 0) a.dbg[((size_t)S.step * a.n_layer + l) * 64 + 31] = __builtin_amdgcn_s_memtime(); /* the shader clock beside the 100 MHz stamp: the frequency the CU really runs at */
         // P1's x (P4 adds it as the residual)
         if (l == 0) {
-            int tok = a.d_state[S.seq * 4];
+            int tok = a.d_state[S.sq * 4];
             if (S.step > 0) { /* the id workgroup 0 of this decoder picked at the end of the previous step: {id, epoch of this step} */
                 const __amdgpu_buffer_rsrc_t rt = eng_rsrc(loc + C::tokg, 8u);
                 for (int spins = 0;; spins++) {
@@ -504,15 +575,19 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, co
                 }
             }
             if (a.d_forced) {
-                const int f = a.d_forced[(size_t)S.seq * a.forced_stride + S.pos];
+                const int f = a.d_forced[(size_t)S.sq * a.forced_stride + S.pos];
                 if (f >= 0) tok = f;
             }
             if (tok < 0 || tok >= a.emb_rows) tok = 0;
-            eng_poll_stage<XCH, ND, C::XS, true, true, true>(nullptr, a.emb + (size_t)tok * C::DIM, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, nullptr, nullptr, 0, 0);
+            if constexpr (ND > 12) eng_poll_stage_norm_long<XCH, ND, C::XS, true, true, 8>(nullptr, a.emb + (size_t)tok * C::DIM, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead);
+            else eng_poll_stage<XCH, ND, C::XS, true, true, true>(nullptr, a.emb + (size_t)tok * C::DIM, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, nullptr, nullptr, 0, 0);
         } else {
             eng_wait_pub(L.pub + 3, S.step * a.n_layer + l, 0, dead);
             XE_STAMP(12);
-            eng_poll_stage<XCH, ND, C::XS, true, false, true>(loc + C::xA, nullptr, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, nullptr, nullptr, 0, 0);
+            if constexpr (C::TP) /* the down_proj exchange of the layer before: this workgroup's rows summed over the ranks + the residual xB -> the local x area */
+                xe_tp_reduce<C>(a, S, 1, 2u * (gen - 1u) + 2u, L.xrawB, loc + C::xA + S.r * RT, tag, nullptr, lane, dead);
+            if constexpr (ND > 12) eng_poll_stage_norm_long<XCH, ND, C::XS, false, true, 8>(loc + C::xA, nullptr, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead);
+            else eng_poll_stage<XCH, ND, C::XS, true, false, true>(loc + C::xA, nullptr, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, nullptr, nullptr, 0, 0);
         }
         XE_STAMP(1);
         __syncthreads(); /* B1 */
@@ -614,7 +689,9 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, co
         __syncthreads(); /* B4 */
         eng_wait_pub(L.pub + 1, S.step * a.n_layer + l + 1, 0, dead);
         XE_STAMP(10);
-        eng_poll_stage<XCH, ND, C::XS, true, false, true>(loc + C::xB, nullptr, tag, ly.norm_post, a.eps, L.xs[0], L.xrawB, lane, a.ws, dead, nullptr, nullptr, 0, 0);
+        if constexpr (C::TP) xe_tp_reduce<C>(a, S, 0, 2u * gen + 1u, L.xrawA, loc + C::xB + S.r * RT, tag, nullptr, lane, dead); /* the o_proj exchange + the residual x */
+        if constexpr (ND > 12) eng_poll_stage_norm_long<XCH, ND, C::XS, false, true, 8>(loc + C::xB, nullptr, tag, ly.norm_post, a.eps, L.xs[0], L.xrawB, lane, a.ws, dead);
+        else eng_poll_stage<XCH, ND, C::XS, true, false, true>(loc + C::xB, nullptr, tag, ly.norm_post, a.eps, L.xs[0], L.xrawB, lane, a.ws, dead, nullptr, nullptr, 0, 0);
         XE_STAMP(7);
         __syncthreads(); /* B5 */
         eng_wait_pub(L.pub + 2, S.step * a.n_layer + l + 1, 0, dead);
@@ -640,6 +717,7 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
     static_assert(P1::R % 4 == 0 && P4::R % 4 == 0 && P5::R % 4 == 0 && P6::R % 4 == 0, "16-byte pieces");
     static_assert(P1::total == C::P1W * P1::spg && P4::total == XE_NWG * P4::spg && P5::total == XE_NWG * P5::spg && P6::total == XE_NWG * P6::spg, "every workgroup owns rows of every phase");
     static_assert(P1::S1 % P1::spg == 0 && P1::S2 % P1::spg == 0, "a workgroup's P1 rows belong to one matrix");
+    static_assert(!C::TP || (P4::R == C::DIM / XE_NWG && P6::R == C::DIM / XE_NWG && C::WPC == 1), "TP: a workgroup sums the rows it produced (xe_tp_reduce)");
     uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)S.seq * a.loc_stride);
     const float qb1 = S.j1 == 0 ? a.qbias[0] : (S.j1 == 1 ? a.qbias[1] : a.qbias[2]);
     const int wg = S.r;
@@ -711,6 +789,8 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
                     uint32_t g;
                     if (q == 0) {
                         g = (tag << 16) | (uint32_t)f2bf(v);
+                    } else if (C::TP && (q == 1 || q == 3)) {
+                        g = __float_as_uint(v); /* a column shard's row: the un-rounded fp32 partial (xe_publish pushes it to every rank) */
                     } else if (q == 1) {
                         g = (tag << 16) | (uint32_t)f2bf(bf2f(L.xrawA[row]) + bf2f(f2bf(v))); /* CU_add3: bf16(x + bf16(W.x)) */
                     } else if (q == 2) {
@@ -728,7 +808,15 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
                 a.dbg[((size_t)S.step * a.n_layer + l) * 64 + ((cw & 7) < 2 ? 14 + (cw & 7) : 23 + (cw & 7))] = hw; /* slots 14, 15, 25 .. 30: where (SIMD, CU) the wave runs */
             }
             if (q == 0) xe_attn_issue<C>(a, ly, S, cw, lane, T, 0, 0); /* the slice's first tiles (rows of earlier positions; row `pos` is substituted): the q | k | v hand-off hides them */
-            if (xe_deal<NCW, C::DEAL_CONTIG>(cw, spg, a.deal_wl).n > 0 && !(C::P1W < XE_NWG && q == 0 && wg >= C::P1W)) xe_publish(L, q, tag, dst, nrows, nwp, lane, (q == 3 && last) ? a.x_out + (size_t)S.seq * C::DIM + wg * P6::R : nullptr);
+            if (xe_deal<NCW, C::DEAL_CONTIG>(cw, spg, a.deal_wl).n > 0 && !(C::P1W < XE_NWG && q == 0 && wg >= C::P1W)) {
+                if constexpr (C::TP) {
+                    // o_proj (q == 1) / down_proj (q == 3): this rank's slot [buffer][S.seq][rows wg * R ..] of rank 0's receive area, the other ranks' areas 2 * 8 * DIM granules apart
+                    unsigned long long* push = (q == 1 || q == 3) ? a.tp_recv + ((size_t)(q == 3 ? 1 : 0) * XE_NXCD + S.seq) * C::DIM + wg * nrows : nullptr;
+                    xe_publish(L, q, tag, dst, nrows, nwp, lane, nullptr, push, (size_t)2 * XE_NXCD * C::DIM, 2u * gen + (q == 3 ? 2u : 1u), (q == 2 && wg == XE_NWG - 1) ? C::FFNP - C::FFN : 0);
+                } else {
+                    xe_publish(L, q, tag, dst, nrows, nwp, lane, (q == 3 && last) ? a.x_out + (size_t)S.seq * C::DIM + wg * P6::R : nullptr);
+                }
+            }
             if (cw == 0) XE_STAMP(17 + 2 * q);
             if (q == 0) { /* q/k-norm + RoPE + attention over the workgroup's key slice; the slice partial into the XCD's partial area; then the first o_proj blocks */
                 xe_attn_phase<C>(a, L, S, ly, gen, cw, lane, T, l, [&]() { xe_fill<NCW, D>(phase_of(1, ly), cw, lane, R); });
@@ -747,9 +835,17 @@ __device__ __forceinline__ void xe_head_main(const XArgs& a, const XLds& L, cons
     constexpr int ND = C::DIM / 256;
     const int wg = S.r;
     uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)S.seq * a.loc_stride);
-    uint16_t* const logits = a.logits + (size_t)S.seq * a.vocab;
+    // TP: this rank's vocabulary shard (rows row0 .. of the full head), its logits; chosen by compares (an index into the kernel arguments at run time is a copy in scratch)
+    uint16_t* logits = a.logits + (size_t)S.seq * a.vocab;
+    g_u32x4 head_w = a.head_w;
+    int vocab = a.vocab, row0g = 0;
+    if constexpr (C::TP) {
+#pragma unroll
+        for (int r = 0; r < XE_NXCD; r++)
+            if (r == S.seq) logits = a.logits_r[r], head_w = a.head_w_r[r], vocab = a.vocab_r[r], row0g = a.row0_r[r];
+    }
     const int sub = lane >> C::Hlpr_log2, ll = lane & (LPR - 1);
-    const int total = (a.vocab + RPS - 1) / RPS, spg = (total + NWG - 1) / NWG;
+    const int total = (vocab + RPS - 1) / RPS, spg = (total + NWG - 1) / NWG;
     const int s_wg = wg * spg;
     int s_end = s_wg + spg;
     s_end = s_end < total ? s_end : total;
@@ -762,19 +858,24 @@ __device__ __forceinline__ void xe_head_main(const XArgs& a, const XLds& L, cons
             int i = b * HG + g;
             i = i < nmine ? i : (nmine > 0 ? nmine - 1 : 0);
             int row = (s_wg + wave + NWV * i) * RPS + sub;
-            row = row < a.vocab ? row : a.vocab - 1;
+            row = row < vocab ? row : vocab - 1;
 #pragma unroll
             for (int it = 0; it < ITERS; it++) {
                 int col = it * LPR + ll;
                 col = col < nBlk ? col : nBlk - 1;
-                w[buf][g][it] = __builtin_nontemporal_load(a.head_w + (size_t)row * nBlk + col);
+                w[buf][g][it] = __builtin_nontemporal_load(head_w + (size_t)row * nBlk + col);
             }
         }
     };
     const uint32_t gen = (uint32_t)(epoch + 1) * (uint32_t)a.n_layer, tag = gen & 0xffffu; /* the generation the last layer's down_proj published its rows with */
     if (wave == NWV - 1) {
         bool dead = false;
-        eng_poll_stage<1, ND, nBlk, true, false, false>(loc + C::xA, nullptr, tag, a.head_norm, a.eps, L.xs[0], nullptr, lane, a.ws, dead, nullptr, L.pub + 3, (S.step + 1) * a.n_layer, 0);
+        if constexpr (C::TP) { /* the last layer's down_proj exchange: this workgroup's rows -> the local x area (rank 0: also x_out) */
+            eng_wait_pub(L.pub + 3, (S.step + 1) * a.n_layer, 0, dead);
+            xe_tp_reduce<C>(a, S, 1, 2u * (gen - 1u) + 2u, L.xrawB, loc + C::xA + wg * (C::DIM / XE_NWG), tag, S.seq == 0 ? a.x_out : nullptr, lane, dead);
+        }
+        if constexpr (ND > 12) eng_poll_stage_norm_long<1, ND, nBlk, false, false, 8>(loc + C::xA, nullptr, tag, a.head_norm, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead);
+        else eng_poll_stage<1, ND, nBlk, true, false, false>(loc + C::xA, nullptr, tag, a.head_norm, a.eps, L.xs[0], nullptr, lane, a.ws, dead, nullptr, L.pub + 3, (S.step + 1) * a.n_layer, 0);
     } else {
         issue(0, 0); /* ahead of the hand-off of x (the poller's own first rows are requested behind its sweep: loads return in order) */
     }
@@ -807,7 +908,7 @@ __device__ __forceinline__ void xe_head_main(const XArgs& a, const XLds& L, cons
                 acc = acc_pick(it * LPR + ll < nBlk, r, acc);
             }
             const float v = group_sum(acc_join(acc), C::Hlpr_log2);
-            if (ll == 0 && i < nmine && row < a.vocab) {
+            if (ll == 0 && i < nmine && row < vocab) {
                 const uint16_t o = f2bf(v);
                 logits[row] = o;
                 const float fv = bf2f(o);
@@ -869,13 +970,45 @@ __device__ __forceinline__ void xe_head_main(const XArgs& a, const XLds& L, cons
             const int oi = __shfl_xor(bi, m, 64);
             if (ov > bv || (ov == bv && oi < bi)) bv = ov, bi = oi;
         }
+        int vocab_all = vocab;
+        if constexpr (C::TP) { /* the rank's maximum (GLOBAL row) to every rank; then the first maximum over the ranks (tp_pick_kernel, kf_tp.hip: lowest row among equals) */
+            vocab_all = 0;
+#pragma unroll
+            for (int r = 0; r < XE_NXCD; r++) vocab_all += a.vocab_r[r];
+            if (lane < XE_NXCD) {
+                const unsigned long long gr = ((unsigned long long)((tag << 16) | (uint32_t)f2bf(bv)) << 32) | (unsigned long long)(uint32_t)(bi + row0g);
+                __hip_atomic_store(a.tp_best + (size_t)lane * XE_NXCD + S.seq, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const __amdgpu_buffer_rsrc_t rb = eng_rsrc(a.tp_best + (size_t)S.seq * XE_NXCD, XE_NXCD * 8u);
+            u32x2 gb{0, 0};
+            const bool src = lane < XE_NXCD;
+            bool ok2 = false;
+            for (int spins = 0; spins <= ENG_SPIN_MAX; spins++) {
+                gb = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rb, (src ? lane : 0) * 8, 0, 16 /* sc1 */));
+                if (all_good((gb.y >> 16) ^ tag)) {
+                    ok2 = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            ok = ok && ok2;
+            bv = src ? bf2f((uint16_t)(gb.y & 0xffffu)) : -__builtin_inff(), bi = src ? (int)gb.x : 0x7fffffff;
+#pragma unroll
+            for (int m = 4; m > 0; m >>= 1) {
+                const float ov = __shfl_xor(bv, m, 64);
+                const int oi = __shfl_xor(bi, m, 64);
+                if (ov > bv || (ov == bv && oi < bi)) bv = ov, bi = oi;
+            }
+        }
         if (lane == 0) {
             const int err = __hip_atomic_load(a.ws + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (ok && err == 0 && bi >= 0 && bi < a.vocab) { /* never advance the decode state on a timed-out hand-off */
-                int32_t* st = a.d_state + S.seq * 4;
-                const int p = st[1];
-                if (a.d_tokens_out) a.d_tokens_out[(size_t)S.seq * a.tokens_stride + p] = bi;
-                st[0] = bi, st[1] = p + 1;
+            if (ok && err == 0 && bi >= 0 && bi < vocab_all) { /* never advance the decode state on a timed-out hand-off */
+                if (!C::TP || S.seq == 0) { /* TP: every rank knows the id (its next embedding row); rank 0 keeps the books */
+                    int32_t* st = a.d_state + S.sq * 4;
+                    const int p = st[1];
+                    if (a.d_tokens_out) a.d_tokens_out[(size_t)S.sq * a.tokens_stride + p] = bi;
+                    st[0] = bi, st[1] = p + 1;
+                }
                 if (more_steps) *reinterpret_cast<u32x2*>(loc + C::tokg) = u32x2{(uint32_t)bi, (uint32_t)(epoch + 1)};
             } else if (err == 0) {
                 atomicOr(a.ws + 1, 16);
@@ -954,13 +1087,14 @@ __global__ void __launch_bounds__(C::NWV * 64, (C::NWV * C::WPC + 3) / 4 /* wave
         return;
     }
     {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.layers);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.layers + (C::TP ? (size_t)S.seq * a.n_layer : 0)); /* TP: this rank's table */
         uint32_t* dst = reinterpret_cast<uint32_t*>(lay);
         const int nw = a.n_layer * (int)(sizeof(EngLayer) / 4);
         for (int i = tid; i < nw; i += NWV * 64) dst[i] = src[i];
     }
     __syncthreads();
-    S.kv_off = (long long)S.seq * a.kv_seq_stride;
+    S.sq = C::TP ? 0 : S.seq;
+    S.kv_off = C::TP ? 0 : (long long)S.seq * a.kv_seq_stride; /* TP: the rank's cache rows are in its layer table */
     {
         const int s1_abs = S.r * P1::spg;
         S.j1 = s1_abs >= P1::S2 ? 2 : (s1_abs >= P1::S1 ? 1 : 0);
@@ -973,7 +1107,7 @@ __global__ void __launch_bounds__(C::NWV * 64, (C::NWV * C::WPC + 3) / 4 /* wave
         S.kvh = S.r / per_kv, S.split = idx - grp * C::SPK, S.h0 = S.kvh * C::GQ + grp * C::GQW, S.me0 = S.r * C::ME;
         S.grp0 = grp == 0;
     }
-    const int pos0 = a.d_state[S.seq * 4 + 1];
+    const int pos0 = a.d_state[S.sq * 4 + 1]; /* (TP: rank 0 moves the state on at the end of a step -- which no workgroup reaches before every workgroup has passed here) */
     const int nst = a.n_steps > 1 ? a.n_steps : 1;
     if (pos0 < 0 || pos0 + nst > a.max_seq) { /* a position of this launch lies beyond the cache rows: refuse, loudly */
         if (tid == 0) atomicOr(a.ws + 1, 64);
@@ -1013,6 +1147,7 @@ struct XEngineHost {
     size_t ws_bytes;
     int nwv, depth; /* the instantiation in use */
     int deal_wl;    /* 0: the form's default (xengine_go) */
+    size_t tp_bytes; /* TP: bytes of the receive + pick areas behind the exchange areas (reset with them) */
 };
 
 static int xe_shape_class(int GQ, int hd, int dim, int q_dim, int ffn) {
@@ -1056,7 +1191,8 @@ size_t xengine_ws_bytes(const kf_engine_desc* d) {
 }
 static int xengine_init_state(XEngineHost* E, hipStream_t st) {
     XArgs& a = E->args;
-    if (hipMemsetAsync(a.loc, 0xff, (size_t)XE_MAXSEQ * E->loc_stride, st) != hipSuccess) return KF_HIP_CHECK;
+    if (hipMemsetAsync(a.loc, 0xff, (size_t)(E->shape_class == 7 ? XE_NXCD : XE_MAXSEQ) * E->loc_stride, st) != hipSuccess) return KF_HIP_CHECK;
+    if (E->tp_bytes && hipMemsetAsync(a.tp_recv, 0xff, E->tp_bytes, st) != hipSuccess) return KF_HIP_CHECK;
     static int init[16 + 32 * XE_NXCD];
     memset(init, 0, sizeof(init));
     init[0] = 1; /* epoch 1, no error, tickets zero */
@@ -1067,6 +1203,33 @@ void xengine_free(XEngineHost* E) {
     if (!E) return;
     if (E->args.dbg) (void)hipFree(E->args.dbg);
     delete E;
+}
+// one model's (one TP rank's) layer table out of its descriptor; qbias: the seven matrices' zero points of layer 0 (every layer, every rank: the same)
+static int xe_fill_layers(const kf_engine_desc* d, EngLayer* tab, float* qbias, bool qbias_set, bool& q4p_ok) {
+    const int hd = d->head_dim, q_dim = d->n_head * hd, kv_dim = d->n_kv * hd;
+    const int Ks[7] = {d->dim, d->dim, d->dim, q_dim, d->dim, d->dim, d->ffn}, Ms[7] = {q_dim, kv_dim, kv_dim, d->dim, d->ffn, d->ffn, d->dim};
+    for (int l = 0; l < d->n_layer; l++) {
+        const kf_engine_layer& Ly = d->layers[l];
+        if (Ly.hot_ffn) return KF_UNSUPPORTED_DATATYPE;
+        if (!Ly.norm_in || !Ly.norm_post || !Ly.kcache || !Ly.vcache || (((uintptr_t)Ly.kcache | (uintptr_t)Ly.vcache) & 15) != 0) return KF_UNSUPPORTED_DATATYPE;
+        for (int j = 0; j < 7; j++) {
+            const kf_weight& w = Ly.w[j];
+            if (gemv_fmt_of(&w) != FMT_Q4 || w.ne0 != Ms[j] || w.ne1 != Ks[j] || w.qzeros || w.qscales || !w.gama || w.lGroup != 128 || (Ks[j] % 128) != 0 || ((uintptr_t)w.data & 15) != 0)
+                return KF_UNSUPPORTED_DATATYPE;
+            const long rows = j < 3 ? (long)q_dim + 2 * kv_dim : (j == 4 || j == 5 ? (long)d->ffn : (long)Ms[j]);
+            if (gemv_lpr_log2(Ks[j] / 32, rows) < 2) q4p_ok = false; /* the register-table form needs a group's four blocks in one aligned lane quad */
+            tab[l].m[j].w = (g_u32x4)(uintptr_t)w.data;
+            tab[l].m[j].zero = (g_u16)(uintptr_t)(w.gama + w.ne0 + w.ne1);
+            tab[l].m[j].step = (g_u16)(uintptr_t)(w.gama + w.ne0 + w.ne1 + (size_t)w.ne0 * w.ne1 / w.lGroup);
+            if (l == 0 && !qbias_set) qbias[j] = (float)w.qBias;
+            else if (qbias[j] != (float)w.qBias) return KF_UNSUPPORTED_DATATYPE;
+        }
+        tab[l].norm_in = (g_u16)(uintptr_t)Ly.norm_in, tab[l].norm_post = (g_u16)(uintptr_t)Ly.norm_post;
+        tab[l].norm_q = (g_u16)(uintptr_t)Ly.q_norm, tab[l].norm_k = (g_u16)(uintptr_t)Ly.k_norm;
+        tab[l].kcache = (g_u16w)(uintptr_t)Ly.kcache, tab[l].vcache = (g_u16w)(uintptr_t)Ly.vcache;
+        tab[l].hot = nullptr;
+    }
+    return KF_OK;
 }
 int xengine_build(const kf_engine_desc* d, int n_seq, long long kv_seq_stride, void* ws, size_t ws_bytes, hipStream_t st, XEngineHost** out, const char** why, bool dry) {
     const char* dummy;
@@ -1098,28 +1261,7 @@ int xengine_build(const kf_engine_desc* d, int n_seq, long long kv_seq_stride, v
     std::vector<EngLayer> tab(d->n_layer);
     float qbias[7] = {0};
     bool q4p_ok = true;
-    const int Ks[7] = {d->dim, d->dim, d->dim, q_dim, d->dim, d->dim, d->ffn}, Ms[7] = {q_dim, kv_dim, kv_dim, d->dim, d->ffn, d->ffn, d->dim};
-    for (int l = 0; l < d->n_layer; l++) {
-        const kf_engine_layer& Ly = d->layers[l];
-        if (Ly.hot_ffn) return KF_UNSUPPORTED_DATATYPE;
-        if (!Ly.norm_in || !Ly.norm_post || !Ly.kcache || !Ly.vcache || (((uintptr_t)Ly.kcache | (uintptr_t)Ly.vcache) & 15) != 0) return KF_UNSUPPORTED_DATATYPE;
-        for (int j = 0; j < 7; j++) {
-            const kf_weight& w = Ly.w[j];
-            if (gemv_fmt_of(&w) != FMT_Q4 || w.ne0 != Ms[j] || w.ne1 != Ks[j] || w.qzeros || w.qscales || !w.gama || w.lGroup != 128 || (Ks[j] % 128) != 0 || ((uintptr_t)w.data & 15) != 0)
-                return KF_UNSUPPORTED_DATATYPE;
-            const long rows = j < 3 ? (long)q_dim + 2 * kv_dim : (j == 4 || j == 5 ? (long)d->ffn : (long)Ms[j]);
-            if (gemv_lpr_log2(Ks[j] / 32, rows) < 2) q4p_ok = false; /* the register-table form needs a group's four blocks in one aligned lane quad */
-            tab[l].m[j].w = (g_u32x4)(uintptr_t)w.data;
-            tab[l].m[j].zero = (g_u16)(uintptr_t)(w.gama + w.ne0 + w.ne1);
-            tab[l].m[j].step = (g_u16)(uintptr_t)(w.gama + w.ne0 + w.ne1 + (size_t)w.ne0 * w.ne1 / w.lGroup);
-            if (l == 0) qbias[j] = (float)w.qBias;
-            else if (qbias[j] != (float)w.qBias) return KF_UNSUPPORTED_DATATYPE;
-        }
-        tab[l].norm_in = (g_u16)(uintptr_t)Ly.norm_in, tab[l].norm_post = (g_u16)(uintptr_t)Ly.norm_post;
-        tab[l].norm_q = (g_u16)(uintptr_t)Ly.q_norm, tab[l].norm_k = (g_u16)(uintptr_t)Ly.k_norm;
-        tab[l].kcache = (g_u16w)(uintptr_t)Ly.kcache, tab[l].vcache = (g_u16w)(uintptr_t)Ly.vcache;
-        tab[l].hot = nullptr;
-    }
+    if (xe_fill_layers(d, tab.data(), qbias, false, q4p_ok) != KF_OK) return KF_UNSUPPORTED_DATATYPE;
     if (!q4p_ok) return KF_UNSUPPORTED_DATATYPE;
     if (dry) {
         *why = "";
@@ -1148,6 +1290,96 @@ int xengine_build(const kf_engine_desc* d, int n_seq, long long kv_seq_stride, v
     }
     *out = E;
     *why = "";
+    return KF_OK;
+}
+// ---- tensor parallel over the XCDs: ONE sequence of a model too wide for one XCD's share to be a decoder of its own -- eight ranks = eight XCDs (XCfg::TP)
+// a rank of Qwen3-32B under TP = 8: 8 query heads on 1 kv-head, q_dim 1024, ffn 3200 (koifish_amd/tp.py TPPlan)
+using XC7 = XCfg<FMT_Q4P, 8, 128, 12, 5120, 1024, 128, 3200, 6, false, 1, 1, true>;
+static bool xe_tp_shape(const kf_engine_desc* d) { return d->head_dim == 128 && d->n_head == 8 && d->n_kv == 1 && d->dim == 5120 && d->ffn == 3200; }
+static size_t xe_tp_recv_granules() { return (size_t)XE_NXCD * 2 * XE_NXCD * XC7::DIM; }
+size_t xengine_ws_bytes_tp(const kf_engine_desc* d0) {
+    size_t b = 4096 + (((size_t)XE_NXCD * d0->n_layer * sizeof(EngLayer) + 255) & ~(size_t)255);
+    b += (size_t)XE_NXCD * xe_loc_stride(XC7::loc_dw) + 4096;
+    b += xe_tp_recv_granules() * 8 + (size_t)XE_NXCD * XE_NXCD * 8 + 4096;
+    return b;
+}
+int xengine_build_tp(const kf_engine_desc* const* ds, int world, void* ws, size_t ws_bytes, hipStream_t st, XEngineHost** out, const char** why) {
+    const char* dummy;
+    if (!why) why = &dummy;
+    *why = "bad arguments";
+    if (!ds || !ws || !out || world < 1) return KF_INVALID_ARGS;
+    *why = "tensor parallel over the XCDs: exactly 8 ranks (one per XCD)";
+    if (world != XE_NXCD) return KF_UNSUPPORTED_DATATYPE;
+    for (int r = 0; r < world; r++)
+        if (!ds[r] || !ds[r]->layers || ds[r]->n_layer < 1 || ds[r]->n_layer != ds[0]->n_layer) return KF_INVALID_ARGS;
+    *why = "rank shape not instantiated: built for the TP = 8 ranks of Qwen3-32B (dim 5120, 8 / 1 heads of 128, ffn 3200 per rank)";
+    for (int r = 0; r < world; r++)
+        if (!xe_tp_shape(ds[r])) return KF_UNSUPPORTED_DATATYPE;
+    const kf_engine_desc* d = ds[0];
+    if (ws_bytes < xengine_ws_bytes_tp(d) || ((uintptr_t)ws & 255) != 0) {
+        *why = "workspace too small or not 256-byte aligned";
+        return KF_INVALID_ARGS;
+    }
+    int dev = 0, n_cu = 0;
+    *why = "HIP failure";
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return KF_HIP_CHECK;
+    *why = "the device does not show 256 compute units (8 XCDs of 32): one resident workgroup per CU, 32 per XCD, is the premise";
+    if (n_cu != XE_GRID) return KF_UNSUPPORTED_DATATYPE;
+    *why = "rope_table missing, kv_stride not a multiple of 8, max_seq < 1, or the ranks disagree";
+    for (int r = 0; r < world; r++)
+        if (!ds[r]->rope_table || (ds[r]->kv_stride % 8) != 0 || ds[r]->max_seq < 1 || ds[r]->max_seq != d->max_seq || ds[r]->kv_stride != d->kv_stride || ds[r]->rms_eps != d->rms_eps ||
+            ds[r]->qk_eps != d->qk_eps)
+            return KF_INVALID_ARGS;
+    *why = "layer storage not served: 4-bit PackedQ (RTN) layers in groups of 128 with 16-byte aligned blocks, dense FFN, every layer and rank the same shapes";
+    std::vector<EngLayer> tab((size_t)world * d->n_layer);
+    float qbias[7] = {0};
+    bool q4p_ok = true;
+    for (int r = 0; r < world; r++)
+        if (xe_fill_layers(ds[r], tab.data() + (size_t)r * d->n_layer, qbias, r > 0, q4p_ok) != KF_OK) return KF_UNSUPPORTED_DATATYPE;
+    if (!q4p_ok) return KF_UNSUPPORTED_DATATYPE;
+    XEngineHost* E = new XEngineHost();
+    memset(E, 0, sizeof(*E));
+    XArgs& a = E->args;
+    E->shape_class = 7, E->fmt = FMT_Q4P, E->dim = d->dim, E->q_dim = d->n_head * d->head_dim, E->kv_dim = d->n_kv * d->head_dim, E->ffn = d->ffn, E->n_head = d->n_head, E->n_kv = d->n_kv, E->hd = d->head_dim;
+    E->nwv = 12, E->depth = 6;
+    a.n_layer = d->n_layer, a.n_seq = XE_NXCD /* decoders = ranks */, a.kv_seq_stride = 0, a.kv_stride = d->kv_stride, a.max_seq = d->max_seq;
+    a.eps = d->rms_eps, a.qk_eps = d->qk_eps, a.rope_table = d->rope_table;
+    for (int j = 0; j < 7; j++) a.qbias[j] = qbias[j];
+    char* p = reinterpret_cast<char*>(ws);
+    E->ws = ws, E->ws_bytes = ws_bytes;
+    a.ws = reinterpret_cast<int*>(p), p += 4096;
+    a.layers = reinterpret_cast<const EngLayer*>(p), p += (tab.size() * sizeof(EngLayer) + 255) & ~(size_t)255;
+    p = reinterpret_cast<char*>(((uintptr_t)p + 4095) & ~(uintptr_t)4095);
+    E->loc_stride = xe_loc_stride(XC7::loc_dw);
+    a.loc = p, a.loc_stride = E->loc_stride, p += (size_t)XE_NXCD * E->loc_stride;
+    a.tp_recv = reinterpret_cast<unsigned long long*>(p), p += xe_tp_recv_granules() * 8;
+    a.tp_best = reinterpret_cast<unsigned long long*>(p);
+    E->tp_bytes = xe_tp_recv_granules() * 8 + (size_t)XE_NXCD * XE_NXCD * 8;
+    if (xengine_init_state(E, st) != KF_OK || hipMemcpyAsync(const_cast<EngLayer*>(a.layers), tab.data(), tab.size() * sizeof(EngLayer), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+        xengine_free(E);
+        *why = "HIP failure while initialising the workspace";
+        return KF_HIP_CHECK;
+    }
+    *out = E;
+    *why = "";
+    return KF_OK;
+}
+// the head in vocabulary shards (rank r: rows row0[r] .. of the full matrix), logits: the full vector, the shards in rank order
+int xengine_set_head_tp(XEngineHost* E, const kf_weight* const* ws, const int* row0, const uint16_t* norm_w, uint16_t* logits, int32_t* d_tokens_out, int tokens_stride) {
+    XArgs& a = E->args;
+    if (E->shape_class != 7 || !ws || !row0 || !norm_w || !logits) return KF_INVALID_ARGS;
+    const int nBlk = E->dim / 8;
+    long at = 0;
+    for (int r = 0; r < XE_NXCD; r++) {
+        const kf_weight* w = ws[r];
+        if (!w || w->type != KF_BF16 || w->quant != KF_QUANT_GROUP || w->qzeros || w->ne1 != E->dim || !w->data || ((uintptr_t)w->data & 15) != 0 || w->ne0 < 64 || row0[r] != at) return KF_UNSUPPORTED_DATATYPE;
+        if (gemv_lpr_log2(nBlk, w->ne0) != c_lpr_log2(nBlk, 1L << 20)) return KF_UNSUPPORTED_DATATYPE; /* same lanes per row as the mat-vec launcher: same summation order */
+        a.head_w_r[r] = (g_u32x4)(uintptr_t)w->data, a.logits_r[r] = logits + at, a.vocab_r[r] = w->ne0, a.row0_r[r] = row0[r];
+        at += w->ne0;
+    }
+    a.head_w = a.head_w_r[0], a.vocab = a.vocab_r[0], a.logits = logits; /* (head_w: "a head is set") */
+    a.head_norm = (g_u16)(uintptr_t)norm_w, a.d_tokens_out = d_tokens_out, a.tokens_stride = tokens_stride;
     return KF_OK;
 }
 template <class C>
@@ -1223,6 +1455,8 @@ int xengine_steps(XEngineHost* E, hipStream_t st, int32_t* d_state, uint16_t* x_
         rc = E->nwv == 8 ? xengine_go<XC5>(E, st) : xengine_go<XC5W>(E, st);
     else if (E->shape_class == 6)
         rc = xengine_go<XC6>(E, st);
+    else if (E->shape_class == 7)
+        rc = xengine_go<XC7>(E, st);
     else
         rc = E->shape_class == 1 ? xengine_go_shape<XC1>(E, st) : xengine_go_shape<XC2>(E, st);
     a.head_w = save.head_w;

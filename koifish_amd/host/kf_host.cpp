@@ -910,6 +910,133 @@ int XcdReplicas::Check() {
     return rc;
 }
 
+// ---- tensor parallel over the XCDs
+XcdTP::~XcdTP() {
+    if (ranks.empty()) return;
+    kf_ctx* ctx = ranks[0]->ctx;
+    kf_sync(ctx);
+    if (engine) kf_xengine_destroy(engine);
+    if (engine_ws) kf_free(ctx, engine_ws);
+    if (d_state) kf_free(ctx, d_state);
+    if (d_forced) kf_free(ctx, d_forced);
+    if (d_tokens_out) kf_free(ctx, d_tokens_out);
+}
+int XcdTP::Build(Fish** fs, int world) {
+    if (!fs || world < 1) return KF_INVALID_ARGS;
+    for (int r = 0; r < world; r++)
+        if (!fs[r]) return KF_INVALID_ARGS;
+    ranks.assign(fs, fs + world);
+    Fish* f0 = fs[0];
+    kf_ctx* ctx = f0->ctx;
+    const MODEL_CARD& c = f0->config;
+    const int kvd = c.n_head_kv * c.head_dim;
+    const size_t rank_elems = (size_t)c.nLayer * c.n_ctx * kvd;
+    key = GT(ctx, "xtp.key", typNUMBER::BF16, kvd, c.n_ctx * c.nLayer * world);
+    val = GT(ctx, "xtp.val", typNUMBER::BF16, kvd, c.n_ctx * c.nLayer * world);
+    if (!key || !val) return KF_OUTOF_GPUMEMORY;
+    KF_TRY(kf_memset(ctx, key->data, 0, rank_elems * world * 2));
+    KF_TRY(kf_memset(ctx, val->data, 0, rank_elems * world * 2));
+    std::vector<std::vector<kf_engine_layer>> Ls(world);
+    std::vector<kf_engine_desc> ds(world);
+    std::vector<const kf_engine_desc*> dp(world);
+    std::vector<kf_weight> heads(world);
+    std::vector<const kf_weight*> hp(world);
+    std::vector<int32_t> row0(world);
+    vocab = 0;
+    for (int r = 0; r < world; r++) {
+        Fish* f = fs[r];
+        const MODEL_CARD& cr = f->config;
+        if (cr.nLayer != c.nLayer || cr.n_ctx != c.n_ctx || cr.nEmbed != c.nEmbed || cr.n_head_kv * cr.head_dim != kvd) {
+            why = "the ranks' cards disagree";
+            return KF_INVALID_ARGS;
+        }
+        Ls[r].resize(c.nLayer);
+        for (int l = 0; l < c.nLayer; l++) {
+            SelfAttention* a = f->attn[l].get();
+            FFN* m = f->ffn[l].get();
+            SLP* s[7] = {&a->Q, &a->K, &a->V, &a->proj_cat, &m->gate, &m->up, &m->down};
+            for (int j = 0; j < 7; j++) {
+                if (!s[j]->w || s[j]->b) {
+                    why = "a layer matrix is missing or carries a bias";
+                    return KF_ENGINE_NOT_SERVED;
+                }
+                Ls[r][l].w[j] = s[j]->w->desc();
+            }
+            if (!a->norm.w || !m->norm.w || m->n_hot >= 0) {
+                why = "a norm weight is missing or a hot-row mask is set";
+                return KF_ENGINE_NOT_SERVED;
+            }
+            Ls[r][l].hot_ffn = nullptr;
+            Ls[r][l].norm_in = ToX(a->norm.w), Ls[r][l].norm_post = ToX(m->norm.w);
+            Ls[r][l].q_norm = a->normQ.w ? ToX(a->normQ.w) : nullptr, Ls[r][l].k_norm = a->normK.w ? ToX(a->normK.w) : nullptr;
+            Ls[r][l].kcache = ToX(key) + (size_t)r * rank_elems + (size_t)l * c.n_ctx * kvd;
+            Ls[r][l].vcache = ToX(val) + (size_t)r * rank_elems + (size_t)l * c.n_ctx * kvd;
+        }
+        kf_engine_desc& d = ds[r];
+        std::memset(&d, 0, sizeof(d));
+        d.n_layer = c.nLayer, d.dim = cr.nEmbed, d.n_head = cr.n_head, d.n_kv = cr.n_head_kv, d.head_dim = cr.head_dim, d.ffn = cr.n_ff;
+        d.kv_stride = kvd, d.max_seq = c.n_ctx;
+        d.rms_eps = cr.rms_eps, d.qk_eps = cr.qk_eps, d.rope_table = f0->rope_table, d.layers = Ls[r].data();
+        dp[r] = &d;
+        if (!f->embed.w || !f->head.proj.w || !f->final_norm.w) {
+            why = "embedding / head / final norm missing";
+            return KF_ENGINE_NOT_SERVED;
+        }
+        heads[r] = f->head.proj.w->desc(), hp[r] = &heads[r], row0[r] = vocab;
+        vocab += cr.vocab;
+    }
+    logits = GT(ctx, "xtp.logits", typNUMBER::BF16, vocab, 1);
+    x = GT(ctx, "xtp.x", typNUMBER::BF16, c.nEmbed, 1);
+    if (!logits || !x) return KF_OUTOF_GPUMEMORY;
+    KF_TRY(kf_malloc(ctx, 16, (void**)&d_state));
+    KF_TRY(kf_malloc(ctx, (size_t)c.n_ctx * 4, (void**)&d_forced));
+    KF_TRY(kf_malloc(ctx, (size_t)c.n_ctx * 4, (void**)&d_tokens_out));
+    KF_TRY(kf_memset(ctx, d_state, 0, 16));
+    KF_TRY(kf_memset(ctx, d_forced, 0xff, (size_t)c.n_ctx * 4));
+    KF_TRY(kf_memset(ctx, d_tokens_out, 0, (size_t)c.n_ctx * 4));
+    const size_t bytes = kf_xengine_workspace_bytes_tp(dp[0]);
+    KF_TRY(kf_malloc(ctx, bytes, &engine_ws));
+    int rc = kf_xengine_create_tp(ctx, dp.data(), world, engine_ws, bytes, &engine);
+    if (rc != KF_OK) {
+        why = kf_last_error();
+        return rc == KF_UNSUPPORTED_DATATYPE ? KF_ENGINE_NOT_SERVED : rc;
+    }
+    kf_weight we = f0->embed.w->desc();
+    rc = kf_xengine_set_embedding(ctx, engine, &we, d_forced, c.n_ctx);
+    if (rc == KF_OK) rc = kf_xengine_set_head_tp(ctx, engine, hp.data(), row0.data(), ToX(f0->final_norm.w), ToX(logits), d_tokens_out, c.n_ctx);
+    if (rc != KF_OK) {
+        why = kf_last_error();
+        return rc == KF_UNSUPPORTED_DATATYPE ? KF_ENGINE_NOT_SERVED : rc;
+    }
+    return KF_OK;
+}
+int XcdTP::SetForced(const int32_t* ids, int n) {
+    const int n_ctx = ranks[0]->config.n_ctx;
+    if (n < 0 || n > n_ctx) return KF_INVALID_ARGS;
+    std::vector<int32_t> row(n_ctx, -1);
+    for (int i = 0; i < n; i++) row[i] = ids[i];
+    return kf_h2d(ranks[0]->ctx, d_forced, row.data(), row.size() * 4);
+}
+int XcdTP::SetState(int token, int pos) {
+    if (pos < 0 || pos >= ranks[0]->config.n_ctx || token < 0 || token >= vocab) return KF_INVALID_ARGS;
+    return kf_set_state(ranks[0]->ctx, d_state, token, pos);
+}
+int XcdTP::RunSteps(int n) {
+    if (!engine || n < 1) return KF_INVALID_ARGS;
+    for (int i = 0; i < n;) {
+        const int m = n - i < steps_per_launch ? n - i : steps_per_launch;
+        KF_TRY(kf_xengine_steps(ranks[0]->ctx, engine, ToX(x), d_state, m, 1));
+        i += m;
+    }
+    return KF_OK;
+}
+int XcdTP::Check() {
+    if (!engine) return KF_OK;
+    const int rc = kf_xengine_check(ranks[0]->ctx, engine);
+    if (rc == KF_INTERNAL_ERR) kf_xengine_reset(ranks[0]->ctx, engine);
+    return rc;
+}
+
 }  // namespace koifish
 
 // ================================================================================================ C entry points
@@ -1328,6 +1455,37 @@ void* kfh_xr_vcache(void* h, int seq) {
     XcdReplicas* r = reinterpret_cast<XcdReplicas*>(h);
     return ToX(r->val) + (size_t)seq * r->kv_seq_elems();
 }
+void* kfh_xtp_create(void** fishes, int world, int* rc_out) {
+    XcdTP* t = new XcdTP();
+    const int rc = t->Build(reinterpret_cast<Fish**>(fishes), world);
+    if (rc_out) *rc_out = rc;
+    if (rc != KF_OK) {
+        g_host_err = t->why;
+        delete t;
+        return nullptr;
+    }
+    return t;
+}
+void kfh_xtp_destroy(void* h) { delete reinterpret_cast<XcdTP*>(h); }
+int kfh_xtp_set_forced(void* h, const int32_t* ids, int n) { return reinterpret_cast<XcdTP*>(h)->SetForced(ids, n); }
+int kfh_xtp_set_state(void* h, int token, int pos) { return reinterpret_cast<XcdTP*>(h)->SetState(token, pos); }
+int kfh_xtp_run_steps(void* h, int n) { return reinterpret_cast<XcdTP*>(h)->RunSteps(n); }
+int kfh_xtp_check(void* h) { return reinterpret_cast<XcdTP*>(h)->Check(); }
+int kfh_xtp_set_steps_per_launch(void* h, int n) {
+    if (n < 1 || n > 4096) return KF_INVALID_ARGS;
+    reinterpret_cast<XcdTP*>(h)->steps_per_launch = n;
+    return KF_OK;
+}
+int kfh_xtp_get_tokens(void* h, int32_t* out, int n) {
+    XcdTP* t = reinterpret_cast<XcdTP*>(h);
+    if (n < 0 || n > t->ranks[0]->config.n_ctx) return KF_INVALID_ARGS;
+    return kf_d2h(t->ranks[0]->ctx, out, t->d_tokens_out, (size_t)n * 4);
+}
+int kfh_xtp_vocab(void* h) { return reinterpret_cast<XcdTP*>(h)->vocab; }
+void* kfh_xtp_logits(void* h) { return ToX(reinterpret_cast<XcdTP*>(h)->logits); }
+void* kfh_xtp_hidden(void* h) { return ToX(reinterpret_cast<XcdTP*>(h)->x); }
+void* kfh_xtp_kcache(void* h) { return ToX(reinterpret_cast<XcdTP*>(h)->key); }
+void* kfh_xtp_vcache(void* h) { return ToX(reinterpret_cast<XcdTP*>(h)->val); }
 extern "C" int kfdbg_xengine_variant(kf_xengine* e, int nwv, int depth);
 extern "C" int kfdbg_xengine_stamps_enable(kf_xengine* e, int seq, int wg, int max_steps);
 extern "C" int kfdbg_xengine_stamps(kf_xengine* e, unsigned long long* h_out, int n_words);

@@ -306,4 +306,26 @@ struct XcdReplicas {
     size_t kv_seq_elems() const;
 };
 
+// ONE sequence of a model split over eight tensor-parallel ranks, the ranks as the eight XCDs of ONE launch (kf_xengine_create_tp): the Fish of every rank holds its shards
+// (koifish_amd/tp.py build_native_rank); this object owns the ranks' K / V rows, the sequence's state / forced ids / ids out, the full logits vector.
+struct XcdTP {
+    std::vector<Fish*> ranks;  // not owned
+    kf_xengine* engine = nullptr;
+    void* engine_ws = nullptr;
+    hGTensor key, val;         // [rank][n_layer][n_ctx][kv_dim of a rank] bf16
+    hGTensor logits, x;        // [vocab] (the shards in rank order), [nEmbed]
+    int32_t* d_state = nullptr;
+    int32_t* d_forced = nullptr;
+    int32_t* d_tokens_out = nullptr;
+    int vocab = 0;
+    std::string why;
+    int steps_per_launch = 16;
+    ~XcdTP();
+    int Build(Fish** fs, int world);
+    int SetForced(const int32_t* ids, int n);
+    int SetState(int token, int pos);
+    int RunSteps(int n);
+    int Check();
+};
+
 }  // namespace koifish

@@ -691,3 +691,73 @@ class XcdReplicas:
         out = np.zeros((-steps) * n_layer * 64, dtype=np.uint64)
         self.host.kfh_xr_stamps(self.h, out.ctypes.data_as(C.c_void_p), out.size)
         return out.reshape(-steps, n_layer, 64)
+
+
+class XcdTP:
+    """ONE sequence of a model split over eight tensor-parallel ranks, the ranks as the eight XCDs of ONE launch (koifish::XcdTP over kf_xengine_create_tp).  `native_tp`: a
+    koifish_amd.tp.NativeTP -- its ranks hold the shards (and stay usable: the per-launch rank step and this engine give the same bits).  K / V rows, state, forced ids, ids
+    out and the full logits vector live in this object."""
+
+    def __init__(self, native_tp):
+        self.nt = native_tp
+        r0 = native_tp.ranks[0]
+        self.host, self.hip = r0.host, r0.hip
+        self._hs = (C.c_void_p * len(native_tp.ranks))(*[m.h for m in native_tp.ranks])
+        rc = C.c_int(0)
+        h = self.host.kfh_xtp_create(self._hs, len(native_tp.ranks), C.byref(rc))
+        if not h:
+            raise L.KFError("kfh_xtp_create failed with %d: %s" % (rc.value, self.host.kfh_host_error().decode() or self.hip.kf_last_error().decode()))
+        self.h = C.c_void_p(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.host.kfh_xtp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_forced(self, ids):
+        a = np.ascontiguousarray(ids, dtype=np.int32)
+        L.check(self.host.kfh_xtp_set_forced(self.h, a.ctypes.data_as(C.c_void_p), a.size), "kfh_xtp_set_forced")
+
+    def set_state(self, token, pos):
+        L.check(self.host.kfh_xtp_set_state(self.h, int(token), int(pos)), "kfh_xtp_set_state")
+
+    def run_steps(self, n):
+        L.check(self.host.kfh_xtp_run_steps(self.h, int(n)), "kfh_xtp_run_steps")
+
+    def set_steps_per_launch(self, n):
+        L.check(self.host.kfh_xtp_set_steps_per_launch(self.h, int(n)), "kfh_xtp_set_steps_per_launch")
+
+    def check(self):
+        L.check(self.host.kfh_xtp_check(self.h), "kfh_xtp_check")
+
+    def tokens_out(self, n):
+        out = np.zeros(n, dtype=np.int32)
+        L.check(self.host.kfh_xtp_get_tokens(self.h, out.ctypes.data_as(C.c_void_p), n), "kfh_xtp_get_tokens")
+        return out
+
+    def _d2h(self, ptr, n_u16):
+        out = np.zeros(n_u16, dtype=np.uint16)
+        ctx = C.c_void_p(self.host.kfh_ctx(self.nt.ranks[0].h))
+        L.check(self.hip.kf_d2h(ctx, out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(out.size * 2)), "kf_d2h")
+        return out
+
+    def logits(self):
+        """the last step's logits of the FULL vocabulary (the ranks' shards in rank order), bf16 bit patterns"""
+        return self._d2h(self.host.kfh_xtp_logits(self.h), int(self.host.kfh_xtp_vocab(self.h)))
+
+    def hidden(self):
+        return self._d2h(self.host.kfh_xtp_hidden(self.h), self.nt.cfg["dim"])
+
+    def kv_to_host(self):
+        """[rank][layer][max_seq][head_dim]: rank r = kv-head r's rows"""
+        c = self.nt.cfg
+        kvd = (c["n_kv"] // len(self.nt.ranks)) * c["head_dim"]
+        n = len(self.nt.ranks) * c["n_layer"] * c["max_seq"] * kvd
+        shp = (len(self.nt.ranks), c["n_layer"], c["max_seq"], kvd)
+        return self._d2h(self.host.kfh_xtp_kcache(self.h), n).reshape(shp), self._d2h(self.host.kfh_xtp_vcache(self.h), n).reshape(shp)

@@ -290,3 +290,79 @@ def test_native_tp8_full_depth_qwen3_32b_vs_the_oracle(ctx):
     assert np.array_equal(g_logits, o_logits), "%d of %d logits differ" % (int((g_logits != o_logits).sum()), g_logits.size)
     om.close()
     nt.close()
+
+
+def test_tp8_ranks_as_the_eight_xcds_of_one_launch_vs_the_oracle(ctx):
+    """The TP = 8 ranks of a Qwen3-32B-shaped model as the eight XCDs of ONE launch (kf_xengine_create_tp, koifish::XcdTP; round 5): rank r's 32 workgroups stream rank r's
+    shards, q | k | v / attention / gate | up inside the XCD, the o_proj / down_proj partials exchanged between the XCDs inside the kernel and summed in rank order, the head
+    in vocabulary shards with a cross-XCD pick, several tokens per launch.  A 3-layer slice decoded from position 0 -- 24 forced ids, then free running -- against the
+    oracle's tensor-parallel emulation in the canonical order: every id, the last logits and every K / V row bit for bit; and the same ids from the per-launch rank step
+    (NativeTP, the kernels an 8-GPU node runs)."""
+    from koifish_amd.runtime import XcdTP
+    cfg = dict(synth.CONFIGS["qwen3-32b"], n_layer=3, vocab=8192, max_seq=320, tied=True)
+    g = torch.Generator(device=ctx.device)
+    g.manual_seed(77)
+
+    def mat(r, c, std=0.05):
+        return (torch.randn(r, c, generator=g, device=ctx.device, dtype=torch.float32) * std).to(torch.bfloat16)
+
+    def nrm(n):
+        return (1.0 + 0.01 * torch.randn(n, generator=g, device=ctx.device, dtype=torch.float32)).to(torch.bfloat16)
+    w, norms = {}, {}
+    w[(-1, 0)] = ctx.quantize(mat(cfg["vocab"], cfg["dim"], std=0.1), L.BF16)
+    w[(-1, 1)] = w[(-1, 0)]
+    norms[(-1, 0)] = nrm(cfg["dim"])
+    for li in range(cfg["n_layer"]):
+        for si, s in enumerate(synth.SLOTS):
+            w[(li, si)] = ctx.quantize(mat(*synth.SHAPES[s](cfg)), L.Q4)
+        norms[(li, 0)], norms[(li, 1)], norms[(li, 2)], norms[(li, 3)] = nrm(cfg["dim"]), nrm(cfg["dim"]), nrm(128), nrm(128)
+    nt = TP.NativeTP(cfg, w, norms, 8, ctx)
+    for rk in nt.ranks:
+        rk.set_canonical(True)
+    n_prompt, n = 24, 272
+    forced = np.full(cfg["max_seq"], -1, dtype=np.int32)
+    forced[:n_prompt] = np.random.default_rng(5).integers(0, cfg["vocab"], size=n_prompt)
+    xt = XcdTP(nt)
+    xt.set_forced(forced)
+    xt.set_state(int(forced[0]), 0)
+    xt.set_steps_per_launch(16)
+    xt.run_steps(n)
+    ctx.sync()
+    xt.check()
+    ids = xt.tokens_out(n)
+    g_logits = xt.logits()
+    gk, gv = xt.kv_to_host()                            # [rank][layer][pos][128]
+    # the per-launch rank step on the same ids
+    nt.set_forced(forced)
+    nt.set_state(int(forced[0]), 0)
+    nt.run_steps(0, n, use_graph=True)
+    nt.check()
+    assert nt.ranks[0].tokens_out(n).tolist() == ids.tolist()
+    assert np.array_equal(nt.logits(), g_logits)
+
+    class Dev:
+        pass
+    m = Dev()
+    m.cfg, m.weights, m._norms = cfg, w, norms
+    om = O.from_device_model(m, attn_mode=O.ATTN_CANON)
+    O.lib().kfo_qwen3_set_tp(om.h, 8)
+    om.prepare_fast()
+    O.set_order(O.ORDER_CANON)
+    try:
+        tok, o_ids, o_logits = int(forced[0]), [], None
+        for pos in range(n):
+            if forced[pos] >= 0:
+                tok = int(forced[pos])
+            o_id, o_logits, _ = om.decode(tok, pos)
+            o_ids.append(int(o_id))
+            tok = int(o_id)
+    finally:
+        O.set_order(O.ORDER_DOT16)
+    assert ids.tolist() == o_ids
+    assert np.array_equal(g_logits, o_logits), "%d of %d logits differ" % (int((g_logits != o_logits).sum()), g_logits.size)
+    ok, ov = om.kv()                                    # [layer][pos][8 * 128]
+    for r in range(8):
+        assert np.array_equal(gk[r][:, :n], ok[:, :n, r * 128:(r + 1) * 128]) and np.array_equal(gv[r][:, :n], ov[:, :n, r * 128:(r + 1) * 128]), "rank %d" % r
+    om.close()
+    xt.close()
+    nt.close()
