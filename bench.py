@@ -56,6 +56,7 @@ def main():
                     "torch.distributed all-gathers per layer")
     ap.add_argument("--tp-virtual", type=int, default=0, help="side measurement on ONE GPU: this many TP ranks of qwen3-32b in one process, lock-step on one stream "
                     "(the per-rank kernels and the exchange kernels of TP = R, serialised: R x the work of one rank's GPU, no xGMI)")
+    ap.add_argument("--tp-xcd", type=int, default=0, help="with --tp-virtual 8: the eight ranks as the eight XCDs of ONE launch (kf_xengine_create_tp) instead of the per-launch rank step")
     ap.add_argument("--tp-layers", type=int, default=0, help="with --tp-virtual: this many of the model's layers (0 = all): bounds the side leg's wall time")
     ap.add_argument("--lean-cpu", type=float, default=0.0, help="with --lean: also the CPU-baseline leg (parity passes + a timed sample of this many seconds) of the model being run")
     ap.add_argument("--lean-prefill", type=int, default=0, help="with --lean: also a prompt of this many tokens through Fish::Prefill (prefill_rate)")
@@ -435,6 +436,7 @@ def side_legs(which):
             "prefill_2047_tokens": {k: (d.get("prefill") or {}).get(k) for k in ("ms", "tokens_per_s", "first_call_ms", "resident_copy_bytes", "roofline", "error") if (d.get("prefill") or {}).get(k) is not None},
             "cpu_baseline_4_layer_slice": _child(["--leg", "config4cpu"], 420),
             "tp8_virtual_ranks": _tp_virtual_leg(),
+            "tp8_ranks_as_xcds": _child(["--config", "qwen3-32b", "--tp-virtual", "8", "--tp-xcd", "1", "--steps", "32", "--warmup", "8"], 600),
             "note": "TP = 8 over xGMI needs an 8-GPU node: bench.py --config qwen3-32b --gpus 8 (no scaling curve has been measured on hardware)"}
     return out
 
@@ -610,6 +612,8 @@ def tp_main(args, cfg, rank, world, dev):
                     L.check(nt.host.kfh_tp_set_peer(a.h, r, C.c_void_p(nt.host.kfh_tp_area(b.h))), "kfh_tp_set_peer")
             nt._hs = (C.c_void_p * R)(*[m.h for m in nt.ranks])
             drv = nt
+            if args.tp_xcd:
+                return xcd_tp_leg(nt, cfg, ctx, forced, S, K, W, shards, plan)
         else:
             drv = TP.NativeRank(cfg, plan, rank, shards[rank], norms, dev)
         drv.set_forced(forced)
@@ -661,6 +665,52 @@ def tp_main(args, cfg, rank, world, dev):
         print(json.dumps(out))
     if not virtual and dist.is_initialized():
         dist.destroy_process_group()
+
+
+def xcd_tp_leg(nt, cfg, ctx, forced, S, K, W, shards, plan):
+    """Qwen3-32B on ONE MI355X as tensor parallel over the XCDs: rank r of the TP = 8 plan on XCD r, all of them in ONE launch (koifish::XcdTP, kf_xengine_create_tp) -- the
+    o_proj / down_proj partials exchanged between the XCDs inside the kernel.  The whole sequence is decoded token by token by this engine from position 0; timed: the last K
+    positions of the context.  Bits: those of the TP = 8 rank step (tests/test_gpu_tp.py::test_tp8_ranks_as_the_eight_xcds_of_one_launch_vs_the_oracle); here the first 24 ids
+    are compared with the per-launch rank step's."""
+    import numpy as np
+    import torch
+    from koifish_amd.runtime import XcdTP
+    for rk in nt.ranks:
+        rk.set_canonical(True)
+    xt = XcdTP(nt)
+    xt.set_forced(forced)
+    xt.set_state(int(forced[0]), 0)
+    start = S - (W + K)
+    xt.run_steps(start)
+    xt.run_steps(W)
+    torch.cuda.synchronize()
+    e0, e1 = ctx.event(), ctx.event()
+    t0 = time.perf_counter()
+    ctx.record(e0)
+    xt.run_steps(K)
+    ctx.record(e1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    xt.check()
+    ids_x = xt.tokens_out(S)
+    nt.set_forced(forced)
+    nt.set_state(int(forced[0]), 0)
+    nt.run_steps(0, 24, True)
+    nt.check()
+    same = bool(np.array_equal(nt.ranks[0].tokens_out(24), ids_x[:24]))
+    ms = dt * 1e3 / K
+    mean_pos = S - K / 2.0
+    weights = sum(x.algorithmic_bytes() for r in shards for k, x in shards[r].items() if k != (-1, 0)) + cfg["dim"] * 2
+    step_bytes = weights + 2 * cfg["n_layer"] * mean_pos * cfg["n_kv"] * cfg["head_dim"] * 2
+    ach = step_bytes / (ms * 1e-3) / 1e9
+    print(json.dumps({
+        "workload": "Qwen3-32B 4-bit PackedQ greedy decode on ONE MI355X, the TP = 8 ranks as the eight XCDs of one launch, context %d: timed positions %d..%d" % (S, S - K, S - 1),
+        "tokens_per_s": round(K / dt, 2), "ms_per_step": round(ms, 4), "device_ms_per_step": round(ctx.elapsed_ms(e0, e1) / K, 4), "steps": K, "layers": cfg["n_layer"], "vocab": cfg["vocab"],
+        "bytes_per_step": int(step_bytes), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+        "kernel": "kf::xengine_kernel<XCfg<..., TP>> (koifish_amd/csrc/kf_xengine.hip): per layer four hand-offs inside each XCD + two exchanges between them",
+        "summation_order": "canonical, tensor parallel TP = 8 (column shards as fp32 partials summed in rank order: the bits an 8-GPU node computes)",
+        "parity": {"first_24_ids_equal_per_launch_rank_step": same, "oracle": "tests/test_gpu_tp.py::test_tp8_ranks_as_the_eight_xcds_of_one_launch_vs_the_oracle (ids, logits, K / V rows bit for bit)"}}))
+    xt.close()
 
 
 def prefill_rate(m, prompt, decode_ms_per_step, reps=5, bound=None):

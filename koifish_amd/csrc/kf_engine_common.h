@@ -249,15 +249,18 @@ __device__ __forceinline__ void eng_norm_long_pass1(const uint32_t* gsrc, const 
 template <int XCH, int NLD, int NBLK, bool PLAIN, bool F32X, int PIECE>
 __device__ __forceinline__ void eng_poll_stage_norm_long(const uint32_t* gsrc, const uint16_t* plain, uint32_t tag, g_u16 norm_w, float eps, u32x4* xs, uint16_t* xraw, int lane, int* ws, bool& dead) {
     constexpr int n = NLD * 256;
+    u32x2 wn[NLD]; /* the norm weights: requested in front of the sweep (inside pass 2 each batch of them would be a round trip to the L2 on the hand-off's critical path) */
+#pragma unroll
+    for (int r = 0; r < NLD; r++) wn[r] = *reinterpret_cast<const u32x2 KF_GLOBAL*>(norm_w + 4 * (r * 64 + lane));
     double ss = 0.0;
     eng_norm_long_pass1<XCH, NLD, NBLK, PLAIN, F32X, PIECE>(gsrc, plain, tag, xraw, lane, ws, dead, ss);
     const double tot = wave_sum_f64_fast(ss);
     const float mul = 1.0f / sqrtf(fmaf((float)tot, 1.0f / (float)n, eps));
-#pragma unroll 4
+#pragma unroll
     for (int r = 0; r < NLD; r++) {
         const int e0 = 4 * (r * 64 + lane);
         const u32x2 raw = *reinterpret_cast<const u32x2*>(xraw + e0); /* this lane's own words of pass 1 */
-        const u32x2 w = *reinterpret_cast<const u32x2 KF_GLOBAL*>(norm_w + e0);
+        const u32x2 w = wn[r];
         const uint32_t o0 = pack_bf16x2((bf_lo(raw.x) * mul) * bf_lo(w.x), (bf_hi(raw.x) * mul) * bf_hi(w.x));
         const uint32_t o1 = pack_bf16x2((bf_lo(raw.y) * mul) * bf_lo(w.y), (bf_hi(raw.y) * mul) * bf_hi(w.y));
         if (F32X) {

@@ -554,7 +554,7 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, co
         const EngLayer& ly = L.lay[l];
         const uint32_t gen = (uint32_t)epoch * (uint32_t)a.n_layer + (uint32_t)l, tag = gen & 0xffffu;
         XE_STAMP(0);
-        if (C::DBG && S.stamp && lane == 0) a.dbg[((size_t)S.step * a.n_layer + l) * 64 + 31] = __builtin_amdgcn_s_memtime(); /* the shader clock beside the 100 MHz stamp: the frequency the CU really runs at */
+        if (C::DBG && !C::TP && S.stamp && lane == 0) a.dbg[((size_t)S.step * a.n_layer + l) * 64 + 31] = __builtin_amdgcn_s_memtime(); /* the shader clock beside the 100 MHz stamp: the frequency the CU really runs at */
         // P1's x (P4 adds it as the residual)
         if (l == 0) {
             int tok = a.d_state[S.sq * 4];
@@ -586,6 +586,7 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, co
             XE_STAMP(12);
             if constexpr (C::TP) /* the down_proj exchange of the layer before: this workgroup's rows summed over the ranks + the residual xB -> the local x area */
                 xe_tp_reduce<C>(a, S, 1, 2u * (gen - 1u) + 2u, L.xrawB, loc + C::xA + S.r * RT, tag, nullptr, lane, dead);
+            if constexpr (C::TP) XE_STAMP(31); /* (TP: the slot of the shader-clock stamp) this workgroup's rows of the down_proj exchange are summed */
             if constexpr (ND > 12) eng_poll_stage_norm_long<XCH, ND, C::XS, false, true, 8>(loc + C::xA, nullptr, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead);
             else eng_poll_stage<XCH, ND, C::XS, true, false, true>(loc + C::xA, nullptr, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, nullptr, nullptr, 0, 0);
         }
@@ -690,6 +691,7 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, co
         eng_wait_pub(L.pub + 1, S.step * a.n_layer + l + 1, 0, dead);
         XE_STAMP(10);
         if constexpr (C::TP) xe_tp_reduce<C>(a, S, 0, 2u * gen + 1u, L.xrawA, loc + C::xB + S.r * RT, tag, nullptr, lane, dead); /* the o_proj exchange + the residual x */
+        if constexpr (C::TP) XE_STAMP(13); /* (TP: the slot of the act sweep count) this workgroup's rows of the o_proj exchange are summed */
         if constexpr (ND > 12) eng_poll_stage_norm_long<XCH, ND, C::XS, false, true, 8>(loc + C::xB, nullptr, tag, ly.norm_post, a.eps, L.xs[0], L.xrawB, lane, a.ws, dead);
         else eng_poll_stage<XCH, ND, C::XS, true, false, true>(loc + C::xB, nullptr, tag, ly.norm_post, a.eps, L.xs[0], L.xrawB, lane, a.ws, dead, nullptr, nullptr, 0, 0);
         XE_STAMP(7);
@@ -699,7 +701,7 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, co
         int nsw_act = 0;
         if constexpr (NF > 24) eng_poll_stage_long<XCH, NF, C::XS, 16>(loc + C::act, tag, L.xs[1], lane, a.ws, dead, &nsw_act); /* a 9728-wide vector in one sweep: 152 registers */
         else eng_poll_stage<XCH, NF, C::XS, false, false, true>(loc + C::act, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, &nsw_act, nullptr, 0, 0);
-        if (C::DBG && S.stamp && lane == 0) a.dbg[((size_t)S.step * a.n_layer + l) * 64 + 13] = (unsigned long long)nsw_act;
+        if (C::DBG && !C::TP && S.stamp && lane == 0) a.dbg[((size_t)S.step * a.n_layer + l) * 64 + 13] = (unsigned long long)nsw_act;
         XE_STAMP(8);
         __syncthreads(); /* B6 */
     }
@@ -1295,6 +1297,7 @@ int xengine_build(const kf_engine_desc* d, int n_seq, long long kv_seq_stride, v
 // ---- tensor parallel over the XCDs: ONE sequence of a model too wide for one XCD's share to be a decoder of its own -- eight ranks = eight XCDs (XCfg::TP)
 // a rank of Qwen3-32B under TP = 8: 8 query heads on 1 kv-head, q_dim 1024, ffn 3200 (koifish_amd/tp.py TPPlan)
 using XC7 = XCfg<FMT_Q4P, 8, 128, 12, 5120, 1024, 128, 3200, 6, false, 1, 1, true>;
+using XC7D = XCfg<FMT_Q4P, 8, 128, 12, 5120, 1024, 128, 3200, 6, true, 1, 1, true>; /* + the per-phase stamps of one workgroup of one rank */
 static bool xe_tp_shape(const kf_engine_desc* d) { return d->head_dim == 128 && d->n_head == 8 && d->n_kv == 1 && d->dim == 5120 && d->ffn == 3200; }
 static size_t xe_tp_recv_granules() { return (size_t)XE_NXCD * 2 * XE_NXCD * XC7::DIM; }
 size_t xengine_ws_bytes_tp(const kf_engine_desc* d0) {
@@ -1456,7 +1459,7 @@ int xengine_steps(XEngineHost* E, hipStream_t st, int32_t* d_state, uint16_t* x_
     else if (E->shape_class == 6)
         rc = xengine_go<XC6>(E, st);
     else if (E->shape_class == 7)
-        rc = xengine_go<XC7>(E, st);
+        rc = E->args.dbg ? xengine_go<XC7D>(E, st) : xengine_go<XC7>(E, st);
     else
         rc = E->shape_class == 1 ? xengine_go_shape<XC1>(E, st) : xengine_go_shape<XC2>(E, st);
     a.head_w = save.head_w;

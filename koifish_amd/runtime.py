@@ -761,3 +761,13 @@ class XcdTP:
         n = len(self.nt.ranks) * c["n_layer"] * c["max_seq"] * kvd
         shp = (len(self.nt.ranks), c["n_layer"], c["max_seq"], kvd)
         return self._d2h(self.host.kfh_xtp_kcache(self.h), n).reshape(shp), self._d2h(self.host.kfh_xtp_vcache(self.h), n).reshape(shp)
+
+    def stamps(self, rank, wg, steps, n_layer):
+        """enable (steps > 0) / read the per-phase wall-clock stamps [step][layer][64] of one workgroup of one rank (diagnostic instantiation)"""
+        if steps > 0:
+            L.check(self.host.kfh_xtp_stamps_enable(self.h, int(rank), int(wg), int(steps)), "kfh_xtp_stamps_enable")
+            return None
+        n = -steps * n_layer * 64
+        out = np.zeros(n, dtype=np.uint64)
+        self.host.kfh_xtp_stamps(self.h, out.ctypes.data_as(C.c_void_p), n)
+        return out.reshape(-steps, n_layer, 64)

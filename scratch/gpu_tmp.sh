@@ -1,3 +1,3 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-timeout 1500 python -m pytest tests/test_gpu_tp.py -x -q -k "eight_xcds" 2>&1 | tail -25
+STAMPS=1 timeout 900 python3 scratch/xtp_time.py 16 4000 16 2>&1 | grep -v amdgpu.ids | tail -40
