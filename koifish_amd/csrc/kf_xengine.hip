@@ -84,6 +84,9 @@ struct XCfg {
     // partials into every rank's receive area (the protocol of kf_tp.hip, inside the launch), each workgroup sums its 1 / 32 of the rows over the ranks in rank order,
     // adds the residual and publishes the slice inside its XCD -- from there on the hand-off is the local one.
     static constexpr bool TP = TP_;
+    // wide residual streams: EVERY wave of the workgroup sweeps, normalises and stages its own 1 KiB units of x / xB (the compute waves stand at the barrier behind that
+    // staging anyway; ONE wave doing it took 14 us of a 192 us layer at 5120 values: scratch/xtp_time.py)
+    static constexpr bool COOP = DIM_ >= 2048;
     static constexpr int FFNP = (FFN_ + 255) & ~255; /* the SwiGLU vector's exchange area in whole 1 KiB sweeps (a rank's 3200: 128 granules of padding, published as zeros) */
     static constexpr int AU = AU_; /* key tiles per attention batch and wave */
     static constexpr bool DEAL_CONTIG = WPC_ > 1 || NWV_ == 8; /* xe_deal: 7 compute waves = ONE beside the poller on its SIMD: a run per wave, that wave's shorter */
@@ -536,6 +539,71 @@ __device__ __forceinline__ void xe_attn_phase(const XArgs& a, const XLds& L, con
     }
 }
 
+// ---- cooperative RMSNorm staging (XCfg::COOP): wave w owns the 1 KiB units w, w + NWV, ... of the vector.  Sweep until tagged; raw bf16 -> xraw (the residual of the phase
+// after next), fp64 sum of squares -> one LDS slot per wave; barrier; total = the slots in wave order (an fp64 sum: the order is far below an fp32 ulp -- the argument of
+// oracle section 5); normalise and stage the own units as fp32 chunks.  The caller's phase barrier follows.
+template <class C>
+__device__ __forceinline__ void xe_coop_norm_stage(const XArgs& a, const XLds& L, const uint32_t* gsrc, uint32_t tag, g_u16 norm_w, u32x4* xs, uint16_t* xraw, int wave, int lane, bool* dead_io) {
+    constexpr int ND = C::DIM / 256, NWV = C::NWV, NR = (ND + NWV - 1) / NWV, XCH = C::XCH, NBLK = C::XS;
+    const __amdgpu_buffer_rsrc_t rs = eng_rsrc(gsrc, (uint32_t)ND * 1024u);
+    u32x4 g[NR];
+    u32x2 wn[NR];
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+        const int r = wave + k * NWV;
+        wn[k] = *reinterpret_cast<const u32x2 KF_GLOBAL*>(norm_w + 4 * ((r < ND ? r : 0) * 64 + lane));
+    }
+    const uint32_t tagw = tag << 16;
+    bool dead = dead_io ? *dead_io : false;
+    for (int spins = 0;; spins++) {
+        uint32_t bad = 0;
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            const int r = wave + k * NWV;
+            g[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ((r < ND ? r : 0) * 64 + lane) * 16, 0, 16 /* sc1 */));
+        }
+#pragma unroll
+        for (int k = 0; k < NR; k++) bad = (wave + k * NWV) < ND ? tags_bad(g[k], tagw, bad) : bad;
+        if (all_good(bad)) break;
+        if (dead || spins > ENG_SPIN_MAX || ((spins & 1023) == 1023 && __hip_atomic_load(a.ws + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            if (!dead && spins > ENG_SPIN_MAX && lane == 0) atomicOr(a.ws + 1, 1);
+            dead = true;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (dead_io) *dead_io = dead;
+    uint32_t p0[NR], p1[NR];
+    double ss = 0.0;
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+        const int r = wave + k * NWV;
+        p0[k] = (g[k].x & 0xffffu) | (g[k].y << 16), p1[k] = (g[k].z & 0xffffu) | (g[k].w << 16);
+        if (r < ND) {
+            const double x0 = (double)bf_lo(p0[k]), x1 = (double)bf_hi(p0[k]), x2 = (double)bf_lo(p1[k]), x3 = (double)bf_hi(p1[k]);
+            ss = fma(x0, x0, ss), ss = fma(x1, x1, ss), ss = fma(x2, x2, ss), ss = fma(x3, x3, ss);
+            *reinterpret_cast<u32x2*>(xraw + 4 * (r * 64 + lane)) = u32x2{p0[k], p1[k]};
+        }
+    }
+    const double mine = wave_sum_f64_fast(ss);
+    if (lane == 0) L.msc[wave] = mine;
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < NWV; w++) tot += L.msc[w];
+    const float mul = 1.0f / sqrtf(fmaf((float)tot, 1.0f / (float)C::DIM, a.eps));
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+        const int r = wave + k * NWV;
+        if (r < ND) {
+            const int e0 = 4 * (r * 64 + lane), q = e0 >> 2, c = q / XCH, j = q - c * XCH;
+            const uint32_t o0 = pack_bf16x2((bf_lo(p0[k]) * mul) * bf_lo(wn[k].x), (bf_hi(p0[k]) * mul) * bf_hi(wn[k].x));
+            const uint32_t o1 = pack_bf16x2((bf_lo(p1[k]) * mul) * bf_lo(wn[k].y), (bf_hi(p1[k]) * mul) * bf_hi(wn[k].y));
+            xs[j * NBLK + c] = u32x4{o0 << 16, o0 & 0xffff0000u, o1 << 16, o1 & 0xffff0000u};
+        }
+    }
+}
+
 // ---- the poller wave of a workgroup
 template <class C>
 __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, const XSeq& S, int epoch, int lane) {
@@ -587,7 +655,8 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, co
             if constexpr (C::TP) /* the down_proj exchange of the layer before: this workgroup's rows summed over the ranks + the residual xB -> the local x area */
                 xe_tp_reduce<C>(a, S, 1, 2u * (gen - 1u) + 2u, L.xrawB, loc + C::xA + S.r * RT, tag, nullptr, lane, dead);
             if constexpr (C::TP) XE_STAMP(31); /* (TP: the slot of the shader-clock stamp) this workgroup's rows of the down_proj exchange are summed */
-            if constexpr (ND > 12) eng_poll_stage_norm_long<XCH, ND, C::XS, false, true, 8>(loc + C::xA, nullptr, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead);
+            if constexpr (C::COOP) xe_coop_norm_stage<C>(a, L, loc + C::xA, tag, ly.norm_in, L.xs[0], L.xrawA, C::NWV - 1, lane, &dead);
+            else if constexpr (ND > 12) eng_poll_stage_norm_long<XCH, ND, C::XS, false, true, 8>(loc + C::xA, nullptr, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead);
             else eng_poll_stage<XCH, ND, C::XS, true, false, true>(loc + C::xA, nullptr, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, nullptr, nullptr, 0, 0);
         }
         XE_STAMP(1);
@@ -692,7 +761,8 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, co
         XE_STAMP(10);
         if constexpr (C::TP) xe_tp_reduce<C>(a, S, 0, 2u * gen + 1u, L.xrawA, loc + C::xB + S.r * RT, tag, nullptr, lane, dead); /* the o_proj exchange + the residual x */
         if constexpr (C::TP) XE_STAMP(13); /* (TP: the slot of the act sweep count) this workgroup's rows of the o_proj exchange are summed */
-        if constexpr (ND > 12) eng_poll_stage_norm_long<XCH, ND, C::XS, false, true, 8>(loc + C::xB, nullptr, tag, ly.norm_post, a.eps, L.xs[0], L.xrawB, lane, a.ws, dead);
+        if constexpr (C::COOP) xe_coop_norm_stage<C>(a, L, loc + C::xB, tag, ly.norm_post, L.xs[0], L.xrawB, C::NWV - 1, lane, &dead);
+        else if constexpr (ND > 12) eng_poll_stage_norm_long<XCH, ND, C::XS, false, true, 8>(loc + C::xB, nullptr, tag, ly.norm_post, a.eps, L.xs[0], L.xrawB, lane, a.ws, dead);
         else eng_poll_stage<XCH, ND, C::XS, true, false, true>(loc + C::xB, nullptr, tag, ly.norm_post, a.eps, L.xs[0], L.xrawB, lane, a.ws, dead, nullptr, nullptr, 0, 0);
         XE_STAMP(7);
         __syncthreads(); /* B5 */
@@ -783,6 +853,11 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
 #pragma unroll
             for (int w = 0; w < NCW; w++) nwp += xe_deal<NCW, C::DEAL_CONTIG>(w, spg, a.deal_wl).n > 0 ? 1 : 0;
             uint32_t* const dst = loc + (q == 0 ? C::qkv + S.q_out0 : (q == 1 ? C::xB + wg * P4::R : (q == 2 ? C::act + wg * P5::R : C::xA + wg * P6::R)));
+            if constexpr (C::COOP) { /* this wave's share of the sweep + RMSNorm + staging of x (layers behind the first: layer 0's row comes from the embedding table) / xB */
+                uint32_t* const lc = reinterpret_cast<uint32_t*>(a.loc + (size_t)S.seq * a.loc_stride);
+                if (q == 0 && l > 0) xe_coop_norm_stage<C>(a, L, lc + C::xA, tag, ly.norm_in, L.xs[0], L.xrawA, cw, lane, nullptr);
+                if (q == 2) xe_coop_norm_stage<C>(a, L, lc + C::xB, tag, ly.norm_post, L.xs[0], L.xrawB, cw, lane, nullptr);
+            }
             __syncthreads(); /* the phase's activations are staged (B1 / B4 / B5 / B6) */
             if (cw == 0) XE_STAMP(16 + 2 * q);
             xe_mv_run<C, D>(
