@@ -319,7 +319,7 @@ def test_tp8_ranks_as_the_eight_xcds_of_one_launch_vs_the_oracle(ctx):
     nt = TP.NativeTP(cfg, w, norms, 8, ctx)
     for rk in nt.ranks:
         rk.set_canonical(True)
-    n_prompt, n = 24, 272
+    n_prompt, n = 24, 136
     forced = np.full(cfg["max_seq"], -1, dtype=np.int32)
     forced[:n_prompt] = np.random.default_rng(5).integers(0, cfg["vocab"], size=n_prompt)
     xt = XcdTP(nt)
