@@ -463,6 +463,7 @@ __global__ void __launch_bounds__(C::NTH, C::WGS_PER_CU * C::NW / 4) gemm3_sk_ke
 // The flag value of one split-K launch.  Launches outside a capture take a fresh value each (a process-wide counter from 2 up), so the flags of the launch before need
 // no clearing -- the memset was a dependent 2-3 us node in front of every such product; a flag area seen for the first time is cleared once.  A launch that is being
 // CAPTURED is replayed with the arguments it was recorded with: it keeps the clearing node and the value 1.
+constexpr size_t G3_SK_FLAG_BYTES = 8192; /* up to 2048 resident workgroups (64 x 64 tiles, eight per CU) */
 static std::mutex g_sk_mu;
 static uint32_t g_sk_epoch = 1;
 static const void* g_sk_seen[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -504,7 +505,10 @@ static int g3_go_c(hipStream_t st, const GemmArgs& a, long nwg, void* ws, size_t
     const int G = 256 * C::WGS_PER_CU, nkt = a.K / BK, min_steps = 512 / BK;
     if (ws && ws_bytes >= gemm3_sk_ws_bytes() && 5 * nwg < 4 * G) {
         G3SkArgs s;
-        s.ws = (float*)ws, s.flags = (uint32_t*)((char*)ws + (size_t)G * C::BM * C::BN * 4);
+        // the flags live in the LAST 8 KiB of the lent workspace whatever the tile configuration (behind the partial tiles of THIS configuration they moved with it,
+        // and another configuration's fp32 partials could overwrite words already marked "seen" with values that pass for an epoch)
+        static_assert((size_t)256 * C::WGS_PER_CU * C::BM * C::BN * 4 <= (size_t)256 * G3_BM * G3_BN * 4 && 256 * C::WGS_PER_CU * 4 <= G3_SK_FLAG_BYTES, "partials and flags fit the lent workspace");
+        s.ws = (float*)ws, s.flags = (uint32_t*)((char*)ws + gemm3_sk_ws_bytes() - G3_SK_FLAG_BYTES);
         s.P = (int)nwg, s.S = G / s.P, s.kp = 0, s.R = 1;
         int nlaunch;
         if (s.S >= 2) {
@@ -531,7 +535,7 @@ template <bool AKM, bool BKM>
 static int g3_go(hipStream_t st, const GemmArgs& a, long nwg, void* ws, size_t ws_bytes) {
     return g3_go_c<AKM, BKM, G3Big>(st, a, nwg, ws, ws_bytes, 64);
 }
-size_t gemm3_sk_ws_bytes() { return (size_t)256 * G3_BM * G3_BN * 4 + 4096; }
+size_t gemm3_sk_ws_bytes() { return (size_t)256 * G3_BM * G3_BN * 4 + G3_SK_FLAG_BYTES; }
 int gemm3_launch(hipStream_t st, int fmt, const GemmArgs& a, void* ws, size_t ws_bytes) {
     if (fmt != FMT_BF16 || a.K % G3_BK != 0 || a.K < G3_BK) return 1;
     if ((a.ldx & 7) != 0 || (reinterpret_cast<uintptr_t>(a.x) & 15) != 0 || (reinterpret_cast<uintptr_t>(a.w) & 15) != 0 || (a.K & 7) != 0) return 1;

@@ -18,6 +18,9 @@ for NS in 16 8; do
   python3 scratch/pmc_xengine_json.py $O/x$NS $NS 4 $ALG $O/r05_pmc_xengine_$NS > /dev/null
 done
 VARIANTS="12x6" NSEQ="8,16" STAMPS=1 timeout 400 python3 scratch/xr_time.py 2028 20 2>&1 | grep -v amdgpu.ids > $O/xengine_stamps.txt
+STAMPS=1 timeout 600 python3 scratch/xtp_time.py 16 4000 16 2>&1 | grep -v amdgpu.ids > $O/xtp_stamps.txt
+for c in qwen3-1.7b qwen3-4b qwen3-8b; do CONFIG=$c VARIANTS="12x6" NSEQ="8" timeout 600 python3 scratch/xr_time.py 2028 20 2>&1 | grep -v amdgpu.ids | sed "s/^/$c  /" >> $O/xengine_shapes.txt; done
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_xtp -- python3 $R/bench.py --config qwen3-32b --tp-virtual 8 --tp-xcd 1 --tp-layers 16 --steps 32 --warmup 8 > $O/xtp_traced.log 2>&1; echo "xtp trace rc=$?")
 timeout 2400 python3 bench.py --steps 20 --warmup 5 > $O/bench_driver_flags.json 2> $O/bench_driver_flags.err; tail -c 300 $O/bench_driver_flags.json
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*counter_collection.csv" -size +2M -delete
 du -sh $O; find $O -name "*stats*.csv" | head -20

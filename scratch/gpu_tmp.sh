@@ -1,4 +1,4 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-timeout 1500 python3 bench.py --config qwen3-32b --tp-virtual 8 --tp-xcd 1 --steps 32 --warmup 8 2>&1 | tail -1 | cut -c1-700
-timeout 1500 python -m pytest tests/test_gpu_xengine.py -x -q -k "gqa4" 2>&1 | tail -3
+VARIANTS="8x4,86x6,81x8,82x4,8x4" NSEQ="16" timeout 900 python3 scratch/xr_time.py 2028 20 2>&1 | grep -v amdgpu.ids
+VARIANTS="8x4" NSEQ="16" DEAL="14,13,15" timeout 900 python3 scratch/xr_time.py 2028 20 2>&1 | grep -v amdgpu.ids
