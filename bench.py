@@ -56,6 +56,13 @@ def main():
                     "torch.distributed all-gathers per layer")
     ap.add_argument("--tp-virtual", type=int, default=0, help="side measurement on ONE GPU: this many TP ranks of qwen3-32b in one process, lock-step on one stream "
                     "(the per-rank kernels and the exchange kernels of TP = R, serialised: R x the work of one rank's GPU, no xGMI)")
+    # test hooks (tests/test_gpu_bench_ranks.py: two ranks sharing ONE GPU over gloo exercise the multi-process path on a 1-GPU box; a cut TP model); the launcher of a bare
+    # `--gpus N` hands them to its ranks on the command line -- the product bench reads no environment variable of its own
+    ap.add_argument("--x-backend", default="nccl", help=argparse.SUPPRESS)
+    ap.add_argument("--x-device", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--x-tp-layers", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--x-tp-vocab", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--x-no-tp-leg", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--tp-xcd", type=int, default=0, help="with --tp-virtual 8: the eight ranks as the eight XCDs of ONE launch (kf_xengine_create_tp) instead of the per-launch rank step")
     ap.add_argument("--tp-layers", type=int, default=0, help="with --tp-virtual: this many of the model's layers (0 = all): bounds the side leg's wall time")
     ap.add_argument("--lean-cpu", type=float, default=0.0, help="with --lean: also the CPU-baseline leg (parity passes + a timed sample of this many seconds) of the model being run")
@@ -87,9 +94,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    # KF_BENCH_BACKEND / KF_BENCH_DEVICE: test hooks only (two ranks sharing one GPU over gloo exercise the multi-process path on a 1-GPU box)
-    backend = os.environ.get("KF_BENCH_BACKEND", "nccl")
-    dev = int(os.environ["KF_BENCH_DEVICE"]) if "KF_BENCH_DEVICE" in os.environ else (local if world > 1 else 0)
+    backend = args.x_backend   # --x-backend / --x-device: test hooks only
+    dev = args.x_device if args.x_device >= 0 else (local if world > 1 else 0)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -121,7 +127,7 @@ def main():
     m.set_engine_autotune(args.autotune)   # kf_engine_tune once per position bucket, at the first multi-step launch inside it (set-up span: never inside the timed region)
     if args.engine >= 0:
         m.set_engine(bool(args.engine))
-    elif "KF_BENCH_DEVICE" in os.environ and world > 1:
+    elif args.x_device >= 0 and world > 1:
         m.set_engine(False)  # test hook: several ranks share one GPU; the persistent engine needs the CUs to itself
     use_graph = not args.no_graph
 
@@ -350,8 +356,9 @@ def launch_ranks(args):
         sys.stderr.write(err + "\n")
         return rc if rc != 0 else 1
     out = json.loads(line)
-    if args.config == "qwen3-0.6b" and os.environ.get("KF_BENCH_NO_TP_LEG", "") != "1":
-        tp_argv = ["--gpus", str(args.gpus), "--config", "qwen3-32b", "--steps", "64", "--warmup", "16", "--tp-exchange", args.tp_exchange]
+    if args.config == "qwen3-0.6b" and not args.x_no_tp_leg:
+        tp_argv = ["--gpus", str(args.gpus), "--config", "qwen3-32b", "--steps", "64", "--warmup", "16", "--tp-exchange", args.tp_exchange, "--x-backend", args.x_backend,
+                   "--x-device", str(args.x_device), "--x-tp-layers", str(args.x_tp_layers), "--x-tp-vocab", str(args.x_tp_vocab)]
         rc2, line2, err2 = _run_ranks(args.gpus, tp_argv, 1500)
         if rc2 == 0 and line2:
             d = json.loads(line2)
@@ -546,8 +553,8 @@ def tp_main(args, cfg, rank, world, dev):
     from koifish_amd.runtime import Context
     virtual = world == 1
     R = args.tp_virtual if virtual else world
-    if "KF_BENCH_TP_LAYERS" in os.environ:   # test hook only (tests/test_gpu_bench_ranks.py): a cut model; the line says so
-        cfg = dict(cfg, n_layer=int(os.environ["KF_BENCH_TP_LAYERS"]), vocab=int(os.environ.get("KF_BENCH_TP_VOCAB", cfg["vocab"])))
+    if args.x_tp_layers > 0:   # test hook only (tests/test_gpu_bench_ranks.py): a cut model; the line says so
+        cfg = dict(cfg, n_layer=args.x_tp_layers, vocab=args.x_tp_vocab if args.x_tp_vocab > 0 else cfg["vocab"])
     elif args.tp_layers > 0:                 # the side leg of the default run: a cut of the layer stack bounds its wall time; the line says so
         cfg = dict(cfg, n_layer=args.tp_layers)
     ctx = Context(dev)
