@@ -102,9 +102,22 @@ struct XCfg {
     static constexpr int SPK = XE_NWG / (n_kv * NG); /* key slices (= workgroups) per kv-head and head group */
     // q | k | v rows: a workgroup's rows belong to ONE of the three matrices.  With 16 / 8 heads the 32 workgroups cut the row slots that way; the GQA-4 shapes (32 / 8 heads:
     // 4 + 1 + 1 parts) do with 24 workgroups -- the other eight own no row of this phase (a fifth of a layer's weights at three quarters of the workgroups)
-    static constexpr int P1W = xe_p1_wgs(DIM_, eng_vepb<FMT_>(), QD_, KVD_);
-    static_assert(P1W > 0, "no cut of the q | k | v row slots into whole-matrix pieces");
-    using SH = EngShape<FMT_, DIM_, QD_, KVD_, FFN_, XE_NWG, P1W>;
+    static constexpr int P1W0 = xe_p1_wgs(DIM_, eng_vepb<FMT_>(), QD_, KVD_);
+    static_assert(P1W0 > 0, "no cut of the q | k | v row slots into whole-matrix pieces");
+    // FUSED: where 32 equal pieces would straddle the matrices, the engine multiplies ONE matrix of QD + 2 KVD rows -- a copy of the three shards' blocks and zero / step words,
+    // q rows then k rows then v rows, built once at create time inside the workspace (same rows, same lanes per row: the launch's rows were QD + 2 KVD all along) -- and all 32
+    // workgroups own rows of the phase.  (The 8-on-1 test shape's 80 row slots do not divide by 32: it keeps the 20-workgroup cut.)
+    static constexpr bool FUSED = P1W0 < XE_NWG && c_plan(DIM_, eng_vepb<FMT_>(), QD_ + 2 * KVD_, 0, 0, false, XE_NWG).total % XE_NWG == 0;
+    static constexpr int P1W = FUSED ? XE_NWG : P1W0;
+    struct SHF {
+        using B = EngShape<FMT_, DIM_, QD_, KVD_, FFN_, XE_NWG>;
+        using P1 = PlanT<DIM_, eng_vepb<FMT_>(), QD_ + 2 * KVD_, 0, 0, false, XE_NWG>;
+        using P4 = typename B::P4;
+        using P5 = typename B::P5;
+        using P6 = typename B::P6;
+    };
+    using SH = std::conditional_t<FUSED, SHF, EngShape<FMT_, DIM_, QD_, KVD_, FFN_, XE_NWG, P1W0>>;
+    static_assert(!FUSED || SH::P1::lpr_log2 == EngShape<FMT_, DIM_, QD_, KVD_, FFN_, XE_NWG, P1W0>::P1::lpr_log2, "the fused matrix is walked with the launch's lanes per row");
     static constexpr int ME = QD_ / XE_NWG; /* ao elements a workgroup merges */
     static_assert(QD_ % XE_NWG == 0 && ME % 4 == 0 && ME <= HD_ && HD_ % ME == 0 && ME <= 128, "merge elements per workgroup");
     static constexpr int PSH = SPK * (2 * HD_ + 4); /* 8-byte granules of one head's slice partials: [HD / ME][SPK][ME] values x 2, then [SPK][4] {m, L lo, L hi, -} */
@@ -788,7 +801,7 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
     constexpr int NCW = C::NCW, D = C::DEPTH;
     static_assert(P1::R % 4 == 0 && P4::R % 4 == 0 && P5::R % 4 == 0 && P6::R % 4 == 0, "16-byte pieces");
     static_assert(P1::total == C::P1W * P1::spg && P4::total == XE_NWG * P4::spg && P5::total == XE_NWG * P5::spg && P6::total == XE_NWG * P6::spg, "every workgroup owns rows of every phase");
-    static_assert(P1::S1 % P1::spg == 0 && P1::S2 % P1::spg == 0, "a workgroup's P1 rows belong to one matrix");
+    static_assert(C::FUSED || (P1::S1 % P1::spg == 0 && P1::S2 % P1::spg == 0), "a workgroup's P1 rows belong to one matrix");
     static_assert(!C::TP || (P4::R == C::DIM / XE_NWG && P6::R == C::DIM / XE_NWG && C::WPC == 1), "TP: a workgroup sums the rows it produced (xe_tp_reduce)");
     uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)S.seq * a.loc_stride);
     const float qb1 = S.j1 == 0 ? a.qbias[0] : (S.j1 == 1 ? a.qbias[1] : a.qbias[2]);
@@ -1259,11 +1272,44 @@ static int xe_loc_dw(int shape_class) {
     return XC2<9, 8, false, 1>::loc_dw;
 }
 
+static bool xe_class_fused(int sc); /* below the shape aliases */
+// FUSED shapes (XCfg::FUSED): q | k | v of a layer as ONE matrix -- blocks, then the zero words, then the step words of the QD + 2 KVD rows -- copied once into the workspace
+static size_t xe_fused_layer_bytes(const kf_engine_desc* d) {
+    const size_t rows = (size_t)(d->n_head + 2 * d->n_kv) * d->head_dim, nblk = d->dim / 32, grp = d->dim / 128;
+    return ((rows * nblk * 16 + 255) & ~(size_t)255) + 2 * ((rows * grp * 2 + 255) & ~(size_t)255);
+}
+static int xe_fuse_qkv(const kf_engine_desc* d, EngLayer* tab, const float* qbias, char*& p, hipStream_t st) {
+    if (qbias[0] != qbias[1] || qbias[0] != qbias[2]) return KF_UNSUPPORTED_DATATYPE; /* one zero point for the fused rows */
+    const size_t nblk = d->dim / 32, grp = d->dim / 128;
+    const size_t rows_all = (size_t)(d->n_head + 2 * d->n_kv) * d->head_dim;
+    for (int l = 0; l < d->n_layer; l++) {
+        char* wdst = p;
+        char* zdst = wdst + ((rows_all * nblk * 16 + 255) & ~(size_t)255);
+        char* sdst = zdst + ((rows_all * grp * 2 + 255) & ~(size_t)255);
+        size_t r0 = 0;
+        for (int j = 0; j < 3; j++) {
+            const kf_weight& w = d->layers[l].w[j];
+            const size_t rows = (size_t)w.ne0;
+            const uint16_t* zero = w.gama + w.ne0 + w.ne1;
+            const uint16_t* step = zero + rows * grp;
+            if (hipMemcpyAsync(wdst + r0 * nblk * 16, w.data, rows * nblk * 16, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+                hipMemcpyAsync(zdst + r0 * grp * 2, zero, rows * grp * 2, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+                hipMemcpyAsync(sdst + r0 * grp * 2, step, rows * grp * 2, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                return KF_HIP_CHECK;
+            r0 += rows;
+        }
+        tab[l].m[0].w = (g_u32x4)(uintptr_t)wdst, tab[l].m[0].zero = (g_u16)(uintptr_t)zdst, tab[l].m[0].step = (g_u16)(uintptr_t)sdst;
+        p += xe_fused_layer_bytes(d);
+    }
+    return KF_OK;
+}
+
 size_t xengine_ws_bytes(const kf_engine_desc* d) {
     const int hd = d->head_dim, GQ = d->n_kv > 0 ? d->n_head / d->n_kv : 1;
     const int sc = xe_shape_class(GQ, hd, d->dim, d->n_head * hd, d->ffn);
     size_t b = 4096 + (((size_t)d->n_layer * sizeof(EngLayer) + 255) & ~(size_t)255);
     b += (size_t)XE_MAXSEQ * xe_loc_stride(sc ? xe_loc_dw(sc) : 0) + 4096;
+    if (sc && xe_class_fused(sc)) b += (size_t)d->n_layer * xe_fused_layer_bytes(d) + 256;
     return b;
 }
 static int xengine_init_state(XEngineHost* E, hipStream_t st) {
@@ -1359,6 +1405,15 @@ int xengine_build(const kf_engine_desc* d, int n_seq, long long kv_seq_stride, v
     p = reinterpret_cast<char*>(((uintptr_t)p + 4095) & ~(uintptr_t)4095);
     E->loc_stride = xe_loc_stride(xe_loc_dw(sc));
     a.loc = p, a.loc_stride = E->loc_stride;
+    if (xe_class_fused(sc)) {
+        char* fp = reinterpret_cast<char*>(((uintptr_t)(p + (size_t)XE_MAXSEQ * E->loc_stride) + 255) & ~(uintptr_t)255);
+        const int frc = xe_fuse_qkv(d, tab.data(), qbias, fp, st);
+        if (frc != KF_OK) {
+            xengine_free(E);
+            *why = "q / k / v carry different zero points (the fused copy of the three takes one), or a HIP failure while copying";
+            return frc;
+        }
+    }
     if (xengine_init_state(E, st) != KF_OK || hipMemcpyAsync(const_cast<EngLayer*>(a.layers), tab.data(), tab.size() * sizeof(EngLayer), hipMemcpyHostToDevice, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess) {
         xengine_free(E);
@@ -1373,12 +1428,14 @@ int xengine_build(const kf_engine_desc* d, int n_seq, long long kv_seq_stride, v
 // a rank of Qwen3-32B under TP = 8: 8 query heads on 1 kv-head, q_dim 1024, ffn 3200 (koifish_amd/tp.py TPPlan)
 using XC7 = XCfg<FMT_Q4P, 8, 128, 12, 5120, 1024, 128, 3200, 6, false, 1, 1, true>;
 using XC7D = XCfg<FMT_Q4P, 8, 128, 12, 5120, 1024, 128, 3200, 6, true, 1, 1, true>; /* + the per-phase stamps of one workgroup of one rank */
+static bool xe_class_fused(int sc) { return sc == 4 ? XC4::FUSED : (sc == 5 ? XC5::FUSED : (sc == 6 ? XC6::FUSED : (sc == 7 ? XC7::FUSED : false))); }
 static bool xe_tp_shape(const kf_engine_desc* d) { return d->head_dim == 128 && d->n_head == 8 && d->n_kv == 1 && d->dim == 5120 && d->ffn == 3200; }
 static size_t xe_tp_recv_granules() { return (size_t)XE_NXCD * 2 * XE_NXCD * XC7::DIM; }
 size_t xengine_ws_bytes_tp(const kf_engine_desc* d0) {
     size_t b = 4096 + (((size_t)XE_NXCD * d0->n_layer * sizeof(EngLayer) + 255) & ~(size_t)255);
     b += (size_t)XE_NXCD * xe_loc_stride(XC7::loc_dw) + 4096;
     b += xe_tp_recv_granules() * 8 + (size_t)XE_NXCD * XE_NXCD * 8 + 4096;
+    if (XC7::FUSED) b += (size_t)XE_NXCD * d0->n_layer * xe_fused_layer_bytes(d0) + 256;
     return b;
 }
 int xengine_build_tp(const kf_engine_desc* const* ds, int world, void* ws, size_t ws_bytes, hipStream_t st, XEngineHost** out, const char** why) {
@@ -1433,6 +1490,17 @@ int xengine_build_tp(const kf_engine_desc* const* ds, int world, void* ws, size_
     a.tp_recv = reinterpret_cast<unsigned long long*>(p), p += xe_tp_recv_granules() * 8;
     a.tp_best = reinterpret_cast<unsigned long long*>(p);
     E->tp_bytes = xe_tp_recv_granules() * 8 + (size_t)XE_NXCD * XE_NXCD * 8;
+    if (XC7::FUSED) {
+        char* fp = reinterpret_cast<char*>(((uintptr_t)(p + (size_t)XE_NXCD * XE_NXCD * 8) + 255) & ~(uintptr_t)255);
+        for (int r = 0; r < world; r++) {
+            const int frc = xe_fuse_qkv(ds[r], tab.data() + (size_t)r * d->n_layer, qbias, fp, st);
+            if (frc != KF_OK) {
+                xengine_free(E);
+                *why = "q / k / v carry different zero points (the fused copy of the three takes one), or a HIP failure while copying";
+                return frc;
+            }
+        }
+    }
     if (xengine_init_state(E, st) != KF_OK || hipMemcpyAsync(const_cast<EngLayer*>(a.layers), tab.data(), tab.size() * sizeof(EngLayer), hipMemcpyHostToDevice, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess) {
         xengine_free(E);

@@ -366,3 +366,19 @@ def test_tp8_ranks_as_the_eight_xcds_of_one_launch_vs_the_oracle(ctx):
     om.close()
     xt.close()
     nt.close()
+
+
+def test_tp_over_the_xcds_refuses_what_it_does_not_serve(ctx):
+    """koifish::XcdTP / kf_xengine_create_tp serves the TP = 8 ranks of the Qwen3-32B shape; other rank shapes and other rank counts are refused with the reason"""
+    from koifish_amd.runtime import XcdTP
+    cfg = dict(synth.CONFIGS["small"])
+    raw = synth.raw_weights_numpy(cfg, 31, w_std=0.1)
+    w, norms = full_weights_on_gpu(ctx, cfg, raw)
+    for world, what in ((8, "not instantiated"), (2, "8 ranks")):
+        nt = TP.NativeTP(cfg, w, norms, world, ctx)
+        for rk in nt.ranks:
+            rk.set_canonical(True)
+        with pytest.raises(L.KFError) as e:
+            XcdTP(nt)
+        assert what in str(e.value), str(e.value)
+        nt.close()

@@ -14,6 +14,11 @@ from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
 
+GQA4_SHAPES = {  # cases/tutorial/history.md:4-6 -- the models the reference lists beside 0.6B / 1.7B / 32B
+    "qwen3-4b": dict(dim=2560, n_layer=3, n_head=32, n_kv=8, head_dim=128, ffn=9728, vocab=4096, max_seq=160, theta=1e6, tied=True),
+    "qwen3-8b": dict(dim=4096, n_layer=3, n_head=32, n_kv=8, head_dim=128, ffn=12288, vocab=4096, max_seq=160, theta=1e6, tied=True),
+}
+
 
 @pytest.fixture()
 def canon():
@@ -202,6 +207,12 @@ def test_refusals():
     assert "canonical" in str(e.value)
     xr.close()
     m.close()
+    cfg4 = dict(GQA4_SHAPES["qwen3-4b"], n_layer=1, vocab=512)    # a GQA-4 shape: one decoder per XCD only
+    m = synth.build_from_raw(cfg4, synth.raw_weights_numpy(cfg4, 3, w_std=0.05), L.Q4, L.BF16)
+    with pytest.raises(L.KFError) as e:
+        XcdReplicas(m, 9)
+    assert "at most 8 sequences" in str(e.value)
+    m.close()
     cfg2 = dict(synth.CONFIGS["qwen3-1.7b"], n_layer=2, vocab=4096, max_seq=128, ffn=4096)   # no such shape
     m = synth.build_from_raw(cfg2, synth.raw_weights_numpy(cfg2, 2, w_std=0.05), L.Q4, L.BF16)
     with pytest.raises(L.KFError) as e:
@@ -239,10 +250,6 @@ def test_qwen3_1p7b_shape_equals_the_oracle(canon):
     m.close()
 
 
-GQA4_SHAPES = {  # cases/tutorial/history.md:4-6 -- the models the reference lists beside 0.6B / 1.7B / 32B
-    "qwen3-4b": dict(dim=2560, n_layer=3, n_head=32, n_kv=8, head_dim=128, ffn=9728, vocab=4096, max_seq=160, theta=1e6, tied=True),
-    "qwen3-8b": dict(dim=4096, n_layer=3, n_head=32, n_kv=8, head_dim=128, ffn=12288, vocab=4096, max_seq=160, theta=1e6, tied=True),
-}
 
 
 @pytest.mark.parametrize("name,variant", [("qwen3-4b", None), ("qwen3-8b", None), ("qwen3-4b", (8, 8))])
