@@ -18,6 +18,11 @@
 // gemv_kernel<.., CANON> (the geometry is a property of the matrix shape: PlanT, kf_engine_common.h), the order-free fp64 softmax sums of kf_attn_common.h.  Every id,
 // logit and K/V row of every sequence equals what kf_engine.hip, the per-layer launches and the oracle produce for that sequence alone.
 //
+// Forms of the one kernel (XCfg): one decoder per XCD (12 waves, 168 registers) or two (two workgroups of 8 waves per CU, 128 registers: sequences x and x + 8); the model
+// shapes of Qwen3-0.6B / 1.7B / 4B / 8B (GQA-4: four query heads per key tile, q | k | v as one fused matrix, wide vectors staged by all waves); and TP (XCfg::TP): ONE sequence
+// whose eight tensor-parallel ranks are the eight XCDs -- o_proj / down_proj rows leave as fp32 partials into every rank's receive area, are summed in rank order by the
+// workgroup that owns the rows and continue as a local hand-off (xe_publish push / xe_tp_reduce), the head in vocabulary shards with a pick across the XCDs.
+//
 // Replaces, for eight sequences at once: Fish::ForwardOnRLS (gLLM.cpp:722-787) over TokenEmbed::cuInfer (NeuronFuse.cu:176-218), SelfAttention::cuInfer (QKV.cu:617-702),
 // FFN::cuInfer (NeuronFuse.cu:615-656), Head4Token::cuInfer_1 (NeuronFuse.cu:842-862) and sample_argmax (GoPT.cpp:602-612).
 #include <stdlib.h>
@@ -69,7 +74,7 @@ struct XArgs {
     int stagger_us; /* two decoders per XCD: microseconds the second one starts behind the first */
 };
 
-// error word bits: 1 x, 2 q|k|v, 4 partials, 8 workgroups per XCD != 32, 16 pick, 32 token granule, 64 position beyond the cache, 128 ao, 256 xB, 512 act, 1024 head x
+// error word bits: 1 a hand-off vector (x, ao, xB, act, head x), 2 q|k|v, 4 partials, 8 workgroups per XCD != 32, 16 pick, 32 token granule, 64 position beyond the cache, 2048 a TP exchange
 
 constexpr int xe_p1_wgs(int dim, int epb, int qd, int kvd) { /* the most workgroups (32 ... 8) whose equal pieces of the q | k | v row slots do not straddle a matrix */
     for (int w = 32; w >= 8; w--) {
