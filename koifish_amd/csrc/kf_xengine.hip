@@ -72,6 +72,7 @@ struct XArgs {
     unsigned long long* tp_recv; /* [rank][2][source rank][DIM] granules {fp32 partial | generation}: o_proj exchanges in buffer 0, down_proj exchanges in buffer 1 */
     unsigned long long* tp_best; /* [rank][source rank] {global row | tag16, bf16 value} */
     int stagger_us; /* two decoders per XCD: microseconds the second one starts behind the first */
+    int twin_sync;  /* two decoders per XCD: twin workgroups meet in front of the LM head (xe_head_main) */
 };
 
 // error word bits: 1 a hand-off vector (x, ao, xB, act, head x), 2 q|k|v, 4 partials, 8 workgroups per XCD != 32, 16 pick, 32 token granule, 64 position beyond the cache, 2048 a TP exchange
@@ -89,6 +90,11 @@ struct XCfg {
     // partials into every rank's receive area (the protocol of kf_tp.hip, inside the launch), each workgroup sums its 1 / 32 of the rows over the ranks in rank order,
     // adds the residual and publishes the slice inside its XCD -- from there on the hand-off is the local one.
     static constexpr bool TP = TP_;
+    // The decoders of a launch stream the SAME head and the SAME layer weights (only a TP rank's shards are its own).  The head rows are read with PLAIN loads: with the
+    // non-temporal hint (a stream read once) every decoder's 311 MB came from HBM; plain, the lines stay in the 256 MB memory-side cache for the other XCDs' decoders --
+    // 16 sequences 3.46 -> 3.37 ms per step, 8 sequences 1.87 -> 1.83.  The layer weights: plain for one decoder per XCD (1.83 -> 1.82), non-temporal for two (plain: 3.43 --
+    // two decoders' 8.4 MB layers and their K / V rows already fight for the XCD's 4 MB L2).
+    static constexpr int WAUX = (TP_ || WPC_ > 1) ? 2 /* nt */ : 0;
     // wide residual streams: EVERY wave of the workgroup sweeps, normalises and stages its own 1 KiB units of x / xB (the compute waves stand at the barrier behind that
     // staging anyway; ONE wave doing it took 14 us of a 192 us layer at 5120 values: scratch/xtp_time.py)
     static constexpr bool COOP = DIM_ >= 2048;
@@ -128,7 +134,7 @@ struct XCfg {
     static constexpr int PSH = SPK * (2 * HD_ + 4); /* 8-byte granules of one head's slice partials: [HD / ME][SPK][ME] values x 2, then [SPK][4] {m, L lo, L hi, -} */
     // the XCD-local exchange area (dwords)
     static constexpr int xA = 0, qkv = xA + eng_gran_dw(DIM_), ao = qkv + eng_gran_dw(QD_ + 2 * KVD_), xB = ao + eng_gran_dw(QD_), act = xB + eng_gran_dw(DIM_),
-                         part = act + eng_gran_dw(FFNP), hbest = part + eng_gran_dw(2 * n_head * PSH), tokg = hbest + eng_gran_dw(2 * XE_NWG), loc_dw = tokg + eng_gran_dw(2);
+                         part = act + eng_gran_dw(FFNP), hbest = part + eng_gran_dw(2 * n_head * PSH), tokg = hbest + eng_gran_dw(2 * XE_NWG), twin = tokg + eng_gran_dw(2), loc_dw = twin + eng_gran_dw(2 * XE_NWG);
     // LM head (bf16 [vocab, DIM]): the geometry gemv_launch picks for a many-row bf16 matrix of this width
     static constexpr int HnBlk = DIM_ / 8, Hlpr_log2 = c_lpr_log2(DIM_ / 8, 1L << 20), HLPR = 1 << Hlpr_log2, HRPS = 64 >> Hlpr_log2, Hiters = (HnBlk + HLPR - 1) / HLPR;
     static constexpr int XCH = 8; /* fp32 activations: 16-byte chunks per 32-weight block */
@@ -239,7 +245,7 @@ __device__ __forceinline__ XLaneGeo xe_lane_geo(const XPhase& P, int lane) {
 // straight-line code -- behind a conditional request it waits with vmcnt(0), i.e. for the block it has just asked for (measured: every entry then paid an HBM round trip).
 // Buffer loads: block index = [scalar: the slot's first row and the iteration] + [lane: sub * nBlk + ll]; rows past the matrix read zeros (the descriptor's bound), columns
 // past the row are masked at the multiply.
-template <int NCW, int D>
+template <int NCW, int D, int WAUX>
 __device__ __forceinline__ void xe_issue(const XPhase& P, const XLaneGeo& G, const XPhase& NX, const XLaneGeo& GN, bool use_nx, int e, int d, int cw, bool on, XRing<D>& R) {
     // every field read into a value FIRST, then chosen: `c ? NX.f : P.f` on two lvalues is a choice between two ADDRESSES followed by one load, which keeps both structs
     // in scratch memory (and every such read an indexed scratch load with a drain of the weight loads in front of it)
@@ -258,16 +264,16 @@ __device__ __forceinline__ void xe_issue(const XPhase& P, const XLaneGeo& G, con
     const g_u16 pz = pick(use_nx, pick(second, z_d, z_c), pick(second, z_b, z_a));
     const uint32_t wbytes = on ? pick(use_nx, +NX.wbytes, +P.wbytes) : 0u, gbytes = on ? pick(use_nx, +NX.gbytes, +P.gbytes) : 0u;
     const uint32_t vblk = pick(use_nx, +GN.vblk, +G.vblk);
-    R.w[d] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(eng_rsrc((const void*)pw, wbytes), vblk * 16u, ublk * 16u, 2 /* nt */));
+    R.w[d] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(eng_rsrc((const void*)pw, wbytes), vblk * 16u, ublk * 16u, WAUX /* XCfg::WAUX */));
     R.st[d] = __builtin_amdgcn_raw_buffer_load_b16(eng_rsrc((const void*)ps, gbytes), (vblk >> 2) * 2u, (ublk >> 2) * 2u, 0);
     R.ze[d] = __builtin_amdgcn_raw_buffer_load_b16(eng_rsrc((const void*)pz, gbytes), (vblk >> 2) * 2u, (ublk >> 2) * 2u, 0);
 }
 // a phase's first entries into an idle ring
-template <int NCW, int D>
+template <int NCW, int D, int WAUX>
 __device__ __forceinline__ void xe_fill(const XPhase& P, int cw, int lane, XRing<D>& R) {
     const XLaneGeo G = xe_lane_geo(P, lane);
 #pragma unroll
-    for (int d = 0; d < D; d++) xe_issue<NCW, D>(P, G, P, G, false, d, d, cw, d < P.n, R);
+    for (int d = 0; d < D; d++) xe_issue<NCW, D, WAUX>(P, G, P, G, false, d, d, cw, d < P.n, R);
 }
 // one block's 32 products into the lane's chain pair: BlockDotF<FMT> (kf_gemv_blocks.h) on the fp32 activation chunks in LDS, chunk j of block column c at xf[j * XS + c]
 // (XS: the chunk stride, a compile-time constant of the model shape -- the same for every phase, so the eight reads of a block are one address and immediate offsets)
@@ -344,7 +350,7 @@ __device__ __forceinline__ void xe_mv_run(const XPhase& P, const XPhase& NX, boo
             }
             // refill slot d (always ONE set of loads: see xe_issue)
             const bool more = e + D < n, nxt = !more && last && nx_on && d < NX.n;
-            xe_issue<NCW, D>(P, G, NX, GN, nxt, more ? e + D : (nxt ? d : 0), d, cw, more || nxt, R);
+            xe_issue<NCW, D, C::WAUX>(P, G, NX, GN, nxt, more ? e + D : (nxt ? d : 0), d, cw, more || nxt, R);
         }
     }
 }
@@ -847,7 +853,7 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
     };
     static_assert(P1::nBlk % 4 == 0 && P4::nBlk % 4 == 0 && P5::nBlk % 4 == 0 && P6::nBlk % 4 == 0 && P1::LPR % 4 == 0 && P4::LPR % 4 == 0 && P5::LPR % 4 == 0 && P6::LPR % 4 == 0,
                   "a group's four blocks start at a multiple of four");
-    xe_fill<NCW, D>(phase_of(0, L.lay[0]), cw, lane, R);
+    xe_fill<NCW, D, C::WAUX>(phase_of(0, L.lay[0]), cw, lane, R);
     for (int l = 0; l < a.n_layer; l++) {
         const EngLayer& ly = L.lay[l];
         const uint32_t gen = (uint32_t)epoch * (uint32_t)a.n_layer + (uint32_t)l, tag = gen & 0xffffu, tag_next = (gen + 1u) & 0xffffu;
@@ -914,7 +920,7 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
             }
             if (cw == 0) XE_STAMP(17 + 2 * q);
             if (q == 0) { /* q/k-norm + RoPE + attention over the workgroup's key slice; the slice partial into the XCD's partial area; then the first o_proj blocks */
-                xe_attn_phase<C>(a, L, S, ly, gen, cw, lane, T, l, [&]() { xe_fill<NCW, D>(phase_of(1, ly), cw, lane, R); });
+                xe_attn_phase<C>(a, L, S, ly, gen, cw, lane, T, l, [&]() { xe_fill<NCW, D, C::WAUX>(phase_of(1, ly), cw, lane, R); });
                 if (cw == 0) XE_STAMP(24);
             }
         }
@@ -958,7 +964,8 @@ __device__ __forceinline__ void xe_head_main(const XArgs& a, const XLds& L, cons
             for (int it = 0; it < ITERS; it++) {
                 int col = it * LPR + ll;
                 col = col < nBlk ? col : nBlk - 1;
-                w[buf][g][it] = __builtin_nontemporal_load(head_w + (size_t)row * nBlk + col);
+                if constexpr (C::TP) w[buf][g][it] = __builtin_nontemporal_load(head_w + (size_t)row * nBlk + col); /* a rank's vocabulary shard: read once */
+                else w[buf][g][it] = head_w[(size_t)row * nBlk + col]; /* the same rows for every decoder (XCfg::WAUX) */
             }
         }
     };
@@ -976,6 +983,25 @@ __device__ __forceinline__ void xe_head_main(const XArgs& a, const XLds& L, cons
     }
     __syncthreads();
     if (wave == NWV - 1) issue(0, 0);
+    if constexpr (C::WPC == 2) {
+        // Two decoders per XCD stream the SAME head rows through the SAME L2: workgroup w of either decoder walks rows w * spg ... of the one matrix.  Started together the
+        // second one's requests meet the first one's lines in the L2 (the head is the one phase bound by the XCD's link, not by arithmetic: 311 MB per decoder at 1.1 TB/s);
+        // apart they cross the fabric twice.  So twin workgroups wait for each other here -- a performance rendezvous only: bounded, and a timeout is not an error.
+        const bool has_twin = S.seq >= XE_NXCD || S.seq + XE_NXCD < a.n_seq;
+        if (has_twin && a.twin_sync) {
+            uint32_t* tw = reinterpret_cast<uint32_t*>(a.loc + (size_t)(S.seq & (XE_NXCD - 1)) * a.loc_stride) + C::twin + 2 * wg;
+            const int me = S.seq >= XE_NXCD ? 1 : 0;
+            if (wave == 0) {
+                if (lane == 0) tw[me] = (uint32_t)epoch;
+                const __amdgpu_buffer_rsrc_t rt = eng_rsrc(tw, 8u);
+                for (int spins = 0; spins < 40000; spins++) {
+                    if (__builtin_amdgcn_raw_buffer_load_b32(rt, (1 - me) * 4, 0, 16 /* sc1 */) == (uint32_t)epoch) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            __syncthreads();
+        }
+    }
     float xf[ITERS][8];
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
@@ -1400,6 +1426,7 @@ int xengine_build(const kf_engine_desc* d, int n_seq, long long kv_seq_stride, v
     XArgs& a = E->args;
     E->shape_class = sc, E->fmt = FMT_Q4P, E->dim = d->dim, E->q_dim = q_dim, E->kv_dim = kv_dim, E->ffn = d->ffn, E->n_head = d->n_head, E->n_kv = d->n_kv, E->hd = hd;
     E->nwv = 12, E->depth = 6; /* 11 compute waves + the poller: three waves per SIMD (measured best: 1.89 ms per step of eight sequences against 1.92 with 9 x 8) */
+    a.twin_sync = 0; /* the rendezvous of twin workgroups in front of the head: measured, no gain (3.407 with, 3.368 without) */
     a.n_layer = d->n_layer, a.n_seq = n_seq, a.kv_seq_stride = kv_seq_stride, a.kv_stride = d->kv_stride, a.max_seq = d->max_seq;
     a.eps = d->rms_eps, a.qk_eps = d->qk_eps, a.rope_table = d->rope_table;
     for (int j = 0; j < 7; j++) a.qbias[j] = qbias[j];
@@ -1645,6 +1672,10 @@ int xengine_reset(XEngineHost* E, hipStream_t st) {
 void xengine_set_variant(XEngineHost* E, int nwv, int depth) {
     if (nwv == 0) { /* tuning hook: depth = the stagger of the second decoder in microseconds */
         E->args.stagger_us = depth;
+        return;
+    }
+    if (nwv == -2) { /* tuning hook: depth = XArgs::twin_sync */
+        E->args.twin_sync = depth;
         return;
     }
     if (nwv == -1) { /* tuning hook: depth = XArgs::deal_wl (0: the default of the form) */
