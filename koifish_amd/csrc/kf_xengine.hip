@@ -32,6 +32,9 @@
 
 #include "kf_engine_common.h"
 
+#ifndef KF_XE_KV_NT
+#define KF_XE_KV_NT 1
+#endif
 namespace kf {
 
 constexpr int XE_NWG = 32;   /* workgroups of one decoder = the CUs of one XCD */
@@ -95,6 +98,7 @@ struct XCfg {
     // 16 sequences 3.46 -> 3.37 ms per step, 8 sequences 1.87 -> 1.83.  The layer weights: plain for one decoder per XCD (1.83 -> 1.82), non-temporal for two (plain: 3.43 --
     // two decoders' 8.4 MB layers and their K / V rows already fight for the XCD's 4 MB L2).
     static constexpr int WAUX = (TP_ || WPC_ > 1) ? 2 /* nt */ : 0;
+    static constexpr bool KV_NT = KF_XE_KV_NT != 0 && GQ_ <= 4; /* (head groups read the K / V rows twice: plain) */
     // wide residual streams: EVERY wave of the workgroup sweeps, normalises and stages its own 1 KiB units of x / xB (the compute waves stand at the barrier behind that
     // staging anyway; ONE wave doing it took 14 us of a 192 us layer at 5120 values: scratch/xtp_time.py)
     static constexpr bool COOP = DIM_ >= 2048;
@@ -456,8 +460,13 @@ __device__ __forceinline__ void xe_attn_issue(const XArgs& a, const EngLayer& ly
         int t = tb + u * NWA * KPW;
         t = t < tmax ? t : tmax;
         const size_t off = (size_t)S.kv_off + (size_t)t * a.kv_stride + (size_t)S.kvh * hd + d0;
-        T.kk[buf][u] = *reinterpret_cast<const u32x4 KF_GLOBAL*>(ly.kcache + off);
-        T.vv[buf][u] = *reinterpret_cast<const u32x4 KF_GLOBAL*>(ly.vcache + off);
+        if constexpr (C::KV_NT) { /* a sequence's own rows, read once per step */
+            T.kk[buf][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 KF_GLOBAL*>(ly.kcache + off));
+            T.vv[buf][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 KF_GLOBAL*>(ly.vcache + off));
+        } else {
+            T.kk[buf][u] = *reinterpret_cast<const u32x4 KF_GLOBAL*>(ly.kcache + off);
+            T.vv[buf][u] = *reinterpret_cast<const u32x4 KF_GLOBAL*>(ly.vcache + off);
+        }
     }
 }
 // compute waves only (the poller meets the three barriers in xe_poller_main).  p4_fill: requests the first o_proj blocks, called when the last batch's tiles are in registers
