@@ -419,13 +419,13 @@ def side_legs(which):
             "summation_order": d["config"].get("summation_order"), "cpu_baseline": d.get("cpu_baseline"), "engine_handoffs": d.get("engine_handoffs"),
             "decode_path": d["config"]["decode_path"], "profile": "profiles/r04_config5_sparse_1bit_kernel_stats.csv", "leg_wall_s": d.get("leg_wall_s")}
     if "qwen3_1p7b" in which:   # not a BASELINE configuration: the second model shape the persistent engine is instantiated for (round 4)
-        d = _child(["--config", "qwen3-1.7b", "--steps", "64", "--warmup", "16", "--lean"], 420)
+        d = _child(["--config", "qwen3-1.7b", "--steps", "64", "--warmup", "16", "--lean", "--lean-xcd", "16"], 420)
         e = _child(["--config", "qwen3-1.7b", "--steps", "64", "--warmup", "16", "--lean", "--engine", "0"], 420)
         out["qwen3_1p7b_shape"] = d if "error" in d else {
             "workload": "Qwen3-1.7B shape (dim 2048, 16 / 8 heads of 128, ffn 6144), 4-bit PackedQ greedy decode: %s" % d["config"]["workload"].split("seq=")[-1],
             "tokens_per_s": d["value"], "ms_per_step": d["ms_per_step"], "bytes_per_step": d["step_roofline"]["bytes_per_step"], "frac": d["step_roofline"]["frac"],
             "fast_order_tokens_per_s": d.get("fast_order_mode", {}).get("tokens_per_s"), "decode_path": d["config"]["decode_path"],
-            "per_layer_launches_tokens_per_s": e.get("value"), "per_layer_launches_ms_per_step": e.get("ms_per_step"), "leg_wall_s": d.get("leg_wall_s")}
+            "per_layer_launches_tokens_per_s": e.get("value"), "per_layer_launches_ms_per_step": e.get("ms_per_step"), "xcd_replicas": d.get("xcd_replicas"), "leg_wall_s": d.get("leg_wall_s")}
     for nm, title in (("qwen3_4b", "Qwen3-4B shape (dim 2560, 32 / 8 heads of 128, ffn 9728, 36 layers)"), ("qwen3_8b", "Qwen3-8B shape (dim 4096, 32 / 8 heads of 128, ffn 12288, 36 layers)")):
         if nm in which:   # not BASELINE configurations: the GQA-4 models the reference lists as supported (cases/tutorial/history.md:4-6); round 5: served by the XCD-confined engines
             d = _child(["--config", nm.replace("_", "-"), "--steps", "64", "--warmup", "16", "--lean", "--lean-xcd", "8"], 600)
