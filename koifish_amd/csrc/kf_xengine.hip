@@ -1313,6 +1313,9 @@ static int xe_loc_dw(int shape_class) {
 }
 
 static bool xe_class_fused(int sc); /* below the shape aliases */
+static size_t xe_smem_class3_two(int n_layer);
+template <class C>
+static size_t xe_smem(int n_layer);
 // FUSED shapes (XCfg::FUSED): q | k | v of a layer as ONE matrix -- blocks, then the zero words, then the step words of the QD + 2 KVD rows -- copied once into the workspace
 static size_t xe_fused_layer_bytes(const kf_engine_desc* d) {
     const size_t rows = (size_t)(d->n_head + 2 * d->n_kv) * d->head_dim, nblk = d->dim / 32, grp = d->dim / 128;
@@ -1409,6 +1412,8 @@ int xengine_build(const kf_engine_desc* d, int n_seq, long long kv_seq_stride, v
     if (!sc) return KF_UNSUPPORTED_DATATYPE;
     *why = "the GQA-4 / GQA-8 shapes (Qwen3-4B / 8B, the 8-on-1 test shape) run one decoder per XCD: at most 8 sequences (two workgroups per CU would need 2 x 78 KB (2 x 98 KB) of activations in LDS)";
     if (sc >= 4 && n_seq > XE_NXCD) return KF_UNSUPPORTED_DATATYPE;
+    *why = "two decoders per XCD (more than 8 sequences) do not fit this shape and depth: two workgroups per CU need 2 x the activations + the layer table in 160 KB of LDS";
+    if (sc == 3 && n_seq > XE_NXCD && 2 * xe_smem_class3_two(d->n_layer) > 160 * 1024) return KF_UNSUPPORTED_DATATYPE;
     if (!dry && (ws_bytes < xengine_ws_bytes(d) || ((uintptr_t)ws & 255) != 0)) {
         *why = "workspace too small or not 256-byte aligned";
         return KF_INVALID_ARGS;
@@ -1469,6 +1474,7 @@ int xengine_build(const kf_engine_desc* d, int n_seq, long long kv_seq_stride, v
 // a rank of Qwen3-32B under TP = 8: 8 query heads on 1 kv-head, q_dim 1024, ffn 3200 (koifish_amd/tp.py TPPlan)
 using XC7 = XCfg<FMT_Q4P, 8, 128, 12, 5120, 1024, 128, 3200, 6, false, 1, 1, true>;
 using XC7D = XCfg<FMT_Q4P, 8, 128, 12, 5120, 1024, 128, 3200, 6, true, 1, 1, true>; /* + the per-phase stamps of one workgroup of one rank */
+static size_t xe_smem_class3_two(int n_layer) { return xe_smem<XC3<8, 4, false, 2, 1>>(n_layer); }
 static bool xe_class_fused(int sc) { return sc == 4 ? XC4::FUSED : (sc == 5 ? XC5::FUSED : (sc == 6 ? XC6::FUSED : (sc == 7 ? XC7::FUSED : false))); }
 static bool xe_tp_shape(const kf_engine_desc* d) { return d->head_dim == 128 && d->n_head == 8 && d->n_kv == 1 && d->dim == 5120 && d->ffn == 3200; }
 static size_t xe_tp_recv_granules() { return (size_t)XE_NXCD * 2 * XE_NXCD * XC7::DIM; }

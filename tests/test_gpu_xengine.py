@@ -213,6 +213,13 @@ def test_refusals():
         XcdReplicas(m, 9)
     assert "at most 8 sequences" in str(e.value)
     m.close()
+    cfg17 = dict(synth.CONFIGS["qwen3-1.7b"], n_layer=28, vocab=512, max_seq=64)    # 28 layers of the 1.7B shape: two workgroups per CU do not fit the LDS
+    m = synth.build_from_raw(cfg17, synth.raw_weights_numpy(cfg17, 4, w_std=0.05), L.Q4, L.BF16)
+    with pytest.raises(L.KFError) as e:
+        XcdReplicas(m, 16)
+    assert "160 KB" in str(e.value)
+    XcdReplicas(m, 8).close()
+    m.close()
     cfg2 = dict(synth.CONFIGS["qwen3-1.7b"], n_layer=2, vocab=4096, max_seq=128, ffn=4096)   # no such shape
     m = synth.build_from_raw(cfg2, synth.raw_weights_numpy(cfg2, 2, w_std=0.05), L.Q4, L.BF16)
     with pytest.raises(L.KFError) as e:
