@@ -32,9 +32,6 @@
 
 #include "kf_engine_common.h"
 
-#ifndef KF_XE_KV_NT
-#define KF_XE_KV_NT 1
-#endif
 namespace kf {
 
 constexpr int XE_NWG = 32;   /* workgroups of one decoder = the CUs of one XCD */
@@ -75,7 +72,6 @@ struct XArgs {
     unsigned long long* tp_recv; /* [rank][2][source rank][DIM] granules {fp32 partial | generation}: o_proj exchanges in buffer 0, down_proj exchanges in buffer 1 */
     unsigned long long* tp_best; /* [rank][source rank] {global row | tag16, bf16 value} */
     int stagger_us; /* two decoders per XCD: microseconds the second one starts behind the first */
-    int twin_sync;  /* two decoders per XCD: twin workgroups meet in front of the LM head (xe_head_main) */
 };
 
 // error word bits: 1 a hand-off vector (x, ao, xB, act, head x), 2 q|k|v, 4 partials, 8 workgroups per XCD != 32, 16 pick, 32 token granule, 64 position beyond the cache, 2048 a TP exchange
@@ -98,7 +94,7 @@ struct XCfg {
     // 16 sequences 3.46 -> 3.37 ms per step, 8 sequences 1.87 -> 1.83.  The layer weights: plain for one decoder per XCD (1.83 -> 1.82), non-temporal for two (plain: 3.43 --
     // two decoders' 8.4 MB layers and their K / V rows already fight for the XCD's 4 MB L2).
     static constexpr int WAUX = (TP_ || WPC_ > 1) ? 2 /* nt */ : 0;
-    static constexpr bool KV_NT = KF_XE_KV_NT != 0 && GQ_ <= 4; /* (head groups read the K / V rows twice: plain) */
+    static constexpr bool KV_NT = GQ_ <= 4; /* a sequence's K / V rows, read once per step: non-temporal (head groups read them twice: plain) */
     // wide residual streams: EVERY wave of the workgroup sweeps, normalises and stages its own 1 KiB units of x / xB (the compute waves stand at the barrier behind that
     // staging anyway; ONE wave doing it took 14 us of a 192 us layer at 5120 values: scratch/xtp_time.py)
     static constexpr bool COOP = DIM_ >= 2048;
@@ -138,7 +134,7 @@ struct XCfg {
     static constexpr int PSH = SPK * (2 * HD_ + 4); /* 8-byte granules of one head's slice partials: [HD / ME][SPK][ME] values x 2, then [SPK][4] {m, L lo, L hi, -} */
     // the XCD-local exchange area (dwords)
     static constexpr int xA = 0, qkv = xA + eng_gran_dw(DIM_), ao = qkv + eng_gran_dw(QD_ + 2 * KVD_), xB = ao + eng_gran_dw(QD_), act = xB + eng_gran_dw(DIM_),
-                         part = act + eng_gran_dw(FFNP), hbest = part + eng_gran_dw(2 * n_head * PSH), tokg = hbest + eng_gran_dw(2 * XE_NWG), twin = tokg + eng_gran_dw(2), loc_dw = twin + eng_gran_dw(2 * XE_NWG);
+                         part = act + eng_gran_dw(FFNP), hbest = part + eng_gran_dw(2 * n_head * PSH), tokg = hbest + eng_gran_dw(2 * XE_NWG), loc_dw = tokg + eng_gran_dw(2);
     // LM head (bf16 [vocab, DIM]): the geometry gemv_launch picks for a many-row bf16 matrix of this width
     static constexpr int HnBlk = DIM_ / 8, Hlpr_log2 = c_lpr_log2(DIM_ / 8, 1L << 20), HLPR = 1 << Hlpr_log2, HRPS = 64 >> Hlpr_log2, Hiters = (HnBlk + HLPR - 1) / HLPR;
     static constexpr int XCH = 8; /* fp32 activations: 16-byte chunks per 32-weight block */
@@ -992,25 +988,6 @@ __device__ __forceinline__ void xe_head_main(const XArgs& a, const XLds& L, cons
     }
     __syncthreads();
     if (wave == NWV - 1) issue(0, 0);
-    if constexpr (C::WPC == 2) {
-        // Two decoders per XCD stream the SAME head rows through the SAME L2: workgroup w of either decoder walks rows w * spg ... of the one matrix.  Started together the
-        // second one's requests meet the first one's lines in the L2 (the head is the one phase bound by the XCD's link, not by arithmetic: 311 MB per decoder at 1.1 TB/s);
-        // apart they cross the fabric twice.  So twin workgroups wait for each other here -- a performance rendezvous only: bounded, and a timeout is not an error.
-        const bool has_twin = S.seq >= XE_NXCD || S.seq + XE_NXCD < a.n_seq;
-        if (has_twin && a.twin_sync) {
-            uint32_t* tw = reinterpret_cast<uint32_t*>(a.loc + (size_t)(S.seq & (XE_NXCD - 1)) * a.loc_stride) + C::twin + 2 * wg;
-            const int me = S.seq >= XE_NXCD ? 1 : 0;
-            if (wave == 0) {
-                if (lane == 0) tw[me] = (uint32_t)epoch;
-                const __amdgpu_buffer_rsrc_t rt = eng_rsrc(tw, 8u);
-                for (int spins = 0; spins < 40000; spins++) {
-                    if (__builtin_amdgcn_raw_buffer_load_b32(rt, (1 - me) * 4, 0, 16 /* sc1 */) == (uint32_t)epoch) break;
-                    __builtin_amdgcn_s_sleep(2);
-                }
-            }
-            __syncthreads();
-        }
-    }
     float xf[ITERS][8];
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
@@ -1440,7 +1417,6 @@ int xengine_build(const kf_engine_desc* d, int n_seq, long long kv_seq_stride, v
     XArgs& a = E->args;
     E->shape_class = sc, E->fmt = FMT_Q4P, E->dim = d->dim, E->q_dim = q_dim, E->kv_dim = kv_dim, E->ffn = d->ffn, E->n_head = d->n_head, E->n_kv = d->n_kv, E->hd = hd;
     E->nwv = 12, E->depth = 6; /* 11 compute waves + the poller: three waves per SIMD (measured best: 1.89 ms per step of eight sequences against 1.92 with 9 x 8) */
-    a.twin_sync = 0; /* the rendezvous of twin workgroups in front of the head: measured, no gain (3.407 with, 3.368 without) */
     a.n_layer = d->n_layer, a.n_seq = n_seq, a.kv_seq_stride = kv_seq_stride, a.kv_stride = d->kv_stride, a.max_seq = d->max_seq;
     a.eps = d->rms_eps, a.qk_eps = d->qk_eps, a.rope_table = d->rope_table;
     for (int j = 0; j < 7; j++) a.qbias[j] = qbias[j];
@@ -1687,10 +1663,6 @@ int xengine_reset(XEngineHost* E, hipStream_t st) {
 void xengine_set_variant(XEngineHost* E, int nwv, int depth) {
     if (nwv == 0) { /* tuning hook: depth = the stagger of the second decoder in microseconds */
         E->args.stagger_us = depth;
-        return;
-    }
-    if (nwv == -2) { /* tuning hook: depth = XArgs::twin_sync */
-        E->args.twin_sync = depth;
         return;
     }
     if (nwv == -1) { /* tuning hook: depth = XArgs::deal_wl (0: the default of the form) */

@@ -1,6 +1,6 @@
 """Eight XCD-confined decoders (kf_xengine_*) on Qwen3-0.6B 4-bit: aggregate tokens/s at a position range, per variant (waves per workgroup x ring depth), n_seq sweep,
 and the per-phase stamps of one workgroup.
-  python scratch/xr_time.py [pos0=2028] [steps=20]      env: VARIANTS="9x8,13x6,16x4,9x12"  NSEQ="8,4,1"  STAMPS=1  DEAL="0,8,11,16" (xe_deal's weight, 0 = default)  CONFIG=qwen3-4b  TWIN=0 (no rendezvous of twin workgroups in front of the head)"""
+  python scratch/xr_time.py [pos0=2028] [steps=20]      env: VARIANTS="9x8,13x6,16x4,9x12"  NSEQ="8,4,1"  STAMPS=1  DEAL="0,8,11,16" (xe_deal's weight, 0 = default)  CONFIG=qwen3-4b"""
 import os
 import sys
 import time
@@ -30,7 +30,6 @@ for n_seq in [int(x) for x in os.environ.get("NSEQ", "8").split(",")]:
     for (nwv, depth, deal) in [(v[0], v[1], int(d)) for v in variants for d in os.environ.get("DEAL", "0").split(",")]:
         xr.variant(nwv, depth)
         xr.variant(-1, deal)
-        xr.variant(-2, int(os.environ.get("TWIN", "1")))
         for s in range(n_seq):   # the K / V rows below pos0 hold whatever earlier runs left (zeros at first): the arithmetic does not care
             xr.set_state(s, 1 + s, pos0 - 4)
         xr.run_steps(4)
