@@ -382,3 +382,56 @@ def test_tp_over_the_xcds_refuses_what_it_does_not_serve(ctx):
             XcdTP(nt)
         assert what in str(e.value), str(e.value)
         nt.close()
+
+
+def test_tp_over_the_xcds_at_long_context_equals_the_per_launch_rank_step(ctx):
+    """the one-launch TP engine over all 4096 positions of a 2-layer Qwen3-32B-shaped slice, teacher-forced (16 key slices x two head groups per rank: up to 256 keys per
+    workgroup), against the per-launch rank step on the same ids: every greedy id, the last logits and the ranks' K / V rows bit for bit (the per-launch step itself is held
+    to the oracle at positions 128 / 1024 / 4095 by test_native_tp8_32b_slice_at_depth_vs_the_oracle_bit_for_bit)"""
+    import ctypes as C
+    from koifish_amd.runtime import XcdTP
+    cfg = dict(synth.CONFIGS["qwen3-32b"], n_layer=2, vocab=8192, max_seq=4096, tied=True)
+    g = torch.Generator(device=ctx.device)
+    g.manual_seed(9)
+
+    def mat(r, c):
+        return (torch.randn(r, c, generator=g, device=ctx.device, dtype=torch.float32) * 0.05).to(torch.bfloat16)
+
+    def nrm(n):
+        return (1.0 + 0.01 * torch.randn(n, generator=g, device=ctx.device, dtype=torch.float32)).to(torch.bfloat16)
+    w, norms = {}, {}
+    w[(-1, 0)] = ctx.quantize(mat(cfg["vocab"], cfg["dim"]), L.BF16)
+    w[(-1, 1)] = w[(-1, 0)]
+    norms[(-1, 0)] = nrm(cfg["dim"])
+    for li in range(cfg["n_layer"]):
+        for si, s in enumerate(synth.SLOTS):
+            w[(li, si)] = ctx.quantize(mat(*synth.SHAPES[s](cfg)), L.Q4)
+        norms[(li, 0)], norms[(li, 1)], norms[(li, 2)], norms[(li, 3)] = nrm(cfg["dim"]), nrm(cfg["dim"]), nrm(128), nrm(128)
+    nt = TP.NativeTP(cfg, w, norms, 8, ctx)
+    for rk in nt.ranks:
+        rk.set_canonical(True)
+    S = cfg["max_seq"]
+    forced = np.random.default_rng(21).integers(0, cfg["vocab"], size=S).astype(np.int32)
+    xt = XcdTP(nt)
+    xt.set_forced(forced)
+    xt.set_state(int(forced[0]), 0)
+    xt.set_steps_per_launch(32)
+    xt.run_steps(S)
+    ctx.sync()
+    xt.check()
+    ids, g_logits = xt.tokens_out(S), xt.logits()
+    gk, gv = xt.kv_to_host()
+    nt.set_forced(forced)
+    nt.set_state(int(forced[0]), 0)
+    nt.run_steps(0, S, use_graph=True)
+    nt.check()
+    assert np.array_equal(nt.ranks[0].tokens_out(S), ids)
+    assert np.array_equal(nt.logits(), g_logits)
+    n = cfg["n_layer"] * S * 128
+    for r, a in enumerate(nt.ranks):
+        hk, hv = np.zeros(n, dtype=np.uint16), np.zeros(n, dtype=np.uint16)
+        L.check(ctx.hip.kf_d2h(ctx.h, hk.ctypes.data_as(C.c_void_p), C.c_void_p(a.host.kfh_kcache(a.h)), C.c_size_t(n * 2)), "d2h")
+        L.check(ctx.hip.kf_d2h(ctx.h, hv.ctypes.data_as(C.c_void_p), C.c_void_p(a.host.kfh_vcache(a.h)), C.c_size_t(n * 2)), "d2h")
+        assert np.array_equal(gk[r].reshape(-1), hk) and np.array_equal(gv[r].reshape(-1), hv), "rank %d" % r
+    xt.close()
+    nt.close()
