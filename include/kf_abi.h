@@ -479,7 +479,7 @@ int kf_engine_destroy(kf_engine* e);
  * n_seq <= 8: sequence s on XCD s, one workgroup per CU.  n_seq 9 .. 16: TWO decoders per XCD (sequences x and x + 8 on XCD x), two workgroups per CU -- while one
  * decoder waits on a hand-off the hardware issues the other's arithmetic, so the aggregate rate nearly doubles (a decoder's own step gets slower).
  * Served: 4-bit PackedQ (RTN, groups of 128) layers of the Qwen3-0.6B, 1.7B, 4B and 8B shapes (and two small test shapes), bf16 embedding / head, dense FFNs; the GQA-4
- * shapes (4B, 8B) with one decoder per XCD only (n_seq <= 8), the full-depth 1.7B too (LDS).  Weights are read in place and must not change while an engine built on them
+ * shapes (4B, 8B) with one decoder per XCD only (n_seq <= 8; 1.7B: sixteen are served, eight are faster).  Weights are read in place and must not change while an engine built on them
  * lives; for the GQA-4 shapes (and the TP form below) the engine keeps a fused COPY of every layer's q | k | v rows in its workspace, made at create time: after a weight
  * update destroy the engine and create it again. */
 typedef struct kf_xengine kf_xengine;

@@ -142,7 +142,7 @@ struct XCfg {
     // the waves' attention sums (fp64, [NCW][GQ][hd + 2]) in the second activation buffer when the two would not fit side by side (Qwen3-8B: 2 x 48 KB of activations): the
     // buffer is idle between the barrier in front of q | k | v (down_proj of the layer before has read it) and the staging of the attention output, which waits for every
     // slice partial of the XCD -- so for this workgroup's, written after the last read of the sums
-    static constexpr bool COMB_IN_XS1 = (size_t)maxKc * 8 + (size_t)DIM_ * 4 + sizeof(double) * (size_t)(NWV_ - 1) * GQW * (HD_ + 2) > 140 * 1024;
+    static constexpr bool COMB_IN_XS1 = (size_t)maxKc * 8 + (size_t)DIM_ * 4 + sizeof(double) * (size_t)(NWV_ - 1) * GQW * (HD_ + 2) > (size_t)(WPC_ > 1 ? 70 : 140) * 1024; /* (two workgroups per CU: half the LDS each -- the 1.7B shape) */
     static_assert(!COMB_IN_XS1 || sizeof(double) * (size_t)(NWV_ - 1) * GQW * (HD_ + 2) <= (size_t)maxKc * 4, "the sums fit the buffer");
     static constexpr int XS = maxKc / 32; /* chunk stride of the staged activations (16-byte units): chunk j of block column c at [j * XS + c], whatever the phase's width */
     // every phase in whole rows and whole iterations: no masks at the multiply
