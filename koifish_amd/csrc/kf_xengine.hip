@@ -1624,8 +1624,17 @@ int xengine_steps(XEngineHost* E, hipStream_t st, int32_t* d_state, uint16_t* x_
         rc = E->nwv == 8 ? xengine_go<XC5>(E, st) : xengine_go<XC5W>(E, st);
     else if (E->shape_class == 6)
         rc = xengine_go<XC6>(E, st);
-    else if (E->shape_class == 7)
-        rc = E->args.dbg ? xengine_go<XC7D>(E, st) : xengine_go<XC7>(E, st);
+    else if (E->shape_class == 7) {
+        if (E->args.dbg) rc = xengine_go<XC7D>(E, st);
+#ifdef XE_TP_VARIANTS /* tuning builds only (scratch/xtp_time.py VARIANT=): ring depth 8 / 4, two key tiles per attention batch, the 8-wave 256-register form.  Measured,
+                         ms per step of 16 layers at 4 k keys: default (12 waves, depth 6, one tile) 2.802, depth 8 2.895, depth 4 2.786, two tiles 3.157, 8 waves 2.896 */
+        else if (E->depth == 8) rc = xengine_go<XCfg<FMT_Q4P, 8, 128, 12, 5120, 1024, 128, 3200, 8, false, 1, 1, true>>(E, st);
+        else if (E->depth == 4) rc = xengine_go<XCfg<FMT_Q4P, 8, 128, 12, 5120, 1024, 128, 3200, 4, false, 1, 1, true>>(E, st);
+        else if (E->depth == 62) rc = xengine_go<XCfg<FMT_Q4P, 8, 128, 12, 5120, 1024, 128, 3200, 6, false, 1, 2, true>>(E, st);
+        else if (E->nwv == 8) rc = xengine_go<XCfg<FMT_Q4P, 8, 128, 8, 5120, 1024, 128, 3200, 8, false, 1, 2, true>>(E, st);
+#endif
+        else rc = xengine_go<XC7>(E, st);
+    }
     else
         rc = E->shape_class == 1 ? xengine_go_shape<XC1>(E, st) : xengine_go_shape<XC2>(E, st);
     a.head_w = save.head_w;

@@ -1489,6 +1489,7 @@ void* kfh_xtp_vcache(void* h) { return ToX(reinterpret_cast<XcdTP*>(h)->val); }
 extern "C" int kfdbg_xengine_variant(kf_xengine* e, int nwv, int depth);
 extern "C" int kfdbg_xengine_stamps_enable(kf_xengine* e, int seq, int wg, int max_steps);
 extern "C" int kfdbg_xengine_stamps(kf_xengine* e, unsigned long long* h_out, int n_words);
+int kfh_xtp_variant(void* h, int nwv, int depth) { return kfdbg_xengine_variant(reinterpret_cast<XcdTP*>(h)->engine, nwv, depth); }
 int kfh_xtp_stamps_enable(void* h, int rank, int wg, int max_steps) { return kfdbg_xengine_stamps_enable(reinterpret_cast<XcdTP*>(h)->engine, rank, wg, max_steps); }
 int kfh_xtp_stamps(void* h, unsigned long long* out, int n) { return kfdbg_xengine_stamps(reinterpret_cast<XcdTP*>(h)->engine, out, n); }
 int kfh_xr_variant(void* h, int nwv, int depth) { return kfdbg_xengine_variant(reinterpret_cast<XcdReplicas*>(h)->engine, nwv, depth); }

@@ -214,6 +214,7 @@ def load():
         host.kfh_xtp_set_steps_per_launch.argtypes = [C.c_void_p, C.c_int]
         host.kfh_xtp_get_tokens.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         host.kfh_xtp_vocab.argtypes = [C.c_void_p]
+        host.kfh_xtp_variant.argtypes = [C.c_void_p, C.c_int, C.c_int]
         host.kfh_xtp_stamps_enable.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         host.kfh_xtp_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         for f in ("kfh_xtp_logits", "kfh_xtp_hidden", "kfh_xtp_kcache", "kfh_xtp_vcache"):

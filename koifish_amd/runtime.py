@@ -762,6 +762,10 @@ class XcdTP:
         shp = (len(self.nt.ranks), c["n_layer"], c["max_seq"], kvd)
         return self._d2h(self.host.kfh_xtp_kcache(self.h), n).reshape(shp), self._d2h(self.host.kfh_xtp_vcache(self.h), n).reshape(shp)
 
+    def variant(self, nwv, depth):
+        """tuning builds (-DXE_TP_VARIANTS): another instantiation for the next launches"""
+        self.host.kfh_xtp_variant(self.h, int(nwv), int(depth))
+
     def stamps(self, rank, wg, steps, n_layer):
         """enable (steps > 0) / read the per-phase wall-clock stamps [step][layer][64] of one workgroup of one rank (diagnostic instantiation)"""
         if steps > 0:

@@ -1,4 +1,3 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-timeout 1200 python -m pytest tests/test_gpu_xengine.py -x -q -k "1p7b or refusals" 2>&1 | tail -4
-CONFIG=qwen3-1.7b VARIANTS="8x4" NSEQ="16" timeout 900 python3 scratch/xr_time.py 2028 20 2>&1 | grep -v amdgpu.ids
+for V in "" 12x8 12x4 12x62 8x8; do VARIANT=$V timeout 600 python3 scratch/xtp_time.py 16 4000 16 2>&1 | grep -v amdgpu.ids | head -1 | sed "s/^/variant [$V]: /"; done

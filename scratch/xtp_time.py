@@ -46,6 +46,8 @@ forced = np.full(cfg["max_seq"], -1, dtype=np.int32)
 forced[:16] = 5
 xt.set_forced(forced)
 xt.set_steps_per_launch(steps)
+if os.environ.get("VARIANT"):   # a library built with -DXE_TP_VARIANTS: "12x8", "12x4", "12x62" (two key tiles per batch), "8x8"
+    xt.variant(*[int(v) for v in os.environ["VARIANT"].split("x")])
 best = 1e9
 for rep in range(3):
     xt.set_state(7, pos0)          # the K / V rows below pos0 are zeros: the arithmetic does not care
