@@ -1,3 +1,5 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r05s
+mkdir -p $O
 cd $R
-for V in "" 12x8 12x4 12x62 8x8; do VARIANT=$V timeout 600 python3 scratch/xtp_time.py 16 4000 16 2>&1 | grep -v amdgpu.ids | head -1 | sed "s/^/variant [$V]: /"; done
+timeout 3000 python -m pytest tests -m gpu -q --kf-shipped-order -k "not full_depth and not eight_xcds" > $O/pytest_shipped.log 2>&1; echo "rc=$?"; tail -40 $O/pytest_shipped.log | cut -c1-220

@@ -9,8 +9,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def pytest_addoption(parser):
+    parser.addoption("--kf-shipped-order", action="store_true", default=False,
+                     help="leave the library's own default summation order (canonical) in place for the whole suite instead of starting contexts in the v_dot2c order")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "fast_order: written against the v_dot2c order on BOTH sides (skipped under --kf-shipped-order)")
+    if config.getoption("--kf-shipped-order"):   # the whole suite on what ships by default (run: 630 pass, the fast_order ones skipped)
+        return
     # The library's default summation order is the canonical one (round 4).  The tolerance tests of this suite were written against the v_dot2c order and keep
     # covering it: contexts and models built through koifish_amd.runtime start in that order here; every bit-exact test switches the canonical order on itself
     # (set_canonical(True)), and tests/test_gpu_canonical.py::test_library_default_is_the_canonical_order checks the untouched default.
@@ -27,6 +35,11 @@ def _has_gpu():
 
 
 def pytest_collection_modifyitems(config, items):
+    if config.getoption("--kf-shipped-order"):
+        sk = pytest.mark.skip(reason="compares two v_dot2c-order computations (or a v_dot2c launch with the oracle's dot16 order at its tolerance): not meaningful in the canonical order")
+        for it in items:
+            if "fast_order" in it.keywords:
+                it.add_marker(sk)
     if _has_gpu():
         return
     skip = pytest.mark.skip(reason="no GPU in this container")

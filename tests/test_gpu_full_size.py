@@ -19,6 +19,7 @@ def model():
     m.close()
 
 
+@pytest.mark.fast_order   # (against the oracle's dot16 order at 2^-6; the canonical order's own check is bit-exact: test_gpu_canonical.py)
 def test_full_size_logits_and_ids_vs_oracle(model):
     cfg, m = model
     om = O.from_device_model(m)

@@ -95,6 +95,7 @@ def test_qwen3_32b_shapes_tp8_slice(ctx):
 
 
 # ---------------------------------------------------------------------------------------------- the C++ host's TP step (Fish::TPPhase + kf_tp_*)
+@pytest.mark.fast_order   # (the Python-stepped ranks launch q, k, v one by one: in the canonical order their lanes per row are those of THEIR launches, not of the fused one)
 @pytest.mark.parametrize("cfg_name,world,use_graph", [("tiny", 2, False), ("small", 2, True), ("small", 8, True)])
 def test_native_tp_equals_python_stepped_tp_bit_for_bit(ctx, cfg_name, world, use_graph):
     """The step in the C++ host with the exchange done by kernels (push into every rank's receive area, rank-ordered sum, arg-max pairs the
