@@ -894,6 +894,24 @@ int XcdReplicas::SetState(int seq, int token, int pos) {
     if (seq < 0 || seq >= n_seq || pos < 0 || pos >= hFish->config.n_ctx || token < 0 || token >= hFish->config.vocab) return KF_INVALID_ARGS;
     return kf_set_state(hFish->ctx, d_state + 4 * seq, token, pos);
 }
+// The prompt half of "prefill + decode" for one of the sequences: the model's own batched prefill (Fish::Prefill: the reference prefills token by token through the decode
+// path, GoPT.cpp:1139-1146), then the prompt's K / V rows of every layer move into the sequence's cache and the sequence stands at {first generated id, n}.
+int XcdReplicas::Prefill(int seq, const int* tokens, int n) {
+    const MODEL_CARD& c = hFish->config;
+    if (seq < 0 || seq >= n_seq || !tokens || n < 1 || n >= c.n_ctx) return KF_INVALID_ARGS;
+    kf_ctx* ctx = hFish->ctx;
+    KF_TRY(hFish->Prefill(tokens, n, 0));
+    const int kvd = c.n_head_kv * c.head_dim;
+    const size_t seq_elems = kv_seq_elems();
+    for (int l = 0; l < c.nLayer; l++) {
+        const size_t off = (size_t)seq * seq_elems + (size_t)l * c.n_ctx * kvd;
+        KF_TRY(kf_d2d(ctx, ToX(key) + off, hFish->cache.Get(KVCache::KV_KEY, l, 0), (size_t)n * kvd * 2));
+        KF_TRY(kf_d2d(ctx, ToX(val) + off, hFish->cache.Get(KVCache::KV_VAL, l, 0), (size_t)n * kvd * 2));
+    }
+    KF_TRY(kf_d2d(ctx, d_state + 4 * seq, hFish->d_state, 8));                                                   /* {the id picked behind the prompt, n} */
+    KF_TRY(kf_d2d(ctx, d_tokens_out + (size_t)seq * c.n_ctx + (n - 1), hFish->d_tokens_out + (n - 1), 4));      /* ids out: position n - 1 holds that id, as after decode steps */
+    return KF_OK;
+}
 int XcdReplicas::RunSteps(int n) {
     if (!engine || n < 1) return KF_INVALID_ARGS;
     for (int i = 0; i < n;) {
@@ -1422,6 +1440,7 @@ void* kfh_xr_create(void* fish, int n_seq, int* rc_out) {
 void kfh_xr_destroy(void* h) { delete reinterpret_cast<XcdReplicas*>(h); }
 int kfh_xr_set_forced(void* h, int seq, const int32_t* ids, int n) { return reinterpret_cast<XcdReplicas*>(h)->SetForced(seq, ids, n); }
 int kfh_xr_set_state(void* h, int seq, int token, int pos) { return reinterpret_cast<XcdReplicas*>(h)->SetState(seq, token, pos); }
+int kfh_xr_prefill(void* h, int seq, const int* tokens, int n) { return reinterpret_cast<XcdReplicas*>(h)->Prefill(seq, tokens, n); }
 int kfh_xr_run_steps(void* h, int n) { return reinterpret_cast<XcdReplicas*>(h)->RunSteps(n); }
 int kfh_xr_check(void* h) { return reinterpret_cast<XcdReplicas*>(h)->Check(); }
 int kfh_xr_set_steps_per_launch(void* h, int n) {

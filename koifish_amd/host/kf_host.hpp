@@ -301,6 +301,7 @@ struct XcdReplicas {
     int Build(Fish* f, int n_seq_);
     int SetForced(int seq, const int32_t* ids, int n);
     int SetState(int seq, int token, int pos);
+    int Prefill(int seq, const int* tokens, int n);  // the sequence's prompt through Fish::Prefill (token batches on the tile kernels), its K / V rows into the sequence's cache; the sequence then stands behind the prompt
     int RunSteps(int n);  // n greedy steps of EVERY sequence from wherever each stands; no host sync
     int Check();          // synchronises; a timed-out hand-off is reported once (KF_INTERNAL_ERR) and the engine reset
     size_t kv_seq_elems() const;

@@ -639,6 +639,11 @@ class XcdReplicas:
     def set_state(self, seq, token, pos):
         L.check(self.host.kfh_xr_set_state(self.h, int(seq), int(token), int(pos)), "kfh_xr_set_state")
 
+    def prefill(self, seq, tokens):
+        """the sequence's prompt through the model's batched prefill; its K / V rows into the sequence's cache; the sequence then stands behind the prompt (state = {first generated id, len(tokens)})"""
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        L.check(self.host.kfh_xr_prefill(self.h, int(seq), t.ctypes.data_as(C.c_void_p), t.size), "kfh_xr_prefill")
+
     def run_steps(self, n):
         """n greedy steps of EVERY sequence from wherever each stands; no host sync"""
         L.check(self.host.kfh_xr_run_steps(self.h, int(n)), "kfh_xr_run_steps")

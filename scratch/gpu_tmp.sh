@@ -1,5 +1,3 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r05s
-mkdir -p $O
 cd $R
-timeout 3000 python -m pytest tests -m gpu -q --kf-shipped-order -k "not full_depth and not eight_xcds" > $O/pytest_shipped.log 2>&1; echo "rc=$?"; tail -40 $O/pytest_shipped.log | cut -c1-220
+timeout 1200 python -m pytest tests/test_gpu_xengine.py -x -q -k "prefill_then_decode" 2>&1 | tail -12

@@ -327,3 +327,38 @@ def test_eight_query_heads_on_one_kv_head(canon):
         assert np.array_equal(gk[:, :n_steps], ok[:, :n_steps]) and np.array_equal(gv[:, :n_steps], ov[:, :n_steps])
     xr.close()
     m.close()
+
+
+def test_prefill_then_decode_per_sequence(canon):
+    """prefill + decode for the replicas: every sequence's prompt (different lengths: 40 ... 250 tokens, the longer ones on the tile-GEMM routes) goes through the model's own
+    batched prefill (XcdReplicas.prefill -> Fish::Prefill), its K / V rows into the sequence's cache; then all sequences decode together.  Against the model ALONE doing the same
+    for that sequence (prefill, then the single-sequence decode in the canonical order): the prompt's K / V rows, every generated id, the last logits and the generated
+    positions' K / V rows bit for bit."""
+    cfg = dict(synth.CONFIGS["small"], max_seq=320)
+    raw = synth.raw_weights_numpy(cfg, 777, w_std=0.1)
+    m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
+    m.set_canonical(True)
+    n_seq, n_new = 8, 40
+    xr = XcdReplicas(m, n_seq)
+    prompts = [prompt_ids(cfg, 40 + 30 * s, seed=900 + s) for s in range(n_seq)]
+    for s in range(n_seq):
+        xr.prefill(s, prompts[s])
+    xr.set_steps_per_launch(8)
+    xr.run_steps(n_new)
+    m.sync()
+    xr.check()
+    for s in (0, 3, 7):
+        P = len(prompts[s])
+        nxt, _ = m.prefill(prompts[s], want_logits=False)
+        m.set_forced(np.full(cfg["max_seq"], -1, dtype=np.int32))
+        m.run_steps(P, n_new, use_graph=False)
+        m.sync()
+        ref_ids = m.tokens_out(P + n_new)
+        got = xr.tokens_out(s, P + n_new)
+        assert got[P - 1:].tolist() == ref_ids[P - 1:].tolist(), "sequence %d" % s
+        assert np.array_equal(xr.logits(s), m.logits())
+        rk, rv = m.kv_to_host()
+        gk, gv = xr.kv_to_host(s)
+        assert np.array_equal(gk[:, :P + n_new], rk[:, :P + n_new]) and np.array_equal(gv[:, :P + n_new], rv[:, :P + n_new])
+    xr.close()
+    m.close()
