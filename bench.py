@@ -850,6 +850,26 @@ def xcd_replicas(m, cfg, forced, timed_positions, warmup, n_seq, ids_main):
         distinct = len({tuple(xr.tokens_out(s, S)[128:160].tolist()) for s in range(n_seq)})
         tps = n_seq * K / dt
         bytes_tok = float(np.mean([m.step_bytes(p) for p in timed_positions]))
+        prompt_leg = None
+        try:   # the prompt half for the replicas (after every check above: it overwrites the sequences' rows): each sequence's 128-token prompt through the model's batched prefill, then 32 tokens of all
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for s in range(n_seq):
+                pr = forced[:128] if s == 0 else np.random.default_rng(200 + s).integers(0, cfg["vocab"], size=128).astype(np.int32)
+                xr.prefill(s, pr)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for s in range(n_seq):
+                xr.set_forced(s, np.full(S, -1, dtype=np.int32))
+            xr.run_steps(32)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            xr.check()
+            prompt_leg = {"prompt_tokens": 128, "prefill_ms_per_sequence": round((t2 - t1) * 1e3 / n_seq, 3), "then_32_tokens_of_every_sequence_ms": round((t3 - t2) * 1e3, 3),
+                          "prompt_plus_32_tokens_per_s": round(n_seq * (128 + 32) / (t3 - t1), 1),
+                          "parity": "tests/test_gpu_xengine.py::test_prefill_then_decode_per_sequence (rows, ids, logits == the model alone doing prefill + decode)"}
+        except Exception as e:
+            prompt_leg = {"error": repr(e)[:200]}
         return {"streams": n_seq, "decoders_per_xcd": 2 if n_seq > 8 else 1,
                 "layout": "32 workgroups of one launch per decoder, every hand-off inside that XCD's L2" + ("; two decoders per XCD = two workgroups per CU: one decoder's hand-off waits and K / V "
                           "streaming run under the other's mat-vec arithmetic" if n_seq > 8 else ""),
@@ -860,7 +880,7 @@ def xcd_replicas(m, cfg, forced, timed_positions, warmup, n_seq, ids_main):
                 "note": "algorithmic bytes of ONE sequence's step x aggregate tokens/s / 8 TB/s: every decoder streams the layer weights, its own K / V rows and the head through its own XCD's L2 "
                         "(counter traffic at the L2s = 1.04 x the sum of the sequences' algorithmic bytes: profiles/r05_pmc_xengine_16.json; the weights are shared, so the memory-side "
                         "cache may answer part of it); never `value`",
-                "traffic_per_sequence_step": traffic, "traffic_source": traffic_src,
+                "traffic_per_sequence_step": traffic, "traffic_source": traffic_src, "prefill_then_decode": prompt_leg,
                 "summation_order": "canonical (the only order the XCD-confined engines run)", "kernel": "kf::xengine_kernel (koifish_amd/csrc/kf_xengine.hip)",
                 "parity": {"sequence_0_ids_equal_single_sequence_engine": same, "positions_compared": int(S), "distinct_continuations": distinct,
                            "per_sequence_oracle_parity": "tests/test_gpu_xengine.py (ids, logits, K / V rows of every sequence, bit for bit)"}}
