@@ -234,7 +234,7 @@ def test_native_tp8_32b_slice_at_depth_vs_the_oracle_bit_for_bit(ctx):
 def test_native_tp8_full_depth_qwen3_32b_vs_the_oracle(ctx):
     """north_star's second target at FULL DEPTH (missing 5): all 64 layers of the Qwen3-32B shape (dim 5120, 64 / 8 heads of 128, ffn 25600, the 151936-row
     vocabulary: 16.6 GB of 4-bit layers + a 1.56 GB head), tensor parallel TP = 8 as eight virtual ranks on this GPU (the ranks' kernels and the kernel-side exchange; no
-    xGMI), decoding a 6-token prompt and then 6 free-running greedy ids -- against the oracle's tensor-parallel emulation (row shards as they are, column shards as fp32
+    xGMI), decoding a 4-token prompt and then 5 free-running greedy ids -- against the oracle's tensor-parallel emulation (row shards as they are, column shards as fp32
     partials summed in rank order) in the canonical order: every id and the last position's 151936 logits bit for bit."""
     cfg = dict(synth.CONFIGS["qwen3-32b"], max_seq=64)
     g = torch.Generator(device=ctx.device)
@@ -256,7 +256,7 @@ def test_native_tp8_full_depth_qwen3_32b_vs_the_oracle(ctx):
     nt = TP.NativeTP(cfg, w, norms, 8, ctx)
     for rk in nt.ranks:
         rk.set_canonical(True)
-    n_prompt, n_new = 6, 6
+    n_prompt, n_new = 4, 5
     forced = np.full(cfg["max_seq"], -1, dtype=np.int32)
     forced[:n_prompt] = np.random.default_rng(64).integers(0, cfg["vocab"], size=n_prompt)
     nt.set_forced(forced)
@@ -320,7 +320,7 @@ def test_tp8_ranks_as_the_eight_xcds_of_one_launch_vs_the_oracle(ctx):
     nt = TP.NativeTP(cfg, w, norms, 8, ctx)
     for rk in nt.ranks:
         rk.set_canonical(True)
-    n_prompt, n = 24, 136
+    n_prompt, n = 24, 96
     forced = np.full(cfg["max_seq"], -1, dtype=np.int32)
     forced[:n_prompt] = np.random.default_rng(5).integers(0, cfg["vocab"], size=n_prompt)
     xt = XcdTP(nt)

@@ -264,7 +264,7 @@ def test_gqa4_shapes_equal_the_per_layer_launches_and_the_oracle(canon, name, va
     raw = synth.raw_weights_numpy(cfg, 4040, w_std=0.04)
     m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
     m.set_canonical(True)
-    n_seq, n_steps = 8, 90
+    n_seq, n_steps = 8, 64
     xr = XcdReplicas(m, n_seq)
     forced = []
     for s in range(n_seq):
