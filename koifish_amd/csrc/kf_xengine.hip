@@ -111,8 +111,8 @@ struct XCfg {
     static constexpr int NG = GQ_ > 4 ? GQ_ / 4 : 1, GQW = GQ_ / NG;
     static_assert(GQ_ % NG == 0 && XE_NWG % (n_kv * NG) == 0, "whole workgroups per kv-head and head group");
     static constexpr int SPK = XE_NWG / (n_kv * NG); /* key slices (= workgroups) per kv-head and head group */
-    // q | k | v rows: a workgroup's rows belong to ONE of the three matrices.  With 16 / 8 heads the 32 workgroups cut the row slots that way; the GQA-4 shapes (32 / 8 heads:
-    // 4 + 1 + 1 parts) do with 24 workgroups -- the other eight own no row of this phase (a fifth of a layer's weights at three quarters of the workgroups)
+    // q | k | v rows: a workgroup's rows belong to ONE of the three matrices.  With 16 / 8 heads the 32 workgroups cut the row slots that way; for the GQA-4 shapes (32 / 8 heads:
+    // 4 + 1 + 1 parts) only 24 equal pieces would (P1W0) -- the other eight workgroups would own no row of the phase: see FUSED below
     static constexpr int P1W0 = xe_p1_wgs(DIM_, eng_vepb<FMT_>(), QD_, KVD_);
     static_assert(P1W0 > 0, "no cut of the q | k | v row slots into whole-matrix pieces");
     // FUSED: where 32 equal pieces would straddle the matrices, the engine multiplies ONE matrix of QD + 2 KVD rows -- a copy of the three shards' blocks and zero / step words,
@@ -1416,7 +1416,7 @@ int xengine_build(const kf_engine_desc* d, int n_seq, long long kv_seq_stride, v
     memset(E, 0, sizeof(*E));
     XArgs& a = E->args;
     E->shape_class = sc, E->fmt = FMT_Q4P, E->dim = d->dim, E->q_dim = q_dim, E->kv_dim = kv_dim, E->ffn = d->ffn, E->n_head = d->n_head, E->n_kv = d->n_kv, E->hd = hd;
-    E->nwv = 12, E->depth = 6; /* 11 compute waves + the poller: three waves per SIMD (measured best: 1.89 ms per step of eight sequences against 1.92 with 9 x 8) */
+    E->nwv = 12, E->depth = 6; /* 11 compute waves + the poller: three waves per SIMD (measured best: 1.89 ms per step of eight sequences against 1.92 with 9 x 8; 1.82 since the head rows are read with plain loads) */
     a.n_layer = d->n_layer, a.n_seq = n_seq, a.kv_seq_stride = kv_seq_stride, a.kv_stride = d->kv_stride, a.max_seq = d->max_seq;
     a.eps = d->rms_eps, a.qk_eps = d->qk_eps, a.rope_table = d->rope_table;
     for (int j = 0; j < 7; j++) a.qbias[j] = qbias[j];
