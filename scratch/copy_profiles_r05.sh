@@ -11,3 +11,4 @@ tail -1 $O/bench_driver_flags.json > $P/$1
 [ -f $O/xtp_stamps.txt ] && cp $O/xtp_stamps.txt $P/r05_xtp_stamps.txt
 [ -f $O/xengine_shapes.txt ] && cp $O/xengine_shapes.txt $P/r05_xengine_shapes.txt
 X=$(ls -t $(find $O/trace_xtp -name "*kernel_stats.csv" 2>/dev/null) 2>/dev/null | head -1); [ -n "$X" ] && cp $X $P/r05_xtp_kernel_stats.csv
+cp $O/r05_pmc_xengine_16_sq.json $O/r05_pmc_xengine_8_sq.json $P/ 2>/dev/null
