@@ -28,6 +28,15 @@ try:   # the CPUs this process may use, before an OpenMP runtime pins its initia
 except Exception:
     _ALL_CPUS = None
 
+_T_START = time.perf_counter()
+_LAPS = []
+
+
+def _lap(name):
+    """wall-clock bookkeeping of the run's phases (detail file only)"""
+    _LAPS.append((name, round(time.perf_counter() - _T_START, 1)))
+
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy achieves
 
 
@@ -63,14 +72,16 @@ def main():
     ap.add_argument("--x-tp-layers", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--x-tp-vocab", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--x-no-tp-leg", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--tp-xcd", type=int, default=0, help="with --tp-virtual 8: the eight ranks as the eight XCDs of ONE launch (kf_xengine_create_tp) instead of the per-launch rank step")
+    ap.add_argument("--tp-xcd", type=int, default=0, help="with --tp-virtual 8: 1 = the eight ranks as the eight XCDs of ONE launch (kf_xengine_create_tp) instead of the per-launch rank step; 2 = both, one after the other")
     ap.add_argument("--tp-layers", type=int, default=0, help="with --tp-virtual: this many of the model's layers (0 = all): bounds the side leg's wall time")
     ap.add_argument("--lean-cpu", type=float, default=0.0, help="with --lean: also the CPU-baseline leg (parity passes + a timed sample of this many seconds) of the model being run")
     ap.add_argument("--lean-prefill", type=int, default=0, help="with --lean: also a prompt of this many tokens through Fish::Prefill (prefill_rate)")
     ap.add_argument("--lean-xcd", type=int, default=0, help="with --lean: also the XCD-confined engines on this many independent sequences of the model being run (xcd_replicas)")
+    ap.add_argument("--jump", action="store_true", help="side legs only (never the run behind `value`): no token-serial run-up to the timed window -- the K / V rows of the positions in front of it "
+                    "are synthetic N(0, 1) bf16 rows written once (a step's time depends on how many rows it reads, not on their values), the decode state is set to the window's first position")
     ap.add_argument("--lean", action="store_true", help="only the timed decode and step_roofline (what the side legs run in their child processes)")
     ap.add_argument("--leg", default="", choices=["", "config3", "config4cpu"], help="run ONE side leg and print its JSON (child processes of the main run)")
-    ap.add_argument("--side-legs", default="config3,config5,config4,qwen3_1p7b,qwen3_4b", help="side objects beside the line, each measured in a child process after the main measurements "
+    ap.add_argument("--side-legs", default="config3,config5,config4,qwen3_1p7b", help="side objects beside the line, each measured in a child process after the main measurements "
                     "(never `value`): config3 = GPT2-1558M operator path of a training step (sum of separately timed forward+loss, backward, AdamW phases; no parameter update), config5 = 1-bit layers + 20 %% hot FFN rows, config4 = Qwen3-32B on ONE GPU; '' = none")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -115,6 +126,7 @@ def main():
     head_type = {"bf16": L.BF16, "q4": L.Q4, "nf4": L.NF4}[args.head]
     layer_type = {"q4": L.Q4, "bf16": L.BF16, "f8": L.F8E5M2, "ternary": L.T_SIGN, "1bit": L.BOOL1, "nf4": L.NF4}[args.layers]
     m = synth.build_on_gpu(cfg, seed=1234 + rank, layer_type=layer_type, head_type=head_type, device=dev)
+    _lap("model built")
     m.set_prefill_resident(True, 96 << 30)   # opt-in (library default: off): this run never changes a weight in place, so long prompts may keep bf16 copies of the layer matrices in HBM
     ctx = m._ctx
     hots = {}
@@ -160,7 +172,14 @@ def main():
             m.set_state(int(forced[0]), b)
             m.run_steps(b, 16, use_graph)
     m.set_state(int(forced[0]), 0)
-    pos = run_span(0, start) if start else 0
+    if args.jump and start > 0:
+        import ctypes as C
+        kvb = cfg["n_layer"] * S * cfg["n_kv"] * cfg["head_dim"] * 2
+        _fill_kv_synthetic(m.hip, C.c_void_p(m.host.kfh_ctx(m.h)), [(m.host.kfh_kcache(m.h), kvb), (m.host.kfh_vcache(m.h), kvb)])
+        m.set_state(1, start)
+        pos = start
+    else:
+        pos = run_span(0, start) if start else 0
     pos = run_span(pos, W)
     timed_positions = [(pos + i) % S for i in range(K)]
 
@@ -171,6 +190,7 @@ def main():
         torch.cuda.synchronize()
 
     e0, e1 = ctx.event(), ctx.event()
+    _lap("run-up + warm-up")
     barrier()
     t0 = time.perf_counter()
     ctx.record(e0)
@@ -198,12 +218,11 @@ def main():
             "metric": "tokens/sec/GPU Qwen3 4-bit prefill+decode; achieved HBM GB/s vs peak",
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"q4": "u4 weights (PackedQ RTN g128)", "bf16": "bf16 weights", "f8": "f8e5m2 weights", "ternary": "2-bit ternary weights (PackedQ YinYang g128)",
-                      "1bit": "1-bit weights (PackedQ YinYang g128)", "nf4": "u4 weights (NF4 row codebooks)"}[args.layers] + " x bf16 activations, fp32 accumulate; bf16 KV",
+            "dtype": {"q4": "u4", "bf16": "bf16", "f8": "f8e5m2", "ternary": "u2", "1bit": "u1", "nf4": "u4 (NF4)"}[args.layers] + " weights x bf16, fp32 accumulate",
             "data": "synthetic",
             "config": {"workload": "%s %s greedy decode, 1xMI355X per replica, seq=%d: prompt 128, timed positions %d..%d"
                                    % ({"qwen3-0.6b": "Qwen3-0.6B", "qwen3-32b": "Qwen3-32B", "qwen3-1.7b": "Qwen3-1.7B", "qwen3-4b": "Qwen3-4B", "qwen3-8b": "Qwen3-8B"}.get(args.config, args.config), {"q4": "4-bit PackedQ", "bf16": "bf16", "f8": "f8e5m2", "ternary": "2-bit ternary PackedQ", "1bit": "1-bit PackedQ", "nf4": "4-bit NF4 row-codebook"}[args.layers],
-                                      S, timed_positions[0], timed_positions[-1]),
+                                      S, timed_positions[0], timed_positions[-1]) + ("; K / V rows in front of the window synthetic (--jump)" if args.jump else ""),
                        "lm_head": args.head, "sparse_ffn_rows_hot": args.sparse if args.sparse > 0 else None, "replicas": world,
                        "hipgraph": bool(use_graph and m.num_graphs() > 0),  # a step that is ONE launch (the engine with head and pick) is launched directly: a one-node graph only adds replay cost
                        "device_ms_per_step": round(dev_ms / K, 5)},
@@ -255,7 +274,7 @@ def main():
                     out["cpu_baseline"] = {"error": repr(e)[:300]}
             if args.lean_xcd > 0 and world == 1:
                 try:
-                    out["xcd_replicas"] = xcd_replicas(m, cfg, forced, timed_positions, W, args.lean_xcd, ids_timed_run)
+                    out["xcd_replicas"] = xcd_replicas(m, cfg, forced, timed_positions, W, args.lean_xcd, ids_timed_run, jump=args.jump)
                 except Exception as e:
                     out["xcd_replicas"] = {"error": repr(e)[:300]}
             if args.lean_prefill > 0 and world == 1:
@@ -266,6 +285,7 @@ def main():
                     out["prefill"] = {"error": repr(e)[:200]}
             print(json.dumps(out))
             return
+        _lap("timed + fast order")
         out["prefill"] = prefill_rate(m, forced[:n_prompt], ms_per_step)
         if world == 1 and args.streams > 1 and args.config == "qwen3-0.6b":
             try:
@@ -282,8 +302,10 @@ def main():
             out["roofline"] = head_rl
             out["roofline_error"] = repr(e)[:200]
         m.engine_check()
+        _lap("prefill + rooflines")
         out["roofline_lm_head"] = head_rl
         out["cpu_baseline"] = cpu_baseline(m, cfg, forced, args.cpu_seconds, hots=hots) if (world == 1 and args.cpu_seconds > 0) else None
+        _lap("cpu_baseline")
         if args.config == "qwen3-0.6b":   # last (it overwrites the KV rows and ids the checks above read): the prompt half through a prompt that fills the context, one token batch
             try:
                 long_prompt = np.random.default_rng(7).integers(0, cfg["vocab"], size=S - 1).astype(np.int32)
@@ -297,14 +319,16 @@ def main():
                 out["cpu_baseline_fp16"] = cpu_fp16_decode(cfg, ctx.device, args.cpu_fp16_steps)
             except Exception as e:   # a side measurement must never cost the bench line
                 out["cpu_baseline_fp16"] = {"error": repr(e)[:200]}
+        _lap("long prompt + cpu fp16")
         if args.config == "qwen3-0.6b" and args.layers == "q4" and args.sparse == 0.0 and args.xcd_replicas > 0:
             try:   # eight independent decoders, one per XCD, sharing this model's weights (kf_xengine_*): the aggregate beside the single-sequence `value`
                 out["xcd_replicas"] = xcd_replicas(m, cfg, forced, timed_positions, W, args.xcd_replicas, ids_timed_run)
                 if args.xcd_replicas > 8 and "error" not in out["xcd_replicas"]:   # the one-decoder-per-XCD form beside it (what VERDICT r04 asked for by name)
                     e8 = xcd_replicas(m, cfg, forced, timed_positions, W, 8, ids_timed_run)
-                    out["xcd_replicas"]["one_per_xcd"] = {k: e8.get(k) for k in ("streams", "tokens_per_s", "per_stream_tokens_per_s", "ms_per_step_all_streams", "frac", "parity", "skipped")}
+                    out["xcd_replicas"]["one_per_xcd"] = {k: e8.get(k) for k in ("streams", "batch", "decoders_per_xcd", "tokens_per_s", "per_stream_tokens_per_s", "ms_per_step_all_streams", "frac_vs_single_sequence_roofline", "hbm_frac_batch", "parity", "skipped")}
             except Exception as e:   # a side measurement must never cost the bench line
                 out["xcd_replicas"] = {"error": repr(e)[:300]}
+        _lap("xcd_replicas")
         if world == 1 and args.config == "qwen3-0.6b" and args.layers == "q4" and args.sparse == 0.0:
             m.close()
             del m
@@ -317,7 +341,24 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        _lap("side legs")
+        out["wall_s"] = round(time.perf_counter() - _T_START, 1)
+        out["wall_laps_s"] = _LAPS
+        emit(out)
+
+
+def _fill_kv_synthetic(hip, ctx_h, ptrs_bytes, seed=11):
+    """--jump: N(0, 1) bf16 rows into K / V caches (device pointers + byte counts) from one 16 MB host block copied at consecutive offsets (it repeats every 8192 rows of 1024)"""
+    import ctypes as C
+    import numpy as np
+    from koifish_amd import lib as L
+    blk = (np.random.default_rng(seed).standard_normal(8 << 20, dtype=np.float32).view(np.uint32) >> 16).astype(np.uint16)
+    for ptr, nbytes in ptrs_bytes:
+        off = 0
+        while off < nbytes:
+            n = min(blk.nbytes, nbytes - off)
+            L.check(hip.kf_h2d(ctx_h, C.c_void_p(ptr + off), blk.ctypes.data_as(C.c_void_p), C.c_size_t(n)), "kf_h2d")
+            off += n
 
 
 def _free_port():
@@ -355,19 +396,20 @@ def launch_ranks(args):
     if rc != 0 or line is None:
         sys.stderr.write(err + "\n")
         return rc if rc != 0 else 1
-    out = json.loads(line)
+    out = json.loads(line)   # rank 0's COMPACT line (its detail file: bench_detail.json)
     if args.config == "qwen3-0.6b" and not args.x_no_tp_leg:
         tp_argv = ["--gpus", str(args.gpus), "--config", "qwen3-32b", "--steps", "64", "--warmup", "16", "--tp-exchange", args.tp_exchange, "--x-backend", args.x_backend,
                    "--x-device", str(args.x_device), "--x-tp-layers", str(args.x_tp_layers), "--x-tp-vocab", str(args.x_tp_vocab)]
         rc2, line2, err2 = _run_ranks(args.gpus, tp_argv, 1500)
+        side = out.setdefault("side", {})
         if rc2 == 0 and line2:
-            d = json.loads(line2)
-            out["config4_tp"] = {"workload": d["config"]["workload"], "tokens_per_s": d["value"], "ms_per_step": d["ms_per_step"], "n_gpus": d["n_gpus"], "scaling": d["scaling"],
-                                 "tp": d["config"]["tp"], "exchange": d["config"]["exchange"], "ranks_in_process_group": d["config"].get("ranks_in_process_group"),
-                                 "decode_path": d["config"]["decode_path"], "layers": d["config"]["layers"], "roofline": d["roofline"], "steps": d["steps"], "warmup": d["warmup"]}
+            d = json.loads(line2)   # tp_main's compact line (detail: bench_detail_tp.json)
+            side["config4_tp"] = {"tokens_per_s": d["value"], "ms_per_step": d["ms_per_step"], "n_gpus": d["n_gpus"], "scaling": d["scaling"], "tp": d["config"].get("tp"),
+                                  "exchange": d["config"].get("exchange"), "ranks_in_process_group": d["config"].get("ranks_in_process_group"), "layers": d["config"].get("layers"),
+                                  "decode_path": d["config"].get("decode_path"), "frac": (d.get("roofline") or {}).get("frac"), "detail": d.get("detail")}
         else:
-            out["config4_tp"] = {"error": (err2 or "")[-400:], "returncode": rc2}
-    print(json.dumps(out))
+            side["config4_tp"] = {"error": (err2 or "")[-200:], "returncode": rc2}
+    print(json.dumps(out, separators=(",", ":")), flush=True)
     return 0
 
 
@@ -390,19 +432,20 @@ def _child(argv, timeout_s):
         return {"error": repr(e)[:300]}
 
 
-def _tp_virtual_leg(layers=16):
-    """BASELINE config 4's rank step without an 8-GPU node: the 8 ranks of TP = 8 (8 q-heads + 1 kv-head + 3200 FFN rows + 18992 vocabulary rows each) in ONE process on ONE GPU,
-    lock-step on one stream with the kernel-side exchange through local pointers -- every rank's kernels and the exchange kernels run, serialised; no xGMI.  `layers` of the 64
-    layers (stated) bound the leg's wall time; per-rank figures scale with the layer count, the head does not."""
-    d = _child(["--config", "qwen3-32b", "--tp-virtual", "8", "--tp-layers", str(layers), "--steps", "32", "--warmup", "8"], 600)
+def _tp_legs(layers=64):
+    """BASELINE config 4's rank step without an 8-GPU node, ONE child process for both forms (the shards are built once): (1) the 8 ranks of TP = 8 (8 q-heads + 1 kv-head + 3200 FFN
+    rows + 18992 vocabulary rows each) in lock-step on one stream with the kernel-side exchange through local pointers -- every rank's kernels and the exchange kernels run,
+    serialised; no xGMI; (2) the SAME ranks as the eight XCDs of ONE launch (kf_xengine_create_tp).  All 64 layers; K / V rows in front of the timed window are synthetic (--jump)."""
+    d = _child(["--config", "qwen3-32b", "--tp-virtual", "8", "--tp-xcd", "2", "--tp-layers", str(layers), "--steps", "24", "--warmup", "8", "--jump"], 600)
     if "error" in d:
-        return d
+        return d, d
     ms8 = d["ms_per_step"]   # 8 ranks serialised
-    return {"workload": d["config"]["workload"], "layers_run": layers, "layers_of_model": 64, "ms_per_step_8_ranks_serialised": ms8, "ms_per_rank_step": round(ms8 / 8, 4),
-            "bytes_per_step_per_rank": d["roofline"]["bytes_per_step_per_rank"], "achieved_GBs_per_rank_kernel_time": d["roofline"]["achieved"], "frac": d["roofline"]["frac"],
-            "decode_path": d["config"]["decode_path"], "summation_order": "canonical (library default)",
-            "note": "what ONE rank's GPU would spend per token at TP = 8 if the exchange cost nothing more than here: ms_per_rank_step x 64 / %d layers; no scaling curve has been measured on hardware" % layers,
-            "leg_wall_s": d.get("leg_wall_s")}
+    xcd = d.pop("xcd", {"error": "missing"})
+    return ({"workload": d["config"]["workload"], "layers_run": layers, "layers_of_model": 64, "ms_per_step_8_ranks_serialised": ms8, "ms_per_rank_step": round(ms8 / 8, 4),
+             "bytes_per_step_per_rank": d["roofline"]["bytes_per_step_per_rank"], "achieved_GBs_per_rank_kernel_time": d["roofline"]["achieved"], "frac": d["roofline"]["frac"],
+             "decode_path": d["config"]["decode_path"], "summation_order": "canonical (library default)",
+             "note": "what ONE rank's GPU would spend per token at TP = 8 if the exchange cost nothing more than here (ms_per_rank_step, all %d layers); no scaling curve has been measured on hardware" % layers,
+             "leg_wall_s": d.get("leg_wall_s")}, xcd)
 
 
 def side_legs(which):
@@ -419,8 +462,8 @@ def side_legs(which):
             "summation_order": d["config"].get("summation_order"), "cpu_baseline": d.get("cpu_baseline"), "engine_handoffs": d.get("engine_handoffs"),
             "decode_path": d["config"]["decode_path"], "profile": "profiles/r04_config5_sparse_1bit_kernel_stats.csv", "leg_wall_s": d.get("leg_wall_s")}
     if "qwen3_1p7b" in which:   # not a BASELINE configuration: the second model shape the persistent engine is instantiated for (round 4)
-        d = _child(["--config", "qwen3-1.7b", "--steps", "64", "--warmup", "16", "--lean", "--lean-xcd", "8"], 420)
-        e = _child(["--config", "qwen3-1.7b", "--steps", "64", "--warmup", "16", "--lean", "--engine", "0"], 420)
+        d = _child(["--config", "qwen3-1.7b", "--steps", "64", "--warmup", "16", "--lean", "--lean-xcd", "8", "--jump"], 420)
+        e = _child(["--config", "qwen3-1.7b", "--steps", "64", "--warmup", "16", "--lean", "--engine", "0", "--jump"], 420) if "qwen3_1p7b_launches" in which else {}
         out["qwen3_1p7b_shape"] = d if "error" in d else {
             "workload": "Qwen3-1.7B shape (dim 2048, 16 / 8 heads of 128, ffn 6144), 4-bit PackedQ greedy decode: %s" % d["config"]["workload"].split("seq=")[-1],
             "tokens_per_s": d["value"], "ms_per_step": d["ms_per_step"], "bytes_per_step": d["step_roofline"]["bytes_per_step"], "frac": d["step_roofline"]["frac"],
@@ -428,13 +471,14 @@ def side_legs(which):
             "per_layer_launches_tokens_per_s": e.get("value"), "per_layer_launches_ms_per_step": e.get("ms_per_step"), "xcd_replicas": d.get("xcd_replicas"), "leg_wall_s": d.get("leg_wall_s")}
     for nm, title in (("qwen3_4b", "Qwen3-4B shape (dim 2560, 32 / 8 heads of 128, ffn 9728, 36 layers)"), ("qwen3_8b", "Qwen3-8B shape (dim 4096, 32 / 8 heads of 128, ffn 12288, 36 layers)")):
         if nm in which:   # not BASELINE configurations: the GQA-4 models the reference lists as supported (cases/tutorial/history.md:4-6); round 5: served by the XCD-confined engines
-            d = _child(["--config", nm.replace("_", "-"), "--steps", "64", "--warmup", "16", "--lean", "--lean-xcd", "8"], 600)
+            d = _child(["--config", nm.replace("_", "-"), "--steps", "64", "--warmup", "16", "--lean", "--lean-xcd", "8", "--jump"], 600)
             out[nm + "_shape"] = d if "error" in d else {
                 "workload": "%s, 4-bit PackedQ greedy decode: %s" % (title, d["config"]["workload"].split("seq=")[-1]),
                 "tokens_per_s": d["value"], "ms_per_step": d["ms_per_step"], "bytes_per_step": d["step_roofline"]["bytes_per_step"], "frac": d["step_roofline"]["frac"],
                 "decode_path": d["config"]["decode_path"], "xcd_replicas": d.get("xcd_replicas"), "leg_wall_s": d.get("leg_wall_s")}
     if "config4" in which:
-        d = _child(["--config", "qwen3-32b", "--steps", "64", "--warmup", "16", "--lean", "--lean-prefill", "2047"], 600)
+        d = _child(["--config", "qwen3-32b", "--steps", "48", "--warmup", "16", "--lean", "--lean-prefill", "2047", "--jump"], 600)
+        tpv, tpx = _tp_legs()
         out["config4_one_gpu"] = d if "error" in d else {
             "workload": "Qwen3-32B 4-bit PackedQ greedy decode on ONE MI355X (the reference shards it over 8 GPUs for memory): %s" % d["config"]["workload"].split("seq=")[-1],
             "tokens_per_s": d["value"], "ms_per_step": d["ms_per_step"], "bytes_per_step": d["step_roofline"]["bytes_per_step"], "frac": d["step_roofline"]["frac"],
@@ -442,8 +486,7 @@ def side_legs(which):
             "decode_path": d["config"]["decode_path"], "profile": "profiles/r04_config4_one_gpu_kernel_stats.csv", "leg_wall_s": d.get("leg_wall_s"),
             "prefill_2047_tokens": {k: (d.get("prefill") or {}).get(k) for k in ("ms", "tokens_per_s", "first_call_ms", "resident_copy_bytes", "roofline", "error") if (d.get("prefill") or {}).get(k) is not None},
             "cpu_baseline_4_layer_slice": _child(["--leg", "config4cpu"], 420),
-            "tp8_virtual_ranks": _tp_virtual_leg(),
-            "tp8_ranks_as_xcds": _child(["--config", "qwen3-32b", "--tp-virtual", "8", "--tp-xcd", "1", "--steps", "32", "--warmup", "8"], 600),
+            "tp8_virtual_ranks": tpv, "tp8_ranks_as_xcds": tpx,
             "note": "TP = 8 over xGMI needs an 8-GPU node: bench.py --config qwen3-32b --gpus 8 (no scaling curve has been measured on hardware)"}
     return out
 
@@ -496,6 +539,7 @@ def config3_train_step():
     n_par = st.n_params()
     cpu_leg = None
     try:   # "CPU fwd of 1 layer x 1 batch row only (extrapolated; stated as such)": plain fp32 torch on this host's cores, the same operator sequence
+        torch.set_num_threads(_physical_cores())   # one thread per CORE (the default is one per hardware thread), as the other CPU legs
         xc = torch.randn(T, Cn)
         wq_, wp_, wf_, wp2_ = (torch.randn(3 * Cn, Cn) * 0.02, torch.randn(Cn, Cn) * 0.02, torch.randn(4 * Cn, Cn) * 0.02, torch.randn(Cn, 4 * Cn) * 0.02)
 
@@ -619,8 +663,9 @@ def tp_main(args, cfg, rank, world, dev):
                     L.check(nt.host.kfh_tp_set_peer(a.h, r, C.c_void_p(nt.host.kfh_tp_area(b.h))), "kfh_tp_set_peer")
             nt._hs = (C.c_void_p * R)(*[m.h for m in nt.ranks])
             drv = nt
-            if args.tp_xcd:
-                return xcd_tp_leg(nt, cfg, ctx, forced, S, K, W, shards, plan)
+            if args.tp_xcd == 1:
+                print(json.dumps(xcd_tp_leg(nt, cfg, ctx, forced, S, K, W, shards, plan, args.jump)))
+                return
         else:
             drv = TP.NativeRank(cfg, plan, rank, shards[rank], norms, dev)
         drv.set_forced(forced)
@@ -630,7 +675,14 @@ def tp_main(args, cfg, rank, world, dev):
         path = "C++ host, one hipGraph per position bucket: per layer 2 x [mat-vec whose epilogue stores fp32 partials into every rank's peer-mapped receive area, " \
                "rank-ordered sum kernel], arg-max pairs the same way; no collective call, no host round trip"
     start = S - (W + K)
-    run(0, start)
+    if args.jump and virtual:   # side leg: synthetic K / V rows in front of the window, no token-serial run-up
+        import ctypes as C
+        kvb = cfg["n_layer"] * S * plan.kvd_l * 2
+        for rk in drv.ranks:
+            _fill_kv_synthetic(rk.hip, C.c_void_p(rk.host.kfh_ctx(rk.h)), [(rk.host.kfh_kcache(rk.h), kvb), (rk.host.kfh_vcache(rk.h), kvb)])
+        drv.set_state(1, start)
+    else:
+        run(0, start)
     run(start, W)
     torch.cuda.synchronize()
     if not virtual:
@@ -659,7 +711,7 @@ def tp_main(args, cfg, rank, world, dev):
         ach = step_bytes / (ms * 1e-3) / 1e9 * (R if virtual else 1)
         out = {"metric": "tokens/sec/GPU Qwen3 4-bit prefill+decode; achieved HBM GB/s vs peak", "value": round(K / dt, 3), "unit": "tokens/s", "n_gpus": world, "steps": K,
                "warmup": W, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-               "dtype": "u4 weights (PackedQ RTN g128) x bf16 activations, fp32 accumulate; bf16 KV; fp32 partial sums exchanged", "data": "synthetic",
+               "dtype": "u4 weights x bf16, fp32 accumulate", "data": "synthetic",
                "config": {"workload": "Qwen3-32B 4-bit PackedQ greedy decode, tensor parallel TP=%d%s, context %d: timed positions %d..%d" % (
                    R, " (all ranks on ONE GPU, lock-step: a side measurement, not a scaling point)" if virtual else " over %d MI355X" % world, S, S - K, S - 1),
                    "layers": cfg["n_layer"], "vocab": cfg["vocab"], "tp": R, "exchange": args.tp_exchange if not virtual else "p2p (local pointers)", "decode_path": path, "hipgraph": use_graph,
@@ -669,16 +721,24 @@ def tp_main(args, cfg, rank, world, dev):
                             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                             "note": "per GPU; %s" % ("R ranks share this GPU, so the per-rank rate is the step's bytes x R / time" if virtual else "every GPU streams its own shard")},
                "scaling_curve": "none measured on hardware yet: this container's GPU boxes have one MI355X; the driver's N = 2, 4, 8 runs of this command produce it"}
-        print(json.dumps(out))
+        if virtual:
+            if args.tp_xcd == 2:   # the same ranks, the same shards: the one-launch form (the eight ranks as the eight XCDs) timed in this process too
+                try:
+                    out["xcd"] = xcd_tp_leg(drv, cfg, ctx, forced, S, K, W, shards, plan, args.jump)
+                except Exception as e:
+                    out["xcd"] = {"error": repr(e)[:300]}
+            print(json.dumps(out))   # a side leg's child: the parent takes what it needs
+        else:
+            emit(out, "bench_detail_tp.json")
     if not virtual and dist.is_initialized():
         dist.destroy_process_group()
 
 
-def xcd_tp_leg(nt, cfg, ctx, forced, S, K, W, shards, plan):
+def xcd_tp_leg(nt, cfg, ctx, forced, S, K, W, shards, plan, jump=False):
     """Qwen3-32B on ONE MI355X as tensor parallel over the XCDs: rank r of the TP = 8 plan on XCD r, all of them in ONE launch (koifish::XcdTP, kf_xengine_create_tp) -- the
-    o_proj / down_proj partials exchanged between the XCDs inside the kernel.  The whole sequence is decoded token by token by this engine from position 0; timed: the last K
-    positions of the context.  Bits: those of the TP = 8 rank step (tests/test_gpu_tp.py::test_tp8_ranks_as_the_eight_xcds_of_one_launch_vs_the_oracle); here the first 24 ids
-    are compared with the per-launch rank step's."""
+    o_proj / down_proj partials exchanged between the XCDs inside the kernel.  Timed: the last K positions of the context (after a token-serial run-up by this engine itself,
+    or -- jump -- on synthetic K / V rows).  Bits: those of the TP = 8 rank step (tests/test_gpu_tp.py::test_tp8_ranks_as_the_eight_xcds_of_one_launch_vs_the_oracle); here the
+    first 24 ids from position 0 are compared with the per-launch rank step's."""
     import numpy as np
     import torch
     from koifish_amd.runtime import XcdTP
@@ -688,7 +748,18 @@ def xcd_tp_leg(nt, cfg, ctx, forced, S, K, W, shards, plan):
     xt.set_forced(forced)
     xt.set_state(int(forced[0]), 0)
     start = S - (W + K)
-    xt.run_steps(start)
+    if jump:
+        import ctypes as C
+        xt.run_steps(24)
+        xt.check()
+        ids_x = xt.tokens_out(24)
+        kvb = len(nt.ranks) * cfg["n_layer"] * S * plan.kvd_l * 2
+        r0 = nt.ranks[0]
+        _fill_kv_synthetic(r0.hip, C.c_void_p(r0.host.kfh_ctx(r0.h)), [(xt.host.kfh_xtp_kcache(xt.h), kvb), (xt.host.kfh_xtp_vcache(xt.h), kvb)])
+        xt.set_forced(np.full(S, -1, dtype=np.int32))
+        xt.set_state(1, start)
+    else:
+        xt.run_steps(start)
     xt.run_steps(W)
     torch.cuda.synchronize()
     e0, e1 = ctx.event(), ctx.event()
@@ -699,7 +770,8 @@ def xcd_tp_leg(nt, cfg, ctx, forced, S, K, W, shards, plan):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     xt.check()
-    ids_x = xt.tokens_out(S)
+    if not jump:
+        ids_x = xt.tokens_out(S)
     nt.set_forced(forced)
     nt.set_state(int(forced[0]), 0)
     nt.run_steps(0, 24, True)
@@ -710,14 +782,16 @@ def xcd_tp_leg(nt, cfg, ctx, forced, S, K, W, shards, plan):
     weights = sum(x.algorithmic_bytes() for r in shards for k, x in shards[r].items() if k != (-1, 0)) + cfg["dim"] * 2
     step_bytes = weights + 2 * cfg["n_layer"] * mean_pos * cfg["n_kv"] * cfg["head_dim"] * 2
     ach = step_bytes / (ms * 1e-3) / 1e9
-    print(json.dumps({
-        "workload": "Qwen3-32B 4-bit PackedQ greedy decode on ONE MI355X, the TP = 8 ranks as the eight XCDs of one launch, context %d: timed positions %d..%d" % (S, S - K, S - 1),
+    res = {
+        "workload": "Qwen3-32B 4-bit PackedQ greedy decode on ONE MI355X, the TP = 8 ranks as the eight XCDs of one launch, context %d: timed positions %d..%d%s" % (
+            S, S - K, S - 1, "; K / V rows in front of the window synthetic" if jump else ""),
         "tokens_per_s": round(K / dt, 2), "ms_per_step": round(ms, 4), "device_ms_per_step": round(ctx.elapsed_ms(e0, e1) / K, 4), "steps": K, "layers": cfg["n_layer"], "vocab": cfg["vocab"],
         "bytes_per_step": int(step_bytes), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
         "kernel": "kf::xengine_kernel<XCfg<..., TP>> (koifish_amd/csrc/kf_xengine.hip): per layer four hand-offs inside each XCD + two exchanges between them",
         "summation_order": "canonical, tensor parallel TP = 8 (column shards as fp32 partials summed in rank order: the bits an 8-GPU node computes)",
-        "parity": {"first_24_ids_equal_per_launch_rank_step": same, "oracle": "tests/test_gpu_tp.py::test_tp8_ranks_as_the_eight_xcds_of_one_launch_vs_the_oracle (ids, logits, K / V rows bit for bit)"}}))
+        "parity": {"first_24_ids_equal_per_launch_rank_step": same, "oracle": "tests/test_gpu_tp.py::test_tp8_ranks_as_the_eight_xcds_of_one_launch_vs_the_oracle (ids, logits, K / V rows bit for bit)"}}
     xt.close()
+    return res
 
 
 def prefill_rate(m, prompt, decode_ms_per_step, reps=5, bound=None):
@@ -800,7 +874,7 @@ def concurrent_streams(cfg, layer_type, head_type, dev, S, forced, n_prompt, mea
             "note": "independent decoders, separate weight copies and HIP streams, positions %d..%d each" % (n_prompt, S_len - 1)}
 
 
-def xcd_replicas(m, cfg, forced, timed_positions, warmup, n_seq, ids_main):
+def xcd_replicas(m, cfg, forced, timed_positions, warmup, n_seq, ids_main, jump=False):
     """The chip's aggregate rate on INDEPENDENT sequences (never `value`, which stays the single-sequence rate): n_seq decoders inside one launch, one per XCD (32 workgroups
     each, every hand-off in that XCD's L2: koifish_amd/csrc/kf_xengine.hip), sharing this model's weights; own K / V cache, state, prompt and logits per sequence.  The
     reference decodes one sequence per process (GoPT.cpp:1139-1180) and scales a small model with more processes -- these are the processes, moved inside the package.
@@ -832,7 +906,14 @@ def xcd_replicas(m, cfg, forced, timed_positions, warmup, n_seq, ids_main):
                 f[:128] = np.random.default_rng(200 + s).integers(0, cfg["vocab"], size=128)
             xr.set_forced(s, f)
             xr.set_state(s, int(f[0]), 0)
-        xr.run_steps(first - warmup)     # set-up: every sequence's own history
+        if jump:   # side shapes: synthetic K / V rows in front of the window instead of a token-serial run-up (the 0.6B leg of the default run keeps the run-up: its sequence 0 is compared id for id)
+            import ctypes as C
+            kvb = cfg["n_layer"] * S * cfg["n_kv"] * cfg["head_dim"] * 2
+            _fill_kv_synthetic(m.hip, C.c_void_p(m.host.kfh_ctx(m.h)), [(f(xr.h, s), kvb) for s in range(n_seq) for f in (xr.host.kfh_xr_kcache, xr.host.kfh_xr_vcache)])
+            for s in range(n_seq):
+                xr.set_state(s, 1 + s, first - warmup)
+        else:
+            xr.run_steps(first - warmup)     # set-up: every sequence's own history
         xr.run_steps(warmup)
         torch.cuda.synchronize()
         ctx = m._ctx
@@ -846,7 +927,7 @@ def xcd_replicas(m, cfg, forced, timed_positions, warmup, n_seq, ids_main):
         xr.check()
         dev_ms = ctx.elapsed_ms(e0, e1)
         ids0 = xr.tokens_out(0, S)
-        same = bool(np.array_equal(ids0, ids_main))
+        same = None if jump else bool(np.array_equal(ids0, ids_main))
         distinct = len({tuple(xr.tokens_out(s, S)[128:160].tolist()) for s in range(n_seq)})
         tps = n_seq * K / dt
         bytes_tok = float(np.mean([m.step_bytes(p) for p in timed_positions]))
@@ -870,16 +951,21 @@ def xcd_replicas(m, cfg, forced, timed_positions, warmup, n_seq, ids_main):
                           "parity": "tests/test_gpu_xengine.py::test_prefill_then_decode_per_sequence (rows, ids, logits == the model alone doing prefill + decode)"}
         except Exception as e:
             prompt_leg = {"error": repr(e)[:200]}
-        return {"streams": n_seq, "decoders_per_xcd": 2 if n_seq > 8 else 1,
-                "layout": "32 workgroups of one launch per decoder, every hand-off inside that XCD's L2" + ("; two decoders per XCD = two workgroups per CU: one decoder's hand-off waits and K / V "
-                          "streaming run under the other's mat-vec arithmetic" if n_seq > 8 else ""),
+        # two readings, neither of them `roofline.frac`: (1) aggregate tokens/s against the rate ONE sequence's algorithmic bytes allow at the HBM peak (what north_star's 0.70 is quoted
+        # on: 0.70 <-> 7.2 k tokens/s here); (2) HBM utilisation in BATCH-AWARE bytes -- the decoders share the layer weights and the head (counted once per step of all
+        # sequences), each adds only its own K / V rows and vectors
+        kv_tok = float(np.mean([2.0 * cfg["n_layer"] * (p + 1.5) * cfg["n_kv"] * cfg["head_dim"] * 2 for p in timed_positions]))
+        bytes_batch = bytes_tok + (n_seq - 1) * kv_tok
+        return {"streams": n_seq, "batch": getattr(xr, "batch", 1), "decoders_per_xcd": getattr(xr, "decoders_per_xcd", 2 if n_seq > 8 else 1),
+                "layout": "32 workgroups of one launch per decoder, every hand-off inside that XCD's L2",
                 "tokens_per_s": round(tps, 1), "per_stream_tokens_per_s": round(tps / n_seq, 1),
                 "ms_per_step_all_streams": round(dt * 1e3 / K, 4), "device_ms_per_step": round(dev_ms / K, 4), "steps": K, "positions": "%d..%d" % (first, S - 1),
-                "bytes_per_token": int(bytes_tok), "achieved": round(bytes_tok * tps / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bytes_tok * tps / 1e9 / HBM_PEAK_GBS, 4),
+                "bytes_per_token_one_sequence": int(bytes_tok), "single_sequence_roofline_tokens_per_s": round(HBM_PEAK_GBS * 1e9 / bytes_tok, 1),
+                "frac_vs_single_sequence_roofline": round(bytes_tok * tps / 1e9 / HBM_PEAK_GBS, 4),
+                "bytes_per_step_batch_aware": int(bytes_batch), "hbm_GBs_batch": round(bytes_batch * (tps / n_seq) / 1e9, 1), "hbm_frac_batch": round(bytes_batch * (tps / n_seq) / 1e9 / HBM_PEAK_GBS, 4),
                 "aggregate_of_independent_sequences": True,
-                "note": "algorithmic bytes of ONE sequence's step x aggregate tokens/s / 8 TB/s: every decoder streams the layer weights, its own K / V rows and the head through its own XCD's L2 "
-                        "(counter traffic at the L2s = 1.04 x the sum of the sequences' algorithmic bytes: profiles/r05_pmc_xengine_16.json; the weights are shared, so the memory-side "
-                        "cache may answer part of it); never `value`",
+                "note": "frac_vs_single_sequence_roofline = ONE sequence's algorithmic bytes x aggregate tokens/s / 8 TB/s: a RATE ratio, not HBM utilisation (the decoders share the weights and the "
+                        "head: L2 / memory-side-cache traffic); hbm_frac_batch counts the shared bytes once per step of all sequences; never `value`",
                 "traffic_per_sequence_step": traffic, "traffic_source": traffic_src, "prefill_then_decode": prompt_leg,
                 "summation_order": "canonical (the only order the XCD-confined engines run)", "kernel": "kf::xengine_kernel (koifish_amd/csrc/kf_xengine.hip)",
                 "parity": {"sequence_0_ids_equal_single_sequence_engine": same, "positions_compared": int(S), "distinct_continuations": distinct,
@@ -1150,7 +1236,7 @@ def cpu_baseline(m, cfg, forced, budget_s, min_steps=64, max_steps=256, canon_st
     sp = _spread(steps[2:] if n > 8 else steps)
     om.close()
     return {"value": round(1e3 / sp["median_ms"], 3), "unit": "tokens/s", "cores": O.num_threads(), "kind": "port",
-            "sample": "%d decode steps at positions %d..%d of the same 4-bit model; AVX2 two-accumulator dot on a bf16 dequantised copy (%d MB), OpenMP rows, "
+            "sample": "%d decode steps at positions %d..%d of the same model; AVX2 two-accumulator dot on a bf16 dequantised copy (%d MB), OpenMP rows, "
                       "threads pinned one per core" % (n, p0, p0 + n - 1, max(prep, 0) // 2 ** 20), "step_ms": sp,
             "parity_pass": "%d free-running greedy steps at positions %d..%d per summation order, oracle teacher-forced on the GPU's ids; the timed order must be equal bit for bit "
                            "(ids and all %d logits of position %d)" % (n_c, p0, p0 + n_c - 1, n_logits, p0 + canon_steps),
@@ -1231,6 +1317,19 @@ def _pick_threads():
     return best
 
 
+def _physical_cores():
+    """distinct (package, core) pairs among the CPUs this process may run on: hardware threads are not cores"""
+    try:
+        allowed = _ALL_CPUS or os.sched_getaffinity(0)
+        seen = set()
+        for c in allowed:
+            base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+            seen.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+        return max(1, len(seen))
+    except Exception:
+        return max(1, (os.cpu_count() or 2) // 2)
+
+
 def _spread(step_s):
     import numpy as np
     a = np.sort(np.asarray(step_s))
@@ -1284,6 +1383,188 @@ def cpu_fp16_decode(cfg, device, n_new, n_prompt=128):
             "workload": "Qwen3-0.6B fp16 greedy decode, 128-token prompt, CPU inference path (BASELINE.json configs[0])",
             "sample": "%d-token prompt fed token by token (%.1f tokens/s), then %d greedy steps" % (n_prompt, n_prompt / t_prompt, n_new), "step_ms": sp,
             "weight_bytes_per_token": int(nbytes), "host_GBs": round(nbytes / (sp["median_ms"] * 1e-3) / 1e9, 1), "distinct_ids": len(set(ids))}
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------------------
+# The ONE line on stdout is a compact record (target <= 4 KB, hard limit 8 KB: tests/test_bench_line.py): metric / value / config / roofline / cpu_baseline and one
+# short numeric object per side leg.  Everything else this run measured -- prose notes, workloads, nested parity tables -- goes to bench_detail.json next to this
+# file (and to gpurun_out/ when that directory exists, so that it travels back from a GPU box); the line names the file.
+LINE_LIMIT = 8192
+DETAIL_FILE = "bench_detail.json"
+
+
+def _g(d, *path, default=None):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return default
+        d = d[k]
+    return d
+
+
+def _keep(d, keys):
+    """the named keys of d that exist and are not None; a leg that failed keeps only a short error"""
+    if not isinstance(d, dict):
+        return None
+    if "error" in d:
+        return {"error": str(d["error"])[:120]}
+    return {k: d[k] for k in keys if d.get(k) is not None}
+
+
+def _cpu_short(cb):
+    """a cpu_baseline object as {value, unit, cores, kind, sample (short), ids_equal [equal, compared], logits_equal [equal, compared]}"""
+    if not isinstance(cb, dict):
+        return None
+    if "error" in cb:
+        return {"error": str(cb["error"])[:120]}
+    o = {k: cb[k] for k in ("value", "unit", "cores", "kind") if k in cb}
+    if "sample" in cb:
+        o["sample"] = str(cb["sample"]).split(";")[0][:110]
+    if cb.get("greedy_ids_compared") is not None:
+        o["ids_equal"] = [cb.get("greedy_ids_equal_gpu"), cb.get("greedy_ids_compared")]
+    if cb.get("logits_compared") is not None:
+        o["logits_equal"] = [cb.get("logits_equal_bit_for_bit"), cb.get("logits_compared")]
+    if cb.get("extrapolated_step_ms") is not None:
+        o["extrapolated_step_ms"] = cb["extrapolated_step_ms"]
+    return o
+
+
+def _parity_ok(cb):
+    """True when a cpu_baseline object's timed-order parity pass found every id and every logit equal"""
+    if not isinstance(cb, dict) or cb.get("greedy_ids_compared") in (None, 0):
+        return None
+    return bool(cb.get("greedy_ids_equal_gpu") == cb.get("greedy_ids_compared") and cb.get("logits_equal_bit_for_bit") == cb.get("logits_compared"))
+
+
+def _xcd_short(x):
+    if not isinstance(x, dict):
+        return None
+    if x.get("error") or x.get("skipped"):
+        return {"error": str(x.get("error") or x.get("skipped"))[:120]}
+    o = _keep(x, ("streams", "batch", "decoders_per_xcd", "tokens_per_s", "ms_per_step_all_streams", "frac_vs_single_sequence_roofline", "hbm_frac_batch", "valu_insts_per_sequence_step", "traffic_per_sequence_step"))
+    p = x.get("parity") or {}
+    v = p.get("sequence_0_ids_equal_single_sequence_engine") if p else None
+    o["parity"] = None if v is None else bool(v)
+    return o
+
+
+def compact_line(out, detail=DETAIL_FILE):
+    """the compact record of a full result dict (what main() / tp_main() assembled)"""
+    c = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    cfg = out.get("config") or {}
+    c["config"] = {k: v for k, v in (("workload", cfg.get("workload")), ("order", "canonical: bit-exact vs the CPU oracle" if "summation_order" in cfg else None),
+                                     ("decode_path", str(cfg.get("decode_path", "")).split(":")[0][:80] or None), ("lm_head", cfg.get("lm_head")), ("replicas", cfg.get("replicas")),
+                                     ("tp", cfg.get("tp")), ("exchange", cfg.get("exchange")), ("layers", cfg.get("layers")), ("ranks_in_process_group", cfg.get("ranks_in_process_group")),
+                                     ("device_ms_per_step", cfg.get("device_ms_per_step"))) if v is not None}
+    rl = out.get("roofline")
+    if isinstance(rl, dict):
+        r = {k: rl[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_launch", "bytes_per_step_per_rank", "us_per_launch", "launches") if k in rl}
+        r.setdefault("traffic", None)
+        r["kernel"] = str(rl.get("kernel", "")).split(" = ")[0].split(" (")[0][:60]
+        if rl.get("traffic_source"):
+            r["traffic_source"] = str(rl["traffic_source"]).split(":")[0]
+        if isinstance(rl.get("run_of_steps"), dict) and "frac" in rl["run_of_steps"]:
+            r["run_of_16"] = {k: rl["run_of_steps"][k] for k in ("us_per_step", "frac") if k in rl["run_of_steps"]}
+        c["roofline"] = r
+    if isinstance(out.get("step_roofline"), dict):
+        c["step_roofline"] = {k: out["step_roofline"][k] for k in ("bytes_per_step", "achieved", "peak", "unit", "frac") if k in out["step_roofline"]}
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c["cpu_baseline"] = _cpu_short(cb)
+        fo = cb.get("parity_fast_order") or {}
+        if fo:
+            c["cpu_baseline"]["fast_order_ids_equal"] = [fo.get("greedy_ids_equal_oracle"), fo.get("greedy_ids_compared")]
+    else:
+        c["cpu_baseline"] = None
+    side = {}
+    if isinstance(out.get("fast_order_mode"), dict):
+        side["fast_order"] = _keep(out["fast_order_mode"], ("tokens_per_s", "ms_per_step"))
+    if isinstance(out.get("roofline_lm_head"), dict):
+        side["lm_head_kernel"] = _keep(out["roofline_lm_head"], ("frac", "us_per_launch", "traffic"))
+    pf = out.get("prefill")
+    if isinstance(pf, dict):
+        def one(p):
+            if not isinstance(p, dict) or "error" in p:
+                return _keep(p, ())
+            return {k: v for k, v in (("tokens", p.get("prompt_tokens")), ("ms", p.get("ms")), ("mfma_frac", _g(p, "roofline", "mfma_frac")), ("hbm_frac", _g(p, "roofline", "hbm_frac")),
+                                      ("path", p.get("path"))) if v is not None}
+        side["prefill"] = [x for x in (one(pf), one(pf.get("long_prompt")) if pf.get("long_prompt") else None) if x]
+    if isinstance(out.get("cpu_baseline_fp16"), dict):   # BASELINE config 1
+        side["config1_cpu_fp16"] = _keep(out["cpu_baseline_fp16"], ("value", "unit", "cores", "host_GBs"))
+    x = out.get("xcd_replicas")
+    if isinstance(x, dict):
+        side["xcd_replicas"] = _xcd_short(x)
+        for k in ("one_per_xcd", "two_per_xcd", "batched"):
+            if isinstance(x.get(k), dict) and side["xcd_replicas"] is not None and "error" not in side["xcd_replicas"]:
+                side["xcd_replicas"][k] = _xcd_short(x[k])
+        if isinstance(x.get("prefill_then_decode"), dict) and "error" not in side["xcd_replicas"]:
+            side["xcd_replicas"]["prompt_plus_32_tokens_per_s"] = x["prefill_then_decode"].get("prompt_plus_32_tokens_per_s")
+    t = out.get("config3_train_step")
+    if isinstance(t, dict):
+        side["config3_train_step"] = _keep(t, ("ms", "tokens_per_s", "mfma_frac", "params_updated", "one_timed_region", "host_loop"))
+        if "error" not in t:
+            side["config3_train_step"]["cpu_baseline"] = _cpu_short(t.get("cpu_baseline"))
+    t = out.get("config5_sparse_1bit")
+    if isinstance(t, dict):
+        side["config5_sparse_1bit"] = _keep(t, ("tokens_per_s", "ms_per_step", "frac"))
+        if "error" not in t:
+            side["config5_sparse_1bit"]["parity"] = _parity_ok(t.get("cpu_baseline"))
+            side["config5_sparse_1bit"]["cpu_tokens_per_s"] = _g(t, "cpu_baseline", "value")
+    for nm in ("qwen3_1p7b_shape", "qwen3_4b_shape", "qwen3_8b_shape"):
+        t = out.get(nm)
+        if isinstance(t, dict):
+            side[nm] = _keep(t, ("tokens_per_s", "frac", "per_layer_launches_tokens_per_s", "one_sequence_path"))
+            if "error" not in t and isinstance(t.get("xcd_replicas"), dict):
+                side[nm]["xcd_replicas"] = _keep(_xcd_short(t["xcd_replicas"]), ("streams", "batch", "tokens_per_s", "frac_vs_single_sequence_roofline", "hbm_frac_batch", "parity", "error"))
+    t = out.get("config4_one_gpu")
+    if isinstance(t, dict):
+        o = _keep(t, ("tokens_per_s", "ms_per_step", "frac"))
+        if "error" not in t:
+            o["prefill_2047_ms"] = _g(t, "prefill_2047_tokens", "ms")
+            o["prefill_2047_mfma_frac"] = _g(t, "prefill_2047_tokens", "roofline", "mfma_frac")
+            cs = t.get("cpu_baseline_4_layer_slice")
+            o["cpu_4_layer_slice"] = {"value": _g(cs, "value"), "cores": _g(cs, "cores"), "parity": _parity_ok(cs)} if isinstance(cs, dict) and "error" not in cs else _keep(cs, ())
+            o["tp8_rank_step_per_launch"] = _keep(t.get("tp8_virtual_ranks"), ("layers_run", "ms_per_rank_step", "frac"))
+            o["tp8_rank_engine"] = _keep(t.get("tp8_rank_engine"), ("layers_run", "ms_per_rank_step", "frac", "xcds_per_rank", "parity"))
+            xx = t.get("tp8_ranks_as_xcds")
+            o["tp8_ranks_as_xcds"] = _keep(xx, ("tokens_per_s", "ms_per_step", "frac"))
+            if isinstance(xx, dict) and "error" not in xx:
+                o["tp8_ranks_as_xcds"]["parity"] = _g(xx, "parity", "first_24_ids_equal_per_launch_rank_step")
+            o["multi_gpu"] = "no scaling curve measured on hardware"
+        side["config4_one_gpu"] = {k: v for k, v in o.items() if v is not None}
+    t = out.get("config4_tp")
+    if isinstance(t, dict):
+        side["config4_tp"] = _keep(t, ("tokens_per_s", "ms_per_step", "n_gpus", "scaling", "tp", "exchange", "ranks_in_process_group", "layers"))
+        if "error" not in t:
+            side["config4_tp"]["frac"] = _g(t, "roofline", "frac")
+    for k in ("side_legs_error", "roofline_error"):
+        if out.get(k):
+            side[k] = str(out[k])[:120]
+    if side:
+        c["side"] = side
+    if out.get("scaling_curve"):
+        c["scaling_curve"] = "none measured on hardware"
+    if out.get("wall_s") is not None:
+        c["wall_s"] = out["wall_s"]
+    c["detail"] = detail
+    return c
+
+
+def emit(out, detail=DETAIL_FILE):
+    """write the full result beside this file, print the compact line (the only thing on stdout)"""
+    txt = json.dumps(out, indent=1, allow_nan=False, default=str)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, detail), "w") as f:
+                    f.write(txt + "\n")
+        except Exception:
+            pass
+    line = json.dumps(compact_line(out, detail), allow_nan=False, separators=(",", ":"))
+    if len(line) >= LINE_LIMIT:   # never hand the driver a line it cannot parse: drop the side objects, keep the contract's fields
+        c = compact_line(out, detail)
+        c["side"] = {"dropped": "line would be %d bytes: see %s" % (len(line), detail)}
+        line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    print(line, flush=True)
 
 
 if __name__ == "__main__":
