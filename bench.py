@@ -81,7 +81,7 @@ def main():
                     "are synthetic N(0, 1) bf16 rows written once (a step's time depends on how many rows it reads, not on their values), the decode state is set to the window's first position")
     ap.add_argument("--lean", action="store_true", help="only the timed decode and step_roofline (what the side legs run in their child processes)")
     ap.add_argument("--leg", default="", choices=["", "config3", "config4cpu"], help="run ONE side leg and print its JSON (child processes of the main run)")
-    ap.add_argument("--side-legs", default="config3,config5,config4,qwen3_1p7b", help="side objects beside the line, each measured in a child process after the main measurements "
+    ap.add_argument("--side-legs", default="config3,config5,config4,qwen3_1p7b,qwen3_1p7b_launches,qwen3_4b", help="side objects beside the line, each measured in a child process after the main measurements "
                     "(never `value`): config3 = GPT2-1558M operator path of a training step (sum of separately timed forward+loss, backward, AdamW phases; no parameter update), config5 = 1-bit layers + 20 %% hot FFN rows, config4 = Qwen3-32B on ONE GPU; '' = none")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -1325,9 +1325,16 @@ def _physical_cores():
         for c in allowed:
             base = "/sys/devices/system/cpu/cpu%d/topology/" % c
             seen.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
-        return max(1, len(seen))
+        n = max(1, len(seen))
     except Exception:
-        return max(1, (os.cpu_count() or 2) // 2)
+        n = max(1, (os.cpu_count() or 2) // 2)
+    try:   # a cgroup CPU quota below the core count: more busy threads than the quota are throttled (what _pick_threads honours for the OpenMP legs)
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
 
 
 def _spread(step_s):
