@@ -468,7 +468,7 @@ int kf_engine_check(kf_ctx* ctx, kf_engine* e); /* synchronises; KF_INTERNAL_ERR
 int kf_engine_reset(kf_ctx* ctx, kf_engine* e);
 int kf_engine_destroy(kf_engine* e);
 
-/* ---- EIGHT (or SIXTEEN) independent decoders per GPU, one (two) per XCD (kf_xengine.hip; round 5).  The reference decodes ONE sequence per process (Fish::Chat, GoPT.cpp:1139-1180) and
+/* ---- EIGHT decoders per GPU, one per XCD, for up to 32 independent sequences (kf_xengine.hip; rounds 5 - 6).  The reference decodes ONE sequence per process (Fish::Chat, GoPT.cpp:1139-1180) and
  * scales a small model by running more processes; on this part a single sequence cannot keep the HBM busy (its step is a chain of hand-offs), so the replicas move
  * INSIDE the package: the 32 workgroups of XCD s are the decoder of sequence s, every hand-off stays in that XCD's L2, and the chip streams eight sequences' bytes at
  * once.  The sequences share the weights (the kf_engine_desc's layer table, the embedding, the head) and nothing else; per sequence: a K/V cache (sequence s at
@@ -476,14 +476,18 @@ int kf_engine_destroy(kf_engine* e);
  * (logits + s * vocab), the residual stream out (x_out + s * dim).  Each sequence's ids, logits and K/V rows are bit for bit those kf_engine_steps_head, the per-layer
  * calls and the oracle give for that sequence alone (canonical order only: kf_set_canonical(ctx, 0) is refused).  One workgroup per CU, 32 per XCD: the launch must have
  * the GPU to itself (bounded polls, error word, kf_xengine_check / _reset as for kf_engine).  Sequences may stand at different positions.
- * n_seq <= 8: sequence s on XCD s, one workgroup per CU.  n_seq 9 .. 16: TWO decoders per XCD (sequences x and x + 8 on XCD x), two workgroups per CU -- while one
- * decoder waits on a hand-off the hardware issues the other's arithmetic, so the aggregate rate nearly doubles (a decoder's own step gets slower).
- * Served: 4-bit PackedQ (RTN, groups of 128) layers of the Qwen3-0.6B, 1.7B, 4B and 8B shapes (and two small test shapes), bf16 embedding / head, dense FFNs; the GQA-4
- * shapes (4B, 8B) with one decoder per XCD only (n_seq <= 8; 1.7B: sixteen are served, eight are faster).  Weights are read in place and must not change while an engine built on them
- * lives; for the GQA-4 shapes (and the TP form below) the engine keeps a fused COPY of every layer's q | k | v rows in its workspace, made at create time: after a weight
- * update destroy the engine and create it again. */
+ * n_seq <= 8: sequence s on XCD s, one workgroup per CU.  More (round 6): still ONE decoder per XCD, each decoding 2 (n_seq <= 16) or 4 (n_seq <= 32) sequences -- XCD x takes
+ * sequences x, x + 8, x + 16, x + 24.  Every 4-bit block a decoder streams is unpacked ONCE (the exact bf16-stepwise dequantisation, T.cu:274, is what bounds these engines) and
+ * multiplied against the activations of all its sequences; each sequence keeps its own canonical chains, attention, K / V cache and state, so its bits do not change.
+ * Served: 4-bit PackedQ (RTN, groups of 128) layers of the Qwen3-0.6B, 1.7B, 4B and 8B shapes (and two small test shapes), bf16 embedding / head, dense FFNs; more than 8
+ * sequences for the 0.6B / 1.7B shapes (1.7B: at most 16, in the round-5 form of two decoders per XCD), more than 16 for the 0.6B shape.  Weights are read in place and must not
+ * change while an engine built on them lives; for the GQA-4 shapes (and the TP form below) the engine keeps a fused COPY of every layer's q | k | v rows in its workspace, made at
+ * create time: after a weight update destroy the engine and create it again.
+ * d_state [n_seq][4] = {token, pos, parked, status}.  parked != 0: the launch skips the sequence (the other sequences of its decoder go on).  A launch one of whose positions
+ * would lie beyond a sequence's cache rows (pos + n_steps > max_seq) skips THAT sequence and sets bit 64 of its status word -- the others decode on; nothing is shared but
+ * the weights, so one finished sequence never stops the rest (the caller clears the word when it re-aims the sequence). */
 typedef struct kf_xengine kf_xengine;
-#define KF_XENGINE_MAX_SEQ 16
+#define KF_XENGINE_MAX_SEQ 32
 size_t kf_xengine_workspace_bytes(const kf_engine_desc* desc);
 int kf_xengine_create(kf_ctx* ctx, const kf_engine_desc* desc, int n_seq, int64_t kv_seq_stride, void* workspace, size_t workspace_bytes, kf_xengine** out);
 int kf_xengine_served(kf_ctx* ctx, const kf_engine_desc* desc, char* why, size_t why_bytes); /* KF_OK or KF_ENGINE_NOT_SERVED + the reason */

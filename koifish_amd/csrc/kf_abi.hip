@@ -1214,7 +1214,7 @@ int kf_xengine_create(kf_ctx* c, const kf_engine_desc* d, int n_seq, int64_t kv_
     CHKCTX(c);
     if (!d || !ws || !out) return fail(KF_INVALID_ARGS, "kf_xengine_create: null argument");
     if (c->capturing) return fail(KF_INVALID_ARGS, "kf_xengine_create: not while capturing");
-    if (n_seq < 1 || n_seq > KF_XENGINE_MAX_SEQ) return fail(KF_INVALID_ARGS, "kf_xengine_create: n_seq %d outside 1 .. %d (one or two sequences per XCD)", n_seq, KF_XENGINE_MAX_SEQ);
+    if (n_seq < 1 || n_seq > KF_XENGINE_MAX_SEQ) return fail(KF_INVALID_ARGS, "kf_xengine_create: n_seq %d outside 1 .. %d (up to four sequences per XCD)", n_seq, KF_XENGINE_MAX_SEQ);
     kf::XEngineHost* h = nullptr;
     const char* why = "";
     const int rc = kf::xengine_build(d, n_seq, (long long)kv_seq_stride, ws, ws_bytes, c->stream, &h, &why);
@@ -1284,7 +1284,7 @@ int kf_xengine_check(kf_ctx* c, kf_xengine* e) {
     int err = 0;
     const int rc = kf::xengine_error_word(e->h, c->stream, &err);
     if (rc != KF_OK) return fail(rc, "kf_xengine_check: HIP failure");
-    if (err) return fail(KF_INTERNAL_ERR, "kf_xengine: error word 0x%x (8: an XCD did not get 32 workgroups; 64: a position beyond the cache rows; others: a hand-off poll timed out -- the launch was not fully resident)", err);
+    if (err) return fail(KF_INTERNAL_ERR, "kf_xengine: error word 0x%x (8: an XCD did not get 32 workgroups; 64: a position beyond the cache rows (TP form); others: a hand-off poll timed out -- the launch was not fully resident)", err);
     return KF_OK;
 }
 int kf_xengine_reset(kf_ctx* c, kf_xengine* e) {

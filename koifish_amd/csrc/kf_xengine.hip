@@ -37,7 +37,7 @@ namespace kf {
 constexpr int XE_NWG = 32;   /* workgroups of one decoder = the CUs of one XCD */
 constexpr int XE_NXCD = 8;
 constexpr int XE_GRID = XE_NWG * XE_NXCD; /* workgroups of a launch with ONE decoder per XCD; two decoders per XCD (WPC = 2): twice that, two workgroups per CU */
-constexpr int XE_MAXSEQ = 16;
+constexpr int XE_MAXSEQ = 32; /* 8 XCDs x up to 4 sequences per decoder (XCfg::NB) or 2 decoders (XCfg::WPC) */
 
 struct XArgs {
     const EngLayer* layers; /* kcache / vcache = sequence 0's; sequence s at + s * kv_seq_stride elements */
@@ -60,7 +60,7 @@ struct XArgs {
     int vocab, pick; /* pick: the greedy pick and the state update run inside (needed for n_steps > 1) */
     char* loc;       /* XCD-local exchange areas, loc_stride bytes each */
     size_t loc_stride;
-    int* ws;         /* [0] epoch, [1] error word, [16 + 32 x] ticket of XCD x, [17 + 32 x] its workgroups that have left */
+    int* ws;         /* [0] (unused since round 6: the epoch is XArgs::epoch0), [1] error word, [16 + 32 x] ticket of XCD x, [17 + 32 x] its workgroups that have left */
     unsigned long long* dbg; /* diagnostic instantiation: [step][layer][16] stamps of (sequence dbg_seq, workgroup rank dbg_wg) */
     int dbg_seq, dbg_wg, dbg_steps;
     int deal_wl;    /* weight (x 8) of the compute waves that share the poller's SIMD: see xe_deal */
@@ -72,6 +72,7 @@ struct XArgs {
     unsigned long long* tp_recv; /* [rank][2][source rank][DIM] granules {fp32 partial | generation}: o_proj exchanges in buffer 0, down_proj exchanges in buffer 1 */
     unsigned long long* tp_best; /* [rank][source rank] {global row | tag16, bf16 value} */
     int stagger_us; /* two decoders per XCD: microseconds the second one starts behind the first */
+    int epoch0;     /* the generation of the launch's first step (the host counts: + n_steps per launch; 1 after a reset) */
 };
 
 // error word bits: 1 a hand-off vector (x, ao, xB, act, head x), 2 q|k|v, 4 partials, 8 workgroups per XCD != 32, 16 pick, 32 token granule, 64 position beyond the cache, 2048 a TP exchange
@@ -83,8 +84,14 @@ constexpr int xe_p1_wgs(int dim, int epb, int qd, int kvd) { /* the most workgro
     }
     return 0;
 }
-template <int FMT_, int GQ_, int HD_, int NWV_, int DIM_, int QD_, int KVD_, int FFN_, int DEPTH_, bool DBG_, int WPC_ = 1, int AU_ = 2, bool TP_ = false>
+template <int FMT_, int GQ_, int HD_, int NWV_, int DIM_, int QD_, int KVD_, int FFN_, int DEPTH_, bool DBG_, int WPC_ = 1, int AU_ = 2, bool TP_ = false, int NB_ = 1>
 struct XCfg {
+    // NB: sequences per decoder (round 6).  The decoders of a launch unpack the SAME 4-bit blocks; with NB > 1 a decoder multiplies every unpacked block against the
+    // activations of NB sequences (xcc + 8 b, b = 0 .. NB - 1) staged side by side in LDS -- the exact bf16-stepwise unpack (7 vector instructions per weight with its
+    // bookkeeping) is paid once, each sequence adds its half-instruction per weight (v_pk_fma_f32) and keeps its own canonical chain, lane tree and rounding: every id, logit
+    // and K / V row of every sequence stays bit for bit what the sequence alone produces.  Hand-offs carry NB vectors (one wait, NB sweeps), the attention, the K / V caches
+    // and the decode state stay per sequence, the head's bf16 rows are read once for the NB sequences.
+    static constexpr int NB = NB_;
     // TP: the eight XCDs are the eight ranks of ONE sequence (QD_, KVD_, FFN_: a rank's shard widths).  o_proj / down_proj are column shards: their rows leave as fp32
     // partials into every rank's receive area (the protocol of kf_tp.hip, inside the launch), each workgroup sums its 1 / 32 of the rows over the ranks in rank order,
     // adds the residual and publishes the slice inside its XCD -- from there on the hand-off is the local one.
@@ -151,6 +158,25 @@ struct XCfg {
                                   SH::P6::nBlk == SH::P6::iters * SH::P6::LPR;
     static constexpr int maxR = (SH::P1::R > SH::P5::R ? SH::P1::R : SH::P5::R) > (SH::P4::R > SH::P6::R ? SH::P4::R : SH::P6::R) ? (SH::P1::R > SH::P5::R ? SH::P1::R : SH::P5::R)
                                                                                                                                       : (SH::P4::R > SH::P6::R ? SH::P4::R : SH::P6::R);
+    static_assert(NB_ >= 1 && NB_ <= 4, "sequences per decoder");
+    static_assert(NB_ == 1 || (!TP_ && WPC_ == 1 && !COOP && !FUSED && NG == 1 && FMT_ == FMT_Q4P && DIM_ / 256 <= 12 && FFNP / 256 <= 24 && !COMB_IN_XS1),
+                  "the batched form: plain (non-TP, one workgroup per CU) decoders of the shapes whose vectors are staged by the poller in one sweep");
+};
+// LDS of a workgroup: NB per-sequence blocks (activations, raw residuals, the attention's head staging, the rows of the phase being published, head maxima), then what the
+// sequences share in turn (the waves' attention sums, the merge scratch, counters), then the layer table
+template <class C>
+struct XLay {
+    static constexpr int hd = C::HD, GQ = C::GQW, NCW = C::NCW;
+    static constexpr int maxK = C::DIM > C::QD ? (C::DIM > C::FFN ? C::DIM : C::FFN) : (C::QD > C::FFN ? C::QD : C::FFN);
+    static constexpr int xs_bytes = (maxK * 4 + 15) & ~15, xr_bytes = (C::DIM * 2 + 15) & ~15;
+    static constexpr size_t o_attn = (size_t)2 * xs_bytes + 2 * xr_bytes;
+    static constexpr size_t o_outb = (o_attn + sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + 15) & ~(size_t)15;
+    static constexpr size_t o_wmax = o_outb + 4 * (size_t)((C::maxR + 63) & ~63);
+    static constexpr size_t seq_bytes = (o_wmax + 4 * 2 * 16 + 15) & ~(size_t)15;
+    static constexpr size_t o_comb = (size_t)C::NB * seq_bytes;
+    static constexpr size_t o_msc = o_comb + (C::COMB_IN_XS1 ? 0 : sizeof(double) * (size_t)NCW * GQ * (hd + 2));
+    static constexpr size_t o_cnt = o_msc + sizeof(double) * ((size_t)C::ME * C::SPK) + 4 * 64 + 4 * 128;
+    static constexpr size_t fixed_bytes = (o_cnt + 64 + 15) & ~(size_t)15;
 };
 constexpr size_t xe_loc_stride(int loc_dw) { return ((size_t)loc_dw * 4 + 4095) & ~(size_t)4095; }
 
@@ -171,11 +197,27 @@ struct XLds {
     int* pub; /* [4] pieces of q | k | v, xB, act, x this workgroup has published since the launch began: its poller sleeps until then instead of sweeping (a spinning poller takes
                  issue slots from the two compute waves of its SIMD, which then finish last and hold the whole decoder's hand-off back) */
 };
+// the LDS pointers of sub-sequence b of a decoder (XCfg::NB > 1): the per-sequence block b, the shared parts as they are
+template <class C>
+__device__ __forceinline__ XLds xe_lds_view(const XLds& L, int b) {
+    if constexpr (C::NB == 1) {
+        return L;
+    } else {
+        const size_t sh = (size_t)b * XLay<C>::seq_bytes;
+        auto mv = [&](auto* q) { return reinterpret_cast<decltype(q)>(reinterpret_cast<unsigned char*>(q) + sh); };
+        XLds V = L;
+        V.xs[0] = mv(L.xs[0]), V.xs[1] = mv(L.xs[1]), V.xrawA = mv(L.xrawA), V.xrawB = mv(L.xrawB);
+        V.qraw = mv(L.qraw), V.kraw = mv(L.kraw), V.vraw = mv(L.vraw), V.qb = mv(L.qb), V.knew = mv(L.knew);
+        V.wmax = mv(L.wmax), V.outb = mv(L.outb);
+        return V;
+    }
+}
 struct XSeq { /* this workgroup's place in its decoder, and the step's slice */
     int seq, r, step; /* seq: the decoder (its exchange area, its XCD); TP: = the rank */
     int sq;           /* the sequence whose state / forced ids / ids out this decoder follows (TP: 0) */
     int pos, len, kvh, split, h0, t0, t1, me0;
     bool empty, own_new, stamp, grp0; /* grp0: the first head group of its kv-head (it writes the new K / V row) */
+    bool act;                         /* the sequence exists, is not parked and stands inside its cache: an inactive one touches nothing outside its own exchange area */
     int j1, s1, M1, q_out0;
     long long kv_off; /* elements: this sequence's K/V cache behind sequence 0's */
 };
@@ -306,17 +348,56 @@ __device__ __forceinline__ f32x2_t xe_block(u32x4 w, uint16_t st16, uint16_t ze1
     }
     return acc;
 }
+// The same block against the activations of NB sequences (XCfg::NB > 1): the group's table and the block's 32 weights are formed ONCE (the byte-plane lookups and the fp32
+// assembly of perm_fma_dword), then every sequence's chain pair takes its sixteen v_pk_fma_f32 -- element after element of the block, as xe_block does for one sequence
+template <int XS, int NB, size_t SEQB>
+__device__ __forceinline__ void xe_block_nb(u32x4 w, uint16_t st16, uint16_t ze16, float qb, const f32x4* xc0, int lane, f32x2_t (&acc)[NB]) {
+    const float step = bf2f(st16), zero = bf2f(ze16), nb = -(qb * step);
+    const uint32_t D[4] = {w.w, w.z, w.y, w.x};
+    const float q0 = (float)((lane & 3) << 2);
+    uint32_t r = pack_bf16x2(fmaf(q0, step, nb), fmaf(q0 + 1.0f, step, nb));
+    const uint32_t P0 = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
+    r = pack_bf16x2(fmaf(q0 + 2.0f, step, nb), fmaf(q0 + 3.0f, step, nb));
+    const uint32_t P1 = pack_bf16x2(bf_lo(r) - zero, bf_hi(r) - zero);
+    const uint32_t tlm = __builtin_amdgcn_perm(P1, P0, 0x06040200u), thm = __builtin_amdgcn_perm(P1, P0, 0x07050301u);
+    PermLut t;
+    t.tl[0] = quad_bcast<0>(tlm), t.tl[1] = quad_bcast<1>(tlm), t.tl[2] = quad_bcast<2>(tlm), t.tl[3] = quad_bcast<3>(tlm);
+    t.th[0] = quad_bcast<0>(thm), t.th[1] = quad_bcast<1>(thm), t.th[2] = quad_bcast<2>(thm), t.th[3] = quad_bcast<3>(thm);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint32_t le, he, lo, ho;
+        perm_lookup4(D[i] >> 4, t, le, he);
+        perm_lookup4(D[i], t, lo, ho);
+        const f32x2_t w0{__uint_as_float(__builtin_amdgcn_perm(he, le, 0x07030c0cu)), __uint_as_float(__builtin_amdgcn_perm(ho, lo, 0x07030c0cu))}; /* elements 0, 1 of the dword */
+        const f32x2_t w1{__uint_as_float(__builtin_amdgcn_perm(he, le, 0x06020c0cu)), __uint_as_float(__builtin_amdgcn_perm(ho, lo, 0x06020c0cu))}; /* 2, 3 */
+        const f32x2_t w2{__uint_as_float(__builtin_amdgcn_perm(he, le, 0x05010c0cu)), __uint_as_float(__builtin_amdgcn_perm(ho, lo, 0x05010c0cu))}; /* 4, 5 */
+        const f32x2_t w3{__uint_as_float(__builtin_amdgcn_perm(he, le, 0x04000c0cu)), __uint_as_float(__builtin_amdgcn_perm(ho, lo, 0x04000c0cu))}; /* 6, 7 */
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const f32x4* xc = reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(xc0) + (size_t)b * SEQB);
+            const f32x4 X0 = xc[(2 * i) * XS], X1 = xc[(2 * i + 1) * XS];
+            f32x2_t a = acc[b];
+            a = pk_fma(w0, f32x2_t{X0.x, X0.y}, a);
+            a = pk_fma(w1, f32x2_t{X0.z, X0.w}, a);
+            a = pk_fma(w2, f32x2_t{X1.x, X1.y}, a);
+            a = pk_fma(w3, f32x2_t{X1.z, X1.w}, a);
+            acc[b] = a;
+        }
+    }
+}
 // One mat-vec phase of a compute wave: ONE copy of this loop serves every phase.  The ring holds the wave's first min(D, n) entries on entry (xe_fill / the previous phase's
 // last round); entry e + D is requested when entry e has been multiplied, and in the last round slot d takes entry d of the NEXT phase NX (nx_on; they do not depend on the
 // hand-off that separates the phases).  epi(row, v, v2) runs in the lane that owns a finished row (LDS only: no memory operation inside the loop but the refills).
 template <class C, int D, typename Epi>
 __device__ __forceinline__ void xe_mv_run(const XPhase& P, const XPhase& NX, bool nx_on, int cw, int lane, const u32x4* xs, XRing<D>& R, Epi&& epi) {
-    constexpr int NCW = C::NCW, XS = C::XS;
+    constexpr int NCW = C::NCW, XS = C::XS, NB = C::NB;
     static_assert((D % 2) == 0, "gate | up entries come in pairs");
     const int n = P.n, n_pad = n > 0 ? (n + D - 1) / D * D : D; /* at least one round: the last round is where the next phase's entries are requested */
-    const f32x4* xf = reinterpret_cast<const f32x4*>(xs);
+    const f32x4* xf = reinterpret_cast<const f32x4*>(xs); /* sequence 0's activations; sequence b's lie XLay::seq_bytes x b behind them */
     const XLaneGeo G = xe_lane_geo(P, lane), GN = xe_lane_geo(NX, lane);
-    f32x2_t acc{0.f, 0.f}, acc2{0.f, 0.f};
+    f32x2_t acc[NB], acc2[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) acc[b] = f32x2_t{0.f, 0.f}, acc2[b] = f32x2_t{0.f, 0.f};
     for (int e0 = 0; e0 < n_pad; e0 += D) {
         const bool last = e0 + D >= n_pad;
 #pragma unroll
@@ -327,27 +408,45 @@ __device__ __forceinline__ void xe_mv_run(const XPhase& P, const XPhase& NX, boo
                 const int sl = k / P.iters, it = k - sl * P.iters;
                 const int row = ((P.s0 + sl * P.sl_b) << P.rps_log2) + G.sub, colr = (it << P.lpr_log2) + G.ll;
                 const bool second = P.paired && (d & 1);
-                if (it == 0) {
-                    if (second) acc2 = f32x2_t{0.f, 0.f};
-                    else acc = f32x2_t{0.f, 0.f};
-                }
-                const f32x2_t in = second ? acc2 : acc;
                 const float qb_a = P.qb, qb_b = P.qb2;
-                f32x2_t o;
-                if constexpr (C::EXACT) { /* whole rows, whole iterations: nothing to mask */
-                    o = xe_block<C::FMT, XS, (C::WPC > 1)>(R.w[d], R.st[d], R.ze[d], second ? qb_b : qb_a, xf + colr, lane, in);
-                } else {
-                    const bool ok = row < P.Mj && colr < P.nBlk;
-                    const int col = colr < P.nBlk ? colr : P.nBlk - 1;
-                    o = acc_pick(ok, xe_block<C::FMT, XS, (C::WPC > 1)>(R.w[d], R.st[d], R.ze[d], second ? qb_b : qb_a, xf + col, lane, in), in);
+                if constexpr (NB == 1) {
+                    if (it == 0) {
+                        if (second) acc2[0] = f32x2_t{0.f, 0.f};
+                        else acc[0] = f32x2_t{0.f, 0.f};
+                    }
+                    const f32x2_t in = second ? acc2[0] : acc[0];
+                    f32x2_t o;
+                    if constexpr (C::EXACT) { /* whole rows, whole iterations: nothing to mask */
+                        o = xe_block<C::FMT, XS, (C::WPC > 1)>(R.w[d], R.st[d], R.ze[d], second ? qb_b : qb_a, xf + colr, lane, in);
+                    } else {
+                        const bool ok = row < P.Mj && colr < P.nBlk;
+                        const int col = colr < P.nBlk ? colr : P.nBlk - 1;
+                        o = acc_pick(ok, xe_block<C::FMT, XS, (C::WPC > 1)>(R.w[d], R.st[d], R.ze[d], second ? qb_b : qb_a, xf + col, lane, in), in);
+                    }
+                    if (second) acc2[0] = o;
+                    else acc[0] = o;
+                } else { /* NB sequences against one unpacked block */
+                    f32x2_t in[NB], o[NB];
+#pragma unroll
+                    for (int b = 0; b < NB; b++) in[b] = it == 0 ? f32x2_t{0.f, 0.f} : (second ? acc2[b] : acc[b]), o[b] = in[b];
+                    const bool ok = C::EXACT || (row < P.Mj && colr < P.nBlk);
+                    const int col = (C::EXACT || colr < P.nBlk) ? colr : P.nBlk - 1;
+                    xe_block_nb<XS, NB, XLay<C>::seq_bytes>(R.w[d], R.st[d], R.ze[d], second ? qb_b : qb_a, xf + col, lane, o);
+#pragma unroll
+                    for (int b = 0; b < NB; b++) {
+                        const f32x2_t r = C::EXACT ? o[b] : acc_pick(ok, o[b], in[b]);
+                        if (second) acc2[b] = r;
+                        else acc[b] = r;
+                    }
                 }
-                if (second) acc2 = o;
-                else acc = o;
                 if (it == P.iters - 1 && (!P.paired || second)) {
-                    const float v = group_sum(acc_join(acc), P.lpr_log2);
-                    float v2 = 0.f;
-                    if (P.paired) v2 = group_sum(acc_join(acc2), P.lpr_log2);
-                    if (G.ll == 0 && (C::EXACT || row < P.Mj)) epi(row, v, v2);
+#pragma unroll
+                    for (int b = 0; b < NB; b++) {
+                        const float v = group_sum(acc_join(acc[b]), P.lpr_log2);
+                        float v2 = 0.f;
+                        if (P.paired) v2 = group_sum(acc_join(acc2[b]), P.lpr_log2);
+                        if (G.ll == 0 && (C::EXACT || row < P.Mj)) epi(b, row, v, v2);
+                    }
                 }
             }
             // refill slot d (always ONE set of loads: see xe_issue)
@@ -361,8 +460,11 @@ __device__ __forceinline__ void xe_mv_run(const XPhase& P, const XPhase& NX, boo
 // push (TP, o_proj / down_proj): the rows are fp32 partials; they go as {fp32 | generation} granules into this rank's slot of EVERY rank's receive area (push: rank 0's
 // slot for these rows, push_stride granules from one rank's area to the next), agent-scope stores -- the areas are read from the other XCDs
 // pad: zero granules behind the piece (the SwiGLU vector of a rank is swept in whole 1 KiB units)
+// NB > 1: the pieces of the decoder's NB sequences, one after the other -- rows in L.outb + b * LBS bytes, destination dst + b * dst_bs dwords (plain + b * plain_bs elements);
+// actm: bit b set = sequence b is active (an inactive one publishes nothing)
+template <int NB = 1, size_t LBS = 0>
 __device__ __forceinline__ void xe_publish(const XLds& L, int phase, uint32_t tag, uint32_t* dst, int nrows, int nwaves, int lane, uint16_t* plain = nullptr,
-                                           unsigned long long* push = nullptr, size_t push_stride = 0, uint32_t tagx = 0, int pad = 0) {
+                                           unsigned long long* push = nullptr, size_t push_stride = 0, uint32_t tagx = 0, int pad = 0, size_t dst_bs = 0, size_t plain_bs = 0, uint32_t actm = 1u) {
     int old = 0;
     if (lane == 0) old = __hip_atomic_fetch_add(L.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     old = __builtin_amdgcn_readfirstlane(old);
@@ -377,21 +479,28 @@ __device__ __forceinline__ void xe_publish(const XLds& L, int phase, uint32_t ta
         if (lane == 0) __hip_atomic_fetch_add(L.pub + phase, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return;
     }
-    for (int i = lane; i < pad; i += 64) dst[nrows + i] = tag << 16;
-    // one descriptor for the piece, the lane's 16 bytes as an offset: no 64-bit per-lane address (it was spilled, and its reload in front of the store drained the next phase's
-    // weight loads in flight)
-    const __amdgpu_buffer_rsrc_t rd = eng_rsrc(dst, (uint32_t)nrows * 4u), rp = eng_rsrc(plain ? (const void*)plain : (const void*)dst, plain ? (uint32_t)nrows * 2u : 0u);
-    if (phase == 2) { /* gate | up: the rows were left as bf16 pairs {gate, up}: SwiGLU (CU_swiglu_v0) and the tag now */
-        for (int i = lane; i < nrows; i += 64) {
-            const uint32_t pr = L.outb[i];
-            const float gt = bf_lo(pr), up = bf_hi(pr);
-            L.outb[i] = (tag << 16) | (uint32_t)f2bf((gt * up) / (1.0f + kf_expf(-gt)));
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        if (NB > 1 && !((actm >> b) & 1u)) continue;
+        uint32_t* const ob = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(L.outb) + (size_t)b * LBS);
+        uint32_t* const db = dst + (size_t)b * dst_bs;
+        uint16_t* const pb = plain ? plain + (size_t)b * plain_bs : nullptr;
+        for (int i = lane; i < pad; i += 64) db[nrows + i] = tag << 16;
+        // one descriptor for the piece, the lane's 16 bytes as an offset: no 64-bit per-lane address (it was spilled, and its reload in front of the store drained the next phase's
+        // weight loads in flight)
+        const __amdgpu_buffer_rsrc_t rd = eng_rsrc(db, (uint32_t)nrows * 4u), rp = eng_rsrc(pb ? (const void*)pb : (const void*)db, pb ? (uint32_t)nrows * 2u : 0u);
+        if (phase == 2) { /* gate | up: the rows were left as bf16 pairs {gate, up}: SwiGLU (CU_swiglu_v0) and the tag now */
+            for (int i = lane; i < nrows; i += 64) {
+                const uint32_t pr = ob[i];
+                const float gt = bf_lo(pr), up = bf_hi(pr);
+                ob[i] = (tag << 16) | (uint32_t)f2bf((gt * up) / (1.0f + kf_expf(-gt)));
+            }
         }
-    }
-    for (int i = 4 * lane; i < nrows; i += 256) {
-        const u32x4 g = *reinterpret_cast<const u32x4*>(L.outb + i);
-        __builtin_amdgcn_raw_buffer_store_b128(g, rd, i * 4, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2{(g.x & 0xffffu) | (g.y << 16), (g.z & 0xffffu) | (g.w << 16)}, rp, i * 2, 0, 0); /* out of range (dropped) without `plain` */
+        for (int i = 4 * lane; i < nrows; i += 256) {
+            const u32x4 g = *reinterpret_cast<const u32x4*>(ob + i);
+            __builtin_amdgcn_raw_buffer_store_b128(g, rd, i * 4, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{(g.x & 0xffffu) | (g.y << 16), (g.z & 0xffffu) | (g.w << 16)}, rp, i * 2, 0, 0); /* out of range (dropped) without `plain` */
+        }
     }
     if (lane == 0) __hip_atomic_fetch_add(L.pub + phase, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -445,7 +554,7 @@ struct XAttn {
     static constexpr int U = C::AU;
     u32x4 kk[2][U], vv[2][U];
     uint16_t nw0, nw1;
-    float rc, rs;
+    float rc[C::NB], rs[C::NB]; /* the lane's RoPE pair at the position of sub-sequence b */
 };
 template <class C>
 __device__ __forceinline__ void xe_attn_issue(const XArgs& a, const EngLayer& ly, const XSeq& S, int cw, int lane, XAttn<C>& T, int b, int buf) {
@@ -468,8 +577,10 @@ __device__ __forceinline__ void xe_attn_issue(const XArgs& a, const EngLayer& ly
     }
 }
 // compute waves only (the poller meets the three barriers in xe_poller_main).  p4_fill: requests the first o_proj blocks, called when the last batch's tiles are in registers
+// bi: the sub-sequence (XCfg::NB > 1: called once per sequence of the decoder, S and L being that sequence's views); p4_fill runs behind the key loop (the last sequence: the
+// first o_proj blocks; before that: the next sequence's first tiles)
 template <class C, typename Fill>
-__device__ __forceinline__ void xe_attn_phase(const XArgs& a, const XLds& L, const XSeq& S, const EngLayer& ly, uint32_t gen, int cw, int lane, XAttn<C>& T, int l, Fill&& p4_fill) {
+__device__ __forceinline__ void xe_attn_phase(const XArgs& a, const XLds& L, const XSeq& S, const EngLayer& ly, uint32_t gen, int cw, int lane, XAttn<C>& T, int l, Fill&& p4_fill, int bi = 0) {
     constexpr int GQ = C::GQW /* the heads of this workgroup's group */, hd = C::HD, hd_log2 = C::HD == 128 ? 7 : 6, LPK = hd >> 3, KPW = 64 / LPK, lpk_log2 = hd_log2 - 3, NWA = C::NCW, U = XAttn<C>::U;
     constexpr int NQ = (GQ + NWA - 1) / NWA;
     const int tid = (cw << 6) | lane, pos = S.pos, t1 = S.t1;
@@ -487,14 +598,14 @@ __device__ __forceinline__ void xe_attn_phase(const XArgs& a, const XLds& L, con
                 HeadRaw r;
                 r.x0 = L.qraw[hq * hd + j], r.x1 = L.qraw[hq * hd + j + half];
                 r.w0 = qnorm ? T.nw0 : r.x0, r.w1 = qnorm ? T.nw1 : r.x1;
-                prep_head_cs(r, qnorm, rope, T.rc, T.rs, hd, a.qk_eps, L.qb + hq * hd, nullptr, lane);
+                prep_head_cs(r, qnorm, rope, T.rc[bi], T.rs[bi], hd, a.qk_eps, L.qb + hq * hd, nullptr, lane);
             }
         }
         if (S.own_new && cw == (GQ % NWA)) {
             HeadRaw r;
             r.x0 = L.kraw[j], r.x1 = L.kraw[j + half];
             r.w0 = ly.norm_k ? T.nw0 : r.x0, r.w1 = ly.norm_k ? T.nw1 : r.x1;
-            prep_head_cs(r, ly.norm_k != nullptr, rope, T.rc, T.rs, hd, a.qk_eps, L.knew, nullptr, lane);
+            prep_head_cs(r, ly.norm_k != nullptr, rope, T.rc[bi], T.rs[bi], hd, a.qk_eps, L.knew, nullptr, lane);
         }
     }
     __syncthreads(); /* heads prepared */
@@ -544,7 +655,7 @@ __device__ __forceinline__ void xe_attn_phase(const XArgs& a, const XLds& L, con
     constexpr int PSD = hd + 2, ME = C::ME, SPK = C::SPK;
     unsigned long long* const pbase = reinterpret_cast<unsigned long long*>(reinterpret_cast<uint32_t*>(a.loc + (size_t)S.seq * a.loc_stride) + C::part);
     const unsigned long long gg = (unsigned long long)gen << 32;
-    for (int i = tid; i < GQ * hd; i += NWA * 64) {
+    for (int i = tid; i < (S.act ? GQ * hd : 0); i += NWA * 64) {
         const int hq = i >> hd_log2, d = i & (hd - 1);
         double o = 0.0, Ls = 0.0;
         float ms = -__builtin_inff();
@@ -635,19 +746,21 @@ __device__ __forceinline__ void xe_coop_norm_stage(const XArgs& a, const XLds& L
     }
 }
 
-// ---- the poller wave of a workgroup
+// ---- the poller wave of a workgroup.  SS: the decoder's NB sequences (XCfg::NB; SS[0] carries the workgroup's place); per hand-off the vectors of all of them are swept
+// and staged, one after the other, into their own LDS blocks
 template <class C>
-__device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, const XSeq& S, int epoch, int lane) {
+__device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L0, const XSeq (&SS)[C::NB], int epoch, int lane) {
     using SH = typename C::SH;
     using P1 = typename SH::P1;
     using P4 = typename SH::P4;
     using P5 = typename SH::P5;
     using P6 = typename SH::P6;
-    constexpr int GQ = C::GQW, hd = C::HD, XCH = C::XCH;
+    constexpr int GQ = C::GQW, hd = C::HD, XCH = C::XCH, NB = C::NB;
     constexpr int ND = C::DIM / 256, NQD = C::QD / 256, NF = C::FFNP / 256;
     static_assert(C::DIM % 256 == 0 && C::QD % 256 == 0 && (C::TP || C::FFN % 256 == 0), "hand-off vectors in 1 KiB pieces");
     constexpr int RT = C::DIM / XE_NWG; /* TP: the rows of an exchange this workgroup sums */
-    uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)S.seq * a.loc_stride);
+    const XSeq& S = SS[0];
+    const XLds& L = L0;
     bool dead = false;
     for (int l = 0; l < a.n_layer; l++) {
         const EngLayer& ly = L.lay[l];
@@ -655,58 +768,72 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, co
         XE_STAMP(0);
         if (C::DBG && !C::TP && S.stamp && lane == 0) a.dbg[((size_t)S.step * a.n_layer + l) * 64 + 31] = __builtin_amdgcn_s_memtime(); /* the shader clock beside the 100 MHz stamp: the frequency the CU really runs at */
         // P1's x (P4 adds it as the residual)
-        if (l == 0) {
-            int tok = a.d_state[S.sq * 4];
-            if (S.step > 0) { /* the id workgroup 0 of this decoder picked at the end of the previous step: {id, epoch of this step} */
-                const __amdgpu_buffer_rsrc_t rt = eng_rsrc(loc + C::tokg, 8u);
-                for (int spins = 0;; spins++) {
-                    const u32x2 g = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rt, 0, 0, 16 /* sc1 */));
-                    if (g.y == (uint32_t)epoch) {
-                        tok = (int)g.x;
-                        break;
-                    }
-                    if (dead || spins > ENG_SPIN_MAX) {
-                        if (!dead && lane == 0) atomicOr(a.ws + 1, 32);
-                        dead = true;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            if (a.d_forced) {
-                const int f = a.d_forced[(size_t)S.sq * a.forced_stride + S.pos];
-                if (f >= 0) tok = f;
-            }
-            if (tok < 0 || tok >= a.emb_rows) tok = 0;
-            if constexpr (ND > 12) eng_poll_stage_norm_long<XCH, ND, C::XS, true, true, 8>(nullptr, a.emb + (size_t)tok * C::DIM, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead);
-            else eng_poll_stage<XCH, ND, C::XS, true, true, true>(nullptr, a.emb + (size_t)tok * C::DIM, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, nullptr, nullptr, 0, 0);
-        } else {
+        if (l > 0) {
             eng_wait_pub(L.pub + 3, S.step * a.n_layer + l, 0, dead);
             XE_STAMP(12);
-            if constexpr (C::TP) /* the down_proj exchange of the layer before: this workgroup's rows summed over the ranks + the residual xB -> the local x area */
-                xe_tp_reduce<C>(a, S, 1, 2u * (gen - 1u) + 2u, L.xrawB, loc + C::xA + S.r * RT, tag, nullptr, lane, dead);
-            if constexpr (C::TP) XE_STAMP(31); /* (TP: the slot of the shader-clock stamp) this workgroup's rows of the down_proj exchange are summed */
-            if constexpr (C::COOP) xe_coop_norm_stage<C>(a, L, loc + C::xA, tag, ly.norm_in, L.xs[0], L.xrawA, C::NWV - 1, lane, &dead);
-            else if constexpr (ND > 12) eng_poll_stage_norm_long<XCH, ND, C::XS, false, true, 8>(loc + C::xA, nullptr, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead);
-            else eng_poll_stage<XCH, ND, C::XS, true, false, true>(loc + C::xA, nullptr, tag, ly.norm_in, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead, nullptr, nullptr, 0, 0);
+        }
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const XSeq& Sb = SS[b];
+            if (NB > 1 && !Sb.act) continue;
+            const XLds Lb = xe_lds_view<C>(L, b);
+            uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)Sb.seq * a.loc_stride);
+            if (l == 0) {
+                int tok = a.d_state[Sb.sq * 4];
+                if (Sb.step > 0) { /* the id workgroup 0 of this decoder picked at the end of the previous step: {id, epoch of this step} */
+                    const __amdgpu_buffer_rsrc_t rt = eng_rsrc(loc + C::tokg, 8u);
+                    for (int spins = 0;; spins++) {
+                        const u32x2 g = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rt, 0, 0, 16 /* sc1 */));
+                        if (g.y == (uint32_t)epoch) {
+                            tok = (int)g.x;
+                            break;
+                        }
+                        if (dead || spins > ENG_SPIN_MAX) {
+                            if (!dead && lane == 0) atomicOr(a.ws + 1, 32);
+                            dead = true;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                if (a.d_forced) {
+                    const int f = a.d_forced[(size_t)Sb.sq * a.forced_stride + Sb.pos];
+                    if (f >= 0) tok = f;
+                }
+                if (tok < 0 || tok >= a.emb_rows) tok = 0;
+                if constexpr (ND > 12) eng_poll_stage_norm_long<XCH, ND, C::XS, true, true, 8>(nullptr, a.emb + (size_t)tok * C::DIM, tag, ly.norm_in, a.eps, Lb.xs[0], Lb.xrawA, lane, a.ws, dead);
+                else eng_poll_stage<XCH, ND, C::XS, true, true, true>(nullptr, a.emb + (size_t)tok * C::DIM, tag, ly.norm_in, a.eps, Lb.xs[0], Lb.xrawA, lane, a.ws, dead, nullptr, nullptr, 0, 0);
+            } else {
+                if constexpr (C::TP) /* the down_proj exchange of the layer before: this workgroup's rows summed over the ranks + the residual xB -> the local x area */
+                    xe_tp_reduce<C>(a, S, 1, 2u * (gen - 1u) + 2u, L.xrawB, loc + C::xA + S.r * RT, tag, nullptr, lane, dead);
+                if constexpr (C::TP) XE_STAMP(31); /* (TP: the slot of the shader-clock stamp) this workgroup's rows of the down_proj exchange are summed */
+                if constexpr (C::COOP) xe_coop_norm_stage<C>(a, L, loc + C::xA, tag, ly.norm_in, L.xs[0], L.xrawA, C::NWV - 1, lane, &dead);
+                else if constexpr (ND > 12) eng_poll_stage_norm_long<XCH, ND, C::XS, false, true, 8>(loc + C::xA, nullptr, tag, ly.norm_in, a.eps, Lb.xs[0], Lb.xrawA, lane, a.ws, dead);
+                else eng_poll_stage<XCH, ND, C::XS, true, false, true>(loc + C::xA, nullptr, tag, ly.norm_in, a.eps, Lb.xs[0], Lb.xrawA, lane, a.ws, dead, nullptr, nullptr, 0, 0);
+            }
         }
         XE_STAMP(1);
         __syncthreads(); /* B1 */
         // P2: the raw q heads of this workgroup's kv-head, its k and v rows (only a slice with keys needs them)
-        if (!S.empty) {
+        if (!(C::P1W < XE_NWG && S.r >= C::P1W)) eng_wait_pub(L.pub + 0, S.step * a.n_layer + l + 1, 0, dead); /* (a workgroup without q | k | v rows publishes none) */
+        XE_STAMP(9);
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const XSeq& Sb = SS[b];
+            if (Sb.empty) continue; /* (an inactive sequence is an empty one) */
+            const XLds Lb = xe_lds_view<C>(L, b);
+            uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)Sb.seq * a.loc_stride);
             const __amdgpu_buffer_rsrc_t rs = eng_rsrc(loc + C::qkv, (uint32_t)(C::QD + 2 * C::KVD) * 4u);
             const uint32_t tagw = tag << 16;
             constexpr int NLQ = (GQ * hd + 255) / 256;
             u32x4 g[NLQ], gk;
             const int e_kv = 4 * lane; /* < hd: k, < 2 hd: v */
             const bool kv_in = e_kv < 2 * hd;
-            const int kv_src = e_kv < hd ? C::QD + S.kvh * hd + e_kv : C::QD + C::KVD + S.kvh * hd + (e_kv - hd);
-            if (!(C::P1W < XE_NWG && S.r >= C::P1W)) eng_wait_pub(L.pub + 0, S.step * a.n_layer + l + 1, 0, dead); /* (a workgroup without q | k | v rows publishes none) */
-            XE_STAMP(9);
+            const int kv_src = e_kv < hd ? C::QD + Sb.kvh * hd + e_kv : C::QD + C::KVD + Sb.kvh * hd + (e_kv - hd);
             for (int spins = 0;; spins++) {
                 uint32_t bad = 0;
 #pragma unroll
-                for (int r = 0; r < NLQ; r++) g[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (S.h0 * hd + 4 * (r * 64 + lane)) * 4, 0, 16));
+                for (int r = 0; r < NLQ; r++) g[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (Sb.h0 * hd + 4 * (r * 64 + lane)) * 4, 0, 16));
                 gk = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (kv_in ? kv_src : 0) * 4, 0, 16));
 #pragma unroll
                 for (int r = 0; r < NLQ; r++) bad = (4 * (r * 64 + lane) < GQ * hd) ? tags_bad(g[r], tagw, bad) : bad;
@@ -722,19 +849,26 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, co
 #pragma unroll
             for (int r = 0; r < NLQ; r++) {
                 const int e0 = 4 * (r * 64 + lane);
-                if (e0 < GQ * hd) *reinterpret_cast<u32x2*>(L.qraw + e0) = u32x2{(g[r].x & 0xffffu) | (g[r].y << 16), (g[r].z & 0xffffu) | (g[r].w << 16)};
+                if (e0 < GQ * hd) *reinterpret_cast<u32x2*>(Lb.qraw + e0) = u32x2{(g[r].x & 0xffffu) | (g[r].y << 16), (g[r].z & 0xffffu) | (g[r].w << 16)};
             }
-            if (kv_in) *reinterpret_cast<u32x2*>(L.kraw + e_kv) = u32x2{(gk.x & 0xffffu) | (gk.y << 16), (gk.z & 0xffffu) | (gk.w << 16)}; /* vraw = kraw + hd */
+            if (kv_in) *reinterpret_cast<u32x2*>(Lb.kraw + e_kv) = u32x2{(gk.x & 0xffffu) | (gk.y << 16), (gk.z & 0xffffu) | (gk.w << 16)}; /* vraw = kraw + hd */
         }
         XE_STAMP(2);
-        __syncthreads(); /* raw heads staged */
-        __syncthreads(); /* heads prepared */
-        __syncthreads(); /* the waves' sums in LDS */
+#pragma unroll
+        for (int b = 0; b < NB; b++) { /* the compute waves' attention, sequence after sequence (xe_attn_phase) */
+            __syncthreads(); /* raw heads staged */
+            __syncthreads(); /* heads prepared */
+            __syncthreads(); /* the waves' sums in LDS */
+        }
         XE_STAMP(3);
         // P3: merge the SPK slices of this workgroup's ME output elements (exact rescales to the largest exponent, fp64 sums, one division: kf_attn_common.h)
-        {
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const XSeq& Sb = SS[b];
+            if (NB > 1 && !Sb.act) continue;
+            uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)Sb.seq * a.loc_stride);
             constexpr int ME = C::ME, SPK = C::SPK, NV = ME * SPK, NLM = (NV * 2 + 127) / 128; /* values; 16-byte loads (2 granules) per lane and sweep */
-            const int h = S.me0 >> (hd == 128 ? 7 : 6), dd = S.me0 & (hd - 1);
+            const int h = Sb.me0 >> (hd == 128 ? 7 : 6), dd = Sb.me0 & (hd - 1);
             const unsigned long long* hbase = reinterpret_cast<const unsigned long long*>(loc + C::part) + (size_t)h * C::PSH;
             const __amdgpu_buffer_rsrc_t rs_o = eng_rsrc(hbase + (size_t)(dd / ME) * (SPK * ME * 2), (uint32_t)(SPK * ME * 2) * 8u);
             const __amdgpu_buffer_rsrc_t rs_ml = eng_rsrc(hbase + (size_t)hd * SPK * 2, (uint32_t)SPK * 32u);
@@ -757,7 +891,7 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, co
                 }
                 __builtin_amdgcn_s_sleep(1);
             }
-            XE_STAMP(4);
+            if (b == 0) XE_STAMP(4);
 #pragma unroll
             for (int r = 0; r < NLM; r++) { /* value index vi = sp * ME + e */
                 const int vi = r * 64 + lane;
@@ -781,27 +915,45 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, co
                     mo[e] = (tag << 16) | (uint32_t)f2bf((float)(o / Lt));
                 }
             }
-            if (4 * lane < ME) *reinterpret_cast<u32x4*>(loc + C::ao + S.me0 + 4 * lane) = *reinterpret_cast<const u32x4*>(mo + 4 * lane);
+            if (4 * lane < ME) *reinterpret_cast<u32x4*>(loc + C::ao + Sb.me0 + 4 * lane) = *reinterpret_cast<const u32x4*>(mo + 4 * lane);
         }
         XE_STAMP(5);
         // P4's ao, P5's xB (P6 adds it as the residual), P6's act
-        eng_poll_stage<XCH, NQD, C::XS, false, false, true>(loc + C::ao, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, nullptr, nullptr, 0, 0);
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            if (NB > 1 && !SS[b].act) continue;
+            const XLds Lb = xe_lds_view<C>(L, b);
+            uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)SS[b].seq * a.loc_stride);
+            eng_poll_stage<XCH, NQD, C::XS, false, false, true>(loc + C::ao, nullptr, tag, nullptr, 0.f, Lb.xs[1], nullptr, lane, a.ws, dead, nullptr, nullptr, 0, 0);
+        }
         XE_STAMP(6);
         __syncthreads(); /* B4 */
         eng_wait_pub(L.pub + 1, S.step * a.n_layer + l + 1, 0, dead);
         XE_STAMP(10);
-        if constexpr (C::TP) xe_tp_reduce<C>(a, S, 0, 2u * gen + 1u, L.xrawA, loc + C::xB + S.r * RT, tag, nullptr, lane, dead); /* the o_proj exchange + the residual x */
-        if constexpr (C::TP) XE_STAMP(13); /* (TP: the slot of the act sweep count) this workgroup's rows of the o_proj exchange are summed */
-        if constexpr (C::COOP) xe_coop_norm_stage<C>(a, L, loc + C::xB, tag, ly.norm_post, L.xs[0], L.xrawB, C::NWV - 1, lane, &dead);
-        else if constexpr (ND > 12) eng_poll_stage_norm_long<XCH, ND, C::XS, false, true, 8>(loc + C::xB, nullptr, tag, ly.norm_post, a.eps, L.xs[0], L.xrawB, lane, a.ws, dead);
-        else eng_poll_stage<XCH, ND, C::XS, true, false, true>(loc + C::xB, nullptr, tag, ly.norm_post, a.eps, L.xs[0], L.xrawB, lane, a.ws, dead, nullptr, nullptr, 0, 0);
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            if (NB > 1 && !SS[b].act) continue;
+            const XLds Lb = xe_lds_view<C>(L, b);
+            uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)SS[b].seq * a.loc_stride);
+            if constexpr (C::TP) xe_tp_reduce<C>(a, S, 0, 2u * gen + 1u, L.xrawA, loc + C::xB + S.r * RT, tag, nullptr, lane, dead); /* the o_proj exchange + the residual x */
+            if constexpr (C::TP) XE_STAMP(13); /* (TP: the slot of the act sweep count) this workgroup's rows of the o_proj exchange are summed */
+            if constexpr (C::COOP) xe_coop_norm_stage<C>(a, L, loc + C::xB, tag, ly.norm_post, L.xs[0], L.xrawB, C::NWV - 1, lane, &dead);
+            else if constexpr (ND > 12) eng_poll_stage_norm_long<XCH, ND, C::XS, false, true, 8>(loc + C::xB, nullptr, tag, ly.norm_post, a.eps, Lb.xs[0], Lb.xrawB, lane, a.ws, dead);
+            else eng_poll_stage<XCH, ND, C::XS, true, false, true>(loc + C::xB, nullptr, tag, ly.norm_post, a.eps, Lb.xs[0], Lb.xrawB, lane, a.ws, dead, nullptr, nullptr, 0, 0);
+        }
         XE_STAMP(7);
         __syncthreads(); /* B5 */
         eng_wait_pub(L.pub + 2, S.step * a.n_layer + l + 1, 0, dead);
         XE_STAMP(11);
         int nsw_act = 0;
-        if constexpr (NF > 24) eng_poll_stage_long<XCH, NF, C::XS, 16>(loc + C::act, tag, L.xs[1], lane, a.ws, dead, &nsw_act); /* a 9728-wide vector in one sweep: 152 registers */
-        else eng_poll_stage<XCH, NF, C::XS, false, false, true>(loc + C::act, nullptr, tag, nullptr, 0.f, L.xs[1], nullptr, lane, a.ws, dead, &nsw_act, nullptr, 0, 0);
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            if (NB > 1 && !SS[b].act) continue;
+            const XLds Lb = xe_lds_view<C>(L, b);
+            uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)SS[b].seq * a.loc_stride);
+            if constexpr (NF > 24) eng_poll_stage_long<XCH, NF, C::XS, 16>(loc + C::act, tag, Lb.xs[1], lane, a.ws, dead, &nsw_act); /* a 9728-wide vector in one sweep: 152 registers */
+            else eng_poll_stage<XCH, NF, C::XS, false, false, true>(loc + C::act, nullptr, tag, nullptr, 0.f, Lb.xs[1], nullptr, lane, a.ws, dead, &nsw_act, nullptr, 0, 0);
+        }
         if (C::DBG && !C::TP && S.stamp && lane == 0) a.dbg[((size_t)S.step * a.n_layer + l) * 64 + 13] = (unsigned long long)nsw_act;
         XE_STAMP(8);
         __syncthreads(); /* B6 */
@@ -810,7 +962,9 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, co
 
 // ---- the compute waves
 template <class C>
-__device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, const XSeq& S, int epoch, int cw, int lane, XRing<C::DEPTH>& R) {
+__device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, const XSeq (&SS)[C::NB], int epoch, int cw, int lane, XRing<C::DEPTH>& R) {
+    constexpr int NB = C::NB;
+    const XSeq& S = SS[0]; /* the workgroup's place (and, NB == 1, the sequence) */
     using SH = typename C::SH;
     using P1 = typename SH::P1;
     using P4 = typename SH::P4;
@@ -825,13 +979,17 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
     const float qb1 = S.j1 == 0 ? a.qbias[0] : (S.j1 == 1 ? a.qbias[1] : a.qbias[2]);
     const int wg = S.r;
     XAttn<C> T;
-    {
-        T.rc = 1.f, T.rs = 0.f;
+    uint32_t actm = 0; /* bit b: sequence b of the decoder is active */
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        actm |= SS[b].act ? (1u << b) : 0u;
+        T.rc[b] = 1.f, T.rs[b] = 0.f;
         if (a.rope_table && lane < (C::HD >> 1)) {
-            const float* tab_pos = a.rope_table + (size_t)S.pos * C::HD;
-            T.rc = tab_pos[2 * lane], T.rs = tab_pos[2 * lane + 1];
+            const float* tab_pos = a.rope_table + (size_t)SS[b].pos * C::HD;
+            T.rc[b] = tab_pos[2 * lane], T.rs[b] = tab_pos[2 * lane + 1];
         }
     }
+    const size_t loc_bs = (size_t)XE_NXCD * a.loc_stride / 4; /* dwords from sequence b's exchange area to sequence b + 1's (sequences xcc + 8 b) */
     // phase q of a layer (0: q | k | v, 1: o_proj, 2: gate | up, 3: down_proj) as scalars: every field by a chain of selects on q -- never a struct chosen among four (the
     // compiler keeps such a value in scratch memory and every later field read becomes an indexed scratch load, in front of which it drains the weight loads in flight)
     auto sel4 = [](int q, auto v0, auto v1, auto v2, auto v3) { return q == 0 ? v0 : (q == 1 ? v1 : (q == 2 ? v2 : v3)); };
@@ -866,7 +1024,7 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
         const uint32_t gen = (uint32_t)epoch * (uint32_t)a.n_layer + (uint32_t)l, tag = gen & 0xffffu, tag_next = (gen + 1u) & 0xffffu;
         const bool last = l == a.n_layer - 1;
         const EngLayer& lyn = L.lay[last ? l : l + 1];
-        if (!S.empty) { /* q-norm (waves that prepare a q head) / k-norm (the wave that prepares the new key) weights of this lane's pair */
+        if (NB > 1 || !S.empty) { /* q-norm (waves that prepare a q head) / k-norm (the wave that prepares the new key) weights of this lane's pair */
             const int half = C::HD >> 1, j = lane < half ? lane : half - 1;
             g_u16 np = cw < C::GQW ? ly.norm_q : ly.norm_k;
             T.nw0 = T.nw1 = 0;
@@ -893,21 +1051,22 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
             if (cw == 0) XE_STAMP(16 + 2 * q);
             xe_mv_run<C, D>(
                 P, NX, nx_on, cw, lane, xs, R,
-                [&](int row, float v, float v2) {
+                [&](int b, int row, float v, float v2) {
+                    const XLds Lb = xe_lds_view<C>(L, b);
                     uint32_t g;
                     if (q == 0) {
                         g = (tag << 16) | (uint32_t)f2bf(v);
                     } else if (C::TP && (q == 1 || q == 3)) {
                         g = __float_as_uint(v); /* a column shard's row: the un-rounded fp32 partial (xe_publish pushes it to every rank) */
                     } else if (q == 1) {
-                        g = (tag << 16) | (uint32_t)f2bf(bf2f(L.xrawA[row]) + bf2f(f2bf(v))); /* CU_add3: bf16(x + bf16(W.x)) */
+                        g = (tag << 16) | (uint32_t)f2bf(bf2f(Lb.xrawA[row]) + bf2f(f2bf(v))); /* CU_add3: bf16(x + bf16(W.x)) */
                     } else if (q == 2) {
                         g = pack_bf16x2(v, v2); /* the two bf16-rounded projections; CU_swiglu_v0 on them runs in xe_publish, once per row with every lane busy (here: the whole wave would walk
                                                    the exponential and the division for two rows) */
                     } else {
-                        g = (tag_next << 16) | (uint32_t)f2bf(bf2f(L.xrawB[row]) + bf2f(f2bf(v)));
+                        g = (tag_next << 16) | (uint32_t)f2bf(bf2f(Lb.xrawB[row]) + bf2f(f2bf(v)));
                     }
-                    L.outb[row - P.row0] = g;
+                    Lb.outb[row - P.row0] = g;
                 });
             XE_STAMP(32 + 8 * q + (cw & 7)); /* this wave's rows of the phase are done */
             if (C::DBG && S.stamp && lane == 0 && q == 0) {
@@ -915,19 +1074,32 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
                 a.dbg[((size_t)S.step * a.n_layer + l) * 64 + ((cw & 7) < 2 ? 14 + (cw & 7) : 23 + (cw & 7))] = hw; /* slots 14, 15, 25 .. 30: where (SIMD, CU) the wave runs */
             }
-            if (q == 0) xe_attn_issue<C>(a, ly, S, cw, lane, T, 0, 0); /* the slice's first tiles (rows of earlier positions; row `pos` is substituted): the q | k | v hand-off hides them */
+            if (q == 0 && (NB == 1 || SS[0].act)) xe_attn_issue<C>(a, ly, SS[0], cw, lane, T, 0, 0); /* the slice's first tiles (rows of earlier positions; row `pos` is substituted): the q | k | v hand-off hides them */
             if (xe_deal<NCW, C::DEAL_CONTIG>(cw, spg, a.deal_wl).n > 0 && !(C::P1W < XE_NWG && q == 0 && wg >= C::P1W)) {
                 if constexpr (C::TP) {
                     // o_proj (q == 1) / down_proj (q == 3): this rank's slot [buffer][S.seq][rows wg * R ..] of rank 0's receive area, the other ranks' areas 2 * 8 * DIM granules apart
                     unsigned long long* push = (q == 1 || q == 3) ? a.tp_recv + ((size_t)(q == 3 ? 1 : 0) * XE_NXCD + S.seq) * C::DIM + wg * nrows : nullptr;
                     xe_publish(L, q, tag, dst, nrows, nwp, lane, nullptr, push, (size_t)2 * XE_NXCD * C::DIM, 2u * gen + (q == 3 ? 2u : 1u), (q == 2 && wg == XE_NWG - 1) ? C::FFNP - C::FFN : 0);
                 } else {
-                    xe_publish(L, q, tag, dst, nrows, nwp, lane, (q == 3 && last) ? a.x_out + (size_t)S.seq * C::DIM + wg * P6::R : nullptr);
+                    xe_publish<NB, XLay<C>::seq_bytes>(L, q, tag, dst, nrows, nwp, lane, (q == 3 && last) ? a.x_out + (size_t)S.seq * C::DIM + wg * P6::R : nullptr, nullptr, 0, 0, 0, loc_bs,
+                                                       (size_t)XE_NXCD * C::DIM, actm);
                 }
             }
             if (cw == 0) XE_STAMP(17 + 2 * q);
             if (q == 0) { /* q/k-norm + RoPE + attention over the workgroup's key slice; the slice partial into the XCD's partial area; then the first o_proj blocks */
-                xe_attn_phase<C>(a, L, S, ly, gen, cw, lane, T, l, [&]() { xe_fill<NCW, D, C::WAUX>(phase_of(1, ly), cw, lane, R); });
+#pragma unroll
+                for (int b = 0; b < NB; b++) { /* sequence after sequence (own positions, own slices, own K / V rows); behind a sequence's key loop the next one's first tiles are requested */
+                    xe_attn_phase<C>(
+                        a, xe_lds_view<C>(L, b), SS[b], ly, gen, cw, lane, T, l,
+                        [&]() {
+                            if (b + 1 < NB) {
+                                if (SS[b + 1 < NB ? b + 1 : b].act) xe_attn_issue<C>(a, ly, SS[b + 1 < NB ? b + 1 : b], cw, lane, T, 0, 0);
+                            } else {
+                                xe_fill<NCW, D, C::WAUX>(phase_of(1, ly), cw, lane, R);
+                            }
+                        },
+                        b);
+                }
                 if (cw == 0) XE_STAMP(24);
             }
         }
@@ -937,14 +1109,14 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
 // ---- the LM head + greedy pick as trailing phases (eng_head_main of kf_engine.hip on 32 workgroups): final RMSNorm, the [vocab, dim] bf16 mat-vec with the arithmetic
 // of gemv_kernel<FMT_BF16, .., CANON> (same lanes per row, chain pair, tree, bf16 store), first-maximum arg-max over the stored values
 template <class C>
-__device__ __forceinline__ void xe_head_main(const XArgs& a, const XLds& L, const XSeq& S, int epoch, bool more_steps, int wave, int lane) {
-    constexpr int NWV = C::NWV, NWG = XE_NWG, nBlk = C::HnBlk, LPR = C::HLPR, RPS = C::HRPS, ITERS = C::Hiters;
-    constexpr int HG = ITERS <= 4 ? 4 : (ITERS <= 5 ? 2 : 1); /* row slots per batch and wave, two batches in flight: 2 x HG x ITERS x 4 registers (2560-wide rows: 80, 4096-wide: 64) */
+__device__ __forceinline__ void xe_head_main(const XArgs& a, const XLds& L, const XSeq (&SS)[C::NB], int epoch, bool more_steps, int wave, int lane) {
+    constexpr int NWV = C::NWV, NWG = XE_NWG, nBlk = C::HnBlk, LPR = C::HLPR, RPS = C::HRPS, ITERS = C::Hiters, NB = C::NB;
+    constexpr int HG = NB > 2 ? 2 : (ITERS <= 4 ? 4 : (ITERS <= 5 ? 2 : 1)); /* row slots per batch and wave, two batches in flight: 2 x HG x ITERS x 4 registers (2560-wide rows: 80, 4096-wide: 64) */
     constexpr int ND = C::DIM / 256;
+    const XSeq& S = SS[0];
     const int wg = S.r;
-    uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)S.seq * a.loc_stride);
     // TP: this rank's vocabulary shard (rows row0 .. of the full head), its logits; chosen by compares (an index into the kernel arguments at run time is a copy in scratch)
-    uint16_t* logits = a.logits + (size_t)S.seq * a.vocab;
+    uint16_t* logits = a.logits + (size_t)S.seq * a.vocab; /* sequence b's: + 8 b vocab */
     g_u32x4 head_w = a.head_w;
     int vocab = a.vocab, row0g = 0;
     if constexpr (C::TP) {
@@ -980,48 +1152,64 @@ __device__ __forceinline__ void xe_head_main(const XArgs& a, const XLds& L, cons
     if (wave == NWV - 1) {
         bool dead = false;
         if constexpr (C::TP) { /* the last layer's down_proj exchange: this workgroup's rows -> the local x area (rank 0: also x_out) */
+            uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)S.seq * a.loc_stride);
             eng_wait_pub(L.pub + 3, (S.step + 1) * a.n_layer, 0, dead);
             xe_tp_reduce<C>(a, S, 1, 2u * (gen - 1u) + 2u, L.xrawB, loc + C::xA + wg * (C::DIM / XE_NWG), tag, S.seq == 0 ? a.x_out : nullptr, lane, dead);
         }
-        if constexpr (ND > 12) eng_poll_stage_norm_long<1, ND, nBlk, false, false, 8>(loc + C::xA, nullptr, tag, a.head_norm, a.eps, L.xs[0], L.xrawA, lane, a.ws, dead);
-        else eng_poll_stage<1, ND, nBlk, true, false, false>(loc + C::xA, nullptr, tag, a.head_norm, a.eps, L.xs[0], nullptr, lane, a.ws, dead, nullptr, L.pub + 3, (S.step + 1) * a.n_layer, 0);
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            if (NB > 1 && !SS[b].act) continue;
+            const XLds Lb = xe_lds_view<C>(L, b);
+            uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)SS[b].seq * a.loc_stride);
+            if constexpr (ND > 12) eng_poll_stage_norm_long<1, ND, nBlk, false, false, 8>(loc + C::xA, nullptr, tag, a.head_norm, a.eps, Lb.xs[0], Lb.xrawA, lane, a.ws, dead);
+            else eng_poll_stage<1, ND, nBlk, true, false, false>(loc + C::xA, nullptr, tag, a.head_norm, a.eps, Lb.xs[0], nullptr, lane, a.ws, dead, nullptr, b == 0 ? L.pub + 3 : nullptr, (S.step + 1) * a.n_layer, 0);
+        }
     } else {
         issue(0, 0); /* ahead of the hand-off of x (the poller's own first rows are requested behind its sweep: loads return in order) */
     }
     __syncthreads();
     if (wave == NWV - 1) issue(0, 0);
-    float xf[ITERS][8];
+    float xf[NB][ITERS][8];
 #pragma unroll
-    for (int it = 0; it < ITERS; it++) {
-        int col = it * LPR + ll;
-        col = col < nBlk ? col : nBlk - 1;
-        const u32x4 xv = L.xs[0][col];
-        const uint32_t x4[4] = {xv.x, xv.y, xv.z, xv.w};
+    for (int b = 0; b < NB; b++) {
+        const XLds Lb = xe_lds_view<C>(L, b);
 #pragma unroll
-        for (int i = 0; i < 4; i++) xf[it][2 * i] = bf_lo(x4[i]), xf[it][2 * i + 1] = bf_hi(x4[i]);
+        for (int it = 0; it < ITERS; it++) {
+            int col = it * LPR + ll;
+            col = col < nBlk ? col : nBlk - 1;
+            const u32x4 xv = Lb.xs[0][col];
+            const uint32_t x4[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) xf[b][it][2 * i] = bf_lo(x4[i]), xf[b][it][2 * i + 1] = bf_hi(x4[i]);
+        }
     }
-    float best_v = -__builtin_inff();
-    int best_i = 0x7fffffff;
-    auto compute = [&](int b, int buf) {
+    float best_v[NB];
+    int best_i[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) best_v[b] = -__builtin_inff(), best_i[b] = 0x7fffffff;
+    auto compute = [&](int bt, int buf) {
 #pragma unroll
         for (int g = 0; g < HG; g++) {
-            const int i = b * HG + g;
+            const int i = bt * HG + g;
             const int row = (s_wg + wave + NWV * i) * RPS + sub;
-            f32x2_t acc{0.f, 0.f};
 #pragma unroll
-            for (int it = 0; it < ITERS; it++) {
-                const uint32_t w4[4] = {w[buf][g][it].x, w[buf][g][it].y, w[buf][g][it].z, w[buf][g][it].w};
-                f32x2_t r = acc;
+            for (int b = 0; b < NB; b++) { /* the rows are read once; every sequence of the decoder takes its own chain pair over them */
+                f32x2_t acc{0.f, 0.f};
 #pragma unroll
-                for (int i2 = 0; i2 < 4; i2++) r = pk_fma(f32x2_t{bf_lo(w4[i2]), bf_hi(w4[i2])}, f32x2_t{xf[it][2 * i2], xf[it][2 * i2 + 1]}, r);
-                acc = acc_pick(it * LPR + ll < nBlk, r, acc);
-            }
-            const float v = group_sum(acc_join(acc), C::Hlpr_log2);
-            if (ll == 0 && i < nmine && row < vocab) {
-                const uint16_t o = f2bf(v);
-                logits[row] = o;
-                const float fv = bf2f(o);
-                if (fv > best_v || (fv == best_v && row < best_i)) best_v = fv, best_i = row;
+                for (int it = 0; it < ITERS; it++) {
+                    const uint32_t w4[4] = {w[buf][g][it].x, w[buf][g][it].y, w[buf][g][it].z, w[buf][g][it].w};
+                    f32x2_t r = acc;
+#pragma unroll
+                    for (int i2 = 0; i2 < 4; i2++) r = pk_fma(f32x2_t{bf_lo(w4[i2]), bf_hi(w4[i2])}, f32x2_t{xf[b][it][2 * i2], xf[b][it][2 * i2 + 1]}, r);
+                    acc = acc_pick(it * LPR + ll < nBlk, r, acc);
+                }
+                const float v = group_sum(acc_join(acc), C::Hlpr_log2);
+                if (ll == 0 && i < nmine && row < vocab && (NB == 1 || SS[b].act)) {
+                    const uint16_t o = f2bf(v);
+                    logits[(size_t)b * XE_NXCD * vocab + row] = o;
+                    const float fv = bf2f(o);
+                    if (fv > best_v[b] || (fv == best_v[b] && row < best_i[b])) best_v[b] = fv, best_i[b] = row;
+                }
             }
         }
     };
@@ -1033,94 +1221,109 @@ __device__ __forceinline__ void xe_head_main(const XArgs& a, const XLds& L, cons
         compute(b + 1, 1);
     }
 #pragma unroll
-    for (int m = 32; m > 0; m >>= 1) {
-        const float ov = __shfl_xor(best_v, m, 64);
-        const int oi = __shfl_xor(best_i, m, 64);
-        if (ov > best_v || (ov == best_v && oi < best_i)) best_v = ov, best_i = oi;
-    }
-    float* rv = L.wmax;
-    int* ri = reinterpret_cast<int*>(L.wmax + NWV);
-    if (lane == 0) rv[wave] = best_v, ri[wave] = best_i;
-    __syncthreads();
-    unsigned long long* hb = reinterpret_cast<unsigned long long*>(loc + C::hbest);
-    if (wave == 0 && lane == 0) {
-        for (int k = 1; k < NWV; k++)
-            if (rv[k] > best_v || (rv[k] == best_v && ri[k] < best_i)) best_v = rv[k], best_i = ri[k];
-        hb[wg] = ((unsigned long long)((tag << 16) | (uint32_t)f2bf(best_v)) << 32) | (unsigned long long)(uint32_t)best_i;
-    }
-    if (wg == 0 && wave == NWV - 1 && a.pick) { /* the pick over the decoder's 32 workgroup maxima: two granules per lane */
-        const __amdgpu_buffer_rsrc_t rs = eng_rsrc(hb, NWG * 8u);
-        u32x4 g0{0, 0, 0, 0};
-        bool ok = false;
-        const bool mine = lane < NWG / 2;
-        for (int spins = 0; spins <= ENG_SPIN_MAX; spins++) {
-            g0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (mine ? lane : 0) * 16, 0, 16 /* sc1 */));
-            const uint32_t bad = ((g0.y >> 16) ^ tag) | ((g0.w >> 16) ^ tag);
-            if (all_good(bad)) {
-                ok = true;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        float bv = -__builtin_inff();
-        int bi = 0x7fffffff;
-        if (mine) {
-            const uint32_t hv[2] = {g0.y, g0.w}, hi[2] = {g0.x, g0.z};
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const float fv = bf2f((uint16_t)(hv[k] & 0xffffu));
-                const int ix = (int)hi[k];
-                if (fv > bv || (fv == bv && ix < bi)) bv = fv, bi = ix;
-            }
-        }
+    for (int b = 0; b < NB; b++) {
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) {
-            const float ov = __shfl_xor(bv, m, 64);
-            const int oi = __shfl_xor(bi, m, 64);
-            if (ov > bv || (ov == bv && oi < bi)) bv = ov, bi = oi;
+            const float ov = __shfl_xor(best_v[b], m, 64);
+            const int oi = __shfl_xor(best_i[b], m, 64);
+            if (ov > best_v[b] || (ov == best_v[b] && oi < best_i[b])) best_v[b] = ov, best_i[b] = oi;
         }
-        int vocab_all = vocab;
-        if constexpr (C::TP) { /* the rank's maximum (GLOBAL row) to every rank; then the first maximum over the ranks (tp_pick_kernel, kf_tp.hip: lowest row among equals) */
-            vocab_all = 0;
+        const XLds Lb = xe_lds_view<C>(L, b);
+        float* rv = Lb.wmax;
+        int* ri = reinterpret_cast<int*>(Lb.wmax + NWV);
+        if (lane == 0) rv[wave] = best_v[b], ri[wave] = best_i[b];
+    }
+    __syncthreads();
 #pragma unroll
-            for (int r = 0; r < XE_NXCD; r++) vocab_all += a.vocab_r[r];
-            if (lane < XE_NXCD) {
-                const unsigned long long gr = ((unsigned long long)((tag << 16) | (uint32_t)f2bf(bv)) << 32) | (unsigned long long)(uint32_t)(bi + row0g);
-                __hip_atomic_store(a.tp_best + (size_t)lane * XE_NXCD + S.seq, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            const __amdgpu_buffer_rsrc_t rb = eng_rsrc(a.tp_best + (size_t)S.seq * XE_NXCD, XE_NXCD * 8u);
-            u32x2 gb{0, 0};
-            const bool src = lane < XE_NXCD;
-            bool ok2 = false;
+    for (int b = 0; b < NB; b++) {
+        const XSeq& Sb = SS[b];
+        if (NB > 1 && !Sb.act) continue;
+        const XLds Lb = xe_lds_view<C>(L, b);
+        uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)Sb.seq * a.loc_stride);
+        float* rv = Lb.wmax;
+        int* ri = reinterpret_cast<int*>(Lb.wmax + NWV);
+        unsigned long long* hb = reinterpret_cast<unsigned long long*>(loc + C::hbest);
+        if (wave == 0 && lane == 0) {
+            float bv0 = best_v[b];
+            int bi0 = best_i[b];
+            for (int k = 1; k < NWV; k++)
+                if (rv[k] > bv0 || (rv[k] == bv0 && ri[k] < bi0)) bv0 = rv[k], bi0 = ri[k];
+            hb[wg] = ((unsigned long long)((tag << 16) | (uint32_t)f2bf(bv0)) << 32) | (unsigned long long)(uint32_t)bi0;
+        }
+        if (wg == 0 && wave == NWV - 1 && a.pick) { /* the pick over the decoder's 32 workgroup maxima: two granules per lane */
+            const __amdgpu_buffer_rsrc_t rs = eng_rsrc(hb, NWG * 8u);
+            u32x4 g0{0, 0, 0, 0};
+            bool ok = false;
+            const bool mine = lane < NWG / 2;
             for (int spins = 0; spins <= ENG_SPIN_MAX; spins++) {
-                gb = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rb, (src ? lane : 0) * 8, 0, 16 /* sc1 */));
-                if (all_good((gb.y >> 16) ^ tag)) {
-                    ok2 = true;
+                g0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (mine ? lane : 0) * 16, 0, 16 /* sc1 */));
+                const uint32_t bad = ((g0.y >> 16) ^ tag) | ((g0.w >> 16) ^ tag);
+                if (all_good(bad)) {
+                    ok = true;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
             }
-            ok = ok && ok2;
-            bv = src ? bf2f((uint16_t)(gb.y & 0xffffu)) : -__builtin_inff(), bi = src ? (int)gb.x : 0x7fffffff;
+            float bv = -__builtin_inff();
+            int bi = 0x7fffffff;
+            if (mine) {
+                const uint32_t hv[2] = {g0.y, g0.w}, hi[2] = {g0.x, g0.z};
 #pragma unroll
-            for (int m = 4; m > 0; m >>= 1) {
+                for (int k = 0; k < 2; k++) {
+                    const float fv = bf2f((uint16_t)(hv[k] & 0xffffu));
+                    const int ix = (int)hi[k];
+                    if (fv > bv || (fv == bv && ix < bi)) bv = fv, bi = ix;
+                }
+            }
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) {
                 const float ov = __shfl_xor(bv, m, 64);
                 const int oi = __shfl_xor(bi, m, 64);
                 if (ov > bv || (ov == bv && oi < bi)) bv = ov, bi = oi;
             }
-        }
-        if (lane == 0) {
-            const int err = __hip_atomic_load(a.ws + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (ok && err == 0 && bi >= 0 && bi < vocab_all) { /* never advance the decode state on a timed-out hand-off */
-                if (!C::TP || S.seq == 0) { /* TP: every rank knows the id (its next embedding row); rank 0 keeps the books */
-                    int32_t* st = a.d_state + S.sq * 4;
-                    const int p = st[1];
-                    if (a.d_tokens_out) a.d_tokens_out[(size_t)S.sq * a.tokens_stride + p] = bi;
-                    st[0] = bi, st[1] = p + 1;
+            int vocab_all = vocab;
+            if constexpr (C::TP) { /* the rank's maximum (GLOBAL row) to every rank; then the first maximum over the ranks (tp_pick_kernel, kf_tp.hip: lowest row among equals) */
+                vocab_all = 0;
+#pragma unroll
+                for (int r = 0; r < XE_NXCD; r++) vocab_all += a.vocab_r[r];
+                if (lane < XE_NXCD) {
+                    const unsigned long long gr = ((unsigned long long)((tag << 16) | (uint32_t)f2bf(bv)) << 32) | (unsigned long long)(uint32_t)(bi + row0g);
+                    __hip_atomic_store(a.tp_best + (size_t)lane * XE_NXCD + S.seq, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (more_steps) *reinterpret_cast<u32x2*>(loc + C::tokg) = u32x2{(uint32_t)bi, (uint32_t)(epoch + 1)};
-            } else if (err == 0) {
-                atomicOr(a.ws + 1, 16);
+                const __amdgpu_buffer_rsrc_t rb = eng_rsrc(a.tp_best + (size_t)S.seq * XE_NXCD, XE_NXCD * 8u);
+                u32x2 gb{0, 0};
+                const bool src = lane < XE_NXCD;
+                bool ok2 = false;
+                for (int spins = 0; spins <= ENG_SPIN_MAX; spins++) {
+                    gb = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rb, (src ? lane : 0) * 8, 0, 16 /* sc1 */));
+                    if (all_good((gb.y >> 16) ^ tag)) {
+                        ok2 = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                ok = ok && ok2;
+                bv = src ? bf2f((uint16_t)(gb.y & 0xffffu)) : -__builtin_inff(), bi = src ? (int)gb.x : 0x7fffffff;
+#pragma unroll
+                for (int m = 4; m > 0; m >>= 1) {
+                    const float ov = __shfl_xor(bv, m, 64);
+                    const int oi = __shfl_xor(bi, m, 64);
+                    if (ov > bv || (ov == bv && oi < bi)) bv = ov, bi = oi;
+                }
+            }
+            if (lane == 0) {
+                const int err = __hip_atomic_load(a.ws + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ok && err == 0 && bi >= 0 && bi < vocab_all) { /* never advance the decode state on a timed-out hand-off */
+                    if (!C::TP || S.seq == 0) { /* TP: every rank knows the id (its next embedding row); rank 0 keeps the books */
+                        int32_t* st = a.d_state + Sb.sq * 4;
+                        const int p = st[1];
+                        if (a.d_tokens_out) a.d_tokens_out[(size_t)Sb.sq * a.tokens_stride + p] = bi;
+                        st[0] = bi, st[1] = p + 1;
+                    }
+                    if (more_steps) *reinterpret_cast<u32x2*>(loc + C::tokg) = u32x2{(uint32_t)bi, (uint32_t)(epoch + 1)};
+                } else if (err == 0) {
+                    atomicOr(a.ws + 1, 16);
+                }
             }
         }
     }
@@ -1128,42 +1331,35 @@ __device__ __forceinline__ void xe_head_main(const XArgs& a, const XLds& L, cons
 
 template <class C>
 __global__ void __launch_bounds__(C::NWV * 64, (C::NWV * C::WPC + 3) / 4 /* waves per SIMD: the register budget that lets WPC workgroups share a CU */) xengine_kernel(const XArgs a) {
-    constexpr int hd = C::HD, GQ = C::GQW, NWV = C::NWV, NCW = C::NCW;
+    constexpr int hd = C::HD, GQ = C::GQW, NWV = C::NWV, NB = C::NB;
     using P1 = typename C::SH::P1;
+    using LY = XLay<C>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // ---- LDS carve (compile-time offsets; the layer table behind them)
+    // ---- LDS carve (compile-time offsets: XLay; the layer table behind them)
     XLds L;
-    constexpr int maxK = C::DIM > C::QD ? (C::DIM > C::FFN ? C::DIM : C::FFN) : (C::QD > C::FFN ? C::QD : C::FFN);
-    constexpr int xs_bytes = (maxK * 4 + 15) & ~15, xr_bytes = (C::DIM * 2 + 15) & ~15;
-    constexpr size_t o_attn = (size_t)2 * xs_bytes + 2 * xr_bytes;
-    constexpr size_t o_comb = (o_attn + sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + 15) & ~(size_t)15;
-    constexpr size_t o_msc = o_comb + (C::COMB_IN_XS1 ? 0 : sizeof(double) * (size_t)NCW * GQ * (hd + 2));
-    constexpr size_t o_wmax = o_msc + sizeof(double) * ((size_t)C::ME * C::SPK) + 4 * 64 + 4 * 128;
-    constexpr size_t o_outb = o_wmax + 4 * 2 * 16;
-    constexpr size_t o_cnt = o_outb + 4 * (size_t)((C::maxR + 63) & ~63);
-    constexpr size_t fixed_bytes = (o_cnt + 64 + 15) & ~(size_t)15;
     static_assert(NWV <= 16, "wmax scratch");
-    EngLayer* lay = reinterpret_cast<EngLayer*>(smem + fixed_bytes);
+    EngLayer* lay = reinterpret_cast<EngLayer*>(smem + LY::fixed_bytes);
     L.lay = lay;
     L.xs[0] = reinterpret_cast<u32x4*>(smem);
-    L.xs[1] = reinterpret_cast<u32x4*>(smem + xs_bytes);
-    L.xrawA = reinterpret_cast<uint16_t*>(smem + 2 * xs_bytes);
-    L.xrawB = reinterpret_cast<uint16_t*>(smem + 2 * xs_bytes + xr_bytes);
-    L.qraw = reinterpret_cast<uint16_t*>(smem + o_attn);
+    L.xs[1] = reinterpret_cast<u32x4*>(smem + LY::xs_bytes);
+    L.xrawA = reinterpret_cast<uint16_t*>(smem + 2 * LY::xs_bytes);
+    L.xrawB = reinterpret_cast<uint16_t*>(smem + 2 * LY::xs_bytes + LY::xr_bytes);
+    L.qraw = reinterpret_cast<uint16_t*>(smem + LY::o_attn);
     L.kraw = L.qraw + GQ * hd, L.vraw = L.kraw + hd, L.qb = L.vraw + hd, L.knew = L.qb + GQ * hd;
-    L.comb = reinterpret_cast<double*>(smem + (C::COMB_IN_XS1 ? (size_t)xs_bytes : o_comb));
-    L.msc = reinterpret_cast<double*>(smem + o_msc);
-    L.wmax = reinterpret_cast<float*>(smem + o_wmax);
-    L.outb = reinterpret_cast<uint32_t*>(smem + o_outb);
-    L.cnt = reinterpret_cast<int*>(smem + o_cnt);
+    L.outb = reinterpret_cast<uint32_t*>(smem + LY::o_outb);
+    L.wmax = reinterpret_cast<float*>(smem + LY::o_wmax);
+    L.comb = reinterpret_cast<double*>(smem + (C::COMB_IN_XS1 ? (size_t)LY::xs_bytes : LY::o_comb));
+    L.msc = reinterpret_cast<double*>(smem + LY::o_msc);
+    L.cnt = reinterpret_cast<int*>(smem + LY::o_cnt);
     L.pub = L.cnt + 8;
     if (tid == 0) *L.cnt = 0;
     if (tid < 4) L.pub[tid] = 0;
     if (a.ws[1] != 0) return; /* an earlier launch timed out: nothing runs until the host has cleared the word (xengine_reset) */
     // ---- which decoder, which place in it: the XCD from the hardware register, a ticket there; with two decoders per XCD the first 32 tickets (the workgroups the
-    // dispatcher placed first: one per CU) are decoder 0, the next 32 decoder 1 -- sequences x and x + 8
-    XSeq S;
+    // dispatcher placed first: one per CU) are decoder 0, the next 32 decoder 1 -- sequences x and x + 8.  NB > 1: ONE decoder per XCD whose sequences are x + 8 b.
+    XSeq SS[NB];
+    XSeq& S = SS[0];
     int xcc;
     {
         int* xi = L.cnt + 1;
@@ -1185,13 +1381,47 @@ __global__ void __launch_bounds__(C::NWV * 64, (C::NWV * C::WPC + 3) / 4 /* wave
             }
         }
     };
-    const int epoch0 = a.ws[0];
+    const int epoch0 = a.epoch0; /* the generation of this launch's first step: counted by the host (xengine_steps), never written by the kernel -- a decoder whose sequences are
+                                    all parked leaves at once, and no workgroup may find the word already moved on */
     if (C::WPC == 2 && S.seq >= XE_NXCD && a.stagger_us > 0) { /* the second decoder of an XCD starts late: the two then stand in different phases, and one's hand-off waits and K / V streaming run
                                                                   under the other's mat-vec arithmetic (started together they stay in lockstep: same phase, same wait, no overlap) */
         const unsigned long long t1 = __builtin_amdgcn_s_memrealtime() + (unsigned long long)a.stagger_us * 100ull;
         while (__builtin_amdgcn_s_memrealtime() < t1) __builtin_amdgcn_s_sleep(8);
     }
-    if (S.seq >= a.n_seq) { /* a decoder without a sequence: its workgroups leave */
+    // ---- the decoder's sequences: which exist, are not parked ({token, pos, parked, status}: d_state[s][2] != 0) and stand inside their cache rows for every step of this launch.
+    // A sequence that does not is INACTIVE for the launch -- it touches nothing outside its own exchange area and says why in its own status word (d_state[s][3]: 64 = a
+    // position of the launch lies beyond the cache; ADVICE r05: one finished sequence must not stop the others) -- and a decoder without an active sequence leaves.
+    const int nst = a.n_steps > 1 ? a.n_steps : 1;
+    int pos0[NB];
+    bool any_act = false;
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        XSeq& Sb = SS[b];
+        Sb = S;
+        Sb.seq = S.seq + XE_NXCD * b;
+        Sb.sq = C::TP ? 0 : Sb.seq;
+        Sb.act = C::TP ? (Sb.seq < a.n_seq) : false;
+        pos0[b] = 0;
+        if (C::TP || Sb.seq < a.n_seq) {
+            const int p = a.d_state[Sb.sq * 4 + 1]; /* (TP: rank 0 moves the state on at the end of a step -- which no workgroup reaches before every workgroup has passed here) */
+            pos0[b] = p;
+            if constexpr (C::TP) {
+                if (p < 0 || p + nst > a.max_seq) { /* a position of this launch lies beyond the cache rows: refuse, loudly */
+                    if (tid == 0) atomicOr(a.ws + 1, 64);
+                    leave();
+                    return;
+                }
+            } else {
+                const bool parked = a.d_state[Sb.sq * 4 + 2] != 0;
+                const bool inside = p >= 0 && p + nst <= a.max_seq;
+                Sb.act = !parked && inside;
+                if (!parked && !inside && S.r == 0 && tid == 0) atomicOr(a.d_state + Sb.sq * 4 + 3, 64);
+            }
+        }
+        Sb.kv_off = C::TP ? 0 : (long long)Sb.seq * a.kv_seq_stride; /* TP: the rank's cache rows are in its layer table */
+        any_act = any_act || Sb.act;
+    }
+    if (!any_act) { /* a decoder without a sequence: its workgroups leave */
         leave();
         return;
     }
@@ -1202,47 +1432,46 @@ __global__ void __launch_bounds__(C::NWV * 64, (C::NWV * C::WPC + 3) / 4 /* wave
         for (int i = tid; i < nw; i += NWV * 64) dst[i] = src[i];
     }
     __syncthreads();
-    S.sq = C::TP ? 0 : S.seq;
-    S.kv_off = C::TP ? 0 : (long long)S.seq * a.kv_seq_stride; /* TP: the rank's cache rows are in its layer table */
     {
         const int s1_abs = S.r * P1::spg;
-        S.j1 = s1_abs >= P1::S2 ? 2 : (s1_abs >= P1::S1 ? 1 : 0);
-        S.s1 = s1_abs - (S.j1 == 0 ? 0 : (S.j1 == 1 ? P1::S1 : P1::S2));
-        S.M1 = S.j1 == 0 ? P1::M0 : (S.j1 == 1 ? P1::M1 : P1::M2);
-        S.q_out0 = (S.j1 == 0 ? 0 : (S.j1 == 1 ? C::QD : C::QD + C::KVD)) + S.s1 * P1::RPS;
-    }
-    {
+        const int j1 = s1_abs >= P1::S2 ? 2 : (s1_abs >= P1::S1 ? 1 : 0);
+        const int s1 = s1_abs - (j1 == 0 ? 0 : (j1 == 1 ? P1::S1 : P1::S2));
         const int per_kv = C::SPK * C::NG, idx = S.r % per_kv, grp = idx / C::SPK;
-        S.kvh = S.r / per_kv, S.split = idx - grp * C::SPK, S.h0 = S.kvh * C::GQ + grp * C::GQW, S.me0 = S.r * C::ME;
-        S.grp0 = grp == 0;
-    }
-    const int pos0 = a.d_state[S.sq * 4 + 1]; /* (TP: rank 0 moves the state on at the end of a step -- which no workgroup reaches before every workgroup has passed here) */
-    const int nst = a.n_steps > 1 ? a.n_steps : 1;
-    if (pos0 < 0 || pos0 + nst > a.max_seq) { /* a position of this launch lies beyond the cache rows: refuse, loudly */
-        if (tid == 0) atomicOr(a.ws + 1, 64);
-        return;
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            XSeq& Sb = SS[b];
+            Sb.j1 = j1, Sb.s1 = s1;
+            Sb.M1 = j1 == 0 ? P1::M0 : (j1 == 1 ? P1::M1 : P1::M2);
+            Sb.q_out0 = (j1 == 0 ? 0 : (j1 == 1 ? C::QD : C::QD + C::KVD)) + s1 * P1::RPS;
+            Sb.kvh = S.r / per_kv, Sb.split = idx - grp * C::SPK, Sb.h0 = Sb.kvh * C::GQ + grp * C::GQW, Sb.me0 = S.r * C::ME;
+            Sb.grp0 = grp == 0;
+        }
     }
     XRing<C::DEPTH> R;
     for (int step = 0; step < nst; step++) {
         const int epoch = epoch0 + step;
-        S.step = step, S.pos = pos0 + step, S.len = S.pos + 1;
-        S.stamp = C::DBG && a.dbg && S.seq == a.dbg_seq && S.r == a.dbg_wg && step < a.dbg_steps;
-        const int chunk = (((S.len + C::SPK - 1) / C::SPK) + 63) & ~63; /* keys per slice: the context cut into SPK pieces, whole 64-key runs */
-        S.t0 = S.split * chunk;
-        S.t1 = S.t0 + chunk < S.len ? S.t0 + chunk : S.len;
-        S.empty = S.t0 >= S.len;
-        S.own_new = S.pos >= S.t0 && S.pos < S.t1;
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            XSeq& Sb = SS[b];
+            Sb.step = step, Sb.pos = pos0[b] + step, Sb.len = Sb.pos + 1;
+            Sb.stamp = C::DBG && a.dbg && Sb.seq == a.dbg_seq && Sb.r == a.dbg_wg && step < a.dbg_steps;
+            const int chunk = (((Sb.len + C::SPK - 1) / C::SPK) + 63) & ~63; /* keys per slice: the context cut into SPK pieces, whole 64-key runs */
+            Sb.t0 = Sb.split * chunk;
+            Sb.t1 = Sb.t0 + chunk < Sb.len ? Sb.t0 + chunk : Sb.len;
+            Sb.empty = Sb.t0 >= Sb.len || !Sb.act;
+            Sb.own_new = Sb.act && Sb.pos >= Sb.t0 && Sb.pos < Sb.t1;
+            if (!Sb.act) Sb.pos = 0, Sb.len = 1, Sb.t0 = 0, Sb.t1 = 0;
+        }
         if (step > 0) { /* a step behind a timed-out one does not start */
             __syncthreads();
             if (tid == 0) L.cnt[3] = __hip_atomic_load(a.ws + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             if (L.cnt[3] != 0) break;
         }
-        if (wave == NWV - 1) xe_poller_main<C>(a, L, S, epoch, lane);
-        else xe_compute_main<C>(a, L, S, epoch, wave, lane, R);
-        if (a.head_w) xe_head_main<C>(a, L, S, epoch, step + 1 < nst, wave, lane);
+        if (wave == NWV - 1) xe_poller_main<C>(a, L, SS, epoch, lane);
+        else xe_compute_main<C>(a, L, SS, epoch, wave, lane, R);
+        if (a.head_w) xe_head_main<C>(a, L, SS, epoch, step + 1 < nst, wave, lane);
     }
-    if (S.seq == 0 && S.r == 0 && tid == 0) a.ws[0] = epoch0 + nst; /* the next launch's generation (every decoder advances by the same number of steps; every workgroup read it long ago) */
     leave();
 }
 
@@ -1257,6 +1486,9 @@ struct XEngineHost {
     int nwv, depth; /* the instantiation in use */
     int deal_wl;    /* 0: the form's default (xengine_go) */
     size_t tp_bytes; /* TP: bytes of the receive + pick areas behind the exchange areas (reset with them) */
+    int epoch;       /* the generation the next launch starts at (XArgs::epoch0) */
+    int batch;       /* sequences per decoder of the form in use (XCfg::NB): 1, 2 or 4 */
+    int two_wpc;     /* n_seq 9 .. 16 through the round-5 form (two decoders per XCD, two workgroups per CU) instead of the batched one: A/B hook */
 };
 
 static int xe_shape_class(int GQ, int hd, int dim, int q_dim, int ffn) {
@@ -1270,10 +1502,10 @@ static int xe_shape_class(int GQ, int hd, int dim, int q_dim, int ffn) {
 }
 template <int NWV, int DEPTH, bool DBG, int WPC, int AU = 2>
 using XC3 = XCfg<FMT_Q4P, 2, 128, NWV, 2048, 2048, 1024, 6144, DEPTH, DBG, WPC, AU>;
-template <int NWV, int DEPTH, bool DBG, int WPC, int AU = 2>
-using XC1 = XCfg<FMT_Q4P, 2, 128, NWV, 1024, 2048, 1024, 3072, DEPTH, DBG, WPC, AU>;
-template <int NWV, int DEPTH, bool DBG, int WPC, int AU = 2>
-using XC2 = XCfg<FMT_Q4P, 2, 64, NWV, 256, 256, 128, 512, DEPTH, DBG, WPC, AU>;
+template <int NWV, int DEPTH, bool DBG, int WPC, int AU = 2, int NB = 1>
+using XC1 = XCfg<FMT_Q4P, 2, 128, NWV, 1024, 2048, 1024, 3072, DEPTH, DBG, WPC, AU, false, NB>;
+template <int NWV, int DEPTH, bool DBG, int WPC, int AU = 2, int NB = 1>
+using XC2 = XCfg<FMT_Q4P, 2, 64, NWV, 256, 256, 128, 512, DEPTH, DBG, WPC, AU, false, NB>;
 // the GQA-4 shapes: one decoder per XCD, 8 waves (two per SIMD: 256 registers -- the attention sums of four query heads are 36 fp64 values per lane)
 using XC4 = XCfg<FMT_Q4P, 4, 128, 8, 2560, 4096, 1024, 9728, 8, false, 1, 2>;
 using XC5 = XCfg<FMT_Q4P, 4, 128, 8, 4096, 4096, 1024, 12288, 8, false, 1, 2>;
@@ -1295,6 +1527,8 @@ static bool xe_class_fused(int sc); /* below the shape aliases */
 static size_t xe_smem_class3_two(int n_layer);
 template <class C>
 static size_t xe_smem(int n_layer);
+template <template <int, int, bool, int, int, int> class XC>
+static size_t xe_shape_smem(int n_seq, int n_layer, bool two_wpc);
 // FUSED shapes (XCfg::FUSED): q | k | v of a layer as ONE matrix -- blocks, then the zero words, then the step words of the QD + 2 KVD rows -- copied once into the workspace
 static size_t xe_fused_layer_bytes(const kf_engine_desc* d) {
     const size_t rows = (size_t)(d->n_head + 2 * d->n_kv) * d->head_dim, nblk = d->dim / 32, grp = d->dim / 128;
@@ -1340,8 +1574,9 @@ static int xengine_init_state(XEngineHost* E, hipStream_t st) {
     if (E->tp_bytes && hipMemsetAsync(a.tp_recv, 0xff, E->tp_bytes, st) != hipSuccess) return KF_HIP_CHECK;
     static int init[16 + 32 * XE_NXCD];
     memset(init, 0, sizeof(init));
-    init[0] = 1; /* epoch 1, no error, tickets zero */
+    init[0] = 1; /* no error, tickets zero */
     if (hipMemcpyAsync(a.ws, init, sizeof(init), hipMemcpyHostToDevice, st) != hipSuccess) return KF_HIP_CHECK;
+    E->epoch = 1;
     return KF_OK;
 }
 void xengine_free(XEngineHost* E) {
@@ -1391,6 +1626,14 @@ int xengine_build(const kf_engine_desc* d, int n_seq, long long kv_seq_stride, v
     if (!sc) return KF_UNSUPPORTED_DATATYPE;
     *why = "the GQA-4 / GQA-8 shapes (Qwen3-4B / 8B, the 8-on-1 test shape) run one decoder per XCD: at most 8 sequences (two workgroups per CU would need 2 x 78 KB (2 x 98 KB) of activations in LDS)";
     if (sc >= 4 && n_seq > XE_NXCD) return KF_UNSUPPORTED_DATATYPE;
+    *why = "more than 16 sequences (four per decoder) are served for the Qwen3-0.6B shape and the 256-wide test shape only";
+    if (sc == 3 && n_seq > 2 * XE_NXCD) return KF_UNSUPPORTED_DATATYPE;
+    *why = "the model is too deep for this many sequences: the workgroup's activations of every sequence of a decoder + the layer table must fit 160 KB of LDS";
+    if (sc == 1 && xe_shape_smem<XC1>(n_seq, d->n_layer, false) > 160 * 1024) return KF_UNSUPPORTED_DATATYPE;
+    if (sc == 2 && xe_shape_smem<XC2>(n_seq, d->n_layer, false) > 160 * 1024) return KF_UNSUPPORTED_DATATYPE;
+    if (sc == 4 && xe_smem<XC4W>(d->n_layer) > 160 * 1024) return KF_UNSUPPORTED_DATATYPE;
+    if (sc == 5 && xe_smem<XC5W>(d->n_layer) > 160 * 1024) return KF_UNSUPPORTED_DATATYPE;
+    if (sc == 3 && n_seq <= XE_NXCD && xe_smem<XC3<12, 6, false, 1>>(d->n_layer) > 160 * 1024) return KF_UNSUPPORTED_DATATYPE;
     *why = "two decoders per XCD (more than 8 sequences) do not fit this shape and depth: two workgroups per CU need 2 x the activations + the layer table in 160 KB of LDS";
     if (sc == 3 && n_seq > XE_NXCD && 2 * xe_smem_class3_two(d->n_layer) > 160 * 1024) return KF_UNSUPPORTED_DATATYPE;
     if (!dry && (ws_bytes < xengine_ws_bytes(d) || ((uintptr_t)ws & 255) != 0)) {
@@ -1555,24 +1798,16 @@ int xengine_set_head_tp(XEngineHost* E, const kf_weight* const* ws, const int* r
 }
 template <class C>
 static size_t xe_smem(int n_layer) {
-    constexpr int hd = C::HD, GQ = C::GQW, NCW = C::NCW;
-    constexpr int maxK = C::DIM > C::QD ? (C::DIM > C::FFN ? C::DIM : C::FFN) : (C::QD > C::FFN ? C::QD : C::FFN);
-    constexpr int xs_bytes = (maxK * 4 + 15) & ~15, xr_bytes = (C::DIM * 2 + 15) & ~15;
-    constexpr size_t o_attn = (size_t)2 * xs_bytes + 2 * xr_bytes;
-    constexpr size_t o_comb = (o_attn + sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + 15) & ~(size_t)15;
-    constexpr size_t o_msc = o_comb + (C::COMB_IN_XS1 ? 0 : sizeof(double) * (size_t)NCW * GQ * (hd + 2));
-    constexpr size_t o_wmax = o_msc + sizeof(double) * ((size_t)C::ME * C::SPK) + 4 * 64 + 4 * 128;
-    constexpr size_t o_outb = o_wmax + 4 * 2 * 16;
-    constexpr size_t o_cnt = o_outb + 4 * (size_t)((C::maxR + 63) & ~63);
-    constexpr size_t fixed_bytes = (o_cnt + 64 + 15) & ~(size_t)15;
-    return fixed_bytes + (((size_t)n_layer * sizeof(EngLayer) + 15) & ~(size_t)15);
+    return XLay<C>::fixed_bytes + (((size_t)n_layer * sizeof(EngLayer) + 15) & ~(size_t)15);
 }
 template <class C>
 static int xengine_go(XEngineHost* E, hipStream_t st) {
-    static int ready = 0;
-    if (!ready) {
+    static unsigned long long ready = 0; /* bit d: the attribute is set on device d (it is per device: ADVICE r05) */
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return KF_HIP_CHECK;
+    if (dev < 0 || dev >= 64 || !((ready >> dev) & 1ull)) {
         if (hipFuncSetAttribute((const void*)xengine_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return KF_HIP_CHECK;
-        ready = 1;
+        if (dev >= 0 && dev < 64) ready |= 1ull << dev;
     }
     size_t smem = xe_smem<C>(E->args.n_layer);
     if (C::WPC == 2 && smem < 54 * 1024) smem = 54 * 1024; /* two workgroups per CU, never three: a third would be a workgroup of some decoder queued behind its own peers */
@@ -1585,29 +1820,44 @@ static int xengine_go(XEngineHost* E, hipStream_t st) {
 #define XE_VARIANTS 1 /* the tuning instantiations (waves per workgroup x ring depth) beside the defaults.  Measured and dropped (ms per step of eight sequences at 2 k keys, default
                          12 x 6: 1.89): 13 x 6 2.22, 16 x 4 2.17 (128 registers: spills), four key tiles per attention batch 2.29 - 2.37 (spills) */
 #endif
-// n_seq <= 8: one decoder per XCD, 9 waves (8 compute + the poller; 168 registers); more: two per XCD, two workgroups of 8 waves per CU (128 registers)
-template <template <int, int, bool, int, int> class XC>
+// n_seq <= 8: one decoder per XCD (12 waves, 168 registers), one sequence each.  More: the BATCHED form (round 6) -- still one decoder per XCD, every unpacked block multiplied
+// against the activations of 2 (n_seq <= 16) or 4 (n_seq <= 32) sequences.  The round-5 form of 9 .. 16 sequences (two decoders per XCD, two workgroups of 8 waves per CU,
+// 128 registers) stays behind XEngineHost::two_wpc as the A/B reference.
+static int xe_batch_of(const XEngineHost* E) { return E->args.n_seq <= XE_NXCD ? 1 : ((E->args.n_seq <= 2 * XE_NXCD) ? (E->two_wpc ? 1 : 2) : 4); }
+template <template <int, int, bool, int, int, int> class XC>
 static int xengine_go_shape(XEngineHost* E, hipStream_t st) {
-    const bool two = E->args.n_seq > XE_NXCD;
+    const int nb = xe_batch_of(E);
+    const bool two = E->args.n_seq > XE_NXCD && nb == 1;
 #ifndef XE_ONLY_DEFAULT
     const bool dbg = E->args.dbg != nullptr;
-    if (dbg) return two ? xengine_go<XC<8, 4, true, 2, 1>>(E, st) : xengine_go<XC<9, 8, true, 1, 2>>(E, st);
+    if (dbg && nb == 2) return xengine_go<XC<12, 6, true, 1, 2, 2>>(E, st);
+    if (dbg && nb == 1) return two ? xengine_go<XC<8, 4, true, 2, 1, 1>>(E, st) : xengine_go<XC<9, 8, true, 1, 2, 1>>(E, st);
 #endif
+    if (nb == 4) {
+        if (E->nwv == 8) return xengine_go<XC<8, 8, false, 1, 2, 4>>(E, st);
+        return xengine_go<XC<12, 6, false, 1, 2, 4>>(E, st);
+    }
+    if (nb == 2) {
+        if (E->nwv == 8) return xengine_go<XC<8, 8, false, 1, 2, 2>>(E, st);
+        if (E->nwv == 12 && E->depth == 8) return xengine_go<XC<12, 8, false, 1, 2, 2>>(E, st);
+        return xengine_go<XC<12, 6, false, 1, 2, 2>>(E, st);
+    }
 #if XE_VARIANTS && !defined(XE_ONLY_DEFAULT)
     if (!two) {
-        if (E->nwv == 8 && E->depth == 8) return xengine_go<XC<8, 8, false, 1, 2>>(E, st);
-        if (E->nwv == 12 && E->depth == 6) return xengine_go<XC<12, 6, false, 1, 2>>(E, st);
-        if (E->nwv == 12 && E->depth == 8) return xengine_go<XC<12, 8, false, 1, 2>>(E, st);
-        if (E->nwv == 9 && E->depth == 6) return xengine_go<XC<9, 6, false, 1, 2>>(E, st);
-    } else {
+        if (E->nwv == 8 && E->depth == 8) return xengine_go<XC<8, 8, false, 1, 2, 1>>(E, st);
+        if (E->nwv == 12 && E->depth == 8) return xengine_go<XC<12, 8, false, 1, 2, 1>>(E, st);
+        if (E->nwv == 9 && E->depth == 6) return xengine_go<XC<9, 6, false, 1, 2, 1>>(E, st);
     }
 #endif
-    if (!two && E->nwv == 12) return xengine_go<XC<12, 6, false, 1, 2>>(E, st);
-    if (two && E->nwv == 88) return xengine_go<XC<8, 8, false, 2, 2>>(E, st);
-    if (two && E->nwv == 82) return xengine_go<XC<8, 4, false, 2, 2>>(E, st);
-    if (two && E->nwv == 86) return xengine_go<XC<8, 6, false, 2, 1>>(E, st);
-    if (two && E->nwv == 81) return xengine_go<XC<8, 8, false, 2, 1>>(E, st);
-    return two ? xengine_go<XC<8, 4, false, 2, 1>>(E, st) : xengine_go<XC<9, 8, false, 1, 2>>(E, st);
+    if (!two && E->nwv == 12) return xengine_go<XC<12, 6, false, 1, 2, 1>>(E, st);
+    return two ? xengine_go<XC<8, 4, false, 2, 1, 1>>(E, st) : xengine_go<XC<9, 8, false, 1, 2, 1>>(E, st);
+}
+// the LDS the chosen form needs (classes 1 and 2), so that create / served can refuse a model too deep for it instead of the first step
+template <template <int, int, bool, int, int, int> class XC>
+static size_t xe_shape_smem(int n_seq, int n_layer, bool two_wpc) {
+    if (n_seq <= XE_NXCD) return xe_smem<XC<12, 6, false, 1, 2, 1>>(n_layer);
+    if (n_seq <= 2 * XE_NXCD) return two_wpc ? 2 * (xe_smem<XC<8, 4, false, 2, 1, 1>>(n_layer) < 54 * 1024 ? (size_t)54 * 1024 : xe_smem<XC<8, 4, false, 2, 1, 1>>(n_layer)) : xe_smem<XC<12, 6, false, 1, 2, 2>>(n_layer);
+    return xe_smem<XC<12, 6, false, 1, 2, 4>>(n_layer);
 }
 // n_steps decode steps of every sequence in ONE launch; with_head: 0 layers only (x_out), 1 + logits, 2 + greedy pick and state update (needed for n_steps > 1)
 int xengine_steps(XEngineHost* E, hipStream_t st, int32_t* d_state, uint16_t* x_out, int with_head, int n_steps) {
@@ -1616,6 +1866,7 @@ int xengine_steps(XEngineHost* E, hipStream_t st, int32_t* d_state, uint16_t* x_
     if (with_head && !a.head_w) return KF_INVALID_ARGS;
     XArgs save = a;
     a.d_state = d_state, a.x_out = x_out, a.n_steps = n_steps, a.pick = with_head == 2 ? 1 : 0;
+    a.epoch0 = E->epoch, E->epoch += n_steps; /* generations never repeat between resets (a 31-bit count of steps) */
     if (!with_head) a.head_w = nullptr;
     int rc;
     if (E->shape_class == 3) /* the default instantiations only (no tuning variants, no stamps) */
@@ -1649,7 +1900,8 @@ int xengine_set_embedding(XEngineHost* E, const kf_weight* w, const int32_t* d_f
 }
 int xengine_set_head(XEngineHost* E, const kf_weight* w, const uint16_t* norm_w, uint16_t* logits, int32_t* d_tokens_out, int tokens_stride) {
     XArgs& a = E->args;
-    if (!w) {
+    if (E->shape_class == 7) return KF_INVALID_ARGS; /* a TP engine takes its head in vocabulary shards: kf_xengine_set_head_tp */
+    if (!w) { /* no head: kf_xengine_steps then refuses (every step of the ABI ends in the head); kept so that a head can be taken away before its weight is freed */
         a.head_w = nullptr, a.head_norm = nullptr, a.logits = nullptr, a.d_tokens_out = nullptr, a.vocab = 0;
         return KF_OK;
     }
@@ -1678,6 +1930,10 @@ void xengine_set_variant(XEngineHost* E, int nwv, int depth) {
     }
     if (nwv == -1) { /* tuning hook: depth = XArgs::deal_wl (0: the default of the form) */
         E->deal_wl = depth;
+        return;
+    }
+    if (nwv == -2) { /* A/B hook: depth != 0 = 9 .. 16 sequences through the round-5 form (two decoders per XCD) instead of the batched one */
+        E->two_wpc = depth != 0;
         return;
     }
     E->nwv = nwv, E->depth = depth;

@@ -406,6 +406,7 @@ void Fish::DropEngineTable() {
     engine_state = 0, engine_embed = engine_head = false;
 }
 void Fish::DropEngine() {
+    weights_gen++; /* what XcdReplicas / XcdTP objects built on this Fish compare their own copy with */
     DropEngineTable();
     bucket_tuned.clear(); /* the measured delays belonged to that engine */
     DropResident(); /* the resident bf16 copies are keyed by the old tensors' addresses too */
@@ -802,9 +803,10 @@ size_t XcdReplicas::kv_seq_elems() const {
     const MODEL_CARD& c = hFish->config;
     return (size_t)c.nLayer * c.n_ctx * c.n_head_kv * c.head_dim;
 }
-int XcdReplicas::Build(Fish* f, int n_seq_) {
-    if (!f || n_seq_ < 1 || n_seq_ > KF_XENGINE_MAX_SEQ) return KF_INVALID_ARGS;
-    hFish = f, n_seq = n_seq_;
+// the engine over the Fish's weights AS THEY ARE NOW (their device addresses go into the engine's layer table; the GQA-4 forms copy q | k | v): called by Build, and again by
+// the first use after the Fish's weights changed (kfh_weights_changed / a weight set again: Fish::weights_gen) -- a decode through this object never reads stale weights
+int XcdReplicas::MakeEngine(bool allocate) {
+    Fish* f = hFish;
     kf_ctx* ctx = f->ctx;
     const MODEL_CARD& c = f->config;
     const int kvd = c.n_head_kv * c.head_dim;
@@ -849,28 +851,33 @@ int XcdReplicas::Build(Fish* f, int n_seq_) {
         why = "embedding / head / final norm missing";
         return KF_ENGINE_NOT_SERVED;
     }
-    // per sequence: K / V cache, state, forced ids, ids out, logits, residual stream
     const size_t seq_elems = kv_seq_elems();
-    key = GT(ctx, "xr.key", typNUMBER::BF16, kvd, c.n_ctx * c.nLayer * n_seq);
-    val = GT(ctx, "xr.val", typNUMBER::BF16, kvd, c.n_ctx * c.nLayer * n_seq);
-    logits = GT(ctx, "xr.logits", typNUMBER::BF16, c.vocab, n_seq);
-    x = GT(ctx, "xr.x", typNUMBER::BF16, c.nEmbed, n_seq);
-    if (!key || !val || !logits || !x) return KF_OUTOF_GPUMEMORY;
-    KF_TRY(kf_memset(ctx, key->data, 0, seq_elems * n_seq * 2));
-    KF_TRY(kf_memset(ctx, val->data, 0, seq_elems * n_seq * 2));
-    KF_TRY(kf_malloc(ctx, (size_t)n_seq * 16, (void**)&d_state));
-    KF_TRY(kf_malloc(ctx, (size_t)n_seq * c.n_ctx * 4, (void**)&d_forced));
-    KF_TRY(kf_malloc(ctx, (size_t)n_seq * c.n_ctx * 4, (void**)&d_tokens_out));
-    KF_TRY(kf_memset(ctx, d_state, 0, (size_t)n_seq * 16));
-    KF_TRY(kf_memset(ctx, d_forced, 0xff, (size_t)n_seq * c.n_ctx * 4));
-    KF_TRY(kf_memset(ctx, d_tokens_out, 0, (size_t)n_seq * c.n_ctx * 4));
+    if (allocate) { // per sequence: K / V cache, state {token, pos, parked, status}, forced ids, ids out, logits, residual stream
+        key = GT(ctx, "xr.key", typNUMBER::BF16, kvd, c.n_ctx * c.nLayer * n_seq);
+        val = GT(ctx, "xr.val", typNUMBER::BF16, kvd, c.n_ctx * c.nLayer * n_seq);
+        logits = GT(ctx, "xr.logits", typNUMBER::BF16, c.vocab, n_seq);
+        x = GT(ctx, "xr.x", typNUMBER::BF16, c.nEmbed, n_seq);
+        if (!key || !val || !logits || !x) return KF_OUTOF_GPUMEMORY;
+        KF_TRY(kf_memset(ctx, key->data, 0, seq_elems * n_seq * 2));
+        KF_TRY(kf_memset(ctx, val->data, 0, seq_elems * n_seq * 2));
+        KF_TRY(kf_malloc(ctx, (size_t)n_seq * 16, (void**)&d_state));
+        KF_TRY(kf_malloc(ctx, (size_t)n_seq * c.n_ctx * 4, (void**)&d_forced));
+        KF_TRY(kf_malloc(ctx, (size_t)n_seq * c.n_ctx * 4, (void**)&d_tokens_out));
+        KF_TRY(kf_memset(ctx, d_state, 0, (size_t)n_seq * 16));
+        KF_TRY(kf_memset(ctx, d_forced, 0xff, (size_t)n_seq * c.n_ctx * 4));
+        KF_TRY(kf_memset(ctx, d_tokens_out, 0, (size_t)n_seq * c.n_ctx * 4));
+    }
     for (int l = 0; l < c.nLayer; l++) {
         L[l].kcache = ToX(key) + (size_t)l * c.n_ctx * kvd;
         L[l].vcache = ToX(val) + (size_t)l * c.n_ctx * kvd;
     }
     const size_t bytes = kf_xengine_workspace_bytes(&d);
-    KF_TRY(kf_malloc(ctx, bytes, &engine_ws));
-    int rc = kf_xengine_create(ctx, &d, n_seq, (int64_t)seq_elems, engine_ws, bytes, &engine);
+    if (!engine_ws || bytes > engine_ws_bytes) {
+        if (engine_ws) kf_free(ctx, engine_ws), engine_ws = nullptr;
+        KF_TRY(kf_malloc(ctx, bytes, &engine_ws));
+        engine_ws_bytes = bytes;
+    }
+    int rc = kf_xengine_create(ctx, &d, n_seq, (int64_t)seq_elems, engine_ws, engine_ws_bytes, &engine);
     if (rc != KF_OK) {
         why = kf_last_error();
         return rc;
@@ -882,7 +889,22 @@ int XcdReplicas::Build(Fish* f, int n_seq_) {
         why = "the embedding table and the LM head must be bf16 (read inside the launch)";
         return rc == KF_UNSUPPORTED_DATATYPE ? KF_ENGINE_NOT_SERVED : rc;
     }
+    built_gen = f->weights_gen;
     return KF_OK;
+}
+int XcdReplicas::Build(Fish* f, int n_seq_) {
+    if (!f || n_seq_ < 1 || n_seq_ > KF_XENGINE_MAX_SEQ) return KF_INVALID_ARGS;
+    hFish = f, n_seq = n_seq_;
+    return MakeEngine(true);
+}
+int XcdReplicas::Fresh() {
+    if (engine && built_gen == hFish->weights_gen) return KF_OK;
+    kf_ctx* ctx = hFish->ctx;
+    if (engine) {
+        KF_TRY(kf_sync(ctx));
+        kf_xengine_destroy(engine), engine = nullptr;
+    }
+    return MakeEngine(false); /* caches, states, forced ids and ids out stay: the sequences go on where they stand, on the new weights */
 }
 int XcdReplicas::SetForced(int seq, const int32_t* ids, int n) {
     if (seq < 0 || seq >= n_seq || n < 0 || n > hFish->config.n_ctx) return KF_INVALID_ARGS;
@@ -892,7 +914,20 @@ int XcdReplicas::SetForced(int seq, const int32_t* ids, int n) {
 }
 int XcdReplicas::SetState(int seq, int token, int pos) {
     if (seq < 0 || seq >= n_seq || pos < 0 || pos >= hFish->config.n_ctx || token < 0 || token >= hFish->config.vocab) return KF_INVALID_ARGS;
+    const int32_t zero = 0;
+    KF_TRY(kf_h2d(hFish->ctx, d_state + 4 * seq + 3, &zero, 4)); /* the status word of the re-aimed sequence */
     return kf_set_state(hFish->ctx, d_state + 4 * seq, token, pos);
+}
+// A parked sequence is skipped by the launches (the others decode on); its cache, state and ids stay.  Status: 0, or 64 = the last launch would have left the
+// sequence's cache rows and skipped it (kf_abi.h: d_state [n_seq][4] = {token, pos, parked, status}).
+int XcdReplicas::Park(int seq, bool on) {
+    if (seq < 0 || seq >= n_seq) return KF_INVALID_ARGS;
+    const int32_t v = on ? 1 : 0;
+    return kf_h2d(hFish->ctx, d_state + 4 * seq + 2, &v, 4);
+}
+int XcdReplicas::Status(int seq, int32_t* out4) {
+    if (seq < 0 || seq >= n_seq || !out4) return KF_INVALID_ARGS;
+    return kf_d2h(hFish->ctx, out4, d_state + 4 * seq, 16);
 }
 // The prompt half of "prefill + decode" for one of the sequences: the model's own batched prefill (Fish::Prefill: the reference prefills token by token through the decode
 // path, GoPT.cpp:1139-1146), then the prompt's K / V rows of every layer move into the sequence's cache and the sequence stands at {first generated id, n}.
@@ -900,6 +935,7 @@ int XcdReplicas::Prefill(int seq, const int* tokens, int n) {
     const MODEL_CARD& c = hFish->config;
     if (seq < 0 || seq >= n_seq || !tokens || n < 1 || n >= c.n_ctx) return KF_INVALID_ARGS;
     kf_ctx* ctx = hFish->ctx;
+    KF_TRY(Fresh());
     KF_TRY(hFish->Prefill(tokens, n, 0));
     const int kvd = c.n_head_kv * c.head_dim;
     const size_t seq_elems = kv_seq_elems();
@@ -909,11 +945,13 @@ int XcdReplicas::Prefill(int seq, const int* tokens, int n) {
         KF_TRY(kf_d2d(ctx, ToX(val) + off, hFish->cache.Get(KVCache::KV_VAL, l, 0), (size_t)n * kvd * 2));
     }
     KF_TRY(kf_d2d(ctx, d_state + 4 * seq, hFish->d_state, 8));                                                   /* {the id picked behind the prompt, n} */
+    KF_TRY(kf_memset(ctx, d_state + 4 * seq + 3, 0, 4));                                                         /* status: clear */
     KF_TRY(kf_d2d(ctx, d_tokens_out + (size_t)seq * c.n_ctx + (n - 1), hFish->d_tokens_out + (n - 1), 4));      /* ids out: position n - 1 holds that id, as after decode steps */
     return KF_OK;
 }
 int XcdReplicas::RunSteps(int n) {
-    if (!engine || n < 1) return KF_INVALID_ARGS;
+    if (n < 1) return KF_INVALID_ARGS;
+    KF_TRY(Fresh());
     for (int i = 0; i < n;) {
         const int m = n - i < steps_per_launch ? n - i : steps_per_launch;
         KF_TRY(kf_xengine_steps(hFish->ctx, engine, ToX(x), d_state, m, 1));
@@ -1026,6 +1064,8 @@ int XcdTP::Build(Fish** fs, int world) {
         why = kf_last_error();
         return rc == KF_UNSUPPORTED_DATATYPE ? KF_ENGINE_NOT_SERVED : rc;
     }
+    built_gen.clear();
+    for (int r = 0; r < world; r++) built_gen.push_back(fs[r]->weights_gen);
     return KF_OK;
 }
 int XcdTP::SetForced(const int32_t* ids, int n) {
@@ -1041,6 +1081,11 @@ int XcdTP::SetState(int token, int pos) {
 }
 int XcdTP::RunSteps(int n) {
     if (!engine || n < 1) return KF_INVALID_ARGS;
+    for (size_t r = 0; r < ranks.size(); r++)
+        if (r >= built_gen.size() || ranks[r]->weights_gen != built_gen[r]) { /* never a step on stale shards (the engine's tables and its fused q | k | v copy are of the old weights) */
+            why = "a rank's weights changed since this engine was built (kfh_weights_changed / a weight set again): destroy it and create it again";
+            return KF_INVALID_ARGS;
+        }
     for (int i = 0; i < n;) {
         const int m = n - i < steps_per_launch ? n - i : steps_per_launch;
         KF_TRY(kf_xengine_steps(ranks[0]->ctx, engine, ToX(x), d_state, m, 1));
@@ -1443,6 +1488,8 @@ int kfh_xr_set_state(void* h, int seq, int token, int pos) { return reinterpret_
 int kfh_xr_prefill(void* h, int seq, const int* tokens, int n) { return reinterpret_cast<XcdReplicas*>(h)->Prefill(seq, tokens, n); }
 int kfh_xr_run_steps(void* h, int n) { return reinterpret_cast<XcdReplicas*>(h)->RunSteps(n); }
 int kfh_xr_check(void* h) { return reinterpret_cast<XcdReplicas*>(h)->Check(); }
+int kfh_xr_park(void* h, int seq, int on) { return reinterpret_cast<XcdReplicas*>(h)->Park(seq, on != 0); }
+int kfh_xr_status(void* h, int seq, int32_t* out4) { return reinterpret_cast<XcdReplicas*>(h)->Status(seq, out4); }
 int kfh_xr_set_steps_per_launch(void* h, int n) {
     if (n < 1 || n > 4096) return KF_INVALID_ARGS;
     reinterpret_cast<XcdReplicas*>(h)->steps_per_launch = n;

@@ -225,6 +225,7 @@ struct Fish {
     kf_engine* engine = nullptr;
     void* engine_ws = nullptr;
     int engine_state = 0;  // 0 not tried, 1 built, -1 not served
+    unsigned weights_gen = 0;  // counts DropEngine calls (a weight set again, kfh_weights_changed): engines other objects built on this Fish compare it with their own copy
     bool engine_embed = false;  // the engine reads the (bf16) embedding row itself
     bool engine_head = false;   // ... and runs the final norm, the (bf16) LM head and the greedy pick as trailing phases of its launch
     int masked_layers = 0;      // layers with a hot-row mask (kfh_set_hot): the engine walks dense FFNs only
@@ -291,14 +292,20 @@ struct XcdReplicas {
     void* engine_ws = nullptr;
     hGTensor key, val;      // [n_seq][n_layer][n_ctx][kv_dim] bf16
     hGTensor logits, x;     // [n_seq][vocab], [n_seq][nEmbed]
-    int32_t* d_state = nullptr;       // [n_seq][4]: {token, pos, -, -}
+    int32_t* d_state = nullptr;       // [n_seq][4]: {token, pos, parked, status}
     int32_t* d_forced = nullptr;      // [n_seq][n_ctx], -1 = free running
     int32_t* d_tokens_out = nullptr;  // [n_seq][n_ctx]
     std::string why;        // why the model is not served, "" when it is
     int steps_per_launch = 32;
     long long steps_run = 0;
+    size_t engine_ws_bytes = 0;
+    unsigned built_gen = 0;  // Fish::weights_gen the engine was built on
     ~XcdReplicas();
     int Build(Fish* f, int n_seq_);
+    int MakeEngine(bool allocate);
+    int Fresh();          // re-creates the engine when the Fish's weights changed since it was built (kfh_weights_changed, a weight set again)
+    int Park(int seq, bool on);
+    int Status(int seq, int32_t* out4);
     int SetForced(int seq, const int32_t* ids, int n);
     int SetState(int seq, int token, int pos);
     int Prefill(int seq, const int* tokens, int n);  // the sequence's prompt through Fish::Prefill (token batches on the tile kernels), its K / V rows into the sequence's cache; the sequence then stands behind the prompt
@@ -321,6 +328,7 @@ struct XcdTP {
     int vocab = 0;
     std::string why;
     int steps_per_launch = 16;
+    std::vector<unsigned> built_gen;  // the ranks' Fish::weights_gen at Build: a rank whose weights changed since makes RunSteps refuse (the engine holds a fused copy of q | k | v)
     ~XcdTP();
     int Build(Fish** fs, int world);
     int SetForced(const int32_t* ids, int n);

@@ -654,6 +654,23 @@ class XcdReplicas:
     def check(self):
         L.check(self.host.kfh_xr_check(self.h), "kfh_xr_check")
 
+    @property
+    def batch(self):
+        """sequences per decoder of the form the engine launches: 1 (<= 8 sequences), 2 (<= 16) or 4 (<= 32): every unpacked block is multiplied against that many sequences' activations"""
+        return 1 if self.n_seq <= 8 else (2 if self.n_seq <= 16 else 4)
+
+    decoders_per_xcd = 1
+
+    def park(self, seq, on=True):
+        """a parked sequence is skipped by the launches; the others decode on"""
+        L.check(self.host.kfh_xr_park(self.h, int(seq), int(bool(on))), "kfh_xr_park")
+
+    def status(self, seq):
+        """{token, pos, parked, status} of the sequence (status 64: the last launch would have left its cache rows and skipped it)"""
+        out = np.zeros(4, dtype=np.int32)
+        L.check(self.host.kfh_xr_status(self.h, int(seq), out.ctypes.data_as(C.c_void_p)), "kfh_xr_status")
+        return [int(v) for v in out]
+
     def state(self, seq):
         out = np.zeros(2, dtype=np.int32)
         L.check(self.host.kfh_xr_get_state(self.h, int(seq), out.ctypes.data_as(C.c_void_p)), "kfh_xr_get_state")

@@ -43,21 +43,25 @@ def _oracle_run(cfg, raw, forced, n, pos0=0):
     return ids, logits, k, v
 
 
-@pytest.mark.parametrize("cfg_name,max_seq,n_steps,n_seq,spl", [("tiny", 96, 90, 8, 7), ("small", 320, 150, 8, 32), ("tiny", 700, 300, 3, 16), ("small", 320, 150, 16, 32), ("tiny", 700, 200, 11, 9)])
-def test_every_sequence_equals_the_oracle(canon, cfg_name, max_seq, n_steps, n_seq, spl):
+@pytest.mark.parametrize("cfg_name,max_seq,n_steps,n_seq,spl,form", [("tiny", 96, 90, 8, 7, 0), ("small", 320, 150, 8, 32, 0), ("tiny", 700, 300, 3, 16, 0), ("small", 320, 150, 16, 32, 0),
+                                                                      ("tiny", 700, 200, 11, 9, 0), ("small", 320, 150, 32, 32, 0), ("tiny", 700, 200, 27, 9, 0), ("small", 320, 150, 16, 32, 1),
+                                                                      ("tiny", 700, 200, 11, 9, 1)])
+def test_every_sequence_equals_the_oracle(canon, cfg_name, max_seq, n_steps, n_seq, spl, form):
     """different prompts per sequence (the first 12 .. 40 ids forced, then free running), several steps per launch: ids at every position, the last logits and all K / V rows
-    of every sequence against the oracle run on that sequence alone; n_seq < 8 leaves XCDs idle, n_seq > 8 runs TWO decoders per XCD (two workgroups per CU; 11: the second
-    decoder of five XCDs idles)"""
+    of every sequence against the oracle run on that sequence alone; n_seq < 8 leaves XCDs idle; n_seq > 8 (round 6): every decoder multiplies each unpacked block against 2
+    (<= 16) or 4 (<= 32) sequences' activations (11, 27: some decoders carry one sequence fewer); form 1: the round-5 form of 9 .. 16 sequences, two decoders per XCD"""
     cfg = dict(synth.CONFIGS[cfg_name], max_seq=max_seq)
     raw = synth.raw_weights_numpy(cfg, 4321, w_std=0.1)
     m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
     m.set_canonical(True)
     xr = XcdReplicas(m, n_seq)
+    if form:
+        xr.variant(-2, 1)
     xr.set_steps_per_launch(spl)
     forced = []
     for s in range(n_seq):
         f = np.full(max_seq, -1, dtype=np.int32)
-        npr = 12 + 4 * s
+        npr = 12 + 4 * (s % 16)
         f[:npr] = prompt_ids(cfg, npr, seed=100 + s)
         forced.append(f)
         xr.set_forced(s, f)
@@ -186,6 +190,103 @@ def test_full_size_eight_sequences(canon):
     m.close()
 
 
+@pytest.mark.parametrize("n_seq", [8, 16, 32])
+def test_a_finished_or_parked_sequence_does_not_stop_the_others(canon, n_seq):
+    """the sequences are independent, so they end at different times.  One sequence stands near the end of its cache: the launch that would leave the cache skips
+    THAT sequence (status 64 in its own state word, no shared error), the others decode on, bit for bit the oracle's; a parked sequence is skipped the same way and goes on
+    where it stood once it is un-parked."""
+    S = 96
+    cfg = dict(synth.CONFIGS["tiny"], max_seq=S)
+    raw = synth.raw_weights_numpy(cfg, 77, w_std=0.1)
+    m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
+    m.set_canonical(True)
+    xr = XcdReplicas(m, n_seq)
+    xr.set_steps_per_launch(10)
+    late, parked = 3, n_seq - 2     # sequence `late` is first decoded to position 80 of 96
+    forced = []
+    for s in range(n_seq):
+        f = np.full(S, -1, dtype=np.int32)
+        f[:10] = prompt_ids(cfg, 10, seed=300 + s)
+        forced.append(f)
+        xr.set_forced(s, f)
+        xr.set_state(s, int(f[0]), 0)
+    for s in range(n_seq):
+        if s != late:
+            xr.park(s)
+    xr.run_steps(80)                # only `late` moves
+    for s in range(n_seq):
+        xr.park(s, s == parked)     # everyone back except `parked`
+    xr.run_steps(10)                # late: 80 -> 90; the others 0 -> 10
+    xr.run_steps(10)                # late would reach 100 > 96: skipped, status 64; the others 10 -> 20
+    xr.park(parked, False)
+    xr.run_steps(10)                # parked: 0 -> 10; late still skipped; the others 20 -> 30
+    m.sync()
+    xr.check()                      # no shared error: nothing timed out, nothing was poisoned
+    st = xr.status(late)
+    assert st[1] == 90 and st[3] == 64, st
+    o_ids, _, _, _ = _oracle_run(cfg, raw, forced[late], 90)
+    assert xr.tokens_out(late, 90).tolist() == o_ids
+    for s in range(n_seq):
+        if s == late:
+            continue
+        n = 10 if s == parked else 30
+        assert xr.status(s)[1:] == [n, 0, 0], (s, xr.status(s))
+        o_ids, o_logits, ok, ov = _oracle_run(cfg, raw, forced[s], n)
+        assert xr.tokens_out(s, n).tolist() == o_ids, "sequence %d" % s
+        assert np.array_equal(xr.logits(s), o_logits), "sequence %d" % s
+        gk, gv = xr.kv_to_host(s)
+        assert np.array_equal(gk[:, :n], ok[:, :n]) and np.array_equal(gv[:, :n], ov[:, :n]), "sequence %d" % s
+    xr.set_state(late, int(xr.tokens_out(late, 90)[84]), 85)   # re-aimed inside its cache: the status word clears and it decodes again
+    xr.run_steps(5)
+    m.sync()
+    xr.check()
+    assert xr.status(late)[1:] == [90, 0, 0]
+    xr.close()
+    m.close()
+
+
+@pytest.mark.parametrize("name", ["qwen3-4b", "tiny"])
+def test_a_weight_update_reaches_an_existing_replicas_object(canon, name):
+    """kfh_weights_changed / a weight set again on the Fish must reach every XcdReplicas built on it -- the GQA-4 forms hold a fused COPY of q | k | v made
+    at create time, every form holds the weights' addresses.  The next use re-creates the engine on the weights as they are now; caches and states stay.  Never stale ids."""
+    cfg = dict(GQA4_SHAPES[name], n_layer=2, vocab=1024, max_seq=64) if name in GQA4_SHAPES else dict(synth.CONFIGS[name], max_seq=64)
+    raw = synth.raw_weights_numpy(cfg, 5, w_std=0.05 if name in GQA4_SHAPES else 0.1)
+    m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
+    m.set_canonical(True)
+    n_seq = 8
+    xr = XcdReplicas(m, n_seq)
+    forced = []
+    for s in range(n_seq):
+        f = np.full(cfg["max_seq"], -1, dtype=np.int32)
+        f[:8] = prompt_ids(cfg, 8, seed=40 + s)
+        forced.append(f)
+        xr.set_forced(s, f)
+        xr.set_state(s, int(f[0]), 0)
+    xr.run_steps(12)
+    m.sync()
+    xr.check()
+    raw2 = synth.raw_weights_numpy(cfg, 6, w_std=0.05 if name in GQA4_SHAPES else 0.1)   # "a training step": every layer matrix replaced, same shapes
+    m2 = synth.build_from_raw(cfg, raw2, L.Q4, L.BF16)
+    for key, w in m2.weights.items():
+        m.set_weight(key[0], key[1], w)
+    for key, nw in m2._norms.items():
+        m.set_norm(key[0], key[1], nw)
+    if cfg.get("tied", True):
+        m.tie_head()
+    for s in range(n_seq):
+        xr.set_state(s, int(forced[s][0]), 0)
+    xr.run_steps(12)                # through the PRE-EXISTING object
+    m.sync()
+    xr.check()
+    for s in (0, 5):
+        o_ids, o_logits, ok, ov = _oracle_run(cfg, raw2, forced[s], 12)
+        assert xr.tokens_out(s, 12).tolist() == o_ids, "sequence %d decoded stale weights" % s
+        assert np.array_equal(xr.logits(s), o_logits)
+    xr.close()
+    m.close()
+    m2.close()
+
+
 def test_refusals():
     """what the XCD-confined engines do not serve is refused with a reason, never silently routed elsewhere: other shapes, other storages, more than eight sequences, the
     v_dot2c order"""
@@ -198,7 +299,7 @@ def test_refusals():
     m.close()
     m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
     with pytest.raises(L.KFError):
-        XcdReplicas(m, 17)
+        XcdReplicas(m, 33)
     m.set_canonical(False)
     xr = XcdReplicas(m, 2)
     xr.set_state(0, 1, 0), xr.set_state(1, 2, 0)
