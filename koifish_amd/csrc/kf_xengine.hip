@@ -109,7 +109,9 @@ struct XCfg {
     static constexpr int AU = AU_; /* key tiles per attention batch and wave */
     static constexpr bool DEAL_CONTIG = WPC_ > 1 || NWV_ == 8; /* xe_deal: 7 compute waves = ONE beside the poller on its SIMD: a run per wave, that wave's shorter */
     static constexpr int WPC = WPC_; /* decoders per XCD = workgroups per CU: 2 lets one decoder's hand-off waits run under the other's arithmetic (the hardware interleaves the two workgroups' waves) */
-    static constexpr int FMT = FMT_, GQ = GQ_, HD = HD_, NWV = NWV_, NCW = NWV_ - 1, DIM = DIM_, QD = QD_, KVD = KVD_, FFN = FFN_, DEPTH = DEPTH_, NWG = XE_NWG;
+    // NB pollers (waves NCW .. NWV - 1: wave NCW + b runs the hand-offs of sequence b, side by side) and NWV - NB compute waves.  (One poller staging four sequences' vectors one
+    // after the other took 43 of a 169 us layer period; hand-offs run by compute waves beside their rows cost the attention loop its registers: 23 -> 32 us per layer.)
+    static constexpr int FMT = FMT_, GQ = GQ_, HD = HD_, NWV = NWV_, NCW = NWV_ - NB_, DIM = DIM_, QD = QD_, KVD = KVD_, FFN = FFN_, DEPTH = DEPTH_, NWG = XE_NWG;
     static constexpr bool DBG = DBG_;
     static_assert(FMT_ == FMT_Q4 || FMT_ == FMT_Q4P, "4-bit PackedQ layers (arithmetic or register-table unpack)");
     static constexpr int n_head = QD_ / HD_, n_kv = KVD_ / HD_;
@@ -172,10 +174,10 @@ struct XLay {
     static constexpr size_t o_attn = (size_t)2 * xs_bytes + 2 * xr_bytes;
     static constexpr size_t o_outb = (o_attn + sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + 15) & ~(size_t)15;
     static constexpr size_t o_wmax = o_outb + 4 * (size_t)((C::maxR + 63) & ~63);
-    static constexpr size_t seq_bytes = (o_wmax + 4 * 2 * 16 + 15) & ~(size_t)15;
+    static constexpr size_t o_msc = (o_wmax + 4 * 2 * 16 + 15) & ~(size_t)15; /* the slice merge's scratch ([SPK][ME] fp64 + shifts + the merged granules; xe_coop_norm_stage: a slot per wave) */
+    static constexpr size_t seq_bytes = (o_msc + sizeof(double) * ((size_t)C::ME * C::SPK) + 4 * 64 + 4 * 128 + 15) & ~(size_t)15;
     static constexpr size_t o_comb = (size_t)C::NB * seq_bytes;
-    static constexpr size_t o_msc = o_comb + (C::COMB_IN_XS1 ? 0 : sizeof(double) * (size_t)NCW * GQ * (hd + 2));
-    static constexpr size_t o_cnt = o_msc + sizeof(double) * ((size_t)C::ME * C::SPK) + 4 * 64 + 4 * 128;
+    static constexpr size_t o_cnt = o_comb + (C::COMB_IN_XS1 ? 0 : sizeof(double) * (size_t)NCW * GQ * (hd + 2));
     static constexpr size_t fixed_bytes = (o_cnt + 64 + 15) & ~(size_t)15;
 };
 constexpr size_t xe_loc_stride(int loc_dw) { return ((size_t)loc_dw * 4 + 4095) & ~(size_t)4095; }
@@ -208,7 +210,7 @@ __device__ __forceinline__ XLds xe_lds_view(const XLds& L, int b) {
         XLds V = L;
         V.xs[0] = mv(L.xs[0]), V.xs[1] = mv(L.xs[1]), V.xrawA = mv(L.xrawA), V.xrawB = mv(L.xrawB);
         V.qraw = mv(L.qraw), V.kraw = mv(L.kraw), V.vraw = mv(L.vraw), V.qb = mv(L.qb), V.knew = mv(L.knew);
-        V.wmax = mv(L.wmax), V.outb = mv(L.outb);
+        V.wmax = mv(L.wmax), V.outb = mv(L.outb), V.msc = mv(L.msc);
         return V;
     }
 }
@@ -255,16 +257,23 @@ struct XPhase {
 struct XDeal {
     int a, b, n;
 };
-template <int NCW>
-__device__ __forceinline__ int xe_deal_cum(int cw, int wl) { /* weights of waves 0 .. cw - 1 */
-    const int pc = NCW & 3, npc = cw > pc ? (cw - pc + 3) >> 2 : 0; /* waves of the poller's class below cw */
-    return 8 * (cw - npc) + wl * npc;
+template <int NCW, int NPOLL>
+__device__ __forceinline__ int xe_deal_cum(int cw, int wl) { /* weights of waves 0 .. cw - 1: `wl` for a wave that shares its SIMD with a poller (waves NCW .. NCW + NPOLL - 1), 8 otherwise */
+    int tot = 0;
+#pragma unroll
+    for (int w = 0; w < NCW; w++) {
+        bool beside = false;
+#pragma unroll
+        for (int i = 0; i < NPOLL; i++) beside = beside || (((NCW + i) & 3) == (w & 3));
+        tot += w < cw ? (beside ? wl : 8) : 0;
+    }
+    return tot;
 }
-template <int NCW, bool CONTIG>
+template <int NCW, bool CONTIG, int NPOLL = 1>
 __device__ __forceinline__ XDeal xe_deal(int cw, int spg, int wl) {
     if constexpr (CONTIG) {
-        const int tot = xe_deal_cum<NCW>(NCW, wl);
-        const int f0 = (spg * xe_deal_cum<NCW>(cw, wl) + (tot >> 1)) / tot, f1 = (spg * xe_deal_cum<NCW>(cw + 1, wl) + (tot >> 1)) / tot;
+        const int tot = xe_deal_cum<NCW, NPOLL>(NCW, wl);
+        const int f0 = (spg * xe_deal_cum<NCW, NPOLL>(cw, wl) + (tot >> 1)) / tot, f1 = (spg * xe_deal_cum<NCW, NPOLL>(cw + 1, wl) + (tot >> 1)) / tot;
         return XDeal{f0, 1, f1 - f0};
     } else {
         const int cls = cw & 3, idx = cw >> 2, nw = (NCW - cls + 3) / 4;
@@ -746,113 +755,179 @@ __device__ __forceinline__ void xe_coop_norm_stage(const XArgs& a, const XLds& L
     }
 }
 
-// ---- the poller wave of a workgroup.  SS: the decoder's NB sequences (XCfg::NB; SS[0] carries the workgroup's place); per hand-off the vectors of all of them are swept
-// and staged, one after the other, into their own LDS blocks
+// ---- the hand-offs of ONE sequence of a decoder (sweep until whole, stage into that sequence's LDS block; the slice merge): run by that sequence's poller wave
 template <class C>
-__device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L0, const XSeq (&SS)[C::NB], int epoch, int lane) {
-    using SH = typename C::SH;
-    using P1 = typename SH::P1;
-    using P4 = typename SH::P4;
-    using P5 = typename SH::P5;
-    using P6 = typename SH::P6;
-    constexpr int GQ = C::GQW, hd = C::HD, XCH = C::XCH, NB = C::NB;
-    constexpr int ND = C::DIM / 256, NQD = C::QD / 256, NF = C::FFNP / 256;
+__device__ __forceinline__ void xe_ho_x(const XArgs& a, const XLds& Lb, const XSeq& Sb, const EngLayer& ly, int l, int epoch, uint32_t gen, int lane, bool& dead) { /* P1's x (P4 adds it as the residual) */
+    constexpr int XCH = C::XCH, ND = C::DIM / 256, RT = C::DIM / XE_NWG;
+    const uint32_t tag = gen & 0xffffu;
+    uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)Sb.seq * a.loc_stride);
+    if (l == 0) {
+        int tok = a.d_state[Sb.sq * 4];
+        if (Sb.step > 0) { /* the id workgroup 0 of this decoder picked at the end of the previous step: {id, epoch of this step} */
+            const __amdgpu_buffer_rsrc_t rt = eng_rsrc(loc + C::tokg, 8u);
+            for (int spins = 0;; spins++) {
+                const u32x2 g = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rt, 0, 0, 16 /* sc1 */));
+                if (g.y == (uint32_t)epoch) {
+                    tok = (int)g.x;
+                    break;
+                }
+                if (dead || spins > ENG_SPIN_MAX) {
+                    if (!dead && lane == 0) atomicOr(a.ws + 1, 32);
+                    dead = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        if (a.d_forced) {
+            const int f = a.d_forced[(size_t)Sb.sq * a.forced_stride + Sb.pos];
+            if (f >= 0) tok = f;
+        }
+        if (tok < 0 || tok >= a.emb_rows) tok = 0;
+        if constexpr (ND > 12) eng_poll_stage_norm_long<XCH, ND, C::XS, true, true, 8>(nullptr, a.emb + (size_t)tok * C::DIM, tag, ly.norm_in, a.eps, Lb.xs[0], Lb.xrawA, lane, a.ws, dead);
+        else eng_poll_stage<XCH, ND, C::XS, true, true, true>(nullptr, a.emb + (size_t)tok * C::DIM, tag, ly.norm_in, a.eps, Lb.xs[0], Lb.xrawA, lane, a.ws, dead, nullptr, nullptr, 0, 0);
+    } else {
+        if constexpr (C::TP) /* the down_proj exchange of the layer before: this workgroup's rows summed over the ranks + the residual xB -> the local x area */
+            xe_tp_reduce<C>(a, Sb, 1, 2u * (gen - 1u) + 2u, Lb.xrawB, loc + C::xA + Sb.r * RT, tag, nullptr, lane, dead);
+        if constexpr (C::COOP) xe_coop_norm_stage<C>(a, Lb, loc + C::xA, tag, ly.norm_in, Lb.xs[0], Lb.xrawA, C::NWV - 1, lane, &dead);
+        else if constexpr (ND > 12) eng_poll_stage_norm_long<XCH, ND, C::XS, false, true, 8>(loc + C::xA, nullptr, tag, ly.norm_in, a.eps, Lb.xs[0], Lb.xrawA, lane, a.ws, dead);
+        else eng_poll_stage<XCH, ND, C::XS, true, false, true>(loc + C::xA, nullptr, tag, ly.norm_in, a.eps, Lb.xs[0], Lb.xrawA, lane, a.ws, dead, nullptr, nullptr, 0, 0);
+    }
+}
+template <class C>
+__device__ __forceinline__ void xe_ho_qkv(const XArgs& a, const XLds& Lb, const XSeq& Sb, uint32_t tag, int lane, bool& dead) { /* P2: the raw q heads of this workgroup's kv-head, its k and v rows */
+    constexpr int GQ = C::GQW, hd = C::HD;
+    uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)Sb.seq * a.loc_stride);
+    const __amdgpu_buffer_rsrc_t rs = eng_rsrc(loc + C::qkv, (uint32_t)(C::QD + 2 * C::KVD) * 4u);
+    const uint32_t tagw = tag << 16;
+    constexpr int NLQ = (GQ * hd + 255) / 256;
+    u32x4 g[NLQ], gk;
+    const int e_kv = 4 * lane; /* < hd: k, < 2 hd: v */
+    const bool kv_in = e_kv < 2 * hd;
+    const int kv_src = e_kv < hd ? C::QD + Sb.kvh * hd + e_kv : C::QD + C::KVD + Sb.kvh * hd + (e_kv - hd);
+    for (int spins = 0;; spins++) {
+        uint32_t bad = 0;
+#pragma unroll
+        for (int r = 0; r < NLQ; r++) g[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (Sb.h0 * hd + 4 * (r * 64 + lane)) * 4, 0, 16));
+        gk = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (kv_in ? kv_src : 0) * 4, 0, 16));
+#pragma unroll
+        for (int r = 0; r < NLQ; r++) bad = (4 * (r * 64 + lane) < GQ * hd) ? tags_bad(g[r], tagw, bad) : bad;
+        bad = kv_in ? tags_bad(gk, tagw, bad) : bad;
+        if (all_good(bad)) break;
+        if (dead || spins > ENG_SPIN_MAX) {
+            if (!dead && lane == 0) atomicOr(a.ws + 1, 2);
+            dead = true;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int r = 0; r < NLQ; r++) {
+        const int e0 = 4 * (r * 64 + lane);
+        if (e0 < GQ * hd) *reinterpret_cast<u32x2*>(Lb.qraw + e0) = u32x2{(g[r].x & 0xffffu) | (g[r].y << 16), (g[r].z & 0xffffu) | (g[r].w << 16)};
+    }
+    if (kv_in) *reinterpret_cast<u32x2*>(Lb.kraw + e_kv) = u32x2{(gk.x & 0xffffu) | (gk.y << 16), (gk.z & 0xffffu) | (gk.w << 16)}; /* vraw = kraw + hd */
+}
+// P3: merge the SPK slices of this workgroup's ME output elements (exact rescales to the largest exponent, fp64 sums, one division: kf_attn_common.h) -> the ao area
+template <class C>
+__device__ __forceinline__ void xe_ho_merge(const XArgs& a, const XLds& Lb, const XSeq& Sb, uint32_t gen, int lane, bool& dead) {
+    constexpr int hd = C::HD;
+    const uint32_t tag = gen & 0xffffu;
+    uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)Sb.seq * a.loc_stride);
+    constexpr int ME = C::ME, SPK = C::SPK, NV = ME * SPK, NLM = (NV * 2 + 127) / 128; /* values; 16-byte loads (2 granules) per lane and sweep */
+    const int h = Sb.me0 >> (hd == 128 ? 7 : 6), dd = Sb.me0 & (hd - 1);
+    const unsigned long long* hbase = reinterpret_cast<const unsigned long long*>(loc + C::part) + (size_t)h * C::PSH;
+    const __amdgpu_buffer_rsrc_t rs_o = eng_rsrc(hbase + (size_t)(dd / ME) * (SPK * ME * 2), (uint32_t)(SPK * ME * 2) * 8u);
+    const __amdgpu_buffer_rsrc_t rs_ml = eng_rsrc(hbase + (size_t)hd * SPK * 2, (uint32_t)SPK * 32u);
+    u32x4 go[NLM], gm0, gm1;
+    const bool mine = lane < SPK;
+    for (int spins = 0;; spins++) {
+        uint32_t bad = 0;
+#pragma unroll
+        for (int r = 0; r < NLM; r++) go[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_o, (r * 64 + lane) * 16, 0, 16 /* sc1 */));
+        gm0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ml, (mine ? lane : 0) * 32, 0, 16));
+        gm1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ml, (mine ? lane : 0) * 32 + 16, 0, 16));
+#pragma unroll
+        for (int r = 0; r < NLM; r++) bad |= (r * 64 + lane) < NV ? ((go[r].y ^ gen) | (go[r].w ^ gen)) : 0u;
+        bad |= mine ? ((gm0.y ^ gen) | (gm0.w ^ gen) | (gm1.y ^ gen)) : 0u;
+        if (all_good(bad)) break;
+        if (dead || spins > ENG_SPIN_MAX) {
+            if (!dead && lane == 0) atomicOr(a.ws + 1, 4);
+            dead = true;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int r = 0; r < NLM; r++) { /* value index vi = sp * ME + e */
+        const int vi = r * 64 + lane;
+        if (vi < NV) Lb.msc[vi] = __builtin_bit_cast(double, ((unsigned long long)go[r].z << 32) | go[r].x);
+    }
+    const float ms = mine ? __uint_as_float(gm0.x) : -__builtin_inff();
+    const double ls = mine ? __builtin_bit_cast(double, ((unsigned long long)gm1.x << 32) | gm0.z) : 0.0;
+    const float Mx = wave_max(ms);
+    const int sh = canon_shift(ms - Mx);
+    const double Lt = wave_sum_f64_fast(ldexp_d(ls, sh));
+    int* shl = reinterpret_cast<int*>(Lb.msc + NV);
+    if (mine) shl[lane] = sh;
+    uint32_t* mo = reinterpret_cast<uint32_t*>(Lb.msc + NV) + 64;
+#pragma unroll
+    for (int e0 = 0; e0 < ME; e0 += 64) {
+        const int e = e0 + lane;
+        if (e < ME) {
+            double o = 0.0;
+#pragma unroll
+            for (int sp = 0; sp < SPK; sp++) o += ldexp_d(Lb.msc[sp * ME + e], shl[sp]);
+            mo[e] = (tag << 16) | (uint32_t)f2bf((float)(o / Lt));
+        }
+    }
+    if (4 * lane < ME) *reinterpret_cast<u32x4*>(loc + C::ao + Sb.me0 + 4 * lane) = *reinterpret_cast<const u32x4*>(mo + 4 * lane);
+}
+template <class C>
+__device__ __forceinline__ void xe_ho_ao(const XArgs& a, const XLds& Lb, const XSeq& Sb, uint32_t tag, int lane, bool& dead) { /* P4's ao */
+    uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)Sb.seq * a.loc_stride);
+    eng_poll_stage<C::XCH, C::QD / 256, C::XS, false, false, true>(loc + C::ao, nullptr, tag, nullptr, 0.f, Lb.xs[1], nullptr, lane, a.ws, dead, nullptr, nullptr, 0, 0);
+}
+template <class C>
+__device__ __forceinline__ void xe_ho_xB(const XArgs& a, const XLds& Lb, const XSeq& Sb, const EngLayer& ly, uint32_t gen, int lane, bool& dead) { /* P5's xB (P6 adds it as the residual) */
+    constexpr int XCH = C::XCH, ND = C::DIM / 256, RT = C::DIM / XE_NWG;
+    const uint32_t tag = gen & 0xffffu;
+    uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)Sb.seq * a.loc_stride);
+    if constexpr (C::TP) xe_tp_reduce<C>(a, Sb, 0, 2u * gen + 1u, Lb.xrawA, loc + C::xB + Sb.r * RT, tag, nullptr, lane, dead); /* the o_proj exchange + the residual x */
+    if constexpr (C::COOP) xe_coop_norm_stage<C>(a, Lb, loc + C::xB, tag, ly.norm_post, Lb.xs[0], Lb.xrawB, C::NWV - 1, lane, &dead);
+    else if constexpr (ND > 12) eng_poll_stage_norm_long<XCH, ND, C::XS, false, true, 8>(loc + C::xB, nullptr, tag, ly.norm_post, a.eps, Lb.xs[0], Lb.xrawB, lane, a.ws, dead);
+    else eng_poll_stage<XCH, ND, C::XS, true, false, true>(loc + C::xB, nullptr, tag, ly.norm_post, a.eps, Lb.xs[0], Lb.xrawB, lane, a.ws, dead, nullptr, nullptr, 0, 0);
+}
+template <class C>
+__device__ __forceinline__ void xe_ho_act(const XArgs& a, const XLds& Lb, const XSeq& Sb, uint32_t tag, int lane, bool& dead, int* nsw) { /* P6's act */
+    constexpr int XCH = C::XCH, NF = C::FFNP / 256;
+    uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)Sb.seq * a.loc_stride);
+    if constexpr (NF > 24) eng_poll_stage_long<XCH, NF, C::XS, 16>(loc + C::act, tag, Lb.xs[1], lane, a.ws, dead, nsw); /* a 9728-wide vector in one sweep: 152 registers */
+    else eng_poll_stage<XCH, NF, C::XS, false, false, true>(loc + C::act, nullptr, tag, nullptr, 0.f, Lb.xs[1], nullptr, lane, a.ws, dead, nsw, nullptr, 0, 0);
+}
+// ---- a poller wave of a workgroup: the hand-offs of ONE sequence of the decoder (S, L: that sequence's place and LDS block; stamps: sequence 0's poller), and every barrier
+template <class C>
+__device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, const XSeq& S, int epoch, int lane) {
+    constexpr int NB = C::NB;
     static_assert(C::DIM % 256 == 0 && C::QD % 256 == 0 && (C::TP || C::FFN % 256 == 0), "hand-off vectors in 1 KiB pieces");
-    constexpr int RT = C::DIM / XE_NWG; /* TP: the rows of an exchange this workgroup sums */
-    const XSeq& S = SS[0];
-    const XLds& L = L0;
+    const bool on = NB == 1 || S.act;
     bool dead = false;
     for (int l = 0; l < a.n_layer; l++) {
         const EngLayer& ly = L.lay[l];
         const uint32_t gen = (uint32_t)epoch * (uint32_t)a.n_layer + (uint32_t)l, tag = gen & 0xffffu;
         XE_STAMP(0);
         if (C::DBG && !C::TP && S.stamp && lane == 0) a.dbg[((size_t)S.step * a.n_layer + l) * 64 + 31] = __builtin_amdgcn_s_memtime(); /* the shader clock beside the 100 MHz stamp: the frequency the CU really runs at */
-        // P1's x (P4 adds it as the residual)
         if (l > 0) {
             eng_wait_pub(L.pub + 3, S.step * a.n_layer + l, 0, dead);
             XE_STAMP(12);
         }
-#pragma unroll
-        for (int b = 0; b < NB; b++) {
-            const XSeq& Sb = SS[b];
-            if (NB > 1 && !Sb.act) continue;
-            const XLds Lb = xe_lds_view<C>(L, b);
-            uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)Sb.seq * a.loc_stride);
-            if (l == 0) {
-                int tok = a.d_state[Sb.sq * 4];
-                if (Sb.step > 0) { /* the id workgroup 0 of this decoder picked at the end of the previous step: {id, epoch of this step} */
-                    const __amdgpu_buffer_rsrc_t rt = eng_rsrc(loc + C::tokg, 8u);
-                    for (int spins = 0;; spins++) {
-                        const u32x2 g = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rt, 0, 0, 16 /* sc1 */));
-                        if (g.y == (uint32_t)epoch) {
-                            tok = (int)g.x;
-                            break;
-                        }
-                        if (dead || spins > ENG_SPIN_MAX) {
-                            if (!dead && lane == 0) atomicOr(a.ws + 1, 32);
-                            dead = true;
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                }
-                if (a.d_forced) {
-                    const int f = a.d_forced[(size_t)Sb.sq * a.forced_stride + Sb.pos];
-                    if (f >= 0) tok = f;
-                }
-                if (tok < 0 || tok >= a.emb_rows) tok = 0;
-                if constexpr (ND > 12) eng_poll_stage_norm_long<XCH, ND, C::XS, true, true, 8>(nullptr, a.emb + (size_t)tok * C::DIM, tag, ly.norm_in, a.eps, Lb.xs[0], Lb.xrawA, lane, a.ws, dead);
-                else eng_poll_stage<XCH, ND, C::XS, true, true, true>(nullptr, a.emb + (size_t)tok * C::DIM, tag, ly.norm_in, a.eps, Lb.xs[0], Lb.xrawA, lane, a.ws, dead, nullptr, nullptr, 0, 0);
-            } else {
-                if constexpr (C::TP) /* the down_proj exchange of the layer before: this workgroup's rows summed over the ranks + the residual xB -> the local x area */
-                    xe_tp_reduce<C>(a, S, 1, 2u * (gen - 1u) + 2u, L.xrawB, loc + C::xA + S.r * RT, tag, nullptr, lane, dead);
-                if constexpr (C::TP) XE_STAMP(31); /* (TP: the slot of the shader-clock stamp) this workgroup's rows of the down_proj exchange are summed */
-                if constexpr (C::COOP) xe_coop_norm_stage<C>(a, L, loc + C::xA, tag, ly.norm_in, L.xs[0], L.xrawA, C::NWV - 1, lane, &dead);
-                else if constexpr (ND > 12) eng_poll_stage_norm_long<XCH, ND, C::XS, false, true, 8>(loc + C::xA, nullptr, tag, ly.norm_in, a.eps, Lb.xs[0], Lb.xrawA, lane, a.ws, dead);
-                else eng_poll_stage<XCH, ND, C::XS, true, false, true>(loc + C::xA, nullptr, tag, ly.norm_in, a.eps, Lb.xs[0], Lb.xrawA, lane, a.ws, dead, nullptr, nullptr, 0, 0);
-            }
-        }
+        if (on) xe_ho_x<C>(a, L, S, ly, l, epoch, gen, lane, dead);
+        if (C::TP && l > 0) XE_STAMP(31); /* (TP: the slot of the shader-clock stamp) this workgroup's rows of the down_proj exchange are summed */
         XE_STAMP(1);
         __syncthreads(); /* B1 */
-        // P2: the raw q heads of this workgroup's kv-head, its k and v rows (only a slice with keys needs them)
         if (!(C::P1W < XE_NWG && S.r >= C::P1W)) eng_wait_pub(L.pub + 0, S.step * a.n_layer + l + 1, 0, dead); /* (a workgroup without q | k | v rows publishes none) */
         XE_STAMP(9);
-#pragma unroll
-        for (int b = 0; b < NB; b++) {
-            const XSeq& Sb = SS[b];
-            if (Sb.empty) continue; /* (an inactive sequence is an empty one) */
-            const XLds Lb = xe_lds_view<C>(L, b);
-            uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)Sb.seq * a.loc_stride);
-            const __amdgpu_buffer_rsrc_t rs = eng_rsrc(loc + C::qkv, (uint32_t)(C::QD + 2 * C::KVD) * 4u);
-            const uint32_t tagw = tag << 16;
-            constexpr int NLQ = (GQ * hd + 255) / 256;
-            u32x4 g[NLQ], gk;
-            const int e_kv = 4 * lane; /* < hd: k, < 2 hd: v */
-            const bool kv_in = e_kv < 2 * hd;
-            const int kv_src = e_kv < hd ? C::QD + Sb.kvh * hd + e_kv : C::QD + C::KVD + Sb.kvh * hd + (e_kv - hd);
-            for (int spins = 0;; spins++) {
-                uint32_t bad = 0;
-#pragma unroll
-                for (int r = 0; r < NLQ; r++) g[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (Sb.h0 * hd + 4 * (r * 64 + lane)) * 4, 0, 16));
-                gk = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (kv_in ? kv_src : 0) * 4, 0, 16));
-#pragma unroll
-                for (int r = 0; r < NLQ; r++) bad = (4 * (r * 64 + lane) < GQ * hd) ? tags_bad(g[r], tagw, bad) : bad;
-                bad = kv_in ? tags_bad(gk, tagw, bad) : bad;
-                if (all_good(bad)) break;
-                if (dead || spins > ENG_SPIN_MAX) {
-                    if (!dead && lane == 0) atomicOr(a.ws + 1, 2);
-                    dead = true;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-#pragma unroll
-            for (int r = 0; r < NLQ; r++) {
-                const int e0 = 4 * (r * 64 + lane);
-                if (e0 < GQ * hd) *reinterpret_cast<u32x2*>(Lb.qraw + e0) = u32x2{(g[r].x & 0xffffu) | (g[r].y << 16), (g[r].z & 0xffffu) | (g[r].w << 16)};
-            }
-            if (kv_in) *reinterpret_cast<u32x2*>(Lb.kraw + e_kv) = u32x2{(gk.x & 0xffffu) | (gk.y << 16), (gk.z & 0xffffu) | (gk.w << 16)}; /* vraw = kraw + hd */
-        }
+        if (!S.empty) xe_ho_qkv<C>(a, L, S, tag, lane, dead); /* only a slice with keys needs the heads (an inactive sequence is an empty one) */
         XE_STAMP(2);
 #pragma unroll
         for (int b = 0; b < NB; b++) { /* the compute waves' attention, sequence after sequence (xe_attn_phase) */
@@ -861,99 +936,21 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L0, c
             __syncthreads(); /* the waves' sums in LDS */
         }
         XE_STAMP(3);
-        // P3: merge the SPK slices of this workgroup's ME output elements (exact rescales to the largest exponent, fp64 sums, one division: kf_attn_common.h)
-#pragma unroll
-        for (int b = 0; b < NB; b++) {
-            const XSeq& Sb = SS[b];
-            if (NB > 1 && !Sb.act) continue;
-            uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)Sb.seq * a.loc_stride);
-            constexpr int ME = C::ME, SPK = C::SPK, NV = ME * SPK, NLM = (NV * 2 + 127) / 128; /* values; 16-byte loads (2 granules) per lane and sweep */
-            const int h = Sb.me0 >> (hd == 128 ? 7 : 6), dd = Sb.me0 & (hd - 1);
-            const unsigned long long* hbase = reinterpret_cast<const unsigned long long*>(loc + C::part) + (size_t)h * C::PSH;
-            const __amdgpu_buffer_rsrc_t rs_o = eng_rsrc(hbase + (size_t)(dd / ME) * (SPK * ME * 2), (uint32_t)(SPK * ME * 2) * 8u);
-            const __amdgpu_buffer_rsrc_t rs_ml = eng_rsrc(hbase + (size_t)hd * SPK * 2, (uint32_t)SPK * 32u);
-            u32x4 go[NLM], gm0, gm1;
-            const bool mine = lane < SPK;
-            for (int spins = 0;; spins++) {
-                uint32_t bad = 0;
-#pragma unroll
-                for (int r = 0; r < NLM; r++) go[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_o, (r * 64 + lane) * 16, 0, 16 /* sc1 */));
-                gm0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ml, (mine ? lane : 0) * 32, 0, 16));
-                gm1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ml, (mine ? lane : 0) * 32 + 16, 0, 16));
-#pragma unroll
-                for (int r = 0; r < NLM; r++) bad |= (r * 64 + lane) < NV ? ((go[r].y ^ gen) | (go[r].w ^ gen)) : 0u;
-                bad |= mine ? ((gm0.y ^ gen) | (gm0.w ^ gen) | (gm1.y ^ gen)) : 0u;
-                if (all_good(bad)) break;
-                if (dead || spins > ENG_SPIN_MAX) {
-                    if (!dead && lane == 0) atomicOr(a.ws + 1, 4);
-                    dead = true;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (b == 0) XE_STAMP(4);
-#pragma unroll
-            for (int r = 0; r < NLM; r++) { /* value index vi = sp * ME + e */
-                const int vi = r * 64 + lane;
-                if (vi < NV) L.msc[vi] = __builtin_bit_cast(double, ((unsigned long long)go[r].z << 32) | go[r].x);
-            }
-            const float ms = mine ? __uint_as_float(gm0.x) : -__builtin_inff();
-            const double ls = mine ? __builtin_bit_cast(double, ((unsigned long long)gm1.x << 32) | gm0.z) : 0.0;
-            const float Mx = wave_max(ms);
-            const int sh = canon_shift(ms - Mx);
-            const double Lt = wave_sum_f64_fast(ldexp_d(ls, sh));
-            int* shl = reinterpret_cast<int*>(L.msc + NV);
-            if (mine) shl[lane] = sh;
-            uint32_t* mo = reinterpret_cast<uint32_t*>(L.msc + NV) + 64;
-#pragma unroll
-            for (int e0 = 0; e0 < ME; e0 += 64) {
-                const int e = e0 + lane;
-                if (e < ME) {
-                    double o = 0.0;
-#pragma unroll
-                    for (int sp = 0; sp < SPK; sp++) o += ldexp_d(L.msc[sp * ME + e], shl[sp]);
-                    mo[e] = (tag << 16) | (uint32_t)f2bf((float)(o / Lt));
-                }
-            }
-            if (4 * lane < ME) *reinterpret_cast<u32x4*>(loc + C::ao + Sb.me0 + 4 * lane) = *reinterpret_cast<const u32x4*>(mo + 4 * lane);
-        }
+        if (on) xe_ho_merge<C>(a, L, S, gen, lane, dead);
         XE_STAMP(5);
-        // P4's ao, P5's xB (P6 adds it as the residual), P6's act
-#pragma unroll
-        for (int b = 0; b < NB; b++) {
-            if (NB > 1 && !SS[b].act) continue;
-            const XLds Lb = xe_lds_view<C>(L, b);
-            uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)SS[b].seq * a.loc_stride);
-            eng_poll_stage<XCH, NQD, C::XS, false, false, true>(loc + C::ao, nullptr, tag, nullptr, 0.f, Lb.xs[1], nullptr, lane, a.ws, dead, nullptr, nullptr, 0, 0);
-        }
+        if (on) xe_ho_ao<C>(a, L, S, tag, lane, dead);
         XE_STAMP(6);
         __syncthreads(); /* B4 */
         eng_wait_pub(L.pub + 1, S.step * a.n_layer + l + 1, 0, dead);
         XE_STAMP(10);
-#pragma unroll
-        for (int b = 0; b < NB; b++) {
-            if (NB > 1 && !SS[b].act) continue;
-            const XLds Lb = xe_lds_view<C>(L, b);
-            uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)SS[b].seq * a.loc_stride);
-            if constexpr (C::TP) xe_tp_reduce<C>(a, S, 0, 2u * gen + 1u, L.xrawA, loc + C::xB + S.r * RT, tag, nullptr, lane, dead); /* the o_proj exchange + the residual x */
-            if constexpr (C::TP) XE_STAMP(13); /* (TP: the slot of the act sweep count) this workgroup's rows of the o_proj exchange are summed */
-            if constexpr (C::COOP) xe_coop_norm_stage<C>(a, L, loc + C::xB, tag, ly.norm_post, L.xs[0], L.xrawB, C::NWV - 1, lane, &dead);
-            else if constexpr (ND > 12) eng_poll_stage_norm_long<XCH, ND, C::XS, false, true, 8>(loc + C::xB, nullptr, tag, ly.norm_post, a.eps, Lb.xs[0], Lb.xrawB, lane, a.ws, dead);
-            else eng_poll_stage<XCH, ND, C::XS, true, false, true>(loc + C::xB, nullptr, tag, ly.norm_post, a.eps, Lb.xs[0], Lb.xrawB, lane, a.ws, dead, nullptr, nullptr, 0, 0);
-        }
+        if (on) xe_ho_xB<C>(a, L, S, ly, gen, lane, dead);
+        if constexpr (C::TP) XE_STAMP(13); /* (TP: the slot of the act sweep count) this workgroup's rows of the o_proj exchange are summed */
         XE_STAMP(7);
         __syncthreads(); /* B5 */
         eng_wait_pub(L.pub + 2, S.step * a.n_layer + l + 1, 0, dead);
         XE_STAMP(11);
         int nsw_act = 0;
-#pragma unroll
-        for (int b = 0; b < NB; b++) {
-            if (NB > 1 && !SS[b].act) continue;
-            const XLds Lb = xe_lds_view<C>(L, b);
-            uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)SS[b].seq * a.loc_stride);
-            if constexpr (NF > 24) eng_poll_stage_long<XCH, NF, C::XS, 16>(loc + C::act, tag, Lb.xs[1], lane, a.ws, dead, &nsw_act); /* a 9728-wide vector in one sweep: 152 registers */
-            else eng_poll_stage<XCH, NF, C::XS, false, false, true>(loc + C::act, nullptr, tag, nullptr, 0.f, Lb.xs[1], nullptr, lane, a.ws, dead, &nsw_act, nullptr, 0, 0);
-        }
+        if (on) xe_ho_act<C>(a, L, S, tag, lane, dead, &nsw_act);
         if (C::DBG && !C::TP && S.stamp && lane == 0) a.dbg[((size_t)S.step * a.n_layer + l) * 64 + 13] = (unsigned long long)nsw_act;
         XE_STAMP(8);
         __syncthreads(); /* B6 */
@@ -1009,7 +1006,7 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
         P.s0 = sel4(q, S.s1, wg * P4::spg, wg * P5::spg, wg * P6::spg), P.Mj = sel4(q, S.M1, P4::M0, P5::M0, P6::M0);
         P.row0 = P.s0 << P.rps_log2;
         const int spg = sel4(q, P1::spg, P4::spg, P5::spg, P6::spg);
-        const XDeal dl = xe_deal<NCW, C::DEAL_CONTIG>(cw, spg, a.deal_wl);
+        const XDeal dl = xe_deal<NCW, C::DEAL_CONTIG, C::NB>(cw, spg, a.deal_wl);
         P.s0 += __builtin_amdgcn_readfirstlane(dl.a), P.sl_b = __builtin_amdgcn_readfirstlane(dl.b);
         P.n = __builtin_amdgcn_readfirstlane(dl.n) * P.iters * (P.paired ? 2 : 1);
         if (C::P1W < XE_NWG && q == 0 && wg >= C::P1W) P.n = 0;
@@ -1040,7 +1037,7 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
             const int spg = q == 0 ? P1::spg : (q == 1 ? P4::spg : (q == 2 ? P5::spg : P6::spg));
             int nwp = 0; /* waves that own rows of the phase */
 #pragma unroll
-            for (int w = 0; w < NCW; w++) nwp += xe_deal<NCW, C::DEAL_CONTIG>(w, spg, a.deal_wl).n > 0 ? 1 : 0;
+            for (int w = 0; w < NCW; w++) nwp += xe_deal<NCW, C::DEAL_CONTIG, C::NB>(w, spg, a.deal_wl).n > 0 ? 1 : 0;
             uint32_t* const dst = loc + (q == 0 ? C::qkv + S.q_out0 : (q == 1 ? C::xB + wg * P4::R : (q == 2 ? C::act + wg * P5::R : C::xA + wg * P6::R)));
             if constexpr (C::COOP) { /* this wave's share of the sweep + RMSNorm + staging of x (layers behind the first: layer 0's row comes from the embedding table) / xB */
                 uint32_t* const lc = reinterpret_cast<uint32_t*>(a.loc + (size_t)S.seq * a.loc_stride);
@@ -1075,7 +1072,7 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
                 a.dbg[((size_t)S.step * a.n_layer + l) * 64 + ((cw & 7) < 2 ? 14 + (cw & 7) : 23 + (cw & 7))] = hw; /* slots 14, 15, 25 .. 30: where (SIMD, CU) the wave runs */
             }
             if (q == 0 && (NB == 1 || SS[0].act)) xe_attn_issue<C>(a, ly, SS[0], cw, lane, T, 0, 0); /* the slice's first tiles (rows of earlier positions; row `pos` is substituted): the q | k | v hand-off hides them */
-            if (xe_deal<NCW, C::DEAL_CONTIG>(cw, spg, a.deal_wl).n > 0 && !(C::P1W < XE_NWG && q == 0 && wg >= C::P1W)) {
+            if (xe_deal<NCW, C::DEAL_CONTIG, C::NB>(cw, spg, a.deal_wl).n > 0 && !(C::P1W < XE_NWG && q == 0 && wg >= C::P1W)) {
                 if constexpr (C::TP) {
                     // o_proj (q == 1) / down_proj (q == 3): this rank's slot [buffer][S.seq][rows wg * R ..] of rank 0's receive area, the other ranks' areas 2 * 8 * DIM granules apart
                     unsigned long long* push = (q == 1 || q == 3) ? a.tp_recv + ((size_t)(q == 3 ? 1 : 0) * XE_NXCD + S.seq) * C::DIM + wg * nrows : nullptr;
@@ -1149,7 +1146,7 @@ __device__ __forceinline__ void xe_head_main(const XArgs& a, const XLds& L, cons
         }
     };
     const uint32_t gen = (uint32_t)(epoch + 1) * (uint32_t)a.n_layer, tag = gen & 0xffffu; /* the generation the last layer's down_proj published its rows with */
-    if (wave == NWV - 1) {
+    if (wave >= C::NCW) { /* the pollers: each its sequence's final x */
         bool dead = false;
         if constexpr (C::TP) { /* the last layer's down_proj exchange: this workgroup's rows -> the local x area (rank 0: also x_out) */
             uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)S.seq * a.loc_stride);
@@ -1158,17 +1155,18 @@ __device__ __forceinline__ void xe_head_main(const XArgs& a, const XLds& L, cons
         }
 #pragma unroll
         for (int b = 0; b < NB; b++) {
-            if (NB > 1 && !SS[b].act) continue;
-            const XLds Lb = xe_lds_view<C>(L, b);
-            uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)SS[b].seq * a.loc_stride);
-            if constexpr (ND > 12) eng_poll_stage_norm_long<1, ND, nBlk, false, false, 8>(loc + C::xA, nullptr, tag, a.head_norm, a.eps, Lb.xs[0], Lb.xrawA, lane, a.ws, dead);
-            else eng_poll_stage<1, ND, nBlk, true, false, false>(loc + C::xA, nullptr, tag, a.head_norm, a.eps, Lb.xs[0], nullptr, lane, a.ws, dead, nullptr, b == 0 ? L.pub + 3 : nullptr, (S.step + 1) * a.n_layer, 0);
+            if (wave == C::NCW + b && (NB == 1 || SS[b].act)) {
+                const XLds Lb = xe_lds_view<C>(L, b);
+                uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)SS[b].seq * a.loc_stride);
+                if constexpr (ND > 12) eng_poll_stage_norm_long<1, ND, nBlk, false, false, 8>(loc + C::xA, nullptr, tag, a.head_norm, a.eps, Lb.xs[0], Lb.xrawA, lane, a.ws, dead);
+                else eng_poll_stage<1, ND, nBlk, true, false, false>(loc + C::xA, nullptr, tag, a.head_norm, a.eps, Lb.xs[0], nullptr, lane, a.ws, dead, nullptr, L.pub + 3, (S.step + 1) * a.n_layer, 0);
+            }
         }
     } else {
-        issue(0, 0); /* ahead of the hand-off of x (the poller's own first rows are requested behind its sweep: loads return in order) */
+        issue(0, 0); /* ahead of the hand-off of x (the pollers' own first rows are requested behind their sweeps: loads return in order) */
     }
     __syncthreads();
-    if (wave == NWV - 1) issue(0, 0);
+    if (wave >= C::NCW) issue(0, 0);
     float xf[NB][ITERS][8];
 #pragma unroll
     for (int b = 0; b < NB; b++) {
@@ -1250,7 +1248,7 @@ __device__ __forceinline__ void xe_head_main(const XArgs& a, const XLds& L, cons
                 if (rv[k] > bv0 || (rv[k] == bv0 && ri[k] < bi0)) bv0 = rv[k], bi0 = ri[k];
             hb[wg] = ((unsigned long long)((tag << 16) | (uint32_t)f2bf(bv0)) << 32) | (unsigned long long)(uint32_t)bi0;
         }
-        if (wg == 0 && wave == NWV - 1 && a.pick) { /* the pick over the decoder's 32 workgroup maxima: two granules per lane */
+        if (wg == 0 && wave == C::NCW + b && a.pick) { /* the pick over the decoder's 32 workgroup maxima (sequence b's poller): two granules per lane */
             const __amdgpu_buffer_rsrc_t rs = eng_rsrc(hb, NWG * 8u);
             u32x4 g0{0, 0, 0, 0};
             bool ok = false;
@@ -1468,8 +1466,20 @@ __global__ void __launch_bounds__(C::NWV * 64, (C::NWV * C::WPC + 3) / 4 /* wave
             __syncthreads();
             if (L.cnt[3] != 0) break;
         }
-        if (wave == NWV - 1) xe_poller_main<C>(a, L, SS, epoch, lane);
-        else xe_compute_main<C>(a, L, SS, epoch, wave, lane, R);
+        if (wave >= C::NCW) { /* the poller of sequence wave - NCW */
+            bool done = false;
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                if (!done && wave == C::NCW + b) {
+                    XSeq Sp = SS[b];
+                    if (b > 0) Sp.stamp = false;
+                    xe_poller_main<C>(a, xe_lds_view<C>(L, b), Sp, epoch, lane);
+                    done = true;
+                }
+            }
+        } else {
+            xe_compute_main<C>(a, L, SS, epoch, wave, lane, R);
+        }
         if (a.head_w) xe_head_main<C>(a, L, SS, epoch, step + 1 < nst, wave, lane);
     }
     leave();
@@ -1488,6 +1498,7 @@ struct XEngineHost {
     size_t tp_bytes; /* TP: bytes of the receive + pick areas behind the exchange areas (reset with them) */
     int epoch;       /* the generation the next launch starts at (XArgs::epoch0) */
     int batch;       /* sequences per decoder of the form in use (XCfg::NB): 1, 2 or 4 */
+    int variant_set; /* xengine_set_variant was called with a waves x depth pair (tuning runs) */
     int two_wpc;     /* n_seq 9 .. 16 through the round-5 form (two decoders per XCD, two workgroups per CU) instead of the batched one: A/B hook */
 };
 
@@ -1830,12 +1841,13 @@ static int xengine_go_shape(XEngineHost* E, hipStream_t st) {
     const bool two = E->args.n_seq > XE_NXCD && nb == 1;
 #ifndef XE_ONLY_DEFAULT
     const bool dbg = E->args.dbg != nullptr;
+    if (dbg && nb == 4) return xengine_go<XC<12, 6, true, 1, 2, 4>>(E, st);
     if (dbg && nb == 2) return xengine_go<XC<12, 6, true, 1, 2, 2>>(E, st);
     if (dbg && nb == 1) return two ? xengine_go<XC<8, 4, true, 2, 1, 1>>(E, st) : xengine_go<XC<9, 8, true, 1, 2, 1>>(E, st);
 #endif
-    if (nb == 4) {
-        if (E->nwv == 8) return xengine_go<XC<8, 8, false, 1, 2, 4>>(E, st);
-        return xengine_go<XC<12, 6, false, 1, 2, 4>>(E, st);
+    if (nb == 4) { /* 8 compute waves + the four sequences' pollers (168 registers), where the four sequences' activations + the layer table fit the LDS; else 4 + 4 waves */
+        if (!(E->variant_set && E->nwv == 8) && xe_smem<XC<12, 6, false, 1, 2, 4>>(E->args.n_layer) <= 160 * 1024) return xengine_go<XC<12, 6, false, 1, 2, 4>>(E, st);
+        return xengine_go<XC<8, 8, false, 1, 2, 4>>(E, st);
     }
     if (nb == 2) {
         if (E->nwv == 8) return xengine_go<XC<8, 8, false, 1, 2, 2>>(E, st);
@@ -1857,7 +1869,8 @@ template <template <int, int, bool, int, int, int> class XC>
 static size_t xe_shape_smem(int n_seq, int n_layer, bool two_wpc) {
     if (n_seq <= XE_NXCD) return xe_smem<XC<12, 6, false, 1, 2, 1>>(n_layer);
     if (n_seq <= 2 * XE_NXCD) return two_wpc ? 2 * (xe_smem<XC<8, 4, false, 2, 1, 1>>(n_layer) < 54 * 1024 ? (size_t)54 * 1024 : xe_smem<XC<8, 4, false, 2, 1, 1>>(n_layer)) : xe_smem<XC<12, 6, false, 1, 2, 2>>(n_layer);
-    return xe_smem<XC<12, 6, false, 1, 2, 4>>(n_layer);
+    const size_t s12 = xe_smem<XC<12, 6, false, 1, 2, 4>>(n_layer), s8 = xe_smem<XC<8, 8, false, 1, 2, 4>>(n_layer);
+    return s12 < s8 ? s12 : s8;
 }
 // n_steps decode steps of every sequence in ONE launch; with_head: 0 layers only (x_out), 1 + logits, 2 + greedy pick and state update (needed for n_steps > 1)
 int xengine_steps(XEngineHost* E, hipStream_t st, int32_t* d_state, uint16_t* x_out, int with_head, int n_steps) {
@@ -1936,7 +1949,7 @@ void xengine_set_variant(XEngineHost* E, int nwv, int depth) {
         E->two_wpc = depth != 0;
         return;
     }
-    E->nwv = nwv, E->depth = depth;
+    E->nwv = nwv, E->depth = depth, E->variant_set = 1;
 }
 int xengine_debug_enable(XEngineHost* E, int seq, int wg, int max_steps) {
     XArgs& a = E->args;

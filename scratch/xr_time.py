@@ -48,7 +48,7 @@ for n_seq in [int(x) for x in os.environ.get("NSEQ", "8").split(",")]:
         tps = n_seq * steps / best
         print("n_seq %d  waves %2d depth %2d deal %2d  positions %d..%d: %.3f ms per step (all sequences), %.1f tokens/s aggregate, %.1f per sequence, %.1f GB/s = %.3f of 8 TB/s" % (
             n_seq, nwv, depth, deal, pos0, pos0 + steps - 1, best * 1e3 / steps, tps, tps / n_seq, bytes_step * tps / 1e9, bytes_step * tps / 8e12), flush=True)
-    if os.environ.get("STAMPS") and n_seq in (8, 16):
+    if os.environ.get("STAMPS") and n_seq in (8, 16, 32):
         xr.variant(9, 8) if n_seq == 8 else xr.variant(8, 8)
         xr.variant(-1, int(os.environ.get("STAMP_DEAL", "0")))
         nl = cfg["n_layer"]
@@ -62,7 +62,7 @@ for n_seq in [int(x) for x in os.environ.get("NSEQ", "8").split(",")]:
         names = {0: "poll x", 1: "x staged", 2: "qkv staged", 3: "sums in LDS", 4: "partials seen", 5: "ao stored", 6: "ao staged", 7: "xB staged", 8: "act staged",
                  16: "P1 go", 17: "P1 pub", 24: "attn done", 18: "P4 go", 19: "P4 pub", 20: "P5 go", 21: "P5 pub", 22: "P6 go", 23: "P6 pub",
                  9: "own qkv out", 10: "own xB out", 11: "own act out", 12: "own x out"}
-        order = [0, 12, 1, 16, 17, 9, 2, 3, 24, 4, 5, 6, 18, 19, 10, 7, 20, 21, 11, 8, 22, 23]
+        order = [0, 12, 1, 16, 17, 9, 2, 3, 24, 5, 6, 18, 19, 10, 7, 20, 21, 11, 8, 22, 23]
         for step in (1,):
             acc = np.zeros(len(order))
             cnt = 0
