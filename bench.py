@@ -58,8 +58,8 @@ def main():
     ap.add_argument("--autotune", type=int, default=2, help="passes of kf_engine_tune (self-calibrated first-sweep delays of the engine's hand-offs) per position bucket; 0 = the built-in delays")
     ap.add_argument("--streams", type=int, default=0, help="side measurement after the timed region: this many INDEPENDENT decoders (own weights, own "
                     "KV cache, own HIP stream) running concurrently on the GPU over the same positions; 0/1 = skip.  Never part of `value`.")
-    ap.add_argument("--xcd-replicas", type=int, default=16, help="side object beside the line (never `value`): this many INDEPENDENT sequences decoded by one launch, one (<= 8) or two (9 .. 16) per "
-                    "XCD (kf_xengine_*), over the same timed positions; 0 = skip")
+    ap.add_argument("--xcd-replicas", type=int, default=32, help="side object beside the line (never `value`): this many INDEPENDENT sequences decoded by one launch, one decoder per XCD with "
+                    "1 (<= 8 sequences), 2 (<= 16) or 4 (<= 32) sequences each (kf_xengine_*: every unpacked 4-bit block multiplied against all of a decoder's sequences), over the same timed positions; 0 = skip")
     ap.add_argument("--tp-exchange", default="p2p", choices=["p2p", "rccl"], help="--config qwen3-32b --gpus N > 1 runs tensor parallel TP = N (BASELINE config 4): "
                     "p2p = the C++ host's graph with kernel-side exchange over peer-mapped receive areas; rccl = the Python-stepped baseline with two "
                     "torch.distributed all-gathers per layer")
@@ -323,9 +323,13 @@ def main():
         if args.config == "qwen3-0.6b" and args.layers == "q4" and args.sparse == 0.0 and args.xcd_replicas > 0:
             try:   # eight independent decoders, one per XCD, sharing this model's weights (kf_xengine_*): the aggregate beside the single-sequence `value`
                 out["xcd_replicas"] = xcd_replicas(m, cfg, forced, timed_positions, W, args.xcd_replicas, ids_timed_run)
-                if args.xcd_replicas > 8 and "error" not in out["xcd_replicas"]:   # the one-decoder-per-XCD form beside it (what VERDICT r04 asked for by name)
+                keys = ("streams", "batch", "decoders_per_xcd", "tokens_per_s", "per_stream_tokens_per_s", "ms_per_step_all_streams", "frac_vs_single_sequence_roofline", "hbm_frac_batch", "parity", "skipped")
+                if args.xcd_replicas > 16 and "error" not in out["xcd_replicas"]:   # two sequences per decoder beside the four
+                    e16 = xcd_replicas(m, cfg, forced, timed_positions, W, 16, ids_timed_run)
+                    out["xcd_replicas"]["two_per_xcd"] = {k: e16.get(k) for k in keys}
+                if args.xcd_replicas > 8 and "error" not in out["xcd_replicas"]:   # the one-sequence-per-XCD form beside it (what VERDICT r04 asked for by name)
                     e8 = xcd_replicas(m, cfg, forced, timed_positions, W, 8, ids_timed_run)
-                    out["xcd_replicas"]["one_per_xcd"] = {k: e8.get(k) for k in ("streams", "batch", "decoders_per_xcd", "tokens_per_s", "per_stream_tokens_per_s", "ms_per_step_all_streams", "frac_vs_single_sequence_roofline", "hbm_frac_batch", "parity", "skipped")}
+                    out["xcd_replicas"]["one_per_xcd"] = {k: e8.get(k) for k in keys}
             except Exception as e:   # a side measurement must never cost the bench line
                 out["xcd_replicas"] = {"error": repr(e)[:300]}
         _lap("xcd_replicas")
@@ -887,13 +891,16 @@ def xcd_replicas(m, cfg, forced, timed_positions, warmup, n_seq, ids_main, jump=
     S = cfg["max_seq"]
     K = len(timed_positions)
     first = timed_positions[0]
-    traffic, traffic_src = None, None
-    try:   # counter passes of scratch/gpu_r05_profile.sh (not re-collected by this run: --pmc around bench.py itself crashes the profiler on this pool)
+    traffic, traffic_src, valu = None, None, None
+    try:   # counter passes of scratch/gpu_r05_profile.sh / gpu_r06_pmc.sh (not re-collected by this run: --pmc around bench.py itself crashes the profiler on this pool)
         if cfg["dim"] != 1024:
             raise KeyError("the passes were taken on Qwen3-0.6B")
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_xengine_%d.json" % (16 if n_seq > 8 else 8))))
-        traffic = int(pj["hbm_bytes_per_launch"] / ((16 if n_seq > 8 else 8) * 4))
-        traffic_src = "profiles/r05_pmc_xengine_%d.json: FETCH_SIZE / WRITE_SIZE passes of scratch/ub_xengine.py (4 steps per launch at positions 2037..2040), per sequence and step" % (16 if n_seq > 8 else 8)
+        ns = 32 if n_seq > 16 else (16 if n_seq > 8 else 8)
+        pf = "r06_pmc_xengine_%d.json" % ns if ns > 8 else "r05_pmc_xengine_8.json"
+        pj = json.load(open(os.path.join(ROOT, "profiles", pf)))
+        traffic = int(pj["hbm_bytes_per_launch"] / (ns * 4))
+        traffic_src = "profiles/%s: FETCH_SIZE / WRITE_SIZE passes of scratch/ub_xengine.py (4 steps per launch at positions 2037..2040), per sequence and step" % pf
+        valu = int(json.load(open(os.path.join(ROOT, "profiles", pf.replace(".json", "_sq.json"))))["valu_instructions_per_sequence_step"])
     except Exception:
         pass
     if first + K != S or first - warmup < 1:
@@ -957,7 +964,7 @@ def xcd_replicas(m, cfg, forced, timed_positions, warmup, n_seq, ids_main, jump=
         kv_tok = float(np.mean([2.0 * cfg["n_layer"] * (p + 1.5) * cfg["n_kv"] * cfg["head_dim"] * 2 for p in timed_positions]))
         bytes_batch = bytes_tok + (n_seq - 1) * kv_tok
         return {"streams": n_seq, "batch": getattr(xr, "batch", 1), "decoders_per_xcd": getattr(xr, "decoders_per_xcd", 2 if n_seq > 8 else 1),
-                "layout": "32 workgroups of one launch per decoder, every hand-off inside that XCD's L2",
+                "layout": "32 workgroups of one launch per decoder (one decoder per XCD), every hand-off inside that XCD's L2; a decoder's sequences share every unpacked 4-bit block",
                 "tokens_per_s": round(tps, 1), "per_stream_tokens_per_s": round(tps / n_seq, 1),
                 "ms_per_step_all_streams": round(dt * 1e3 / K, 4), "device_ms_per_step": round(dev_ms / K, 4), "steps": K, "positions": "%d..%d" % (first, S - 1),
                 "bytes_per_token_one_sequence": int(bytes_tok), "single_sequence_roofline_tokens_per_s": round(HBM_PEAK_GBS * 1e9 / bytes_tok, 1),
@@ -966,7 +973,7 @@ def xcd_replicas(m, cfg, forced, timed_positions, warmup, n_seq, ids_main, jump=
                 "aggregate_of_independent_sequences": True,
                 "note": "frac_vs_single_sequence_roofline = ONE sequence's algorithmic bytes x aggregate tokens/s / 8 TB/s: a RATE ratio, not HBM utilisation (the decoders share the weights and the "
                         "head: L2 / memory-side-cache traffic); hbm_frac_batch counts the shared bytes once per step of all sequences; never `value`",
-                "traffic_per_sequence_step": traffic, "traffic_source": traffic_src, "prefill_then_decode": prompt_leg,
+                "traffic_per_sequence_step": traffic, "traffic_source": traffic_src, "valu_insts_per_sequence_step": valu, "prefill_then_decode": prompt_leg,
                 "summation_order": "canonical (the only order the XCD-confined engines run)", "kernel": "kf::xengine_kernel (koifish_amd/csrc/kf_xengine.hip)",
                 "parity": {"sequence_0_ids_equal_single_sequence_engine": same, "positions_compared": int(S), "distinct_continuations": distinct,
                            "per_sequence_oracle_parity": "tests/test_gpu_xengine.py (ids, logits, K / V rows of every sequence, bit for bit)"}}

@@ -10,12 +10,14 @@ if ROOT not in sys.path:
 
 
 def pytest_addoption(parser):
+    parser.addoption("--kf-slow", action="store_true", default=False, help="also run the tests marked `slow` (the long forms: full-depth TP, 4096-position runs, every sequence of the widest launches)")
     parser.addoption("--kf-shipped-order", action="store_true", default=False,
                      help="leave the library's own default summation order (canonical) in place for the whole suite instead of starting contexts in the v_dot2c order")
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: the long form of a GPU test whose shortened variant runs by default (run with --kf-slow; the default `-m gpu` run stays inside the driver's step limit)")
     config.addinivalue_line("markers", "fast_order: written against the v_dot2c order on BOTH sides (skipped under --kf-shipped-order)")
     if config.getoption("--kf-shipped-order"):   # the whole suite on what ships by default (run: 630 pass, the fast_order ones skipped)
         return
@@ -35,6 +37,11 @@ def _has_gpu():
 
 
 def pytest_collection_modifyitems(config, items):
+    if not config.getoption("--kf-slow"):
+        sk_slow = pytest.mark.skip(reason="long form: run with --kf-slow (its shortened variant runs by default)")
+        for it in items:
+            if "slow" in it.keywords:
+                it.add_marker(sk_slow)
     if config.getoption("--kf-shipped-order"):
         sk = pytest.mark.skip(reason="compares two v_dot2c-order computations (or a v_dot2c launch with the oracle's dot16 order at its tolerance): not meaningful in the canonical order")
         for it in items:

@@ -27,9 +27,19 @@ def canon():
     O.set_order(O.ORDER_DOT16)
 
 
+_OM = {}
+
+
 def _oracle_run(cfg, raw, forced, n, pos0=0):
-    """the oracle alone on one sequence: teacher-forced where forced >= 0, free running elsewhere -> ids per position, last logits, K / V"""
-    om = oracle_model(cfg, raw, L.Q4, L.BF16, attn_mode=O.ATTN_CANON)
+    """the oracle alone on one sequence: teacher-forced where forced >= 0, free running elsewhere -> ids per position, last logits, K / V.  One oracle model per (cfg, weights)
+    serves every sequence of a test (a sequence starts at position 0 and rewrites the cache rows as it goes): quantising the weights once instead of once per sequence"""
+    key = (raw["embed"][:2, :32].tobytes(), raw["layers"][0]["q"][:2, :32].tobytes(), tuple(sorted((k, str(v)) for k, v in cfg.items())))
+    if key not in _OM:
+        for o in _OM.values():
+            o.close()
+        _OM.clear()
+        _OM[key] = oracle_model(cfg, raw, L.Q4, L.BF16, attn_mode=O.ATTN_CANON)
+    om = _OM[key]
     ids, logits, tok = [], None, int(forced[0])
     for p in range(pos0 + n):
         if forced[p] >= 0:
@@ -39,17 +49,21 @@ def _oracle_run(cfg, raw, forced, n, pos0=0):
         tok = int(o_id)
     k, v = om.kv()
     k, v = k.copy(), v.copy()
-    om.close()
-    return ids, logits, k, v
+    return ids, np.array(logits, copy=True), k, v
 
 
-@pytest.mark.parametrize("cfg_name,max_seq,n_steps,n_seq,spl,form", [("tiny", 96, 90, 8, 7, 0), ("small", 320, 150, 8, 32, 0), ("tiny", 700, 300, 3, 16, 0), ("small", 320, 150, 16, 32, 0),
-                                                                      ("tiny", 700, 200, 11, 9, 0), ("small", 320, 150, 32, 32, 0), ("tiny", 700, 200, 27, 9, 0), ("small", 320, 150, 16, 32, 1),
-                                                                      ("tiny", 700, 200, 11, 9, 1)])
-def test_every_sequence_equals_the_oracle(canon, cfg_name, max_seq, n_steps, n_seq, spl, form):
+SLOW = pytest.mark.slow
+
+
+@pytest.mark.parametrize("cfg_name,max_seq,n_steps,n_seq,spl,form,check", [
+    ("tiny", 96, 90, 8, 7, 0, None), ("small", 320, 150, 8, 32, 0, None), ("tiny", 700, 300, 3, 16, 0, None), ("tiny", 700, 200, 11, 9, 0, None), ("tiny", 700, 130, 27, 9, 0, None),
+    ("small", 320, 150, 16, 32, 0, (0, 3, 6, 9, 12, 15)), ("small", 320, 150, 32, 32, 0, (0, 5, 10, 15, 17, 20, 27, 30)), ("tiny", 700, 130, 11, 9, 1, None),
+    pytest.param("small", 320, 150, 16, 32, 0, None, marks=SLOW), pytest.param("small", 320, 150, 32, 32, 0, None, marks=SLOW), pytest.param("small", 320, 150, 16, 32, 1, None, marks=SLOW)])
+def test_every_sequence_equals_the_oracle(canon, cfg_name, max_seq, n_steps, n_seq, spl, form, check):
     """different prompts per sequence (the first 12 .. 40 ids forced, then free running), several steps per launch: ids at every position, the last logits and all K / V rows
     of every sequence against the oracle run on that sequence alone; n_seq < 8 leaves XCDs idle; n_seq > 8 (round 6): every decoder multiplies each unpacked block against 2
-    (<= 16) or 4 (<= 32) sequences' activations (11, 27: some decoders carry one sequence fewer); form 1: the round-5 form of 9 .. 16 sequences, two decoders per XCD"""
+    (<= 16) or 4 (<= 32) sequences' activations (11, 27: some decoders carry one sequence fewer); form 1: the round-5 form of 9 .. 16 sequences, two decoders per XCD.
+    check: the sequences compared with the oracle (None: all; the default run checks a spread over the XCDs and over a decoder's places on the 3-layer shape, --kf-slow all)"""
     cfg = dict(synth.CONFIGS[cfg_name], max_seq=max_seq)
     raw = synth.raw_weights_numpy(cfg, 4321, w_std=0.1)
     m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
@@ -69,7 +83,7 @@ def test_every_sequence_equals_the_oracle(canon, cfg_name, max_seq, n_steps, n_s
     xr.run_steps(n_steps)
     m.sync()
     xr.check()
-    for s in range(n_seq):
+    for s in (range(n_seq) if check is None else check):
         o_ids, o_logits, ok, ov = _oracle_run(cfg, raw, forced[s], n_steps)
         g_ids = xr.tokens_out(s, n_steps).tolist()
         assert g_ids == o_ids, "sequence %d: first differing position %d" % (s, next(i for i, (a, b) in enumerate(zip(g_ids, o_ids)) if a != b))
@@ -121,15 +135,18 @@ def test_sequences_at_different_positions(canon):
     m.close()
 
 
-def test_full_size_eight_sequences(canon):
-    """Qwen3-0.6B at the benchmark's positions: eight sequences with different histories (each prefilled with its own 2028-token prompt through the batched prefill, whose
+@pytest.mark.parametrize("n_seq", [8, 32, pytest.param(16, marks=SLOW)])
+def test_full_size_eight_sequences(canon, n_seq):
+    """(n_seq 32: the form bench.py's `xcd_replicas` headlines -- four sequences per decoder; 16: two.)
+    Qwen3-0.6B at the benchmark's positions: eight sequences with different histories (each prefilled with its own 2028-token prompt through the batched prefill, whose
     K / V rows are copied into the sequence's cache) decode 2028 .. 2043 in one 16-step launch.  Sequence by sequence: the 16 ids, the last logits and the 16 new K / V rows
     equal the single-sequence engine's on the same history; sequences 0 and 5 also equal the oracle's."""
     import torch
     cfg = dict(synth.CONFIGS["qwen3-0.6b"])
     m = synth.build_on_gpu(cfg, seed=1234, layer_type=L.Q4, head_type=L.BF16, head_std=0.1)
     m.set_canonical(True)
-    P, n, n_seq = 2028, 16, 8
+    P, n = 2028, 16
+    osel = (0, 5) if n_seq == 8 else (0, 21)   # the sequences also compared with the oracle itself
     kvd = cfg["n_kv"] * cfg["head_dim"]
     xr = XcdReplicas(m, n_seq)
     ref = []
@@ -146,7 +163,7 @@ def test_full_size_eight_sequences(canon):
         L.check(hip.kf_d2d(ctx, C.c_void_p(host.kfh_xr_kcache(xr.h, s)), C.c_void_p(host.kfh_kcache(m.h)), C.c_size_t(nbytes)), "kf_d2d")
         L.check(hip.kf_d2d(ctx, C.c_void_p(host.kfh_xr_vcache(xr.h, s)), C.c_void_p(host.kfh_vcache(m.h)), C.c_size_t(nbytes)), "kf_d2d")
         m.sync()
-        hist = m.kv_to_host() if s in (0, 5) else None
+        hist = m.kv_to_host() if s in osel else None
         # the single-sequence engine on the same history
         m.set_forced(free)
         m.set_state(int(toks[P]), P)
@@ -171,7 +188,7 @@ def test_full_size_eight_sequences(canon):
     # two of them against the oracle itself
     om = O.from_device_model(m, attn_mode=O.ATTN_CANON)
     om.prepare_fast()
-    for s in (0, 5):
+    for s in osel:
         ids, logits, rk, rv, toks, hist = ref[s]
         ok, ov = om.kv()
         ok[:, :P] = hist[0][:, :P]
