@@ -1108,7 +1108,10 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
 template <class C>
 __device__ __forceinline__ void xe_head_main(const XArgs& a, const XLds& L, const XSeq (&SS)[C::NB], int epoch, bool more_steps, int wave, int lane) {
     constexpr int NWV = C::NWV, NWG = XE_NWG, nBlk = C::HnBlk, LPR = C::HLPR, RPS = C::HRPS, ITERS = C::Hiters, NB = C::NB;
-    constexpr int HG = NB > 2 ? 2 : (ITERS <= 4 ? 4 : (ITERS <= 5 ? 2 : 1)); /* row slots per batch and wave, two batches in flight: 2 x HG x ITERS x 4 registers (2560-wide rows: 80, 4096-wide: 64) */
+#ifndef XE_HEAD_HG_NB4
+#define XE_HEAD_HG_NB4 2
+#endif
+    constexpr int HG = NB > 2 ? XE_HEAD_HG_NB4 : (ITERS <= 4 ? 4 : (ITERS <= 5 ? 2 : 1)); /* row slots per batch and wave, two batches in flight: 2 x HG x ITERS x 4 registers (2560-wide rows: 80, 4096-wide: 64) */
     constexpr int ND = C::DIM / 256;
     const XSeq& S = SS[0];
     const int wg = S.r;
@@ -1841,35 +1844,47 @@ static int xengine_go_shape(XEngineHost* E, hipStream_t st) {
     const bool two = E->args.n_seq > XE_NXCD && nb == 1;
 #ifndef XE_ONLY_DEFAULT
     const bool dbg = E->args.dbg != nullptr;
-    if (dbg && nb == 4) return xengine_go<XC<12, 6, true, 1, 2, 4>>(E, st);
-    if (dbg && nb == 2) return xengine_go<XC<12, 6, true, 1, 2, 2>>(E, st);
+    if (dbg && nb == 4) return xengine_go<XC<12, 2, true, 1, 2, 4>>(E, st);
+    if (dbg && nb == 2) return xengine_go<XC<12, 4, true, 1, 2, 2>>(E, st);
     if (dbg && nb == 1) return two ? xengine_go<XC<8, 4, true, 2, 1, 1>>(E, st) : xengine_go<XC<9, 8, true, 1, 2, 1>>(E, st);
 #endif
     if (nb == 4) { /* 8 compute waves + the four sequences' pollers (168 registers), where the four sequences' activations + the layer table fit the LDS; else 4 + 4 waves */
-        if (!(E->variant_set && E->nwv == 8) && xe_smem<XC<12, 6, false, 1, 2, 4>>(E->args.n_layer) <= 160 * 1024) return xengine_go<XC<12, 6, false, 1, 2, 4>>(E, st);
+#ifdef XE_NB4_VARIANTS /* tuning builds only */
+        if (E->variant_set && E->nwv == 12 && E->depth == 8) return xengine_go<XC<12, 8, false, 1, 2, 4>>(E, st);
+        if (E->variant_set && E->nwv == 12 && E->depth == 4) return xengine_go<XC<12, 4, false, 1, 2, 4>>(E, st);
+        if (E->variant_set && E->nwv == 12 && E->depth == 61) return xengine_go<XC<12, 6, false, 1, 1, 4>>(E, st);
+        if (E->variant_set && E->nwv == 12 && E->depth == 41) return xengine_go<XC<12, 4, false, 1, 1, 4>>(E, st);
+        if (E->variant_set && E->nwv == 12 && E->depth == 21) return xengine_go<XC<12, 2, false, 1, 1, 4>>(E, st);
+        if (E->variant_set && E->nwv == 12 && E->depth == 6) return xengine_go<XC<12, 6, false, 1, 2, 4>>(E, st);
+#endif
+        // ring depth 2 (measured, 32 sequences at 2 k keys, tokens/s: depth 8 5320 -- spills --, 6 6970, 4 7360, 2 7815; one key tile per attention batch 7480 / 7720 at depth 6 / 2): with
+        // four sequences' chain pairs and activation chunks live, every register the ring does not hold is worth more than a deeper queue -- twelve waves hide the latency
+        if (!(E->variant_set && E->nwv == 8) && xe_smem<XC<12, 2, false, 1, 2, 4>>(E->args.n_layer) <= 160 * 1024) return xengine_go<XC<12, 2, false, 1, 2, 4>>(E, st);
         return xengine_go<XC<8, 8, false, 1, 2, 4>>(E, st);
     }
     if (nb == 2) {
-        if (E->nwv == 8) return xengine_go<XC<8, 8, false, 1, 2, 2>>(E, st);
-        if (E->nwv == 12 && E->depth == 8) return xengine_go<XC<12, 8, false, 1, 2, 2>>(E, st);
-        return xengine_go<XC<12, 6, false, 1, 2, 2>>(E, st);
-    }
-#if XE_VARIANTS && !defined(XE_ONLY_DEFAULT)
-    if (!two) {
-        if (E->nwv == 8 && E->depth == 8) return xengine_go<XC<8, 8, false, 1, 2, 1>>(E, st);
-        if (E->nwv == 12 && E->depth == 8) return xengine_go<XC<12, 8, false, 1, 2, 1>>(E, st);
-        if (E->nwv == 9 && E->depth == 6) return xengine_go<XC<9, 6, false, 1, 2, 1>>(E, st);
-    }
+#ifdef XE_NB4_VARIANTS /* tuning builds only */
+        if (E->variant_set && E->nwv == 12 && E->depth == 61) return xengine_go<XC<12, 6, false, 1, 1, 2>>(E, st);
+        if (E->variant_set && E->nwv == 12 && E->depth == 6) return xengine_go<XC<12, 6, false, 1, 2, 2>>(E, st);
+        if (E->variant_set && E->nwv == 12 && E->depth == 41) return xengine_go<XC<12, 4, false, 1, 1, 2>>(E, st);
+        if (E->variant_set && E->nwv == 12 && E->depth == 2) return xengine_go<XC<12, 2, false, 1, 2, 2>>(E, st);
 #endif
-    if (!two && E->nwv == 12) return xengine_go<XC<12, 6, false, 1, 2, 1>>(E, st);
-    return two ? xengine_go<XC<8, 4, false, 2, 1, 1>>(E, st) : xengine_go<XC<9, 8, false, 1, 2, 1>>(E, st);
+        if (E->variant_set && E->nwv == 8) return xengine_go<XC<8, 8, false, 1, 2, 2>>(E, st);
+        return xengine_go<XC<12, 4, false, 1, 2, 2>>(E, st); /* (16 sequences: depth 6 5990, 4 6250, 2 6200 tokens/s) */
+    }
+#ifdef XE_NB4_VARIANTS
+    if (!two && E->variant_set && E->nwv == 12 && E->depth == 4) return xengine_go<XC<12, 4, false, 1, 2, 1>>(E, st);
+#endif
+    if (!two && E->variant_set && E->nwv == 12 && E->depth == 6) return xengine_go<XC<12, 6, false, 1, 2, 1>>(E, st);
+    if (!two && E->variant_set && E->nwv == 9) return xengine_go<XC<9, 8, false, 1, 2, 1>>(E, st);
+    return two ? xengine_go<XC<8, 4, false, 2, 1, 1>>(E, st) : xengine_go<XC<12, 2, false, 1, 2, 1>>(E, st); /* (8 sequences: depth 6 4370, 4 4570, 2 4630 tokens/s) */
 }
 // the LDS the chosen form needs (classes 1 and 2), so that create / served can refuse a model too deep for it instead of the first step
 template <template <int, int, bool, int, int, int> class XC>
 static size_t xe_shape_smem(int n_seq, int n_layer, bool two_wpc) {
-    if (n_seq <= XE_NXCD) return xe_smem<XC<12, 6, false, 1, 2, 1>>(n_layer);
-    if (n_seq <= 2 * XE_NXCD) return two_wpc ? 2 * (xe_smem<XC<8, 4, false, 2, 1, 1>>(n_layer) < 54 * 1024 ? (size_t)54 * 1024 : xe_smem<XC<8, 4, false, 2, 1, 1>>(n_layer)) : xe_smem<XC<12, 6, false, 1, 2, 2>>(n_layer);
-    const size_t s12 = xe_smem<XC<12, 6, false, 1, 2, 4>>(n_layer), s8 = xe_smem<XC<8, 8, false, 1, 2, 4>>(n_layer);
+    if (n_seq <= XE_NXCD) return xe_smem<XC<12, 2, false, 1, 2, 1>>(n_layer);
+    if (n_seq <= 2 * XE_NXCD) return two_wpc ? 2 * (xe_smem<XC<8, 4, false, 2, 1, 1>>(n_layer) < 54 * 1024 ? (size_t)54 * 1024 : xe_smem<XC<8, 4, false, 2, 1, 1>>(n_layer)) : xe_smem<XC<12, 4, false, 1, 2, 2>>(n_layer);
+    const size_t s12 = xe_smem<XC<12, 2, false, 1, 2, 4>>(n_layer), s8 = xe_smem<XC<8, 8, false, 1, 2, 4>>(n_layer);
     return s12 < s8 ? s12 : s8;
 }
 // n_steps decode steps of every sequence in ONE launch; with_head: 0 layers only (x_out), 1 + logits, 2 + greedy pick and state update (needed for n_steps > 1)
@@ -1882,6 +1897,14 @@ int xengine_steps(XEngineHost* E, hipStream_t st, int32_t* d_state, uint16_t* x_
     a.epoch0 = E->epoch, E->epoch += n_steps; /* generations never repeat between resets (a 31-bit count of steps) */
     if (!with_head) a.head_w = nullptr;
     int rc;
+#ifdef XE_NB4_VARIANTS /* tuning builds: the ring depth of the other shapes */
+    if (E->shape_class == 3 && a.n_seq <= XE_NXCD && E->variant_set && E->depth == 4) rc = xengine_go<XC3<12, 4, false, 1>>(E, st);
+    else if (E->shape_class == 3 && a.n_seq <= XE_NXCD && E->variant_set && E->depth == 2) rc = xengine_go<XC3<12, 2, false, 1>>(E, st);
+    else if (E->shape_class == 4 && E->variant_set && E->depth == 4) rc = xengine_go<XCfg<FMT_Q4P, 4, 128, 12, 2560, 4096, 1024, 9728, 4, false, 1, 1>>(E, st);
+    else if (E->shape_class == 4 && E->variant_set && E->depth == 2) rc = xengine_go<XCfg<FMT_Q4P, 4, 128, 12, 2560, 4096, 1024, 9728, 2, false, 1, 1>>(E, st);
+    else if (E->shape_class == 5 && E->variant_set && E->depth == 2) rc = xengine_go<XCfg<FMT_Q4P, 4, 128, 12, 4096, 4096, 1024, 12288, 2, false, 1, 1>>(E, st);
+    else
+#endif
     if (E->shape_class == 3) /* the default instantiations only (no tuning variants, no stamps) */
         rc = a.n_seq > XE_NXCD ? xengine_go<XC3<8, 4, false, 2, 1>>(E, st) : xengine_go<XC3<12, 6, false, 1>>(E, st);
     else if (E->shape_class == 4)
