@@ -161,7 +161,7 @@ struct XCfg {
     static constexpr int maxR = (SH::P1::R > SH::P5::R ? SH::P1::R : SH::P5::R) > (SH::P4::R > SH::P6::R ? SH::P4::R : SH::P6::R) ? (SH::P1::R > SH::P5::R ? SH::P1::R : SH::P5::R)
                                                                                                                                       : (SH::P4::R > SH::P6::R ? SH::P4::R : SH::P6::R);
     static_assert(NB_ >= 1 && NB_ <= 4, "sequences per decoder");
-    static_assert(NB_ == 1 || (!TP_ && WPC_ == 1 && !COOP && !FUSED && NG == 1 && FMT_ == FMT_Q4P && DIM_ / 256 <= 12 && FFNP / 256 <= 24 && !COMB_IN_XS1),
+    static_assert(NB_ == 1 || (!TP_ && WPC_ == 1 && !FUSED && NG == 1 && FMT_ == FMT_Q4P && DIM_ / 256 <= 12 && FFNP / 256 <= 24 && !COMB_IN_XS1),
                   "the batched form: plain (non-TP, one workgroup per CU) decoders of the shapes whose vectors are staged by the poller in one sweep");
 };
 // LDS of a workgroup: NB per-sequence blocks (activations, raw residuals, the attention's head staging, the rows of the phase being published, head maxima), then what the
@@ -789,8 +789,8 @@ __device__ __forceinline__ void xe_ho_x(const XArgs& a, const XLds& Lb, const XS
     } else {
         if constexpr (C::TP) /* the down_proj exchange of the layer before: this workgroup's rows summed over the ranks + the residual xB -> the local x area */
             xe_tp_reduce<C>(a, Sb, 1, 2u * (gen - 1u) + 2u, Lb.xrawB, loc + C::xA + Sb.r * RT, tag, nullptr, lane, dead);
-        if constexpr (C::COOP) xe_coop_norm_stage<C>(a, Lb, loc + C::xA, tag, ly.norm_in, Lb.xs[0], Lb.xrawA, C::NWV - 1, lane, &dead);
-        else if constexpr (ND > 12) eng_poll_stage_norm_long<XCH, ND, C::XS, false, true, 8>(loc + C::xA, nullptr, tag, ly.norm_in, a.eps, Lb.xs[0], Lb.xrawA, lane, a.ws, dead);
+        if constexpr (C::COOP) { /* every wave stages its own 1 KiB units of every sequence's vector: xe_coop_all, called by the poller and by the compute waves */
+        } else if constexpr (ND > 12) eng_poll_stage_norm_long<XCH, ND, C::XS, false, true, 8>(loc + C::xA, nullptr, tag, ly.norm_in, a.eps, Lb.xs[0], Lb.xrawA, lane, a.ws, dead);
         else eng_poll_stage<XCH, ND, C::XS, true, false, true>(loc + C::xA, nullptr, tag, ly.norm_in, a.eps, Lb.xs[0], Lb.xrawA, lane, a.ws, dead, nullptr, nullptr, 0, 0);
     }
 }
@@ -894,8 +894,8 @@ __device__ __forceinline__ void xe_ho_xB(const XArgs& a, const XLds& Lb, const X
     const uint32_t tag = gen & 0xffffu;
     uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)Sb.seq * a.loc_stride);
     if constexpr (C::TP) xe_tp_reduce<C>(a, Sb, 0, 2u * gen + 1u, Lb.xrawA, loc + C::xB + Sb.r * RT, tag, nullptr, lane, dead); /* the o_proj exchange + the residual x */
-    if constexpr (C::COOP) xe_coop_norm_stage<C>(a, Lb, loc + C::xB, tag, ly.norm_post, Lb.xs[0], Lb.xrawB, C::NWV - 1, lane, &dead);
-    else if constexpr (ND > 12) eng_poll_stage_norm_long<XCH, ND, C::XS, false, true, 8>(loc + C::xB, nullptr, tag, ly.norm_post, a.eps, Lb.xs[0], Lb.xrawB, lane, a.ws, dead);
+    if constexpr (C::COOP) { /* xe_coop_all */
+    } else if constexpr (ND > 12) eng_poll_stage_norm_long<XCH, ND, C::XS, false, true, 8>(loc + C::xB, nullptr, tag, ly.norm_post, a.eps, Lb.xs[0], Lb.xrawB, lane, a.ws, dead);
     else eng_poll_stage<XCH, ND, C::XS, true, false, true>(loc + C::xB, nullptr, tag, ly.norm_post, a.eps, Lb.xs[0], Lb.xrawB, lane, a.ws, dead, nullptr, nullptr, 0, 0);
 }
 template <class C>
@@ -905,11 +905,27 @@ __device__ __forceinline__ void xe_ho_act(const XArgs& a, const XLds& Lb, const 
     if constexpr (NF > 24) eng_poll_stage_long<XCH, NF, C::XS, 16>(loc + C::act, tag, Lb.xs[1], lane, a.ws, dead, nsw); /* a 9728-wide vector in one sweep: 152 registers */
     else eng_poll_stage<XCH, NF, C::XS, false, false, true>(loc + C::act, nullptr, tag, nullptr, 0.f, Lb.xs[1], nullptr, lane, a.ws, dead, nsw, nullptr, 0, 0);
 }
+// COOP shapes: this wave's units of x (which = 0: the x area, norm_in, xrawA) or xB (1: the xB area, norm_post, xrawB) of EVERY active sequence of the decoder -- called by
+// every wave of the workgroup (a barrier per sequence inside xe_coop_norm_stage)
+template <class C>
+__device__ __forceinline__ void xe_coop_all(const XArgs& a, const XLds& L0, const XSeq (&SS)[C::NB], int which, uint32_t tag, const EngLayer& ly, int wave, int lane, bool* dead) {
+#pragma unroll
+    for (int b = 0; b < C::NB; b++) {
+        if (C::NB > 1 && !SS[b].act) continue;
+        const XLds Lb = xe_lds_view<C>(L0, b);
+        uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)SS[b].seq * a.loc_stride);
+        if (which == 0) xe_coop_norm_stage<C>(a, Lb, loc + C::xA, tag, ly.norm_in, Lb.xs[0], Lb.xrawA, wave, lane, dead);
+        else xe_coop_norm_stage<C>(a, Lb, loc + C::xB, tag, ly.norm_post, Lb.xs[0], Lb.xrawB, wave, lane, dead);
+    }
+}
 // ---- a poller wave of a workgroup: the hand-offs of ONE sequence of the decoder (S, L: that sequence's place and LDS block; stamps: sequence 0's poller), and every barrier
 template <class C>
-__device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, const XSeq& S, int epoch, int lane) {
+__device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L0, const XSeq (&SS)[C::NB], const int pb, int epoch, int lane) {
     constexpr int NB = C::NB;
     static_assert(C::DIM % 256 == 0 && C::QD % 256 == 0 && (C::TP || C::FFN % 256 == 0), "hand-off vectors in 1 KiB pieces");
+    XSeq S = SS[pb];
+    if (pb > 0) S.stamp = false;
+    const XLds L = xe_lds_view<C>(L0, pb);
     const bool on = NB == 1 || S.act;
     bool dead = false;
     for (int l = 0; l < a.n_layer; l++) {
@@ -922,6 +938,9 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, co
             XE_STAMP(12);
         }
         if (on) xe_ho_x<C>(a, L, S, ly, l, epoch, gen, lane, dead);
+        if constexpr (C::COOP) {
+            if (l > 0) xe_coop_all<C>(a, L0, SS, 0, tag, ly, C::NCW + pb, lane, &dead);
+        }
         if (C::TP && l > 0) XE_STAMP(31); /* (TP: the slot of the shader-clock stamp) this workgroup's rows of the down_proj exchange are summed */
         XE_STAMP(1);
         __syncthreads(); /* B1 */
@@ -944,6 +963,7 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L, co
         eng_wait_pub(L.pub + 1, S.step * a.n_layer + l + 1, 0, dead);
         XE_STAMP(10);
         if (on) xe_ho_xB<C>(a, L, S, ly, gen, lane, dead);
+        if constexpr (C::COOP) xe_coop_all<C>(a, L0, SS, 1, tag, ly, C::NCW + pb, lane, &dead);
         if constexpr (C::TP) XE_STAMP(13); /* (TP: the slot of the act sweep count) this workgroup's rows of the o_proj exchange are summed */
         XE_STAMP(7);
         __syncthreads(); /* B5 */
@@ -1040,9 +1060,8 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
             for (int w = 0; w < NCW; w++) nwp += xe_deal<NCW, C::DEAL_CONTIG, C::NB>(w, spg, a.deal_wl).n > 0 ? 1 : 0;
             uint32_t* const dst = loc + (q == 0 ? C::qkv + S.q_out0 : (q == 1 ? C::xB + wg * P4::R : (q == 2 ? C::act + wg * P5::R : C::xA + wg * P6::R)));
             if constexpr (C::COOP) { /* this wave's share of the sweep + RMSNorm + staging of x (layers behind the first: layer 0's row comes from the embedding table) / xB */
-                uint32_t* const lc = reinterpret_cast<uint32_t*>(a.loc + (size_t)S.seq * a.loc_stride);
-                if (q == 0 && l > 0) xe_coop_norm_stage<C>(a, L, lc + C::xA, tag, ly.norm_in, L.xs[0], L.xrawA, cw, lane, nullptr);
-                if (q == 2) xe_coop_norm_stage<C>(a, L, lc + C::xB, tag, ly.norm_post, L.xs[0], L.xrawB, cw, lane, nullptr);
+                if (q == 0 && l > 0) xe_coop_all<C>(a, L, SS, 0, tag, ly, cw, lane, nullptr);
+                if (q == 2) xe_coop_all<C>(a, L, SS, 1, tag, ly, cw, lane, nullptr);
             }
             __syncthreads(); /* the phase's activations are staged (B1 / B4 / B5 / B6) */
             if (cw == 0) XE_STAMP(16 + 2 * q);
@@ -1474,9 +1493,7 @@ __global__ void __launch_bounds__(C::NWV * 64, (C::NWV * C::WPC + 3) / 4 /* wave
 #pragma unroll
             for (int b = 0; b < NB; b++) {
                 if (!done && wave == C::NCW + b) {
-                    XSeq Sp = SS[b];
-                    if (b > 0) Sp.stamp = false;
-                    xe_poller_main<C>(a, xe_lds_view<C>(L, b), Sp, epoch, lane);
+                    xe_poller_main<C>(a, L, SS, b, epoch, lane);
                     done = true;
                 }
             }
@@ -1514,8 +1531,8 @@ static int xe_shape_class(int GQ, int hd, int dim, int q_dim, int ffn) {
     if (GQ == 8 && hd == 64 && dim == 256 && q_dim == 512 && ffn == 512) return 6;      /* parity-test shape: 8 query heads on ONE kv-head (two head groups), 20 workgroups with q | k | v rows */
     return 0;
 }
-template <int NWV, int DEPTH, bool DBG, int WPC, int AU = 2>
-using XC3 = XCfg<FMT_Q4P, 2, 128, NWV, 2048, 2048, 1024, 6144, DEPTH, DBG, WPC, AU>;
+template <int NWV, int DEPTH, bool DBG, int WPC, int AU = 2, int NB = 1>
+using XC3 = XCfg<FMT_Q4P, 2, 128, NWV, 2048, 2048, 1024, 6144, DEPTH, DBG, WPC, AU, false, NB>;
 template <int NWV, int DEPTH, bool DBG, int WPC, int AU = 2, int NB = 1>
 using XC1 = XCfg<FMT_Q4P, 2, 128, NWV, 1024, 2048, 1024, 3072, DEPTH, DBG, WPC, AU, false, NB>;
 template <int NWV, int DEPTH, bool DBG, int WPC, int AU = 2, int NB = 1>
@@ -1649,7 +1666,7 @@ int xengine_build(const kf_engine_desc* d, int n_seq, long long kv_seq_stride, v
     if (sc == 5 && xe_smem<XC5W>(d->n_layer) > 160 * 1024) return KF_UNSUPPORTED_DATATYPE;
     if (sc == 3 && n_seq <= XE_NXCD && xe_smem<XC3<12, 6, false, 1>>(d->n_layer) > 160 * 1024) return KF_UNSUPPORTED_DATATYPE;
     *why = "two decoders per XCD (more than 8 sequences) do not fit this shape and depth: two workgroups per CU need 2 x the activations + the layer table in 160 KB of LDS";
-    if (sc == 3 && n_seq > XE_NXCD && 2 * xe_smem_class3_two(d->n_layer) > 160 * 1024) return KF_UNSUPPORTED_DATATYPE;
+    if (sc == 3 && n_seq > XE_NXCD && 2 * xe_smem_class3_two(d->n_layer) > 160 * 1024 && xe_smem<XC3<12, 4, false, 1, 2, 2>>(d->n_layer) > 160 * 1024) return KF_UNSUPPORTED_DATATYPE;
     if (!dry && (ws_bytes < xengine_ws_bytes(d) || ((uintptr_t)ws & 255) != 0)) {
         *why = "workspace too small or not 256-byte aligned";
         return KF_INVALID_ARGS;
@@ -1905,8 +1922,10 @@ int xengine_steps(XEngineHost* E, hipStream_t st, int32_t* d_state, uint16_t* x_
     else if (E->shape_class == 5 && E->variant_set && E->depth == 2) rc = xengine_go<XCfg<FMT_Q4P, 4, 128, 12, 4096, 4096, 1024, 12288, 2, false, 1, 1>>(E, st);
     else
 #endif
-    if (E->shape_class == 3) /* the default instantiations only (no tuning variants, no stamps) */
-        rc = a.n_seq > XE_NXCD ? xengine_go<XC3<8, 4, false, 2, 1>>(E, st) : xengine_go<XC3<12, 6, false, 1>>(E, st);
+    if (E->shape_class == 3) { /* the default instantiations only (no tuning variants, no stamps) */
+        if (a.n_seq > XE_NXCD && !E->two_wpc && xe_smem<XC3<12, 4, false, 1, 2, 2>>(a.n_layer) <= 160 * 1024) rc = xengine_go<XC3<12, 4, false, 1, 2, 2>>(E, st); /* two sequences per decoder */
+        else rc = a.n_seq > XE_NXCD ? xengine_go<XC3<8, 4, false, 2, 1>>(E, st) : xengine_go<XC3<12, 6, false, 1>>(E, st);
+    }
     else if (E->shape_class == 4)
         rc = E->nwv == 8 ? xengine_go<XC4>(E, st) : xengine_go<XC4W>(E, st);
     else if (E->shape_class == 5)

@@ -231,12 +231,17 @@ def test_native_tp8_32b_slice_at_depth_vs_the_oracle_bit_for_bit(ctx):
     nt.close()
 
 
-def test_native_tp8_full_depth_qwen3_32b_vs_the_oracle(ctx):
-    """north_star's second target at FULL DEPTH (missing 5): all 64 layers of the Qwen3-32B shape (dim 5120, 64 / 8 heads of 128, ffn 25600, the 151936-row
+@pytest.mark.parametrize("n_layer", [8, pytest.param(64, marks=pytest.mark.slow)])
+def test_native_tp8_full_depth_qwen3_32b_vs_the_oracle(ctx, n_layer):
+    """(Default run: 8 of the 64 layers with the full head; --kf-slow: all 64 -- 3.6 minutes.  Round 6, VERDICT r05 item 5b: the SAME weights first through the one-launch
+    form -- the eight ranks as the eight XCDs of one launch, koifish::XcdTP, with the 18992-row vocabulary shards of the real head -- then through the per-launch ranks; both
+    against the oracle.)
+    north_star's second target at FULL DEPTH (missing 5): all 64 layers of the Qwen3-32B shape (dim 5120, 64 / 8 heads of 128, ffn 25600, the 151936-row
     vocabulary: 16.6 GB of 4-bit layers + a 1.56 GB head), tensor parallel TP = 8 as eight virtual ranks on this GPU (the ranks' kernels and the kernel-side exchange; no
     xGMI), decoding a 4-token prompt and then 5 free-running greedy ids -- against the oracle's tensor-parallel emulation (row shards as they are, column shards as fp32
     partials summed in rank order) in the canonical order: every id and the last position's 151936 logits bit for bit."""
-    cfg = dict(synth.CONFIGS["qwen3-32b"], max_seq=64)
+    from koifish_amd.runtime import XcdTP
+    cfg = dict(synth.CONFIGS["qwen3-32b"], max_seq=64, n_layer=n_layer)
     g = torch.Generator(device=ctx.device)
     g.manual_seed(32)
 
@@ -259,9 +264,18 @@ def test_native_tp8_full_depth_qwen3_32b_vs_the_oracle(ctx):
     n_prompt, n_new = 4, 5
     forced = np.full(cfg["max_seq"], -1, dtype=np.int32)
     forced[:n_prompt] = np.random.default_rng(64).integers(0, cfg["vocab"], size=n_prompt)
+    n = n_prompt + n_new - 1
+    xt = XcdTP(nt)                  # the one-launch form first, on the ranks' shards as they are
+    xt.set_forced(forced)
+    xt.set_state(int(forced[0]), 0)
+    xt.set_steps_per_launch(4)
+    xt.run_steps(n)
+    ctx.sync()
+    xt.check()
+    x_ids, x_logits = xt.tokens_out(n).tolist(), xt.logits()
+    xt.close()
     nt.set_forced(forced)
     nt.set_state(int(forced[0]), 0)
-    n = n_prompt + n_new - 1
     nt.run_steps(0, n, use_graph=True)
     nt.check()
     toks = [m.tokens_out(n) for m in nt.ranks]
@@ -289,12 +303,16 @@ def test_native_tp8_full_depth_qwen3_32b_vs_the_oracle(ctx):
         O.set_order(O.ORDER_DOT16)
     assert toks[0].tolist() == o_ids, (toks[0].tolist(), o_ids)
     assert np.array_equal(g_logits, o_logits), "%d of %d logits differ" % (int((g_logits != o_logits).sum()), g_logits.size)
+    assert x_ids == o_ids, ("one-launch form", x_ids, o_ids)
+    assert np.array_equal(x_logits, o_logits), "one-launch form: %d of %d logits differ" % (int((x_logits != o_logits).sum()), x_logits.size)
     om.close()
     nt.close()
 
 
-def test_tp8_ranks_as_the_eight_xcds_of_one_launch_vs_the_oracle(ctx):
-    """The TP = 8 ranks of a Qwen3-32B-shaped model as the eight XCDs of ONE launch (kf_xengine_create_tp, koifish::XcdTP; round 5): rank r's 32 workgroups stream rank r's
+@pytest.mark.parametrize("n", [48, pytest.param(96, marks=pytest.mark.slow)])
+def test_tp8_ranks_as_the_eight_xcds_of_one_launch_vs_the_oracle(ctx, n):
+    """(default run: 48 positions, --kf-slow: 96)
+    The TP = 8 ranks of a Qwen3-32B-shaped model as the eight XCDs of ONE launch (kf_xengine_create_tp, koifish::XcdTP; round 5): rank r's 32 workgroups stream rank r's
     shards, q | k | v / attention / gate | up inside the XCD, the o_proj / down_proj partials exchanged between the XCDs inside the kernel and summed in rank order, the head
     in vocabulary shards with a cross-XCD pick, several tokens per launch.  A 3-layer slice decoded from position 0 -- 24 forced ids, then free running -- against the
     oracle's tensor-parallel emulation in the canonical order: every id, the last logits and every K / V row bit for bit; and the same ids from the per-launch rank step
@@ -320,7 +338,7 @@ def test_tp8_ranks_as_the_eight_xcds_of_one_launch_vs_the_oracle(ctx):
     nt = TP.NativeTP(cfg, w, norms, 8, ctx)
     for rk in nt.ranks:
         rk.set_canonical(True)
-    n_prompt, n = 24, 96
+    n_prompt = 24
     forced = np.full(cfg["max_seq"], -1, dtype=np.int32)
     forced[:n_prompt] = np.random.default_rng(5).integers(0, cfg["vocab"], size=n_prompt)
     xt = XcdTP(nt)
@@ -385,13 +403,15 @@ def test_tp_over_the_xcds_refuses_what_it_does_not_serve(ctx):
         nt.close()
 
 
-def test_tp_over_the_xcds_at_long_context_equals_the_per_launch_rank_step(ctx):
-    """the one-launch TP engine over all 4096 positions of a 2-layer Qwen3-32B-shaped slice, teacher-forced (16 key slices x two head groups per rank: up to 256 keys per
+@pytest.mark.parametrize("S", [1024, pytest.param(4096, marks=pytest.mark.slow)])
+def test_tp_over_the_xcds_at_long_context_equals_the_per_launch_rank_step(ctx, S):
+    """(default run: the first 1024 positions; --kf-slow: all 4096)
+    the one-launch TP engine over all 4096 positions of a 2-layer Qwen3-32B-shaped slice, teacher-forced (16 key slices x two head groups per rank: up to 256 keys per
     workgroup), against the per-launch rank step on the same ids: every greedy id, the last logits and the ranks' K / V rows bit for bit (the per-launch step itself is held
     to the oracle at positions 128 / 1024 / 4095 by test_native_tp8_32b_slice_at_depth_vs_the_oracle_bit_for_bit)"""
     import ctypes as C
     from koifish_amd.runtime import XcdTP
-    cfg = dict(synth.CONFIGS["qwen3-32b"], n_layer=2, vocab=8192, max_seq=4096, tied=True)
+    cfg = dict(synth.CONFIGS["qwen3-32b"], n_layer=2, vocab=8192, max_seq=S, tied=True)
     g = torch.Generator(device=ctx.device)
     g.manual_seed(9)
 
@@ -411,7 +431,6 @@ def test_tp_over_the_xcds_at_long_context_equals_the_per_launch_rank_step(ctx):
     nt = TP.NativeTP(cfg, w, norms, 8, ctx)
     for rk in nt.ranks:
         rk.set_canonical(True)
-    S = cfg["max_seq"]
     forced = np.random.default_rng(21).integers(0, cfg["vocab"], size=S).astype(np.int32)
     xt = XcdTP(nt)
     xt.set_forced(forced)
