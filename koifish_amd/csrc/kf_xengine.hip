@@ -1863,7 +1863,7 @@ static int xengine_go_shape(XEngineHost* E, hipStream_t st) {
     const bool dbg = E->args.dbg != nullptr;
     if (dbg && nb == 4) return xengine_go<XC<12, 2, true, 1, 2, 4>>(E, st);
     if (dbg && nb == 2) return xengine_go<XC<12, 4, true, 1, 2, 2>>(E, st);
-    if (dbg && nb == 1) return two ? xengine_go<XC<8, 4, true, 2, 1, 1>>(E, st) : xengine_go<XC<9, 8, true, 1, 2, 1>>(E, st);
+    if (dbg && nb == 1) return two ? xengine_go<XC<8, 4, true, 2, 1, 1>>(E, st) : xengine_go<XC<12, 2, true, 1, 2, 1>>(E, st);
 #endif
     if (nb == 4) { /* 8 compute waves + the four sequences' pollers (168 registers), where the four sequences' activations + the layer table fit the LDS; else 4 + 4 waves */
 #ifdef XE_NB4_VARIANTS /* tuning builds only */

@@ -49,7 +49,6 @@ for n_seq in [int(x) for x in os.environ.get("NSEQ", "8").split(",")]:
         print("n_seq %d  waves %2d depth %2d deal %2d  positions %d..%d: %.3f ms per step (all sequences), %.1f tokens/s aggregate, %.1f per sequence, %.1f GB/s = %.3f of 8 TB/s" % (
             n_seq, nwv, depth, deal, pos0, pos0 + steps - 1, best * 1e3 / steps, tps, tps / n_seq, bytes_step * tps / 1e9, bytes_step * tps / 8e12), flush=True)
     if os.environ.get("STAMPS") and n_seq in (8, 16, 32):
-        xr.variant(9, 8) if n_seq == 8 else xr.variant(8, 8)
         xr.variant(-1, int(os.environ.get("STAMP_DEAL", "0")))
         nl = cfg["n_layer"]
         xr.stamps(int(os.environ.get("STAMP_SEQ", "3")), int(os.environ.get("STAMP_WG", "5")), 2, nl)
