@@ -121,7 +121,7 @@ def main():
     K, W = args.steps, args.warmup
     if K < 1 or W < 0:
         raise SystemExit("steps >= 1, warmup >= 0")
-    if args.config == "qwen3-32b" and (world > 1 or args.tp_virtual > 1):
+    if (args.config == "qwen3-32b" and world > 1) or args.tp_virtual > 1:   # (--tp-virtual 8 --tp-xcd 1 also serves ONE sequence of Qwen3-4B / 8B: the eight TP ranks as the eight XCDs)
         return tp_main(args, cfg, rank, world, dev)
     head_type = {"bf16": L.BF16, "q4": L.Q4, "nf4": L.NF4}[args.head]
     layer_type = {"q4": L.Q4, "bf16": L.BF16, "f8": L.F8E5M2, "ternary": L.T_SIGN, "1bit": L.BOOL1, "nf4": L.NF4}[args.layers]
@@ -476,7 +476,11 @@ def side_legs(which):
     for nm, title in (("qwen3_4b", "Qwen3-4B shape (dim 2560, 32 / 8 heads of 128, ffn 9728, 36 layers)"), ("qwen3_8b", "Qwen3-8B shape (dim 4096, 32 / 8 heads of 128, ffn 12288, 36 layers)")):
         if nm in which:   # not BASELINE configurations: the GQA-4 models the reference lists as supported (cases/tutorial/history.md:4-6); round 5: served by the XCD-confined engines
             d = _child(["--config", nm.replace("_", "-"), "--steps", "64", "--warmup", "16", "--lean", "--lean-xcd", "8", "--jump"], 600)
+            # ONE sequence through the eight XCDs as the eight tensor-parallel ranks of the model (round 6: kf_xengine_create_tp serves the TP = 8 ranks of Qwen3-8B and of Qwen3-4B with
+            # its FFN padded to whole groups per rank); the bits are those of the TP = 8 rank step (oracle: tests/test_gpu_tp.py), not of the unsplit model
+            t = _child(["--config", nm.replace("_", "-"), "--tp-virtual", "8", "--tp-xcd", "1", "--steps", "24", "--warmup", "8", "--jump"], 600)
             out[nm + "_shape"] = d if "error" in d else {
+                "one_sequence_tp_over_xcds": t if "error" in t else {k: t.get(k) for k in ("workload", "tokens_per_s", "ms_per_step", "bytes_per_step", "frac", "summation_order", "parity", "leg_wall_s")},
                 "workload": "%s, 4-bit PackedQ greedy decode: %s" % (title, d["config"]["workload"].split("seq=")[-1]),
                 "tokens_per_s": d["value"], "ms_per_step": d["ms_per_step"], "bytes_per_step": d["step_roofline"]["bytes_per_step"], "frac": d["step_roofline"]["frac"],
                 "decode_path": d["config"]["decode_path"], "xcd_replicas": d.get("xcd_replicas"), "leg_wall_s": d.get("leg_wall_s")}
@@ -606,12 +610,20 @@ def tp_main(args, cfg, rank, world, dev):
     elif args.tp_layers > 0:                 # the side leg of the default run: a cut of the layer stack bounds its wall time; the line says so
         cfg = dict(cfg, n_layer=args.tp_layers)
     ctx = Context(dev)
+    ffn_real = cfg["ffn"]
+    if cfg["ffn"] % (128 * R) != 0:   # Qwen3-4B: 9728 = 76 groups of 128 do not split into R whole-group column shards -- the FFN padded with zero rows of gate / up and zero columns of down_proj
+        cfg = dict(cfg, ffn=(cfg["ffn"] + 128 * R - 1) // (128 * R) * (128 * R))
     plan = TP.TPPlan(cfg, R)
     g = torch.Generator(device=ctx.device)
     g.manual_seed(1234)
 
     def mat(r, c):
-        return (torch.randn(r, c, generator=g, device=ctx.device, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+        t = (torch.randn(r, c, generator=g, device=ctx.device, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+        if r == cfg["ffn"] and ffn_real < r:
+            t[ffn_real:] = 0
+        if c == cfg["ffn"] and ffn_real < c:
+            t[:, ffn_real:] = 0
+        return t
 
     def nrm(n):
         return (1.0 + 0.01 * torch.randn(n, generator=g, device=ctx.device, dtype=torch.float32)).to(torch.bfloat16)
@@ -787,8 +799,8 @@ def xcd_tp_leg(nt, cfg, ctx, forced, S, K, W, shards, plan, jump=False):
     step_bytes = weights + 2 * cfg["n_layer"] * mean_pos * cfg["n_kv"] * cfg["head_dim"] * 2
     ach = step_bytes / (ms * 1e-3) / 1e9
     res = {
-        "workload": "Qwen3-32B 4-bit PackedQ greedy decode on ONE MI355X, the TP = 8 ranks as the eight XCDs of one launch, context %d: timed positions %d..%d%s" % (
-            S, S - K, S - 1, "; K / V rows in front of the window synthetic" if jump else ""),
+        "workload": "%s (dim %d, ffn %d) 4-bit PackedQ greedy decode of ONE sequence on ONE MI355X, the TP = 8 ranks as the eight XCDs of one launch, context %d: timed positions %d..%d%s" % (
+            {5120: "Qwen3-32B", 4096: "Qwen3-8B", 2560: "Qwen3-4B (FFN padded to 10240 with zero rows)"}.get(cfg["dim"], "model"), cfg["dim"], cfg["ffn"], S, S - K, S - 1, "; K / V rows in front of the window synthetic" if jump else ""),
         "tokens_per_s": round(K / dt, 2), "ms_per_step": round(ms, 4), "device_ms_per_step": round(ctx.elapsed_ms(e0, e1) / K, 4), "steps": K, "layers": cfg["n_layer"], "vocab": cfg["vocab"],
         "bytes_per_step": int(step_bytes), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
         "kernel": "kf::xengine_kernel<XCfg<..., TP>> (koifish_amd/csrc/kf_xengine.hip): per layer four hand-offs inside each XCD + two exchanges between them",
@@ -1527,6 +1539,11 @@ def compact_line(out, detail=DETAIL_FILE):
         t = out.get(nm)
         if isinstance(t, dict):
             side[nm] = _keep(t, ("tokens_per_s", "frac", "per_layer_launches_tokens_per_s", "one_sequence_path"))
+            if "error" not in t and isinstance(t.get("one_sequence_tp_over_xcds"), dict):
+                o1 = t["one_sequence_tp_over_xcds"]
+                side[nm]["one_seq_tp_over_xcds"] = _keep(o1, ("tokens_per_s", "frac"))
+                if "error" not in o1:
+                    side[nm]["one_seq_tp_over_xcds"]["parity"] = _g(o1, "parity", "first_24_ids_equal_per_launch_rank_step")
             if "error" not in t and isinstance(t.get("xcd_replicas"), dict):
                 side[nm]["xcd_replicas"] = _keep(_xcd_short(t["xcd_replicas"]), ("streams", "batch", "tokens_per_s", "frac_vs_single_sequence_roofline", "hbm_frac_batch", "parity", "error"))
     t = out.get("config4_one_gpu")

@@ -1601,7 +1601,7 @@ size_t xengine_ws_bytes(const kf_engine_desc* d) {
 }
 static int xengine_init_state(XEngineHost* E, hipStream_t st) {
     XArgs& a = E->args;
-    if (hipMemsetAsync(a.loc, 0xff, (size_t)(E->shape_class == 7 ? XE_NXCD : XE_MAXSEQ) * E->loc_stride, st) != hipSuccess) return KF_HIP_CHECK;
+    if (hipMemsetAsync(a.loc, 0xff, (size_t)(E->tp_bytes ? XE_NXCD : XE_MAXSEQ) * E->loc_stride, st) != hipSuccess) return KF_HIP_CHECK;
     if (E->tp_bytes && hipMemsetAsync(a.tp_recv, 0xff, E->tp_bytes, st) != hipSuccess) return KF_HIP_CHECK;
     static int init[16 + 32 * XE_NXCD];
     memset(init, 0, sizeof(init));
@@ -1727,14 +1727,28 @@ int xengine_build(const kf_engine_desc* d, int n_seq, long long kv_seq_stride, v
 using XC7 = XCfg<FMT_Q4P, 8, 128, 12, 5120, 1024, 128, 3200, 6, false, 1, 1, true>;
 using XC7D = XCfg<FMT_Q4P, 8, 128, 12, 5120, 1024, 128, 3200, 6, true, 1, 1, true>; /* + the per-phase stamps of one workgroup of one rank */
 static size_t xe_smem_class3_two(int n_layer) { return xe_smem<XC3<8, 4, false, 2, 1>>(n_layer); }
-static bool xe_class_fused(int sc) { return sc == 4 ? XC4::FUSED : (sc == 5 ? XC5::FUSED : (sc == 6 ? XC6::FUSED : (sc == 7 ? XC7::FUSED : false))); }
-static bool xe_tp_shape(const kf_engine_desc* d) { return d->head_dim == 128 && d->n_head == 8 && d->n_kv == 1 && d->dim == 5120 && d->ffn == 3200; }
-static size_t xe_tp_recv_granules() { return (size_t)XE_NXCD * 2 * XE_NXCD * XC7::DIM; }
+// a rank of Qwen3-8B under TP = 8 (round 6: ONE sequence of a GQA-4 model on the eight XCDs): 4 query heads on 1 kv-head, q_dim 512, ffn 1536 (12 groups of 128)
+using XC8 = XCfg<FMT_Q4P, 4, 128, 12, 4096, 512, 128, 1536, 6, false, 1, 1, true>;
+// a rank of Qwen3-4B under TP = 8: ffn 9728 = 76 groups of 128 does not split into eight whole-group column shards -- the model is run with its FFN padded to 80 groups (512
+// zero rows of gate / up, 512 zero columns of down_proj: exact zeros in every sum), 1280 per rank
+using XC9 = XCfg<FMT_Q4P, 4, 128, 12, 2560, 512, 128, 1280, 2, false, 1, 1, true>; /* (ring depth, ms per token at 2 k keys: 6 2.33, 4 2.25, 2 2.22; 8 waves 2.42 - 2.48, 16 waves 2.87) */
+static_assert(XC7::FUSED && XC8::FUSED && XC9::FUSED, "the TP forms multiply q | k | v as one fused matrix");
+static bool xe_class_fused(int sc) { return sc == 4 ? XC4::FUSED : (sc == 5 ? XC5::FUSED : (sc == 6 ? XC6::FUSED : (sc == 7 ? XC7::FUSED : ((sc == 8 || sc == 9) ? true : false)))); }
+static bool xe_class_tp(int sc) { return sc >= 7 && sc <= 9; }
+static int xe_tp_shape(const kf_engine_desc* d) { /* the TP shape class of a rank's card, 0: not instantiated */
+    if (d->head_dim == 128 && d->n_head == 8 && d->n_kv == 1 && d->dim == 5120 && d->ffn == 3200) return 7;
+    if (d->head_dim == 128 && d->n_head == 4 && d->n_kv == 1 && d->dim == 4096 && d->ffn == 1536) return 8;
+    if (d->head_dim == 128 && d->n_head == 4 && d->n_kv == 1 && d->dim == 2560 && d->ffn == 1280) return 9;
+    return 0;
+}
+static int xe_tp_loc_dw(int sc) { return sc == 8 ? XC8::loc_dw : (sc == 9 ? XC9::loc_dw : XC7::loc_dw); }
+static size_t xe_tp_recv_granules(int dim) { return (size_t)XE_NXCD * 2 * XE_NXCD * dim; }
 size_t xengine_ws_bytes_tp(const kf_engine_desc* d0) {
+    const int sc = xe_tp_shape(d0);
     size_t b = 4096 + (((size_t)XE_NXCD * d0->n_layer * sizeof(EngLayer) + 255) & ~(size_t)255);
-    b += (size_t)XE_NXCD * xe_loc_stride(XC7::loc_dw) + 4096;
-    b += xe_tp_recv_granules() * 8 + (size_t)XE_NXCD * XE_NXCD * 8 + 4096;
-    if (XC7::FUSED) b += (size_t)XE_NXCD * d0->n_layer * xe_fused_layer_bytes(d0) + 256;
+    b += (size_t)XE_NXCD * xe_loc_stride(xe_tp_loc_dw(sc)) + 4096;
+    b += xe_tp_recv_granules(d0->dim) * 8 + (size_t)XE_NXCD * XE_NXCD * 8 + 4096;
+    b += (size_t)XE_NXCD * d0->n_layer * xe_fused_layer_bytes(d0) + 256;
     return b;
 }
 int xengine_build_tp(const kf_engine_desc* const* ds, int world, void* ws, size_t ws_bytes, hipStream_t st, XEngineHost** out, const char** why) {
@@ -1746,9 +1760,11 @@ int xengine_build_tp(const kf_engine_desc* const* ds, int world, void* ws, size_
     if (world != XE_NXCD) return KF_UNSUPPORTED_DATATYPE;
     for (int r = 0; r < world; r++)
         if (!ds[r] || !ds[r]->layers || ds[r]->n_layer < 1 || ds[r]->n_layer != ds[0]->n_layer) return KF_INVALID_ARGS;
-    *why = "rank shape not instantiated: built for the TP = 8 ranks of Qwen3-32B (dim 5120, 8 / 1 heads of 128, ffn 3200 per rank)";
+    *why = "rank shape not instantiated: built for the TP = 8 ranks of Qwen3-32B (dim 5120, 8 / 1 heads of 128, ffn 3200 per rank), Qwen3-8B (dim 4096, 4 / 1 heads, ffn 1536) and Qwen3-4B with "
+           "its FFN padded to 10240 (dim 2560, 4 / 1 heads, ffn 1280)";
+    const int sc = xe_tp_shape(ds[0]);
     for (int r = 0; r < world; r++)
-        if (!xe_tp_shape(ds[r])) return KF_UNSUPPORTED_DATATYPE;
+        if (!sc || xe_tp_shape(ds[r]) != sc) return KF_UNSUPPORTED_DATATYPE;
     const kf_engine_desc* d = ds[0];
     if (ws_bytes < xengine_ws_bytes_tp(d) || ((uintptr_t)ws & 255) != 0) {
         *why = "workspace too small or not 256-byte aligned";
@@ -1774,7 +1790,7 @@ int xengine_build_tp(const kf_engine_desc* const* ds, int world, void* ws, size_
     XEngineHost* E = new XEngineHost();
     memset(E, 0, sizeof(*E));
     XArgs& a = E->args;
-    E->shape_class = 7, E->fmt = FMT_Q4P, E->dim = d->dim, E->q_dim = d->n_head * d->head_dim, E->kv_dim = d->n_kv * d->head_dim, E->ffn = d->ffn, E->n_head = d->n_head, E->n_kv = d->n_kv, E->hd = d->head_dim;
+    E->shape_class = sc, E->fmt = FMT_Q4P, E->dim = d->dim, E->q_dim = d->n_head * d->head_dim, E->kv_dim = d->n_kv * d->head_dim, E->ffn = d->ffn, E->n_head = d->n_head, E->n_kv = d->n_kv, E->hd = d->head_dim;
     E->nwv = 12, E->depth = 6;
     a.n_layer = d->n_layer, a.n_seq = XE_NXCD /* decoders = ranks */, a.kv_seq_stride = 0, a.kv_stride = d->kv_stride, a.max_seq = d->max_seq;
     a.eps = d->rms_eps, a.qk_eps = d->qk_eps, a.rope_table = d->rope_table;
@@ -1784,12 +1800,12 @@ int xengine_build_tp(const kf_engine_desc* const* ds, int world, void* ws, size_
     a.ws = reinterpret_cast<int*>(p), p += 4096;
     a.layers = reinterpret_cast<const EngLayer*>(p), p += (tab.size() * sizeof(EngLayer) + 255) & ~(size_t)255;
     p = reinterpret_cast<char*>(((uintptr_t)p + 4095) & ~(uintptr_t)4095);
-    E->loc_stride = xe_loc_stride(XC7::loc_dw);
+    E->loc_stride = xe_loc_stride(xe_tp_loc_dw(sc));
     a.loc = p, a.loc_stride = E->loc_stride, p += (size_t)XE_NXCD * E->loc_stride;
-    a.tp_recv = reinterpret_cast<unsigned long long*>(p), p += xe_tp_recv_granules() * 8;
+    a.tp_recv = reinterpret_cast<unsigned long long*>(p), p += xe_tp_recv_granules(d->dim) * 8;
     a.tp_best = reinterpret_cast<unsigned long long*>(p);
-    E->tp_bytes = xe_tp_recv_granules() * 8 + (size_t)XE_NXCD * XE_NXCD * 8;
-    if (XC7::FUSED) {
+    E->tp_bytes = xe_tp_recv_granules(d->dim) * 8 + (size_t)XE_NXCD * XE_NXCD * 8;
+    {
         char* fp = reinterpret_cast<char*>(((uintptr_t)(p + (size_t)XE_NXCD * XE_NXCD * 8) + 255) & ~(uintptr_t)255);
         for (int r = 0; r < world; r++) {
             const int frc = xe_fuse_qkv(ds[r], tab.data() + (size_t)r * d->n_layer, qbias, fp, st);
@@ -1813,7 +1829,7 @@ int xengine_build_tp(const kf_engine_desc* const* ds, int world, void* ws, size_
 // the head in vocabulary shards (rank r: rows row0[r] .. of the full matrix), logits: the full vector, the shards in rank order
 int xengine_set_head_tp(XEngineHost* E, const kf_weight* const* ws, const int* row0, const uint16_t* norm_w, uint16_t* logits, int32_t* d_tokens_out, int tokens_stride) {
     XArgs& a = E->args;
-    if (E->shape_class != 7 || !ws || !row0 || !norm_w || !logits) return KF_INVALID_ARGS;
+    if (!E->tp_bytes || !ws || !row0 || !norm_w || !logits) return KF_INVALID_ARGS;
     const int nBlk = E->dim / 8;
     long at = 0;
     for (int r = 0; r < XE_NXCD; r++) {
@@ -1932,6 +1948,25 @@ int xengine_steps(XEngineHost* E, hipStream_t st, int32_t* d_state, uint16_t* x_
         rc = E->nwv == 8 ? xengine_go<XC5>(E, st) : xengine_go<XC5W>(E, st);
     else if (E->shape_class == 6)
         rc = xengine_go<XC6>(E, st);
+    else if (E->shape_class == 8) {
+#ifdef XE_TP9_VARIANTS
+        if (E->variant_set && E->nwv == 12 && E->depth == 2) rc = xengine_go<XCfg<FMT_Q4P, 4, 128, 12, 4096, 512, 128, 1536, 2, false, 1, 1, true>>(E, st);
+        else
+#endif
+        rc = xengine_go<XC8>(E, st);
+    }
+    else if (E->shape_class == 9) {
+#ifdef XE_TP9_VARIANTS /* tuning builds (scratch/xtp_time.py CONFIG=qwen3-4b VARIANT=): stamps, ring depth, the 8-wave 256-register form, two key tiles per batch */
+        if (E->args.dbg) rc = xengine_go<XCfg<FMT_Q4P, 4, 128, 12, 2560, 512, 128, 1280, 6, true, 1, 1, true>>(E, st);
+        else if (E->variant_set && E->nwv == 12 && E->depth == 6) rc = xengine_go<XCfg<FMT_Q4P, 4, 128, 12, 2560, 512, 128, 1280, 6, false, 1, 1, true>>(E, st);
+        else if (E->variant_set && E->nwv == 12 && E->depth == 4) rc = xengine_go<XCfg<FMT_Q4P, 4, 128, 12, 2560, 512, 128, 1280, 4, false, 1, 1, true>>(E, st);
+        else if (E->variant_set && E->nwv == 8 && E->depth == 8) rc = xengine_go<XCfg<FMT_Q4P, 4, 128, 8, 2560, 512, 128, 1280, 8, false, 1, 2, true>>(E, st);
+        else if (E->variant_set && E->nwv == 8 && E->depth == 4) rc = xengine_go<XCfg<FMT_Q4P, 4, 128, 8, 2560, 512, 128, 1280, 4, false, 1, 2, true>>(E, st);
+        else if (E->variant_set && E->nwv == 16 && E->depth == 2) rc = xengine_go<XCfg<FMT_Q4P, 4, 128, 16, 2560, 512, 128, 1280, 2, false, 1, 1, true>>(E, st);
+        else
+#endif
+        rc = xengine_go<XC9>(E, st);
+    }
     else if (E->shape_class == 7) {
         if (E->args.dbg) rc = xengine_go<XC7D>(E, st);
 #ifdef XE_TP_VARIANTS /* tuning builds only (scratch/xtp_time.py VARIANT=): ring depth 8 / 4, two key tiles per attention batch, the 8-wave 256-register form.  Measured,
@@ -1955,7 +1990,7 @@ int xengine_set_embedding(XEngineHost* E, const kf_weight* w, const int32_t* d_f
 }
 int xengine_set_head(XEngineHost* E, const kf_weight* w, const uint16_t* norm_w, uint16_t* logits, int32_t* d_tokens_out, int tokens_stride) {
     XArgs& a = E->args;
-    if (E->shape_class == 7) return KF_INVALID_ARGS; /* a TP engine takes its head in vocabulary shards: kf_xengine_set_head_tp */
+    if (E->tp_bytes) return KF_INVALID_ARGS; /* a TP engine takes its head in vocabulary shards: kf_xengine_set_head_tp */
     if (!w) { /* no head: kf_xengine_steps then refuses (every step of the ABI ends in the head); kept so that a head can be taken away before its weight is freed */
         a.head_w = nullptr, a.head_norm = nullptr, a.logits = nullptr, a.d_tokens_out = nullptr, a.vocab = 0;
         return KF_OK;

@@ -16,14 +16,22 @@ from koifish_amd.runtime import Context, XcdTP
 layers = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 pos0 = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 16
-cfg = dict(synth.CONFIGS["qwen3-32b"], n_layer=layers)
+cfg = dict(synth.CONFIGS[os.environ.get("CONFIG", "qwen3-32b")], n_layer=layers)
+ffn_real = cfg["ffn"]
+if cfg["ffn"] % 1024:   # Qwen3-4B: the FFN padded to whole groups per rank (zero rows / columns)
+    cfg["ffn"] = (cfg["ffn"] + 1023) // 1024 * 1024
 ctx = Context(0)
 g = torch.Generator(device=ctx.device)
 g.manual_seed(1)
 
 
 def mat(r, c):
-    return (torch.randn(r, c, generator=g, device=ctx.device, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+    t = (torch.randn(r, c, generator=g, device=ctx.device, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+    if r == cfg["ffn"] and ffn_real < r:
+        t[ffn_real:] = 0
+    if c == cfg["ffn"] and ffn_real < c:
+        t[:, ffn_real:] = 0
+    return t
 
 
 def nrm(n):

@@ -309,16 +309,20 @@ def test_native_tp8_full_depth_qwen3_32b_vs_the_oracle(ctx, n_layer):
     nt.close()
 
 
-@pytest.mark.parametrize("n", [48, pytest.param(96, marks=pytest.mark.slow)])
-def test_tp8_ranks_as_the_eight_xcds_of_one_launch_vs_the_oracle(ctx, n):
-    """(default run: 48 positions, --kf-slow: 96)
+@pytest.mark.parametrize("name,n", [("qwen3-32b", 48), ("qwen3-8b", 40), ("qwen3-4b", 40), pytest.param("qwen3-32b", 96, marks=pytest.mark.slow)])
+def test_tp8_ranks_as_the_eight_xcds_of_one_launch_vs_the_oracle(ctx, name, n):
+    """(default run: 48 positions, --kf-slow: 96.  qwen3-8b, round 6: ONE sequence of a GQA-4 model decoded by the eight XCDs as the eight TP ranks -- 4 query heads on 1 kv-head,
+    ffn 1536 per rank: the same kernel, another rank shape)
     The TP = 8 ranks of a Qwen3-32B-shaped model as the eight XCDs of ONE launch (kf_xengine_create_tp, koifish::XcdTP; round 5): rank r's 32 workgroups stream rank r's
     shards, q | k | v / attention / gate | up inside the XCD, the o_proj / down_proj partials exchanged between the XCDs inside the kernel and summed in rank order, the head
     in vocabulary shards with a cross-XCD pick, several tokens per launch.  A 3-layer slice decoded from position 0 -- 24 forced ids, then free running -- against the
     oracle's tensor-parallel emulation in the canonical order: every id, the last logits and every K / V row bit for bit; and the same ids from the per-launch rank step
     (NativeTP, the kernels an 8-GPU node runs)."""
     from koifish_amd.runtime import XcdTP
-    cfg = dict(synth.CONFIGS["qwen3-32b"], n_layer=3, vocab=8192, max_seq=320, tied=True)
+    cfg = dict(synth.CONFIGS[name], n_layer=3, vocab=8192, max_seq=320, tied=True)
+    ffn_real = cfg["ffn"]
+    if name == "qwen3-4b":   # 9728 = 76 groups of 128 do not split into eight whole-group column shards: the FFN padded to 80 groups (zero rows of gate / up, zero columns of down_proj)
+        cfg["ffn"] = 10240
     g = torch.Generator(device=ctx.device)
     g.manual_seed(77)
 
@@ -333,7 +337,12 @@ def test_tp8_ranks_as_the_eight_xcds_of_one_launch_vs_the_oracle(ctx, n):
     norms[(-1, 0)] = nrm(cfg["dim"])
     for li in range(cfg["n_layer"]):
         for si, s in enumerate(synth.SLOTS):
-            w[(li, si)] = ctx.quantize(mat(*synth.SHAPES[s](cfg)), L.Q4)
+            t = mat(*synth.SHAPES[s](cfg))
+            if s in ("gate", "up"):
+                t[ffn_real:] = 0
+            if s == "down":
+                t[:, ffn_real:] = 0
+            w[(li, si)] = ctx.quantize(t, L.Q4)
         norms[(li, 0)], norms[(li, 1)], norms[(li, 2)], norms[(li, 3)] = nrm(cfg["dim"]), nrm(cfg["dim"]), nrm(128), nrm(128)
     nt = TP.NativeTP(cfg, w, norms, 8, ctx)
     for rk in nt.ranks:
