@@ -112,9 +112,119 @@ struct CanonAcc {
         }
     }
 };
+// row broadcast (gfx90a+: row_newbcast:K -- every lane of a row of 16 gets lane K's value) and row rotate (row_ror:K: lane i gets lane i + K (mod 16)... of its row)
+template <int K>
+__device__ __forceinline__ uint32_t row_bcast_u(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + K, 0xF, 0xF, true);
+}
+template <int K>
+__device__ __forceinline__ float row_bcast_f(float v) { return __uint_as_float(row_bcast_u<K>(__float_as_uint(v))); }
+template <int K>
+__device__ __forceinline__ double row_bcast_d(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    return __builtin_bit_cast(double, ((unsigned long long)row_bcast_u<K>((uint32_t)(u >> 32)) << 32) | row_bcast_u<K>((uint32_t)u));
+}
+// the q.k dot of canon_score without the scale and the rounding
+__device__ __forceinline__ float canon_dot(const float (&q)[8], u32x4 kw, int lpk_log2) {
+    const uint32_t k4[4] = {kw.x, kw.y, kw.z, kw.w};
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        d = fmaf(q[2 * i], bf_lo(k4[i]), d);
+        d = fmaf(q[2 * i + 1], bf_hi(k4[i]), d);
+    }
+    return group_sum16(d, lpk_log2);
+}
+template <int GQ, int U, int I = 1>
+__device__ __forceinline__ void canon_pick_item(const float (&d)[U][GQ], const bool (&valid)[U], int lig, float& mine, bool& vmine) {
+    if constexpr (I < U * GQ) {
+        mine = lig == I ? d[I / GQ][I % GQ] : mine;
+        vmine = lig == I ? valid[I / GQ] : vmine;
+        canon_pick_item<GQ, U, I + 1>(d, valid, lig, mine, vmine);
+    }
+}
+// max over the lanes lig, lig + GQ, lig + 2 GQ, ... (U of them) of a row: after the steps lane i holds the maximum over i, i + GQ, ..., i + (U - 1) GQ (mod 16)
+template <int GQ, int U, int STEP = 1>
+__device__ __forceinline__ float canon_items_max(float v) {
+    if constexpr (STEP < U) {
+        v = fmaxf(v, dpp_f<0x120 + ((16 - GQ * STEP) & 15)>(v)); /* row_ror:(16 - s): lane i reads lane i + s (mod 16) */
+        return canon_items_max<GQ, U, STEP * 2>(v);
+    } else {
+        return v;
+    }
+}
+template <int GQ, int HQ = 0>
+__device__ __forceinline__ void canon_heads_max(float nm, float (&bn)[GQ]) {
+    if constexpr (HQ < GQ) {
+        bn[HQ] = row_bcast_f<HQ>(nm); /* lane hq of the row: the maximum over the head's items hq, hq + GQ, ... */
+        canon_heads_max<GQ, HQ + 1>(nm, bn);
+    }
+}
+template <int GQ, int U, int I = 0>
+__device__ __forceinline__ void canon_apply_items(CanonAcc<GQ>& A, double p, const double (&vd)[U][8]) {
+    if constexpr (I < U * GQ) {
+        constexpr int u = I / GQ, hq = I % GQ;
+        const double pi = row_bcast_d<I>(p);
+        A.l[hq] += pi;
+#pragma unroll
+        for (int i = 0; i < 8; i++) A.o[hq][i] = fma(pi, vd[u][i], A.o[hq][i]);
+        canon_apply_items<GQ, U, I + 1>(A, p, vd);
+    }
+}
+#ifndef KF_CANON_ITEMS
+#define KF_CANON_ITEMS 0 /* scratch/build_variant.py A/B.  1 = the item-per-lane form below: bit for bit the same (194 canonical tests), a quarter fewer vector instructions per key
+                            tile on paper -- and SLOWER on the part: 32 sequences 7770 -> 6360 tokens/s, 16: 6240 -> 5710, 8: 4625 -> 4450, the single-sequence engine unchanged (each
+                            broadcast is a DPP move with its wait states in front of a dependent fp64 chain; the replicated form keeps sixteen independent lanes busy instead).  Off. */
+#endif
 // one batch of U key tiles of this lane's key group: k / v tiles (8 elements of this lane), validity per tile; q as 8 floats per head
+// KF_CANON_ITEMS (round 6, measured and left off): hd = 128, a key group is a row of 16 lanes -- the U * GQ dots of a group stand in all of its 16 lanes after the tree; the
+// score's scale and rounding, the exponential's parts and the exact power-of-two weight p worked out ONCE, item i = u * GQ + hq in lane i of the group, p_i handed to the
+// group's lanes by a row broadcast: the same operations on the same values as the per-lane form.
 template <int GQ, int LPK, int U = ATTN_U>
 __device__ __forceinline__ void canon_batch(CanonAcc<GQ>& A, const float (&qf)[GQ][8], const u32x4 (&kk)[U], const u32x4 (&vv)[U], const bool (&valid)[U], int lpk_log2, float rden) {
+    if constexpr (KF_CANON_ITEMS && LPK == 16 && U * GQ <= 16 && (GQ & (GQ - 1)) == 0 && (U & (U - 1)) == 0) {
+        constexpr int NI = U * GQ;
+        const int lig = (int)(threadIdx.x & 15);
+        float d[U][GQ];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int hq = 0; hq < GQ; hq++) d[u][hq] = canon_dot(qf[hq], kk[u], lpk_log2);
+        float mine = d[0][0];
+        bool vmine = valid[0];
+        canon_pick_item<GQ, U>(d, valid, lig, mine, vmine);
+        float f, n;
+        kf_exp2_parts(round_bf16(mine * rden) * KF_LOG2E, f, n);
+        vmine = vmine && lig < NI;
+        n = vmine ? n : -__builtin_inff();
+        float bn[GQ];
+        canon_heads_max<GQ>(canon_items_max<GQ, U>(n), bn);
+        float m_mine = A.m[0];
+#pragma unroll
+        for (int hq = 0; hq < GQ; hq++) { /* the wave's maximum exponent of this batch */
+            bn[hq] = xmax32(xmax16(bn[hq]));
+            if (bn[hq] > A.m[hq]) { /* exact rescale of what has been summed so far (wave-uniform branch; the first batch has nothing to rescale) */
+                if (A.m[hq] > -__builtin_inff()) {
+                    const int e = canon_shift(A.m[hq] - bn[hq]);
+                    A.l[hq] = ldexp_d(A.l[hq], e);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) A.o[hq][i] = ldexp_d(A.o[hq][i], e);
+                }
+                A.m[hq] = bn[hq];
+            }
+            m_mine = (lig & (GQ - 1)) == hq ? A.m[hq] : m_mine;
+        }
+        const double p = vmine ? ldexp_d((double)f, canon_shift(n - m_mine)) : 0.0;
+        double vd[U][8];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t vw[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) vd[u][2 * i] = (double)bf_lo(vw[i]), vd[u][2 * i + 1] = (double)bf_hi(vw[i]);
+        }
+        canon_apply_items<GQ, U>(A, p, vd);
+        return;
+    }
     float f[U][GQ], n[U][GQ], bn[GQ];
 #pragma unroll
     for (int hq = 0; hq < GQ; hq++) bn[hq] = -__builtin_inff();
