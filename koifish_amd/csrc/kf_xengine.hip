@@ -84,7 +84,7 @@ constexpr int xe_p1_wgs(int dim, int epb, int qd, int kvd) { /* the most workgro
     }
     return 0;
 }
-template <int FMT_, int GQ_, int HD_, int NWV_, int DIM_, int QD_, int KVD_, int FFN_, int DEPTH_, bool DBG_, int WPC_ = 1, int AU_ = 2, bool TP_ = false, int NB_ = 1>
+template <int FMT_, int GQ_, int HD_, int NWV_, int DIM_, int QD_, int KVD_, int FFN_, int DEPTH_, bool DBG_, int WPC_ = 1, int AU_ = 2, bool TP_ = false, int NB_ = 1, int NP_ = 0>
 struct XCfg {
     // NB: sequences per decoder (round 6).  The decoders of a launch unpack the SAME 4-bit blocks; with NB > 1 a decoder multiplies every unpacked block against the
     // activations of NB sequences (xcc + 8 b, b = 0 .. NB - 1) staged side by side in LDS -- the exact bf16-stepwise unpack (7 vector instructions per weight with its
@@ -111,7 +111,11 @@ struct XCfg {
     static constexpr int WPC = WPC_; /* decoders per XCD = workgroups per CU: 2 lets one decoder's hand-off waits run under the other's arithmetic (the hardware interleaves the two workgroups' waves) */
     // NB pollers (waves NCW .. NWV - 1: wave NCW + b runs the hand-offs of sequence b, side by side) and NWV - NB compute waves.  (One poller staging four sequences' vectors one
     // after the other took 43 of a 169 us layer period; hand-offs run by compute waves beside their rows cost the attention loop its registers: 23 -> 32 us per layer.)
-    static constexpr int FMT = FMT_, GQ = GQ_, HD = HD_, NWV = NWV_, NCW = NWV_ - NB_, DIM = DIM_, QD = QD_, KVD = KVD_, FFN = FFN_, DEPTH = DEPTH_, NWG = XE_NWG;
+    // NP pollers for the NB sequences (NP_ = 0: one each): poller p runs the hand-offs of sequences p, p + NP, ... one after the other.  Two pollers for four sequences leave
+    // ten of twelve waves to the arithmetic (the mat-vec phases and the attention are 86 % of the NB = 4 layer period; the hand-offs 12 %)
+    static constexpr int NP = NP_ > 0 ? NP_ : NB_;
+    static_assert(NB_ % NP == 0, "every poller the same number of sequences");
+    static constexpr int FMT = FMT_, GQ = GQ_, HD = HD_, NWV = NWV_, NCW = NWV_ - NP, DIM = DIM_, QD = QD_, KVD = KVD_, FFN = FFN_, DEPTH = DEPTH_, NWG = XE_NWG;
     static constexpr bool DBG = DBG_;
     static_assert(FMT_ == FMT_Q4 || FMT_ == FMT_Q4P, "4-bit PackedQ layers (arithmetic or register-table unpack)");
     static constexpr int n_head = QD_ / HD_, n_kv = KVD_ / HD_;
@@ -161,6 +165,7 @@ struct XCfg {
     static constexpr int maxR = (SH::P1::R > SH::P5::R ? SH::P1::R : SH::P5::R) > (SH::P4::R > SH::P6::R ? SH::P4::R : SH::P6::R) ? (SH::P1::R > SH::P5::R ? SH::P1::R : SH::P5::R)
                                                                                                                                       : (SH::P4::R > SH::P6::R ? SH::P4::R : SH::P6::R);
     static_assert(NB_ >= 1 && NB_ <= 4, "sequences per decoder");
+    static_assert(!COOP || NP == NB_, "cooperative staging: a merge / norm scratch per sequence");
     static_assert(NB_ == 1 || (!TP_ && WPC_ == 1 && !FUSED && NG == 1 && FMT_ == FMT_Q4P && DIM_ / 256 <= 12 && FFNP / 256 <= 24 && !COMB_IN_XS1),
                   "the batched form: plain (non-TP, one workgroup per CU) decoders of the shapes whose vectors are staged by the poller in one sweep");
 };
@@ -174,9 +179,10 @@ struct XLay {
     static constexpr size_t o_attn = (size_t)2 * xs_bytes + 2 * xr_bytes;
     static constexpr size_t o_outb = (o_attn + sizeof(uint16_t) * ((size_t)2 * GQ * hd + 3 * hd) + 15) & ~(size_t)15;
     static constexpr size_t o_wmax = o_outb + 4 * (size_t)((C::maxR + 63) & ~63);
-    static constexpr size_t o_msc = (o_wmax + 4 * 2 * 16 + 15) & ~(size_t)15; /* the slice merge's scratch ([SPK][ME] fp64 + shifts + the merged granules; xe_coop_norm_stage: a slot per wave) */
-    static constexpr size_t seq_bytes = (o_msc + sizeof(double) * ((size_t)C::ME * C::SPK) + 4 * 64 + 4 * 128 + 15) & ~(size_t)15;
-    static constexpr size_t o_comb = (size_t)C::NB * seq_bytes;
+    static constexpr size_t seq_bytes = (o_wmax + 4 * 2 * 16 + 15) & ~(size_t)15;
+    static constexpr size_t msc_bytes = (sizeof(double) * ((size_t)C::ME * C::SPK) + 4 * 64 + 4 * 128 + 15) & ~(size_t)15; /* the slice merge's scratch of ONE poller ([SPK][ME] fp64 + shifts + the merged granules; xe_coop_norm_stage: a slot per wave) */
+    static constexpr size_t o_msc = (size_t)C::NB * seq_bytes;
+    static constexpr size_t o_comb = o_msc + (size_t)C::NP * msc_bytes;
     static constexpr size_t o_cnt = o_comb + (C::COMB_IN_XS1 ? 0 : sizeof(double) * (size_t)NCW * GQ * (hd + 2));
     static constexpr size_t fixed_bytes = (o_cnt + 64 + 15) & ~(size_t)15;
 };
@@ -210,7 +216,8 @@ __device__ __forceinline__ XLds xe_lds_view(const XLds& L, int b) {
         XLds V = L;
         V.xs[0] = mv(L.xs[0]), V.xs[1] = mv(L.xs[1]), V.xrawA = mv(L.xrawA), V.xrawB = mv(L.xrawB);
         V.qraw = mv(L.qraw), V.kraw = mv(L.kraw), V.vraw = mv(L.vraw), V.qb = mv(L.qb), V.knew = mv(L.knew);
-        V.wmax = mv(L.wmax), V.outb = mv(L.outb), V.msc = mv(L.msc);
+        V.wmax = mv(L.wmax), V.outb = mv(L.outb);
+        V.msc = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(L.msc) + (size_t)(b % C::NP) * XLay<C>::msc_bytes); /* the scratch of the sequence's poller */
         return V;
     }
 }
@@ -918,15 +925,14 @@ __device__ __forceinline__ void xe_coop_all(const XArgs& a, const XLds& L0, cons
         else xe_coop_norm_stage<C>(a, Lb, loc + C::xB, tag, ly.norm_post, Lb.xs[0], Lb.xrawB, wave, lane, dead);
     }
 }
-// ---- a poller wave of a workgroup: the hand-offs of ONE sequence of the decoder (S, L: that sequence's place and LDS block; stamps: sequence 0's poller), and every barrier
-template <class C>
-__device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L0, const XSeq (&SS)[C::NB], const int pb, int epoch, int lane) {
-    constexpr int NB = C::NB;
+// ---- poller wave PB of a workgroup: the hand-offs of the decoder's sequences PB, PB + NP, ... (one after the other), and every barrier; stamps: poller 0's first sequence
+template <class C, int PB>
+__device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L0, const XSeq (&SS)[C::NB], int epoch, int lane) {
+    constexpr int NB = C::NB, NP = C::NP, NMINE = NB / NP;
     static_assert(C::DIM % 256 == 0 && C::QD % 256 == 0 && (C::TP || C::FFN % 256 == 0), "hand-off vectors in 1 KiB pieces");
-    XSeq S = SS[pb];
-    if (pb > 0) S.stamp = false;
-    const XLds L = xe_lds_view<C>(L0, pb);
-    const bool on = NB == 1 || S.act;
+    XSeq S = SS[PB];
+    if (PB > 0) S.stamp = false;
+    const XLds L = xe_lds_view<C>(L0, PB);
     bool dead = false;
     for (int l = 0; l < a.n_layer; l++) {
         const EngLayer& ly = L.lay[l];
@@ -937,16 +943,20 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L0, c
             eng_wait_pub(L.pub + 3, S.step * a.n_layer + l, 0, dead);
             XE_STAMP(12);
         }
-        if (on) xe_ho_x<C>(a, L, S, ly, l, epoch, gen, lane, dead);
+#pragma unroll
+        for (int k = 0; k < NMINE; k++)
+            if (NB == 1 || SS[PB + k * NP].act) xe_ho_x<C>(a, xe_lds_view<C>(L0, PB + k * NP), SS[PB + k * NP], ly, l, epoch, gen, lane, dead);
         if constexpr (C::COOP) {
-            if (l > 0) xe_coop_all<C>(a, L0, SS, 0, tag, ly, C::NCW + pb, lane, &dead);
+            if (l > 0) xe_coop_all<C>(a, L0, SS, 0, tag, ly, C::NCW + PB, lane, &dead);
         }
         if (C::TP && l > 0) XE_STAMP(31); /* (TP: the slot of the shader-clock stamp) this workgroup's rows of the down_proj exchange are summed */
         XE_STAMP(1);
         __syncthreads(); /* B1 */
         if (!(C::P1W < XE_NWG && S.r >= C::P1W)) eng_wait_pub(L.pub + 0, S.step * a.n_layer + l + 1, 0, dead); /* (a workgroup without q | k | v rows publishes none) */
         XE_STAMP(9);
-        if (!S.empty) xe_ho_qkv<C>(a, L, S, tag, lane, dead); /* only a slice with keys needs the heads (an inactive sequence is an empty one) */
+#pragma unroll
+        for (int k = 0; k < NMINE; k++)
+            if (!SS[PB + k * NP].empty) xe_ho_qkv<C>(a, xe_lds_view<C>(L0, PB + k * NP), SS[PB + k * NP], tag, lane, dead); /* only a slice with keys needs the heads (an inactive sequence is an empty one) */
         XE_STAMP(2);
 #pragma unroll
         for (int b = 0; b < NB; b++) { /* the compute waves' attention, sequence after sequence (xe_attn_phase) */
@@ -955,22 +965,30 @@ __device__ __forceinline__ void xe_poller_main(const XArgs& a, const XLds& L0, c
             __syncthreads(); /* the waves' sums in LDS */
         }
         XE_STAMP(3);
-        if (on) xe_ho_merge<C>(a, L, S, gen, lane, dead);
+#pragma unroll
+        for (int k = 0; k < NMINE; k++)
+            if (NB == 1 || SS[PB + k * NP].act) xe_ho_merge<C>(a, xe_lds_view<C>(L0, PB + k * NP), SS[PB + k * NP], gen, lane, dead);
         XE_STAMP(5);
-        if (on) xe_ho_ao<C>(a, L, S, tag, lane, dead);
+#pragma unroll
+        for (int k = 0; k < NMINE; k++)
+            if (NB == 1 || SS[PB + k * NP].act) xe_ho_ao<C>(a, xe_lds_view<C>(L0, PB + k * NP), SS[PB + k * NP], tag, lane, dead);
         XE_STAMP(6);
         __syncthreads(); /* B4 */
         eng_wait_pub(L.pub + 1, S.step * a.n_layer + l + 1, 0, dead);
         XE_STAMP(10);
-        if (on) xe_ho_xB<C>(a, L, S, ly, gen, lane, dead);
-        if constexpr (C::COOP) xe_coop_all<C>(a, L0, SS, 1, tag, ly, C::NCW + pb, lane, &dead);
+#pragma unroll
+        for (int k = 0; k < NMINE; k++)
+            if (NB == 1 || SS[PB + k * NP].act) xe_ho_xB<C>(a, xe_lds_view<C>(L0, PB + k * NP), SS[PB + k * NP], ly, gen, lane, dead);
+        if constexpr (C::COOP) xe_coop_all<C>(a, L0, SS, 1, tag, ly, C::NCW + PB, lane, &dead);
         if constexpr (C::TP) XE_STAMP(13); /* (TP: the slot of the act sweep count) this workgroup's rows of the o_proj exchange are summed */
         XE_STAMP(7);
         __syncthreads(); /* B5 */
         eng_wait_pub(L.pub + 2, S.step * a.n_layer + l + 1, 0, dead);
         XE_STAMP(11);
         int nsw_act = 0;
-        if (on) xe_ho_act<C>(a, L, S, tag, lane, dead, &nsw_act);
+#pragma unroll
+        for (int k = 0; k < NMINE; k++)
+            if (NB == 1 || SS[PB + k * NP].act) xe_ho_act<C>(a, xe_lds_view<C>(L0, PB + k * NP), SS[PB + k * NP], tag, lane, dead, &nsw_act);
         if (C::DBG && !C::TP && S.stamp && lane == 0) a.dbg[((size_t)S.step * a.n_layer + l) * 64 + 13] = (unsigned long long)nsw_act;
         XE_STAMP(8);
         __syncthreads(); /* B6 */
@@ -1026,7 +1044,7 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
         P.s0 = sel4(q, S.s1, wg * P4::spg, wg * P5::spg, wg * P6::spg), P.Mj = sel4(q, S.M1, P4::M0, P5::M0, P6::M0);
         P.row0 = P.s0 << P.rps_log2;
         const int spg = sel4(q, P1::spg, P4::spg, P5::spg, P6::spg);
-        const XDeal dl = xe_deal<NCW, C::DEAL_CONTIG, C::NB>(cw, spg, a.deal_wl);
+        const XDeal dl = xe_deal<NCW, C::DEAL_CONTIG, C::NP>(cw, spg, a.deal_wl);
         P.s0 += __builtin_amdgcn_readfirstlane(dl.a), P.sl_b = __builtin_amdgcn_readfirstlane(dl.b);
         P.n = __builtin_amdgcn_readfirstlane(dl.n) * P.iters * (P.paired ? 2 : 1);
         if (C::P1W < XE_NWG && q == 0 && wg >= C::P1W) P.n = 0;
@@ -1057,7 +1075,7 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
             const int spg = q == 0 ? P1::spg : (q == 1 ? P4::spg : (q == 2 ? P5::spg : P6::spg));
             int nwp = 0; /* waves that own rows of the phase */
 #pragma unroll
-            for (int w = 0; w < NCW; w++) nwp += xe_deal<NCW, C::DEAL_CONTIG, C::NB>(w, spg, a.deal_wl).n > 0 ? 1 : 0;
+            for (int w = 0; w < NCW; w++) nwp += xe_deal<NCW, C::DEAL_CONTIG, C::NP>(w, spg, a.deal_wl).n > 0 ? 1 : 0;
             uint32_t* const dst = loc + (q == 0 ? C::qkv + S.q_out0 : (q == 1 ? C::xB + wg * P4::R : (q == 2 ? C::act + wg * P5::R : C::xA + wg * P6::R)));
             if constexpr (C::COOP) { /* this wave's share of the sweep + RMSNorm + staging of x (layers behind the first: layer 0's row comes from the embedding table) / xB */
                 if (q == 0 && l > 0) xe_coop_all<C>(a, L, SS, 0, tag, ly, cw, lane, nullptr);
@@ -1091,7 +1109,7 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
                 a.dbg[((size_t)S.step * a.n_layer + l) * 64 + ((cw & 7) < 2 ? 14 + (cw & 7) : 23 + (cw & 7))] = hw; /* slots 14, 15, 25 .. 30: where (SIMD, CU) the wave runs */
             }
             if (q == 0 && (NB == 1 || SS[0].act)) xe_attn_issue<C>(a, ly, SS[0], cw, lane, T, 0, 0); /* the slice's first tiles (rows of earlier positions; row `pos` is substituted): the q | k | v hand-off hides them */
-            if (xe_deal<NCW, C::DEAL_CONTIG, C::NB>(cw, spg, a.deal_wl).n > 0 && !(C::P1W < XE_NWG && q == 0 && wg >= C::P1W)) {
+            if (xe_deal<NCW, C::DEAL_CONTIG, C::NP>(cw, spg, a.deal_wl).n > 0 && !(C::P1W < XE_NWG && q == 0 && wg >= C::P1W)) {
                 if constexpr (C::TP) {
                     // o_proj (q == 1) / down_proj (q == 3): this rank's slot [buffer][S.seq][rows wg * R ..] of rank 0's receive area, the other ranks' areas 2 * 8 * DIM granules apart
                     unsigned long long* push = (q == 1 || q == 3) ? a.tp_recv + ((size_t)(q == 3 ? 1 : 0) * XE_NXCD + S.seq) * C::DIM + wg * nrows : nullptr;
@@ -1177,7 +1195,7 @@ __device__ __forceinline__ void xe_head_main(const XArgs& a, const XLds& L, cons
         }
 #pragma unroll
         for (int b = 0; b < NB; b++) {
-            if (wave == C::NCW + b && (NB == 1 || SS[b].act)) {
+            if (wave == C::NCW + b % C::NP && (NB == 1 || SS[b].act)) {
                 const XLds Lb = xe_lds_view<C>(L, b);
                 uint32_t* const loc = reinterpret_cast<uint32_t*>(a.loc + (size_t)SS[b].seq * a.loc_stride);
                 if constexpr (ND > 12) eng_poll_stage_norm_long<1, ND, nBlk, false, false, 8>(loc + C::xA, nullptr, tag, a.head_norm, a.eps, Lb.xs[0], Lb.xrawA, lane, a.ws, dead);
@@ -1270,7 +1288,7 @@ __device__ __forceinline__ void xe_head_main(const XArgs& a, const XLds& L, cons
                 if (rv[k] > bv0 || (rv[k] == bv0 && ri[k] < bi0)) bv0 = rv[k], bi0 = ri[k];
             hb[wg] = ((unsigned long long)((tag << 16) | (uint32_t)f2bf(bv0)) << 32) | (unsigned long long)(uint32_t)bi0;
         }
-        if (wg == 0 && wave == C::NCW + b && a.pick) { /* the pick over the decoder's 32 workgroup maxima (sequence b's poller): two granules per lane */
+        if (wg == 0 && wave == C::NCW + b % C::NP && a.pick) { /* the pick over the decoder's 32 workgroup maxima (sequence b's poller): two granules per lane */
             const __amdgpu_buffer_rsrc_t rs = eng_rsrc(hb, NWG * 8u);
             u32x4 g0{0, 0, 0, 0};
             bool ok = false;
@@ -1488,14 +1506,18 @@ __global__ void __launch_bounds__(C::NWV * 64, (C::NWV * C::WPC + 3) / 4 /* wave
             __syncthreads();
             if (L.cnt[3] != 0) break;
         }
-        if (wave >= C::NCW) { /* the poller of sequence wave - NCW */
-            bool done = false;
-#pragma unroll
-            for (int b = 0; b < NB; b++) {
-                if (!done && wave == C::NCW + b) {
-                    xe_poller_main<C>(a, L, SS, b, epoch, lane);
-                    done = true;
-                }
+        if (wave >= C::NCW) { /* poller wave - NCW */
+            if constexpr (C::NP == 1) {
+                xe_poller_main<C, 0>(a, L, SS, epoch, lane);
+            } else if constexpr (C::NP == 2) {
+                if (wave == C::NCW) xe_poller_main<C, 0>(a, L, SS, epoch, lane);
+                else xe_poller_main<C, 1>(a, L, SS, epoch, lane);
+            } else {
+                static_assert(C::NP == 4, "one, two or four pollers");
+                if (wave == C::NCW) xe_poller_main<C, 0>(a, L, SS, epoch, lane);
+                else if (wave == C::NCW + 1) xe_poller_main<C, 1>(a, L, SS, epoch, lane);
+                else if (wave == C::NCW + 2) xe_poller_main<C, 2>(a, L, SS, epoch, lane);
+                else xe_poller_main<C, 3>(a, L, SS, epoch, lane);
             }
         } else {
             xe_compute_main<C>(a, L, SS, epoch, wave, lane, R);
@@ -1533,10 +1555,10 @@ static int xe_shape_class(int GQ, int hd, int dim, int q_dim, int ffn) {
 }
 template <int NWV, int DEPTH, bool DBG, int WPC, int AU = 2, int NB = 1>
 using XC3 = XCfg<FMT_Q4P, 2, 128, NWV, 2048, 2048, 1024, 6144, DEPTH, DBG, WPC, AU, false, NB>;
-template <int NWV, int DEPTH, bool DBG, int WPC, int AU = 2, int NB = 1>
-using XC1 = XCfg<FMT_Q4P, 2, 128, NWV, 1024, 2048, 1024, 3072, DEPTH, DBG, WPC, AU, false, NB>;
-template <int NWV, int DEPTH, bool DBG, int WPC, int AU = 2, int NB = 1>
-using XC2 = XCfg<FMT_Q4P, 2, 64, NWV, 256, 256, 128, 512, DEPTH, DBG, WPC, AU, false, NB>;
+template <int NWV, int DEPTH, bool DBG, int WPC, int AU = 2, int NB = 1, int NP = 0>
+using XC1 = XCfg<FMT_Q4P, 2, 128, NWV, 1024, 2048, 1024, 3072, DEPTH, DBG, WPC, AU, false, NB, NP>;
+template <int NWV, int DEPTH, bool DBG, int WPC, int AU = 2, int NB = 1, int NP = 0>
+using XC2 = XCfg<FMT_Q4P, 2, 64, NWV, 256, 256, 128, 512, DEPTH, DBG, WPC, AU, false, NB, NP>;
 // the GQA-4 shapes: one decoder per XCD, 8 waves (two per SIMD: 256 registers -- the attention sums of four query heads are 36 fp64 values per lane)
 using XC4 = XCfg<FMT_Q4P, 4, 128, 8, 2560, 4096, 1024, 9728, 8, false, 1, 2>;
 using XC5 = XCfg<FMT_Q4P, 4, 128, 8, 4096, 4096, 1024, 12288, 8, false, 1, 2>;
@@ -1558,7 +1580,7 @@ static bool xe_class_fused(int sc); /* below the shape aliases */
 static size_t xe_smem_class3_two(int n_layer);
 template <class C>
 static size_t xe_smem(int n_layer);
-template <template <int, int, bool, int, int, int> class XC>
+template <template <int, int, bool, int, int, int, int> class XC>
 static size_t xe_shape_smem(int n_seq, int n_layer, bool two_wpc);
 // FUSED shapes (XCfg::FUSED): q | k | v of a layer as ONE matrix -- blocks, then the zero words, then the step words of the QD + 2 KVD rows -- copied once into the workspace
 static size_t xe_fused_layer_bytes(const kf_engine_desc* d) {
@@ -1870,54 +1892,61 @@ static int xengine_go(XEngineHost* E, hipStream_t st) {
 // n_seq <= 8: one decoder per XCD (12 waves, 168 registers), one sequence each.  More: the BATCHED form (round 6) -- still one decoder per XCD, every unpacked block multiplied
 // against the activations of 2 (n_seq <= 16) or 4 (n_seq <= 32) sequences.  The round-5 form of 9 .. 16 sequences (two decoders per XCD, two workgroups of 8 waves per CU,
 // 128 registers) stays behind XEngineHost::two_wpc as the A/B reference.
+template <template <int, int, bool, int, int, int, int> class XC, int NWV, int DEPTH, bool DBG, int WPC, int AU, int NB, int NP = 0>
+using XF = XC<NWV, DEPTH, DBG, WPC, AU, NB, NP>; /* (a template template parameter carries no default arguments) */
 static int xe_batch_of(const XEngineHost* E) { return E->args.n_seq <= XE_NXCD ? 1 : ((E->args.n_seq <= 2 * XE_NXCD) ? (E->two_wpc ? 1 : 2) : 4); }
-template <template <int, int, bool, int, int, int> class XC>
+template <template <int, int, bool, int, int, int, int> class XC>
 static int xengine_go_shape(XEngineHost* E, hipStream_t st) {
     const int nb = xe_batch_of(E);
     const bool two = E->args.n_seq > XE_NXCD && nb == 1;
 #ifndef XE_ONLY_DEFAULT
     const bool dbg = E->args.dbg != nullptr;
-    if (dbg && nb == 4) return xengine_go<XC<12, 2, true, 1, 2, 4>>(E, st);
-    if (dbg && nb == 2) return xengine_go<XC<12, 4, true, 1, 2, 2>>(E, st);
-    if (dbg && nb == 1) return two ? xengine_go<XC<8, 4, true, 2, 1, 1>>(E, st) : xengine_go<XC<12, 2, true, 1, 2, 1>>(E, st);
+    if (dbg && nb == 4) return xengine_go<XF<XC, 12, 2, true, 1, 2, 4>>(E, st);
+    if (dbg && nb == 2) return xengine_go<XF<XC, 12, 4, true, 1, 2, 2>>(E, st);
+    if (dbg && nb == 1) return two ? xengine_go<XF<XC, 8, 4, true, 2, 1, 1>>(E, st) : xengine_go<XF<XC, 12, 2, true, 1, 2, 1>>(E, st);
 #endif
     if (nb == 4) { /* 8 compute waves + the four sequences' pollers (168 registers), where the four sequences' activations + the layer table fit the LDS; else 4 + 4 waves */
 #ifdef XE_NB4_VARIANTS /* tuning builds only */
-        if (E->variant_set && E->nwv == 12 && E->depth == 8) return xengine_go<XC<12, 8, false, 1, 2, 4>>(E, st);
-        if (E->variant_set && E->nwv == 12 && E->depth == 4) return xengine_go<XC<12, 4, false, 1, 2, 4>>(E, st);
-        if (E->variant_set && E->nwv == 12 && E->depth == 61) return xengine_go<XC<12, 6, false, 1, 1, 4>>(E, st);
-        if (E->variant_set && E->nwv == 12 && E->depth == 41) return xengine_go<XC<12, 4, false, 1, 1, 4>>(E, st);
-        if (E->variant_set && E->nwv == 12 && E->depth == 21) return xengine_go<XC<12, 2, false, 1, 1, 4>>(E, st);
-        if (E->variant_set && E->nwv == 12 && E->depth == 6) return xengine_go<XC<12, 6, false, 1, 2, 4>>(E, st);
+        if (E->variant_set && E->nwv == 12 && E->depth == 8) return xengine_go<XF<XC, 12, 8, false, 1, 2, 4>>(E, st);
+        if (E->variant_set && E->nwv == 12 && E->depth == 4) return xengine_go<XF<XC, 12, 4, false, 1, 2, 4>>(E, st);
+        if (E->variant_set && E->nwv == 12 && E->depth == 61) return xengine_go<XF<XC, 12, 6, false, 1, 1, 4>>(E, st);
+        if (E->variant_set && E->nwv == 12 && E->depth == 41) return xengine_go<XF<XC, 12, 4, false, 1, 1, 4>>(E, st);
+        if (E->variant_set && E->nwv == 12 && E->depth == 21) return xengine_go<XF<XC, 12, 2, false, 1, 1, 4>>(E, st);
+        if (E->variant_set && E->nwv == 12 && E->depth == 6) return xengine_go<XF<XC, 12, 6, false, 1, 2, 4>>(E, st);
+        if (E->variant_set && E->nwv == 12 && E->depth == 22) return xengine_go<XF<XC, 12, 2, false, 1, 2, 4, 2>>(E, st); /* two pollers for the four sequences */
+        if (E->variant_set && E->nwv == 12 && E->depth == 12) return xengine_go<XF<XC, 12, 2, false, 1, 2, 4, 1>>(E, st); /* one */
+        if (E->variant_set && E->nwv == 12 && E->depth == 44) return xengine_go<XF<XC, 12, 4, false, 1, 2, 4, 4>>(E, st);
 #endif
         // ring depth 2 (measured, 32 sequences at 2 k keys, tokens/s: depth 8 5320 -- spills --, 6 6970, 4 7360, 2 7815; one key tile per attention batch 7480 / 7720 at depth 6 / 2): with
         // four sequences' chain pairs and activation chunks live, every register the ring does not hold is worth more than a deeper queue -- twelve waves hide the latency
-        if (!(E->variant_set && E->nwv == 8) && xe_smem<XC<12, 2, false, 1, 2, 4>>(E->args.n_layer) <= 160 * 1024) return xengine_go<XC<12, 2, false, 1, 2, 4>>(E, st);
-        return xengine_go<XC<8, 8, false, 1, 2, 4>>(E, st);
+        if (!(E->variant_set && E->nwv == 8) && xe_smem<XF<XC, 12, 2, false, 1, 2, 4>>(E->args.n_layer) <= 160 * 1024) return xengine_go<XF<XC, 12, 2, false, 1, 2, 4>>(E, st);
+        return xengine_go<XF<XC, 8, 8, false, 1, 2, 4>>(E, st);
     }
     if (nb == 2) {
 #ifdef XE_NB4_VARIANTS /* tuning builds only */
-        if (E->variant_set && E->nwv == 12 && E->depth == 61) return xengine_go<XC<12, 6, false, 1, 1, 2>>(E, st);
-        if (E->variant_set && E->nwv == 12 && E->depth == 6) return xengine_go<XC<12, 6, false, 1, 2, 2>>(E, st);
-        if (E->variant_set && E->nwv == 12 && E->depth == 41) return xengine_go<XC<12, 4, false, 1, 1, 2>>(E, st);
-        if (E->variant_set && E->nwv == 12 && E->depth == 2) return xengine_go<XC<12, 2, false, 1, 2, 2>>(E, st);
+        if (E->variant_set && E->nwv == 12 && E->depth == 61) return xengine_go<XF<XC, 12, 6, false, 1, 1, 2>>(E, st);
+        if (E->variant_set && E->nwv == 12 && E->depth == 6) return xengine_go<XF<XC, 12, 6, false, 1, 2, 2>>(E, st);
+        if (E->variant_set && E->nwv == 12 && E->depth == 41) return xengine_go<XF<XC, 12, 4, false, 1, 1, 2>>(E, st);
+        if (E->variant_set && E->nwv == 12 && E->depth == 2) return xengine_go<XF<XC, 12, 2, false, 1, 2, 2>>(E, st);
+        if (E->variant_set && E->nwv == 12 && E->depth == 14) return xengine_go<XF<XC, 12, 4, false, 1, 2, 2, 1>>(E, st); /* one poller for the two sequences */
+        if (E->variant_set && E->nwv == 12 && E->depth == 12) return xengine_go<XF<XC, 12, 2, false, 1, 2, 2, 1>>(E, st);
 #endif
-        if (E->variant_set && E->nwv == 8) return xengine_go<XC<8, 8, false, 1, 2, 2>>(E, st);
-        return xengine_go<XC<12, 4, false, 1, 2, 2>>(E, st); /* (16 sequences: depth 6 5990, 4 6250, 2 6200 tokens/s) */
+        if (E->variant_set && E->nwv == 8) return xengine_go<XF<XC, 8, 8, false, 1, 2, 2>>(E, st);
+        return xengine_go<XF<XC, 12, 4, false, 1, 2, 2>>(E, st); /* (16 sequences: depth 6 5990, 4 6250, 2 6200 tokens/s) */
     }
 #ifdef XE_NB4_VARIANTS
-    if (!two && E->variant_set && E->nwv == 12 && E->depth == 4) return xengine_go<XC<12, 4, false, 1, 2, 1>>(E, st);
+    if (!two && E->variant_set && E->nwv == 12 && E->depth == 4) return xengine_go<XF<XC, 12, 4, false, 1, 2, 1>>(E, st);
 #endif
-    if (!two && E->variant_set && E->nwv == 12 && E->depth == 6) return xengine_go<XC<12, 6, false, 1, 2, 1>>(E, st);
-    if (!two && E->variant_set && E->nwv == 9) return xengine_go<XC<9, 8, false, 1, 2, 1>>(E, st);
-    return two ? xengine_go<XC<8, 4, false, 2, 1, 1>>(E, st) : xengine_go<XC<12, 2, false, 1, 2, 1>>(E, st); /* (8 sequences: depth 6 4370, 4 4570, 2 4630 tokens/s) */
+    if (!two && E->variant_set && E->nwv == 12 && E->depth == 6) return xengine_go<XF<XC, 12, 6, false, 1, 2, 1>>(E, st);
+    if (!two && E->variant_set && E->nwv == 9) return xengine_go<XF<XC, 9, 8, false, 1, 2, 1>>(E, st);
+    return two ? xengine_go<XF<XC, 8, 4, false, 2, 1, 1>>(E, st) : xengine_go<XF<XC, 12, 2, false, 1, 2, 1>>(E, st); /* (8 sequences: depth 6 4370, 4 4570, 2 4630 tokens/s) */
 }
 // the LDS the chosen form needs (classes 1 and 2), so that create / served can refuse a model too deep for it instead of the first step
-template <template <int, int, bool, int, int, int> class XC>
+template <template <int, int, bool, int, int, int, int> class XC>
 static size_t xe_shape_smem(int n_seq, int n_layer, bool two_wpc) {
-    if (n_seq <= XE_NXCD) return xe_smem<XC<12, 2, false, 1, 2, 1>>(n_layer);
-    if (n_seq <= 2 * XE_NXCD) return two_wpc ? 2 * (xe_smem<XC<8, 4, false, 2, 1, 1>>(n_layer) < 54 * 1024 ? (size_t)54 * 1024 : xe_smem<XC<8, 4, false, 2, 1, 1>>(n_layer)) : xe_smem<XC<12, 4, false, 1, 2, 2>>(n_layer);
-    const size_t s12 = xe_smem<XC<12, 2, false, 1, 2, 4>>(n_layer), s8 = xe_smem<XC<8, 8, false, 1, 2, 4>>(n_layer);
+    if (n_seq <= XE_NXCD) return xe_smem<XF<XC, 12, 2, false, 1, 2, 1>>(n_layer);
+    if (n_seq <= 2 * XE_NXCD) return two_wpc ? 2 * (xe_smem<XF<XC, 8, 4, false, 2, 1, 1>>(n_layer) < 54 * 1024 ? (size_t)54 * 1024 : xe_smem<XF<XC, 8, 4, false, 2, 1, 1>>(n_layer)) : xe_smem<XF<XC, 12, 4, false, 1, 2, 2>>(n_layer);
+    const size_t s12 = xe_smem<XF<XC, 12, 2, false, 1, 2, 4>>(n_layer), s8 = xe_smem<XF<XC, 8, 8, false, 1, 2, 4>>(n_layer);
     return s12 < s8 ? s12 : s8;
 }
 // n_steps decode steps of every sequence in ONE launch; with_head: 0 layers only (x_out), 1 + logits, 2 + greedy pick and state update (needed for n_steps > 1)
@@ -1939,6 +1968,13 @@ int xengine_steps(XEngineHost* E, hipStream_t st, int32_t* d_state, uint16_t* x_
     else
 #endif
     if (E->shape_class == 3) { /* the default instantiations only (no tuning variants, no stamps) */
+#ifdef XE_C3_VARIANTS /* tuning builds: the two-sequences-per-decoder form of the 1.7B shape */
+        if (a.n_seq > XE_NXCD && E->variant_set && E->nwv == 12 && E->depth == 2) rc = xengine_go<XC3<12, 2, false, 1, 2, 2>>(E, st);
+        else if (a.n_seq > XE_NXCD && E->variant_set && E->nwv == 12 && E->depth == 21) rc = xengine_go<XC3<12, 2, false, 1, 1, 2>>(E, st);
+        else if (a.n_seq > XE_NXCD && E->variant_set && E->nwv == 8 && E->depth == 4) rc = xengine_go<XC3<8, 4, false, 1, 2, 2>>(E, st);
+        else if (a.n_seq > XE_NXCD && E->variant_set && E->nwv == 8 && E->depth == 2) rc = xengine_go<XC3<8, 2, false, 1, 2, 2>>(E, st);
+        else
+#endif
         if (a.n_seq > XE_NXCD && !E->two_wpc && xe_smem<XC3<12, 4, false, 1, 2, 2>>(a.n_layer) <= 160 * 1024) rc = xengine_go<XC3<12, 4, false, 1, 2, 2>>(E, st); /* two sequences per decoder */
         else rc = a.n_seq > XE_NXCD ? xengine_go<XC3<8, 4, false, 2, 1>>(E, st) : xengine_go<XC3<12, 6, false, 1>>(E, st);
     }

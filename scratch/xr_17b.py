@@ -10,7 +10,7 @@ m = synth.build_on_gpu(cfg, seed=1234, layer_type=L.Q4, head_type=L.BF16)
 m.set_canonical(True)
 K, W = 20, 5
 first = S - K
-for n_seq, var in [(8, None), (16, None), (16, (-2, 1))]:
+for n_seq, var in ([(8, None), (16, None), (16, (-2, 1))] if len(sys.argv) < 2 else [eval(x) for x in sys.argv[1:]]):
     xr = XcdReplicas(m, n_seq)
     if var:
         xr.variant(*var)

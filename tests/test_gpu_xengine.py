@@ -146,7 +146,7 @@ def test_full_size_eight_sequences(canon, n_seq):
     m = synth.build_on_gpu(cfg, seed=1234, layer_type=L.Q4, head_type=L.BF16, head_std=0.1)
     m.set_canonical(True)
     P, n = 2028, 16
-    osel = (0, 5) if n_seq == 8 else (0, 21)   # the sequences also compared with the oracle itself
+    osel = (0, 5) if n_seq <= 16 else (0, 21)   # the sequences also compared with the oracle itself (21: the third of its decoder's four)
     kvd = cfg["n_kv"] * cfg["head_dim"]
     xr = XcdReplicas(m, n_seq)
     ref = []
