@@ -466,7 +466,7 @@ def side_legs(which):
             "summation_order": d["config"].get("summation_order"), "cpu_baseline": d.get("cpu_baseline"), "engine_handoffs": d.get("engine_handoffs"),
             "decode_path": d["config"]["decode_path"], "profile": "profiles/r04_config5_sparse_1bit_kernel_stats.csv", "leg_wall_s": d.get("leg_wall_s")}
     if "qwen3_1p7b" in which:   # not a BASELINE configuration: the second model shape the persistent engine is instantiated for (round 4)
-        d = _child(["--config", "qwen3-1.7b", "--steps", "64", "--warmup", "16", "--lean", "--lean-xcd", "8", "--jump"], 420)
+        d = _child(["--config", "qwen3-1.7b", "--steps", "64", "--warmup", "16", "--lean", "--lean-xcd", "16", "--jump"], 420)
         e = _child(["--config", "qwen3-1.7b", "--steps", "64", "--warmup", "16", "--lean", "--engine", "0", "--jump"], 420) if "qwen3_1p7b_launches" in which else {}
         out["qwen3_1p7b_shape"] = d if "error" in d else {
             "workload": "Qwen3-1.7B shape (dim 2048, 16 / 8 heads of 128, ffn 6144), 4-bit PackedQ greedy decode: %s" % d["config"]["workload"].split("seq=")[-1],

@@ -1688,7 +1688,7 @@ int xengine_build(const kf_engine_desc* d, int n_seq, long long kv_seq_stride, v
     if (sc == 5 && xe_smem<XC5W>(d->n_layer) > 160 * 1024) return KF_UNSUPPORTED_DATATYPE;
     if (sc == 3 && n_seq <= XE_NXCD && xe_smem<XC3<12, 6, false, 1>>(d->n_layer) > 160 * 1024) return KF_UNSUPPORTED_DATATYPE;
     *why = "two decoders per XCD (more than 8 sequences) do not fit this shape and depth: two workgroups per CU need 2 x the activations + the layer table in 160 KB of LDS";
-    if (sc == 3 && n_seq > XE_NXCD && 2 * xe_smem_class3_two(d->n_layer) > 160 * 1024 && xe_smem<XC3<12, 4, false, 1, 2, 2>>(d->n_layer) > 160 * 1024) return KF_UNSUPPORTED_DATATYPE;
+    if (sc == 3 && n_seq > XE_NXCD && 2 * xe_smem_class3_two(d->n_layer) > 160 * 1024 && xe_smem<XC3<8, 8, false, 1, 2, 2>>(d->n_layer) > 160 * 1024) return KF_UNSUPPORTED_DATATYPE;
     if (!dry && (ws_bytes < xengine_ws_bytes(d) || ((uintptr_t)ws & 255) != 0)) {
         *why = "workspace too small or not 256-byte aligned";
         return KF_INVALID_ARGS;
@@ -1971,11 +1971,15 @@ int xengine_steps(XEngineHost* E, hipStream_t st, int32_t* d_state, uint16_t* x_
 #ifdef XE_C3_VARIANTS /* tuning builds: the two-sequences-per-decoder form of the 1.7B shape */
         if (a.n_seq > XE_NXCD && E->variant_set && E->nwv == 12 && E->depth == 2) rc = xengine_go<XC3<12, 2, false, 1, 2, 2>>(E, st);
         else if (a.n_seq > XE_NXCD && E->variant_set && E->nwv == 12 && E->depth == 21) rc = xengine_go<XC3<12, 2, false, 1, 1, 2>>(E, st);
+        else if (a.n_seq > XE_NXCD && E->variant_set && E->nwv == 12 && E->depth == 4) rc = xengine_go<XC3<12, 4, false, 1, 2, 2>>(E, st);
         else if (a.n_seq > XE_NXCD && E->variant_set && E->nwv == 8 && E->depth == 4) rc = xengine_go<XC3<8, 4, false, 1, 2, 2>>(E, st);
+        else if (a.n_seq > XE_NXCD && E->variant_set && E->nwv == 8 && E->depth == 6) rc = xengine_go<XC3<8, 6, false, 1, 2, 2>>(E, st);
         else if (a.n_seq > XE_NXCD && E->variant_set && E->nwv == 8 && E->depth == 2) rc = xengine_go<XC3<8, 2, false, 1, 2, 2>>(E, st);
         else
 #endif
-        if (a.n_seq > XE_NXCD && !E->two_wpc && xe_smem<XC3<12, 4, false, 1, 2, 2>>(a.n_layer) <= 160 * 1024) rc = xengine_go<XC3<12, 4, false, 1, 2, 2>>(E, st); /* two sequences per decoder */
+        // two sequences per decoder: 6 compute waves + 2 pollers at 256 registers (measured at 2 k keys, 16 sequences: 2180 tokens/s; 12 waves at 168 registers spill in the
+        // streaming loops: 1650 - 1690; round 5's two decoders per XCD 1600; eight sequences, one per decoder: 1940)
+        if (a.n_seq > XE_NXCD && !E->two_wpc && xe_smem<XC3<8, 8, false, 1, 2, 2>>(a.n_layer) <= 160 * 1024) rc = xengine_go<XC3<8, 8, false, 1, 2, 2>>(E, st); /* (ring depth 4 / 6 / 8: 2180 / 2230 / 2240) */
         else rc = a.n_seq > XE_NXCD ? xengine_go<XC3<8, 4, false, 2, 1>>(E, st) : xengine_go<XC3<12, 6, false, 1>>(E, st);
     }
     else if (E->shape_class == 4)
