@@ -12,8 +12,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 HOST = os.path.join(HERE, "host")
-HIP_SOURCES = ["kf_gemv.hip", "kf_gemv_canon.hip", "kf_gemm.hip", "kf_gemm2.hip", "kf_gemm3.hip", "kf_attn.hip", "kf_engine.hip", "kf_xengine.hip", "kf_attn_prefill.hip", "kf_ops.hip", "kf_lut.hip", "kf_loss.hip", "kf_norm_bwd.hip", "kf_linear_bwd.hip", "kf_embed_bwd.hip", "kf_attn_bwd_mfma.hip", "kf_awq.hip", "kf_tp.hip", "kf_abi.hip"]
-HIP_DEPS = ["kf_device.h", "kf_kernels.h", "kf_gemm_common.h", "kf_gemv_blocks.h", "kf_attn_common.h", "kf_engine_common.h"]
+HIP_SOURCES = ["kf_gemv.hip", "kf_gemv_canon.hip", "kf_gemm.hip", "kf_gemm2.hip", "kf_gemm3.hip", "kf_attn.hip", "kf_engine.hip", "kf_xengine.hip", "kf_xengine_q1.hip", "kf_attn_prefill.hip", "kf_ops.hip", "kf_lut.hip", "kf_loss.hip", "kf_norm_bwd.hip", "kf_linear_bwd.hip", "kf_embed_bwd.hip", "kf_attn_bwd_mfma.hip", "kf_awq.hip", "kf_tp.hip", "kf_abi.hip"]
+HIP_DEPS = ["kf_device.h", "kf_kernels.h", "kf_gemm_common.h", "kf_gemv_blocks.h", "kf_attn_common.h", "kf_engine_common.h", "kf_xengine_kernel.h"]
 LIB_HIP = os.path.join(HERE, "libkf_hip.so")
 LIB_HOST = os.path.join(HERE, "libkf_host.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -30,15 +30,15 @@ def canon():
 _OM = {}
 
 
-def _oracle_run(cfg, raw, forced, n, pos0=0):
+def _oracle_run(cfg, raw, forced, n, pos0=0, layer_type=L.Q4):
     """the oracle alone on one sequence: teacher-forced where forced >= 0, free running elsewhere -> ids per position, last logits, K / V.  One oracle model per (cfg, weights)
     serves every sequence of a test (a sequence starts at position 0 and rewrites the cache rows as it goes): quantising the weights once instead of once per sequence"""
-    key = (raw["embed"][:2, :32].tobytes(), raw["layers"][0]["q"][:2, :32].tobytes(), tuple(sorted((k, str(v)) for k, v in cfg.items())))
+    key = (layer_type, raw["embed"][:2, :32].tobytes(), raw["layers"][0]["q"][:2, :32].tobytes(), tuple(sorted((k, str(v)) for k, v in cfg.items())))
     if key not in _OM:
         for o in _OM.values():
             o.close()
         _OM.clear()
-        _OM[key] = oracle_model(cfg, raw, L.Q4, L.BF16, attn_mode=O.ATTN_CANON)
+        _OM[key] = oracle_model(cfg, raw, layer_type, L.BF16, attn_mode=O.ATTN_CANON)
     om = _OM[key]
     ids, logits, tok = [], None, int(forced[0])
     for p in range(pos0 + n):
@@ -90,6 +90,39 @@ def test_every_sequence_equals_the_oracle(canon, cfg_name, max_seq, n_steps, n_s
         assert xr.state(s) == (o_ids[-1], n_steps)
         g_logits = xr.logits(s)
         assert np.array_equal(g_logits, o_logits), "sequence %d: %d logits differ" % (s, int((g_logits != o_logits).sum()))
+        gk, gv = xr.kv_to_host(s)
+        assert np.array_equal(gk[:, :n_steps], ok[:, :n_steps]) and np.array_equal(gv[:, :n_steps], ov[:, :n_steps]), "sequence %d: K / V rows" % s
+    xr.close()
+    m.close()
+
+
+@pytest.mark.parametrize("cfg_name,max_seq,n_steps,n_seq,check", [("tiny", 200, 150, 8, None), ("small", 320, 100, 16, (0, 5, 9, 14)), ("small", 320, 100, 32, (0, 7, 13, 18, 24, 31)), ("tiny", 200, 150, 27, None)])
+def test_one_bit_layers_every_sequence_equals_the_oracle(canon, cfg_name, max_seq, n_steps, n_seq, check):
+    """Round 6: the XCD-confined engines on 1-bit PackedQ layers (YinYang, groups of 128: BASELINE config 5's storage) -- a lane takes one dword of a 128-element block, the
+    block's pair words come out of the LDS selector table once per decoder and every sequence takes its canonical chain pair over them; one, two and four sequences per
+    decoder: ids at every position, the last logits and all K / V rows against the oracle run on the sequence alone."""
+    cfg = dict(synth.CONFIGS[cfg_name], max_seq=max_seq)
+    raw = synth.raw_weights_numpy(cfg, 2468, w_std=0.1)
+    m = synth.build_from_raw(cfg, raw, L.BOOL1, L.BF16)
+    m.set_canonical(True)
+    xr = XcdReplicas(m, n_seq)
+    xr.set_steps_per_launch(13)
+    forced = []
+    for s in range(n_seq):
+        f = np.full(max_seq, -1, dtype=np.int32)
+        npr = 10 + 3 * (s % 16)
+        f[:npr] = prompt_ids(cfg, npr, seed=500 + s)
+        forced.append(f)
+        xr.set_forced(s, f)
+        xr.set_state(s, int(f[0]), 0)
+    xr.run_steps(n_steps)
+    m.sync()
+    xr.check()
+    for s in (range(n_seq) if check is None else check):
+        o_ids, o_logits, ok, ov = _oracle_run(cfg, raw, forced[s], n_steps, layer_type=L.BOOL1)
+        g_ids = xr.tokens_out(s, n_steps).tolist()
+        assert g_ids == o_ids, "sequence %d: first differing position %d" % (s, next(i for i, (a, b) in enumerate(zip(g_ids, o_ids)) if a != b))
+        assert np.array_equal(xr.logits(s), o_logits), "sequence %d: logits" % s
         gk, gv = xr.kv_to_host(s)
         assert np.array_equal(gk[:, :n_steps], ok[:, :n_steps]) and np.array_equal(gv[:, :n_steps], ov[:, :n_steps]), "sequence %d: K / V rows" % s
     xr.close()
