@@ -458,12 +458,13 @@ def side_legs(which):
     if "config3" in which:
         out["config3_train_step"] = _child(["--leg", "config3"], 420)
     if "config5" in which:
-        d = _child(["--layers", "1bit", "--sparse", "0.2", "--steps", "512", "--warmup", "64", "--lean", "--lean-cpu", "6"], 420)
+        d = _child(["--layers", "1bit", "--sparse", "0.2", "--steps", "512", "--warmup", "64", "--lean", "--lean-cpu", "6", "--lean-xcd", "32"], 420)
         out["config5_sparse_1bit"] = d if "error" in d else {
             "workload": "Qwen3-0.6B, 1-bit PackedQ layers (YinYang), 20 %% of every FFN's rows hot (D_matmul_sparse: cold rows cost no HBM), bf16 head; positions %s" % d["config"]["workload"].split("timed positions ")[-1],
             "tokens_per_s": d["value"], "ms_per_step": d["ms_per_step"], "bytes_per_step": d["step_roofline"]["bytes_per_step"], "frac": d["step_roofline"]["frac"],
             "fast_order_tokens_per_s": d.get("fast_order_mode", {}).get("tokens_per_s"),
             "summation_order": d["config"].get("summation_order"), "cpu_baseline": d.get("cpu_baseline"), "engine_handoffs": d.get("engine_handoffs"),
+            "xcd_replicas": d.get("xcd_replicas"),   # round 6: the same model (1-bit layers, the same hot-row masks) through the batched XCD decoders, 32 independent sequences
             "decode_path": d["config"]["decode_path"], "profile": "profiles/r04_config5_sparse_1bit_kernel_stats.csv", "leg_wall_s": d.get("leg_wall_s")}
     if "qwen3_1p7b" in which:   # not a BASELINE configuration: the second model shape the persistent engine is instantiated for (round 4)
         d = _child(["--config", "qwen3-1.7b", "--steps", "64", "--warmup", "16", "--lean", "--lean-xcd", "16", "--jump"], 420)
@@ -1535,6 +1536,8 @@ def compact_line(out, detail=DETAIL_FILE):
         if "error" not in t:
             side["config5_sparse_1bit"]["parity"] = _parity_ok(t.get("cpu_baseline"))
             side["config5_sparse_1bit"]["cpu_tokens_per_s"] = _g(t, "cpu_baseline", "value")
+            if isinstance(t.get("xcd_replicas"), dict):
+                side["config5_sparse_1bit"]["xcd_replicas"] = _keep(_xcd_short(t["xcd_replicas"]), ("streams", "batch", "tokens_per_s", "frac_vs_single_sequence_roofline", "hbm_frac_batch", "parity", "error"))
     for nm in ("qwen3_1p7b_shape", "qwen3_4b_shape", "qwen3_8b_shape"):
         t = out.get(nm)
         if isinstance(t, dict):

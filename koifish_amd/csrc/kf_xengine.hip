@@ -107,12 +107,12 @@ void xengine_free(XEngineHost* E) {
 }
 // one model's (one TP rank's) layer table out of its descriptor; qbias: the seven matrices' zero points of layer 0 (every layer, every rank: the same)
 // *fmt_io: the storage every matrix of the model carries (0 on entry = not known yet): FMT_Q4P (4-bit PackedQ) or FMT_Q1T (1-bit, round 6)
-static int xe_fill_layers(const kf_engine_desc* d, EngLayer* tab, float* qbias, bool qbias_set, bool& q4p_ok, int* fmt_io = nullptr) {
+static int xe_fill_layers(const kf_engine_desc* d, EngLayer* tab, float* qbias, bool qbias_set, bool& q4p_ok, int* fmt_io = nullptr, bool allow_hot = false) {
     const int hd = d->head_dim, q_dim = d->n_head * hd, kv_dim = d->n_kv * hd;
     const int Ks[7] = {d->dim, d->dim, d->dim, q_dim, d->dim, d->dim, d->ffn}, Ms[7] = {q_dim, kv_dim, kv_dim, d->dim, d->ffn, d->ffn, d->dim};
     for (int l = 0; l < d->n_layer; l++) {
         const kf_engine_layer& Ly = d->layers[l];
-        if (Ly.hot_ffn) return KF_UNSUPPORTED_DATATYPE;
+        if (Ly.hot_ffn && !allow_hot) return KF_UNSUPPORTED_DATATYPE;
         if (!Ly.norm_in || !Ly.norm_post || !Ly.kcache || !Ly.vcache || (((uintptr_t)Ly.kcache | (uintptr_t)Ly.vcache) & 15) != 0) return KF_UNSUPPORTED_DATATYPE;
         for (int j = 0; j < 7; j++) {
             const kf_weight& w = Ly.w[j];
@@ -132,7 +132,7 @@ static int xe_fill_layers(const kf_engine_desc* d, EngLayer* tab, float* qbias, 
         tab[l].norm_in = (g_u16)(uintptr_t)Ly.norm_in, tab[l].norm_post = (g_u16)(uintptr_t)Ly.norm_post;
         tab[l].norm_q = (g_u16)(uintptr_t)Ly.q_norm, tab[l].norm_k = (g_u16)(uintptr_t)Ly.k_norm;
         tab[l].kcache = (g_u16w)(uintptr_t)Ly.kcache, tab[l].vcache = (g_u16w)(uintptr_t)Ly.vcache;
-        tab[l].hot = nullptr;
+        tab[l].hot = (g_i32)(uintptr_t)Ly.hot_ffn; /* sparse forward: CS_Picker's hot[ffn] on the device (kf_abi.h kf_engine_layer::hot_ffn); NULL: dense */
     }
     return KF_OK;
 }
@@ -172,12 +172,12 @@ int xengine_build(const kf_engine_desc* d, int n_seq, long long kv_seq_stride, v
     if (n_cu != XE_GRID) return KF_UNSUPPORTED_DATATYPE;
     *why = "rope_table missing, kv_stride not a multiple of 8, or max_seq < 1";
     if (!d->rope_table || (d->kv_stride % 8) != 0 || d->max_seq < 1) return KF_INVALID_ARGS;
-    *why = "layer storage not served: 4-bit (RTN) or 1-bit (YinYang) PackedQ layers in groups of 128 with 16-byte aligned blocks, every matrix the same storage, dense FFN, every layer the same shapes";
+    *why = "layer storage not served: 4-bit (RTN) or 1-bit (YinYang) PackedQ layers in groups of 128 with 16-byte aligned blocks, every matrix the same storage, every layer the same shapes (FFN dense or with a hot-row mask)";
     std::vector<EngLayer> tab(d->n_layer);
     float qbias[7] = {0};
     bool q4p_ok = true;
     int fmt = 0;
-    if (xe_fill_layers(d, tab.data(), qbias, false, q4p_ok, &fmt) != KF_OK) return KF_UNSUPPORTED_DATATYPE;
+    if (xe_fill_layers(d, tab.data(), qbias, false, q4p_ok, &fmt, true) != KF_OK) return KF_UNSUPPORTED_DATATYPE;
     if (!q4p_ok) return KF_UNSUPPORTED_DATATYPE;
     *why = "1-bit PackedQ layers are served for the Qwen3-0.6B shape and the 256-wide test shape";
     if (fmt == FMT_Q1T && sc != 1 && sc != 2) return KF_UNSUPPORTED_DATATYPE;

@@ -514,7 +514,8 @@ __device__ __forceinline__ void xe_mv_run(const XPhase& P, const XPhase& NX, boo
 // actm: bit b set = sequence b is active (an inactive one publishes nothing)
 template <int NB = 1, size_t LBS = 0>
 __device__ __forceinline__ void xe_publish(const XLds& L, int phase, uint32_t tag, uint32_t* dst, int nrows, int nwaves, int lane, uint16_t* plain = nullptr,
-                                           unsigned long long* push = nullptr, size_t push_stride = 0, uint32_t tagx = 0, int pad = 0, size_t dst_bs = 0, size_t plain_bs = 0, uint32_t actm = 1u) {
+                                           unsigned long long* push = nullptr, size_t push_stride = 0, uint32_t tagx = 0, int pad = 0, size_t dst_bs = 0, size_t plain_bs = 0, uint32_t actm = 1u,
+                                           g_i32 hot = nullptr /* phase 2, sparse forward: hot[] of this workgroup's first gate / up row on (D_matmul_sparse: a cold row's output is 0) */) {
     int old = 0;
     if (lane == 0) old = __hip_atomic_fetch_add(L.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     old = __builtin_amdgcn_readfirstlane(old);
@@ -543,7 +544,8 @@ __device__ __forceinline__ void xe_publish(const XLds& L, int phase, uint32_t ta
             for (int i = lane; i < nrows; i += 64) {
                 const uint32_t pr = ob[i];
                 const float gt = bf_lo(pr), up = bf_hi(pr);
-                ob[i] = (tag << 16) | (uint32_t)f2bf((gt * up) / (1.0f + kf_expf(-gt)));
+                const bool cold = hot != nullptr && hot[i] != 1; /* (the single-sequence engine and the masked launches publish the same zero) */
+                ob[i] = (tag << 16) | (cold ? 0u : (uint32_t)f2bf((gt * up) / (1.0f + kf_expf(-gt))));
             }
         }
         for (int i = 4 * lane; i < nrows; i += 256) {
@@ -1151,7 +1153,7 @@ __device__ __forceinline__ void xe_compute_main(const XArgs& a, const XLds& L, c
                     xe_publish(L, q, tag, dst, nrows, nwp, lane, nullptr, push, (size_t)2 * XE_NXCD * C::DIM, 2u * gen + (q == 3 ? 2u : 1u), (q == 2 && wg == XE_NWG - 1) ? C::FFNP - C::FFN : 0);
                 } else {
                     xe_publish<NB, XLay<C>::seq_bytes>(L, q, tag, dst, nrows, nwp, lane, (q == 3 && last) ? a.x_out + (size_t)S.seq * C::DIM + wg * P6::R : nullptr, nullptr, 0, 0, 0, loc_bs,
-                                                       (size_t)XE_NXCD * C::DIM, actm);
+                                                       (size_t)XE_NXCD * C::DIM, actm, (q == 2 && ly.hot) ? ly.hot + wg * P5::R : nullptr);
                 }
             }
             if (cw == 0) XE_STAMP(17 + 2 * q);

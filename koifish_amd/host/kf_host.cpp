@@ -826,11 +826,7 @@ int XcdReplicas::MakeEngine(bool allocate) {
             why = "a norm weight is missing";
             return KF_ENGINE_NOT_SERVED;
         }
-        if (m->n_hot >= 0) {
-            why = "a hot-row mask is set: the XCD-confined engines walk dense FFNs only";
-            return KF_ENGINE_NOT_SERVED;
-        }
-        L[l].hot_ffn = nullptr;
+        L[l].hot_ffn = m->n_hot >= 0 ? reinterpret_cast<const int32_t*>(m->hot_mask->data) : nullptr; /* the sparse forward (round 6): cold gate / up rows publish zeros */
         L[l].norm_in = ToX(a->norm.w), L[l].norm_post = ToX(m->norm.w);
         L[l].q_norm = a->normQ.w ? ToX(a->normQ.w) : nullptr, L[l].k_norm = a->normK.w ? ToX(a->normK.w) : nullptr;
         L[l].kcache = L[l].vcache = reinterpret_cast<floatX*>(f->cache.Get(KVCache::KV_KEY, l, 0)); /* stand-ins for the validation call below; set after the allocation */
@@ -1137,6 +1133,7 @@ int kfh_set_hot(void* h, int layer, const int32_t* h_hot, int n) {
     if (h_hot && n != f->config.n_ff) return KF_INVALID_ARGS; /* arguments first: a rejected call changes nothing */
     f->DropEngineTable(); /* the engine's layer table (and the captured graphs) hold the masks: rebuilt on the next step; the resident bf16 copies and the measured delays do not
                              depend on them and stay */
+    f->weights_gen++;     /* an XcdReplicas built on this Fish holds the masks' addresses in its layer table too: its next use re-creates the engine */
     if (!h_hot) {
         if (m->n_hot >= 0) f->masked_layers--;
         m->n_hot = -1, m->hot_rows.reset(), m->hot_mask.reset();

@@ -129,6 +129,53 @@ def test_one_bit_layers_every_sequence_equals_the_oracle(canon, cfg_name, max_se
     m.close()
 
 
+@pytest.mark.parametrize("layer_type,n_seq", [(L.BOOL1, 32), (L.BOOL1, 8), (L.Q4, 16)])
+def test_sparse_forward_every_sequence_equals_the_oracle(canon, layer_type, n_seq):
+    """BASELINE config 5's forward through the XCD-confined engines (round 6): 1-bit (and 4-bit) layers with a hot-row mask on every layer's FFN (CS_Picker's hot[], 20 % hot,
+    seeded per layer; D_matmul_sparse: a cold gate / up row contributes nothing) -- ids, last logits and K / V rows of the checked sequences against the oracle with the same
+    masks; the mask set AFTER the replicas object was built (its next use re-creates the engine: Fish::weights_gen)."""
+    cfg = dict(synth.CONFIGS["small"], max_seq=160)
+    raw = synth.raw_weights_numpy(cfg, 97, w_std=0.1)
+    m = synth.build_from_raw(cfg, raw, layer_type, L.BF16)
+    m.set_canonical(True)
+    xr = XcdReplicas(m, n_seq)
+    hots = {}
+    for l in range(cfg["n_layer"]):
+        hot = np.zeros(cfg["ffn"], dtype=np.int32)
+        hot[np.random.default_rng(5 + l).permutation(cfg["ffn"])[: max(int(cfg["ffn"] * 0.2), 16)]] = 1
+        m.set_hot(l, hot)
+        hots[l] = hot
+    n_steps = 70
+    forced = []
+    for s in range(n_seq):
+        f = np.full(cfg["max_seq"], -1, dtype=np.int32)
+        f[:9 + s % 7] = prompt_ids(cfg, 9 + s % 7, seed=800 + s)
+        forced.append(f)
+        xr.set_forced(s, f)
+        xr.set_state(s, int(f[0]), 0)
+    xr.run_steps(n_steps)
+    m.sync()
+    xr.check()
+    om = oracle_model(cfg, raw, layer_type, L.BF16, attn_mode=O.ATTN_CANON)
+    for l, hot in hots.items():
+        om.set_hot(l, hot)
+    for s in sorted({0, 3, n_seq // 2 + 1, n_seq - 1}):
+        tok, o_ids, o_logits = int(forced[s][0]), [], None
+        for p in range(n_steps):
+            if forced[s][p] >= 0:
+                tok = int(forced[s][p])
+            tok, o_logits, _ = om.decode(tok, p)
+            o_ids.append(tok)
+        assert xr.tokens_out(s, n_steps).tolist() == o_ids, "sequence %d" % s
+        assert np.array_equal(xr.logits(s), o_logits), "sequence %d: logits" % s
+        ok, ov = om.kv()
+        gk, gv = xr.kv_to_host(s)
+        assert np.array_equal(gk[:, :n_steps], ok[:, :n_steps]) and np.array_equal(gv[:, :n_steps], ov[:, :n_steps]), "sequence %d: K / V rows" % s
+    om.close()
+    xr.close()
+    m.close()
+
+
 def test_sequences_at_different_positions(canon):
     """the sequences of one launch need not be in step: all eight are first decoded from position 0 (so that every cache holds its sequence's history), then each is put back
     to a start of its own -- 0, 5, 63, 64, 65, 130, 257, 300: on both sides of the 64-key slice boundaries -- and all advance together; the slices of a sequence's attention
