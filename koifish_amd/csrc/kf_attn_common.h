@@ -171,6 +171,9 @@ __device__ __forceinline__ void canon_apply_items(CanonAcc<GQ>& A, double p, con
         canon_apply_items<GQ, U, I + 1>(A, p, vd);
     }
 }
+// (Round 6, measured and removed: two query heads per v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 in the score chain and in the exponential's polynomial -- bit-identical (179
+//  canonical tests), half the vector instructions of those two parts, and slower: the single-sequence engine 2304 -> 2103 tokens/s, 32 batched sequences 7770 -> 7410: the operand
+//  pairs have to be assembled in even-aligned register pairs per use.)
 #ifndef KF_CANON_ITEMS
 #define KF_CANON_ITEMS 0 /* scratch/build_variant.py A/B.  1 = the item-per-lane form below: bit for bit the same (194 canonical tests), a quarter fewer vector instructions per key
                             tile on paper -- and SLOWER on the part: 32 sequences 7770 -> 6360 tokens/s, 16: 6240 -> 5710, 8: 4625 -> 4450, the single-sequence engine unchanged (each
