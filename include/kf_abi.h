@@ -480,8 +480,8 @@ int kf_engine_destroy(kf_engine* e);
  * sequences x, x + 8, x + 16, x + 24.  Every 4-bit block a decoder streams is unpacked ONCE (the exact bf16-stepwise dequantisation, T.cu:274, is what bounds these engines) and
  * multiplied against the activations of all its sequences; each sequence keeps its own canonical chains, attention, K / V cache and state, so its bits do not change.
  * Served: 4-bit PackedQ (RTN, groups of 128) layers of the Qwen3-0.6B, 1.7B, 4B and 8B shapes (and two small test shapes), bf16 embedding / head; more than 8
- * sequences for the 0.6B / 1.7B shapes (1.7B: at most 16), more than 16 for the 0.6B shape.  Round 6: 1-bit PackedQ (YinYang) layers for the 0.6B shape and the 256-wide
- * test shape (BASELINE config 5's storage), and FFNs with a hot-row mask (kf_engine_layer::hot_ffn: a cold gate / up row publishes a zero, D_matmul_sparse).  Weights are read in place and must not
+ * sequences for the 0.6B / 1.7B shapes (1.7B: at most 16), more than 16 for the 0.6B shape.  Round 6: 1-bit and 2-bit PackedQ (YinYang) layers for the 0.6B shape and the 256-wide
+ * test shape (1-bit: BASELINE config 5's storage), and FFNs with a hot-row mask (kf_engine_layer::hot_ffn: a cold gate / up row publishes a zero, D_matmul_sparse).  Weights are read in place and must not
  * change while an engine built on them lives; for the GQA-4 shapes (and the TP form below) the engine keeps a fused COPY of every layer's q | k | v rows in its workspace, made at
  * create time: after a weight update destroy the engine and create it again.
  * d_state [n_seq][4] = {token, pos, parked, status}.  parked != 0: the launch skips the sequence (the other sequences of its decoder go on).  A launch one of whose positions

@@ -12,8 +12,8 @@ namespace kf {
 // ------------------------------------------------------------------------------------------------ host side
 
 // kf_xengine_q1.hip: the 1-bit forms (their own translation unit: the instantiations compile side by side)
-int xengine_go_q1t(XEngineHost* E, hipStream_t st);
-size_t xe_smem_q1t(int shape_class, int n_seq, int n_layer);
+int xengine_go_lowbit(XEngineHost* E, hipStream_t st);
+size_t xe_smem_lowbit(int fmt, int shape_class, int n_seq, int n_layer);
 static int xe_shape_class(int GQ, int hd, int dim, int q_dim, int ffn) {
     if (GQ == 2 && hd == 128 && dim == 1024 && q_dim == 2048 && ffn == 3072) return 1; /* Qwen3-0.6B (BASELINE config 2) */
     if (GQ == 2 && hd == 64 && dim == 256 && q_dim == 256 && ffn == 512) return 2;     /* the small parity-test shape */
@@ -116,7 +116,7 @@ static int xe_fill_layers(const kf_engine_desc* d, EngLayer* tab, float* qbias, 
         if (!Ly.norm_in || !Ly.norm_post || !Ly.kcache || !Ly.vcache || (((uintptr_t)Ly.kcache | (uintptr_t)Ly.vcache) & 15) != 0) return KF_UNSUPPORTED_DATATYPE;
         for (int j = 0; j < 7; j++) {
             const kf_weight& w = Ly.w[j];
-            const int wf = gemv_fmt_of(&w), ef = wf == FMT_Q4 ? FMT_Q4P : (wf == FMT_Q1 ? FMT_Q1T : -1);
+            const int wf = gemv_fmt_of(&w), ef = wf == FMT_Q4 ? FMT_Q4P : (wf == FMT_Q1 ? FMT_Q1T : (wf == FMT_Q2 ? FMT_Q2T : -1));
             if (ef < 0 || (!fmt_io && ef != FMT_Q4P) || (fmt_io && *fmt_io != 0 && *fmt_io != ef)) return KF_UNSUPPORTED_DATATYPE;
             if (fmt_io) *fmt_io = ef;
             if (w.ne0 != Ms[j] || w.ne1 != Ks[j] || w.qzeros || w.qscales || !w.gama || w.lGroup != 128 || (Ks[j] % 128) != 0 || ((uintptr_t)w.data & 15) != 0)
@@ -172,17 +172,17 @@ int xengine_build(const kf_engine_desc* d, int n_seq, long long kv_seq_stride, v
     if (n_cu != XE_GRID) return KF_UNSUPPORTED_DATATYPE;
     *why = "rope_table missing, kv_stride not a multiple of 8, or max_seq < 1";
     if (!d->rope_table || (d->kv_stride % 8) != 0 || d->max_seq < 1) return KF_INVALID_ARGS;
-    *why = "layer storage not served: 4-bit (RTN) or 1-bit (YinYang) PackedQ layers in groups of 128 with 16-byte aligned blocks, every matrix the same storage, every layer the same shapes (FFN dense or with a hot-row mask)";
+    *why = "layer storage not served: 4-bit (RTN), 2-bit or 1-bit (YinYang) PackedQ layers in groups of 128 with 16-byte aligned blocks, every matrix the same storage, every layer the same shapes (FFN dense or with a hot-row mask)";
     std::vector<EngLayer> tab(d->n_layer);
     float qbias[7] = {0};
     bool q4p_ok = true;
     int fmt = 0;
     if (xe_fill_layers(d, tab.data(), qbias, false, q4p_ok, &fmt, true) != KF_OK) return KF_UNSUPPORTED_DATATYPE;
     if (!q4p_ok) return KF_UNSUPPORTED_DATATYPE;
-    *why = "1-bit PackedQ layers are served for the Qwen3-0.6B shape and the 256-wide test shape";
-    if (fmt == FMT_Q1T && sc != 1 && sc != 2) return KF_UNSUPPORTED_DATATYPE;
+    *why = "1-bit / 2-bit PackedQ layers are served for the Qwen3-0.6B shape and the 256-wide test shape";
+    if (fmt != FMT_Q4P && sc != 1 && sc != 2) return KF_UNSUPPORTED_DATATYPE;
     *why = "the model is too deep for this many sequences: the workgroup's activations of every sequence of a decoder + the layer table must fit 160 KB of LDS";
-    if (fmt == FMT_Q1T && xe_smem_q1t(sc, n_seq, d->n_layer) > 160 * 1024) return KF_UNSUPPORTED_DATATYPE;
+    if (fmt != FMT_Q4P && xe_smem_lowbit(fmt, sc, n_seq, d->n_layer) > 160 * 1024) return KF_UNSUPPORTED_DATATYPE;
     if (dry) {
         *why = "";
         return KF_OK;
@@ -416,7 +416,7 @@ int xengine_steps(XEngineHost* E, hipStream_t st, int32_t* d_state, uint16_t* x_
     a.epoch0 = E->epoch, E->epoch += n_steps; /* generations never repeat between resets (a 31-bit count of steps) */
     if (!with_head) a.head_w = nullptr;
     int rc;
-    if (E->fmt == FMT_Q1T) rc = xengine_go_q1t(E, st);
+    if (E->fmt != FMT_Q4P) rc = xengine_go_lowbit(E, st);
     else
 #ifdef XE_NB4_VARIANTS /* tuning builds: the ring depth of the other shapes */
     if (E->shape_class == 3 && a.n_seq <= XE_NXCD && E->variant_set && E->depth == 4) rc = xengine_go<XC3<12, 4, false, 1>>(E, st);

@@ -118,8 +118,10 @@ struct XCfg {
     static_assert(NB_ % NP == 0, "every poller the same number of sequences");
     static constexpr int FMT = FMT_, GQ = GQ_, HD = HD_, NWV = NWV_, NCW = NWV_ - NP, DIM = DIM_, QD = QD_, KVD = KVD_, FFN = FFN_, DEPTH = DEPTH_, NWG = XE_NWG;
     static constexpr bool DBG = DBG_;
-    static_assert(FMT_ == FMT_Q4 || FMT_ == FMT_Q4P || FMT_ == FMT_Q1T, "4-bit PackedQ layers (arithmetic or register-table unpack), or 1-bit (round 6: one dword of a 128-element block per lane)");
-    static constexpr int VBYTES = FMT_ == FMT_Q1T ? 4 : 16; /* bytes of a lane's 32-weight piece of the packed stream */
+    static_assert(FMT_ == FMT_Q4 || FMT_ == FMT_Q4P || FMT_ == FMT_Q1T || FMT_ == FMT_Q2T,
+                  "4-bit PackedQ layers (arithmetic or register-table unpack), or -- round 6 -- 1-bit / 2-bit: one dword of a 128-element block, resp. one 8-byte half of a 64-element block per lane");
+    static constexpr int VBYTES = FMT_ == FMT_Q1T ? 4 : (FMT_ == FMT_Q2T ? 8 : 16); /* bytes of a lane's 32-weight piece of the packed stream */
+    static constexpr bool PREP = FMT_ == FMT_Q1T || FMT_ == FMT_Q2T;                  /* unpacked through BlockPrep<FMT> and the LDS selector table */
     static constexpr int n_head = QD_ / HD_, n_kv = KVD_ / HD_;
     // more than four query heads per kv-head (a TP rank of Qwen3-32B: 8 on 1): NG groups of GQW heads, each group its own workgroups over the same key slices (the fp64 sums
     // of eight heads would be 144 registers per lane) -- K / V rows are then read NG times, from this XCD's L2
@@ -143,7 +145,7 @@ struct XCfg {
         using P6 = typename B::P6;
     };
     using SH = std::conditional_t<FUSED, SHF, EngShape<FMT_, DIM_, QD_, KVD_, FFN_, XE_NWG, P1W0>>;
-    static_assert(!FUSED || FMT_ != FMT_Q1T, "the fused q | k | v copy is laid out for 16-byte blocks");
+    static_assert(!FUSED || !PREP, "the fused q | k | v copy is laid out for 16-byte blocks");
     static_assert(!FUSED || SH::P1::lpr_log2 == EngShape<FMT_, DIM_, QD_, KVD_, FFN_, XE_NWG, P1W0>::P1::lpr_log2, "the fused matrix is walked with the launch's lanes per row");
     static constexpr int ME = QD_ / XE_NWG; /* ao elements a workgroup merges */
     static_assert(QD_ % XE_NWG == 0 && ME % 4 == 0 && ME <= HD_ && HD_ % ME == 0 && ME <= 128, "merge elements per workgroup");
@@ -169,7 +171,7 @@ struct XCfg {
                                                                                                                                       : (SH::P4::R > SH::P6::R ? SH::P4::R : SH::P6::R);
     static_assert(NB_ >= 1 && NB_ <= 4, "sequences per decoder");
     static_assert(!COOP || NP == NB_, "cooperative staging: a merge / norm scratch per sequence");
-    static_assert(NB_ == 1 || (!TP_ && WPC_ == 1 && !FUSED && NG == 1 && (FMT_ == FMT_Q4P || FMT_ == FMT_Q1T) && DIM_ / 256 <= 12 && FFNP / 256 <= 24 && !COMB_IN_XS1),
+    static_assert(NB_ == 1 || (!TP_ && WPC_ == 1 && !FUSED && NG == 1 && (FMT_ == FMT_Q4P || PREP) && DIM_ / 256 <= 12 && FFNP / 256 <= 24 && !COMB_IN_XS1),
                   "the batched form: plain (non-TP, one workgroup per CU) decoders of the shapes whose vectors are staged by the poller in one sweep");
 };
 // LDS of a workgroup: NB per-sequence blocks (activations, raw residuals, the attention's head staging, the rows of the phase being published, head maxima), then what the
@@ -188,7 +190,7 @@ struct XLay {
     static constexpr size_t o_comb = o_msc + (size_t)C::NP * msc_bytes;
     static constexpr size_t o_cnt = o_comb + (C::COMB_IN_XS1 ? 0 : sizeof(double) * (size_t)NCW * GQ * (hd + 2));
     static constexpr size_t o_tab = (o_cnt + 64 + 15) & ~(size_t)15; /* FMT_Q1T: the 256 x 16 B selector table of BlockPrep<FMT_Q1T> */
-    static constexpr size_t fixed_bytes = o_tab + (C::FMT == FMT_Q1T ? 4096 : 0);
+    static constexpr size_t fixed_bytes = o_tab + (C::FMT == FMT_Q1T ? 4096 : (C::FMT == FMT_Q2T ? 2048 : 0));
 };
 constexpr size_t xe_loc_stride(int loc_dw) { return ((size_t)loc_dw * 4 + 4095) & ~(size_t)4095; }
 
@@ -331,6 +333,9 @@ __device__ __forceinline__ void xe_issue(const XPhase& P, const XLaneGeo& G, con
     //  Sending those lanes past the buffer instead was measured: 2.9 % less fetch traffic, 1.7 - 2.9 % MORE time -- the five instructions per entry cost more than the bytes)
     if constexpr (FMT == FMT_Q1T) { /* this lane's DWORD of the 16-byte block of 128 elements (dword 3 holds elements 0 .. 31): virtual block v = 32 weights -> real block v / 4, dword 3 - v % 4 (ublk is a multiple of 4) */
         R.w[d] = u32x4{(uint32_t)__builtin_amdgcn_raw_buffer_load_b32(eng_rsrc((const void*)pw, wbytes), (vblk & ~3u) * 4u + (3u - (vblk & 3u)) * 4u, ublk * 4u, WAUX), 0u, 0u, 0u};
+    } else if constexpr (FMT == FMT_Q2T) { /* this lane's 8-byte HALF of the 16-byte block of 64 elements (bytes 8 .. 15 hold elements 0 .. 31): virtual block v -> half (v & ~1) + 1 - (v & 1) */
+        const u32x2 h = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(eng_rsrc((const void*)pw, wbytes), (vblk & ~1u) * 8u + (1u - (vblk & 1u)) * 8u, ublk * 8u, WAUX));
+        R.w[d] = u32x4{h.x, h.y, 0u, 0u}; /* .y = the half's first 16 elements, .x = its last 16 (BlockPrep<FMT_Q2T>) */
     } else {
         R.w[d] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(eng_rsrc((const void*)pw, wbytes), vblk * 16u, ublk * 16u, WAUX /* XCfg::WAUX */));
     }
@@ -458,7 +463,7 @@ __device__ __forceinline__ void xe_mv_run(const XPhase& P, const XPhase& NX, boo
                 const int row = ((P.s0 + sl * P.sl_b) << P.rps_log2) + G.sub, colr = (it << P.lpr_log2) + G.ll;
                 const bool second = P.paired && (d & 1);
                 const float qb_a = P.qb, qb_b = P.qb2;
-                if constexpr (NB == 1 && C::FMT != FMT_Q1T) {
+                if constexpr (NB == 1 && !C::PREP) {
                     if (it == 0) {
                         if (second) acc2[0] = f32x2_t{0.f, 0.f};
                         else acc[0] = f32x2_t{0.f, 0.f};
@@ -480,7 +485,7 @@ __device__ __forceinline__ void xe_mv_run(const XPhase& P, const XPhase& NX, boo
                     for (int b = 0; b < NB; b++) in[b] = it == 0 ? f32x2_t{0.f, 0.f} : (second ? acc2[b] : acc[b]), o[b] = in[b];
                     const bool ok = C::EXACT || (row < P.Mj && colr < P.nBlk);
                     const int col = (C::EXACT || colr < P.nBlk) ? colr : P.nBlk - 1;
-                    if constexpr (C::FMT == FMT_Q1T) xe_block_prep_nb<C::FMT, XS, NB, XLay<C>::seq_bytes>(R.w[d], R.st[d], R.ze[d], second ? qb_b : qb_a, xf + col, lane, qtab, o);
+                    if constexpr (C::PREP) xe_block_prep_nb<C::FMT, XS, NB, XLay<C>::seq_bytes>(R.w[d], R.st[d], R.ze[d], second ? qb_b : qb_a, xf + col, lane, qtab, o);
                     else xe_block_nb<XS, NB, XLay<C>::seq_bytes>(R.w[d], R.st[d], R.ze[d], second ? qb_b : qb_a, xf + col, lane, o);
 #pragma unroll
                     for (int b = 0; b < NB; b++) {
@@ -1435,6 +1440,14 @@ __global__ void __launch_bounds__(C::NWV * 64, (C::NWV * C::WPC + 3) / 4 /* wave
 #pragma unroll
             for (int p = 0; p < 4; p++) e[p] = 0x01000100u + 0x0202u * ((tid >> (7 - 2 * p)) & 1u) + 0x02020000u * ((tid >> (6 - 2 * p)) & 1u);
             reinterpret_cast<u32x4*>(smem + LY::o_tab)[tid] = u32x4{e[0], e[1], e[2], e[3]};
+        }
+    }
+    if constexpr (C::FMT == FMT_Q2T) { /* selector table of BlockDot<FMT_Q2T>: entry B, dword p = bytes {2q, 2q+1, 2q', 2q'+1}, q / q' = the levels of elements 2p, 2p+1 of byte B */
+        if (tid < 256) {
+            uint32_t e[2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) e[p] = 0x01000100u + 0x0202u * ((tid >> (6 - 4 * p)) & 3u) + 0x02020000u * ((tid >> (4 - 4 * p)) & 3u);
+            reinterpret_cast<u32x2*>(smem + LY::o_tab)[tid] = u32x2{e[0], e[1]};
         }
     }
     if (tid == 0) *L.cnt = 0;

@@ -96,14 +96,16 @@ def test_every_sequence_equals_the_oracle(canon, cfg_name, max_seq, n_steps, n_s
     m.close()
 
 
-@pytest.mark.parametrize("cfg_name,max_seq,n_steps,n_seq,check", [("tiny", 200, 150, 8, None), ("small", 320, 100, 16, (0, 5, 9, 14)), ("small", 320, 100, 32, (0, 7, 13, 18, 24, 31)), ("tiny", 200, 150, 27, None)])
-def test_one_bit_layers_every_sequence_equals_the_oracle(canon, cfg_name, max_seq, n_steps, n_seq, check):
+@pytest.mark.parametrize("layer_type,cfg_name,max_seq,n_steps,n_seq,check", [
+    (L.BOOL1, "tiny", 200, 150, 8, None), (L.BOOL1, "small", 320, 100, 16, (0, 5, 9, 14)), (L.BOOL1, "small", 320, 100, 32, (0, 7, 13, 18, 24, 31)), (L.BOOL1, "tiny", 200, 150, 27, None),
+    (L.T_SIGN, "tiny", 200, 150, 8, None), (L.T_SIGN, "small", 320, 100, 32, (0, 7, 13, 18, 24, 31)), (L.T_SIGN, "tiny", 200, 100, 11, None)])
+def test_one_bit_layers_every_sequence_equals_the_oracle(canon, layer_type, cfg_name, max_seq, n_steps, n_seq, check):
     """Round 6: the XCD-confined engines on 1-bit PackedQ layers (YinYang, groups of 128: BASELINE config 5's storage) -- a lane takes one dword of a 128-element block, the
     block's pair words come out of the LDS selector table once per decoder and every sequence takes its canonical chain pair over them; one, two and four sequences per
     decoder: ids at every position, the last logits and all K / V rows against the oracle run on the sequence alone."""
     cfg = dict(synth.CONFIGS[cfg_name], max_seq=max_seq)
     raw = synth.raw_weights_numpy(cfg, 2468, w_std=0.1)
-    m = synth.build_from_raw(cfg, raw, L.BOOL1, L.BF16)
+    m = synth.build_from_raw(cfg, raw, layer_type, L.BF16)   # (T_SIGN: 2-bit ternary, a lane takes one 8-byte half of a 64-element block)
     m.set_canonical(True)
     xr = XcdReplicas(m, n_seq)
     xr.set_steps_per_launch(13)
@@ -119,7 +121,7 @@ def test_one_bit_layers_every_sequence_equals_the_oracle(canon, cfg_name, max_se
     m.sync()
     xr.check()
     for s in (range(n_seq) if check is None else check):
-        o_ids, o_logits, ok, ov = _oracle_run(cfg, raw, forced[s], n_steps, layer_type=L.BOOL1)
+        o_ids, o_logits, ok, ov = _oracle_run(cfg, raw, forced[s], n_steps, layer_type=layer_type)
         g_ids = xr.tokens_out(s, n_steps).tolist()
         assert g_ids == o_ids, "sequence %d: first differing position %d" % (s, next(i for i, (a, b) in enumerate(zip(g_ids, o_ids)) if a != b))
         assert np.array_equal(xr.logits(s), o_logits), "sequence %d: logits" % s
@@ -389,7 +391,7 @@ def test_refusals():
     v_dot2c order"""
     cfg = dict(synth.CONFIGS["tiny"], max_seq=96)
     raw = synth.raw_weights_numpy(cfg, 1, w_std=0.1)
-    m = synth.build_from_raw(cfg, raw, L.T_SIGN, L.BF16)
+    m = synth.build_from_raw(cfg, raw, L.BF16, L.BF16)
     with pytest.raises(L.KFError) as e:
         XcdReplicas(m, 8)
     assert "4-bit" in str(e.value)
