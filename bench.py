@@ -1467,7 +1467,7 @@ def _xcd_short(x):
         return None
     if x.get("error") or x.get("skipped"):
         return {"error": str(x.get("error") or x.get("skipped"))[:120]}
-    o = _keep(x, ("streams", "batch", "decoders_per_xcd", "tokens_per_s", "ms_per_step_all_streams", "frac_vs_single_sequence_roofline", "hbm_frac_batch", "valu_insts_per_sequence_step", "traffic_per_sequence_step"))
+    o = _keep(x, ("streams", "batch", "tokens_per_s", "ms_per_step_all_streams", "frac_vs_single_sequence_roofline", "hbm_frac_batch", "valu_insts_per_sequence_step", "traffic_per_sequence_step"))
     p = x.get("parity") or {}
     v = p.get("sequence_0_ids_equal_single_sequence_engine") if p else None
     o["parity"] = None if v is None else bool(v)
@@ -1522,7 +1522,7 @@ def compact_line(out, detail=DETAIL_FILE):
         side["xcd_replicas"] = _xcd_short(x)
         for k in ("one_per_xcd", "two_per_xcd", "batched"):
             if isinstance(x.get(k), dict) and side["xcd_replicas"] is not None and "error" not in side["xcd_replicas"]:
-                side["xcd_replicas"][k] = _xcd_short(x[k])
+                side["xcd_replicas"][k] = _keep(_xcd_short(x[k]), ("streams", "batch", "tokens_per_s", "frac_vs_single_sequence_roofline", "hbm_frac_batch", "parity", "error"))
         if isinstance(x.get("prefill_then_decode"), dict) and "error" not in side["xcd_replicas"]:
             side["xcd_replicas"]["prompt_plus_32_tokens_per_s"] = x["prefill_then_decode"].get("prompt_plus_32_tokens_per_s")
     t = out.get("config3_train_step")

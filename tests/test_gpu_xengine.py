@@ -56,9 +56,9 @@ SLOW = pytest.mark.slow
 
 
 @pytest.mark.parametrize("cfg_name,max_seq,n_steps,n_seq,spl,form,check", [
-    ("tiny", 96, 90, 8, 7, 0, None), ("small", 320, 150, 8, 32, 0, None), ("tiny", 700, 300, 3, 16, 0, None), ("tiny", 700, 200, 11, 9, 0, None), ("tiny", 700, 130, 27, 9, 0, None),
+    ("tiny", 96, 90, 8, 7, 0, None), ("small", 320, 150, 8, 32, 0, (0, 2, 5, 7)), ("tiny", 700, 300, 3, 16, 0, None), ("tiny", 700, 200, 11, 9, 0, None), ("tiny", 700, 130, 27, 9, 0, (0, 4, 9, 13, 18, 22, 26)),
     ("small", 320, 150, 16, 32, 0, (0, 3, 6, 9, 12, 15)), ("small", 320, 150, 32, 32, 0, (0, 5, 10, 15, 17, 20, 27, 30)), ("tiny", 700, 130, 11, 9, 1, None),
-    pytest.param("small", 320, 150, 16, 32, 0, None, marks=SLOW), pytest.param("small", 320, 150, 32, 32, 0, None, marks=SLOW), pytest.param("small", 320, 150, 16, 32, 1, None, marks=SLOW)])
+    pytest.param("small", 320, 150, 8, 32, 0, None, marks=SLOW), pytest.param("tiny", 700, 130, 27, 9, 0, None, marks=SLOW), pytest.param("small", 320, 150, 16, 32, 0, None, marks=SLOW), pytest.param("small", 320, 150, 32, 32, 0, None, marks=SLOW), pytest.param("small", 320, 150, 16, 32, 1, None, marks=SLOW)])
 def test_every_sequence_equals_the_oracle(canon, cfg_name, max_seq, n_steps, n_seq, spl, form, check):
     """different prompts per sequence (the first 12 .. 40 ids forced, then free running), several steps per launch: ids at every position, the last logits and all K / V rows
     of every sequence against the oracle run on that sequence alone; n_seq < 8 leaves XCDs idle; n_seq > 8 (round 6): every decoder multiplies each unpacked block against 2
@@ -97,7 +97,7 @@ def test_every_sequence_equals_the_oracle(canon, cfg_name, max_seq, n_steps, n_s
 
 
 @pytest.mark.parametrize("layer_type,cfg_name,max_seq,n_steps,n_seq,check", [
-    (L.BOOL1, "tiny", 200, 150, 8, None), (L.BOOL1, "small", 320, 100, 16, (0, 5, 9, 14)), (L.BOOL1, "small", 320, 100, 32, (0, 7, 13, 18, 24, 31)), (L.BOOL1, "tiny", 200, 150, 27, None),
+    (L.BOOL1, "tiny", 200, 150, 8, None), (L.BOOL1, "small", 320, 100, 16, (0, 5, 9, 14)), (L.BOOL1, "small", 320, 100, 32, (0, 7, 13, 18, 24, 31)), (L.BOOL1, "tiny", 200, 150, 27, (1, 6, 10, 15, 19, 24)),
     (L.T_SIGN, "tiny", 200, 150, 8, None), (L.T_SIGN, "small", 320, 100, 32, (0, 7, 13, 18, 24, 31)), (L.T_SIGN, "tiny", 200, 100, 11, None)])
 def test_one_bit_layers_every_sequence_equals_the_oracle(canon, layer_type, cfg_name, max_seq, n_steps, n_seq, check):
     """Round 6: the XCD-confined engines on 1-bit PackedQ layers (YinYang, groups of 128: BASELINE config 5's storage) -- a lane takes one dword of a 128-element block, the
@@ -454,7 +454,7 @@ def test_qwen3_1p7b_shape_equals_the_oracle(canon, n_seq):
 
 
 
-@pytest.mark.parametrize("name,variant", [("qwen3-4b", None), ("qwen3-8b", None), ("qwen3-4b", (8, 8))])
+@pytest.mark.parametrize("name,variant", [("qwen3-4b", None), ("qwen3-8b", None), pytest.param("qwen3-4b", (8, 8), marks=SLOW)])
 def test_gqa4_shapes_equal_the_per_layer_launches_and_the_oracle(canon, name, variant):
     """three layers of the Qwen3-4B / Qwen3-8B shapes (32 query heads on 8 kv-heads: four query heads per key tile; 24 of the 32 workgroups own q | k | v rows; the 9728- /
     12288-wide SwiGLU vector staged in pieces; 8B: the attention sums inside the second activation buffer) through the XCD-confined engines: eight sequences, ids at every
