@@ -498,7 +498,7 @@ int kf_xengine_set_embedding(kf_ctx* ctx, kf_xengine* e, const kf_weight* embed_
 int kf_xengine_set_head(kf_ctx* ctx, kf_xengine* e, const kf_weight* head_bf16_or_null, const kf_bf16* final_norm_w, kf_bf16* logits, int32_t* d_tokens_out_or_null, int tokens_stride);
 /* n_steps greedy decode steps of EVERY sequence in one launch (Fish::ForwardOnRLS + Head4Token::cuInfer_1 + sample_argmax per sequence and step): d_state [n_seq][4] is
  * read and advanced per step, x_out [n_seq][dim] holds the last step's residual stream.  pick = 0 (n_steps = 1 only): logits without the pick, the state stays. */
-int kf_xengine_steps(kf_ctx* ctx, kf_xengine* e, kf_bf16* x_out, int32_t* d_state, int n_steps, int pick);
+int kf_xengine_steps(kf_ctx* ctx, kf_xengine* e, kf_bf16* x_out, int32_t* d_state, int n_steps, int pick); /* (launched directly: refused inside kf_graph_begin / _end) */
 int kf_xengine_check(kf_ctx* ctx, kf_xengine* e); /* synchronises; KF_INTERNAL_ERR when a hand-off poll has timed out since creation or the last kf_xengine_reset */
 int kf_xengine_reset(kf_ctx* ctx, kf_xengine* e);
 int kf_xengine_destroy(kf_xengine* e);

@@ -1274,7 +1274,9 @@ int kf_xengine_steps(kf_ctx* c, kf_xengine* e, kf_bf16* x_out, int32_t* d_state,
     if (!e || !e->h) return fail(KF_INVALID_ARGS, "kf_xengine_steps: null engine");
     if (!c->canonical) return fail(KF_UNSUPPORTED_DATATYPE, "kf_xengine_steps: the XCD-confined engines run the canonical summation order only (kf_set_canonical(ctx, 1))");
     if (n_steps < 1 || (n_steps > 1 && !pick)) return fail(KF_INVALID_ARGS, "kf_xengine_steps: n_steps %d (several steps per launch need the pick inside)", n_steps);
+    if (c->capturing) return fail(KF_INVALID_ARGS, "kf_xengine_steps: not while capturing (the launch's generation is a kernel argument the host counts: a replayed launch would repeat it)");
     const int rc = kf::xengine_steps(e->h, c->stream, d_state, x_out, pick ? 2 : 1, n_steps);
+    if (rc == KF_UNSUPPORTED_DATATYPE) return fail(rc, "kf_xengine_steps: the form for this many sequences does not fit the LDS at this depth");
     if (rc != KF_OK) return fail(rc, "kf_xengine_steps failed with %d (no embedding / head set?)", rc);
     return KF_OK;
 }
