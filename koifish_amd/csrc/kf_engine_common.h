@@ -12,6 +12,9 @@ namespace kf {
 
 constexpr int ENG_MAXLD = 24;             /* 1 KiB granule pieces (256 values) per sweep: vectors up to 6144 (Qwen3-1.7B's ffn) */
 constexpr int ENG_NWG = 256, ENG_NWV = 8; /* MI355X: 256 CUs, one 8-wave workgroup each (7 compute waves + the poller) */
+#ifndef KF_SWEEP_SLEEP
+#define KF_SWEEP_SLEEP 1 /* s_sleep units between two sweeps of a hand-off vector that was not whole yet */
+#endif
 constexpr int ENG_SPIN_MAX = 1 << 17;     /* sweeps before a poll gives up (~0.1 s): sets the error word, never hangs */
 
 // device tables hold GLOBAL pointers (address space 1): read back from LDS they would otherwise be generic, and every access through them a
@@ -131,7 +134,7 @@ __device__ __forceinline__ void eng_poll_stage(const uint32_t* gsrc, const uint1
                 dead = true;
                 break;
             }
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(KF_SWEEP_SLEEP);
         }
 #pragma unroll
         for (int r = 0; r < NLD; r++) p0[r] = (g[r].x & 0xffffu) | (g[r].y << 16), p1[r] = (g[r].z & 0xffffu) | (g[r].w << 16);
@@ -190,7 +193,7 @@ __device__ __forceinline__ void eng_poll_stage_long(const uint32_t* gsrc, uint32
                 dead = true;
                 break;
             }
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(KF_SWEEP_SLEEP);
         }
 #pragma unroll
         for (int r = 0; r < NP; r++) {
@@ -232,7 +235,7 @@ __device__ __forceinline__ void eng_norm_long_pass1(const uint32_t* gsrc, const 
                     dead = true;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(KF_SWEEP_SLEEP);
             }
 #pragma unroll
             for (int r = 0; r < NP; r++) p0[r] = (g[r].x & 0xffffu) | (g[r].y << 16), p1[r] = (g[r].z & 0xffffu) | (g[r].w << 16);

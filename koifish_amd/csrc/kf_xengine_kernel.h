@@ -589,7 +589,7 @@ __device__ __forceinline__ void xe_tp_reduce(const XArgs& a, const XSeq& S, int 
             dead = true;
             break;
         }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(KF_SWEEP_SLEEP);
     }
 #pragma unroll
     for (int k = 0; k < NK; k++) {
@@ -769,7 +769,7 @@ __device__ __forceinline__ void xe_coop_norm_stage(const XArgs& a, const XLds& L
             dead = true;
             break;
         }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(KF_SWEEP_SLEEP);
     }
     if (dead_io) *dead_io = dead;
     uint32_t p0[NR], p1[NR];
@@ -824,7 +824,7 @@ __device__ __forceinline__ void xe_ho_x(const XArgs& a, const XLds& Lb, const XS
                     dead = true;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(KF_SWEEP_SLEEP);
             }
         }
         if (a.d_forced) {
@@ -867,7 +867,7 @@ __device__ __forceinline__ void xe_ho_qkv(const XArgs& a, const XLds& Lb, const 
             dead = true;
             break;
         }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(KF_SWEEP_SLEEP);
     }
 #pragma unroll
     for (int r = 0; r < NLQ; r++) {
@@ -904,7 +904,7 @@ __device__ __forceinline__ void xe_ho_merge(const XArgs& a, const XLds& Lb, cons
             dead = true;
             break;
         }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(KF_SWEEP_SLEEP);
     }
 #pragma unroll
     for (int r = 0; r < NLM; r++) { /* value index vi = sp * ME + e */
@@ -1342,7 +1342,7 @@ __device__ __forceinline__ void xe_head_main(const XArgs& a, const XLds& L, cons
                     ok = true;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(KF_SWEEP_SLEEP);
             }
             float bv = -__builtin_inff();
             int bi = 0x7fffffff;
@@ -1380,7 +1380,7 @@ __device__ __forceinline__ void xe_head_main(const XArgs& a, const XLds& L, cons
                         ok2 = true;
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(KF_SWEEP_SLEEP);
                 }
                 ok = ok && ok2;
                 bv = src ? bf2f((uint16_t)(gb.y & 0xffffu)) : -__builtin_inff(), bi = src ? (int)gb.x : 0x7fffffff;
