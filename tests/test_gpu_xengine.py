@@ -178,7 +178,8 @@ def test_sparse_forward_every_sequence_equals_the_oracle(canon, layer_type, n_se
     m.close()
 
 
-def test_sequences_at_different_positions(canon):
+@pytest.mark.parametrize("n_seq", [8, 32])
+def test_sequences_at_different_positions(canon, n_seq):
     """the sequences of one launch need not be in step: all eight are first decoded from position 0 (so that every cache holds its sequence's history), then each is put back
     to a start of its own -- 0, 5, 63, 64, 65, 130, 257, 300: on both sides of the 64-key slice boundaries -- and all advance together; the slices of a sequence's attention
     follow ITS position, and the rows past a start are rewritten with the same values"""
@@ -186,15 +187,17 @@ def test_sequences_at_different_positions(canon):
     raw = synth.raw_weights_numpy(cfg, 99, w_std=0.1)
     m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
     m.set_canonical(True)
-    n_seq, together = 8, 40
-    starts = [0, 5, 63, 64, 65, 130, 257, 300]
+    together = 40   # (n_seq 32: the four sequences of a decoder stand at four different positions -- their slices, RoPE pairs and cache rows are their own)
+    starts = [0, 5, 63, 64, 65, 130, 257, 300] if n_seq == 8 else [(37 * s + 11 * (s // 8)) % 301 for s in range(32)]
+    starts[:4] = [0, 5, 63, 64]
+    checked = set(range(8)) if n_seq == 8 else {0, 1, 2, 3, 9, 12, 17, 22, 26, 31}   # (the 32-sequence run: a spread over the XCDs and over a decoder's four places)
     xr = XcdReplicas(m, n_seq)
     forced, o = [], []
     for s in range(n_seq):
         f = np.full(400, -1, dtype=np.int32)
         f[:starts[s] + 3] = prompt_ids(cfg, starts[s] + 3, seed=7 + s)
         forced.append(f)
-        o.append(_oracle_run(cfg, raw, f, together, pos0=starts[s]))
+        o.append(_oracle_run(cfg, raw, f, together, pos0=starts[s]) if s in checked else None)
         xr.set_forced(s, f)
         xr.set_state(s, int(f[0]), 0)
     xr.run_steps(max(starts))
@@ -204,7 +207,7 @@ def test_sequences_at_different_positions(canon):
     xr.run_steps(together)
     m.sync()
     xr.check()
-    for s in range(n_seq):
+    for s in sorted(checked):
         o_ids, o_logits, ok, ov = o[s]
         n = starts[s] + together
         assert xr.state(s)[1] == n
