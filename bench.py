@@ -322,7 +322,7 @@ def main():
         _lap("long prompt + cpu fp16")
         if args.config == "qwen3-0.6b" and args.layers == "q4" and args.sparse == 0.0 and args.xcd_replicas > 0:
             try:   # eight independent decoders, one per XCD, sharing this model's weights (kf_xengine_*): the aggregate beside the single-sequence `value`
-                out["xcd_replicas"] = xcd_replicas(m, cfg, forced, timed_positions, W, args.xcd_replicas, ids_timed_run)
+                out["xcd_replicas"] = xcd_replicas(m, cfg, forced, timed_positions, W, args.xcd_replicas, ids_timed_run, queue=True)
                 keys = ("streams", "batch", "decoders_per_xcd", "tokens_per_s", "per_stream_tokens_per_s", "ms_per_step_all_streams", "frac_vs_single_sequence_roofline", "hbm_frac_batch", "parity", "skipped")
                 if args.xcd_replicas > 16 and "error" not in out["xcd_replicas"]:   # two sequences per decoder beside the four
                     e16 = xcd_replicas(m, cfg, forced, timed_positions, W, 16, ids_timed_run)
@@ -891,7 +891,7 @@ def concurrent_streams(cfg, layer_type, head_type, dev, S, forced, n_prompt, mea
             "note": "independent decoders, separate weight copies and HIP streams, positions %d..%d each" % (n_prompt, S_len - 1)}
 
 
-def xcd_replicas(m, cfg, forced, timed_positions, warmup, n_seq, ids_main, jump=False):
+def xcd_replicas(m, cfg, forced, timed_positions, warmup, n_seq, ids_main, jump=False, queue=False):
     """The chip's aggregate rate on INDEPENDENT sequences (never `value`, which stays the single-sequence rate): n_seq decoders inside one launch, one per XCD (32 workgroups
     each, every hand-off in that XCD's L2: koifish_amd/csrc/kf_xengine.hip), sharing this model's weights; own K / V cache, state, prompt and logits per sequence.  The
     reference decodes one sequence per process (GoPT.cpp:1139-1180) and scales a small model with more processes -- these are the processes, moved inside the package.
@@ -971,6 +971,24 @@ def xcd_replicas(m, cfg, forced, timed_positions, warmup, n_seq, ids_main, jump=
                           "parity": "tests/test_gpu_xengine.py::test_prefill_then_decode_per_sequence (rows, ids, logits == the model alone doing prefill + decode)"}
         except Exception as e:
             prompt_leg = {"error": repr(e)[:200]}
+        chat_leg = None
+        try:   # (the primary leg only) a queue of requests through the slots (XcdReplicas.chat: Fish::Chat's rounds over a prompt list, n_seq in flight): 3 x n_seq requests, 128-token prompt, 128 new ids each
+            if not queue:
+                raise KeyError("not asked for")
+            n_req, rng_q = 3 * n_seq, np.random.default_rng(31)
+            prompts_q = [rng_q.integers(0, cfg["vocab"], size=128).astype(np.int32) for _ in range(n_req)]
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ans, qst = xr.chat(prompts_q, 128)
+            t2 = time.perf_counter()
+            chat_leg = {"requests": n_req, "prompt_tokens": 128, "new_tokens": 128, "seconds": round(t2 - t1, 4), "requests_per_s": round(n_req / (t2 - t1), 1),
+                        "generated_tokens_per_s": round(sum(len(a) for a in ans) / (t2 - t1), 1), "launches": qst["launches"], "prefills": qst["prefills"],
+                        "note": "prefill of every request included; positions 128..255 (short context: a step moves fewer K / V rows than at the 2 k window the headline is quoted on)",
+                        "parity": "tests/test_gpu_xengine.py::test_a_queue_of_prompts_through_the_slots (every answer == the model alone on that prompt; EOS cut)"}
+        except KeyError:
+            chat_leg = None
+        except Exception as e:
+            chat_leg = {"error": repr(e)[:200]}
         # two readings, neither of them `roofline.frac`: (1) aggregate tokens/s against the rate ONE sequence's algorithmic bytes allow at the HBM peak (what north_star's 0.70 is quoted
         # on: 0.70 <-> 7.2 k tokens/s here); (2) HBM utilisation in BATCH-AWARE bytes -- the decoders share the layer weights and the head (counted once per step of all
         # sequences), each adds only its own K / V rows and vectors
@@ -986,7 +1004,7 @@ def xcd_replicas(m, cfg, forced, timed_positions, warmup, n_seq, ids_main, jump=
                 "aggregate_of_independent_sequences": True,
                 "note": "frac_vs_single_sequence_roofline = ONE sequence's algorithmic bytes x aggregate tokens/s / 8 TB/s: a RATE ratio, not HBM utilisation (the decoders share the weights and the "
                         "head: L2 / memory-side-cache traffic); hbm_frac_batch counts the shared bytes once per step of all sequences; never `value`",
-                "traffic_per_sequence_step": traffic, "traffic_source": traffic_src, "valu_insts_per_sequence_step": valu, "prefill_then_decode": prompt_leg,
+                "traffic_per_sequence_step": traffic, "traffic_source": traffic_src, "valu_insts_per_sequence_step": valu, "prefill_then_decode": prompt_leg, "request_queue": chat_leg,
                 "summation_order": "canonical (the only order the XCD-confined engines run)", "kernel": "kf::xengine_kernel (koifish_amd/csrc/kf_xengine.hip)",
                 "parity": {"sequence_0_ids_equal_single_sequence_engine": same, "positions_compared": int(S), "distinct_continuations": distinct,
                            "per_sequence_oracle_parity": "tests/test_gpu_xengine.py (ids, logits, K / V rows of every sequence, bit for bit)"}}
@@ -1471,6 +1489,9 @@ def _xcd_short(x):
     p = x.get("parity") or {}
     v = p.get("sequence_0_ids_equal_single_sequence_engine") if p else None
     o["parity"] = None if v is None else bool(v)
+    q = x.get("request_queue")
+    if isinstance(q, dict) and "generated_tokens_per_s" in q:
+        o["request_queue"] = _keep(q, ("requests", "prompt_tokens", "new_tokens", "requests_per_s", "generated_tokens_per_s"))
     return o
 
 

@@ -955,6 +955,76 @@ int XcdReplicas::RunSteps(int n) {
     }
     return KF_OK;
 }
+// A queue of prompts answered through the sequences' slots: what Fish::Chat does round by round over DEBUG.prompts (GoPT.cpp:1111-1180: prefill the prompt, then sample
+// until the tokenizer's EOS or the context is full, then the next prompt), with n_seq rounds in flight at once.  A free slot takes the next prompt (Prefill), the launches
+// decode every occupied slot, a finished round's slot is parked until the queue refills it; an answer ends at `eos` (eos < 0: never), at max_new ids, or at the last cache
+// row.  out [n_req][max_new] (-1 behind an answer's end), out_len [n_req]; every answer equals Fish::Generate's on the same prompt (same prefill, same decode arithmetic).
+// With eos >= 0 the ids of each launch are read back (one sync per launch) and a sequence may run up to steps_per_launch - 1 ids past its EOS before its slot is freed --
+// those ids are dropped; stats [4] = {launches, steps, prefills, sequence-steps decoded and dropped}.
+int XcdReplicas::Chat(const int32_t* prompts, const int32_t* prompt_len, int n_req, int stride, int max_new, int eos, int32_t* out, int32_t* out_len, long long* stats) {
+    const MODEL_CARD& c = hFish->config;
+    if (!prompts || !prompt_len || !out || !out_len || n_req < 1 || stride < 1 || max_new < 1) return KF_INVALID_ARGS;
+    for (int r = 0; r < n_req; r++)
+        if (prompt_len[r] < 1 || prompt_len[r] > stride || prompt_len[r] >= c.n_ctx) return KF_INVALID_ARGS;
+    kf_ctx* ctx = hFish->ctx;
+    KF_TRY(Fresh());
+    struct Slot { int req = -1, len = 0, want = 0, have = 0; };
+    std::vector<Slot> slot(n_seq);
+    std::vector<int32_t> row(c.n_ctx), none(c.n_ctx, -1);
+    long long st[4] = {0, 0, 0, 0};
+    int next = 0, done = 0;
+    for (int s = 0; s < n_seq; s++) KF_TRY(Park(s, true));
+    auto finish = [&](int s, int n_ids) -> int {  // the slot's answer out, the slot parked
+        Slot& q = slot[s];
+        KF_TRY(kf_d2h(ctx, row.data(), d_tokens_out + (size_t)s * c.n_ctx, (size_t)(q.len - 1 + q.have) * 4));
+        for (int i = 0; i < max_new; i++) out[(size_t)q.req * max_new + i] = i < n_ids ? row[q.len - 1 + i] : -1;
+        out_len[q.req] = n_ids;
+        st[3] += q.have - n_ids;
+        q.req = -1, done++;
+        return Park(s, true);
+    };
+    while (done < n_req) {
+        for (int s = 0; s < n_seq && next < n_req; s++) {
+            Slot& q = slot[s];
+            if (q.req >= 0) continue;
+            q.req = next++, q.len = prompt_len[q.req], q.have = 1;  // the prefill picks the answer's first id
+            const int room = c.n_ctx - q.len;                       // the ids the cache has rows for: the id behind row p needs row p
+            q.want = max_new < room + 1 ? max_new : room + 1;
+            KF_TRY(kf_h2d(ctx, d_forced + (size_t)s * c.n_ctx, none.data(), (size_t)c.n_ctx * 4));
+            KF_TRY(Prefill(s, prompts + (size_t)q.req * stride, q.len));
+            st[2]++;
+            if (eos >= 0) {
+                int32_t first;
+                KF_TRY(kf_d2h(ctx, &first, d_tokens_out + (size_t)s * c.n_ctx + (q.len - 1), 4));
+                if (first == eos) q.want = 1;
+            }
+            if (q.have >= q.want) { KF_TRY(finish(s, q.want)); s--; continue; }  // a one-id answer: the slot takes the next prompt at once
+            KF_TRY(Park(s, false));
+        }
+        int k = steps_per_launch, active = 0;
+        for (int s = 0; s < n_seq; s++)
+            if (slot[s].req >= 0) active++, k = slot[s].want - slot[s].have < k ? slot[s].want - slot[s].have : k;
+        if (!active) continue;
+        KF_TRY(kf_xengine_steps(ctx, engine, ToX(x), d_state, k, 1));
+        st[0]++, st[1] += k, steps_run += k;
+        for (int s = 0; s < n_seq; s++) {
+            Slot& q = slot[s];
+            if (q.req < 0) continue;
+            const int had = q.have;
+            q.have += k;
+            int n_ids = q.have >= q.want ? q.want : -1;
+            if (eos >= 0) {
+                KF_TRY(kf_d2h(ctx, row.data(), d_tokens_out + (size_t)s * c.n_ctx + (q.len - 1 + had), (size_t)k * 4));
+                for (int i = 0; i < k; i++)
+                    if (row[i] == eos) { n_ids = had + i + 1; break; }
+            }
+            if (n_ids >= 0) KF_TRY(finish(s, n_ids));
+        }
+    }
+    for (int s = 0; s < n_seq; s++) KF_TRY(Park(s, false));
+    if (stats) for (int i = 0; i < 4; i++) stats[i] = st[i];
+    return Check();
+}
 int XcdReplicas::Check() {
     if (!engine) return KF_OK;
     const int rc = kf_xengine_check(hFish->ctx, engine);
@@ -1486,6 +1556,9 @@ int kfh_xr_prefill(void* h, int seq, const int* tokens, int n) { return reinterp
 int kfh_xr_run_steps(void* h, int n) { return reinterpret_cast<XcdReplicas*>(h)->RunSteps(n); }
 int kfh_xr_check(void* h) { return reinterpret_cast<XcdReplicas*>(h)->Check(); }
 int kfh_xr_park(void* h, int seq, int on) { return reinterpret_cast<XcdReplicas*>(h)->Park(seq, on != 0); }
+int kfh_xr_chat(void* h, const int32_t* prompts, const int32_t* prompt_len, int n_req, int stride, int max_new, int eos, int32_t* out, int32_t* out_len, long long* stats) {
+    return reinterpret_cast<XcdReplicas*>(h)->Chat(prompts, prompt_len, n_req, stride, max_new, eos, out, out_len, stats);
+}
 int kfh_xr_status(void* h, int seq, int32_t* out4) { return reinterpret_cast<XcdReplicas*>(h)->Status(seq, out4); }
 int kfh_xr_set_steps_per_launch(void* h, int n) {
     if (n < 1 || n > 4096) return KF_INVALID_ARGS;

@@ -310,6 +310,8 @@ struct XcdReplicas {
     int SetState(int seq, int token, int pos);
     int Prefill(int seq, const int* tokens, int n);  // the sequence's prompt through Fish::Prefill (token batches on the tile kernels), its K / V rows into the sequence's cache; the sequence then stands behind the prompt
     int RunSteps(int n);  // n greedy steps of EVERY sequence from wherever each stands; no host sync
+    // a queue of prompts answered through the slots (Fish::Chat's rounds over DEBUG.prompts, GoPT.cpp:1111-1180, n_seq at once); see kf_host.cpp
+    int Chat(const int32_t* prompts, const int32_t* prompt_len, int n_req, int stride, int max_new, int eos, int32_t* out, int32_t* out_len, long long* stats);
     int Check();          // synchronises; a timed-out hand-off is reported once (KF_INTERNAL_ERR) and the engine reset
     size_t kv_seq_elems() const;
 };

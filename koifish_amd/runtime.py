@@ -665,6 +665,23 @@ class XcdReplicas:
         """a parked sequence is skipped by the launches; the others decode on"""
         L.check(self.host.kfh_xr_park(self.h, int(seq), int(bool(on))), "kfh_xr_park")
 
+    def chat(self, prompts, max_new, eos=-1):
+        """a queue of prompts answered through the sequences' slots (Fish::Chat's rounds over its prompt list, GoPT.cpp:1111-1180, n_seq rounds in flight): a free slot
+        prefills the next prompt, the launches decode every occupied slot, an answer ends at `eos`, at max_new ids or at the last cache row.
+        Returns (list of id lists in the prompts' order, {launches, steps, prefills, dropped})."""
+        n = len(prompts)
+        lens = np.array([len(p) for p in prompts], dtype=np.int32)
+        stride = int(lens.max())
+        flat = np.zeros((n, stride), dtype=np.int32)
+        for i, p in enumerate(prompts):
+            flat[i, :len(p)] = p
+        out = np.zeros((n, int(max_new)), dtype=np.int32)
+        out_len = np.zeros(n, dtype=np.int32)
+        stats = np.zeros(4, dtype=np.int64)
+        L.check(self.host.kfh_xr_chat(self.h, flat.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), n, stride, int(max_new), int(eos),
+                                      out.ctypes.data_as(C.c_void_p), out_len.ctypes.data_as(C.c_void_p), stats.ctypes.data_as(C.c_void_p)), "kfh_xr_chat")
+        return [out[i, :out_len[i]].tolist() for i in range(n)], dict(zip(("launches", "steps", "prefills", "dropped"), (int(v) for v in stats)))
+
     def status(self, seq):
         """{token, pos, parked, status} of the sequence (status 64: the last launch would have left its cache rows and skipped it)"""
         out = np.zeros(4, dtype=np.int32)

@@ -565,3 +565,41 @@ def test_prefill_then_decode_per_sequence(canon):
         assert np.array_equal(gk[:, :P + n_new], rk[:, :P + n_new]) and np.array_equal(gv[:, :P + n_new], rv[:, :P + n_new])
     xr.close()
     m.close()
+
+
+@pytest.mark.parametrize("n_seq,n_req", [(8, 21), (32, 45)])
+def test_a_queue_of_prompts_through_the_slots(canon, n_seq, n_req):
+    """XcdReplicas.chat: Fish::Chat's rounds over a prompt list (GoPT.cpp:1111-1180) with n_seq rounds in flight -- ragged prompts (2 ... 40 tokens, one standing five rows
+    before the cache's end), a free slot refilled from the queue while the others decode on.  Every answer equals the model ALONE generating on that prompt (same batched
+    prefill, the single-sequence decode); with an EOS id the answers are those cut behind their first EOS, and the ids a sequence decoded past it are dropped."""
+    cfg = dict(synth.CONFIGS["small"], max_seq=96)
+    raw = synth.raw_weights_numpy(cfg, 4242, w_std=0.1)
+    m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
+    m.set_canonical(True)
+    rng = np.random.default_rng(5)
+    prompts = [prompt_ids(cfg, int(rng.integers(2, 41)), seed=300 + r) for r in range(n_req)]
+    prompts[3] = prompt_ids(cfg, cfg["max_seq"] - 5, seed=77)   # room for 5 rows behind the prompt: 6 ids
+    max_new = 12
+    m.set_prefill_mode(1)   # the batched prefill XcdReplicas.prefill uses
+    ref = []
+    for p in prompts:
+        ref.append(m.generate(p, min(max_new, cfg["max_seq"] - len(p) + 1), use_graph=False))
+    assert len(ref[3]) == 6
+    xr = XcdReplicas(m, n_seq)
+    xr.set_steps_per_launch(5)
+    got, st = xr.chat(prompts, max_new)
+    assert got == ref
+    assert st["prefills"] == n_req and st["dropped"] == 0 and st["launches"] >= 3
+    # an EOS id: the most frequent id behind the answers' second position
+    ids, cnt = np.unique(np.concatenate([np.array(a[2:]) for a in ref]), return_counts=True)
+    eos = int(ids[cnt.argmax()])
+    cut = [a[:a.index(eos) + 1] if eos in a else a for a in ref]
+    assert any(len(c) < len(a) for c, a in zip(cut, ref))
+    got, st = xr.chat(prompts, max_new, eos=eos)
+    assert got == cut
+    assert st["prefills"] == n_req
+    # the object is as before the queue: all slots free running
+    for s in range(n_seq):
+        assert xr.status(s)[2] == 0
+    xr.close()
+    m.close()
