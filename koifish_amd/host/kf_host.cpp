@@ -932,13 +932,14 @@ int XcdReplicas::Prefill(int seq, const int* tokens, int n) {
     if (seq < 0 || seq >= n_seq || !tokens || n < 1 || n >= c.n_ctx) return KF_INVALID_ARGS;
     kf_ctx* ctx = hFish->ctx;
     KF_TRY(Fresh());
-    KF_TRY(hFish->Prefill(tokens, n, 0));
-    const int kvd = c.n_head_kv * c.head_dim;
-    const size_t seq_elems = kv_seq_elems();
-    for (int l = 0; l < c.nLayer; l++) {
-        const size_t off = (size_t)seq * seq_elems + (size_t)l * c.n_ctx * kvd;
-        KF_TRY(kf_d2d(ctx, ToX(key) + off, hFish->cache.Get(KVCache::KV_KEY, l, 0), (size_t)n * kvd * 2));
-        KF_TRY(kf_d2d(ctx, ToX(val) + off, hFish->cache.Get(KVCache::KV_VAL, l, 0), (size_t)n * kvd * 2));
+    {   /* the sequence's cache has the model's own layout ([layer][row][kv_dim]): for the length of the call the model's cache IS the sequence's, the rows land where they stay */
+        struct Aim {
+            KVCache& kc;
+            void *k0, *v0;
+            Aim(KVCache& c_, void* k, void* v) : kc(c_), k0(c_.key->data), v0(c_.val->data) { kc.key->data = k, kc.val->data = v; }
+            ~Aim() { kc.key->data = k0, kc.val->data = v0; }
+        } aim(hFish->cache, ToX(key) + (size_t)seq * kv_seq_elems(), ToX(val) + (size_t)seq * kv_seq_elems());
+        KF_TRY(hFish->Prefill(tokens, n, 0));
     }
     KF_TRY(kf_d2d(ctx, d_state + 4 * seq, hFish->d_state, 8));                                                   /* {the id picked behind the prompt, n} */
     KF_TRY(kf_memset(ctx, d_state + 4 * seq + 3, 0, 4));                                                         /* status: clear */
