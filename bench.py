@@ -505,7 +505,8 @@ def config3_train_step():
     tests/test_gpu_train_step.py::test_gpt2_two_consecutive_steps_with_update checks against the oracle at toy size): n_embd 1600, 48 layers, 25 heads, ffn 6400, vocab 50257
     padded to 50304; attention matrices f8e5m2, MLP matrices RTN 4-bit, tied bf16 wte; batch 8 x 1024 random ids.  forward (every activation kept) + fused classifier loss ->
     backward through every operator into PER-TENSOR gradient buffers -> kf_adamw on the model's own bf16 masters and moments (seeded stochastic rounding) -> kf_quantize of every
-    matrix back into the blob the next forward reads.  The embedding gather / add, one q copy and the zero fills are torch ops; everything else is this library's kernels.
+    matrix back into the blob the next forward reads.  The step is sequenced by the host library (koifish::GPT2Trainer, koifish_amd/host/kf_train.cpp): the timed region holds
+    three C calls per step and no torch op (embedding gather + add = kf_embed_pos, q read out of the fused rows, zero fills = kf_memset / kf_memset2d).
     Synthetic data and weights: not comparable one-to-one with the reference's end-to-end training throughput (48.8 k tokens/s on an RTX 4090,
     cases/gpt2/1558M_F8_B80/F8_B80.info:2928-2951: a real run with a data loader); it says what the step's kernel path sustains."""
     import torch
@@ -577,7 +578,8 @@ def config3_train_step():
     flops = 3.0 * fwd
     return {"workload": "GPT2-1558M (48 layers, n_embd 1600, 25 heads, ffn 6400, vocab 50257), hybrid f8e5m2 / 4-bit blocks, tied bf16 head, 8 x 1024 random tokens, every activation kept: "
                         "ONE timed region per step -- forward + loss, backward into per-tensor gradient buffers, AdamW on the model's own bf16 masters and moments, re-quantisation of "
-                        "every matrix into the blob the next forward reads; embedding gather / add and zero fills are torch ops",
+                        "every matrix into the blob the next forward reads; sequenced in C++ (koifish::GPT2Trainer in libkf_host.so): no torch op in the timed region",
+            "host_loop": "C++ (libkf_host.so: kfh_gpt2_forward / _backward / _update; kfh_gpt2_step is the three in one call)",
             "params_updated": moved, "one_timed_region": True, "parameters": int(n_par), "steps_timed": reps,
             "ms": round(ms, 2), "tokens_per_s": round(N / ms * 1e3, 1), "forward_loss_ms": round(t_f, 2), "backward_ms": round(t_b, 2), "adamw_requantise_ms": round(t_a, 2),
             "loss_after_1_and_%d_steps_on_one_batch" % (1 + reps): [round(v, 4) for v in loss_hist],

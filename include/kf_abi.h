@@ -301,6 +301,11 @@ int kf_qknorm_rope_train(kf_ctx* ctx, kf_bf16* q, kf_bf16* k, const kf_bf16* wq_
 int kf_attn_prefill_batch(kf_ctx* ctx, const kf_bf16* q, const kf_bf16* k, const kf_bf16* v, kf_bf16* out, int n_tok, int64_t q_stride, int n_head, int n_kv, int head_dim,
                           int kv_stride, int n_seq);
 
+/* the same with a row stride of its own for out: a training step reads q out of the fused [rows, 3C] buffer (q_stride 3C) and writes a dense [rows, C] out (out_stride C),
+ * which saves the copy of the q columns (GPT-2's c_attn output: QKV.cu's fused qkv, /root/reference/src/Device/CUDA/QKV.cu) */
+int kf_attn_prefill_batch_strided(kf_ctx* ctx, const kf_bf16* q, const kf_bf16* k, const kf_bf16* v, kf_bf16* out, int n_tok, int64_t q_stride, int64_t out_stride, int n_head,
+                                  int n_kv, int head_dim, int kv_stride, int n_seq);
+
 /* Causal attention backward for n_seq sequences of T tokens each, stored back to back in every tensor (the training path's SDPA backward:
  * cudnn-frontend in the reference, QKV.cu:130-315, 427-447).  q: rows of n_head * head_dim, k / v: rows of n_kv * head_dim (GQA: n_head a multiple of
  * n_kv), all with row stride ld_qkv (e.g. the column blocks of a fused q|k|v buffer); o (the forward output) and dO: n_head * head_dim with stride ld_o;
@@ -310,6 +315,12 @@ int kf_attn_prefill_batch(kf_ctx* ctx, const kf_bf16* q, const kf_bf16* k, const
 size_t kf_attn_backward_scratch_bytes(int T, int n_head, int n_seq);
 int kf_attn_backward(kf_ctx* ctx, const kf_bf16* q, const kf_bf16* k, const kf_bf16* v, long long ld_qkv, const kf_bf16* o, const kf_bf16* dO, long long ld_o, kf_bf16* dq,
                      kf_bf16* dk, kf_bf16* dv, long long ld_d, int T, int n_head, int n_kv, int head_dim, int n_seq, void* scratch);
+
+/* Embedding forward of a training batch (encoder_forward -> encoder_forward_kernel3, kernel/embed.cuh:20-45,372-376): out[bt][c] = bf16(wte[tokens[bt]][c] + wpe[bt % T][c]), fp32 sum, round to nearest.
+ * wte rows ldw apart; an id outside [0, V) reads row 0. */
+int kf_embed_pos(kf_ctx* ctx, const kf_bf16* wte, long long ldw, const kf_bf16* wpe, const int32_t* tokens, int B, int T, int C, int V, kf_bf16* out);
+/* value into `width` bytes of each of `rows` rows `pitch` bytes apart, on the context's stream (the padded logit columns of a step) */
+int kf_memset2d(kf_ctx* ctx, void* p, size_t pitch, int value, size_t width, size_t rows);
 
 /* Embedding backward (encoder_backward, kernel/embed.cuh:380-470): dout [B*T, C] is the gradient of  wte[tokens[bt]] + wpe[t].
  *   dwpe [T, C]        += sum over the batch                         (NULL: no position table, e.g. a RoPE model)

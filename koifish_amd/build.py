@@ -65,9 +65,10 @@ def build_hip(force=False, verbose=False):
 def build_host(force=False, verbose=False):
     src = os.path.join(HOST, "kf_host.cpp")
     src2 = os.path.join(HOST, "kf_safetensors.cpp")
-    deps = [src, src2, os.path.join(HOST, "kf_safetensors.hpp"), os.path.join(HOST, "kf_host.hpp"), os.path.join(HERE, "..", "include", "kf_abi.h"), LIB_HIP]
+    src3 = os.path.join(HOST, "kf_train.cpp")
+    deps = [src, src2, src3, os.path.join(HOST, "kf_safetensors.hpp"), os.path.join(HOST, "kf_host.hpp"), os.path.join(HERE, "..", "include", "kf_abi.h"), LIB_HIP]
     if force or _stale(LIB_HOST, deps):
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", LIB_HOST, src, src2, "-L" + HERE, "-lkf_hip", "-Wl,-rpath,$ORIGIN"]
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", LIB_HOST, src, src2, src3, "-L" + HERE, "-lkf_hip", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -81,10 +82,11 @@ def build_host_asan(verbose=False):
     out = os.path.join(HERE, "libkf_host_asan.so")
     src = os.path.join(HOST, "kf_host.cpp")
     src2 = os.path.join(HOST, "kf_safetensors.cpp")
-    deps = [src, src2, os.path.join(HOST, "kf_safetensors.hpp"), os.path.join(HOST, "kf_host.hpp"), os.path.join(HERE, "..", "include", "kf_abi.h"), LIB_HIP]
+    src3 = os.path.join(HOST, "kf_train.cpp")
+    deps = [src, src2, src3, os.path.join(HOST, "kf_safetensors.hpp"), os.path.join(HOST, "kf_host.hpp"), os.path.join(HERE, "..", "include", "kf_abi.h"), LIB_HIP]
     if _stale(out, deps):
         cmd = ["g++", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-std=c++17", "-fPIC", "-shared", "-Wall",
-               "-o", out, src, src2, "-L" + HERE, "-lkf_hip", "-Wl,-rpath,$ORIGIN"]
+               "-o", out, src, src2, src3, "-L" + HERE, "-lkf_hip", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -891,6 +891,15 @@ int kf_attn_prefill_batch(kf_ctx* c, const kf_bf16* q, const kf_bf16* k, const k
     if (rc == 1) return fail(KF_INVALID_ARGS, "kf_attn_prefill_batch: shape not covered by the tile kernel (head_dim 64 / 128, n_head / n_kv in 1, 2, 4, 8, 16-byte aligned rows)");
     RET(rc);
 }
+int kf_attn_prefill_batch_strided(kf_ctx* c, const kf_bf16* q, const kf_bf16* k, const kf_bf16* v, kf_bf16* out, int n_tok, int64_t q_stride, int64_t out_stride, int n_head,
+                                  int n_kv, int hd, int kv_stride, int n_seq) {
+    CHKCTX(c);
+    if (!q || !k || !v || !out || n_tok < 1 || n_seq < 1 || out_stride < (int64_t)n_head * hd) return fail(KF_INVALID_ARGS, "kf_attn_prefill_batch_strided: bad args");
+    if (!al16(k) || !al16(v) || (kv_stride % 8)) return fail(KF_BLAS_UNALIGN, "kf_attn_prefill_batch_strided: k / v rows not 16-byte aligned");
+    const int rc = kf::attn_prefill_mfma_launch(c->stream, q, k, v, out, 0, n_tok, q_stride, n_head, n_kv, hd, kv_stride, n_seq, out_stride);
+    if (rc == 1) return fail(KF_INVALID_ARGS, "kf_attn_prefill_batch_strided: shape not covered by the tile kernel (head_dim 64 / 128, n_head / n_kv in 1, 2, 4, 8, 16-byte aligned rows)");
+    RET(rc);
+}
 
 int kf_set_state(kf_ctx* c, int32_t* d_state, int token, int pos) {
     CHKCTX(c);
@@ -1046,6 +1055,20 @@ int kf_attn_backward(kf_ctx* c, const kf_bf16* q, const kf_bf16* k, const kf_bf1
     if (r == 1) r = KF_UNSUPPORTED_DATATYPE; /* shape outside the MFMA tile kernels */
     if (r == KF_UNSUPPORTED_DATATYPE) return fail(r, "kf_attn_backward: head_dim %d not covered (64, 128)", hd);
     RET(r);
+}
+int kf_embed_pos(kf_ctx* c, const kf_bf16* wte, long long ldw, const kf_bf16* wpe, const int32_t* tokens, int B, int T, int C, int V, kf_bf16* out) {
+    CHKCTX(c);
+    if (!wte || !wpe || !tokens || !out) return fail(KF_INVALID_ARGS, "kf_embed_pos: null pointer");
+    if (!al16(wte) || !al16(wpe) || !al16(out)) return fail(KF_BLAS_UNALIGN, "kf_embed_pos: tensors must be 16-byte aligned");
+    const int r = kf::embed_pos_launch(c->stream, wte, ldw, wpe, tokens, B, T, C, V, out);
+    if (r == KF_INVALID_ARGS) return fail(r, "kf_embed_pos: needs B, T, V >= 1, C a multiple of 8, ldw >= C a multiple of 8 (got %d %d %d %d %lld)", B, T, C, V, ldw);
+    RET(r);
+}
+int kf_memset2d(kf_ctx* c, void* p, size_t pitch, int value, size_t width, size_t rows) {
+    CHKCTX(c);
+    if (!p || width > pitch) return fail(KF_INVALID_ARGS, "kf_memset2d: null pointer or width > pitch");
+    if (!width || !rows) return KF_OK;
+    RET(hipMemset2DAsync(p, pitch, value, width, rows, c->stream) == hipSuccess ? KF_OK : KF_HIP_CHECK);
 }
 int kf_embed_backward(kf_ctx* c, kf_bf16* dwte, long long ldw, kf_bf16* dwpe, const kf_bf16* dout, const int32_t* tokens, int B, int T, int C, int V) {
     CHKCTX(c);

@@ -49,6 +49,7 @@ struct AttnPrefillArgs {
     int pos0, n_tok, n_kv, kv_stride;
     int n_seq; /* sequences of n_tok rows each, back to back in q / out and in the K / V rows (blockIdx.z); 1 for prompt prefill */
     long long q_stride;
+    long long out_stride; /* row stride of out (a training step reads q out of the fused [rows, 3C] buffer and writes a dense [rows, C] out) */
     float rden;
 };
 
@@ -327,7 +328,7 @@ __global__ void __launch_bounds__(256 * KH) attn_prefill_kernel(const AttnPrefil
     l += __shfl_xor(l, 32, 64);
     if (!col_ok) return;
     const float inv = 1.0f / l;
-    uint16_t* orow = a.out + (seq_row + tok) * a.q_stride + (size_t)(g * GQ + hq) * HD;
+    uint16_t* orow = a.out + (seq_row + tok) * a.out_stride + (size_t)(g * GQ + hq) * HD;
 #pragma unroll
     for (int db = 0; db < NDB; db++)
 #pragma unroll
@@ -365,13 +366,15 @@ static int ap_launch_gq(hipStream_t st, const AttnPrefillArgs& a, int GQ, dim3 g
 
 // KF_OK launched; 1 = shape not covered (the caller falls back to the per-token kernel)
 int attn_prefill_mfma_launch(hipStream_t st, const uint16_t* q, const uint16_t* kc, const uint16_t* vc, uint16_t* out, int pos0, int n_tok, long long q_stride,
-                             int n_head, int n_kv, int hd, int kv_stride, int n_seq) {
+                             int n_head, int n_kv, int hd, int kv_stride, int n_seq, long long out_stride) {
+    if (out_stride <= 0) out_stride = q_stride;
+    if (out_stride & 3) return 1;
     if ((hd != 64 && hd != 128) || n_kv <= 0 || n_head % n_kv != 0) return 1;
     if ((q_stride & 7) != 0 || (kv_stride & 7) != 0 || (reinterpret_cast<uintptr_t>(q) & 15) != 0 || (reinterpret_cast<uintptr_t>(out) & 7) != 0) return 1;
     const int GQ = n_head / n_kv;
     if (GQ != 1 && GQ != 2 && GQ != 4 && GQ != 8) return 1;
     AttnPrefillArgs a;
-    a.q = q, a.kcache = kc, a.vcache = vc, a.out = out, a.pos0 = pos0, a.n_tok = n_tok, a.n_kv = n_kv, a.kv_stride = kv_stride, a.q_stride = q_stride;
+    a.q = q, a.kcache = kc, a.vcache = vc, a.out = out, a.pos0 = pos0, a.n_tok = n_tok, a.n_kv = n_kv, a.kv_stride = kv_stride, a.q_stride = q_stride, a.out_stride = out_stride;
     a.rden = 1.0f / sqrtf((float)hd);
     a.n_seq = n_seq;
     const int TQ = 128 / GQ;

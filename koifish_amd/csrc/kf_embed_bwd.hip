@@ -11,6 +11,32 @@
 
 namespace kf {
 
+// Forward of the same pair (encoder_forward_kernel3, embed.cuh:20-45: out[bt] = wte[tokens[bt]] + wpe[t], fp32 sum, round to nearest): one 8-column vector per thread.
+// A token id outside [0, V) reads row 0 (the ABI has checked nothing on the device ids; the loss of such a row is the caller's problem, never a fault).
+__global__ void __launch_bounds__(256) embed_pos_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict__ wte, long long ldw, const uint16_t* __restrict__ wpe,
+                                                        const int* __restrict__ tokens, int N, int T, int C, int V) {
+    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int cv = C / 8;
+    if (v >= (size_t)N * cv) return;
+    const int bt = (int)(v / cv), c8 = (int)(v % cv) * 8;
+    int id = tokens[bt];
+    id = (id < 0 || id >= V) ? 0 : id;
+    const u32x4 a = *reinterpret_cast<const u32x4*>(wte + (size_t)id * ldw + c8);
+    const u32x4 b = *reinterpret_cast<const u32x4*>(wpe + (size_t)(bt % T) * C + c8);
+    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+    uint32_t r[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) r[k] = pack_bf16x2(bf_lo(aw[k]) + bf_lo(bw[k]), bf_hi(aw[k]) + bf_hi(bw[k]));
+    *reinterpret_cast<u32x4*>(out + (size_t)bt * C + c8) = u32x4{r[0], r[1], r[2], r[3]};
+}
+
+int embed_pos_launch(hipStream_t st, const uint16_t* wte, long long ldw, const uint16_t* wpe, const int* tokens, int B, int T, int C, int V, uint16_t* out) {
+    if (B < 1 || T < 1 || V < 1 || C < 8 || (C & 7) || ldw < C || (ldw & 7)) return KF_INVALID_ARGS;
+    const size_t nv = (size_t)B * T * (C / 8);
+    hipLaunchKernelGGL(embed_pos_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, out, wte, ldw, wpe, tokens, B * T, T, C, V);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+
 constexpr int EB_MAXV = 4; /* 8-column vectors per thread: C <= 8192 */
 
 __global__ void __launch_bounds__(256) wpe_backward_kernel(uint16_t* __restrict__ dwpe, const uint16_t* __restrict__ dout, int B, int T, int C) {

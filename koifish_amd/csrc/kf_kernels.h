@@ -131,7 +131,7 @@ int attn_launch(hipStream_t st, AttnArgs& a);
 int attn_splits(int pos_bound, int n_kv);
 // token-batch causal attention on MFMA (kf_attn_prefill.hip): KF_OK launched, 1 = shape not covered, < 0 error
 int attn_prefill_mfma_launch(hipStream_t st, const uint16_t* q, const uint16_t* kc, const uint16_t* vc, uint16_t* out, int pos0, int n_tok, long long q_stride,
-                             int n_head, int n_kv, int hd, int kv_stride, int n_seq = 1);
+                             int n_head, int n_kv, int hd, int kv_stride, int n_seq = 1, long long out_stride = 0 /* 0: q_stride */);
 int qknorm_rope_launch(hipStream_t st, uint16_t* q, uint16_t* k, const uint16_t* wq, const uint16_t* wk, const float* table, int pos,
                        const int* d_pos, int n_head, int n_kv, int hd, float eps, int n_tok = 1, long long q_stride = 0, long long k_stride = 0, int seq_len = 0,
                        float* rstd_q = nullptr, float* rstd_k = nullptr);
@@ -209,6 +209,7 @@ int attn_backward_mfma_launch(hipStream_t st, const uint16_t* q, const uint16_t*
                               uint16_t* dq, uint16_t* dk, uint16_t* dv, long long ld_d, int T, int n_head, int hd, int n_seq, float* scratch, int n_kv, long long ld_kv,
                               long long ld_dkv); /* kf_attn_bwd_mfma.hip: 1 = not covered */
 // embedding backward (kf_embed_bwd.hip)
+int embed_pos_launch(hipStream_t st, const uint16_t* wte, long long ldw, const uint16_t* wpe, const int* tokens, int B, int T, int C, int V, uint16_t* out);
 int embed_backward_launch(hipStream_t st, uint16_t* dwte, long long ldw, uint16_t* dwpe, const uint16_t* dout, const int* tokens, int B, int T, int C, int V);
 // fused classifier (kf_loss.hip): cross-entropy loss per row + logit gradient in place
 int fused_classifier_launch(hipStream_t st, uint16_t* logits, float* losses, uint16_t* probs, float dloss, const int* targets, long rows, int V, int P,

@@ -7,8 +7,10 @@
   update   CU_adamw_ (Optimizer.cu:135-160: seeded stochastic rounding) on the model's OWN bf16 master weights and bf16 moments
   requant  CU_XtoQ128_ / Float2T<f8e5> (T.cu:105-175) of every updated matrix back into its blob, which the next forward reads
 
-The step keeps every activation (no recomputation).  Python here only sequences ABI calls and owns the device buffers (torch tensors); embedding gather / add and the
-zero fills are torch ops.  Used by tests/test_gpu_train_step.py (a 2-layer toy, two consecutive steps against the oracle) and by bench.py's config3 leg (full size)."""
+The step keeps every activation (no recomputation).  Python here OWNS the device buffers (torch tensors: setup, outside any timed region) and registers them with
+koifish::GPT2Trainer (koifish_amd/host/kf_train.cpp, libkf_host.so), which sequences the step: forward / backward / update are one C call each, step() is ONE call,
+and nothing in them is a torch op (the embedding gather + add is kf_embed_pos, the attention reads q out of the fused rows, the zero fills are kf_memset / kf_memset2d).
+Used by tests/test_gpu_train_step.py (a 2-layer toy, two consecutive steps against the oracle) and by bench.py's config3 leg (full size)."""
 import ctypes as C
 
 import torch
@@ -74,91 +76,54 @@ class GPT2Step:
         self._sp_lin = (self._sc_lin.data_ptr() + 255) & ~255
         self._sc_ln = torch.empty(hip.kf_norm_backward_scratch_bytes(N, C_, 1) // 8 + 1, dtype=torch.float64, device=dev)
         self._sc_at = torch.empty(hip.kf_attn_backward_scratch_bytes(T, H, B) // 4 + 1, dtype=torch.float32, device=dev)
-        self.t = 0   # optimizer steps taken
 
-    # ---- operators
-    def _lin(self, e, xin, y, bias, res=None):
-        d = e["blob"].desc()
-        L.check(self.ctx.hip.kf_linear(self.ctx.h, C.byref(d), xin.data_ptr(), y.data_ptr(), bias["p"].data_ptr() if bias is not None else None, self.N, 1.0, 0.0,
-                                       1 if res is not None else 0, res.data_ptr() if res is not None else None), "kf_linear")
+        # the step's sequencer: koifish::GPT2Trainer of libkf_host.so (koifish_amd/host/kf_train.cpp) over the buffers above -- every tensor registered once
+        host = ctx.host
+        self.h = host.kfh_gpt2_create(ctx.h, C_, H, NL, V, Vp, B, T)
+        if not self.h:
+            raise RuntimeError("kfh_gpt2_create refused the shape")
+        assert host.kfh_gpt2_n_params(self.h) == len(self.params)
+        for i, e in enumerate(self.params):
+            d = e["blob"].desc() if e["blob"] is not None else None
+            L.check(host.kfh_gpt2_set_param(self.h, i, e["p"].data_ptr(), e["g"].data_ptr(), e["m"].data_ptr(), e["v"].data_ptr(), e["p"].numel(), int(e["wd"]),
+                                            C.byref(d) if d is not None else None, int(e["type"] is not None and e["type"] != L.BF16)), "kfh_gpt2_set_param")
+        for l, a in enumerate(self.A):
+            arr = (C.c_void_p * 12)(*[a[k].data_ptr() for k in ("x", "h1", "m1", "r1", "qkv", "att", "x2", "h2", "m2", "r2", "f", "g")])
+            L.check(host.kfh_gpt2_set_block_acts(self.h, l, arr), "kfh_gpt2_set_block_acts")
+        arr = (C.c_void_p * 14)(*([t_.data_ptr() for t_ in (self.xf, self.hf, self.mf, self.rf, self.logits, self.losses, self.dx, self.dh, self.dqkv, self.datt, self.d4)]
+                                  + [self._sp_lin, self._sc_ln.data_ptr(), self._sc_at.data_ptr()]))
+        L.check(host.kfh_gpt2_set_buffers(self.h, arr), "kfh_gpt2_set_buffers")
 
-    def _ln(self, x, w, b, y, m_, r_):
-        L.check(self.ctx.hip.kf_layernorm(self.ctx.h, x.data_ptr(), w["p"].data_ptr(), b["p"].data_ptr(), y.data_ptr(), self.N, self.C, 1e-5, m_.data_ptr(), r_.data_ptr()), "kf_layernorm")
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.host.kfh_gpt2_destroy(self.h)
+            self.h = None
 
+    __del__ = close
+
+    @property
+    def t(self):
+        """optimizer steps taken"""
+        return int(self.ctx.host.kfh_gpt2_steps_taken(self.h))
+
+    # ---- the step: sequenced by the host library; Python passes two device pointers and the hyper-parameters
     def forward(self, ids, tgt):
         """ids, tgt: int32 [B * T] on the device.  Leaves the per-row losses in self.losses and the logit gradients (of the MEAN loss) in self.logits."""
-        ctx, hip, C_, NL, B, T = self.ctx, self.ctx.hip, self.C, self.NL, self.B, self.T
-        A = self.A
-        A[0]["x"].copy_(self.wte["p"][ids.long()])
-        A[0]["x"].add_(self.wpe["p"].repeat(B, 1))
-        for l in range(NL):
-            a, b = A[l], self.blocks[l]
-            self._ln(a["x"], b["ln1.w"], b["ln1.b"], a["h1"], a["m1"], a["r1"])
-            self._lin(b["qkv"], a["h1"], a["qkv"], b["qkv_b"])
-            self.qc.copy_(a["qkv"][:, :C_])
-            L.check(hip.kf_attn_prefill_batch(ctx.h, self.qc.data_ptr(), a["qkv"][:, C_:].data_ptr(), a["qkv"][:, 2 * C_:].data_ptr(), a["att"].data_ptr(), T, C_, self.H, self.H, self.hd,
-                                              3 * C_, B), "kf_attn_prefill_batch")
-            self._lin(b["proj"], a["att"], a["x2"], b["proj_b"], a["x"])
-            self._ln(a["x2"], b["ln2.w"], b["ln2.b"], a["h2"], a["m2"], a["r2"])
-            self._lin(b["fc"], a["h2"], a["f"], b["fc_b"])
-            L.check(hip.kf_gelu(ctx.h, a["f"].data_ptr(), a["g"].data_ptr(), a["f"].numel()), "kf_gelu")
-            self._lin(b["proj2"], a["g"], A[l + 1]["x"] if l + 1 < NL else self.xf, b["proj2_b"], a["x2"])
-        self._ln(self.xf, self.lnf_w, self.lnf_b, self.hf, self.mf, self.rf)
-        self._lin(self.wte, self.hf, self.logits, None)
-        self.losses.zero_()
-        L.check(hip.kf_fused_classifier(ctx.h, self.logits.data_ptr(), self.losses.data_ptr(), None, 1.0 / self.N, tgt.data_ptr(), B, T, self.V, self.Vp, None, 1), "kf_fused_classifier")
-        self._ids = ids
-
-    def _lin_bwd(self, e, dIn, inp, delta, bias):
-        d = e["blob"].desc()
-        L.check(self.ctx.hip.kf_linear_backward(self.ctx.h, C.byref(d), dIn.data_ptr(), inp.data_ptr(), delta.data_ptr(), e["g"].data_ptr(), bias["g"].data_ptr() if bias is not None else None,
-                                                self.N, 0, self._sp_lin), "kf_linear_backward")
-
-    def _ln_bwd(self, dxx, dout, inp, w, b, m_, r_):
-        # kf_norm_backward ADDS into dweight / dbias (one shared LayerNorm in the operator tests): the per-tensor gradients are zero here (kf_adamw zeroes what it consumed)
-        L.check(self.ctx.hip.kf_norm_backward(self.ctx.h, dxx.data_ptr(), w["g"].data_ptr(), b["g"].data_ptr(), dout.data_ptr(), inp.data_ptr(), w["p"].data_ptr(), m_.data_ptr(), r_.data_ptr(),
-                                              self.N, self.C, self._sc_ln.data_ptr()), "kf_norm_backward")
+        self._ids = ids   # kept alive: the backward reads them
+        L.check(self.ctx.host.kfh_gpt2_forward(self.h, ids.data_ptr(), tgt.data_ptr()), "kfh_gpt2_forward")
 
     def backward(self):
-        ctx, hip, C_, NL, B, T = self.ctx, self.ctx.hip, self.C, self.NL, self.B, self.T
-        A, dx, dh, dqkv, datt, d4 = self.A, self.dx, self.dh, self.dqkv, self.datt, self.d4
-        self.logits[:, self.V:].zero_()
-        self._lin_bwd(self.wte, self.logits, self.hf, dh, None)
-        dx.zero_()
-        self._ln_bwd(dx, dh, self.xf, self.lnf_w, self.lnf_b, self.mf, self.rf)
-        for l in reversed(range(NL)):
-            a, b = A[l], self.blocks[l]
-            self._lin_bwd(b["proj2"], dx, a["g"], d4, b["proj2_b"])
-            L.check(hip.kf_gelu_backward(ctx.h, d4.data_ptr(), a["f"].data_ptr(), d4.numel()), "kf_gelu_backward")
-            self._lin_bwd(b["fc"], d4, a["h2"], dh, b["fc_b"])
-            self._ln_bwd(dx, dh, a["x2"], b["ln2.w"], b["ln2.b"], a["m2"], a["r2"])
-            self._lin_bwd(b["proj"], dx, a["att"], datt, b["proj_b"])
-            L.check(hip.kf_attn_backward(ctx.h, a["qkv"][:, :C_].data_ptr(), a["qkv"][:, C_:2 * C_].data_ptr(), a["qkv"][:, 2 * C_:].data_ptr(), 3 * C_, a["att"].data_ptr(), datt.data_ptr(), C_,
-                                         dqkv[:, :C_].data_ptr(), dqkv[:, C_:2 * C_].data_ptr(), dqkv[:, 2 * C_:].data_ptr(), 3 * C_, T, self.H, self.H, self.hd, B, self._sc_at.data_ptr()),
-                    "kf_attn_backward")
-            self._lin_bwd(b["qkv"], dqkv, a["h1"], dh, b["qkv_b"])
-            self._ln_bwd(dx, dh, a["x"], b["ln1.w"], b["ln1.b"], a["m1"], a["r1"])
-        L.check(hip.kf_embed_backward(ctx.h, self.wte["g"].data_ptr(), C_, self.wpe["g"].data_ptr(), dx.data_ptr(), self._ids.data_ptr(), B, T, C_, self.Vp), "kf_embed_backward")
+        L.check(self.ctx.host.kfh_gpt2_backward(self.h), "kfh_gpt2_backward")
 
     def update(self, lr=3e-4, beta1=0.9, beta2=0.95, eps=1e-8, wd=0.1, seed=1234):
-        """AdamW on every tensor (its own master, moments and gradient; seeded stochastic rounding: seed + the tensor's index, as one seed per launch in the reference), then
-        the re-quantisation of every quantised matrix from its updated master.  kf_adamw zeroes the gradients it has consumed."""
-        ctx, hip = self.ctx, self.ctx.hip
-        self.t += 1
-        b1c, b2c = 1.0 - beta1 ** self.t, 1.0 - beta2 ** self.t
-        for i, e in enumerate(self.params):
-            n = e["p"].numel()
-            assert n % 8 == 0
-            L.check(hip.kf_adamw(ctx.h, e["p"].data_ptr(), e["g"].data_ptr(), e["m"].data_ptr(), e["v"].data_ptr(), n, L.BF16, lr, beta1, beta2, b1c, b2c, eps, wd if e["wd"] else 0.0, 1.0,
-                                 (seed + 7919 * self.t + i) & 0xFFFFFFFF, None), "kf_adamw")
-            if e["type"] is not None and e["type"] != L.BF16:
-                d = e["blob"].desc()
-                L.check(hip.kf_quantize(ctx.h, C.byref(d), e["p"].data_ptr(), 0), "kf_quantize")
+        """AdamW on every tensor (its own master, moments and gradient; seeded stochastic rounding: seed + 7919 t + the tensor's index, as one seed per launch in the
+        reference), then the re-quantisation of every quantised matrix from its updated master.  kf_adamw zeroes the gradients it has consumed."""
+        L.check(self.ctx.host.kfh_gpt2_update(self.h, lr, beta1, beta2, eps, wd, seed & 0xFFFFFFFF), "kfh_gpt2_update")
 
-    def step(self, ids, tgt, **hp):
-        self.forward(ids, tgt)
-        self.backward()
-        self.update(**hp)
+    def step(self, ids, tgt, lr=3e-4, beta1=0.9, beta2=0.95, eps=1e-8, wd=0.1, seed=1234):
+        """forward + loss, backward, update + re-quantisation: ONE call into the host library"""
+        self._ids = ids
+        L.check(self.ctx.host.kfh_gpt2_step(self.h, ids.data_ptr(), tgt.data_ptr(), lr, beta1, beta2, eps, wd, seed & 0xFFFFFFFF), "kfh_gpt2_step")
 
     def n_params(self):
         return sum(e["p"].numel() for e in self.params)

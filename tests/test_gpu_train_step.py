@@ -425,3 +425,44 @@ def test_gpt2_two_consecutive_steps_with_update(ctx):
                 assert np.array_equal(e["blob"].blob.cpu().numpy(), np.frombuffer(ow.blob(), dtype=np.uint8)), "step %d: blob of %s" % (step, e["name"])
     assert losses[1] < losses[0] and losses[2] < losses[1], losses
     print("toy losses over three forwards on one batch:", ["%.4f" % v for v in losses])
+
+
+def test_embed_pos_and_strided_attention(ctx):
+    """the two operators the step's C++ sequencer uses instead of torch ops:
+      * kf_embed_pos == bf16(wte[id] + wpe[t]) in fp32, round to nearest (encoder_forward_kernel3, kernel/embed.cuh:20-45) bit for bit, an out-of-range id reading row 0;
+      * kf_attn_prefill_batch_strided reading q out of the fused [rows, 3C] buffer and writing a dense [rows, C] out == kf_attn_prefill_batch on a copy of the q columns,
+        bit for bit;
+      * kf_memset2d clears exactly the padded columns."""
+    hip, dev = ctx.hip, ctx.device
+    rng = np.random.default_rng(8)
+    Bn, T, Cn, V, H = 3, 70, 128, 300, 2
+    N = Bn * T
+    wte = O.f32_to_bf16(rng.normal(0, 0.3, (V, Cn)).astype(np.float32))
+    wpe = O.f32_to_bf16(rng.normal(0, 0.1, (T, Cn)).astype(np.float32))
+    ids = rng.integers(0, V, N).astype(np.int32)
+    ids[5], ids[9] = -3, V + 10
+    d_wte, d_wpe, d_ids = bf16_t(wte, dev), bf16_t(wpe, dev), torch.from_numpy(ids).to(dev)
+    out = torch.zeros(N, Cn, dtype=torch.bfloat16, device=dev)
+    assert hip.kf_embed_pos(ctx.h, d_wte.data_ptr(), Cn, d_wpe.data_ptr(), d_ids.data_ptr(), Bn, T, Cn, V, out.data_ptr()) == 0, hip.kf_last_error()
+    ctx.sync()
+    safe = np.where((ids < 0) | (ids >= V), 0, ids)
+    ref = O.f32_to_bf16(O.bf16_to_f32(wte[safe]) + O.bf16_to_f32(np.tile(wpe, (Bn, 1))))
+    assert np.array_equal(u16(out), ref)
+    assert hip.kf_embed_pos(ctx.h, d_wte.data_ptr(), Cn, d_wpe.data_ptr(), d_ids.data_ptr(), Bn, T, Cn + 4, V, out.data_ptr()) != 0   # C not a multiple of 8
+    # attention on the fused rows
+    qkv = bf16_t(O.f32_to_bf16(rng.normal(0, 1.0, (N, 3 * Cn)).astype(np.float32)), dev)
+    qc = qkv[:, :Cn].contiguous()
+    a0 = torch.zeros(N, Cn, dtype=torch.bfloat16, device=dev)
+    a1 = torch.zeros(N, Cn, dtype=torch.bfloat16, device=dev)
+    assert hip.kf_attn_prefill_batch(ctx.h, qc.data_ptr(), qkv[:, Cn:].data_ptr(), qkv[:, 2 * Cn:].data_ptr(), a0.data_ptr(), T, Cn, H, H, Cn // H, 3 * Cn, Bn) == 0, hip.kf_last_error()
+    assert hip.kf_attn_prefill_batch_strided(ctx.h, qkv.data_ptr(), qkv[:, Cn:].data_ptr(), qkv[:, 2 * Cn:].data_ptr(), a1.data_ptr(), T, 3 * Cn, Cn, H, H, Cn // H, 3 * Cn, Bn) == 0, hip.kf_last_error()
+    ctx.sync()
+    assert u16(a0).any() and np.array_equal(u16(a0), u16(a1))
+    assert hip.kf_attn_prefill_batch_strided(ctx.h, qkv.data_ptr(), qkv[:, Cn:].data_ptr(), qkv[:, 2 * Cn:].data_ptr(), a1.data_ptr(), T, 3 * Cn, Cn - 8, H, H, Cn // H, 3 * Cn, Bn) != 0   # out rows would overlap
+    # the padded columns of a [rows, Vp] buffer
+    Vp = 320
+    lg = torch.full((N, Vp), 1.5, dtype=torch.bfloat16, device=dev)
+    assert hip.kf_memset2d(ctx.h, lg.data_ptr() + V * 2, Vp * 2, 0, (Vp - V) * 2, N) == 0, hip.kf_last_error()
+    ctx.sync()
+    h = u16(lg)
+    assert not h[:, V:].any() and (h[:, :V] == h[0, 0]).all()
