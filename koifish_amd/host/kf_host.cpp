@@ -798,6 +798,7 @@ XcdReplicas::~XcdReplicas() {
     if (d_state) kf_free(ctx, d_state);
     if (d_forced) kf_free(ctx, d_forced);
     if (d_tokens_out) kf_free(ctx, d_tokens_out);
+    if (d_rng) kf_free(ctx, d_rng);
 }
 size_t XcdReplicas::kv_seq_elems() const {
     const MODEL_CARD& c = hFish->config;
@@ -914,6 +915,16 @@ int XcdReplicas::SetState(int seq, int token, int pos) {
     KF_TRY(kf_h2d(hFish->ctx, d_state + 4 * seq + 3, &zero, 4)); /* the status word of the re-aimed sequence */
     return kf_set_state(hFish->ctx, d_state + 4 * seq, token, pos);
 }
+// CHAT_SAMPLER for Chat (greedy by default): one rng word per sequence, seeded per request
+int XcdReplicas::SetSampler(const CHAT_SAMPLER& sp) {
+    if (!sp.greedy()) {
+        const int k = sp.top_k < hFish->config.vocab ? sp.top_k : hFish->config.vocab;
+        if (k < 2 || k >= hFish->config.vocab / 2 || k > 1024 || !(sp.temperature > 0.0f) || !(sp.top_p > 0.0f)) return KF_INVALID_ARGS;
+        if (!d_rng) KF_TRY(kf_malloc(hFish->ctx, (size_t)n_seq * 8, (void**)&d_rng));
+    }
+    samp_params = sp;
+    return KF_OK;
+}
 // A parked sequence is skipped by the launches (the others decode on); its cache, state and ids stay.  Status: 0, or 64 = the last launch would have left the
 // sequence's cache rows and skipped it (kf_abi.h: d_state [n_seq][4] = {token, pos, parked, status}).
 int XcdReplicas::Park(int seq, bool on) {
@@ -962,9 +973,19 @@ int XcdReplicas::RunSteps(int n) {
 // row.  out [n_req][max_new] (-1 behind an answer's end), out_len [n_req]; every answer equals Fish::Generate's on the same prompt (same prefill, same decode arithmetic).
 // With eos >= 0 the ids of each launch are read back (one sync per launch) and a sequence may run up to steps_per_launch - 1 ids past its EOS before its slot is freed --
 // those ids are dropped; stats [4] = {launches, steps, prefills, sequence-steps decoded and dropped}.
+//
+// With a non-greedy sampler (SetSampler: GeneratOnPrompt::Sample, GoPT.cpp:614-630 -- temperature, top-k, top-p, xorshift coin) the launches run ONE step each and leave the
+// logits (pick = 0); kf_sample then draws every occupied slot's id from its own logits with the slot's own rng state, seeded at the request's start with seed + request
+// index: answer r equals Fish::Generate's on prompt r under SetSampler(seed + r).
 int XcdReplicas::Chat(const int32_t* prompts, const int32_t* prompt_len, int n_req, int stride, int max_new, int eos, int32_t* out, int32_t* out_len, long long* stats) {
     const MODEL_CARD& c = hFish->config;
     if (!prompts || !prompt_len || !out || !out_len || n_req < 1 || stride < 1 || max_new < 1) return KF_INVALID_ARGS;
+    const bool sampled = !samp_params.greedy();
+    auto draw = [&](int s) -> int {  // the slot's next id from its logits: state {token, pos} -> {id, pos + 1}, ids out [pos] = id
+        return (samp_params.true_topk ? kf_sample_topk : kf_sample)(hFish->ctx, ToX(logits) + (size_t)s * c.vocab, c.vocab, samp_params.top_k, samp_params.temperature,
+                                                                     samp_params.top_p, d_rng + s, nullptr, d_state + 4 * s, d_tokens_out + (size_t)s * c.n_ctx,
+                                                                     d_forced + (size_t)s * c.n_ctx, c.n_ctx);
+    };
     for (int r = 0; r < n_req; r++)
         if (prompt_len[r] < 1 || prompt_len[r] > stride || prompt_len[r] >= c.n_ctx) return KF_INVALID_ARGS;
     kf_ctx* ctx = hFish->ctx;
@@ -994,6 +1015,13 @@ int XcdReplicas::Chat(const int32_t* prompts, const int32_t* prompt_len, int n_r
             KF_TRY(kf_h2d(ctx, d_forced + (size_t)s * c.n_ctx, none.data(), (size_t)c.n_ctx * 4));
             KF_TRY(Prefill(s, prompts + (size_t)q.req * stride, q.len));
             st[2]++;
+            if (sampled) { /* the prefill left the last prompt token's logits in the model's head buffer and picked greedily: draw the answer's first id instead */
+                const uint64_t seed = samp_params.seed + (uint64_t)q.req;
+                KF_TRY(kf_h2d(ctx, d_rng + s, &seed, 8));
+                KF_TRY(kf_d2d(ctx, ToX(logits) + (size_t)s * c.vocab, ToX(hFish->head.preLogits), (size_t)c.vocab * 2));
+                KF_TRY(kf_set_state(ctx, d_state + 4 * s, prompts[(size_t)q.req * stride + q.len - 1], q.len - 1));
+                KF_TRY(draw(s));
+            }
             if (eos >= 0) {
                 int32_t first;
                 KF_TRY(kf_d2h(ctx, &first, d_tokens_out + (size_t)s * c.n_ctx + (q.len - 1), 4));
@@ -1002,11 +1030,14 @@ int XcdReplicas::Chat(const int32_t* prompts, const int32_t* prompt_len, int n_r
             if (q.have >= q.want) { KF_TRY(finish(s, q.want)); s--; continue; }  // a one-id answer: the slot takes the next prompt at once
             KF_TRY(Park(s, false));
         }
-        int k = steps_per_launch, active = 0;
+        int k = sampled ? 1 : steps_per_launch, active = 0;
         for (int s = 0; s < n_seq; s++)
             if (slot[s].req >= 0) active++, k = slot[s].want - slot[s].have < k ? slot[s].want - slot[s].have : k;
         if (!active) continue;
-        KF_TRY(kf_xengine_steps(ctx, engine, ToX(x), d_state, k, 1));
+        KF_TRY(kf_xengine_steps(ctx, engine, ToX(x), d_state, k, sampled ? 0 : 1));
+        if (sampled)
+            for (int s = 0; s < n_seq; s++)
+                if (slot[s].req >= 0) KF_TRY(draw(s));
         st[0]++, st[1] += k, steps_run += k;
         for (int s = 0; s < n_seq; s++) {
             Slot& q = slot[s];
@@ -1557,6 +1588,12 @@ int kfh_xr_prefill(void* h, int seq, const int* tokens, int n) { return reinterp
 int kfh_xr_run_steps(void* h, int n) { return reinterpret_cast<XcdReplicas*>(h)->RunSteps(n); }
 int kfh_xr_check(void* h) { return reinterpret_cast<XcdReplicas*>(h)->Check(); }
 int kfh_xr_park(void* h, int seq, int on) { return reinterpret_cast<XcdReplicas*>(h)->Park(seq, on != 0); }
+int kfh_xr_set_sampler(void* h, float temperature, float top_p, int top_k, uint64_t seed) {
+    CHAT_SAMPLER s;
+    s.temperature = temperature, s.top_p = top_p, s.top_k = top_k & 0xFFFF, s.seed = seed;
+    s.true_topk = (top_k & 0x10000) != 0;
+    return reinterpret_cast<XcdReplicas*>(h)->SetSampler(s);
+}
 int kfh_xr_chat(void* h, const int32_t* prompts, const int32_t* prompt_len, int n_req, int stride, int max_new, int eos, int32_t* out, int32_t* out_len, long long* stats) {
     return reinterpret_cast<XcdReplicas*>(h)->Chat(prompts, prompt_len, n_req, stride, max_new, eos, out, out_len, stats);
 }

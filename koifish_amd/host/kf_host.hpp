@@ -312,6 +312,9 @@ struct XcdReplicas {
     int RunSteps(int n);  // n greedy steps of EVERY sequence from wherever each stands; no host sync
     // a queue of prompts answered through the slots (Fish::Chat's rounds over DEBUG.prompts, GoPT.cpp:1111-1180, n_seq at once); see kf_host.cpp
     int Chat(const int32_t* prompts, const int32_t* prompt_len, int n_req, int stride, int max_new, int eos, int32_t* out, int32_t* out_len, long long* stats);
+    CHAT_SAMPLER samp_params;     // Chat's sampler (greedy by default); non-greedy: one launch per token, kf_sample per occupied slot
+    uint64_t* d_rng = nullptr;    // [n_seq] xorshift states, seeded per request (seed + request index)
+    int SetSampler(const CHAT_SAMPLER& s);
     int Check();          // synchronises; a timed-out hand-off is reported once (KF_INTERNAL_ERR) and the engine reset
     size_t kv_seq_elems() const;
 };

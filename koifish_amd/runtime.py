@@ -665,6 +665,11 @@ class XcdReplicas:
         """a parked sequence is skipped by the launches; the others decode on"""
         L.check(self.host.kfh_xr_park(self.h, int(seq), int(bool(on))), "kfh_xr_park")
 
+    def set_sampler(self, temperature=0.0, top_p=0.95, top_k=50, seed=42, true_topk=False):
+        """chat()'s sampler (CHAT_SAMPLER; greedy by default).  Non-greedy: one launch per token leaves every slot's logits, kf_sample draws each slot's id with the slot's own
+        rng, seeded with seed + the request's index at the request's start -- answer r == the model alone on prompt r under set_sampler(seed=seed + r)."""
+        L.check(self.host.kfh_xr_set_sampler(self.h, float(temperature), float(top_p), int(top_k) | (0x10000 if true_topk else 0), int(seed)), "kfh_xr_set_sampler")
+
     def chat(self, prompts, max_new, eos=-1):
         """a queue of prompts answered through the sequences' slots (Fish::Chat's rounds over its prompt list, GoPT.cpp:1111-1180, n_seq rounds in flight): a free slot
         prefills the next prompt, the launches decode every occupied slot, an answer ends at `eos`, at max_new ids or at the last cache row.

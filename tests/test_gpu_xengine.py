@@ -571,7 +571,8 @@ def test_prefill_then_decode_per_sequence(canon):
 def test_a_queue_of_prompts_through_the_slots(canon, n_seq, n_req):
     """XcdReplicas.chat: Fish::Chat's rounds over a prompt list (GoPT.cpp:1111-1180) with n_seq rounds in flight -- ragged prompts (2 ... 40 tokens, one standing five rows
     before the cache's end), a free slot refilled from the queue while the others decode on.  Every answer equals the model ALONE generating on that prompt (same batched
-    prefill, the single-sequence decode); with an EOS id the answers are those cut behind their first EOS, and the ids a sequence decoded past it are dropped."""
+    prefill, the single-sequence decode); with an EOS id the answers are those cut behind their first EOS, and the ids a sequence decoded past it are dropped; with the
+    reference's sampler every answer equals the model alone sampling under the request's seed."""
     cfg = dict(synth.CONFIGS["small"], max_seq=96)
     raw = synth.raw_weights_numpy(cfg, 4242, w_std=0.1)
     m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
@@ -598,6 +599,19 @@ def test_a_queue_of_prompts_through_the_slots(canon, n_seq, n_req):
     got, st = xr.chat(prompts, max_new, eos=eos)
     assert got == cut
     assert st["prefills"] == n_req
+    # the reference's sampler (GeneratOnPrompt::Sample: temperature, top-k, top-p, xorshift coin) per slot: request r draws with seed + r
+    sub = list(range(0, n_req, 2))
+    xr.set_sampler(temperature=0.8, top_p=0.9, top_k=40, seed=1000)
+    got, st = xr.chat([prompts[r] for r in sub], max_new)
+    for i, r in enumerate(sub):
+        m.set_sampler(temperature=0.8, top_p=0.9, top_k=40, seed=1000 + i)
+        want = m.generate(prompts[r], min(max_new, cfg["max_seq"] - len(prompts[r]) + 1), use_graph=False)
+        assert got[i] == want, "request %d (sampled)" % i
+    assert any(g != ref[r] for g, r in zip(got, sub)), "the sampler drew the greedy ids everywhere"
+    m.set_sampler()
+    xr.set_sampler()
+    got, _ = xr.chat(prompts[:5], max_new)
+    assert got == ref[:5]
     # the object is as before the queue: all slots free running
     for s in range(n_seq):
         assert xr.status(s)[2] == 0
