@@ -1005,57 +1005,64 @@ int XcdReplicas::Chat(const int32_t* prompts, const int32_t* prompt_len, int n_r
         q.req = -1, done++;
         return Park(s, true);
     };
-    while (done < n_req) {
-        for (int s = 0; s < n_seq && next < n_req; s++) {
-            Slot& q = slot[s];
-            if (q.req >= 0) continue;
-            q.req = next++, q.len = prompt_len[q.req], q.have = 1;  // the prefill picks the answer's first id
-            const int room = c.n_ctx - q.len;                       // the ids the cache has rows for: the id behind row p needs row p
-            q.want = max_new < room + 1 ? max_new : room + 1;
-            KF_TRY(kf_h2d(ctx, d_forced + (size_t)s * c.n_ctx, none.data(), (size_t)c.n_ctx * 4));
-            KF_TRY(Prefill(s, prompts + (size_t)q.req * stride, q.len));
-            st[2]++;
-            if (sampled) { /* the prefill left the last prompt token's logits in the model's head buffer and picked greedily: draw the answer's first id instead */
-                const uint64_t seed = samp_params.seed + (uint64_t)q.req;
-                KF_TRY(kf_h2d(ctx, d_rng + s, &seed, 8));
-                KF_TRY(kf_d2d(ctx, ToX(logits) + (size_t)s * c.vocab, ToX(hFish->head.preLogits), (size_t)c.vocab * 2));
-                KF_TRY(kf_set_state(ctx, d_state + 4 * s, prompts[(size_t)q.req * stride + q.len - 1], q.len - 1));
-                KF_TRY(draw(s));
+    auto serve = [&]() -> int {
+        while (done < n_req) {
+            for (int s = 0; s < n_seq && next < n_req; s++) {
+                Slot& q = slot[s];
+                if (q.req >= 0) continue;
+                q.req = next++, q.len = prompt_len[q.req], q.have = 1;  // the prefill picks the answer's first id
+                const int room = c.n_ctx - q.len;                       // the ids the cache has rows for: the id behind row p needs row p
+                q.want = max_new < room + 1 ? max_new : room + 1;
+                KF_TRY(kf_h2d(ctx, d_forced + (size_t)s * c.n_ctx, none.data(), (size_t)c.n_ctx * 4));
+                KF_TRY(Prefill(s, prompts + (size_t)q.req * stride, q.len));
+                st[2]++;
+                if (sampled) { /* the prefill left the last prompt token's logits in the model's head buffer and picked greedily: draw the answer's first id instead */
+                    const uint64_t seed = samp_params.seed + (uint64_t)q.req;
+                    KF_TRY(kf_h2d(ctx, d_rng + s, &seed, 8));
+                    KF_TRY(kf_d2d(ctx, ToX(logits) + (size_t)s * c.vocab, ToX(hFish->head.preLogits), (size_t)c.vocab * 2));
+                    KF_TRY(kf_set_state(ctx, d_state + 4 * s, prompts[(size_t)q.req * stride + q.len - 1], q.len - 1));
+                    KF_TRY(draw(s));
+                }
+                if (eos >= 0) {
+                    int32_t first;
+                    KF_TRY(kf_d2h(ctx, &first, d_tokens_out + (size_t)s * c.n_ctx + (q.len - 1), 4));
+                    if (first == eos) q.want = 1;
+                }
+                if (q.have >= q.want) { KF_TRY(finish(s, q.want)); s--; continue; }  // a one-id answer: the slot takes the next prompt at once
+                KF_TRY(Park(s, false));
             }
-            if (eos >= 0) {
-                int32_t first;
-                KF_TRY(kf_d2h(ctx, &first, d_tokens_out + (size_t)s * c.n_ctx + (q.len - 1), 4));
-                if (first == eos) q.want = 1;
-            }
-            if (q.have >= q.want) { KF_TRY(finish(s, q.want)); s--; continue; }  // a one-id answer: the slot takes the next prompt at once
-            KF_TRY(Park(s, false));
-        }
-        int k = sampled ? 1 : steps_per_launch, active = 0;
-        for (int s = 0; s < n_seq; s++)
-            if (slot[s].req >= 0) active++, k = slot[s].want - slot[s].have < k ? slot[s].want - slot[s].have : k;
-        if (!active) continue;
-        KF_TRY(kf_xengine_steps(ctx, engine, ToX(x), d_state, k, sampled ? 0 : 1));
-        if (sampled)
+            int k = sampled ? 1 : steps_per_launch, active = 0;
             for (int s = 0; s < n_seq; s++)
-                if (slot[s].req >= 0) KF_TRY(draw(s));
-        st[0]++, st[1] += k, steps_run += k;
-        for (int s = 0; s < n_seq; s++) {
-            Slot& q = slot[s];
-            if (q.req < 0) continue;
-            const int had = q.have;
-            q.have += k;
-            int n_ids = q.have >= q.want ? q.want : -1;
-            if (eos >= 0) {
-                KF_TRY(kf_d2h(ctx, row.data(), d_tokens_out + (size_t)s * c.n_ctx + (q.len - 1 + had), (size_t)k * 4));
-                for (int i = 0; i < k; i++)
-                    if (row[i] == eos) { n_ids = had + i + 1; break; }
+                if (slot[s].req >= 0) active++, k = slot[s].want - slot[s].have < k ? slot[s].want - slot[s].have : k;
+            if (!active) continue;
+            KF_TRY(kf_xengine_steps(ctx, engine, ToX(x), d_state, k, sampled ? 0 : 1));
+            if (sampled)
+                for (int s = 0; s < n_seq; s++)
+                    if (slot[s].req >= 0) KF_TRY(draw(s));
+            st[0]++, st[1] += k, steps_run += k;
+            for (int s = 0; s < n_seq; s++) {
+                Slot& q = slot[s];
+                if (q.req < 0) continue;
+                const int had = q.have;
+                q.have += k;
+                int n_ids = q.have >= q.want ? q.want : -1;
+                if (eos >= 0) {
+                    KF_TRY(kf_d2h(ctx, row.data(), d_tokens_out + (size_t)s * c.n_ctx + (q.len - 1 + had), (size_t)k * 4));
+                    for (int i = 0; i < k; i++)
+                        if (row[i] == eos) { n_ids = had + i + 1; break; }
+                }
+                if (n_ids >= 0) KF_TRY(finish(s, n_ids));
             }
-            if (n_ids >= 0) KF_TRY(finish(s, n_ids));
         }
+        return KF_OK;
+    };
+    const int rc = serve();
+    for (int s = 0; s < n_seq; s++) { /* whatever happened, the object leaves as it came: every slot free running */
+        const int r2 = Park(s, false);
+        if (rc == KF_OK && r2 != KF_OK) return r2;
     }
-    for (int s = 0; s < n_seq; s++) KF_TRY(Park(s, false));
     if (stats) for (int i = 0; i < 4; i++) stats[i] = st[i];
-    return Check();
+    return rc != KF_OK ? rc : Check();
 }
 int XcdReplicas::Check() {
     if (!engine) return KF_OK;
