@@ -721,6 +721,46 @@ __global__ void __launch_bounds__(256) quantize_kernel(const uint16_t* __restric
         }
     }
 }
+// The same for the storage every 4-bit model here uses (RTN, groups of 128, asymmetric or symmetric), HBM-shaped: 16 lanes per group, a lane takes 8 consecutive elements
+// as ONE 16-byte load, min / max over its 8 then four xor-shuffles inside the 16 lanes; its 8 codes are one dword of the Packed128 block (element i < 16 in `high`
+// = bytes 8..15, MSB first: elements 8 j .. 8 j + 7 of a block are the dword at byte 4 (3 - j)), stored as such -- a wave writes 256 contiguous bytes.  Same arithmetic
+// as quantize_kernel (fp32 min / max, IEEE division, roundf), same bits; the re-quantisation of a training step's matrices ran at 0.6 TB/s through the general kernel.
+__global__ void __launch_bounds__(256) quantize4_g128_kernel(const uint16_t* __restrict__ src, unsigned char* __restrict__ packed, uint16_t* __restrict__ zero_out,
+                                                             uint16_t* __restrict__ step_out, size_t nGroup, int mode, int qMin, int qMax, int qBias) {
+    const int lane = threadIdx.x & 63, sub = lane & 15;
+    const size_t g = ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const bool live = g < nGroup;
+    u32x4 raw = u32x4{0, 0, 0, 0};
+    if (live) raw = *reinterpret_cast<const u32x4*>(src + g * 128 + sub * 8);
+    const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+    float a[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) a[2 * k] = bf_lo(w[k]), a[2 * k + 1] = bf_hi(w[k]);
+    float vmax = -3.402823466e+38f, vmin = 3.402823466e+38f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) vmax = fmaxf(vmax, a[k]), vmin = fminf(vmin, a[k]);
+#pragma unroll
+    for (int m = 8; m > 0; m >>= 1) {
+        vmax = fmaxf(vmax, __shfl_xor(vmax, m, 64));
+        vmin = fminf(vmin, __shfl_xor(vmin, m, 64));
+    }
+    float step, zero;
+    if (mode == 1)
+        step = fmaxf(fabsf(vmax), fabsf(vmin)) / (float)qMax, zero = 0.f;
+    else
+        step = (vmax - vmin) / (float)(qMax - qMin), zero = -vmin;
+    if (!live) return;
+    if (sub == 0) zero_out[g] = f2bf(zero), step_out[g] = f2bf(step);
+    uint32_t word = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        int q = (int)roundf((a[k] + zero) / step);
+        q = q < qMin ? qMin : (q > qMax ? qMax : q);
+        word |= (uint32_t)((q + qBias) & 15) << (28 - 4 * k);
+    }
+    // element e = 8 sub + k of the group: block e / 32 = sub >> 2, dword j = sub & 3 of the block -> byte 4 (3 - j)
+    *reinterpret_cast<uint32_t*>(packed + g * 64 + (size_t)(sub >> 2) * 16 + 4 * (3 - (sub & 3))) = word;
+}
 // bf16 -> f8e5m2 storage (Float2T<f8e5>, g_float.hpp:433-443; ToF8Ex huTensor.cu:821): float -> half round-to-nearest-even, keep the high byte
 __global__ void to_f8e5m2_kernel(const uint16_t* __restrict__ src, unsigned char* __restrict__ dst, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -746,6 +786,11 @@ int quantize_launch(hipStream_t st, const kf_weight* w, const uint16_t* src, int
     const size_t nGroup = n / w->lGroup;
     uint16_t* zero = const_cast<uint16_t*>(w->gama) + w->ne0 + w->ne1;
     uint16_t* step = zero + nGroup;
+    if (bits == 4 && w->lGroup == 128 && mode != 2 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)w->data & 3) == 0) {
+        hipLaunchKernelGGL(quantize4_g128_kernel, dim3((unsigned)((nGroup + 15) / 16)), dim3(256), 0, st, src, (unsigned char*)const_cast<void*>(w->data), zero, step, nGroup, mode,
+                           w->qMin, w->qMax, w->qBias);
+        return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+    }
     hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)((nGroup + 3) / 4)), dim3(256), 0, st, src, (unsigned char*)const_cast<void*>(w->data), zero, step, nGroup,
                        w->lGroup, bits, mode, w->qMin, w->qMax, w->qBias);
     return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
