@@ -319,6 +319,10 @@ int kf_attn_backward(kf_ctx* ctx, const kf_bf16* q, const kf_bf16* k, const kf_b
 /* Embedding forward of a training batch (encoder_forward -> encoder_forward_kernel3, kernel/embed.cuh:20-45,372-376): out[bt][c] = bf16(wte[tokens[bt]][c] + wpe[bt % T][c]), fp32 sum, round to nearest.
  * wte rows ldw apart; an id outside [0, V) reads row 0. */
 int kf_embed_pos(kf_ctx* ctx, const kf_bf16* wte, long long ldw, const kf_bf16* wpe, const int32_t* tokens, int B, int T, int C, int V, kf_bf16* out);
+/* block b (b < n_blocks) of src, blocks src_stride bytes apart, copied to d_dst_table[b] + dst_offset -- d_dst_table is a DEVICE array of device pointers (16-byte aligned
+ * destinations); sizes, strides and the offset multiples of 16 bytes.  One launch scatters the K / V rows of a batch of prompts into the prompts' own caches
+ * (the reference re-aims K.out / V.out at the cache rows of ONE sequence, TGraph.cpp:198-207). */
+int kf_copy_blocks(kf_ctx* ctx, void* const* d_dst_table, size_t dst_offset, const void* src, size_t src_stride, size_t block_bytes, int n_blocks);
 /* value into `width` bytes of each of `rows` rows `pitch` bytes apart, on the context's stream (the padded logit columns of a step) */
 int kf_memset2d(kf_ctx* ctx, void* p, size_t pitch, int value, size_t width, size_t rows);
 

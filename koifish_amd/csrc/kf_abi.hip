@@ -1064,6 +1064,14 @@ int kf_embed_pos(kf_ctx* c, const kf_bf16* wte, long long ldw, const kf_bf16* wp
     if (r == KF_INVALID_ARGS) return fail(r, "kf_embed_pos: needs B, T, V >= 1, C a multiple of 8, ldw >= C a multiple of 8 (got %d %d %d %d %lld)", B, T, C, V, ldw);
     RET(r);
 }
+int kf_copy_blocks(kf_ctx* c, void* const* d_dst_table, size_t dst_offset, const void* src, size_t src_stride, size_t block_bytes, int n_blocks) {
+    CHKCTX(c);
+    if (!d_dst_table || !src) return fail(KF_INVALID_ARGS, "kf_copy_blocks: null pointer");
+    if (!al16(src)) return fail(KF_BLAS_UNALIGN, "kf_copy_blocks: src must be 16-byte aligned");
+    const int r = kf::copy_blocks_launch(c->stream, d_dst_table, dst_offset, src, src_stride, block_bytes, n_blocks);
+    if (r == KF_INVALID_ARGS) return fail(r, "kf_copy_blocks: 1 .. 65535 blocks, sizes / strides / offset multiples of 16 bytes");
+    RET(r);
+}
 int kf_memset2d(kf_ctx* c, void* p, size_t pitch, int value, size_t width, size_t rows) {
     CHKCTX(c);
     if (!p || width > pitch) return fail(KF_INVALID_ARGS, "kf_memset2d: null pointer or width > pitch");

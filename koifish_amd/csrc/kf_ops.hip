@@ -761,6 +761,22 @@ __global__ void __launch_bounds__(256) quantize4_g128_kernel(const uint16_t* __r
     // element e = 8 sub + k of the group: block e / 32 = sub >> 2, dword j = sub & 3 of the block -> byte 4 (3 - j)
     *reinterpret_cast<uint32_t*>(packed + g * 64 + (size_t)(sub >> 2) * 16 + 4 * (3 - (sub & 3))) = word;
 }
+// block b of src (blocks src_stride bytes apart) -> dst_table[b] + dst_offset: the K / V rows of a batch of prompts into the prompts' own caches (16-byte units)
+__global__ void __launch_bounds__(256) copy_blocks_kernel(void* const* __restrict__ dst_table, size_t dst_offset, const unsigned char* __restrict__ src, size_t src_stride,
+                                                          size_t block_bytes) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (i >= block_bytes) return;
+    unsigned char* d = reinterpret_cast<unsigned char*>(dst_table[blockIdx.y]) + dst_offset;
+    *reinterpret_cast<u32x4*>(d + i) = *reinterpret_cast<const u32x4*>(src + (size_t)blockIdx.y * src_stride + i);
+}
+int copy_blocks_launch(hipStream_t st, void* const* dst_table, size_t dst_offset, const void* src, size_t src_stride, size_t block_bytes, int n_blocks) {
+    if (n_blocks < 1 || n_blocks > 65535 || (block_bytes & 15) || (src_stride & 15) || (dst_offset & 15)) return KF_INVALID_ARGS;
+    if (!block_bytes) return KF_OK;
+    hipLaunchKernelGGL(copy_blocks_kernel, dim3((unsigned)((block_bytes / 16 + 255) / 256), n_blocks), dim3(256), 0, st, dst_table, dst_offset, (const unsigned char*)src, src_stride,
+                       block_bytes);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+
 // bf16 -> f8e5m2 storage (Float2T<f8e5>, g_float.hpp:433-443; ToF8Ex huTensor.cu:821): float -> half round-to-nearest-even, keep the high byte
 __global__ void to_f8e5m2_kernel(const uint16_t* __restrict__ src, unsigned char* __restrict__ dst, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -694,8 +694,41 @@ int Fish::Prefill(const int* tokens, int n, int pos0) {
     if (n < 1 || pos0 < 0 || pos0 + n > config.n_ctx) return KF_INVALID_ARGS;
     for (int i = 0; i < n; i++)
         if (tokens[i] < 0 || tokens[i] >= config.vocab) return KF_INVALID_ARGS;
-    const int PC = prefill_chunk < config.n_ctx ? prefill_chunk : config.n_ctx, C = config.nEmbed, qd = config.n_head * config.head_dim;
+    const int PC = prefill_chunk < config.n_ctx ? prefill_chunk : config.n_ctx, C = config.nEmbed;
+    KF_TRY(PrefillReady());
+    floatX* bx = ToX(gBUFF.bX);
+    kf_weight we = embed.w->desc();
+    int m = 0;
+    for (int c0 = 0; c0 < n; c0 += PC) {
+        m = n - c0 < PC ? n - c0 : PC;
+        KF_TRY(kf_h2d(ctx, gBUFF.d_ptok, tokens + c0, (size_t)m * 4));
+        KF_TRY(kf_embed_batch(ctx, &we, gBUFF.d_ptok, m, bx));
+        for (int l = 0; l < config.nLayer; l++) {
+            KF_TRY(attn[l]->cuFlow(bx, pos0 + c0, m));
+            KF_TRY(ffn[l]->cuFlow(bx, m));
+        }
+    }
+    // head on the last token; the state update leaves {next token, pos0 + n}
+    KF_TRY(kf_d2d(ctx, x->data, bx + (size_t)(m - 1) * C, (size_t)C * 2));
+    KF_TRY(SetState(tokens[n - 1], pos0 + n - 1));
+    tok_pos = pos0 + n - 1;
+    return HeadAndPick(ToX(x));
+}
+
+// the token-batch buffers ([prefill_chunk rows]) and the tile kernels' scratch / resident copies: allocated by the first prefill, never inside a later one
+int Fish::PrefillReady(int min_rows) {
+    int PC = prefill_chunk < config.n_ctx ? prefill_chunk : config.n_ctx; /* one prompt never has more rows than the context; a batch of prompts (XcdReplicas::PrefillBatch) may */
+    const int C = config.nEmbed, qd = config.n_head * config.head_dim;
+    if (min_rows > prefill_chunk) return KF_INVALID_ARGS;
+    PC = min_rows > PC ? min_rows : PC;
+    if (gBUFF.bX && gBUFF.rows < PC) { /* a later, larger batch: the buffers grow once (never inside a captured region: prefill launches are eager) */
+        KF_TRY(kf_sync(ctx));
+        gBUFF.bX.reset(), gBUFF.bNorm.reset(), gBUFF.bQ.reset(), gBUFF.bAttn.reset(), gBUFF.bGate.reset(), gBUFF.bUp.reset();
+        kf_free(ctx, gBUFF.d_ptok), gBUFF.d_ptok = nullptr;
+        if (!deq_arena) resident_tried = false; /* the larger batch may be one the resident bf16 copies serve (>= 1024 rows) */
+    }
     if (!gBUFF.bX) {
+        gBUFF.rows = PC;
         gBUFF.bX = GT(ctx, "bX", typNUMBER::BF16, C, PC);
         gBUFF.bNorm = GT(ctx, "bNorm", typNUMBER::BF16, C, PC);
         gBUFF.bQ = GT(ctx, "bQ", typNUMBER::BF16, qd, PC);
@@ -722,24 +755,7 @@ int Fish::Prefill(const int* tokens, int n, int pos0) {
             }
         }
     }
-    KF_TRY(EnsureResident(PC));
-    floatX* bx = ToX(gBUFF.bX);
-    kf_weight we = embed.w->desc();
-    int m = 0;
-    for (int c0 = 0; c0 < n; c0 += PC) {
-        m = n - c0 < PC ? n - c0 : PC;
-        KF_TRY(kf_h2d(ctx, gBUFF.d_ptok, tokens + c0, (size_t)m * 4));
-        KF_TRY(kf_embed_batch(ctx, &we, gBUFF.d_ptok, m, bx));
-        for (int l = 0; l < config.nLayer; l++) {
-            KF_TRY(attn[l]->cuFlow(bx, pos0 + c0, m));
-            KF_TRY(ffn[l]->cuFlow(bx, m));
-        }
-    }
-    // head on the last token; the state update leaves {next token, pos0 + n}
-    KF_TRY(kf_d2d(ctx, x->data, bx + (size_t)(m - 1) * C, (size_t)C * 2));
-    KF_TRY(SetState(tokens[n - 1], pos0 + n - 1));
-    tok_pos = pos0 + n - 1;
-    return HeadAndPick(ToX(x));
+    return EnsureResident(gBUFF.rows);
 }
 
 int Fish::HeadAndPick(const floatX* x_last) {
@@ -799,6 +815,7 @@ XcdReplicas::~XcdReplicas() {
     if (d_forced) kf_free(ctx, d_forced);
     if (d_tokens_out) kf_free(ctx, d_tokens_out);
     if (d_rng) kf_free(ctx, d_rng);
+    if (d_dst) kf_free(ctx, d_dst);
 }
 size_t XcdReplicas::kv_seq_elems() const {
     const MODEL_CARD& c = hFish->config;
@@ -952,9 +969,75 @@ int XcdReplicas::Prefill(int seq, const int* tokens, int n) {
         } aim(hFish->cache, ToX(key) + (size_t)seq * kv_seq_elems(), ToX(val) + (size_t)seq * kv_seq_elems());
         KF_TRY(hFish->Prefill(tokens, n, 0));
     }
+    KF_TRY(kf_d2d(ctx, ToX(logits) + (size_t)seq * c.vocab, ToX(hFish->head.preLogits), (size_t)c.vocab * 2));   /* the last prompt token's logits */
     KF_TRY(kf_d2d(ctx, d_state + 4 * seq, hFish->d_state, 8));                                                   /* {the id picked behind the prompt, n} */
     KF_TRY(kf_memset(ctx, d_state + 4 * seq + 3, 0, 4));                                                         /* status: clear */
     KF_TRY(kf_d2d(ctx, d_tokens_out + (size_t)seq * c.n_ctx + (n - 1), hFish->d_tokens_out + (n - 1), 4));      /* ids out: position n - 1 holds that id, as after decode steps */
+    return KF_OK;
+}
+int XcdReplicas::PrefillBatch(const int* slots, const int32_t* tokens, const int* lens, int S, int stride) {
+    Fish* f = hFish;
+    const MODEL_CARD& c = f->config;
+    kf_ctx* ctx = f->ctx;
+    if (!slots || !tokens || !lens || S < 1 || S > n_seq || stride < 1) return KF_INVALID_ARGS;
+    int T = 0;
+    for (int i = 0; i < S; i++) {
+        if (slots[i] < 0 || slots[i] >= n_seq || lens[i] < 1 || lens[i] > stride || lens[i] >= c.n_ctx) return KF_INVALID_ARGS;
+        for (int j = 0; j < i; j++)
+            if (slots[j] == slots[i]) return KF_INVALID_ARGS;
+        for (int t = 0; t < lens[i]; t++)
+            if (tokens[(size_t)i * stride + t] < 0 || tokens[(size_t)i * stride + t] >= c.vocab) return KF_INVALID_ARGS;
+        T = lens[i] > T ? lens[i] : T;
+    }
+    /* rows of a prompt behind its end (padding up to the batch's longest): finite values that nobody reads before a decode step rewrites them */
+    const int R = S * T, C = c.nEmbed;
+    const int qd = c.n_head * c.head_dim, kvd = c.n_head_kv * c.head_dim;
+    if (T >= c.n_ctx || R > f->prefill_chunk) return KF_INVALID_ARGS;
+    KF_TRY(Fresh());
+    KF_TRY(f->PrefillReady(R));
+    if (!bK || bK->ne[1] < R) {
+        KF_TRY(kf_sync(ctx));
+        const int rows = f->gBUFF.rows;
+        bK = GT(ctx, "xr.bK", typNUMBER::BF16, kvd, rows), bV = GT(ctx, "xr.bV", typNUMBER::BF16, kvd, rows);
+        if (!bK || !bV) return KF_OUTOF_GPUMEMORY;
+        if (!d_dst) KF_TRY(kf_malloc(ctx, (size_t)2 * n_seq * sizeof(void*), (void**)&d_dst));
+    }
+    std::vector<int32_t> rows((size_t)R, 0);
+    std::vector<void*> dst((size_t)2 * n_seq, nullptr);
+    for (int i = 0; i < S; i++) {
+        memcpy(rows.data() + (size_t)i * T, tokens + (size_t)i * stride, (size_t)lens[i] * 4);
+        dst[i] = ToX(key) + (size_t)slots[i] * kv_seq_elems(), dst[n_seq + i] = ToX(val) + (size_t)slots[i] * kv_seq_elems();
+    }
+    KF_TRY(kf_h2d(ctx, f->gBUFF.d_ptok, rows.data(), (size_t)R * 4));
+    KF_TRY(kf_h2d(ctx, d_dst, dst.data(), dst.size() * sizeof(void*)));
+    floatX *bx = ToX(f->gBUFF.bX), *bn = ToX(f->gBUFF.bNorm), *bq = ToX(f->gBUFF.bQ), *ba = ToX(f->gBUFF.bAttn), *bk = ToX(bK), *bv = ToX(bV);
+    kf_weight we = f->embed.w->desc();
+    KF_TRY(kf_embed_batch(ctx, &we, f->gBUFF.d_ptok, R, bx));
+    for (int l = 0; l < c.nLayer; l++) {
+        SelfAttention& a = *f->attn[l];
+        kf_weight wq = a.Q.w->desc(), wk = a.K.w->desc(), wv = a.V.w->desc(), wo = a.proj_cat.w->desc();
+        const kf_weight* ws[3] = {&wq, &wk, &wv};
+        kf_bf16* ys[3] = {bq, bk, bv};
+        KF_TRY(kf_rmsnorm(ctx, bx, ToX(a.norm.w), bn, R, C, a.norm.rms_eps, nullptr));
+        KF_TRY(kf_linear_multi(ctx, 3, ws, bn, ys, R));
+        KF_TRY(kf_qknorm_rope_train(ctx, bq, bk, a.normQ.w ? ToX(a.normQ.w) : nullptr, a.normK.w ? ToX(a.normK.w) : nullptr, f->rope_table, R, T, qd, kvd, c.n_head, c.n_head_kv,
+                                    c.head_dim, a.normQ.rms_eps, nullptr, nullptr)); /* positions restart with every prompt */
+        KF_TRY(kf_attn_prefill_batch(ctx, bq, bk, bv, ba, T, qd, c.n_head, c.n_head_kv, c.head_dim, kvd, S)); /* the rows of a prompt see that prompt's keys only */
+        const size_t off = (size_t)l * c.n_ctx * kvd * 2, blk = (size_t)T * kvd * 2;
+        KF_TRY(kf_copy_blocks(ctx, d_dst, off, bk, blk, blk, S));
+        KF_TRY(kf_copy_blocks(ctx, d_dst + n_seq, off, bv, blk, blk, S));
+        KF_TRY(kf_linear(ctx, &wo, ba, bx, nullptr, R, 1.0f, 0.0f, KF_EPI_RESIDUAL, bx));
+        KF_TRY(f->ffn[l]->cuFlow(bx, R));
+    }
+    // the head on every prompt's last row: state {last prompt token, len - 1} -> {picked id, len}, ids out [len - 1] = that id, the row's logits into the slot's
+    kf_weight wh = f->head.proj.w->desc();
+    for (int i = 0; i < S; i++) {
+        const int s = slots[i], n = lens[i];
+        KF_TRY(kf_set_state(ctx, d_state + 4 * s, tokens[(size_t)i * stride + n - 1], n - 1));
+        KF_TRY(kf_memset(ctx, d_state + 4 * s + 3, 0, 4));
+        KF_TRY(kf_norm_lm_head(ctx, bx + ((size_t)i * T + n - 1) * C, ToX(f->final_norm.w), f->final_norm.rms_eps, &wh, ToX(logits) + (size_t)s * c.vocab, d_state + 4 * s,
+                               d_tokens_out + (size_t)s * c.n_ctx, f->gBUFF.head_ws->data));
+    }
     return KF_OK;
 }
 int XcdReplicas::RunSteps(int n) {
@@ -1007,29 +1090,49 @@ int XcdReplicas::Chat(const int32_t* prompts, const int32_t* prompt_len, int n_r
     };
     auto serve = [&]() -> int {
         while (done < n_req) {
-            for (int s = 0; s < n_seq && next < n_req; s++) {
-                Slot& q = slot[s];
-                if (q.req >= 0) continue;
-                q.req = next++, q.len = prompt_len[q.req], q.have = 1;  // the prefill picks the answer's first id
-                const int room = c.n_ctx - q.len;                       // the ids the cache has rows for: the id behind row p needs row p
-                q.want = max_new < room + 1 ? max_new : room + 1;
-                KF_TRY(kf_h2d(ctx, d_forced + (size_t)s * c.n_ctx, none.data(), (size_t)c.n_ctx * 4));
-                KF_TRY(Prefill(s, prompts + (size_t)q.req * stride, q.len));
-                st[2]++;
-                if (sampled) { /* the prefill left the last prompt token's logits in the model's head buffer and picked greedily: draw the answer's first id instead */
-                    const uint64_t seed = samp_params.seed + (uint64_t)q.req;
-                    KF_TRY(kf_h2d(ctx, d_rng + s, &seed, 8));
-                    KF_TRY(kf_d2d(ctx, ToX(logits) + (size_t)s * c.vocab, ToX(hFish->head.preLogits), (size_t)c.vocab * 2));
-                    KF_TRY(kf_set_state(ctx, d_state + 4 * s, prompts[(size_t)q.req * stride + q.len - 1], q.len - 1));
-                    KF_TRY(draw(s));
+            for (bool again = true; again && next < n_req;) { /* refill: the free slots take the next prompts -- together (PrefillBatch) when several are free and asked for */
+                again = false;
+                std::vector<int> fs;
+                const int PC = hFish->prefill_chunk; /* rows of one token batch */
+                int tmax = 0;
+                for (int s = 0; s < n_seq && next + (int)fs.size() < n_req && (int)fs.size() < (prefill_batch > 1 ? prefill_batch : 1); s++) {
+                    if (slot[s].req >= 0) continue;
+                    const int len = prompt_len[next + (int)fs.size()], t2 = len > tmax ? len : tmax;
+                    if (!fs.empty() && (long long)(fs.size() + 1) * t2 > PC) break; /* the batch's rows fit the token-batch buffers */
+                    tmax = t2, fs.push_back(s);
                 }
-                if (eos >= 0) {
-                    int32_t first;
-                    KF_TRY(kf_d2h(ctx, &first, d_tokens_out + (size_t)s * c.n_ctx + (q.len - 1), 4));
-                    if (first == eos) q.want = 1;
+                if (fs.empty()) break;
+                const int m = (int)fs.size(), r0 = next;
+                for (int i = 0; i < m; i++) {
+                    Slot& q = slot[fs[i]];
+                    q.req = next++, q.len = prompt_len[q.req], q.have = 1;  // the prefill picks the answer's first id
+                    const int room = c.n_ctx - q.len;                       // the ids the cache has rows for: the id behind row p needs row p
+                    q.want = max_new < room + 1 ? max_new : room + 1;
+                    KF_TRY(kf_h2d(ctx, d_forced + (size_t)fs[i] * c.n_ctx, none.data(), (size_t)c.n_ctx * 4));
                 }
-                if (q.have >= q.want) { KF_TRY(finish(s, q.want)); s--; continue; }  // a one-id answer: the slot takes the next prompt at once
-                KF_TRY(Park(s, false));
+                if (m > 1)
+                    KF_TRY(PrefillBatch(fs.data(), prompts + (size_t)r0 * stride, prompt_len + r0, m, stride));
+                else
+                    KF_TRY(Prefill(fs[0], prompts + (size_t)r0 * stride, prompt_len[r0]));
+                st[2] += m;
+                for (int i = 0; i < m; i++) {
+                    const int s = fs[i];
+                    Slot& q = slot[s];
+                    if (sampled) { /* the prefill left the last prompt token's logits in the slot's logits and picked greedily: draw the answer's first id instead */
+                        const uint64_t seed = samp_params.seed + (uint64_t)q.req;
+                        KF_TRY(kf_h2d(ctx, d_rng + s, &seed, 8));
+                        KF_TRY(kf_set_state(ctx, d_state + 4 * s, prompts[(size_t)q.req * stride + q.len - 1], q.len - 1));
+                        KF_TRY(draw(s));
+                    }
+                    if (eos >= 0) {
+                        int32_t first;
+                        KF_TRY(kf_d2h(ctx, &first, d_tokens_out + (size_t)s * c.n_ctx + (q.len - 1), 4));
+                        if (first == eos) q.want = 1;
+                    }
+                    if (q.have >= q.want) { KF_TRY(finish(s, q.want)); continue; }  // a one-id answer: the slot takes another prompt at once
+                    KF_TRY(Park(s, false));
+                }
+                again = true; /* more free slots may be waiting (the batch limit, the buffer's rows, a one-id answer) */
             }
             int k = sampled ? 1 : steps_per_launch, active = 0;
             for (int s = 0; s < n_seq; s++)
@@ -1595,6 +1698,15 @@ int kfh_xr_prefill(void* h, int seq, const int* tokens, int n) { return reinterp
 int kfh_xr_run_steps(void* h, int n) { return reinterpret_cast<XcdReplicas*>(h)->RunSteps(n); }
 int kfh_xr_check(void* h) { return reinterpret_cast<XcdReplicas*>(h)->Check(); }
 int kfh_xr_park(void* h, int seq, int on) { return reinterpret_cast<XcdReplicas*>(h)->Park(seq, on != 0); }
+int kfh_xr_prefill_batch(void* h, const int* slots, const int32_t* tokens, const int* lens, int S, int stride) {
+    return reinterpret_cast<XcdReplicas*>(h)->PrefillBatch(slots, tokens, lens, S, stride);
+}
+int kfh_xr_set_prefill_batch(void* h, int n) {
+    XcdReplicas* r = reinterpret_cast<XcdReplicas*>(h);
+    if (n < 1 || n > r->n_seq) return KF_INVALID_ARGS;
+    r->prefill_batch = n;
+    return KF_OK;
+}
 int kfh_xr_set_sampler(void* h, float temperature, float top_p, int top_k, uint64_t seed) {
     CHAT_SAMPLER s;
     s.temperature = temperature, s.top_p = top_p, s.top_k = top_k & 0xFFFF, s.seed = seed;

@@ -165,6 +165,7 @@ struct MemBuffer {
     // token-batch (prefill) activations, [prefill_chunk, .] rows, allocated by the first Prefill
     hGTensor bX, bNorm, bQ, bAttn, bGate, bUp;
     int32_t* d_ptok = nullptr;
+    int rows = 0;       // rows of the token-batch buffers
 };
 
 // CHAT_SAMPLER (CLI_params.hpp:663-683): the fields GeneratOnPrompt::Sample reads.  temperature == 0 or top_k == 1 -> sample_argmax.
@@ -275,6 +276,7 @@ struct Fish {
     // afterwards the KV cache holds rows pos0..pos0+n-1, d_state = {greedy next token, pos0+n}, d_tokens_out[pos0+n-1] = that token.
     // The reference prefills token by token (Fish::Chat, GoPT.cpp:1139-1146); same arithmetic per token, fp32 sums in MFMA order.
     int Prefill(const int* tokens, int n, int pos0);
+    int PrefillReady(int min_rows = 0);  // the token-batch buffers ([rows >= min_rows]), scratch and resident copies: allocated by the first prefill, grown by a larger batch
     // rows per token batch (clamped to n_ctx).  Measured, Qwen3-0.6B 4-bit, prompt filling the context: 2047 tokens 20.9 / 15.5 / 9.8 ms at 512 / 1024 / 2048 rows,
     // 8191 tokens 92.3 / 53.9 / 42.7 / 36.6 ms at 1024 / 2048 / 4096 / 8192 (scratch/prefill_chunk.py): the tile kernels want many rows per launch.
     int prefill_chunk = 8192;
@@ -312,6 +314,13 @@ struct XcdReplicas {
     int RunSteps(int n);  // n greedy steps of EVERY sequence from wherever each stands; no host sync
     // a queue of prompts answered through the slots (Fish::Chat's rounds over DEBUG.prompts, GoPT.cpp:1111-1180, n_seq at once); see kf_host.cpp
     int Chat(const int32_t* prompts, const int32_t* prompt_len, int n_req, int stride, int max_new, int eos, int32_t* out, int32_t* out_len, long long* stats);
+    // S prompts at once (rows = S x T, T = the longest, shorter ones padded): ONE token batch through the tile kernels -- the rows of a prompt attend to that prompt only
+    // (kf_attn_prefill_batch), positions restart per prompt (kf_qknorm_rope_train), every prompt's K / V rows scattered into its slot's cache (kf_copy_blocks), the head on
+    // each prompt's last row.  What Fish::Chat's token-serial prefill loop (GoPT.cpp:1139-1146) does for one prompt, for S of them in the launches of one.
+    int PrefillBatch(const int* slots, const int32_t* tokens, const int* lens, int S, int stride);
+    int prefill_batch = 1;        // Chat: prompts prefilled together when several slots are free (1: one by one, the bits of Fish::Prefill)
+    hGTensor bK, bV;              // [rows, kv_dim] K / V rows of a prompt batch before they are scattered
+    void** d_dst = nullptr;       // [2][n_seq] device table of the scatter's destinations
     CHAT_SAMPLER samp_params;     // Chat's sampler (greedy by default); non-greedy: one launch per token, kf_sample per occupied slot
     uint64_t* d_rng = nullptr;    // [n_seq] xorshift states, seeded per request (seed + request index)
     int SetSampler(const CHAT_SAMPLER& s);

@@ -405,9 +405,21 @@ class Qwen3:
             raise L.KFError("kfh_save_kun(%s) failed with %d: %s" % (path, rc, self.host.kfh_last_error().decode()))
 
     def close(self):
+        """the objects built on this model (XcdReplicas / XcdTP: they read its context and weights when they go) are closed first"""
+        for d in list(getattr(self, "_dependents", ())):
+            try:
+                d.close()
+            except Exception:
+                pass
         if getattr(self, "h", None):
             self.host.kfh_destroy(self.h)
             self.h = None
+
+    def _depends(self, obj):
+        import weakref
+        if not hasattr(self, "_dependents"):
+            self._dependents = weakref.WeakSet()
+        self._dependents.add(obj)
 
     def __del__(self):
         try:
@@ -620,6 +632,7 @@ class XcdReplicas:
         if not h:
             raise L.KFError("kfh_xr_create failed with %d: %s" % (rc.value, self.host.kfh_host_error().decode() or self.hip.kf_last_error().decode()))
         self.h = C.c_void_p(h)
+        model._depends(self)
 
     def close(self):
         if getattr(self, "h", None):
@@ -664,6 +677,22 @@ class XcdReplicas:
     def park(self, seq, on=True):
         """a parked sequence is skipped by the launches; the others decode on"""
         L.check(self.host.kfh_xr_park(self.h, int(seq), int(bool(on))), "kfh_xr_park")
+
+    def prefill_batch(self, slots, prompts):
+        """several prompts at once (one token batch of len(prompts) x longest rows through the tile kernels; a prompt's rows attend to that prompt only): every prompt's
+        K / V rows into its slot's cache, the slot stands behind its prompt, the last prompt token's logits in the slot's logits"""
+        n = len(prompts)
+        lens = np.array([len(p) for p in prompts], dtype=np.int32)
+        stride = int(lens.max())
+        flat = np.zeros((n, stride), dtype=np.int32)
+        for i, p in enumerate(prompts):
+            flat[i, :len(p)] = p
+        sl = np.ascontiguousarray(slots, dtype=np.int32)
+        L.check(self.host.kfh_xr_prefill_batch(self.h, sl.ctypes.data_as(C.c_void_p), flat.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), n, stride), "kfh_xr_prefill_batch")
+
+    def set_prefill_batch(self, n):
+        """chat(): up to n waiting prompts are prefilled together when as many slots are free (1, the default: one by one -- the bits of the model's own prefill)"""
+        L.check(self.host.kfh_xr_set_prefill_batch(self.h, int(n)), "kfh_xr_set_prefill_batch")
 
     def set_sampler(self, temperature=0.0, top_p=0.95, top_k=50, seed=42, true_topk=False):
         """chat()'s sampler (CHAT_SAMPLER; greedy by default).  Non-greedy: one launch per token leaves every slot's logits, kf_sample draws each slot's id with the slot's own
@@ -752,6 +781,8 @@ class XcdTP:
         if not h:
             raise L.KFError("kfh_xtp_create failed with %d: %s" % (rc.value, self.host.kfh_host_error().decode() or self.hip.kf_last_error().decode()))
         self.h = C.c_void_p(h)
+        for m in native_tp.ranks:
+            m._depends(self)
 
     def close(self):
         if getattr(self, "h", None):

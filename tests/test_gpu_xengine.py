@@ -612,8 +612,81 @@ def test_a_queue_of_prompts_through_the_slots(canon, n_seq, n_req):
     xr.set_sampler()
     got, _ = xr.chat(prompts[:5], max_new)
     assert got == ref[:5]
+    # prompts prefilled together when several slots are free (set_prefill_batch): one token batch per refill -- the batch sums in MFMA order over more rows, so the bar is
+    # tests/test_gpu_prefill.py's (ids identical on the committed seeds), not bits
+    xr.set_prefill_batch(8)
+    got, st = xr.chat(prompts, max_new)
+    assert st["prefills"] == n_req and [len(a) for a in got] == [len(a) for a in ref]
+    same = sum(a == b for a, b in zip(got, ref))
+    assert same >= 0.8 * n_req, "%d of %d answers equal the one-by-one prefill's" % (same, n_req)   # a near-tie may flip under the other summation order (w_std 0.1: spiky logits)
+    again, _ = xr.chat(prompts, max_new)
+    assert again == got                                                                             # the same batches, the same bits
+    xr.set_prefill_batch(1)
     # the object is as before the queue: all slots free running
     for s in range(n_seq):
         assert xr.status(s)[2] == 0
+    xr.close()
+    m.close()
+
+
+@pytest.mark.parametrize("lens,slots", [((5, 40, 17, 64, 33, 8), (3, 0, 7, 5, 1, 6)), ((64,) * 8, tuple(range(8))), ((100, 90, 3), (2, 6, 4))])
+def test_prefill_batch_vs_the_oracle(lens, slots):
+    """XcdReplicas.prefill_batch: several prompts as ONE token batch (ragged lengths padded to the longest; 8 x 64 = 512 rows takes the large-batch tile routes) -- a
+    prompt's rows attend to that prompt only, positions restart per prompt, every prompt's K / V rows land in ITS slot's cache.  Against the oracle's token-serial forward
+    of each prompt alone, at the bar of tests/test_gpu_prefill.py (token batches sum in MFMA order): K / V rows and the last logits within 2^-6 of scale, the picked id equal;
+    then all slots decode together, teacher-forced along the oracle's continuation, and the logits six steps behind every prompt meet the same bar.  Slots that took no
+    prompt keep their state."""
+    cfg = dict(synth.CONFIGS["small"], max_seq=128)
+    raw = synth.raw_weights_numpy(cfg, 1234, w_std=0.1)
+    m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
+    m.set_canonical(True)
+    xr = XcdReplicas(m, 8)
+    idle = [s for s in range(8) if s not in slots]
+    for s in idle:
+        xr.set_state(s, 7, 0)
+        xr.park(s)
+    prompts = [prompt_ids(cfg, n, seed=40 + i) for i, n in enumerate(lens)]
+    xr.prefill_batch(slots, prompts)
+    m.sync()
+    n_new = 6
+    TOL = 2.0 ** -6
+    om = oracle_model(cfg, raw, L.Q4, L.BF16)   # the reference's own order, as tests/test_gpu_prefill.py
+    want_ids = {}
+    for p, s in zip(prompts, slots):
+        n = len(p)
+        nxt = lg = None
+        for pos, tok in enumerate(p):
+            nxt, lg, _ = om.decode(int(tok), pos)
+        ok, ov = om.kv()
+        gk, gv = xr.kv_to_host(s)
+        for g, o in ((gk, ok), (gv, ov)):
+            for l in range(cfg["n_layer"]):
+                a, b = O.bf16_to_f32(g[l, :n]), O.bf16_to_f32(o[l, :n])
+                assert np.abs(a - b).max() <= TOL * np.abs(b).max(), "slot %d layer %d K / V rows" % (s, l)
+        gl, ol = O.bf16_to_f32(xr.logits(s)), O.bf16_to_f32(lg)
+        assert np.abs(gl - ol).max() <= TOL * np.abs(ol).max(), "slot %d logits" % s
+        assert xr.state(s) == (nxt, n), "slot %d: state %s, the oracle picks %d" % (s, xr.state(s), nxt)
+        assert int(xr.tokens_out(s, n)[n - 1]) == nxt
+        f = np.full(cfg["max_seq"], -1, dtype=np.int32)   # the continuation teacher-forced along the oracle's own ids: the logits behind it read every prompt row of the slot
+        tok = nxt
+        for k in range(n_new):
+            f[n + k] = tok
+            tok, lg, _ = om.decode(int(tok), n + k)
+        xr.set_forced(s, f)
+        want_ids[s] = np.array(lg, copy=True)
+    om.close()
+    xr.run_steps(n_new)
+    m.sync()
+    xr.check()
+    for p, s in zip(prompts, slots):
+        gl, ol = O.bf16_to_f32(xr.logits(s)), O.bf16_to_f32(want_ids[s])
+        assert np.abs(gl - ol).max() <= TOL * np.abs(ol).max(), "slot %d: logits %d steps behind the prompt" % (s, n_new)
+        assert xr.state(s)[1] == len(p) + n_new
+    for s in idle:
+        assert xr.status(s)[:3] == [7, 0, 1]
+    with pytest.raises(Exception):
+        xr.prefill_batch((1, 1), prompts[:2])          # one slot twice
+    with pytest.raises(Exception):
+        xr.prefill_batch((0,), [prompt_ids(cfg, cfg["max_seq"], seed=1)])   # no row left behind the prompt
     xr.close()
     m.close()
