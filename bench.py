@@ -987,6 +987,23 @@ def xcd_replicas(m, cfg, forced, timed_positions, warmup, n_seq, ids_main, jump=
                         "generated_tokens_per_s": round(sum(len(a) for a in ans) / (t2 - t1), 1), "launches": qst["launches"], "prefills": qst["prefills"],
                         "note": "prefill of every request included; positions 128..255 (short context: a step moves fewer K / V rows than at the 2 k window the headline is quoted on)",
                         "parity": "tests/test_gpu_xengine.py::test_a_queue_of_prompts_through_the_slots (every answer == the model alone on that prompt; EOS cut)"}
+            # the same queue with the waiting prompts prefilled TOGETHER (XcdReplicas::PrefillBatch: one token batch of 16 x 128 rows on the tile kernels per refill)
+            pb = min(16, n_seq)
+            xr.set_prefill_batch(pb)
+            xr.prefill_batch(list(range(pb)), prompts_q[:pb])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                xr.prefill_batch(list(range(pb)), prompts_q[:pb])
+            torch.cuda.synchronize()
+            t_pb = (time.perf_counter() - t1) / 3
+            t1 = time.perf_counter()
+            ans, qst = xr.chat(prompts_q, 128)
+            t2 = time.perf_counter()
+            xr.set_prefill_batch(1)
+            chat_leg["prefill_batch"] = {"prompts_per_batch": pb, "batch_ms": round(t_pb * 1e3, 3), "ms_per_prompt": round(t_pb * 1e3 / pb, 3), "seconds": round(t2 - t1, 4),
+                                         "requests_per_s": round(n_req / (t2 - t1), 1), "generated_tokens_per_s": round(sum(len(a) for a in ans) / (t2 - t1), 1),
+                                         "parity": "tests/test_gpu_xengine.py::test_prefill_batch_vs_the_oracle (K / V rows, logits within 2^-6 of scale: token batches sum in MFMA order)"}
         except KeyError:
             chat_leg = None
         except Exception as e:
@@ -1494,6 +1511,8 @@ def _xcd_short(x):
     q = x.get("request_queue")
     if isinstance(q, dict) and "generated_tokens_per_s" in q:
         o["request_queue"] = _keep(q, ("requests", "prompt_tokens", "new_tokens", "requests_per_s", "generated_tokens_per_s"))
+        if isinstance(q.get("prefill_batch"), dict):
+            o["request_queue"]["prefill_batch"] = _keep(q["prefill_batch"], ("prompts_per_batch", "ms_per_prompt", "generated_tokens_per_s"))
     return o
 
 

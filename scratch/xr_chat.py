@@ -22,15 +22,26 @@ prompts = [rng.integers(0, cfg["vocab"], size=n_prompt).astype(np.int32) for _ i
 for n_seq in [int(x) for x in os.environ.get("NSEQ", "32").split(",")]:
     xr = XcdReplicas(m, n_seq)
     xr.set_steps_per_launch(int(os.environ.get("SPL", "32")))
-    xr.chat(prompts[:n_seq], 8)
-    best, st = 1e9, None
-    for rep in range(2):
+    for pb in [int(x) for x in os.environ.get("PB", "1").split(",")]:
+      xr.set_prefill_batch(min(pb, n_seq))
+      if pb > 1:   # the batch prefill alone
+        xr.prefill_batch(list(range(min(pb, n_seq))), prompts[:min(pb, n_seq)])
+        m.sync()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            xr.prefill_batch(list(range(min(pb, n_seq))), prompts[:min(pb, n_seq)])
+        m.sync()
+        dt = (time.perf_counter() - t0) / 5
+        print("   prefill_batch of %d x %d tokens: %.3f ms = %.3f ms per prompt" % (min(pb, n_seq), n_prompt, dt * 1e3, dt * 1e3 / min(pb, n_seq)), flush=True)
+      xr.chat(prompts[:n_seq], 8)
+      best, st = 1e9, None
+      for rep in range(2):
         m.sync()
         t0 = time.perf_counter()
         got, st = xr.chat(prompts, n_new)
         best = min(best, time.perf_counter() - t0)
-    assert all(len(g) == n_new for g in got)
-    print("n_seq %d: %d requests (%d-token prompt, %d new) in %.3f s: %.1f requests/s, %.1f generated tokens/s, %.1f prompt+generated tokens/s  %s" % (
-        n_seq, n_req, n_prompt, n_new, best, n_req / best, n_req * n_new / best, n_req * (n_prompt + n_new) / best, st), flush=True)
+      assert all(len(g) == n_new for g in got)
+      print("prefill batch %d  n_seq %d: %d requests (%d-token prompt, %d new) in %.3f s: %.1f requests/s, %.1f generated tokens/s, %.1f prompt+generated tokens/s  %s" % (
+        pb, n_seq, n_req, n_prompt, n_new, best, n_req / best, n_req * n_new / best, n_req * (n_prompt + n_new) / best, st), flush=True)
     xr.close()
 m.close()
