@@ -319,6 +319,10 @@ int kf_attn_backward(kf_ctx* ctx, const kf_bf16* q, const kf_bf16* k, const kf_b
 /* Embedding forward of a training batch (encoder_forward -> encoder_forward_kernel3, kernel/embed.cuh:20-45,372-376): out[bt][c] = bf16(wte[tokens[bt]][c] + wpe[bt % T][c]), fp32 sum, round to nearest.
  * wte rows ldw apart; an id outside [0, V) reads row 0. */
 int kf_embed_pos(kf_ctx* ctx, const kf_bf16* wte, long long ldw, const kf_bf16* wpe, const int32_t* tokens, int B, int T, int C, int V, kf_bf16* out);
+/* The greedy pick (sample_argmax, GoPT.cpp:602-612: first maximum over float(logits)) of n_rows rows of bf16 logits [n] (rows ld apart) at once, each followed by the
+ * decode-state update of kf_norm_lm_head for sequence d_seq[row] of a [n_seq][4] state array {token, pos, ..}: d_tokens_out[seq * tokens_stride + pos] = id (when non-NULL),
+ * state = {id, pos + 1}.  The head of a batch of prompts: ONE product over the rows' hidden states (kf_linear), one pick launch. */
+int kf_argmax_rows_state(kf_ctx* ctx, const kf_bf16* logits, long long ld, int n, int n_rows, const int32_t* d_seq, int32_t* d_states, int32_t* d_tokens_out, int tokens_stride);
 /* block b (b < n_blocks) of src, blocks src_stride bytes apart, copied to d_dst_table[b] + dst_offset -- d_dst_table is a DEVICE array of device pointers (16-byte aligned
  * destinations); sizes, strides and the offset multiples of 16 bytes.  One launch scatters the K / V rows of a batch of prompts into the prompts' own caches
  * (the reference re-aims K.out / V.out at the cache rows of ONE sequence, TGraph.cpp:198-207). */

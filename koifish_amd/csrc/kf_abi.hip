@@ -1064,6 +1064,13 @@ int kf_embed_pos(kf_ctx* c, const kf_bf16* wte, long long ldw, const kf_bf16* wp
     if (r == KF_INVALID_ARGS) return fail(r, "kf_embed_pos: needs B, T, V >= 1, C a multiple of 8, ldw >= C a multiple of 8 (got %d %d %d %d %lld)", B, T, C, V, ldw);
     RET(r);
 }
+int kf_argmax_rows_state(kf_ctx* c, const kf_bf16* logits, long long ld, int n, int n_rows, const int32_t* d_seq, int32_t* d_states, int32_t* d_tokens_out, int tokens_stride) {
+    CHKCTX(c);
+    if (!logits || !d_seq || !d_states) return fail(KF_INVALID_ARGS, "kf_argmax_rows_state: null pointer");
+    const int r = kf::argmax_rows_state_launch(c->stream, logits, ld, n, n_rows, d_seq, d_states, d_tokens_out, tokens_stride);
+    if (r == KF_INVALID_ARGS) return fail(r, "kf_argmax_rows_state: needs n, n_rows >= 1 and ld >= n");
+    RET(r);
+}
 int kf_copy_blocks(kf_ctx* c, void* const* d_dst_table, size_t dst_offset, const void* src, size_t src_stride, size_t block_bytes, int n_blocks) {
     CHKCTX(c);
     if (!d_dst_table || !src) return fail(KF_INVALID_ARGS, "kf_copy_blocks: null pointer");

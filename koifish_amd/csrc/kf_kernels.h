@@ -209,6 +209,7 @@ int attn_backward_mfma_launch(hipStream_t st, const uint16_t* q, const uint16_t*
                               uint16_t* dq, uint16_t* dk, uint16_t* dv, long long ld_d, int T, int n_head, int hd, int n_seq, float* scratch, int n_kv, long long ld_kv,
                               long long ld_dkv); /* kf_attn_bwd_mfma.hip: 1 = not covered */
 // embedding backward (kf_embed_bwd.hip)
+int argmax_rows_state_launch(hipStream_t st, const uint16_t* logits, long long ld, int n, int n_rows, const int* d_seq, int32_t* states, int32_t* tokens_out, int tokens_stride);
 int copy_blocks_launch(hipStream_t st, void* const* dst_table, size_t dst_offset, const void* src, size_t src_stride, size_t block_bytes, int n_blocks);
 int embed_pos_launch(hipStream_t st, const uint16_t* wte, long long ldw, const uint16_t* wpe, const int* tokens, int B, int T, int C, int V, uint16_t* out);
 int embed_backward_launch(hipStream_t st, uint16_t* dwte, long long ldw, uint16_t* dwpe, const uint16_t* dout, const int* tokens, int B, int T, int C, int V);

@@ -761,6 +761,43 @@ __global__ void __launch_bounds__(256) quantize4_g128_kernel(const uint16_t* __r
     // element e = 8 sub + k of the group: block e / 32 = sub >> 2, dword j = sub & 3 of the block -> byte 4 (3 - j)
     *reinterpret_cast<uint32_t*>(packed + g * 64 + (size_t)(sub >> 2) * 16 + 4 * (3 - (sub & 3))) = word;
 }
+// greedy pick over each of n_rows rows of bf16 logits (sample_argmax, GoPT.cpp:602-612: the FIRST maximum over float(logits)), one workgroup per row, followed by the
+// decode-state update of kf_norm_lm_head for the sequence d_seq[row]: states [seq][4] = {token, pos, ..}: tokens_out[seq][pos] = id, state = {id, pos + 1}
+__global__ void __launch_bounds__(1024) argmax_rows_state_kernel(const uint16_t* __restrict__ logits, long long ld, int n, const int* __restrict__ d_seq, int32_t* __restrict__ states,
+                                                                 int32_t* __restrict__ tokens_out, int tokens_stride) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    const uint16_t* row = logits + (size_t)blockIdx.x * ld;
+    float best = -__builtin_inff();
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += 1024) { /* ascending i per thread: a strict > keeps the thread's first maximum */
+        const float v = bf2f(row[i]);
+        if (v > best || bi == 0x7fffffff) best = v, bi = i;
+    }
+    auto better = [](float v, int i, float bv, int bi2) { return v > bv || (v == bv && i < bi2); };
+    for (int m = 32; m > 0; m >>= 1) {
+        const float ov = __shfl_xor(best, m, 64);
+        const int oi = __shfl_xor(bi, m, 64);
+        if (better(ov, oi, best, bi)) best = ov, bi = oi;
+    }
+    if ((threadIdx.x & 63) == 0) sv[threadIdx.x >> 6] = best, si[threadIdx.x >> 6] = bi;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; w++)
+            if (better(sv[w], si[w], best, bi)) best = sv[w], bi = si[w];
+        const int seq = d_seq[blockIdx.x];
+        int32_t* st = states + 4 * (size_t)seq;
+        const int p = st[1];
+        if (tokens_out) tokens_out[(size_t)seq * tokens_stride + p] = bi;
+        st[0] = bi, st[1] = p + 1;
+    }
+}
+int argmax_rows_state_launch(hipStream_t st, const uint16_t* logits, long long ld, int n, int n_rows, const int* d_seq, int32_t* states, int32_t* tokens_out, int tokens_stride) {
+    if (n < 1 || n_rows < 1 || ld < n) return KF_INVALID_ARGS;
+    hipLaunchKernelGGL(argmax_rows_state_kernel, dim3(n_rows), dim3(1024), 0, st, logits, ld, n, d_seq, states, tokens_out, tokens_stride);
+    return hipGetLastError() == hipSuccess ? KF_OK : KF_HIP_CHECK;
+}
+
 // block b of src (blocks src_stride bytes apart) -> dst_table[b] + dst_offset: the K / V rows of a batch of prompts into the prompts' own caches (16-byte units)
 __global__ void __launch_bounds__(256) copy_blocks_kernel(void* const* __restrict__ dst_table, size_t dst_offset, const unsigned char* __restrict__ src, size_t src_stride,
                                                           size_t block_bytes) {

@@ -1000,16 +1000,22 @@ int XcdReplicas::PrefillBatch(const int* slots, const int32_t* tokens, const int
         const int rows = f->gBUFF.rows;
         bK = GT(ctx, "xr.bK", typNUMBER::BF16, kvd, rows), bV = GT(ctx, "xr.bV", typNUMBER::BF16, kvd, rows);
         if (!bK || !bV) return KF_OUTOF_GPUMEMORY;
-        if (!d_dst) KF_TRY(kf_malloc(ctx, (size_t)2 * n_seq * sizeof(void*), (void**)&d_dst));
+        if (!d_dst) KF_TRY(kf_malloc(ctx, (size_t)3 * n_seq * sizeof(void*) + (size_t)n_seq * 4, (void**)&d_dst)); /* three tables of destinations (K, V, logits) + the slots */
+        if (!bL) bL = GT(ctx, "xr.bL", typNUMBER::BF16, c.vocab, n_seq);
+        if (!bL) return KF_OUTOF_GPUMEMORY;
     }
     std::vector<int32_t> rows((size_t)R, 0);
-    std::vector<void*> dst((size_t)2 * n_seq, nullptr);
+    std::vector<void*> dst((size_t)3 * n_seq + (n_seq + 1) / 2, nullptr); /* the slots ride behind the pointer tables as int32 */
+    int32_t* h_slots = reinterpret_cast<int32_t*>(dst.data() + (size_t)3 * n_seq);
     for (int i = 0; i < S; i++) {
         memcpy(rows.data() + (size_t)i * T, tokens + (size_t)i * stride, (size_t)lens[i] * 4);
         dst[i] = ToX(key) + (size_t)slots[i] * kv_seq_elems(), dst[n_seq + i] = ToX(val) + (size_t)slots[i] * kv_seq_elems();
+        dst[2 * n_seq + i] = ToX(logits) + (size_t)slots[i] * c.vocab;
+        h_slots[i] = slots[i];
     }
+    const int32_t* d_slots = reinterpret_cast<const int32_t*>(d_dst + (size_t)3 * n_seq);
     KF_TRY(kf_h2d(ctx, f->gBUFF.d_ptok, rows.data(), (size_t)R * 4));
-    KF_TRY(kf_h2d(ctx, d_dst, dst.data(), dst.size() * sizeof(void*)));
+    KF_TRY(kf_h2d(ctx, d_dst, dst.data(), (size_t)3 * n_seq * sizeof(void*) + (size_t)n_seq * 4));
     floatX *bx = ToX(f->gBUFF.bX), *bn = ToX(f->gBUFF.bNorm), *bq = ToX(f->gBUFF.bQ), *ba = ToX(f->gBUFF.bAttn), *bk = ToX(bK), *bv = ToX(bV);
     kf_weight we = f->embed.w->desc();
     KF_TRY(kf_embed_batch(ctx, &we, f->gBUFF.d_ptok, R, bx));
@@ -1030,13 +1036,23 @@ int XcdReplicas::PrefillBatch(const int* slots, const int32_t* tokens, const int
         KF_TRY(f->ffn[l]->cuFlow(bx, R));
     }
     // the head on every prompt's last row: state {last prompt token, len - 1} -> {picked id, len}, ids out [len - 1] = that id, the row's logits into the slot's
+    // (the head matrix -- 311 MB on Qwen3-0.6B -- is read ONCE for all prompts: the last rows normed side by side, one product, one pick launch, one scatter of the logits)
     kf_weight wh = f->head.proj.w->desc();
+    const bool together = S > 1 && c.vocab % 8 == 0;
     for (int i = 0; i < S; i++) {
         const int s = slots[i], n = lens[i];
         KF_TRY(kf_set_state(ctx, d_state + 4 * s, tokens[(size_t)i * stride + n - 1], n - 1));
         KF_TRY(kf_memset(ctx, d_state + 4 * s + 3, 0, 4));
-        KF_TRY(kf_norm_lm_head(ctx, bx + ((size_t)i * T + n - 1) * C, ToX(f->final_norm.w), f->final_norm.rms_eps, &wh, ToX(logits) + (size_t)s * c.vocab, d_state + 4 * s,
-                               d_tokens_out + (size_t)s * c.n_ctx, f->gBUFF.head_ws->data));
+        if (together)
+            KF_TRY(kf_rmsnorm(ctx, bx + ((size_t)i * T + n - 1) * C, ToX(f->final_norm.w), bn + (size_t)i * C, 1, C, f->final_norm.rms_eps, nullptr));
+        else
+            KF_TRY(kf_norm_lm_head(ctx, bx + ((size_t)i * T + n - 1) * C, ToX(f->final_norm.w), f->final_norm.rms_eps, &wh, ToX(logits) + (size_t)s * c.vocab, d_state + 4 * s,
+                                   d_tokens_out + (size_t)s * c.n_ctx, f->gBUFF.head_ws->data));
+    }
+    if (together) {
+        KF_TRY(kf_linear(ctx, &wh, bn, ToX(bL), nullptr, S, 1.0f, 0.0f, 0u, nullptr));
+        KF_TRY(kf_argmax_rows_state(ctx, ToX(bL), c.vocab, c.vocab, S, d_slots, d_state, d_tokens_out, c.n_ctx));
+        KF_TRY(kf_copy_blocks(ctx, d_dst + 2 * n_seq, 0, ToX(bL), (size_t)c.vocab * 2, (size_t)c.vocab * 2, S));
     }
     return KF_OK;
 }

@@ -319,8 +319,8 @@ struct XcdReplicas {
     // each prompt's last row.  What Fish::Chat's token-serial prefill loop (GoPT.cpp:1139-1146) does for one prompt, for S of them in the launches of one.
     int PrefillBatch(const int* slots, const int32_t* tokens, const int* lens, int S, int stride);
     int prefill_batch = 1;        // Chat: prompts prefilled together when several slots are free (1: one by one, the bits of Fish::Prefill)
-    hGTensor bK, bV;              // [rows, kv_dim] K / V rows of a prompt batch before they are scattered
-    void** d_dst = nullptr;       // [2][n_seq] device table of the scatter's destinations
+    hGTensor bK, bV, bL;          // [rows, kv_dim] K / V rows of a prompt batch before they are scattered; [n_seq, vocab] the batch's logits
+    void** d_dst = nullptr;       // [3][n_seq] device tables of the scatters' destinations (K, V, logits), then the batch's slots as int32
     CHAT_SAMPLER samp_params;     // Chat's sampler (greedy by default); non-greedy: one launch per token, kf_sample per occupied slot
     uint64_t* d_rng = nullptr;    // [n_seq] xorshift states, seeded per request (seed + request index)
     int SetSampler(const CHAT_SAMPLER& s);

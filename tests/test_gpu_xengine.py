@@ -433,7 +433,7 @@ def test_qwen3_1p7b_shape_equals_the_oracle(canon, n_seq):
     raw = synth.raw_weights_numpy(cfg, 1717, w_std=0.05)
     m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
     m.set_canonical(True)
-    n_steps = 100
+    n_steps = 72
     xr = XcdReplicas(m, n_seq)
     forced = []
     for s in range(n_seq):
@@ -445,7 +445,7 @@ def test_qwen3_1p7b_shape_equals_the_oracle(canon, n_seq):
     xr.run_steps(n_steps)
     m.sync()
     xr.check()
-    for s in (0, 3, n_seq - 1):
+    for s in (0, n_seq - 5):   # two decoders; with 16 sequences the second place of a decoder
         o_ids, o_logits, ok, ov = _oracle_run(cfg, raw, forced[s], n_steps)
         assert xr.tokens_out(s, n_steps).tolist() == o_ids, "sequence %d" % s
         assert np.array_equal(xr.logits(s), o_logits)
@@ -457,12 +457,14 @@ def test_qwen3_1p7b_shape_equals_the_oracle(canon, n_seq):
 
 
 
-@pytest.mark.parametrize("name,variant", [("qwen3-4b", None), ("qwen3-8b", None), pytest.param("qwen3-4b", (8, 8), marks=SLOW)])
-def test_gqa4_shapes_equal_the_per_layer_launches_and_the_oracle(canon, name, variant):
+@pytest.mark.parametrize("name,variant,check", [("qwen3-4b", None, (0, 5)), ("qwen3-8b", None, (0, 5)), pytest.param("qwen3-4b", (8, 8), (0, 2, 5, 7), marks=SLOW),
+                                                pytest.param("qwen3-8b", None, (0, 2, 5, 7), marks=SLOW)])
+def test_gqa4_shapes_equal_the_per_layer_launches_and_the_oracle(canon, name, variant, check):
     """three layers of the Qwen3-4B / Qwen3-8B shapes (32 query heads on 8 kv-heads: four query heads per key tile; 24 of the 32 workgroups own q | k | v rows; the 9728- /
     12288-wide SwiGLU vector staged in pieces; 8B: the attention sums inside the second activation buffer) through the XCD-confined engines: eight sequences, ids at every
     position, last logits and K / V rows against the oracle; sequence 0 also through the per-layer launches of the same library.  variant: the 8-wave form (256 registers,
-    contiguous row runs per wave) instead of the default 12-wave one"""
+    contiguous row runs per wave) instead of the default 12-wave one; check: the sequences compared with the oracle (two by default, four with --kf-slow: the oracle at
+    these widths is most of the test's time)"""
     cfg = dict(GQA4_SHAPES[name])
     raw = synth.raw_weights_numpy(cfg, 4040, w_std=0.04)
     m = synth.build_from_raw(cfg, raw, L.Q4, L.BF16)
@@ -482,7 +484,7 @@ def test_gqa4_shapes_equal_the_per_layer_launches_and_the_oracle(canon, name, va
     xr.run_steps(n_steps)
     m.sync()
     xr.check()
-    for s in (0, 2, 5, 7):
+    for s in check:
         o_ids, o_logits, ok, ov = _oracle_run(cfg, raw, forced[s], n_steps)
         assert xr.tokens_out(s, n_steps).tolist() == o_ids, "sequence %d" % s
         assert np.array_equal(xr.logits(s), o_logits)
@@ -629,9 +631,9 @@ def test_a_queue_of_prompts_through_the_slots(canon, n_seq, n_req):
     m.close()
 
 
-@pytest.mark.parametrize("lens,slots", [((5, 40, 17, 64, 33, 8), (3, 0, 7, 5, 1, 6)), ((64,) * 8, tuple(range(8))), ((100, 90, 3), (2, 6, 4))])
+@pytest.mark.parametrize("lens,slots", [((5, 40, 17, 64, 33, 8), (3, 0, 7, 5, 1, 6)), ((40,) * 8, tuple(range(8))), ((100, 90, 3), (2, 6, 4))])
 def test_prefill_batch_vs_the_oracle(lens, slots):
-    """XcdReplicas.prefill_batch: several prompts as ONE token batch (ragged lengths padded to the longest; 8 x 64 = 512 rows takes the large-batch tile routes) -- a
+    """XcdReplicas.prefill_batch: several prompts as ONE token batch (ragged lengths padded to the longest; 8 x 40 = 320 rows takes the large-batch tile routes) -- a
     prompt's rows attend to that prompt only, positions restart per prompt, every prompt's K / V rows land in ITS slot's cache.  Against the oracle's token-serial forward
     of each prompt alone, at the bar of tests/test_gpu_prefill.py (token batches sum in MFMA order): K / V rows and the last logits within 2^-6 of scale, the picked id equal;
     then all slots decode together, teacher-forced along the oracle's continuation, and the logits six steps behind every prompt meet the same bar.  Slots that took no
