@@ -94,6 +94,8 @@ const char* kf_version(void);
 int kf_malloc(kf_ctx* ctx, size_t bytes, void** out);
 int kf_free(kf_ctx* ctx, void* p);
 int kf_memset(kf_ctx* ctx, void* p, int value, size_t bytes);
+/* `count` 32-bit words of `value`, on the context's stream, no host sync (kf_h2d synchronises: a flag or a seed set between launches goes through this) */
+int kf_memset32(kf_ctx* ctx, void* p, int32_t value, size_t count);
 int kf_h2d(kf_ctx* ctx, void* dst, const void* h_src, size_t bytes);
 int kf_d2h(kf_ctx* ctx, void* h_dst, const void* src, size_t bytes);
 int kf_d2d(kf_ctx* ctx, void* dst, const void* src, size_t bytes);

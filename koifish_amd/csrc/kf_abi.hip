@@ -176,6 +176,12 @@ int kf_memset(kf_ctx* c, void* p, int v, size_t bytes) {
     HIPCHK(hipMemsetAsync(p, v, bytes, c->stream));
     return KF_OK;
 }
+int kf_memset32(kf_ctx* c, void* p, int32_t v, size_t count) {
+    CHKCTX(c);
+    if (!p || ((uintptr_t)p & 3)) return fail(KF_INVALID_ARGS, "kf_memset32: null or unaligned pointer");
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)p, v, count, c->stream));
+    return KF_OK;
+}
 int kf_h2d(kf_ctx* c, void* dst, const void* src, size_t bytes) {
     CHKCTX(c);
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));

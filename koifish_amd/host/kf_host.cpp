@@ -928,8 +928,7 @@ int XcdReplicas::SetForced(int seq, const int32_t* ids, int n) {
 }
 int XcdReplicas::SetState(int seq, int token, int pos) {
     if (seq < 0 || seq >= n_seq || pos < 0 || pos >= hFish->config.n_ctx || token < 0 || token >= hFish->config.vocab) return KF_INVALID_ARGS;
-    const int32_t zero = 0;
-    KF_TRY(kf_h2d(hFish->ctx, d_state + 4 * seq + 3, &zero, 4)); /* the status word of the re-aimed sequence */
+    KF_TRY(kf_memset32(hFish->ctx, d_state + 4 * seq + 3, 0, 1)); /* the status word of the re-aimed sequence */
     return kf_set_state(hFish->ctx, d_state + 4 * seq, token, pos);
 }
 // CHAT_SAMPLER for Chat (greedy by default): one rng word per sequence, seeded per request
@@ -946,8 +945,7 @@ int XcdReplicas::SetSampler(const CHAT_SAMPLER& sp) {
 // sequence's cache rows and skipped it (kf_abi.h: d_state [n_seq][4] = {token, pos, parked, status}).
 int XcdReplicas::Park(int seq, bool on) {
     if (seq < 0 || seq >= n_seq) return KF_INVALID_ARGS;
-    const int32_t v = on ? 1 : 0;
-    return kf_h2d(hFish->ctx, d_state + 4 * seq + 2, &v, 4);
+    return kf_memset32(hFish->ctx, d_state + 4 * seq + 2, on ? 1 : 0, 1); /* on the stream, no host sync: the queue flips these between launches */
 }
 int XcdReplicas::Status(int seq, int32_t* out4) {
     if (seq < 0 || seq >= n_seq || !out4) return KF_INVALID_ARGS;
@@ -1091,7 +1089,7 @@ int XcdReplicas::Chat(const int32_t* prompts, const int32_t* prompt_len, int n_r
     KF_TRY(Fresh());
     struct Slot { int req = -1, len = 0, want = 0, have = 0; };
     std::vector<Slot> slot(n_seq);
-    std::vector<int32_t> row(c.n_ctx), none(c.n_ctx, -1);
+    std::vector<int32_t> row(c.n_ctx);
     long long st[4] = {0, 0, 0, 0};
     int next = 0, done = 0;
     for (int s = 0; s < n_seq; s++) KF_TRY(Park(s, true));
@@ -1124,7 +1122,7 @@ int XcdReplicas::Chat(const int32_t* prompts, const int32_t* prompt_len, int n_r
                     q.req = next++, q.len = prompt_len[q.req], q.have = 1;  // the prefill picks the answer's first id
                     const int room = c.n_ctx - q.len;                       // the ids the cache has rows for: the id behind row p needs row p
                     q.want = max_new < room + 1 ? max_new : room + 1;
-                    KF_TRY(kf_h2d(ctx, d_forced + (size_t)fs[i] * c.n_ctx, none.data(), (size_t)c.n_ctx * 4));
+                    KF_TRY(kf_memset32(ctx, d_forced + (size_t)fs[i] * c.n_ctx, -1, (size_t)c.n_ctx)); /* free running */
                 }
                 if (m > 1)
                     KF_TRY(PrefillBatch(fs.data(), prompts + (size_t)r0 * stride, prompt_len + r0, m, stride));
@@ -1136,7 +1134,7 @@ int XcdReplicas::Chat(const int32_t* prompts, const int32_t* prompt_len, int n_r
                     Slot& q = slot[s];
                     if (sampled) { /* the prefill left the last prompt token's logits in the slot's logits and picked greedily: draw the answer's first id instead */
                         const uint64_t seed = samp_params.seed + (uint64_t)q.req;
-                        KF_TRY(kf_h2d(ctx, d_rng + s, &seed, 8));
+                        KF_TRY(kf_set_state(ctx, reinterpret_cast<int32_t*>(d_rng + s), (int)(uint32_t)seed, (int)(uint32_t)(seed >> 32))); /* two words on the stream */
                         KF_TRY(kf_set_state(ctx, d_state + 4 * s, prompts[(size_t)q.req * stride + q.len - 1], q.len - 1));
                         KF_TRY(draw(s));
                     }

@@ -16,7 +16,7 @@ NF4 = 1000  # not a typNUMBER: "Q4 with the normal-float quant card" (QUANT_MODE
 
 # every symbol include/kf_abi.h declares (tests/test_abi_symbols.py checks the header against this list and the .so)
 ABI_SYMBOLS = [
-    "kf_init", "kf_destroy", "kf_sync", "kf_last_error", "kf_version", "kf_malloc", "kf_free", "kf_memset", "kf_h2d", "kf_d2h", "kf_d2d",
+    "kf_init", "kf_destroy", "kf_sync", "kf_last_error", "kf_version", "kf_malloc", "kf_free", "kf_memset", "kf_memset32", "kf_h2d", "kf_d2h", "kf_d2d",
     "kf_graph_begin", "kf_graph_end", "kf_graph_launch", "kf_graph_destroy", "kf_event_create", "kf_event_record", "kf_event_elapsed_ms",
     "kf_event_destroy", "kf_dequant", "kf_quantize", "kf_linear", "kf_rmsnorm", "kf_qknorm_rope", "kf_rope_table_host", "kf_attn_decode",
     "kf_attn_scratch_bytes", "kf_linear_f32", "kf_tp_reduce", "kf_swiglu", "kf_add", "kf_embed", "kf_lm_head", "kf_head_scratch_bytes", "kf_norm_linear",
@@ -76,6 +76,7 @@ def load():
         hip.kf_attn_prefill_batch_strided.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         hip.kf_embed_pos.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         hip.kf_argmax_rows_state.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        hip.kf_memset32.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t]
         hip.kf_copy_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
         hip.kf_memset2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_size_t]
         hip.kf_embed_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
