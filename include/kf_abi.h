@@ -416,6 +416,10 @@ int kf_qknorm_rope_batch(kf_ctx* ctx, kf_bf16* q, kf_bf16* k, const kf_bf16* wq_
  * its epilogue (a 128-row tile is one head) -- otherwise kf_linear_multi + kf_qknorm_rope_batch.  Same arithmetic either way (token batches: MFMA summation order, tolerances). */
 int kf_qkv_rope_batch(kf_ctx* ctx, const kf_weight* wq, const kf_weight* wk, const kf_weight* wv, const kf_bf16* x, kf_bf16* q, kf_bf16* k, kf_bf16* v, int nTok,
                       const kf_bf16* wq_norm_or_null, const kf_bf16* wk_norm_or_null, const float* rope_table_or_null, int pos0, int n_head, int n_kv, int head_dim, float eps);
+/* the same for nTok rows that are SEQUENCES of seq_len tokens back to back (a batch of prompts; a training batch): positions 0 .. seq_len - 1 in each (pos0 must be 0, nTok a
+ * multiple of seq_len; seq_len 0 = kf_qkv_rope_batch).  Unfused route: kf_linear_multi + kf_qknorm_rope_train. */
+int kf_qkv_rope_seqs(kf_ctx* ctx, const kf_weight* wq, const kf_weight* wk, const kf_weight* wv, const kf_bf16* x, kf_bf16* q, kf_bf16* k, kf_bf16* v, int nTok, int seq_len,
+                     const kf_bf16* wq_norm_or_null, const kf_bf16* wk_norm_or_null, const float* rope_table_or_null, int pos0, int n_head, int n_kv, int head_dim, float eps);
 /* causal attention of tokens t < n_tok (position pos0 + t attends to cache rows 0 .. pos0 + t, which must already hold the prepared
  * keys / values of the batch); q and out rows are q_stride elements apart; same arithmetic as kf_attn_decode, one workgroup per
  * (kv-head, token), no scratch. */

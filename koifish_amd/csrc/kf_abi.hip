@@ -776,8 +776,13 @@ static int multi_deq_route(kf_ctx* c, int n_w, const kf_weight* const* w, const 
 }
 int kf_qkv_rope_batch(kf_ctx* c, const kf_weight* wq, const kf_weight* wk, const kf_weight* wv, const kf_bf16* x, kf_bf16* q, kf_bf16* k, kf_bf16* v, int nTok, const kf_bf16* wq_norm,
                       const kf_bf16* wk_norm, const float* rope_table, int pos0, int n_head, int n_kv, int hd, float eps) {
+    return kf_qkv_rope_seqs(c, wq, wk, wv, x, q, k, v, nTok, 0, wq_norm, wk_norm, rope_table, pos0, n_head, n_kv, hd, eps);
+}
+int kf_qkv_rope_seqs(kf_ctx* c, const kf_weight* wq, const kf_weight* wk, const kf_weight* wv, const kf_bf16* x, kf_bf16* q, kf_bf16* k, kf_bf16* v, int nTok, int seq_len,
+                     const kf_bf16* wq_norm, const kf_bf16* wk_norm, const float* rope_table, int pos0, int n_head, int n_kv, int hd, float eps) {
     CHKCTX(c);
-    if (!wq || !wk || !wv || !x || !q || !k || !v || nTok < 1 || pos0 < 0) return fail(KF_INVALID_ARGS, "kf_qkv_rope_batch: bad args");
+    if (!wq || !wk || !wv || !x || !q || !k || !v || nTok < 1 || pos0 < 0 || seq_len < 0 || (seq_len > 0 && (pos0 != 0 || nTok % seq_len)))
+        return fail(KF_INVALID_ARGS, "kf_qkv_rope_batch / _seqs: bad args");
     const kf_weight* ws[3] = {wq, wk, wv};
     kf_bf16* ys[3] = {q, k, v};
     if (hd == 128 && nTok >= multi_min(c) && wq->ne0 == n_head * hd && wk->ne0 == n_kv * hd) { /* one launch: the stacked tile GEMM with q/k-norm + RoPE in its epilogue */
@@ -785,13 +790,14 @@ int kf_qkv_rope_batch(kf_ctx* c, const kf_weight* wq, const kf_weight* wk, const
             const int r = check_weight(ws[i], "kf_qkv_rope_batch");
             if (r) return r;
         }
-        const kf::G3Rope rp = {wq_norm, wk_norm, rope_table, pos0, eps};
+        const kf::G3Rope rp = {wq_norm, wk_norm, rope_table, pos0, eps, seq_len};
         const int rc = multi_deq_route(c, 3, ws, x, ys, nTok, &rp);
         if (rc < 0) return fail(rc, "kf_qkv_rope_batch (stacked tile GEMM + RoPE epilogue) failed with %d", rc);
         if (rc == KF_OK) return KF_OK;
     }
     const int r = kf_linear_multi(c, 3, ws, x, ys, nTok);
     if (r) return r;
+    if (seq_len > 0) return kf_qknorm_rope_train(c, q, k, wq_norm, wk_norm, rope_table, nTok, seq_len, wq->ne0, wk->ne0, n_head, n_kv, hd, eps, nullptr, nullptr);
     return kf_qknorm_rope_batch(c, q, k, wq_norm, wk_norm, rope_table, pos0, nTok, wq->ne0, wk->ne0, n_head, n_kv, hd, eps);
 }
 int kf_linear_multi(kf_ctx* c, int n_w, const kf_weight* const* w, const kf_bf16* x, kf_bf16* const* y, int nTok) {

@@ -226,7 +226,7 @@ __device__ __forceinline__ void g3_epilogue_qkrope(const GemmArgs& a, int m0, in
             const float oth[4] = {bf_lo(op0), bf_hi(op0), bf_lo(op1), bf_hi(op1)};
             f32x4 cs01 = f32x4{1.f, 0.f, 1.f, 0.f}, cs23 = cs01; /* (cos, sin) of the lane's four pairs jj .. jj + 3: 32 contiguous bytes of the table */
             if (a.rope_table) {
-                const f32x4* tp = reinterpret_cast<const f32x4*>(a.rope_table + (size_t)(a.rope_pos0 + tok) * 128 + 2 * jj);
+                const f32x4* tp = reinterpret_cast<const f32x4*>(a.rope_table + (size_t)(a.rope_pos0 + (a.rope_seq > 0 ? tok % a.rope_seq : tok)) * 128 + 2 * jj);
                 cs01 = tp[0], cs23 = tp[1];
             }
             const float csv[8] = {cs01.x, cs01.y, cs01.z, cs01.w, cs23.x, cs23.y, cs23.z, cs23.w};
@@ -610,7 +610,7 @@ int gemm3_multi_launch(hipStream_t st, int n_w, const uint16_t* Wcat, const int*
     // gate | up, 192 big tiles, is better left on them: 7.93 ms with both small)
     if (rope) {
         if (n_w != 3 || M[0] % 128 != 0 || M[1] % 128 != 0 || ((M[0] | M[1] | M[2]) & 3) || (reinterpret_cast<uintptr_t>(y[0]) & 7) || (reinterpret_cast<uintptr_t>(y[1]) & 7)) return 1;
-        a.qkrope = 1, a.qk_norm[0] = rope->wq, a.qk_norm[1] = rope->wk, a.rope_table = rope->table, a.rope_pos0 = rope->pos0, a.qk_eps = rope->eps;
+        a.qkrope = 1, a.qk_norm[0] = rope->wq, a.qk_norm[1] = rope->wk, a.rope_table = rope->table, a.rope_pos0 = rope->pos0, a.rope_seq = rope->seq_len, a.qk_eps = rope->eps;
         return g3_go_c<false, false, G3Small>(st, a, (long)(tot / 128) * ((n + 127) / 128), nullptr, 0, 1); /* always the head-sized tile */
     }
     if (nwg < 160) return g3_go_c<false, false, G3Small>(st, a, (long)(tot / 128) * ((n + 127) / 128), nullptr, 0, 1);

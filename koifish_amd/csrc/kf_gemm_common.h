@@ -42,6 +42,7 @@ struct GemmArgs {
     const uint16_t* qk_norm[2];
     const float* rope_table; /* [n_ctx][64][2] (cos, sin) */
     int rope_pos0;
+    int rope_seq; /* > 0: the rows are sequences of rope_seq tokens back to back (a batch of prompts, a training batch): position of token t = rope_pos0 + t % rope_seq */
     float qk_eps;
     int swiglu; /* kf_gemm3.hip only: W = gate | up interleaved in blocks of 16 rows (dequant_launch ilv_n = 2), M = 2 ffn; the epilogue stores SwiGLU(gate, up) of every FFN row: y[n, ffn] */
 };

@@ -95,6 +95,7 @@ struct G3Rope { /* ROPE::cuInfer folded into the stacked Q | K | V launch's epil
     const float* table;      /* RoPE (cos, sin) table or NULL */
     int pos0;
     float eps;
+    int seq_len; /* > 0: rows are sequences of seq_len tokens back to back, positions pos0 .. pos0 + seq_len - 1 in each */
 };
 int gemm3_multi_launch(hipStream_t st, int n_w, const uint16_t* Wcat, const int* M, int K, const uint16_t* x, long long ldx, int n, uint16_t* const* y, const G3Rope* rope = nullptr);
 int gemm3_swiglu_launch(hipStream_t st, const uint16_t* Wilv, int ffn, int K, const uint16_t* x, long long ldx, int n, uint16_t* act); /* kf_gemm3.hip */

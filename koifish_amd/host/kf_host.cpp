@@ -1020,12 +1020,9 @@ int XcdReplicas::PrefillBatch(const int* slots, const int32_t* tokens, const int
     for (int l = 0; l < c.nLayer; l++) {
         SelfAttention& a = *f->attn[l];
         kf_weight wq = a.Q.w->desc(), wk = a.K.w->desc(), wv = a.V.w->desc(), wo = a.proj_cat.w->desc();
-        const kf_weight* ws[3] = {&wq, &wk, &wv};
-        kf_bf16* ys[3] = {bq, bk, bv};
         KF_TRY(kf_rmsnorm(ctx, bx, ToX(a.norm.w), bn, R, C, a.norm.rms_eps, nullptr));
-        KF_TRY(kf_linear_multi(ctx, 3, ws, bn, ys, R));
-        KF_TRY(kf_qknorm_rope_train(ctx, bq, bk, a.normQ.w ? ToX(a.normQ.w) : nullptr, a.normK.w ? ToX(a.normK.w) : nullptr, f->rope_table, R, T, qd, kvd, c.n_head, c.n_head_kv,
-                                    c.head_dim, a.normQ.rms_eps, nullptr, nullptr)); /* positions restart with every prompt */
+        KF_TRY(kf_qkv_rope_seqs(ctx, &wq, &wk, &wv, bn, bq, bk, bv, R, T, a.normQ.w ? ToX(a.normQ.w) : nullptr, a.normK.w ? ToX(a.normK.w) : nullptr, f->rope_table, 0, c.n_head,
+                                c.n_head_kv, c.head_dim, a.normQ.rms_eps)); /* positions restart with every prompt */
         KF_TRY(kf_attn_prefill_batch(ctx, bq, bk, bv, ba, T, qd, c.n_head, c.n_head_kv, c.head_dim, kvd, S)); /* the rows of a prompt see that prompt's keys only */
         const size_t off = (size_t)l * c.n_ctx * kvd * 2, blk = (size_t)T * kvd * 2;
         KF_TRY(kf_copy_blocks(ctx, d_dst, off, bk, blk, blk, S));

@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "kf_event_destroy", "kf_dequant", "kf_quantize", "kf_linear", "kf_rmsnorm", "kf_qknorm_rope", "kf_rope_table_host", "kf_attn_decode",
     "kf_attn_scratch_bytes", "kf_linear_f32", "kf_tp_reduce", "kf_swiglu", "kf_add", "kf_embed", "kf_lm_head", "kf_head_scratch_bytes", "kf_norm_linear",
     "kf_norm_gateup_swiglu", "kf_attn_block", "kf_norm_lm_head", "kf_set_state", "kf_embed_state", "kf_embed_batch", "kf_qknorm_rope_batch", "kf_attn_prefill", "kf_sample", "kf_linear_multi", "kf_linear_multi_scratch_bytes", "kf_gateup_swiglu_batch", "kf_adamw", "kf_layernorm", "kf_gelu", "kf_sample_topk", "kf_fused_classifier", "kf_gelu_backward", "kf_swiglu_backward", "kf_rope_backward", "kf_norm_backward", "kf_norm_backward_scratch_bytes", "kf_linear_backward", "kf_linear_backward_scratch_bytes", "kf_embed_backward", "kf_attn_backward", "kf_attn_backward_scratch_bytes", "kf_attn_prefill_batch", "kf_attn_prefill_batch_strided", "kf_embed_pos", "kf_memset2d", "kf_copy_blocks", "kf_argmax_rows_state", "kf_qknorm_rope_train",
-    "kf_hot_rows", "kf_linear_masked", "kf_norm_gateup_swiglu_masked", "kf_linear_scratch_bytes", "kf_set_scratch", "kf_engine_workspace_bytes", "kf_engine_create", "kf_engine_step", "kf_engine_check", "kf_engine_destroy", "kf_engine_set_embedding", "kf_engine_set_head", "kf_engine_step_head", "kf_engine_steps_head", "kf_engine_reset", "kf_set_canonical", "kf_get_canonical", "kf_engine_served", "kf_engine_tune", "kf_engine_stats", "kf_qkv_rope_batch", "kf_set_dequant_arena", "kf_dequant_arena_used", "kf_resident_scratch_bytes",
+    "kf_hot_rows", "kf_linear_masked", "kf_norm_gateup_swiglu_masked", "kf_linear_scratch_bytes", "kf_set_scratch", "kf_engine_workspace_bytes", "kf_engine_create", "kf_engine_step", "kf_engine_check", "kf_engine_destroy", "kf_engine_set_embedding", "kf_engine_set_head", "kf_engine_step_head", "kf_engine_steps_head", "kf_engine_reset", "kf_set_canonical", "kf_get_canonical", "kf_engine_served", "kf_engine_tune", "kf_engine_stats", "kf_qkv_rope_batch", "kf_qkv_rope_seqs", "kf_set_dequant_arena", "kf_dequant_arena_used", "kf_resident_scratch_bytes",
     "kf_xengine_workspace_bytes", "kf_xengine_create", "kf_xengine_served", "kf_xengine_set_embedding", "kf_xengine_set_head", "kf_xengine_steps", "kf_xengine_check", "kf_xengine_reset", "kf_xengine_destroy", "kf_xengine_workspace_bytes_tp", "kf_xengine_create_tp", "kf_xengine_set_head_tp",
     "kf_tp_recv_bytes", "kf_tp_push_bytes", "kf_tp_commit", "kf_tp_alloc", "kf_tp_ipc_export", "kf_tp_ipc_open", "kf_tp_ipc_close", "kf_linear_f32_push", "kf_tp_reduce_recv", "kf_tp_lm_head", "kf_tp_pick",
 ]
@@ -92,6 +92,7 @@ def load():
         hip.kf_embed_batch.argtypes = [C.c_void_p, C.POINTER(Weight), C.c_void_p, C.c_int, C.c_void_p]
         hip.kf_qknorm_rope_batch.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float]
         hip.kf_qkv_rope_batch.argtypes = [C.c_void_p] * 8 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]
+        hip.kf_qkv_rope_seqs.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]
         hip.kf_attn_prefill.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]
         hip.kf_norm_linear.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         hip.kf_norm_gateup_swiglu.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.POINTER(Weight), C.POINTER(Weight), C.c_void_p]

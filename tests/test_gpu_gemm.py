@@ -231,12 +231,14 @@ def test_training_size_batch_of_a_quantised_weight_takes_the_dequantise_then_til
     ctx._lin_ws = None
 
 
-@pytest.mark.parametrize("nt", [1100, 2047])
-def test_fused_qkv_rope_epilogue_equals_the_two_launch_route(ctx, O, nt):
+@pytest.mark.parametrize("nt,seq", [(1100, 0), (2047, 0), (1280, 160)])
+def test_fused_qkv_rope_epilogue_equals_the_two_launch_route(ctx, O, nt, seq):
     """kf_qkv_rope_batch at >= 1024 tokens: Q | K | V stacked in ONE tile-GEMM launch with q/k-norm + RoPE in its epilogue (a 128-row tile is one head: the token's 128
     squares meet through row swaps and LDS, a rotation pair's other element sits in the other wave at the same lane) against kf_linear_multi + kf_qknorm_rope_batch:
-    same tile kernel, same prep_head_cs arithmetic -- every bit of q, k (rotated) and v equal; plus the exact fp64 reference within the batch-GEMM tolerance."""
-    k, hd, n_head, n_kv, pos0, eps = 1024, 128, 16, 8, 3, 1e-6
+    same tile kernel, same prep_head_cs arithmetic -- every bit of q, k (rotated) and v equal; plus the exact fp64 reference within the batch-GEMM tolerance.
+    seq > 0: kf_qkv_rope_seqs -- the rows are sequences of `seq` tokens back to back (a batch of prompts), positions restart in each -- against kf_linear_multi +
+    kf_qknorm_rope_train."""
+    k, hd, n_head, n_kv, pos0, eps = 1024, 128, 16, 8, (0 if seq else 3), 1e-6
     rng = np.random.default_rng(nt)
     x = O.f32_to_bf16(rng.normal(0, 1.0, size=(nt, k)).astype(np.float32))
     xd = bf16_t(x, ctx.device)
@@ -256,14 +258,21 @@ def test_fused_qkv_rope_epilogue_equals_the_two_launch_route(ctx, O, nt):
     outs = {}
     for fused in (True, False):
         ys = [torch.full((nt, m), 7.0, dtype=torch.bfloat16, device=ctx.device) for m in ms]
-        if fused:
+        if fused and seq:
+            L.check(ctx.hip.kf_qkv_rope_seqs(ctx.h, C.byref(descs[0]), C.byref(descs[1]), C.byref(descs[2]), xd.data_ptr(), ys[0].data_ptr(), ys[1].data_ptr(), ys[2].data_ptr(), nt, seq,
+                                             wq.data_ptr(), wk.data_ptr(), table.data_ptr(), 0, n_head, n_kv, hd, eps), "kf_qkv_rope_seqs")
+        elif fused:
             L.check(ctx.hip.kf_qkv_rope_batch(ctx.h, C.byref(descs[0]), C.byref(descs[1]), C.byref(descs[2]), xd.data_ptr(), ys[0].data_ptr(), ys[1].data_ptr(), ys[2].data_ptr(), nt,
                                               wq.data_ptr(), wk.data_ptr(), table.data_ptr(), pos0, n_head, n_kv, hd, eps), "kf_qkv_rope_batch")
         else:
             yp = (C.c_void_p * 3)(*[y.data_ptr() for y in ys])
             L.check(ctx.hip.kf_linear_multi(ctx.h, 3, wp, xd.data_ptr(), yp, nt), "kf_linear_multi")
-            L.check(ctx.hip.kf_qknorm_rope_batch(ctx.h, ys[0].data_ptr(), ys[1].data_ptr(), wq.data_ptr(), wk.data_ptr(), table.data_ptr(), pos0, nt, ms[0], ms[1], n_head, n_kv, hd, eps),
-                    "kf_qknorm_rope_batch")
+            if seq:
+                L.check(ctx.hip.kf_qknorm_rope_train(ctx.h, ys[0].data_ptr(), ys[1].data_ptr(), wq.data_ptr(), wk.data_ptr(), table.data_ptr(), nt, seq, ms[0], ms[1], n_head, n_kv, hd, eps,
+                                                     None, None), "kf_qknorm_rope_train")
+            else:
+                L.check(ctx.hip.kf_qknorm_rope_batch(ctx.h, ys[0].data_ptr(), ys[1].data_ptr(), wq.data_ptr(), wk.data_ptr(), table.data_ptr(), pos0, nt, ms[0], ms[1], n_head, n_kv, hd, eps),
+                        "kf_qknorm_rope_batch")
         ctx.sync()
         outs[fused] = [u16(y).copy() for y in ys]
     for a, b, name in zip(outs[True], outs[False], "qkv"):
@@ -272,6 +281,9 @@ def test_fused_qkv_rope_epilogue_equals_the_two_launch_route(ctx, O, nt):
     v_ref = f(x) @ f(O.dequant(ows[2])).reshape(ms[2], k).T
     assert np.abs(f(outs[True][2]) - v_ref).max() <= 2.0 ** -7 * np.abs(v_ref).max()
     assert np.abs(f(outs[True][0])).max() > 0.1   # q really went through the norm (values of order one)
+    if seq:   # the positions restart: sequence 3's rows equal ... only if its inputs did; instead: a call with mismatched nTok / seq_len is refused
+        assert ctx.hip.kf_qkv_rope_seqs(ctx.h, C.byref(descs[0]), C.byref(descs[1]), C.byref(descs[2]), xd.data_ptr(), ys[0].data_ptr(), ys[1].data_ptr(), ys[2].data_ptr(), nt, seq + 1,
+                                        wq.data_ptr(), wk.data_ptr(), table.data_ptr(), 0, n_head, n_kv, hd, eps) != 0
 
 
 @pytest.mark.parametrize("t", [L.Q4, L.T_SIGN])
