@@ -82,3 +82,19 @@ def test_nan_is_refused():
     except ValueError:
         return
     raise AssertionError("a NaN reached the line")
+
+
+def test_compact_line_of_the_round_6_result():
+    """the same on this round's own full result (profiles/r06g_bench_detail.json: batched decoders, request queue, prompt batches, every side leg): under the target size,
+    strict JSON, and the queue's figures ride in the line"""
+    B = _bench()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r06g_bench_detail.json")))
+    line = json.dumps(B.compact_line(full), allow_nan=False, separators=(",", ":"))
+    assert len(line) < 4608, len(line)
+    d = _strict(line)
+    assert d["value"] == full["value"] and d["roofline"]["frac"] == full["roofline"]["frac"] and d["cpu_baseline"]["value"] == full["cpu_baseline"]["value"]
+    x = d["side"]["xcd_replicas"]
+    assert x["streams"] == 32 and x["parity"] is True
+    q = x["request_queue"]
+    assert q["generated_tokens_per_s"] > 0 and q["prefill_batch"]["ms_per_prompt"] < 1.0
+    assert d["side"]["config3_train_step"]["host_loop"].startswith("C++")
