@@ -347,3 +347,57 @@ def test_f8e5m2_matvec_every_byte_value(ctx, O):
     nz = finite & (np.arange(256) != 0x80)   # byte 0x80 is -0: the dot product 0 + (-0 * 1) is +0 on both sides
     assert np.array_equal(y[nz], O.dequant(ow)[nz, 0])
     assert y[0x80] == 0x0000 and O.bf16_to_f32(y[0x01:0x02])[0] == 2.0 ** -16   # the smallest subnormal
+
+
+def test_argmax_rows_state_copy_blocks_memset32(ctx, O):
+    """the three small entries behind a batch of prompts (XcdReplicas::PrefillBatch):
+      * kf_argmax_rows_state: the FIRST maximum over float(logits) of every row (sample_argmax, GoPT.cpp:602-612) -- ties, negative rows, a maximum in the last column -- and the
+        decode-state update of the row's sequence: tokens_out[seq][pos] = id, state = {id, pos + 1}, the other words and sequences untouched;
+      * kf_copy_blocks: block b of a source to table[b] + offset, nothing else written;
+      * kf_memset32: words on the stream."""
+    import ctypes as C
+    hip, dev = ctx.hip, ctx.device
+    rng = np.random.default_rng(21)
+    n, n_rows, n_seq, stride = 5003, 5, 9, 40
+    lg = O.f32_to_bf16(rng.normal(0, 2.0, (n_rows, n)).astype(np.float32))
+    top = O.f32_to_bf16(np.array([9.0], dtype=np.float32))[0]
+    lg[0, 17] = lg[0, 4000] = lg[0, 900] = top          # three equal maxima: the first wins
+    lg[1, n - 1] = top                                   # the last column
+    lg[2] = O.f32_to_bf16(-np.abs(rng.normal(1, 0.2, n)).astype(np.float32))   # all negative
+    lg[3, 0] = top                                       # the first column
+    seqs = np.array([7, 2, 0, 8, 4], dtype=np.int32)
+    states = np.tile(np.array([[-5, 3, 11, 12]], dtype=np.int32), (n_seq, 1))
+    states[:, 1] = np.arange(n_seq) + 3
+    out = np.full((n_seq, stride), -1, dtype=np.int32)
+    d_lg, d_seq, d_st, d_out = bf16_t(lg, dev), torch.from_numpy(seqs).to(dev), torch.from_numpy(states.copy()).to(dev), torch.from_numpy(out.copy()).to(dev)
+    assert hip.kf_argmax_rows_state(ctx.h, d_lg.data_ptr(), n, n, n_rows, d_seq.data_ptr(), d_st.data_ptr(), d_out.data_ptr(), stride) == 0, hip.kf_last_error()
+    ctx.sync()
+    f = O.bf16_to_f32(lg)
+    want = [int(np.argmax(f[r])) for r in range(n_rows)]   # numpy's argmax is the first maximum
+    assert want[0] == 17 and want[1] == n - 1 and want[3] == 0
+    g_st, g_out = d_st.cpu().numpy(), d_out.cpu().numpy()
+    for r, s in enumerate(seqs):
+        assert g_st[s].tolist() == [want[r], states[s, 1] + 1, 11, 12] and g_out[s, states[s, 1]] == want[r]
+        g_out[s, states[s, 1]] = -1
+    for s in set(range(n_seq)) - set(seqs.tolist()):
+        assert g_st[s].tolist() == states[s].tolist()
+    assert (g_out == -1).all()
+    assert hip.kf_argmax_rows_state(ctx.h, d_lg.data_ptr(), n - 1, n, n_rows, d_seq.data_ptr(), d_st.data_ptr(), None, stride) != 0   # ld < n
+    # scatter of blocks through a device table
+    blk, nb = 4096 + 16, 6
+    src = torch.from_numpy(rng.integers(0, 255, (nb, blk + 32), dtype=np.uint8)).to(dev)      # blocks blk + 32 bytes apart
+    dst = torch.zeros(nb + 2, 2 * blk, dtype=torch.uint8, device=dev)
+    order = [5, 0, 3, 1, 7, 2]
+    table = torch.tensor([dst[o].data_ptr() for o in order], dtype=torch.int64, device=dev)
+    assert hip.kf_copy_blocks(ctx.h, table.data_ptr(), 64, src.data_ptr(), blk + 32, blk, nb) == 0, hip.kf_last_error()
+    ctx.sync()
+    h_src, h_dst = src.cpu().numpy(), dst.cpu().numpy()
+    for b, o in enumerate(order):
+        assert np.array_equal(h_dst[o, 64:64 + blk], h_src[b, :blk]) and not h_dst[o, :64].any() and not h_dst[o, 64 + blk:].any()
+    assert not h_dst[4].any() and not h_dst[6].any()
+    assert hip.kf_copy_blocks(ctx.h, table.data_ptr(), 8, src.data_ptr(), blk + 32, blk, nb) != 0       # offset not a multiple of 16
+    # words on the stream
+    w = torch.zeros(10, dtype=torch.int32, device=dev)
+    assert hip.kf_memset32(ctx.h, w.data_ptr() + 8, -7, 5) == 0, hip.kf_last_error()
+    ctx.sync()
+    assert w.cpu().numpy().tolist() == [0, 0, -7, -7, -7, -7, -7, 0, 0, 0]
