@@ -1071,9 +1071,13 @@ int XcdReplicas::RunSteps(int n) {
 // With a non-greedy sampler (SetSampler: GeneratOnPrompt::Sample, GoPT.cpp:614-630 -- temperature, top-k, top-p, xorshift coin) the launches run ONE step each and leave the
 // logits (pick = 0); kf_sample then draws every occupied slot's id from its own logits with the slot's own rng state, seeded at the request's start with seed + request
 // index: answer r equals Fish::Generate's on prompt r under SetSampler(seed + r).
-int XcdReplicas::Chat(const int32_t* prompts, const int32_t* prompt_len, int n_req, int stride, int max_new, int eos, int32_t* out, int32_t* out_len, long long* stats) {
+int XcdReplicas::Chat(const int32_t* prompts, const int32_t* prompt_len, int n_req, int stride, int max_new, int eos, int32_t* out, int32_t* out_len, long long* stats,
+                      const int32_t* max_new_each) {
     const MODEL_CARD& c = hFish->config;
     if (!prompts || !prompt_len || !out || !out_len || n_req < 1 || stride < 1 || max_new < 1) return KF_INVALID_ARGS;
+    if (max_new_each)
+        for (int r = 0; r < n_req; r++)
+            if (max_new_each[r] < 1 || max_new_each[r] > max_new) return KF_INVALID_ARGS;
     const bool sampled = !samp_params.greedy();
     auto draw = [&](int s) -> int {  // the slot's next id from its logits: state {token, pos} -> {id, pos + 1}, ids out [pos] = id
         return (samp_params.true_topk ? kf_sample_topk : kf_sample)(hFish->ctx, ToX(logits) + (size_t)s * c.vocab, c.vocab, samp_params.top_k, samp_params.temperature,
@@ -1118,7 +1122,8 @@ int XcdReplicas::Chat(const int32_t* prompts, const int32_t* prompt_len, int n_r
                     Slot& q = slot[fs[i]];
                     q.req = next++, q.len = prompt_len[q.req], q.have = 1;  // the prefill picks the answer's first id
                     const int room = c.n_ctx - q.len;                       // the ids the cache has rows for: the id behind row p needs row p
-                    q.want = max_new < room + 1 ? max_new : room + 1;
+                    const int asked = max_new_each ? max_new_each[q.req] : max_new; /* a limit of its own per request, or the common one */
+                    q.want = asked < room + 1 ? asked : room + 1;
                     KF_TRY(kf_memset32(ctx, d_forced + (size_t)fs[i] * c.n_ctx, -1, (size_t)c.n_ctx)); /* free running */
                 }
                 if (m > 1)
@@ -1726,6 +1731,11 @@ int kfh_xr_set_sampler(void* h, float temperature, float top_p, int top_k, uint6
 }
 int kfh_xr_chat(void* h, const int32_t* prompts, const int32_t* prompt_len, int n_req, int stride, int max_new, int eos, int32_t* out, int32_t* out_len, long long* stats) {
     return reinterpret_cast<XcdReplicas*>(h)->Chat(prompts, prompt_len, n_req, stride, max_new, eos, out, out_len, stats);
+}
+// max_new_each [n_req] (or NULL): request r's own limit, <= max_new (the width of out's rows)
+int kfh_xr_chat_each(void* h, const int32_t* prompts, const int32_t* prompt_len, int n_req, int stride, int max_new, int eos, int32_t* out, int32_t* out_len, long long* stats,
+                     const int32_t* max_new_each) {
+    return reinterpret_cast<XcdReplicas*>(h)->Chat(prompts, prompt_len, n_req, stride, max_new, eos, out, out_len, stats, max_new_each);
 }
 int kfh_xr_status(void* h, int seq, int32_t* out4) { return reinterpret_cast<XcdReplicas*>(h)->Status(seq, out4); }
 int kfh_xr_set_steps_per_launch(void* h, int n) {

@@ -313,7 +313,8 @@ struct XcdReplicas {
     int Prefill(int seq, const int* tokens, int n);  // the sequence's prompt through Fish::Prefill (token batches on the tile kernels), its K / V rows into the sequence's cache; the sequence then stands behind the prompt
     int RunSteps(int n);  // n greedy steps of EVERY sequence from wherever each stands; no host sync
     // a queue of prompts answered through the slots (Fish::Chat's rounds over DEBUG.prompts, GoPT.cpp:1111-1180, n_seq at once); see kf_host.cpp
-    int Chat(const int32_t* prompts, const int32_t* prompt_len, int n_req, int stride, int max_new, int eos, int32_t* out, int32_t* out_len, long long* stats);
+    int Chat(const int32_t* prompts, const int32_t* prompt_len, int n_req, int stride, int max_new, int eos, int32_t* out, int32_t* out_len, long long* stats,
+             const int32_t* max_new_each = nullptr);  // max_new_each: a limit of its own per request (<= max_new)
     // S prompts at once (rows = S x T, T = the longest, shorter ones padded): ONE token batch through the tile kernels -- the rows of a prompt attend to that prompt only
     // (kf_attn_prefill_batch), positions restart per prompt (kf_qknorm_rope_train), every prompt's K / V rows scattered into its slot's cache (kf_copy_blocks), the head on
     // each prompt's last row.  What Fish::Chat's token-serial prefill loop (GoPT.cpp:1139-1146) does for one prompt, for S of them in the launches of one.

@@ -223,6 +223,7 @@ def load():
         host.kfh_xr_set_prefill_batch.argtypes = [C.c_void_p, C.c_int]
         host.kfh_xr_set_sampler.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_uint64]
         host.kfh_xr_chat.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        host.kfh_xr_chat_each.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         host.kfh_xr_set_steps_per_launch.argtypes = [C.c_void_p, C.c_int]
         host.kfh_xr_get_tokens.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         host.kfh_xr_get_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p]

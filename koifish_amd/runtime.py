@@ -699,9 +699,10 @@ class XcdReplicas:
         rng, seeded with seed + the request's index at the request's start -- answer r == the model alone on prompt r under set_sampler(seed=seed + r)."""
         L.check(self.host.kfh_xr_set_sampler(self.h, float(temperature), float(top_p), int(top_k) | (0x10000 if true_topk else 0), int(seed)), "kfh_xr_set_sampler")
 
-    def chat(self, prompts, max_new, eos=-1):
+    def chat(self, prompts, max_new, eos=-1, max_new_each=None):
         """a queue of prompts answered through the sequences' slots (Fish::Chat's rounds over its prompt list, GoPT.cpp:1111-1180, n_seq rounds in flight): a free slot
         prefills the next prompt, the launches decode every occupied slot, an answer ends at `eos`, at max_new ids or at the last cache row.
+        max_new_each: a limit of its own per request (each <= max_new).
         Returns (list of id lists in the prompts' order, {launches, steps, prefills, dropped})."""
         n = len(prompts)
         lens = np.array([len(p) for p in prompts], dtype=np.int32)
@@ -712,8 +713,11 @@ class XcdReplicas:
         out = np.zeros((n, int(max_new)), dtype=np.int32)
         out_len = np.zeros(n, dtype=np.int32)
         stats = np.zeros(4, dtype=np.int64)
-        L.check(self.host.kfh_xr_chat(self.h, flat.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), n, stride, int(max_new), int(eos),
-                                      out.ctypes.data_as(C.c_void_p), out_len.ctypes.data_as(C.c_void_p), stats.ctypes.data_as(C.c_void_p)), "kfh_xr_chat")
+        each = None if max_new_each is None else np.ascontiguousarray(max_new_each, dtype=np.int32)
+        assert each is None or each.size == n
+        L.check(self.host.kfh_xr_chat_each(self.h, flat.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), n, stride, int(max_new), int(eos),
+                                           out.ctypes.data_as(C.c_void_p), out_len.ctypes.data_as(C.c_void_p), stats.ctypes.data_as(C.c_void_p),
+                                           None if each is None else each.ctypes.data_as(C.c_void_p)), "kfh_xr_chat_each")
         return [out[i, :out_len[i]].tolist() for i in range(n)], dict(zip(("launches", "steps", "prefills", "dropped"), (int(v) for v in stats)))
 
     def status(self, seq):

@@ -601,6 +601,13 @@ def test_a_queue_of_prompts_through_the_slots(canon, n_seq, n_req):
     got, st = xr.chat(prompts, max_new, eos=eos)
     assert got == cut
     assert st["prefills"] == n_req
+    # a limit of its own per request: the answers are the common run's, cut; slots free up at scattered steps and are refilled while the others decode on
+    each = [1 + (5 * r) % max_new for r in range(n_req)]
+    got, st = xr.chat(prompts, max_new, max_new_each=each)
+    assert got == [a[:k] for a, k in zip(ref, each)]
+    assert st["prefills"] == n_req and st["dropped"] == 0
+    with pytest.raises(Exception):
+        xr.chat(prompts[:2], 4, max_new_each=[4, 5])
     # the reference's sampler (GeneratOnPrompt::Sample: temperature, top-k, top-p, xorshift coin) per slot: request r draws with seed + r
     sub = list(range(0, n_req, 2))
     xr.set_sampler(temperature=0.8, top_p=0.9, top_k=40, seed=1000)
